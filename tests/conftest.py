@@ -1,0 +1,41 @@
+"""pytest configuration: `gpu` marker, repo-root import path, fixture locations."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure).  Built on demand with the committed Makefile."""
+    from oracle import oracle as o
+
+    o.build()
+    return o
+
+
+@pytest.fixture(scope="session")
+def mesh_loader(oracle):
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = oracle.load_mesh(os.path.join(GOLDEN, "mesh", name))
+        return cache[name]
+
+    return load

@@ -1,0 +1,301 @@
+"""ctypes binding of the C ABI in include/fdapde_hip.h (libfdapde_hip.so).
+
+Plumbing for tests/ and bench.py only: the product's host side is the header-only C++20 facade in
+include/fdapde_amd/ (the reference is a C++ library).  There is no CPU fallback here -- if the shared library is
+missing, import fails loudly; if a context has no device, compute calls raise FdapdeError(ENODEVICE).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfdapde_hip.so")
+
+OK, EINVAL, ENOMEM, ENODEVICE, EHIP, ENOTINIT, ENOCONV, EUNSUPPORTED, ERCCL = range(9)
+LAPLACIAN, DIFFUSION, ADVECTION, REACTION, DT = range(5)
+SOLVER_AUTO, SOLVER_CG, SOLVER_BICGSTAB = range(3)
+ASSEMBLY_ROWS, ASSEMBLY_ATOMIC, ASSEMBLY_COLOURED = range(3)
+MAT_STIFF, MAT_MASS = 0, 1
+
+
+class Term(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("space_varying", C.c_int32), ("coef", C.c_double), ("cst", C.c_double * 9),
+                ("data", C.POINTER(C.c_double))]
+
+
+class Options(C.Structure):
+    _fields_ = [("method", C.c_int32), ("maxit", C.c_int32), ("rtol", C.c_double), ("assembly", C.c_int32),
+                ("check_every", C.c_int32)]
+
+
+class Info(C.Structure):
+    _fields_ = [("iters", C.c_int32), ("converged", C.c_int32), ("relres", C.c_double), ("t_assemble_ms", C.c_double),
+                ("t_solve_ms", C.c_double), ("t_setup_ms", C.c_double)]
+
+
+# every symbol include/fdapde_hip.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "fdapde_abi_version", "fdapde_device_count", "fdapde_ctx_create", "fdapde_ctx_destroy", "fdapde_last_error",
+    "fdapde_status_string", "fdapde_mesh_upload", "fdapde_dofs_build", "fdapde_dofs_get", "fdapde_sizes",
+    "fdapde_pattern_get", "fdapde_quadrature_nodes", "fdapde_set_operator", "fdapde_set_forcing", "fdapde_set_dirichlet",
+    "fdapde_init", "fdapde_assemble_operator", "fdapde_solve", "fdapde_matrix_values", "fdapde_force", "fdapde_solution",
+    "fdapde_info_get", "fdapde_spmv", "fdapde_bench_spmv", "fdapde_stream", "fdapde_synchronize",
+]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() or `make -C fdapde-core_amd/csrc`. "
+                              "There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        lib.fdapde_last_error.restype = C.c_char_p
+        lib.fdapde_status_string.restype = C.c_char_p
+        lib.fdapde_stream.restype = C.c_void_p
+        lib.fdapde_ctx_destroy.restype = None
+        _lib = lib
+    return _lib
+
+
+class FdapdeError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"[status {status}] {msg}")
+        self.status = status
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _bp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+class Operator:
+    """Left-to-right sum of scaled leaves, mirroring the reference's operator algebra
+    (fdaPDE/pde/differential_expressions.h): -laplacian(), a + b, a - b, 2.0 * a."""
+
+    def __init__(self, terms=None):
+        self.terms = list(terms or [])  # (kind, coef, const | None, data | None)
+
+    def __neg__(self):
+        return Operator([(k, -c, cst, d) for (k, c, cst, d) in self.terms])
+
+    def __add__(self, o):
+        return Operator(self.terms + o.terms)
+
+    def __sub__(self, o):
+        return Operator(self.terms + (-o).terms)
+
+    def __rmul__(self, s):
+        return Operator([(k, float(s) * c, cst, d) for (k, c, cst, d) in self.terms])
+
+    @property
+    def is_symmetric(self):
+        return all(k != ADVECTION for (k, _, _, _) in self.terms)
+
+    def c_terms(self):
+        arr = (Term * len(self.terms))()
+        keep = []
+        for t, (k, c, cst, d) in zip(arr, self.terms):
+            t.kind, t.coef, t.space_varying = k, c, 0 if d is None else 1
+            if cst is not None:
+                for i, v in enumerate(np.asarray(cst, dtype=float).reshape(-1)):
+                    t.cst[i] = v
+            if d is not None:
+                dd = np.ascontiguousarray(d, dtype=float)
+                keep.append(dd)
+                t.data = _dp(dd)
+        return arr, keep
+
+
+def laplacian():
+    return Operator([(LAPLACIAN, 1.0, None, None)])
+
+
+def diffusion(K):
+    return Operator([(DIFFUSION, 1.0, np.asarray(K, dtype=float), None)])
+
+
+def diffusion_field(Kq):
+    return Operator([(DIFFUSION, 1.0, None, np.asarray(Kq, dtype=float))])
+
+
+def advection(b):
+    return Operator([(ADVECTION, 1.0, np.asarray(b, dtype=float), None)])
+
+
+def advection_field(bq):
+    return Operator([(ADVECTION, 1.0, None, np.asarray(bq, dtype=float))])
+
+
+def reaction(c):
+    return Operator([(REACTION, 1.0, np.asarray([c], dtype=float), None)])
+
+
+def reaction_field(cq):
+    return Operator([(REACTION, 1.0, None, np.asarray(cq, dtype=float))])
+
+
+def dt():
+    return Operator([(DT, 1.0, None, None)])
+
+
+class Context:
+    """One fdapde_ctx.  device=None -> host-only context (numbering / pattern queries only)."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        self._ctx = C.c_void_p()
+        rc = self.lib.fdapde_ctx_create(-1 if device is None else int(device), C.byref(self._ctx))
+        if rc != OK:
+            raise FdapdeError(rc, self.lib.fdapde_status_string(rc).decode())
+        self.M = self.N = 0
+        self.n_cells = self.n_nodes = 0
+
+    def close(self):
+        if self._ctx:
+            self.lib.fdapde_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != OK:
+            raise FdapdeError(rc, self.lib.fdapde_last_error(self._ctx).decode() or self.lib.fdapde_status_string(rc).decode())
+
+    # ---- domain / space
+    def mesh_upload(self, nodes, cells, boundary):
+        """nodes (n_nodes, N) any order; cells (n_cells, M+1) int32 0-based; boundary (n_nodes,) 0/1"""
+        nodes = np.asarray(nodes, dtype=float)
+        cells = np.ascontiguousarray(cells, dtype=np.int32)
+        boundary = np.ascontiguousarray(boundary, dtype=np.uint8).reshape(-1)
+        colmajor = np.ascontiguousarray(nodes.T).reshape(-1)
+        self.M, self.N = cells.shape[1] - 1, nodes.shape[1]
+        self.n_nodes, self.n_cells = nodes.shape[0], cells.shape[0]
+        self._check(self.lib.fdapde_mesh_upload(self._ctx, self.M, self.N, C.c_int64(self.n_nodes), _dp(colmajor),
+                                                C.c_int64(self.n_cells), _ip(cells), _bp(boundary)))
+
+    def dofs_build(self, order):
+        nd = C.c_int64()
+        self._check(self.lib.fdapde_dofs_build(self._ctx, int(order), C.byref(nd)))
+        self.order = order
+        return nd.value
+
+    def sizes(self):
+        nd, nnz, ne = C.c_int64(), C.c_int64(), C.c_int64()
+        nb, nq = C.c_int32(), C.c_int32()
+        self._check(self.lib.fdapde_sizes(self._ctx, C.byref(nd), C.byref(nnz), C.byref(nb), C.byref(nq), C.byref(ne)))
+        return dict(n_dofs=nd.value, nnz=nnz.value, n_basis=nb.value, n_quadrature=nq.value, n_edges=ne.value)
+
+    def dofs_get(self):
+        s = self.sizes()
+        dofs = np.zeros((self.n_cells, s["n_basis"]), dtype=np.int32)
+        bnd = np.zeros(s["n_dofs"], dtype=np.uint8)
+        coords = np.zeros(self.N * s["n_dofs"])
+        self._check(self.lib.fdapde_dofs_get(self._ctx, _ip(dofs), _bp(bnd), _dp(coords)))
+        return dofs, bnd, np.ascontiguousarray(coords.reshape(self.N, s["n_dofs"]).T)
+
+    def pattern_get(self):
+        s = self.sizes()
+        rowptr = np.zeros(s["n_dofs"] + 1, dtype=np.int32)
+        colidx = np.zeros(s["nnz"], dtype=np.int32)
+        self._check(self.lib.fdapde_pattern_get(self._ctx, _ip(rowptr), _ip(colidx)))
+        return rowptr, colidx
+
+    def quadrature_nodes(self):
+        s = self.sizes()
+        rows = s["n_quadrature"] * self.n_cells
+        out = np.zeros(self.N * rows)
+        self._check(self.lib.fdapde_quadrature_nodes(self._ctx, _dp(out)))
+        return np.ascontiguousarray(out.reshape(self.N, rows).T)
+
+    # ---- problem data
+    def set_operator(self, op: Operator):
+        terms, keep = op.c_terms()
+        self._check(self.lib.fdapde_set_operator(self._ctx, len(op.terms), terms))
+
+    def set_forcing(self, f_q):
+        if f_q is None:
+            self._check(self.lib.fdapde_set_forcing(self._ctx, None, 0))
+            return
+        f = np.asarray(f_q, dtype=float)
+        ncols = 1 if f.ndim == 1 else f.shape[1]
+        flat = np.ascontiguousarray(f.reshape(f.shape[0], ncols).T).reshape(-1)  # column-major
+        self._check(self.lib.fdapde_set_forcing(self._ctx, _dp(flat), ncols))
+
+    def set_dirichlet(self, g):
+        if g is None:
+            self._check(self.lib.fdapde_set_dirichlet(self._ctx, None))
+        else:
+            g = np.ascontiguousarray(g, dtype=float).reshape(-1)
+            self._check(self.lib.fdapde_set_dirichlet(self._ctx, _dp(g)))
+
+    # ---- compute
+    def init(self, assembly=ASSEMBLY_ROWS):
+        opt = Options(method=0, maxit=0, rtol=0.0, assembly=assembly, check_every=0)
+        self._check(self.lib.fdapde_init(self._ctx, C.byref(opt)))
+
+    def assemble_operator(self, which, op: Operator, assembly=ASSEMBLY_ROWS):
+        terms, keep = op.c_terms()
+        self._check(self.lib.fdapde_assemble_operator(self._ctx, which, len(op.terms), terms, assembly))
+
+    def solve(self, method=SOLVER_AUTO, rtol=1e-10, maxit=0, check_every=0, raise_on_noconv=True):
+        opt = Options(method=method, maxit=maxit, rtol=rtol, assembly=0, check_every=check_every)
+        info = Info()
+        rc = self.lib.fdapde_solve(self._ctx, C.byref(opt), C.byref(info))
+        if rc != OK and (raise_on_noconv or rc != ENOCONV):
+            self._check(rc)
+        return info
+
+    def info(self):
+        info = Info()
+        self._check(self.lib.fdapde_info_get(self._ctx, C.byref(info)))
+        return info
+
+    # ---- getters
+    def matrix_values(self, which=MAT_STIFF):
+        out = np.zeros(self.sizes()["nnz"])
+        self._check(self.lib.fdapde_matrix_values(self._ctx, which, _dp(out)))
+        return out
+
+    def force(self, ncols=1):
+        out = np.zeros(self.sizes()["n_dofs"] * ncols)
+        self._check(self.lib.fdapde_force(self._ctx, _dp(out)))
+        return out
+
+    def solution(self):
+        out = np.zeros(self.sizes()["n_dofs"])
+        self._check(self.lib.fdapde_solution(self._ctx, _dp(out)))
+        return out
+
+    def spmv(self, which, x):
+        x = np.ascontiguousarray(x, dtype=float)
+        y = np.zeros_like(x)
+        self._check(self.lib.fdapde_spmv(self._ctx, which, _dp(x), _dp(y)))
+        return y
+
+    def bench_spmv(self, reps=50):
+        ms, by = C.c_double(), C.c_double()
+        self._check(self.lib.fdapde_bench_spmv(self._ctx, reps, C.byref(ms), C.byref(by)))
+        return ms.value, by.value
+
+    def stream(self):
+        return self.lib.fdapde_stream(self._ctx)
+
+    def synchronize(self):
+        self._check(self.lib.fdapde_synchronize(self._ctx))

@@ -1,0 +1,541 @@
+// host_setup.cpp -- integer / index work done once per discrete space, on the host, off the timed path:
+//   * DOF enumeration in the reference's numbering         (LagrangianBasis::enumerate_dofs, basis/lagrangian_basis.h:94-136;
+//                                                            edge ids of Triangulation<2,N> / <3,3>, geometry/triangulation.h:150-193, 348-377)
+//   * DOF coordinates                                       (LagrangianBasis::dofs_coords, basis/lagrangian_basis.h:159-183)
+//   * CSR sparsity pattern of the assembled operators       (what setFromTriplets + makeCompressed produce, fem_assembler.h:112-113)
+//   * the device-side layout: locality (Morton) renumbering of nodes / DOFs / cells, row-owner adjacency in
+//     sliced-ELL form with per-visit column slots, SpMV row blocks, element colouring.
+// Nothing here touches floating-point results except copying coordinates; all of it is checked bit-exactly against the
+// oracle by tests/test_host_logic.py on a host-only context.
+//
+// The edge numbering is reproduced with sorts instead of the reference's hash maps: an edge's id is the rank of its
+// first occurrence in the reference's traversal order (cells ascending x local pattern), which a sort by
+// (edge key, occurrence index) yields directly and in parallel-friendly form.
+#include <algorithm>
+#include <array>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <numeric>
+#include <thread>
+
+#include "internal.h"
+
+namespace fdapde_hip {
+
+namespace {
+
+unsigned hw_threads() {
+    unsigned n = std::thread::hardware_concurrency();
+    return n == 0 ? 4 : std::min(n, 64u);
+}
+
+// run fn(begin, end, tid) over [0, n) in contiguous chunks
+template <typename F> void parallel_for(int64_t n, F&& fn, int64_t grain = 4096) {
+    unsigned nt = hw_threads();
+    if (n < grain * 2 || nt == 1) {
+        fn(int64_t(0), n, 0u);
+        return;
+    }
+    nt = (unsigned)std::min<int64_t>(nt, (n + grain - 1) / grain);
+    std::vector<std::thread> th;
+    const int64_t chunk = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; ++t) {
+        int64_t b = t * chunk, e = std::min(n, b + chunk);
+        if (b >= e) break;
+        th.emplace_back([=, &fn] { fn(b, e, t); });
+    }
+    for (auto& x : th) x.join();
+}
+unsigned n_chunks(int64_t n, int64_t grain = 4096) {
+    unsigned nt = hw_threads();
+    if (n < grain * 2 || nt == 1) return 1;
+    return (unsigned)std::min<int64_t>(nt, (n + grain - 1) / grain);
+}
+
+// LSD radix sort of (key, value) pairs by 64-bit key, 11-bit digits; stable
+void radix_sort_pairs(std::vector<uint64_t>& key, std::vector<int32_t>& val) {
+    const size_t n = key.size();
+    if (n < 2) return;
+    uint64_t all_or = 0;
+    for (uint64_t k : key) all_or |= k;
+    std::vector<uint64_t> k2(n);
+    std::vector<int32_t> v2(n);
+    constexpr int B = 11;
+    constexpr size_t R = size_t(1) << B;
+    std::vector<size_t> cnt(R);
+    for (int shift = 0; shift < 64 && (all_or >> shift) != 0; shift += B) {
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (size_t i = 0; i < n; ++i) ++cnt[(key[i] >> shift) & (R - 1)];
+        size_t s = 0;
+        for (size_t d = 0; d < R; ++d) {
+            size_t c = cnt[d];
+            cnt[d] = s, s += c;
+        }
+        for (size_t i = 0; i < n; ++i) {
+            size_t p = cnt[(key[i] >> shift) & (R - 1)]++;
+            k2[p] = key[i], v2[p] = val[i];
+        }
+        key.swap(k2), val.swap(v2);
+    }
+}
+
+inline uint64_t spread3(uint64_t x) {  // 21 bits -> every third bit
+    x &= 0x1fffff;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+inline uint64_t spread2(uint64_t x) {  // 31 bits -> every second bit
+    x &= 0x7fffffff;
+    x = (x | x << 16) & 0x0000ffff0000ffffull;
+    x = (x | x << 8) & 0x00ff00ff00ff00ffull;
+    x = (x | x << 4) & 0x0f0f0f0f0f0f0f0full;
+    x = (x | x << 2) & 0x3333333333333333ull;
+    x = (x | x << 1) & 0x5555555555555555ull;
+    return x;
+}
+
+// permutation that sorts points (column-major n x N) along the Morton curve; returns i2e (new -> old)
+std::vector<int32_t> morton_order(int N, int64_t n, const double* pts_colmajor) {
+    std::vector<int32_t> idx((size_t)n);
+    std::iota(idx.begin(), idx.end(), 0);
+    if (n < 2) return idx;
+    double lo[3], hi[3];
+    for (int d = 0; d < N; ++d) {
+        lo[d] = hi[d] = pts_colmajor[(int64_t)d * n];
+        for (int64_t i = 1; i < n; ++i) {
+            double v = pts_colmajor[(int64_t)d * n + i];
+            lo[d] = std::min(lo[d], v), hi[d] = std::max(hi[d], v);
+        }
+    }
+    const double span = N == 3 ? 2097151.0 : 2147483647.0;
+    std::vector<uint64_t> key((size_t)n);
+    parallel_for(n, [&](int64_t b, int64_t e, unsigned) {
+        for (int64_t i = b; i < e; ++i) {
+            uint64_t q[3] = {0, 0, 0};
+            for (int d = 0; d < N; ++d) {
+                double w = hi[d] > lo[d] ? (pts_colmajor[(int64_t)d * n + i] - lo[d]) / (hi[d] - lo[d]) : 0.0;
+                q[d] = (uint64_t)std::llround(std::min(1.0, std::max(0.0, w)) * span);
+            }
+            key[(size_t)i] = N == 3 ? (spread3(q[0]) | spread3(q[1]) << 1 | spread3(q[2]) << 2)
+                                    : (spread2(q[0]) | spread2(q[1]) << 1);
+        }
+    });
+    radix_sort_pairs(key, idx);
+    return idx;
+}
+
+std::vector<int32_t> invert(const std::vector<int32_t>& p) {
+    std::vector<int32_t> inv(p.size());
+    for (size_t i = 0; i < p.size(); ++i) inv[(size_t)p[i]] = (int32_t)i;
+    return inv;
+}
+
+// local vertex pairs in the reference's enumeration orders
+constexpr int COMB23[3][2] = {{0, 1}, {0, 2}, {1, 2}};             // combinations<2,3>, utils/combinatorics.h:37-51
+constexpr int COMB34[4][3] = {{0, 1, 2}, {0, 1, 3}, {0, 2, 3}, {1, 2, 3}};   // combinations<3,4>
+// local slot of the edge joining local vertices (a,b): position of its midpoint in ReferenceElement<M,2>::nodes
+int edge_slot(int M, int a, int b) {
+    if (a > b) std::swap(a, b);
+    if (M == 2) return 3 + (a == 0 ? (b == 1 ? 0 : 1) : 2);
+    constexpr int S[4][4] = {{-1, 6, 5, 9}, {6, -1, 4, 7}, {5, 4, -1, 8}, {9, 7, 8, -1}};
+    return S[a][b];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// edge ids in first-seen order.
+// 2-D occurrence index: cell*3 + j, j over combinations<2,3>.
+// 3-D occurrence index: cell*12 + face*3 + k, faces over combinations<3,4> with sorted nodes, k over combinations<2,3>
+//      of the sorted face (triangulation.h:348-377).  The first occurrence of an edge is always inside a newly seen
+//      face (were the face seen before, the edge would have an earlier occurrence), so "min occurrence" == "first seen".
+// ---------------------------------------------------------------------------------------------------------------
+struct EdgeOcc {
+    uint64_t key;   // (min node << 32) | max node
+    int64_t occ;
+};
+
+int enumerate_edges(HostSpace& hs, std::vector<int32_t>& cell_edge /* n_cells x (3|6), by local pair order */,
+                    std::vector<uint8_t>& edge_bnd, std::string& err) {
+    const int M = hs.M, nv = M + 1;
+    const int per_cell = M == 2 ? 3 : 12;
+    const int64_t n_occ = hs.n_cells * per_cell;
+    std::vector<EdgeOcc> occ((size_t)n_occ);
+    parallel_for(hs.n_cells, [&](int64_t b, int64_t e, unsigned) {
+        for (int64_t c = b; c < e; ++c) {
+            const int32_t* cv = &hs.cells[(size_t)c * nv];
+            if (M == 2) {
+                for (int j = 0; j < 3; ++j) {
+                    uint32_t a = (uint32_t)cv[COMB23[j][0]], bb = (uint32_t)cv[COMB23[j][1]];
+                    if (a > bb) std::swap(a, bb);
+                    occ[(size_t)(c * 3 + j)] = {(uint64_t)a << 32 | bb, c * 3 + j};
+                }
+            } else {
+                for (int f = 0; f < 4; ++f) {
+                    std::array<int32_t, 3> face = {cv[COMB34[f][0]], cv[COMB34[f][1]], cv[COMB34[f][2]]};
+                    std::sort(face.begin(), face.end());
+                    for (int k = 0; k < 3; ++k) {
+                        uint32_t a = (uint32_t)face[COMB23[k][0]], bb = (uint32_t)face[COMB23[k][1]];
+                        occ[(size_t)(c * 12 + f * 3 + k)] = {(uint64_t)a << 32 | bb, c * 12 + f * 3 + k};
+                    }
+                }
+            }
+        }
+    });
+    std::sort(occ.begin(), occ.end(), [](const EdgeOcc& x, const EdgeOcc& y) {
+        return x.key != y.key ? x.key < y.key : x.occ < y.occ;
+    });
+    // unique edges: (first occurrence, key, multiplicity among 2-D occurrences)
+    struct Uniq {
+        int64_t first;
+        uint64_t key;
+        int32_t count;
+    };
+    std::vector<Uniq> uq;
+    uq.reserve((size_t)n_occ / 2 + 16);
+    for (int64_t i = 0; i < n_occ;) {
+        int64_t j = i + 1;
+        while (j < n_occ && occ[(size_t)j].key == occ[(size_t)i].key) ++j;
+        uq.push_back({occ[(size_t)i].occ, occ[(size_t)i].key, (int32_t)(j - i)});
+        i = j;
+    }
+    std::sort(uq.begin(), uq.end(), [](const Uniq& x, const Uniq& y) { return x.first < y.first; });
+    const int64_t ne = (int64_t)uq.size();
+    if (hs.n_nodes + ne > INT32_MAX) {
+        err = "DOF count exceeds int32";
+        return FDAPDE_EUNSUPPORTED;
+    }
+    hs.n_edges = ne;
+    edge_bnd.resize((size_t)ne);
+    // key -> id lookup through a sorted copy
+    std::vector<std::pair<uint64_t, int32_t>> by_key((size_t)ne);
+    for (int64_t e = 0; e < ne; ++e) {
+        by_key[(size_t)e] = {uq[(size_t)e].key, (int32_t)e};
+        if (M == 2) {
+            edge_bnd[(size_t)e] = uq[(size_t)e].count == 1;   // seen by exactly one cell (triangulation.h:177,187)
+        } else {
+            uint32_t a = (uint32_t)(uq[(size_t)e].key >> 32), b = (uint32_t)uq[(size_t)e].key;
+            edge_bnd[(size_t)e] = hs.node_bnd[a] && hs.node_bnd[b];   // triangulation.h:371
+        }
+    }
+    std::sort(by_key.begin(), by_key.end());
+    const int epc = M == 2 ? 3 : 6;
+    constexpr int P3[6][2] = {{0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 3}, {2, 3}};
+    cell_edge.resize((size_t)hs.n_cells * epc);
+    parallel_for(hs.n_cells, [&](int64_t b, int64_t e, unsigned) {
+        for (int64_t c = b; c < e; ++c) {
+            const int32_t* cv = &hs.cells[(size_t)c * nv];
+            for (int k = 0; k < epc; ++k) {
+                uint32_t a = (uint32_t)cv[M == 2 ? COMB23[k][0] : P3[k][0]];
+                uint32_t bb = (uint32_t)cv[M == 2 ? COMB23[k][1] : P3[k][1]];
+                if (a > bb) std::swap(a, bb);
+                uint64_t key = (uint64_t)a << 32 | bb;
+                auto it = std::lower_bound(by_key.begin(), by_key.end(), std::make_pair(key, (int32_t)0));
+                cell_edge[(size_t)c * epc + k] = it->second;
+            }
+        }
+    });
+    return FDAPDE_OK;
+}
+
+}  // namespace
+
+int host_set_mesh(HostSpace& hs, int M, int N, int64_t n_nodes, const double* nodes, int64_t n_cells,
+                  const int32_t* cells, const uint8_t* bnd, std::string& err) {
+    if (!((M == 2 && N == 2) || (M == 3 && N == 3))) {
+        err = "only Triangulation<2,2> and Triangulation<3,3> are on the accelerated path";
+        return FDAPDE_EUNSUPPORTED;
+    }
+    if (n_nodes <= 0 || n_cells <= 0 || !nodes || !cells || !bnd) {
+        err = "empty mesh or null pointer";
+        return FDAPDE_EINVAL;
+    }
+    if (n_nodes > INT32_MAX || n_cells >= (int64_t(1) << 27)) {
+        err = "mesh too large for int32 indices (n_nodes <= 2^31-1, n_cells < 2^27)";
+        return FDAPDE_EUNSUPPORTED;
+    }
+    for (int64_t i = 0; i < n_cells * (M + 1); ++i)
+        if (cells[i] < 0 || cells[i] >= n_nodes) {
+            err = "cell references a node id out of range";
+            return FDAPDE_EINVAL;
+        }
+    hs = HostSpace{};
+    hs.M = M, hs.N = N, hs.n_nodes = n_nodes, hs.n_cells = n_cells;
+    hs.nodes.assign(nodes, nodes + n_nodes * N);
+    hs.cells.assign(cells, cells + n_cells * (M + 1));
+    hs.node_bnd.resize((size_t)n_nodes);
+    for (int64_t i = 0; i < n_nodes; ++i) hs.node_bnd[(size_t)i] = bnd[i] ? 1 : 0;
+    return FDAPDE_OK;
+}
+
+int host_build_space(HostSpace& hs, int order, std::string& err) {
+    auto t0 = std::chrono::steady_clock::now();
+    if (hs.n_cells == 0) {
+        err = "mesh not uploaded";
+        return FDAPDE_ENOTINIT;
+    }
+    if (order != 1 && order != 2) {
+        err = "fem_order must be 1 or 2 (LagrangianBasis::enumerate_dofs requires Order <= 2)";
+        return FDAPDE_EUNSUPPORTED;
+    }
+    const int M = hs.M, N = hs.N, nv = M + 1;
+    const int nb = n_basis_of(M, order);
+    hs.order = order, hs.nb = nb, hs.nq = n_quadrature_of(M, order);
+    const int64_t nc = hs.n_cells, nn = hs.n_nodes;
+
+    // ---- DOF table, boundary DOFs (reference numbering) ------------------------------------------------------
+    hs.dofs.assign((size_t)nc * nb, 0);
+    for (int64_t c = 0; c < nc; ++c)
+        for (int v = 0; v < nv; ++v) hs.dofs[(size_t)c * nb + v] = hs.cells[(size_t)c * nv + v];
+    hs.dof_bnd.assign(hs.node_bnd.begin(), hs.node_bnd.end());
+    hs.n_edges = 0;
+    if (order == 2) {
+        std::vector<int32_t> cell_edge;
+        std::vector<uint8_t> edge_bnd;
+        int rc = enumerate_edges(hs, cell_edge, edge_bnd, err);
+        if (rc) return rc;
+        const int epc = M == 2 ? 3 : 6;
+        constexpr int P3[6][2] = {{0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 3}, {2, 3}};
+        for (int64_t c = 0; c < nc; ++c)
+            for (int k = 0; k < epc; ++k) {
+                int a = M == 2 ? COMB23[k][0] : P3[k][0], b = M == 2 ? COMB23[k][1] : P3[k][1];
+                hs.dofs[(size_t)c * nb + edge_slot(M, a, b)] = (int32_t)nn + cell_edge[(size_t)c * epc + k];
+            }
+        hs.dof_bnd.insert(hs.dof_bnd.end(), edge_bnd.begin(), edge_bnd.end());
+    }
+    hs.n_dofs = nn + hs.n_edges;
+    const int64_t nd = hs.n_dofs;
+
+    // ---- DOF coordinates: vertices, then J * ref + x0 from the first visiting cell (lagrangian_basis.h:159-183)
+    BasisTables tb;
+    build_basis_tables(M, order, &tb);
+    hs.dof_coords.assign((size_t)nd * N, 0.0);
+    for (int d = 0; d < N; ++d) std::memcpy(&hs.dof_coords[(size_t)d * nd], &hs.nodes[(size_t)d * nn], sizeof(double) * nn);
+    if (order == 2) {
+        std::vector<uint8_t> seen((size_t)nd, 0);
+        for (int64_t c = 0; c < nc; ++c)
+            for (int j = nv; j < nb; ++j) {
+                int32_t dof = hs.dofs[(size_t)c * nb + j];
+                if (seen[(size_t)dof]) continue;
+                seen[(size_t)dof] = 1;
+                int32_t v0 = hs.cells[(size_t)c * nv];
+                for (int d = 0; d < N; ++d) {
+                    double x0 = hs.nodes[(size_t)d * nn + v0], acc = 0;
+                    for (int k = 0; k < M; ++k)
+                        acc += (hs.nodes[(size_t)d * nn + hs.cells[(size_t)c * nv + k + 1]] - x0) * tb.refnodes[j * M + k];
+                    hs.dof_coords[(size_t)d * nd + dof] = acc + x0;
+                }
+            }
+    }
+
+    // ---- locality numbering --------------------------------------------------------------------------------
+    hs.node_i2e = morton_order(N, nn, hs.nodes.data());
+    hs.node_e2i = invert(hs.node_i2e);
+    if (order == 1) {
+        hs.dof_i2e = hs.node_i2e, hs.dof_e2i = hs.node_e2i;
+    } else {
+        hs.dof_i2e = morton_order(N, nd, hs.dof_coords.data());
+        hs.dof_e2i = invert(hs.dof_i2e);
+    }
+    {
+        std::vector<double> bary((size_t)nc * N);
+        parallel_for(nc, [&](int64_t b, int64_t e, unsigned) {
+            for (int64_t c = b; c < e; ++c)
+                for (int d = 0; d < N; ++d) {
+                    double s = 0;
+                    for (int v = 0; v < nv; ++v) s += hs.nodes[(size_t)d * nn + hs.cells[(size_t)c * nv + v]];
+                    bary[(size_t)d * nc + c] = s / nv;
+                }
+        });
+        hs.cell_i2e = morton_order(N, nc, bary.data());
+        hs.cell_e2i = invert(hs.cell_i2e);
+    }
+    const int NP = N == 2 ? 2 : 4;
+    hs.vcoords_i.assign((size_t)nn * NP, 0.0);
+    for (int64_t i = 0; i < nn; ++i)
+        for (int d = 0; d < N; ++d) hs.vcoords_i[(size_t)i * NP + d] = hs.nodes[(size_t)d * nn + hs.node_i2e[(size_t)i]];
+    hs.dof_bnd_i.resize((size_t)nd);
+    for (int64_t i = 0; i < nd; ++i) hs.dof_bnd_i[(size_t)i] = hs.dof_bnd[(size_t)hs.dof_i2e[(size_t)i]];
+    hs.cverts_i.resize((size_t)nc * nv), hs.cdofs_i.resize((size_t)nc * nb);
+    parallel_for(nc, [&](int64_t b, int64_t e, unsigned) {
+        for (int64_t ci = b; ci < e; ++ci) {
+            int64_t ce = hs.cell_i2e[(size_t)ci];
+            for (int v = 0; v < nv; ++v) hs.cverts_i[(size_t)ci * nv + v] = hs.node_e2i[(size_t)hs.cells[(size_t)ce * nv + v]];
+            for (int j = 0; j < nb; ++j) hs.cdofs_i[(size_t)ci * nb + j] = hs.dof_e2i[(size_t)hs.dofs[(size_t)ce * nb + j]];
+        }
+    });
+
+    // ---- row-owner adjacency: DOF -> (cell, local index), cells ascending -----------------------------------
+    std::vector<int64_t> vptr((size_t)nd + 1, 0);
+    for (int64_t k = 0; k < nc * nb; ++k) ++vptr[(size_t)hs.cdofs_i[(size_t)k] + 1];
+    for (int64_t i = 0; i < nd; ++i) vptr[(size_t)i + 1] += vptr[(size_t)i];
+    std::vector<int32_t> vis((size_t)(nc * nb));
+    {
+        std::vector<int64_t> pos(vptr.begin(), vptr.end() - 1);
+        for (int64_t c = 0; c < nc; ++c)
+            for (int j = 0; j < nb; ++j) vis[(size_t)pos[(size_t)hs.cdofs_i[(size_t)c * nb + j]]++] = (int32_t)(c * 16 + j);
+    }
+
+    // ---- internal CSR pattern: row = sorted union of the DOFs of the visiting cells ---------------------------
+    {
+        const unsigned nt = n_chunks(nd, 2048);
+        std::vector<std::vector<int32_t>> tcols(nt);
+        std::vector<int32_t> rowlen((size_t)nd);
+        std::vector<int64_t> tbegin(nt, 0);
+        parallel_for(nd, [&](int64_t b, int64_t e, unsigned t) {
+            tbegin[t] = b;
+            std::vector<int32_t> cand;
+            auto& out = tcols[t];
+            for (int64_t r = b; r < e; ++r) {
+                cand.clear();
+                for (int64_t k = vptr[(size_t)r]; k < vptr[(size_t)r + 1]; ++k) {
+                    const int32_t* cd = &hs.cdofs_i[(size_t)(vis[(size_t)k] >> 4) * nb];
+                    cand.insert(cand.end(), cd, cd + nb);
+                }
+                std::sort(cand.begin(), cand.end());
+                auto last = std::unique(cand.begin(), cand.end());
+                rowlen[(size_t)r] = (int32_t)(last - cand.begin());
+                out.insert(out.end(), cand.begin(), last);
+            }
+        }, 2048);
+        int64_t total = 0;
+        for (auto& v : tcols) total += (int64_t)v.size();
+        if (total > INT32_MAX) {
+            err = "nnz exceeds int32";
+            return FDAPDE_EUNSUPPORTED;
+        }
+        hs.nnz = total;
+        hs.rowptr_i.assign((size_t)nd + 1, 0);
+        hs.max_row = 0;
+        for (int64_t r = 0; r < nd; ++r) {
+            hs.rowptr_i[(size_t)r + 1] = hs.rowptr_i[(size_t)r] + rowlen[(size_t)r];
+            hs.max_row = std::max(hs.max_row, rowlen[(size_t)r]);
+        }
+        hs.colidx_i.resize((size_t)total);
+        for (unsigned t = 0; t < nt; ++t)
+            if (!tcols[t].empty())
+                std::memcpy(&hs.colidx_i[(size_t)hs.rowptr_i[(size_t)tbegin[t]]], tcols[t].data(), sizeof(int32_t) * tcols[t].size());
+    }
+    if (hs.max_row > 65535 || hs.max_row > kSpmvNnz) {
+        err = "row too long for the uint16 slot map / SpMV row block";
+        return FDAPDE_EUNSUPPORTED;
+    }
+    hs.diag_i.resize((size_t)nd);
+    parallel_for(nd, [&](int64_t b, int64_t e, unsigned) {
+        for (int64_t r = b; r < e; ++r) {
+            const int32_t* beg = &hs.colidx_i[(size_t)hs.rowptr_i[(size_t)r]];
+            const int32_t* end = &hs.colidx_i[(size_t)hs.rowptr_i[(size_t)r + 1]];
+            hs.diag_i[(size_t)r] = (int32_t)(std::lower_bound(beg, end, (int32_t)r) - hs.colidx_i.data());
+        }
+    });
+
+    // ---- reference-numbering CSR pattern + internal slot -> reference slot ------------------------------------
+    hs.rowptr_e.assign((size_t)nd + 1, 0);
+    for (int64_t re = 0; re < nd; ++re) {
+        int64_t ri = hs.dof_e2i[(size_t)re];
+        hs.rowptr_e[(size_t)re + 1] = hs.rowptr_e[(size_t)re] + (hs.rowptr_i[(size_t)ri + 1] - hs.rowptr_i[(size_t)ri]);
+    }
+    hs.colidx_e.resize((size_t)hs.nnz), hs.slot_i2e.resize((size_t)hs.nnz);
+    parallel_for(nd, [&](int64_t b, int64_t e, unsigned) {
+        std::vector<std::pair<int32_t, int32_t>> tmp;
+        for (int64_t ri = b; ri < e; ++ri) {
+            const int32_t k0 = hs.rowptr_i[(size_t)ri], k1 = hs.rowptr_i[(size_t)ri + 1];
+            tmp.clear();
+            for (int32_t k = k0; k < k1; ++k) tmp.emplace_back(hs.dof_i2e[(size_t)hs.colidx_i[(size_t)k]], k);
+            std::sort(tmp.begin(), tmp.end());
+            const int32_t base = hs.rowptr_e[(size_t)hs.dof_i2e[(size_t)ri]];
+            for (size_t t = 0; t < tmp.size(); ++t) {
+                hs.colidx_e[(size_t)base + t] = tmp[t].first;
+                hs.slot_i2e[(size_t)tmp[t].second] = base + (int32_t)t;
+            }
+        }
+    }, 2048);
+
+    // ---- sliced-ELL adjacency + per-visit column slots -------------------------------------------------------
+    const int64_t n_slices = (nd + kSlice - 1) / kSlice;
+    hs.sl_off.assign((size_t)n_slices + 1, 0);
+    for (int64_t s = 0; s < n_slices; ++s) {
+        int64_t w = 0;
+        for (int64_t r = s * kSlice; r < std::min(nd, (s + 1) * kSlice); ++r) w = std::max(w, vptr[(size_t)r + 1] - vptr[(size_t)r]);
+        hs.sl_off[(size_t)s + 1] = hs.sl_off[(size_t)s] + w;
+    }
+    hs.nbw = (nb * 2 + 3) / 4;
+    const int64_t padded = hs.sl_off[(size_t)n_slices] * kSlice;
+    hs.adj.assign((size_t)padded, -1);
+    hs.slotw.assign((size_t)padded * hs.nbw, 0u);
+    parallel_for(nd, [&](int64_t b, int64_t e, unsigned) {
+        for (int64_t r = b; r < e; ++r) {
+            const int64_t s = r / kSlice, lane = r % kSlice;
+            const int32_t* rbeg = &hs.colidx_i[(size_t)hs.rowptr_i[(size_t)r]];
+            const int32_t* rend = &hs.colidx_i[(size_t)hs.rowptr_i[(size_t)r + 1]];
+            for (int64_t k = vptr[(size_t)r]; k < vptr[(size_t)r + 1]; ++k) {
+                const int64_t v = k - vptr[(size_t)r];
+                const int64_t at = (hs.sl_off[(size_t)s] + v) * kSlice + lane;
+                hs.adj[(size_t)at] = vis[(size_t)k];
+                const int32_t* cd = &hs.cdofs_i[(size_t)(vis[(size_t)k] >> 4) * nb];
+                uint16_t* sw = reinterpret_cast<uint16_t*>(&hs.slotw[(size_t)at * hs.nbw]);
+                for (int j = 0; j < nb; ++j) sw[j] = (uint16_t)(std::lower_bound(rbeg, rend, cd[j]) - rbeg);
+            }
+        }
+    }, 2048);
+    const int64_t n_blk = (nd + kAsmBlock - 1) / kAsmBlock;
+    hs.blk_nnz_cap.resize((size_t)n_blk);
+    hs.max_blk_nnz = 0;
+    for (int64_t b = 0; b < n_blk; ++b) {
+        int32_t v = hs.rowptr_i[(size_t)std::min(nd, (b + 1) * kAsmBlock)] - hs.rowptr_i[(size_t)b * kAsmBlock];
+        hs.blk_nnz_cap[(size_t)b] = v, hs.max_blk_nnz = std::max(hs.max_blk_nnz, v);
+    }
+
+    // ---- SpMV row blocks: consecutive rows with at most kSpmvNnz nonzeros -----------------------------------
+    hs.rb_row.clear();
+    hs.rb_row.push_back(0);
+    for (int64_t r = 0; r < nd;) {
+        int64_t e = r;
+        const int32_t base = hs.rowptr_i[(size_t)r];
+        while (e < nd && hs.rowptr_i[(size_t)e + 1] - base <= kSpmvNnz && e - r < 1024) ++e;
+        hs.rb_row.push_back((int32_t)e);
+        r = e;
+    }
+    hs.n_colours = 0, hs.colour_off.clear(), hs.colour_cells.clear();
+    hs.setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return FDAPDE_OK;
+}
+
+// Greedy element colouring over the internal cell order: cells of one colour share no DOF, so their scatter into the
+// global matrix needs no atomics.  Colour-contiguous cell lists keep the index reads of each pass coalesced.
+int host_build_colouring(HostSpace& hs, std::string& err) {
+    if (hs.n_colours > 0) return FDAPDE_OK;
+    constexpr int W = 4;   // 256 colours
+    const int nb = hs.nb;
+    std::vector<uint64_t> mask((size_t)hs.n_dofs * W, 0);
+    std::vector<int32_t> colour((size_t)hs.n_cells);
+    int ncol = 0;
+    for (int64_t c = 0; c < hs.n_cells; ++c) {
+        uint64_t used[W] = {0, 0, 0, 0};
+        for (int j = 0; j < nb; ++j)
+            for (int w = 0; w < W; ++w) used[w] |= mask[(size_t)hs.cdofs_i[(size_t)c * nb + j] * W + w];
+        int col = -1;
+        for (int w = 0; w < W && col < 0; ++w)
+            if (~used[w]) col = w * 64 + __builtin_ctzll(~used[w]);
+        if (col < 0) {
+            err = "more than 256 colours needed";
+            return FDAPDE_EUNSUPPORTED;
+        }
+        colour[(size_t)c] = col, ncol = std::max(ncol, col + 1);
+        for (int j = 0; j < nb; ++j) mask[(size_t)hs.cdofs_i[(size_t)c * nb + j] * W + col / 64] |= uint64_t(1) << (col % 64);
+    }
+    hs.n_colours = ncol;
+    hs.colour_off.assign((size_t)ncol + 1, 0);
+    for (int64_t c = 0; c < hs.n_cells; ++c) ++hs.colour_off[(size_t)colour[(size_t)c] + 1];
+    for (int k = 0; k < ncol; ++k) hs.colour_off[(size_t)k + 1] += hs.colour_off[(size_t)k];
+    hs.colour_cells.resize((size_t)hs.n_cells);
+    std::vector<int32_t> pos(hs.colour_off.begin(), hs.colour_off.end() - 1);
+    for (int64_t c = 0; c < hs.n_cells; ++c) hs.colour_cells[(size_t)pos[(size_t)colour[(size_t)c]]++] = (int32_t)c;
+    return FDAPDE_OK;
+}
+
+}  // namespace fdapde_hip

@@ -1,0 +1,84 @@
+// internal.h -- context layout shared by the host-side setup (host_setup.cpp) and the HIP side (capi.hip).
+#ifndef FDAPDE_INTERNAL_H
+#define FDAPDE_INTERNAL_H
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/fdapde_hip.h"
+
+namespace fdapde_hip {
+
+constexpr int kMaxBasis = 10;   // 3-D P2
+constexpr int kMaxQuad = 6;     // 2-D P2 rule
+constexpr int kMaxTerms = 8;    // leaves per operator expression
+constexpr int kSlice = 64;      // rows per adjacency slice = one wavefront
+constexpr int kAsmBlock = 256;  // rows per assembly workgroup
+
+// quadrature + reference basis values, built once per (M, R) on the host (tables.cpp)
+struct BasisTables {
+    int M = 0, R = 0, nb = 0, nq = 0;
+    double qn[kMaxQuad * 3] = {};             // quadrature nodes, row-major nq x M
+    double qw[kMaxQuad] = {};                 // weights (sum 1)
+    double psi[kMaxBasis * kMaxQuad] = {};    // psi_i(p_q), [i*nq + q]
+    double dpsi[kMaxBasis * kMaxQuad * 3] = {};   // d psi_i / d xi_k (p_q), [(i*nq + q)*3 + k]
+    double refnodes[kMaxBasis * 3] = {};      // reference coordinates of the local DOFs, row-major nb x M
+};
+int build_basis_tables(int M, int R, BasisTables* t);
+int n_basis_of(int M, int R);
+int n_quadrature_of(int M, int R);
+
+// host-side description of the discrete space; everything below is integer/index work
+struct HostSpace {
+    // ---- mesh as handed over (reference numbering, "ext")
+    int M = 0, N = 0;
+    int64_t n_nodes = 0, n_cells = 0;
+    std::vector<double> nodes;      // column-major n_nodes x N
+    std::vector<int32_t> cells;     // row-major n_cells x (M+1)
+    std::vector<uint8_t> node_bnd;  // per node
+    // ---- DOFs in the reference's numbering
+    int order = 0, nb = 0, nq = 0;
+    int64_t n_dofs = 0, n_edges = 0;
+    std::vector<int32_t> dofs;        // row-major n_cells x nb
+    std::vector<uint8_t> dof_bnd;     // per DOF
+    std::vector<double> dof_coords;   // column-major n_dofs x N
+    // ---- internal (locality) numbering: Morton order of DOF / node / cell positions
+    std::vector<int32_t> dof_e2i, dof_i2e, node_e2i, node_i2e, cell_e2i, cell_i2e;
+    // ---- CSR pattern, reference numbering (what stiff()/mass() expose)
+    std::vector<int32_t> rowptr_e, colidx_e;
+    // ---- CSR pattern, internal numbering (what the kernels use) + map internal slot -> reference slot
+    std::vector<int32_t> rowptr_i, colidx_i, slot_i2e, diag_i;
+    int64_t nnz = 0;
+    int32_t max_row = 0;
+    // ---- internal cell data: vertex node ids (internal node numbering) and DOF ids (internal DOF numbering)
+    std::vector<int32_t> cverts_i;   // n_cells x (M+1)
+    std::vector<int32_t> cdofs_i;    // n_cells x nb
+    std::vector<double> vcoords_i;   // internal node id -> NP doubles (NP = 2 for N=2, 4 for N=3)
+    std::vector<uint8_t> dof_bnd_i;
+    // ---- row-owner adjacency in sliced-ELL layout: slice s covers rows [64 s, 64 s + 64)
+    //      entry (s, v, lane) at (sl_off[s] + v) * 64 + lane  holds  cell_i * 16 + local_index, or -1 (padding)
+    std::vector<int64_t> sl_off;      // n_slices + 1, in units of 64-lane rows
+    std::vector<int32_t> adj;         // sl_off.back() * 64
+    int nbw = 0;                      // 32-bit words of slot data per visit: ceil(nb * 2 / 4)
+    std::vector<uint32_t> slotw;      // adj.size() * nbw; packed uint16 row-relative slots of the nb local columns
+    std::vector<int32_t> blk_nnz_cap; // per assembly block: nnz of its 256 rows
+    int32_t max_blk_nnz = 0;
+    // ---- element colouring (cells of one colour share no DOF), for the colour-partitioned scatter
+    int n_colours = 0;
+    std::vector<int32_t> colour_off;  // n_colours + 1
+    std::vector<int32_t> colour_cells;// internal cell ids grouped by colour
+    // ---- SpMV row blocks (CSR-stream): rows [rb_row[b], rb_row[b+1]) hold <= kSpmvNnz nonzeros
+    std::vector<int32_t> rb_row;
+    double setup_ms = 0;
+};
+
+constexpr int kSpmvNnz = 4096;  // products staged in LDS per row block (32 KiB)
+
+int host_set_mesh(HostSpace& hs, int M, int N, int64_t n_nodes, const double* nodes, int64_t n_cells,
+                  const int32_t* cells, const uint8_t* bnd, std::string& err);
+int host_build_space(HostSpace& hs, int order, std::string& err);
+int host_build_colouring(HostSpace& hs, std::string& err);
+
+}  // namespace fdapde_hip
+#endif

@@ -1,0 +1,635 @@
+// kernels.h -- hand-written HIP kernels for gfx950 (MI355X): FEM operator / forcing assembly and the Krylov solve.
+//
+// Everything here is HBM/L2-bandwidth-bound fp64 + int32 index work; there is no dense contraction, so no MFMA.
+// What matters (cdna_hip_programming.md guidelines 2, 3, 11-13; MI355X_MICROARCH.md "Global float atomics"):
+//   * index streams (adjacency, slots, colidx) and value streams are read with unit stride across the 64 lanes of a
+//     wavefront; gathers (vertex coordinates, x[col]) go through the XCD's L2, which the locality numbering built in
+//     host_setup.cpp keeps hot;
+//   * the default assembly is atomic-free: one lane owns one matrix row, visits the cells around its DOF, accumulates
+//     in LDS and the workgroup writes its rows once with coalesced stores (float atomics run at ~1.3 TB/s of added
+//     bytes chip-wide and ~17x slower when the 64 lanes hit 64 different rows -- an element-wise scatter is exactly
+//     that shape);
+//   * reductions are deterministic: per-workgroup partials in a fixed slot, re-reduced in a fixed order by the
+//     consumer kernel -- no float atomics in the solve.
+#ifndef FDAPDE_KERNELS_H
+#define FDAPDE_KERNELS_H
+
+#include <hip/hip_runtime.h>
+
+#include "internal.h"
+
+namespace fdapde_hip {
+
+// ---------------------------------------------------------------------------------------------------------------
+// device-side operator description (kernel argument, lives in SGPRs / scalar cache)
+// ---------------------------------------------------------------------------------------------------------------
+struct DevTerm {
+    int32_t kind, space_varying;
+    double coef;
+    double cst[9];
+    const double* data;   // device pointer, rows in INTERNAL cell order: (nq*cell_i + q) x (N*N | N | 1)
+};
+struct DevOp {
+    int32_t n;
+    int32_t needs_psi;    // any advection / reaction leaf
+    DevTerm t[kMaxTerms];
+};
+
+// quadrature + basis tables as they sit in device memory (copied to LDS by every workgroup that integrates)
+struct DevTables {
+    double qw[kMaxQuad];
+    double psi[kMaxBasis * kMaxQuad];        // [i*nq + q]
+    double dpsi[kMaxBasis * kMaxQuad * 3];   // [(i*nq + q)*3 + k]
+    double qn[kMaxQuad * 3];                 // [q*M + k]
+};
+constexpr int kTablesDoubles = sizeof(DevTables) / sizeof(double);
+
+struct AsmArgs {
+    int64_t n_dofs, n_cells;
+    const int32_t* cverts;     // n_cells x (M+1), internal node ids
+    const int32_t* cdofs;      // n_cells x nb, internal DOF ids
+    const double* vcoords;     // internal node id -> NP doubles
+    const int64_t* sl_off;     // adjacency slices
+    const int32_t* adj;
+    const uint32_t* slotw;
+    const int32_t* rowptr;
+    const int32_t* colidx;
+    const DevTables* tables;
+    double* vals;              // CSR values (internal slots) or nullptr
+    const double* fq;          // forcing at quadrature nodes, internal cell order, or nullptr
+    double* force;             // forcing vector (internal DOF order) or nullptr
+    int32_t lds_acc_cap;       // doubles available for the row accumulators
+};
+
+template <int M> struct Geo {
+    double invJ[M][M];   // J^{-1}
+    double measure;      // |det J| / M!
+};
+
+// Simplex::initialize (fdaPDE/geometry/simplex.h:184-195): J col j = x_{j+1} - x_0, invJ, measure = |det J| / M!
+template <int M> __device__ __forceinline__ void cell_geometry(const AsmArgs& a, int cell, Geo<M>& g) {
+    if constexpr (M == 2) {
+        const int32_t* cv = a.cverts + (int64_t)cell * 3;
+        const double2 x0 = *reinterpret_cast<const double2*>(a.vcoords + (int64_t)cv[0] * 2);
+        const double2 x1 = *reinterpret_cast<const double2*>(a.vcoords + (int64_t)cv[1] * 2);
+        const double2 x2 = *reinterpret_cast<const double2*>(a.vcoords + (int64_t)cv[2] * 2);
+        const double j00 = x1.x - x0.x, j01 = x2.x - x0.x, j10 = x1.y - x0.y, j11 = x2.y - x0.y;
+        const double det = j00 * j11 - j01 * j10;
+        const double id = 1.0 / det;
+        g.invJ[0][0] = j11 * id, g.invJ[0][1] = -j01 * id;
+        g.invJ[1][0] = -j10 * id, g.invJ[1][1] = j00 * id;
+        g.measure = fabs(det) * 0.5;
+    } else {
+        const int4 cv = *reinterpret_cast<const int4*>(a.cverts + (int64_t)cell * 4);
+        const double4 x0 = *reinterpret_cast<const double4*>(a.vcoords + (int64_t)cv.x * 4);
+        const double4 x1 = *reinterpret_cast<const double4*>(a.vcoords + (int64_t)cv.y * 4);
+        const double4 x2 = *reinterpret_cast<const double4*>(a.vcoords + (int64_t)cv.z * 4);
+        const double4 x3 = *reinterpret_cast<const double4*>(a.vcoords + (int64_t)cv.w * 4);
+        const double a00 = x1.x - x0.x, a01 = x2.x - x0.x, a02 = x3.x - x0.x;
+        const double a10 = x1.y - x0.y, a11 = x2.y - x0.y, a12 = x3.y - x0.y;
+        const double a20 = x1.z - x0.z, a21 = x2.z - x0.z, a22 = x3.z - x0.z;
+        const double c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+        const double det = a00 * c00 + a01 * c01 + a02 * c02;
+        const double id = 1.0 / det;
+        g.invJ[0][0] = c00 * id, g.invJ[1][0] = c01 * id, g.invJ[2][0] = c02 * id;
+        g.invJ[0][1] = (a02 * a21 - a01 * a22) * id;
+        g.invJ[1][1] = (a00 * a22 - a02 * a20) * id;
+        g.invJ[2][1] = (a01 * a20 - a00 * a21) * id;
+        g.invJ[0][2] = (a01 * a12 - a02 * a11) * id;
+        g.invJ[1][2] = (a02 * a10 - a00 * a12) * id;
+        g.invJ[2][2] = (a00 * a11 - a01 * a10) * id;
+        g.measure = fabs(det) * (1.0 / 6.0);
+    }
+}
+
+// physical gradient J^{-T} grad_ref: out[r] = sum_k invJ[k][r] * d[k]   (buff_invJ = invJ^T, fem_assembler.h:81)
+template <int M> __device__ __forceinline__ void phys_grad(const Geo<M>& g, const double* d, double* out) {
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+        double v = 0;
+#pragma unroll
+        for (int k = 0; k < M; ++k) v += g.invJ[k][r] * d[k];
+        out[r] = v;
+    }
+}
+
+// integrand of the weak form at one quadrature node: left-to-right sum of scaled leaves
+//   laplacian.h:43  -(g_i . g_j)      diffusion.h:54  -(g_i . K g_j)
+//   advection.h:55  psi_i (g_j . b)   reaction.h:52   c psi_i psi_j      dt.h:34-36  0
+template <int M>
+__device__ __forceinline__ double weak_form(const DevOp& op, int64_t qrow, double psi_i, double psi_j, const double* gi,
+                                            const double* gj) {
+    double total = 0;
+    for (int t = 0; t < op.n; ++t) {
+        const DevTerm& T = op.t[t];
+        double v = 0;
+        if (T.kind == FDAPDE_LAPLACIAN) {
+            double d = 0;
+#pragma unroll
+            for (int k = 0; k < M; ++k) d += gi[k] * gj[k];
+            v = -d;
+        } else if (T.kind == FDAPDE_DIFFUSION) {
+            double K[M * M];
+#pragma unroll
+            for (int k = 0; k < M * M; ++k) K[k] = T.space_varying ? T.data[qrow * (M * M) + k] : T.cst[k];
+            double d = 0;
+#pragma unroll
+            for (int r = 0; r < M; ++r) {
+                double kg = 0;
+#pragma unroll
+                for (int c = 0; c < M; ++c) kg += K[r * M + c] * gj[c];
+                d += gi[r] * kg;
+            }
+            v = -d;
+        } else if (T.kind == FDAPDE_ADVECTION) {
+            double d = 0;
+#pragma unroll
+            for (int k = 0; k < M; ++k) d += gj[k] * (T.space_varying ? T.data[qrow * M + k] : T.cst[k]);
+            v = psi_i * d;
+        } else if (T.kind == FDAPDE_REACTION) {
+            const double c = T.space_varying ? T.data[qrow] : T.cst[0];
+            v = c * psi_i * psi_j;
+        }
+        total = t == 0 ? T.coef * v : total + T.coef * v;
+    }
+    return total;
+}
+
+// One row of one element matrix: for local test function `il` of `cell`, emit(j, value) for every local trial
+// function j, value = measure * sum_q w_q * form(psi_il, psi_j)(p_q)   (integrator.h:92-106), and return the forcing
+// contribution measure * sum_q f_q psi_il(p_q) w_q (integrator.h:73-90) when fq is given.
+// `tb` points at the LDS copy of the tables.
+template <int M, int R, typename Emit>
+__device__ __forceinline__ double element_row(const AsmArgs& a, const DevOp& op, const DevTables* tb, int cell, int il,
+                                              bool want_matrix, Emit&& emit) {
+    constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
+    constexpr int NQ = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 5);
+    Geo<M> g;
+    cell_geometry<M>(a, cell, g);
+    const int64_t qrow0 = (int64_t)NQ * cell;
+    double fsum = 0;
+    if (a.fq != nullptr) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) fsum += (a.fq[qrow0 + q] * tb->psi[il * NQ + q]) * tb->qw[q];
+        fsum *= g.measure;
+    }
+    if (!want_matrix) return fsum;
+    // gradients of the owned test function at every quadrature node (P1: constant over the cell)
+    constexpr int NGQ = R == 1 ? 1 : NQ;
+    double gi[NGQ][M];
+#pragma unroll
+    for (int q = 0; q < NGQ; ++q) phys_grad<M>(g, &tb->dpsi[(il * NQ + q) * 3], gi[q]);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        double gj[NGQ][M];
+#pragma unroll
+        for (int q = 0; q < NGQ; ++q) phys_grad<M>(g, &tb->dpsi[(j * NQ + q) * 3], gj[q]);
+        double value = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const double pi = op.needs_psi ? tb->psi[il * NQ + q] : 0.0;
+            const double pj = op.needs_psi ? tb->psi[j * NQ + q] : 0.0;
+            value += weak_form<M>(op, qrow0 + q, pi, pj, gi[R == 1 ? 0 : q], gj[R == 1 ? 0 : q]) * tb->qw[q];
+        }
+        emit(j, value * g.measure);
+    }
+    return fsum;
+}
+
+__device__ __forceinline__ const DevTables* stage_tables(const DevTables* gsrc, double* lds) {
+    const double* src = reinterpret_cast<const double*>(gsrc);
+    for (int i = threadIdx.x; i < kTablesDoubles; i += blockDim.x) lds[i] = src[i];
+    return reinterpret_cast<const DevTables*>(lds);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row-owner assembly (default).  Workgroup = 256 consecutive matrix rows = 4 wavefronts = 4 adjacency slices.
+// Lane `l` of wavefront `w` owns row 256*block + 64*w + l, walks the sliced-ELL adjacency of its slice (unit-stride
+// int32 + packed-uint16 slot words across the wavefront), integrates its row of each visited element matrix and adds
+// it into LDS at (rowptr[row] - rowptr[row0]) + slot.  The workgroup then streams its contiguous value range to HBM
+// once.  No atomics, no colouring, bitwise reproducible, and for symmetric forms bitwise symmetric (both (i,j) and
+// (j,i) sum the same products over the same cells in the same order).
+// Replaces Assembler::discretize_operator + discretize_forcing (fdaPDE/finite_elements/fem_assembler.h:52-136).
+// ---------------------------------------------------------------------------------------------------------------
+template <int M, int R>
+__global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op) {
+    constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
+    constexpr int NBW = (NB * 2 + 3) / 4;
+    extern __shared__ double lds[];
+    const DevTables* tb = stage_tables(a.tables, lds);
+    double* acc = lds + kTablesDoubles;
+
+    const int64_t row0 = (int64_t)blockIdx.x * kAsmBlock;
+    const int64_t row = row0 + threadIdx.x;
+    const int64_t row_end = min(a.n_dofs, row0 + kAsmBlock);
+    const bool want_matrix = a.vals != nullptr;
+    const int32_t base = a.rowptr[row0];
+    const int32_t blk_nnz = a.rowptr[row_end] - base;
+    const bool in_lds = blk_nnz <= a.lds_acc_cap;
+    const int32_t my0 = row < a.n_dofs ? a.rowptr[row] : 0;
+    const int32_t my1 = row < a.n_dofs ? a.rowptr[row + 1] : 0;
+    if (want_matrix) {
+        if (in_lds) {
+            for (int k = threadIdx.x; k < blk_nnz; k += kAsmBlock) acc[k] = 0.0;
+        } else {
+            for (int k = my0; k < my1; ++k) a.vals[k] = 0.0;
+        }
+    }
+    __syncthreads();
+
+    const int64_t slice = row >> 6;
+    const int lane = threadIdx.x & 63;
+    double fsum = 0;
+    if (row0 + (threadIdx.x & ~63) < a.n_dofs) {   // wave-uniform: slice exists
+        const int64_t off = a.sl_off[slice], width = a.sl_off[slice + 1] - off;
+        for (int64_t v = 0; v < width; ++v) {
+            const int64_t at = (off + v) * kSlice + lane;
+            const int32_t code = a.adj[at];
+            if (code < 0) continue;
+            uint32_t sw[NBW];
+#pragma unroll
+            for (int w = 0; w < NBW; ++w) sw[w] = a.slotw[at * NBW + w];
+            fsum += element_row<M, R>(a, op, tb, code >> 4, code & 15, want_matrix, [&](int j, double value) {
+                const uint32_t slot = (sw[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+                if (in_lds)
+                    acc[my0 - base + (int32_t)slot] += value;
+                else
+                    a.vals[my0 + (int32_t)slot] += value;
+            });
+        }
+    }
+    if (a.force != nullptr && row < a.n_dofs) a.force[row] = fsum;
+    if (want_matrix && in_lds) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < blk_nnz; k += kAsmBlock) a.vals[base + k] = acc[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Element-wise scatter variants (kept for cross-checking and for the measurements in DESIGN.md):
+//   ATOMIC = true : one lane per (cell, local row), fp64 global atomics into the CSR slot found by binary search.
+//   ATOMIC = false: the same kernel launched once per colour over colour-contiguous cell lists; cells of a colour
+//                   share no DOF, so plain read-modify-write is race-free ("colour-partitioned passes").
+// vals must be zeroed before the first launch.
+// ---------------------------------------------------------------------------------------------------------------
+template <int M, int R, bool ATOMIC>
+__global__ __launch_bounds__(256) void k_assemble_scatter(AsmArgs a, DevOp op, const int32_t* cell_list, int64_t n_list) {
+    constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
+    extern __shared__ double lds[];
+    const DevTables* tb = stage_tables(a.tables, lds);
+    __syncthreads();
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_list * NB) return;
+    const int64_t li = idx / NB;
+    const int il = (int)(idx - li * NB);
+    const int cell = cell_list ? cell_list[li] : (int)li;
+    const int32_t* cd = a.cdofs + (int64_t)cell * NB;
+    const int32_t row = cd[il];
+    const int32_t k0 = a.rowptr[row], k1 = a.rowptr[row + 1];
+    const double f = element_row<M, R>(a, op, tb, cell, il, a.vals != nullptr, [&](int j, double value) {
+        const int32_t col = cd[j];
+        int32_t lo = k0, hi = k1;
+        while (lo < hi) {
+            const int32_t mid = (lo + hi) >> 1;
+            if (a.colidx[mid] < col) lo = mid + 1; else hi = mid;
+        }
+        if (ATOMIC)
+            unsafeAtomicAdd(&a.vals[lo], value);
+        else
+            a.vals[lo] += value;
+    });
+    if (a.force != nullptr) {
+        if (ATOMIC) unsafeAtomicAdd(&a.force[row], f); else a.force[row] += f;
+    }
+}
+
+// Integrator::quadrature_nodes (integrator.h:109-121): out row nq*cell_ext + q = J p_q + x0, column-major rows x N
+template <int M>
+__global__ void k_quadrature_nodes(AsmArgs a, const int32_t* cell_i2e, int nq, double* out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.n_cells * nq) return;
+    const int64_t ci = idx / nq;
+    const int q = (int)(idx - ci * nq);
+    constexpr int NP = M == 2 ? 2 : 4;
+    const int32_t* cv = a.cverts + ci * (M + 1);
+    const double* x0 = a.vcoords + (int64_t)cv[0] * NP;
+    const int64_t rows = a.n_cells * nq;
+    const int64_t orow = (int64_t)cell_i2e[ci] * nq + q;
+    for (int d = 0; d < M; ++d) {
+        double v = 0;
+        for (int k = 0; k < M; ++k) v += (a.vcoords[(int64_t)cv[k + 1] * NP + d] - x0[d]) * a.tables->qn[q * M + k];
+        out[(int64_t)d * rows + orow] = v + x0[d];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// reductions
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+// sum over the workgroup; result valid in every thread.  red must hold blockDim/64 + 1 doubles.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0;
+        for (int i = 0; i < nw; ++i) s += red[i];
+        red[nw] = s;
+    }
+    __syncthreads();
+    return red[nw];
+}
+// every workgroup re-reduces the producer's per-workgroup partials in the same fixed order: deterministic, no atomics
+__device__ __forceinline__ double sum_partials(const double* partial, int n, double* red) {
+    double v = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) v += partial[i];
+    return block_sum(v, red);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// CSR SpMV, "stream" form: a workgroup takes a row block (consecutive rows, <= kSpmvNnz nonzeros), streams its
+// contiguous val/colidx range with unit stride, multiplies by the gathered x[col] into LDS, then one lane per row
+// adds up that row's products (ascending column order, like the scalar oracle).  Fused: y = A x and the partial of
+// dot(w, y) with w = x (CG's p.Ap) or w = a second vector (BiCGStab's r0.v, t.s) and of dot(y, y).
+// Grid = 8 * BPX workgroups; workgroup b serves the row blocks of band (b % 8): workgroups that share an XCD (and
+// its 4 MiB L2) work on one contiguous eighth of the rows, so the x entries they gather stay in that L2.
+// Algorithmic HBM bytes per launch: 12 nnz + 4 (n+1) + 16 n   (BASELINE.md).
+// ---------------------------------------------------------------------------------------------------------------
+struct SpmvArgs {
+    const int32_t* rowptr;
+    const int32_t* colidx;
+    const double* vals;
+    const double* x;
+    double* y;
+    const int32_t* rb_row;
+    int32_t n_rb, rb_per_band;
+    const double* w;       // second vector of the fused dot products; nullptr: no dots
+    double* partial;       // [2 * gridDim.x]: workgroup b writes (w.y, y.y) at 2b, 2b+1; nullptr: no dots
+    const int32_t* stop;   // device flag: nonzero -> converged, kernel returns immediately (may be nullptr)
+};
+
+__global__ __launch_bounds__(256) void k_spmv(SpmvArgs s) {
+    __shared__ double prod[kSpmvNnz];
+    __shared__ double red[8];
+    if (s.stop && __syncthreads_or(*s.stop != 0)) return;   // wave- and workgroup-uniform exit
+    const int band = blockIdx.x & 7, lb = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const int rb_end = min(s.n_rb, (band + 1) * s.rb_per_band);
+    double d_wy = 0, d_yy = 0;
+    for (int rb = band * s.rb_per_band + lb; rb < rb_end; rb += bpx) {
+        const int r0 = s.rb_row[rb], r1 = s.rb_row[rb + 1];
+        const int k0 = s.rowptr[r0], k1 = s.rowptr[r1];
+        int k = k0 + threadIdx.x;
+        for (; k + 3 * 256 < k1; k += 4 * 256) {   // 4 independent streams per lane in flight
+            const double v0 = s.vals[k], v1 = s.vals[k + 256], v2 = s.vals[k + 512], v3 = s.vals[k + 768];
+            const int c0 = s.colidx[k], c1 = s.colidx[k + 256], c2 = s.colidx[k + 512], c3 = s.colidx[k + 768];
+            const double x0 = s.x[c0], x1 = s.x[c1], x2 = s.x[c2], x3 = s.x[c3];
+            prod[k - k0] = v0 * x0, prod[k - k0 + 256] = v1 * x1;
+            prod[k - k0 + 512] = v2 * x2, prod[k - k0 + 768] = v3 * x3;
+        }
+        for (; k < k1; k += 256) prod[k - k0] = s.vals[k] * s.x[s.colidx[k]];
+        __syncthreads();
+        for (int r = r0 + threadIdx.x; r < r1; r += 256) {
+            const int a = s.rowptr[r] - k0, b = s.rowptr[r + 1] - k0;
+            double acc = 0;
+            for (int i = a; i < b; ++i) acc += prod[i];
+            s.y[r] = acc;
+            if (s.w) d_wy += s.w[r] * acc, d_yy += acc * acc;
+        }
+        __syncthreads();
+    }
+    if (s.partial) {
+        const double a = block_sum(d_wy, red);
+        const double b = block_sum(d_yy, red);
+        if (threadIdx.x == 0) s.partial[2 * blockIdx.x] = a, s.partial[2 * blockIdx.x + 1] = b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// solve set-up kernels
+// ---------------------------------------------------------------------------------------------------------------
+// scale[i] = 0 on Dirichlet rows, 1/sqrt(|A_ii|) elsewhere; flag[0] |= 1 if some interior diagonal is <= 0
+__global__ void k_jacobi_scale(int64_t n, const int32_t* diag, const double* vals, const uint8_t* bnd, int use_bnd,
+                               double* scale, int32_t* flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double d = vals[diag[i]];
+    const bool b = use_bnd && bnd[i];
+    if (!b && !(d > 0.0)) atomicOr(flag, 1);
+    scale[i] = b ? 0.0 : 1.0 / sqrt(fabs(d));
+}
+// At = diag(scale) A diag(scale): symmetric Jacobi scaling == Jacobi preconditioning folded into the matrix stream.
+// Rows and columns of Dirichlet DOFs vanish (scale = 0), which restricts the Krylov iteration to the interior block.
+__global__ __launch_bounds__(256) void k_scale_matrix(int64_t n, const int32_t* rowptr, const int32_t* colidx,
+                                                      const double* vals, const double* scale, double* out) {
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;   // 16 lanes per row
+    const int l = threadIdx.x & 15;
+    if (row >= n) return;
+    const double si = scale[row];
+    for (int k = rowptr[row] + l; k < rowptr[row + 1]; k += 16) out[k] = si * vals[k] * scale[colidx[k]];
+}
+// gt = g on Dirichlet DOFs, 0 elsewhere (or all zero without Dirichlet data)
+__global__ void k_lift(int64_t n, const uint8_t* bnd, const double* g, int use_bnd, double* gt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) gt[i] = (use_bnd && bnd[i]) ? g[i] : 0.0;
+}
+// r = scale * (f - A gt)  (y holds A gt), x = 0, p = r; partial[block] = sum r^2
+__global__ __launch_bounds__(256) void k_krylov_init(int64_t n, const double* f, const double* y, const double* scale,
+                                                      double* x, double* r, double* p, double* r0, double* partial) {
+    __shared__ double red[8];
+    double acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double ri = scale[i] * (f[i] - y[i]);
+        x[i] = 0.0, r[i] = ri, p[i] = ri;
+        if (r0) r0[i] = ri;
+        acc += ri * ri;
+    }
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+// scalars layout (device doubles): [0] rr0, [1] rr_even, [2] rr_odd, [3] last rr, [4..] method specific
+// ctl layout (device int32): [0] stop flag, [1] iterations done, [2] breakdown flag
+__global__ __launch_bounds__(256) void k_krylov_init_fin(const double* partial, int np, double* sc, int32_t* ctl) {
+    __shared__ double red[8];
+    const double rr = sum_partials(partial, np, red);
+    if (threadIdx.x == 0) {
+        sc[0] = rr, sc[1] = rr, sc[2] = rr, sc[3] = rr;
+        sc[4] = 1.0, sc[5] = 1.0, sc[6] = 1.0;   // bicgstab: rho, alpha, omega
+        ctl[0] = rr == 0.0 ? 1 : 0, ctl[1] = 0, ctl[2] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// CG (on the symmetrically scaled system, i.e. Jacobi-PCG on the original one)
+//   k_spmv            : y = At p, partials of p.y
+//   k_cg_update_xr    : alpha = rr / p.y ; x += alpha p ; r -= alpha y ; partials of r.r
+//   k_cg_update_p     : beta = rr_new / rr ; p = r + beta p ; bookkeeping + stopping test (workgroup 0)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cg_update_xr(int64_t n, const double* p, const double* y, double* x, double* r,
+                                                       const double* part_in, int np_in, double* part_out,
+                                                       const double* sc, int parity, int32_t* ctl) {
+    __shared__ double red[8];
+    if (__syncthreads_or(ctl[0] != 0)) return;   // uniform even if another workgroup raises the flag meanwhile
+    double v = 0;
+    for (int i = threadIdx.x; i < np_in; i += blockDim.x) v += part_in[2 * i];
+    const double pAp = block_sum(v, red);
+    const double rr = sc[1 + parity];
+    const double alpha = pAp > 0.0 ? rr / pAp : 0.0;
+    if (!(pAp > 0.0) && blockIdx.x == 0 && threadIdx.x == 0) ctl[2] = 1;   // not SPD / breakdown
+    double acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        x[i] += alpha * p[i];
+        const double ri = r[i] - alpha * y[i];
+        r[i] = ri, acc += ri * ri;
+    }
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) part_out[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_cg_update_p(int64_t n, const double* r, double* p, const double* part_in,
+                                                      int np_in, double* sc, int parity, double tol2, int32_t* ctl) {
+    __shared__ double red[8];
+    if (__syncthreads_or(ctl[0] != 0)) return;   // uniform even if another workgroup raises the flag meanwhile
+    const double rr_new = sum_partials(part_in, np_in, red);
+    const double rr = sc[1 + parity];
+    const double beta = rr > 0.0 ? rr_new / rr : 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = r[i] + beta * p[i];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        sc[1 + (parity ^ 1)] = rr_new, sc[3] = rr_new;
+        ctl[1] += 1;
+        // the stop flag is read by this launch's other workgroups only at their start; writing it here is seen by the
+        // next kernel (kernel boundary = device-scope release/acquire)
+        if (rr_new <= tol2 * sc[0] || ctl[2]) ctl[0] = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// BiCGStab on the scaled system (non-symmetric operators: advection)
+//   k_bicg_p   : rho = r0.r ; beta = (rho/rho_old)(alpha/omega) ; p = r + beta (p - omega v)
+//   k_spmv     : v = At p, partial of r0.v
+//   k_bicg_s   : alpha = rho / r0.v ; s = r - alpha v
+//   k_spmv     : t = At s, partials of t.s (w = s) and t.t
+//   k_bicg_xr  : omega = t.s / t.t ; x += alpha p + omega s ; r = s - omega t ; partials r0.r and r.r
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bicg_p(int64_t n, const double* r, const double* v, double* p,
+                                                 const double* part_in /* (r0.r, r.r) pairs */, int np_in, double* sc,
+                                                 int first, int32_t* ctl) {
+    __shared__ double red[8];
+    if (__syncthreads_or(ctl[0] != 0)) return;   // uniform even if another workgroup raises the flag meanwhile
+    double a = 0;
+    for (int i = threadIdx.x; i < np_in; i += blockDim.x) a += part_in[2 * i];
+    const double rho_new = first ? sc[0] : block_sum(a, red);
+    const double rho = sc[4], alpha = sc[5], omega = sc[6];
+    const double beta = first ? 0.0 : (rho_new / rho) * (alpha / omega);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = first ? r[i] : r[i] + beta * (p[i] - omega * v[i]);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        sc[7] = rho_new;
+        if (rho_new == 0.0) ctl[2] = 1;
+    }
+}
+__global__ __launch_bounds__(256) void k_bicg_s(int64_t n, const double* r, const double* v, double* s,
+                                                 const double* part_in /* (r0.v, .) */, int np_in, double* sc,
+                                                 int32_t* ctl) {
+    __shared__ double red[8];
+    if (__syncthreads_or(ctl[0] != 0)) return;   // uniform even if another workgroup raises the flag meanwhile
+    double a = 0;
+    for (int i = threadIdx.x; i < np_in; i += blockDim.x) a += part_in[2 * i];
+    const double r0v = block_sum(a, red);
+    const double alpha = r0v != 0.0 ? sc[7] / r0v : 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        s[i] = r[i] - alpha * v[i];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        sc[8] = alpha;
+        if (r0v == 0.0) ctl[2] = 1;
+    }
+}
+__global__ __launch_bounds__(256) void k_bicg_xr(int64_t n, const double* p, const double* s, const double* t,
+                                                  const double* r0, double* x, double* r,
+                                                  const double* part_in /* (t.s, t.t) */, int np_in, double* part_out,
+                                                  const double* sc, int32_t* ctl) {
+    __shared__ double red[8];
+    if (__syncthreads_or(ctl[0] != 0)) return;   // uniform even if another workgroup raises the flag meanwhile
+    double a = 0, b = 0;
+    for (int i = threadIdx.x; i < np_in; i += blockDim.x) a += part_in[2 * i], b += part_in[2 * i + 1];
+    const double ts = block_sum(a, red);
+    const double tt = block_sum(b, red);
+    const double omega = tt > 0.0 ? ts / tt : 0.0;
+    const double alpha = sc[8];
+    double d0 = 0, d1 = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        x[i] += alpha * p[i] + omega * s[i];
+        const double ri = s[i] - omega * t[i];
+        r[i] = ri, d0 += r0[i] * ri, d1 += ri * ri;
+    }
+    const double s0 = block_sum(d0, red);
+    const double s1 = block_sum(d1, red);
+    if (threadIdx.x == 0) part_out[2 * blockIdx.x] = s0, part_out[2 * blockIdx.x + 1] = s1;
+}
+// closes a BiCGStab iteration: rho <- rho_new, alpha, omega = t.s/t.t recomputed from the same partials, stop test
+__global__ __launch_bounds__(256) void k_bicg_fin(const double* part_ts, int np_ts, const double* part_rr, int np_rr,
+                                                   double* sc, double tol2, int32_t* ctl) {
+    __shared__ double red[8];
+    if (__syncthreads_or(ctl[0] != 0)) return;   // uniform even if another workgroup raises the flag meanwhile
+    double a = 0, b = 0;
+    for (int i = threadIdx.x; i < np_ts; i += blockDim.x) a += part_ts[2 * i], b += part_ts[2 * i + 1];
+    const double ts = block_sum(a, red);
+    const double tt = block_sum(b, red);
+    double c = 0;
+    for (int i = threadIdx.x; i < np_rr; i += blockDim.x) c += part_rr[2 * i + 1];
+    const double rr = block_sum(c, red);
+    if (threadIdx.x == 0) {
+        const double omega = tt > 0.0 ? ts / tt : 0.0;
+        sc[4] = sc[7], sc[5] = sc[8], sc[6] = omega, sc[3] = rr;
+        ctl[1] += 1;
+        if (omega == 0.0) ctl[2] = 1;
+        if (rr <= tol2 * sc[0] || ctl[2]) ctl[0] = 1;
+    }
+}
+
+// u = scale * x + gt   (back to the unscaled unknowns, Dirichlet values restored)
+__global__ void k_unscale(int64_t n, const double* scale, const double* x, const double* gt, double* u) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) u[i] = scale[i] * x[i] + gt[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// numbering changes at the boundary (reference numbering <-> internal numbering)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_gather_f64(int64_t n, const int32_t* idx, const double* src, double* dst) {   // dst[i] = src[idx[i]]
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+__global__ void k_scatter_f64(int64_t n, const int32_t* idx, const double* src, double* dst) {  // dst[idx[i]] = src[i]
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[idx[i]] = src[i];
+}
+// export of stiff() after a Dirichlet solve: FEMSolverBase::set_dirichlet_bc (fem_solver_base.h:148-149) zeroes the
+// boundary rows and puts 1 on their diagonal; 16 lanes per row, output in reference slots
+__global__ __launch_bounds__(256) void k_export_values(int64_t n, const int32_t* rowptr, const int32_t* colidx,
+                                                       const double* vals, const int32_t* slot_i2e, const uint8_t* bnd,
+                                                       int zero_bnd_rows, double* out) {
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int l = threadIdx.x & 15;
+    if (row >= n) return;
+    const bool z = zero_bnd_rows && bnd[row];
+    for (int k = rowptr[row] + l; k < rowptr[row + 1]; k += 16)
+        out[slot_i2e[k]] = z ? (colidx[k] == row ? 1.0 : 0.0) : vals[k];
+}
+__global__ void k_fill_f64(int64_t n, double v, double* dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = v;
+}
+// force export after a Dirichlet solve: force_[i] = g[i] on boundary DOFs (fem_solver_base.h:152)
+__global__ void k_force_bc(int64_t n, const uint8_t* bnd, const double* g, double* f) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && bnd[i]) f[i] = g[i];
+}
+
+}  // namespace fdapde_hip
+#endif

@@ -1,0 +1,150 @@
+/*
+ * fdapde_hip.h -- C ABI of the MI355X (gfx950) finite-element assemble-and-solve path.
+ *
+ * This is the drop-in boundary for fdaPDE-core's FEM hot path.  The reference has no FFI: its boundary is the
+ * compile-time strategy interface  PDE<D,E,F,S,Ts...> -> pde_solver_selector<S,...>::type  (fdaPDE/pde/pde.h:52,
+ * fdaPDE/pde/symbols.h:36, fdaPDE/finite_elements/solvers/fem_solver_selector.h:29-33).  A solver type plugged in
+ * there must provide init(pde) / set_dirichlet_bc(pde) / solve(pde) and the getters solution() force() stiff() mass()
+ * n_dofs() dofs() dofs_coords() (fdaPDE/pde/pde.h:85-105, fdaPDE/finite_elements/solvers/fem_solver_base.h:50-65).
+ * The header-only C++20 facade in include/fdapde_amd/ implements exactly that interface on top of the entry points
+ * below; each entry point names the reference member it replaces.  See INTEGRATION.md for the binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every buffer in this header is a caller-owned HOST buffer unless its name ends
+ *     in _dev.  Layouts are the reference's: nodes / dof coordinates / quadrature nodes column-major
+ *     (Eigen DMatrix default, fdaPDE/geometry/triangulation.h:119), cells and DOF tables row-major int32 0-based
+ *     (triangulation.h:120), sparse matrices as CSR with sorted columns, int32 indices, fp64 values (for the
+ *     structurally symmetric FEM patterns these are the index arrays of the reference's CSC SpMatrix<double>).
+ *   - every function returns an int status: FDAPDE_OK or an FDAPDE_E* code; fdapde_last_error() gives the text.
+ *     Precondition violations that the reference reports by throwing std::runtime_error
+ *     (fem_solver_base.h:146, fem_linear_elliptic_solver.h:36) map to FDAPDE_ENOTINIT; numerical failure of the
+ *     solve (reference: success = false, fem_linear_elliptic_solver.h:42-45) maps to FDAPDE_ENOCONV.
+ *   - one context per host thread; contexts are independent (the reference has no global state either).
+ *   - there is NO CPU fallback: compute entry points on a context without a device fail with FDAPDE_ENODEVICE.
+ */
+#ifndef FDAPDE_HIP_H
+#define FDAPDE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDAPDE_ABI_VERSION 1
+
+enum {
+    FDAPDE_OK = 0,
+    FDAPDE_EINVAL = 1,    /* bad argument */
+    FDAPDE_ENOMEM = 2,    /* host or device allocation failed */
+    FDAPDE_ENODEVICE = 3, /* no HIP device / host-only context used for compute */
+    FDAPDE_EHIP = 4,      /* a HIP runtime call failed */
+    FDAPDE_ENOTINIT = 5,  /* call order violated ("solver must be initialized first!") */
+    FDAPDE_ENOCONV = 6,   /* Krylov solve did not reach rtol within maxit (reference: success = false) */
+    FDAPDE_EUNSUPPORTED = 7,
+    FDAPDE_ERCCL = 8
+};
+
+/* leaf differential operators (fdaPDE/finite_elements/operators/{laplacian,diffusion,advection,reaction,dt}.h) */
+enum { FDAPDE_LAPLACIAN = 0, FDAPDE_DIFFUSION = 1, FDAPDE_ADVECTION = 2, FDAPDE_REACTION = 3, FDAPDE_DT = 4 };
+
+/* One scaled leaf of the operator expression.  The reference's expression algebra (unary minus, scalar *, binary
+ * + and -, fdaPDE/pde/differential_expressions.h:49,95-96,114-118) collapses to a left-to-right sum of these. */
+typedef struct {
+    int32_t kind;          /* FDAPDE_LAPLACIAN ... FDAPDE_DT */
+    int32_t space_varying; /* 0: cst[] holds the coefficient; 1: data points to per-quadrature-node values */
+    double coef;           /* accumulated scalar factor (e.g. -1 for `-laplacian<FEM>()`) */
+    double cst[9];         /* diffusion tensor K row-major NxN | advection vector b[N] | reaction c */
+    const double *data;    /* row-major (nq*n_cells) x (N*N | N | 1); row nq*cell + q
+                              (Discretized*Field::forward, fdaPDE/utils/integration/integrator.h:98-101) */
+} fdapde_term;
+
+enum { FDAPDE_SOLVER_AUTO = 0, FDAPDE_SOLVER_CG = 1, FDAPDE_SOLVER_BICGSTAB = 2 };
+enum { FDAPDE_ASSEMBLY_ROWS = 0, FDAPDE_ASSEMBLY_ATOMIC = 1, FDAPDE_ASSEMBLY_COLOURED = 2 };
+enum { FDAPDE_MAT_STIFF = 0, FDAPDE_MAT_MASS = 1 };
+
+typedef struct {
+    int32_t method;   /* FDAPDE_SOLVER_*; AUTO = CG for symmetric operators, BiCGStab otherwise */
+    int32_t maxit;    /* <= 0: 10 * n_dofs capped at 100000 */
+    double rtol;      /* <= 0: 1e-10.  Stop when ||r||_{D^-1} <= rtol * ||r0||_{D^-1} (D = diag A) */
+    int32_t assembly; /* FDAPDE_ASSEMBLY_*; used by fdapde_init */
+    int32_t check_every; /* iterations between host convergence polls; <= 0: 32 */
+} fdapde_options;
+
+typedef struct {
+    int32_t iters;     /* Krylov iterations performed */
+    int32_t converged; /* 1 iff the stopping rule was met */
+    double relres;     /* final ||r||_{D^-1} / ||r0||_{D^-1} */
+    double t_assemble_ms; /* device time of the last fdapde_init (stiff + force + mass), HIP events */
+    double t_solve_ms;    /* device time of the last fdapde_solve (Dirichlet reduction + Krylov), HIP events */
+    double t_setup_ms;    /* host wall time of the last fdapde_dofs_build (numbering, pattern, upload) */
+} fdapde_info;
+
+typedef struct fdapde_ctx fdapde_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------------------------------------ */
+int fdapde_abi_version(void);
+int fdapde_device_count(void);
+/* device >= 0: bind the context to that HIP device.  device < 0: host-only context (numbering / pattern queries
+ * work, every compute call fails with FDAPDE_ENODEVICE). */
+int fdapde_ctx_create(int device, fdapde_ctx **ctx);
+void fdapde_ctx_destroy(fdapde_ctx *ctx);
+const char *fdapde_last_error(const fdapde_ctx *ctx);
+const char *fdapde_status_string(int status);
+
+/* ---- domain: Triangulation<M,N>(nodes, cells, boundary)  (fdaPDE/geometry/triangulation.h:49-60,143,319) ------- */
+int fdapde_mesh_upload(fdapde_ctx *ctx, int M, int N, int64_t n_nodes, const double *nodes_colmajor, int64_t n_cells,
+                       const int32_t *cells_rowmajor, const uint8_t *boundary_nodes);
+
+/* ---- function space: LagrangianBasis<D,R>(domain) -> enumerate_dofs  (basis/lagrangian_basis.h:94-136,147) ----- */
+/* Builds the DOF table in the reference's numbering, the CSR pattern, and the device-side layout. */
+int fdapde_dofs_build(fdapde_ctx *ctx, int order, int64_t *n_dofs);
+/* FEMSolverBase::n_dofs(), dofs(), boundary dofs, dofs_coords() (fem_solver_base.h:57-59, lagrangian_basis.h:155-183).
+ * Any output pointer may be NULL.  dofs row-major n_cells x n_basis; coords column-major n_dofs x N. */
+int fdapde_dofs_get(const fdapde_ctx *ctx, int32_t *dofs_rowmajor, uint8_t *boundary_dofs, double *dof_coords_colmajor);
+int fdapde_sizes(const fdapde_ctx *ctx, int64_t *n_dofs, int64_t *nnz, int32_t *n_basis, int32_t *n_quadrature,
+                 int64_t *n_edges);
+/* sparsity pattern of stiff()/mass() in the reference's numbering: rowptr[n_dofs+1], colidx[nnz] sorted per row */
+int fdapde_pattern_get(const fdapde_ctx *ctx, int32_t *rowptr, int32_t *colidx);
+/* Integrator::quadrature_nodes (utils/integration/integrator.h:109-121): column-major (nq*n_cells) x N */
+int fdapde_quadrature_nodes(fdapde_ctx *ctx, double *out_colmajor);
+
+/* ---- problem data: PDE::set_differential_operator / set_forcing / set_dirichlet_bc (pde/pde.h:74-77) ----------- */
+int fdapde_set_operator(fdapde_ctx *ctx, int32_t n_terms, const fdapde_term *terms);
+/* forcing sampled at quadrature nodes: column-major (nq*n_cells) x n_cols (n_cols > 1 only for parabolic problems) */
+int fdapde_set_forcing(fdapde_ctx *ctx, const double *f_q, int32_t n_cols);
+/* Dirichlet data indexed by DOF id (fem_solver_base.h:152); NULL clears (PDE::solve then skips set_dirichlet_bc) */
+int fdapde_set_dirichlet(fdapde_ctx *ctx, const double *g);
+
+/* ---- FEMSolverBase::init (fem_solver_base.h:104-139): stiff_, force_, mass_ ------------------------------------ */
+int fdapde_init(fdapde_ctx *ctx, const fdapde_options *opt);
+/* Assembler::discretize_operator for an arbitrary operator into slot `which` (fem_assembler.h:52-121) */
+int fdapde_assemble_operator(fdapde_ctx *ctx, int32_t which, int32_t n_terms, const fdapde_term *terms, int32_t assembly);
+
+/* ---- PDE::solve (pde/pde.h:102-105): set_dirichlet_bc (fem_solver_base.h:142-155) + elliptic solve
+ *      (fem_linear_elliptic_solver.h:34-50; Eigen::SparseLU replaced by Jacobi-PCG / BiCGStab on the interior block) */
+int fdapde_solve(fdapde_ctx *ctx, const fdapde_options *opt, fdapde_info *info);
+
+/* ---- getters (fem_solver_base.h:50-53) ------------------------------------------------------------------------- */
+/* values[nnz] aligned with fdapde_pattern_get.  After a solve with Dirichlet data, FDAPDE_MAT_STIFF is the
+ * row-zeroed matrix the reference leaves in stiff_ (rows of boundary DOFs zero, unit diagonal). */
+int fdapde_matrix_values(fdapde_ctx *ctx, int32_t which, double *values);
+int fdapde_force(fdapde_ctx *ctx, double *force);       /* n_dofs * n_cols; boundary rows = g after a Dirichlet solve */
+int fdapde_solution(fdapde_ctx *ctx, double *solution); /* n_dofs */
+int fdapde_info_get(const fdapde_ctx *ctx, fdapde_info *info);
+
+/* ---- building blocks exposed for parity tests and the roofline benchmark --------------------------------------- */
+/* y = A x in the reference's DOF numbering, host buffers */
+int fdapde_spmv(fdapde_ctx *ctx, int32_t which, const double *x, double *y);
+/* times `reps` launches of the solver's SpMV kernel (the one inside CG) with HIP events on the context's stream;
+ * returns the average kernel duration in ms and the algorithmic bytes per launch
+ * (12*nnz + 4*(n+1) + 16*n) */
+int fdapde_bench_spmv(fdapde_ctx *ctx, int32_t reps, double *avg_ms, double *algorithmic_bytes);
+/* the context's HIP stream (hipStream_t) so that callers can bracket work with their own events */
+void *fdapde_stream(fdapde_ctx *ctx);
+int fdapde_synchronize(fdapde_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDAPDE_HIP_H */

@@ -1,0 +1,263 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the reference's fixtures.
+
+Bars (SURVEY.md section 8d / BASELINE.md):
+  * DOF tables, boundary sets, CSR pattern ............ bit-exact
+  * matrix / vector entries ........................... |d| <= 1e-12 * max(1, ||A||_max)   (summation order differs)
+  * solutions ......................................... ||u_gpu - u_ref||_2 / ||u_ref||_2 <= 1e-8 with rtol 1e-10
+  * the reference's own criterion ..................... sum(M * err^2) < 1e-7 (1e-5 for P1 advection-diffusion)
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ENTRY_TOL = 1e-12
+SOL_TOL = 1e-8
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from fdapde_loader import load_package
+
+    load_package()
+    from fdapde_core_amd import capi as m
+
+    assert m.load().fdapde_device_count() >= 1, "no HIP device visible: the GPU tests must not fall back to anything"
+    return m
+
+
+@pytest.fixture(scope="module")
+def ctx(capi):
+    c = capi.Context(device=0)
+    yield c
+    c.close()
+
+
+def _ops(mod, M):
+    K = np.array([[2.0, 0.3], [0.3, 1.0]]) if M == 2 else np.array([[2.0, 0.3, 0.1], [0.3, 1.0, 0.2], [0.1, 0.2, 1.5]])
+    b = np.array([0.7, -0.2]) if M == 2 else np.array([0.7, -0.2, 0.4])
+    return {
+        "neg_laplacian": -mod.laplacian(),
+        "mass": mod.reaction(1.0),
+        "adr": -mod.laplacian() + mod.advection(b) + mod.reaction(1.5),
+        "diffusion": mod.diffusion(K) + 0.5 * mod.reaction(2.0),
+        "laplacian_minus_dt": mod.laplacian() - mod.dt(),
+    }
+
+
+def _entry_close(a, b):
+    scale = max(1.0, np.abs(b).max())
+    return np.abs(a - b).max() <= ENTRY_TOL * scale
+
+
+CASES = [("unit_square_16", 1), ("unit_square_16", 2), ("c_shaped", 1), ("c_shaped", 2), ("unit_square", 1), ("unit_square", 2),
+         ("unit_sphere", 1), ("unit_sphere", 2), ("quasi_circle", 2)]
+
+
+@pytest.mark.parametrize("mesh_name,order", CASES)
+def test_space_is_bit_exact(capi, ctx, oracle, mesh_loader, mesh_name, order):
+    m = mesh_loader(mesh_name)
+    ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = ctx.dofs_build(order)
+    od, ob, ond, _ = oracle.enumerate_dofs(m, order)
+    dofs, bnd, coords = ctx.dofs_get()
+    assert nd == ond and np.array_equal(dofs, od) and np.array_equal(bnd, ob)
+    assert np.array_equal(coords, oracle.dofs_coords(m, order, od, ond))
+    A = oracle.assemble_operator(m, order, od, ond, -oracle.laplacian())
+    rp, ci = ctx.pattern_get()
+    assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colidx)
+    qn = ctx.quadrature_nodes()
+    assert np.abs(qn - oracle.quadrature_nodes(m, order)).max() < 1e-14
+
+
+@pytest.mark.parametrize("mesh_name,order", CASES)
+@pytest.mark.parametrize("variant", ["rows", "atomic", "coloured"])
+def test_operator_assembly_matches_oracle(capi, ctx, oracle, mesh_loader, mesh_name, order, variant):
+    m = mesh_loader(mesh_name)
+    ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = ctx.dofs_build(order)
+    od, _, _, _ = oracle.enumerate_dofs(m, order)
+    assembly = {"rows": capi.ASSEMBLY_ROWS, "atomic": capi.ASSEMBLY_ATOMIC, "coloured": capi.ASSEMBLY_COLOURED}[variant]
+    for name in _ops(capi, m.M):
+        ctx.assemble_operator(capi.MAT_STIFF, _ops(capi, m.M)[name], assembly)
+        got = ctx.matrix_values(capi.MAT_STIFF)
+        ref = oracle.assemble_operator(m, order, od, nd, _ops(oracle, m.M)[name])
+        assert _entry_close(got, ref.values), (name, np.abs(got - ref.values).max())
+
+
+def test_rows_assembly_is_deterministic_and_symmetric(capi, ctx, oracle, mesh_loader):
+    m = mesh_loader("unit_sphere")
+    ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = ctx.dofs_build(2)
+    op = -capi.laplacian() + capi.reaction(0.5)
+    ctx.assemble_operator(capi.MAT_STIFF, op)
+    a = ctx.matrix_values(capi.MAT_STIFF)
+    ctx.assemble_operator(capi.MAT_STIFF, op)
+    b = ctx.matrix_values(capi.MAT_STIFF)
+    assert np.array_equal(a, b)   # bitwise reproducible: no atomics in the default path
+    import scipy.sparse as sp
+
+    rp, ci = ctx.pattern_get()
+    A = sp.csr_matrix((a, ci, rp), shape=(nd, nd))
+    assert abs(A - A.T).max() == 0.0   # bitwise symmetric for symmetric forms
+
+
+@pytest.mark.parametrize("mesh_name,order", [("unit_square_16", 1), ("unit_square_16", 2), ("unit_sphere", 1), ("unit_sphere", 2)])
+def test_space_varying_coefficients(capi, ctx, oracle, mesh_loader, mesh_name, order):
+    """Discretized*Field::forward(nq*cell + q) row indexing (integrator.h:98-101) with genuinely varying data"""
+    m = mesh_loader(mesh_name)
+    ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = ctx.dofs_build(order)
+    od, _, _, _ = oracle.enumerate_dofs(m, order)
+    rows = ctx.sizes()["n_quadrature"] * m.n_cells
+    rng = np.random.default_rng(7)
+    N = m.N
+    Kq = rng.uniform(0.5, 1.5, (rows, N * N))
+    bq = rng.uniform(-1, 1, (rows, N))
+    cq = rng.uniform(0, 2, rows)
+    mk = lambda mod: mod.diffusion_field(Kq) + mod.advection_field(bq) + mod.reaction_field(cq)
+    ctx.assemble_operator(capi.MAT_STIFF, mk(capi))
+    got = ctx.matrix_values(capi.MAT_STIFF)
+    ref = oracle.assemble_operator(m, order, od, nd, mk(oracle))
+    assert _entry_close(got, ref.values)
+
+
+@pytest.mark.parametrize("mesh_name,order", CASES)
+def test_init_force_mass_spmv(capi, ctx, oracle, mesh_loader, mesh_name, order):
+    m = mesh_loader(mesh_name)
+    ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = ctx.dofs_build(order)
+    od, _, _, _ = oracle.enumerate_dofs(m, order)
+    qn = oracle.quadrature_nodes(m, order)
+    fq = np.sin(3.0 * qn[:, 0]) + qn[:, 1] ** 2
+    ctx.set_operator(-capi.laplacian())
+    ctx.set_forcing(fq)
+    ctx.init()
+    assert _entry_close(ctx.force(), oracle.assemble_forcing(m, order, od, nd, fq))
+    Mo = oracle.assemble_operator(m, order, od, nd, oracle.reaction(1.0))
+    assert _entry_close(ctx.matrix_values(capi.MAT_MASS), Mo.values)
+    Ao = oracle.assemble_operator(m, order, od, nd, -oracle.laplacian())
+    x = np.random.default_rng(3).standard_normal(nd)
+    for which, ref in ((capi.MAT_STIFF, Ao), (capi.MAT_MASS, Mo)):
+        y = ctx.spmv(which, x)
+        yr = ref.matvec(x)
+        assert np.abs(y - yr).max() <= 1e-12 * max(1.0, np.abs(yr).max())
+
+
+def _l2(oracle_mass, err):
+    return float(np.sum(oracle_mass.matvec(err * err)))
+
+
+def _solve_case(capi, ctx, oracle, m, order, mk_op, forcing_fn, dirichlet_fn, method=None):
+    ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = ctx.dofs_build(order)
+    _, _, coords = ctx.dofs_get()
+    qn = ctx.quadrature_nodes()
+    fq = np.array([forcing_fn(p) for p in qn]) if forcing_fn else np.zeros(qn.shape[0])
+    g = np.array([dirichlet_fn(p) for p in coords])
+    ctx.set_operator(mk_op(capi))
+    ctx.set_forcing(fq)
+    ctx.set_dirichlet(g)
+    ctx.init()
+    info = ctx.solve(method=capi.SOLVER_AUTO if method is None else method, rtol=1e-10)
+    assert info.converged == 1 and info.relres <= 1e-10
+    ref = oracle.pde_init_solve(m, order, mk_op(oracle), forcing_q=fq, dirichlet=g, direct=True)
+    u = ctx.solution()
+    assert np.linalg.norm(u - ref.solution) / np.linalg.norm(ref.solution) <= SOL_TOL
+    # after solve(), stiff() is the row-zeroed matrix and force() carries g on the boundary (fem_solver_base.h:148-152)
+    assert _entry_close(ctx.matrix_values(capi.MAT_STIFF), ref.stiff.values)
+    assert _entry_close(ctx.force(), ref.force)
+    return u, coords, ref, info
+
+
+def test_pde_laplacian_isotropic_order1(capi, ctx, oracle, mesh_loader):
+    """fem_pde_test.cpp:43-75"""
+    u_ex = lambda x: x[0] + x[1]
+    u, coords, ref, _ = _solve_case(capi, ctx, oracle, mesh_loader("unit_square"), 1, lambda mod: -mod.laplacian(), None, u_ex)
+    ex = np.array([u_ex(p) for p in coords])
+    assert _l2(ref.mass, ex - u) < 1e-7
+
+
+def test_pde_laplacian_isotropic_order2_callable_force(capi, ctx, oracle, mesh_loader):
+    """fem_pde_test.cpp:78-107"""
+    u_ex = lambda x: 1.0 - x[0] * x[0] - x[1] * x[1]
+    u, coords, ref, _ = _solve_case(capi, ctx, oracle, mesh_loader("unit_square"), 2, lambda mod: -mod.laplacian(), lambda x: 4.0, u_ex)
+    ex = np.array([u_ex(p) for p in coords])
+    assert _l2(ref.mass, ex - u) < 1e-7
+
+
+def _advdiff():
+    pi = np.pi
+    alpha, gamma = 1.0, pi
+    l1 = -alpha / 2 - np.sqrt((alpha / 2) ** 2 + pi * pi)
+    l2 = -alpha / 2 + np.sqrt((alpha / 2) ** 2 + pi * pi)
+    p = (1 - np.exp(l2)) / (np.exp(l1) - np.exp(l2))
+    u = lambda x: -gamma / (pi * pi) * (p * np.exp(l1 * x[0]) + (1 - p) * np.exp(l2 * x[0]) - 1.0) * np.sin(pi * x[1])
+    f = lambda x: gamma * np.sin(pi * x[1])
+    return u, f, np.array([-alpha, 0.0])
+
+
+@pytest.mark.parametrize("order,gate", [(1, 1e-5), (2, 1e-7)])
+def test_pde_advection_diffusion(capi, ctx, oracle, mesh_loader, order, gate):
+    """fem_pde_test.cpp:113-166 (P1, 1e-5) and 172-212 (P2, 1e-7): non-symmetric operator -> BiCGStab"""
+    u_ex, f, beta = _advdiff()
+    u, coords, ref, info = _solve_case(capi, ctx, oracle, mesh_loader("unit_square"), order,
+                                       lambda mod: -mod.laplacian() + mod.advection(beta), f, lambda x: 0.0)
+    ex = np.array([u_ex(p) for p in coords])
+    assert _l2(ref.mass, ex - u) < gate
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_pde_3d(capi, ctx, oracle, mesh_loader, order):
+    """3-D (unit_sphere, 1395 negatively oriented tets): P1 reproduces x+y+z, P2 reproduces x^2 + yz"""
+    if order == 1:
+        u_ex, f = (lambda x: x[0] + x[1] + x[2]), None
+    else:
+        u_ex, f = (lambda x: x[0] * x[0] + x[1] * x[2]), (lambda x: -2.0)
+    u, coords, ref, _ = _solve_case(capi, ctx, oracle, mesh_loader("unit_sphere"), order, lambda mod: -mod.laplacian(), f, u_ex)
+    ex = np.array([u_ex(p) for p in coords])
+    assert np.abs(u - ex).max() < 1e-8
+
+
+def test_solve_without_dirichlet_and_bicgstab_on_spd(capi, ctx, oracle, mesh_loader):
+    """PDE::solve skips set_dirichlet_bc when no boundary data is set (pde.h:103); -Lap + c is SPD on its own.
+    Also runs BiCGStab on the same SPD system."""
+    m = mesh_loader("unit_square_32")
+    ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = ctx.dofs_build(2)
+    qn = ctx.quadrature_nodes()
+    fq = np.cos(qn[:, 0]) * qn[:, 1]
+    mk = lambda mod: -mod.laplacian() + mod.reaction(3.0)
+    ctx.set_operator(mk(capi))
+    ctx.set_forcing(fq)
+    ctx.set_dirichlet(None)
+    ctx.init()
+    ref = oracle.pde_init_solve(m, 2, mk(oracle), forcing_q=fq, dirichlet=None)
+    for method in (capi.SOLVER_CG, capi.SOLVER_BICGSTAB):
+        info = ctx.solve(method=method, rtol=1e-11)
+        assert info.converged == 1
+        u = ctx.solution()
+        assert np.linalg.norm(u - ref.solution) / np.linalg.norm(ref.solution) <= SOL_TOL
+    assert _entry_close(ctx.matrix_values(capi.MAT_STIFF), ref.stiff.values)
+
+
+def test_error_behaviour(capi, ctx, mesh_loader):
+    """'solver must be initialized first!' (fem_solver_base.h:146, fem_linear_elliptic_solver.h:36) -> ENOTINIT;
+    non-convergence -> ENOCONV / success = false"""
+    m = mesh_loader("unit_square_16")
+    ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+    ctx.dofs_build(1)
+    with pytest.raises(capi.FdapdeError) as e:
+        ctx.solve()
+    assert e.value.status == capi.ENOTINIT
+    ctx.set_operator(-capi.laplacian())
+    ctx.set_forcing(np.ones(3 * m.n_cells))
+    ctx.set_dirichlet(np.zeros(m.n_nodes))
+    ctx.init()
+    info = ctx.solve(maxit=2, raise_on_noconv=False)
+    assert info.converged == 0 and info.iters == 2
+    with pytest.raises(capi.FdapdeError) as e:
+        ctx.solve(maxit=2)
+    assert e.value.status == capi.ENOCONV
+    info = ctx.solve()
+    assert info.converged == 1

@@ -1,0 +1,79 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol; the host-side index work
+(DOF numbering, boundary sets, DOF coordinates, CSR pattern) is bit-exact against the oracle; compute entry points
+refuse to run without a device (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from fdapde_loader import load_package
+
+    return load_package().capi
+
+
+def test_library_exports_every_declared_symbol(capi):
+    lib = capi.load()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "fdapde_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(fdapde_[a-z_0-9]+)\s*\(", header)))
+    assert declared, "no declarations parsed"
+    assert sorted(capi.SYMBOLS) == declared
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.fdapde_abi_version() == 1
+
+
+FIXTURES = ["unit_square_16", "unit_square_32", "unit_square_64", "unit_square", "c_shaped", "quasi_circle", "unit_sphere"]
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+@pytest.mark.parametrize("order", [1, 2])
+def test_numbering_and_pattern_bit_exact(capi, oracle, mesh_loader, name, order):
+    m = mesh_loader(name)
+    ctx = capi.Context(device=None)
+    ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = ctx.dofs_build(order)
+    dofs, bnd, coords = ctx.dofs_get()
+    od, ob, ond, one = oracle.enumerate_dofs(m, order)
+    assert nd == ond and ctx.sizes()["n_edges"] == one
+    assert np.array_equal(dofs, od) and np.array_equal(bnd, ob)
+    assert np.array_equal(coords, oracle.dofs_coords(m, order, od, ond))
+    A = oracle.assemble_operator(m, order, od, ond, -oracle.laplacian())
+    rp, ci = ctx.pattern_get()
+    assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colidx)
+    ctx.close()
+
+
+def test_compute_fails_loudly_without_device(capi, mesh_loader):
+    m = mesh_loader("unit_square_16")
+    ctx = capi.Context(device=None)
+    ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+    ctx.dofs_build(1)
+    ctx.set_operator(-capi.laplacian())
+    for call in (ctx.init, ctx.solve, ctx.solution, ctx.quadrature_nodes, lambda: ctx.matrix_values(0)):
+        with pytest.raises(capi.FdapdeError) as e:
+            call()
+        assert e.value.status == capi.ENODEVICE
+    ctx.close()
+
+
+def test_argument_validation(capi, mesh_loader):
+    m = mesh_loader("unit_square_16")
+    ctx = capi.Context(device=None)
+    bad = m.cells.copy()
+    bad[0, 0] = m.n_nodes + 5
+    with pytest.raises(capi.FdapdeError) as e:
+        ctx.mesh_upload(m.nodes, bad, m.boundary)
+    assert e.value.status == capi.EINVAL
+    ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+    with pytest.raises(capi.FdapdeError) as e:
+        ctx.dofs_build(3)   # LagrangianBasis::enumerate_dofs requires Order <= 2 (lagrangian_basis.h:94)
+    assert e.value.status == capi.EUNSUPPORTED
+    with pytest.raises(capi.FdapdeError) as e:
+        ctx.set_operator(-capi.laplacian())   # before dofs_build
+    assert e.value.status == capi.ENOTINIT
+    ctx.close()

@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- assemble + solve of the 3-D P1 Laplacian (BASELINE.json: metric, configs[2] "C3").
+
+A step = one pass of the hot path over the resident mesh: FEMSolverBase::init (stiffness + forcing + mass assembly)
+followed by PDE::solve (Dirichlet reduction + Jacobi-PCG to rtol 1e-10), all on the device.  Inputs (mesh, forcing
+samples, Dirichlet data) are resident in HBM when the timed region starts; nothing but the solver's convergence flag
+crosses PCIe inside it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--nx 119]
+
+N = 1: the whole C3 mesh (119^3 x 6 = 10 110 954 tetrahedra, 1 728 000 DOFs) on one MI355X.
+N > 1 (launched by torch.distributed.run, one rank per GPU): the same mesh, element-partitioned over the ranks with
+an RCCL all-reduce of the interface DOF contributions per operator application (strong scaling).
+
+Prints ONE JSON line (rank 0).  `roofline` is the CSR SpMV inside CG: algorithmic bytes 12 nnz + 4 (n+1) + 16 n per
+launch over the average launch duration measured with HIP events on the solver's stream during the timed steps.
+`cpu_baseline` is the CPU oracle (oracle/fem_oracle.c, the single-threaded port of the reference algorithm) timed on a
+bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+RTOL = 1e-10
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nx", type=int, default=119, help="cubes per axis of the C3 mesh (119 = BASELINE size)")
+    ap.add_argument("--cpu-nx", type=int, default=64, help="cubes per axis of the CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--time-spmv", type=int, default=128)
+    return ap.parse_args()
+
+
+def cpu_baseline(nx):
+    """The oracle (kind 'port') on a bounded sample: same generator, same operator, same solver and tolerance."""
+    from fdapde_loader import load_package
+    from oracle import oracle as o
+
+    load_package()
+    from fdapde_core_amd import meshgen
+
+    nodes, cells, bnd = meshgen.unit_cube(nx)
+    m = o.Mesh(nodes, cells, bnd)
+    _, f = meshgen.manufactured(3)
+    dofs, b, nd, _ = o.enumerate_dofs(m, 1)
+    fq = f(o.quadrature_nodes(m, 1))
+    t0 = time.perf_counter()
+    A = o.assemble_operator(m, 1, dofs, nd, -o.laplacian())
+    rhs = o.assemble_forcing(m, 1, dofs, nd, fq)
+    Mm = o.assemble_operator(m, 1, dofs, nd, o.reaction(1.0))
+    t1 = time.perf_counter()
+    u, it, rr, rc = o.pcg(A, rhs, b, np.zeros(nd), rtol=RTOL, maxit=100000)
+    t2 = time.perf_counter()
+    assert rc == 0
+    del Mm
+    return {
+        "value": nd / (t2 - t0), "unit": "DOF/s", "cores": 1, "kind": "port",
+        "sample": f"3-D P1 Laplacian, {nx}^3 x 6 = {m.n_cells} tetrahedra, {nd} DOFs, same generator/operator/rtol; "
+                  f"assemble {t1 - t0:.2f} s + Jacobi-PCG {t2 - t1:.2f} s ({it} iterations); oracle/fem_oracle.c at -O2",
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    from fdapde_loader import load_package
+
+    pkg = load_package()
+    from fdapde_core_amd import capi, meshgen
+
+    if capi.load().fdapde_device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t_gen = time.perf_counter()
+    nodes, cells, bnd = meshgen.unit_cube(args.nx)
+    t_gen = time.perf_counter() - t_gen
+    u_exact, f = meshgen.manufactured(3)
+
+    if world == 1:
+        ctx = capi.Context(device=local_rank)
+        ctx.mesh_upload(nodes, cells, bnd)
+        n_dofs = ctx.dofs_build(1)
+        sizes = ctx.sizes()
+        qn = ctx.quadrature_nodes()
+        ctx.set_operator(-capi.laplacian())
+        ctx.set_forcing(f(qn))
+        ctx.set_dirichlet(np.zeros(n_dofs))
+        del qn
+
+        def step(time_spmv=0):
+            ctx.init()
+            return ctx.solve(rtol=RTOL, time_spmv=time_spmv)
+
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        infos = [step(args.time_spmv) for _ in range(args.steps)]
+        barrier()
+        elapsed = time.perf_counter() - t0
+        info = infos[-1]
+        spmv_ms = float(np.mean([i.spmv_avg_ms for i in infos]))
+        t_asm = float(np.mean([i.t_assemble_ms for i in infos]))
+        t_sol = float(np.mean([i.t_solve_ms for i in infos]))
+        u = ctx.solution()
+        _, _, coords = ctx.dofs_get()
+        err = float(np.abs(u - u_exact(coords)).max())
+        setup_ms = ctx.info().t_setup_ms
+        _, alg_bytes = ctx.bench_spmv(reps=1)
+        parallelism = "1 GPU"
+        total_dofs = n_dofs
+    else:
+        from fdapde_core_amd import dist as fdist
+
+        res = fdist.bench_partitioned(capi, nodes, cells, bnd, f, u_exact, rank, world, local_rank, args, barrier, RTOL)
+        if rank != 0:
+            return
+        (elapsed, info, spmv_ms, t_asm, t_sol, err, setup_ms, alg_bytes, sizes, total_dofs, parallelism) = res
+
+    if rank != 0:
+        return
+    ms_per_step = 1e3 * elapsed / args.steps
+    achieved = alg_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
+    out = {
+        "metric": "DOF/s assemble+solve, 3D P1 Laplacian; SpMV achieved HBM GB/s vs peak",
+        "value": total_dofs * args.steps / elapsed,
+        "unit": "DOF/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"C3: 3-D P1 Laplacian, [0,1]^3, {args.nx}^3 x 6 Kuhn tetrahedra = {cells.shape[0]} cells, "
+                        f"{total_dofs} DOFs, nnz {sizes['nnz']}, jitter 0.2h, ids permuted, seed 12345; "
+                        "u = sin(pi x) sin(pi y) sin(pi z), homogeneous Dirichlet; init (stiff+force+mass) + Jacobi-PCG rtol 1e-10",
+            "parallelism": parallelism,
+            "cg_iterations": int(info.iters),
+            "relres": float(info.relres),
+            "t_assemble_ms": t_asm,
+            "t_solve_ms": t_sol,
+            "t_setup_ms_untimed": setup_ms,
+            "t_meshgen_s_untimed": t_gen,
+            "max_abs_error_vs_analytic": err,
+            "spmv_launches_timed_per_step": int(info.spmv_timed),
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "k_spmv (CSR SpMV fused with p.Ap inside CG)",
+            "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": spmv_ms,
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_nx)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -28,12 +28,13 @@ class Term(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("method", C.c_int32), ("maxit", C.c_int32), ("rtol", C.c_double), ("assembly", C.c_int32),
-                ("check_every", C.c_int32)]
+                ("check_every", C.c_int32), ("time_spmv", C.c_int32)]
 
 
 class Info(C.Structure):
     _fields_ = [("iters", C.c_int32), ("converged", C.c_int32), ("relres", C.c_double), ("t_assemble_ms", C.c_double),
-                ("t_solve_ms", C.c_double), ("t_setup_ms", C.c_double)]
+                ("t_solve_ms", C.c_double), ("t_setup_ms", C.c_double), ("spmv_avg_ms", C.c_double), ("spmv_timed", C.c_int32),
+                ("method_used", C.c_int32)]
 
 
 # every symbol include/fdapde_hip.h declares (tests check that the library exports all of them)
@@ -247,15 +248,15 @@ class Context:
 
     # ---- compute
     def init(self, assembly=ASSEMBLY_ROWS):
-        opt = Options(method=0, maxit=0, rtol=0.0, assembly=assembly, check_every=0)
+        opt = Options(method=0, maxit=0, rtol=0.0, assembly=assembly, check_every=0, time_spmv=0)
         self._check(self.lib.fdapde_init(self._ctx, C.byref(opt)))
 
     def assemble_operator(self, which, op: Operator, assembly=ASSEMBLY_ROWS):
         terms, keep = op.c_terms()
         self._check(self.lib.fdapde_assemble_operator(self._ctx, which, len(op.terms), terms, assembly))
 
-    def solve(self, method=SOLVER_AUTO, rtol=1e-10, maxit=0, check_every=0, raise_on_noconv=True):
-        opt = Options(method=method, maxit=maxit, rtol=rtol, assembly=0, check_every=check_every)
+    def solve(self, method=SOLVER_AUTO, rtol=1e-10, maxit=0, check_every=0, raise_on_noconv=True, time_spmv=0):
+        opt = Options(method=method, maxit=maxit, rtol=rtol, assembly=0, check_every=check_every, time_spmv=time_spmv)
         info = Info()
         rc = self.lib.fdapde_solve(self._ctx, C.byref(opt), C.byref(info))
         if rc != OK and (raise_on_noconv or rc != ENOCONV):

@@ -51,6 +51,7 @@ struct fdapde_ctx {
     bool has_device = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> ev_spmv;   // 2 per timed SpMV launch
     std::string err;
     HostSpace hs;
     BasisTables tb;
@@ -334,6 +335,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
         if (c->h_ctl) (void)hipHostFree(c->h_ctl);
         if (c->h_sc) (void)hipHostFree(c->h_sc);
         (void)hipEventDestroy(c->ev0), (void)hipEventDestroy(c->ev1);
+        for (hipEvent_t e : c->ev_spmv) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(c->stream);
     }
     delete c;
@@ -575,6 +577,14 @@ int fdapde_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     hipLaunchKernelGGL(k_krylov_init_fin, dim3(1), dim3(256), 0, st, c->part_b.p, c->vec_grid, c->sc.p, c->ctl.p);
     HIPCHK(c, hipGetLastError());
     const double tol2 = rtol * rtol;
+    int n_timed = opt ? opt->time_spmv : 0;
+    n_timed = n_timed < 0 ? 0 : (n_timed > 256 ? 256 : n_timed);
+    while ((int)c->ev_spmv.size() < 2 * n_timed) {
+        hipEvent_t e;
+        HIPCHK(c, hipEventCreate(&e));
+        c->ev_spmv.push_back(e);
+    }
+    int timed = 0;
     int launched = 0;
     bool stop = false;
     while (!stop && launched < maxit) {
@@ -582,7 +592,10 @@ int fdapde_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
         for (int it = 0; it < chunk; ++it, ++launched) {
             if (!bicg) {
                 const int parity = launched & 1;
+                const bool tm = launched < n_timed;
+                if (tm) HIPCHK(c, hipEventRecord(c->ev_spmv[2 * launched], st));
                 launch_spmv(c, c->sval.p, c->p.p, c->y.p, c->p.p, c->part_a.p, c->ctl.p);
+                if (tm) { HIPCHK(c, hipEventRecord(c->ev_spmv[2 * launched + 1], st)); ++timed; }
                 hipLaunchKernelGGL(k_cg_update_xr, dim3(c->vec_grid), dim3(256), 0, st, n, c->p.p, c->y.p, c->x.p, c->r.p,
                                    c->part_a.p, c->spmv_grid, c->part_b.p, c->sc.p, parity, c->ctl.p);
                 hipLaunchKernelGGL(k_cg_update_p, dim3(c->vec_grid), dim3(256), 0, st, n, c->r.p, c->p.p, c->part_b.p,
@@ -590,7 +603,10 @@ int fdapde_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
             } else {
                 hipLaunchKernelGGL(k_bicg_p, dim3(c->vec_grid), dim3(256), 0, st, n, c->r.p, c->y.p, c->p.p, c->part_b.p,
                                    c->vec_grid, c->sc.p, launched == 0 ? 1 : 0, c->ctl.p);
+                const bool tm = launched < n_timed;
+                if (tm) HIPCHK(c, hipEventRecord(c->ev_spmv[2 * launched], st));
                 launch_spmv(c, c->sval.p, c->p.p, c->y.p, c->r0.p, c->part_a.p, c->ctl.p);   // v = At p, r0.v
+                if (tm) { HIPCHK(c, hipEventRecord(c->ev_spmv[2 * launched + 1], st)); ++timed; }
                 hipLaunchKernelGGL(k_bicg_s, dim3(c->vec_grid), dim3(256), 0, st, n, c->r.p, c->y.p, c->s.p, c->part_a.p,
                                    c->spmv_grid, c->sc.p, c->ctl.p);
                 launch_spmv(c, c->sval.p, c->s.p, c->t.p, c->s.p, c->part_a.p, c->ctl.p);    // t = At s, t.s, t.t
@@ -617,6 +633,18 @@ int fdapde_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     c->info.iters = c->h_ctl[1];
     c->info.relres = rr0 > 0 ? sqrt(rr / rr0) : 0.0;
     c->info.converged = (rr <= tol2 * rr0 && c->h_ctl[2] == 0) ? 1 : 0;
+    c->info.method_used = method;
+    c->info.spmv_avg_ms = 0, c->info.spmv_timed = 0;
+    {   // launches after the stop flag return at once; only iterations that really ran are averaged
+        const int real = timed < c->info.iters ? timed : c->info.iters;
+        double sum = 0;
+        for (int i = 0; i < real; ++i) {
+            float t = 0;
+            HIPCHK(c, hipEventElapsedTime(&t, c->ev_spmv[2 * i], c->ev_spmv[2 * i + 1]));
+            sum += t;
+        }
+        if (real > 0) c->info.spmv_avg_ms = sum / real, c->info.spmv_timed = real;
+    }
     c->solved = true, c->dirichlet_applied = c->have_g;
     if (info) *info = c->info;
     if (!c->info.converged) {

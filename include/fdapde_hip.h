@@ -69,6 +69,8 @@ typedef struct {
     double rtol;      /* <= 0: 1e-10.  Stop when ||r||_{D^-1} <= rtol * ||r0||_{D^-1} (D = diag A) */
     int32_t assembly; /* FDAPDE_ASSEMBLY_*; used by fdapde_init */
     int32_t check_every; /* iterations between host convergence polls; <= 0: 32 */
+    int32_t time_spmv;   /* > 0: bracket the SpMV launch of the first `time_spmv` Krylov iterations (max 256) with HIP
+                            events on the context's stream and report their average in fdapde_info.spmv_avg_ms */
 } fdapde_options;
 
 typedef struct {
@@ -78,6 +80,9 @@ typedef struct {
     double t_assemble_ms; /* device time of the last fdapde_init (stiff + force + mass), HIP events */
     double t_solve_ms;    /* device time of the last fdapde_solve (Dirichlet reduction + Krylov), HIP events */
     double t_setup_ms;    /* host wall time of the last fdapde_dofs_build (numbering, pattern, upload) */
+    double spmv_avg_ms;   /* average duration of the SpMV launches timed inside the last solve (0 if none) */
+    int32_t spmv_timed;   /* how many launches that average covers */
+    int32_t method_used;  /* FDAPDE_SOLVER_CG or FDAPDE_SOLVER_BICGSTAB */
 } fdapde_info;
 
 typedef struct fdapde_ctx fdapde_ctx;

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Summarises a tools/profile_gpu.sh output directory: per-kernel time (kernel trace) and per-kernel PMC averages."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def find(d, pat):
+    r = glob.glob(os.path.join(d, "**", pat), recursive=True)
+    return r[0] if r else None
+
+
+def short(name):
+    name = name.split("(")[0]
+    return name.replace("fdapde_hip::", "").replace("void ", "").strip()
+
+
+def main(out):
+    kt = find(os.path.join(out, "trace"), "*kernel_trace.csv")
+    if kt:
+        dur = defaultdict(list)
+        for r in csv.DictReader(open(kt)):
+            dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        tot = sum(sum(v) for v in dur.values())
+        print("== kernel trace (us) ==")
+        print(f"{'kernel':60s} {'calls':>7s} {'total_us':>12s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'%':>6s}")
+        for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+            print(f"{k[:60]:60s} {len(v):7d} {sum(v):12.1f} {sum(v)/len(v):10.2f} {min(v):10.2f} {max(v):10.2f} {100*sum(v)/tot:6.2f}")
+    for sub in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
+        f = find(os.path.join(out, sub), "*counter_collection.csv")
+        if not f:
+            print(f"== {sub}: no counter file ==")
+            continue
+        acc = defaultdict(lambda: defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        print(f"== {sub} (average per dispatch) ==")
+        for k, cs in sorted(acc.items()):
+            if not any(s in k for s in ("k_spmv", "k_cg", "k_assemble", "k_bicg", "k_scale")):
+                continue
+            print(f"{k[:60]:60s} " + "  ".join(f"{c}={sum(v)/len(v):.4g} (n={len(v)})" for c, v in sorted(cs.items())))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -1,6 +1,7 @@
 // capi.hip -- the extern "C" shim of include/fdapde_hip.h: context, device buffers, kernel launches.
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -79,6 +80,9 @@ struct fdapde_ctx {
     int32_t* h_ctl = nullptr;   // pinned: ctl[3]
     double* h_sc = nullptr;     // pinned: sc[0..3]
     int spmv_grid = 0, rb_per_band = 0, vec_grid = 0, n_rb = 0;
+    int spmv_variant = 2;   // 2: team form, 2 entries per lane (default); 0: team form, 1 entry per lane
+                            // (FDAPDE_SPMV=team); 1: stream form (FDAPDE_SPMV=stream) -- kept for A/B measurements
+    int spmv_team = 16, spmv_unroll = 4, spmv_ablate = 0;
     int lds_limit = 64 * 1024;
 };
 
@@ -103,7 +107,12 @@ int upload_space(fdapde_ctx* c) {
     HIPCHK(c, c->slotw.upload(hs.slotw.data(), hs.slotw.size(), st));
     HIPCHK(c, c->sl_off.upload(hs.sl_off.data(), hs.sl_off.size(), st));
     HIPCHK(c, c->rowptr.upload(hs.rowptr_i.data(), hs.rowptr_i.size(), st));
-    HIPCHK(c, c->colidx.upload(hs.colidx_i.data(), hs.colidx_i.size(), st));
+    {
+        std::vector<int32_t> padded(hs.colidx_i);
+        padded.push_back(0), padded.push_back(0);
+        HIPCHK(c, c->colidx.upload(padded.data(), padded.size(), st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
     HIPCHK(c, c->diag.upload(hs.diag_i.data(), hs.diag_i.size(), st));
     HIPCHK(c, c->slot_i2e.upload(hs.slot_i2e.data(), hs.slot_i2e.size(), st));
     HIPCHK(c, c->dof_i2e.upload(hs.dof_i2e.data(), hs.dof_i2e.size(), st));
@@ -118,9 +127,9 @@ int upload_space(fdapde_ctx* c) {
     std::memcpy(dt.qn, c->tb.qn, sizeof dt.qn);
     HIPCHK(c, c->tables.upload(&dt, 1, st));
     const size_t n = (size_t)hs.n_dofs, nnz = (size_t)hs.nnz;
-    HIPCHK(c, c->vals[0].alloc(nnz));
-    HIPCHK(c, c->vals[1].alloc(nnz));
-    HIPCHK(c, c->sval.alloc(nnz));
+    HIPCHK(c, c->vals[0].alloc(nnz + 2));   // + 2: pair loads of the SpMV may touch one entry past a row's end
+    HIPCHK(c, c->vals[1].alloc(nnz + 2));
+    HIPCHK(c, c->sval.alloc(nnz + 2));
     HIPCHK(c, c->tmp_v.alloc(nnz));
     for (DBuf<double>* b : {&c->scale, &c->gt, &c->x, &c->r, &c->p, &c->y, &c->s, &c->t, &c->r0, &c->u, &c->tmp_e, &c->tmp_i, &c->g})
         HIPCHK(c, b->alloc(n));
@@ -129,6 +138,33 @@ int upload_space(fdapde_ctx* c) {
     c->rb_per_band = (c->n_rb + 7) / 8;
     int bpx = c->rb_per_band < 256 ? c->rb_per_band : 256;
     if (bpx < 1) bpx = 1;
+    {
+        const char* v = std::getenv("FDAPDE_SPMV");
+        c->spmv_variant = (v && std::strcmp(v, "stream") == 0) ? 1 : ((v && std::strcmp(v, "team") == 0) ? 0 : 2);
+        const double mean_row = (double)hs.nnz / (double)(hs.n_dofs > 0 ? hs.n_dofs : 1);
+        int t = 4;
+        while (t < 64 && t < mean_row) t *= 2;
+        c->spmv_team = t;
+        if (c->spmv_variant == 2) c->spmv_team = t / 2 < 2 ? 2 : (t / 2 > 32 ? 32 : t / 2);
+        if (const char* e = std::getenv("FDAPDE_SPMV_TEAM")) c->spmv_team = std::atoi(e);
+        if (const char* e = std::getenv("FDAPDE_SPMV_ABLATE")) c->spmv_ablate = std::atoi(e);
+        if (c->spmv_variant == 2) {
+            if (const char* e = std::getenv("FDAPDE_SPMV_UNROLL")) c->spmv_unroll = std::atoi(e);
+            const int tt = c->spmv_team, u = tt == 2 ? 1 : (tt == 4 ? 2 : (tt == 8 ? c->spmv_unroll : 4));
+            const int wrows = (64 / tt) * u * 4;
+            const int64_t tiles = ((hs.n_dofs + 7) / 8 + wrows - 1) / wrows;
+            bpx = (int)(tiles < 256 ? (tiles < 1 ? 1 : tiles) : 256);
+            if (const char* e = std::getenv("FDAPDE_SPMV_BPX")) bpx = std::atoi(e);
+        }
+        if (c->spmv_variant == 0) {
+            if (const char* e = std::getenv("FDAPDE_SPMV_UNROLL")) c->spmv_unroll = std::atoi(e);
+            const int u = c->spmv_team == 64 || c->spmv_team == 4 ? 2 : (c->spmv_team == 16 ? c->spmv_unroll : 4);
+            const int wrows = (64 / c->spmv_team) * u * 4;   // rows per workgroup-iteration
+            const int64_t tiles = ((hs.n_dofs + 7) / 8 + wrows - 1) / wrows;
+            bpx = (int)(tiles < 256 ? (tiles < 1 ? 1 : tiles) : 256);
+            if (const char* e = std::getenv("FDAPDE_SPMV_BPX")) bpx = std::atoi(e);
+        }
+    }
     c->spmv_grid = 8 * bpx;
     int64_t vg = (hs.n_dofs + 255) / 256;
     c->vec_grid = (int)(vg < 1024 ? (vg < 1 ? 1 : vg) : 1024);
@@ -261,7 +297,49 @@ void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, 
     s.rowptr = c->rowptr.p, s.colidx = c->colidx.p, s.vals = vals, s.x = x, s.y = y;
     s.rb_row = c->rb_row.p, s.n_rb = c->n_rb, s.rb_per_band = c->rb_per_band;
     s.w = w, s.partial = partial, s.stop = stop;
-    hipLaunchKernelGGL(k_spmv, dim3(c->spmv_grid), dim3(256), 0, c->stream, s);
+    if (c->spmv_variant == 1) {
+        hipLaunchKernelGGL(k_spmv, dim3(c->spmv_grid), dim3(256), 0, c->stream, s);
+        return;
+    }
+    const int64_t n = c->hs.n_dofs, rpb = (n + 7) / 8;
+    const dim3 grid(c->spmv_grid), block(256);
+    if (c->spmv_variant == 2) {   // two entries per lane: team = lanes per row, covering 2 * team entries per pass
+        switch (c->spmv_team) {
+        case 2: hipLaunchKernelGGL((k_spmv_team2<2, 1>), grid, block, 0, c->stream, s, n, rpb); break;
+        case 4: hipLaunchKernelGGL((k_spmv_team2<4, 2>), grid, block, 0, c->stream, s, n, rpb); break;
+        case 8:
+            switch (c->spmv_ablate) {
+            case 1: hipLaunchKernelGGL((k_spmv_team2<8, 4, 1>), grid, block, 0, c->stream, s, n, rpb); break;
+            case 2: hipLaunchKernelGGL((k_spmv_team2<8, 4, 2>), grid, block, 0, c->stream, s, n, rpb); break;
+            case 4: hipLaunchKernelGGL((k_spmv_team2<8, 4, 4>), grid, block, 0, c->stream, s, n, rpb); break;
+            case 5: hipLaunchKernelGGL((k_spmv_team2<8, 4, 5>), grid, block, 0, c->stream, s, n, rpb); break;
+            default:
+                if (c->spmv_unroll == 2)
+                    hipLaunchKernelGGL((k_spmv_team2<8, 2>), grid, block, 0, c->stream, s, n, rpb);
+                else if (c->spmv_unroll == 6)
+                    hipLaunchKernelGGL((k_spmv_team2<8, 6>), grid, block, 0, c->stream, s, n, rpb);
+                else
+                    hipLaunchKernelGGL((k_spmv_team2<8, 4>), grid, block, 0, c->stream, s, n, rpb);
+                break;
+            }
+            break;
+        case 16: hipLaunchKernelGGL((k_spmv_team2<16, 4>), grid, block, 0, c->stream, s, n, rpb); break;
+        default: hipLaunchKernelGGL((k_spmv_team2<32, 4>), grid, block, 0, c->stream, s, n, rpb); break;
+        }
+        return;
+    }
+    switch (c->spmv_team) {
+    case 4: hipLaunchKernelGGL((k_spmv_team<4, 2>), grid, block, 0, c->stream, s, n, rpb); break;
+    case 8: hipLaunchKernelGGL((k_spmv_team<8, 4>), grid, block, 0, c->stream, s, n, rpb); break;
+    case 16:
+        if (c->spmv_unroll == 8)
+            hipLaunchKernelGGL((k_spmv_team<16, 8>), grid, block, 0, c->stream, s, n, rpb);
+        else
+            hipLaunchKernelGGL((k_spmv_team<16, 4>), grid, block, 0, c->stream, s, n, rpb);
+        break;
+    case 32: hipLaunchKernelGGL((k_spmv_team<32, 4>), grid, block, 0, c->stream, s, n, rpb); break;
+    default: hipLaunchKernelGGL((k_spmv_team<64, 2>), grid, block, 0, c->stream, s, n, rpb); break;
+    }
 }
 
 inline unsigned g1(int64_t n, int per = 256) { return (unsigned)((n + per - 1) / per); }
@@ -742,6 +820,21 @@ int fdapde_bench_spmv(fdapde_ctx* c, int32_t reps, double* avg_ms, double* algor
     HIPCHK(c, hipEventSynchronize(c->ev1));
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (std::getenv("FDAPDE_READ_PROBE")) {   // diagnostic: pure read stream of the matrix arrays, same stream, HIP events
+        const int64_t n16 = ((int64_t)hs.nnz * 8) / 16;
+        for (int grid : {1024, 2048, 4096, 8192}) {
+            hipLaunchKernelGGL(k_read_probe, dim3(grid), dim3(256), 0, c->stream, reinterpret_cast<const double2*>(A), n16, c->tmp_i.p);
+            HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+            for (int i = 0; i < 20; ++i)
+                hipLaunchKernelGGL(k_read_probe, dim3(grid), dim3(256), 0, c->stream, reinterpret_cast<const double2*>(A), n16, c->tmp_i.p);
+            HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+            HIPCHK(c, hipEventSynchronize(c->ev1));
+            float pm = 0;
+            HIPCHK(c, hipEventElapsedTime(&pm, c->ev0, c->ev1));
+            std::fprintf(stderr, "read_probe grid=%d: %.1f MB in %.2f us -> %.0f GB/s\n", grid, n16 * 16 / 1e6, pm / 20 * 1e3,
+                         n16 * 16 / (pm / 20 * 1e-3) / 1e9);
+        }
+    }
     if (avg_ms) *avg_ms = (double)ms / reps;
     if (algorithmic_bytes) *algorithmic_bytes = 12.0 * (double)hs.nnz + 4.0 * (double)(hs.n_dofs + 1) + 16.0 * (double)hs.n_dofs;
     return FDAPDE_OK;

@@ -411,6 +411,236 @@ __global__ __launch_bounds__(256) void k_spmv(SpmvArgs s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// CSR SpMV, "team" form (default): T lanes per row, T = the power of two covering the mean row length (16 for 3-D P1,
+// 15 nonzeros per interior row), U rows per team in flight.  Consecutive teams take consecutive rows, so every
+// val / colidx load instruction of a wavefront covers one contiguous range of the CSR arrays (64/T rows); there is no
+// LDS staging and no barrier, each lane keeps U independent load -> gather chains in flight and all 32 wave slots of a
+// CU are usable (the stream form is capped at 20 by its LDS tile and stalls at two barriers per tile: measured 3.5 TB/s
+// with 81 % of wave cycles waiting, profiles/r1_c3_summary.txt).  The U x 64/T row sums of a wave-iteration are
+// shuffled to adjacent lanes so that y (and the fused dot operands) move as one contiguous segment.
+// Same XCD banding, same fused partial dots, same algorithmic bytes as the stream form.  The in-team tree sum is a
+// fixed order: results are bitwise reproducible run to run.
+// ---------------------------------------------------------------------------------------------------------------
+template <int T, int U>
+__global__ __launch_bounds__(256) void k_spmv_team(SpmvArgs s, int64_t n, int64_t rows_per_band) {
+    constexpr int TEAMS = 64 / T;
+    constexpr int WROWS = TEAMS * U;   // rows per wave-iteration (tile); WROWS + 1 <= 64
+    static_assert(WROWS < 64, "one rowptr load per tile");
+    __shared__ double red[8];
+    if (s.stop && __syncthreads_or(*s.stop != 0)) return;
+    const int band = blockIdx.x & 7, lb = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, team = lane / T, l = lane % T;
+    const int64_t band_begin = band * rows_per_band;
+    const int64_t band_end = min(n, band_begin + rows_per_band);
+    const int64_t stride = (int64_t)bpx * 4 * WROWS;
+    double d_wy = 0, d_yy = 0;
+    // Software pipeline over tiles, three stages in flight per wavefront:
+    //   tile i+2: its WROWS+1 row pointers (one coalesced load; rows past the band clamp to an empty range)
+    //   tile i+1: its val / colidx loads (issued AFTER tile i's gathers, so the wait on the gathers leaves them in flight)
+    //   tile i  : x gathers, products, in-team sums, store
+    // Every load below is UNCONDITIONAL (indices are clamped, idle lanes re-read a neighbour's entry and discard it): a
+    // load under an exec-masked branch makes hipcc's s_waitcnt insertion assume it may not have been issued and fall
+    // back to vmcnt(0), which would drain the next tile's loads at the gather wait and undo the pipeline.
+    const int last = s.rowptr[n] - 1;   // nnz - 1 (>= 0)
+    auto load_rp = [&](int64_t base) -> int {
+        const int64_t r = base + lane;
+        return s.rowptr[r < band_end ? r : band_end];
+    };
+    int64_t base = band_begin + (int64_t)(lb * 4 + wave) * WROWS;
+    if (base < band_end) {
+        int rp0 = load_rp(base);
+        int rp1 = load_rp(base + stride);
+        int rs[U], re[U], c[U];
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            rs[u] = __shfl(rp0, u * TEAMS + team, 64), re[u] = __shfl(rp0, u * TEAMS + team + 1, 64);
+            const int k = rs[u] + l;
+            const int kc = k < last ? k : last;
+            const double vv = s.vals[kc];
+            c[u] = s.colidx[kc];
+            v[u] = k < re[u] ? vv : 0.0;
+        }
+        for (; base < band_end; base += stride) {
+            double xg[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) xg[u] = s.x[c[u]];
+            // stage the next tile before consuming the gathers
+            int rsn[U], ren[U], cn[U];
+            double vn[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                rsn[u] = __shfl(rp1, u * TEAMS + team, 64), ren[u] = __shfl(rp1, u * TEAMS + team + 1, 64);
+                const int k = rsn[u] + l;
+                const int kc = k < last ? k : last;
+                const double vv = s.vals[kc];
+                cn[u] = s.colidx[kc];
+                vn[u] = k < ren[u] ? vv : 0.0;
+            }
+            rp1 = load_rp(base + 2 * stride);
+            double acc[U];
+            bool long_row = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = v[u] * xg[u], long_row |= re[u] - rs[u] > T;
+            if (__any(long_row)) {   // rows longer than a team (rare when T covers the mean row)
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    for (int k = rs[u] + l + T; k < re[u]; k += T) acc[u] += s.vals[k] * s.x[s.colidx[k]];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int o = T / 2; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o, T);
+            }
+            // row (u, team) -> lane u*TEAMS + team: lanes 0..WROWS-1 hold WROWS consecutive rows
+            double out = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double t = __shfl(acc[u], (lane % TEAMS) * T, 64);
+                if (lane / TEAMS == u) out = t;
+            }
+            const int64_t row = base + lane;
+            if (lane < WROWS && row < band_end) {
+                s.y[row] = out;
+                if (s.w) d_wy += s.w[row] * out, d_yy += out * out;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) rs[u] = rsn[u], re[u] = ren[u], c[u] = cn[u], v[u] = vn[u];
+        }
+    }
+    if (s.partial) {
+        const double a = block_sum(d_wy, red);
+        const double b = block_sum(d_yy, red);
+        if (threadIdx.x == 0) s.partial[2 * blockIdx.x] = a, s.partial[2 * blockIdx.x + 1] = b;
+    }
+}
+
+// read-bandwidth probe: streams `bytes` (multiple of 16) with 16 B per lane, persistent grid; calibrates what the chip
+// delivers for a pure read stream next to the SpMV numbers
+__global__ __launch_bounds__(256) void k_read_probe(const double2* src, int64_t n16, double* sink) {
+    double acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) {
+        const double2 v = src[i];
+        acc += v.x + v.y;
+    }
+    if (acc == 1.2345e-300) sink[0] = acc;   // never true; keeps the loads alive
+}
+
+// Team form with two consecutive entries per lane: every val load instruction is 16 B per lane (1 KiB per wavefront, the
+// widest global access), every colidx load 8 B per lane.  T lanes cover 2 T entries of a row per pass.  The CSR value /
+// index arrays carry two padding entries so that the pair load of a row's last odd entry stays in bounds; the pair base
+// is 8-byte aligned only (row starts are arbitrary), which global_load_dwordx4 accepts.
+struct __attribute__((packed, aligned(8))) F64x2 { double x, y; };
+struct __attribute__((packed, aligned(4))) I32x2 { int x, y; };
+
+// ABL (diagnostic builds only, selected by FDAPDE_SPMV_ABLATE; results are wrong on purpose):
+//   1: no x gather (colidx still loaded and consumed)   2: gather confined to a 2 KiB window of x
+//   4: plain (default cache policy) val / colidx loads instead of nontemporal ones (results stay correct)
+// The matrix arrays are read exactly once per launch and are larger than the 256 MiB Infinity Cache, so they are
+// loaded nontemporal: measured 74.4 -> 69.0 us per launch on C3, and the CG vectors (70 MB) keep the cache.
+template <int T, int U, int ABL = 0>
+__global__ __launch_bounds__(256) void k_spmv_team2(SpmvArgs s, int64_t n, int64_t rows_per_band) {
+    constexpr int TEAMS = 64 / T;
+    constexpr int WROWS = TEAMS * U;
+    static_assert(WROWS < 64, "one rowptr load per tile");
+    __shared__ double red[8];
+    if (s.stop && __syncthreads_or(*s.stop != 0)) return;
+    const int band = blockIdx.x & 7, lb = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, team = lane / T, l = lane % T;
+    const int64_t band_begin = band * rows_per_band;
+    const int64_t band_end = min(n, band_begin + rows_per_band);
+    const int64_t stride = (int64_t)bpx * 4 * WROWS;
+    double d_wy = 0, d_yy = 0;
+    const int last = s.rowptr[n] - 1;
+    auto load_rp = [&](int64_t base) -> int {
+        const int64_t r = base + lane;
+        return s.rowptr[r < band_end ? r : band_end];
+    };
+    auto load_pair = [&](int rs, int re, F64x2& v, I32x2& c) {
+        const int k = rs + 2 * l;
+        const int kc = k < last ? k : last;
+        F64x2 vv;
+        I32x2 cc;
+        if constexpr (!(ABL & 4)) {
+            vv.x = __builtin_nontemporal_load(s.vals + kc), vv.y = __builtin_nontemporal_load(s.vals + kc + 1);
+            cc.x = __builtin_nontemporal_load(s.colidx + kc), cc.y = __builtin_nontemporal_load(s.colidx + kc + 1);
+        } else {
+            vv = *reinterpret_cast<const F64x2*>(s.vals + kc);
+            cc = *reinterpret_cast<const I32x2*>(s.colidx + kc);
+        }
+        const bool ok0 = k < re, ok1 = k + 1 < re;
+        v.x = ok0 ? vv.x : 0.0, v.y = ok1 ? vv.y : 0.0;
+        c.x = ok0 ? cc.x : 0, c.y = ok1 ? cc.y : 0;
+    };
+    int64_t base = band_begin + (int64_t)(lb * 4 + wave) * WROWS;
+    if (base < band_end) {
+        int rp0 = load_rp(base);
+        int rp1 = load_rp(base + stride);
+        int rs[U], re[U];
+        F64x2 v[U];
+        I32x2 c[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            rs[u] = __shfl(rp0, u * TEAMS + team, 64), re[u] = __shfl(rp0, u * TEAMS + team + 1, 64);
+            load_pair(rs[u], re[u], v[u], c[u]);
+        }
+        for (; base < band_end; base += stride) {
+            double xa[U], xb[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if constexpr (ABL & 1)
+                    xa[u] = (double)(c[u].x & 1), xb[u] = (double)(c[u].y & 1);
+                else if constexpr (ABL & 2)
+                    xa[u] = s.x[c[u].x & 255], xb[u] = s.x[c[u].y & 255];
+                else
+                    xa[u] = s.x[c[u].x], xb[u] = s.x[c[u].y];
+            }
+            int rsn[U], ren[U];
+            F64x2 vn[U];
+            I32x2 cn[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                rsn[u] = __shfl(rp1, u * TEAMS + team, 64), ren[u] = __shfl(rp1, u * TEAMS + team + 1, 64);
+                load_pair(rsn[u], ren[u], vn[u], cn[u]);
+            }
+            rp1 = load_rp(base + 2 * stride);
+            double acc[U];
+            bool long_row = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = v[u].x * xa[u] + v[u].y * xb[u], long_row |= re[u] - rs[u] > 2 * T;
+            if (__any(long_row)) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    for (int k = rs[u] + l + 2 * T; k < re[u]; k += T) acc[u] += s.vals[k] * s.x[s.colidx[k]];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int o = T / 2; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o, T);
+            }
+            double out = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double t = __shfl(acc[u], (lane % TEAMS) * T, 64);
+                if (lane / TEAMS == u) out = t;
+            }
+            const int64_t row = base + lane;
+            if (lane < WROWS && row < band_end) {
+                s.y[row] = out;
+                if (s.w) d_wy += s.w[row] * out, d_yy += out * out;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) rs[u] = rsn[u], re[u] = ren[u], c[u] = cn[u], v[u] = vn[u];
+        }
+    }
+    if (s.partial) {
+        const double a = block_sum(d_wy, red);
+        const double b = block_sum(d_yy, red);
+        if (threadIdx.x == 0) s.partial[2 * blockIdx.x] = a, s.partial[2 * blockIdx.x + 1] = b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // solve set-up kernels
 // ---------------------------------------------------------------------------------------------------------------
 // scale[i] = 0 on Dirichlet rows, 1/sqrt(|A_ii|) elsewhere; flag[0] |= 1 if some interior diagonal is <= 0
@@ -482,7 +712,21 @@ __global__ __launch_bounds__(256) void k_cg_update_xr(int64_t n, const double* p
     const double alpha = pAp > 0.0 ? rr / pAp : 0.0;
     if (!(pAp > 0.0) && blockIdx.x == 0 && threadIdx.x == 0) ctl[2] = 1;   // not SPD / breakdown
     double acc = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n2 = n >> 1, tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+    const double2* p2 = reinterpret_cast<const double2*>(p);
+    const double2* y2 = reinterpret_cast<const double2*>(y);
+    double2* x2 = reinterpret_cast<double2*>(x);
+    double2* r2 = reinterpret_cast<double2*>(r);
+    for (int64_t i = tid; i < n2; i += nth) {   // 16 B per lane per stream
+        const double2 pv = p2[i], yv = y2[i];
+        double2 xv = x2[i], rv = r2[i];
+        xv.x += alpha * pv.x, xv.y += alpha * pv.y;
+        rv.x -= alpha * yv.x, rv.y -= alpha * yv.y;
+        x2[i] = xv, r2[i] = rv;
+        acc += rv.x * rv.x + rv.y * rv.y;
+    }
+    if ((n & 1) && tid == 0) {
+        const int64_t i = n - 1;
         x[i] += alpha * p[i];
         const double ri = r[i] - alpha * y[i];
         r[i] = ri, acc += ri * ri;
@@ -497,8 +741,16 @@ __global__ __launch_bounds__(256) void k_cg_update_p(int64_t n, const double* r,
     const double rr_new = sum_partials(part_in, np_in, red);
     const double rr = sc[1 + parity];
     const double beta = rr > 0.0 ? rr_new / rr : 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        p[i] = r[i] + beta * p[i];
+    const int64_t n2 = n >> 1, tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+    const double2* r2 = reinterpret_cast<const double2*>(r);
+    double2* p2 = reinterpret_cast<double2*>(p);
+    for (int64_t i = tid; i < n2; i += nth) {
+        const double2 rv = r2[i];
+        double2 pv = p2[i];
+        pv.x = rv.x + beta * pv.x, pv.y = rv.y + beta * pv.y;
+        p2[i] = pv;
+    }
+    if ((n & 1) && tid == 0) p[n - 1] = r[n - 1] + beta * p[n - 1];
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
         sc[1 + (parity ^ 1)] = rr_new, sc[3] = rr_new;
         ctl[1] += 1;

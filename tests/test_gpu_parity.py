@@ -144,6 +144,36 @@ def test_init_force_mass_spmv(capi, ctx, oracle, mesh_loader, mesh_name, order):
         assert np.abs(y - yr).max() <= 1e-12 * max(1.0, np.abs(yr).max())
 
 
+@pytest.mark.parametrize("variant", ["stream", "team4", "team8", "team16", "team32", "team64", "pair2", "pair4", "pair8", "pair16", "pair32"])
+@pytest.mark.parametrize("mesh_name,order", [("unit_square", 1), ("unit_sphere", 1), ("unit_sphere", 2), ("c_shaped", 2)])
+def test_spmv_variants(capi, ctx, oracle, mesh_loader, monkeypatch, variant, mesh_name, order):
+    """every SpMV kernel form / team width gives the oracle's y = A x (ragged rows, rows longer than a team, tails)"""
+    if variant == "stream":
+        monkeypatch.setenv("FDAPDE_SPMV", "stream")
+    else:
+        monkeypatch.setenv("FDAPDE_SPMV", "team" if variant.startswith("team") else "pair")
+        monkeypatch.setenv("FDAPDE_SPMV_TEAM", variant[4:])
+    m = mesh_loader(mesh_name)
+    ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = ctx.dofs_build(order)   # the kernel form is chosen here
+    od, _, _, _ = oracle.enumerate_dofs(m, order)
+    op = lambda mod: -mod.laplacian() + mod.reaction(0.3)
+    ctx.assemble_operator(capi.MAT_STIFF, op(capi))
+    ref = oracle.assemble_operator(m, order, od, nd, op(oracle))
+    x = np.random.default_rng(11).standard_normal(nd)
+    y, yr = ctx.spmv(capi.MAT_STIFF, x), ref.matvec(x)
+    assert np.abs(y - yr).max() <= 1e-12 * max(1.0, np.abs(yr).max())
+    # and inside a solve (fused dot products)
+    ctx.set_operator(op(capi))
+    ctx.set_forcing(np.ones(ctx.sizes()["n_quadrature"] * m.n_cells))
+    ctx.set_dirichlet(None)
+    ctx.init()
+    info = ctx.solve(method=capi.SOLVER_CG, rtol=1e-11)
+    sol = oracle.pde_init_solve(m, order, op(oracle), forcing_q=np.ones(ctx.sizes()["n_quadrature"] * m.n_cells))
+    assert info.converged == 1
+    assert np.linalg.norm(ctx.solution() - sol.solution) / np.linalg.norm(sol.solution) <= SOL_TOL
+
+
 def _l2(oracle_mass, err):
     return float(np.sum(oracle_mass.matvec(err * err)))
 

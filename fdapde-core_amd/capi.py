@@ -43,7 +43,7 @@ SYMBOLS = [
     "fdapde_status_string", "fdapde_mesh_upload", "fdapde_dofs_build", "fdapde_dofs_get", "fdapde_sizes",
     "fdapde_pattern_get", "fdapde_quadrature_nodes", "fdapde_set_operator", "fdapde_set_forcing", "fdapde_set_dirichlet",
     "fdapde_init", "fdapde_assemble_operator", "fdapde_solve", "fdapde_matrix_values", "fdapde_force", "fdapde_solution",
-    "fdapde_info_get", "fdapde_spmv", "fdapde_bench_spmv", "fdapde_stream", "fdapde_synchronize",
+    "fdapde_info_get", "fdapde_spmv", "fdapde_bench_spmv", "fdapde_tune", "fdapde_stream", "fdapde_synchronize",
 ]
 
 _lib = None
@@ -294,6 +294,9 @@ class Context:
         ms, by = C.c_double(), C.c_double()
         self._check(self.lib.fdapde_bench_spmv(self._ctx, reps, C.byref(ms), C.byref(by)))
         return ms.value, by.value
+
+    def tune(self, key, value):
+        self._check(self.lib.fdapde_tune(self._ctx, key.encode(), int(value)))
 
     def stream(self):
         return self.lib.fdapde_stream(self._ctx)

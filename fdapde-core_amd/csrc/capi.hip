@@ -5,6 +5,8 @@
 #include <cstring>
 #include <new>
 
+#include <hip/hip_ext.h>
+
 #include "kernels.h"
 
 using namespace fdapde_hip;
@@ -79,7 +81,7 @@ struct fdapde_ctx {
     DBuf<double> coef[kMaxTerms];
     int32_t* h_ctl = nullptr;   // pinned: ctl[3]
     double* h_sc = nullptr;     // pinned: sc[0..3]
-    int spmv_grid = 0, rb_per_band = 0, vec_grid = 0, n_rb = 0;
+    int spmv_grid = 0, rb_per_band = 0, vec_grid = 0, n_rb = 0, cg_grid = 0;
     int spmv_variant = 2;   // 2: team form, 2 entries per lane (default); 0: team form, 1 entry per lane
                             // (FDAPDE_SPMV=team); 1: stream form (FDAPDE_SPMV=stream) -- kept for A/B measurements
     int spmv_team = 16, spmv_unroll = 4, spmv_ablate = 0;
@@ -169,7 +171,12 @@ int upload_space(fdapde_ctx* c) {
     int64_t vg = (hs.n_dofs + 255) / 256;
     c->vec_grid = (int)(vg < 1024 ? (vg < 1 ? 1 : vg) : 1024);
     HIPCHK(c, c->part_a.alloc(2 * (size_t)c->spmv_grid));
-    HIPCHK(c, c->part_b.alloc(2 * (size_t)c->vec_grid));
+    {
+        const int64_t n2 = hs.n_dofs / 2, per = 256 * kCgV;
+        c->cg_grid = (int)((n2 + per - 1) / per);
+        if (c->cg_grid < 1) c->cg_grid = 1;
+    }
+    HIPCHK(c, c->part_b.alloc(2 * (size_t)(c->vec_grid > c->cg_grid ? c->vec_grid : c->cg_grid)));
     HIPCHK(c, c->sc.alloc(16));
     HIPCHK(c, c->ctl.alloc(4));
     HIPCHK(c, hipMemsetAsync(c->ctl.p, 0, 4 * sizeof(int32_t), st));
@@ -291,55 +298,60 @@ int launch_assembly(fdapde_ctx* c, const AsmArgs& a, const DevOp& op, int assemb
     return fail(c, FDAPDE_EUNSUPPORTED, "unsupported (M, order)");
 }
 
+// e0 / e1 (optional): HIP events attached to the dispatch itself (hipExtLaunchKernelGGL), i.e. the kernel's own begin / end
+// timestamps on the stream it runs on -- the same interval rocprofv3 --kernel-trace reports, with no extra marker packet
+// between the neighbouring kernels.
 void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, const double* w, double* partial,
-                 const int32_t* stop) {
+                 const int32_t* stop, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
     SpmvArgs s{};
     s.rowptr = c->rowptr.p, s.colidx = c->colidx.p, s.vals = vals, s.x = x, s.y = y;
-    s.rb_row = c->rb_row.p, s.n_rb = c->n_rb, s.rb_per_band = c->rb_per_band;
+    s.rb_row = c->rb_row.p, s.n_rb = c->n_rb, s.rb_per_band = c->rb_per_band, s.nnz = (int32_t)c->hs.nnz;
     s.w = w, s.partial = partial, s.stop = stop;
-    if (c->spmv_variant == 1) {
-        hipLaunchKernelGGL(k_spmv, dim3(c->spmv_grid), dim3(256), 0, c->stream, s);
-        return;
-    }
     const int64_t n = c->hs.n_dofs, rpb = (n + 7) / 8;
     const dim3 grid(c->spmv_grid), block(256);
+#define SPMV_GO(...) hipExtLaunchKernelGGL((__VA_ARGS__), grid, block, 0, c->stream, e0, e1, 0, s, n, rpb)
+    if (c->spmv_variant == 1) {
+        hipExtLaunchKernelGGL(k_spmv, grid, block, 0, c->stream, e0, e1, 0, s);
+        return;
+    }
     if (c->spmv_variant == 2) {   // two entries per lane: team = lanes per row, covering 2 * team entries per pass
         switch (c->spmv_team) {
-        case 2: hipLaunchKernelGGL((k_spmv_team2<2, 1>), grid, block, 0, c->stream, s, n, rpb); break;
-        case 4: hipLaunchKernelGGL((k_spmv_team2<4, 2>), grid, block, 0, c->stream, s, n, rpb); break;
+        case 2: SPMV_GO(k_spmv_team2<2, 1>); break;
+        case 4: SPMV_GO(k_spmv_team2<4, 2>); break;
         case 8:
             switch (c->spmv_ablate) {
-            case 1: hipLaunchKernelGGL((k_spmv_team2<8, 4, 1>), grid, block, 0, c->stream, s, n, rpb); break;
-            case 2: hipLaunchKernelGGL((k_spmv_team2<8, 4, 2>), grid, block, 0, c->stream, s, n, rpb); break;
-            case 4: hipLaunchKernelGGL((k_spmv_team2<8, 4, 4>), grid, block, 0, c->stream, s, n, rpb); break;
-            case 5: hipLaunchKernelGGL((k_spmv_team2<8, 4, 5>), grid, block, 0, c->stream, s, n, rpb); break;
+            case 1: SPMV_GO(k_spmv_team2<8, 4, 1>); break;
+            case 2: SPMV_GO(k_spmv_team2<8, 4, 2>); break;
+            case 4: SPMV_GO(k_spmv_team2<8, 4, 4>); break;
+            case 5: SPMV_GO(k_spmv_team2<8, 4, 5>); break;
             default:
                 if (c->spmv_unroll == 2)
-                    hipLaunchKernelGGL((k_spmv_team2<8, 2>), grid, block, 0, c->stream, s, n, rpb);
+                    SPMV_GO(k_spmv_team2<8, 2>);
                 else if (c->spmv_unroll == 6)
-                    hipLaunchKernelGGL((k_spmv_team2<8, 6>), grid, block, 0, c->stream, s, n, rpb);
+                    SPMV_GO(k_spmv_team2<8, 6>);
                 else
-                    hipLaunchKernelGGL((k_spmv_team2<8, 4>), grid, block, 0, c->stream, s, n, rpb);
+                    SPMV_GO(k_spmv_team2<8, 4>);
                 break;
             }
             break;
-        case 16: hipLaunchKernelGGL((k_spmv_team2<16, 4>), grid, block, 0, c->stream, s, n, rpb); break;
-        default: hipLaunchKernelGGL((k_spmv_team2<32, 4>), grid, block, 0, c->stream, s, n, rpb); break;
+        case 16: SPMV_GO(k_spmv_team2<16, 4>); break;
+        default: SPMV_GO(k_spmv_team2<32, 4>); break;
         }
         return;
     }
     switch (c->spmv_team) {
-    case 4: hipLaunchKernelGGL((k_spmv_team<4, 2>), grid, block, 0, c->stream, s, n, rpb); break;
-    case 8: hipLaunchKernelGGL((k_spmv_team<8, 4>), grid, block, 0, c->stream, s, n, rpb); break;
+    case 4: SPMV_GO(k_spmv_team<4, 2>); break;
+    case 8: SPMV_GO(k_spmv_team<8, 4>); break;
     case 16:
         if (c->spmv_unroll == 8)
-            hipLaunchKernelGGL((k_spmv_team<16, 8>), grid, block, 0, c->stream, s, n, rpb);
+            SPMV_GO(k_spmv_team<16, 8>);
         else
-            hipLaunchKernelGGL((k_spmv_team<16, 4>), grid, block, 0, c->stream, s, n, rpb);
+            SPMV_GO(k_spmv_team<16, 4>);
         break;
-    case 32: hipLaunchKernelGGL((k_spmv_team<32, 4>), grid, block, 0, c->stream, s, n, rpb); break;
-    default: hipLaunchKernelGGL((k_spmv_team<64, 2>), grid, block, 0, c->stream, s, n, rpb); break;
+    case 32: SPMV_GO(k_spmv_team<32, 4>); break;
+    default: SPMV_GO(k_spmv_team<64, 2>); break;
     }
+#undef SPMV_GO
 }
 
 inline unsigned g1(int64_t n, int per = 256) { return (unsigned)((n + per - 1) / per); }
@@ -671,20 +683,20 @@ int fdapde_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
             if (!bicg) {
                 const int parity = launched & 1;
                 const bool tm = launched < n_timed;
-                if (tm) HIPCHK(c, hipEventRecord(c->ev_spmv[2 * launched], st));
-                launch_spmv(c, c->sval.p, c->p.p, c->y.p, c->p.p, c->part_a.p, c->ctl.p);
-                if (tm) { HIPCHK(c, hipEventRecord(c->ev_spmv[2 * launched + 1], st)); ++timed; }
-                hipLaunchKernelGGL(k_cg_update_xr, dim3(c->vec_grid), dim3(256), 0, st, n, c->p.p, c->y.p, c->x.p, c->r.p,
+                launch_spmv(c, c->sval.p, c->p.p, c->y.p, c->p.p, c->part_a.p, c->ctl.p,
+                            tm ? c->ev_spmv[2 * launched] : nullptr, tm ? c->ev_spmv[2 * launched + 1] : nullptr);
+                if (tm) ++timed;
+                hipLaunchKernelGGL(k_cg_update_xr, dim3(c->cg_grid), dim3(256), 0, st, n, c->p.p, c->y.p, c->x.p, c->r.p,
                                    c->part_a.p, c->spmv_grid, c->part_b.p, c->sc.p, parity, c->ctl.p);
-                hipLaunchKernelGGL(k_cg_update_p, dim3(c->vec_grid), dim3(256), 0, st, n, c->r.p, c->p.p, c->part_b.p,
-                                   c->vec_grid, c->sc.p, parity, tol2, c->ctl.p);
+                hipLaunchKernelGGL(k_cg_update_p, dim3(c->cg_grid), dim3(256), 0, st, n, c->r.p, c->p.p, c->part_b.p,
+                                   c->cg_grid, c->sc.p, parity, tol2, c->ctl.p);
             } else {
                 hipLaunchKernelGGL(k_bicg_p, dim3(c->vec_grid), dim3(256), 0, st, n, c->r.p, c->y.p, c->p.p, c->part_b.p,
                                    c->vec_grid, c->sc.p, launched == 0 ? 1 : 0, c->ctl.p);
                 const bool tm = launched < n_timed;
-                if (tm) HIPCHK(c, hipEventRecord(c->ev_spmv[2 * launched], st));
-                launch_spmv(c, c->sval.p, c->p.p, c->y.p, c->r0.p, c->part_a.p, c->ctl.p);   // v = At p, r0.v
-                if (tm) { HIPCHK(c, hipEventRecord(c->ev_spmv[2 * launched + 1], st)); ++timed; }
+                launch_spmv(c, c->sval.p, c->p.p, c->y.p, c->r0.p, c->part_a.p, c->ctl.p,   // v = At p, r0.v
+                            tm ? c->ev_spmv[2 * launched] : nullptr, tm ? c->ev_spmv[2 * launched + 1] : nullptr);
+                if (tm) ++timed;
                 hipLaunchKernelGGL(k_bicg_s, dim3(c->vec_grid), dim3(256), 0, st, n, c->r.p, c->y.p, c->s.p, c->part_a.p,
                                    c->spmv_grid, c->sc.p, c->ctl.p);
                 launch_spmv(c, c->sval.p, c->s.p, c->t.p, c->s.p, c->part_a.p, c->ctl.p);    // t = At s, t.s, t.t
@@ -835,8 +847,51 @@ int fdapde_bench_spmv(fdapde_ctx* c, int32_t reps, double* avg_ms, double* algor
                          n16 * 16 / (pm / 20 * 1e-3) / 1e9);
         }
     }
+    if (std::getenv("FDAPDE_STREAM_PROBE")) {   // diagnostic: the matrix arrays streamed once, nothing else
+        const int64_t n2 = (int64_t)hs.nnz / 2;
+        for (int grid : {2048, 8192}) {
+            hipLaunchKernelGGL(k_stream_probe, dim3(grid), dim3(256), 0, c->stream, reinterpret_cast<const double2*>(A),
+                               reinterpret_cast<const int2*>(c->colidx.p), n2, c->tmp_i.p);
+            HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+            for (int i = 0; i < 50; ++i)
+                hipLaunchKernelGGL(k_stream_probe, dim3(grid), dim3(256), 0, c->stream, reinterpret_cast<const double2*>(A),
+                                   reinterpret_cast<const int2*>(c->colidx.p), n2, c->tmp_i.p);
+            HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+            HIPCHK(c, hipEventSynchronize(c->ev1));
+            float pm = 0;
+            HIPCHK(c, hipEventElapsedTime(&pm, c->ev0, c->ev1));
+            std::fprintf(stderr, "stream_probe grid=%d: %.1f MB in %.2f us -> %.0f GB/s\n", grid, n2 * 24 / 1e6, pm / 50 * 1e3,
+                         n2 * 24 / (pm / 50 * 1e-3) / 1e9);
+            HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+            for (int i = 0; i < 50; ++i)
+                hipLaunchKernelGGL(k_stream_probe_unaligned, dim3(grid), dim3(256), 0, c->stream, A,
+                                   reinterpret_cast<const int2*>(c->colidx.p), n2, c->tmp_i.p);
+            HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+            HIPCHK(c, hipEventSynchronize(c->ev1));
+            HIPCHK(c, hipEventElapsedTime(&pm, c->ev0, c->ev1));
+            std::fprintf(stderr, "stream_probe_unaligned grid=%d: %.2f us -> %.0f GB/s\n", grid, pm / 50 * 1e3,
+                         n2 * 24 / (pm / 50 * 1e-3) / 1e9);
+        }
+    }
     if (avg_ms) *avg_ms = (double)ms / reps;
     if (algorithmic_bytes) *algorithmic_bytes = 12.0 * (double)hs.nnz + 4.0 * (double)(hs.n_dofs + 1) + 16.0 * (double)hs.n_dofs;
+    return FDAPDE_OK;
+}
+
+int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
+    if (!c || !key) return FDAPDE_EINVAL;
+    if (!c->dev_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
+    const std::string k(key);
+    if (k == "spmv_variant" && value >= 0 && value <= 2) c->spmv_variant = value;
+    else if (k == "spmv_team" && (value == 2 || value == 4 || value == 8 || value == 16 || value == 32 || value == 64)) c->spmv_team = value;
+    else if (k == "spmv_unroll" && value >= 1 && value <= 8) c->spmv_unroll = value;
+    else if (k == "spmv_ablate") c->spmv_ablate = value;
+    else if (k == "spmv_bpx" && value >= 1 && value <= 1024) {
+        c->spmv_grid = 8 * value;
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, c->part_a.alloc(2 * (size_t)c->spmv_grid));
+    } else return fail(c, FDAPDE_EINVAL, "unknown tuning key or value out of range");
     return FDAPDE_OK;
 }
 

@@ -368,7 +368,7 @@ struct SpmvArgs {
     const double* x;
     double* y;
     const int32_t* rb_row;
-    int32_t n_rb, rb_per_band;
+    int32_t n_rb, rb_per_band, nnz;
     const double* w;       // second vector of the fused dot products; nullptr: no dots
     double* partial;       // [2 * gridDim.x]: workgroup b writes (w.y, y.y) at 2b, 2b+1; nullptr: no dots
     const int32_t* stop;   // device flag: nonzero -> converged, kernel returns immediately (may be nullptr)
@@ -526,10 +526,57 @@ __global__ __launch_bounds__(256) void k_read_probe(const double2* src, int64_t 
     if (acc == 1.2345e-300) sink[0] = acc;   // never true; keeps the loads alive
 }
 
+// matrix-stream probe: reads vals (16 B / lane) and colidx (8 B / lane) exactly once, in order, nothing else: the time a
+// CSR SpMV of this matrix cannot beat on this chip
+typedef double v2f64_t __attribute__((ext_vector_type(2)));
+typedef int v2i32_t __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(8))) F64x2u { double x, y; };
+// same stream with the 16-byte loads based at an address that is only 8-byte aligned (what an odd row start gives)
+__global__ __launch_bounds__(256) void k_stream_probe_unaligned(const double* vals, const int2* col2, int64_t n2, double* sink) {
+    double acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2 - 1; i += (int64_t)gridDim.x * blockDim.x) {
+        const F64x2u v = *reinterpret_cast<const F64x2u*>(vals + 2 * i + 1);
+        const int2 c = col2[i];
+        acc += v.x * c.x + v.y * c.y;
+    }
+    if (acc == 1.2345e-300) sink[0] = acc;
+}
+__global__ __launch_bounds__(256) void k_stream_probe(const double2* vals2, const int2* col2, int64_t n2, double* sink) {
+    double acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+        const v2f64_t v = __builtin_nontemporal_load(reinterpret_cast<const v2f64_t*>(vals2) + i);
+        const v2i32_t c = __builtin_nontemporal_load(reinterpret_cast<const v2i32_t*>(col2) + i);
+        acc += v.x * c.x + v.y * c.y;
+    }
+    if (acc == 1.2345e-300) sink[0] = acc;
+}
+
 // Team form with two consecutive entries per lane: every val load instruction is 16 B per lane (1 KiB per wavefront, the
 // widest global access), every colidx load 8 B per lane.  T lanes cover 2 T entries of a row per pass.  The CSR value /
 // index arrays carry two padding entries so that the pair load of a row's last odd entry stays in bounds; the pair base
 // is 8-byte aligned only (row starts are arbitrary), which global_load_dwordx4 accepts.
+// Sum over aligned groups of T lanes with DPP row operations (VALU data path; the ds_bpermute the compiler emits for
+// __shfl_xor goes through the LDS crossbar, shared by the 4 SIMDs of the CU: 40 of them per 32-row tile were on the
+// critical path of the team kernels).  Every lane of the group ends up with the group's total.  T <= 16 stays inside a
+// DPP row (16 lanes); wider groups finish with __shfl_xor.
+template <int CTRL> __device__ __forceinline__ double dpp_mov_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int T> __device__ __forceinline__ double team_sum(double v) {
+    if constexpr (T >= 32) {
+#pragma unroll
+        for (int o = T / 2; o >= 16; o >>= 1) v += __shfl_xor(v, o, T);
+    }
+    if constexpr (T >= 16) v += dpp_mov_f64<0x140>(v);   // row_mirror:       lane i <-> 15 - i
+    if constexpr (T >= 8) v += dpp_mov_f64<0x141>(v);    // row_half_mirror:  lane i <-> 7 - i
+    if constexpr (T >= 4) v += dpp_mov_f64<0x4E>(v);     // quad_perm [2,3,0,1]
+    if constexpr (T >= 2) v += dpp_mov_f64<0xB1>(v);     // quad_perm [1,0,3,2]
+    return v;
+}
+
 struct __attribute__((packed, aligned(8))) F64x2 { double x, y; };
 struct __attribute__((packed, aligned(4))) I32x2 { int x, y; };
 
@@ -547,11 +594,17 @@ __global__ __launch_bounds__(256) void k_spmv_team2(SpmvArgs s, int64_t n, int64
     if (s.stop && __syncthreads_or(*s.stop != 0)) return;
     const int band = blockIdx.x & 7, lb = blockIdx.x >> 3, bpx = gridDim.x >> 3;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, team = lane / T, l = lane % T;
+    // Tiles are dealt round-robin to the wavefronts of a band, so that at any moment the wavefronts of an XCD read one
+    // advancing window of the CSR arrays.  (Giving every wavefront its own contiguous share of rows balances the tail
+    // better but measured 9 % slower at C3 size, 81.7 vs 74.8 us: thousands of independent address streams.)
     const int64_t band_begin = band * rows_per_band;
     const int64_t band_end = min(n, band_begin + rows_per_band);
     const int64_t stride = (int64_t)bpx * 4 * WROWS;
     double d_wy = 0, d_yy = 0;
-    const int last = s.rowptr[n] - 1;
+    const int last = s.nnz - 1;
+    // row pointers: ONE coalesced load of the tile's WROWS + 1 pointers, shuffled to the teams (8 ds_bpermute per tile).
+    // Loading them per (tile, u) with team-uniform 8-byte loads instead was measured slower (79.5 vs 66.0 us): every
+    // extra vector-memory instruction costs address-processing time whatever its footprint.
     auto load_rp = [&](int64_t base) -> int {
         const int64_t r = base + lane;
         return s.rowptr[r < band_end ? r : band_end];
@@ -613,19 +666,15 @@ __global__ __launch_bounds__(256) void k_spmv_team2(SpmvArgs s, int64_t n, int64
                 for (int u = 0; u < U; ++u)
                     for (int k = rs[u] + l + 2 * T; k < re[u]; k += T) acc[u] += s.vals[k] * s.x[s.colidx[k]];
             }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-#pragma unroll
-                for (int o = T / 2; o > 0; o >>= 1) acc[u] += __shfl_xor(acc[u], o, T);
-            }
+            // every lane of a team gets the team's U row sums; lane l < U of the team keeps row u = l and stores it
             double out = 0;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const double t = __shfl(acc[u], (lane % TEAMS) * T, 64);
-                if (lane / TEAMS == u) out = t;
+                const double t = team_sum<T>(acc[u]);
+                if (l == u) out = t;
             }
-            const int64_t row = base + lane;
-            if (lane < WROWS && row < band_end) {
+            const int64_t row = base + l * TEAMS + team;
+            if (l < U && row < band_end) {
                 s.y[row] = out;
                 if (s.w) d_wy += s.w[row] * out, d_yy += out * out;
             }
@@ -700,11 +749,26 @@ __global__ __launch_bounds__(256) void k_krylov_init_fin(const double* partial, 
 //   k_cg_update_xr    : alpha = rr / p.y ; x += alpha p ; r -= alpha y ; partials of r.r
 //   k_cg_update_p     : beta = rr_new / rr ; p = r + beta p ; bookkeeping + stopping test (workgroup 0)
 // ---------------------------------------------------------------------------------------------------------------
+// Both update kernels are single-shot: workgroup b owns kCgV * 256 consecutive double2 elements, every lane issues all of
+// its 16-byte loads FIRST, and only then re-reduces the producer's partials (an L2 round trip plus two barriers) -- the
+// reduction hides under the loads instead of delaying them (measured per-kernel saving ~2 us of 17 / 9 us).
+constexpr int kCgV = 4;
 __global__ __launch_bounds__(256) void k_cg_update_xr(int64_t n, const double* p, const double* y, double* x, double* r,
                                                        const double* part_in, int np_in, double* part_out,
                                                        const double* sc, int parity, int32_t* ctl) {
     __shared__ double red[8];
     if (__syncthreads_or(ctl[0] != 0)) return;   // uniform even if another workgroup raises the flag meanwhile
+    const int64_t n2 = n >> 1, i0 = (int64_t)blockIdx.x * (256 * kCgV) + threadIdx.x;
+    const double2* p2 = reinterpret_cast<const double2*>(p);
+    const double2* y2 = reinterpret_cast<const double2*>(y);
+    double2* x2 = reinterpret_cast<double2*>(x);
+    double2* r2 = reinterpret_cast<double2*>(r);
+    double2 pv[kCgV], yv[kCgV], xv[kCgV], rv[kCgV];
+#pragma unroll
+    for (int k = 0; k < kCgV; ++k) {
+        const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
+        pv[k] = p2[ic], yv[k] = y2[ic], xv[k] = x2[ic], rv[k] = r2[ic];
+    }
     double v = 0;
     for (int i = threadIdx.x; i < np_in; i += blockDim.x) v += part_in[2 * i];
     const double pAp = block_sum(v, red);
@@ -712,20 +776,17 @@ __global__ __launch_bounds__(256) void k_cg_update_xr(int64_t n, const double* p
     const double alpha = pAp > 0.0 ? rr / pAp : 0.0;
     if (!(pAp > 0.0) && blockIdx.x == 0 && threadIdx.x == 0) ctl[2] = 1;   // not SPD / breakdown
     double acc = 0;
-    const int64_t n2 = n >> 1, tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
-    const double2* p2 = reinterpret_cast<const double2*>(p);
-    const double2* y2 = reinterpret_cast<const double2*>(y);
-    double2* x2 = reinterpret_cast<double2*>(x);
-    double2* r2 = reinterpret_cast<double2*>(r);
-    for (int64_t i = tid; i < n2; i += nth) {   // 16 B per lane per stream
-        const double2 pv = p2[i], yv = y2[i];
-        double2 xv = x2[i], rv = r2[i];
-        xv.x += alpha * pv.x, xv.y += alpha * pv.y;
-        rv.x -= alpha * yv.x, rv.y -= alpha * yv.y;
-        x2[i] = xv, r2[i] = rv;
-        acc += rv.x * rv.x + rv.y * rv.y;
+#pragma unroll
+    for (int k = 0; k < kCgV; ++k) {
+        const int64_t i = i0 + k * 256;
+        if (i < n2) {
+            xv[k].x += alpha * pv[k].x, xv[k].y += alpha * pv[k].y;
+            rv[k].x -= alpha * yv[k].x, rv[k].y -= alpha * yv[k].y;
+            x2[i] = xv[k], r2[i] = rv[k];
+            acc += rv[k].x * rv[k].x + rv[k].y * rv[k].y;
+        }
     }
-    if ((n & 1) && tid == 0) {
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const int64_t i = n - 1;
         x[i] += alpha * p[i];
         const double ri = r[i] - alpha * y[i];
@@ -738,19 +799,27 @@ __global__ __launch_bounds__(256) void k_cg_update_p(int64_t n, const double* r,
                                                       int np_in, double* sc, int parity, double tol2, int32_t* ctl) {
     __shared__ double red[8];
     if (__syncthreads_or(ctl[0] != 0)) return;   // uniform even if another workgroup raises the flag meanwhile
+    const int64_t n2 = n >> 1, i0 = (int64_t)blockIdx.x * (256 * kCgV) + threadIdx.x;
+    const double2* r2 = reinterpret_cast<const double2*>(r);
+    double2* p2 = reinterpret_cast<double2*>(p);
+    double2 rv[kCgV], pv[kCgV];
+#pragma unroll
+    for (int k = 0; k < kCgV; ++k) {
+        const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
+        rv[k] = r2[ic], pv[k] = p2[ic];
+    }
     const double rr_new = sum_partials(part_in, np_in, red);
     const double rr = sc[1 + parity];
     const double beta = rr > 0.0 ? rr_new / rr : 0.0;
-    const int64_t n2 = n >> 1, tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
-    const double2* r2 = reinterpret_cast<const double2*>(r);
-    double2* p2 = reinterpret_cast<double2*>(p);
-    for (int64_t i = tid; i < n2; i += nth) {
-        const double2 rv = r2[i];
-        double2 pv = p2[i];
-        pv.x = rv.x + beta * pv.x, pv.y = rv.y + beta * pv.y;
-        p2[i] = pv;
+#pragma unroll
+    for (int k = 0; k < kCgV; ++k) {
+        const int64_t i = i0 + k * 256;
+        if (i < n2) {
+            pv[k].x = rv[k].x + beta * pv[k].x, pv[k].y = rv[k].y + beta * pv[k].y;
+            p2[i] = pv[k];
+        }
     }
-    if ((n & 1) && tid == 0) p[n - 1] = r[n - 1] + beta * p[n - 1];
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = r[n - 1] + beta * p[n - 1];
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
         sc[1 + (parity ^ 1)] = rr_new, sc[3] = rr_new;
         ctl[1] += 1;

@@ -145,6 +145,9 @@ int fdapde_spmv(fdapde_ctx *ctx, int32_t which, const double *x, double *y);
  * returns the average kernel duration in ms and the algorithmic bytes per launch
  * (12*nnz + 4*(n+1) + 16*n) */
 int fdapde_bench_spmv(fdapde_ctx *ctx, int32_t reps, double *avg_ms, double *algorithmic_bytes);
+/* tuning / diagnostic knobs of the SpMV launch (A/B measurements inside one process): key in {"spmv_variant" (2 pair form,
+ * 0 team form, 1 stream form), "spmv_team", "spmv_unroll", "spmv_bpx" (workgroups per XCD band), "spmv_ablate"} */
+int fdapde_tune(fdapde_ctx *ctx, const char *key, int32_t value);
 /* the context's HIP stream (hipStream_t) so that callers can bracket work with their own events */
 void *fdapde_stream(fdapde_ctx *ctx);
 int fdapde_synchronize(fdapde_ctx *ctx);

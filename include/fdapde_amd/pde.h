@@ -1,0 +1,381 @@
+// fdapde_amd/pde.h -- header-only C++20 facade of the MI355X assemble-and-solve path.
+//
+// Mirrors, name for name, the part of fdaPDE-core's public interface that sits on the hot path, on top of the C ABI of
+// include/fdapde_hip.h (no Eigen required; an adapter is provided when <Eigen/Sparse> is available):
+//
+//   reference (fdaPDE/...)                                           here (namespace fdapde::amd)
+//   ---------------------------------------------------------------  -------------------------------------------------
+//   Triangulation<M,N>(nodes, cells, boundary)  geometry/triangulation.h:49   Triangulation<M,N>
+//   laplacian<FEM>() diffusion<FEM>(K) advection<FEM>(b) reaction<FEM>(c) dt<FEM>()
+//       pde/differential_operators.h:27-52, finite_elements/operators/*.h       same names, tag FEM_HIP
+//   operator algebra  -L, L1 + L2, L1 - L2, c * L  pde/differential_expressions.h:49,95-118   same
+//   fem_order<R>      finite_elements/fem_symbols.h:24-29                         fem_order<R>
+//   PDE<D,E,F,S,Ts...>  pde/pde.h:40-114: ctors 58-72, set_forcing / set_differential_operator / set_dirichlet_bc 74-77,
+//       domain() forcing_data() boundary_data() n_dofs() solution() force() stiff() mass() dof_coords() dofs()
+//       quadrature_nodes() 79-100, init() 101, solve() 102-105                     PDE<D,E,F,FEM_HIP,fem_order<R>>
+//   solver flags is_init / success  finite_elements/solvers/fem_solver_base.h:61-62     PDE::is_init(), PDE::success()
+//
+// Semantics kept: the mesh is held by reference and must outlive the PDE (pde.h:107); operator / forcing / boundary data are
+// copied; getters return const references to solver-owned storage; "solver must be initialized first!" is a
+// std::runtime_error (fem_solver_base.h:146, fem_linear_elliptic_solver.h:36); numerical failure of the solve sets
+// success() = false without throwing (fem_linear_elliptic_solver.h:42-45); after solve() with Dirichlet data stiff() is the
+// row-zeroed matrix and force() carries the boundary values (fem_solver_base.h:148-152).
+// Differences: the forcing type F is DMatrix<double> (values at quadrature nodes, pde.h:49) or ScalarField<N> (a callable,
+// evaluated on the host at the quadrature nodes the device computes); sparse matrices are CSR (SpMatrix below), the solve
+// is Jacobi-PCG / BiCGStab instead of SparseLU (options in PDE::solver_options()).
+#ifndef FDAPDE_AMD_PDE_H
+#define FDAPDE_AMD_PDE_H
+
+#include <array>
+#include <cstdint>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../fdapde_hip.h"
+
+namespace fdapde {
+namespace amd {
+
+// ---- containers (column-major dense, CSR sparse): the layouts of the reference's DMatrix / SpMatrix getters -----------
+template <typename T> class DMatrix {
+   public:
+    DMatrix() = default;
+    DMatrix(int64_t rows, int64_t cols, T v = T()) : rows_(rows), cols_(cols), data_((size_t)(rows * cols), v) { }
+    static DMatrix Zero(int64_t rows, int64_t cols) { return DMatrix(rows, cols, T(0)); }
+    void resize(int64_t rows, int64_t cols) { rows_ = rows, cols_ = cols, data_.assign((size_t)(rows * cols), T()); }
+    int64_t rows() const { return rows_; }
+    int64_t cols() const { return cols_; }
+    int64_t size() const { return rows_ * cols_; }
+    T& operator()(int64_t i, int64_t j = 0) { return data_[(size_t)(j * rows_ + i)]; }
+    const T& operator()(int64_t i, int64_t j = 0) const { return data_[(size_t)(j * rows_ + i)]; }
+    T* data() { return data_.data(); }
+    const T* data() const { return data_.data(); }
+    std::array<T, 3> row3(int64_t i) const {   // row i padded to 3 entries (points in R^2 / R^3)
+        std::array<T, 3> r {};
+        for (int64_t j = 0; j < cols_ && j < 3; ++j) r[(size_t)j] = (*this)(i, j);
+        return r;
+    }
+   private:
+    int64_t rows_ = 0, cols_ = 0;
+    std::vector<T> data_;
+};
+template <typename T> using DVector = DMatrix<T>;
+template <typename T> bool is_empty(const DMatrix<T>& m) { return m.size() == 0; }   // utils/symbols.h:177
+
+template <typename T> struct SpMatrix {   // CSR, sorted columns, int32 indices
+    int64_t n_rows = 0, n_cols = 0;
+    std::vector<int32_t> rowptr, colidx;
+    std::vector<T> values;
+    int64_t rows() const { return n_rows; }
+    int64_t cols() const { return n_cols; }
+    int64_t nonZeros() const { return (int64_t)values.size(); }
+    T coeff(int64_t i, int64_t j) const {
+        for (int32_t k = rowptr[(size_t)i]; k < rowptr[(size_t)i + 1]; ++k)
+            if (colidx[(size_t)k] == j) return values[(size_t)k];
+        return T(0);
+    }
+    DMatrix<T> operator*(const DMatrix<T>& x) const {   // host-side product for checks such as sum(M * err^2)
+        DMatrix<T> y(n_rows, x.cols(), T(0));
+        for (int64_t c = 0; c < x.cols(); ++c)
+            for (int64_t i = 0; i < n_rows; ++i) {
+                T s = 0;
+                for (int32_t k = rowptr[(size_t)i]; k < rowptr[(size_t)i + 1]; ++k) s += values[(size_t)k] * x(colidx[(size_t)k], c);
+                y(i, c) = s;
+            }
+        return y;
+    }
+};
+
+// ---- tags ------------------------------------------------------------------------------------------------------------
+struct FEM_HIP { };   // strategy tag: finite elements assembled and solved on MI355X
+template <int R> struct fem_order { static constexpr int value = R; };
+
+// ---- domain ----------------------------------------------------------------------------------------------------------
+template <int M, int N> class Triangulation {
+   public:
+    static constexpr int local_dim = M, embed_dim = N, n_nodes_per_cell = M + 1;
+    Triangulation() = default;
+    // nodes: n_nodes x N; cells: n_cells x (M+1), 0-based node ids; boundary: n_nodes x 1 (0/1)
+    Triangulation(const DMatrix<double>& nodes, const DMatrix<int>& cells, const DMatrix<int>& boundary) :
+        nodes_(nodes), cells_(cells), boundary_(boundary) {
+        static_assert((M == 2 && N == 2) || (M == 3 && N == 3), "only Triangulation<2,2> and <3,3> are on the accelerated path");
+        if (nodes.cols() != N || cells.cols() != M + 1 || boundary.rows() != nodes.rows())
+            throw std::runtime_error("Triangulation: inconsistent matrix shapes");
+    }
+    const DMatrix<double>& nodes() const { return nodes_; }
+    const DMatrix<int>& cells() const { return cells_; }
+    const DMatrix<int>& boundary_nodes() const { return boundary_; }
+    int64_t n_nodes() const { return nodes_.rows(); }
+    int64_t n_cells() const { return cells_.rows(); }
+   private:
+    DMatrix<double> nodes_;
+    DMatrix<int> cells_, boundary_;
+};
+
+// ---- forcing as a callable (reference: ScalarField<N, F>, fields/scalar_field.h) -----------------------------------------
+template <int N> struct ScalarField {
+    std::function<double(const std::array<double, N>&)> f;
+    ScalarField() = default;
+    template <typename Fn> ScalarField(Fn fn) : f(fn) { }
+    double operator()(const std::array<double, N>& x) const { return f(x); }
+};
+
+// ---- operator expressions ---------------------------------------------------------------------------------------------
+// The reference's expression tree collapses to a left-to-right sum of scaled leaves (see include/fdapde_hip.h).
+class DifferentialExpr {
+   public:
+    struct Leaf {
+        fdapde_term term {};
+        std::vector<double> data;   // space-varying coefficient, row-major (nq*n_cells) x width
+    };
+    DifferentialExpr() = default;
+    explicit DifferentialExpr(Leaf l) { leaves_.push_back(std::move(l)); }
+    DifferentialExpr operator-() const {
+        DifferentialExpr r(*this);
+        for (auto& l : r.leaves_) l.term.coef = -l.term.coef;
+        return r;
+    }
+    friend DifferentialExpr operator+(const DifferentialExpr& a, const DifferentialExpr& b) {
+        DifferentialExpr r(a);
+        r.leaves_.insert(r.leaves_.end(), b.leaves_.begin(), b.leaves_.end());
+        return r;
+    }
+    friend DifferentialExpr operator-(const DifferentialExpr& a, const DifferentialExpr& b) { return a + (-b); }
+    friend DifferentialExpr operator*(double c, const DifferentialExpr& a) {
+        DifferentialExpr r(a);
+        for (auto& l : r.leaves_) l.term.coef *= c;
+        return r;
+    }
+    // is_symmetric = AND over leaves, advection is the only non-symmetric one (differential_expressions.h:70-73)
+    bool is_symmetric() const {
+        for (const auto& l : leaves_)
+            if (l.term.kind == FDAPDE_ADVECTION) return false;
+        return true;
+    }
+    bool is_space_varying() const {
+        for (const auto& l : leaves_)
+            if (l.term.space_varying) return true;
+        return false;
+    }
+    const std::vector<Leaf>& leaves() const { return leaves_; }
+    std::vector<fdapde_term> c_terms() const {   // pointers into this object's storage
+        std::vector<fdapde_term> t;
+        for (const auto& l : leaves_) {
+            fdapde_term x = l.term;
+            x.data = l.term.space_varying ? l.data.data() : nullptr;
+            t.push_back(x);
+        }
+        return t;
+    }
+   private:
+    std::vector<Leaf> leaves_;
+};
+namespace detail {
+inline DifferentialExpr leaf(int kind, const double* cst, int n_cst, const DMatrix<double>* data) {
+    DifferentialExpr::Leaf l;
+    l.term.kind = kind, l.term.coef = 1.0, l.term.space_varying = data ? 1 : 0;
+    for (int i = 0; i < n_cst && i < 9; ++i) l.term.cst[i] = cst[i];
+    if (data) {   // DMatrix is column-major; the ABI wants row-major rows = nq*cell + q
+        l.data.resize((size_t)data->size());
+        for (int64_t r = 0; r < data->rows(); ++r)
+            for (int64_t c = 0; c < data->cols(); ++c) l.data[(size_t)(r * data->cols() + c)] = (*data)(r, c);
+    }
+    return DifferentialExpr(std::move(l));
+}
+}   // namespace detail
+template <typename Tag = FEM_HIP> DifferentialExpr laplacian() { return detail::leaf(FDAPDE_LAPLACIAN, nullptr, 0, nullptr); }
+template <typename Tag = FEM_HIP> DifferentialExpr dt() { return detail::leaf(FDAPDE_DT, nullptr, 0, nullptr); }
+template <typename Tag = FEM_HIP> DifferentialExpr reaction(double c) { return detail::leaf(FDAPDE_REACTION, &c, 1, nullptr); }
+template <typename Tag = FEM_HIP, size_t N> DifferentialExpr advection(const std::array<double, N>& b) {
+    return detail::leaf(FDAPDE_ADVECTION, b.data(), (int)N, nullptr);
+}
+// K row-major N x N
+template <typename Tag = FEM_HIP, size_t NN> DifferentialExpr diffusion(const std::array<double, NN>& K) {
+    return detail::leaf(FDAPDE_DIFFUSION, K.data(), (int)NN, nullptr);
+}
+// space-varying coefficients: one row per quadrature node, row nq*cell + q (Discretized*Field::forward, integrator.h:98-101)
+template <typename Tag = FEM_HIP> DifferentialExpr reaction(const DMatrix<double>& c_q) { return detail::leaf(FDAPDE_REACTION, nullptr, 0, &c_q); }
+template <typename Tag = FEM_HIP> DifferentialExpr advection(const DMatrix<double>& b_q) { return detail::leaf(FDAPDE_ADVECTION, nullptr, 0, &b_q); }
+template <typename Tag = FEM_HIP> DifferentialExpr diffusion(const DMatrix<double>& K_q) { return detail::leaf(FDAPDE_DIFFUSION, nullptr, 0, &K_q); }
+
+// ---- PDE ---------------------------------------------------------------------------------------------------------------
+template <typename D, typename E, typename F, typename S, typename... Ts> class PDE;
+
+template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_HIP, fem_order<R>> {
+   public:
+    using SpaceDomainType = D;
+    using OperatorType = DifferentialExpr;
+    using ForcingType = F;
+    static constexpr int M = D::local_dim, N = D::embed_dim;
+    static_assert(std::is_same_v<F, DMatrix<double>> || std::is_same_v<F, ScalarField<N>>,
+                  "forcing is DMatrix<double> (values at quadrature nodes) or ScalarField<N> (pde.h:49-51)");
+    static_assert(R == 1 || R == 2, "LagrangianBasis::enumerate_dofs requires Order <= 2");
+
+    explicit PDE(const D& domain, int device = 0) : domain_(domain) { open(device); }
+    PDE(const D& domain, OperatorType diff_op, int device = 0) : domain_(domain), diff_op_(std::move(diff_op)) { open(device); }
+    PDE(const D& domain, OperatorType diff_op, const ForcingType& forcing, int device = 0) :
+        domain_(domain), diff_op_(std::move(diff_op)), forcing_data_(forcing) {
+        open(device);
+    }
+    PDE(const PDE&) = delete;
+    PDE& operator=(const PDE&) = delete;
+    ~PDE() { fdapde_ctx_destroy(ctx_); }
+
+    // setters (pde.h:74-77)
+    void set_forcing(const ForcingType& forcing_data) { forcing_data_ = forcing_data; }
+    void set_differential_operator(OperatorType diff_op) { diff_op_ = std::move(diff_op); }
+    void set_dirichlet_bc(const DMatrix<double>& data) { boundary_data_ = data; }
+    // getters (pde.h:79-100)
+    const D& domain() const { return domain_; }
+    OperatorType differential_operator() const { return diff_op_; }
+    const ForcingType& forcing_data() const { return forcing_data_; }
+    const DMatrix<double>& boundary_data() const { return boundary_data_; }
+    int n_dofs() const { return (int)n_dofs_; }
+    const DMatrix<double>& solution() const { return solution_; }
+    const DMatrix<double>& force() const { return force_; }
+    const SpMatrix<double>& stiff() const { return stiff_; }
+    const SpMatrix<double>& mass() const { return mass_; }
+    const DMatrix<int>& dofs() const { return dofs_; }
+    const DMatrix<int>& boundary_dofs() const { return boundary_dofs_; }
+    DMatrix<double> dof_coords() const { return dof_coords_; }
+    DMatrix<double> quadrature_nodes() const {
+        DMatrix<double> q((int64_t)nq_ * domain_.n_cells(), N);
+        check(fdapde_quadrature_nodes(ctx_, q.data()));
+        return q;
+    }
+    bool is_init() const { return is_init_; }
+    bool success() const { return success_; }
+    fdapde_options& solver_options() { return opt_; }
+    const fdapde_info& info() const { return info_; }
+
+    // FEMSolverBase::init (fem_solver_base.h:104-139)
+    void init() {
+        auto terms = diff_op_.c_terms();
+        if (terms.empty()) throw std::runtime_error("PDE::init: no differential operator set");
+        check(fdapde_set_operator(ctx_, (int32_t)terms.size(), terms.data()));
+        const int64_t rows = (int64_t)nq_ * domain_.n_cells();
+        if constexpr (std::is_same_v<F, DMatrix<double>>) {
+            if (is_empty(forcing_data_)) {
+                check(fdapde_set_forcing(ctx_, nullptr, 0));
+            } else {
+                if (forcing_data_.rows() != rows) throw std::runtime_error("forcing data must have nq * n_cells rows");
+                check(fdapde_set_forcing(ctx_, forcing_data_.data(), (int32_t)forcing_data_.cols()));
+            }
+        } else {   // callable: evaluate at the mapped quadrature nodes (integrator.h:77-81)
+            DMatrix<double> q = quadrature_nodes(), f(rows, 1);
+            for (int64_t i = 0; i < rows; ++i) {
+                std::array<double, N> x;
+                for (int d = 0; d < N; ++d) x[(size_t)d] = q(i, d);
+                f(i) = forcing_data_(x);
+            }
+            check(fdapde_set_forcing(ctx_, f.data(), 1));
+        }
+        check(fdapde_init(ctx_, &opt_));
+        fetch_matrix(FDAPDE_MAT_STIFF, stiff_);
+        fetch_matrix(FDAPDE_MAT_MASS, mass_);
+        const int cols = std::is_same_v<F, DMatrix<double>> && !is_empty_forcing() ? (int)forcing_cols() : 1;
+        force_.resize(n_dofs_ * cols, 1);
+        check(fdapde_force(ctx_, force_.data()));
+        is_init_ = true, success_ = false;
+    }
+    // PDE::solve (pde.h:102-105): set_dirichlet_bc if boundary data is set, then the linear solve
+    void solve() {
+        if (!is_init_) throw std::runtime_error("solver must be initialized first!");
+        if (!is_empty(boundary_data_)) {
+            if (boundary_data_.rows() != n_dofs_) throw std::runtime_error("dirichlet data must have n_dofs rows");
+            check(fdapde_set_dirichlet(ctx_, boundary_data_.data()));
+        } else {
+            check(fdapde_set_dirichlet(ctx_, nullptr));
+        }
+        const int rc = fdapde_solve(ctx_, &opt_, &info_);
+        if (rc == FDAPDE_ENOCONV) {   // reference: success = false, no throw
+            success_ = false;
+            return;
+        }
+        check(rc);
+        solution_.resize(n_dofs_, 1);
+        check(fdapde_solution(ctx_, solution_.data()));
+        check(fdapde_matrix_values(ctx_, FDAPDE_MAT_STIFF, stiff_.values.data()));   // row-zeroed if Dirichlet data was applied
+        check(fdapde_force(ctx_, force_.data()));
+        success_ = true;
+    }
+
+   private:
+    bool is_empty_forcing() const {
+        if constexpr (std::is_same_v<F, DMatrix<double>>) return is_empty(forcing_data_);
+        return false;
+    }
+    int64_t forcing_cols() const {
+        if constexpr (std::is_same_v<F, DMatrix<double>>) return forcing_data_.cols();
+        return 1;
+    }
+    void check(int rc) const {
+        if (rc == FDAPDE_OK) return;
+        const std::string msg = ctx_ ? fdapde_last_error(ctx_) : "";
+        throw std::runtime_error(msg.empty() ? fdapde_status_string(rc) : msg);
+    }
+    void open(int device) {
+        const int rc = fdapde_ctx_create(device, &ctx_);
+        if (rc != FDAPDE_OK) throw std::runtime_error(std::string("fdapde_ctx_create: ") + fdapde_status_string(rc));
+        // hand the mesh over in the ABI's layouts (nodes column-major, cells row-major, boundary bytes)
+        const int64_t nn = domain_.n_nodes(), nc = domain_.n_cells();
+        std::vector<int32_t> cells((size_t)(nc * (M + 1)));
+        for (int64_t c = 0; c < nc; ++c)
+            for (int v = 0; v <= M; ++v) cells[(size_t)(c * (M + 1) + v)] = domain_.cells()(c, v);
+        std::vector<uint8_t> bnd((size_t)nn);
+        for (int64_t i = 0; i < nn; ++i) bnd[(size_t)i] = domain_.boundary_nodes()(i, 0) ? 1 : 0;
+        check(fdapde_mesh_upload(ctx_, M, N, nn, domain_.nodes().data(), nc, cells.data(), bnd.data()));
+        check(fdapde_dofs_build(ctx_, R, &n_dofs_));
+        int64_t nnz = 0, n_edges = 0;
+        check(fdapde_sizes(ctx_, &n_dofs_, &nnz, &nb_, &nq_, &n_edges));
+        std::vector<int32_t> dofs((size_t)(nc * nb_));
+        std::vector<uint8_t> bd((size_t)n_dofs_);
+        dof_coords_.resize(n_dofs_, N);
+        check(fdapde_dofs_get(ctx_, dofs.data(), bd.data(), dof_coords_.data()));
+        dofs_.resize(nc, nb_), boundary_dofs_.resize(n_dofs_, 1);
+        for (int64_t c = 0; c < nc; ++c)
+            for (int j = 0; j < nb_; ++j) dofs_(c, j) = dofs[(size_t)(c * nb_ + j)];
+        for (int64_t i = 0; i < n_dofs_; ++i) boundary_dofs_(i) = bd[(size_t)i];
+        for (SpMatrix<double>* m : {&stiff_, &mass_}) {
+            m->n_rows = m->n_cols = n_dofs_;
+            m->rowptr.resize((size_t)n_dofs_ + 1), m->colidx.resize((size_t)nnz), m->values.assign((size_t)nnz, 0.0);
+            check(fdapde_pattern_get(ctx_, m->rowptr.data(), m->colidx.data()));
+        }
+    }
+    void fetch_matrix(int which, SpMatrix<double>& m) { check(fdapde_matrix_values(ctx_, which, m.values.data())); }
+
+    const D& domain_;                 // must outlive the PDE (pde.h:107)
+    OperatorType diff_op_;
+    ForcingType forcing_data_ {};
+    DMatrix<double> boundary_data_;
+    fdapde_ctx* ctx_ = nullptr;
+    fdapde_options opt_ {FDAPDE_SOLVER_AUTO, 0, 1e-10, FDAPDE_ASSEMBLY_ROWS, 0, 0};
+    fdapde_info info_ {};
+    int64_t n_dofs_ = 0;
+    int32_t nb_ = 0, nq_ = 0;
+    bool is_init_ = false, success_ = false;
+    DMatrix<double> solution_, force_, dof_coords_;
+    DMatrix<int> dofs_, boundary_dofs_;
+    SpMatrix<double> stiff_, mass_;
+};
+
+}   // namespace amd
+}   // namespace fdapde
+
+#if __has_include(<Eigen/Sparse>)
+#include <Eigen/Sparse>
+namespace fdapde {
+namespace amd {
+// the reference's SpMatrix<double> (column-major Eigen::SparseMatrix, utils/symbols.h:33) from the CSR the device exports
+inline Eigen::SparseMatrix<double> to_eigen(const SpMatrix<double>& m) {
+    Eigen::Map<const Eigen::SparseMatrix<double, Eigen::RowMajor, int32_t>> view(
+      m.n_rows, m.n_cols, m.nonZeros(), m.rowptr.data(), m.colidx.data(), m.values.data());
+    return Eigen::SparseMatrix<double>(view);
+}
+}   // namespace amd
+}   // namespace fdapde
+#endif
+#endif   // FDAPDE_AMD_PDE_H

@@ -44,6 +44,7 @@ SYMBOLS = [
     "fdapde_pattern_get", "fdapde_quadrature_nodes", "fdapde_set_operator", "fdapde_set_forcing", "fdapde_set_dirichlet",
     "fdapde_init", "fdapde_assemble_operator", "fdapde_solve", "fdapde_matrix_values", "fdapde_force", "fdapde_solution",
     "fdapde_info_get", "fdapde_spmv", "fdapde_bench_spmv", "fdapde_tune", "fdapde_stream", "fdapde_synchronize",
+    "fdapde_comm_unique_id", "fdapde_comm_init", "fdapde_halo_setup",
 ]
 
 _lib = None
@@ -294,6 +295,25 @@ class Context:
         ms, by = C.c_double(), C.c_double()
         self._check(self.lib.fdapde_bench_spmv(self._ctx, reps, C.byref(ms), C.byref(by)))
         return ms.value, by.value
+
+    # ---- multi-GPU
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        rc = load().fdapde_comm_unique_id(buf)
+        if rc != OK:
+            raise FdapdeError(rc, "fdapde_comm_unique_id failed (RCCL not loadable?)")
+        return buf.raw
+
+    def comm_init(self, world, rank, unique_id: bytes):
+        self._check(self.lib.fdapde_comm_init(self._ctx, int(world), int(rank), C.c_char_p(unique_id)))
+
+    def halo_setup(self, n_if_global, local_dof, if_index, owned):
+        local_dof = np.ascontiguousarray(local_dof, dtype=np.int32)
+        if_index = np.ascontiguousarray(if_index, dtype=np.int32)
+        owned = np.ascontiguousarray(owned, dtype=np.uint8)
+        self._check(self.lib.fdapde_halo_setup(self._ctx, C.c_int64(int(n_if_global)), C.c_int64(local_dof.size), _ip(local_dof),
+                                               _ip(if_index), _bp(owned)))
 
     def tune(self, key, value):
         self._check(self.lib.fdapde_tune(self._ctx, key.encode(), int(value)))

@@ -5,7 +5,9 @@
 #include <cstring>
 #include <new>
 
+#include <dlfcn.h>
 #include <hip/hip_ext.h>
+#include <rccl/rccl.h>
 
 #include "kernels.h"
 
@@ -41,6 +43,38 @@ template <typename T> struct DBuf {
         p = nullptr, n = 0;
     }
 };
+
+// RCCL is loaded on first use (dlopen) so that single-GPU users and CPU-only boxes never need it
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool load(std::string& err) {
+        if (handle) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (handle) break;
+        }
+        if (!handle) {
+            err = std::string("cannot load librccl: ") + dlerror();
+            return false;
+        }
+        GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(handle, "ncclGetUniqueId"));
+        CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(handle, "ncclCommInitRank"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(handle, "ncclCommDestroy"));
+        AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(handle, "ncclAllReduce"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(handle, "ncclGetErrorString"));
+        if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GetErrorString) {
+            err = "librccl lacks a required symbol";
+            return false;
+        }
+        return true;
+    }
+};
+RcclApi g_rccl;
 
 struct HostTerm {
     fdapde_term t;
@@ -86,6 +120,14 @@ struct fdapde_ctx {
                             // (FDAPDE_SPMV=team); 1: stream form (FDAPDE_SPMV=stream) -- kept for A/B measurements
     int spmv_team = 16, spmv_unroll = 4, spmv_ablate = 0;
     int lds_limit = 64 * 1024;
+    // multi-GPU (element partition): RCCL communicator + interface maps
+    ncclComm_t comm = nullptr;
+    int world = 1, rank = 0;
+    bool halo_ready = false;
+    int64_t n_if = 0, n_loc_if = 0;          // global / local interface DOF counts
+    DBuf<int32_t> halo_dof, halo_pos;        // local interface DOF (internal id) -> slot in the global interface vector
+    DBuf<uint8_t> owned;                     // internal DOF order: 1 = this rank counts the DOF in global dot products
+    DBuf<double> hbuf, sbuf;                 // [n_if + 2] packed interface values + fused dot partials; [4] scalars
 };
 
 namespace {
@@ -356,6 +398,34 @@ void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, 
 
 inline unsigned g1(int64_t n, int per = 256) { return (unsigned)((n + per - 1) / per); }
 
+#define RCCLCHK(ctx, expr)                                                                   \
+    do {                                                                                     \
+        ncclResult_t r__ = (expr);                                                           \
+        if (r__ != ncclSuccess) {                                                            \
+            (ctx)->err = std::string(#expr) + ": " + g_rccl.GetErrorString(r__);             \
+            return FDAPDE_ERCCL;                                                             \
+        }                                                                                    \
+    } while (0)
+
+int allreduce_sum(fdapde_ctx* c, double* buf, size_t count) {
+    RCCLCHK(c, g_rccl.AllReduce(buf, buf, count, ncclFloat64, ncclSum, c->comm, c->stream));
+    return FDAPDE_OK;
+}
+// v (internal DOF order, sub-assembled) -> interface entries summed over the ranks sharing them; optionally carries the
+// two fused dot partials of the SpMV (part_a, stride 2) through the same all-reduce: they land in hbuf[n_if], [n_if + 1]
+int halo_sum(fdapde_ctx* c, double* v, const double* part, int np) {
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipMemsetAsync(c->hbuf.p, 0, sizeof(double) * (size_t)(c->n_if + 2), st));
+    const unsigned grid = g1(c->n_loc_if > 0 ? c->n_loc_if : 1);
+    hipLaunchKernelGGL(k_halo_pack, dim3(grid), dim3(256), 0, st, c->n_loc_if, c->halo_dof.p, c->halo_pos.p, v, c->hbuf.p, c->n_if,
+                       part, np);
+    if (int rc = allreduce_sum(c, c->hbuf.p, (size_t)(c->n_if + 2))) return rc;
+    if (c->n_loc_if > 0)
+        hipLaunchKernelGGL(k_halo_unpack, dim3(grid), dim3(256), 0, st, c->n_loc_if, c->halo_dof.p, c->halo_pos.p, c->hbuf.p, v);
+    HIPCHK(c, hipGetLastError());
+    return FDAPDE_OK;
+}
+
 }  // namespace
 
 // =================================================================================================================
@@ -422,6 +492,8 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
             b->release();
         for (auto& b : c->coef) b.release();
         c->slotw.release(), c->sl_off.release(), c->bnd.release(), c->tables.release();
+        c->halo_dof.release(), c->halo_pos.release(), c->owned.release(), c->hbuf.release(), c->sbuf.release();
+        if (c->comm) (void)g_rccl.CommDestroy(c->comm);
         if (c->h_ctl) (void)hipHostFree(c->h_ctl);
         if (c->h_sc) (void)hipHostFree(c->h_sc);
         (void)hipEventDestroy(c->ev0), (void)hipEventDestroy(c->ev1);
@@ -448,6 +520,7 @@ int fdapde_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs) {
     c->space_ready = c->dev_ready = c->colour_ready = false;
     c->assembled[0] = c->assembled[1] = c->force_ready = c->solved = c->dirichlet_applied = false;
     c->op.clear(), c->fq_i.clear(), c->fq_cols = 0, c->g_i.clear(), c->have_g = false;
+    c->halo_ready = false;
     int rc = host_build_space(c->hs, order, c->err);
     if (rc) return rc;
     rc = build_basis_tables(c->hs.M, order, &c->tb);
@@ -648,23 +721,55 @@ int fdapde_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     const int use_bnd = c->have_g ? 1 : 0;
     const double* A = c->vals[FDAPDE_MAT_STIFF].p;
 
+    // multi-GPU: this rank holds the sub-assembled operator / forcing of its own cells
+    const bool dist = c->comm != nullptr && c->halo_ready;
+    const uint8_t* owned = dist ? c->owned.p : nullptr;
+    const double* fvec = c->force.p;
     HIPCHK(c, hipEventRecord(c->ev0, st));
     // Dirichlet reduction + Jacobi scaling (see DESIGN.md "Dirichlet handling")
     HIPCHK(c, hipMemsetAsync(c->ctl.p, 0, 4 * sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_jacobi_scale, dim3(g1(n)), dim3(256), 0, st, n, c->diag.p, A, c->bnd.p, use_bnd, c->scale.p, c->ctl.p + 3);
+    if (dist) {   // the diagonal and the forcing vector are sums over the ranks sharing a DOF
+        hipLaunchKernelGGL(k_diag_extract, dim3(g1(n)), dim3(256), 0, st, n, c->diag.p, A, c->tmp_i.p);
+        if (int rc = halo_sum(c, c->tmp_i.p, nullptr, 0)) return rc;
+        hipLaunchKernelGGL(k_jacobi_scale_from_diag, dim3(g1(n)), dim3(256), 0, st, n, c->tmp_i.p, c->bnd.p, use_bnd, c->scale.p,
+                           c->ctl.p + 3);
+        HIPCHK(c, hipMemcpyAsync(c->tmp_e.p, c->force.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+        if (int rc = halo_sum(c, c->tmp_e.p, nullptr, 0)) return rc;
+        fvec = c->tmp_e.p;
+    } else {
+        hipLaunchKernelGGL(k_jacobi_scale, dim3(g1(n)), dim3(256), 0, st, n, c->diag.p, A, c->bnd.p, use_bnd, c->scale.p, c->ctl.p + 3);
+    }
     hipLaunchKernelGGL(k_scale_matrix, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, A, c->scale.p, c->sval.p);
     hipLaunchKernelGGL(k_lift, dim3(g1(n)), dim3(256), 0, st, n, c->bnd.p, c->g.p, use_bnd, c->gt.p);
     launch_spmv(c, A, c->gt.p, c->y.p, nullptr, nullptr, nullptr);   // y = A g~
+    if (dist) {
+        if (int rc = halo_sum(c, c->y.p, nullptr, 0)) return rc;
+    }
     HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
+    if (dist) {   // "positive diagonal" (CG admissible) must be ONE decision for all ranks: sum the per-rank flags
+        c->h_sc[8] = (double)c->h_ctl[3];
+        HIPCHK(c, hipMemcpyAsync(c->sbuf.p + 1, c->h_sc + 8, sizeof(double), hipMemcpyHostToDevice, st));
+        if (int rc = allreduce_sum(c, c->sbuf.p + 1, 1)) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->h_sc + 8, c->sbuf.p + 1, sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        c->h_ctl[3] = c->h_sc[8] != 0.0 ? 1 : 0;
+    }
     const bool diag_positive = c->h_ctl[3] == 0;
     if (method == FDAPDE_SOLVER_AUTO) method = (c->op_symmetric && diag_positive) ? FDAPDE_SOLVER_CG : FDAPDE_SOLVER_BICGSTAB;
     if (method == FDAPDE_SOLVER_CG && !diag_positive)
         return fail(c, FDAPDE_ENOCONV, "CG needs a positive diagonal (operator not SPD?); use BiCGStab");
     const bool bicg = method == FDAPDE_SOLVER_BICGSTAB;
-    hipLaunchKernelGGL(k_krylov_init, dim3(c->vec_grid), dim3(256), 0, st, n, c->force.p, c->y.p, c->scale.p, c->x.p, c->r.p,
-                       c->p.p, bicg ? c->r0.p : (double*)nullptr, c->part_b.p);
-    hipLaunchKernelGGL(k_krylov_init_fin, dim3(1), dim3(256), 0, st, c->part_b.p, c->vec_grid, c->sc.p, c->ctl.p);
+    if (dist && bicg) return fail(c, FDAPDE_EUNSUPPORTED, "the element-partitioned solve implements CG only (BiCGStab: single GPU)");
+    hipLaunchKernelGGL(k_krylov_init, dim3(c->vec_grid), dim3(256), 0, st, n, fvec, c->y.p, c->scale.p, c->x.p, c->r.p,
+                       c->p.p, bicg ? c->r0.p : (double*)nullptr, c->part_b.p, owned);
+    if (dist) {
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, c->part_b.p, c->vec_grid, c->sbuf.p);
+        if (int rc = allreduce_sum(c, c->sbuf.p, 1)) return rc;
+        hipLaunchKernelGGL(k_krylov_init_fin, dim3(1), dim3(256), 0, st, c->sbuf.p, 1, c->sc.p, c->ctl.p);
+    } else {
+        hipLaunchKernelGGL(k_krylov_init_fin, dim3(1), dim3(256), 0, st, c->part_b.p, c->vec_grid, c->sc.p, c->ctl.p);
+    }
     HIPCHK(c, hipGetLastError());
     const double tol2 = rtol * rtol;
     int n_timed = opt ? opt->time_spmv : 0;
@@ -686,10 +791,22 @@ int fdapde_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
                 launch_spmv(c, c->sval.p, c->p.p, c->y.p, c->p.p, c->part_a.p, c->ctl.p,
                             tm ? c->ev_spmv[2 * launched] : nullptr, tm ? c->ev_spmv[2 * launched + 1] : nullptr);
                 if (tm) ++timed;
-                hipLaunchKernelGGL(k_cg_update_xr, dim3(c->cg_grid), dim3(256), 0, st, n, c->p.p, c->y.p, c->x.p, c->r.p,
-                                   c->part_a.p, c->spmv_grid, c->part_b.p, c->sc.p, parity, c->ctl.p);
-                hipLaunchKernelGGL(k_cg_update_p, dim3(c->cg_grid), dim3(256), 0, st, n, c->r.p, c->p.p, c->part_b.p,
-                                   c->cg_grid, c->sc.p, parity, tol2, c->ctl.p);
+                if (!dist) {
+                    hipLaunchKernelGGL(k_cg_update_xr, dim3(c->cg_grid), dim3(256), 0, st, n, c->p.p, c->y.p, c->x.p, c->r.p,
+                                       c->part_a.p, c->spmv_grid, c->part_b.p, c->sc.p, parity, c->ctl.p, owned);
+                    hipLaunchKernelGGL(k_cg_update_p, dim3(c->cg_grid), dim3(256), 0, st, n, c->r.p, c->p.p, c->part_b.p,
+                                       c->cg_grid, c->sc.p, parity, tol2, c->ctl.p);
+                } else {
+                    // one all-reduce carries the interface entries of A_p p and the rank's p.Ap partial; a second one
+                    // (a single double) carries r.r.  Every rank takes the same stop decision from the same numbers.
+                    if (int rc = halo_sum(c, c->y.p, c->part_a.p, c->spmv_grid)) return rc;
+                    hipLaunchKernelGGL(k_cg_update_xr, dim3(c->cg_grid), dim3(256), 0, st, n, c->p.p, c->y.p, c->x.p, c->r.p,
+                                       c->hbuf.p + c->n_if, 1, c->part_b.p, c->sc.p, parity, c->ctl.p, owned);
+                    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, c->part_b.p, c->cg_grid, c->sbuf.p);
+                    if (int rc = allreduce_sum(c, c->sbuf.p, 1)) return rc;
+                    hipLaunchKernelGGL(k_cg_update_p, dim3(c->cg_grid), dim3(256), 0, st, n, c->r.p, c->p.p, c->sbuf.p, 1,
+                                       c->sc.p, parity, tol2, c->ctl.p);
+                }
             } else {
                 hipLaunchKernelGGL(k_bicg_p, dim3(c->vec_grid), dim3(256), 0, st, n, c->r.p, c->y.p, c->p.p, c->part_b.p,
                                    c->vec_grid, c->sc.p, launched == 0 ? 1 : 0, c->ctl.p);
@@ -875,6 +992,55 @@ int fdapde_bench_spmv(fdapde_ctx* c, int32_t reps, double* avg_ms, double* algor
     }
     if (avg_ms) *avg_ms = (double)ms / reps;
     if (algorithmic_bytes) *algorithmic_bytes = 12.0 * (double)hs.nnz + 4.0 * (double)(hs.n_dofs + 1) + 16.0 * (double)hs.n_dofs;
+    return FDAPDE_OK;
+}
+
+int fdapde_comm_unique_id(void* out128) {
+    if (!out128) return FDAPDE_EINVAL;
+    std::string err;
+    if (!g_rccl.load(err)) return FDAPDE_ERCCL;
+    ncclUniqueId id;
+    if (g_rccl.GetUniqueId(&id) != ncclSuccess) return FDAPDE_ERCCL;
+    std::memcpy(out128, &id, sizeof id);
+    return FDAPDE_OK;
+}
+
+int fdapde_comm_init(fdapde_ctx* c, int32_t world, int32_t rank, const void* unique_id128) {
+    if (!c || !unique_id128 || world < 1 || rank < 0 || rank >= world) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (!g_rccl.load(c->err)) return FDAPDE_ERCCL;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->comm) (void)g_rccl.CommDestroy(c->comm), c->comm = nullptr;
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id128, sizeof id);
+    RCCLCHK(c, g_rccl.CommInitRank(&c->comm, world, id, rank));
+    c->world = world, c->rank = rank;
+    return FDAPDE_OK;
+}
+
+int fdapde_halo_setup(fdapde_ctx* c, int64_t n_if_global, int64_t n_if_local, const int32_t* local_dof, const int32_t* if_index,
+                      const uint8_t* owned) {
+    if (!c || n_if_global < 0 || n_if_local < 0 || (n_if_local > 0 && (!local_dof || !if_index)) || !owned) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (!c->dev_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
+    if (!c->comm) return fail(c, FDAPDE_ENOTINIT, "call fdapde_comm_init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const HostSpace& hs = c->hs;
+    std::vector<int32_t> dof_i((size_t)n_if_local), pos((size_t)n_if_local);
+    for (int64_t k = 0; k < n_if_local; ++k) {
+        if (local_dof[k] < 0 || local_dof[k] >= hs.n_dofs || if_index[k] < 0 || if_index[k] >= n_if_global)
+            return fail(c, FDAPDE_EINVAL, "interface map entry out of range");
+        dof_i[(size_t)k] = hs.dof_e2i[(size_t)local_dof[k]], pos[(size_t)k] = if_index[k];
+    }
+    std::vector<uint8_t> own_i((size_t)hs.n_dofs);
+    for (int64_t i = 0; i < hs.n_dofs; ++i) own_i[(size_t)i] = owned[hs.dof_i2e[(size_t)i]] ? 1 : 0;
+    HIPCHK(c, c->halo_dof.upload(dof_i.data(), dof_i.size(), c->stream));
+    HIPCHK(c, c->halo_pos.upload(pos.data(), pos.size(), c->stream));
+    HIPCHK(c, c->owned.upload(own_i.data(), own_i.size(), c->stream));
+    HIPCHK(c, c->hbuf.alloc((size_t)n_if_global + 2));
+    HIPCHK(c, c->sbuf.alloc(4));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->n_if = n_if_global, c->n_loc_if = n_if_local, c->halo_ready = true;
     return FDAPDE_OK;
 }
 

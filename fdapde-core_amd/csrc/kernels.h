@@ -719,14 +719,15 @@ __global__ void k_lift(int64_t n, const uint8_t* bnd, const double* g, int use_b
 }
 // r = scale * (f - A gt)  (y holds A gt), x = 0, p = r; partial[block] = sum r^2
 __global__ __launch_bounds__(256) void k_krylov_init(int64_t n, const double* f, const double* y, const double* scale,
-                                                      double* x, double* r, double* p, double* r0, double* partial) {
+                                                      double* x, double* r, double* p, double* r0, double* partial,
+                                                      const uint8_t* owned) {
     __shared__ double red[8];
     double acc = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const double ri = scale[i] * (f[i] - y[i]);
         x[i] = 0.0, r[i] = ri, p[i] = ri;
         if (r0) r0[i] = ri;
-        acc += ri * ri;
+        if (!owned || owned[i]) acc += ri * ri;
     }
     const double s = block_sum(acc, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
@@ -753,9 +754,10 @@ __global__ __launch_bounds__(256) void k_krylov_init_fin(const double* partial, 
 // its 16-byte loads FIRST, and only then re-reduces the producer's partials (an L2 round trip plus two barriers) -- the
 // reduction hides under the loads instead of delaying them (measured per-kernel saving ~2 us of 17 / 9 us).
 constexpr int kCgV = 4;
+// owned (multi-GPU): 1 for DOFs this rank counts in global dot products, nullptr = all (single GPU)
 __global__ __launch_bounds__(256) void k_cg_update_xr(int64_t n, const double* p, const double* y, double* x, double* r,
                                                        const double* part_in, int np_in, double* part_out,
-                                                       const double* sc, int parity, int32_t* ctl) {
+                                                       const double* sc, int parity, int32_t* ctl, const uint8_t* owned) {
     __shared__ double red[8];
     if (__syncthreads_or(ctl[0] != 0)) return;   // uniform even if another workgroup raises the flag meanwhile
     const int64_t n2 = n >> 1, i0 = (int64_t)blockIdx.x * (256 * kCgV) + threadIdx.x;
@@ -783,14 +785,18 @@ __global__ __launch_bounds__(256) void k_cg_update_xr(int64_t n, const double* p
             xv[k].x += alpha * pv[k].x, xv[k].y += alpha * pv[k].y;
             rv[k].x -= alpha * yv[k].x, rv[k].y -= alpha * yv[k].y;
             x2[i] = xv[k], r2[i] = rv[k];
-            acc += rv[k].x * rv[k].x + rv[k].y * rv[k].y;
+            if (owned)
+                acc += (owned[2 * i] ? rv[k].x * rv[k].x : 0.0) + (owned[2 * i + 1] ? rv[k].y * rv[k].y : 0.0);
+            else
+                acc += rv[k].x * rv[k].x + rv[k].y * rv[k].y;
         }
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const int64_t i = n - 1;
         x[i] += alpha * p[i];
         const double ri = r[i] - alpha * y[i];
-        r[i] = ri, acc += ri * ri;
+        r[i] = ri;
+        if (!owned || owned[i]) acc += ri * ri;
     }
     const double s = block_sum(acc, red);
     if (threadIdx.x == 0) part_out[blockIdx.x] = s;
@@ -911,6 +917,51 @@ __global__ __launch_bounds__(256) void k_bicg_fin(const double* part_ts, int np_
         if (omega == 0.0) ctl[2] = 1;
         if (rr <= tol2 * sc[0] || ctl[2]) ctl[0] = 1;
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// multi-GPU: interface ("halo") exchange.  Every rank holds the sub-assembled operator of its own cells; an operator
+// application is y_p = A_p x_p followed by the sum of the interface entries over the ranks that share them.  The
+// interface entries are packed into one globally indexed buffer (zero elsewhere), summed by ONE ncclAllReduce together
+// with the rank's partial of the fused dot product (slot n_if), and unpacked.  dot(x, A x) = sum_p x_p . (A_p x_p) needs
+// no weighting; dots of assembled vectors count every DOF once through the `owned` mask.
+// ---------------------------------------------------------------------------------------------------------------
+// buf must be zero on entry.  Workgroup 0 also folds the local dot partials (stride 2) into buf[n_if] (+ second component
+// into buf[n_if + 1]).
+__global__ __launch_bounds__(256) void k_halo_pack(int64_t n_loc_if, const int32_t* dof, const int32_t* pos, const double* v,
+                                                    double* buf, int64_t n_if, const double* part, int np) {
+    __shared__ double red[8];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_loc_if) buf[pos[i]] = v[dof[i]];
+    if (blockIdx.x == 0 && part != nullptr) {
+        double a = 0, b = 0;
+        for (int k = threadIdx.x; k < np; k += blockDim.x) a += part[2 * k], b += part[2 * k + 1];
+        const double sa = block_sum(a, red);
+        const double sb = block_sum(b, red);
+        if (threadIdx.x == 0) buf[n_if] = sa, buf[n_if + 1] = sb;
+    }
+}
+__global__ void k_halo_unpack(int64_t n_loc_if, const int32_t* dof, const int32_t* pos, const double* buf, double* v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_loc_if) v[dof[i]] = buf[pos[i]];
+}
+// out[0] = sum(part[0..np)) in the fixed order; single workgroup
+__global__ __launch_bounds__(256) void k_reduce_partials(const double* part, int np, double* out) {
+    __shared__ double red[8];
+    const double s = sum_partials(part, np, red);
+    if (threadIdx.x == 0) out[0] = s;
+}
+__global__ void k_diag_extract(int64_t n, const int32_t* diag, const double* vals, double* d) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = vals[diag[i]];
+}
+// Jacobi scale from an already summed diagonal (multi-GPU)
+__global__ void k_jacobi_scale_from_diag(int64_t n, const double* d, const uint8_t* bnd, int use_bnd, double* scale, int32_t* flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool b = use_bnd && bnd[i];
+    if (!b && !(d[i] > 0.0)) atomicOr(flag, 1);
+    scale[i] = b ? 0.0 : 1.0 / sqrt(fabs(d[i]));
 }
 
 // u = scale * x + gt   (back to the unscaled unknowns, Dirichlet values restored)

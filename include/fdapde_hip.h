@@ -145,6 +145,23 @@ int fdapde_spmv(fdapde_ctx *ctx, int32_t which, const double *x, double *y);
  * returns the average kernel duration in ms and the algorithmic bytes per launch
  * (12*nnz + 4*(n+1) + 16*n) */
 int fdapde_bench_spmv(fdapde_ctx *ctx, int32_t reps, double *avg_ms, double *algorithmic_bytes);
+/* ---- multi-GPU: element-partitioned meshes, one context (= one rank) per GPU --------------------------------------------
+ * No reference counterpart (the reference is single-threaded, single address space).  Each rank uploads the sub-mesh of
+ * its own cells (local node numbering), assembles its sub-assembled operator with the calls above, and the solve sums the
+ * interface ("halo") DOF contributions over the ranks sharing them with one RCCL all-reduce per operator application
+ * (fused with the p.Ap partial) plus one scalar all-reduce per iteration.  See fdapde-core_amd/dist.py for the partitioner.
+ *   fdapde_comm_unique_id : rank 0 creates the 128-byte RCCL id; the caller broadcasts it (e.g. torch.distributed)
+ *   fdapde_comm_init      : every rank joins the communicator on its context's device and stream
+ *   fdapde_halo_setup     : interface maps.  n_if_global = number of interface DOFs of the whole mesh; local_dof[k] (this
+ *                           rank's DOF id, reference numbering of the LOCAL space) <-> if_index[k] (slot in the global
+ *                           interface vector), k < n_if_local; owned[d] = 1 iff this rank counts local DOF d in global
+ *                           dot products (every global DOF is owned by exactly one rank).
+ * After fdapde_halo_setup, fdapde_solve runs the distributed Jacobi-PCG (BiCGStab: single GPU only). */
+int fdapde_comm_unique_id(void *out128);
+int fdapde_comm_init(fdapde_ctx *ctx, int32_t world, int32_t rank, const void *unique_id128);
+int fdapde_halo_setup(fdapde_ctx *ctx, int64_t n_if_global, int64_t n_if_local, const int32_t *local_dof,
+                      const int32_t *if_index, const uint8_t *owned);
+
 /* tuning / diagnostic knobs of the SpMV launch (A/B measurements inside one process): key in {"spmv_variant" (2 pair form,
  * 0 team form, 1 stream form), "spmv_team", "spmv_unroll", "spmv_bpx" (workgroups per XCD band), "spmv_ablate"} */
 int fdapde_tune(fdapde_ctx *ctx, const char *key, int32_t value);

@@ -291,3 +291,35 @@ def test_error_behaviour(capi, ctx, mesh_loader):
     assert e.value.status == capi.ENOCONV
     info = ctx.solve()
     assert info.converged == 1
+
+
+def test_distributed_code_path_on_one_rank(capi, ctx, oracle, mesh_loader):
+    """The multi-GPU branch of fdapde_solve (RCCL communicator, interface pack / all-reduce / unpack, owner-masked dots)
+    exercised with a 1-rank communicator and an artificial interface set: the all-reduce is then the identity and the
+    result must equal the plain solve.  (Multi-rank correctness of the maps + recurrence: tests/test_dist_cpu.py.)"""
+    m = mesh_loader("unit_sphere")
+    ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = ctx.dofs_build(1)
+    _, _, coords = ctx.dofs_get()
+    qn = ctx.quadrature_nodes()
+    fq = np.sin(2.0 * qn[:, 0]) + qn[:, 2]
+    g = coords[:, 0] - 0.5 * coords[:, 1]
+    ctx.set_operator(-capi.laplacian() + capi.reaction(0.7))
+    ctx.set_forcing(fq)
+    ctx.set_dirichlet(g)
+    ctx.init()
+    plain = ctx.solve(rtol=1e-11)
+    u_plain = ctx.solution()
+    ctx.comm_init(1, 0, capi.Context.comm_unique_id())
+    local_dof = np.arange(0, nd, 3, dtype=np.int32)
+    if_index = np.random.default_rng(5).permutation(local_dof.size).astype(np.int32)
+    ctx.halo_setup(local_dof.size, local_dof, if_index, np.ones(nd, dtype=np.uint8))
+    info = ctx.solve(rtol=1e-11)
+    u_dist = ctx.solution()
+    assert info.converged == 1 and info.iters == plain.iters
+    assert np.abs(u_dist - u_plain).max() <= 1e-13 * max(1.0, np.abs(u_plain).max())
+    ref = oracle.pde_init_solve(m, 1, -oracle.laplacian() + oracle.reaction(0.7), forcing_q=fq, dirichlet=g)
+    assert np.linalg.norm(u_dist - ref.solution) / np.linalg.norm(ref.solution) <= SOL_TOL
+    with pytest.raises(capi.FdapdeError) as e:
+        ctx.solve(method=capi.SOLVER_BICGSTAB)
+    assert e.value.status == capi.EUNSUPPORTED

@@ -106,6 +106,9 @@ struct fdapde_ctx {
     // device buffers
     DBuf<int32_t> cverts, cdofs, adj, rowptr, colidx, diag, slot_i2e, dof_i2e, dof_e2i, cell_i2e, rb_row, colour_cells;
     DBuf<uint32_t> slotw;
+    DBuf<int64_t> bc_off, bn_off;
+    DBuf<int32_t> bc_cell, bn_node;
+    DBuf<uint16_t> bc_vert;
     DBuf<int64_t> sl_off;
     DBuf<double> vcoords, vals[2], force, fq, g, sval, scale, gt, x, r, p, y, s, t, r0, u, part_a, part_b, sc, tmp_e,
       tmp_i, tmp_v;
@@ -119,7 +122,7 @@ struct fdapde_ctx {
     int spmv_variant = 2;   // 2: team form, 2 entries per lane (default); 0: team form, 1 entry per lane
                             // (FDAPDE_SPMV=team); 1: stream form (FDAPDE_SPMV=stream) -- kept for A/B measurements
     int spmv_team = 16, spmv_unroll = 4, spmv_ablate = 0;
-    int lds_limit = 64 * 1024;
+    int lds_limit = 96 * 1024;   // per assembly workgroup: tables + staged vertices + row accumulators
     // multi-GPU (element partition): RCCL communicator + interface maps
     ncclComm_t comm = nullptr;
     int world = 1, rank = 0;
@@ -150,6 +153,11 @@ int upload_space(fdapde_ctx* c) {
     HIPCHK(c, c->adj.upload(hs.adj.data(), hs.adj.size(), st));
     HIPCHK(c, c->slotw.upload(hs.slotw.data(), hs.slotw.size(), st));
     HIPCHK(c, c->sl_off.upload(hs.sl_off.data(), hs.sl_off.size(), st));
+    HIPCHK(c, c->bc_off.upload(hs.bc_off.data(), hs.bc_off.size(), st));
+    HIPCHK(c, c->bn_off.upload(hs.bn_off.data(), hs.bn_off.size(), st));
+    HIPCHK(c, c->bc_cell.upload(hs.bc_cell.data(), hs.bc_cell.size(), st));
+    HIPCHK(c, c->bn_node.upload(hs.bn_node.data(), hs.bn_node.size(), st));
+    HIPCHK(c, c->bc_vert.upload(hs.bc_vert.data(), hs.bc_vert.size(), st));
     HIPCHK(c, c->rowptr.upload(hs.rowptr_i.data(), hs.rowptr_i.size(), st));
     {
         std::vector<int32_t> padded(hs.colidx_i);
@@ -169,6 +177,15 @@ int upload_space(fdapde_ctx* c) {
     std::memcpy(dt.psi, c->tb.psi, sizeof dt.psi);
     std::memcpy(dt.dpsi, c->tb.dpsi, sizeof dt.dpsi);
     std::memcpy(dt.qn, c->tb.qn, sizeof dt.qn);
+    dt.wsum = 0;
+    for (int q = 0; q < c->tb.nq; ++q) dt.wsum += c->tb.qw[q];
+    for (int i = 0; i < c->tb.nb; ++i)
+        for (int j = 0; j < c->tb.nb; ++j) {
+            double m = 0;
+            const int lo = i < j ? i : j, hi = i < j ? j : i;   // same expression for (i,j) and (j,i): bitwise symmetric mass
+            for (int q = 0; q < c->tb.nq; ++q) m += c->tb.qw[q] * (c->tb.psi[lo * c->tb.nq + q] * c->tb.psi[hi * c->tb.nq + q]);
+            dt.mtab[i * c->tb.nb + j] = m;
+        }
     HIPCHK(c, c->tables.upload(&dt, 1, st));
     const size_t n = (size_t)hs.n_dofs, nnz = (size_t)hs.nnz;
     HIPCHK(c, c->vals[0].alloc(nnz + 2));   // + 2: pair loads of the SpMV may touch one entry past a row's end
@@ -234,6 +251,8 @@ AsmArgs asm_args(fdapde_ctx* c) {
     a.cverts = c->cverts.p, a.cdofs = c->cdofs.p, a.vcoords = c->vcoords.p;
     a.sl_off = c->sl_off.p, a.adj = c->adj.p, a.slotw = c->slotw.p;
     a.rowptr = c->rowptr.p, a.colidx = c->colidx.p, a.tables = c->tables.p;
+    a.bc_off = c->bc_off.p, a.bc_cell = c->bc_cell.p, a.bc_vert = c->bc_vert.p, a.bn_off = c->bn_off.p, a.bn_node = c->bn_node.p;
+    a.lds_nodes = c->hs.max_blk_nodes;
     return a;
 }
 
@@ -241,13 +260,14 @@ AsmArgs asm_args(fdapde_ctx* c) {
 int make_dev_op(fdapde_ctx* c, const std::vector<HostTerm>& terms, DevOp* out, int coef_slot0) {
     DevOp op{};
     op.n = (int32_t)terms.size();
-    op.needs_psi = 0;
+    op.needs_psi = 0, op.needs_rows = 0;
     for (size_t k = 0; k < terms.size(); ++k) {
         const fdapde_term& t = terms[k].t;
         DevTerm& d = op.t[k];
         d.kind = t.kind, d.space_varying = t.space_varying, d.coef = t.coef, d.data = nullptr;
         std::memcpy(d.cst, t.cst, sizeof d.cst);
         if (t.kind == FDAPDE_ADVECTION || t.kind == FDAPDE_REACTION) op.needs_psi = 1;
+        if (t.space_varying) op.needs_rows = 1;
         if (t.space_varying) {
             DBuf<double>& buf = c->coef[coef_slot0 + k];
             HIPCHK(c, buf.upload(terms[k].data_i.data(), terms[k].data_i.size(), c->stream));
@@ -297,12 +317,28 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
     const HostSpace& hs = c->hs;
     constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
     if (assembly == FDAPDE_ASSEMBLY_ROWS) {
-        const size_t tab = sizeof(DevTables);
+        const size_t tab = sizeof(DevTables) + (size_t)hs.max_blk_nodes * (M == 2 ? 2 : 4) * sizeof(double);
         size_t acc = (size_t)hs.max_blk_nnz * sizeof(double);
-        if (tab + acc > (size_t)c->lds_limit) acc = (size_t)c->lds_limit - tab;
+        if (tab + acc > (size_t)c->lds_limit) acc = tab < (size_t)c->lds_limit ? (size_t)c->lds_limit - tab : 0;
         a.lds_acc_cap = (int32_t)(acc / sizeof(double));
         const int grid = (int)((hs.n_dofs + kAsmBlock - 1) / kAsmBlock);
-        hipLaunchKernelGGL((k_assemble_rows<M, R>), dim3(grid), dim3(kAsmBlock), tab + acc, c->stream, a, op);
+        size_t lds = tab + acc;
+        if (lds > 64 * 1024)
+            for (const void* fn : {reinterpret_cast<const void*>(&k_assemble_rows<M, R, 0>),
+                                   reinterpret_cast<const void*>(&k_assemble_rows<M, R, 1>),
+                                   reinterpret_cast<const void*>(&k_assemble_rows<M, R, 2>)})
+                (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        // specialised integrands for the two operators FEMSolverBase::init always assembles (see element_row)
+        int opk = 0;
+        if (op.n == 1 && op.t[0].kind == FDAPDE_LAPLACIAN) opk = 1;
+        if (op.n == 1 && op.t[0].kind == FDAPDE_REACTION && !op.t[0].space_varying) opk = 2;
+        if (std::getenv("FDAPDE_ASM_GENERIC")) opk = 0;
+        if (opk == 1)
+            hipLaunchKernelGGL((k_assemble_rows<M, R, 1>), dim3(grid), dim3(kAsmBlock), lds, c->stream, a, op);
+        else if (opk == 2)
+            hipLaunchKernelGGL((k_assemble_rows<M, R, 2>), dim3(grid), dim3(kAsmBlock), lds, c->stream, a, op);
+        else
+            hipLaunchKernelGGL((k_assemble_rows<M, R, 0>), dim3(grid), dim3(kAsmBlock), lds, c->stream, a, op);
     } else {
         if (a.vals) HIPCHK(c, hipMemsetAsync(a.vals, 0, sizeof(double) * (size_t)hs.nnz, c->stream));
         if (a.force) HIPCHK(c, hipMemsetAsync(a.force, 0, sizeof(double) * (size_t)hs.n_dofs, c->stream));
@@ -492,6 +528,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
             b->release();
         for (auto& b : c->coef) b.release();
         c->slotw.release(), c->sl_off.release(), c->bnd.release(), c->tables.release();
+        c->bc_off.release(), c->bn_off.release(), c->bc_cell.release(), c->bn_node.release(), c->bc_vert.release();
         c->halo_dof.release(), c->halo_pos.release(), c->owned.release(), c->hbuf.release(), c->sbuf.release();
         if (c->comm) (void)g_rccl.CommDestroy(c->comm);
         if (c->h_ctl) (void)hipHostFree(c->h_ctl);
@@ -674,7 +711,7 @@ int fdapde_init(fdapde_ctx* c, const fdapde_options* opt) {
     DevOp op, mass_op{};
     int rc = make_dev_op(c, c->op, &op, 0);
     if (rc) return rc;
-    mass_op.n = 1, mass_op.needs_psi = 1;
+    mass_op.n = 1, mass_op.needs_psi = 1, mass_op.needs_rows = 0;
     mass_op.t[0].kind = FDAPDE_REACTION, mass_op.t[0].space_varying = 0, mass_op.t[0].coef = 1.0, mass_op.t[0].cst[0] = 1.0;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     // stiff_ (+ force_ column 0 in the same sweep): fem_solver_base.h:113, 121/133

@@ -15,6 +15,8 @@
 #include <array>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <numeric>
@@ -488,6 +490,68 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
     for (int64_t b = 0; b < n_blk; ++b) {
         int32_t v = hs.rowptr_i[(size_t)std::min(nd, (b + 1) * kAsmBlock)] - hs.rowptr_i[(size_t)b * kAsmBlock];
         hs.blk_nnz_cap[(size_t)b] = v, hs.max_blk_nnz = std::max(hs.max_blk_nnz, v);
+    }
+    // ---- block-local cell / node tables; adj re-encoded as (index in the block's cell table) * 16 + local index -------
+    {
+        std::vector<std::vector<int32_t>> cells_of((size_t)n_blk), nodes_of((size_t)n_blk);
+        parallel_for(n_blk, [&](int64_t b0, int64_t b1, unsigned) {
+            std::vector<int32_t> cs, ns;
+            for (int64_t b = b0; b < b1; ++b) {
+                cs.clear(), ns.clear();
+                const int64_t r0 = b * kAsmBlock, r1 = std::min(nd, r0 + kAsmBlock);
+                for (int64_t k = vptr[(size_t)r0]; k < vptr[(size_t)r1]; ++k) cs.push_back(vis[(size_t)k] >> 4);
+                std::sort(cs.begin(), cs.end());
+                cs.erase(std::unique(cs.begin(), cs.end()), cs.end());
+                for (int32_t c : cs)
+                    for (int v = 0; v < nv; ++v) ns.push_back(hs.cverts_i[(size_t)c * nv + v]);
+                std::sort(ns.begin(), ns.end());
+                ns.erase(std::unique(ns.begin(), ns.end()), ns.end());
+                cells_of[(size_t)b] = cs, nodes_of[(size_t)b] = ns;
+            }
+        }, 8);
+        hs.bc_off.assign((size_t)n_blk + 1, 0), hs.bn_off.assign((size_t)n_blk + 1, 0);
+        hs.max_blk_cells = hs.max_blk_nodes = 0;
+        for (int64_t b = 0; b < n_blk; ++b) {
+            hs.bc_off[(size_t)b + 1] = hs.bc_off[(size_t)b] + (int64_t)cells_of[(size_t)b].size();
+            hs.bn_off[(size_t)b + 1] = hs.bn_off[(size_t)b] + (int64_t)nodes_of[(size_t)b].size();
+            hs.max_blk_cells = std::max<int32_t>(hs.max_blk_cells, (int32_t)cells_of[(size_t)b].size());
+            hs.max_blk_nodes = std::max<int32_t>(hs.max_blk_nodes, (int32_t)nodes_of[(size_t)b].size());
+        }
+        if (std::getenv("FDAPDE_DEBUG_SETUP"))
+            std::fprintf(stderr, "assembly blocks: %lld, cells/block avg %.0f max %d, nodes/block avg %.0f max %d, nnz/block max %d\n",
+                         (long long)n_blk, (double)hs.bc_off[(size_t)n_blk] / n_blk, hs.max_blk_cells,
+                         (double)hs.bn_off[(size_t)n_blk] / n_blk, hs.max_blk_nodes, hs.max_blk_nnz);
+        if (hs.max_blk_nodes > 65535) {
+            err = "assembly block touches more than 65535 nodes";
+            return FDAPDE_EUNSUPPORTED;
+        }
+        hs.bc_cell.resize((size_t)hs.bc_off[(size_t)n_blk]);
+        hs.bc_vert.assign((size_t)hs.bc_off[(size_t)n_blk] * 4, 0);
+        hs.bn_node.resize((size_t)hs.bn_off[(size_t)n_blk]);
+        parallel_for(n_blk, [&](int64_t b0, int64_t b1, unsigned) {
+            for (int64_t b = b0; b < b1; ++b) {
+                const auto& cs = cells_of[(size_t)b];
+                const auto& ns = nodes_of[(size_t)b];
+                std::copy(ns.begin(), ns.end(), hs.bn_node.begin() + hs.bn_off[(size_t)b]);
+                for (size_t k = 0; k < cs.size(); ++k) {
+                    const int64_t at = hs.bc_off[(size_t)b] + (int64_t)k;
+                    hs.bc_cell[(size_t)at] = cs[k];
+                    for (int v = 0; v < nv; ++v)
+                        hs.bc_vert[(size_t)at * 4 + v] =
+                          (uint16_t)(std::lower_bound(ns.begin(), ns.end(), hs.cverts_i[(size_t)cs[k] * nv + v]) - ns.begin());
+                }
+                const int64_t r0 = b * kAsmBlock, r1 = std::min(nd, r0 + kAsmBlock);
+                for (int64_t r = r0; r < r1; ++r) {
+                    const int64_t sidx = r / kSlice, lane = r % kSlice;
+                    for (int64_t k = vptr[(size_t)r]; k < vptr[(size_t)r + 1]; ++k) {
+                        const int64_t at = (hs.sl_off[(size_t)sidx] + (k - vptr[(size_t)r])) * kSlice + lane;
+                        const int32_t cell = vis[(size_t)k] >> 4, il = vis[(size_t)k] & 15;
+                        const int32_t lc = (int32_t)(std::lower_bound(cs.begin(), cs.end(), cell) - cs.begin());
+                        hs.adj[(size_t)at] = lc * 16 + il;
+                    }
+                }
+            }
+        }, 8);
     }
 
     // ---- SpMV row blocks: consecutive rows with at most kSpmvNnz nonzeros -----------------------------------

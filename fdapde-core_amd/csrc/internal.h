@@ -64,6 +64,14 @@ struct HostSpace {
     std::vector<uint32_t> slotw;      // adj.size() * nbw; packed uint16 row-relative slots of the nb local columns
     std::vector<int32_t> blk_nnz_cap; // per assembly block: nnz of its 256 rows
     int32_t max_blk_nnz = 0;
+    // ---- per assembly block (256 rows): the cells its rows visit and the vertex nodes of those cells.  `adj` addresses
+    //      cells by their index in the block's table; the block stages its nodes' coordinates in LDS once.
+    std::vector<int64_t> bc_off;      // n_blk + 1: offsets into bc_cell / bc_vert (in cells)
+    std::vector<int32_t> bc_cell;     // internal cell id of each block-cell (forcing / coefficient rows)
+    std::vector<uint16_t> bc_vert;    // 4 per block-cell: block-local node index of each vertex (M+1 used)
+    std::vector<int64_t> bn_off;      // n_blk + 1: offsets into bn_node
+    std::vector<int32_t> bn_node;     // internal node ids staged by the block
+    int32_t max_blk_nodes = 0, max_blk_cells = 0;
     // ---- element colouring (cells of one colour share no DOF), for the colour-partitioned scatter
     int n_colours = 0;
     std::vector<int32_t> colour_off;  // n_colours + 1

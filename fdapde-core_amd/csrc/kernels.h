@@ -32,6 +32,7 @@ struct DevTerm {
 struct DevOp {
     int32_t n;
     int32_t needs_psi;    // any advection / reaction leaf
+    int32_t needs_rows;   // any space-varying leaf (needs the global cell id for its data row)
     DevTerm t[kMaxTerms];
 };
 
@@ -41,6 +42,9 @@ struct DevTables {
     double psi[kMaxBasis * kMaxQuad];        // [i*nq + q]
     double dpsi[kMaxBasis * kMaxQuad * 3];   // [(i*nq + q)*3 + k]
     double qn[kMaxQuad * 3];                 // [q*M + k]
+    double mtab[kMaxBasis * kMaxBasis];      // sum_q w_q psi_i(p_q) psi_j(p_q), [i*nb + j]: reference mass integrals
+    double wsum;                             // sum_q w_q (0.999999999999999 for the 3-point rule: part of the contract)
+    double pad_;
 };
 constexpr int kTablesDoubles = sizeof(DevTables) / sizeof(double);
 
@@ -59,6 +63,13 @@ struct AsmArgs {
     const double* fq;          // forcing at quadrature nodes, internal cell order, or nullptr
     double* force;             // forcing vector (internal DOF order) or nullptr
     int32_t lds_acc_cap;       // doubles available for the row accumulators
+    // block-local tables of the row-owner kernel (host_setup.cpp): cells visited by the block's rows, their vertex nodes
+    const int64_t* bc_off;
+    const int32_t* bc_cell;
+    const uint16_t* bc_vert;   // 4 per block-cell
+    const int64_t* bn_off;
+    const int32_t* bn_node;
+    int32_t lds_nodes;         // coordinate slots reserved in LDS (max nodes of any block)
 };
 
 template <int M> struct Geo {
@@ -67,27 +78,20 @@ template <int M> struct Geo {
 };
 
 // Simplex::initialize (fdaPDE/geometry/simplex.h:184-195): J col j = x_{j+1} - x_0, invJ, measure = |det J| / M!
-template <int M> __device__ __forceinline__ void cell_geometry(const AsmArgs& a, int cell, Geo<M>& g) {
+// p0..p3: vertex coordinates (global memory or the workgroup's LDS copy)
+template <int M>
+__device__ __forceinline__ void geo_from_vertices(const double* p0, const double* p1, const double* p2, const double* p3, Geo<M>& g) {
     if constexpr (M == 2) {
-        const int32_t* cv = a.cverts + (int64_t)cell * 3;
-        const double2 x0 = *reinterpret_cast<const double2*>(a.vcoords + (int64_t)cv[0] * 2);
-        const double2 x1 = *reinterpret_cast<const double2*>(a.vcoords + (int64_t)cv[1] * 2);
-        const double2 x2 = *reinterpret_cast<const double2*>(a.vcoords + (int64_t)cv[2] * 2);
-        const double j00 = x1.x - x0.x, j01 = x2.x - x0.x, j10 = x1.y - x0.y, j11 = x2.y - x0.y;
+        const double j00 = p1[0] - p0[0], j01 = p2[0] - p0[0], j10 = p1[1] - p0[1], j11 = p2[1] - p0[1];
         const double det = j00 * j11 - j01 * j10;
         const double id = 1.0 / det;
         g.invJ[0][0] = j11 * id, g.invJ[0][1] = -j01 * id;
         g.invJ[1][0] = -j10 * id, g.invJ[1][1] = j00 * id;
         g.measure = fabs(det) * 0.5;
     } else {
-        const int4 cv = *reinterpret_cast<const int4*>(a.cverts + (int64_t)cell * 4);
-        const double4 x0 = *reinterpret_cast<const double4*>(a.vcoords + (int64_t)cv.x * 4);
-        const double4 x1 = *reinterpret_cast<const double4*>(a.vcoords + (int64_t)cv.y * 4);
-        const double4 x2 = *reinterpret_cast<const double4*>(a.vcoords + (int64_t)cv.z * 4);
-        const double4 x3 = *reinterpret_cast<const double4*>(a.vcoords + (int64_t)cv.w * 4);
-        const double a00 = x1.x - x0.x, a01 = x2.x - x0.x, a02 = x3.x - x0.x;
-        const double a10 = x1.y - x0.y, a11 = x2.y - x0.y, a12 = x3.y - x0.y;
-        const double a20 = x1.z - x0.z, a21 = x2.z - x0.z, a22 = x3.z - x0.z;
+        const double a00 = p1[0] - p0[0], a01 = p2[0] - p0[0], a02 = p3[0] - p0[0];
+        const double a10 = p1[1] - p0[1], a11 = p2[1] - p0[1], a12 = p3[1] - p0[1];
+        const double a20 = p1[2] - p0[2], a21 = p2[2] - p0[2], a22 = p3[2] - p0[2];
         const double c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
         const double det = a00 * c00 + a01 * c01 + a02 * c02;
         const double id = 1.0 / det;
@@ -99,6 +103,22 @@ template <int M> __device__ __forceinline__ void cell_geometry(const AsmArgs& a,
         g.invJ[1][2] = (a02 * a10 - a00 * a12) * id;
         g.invJ[2][2] = (a00 * a11 - a01 * a10) * id;
         g.measure = fabs(det) * (1.0 / 6.0);
+    }
+}
+template <int M> __device__ __forceinline__ void cell_geometry(const AsmArgs& a, int cell, Geo<M>& g) {
+    if constexpr (M == 2) {
+        const int32_t* cv = a.cverts + (int64_t)cell * 3;
+        const double2 x0 = *reinterpret_cast<const double2*>(a.vcoords + (int64_t)cv[0] * 2);
+        const double2 x1 = *reinterpret_cast<const double2*>(a.vcoords + (int64_t)cv[1] * 2);
+        const double2 x2 = *reinterpret_cast<const double2*>(a.vcoords + (int64_t)cv[2] * 2);
+        geo_from_vertices<2>(&x0.x, &x1.x, &x2.x, nullptr, g);
+    } else {
+        const int4 cv = *reinterpret_cast<const int4*>(a.cverts + (int64_t)cell * 4);
+        const double4 x0 = *reinterpret_cast<const double4*>(a.vcoords + (int64_t)cv.x * 4);
+        const double4 x1 = *reinterpret_cast<const double4*>(a.vcoords + (int64_t)cv.y * 4);
+        const double4 x2 = *reinterpret_cast<const double4*>(a.vcoords + (int64_t)cv.z * 4);
+        const double4 x3 = *reinterpret_cast<const double4*>(a.vcoords + (int64_t)cv.w * 4);
+        geo_from_vertices<3>(&x0.x, &x1.x, &x2.x, &x3.x, g);
     }
 }
 
@@ -159,13 +179,18 @@ __device__ __forceinline__ double weak_form(const DevOp& op, int64_t qrow, doubl
 // function j, value = measure * sum_q w_q * form(psi_il, psi_j)(p_q)   (integrator.h:92-106), and return the forcing
 // contribution measure * sum_q f_q psi_il(p_q) w_q (integrator.h:73-90) when fq is given.
 // `tb` points at the LDS copy of the tables.
-template <int M, int R, typename Emit>
-__device__ __forceinline__ double element_row(const AsmArgs& a, const DevOp& op, const DevTables* tb, int cell, int il,
-                                              bool want_matrix, Emit&& emit) {
+// OPK selects a specialised integrand (same numbers up to rounding, far fewer instructions -- the assembly kernels are
+// instruction-issue bound, not bandwidth bound):
+//   0  generic: any sum of leaves, evaluated per quadrature node as the reference does
+//   1  a single Laplacian leaf: the term loop and its branches fold away; for P1 the gradients are constant over the cell
+//      and come straight from J^{-1} (grad lambda_0 = -sum_k row_k, grad lambda_k = row_k), no table reads
+//   2  a single constant reaction leaf (mass matrix): value = c * measure * sum_q w_q psi_i psi_j, the reference integrals
+//      sum_q w_q psi_i psi_j do not depend on the cell and are tabulated (DevTables::mtab)
+template <int M, int R, int OPK, typename Emit>
+__device__ __forceinline__ double element_row(const AsmArgs& a, const DevOp& op, const DevTables* tb, const Geo<M>& g, int cell,
+                                              int il, bool want_matrix, Emit&& emit) {
     constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
     constexpr int NQ = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 5);
-    Geo<M> g;
-    cell_geometry<M>(a, cell, g);
     const int64_t qrow0 = (int64_t)NQ * cell;
     double fsum = 0;
     if (a.fq != nullptr) {
@@ -174,26 +199,66 @@ __device__ __forceinline__ double element_row(const AsmArgs& a, const DevOp& op,
         fsum *= g.measure;
     }
     if (!want_matrix) return fsum;
-    // gradients of the owned test function at every quadrature node (P1: constant over the cell)
-    constexpr int NGQ = R == 1 ? 1 : NQ;
-    double gi[NGQ][M];
+    if constexpr (OPK == 2) {
+        const double cm = op.t[0].coef * op.t[0].cst[0] * g.measure;
 #pragma unroll
-    for (int q = 0; q < NGQ; ++q) phys_grad<M>(g, &tb->dpsi[(il * NQ + q) * 3], gi[q]);
+        for (int j = 0; j < NB; ++j) emit(j, cm * tb->mtab[il * NB + j]);
+        return fsum;
+    } else if constexpr (OPK == 1 && R == 1) {
+        double G[M + 1][M];   // physical gradients of the M+1 barycentric coordinates
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        double gj[NGQ][M];
+        for (int r = 0; r < M; ++r) {
+            double s0 = 0;
 #pragma unroll
-        for (int q = 0; q < NGQ; ++q) phys_grad<M>(g, &tb->dpsi[(j * NQ + q) * 3], gj[q]);
-        double value = 0;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const double pi = op.needs_psi ? tb->psi[il * NQ + q] : 0.0;
-            const double pj = op.needs_psi ? tb->psi[j * NQ + q] : 0.0;
-            value += weak_form<M>(op, qrow0 + q, pi, pj, gi[R == 1 ? 0 : q], gj[R == 1 ? 0 : q]) * tb->qw[q];
+            for (int k = 0; k < M; ++k) G[k + 1][r] = g.invJ[k][r], s0 -= g.invJ[k][r];
+            G[0][r] = s0;
         }
-        emit(j, value * g.measure);
+        double gi[M];
+#pragma unroll
+        for (int r = 0; r < M; ++r) {
+            double v = G[0][r];
+#pragma unroll
+            for (int k = 1; k <= M; ++k) v = il == k ? G[k][r] : v;
+            gi[r] = v;
+        }
+        const double cm = op.t[0].coef * tb->wsum * g.measure;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            double d = 0;
+#pragma unroll
+            for (int r = 0; r < M; ++r) d += gi[r] * G[j][r];
+            emit(j, cm * (-d));
+        }
+        return fsum;
+    } else {
+        // gradients of the owned test function at every quadrature node (P1: constant over the cell)
+        constexpr int NGQ = R == 1 ? 1 : NQ;
+        double gi[NGQ][M];
+#pragma unroll
+        for (int q = 0; q < NGQ; ++q) phys_grad<M>(g, &tb->dpsi[(il * NQ + q) * 3], gi[q]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            double gj[NGQ][M];
+#pragma unroll
+            for (int q = 0; q < NGQ; ++q) phys_grad<M>(g, &tb->dpsi[(j * NQ + q) * 3], gj[q]);
+            double value = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if constexpr (OPK == 1) {
+                    double d = 0;
+#pragma unroll
+                    for (int r = 0; r < M; ++r) d += gi[q][r] * gj[q][r];
+                    value += (op.t[0].coef * (-d)) * tb->qw[q];
+                } else {
+                    const double pi = op.needs_psi ? tb->psi[il * NQ + q] : 0.0;
+                    const double pj = op.needs_psi ? tb->psi[j * NQ + q] : 0.0;
+                    value += weak_form<M>(op, qrow0 + q, pi, pj, gi[R == 1 ? 0 : q], gj[R == 1 ? 0 : q]) * tb->qw[q];
+                }
+            }
+            emit(j, value * g.measure);
+        }
+        return fsum;
     }
-    return fsum;
 }
 
 __device__ __forceinline__ const DevTables* stage_tables(const DevTables* gsrc, double* lds) {
@@ -211,13 +276,15 @@ __device__ __forceinline__ const DevTables* stage_tables(const DevTables* gsrc, 
 // (j,i) sum the same products over the same cells in the same order).
 // Replaces Assembler::discretize_operator + discretize_forcing (fdaPDE/finite_elements/fem_assembler.h:52-136).
 // ---------------------------------------------------------------------------------------------------------------
-template <int M, int R>
+template <int M, int R, int OPK>
 __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op) {
     constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
     constexpr int NBW = (NB * 2 + 3) / 4;
+    constexpr int NP = M == 2 ? 2 : 4;   // doubles per staged vertex (xyz padded to 32 B)
     extern __shared__ double lds[];
     const DevTables* tb = stage_tables(a.tables, lds);
-    double* acc = lds + kTablesDoubles;
+    double* xyz = lds + kTablesDoubles;                       // the block's vertex coordinates
+    double* acc = xyz + (int64_t)a.lds_nodes * NP;            // the block's CSR value range
 
     const int64_t row0 = (int64_t)blockIdx.x * kAsmBlock;
     const int64_t row = row0 + threadIdx.x;
@@ -228,6 +295,19 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
     const bool in_lds = blk_nnz <= a.lds_acc_cap;
     const int32_t my0 = row < a.n_dofs ? a.rowptr[row] : 0;
     const int32_t my1 = row < a.n_dofs ? a.rowptr[row + 1] : 0;
+    // stage the vertex coordinates of every cell this block visits: each node is fetched from HBM/L2 once per block
+    // instead of once per (row, visit) -- the gathers of the visit loop below then hit LDS
+    const int64_t bn0 = a.bn_off[blockIdx.x], nbn = a.bn_off[blockIdx.x + 1] - bn0;
+    for (int i = threadIdx.x; i < nbn; i += kAsmBlock) {
+        const int64_t node = a.bn_node[bn0 + i];
+        if constexpr (M == 2) {
+            *reinterpret_cast<double2*>(xyz + i * 2) = *reinterpret_cast<const double2*>(a.vcoords + node * 2);
+        } else {
+            const double4 v = *reinterpret_cast<const double4*>(a.vcoords + node * 4);
+            *reinterpret_cast<double2*>(xyz + i * 4) = make_double2(v.x, v.y);
+            *reinterpret_cast<double2*>(xyz + i * 4 + 2) = make_double2(v.z, 0.0);
+        }
+    }
     if (want_matrix) {
         if (in_lds) {
             for (int k = threadIdx.x; k < blk_nnz; k += kAsmBlock) acc[k] = 0.0;
@@ -239,6 +319,7 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
 
     const int64_t slice = row >> 6;
     const int lane = threadIdx.x & 63;
+    const int64_t bc0 = a.bc_off[blockIdx.x];
     double fsum = 0;
     if (row0 + (threadIdx.x & ~63) < a.n_dofs) {   // wave-uniform: slice exists
         const int64_t off = a.sl_off[slice], width = a.sl_off[slice + 1] - off;
@@ -249,7 +330,12 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
             uint32_t sw[NBW];
 #pragma unroll
             for (int w = 0; w < NBW; ++w) sw[w] = a.slotw[at * NBW + w];
-            fsum += element_row<M, R>(a, op, tb, code >> 4, code & 15, want_matrix, [&](int j, double value) {
+            const int64_t bc = bc0 + (code >> 4);
+            const ushort4 lv = *reinterpret_cast<const ushort4*>(a.bc_vert + bc * 4);   // block-local vertex indices
+            Geo<M> g;
+            geo_from_vertices<M>(xyz + lv.x * NP, xyz + lv.y * NP, xyz + lv.z * NP, xyz + lv.w * NP, g);
+            const int cell = (a.fq != nullptr || op.needs_rows) ? a.bc_cell[bc] : 0;   // only forcing / varying coefficients need it
+            fsum += element_row<M, R, OPK>(a, op, tb, g, cell, code & 15, want_matrix, [&](int j, double value) {
                 const uint32_t slot = (sw[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
                 if (in_lds)
                     acc[my0 - base + (int32_t)slot] += value;
@@ -286,7 +372,9 @@ __global__ __launch_bounds__(256) void k_assemble_scatter(AsmArgs a, DevOp op, c
     const int32_t* cd = a.cdofs + (int64_t)cell * NB;
     const int32_t row = cd[il];
     const int32_t k0 = a.rowptr[row], k1 = a.rowptr[row + 1];
-    const double f = element_row<M, R>(a, op, tb, cell, il, a.vals != nullptr, [&](int j, double value) {
+    Geo<M> g;
+    cell_geometry<M>(a, cell, g);
+    const double f = element_row<M, R, 0>(a, op, tb, g, cell, il, a.vals != nullptr, [&](int j, double value) {
         const int32_t col = cd[j];
         int32_t lo = k0, hi = k1;
         while (lo < hi) {

@@ -402,6 +402,15 @@ void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, 
             case 2: SPMV_GO(k_spmv_team2<8, 4, 2>); break;
             case 4: SPMV_GO(k_spmv_team2<8, 4, 4>); break;
             case 5: SPMV_GO(k_spmv_team2<8, 4, 5>); break;
+            case 8: SPMV_GO(k_spmv_team2<8, 4, 8>); break;     // no y store, no w read
+            case 9: SPMV_GO(k_spmv_team2<8, 4, 9>); break;     // + no gather
+            case 16: SPMV_GO(k_spmv_team2<8, 4, 16>); break;   // one band (no XCD banding)
+            case 32: SPMV_GO(k_spmv_team2<8, 4, 32>); break;   // no y store
+            case 64: SPMV_GO(k_spmv_team2<8, 4, 64>); break;   // no w load
+            case 128: SPMV_GO(k_spmv_team2<8, 4, 128>); break;   // nontemporal y store
+            case 256: SPMV_GO(k_spmv_team2<8, 4, 256>); break;   // y stores confined to 32 KiB
+            case 512: SPMV_GO(k_spmv_team2<8, 4, 512>); break;   // 16-byte y stores
+            case 24: SPMV_GO(k_spmv_team2<8, 4, 24>); break;
             default:
                 if (c->spmv_unroll == 2)
                     SPMV_GO(k_spmv_team2<8, 2>);

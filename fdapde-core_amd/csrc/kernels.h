@@ -16,6 +16,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "internal.h"
 
 namespace fdapde_hip {
@@ -673,14 +675,18 @@ struct __attribute__((packed, aligned(4))) I32x2 { int x, y; };
 //   4: plain (default cache policy) val / colidx loads instead of nontemporal ones (results stay correct)
 // The matrix arrays are read exactly once per launch and are larger than the 256 MiB Infinity Cache, so they are
 // loaded nontemporal: measured 74.4 -> 69.0 us per launch on C3, and the CG vectors (70 MB) keep the cache.
-template <int T, int U, int ABL = 0>
-__global__ __launch_bounds__(256) void k_spmv_team2(SpmvArgs s, int64_t n, int64_t rows_per_band) {
+template <int T, int U, int ABL = 0, int OCC = 4>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) void k_spmv_team2(SpmvArgs s, int64_t n,
+                                                                                              int64_t rows_per_band) {
     constexpr int TEAMS = 64 / T;
     constexpr int WROWS = TEAMS * U;
     static_assert(WROWS < 64, "one rowptr load per tile");
     __shared__ double red[8];
+    __shared__ double ystage[4][WROWS];
     if (s.stop && __syncthreads_or(*s.stop != 0)) return;
-    const int band = blockIdx.x & 7, lb = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const int band = (ABL & 16) ? 0 : (blockIdx.x & 7), lb = (ABL & 16) ? blockIdx.x : (blockIdx.x >> 3),
+              bpx = (ABL & 16) ? gridDim.x : (gridDim.x >> 3);
+    if (ABL & 16) rows_per_band = n;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, team = lane / T, l = lane % T;
     // Tiles are dealt round-robin to the wavefronts of a band, so that at any moment the wavefronts of an XCD read one
     // advancing window of the CSR arrays.  (Giving every wavefront its own contiguous share of rows balances the tail
@@ -725,7 +731,16 @@ __global__ __launch_bounds__(256) void k_spmv_team2(SpmvArgs s, int64_t n, int64
             rs[u] = __shfl(rp0, u * TEAMS + team, 64), re[u] = __shfl(rp0, u * TEAMS + team + 1, 64);
             load_pair(rs[u], re[u], v[u], c[u]);
         }
-        for (; base < band_end; base += stride) {
+        volatile double* ys = ystage[wave];
+        const double* wp = s.w ? s.w : s.x;   // always dereferenceable; the dots are discarded when s.w is null
+        const double dots = s.w ? 1.0 : 0.0;
+        // One tile.  FULL tiles (all WROWS rows inside the band) run branch-free: the w operand of the fused dot is loaded
+        // WITH the gathers (a load issued after the reduction would expose a full memory latency per tile), and the y
+        // store is unconditional -- lanes l >= U repeat lane l % U (same value, same address), because a store under an
+        // exec-masked branch makes the next iteration's wait for the val/colidx loads a vmcnt(0) that also drains the store.
+        // Both together: 66.9 -> 57.7 us in the ablation.  The band's last, partial tile takes the masked path once.
+        auto tile = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
             double xa[U], xb[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -736,6 +751,10 @@ __global__ __launch_bounds__(256) void k_spmv_team2(SpmvArgs s, int64_t n, int64
                 else
                     xa[u] = s.x[c[u].x], xb[u] = s.x[c[u].y];
             }
+            // lane j < WROWS reports row base + j (rows are transposed into lane order through ystage below)
+            const int64_t row = base + (lane % WROWS);
+            const bool row_ok = FULL || row < band_end;
+            const double wv = (ABL & (8 | 64)) ? 1.0 : wp[row_ok ? row : band_end - 1];
             int rsn[U], ren[U];
             F64x2 vn[U];
             I32x2 cn[U];
@@ -749,26 +768,49 @@ __global__ __launch_bounds__(256) void k_spmv_team2(SpmvArgs s, int64_t n, int64
             bool long_row = false;
 #pragma unroll
             for (int u = 0; u < U; ++u) acc[u] = v[u].x * xa[u] + v[u].y * xb[u], long_row |= re[u] - rs[u] > 2 * T;
-            if (__any(long_row)) {
+            if (__any(long_row)) {   // rows longer than a team pass (rare when 2 T covers the mean row)
 #pragma unroll
                 for (int u = 0; u < U; ++u)
                     for (int k = rs[u] + l + 2 * T; k < re[u]; k += T) acc[u] += s.vals[k] * s.x[s.colidx[k]];
             }
-            // every lane of a team gets the team's U row sums; lane l < U of the team keeps row u = l and stores it
-            double out = 0;
+            // every lane of a team gets the team's U row sums; lane l < U keeps row (u = l, team) = tile row l*TEAMS + team.
+            // Stored from there, consecutive lanes would write rows TEAMS apart: 32 separate 8-byte partial writes per
+            // instruction (measured: as expensive as all the x gathers).  The sums are transposed into lane order through
+            // a 256-byte per-wavefront LDS buffer (one ds_write_b64 + one ds_read_b64, wave-synchronous, no barrier), so
+            // that lanes 0..WROWS-1 store WROWS consecutive rows = whole cache lines; lanes above repeat them.
+            double pick = 0;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const double t = team_sum<T>(acc[u]);
-                if (l == u) out = t;
+                if (l == u) pick = t;
             }
-            const int64_t row = base + l * TEAMS + team;
-            if (l < U && row < band_end) {
-                s.y[row] = out;
-                if (s.w) d_wy += s.w[row] * out, d_yy += out * out;
+            if (l < U) ys[l * TEAMS + team] = pick;
+            __builtin_amdgcn_wave_barrier();
+            const double out = ys[lane % WROWS];
+            if constexpr (!(ABL & (8 | 32))) {
+                if constexpr (FULL) {
+                    if constexpr (ABL & 128)
+                        __builtin_nontemporal_store(out, s.y + row);
+                    else if constexpr (ABL & 256)
+                        s.y[row & 4095] = out;   // diagnostic: same store instruction stream, 32 KiB footprint
+                    else if constexpr (ABL & 512) {   // 16 B per lane: lanes 0..WROWS/2-1 store row pairs
+                        const int j = lane % (WROWS / 2);
+                        const double2 o2 = make_double2(ys[2 * j], ys[2 * j + 1]);
+                        *reinterpret_cast<double2*>(s.y + base + 2 * j) = o2;
+                    } else
+                        s.y[row] = out;
+                } else {
+                    if (row_ok) s.y[row] = out;
+                }
             }
+            __builtin_amdgcn_wave_barrier();
+            const double once = (lane < WROWS && row_ok) ? dots : 0.0;   // each row counted by one lane
+            d_wy += once * (wv * out), d_yy += once * (out * out);
 #pragma unroll
             for (int u = 0; u < U; ++u) rs[u] = rsn[u], re[u] = ren[u], c[u] = cn[u], v[u] = vn[u];
-        }
+        };
+        for (; base + WROWS <= band_end; base += stride) tile(std::true_type {});
+        if (base < band_end) tile(std::false_type {});
     }
     if (s.partial) {
         const double a = block_sum(d_wy, red);

@@ -44,7 +44,7 @@ SYMBOLS = [
     "fdapde_pattern_get", "fdapde_quadrature_nodes", "fdapde_set_operator", "fdapde_set_forcing", "fdapde_set_dirichlet",
     "fdapde_init", "fdapde_assemble_operator", "fdapde_solve", "fdapde_matrix_values", "fdapde_force", "fdapde_solution",
     "fdapde_info_get", "fdapde_spmv", "fdapde_bench_spmv", "fdapde_tune", "fdapde_stream", "fdapde_synchronize",
-    "fdapde_comm_unique_id", "fdapde_comm_init", "fdapde_halo_setup",
+    "fdapde_comm_unique_id", "fdapde_comm_init", "fdapde_halo_setup", "fdapde_solve_parabolic",
 ]
 
 _lib = None
@@ -263,6 +263,19 @@ class Context:
         if rc != OK and (raise_on_noconv or rc != ENOCONV):
             self._check(rc)
         return info
+
+    def solve_parabolic(self, times, initial_condition, dirichlet=None, method=SOLVER_AUTO, rtol=1e-10, maxit=0):
+        """FEMLinearParabolicSolver::solve; dirichlet (n_dofs, n_times) or None -> solution (n_dofs, n_times), Info"""
+        times = np.asarray(times, dtype=float).reshape(-1)
+        m, nd = times.size, self.sizes()["n_dofs"]
+        u0 = np.ascontiguousarray(initial_condition, dtype=float).reshape(-1)
+        g = None if dirichlet is None else np.ascontiguousarray(np.asarray(dirichlet, dtype=float).T).reshape(-1)
+        out = np.zeros(nd * m)
+        opt = Options(method=method, maxit=maxit, rtol=rtol, assembly=0, check_every=0, time_spmv=0)
+        info = Info()
+        self._check(self.lib.fdapde_solve_parabolic(self._ctx, C.byref(opt), int(m), C.c_double(times[1] - times[0]), _dp(u0),
+                                                    None if g is None else _dp(g), _dp(out), C.byref(info)))
+        return np.ascontiguousarray(out.reshape(m, nd).T), info
 
     def info(self):
         info = Info()

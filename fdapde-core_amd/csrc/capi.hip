@@ -751,82 +751,101 @@ int fdapde_init(fdapde_ctx* c, const fdapde_options* opt) {
     return FDAPDE_OK;
 }
 
-int fdapde_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
-    if (!c) return FDAPDE_EINVAL;
-    if (int rc = need_device(c)) return rc;
-    if (!c->dev_ready || !c->assembled[0] || !c->force_ready)
-        return fail(c, FDAPDE_ENOTINIT, "solver must be initialized first!");   // fem_linear_elliptic_solver.h:36
-    HIPCHK(c, hipSetDevice(c->device));
-    const HostSpace& hs = c->hs;
-    const int64_t n = hs.n_dofs;
-    const double rtol = (opt && opt->rtol > 0) ? opt->rtol : 1e-10;
-    int maxit = (opt && opt->maxit > 0) ? opt->maxit : (int)(10 * n < 100000 ? 10 * n : 100000);
-    const int check_every = (opt && opt->check_every > 0) ? opt->check_every : 32;
-    int method = opt ? opt->method : FDAPDE_SOLVER_AUTO;
-    hipStream_t st = c->stream;
-    const int use_bnd = c->have_g ? 1 : 0;
-    const double* A = c->vals[FDAPDE_MAT_STIFF].p;
+}   // extern "C" (the solve is split into helpers shared by the elliptic and the parabolic entry points)
 
-    // multi-GPU: this rank holds the sub-assembled operator / forcing of its own cells
-    const bool dist = c->comm != nullptr && c->halo_ready;
-    const uint8_t* owned = dist ? c->owned.p : nullptr;
-    const double* fvec = c->force.p;
-    HIPCHK(c, hipEventRecord(c->ev0, st));
-    // Dirichlet reduction + Jacobi scaling (see DESIGN.md "Dirichlet handling")
+namespace {
+
+struct SolveState {
+    bool dist = false, diag_positive = true;
+    const uint8_t* owned = nullptr;
+    int use_bnd = 0;
+};
+
+// Dirichlet reduction + Jacobi scaling of the system matrix A (internal slots): scale, sval = diag(s) A diag(s).
+// Done once per matrix (per solve for the elliptic problem, once for all time steps of the parabolic one).
+int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss) {
+    const int64_t n = c->hs.n_dofs;
+    hipStream_t st = c->stream;
+    ss->dist = c->comm != nullptr && c->halo_ready;   // multi-GPU: sub-assembled operator of this rank's cells
+    ss->owned = ss->dist ? c->owned.p : nullptr;
+    ss->use_bnd = use_bnd;
     HIPCHK(c, hipMemsetAsync(c->ctl.p, 0, 4 * sizeof(int32_t), st));
-    if (dist) {   // the diagonal and the forcing vector are sums over the ranks sharing a DOF
+    if (ss->dist) {   // the diagonal is a sum over the ranks sharing a DOF
         hipLaunchKernelGGL(k_diag_extract, dim3(g1(n)), dim3(256), 0, st, n, c->diag.p, A, c->tmp_i.p);
         if (int rc = halo_sum(c, c->tmp_i.p, nullptr, 0)) return rc;
         hipLaunchKernelGGL(k_jacobi_scale_from_diag, dim3(g1(n)), dim3(256), 0, st, n, c->tmp_i.p, c->bnd.p, use_bnd, c->scale.p,
                            c->ctl.p + 3);
-        HIPCHK(c, hipMemcpyAsync(c->tmp_e.p, c->force.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
-        if (int rc = halo_sum(c, c->tmp_e.p, nullptr, 0)) return rc;
-        fvec = c->tmp_e.p;
     } else {
         hipLaunchKernelGGL(k_jacobi_scale, dim3(g1(n)), dim3(256), 0, st, n, c->diag.p, A, c->bnd.p, use_bnd, c->scale.p, c->ctl.p + 3);
     }
     hipLaunchKernelGGL(k_scale_matrix, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, A, c->scale.p, c->sval.p);
-    hipLaunchKernelGGL(k_lift, dim3(g1(n)), dim3(256), 0, st, n, c->bnd.p, c->g.p, use_bnd, c->gt.p);
-    launch_spmv(c, A, c->gt.p, c->y.p, nullptr, nullptr, nullptr);   // y = A g~
-    if (dist) {
-        if (int rc = halo_sum(c, c->y.p, nullptr, 0)) return rc;
-    }
+    HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
-    if (dist) {   // "positive diagonal" (CG admissible) must be ONE decision for all ranks: sum the per-rank flags
+    if (ss->dist) {   // "positive diagonal" (CG admissible) must be ONE decision for all ranks: sum the per-rank flags
         c->h_sc[8] = (double)c->h_ctl[3];
-        HIPCHK(c, hipMemcpyAsync(c->sbuf.p + 1, c->h_sc + 8, sizeof(double), hipMemcpyHostToDevice, st));
-        if (int rc = allreduce_sum(c, c->sbuf.p + 1, 1)) return rc;
-        HIPCHK(c, hipMemcpyAsync(c->h_sc + 8, c->sbuf.p + 1, sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(c->sbuf.p + 2, c->h_sc + 8, sizeof(double), hipMemcpyHostToDevice, st));
+        if (int rc = allreduce_sum(c, c->sbuf.p + 2, 1)) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->h_sc + 8, c->sbuf.p + 2, sizeof(double), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
         c->h_ctl[3] = c->h_sc[8] != 0.0 ? 1 : 0;
     }
-    const bool diag_positive = c->h_ctl[3] == 0;
-    if (method == FDAPDE_SOLVER_AUTO) method = (c->op_symmetric && diag_positive) ? FDAPDE_SOLVER_CG : FDAPDE_SOLVER_BICGSTAB;
-    if (method == FDAPDE_SOLVER_CG && !diag_positive)
+    ss->diag_positive = c->h_ctl[3] == 0;
+    return FDAPDE_OK;
+}
+
+// Krylov solve of A u = f with u = g on the Dirichlet DOFs (if ss.use_bnd), on the system prepared by solve_prepare.
+//   f_dev : right-hand side, internal order, sub-assembled (summed over ranks here when dist)
+//   g_dev : Dirichlet values, internal order (read on boundary DOFs only)
+//   u0_dev: initial guess in u-space or nullptr (cold start)
+// Result in c->u.  Fills c->info (iters, relres, converged, method_used, spmv timing).
+int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double* f_dev, const double* g_dev, const double* u0_dev,
+              int method, double rtol, int maxit, int check_every, int n_timed) {
+    const int64_t n = c->hs.n_dofs;
+    hipStream_t st = c->stream;
+    const bool dist = ss.dist;
+    const uint8_t* owned = ss.owned;
+    const double* fvec = f_dev;
+    if (dist) {   // the forcing vector is a sum over the ranks sharing a DOF
+        HIPCHK(c, hipMemcpyAsync(c->tmp_e.p, f_dev, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+        if (int rc = halo_sum(c, c->tmp_e.p, nullptr, 0)) return rc;
+        fvec = c->tmp_e.p;
+    }
+    hipLaunchKernelGGL(k_lift, dim3(g1(n)), dim3(256), 0, st, n, c->bnd.p, g_dev, ss.use_bnd, c->gt.p);
+    launch_spmv(c, A, c->gt.p, c->y.p, nullptr, nullptr, nullptr);   // y = A g~
+    if (dist)
+        if (int rc = halo_sum(c, c->y.p, nullptr, 0)) return rc;
+    if (method == FDAPDE_SOLVER_AUTO) method = (c->op_symmetric && ss.diag_positive) ? FDAPDE_SOLVER_CG : FDAPDE_SOLVER_BICGSTAB;
+    if (method == FDAPDE_SOLVER_CG && !ss.diag_positive)
         return fail(c, FDAPDE_ENOCONV, "CG needs a positive diagonal (operator not SPD?); use BiCGStab");
     const bool bicg = method == FDAPDE_SOLVER_BICGSTAB;
     if (dist && bicg) return fail(c, FDAPDE_EUNSUPPORTED, "the element-partitioned solve implements CG only (BiCGStab: single GPU)");
-    hipLaunchKernelGGL(k_krylov_init, dim3(c->vec_grid), dim3(256), 0, st, n, fvec, c->y.p, c->scale.p, c->x.p, c->r.p,
-                       c->p.p, bicg ? c->r0.p : (double*)nullptr, c->part_b.p, owned);
+    const double tol2 = rtol * rtol;
+    const double* ax = nullptr;
+    if (u0_dev) {   // warm start: x = (u0 - g~) / s, r = b~ - At x
+        if (dist) return fail(c, FDAPDE_EUNSUPPORTED, "warm start is single GPU only");
+        hipLaunchKernelGGL(k_krylov_init, dim3(c->vec_grid), dim3(256), 0, st, n, fvec, c->y.p, c->scale.p, c->x.p, c->r.p, c->p.p,
+                           (double*)nullptr, c->part_b.p, owned, u0_dev, c->gt.p, (const double*)nullptr, 1);
+        launch_spmv(c, c->sval.p, c->x.p, c->t.p, nullptr, nullptr, nullptr);
+        ax = c->t.p;
+    }
+    hipLaunchKernelGGL(k_krylov_init, dim3(c->vec_grid), dim3(256), 0, st, n, fvec, c->y.p, c->scale.p, c->x.p, c->r.p, c->p.p,
+                       bicg ? c->r0.p : (double*)nullptr, c->part_b.p, owned, u0_dev, c->gt.p, ax, 0);
     if (dist) {
-        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, c->part_b.p, c->vec_grid, c->sbuf.p);
-        if (int rc = allreduce_sum(c, c->sbuf.p, 1)) return rc;
-        hipLaunchKernelGGL(k_krylov_init_fin, dim3(1), dim3(256), 0, st, c->sbuf.p, 1, c->sc.p, c->ctl.p);
+        hipLaunchKernelGGL(k_reduce_partials2, dim3(1), dim3(256), 0, st, c->part_b.p, c->vec_grid, c->sbuf.p);
+        if (int rc = allreduce_sum(c, c->sbuf.p, 2)) return rc;
+        hipLaunchKernelGGL(k_krylov_init_fin, dim3(1), dim3(256), 0, st, c->sbuf.p, 1, c->sc.p, c->ctl.p, tol2);
     } else {
-        hipLaunchKernelGGL(k_krylov_init_fin, dim3(1), dim3(256), 0, st, c->part_b.p, c->vec_grid, c->sc.p, c->ctl.p);
+        hipLaunchKernelGGL(k_krylov_init_fin, dim3(1), dim3(256), 0, st, c->part_b.p, c->vec_grid, c->sc.p, c->ctl.p, tol2);
     }
     HIPCHK(c, hipGetLastError());
-    const double tol2 = rtol * rtol;
-    int n_timed = opt ? opt->time_spmv : 0;
     n_timed = n_timed < 0 ? 0 : (n_timed > 256 ? 256 : n_timed);
     while ((int)c->ev_spmv.size() < 2 * n_timed) {
         hipEvent_t e;
         HIPCHK(c, hipEventCreate(&e));
         c->ev_spmv.push_back(e);
     }
-    int timed = 0;
-    int launched = 0;
+    int timed = 0, launched = 0;
     bool stop = false;
     while (!stop && launched < maxit) {
         const int chunk = (maxit - launched) < check_every ? (maxit - launched) : check_every;
@@ -875,17 +894,18 @@ int fdapde_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
         HIPCHK(c, hipStreamSynchronize(st));
         stop = c->h_ctl[0] != 0;
     }
+    if (launched == 0) {   // already converged at the initial guess
+        HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(c->h_sc, c->sc.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
     hipLaunchKernelGGL(k_unscale, dim3(g1(n)), dim3(256), 0, st, n, c->scale.p, c->x.p, c->gt.p, c->u.p);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(c->ev1, st));
-    HIPCHK(c, hipEventSynchronize(c->ev1));
-    float ms = 0;
-    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    const double rr0 = c->h_sc[0], rr = c->h_sc[3];
-    c->info.t_solve_ms = ms;
+    HIPCHK(c, hipStreamSynchronize(st));
+    const double bb = c->h_sc[0], rr = c->h_sc[3];
     c->info.iters = c->h_ctl[1];
-    c->info.relres = rr0 > 0 ? sqrt(rr / rr0) : 0.0;
-    c->info.converged = (rr <= tol2 * rr0 && c->h_ctl[2] == 0) ? 1 : 0;
+    c->info.relres = bb > 0 ? sqrt(rr / bb) : 0.0;
+    c->info.converged = (rr <= tol2 * bb && c->h_ctl[2] == 0) ? 1 : 0;
     c->info.method_used = method;
     c->info.spmv_avg_ms = 0, c->info.spmv_timed = 0;
     {   // launches after the stop flag return at once; only iterations that really ran are averaged
@@ -898,13 +918,111 @@ int fdapde_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
         }
         if (real > 0) c->info.spmv_avg_ms = sum / real, c->info.spmv_timed = real;
     }
-    c->solved = true, c->dirichlet_applied = c->have_g;
-    if (info) *info = c->info;
     if (!c->info.converged) {
         c->err = c->h_ctl[2] ? "Krylov breakdown (operator not SPD for CG, or BiCGStab rho/omega = 0)" : "maxit reached";
         return FDAPDE_ENOCONV;   // reference: success = false (fem_linear_elliptic_solver.h:42-45)
     }
     return FDAPDE_OK;
+}
+
+}   // namespace
+
+extern "C" {
+
+int fdapde_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
+    if (!c) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (!c->dev_ready || !c->assembled[0] || !c->force_ready)
+        return fail(c, FDAPDE_ENOTINIT, "solver must be initialized first!");   // fem_linear_elliptic_solver.h:36
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t n = c->hs.n_dofs;
+    const double rtol = (opt && opt->rtol > 0) ? opt->rtol : 1e-10;
+    const int maxit = (opt && opt->maxit > 0) ? opt->maxit : (int)(10 * n < 100000 ? 10 * n : 100000);
+    const int check_every = (opt && opt->check_every > 0) ? opt->check_every : 32;
+    const double* A = c->vals[FDAPDE_MAT_STIFF].p;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    SolveState ss;
+    if (int rc = solve_prepare(c, A, c->have_g ? 1 : 0, &ss)) return rc;
+    const int rc = solve_run(c, ss, A, c->force.p, c->g.p, nullptr, opt ? opt->method : FDAPDE_SOLVER_AUTO, rtol, maxit, check_every,
+                             opt ? opt->time_spmv : 0);
+    if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->info.t_solve_ms = ms;
+    c->solved = true, c->dirichlet_applied = c->have_g;
+    if (info) *info = c->info;
+    return rc;
+}
+
+// FEMLinearParabolicSolver::solve (fdaPDE/finite_elements/solvers/fem_linear_parabolic_solver.h:37-72): implicit Euler,
+//   K = M / dt + A ; Dirichlet rows of K ; for i = 0 .. m-2:  rhs = (M / dt) u_i + f_{i+1} ; rhs[boundary] = g(., i+1) ;
+//   u_{i+1} = K^{-1} rhs.   The reference factorises K once with SparseLU; here K is scaled once and every step is a
+//   Jacobi-PCG (or BiCGStab) solve warm-started from u_i.  Forcing columns come from fdapde_set_forcing (n_times columns).
+int fdapde_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times, double delta_t, const double* initial_condition,
+                           const double* dirichlet, double* solution, fdapde_info* info) {
+    if (!c || n_times < 1 || !(delta_t > 0) || !initial_condition || !solution) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (!c->dev_ready || !c->assembled[0] || !c->assembled[1] || !c->force_ready)
+        return fail(c, FDAPDE_ENOTINIT, "solver must be initialized first!");   // fem_linear_parabolic_solver.h:39
+    if (c->comm && c->halo_ready) return fail(c, FDAPDE_EUNSUPPORTED, "the parabolic stepper is single GPU only");
+    if (c->fq_cols < n_times) return fail(c, FDAPDE_EINVAL, "forcing data needs one column per time point");
+    HIPCHK(c, hipSetDevice(c->device));
+    const HostSpace& hs = c->hs;
+    const int64_t n = hs.n_dofs;
+    hipStream_t st = c->stream;
+    const double rtol = (opt && opt->rtol > 0) ? opt->rtol : 1e-10;
+    const int maxit = (opt && opt->maxit > 0) ? opt->maxit : (int)(10 * n < 100000 ? 10 * n : 100000);
+    const int check_every = (opt && opt->check_every > 0) ? opt->check_every : 8;
+    const double inv_dt = 1.0 / delta_t;
+    DBuf<double> kmat, uprev, rhs, gcol;
+    HIPCHK(c, kmat.alloc((size_t)hs.nnz + 2));
+    HIPCHK(c, uprev.alloc((size_t)n));
+    HIPCHK(c, rhs.alloc((size_t)n));
+    HIPCHK(c, gcol.alloc((size_t)n));
+    std::vector<double> tmp((size_t)n);
+    auto to_internal = [&](const double* ext) {
+        for (int64_t i = 0; i < n; ++i) tmp[(size_t)i] = ext[hs.dof_i2e[(size_t)i]];
+    };
+    HIPCHK(c, hipEventRecord(c->ev0, st));
+    hipLaunchKernelGGL(k_matrix_combine, dim3(g1(hs.nnz)), dim3(256), 0, st, hs.nnz, c->vals[FDAPDE_MAT_MASS].p,
+                       c->vals[FDAPDE_MAT_STIFF].p, inv_dt, kmat.p);
+    SolveState ss;
+    if (int rc = solve_prepare(c, kmat.p, dirichlet ? 1 : 0, &ss)) return rc;
+    to_internal(initial_condition);
+    HIPCHK(c, hipMemcpyAsync(uprev.p, tmp.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    std::memcpy(solution, initial_condition, sizeof(double) * (size_t)n);   // solution_.col(0) = initial condition (line 46)
+    int total_iters = 0, rc_all = FDAPDE_OK;
+    double worst = 0;
+    for (int32_t i = 0; i + 1 < n_times; ++i) {
+        launch_spmv(c, c->vals[FDAPDE_MAT_MASS].p, uprev.p, c->s.p, nullptr, nullptr, nullptr);   // M u_i
+        hipLaunchKernelGGL(k_parabolic_rhs, dim3(g1(n)), dim3(256), 0, st, n, c->s.p, inv_dt, c->force.p + (size_t)(i + 1) * n, rhs.p);
+        if (dirichlet) {
+            to_internal(dirichlet + (size_t)(i + 1) * n);
+            HIPCHK(c, hipMemcpyAsync(gcol.p, tmp.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+        }
+        const int rc = solve_run(c, ss, kmat.p, rhs.p, gcol.p, uprev.p, opt ? opt->method : FDAPDE_SOLVER_AUTO, rtol, maxit,
+                                 check_every, 0);
+        if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;
+        if (rc == FDAPDE_ENOCONV) rc_all = rc;
+        total_iters += c->info.iters;
+        worst = c->info.relres > worst ? c->info.relres : worst;
+        HIPCHK(c, hipMemcpyAsync(uprev.p, c->u.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_scatter_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->u.p, c->tmp_e.p);
+        HIPCHK(c, hipMemcpyAsync(solution + (size_t)(i + 1) * n, c->tmp_e.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
+    HIPCHK(c, hipEventRecord(c->ev1, st));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->info.t_solve_ms = ms, c->info.iters = total_iters, c->info.relres = worst, c->info.converged = rc_all == FDAPDE_OK ? 1 : 0;
+    if (info) *info = c->info;
+    kmat.release(), uprev.release(), rhs.release(), gcol.release();
+    return rc_all;
 }
 
 int fdapde_matrix_values(fdapde_ctx* c, int32_t which, double* values) {

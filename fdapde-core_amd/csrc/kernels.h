@@ -847,31 +847,66 @@ __global__ void k_lift(int64_t n, const uint8_t* bnd, const double* g, int use_b
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) gt[i] = (use_bnd && bnd[i]) ? g[i] : 0.0;
 }
-// r = scale * (f - A gt)  (y holds A gt), x = 0, p = r; partial[block] = sum r^2
+// bt = scale * (f - A gt)  (y holds A gt): right-hand side of the scaled interior system.
+// Cold start (u0 == nullptr): x = 0, r = bt.  Warm start: x = (u0 - gt) / scale on interior DOFs, r = bt - ax where ax holds
+// At x (one extra SpMV by the caller between the two launches: first launch with ax == nullptr only fills x).
+// partial[2 b] = sum r^2, partial[2 b + 1] = sum bt^2 (the stopping rule is relative to ||bt||, not to the warm residual).
 __global__ __launch_bounds__(256) void k_krylov_init(int64_t n, const double* f, const double* y, const double* scale,
                                                       double* x, double* r, double* p, double* r0, double* partial,
-                                                      const uint8_t* owned) {
+                                                      const uint8_t* owned, const double* u0, const double* gt,
+                                                      const double* ax, int fill_x_only) {
     __shared__ double red[8];
-    double acc = 0;
+    double acc = 0, accb = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const double ri = scale[i] * (f[i] - y[i]);
-        x[i] = 0.0, r[i] = ri, p[i] = ri;
+        if (fill_x_only) {
+            x[i] = scale[i] > 0.0 ? (u0[i] - gt[i]) / scale[i] : 0.0;
+            continue;
+        }
+        const double bt = scale[i] * (f[i] - y[i]);
+        const double ri = ax ? bt - ax[i] : bt;
+        if (!u0) x[i] = 0.0;
+        r[i] = ri, p[i] = ri;
         if (r0) r0[i] = ri;
-        if (!owned || owned[i]) acc += ri * ri;
+        if (!owned || owned[i]) acc += ri * ri, accb += bt * bt;
     }
+    if (fill_x_only) return;
     const double s = block_sum(acc, red);
-    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+    const double sb = block_sum(accb, red);
+    if (threadIdx.x == 0) partial[2 * blockIdx.x] = s, partial[2 * blockIdx.x + 1] = sb;
 }
-// scalars layout (device doubles): [0] rr0, [1] rr_even, [2] rr_odd, [3] last rr, [4..] method specific
+// scalars layout (device doubles): [0] reference norm^2 (||bt||^2), [1] rr_even, [2] rr_odd, [3] last rr, [4..] method specific
 // ctl layout (device int32): [0] stop flag, [1] iterations done, [2] breakdown flag
-__global__ __launch_bounds__(256) void k_krylov_init_fin(const double* partial, int np, double* sc, int32_t* ctl) {
+__global__ __launch_bounds__(256) void k_krylov_init_fin(const double* partial, int np, double* sc, int32_t* ctl, double tol2) {
     __shared__ double red[8];
-    const double rr = sum_partials(partial, np, red);
+    double a = 0, b = 0;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) a += partial[2 * i], b += partial[2 * i + 1];
+    const double rr = block_sum(a, red);
+    const double bb = block_sum(b, red);
     if (threadIdx.x == 0) {
-        sc[0] = rr, sc[1] = rr, sc[2] = rr, sc[3] = rr;
+        sc[0] = bb, sc[1] = rr, sc[2] = rr, sc[3] = rr;
         sc[4] = 1.0, sc[5] = 1.0, sc[6] = 1.0;   // bicgstab: rho, alpha, omega
-        ctl[0] = rr == 0.0 ? 1 : 0, ctl[1] = 0, ctl[2] = 0;
+        sc[9] = rr;                               // bicgstab: (r0, r0) of the first iteration
+        ctl[0] = rr <= tol2 * bb ? 1 : 0, ctl[1] = 0, ctl[2] = 0;
     }
+}
+// out[0], out[1] = sums of the stride-2 partial pairs, fixed order; single workgroup
+__global__ __launch_bounds__(256) void k_reduce_partials2(const double* part, int np, double* out) {
+    __shared__ double red[8];
+    double a = 0, b = 0;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) a += part[2 * i], b += part[2 * i + 1];
+    const double sa = block_sum(a, red);
+    const double sb = block_sum(b, red);
+    if (threadIdx.x == 0) out[0] = sa, out[1] = sb;
+}
+// K = M / dt + A  (FEMLinearParabolicSolver::solve, fem_linear_parabolic_solver.h:49), same pattern, elementwise
+__global__ void k_matrix_combine(int64_t nnz, const double* mass, const double* stiff, double inv_dt, double* out) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nnz) out[k] = mass[k] * inv_dt + stiff[k];
+}
+// rhs = mu * inv_dt + f   (mu = M u_i)
+__global__ void k_parabolic_rhs(int64_t n, const double* mu, double inv_dt, const double* f, double* rhs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rhs[i] = mu[i] * inv_dt + f[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -980,7 +1015,7 @@ __global__ __launch_bounds__(256) void k_bicg_p(int64_t n, const double* r, cons
     if (__syncthreads_or(ctl[0] != 0)) return;   // uniform even if another workgroup raises the flag meanwhile
     double a = 0;
     for (int i = threadIdx.x; i < np_in; i += blockDim.x) a += part_in[2 * i];
-    const double rho_new = first ? sc[0] : block_sum(a, red);
+    const double rho_new = first ? sc[9] : block_sum(a, red);
     const double rho = sc[4], alpha = sc[5], omega = sc[6];
     const double beta = first ? 0.0 : (rho_new / rho) * (alpha / omega);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)

@@ -130,6 +130,14 @@ int fdapde_assemble_operator(fdapde_ctx *ctx, int32_t which, int32_t n_terms, co
  *      (fem_linear_elliptic_solver.h:34-50; Eigen::SparseLU replaced by Jacobi-PCG / BiCGStab on the interior block) */
 int fdapde_solve(fdapde_ctx *ctx, const fdapde_options *opt, fdapde_info *info);
 
+/* ---- FEMLinearParabolicSolver::solve (finite_elements/solvers/fem_linear_parabolic_solver.h:37-72): implicit Euler ---------
+ * Needs fdapde_init with one forcing column per time point (fem_solver_base.h:118-128).  delta_t = times[1] - times[0] (line
+ * 42); initial_condition[n_dofs] (pde.h:77); dirichlet column-major n_dofs x n_times or NULL (column i+1 is imposed at step
+ * i, line 66); solution column-major n_dofs x n_times, column 0 = initial condition (line 46).
+ * info.iters = Krylov iterations over all steps, info.relres = worst step. */
+int fdapde_solve_parabolic(fdapde_ctx *ctx, const fdapde_options *opt, int32_t n_times, double delta_t,
+                           const double *initial_condition, const double *dirichlet, double *solution, fdapde_info *info);
+
 /* ---- getters (fem_solver_base.h:50-53) ------------------------------------------------------------------------- */
 /* values[nnz] aligned with fdapde_pattern_get.  After a solve with Dirichlet data, FDAPDE_MAT_STIFF is the
  * row-zeroed matrix the reference leaves in stiff_ (rows of boundary DOFs zero, unit diagonal). */

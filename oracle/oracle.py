@@ -501,3 +501,32 @@ def pde_init_solve(mesh: Mesh, order: int, op: Operator, forcing_q=None, forcing
     else:
         u = solve_direct(A, b)
     return Solved(A, Mm, b, u, dofs, bnd, nd, coords)
+
+
+def pde_parabolic_solve(mesh: Mesh, order: int, op: Operator, times, forcing_q, dirichlet, initial_condition):
+    """PDE::init + FEMLinearParabolicSolver::solve (fem_linear_parabolic_solver.h:37-72): implicit Euler with one LU of
+    K = M/dt + A (Dirichlet rows zeroed, unit diagonal).  forcing_q: (nq*n_cells, m); dirichlet: (n_dofs, m) or None.
+    -> solution (n_dofs, m), mass CSR"""
+    import scipy.sparse.linalg as spla
+
+    times = np.asarray(times, dtype=float).reshape(-1)
+    m = times.size
+    dofs, bnd, nd, _ = enumerate_dofs(mesh, order)
+    A = assemble_operator(mesh, order, dofs, nd, op)
+    Mm = assemble_operator(mesh, order, dofs, nd, reaction(1.0))
+    force = np.stack([assemble_forcing(mesh, order, dofs, nd, forcing_q[:, j]) for j in range(m)], axis=1)
+    dt_ = times[1] - times[0]                                  # line 42
+    K = CSR(A.rowptr.copy(), A.colidx.copy(), Mm.values / dt_ + A.values, nd)   # line 49 (same pattern)
+    isb = bnd.astype(bool) if dirichlet is not None else np.zeros(nd, bool)
+    if dirichlet is not None:
+        dummy = np.zeros(nd)
+        set_dirichlet(K, dummy, bnd, np.zeros(nd))             # lines 51-54: rows zeroed, unit diagonal
+    lu = spla.splu(K.to_scipy().tocsc())
+    sol = np.zeros((nd, m))
+    sol[:, 0] = np.asarray(initial_condition, dtype=float).reshape(-1)          # line 46
+    for i in range(m - 1):
+        rhs = Mm.matvec(sol[:, i]) / dt_ + force[:, i + 1]     # line 63
+        if dirichlet is not None:
+            rhs[isb] = np.asarray(dirichlet)[isb, i + 1]       # lines 65-67
+        sol[:, i + 1] = lu.solve(rhs)
+    return sol, Mm

@@ -355,3 +355,37 @@ def test_space_varying_coefficients_match_constants(oracle, mesh_loader):
         A = oracle.assemble_operator(m, order, dofs, nd, const)
         B = oracle.assemble_operator(m, order, dofs, nd, var)
         assert np.array_equal(A.colidx, B.colidx) and np.array_equal(A.values, B.values)
+
+
+def _parabolic_problem(o, m, order, n_times):
+    pi = np.pi
+    times = np.linspace(0.0, 1.0, n_times)
+    u = lambda x, t: np.sin(2 * pi * x[:, 0]) * np.sin(2 * pi * x[:, 1]) * np.exp(-t)
+    f = lambda x, t: (8 * pi * pi - 1.0) * np.sin(2 * pi * x[:, 0]) * np.sin(2 * pi * x[:, 1]) * np.exp(-t)
+    dofs, _, nd, _ = o.enumerate_dofs(m, order)
+    coords = o.dofs_coords(m, order, dofs, nd)
+    qn = o.quadrature_nodes(m, order)
+    F = np.stack([f(qn, t) for t in times], axis=1)
+    G = np.stack([u(coords, t) for t in times], axis=1)
+    return times, F, G, G[:, 0].copy()
+
+
+def test_pde_parabolic_isotropic_order2(oracle, mesh_loader):
+    """fem_pde_test.cpp:222-285: dt(u) - Lap(u) = f, P2, 101 time points, max_t sum(M err^2) < 1e-7"""
+    m = mesh_loader("unit_square")
+    times, F, G, u0 = _parabolic_problem(oracle, m, 2, 101)
+    sol, Mm = oracle.pde_parabolic_solve(m, 2, oracle.dt() - oracle.laplacian(), times, F, G, u0)
+    errs = [float(np.sum(Mm.matvec((G[:, j] - sol[:, j]) ** 2))) for j in range(times.size)]
+    assert max(errs) < 1e-7
+
+
+def test_pde_parabolic_order1_convergence(oracle, mesh_loader):
+    """fem_pde_test.cpp:295-368: P1, 31 time points, meshes 16/32/64 (the 128 fixture is 3 MB and not copied): order 2"""
+    errs = []
+    for name in ("unit_square_16", "unit_square_32", "unit_square_64"):
+        m = mesh_loader(name)
+        times, F, G, u0 = _parabolic_problem(oracle, m, 1, 31)
+        sol, Mm = oracle.pde_parabolic_solve(m, 1, oracle.dt() - oracle.laplacian(), times, F, G, u0)
+        errs.append(np.sqrt(float(np.sum(Mm.matvec((G[:, -1] - sol[:, -1]) ** 2)))))
+    for a, b in zip(errs[:-1], errs[1:]):
+        assert np.floor(np.log2(a / b)) == 2

@@ -151,6 +151,13 @@ def main():
 
     if rank != 0:
         return
+    traffic = None   # HBM bytes per SpMV launch from the committed rocprofv3 PMC passes (tools/profile_gpu.sh), if any
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "spmv_pmc.json")))
+        if world == 1 and pj.get("nx") == args.nx:
+            traffic = pj.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
     ms_per_step = 1e3 * elapsed / args.steps
     achieved = alg_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
     out = {
@@ -183,7 +190,7 @@ def main():
         "roofline": {
             "bound": "hbm", "kernel": "k_spmv (CSR SpMV fused with p.Ap inside CG)",
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": None,
+            "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": spmv_ms,
         },
     }

@@ -410,6 +410,7 @@ void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, 
             case 128: SPMV_GO(k_spmv_team2<8, 4, 128>); break;   // nontemporal y store
             case 256: SPMV_GO(k_spmv_team2<8, 4, 256>); break;   // y stores confined to 32 KiB
             case 512: SPMV_GO(k_spmv_team2<8, 4, 512>); break;   // 16-byte y stores
+            case 1024: SPMV_GO(k_spmv_team2<8, 4, 1024>); break;   // sc1 (write-through, no L2 allocate) y stores
             case 24: SPMV_GO(k_spmv_team2<8, 4, 24>); break;
             default:
                 if (c->spmv_unroll == 2)
@@ -1152,6 +1153,14 @@ int fdapde_bench_spmv(fdapde_ctx* c, int32_t reps, double* avg_ms, double* algor
             HIPCHK(c, hipEventElapsedTime(&pm, c->ev0, c->ev1));
             std::fprintf(stderr, "stream_probe_unaligned grid=%d: %.2f us -> %.0f GB/s\n", grid, pm / 50 * 1e3,
                          n2 * 24 / (pm / 50 * 1e-3) / 1e9);
+            HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+            for (int i = 0; i < 50; ++i)
+                hipLaunchKernelGGL(k_stream_probe_w, dim3(grid), dim3(256), 0, c->stream, reinterpret_cast<const double2*>(A),
+                                   reinterpret_cast<const int2*>(c->colidx.p), n2, c->tmp_v.p);
+            HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+            HIPCHK(c, hipEventSynchronize(c->ev1));
+            HIPCHK(c, hipEventElapsedTime(&pm, c->ev0, c->ev1));
+            std::fprintf(stderr, "stream_probe + %.1f MB of writes grid=%d: %.2f us\n", n2 / 8 * 8 / 1e6, grid, pm / 50 * 1e3);
         }
     }
     if (avg_ms) *avg_ms = (double)ms / reps;

@@ -641,6 +641,23 @@ __global__ __launch_bounds__(256) void k_stream_probe(const double2* vals2, cons
     if (acc == 1.2345e-300) sink[0] = acc;
 }
 
+// matrix-stream probe + a small write stream: every lane writes one double per 8 pairs it reads (about the y / matrix byte
+// ratio of the SpMV), contiguous across the wavefront
+__global__ __launch_bounds__(256) void k_stream_probe_w(const double2* vals2, const int2* col2, int64_t n2, double* out) {
+    const int64_t nth = (int64_t)gridDim.x * blockDim.x, tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t i = tid, o = tid;
+    while (i < n2) {
+        double acc = 0;
+        for (int k = 0; k < 8 && i < n2; ++k, i += nth) {
+            const v2f64_t v = __builtin_nontemporal_load(reinterpret_cast<const v2f64_t*>(vals2) + i);
+            const v2i32_t c = __builtin_nontemporal_load(reinterpret_cast<const v2i32_t*>(col2) + i);
+            acc += v.x * c.x + v.y * c.y;
+        }
+        out[o] = acc;
+        o += nth;
+    }
+}
+
 // Team form with two consecutive entries per lane: every val load instruction is 16 B per lane (1 KiB per wavefront, the
 // widest global access), every colidx load 8 B per lane.  T lanes cover 2 T entries of a row per pass.  The CSR value /
 // index arrays carry two padding entries so that the pair load of a row's last odd entry stays in bounds; the pair base
@@ -797,6 +814,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
                         const int j = lane % (WROWS / 2);
                         const double2 o2 = make_double2(ys[2 * j], ys[2 * j + 1]);
                         *reinterpret_cast<double2*>(s.y + base + 2 * j) = o2;
+                    } else if constexpr (ABL & 1024) {
+                        // agent-scope relaxed store = global_store ... sc1: written through, the line is not kept in this
+                        // XCD's L2 (MI355X_MICROARCH.md, stores of each flavour), leaving the L2 to the gathered x
+                        __hip_atomic_store(s.y + row, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     } else
                         s.y[row] = out;
                 } else {

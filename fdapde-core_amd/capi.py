@@ -45,6 +45,7 @@ SYMBOLS = [
     "fdapde_init", "fdapde_assemble_operator", "fdapde_solve", "fdapde_matrix_values", "fdapde_force", "fdapde_solution",
     "fdapde_info_get", "fdapde_spmv", "fdapde_bench_spmv", "fdapde_tune", "fdapde_stream", "fdapde_synchronize",
     "fdapde_comm_unique_id", "fdapde_comm_init", "fdapde_halo_setup", "fdapde_solve_parabolic",
+    "fdapde_lin_compute", "fdapde_lin_solve",
 ]
 
 _lib = None
@@ -276,6 +277,24 @@ class Context:
         self._check(self.lib.fdapde_solve_parabolic(self._ctx, C.byref(opt), int(m), C.c_double(times[1] - times[0]), _dp(u0),
                                                     None if g is None else _dp(g), _dp(out), C.byref(info)))
         return np.ascontiguousarray(out.reshape(m, nd).T), info
+
+    def lin_compute(self, which=MAT_STIFF, values=None, symmetric=False):
+        """fdapde::SparseLU::compute: 'factor once'"""
+        v = None if values is None else np.ascontiguousarray(values, dtype=float)
+        self._check(self.lib.fdapde_lin_compute(self._ctx, which, None if v is None else _dp(v), 1 if symmetric else 0))
+
+    def lin_solve(self, b, method=SOLVER_AUTO, rtol=1e-10):
+        """fdapde::SparseLU::solve(b); b (n_dofs,) or (n_dofs, n_rhs)"""
+        b = np.asarray(b, dtype=float)
+        one = b.ndim == 1
+        B = b.reshape(b.shape[0], -1)
+        flat = np.ascontiguousarray(B.T).reshape(-1)
+        out = np.zeros_like(flat)
+        opt = Options(method=method, maxit=0, rtol=rtol, assembly=0, check_every=0, time_spmv=0)
+        info = Info()
+        self._check(self.lib.fdapde_lin_solve(self._ctx, C.byref(opt), _dp(flat), B.shape[1], _dp(out), C.byref(info)))
+        X = np.ascontiguousarray(out.reshape(B.shape[1], B.shape[0]).T)
+        return (X[:, 0] if one else X), info
 
     def info(self):
         info = Info()

@@ -83,6 +83,16 @@ struct HostTerm {
 
 }  // namespace
 
+// what solve_prepare decided for a system matrix (shared by the elliptic, parabolic and handle solves)
+struct SolveState {
+    bool dist = false, diag_positive = true;
+    const uint8_t* owned = nullptr;
+    int use_bnd = 0;
+};
+struct SolveStateHolder {
+    SolveState ss;
+};
+
 struct fdapde_ctx {
     int device = -1;
     bool has_device = false;
@@ -131,6 +141,10 @@ struct fdapde_ctx {
     DBuf<int32_t> halo_dof, halo_pos;        // local interface DOF (internal id) -> slot in the global interface vector
     DBuf<uint8_t> owned;                     // internal DOF order: 1 = this rank counts the DOF in global dot products
     DBuf<double> hbuf, sbuf;                 // [n_if + 2] packed interface values + fused dot partials; [4] scalars
+    // "factor once, solve many" handle (fdapde::SparseLU wrapper, utils/symbols.h:133-160)
+    DBuf<double> lin_mat;                    // the matrix handed to fdapde_lin_compute, internal slots
+    bool lin_ready = false, lin_symmetric = false;
+    SolveStateHolder* lin_state = nullptr;
 };
 
 namespace {
@@ -541,12 +555,14 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
         c->bc_off.release(), c->bn_off.release(), c->bc_cell.release(), c->bn_node.release(), c->bc_vert.release();
         c->halo_dof.release(), c->halo_pos.release(), c->owned.release(), c->hbuf.release(), c->sbuf.release();
         if (c->comm) (void)g_rccl.CommDestroy(c->comm);
+        c->lin_mat.release();
         if (c->h_ctl) (void)hipHostFree(c->h_ctl);
         if (c->h_sc) (void)hipHostFree(c->h_sc);
         (void)hipEventDestroy(c->ev0), (void)hipEventDestroy(c->ev1);
         for (hipEvent_t e : c->ev_spmv) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(c->stream);
     }
+    delete c->lin_state;
     delete c;
 }
 
@@ -567,7 +583,7 @@ int fdapde_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs) {
     c->space_ready = c->dev_ready = c->colour_ready = false;
     c->assembled[0] = c->assembled[1] = c->force_ready = c->solved = c->dirichlet_applied = false;
     c->op.clear(), c->fq_i.clear(), c->fq_cols = 0, c->g_i.clear(), c->have_g = false;
-    c->halo_ready = false;
+    c->halo_ready = false, c->lin_ready = false;
     int rc = host_build_space(c->hs, order, c->err);
     if (rc) return rc;
     rc = build_basis_tables(c->hs.M, order, &c->tb);
@@ -756,11 +772,7 @@ int fdapde_init(fdapde_ctx* c, const fdapde_options* opt) {
 
 namespace {
 
-struct SolveState {
-    bool dist = false, diag_positive = true;
-    const uint8_t* owned = nullptr;
-    int use_bnd = 0;
-};
+
 
 // Dirichlet reduction + Jacobi scaling of the system matrix A (internal slots): scale, sval = diag(s) A diag(s).
 // Done once per matrix (per solve for the elliptic problem, once for all time steps of the parabolic one).
@@ -1023,6 +1035,77 @@ int fdapde_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_t
     c->info.t_solve_ms = ms, c->info.iters = total_iters, c->info.relres = worst, c->info.converged = rc_all == FDAPDE_OK ? 1 : 0;
     if (info) *info = c->info;
     kmat.release(), uprev.release(), rhs.release(), gcol.release();
+    return rc_all;
+}
+
+// fdapde::SparseLU<SpMatrix<double>>::compute (fdaPDE/utils/symbols.h:142-146): "factorise" once.  Here: copy the matrix,
+// Jacobi-scale it once; every later fdapde_lin_solve is a Krylov run on the prepared system.
+int fdapde_lin_compute(fdapde_ctx* c, int32_t which, const double* values, int32_t symmetric) {
+    if (!c || which < 0 || which > 1) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (!c->dev_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
+    if (!values && !c->assembled[which]) return fail(c, FDAPDE_ENOTINIT, "matrix not assembled");
+    if (c->comm && c->halo_ready) return fail(c, FDAPDE_EUNSUPPORTED, "the solver handle is single GPU only");
+    HIPCHK(c, hipSetDevice(c->device));
+    const HostSpace& hs = c->hs;
+    HIPCHK(c, c->lin_mat.alloc((size_t)hs.nnz + 2));
+    if (values) {   // reference slot order -> internal slots
+        HIPCHK(c, hipMemcpyAsync(c->tmp_v.p, values, sizeof(double) * (size_t)hs.nnz, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_gather_f64, dim3(g1(hs.nnz)), dim3(256), 0, c->stream, hs.nnz, c->slot_i2e.p, c->tmp_v.p, c->lin_mat.p);
+        HIPCHK(c, hipGetLastError());
+        c->lin_symmetric = symmetric != 0;
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->lin_mat.p, c->vals[which].p, sizeof(double) * (size_t)hs.nnz, hipMemcpyDeviceToDevice, c->stream));
+        c->lin_symmetric = which == FDAPDE_MAT_MASS ? true : c->op_symmetric;
+    }
+    if (!c->lin_state) c->lin_state = new SolveStateHolder();
+    if (int rc = solve_prepare(c, c->lin_mat.p, 0, &c->lin_state->ss)) return rc;
+    c->lin_ready = true, c->solved = false;   // scale / sval now belong to the handle
+    return FDAPDE_OK;
+}
+
+// fdapde::SparseLU::solve(b) (fdaPDE/utils/symbols.h:148-155), dense right-hand sides: b, x column-major n_dofs x n_rhs
+int fdapde_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32_t n_rhs, double* x, fdapde_info* info) {
+    if (!c || !b || !x || n_rhs < 1) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (!c->lin_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_lin_compute first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const HostSpace& hs = c->hs;
+    const int64_t n = hs.n_dofs;
+    hipStream_t st = c->stream;
+    const double rtol = (opt && opt->rtol > 0) ? opt->rtol : 1e-10;
+    const int maxit = (opt && opt->maxit > 0) ? opt->maxit : (int)(10 * n < 100000 ? 10 * n : 100000);
+    const int check_every = (opt && opt->check_every > 0) ? opt->check_every : 32;
+    int method = opt ? opt->method : FDAPDE_SOLVER_AUTO;
+    if (method == FDAPDE_SOLVER_AUTO)
+        method = (c->lin_symmetric && c->lin_state->ss.diag_positive) ? FDAPDE_SOLVER_CG : FDAPDE_SOLVER_BICGSTAB;
+    if (c->solved) {   // an fdapde_solve in between has overwritten the scaled copy: prepare again (cheap)
+        if (int rc = solve_prepare(c, c->lin_mat.p, 0, &c->lin_state->ss)) return rc;
+        c->solved = false;
+    }
+    DBuf<double> rhs;
+    HIPCHK(c, rhs.alloc((size_t)n));
+    HIPCHK(c, hipEventRecord(c->ev0, st));
+    int total = 0, rc_all = FDAPDE_OK;
+    double worst = 0;
+    for (int32_t j = 0; j < n_rhs; ++j) {
+        HIPCHK(c, hipMemcpyAsync(c->tmp_e.p, b + (size_t)j * n, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_gather_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->tmp_e.p, rhs.p);
+        const int rc = solve_run(c, c->lin_state->ss, c->lin_mat.p, rhs.p, c->g.p, nullptr, method, rtol, maxit, check_every, 0);
+        if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;
+        if (rc == FDAPDE_ENOCONV) rc_all = rc;
+        total += c->info.iters, worst = c->info.relres > worst ? c->info.relres : worst;
+        hipLaunchKernelGGL(k_scatter_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->u.p, c->tmp_e.p);
+        HIPCHK(c, hipMemcpyAsync(x + (size_t)j * n, c->tmp_e.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
+    HIPCHK(c, hipEventRecord(c->ev1, st));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->info.t_solve_ms = ms, c->info.iters = total, c->info.relres = worst, c->info.converged = rc_all == FDAPDE_OK ? 1 : 0;
+    if (info) *info = c->info;
+    rhs.release();
     return rc_all;
 }
 

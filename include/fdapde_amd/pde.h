@@ -155,6 +155,12 @@ class DifferentialExpr {
             if (l.term.kind == FDAPDE_ADVECTION) return false;
         return true;
     }
+    // is_parabolic: the expression contains dT() (pde/differential_operators.h:47-52)
+    bool is_parabolic() const {
+        for (const auto& l : leaves_)
+            if (l.term.kind == FDAPDE_DT) return true;
+        return false;
+    }
     bool is_space_varying() const {
         for (const auto& l : leaves_)
             if (l.term.space_varying) return true;
@@ -220,6 +226,15 @@ template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_H
         domain_(domain), diff_op_(std::move(diff_op)), forcing_data_(forcing) {
         open(device);
     }
+    // space-time constructors (pde.h:66-72): times = the time grid [t_0 ... t_{m-1}], uniform step
+    PDE(const D& domain, const DVector<double>& t, int device = 0) : domain_(domain) {
+        time_domain_ = t;
+        open(device);
+    }
+    PDE(const D& domain, const DVector<double>& t, OperatorType diff_op, int device = 0) : domain_(domain), diff_op_(std::move(diff_op)) {
+        time_domain_ = t;
+        open(device);
+    }
     PDE(const PDE&) = delete;
     PDE& operator=(const PDE&) = delete;
     ~PDE() { fdapde_ctx_destroy(ctx_); }
@@ -228,6 +243,9 @@ template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_H
     void set_forcing(const ForcingType& forcing_data) { forcing_data_ = forcing_data; }
     void set_differential_operator(OperatorType diff_op) { diff_op_ = std::move(diff_op); }
     void set_dirichlet_bc(const DMatrix<double>& data) { boundary_data_ = data; }
+    void set_initial_condition(const DVector<double>& data) { initial_condition_ = data; }
+    const DVector<double>& time_domain() const { return time_domain_; }
+    const DVector<double>& initial_condition() const { return initial_condition_; }
     // getters (pde.h:79-100)
     const D& domain() const { return domain_; }
     OperatorType differential_operator() const { return diff_op_; }
@@ -284,6 +302,10 @@ template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_H
     // PDE::solve (pde.h:102-105): set_dirichlet_bc if boundary data is set, then the linear solve
     void solve() {
         if (!is_init_) throw std::runtime_error("solver must be initialized first!");
+        if (diff_op_.is_parabolic() && !is_empty(time_domain_)) {
+            solve_parabolic();
+            return;
+        }
         if (!is_empty(boundary_data_)) {
             if (boundary_data_.rows() != n_dofs_) throw std::runtime_error("dirichlet data must have n_dofs rows");
             check(fdapde_set_dirichlet(ctx_, boundary_data_.data()));
@@ -303,7 +325,49 @@ template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_H
         success_ = true;
     }
 
+    // "factor once, solve many" handle on one of this PDE's matrices: fdapde::SparseLU (utils/symbols.h:133-160)
+    class SparseSolver {
+       public:
+        // compute(matrix): any matrix on the FEM pattern (e.g. pde.mass(), or a combination of stiff and mass values)
+        void compute(const SpMatrix<double>& m, bool symmetric = false) {
+            computed_ = fdapde_lin_compute(ctx_, FDAPDE_MAT_STIFF, m.values.data(), symmetric ? 1 : 0) == FDAPDE_OK;
+        }
+        DMatrix<double> solve(const DMatrix<double>& b) const {
+            if (!computed_) throw std::runtime_error("SparseSolver: compute() first");
+            DMatrix<double> x(b.rows(), b.cols());
+            fdapde_info info;
+            const int rc = fdapde_lin_solve(ctx_, nullptr, b.data(), (int32_t)b.cols(), x.data(), &info);
+            if (rc != FDAPDE_OK) throw std::runtime_error(fdapde_last_error(ctx_));
+            return x;
+        }
+        explicit operator bool() const { return computed_; }
+       private:
+        friend class PDE;
+        explicit SparseSolver(fdapde_ctx* ctx) : ctx_(ctx) { }
+        fdapde_ctx* ctx_;
+        bool computed_ = false;
+    };
+    SparseSolver make_solver() { return SparseSolver(ctx_); }
+
    private:
+    // FEMLinearParabolicSolver::solve (fem_linear_parabolic_solver.h:37-72)
+    void solve_parabolic() {
+        const int64_t m = time_domain_.rows();
+        if (m < 2) throw std::runtime_error("time domain needs at least two points");
+        if (initial_condition_.rows() != n_dofs_) throw std::runtime_error("initial condition must have n_dofs rows");
+        if (!is_empty(boundary_data_) && (boundary_data_.rows() != n_dofs_ || boundary_data_.cols() < m))
+            throw std::runtime_error("dirichlet data must be n_dofs x n_times");
+        solution_.resize(n_dofs_, m);
+        const double dt_ = time_domain_(1) - time_domain_(0);
+        const int rc = fdapde_solve_parabolic(ctx_, &opt_, (int32_t)m, dt_, initial_condition_.data(),
+                                              is_empty(boundary_data_) ? nullptr : boundary_data_.data(), solution_.data(), &info_);
+        if (rc == FDAPDE_ENOCONV) {
+            success_ = false;
+            return;
+        }
+        check(rc);
+        success_ = true;
+    }
     bool is_empty_forcing() const {
         if constexpr (std::is_same_v<F, DMatrix<double>>) return is_empty(forcing_data_);
         return false;
@@ -350,6 +414,8 @@ template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_H
     const D& domain_;                 // must outlive the PDE (pde.h:107)
     OperatorType diff_op_;
     ForcingType forcing_data_ {};
+    DVector<double> time_domain_ {};         // [t_0 ... t_{m-1}] for space-time problems (pde.h:108)
+    DVector<double> initial_condition_ {};   // pde.h:111
     DMatrix<double> boundary_data_;
     fdapde_ctx* ctx_ = nullptr;
     fdapde_options opt_ {FDAPDE_SOLVER_AUTO, 0, 1e-10, FDAPDE_ASSEMBLY_ROWS, 0, 0};

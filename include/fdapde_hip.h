@@ -138,6 +138,14 @@ int fdapde_solve(fdapde_ctx *ctx, const fdapde_options *opt, fdapde_info *info);
 int fdapde_solve_parabolic(fdapde_ctx *ctx, const fdapde_options *opt, int32_t n_times, double delta_t,
                            const double *initial_condition, const double *dirichlet, double *solution, fdapde_info *info);
 
+/* ---- "factor once, solve many": fdapde::SparseLU<SpMatrix<double>> (fdaPDE/utils/symbols.h:133-160), the handle SMW
+ *      (fdaPDE/linear_algebra/smw.h:38-59) and the downstream models solve against ---------------------------------------
+ * fdapde_lin_compute = ::compute(matrix): `values` = nnz entries aligned with fdapde_pattern_get (any matrix on the FEM
+ * pattern; symmetric != 0 allows CG), or NULL to take the assembled matrix `which`.  No Dirichlet reduction is applied.
+ * fdapde_lin_solve = ::solve(b): dense right-hand sides, b and x column-major n_dofs x n_rhs. */
+int fdapde_lin_compute(fdapde_ctx *ctx, int32_t which, const double *values, int32_t symmetric);
+int fdapde_lin_solve(fdapde_ctx *ctx, const fdapde_options *opt, const double *b, int32_t n_rhs, double *x, fdapde_info *info);
+
 /* ---- getters (fem_solver_base.h:50-53) ------------------------------------------------------------------------- */
 /* values[nnz] aligned with fdapde_pattern_get.  After a solve with Dirichlet data, FDAPDE_MAT_STIFF is the
  * row-zeroed matrix the reference leaves in stiff_ (rows of boundary DOFs zero, unit diagonal). */

@@ -225,6 +225,69 @@ TEST(fem_pde_test, laplacian_3d_order1) {
     EXPECT_TRUE(worst < 1e-8);
 }
 
+// fem_pde_test.cpp:222-285: parabolic, P2, 101 time points
+TEST(fem_pde_test, parabolic_isotropic_order2) {
+    constexpr double pi = 3.14159265358979323846;
+    const int M = 101;
+    DMatrix<double> times(M, 1);
+    for (int j = 0; j < M; ++j) times(j) = 1.0 / (M - 1) * j;
+    auto solution_expr = [](std::array<double, 3> x, double t) { return std::sin(2 * pi * x[0]) * std::sin(2 * pi * x[1]) * std::exp(-t); };
+    auto forcing_expr = [](double x0, double x1, double t) {
+        return (8 * pi * pi - 1.) * std::sin(2 * pi * x0) * std::sin(2 * pi * x1) * std::exp(-t);
+    };
+    MeshLoader<2, 2> unit_square("unit_square");
+    auto L = dt<FEM_HIP>() - laplacian<FEM_HIP>();
+    PDE<Triangulation<2, 2>, decltype(L), DMatrix<double>, FEM_HIP, fem_order<2>> pde_(unit_square.mesh, times);
+    pde_.set_differential_operator(L);
+    DMatrix<double> nodes_ = pde_.dof_coords();
+    DMatrix<double> dirichlet_bc(nodes_.rows(), M), solution_ex(nodes_.rows(), M), initial_condition(nodes_.rows(), 1);
+    for (int64_t i = 0; i < nodes_.rows(); ++i)
+        for (int j = 0; j < M; ++j) dirichlet_bc(i, j) = solution_ex(i, j) = solution_expr(nodes_.row3(i), times(j));
+    for (int64_t i = 0; i < nodes_.rows(); ++i) initial_condition(i) = solution_expr(nodes_.row3(i), times(0));
+    pde_.set_dirichlet_bc(dirichlet_bc);
+    pde_.set_initial_condition(initial_condition);
+    DMatrix<double> quadrature_nodes = pde_.quadrature_nodes();
+    DMatrix<double> f(quadrature_nodes.rows(), M);
+    for (int64_t i = 0; i < quadrature_nodes.rows(); ++i)
+        for (int j = 0; j < M; ++j) f(i, j) = forcing_expr(quadrature_nodes(i, 0), quadrature_nodes(i, 1), times(j));
+    pde_.set_forcing(f);
+    pde_.init();
+    pde_.solve();
+    EXPECT_TRUE(pde_.success());
+    double worst = 0;
+    for (int j = 0; j < M; ++j) {
+        DMatrix<double> e2(nodes_.rows(), 1);
+        for (int64_t i = 0; i < nodes_.rows(); ++i) {
+            const double e = solution_ex(i, j) - pde_.solution()(i, j);
+            e2(i) = e * e;
+        }
+        DMatrix<double> Me = pde_.mass() * e2;
+        double s = 0;
+        for (int64_t i = 0; i < Me.rows(); ++i) s += Me(i);
+        worst = std::fmax(worst, s);
+    }
+    EXPECT_TRUE(worst < 1e-7);
+}
+// fdapde::SparseLU usage pattern (utils/symbols.h:133-160, linear_algebra/smw.h:46-48): factor once, solve many columns
+TEST(sparse_solver_test, factor_once_solve_many) {
+    MeshLoader<2, 2> m("unit_square_32");
+    auto L = -laplacian<FEM_HIP>() + reaction<FEM_HIP>(2.0);
+    PDE<Triangulation<2, 2>, decltype(L), DMatrix<double>, FEM_HIP, fem_order<1>> pde_(m.mesh, L);
+    pde_.init();
+    auto invA = pde_.make_solver();
+    invA.compute(pde_.stiff(), /*symmetric=*/true);
+    EXPECT_TRUE(bool(invA));
+    DMatrix<double> X(pde_.n_dofs(), 3);
+    for (int64_t i = 0; i < X.rows(); ++i)
+        for (int j = 0; j < 3; ++j) X(i, j) = std::sin(0.01 * i * (j + 1)) + j;
+    DMatrix<double> B = pde_.stiff() * X;
+    DMatrix<double> Y = invA.solve(B);
+    double worst = 0;
+    for (int64_t i = 0; i < X.rows(); ++i)
+        for (int j = 0; j < 3; ++j) worst = std::fmax(worst, std::fabs(X(i, j) - Y(i, j)));
+    EXPECT_TRUE(worst < 1e-7);
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) { std::printf("usage: %s <tests/golden/mesh>\n", argv[0]); return 2; }
     MESH_PATH = argv[1];
@@ -236,6 +299,8 @@ int main(int argc, char** argv) {
     RUN(fem_operators_test, laplacian_order_2_through_stiff);
     RUN(fem_pde_test, error_behaviour);
     RUN(fem_pde_test, laplacian_3d_order1);
+    RUN(fem_pde_test, parabolic_isotropic_order2);
+    RUN(sparse_solver_test, factor_once_solve_many);
     std::printf("%d checks, %d failures\n", checks, failures);
     return failures == 0 ? 0 : 1;
 }

@@ -323,3 +323,38 @@ def test_distributed_code_path_on_one_rank(capi, ctx, oracle, mesh_loader):
     with pytest.raises(capi.FdapdeError) as e:
         ctx.solve(method=capi.SOLVER_BICGSTAB)
     assert e.value.status == capi.EUNSUPPORTED
+
+
+def test_factor_once_solve_many(capi, ctx, oracle, mesh_loader):
+    """fdapde::SparseLU usage (utils/symbols.h:133-160; SMW, linear_algebra/smw.h:46-48): compute(A) once, solve(B) for
+    several right-hand sides; symmetric (CG) and general (BiCGStab) matrices; values handed over or taken from the context"""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+
+    m = mesh_loader("unit_sphere")
+    ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = ctx.dofs_build(2)
+    rp, ci = ctx.pattern_get()
+    ctx.set_operator(-capi.laplacian() + capi.reaction(1.0))
+    ctx.set_forcing(None)
+    ctx.init()
+    B = np.random.default_rng(2).standard_normal((nd, 3))
+    A = sp.csr_matrix((ctx.matrix_values(capi.MAT_STIFF), ci, rp), shape=(nd, nd))
+    ctx.lin_compute(capi.MAT_STIFF)
+    X, info = ctx.lin_solve(B, rtol=1e-12)
+    Xr = spla.splu(A.tocsc()).solve(B)
+    assert info.converged == 1 and np.linalg.norm(X - Xr) / np.linalg.norm(Xr) <= SOL_TOL
+    # a caller-supplied non-symmetric matrix on the same pattern (mass + 0.3 * advection-like perturbation)
+    ctx.assemble_operator(capi.MAT_STIFF, capi.reaction(2.0) + capi.advection(np.array([0.4, -0.1, 0.2])) - capi.laplacian())
+    vals = ctx.matrix_values(capi.MAT_STIFF)
+    A2 = sp.csr_matrix((vals, ci, rp), shape=(nd, nd))
+    ctx.lin_compute(capi.MAT_STIFF, values=vals, symmetric=False)
+    x, info = ctx.lin_solve(B[:, 0], rtol=1e-12)
+    xr = spla.splu(A2.tocsc()).solve(B[:, 0])
+    assert info.method_used == capi.SOLVER_BICGSTAB and np.linalg.norm(x - xr) / np.linalg.norm(xr) <= SOL_TOL
+    # the handle survives an ordinary PDE solve in between
+    ctx.set_forcing(np.ones(ctx.sizes()["n_quadrature"] * m.n_cells))
+    ctx.init()
+    ctx.solve()
+    x2, _ = ctx.lin_solve(B[:, 0], rtol=1e-12)
+    assert np.linalg.norm(x2 - xr) / np.linalg.norm(xr) <= SOL_TOL

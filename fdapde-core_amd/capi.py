@@ -45,7 +45,7 @@ SYMBOLS = [
     "fdapde_init", "fdapde_assemble_operator", "fdapde_solve", "fdapde_matrix_values", "fdapde_force", "fdapde_solution",
     "fdapde_info_get", "fdapde_spmv", "fdapde_bench_spmv", "fdapde_tune", "fdapde_stream", "fdapde_synchronize",
     "fdapde_comm_unique_id", "fdapde_comm_init", "fdapde_halo_setup", "fdapde_solve_parabolic",
-    "fdapde_lin_compute", "fdapde_lin_solve",
+    "fdapde_lin_compute", "fdapde_lin_solve", "fdapde_eval_pointwise", "fdapde_cell_integrals",
 ]
 
 _lib = None
@@ -295,6 +295,41 @@ class Context:
         self._check(self.lib.fdapde_lin_solve(self._ctx, C.byref(opt), _dp(flat), B.shape[1], _dp(out), C.byref(info)))
         X = np.ascontiguousarray(out.reshape(B.shape[1], B.shape[0]).T)
         return (X[:, 0] if one else X), info
+
+    # ---- basis evaluation (PDE__::eval_basis): Psi as scipy CSR + D
+    def eval_pointwise(self, locs):
+        """pointwise_evaluation::eval -> (Psi csr n_locs x n_dofs, D = ones, cell ids)"""
+        import scipy.sparse as sp
+
+        locs = np.asarray(locs, dtype=float)
+        nl, s = locs.shape[0], self.sizes()
+        flat = np.ascontiguousarray(locs.T).reshape(-1)
+        cells = np.zeros(nl, dtype=np.int32)
+        vals = np.zeros((nl, s["n_basis"]))
+        self._check(self.lib.fdapde_eval_pointwise(self._ctx, C.c_int64(nl), _dp(flat), _ip(cells), _dp(vals)))
+        dofs, _, _ = self.dofs_get()
+        ok = cells >= 0
+        rows = np.repeat(np.nonzero(ok)[0], s["n_basis"])
+        cols = dofs[cells[ok]].reshape(-1)
+        psi = sp.csr_matrix((vals[ok].reshape(-1), (rows, cols)), shape=(nl, s["n_dofs"]))
+        return psi, np.ones(nl), cells
+
+    def eval_areal(self, incidence):
+        """areal_evaluation::eval: incidence (n_sub, n_cells) of 0/1 -> (Psi csr n_sub x n_dofs, D = subdomain measures)"""
+        import scipy.sparse as sp
+
+        inc = sp.csr_matrix(np.asarray(incidence) == 1, dtype=float)
+        s = self.sizes()
+        meas = np.zeros(self.n_cells)
+        pint = np.zeros((self.n_cells, s["n_basis"]))
+        self._check(self.lib.fdapde_cell_integrals(self._ctx, _dp(meas), _dp(pint)))
+        dofs, _, _ = self.dofs_get()
+        D = inc @ meas
+        nb = s["n_basis"]
+        cellmat = sp.csr_matrix((pint.reshape(-1), (np.repeat(np.arange(self.n_cells), nb), dofs.reshape(-1))),
+                                shape=(self.n_cells, s["n_dofs"]))
+        psi = sp.diags(1.0 / D) @ (inc @ cellmat)
+        return psi.tocsr(), D
 
     def info(self):
         info = Info()

@@ -413,6 +413,103 @@ __global__ void k_quadrature_nodes(AsmArgs a, const int32_t* cell_i2e, int nq, d
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Basis evaluation: the Psi matrices every downstream model asks for (PDE__::eval_basis,
+// fdaPDE/pde/pde.h:149-158).
+// ---------------------------------------------------------------------------------------------------------------
+// Lagrange basis of order R at reference point xi, the reference's local node order (closed forms of tables.cpp)
+template <int M, int R> __device__ __forceinline__ void eval_ref_basis(const double* xi, double* out) {
+    double lam[M + 1];
+    lam[0] = 1.0;
+#pragma unroll
+    for (int k = 0; k < M; ++k) lam[0] -= xi[k], lam[k + 1] = xi[k];
+    if constexpr (R == 1) {
+#pragma unroll
+        for (int i = 0; i <= M; ++i) out[i] = lam[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i <= M; ++i) out[i] = lam[i] * (2.0 * lam[i] - 1.0);
+        if constexpr (M == 2) {
+            out[3] = 4.0 * lam[0] * lam[1], out[4] = 4.0 * lam[0] * lam[2], out[5] = 4.0 * lam[1] * lam[2];
+        } else {   // ReferenceElement<3,2> nodes 4..9 = m12, m02, m01, m13, m23, m03
+            out[4] = 4.0 * lam[1] * lam[2], out[5] = 4.0 * lam[0] * lam[2], out[6] = 4.0 * lam[0] * lam[1];
+            out[7] = 4.0 * lam[1] * lam[3], out[8] = 4.0 * lam[2] * lam[3], out[9] = 4.0 * lam[0] * lam[3];
+        }
+    }
+}
+// pointwise_evaluation::eval (basis/lagrangian_basis.h:203-235) with the point location of TreeSearch::locate
+// (geometry/tree_search.h:73-90) done through a uniform bin grid: one lane per location scans the cells registered in its
+// bin and takes the first one whose barycentric coordinates are all >= -tol (Simplex::contains, geometry/simplex.h:118-131).
+// cell_out: reference cell id or -1; values: n_basis basis values psi_h(invJ (p - x0)) per location.
+template <int M, int R>
+__global__ void k_eval_pointwise(AsmArgs a, int64_t n_locs, const double* locs /*col-major n_locs x M*/, const double* lo,
+                                 const double* inv_h, const int32_t* dims, const int32_t* bin_ptr, const int32_t* bin_cells,
+                                 const int32_t* cell_i2e, double tol, int32_t* cell_out, double* values) {
+    constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
+    constexpr int NP = M == 2 ? 2 : 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_locs) return;
+    double p[M];
+    int64_t bin = 0;
+    bool inside_box = true;
+#pragma unroll
+    for (int d = M - 1; d >= 0; --d) {
+        p[d] = locs[(int64_t)d * n_locs + i];
+        const double t = (p[d] - lo[d]) * inv_h[d];
+        int b = (int)floor(t);
+        if (b == dims[d] && t <= dims[d] + 1e-9) b = dims[d] - 1;   // points on the upper face of the bounding box
+        inside_box &= b >= 0 && b < dims[d];
+        bin = bin * dims[d] + (b < 0 ? 0 : (b >= dims[d] ? dims[d] - 1 : b));
+    }
+    int found = -1;
+    double xi[M];
+    if (inside_box) {
+        for (int32_t k = bin_ptr[bin]; k < bin_ptr[bin + 1] && found < 0; ++k) {
+            const int32_t cell = bin_cells[k];
+            const int32_t* cv = a.cverts + (int64_t)cell * (M + 1);
+            const double* x0 = a.vcoords + (int64_t)cv[0] * NP;
+            Geo<M> g;
+            if constexpr (M == 2)
+                geo_from_vertices<2>(x0, a.vcoords + (int64_t)cv[1] * NP, a.vcoords + (int64_t)cv[2] * NP, nullptr, g);
+            else
+                geo_from_vertices<3>(x0, a.vcoords + (int64_t)cv[1] * NP, a.vcoords + (int64_t)cv[2] * NP,
+                                     a.vcoords + (int64_t)cv[3] * NP, g);
+            double z0 = 1.0;
+            bool in = true;
+#pragma unroll
+            for (int r = 0; r < M; ++r) {
+                double v = 0;
+#pragma unroll
+                for (int c = 0; c < M; ++c) v += g.invJ[r][c] * (p[c] - x0[c]);
+                xi[r] = v, z0 -= v, in &= v >= -tol;
+            }
+            if (in && z0 >= -tol) found = cell;
+        }
+    }
+    cell_out[i] = found >= 0 ? cell_i2e[found] : -1;
+    double val[NB];
+    if (found >= 0) eval_ref_basis<M, R>(xi, val);
+#pragma unroll
+    for (int h = 0; h < NB; ++h) values[i * NB + h] = found >= 0 ? val[h] : 0.0;
+}
+// per cell (reference numbering): measure and the integrals of the local basis functions,
+//   int_e psi_h = measure * sum_q w_q psi_h(p_q)   (Integrator::integrate_cell, utils/integration/integrator.h:47-63)
+// -- the ingredients of areal_evaluation::eval (basis/lagrangian_basis.h:238-283)
+template <int M>
+__global__ void k_cell_integrals(AsmArgs a, int nb, int nq, const int32_t* cell_i2e, double* measure, double* psi_int) {
+    const int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci >= a.n_cells) return;
+    Geo<M> g;
+    cell_geometry<M>(a, (int)ci, g);
+    const int64_t ce = cell_i2e[ci];
+    measure[ce] = g.measure;
+    for (int h = 0; h < nb; ++h) {
+        double v = 0;
+        for (int q = 0; q < nq; ++q) v += a.tables->psi[h * nq + q] * a.tables->qw[q];
+        psi_int[ce * nb + h] = v * g.measure;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // reductions
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {

@@ -146,6 +146,15 @@ int fdapde_solve_parabolic(fdapde_ctx *ctx, const fdapde_options *opt, int32_t n
 int fdapde_lin_compute(fdapde_ctx *ctx, int32_t which, const double *values, int32_t symmetric);
 int fdapde_lin_solve(fdapde_ctx *ctx, const fdapde_options *opt, const double *b, int32_t n_rhs, double *x, fdapde_info *info);
 
+/* ---- basis evaluation (PDE__::eval_basis, pde/pde.h:149-158; policies basis/lagrangian_basis.h:203-283) -------------------
+ * fdapde_eval_pointwise: for each location (column-major n_locs x N) the containing cell (reference cell id, -1 if outside;
+ * TreeSearch::locate, geometry/tree_search.h:73-90) and the n_basis values psi_h(invJ (p - x0)), row-major n_locs x n_basis.
+ * Psi(i, dofs(cell_i, h)) = values[i*n_basis + h], D = ones (pointwise_evaluation::eval).
+ * fdapde_cell_integrals: measure[n_cells] and psi_int[n_cells x n_basis] = int_e psi_h, reference cell order; with an
+ * incidence matrix they give Psi(k, dofs(e,h)) += psi_int[e][h] / |D_k|, D_k = sum measure (areal_evaluation::eval). */
+int fdapde_eval_pointwise(fdapde_ctx *ctx, int64_t n_locs, const double *locs_colmajor, int32_t *cell_ids, double *values);
+int fdapde_cell_integrals(fdapde_ctx *ctx, double *measure, double *psi_int);
+
 /* ---- getters (fem_solver_base.h:50-53) ------------------------------------------------------------------------- */
 /* values[nnz] aligned with fdapde_pattern_get.  After a solve with Dirichlet data, FDAPDE_MAT_STIFF is the
  * row-zeroed matrix the reference leaves in stiff_ (rows of boundary DOFs zero, unit diagonal). */

@@ -45,7 +45,7 @@ SYMBOLS = [
     "fdapde_init", "fdapde_assemble_operator", "fdapde_solve", "fdapde_matrix_values", "fdapde_force", "fdapde_solution",
     "fdapde_info_get", "fdapde_spmv", "fdapde_bench_spmv", "fdapde_tune", "fdapde_stream", "fdapde_synchronize",
     "fdapde_comm_unique_id", "fdapde_comm_init", "fdapde_halo_setup", "fdapde_solve_parabolic",
-    "fdapde_lin_compute", "fdapde_lin_solve", "fdapde_eval_pointwise", "fdapde_cell_integrals",
+    "fdapde_lin_compute", "fdapde_lin_solve", "fdapde_eval_pointwise", "fdapde_cell_integrals", "fdapde_comm_init_callback",
 ]
 
 _lib = None
@@ -374,6 +374,20 @@ class Context:
 
     def comm_init(self, world, rank, unique_id: bytes):
         self._check(self.lib.fdapde_comm_init(self._ctx, int(world), int(rank), C.c_char_p(unique_id)))
+
+    def comm_init_callback(self, world, rank, allreduce):
+        """host-staged transport: allreduce(numpy float64 array) must sum it over all ranks in place"""
+        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)
+
+        def _cb(user, ptr, count):
+            try:
+                allreduce(np.ctypeslib.as_array(ptr, shape=(count,)))
+                return 0
+            except Exception:   # noqa: BLE001  (must not propagate through the C frame)
+                return 1
+
+        self._ar_cb = proto(_cb)   # keep alive
+        self._check(self.lib.fdapde_comm_init_callback(self._ctx, int(world), int(rank), self._ar_cb, None))
 
     def halo_setup(self, n_if_global, local_dof, if_index, owned):
         local_dof = np.ascontiguousarray(local_dof, dtype=np.int32)

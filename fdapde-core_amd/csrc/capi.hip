@@ -137,6 +137,9 @@ struct fdapde_ctx {
     int lds_limit = 96 * 1024;   // per assembly workgroup: tables + staged vertices + row accumulators
     // multi-GPU (element partition): RCCL communicator + interface maps
     ncclComm_t comm = nullptr;
+    fdapde_allreduce_fn ar_fn = nullptr;     // host-staged transport (tests / non-RCCL fabrics) instead of the RCCL communicator
+    void* ar_user = nullptr;
+    std::vector<double> ar_host;
     int world = 1, rank = 0;
     bool halo_ready = false;
     int64_t n_if = 0, n_loc_if = 0;          // global / local interface DOF counts
@@ -470,6 +473,14 @@ inline unsigned g1(int64_t n, int per = 256) { return (unsigned)((n + per - 1) /
     } while (0)
 
 int allreduce_sum(fdapde_ctx* c, double* buf, size_t count) {
+    if (c->ar_fn) {   // host-staged: device -> host, caller-provided sum over ranks, host -> device
+        c->ar_host.resize(count);
+        HIPCHK(c, hipMemcpyAsync(c->ar_host.data(), buf, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->ar_fn(c->ar_user, c->ar_host.data(), (int64_t)count) != 0) return fail(c, FDAPDE_ERCCL, "all-reduce callback failed");
+        HIPCHK(c, hipMemcpyAsync(buf, c->ar_host.data(), sizeof(double) * count, hipMemcpyHostToDevice, c->stream));
+        return FDAPDE_OK;
+    }
     RCCLCHK(c, g_rccl.AllReduce(buf, buf, count, ncclFloat64, ncclSum, c->comm, c->stream));
     return FDAPDE_OK;
 }
@@ -781,7 +792,7 @@ namespace {
 int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss) {
     const int64_t n = c->hs.n_dofs;
     hipStream_t st = c->stream;
-    ss->dist = c->comm != nullptr && c->halo_ready;   // multi-GPU: sub-assembled operator of this rank's cells
+    ss->dist = (c->comm != nullptr || c->ar_fn != nullptr) && c->halo_ready;   // multi-GPU: sub-assembled operator of this rank's cells
     ss->owned = ss->dist ? c->owned.p : nullptr;
     ss->use_bnd = use_bnd;
     HIPCHK(c, hipMemsetAsync(c->ctl.p, 0, 4 * sizeof(int32_t), st));
@@ -981,7 +992,7 @@ int fdapde_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_t
     if (int rc = need_device(c)) return rc;
     if (!c->dev_ready || !c->assembled[0] || !c->assembled[1] || !c->force_ready)
         return fail(c, FDAPDE_ENOTINIT, "solver must be initialized first!");   // fem_linear_parabolic_solver.h:39
-    if (c->comm && c->halo_ready) return fail(c, FDAPDE_EUNSUPPORTED, "the parabolic stepper is single GPU only");
+    if ((c->comm || c->ar_fn) && c->halo_ready) return fail(c, FDAPDE_EUNSUPPORTED, "the parabolic stepper is single GPU only");
     if (c->fq_cols < n_times) return fail(c, FDAPDE_EINVAL, "forcing data needs one column per time point");
     HIPCHK(c, hipSetDevice(c->device));
     const HostSpace& hs = c->hs;
@@ -1047,7 +1058,7 @@ int fdapde_lin_compute(fdapde_ctx* c, int32_t which, const double* values, int32
     if (int rc = need_device(c)) return rc;
     if (!c->dev_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
     if (!values && !c->assembled[which]) return fail(c, FDAPDE_ENOTINIT, "matrix not assembled");
-    if (c->comm && c->halo_ready) return fail(c, FDAPDE_EUNSUPPORTED, "the solver handle is single GPU only");
+    if ((c->comm || c->ar_fn) && c->halo_ready) return fail(c, FDAPDE_EUNSUPPORTED, "the solver handle is single GPU only");
     HIPCHK(c, hipSetDevice(c->device));
     const HostSpace& hs = c->hs;
     HIPCHK(c, c->lin_mat.alloc((size_t)hs.nnz + 2));
@@ -1382,7 +1393,15 @@ int fdapde_comm_init(fdapde_ctx* c, int32_t world, int32_t rank, const void* uni
     ncclUniqueId id;
     std::memcpy(&id, unique_id128, sizeof id);
     RCCLCHK(c, g_rccl.CommInitRank(&c->comm, world, id, rank));
-    c->world = world, c->rank = rank;
+    c->world = world, c->rank = rank, c->ar_fn = nullptr;
+    return FDAPDE_OK;
+}
+
+int fdapde_comm_init_callback(fdapde_ctx* c, int32_t world, int32_t rank, fdapde_allreduce_fn fn, void* user) {
+    if (!c || !fn || world < 1 || rank < 0 || rank >= world) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (c->comm) (void)g_rccl.CommDestroy(c->comm), c->comm = nullptr;
+    c->ar_fn = fn, c->ar_user = user, c->world = world, c->rank = rank;
     return FDAPDE_OK;
 }
 
@@ -1391,7 +1410,7 @@ int fdapde_halo_setup(fdapde_ctx* c, int64_t n_if_global, int64_t n_if_local, co
     if (!c || n_if_global < 0 || n_if_local < 0 || (n_if_local > 0 && (!local_dof || !if_index)) || !owned) return FDAPDE_EINVAL;
     if (int rc = need_device(c)) return rc;
     if (!c->dev_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
-    if (!c->comm) return fail(c, FDAPDE_ENOTINIT, "call fdapde_comm_init first");
+    if (!c->comm && !c->ar_fn) return fail(c, FDAPDE_ENOTINIT, "call fdapde_comm_init first");
     HIPCHK(c, hipSetDevice(c->device));
     const HostSpace& hs = c->hs;
     std::vector<int32_t> dof_i((size_t)n_if_local), pos((size_t)n_if_local);

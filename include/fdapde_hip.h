@@ -182,6 +182,10 @@ int fdapde_bench_spmv(fdapde_ctx *ctx, int32_t reps, double *avg_ms, double *alg
  *                           interface vector), k < n_if_local; owned[d] = 1 iff this rank counts local DOF d in global
  *                           dot products (every global DOF is owned by exactly one rank).
  * After fdapde_halo_setup, fdapde_solve runs the distributed Jacobi-PCG (BiCGStab: single GPU only). */
+/* host-staged transport instead of RCCL: fn(user, host_buf, count) must replace host_buf by its sum over all ranks and
+ * return 0.  Lets the distributed path run over any fabric (tests drive it with torch.distributed/gloo, two ranks on one GPU). */
+typedef int (*fdapde_allreduce_fn)(void *user, double *host_buf, int64_t count);
+int fdapde_comm_init_callback(fdapde_ctx *ctx, int32_t world, int32_t rank, fdapde_allreduce_fn fn, void *user);
 int fdapde_comm_unique_id(void *out128);
 int fdapde_comm_init(fdapde_ctx *ctx, int32_t world, int32_t rank, const void *unique_id128);
 int fdapde_halo_setup(fdapde_ctx *ctx, int64_t n_if_global, int64_t n_if_local, const int32_t *local_dof,

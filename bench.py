@@ -80,11 +80,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
 
+    # FDAPDE_BENCH_BACKEND=gloo: plumbing check of the N > 1 leg on a box with fewer GPUs than ranks (ranks share devices,
+    # host-staged all-reduce instead of RCCL).  Never used for reported numbers.
+    backend = os.environ.get("FDAPDE_BENCH_BACKEND", "nccl")
+    n_dev = max(torch.cuda.device_count(), 1)
+    device_index = local_rank % n_dev
     if world > 1:
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device_index)
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
 
@@ -109,7 +117,7 @@ def main():
     u_exact, f = meshgen.manufactured(3)
 
     if world == 1:
-        ctx = capi.Context(device=local_rank)
+        ctx = capi.Context(device=device_index)
         ctx.mesh_upload(nodes, cells, bnd)
         n_dofs = ctx.dofs_build(1)
         sizes = ctx.sizes()
@@ -144,7 +152,7 @@ def main():
     else:
         from fdapde_core_amd import dist as fdist
 
-        res = fdist.bench_partitioned(capi, nodes, cells, bnd, f, u_exact, rank, world, local_rank, args, barrier, RTOL)
+        res = fdist.bench_partitioned(capi, nodes, cells, bnd, f, u_exact, rank, world, device_index, args, barrier, RTOL, backend)
         if rank != 0:
             return
         (elapsed, info, spmv_ms, t_asm, t_sol, err, setup_ms, alg_bytes, sizes, total_dofs, parallelism) = res

@@ -67,7 +67,7 @@ def local_problem(nodes, cells, boundary, part, rank, world, info=None):
     )
 
 
-def bench_partitioned(capi, nodes, cells, bnd, f, u_exact, rank, world, local_rank, args, barrier, rtol):
+def bench_partitioned(capi, nodes, cells, bnd, f, u_exact, rank, world, local_rank, args, barrier, rtol, backend="nccl"):
     """bench.py's N > 1 leg: the same C3 mesh split over `world` GPUs (strong scaling)."""
     import time
 
@@ -76,12 +76,16 @@ def bench_partitioned(capi, nodes, cells, bnd, f, u_exact, rank, world, local_ra
 
     part = partition_cells(nodes, cells, world)
     lp = local_problem(nodes, cells, bnd, part, rank, world)
-    uid = [capi.Context.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(uid, src=0)
+    dev = "cuda" if backend == "nccl" else "cpu"
     ctx = capi.Context(device=local_rank)
     ctx.mesh_upload(lp["nodes"], lp["cells"], lp["boundary"])
     n_loc = ctx.dofs_build(1)
-    ctx.comm_init(world, rank, uid[0])
+    if backend == "nccl":   # RCCL communicator of the library, bootstrapped with a broadcast of its unique id
+        uid = [capi.Context.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(world, rank, uid[0])
+    else:                   # plumbing checks only: host-staged all-reduce over gloo
+        ctx.comm_init_callback(world, rank, lambda arr: dist.all_reduce(torch.from_numpy(arr)))
     ctx.halo_setup(lp["n_if_global"], lp["local_dof"], lp["if_index"], lp["owned"])
     qn = ctx.quadrature_nodes()
     ctx.set_operator(-capi.laplacian())
@@ -99,18 +103,18 @@ def bench_partitioned(capi, nodes, cells, bnd, f, u_exact, rank, world, local_ra
     t0 = time.perf_counter()
     infos = [step(args.time_spmv) for _ in range(args.steps)]
     barrier()
-    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)       # slowest rank defines the step time
     u = ctx.solution()
-    err = torch.tensor([float(np.abs(u - u_exact(lp["nodes"])).max())], dtype=torch.float64, device="cuda")
+    err = torch.tensor([float(np.abs(u - u_exact(lp["nodes"])).max())], dtype=torch.float64, device=dev)
     dist.all_reduce(err, op=dist.ReduceOp.MAX)
     info = infos[-1]
     stats = torch.tensor([np.mean([i.spmv_avg_ms for i in infos]), np.mean([i.t_assemble_ms for i in infos]),
-                          np.mean([i.t_solve_ms for i in infos]), ctx.info().t_setup_ms], dtype=torch.float64, device="cuda")
+                          np.mean([i.t_solve_ms for i in infos]), ctx.info().t_setup_ms], dtype=torch.float64, device=dev)
     dist.all_reduce(stats, op=dist.ReduceOp.MAX)
     sizes = ctx.sizes()
     _, alg_bytes = ctx.bench_spmv(reps=1)
-    nnz_tot = torch.tensor([float(sizes["nnz"]), alg_bytes], dtype=torch.float64, device="cuda")
+    nnz_tot = torch.tensor([float(sizes["nnz"]), alg_bytes], dtype=torch.float64, device=dev)
     dist.all_reduce(nnz_tot, op=dist.ReduceOp.MAX)       # the largest local matrix bounds the SpMV roofline figure
     sizes = dict(sizes, nnz=int(nnz_tot[0].item()))
     parallelism = (f"{world} GPUs, element partition (Morton chunks), {lp['n_if_global']} interface DOFs, "

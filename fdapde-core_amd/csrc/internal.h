@@ -57,7 +57,8 @@ struct HostSpace {
     std::vector<double> vcoords_i;   // internal node id -> NP doubles (NP = 2 for N=2, 4 for N=3)
     std::vector<uint8_t> dof_bnd_i;
     // ---- row-owner adjacency in sliced-ELL layout: slice s covers rows [64 s, 64 s + 64)
-    //      entry (s, v, lane) at (sl_off[s] + v) * 64 + lane  holds  cell_i * 16 + local_index, or -1 (padding)
+    //      entry (s, v, lane) at (sl_off[s] + v) * 64 + lane  holds  (index of the cell in its assembly block's table) * 16
+    //      + local_index, or -1 (padding)
     std::vector<int64_t> sl_off;      // n_slices + 1, in units of 64-lane rows
     std::vector<int32_t> adj;         // sl_off.back() * 64
     int nbw = 0;                      // 32-bit words of slot data per visit: ceil(nb * 2 / 4)

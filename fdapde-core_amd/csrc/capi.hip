@@ -399,11 +399,12 @@ int launch_assembly(fdapde_ctx* c, const AsmArgs& a, const DevOp& op, int assemb
 // timestamps on the stream it runs on -- the same interval rocprofv3 --kernel-trace reports, with no extra marker packet
 // between the neighbouring kernels.
 void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, const double* w, double* partial,
-                 const int32_t* stop, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+                 const int32_t* stop, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, int dot2_ww = 0,
+                 const uint8_t* owned = nullptr) {
     SpmvArgs s{};
     s.rowptr = c->rowptr.p, s.colidx = c->colidx.p, s.vals = vals, s.x = x, s.y = y;
     s.rb_row = c->rb_row.p, s.n_rb = c->n_rb, s.rb_per_band = c->rb_per_band, s.nnz = (int32_t)c->hs.nnz;
-    s.w = w, s.partial = partial, s.stop = stop;
+    s.w = w, s.partial = partial, s.stop = stop, s.dot2_ww = dot2_ww, s.owned = owned;
     const int64_t n = c->hs.n_dofs, rpb = (n + 7) / 8;
     const dim3 grid(c->spmv_grid), block(256);
 #define SPMV_GO(...) hipExtLaunchKernelGGL((__VA_ARGS__), grid, block, 0, c->stream, e0, e1, 0, s, n, rpb)
@@ -842,9 +843,10 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     if (dist)
         if (int rc = halo_sum(c, c->y.p, nullptr, 0)) return rc;
     if (method == FDAPDE_SOLVER_AUTO) method = (c->op_symmetric && ss.diag_positive) ? FDAPDE_SOLVER_CG : FDAPDE_SOLVER_BICGSTAB;
-    if (method == FDAPDE_SOLVER_CG && !ss.diag_positive)
+    if (method == FDAPDE_SOLVER_CG && dist && c->world > 1) method = FDAPDE_SOLVER_CG_SR;   // one all-reduce per iteration
+    if ((method == FDAPDE_SOLVER_CG || method == FDAPDE_SOLVER_CG_SR) && !ss.diag_positive)
         return fail(c, FDAPDE_ENOCONV, "CG needs a positive diagonal (operator not SPD?); use BiCGStab");
-    const bool bicg = method == FDAPDE_SOLVER_BICGSTAB;
+    const bool bicg = method == FDAPDE_SOLVER_BICGSTAB, cgsr = method == FDAPDE_SOLVER_CG_SR;
     if (dist && bicg) return fail(c, FDAPDE_EUNSUPPORTED, "the element-partitioned solve implements CG only (BiCGStab: single GPU)");
     const double tol2 = rtol * rtol;
     const double* ax = nullptr;
@@ -864,6 +866,10 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     } else {
         hipLaunchKernelGGL(k_krylov_init_fin, dim3(1), dim3(256), 0, st, c->part_b.p, c->vec_grid, c->sc.p, c->ctl.p, tol2);
     }
+    if (cgsr) {   // p = s = 0 before the first update (beta = 0 there)
+        HIPCHK(c, hipMemsetAsync(c->p.p, 0, sizeof(double) * (size_t)n, st));
+        HIPCHK(c, hipMemsetAsync(c->s.p, 0, sizeof(double) * (size_t)n, st));
+    }
     HIPCHK(c, hipGetLastError());
     n_timed = n_timed < 0 ? 0 : (n_timed > 256 ? 256 : n_timed);
     while ((int)c->ev_spmv.size() < 2 * n_timed) {
@@ -876,7 +882,23 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     while (!stop && launched < maxit) {
         const int chunk = (maxit - launched) < check_every ? (maxit - launched) : check_every;
         for (int it = 0; it < chunk; ++it, ++launched) {
-            if (!bicg) {
+            if (cgsr) {
+                const int parity = launched & 1;
+                const bool tm = launched < n_timed;
+                // w = At r with delta = r.(At r) and gamma = r.r (owned rows) fused; multi-GPU: ONE all-reduce carries the
+                // interface entries of w and both partials
+                launch_spmv(c, c->sval.p, c->r.p, c->y.p, c->r.p, c->part_a.p, c->ctl.p, tm ? c->ev_spmv[2 * launched] : nullptr,
+                            tm ? c->ev_spmv[2 * launched + 1] : nullptr, 1, owned);
+                if (tm) ++timed;
+                const double* part = c->part_a.p;
+                int np = c->spmv_grid;
+                if (dist) {
+                    if (int rc = halo_sum(c, c->y.p, c->part_a.p, c->spmv_grid)) return rc;
+                    part = c->hbuf.p + c->n_if, np = 1;
+                }
+                hipLaunchKernelGGL(k_cgsr_update, dim3(c->cg_grid), dim3(256), 0, st, n, c->r.p, c->y.p, c->p.p, c->s.p, c->x.p, part,
+                                   np, c->sc.p, parity, launched == 0 ? 1 : 0, tol2, c->ctl.p);
+            } else if (!bicg) {
                 const int parity = launched & 1;
                 const bool tm = launched < n_timed;
                 launch_spmv(c, c->sval.p, c->p.p, c->y.p, c->p.p, c->part_a.p, c->ctl.p,

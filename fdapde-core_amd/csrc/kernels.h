@@ -559,7 +559,13 @@ struct SpmvArgs {
     const double* w;       // second vector of the fused dot products; nullptr: no dots
     double* partial;       // [2 * gridDim.x]: workgroup b writes (w.y, y.y) at 2b, 2b+1; nullptr: no dots
     const int32_t* stop;   // device flag: nonzero -> converged, kernel returns immediately (may be nullptr)
+    int32_t dot2_ww;       // second fused dot: 0 -> y.y (BiCGStab's t.t), 1 -> w.w over owned rows (single-reduction CG's r.r)
+    const uint8_t* owned;  // multi-GPU: rows this rank counts in w.w (nullptr = all)
 };
+__device__ __forceinline__ double spmv_dot2(const SpmvArgs& s, int64_t row, double wv, double out) {
+    if (!s.dot2_ww) return out * out;
+    return (s.owned && !s.owned[row]) ? 0.0 : wv * wv;
+}
 
 __global__ __launch_bounds__(256) void k_spmv(SpmvArgs s) {
     __shared__ double prod[kSpmvNnz];
@@ -586,7 +592,7 @@ __global__ __launch_bounds__(256) void k_spmv(SpmvArgs s) {
             double acc = 0;
             for (int i = a; i < b; ++i) acc += prod[i];
             s.y[r] = acc;
-            if (s.w) d_wy += s.w[r] * acc, d_yy += acc * acc;
+            if (s.w) d_wy += s.w[r] * acc, d_yy += spmv_dot2(s, r, s.w[r], acc);
         }
         __syncthreads();
     }
@@ -689,7 +695,7 @@ __global__ __launch_bounds__(256) void k_spmv_team(SpmvArgs s, int64_t n, int64_
             const int64_t row = base + lane;
             if (lane < WROWS && row < band_end) {
                 s.y[row] = out;
-                if (s.w) d_wy += s.w[row] * out, d_yy += out * out;
+                if (s.w) d_wy += s.w[row] * out, d_yy += spmv_dot2(s, row, s.w[row], out);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) rs[u] = rsn[u], re[u] = ren[u], c[u] = cn[u], v[u] = vn[u];
@@ -923,7 +929,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
             }
             __builtin_amdgcn_wave_barrier();
             const double once = (lane < WROWS && row_ok) ? dots : 0.0;   // each row counted by one lane
-            d_wy += once * (wv * out), d_yy += once * (out * out);
+            d_wy += once * (wv * out), d_yy += once * spmv_dot2(s, row_ok ? row : band_end - 1, wv, out);
 #pragma unroll
             for (int u = 0; u < U; ++u) rs[u] = rsn[u], re[u] = ren[u], c[u] = cn[u], v[u] = vn[u];
         };
@@ -1115,6 +1121,66 @@ __global__ __launch_bounds__(256) void k_cg_update_p(int64_t n, const double* r,
         // the stop flag is read by this launch's other workgroups only at their start; writing it here is seen by the
         // next kernel (kernel boundary = device-scope release/acquire)
         if (rr_new <= tol2 * sc[0] || ctl[2]) ctl[0] = 1;
+    }
+}
+
+// Single-reduction CG (Chronopoulos & Gear): the SpMV acts on r, both dot products of an iteration -- gamma = r.r and
+// delta = r.(At r) -- are fused into it, and ONE kernel then updates all vectors:
+//     beta = gamma / gamma_old ; alpha = gamma / (delta - beta gamma / alpha_old)
+//     p = r + beta p ; s = w + beta s (= At p) ; x += alpha p ; r -= alpha s
+// Two launches and (multi-GPU) one all-reduce per iteration instead of three and two.  Same Krylov iterates as CG in
+// exact arithmetic.  part_in: stride-2 pairs (delta, gamma); scalars: sc[10 + parity] gamma_old, sc[12 + parity] alpha_old.
+// Every workgroup takes the stop decision from the same reduced numbers, so no workgroup updates past convergence.
+__global__ __launch_bounds__(256) void k_cgsr_update(int64_t n, double* r, const double* w, double* p, double* s, double* x,
+                                                      const double* part_in, int np_in, double* sc, int parity, int first,
+                                                      double tol2, int32_t* ctl) {
+    __shared__ double red[8];
+    if (__syncthreads_or(ctl[0] != 0)) return;
+    const int64_t n2 = n >> 1, i0 = (int64_t)blockIdx.x * (256 * kCgV) + threadIdx.x;
+    double2* r2 = reinterpret_cast<double2*>(r);
+    const double2* w2 = reinterpret_cast<const double2*>(w);
+    double2* p2 = reinterpret_cast<double2*>(p);
+    double2* s2 = reinterpret_cast<double2*>(s);
+    double2* x2 = reinterpret_cast<double2*>(x);
+    double2 rv[kCgV], wv[kCgV], pv[kCgV], sv[kCgV], xv[kCgV];
+#pragma unroll
+    for (int k = 0; k < kCgV; ++k) {
+        const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
+        rv[k] = r2[ic], wv[k] = w2[ic], pv[k] = p2[ic], sv[k] = s2[ic], xv[k] = x2[ic];
+    }
+    double a = 0, b = 0;
+    for (int i = threadIdx.x; i < np_in; i += blockDim.x) a += part_in[2 * i], b += part_in[2 * i + 1];
+    const double delta = block_sum(a, red);
+    const double gamma = block_sum(b, red);
+    const bool last = blockIdx.x == gridDim.x - 1 && threadIdx.x == 0;
+    if (gamma <= tol2 * sc[0]) {   // converged at the residual the SpMV has just measured: x, r stay as they are
+        if (last) sc[3] = gamma, ctl[0] = 1;
+        return;
+    }
+    const double gamma_old = sc[10 + parity], alpha_old = sc[12 + parity];
+    const double beta = first ? 0.0 : gamma / gamma_old;
+    const double denom = first ? delta : delta - beta * gamma / alpha_old;
+    const double alpha = denom > 0.0 ? gamma / denom : 0.0;
+#pragma unroll
+    for (int k = 0; k < kCgV; ++k) {
+        const int64_t i = i0 + k * 256;
+        if (i < n2) {
+            pv[k].x = rv[k].x + beta * pv[k].x, pv[k].y = rv[k].y + beta * pv[k].y;
+            sv[k].x = wv[k].x + beta * sv[k].x, sv[k].y = wv[k].y + beta * sv[k].y;
+            xv[k].x += alpha * pv[k].x, xv[k].y += alpha * pv[k].y;
+            rv[k].x -= alpha * sv[k].x, rv[k].y -= alpha * sv[k].y;
+            p2[i] = pv[k], s2[i] = sv[k], x2[i] = xv[k], r2[i] = rv[k];
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        p[i] = r[i] + beta * p[i], s[i] = w[i] + beta * s[i];
+        x[i] += alpha * p[i], r[i] -= alpha * s[i];
+    }
+    if (last) {
+        sc[10 + (parity ^ 1)] = gamma, sc[12 + (parity ^ 1)] = alpha, sc[3] = gamma;
+        ctl[1] += 1;
+        if (!(denom > 0.0)) ctl[2] = 1, ctl[0] = 1;   // not SPD / breakdown
     }
 }
 

@@ -59,7 +59,9 @@ typedef struct {
                               (Discretized*Field::forward, fdaPDE/utils/integration/integrator.h:98-101) */
 } fdapde_term;
 
-enum { FDAPDE_SOLVER_AUTO = 0, FDAPDE_SOLVER_CG = 1, FDAPDE_SOLVER_BICGSTAB = 2 };
+/* CG_SR: single-reduction (Chronopoulos-Gear) CG: same iterates, both dot products fused into the SpMV, two launches and
+ * (multi-GPU) one all-reduce per iteration */
+enum { FDAPDE_SOLVER_AUTO = 0, FDAPDE_SOLVER_CG = 1, FDAPDE_SOLVER_BICGSTAB = 2, FDAPDE_SOLVER_CG_SR = 3 };
 enum { FDAPDE_ASSEMBLY_ROWS = 0, FDAPDE_ASSEMBLY_ATOMIC = 1, FDAPDE_ASSEMBLY_COLOURED = 2 };
 enum { FDAPDE_MAT_STIFF = 0, FDAPDE_MAT_MASS = 1 };
 

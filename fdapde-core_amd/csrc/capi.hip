@@ -135,6 +135,11 @@ struct fdapde_ctx {
                             // (FDAPDE_SPMV=team); 1: stream form (FDAPDE_SPMV=stream) -- kept for A/B measurements
     int spmv_team = 16, spmv_unroll = 4, spmv_ablate = 0;
     int lds_limit = 96 * 1024;   // per assembly workgroup: tables + staged vertices + row accumulators
+    // compact solver pattern (no diagonal; [1]: also no Dirichlet rows / columns), built on first use
+    DBuf<int32_t> sp_rowptr[2], sp_colidx[2], sp_map[2];
+    int64_t sp_nnz[2] = {0, 0};
+    bool sp_built[2] = {false, false};
+    int sp_cur = -1;   // which compact pattern c->sval currently holds (-1: full pattern)
     // multi-GPU (element partition): RCCL communicator + interface maps
     ncclComm_t comm = nullptr;
     fdapde_allreduce_fn ar_fn = nullptr;     // host-staged transport (tests / non-RCCL fabrics) instead of the RCCL communicator
@@ -404,7 +409,14 @@ void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, 
     SpmvArgs s{};
     s.rowptr = c->rowptr.p, s.colidx = c->colidx.p, s.vals = vals, s.x = x, s.y = y;
     s.rb_row = c->rb_row.p, s.n_rb = c->n_rb, s.rb_per_band = c->rb_per_band, s.nnz = (int32_t)c->hs.nnz;
-    s.w = w, s.partial = partial, s.stop = stop, s.dot2_ww = dot2_ww, s.owned = owned;
+    s.w = w, s.partial = partial, s.stop = stop, s.dot2_ww = dot2_ww, s.owned = owned, s.unit_diag = 0;
+    if (vals == c->sval.p && c->sp_cur >= 0) {   // the solver's scaled matrix lives in the compact pattern
+        s.rowptr = c->sp_rowptr[c->sp_cur].p, s.colidx = c->sp_colidx[c->sp_cur].p, s.nnz = (int32_t)c->sp_nnz[c->sp_cur];
+        s.unit_diag = 1;
+        // multi-GPU: the local diagonals s_i^2 (A_p)_ii of an interface DOF sum to 1 over the ranks sharing it; the implicit
+        // unit diagonal is therefore contributed by the DOF's owner only (any split of the entries among ranks is valid)
+        if ((c->comm != nullptr || c->ar_fn != nullptr) && c->halo_ready) s.owned = c->owned.p;
+    }
     const int64_t n = c->hs.n_dofs, rpb = (n + 7) / 8;
     const dim3 grid(c->spmv_grid), block(256);
 #define SPMV_GO(...) hipExtLaunchKernelGGL((__VA_ARGS__), grid, block, 0, c->stream, e0, e1, 0, s, n, rpb)
@@ -570,6 +582,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
         c->halo_dof.release(), c->halo_pos.release(), c->owned.release(), c->hbuf.release(), c->sbuf.release();
         if (c->comm) (void)g_rccl.CommDestroy(c->comm);
         c->lin_mat.release();
+        for (int v = 0; v < 2; ++v) c->sp_rowptr[v].release(), c->sp_colidx[v].release(), c->sp_map[v].release();
         if (c->h_ctl) (void)hipHostFree(c->h_ctl);
         if (c->h_sc) (void)hipHostFree(c->h_sc);
         (void)hipEventDestroy(c->ev0), (void)hipEventDestroy(c->ev1);
@@ -597,7 +610,7 @@ int fdapde_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs) {
     c->space_ready = c->dev_ready = c->colour_ready = false;
     c->assembled[0] = c->assembled[1] = c->force_ready = c->solved = c->dirichlet_applied = false;
     c->op.clear(), c->fq_i.clear(), c->fq_cols = 0, c->g_i.clear(), c->have_g = false;
-    c->halo_ready = false, c->lin_ready = false;
+    c->halo_ready = false, c->lin_ready = false, c->sp_built[0] = c->sp_built[1] = false, c->sp_cur = -1;
     int rc = host_build_space(c->hs, order, c->err);
     if (rc) return rc;
     rc = build_basis_tables(c->hs.M, order, &c->tb);
@@ -805,7 +818,6 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss) {
     } else {
         hipLaunchKernelGGL(k_jacobi_scale, dim3(g1(n)), dim3(256), 0, st, n, c->diag.p, A, c->bnd.p, use_bnd, c->scale.p, c->ctl.p + 3);
     }
-    hipLaunchKernelGGL(k_scale_matrix, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, A, c->scale.p, c->sval.p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
@@ -818,6 +830,28 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss) {
         c->h_ctl[3] = c->h_sc[8] != 0.0 ? 1 : 0;
     }
     ss->diag_positive = c->h_ctl[3] == 0;
+    // scaled matrix: compact (no diagonal, no Dirichlet rows / columns: ~12 % fewer entries on C3) when every interior
+    // diagonal is positive, so that the scaled diagonal is exactly 1; else the full pattern
+    const bool compact = ss->diag_positive && c->spmv_variant == 2 && !std::getenv("FDAPDE_SPMV_FULL");
+    if (compact) {
+        const int v = use_bnd ? 1 : 0;
+        if (!c->sp_built[v]) {
+            std::vector<int32_t> rp, ci, map;
+            if (int rc = host_build_solver_pattern(c->hs, v == 1, rp, ci, map)) return rc;
+            HIPCHK(c, c->sp_rowptr[v].upload(rp.data(), rp.size(), st));
+            HIPCHK(c, c->sp_colidx[v].upload(ci.data(), ci.size(), st));
+            HIPCHK(c, c->sp_map[v].upload(map.data(), map.size(), st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            c->sp_nnz[v] = rp.back(), c->sp_built[v] = true;
+        }
+        hipLaunchKernelGGL(k_scale_matrix_compact, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, A, c->scale.p,
+                           c->sp_map[v].p, c->sval.p);
+        c->sp_cur = v;
+    } else {
+        hipLaunchKernelGGL(k_scale_matrix, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, A, c->scale.p, c->sval.p);
+        c->sp_cur = -1;
+    }
+    HIPCHK(c, hipGetLastError());
     return FDAPDE_OK;
 }
 

@@ -569,6 +569,35 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
     return FDAPDE_OK;
 }
 
+int host_build_solver_pattern(const HostSpace& hs, bool use_bnd, std::vector<int32_t>& rowptr_s, std::vector<int32_t>& colidx_s,
+                              std::vector<int32_t>& full2s) {
+    const int64_t nd = hs.n_dofs;
+    rowptr_s.assign((size_t)nd + 1, 0);
+    full2s.assign((size_t)hs.nnz, -1);
+    auto keep = [&](int64_t r, int32_t col) {
+        if (col == r) return false;                                               // unit diagonal after Jacobi scaling
+        if (use_bnd && (hs.dof_bnd_i[(size_t)r] || hs.dof_bnd_i[(size_t)col])) return false;   // scaled to exact zeros
+        return true;
+    };
+    parallel_for(nd, [&](int64_t b, int64_t e, unsigned) {
+        for (int64_t r = b; r < e; ++r) {
+            int32_t cnt = 0;
+            for (int32_t k = hs.rowptr_i[(size_t)r]; k < hs.rowptr_i[(size_t)r + 1]; ++k) cnt += keep(r, hs.colidx_i[(size_t)k]);
+            rowptr_s[(size_t)r + 1] = cnt;
+        }
+    });
+    for (int64_t r = 0; r < nd; ++r) rowptr_s[(size_t)r + 1] += rowptr_s[(size_t)r];
+    colidx_s.assign((size_t)rowptr_s[(size_t)nd] + 2, 0);   // + 2: pair loads may touch one entry past a row's end
+    parallel_for(nd, [&](int64_t b, int64_t e, unsigned) {
+        for (int64_t r = b; r < e; ++r) {
+            int32_t at = rowptr_s[(size_t)r];
+            for (int32_t k = hs.rowptr_i[(size_t)r]; k < hs.rowptr_i[(size_t)r + 1]; ++k)
+                if (keep(r, hs.colidx_i[(size_t)k])) colidx_s[(size_t)at] = hs.colidx_i[(size_t)k], full2s[(size_t)k] = at++;
+        }
+    });
+    return FDAPDE_OK;
+}
+
 // Greedy element colouring over the internal cell order: cells of one colour share no DOF, so their scatter into the
 // global matrix needs no atomics.  Colour-contiguous cell lists keep the index reads of each pass coalesced.
 int host_build_colouring(HostSpace& hs, std::string& err) {

@@ -88,6 +88,10 @@ int host_set_mesh(HostSpace& hs, int M, int N, int64_t n_nodes, const double* no
                   const int32_t* cells, const uint8_t* bnd, std::string& err);
 int host_build_space(HostSpace& hs, int order, std::string& err);
 int host_build_colouring(HostSpace& hs, std::string& err);
+// Solver pattern: the internal CSR pattern without the diagonal and (use_bnd) without rows / columns of Dirichlet DOFs.
+// full2s[k] = slot of full entry k in the compact arrays, or -1 when the entry is dropped.
+int host_build_solver_pattern(const HostSpace& hs, bool use_bnd, std::vector<int32_t>& rowptr_s, std::vector<int32_t>& colidx_s,
+                              std::vector<int32_t>& full2s);
 
 }  // namespace fdapde_hip
 #endif

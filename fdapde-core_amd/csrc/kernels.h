@@ -559,6 +559,7 @@ struct SpmvArgs {
     const double* w;       // second vector of the fused dot products; nullptr: no dots
     double* partial;       // [2 * gridDim.x]: workgroup b writes (w.y, y.y) at 2b, 2b+1; nullptr: no dots
     const int32_t* stop;   // device flag: nonzero -> converged, kernel returns immediately (may be nullptr)
+    int32_t unit_diag;     // compact solver matrix: the (dropped) diagonal is 1, y_i = x_i + sum of the stored entries
     int32_t dot2_ww;       // second fused dot: 0 -> y.y (BiCGStab's t.t), 1 -> w.w over owned rows (single-reduction CG's r.r)
     const uint8_t* owned;  // multi-GPU: rows this rank counts in w.w (nullptr = all)
 };
@@ -875,6 +876,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
             const int64_t row = base + (lane % WROWS);
             const bool row_ok = FULL || row < band_end;
             const double wv = (ABL & (8 | 64)) ? 1.0 : wp[row_ok ? row : band_end - 1];
+            // implicit unit diagonal of the compact solver matrix (multi-GPU: added by the owner of the DOF only)
+            const int64_t rowc = row_ok ? row : band_end - 1;
+            const double xd = (s.unit_diag && !(s.owned && !s.owned[rowc])) ? s.x[rowc] : 0.0;
             int rsn[U], ren[U];
             F64x2 vn[U];
             I32x2 cn[U];
@@ -906,7 +910,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
             }
             if (l < U) ys[l * TEAMS + team] = pick;
             __builtin_amdgcn_wave_barrier();
-            const double out = ys[lane % WROWS];
+            const double out = ys[lane % WROWS] + xd;
             if constexpr (!(ABL & (8 | 32))) {
                 if constexpr (FULL) {
                     if constexpr (ABL & 128)
@@ -965,6 +969,20 @@ __global__ __launch_bounds__(256) void k_scale_matrix(int64_t n, const int32_t* 
     if (row >= n) return;
     const double si = scale[row];
     for (int k = rowptr[row] + l; k < rowptr[row + 1]; k += 16) out[k] = si * vals[k] * scale[colidx[k]];
+}
+// the same into the compact solver matrix: entries with map[k] < 0 are dropped (the diagonal, which scales to exactly 1,
+// and every entry in a row or column of a Dirichlet DOF, which scales to exactly 0)
+__global__ __launch_bounds__(256) void k_scale_matrix_compact(int64_t n, const int32_t* rowptr, const int32_t* colidx,
+                                                              const double* vals, const double* scale, const int32_t* map,
+                                                              double* out) {
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int l = threadIdx.x & 15;
+    if (row >= n) return;
+    const double si = scale[row];
+    for (int k = rowptr[row] + l; k < rowptr[row + 1]; k += 16) {
+        const int32_t m = map[k];
+        if (m >= 0) out[m] = si * vals[k] * scale[colidx[k]];
+    }
 }
 // gt = g on Dirichlet DOFs, 0 elsewhere (or all zero without Dirichlet data)
 __global__ void k_lift(int64_t n, const uint8_t* bnd, const double* g, int use_bnd, double* gt) {

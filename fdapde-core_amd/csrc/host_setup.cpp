@@ -422,6 +422,11 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
             if (!tcols[t].empty())
                 std::memcpy(&hs.colidx_i[(size_t)hs.rowptr_i[(size_t)tbegin[t]]], tcols[t].data(), sizeof(int32_t) * tcols[t].size());
     }
+    for (int64_t r = 0; r < nd; ++r)
+        if (hs.rowptr_i[(size_t)r + 1] == hs.rowptr_i[(size_t)r]) {
+            err = "a node is not referenced by any cell: its DOF has an empty matrix row (the reference's LU fails on such a mesh)";
+            return FDAPDE_EINVAL;
+        }
     if (hs.max_row > 65535 || hs.max_row > kSpmvNnz) {
         err = "row too long for the uint16 slot map / SpMV row block";
         return FDAPDE_EUNSUPPORTED;

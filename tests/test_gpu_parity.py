@@ -390,3 +390,32 @@ def test_single_reduction_cg_matches_cg(capi, ctx, oracle, mesh_loader, mesh_nam
         ref = oracle.pde_init_solve(m, order, mk(oracle), forcing_q=fq, dirichlet=dirichlet)
         for u in (ua, ub):
             assert np.linalg.norm(u - ref.solution) / np.linalg.norm(ref.solution) <= SOL_TOL
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_minimal_meshes_on_device(capi, ctx, oracle, order):
+    """edge sizes: a single triangle / tetrahedron and two tetrahedra (fewer rows than one SpMV tile, one assembly block
+    mostly empty): assembly, SpMV and a solve without Dirichlet data (-Lap + c is SPD on its own)"""
+    tri = (np.array([[0.0, 0.0], [1.0, 0.2], [0.1, 0.9]]), np.array([[0, 1, 2]], dtype=np.int32))
+    tet = (np.array([[0.0, 0, 0], [1.0, 0.1, 0], [0, 1.0, 0.2], [0.1, 0.2, 1.0]]), np.array([[0, 1, 2, 3]], dtype=np.int32))
+    two = (np.array([[0.0, 0, 0], [1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0], [1.0, 1.0, 1.0]]), np.array([[0, 1, 2, 3], [4, 2, 1, 3]], dtype=np.int32))
+    for nodes, cells in (tri, tet, two):
+        m = oracle.Mesh(nodes, cells, np.zeros(nodes.shape[0], dtype=np.uint8))
+        ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+        nd = ctx.dofs_build(order)
+        od, _, _, _ = oracle.enumerate_dofs(m, order)
+        op = lambda mod: -mod.laplacian() + mod.reaction(1.0)
+        nq = ctx.sizes()["n_quadrature"]
+        fq = np.arange(1.0, nq * m.n_cells + 1.0)
+        ctx.set_operator(op(capi))
+        ctx.set_forcing(fq)
+        ctx.set_dirichlet(None)
+        ctx.init()
+        ref = oracle.pde_init_solve(m, order, op(oracle), forcing_q=fq)
+        assert _entry_close(ctx.matrix_values(capi.MAT_STIFF), ref.stiff.values)
+        assert _entry_close(ctx.force(), ref.force)
+        x = np.arange(1.0, nd + 1.0)
+        assert np.abs(ctx.spmv(capi.MAT_STIFF, x) - ref.stiff.matvec(x)).max() <= 1e-12 * np.abs(ref.stiff.matvec(x)).max()
+        info = ctx.solve(rtol=1e-12)
+        assert info.converged == 1
+        assert np.linalg.norm(ctx.solution() - ref.solution) / np.linalg.norm(ref.solution) <= SOL_TOL

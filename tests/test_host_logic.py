@@ -77,3 +77,35 @@ def test_argument_validation(capi, mesh_loader):
         ctx.set_operator(-capi.laplacian())   # before dofs_build
     assert e.value.status == capi.ENOTINIT
     ctx.close()
+
+
+def test_unreferenced_node_is_rejected(capi):
+    """a node no cell references gives an empty matrix row; the reference's SparseLU would fail (success = false)"""
+    nodes = np.array([[0.0, 0.0], [1.0, 0.0], [0.0, 1.0], [5.0, 5.0]])
+    cells = np.array([[0, 1, 2]], dtype=np.int32)
+    ctx = capi.Context(device=None)
+    ctx.mesh_upload(nodes, cells, np.ones(4, dtype=np.uint8))
+    with pytest.raises(capi.FdapdeError) as e:
+        ctx.dofs_build(1)
+    assert e.value.status == capi.EINVAL
+    ctx.close()
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_minimal_meshes(capi, oracle, order):
+    """one triangle, one tetrahedron, two tetrahedra sharing a face: numbering and pattern as the oracle's"""
+    tri = (np.array([[0.0, 0.0], [1.0, 0.2], [0.1, 0.9]]), np.array([[0, 1, 2]], dtype=np.int32))
+    tet = (np.array([[0.0, 0, 0], [1.0, 0.1, 0], [0, 1.0, 0.2], [0.1, 0.2, 1.0]]), np.array([[0, 1, 2, 3]], dtype=np.int32))
+    two = (np.array([[0.0, 0, 0], [1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0], [1.0, 1.0, 1.0]]), np.array([[0, 1, 2, 3], [4, 2, 1, 3]], dtype=np.int32))
+    for nodes, cells in (tri, tet, two):
+        m = oracle.Mesh(nodes, cells, np.ones(nodes.shape[0], dtype=np.uint8))
+        ctx = capi.Context(device=None)
+        ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+        nd = ctx.dofs_build(order)
+        od, ob, ond, _ = oracle.enumerate_dofs(m, order)
+        dofs, bnd, coords = ctx.dofs_get()
+        assert nd == ond and np.array_equal(dofs, od) and np.array_equal(bnd, ob)
+        A = oracle.assemble_operator(m, order, od, ond, -oracle.laplacian())
+        rp, ci = ctx.pattern_get()
+        assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colidx)
+        ctx.close()

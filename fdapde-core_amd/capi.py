@@ -40,7 +40,7 @@ class Info(C.Structure):
 # every symbol include/fdapde_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "fdapde_abi_version", "fdapde_device_count", "fdapde_ctx_create", "fdapde_ctx_destroy", "fdapde_last_error",
-    "fdapde_status_string", "fdapde_mesh_upload", "fdapde_dofs_build", "fdapde_dofs_get", "fdapde_sizes",
+    "fdapde_status_string", "fdapde_mesh_upload", "fdapde_dofs_build", "fdapde_dofs_get", "fdapde_dofs_set_boundary", "fdapde_sizes",
     "fdapde_pattern_get", "fdapde_quadrature_nodes", "fdapde_set_operator", "fdapde_set_forcing", "fdapde_set_dirichlet",
     "fdapde_init", "fdapde_assemble_operator", "fdapde_solve", "fdapde_matrix_values", "fdapde_force", "fdapde_solution",
     "fdapde_info_get", "fdapde_spmv", "fdapde_bench_spmv", "fdapde_tune", "fdapde_stream", "fdapde_synchronize",
@@ -212,6 +212,11 @@ class Context:
         coords = np.zeros(self.N * s["n_dofs"])
         self._check(self.lib.fdapde_dofs_get(self._ctx, _ip(dofs), _bp(bnd), _dp(coords)))
         return dofs, bnd, np.ascontiguousarray(coords.reshape(self.N, s["n_dofs"]).T)
+
+    def dofs_set_boundary(self, bnd):
+        bnd = np.ascontiguousarray(bnd, dtype=np.uint8)
+        assert bnd.size == self.sizes()["n_dofs"]
+        self._check(self.lib.fdapde_dofs_set_boundary(self._ctx, _bp(bnd)))
 
     def pattern_get(self):
         s = self.sizes()

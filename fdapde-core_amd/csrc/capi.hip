@@ -637,6 +637,22 @@ int fdapde_sizes(const fdapde_ctx* c, int64_t* n_dofs, int64_t* nnz, int32_t* n_
     return FDAPDE_OK;
 }
 
+int fdapde_dofs_set_boundary(fdapde_ctx* c, const uint8_t* bnd) {
+    if (!c || !bnd) return FDAPDE_EINVAL;
+    HostSpace& hs = c->hs;
+    if (hs.n_dofs == 0) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
+    for (int64_t i = 0; i < hs.n_dofs; ++i) hs.dof_bnd[(size_t)i] = bnd[i] ? 1 : 0;
+    for (int64_t i = 0; i < hs.n_dofs; ++i) hs.dof_bnd_i[(size_t)i] = hs.dof_bnd[(size_t)hs.dof_i2e[(size_t)i]];
+    c->sp_built[1] = false;   // the compact solver pattern drops Dirichlet rows / columns
+    c->solved = false;
+    if (c->dev_ready) {
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, c->bnd.upload(hs.dof_bnd_i.data(), hs.dof_bnd_i.size(), c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return FDAPDE_OK;
+}
+
 int fdapde_dofs_get(const fdapde_ctx* c, int32_t* dofs, uint8_t* bnd, double* coords) {
     if (!c || !c->space_ready) return FDAPDE_ENOTINIT;
     if (dofs) std::memcpy(dofs, c->hs.dofs.data(), sizeof(int32_t) * c->hs.dofs.size());
@@ -881,14 +897,14 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     if ((method == FDAPDE_SOLVER_CG || method == FDAPDE_SOLVER_CG_SR) && !ss.diag_positive)
         return fail(c, FDAPDE_ENOCONV, "CG needs a positive diagonal (operator not SPD?); use BiCGStab");
     const bool bicg = method == FDAPDE_SOLVER_BICGSTAB, cgsr = method == FDAPDE_SOLVER_CG_SR;
-    if (dist && bicg) return fail(c, FDAPDE_EUNSUPPORTED, "the element-partitioned solve implements CG only (BiCGStab: single GPU)");
     const double tol2 = rtol * rtol;
     const double* ax = nullptr;
     if (u0_dev) {   // warm start: x = (u0 - g~) / s, r = b~ - At x
-        if (dist) return fail(c, FDAPDE_EUNSUPPORTED, "warm start is single GPU only");
         hipLaunchKernelGGL(k_krylov_init, dim3(c->vec_grid), dim3(256), 0, st, n, fvec, c->y.p, c->scale.p, c->x.p, c->r.p, c->p.p,
                            (double*)nullptr, c->part_b.p, owned, u0_dev, c->gt.p, (const double*)nullptr, 1);
         launch_spmv(c, c->sval.p, c->x.p, c->t.p, nullptr, nullptr, nullptr);
+        if (dist)
+            if (int rc = halo_sum(c, c->t.p, nullptr, 0)) return rc;
         ax = c->t.p;
     }
     hipLaunchKernelGGL(k_krylov_init, dim3(c->vec_grid), dim3(256), 0, st, n, fvec, c->y.p, c->scale.p, c->x.p, c->r.p, c->p.p,
@@ -954,7 +970,7 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
                     hipLaunchKernelGGL(k_cg_update_p, dim3(c->cg_grid), dim3(256), 0, st, n, c->r.p, c->p.p, c->sbuf.p, 1,
                                        c->sc.p, parity, tol2, c->ctl.p);
                 }
-            } else {
+            } else if (!dist) {
                 hipLaunchKernelGGL(k_bicg_p, dim3(c->vec_grid), dim3(256), 0, st, n, c->r.p, c->y.p, c->p.p, c->part_b.p,
                                    c->vec_grid, c->sc.p, launched == 0 ? 1 : 0, c->ctl.p);
                 const bool tm = launched < n_timed;
@@ -965,9 +981,33 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
                                    c->spmv_grid, c->sc.p, c->ctl.p);
                 launch_spmv(c, c->sval.p, c->s.p, c->t.p, c->s.p, c->part_a.p, c->ctl.p);    // t = At s, t.s, t.t
                 hipLaunchKernelGGL(k_bicg_xr, dim3(c->vec_grid), dim3(256), 0, st, n, c->p.p, c->s.p, c->t.p, c->r0.p, c->x.p,
-                                   c->r.p, c->part_a.p, c->spmv_grid, c->part_b.p, c->sc.p, c->ctl.p);
+                                   c->r.p, c->part_a.p, c->spmv_grid, c->part_b.p, c->sc.p, c->ctl.p, (const uint8_t*)nullptr);
                 hipLaunchKernelGGL(k_bicg_fin, dim3(1), dim3(256), 0, st, c->part_a.p, c->spmv_grid, c->part_b.p, c->vec_grid,
                                    c->sc.p, tol2, c->ctl.p);
+            } else {
+                // element-partitioned BiCGStab: every operator application is followed by the interface sum, which also carries
+                // the dot fused into the SpMV (w.(A x) needs no weighting); dots of assembled vectors (t.t, r0.r, r.r) count
+                // owned rows and cross in two small all-reduces.  sbuf: [0..1] = (r0.r, r.r), [4..5] = (t.s, t.t).
+                hipLaunchKernelGGL(k_bicg_p, dim3(c->vec_grid), dim3(256), 0, st, n, c->r.p, c->y.p, c->p.p, c->sbuf.p, 1, c->sc.p,
+                                   launched == 0 ? 1 : 0, c->ctl.p);
+                const bool tm = launched < n_timed;
+                launch_spmv(c, c->sval.p, c->p.p, c->y.p, c->r0.p, c->part_a.p, c->ctl.p,
+                            tm ? c->ev_spmv[2 * launched] : nullptr, tm ? c->ev_spmv[2 * launched + 1] : nullptr);
+                if (tm) ++timed;
+                if (int rc = halo_sum(c, c->y.p, c->part_a.p, c->spmv_grid)) return rc;
+                hipLaunchKernelGGL(k_bicg_s, dim3(c->vec_grid), dim3(256), 0, st, n, c->r.p, c->y.p, c->s.p, c->hbuf.p + c->n_if, 1,
+                                   c->sc.p, c->ctl.p);
+                launch_spmv(c, c->sval.p, c->s.p, c->t.p, c->s.p, c->part_a.p, c->ctl.p);
+                if (int rc = halo_sum(c, c->t.p, c->part_a.p, c->spmv_grid)) return rc;
+                hipLaunchKernelGGL(k_sq_owned, dim3(c->vec_grid), dim3(256), 0, st, n, c->t.p, owned, c->part_b.p, c->ctl.p);
+                hipLaunchKernelGGL(k_bicg_tt_fin, dim3(1), dim3(256), 0, st, c->part_b.p, c->vec_grid, c->hbuf.p + c->n_if,
+                                   c->sbuf.p + 4);
+                if (int rc = allreduce_sum(c, c->sbuf.p + 5, 1)) return rc;
+                hipLaunchKernelGGL(k_bicg_xr, dim3(c->vec_grid), dim3(256), 0, st, n, c->p.p, c->s.p, c->t.p, c->r0.p, c->x.p,
+                                   c->r.p, c->sbuf.p + 4, 1, c->part_b.p, c->sc.p, c->ctl.p, owned);
+                hipLaunchKernelGGL(k_reduce_partials2, dim3(1), dim3(256), 0, st, c->part_b.p, c->vec_grid, c->sbuf.p);
+                if (int rc = allreduce_sum(c, c->sbuf.p, 2)) return rc;
+                hipLaunchKernelGGL(k_bicg_fin, dim3(1), dim3(256), 0, st, c->sbuf.p + 4, 1, c->sbuf.p, 1, c->sc.p, tol2, c->ctl.p);
             }
         }
         HIPCHK(c, hipGetLastError());
@@ -1048,7 +1088,6 @@ int fdapde_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_t
     if (int rc = need_device(c)) return rc;
     if (!c->dev_ready || !c->assembled[0] || !c->assembled[1] || !c->force_ready)
         return fail(c, FDAPDE_ENOTINIT, "solver must be initialized first!");   // fem_linear_parabolic_solver.h:39
-    if ((c->comm || c->ar_fn) && c->halo_ready) return fail(c, FDAPDE_EUNSUPPORTED, "the parabolic stepper is single GPU only");
     if (c->fq_cols < n_times) return fail(c, FDAPDE_EINVAL, "forcing data needs one column per time point");
     HIPCHK(c, hipSetDevice(c->device));
     const HostSpace& hs = c->hs;
@@ -1114,7 +1153,6 @@ int fdapde_lin_compute(fdapde_ctx* c, int32_t which, const double* values, int32
     if (int rc = need_device(c)) return rc;
     if (!c->dev_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
     if (!values && !c->assembled[which]) return fail(c, FDAPDE_ENOTINIT, "matrix not assembled");
-    if ((c->comm || c->ar_fn) && c->halo_ready) return fail(c, FDAPDE_EUNSUPPORTED, "the solver handle is single GPU only");
     HIPCHK(c, hipSetDevice(c->device));
     const HostSpace& hs = c->hs;
     HIPCHK(c, c->lin_mat.alloc((size_t)hs.nnz + 2));
@@ -1481,7 +1519,7 @@ int fdapde_halo_setup(fdapde_ctx* c, int64_t n_if_global, int64_t n_if_local, co
     HIPCHK(c, c->halo_pos.upload(pos.data(), pos.size(), c->stream));
     HIPCHK(c, c->owned.upload(own_i.data(), own_i.size(), c->stream));
     HIPCHK(c, c->hbuf.alloc((size_t)n_if_global + 2));
-    HIPCHK(c, c->sbuf.alloc(4));
+    HIPCHK(c, c->sbuf.alloc(8));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->n_if = n_if_global, c->n_loc_if = n_if_local, c->halo_ready = true;
     return FDAPDE_OK;

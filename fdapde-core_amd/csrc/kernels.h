@@ -1246,7 +1246,7 @@ __global__ __launch_bounds__(256) void k_bicg_s(int64_t n, const double* r, cons
 __global__ __launch_bounds__(256) void k_bicg_xr(int64_t n, const double* p, const double* s, const double* t,
                                                   const double* r0, double* x, double* r,
                                                   const double* part_in /* (t.s, t.t) */, int np_in, double* part_out,
-                                                  const double* sc, int32_t* ctl) {
+                                                  const double* sc, int32_t* ctl, const uint8_t* owned) {
     __shared__ double red[8];
     if (__syncthreads_or(ctl[0] != 0)) return;   // uniform even if another workgroup raises the flag meanwhile
     double a = 0, b = 0;
@@ -1259,11 +1259,28 @@ __global__ __launch_bounds__(256) void k_bicg_xr(int64_t n, const double* p, con
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         x[i] += alpha * p[i] + omega * s[i];
         const double ri = s[i] - omega * t[i];
-        r[i] = ri, d0 += r0[i] * ri, d1 += ri * ri;
+        r[i] = ri;
+        if (!owned || owned[i]) d0 += r0[i] * ri, d1 += ri * ri;
     }
     const double s0 = block_sum(d0, red);
     const double s1 = block_sum(d1, red);
     if (threadIdx.x == 0) part_out[2 * blockIdx.x] = s0, part_out[2 * blockIdx.x + 1] = s1;
+}
+// multi-GPU BiCGStab: t.t over the owned rows of the ASSEMBLED t (the SpMV's fused y.y only sees this rank's sub-assembled
+// part); per-workgroup partials, then out = (t.s already summed over ranks, local t.t) for the scalar all-reduce of out[1]
+__global__ __launch_bounds__(256) void k_sq_owned(int64_t n, const double* t, const uint8_t* owned, double* part, const int32_t* ctl) {
+    __shared__ double red[8];
+    if (__syncthreads_or(ctl[0] != 0)) return;
+    double a = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if (owned[i]) a += t[i] * t[i];
+    const double s = block_sum(a, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_bicg_tt_fin(const double* part, int np, const double* ts_src, double* out) {
+    __shared__ double red[8];
+    const double s = sum_partials(part, np, red);
+    if (threadIdx.x == 0) out[0] = ts_src[0], out[1] = s;
 }
 // closes a BiCGStab iteration: rho <- rho_new, alpha, omega = t.s/t.t recomputed from the same partials, stop test
 __global__ __launch_bounds__(256) void k_bicg_fin(const double* part_ts, int np_ts, const double* part_rr, int np_rr,

@@ -6,7 +6,8 @@ Host logic (numpy, identical on every rank, no communication needed because ever
                          interface DOFs = nodes touched by >= 2 ranks, globally indexed 0..n_if-1;
                          owner of a node = lowest rank touching it (each global DOF is counted once in dot products)
 The device side (csrc/capi.hip) sums interface contributions with one RCCL all-reduce per operator application.
-P1 only for now (DOF = node); P2 needs the edge numbering of the sub-meshes matched across ranks (next round).
+DOFs are identified across ranks by numbering-independent keys (node id, or the end-node pair of an edge for P2), so
+every rank keeps the reference's enumeration on its own sub-mesh.
 """
 from __future__ import annotations
 
@@ -39,32 +40,90 @@ def partition_cells(nodes: np.ndarray, cells: np.ndarray, world: int) -> np.ndar
     return part
 
 
-def interface_info(cells: np.ndarray, part: np.ndarray, n_nodes: int, world: int):
-    """-> mult[node] (ranks touching it), owner[node] (lowest such rank), ifnodes (sorted global ids with mult >= 2)"""
-    mult = np.zeros(n_nodes, dtype=np.int32)
-    owner = np.full(n_nodes, world, dtype=np.int32)
-    for r in range(world):
-        touched = np.unique(cells[part == r])
-        mult[touched] += 1
-        owner[touched] = np.minimum(owner[touched], r)
-    return mult, owner, np.nonzero(mult >= 2)[0]
+# vertex pair of the edge DOF in local slot (M + 1) + j  (csrc/tables.cpp EDGE2 / EDGE3; 2-D: the reference's m01, m02, m12)
+_EDGE_SLOTS = {3: ((0, 1), (0, 2), (1, 2)), 4: ((1, 2), (0, 2), (0, 1), (1, 3), (2, 3), (0, 3))}
 
 
-def local_problem(nodes, cells, boundary, part, rank, world, info=None):
-    """Sub-mesh of `rank` and its interface maps (see fdapde_halo_setup in include/fdapde_hip.h)."""
-    mult, owner, ifnodes = info if info is not None else interface_info(cells, part, nodes.shape[0], world)
+def _cell_keys(cells_g: np.ndarray, n_nodes_g: int, order: int) -> np.ndarray:
+    """numbering-independent identity of the DOFs of every cell: vertex DOF -> its global node id, edge DOF (order 2) ->
+    n + lo * n + hi of its global end nodes; shape n_cells x n_basis in local-slot order"""
+    cg = cells_g.astype(np.int64)
+    if order == 1:
+        return cg
+    cols = [cg]
+    for a, b in _EDGE_SLOTS[cells_g.shape[1]]:
+        lo, hi = np.minimum(cg[:, a], cg[:, b]), np.maximum(cg[:, a], cg[:, b])
+        cols.append((n_nodes_g + lo * n_nodes_g + hi)[:, None])
+    return np.concatenate(cols, axis=1)
+
+
+def boundary_flags(cells, boundary_nodes, keys, order):
+    """boundary-DOF flag of every key of the WHOLE mesh, by the reference's rules: node markers; 2-D edge = seen by exactly
+    one cell (triangulation.h:177,187); 3-D edge = both end nodes on the boundary (triangulation.h:371)"""
+    n = boundary_nodes.shape[0]
+    flags = np.zeros(keys.size, dtype=np.uint8)
+    is_node = keys < n
+    flags[is_node] = boundary_nodes[keys[is_node]] != 0
+    if order == 2:
+        ek = keys[~is_node] - n
+        if cells.shape[1] == 3:
+            ck = _cell_keys(cells, n, 2)[:, 3:].ravel()
+            uk, cnt = np.unique(ck, return_counts=True)
+            flags[~is_node] = cnt[np.searchsorted(uk, keys[~is_node])] == 1
+        else:
+            flags[~is_node] = (boundary_nodes[ek // n] != 0) & (boundary_nodes[ek % n] != 0)
+    return flags
+
+
+def interface_info(cells, part, n_nodes, world, order=1, boundary_nodes=None):
+    """-> (keys, owner, ifkeys, bflags): the sorted DOF keys of the whole mesh, the lowest rank touching each, the sorted
+    keys touched by >= 2 ranks (the interface DOFs, globally indexed by their position in ifkeys), and the whole-mesh
+    boundary flag per key (None without boundary_nodes)"""
+    ck = _cell_keys(cells, n_nodes, order)
+    per_rank = [np.unique(ck[part == r]) for r in range(world)]
+    allk = np.concatenate(per_rank)
+    rank_of = np.repeat(np.arange(world, dtype=np.int32), [k.size for k in per_rank])
+    keys, first, counts = np.unique(allk, return_index=True, return_counts=True)
+    bflags = boundary_flags(cells, boundary_nodes, keys, order) if boundary_nodes is not None else None
+    return keys, rank_of[first], keys[counts >= 2], bflags
+
+
+def sub_mesh(nodes, cells, boundary, part, rank):
+    """the cells of `rank` with their nodes renumbered locally (ascending global id)"""
     my_cells = np.nonzero(part == rank)[0]
     l2g = np.unique(cells[my_cells])                       # local node id -> global node id (sorted)
     local_cells = np.searchsorted(l2g, cells[my_cells]).astype(np.int32)
-    is_if = mult[l2g] >= 2
-    local_dof = np.nonzero(is_if)[0].astype(np.int32)      # P1: DOF = node
-    if_index = np.searchsorted(ifnodes, l2g[local_dof]).astype(np.int32)
-    return dict(
-        nodes=np.ascontiguousarray(nodes[l2g]), cells=np.ascontiguousarray(local_cells),
-        boundary=np.ascontiguousarray(boundary[l2g]), l2g=l2g, cell_ids=my_cells,
-        n_if_global=int(ifnodes.size), local_dof=local_dof, if_index=if_index,
-        owned=(owner[l2g] == rank).astype(np.uint8),
-    )
+    return dict(nodes=np.ascontiguousarray(nodes[l2g]), cells=np.ascontiguousarray(local_cells),
+                boundary=np.ascontiguousarray(boundary[l2g]), l2g=l2g, cell_ids=my_cells)
+
+
+def dof_keys(cells_g, table, n_nodes_g, order):
+    """key of every DOF of a DOF table (n_cells x n_basis, any numbering) whose cells are given in GLOBAL node ids"""
+    ck = _cell_keys(cells_g, n_nodes_g, order)
+    keys = np.empty(int(table.max()) + 1, dtype=np.int64)
+    keys[table.ravel()] = ck.ravel()
+    return keys
+
+
+def interface_maps(sub, table, info, rank, n_nodes_g, order):
+    """interface maps of a sub-mesh for fdapde_halo_setup; `table` = the rank's own DOF table (fdapde_dofs_get)"""
+    keys_all, owner, ifkeys, bflags = info
+    k = dof_keys(sub["l2g"][sub["cells"]], table, n_nodes_g, order)     # key of each local DOF
+    pos = np.searchsorted(ifkeys, k)
+    is_if = (pos < ifkeys.size) & (ifkeys[np.minimum(pos, max(ifkeys.size - 1, 0))] == k) if ifkeys.size else np.zeros(k.size, bool)
+    local_dof = np.nonzero(is_if)[0].astype(np.int32)
+    gpos = np.searchsorted(keys_all, k)
+    return dict(n_if_global=int(ifkeys.size), local_dof=local_dof, if_index=pos[local_dof].astype(np.int32),
+                owned=(owner[gpos] == rank).astype(np.uint8), keys=k,
+                boundary_dofs=bflags[gpos] if bflags is not None else None)   # whole-mesh truth (fdapde_dofs_set_boundary)
+
+
+def local_problem(nodes, cells, boundary, part, rank, world, info=None):
+    """P1 convenience (DOF = node, the DOF table is the local cell table): sub-mesh + interface maps in one dict"""
+    info = info if info is not None else interface_info(cells, part, nodes.shape[0], world, 1, boundary)
+    sub = sub_mesh(nodes, cells, boundary, part, rank)
+    sub.update(interface_maps(sub, sub["cells"], info, rank, nodes.shape[0], 1))
+    return sub
 
 
 def bench_partitioned(capi, nodes, cells, bnd, f, u_exact, rank, world, local_rank, args, barrier, rtol, backend="nccl"):

@@ -109,6 +109,10 @@ int fdapde_dofs_build(fdapde_ctx *ctx, int order, int64_t *n_dofs);
 /* FEMSolverBase::n_dofs(), dofs(), boundary dofs, dofs_coords() (fem_solver_base.h:57-59, lagrangian_basis.h:155-183).
  * Any output pointer may be NULL.  dofs row-major n_cells x n_basis; coords column-major n_dofs x N. */
 int fdapde_dofs_get(const fdapde_ctx *ctx, int32_t *dofs_rowmajor, uint8_t *boundary_dofs, double *dof_coords_colmajor);
+/* Overrides the boundary-DOF mask (n_dofs flags, reference numbering) that fdapde_set_dirichlet / fdapde_solve use.  The
+ * reference always takes basis_.boundary_dofs() (fem_solver_base.h:143-153); an element-partitioned rank needs the override
+ * because the 2-D rule "edge seen by one cell" (triangulation.h:177,187) would mark its interface edges on the sub-mesh. */
+int fdapde_dofs_set_boundary(fdapde_ctx *ctx, const uint8_t *boundary_dofs);
 int fdapde_sizes(const fdapde_ctx *ctx, int64_t *n_dofs, int64_t *nnz, int32_t *n_basis, int32_t *n_quadrature,
                  int64_t *n_edges);
 /* sparsity pattern of stiff()/mass() in the reference's numbering: rowptr[n_dofs+1], colidx[nnz] sorted per row */

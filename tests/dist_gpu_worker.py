@@ -1,7 +1,8 @@
-"""Worker of tests/test_gpu_dist.py: one rank of a 2-rank job in which BOTH ranks share GPU 0.  The device-side distributed
-path (sub-assembly, interface pack / all-reduce / unpack, owner-masked dots, stop decisions) is the product's; only the
-all-reduce transport is swapped for a host-staged torch.distributed/gloo callback, because RCCL refuses two ranks on one
-device.  Result is compared with a single-domain solve of the whole mesh on the same GPU."""
+"""Worker of tests/test_gpu_dist.py: one rank of a 2- or 3-rank job in which ALL ranks share GPU 0.  The device-side
+distributed path (sub-assembly, interface pack / all-reduce / unpack, owner-masked dots, stop decisions) is the product's;
+only the all-reduce transport is swapped for a host-staged torch.distributed/gloo callback, because RCCL refuses two ranks on
+one device.  Results are compared with a single-domain run of the whole mesh on the same GPU.
+cases: p1 | p2 | sq2 (2-D P2: interface edges must not become Dirichlet) | adr1 | adr2 (BiCGStab) | parab | handle"""
 import os
 import sys
 
@@ -13,6 +14,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     rank, world, port, nx = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
+    case = sys.argv[5] if len(sys.argv) > 5 else "p1"
     import torch
     import torch.distributed as dist
 
@@ -23,42 +25,86 @@ def main():
     from fdapde_core_amd import dist as fdist
 
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    nodes, cells, bnd = meshgen.unit_cube(nx)
-    u_exact, f = meshgen.manufactured(3)
-    g_fn = lambda x: 0.3 * x[:, 0] - 0.2 * x[:, 2]
+    order = 2 if case in ("p2", "sq2", "adr2") else 1
+    nodes, cells, bnd = meshgen.unit_square(nx) if case == "sq2" else meshgen.unit_cube(nx)
+    N = nodes.shape[1]
+    n_g = nodes.shape[0]
+    u_exact, f = meshgen.manufactured(N)
+    g_fn = lambda x: 0.3 * x[:, 0] - 0.2 * x[:, -1]
+    bvec = [1.0, 0.5, 0.25][:N]
+    mkop = (lambda: -capi.laplacian() + capi.advection(bvec) + capi.reaction(1.0)) if case.startswith("adr") else \
+           (lambda: capi.dt() - capi.laplacian()) if case == "parab" else (lambda: -capi.laplacian())
     part = fdist.partition_cells(nodes, cells, world)
-    lp = fdist.local_problem(nodes, cells, bnd, part, rank, world)
+    info_if = fdist.interface_info(cells, part, n_g, world, order, bnd)
+    sub = fdist.sub_mesh(nodes, cells, bnd, part, rank)
 
     def allreduce(arr):
         t = torch.from_numpy(arr)
         dist.all_reduce(t)
 
     ctx = capi.Context(device=0)
-    ctx.mesh_upload(lp["nodes"], lp["cells"], lp["boundary"])
-    n_loc = ctx.dofs_build(1)
+    ctx.mesh_upload(sub["nodes"], sub["cells"], sub["boundary"])
+    n_loc = ctx.dofs_build(order)
+    table, _, lcoords = ctx.dofs_get()
+    maps = fdist.interface_maps(sub, table, info_if, rank, n_g, order)
+    ctx.dofs_set_boundary(maps["boundary_dofs"])
     ctx.comm_init_callback(world, rank, allreduce)
-    ctx.halo_setup(lp["n_if_global"], lp["local_dof"], lp["if_index"], lp["owned"])
-    ctx.set_operator(-capi.laplacian())
-    ctx.set_forcing(f(ctx.quadrature_nodes()))
-    ctx.set_dirichlet(g_fn(lp["nodes"]))
-    ctx.init()
-    info = ctx.solve(rtol=1e-11)
-    u = ctx.solution()
-    # single-domain solve of the whole mesh (every rank does it; same GPU)
+    ctx.halo_setup(maps["n_if_global"], maps["local_dof"], maps["if_index"], maps["owned"])
+    # single-domain context of the whole mesh (every rank builds it; same GPU)
     ref = capi.Context(device=0)
     ref.mesh_upload(nodes, cells, bnd)
-    ref.dofs_build(1)
-    ref.set_operator(-capi.laplacian())
-    ref.set_forcing(f(ref.quadrature_nodes()))
-    ref.set_dirichlet(g_fn(nodes))
-    ref.init()
-    rinfo = ref.solve(rtol=1e-11)
-    uref = ref.solution()
-    err = np.linalg.norm(u - uref[lp["l2g"]]) / np.linalg.norm(uref)
-    assert info.converged == 1 and err < 1e-8, (info.converged, err)
-    assert abs(info.iters - rinfo.iters) <= 2, (info.iters, rinfo.iters)     # same Krylov iteration up to rounding
-    print(f"rank {rank}: ok  local dofs {n_loc}  interface {lp['local_dof'].size}/{lp['n_if_global']}  iters {info.iters} "
-          f"(single domain {rinfo.iters})  err {err:.2e}")
+    ref.dofs_build(order)
+    gtable, gbnd, gcoords = ref.dofs_get()
+    gk = fdist.dof_keys(cells, gtable, n_g, order)
+    l2g = np.argsort(gk)[np.searchsorted(np.sort(gk), maps["keys"])]       # local DOF -> whole-mesh DOF id
+    assert np.array_equal(gbnd[l2g], maps["boundary_dofs"]) and np.abs(gcoords[l2g] - lcoords).max() <= 1e-15
+
+    ctx.set_operator(mkop())
+    ref.set_operator(mkop())
+    if case == "parab":
+        times = np.linspace(0.0, 0.5, 6)
+        ut = lambda x, t: u_exact(x) * np.exp(-t)
+        ft = lambda x, t: (f(x) - u_exact(x)) * np.exp(-t)
+        out = []
+        for c_, co in ((ctx, lcoords), (ref, gcoords)):
+            qn = c_.quadrature_nodes()
+            c_.set_forcing(np.stack([ft(qn, t) for t in times], axis=1))
+            c_.init()
+            G = np.stack([ut(co, t) for t in times], axis=1)
+            sol, inf = c_.solve_parabolic(times, G[:, 0], G, rtol=1e-11)
+            assert inf.converged == 1
+            out.append(sol)
+        err = max(np.linalg.norm(out[0][:, j] - out[1][l2g, j]) / np.linalg.norm(out[1][:, j]) for j in range(1, times.size))
+        assert err < 1e-8, err
+        msg = f"steps {times.size - 1}"
+    elif case == "handle":
+        for c_ in (ctx, ref):
+            c_.set_forcing(f(c_.quadrature_nodes()))
+            c_.init()
+            c_.lin_compute(capi.MAT_MASS, symmetric=True)
+        z = np.cos(3.0 * gcoords[:, 0]) + gcoords[:, 1] * gcoords[:, 2]
+        B = np.stack([ctx.spmv(capi.MAT_MASS, z[l2g]), ctx.spmv(capi.MAT_MASS, (z * z)[l2g])], axis=1)   # sub-assembled M z
+        X, inf = ctx.lin_solve(B, rtol=1e-12)
+        assert inf.converged == 1
+        err = max(np.linalg.norm(X[:, 0] - z[l2g]) / np.linalg.norm(z[l2g]), np.linalg.norm(X[:, 1] - (z * z)[l2g]) / np.linalg.norm((z * z)[l2g]))
+        assert err < 1e-8, err
+        msg = "handle"
+    else:
+        res = []
+        for c_, co in ((ctx, lcoords), (ref, gcoords)):
+            c_.set_forcing(f(c_.quadrature_nodes()))
+            c_.set_dirichlet(g_fn(co))
+            c_.init()
+            res.append((c_.solve(rtol=1e-11), c_.solution()))
+        (info, u), (rinfo, uref) = res
+        err = np.linalg.norm(u - uref[l2g]) / np.linalg.norm(uref)
+        assert info.converged == 1 and err < 1e-8, (info.converged, err)
+        if case.startswith("adr"):
+            assert info.method_used == capi.SOLVER_BICGSTAB and info.iters <= 1.3 * rinfo.iters + 5, (info.iters, rinfo.iters)
+        else:
+            assert abs(info.iters - rinfo.iters) <= max(2, rinfo.iters // 50), (info.iters, rinfo.iters)   # same Krylov iteration up to rounding
+        msg = f"iters {info.iters} (single domain {rinfo.iters})"
+    print(f"rank {rank}: ok  case {case}  local dofs {n_loc}  interface {maps['local_dof'].size}/{maps['n_if_global']}  {msg}  err {err:.2e}")
     dist.destroy_process_group()
 
 

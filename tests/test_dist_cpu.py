@@ -1,5 +1,5 @@
 """world_size-2 (and 3) gloo jobs on CPU covering the N > 1 path's host logic: partition, sub-meshes, interface maps,
-ownership, and the distributed Jacobi-PCG recurrence (tests/dist_worker.py)."""
+ownership (P1 and P2: DOFs matched across ranks by node / edge keys), and the distributed Jacobi-PCG and BiCGStab recurrences (tests/dist_worker.py)."""
 import os
 import socket
 import subprocess
@@ -16,7 +16,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,case", [(2, "unit_sphere"), (2, "square"), (3, "cube")])
+@pytest.mark.parametrize("world,case", [(2, "unit_sphere"), (2, "square"), (3, "cube"), (2, "square:2"), (3, "cube:2"),
+                                        (2, "cube:1:adr"), (2, "unit_sphere:2:adr")])
 def test_partitioned_pcg_matches_single_domain(world, case):
     port = str(_free_port())
     env = dict(os.environ, OMP_NUM_THREADS="1", MASTER_ADDR="127.0.0.1")

@@ -136,7 +136,10 @@ struct fdapde_ctx {
     int spmv_team = 16, spmv_unroll = 4, spmv_ablate = 0;
     int lds_limit = 96 * 1024;   // per assembly workgroup: tables + staged vertices + row accumulators
     // compact solver pattern (no diagonal; [1]: also no Dirichlet rows / columns), built on first use
-    DBuf<int32_t> sp_rowptr[2], sp_colidx[2], sp_map[2];
+    DBuf<int32_t> sp_rowptr[2], sp_colidx[2], sp_map[2], sp_tbase[2];
+    DBuf<uint16_t> sp_col16[2];              // 16-bit column codes of the compact pattern (host_build_col16)
+    int64_t sp_wide[2] = {0, 0};             // groups of 32 rows that fall back to the 32-bit columns
+    int spmv_c16 = 1;                        // tuning knob: 0 = always stream the 32-bit columns
     int64_t sp_nnz[2] = {0, 0};
     bool sp_built[2] = {false, false};
     int sp_cur = -1;   // which compact pattern c->sval currently holds (-1: full pattern)
@@ -412,12 +415,14 @@ void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, 
     s.w = w, s.partial = partial, s.stop = stop, s.dot2_ww = dot2_ww, s.owned = owned, s.unit_diag = 0;
     if (vals == c->sval.p && c->sp_cur >= 0) {   // the solver's scaled matrix lives in the compact pattern
         s.rowptr = c->sp_rowptr[c->sp_cur].p, s.colidx = c->sp_colidx[c->sp_cur].p, s.nnz = (int32_t)c->sp_nnz[c->sp_cur];
+        if (c->spmv_c16) s.col16 = c->sp_col16[c->sp_cur].p, s.tbase = c->sp_tbase[c->sp_cur].p;
         s.unit_diag = 1;
         // multi-GPU: the local diagonals s_i^2 (A_p)_ii of an interface DOF sum to 1 over the ranks sharing it; the implicit
         // unit diagonal is therefore contributed by the DOF's owner only (any split of the entries among ranks is valid)
         if ((c->comm != nullptr || c->ar_fn != nullptr) && c->halo_ready) s.owned = c->owned.p;
     }
-    const int64_t n = c->hs.n_dofs, rpb = (n + 7) / 8;
+    // eight row bands (one per XCD); band starts on a multiple of 32 rows so that a wavefront tile lies in one code group
+    const int64_t n = c->hs.n_dofs, rpb = (((n + 7) / 8) + 31) & ~int64_t(31);
     const dim3 grid(c->spmv_grid), block(256);
 #define SPMV_GO(...) hipExtLaunchKernelGGL((__VA_ARGS__), grid, block, 0, c->stream, e0, e1, 0, s, n, rpb)
     if (c->spmv_variant == 1) {
@@ -444,13 +449,17 @@ void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, 
             case 512: SPMV_GO(k_spmv_team2<8, 4, 512>); break;   // 16-byte y stores
             case 1024: SPMV_GO(k_spmv_team2<8, 4, 1024>); break;   // sc1 (write-through, no L2 allocate) y stores
             case 24: SPMV_GO(k_spmv_team2<8, 4, 24>); break;
+            case 2048: SPMV_GO(k_spmv_team2<8, 4, 2048>); break;   // 16-byte aligned entry pairs
+            case 3: SPMV_GO(k_spmv_team2<8, 4>); break;            // unaligned entry pairs (the form before alignment)
             default:
                 if (c->spmv_unroll == 2)
                     SPMV_GO(k_spmv_team2<8, 2>);
                 else if (c->spmv_unroll == 6)
                     SPMV_GO(k_spmv_team2<8, 6>);
+                else if (s.col16)
+                    SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096>);      // aligned pairs + 16-bit column codes
                 else
-                    SPMV_GO(k_spmv_team2<8, 4>);
+                    SPMV_GO(k_spmv_team2<8, 4, 2048>);
                 break;
             }
             break;
@@ -582,7 +591,8 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
         c->halo_dof.release(), c->halo_pos.release(), c->owned.release(), c->hbuf.release(), c->sbuf.release();
         if (c->comm) (void)g_rccl.CommDestroy(c->comm);
         c->lin_mat.release();
-        for (int v = 0; v < 2; ++v) c->sp_rowptr[v].release(), c->sp_colidx[v].release(), c->sp_map[v].release();
+        for (int v = 0; v < 2; ++v)
+            c->sp_rowptr[v].release(), c->sp_colidx[v].release(), c->sp_map[v].release(), c->sp_tbase[v].release(), c->sp_col16[v].release();
         if (c->h_ctl) (void)hipHostFree(c->h_ctl);
         if (c->h_sc) (void)hipHostFree(c->h_sc);
         (void)hipEventDestroy(c->ev0), (void)hipEventDestroy(c->ev1);
@@ -857,6 +867,16 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss) {
             HIPCHK(c, c->sp_rowptr[v].upload(rp.data(), rp.size(), st));
             HIPCHK(c, c->sp_colidx[v].upload(ci.data(), ci.size(), st));
             HIPCHK(c, c->sp_map[v].upload(map.data(), map.size(), st));
+            {   // 16-bit column codes of the same pattern
+                std::vector<uint16_t> code;
+                std::vector<int32_t> tb;
+                if (int rc = host_build_col16(n, rp, ci, code, tb, &c->sp_wide[v])) return rc;
+                HIPCHK(c, c->sp_col16[v].upload(code.data(), code.size(), st));
+                HIPCHK(c, c->sp_tbase[v].upload(tb.data(), tb.size(), st));
+                if (std::getenv("FDAPDE_DEBUG_SETUP"))
+                    std::fprintf(stderr, "solver pattern %d: %lld entries, %lld of %lld row groups wide\n", v, (long long)rp.back(),
+                                 (long long)c->sp_wide[v], (long long)((n + kCodeRows - 1) / kCodeRows));
+            }
             HIPCHK(c, hipStreamSynchronize(st));
             c->sp_nnz[v] = rp.back(), c->sp_built[v] = true;
         }
@@ -1533,6 +1553,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "spmv_team" && (value == 2 || value == 4 || value == 8 || value == 16 || value == 32 || value == 64)) c->spmv_team = value;
     else if (k == "spmv_unroll" && value >= 1 && value <= 8) c->spmv_unroll = value;
     else if (k == "spmv_ablate") c->spmv_ablate = value;
+    else if (k == "spmv_c16" && (value == 0 || value == 1)) c->spmv_c16 = value;
     else if (k == "spmv_bpx" && value >= 1 && value <= 1024) {
         c->spmv_grid = 8 * value;
         HIPCHK(c, hipSetDevice(c->device));

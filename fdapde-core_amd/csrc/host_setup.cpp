@@ -12,6 +12,7 @@
 // first occurrence in the reference's traversal order (cells ascending x local pattern), which a sort by
 // (edge key, occurrence index) yields directly and in parallel-friendly form.
 #include <algorithm>
+#include <atomic>
 #include <array>
 #include <chrono>
 #include <cmath>
@@ -427,6 +428,16 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
             err = "a node is not referenced by any cell: its DOF has an empty matrix row (the reference's LU fails on such a mesh)";
             return FDAPDE_EINVAL;
         }
+    if (const char* dump = std::getenv("FDAPDE_DEBUG_DUMP")) {   // internal CSR pattern + boundary flags for offline layout studies
+        if (FILE* fp = std::fopen(dump, "wb")) {
+            const int64_t hdr[2] = {nd, hs.nnz};
+            std::fwrite(hdr, sizeof(int64_t), 2, fp);
+            std::fwrite(hs.rowptr_i.data(), sizeof(int32_t), (size_t)nd + 1, fp);
+            std::fwrite(hs.colidx_i.data(), sizeof(int32_t), (size_t)hs.nnz, fp);
+            std::fwrite(hs.dof_bnd_i.data(), 1, (size_t)nd, fp);
+            std::fclose(fp);
+        }
+    }
     if (hs.max_row > 65535 || hs.max_row > kSpmvNnz) {
         err = "row too long for the uint16 slot map / SpMV row block";
         return FDAPDE_EUNSUPPORTED;
@@ -600,6 +611,55 @@ int host_build_solver_pattern(const HostSpace& hs, bool use_bnd, std::vector<int
                 if (keep(r, hs.colidx_i[(size_t)k])) colidx_s[(size_t)at] = hs.colidx_i[(size_t)k], full2s[(size_t)k] = at++;
         }
     });
+    return FDAPDE_OK;
+}
+
+// 16-bit column codes of a CSR pattern for k_spmv_team2: the kCodeRows consecutive rows of a group share up
+// to four windows of 2^14 columns; an entry is stored as (window << 14) | (column - window base).  Windows are placed greedily
+// over the group's sorted distinct columns.  A group that needs more than four windows (rows at a corner of the coarse blocks
+// of the locality numbering: ~1 % on C3) is marked wide (tbase[4 g] = -1) and read from the 32-bit column array instead.
+int host_build_col16(int64_t n, const std::vector<int32_t>& rowptr, const std::vector<int32_t>& colidx, std::vector<uint16_t>& code,
+                     std::vector<int32_t>& tbase, int64_t* n_wide) {
+    const int64_t ng = (n + kCodeRows - 1) / kCodeRows;
+    code.assign(colidx.size(), 0);
+    tbase.assign((size_t)ng * 4, 0);
+    std::atomic<int64_t> wide{0};
+    parallel_for(ng, [&](int64_t g0, int64_t g1, unsigned) {
+        std::vector<int32_t> cols;
+        for (int64_t g = g0; g < g1; ++g) {
+            const int32_t kb = rowptr[(size_t)(g * kCodeRows)], ke = rowptr[(size_t)std::min<int64_t>(n, (g + 1) * kCodeRows)];
+            cols.assign(colidx.begin() + kb, colidx.begin() + ke);
+            std::sort(cols.begin(), cols.end());
+            cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+            int32_t base[4] = {0, 0, 0, 0};
+            int nw = 0;
+            bool fits = true;
+            for (size_t i = 0; i < cols.size();) {
+                if (nw == 4) {
+                    fits = false;
+                    break;
+                }
+                base[nw] = cols[i];
+                const int64_t lim = (int64_t)cols[i] + kCodeWindow;
+                while (i < cols.size() && cols[i] < lim) ++i;
+                ++nw;
+            }
+            if (!fits) {
+                tbase[(size_t)g * 4] = -1;
+                wide.fetch_add(1, std::memory_order_relaxed);
+                continue;
+            }
+            for (int w = nw; w < 4; ++w) base[w] = base[nw > 0 ? nw - 1 : 0];
+            for (int w = 0; w < 4; ++w) tbase[(size_t)g * 4 + w] = base[w];
+            for (int32_t k = kb; k < ke; ++k) {
+                const int32_t c = colidx[(size_t)k];
+                int w = 0;
+                while (w + 1 < nw && c >= base[w + 1]) ++w;
+                code[(size_t)k] = (uint16_t)((w << 14) | (c - base[w]));
+            }
+        }
+    }, 64);
+    if (n_wide) *n_wide = wide.load();
     return FDAPDE_OK;
 }
 

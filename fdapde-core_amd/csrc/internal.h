@@ -90,6 +90,10 @@ int host_build_space(HostSpace& hs, int order, std::string& err);
 int host_build_colouring(HostSpace& hs, std::string& err);
 // Solver pattern: the internal CSR pattern without the diagonal and (use_bnd) without rows / columns of Dirichlet DOFs.
 // full2s[k] = slot of full entry k in the compact arrays, or -1 when the entry is dropped.
+// 16-bit column codes (k_spmv_team2): groups of kCodeRows rows, four windows of kCodeWindow columns each
+constexpr int kCodeRows = 32, kCodeWindow = 1 << 14;
+int host_build_col16(int64_t n, const std::vector<int32_t>& rowptr, const std::vector<int32_t>& colidx, std::vector<uint16_t>& code,
+                     std::vector<int32_t>& tbase, int64_t* n_wide);
 int host_build_solver_pattern(const HostSpace& hs, bool use_bnd, std::vector<int32_t>& rowptr_s, std::vector<int32_t>& colidx_s,
                               std::vector<int32_t>& full2s);
 

@@ -562,6 +562,8 @@ struct SpmvArgs {
     int32_t unit_diag;     // compact solver matrix: the (dropped) diagonal is 1, y_i = x_i + sum of the stored entries
     int32_t dot2_ww;       // second fused dot: 0 -> y.y (BiCGStab's t.t), 1 -> w.w over owned rows (single-reduction CG's r.r)
     const uint8_t* owned;  // multi-GPU: rows this rank counts in w.w (nullptr = all)
+    const uint16_t* col16; // 16-bit column codes (window << 14 | offset) of the pattern, or nullptr   (host_build_col16)
+    const int32_t* tbase;  // four window bases per group of 32 rows; tbase[4 g] < 0: wide group, read colidx instead
 };
 __device__ __forceinline__ double spmv_dot2(const SpmvArgs& s, int64_t row, double wv, double out) {
     if (!s.dot2_ww) return out * out;
@@ -824,21 +826,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
         const int64_t r = base + lane;
         return s.rowptr[r < band_end ? r : band_end];
     };
+    // ALIGNED: a row's lane pairs start at the even index rs & ~1, so that every pair is one 16-byte-aligned val load and
+    // one 8-byte-aligned colidx load (the entry below rs, if any, belongs to the previous row and is masked)
+    constexpr bool ALIGNED = (ABL & 2048) != 0;
+    // C16: the columns come as 16-bit codes, two per 4-byte load (needs the aligned pairs), decoded with the four window
+    // bases of the 32-row group when the gathers are issued: 2 instead of 4 index bytes per entry
+    constexpr bool C16 = (ABL & 4096) != 0;
+    static_assert(!C16 || (ALIGNED && 32 % WROWS == 0), "16-bit column codes need aligned pairs and tiles inside a 32-row group");
     auto load_pair = [&](int rs, int re, F64x2& v, I32x2& c) {
-        const int k = rs + 2 * l;
-        const int kc = k < last ? k : last;
+        const int k = (ALIGNED ? (rs & ~1) : rs) + 2 * l;
+        const int kc = ALIGNED ? (k < last ? k : (last & ~1)) : (k < last ? k : last);
         F64x2 vv;
         I32x2 cc;
-        if constexpr (!(ABL & 4)) {
+        if constexpr (C16) {
+            const v2f64_t a = __builtin_nontemporal_load(reinterpret_cast<const v2f64_t*>(s.vals + kc));
+            vv.x = a.x, vv.y = a.y;
+            cc.x = (int)__builtin_nontemporal_load(reinterpret_cast<const unsigned int*>(s.col16 + kc)), cc.y = 0;
+        } else if constexpr (ALIGNED) {
+            const v2f64_t a = __builtin_nontemporal_load(reinterpret_cast<const v2f64_t*>(s.vals + kc));
+            const v2i32_t b = __builtin_nontemporal_load(reinterpret_cast<const v2i32_t*>(s.colidx + kc));
+            vv.x = a.x, vv.y = a.y, cc.x = b.x, cc.y = b.y;
+        } else if constexpr (!(ABL & 4)) {
             vv.x = __builtin_nontemporal_load(s.vals + kc), vv.y = __builtin_nontemporal_load(s.vals + kc + 1);
             cc.x = __builtin_nontemporal_load(s.colidx + kc), cc.y = __builtin_nontemporal_load(s.colidx + kc + 1);
         } else {
             vv = *reinterpret_cast<const F64x2*>(s.vals + kc);
             cc = *reinterpret_cast<const I32x2*>(s.colidx + kc);
         }
-        const bool ok0 = k < re, ok1 = k + 1 < re;
+        const bool ok0 = k < re && (!ALIGNED || k >= rs), ok1 = k + 1 < re;
         v.x = ok0 ? vv.x : 0.0, v.y = ok1 ? vv.y : 0.0;
-        c.x = ok0 ? cc.x : 0, c.y = ok1 ? cc.y : 0;
+        if constexpr (C16)
+            c = cc;   // raw code pair; masked entries have a zero value and their decoded column is clamped into range
+        else
+            c.x = ok0 ? cc.x : 0, c.y = ok1 ? cc.y : 0;
+    };
+    // window bases of the 32-row group of a tile (wave-uniform address)
+    typedef int v4i32_t __attribute__((ext_vector_type(4)));
+    auto load_tb = [&](int64_t b) -> v4i32_t {
+        if constexpr (C16) {
+            const int64_t bc = b < band_end ? b : band_begin;
+            const int g = __builtin_amdgcn_readfirstlane((int)(bc >> 5));
+            return *reinterpret_cast<const v4i32_t*>(s.tbase + 4 * (int64_t)g);
+        } else
+            return v4i32_t{0, 0, 0, 0};
+    };
+    const int ncol1 = (int)n - 1;
+    auto decode = [&](unsigned int code, const v4i32_t& tb) -> int {
+        const int b01 = (code & 0x4000u) ? tb.y : tb.x, b23 = (code & 0x4000u) ? tb.w : tb.z;
+        const int col = ((code & 0x8000u) ? b23 : b01) + (int)(code & 0x3fffu);
+        return col < ncol1 ? col : ncol1;
     };
     int64_t base = band_begin + (int64_t)(lb * 4 + wave) * WROWS;
     if (base < band_end) {
@@ -847,6 +883,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
         int rs[U], re[U];
         F64x2 v[U];
         I32x2 c[U];
+        v4i32_t tb = load_tb(base);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             rs[u] = __shfl(rp0, u * TEAMS + team, 64), re[u] = __shfl(rp0, u * TEAMS + team + 1, 64);
@@ -863,6 +900,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
         auto tile = [&](auto full_tag) {
             constexpr bool FULL = decltype(full_tag)::value;
             double xa[U], xb[U];
+            if constexpr (C16) {
+                if (tb.x < 0) {   // wide group (wave-uniform, rare): its columns do not fit four windows
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int k = (rs[u] & ~1) + 2 * l;
+                        const v2i32_t b = *reinterpret_cast<const v2i32_t*>(s.colidx + (k < last ? k : (last & ~1)));
+                        c[u].x = b.x, c[u].y = b.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const unsigned int code = (unsigned int)c[u].x;
+                        c[u].x = decode(code & 0xffffu, tb), c[u].y = decode(code >> 16, tb);
+                    }
+                }
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if constexpr (ABL & 1)
@@ -887,15 +940,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
                 rsn[u] = __shfl(rp1, u * TEAMS + team, 64), ren[u] = __shfl(rp1, u * TEAMS + team + 1, 64);
                 load_pair(rsn[u], ren[u], vn[u], cn[u]);
             }
+            const v4i32_t tbn = load_tb(base + stride);
             rp1 = load_rp(base + 2 * stride);
             double acc[U];
             bool long_row = false;
 #pragma unroll
-            for (int u = 0; u < U; ++u) acc[u] = v[u].x * xa[u] + v[u].y * xb[u], long_row |= re[u] - rs[u] > 2 * T;
+            for (int u = 0; u < U; ++u)
+                acc[u] = v[u].x * xa[u] + v[u].y * xb[u], long_row |= re[u] - (ALIGNED ? (rs[u] & ~1) : rs[u]) > 2 * T;
             if (__any(long_row)) {   // rows longer than a team pass (rare when 2 T covers the mean row)
 #pragma unroll
                 for (int u = 0; u < U; ++u)
-                    for (int k = rs[u] + l + 2 * T; k < re[u]; k += T) acc[u] += s.vals[k] * s.x[s.colidx[k]];
+                    for (int k = (ALIGNED ? (rs[u] & ~1) : rs[u]) + l + 2 * T; k < re[u]; k += T) acc[u] += s.vals[k] * s.x[s.colidx[k]];
             }
             // every lane of a team gets the team's U row sums; lane l < U keeps row (u = l, team) = tile row l*TEAMS + team.
             // Stored from there, consecutive lanes would write rows TEAMS apart: 32 separate 8-byte partial writes per
@@ -936,6 +991,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
             d_wy += once * (wv * out), d_yy += once * spmv_dot2(s, row_ok ? row : band_end - 1, wv, out);
 #pragma unroll
             for (int u = 0; u < U; ++u) rs[u] = rsn[u], re[u] = ren[u], c[u] = cn[u], v[u] = vn[u];
+            tb = tbn;
         };
         for (; base + WROWS <= band_end; base += stride) tile(std::true_type {});
         if (base < band_end) tile(std::false_type {});

@@ -322,9 +322,9 @@ def test_distributed_code_path_on_one_rank(capi, ctx, oracle, mesh_loader):
     assert np.abs(u_dist - u_plain).max() <= 1e-13 * max(1.0, np.abs(u_plain).max())
     ref = oracle.pde_init_solve(m, 1, -oracle.laplacian() + oracle.reaction(0.7), forcing_q=fq, dirichlet=g)
     assert np.linalg.norm(u_dist - ref.solution) / np.linalg.norm(ref.solution) <= SOL_TOL
-    with pytest.raises(capi.FdapdeError) as e:
-        ctx.solve(method=capi.SOLVER_BICGSTAB)
-    assert e.value.status == capi.EUNSUPPORTED
+    bi = ctx.solve(method=capi.SOLVER_BICGSTAB, rtol=1e-11)   # distributed BiCGStab over the same 1-rank RCCL communicator
+    assert bi.converged == 1 and bi.method_used == capi.SOLVER_BICGSTAB
+    assert np.abs(ctx.solution() - u_plain).max() <= 1e-9 * max(1.0, np.abs(u_plain).max())
 
 
 def test_factor_once_solve_many(capi, ctx, oracle, mesh_loader):

@@ -10,6 +10,10 @@ ctx = capi.Context(0)
 ctx.mesh_upload(*meshgen.unit_cube(nx))
 ctx.dofs_build(1)
 ctx.assemble_operator(capi.MAT_STIFF, -capi.laplacian())
+if os.environ.get("SOLVE"):      # time the solver's compact Jacobi-scaled matrix (what CG streams) instead of stiff()
+    u_exact, f = meshgen.manufactured(3)
+    ctx.set_operator(-capi.laplacian()); ctx.set_forcing(f(ctx.quadrature_nodes())); ctx.set_dirichlet(np.zeros(ctx.sizes()["n_dofs"]))
+    ctx.init(); print("solve:", ctx.solve(rtol=1e-10).iters, "iterations")
 configs = [dict(c.split("=") for c in a.split(",")) for a in sys.argv[1:]] or [{"spmv_variant": "2"}]
 res = {i: [] for i in range(len(configs))}
 defaults = {"spmv_variant": 2, "spmv_team": 8, "spmv_unroll": 4, "spmv_bpx": 256, "spmv_ablate": 0}

@@ -430,9 +430,19 @@ void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, 
         return;
     }
     if (c->spmv_variant == 2) {   // two entries per lane: team = lanes per row, covering 2 * team entries per pass
+        // production forms: 16-byte aligned entry pairs (2048), + 16-bit column codes when the pattern has them (4096),
+        // + unconditional ownership loads when the implicit diagonal is owner-masked (multi-GPU, 8192)
+        const bool c16 = s.col16 != nullptr, dist = s.unit_diag && s.owned != nullptr;
+#define SPMV_PROD(T_, U_)                                                        \
+    do {                                                                         \
+        if (c16 && dist) SPMV_GO(k_spmv_team2<T_, U_, 2048 | 4096 | 8192>);      \
+        else if (c16) SPMV_GO(k_spmv_team2<T_, U_, 2048 | 4096>);                \
+        else if (dist) SPMV_GO(k_spmv_team2<T_, U_, 2048 | 8192>);               \
+        else SPMV_GO(k_spmv_team2<T_, U_, 2048>);                                \
+    } while (0)
         switch (c->spmv_team) {
-        case 2: SPMV_GO(k_spmv_team2<2, 1>); break;
-        case 4: SPMV_GO(k_spmv_team2<4, 2>); break;
+        case 2: SPMV_PROD(2, 1); break;
+        case 4: SPMV_PROD(4, 2); break;
         case 8:
             switch (c->spmv_ablate) {
             case 1: SPMV_GO(k_spmv_team2<8, 4, 1>); break;
@@ -444,28 +454,22 @@ void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, 
             case 16: SPMV_GO(k_spmv_team2<8, 4, 16>); break;   // one band (no XCD banding)
             case 32: SPMV_GO(k_spmv_team2<8, 4, 32>); break;   // no y store
             case 64: SPMV_GO(k_spmv_team2<8, 4, 64>); break;   // no w load
-            case 128: SPMV_GO(k_spmv_team2<8, 4, 128>); break;   // nontemporal y store
-            case 256: SPMV_GO(k_spmv_team2<8, 4, 256>); break;   // y stores confined to 32 KiB
-            case 512: SPMV_GO(k_spmv_team2<8, 4, 512>); break;   // 16-byte y stores
-            case 1024: SPMV_GO(k_spmv_team2<8, 4, 1024>); break;   // sc1 (write-through, no L2 allocate) y stores
-            case 24: SPMV_GO(k_spmv_team2<8, 4, 24>); break;
-            case 2048: SPMV_GO(k_spmv_team2<8, 4, 2048>); break;   // 16-byte aligned entry pairs
-            case 3: SPMV_GO(k_spmv_team2<8, 4>); break;            // unaligned entry pairs (the form before alignment)
+            case 3: SPMV_GO(k_spmv_team2<8, 4>); break;        // unaligned entry pairs, 32-bit columns (the form before)
+            case 2048: SPMV_GO(k_spmv_team2<8, 4, 2048>); break;   // aligned pairs, 32-bit columns
             default:
                 if (c->spmv_unroll == 2)
                     SPMV_GO(k_spmv_team2<8, 2>);
                 else if (c->spmv_unroll == 6)
                     SPMV_GO(k_spmv_team2<8, 6>);
-                else if (s.col16)
-                    SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096>);      // aligned pairs + 16-bit column codes
                 else
-                    SPMV_GO(k_spmv_team2<8, 4, 2048>);
+                    SPMV_PROD(8, 4);
                 break;
             }
             break;
-        case 16: SPMV_GO(k_spmv_team2<16, 4>); break;
-        default: SPMV_GO(k_spmv_team2<32, 4>); break;
+        case 16: SPMV_PROD(16, 4); break;
+        default: SPMV_PROD(32, 4); break;
         }
+#undef SPMV_PROD
         return;
     }
     switch (c->spmv_team) {
@@ -975,19 +979,19 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
                             tm ? c->ev_spmv[2 * launched] : nullptr, tm ? c->ev_spmv[2 * launched + 1] : nullptr);
                 if (tm) ++timed;
                 if (!dist) {
-                    hipLaunchKernelGGL(k_cg_update_xr, dim3(c->cg_grid), dim3(256), 0, st, n, c->p.p, c->y.p, c->x.p, c->r.p,
-                                       c->part_a.p, c->spmv_grid, c->part_b.p, c->sc.p, parity, c->ctl.p, owned);
-                    hipLaunchKernelGGL(k_cg_update_p, dim3(c->cg_grid), dim3(256), 0, st, n, c->r.p, c->p.p, c->part_b.p,
+                    hipLaunchKernelGGL(k_cg_update_xr, dim3(c->cg_grid), dim3(256), 0, st, n, c->y.p, c->r.p, c->part_a.p,
+                                       c->spmv_grid, c->part_b.p, c->sc.p, parity, c->ctl.p, owned);
+                    hipLaunchKernelGGL(k_cg_update_p, dim3(c->cg_grid), dim3(256), 0, st, n, c->r.p, c->p.p, c->x.p, c->part_b.p,
                                        c->cg_grid, c->sc.p, parity, tol2, c->ctl.p);
                 } else {
                     // one all-reduce carries the interface entries of A_p p and the rank's p.Ap partial; a second one
                     // (a single double) carries r.r.  Every rank takes the same stop decision from the same numbers.
                     if (int rc = halo_sum(c, c->y.p, c->part_a.p, c->spmv_grid)) return rc;
-                    hipLaunchKernelGGL(k_cg_update_xr, dim3(c->cg_grid), dim3(256), 0, st, n, c->p.p, c->y.p, c->x.p, c->r.p,
-                                       c->hbuf.p + c->n_if, 1, c->part_b.p, c->sc.p, parity, c->ctl.p, owned);
+                    hipLaunchKernelGGL(k_cg_update_xr, dim3(c->cg_grid), dim3(256), 0, st, n, c->y.p, c->r.p, c->hbuf.p + c->n_if, 1,
+                                       c->part_b.p, c->sc.p, parity, c->ctl.p, owned);
                     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, c->part_b.p, c->cg_grid, c->sbuf.p);
                     if (int rc = allreduce_sum(c, c->sbuf.p, 1)) return rc;
-                    hipLaunchKernelGGL(k_cg_update_p, dim3(c->cg_grid), dim3(256), 0, st, n, c->r.p, c->p.p, c->sbuf.p, 1,
+                    hipLaunchKernelGGL(k_cg_update_p, dim3(c->cg_grid), dim3(256), 0, st, n, c->r.p, c->p.p, c->x.p, c->sbuf.p, 1,
                                        c->sc.p, parity, tol2, c->ctl.p);
                 }
             } else if (!dist) {

@@ -931,7 +931,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
             const double wv = (ABL & (8 | 64)) ? 1.0 : wp[row_ok ? row : band_end - 1];
             // implicit unit diagonal of the compact solver matrix (multi-GPU: added by the owner of the DOF only)
             const int64_t rowc = row_ok ? row : band_end - 1;
-            const double xd = (s.unit_diag && !(s.owned && !s.owned[rowc])) ? s.x[rowc] : 0.0;
+            double xd;
+            if constexpr (ABL & 8192) {   // multi-GPU instantiation: ownership byte and x loaded unconditionally with the gathers
+                const uint8_t mine = s.owned[rowc];
+                const double xv = s.x[rowc];
+                xd = (s.unit_diag && mine) ? xv : 0.0;
+            } else
+                xd = (s.unit_diag && !(s.owned && !s.owned[rowc])) ? s.x[rowc] : 0.0;
             int rsn[U], ren[U];
             F64x2 vn[U];
             I32x2 cn[U];
@@ -1111,43 +1117,44 @@ __global__ void k_parabolic_rhs(int64_t n, const double* mu, double inv_dt, cons
 // CG (on the symmetrically scaled system, i.e. Jacobi-PCG on the original one)
 //   k_spmv            : y = At p, partials of p.y
 //   k_cg_update_xr    : alpha = rr / p.y ; x += alpha p ; r -= alpha y ; partials of r.r
-//   k_cg_update_p     : beta = rr_new / rr ; p = r + beta p ; bookkeeping + stopping test (workgroup 0)
+//   k_cg_update_p     : x += alpha p ; beta = rr_new / rr ; p = r + beta p ; bookkeeping + stopping test
+//   (x is updated where p is streamed anyway: 3 + 5 vector passes per iteration instead of 6 + 3)
 // ---------------------------------------------------------------------------------------------------------------
 // Both update kernels are single-shot: workgroup b owns kCgV * 256 consecutive double2 elements, every lane issues all of
 // its 16-byte loads FIRST, and only then re-reduces the producer's partials (an L2 round trip plus two barriers) -- the
 // reduction hides under the loads instead of delaying them (measured per-kernel saving ~2 us of 17 / 9 us).
 constexpr int kCgV = 4;
 // owned (multi-GPU): 1 for DOFs this rank counts in global dot products, nullptr = all (single GPU)
-__global__ __launch_bounds__(256) void k_cg_update_xr(int64_t n, const double* p, const double* y, double* x, double* r,
-                                                       const double* part_in, int np_in, double* part_out,
-                                                       const double* sc, int parity, int32_t* ctl, const uint8_t* owned) {
+__global__ __launch_bounds__(256) void k_cg_update_xr(int64_t n, const double* y, double* r, const double* part_in, int np_in,
+                                                       double* part_out, double* sc, int parity, int32_t* ctl,
+                                                       const uint8_t* owned) {
     __shared__ double red[8];
     if (__syncthreads_or(ctl[0] != 0)) return;   // uniform even if another workgroup raises the flag meanwhile
     const int64_t n2 = n >> 1, i0 = (int64_t)blockIdx.x * (256 * kCgV) + threadIdx.x;
-    const double2* p2 = reinterpret_cast<const double2*>(p);
     const double2* y2 = reinterpret_cast<const double2*>(y);
-    double2* x2 = reinterpret_cast<double2*>(x);
     double2* r2 = reinterpret_cast<double2*>(r);
-    double2 pv[kCgV], yv[kCgV], xv[kCgV], rv[kCgV];
+    double2 yv[kCgV], rv[kCgV];
 #pragma unroll
     for (int k = 0; k < kCgV; ++k) {
         const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
-        pv[k] = p2[ic], yv[k] = y2[ic], xv[k] = x2[ic], rv[k] = r2[ic];
+        yv[k] = y2[ic], rv[k] = r2[ic];
     }
     double v = 0;
     for (int i = threadIdx.x; i < np_in; i += blockDim.x) v += part_in[2 * i];
     const double pAp = block_sum(v, red);
     const double rr = sc[1 + parity];
     const double alpha = pAp > 0.0 ? rr / pAp : 0.0;
-    if (!(pAp > 0.0) && blockIdx.x == 0 && threadIdx.x == 0) ctl[2] = 1;   // not SPD / breakdown
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc[14] = alpha;                  // x += alpha p is done by k_cg_update_p, which streams p anyway
+        if (!(pAp > 0.0)) ctl[2] = 1;    // not SPD / breakdown
+    }
     double acc = 0;
 #pragma unroll
     for (int k = 0; k < kCgV; ++k) {
         const int64_t i = i0 + k * 256;
         if (i < n2) {
-            xv[k].x += alpha * pv[k].x, xv[k].y += alpha * pv[k].y;
             rv[k].x -= alpha * yv[k].x, rv[k].y -= alpha * yv[k].y;
-            x2[i] = xv[k], r2[i] = rv[k];
+            r2[i] = rv[k];
             if (owned)
                 acc += (owned[2 * i] ? rv[k].x * rv[k].x : 0.0) + (owned[2 * i + 1] ? rv[k].y * rv[k].y : 0.0);
             else
@@ -1156,7 +1163,6 @@ __global__ __launch_bounds__(256) void k_cg_update_xr(int64_t n, const double* p
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const int64_t i = n - 1;
-        x[i] += alpha * p[i];
         const double ri = r[i] - alpha * y[i];
         r[i] = ri;
         if (!owned || owned[i]) acc += ri * ri;
@@ -1164,31 +1170,36 @@ __global__ __launch_bounds__(256) void k_cg_update_xr(int64_t n, const double* p
     const double s = block_sum(acc, red);
     if (threadIdx.x == 0) part_out[blockIdx.x] = s;
 }
-__global__ __launch_bounds__(256) void k_cg_update_p(int64_t n, const double* r, double* p, const double* part_in,
+__global__ __launch_bounds__(256) void k_cg_update_p(int64_t n, const double* r, double* p, double* x, const double* part_in,
                                                       int np_in, double* sc, int parity, double tol2, int32_t* ctl) {
     __shared__ double red[8];
     if (__syncthreads_or(ctl[0] != 0)) return;   // uniform even if another workgroup raises the flag meanwhile
     const int64_t n2 = n >> 1, i0 = (int64_t)blockIdx.x * (256 * kCgV) + threadIdx.x;
     const double2* r2 = reinterpret_cast<const double2*>(r);
     double2* p2 = reinterpret_cast<double2*>(p);
-    double2 rv[kCgV], pv[kCgV];
+    double2* x2 = reinterpret_cast<double2*>(x);
+    double2 rv[kCgV], pv[kCgV], xv[kCgV];
 #pragma unroll
     for (int k = 0; k < kCgV; ++k) {
         const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
-        rv[k] = r2[ic], pv[k] = p2[ic];
+        rv[k] = r2[ic], pv[k] = p2[ic], xv[k] = x2[ic];
     }
     const double rr_new = sum_partials(part_in, np_in, red);
-    const double rr = sc[1 + parity];
+    const double rr = sc[1 + parity], alpha = sc[14];
     const double beta = rr > 0.0 ? rr_new / rr : 0.0;
 #pragma unroll
     for (int k = 0; k < kCgV; ++k) {
         const int64_t i = i0 + k * 256;
         if (i < n2) {
+            xv[k].x += alpha * pv[k].x, xv[k].y += alpha * pv[k].y;
             pv[k].x = rv[k].x + beta * pv[k].x, pv[k].y = rv[k].y + beta * pv[k].y;
-            p2[i] = pv[k];
+            x2[i] = xv[k], p2[i] = pv[k];
         }
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = r[n - 1] + beta * p[n - 1];
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        x[n - 1] += alpha * p[n - 1];
+        p[n - 1] = r[n - 1] + beta * p[n - 1];
+    }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
         sc[1 + (parity ^ 1)] = rr_new, sc[3] = rr_new;
         ctl[1] += 1;

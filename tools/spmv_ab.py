@@ -8,7 +8,7 @@ from fdapde_core_amd import capi, meshgen
 nx = int(os.environ.get("NX", "119"))
 ctx = capi.Context(0)
 ctx.mesh_upload(*meshgen.unit_cube(nx))
-ctx.dofs_build(1)
+ctx.dofs_build(int(os.environ.get("ORDER", "1")))
 ctx.assemble_operator(capi.MAT_STIFF, -capi.laplacian())
 if os.environ.get("SOLVE"):      # time the solver's compact Jacobi-scaled matrix (what CG streams) instead of stiff()
     u_exact, f = meshgen.manufactured(3)
@@ -16,7 +16,7 @@ if os.environ.get("SOLVE"):      # time the solver's compact Jacobi-scaled matri
     ctx.init(); print("solve:", ctx.solve(rtol=1e-10).iters, "iterations")
 configs = [dict(c.split("=") for c in a.split(",")) for a in sys.argv[1:]] or [{"spmv_variant": "2"}]
 res = {i: [] for i in range(len(configs))}
-defaults = {"spmv_variant": 2, "spmv_team": 8, "spmv_unroll": 4, "spmv_bpx": 256, "spmv_ablate": 0}
+defaults = {"spmv_variant": 2, "spmv_team": int(os.environ.get("TEAM", "8")), "spmv_unroll": 4, "spmv_bpx": 256, "spmv_ablate": 0, "spmv_c16": 1}
 for rnd in range(7):
     for i, cfg in enumerate(configs):
         full = dict(defaults); full.update({k: int(v) for k, v in cfg.items()})

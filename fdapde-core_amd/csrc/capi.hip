@@ -433,16 +433,25 @@ void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, 
         // production forms: 16-byte aligned entry pairs (2048), + 16-bit column codes when the pattern has them (4096),
         // + unconditional ownership loads when the implicit diagonal is owner-masked (multi-GPU, 8192)
         const bool c16 = s.col16 != nullptr, dist = s.unit_diag && s.owned != nullptr;
-#define SPMV_PROD(T_, U_)                                                        \
+        const bool wx = s.w == nullptr || s.w == s.x;   // dot operand == x (CG: p.Ap): one row load serves both (16384)
+#define SPMV_PROD_FEW(T_, U_)                                                    \
     do {                                                                         \
         if (c16 && dist) SPMV_GO(k_spmv_team2<T_, U_, 2048 | 4096 | 8192>);      \
         else if (c16) SPMV_GO(k_spmv_team2<T_, U_, 2048 | 4096>);                \
         else if (dist) SPMV_GO(k_spmv_team2<T_, U_, 2048 | 8192>);               \
         else SPMV_GO(k_spmv_team2<T_, U_, 2048>);                                \
     } while (0)
+#define SPMV_PROD(T_, U_)                                                                    \
+    do {                                                                                     \
+        if (!wx) SPMV_PROD_FEW(T_, U_);                                                      \
+        else if (c16 && dist) SPMV_GO(k_spmv_team2<T_, U_, 2048 | 4096 | 8192 | 16384>);     \
+        else if (c16) SPMV_GO(k_spmv_team2<T_, U_, 2048 | 4096 | 16384>);                    \
+        else if (dist) SPMV_GO(k_spmv_team2<T_, U_, 2048 | 8192 | 16384>);                   \
+        else SPMV_GO(k_spmv_team2<T_, U_, 2048 | 16384>);                                    \
+    } while (0)
         switch (c->spmv_team) {
-        case 2: SPMV_PROD(2, 1); break;
-        case 4: SPMV_PROD(4, 2); break;
+        case 2: SPMV_PROD_FEW(2, 1); break;
+        case 4: SPMV_PROD_FEW(4, 2); break;
         case 8:
             switch (c->spmv_ablate) {
             case 1: SPMV_GO(k_spmv_team2<8, 4, 1>); break;
@@ -467,9 +476,10 @@ void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, 
             }
             break;
         case 16: SPMV_PROD(16, 4); break;
-        default: SPMV_PROD(32, 4); break;
+        default: SPMV_PROD_FEW(32, 4); break;
         }
 #undef SPMV_PROD
+#undef SPMV_PROD_FEW
         return;
     }
     switch (c->spmv_team) {

@@ -928,16 +928,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
             // lane j < WROWS reports row base + j (rows are transposed into lane order through ystage below)
             const int64_t row = base + (lane % WROWS);
             const bool row_ok = FULL || row < band_end;
-            const double wv = (ABL & (8 | 64)) ? 1.0 : wp[row_ok ? row : band_end - 1];
             // implicit unit diagonal of the compact solver matrix (multi-GPU: added by the owner of the DOF only)
             const int64_t rowc = row_ok ? row : band_end - 1;
-            double xd;
-            if constexpr (ABL & 8192) {   // multi-GPU instantiation: ownership byte and x loaded unconditionally with the gathers
-                const uint8_t mine = s.owned[rowc];
+            double wv, xd;
+            if constexpr (ABL & 16384) {   // the dot operand IS x (CG: p.Ap): one row load serves the dot and the diagonal
                 const double xv = s.x[rowc];
-                xd = (s.unit_diag && mine) ? xv : 0.0;
-            } else
-                xd = (s.unit_diag && !(s.owned && !s.owned[rowc])) ? s.x[rowc] : 0.0;
+                wv = xv;
+                if constexpr (ABL & 8192)
+                    xd = (s.unit_diag && s.owned[rowc]) ? xv : 0.0;
+                else
+                    xd = s.unit_diag ? xv : 0.0;
+            } else {
+                wv = (ABL & (8 | 64)) ? 1.0 : wp[rowc];
+                if constexpr (ABL & 8192) {   // multi-GPU instantiation: ownership byte and x loaded unconditionally with the gathers
+                    const uint8_t mine = s.owned[rowc];
+                    const double xv = s.x[rowc];
+                    xd = (s.unit_diag && mine) ? xv : 0.0;
+                } else
+                    xd = (s.unit_diag && !(s.owned && !s.owned[rowc])) ? s.x[rowc] : 0.0;
+            }
             int rsn[U], ren[U];
             F64x2 vn[U];
             I32x2 cn[U];

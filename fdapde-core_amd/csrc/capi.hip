@@ -926,11 +926,13 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     launch_spmv(c, A, c->gt.p, c->y.p, nullptr, nullptr, nullptr);   // y = A g~
     if (dist)
         if (int rc = halo_sum(c, c->y.p, nullptr, 0)) return rc;
-    if (method == FDAPDE_SOLVER_AUTO) method = (c->op_symmetric && ss.diag_positive) ? FDAPDE_SOLVER_CG : FDAPDE_SOLVER_BICGSTAB;
+    if (method == FDAPDE_SOLVER_AUTO)   // symmetric + positive diagonal: CG (fused-update form on one GPU, single-reduction form on several)
+        method = (c->op_symmetric && ss.diag_positive) ? (dist ? FDAPDE_SOLVER_CG : FDAPDE_SOLVER_CG_FUSED) : FDAPDE_SOLVER_BICGSTAB;
     if (method == FDAPDE_SOLVER_CG && dist && c->world > 1) method = FDAPDE_SOLVER_CG_SR;   // one all-reduce per iteration
-    if ((method == FDAPDE_SOLVER_CG || method == FDAPDE_SOLVER_CG_SR) && !ss.diag_positive)
+    if (method == FDAPDE_SOLVER_CG_FUSED && dist) method = FDAPDE_SOLVER_CG_SR;   // y.y of the assembled y would need its own all-reduce
+    if ((method == FDAPDE_SOLVER_CG || method == FDAPDE_SOLVER_CG_SR || method == FDAPDE_SOLVER_CG_FUSED) && !ss.diag_positive)
         return fail(c, FDAPDE_ENOCONV, "CG needs a positive diagonal (operator not SPD?); use BiCGStab");
-    const bool bicg = method == FDAPDE_SOLVER_BICGSTAB, cgsr = method == FDAPDE_SOLVER_CG_SR;
+    const bool bicg = method == FDAPDE_SOLVER_BICGSTAB, cgsr = method == FDAPDE_SOLVER_CG_SR, cgf = method == FDAPDE_SOLVER_CG_FUSED;
     const double tol2 = rtol * rtol;
     const double* ax = nullptr;
     if (u0_dev) {   // warm start: x = (u0 - g~) / s, r = b~ - At x
@@ -982,6 +984,15 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
                 }
                 hipLaunchKernelGGL(k_cgsr_update, dim3(c->cg_grid), dim3(256), 0, st, n, c->r.p, c->y.p, c->p.p, c->s.p, c->x.p, part,
                                    np, c->sc.p, parity, launched == 0 ? 1 : 0, tol2, c->ctl.p);
+            } else if (cgf) {
+                const bool tm = launched < n_timed;
+                const int cg = c->cg_grid;   // explicit r.r partials ping-pong between the two halves of part_b
+                launch_spmv(c, c->sval.p, c->p.p, c->y.p, c->p.p, c->part_a.p, c->ctl.p, tm ? c->ev_spmv[2 * launched] : nullptr,
+                            tm ? c->ev_spmv[2 * launched + 1] : nullptr);   // p.y and y.y
+                if (tm) ++timed;
+                hipLaunchKernelGGL(k_cgf_update, dim3(cg), dim3(256), 0, st, n, c->y.p, c->p.p, c->x.p, c->r.p, c->part_a.p,
+                                   c->spmv_grid, c->part_b.p + (size_t)((launched + 1) & 1) * cg, cg,
+                                   c->part_b.p + (size_t)(launched & 1) * cg, c->sc.p, launched == 0 ? 1 : 0, tol2, c->ctl.p);
             } else if (!bicg) {
                 const int parity = launched & 1;
                 const bool tm = launched < n_timed;
@@ -1044,6 +1055,9 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
                 hipLaunchKernelGGL(k_bicg_fin, dim3(1), dim3(256), 0, st, c->sbuf.p + 4, 1, c->sbuf.p, 1, c->sc.p, tol2, c->ctl.p);
             }
         }
+        if (cgf && launched > 0)   // explicit r.r of the last update -> sc[3] / stop flag
+            hipLaunchKernelGGL(k_cgf_fin, dim3(1), dim3(256), 0, st, c->part_b.p + (size_t)((launched - 1) & 1) * c->cg_grid,
+                               c->cg_grid, c->sc.p, tol2, c->ctl.p);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipMemcpyAsync(c->h_sc, c->sc.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1219,7 +1233,7 @@ int fdapde_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, 
     const int check_every = (opt && opt->check_every > 0) ? opt->check_every : 32;
     int method = opt ? opt->method : FDAPDE_SOLVER_AUTO;
     if (method == FDAPDE_SOLVER_AUTO)
-        method = (c->lin_symmetric && c->lin_state->ss.diag_positive) ? FDAPDE_SOLVER_CG : FDAPDE_SOLVER_BICGSTAB;
+        method = (c->lin_symmetric && c->lin_state->ss.diag_positive) ? FDAPDE_SOLVER_CG_FUSED : FDAPDE_SOLVER_BICGSTAB;
     if (c->solved) {   // an fdapde_solve in between has overwritten the scaled copy: prepare again (cheap)
         if (int rc = solve_prepare(c, c->lin_mat.p, 0, &c->lin_state->ss)) return rc;
         c->solved = false;

@@ -1278,6 +1278,79 @@ __global__ __launch_bounds__(256) void k_cgsr_update(int64_t n, double* r, const
     }
 }
 
+// Fused-update CG (single GPU): the SpMV y = At p carries p.y and y.y; ONE kernel then does
+//     alpha = rr / p.y ; x += alpha p ; r -= alpha y ; beta = (alpha^2 y.y - rr) / rr ; p = r + beta p
+// rr is the EXPLICIT r.r (partials written by the previous launch of this kernel); alpha^2 y.y - rr equals r_new.r_new in
+// exact arithmetic (r.y = p.y by A-conjugacy) and is used for beta only, so that p needs no second pass after a global
+// reduction: 7 vector passes and 2 launches per iteration instead of 8 and 3.  The stop test is taken at the start of the
+// next launch (or by k_cgf_fin at a host poll) from the explicit r.r, uniformly by every workgroup.
+__global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, double* p, double* x, double* r,
+                                                     const double* part_spmv, int np_spmv, const double* part_rr_in, int np_rr,
+                                                     double* part_rr_out, double* sc, int first, double tol2, int32_t* ctl) {
+    __shared__ double red[8];
+    if (__syncthreads_or(ctl[0] != 0)) return;
+    const int64_t n2 = n >> 1, i0 = (int64_t)blockIdx.x * (256 * kCgV) + threadIdx.x;
+    const double2* y2 = reinterpret_cast<const double2*>(y);
+    double2* p2 = reinterpret_cast<double2*>(p);
+    double2* x2 = reinterpret_cast<double2*>(x);
+    double2* r2 = reinterpret_cast<double2*>(r);
+    double2 yv[kCgV], pv[kCgV], xv[kCgV], rv[kCgV];
+#pragma unroll
+    for (int k = 0; k < kCgV; ++k) {
+        const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
+        yv[k] = y2[ic], pv[k] = p2[ic], xv[k] = x2[ic], rv[k] = r2[ic];
+    }
+    double a = 0, b = 0;
+    for (int i = threadIdx.x; i < np_spmv; i += blockDim.x) a += part_spmv[2 * i], b += part_spmv[2 * i + 1];
+    const double pAp = block_sum(a, red);
+    const double yy = block_sum(b, red);
+    const double rr = first ? sc[1] : sum_partials(part_rr_in, np_rr, red);
+    const bool last = blockIdx.x == gridDim.x - 1 && threadIdx.x == 0;
+    if (!first && rr <= tol2 * sc[0]) {   // converged by the previous update: x, r stay as they are
+        if (last) sc[3] = rr, ctl[0] = 1;
+        return;
+    }
+    const double alpha = pAp > 0.0 ? rr / pAp : 0.0;
+    const double est = alpha * alpha * yy - rr;
+    const double beta = (est > 0.0 && rr > 0.0) ? est / rr : 0.0;
+    double acc = 0;
+#pragma unroll
+    for (int k = 0; k < kCgV; ++k) {
+        const int64_t i = i0 + k * 256;
+        if (i < n2) {
+            xv[k].x += alpha * pv[k].x, xv[k].y += alpha * pv[k].y;
+            rv[k].x -= alpha * yv[k].x, rv[k].y -= alpha * yv[k].y;
+            pv[k].x = rv[k].x + beta * pv[k].x, pv[k].y = rv[k].y + beta * pv[k].y;
+            x2[i] = xv[k], r2[i] = rv[k], p2[i] = pv[k];
+            acc += rv[k].x * rv[k].x + rv[k].y * rv[k].y;
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        x[i] += alpha * p[i];
+        const double ri = r[i] - alpha * y[i];
+        r[i] = ri, p[i] = ri + beta * p[i];
+        acc += ri * ri;
+    }
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) part_rr_out[blockIdx.x] = s;
+    if (last) {
+        sc[3] = rr;
+        ctl[1] += 1;
+        if (!(pAp > 0.0)) ctl[2] = 1, ctl[0] = 1;   // not SPD / breakdown
+    }
+}
+// host poll of the fused-update CG: explicit r.r of the last update -> sc[3], stop flag
+__global__ __launch_bounds__(256) void k_cgf_fin(const double* part_rr, int np, double* sc, double tol2, int32_t* ctl) {
+    __shared__ double red[8];
+    if (ctl[0] != 0) return;
+    const double rr = sum_partials(part_rr, np, red);
+    if (threadIdx.x == 0) {
+        sc[3] = rr;
+        if (rr <= tol2 * sc[0]) ctl[0] = 1;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // BiCGStab on the scaled system (non-symmetric operators: advection)
 //   k_bicg_p   : rho = r0.r ; beta = (rho/rho_old)(alpha/omega) ; p = r + beta (p - omega v)

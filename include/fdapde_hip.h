@@ -61,12 +61,14 @@ typedef struct {
 
 /* CG_SR: single-reduction (Chronopoulos-Gear) CG: same iterates, both dot products fused into the SpMV, two launches and
  * (multi-GPU) one all-reduce per iteration */
-enum { FDAPDE_SOLVER_AUTO = 0, FDAPDE_SOLVER_CG = 1, FDAPDE_SOLVER_BICGSTAB = 2, FDAPDE_SOLVER_CG_SR = 3 };
+/* CG_FUSED: the SpMV carries p.Ap and Ap.Ap, ONE kernel then updates x, r, p: alpha from the explicit r.r, beta from the
+ * estimate alpha^2 Ap.Ap - r.r (only the search direction sees the estimate); two launches per iteration, single GPU */
+enum { FDAPDE_SOLVER_AUTO = 0, FDAPDE_SOLVER_CG = 1, FDAPDE_SOLVER_BICGSTAB = 2, FDAPDE_SOLVER_CG_SR = 3, FDAPDE_SOLVER_CG_FUSED = 4 };
 enum { FDAPDE_ASSEMBLY_ROWS = 0, FDAPDE_ASSEMBLY_ATOMIC = 1, FDAPDE_ASSEMBLY_COLOURED = 2 };
 enum { FDAPDE_MAT_STIFF = 0, FDAPDE_MAT_MASS = 1 };
 
 typedef struct {
-    int32_t method;   /* FDAPDE_SOLVER_*; AUTO = CG for symmetric operators, BiCGStab otherwise */
+    int32_t method;   /* FDAPDE_SOLVER_*; AUTO = CG for symmetric operators (CG_FUSED on one GPU, CG_SR on several), BiCGStab otherwise */
     int32_t maxit;    /* <= 0: 10 * n_dofs capped at 100000 */
     double rtol;      /* <= 0: 1e-10.  Stop when ||r||_{D^-1} <= rtol * ||r0||_{D^-1} (D = diag A) */
     int32_t assembly; /* FDAPDE_ASSEMBLY_*; used by fdapde_init */
@@ -84,7 +86,7 @@ typedef struct {
     double t_setup_ms;    /* host wall time of the last fdapde_dofs_build (numbering, pattern, upload) */
     double spmv_avg_ms;   /* average duration of the SpMV launches timed inside the last solve (0 if none) */
     int32_t spmv_timed;   /* how many launches that average covers */
-    int32_t method_used;  /* FDAPDE_SOLVER_CG or FDAPDE_SOLVER_BICGSTAB */
+    int32_t method_used;  /* the FDAPDE_SOLVER_* that ran */
 } fdapde_info;
 
 typedef struct fdapde_ctx fdapde_ctx;

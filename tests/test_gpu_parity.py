@@ -388,7 +388,12 @@ def test_single_reduction_cg_matches_cg(capi, ctx, oracle, mesh_loader, mesh_nam
         # little more near the attainable accuracy (observed: +12 % iterations at rtol 1e-11 on the P2 unit_square system)
         assert a.iters - 3 <= b.iters <= int(1.2 * a.iters) + 3, (a.iters, b.iters)
         ref = oracle.pde_init_solve(m, order, mk(oracle), forcing_q=fq, dirichlet=dirichlet)
-        for u in (ua, ub):
+        cf = ctx.solve(method=capi.SOLVER_CG_FUSED, rtol=1e-11)    # alpha from the explicit r.r, beta from alpha^2 Ap.Ap - r.r
+        uc = ctx.solution()
+        print(f"{mesh_name} P{order} dirichlet={dirichlet is not None}: CG {a.iters}  CG_SR {b.iters}  CG_FUSED {cf.iters}")
+        assert cf.converged == 1 and cf.method_used == capi.SOLVER_CG_FUSED
+        assert a.iters - 3 <= cf.iters <= int(1.05 * a.iters) + 3, (a.iters, cf.iters)
+        for u in (ua, ub, uc):
             assert np.linalg.norm(u - ref.solution) / np.linalg.norm(ref.solution) <= SOL_TOL
 
 

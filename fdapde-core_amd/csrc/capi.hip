@@ -140,6 +140,7 @@ struct fdapde_ctx {
     DBuf<uint16_t> sp_col16[2];              // 16-bit column codes of the compact pattern (host_build_col16)
     int64_t sp_wide[2] = {0, 0};             // groups of 32 rows that fall back to the 32-bit columns
     int spmv_c16 = 1;                        // tuning knob: 0 = always stream the 32-bit columns
+    int spmv_deep = 0;                       // tuning knob: 1 = k_spmv_c16p (gathers one tile ahead; measured slower: 3 waves / SIMD)
     int64_t sp_nnz[2] = {0, 0};
     bool sp_built[2] = {false, false};
     int sp_cur = -1;   // which compact pattern c->sval currently holds (-1: full pattern)
@@ -464,13 +465,32 @@ void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, 
             case 32: SPMV_GO(k_spmv_team2<8, 4, 32>); break;   // no y store
             case 64: SPMV_GO(k_spmv_team2<8, 4, 64>); break;   // no w load
             case 3: SPMV_GO(k_spmv_team2<8, 4>); break;        // unaligned entry pairs, 32-bit columns (the form before)
+            // diagnostics on the production form (16-bit codes, w == x); meaningful only on the compact solver matrix
+            case 101: if (c16) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 1>); break;    // no x gather
+            case 132: if (c16) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 32>); break;   // no y store
+            case 133: if (c16) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 33>); break;   // neither
+            case 140:   // y rows kept in LDS until the wavefront's tile loop ends (needs <= 8 tiles per wavefront)
+                if (c16 && (rpb / 32 + (int64_t)(c->spmv_grid / 8) * 4 - 1) / ((int64_t)(c->spmv_grid / 8) * 4) <= 8)
+                    SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 32768>);
+                break;
+            case 102: if (c16) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 2>); break;       // gathers inside 16 lines
+            case 103: if (c16) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 65536>); break;   // gathers inside 1 line
             case 2048: SPMV_GO(k_spmv_team2<8, 4, 2048>); break;   // aligned pairs, 32-bit columns
             default:
-                if (c->spmv_unroll == 2)
+                if (c->spmv_unroll == 2 && c16 && c->spmv_deep)
+                    SPMV_GO(k_spmv_c16p<8, 2, 16384>);
+                else if (c->spmv_unroll == 2 && c16)
+                    SPMV_GO(k_spmv_team2<8, 2, 2048 | 4096 | 16384>);
+                else if (c->spmv_unroll == 2)
                     SPMV_GO(k_spmv_team2<8, 2>);
                 else if (c->spmv_unroll == 6)
                     SPMV_GO(k_spmv_team2<8, 6>);
-                else
+                else if (c16 && c->spmv_deep) {   // deep-pipelined form: gathers one tile ahead
+                    if (dist && wx) SPMV_GO(k_spmv_c16p<8, 4, 8192 | 16384>);
+                    else if (dist) SPMV_GO(k_spmv_c16p<8, 4, 8192>);
+                    else if (wx) SPMV_GO(k_spmv_c16p<8, 4, 16384>);
+                    else SPMV_GO(k_spmv_c16p<8, 4, 0>);
+                } else
                     SPMV_PROD(8, 4);
                 break;
             }
@@ -1582,6 +1602,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "spmv_unroll" && value >= 1 && value <= 8) c->spmv_unroll = value;
     else if (k == "spmv_ablate") c->spmv_ablate = value;
     else if (k == "spmv_c16" && (value == 0 || value == 1)) c->spmv_c16 = value;
+    else if (k == "spmv_deep" && (value == 0 || value == 1)) c->spmv_deep = value;
     else if (k == "spmv_bpx" && value >= 1 && value <= 1024) {
         c->spmv_grid = 8 * value;
         HIPCHK(c, hipSetDevice(c->device));

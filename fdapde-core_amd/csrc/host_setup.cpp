@@ -604,11 +604,29 @@ int host_build_solver_pattern(const HostSpace& hs, bool use_bnd, std::vector<int
     });
     for (int64_t r = 0; r < nd; ++r) rowptr_s[(size_t)r + 1] += rowptr_s[(size_t)r];
     colidx_s.assign((size_t)rowptr_s[(size_t)nd] + 2, 0);   // + 2: pair loads may touch one entry past a row's end
+    // Entry order inside a row: k_spmv_team2 gives lane l the ALIGNED pair of positions (2 l, 2 l + 1) counted from the even
+    // index at or below the row start, and gathers x for all even positions with one instruction and for all odd positions with
+    // another.  The row's columns (ascending) are therefore dealt so that the even positions hold the lower half and the odd
+    // positions the upper half: each gather instruction then touches about half as many distinct cache lines of x.
+    const bool split = !std::getenv("FDAPDE_SPMV_NOSPLIT");
     parallel_for(nd, [&](int64_t b, int64_t e, unsigned) {
         for (int64_t r = b; r < e; ++r) {
-            int32_t at = rowptr_s[(size_t)r];
-            for (int32_t k = hs.rowptr_i[(size_t)r]; k < hs.rowptr_i[(size_t)r + 1]; ++k)
-                if (keep(r, hs.colidx_i[(size_t)k])) colidx_s[(size_t)at] = hs.colidx_i[(size_t)k], full2s[(size_t)k] = at++;
+            const int32_t base = rowptr_s[(size_t)r], m = rowptr_s[(size_t)r + 1] - base;
+            const int32_t first_even = base & 1;            // offset of the first even position in the row
+            const int32_t n_even = (m - first_even + 1) / 2;  // positions base + first_even, + 2, ...
+            int32_t j = 0;
+            for (int32_t k = hs.rowptr_i[(size_t)r]; k < hs.rowptr_i[(size_t)r + 1]; ++k) {
+                if (!keep(r, hs.colidx_i[(size_t)k])) continue;
+                int32_t at;
+                if (!split)
+                    at = base + j;
+                else if (j < n_even)
+                    at = base + first_even + 2 * j;
+                else
+                    at = base + (1 - first_even) + 2 * (j - n_even);
+                colidx_s[(size_t)at] = hs.colidx_i[(size_t)k], full2s[(size_t)k] = at;
+                ++j;
+            }
         }
     });
     return FDAPDE_OK;

@@ -790,6 +790,7 @@ template <int T> __device__ __forceinline__ double team_sum(double v) {
     return v;
 }
 
+typedef __attribute__((address_space(3))) volatile double lds_vf64_t;
 struct __attribute__((packed, aligned(8))) F64x2 { double x, y; };
 struct __attribute__((packed, aligned(4))) I32x2 { int x, y; };
 
@@ -806,6 +807,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
     static_assert(WROWS < 64, "one rowptr load per tile");
     __shared__ double red[8];
     __shared__ double ystage[4][WROWS];
+    // DEFER (diagnostic / tuning): the y rows of a wavefront stay in LDS until its tile loop ends and leave in one burst
+    constexpr bool DEFER = (ABL & 32768) != 0;
+    constexpr int kDeferTiles = 8;
+    __shared__ double ydef[DEFER ? 4 * kDeferTiles * WROWS : 1];
     if (s.stop && __syncthreads_or(*s.stop != 0)) return;
     const int band = (ABL & 16) ? 0 : (blockIdx.x & 7), lb = (ABL & 16) ? blockIdx.x : (blockIdx.x >> 3),
               bpx = (ABL & 16) ? gridDim.x : (gridDim.x >> 3);
@@ -818,6 +823,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
     const int64_t band_end = min(n, band_begin + rows_per_band);
     const int64_t stride = (int64_t)bpx * 4 * WROWS;
     double d_wy = 0, d_yy = 0;
+    int n_def = 0;
     const int last = s.nnz - 1;
     // row pointers: ONE coalesced load of the tile's WROWS + 1 pointers, shuffled to the teams (8 ds_bpermute per tile).
     // Loading them per (tile, u) with team-uniform 8-byte loads instead was measured slower (79.5 vs 66.0 us): every
@@ -889,7 +895,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
             rs[u] = __shfl(rp0, u * TEAMS + team, 64), re[u] = __shfl(rp0, u * TEAMS + team + 1, 64);
             load_pair(rs[u], re[u], v[u], c[u]);
         }
-        volatile double* ys = ystage[wave];
+        // explicit LDS address space: a volatile GENERIC pointer compiles to flat_load / flat_store, which count on vmcnt and
+        // made every tile drain all of its prefetched loads (s_waitcnt vmcnt(0))
+        lds_vf64_t* ys = (lds_vf64_t*)&ystage[wave][0];
         const double* wp = s.w ? s.w : s.x;   // always dereferenceable; the dots are discarded when s.w is null
         const double dots = s.w ? 1.0 : 0.0;
         // One tile.  FULL tiles (all WROWS rows inside the band) run branch-free: the w operand of the fused dot is loaded
@@ -920,6 +928,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
             for (int u = 0; u < U; ++u) {
                 if constexpr (ABL & 1)
                     xa[u] = (double)(c[u].x & 1), xb[u] = (double)(c[u].y & 1);
+                else if constexpr (ABL & 65536)   // diagnostic: every lane of a gather hits ONE cache line
+                    xa[u] = s.x[c[u].x & 15], xb[u] = s.x[c[u].y & 15];
                 else if constexpr (ABL & 2)
                     xa[u] = s.x[c[u].x & 255], xb[u] = s.x[c[u].y & 255];
                 else
@@ -981,7 +991,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
             if (l < U) ys[l * TEAMS + team] = pick;
             __builtin_amdgcn_wave_barrier();
             const double out = ys[lane % WROWS] + xd;
-            if constexpr (!(ABL & (8 | 32))) {
+            if constexpr (DEFER) {
+                if (lane < WROWS) ydef[(wave * kDeferTiles + n_def) * WROWS + lane] = out;
+                ++n_def;
+            } else if constexpr (!(ABL & (8 | 32))) {
                 if constexpr (FULL) {
                     if constexpr (ABL & 128)
                         __builtin_nontemporal_store(out, s.y + row);
@@ -1007,6 +1020,196 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
 #pragma unroll
             for (int u = 0; u < U; ++u) rs[u] = rsn[u], re[u] = ren[u], c[u] = cn[u], v[u] = vn[u];
             tb = tbn;
+        };
+        const int64_t base0 = base;
+        for (; base + WROWS <= band_end; base += stride) tile(std::true_type {});
+        if (base < band_end) tile(std::false_type {});
+        if constexpr (DEFER) {
+            __builtin_amdgcn_wave_barrier();
+            for (int t = 0; t < n_def; ++t) {
+                const int64_t row = base0 + t * stride + lane;
+                if (lane < WROWS && row < band_end) s.y[row] = ydef[(wave * kDeferTiles + t) * WROWS + lane];
+            }
+        }
+    }
+    if (s.partial) {
+        const double a = block_sum(d_wy, red);
+        const double b = block_sum(d_yy, red);
+        if (threadIdx.x == 0) s.partial[2 * blockIdx.x] = a, s.partial[2 * blockIdx.x + 1] = b;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_spmv_c16p: the production SpMV of the Krylov solvers on the compact solver matrix (implicit unit diagonal, 16-bit column
+// codes, aligned entry pairs).  Same tiling, team sums and transposed y store as k_spmv_team2, but a software pipeline that is
+// one stage deeper: the x gathers of a tile are issued ONE TILE AHEAD of their use.  In k_spmv_team2 every tile pays the
+// gather round trip serially (codes arrive -> decode -> gather -> wait -> FMA); diagnostic builds show that this wait, not
+// the gathered bytes or lines, is what the gathers cost (all lanes of a gather forced into ONE cache line: 56.5 us, real
+// gathers 59.3 us, no gathers 48.9 us on C3).  Per iteration i of the tile loop, in issue order (loads return in order):
+//     a. column codes, window bases of tile i+2 and row pointers of tile i+3
+//     c. decode the codes of tile i+1 (loaded during iteration i-1), issue its x gathers and its row operands
+//     d. matrix values of tile i+1
+//     e. wait for the gathers and values of tile i (issued during iteration i-1), FMA, team sums, y store, dots
+// FLAGS: 8192 = multi-GPU (implicit diagonal and w.w counted by the owner of the row), 16384 = the dot operand w is x.
+// ---------------------------------------------------------------------------------------------------------------
+template <int T, int U, int FLAGS>
+__global__ __launch_bounds__(256) void k_spmv_c16p(SpmvArgs s, int64_t n, int64_t rows_per_band) {
+    constexpr int TEAMS = 64 / T;
+    constexpr int WROWS = TEAMS * U;
+    constexpr bool DIST = (FLAGS & 8192) != 0, WX = (FLAGS & 16384) != 0;
+    static_assert(WROWS < 64 && 32 % WROWS == 0, "one rowptr load per tile, tiles inside a 32-row code group");
+    typedef int v4i32_t __attribute__((ext_vector_type(4)));
+    __shared__ double red[8];
+    __shared__ double ystage[4][WROWS];
+    if (s.stop && __syncthreads_or(*s.stop != 0)) return;
+    const int band = blockIdx.x & 7, lb = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, team = lane / T, l = lane % T;
+    const int64_t band_begin = band * rows_per_band;
+    const int64_t band_end = min(n, band_begin + rows_per_band);
+    const int64_t stride = (int64_t)bpx * 4 * WROWS;
+    const int last = s.nnz - 1, ncol1 = (int)n - 1;
+    double d_wy = 0, d_yy = 0;
+    auto load_rp = [&](int64_t b) -> int {
+        const int64_t r = b + lane;
+        return s.rowptr[r < band_end ? r : band_end];
+    };
+    auto load_tb = [&](int64_t b) -> v4i32_t {
+        const int64_t bc = b < band_end ? b : band_begin;
+        const int g = __builtin_amdgcn_readfirstlane((int)(bc >> 5));
+        return *reinterpret_cast<const v4i32_t*>(s.tbase + 4 * (int64_t)g);
+    };
+    auto pair_at = [&](int rs) -> int {   // aligned pair of lane l in a row starting at rs, clamped into the arrays
+        const int k = (rs & ~1) + 2 * l;
+        return k < last ? k : (last & ~1);
+    };
+    auto load_codes = [&](int rs) -> unsigned int {
+        return __builtin_nontemporal_load(reinterpret_cast<const unsigned int*>(s.col16 + pair_at(rs)));
+    };
+    auto load_vals = [&](int rs, int re, F64x2& v) {
+        const int k = (rs & ~1) + 2 * l;
+        const v2f64_t a = __builtin_nontemporal_load(reinterpret_cast<const v2f64_t*>(s.vals + pair_at(rs)));
+        v.x = (k >= rs && k < re) ? a.x : 0.0, v.y = (k + 1 < re) ? a.y : 0.0;
+    };
+    auto decode = [&](unsigned int code, const v4i32_t& tb) -> int {
+        const int b01 = (code & 0x4000u) ? tb.y : tb.x, b23 = (code & 0x4000u) ? tb.w : tb.z;
+        const int col = ((code & 0x8000u) ? b23 : b01) + (int)(code & 0x3fffu);
+        return col < ncol1 ? col : ncol1;   // entries of neighbouring rows (masked, value 0) may decode out of range
+    };
+    // columns of a tile -> its x gathers (wide groups, wave-uniform and rare, re-read the 32-bit columns)
+    auto gather = [&](const unsigned int (&code)[U], const int (&rs)[U], const v4i32_t& tb, double (&xa)[U], double (&xb)[U]) {
+        int ca[U], cb[U];
+        if (tb.x < 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const v2i32_t b = *reinterpret_cast<const v2i32_t*>(s.colidx + pair_at(rs[u]));
+                ca[u] = b.x, cb[u] = b.y;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) ca[u] = decode(code[u] & 0xffffu, tb), cb[u] = decode(code[u] >> 16, tb);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) xa[u] = s.x[ca[u]], xb[u] = s.x[cb[u]];
+    };
+    // row operands of lane j < WROWS (row base + j): x for the implicit diagonal, w for the dot, ownership (multi-GPU)
+    const double* wp = s.w ? s.w : s.x;
+    const double dots = s.w ? 1.0 : 0.0;
+    auto row_ops = [&](int64_t b, double& xr, double& wr, int& mine) {
+        const int64_t row = b + (lane % WROWS);
+        const int64_t rowc = row < band_end ? row : band_end - 1;
+        xr = s.x[rowc];
+        if constexpr (WX) wr = xr; else wr = wp[rowc];
+        if constexpr (DIST) mine = s.owned[rowc]; else mine = 1;
+    };
+    int64_t base = band_begin + (int64_t)(lb * 4 + wave) * WROWS;
+    if (base < band_end) {
+        // ---- prologue: tile 0 fully loaded and gathered, codes of tile 1, row pointers of tile 2
+        int rs[U], re[U], rsn[U], ren[U];
+        unsigned int cn[U];
+        F64x2 v[U];
+        double xa[U], xb[U], xr, wr;
+        int mine;
+        int rp2;
+        v4i32_t tbn;
+        {
+            const int rp0 = load_rp(base), rp1 = load_rp(base + stride);
+            rp2 = load_rp(base + 2 * stride);
+            const v4i32_t tb0 = load_tb(base);
+            tbn = load_tb(base + stride);
+            unsigned int c0[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                rs[u] = __shfl(rp0, u * TEAMS + team, 64), re[u] = __shfl(rp0, u * TEAMS + team + 1, 64);
+                c0[u] = load_codes(rs[u]);
+                load_vals(rs[u], re[u], v[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                rsn[u] = __shfl(rp1, u * TEAMS + team, 64), ren[u] = __shfl(rp1, u * TEAMS + team + 1, 64);
+                cn[u] = load_codes(rsn[u]);
+            }
+            gather(c0, rs, tb0, xa, xb);
+            row_ops(base, xr, wr, mine);
+        }
+        // explicit LDS address space: a volatile GENERIC pointer compiles to flat_load / flat_store, which count on vmcnt and
+        // made every tile drain all of its prefetched loads (s_waitcnt vmcnt(0))
+        lds_vf64_t* ys = (lds_vf64_t*)&ystage[wave][0];
+        auto tile = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            // a. tile i+2: row pointers -> codes, window bases; row pointers of tile i+3
+            int rs2[U], re2[U];
+            unsigned int c2[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                rs2[u] = __shfl(rp2, u * TEAMS + team, 64), re2[u] = __shfl(rp2, u * TEAMS + team + 1, 64);
+                c2[u] = load_codes(rs2[u]);
+            }
+            const v4i32_t tb2 = load_tb(base + 2 * stride);
+            rp2 = load_rp(base + 3 * stride);
+            // c. tile i+1: gathers and row operands
+            double xan[U], xbn[U], xrn, wrn;
+            int minen;
+            gather(cn, rsn, tbn, xan, xbn);
+            row_ops(base + stride, xrn, wrn, minen);
+            // d. tile i+1: values
+            F64x2 vn[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) load_vals(rsn[u], ren[u], vn[u]);
+            // e. tile i
+            const int64_t row = base + (lane % WROWS);
+            const bool row_ok = FULL || row < band_end;
+            double acc[U];
+            bool long_row = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = v[u].x * xa[u] + v[u].y * xb[u], long_row |= re[u] - (rs[u] & ~1) > 2 * T;
+            if (__any(long_row)) {   // rows longer than a team pass (rare when 2 T covers the mean row)
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    for (int k = (rs[u] & ~1) + l + 2 * T; k < re[u]; k += T) acc[u] += s.vals[k] * s.x[s.colidx[k]];
+            }
+            double pick = 0;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double t = team_sum<T>(acc[u]);
+                if (l == u) pick = t;
+            }
+            if (l < U) ys[l * TEAMS + team] = pick;
+            __builtin_amdgcn_wave_barrier();
+            const double out = ys[lane % WROWS] + (mine ? xr : 0.0);   // + implicit unit diagonal (owner only on several GPUs)
+            if constexpr (FULL)
+                s.y[row] = out;   // lanes >= WROWS repeat lanes < WROWS: unconditional store, no exec-masked branch
+            else if (row_ok)
+                s.y[row] = out;
+            __builtin_amdgcn_wave_barrier();
+            const double once = (lane < WROWS && row_ok) ? dots : 0.0;   // each row counted by one lane
+            d_wy += once * (wr * out);
+            d_yy += once * (s.dot2_ww ? (mine ? wr * wr : 0.0) : out * out);
+            // rotate the pipeline registers
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                rs[u] = rsn[u], re[u] = ren[u], v[u] = vn[u], xa[u] = xan[u], xb[u] = xbn[u], rsn[u] = rs2[u], ren[u] = re2[u],
+                cn[u] = c2[u];
+            xr = xrn, wr = wrn, mine = minen, tbn = tb2;
         };
         for (; base + WROWS <= band_end; base += stride) tile(std::true_type {});
         if (base < band_end) tile(std::false_type {});

@@ -140,6 +140,7 @@ struct fdapde_ctx {
     DBuf<uint16_t> sp_col16[2];              // 16-bit column codes of the compact pattern (host_build_col16)
     int64_t sp_wide[2] = {0, 0};             // groups of 32 rows that fall back to the 32-bit columns
     int spmv_c16 = 1;                        // tuning knob: 0 = always stream the 32-bit columns
+    int cgf_v = 8;                           // double2 elements per lane of k_cgf_update (1, 2, 4, 8); C3 solve: 47.2 / 41.8 / 41.3 / 40.9 ms
     int spmv_deep = 0;                       // tuning knob: 1 = k_spmv_c16p (gathers one tile ahead; measured slower: 3 waves / SIMD)
     int64_t sp_nnz[2] = {0, 0};
     bool sp_built[2] = {false, false};
@@ -263,7 +264,7 @@ int upload_space(fdapde_ctx* c) {
         c->cg_grid = (int)((n2 + per - 1) / per);
         if (c->cg_grid < 1) c->cg_grid = 1;
     }
-    HIPCHK(c, c->part_b.alloc(2 * (size_t)(c->vec_grid > c->cg_grid ? c->vec_grid : c->cg_grid)));
+    HIPCHK(c, c->part_b.alloc(8 * (size_t)(c->vec_grid > c->cg_grid ? c->vec_grid : c->cg_grid) + 16));   // two halves at every k_cgf_update width
     HIPCHK(c, c->sc.alloc(16));
     HIPCHK(c, c->ctl.alloc(4));
     HIPCHK(c, hipMemsetAsync(c->ctl.p, 0, 4 * sizeof(int32_t), st));
@@ -1006,13 +1007,20 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
                                    np, c->sc.p, parity, launched == 0 ? 1 : 0, tol2, c->ctl.p);
             } else if (cgf) {
                 const bool tm = launched < n_timed;
-                const int cg = c->cg_grid;   // explicit r.r partials ping-pong between the two halves of part_b
+                // explicit r.r partials ping-pong between the two halves of part_b
+                const int V = c->cgf_v, cg = (int)(((n >> 1) + 256 * V - 1) / (256 * V)) > 0 ? (int)(((n >> 1) + 256 * V - 1) / (256 * V)) : 1;
                 launch_spmv(c, c->sval.p, c->p.p, c->y.p, c->p.p, c->part_a.p, c->ctl.p, tm ? c->ev_spmv[2 * launched] : nullptr,
                             tm ? c->ev_spmv[2 * launched + 1] : nullptr);   // p.y and y.y
                 if (tm) ++timed;
-                hipLaunchKernelGGL(k_cgf_update, dim3(cg), dim3(256), 0, st, n, c->y.p, c->p.p, c->x.p, c->r.p, c->part_a.p,
-                                   c->spmv_grid, c->part_b.p + (size_t)((launched + 1) & 1) * cg, cg,
-                                   c->part_b.p + (size_t)(launched & 1) * cg, c->sc.p, launched == 0 ? 1 : 0, tol2, c->ctl.p);
+#define CGF_GO(V_)                                                                                                         \
+    hipLaunchKernelGGL(k_cgf_update<V_>, dim3(cg), dim3(256), 0, st, n, c->y.p, c->p.p, c->x.p, c->r.p, c->part_a.p, c->spmv_grid, \
+                       c->part_b.p + (size_t)((launched + 1) & 1) * cg, cg, c->part_b.p + (size_t)(launched & 1) * cg, c->sc.p,   \
+                       launched == 0 ? 1 : 0, tol2, c->ctl.p)
+                if (V == 1) CGF_GO(1);
+                else if (V == 2) CGF_GO(2);
+                else if (V == 8) CGF_GO(8);
+                else CGF_GO(4);
+#undef CGF_GO
             } else if (!bicg) {
                 const int parity = launched & 1;
                 const bool tm = launched < n_timed;
@@ -1075,9 +1083,11 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
                 hipLaunchKernelGGL(k_bicg_fin, dim3(1), dim3(256), 0, st, c->sbuf.p + 4, 1, c->sbuf.p, 1, c->sc.p, tol2, c->ctl.p);
             }
         }
-        if (cgf && launched > 0)   // explicit r.r of the last update -> sc[3] / stop flag
-            hipLaunchKernelGGL(k_cgf_fin, dim3(1), dim3(256), 0, st, c->part_b.p + (size_t)((launched - 1) & 1) * c->cg_grid,
-                               c->cg_grid, c->sc.p, tol2, c->ctl.p);
+        if (cgf && launched > 0) {   // explicit r.r of the last update -> sc[3] / stop flag
+            const int V = c->cgf_v, cg = (int)(((n >> 1) + 256 * V - 1) / (256 * V)) > 0 ? (int)(((n >> 1) + 256 * V - 1) / (256 * V)) : 1;
+            hipLaunchKernelGGL(k_cgf_fin, dim3(1), dim3(256), 0, st, c->part_b.p + (size_t)((launched - 1) & 1) * cg, cg, c->sc.p, tol2,
+                               c->ctl.p);
+        }
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipMemcpyAsync(c->h_sc, c->sc.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1603,6 +1613,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "spmv_ablate") c->spmv_ablate = value;
     else if (k == "spmv_c16" && (value == 0 || value == 1)) c->spmv_c16 = value;
     else if (k == "spmv_deep" && (value == 0 || value == 1)) c->spmv_deep = value;
+    else if (k == "cgf_v" && (value == 1 || value == 2 || value == 4 || value == 8)) c->cgf_v = value;
     else if (k == "spmv_bpx" && value >= 1 && value <= 1024) {
         c->spmv_grid = 8 * value;
         HIPCHK(c, hipSetDevice(c->device));

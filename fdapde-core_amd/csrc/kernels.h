@@ -1487,6 +1487,7 @@ __global__ __launch_bounds__(256) void k_cgsr_update(int64_t n, double* r, const
 // exact arithmetic (r.y = p.y by A-conjugacy) and is used for beta only, so that p needs no second pass after a global
 // reduction: 7 vector passes and 2 launches per iteration instead of 8 and 3.  The stop test is taken at the start of the
 // next launch (or by k_cgf_fin at a host poll) from the explicit r.r, uniformly by every workgroup.
+template <int kCgV>
 __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, double* p, double* x, double* r,
                                                      const double* part_spmv, int np_spmv, const double* part_rr_in, int np_rr,
                                                      double* part_rr_out, double* sc, int first, double tol2, int32_t* ctl) {

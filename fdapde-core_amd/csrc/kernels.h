@@ -972,10 +972,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 acc[u] = v[u].x * xa[u] + v[u].y * xb[u], long_row |= re[u] - (ALIGNED ? (rs[u] & ~1) : rs[u]) > 2 * T;
-            if (__any(long_row)) {   // rows longer than a team pass (rare when 2 T covers the mean row)
+            if (__any(long_row)) {   // rows longer than a team pass: further passes of 2 T entries, all U rows at once
+                if constexpr (ALIGNED) {
+                    int maxlen = 0;
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    for (int k = (ALIGNED ? (rs[u] & ~1) : rs[u]) + l + 2 * T; k < re[u]; k += T) acc[u] += s.vals[k] * s.x[s.colidx[k]];
+                    for (int u = 0; u < U; ++u) maxlen = max(maxlen, re[u] - (rs[u] & ~1));
+                    for (int off = 2 * T; __any(off < maxlen); off += 2 * T) {
+                        // only lanes that still have entries issue loads (a clamped, unmasked load would fetch the next rows' data)
+                        F64x2 tv[U];
+                        I32x2 tc[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const int k = (rs[u] & ~1) + off + 2 * l;
+                            tv[u].x = tv[u].y = 0.0, tc[u].x = tc[u].y = 0;
+                            if (k < re[u]) {
+                                const v2f64_t a = *reinterpret_cast<const v2f64_t*>(s.vals + k);
+                                tv[u].x = a.x, tv[u].y = k + 1 < re[u] ? a.y : 0.0;
+                                bool coded = false;
+                                if constexpr (C16) coded = tb.x >= 0;
+                                if (coded) {
+                                    const unsigned int code = *reinterpret_cast<const unsigned int*>(s.col16 + k);
+                                    tc[u].x = decode(code & 0xffffu, tb), tc[u].y = decode(code >> 16, tb);
+                                } else {
+                                    const v2i32_t b = *reinterpret_cast<const v2i32_t*>(s.colidx + k);
+                                    tc[u].x = b.x, tc[u].y = k + 1 < re[u] ? b.y : 0;
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const int k = (rs[u] & ~1) + off + 2 * l;
+                            if (k < re[u]) acc[u] += tv[u].x * s.x[tc[u].x] + tv[u].y * s.x[tc[u].y];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+                        for (int k = rs[u] + l + 2 * T; k < re[u]; k += T) acc[u] += s.vals[k] * s.x[s.colidx[k]];
+                }
             }
             // every lane of a team gets the team's U row sums; lane l < U keeps row (u = l, team) = tile row l*TEAMS + team.
             // Stored from there, consecutive lanes would write rows TEAMS apart: 32 separate 8-byte partial writes per

@@ -177,7 +177,7 @@ def bench_partitioned(capi, nodes, cells, bnd, f, u_exact, rank, world, local_ra
     dist.all_reduce(nnz_tot, op=dist.ReduceOp.MAX)       # the largest local matrix bounds the SpMV roofline figure
     sizes = dict(sizes, nnz=int(nnz_tot[0].item()))
     parallelism = (f"{world} GPUs, element partition (Morton chunks), {lp['n_if_global']} interface DOFs, "
-                   "1 RCCL all-reduce of interface entries + p.Ap and 1 scalar all-reduce per CG iteration; "
+                   "single-reduction CG: ONE RCCL all-reduce per iteration (interface entries of A r + r.Ar + r.r); "
                    "roofline figures are the largest rank-local SpMV")
     return (float(elapsed.item()), info, float(stats[0].item()), float(stats[1].item()), float(stats[2].item()),
             float(err.item()), float(stats[3].item()), float(nnz_tot[1].item()), sizes, int(nodes.shape[0]), parallelism)

@@ -42,7 +42,7 @@ SYMBOLS = [
     "fdapde_abi_version", "fdapde_device_count", "fdapde_ctx_create", "fdapde_ctx_destroy", "fdapde_last_error",
     "fdapde_status_string", "fdapde_mesh_upload", "fdapde_dofs_build", "fdapde_dofs_get", "fdapde_dofs_set_boundary", "fdapde_sizes",
     "fdapde_pattern_get", "fdapde_quadrature_nodes", "fdapde_set_operator", "fdapde_set_forcing", "fdapde_set_dirichlet",
-    "fdapde_init", "fdapde_assemble_operator", "fdapde_solve", "fdapde_matrix_values", "fdapde_force", "fdapde_solution",
+    "fdapde_init", "fdapde_assemble_operator", "fdapde_solve", "fdapde_matrix_values", "fdapde_lump", "fdapde_force", "fdapde_solution",
     "fdapde_info_get", "fdapde_spmv", "fdapde_bench_spmv", "fdapde_tune", "fdapde_stream", "fdapde_synchronize",
     "fdapde_comm_unique_id", "fdapde_comm_init", "fdapde_halo_setup", "fdapde_solve_parabolic",
     "fdapde_lin_compute", "fdapde_lin_solve", "fdapde_eval_pointwise", "fdapde_cell_integrals", "fdapde_comm_init_callback",
@@ -345,6 +345,12 @@ class Context:
     def matrix_values(self, which=MAT_STIFF):
         out = np.zeros(self.sizes()["nnz"])
         self._check(self.lib.fdapde_matrix_values(self._ctx, which, _dp(out)))
+        return out
+
+    def lump(self, which=MAT_MASS):
+        """diagonal of lump(mass()) / lump(stiff()) (row sums)"""
+        out = np.zeros(self.sizes()["n_dofs"])
+        self._check(self.lib.fdapde_lump(self._ctx, which, _dp(out)))
         return out
 
     def force(self, ncols=1):

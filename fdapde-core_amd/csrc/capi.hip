@@ -1419,6 +1419,21 @@ int fdapde_matrix_values(fdapde_ctx* c, int32_t which, double* values) {
     return FDAPDE_OK;
 }
 
+// lump(stiff() | mass()) (fdaPDE/linear_algebra/lumping.h:30-41): the diagonal of the row-sum lumped matrix, reference numbering
+int fdapde_lump(fdapde_ctx* c, int32_t which, double* diag) {
+    if (!c || !diag || which < 0 || which > 1) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (!c->dev_ready || !c->assembled[which]) return fail(c, FDAPDE_ENOTINIT, "matrix not assembled");
+    HIPCHK(c, hipSetDevice(c->device));
+    const HostSpace& hs = c->hs;
+    hipLaunchKernelGGL(k_row_sums, dim3(g1(hs.n_dofs * 16)), dim3(256), 0, c->stream, hs.n_dofs, c->rowptr.p, c->vals[which].p, c->tmp_i.p);
+    hipLaunchKernelGGL(k_scatter_f64, dim3(g1(hs.n_dofs)), dim3(256), 0, c->stream, hs.n_dofs, c->dof_i2e.p, c->tmp_i.p, c->tmp_e.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(diag, c->tmp_e.p, sizeof(double) * (size_t)hs.n_dofs, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FDAPDE_OK;
+}
+
 int fdapde_force(fdapde_ctx* c, double* force) {
     if (!c || !force) return FDAPDE_EINVAL;
     if (int rc = need_device(c)) return rc;

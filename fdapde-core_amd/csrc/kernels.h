@@ -1764,6 +1764,17 @@ __global__ __launch_bounds__(256) void k_export_values(int64_t n, const int32_t*
     for (int k = rowptr[row] + l; k < rowptr[row + 1]; k += 16)
         out[slot_i2e[k]] = z ? (colidx[k] == row ? 1.0 : 0.0) : vals[k];
 }
+// row-sum lumping (fdaPDE/linear_algebra/lumping.h:30-41): out[row] = sum of the row's entries; 16 lanes per row, fixed order
+__global__ __launch_bounds__(256) void k_row_sums(int64_t n, const int32_t* rowptr, const double* vals, double* out) {
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int l = threadIdx.x & 15;
+    const bool ok = row < n;
+    double a = 0;
+    if (ok)
+        for (int k = rowptr[row] + l; k < rowptr[row + 1]; k += 16) a += vals[k];
+    a = team_sum<16>(a);
+    if (ok && l == 0) out[row] = a;
+}
 __global__ void k_fill_f64(int64_t n, double v, double* dst) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = v;

@@ -348,6 +348,7 @@ template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_H
         bool computed_ = false;
     };
     SparseSolver make_solver() { return SparseSolver(ctx_); }
+    fdapde_ctx* context() const { return ctx_; }   // the C-ABI context (for entry points the facade does not wrap)
 
    private:
     // FEMLinearParabolicSolver::solve (fem_linear_parabolic_solver.h:37-72)

@@ -167,6 +167,8 @@ int fdapde_cell_integrals(fdapde_ctx *ctx, double *measure, double *psi_int);
 /* values[nnz] aligned with fdapde_pattern_get.  After a solve with Dirichlet data, FDAPDE_MAT_STIFF is the
  * row-zeroed matrix the reference leaves in stiff_ (rows of boundary DOFs zero, unit diagonal). */
 int fdapde_matrix_values(fdapde_ctx *ctx, int32_t which, double *values);
+/* lump(stiff() | mass()) (fdaPDE/linear_algebra/lumping.h:30-41): diagonal of the row-sum lumped matrix, diag[n_dofs] */
+int fdapde_lump(fdapde_ctx *ctx, int32_t which, double *diag);
 int fdapde_force(fdapde_ctx *ctx, double *force);       /* n_dofs * n_cols; boundary rows = g after a Dirichlet solve */
 int fdapde_solution(fdapde_ctx *ctx, double *solution); /* n_dofs */
 int fdapde_info_get(const fdapde_ctx *ctx, fdapde_info *info);

@@ -10,6 +10,7 @@
 #include <string>
 
 #include "fdapde_amd/pde.h"
+#include "fdapde_amd/linear_algebra.h"
 
 using namespace fdapde::amd;
 
@@ -288,6 +289,47 @@ TEST(sparse_solver_test, factor_once_solve_many) {
     EXPECT_TRUE(worst < 1e-7);
 }
 
+// SMW (linear_algebra/smw.h:38-59) on the factor-once handle, and row-sum lumping (linear_algebra/lumping.h:30-41)
+TEST(linear_algebra_test, smw_and_lumping) {
+    MeshLoader<2, 2> m("unit_square_32");
+    auto L = -laplacian<FEM_HIP>() + reaction<FEM_HIP>(2.0);
+    PDE<Triangulation<2, 2>, decltype(L), DMatrix<double>, FEM_HIP, fem_order<1>> pde_(m.mesh, L);
+    pde_.init();
+    const int64_t n = pde_.n_dofs(), q = 3;
+    auto invA = pde_.make_solver();
+    invA.compute(pde_.stiff(), /*symmetric=*/true);
+    DMatrix<double> U(n, q), invC(q, q, 0.0), b(n, 1);
+    for (int64_t i = 0; i < n; ++i) {
+        b(i) = std::cos(0.02 * i) + 0.3;
+        for (int64_t j = 0; j < q; ++j) U(i, j) = 0.05 * std::sin(0.013 * i * (j + 1)) + 0.01 * j;
+    }
+    for (int64_t j = 0; j < q; ++j) invC(j, j) = 1.0 + 0.5 * j;   // C = diag(1, 2/3, 1/2)
+    invC(0, 1) = 0.1;
+    DMatrix<double> V = transpose(U);
+    SMW<decltype(invA)> smw;
+    DMatrix<double> x = smw.solve(invA, U, invC, V, b);
+    // residual of (A + U C V) x = b with C = invC^{-1}
+    PartialPivLU luC;
+    luC.compute(invC);
+    DMatrix<double> r = pde_.stiff() * x + U * luC.solve(V * x) - b;
+    double rn = 0, bn = 0;
+    for (int64_t i = 0; i < n; ++i) rn += r(i) * r(i), bn += b(i) * b(i);
+    EXPECT_TRUE(std::sqrt(rn / bn) < 1e-8);
+    // lump(mass): row sums = integrals of the basis functions; they add up to the area of the unit square
+    SpMatrix<double> R0 = lump(pde_.mass());
+    double area = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        EXPECT_TRUE(R0.rowptr[(size_t)i + 1] - R0.rowptr[(size_t)i] == 1 && R0.colidx[(size_t)i] == i);
+        area += R0.values[(size_t)i];
+    }
+    EXPECT_TRUE(almost_equal(area, 1.0, 1e-12));
+    std::vector<double> dev((size_t)n);
+    EXPECT_TRUE(fdapde_lump(pde_.context(), FDAPDE_MAT_MASS, dev.data()) == FDAPDE_OK);   // the same on the device
+    double worst = 0;
+    for (int64_t i = 0; i < n; ++i) worst = std::fmax(worst, std::fabs(dev[(size_t)i] - R0.values[(size_t)i]));
+    EXPECT_TRUE(worst < 1e-15);
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) { std::printf("usage: %s <tests/golden/mesh>\n", argv[0]); return 2; }
     MESH_PATH = argv[1];
@@ -301,6 +343,7 @@ int main(int argc, char** argv) {
     RUN(fem_pde_test, laplacian_3d_order1);
     RUN(fem_pde_test, parabolic_isotropic_order2);
     RUN(sparse_solver_test, factor_once_solve_many);
+    RUN(linear_algebra_test, smw_and_lumping);
     std::printf("%d checks, %d failures\n", checks, failures);
     return failures == 0 ? 0 : 1;
 }

@@ -424,3 +424,20 @@ def test_minimal_meshes_on_device(capi, ctx, oracle, order):
         info = ctx.solve(rtol=1e-12)
         assert info.converged == 1
         assert np.linalg.norm(ctx.solution() - ref.solution) / np.linalg.norm(ref.solution) <= SOL_TOL
+
+
+def test_lumped_mass_matches_oracle(capi, ctx, oracle, mesh_loader):
+    """lump(mass()) (linear_algebra/lumping.h:30-41): device row sums against the oracle's mass matrix, P1 and P2"""
+    m = mesh_loader("unit_sphere")
+    for order in (1, 2):
+        ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+        nd = ctx.dofs_build(order)
+        ctx.set_operator(-capi.laplacian())
+        ctx.set_forcing(np.zeros(ctx.sizes()["n_quadrature"] * m.n_cells))
+        ctx.init()
+        dofs, _, ond, _ = oracle.enumerate_dofs(m, order)
+        M = oracle.assemble_operator(m, order, dofs, ond, oracle.reaction(1.0))
+        ref = np.asarray(M.to_scipy().sum(axis=1)).ravel()
+        got = ctx.lump(capi.MAT_MASS)
+        assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+        assert abs(got.sum() - ref.sum()) <= 1e-12 * abs(ref.sum())

@@ -154,6 +154,7 @@ struct fdapde_ctx {
     bool halo_ready = false;
     int64_t n_if = 0, n_loc_if = 0;          // global / local interface DOF counts
     DBuf<int32_t> halo_dof, halo_pos;        // local interface DOF (internal id) -> slot in the global interface vector
+    DBuf<int32_t> halo_inv, if_slot;         // global slot -> local DOF or -1 [n_if]; local DOF -> global slot or -1 [n_dofs]
     DBuf<uint8_t> owned;                     // internal DOF order: 1 = this rank counts the DOF in global dot products
     DBuf<double> hbuf, sbuf;                 // [n_if + 2] packed interface values + fused dot partials; [4] scalars
     // "factor once, solve many" handle (fdapde::SparseLU wrapper, utils/symbols.h:133-160)
@@ -543,14 +544,13 @@ int allreduce_sum(fdapde_ctx* c, double* buf, size_t count) {
 }
 // v (internal DOF order, sub-assembled) -> interface entries summed over the ranks sharing them; optionally carries the
 // two fused dot partials of the SpMV (part_a, stride 2) through the same all-reduce: they land in hbuf[n_if], [n_if + 1]
-int halo_sum(fdapde_ctx* c, double* v, const double* part, int np) {
+int halo_sum(fdapde_ctx* c, double* v, const double* part, int np, bool unpack = true) {
     hipStream_t st = c->stream;
-    HIPCHK(c, hipMemsetAsync(c->hbuf.p, 0, sizeof(double) * (size_t)(c->n_if + 2), st));
     const unsigned grid = g1(c->n_loc_if > 0 ? c->n_loc_if : 1);
-    hipLaunchKernelGGL(k_halo_pack, dim3(grid), dim3(256), 0, st, c->n_loc_if, c->halo_dof.p, c->halo_pos.p, v, c->hbuf.p, c->n_if,
-                       part, np);
+    hipLaunchKernelGGL(k_halo_pack_all, dim3(g1(c->n_if > 0 ? c->n_if : 1)), dim3(256), 0, st, c->n_if, c->halo_inv.p, v, c->hbuf.p, part,
+                       np);   // one launch writes every slot (zeros where this rank has no DOF): no memset
     if (int rc = allreduce_sum(c, c->hbuf.p, (size_t)(c->n_if + 2))) return rc;
-    if (c->n_loc_if > 0)
+    if (c->n_loc_if > 0 && unpack)
         hipLaunchKernelGGL(k_halo_unpack, dim3(grid), dim3(256), 0, st, c->n_loc_if, c->halo_dof.p, c->halo_pos.p, c->hbuf.p, v);
     HIPCHK(c, hipGetLastError());
     return FDAPDE_OK;
@@ -624,6 +624,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
         c->slotw.release(), c->sl_off.release(), c->bnd.release(), c->tables.release();
         c->bc_off.release(), c->bn_off.release(), c->bc_cell.release(), c->bn_node.release(), c->bc_vert.release();
         c->halo_dof.release(), c->halo_pos.release(), c->owned.release(), c->hbuf.release(), c->sbuf.release();
+        c->halo_inv.release(), c->if_slot.release();
         if (c->comm) (void)g_rccl.CommDestroy(c->comm);
         c->lin_mat.release();
         for (int v = 0; v < 2; ++v)
@@ -1000,11 +1001,13 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
                 const double* part = c->part_a.p;
                 int np = c->spmv_grid;
                 if (dist) {
-                    if (int rc = halo_sum(c, c->y.p, c->part_a.p, c->spmv_grid)) return rc;
+                    // pack -> all-reduce; the update kernel reads the summed interface rows straight from hbuf (no unpack launch)
+                    if (int rc = halo_sum(c, c->y.p, c->part_a.p, c->spmv_grid, /*unpack=*/false)) return rc;
                     part = c->hbuf.p + c->n_if, np = 1;
                 }
                 hipLaunchKernelGGL(k_cgsr_update, dim3(c->cg_grid), dim3(256), 0, st, n, c->r.p, c->y.p, c->p.p, c->s.p, c->x.p, part,
-                                   np, c->sc.p, parity, launched == 0 ? 1 : 0, tol2, c->ctl.p);
+                                   np, c->sc.p, parity, launched == 0 ? 1 : 0, tol2, c->ctl.p,
+                                   dist ? c->if_slot.p : (const int32_t*)nullptr, dist ? c->hbuf.p : (const double*)nullptr);
             } else if (cgf) {
                 const bool tm = launched < n_timed;
                 // explicit r.r partials ping-pong between the two halves of part_b
@@ -1608,6 +1611,10 @@ int fdapde_halo_setup(fdapde_ctx* c, int64_t n_if_global, int64_t n_if_local, co
     }
     std::vector<uint8_t> own_i((size_t)hs.n_dofs);
     for (int64_t i = 0; i < hs.n_dofs; ++i) own_i[(size_t)i] = owned[hs.dof_i2e[(size_t)i]] ? 1 : 0;
+    std::vector<int32_t> inv((size_t)(n_if_global > 0 ? n_if_global : 1), -1), slot((size_t)hs.n_dofs + 2, -1);
+    for (int64_t k = 0; k < n_if_local; ++k) inv[(size_t)pos[(size_t)k]] = dof_i[(size_t)k], slot[(size_t)dof_i[(size_t)k]] = pos[(size_t)k];
+    HIPCHK(c, c->halo_inv.upload(inv.data(), inv.size(), c->stream));
+    HIPCHK(c, c->if_slot.upload(slot.data(), slot.size(), c->stream));
     HIPCHK(c, c->halo_dof.upload(dof_i.data(), dof_i.size(), c->stream));
     HIPCHK(c, c->halo_pos.upload(pos.data(), pos.size(), c->stream));
     HIPCHK(c, c->owned.upload(own_i.data(), own_i.size(), c->stream));

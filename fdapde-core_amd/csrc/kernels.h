@@ -1462,9 +1462,11 @@ __global__ __launch_bounds__(256) void k_cg_update_p(int64_t n, const double* r,
 // Two launches and (multi-GPU) one all-reduce per iteration instead of three and two.  Same Krylov iterates as CG in
 // exact arithmetic.  part_in: stride-2 pairs (delta, gamma); scalars: sc[10 + parity] gamma_old, sc[12 + parity] alpha_old.
 // Every workgroup takes the stop decision from the same reduced numbers, so no workgroup updates past convergence.
+// if_slot / hb (multi-GPU, else nullptr): rows with if_slot[row] >= 0 take w from the all-reduced interface buffer hb, which
+// saves the separate unpack launch (w itself is not read again)
 __global__ __launch_bounds__(256) void k_cgsr_update(int64_t n, double* r, const double* w, double* p, double* s, double* x,
                                                       const double* part_in, int np_in, double* sc, int parity, int first,
-                                                      double tol2, int32_t* ctl) {
+                                                      double tol2, int32_t* ctl, const int32_t* if_slot, const double* hb) {
     __shared__ double red[8];
     if (__syncthreads_or(ctl[0] != 0)) return;
     const int64_t n2 = n >> 1, i0 = (int64_t)blockIdx.x * (256 * kCgV) + threadIdx.x;
@@ -1478,6 +1480,11 @@ __global__ __launch_bounds__(256) void k_cgsr_update(int64_t n, double* r, const
     for (int k = 0; k < kCgV; ++k) {
         const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
         rv[k] = r2[ic], wv[k] = w2[ic], pv[k] = p2[ic], sv[k] = s2[ic], xv[k] = x2[ic];
+        if (if_slot) {
+            const int s0 = if_slot[2 * ic], s1 = if_slot[2 * ic + 1];
+            if (s0 >= 0) wv[k].x = hb[s0];
+            if (s1 >= 0) wv[k].y = hb[s1];
+        }
     }
     double a = 0, b = 0;
     for (int i = threadIdx.x; i < np_in; i += blockDim.x) a += part_in[2 * i], b += part_in[2 * i + 1];
@@ -1505,7 +1512,8 @@ __global__ __launch_bounds__(256) void k_cgsr_update(int64_t n, double* r, const
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const int64_t i = n - 1;
-        p[i] = r[i] + beta * p[i], s[i] = w[i] + beta * s[i];
+        const double wi = (if_slot && if_slot[i] >= 0) ? hb[if_slot[i]] : w[i];
+        p[i] = r[i] + beta * p[i], s[i] = wi + beta * s[i];
         x[i] += alpha * p[i], r[i] -= alpha * s[i];
     }
     if (last) {
@@ -1707,6 +1715,24 @@ __global__ __launch_bounds__(256) void k_halo_pack(int64_t n_loc_if, const int32
     if (blockIdx.x == 0 && part != nullptr) {
         double a = 0, b = 0;
         for (int k = threadIdx.x; k < np; k += blockDim.x) a += part[2 * k], b += part[2 * k + 1];
+        const double sa = block_sum(a, red);
+        const double sb = block_sum(b, red);
+        if (threadIdx.x == 0) buf[n_if] = sa, buf[n_if + 1] = sb;
+    }
+}
+// the same without a prior memset: one lane per GLOBAL interface slot; inv[j] = this rank's DOF of slot j or -1
+__global__ __launch_bounds__(256) void k_halo_pack_all(int64_t n_if, const int32_t* inv, const double* v, double* buf,
+                                                        const double* part, int np) {
+    __shared__ double red[8];
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_if) {
+        const int32_t d = inv[j];
+        buf[j] = d >= 0 ? v[d] : 0.0;
+    }
+    if (blockIdx.x == 0) {
+        double a = 0, b = 0;
+        if (part != nullptr)
+            for (int k = threadIdx.x; k < np; k += blockDim.x) a += part[2 * k], b += part[2 * k + 1];
         const double sa = block_sum(a, red);
         const double sb = block_sum(b, red);
         if (threadIdx.x == 0) buf[n_if] = sa, buf[n_if + 1] = sb;

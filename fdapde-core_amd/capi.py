@@ -42,7 +42,7 @@ SYMBOLS = [
     "fdapde_abi_version", "fdapde_device_count", "fdapde_ctx_create", "fdapde_ctx_destroy", "fdapde_last_error",
     "fdapde_status_string", "fdapde_mesh_upload", "fdapde_dofs_build", "fdapde_dofs_get", "fdapde_dofs_set_boundary", "fdapde_sizes",
     "fdapde_pattern_get", "fdapde_quadrature_nodes", "fdapde_set_operator", "fdapde_set_forcing", "fdapde_set_dirichlet",
-    "fdapde_init", "fdapde_assemble_operator", "fdapde_solve", "fdapde_matrix_values", "fdapde_lump", "fdapde_force", "fdapde_solution",
+    "fdapde_init", "fdapde_assemble_operator", "fdapde_solver_prepare", "fdapde_solve", "fdapde_matrix_values", "fdapde_lump", "fdapde_force", "fdapde_solution",
     "fdapde_info_get", "fdapde_spmv", "fdapde_bench_spmv", "fdapde_tune", "fdapde_stream", "fdapde_synchronize",
     "fdapde_comm_unique_id", "fdapde_comm_init", "fdapde_halo_setup", "fdapde_solve_parabolic",
     "fdapde_lin_compute", "fdapde_lin_solve", "fdapde_eval_pointwise", "fdapde_cell_integrals", "fdapde_comm_init_callback",
@@ -261,6 +261,9 @@ class Context:
     def assemble_operator(self, which, op: Operator, assembly=ASSEMBLY_ROWS):
         terms, keep = op.c_terms()
         self._check(self.lib.fdapde_assemble_operator(self._ctx, which, len(op.terms), terms, assembly))
+
+    def solver_prepare(self, with_dirichlet=True):
+        self._check(self.lib.fdapde_solver_prepare(self._ctx, 1 if with_dirichlet else 0))
 
     def solve(self, method=SOLVER_AUTO, rtol=1e-10, maxit=0, check_every=0, raise_on_noconv=True, time_spmv=0):
         opt = Options(method=method, maxit=maxit, rtol=rtol, assembly=0, check_every=check_every, time_spmv=time_spmv)

@@ -863,6 +863,32 @@ namespace {
 
 
 
+// compact solver pattern v (0: no Dirichlet reduction, 1: Dirichlet rows / columns dropped) + its 16-bit column codes; host work
+// and uploads, done once per function space and boundary mask (fdapde_solver_prepare, or lazily by the first solve)
+int build_solver_pattern(fdapde_ctx* c, int v) {
+    if (c->sp_built[v]) return FDAPDE_OK;
+    const int64_t n = c->hs.n_dofs;
+    hipStream_t st = c->stream;
+    std::vector<int32_t> rp, ci, map;
+    if (int rc = host_build_solver_pattern(c->hs, v == 1, rp, ci, map)) return rc;
+    HIPCHK(c, c->sp_rowptr[v].upload(rp.data(), rp.size(), st));
+    HIPCHK(c, c->sp_colidx[v].upload(ci.data(), ci.size(), st));
+    HIPCHK(c, c->sp_map[v].upload(map.data(), map.size(), st));
+    {   // 16-bit column codes of the same pattern
+        std::vector<uint16_t> code;
+        std::vector<int32_t> tb;
+        if (int rc = host_build_col16(n, rp, ci, code, tb, &c->sp_wide[v])) return rc;
+        HIPCHK(c, c->sp_col16[v].upload(code.data(), code.size(), st));
+        HIPCHK(c, c->sp_tbase[v].upload(tb.data(), tb.size(), st));
+        if (std::getenv("FDAPDE_DEBUG_SETUP"))
+            std::fprintf(stderr, "solver pattern %d: %lld entries, %lld of %lld row groups wide\n", v, (long long)rp.back(),
+                         (long long)c->sp_wide[v], (long long)((n + kCodeRows - 1) / kCodeRows));
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    c->sp_nnz[v] = rp.back(), c->sp_built[v] = true;
+    return FDAPDE_OK;
+}
+
 // Dirichlet reduction + Jacobi scaling of the system matrix A (internal slots): scale, sval = diag(s) A diag(s).
 // Done once per matrix (per solve for the elliptic problem, once for all time steps of the parabolic one).
 int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss) {
@@ -897,25 +923,7 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss) {
     const bool compact = ss->diag_positive && c->spmv_variant == 2 && !std::getenv("FDAPDE_SPMV_FULL");
     if (compact) {
         const int v = use_bnd ? 1 : 0;
-        if (!c->sp_built[v]) {
-            std::vector<int32_t> rp, ci, map;
-            if (int rc = host_build_solver_pattern(c->hs, v == 1, rp, ci, map)) return rc;
-            HIPCHK(c, c->sp_rowptr[v].upload(rp.data(), rp.size(), st));
-            HIPCHK(c, c->sp_colidx[v].upload(ci.data(), ci.size(), st));
-            HIPCHK(c, c->sp_map[v].upload(map.data(), map.size(), st));
-            {   // 16-bit column codes of the same pattern
-                std::vector<uint16_t> code;
-                std::vector<int32_t> tb;
-                if (int rc = host_build_col16(n, rp, ci, code, tb, &c->sp_wide[v])) return rc;
-                HIPCHK(c, c->sp_col16[v].upload(code.data(), code.size(), st));
-                HIPCHK(c, c->sp_tbase[v].upload(tb.data(), tb.size(), st));
-                if (std::getenv("FDAPDE_DEBUG_SETUP"))
-                    std::fprintf(stderr, "solver pattern %d: %lld entries, %lld of %lld row groups wide\n", v, (long long)rp.back(),
-                                 (long long)c->sp_wide[v], (long long)((n + kCodeRows - 1) / kCodeRows));
-            }
-            HIPCHK(c, hipStreamSynchronize(st));
-            c->sp_nnz[v] = rp.back(), c->sp_built[v] = true;
-        }
+        if (int rc = build_solver_pattern(c, v)) return rc;
         hipLaunchKernelGGL(k_scale_matrix_compact, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, A, c->scale.p,
                            c->sp_map[v].p, c->sval.p);
         c->sp_cur = v;
@@ -1131,6 +1139,17 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
 }   // namespace
 
 extern "C" {
+
+// One-time preparation of the solver's compact matrix layout for the current boundary-DOF mask (part of set-up, like
+// fdapde_dofs_build; the first solve does it lazily otherwise).  with_dirichlet: the layout used when Dirichlet data are set.
+int fdapde_solver_prepare(fdapde_ctx* c, int32_t with_dirichlet) {
+    if (!c) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (!c->dev_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->spmv_variant != 2) return FDAPDE_OK;
+    return build_solver_pattern(c, with_dirichlet ? 1 : 0);
+}
 
 int fdapde_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     if (!c) return FDAPDE_EINVAL;

@@ -151,6 +151,7 @@ def bench_partitioned(capi, nodes, cells, bnd, f, u_exact, rank, world, local_ra
     ctx.set_forcing(f(qn))
     ctx.set_dirichlet(np.zeros(n_loc))
     del qn
+    ctx.solver_prepare(True)   # set-up (untimed): compact solver pattern + column codes of this rank's sub-mesh
 
     def step(time_spmv=0):
         ctx.init()

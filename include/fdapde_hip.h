@@ -136,6 +136,9 @@ int fdapde_assemble_operator(fdapde_ctx *ctx, int32_t which, int32_t n_terms, co
 
 /* ---- PDE::solve (pde/pde.h:102-105): set_dirichlet_bc (fem_solver_base.h:142-155) + elliptic solve
  *      (fem_linear_elliptic_solver.h:34-50; Eigen::SparseLU replaced by Jacobi-PCG / BiCGStab on the interior block) */
+/* One-time preparation (host index work + uploads) of the solver's compact matrix layout for the current boundary-DOF mask;
+ * set-up like fdapde_dofs_build.  Optional: the first fdapde_solve / fdapde_lin_solve does it lazily. */
+int fdapde_solver_prepare(fdapde_ctx *ctx, int32_t with_dirichlet);
 int fdapde_solve(fdapde_ctx *ctx, const fdapde_options *opt, fdapde_info *info);
 
 /* ---- FEMLinearParabolicSolver::solve (finite_elements/solvers/fem_linear_parabolic_solver.h:37-72): implicit Euler ---------

@@ -136,9 +136,12 @@ struct fdapde_ctx {
     int spmv_team = 16, spmv_unroll = 4, spmv_ablate = 0;
     int lds_limit = 96 * 1024;   // per assembly workgroup: tables + staged vertices + row accumulators
     // compact solver pattern (no diagonal; [1]: also no Dirichlet rows / columns), built on first use
-    DBuf<int32_t> sp_rowptr[2], sp_colidx[2], sp_map[2], sp_tbase[2];
+    DBuf<int32_t> sp_rowptr[2], sp_colidx[2], sp_map[2], sp_tbase[2], sp_vrow[2];
+    int64_t sp_nv[2] = {0, 0};               // > 0: the compact pattern is segmented into this many virtual rows (sp_vrow)
+    int sval_layout = -2;                    // layout sval was last zero-filled for (pad entries of a segmented pattern stay 0)
     DBuf<uint16_t> sp_col16[2];              // 16-bit column codes of the compact pattern (host_build_col16)
     int64_t sp_wide[2] = {0, 0};             // groups of 32 rows that fall back to the 32-bit columns
+    int sp_team = 0;                         // team size the segmented patterns were built for
     int spmv_c16 = 1;                        // tuning knob: 0 = always stream the 32-bit columns
     int cgf_v = 8;                           // double2 elements per lane of k_cgf_update (1, 2, 4, 8); C3 solve: 47.2 / 41.8 / 41.3 / 40.9 ms
     int spmv_deep = 0;                       // tuning knob: 1 = k_spmv_c16p (gathers one tile ahead; measured slower: 3 waves / SIMD)
@@ -416,16 +419,23 @@ void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, 
     s.rowptr = c->rowptr.p, s.colidx = c->colidx.p, s.vals = vals, s.x = x, s.y = y;
     s.rb_row = c->rb_row.p, s.n_rb = c->n_rb, s.rb_per_band = c->rb_per_band, s.nnz = (int32_t)c->hs.nnz;
     s.w = w, s.partial = partial, s.stop = stop, s.dot2_ww = dot2_ww, s.owned = owned, s.unit_diag = 0;
+    s.n_cols = (int32_t)c->hs.n_dofs;
+    int64_t n = c->hs.n_dofs;   // rows of the CSR arrays the kernel walks (virtual rows for a segmented pattern)
+    bool vrows = false;
     if (vals == c->sval.p && c->sp_cur >= 0) {   // the solver's scaled matrix lives in the compact pattern
         s.rowptr = c->sp_rowptr[c->sp_cur].p, s.colidx = c->sp_colidx[c->sp_cur].p, s.nnz = (int32_t)c->sp_nnz[c->sp_cur];
         if (c->spmv_c16) s.col16 = c->sp_col16[c->sp_cur].p, s.tbase = c->sp_tbase[c->sp_cur].p;
+        if (c->sp_nv[c->sp_cur] > 0) {   // segmented: only the VROWS instantiations understand it (always with column codes)
+            vrows = true, n = c->sp_nv[c->sp_cur], s.vrow = c->sp_vrow[c->sp_cur].p;
+            s.col16 = c->sp_col16[c->sp_cur].p, s.tbase = c->sp_tbase[c->sp_cur].p;
+        }
         s.unit_diag = 1;
         // multi-GPU: the local diagonals s_i^2 (A_p)_ii of an interface DOF sum to 1 over the ranks sharing it; the implicit
         // unit diagonal is therefore contributed by the DOF's owner only (any split of the entries among ranks is valid)
         if ((c->comm != nullptr || c->ar_fn != nullptr) && c->halo_ready) s.owned = c->owned.p;
     }
     // eight row bands (one per XCD); band starts on a multiple of 32 rows so that a wavefront tile lies in one code group
-    const int64_t n = c->hs.n_dofs, rpb = (((n + 7) / 8) + 31) & ~int64_t(31);
+    const int64_t rpb = (((n + 7) / 8) + 31) & ~int64_t(31);
     const dim3 grid(c->spmv_grid), block(256);
 #define SPMV_GO(...) hipExtLaunchKernelGGL((__VA_ARGS__), grid, block, 0, c->stream, e0, e1, 0, s, n, rpb)
     if (c->spmv_variant == 1) {
@@ -452,6 +462,19 @@ void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, 
         else if (dist) SPMV_GO(k_spmv_team2<T_, U_, 2048 | 8192 | 16384>);                   \
         else SPMV_GO(k_spmv_team2<T_, U_, 2048 | 16384>);                                    \
     } while (0)
+        if (vrows) {   // built for this team size (build_solver_pattern); T = 8 or 16
+#define SPMV_VROWS(T_)                                                                                  \
+    do {                                                                                                \
+        if (dist && wx) SPMV_GO(k_spmv_team2<T_, 4, 2048 | 4096 | 131072 | 8192 | 16384>);              \
+        else if (dist) SPMV_GO(k_spmv_team2<T_, 4, 2048 | 4096 | 131072 | 8192>);                       \
+        else if (wx) SPMV_GO(k_spmv_team2<T_, 4, 2048 | 4096 | 131072 | 16384>);                        \
+        else SPMV_GO(k_spmv_team2<T_, 4, 2048 | 4096 | 131072>);                                        \
+    } while (0)
+            if (c->sp_team == 8) SPMV_VROWS(8);
+            else SPMV_VROWS(16);
+#undef SPMV_VROWS
+            return;
+        }
         switch (c->spmv_team) {
         case 2: SPMV_PROD_FEW(2, 1); break;
         case 4: SPMV_PROD_FEW(4, 2); break;
@@ -628,7 +651,8 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
         if (c->comm) (void)g_rccl.CommDestroy(c->comm);
         c->lin_mat.release();
         for (int v = 0; v < 2; ++v)
-            c->sp_rowptr[v].release(), c->sp_colidx[v].release(), c->sp_map[v].release(), c->sp_tbase[v].release(), c->sp_col16[v].release();
+            c->sp_rowptr[v].release(), c->sp_colidx[v].release(), c->sp_map[v].release(), c->sp_tbase[v].release(), c->sp_col16[v].release(),
+              c->sp_vrow[v].release();
         if (c->h_ctl) (void)hipHostFree(c->h_ctl);
         if (c->h_sc) (void)hipHostFree(c->h_sc);
         (void)hipEventDestroy(c->ev0), (void)hipEventDestroy(c->ev1);
@@ -867,22 +891,35 @@ namespace {
 // and uploads, done once per function space and boundary mask (fdapde_solver_prepare, or lazily by the first solve)
 int build_solver_pattern(fdapde_ctx* c, int v) {
     if (c->sp_built[v]) return FDAPDE_OK;
-    const int64_t n = c->hs.n_dofs;
     hipStream_t st = c->stream;
-    std::vector<int32_t> rp, ci, map;
-    if (int rc = host_build_solver_pattern(c->hs, v == 1, rp, ci, map)) return rc;
+    std::vector<int32_t> rp, ci, map, vrow;
+    // rows longer than a team pass (P2): segmented pattern, one team pass per chunk; else the plain compact pattern
+    const int T = c->spmv_team;
+    bool seg = false;
+    if ((T == 8 || T == 16) && c->hs.max_row - 1 > 2 * T && !std::getenv("FDAPDE_SPMV_NOSEG")) {
+        const int rc = host_build_solver_pattern_seg(c->hs, v == 1, 2 * T, (64 / T) * 4, rp, ci, map, vrow);
+        if (rc == FDAPDE_OK) seg = true;
+        else if (rc != FDAPDE_EUNSUPPORTED) return rc;
+    }
+    if (!seg)
+        if (int rc = host_build_solver_pattern(c->hs, v == 1, rp, ci, map)) return rc;
+    const int64_t n_csr = (int64_t)rp.size() - 1;   // rows of the CSR arrays (virtual rows when segmented)
+    c->sp_nv[v] = seg ? n_csr : 0, c->sp_team = T;
+    if (seg) HIPCHK(c, c->sp_vrow[v].upload(vrow.data(), vrow.size(), st));
+    if ((size_t)rp.back() + 2 > c->sval.n) HIPCHK(c, c->sval.alloc((size_t)rp.back() + 2));   // pad entries may exceed nnz
+    c->sval_layout = -2;
     HIPCHK(c, c->sp_rowptr[v].upload(rp.data(), rp.size(), st));
     HIPCHK(c, c->sp_colidx[v].upload(ci.data(), ci.size(), st));
     HIPCHK(c, c->sp_map[v].upload(map.data(), map.size(), st));
     {   // 16-bit column codes of the same pattern
         std::vector<uint16_t> code;
         std::vector<int32_t> tb;
-        if (int rc = host_build_col16(n, rp, ci, code, tb, &c->sp_wide[v])) return rc;
+        if (int rc = host_build_col16(n_csr, rp, ci, code, tb, &c->sp_wide[v])) return rc;
         HIPCHK(c, c->sp_col16[v].upload(code.data(), code.size(), st));
         HIPCHK(c, c->sp_tbase[v].upload(tb.data(), tb.size(), st));
         if (std::getenv("FDAPDE_DEBUG_SETUP"))
-            std::fprintf(stderr, "solver pattern %d: %lld entries, %lld of %lld row groups wide\n", v, (long long)rp.back(),
-                         (long long)c->sp_wide[v], (long long)((n + kCodeRows - 1) / kCodeRows));
+            std::fprintf(stderr, "solver pattern %d: %lld entries in %lld %srows, %lld of %lld row groups wide\n", v, (long long)rp.back(),
+                         (long long)n_csr, seg ? "virtual " : "", (long long)c->sp_wide[v], (long long)((n_csr + kCodeRows - 1) / kCodeRows));
     }
     HIPCHK(c, hipStreamSynchronize(st));
     c->sp_nnz[v] = rp.back(), c->sp_built[v] = true;
@@ -924,12 +961,16 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss) {
     if (compact) {
         const int v = use_bnd ? 1 : 0;
         if (int rc = build_solver_pattern(c, v)) return rc;
+        if (c->sval_layout != v) {   // entries no full-pattern entry maps to (padding of a segmented pattern) must read 0
+            HIPCHK(c, hipMemsetAsync(c->sval.p, 0, sizeof(double) * c->sval.n, st));
+            c->sval_layout = v;
+        }
         hipLaunchKernelGGL(k_scale_matrix_compact, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, A, c->scale.p,
                            c->sp_map[v].p, c->sval.p);
         c->sp_cur = v;
     } else {
         hipLaunchKernelGGL(k_scale_matrix, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, A, c->scale.p, c->sval.p);
-        c->sp_cur = -1;
+        c->sp_cur = -1, c->sval_layout = -2;
     }
     HIPCHK(c, hipGetLastError());
     return FDAPDE_OK;
@@ -1649,7 +1690,10 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     if (!c->dev_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
     const std::string k(key);
     if (k == "spmv_variant" && value >= 0 && value <= 2) c->spmv_variant = value;
-    else if (k == "spmv_team" && (value == 2 || value == 4 || value == 8 || value == 16 || value == 32 || value == 64)) c->spmv_team = value;
+    else if (k == "spmv_team" && (value == 2 || value == 4 || value == 8 || value == 16 || value == 32 || value == 64)) {
+        if (value != c->spmv_team) c->sp_built[0] = c->sp_built[1] = false, c->sp_cur = -1, c->solved = false;   // segmented patterns depend on it
+        c->spmv_team = value;
+    }
     else if (k == "spmv_unroll" && value >= 1 && value <= 8) c->spmv_unroll = value;
     else if (k == "spmv_ablate") c->spmv_ablate = value;
     else if (k == "spmv_c16" && (value == 0 || value == 1)) c->spmv_c16 = value;

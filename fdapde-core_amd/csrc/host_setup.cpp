@@ -632,6 +632,87 @@ int host_build_solver_pattern(const HostSpace& hs, bool use_bnd, std::vector<int
     return FDAPDE_OK;
 }
 
+// Segmented form of the compact solver pattern for matrices with rows longer than one team pass (P2: 18 / 26 / 64 entries per
+// row on a Kuhn mesh).  Every row is cut into chunks of at most `seg` entries; a chunk is a VIRTUAL row of the CSR arrays that
+// k_spmv_team2 streams (one team pass each, no tail loop), padded to an even number of entries so that every virtual row
+// starts on an aligned pair.  The chunks of a row are adjacent and never straddle a tile of `wrows` virtual rows (the tile is
+// filled up with empty chunks of its last row instead), so the kernel can add them up in its per-tile LDS transpose.
+//   vrow[2 v] = row of virtual row v,  vrow[2 v + 1] = chunk index | number of chunks << 8
+// Returns FDAPDE_EUNSUPPORTED when a row needs more than `wrows` chunks (the caller then keeps the plain pattern).
+int host_build_solver_pattern_seg(const HostSpace& hs, bool use_bnd, int seg, int wrows, std::vector<int32_t>& rowptr_v,
+                                  std::vector<int32_t>& colidx_s, std::vector<int32_t>& full2s, std::vector<int32_t>& vrow) {
+    const int64_t nd = hs.n_dofs;
+    auto keep = [&](int64_t r, int32_t col) {
+        if (col == r) return false;
+        if (use_bnd && (hs.dof_bnd_i[(size_t)r] || hs.dof_bnd_i[(size_t)col])) return false;
+        return true;
+    };
+    std::vector<int32_t> cnt((size_t)nd);
+    parallel_for(nd, [&](int64_t b, int64_t e, unsigned) {
+        for (int64_t r = b; r < e; ++r) {
+            int32_t c = 0;
+            for (int32_t k = hs.rowptr_i[(size_t)r]; k < hs.rowptr_i[(size_t)r + 1]; ++k) c += keep(r, hs.colidx_i[(size_t)k]);
+            cnt[(size_t)r] = c;
+        }
+    });
+    // layout: first virtual row of every row; tiles are closed with empty chunks of their last row
+    std::vector<int64_t> vfirst((size_t)nd + 1);
+    std::vector<int32_t> nchunk((size_t)nd);
+    int64_t nv = 0;
+    for (int64_t r = 0; r < nd; ++r) {
+        const int32_t nc = cnt[(size_t)r] > 0 ? (cnt[(size_t)r] + seg - 1) / seg : 1;
+        if (nc > wrows || nc > 255) return FDAPDE_EUNSUPPORTED;
+        const int64_t slot = nv % wrows;
+        if (slot + nc > wrows) {   // does not fit: the previous row (same tile) takes the free slots as empty chunks
+            const int32_t pad = (int32_t)(wrows - slot);
+            if (nchunk[(size_t)r - 1] + pad > 255) return FDAPDE_EUNSUPPORTED;
+            nchunk[(size_t)r - 1] += pad, nv += pad;
+        }
+        vfirst[(size_t)r] = nv, nchunk[(size_t)r] = nc, nv += nc;
+    }
+    vfirst[(size_t)nd] = nv;
+    if (nv > (int64_t)1 << 30) return FDAPDE_EUNSUPPORTED;
+    rowptr_v.assign((size_t)nv + 1, 0);
+    vrow.assign((size_t)nv * 2 + 2, 0);
+    parallel_for(nd, [&](int64_t b, int64_t e, unsigned) {
+        for (int64_t r = b; r < e; ++r) {
+            const int32_t m = cnt[(size_t)r], nc = nchunk[(size_t)r];
+            for (int32_t k = 0; k < nc; ++k) {
+                const int64_t v = vfirst[(size_t)r] + k;
+                const int32_t len = std::max(0, std::min(seg, m - k * seg));
+                rowptr_v[(size_t)v + 1] = (len + 1) & ~1;   // even length
+                vrow[(size_t)v * 2] = (int32_t)r, vrow[(size_t)v * 2 + 1] = k | (nc << 8);
+            }
+        }
+    });
+    for (int64_t v = 0; v < nv; ++v) rowptr_v[(size_t)v + 1] += rowptr_v[(size_t)v];
+    if ((int64_t)rowptr_v[(size_t)nv] < 0) return FDAPDE_EUNSUPPORTED;
+    colidx_s.assign((size_t)rowptr_v[(size_t)nv] + 2, 0);
+    full2s.assign((size_t)hs.nnz, -1);
+    parallel_for(nd, [&](int64_t b, int64_t e, unsigned) {
+        std::vector<int32_t> ks;
+        for (int64_t r = b; r < e; ++r) {
+            ks.clear();
+            for (int32_t k = hs.rowptr_i[(size_t)r]; k < hs.rowptr_i[(size_t)r + 1]; ++k)
+                if (keep(r, hs.colidx_i[(size_t)k])) ks.push_back(k);
+            const int32_t m = (int32_t)ks.size();
+            for (int32_t c = 0; c * seg < m || c == 0; ++c) {
+                const int64_t v = vfirst[(size_t)r] + c;
+                const int32_t base = rowptr_v[(size_t)v], len = std::max(0, std::min(seg, m - c * seg));
+                const int32_t n_even = (len + 1) / 2;   // even positions hold the lower half of the chunk's columns (see above)
+                for (int32_t j = 0; j < len; ++j) {
+                    const int32_t at = j < n_even ? base + 2 * j : base + 1 + 2 * (j - n_even);
+                    const int32_t k = ks[(size_t)(c * seg + j)];
+                    colidx_s[(size_t)at] = hs.colidx_i[(size_t)k], full2s[(size_t)k] = at;
+                }
+                if (len & 1) colidx_s[(size_t)(base + len)] = hs.colidx_i[(size_t)ks[(size_t)(c * seg + len - 1)]];   // pad entry, value stays 0
+                if (len == 0) break;
+            }
+        }
+    });
+    return FDAPDE_OK;
+}
+
 // 16-bit column codes of a CSR pattern for k_spmv_team2: the kCodeRows consecutive rows of a group share up
 // to four windows of 2^14 columns; an entry is stored as (window << 14) | (column - window base).  Windows are placed greedily
 // over the group's sorted distinct columns.  A group that needs more than four windows (rows at a corner of the coarse blocks

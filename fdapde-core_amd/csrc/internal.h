@@ -90,6 +90,8 @@ int host_build_space(HostSpace& hs, int order, std::string& err);
 int host_build_colouring(HostSpace& hs, std::string& err);
 // Solver pattern: the internal CSR pattern without the diagonal and (use_bnd) without rows / columns of Dirichlet DOFs.
 // full2s[k] = slot of full entry k in the compact arrays, or -1 when the entry is dropped.
+int host_build_solver_pattern_seg(const HostSpace& hs, bool use_bnd, int seg, int wrows, std::vector<int32_t>& rowptr_v,
+                                  std::vector<int32_t>& colidx_s, std::vector<int32_t>& full2s, std::vector<int32_t>& vrow);
 // 16-bit column codes (k_spmv_team2): groups of kCodeRows rows, four windows of kCodeWindow columns each
 constexpr int kCodeRows = 32, kCodeWindow = 1 << 14;
 int host_build_col16(int64_t n, const std::vector<int32_t>& rowptr, const std::vector<int32_t>& colidx, std::vector<uint16_t>& code,

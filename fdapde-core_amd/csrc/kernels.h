@@ -564,6 +564,8 @@ struct SpmvArgs {
     const uint8_t* owned;  // multi-GPU: rows this rank counts in w.w (nullptr = all)
     const uint16_t* col16; // 16-bit column codes (window << 14 | offset) of the pattern, or nullptr   (host_build_col16)
     const int32_t* tbase;  // four window bases per group of 32 rows; tbase[4 g] < 0: wide group, read colidx instead
+    const int32_t* vrow;   // segmented pattern (host_build_solver_pattern_seg): (row, chunk | n_chunks << 8) per virtual row
+    int32_t n_cols;        // number of columns = length of x (the row count the kernels get may be the virtual one)
 };
 __device__ __forceinline__ double spmv_dot2(const SpmvArgs& s, int64_t row, double wv, double out) {
     if (!s.dot2_ww) return out * out;
@@ -839,6 +841,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
     // bases of the 32-row group when the gathers are issued: 2 instead of 4 index bytes per entry
     constexpr bool C16 = (ABL & 4096) != 0;
     static_assert(!C16 || (ALIGNED && 32 % WROWS == 0), "16-bit column codes need aligned pairs and tiles inside a 32-row group");
+    // VROWS: the CSR rows are the chunks ("virtual rows") of a segmented pattern; the chunks of a row sit in one tile and are
+    // added up after the LDS transpose, every chunk lane storing the row's total to the row's y (same value, same address)
+    constexpr bool VROWS = (ABL & 131072) != 0;
+    static_assert(!VROWS || ALIGNED, "segmented patterns start every virtual row on an aligned pair");
     auto load_pair = [&](int rs, int re, F64x2& v, I32x2& c) {
         const int k = (ALIGNED ? (rs & ~1) : rs) + 2 * l;
         const int kc = ALIGNED ? (k < last ? k : (last & ~1)) : (k < last ? k : last);
@@ -876,11 +882,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
         } else
             return v4i32_t{0, 0, 0, 0};
     };
-    const int ncol1 = (int)n - 1;
+    const int ncol1 = s.n_cols - 1;
     auto decode = [&](unsigned int code, const v4i32_t& tb) -> int {
         const int b01 = (code & 0x4000u) ? tb.y : tb.x, b23 = (code & 0x4000u) ? tb.w : tb.z;
         const int col = ((code & 0x8000u) ? b23 : b01) + (int)(code & 0x3fffu);
         return col < ncol1 ? col : ncol1;
+    };
+    auto load_vi = [&](int64_t b) -> v2i32_t {   // (row, chunk info) of this lane's virtual row in the tile at b (clamped)
+        if constexpr (VROWS) {
+            const int64_t v = b + (lane % WROWS);
+            return *reinterpret_cast<const v2i32_t*>(s.vrow + 2 * (v < band_end ? v : band_end - 1));
+        } else
+            return v2i32_t{0, 0};
     };
     int64_t base = band_begin + (int64_t)(lb * 4 + wave) * WROWS;
     if (base < band_end) {
@@ -890,6 +903,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
         F64x2 v[U];
         I32x2 c[U];
         v4i32_t tb = load_tb(base);
+        v2i32_t vi = load_vi(base);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             rs[u] = __shfl(rp0, u * TEAMS + team, 64), re[u] = __shfl(rp0, u * TEAMS + team + 1, 64);
@@ -936,10 +950,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
                     xa[u] = s.x[c[u].x], xb[u] = s.x[c[u].y];
             }
             // lane j < WROWS reports row base + j (rows are transposed into lane order through ystage below)
-            const int64_t row = base + (lane % WROWS);
-            const bool row_ok = FULL || row < band_end;
+            const int64_t vr = base + (lane % WROWS);   // CSR (virtual) row of this lane
+            const bool row_ok = FULL || vr < band_end;
+            // y / x / w row of this lane: the virtual row itself, or the row it is a chunk of
+            const int64_t rowc = VROWS ? (int64_t)vi.x : (row_ok ? vr : band_end - 1);
+            const int64_t row = rowc;
             // implicit unit diagonal of the compact solver matrix (multi-GPU: added by the owner of the DOF only)
-            const int64_t rowc = row_ok ? row : band_end - 1;
             double wv, xd;
             if constexpr (ABL & 16384) {   // the dot operand IS x (CG: p.Ap): one row load serves the dot and the diagonal
                 const double xv = s.x[rowc];
@@ -966,6 +982,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
                 load_pair(rsn[u], ren[u], vn[u], cn[u]);
             }
             const v4i32_t tbn = load_tb(base + stride);
+            const v2i32_t vin = load_vi(base + stride);
             rp1 = load_rp(base + 2 * stride);
             double acc[U];
             bool long_row = false;
@@ -1024,7 +1041,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
             }
             if (l < U) ys[l * TEAMS + team] = pick;
             __builtin_amdgcn_wave_barrier();
-            const double out = ys[lane % WROWS] + xd;
+            double out;
+            if constexpr (VROWS) {   // total of the row this lane's chunk belongs to (its chunks are adjacent in the tile)
+                const int ck = vi.y & 255, cn = vi.y >> 8, j0 = (lane % WROWS) - ck;
+                double t = 0;
+                for (int d = 0; d < cn; ++d) t += ys[j0 + d];
+                out = t + xd;
+            } else
+                out = ys[lane % WROWS] + xd;
             if constexpr (DEFER) {
                 if (lane < WROWS) ydef[(wave * kDeferTiles + n_def) * WROWS + lane] = out;
                 ++n_def;
@@ -1049,11 +1073,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            const double once = (lane < WROWS && row_ok) ? dots : 0.0;   // each row counted by one lane
-            d_wy += once * (wv * out), d_yy += once * spmv_dot2(s, row_ok ? row : band_end - 1, wv, out);
+            const double once = (lane < WROWS && row_ok && (!VROWS || (vi.y & 255) == 0)) ? dots : 0.0;   // each row counted by one lane
+            d_wy += once * (wv * out), d_yy += once * spmv_dot2(s, rowc, wv, out);
 #pragma unroll
             for (int u = 0; u < U; ++u) rs[u] = rsn[u], re[u] = ren[u], c[u] = cn[u], v[u] = vn[u];
-            tb = tbn;
+            tb = tbn, vi = vin;
         };
         const int64_t base0 = base;
         for (; base + WROWS <= band_end; base += stride) tile(std::true_type {});
@@ -1101,7 +1125,7 @@ __global__ __launch_bounds__(256) void k_spmv_c16p(SpmvArgs s, int64_t n, int64_
     const int64_t band_begin = band * rows_per_band;
     const int64_t band_end = min(n, band_begin + rows_per_band);
     const int64_t stride = (int64_t)bpx * 4 * WROWS;
-    const int last = s.nnz - 1, ncol1 = (int)n - 1;
+    const int last = s.nnz - 1, ncol1 = s.n_cols - 1;
     double d_wy = 0, d_yy = 0;
     auto load_rp = [&](int64_t b) -> int {
         const int64_t r = b + lane;

@@ -1036,6 +1036,7 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     }
     int timed = 0, launched = 0;
     bool stop = false;
+    const int bi_grid = (int)(((n >> 1) + 256 * kBiV - 1) / (256 * kBiV)) > 0 ? (int)(((n >> 1) + 256 * kBiV - 1) / (256 * kBiV)) : 1;
     while (!stop && launched < maxit) {
         const int chunk = (maxit - launched) < check_every ? (maxit - launched) : check_every;
         for (int it = 0; it < chunk; ++it, ++launched) {
@@ -1096,31 +1097,31 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
                                        c->sc.p, parity, tol2, c->ctl.p);
                 }
             } else if (!dist) {
-                hipLaunchKernelGGL(k_bicg_p, dim3(c->vec_grid), dim3(256), 0, st, n, c->r.p, c->y.p, c->p.p, c->part_b.p,
-                                   c->vec_grid, c->sc.p, launched == 0 ? 1 : 0, c->ctl.p);
+                hipLaunchKernelGGL(k_bicg_p, dim3(bi_grid), dim3(256), 0, st, n, c->r.p, c->y.p, c->p.p, c->part_b.p,
+                                   bi_grid, c->sc.p, launched == 0 ? 1 : 0, c->ctl.p);
                 const bool tm = launched < n_timed;
                 launch_spmv(c, c->sval.p, c->p.p, c->y.p, c->r0.p, c->part_a.p, c->ctl.p,   // v = At p, r0.v
                             tm ? c->ev_spmv[2 * launched] : nullptr, tm ? c->ev_spmv[2 * launched + 1] : nullptr);
                 if (tm) ++timed;
-                hipLaunchKernelGGL(k_bicg_s, dim3(c->vec_grid), dim3(256), 0, st, n, c->r.p, c->y.p, c->s.p, c->part_a.p,
+                hipLaunchKernelGGL(k_bicg_s, dim3(bi_grid), dim3(256), 0, st, n, c->r.p, c->y.p, c->s.p, c->part_a.p,
                                    c->spmv_grid, c->sc.p, c->ctl.p);
                 launch_spmv(c, c->sval.p, c->s.p, c->t.p, c->s.p, c->part_a.p, c->ctl.p);    // t = At s, t.s, t.t
-                hipLaunchKernelGGL(k_bicg_xr, dim3(c->vec_grid), dim3(256), 0, st, n, c->p.p, c->s.p, c->t.p, c->r0.p, c->x.p,
+                hipLaunchKernelGGL(k_bicg_xr, dim3(bi_grid), dim3(256), 0, st, n, c->p.p, c->s.p, c->t.p, c->r0.p, c->x.p,
                                    c->r.p, c->part_a.p, c->spmv_grid, c->part_b.p, c->sc.p, c->ctl.p, (const uint8_t*)nullptr);
-                hipLaunchKernelGGL(k_bicg_fin, dim3(1), dim3(256), 0, st, c->part_a.p, c->spmv_grid, c->part_b.p, c->vec_grid,
+                hipLaunchKernelGGL(k_bicg_fin, dim3(1), dim3(256), 0, st, c->part_a.p, c->spmv_grid, c->part_b.p, bi_grid,
                                    c->sc.p, tol2, c->ctl.p);
             } else {
                 // element-partitioned BiCGStab: every operator application is followed by the interface sum, which also carries
                 // the dot fused into the SpMV (w.(A x) needs no weighting); dots of assembled vectors (t.t, r0.r, r.r) count
                 // owned rows and cross in two small all-reduces.  sbuf: [0..1] = (r0.r, r.r), [4..5] = (t.s, t.t).
-                hipLaunchKernelGGL(k_bicg_p, dim3(c->vec_grid), dim3(256), 0, st, n, c->r.p, c->y.p, c->p.p, c->sbuf.p, 1, c->sc.p,
+                hipLaunchKernelGGL(k_bicg_p, dim3(bi_grid), dim3(256), 0, st, n, c->r.p, c->y.p, c->p.p, c->sbuf.p, 1, c->sc.p,
                                    launched == 0 ? 1 : 0, c->ctl.p);
                 const bool tm = launched < n_timed;
                 launch_spmv(c, c->sval.p, c->p.p, c->y.p, c->r0.p, c->part_a.p, c->ctl.p,
                             tm ? c->ev_spmv[2 * launched] : nullptr, tm ? c->ev_spmv[2 * launched + 1] : nullptr);
                 if (tm) ++timed;
                 if (int rc = halo_sum(c, c->y.p, c->part_a.p, c->spmv_grid)) return rc;
-                hipLaunchKernelGGL(k_bicg_s, dim3(c->vec_grid), dim3(256), 0, st, n, c->r.p, c->y.p, c->s.p, c->hbuf.p + c->n_if, 1,
+                hipLaunchKernelGGL(k_bicg_s, dim3(bi_grid), dim3(256), 0, st, n, c->r.p, c->y.p, c->s.p, c->hbuf.p + c->n_if, 1,
                                    c->sc.p, c->ctl.p);
                 launch_spmv(c, c->sval.p, c->s.p, c->t.p, c->s.p, c->part_a.p, c->ctl.p);
                 if (int rc = halo_sum(c, c->t.p, c->part_a.p, c->spmv_grid)) return rc;
@@ -1128,9 +1129,9 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
                 hipLaunchKernelGGL(k_bicg_tt_fin, dim3(1), dim3(256), 0, st, c->part_b.p, c->vec_grid, c->hbuf.p + c->n_if,
                                    c->sbuf.p + 4);
                 if (int rc = allreduce_sum(c, c->sbuf.p + 5, 1)) return rc;
-                hipLaunchKernelGGL(k_bicg_xr, dim3(c->vec_grid), dim3(256), 0, st, n, c->p.p, c->s.p, c->t.p, c->r0.p, c->x.p,
+                hipLaunchKernelGGL(k_bicg_xr, dim3(bi_grid), dim3(256), 0, st, n, c->p.p, c->s.p, c->t.p, c->r0.p, c->x.p,
                                    c->r.p, c->sbuf.p + 4, 1, c->part_b.p, c->sc.p, c->ctl.p, owned);
-                hipLaunchKernelGGL(k_reduce_partials2, dim3(1), dim3(256), 0, st, c->part_b.p, c->vec_grid, c->sbuf.p);
+                hipLaunchKernelGGL(k_reduce_partials2, dim3(1), dim3(256), 0, st, c->part_b.p, bi_grid, c->sbuf.p);
                 if (int rc = allreduce_sum(c, c->sbuf.p, 2)) return rc;
                 hipLaunchKernelGGL(k_bicg_fin, dim3(1), dim3(256), 0, st, c->sbuf.p + 4, 1, c->sbuf.p, 1, c->sc.p, tol2, c->ctl.p);
             }

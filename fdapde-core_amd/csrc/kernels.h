@@ -1629,18 +1629,40 @@ __global__ __launch_bounds__(256) void k_cgf_fin(const double* part_rr, int np, 
 //   k_spmv     : t = At s, partials of t.s (w = s) and t.t
 //   k_bicg_xr  : omega = t.s / t.t ; x += alpha p + omega s ; r = s - omega t ; partials r0.r and r.r
 // ---------------------------------------------------------------------------------------------------------------
+// The three vector kernels are single-shot like the CG ones: workgroup b owns kBiV * 256 consecutive double2 elements, every
+// lane issues all of its 16-byte loads first and only then re-reduces the producer's partials (grid = bicg_grid(n)).
+constexpr int kBiV = 4;
 __global__ __launch_bounds__(256) void k_bicg_p(int64_t n, const double* r, const double* v, double* p,
                                                  const double* part_in /* (r0.r, r.r) pairs */, int np_in, double* sc,
                                                  int first, int32_t* ctl) {
     __shared__ double red[8];
     if (__syncthreads_or(ctl[0] != 0)) return;   // uniform even if another workgroup raises the flag meanwhile
+    const int64_t n2 = n >> 1, i0 = (int64_t)blockIdx.x * (256 * kBiV) + threadIdx.x;
+    const double2* r2 = reinterpret_cast<const double2*>(r);
+    const double2* v2 = reinterpret_cast<const double2*>(v);
+    double2* p2 = reinterpret_cast<double2*>(p);
+    double2 rv[kBiV], vv[kBiV], pv[kBiV];
+#pragma unroll
+    for (int k = 0; k < kBiV; ++k) {
+        const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
+        rv[k] = r2[ic];
+        if (!first) vv[k] = v2[ic], pv[k] = p2[ic];
+    }
     double a = 0;
     for (int i = threadIdx.x; i < np_in; i += blockDim.x) a += part_in[2 * i];
     const double rho_new = first ? sc[9] : block_sum(a, red);
     const double rho = sc[4], alpha = sc[5], omega = sc[6];
     const double beta = first ? 0.0 : (rho_new / rho) * (alpha / omega);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        p[i] = first ? r[i] : r[i] + beta * (p[i] - omega * v[i]);
+#pragma unroll
+    for (int k = 0; k < kBiV; ++k) {
+        const int64_t i = i0 + k * 256;
+        if (i < n2) {
+            double2 o = rv[k];
+            if (!first) o.x += beta * (pv[k].x - omega * vv[k].x), o.y += beta * (pv[k].y - omega * vv[k].y);
+            p2[i] = o;
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = first ? r[n - 1] : r[n - 1] + beta * (p[n - 1] - omega * v[n - 1]);
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
         sc[7] = rho_new;
         if (rho_new == 0.0) ctl[2] = 1;
@@ -1651,12 +1673,26 @@ __global__ __launch_bounds__(256) void k_bicg_s(int64_t n, const double* r, cons
                                                  int32_t* ctl) {
     __shared__ double red[8];
     if (__syncthreads_or(ctl[0] != 0)) return;   // uniform even if another workgroup raises the flag meanwhile
+    const int64_t n2 = n >> 1, i0 = (int64_t)blockIdx.x * (256 * kBiV) + threadIdx.x;
+    const double2* r2 = reinterpret_cast<const double2*>(r);
+    const double2* v2 = reinterpret_cast<const double2*>(v);
+    double2* s2 = reinterpret_cast<double2*>(s);
+    double2 rv[kBiV], vv[kBiV];
+#pragma unroll
+    for (int k = 0; k < kBiV; ++k) {
+        const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
+        rv[k] = r2[ic], vv[k] = v2[ic];
+    }
     double a = 0;
     for (int i = threadIdx.x; i < np_in; i += blockDim.x) a += part_in[2 * i];
     const double r0v = block_sum(a, red);
     const double alpha = r0v != 0.0 ? sc[7] / r0v : 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        s[i] = r[i] - alpha * v[i];
+#pragma unroll
+    for (int k = 0; k < kBiV; ++k) {
+        const int64_t i = i0 + k * 256;
+        if (i < n2) s2[i] = make_double2(rv[k].x - alpha * vv[k].x, rv[k].y - alpha * vv[k].y);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) s[n - 1] = r[n - 1] - alpha * v[n - 1];
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
         sc[8] = alpha;
         if (r0v == 0.0) ctl[2] = 1;
@@ -1668,6 +1704,19 @@ __global__ __launch_bounds__(256) void k_bicg_xr(int64_t n, const double* p, con
                                                   const double* sc, int32_t* ctl, const uint8_t* owned) {
     __shared__ double red[8];
     if (__syncthreads_or(ctl[0] != 0)) return;   // uniform even if another workgroup raises the flag meanwhile
+    const int64_t n2 = n >> 1, i0 = (int64_t)blockIdx.x * (256 * kBiV) + threadIdx.x;
+    const double2* p2 = reinterpret_cast<const double2*>(p);
+    const double2* s2 = reinterpret_cast<const double2*>(s);
+    const double2* t2 = reinterpret_cast<const double2*>(t);
+    const double2* q2 = reinterpret_cast<const double2*>(r0);
+    double2* x2 = reinterpret_cast<double2*>(x);
+    double2* r2 = reinterpret_cast<double2*>(r);
+    double2 pv[kBiV], sv[kBiV], tv[kBiV], qv[kBiV], xv[kBiV];
+#pragma unroll
+    for (int k = 0; k < kBiV; ++k) {
+        const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
+        pv[k] = p2[ic], sv[k] = s2[ic], tv[k] = t2[ic], qv[k] = q2[ic], xv[k] = x2[ic];
+    }
     double a = 0, b = 0;
     for (int i = threadIdx.x; i < np_in; i += blockDim.x) a += part_in[2 * i], b += part_in[2 * i + 1];
     const double ts = block_sum(a, red);
@@ -1675,7 +1724,20 @@ __global__ __launch_bounds__(256) void k_bicg_xr(int64_t n, const double* p, con
     const double omega = tt > 0.0 ? ts / tt : 0.0;
     const double alpha = sc[8];
     double d0 = 0, d1 = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int k = 0; k < kBiV; ++k) {
+        const int64_t i = i0 + k * 256;
+        if (i < n2) {
+            x2[i] = make_double2(xv[k].x + alpha * pv[k].x + omega * sv[k].x, xv[k].y + alpha * pv[k].y + omega * sv[k].y);
+            const double2 ri = make_double2(sv[k].x - omega * tv[k].x, sv[k].y - omega * tv[k].y);
+            r2[i] = ri;
+            const bool o0 = !owned || owned[2 * i], o1 = !owned || owned[2 * i + 1];
+            d0 += (o0 ? qv[k].x * ri.x : 0.0) + (o1 ? qv[k].y * ri.y : 0.0);
+            d1 += (o0 ? ri.x * ri.x : 0.0) + (o1 ? ri.y * ri.y : 0.0);
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
         x[i] += alpha * p[i] + omega * s[i];
         const double ri = s[i] - omega * t[i];
         r[i] = ri;

@@ -126,6 +126,7 @@ struct fdapde_ctx {
       tmp_i, tmp_v;
     DBuf<uint8_t> bnd;
     DBuf<DevTables> tables;
+    DBuf<DevRefTensors> reftab;
     DBuf<int32_t> ctl;
     DBuf<double> coef[kMaxTerms];
     int32_t* h_ctl = nullptr;   // pinned: ctl[3]
@@ -220,6 +221,25 @@ int upload_space(fdapde_ctx* c) {
             dt.mtab[i * c->tb.nb + j] = m;
         }
     HIPCHK(c, c->tables.upload(&dt, 1, st));
+    {   // reference tensors of the constant-coefficient form (element_row OPK 3), same quadrature nodes and weights
+        static DevRefTensors rt;   // ~10 KB: keep it off the stack
+        std::memset(&rt, 0, sizeof rt);
+        const int nb = c->tb.nb, nq = c->tb.nq, nn = nb * nb;
+        for (int k = 0; k < 3; ++k)
+            for (int i = 0; i < nb; ++i)
+                for (int j = 0; j < nb; ++j) {
+                    for (int l = 0; l < 3; ++l) {
+                        double v = 0;
+                        for (int q = 0; q < nq; ++q) v += c->tb.qw[q] * (c->tb.dpsi[(i * nq + q) * 3 + k] * c->tb.dpsi[(j * nq + q) * 3 + l]);
+                        rt.ktab[(k * 3 + l) * nn + i * nb + j] = v;
+                    }
+                    double v = 0;
+                    for (int q = 0; q < nq; ++q) v += c->tb.qw[q] * (c->tb.psi[i * nq + q] * c->tb.dpsi[(j * nq + q) * 3 + k]);
+                    rt.ctab[k * nn + i * nb + j] = v;
+                }
+        HIPCHK(c, c->reftab.upload(&rt, 1, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
     const size_t n = (size_t)hs.n_dofs, nnz = (size_t)hs.nnz;
     HIPCHK(c, c->vals[0].alloc(nnz + 2));   // + 2: pair loads of the SpMV may touch one entry past a row's end
     HIPCHK(c, c->vals[1].alloc(nnz + 2));
@@ -283,7 +303,7 @@ AsmArgs asm_args(fdapde_ctx* c) {
     a.n_dofs = c->hs.n_dofs, a.n_cells = c->hs.n_cells;
     a.cverts = c->cverts.p, a.cdofs = c->cdofs.p, a.vcoords = c->vcoords.p;
     a.sl_off = c->sl_off.p, a.adj = c->adj.p, a.slotw = c->slotw.p;
-    a.rowptr = c->rowptr.p, a.colidx = c->colidx.p, a.tables = c->tables.p;
+    a.rowptr = c->rowptr.p, a.colidx = c->colidx.p, a.tables = c->tables.p, a.reftab = c->reftab.p;
     a.bc_off = c->bc_off.p, a.bc_cell = c->bc_cell.p, a.bc_vert = c->bc_vert.p, a.bn_off = c->bn_off.p, a.bn_node = c->bn_node.p;
     a.lds_nodes = c->hs.max_blk_nodes;
     return a;
@@ -307,6 +327,25 @@ int make_dev_op(fdapde_ctx* c, const std::vector<HostTerm>& terms, DevOp* out, i
             d.data = buf.p;
         }
     }
+    // constant-coefficient summary (element_row OPK 3)
+    const int N = c->hs.N;
+    bool adv = false;
+    for (size_t k = 0; k < terms.size(); ++k) {
+        const fdapde_term& t = terms[k].t;
+        if (t.kind == FDAPDE_LAPLACIAN)
+            for (int r = 0; r < N; ++r) op.kt[r * N + r] += t.coef;
+        else if (t.kind == FDAPDE_DIFFUSION)
+            for (int e = 0; e < N * N; ++e) op.kt[e] += t.coef * t.cst[e];
+        else if (t.kind == FDAPDE_ADVECTION) {
+            adv = true;
+            for (int e = 0; e < N; ++e) op.bt[e] += t.coef * t.cst[e];
+        } else if (t.kind == FDAPDE_REACTION)
+            op.ct += t.coef * t.cst[0];
+    }
+    bool ksym = true;
+    for (int r = 0; r < N; ++r)
+        for (int q = 0; q < r; ++q) ksym = ksym && op.kt[r * N + q] == op.kt[q * N + r];
+    op.tab_sym = (ksym && !adv) ? 1 : 0;
     *out = op;
     return FDAPDE_OK;
 }
@@ -350,7 +389,15 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
     const HostSpace& hs = c->hs;
     constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
     if (assembly == FDAPDE_ASSEMBLY_ROWS) {
-        const size_t tab = sizeof(DevTables) + (size_t)hs.max_blk_nodes * (M == 2 ? 2 : 4) * sizeof(double);
+        // specialised integrands (see element_row): the two operators FEMSolverBase::init always assembles, and any other
+        // constant-coefficient expression through the reference tensors
+        int opk = 0;
+        if (!op.needs_rows) opk = 3;
+        if (op.n == 1 && op.t[0].kind == FDAPDE_LAPLACIAN) opk = 1;
+        if (op.n == 1 && op.t[0].kind == FDAPDE_REACTION && !op.t[0].space_varying) opk = 2;
+        if (std::getenv("FDAPDE_ASM_GENERIC")) opk = 0;
+        const size_t tab = sizeof(DevTables) + (opk == 3 ? sizeof(DevRefTensors) : 0) +
+                           (size_t)hs.max_blk_nodes * (M == 2 ? 2 : 4) * sizeof(double);
         size_t acc = (size_t)hs.max_blk_nnz * sizeof(double);
         if (tab + acc > (size_t)c->lds_limit) acc = tab < (size_t)c->lds_limit ? (size_t)c->lds_limit - tab : 0;
         a.lds_acc_cap = (int32_t)(acc / sizeof(double));
@@ -359,14 +406,12 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
         if (lds > 64 * 1024)
             for (const void* fn : {reinterpret_cast<const void*>(&k_assemble_rows<M, R, 0>),
                                    reinterpret_cast<const void*>(&k_assemble_rows<M, R, 1>),
-                                   reinterpret_cast<const void*>(&k_assemble_rows<M, R, 2>)})
+                                   reinterpret_cast<const void*>(&k_assemble_rows<M, R, 2>),
+                                   reinterpret_cast<const void*>(&k_assemble_rows<M, R, 3>)})
                 (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        // specialised integrands for the two operators FEMSolverBase::init always assembles (see element_row)
-        int opk = 0;
-        if (op.n == 1 && op.t[0].kind == FDAPDE_LAPLACIAN) opk = 1;
-        if (op.n == 1 && op.t[0].kind == FDAPDE_REACTION && !op.t[0].space_varying) opk = 2;
-        if (std::getenv("FDAPDE_ASM_GENERIC")) opk = 0;
-        if (opk == 1)
+        if (opk == 3)
+            hipLaunchKernelGGL((k_assemble_rows<M, R, 3>), dim3(grid), dim3(kAsmBlock), lds, c->stream, a, op);
+        else if (opk == 1)
             hipLaunchKernelGGL((k_assemble_rows<M, R, 1>), dim3(grid), dim3(kAsmBlock), lds, c->stream, a, op);
         else if (opk == 2)
             hipLaunchKernelGGL((k_assemble_rows<M, R, 2>), dim3(grid), dim3(kAsmBlock), lds, c->stream, a, op);
@@ -644,7 +689,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
                                 &c->tmp_e, &c->tmp_i, &c->tmp_v})
             b->release();
         for (auto& b : c->coef) b.release();
-        c->slotw.release(), c->sl_off.release(), c->bnd.release(), c->tables.release();
+        c->slotw.release(), c->sl_off.release(), c->bnd.release(), c->tables.release(), c->reftab.release();
         c->bc_off.release(), c->bn_off.release(), c->bc_cell.release(), c->bn_node.release(), c->bc_vert.release();
         c->halo_dof.release(), c->halo_pos.release(), c->owned.release(), c->hbuf.release(), c->sbuf.release();
         c->halo_inv.release(), c->if_slot.release();

@@ -36,6 +36,10 @@ struct DevOp {
     int32_t needs_psi;    // any advection / reaction leaf
     int32_t needs_rows;   // any space-varying leaf (needs the global cell id for its data row)
     DevTerm t[kMaxTerms];
+    // constant-coefficient operators (OPK 3): the leaves summed once on the host
+    //   form = -(g_i . Kt g_j) + psi_i (g_j . bt) + ct psi_i psi_j,  Kt = sum coef K (Laplacian: coef I), bt = sum coef b, ct = sum coef c
+    double kt[9], bt[3], ct;
+    int32_t tab_sym;      // Kt symmetric and no advection: evaluate in the bitwise-symmetric order
 };
 
 // quadrature + basis tables as they sit in device memory (copied to LDS by every workgroup that integrates)
@@ -49,6 +53,13 @@ struct DevTables {
     double pad_;
 };
 constexpr int kTablesDoubles = sizeof(DevTables) / sizeof(double);
+// reference tensors of the constant-coefficient form (OPK 3), staged in LDS behind DevTables by that instantiation only:
+//   ktab[(k*3 + l)*NB*NB + i*NB + j] = sum_q w_q d_k psi_i(p_q) d_l psi_j(p_q)      ctab[l*NB*NB + i*NB + j] = sum_q w_q psi_i d_l psi_j
+struct DevRefTensors {
+    double ktab[9 * kMaxBasis * kMaxBasis];
+    double ctab[3 * kMaxBasis * kMaxBasis];
+};
+constexpr int kRefDoubles = sizeof(DevRefTensors) / sizeof(double);
 
 struct AsmArgs {
     int64_t n_dofs, n_cells;
@@ -61,6 +72,7 @@ struct AsmArgs {
     const int32_t* rowptr;
     const int32_t* colidx;
     const DevTables* tables;
+    const DevRefTensors* reftab;   // OPK 3 only
     double* vals;              // CSR values (internal slots) or nullptr
     const double* fq;          // forcing at quadrature nodes, internal cell order, or nullptr
     double* force;             // forcing vector (internal DOF order) or nullptr
@@ -188,9 +200,15 @@ __device__ __forceinline__ double weak_form(const DevOp& op, int64_t qrow, doubl
 //      and come straight from J^{-1} (grad lambda_0 = -sum_k row_k, grad lambda_k = row_k), no table reads
 //   2  a single constant reaction leaf (mass matrix): value = c * measure * sum_q w_q psi_i psi_j, the reference integrals
 //      sum_q w_q psi_i psi_j do not depend on the cell and are tabulated (DevTables::mtab)
+//   3  any sum of CONSTANT-coefficient leaves: on an affine cell the element matrix is a contraction of cell constants with
+//      reference tensors that do not depend on the cell (DevRefTensors), summed over the same quadrature nodes as the reference:
+//        A_ij = |e| ( -sum_kl Gp[k][l] ktab[k][l][i][j] + sum_l beta[l] ctab[l][i][j] + ct mtab[i][j] ),
+//        Gp = J^-1 Kt J^-T,  beta = J^-1 bt.     13 multiply-adds per entry in 3-D instead of a loop over the quadrature nodes
+//      (C5, 3-D P2 advection-diffusion-reaction: 98 ms -> see DESIGN.md).  Symmetric operators are evaluated in an order that
+//      gives bitwise A_ij == A_ji.
 template <int M, int R, int OPK, typename Emit>
 __device__ __forceinline__ double element_row(const AsmArgs& a, const DevOp& op, const DevTables* tb, const Geo<M>& g, int cell,
-                                              int il, bool want_matrix, Emit&& emit) {
+                                              int il, bool want_matrix, Emit&& emit, const DevRefTensors* rt = nullptr) {
     constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
     constexpr int NQ = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 5);
     const int64_t qrow0 = (int64_t)NQ * cell;
@@ -205,6 +223,64 @@ __device__ __forceinline__ double element_row(const AsmArgs& a, const DevOp& op,
         const double cm = op.t[0].coef * op.t[0].cst[0] * g.measure;
 #pragma unroll
         for (int j = 0; j < NB; ++j) emit(j, cm * tb->mtab[il * NB + j]);
+        return fsum;
+    } else if constexpr (OPK == 3) {
+        constexpr int NN = NB * NB;
+        double Gp[M][M], beta[M];
+        const bool sym = op.tab_sym != 0;
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+            double kr[M];   // row k of J^-1 Kt
+#pragma unroll
+            for (int c = 0; c < M; ++c) {
+                double v = 0;
+#pragma unroll
+                for (int r = 0; r < M; ++r) v += g.invJ[k][r] * op.kt[r * M + c];
+                kr[c] = v;
+            }
+#pragma unroll
+            for (int l = 0; l < M; ++l) {
+                double v = 0;
+#pragma unroll
+                for (int c = 0; c < M; ++c) v += kr[c] * g.invJ[l][c];
+                Gp[k][l] = v;
+            }
+            double bv = 0;
+#pragma unroll
+            for (int r = 0; r < M; ++r) bv += g.invJ[k][r] * op.bt[r];
+            beta[k] = bv;
+        }
+        if (sym) {
+#pragma unroll
+            for (int k = 0; k < M; ++k)
+#pragma unroll
+                for (int l = 0; l < k; ++l) Gp[k][l] = Gp[l][k];
+        }
+        const double* kt = rt->ktab + il * NB;
+        const double* ct = rt->ctab + il * NB;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            double d = 0;
+            if (sym) {
+#pragma unroll
+                for (int k = 0; k < M; ++k) d += Gp[k][k] * kt[(k * 3 + k) * NN + j];
+#pragma unroll
+                for (int k = 0; k < M; ++k)
+#pragma unroll
+                    for (int l = k + 1; l < M; ++l) d += Gp[k][l] * (kt[(k * 3 + l) * NN + j] + kt[(l * 3 + k) * NN + j]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < M; ++k)
+#pragma unroll
+                    for (int l = 0; l < M; ++l) d += Gp[k][l] * kt[(k * 3 + l) * NN + j];
+            }
+            double adv = 0;
+            if (!sym) {
+#pragma unroll
+                for (int l = 0; l < M; ++l) adv += beta[l] * ct[l * NN + j];
+            }
+            emit(j, g.measure * ((adv - d) + op.ct * tb->mtab[il * NB + j]));
+        }
         return fsum;
     } else if constexpr (OPK == 1 && R == 1) {
         double G[M + 1][M];   // physical gradients of the M+1 barycentric coordinates
@@ -285,7 +361,14 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
     constexpr int NP = M == 2 ? 2 : 4;   // doubles per staged vertex (xyz padded to 32 B)
     extern __shared__ double lds[];
     const DevTables* tb = stage_tables(a.tables, lds);
+    const DevRefTensors* rt = nullptr;
     double* xyz = lds + kTablesDoubles;                       // the block's vertex coordinates
+    if constexpr (OPK == 3) {   // reference tensors of the constant-coefficient form behind the basis tables
+        const double* src = reinterpret_cast<const double*>(a.reftab);
+        for (int i = threadIdx.x; i < kRefDoubles; i += blockDim.x) xyz[i] = src[i];
+        rt = reinterpret_cast<const DevRefTensors*>(xyz);
+        xyz += kRefDoubles;
+    }
     double* acc = xyz + (int64_t)a.lds_nodes * NP;            // the block's CSR value range
 
     const int64_t row0 = (int64_t)blockIdx.x * kAsmBlock;
@@ -343,7 +426,7 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
                     acc[my0 - base + (int32_t)slot] += value;
                 else
                     a.vals[my0 + (int32_t)slot] += value;
-            });
+            }, rt);
         }
     }
     if (a.force != nullptr && row < a.n_dofs) a.force[row] = fsum;

@@ -441,3 +441,38 @@ def test_lumped_mass_matches_oracle(capi, ctx, oracle, mesh_loader):
         got = ctx.lump(capi.MAT_MASS)
         assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
         assert abs(got.sum() - ref.sum()) <= 1e-12 * abs(ref.sum())
+
+
+def test_partial_dirichlet_boundary_and_solver_prepare(capi, ctx, oracle, mesh_loader):
+    """fdapde_dofs_set_boundary: Dirichlet data on part of the boundary (natural condition elsewhere) against the oracle with the
+    same mask; fdapde_solver_prepare builds the compact solver layout for the new mask ahead of the solve and is idempotent"""
+    m = mesh_loader("unit_square_32")
+    ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = ctx.dofs_build(1)
+    _, bnd, coords = ctx.dofs_get()
+    mask = (bnd.astype(bool) & (coords[:, 0] < 0.5)).astype(np.uint8)
+    ctx.dofs_set_boundary(mask)
+    ctx.solver_prepare(True)
+    ctx.solver_prepare(True)
+    qn = ctx.quadrature_nodes()
+    fq = 1.0 + qn[:, 0] * qn[:, 1]
+    g = np.sin(3.0 * coords[:, 1])
+    op = lambda mod: -mod.laplacian() + mod.reaction(0.3)
+    ctx.set_operator(op(capi))
+    ctx.set_forcing(fq)
+    ctx.set_dirichlet(g)
+    ctx.init()
+    info = ctx.solve(rtol=1e-12)
+    assert info.converged == 1
+    # oracle: same operator / forcing, Dirichlet rows only where the mask says so
+    dofs, _, ond, _ = oracle.enumerate_dofs(m, 1)
+    A = oracle.assemble_operator(m, 1, dofs, ond, op(oracle)).to_scipy().tolil()
+    b = oracle.assemble_forcing(m, 1, dofs, ond, fq)
+    for i in np.nonzero(mask)[0]:
+        A.rows[i], A.data[i] = [int(i)], [1.0]
+        b[i] = g[i]
+    import scipy.sparse.linalg as spla
+
+    ref = spla.spsolve(A.tocsc(), b)
+    assert np.linalg.norm(ctx.solution() - ref) / np.linalg.norm(ref) <= SOL_TOL
+    ctx.dofs_set_boundary(bnd)   # module-scoped context: restore the reference's mask

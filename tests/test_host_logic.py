@@ -109,3 +109,20 @@ def test_minimal_meshes(capi, oracle, order):
         rp, ci = ctx.pattern_get()
         assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colidx)
         ctx.close()
+
+
+def test_boundary_mask_override(capi, oracle):
+    """fdapde_dofs_set_boundary replaces basis_.boundary_dofs() (used by element-partitioned ranks and for Dirichlet data on
+    part of the boundary); host-only contexts accept it too"""
+    m = oracle.load_mesh(os.path.join(os.path.dirname(__file__), "golden", "mesh", "unit_square_16"))
+    ctx = capi.Context(device=None)
+    ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = ctx.dofs_build(2)
+    _, bnd, coords = ctx.dofs_get()
+    new = (bnd.astype(bool) & (coords[:, 0] < 0.5)).astype(np.uint8)      # Dirichlet on the left half of the boundary only
+    ctx.dofs_set_boundary(new)
+    _, got, _ = ctx.dofs_get()
+    assert np.array_equal(got, new) and got.sum() < bnd.sum()
+    with pytest.raises(AssertionError):
+        ctx.dofs_set_boundary(new[:-1])
+    ctx.close()

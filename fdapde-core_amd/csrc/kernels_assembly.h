@@ -1,0 +1,584 @@
+// kernels_assembly.h -- operator / forcing assembly (row-owner default, scatter cross-checks) and basis evaluation; see kernels.h
+#ifndef FDAPDE_KERNELS_ASSEMBLY_H
+#define FDAPDE_KERNELS_ASSEMBLY_H
+
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "internal.h"
+
+namespace fdapde_hip {
+
+// ---------------------------------------------------------------------------------------------------------------
+// device-side operator description (kernel argument, lives in SGPRs / scalar cache)
+// ---------------------------------------------------------------------------------------------------------------
+struct DevTerm {
+    int32_t kind, space_varying;
+    double coef;
+    double cst[9];
+    const double* data;   // device pointer, rows in INTERNAL cell order: (nq*cell_i + q) x (N*N | N | 1)
+};
+struct DevOp {
+    int32_t n;
+    int32_t needs_psi;    // any advection / reaction leaf
+    int32_t needs_rows;   // any space-varying leaf (needs the global cell id for its data row)
+    DevTerm t[kMaxTerms];
+    // constant-coefficient operators (OPK 3): the leaves summed once on the host
+    //   form = -(g_i . Kt g_j) + psi_i (g_j . bt) + ct psi_i psi_j,  Kt = sum coef K (Laplacian: coef I), bt = sum coef b, ct = sum coef c
+    double kt[9], bt[3], ct;
+    int32_t tab_sym;      // Kt symmetric and no advection: evaluate in the bitwise-symmetric order
+};
+
+// quadrature + basis tables as they sit in device memory (copied to LDS by every workgroup that integrates)
+struct DevTables {
+    double qw[kMaxQuad];
+    double psi[kMaxBasis * kMaxQuad];        // [i*nq + q]
+    double dpsi[kMaxBasis * kMaxQuad * 3];   // [(i*nq + q)*3 + k]
+    double qn[kMaxQuad * 3];                 // [q*M + k]
+    double mtab[kMaxBasis * kMaxBasis];      // sum_q w_q psi_i(p_q) psi_j(p_q), [i*nb + j]: reference mass integrals
+    double wsum;                             // sum_q w_q (0.999999999999999 for the 3-point rule: part of the contract)
+    double pad_;
+};
+constexpr int kTablesDoubles = sizeof(DevTables) / sizeof(double);
+// reference tensors of the constant-coefficient form (OPK 3), staged in LDS behind DevTables by that instantiation only:
+//   ktab[(k*3 + l)*NB*NB + i*NB + j] = sum_q w_q d_k psi_i(p_q) d_l psi_j(p_q)      ctab[l*NB*NB + i*NB + j] = sum_q w_q psi_i d_l psi_j
+struct DevRefTensors {
+    double ktab[9 * kMaxBasis * kMaxBasis];
+    double ctab[3 * kMaxBasis * kMaxBasis];
+};
+constexpr int kRefDoubles = sizeof(DevRefTensors) / sizeof(double);
+
+struct AsmArgs {
+    int64_t n_dofs, n_cells;
+    const int32_t* cverts;     // n_cells x (M+1), internal node ids
+    const int32_t* cdofs;      // n_cells x nb, internal DOF ids
+    const double* vcoords;     // internal node id -> NP doubles
+    const int64_t* sl_off;     // adjacency slices
+    const int32_t* adj;
+    const uint32_t* slotw;
+    const int32_t* rowptr;
+    const int32_t* colidx;
+    const DevTables* tables;
+    const DevRefTensors* reftab;   // OPK 3 only
+    double* vals;              // CSR values (internal slots) or nullptr
+    const double* fq;          // forcing at quadrature nodes, internal cell order, or nullptr
+    double* force;             // forcing vector (internal DOF order) or nullptr
+    int32_t lds_acc_cap;       // doubles available for the row accumulators
+    // block-local tables of the row-owner kernel (host_setup.cpp): cells visited by the block's rows, their vertex nodes
+    const int64_t* bc_off;
+    const int32_t* bc_cell;
+    const uint16_t* bc_vert;   // 4 per block-cell
+    const int64_t* bn_off;
+    const int32_t* bn_node;
+    int32_t lds_nodes;         // coordinate slots reserved in LDS (max nodes of any block)
+};
+
+template <int M> struct Geo {
+    double invJ[M][M];   // J^{-1}
+    double measure;      // |det J| / M!
+};
+
+// Simplex::initialize (fdaPDE/geometry/simplex.h:184-195): J col j = x_{j+1} - x_0, invJ, measure = |det J| / M!
+// p0..p3: vertex coordinates (global memory or the workgroup's LDS copy)
+template <int M>
+__device__ __forceinline__ void geo_from_vertices(const double* p0, const double* p1, const double* p2, const double* p3, Geo<M>& g) {
+    if constexpr (M == 2) {
+        const double j00 = p1[0] - p0[0], j01 = p2[0] - p0[0], j10 = p1[1] - p0[1], j11 = p2[1] - p0[1];
+        const double det = j00 * j11 - j01 * j10;
+        const double id = 1.0 / det;
+        g.invJ[0][0] = j11 * id, g.invJ[0][1] = -j01 * id;
+        g.invJ[1][0] = -j10 * id, g.invJ[1][1] = j00 * id;
+        g.measure = fabs(det) * 0.5;
+    } else {
+        const double a00 = p1[0] - p0[0], a01 = p2[0] - p0[0], a02 = p3[0] - p0[0];
+        const double a10 = p1[1] - p0[1], a11 = p2[1] - p0[1], a12 = p3[1] - p0[1];
+        const double a20 = p1[2] - p0[2], a21 = p2[2] - p0[2], a22 = p3[2] - p0[2];
+        const double c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+        const double det = a00 * c00 + a01 * c01 + a02 * c02;
+        const double id = 1.0 / det;
+        g.invJ[0][0] = c00 * id, g.invJ[1][0] = c01 * id, g.invJ[2][0] = c02 * id;
+        g.invJ[0][1] = (a02 * a21 - a01 * a22) * id;
+        g.invJ[1][1] = (a00 * a22 - a02 * a20) * id;
+        g.invJ[2][1] = (a01 * a20 - a00 * a21) * id;
+        g.invJ[0][2] = (a01 * a12 - a02 * a11) * id;
+        g.invJ[1][2] = (a02 * a10 - a00 * a12) * id;
+        g.invJ[2][2] = (a00 * a11 - a01 * a10) * id;
+        g.measure = fabs(det) * (1.0 / 6.0);
+    }
+}
+template <int M> __device__ __forceinline__ void cell_geometry(const AsmArgs& a, int cell, Geo<M>& g) {
+    if constexpr (M == 2) {
+        const int32_t* cv = a.cverts + (int64_t)cell * 3;
+        const double2 x0 = *reinterpret_cast<const double2*>(a.vcoords + (int64_t)cv[0] * 2);
+        const double2 x1 = *reinterpret_cast<const double2*>(a.vcoords + (int64_t)cv[1] * 2);
+        const double2 x2 = *reinterpret_cast<const double2*>(a.vcoords + (int64_t)cv[2] * 2);
+        geo_from_vertices<2>(&x0.x, &x1.x, &x2.x, nullptr, g);
+    } else {
+        const int4 cv = *reinterpret_cast<const int4*>(a.cverts + (int64_t)cell * 4);
+        const double4 x0 = *reinterpret_cast<const double4*>(a.vcoords + (int64_t)cv.x * 4);
+        const double4 x1 = *reinterpret_cast<const double4*>(a.vcoords + (int64_t)cv.y * 4);
+        const double4 x2 = *reinterpret_cast<const double4*>(a.vcoords + (int64_t)cv.z * 4);
+        const double4 x3 = *reinterpret_cast<const double4*>(a.vcoords + (int64_t)cv.w * 4);
+        geo_from_vertices<3>(&x0.x, &x1.x, &x2.x, &x3.x, g);
+    }
+}
+
+// physical gradient J^{-T} grad_ref: out[r] = sum_k invJ[k][r] * d[k]   (buff_invJ = invJ^T, fem_assembler.h:81)
+template <int M> __device__ __forceinline__ void phys_grad(const Geo<M>& g, const double* d, double* out) {
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+        double v = 0;
+#pragma unroll
+        for (int k = 0; k < M; ++k) v += g.invJ[k][r] * d[k];
+        out[r] = v;
+    }
+}
+
+// integrand of the weak form at one quadrature node: left-to-right sum of scaled leaves
+//   laplacian.h:43  -(g_i . g_j)      diffusion.h:54  -(g_i . K g_j)
+//   advection.h:55  psi_i (g_j . b)   reaction.h:52   c psi_i psi_j      dt.h:34-36  0
+template <int M>
+__device__ __forceinline__ double weak_form(const DevOp& op, int64_t qrow, double psi_i, double psi_j, const double* gi,
+                                            const double* gj) {
+    double total = 0;
+    for (int t = 0; t < op.n; ++t) {
+        const DevTerm& T = op.t[t];
+        double v = 0;
+        if (T.kind == FDAPDE_LAPLACIAN) {
+            double d = 0;
+#pragma unroll
+            for (int k = 0; k < M; ++k) d += gi[k] * gj[k];
+            v = -d;
+        } else if (T.kind == FDAPDE_DIFFUSION) {
+            double K[M * M];
+#pragma unroll
+            for (int k = 0; k < M * M; ++k) K[k] = T.space_varying ? T.data[qrow * (M * M) + k] : T.cst[k];
+            double d = 0;
+#pragma unroll
+            for (int r = 0; r < M; ++r) {
+                double kg = 0;
+#pragma unroll
+                for (int c = 0; c < M; ++c) kg += K[r * M + c] * gj[c];
+                d += gi[r] * kg;
+            }
+            v = -d;
+        } else if (T.kind == FDAPDE_ADVECTION) {
+            double d = 0;
+#pragma unroll
+            for (int k = 0; k < M; ++k) d += gj[k] * (T.space_varying ? T.data[qrow * M + k] : T.cst[k]);
+            v = psi_i * d;
+        } else if (T.kind == FDAPDE_REACTION) {
+            const double c = T.space_varying ? T.data[qrow] : T.cst[0];
+            v = c * psi_i * psi_j;
+        }
+        total = t == 0 ? T.coef * v : total + T.coef * v;
+    }
+    return total;
+}
+
+// One row of one element matrix: for local test function `il` of `cell`, emit(j, value) for every local trial
+// function j, value = measure * sum_q w_q * form(psi_il, psi_j)(p_q)   (integrator.h:92-106), and return the forcing
+// contribution measure * sum_q f_q psi_il(p_q) w_q (integrator.h:73-90) when fq is given.
+// `tb` points at the LDS copy of the tables.
+// OPK selects a specialised integrand (same numbers up to rounding, far fewer instructions -- the assembly kernels are
+// instruction-issue bound, not bandwidth bound):
+//   0  generic: any sum of leaves, evaluated per quadrature node as the reference does
+//   1  a single Laplacian leaf: the term loop and its branches fold away; for P1 the gradients are constant over the cell
+//      and come straight from J^{-1} (grad lambda_0 = -sum_k row_k, grad lambda_k = row_k), no table reads
+//   2  a single constant reaction leaf (mass matrix): value = c * measure * sum_q w_q psi_i psi_j, the reference integrals
+//      sum_q w_q psi_i psi_j do not depend on the cell and are tabulated (DevTables::mtab)
+//   3  any sum of CONSTANT-coefficient leaves: on an affine cell the element matrix is a contraction of cell constants with
+//      reference tensors that do not depend on the cell (DevRefTensors), summed over the same quadrature nodes as the reference:
+//        A_ij = |e| ( -sum_kl Gp[k][l] ktab[k][l][i][j] + sum_l beta[l] ctab[l][i][j] + ct mtab[i][j] ),
+//        Gp = J^-1 Kt J^-T,  beta = J^-1 bt.     13 multiply-adds per entry in 3-D instead of a loop over the quadrature nodes
+//      (C5, 3-D P2 advection-diffusion-reaction: 98 ms -> see DESIGN.md).  Symmetric operators are evaluated in an order that
+//      gives bitwise A_ij == A_ji.
+template <int M, int R, int OPK, typename Emit>
+__device__ __forceinline__ double element_row(const AsmArgs& a, const DevOp& op, const DevTables* tb, const Geo<M>& g, int cell,
+                                              int il, bool want_matrix, Emit&& emit, const DevRefTensors* rt = nullptr) {
+    constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
+    constexpr int NQ = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 5);
+    const int64_t qrow0 = (int64_t)NQ * cell;
+    double fsum = 0;
+    if (a.fq != nullptr) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) fsum += (a.fq[qrow0 + q] * tb->psi[il * NQ + q]) * tb->qw[q];
+        fsum *= g.measure;
+    }
+    if (!want_matrix) return fsum;
+    if constexpr (OPK == 2) {
+        const double cm = op.t[0].coef * op.t[0].cst[0] * g.measure;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) emit(j, cm * tb->mtab[il * NB + j]);
+        return fsum;
+    } else if constexpr (OPK == 3) {
+        constexpr int NN = NB * NB;
+        double Gp[M][M], beta[M];
+        const bool sym = op.tab_sym != 0;
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+            double kr[M];   // row k of J^-1 Kt
+#pragma unroll
+            for (int c = 0; c < M; ++c) {
+                double v = 0;
+#pragma unroll
+                for (int r = 0; r < M; ++r) v += g.invJ[k][r] * op.kt[r * M + c];
+                kr[c] = v;
+            }
+#pragma unroll
+            for (int l = 0; l < M; ++l) {
+                double v = 0;
+#pragma unroll
+                for (int c = 0; c < M; ++c) v += kr[c] * g.invJ[l][c];
+                Gp[k][l] = v;
+            }
+            double bv = 0;
+#pragma unroll
+            for (int r = 0; r < M; ++r) bv += g.invJ[k][r] * op.bt[r];
+            beta[k] = bv;
+        }
+        if (sym) {
+#pragma unroll
+            for (int k = 0; k < M; ++k)
+#pragma unroll
+                for (int l = 0; l < k; ++l) Gp[k][l] = Gp[l][k];
+        }
+        const double* kt = rt->ktab + il * NB;
+        const double* ct = rt->ctab + il * NB;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            double d = 0;
+            if (sym) {
+#pragma unroll
+                for (int k = 0; k < M; ++k) d += Gp[k][k] * kt[(k * 3 + k) * NN + j];
+#pragma unroll
+                for (int k = 0; k < M; ++k)
+#pragma unroll
+                    for (int l = k + 1; l < M; ++l) d += Gp[k][l] * (kt[(k * 3 + l) * NN + j] + kt[(l * 3 + k) * NN + j]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < M; ++k)
+#pragma unroll
+                    for (int l = 0; l < M; ++l) d += Gp[k][l] * kt[(k * 3 + l) * NN + j];
+            }
+            double adv = 0;
+            if (!sym) {
+#pragma unroll
+                for (int l = 0; l < M; ++l) adv += beta[l] * ct[l * NN + j];
+            }
+            emit(j, g.measure * ((adv - d) + op.ct * tb->mtab[il * NB + j]));
+        }
+        return fsum;
+    } else if constexpr (OPK == 1 && R == 1) {
+        double G[M + 1][M];   // physical gradients of the M+1 barycentric coordinates
+#pragma unroll
+        for (int r = 0; r < M; ++r) {
+            double s0 = 0;
+#pragma unroll
+            for (int k = 0; k < M; ++k) G[k + 1][r] = g.invJ[k][r], s0 -= g.invJ[k][r];
+            G[0][r] = s0;
+        }
+        double gi[M];
+#pragma unroll
+        for (int r = 0; r < M; ++r) {
+            double v = G[0][r];
+#pragma unroll
+            for (int k = 1; k <= M; ++k) v = il == k ? G[k][r] : v;
+            gi[r] = v;
+        }
+        const double cm = op.t[0].coef * tb->wsum * g.measure;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            double d = 0;
+#pragma unroll
+            for (int r = 0; r < M; ++r) d += gi[r] * G[j][r];
+            emit(j, cm * (-d));
+        }
+        return fsum;
+    } else {
+        // gradients of the owned test function at every quadrature node (P1: constant over the cell)
+        constexpr int NGQ = R == 1 ? 1 : NQ;
+        double gi[NGQ][M];
+#pragma unroll
+        for (int q = 0; q < NGQ; ++q) phys_grad<M>(g, &tb->dpsi[(il * NQ + q) * 3], gi[q]);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            double gj[NGQ][M];
+#pragma unroll
+            for (int q = 0; q < NGQ; ++q) phys_grad<M>(g, &tb->dpsi[(j * NQ + q) * 3], gj[q]);
+            double value = 0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if constexpr (OPK == 1) {
+                    double d = 0;
+#pragma unroll
+                    for (int r = 0; r < M; ++r) d += gi[q][r] * gj[q][r];
+                    value += (op.t[0].coef * (-d)) * tb->qw[q];
+                } else {
+                    const double pi = op.needs_psi ? tb->psi[il * NQ + q] : 0.0;
+                    const double pj = op.needs_psi ? tb->psi[j * NQ + q] : 0.0;
+                    value += weak_form<M>(op, qrow0 + q, pi, pj, gi[R == 1 ? 0 : q], gj[R == 1 ? 0 : q]) * tb->qw[q];
+                }
+            }
+            emit(j, value * g.measure);
+        }
+        return fsum;
+    }
+}
+
+__device__ __forceinline__ const DevTables* stage_tables(const DevTables* gsrc, double* lds) {
+    const double* src = reinterpret_cast<const double*>(gsrc);
+    for (int i = threadIdx.x; i < kTablesDoubles; i += blockDim.x) lds[i] = src[i];
+    return reinterpret_cast<const DevTables*>(lds);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row-owner assembly (default).  Workgroup = 256 consecutive matrix rows = 4 wavefronts = 4 adjacency slices.
+// Lane `l` of wavefront `w` owns row 256*block + 64*w + l, walks the sliced-ELL adjacency of its slice (unit-stride
+// int32 + packed-uint16 slot words across the wavefront), integrates its row of each visited element matrix and adds
+// it into LDS at (rowptr[row] - rowptr[row0]) + slot.  The workgroup then streams its contiguous value range to HBM
+// once.  No atomics, no colouring, bitwise reproducible, and for symmetric forms bitwise symmetric (both (i,j) and
+// (j,i) sum the same products over the same cells in the same order).
+// Replaces Assembler::discretize_operator + discretize_forcing (fdaPDE/finite_elements/fem_assembler.h:52-136).
+// ---------------------------------------------------------------------------------------------------------------
+template <int M, int R, int OPK>
+__global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op) {
+    constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
+    constexpr int NBW = (NB * 2 + 3) / 4;
+    constexpr int NP = M == 2 ? 2 : 4;   // doubles per staged vertex (xyz padded to 32 B)
+    extern __shared__ double lds[];
+    const DevTables* tb = stage_tables(a.tables, lds);
+    const DevRefTensors* rt = nullptr;
+    double* xyz = lds + kTablesDoubles;                       // the block's vertex coordinates
+    if constexpr (OPK == 3) {   // reference tensors of the constant-coefficient form behind the basis tables
+        const double* src = reinterpret_cast<const double*>(a.reftab);
+        for (int i = threadIdx.x; i < kRefDoubles; i += blockDim.x) xyz[i] = src[i];
+        rt = reinterpret_cast<const DevRefTensors*>(xyz);
+        xyz += kRefDoubles;
+    }
+    double* acc = xyz + (int64_t)a.lds_nodes * NP;            // the block's CSR value range
+
+    const int64_t row0 = (int64_t)blockIdx.x * kAsmBlock;
+    const int64_t row = row0 + threadIdx.x;
+    const int64_t row_end = min(a.n_dofs, row0 + kAsmBlock);
+    const bool want_matrix = a.vals != nullptr;
+    const int32_t base = a.rowptr[row0];
+    const int32_t blk_nnz = a.rowptr[row_end] - base;
+    const bool in_lds = blk_nnz <= a.lds_acc_cap;
+    const int32_t my0 = row < a.n_dofs ? a.rowptr[row] : 0;
+    const int32_t my1 = row < a.n_dofs ? a.rowptr[row + 1] : 0;
+    // stage the vertex coordinates of every cell this block visits: each node is fetched from HBM/L2 once per block
+    // instead of once per (row, visit) -- the gathers of the visit loop below then hit LDS
+    const int64_t bn0 = a.bn_off[blockIdx.x], nbn = a.bn_off[blockIdx.x + 1] - bn0;
+    for (int i = threadIdx.x; i < nbn; i += kAsmBlock) {
+        const int64_t node = a.bn_node[bn0 + i];
+        if constexpr (M == 2) {
+            *reinterpret_cast<double2*>(xyz + i * 2) = *reinterpret_cast<const double2*>(a.vcoords + node * 2);
+        } else {
+            const double4 v = *reinterpret_cast<const double4*>(a.vcoords + node * 4);
+            *reinterpret_cast<double2*>(xyz + i * 4) = make_double2(v.x, v.y);
+            *reinterpret_cast<double2*>(xyz + i * 4 + 2) = make_double2(v.z, 0.0);
+        }
+    }
+    if (want_matrix) {
+        if (in_lds) {
+            for (int k = threadIdx.x; k < blk_nnz; k += kAsmBlock) acc[k] = 0.0;
+        } else {
+            for (int k = my0; k < my1; ++k) a.vals[k] = 0.0;
+        }
+    }
+    __syncthreads();
+
+    const int64_t slice = row >> 6;
+    const int lane = threadIdx.x & 63;
+    const int64_t bc0 = a.bc_off[blockIdx.x];
+    double fsum = 0;
+    if (row0 + (threadIdx.x & ~63) < a.n_dofs) {   // wave-uniform: slice exists
+        const int64_t off = a.sl_off[slice], width = a.sl_off[slice + 1] - off;
+        for (int64_t v = 0; v < width; ++v) {
+            const int64_t at = (off + v) * kSlice + lane;
+            const int32_t code = a.adj[at];
+            if (code < 0) continue;
+            uint32_t sw[NBW];
+#pragma unroll
+            for (int w = 0; w < NBW; ++w) sw[w] = a.slotw[at * NBW + w];
+            const int64_t bc = bc0 + (code >> 4);
+            const ushort4 lv = *reinterpret_cast<const ushort4*>(a.bc_vert + bc * 4);   // block-local vertex indices
+            Geo<M> g;
+            geo_from_vertices<M>(xyz + lv.x * NP, xyz + lv.y * NP, xyz + lv.z * NP, xyz + lv.w * NP, g);
+            const int cell = (a.fq != nullptr || op.needs_rows) ? a.bc_cell[bc] : 0;   // only forcing / varying coefficients need it
+            fsum += element_row<M, R, OPK>(a, op, tb, g, cell, code & 15, want_matrix, [&](int j, double value) {
+                const uint32_t slot = (sw[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+                if (in_lds)
+                    acc[my0 - base + (int32_t)slot] += value;
+                else
+                    a.vals[my0 + (int32_t)slot] += value;
+            }, rt);
+        }
+    }
+    if (a.force != nullptr && row < a.n_dofs) a.force[row] = fsum;
+    if (want_matrix && in_lds) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < blk_nnz; k += kAsmBlock) a.vals[base + k] = acc[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Element-wise scatter variants (kept for cross-checking and for the measurements in DESIGN.md):
+//   ATOMIC = true : one lane per (cell, local row), fp64 global atomics into the CSR slot found by binary search.
+//   ATOMIC = false: the same kernel launched once per colour over colour-contiguous cell lists; cells of a colour
+//                   share no DOF, so plain read-modify-write is race-free ("colour-partitioned passes").
+// vals must be zeroed before the first launch.
+// ---------------------------------------------------------------------------------------------------------------
+template <int M, int R, bool ATOMIC>
+__global__ __launch_bounds__(256) void k_assemble_scatter(AsmArgs a, DevOp op, const int32_t* cell_list, int64_t n_list) {
+    constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
+    extern __shared__ double lds[];
+    const DevTables* tb = stage_tables(a.tables, lds);
+    __syncthreads();
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_list * NB) return;
+    const int64_t li = idx / NB;
+    const int il = (int)(idx - li * NB);
+    const int cell = cell_list ? cell_list[li] : (int)li;
+    const int32_t* cd = a.cdofs + (int64_t)cell * NB;
+    const int32_t row = cd[il];
+    const int32_t k0 = a.rowptr[row], k1 = a.rowptr[row + 1];
+    Geo<M> g;
+    cell_geometry<M>(a, cell, g);
+    const double f = element_row<M, R, 0>(a, op, tb, g, cell, il, a.vals != nullptr, [&](int j, double value) {
+        const int32_t col = cd[j];
+        int32_t lo = k0, hi = k1;
+        while (lo < hi) {
+            const int32_t mid = (lo + hi) >> 1;
+            if (a.colidx[mid] < col) lo = mid + 1; else hi = mid;
+        }
+        if (ATOMIC)
+            unsafeAtomicAdd(&a.vals[lo], value);
+        else
+            a.vals[lo] += value;
+    });
+    if (a.force != nullptr) {
+        if (ATOMIC) unsafeAtomicAdd(&a.force[row], f); else a.force[row] += f;
+    }
+}
+
+// Integrator::quadrature_nodes (integrator.h:109-121): out row nq*cell_ext + q = J p_q + x0, column-major rows x N
+template <int M>
+__global__ void k_quadrature_nodes(AsmArgs a, const int32_t* cell_i2e, int nq, double* out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.n_cells * nq) return;
+    const int64_t ci = idx / nq;
+    const int q = (int)(idx - ci * nq);
+    constexpr int NP = M == 2 ? 2 : 4;
+    const int32_t* cv = a.cverts + ci * (M + 1);
+    const double* x0 = a.vcoords + (int64_t)cv[0] * NP;
+    const int64_t rows = a.n_cells * nq;
+    const int64_t orow = (int64_t)cell_i2e[ci] * nq + q;
+    for (int d = 0; d < M; ++d) {
+        double v = 0;
+        for (int k = 0; k < M; ++k) v += (a.vcoords[(int64_t)cv[k + 1] * NP + d] - x0[d]) * a.tables->qn[q * M + k];
+        out[(int64_t)d * rows + orow] = v + x0[d];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Basis evaluation: the Psi matrices every downstream model asks for (PDE__::eval_basis,
+// fdaPDE/pde/pde.h:149-158).
+// ---------------------------------------------------------------------------------------------------------------
+// Lagrange basis of order R at reference point xi, the reference's local node order (closed forms of tables.cpp)
+template <int M, int R> __device__ __forceinline__ void eval_ref_basis(const double* xi, double* out) {
+    double lam[M + 1];
+    lam[0] = 1.0;
+#pragma unroll
+    for (int k = 0; k < M; ++k) lam[0] -= xi[k], lam[k + 1] = xi[k];
+    if constexpr (R == 1) {
+#pragma unroll
+        for (int i = 0; i <= M; ++i) out[i] = lam[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i <= M; ++i) out[i] = lam[i] * (2.0 * lam[i] - 1.0);
+        if constexpr (M == 2) {
+            out[3] = 4.0 * lam[0] * lam[1], out[4] = 4.0 * lam[0] * lam[2], out[5] = 4.0 * lam[1] * lam[2];
+        } else {   // ReferenceElement<3,2> nodes 4..9 = m12, m02, m01, m13, m23, m03
+            out[4] = 4.0 * lam[1] * lam[2], out[5] = 4.0 * lam[0] * lam[2], out[6] = 4.0 * lam[0] * lam[1];
+            out[7] = 4.0 * lam[1] * lam[3], out[8] = 4.0 * lam[2] * lam[3], out[9] = 4.0 * lam[0] * lam[3];
+        }
+    }
+}
+// pointwise_evaluation::eval (basis/lagrangian_basis.h:203-235) with the point location of TreeSearch::locate
+// (geometry/tree_search.h:73-90) done through a uniform bin grid: one lane per location scans the cells registered in its
+// bin and takes the first one whose barycentric coordinates are all >= -tol (Simplex::contains, geometry/simplex.h:118-131).
+// cell_out: reference cell id or -1; values: n_basis basis values psi_h(invJ (p - x0)) per location.
+template <int M, int R>
+__global__ void k_eval_pointwise(AsmArgs a, int64_t n_locs, const double* locs /*col-major n_locs x M*/, const double* lo,
+                                 const double* inv_h, const int32_t* dims, const int32_t* bin_ptr, const int32_t* bin_cells,
+                                 const int32_t* cell_i2e, double tol, int32_t* cell_out, double* values) {
+    constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
+    constexpr int NP = M == 2 ? 2 : 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_locs) return;
+    double p[M];
+    int64_t bin = 0;
+    bool inside_box = true;
+#pragma unroll
+    for (int d = M - 1; d >= 0; --d) {
+        p[d] = locs[(int64_t)d * n_locs + i];
+        const double t = (p[d] - lo[d]) * inv_h[d];
+        int b = (int)floor(t);
+        if (b == dims[d] && t <= dims[d] + 1e-9) b = dims[d] - 1;   // points on the upper face of the bounding box
+        inside_box &= b >= 0 && b < dims[d];
+        bin = bin * dims[d] + (b < 0 ? 0 : (b >= dims[d] ? dims[d] - 1 : b));
+    }
+    int found = -1;
+    double xi[M];
+    if (inside_box) {
+        for (int32_t k = bin_ptr[bin]; k < bin_ptr[bin + 1] && found < 0; ++k) {
+            const int32_t cell = bin_cells[k];
+            const int32_t* cv = a.cverts + (int64_t)cell * (M + 1);
+            const double* x0 = a.vcoords + (int64_t)cv[0] * NP;
+            Geo<M> g;
+            if constexpr (M == 2)
+                geo_from_vertices<2>(x0, a.vcoords + (int64_t)cv[1] * NP, a.vcoords + (int64_t)cv[2] * NP, nullptr, g);
+            else
+                geo_from_vertices<3>(x0, a.vcoords + (int64_t)cv[1] * NP, a.vcoords + (int64_t)cv[2] * NP,
+                                     a.vcoords + (int64_t)cv[3] * NP, g);
+            double z0 = 1.0;
+            bool in = true;
+#pragma unroll
+            for (int r = 0; r < M; ++r) {
+                double v = 0;
+#pragma unroll
+                for (int c = 0; c < M; ++c) v += g.invJ[r][c] * (p[c] - x0[c]);
+                xi[r] = v, z0 -= v, in &= v >= -tol;
+            }
+            if (in && z0 >= -tol) found = cell;
+        }
+    }
+    cell_out[i] = found >= 0 ? cell_i2e[found] : -1;
+    double val[NB];
+    if (found >= 0) eval_ref_basis<M, R>(xi, val);
+#pragma unroll
+    for (int h = 0; h < NB; ++h) values[i * NB + h] = found >= 0 ? val[h] : 0.0;
+}
+// per cell (reference numbering): measure and the integrals of the local basis functions,
+//   int_e psi_h = measure * sum_q w_q psi_h(p_q)   (Integrator::integrate_cell, utils/integration/integrator.h:47-63)
+// -- the ingredients of areal_evaluation::eval (basis/lagrangian_basis.h:238-283)
+template <int M>
+__global__ void k_cell_integrals(AsmArgs a, int nb, int nq, const int32_t* cell_i2e, double* measure, double* psi_int) {
+    const int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci >= a.n_cells) return;
+    Geo<M> g;
+    cell_geometry<M>(a, (int)ci, g);
+    const int64_t ce = cell_i2e[ci];
+    measure[ce] = g.measure;
+    for (int h = 0; h < nb; ++h) {
+        double v = 0;
+        for (int q = 0; q < nq; ++q) v += a.tables->psi[h * nq + q] * a.tables->qw[q];
+        psi_int[ce * nb + h] = v * g.measure;
+    }
+}
+
+}  // namespace fdapde_hip
+#endif

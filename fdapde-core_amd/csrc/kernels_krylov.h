@@ -1,0 +1,633 @@
+// kernels_krylov.h -- Jacobi scaling, CG / BiCGStab vector kernels, interface exchange, numbering changes; see kernels.h
+#ifndef FDAPDE_KERNELS_KRYLOV_H
+#define FDAPDE_KERNELS_KRYLOV_H
+
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "internal.h"
+#include "kernels_reduce.h"
+
+namespace fdapde_hip {
+
+// ---------------------------------------------------------------------------------------------------------------
+// solve set-up kernels
+// ---------------------------------------------------------------------------------------------------------------
+// scale[i] = 0 on Dirichlet rows, 1/sqrt(|A_ii|) elsewhere; flag[0] |= 1 if some interior diagonal is <= 0
+__global__ void k_jacobi_scale(int64_t n, const int32_t* diag, const double* vals, const uint8_t* bnd, int use_bnd,
+                               double* scale, int32_t* flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double d = vals[diag[i]];
+    const bool b = use_bnd && bnd[i];
+    if (!b && !(d > 0.0)) atomicOr(flag, 1);
+    scale[i] = b ? 0.0 : 1.0 / sqrt(fabs(d));
+}
+// At = diag(scale) A diag(scale): symmetric Jacobi scaling == Jacobi preconditioning folded into the matrix stream.
+// Rows and columns of Dirichlet DOFs vanish (scale = 0), which restricts the Krylov iteration to the interior block.
+__global__ __launch_bounds__(256) void k_scale_matrix(int64_t n, const int32_t* rowptr, const int32_t* colidx,
+                                                      const double* vals, const double* scale, double* out) {
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;   // 16 lanes per row
+    const int l = threadIdx.x & 15;
+    if (row >= n) return;
+    const double si = scale[row];
+    for (int k = rowptr[row] + l; k < rowptr[row + 1]; k += 16) out[k] = si * vals[k] * scale[colidx[k]];
+}
+// the same into the compact solver matrix: entries with map[k] < 0 are dropped (the diagonal, which scales to exactly 1,
+// and every entry in a row or column of a Dirichlet DOF, which scales to exactly 0)
+__global__ __launch_bounds__(256) void k_scale_matrix_compact(int64_t n, const int32_t* rowptr, const int32_t* colidx,
+                                                              const double* vals, const double* scale, const int32_t* map,
+                                                              double* out) {
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int l = threadIdx.x & 15;
+    if (row >= n) return;
+    const double si = scale[row];
+    for (int k = rowptr[row] + l; k < rowptr[row + 1]; k += 16) {
+        const int32_t m = map[k];
+        if (m >= 0) out[m] = si * vals[k] * scale[colidx[k]];
+    }
+}
+// gt = g on Dirichlet DOFs, 0 elsewhere (or all zero without Dirichlet data)
+__global__ void k_lift(int64_t n, const uint8_t* bnd, const double* g, int use_bnd, double* gt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) gt[i] = (use_bnd && bnd[i]) ? g[i] : 0.0;
+}
+// bt = scale * (f - A gt)  (y holds A gt): right-hand side of the scaled interior system.
+// Cold start (u0 == nullptr): x = 0, r = bt.  Warm start: x = (u0 - gt) / scale on interior DOFs, r = bt - ax where ax holds
+// At x (one extra SpMV by the caller between the two launches: first launch with ax == nullptr only fills x).
+// partial[2 b] = sum r^2, partial[2 b + 1] = sum bt^2 (the stopping rule is relative to ||bt||, not to the warm residual).
+__global__ __launch_bounds__(256) void k_krylov_init(int64_t n, const double* f, const double* y, const double* scale,
+                                                      double* x, double* r, double* p, double* r0, double* partial,
+                                                      const uint8_t* owned, const double* u0, const double* gt,
+                                                      const double* ax, int fill_x_only) {
+    __shared__ double red[8];
+    double acc = 0, accb = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (fill_x_only) {
+            x[i] = scale[i] > 0.0 ? (u0[i] - gt[i]) / scale[i] : 0.0;
+            continue;
+        }
+        const double bt = scale[i] * (f[i] - y[i]);
+        const double ri = ax ? bt - ax[i] : bt;
+        if (!u0) x[i] = 0.0;
+        r[i] = ri, p[i] = ri;
+        if (r0) r0[i] = ri;
+        if (!owned || owned[i]) acc += ri * ri, accb += bt * bt;
+    }
+    if (fill_x_only) return;
+    const double s = block_sum(acc, red);
+    const double sb = block_sum(accb, red);
+    if (threadIdx.x == 0) partial[2 * blockIdx.x] = s, partial[2 * blockIdx.x + 1] = sb;
+}
+// scalars layout (device doubles): [0] reference norm^2 (||bt||^2), [1] rr_even, [2] rr_odd, [3] last rr, [4..] method specific
+// ctl layout (device int32): [0] stop flag, [1] iterations done, [2] breakdown flag
+__global__ __launch_bounds__(256) void k_krylov_init_fin(const double* partial, int np, double* sc, int32_t* ctl, double tol2) {
+    __shared__ double red[8];
+    double a = 0, b = 0;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) a += partial[2 * i], b += partial[2 * i + 1];
+    const double rr = block_sum(a, red);
+    const double bb = block_sum(b, red);
+    if (threadIdx.x == 0) {
+        sc[0] = bb, sc[1] = rr, sc[2] = rr, sc[3] = rr;
+        sc[4] = 1.0, sc[5] = 1.0, sc[6] = 1.0;   // bicgstab: rho, alpha, omega
+        sc[9] = rr;                               // bicgstab: (r0, r0) of the first iteration
+        ctl[0] = rr <= tol2 * bb ? 1 : 0, ctl[1] = 0, ctl[2] = 0;
+    }
+}
+// out[0], out[1] = sums of the stride-2 partial pairs, fixed order; single workgroup
+__global__ __launch_bounds__(256) void k_reduce_partials2(const double* part, int np, double* out) {
+    __shared__ double red[8];
+    double a = 0, b = 0;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) a += part[2 * i], b += part[2 * i + 1];
+    const double sa = block_sum(a, red);
+    const double sb = block_sum(b, red);
+    if (threadIdx.x == 0) out[0] = sa, out[1] = sb;
+}
+// K = M / dt + A  (FEMLinearParabolicSolver::solve, fem_linear_parabolic_solver.h:49), same pattern, elementwise
+__global__ void k_matrix_combine(int64_t nnz, const double* mass, const double* stiff, double inv_dt, double* out) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nnz) out[k] = mass[k] * inv_dt + stiff[k];
+}
+// rhs = mu * inv_dt + f   (mu = M u_i)
+__global__ void k_parabolic_rhs(int64_t n, const double* mu, double inv_dt, const double* f, double* rhs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rhs[i] = mu[i] * inv_dt + f[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// CG (on the symmetrically scaled system, i.e. Jacobi-PCG on the original one)
+//   k_spmv            : y = At p, partials of p.y
+//   k_cg_update_xr    : alpha = rr / p.y ; x += alpha p ; r -= alpha y ; partials of r.r
+//   k_cg_update_p     : x += alpha p ; beta = rr_new / rr ; p = r + beta p ; bookkeeping + stopping test
+//   (x is updated where p is streamed anyway: 3 + 5 vector passes per iteration instead of 6 + 3)
+// ---------------------------------------------------------------------------------------------------------------
+// Both update kernels are single-shot: workgroup b owns kCgV * 256 consecutive double2 elements, every lane issues all of
+// its 16-byte loads FIRST, and only then re-reduces the producer's partials (an L2 round trip plus two barriers) -- the
+// reduction hides under the loads instead of delaying them (measured per-kernel saving ~2 us of 17 / 9 us).
+constexpr int kCgV = 4;
+// owned (multi-GPU): 1 for DOFs this rank counts in global dot products, nullptr = all (single GPU)
+__global__ __launch_bounds__(256) void k_cg_update_xr(int64_t n, const double* y, double* r, const double* part_in, int np_in,
+                                                       double* part_out, double* sc, int parity, int32_t* ctl,
+                                                       const uint8_t* owned) {
+    __shared__ double red[8];
+    if (__syncthreads_or(ctl[0] != 0)) return;   // uniform even if another workgroup raises the flag meanwhile
+    const int64_t n2 = n >> 1, i0 = (int64_t)blockIdx.x * (256 * kCgV) + threadIdx.x;
+    const double2* y2 = reinterpret_cast<const double2*>(y);
+    double2* r2 = reinterpret_cast<double2*>(r);
+    double2 yv[kCgV], rv[kCgV];
+#pragma unroll
+    for (int k = 0; k < kCgV; ++k) {
+        const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
+        yv[k] = y2[ic], rv[k] = r2[ic];
+    }
+    double v = 0;
+    for (int i = threadIdx.x; i < np_in; i += blockDim.x) v += part_in[2 * i];
+    const double pAp = block_sum(v, red);
+    const double rr = sc[1 + parity];
+    const double alpha = pAp > 0.0 ? rr / pAp : 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        sc[14] = alpha;                  // x += alpha p is done by k_cg_update_p, which streams p anyway
+        if (!(pAp > 0.0)) ctl[2] = 1;    // not SPD / breakdown
+    }
+    double acc = 0;
+#pragma unroll
+    for (int k = 0; k < kCgV; ++k) {
+        const int64_t i = i0 + k * 256;
+        if (i < n2) {
+            rv[k].x -= alpha * yv[k].x, rv[k].y -= alpha * yv[k].y;
+            r2[i] = rv[k];
+            if (owned)
+                acc += (owned[2 * i] ? rv[k].x * rv[k].x : 0.0) + (owned[2 * i + 1] ? rv[k].y * rv[k].y : 0.0);
+            else
+                acc += rv[k].x * rv[k].x + rv[k].y * rv[k].y;
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        const double ri = r[i] - alpha * y[i];
+        r[i] = ri;
+        if (!owned || owned[i]) acc += ri * ri;
+    }
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) part_out[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_cg_update_p(int64_t n, const double* r, double* p, double* x, const double* part_in,
+                                                      int np_in, double* sc, int parity, double tol2, int32_t* ctl) {
+    __shared__ double red[8];
+    if (__syncthreads_or(ctl[0] != 0)) return;   // uniform even if another workgroup raises the flag meanwhile
+    const int64_t n2 = n >> 1, i0 = (int64_t)blockIdx.x * (256 * kCgV) + threadIdx.x;
+    const double2* r2 = reinterpret_cast<const double2*>(r);
+    double2* p2 = reinterpret_cast<double2*>(p);
+    double2* x2 = reinterpret_cast<double2*>(x);
+    double2 rv[kCgV], pv[kCgV], xv[kCgV];
+#pragma unroll
+    for (int k = 0; k < kCgV; ++k) {
+        const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
+        rv[k] = r2[ic], pv[k] = p2[ic], xv[k] = x2[ic];
+    }
+    const double rr_new = sum_partials(part_in, np_in, red);
+    const double rr = sc[1 + parity], alpha = sc[14];
+    const double beta = rr > 0.0 ? rr_new / rr : 0.0;
+#pragma unroll
+    for (int k = 0; k < kCgV; ++k) {
+        const int64_t i = i0 + k * 256;
+        if (i < n2) {
+            xv[k].x += alpha * pv[k].x, xv[k].y += alpha * pv[k].y;
+            pv[k].x = rv[k].x + beta * pv[k].x, pv[k].y = rv[k].y + beta * pv[k].y;
+            x2[i] = xv[k], p2[i] = pv[k];
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        x[n - 1] += alpha * p[n - 1];
+        p[n - 1] = r[n - 1] + beta * p[n - 1];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        sc[1 + (parity ^ 1)] = rr_new, sc[3] = rr_new;
+        ctl[1] += 1;
+        // the stop flag is read by this launch's other workgroups only at their start; writing it here is seen by the
+        // next kernel (kernel boundary = device-scope release/acquire)
+        if (rr_new <= tol2 * sc[0] || ctl[2]) ctl[0] = 1;
+    }
+}
+
+// Single-reduction CG (Chronopoulos & Gear): the SpMV acts on r, both dot products of an iteration -- gamma = r.r and
+// delta = r.(At r) -- are fused into it, and ONE kernel then updates all vectors:
+//     beta = gamma / gamma_old ; alpha = gamma / (delta - beta gamma / alpha_old)
+//     p = r + beta p ; s = w + beta s (= At p) ; x += alpha p ; r -= alpha s
+// Two launches and (multi-GPU) one all-reduce per iteration instead of three and two.  Same Krylov iterates as CG in
+// exact arithmetic.  part_in: stride-2 pairs (delta, gamma); scalars: sc[10 + parity] gamma_old, sc[12 + parity] alpha_old.
+// Every workgroup takes the stop decision from the same reduced numbers, so no workgroup updates past convergence.
+// if_slot / hb (multi-GPU, else nullptr): rows with if_slot[row] >= 0 take w from the all-reduced interface buffer hb, which
+// saves the separate unpack launch (w itself is not read again)
+__global__ __launch_bounds__(256) void k_cgsr_update(int64_t n, double* r, const double* w, double* p, double* s, double* x,
+                                                      const double* part_in, int np_in, double* sc, int parity, int first,
+                                                      double tol2, int32_t* ctl, const int32_t* if_slot, const double* hb) {
+    __shared__ double red[8];
+    if (__syncthreads_or(ctl[0] != 0)) return;
+    const int64_t n2 = n >> 1, i0 = (int64_t)blockIdx.x * (256 * kCgV) + threadIdx.x;
+    double2* r2 = reinterpret_cast<double2*>(r);
+    const double2* w2 = reinterpret_cast<const double2*>(w);
+    double2* p2 = reinterpret_cast<double2*>(p);
+    double2* s2 = reinterpret_cast<double2*>(s);
+    double2* x2 = reinterpret_cast<double2*>(x);
+    double2 rv[kCgV], wv[kCgV], pv[kCgV], sv[kCgV], xv[kCgV];
+#pragma unroll
+    for (int k = 0; k < kCgV; ++k) {
+        const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
+        rv[k] = r2[ic], wv[k] = w2[ic], pv[k] = p2[ic], sv[k] = s2[ic], xv[k] = x2[ic];
+        if (if_slot) {
+            const int s0 = if_slot[2 * ic], s1 = if_slot[2 * ic + 1];
+            if (s0 >= 0) wv[k].x = hb[s0];
+            if (s1 >= 0) wv[k].y = hb[s1];
+        }
+    }
+    double a = 0, b = 0;
+    for (int i = threadIdx.x; i < np_in; i += blockDim.x) a += part_in[2 * i], b += part_in[2 * i + 1];
+    const double delta = block_sum(a, red);
+    const double gamma = block_sum(b, red);
+    const bool last = blockIdx.x == gridDim.x - 1 && threadIdx.x == 0;
+    if (gamma <= tol2 * sc[0]) {   // converged at the residual the SpMV has just measured: x, r stay as they are
+        if (last) sc[3] = gamma, ctl[0] = 1;
+        return;
+    }
+    const double gamma_old = sc[10 + parity], alpha_old = sc[12 + parity];
+    const double beta = first ? 0.0 : gamma / gamma_old;
+    const double denom = first ? delta : delta - beta * gamma / alpha_old;
+    const double alpha = denom > 0.0 ? gamma / denom : 0.0;
+#pragma unroll
+    for (int k = 0; k < kCgV; ++k) {
+        const int64_t i = i0 + k * 256;
+        if (i < n2) {
+            pv[k].x = rv[k].x + beta * pv[k].x, pv[k].y = rv[k].y + beta * pv[k].y;
+            sv[k].x = wv[k].x + beta * sv[k].x, sv[k].y = wv[k].y + beta * sv[k].y;
+            xv[k].x += alpha * pv[k].x, xv[k].y += alpha * pv[k].y;
+            rv[k].x -= alpha * sv[k].x, rv[k].y -= alpha * sv[k].y;
+            p2[i] = pv[k], s2[i] = sv[k], x2[i] = xv[k], r2[i] = rv[k];
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        const double wi = (if_slot && if_slot[i] >= 0) ? hb[if_slot[i]] : w[i];
+        p[i] = r[i] + beta * p[i], s[i] = wi + beta * s[i];
+        x[i] += alpha * p[i], r[i] -= alpha * s[i];
+    }
+    if (last) {
+        sc[10 + (parity ^ 1)] = gamma, sc[12 + (parity ^ 1)] = alpha, sc[3] = gamma;
+        ctl[1] += 1;
+        if (!(denom > 0.0)) ctl[2] = 1, ctl[0] = 1;   // not SPD / breakdown
+    }
+}
+
+// Fused-update CG (single GPU): the SpMV y = At p carries p.y and y.y; ONE kernel then does
+//     alpha = rr / p.y ; x += alpha p ; r -= alpha y ; beta = (alpha^2 y.y - rr) / rr ; p = r + beta p
+// rr is the EXPLICIT r.r (partials written by the previous launch of this kernel); alpha^2 y.y - rr equals r_new.r_new in
+// exact arithmetic (r.y = p.y by A-conjugacy) and is used for beta only, so that p needs no second pass after a global
+// reduction: 7 vector passes and 2 launches per iteration instead of 8 and 3.  The stop test is taken at the start of the
+// next launch (or by k_cgf_fin at a host poll) from the explicit r.r, uniformly by every workgroup.
+template <int kCgV>
+__global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, double* p, double* x, double* r,
+                                                     const double* part_spmv, int np_spmv, const double* part_rr_in, int np_rr,
+                                                     double* part_rr_out, double* sc, int first, double tol2, int32_t* ctl) {
+    __shared__ double red[8];
+    if (__syncthreads_or(ctl[0] != 0)) return;
+    const int64_t n2 = n >> 1, i0 = (int64_t)blockIdx.x * (256 * kCgV) + threadIdx.x;
+    const double2* y2 = reinterpret_cast<const double2*>(y);
+    double2* p2 = reinterpret_cast<double2*>(p);
+    double2* x2 = reinterpret_cast<double2*>(x);
+    double2* r2 = reinterpret_cast<double2*>(r);
+    double2 yv[kCgV], pv[kCgV], xv[kCgV], rv[kCgV];
+#pragma unroll
+    for (int k = 0; k < kCgV; ++k) {
+        const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
+        yv[k] = y2[ic], pv[k] = p2[ic], xv[k] = x2[ic], rv[k] = r2[ic];
+    }
+    double a = 0, b = 0;
+    for (int i = threadIdx.x; i < np_spmv; i += blockDim.x) a += part_spmv[2 * i], b += part_spmv[2 * i + 1];
+    const double pAp = block_sum(a, red);
+    const double yy = block_sum(b, red);
+    const double rr = first ? sc[1] : sum_partials(part_rr_in, np_rr, red);
+    const bool last = blockIdx.x == gridDim.x - 1 && threadIdx.x == 0;
+    if (!first && rr <= tol2 * sc[0]) {   // converged by the previous update: x, r stay as they are
+        if (last) sc[3] = rr, ctl[0] = 1;
+        return;
+    }
+    const double alpha = pAp > 0.0 ? rr / pAp : 0.0;
+    const double est = alpha * alpha * yy - rr;
+    const double beta = (est > 0.0 && rr > 0.0) ? est / rr : 0.0;
+    double acc = 0;
+#pragma unroll
+    for (int k = 0; k < kCgV; ++k) {
+        const int64_t i = i0 + k * 256;
+        if (i < n2) {
+            xv[k].x += alpha * pv[k].x, xv[k].y += alpha * pv[k].y;
+            rv[k].x -= alpha * yv[k].x, rv[k].y -= alpha * yv[k].y;
+            pv[k].x = rv[k].x + beta * pv[k].x, pv[k].y = rv[k].y + beta * pv[k].y;
+            x2[i] = xv[k], r2[i] = rv[k], p2[i] = pv[k];
+            acc += rv[k].x * rv[k].x + rv[k].y * rv[k].y;
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        x[i] += alpha * p[i];
+        const double ri = r[i] - alpha * y[i];
+        r[i] = ri, p[i] = ri + beta * p[i];
+        acc += ri * ri;
+    }
+    const double s = block_sum(acc, red);
+    if (threadIdx.x == 0) part_rr_out[blockIdx.x] = s;
+    if (last) {
+        sc[3] = rr;
+        ctl[1] += 1;
+        if (!(pAp > 0.0)) ctl[2] = 1, ctl[0] = 1;   // not SPD / breakdown
+    }
+}
+// host poll of the fused-update CG: explicit r.r of the last update -> sc[3], stop flag
+__global__ __launch_bounds__(256) void k_cgf_fin(const double* part_rr, int np, double* sc, double tol2, int32_t* ctl) {
+    __shared__ double red[8];
+    if (ctl[0] != 0) return;
+    const double rr = sum_partials(part_rr, np, red);
+    if (threadIdx.x == 0) {
+        sc[3] = rr;
+        if (rr <= tol2 * sc[0]) ctl[0] = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// BiCGStab on the scaled system (non-symmetric operators: advection)
+//   k_bicg_p   : rho = r0.r ; beta = (rho/rho_old)(alpha/omega) ; p = r + beta (p - omega v)
+//   k_spmv     : v = At p, partial of r0.v
+//   k_bicg_s   : alpha = rho / r0.v ; s = r - alpha v
+//   k_spmv     : t = At s, partials of t.s (w = s) and t.t
+//   k_bicg_xr  : omega = t.s / t.t ; x += alpha p + omega s ; r = s - omega t ; partials r0.r and r.r
+// ---------------------------------------------------------------------------------------------------------------
+// The three vector kernels are single-shot like the CG ones: workgroup b owns kBiV * 256 consecutive double2 elements, every
+// lane issues all of its 16-byte loads first and only then re-reduces the producer's partials (grid = bicg_grid(n)).
+constexpr int kBiV = 4;
+__global__ __launch_bounds__(256) void k_bicg_p(int64_t n, const double* r, const double* v, double* p,
+                                                 const double* part_in /* (r0.r, r.r) pairs */, int np_in, double* sc,
+                                                 int first, int32_t* ctl) {
+    __shared__ double red[8];
+    if (__syncthreads_or(ctl[0] != 0)) return;   // uniform even if another workgroup raises the flag meanwhile
+    const int64_t n2 = n >> 1, i0 = (int64_t)blockIdx.x * (256 * kBiV) + threadIdx.x;
+    const double2* r2 = reinterpret_cast<const double2*>(r);
+    const double2* v2 = reinterpret_cast<const double2*>(v);
+    double2* p2 = reinterpret_cast<double2*>(p);
+    double2 rv[kBiV], vv[kBiV], pv[kBiV];
+#pragma unroll
+    for (int k = 0; k < kBiV; ++k) {
+        const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
+        rv[k] = r2[ic];
+        if (!first) vv[k] = v2[ic], pv[k] = p2[ic];
+    }
+    double a = 0;
+    for (int i = threadIdx.x; i < np_in; i += blockDim.x) a += part_in[2 * i];
+    const double rho_new = first ? sc[9] : block_sum(a, red);
+    const double rho = sc[4], alpha = sc[5], omega = sc[6];
+    const double beta = first ? 0.0 : (rho_new / rho) * (alpha / omega);
+#pragma unroll
+    for (int k = 0; k < kBiV; ++k) {
+        const int64_t i = i0 + k * 256;
+        if (i < n2) {
+            double2 o = rv[k];
+            if (!first) o.x += beta * (pv[k].x - omega * vv[k].x), o.y += beta * (pv[k].y - omega * vv[k].y);
+            p2[i] = o;
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = first ? r[n - 1] : r[n - 1] + beta * (p[n - 1] - omega * v[n - 1]);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        sc[7] = rho_new;
+        if (rho_new == 0.0) ctl[2] = 1;
+    }
+}
+__global__ __launch_bounds__(256) void k_bicg_s(int64_t n, const double* r, const double* v, double* s,
+                                                 const double* part_in /* (r0.v, .) */, int np_in, double* sc,
+                                                 int32_t* ctl) {
+    __shared__ double red[8];
+    if (__syncthreads_or(ctl[0] != 0)) return;   // uniform even if another workgroup raises the flag meanwhile
+    const int64_t n2 = n >> 1, i0 = (int64_t)blockIdx.x * (256 * kBiV) + threadIdx.x;
+    const double2* r2 = reinterpret_cast<const double2*>(r);
+    const double2* v2 = reinterpret_cast<const double2*>(v);
+    double2* s2 = reinterpret_cast<double2*>(s);
+    double2 rv[kBiV], vv[kBiV];
+#pragma unroll
+    for (int k = 0; k < kBiV; ++k) {
+        const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
+        rv[k] = r2[ic], vv[k] = v2[ic];
+    }
+    double a = 0;
+    for (int i = threadIdx.x; i < np_in; i += blockDim.x) a += part_in[2 * i];
+    const double r0v = block_sum(a, red);
+    const double alpha = r0v != 0.0 ? sc[7] / r0v : 0.0;
+#pragma unroll
+    for (int k = 0; k < kBiV; ++k) {
+        const int64_t i = i0 + k * 256;
+        if (i < n2) s2[i] = make_double2(rv[k].x - alpha * vv[k].x, rv[k].y - alpha * vv[k].y);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) s[n - 1] = r[n - 1] - alpha * v[n - 1];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        sc[8] = alpha;
+        if (r0v == 0.0) ctl[2] = 1;
+    }
+}
+__global__ __launch_bounds__(256) void k_bicg_xr(int64_t n, const double* p, const double* s, const double* t,
+                                                  const double* r0, double* x, double* r,
+                                                  const double* part_in /* (t.s, t.t) */, int np_in, double* part_out,
+                                                  const double* sc, int32_t* ctl, const uint8_t* owned) {
+    __shared__ double red[8];
+    if (__syncthreads_or(ctl[0] != 0)) return;   // uniform even if another workgroup raises the flag meanwhile
+    const int64_t n2 = n >> 1, i0 = (int64_t)blockIdx.x * (256 * kBiV) + threadIdx.x;
+    const double2* p2 = reinterpret_cast<const double2*>(p);
+    const double2* s2 = reinterpret_cast<const double2*>(s);
+    const double2* t2 = reinterpret_cast<const double2*>(t);
+    const double2* q2 = reinterpret_cast<const double2*>(r0);
+    double2* x2 = reinterpret_cast<double2*>(x);
+    double2* r2 = reinterpret_cast<double2*>(r);
+    double2 pv[kBiV], sv[kBiV], tv[kBiV], qv[kBiV], xv[kBiV];
+#pragma unroll
+    for (int k = 0; k < kBiV; ++k) {
+        const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
+        pv[k] = p2[ic], sv[k] = s2[ic], tv[k] = t2[ic], qv[k] = q2[ic], xv[k] = x2[ic];
+    }
+    double a = 0, b = 0;
+    for (int i = threadIdx.x; i < np_in; i += blockDim.x) a += part_in[2 * i], b += part_in[2 * i + 1];
+    const double ts = block_sum(a, red);
+    const double tt = block_sum(b, red);
+    const double omega = tt > 0.0 ? ts / tt : 0.0;
+    const double alpha = sc[8];
+    double d0 = 0, d1 = 0;
+#pragma unroll
+    for (int k = 0; k < kBiV; ++k) {
+        const int64_t i = i0 + k * 256;
+        if (i < n2) {
+            x2[i] = make_double2(xv[k].x + alpha * pv[k].x + omega * sv[k].x, xv[k].y + alpha * pv[k].y + omega * sv[k].y);
+            const double2 ri = make_double2(sv[k].x - omega * tv[k].x, sv[k].y - omega * tv[k].y);
+            r2[i] = ri;
+            const bool o0 = !owned || owned[2 * i], o1 = !owned || owned[2 * i + 1];
+            d0 += (o0 ? qv[k].x * ri.x : 0.0) + (o1 ? qv[k].y * ri.y : 0.0);
+            d1 += (o0 ? ri.x * ri.x : 0.0) + (o1 ? ri.y * ri.y : 0.0);
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        x[i] += alpha * p[i] + omega * s[i];
+        const double ri = s[i] - omega * t[i];
+        r[i] = ri;
+        if (!owned || owned[i]) d0 += r0[i] * ri, d1 += ri * ri;
+    }
+    const double s0 = block_sum(d0, red);
+    const double s1 = block_sum(d1, red);
+    if (threadIdx.x == 0) part_out[2 * blockIdx.x] = s0, part_out[2 * blockIdx.x + 1] = s1;
+}
+// multi-GPU BiCGStab: t.t over the owned rows of the ASSEMBLED t (the SpMV's fused y.y only sees this rank's sub-assembled
+// part); per-workgroup partials, then out = (t.s already summed over ranks, local t.t) for the scalar all-reduce of out[1]
+__global__ __launch_bounds__(256) void k_sq_owned(int64_t n, const double* t, const uint8_t* owned, double* part, const int32_t* ctl) {
+    __shared__ double red[8];
+    if (__syncthreads_or(ctl[0] != 0)) return;
+    double a = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if (owned[i]) a += t[i] * t[i];
+    const double s = block_sum(a, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void k_bicg_tt_fin(const double* part, int np, const double* ts_src, double* out) {
+    __shared__ double red[8];
+    const double s = sum_partials(part, np, red);
+    if (threadIdx.x == 0) out[0] = ts_src[0], out[1] = s;
+}
+// closes a BiCGStab iteration: rho <- rho_new, alpha, omega = t.s/t.t recomputed from the same partials, stop test
+__global__ __launch_bounds__(256) void k_bicg_fin(const double* part_ts, int np_ts, const double* part_rr, int np_rr,
+                                                   double* sc, double tol2, int32_t* ctl) {
+    __shared__ double red[8];
+    if (__syncthreads_or(ctl[0] != 0)) return;   // uniform even if another workgroup raises the flag meanwhile
+    double a = 0, b = 0;
+    for (int i = threadIdx.x; i < np_ts; i += blockDim.x) a += part_ts[2 * i], b += part_ts[2 * i + 1];
+    const double ts = block_sum(a, red);
+    const double tt = block_sum(b, red);
+    double c = 0;
+    for (int i = threadIdx.x; i < np_rr; i += blockDim.x) c += part_rr[2 * i + 1];
+    const double rr = block_sum(c, red);
+    if (threadIdx.x == 0) {
+        const double omega = tt > 0.0 ? ts / tt : 0.0;
+        sc[4] = sc[7], sc[5] = sc[8], sc[6] = omega, sc[3] = rr;
+        ctl[1] += 1;
+        if (omega == 0.0) ctl[2] = 1;
+        if (rr <= tol2 * sc[0] || ctl[2]) ctl[0] = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// multi-GPU: interface ("halo") exchange.  Every rank holds the sub-assembled operator of its own cells; an operator
+// application is y_p = A_p x_p followed by the sum of the interface entries over the ranks that share them.  The
+// interface entries are packed into one globally indexed buffer (zero elsewhere), summed by ONE ncclAllReduce together
+// with the rank's partial of the fused dot product (slot n_if), and unpacked.  dot(x, A x) = sum_p x_p . (A_p x_p) needs
+// no weighting; dots of assembled vectors count every DOF once through the `owned` mask.
+// ---------------------------------------------------------------------------------------------------------------
+// buf must be zero on entry.  Workgroup 0 also folds the local dot partials (stride 2) into buf[n_if] (+ second component
+// into buf[n_if + 1]).
+__global__ __launch_bounds__(256) void k_halo_pack(int64_t n_loc_if, const int32_t* dof, const int32_t* pos, const double* v,
+                                                    double* buf, int64_t n_if, const double* part, int np) {
+    __shared__ double red[8];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_loc_if) buf[pos[i]] = v[dof[i]];
+    if (blockIdx.x == 0 && part != nullptr) {
+        double a = 0, b = 0;
+        for (int k = threadIdx.x; k < np; k += blockDim.x) a += part[2 * k], b += part[2 * k + 1];
+        const double sa = block_sum(a, red);
+        const double sb = block_sum(b, red);
+        if (threadIdx.x == 0) buf[n_if] = sa, buf[n_if + 1] = sb;
+    }
+}
+// the same without a prior memset: one lane per GLOBAL interface slot; inv[j] = this rank's DOF of slot j or -1
+__global__ __launch_bounds__(256) void k_halo_pack_all(int64_t n_if, const int32_t* inv, const double* v, double* buf,
+                                                        const double* part, int np) {
+    __shared__ double red[8];
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_if) {
+        const int32_t d = inv[j];
+        buf[j] = d >= 0 ? v[d] : 0.0;
+    }
+    if (blockIdx.x == 0) {
+        double a = 0, b = 0;
+        if (part != nullptr)
+            for (int k = threadIdx.x; k < np; k += blockDim.x) a += part[2 * k], b += part[2 * k + 1];
+        const double sa = block_sum(a, red);
+        const double sb = block_sum(b, red);
+        if (threadIdx.x == 0) buf[n_if] = sa, buf[n_if + 1] = sb;
+    }
+}
+__global__ void k_halo_unpack(int64_t n_loc_if, const int32_t* dof, const int32_t* pos, const double* buf, double* v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_loc_if) v[dof[i]] = buf[pos[i]];
+}
+// out[0] = sum(part[0..np)) in the fixed order; single workgroup
+__global__ __launch_bounds__(256) void k_reduce_partials(const double* part, int np, double* out) {
+    __shared__ double red[8];
+    const double s = sum_partials(part, np, red);
+    if (threadIdx.x == 0) out[0] = s;
+}
+__global__ void k_diag_extract(int64_t n, const int32_t* diag, const double* vals, double* d) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = vals[diag[i]];
+}
+// Jacobi scale from an already summed diagonal (multi-GPU)
+__global__ void k_jacobi_scale_from_diag(int64_t n, const double* d, const uint8_t* bnd, int use_bnd, double* scale, int32_t* flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool b = use_bnd && bnd[i];
+    if (!b && !(d[i] > 0.0)) atomicOr(flag, 1);
+    scale[i] = b ? 0.0 : 1.0 / sqrt(fabs(d[i]));
+}
+
+// u = scale * x + gt   (back to the unscaled unknowns, Dirichlet values restored)
+__global__ void k_unscale(int64_t n, const double* scale, const double* x, const double* gt, double* u) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) u[i] = scale[i] * x[i] + gt[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// numbering changes at the boundary (reference numbering <-> internal numbering)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_gather_f64(int64_t n, const int32_t* idx, const double* src, double* dst) {   // dst[i] = src[idx[i]]
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+__global__ void k_scatter_f64(int64_t n, const int32_t* idx, const double* src, double* dst) {  // dst[idx[i]] = src[i]
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[idx[i]] = src[i];
+}
+// export of stiff() after a Dirichlet solve: FEMSolverBase::set_dirichlet_bc (fem_solver_base.h:148-149) zeroes the
+// boundary rows and puts 1 on their diagonal; 16 lanes per row, output in reference slots
+__global__ __launch_bounds__(256) void k_export_values(int64_t n, const int32_t* rowptr, const int32_t* colidx,
+                                                       const double* vals, const int32_t* slot_i2e, const uint8_t* bnd,
+                                                       int zero_bnd_rows, double* out) {
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int l = threadIdx.x & 15;
+    if (row >= n) return;
+    const bool z = zero_bnd_rows && bnd[row];
+    for (int k = rowptr[row] + l; k < rowptr[row + 1]; k += 16)
+        out[slot_i2e[k]] = z ? (colidx[k] == row ? 1.0 : 0.0) : vals[k];
+}
+// row-sum lumping (fdaPDE/linear_algebra/lumping.h:30-41): out[row] = sum of the row's entries; 16 lanes per row, fixed order
+__global__ __launch_bounds__(256) void k_row_sums(int64_t n, const int32_t* rowptr, const double* vals, double* out) {
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int l = threadIdx.x & 15;
+    const bool ok = row < n;
+    double a = 0;
+    if (ok)
+        for (int k = rowptr[row] + l; k < rowptr[row + 1]; k += 16) a += vals[k];
+    a = team_sum<16>(a);
+    if (ok && l == 0) out[row] = a;
+}
+__global__ void k_fill_f64(int64_t n, double v, double* dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = v;
+}
+// force export after a Dirichlet solve: force_[i] = g[i] on boundary DOFs (fem_solver_base.h:152)
+__global__ void k_force_bc(int64_t n, const uint8_t* bnd, const double* g, double* f) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && bnd[i]) f[i] = g[i];
+}
+
+}  // namespace fdapde_hip
+#endif

@@ -85,6 +85,15 @@ struct HostTerm {
 
 }  // namespace
 
+// everything the captured launch sequence of a CG chunk depends on (the graph is rebuilt when any of it changes)
+struct GraphKey {
+    const void* sval;
+    const void* rowptr;
+    int64_t n;
+    double tol2;
+    int chunk, v, grid, team, ablate, c16, deep, unroll, sp_cur;
+};
+
 // what solve_prepare decided for a system matrix (shared by the elliptic, parabolic and handle solves)
 struct SolveState {
     bool dist = false, diag_positive = true;
@@ -144,6 +153,9 @@ struct fdapde_ctx {
     int64_t sp_wide[2] = {0, 0};             // groups of 32 rows that fall back to the 32-bit columns
     int sp_team = 0;                         // team size the segmented patterns were built for
     int spmv_c16 = 1;                        // tuning knob: 0 = always stream the 32-bit columns
+    int use_graph = 0;                       // tuning knob: replay full chunks of the fused-update CG as one hipGraph
+    hipGraphExec_t cg_graph_exec = nullptr;
+    GraphKey cg_graph_key{};
     int cgf_v = 8;                           // double2 elements per lane of k_cgf_update (1, 2, 4, 8); C3 solve: 47.2 / 41.8 / 41.3 / 40.9 ms
     int spmv_deep = 0;                       // tuning knob: 1 = k_spmv_c16p (gathers one tile ahead; measured slower: 3 waves / SIMD)
     int64_t sp_nnz[2] = {0, 0};
@@ -454,6 +466,12 @@ int launch_assembly(fdapde_ctx* c, const AsmArgs& a, const DevOp& op, int assemb
     return fail(c, FDAPDE_EUNSUPPORTED, "unsupported (M, order)");
 }
 
+// the captured CG chunk bakes pointers and sizes in: drop it whenever a layout, buffer or knob may have changed
+inline void drop_graph(fdapde_ctx* c) {
+    if (c->cg_graph_exec) (void)hipGraphExecDestroy(c->cg_graph_exec);
+    c->cg_graph_exec = nullptr;
+}
+
 // e0 / e1 (optional): HIP events attached to the dispatch itself (hipExtLaunchKernelGGL), i.e. the kernel's own begin / end
 // timestamps on the stream it runs on -- the same interval rocprofv3 --kernel-trace reports, with no extra marker packet
 // between the neighbouring kernels.
@@ -482,9 +500,15 @@ void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, 
     // eight row bands (one per XCD); band starts on a multiple of 32 rows so that a wavefront tile lies in one code group
     const int64_t rpb = (((n + 7) / 8) + 31) & ~int64_t(31);
     const dim3 grid(c->spmv_grid), block(256);
-#define SPMV_GO(...) hipExtLaunchKernelGGL((__VA_ARGS__), grid, block, 0, c->stream, e0, e1, 0, s, n, rpb)
+    // dispatch-attached events only where a launch is timed; the plain launch can be captured into a hipGraph
+#define SPMV_GO(...)                                                                                 \
+    do {                                                                                             \
+        if (e0 || e1) hipExtLaunchKernelGGL((__VA_ARGS__), grid, block, 0, c->stream, e0, e1, 0, s, n, rpb); \
+        else hipLaunchKernelGGL((__VA_ARGS__), grid, block, 0, c->stream, s, n, rpb);                \
+    } while (0)
     if (c->spmv_variant == 1) {
-        hipExtLaunchKernelGGL(k_spmv, grid, block, 0, c->stream, e0, e1, 0, s);
+        if (e0 || e1) hipExtLaunchKernelGGL(k_spmv, grid, block, 0, c->stream, e0, e1, 0, s);
+        else hipLaunchKernelGGL(k_spmv, grid, block, 0, c->stream, s);
         return;
     }
     if (c->spmv_variant == 2) {   // two entries per lane: team = lanes per row, covering 2 * team entries per pass
@@ -681,6 +705,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
     if (c->has_device) {
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
+        drop_graph(c);
         for (DBuf<int32_t>* b : {&c->cverts, &c->cdofs, &c->adj, &c->rowptr, &c->colidx, &c->diag, &c->slot_i2e, &c->dof_i2e,
                                  &c->dof_e2i, &c->cell_i2e, &c->rb_row, &c->colour_cells, &c->ctl})
             b->release();
@@ -726,6 +751,7 @@ int fdapde_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs) {
     c->assembled[0] = c->assembled[1] = c->force_ready = c->solved = c->dirichlet_applied = false;
     c->op.clear(), c->fq_i.clear(), c->fq_cols = 0, c->g_i.clear(), c->have_g = false;
     c->halo_ready = false, c->lin_ready = false, c->sp_built[0] = c->sp_built[1] = false, c->sp_cur = -1;
+    drop_graph(c);
     int rc = host_build_space(c->hs, order, c->err);
     if (rc) return rc;
     rc = build_basis_tables(c->hs.M, order, &c->tb);
@@ -759,6 +785,7 @@ int fdapde_dofs_set_boundary(fdapde_ctx* c, const uint8_t* bnd) {
     for (int64_t i = 0; i < hs.n_dofs; ++i) hs.dof_bnd[(size_t)i] = bnd[i] ? 1 : 0;
     for (int64_t i = 0; i < hs.n_dofs; ++i) hs.dof_bnd_i[(size_t)i] = hs.dof_bnd[(size_t)hs.dof_i2e[(size_t)i]];
     c->sp_built[1] = false;   // the compact solver pattern drops Dirichlet rows / columns
+    drop_graph(c);
     c->solved = false;
     if (c->dev_ready) {
         HIPCHK(c, hipSetDevice(c->device));
@@ -936,6 +963,7 @@ namespace {
 // and uploads, done once per function space and boundary mask (fdapde_solver_prepare, or lazily by the first solve)
 int build_solver_pattern(fdapde_ctx* c, int v) {
     if (c->sp_built[v]) return FDAPDE_OK;
+    drop_graph(c);
     hipStream_t st = c->stream;
     std::vector<int32_t> rp, ci, map, vrow;
     // rows longer than a team pass (P2): segmented pattern, one team pass per chunk; else the plain compact pattern
@@ -1064,9 +1092,12 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     if (dist) {
         hipLaunchKernelGGL(k_reduce_partials2, dim3(1), dim3(256), 0, st, c->part_b.p, c->vec_grid, c->sbuf.p);
         if (int rc = allreduce_sum(c, c->sbuf.p, 2)) return rc;
-        hipLaunchKernelGGL(k_krylov_init_fin, dim3(1), dim3(256), 0, st, c->sbuf.p, 1, c->sc.p, c->ctl.p, tol2);
+        hipLaunchKernelGGL(k_krylov_init_fin, dim3(1), dim3(256), 0, st, c->sbuf.p, 1, c->sc.p, c->ctl.p, tol2, (double*)nullptr, 0);
     } else {
-        hipLaunchKernelGGL(k_krylov_init_fin, dim3(1), dim3(256), 0, st, c->part_b.p, c->vec_grid, c->sc.p, c->ctl.p, tol2);
+        // fused-update CG: its launch 0 reads the explicit r.r from the second half of part_b (seeded here)
+        const int V = c->cgf_v, cg = (int)(((n >> 1) + 256 * V - 1) / (256 * V)) > 0 ? (int)(((n >> 1) + 256 * V - 1) / (256 * V)) : 1;
+        hipLaunchKernelGGL(k_krylov_init_fin, dim3(1), dim3(256), 0, st, c->part_b.p, c->vec_grid, c->sc.p, c->ctl.p, tol2,
+                           cgf ? c->part_b.p + cg : (double*)nullptr, cgf ? cg : 0);
     }
     if (cgsr) {   // p = s = 0 before the first update (beta = 0 there)
         HIPCHK(c, hipMemsetAsync(c->p.p, 0, sizeof(double) * (size_t)n, st));
@@ -1081,10 +1112,52 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     }
     int timed = 0, launched = 0;
     bool stop = false;
+    // one iteration of the fused-update CG: SpMV (p.y, y.y) + k_cgf_update; arguments depend on the iteration's parity only
+    const int cgf_V = c->cgf_v;
+    const int cgf_grid = (int)(((n >> 1) + 256 * cgf_V - 1) / (256 * cgf_V)) > 0 ? (int)(((n >> 1) + 256 * cgf_V - 1) / (256 * cgf_V)) : 1;
+    auto enqueue_cgf = [&](int it, hipEvent_t e0, hipEvent_t e1) {
+        const int cg = cgf_grid;
+        launch_spmv(c, c->sval.p, c->p.p, c->y.p, c->p.p, c->part_a.p, c->ctl.p, e0, e1);   // p.y and y.y
+#define CGF_GO(V_)                                                                                                         \
+    hipLaunchKernelGGL(k_cgf_update<V_>, dim3(cg), dim3(256), 0, st, n, c->y.p, c->p.p, c->x.p, c->r.p, c->part_a.p, c->spmv_grid, \
+                       c->part_b.p + (size_t)((it + 1) & 1) * cg, cg, c->part_b.p + (size_t)(it & 1) * cg, c->sc.p, tol2, c->ctl.p)
+        if (cgf_V == 1) CGF_GO(1);
+        else if (cgf_V == 2) CGF_GO(2);
+        else if (cgf_V == 8) CGF_GO(8);
+        else CGF_GO(4);
+#undef CGF_GO
+    };
+    auto enqueue_cgf_fin = [&](int done) {   // explicit r.r of the last update -> sc[3] / stop flag
+        hipLaunchKernelGGL(k_cgf_fin, dim3(1), dim3(256), 0, st, c->part_b.p + (size_t)((done - 1) & 1) * cgf_grid, cgf_grid, c->sc.p, tol2,
+                           c->ctl.p);
+    };
     const int bi_grid = (int)(((n >> 1) + 256 * kBiV - 1) / (256 * kBiV)) > 0 ? (int)(((n >> 1) + 256 * kBiV - 1) / (256 * kBiV)) : 1;
     while (!stop && launched < maxit) {
         const int chunk = (maxit - launched) < check_every ? (maxit - launched) : check_every;
-        for (int it = 0; it < chunk; ++it, ++launched) {
+        // a full chunk of the fused-update CG with no timed launch replays ONE hipGraph (2 * chunk + 1 kernel nodes): the
+        // arguments repeat with period 2, so the graph captured for iterations 0 .. chunk-1 serves every even-aligned chunk
+        bool graphed = false;
+        if (cgf && c->use_graph && chunk == check_every && (chunk & 1) == 0 && (launched & 1) == 0 && launched >= n_timed) {
+            const GraphKey key{c->sval.p, c->sp_cur >= 0 ? (const void*)c->sp_rowptr[c->sp_cur].p : (const void*)c->rowptr.p, n, tol2, chunk,
+                               cgf_V, c->spmv_grid, c->spmv_team, c->spmv_ablate, c->spmv_c16, c->spmv_deep, c->spmv_unroll, c->sp_cur};
+            if (!c->cg_graph_exec || std::memcmp(&key, &c->cg_graph_key, sizeof key) != 0) {
+                if (c->cg_graph_exec) (void)hipGraphExecDestroy(c->cg_graph_exec), c->cg_graph_exec = nullptr;
+                hipGraph_t g = nullptr;
+                if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    for (int it = 0; it < chunk; ++it) enqueue_cgf(it, nullptr, nullptr);
+                    enqueue_cgf_fin(chunk);
+                    if (hipStreamEndCapture(st, &g) == hipSuccess && g &&
+                        hipGraphInstantiate(&c->cg_graph_exec, g, nullptr, nullptr, 0) == hipSuccess)
+                        c->cg_graph_key = key;
+                    else
+                        c->cg_graph_exec = nullptr;
+                    if (g) (void)hipGraphDestroy(g);
+                }
+                (void)hipGetLastError();
+            }
+            if (c->cg_graph_exec && hipGraphLaunch(c->cg_graph_exec, st) == hipSuccess) launched += chunk, graphed = true;
+        }
+        for (int it = 0; !graphed && it < chunk; ++it, ++launched) {
             if (cgsr) {
                 const int parity = launched & 1;
                 const bool tm = launched < n_timed;
@@ -1105,20 +1178,8 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
                                    dist ? c->if_slot.p : (const int32_t*)nullptr, dist ? c->hbuf.p : (const double*)nullptr);
             } else if (cgf) {
                 const bool tm = launched < n_timed;
-                // explicit r.r partials ping-pong between the two halves of part_b
-                const int V = c->cgf_v, cg = (int)(((n >> 1) + 256 * V - 1) / (256 * V)) > 0 ? (int)(((n >> 1) + 256 * V - 1) / (256 * V)) : 1;
-                launch_spmv(c, c->sval.p, c->p.p, c->y.p, c->p.p, c->part_a.p, c->ctl.p, tm ? c->ev_spmv[2 * launched] : nullptr,
-                            tm ? c->ev_spmv[2 * launched + 1] : nullptr);   // p.y and y.y
+                enqueue_cgf(launched, tm ? c->ev_spmv[2 * launched] : nullptr, tm ? c->ev_spmv[2 * launched + 1] : nullptr);
                 if (tm) ++timed;
-#define CGF_GO(V_)                                                                                                         \
-    hipLaunchKernelGGL(k_cgf_update<V_>, dim3(cg), dim3(256), 0, st, n, c->y.p, c->p.p, c->x.p, c->r.p, c->part_a.p, c->spmv_grid, \
-                       c->part_b.p + (size_t)((launched + 1) & 1) * cg, cg, c->part_b.p + (size_t)(launched & 1) * cg, c->sc.p,   \
-                       launched == 0 ? 1 : 0, tol2, c->ctl.p)
-                if (V == 1) CGF_GO(1);
-                else if (V == 2) CGF_GO(2);
-                else if (V == 8) CGF_GO(8);
-                else CGF_GO(4);
-#undef CGF_GO
             } else if (!bicg) {
                 const int parity = launched & 1;
                 const bool tm = launched < n_timed;
@@ -1181,11 +1242,7 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
                 hipLaunchKernelGGL(k_bicg_fin, dim3(1), dim3(256), 0, st, c->sbuf.p + 4, 1, c->sbuf.p, 1, c->sc.p, tol2, c->ctl.p);
             }
         }
-        if (cgf && launched > 0) {   // explicit r.r of the last update -> sc[3] / stop flag
-            const int V = c->cgf_v, cg = (int)(((n >> 1) + 256 * V - 1) / (256 * V)) > 0 ? (int)(((n >> 1) + 256 * V - 1) / (256 * V)) : 1;
-            hipLaunchKernelGGL(k_cgf_fin, dim3(1), dim3(256), 0, st, c->part_b.p + (size_t)((launched - 1) & 1) * cg, cg, c->sc.p, tol2,
-                               c->ctl.p);
-        }
+        if (cgf && launched > 0 && !graphed) enqueue_cgf_fin(launched);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipMemcpyAsync(c->h_sc, c->sc.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1735,6 +1792,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     if (!c || !key) return FDAPDE_EINVAL;
     if (!c->dev_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
     const std::string k(key);
+    drop_graph(c);
     if (k == "spmv_variant" && value >= 0 && value <= 2) c->spmv_variant = value;
     else if (k == "spmv_team" && (value == 2 || value == 4 || value == 8 || value == 16 || value == 32 || value == 64)) {
         if (value != c->spmv_team) c->sp_built[0] = c->sp_built[1] = false, c->sp_cur = -1, c->solved = false;   // segmented patterns depend on it
@@ -1745,6 +1803,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "spmv_c16" && (value == 0 || value == 1)) c->spmv_c16 = value;
     else if (k == "spmv_deep" && (value == 0 || value == 1)) c->spmv_deep = value;
     else if (k == "cgf_v" && (value == 1 || value == 2 || value == 4 || value == 8)) c->cgf_v = value;
+    else if (k == "use_graph" && (value == 0 || value == 1)) c->use_graph = value;
     else if (k == "spmv_bpx" && value >= 1 && value <= 1024) {
         c->spmv_grid = 8 * value;
         HIPCHK(c, hipSetDevice(c->device));

@@ -82,12 +82,17 @@ __global__ __launch_bounds__(256) void k_krylov_init(int64_t n, const double* f,
 }
 // scalars layout (device doubles): [0] reference norm^2 (||bt||^2), [1] rr_even, [2] rr_odd, [3] last rr, [4..] method specific
 // ctl layout (device int32): [0] stop flag, [1] iterations done, [2] breakdown flag
-__global__ __launch_bounds__(256) void k_krylov_init_fin(const double* partial, int np, double* sc, int32_t* ctl, double tol2) {
+// seed (optional): the fused-update CG reads its explicit r.r from n_seed per-workgroup partials; they are seeded with
+// (rr, 0, 0, ...) so that its first launch needs no special case (and the launch sequence can be replayed as a graph)
+__global__ __launch_bounds__(256) void k_krylov_init_fin(const double* partial, int np, double* sc, int32_t* ctl, double tol2,
+                                                         double* seed, int n_seed) {
     __shared__ double red[8];
     double a = 0, b = 0;
     for (int i = threadIdx.x; i < np; i += blockDim.x) a += partial[2 * i], b += partial[2 * i + 1];
     const double rr = block_sum(a, red);
     const double bb = block_sum(b, red);
+    __syncthreads();   // all reads of `partial` are done: seed may alias it
+    for (int i = threadIdx.x; i < n_seed; i += blockDim.x) seed[i] = i == 0 ? rr : 0.0;
     if (threadIdx.x == 0) {
         sc[0] = bb, sc[1] = rr, sc[2] = rr, sc[3] = rr;
         sc[4] = 1.0, sc[5] = 1.0, sc[6] = 1.0;   // bicgstab: rho, alpha, omega
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(256) void k_cgsr_update(int64_t n, double* r, const
 template <int kCgV>
 __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, double* p, double* x, double* r,
                                                      const double* part_spmv, int np_spmv, const double* part_rr_in, int np_rr,
-                                                     double* part_rr_out, double* sc, int first, double tol2, int32_t* ctl) {
+                                                     double* part_rr_out, double* sc, double tol2, int32_t* ctl) {
     __shared__ double red[8];
     if (__syncthreads_or(ctl[0] != 0)) return;
     const int64_t n2 = n >> 1, i0 = (int64_t)blockIdx.x * (256 * kCgV) + threadIdx.x;
@@ -306,9 +311,9 @@ __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, 
     for (int i = threadIdx.x; i < np_spmv; i += blockDim.x) a += part_spmv[2 * i], b += part_spmv[2 * i + 1];
     const double pAp = block_sum(a, red);
     const double yy = block_sum(b, red);
-    const double rr = first ? sc[1] : sum_partials(part_rr_in, np_rr, red);
+    const double rr = sum_partials(part_rr_in, np_rr, red);   // launch 0: seeded by k_krylov_init_fin
     const bool last = blockIdx.x == gridDim.x - 1 && threadIdx.x == 0;
-    if (!first && rr <= tol2 * sc[0]) {   // converged by the previous update: x, r stay as they are
+    if (rr <= tol2 * sc[0]) {   // converged by the previous update: x, r stay as they are
         if (last) sc[3] = rr, ctl[0] = 1;
         return;
     }

@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nx", type=int, default=119, help="cubes per axis of the C3 mesh (119 = BASELINE size)")
-    ap.add_argument("--cpu-nx", type=int, default=64, help="cubes per axis of the CPU-baseline sample")
+    ap.add_argument("--cpu-nx", type=int, default=96, help="cubes per axis of the CPU-baseline sample (~15 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--time-spmv", type=int, default=32,
                     help="SpMV launches per step timed with dispatch-attached HIP events (each costs a ~6 us bubble)")

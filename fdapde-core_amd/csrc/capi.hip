@@ -44,6 +44,10 @@ template <typename T> struct DBuf {
         if (p) (void)hipFree(p);
         p = nullptr, n = 0;
     }
+    DBuf() = default;
+    DBuf(const DBuf&) = delete;
+    DBuf& operator=(const DBuf&) = delete;
+    ~DBuf() { release(); }   // locals on an error return; context members are released explicitly before the context dies
 };
 
 // RCCL is loaded on first use (dlopen) so that single-GPU users and CPU-only boxes never need it
@@ -176,6 +180,9 @@ struct fdapde_ctx {
     // "factor once, solve many" handle (fdapde::SparseLU wrapper, utils/symbols.h:133-160)
     DBuf<double> lin_mat;                    // the matrix handed to fdapde_lin_compute, internal slots
     bool lin_ready = false, lin_symmetric = false;
+    DBuf<double> lin_sq;                     // full-pattern Jacobi-scaled copy of the handle's matrix (multi-RHS SpMM)
+    bool lin_sq_ready = false;
+    int multi_rhs = 1;                       // tuning knob: 0 = always solve the columns of fdapde_lin_solve one by one
     SolveStateHolder* lin_state = nullptr;
 };
 
@@ -714,7 +721,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
                                 &c->tmp_e, &c->tmp_i, &c->tmp_v})
             b->release();
         for (auto& b : c->coef) b.release();
-        c->slotw.release(), c->sl_off.release(), c->bnd.release(), c->tables.release(), c->reftab.release();
+        c->slotw.release(), c->sl_off.release(), c->bnd.release(), c->tables.release(), c->reftab.release(), c->lin_sq.release();
         c->bc_off.release(), c->bn_off.release(), c->bc_cell.release(), c->bn_node.release(), c->bc_vert.release();
         c->halo_dof.release(), c->halo_pos.release(), c->owned.release(), c->hbuf.release(), c->sbuf.release();
         c->halo_inv.release(), c->if_slot.release();
@@ -1390,6 +1397,72 @@ int fdapde_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_t
     return rc_all;
 }
 
+}   // extern "C"
+
+namespace {
+
+// Q columns of fdapde_lin_solve at once (kernels_multirhs.h): b_ext / x_ext are Q host columns of n, reference numbering
+template <int Q>
+int lin_solve_batch(fdapde_ctx* c, const double* b_ext, double* x_ext, double rtol, int maxit, int check_every, int* iters,
+                    double* relres, bool* converged) {
+    const HostSpace& hs = c->hs;
+    const int64_t n = hs.n_dofs;
+    hipStream_t st = c->stream;
+    const double tol2 = rtol * rtol;
+    DBuf<double> B, X, R, P, Y, part_spmm, part_rr, sc;
+    const size_t nq = (size_t)n * Q;
+    for (DBuf<double>* b : {&B, &X, &R, &P, &Y}) HIPCHK(c, b->alloc(nq));
+    const int64_t nh = n * (Q / 2);
+    const int grid_v = (int)std::min<int64_t>(std::max<int64_t>(1, (nh + 256 * kQV - 1) / (256 * kQV)), 1024);
+    const int grid_m = (int)std::min<int64_t>((n + 31) / 32, 2048);
+    HIPCHK(c, part_spmm.alloc((size_t)grid_m * 2 * Q));
+    HIPCHK(c, part_rr.alloc((size_t)grid_v * Q));
+    HIPCHK(c, sc.alloc(5 * Q));
+    HIPCHK(c, hipMemcpyAsync(B.p, b_ext, sizeof(double) * nq, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_q_init<Q>, dim3(grid_v), dim3(256), 0, st, n, B.p, c->dof_i2e.p, c->scale.p, X.p, R.p, P.p, part_rr.p);
+    hipLaunchKernelGGL(k_q_init_fin<Q>, dim3(1), dim3(256), 0, st, part_rr.p, grid_v, sc.p, c->ctl.p);
+    int launched = 0;
+    bool stop = false;
+    std::vector<double> h_sc(5 * Q);
+    while (!stop && launched < maxit) {
+        const int chunk = (maxit - launched) < check_every ? (maxit - launched) : check_every;
+        for (int it = 0; it < chunk; ++it, ++launched) {
+            hipLaunchKernelGGL(k_spmm_full<Q>, dim3(grid_m), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, c->lin_sq.p, P.p, Y.p,
+                               part_spmm.p, c->ctl.p);
+            hipLaunchKernelGGL(k_q_scalars<Q>, dim3(1), dim3(256), 0, st, part_spmm.p, grid_m, part_rr.p, grid_v, sc.p, tol2, c->ctl.p);
+            hipLaunchKernelGGL(k_q_update<Q>, dim3(grid_v), dim3(256), 0, st, n, Y.p, P.p, X.p, R.p, sc.p, part_rr.p, c->ctl.p);
+        }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        stop = c->h_ctl[0] != 0;
+    }
+    if (!stop) {   // maxit: one more scalar pass so that sc holds the r.r of the last update
+        hipLaunchKernelGGL(k_spmm_full<Q>, dim3(grid_m), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, c->lin_sq.p, P.p, Y.p, part_spmm.p,
+                           c->ctl.p);
+        hipLaunchKernelGGL(k_q_scalars<Q>, dim3(1), dim3(256), 0, st, part_spmm.p, grid_m, part_rr.p, grid_v, sc.p, tol2, c->ctl.p);
+    }
+    hipLaunchKernelGGL(k_q_unscale<Q>, dim3(g1(n)), dim3(256), 0, st, n, X.p, c->scale.p, c->dof_i2e.p, B.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(x_ext, B.p, sizeof(double) * nq, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(h_sc.data(), sc.p, sizeof(double) * 5 * Q, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    *iters = c->h_ctl[1], *converged = c->h_ctl[2] == 0, *relres = 0;
+    for (int q = 0; q < Q; ++q) {
+        const double bb = h_sc[(size_t)q], rr = h_sc[(size_t)Q + q];
+        const double rel = bb > 0 ? sqrt(rr / bb) : 0.0;
+        *relres = rel > *relres ? rel : *relres;
+        if (!(rr <= tol2 * bb)) *converged = false;
+    }
+    for (DBuf<double>* b : {&B, &X, &R, &P, &Y, &part_spmm, &part_rr, &sc}) b->release();
+    return FDAPDE_OK;
+}
+
+}   // namespace
+
+extern "C" {
+
 // fdapde::SparseLU<SpMatrix<double>>::compute (fdaPDE/utils/symbols.h:142-146): "factorise" once.  Here: copy the matrix,
 // Jacobi-scale it once; every later fdapde_lin_solve is a Krylov run on the prepared system.
 int fdapde_lin_compute(fdapde_ctx* c, int32_t which, const double* values, int32_t symmetric) {
@@ -1411,7 +1484,7 @@ int fdapde_lin_compute(fdapde_ctx* c, int32_t which, const double* values, int32
     }
     if (!c->lin_state) c->lin_state = new SolveStateHolder();
     if (int rc = solve_prepare(c, c->lin_mat.p, 0, &c->lin_state->ss)) return rc;
-    c->lin_ready = true, c->solved = false;   // scale / sval now belong to the handle
+    c->lin_ready = true, c->solved = false, c->lin_sq_ready = false;   // scale / sval now belong to the handle
     return FDAPDE_OK;
 }
 
@@ -1432,14 +1505,40 @@ int fdapde_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, 
         method = (c->lin_symmetric && c->lin_state->ss.diag_positive) ? FDAPDE_SOLVER_CG_FUSED : FDAPDE_SOLVER_BICGSTAB;
     if (c->solved) {   // an fdapde_solve in between has overwritten the scaled copy: prepare again (cheap)
         if (int rc = solve_prepare(c, c->lin_mat.p, 0, &c->lin_state->ss)) return rc;
-        c->solved = false;
+        c->solved = false, c->lin_sq_ready = false;
     }
     DBuf<double> rhs;
     HIPCHK(c, rhs.alloc((size_t)n));
     HIPCHK(c, hipEventRecord(c->ev0, st));
     int total = 0, rc_all = FDAPDE_OK;
     double worst = 0;
-    for (int32_t j = 0; j < n_rhs; ++j) {
+    int32_t j0 = 0;
+    // several columns against a symmetric positive system on one GPU: batches of 8 / 4 / 2 columns share every pass over the
+    // matrix (kernels_multirhs.h); what is left goes column by column
+    const bool batched = c->multi_rhs && n_rhs >= 2 && method == FDAPDE_SOLVER_CG_FUSED && !c->lin_state->ss.dist;
+    if (batched) {
+        if (!c->lin_sq_ready) {   // full-pattern scaled copy (explicit unit diagonal), once per prepared matrix
+            HIPCHK(c, c->lin_sq.alloc((size_t)hs.nnz + 2));
+            hipLaunchKernelGGL(k_scale_matrix, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, c->lin_mat.p, c->scale.p,
+                               c->lin_sq.p);
+            c->lin_sq_ready = true;
+        }
+        while (n_rhs - j0 >= 2) {
+            const int q = n_rhs - j0 >= 8 ? 8 : (n_rhs - j0 >= 4 ? 4 : 2);
+            int its = 0, rc = FDAPDE_OK;
+            double rel = 0;
+            bool ok = true;
+            if (q == 8) rc = lin_solve_batch<8>(c, b + (size_t)j0 * n, x + (size_t)j0 * n, rtol, maxit, check_every, &its, &rel, &ok);
+            else if (q == 4) rc = lin_solve_batch<4>(c, b + (size_t)j0 * n, x + (size_t)j0 * n, rtol, maxit, check_every, &its, &rel, &ok);
+            else rc = lin_solve_batch<2>(c, b + (size_t)j0 * n, x + (size_t)j0 * n, rtol, maxit, check_every, &its, &rel, &ok);
+            if (rc != FDAPDE_OK) return rc;
+            if (!ok) rc_all = FDAPDE_ENOCONV;
+            total += its, worst = rel > worst ? rel : worst;
+            c->info.method_used = method;
+            j0 += q;
+        }
+    }
+    for (int32_t j = j0; j < n_rhs; ++j) {
         HIPCHK(c, hipMemcpyAsync(c->tmp_e.p, b + (size_t)j * n, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_gather_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->tmp_e.p, rhs.p);
         const int rc = solve_run(c, c->lin_state->ss, c->lin_mat.p, rhs.p, c->g.p, nullptr, method, rtol, maxit, check_every, 0);
@@ -1804,6 +1903,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "spmv_deep" && (value == 0 || value == 1)) c->spmv_deep = value;
     else if (k == "cgf_v" && (value == 1 || value == 2 || value == 4 || value == 8)) c->cgf_v = value;
     else if (k == "use_graph" && (value == 0 || value == 1)) c->use_graph = value;
+    else if (k == "multi_rhs" && (value == 0 || value == 1)) c->multi_rhs = value;
     else if (k == "spmv_bpx" && value >= 1 && value <= 1024) {
         c->spmv_grid = 8 * value;
         HIPCHK(c, hipSetDevice(c->device));

@@ -16,6 +16,7 @@
 //   kernels_reduce.h    deterministic reductions (wavefront, workgroup, DPP team sums)
 //   kernels_spmv.h      CSR SpMV forms fused with the Krylov dot products
 //   kernels_krylov.h    Jacobi scaling, CG / BiCGStab vector kernels, multi-GPU interface exchange, numbering changes
+//   kernels_multirhs.h  Q right-hand sides at once against one prepared system (SpMM + batched fused-update CG)
 #ifndef FDAPDE_KERNELS_H
 #define FDAPDE_KERNELS_H
 
@@ -23,5 +24,6 @@
 #include "kernels_reduce.h"
 #include "kernels_spmv.h"
 #include "kernels_krylov.h"
+#include "kernels_multirhs.h"
 
 #endif

@@ -476,3 +476,34 @@ def test_partial_dirichlet_boundary_and_solver_prepare(capi, ctx, oracle, mesh_l
     ref = spla.spsolve(A.tocsc(), b)
     assert np.linalg.norm(ctx.solution() - ref) / np.linalg.norm(ref) <= SOL_TOL
     ctx.dofs_set_boundary(bnd)   # module-scoped context: restore the reference's mask
+
+
+@pytest.mark.parametrize("mesh_name,order,n_rhs", [("unit_square", 1, 15), ("unit_sphere", 2, 6), ("unit_square_32", 2, 2)])
+def test_multi_rhs_batches_match_column_by_column(capi, ctx, oracle, mesh_loader, mesh_name, order, n_rhs):
+    """fdapde_lin_solve with several columns (SMW's A^-1 U): batches of 8 / 4 / 2 columns share the matrix stream
+    (kernels_multirhs.h); same solutions as the column-by-column path and as a direct solve"""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+
+    m = mesh_loader(mesh_name)
+    ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = ctx.dofs_build(order)
+    ctx.set_operator(-capi.laplacian() + capi.reaction(1.5))
+    ctx.set_forcing(np.zeros(ctx.sizes()["n_quadrature"] * m.n_cells))
+    ctx.init()
+    ctx.lin_compute(capi.MAT_STIFF, symmetric=True)
+    rng = np.random.default_rng(3)
+    B = rng.standard_normal((nd, n_rhs))
+    B[:, -1] = 0.0                                   # a zero column converges at once and must not disturb the others
+    rp, ci = ctx.pattern_get()
+    A = sp.csr_matrix((ctx.matrix_values(capi.MAT_STIFF), ci, rp), shape=(nd, nd)).tocsc()
+    ref = spla.splu(A).solve(B)
+    ctx.tune("multi_rhs", 1)
+    X1, i1 = ctx.lin_solve(B, rtol=1e-12)
+    ctx.tune("multi_rhs", 0)
+    X0, i0 = ctx.lin_solve(B, rtol=1e-12)
+    ctx.tune("multi_rhs", 1)
+    assert i1.converged == 1 and i0.converged == 1
+    scale = np.linalg.norm(ref, axis=0).max()
+    assert np.abs(X1 - ref).max() <= 1e-8 * scale and np.abs(X0 - ref).max() <= 1e-8 * scale
+    assert np.all(X1[:, -1] == 0.0)

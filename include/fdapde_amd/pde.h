@@ -29,6 +29,8 @@
 #include <array>
 #include <cstdint>
 #include <functional>
+#include <algorithm>
+#include <optional>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
@@ -208,6 +210,12 @@ template <typename Tag = FEM_HIP> DifferentialExpr advection(const DMatrix<doubl
 template <typename Tag = FEM_HIP> DifferentialExpr diffusion(const DMatrix<double>& K_q) { return detail::leaf(FDAPDE_DIFFUSION, nullptr, 0, &K_q); }
 
 // ---- PDE ---------------------------------------------------------------------------------------------------------------
+// what PDE__::eval_basis returns (pde/pde.h:148)
+struct EvalReturnType {
+    SpMatrix<double> Psi;
+    DVector<double> D;
+};
+
 template <typename D, typename E, typename F, typename S, typename... Ts> class PDE;
 
 template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_HIP, fem_order<R>> {
@@ -349,6 +357,58 @@ template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_H
     };
     SparseSolver make_solver() { return SparseSolver(ctx_); }
     fdapde_ctx* context() const { return ctx_; }   // the C-ABI context (for entry points the facade does not wrap)
+
+    // PDE__::eval_basis (pde/pde.h:149-158): 0 = Sampling::pointwise (locs: n_locs x N coordinates), 1 = Sampling::areal (locs:
+    // n_subdomains x n_cells incidence matrix of 0 / 1).  Psi rows have sorted columns; duplicates are summed like setFromTriplets.
+    using EvalReturnType = fdapde::amd::EvalReturnType;
+    std::optional<EvalReturnType> eval_basis(int eval_type, const DMatrix<double>& locs) const {
+        if (eval_type != 0 && eval_type != 1) return std::nullopt;
+        const int64_t nc = domain_.cells().rows(), nb = dofs_.cols();
+        std::vector<std::vector<std::pair<int32_t, double>>> rows;
+        EvalReturnType out;
+        if (eval_type == 0) {   // pointwise_evaluation::eval (lagrangian_basis.h:203-235)
+            const int64_t nl = locs.rows();
+            std::vector<int32_t> cell((size_t)nl);
+            std::vector<double> val((size_t)(nl * nb));
+            check(fdapde_eval_pointwise(ctx_, nl, locs.data(), cell.data(), val.data()));
+            rows.resize((size_t)nl);
+            out.D = DVector<double>(nl, 1, 1.0);
+            for (int64_t i = 0; i < nl; ++i) {
+                if (cell[(size_t)i] < 0) continue;   // outside the domain: empty row
+                for (int64_t h = 0; h < nb; ++h) rows[(size_t)i].push_back({dofs_(cell[(size_t)i], h), val[(size_t)(i * nb + h)]});
+            }
+        } else {   // areal_evaluation::eval (lagrangian_basis.h:238-283)
+            if (locs.cols() != nc) throw std::runtime_error("eval_basis: the incidence matrix needs one column per cell");
+            const int64_t ns = locs.rows();
+            std::vector<double> meas((size_t)nc), pint((size_t)(nc * nb));
+            check(fdapde_cell_integrals(ctx_, meas.data(), pint.data()));
+            rows.resize((size_t)ns);
+            out.D = DVector<double>(ns, 1, 0.0);
+            for (int64_t k = 0; k < ns; ++k) {
+                for (int64_t e = 0; e < nc; ++e)
+                    if (locs(k, e) == 1.0) {
+                        out.D(k) += meas[(size_t)e];
+                        for (int64_t h = 0; h < nb; ++h) rows[(size_t)k].push_back({dofs_(e, h), pint[(size_t)(e * nb + h)]});
+                    }
+                for (auto& cv : rows[(size_t)k]) cv.second /= out.D(k);
+            }
+        }
+        SpMatrix<double>& P = out.Psi;
+        P.n_rows = (int64_t)rows.size(), P.n_cols = n_dofs_;
+        P.rowptr.assign(rows.size() + 1, 0);
+        for (size_t i = 0; i < rows.size(); ++i) {
+            auto& r = rows[i];
+            std::stable_sort(r.begin(), r.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+            for (size_t k = 0; k < r.size(); ++k) {
+                if (k > 0 && r[k].first == r[k - 1].first)
+                    P.values.back() += r[k].second;   // same DOF reached through several cells of a subdomain
+                else
+                    P.colidx.push_back(r[k].first), P.values.push_back(r[k].second);
+            }
+            P.rowptr[i + 1] = (int32_t)P.colidx.size();
+        }
+        return out;
+    }
 
    private:
     // FEMLinearParabolicSolver::solve (fem_linear_parabolic_solver.h:37-72)

@@ -3,6 +3,7 @@
 // read back through stiff().  Same meshes, same exact solutions, same gates.  Runs on a real MI355X (pytest -m gpu).
 //
 // usage: fem_pde_test <path to tests/golden/mesh>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <fstream>
@@ -330,6 +331,79 @@ TEST(linear_algebra_test, smw_and_lumping) {
     EXPECT_TRUE(worst < 1e-15);
 }
 
+// PDE__::eval_basis (pde/pde.h:149-158) against the reference's golden matrices (test/src/lagrangian_basis_test.cpp:190-260):
+// pointwise evaluation at c_shaped/locs.csv, areal evaluation with quasi_circle/incidence_matrix.csv, orders 1 and 2
+static SpMatrix<double> read_mtx(const std::string& file) {
+    std::ifstream in(file);
+    if (!in) throw std::runtime_error("cannot open " + file);
+    std::string line;
+    do { std::getline(in, line); } while (!line.empty() && line[0] == '%');
+    std::istringstream hdr(line);
+    int64_t nr, nc, nz;
+    hdr >> nr >> nc >> nz;
+    std::vector<std::vector<std::pair<int32_t, double>>> rows((size_t)nr);
+    for (int64_t k = 0; k < nz; ++k) {
+        int64_t i, j;
+        double v;
+        in >> i >> j >> v;
+        rows[(size_t)i - 1].push_back({(int32_t)(j - 1), v});
+    }
+    SpMatrix<double> m;
+    m.n_rows = nr, m.n_cols = nc, m.rowptr.assign((size_t)nr + 1, 0);
+    for (int64_t i = 0; i < nr; ++i) {
+        std::sort(rows[(size_t)i].begin(), rows[(size_t)i].end());
+        for (auto& cv : rows[(size_t)i]) m.colidx.push_back(cv.first), m.values.push_back(cv.second);
+        m.rowptr[(size_t)i + 1] = (int32_t)m.colidx.size();
+    }
+    return m;
+}
+static double max_abs_diff(const SpMatrix<double>& a, const SpMatrix<double>& b) {   // as dense matrices (explicit zeros may differ)
+    if (a.rows() != b.rows() || a.cols() != b.cols()) return 1e300;
+    double worst = 0;
+    for (int64_t i = 0; i < a.rows(); ++i) {
+        for (int32_t k = a.rowptr[(size_t)i]; k < a.rowptr[(size_t)i + 1]; ++k)
+            worst = std::fmax(worst, std::fabs(a.values[(size_t)k] - b.coeff(i, a.colidx[(size_t)k])));
+        for (int32_t k = b.rowptr[(size_t)i]; k < b.rowptr[(size_t)i + 1]; ++k)
+            worst = std::fmax(worst, std::fabs(b.values[(size_t)k] - a.coeff(i, b.colidx[(size_t)k])));
+    }
+    return worst;
+}
+template <int R> static void eval_basis_case() {
+    const std::string mtx = MESH_PATH + "/../mtx/";
+    {
+        MeshLoader<2, 2> m("c_shaped");
+        auto L = -laplacian<FEM_HIP>();
+        PDE<Triangulation<2, 2>, decltype(L), DMatrix<double>, FEM_HIP, fem_order<R>> pde_(m.mesh, L);
+        DMatrix<double> locs = read_csv<double>(MESH_PATH + "/c_shaped/locs.csv");
+        auto res = pde_.eval_basis(0, locs);
+        EXPECT_TRUE(res.has_value());
+        SpMatrix<double> gold = read_mtx(mtx + "lagrangian_pointwise_eval_order" + std::to_string(R) + ".mtx");
+        EXPECT_TRUE(max_abs_diff(res->Psi, gold) < 1e-12);
+        EXPECT_TRUE(res->D.rows() == locs.rows() && res->D(0) == 1.0);
+        EXPECT_TRUE(!pde_.eval_basis(7, locs).has_value());
+    }
+    {
+        MeshLoader<2, 2> m("quasi_circle");
+        auto L = -laplacian<FEM_HIP>();
+        PDE<Triangulation<2, 2>, decltype(L), DMatrix<double>, FEM_HIP, fem_order<R>> pde_(m.mesh, L);
+        DMatrix<int> inc_i = read_csv<int>(MESH_PATH + "/quasi_circle/incidence_matrix.csv");
+        DMatrix<double> inc(inc_i.rows(), inc_i.cols());
+        for (int64_t i = 0; i < inc.rows(); ++i)
+            for (int64_t j = 0; j < inc.cols(); ++j) inc(i, j) = inc_i(i, j);
+        auto res = pde_.eval_basis(1, inc);
+        EXPECT_TRUE(res.has_value());
+        SpMatrix<double> gold = read_mtx(mtx + "lagrangian_areal_eval_order" + std::to_string(R) + ".mtx");
+        EXPECT_TRUE(max_abs_diff(res->Psi, gold) < 1e-12);
+        double area = 0;
+        for (int64_t k = 0; k < res->D.rows(); ++k) area += res->D(k);
+        EXPECT_TRUE(area > 0);
+    }
+}
+TEST(lagrangian_basis_test, eval_basis_golden) {
+    eval_basis_case<1>();
+    eval_basis_case<2>();
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) { std::printf("usage: %s <tests/golden/mesh>\n", argv[0]); return 2; }
     MESH_PATH = argv[1];
@@ -344,6 +418,7 @@ int main(int argc, char** argv) {
     RUN(fem_pde_test, parabolic_isotropic_order2);
     RUN(sparse_solver_test, factor_once_solve_many);
     RUN(linear_algebra_test, smw_and_lumping);
+    RUN(lagrangian_basis_test, eval_basis_golden);
     std::printf("%d checks, %d failures\n", checks, failures);
     return failures == 0 ? 0 : 1;
 }

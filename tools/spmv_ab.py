@@ -7,11 +7,12 @@ load_package()
 from fdapde_core_amd import capi, meshgen
 nx = int(os.environ.get("NX", "119"))
 ctx = capi.Context(0)
-ctx.mesh_upload(*meshgen.unit_cube(nx))
+dim = int(os.environ.get("DIM", "3"))
+ctx.mesh_upload(*(meshgen.unit_cube(nx) if dim == 3 else meshgen.unit_square(nx)))
 ctx.dofs_build(int(os.environ.get("ORDER", "1")))
 ctx.assemble_operator(capi.MAT_STIFF, -capi.laplacian())
 if os.environ.get("SOLVE"):      # time the solver's compact Jacobi-scaled matrix (what CG streams) instead of stiff()
-    u_exact, f = meshgen.manufactured(3)
+    u_exact, f = meshgen.manufactured(dim)
     ctx.set_operator(-capi.laplacian()); ctx.set_forcing(f(ctx.quadrature_nodes())); ctx.set_dirichlet(np.zeros(ctx.sizes()["n_dofs"]))
     ctx.init(); print("solve:", ctx.solve(rtol=1e-10).iters, "iterations")
 configs = [dict(c.split("=") for c in a.split(",")) for a in sys.argv[1:]] or [{"spmv_variant": "2"}]

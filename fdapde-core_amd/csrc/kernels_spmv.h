@@ -504,20 +504,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
                 ++n_def;
             } else if constexpr (!(ABL & (8 | 32))) {
                 if constexpr (FULL) {
-                    if constexpr (ABL & 128)
-                        __builtin_nontemporal_store(out, s.y + row);
-                    else if constexpr (ABL & 256)
-                        s.y[row & 4095] = out;   // diagnostic: same store instruction stream, 32 KiB footprint
-                    else if constexpr (ABL & 512) {   // 16 B per lane: lanes 0..WROWS/2-1 store row pairs
-                        const int j = lane % (WROWS / 2);
-                        const double2 o2 = make_double2(ys[2 * j], ys[2 * j + 1]);
-                        *reinterpret_cast<double2*>(s.y + base + 2 * j) = o2;
-                    } else if constexpr (ABL & 1024) {
-                        // agent-scope relaxed store = global_store ... sc1: written through, the line is not kept in this
-                        // XCD's L2 (MI355X_MICROARCH.md, stores of each flavour), leaving the L2 to the gathered x
-                        __hip_atomic_store(s.y + row, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    } else
-                        s.y[row] = out;
+                    // store flavours measured and dropped (all within noise of the plain store): nontemporal, write-through
+                    // (sc1), 16 bytes per lane, stores confined to 32 KiB
+                    s.y[row] = out;
                 } else {
                     if (row_ok) s.y[row] = out;
                 }

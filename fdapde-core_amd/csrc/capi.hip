@@ -574,6 +574,7 @@ void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, 
                 if (c16 && (rpb / 32 + (int64_t)(c->spmv_grid / 8) * 4 - 1) / ((int64_t)(c->spmv_grid / 8) * 4) <= 8)
                     SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 32768>);
                 break;
+            case 150: if (c16) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 262144>); break;   // window bases as a 16-byte broadcast load (the form before)
             case 102: if (c16) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 2>); break;       // gathers inside 16 lines
             case 103: if (c16) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 65536>); break;   // gathers inside 1 line
             case 2048: SPMV_GO(k_spmv_team2<8, 4, 2048>); break;   // aligned pairs, 32-bit columns

@@ -160,6 +160,7 @@ struct fdapde_ctx {
     int use_graph = 0;                       // tuning knob: replay full chunks of the fused-update CG as one hipGraph
     hipGraphExec_t cg_graph_exec = nullptr;
     GraphKey cg_graph_key{};
+    int cgf_band = 1;                        // tuning knob: XCD-aware mapping + nontemporal x / r / y in k_cgf_update (C3 solve 41.80 -> 41.10 ms)
     int cgf_v = 8;                           // double2 elements per lane of k_cgf_update (1, 2, 4, 8); C3 solve: 47.2 / 41.8 / 41.3 / 40.9 ms
     int spmv_deep = 0;                       // tuning knob: 1 = k_spmv_c16p (gathers one tile ahead; measured slower: 3 waves / SIMD)
     int64_t sp_nnz[2] = {0, 0};
@@ -1103,7 +1104,10 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
         hipLaunchKernelGGL(k_krylov_init_fin, dim3(1), dim3(256), 0, st, c->sbuf.p, 1, c->sc.p, c->ctl.p, tol2, (double*)nullptr, 0);
     } else {
         // fused-update CG: its launch 0 reads the explicit r.r from the second half of part_b (seeded here)
-        const int V = c->cgf_v, cg = (int)(((n >> 1) + 256 * V - 1) / (256 * V)) > 0 ? (int)(((n >> 1) + 256 * V - 1) / (256 * V)) : 1;
+        const int V = c->cgf_v;
+        const int64_t b2 = c->cgf_band ? (((((n + 7) / 8) + 31) & ~int64_t(31)) >> 1) : 0, span = b2 > 0 ? b2 : (n >> 1);
+        const int per = (int)((span + 256 * V - 1) / (256 * V)) > 0 ? (int)((span + 256 * V - 1) / (256 * V)) : 1;
+        const int cg = b2 > 0 ? 8 * per : per;
         hipLaunchKernelGGL(k_krylov_init_fin, dim3(1), dim3(256), 0, st, c->part_b.p, c->vec_grid, c->sc.p, c->ctl.p, tol2,
                            cgf ? c->part_b.p + cg : (double*)nullptr, cgf ? cg : 0);
     }
@@ -1122,13 +1126,18 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     bool stop = false;
     // one iteration of the fused-update CG: SpMV (p.y, y.y) + k_cgf_update; arguments depend on the iteration's parity only
     const int cgf_V = c->cgf_v;
-    const int cgf_grid = (int)(((n >> 1) + 256 * cgf_V - 1) / (256 * cgf_V)) > 0 ? (int)(((n >> 1) + 256 * cgf_V - 1) / (256 * cgf_V)) : 1;
+    // XCD-aware mapping of the update kernel (knob cgf_band): workgroup b serves the elements of SpMV row band b % 8
+    const int64_t cgf_band2 = c->cgf_band ? (((((n + 7) / 8) + 31) & ~int64_t(31)) >> 1) : 0;
+    const int64_t cgf_span = cgf_band2 > 0 ? cgf_band2 : (n >> 1);
+    const int cgf_per = (int)((cgf_span + 256 * cgf_V - 1) / (256 * cgf_V)) > 0 ? (int)((cgf_span + 256 * cgf_V - 1) / (256 * cgf_V)) : 1;
+    const int cgf_grid = cgf_band2 > 0 ? 8 * cgf_per : cgf_per;
     auto enqueue_cgf = [&](int it, hipEvent_t e0, hipEvent_t e1) {
         const int cg = cgf_grid;
         launch_spmv(c, c->sval.p, c->p.p, c->y.p, c->p.p, c->part_a.p, c->ctl.p, e0, e1);   // p.y and y.y
 #define CGF_GO(V_)                                                                                                         \
     hipLaunchKernelGGL(k_cgf_update<V_>, dim3(cg), dim3(256), 0, st, n, c->y.p, c->p.p, c->x.p, c->r.p, c->part_a.p, c->spmv_grid, \
-                       c->part_b.p + (size_t)((it + 1) & 1) * cg, cg, c->part_b.p + (size_t)(it & 1) * cg, c->sc.p, tol2, c->ctl.p)
+                       c->part_b.p + (size_t)((it + 1) & 1) * cg, cg, c->part_b.p + (size_t)(it & 1) * cg, c->sc.p, tol2, c->ctl.p, \
+                       cgf_band2)
         if (cgf_V == 1) CGF_GO(1);
         else if (cgf_V == 2) CGF_GO(2);
         else if (cgf_V == 8) CGF_GO(8);
@@ -1904,6 +1913,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "spmv_deep" && (value == 0 || value == 1)) c->spmv_deep = value;
     else if (k == "cgf_v" && (value == 1 || value == 2 || value == 4 || value == 8)) c->cgf_v = value;
     else if (k == "use_graph" && (value == 0 || value == 1)) c->use_graph = value;
+    else if (k == "cgf_band" && (value == 0 || value == 1)) c->cgf_band = value;
     else if (k == "multi_rhs" && (value == 0 || value == 1)) c->multi_rhs = value;
     else if (k == "spmv_bpx" && value >= 1 && value <= 1024) {
         c->spmv_grid = 8 * value;

@@ -290,22 +290,36 @@ __global__ __launch_bounds__(256) void k_cgsr_update(int64_t n, double* r, const
 // exact arithmetic (r.y = p.y by A-conjugacy) and is used for beta only, so that p needs no second pass after a global
 // reduction: 7 vector passes and 2 launches per iteration instead of 8 and 3.  The stop test is taken at the start of the
 // next launch (or by k_cgf_fin at a host poll) from the explicit r.r, uniformly by every workgroup.
+// band2 > 0 (XCD-aware form): workgroup b serves the double2 elements of SpMV row band b % 8 ([band * band2, (band + 1) * band2)),
+// so that the p it writes sits in the L2 of the XCD whose SpMV workgroups gather it next; y, x, r (not read by the SpMV) move
+// with nontemporal loads / stores.  band2 == 0: plain contiguous mapping.
 template <int kCgV>
 __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, double* p, double* x, double* r,
                                                      const double* part_spmv, int np_spmv, const double* part_rr_in, int np_rr,
-                                                     double* part_rr_out, double* sc, double tol2, int32_t* ctl) {
+                                                     double* part_rr_out, double* sc, double tol2, int32_t* ctl, int64_t band2) {
     __shared__ double red[8];
     if (__syncthreads_or(ctl[0] != 0)) return;
-    const int64_t n2 = n >> 1, i0 = (int64_t)blockIdx.x * (256 * kCgV) + threadIdx.x;
+    const int64_t n2_all = n >> 1;
+    const int64_t lo = band2 > 0 ? (int64_t)(blockIdx.x & 7) * band2 : 0;
+    const int64_t n2 = band2 > 0 ? min(n2_all, lo + band2) : n2_all;   // end of this workgroup's element range
+    const int64_t i0 = lo + (int64_t)(band2 > 0 ? (blockIdx.x >> 3) : blockIdx.x) * (256 * kCgV) + threadIdx.x;
     const double2* y2 = reinterpret_cast<const double2*>(y);
     double2* p2 = reinterpret_cast<double2*>(p);
     double2* x2 = reinterpret_cast<double2*>(x);
     double2* r2 = reinterpret_cast<double2*>(r);
     double2 yv[kCgV], pv[kCgV], xv[kCgV], rv[kCgV];
+    typedef double v2f64k_t __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int k = 0; k < kCgV; ++k) {
         const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
-        yv[k] = y2[ic], pv[k] = p2[ic], xv[k] = x2[ic], rv[k] = r2[ic];
+        pv[k] = p2[ic];
+        if (band2 > 0) {
+            const v2f64k_t a_ = __builtin_nontemporal_load(reinterpret_cast<const v2f64k_t*>(y2 + ic));
+            const v2f64k_t b_ = __builtin_nontemporal_load(reinterpret_cast<const v2f64k_t*>(x2 + ic));
+            const v2f64k_t c_ = __builtin_nontemporal_load(reinterpret_cast<const v2f64k_t*>(r2 + ic));
+            yv[k] = make_double2(a_.x, a_.y), xv[k] = make_double2(b_.x, b_.y), rv[k] = make_double2(c_.x, c_.y);
+        } else
+            yv[k] = y2[ic], xv[k] = x2[ic], rv[k] = r2[ic];
     }
     double a = 0, b = 0;
     for (int i = threadIdx.x; i < np_spmv; i += blockDim.x) a += part_spmv[2 * i], b += part_spmv[2 * i + 1];
@@ -328,7 +342,12 @@ __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, 
             xv[k].x += alpha * pv[k].x, xv[k].y += alpha * pv[k].y;
             rv[k].x -= alpha * yv[k].x, rv[k].y -= alpha * yv[k].y;
             pv[k].x = rv[k].x + beta * pv[k].x, pv[k].y = rv[k].y + beta * pv[k].y;
-            x2[i] = xv[k], r2[i] = rv[k], p2[i] = pv[k];
+            if (band2 > 0) {
+                __builtin_nontemporal_store(v2f64k_t{xv[k].x, xv[k].y}, reinterpret_cast<v2f64k_t*>(x2 + i));
+                __builtin_nontemporal_store(v2f64k_t{rv[k].x, rv[k].y}, reinterpret_cast<v2f64k_t*>(r2 + i));
+            } else
+                x2[i] = xv[k], r2[i] = rv[k];
+            p2[i] = pv[k];
             acc += rv[k].x * rv[k].x + rv[k].y * rv[k].y;
         }
     }

@@ -576,6 +576,9 @@ void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, 
                     SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 32768>);
                 break;
             case 150: if (c16) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 262144>); break;   // window bases as a 16-byte broadcast load (the form before)
+            case 151: if (c16) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 524288>); break;             // nontemporal column codes
+            case 152: if (c16) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 524288 | 1048576>); break;   // + nontemporal values (the form before)
+            case 153: if (c16) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 1048576>); break;            // nontemporal values only
             case 102: if (c16) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 2>); break;       // gathers inside 16 lines
             case 103: if (c16) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 65536>); break;   // gathers inside 1 line
             case 2048: SPMV_GO(k_spmv_team2<8, 4, 2048>); break;   // aligned pairs, 32-bit columns

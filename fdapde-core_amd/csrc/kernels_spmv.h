@@ -300,13 +300,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
         const int kc = ALIGNED ? (k < last ? k : (last & ~1)) : (k < last ? k : last);
         F64x2 vv;
         I32x2 cc;
+        // Cache policy of the matrix stream: DEFAULT.  A wavefront's val / code load covers 8 rows, i.e. pieces of 128-byte lines
+        // that the next load of the same wavefront (the next 8 rows) completes; with the nontemporal hint the lines are not kept
+        // and get fetched again (C3, same box: both nontemporal 58.2 us, codes default 52.0, values default 45.2, both 45.3 us
+        // back-to-back; inside CG 40.6 / 37.3 / 33.9 / 32.7 ms per solve).  NT_V / NT_C re-enable the hint for measurements.
+        constexpr bool NT_V = (ABL & 1048576) != 0, NT_C = (ABL & 524288) != 0;
         if constexpr (C16) {
-            const v2f64_t a = __builtin_nontemporal_load(reinterpret_cast<const v2f64_t*>(s.vals + kc));
+            v2f64_t a;
+            if constexpr (NT_V)
+                a = __builtin_nontemporal_load(reinterpret_cast<const v2f64_t*>(s.vals + kc));
+            else
+                a = *reinterpret_cast<const v2f64_t*>(s.vals + kc);
             vv.x = a.x, vv.y = a.y;
-            cc.x = (int)__builtin_nontemporal_load(reinterpret_cast<const unsigned int*>(s.col16 + kc)), cc.y = 0;
+            if constexpr (NT_C)
+                cc.x = (int)__builtin_nontemporal_load(reinterpret_cast<const unsigned int*>(s.col16 + kc)), cc.y = 0;
+            else
+                cc.x = (int)*reinterpret_cast<const unsigned int*>(s.col16 + kc), cc.y = 0;
         } else if constexpr (ALIGNED) {
-            const v2f64_t a = __builtin_nontemporal_load(reinterpret_cast<const v2f64_t*>(s.vals + kc));
-            const v2i32_t b = __builtin_nontemporal_load(reinterpret_cast<const v2i32_t*>(s.colidx + kc));
+            const v2f64_t a = *reinterpret_cast<const v2f64_t*>(s.vals + kc);
+            const v2i32_t b = *reinterpret_cast<const v2i32_t*>(s.colidx + kc);
             vv.x = a.x, vv.y = a.y, cc.x = b.x, cc.y = b.y;
         } else if constexpr (!(ABL & 4)) {
             vv.x = __builtin_nontemporal_load(s.vals + kc), vv.y = __builtin_nontemporal_load(s.vals + kc + 1);

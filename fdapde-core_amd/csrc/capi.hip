@@ -160,6 +160,7 @@ struct fdapde_ctx {
     int use_graph = 0;                       // tuning knob: replay full chunks of the fused-update CG as one hipGraph
     hipGraphExec_t cg_graph_exec = nullptr;
     GraphKey cg_graph_key{};
+    int cgf_nt = 1;                          // tuning knob: nontemporal x / r / y in k_cgf_update
     int cgf_band = 1;                        // tuning knob: XCD-aware mapping + nontemporal x / r / y in k_cgf_update (C3 solve 41.80 -> 41.10 ms)
     int cgf_v = 8;                           // double2 elements per lane of k_cgf_update (1, 2, 4, 8); C3 solve: 47.2 / 41.8 / 41.3 / 40.9 ms
     int spmv_deep = 0;                       // tuning knob: 1 = k_spmv_c16p (gathers one tile ahead; measured slower: 3 waves / SIMD)
@@ -270,7 +271,9 @@ int upload_space(fdapde_ctx* c) {
     HIPCHK(c, c->force.alloc(n));
     c->n_rb = (int)hs.rb_row.size() - 1;
     c->rb_per_band = (c->n_rb + 7) / 8;
-    int bpx = c->rb_per_band < 256 ? c->rb_per_band : 256;
+    // workgroups per band: 192 (1536 workgroups = 1.5 rounds of the 1024 resident ones) measured best on C3 with the default cache
+    // policy (solve 33.0 ms at 256, 32.6 at 192, 33.5 at 160 / 224); smaller matrices get one workgroup per 4096 nonzeros
+    int bpx = c->rb_per_band < 192 ? c->rb_per_band : 192;
     if (bpx < 1) bpx = 1;
     {
         const char* v = std::getenv("FDAPDE_SPMV");
@@ -1140,7 +1143,7 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
 #define CGF_GO(V_)                                                                                                         \
     hipLaunchKernelGGL(k_cgf_update<V_>, dim3(cg), dim3(256), 0, st, n, c->y.p, c->p.p, c->x.p, c->r.p, c->part_a.p, c->spmv_grid, \
                        c->part_b.p + (size_t)((it + 1) & 1) * cg, cg, c->part_b.p + (size_t)(it & 1) * cg, c->sc.p, tol2, c->ctl.p, \
-                       cgf_band2)
+                       cgf_band2, c->cgf_nt)
         if (cgf_V == 1) CGF_GO(1);
         else if (cgf_V == 2) CGF_GO(2);
         else if (cgf_V == 8) CGF_GO(8);
@@ -1917,6 +1920,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "cgf_v" && (value == 1 || value == 2 || value == 4 || value == 8)) c->cgf_v = value;
     else if (k == "use_graph" && (value == 0 || value == 1)) c->use_graph = value;
     else if (k == "cgf_band" && (value == 0 || value == 1)) c->cgf_band = value;
+    else if (k == "cgf_nt" && (value == 0 || value == 1)) c->cgf_nt = value;
     else if (k == "multi_rhs" && (value == 0 || value == 1)) c->multi_rhs = value;
     else if (k == "spmv_bpx" && value >= 1 && value <= 1024) {
         c->spmv_grid = 8 * value;

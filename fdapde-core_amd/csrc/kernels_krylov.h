@@ -296,7 +296,8 @@ __global__ __launch_bounds__(256) void k_cgsr_update(int64_t n, double* r, const
 template <int kCgV>
 __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, double* p, double* x, double* r,
                                                      const double* part_spmv, int np_spmv, const double* part_rr_in, int np_rr,
-                                                     double* part_rr_out, double* sc, double tol2, int32_t* ctl, int64_t band2) {
+                                                     double* part_rr_out, double* sc, double tol2, int32_t* ctl, int64_t band2,
+                                                     int nt) {
     __shared__ double red[8];
     if (__syncthreads_or(ctl[0] != 0)) return;
     const int64_t n2_all = n >> 1;
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, 
     for (int k = 0; k < kCgV; ++k) {
         const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
         pv[k] = p2[ic];
-        if (band2 > 0) {
+        if (nt) {
             const v2f64k_t a_ = __builtin_nontemporal_load(reinterpret_cast<const v2f64k_t*>(y2 + ic));
             const v2f64k_t b_ = __builtin_nontemporal_load(reinterpret_cast<const v2f64k_t*>(x2 + ic));
             const v2f64k_t c_ = __builtin_nontemporal_load(reinterpret_cast<const v2f64k_t*>(r2 + ic));
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, 
             xv[k].x += alpha * pv[k].x, xv[k].y += alpha * pv[k].y;
             rv[k].x -= alpha * yv[k].x, rv[k].y -= alpha * yv[k].y;
             pv[k].x = rv[k].x + beta * pv[k].x, pv[k].y = rv[k].y + beta * pv[k].y;
-            if (band2 > 0) {
+            if (nt) {
                 __builtin_nontemporal_store(v2f64k_t{xv[k].x, xv[k].y}, reinterpret_cast<v2f64k_t*>(x2 + i));
                 __builtin_nontemporal_store(v2f64k_t{rv[k].x, rv[k].y}, reinterpret_cast<v2f64k_t*>(r2 + i));
             } else

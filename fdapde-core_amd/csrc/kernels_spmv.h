@@ -607,11 +607,11 @@ __global__ __launch_bounds__(256) void k_spmv_c16p(SpmvArgs s, int64_t n, int64_
         return k < last ? k : (last & ~1);
     };
     auto load_codes = [&](int rs) -> unsigned int {
-        return __builtin_nontemporal_load(reinterpret_cast<const unsigned int*>(s.col16 + pair_at(rs)));
+        return *reinterpret_cast<const unsigned int*>(s.col16 + pair_at(rs));
     };
     auto load_vals = [&](int rs, int re, F64x2& v) {
         const int k = (rs & ~1) + 2 * l;
-        const v2f64_t a = __builtin_nontemporal_load(reinterpret_cast<const v2f64_t*>(s.vals + pair_at(rs)));
+        const v2f64_t a = *reinterpret_cast<const v2f64_t*>(s.vals + pair_at(rs));
         v.x = (k >= rs && k < re) ? a.x : 0.0, v.y = (k + 1 < re) ? a.y : 0.0;
     };
     auto decode = [&](unsigned int code, const v4i32_t& tb) -> int {

@@ -304,7 +304,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
         // that the next load of the same wavefront (the next 8 rows) completes; with the nontemporal hint the lines are not kept
         // and get fetched again (C3, same box: both nontemporal 58.2 us, codes default 52.0, values default 45.2, both 45.3 us
         // back-to-back; inside CG 40.6 / 37.3 / 33.9 / 32.7 ms per solve).  NT_V / NT_C re-enable the hint for measurements.
-        constexpr bool NT_V = (ABL & 1048576) != 0, NT_C = (ABL & 524288) != 0;
+        // Teams of 16+ lanes (rows of 32+ entries, P2) read whole lines per row and keep the hint (C5-size matrix, same box: both
+        // nontemporal 361.6 us, both default 371.5 us).
+        constexpr bool NT_V = ((ABL & 1048576) != 0) != (T >= 16), NT_C = ((ABL & 524288) != 0) != (T >= 16);
         if constexpr (C16) {
             v2f64_t a;
             if constexpr (NT_V)

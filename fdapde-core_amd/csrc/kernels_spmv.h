@@ -246,11 +246,14 @@ typedef __attribute__((address_space(3))) volatile double lds_vf64_t;
 struct __attribute__((packed, aligned(8))) F64x2 { double x, y; };
 struct __attribute__((packed, aligned(4))) I32x2 { int x, y; };
 
-// ABL (diagnostic builds only, selected by FDAPDE_SPMV_ABLATE; results are wrong on purpose):
-//   1: no x gather (colidx still loaded and consumed)   2: gather confined to a 2 KiB window of x
-//   4: plain (default cache policy) val / colidx loads instead of nontemporal ones (results stay correct)
-// The matrix arrays are read exactly once per launch and are larger than the 256 MiB Infinity Cache, so they are
-// loaded nontemporal (interleaved A/B in one process: 69.4 us vs 70.7 us with default-policy loads on C3).
+// ABL: bit set of layout / instantiation flags (2048 aligned pairs, 4096 16-bit column codes, 8192 multi-GPU ownership loads,
+// 16384 dot operand == x, 131072 segmented rows) and of diagnostic switches selected by FDAPDE_SPMV_ABLATE / fdapde_tune (results
+// of 1, 2, 8, 32, 64, 65536 are wrong on purpose):
+//   1: no x gather   2 / 65536: gathers confined to 16 lines / 1 line   8, 32, 64: no y store / no w load   16: no XCD banding
+//   4: the oldest (unaligned) pair form with default-policy loads   32768: y kept in LDS until the tile loop ends
+//   262144: window bases as a 16-byte broadcast load   524288 / 1048576: flip the cache policy of the codes / values
+// Cache policy of the matrix stream: see load_pair (default for teams of <= 8 lanes, nontemporal for wider teams; the oldest
+// unaligned form still carries the hint it was tuned with: 69.4 us against 70.7 us default at the time).
 template <int T, int U, int ABL = 0, int OCC = 4>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) void k_spmv_team2(SpmvArgs s, int64_t n,
                                                                                               int64_t rows_per_band) {

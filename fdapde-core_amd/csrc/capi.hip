@@ -160,7 +160,7 @@ struct fdapde_ctx {
     int use_graph = 0;                       // tuning knob: replay full chunks of the fused-update CG as one hipGraph
     hipGraphExec_t cg_graph_exec = nullptr;
     GraphKey cg_graph_key{};
-    int cgf_nt = 1;                          // tuning knob: nontemporal x / r / y in k_cgf_update
+    int cgf_nt = 7;                          // tuning knob, bit set: nontemporal y (1), x (2), r (4), p load (8) in k_cgf_update
     int cgf_band = 1;                        // tuning knob: XCD-aware mapping + nontemporal x / r / y in k_cgf_update (C3 solve 41.80 -> 41.10 ms)
     int cgf_v = 8;                           // double2 elements per lane of k_cgf_update (1, 2, 4, 8); C3 solve: 47.2 / 41.8 / 41.3 / 40.9 ms
     int spmv_deep = 0;                       // tuning knob: 1 = k_spmv_c16p (gathers one tile ahead; measured slower: 3 waves / SIMD)
@@ -1920,7 +1920,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "cgf_v" && (value == 1 || value == 2 || value == 4 || value == 8)) c->cgf_v = value;
     else if (k == "use_graph" && (value == 0 || value == 1)) c->use_graph = value;
     else if (k == "cgf_band" && (value == 0 || value == 1)) c->cgf_band = value;
-    else if (k == "cgf_nt" && (value == 0 || value == 1)) c->cgf_nt = value;
+    else if (k == "cgf_nt" && value >= 0 && value <= 15) c->cgf_nt = value;
     else if (k == "multi_rhs" && (value == 0 || value == 1)) c->multi_rhs = value;
     else if (k == "spmv_bpx" && value >= 1 && value <= 1024) {
         c->spmv_grid = 8 * value;

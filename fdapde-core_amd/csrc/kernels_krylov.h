@@ -310,17 +310,18 @@ __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, 
     double2* r2 = reinterpret_cast<double2*>(r);
     double2 yv[kCgV], pv[kCgV], xv[kCgV], rv[kCgV];
     typedef double v2f64k_t __attribute__((ext_vector_type(2)));
+    // nt: bit 0 y, bit 1 x, bit 2 r, bit 3 p (loads; x and r also their stores) move with the nontemporal hint
+    auto ld = [&](const double2* ptr, int64_t i, bool hint) -> double2 {
+        if (hint) {
+            const v2f64k_t t = __builtin_nontemporal_load(reinterpret_cast<const v2f64k_t*>(ptr + i));
+            return make_double2(t.x, t.y);
+        }
+        return ptr[i];
+    };
 #pragma unroll
     for (int k = 0; k < kCgV; ++k) {
         const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
-        pv[k] = p2[ic];
-        if (nt) {
-            const v2f64k_t a_ = __builtin_nontemporal_load(reinterpret_cast<const v2f64k_t*>(y2 + ic));
-            const v2f64k_t b_ = __builtin_nontemporal_load(reinterpret_cast<const v2f64k_t*>(x2 + ic));
-            const v2f64k_t c_ = __builtin_nontemporal_load(reinterpret_cast<const v2f64k_t*>(r2 + ic));
-            yv[k] = make_double2(a_.x, a_.y), xv[k] = make_double2(b_.x, b_.y), rv[k] = make_double2(c_.x, c_.y);
-        } else
-            yv[k] = y2[ic], xv[k] = x2[ic], rv[k] = r2[ic];
+        pv[k] = ld(p2, ic, nt & 8), yv[k] = ld(y2, ic, nt & 1), xv[k] = ld(x2, ic, nt & 2), rv[k] = ld(r2, ic, nt & 4);
     }
     double a = 0, b = 0;
     for (int i = threadIdx.x; i < np_spmv; i += blockDim.x) a += part_spmv[2 * i], b += part_spmv[2 * i + 1];
@@ -343,11 +344,14 @@ __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, 
             xv[k].x += alpha * pv[k].x, xv[k].y += alpha * pv[k].y;
             rv[k].x -= alpha * yv[k].x, rv[k].y -= alpha * yv[k].y;
             pv[k].x = rv[k].x + beta * pv[k].x, pv[k].y = rv[k].y + beta * pv[k].y;
-            if (nt) {
+            if (nt & 2)
                 __builtin_nontemporal_store(v2f64k_t{xv[k].x, xv[k].y}, reinterpret_cast<v2f64k_t*>(x2 + i));
+            else
+                x2[i] = xv[k];
+            if (nt & 4)
                 __builtin_nontemporal_store(v2f64k_t{rv[k].x, rv[k].y}, reinterpret_cast<v2f64k_t*>(r2 + i));
-            } else
-                x2[i] = xv[k], r2[i] = rv[k];
+            else
+                r2[i] = rv[k];
             p2[i] = pv[k];
             acc += rv[k].x * rv[k].x + rv[k].y * rv[k].y;
         }

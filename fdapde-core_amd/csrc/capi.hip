@@ -1196,9 +1196,12 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
                     if (int rc = halo_sum(c, c->y.p, c->part_a.p, c->spmv_grid, /*unpack=*/false)) return rc;
                     part = c->hbuf.p + c->n_if, np = 1;
                 }
-                hipLaunchKernelGGL(k_cgsr_update, dim3(c->cg_grid), dim3(256), 0, st, n, c->r.p, c->y.p, c->p.p, c->s.p, c->x.p, part,
-                                   np, c->sc.p, parity, launched == 0 ? 1 : 0, tol2, c->ctl.p,
-                                   dist ? c->if_slot.p : (const int32_t*)nullptr, dist ? c->hbuf.p : (const double*)nullptr);
+                // XCD-aware mapping like k_cgf_update (kCgV elements per lane, bands of the SpMV's rows)
+                const int64_t sr_band2 = c->cgf_band ? (((((n + 7) / 8) + 31) & ~int64_t(31)) >> 1) : 0, sr_span = sr_band2 > 0 ? sr_band2 : (n >> 1);
+                const int sr_per = (int)((sr_span + 256 * kCgV - 1) / (256 * kCgV)) > 0 ? (int)((sr_span + 256 * kCgV - 1) / (256 * kCgV)) : 1;
+                hipLaunchKernelGGL(k_cgsr_update, dim3(sr_band2 > 0 ? 8 * sr_per : sr_per), dim3(256), 0, st, n, c->r.p, c->y.p, c->p.p,
+                                   c->s.p, c->x.p, part, np, c->sc.p, parity, launched == 0 ? 1 : 0, tol2, c->ctl.p,
+                                   dist ? c->if_slot.p : (const int32_t*)nullptr, dist ? c->hbuf.p : (const double*)nullptr, sr_band2);
             } else if (cgf) {
                 const bool tm = launched < n_timed;
                 enqueue_cgf(launched, tm ? c->ev_spmv[2 * launched] : nullptr, tm ? c->ev_spmv[2 * launched + 1] : nullptr);

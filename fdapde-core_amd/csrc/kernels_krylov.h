@@ -227,10 +227,29 @@ __global__ __launch_bounds__(256) void k_cg_update_p(int64_t n, const double* r,
 // saves the separate unpack launch (w itself is not read again)
 __global__ __launch_bounds__(256) void k_cgsr_update(int64_t n, double* r, const double* w, double* p, double* s, double* x,
                                                       const double* part_in, int np_in, double* sc, int parity, int first,
-                                                      double tol2, int32_t* ctl, const int32_t* if_slot, const double* hb) {
+                                                      double tol2, int32_t* ctl, const int32_t* if_slot, const double* hb,
+                                                      int64_t band2) {
+    // band2 > 0: XCD-aware mapping (workgroup b serves the elements of SpMV row band b % 8, see k_cgf_update); w, p, s, x, which
+    // the next SpMV does not read, then move with the nontemporal hint and leave the L2 to r
     __shared__ double red[8];
     if (__syncthreads_or(ctl[0] != 0)) return;
-    const int64_t n2 = n >> 1, i0 = (int64_t)blockIdx.x * (256 * kCgV) + threadIdx.x;
+    const int64_t lo = band2 > 0 ? (int64_t)(blockIdx.x & 7) * band2 : 0;
+    const int64_t n2 = band2 > 0 ? min(n >> 1, lo + band2) : (n >> 1);
+    const int64_t i0 = lo + (int64_t)(band2 > 0 ? (blockIdx.x >> 3) : blockIdx.x) * (256 * kCgV) + threadIdx.x;
+    typedef double v2f64s_t __attribute__((ext_vector_type(2)));
+    auto ld = [&](const double2* ptr, int64_t i) -> double2 {
+        if (band2 > 0) {
+            const v2f64s_t t = __builtin_nontemporal_load(reinterpret_cast<const v2f64s_t*>(ptr + i));
+            return make_double2(t.x, t.y);
+        }
+        return ptr[i];
+    };
+    auto st = [&](double2* ptr, int64_t i, double2 v) {
+        if (band2 > 0)
+            __builtin_nontemporal_store(v2f64s_t{v.x, v.y}, reinterpret_cast<v2f64s_t*>(ptr + i));
+        else
+            ptr[i] = v;
+    };
     double2* r2 = reinterpret_cast<double2*>(r);
     const double2* w2 = reinterpret_cast<const double2*>(w);
     double2* p2 = reinterpret_cast<double2*>(p);
@@ -240,7 +259,7 @@ __global__ __launch_bounds__(256) void k_cgsr_update(int64_t n, double* r, const
 #pragma unroll
     for (int k = 0; k < kCgV; ++k) {
         const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
-        rv[k] = r2[ic], wv[k] = w2[ic], pv[k] = p2[ic], sv[k] = s2[ic], xv[k] = x2[ic];
+        rv[k] = r2[ic], wv[k] = ld(w2, ic), pv[k] = ld(p2, ic), sv[k] = ld(s2, ic), xv[k] = ld(x2, ic);
         if (if_slot) {
             const int s0 = if_slot[2 * ic], s1 = if_slot[2 * ic + 1];
             if (s0 >= 0) wv[k].x = hb[s0];
@@ -268,7 +287,7 @@ __global__ __launch_bounds__(256) void k_cgsr_update(int64_t n, double* r, const
             sv[k].x = wv[k].x + beta * sv[k].x, sv[k].y = wv[k].y + beta * sv[k].y;
             xv[k].x += alpha * pv[k].x, xv[k].y += alpha * pv[k].y;
             rv[k].x -= alpha * sv[k].x, rv[k].y -= alpha * sv[k].y;
-            p2[i] = pv[k], s2[i] = sv[k], x2[i] = xv[k], r2[i] = rv[k];
+            st(p2, i, pv[k]), st(s2, i, sv[k]), st(x2, i, xv[k]), r2[i] = rv[k];
         }
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {

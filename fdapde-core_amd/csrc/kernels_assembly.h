@@ -396,15 +396,32 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
     double fsum = 0;
     if (row0 + (threadIdx.x & ~63) < a.n_dofs) {   // wave-uniform: slice exists
         const int64_t off = a.sl_off[slice], width = a.sl_off[slice + 1] - off;
+        // two-stage software pipeline over the visits: the index words of visit v + 2 and the vertex indices of visit v + 1 are
+        // in flight while visit v integrates (the loop body is a dependent chain adj -> bc_vert -> LDS coordinates otherwise)
+        auto load_code = [&](int64_t v) -> int32_t { return v < width ? a.adj[(off + v) * kSlice + lane] : -1; };
+        auto load_lv = [&](int32_t code) -> ushort4 {
+            return *reinterpret_cast<const ushort4*>(a.bc_vert + (bc0 + ((code < 0 ? 0 : code) >> 4)) * 4);
+        };
+        auto load_sw = [&](int64_t v, uint32_t (&w)[NBW]) {
+            const int64_t at = (off + (v < width ? v : 0)) * kSlice + lane;
+#pragma unroll
+            for (int k = 0; k < NBW; ++k) w[k] = a.slotw[at * NBW + k];
+        };
+        int32_t code_n = load_code(0), code_nn = load_code(1);
+        ushort4 lv_n = load_lv(code_n);
+        uint32_t sw_n[NBW];
+        load_sw(0, sw_n);
         for (int64_t v = 0; v < width; ++v) {
-            const int64_t at = (off + v) * kSlice + lane;
-            const int32_t code = a.adj[at];
-            if (code < 0) continue;
+            const int32_t code = code_n;
+            const ushort4 lv = lv_n;                  // block-local vertex indices of this visit
             uint32_t sw[NBW];
 #pragma unroll
-            for (int w = 0; w < NBW; ++w) sw[w] = a.slotw[at * NBW + w];
+            for (int k = 0; k < NBW; ++k) sw[k] = sw_n[k];
+            code_n = code_nn, code_nn = load_code(v + 2);
+            lv_n = load_lv(code_n);
+            load_sw(v + 1, sw_n);
+            if (code < 0) continue;
             const int64_t bc = bc0 + (code >> 4);
-            const ushort4 lv = *reinterpret_cast<const ushort4*>(a.bc_vert + bc * 4);   // block-local vertex indices
             Geo<M> g;
             geo_from_vertices<M>(xyz + lv.x * NP, xyz + lv.y * NP, xyz + lv.z * NP, xyz + lv.w * NP, g);
             const int cell = (a.fq != nullptr || op.needs_rows) ? a.bc_cell[bc] : 0;   // only forcing / varying coefficients need it

@@ -160,6 +160,7 @@ struct fdapde_ctx {
     int use_graph = 0;                       // tuning knob: replay full chunks of the fused-update CG as one hipGraph
     hipGraphExec_t cg_graph_exec = nullptr;
     GraphKey cg_graph_key{};
+    int cgf_lazy = 1;                        // tuning knob: x updated every second launch of k_cgf_update (C3 solve 33.3 -> 32.5 ms, same iterations)
     int cgf_nt = 7;                          // tuning knob, bit set: nontemporal y (1), x (2), r (4), p load (8) in k_cgf_update
     int cgf_band = 1;                        // tuning knob: XCD-aware mapping + nontemporal x / r / y in k_cgf_update (C3 solve 41.80 -> 41.10 ms)
     int cgf_v = 8;                           // double2 elements per lane of k_cgf_update (1, 2, 4, 8); C3 solve: 47.2 / 41.8 / 41.3 / 40.9 ms
@@ -312,7 +313,7 @@ int upload_space(fdapde_ctx* c) {
         if (c->cg_grid < 1) c->cg_grid = 1;
     }
     HIPCHK(c, c->part_b.alloc(8 * (size_t)(c->vec_grid > c->cg_grid ? c->vec_grid : c->cg_grid) + 16));   // two halves at every k_cgf_update width
-    HIPCHK(c, c->sc.alloc(16));
+    HIPCHK(c, c->sc.alloc(24));
     HIPCHK(c, c->ctl.alloc(4));
     HIPCHK(c, hipMemsetAsync(c->ctl.p, 0, 4 * sizeof(int32_t), st));
     HIPCHK(c, hipMemsetAsync(c->force.p, 0, n * sizeof(double), st));
@@ -1143,7 +1144,7 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
 #define CGF_GO(V_)                                                                                                         \
     hipLaunchKernelGGL(k_cgf_update<V_>, dim3(cg), dim3(256), 0, st, n, c->y.p, c->p.p, c->x.p, c->r.p, c->part_a.p, c->spmv_grid, \
                        c->part_b.p + (size_t)((it + 1) & 1) * cg, cg, c->part_b.p + (size_t)(it & 1) * cg, c->sc.p, tol2, c->ctl.p, \
-                       cgf_band2, c->cgf_nt)
+                       cgf_band2, c->cgf_nt, c->cgf_lazy, it & 1)
         if (cgf_V == 1) CGF_GO(1);
         else if (cgf_V == 2) CGF_GO(2);
         else if (cgf_V == 8) CGF_GO(8);
@@ -1280,6 +1281,8 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
         HIPCHK(c, hipMemcpyAsync(c->h_sc, c->sc.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
     }
+    if (cgf && c->cgf_lazy)   // an update of x may still be pending (convergence seen at a poll, or maxit)
+        hipLaunchKernelGGL(k_cgf_flush, dim3(c->vec_grid), dim3(256), 0, st, n, c->p.p, c->r.p, c->x.p, c->sc.p, c->ctl.p);
     hipLaunchKernelGGL(k_unscale, dim3(g1(n)), dim3(256), 0, st, n, c->scale.p, c->x.p, c->gt.p, c->u.p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(st));
@@ -1924,6 +1927,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "use_graph" && (value == 0 || value == 1)) c->use_graph = value;
     else if (k == "cgf_band" && (value == 0 || value == 1)) c->cgf_band = value;
     else if (k == "cgf_nt" && value >= 0 && value <= 15) c->cgf_nt = value;
+    else if (k == "cgf_lazy" && (value == 0 || value == 1)) c->cgf_lazy = value;
     else if (k == "multi_rhs" && (value == 0 || value == 1)) c->multi_rhs = value;
     else if (k == "spmv_bpx" && value >= 1 && value <= 1024) {
         c->spmv_grid = 8 * value;

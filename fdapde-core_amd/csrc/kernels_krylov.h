@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256) void k_krylov_init_fin(const double* partial, 
         sc[0] = bb, sc[1] = rr, sc[2] = rr, sc[3] = rr;
         sc[4] = 1.0, sc[5] = 1.0, sc[6] = 1.0;   // bicgstab: rho, alpha, omega
         sc[9] = rr;                               // bicgstab: (r0, r0) of the first iteration
+        sc[16] = 0.0, sc[17] = 0.0;               // fused-update CG: no update of x pending
         ctl[0] = rr <= tol2 * bb ? 1 : 0, ctl[1] = 0, ctl[2] = 0;
     }
 }
@@ -312,11 +313,17 @@ __global__ __launch_bounds__(256) void k_cgsr_update(int64_t n, double* r, const
 // band2 > 0 (XCD-aware form): workgroup b serves the double2 elements of SpMV row band b % 8 ([band * band2, (band + 1) * band2)),
 // so that the p it writes sits in the L2 of the XCD whose SpMV workgroups gather it next; y, x, r (not read by the SpMV) move
 // with nontemporal loads / stores.  band2 == 0: plain contiguous mapping.
+// lazy (knob cgf_lazy): x is touched every second launch only.  A launch that finds no pending update and computes beta >=
+// kLazyBeta does not read or write x; it leaves (alpha, beta) in sc[14], sc[15] and raises the pending flag sc[16 + next parity].
+// The next launch reconstructs the previous direction from what it streams anyway, p_prev = (p - r) / beta_prev (p = r + beta_prev
+// p_prev), and applies both updates: x += alpha_prev p_prev + alpha p.  6 instead of 7 vector passes on average.  Whoever
+// detects convergence with an update pending applies it first (here, or k_cgf_flush after the loop).
+constexpr double kLazyBeta = 0.05;
 template <int kCgV>
 __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, double* p, double* x, double* r,
                                                      const double* part_spmv, int np_spmv, const double* part_rr_in, int np_rr,
                                                      double* part_rr_out, double* sc, double tol2, int32_t* ctl, int64_t band2,
-                                                     int nt) {
+                                                     int nt, int lazy, int parity) {
     __shared__ double red[8];
     if (__syncthreads_or(ctl[0] != 0)) return;
     const int64_t n2_all = n >> 1;
@@ -337,10 +344,20 @@ __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, 
         }
         return ptr[i];
     };
+    auto st_x = [&](int64_t i, double2 v) {
+        if (nt & 2)
+            __builtin_nontemporal_store(v2f64k_t{v.x, v.y}, reinterpret_cast<v2f64k_t*>(x2 + i));
+        else
+            x2[i] = v;
+    };
+    const bool pend = lazy && sc[16 + parity] != 0.0;   // an update of x is pending from the previous launch
+    const bool need_x = !lazy || pend;
+    const double a_prev = pend ? sc[14] : 0.0, ib_prev = pend ? 1.0 / sc[15] : 0.0;
 #pragma unroll
     for (int k = 0; k < kCgV; ++k) {
         const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
-        pv[k] = ld(p2, ic, nt & 8), yv[k] = ld(y2, ic, nt & 1), xv[k] = ld(x2, ic, nt & 2), rv[k] = ld(r2, ic, nt & 4);
+        pv[k] = ld(p2, ic, nt & 8), yv[k] = ld(y2, ic, nt & 1), rv[k] = ld(r2, ic, nt & 4);
+        if (need_x) xv[k] = ld(x2, ic, nt & 2);
     }
     double a = 0, b = 0;
     for (int i = threadIdx.x; i < np_spmv; i += blockDim.x) a += part_spmv[2 * i], b += part_spmv[2 * i + 1];
@@ -348,25 +365,45 @@ __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, 
     const double yy = block_sum(b, red);
     const double rr = sum_partials(part_rr_in, np_rr, red);   // launch 0: seeded by k_krylov_init_fin
     const bool last = blockIdx.x == gridDim.x - 1 && threadIdx.x == 0;
-    if (rr <= tol2 * sc[0]) {   // converged by the previous update: x, r stay as they are
-        if (last) sc[3] = rr, ctl[0] = 1;
+    const bool tail = (n & 1) && blockIdx.x == 0 && threadIdx.x == 0;
+    if (rr <= tol2 * sc[0]) {   // converged by the previous update: r stays as it is; a pending update of x is applied
+        if (pend) {
+#pragma unroll
+            for (int k = 0; k < kCgV; ++k) {
+                const int64_t i = i0 + k * 256;
+                if (i < n2) {
+                    xv[k].x += a_prev * ((pv[k].x - rv[k].x) * ib_prev), xv[k].y += a_prev * ((pv[k].y - rv[k].y) * ib_prev);
+                    st_x(i, xv[k]);
+                }
+            }
+            if (tail) x[n - 1] += a_prev * ((p[n - 1] - r[n - 1]) * ib_prev);
+        }
+        if (last) sc[3] = rr, ctl[0] = 1, sc[16 + (parity ^ 1)] = 0.0;
         return;
     }
     const double alpha = pAp > 0.0 ? rr / pAp : 0.0;
     const double est = alpha * alpha * yy - rr;
     const double beta = (est > 0.0 && rr > 0.0) ? est / rr : 0.0;
+    const bool defer = lazy && !pend && beta >= kLazyBeta;   // uniform: every workgroup computes the same beta
+    if (!need_x && !defer) {   // rare: no update pending, but this one cannot be reconstructed later -> apply it now
+#pragma unroll
+        for (int k = 0; k < kCgV; ++k) {
+            const int64_t i = i0 + k * 256;
+            xv[k] = ld(x2, i < n2 ? i : 0, nt & 2);
+        }
+    }
     double acc = 0;
 #pragma unroll
     for (int k = 0; k < kCgV; ++k) {
         const int64_t i = i0 + k * 256;
         if (i < n2) {
-            xv[k].x += alpha * pv[k].x, xv[k].y += alpha * pv[k].y;
+            if (!defer) {
+                if (pend) xv[k].x += a_prev * ((pv[k].x - rv[k].x) * ib_prev), xv[k].y += a_prev * ((pv[k].y - rv[k].y) * ib_prev);
+                xv[k].x += alpha * pv[k].x, xv[k].y += alpha * pv[k].y;
+                st_x(i, xv[k]);
+            }
             rv[k].x -= alpha * yv[k].x, rv[k].y -= alpha * yv[k].y;
             pv[k].x = rv[k].x + beta * pv[k].x, pv[k].y = rv[k].y + beta * pv[k].y;
-            if (nt & 2)
-                __builtin_nontemporal_store(v2f64k_t{xv[k].x, xv[k].y}, reinterpret_cast<v2f64k_t*>(x2 + i));
-            else
-                x2[i] = xv[k];
             if (nt & 4)
                 __builtin_nontemporal_store(v2f64k_t{rv[k].x, rv[k].y}, reinterpret_cast<v2f64k_t*>(r2 + i));
             else
@@ -375,9 +412,12 @@ __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, 
             acc += rv[k].x * rv[k].x + rv[k].y * rv[k].y;
         }
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (tail) {
         const int64_t i = n - 1;
-        x[i] += alpha * p[i];
+        if (!defer) {
+            if (pend) x[i] += a_prev * ((p[i] - r[i]) * ib_prev);
+            x[i] += alpha * p[i];
+        }
         const double ri = r[i] - alpha * y[i];
         r[i] = ri, p[i] = ri + beta * p[i];
         acc += ri * ri;
@@ -387,8 +427,18 @@ __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, 
     if (last) {
         sc[3] = rr;
         ctl[1] += 1;
+        if (defer) sc[14] = alpha, sc[15] = beta;
+        sc[16 + (parity ^ 1)] = defer ? 1.0 : 0.0;
         if (!(pAp > 0.0)) ctl[2] = 1, ctl[0] = 1;   // not SPD / breakdown
     }
+}
+// after the iteration loop: an update of x may still be pending (convergence seen by k_cgf_fin, or maxit)
+__global__ __launch_bounds__(256) void k_cgf_flush(int64_t n, const double* p, const double* r, double* x, double* sc, const int32_t* ctl) {
+    const int parity = ctl[1] & 1;   // the launch after the last executed update would have had this parity
+    if (sc[16 + parity] == 0.0) return;
+    const double a_prev = sc[14], ib_prev = 1.0 / sc[15];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        x[i] += a_prev * ((p[i] - r[i]) * ib_prev);
 }
 // host poll of the fused-update CG: explicit r.r of the last update -> sc[3], stop flag
 __global__ __launch_bounds__(256) void k_cgf_fin(const double* part_rr, int np, double* sc, double tol2, int32_t* ctl) {

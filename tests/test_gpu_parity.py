@@ -319,7 +319,8 @@ def test_distributed_code_path_on_one_rank(capi, ctx, oracle, mesh_loader):
     assert info.converged == 1 and info.iters == plain.iters
     sr = ctx.solve(method=capi.SOLVER_CG_SR, rtol=1e-11)   # the variant multi-rank runs use: one all-reduce per iteration
     assert sr.converged == 1 and np.abs(ctx.solution() - u_plain).max() <= 1e-9 * max(1.0, np.abs(u_plain).max())
-    assert np.abs(u_dist - u_plain).max() <= 1e-13 * max(1.0, np.abs(u_plain).max())
+    # two different CG forms (fused-update with lazy x against the 3-kernel multi-GPU form) stopped at the same residual
+    assert np.abs(u_dist - u_plain).max() <= 1e-9 * max(1.0, np.abs(u_plain).max())
     ref = oracle.pde_init_solve(m, 1, -oracle.laplacian() + oracle.reaction(0.7), forcing_q=fq, dirichlet=g)
     assert np.linalg.norm(u_dist - ref.solution) / np.linalg.norm(ref.solution) <= SOL_TOL
     bi = ctx.solve(method=capi.SOLVER_BICGSTAB, rtol=1e-11)   # distributed BiCGStab over the same 1-rank RCCL communicator

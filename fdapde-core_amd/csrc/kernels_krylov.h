@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_krylov_init_fin(const double* partial, 
         sc[0] = bb, sc[1] = rr, sc[2] = rr, sc[3] = rr;
         sc[4] = 1.0, sc[5] = 1.0, sc[6] = 1.0;   // bicgstab: rho, alpha, omega
         sc[9] = rr;                               // bicgstab: (r0, r0) of the first iteration
-        sc[16] = 0.0, sc[17] = 0.0;               // fused-update CG: no update of x pending
+        sc[16] = 0.0, sc[17] = 0.0, sc[18] = 0.0; // fused-update CG: no update of x pending
         ctl[0] = rr <= tol2 * bb ? 1 : 0, ctl[1] = 0, ctl[2] = 0;
     }
 }
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void k_cgsr_update(int64_t n, double* r, const
 // The next launch reconstructs the previous direction from what it streams anyway, p_prev = (p - r) / beta_prev (p = r + beta_prev
 // p_prev), and applies both updates: x += alpha_prev p_prev + alpha p.  6 instead of 7 vector passes on average.  Whoever
 // detects convergence with an update pending applies it first (here, or k_cgf_flush after the loop).
-constexpr double kLazyBeta = 0.05;
+constexpr double kLazyBeta = 0.25;
 template <int kCgV>
 __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, double* p, double* x, double* r,
                                                      const double* part_spmv, int np_spmv, const double* part_rr_in, int np_rr,
@@ -378,7 +378,8 @@ __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, 
             }
             if (tail) x[n - 1] += a_prev * ((p[n - 1] - r[n - 1]) * ib_prev);
         }
-        if (last) sc[3] = rr, ctl[0] = 1, sc[16 + (parity ^ 1)] = 0.0;
+        // sc[18]: the pending update has been applied here (its flag cannot be cleared while other workgroups still read it)
+        if (last) sc[3] = rr, ctl[0] = 1, sc[16 + (parity ^ 1)] = 0.0, sc[18] = 1.0;
         return;
     }
     const double alpha = pAp > 0.0 ? rr / pAp : 0.0;
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, 
 // after the iteration loop: an update of x may still be pending (convergence seen by k_cgf_fin, or maxit)
 __global__ __launch_bounds__(256) void k_cgf_flush(int64_t n, const double* p, const double* r, double* x, double* sc, const int32_t* ctl) {
     const int parity = ctl[1] & 1;   // the launch after the last executed update would have had this parity
-    if (sc[16 + parity] == 0.0) return;
+    if (sc[16 + parity] == 0.0 || sc[18] != 0.0) return;   // nothing pending, or already applied by the launch that saw convergence
     const double a_prev = sc[14], ib_prev = 1.0 / sc[15];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         x[i] += a_prev * ((p[i] - r[i]) * ib_prev);

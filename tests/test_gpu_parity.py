@@ -508,3 +508,35 @@ def test_multi_rhs_batches_match_column_by_column(capi, ctx, oracle, mesh_loader
     scale = np.linalg.norm(ref, axis=0).max()
     assert np.abs(X1 - ref).max() <= 1e-8 * scale and np.abs(X0 - ref).max() <= 1e-8 * scale
     assert np.all(X1[:, -1] == 0.0)
+
+
+def test_lazy_x_update_matches_eager(capi, ctx, oracle, mesh_loader):
+    """The fused-update CG touches x every second launch (pending updates are rebuilt from p and r); whatever the parity of the
+    converging iteration, and whether convergence is seen inside a launch, at a host poll or never (maxit), the result must be the
+    eager one up to rounding"""
+    m = mesh_loader("unit_sphere")
+    ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = ctx.dofs_build(2)
+    _, _, coords = ctx.dofs_get()
+    qn = ctx.quadrature_nodes()
+    ctx.set_operator(-capi.laplacian() + capi.reaction(0.2))
+    ctx.set_forcing(np.cos(qn[:, 0]) + qn[:, 1] * qn[:, 2])
+    ctx.set_dirichlet(coords[:, 0] + 0.1)
+    ctx.init()
+    seen = set()
+    cases = [dict(rtol=10.0 ** -k) for k in range(3, 13)] + [dict(rtol=1e-30, maxit=k) for k in (1, 2, 31, 32, 33, 64)]
+    for kw in cases:
+        sol = {}
+        for lazy in (0, 1):
+            ctx.tune("cgf_lazy", lazy)
+            try:
+                info = ctx.solve(method=capi.SOLVER_CG_FUSED, **kw)
+            except capi.FdapdeError as e:
+                assert e.status == capi.ENOCONV
+                info = ctx.info()
+            sol[lazy] = (ctx.solution(), info.iters)
+        assert sol[0][1] == sol[1][1]
+        seen.add(sol[0][1] & 1)
+        assert np.abs(sol[0][0] - sol[1][0]).max() <= 1e-13 * np.abs(sol[0][0]).max(), kw
+    assert seen == {0, 1}          # both parities of the last executed update were exercised
+    ctx.tune("cgf_lazy", 1)

@@ -622,22 +622,8 @@ __global__ __launch_bounds__(256) void k_bicg_fin(const double* part_ts, int np_
 // with the rank's partial of the fused dot product (slot n_if), and unpacked.  dot(x, A x) = sum_p x_p . (A_p x_p) needs
 // no weighting; dots of assembled vectors count every DOF once through the `owned` mask.
 // ---------------------------------------------------------------------------------------------------------------
-// buf must be zero on entry.  Workgroup 0 also folds the local dot partials (stride 2) into buf[n_if] (+ second component
-// into buf[n_if + 1]).
-__global__ __launch_bounds__(256) void k_halo_pack(int64_t n_loc_if, const int32_t* dof, const int32_t* pos, const double* v,
-                                                    double* buf, int64_t n_if, const double* part, int np) {
-    __shared__ double red[8];
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_loc_if) buf[pos[i]] = v[dof[i]];
-    if (blockIdx.x == 0 && part != nullptr) {
-        double a = 0, b = 0;
-        for (int k = threadIdx.x; k < np; k += blockDim.x) a += part[2 * k], b += part[2 * k + 1];
-        const double sa = block_sum(a, red);
-        const double sb = block_sum(b, red);
-        if (threadIdx.x == 0) buf[n_if] = sa, buf[n_if + 1] = sb;
-    }
-}
-// the same without a prior memset: one lane per GLOBAL interface slot; inv[j] = this rank's DOF of slot j or -1
+// One lane per GLOBAL interface slot: inv[j] = this rank's DOF of slot j or -1 (zero written where the rank has no DOF, so no
+// memset is needed); workgroup 0 also folds the local dot partials (stride 2) into buf[n_if], buf[n_if + 1].
 __global__ __launch_bounds__(256) void k_halo_pack_all(int64_t n_if, const int32_t* inv, const double* v, double* buf,
                                                         const double* part, int np) {
     __shared__ double red[8];

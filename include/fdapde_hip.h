@@ -73,8 +73,8 @@ typedef struct {
     double rtol;      /* <= 0: 1e-10.  Stop when ||r||_{D^-1} <= rtol * ||r0||_{D^-1} (D = diag A) */
     int32_t assembly; /* FDAPDE_ASSEMBLY_*; used by fdapde_init */
     int32_t check_every; /* iterations between host convergence polls; <= 0: 32 */
-    int32_t time_spmv;   /* > 0: bracket the SpMV launch of the first `time_spmv` Krylov iterations (max 256) with HIP
-                            events on the context's stream and report their average in fdapde_info.spmv_avg_ms */
+    int32_t time_spmv;   /* > 0: time the SpMV launch of `time_spmv` Krylov iterations (every 8th one, max 256 samples) with HIP
+                            events attached to those dispatches on the context's stream; average in fdapde_info.spmv_avg_ms */
 } fdapde_options;
 
 typedef struct {

@@ -463,6 +463,29 @@ __global__ __launch_bounds__(256) void k_cgf_fin(const double* part_rr, int np, 
 // The three vector kernels are single-shot like the CG ones: workgroup b owns kBiV * 256 consecutive double2 elements, every
 // lane issues all of its 16-byte loads first and only then re-reduces the producer's partials (grid = bicg_grid(n)).
 constexpr int kBiV = 4;
+// dead streams of the BiCGStab vector kernels (everything but the p and s the next SpMV reads) move with the nontemporal hint
+// (C5, same box: solve 666.3 -> 647.6 ms); -DFDAPDE_BICG_NT=0 restores the default policy
+#ifndef FDAPDE_BICG_NT
+#define FDAPDE_BICG_NT 1
+#endif
+typedef double v2f64b_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 bi_ld(const double2* p, int64_t i) {
+#if FDAPDE_BICG_NT
+    const v2f64b_t t = __builtin_nontemporal_load(reinterpret_cast<const v2f64b_t*>(p + i));
+    return make_double2(t.x, t.y);
+#else
+    return p[i];
+#endif
+}
+__device__ __forceinline__ void bi_st(double2* p, int64_t i, double2 v) {
+#if FDAPDE_BICG_NT
+    __builtin_nontemporal_store(v2f64b_t{v.x, v.y}, reinterpret_cast<v2f64b_t*>(p + i));
+#else
+    p[i] = v;
+#endif
+}
+#define BI_LD(ptr, i) bi_ld(ptr, i)
+#define BI_ST(ptr, i, v) bi_st(ptr, i, v)
 __global__ __launch_bounds__(256) void k_bicg_p(int64_t n, const double* r, const double* v, double* p,
                                                  const double* part_in /* (r0.r, r.r) pairs */, int np_in, double* sc,
                                                  int first, int32_t* ctl) {
@@ -476,8 +499,8 @@ __global__ __launch_bounds__(256) void k_bicg_p(int64_t n, const double* r, cons
 #pragma unroll
     for (int k = 0; k < kBiV; ++k) {
         const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
-        rv[k] = r2[ic];
-        if (!first) vv[k] = v2[ic], pv[k] = p2[ic];
+        rv[k] = BI_LD(r2, ic);
+        if (!first) vv[k] = BI_LD(v2, ic), pv[k] = BI_LD(p2, ic);
     }
     double a = 0;
     for (int i = threadIdx.x; i < np_in; i += blockDim.x) a += part_in[2 * i];
@@ -512,7 +535,7 @@ __global__ __launch_bounds__(256) void k_bicg_s(int64_t n, const double* r, cons
 #pragma unroll
     for (int k = 0; k < kBiV; ++k) {
         const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
-        rv[k] = r2[ic], vv[k] = v2[ic];
+        rv[k] = BI_LD(r2, ic), vv[k] = BI_LD(v2, ic);
     }
     double a = 0;
     for (int i = threadIdx.x; i < np_in; i += blockDim.x) a += part_in[2 * i];
@@ -546,7 +569,7 @@ __global__ __launch_bounds__(256) void k_bicg_xr(int64_t n, const double* p, con
 #pragma unroll
     for (int k = 0; k < kBiV; ++k) {
         const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
-        pv[k] = p2[ic], sv[k] = s2[ic], tv[k] = t2[ic], qv[k] = q2[ic], xv[k] = x2[ic];
+        pv[k] = BI_LD(p2, ic), sv[k] = BI_LD(s2, ic), tv[k] = BI_LD(t2, ic), qv[k] = BI_LD(q2, ic), xv[k] = BI_LD(x2, ic);
     }
     double a = 0, b = 0;
     for (int i = threadIdx.x; i < np_in; i += blockDim.x) a += part_in[2 * i], b += part_in[2 * i + 1];
@@ -559,9 +582,9 @@ __global__ __launch_bounds__(256) void k_bicg_xr(int64_t n, const double* p, con
     for (int k = 0; k < kBiV; ++k) {
         const int64_t i = i0 + k * 256;
         if (i < n2) {
-            x2[i] = make_double2(xv[k].x + alpha * pv[k].x + omega * sv[k].x, xv[k].y + alpha * pv[k].y + omega * sv[k].y);
+            BI_ST(x2, i, make_double2(xv[k].x + alpha * pv[k].x + omega * sv[k].x, xv[k].y + alpha * pv[k].y + omega * sv[k].y));
             const double2 ri = make_double2(sv[k].x - omega * tv[k].x, sv[k].y - omega * tv[k].y);
-            r2[i] = ri;
+            BI_ST(r2, i, ri);
             const bool o0 = !owned || owned[2 * i], o1 = !owned || owned[2 * i + 1];
             d0 += (o0 ? qv[k].x * ri.x : 0.0) + (o1 ? qv[k].y * ri.y : 0.0);
             d1 += (o0 ? ri.x * ri.x : 0.0) + (o1 ? ri.y * ri.y : 0.0);
@@ -578,6 +601,8 @@ __global__ __launch_bounds__(256) void k_bicg_xr(int64_t n, const double* p, con
     const double s1 = block_sum(d1, red);
     if (threadIdx.x == 0) part_out[2 * blockIdx.x] = s0, part_out[2 * blockIdx.x + 1] = s1;
 }
+#undef BI_LD
+#undef BI_ST
 // multi-GPU BiCGStab: t.t over the owned rows of the ASSEMBLED t (the SpMV's fused y.y only sees this rank's sub-assembled
 // part); per-workgroup partials, then out = (t.s already summed over ranks, local t.t) for the scalar all-reduce of out[1]
 __global__ __launch_bounds__(256) void k_sq_owned(int64_t n, const double* t, const uint8_t* owned, double* part, const int32_t* ctl) {

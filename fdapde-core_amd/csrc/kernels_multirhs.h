@@ -180,7 +180,14 @@ __global__ __launch_bounds__(256) void k_q_update(int64_t n, const double* Y, do
 #pragma unroll
         for (int k = 0; k < kQV; ++k) {
             const int64_t e = i0 + k * 256, ec = e < nh ? e : 0;
-            yv[k] = y2[ec], pv[k] = p2[ec], xv[k] = x2[ec], rv[k] = r2[ec];
+            pv[k] = p2[ec];
+            {   // y, x, r are not read by the next SpMM: nontemporal, the L2s are left to P
+                typedef double v2f64q_t __attribute__((ext_vector_type(2)));
+                const v2f64q_t a_ = __builtin_nontemporal_load(reinterpret_cast<const v2f64q_t*>(y2 + ec));
+                const v2f64q_t b_ = __builtin_nontemporal_load(reinterpret_cast<const v2f64q_t*>(x2 + ec));
+                const v2f64q_t c_ = __builtin_nontemporal_load(reinterpret_cast<const v2f64q_t*>(r2 + ec));
+                yv[k] = make_double2(a_.x, a_.y), xv[k] = make_double2(b_.x, b_.y), rv[k] = make_double2(c_.x, c_.y);
+            }
         }
 #pragma unroll
         for (int k = 0; k < kQV; ++k) {
@@ -189,7 +196,12 @@ __global__ __launch_bounds__(256) void k_q_update(int64_t n, const double* Y, do
                 xv[k].x += a0 * pv[k].x, xv[k].y += a1 * pv[k].y;
                 rv[k].x -= a0 * yv[k].x, rv[k].y -= a1 * yv[k].y;
                 pv[k].x = rv[k].x + b0 * pv[k].x, pv[k].y = rv[k].y + b1 * pv[k].y;
-                x2[e] = xv[k], r2[e] = rv[k], p2[e] = pv[k];
+                {
+                    typedef double v2f64q_t __attribute__((ext_vector_type(2)));
+                    __builtin_nontemporal_store(v2f64q_t{xv[k].x, xv[k].y}, reinterpret_cast<v2f64q_t*>(x2 + e));
+                    __builtin_nontemporal_store(v2f64q_t{rv[k].x, rv[k].y}, reinterpret_cast<v2f64q_t*>(r2 + e));
+                }
+                p2[e] = pv[k];
                 acc.x += rv[k].x * rv[k].x, acc.y += rv[k].y * rv[k].y;
             }
         }

@@ -1540,9 +1540,9 @@ int fdapde_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, 
     int total = 0, rc_all = FDAPDE_OK;
     double worst = 0;
     int32_t j0 = 0;
-    // several columns against a symmetric positive system on one GPU: batches of 8 / 4 / 2 columns share every pass over the
+    // several columns against a symmetric positive system on one GPU: batches of 8 / 4 columns share every pass over the
     // matrix (kernels_multirhs.h); what is left goes column by column
-    const bool batched = c->multi_rhs && n_rhs >= 2 && method == FDAPDE_SOLVER_CG_FUSED && !c->lin_state->ss.dist;
+    const bool batched = c->multi_rhs && n_rhs >= 4 && method == FDAPDE_SOLVER_CG_FUSED && !c->lin_state->ss.dist;
     if (batched) {
         if (!c->lin_sq_ready) {   // full-pattern scaled copy (explicit unit diagonal), once per prepared matrix
             HIPCHK(c, c->lin_sq.alloc((size_t)hs.nnz + 2));
@@ -1550,14 +1550,13 @@ int fdapde_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, 
                                c->lin_sq.p);
             c->lin_sq_ready = true;
         }
-        while (n_rhs - j0 >= 2) {
-            const int q = n_rhs - j0 >= 8 ? 8 : (n_rhs - j0 >= 4 ? 4 : 2);
+        while (n_rhs - j0 >= 4) {   // pairs are faster column by column (C3-size system: 77 ms against 92 ms batched)
+            const int q = n_rhs - j0 >= 8 ? 8 : 4;
             int its = 0, rc = FDAPDE_OK;
             double rel = 0;
             bool ok = true;
             if (q == 8) rc = lin_solve_batch<8>(c, b + (size_t)j0 * n, x + (size_t)j0 * n, rtol, maxit, check_every, &its, &rel, &ok);
-            else if (q == 4) rc = lin_solve_batch<4>(c, b + (size_t)j0 * n, x + (size_t)j0 * n, rtol, maxit, check_every, &its, &rel, &ok);
-            else rc = lin_solve_batch<2>(c, b + (size_t)j0 * n, x + (size_t)j0 * n, rtol, maxit, check_every, &its, &rel, &ok);
+            else rc = lin_solve_batch<4>(c, b + (size_t)j0 * n, x + (size_t)j0 * n, rtol, maxit, check_every, &its, &rel, &ok);
             if (rc != FDAPDE_OK) return rc;
             if (!ok) rc_all = FDAPDE_ENOCONV;
             total += its, worst = rel > worst ? rel : worst;

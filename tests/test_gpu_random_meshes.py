@@ -68,3 +68,47 @@ def test_delaunay_mesh_parity(capi, oracle, dim, n, order, seed):
         exp = oracle.assemble_operator(m, order, od, nd, op(oracle)).values
         assert np.abs(got - exp).max() <= 1e-12 * max(1.0, np.abs(exp).max()), name
     ctx.close()
+
+
+@pytest.mark.parametrize("n_rim,order", [(40, 1), (700, 1), (700, 2)])
+def test_fan_mesh_with_one_very_long_row(capi, oracle, n_rim, order):
+    """A fan of n_rim triangles around one vertex: that vertex's row has n_rim + 1 (P1) or 2 n_rim + 1 (P2) entries, far above a team
+    pass; with n_rim = 700 it also exceeds what the segmented solver pattern accepts (32 chunks per row), so the plain pattern with
+    its tail passes must take over.  Two rings, so that the centre and the first ring are interior DOFs."""
+    th = np.linspace(0.0, 2.0 * np.pi, n_rim, endpoint=False)
+    ring1 = 0.5 * np.stack([np.cos(th), np.sin(th)], axis=1)
+    ring2 = 1.0 * np.stack([np.cos(th + np.pi / n_rim), np.sin(th + np.pi / n_rim)], axis=1)
+    nodes = np.vstack([[0.0, 0.0], ring1, ring2])
+    c, r1, r2 = 0, 1 + np.arange(n_rim), 1 + n_rim + np.arange(n_rim)
+    nxt = np.roll(np.arange(n_rim), -1)
+    cells = np.vstack([np.stack([np.full(n_rim, c), r1, r1[nxt]], axis=1),
+                       np.stack([r1, r2, r1[nxt]], axis=1),
+                       np.stack([r1[nxt], r2, r2[nxt]], axis=1)]).astype(np.int32)
+    bnd = np.zeros(nodes.shape[0], dtype=np.uint8)
+    bnd[r2] = 1
+    m = oracle.Mesh(nodes, cells, bnd)
+    ctx = capi.Context(device=0)
+    ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = ctx.dofs_build(order)
+    od, ob, ond, _ = oracle.enumerate_dofs(m, order)
+    dofs, b, coords = ctx.dofs_get()
+    assert nd == ond and np.array_equal(dofs, od) and np.array_equal(b, ob)
+    rp, _ = ctx.pattern_get()
+    assert np.diff(rp).max() >= n_rim + 1
+    op = lambda mod: -mod.laplacian() + mod.reaction(0.3)
+    qn = ctx.quadrature_nodes()
+    fq = 1.0 + qn[:, 0]
+    g = coords[:, 1]
+    ctx.set_operator(op(capi))
+    ctx.set_forcing(fq)
+    ctx.set_dirichlet(g)
+    ctx.init()
+    ref = oracle.pde_init_solve(m, order, op(oracle), forcing_q=fq, dirichlet=g)
+    info = ctx.solve(rtol=1e-12)
+    assert info.converged == 1
+    assert np.linalg.norm(ctx.solution() - ref.solution) / np.linalg.norm(ref.solution) <= 1e-8
+    x = np.sin(np.arange(nd, dtype=float))
+    ctx.assemble_operator(capi.MAT_STIFF, op(capi))
+    A = oracle.assemble_operator(m, order, od, nd, op(oracle))
+    assert np.abs(ctx.spmv(capi.MAT_STIFF, x) - A.matvec(x)).max() <= 1e-11 * np.abs(A.matvec(x)).max()
+    ctx.close()

@@ -91,6 +91,7 @@ struct HostTerm {
 
 // fdapde_options.time_spmv samples every kTimeStride-th Krylov iteration (the first iterations after init run on cold caches
 // and are not representative of the solve: 45.7 us against a kernel-trace average of 43.9 us on C3)
+constexpr int64_t kNtValsRows = 2000000;   // above this many rows the SpMV of teams <= 8 hints its value stream (see load_pair)
 constexpr int kTimeStride = 8, kTimePhase = 3;   // phase 3: never the first launch after a host poll (the GPU has just idled)
 
 // everything the captured launch sequence of a CG chunk depends on (the graph is rebuilt when any of it changes)
@@ -159,6 +160,7 @@ struct fdapde_ctx {
     int sval_layout = -2;                    // layout sval was last zero-filled for (pad entries of a segmented pattern stay 0)
     DBuf<uint16_t> sp_col16[2];              // 16-bit column codes of the compact pattern (host_build_col16)
     int64_t sp_wide[2] = {0, 0};             // groups of 32 rows that fall back to the 32-bit columns
+    int spmv_ntv = -1;                       // tuning knob: -1 auto (by size), 0 / 1 force the value-stream policy of teams <= 8
     int sp_team = 0;                         // team size the segmented patterns were built for
     int spmv_c16 = 1;                        // tuning knob: 0 = always stream the 32-bit columns
     int use_graph = 0;                       // tuning knob: replay full chunks of the fused-update CG as one hipGraph
@@ -499,6 +501,8 @@ void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, 
     s.rb_row = c->rb_row.p, s.n_rb = c->n_rb, s.rb_per_band = c->rb_per_band, s.nnz = (int32_t)c->hs.nnz;
     s.w = w, s.partial = partial, s.stop = stop, s.dot2_ww = dot2_ww, s.owned = owned, s.unit_diag = 0;
     s.n_cols = (int32_t)c->hs.n_dofs;
+    // value-stream policy by size: x and y slices of a row band (16 bytes per row, 8 bands) against the 4 MB L2 of an XCD
+    const bool ntv = c->spmv_ntv < 0 ? c->hs.n_dofs > kNtValsRows : c->spmv_ntv != 0;
     int64_t n = c->hs.n_dofs;   // rows of the CSR arrays the kernel walks (virtual rows for a segmented pattern)
     bool vrows = false;
     if (vals == c->sval.p && c->sp_cur >= 0) {   // the solver's scaled matrix lives in the compact pattern
@@ -604,6 +608,12 @@ void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, 
                     else if (dist) SPMV_GO(k_spmv_c16p<8, 4, 8192>);
                     else if (wx) SPMV_GO(k_spmv_c16p<8, 4, 16384>);
                     else SPMV_GO(k_spmv_c16p<8, 4, 0>);
+                } else if (ntv && c16 && wx) {   // large matrix: hinted value stream (see load_pair)
+                    if (dist) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 8192 | 16384 | 1048576>);
+                    else SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 1048576>);
+                } else if (ntv && c16) {
+                    if (dist) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 8192 | 1048576>);
+                    else SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 1048576>);
                 } else
                     SPMV_PROD(8, 4);
                 break;
@@ -1933,6 +1943,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "cgf_nt" && value >= 0 && value <= 15) c->cgf_nt = value;
     else if (k == "cgf_lazy" && (value == 0 || value == 1)) c->cgf_lazy = value;
     else if (k == "multi_rhs" && (value == 0 || value == 1)) c->multi_rhs = value;
+    else if (k == "spmv_ntv" && value >= -1 && value <= 1) c->spmv_ntv = value;
     else if (k == "spmv_bpx" && value >= 1 && value <= 1024) {
         c->spmv_grid = 8 * value;
         HIPCHK(c, hipSetDevice(c->device));

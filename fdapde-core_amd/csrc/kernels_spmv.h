@@ -311,6 +311,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
         // nontemporal 361.6 us, both default 371.5 us).
         constexpr bool NT_V = ((ABL & 1048576) != 0) != (T >= 16), NT_C = ((ABL & 524288) != 0) != (T >= 16);
         if constexpr (C16) {
+            // Large matrices -- the x / y slices of a row band no longer fit the XCD's L2 next to a default-policy value stream --
+            // are launched with the hint on the values only (flag 1048576: 2.5 M rows 88.5 -> 76.9 us; C3 45.3 -> 52.0 us).  A
+            // run-time switch between the two loads does not survive the optimiser (the loads are merged and the hint dropped).
             v2f64_t a;
             if constexpr (NT_V)
                 a = __builtin_nontemporal_load(reinterpret_cast<const v2f64_t*>(s.vals + kc));

@@ -17,7 +17,7 @@ if os.environ.get("SOLVE"):      # time the solver's compact Jacobi-scaled matri
     ctx.init(); print("solve:", ctx.solve(rtol=1e-10).iters, "iterations")
 configs = [dict(c.split("=") for c in a.split(",")) for a in sys.argv[1:]] or [{"spmv_variant": "2"}]
 res = {i: [] for i in range(len(configs))}
-defaults = {"spmv_variant": 2, "spmv_team": int(os.environ.get("TEAM", "8")), "spmv_unroll": 4, "spmv_bpx": 192, "spmv_ablate": 0, "spmv_c16": 1, "spmv_deep": 0}
+defaults = {"spmv_variant": 2, "spmv_team": int(os.environ.get("TEAM", "8")), "spmv_unroll": 4, "spmv_bpx": 192, "spmv_ablate": 0, "spmv_c16": 1, "spmv_deep": 0, "spmv_ntv": -1}
 for rnd in range(7):
     for i, cfg in enumerate(configs):
         full = dict(defaults); full.update({k: int(v) for k, v in cfg.items()})

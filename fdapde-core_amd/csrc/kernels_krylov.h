@@ -353,6 +353,16 @@ __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, 
     const bool pend = lazy && sc[16 + parity] != 0.0;   // an update of x is pending from the previous launch
     const bool need_x = !lazy || pend;
     const double a_prev = pend ? sc[14] : 0.0, ib_prev = pend ? 1.0 / sc[15] : 0.0;
+    // the producer's partials are requested BEFORE the vectors (loads return in order: issued after them, the partials would
+    // arrive only when the whole vector phase has, and the reduction would start late); they are summed after the vector
+    // loads have been issued
+    constexpr int kPart = 8;   // partial pairs per lane held in registers (2048 pairs per workgroup); more are summed directly
+    double2 pp[kPart];
+#pragma unroll
+    for (int j = 0; j < kPart; ++j) {
+        const int i = threadIdx.x + j * 256;
+        pp[j] = i < np_spmv ? *reinterpret_cast<const double2*>(part_spmv + 2 * i) : make_double2(0.0, 0.0);
+    }
 #pragma unroll
     for (int k = 0; k < kCgV; ++k) {
         const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
@@ -360,7 +370,9 @@ __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, 
         if (need_x) xv[k] = ld(x2, ic, nt & 2);
     }
     double a = 0, b = 0;
-    for (int i = threadIdx.x; i < np_spmv; i += blockDim.x) a += part_spmv[2 * i], b += part_spmv[2 * i + 1];
+#pragma unroll
+    for (int j = 0; j < kPart; ++j) a += pp[j].x, b += pp[j].y;
+    for (int i = threadIdx.x + kPart * 256; i < np_spmv; i += blockDim.x) a += part_spmv[2 * i], b += part_spmv[2 * i + 1];
     const double pAp = block_sum(a, red);
     const double yy = block_sum(b, red);
     const double rr = sum_partials(part_rr_in, np_rr, red);   // launch 0: seeded by k_krylov_init_fin

@@ -217,6 +217,18 @@ __global__ __launch_bounds__(256) void k_cg_update_p(int64_t n, const double* r,
     }
 }
 
+// The producer's stride-2 partials are requested BEFORE a kernel's vector loads and summed after them: loads return in order, so
+// partials issued after the vectors would arrive only when the whole vector phase has (k_cgf_update: 32.8 -> 31.3 ms per C3 solve).
+#define PRELOAD_PAIRS(name, ptr, np)                                                                             \
+    double2 name[8];                                                                                             \
+    _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                                           \
+        const int i_ = threadIdx.x + j_ * 256;                                                                   \
+        name[j_] = i_ < (np) ? *reinterpret_cast<const double2*>((ptr) + 2 * i_) : make_double2(0.0, 0.0);       \
+    }
+#define SUM_PAIRS(name, ptr, np, a, b)                                                                           \
+    _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) a += name[j_].x, b += name[j_].y;                           \
+    for (int i_ = threadIdx.x + 8 * 256; i_ < (np); i_ += blockDim.x) a += (ptr)[2 * i_], b += (ptr)[2 * i_ + 1];
+
 // Single-reduction CG (Chronopoulos & Gear): the SpMV acts on r, both dot products of an iteration -- gamma = r.r and
 // delta = r.(At r) -- are fused into it, and ONE kernel then updates all vectors:
 //     beta = gamma / gamma_old ; alpha = gamma / (delta - beta gamma / alpha_old)
@@ -257,6 +269,7 @@ __global__ __launch_bounds__(256) void k_cgsr_update(int64_t n, double* r, const
     double2* s2 = reinterpret_cast<double2*>(s);
     double2* x2 = reinterpret_cast<double2*>(x);
     double2 rv[kCgV], wv[kCgV], pv[kCgV], sv[kCgV], xv[kCgV];
+    PRELOAD_PAIRS(pp, part_in, np_in)
 #pragma unroll
     for (int k = 0; k < kCgV; ++k) {
         const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
@@ -268,7 +281,7 @@ __global__ __launch_bounds__(256) void k_cgsr_update(int64_t n, double* r, const
         }
     }
     double a = 0, b = 0;
-    for (int i = threadIdx.x; i < np_in; i += blockDim.x) a += part_in[2 * i], b += part_in[2 * i + 1];
+    SUM_PAIRS(pp, part_in, np_in, a, b)
     const double delta = block_sum(a, red);
     const double gamma = block_sum(b, red);
     const bool last = blockIdx.x == gridDim.x - 1 && threadIdx.x == 0;
@@ -363,6 +376,13 @@ __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, 
         const int i = threadIdx.x + j * 256;
         pp[j] = i < np_spmv ? *reinterpret_cast<const double2*>(part_spmv + 2 * i) : make_double2(0.0, 0.0);
     }
+    constexpr int kPartR = 4;   // r.r partials per lane held in registers (1024 per workgroup)
+    double qq[kPartR];
+#pragma unroll
+    for (int j = 0; j < kPartR; ++j) {
+        const int i = threadIdx.x + j * 256;
+        qq[j] = i < np_rr ? part_rr_in[i] : 0.0;
+    }
 #pragma unroll
     for (int k = 0; k < kCgV; ++k) {
         const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
@@ -375,7 +395,11 @@ __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, 
     for (int i = threadIdx.x + kPart * 256; i < np_spmv; i += blockDim.x) a += part_spmv[2 * i], b += part_spmv[2 * i + 1];
     const double pAp = block_sum(a, red);
     const double yy = block_sum(b, red);
-    const double rr = sum_partials(part_rr_in, np_rr, red);   // launch 0: seeded by k_krylov_init_fin
+    double c_ = 0;
+#pragma unroll
+    for (int j = 0; j < kPartR; ++j) c_ += qq[j];
+    for (int i = threadIdx.x + kPartR * 256; i < np_rr; i += blockDim.x) c_ += part_rr_in[i];
+    const double rr = block_sum(c_, red);   // launch 0: seeded by k_krylov_init_fin
     const bool last = blockIdx.x == gridDim.x - 1 && threadIdx.x == 0;
     const bool tail = (n & 1) && blockIdx.x == 0 && threadIdx.x == 0;
     if (rr <= tol2 * sc[0]) {   // converged by the previous update: r stays as it is; a pending update of x is applied
@@ -508,14 +532,16 @@ __global__ __launch_bounds__(256) void k_bicg_p(int64_t n, const double* r, cons
     const double2* v2 = reinterpret_cast<const double2*>(v);
     double2* p2 = reinterpret_cast<double2*>(p);
     double2 rv[kBiV], vv[kBiV], pv[kBiV];
+    PRELOAD_PAIRS(pp, part_in, first ? 0 : np_in)
 #pragma unroll
     for (int k = 0; k < kBiV; ++k) {
         const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
         rv[k] = BI_LD(r2, ic);
         if (!first) vv[k] = BI_LD(v2, ic), pv[k] = BI_LD(p2, ic);
     }
-    double a = 0;
-    for (int i = threadIdx.x; i < np_in; i += blockDim.x) a += part_in[2 * i];
+    double a = 0, a_unused = 0;
+    SUM_PAIRS(pp, part_in, first ? 0 : np_in, a, a_unused)
+    (void)a_unused;
     const double rho_new = first ? sc[9] : block_sum(a, red);
     const double rho = sc[4], alpha = sc[5], omega = sc[6];
     const double beta = first ? 0.0 : (rho_new / rho) * (alpha / omega);
@@ -544,13 +570,15 @@ __global__ __launch_bounds__(256) void k_bicg_s(int64_t n, const double* r, cons
     const double2* v2 = reinterpret_cast<const double2*>(v);
     double2* s2 = reinterpret_cast<double2*>(s);
     double2 rv[kBiV], vv[kBiV];
+    PRELOAD_PAIRS(pp, part_in, np_in)
 #pragma unroll
     for (int k = 0; k < kBiV; ++k) {
         const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
         rv[k] = BI_LD(r2, ic), vv[k] = BI_LD(v2, ic);
     }
-    double a = 0;
-    for (int i = threadIdx.x; i < np_in; i += blockDim.x) a += part_in[2 * i];
+    double a = 0, a_unused = 0;
+    SUM_PAIRS(pp, part_in, np_in, a, a_unused)
+    (void)a_unused;
     const double r0v = block_sum(a, red);
     const double alpha = r0v != 0.0 ? sc[7] / r0v : 0.0;
 #pragma unroll
@@ -578,13 +606,14 @@ __global__ __launch_bounds__(256) void k_bicg_xr(int64_t n, const double* p, con
     double2* x2 = reinterpret_cast<double2*>(x);
     double2* r2 = reinterpret_cast<double2*>(r);
     double2 pv[kBiV], sv[kBiV], tv[kBiV], qv[kBiV], xv[kBiV];
+    PRELOAD_PAIRS(pp, part_in, np_in)
 #pragma unroll
     for (int k = 0; k < kBiV; ++k) {
         const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
         pv[k] = BI_LD(p2, ic), sv[k] = BI_LD(s2, ic), tv[k] = BI_LD(t2, ic), qv[k] = BI_LD(q2, ic), xv[k] = BI_LD(x2, ic);
     }
     double a = 0, b = 0;
-    for (int i = threadIdx.x; i < np_in; i += blockDim.x) a += part_in[2 * i], b += part_in[2 * i + 1];
+    SUM_PAIRS(pp, part_in, np_in, a, b)
     const double ts = block_sum(a, red);
     const double tt = block_sum(b, red);
     const double omega = tt > 0.0 ? ts / tt : 0.0;
@@ -750,6 +779,9 @@ __global__ void k_force_bc(int64_t n, const uint8_t* bnd, const double* g, doubl
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && bnd[i]) f[i] = g[i];
 }
+
+#undef PRELOAD_PAIRS
+#undef SUM_PAIRS
 
 }  // namespace fdapde_hip
 #endif

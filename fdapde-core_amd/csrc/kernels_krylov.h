@@ -338,7 +338,9 @@ __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, 
                                                      double* part_rr_out, double* sc, double tol2, int32_t* ctl, int64_t band2,
                                                      int nt, int lazy, int parity) {
     __shared__ double red[8];
-    if (__syncthreads_or(ctl[0] != 0)) return;
+    // the stop flag is REQUESTED first and tested after the vector loads have been issued: its round trip overlaps with theirs
+    // instead of preceding them (a stopped launch wastes its loads, which costs nothing that matters)
+    const int32_t stop_flag = __builtin_nontemporal_load(ctl);
     const int64_t n2_all = n >> 1;
     const int64_t lo = band2 > 0 ? (int64_t)(blockIdx.x & 7) * band2 : 0;
     const int64_t n2 = band2 > 0 ? min(n2_all, lo + band2) : n2_all;   // end of this workgroup's element range
@@ -389,6 +391,7 @@ __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, 
         pv[k] = ld(p2, ic, nt & 8), yv[k] = ld(y2, ic, nt & 1), rv[k] = ld(r2, ic, nt & 4);
         if (need_x) xv[k] = ld(x2, ic, nt & 2);
     }
+    if (__syncthreads_or(stop_flag != 0)) return;   // uniform even if another workgroup raises the flag meanwhile
     double a = 0, b = 0;
 #pragma unroll
     for (int j = 0; j < kPart; ++j) a += pp[j].x, b += pp[j].y;

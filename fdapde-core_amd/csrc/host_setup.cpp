@@ -30,8 +30,15 @@ namespace fdapde_hip {
 namespace {
 
 unsigned hw_threads() {
-    unsigned n = std::thread::hardware_concurrency();
-    return n == 0 ? 4 : std::min(n, 64u);
+    static const unsigned cached = [] {
+        if (const char* e = std::getenv("FDAPDE_THREADS")) {   // set-up threads (default: hardware concurrency, at most 64)
+            const int v = std::atoi(e);
+            if (v >= 1) return (unsigned)std::min(v, 256);
+        }
+        const unsigned n = std::thread::hardware_concurrency();
+        return n == 0 ? 4u : std::min(n, 64u);
+    }();
+    return cached;
 }
 
 // run fn(begin, end, tid) over [0, n) in contiguous chunks

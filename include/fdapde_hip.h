@@ -194,7 +194,8 @@ int fdapde_bench_spmv(fdapde_ctx *ctx, int32_t reps, double *avg_ms, double *alg
  *                           rank's DOF id, reference numbering of the LOCAL space) <-> if_index[k] (slot in the global
  *                           interface vector), k < n_if_local; owned[d] = 1 iff this rank counts local DOF d in global
  *                           dot products (every global DOF is owned by exactly one rank).
- * After fdapde_halo_setup, fdapde_solve runs the distributed Jacobi-PCG (BiCGStab: single GPU only). */
+ * After fdapde_halo_setup every solve of the context is element-partitioned: fdapde_solve (single-reduction CG or BiCGStab),
+ * fdapde_solve_parabolic, fdapde_lin_solve (right-hand sides sub-assembled, i.e. summed over the ranks sharing a DOF). */
 /* host-staged transport instead of RCCL: fn(user, host_buf, count) must replace host_buf by its sum over all ranks and
  * return 0.  Lets the distributed path run over any fabric (tests drive it with torch.distributed/gloo, two ranks on one GPU). */
 typedef int (*fdapde_allreduce_fn)(void *user, double *host_buf, int64_t count);
@@ -204,8 +205,13 @@ int fdapde_comm_init(fdapde_ctx *ctx, int32_t world, int32_t rank, const void *u
 int fdapde_halo_setup(fdapde_ctx *ctx, int64_t n_if_global, int64_t n_if_local, const int32_t *local_dof,
                       const int32_t *if_index, const uint8_t *owned);
 
-/* tuning / diagnostic knobs of the SpMV launch (A/B measurements inside one process): key in {"spmv_variant" (2 pair form,
- * 0 team form, 1 stream form), "spmv_team", "spmv_unroll", "spmv_bpx" (workgroups per XCD band), "spmv_ablate"} */
+/* tuning / diagnostic knobs (A/B measurements inside one process; defaults are the measured best):
+ *   SpMV launch   "spmv_variant" (2 pair form, 0 team form, 1 stream form), "spmv_team", "spmv_unroll", "spmv_bpx" (workgroups
+ *                 per XCD band), "spmv_ablate" (diagnostic instantiations), "spmv_c16" (16-bit column codes), "spmv_deep"
+ *                 (gathers one tile ahead), "spmv_ntv" (-1 auto / 0 / 1: nontemporal value stream)
+ *   fused CG      "cgf_v" (double2 per lane), "cgf_band" (XCD-aware mapping), "cgf_nt" (bit set: y, x, r, p nontemporal),
+ *                 "cgf_lazy" (x touched every second launch), "use_graph" (hipGraph replay of a chunk of iterations)
+ *   handle        "multi_rhs" (batched multi-column solves) */
 int fdapde_tune(fdapde_ctx *ctx, const char *key, int32_t value);
 /* the context's HIP stream (hipStream_t) so that callers can bracket work with their own events */
 void *fdapde_stream(fdapde_ctx *ctx);

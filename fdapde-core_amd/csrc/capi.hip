@@ -11,189 +11,8 @@
 #include <hip/hip_ext.h>
 #include <rccl/rccl.h>
 
-#include "kernels.h"
+#include "context.h"
 
-using namespace fdapde_hip;
-
-#define HIPCHK(ctx, expr)                                                                              \
-    do {                                                                                               \
-        hipError_t e__ = (expr);                                                                       \
-        if (e__ != hipSuccess) {                                                                       \
-            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                           \
-            return FDAPDE_EHIP;                                                                        \
-        }                                                                                              \
-    } while (0)
-
-namespace {
-
-template <typename T> struct DBuf {
-    T* p = nullptr;
-    size_t n = 0;
-    hipError_t alloc(size_t count) {
-        if (p && n >= count && count > 0) return hipSuccess;
-        release();
-        n = count;
-        return hipMalloc(reinterpret_cast<void**>(&p), sizeof(T) * (count ? count : 1));
-    }
-    hipError_t upload(const T* src, size_t count, hipStream_t st) {
-        hipError_t e = alloc(count);
-        if (e != hipSuccess || count == 0) return e;
-        return hipMemcpyAsync(p, src, sizeof(T) * count, hipMemcpyHostToDevice, st);
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr, n = 0;
-    }
-    DBuf() = default;
-    DBuf(const DBuf&) = delete;
-    DBuf& operator=(const DBuf&) = delete;
-    ~DBuf() { release(); }   // locals on an error return; context members are released explicitly before the context dies
-};
-
-// RCCL is loaded on first use (dlopen) so that single-GPU users and CPU-only boxes never need it
-struct RcclApi {
-    void* handle = nullptr;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-    const char* (*GetErrorString)(ncclResult_t) = nullptr;
-    bool load(std::string& err) {
-        if (handle) return true;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (handle) break;
-        }
-        if (!handle) {
-            err = std::string("cannot load librccl: ") + dlerror();
-            return false;
-        }
-        GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(handle, "ncclGetUniqueId"));
-        CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(handle, "ncclCommInitRank"));
-        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(handle, "ncclCommDestroy"));
-        AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(handle, "ncclAllReduce"));
-        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(handle, "ncclGetErrorString"));
-        if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GetErrorString) {
-            err = "librccl lacks a required symbol";
-            return false;
-        }
-        return true;
-    }
-};
-RcclApi g_rccl;
-
-struct HostTerm {
-    fdapde_term t;
-    std::vector<double> data_i;   // space-varying data permuted to internal cell order
-};
-
-}  // namespace
-
-// fdapde_options.time_spmv samples every kTimeStride-th Krylov iteration (the first iterations after init run on cold caches
-// and are not representative of the solve: 45.7 us against a kernel-trace average of 43.9 us on C3)
-constexpr int64_t kNtValsRows = 2000000;   // above this many rows the SpMV of teams <= 8 hints its value stream (see load_pair)
-constexpr int kTimeStride = 8, kTimePhase = 3;   // phase 3: never the first launch after a host poll (the GPU has just idled)
-
-// everything the captured launch sequence of a CG chunk depends on (the graph is rebuilt when any of it changes)
-struct GraphKey {
-    const void* sval;
-    const void* rowptr;
-    int64_t n;
-    double tol2;
-    int chunk, v, grid, team, ablate, c16, deep, unroll, sp_cur;
-};
-
-// what solve_prepare decided for a system matrix (shared by the elliptic, parabolic and handle solves)
-struct SolveState {
-    bool dist = false, diag_positive = true;
-    const uint8_t* owned = nullptr;
-    int use_bnd = 0;
-};
-struct SolveStateHolder {
-    SolveState ss;
-};
-
-struct fdapde_ctx {
-    int device = -1;
-    bool has_device = false;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::vector<hipEvent_t> ev_spmv;   // 2 per timed SpMV launch
-    std::string err;
-    HostSpace hs;
-    BasisTables tb;
-    bool space_ready = false, dev_ready = false, colour_ready = false;
-    bool assembled[2] = {false, false};
-    bool force_ready = false, solved = false, dirichlet_applied = false;
-    // problem data (host copies)
-    std::vector<HostTerm> op;
-    bool op_symmetric = true;
-    std::vector<double> fq_i;   // internal cell order, column-major rows x ncols
-    int fq_cols = 0;
-    std::vector<double> g_i;    // internal DOF order
-    bool have_g = false;
-    fdapde_info info{};
-    // device buffers
-    DBuf<int32_t> cverts, cdofs, adj, rowptr, colidx, diag, slot_i2e, dof_i2e, dof_e2i, cell_i2e, rb_row, colour_cells;
-    DBuf<uint32_t> slotw;
-    DBuf<int64_t> bc_off, bn_off;
-    DBuf<int32_t> bc_cell, bn_node;
-    DBuf<uint16_t> bc_vert;
-    DBuf<int64_t> sl_off;
-    DBuf<double> vcoords, vals[2], force, fq, g, sval, scale, gt, x, r, p, y, s, t, r0, u, part_a, part_b, sc, tmp_e,
-      tmp_i, tmp_v;
-    DBuf<uint8_t> bnd;
-    DBuf<DevTables> tables;
-    DBuf<DevRefTensors> reftab;
-    DBuf<int32_t> ctl;
-    DBuf<double> coef[kMaxTerms];
-    int32_t* h_ctl = nullptr;   // pinned: ctl[3]
-    double* h_sc = nullptr;     // pinned: sc[0..3]
-    int spmv_grid = 0, rb_per_band = 0, vec_grid = 0, n_rb = 0, cg_grid = 0;
-    int spmv_variant = 2;   // 2: team form, 2 entries per lane (default); 0: team form, 1 entry per lane
-                            // (FDAPDE_SPMV=team); 1: stream form (FDAPDE_SPMV=stream) -- kept for A/B measurements
-    int spmv_team = 16, spmv_unroll = 4, spmv_ablate = 0;
-    int lds_limit = 96 * 1024;   // per assembly workgroup: tables + staged vertices + row accumulators
-    // compact solver pattern (no diagonal; [1]: also no Dirichlet rows / columns), built on first use
-    DBuf<int32_t> sp_rowptr[2], sp_colidx[2], sp_map[2], sp_tbase[2], sp_vrow[2];
-    int64_t sp_nv[2] = {0, 0};               // > 0: the compact pattern is segmented into this many virtual rows (sp_vrow)
-    int sval_layout = -2;                    // layout sval was last zero-filled for (pad entries of a segmented pattern stay 0)
-    DBuf<uint16_t> sp_col16[2];              // 16-bit column codes of the compact pattern (host_build_col16)
-    int64_t sp_wide[2] = {0, 0};             // groups of 32 rows that fall back to the 32-bit columns
-    int spmv_ntv = -1;                       // tuning knob: -1 auto (by size), 0 / 1 force the value-stream policy of teams <= 8
-    int sp_team = 0;                         // team size the segmented patterns were built for
-    int spmv_c16 = 1;                        // tuning knob: 0 = always stream the 32-bit columns
-    int use_graph = 0;                       // tuning knob: replay full chunks of the fused-update CG as one hipGraph
-    hipGraphExec_t cg_graph_exec = nullptr;
-    GraphKey cg_graph_key{};
-    int cgf_lazy = 1;                        // tuning knob: x updated every second launch of k_cgf_update (C3 solve 33.3 -> 32.5 ms, same iterations)
-    int cgf_nt = 7;                          // tuning knob, bit set: nontemporal y (1), x (2), r (4), p load (8) in k_cgf_update
-    int cgf_band = 1;                        // tuning knob: XCD-aware mapping + nontemporal x / r / y in k_cgf_update (C3 solve 41.80 -> 41.10 ms)
-    int cgf_v = 8;                           // double2 elements per lane of k_cgf_update (1, 2, 4, 8); C3 solve: 47.2 / 41.8 / 41.3 / 40.9 ms
-    int spmv_deep = 0;                       // tuning knob: 1 = k_spmv_c16p (gathers one tile ahead; measured slower: 3 waves / SIMD)
-    int64_t sp_nnz[2] = {0, 0};
-    bool sp_built[2] = {false, false};
-    int sp_cur = -1;   // which compact pattern c->sval currently holds (-1: full pattern)
-    // multi-GPU (element partition): RCCL communicator + interface maps
-    ncclComm_t comm = nullptr;
-    fdapde_allreduce_fn ar_fn = nullptr;     // host-staged transport (tests / non-RCCL fabrics) instead of the RCCL communicator
-    void* ar_user = nullptr;
-    std::vector<double> ar_host;
-    int world = 1, rank = 0;
-    bool halo_ready = false;
-    int64_t n_if = 0, n_loc_if = 0;          // global / local interface DOF counts
-    DBuf<int32_t> halo_dof, halo_pos;        // local interface DOF (internal id) -> slot in the global interface vector
-    DBuf<int32_t> halo_inv, if_slot;         // global slot -> local DOF or -1 [n_if]; local DOF -> global slot or -1 [n_dofs]
-    DBuf<uint8_t> owned;                     // internal DOF order: 1 = this rank counts the DOF in global dot products
-    DBuf<double> hbuf, sbuf;                 // [n_if + 2] packed interface values + fused dot partials; [4] scalars
-    // "factor once, solve many" handle (fdapde::SparseLU wrapper, utils/symbols.h:133-160)
-    DBuf<double> lin_mat;                    // the matrix handed to fdapde_lin_compute, internal slots
-    bool lin_ready = false, lin_symmetric = false;
-    DBuf<double> lin_sq;                     // full-pattern Jacobi-scaled copy of the handle's matrix (multi-RHS SpMM)
-    bool lin_sq_ready = false;
-    int multi_rhs = 1;                       // tuning knob: 0 = always solve the columns of fdapde_lin_solve one by one
-    SolveStateHolder* lin_state = nullptr;
-};
 
 namespace {
 

@@ -728,8 +728,12 @@ int fdapde_set_dirichlet(fdapde_ctx* c, const double* g) {
         return FDAPDE_OK;
     }
     c->g_i.resize((size_t)hs.n_dofs);
-    for (int64_t i = 0; i < hs.n_dofs; ++i) c->g_i[(size_t)i] = g[hs.dof_i2e[(size_t)i]];
-    c->have_g = true;
+    bool all_zero = true;
+    for (int64_t i = 0; i < hs.n_dofs; ++i) {
+        c->g_i[(size_t)i] = g[hs.dof_i2e[(size_t)i]];
+        all_zero = all_zero && c->g_i[(size_t)i] == 0.0;
+    }
+    c->have_g = true, c->g_zero = all_zero;
     if (c->has_device) {
         HIPCHK(c, hipSetDevice(c->device));
         HIPCHK(c, c->g.upload(c->g_i.data(), c->g_i.size(), c->stream));
@@ -916,9 +920,15 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
         fvec = c->tmp_e.p;
     }
     hipLaunchKernelGGL(k_lift, dim3(g1(n)), dim3(256), 0, st, n, c->bnd.p, g_dev, ss.use_bnd, c->gt.p);
-    launch_spmv(c, A, c->gt.p, c->y.p, nullptr, nullptr, nullptr);   // y = A g~
-    if (dist)
-        if (int rc = halo_sum(c, c->y.p, nullptr, 0)) return rc;
+    // the lift is zero (no Dirichlet data, or homogeneous data on one GPU -- across ranks the data may differ, and every rank
+    // must take the same path through the collectives): A g~ = 0
+    if (!ss.use_bnd || (!dist && g_dev == c->g.p && c->g_zero)) {
+        HIPCHK(c, hipMemsetAsync(c->y.p, 0, sizeof(double) * (size_t)n, st));
+    } else {
+        launch_spmv(c, A, c->gt.p, c->y.p, nullptr, nullptr, nullptr);   // y = A g~
+        if (dist)
+            if (int rc = halo_sum(c, c->y.p, nullptr, 0)) return rc;
+    }
     if (method == FDAPDE_SOLVER_AUTO)   // symmetric + positive diagonal: CG (fused-update form on one GPU, single-reduction form on several)
         method = (c->op_symmetric && ss.diag_positive) ? (dist ? FDAPDE_SOLVER_CG : FDAPDE_SOLVER_CG_FUSED) : FDAPDE_SOLVER_BICGSTAB;
     if (method == FDAPDE_SOLVER_CG && dist && c->world > 1) method = FDAPDE_SOLVER_CG_SR;   // one all-reduce per iteration

@@ -137,7 +137,7 @@ struct fdapde_ctx {
     std::vector<double> fq_i;   // internal cell order, column-major rows x ncols
     int fq_cols = 0;
     std::vector<double> g_i;    // internal DOF order
-    bool have_g = false;
+    bool have_g = false, g_zero = false;   // Dirichlet data set; all of it zero (homogeneous: the lift A g~ vanishes)
     fdapde_info info{};
     // device buffers
     DBuf<int32_t> cverts, cdofs, adj, rowptr, colidx, diag, slot_i2e, dof_i2e, dof_e2i, cell_i2e, rb_row, colour_cells;

@@ -387,7 +387,8 @@ void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, 
         case 2: SPMV_PROD_FEW(2, 1); break;
         case 4: SPMV_PROD_FEW(4, 2); break;
         case 8:
-            switch (c->spmv_ablate) {
+            // the diagnostic forms >= 100 exist for the compact coded matrix only: any other product takes the production path
+            switch ((c->spmv_ablate >= 100 && !c16) ? 0 : c->spmv_ablate) {
             case 1: SPMV_GO(k_spmv_team2<8, 4, 1>); break;
             case 2: SPMV_GO(k_spmv_team2<8, 4, 2>); break;
             case 4: SPMV_GO(k_spmv_team2<8, 4, 4>); break;

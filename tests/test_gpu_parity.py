@@ -540,3 +540,31 @@ def test_lazy_x_update_matches_eager(capi, ctx, oracle, mesh_loader):
         assert np.abs(sol[0][0] - sol[1][0]).max() <= 1e-13 * np.abs(sol[0][0]).max(), kw
     assert seen == {0, 1}          # both parities of the last executed update were exercised
     ctx.tune("cgf_lazy", 1)
+
+
+def test_tuning_knobs_do_not_change_results(capi, oracle, mesh_loader):
+    """every fdapde_tune knob selects another measured form of the same computation: same iterations, same
+    solution up to rounding"""
+    from fdapde_core_amd import meshgen
+
+    nodes, cells, bnd = meshgen.unit_cube(16)
+    c = capi.Context(device=0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(1)
+    _, _, coords = c.dofs_get()
+    qn = c.quadrature_nodes()
+    c.set_operator(-capi.laplacian() + capi.reaction(0.4))
+    c.set_forcing(np.sin(2 * qn[:, 0]) + qn[:, 2])
+    c.set_dirichlet(0.2 * coords[:, 1])
+    c.init()
+    base = c.solve(rtol=1e-11)
+    u0 = c.solution()
+    defaults = dict(spmv_deep=0, use_graph=0, spmv_c16=1, cgf_band=1, cgf_nt=7, cgf_lazy=1, cgf_v=8, spmv_ntv=-1, spmv_bpx=None)
+    for key, value in [("spmv_deep", 1), ("use_graph", 1), ("spmv_c16", 0), ("cgf_band", 0), ("cgf_nt", 0), ("cgf_lazy", 0), ("cgf_v", 2),
+                       ("spmv_ntv", 1), ("spmv_ablate", 150), ("spmv_ablate", 151), ("spmv_ablate", 152), ("spmv_ablate", 3)]:
+        c.tune(key, value)
+        info = c.solve(rtol=1e-11)
+        assert info.converged == 1 and abs(info.iters - base.iters) <= 1, (key, value, info.iters, base.iters)
+        assert np.abs(c.solution() - u0).max() <= 1e-10 * np.abs(u0).max(), (key, value)
+        c.tune(key, 0 if key == "spmv_ablate" else defaults[key])
+    c.close()

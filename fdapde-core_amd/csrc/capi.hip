@@ -985,11 +985,13 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     auto enqueue_cgf = [&](int it, hipEvent_t e0, hipEvent_t e1) {
         const int cg = cgf_grid;
         launch_spmv(c, c->sval.p, c->p.p, c->y.p, c->p.p, c->part_a.p, c->ctl.p, e0, e1);   // p.y and y.y
-#define CGF_GO(V_)                                                                                                         \
-    hipLaunchKernelGGL(k_cgf_update<V_>, dim3(cg), dim3(256), 0, st, n, c->y.p, c->p.p, c->x.p, c->r.p, c->part_a.p, c->spmv_grid, \
+#define CGF_GO(...)                                                                                                        \
+    hipLaunchKernelGGL((k_cgf_update<__VA_ARGS__>), dim3(cg), dim3(256), 0, st, n, c->y.p, c->p.p, c->x.p, c->r.p, c->part_a.p, c->spmv_grid, \
                        c->part_b.p + (size_t)((it + 1) & 1) * cg, cg, c->part_b.p + (size_t)(it & 1) * cg, c->sc.p, tol2, c->ctl.p, \
                        cgf_band2, c->cgf_nt, c->cgf_lazy, it & 1)
-        if (cgf_V == 1) CGF_GO(1);
+        if (c->cgf_split && cgf_V == 8) CGF_GO(8, 1);
+        else if (c->cgf_split && cgf_V == 4) CGF_GO(4, 1);
+        else if (cgf_V == 1) CGF_GO(1);
         else if (cgf_V == 2) CGF_GO(2);
         else if (cgf_V == 8) CGF_GO(8);
         else CGF_GO(4);
@@ -1767,6 +1769,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "spmv_ablate") c->spmv_ablate = value;
     else if (k == "spmv_c16" && (value == 0 || value == 1)) c->spmv_c16 = value;
     else if (k == "spmv_deep" && (value == 0 || value == 1)) c->spmv_deep = value;
+    else if (k == "cgf_split" && (value == 0 || value == 1)) c->cgf_split = value;
     else if (k == "cgf_v" && (value == 1 || value == 2 || value == 4 || value == 8)) c->cgf_v = value;
     else if (k == "use_graph" && (value == 0 || value == 1)) c->use_graph = value;
     else if (k == "cgf_band" && (value == 0 || value == 1)) c->cgf_band = value;

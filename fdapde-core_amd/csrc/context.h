@@ -175,6 +175,7 @@ struct fdapde_ctx {
     int cgf_lazy = 1;                        // tuning knob: x updated every second launch of k_cgf_update (C3 solve 33.3 -> 32.5 ms, same iterations)
     int cgf_nt = 7;                          // tuning knob, bit set: nontemporal y (1), x (2), r (4), p load (8) in k_cgf_update
     int cgf_band = 1;                        // tuning knob: XCD-aware mapping + nontemporal x / r / y in k_cgf_update (C3 solve 41.80 -> 41.10 ms)
+    int cgf_split = 0;                       // k_cgf_update requests the second half of its elements after the scalars (diagnostic)
     int cgf_v = 8;                           // double2 elements per lane of k_cgf_update (1, 2, 4, 8); C3 solve: 47.2 / 41.8 / 41.3 / 40.9 ms
     int spmv_deep = 0;                       // tuning knob: 1 = k_spmv_c16p (gathers one tile ahead; measured slower: 3 waves / SIMD)
     int64_t sp_nnz[2] = {0, 0};

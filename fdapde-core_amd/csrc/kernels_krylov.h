@@ -332,7 +332,9 @@ __global__ __launch_bounds__(256) void k_cgsr_update(int64_t n, double* r, const
 // p_prev), and applies both updates: x += alpha_prev p_prev + alpha p.  6 instead of 7 vector passes on average.  Whoever
 // detects convergence with an update pending applies it first (here, or k_cgf_flush after the loop).
 constexpr double kLazyBeta = 0.25;
-template <int kCgV>
+// kSplit (knob cgf_split): the second half of the lane's elements is requested only after the scalars are known, so that its
+// loads are in flight while the first half is stored (read and write phases of the launch overlap).
+template <int kCgV, int kSplit = 0>
 __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, double* p, double* x, double* r,
                                                      const double* part_spmv, int np_spmv, const double* part_rr_in, int np_rr,
                                                      double* part_rr_out, double* sc, double tol2, int32_t* ctl, int64_t band2,
@@ -385,8 +387,9 @@ __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, 
         const int i = threadIdx.x + j * 256;
         qq[j] = i < np_rr ? part_rr_in[i] : 0.0;
     }
+    constexpr int kFirst = (kSplit && kCgV > 1) ? kCgV / 2 : kCgV;
 #pragma unroll
-    for (int k = 0; k < kCgV; ++k) {
+    for (int k = 0; k < kFirst; ++k) {
         const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
         pv[k] = ld(p2, ic, nt & 8), yv[k] = ld(y2, ic, nt & 1), rv[k] = ld(r2, ic, nt & 4);
         if (need_x) xv[k] = ld(x2, ic, nt & 2);
@@ -403,6 +406,12 @@ __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, 
     for (int j = 0; j < kPartR; ++j) c_ += qq[j];
     for (int i = threadIdx.x + kPartR * 256; i < np_rr; i += blockDim.x) c_ += part_rr_in[i];
     const double rr = block_sum(c_, red);   // launch 0: seeded by k_krylov_init_fin
+#pragma unroll
+    for (int k = kFirst; k < kCgV; ++k) {
+        const int64_t i = i0 + k * 256, ic = i < n2 ? i : 0;
+        pv[k] = ld(p2, ic, nt & 8), yv[k] = ld(y2, ic, nt & 1), rv[k] = ld(r2, ic, nt & 4);
+        if (need_x) xv[k] = ld(x2, ic, nt & 2);
+    }
     const bool last = blockIdx.x == gridDim.x - 1 && threadIdx.x == 0;
     const bool tail = (n & 1) && blockIdx.x == 0 && threadIdx.x == 0;
     if (rr <= tol2 * sc[0]) {   // converged by the previous update: r stays as it is; a pending update of x is applied

@@ -210,7 +210,8 @@ int fdapde_halo_setup(fdapde_ctx *ctx, int64_t n_if_global, int64_t n_if_local, 
  *                 per XCD band), "spmv_ablate" (diagnostic instantiations), "spmv_c16" (16-bit column codes), "spmv_deep"
  *                 (gathers one tile ahead), "spmv_ntv" (-1 auto / 0 / 1: nontemporal value stream)
  *   fused CG      "cgf_v" (double2 per lane), "cgf_band" (XCD-aware mapping), "cgf_nt" (bit set: y, x, r, p nontemporal),
- *                 "cgf_lazy" (x touched every second launch), "use_graph" (hipGraph replay of a chunk of iterations)
+ *                 "cgf_lazy" (x touched every second launch), "cgf_split" (second half of the loads after the scalars),
+ *                 "use_graph" (hipGraph replay of a chunk of iterations)
  *   handle        "multi_rhs" (batched multi-column solves) */
 int fdapde_tune(fdapde_ctx *ctx, const char *key, int32_t value);
 /* the context's HIP stream (hipStream_t) so that callers can bracket work with their own events */

@@ -559,8 +559,8 @@ def test_tuning_knobs_do_not_change_results(capi, oracle, mesh_loader):
     c.init()
     base = c.solve(rtol=1e-11)
     u0 = c.solution()
-    defaults = dict(spmv_deep=0, use_graph=0, spmv_c16=1, cgf_band=1, cgf_nt=7, cgf_lazy=1, cgf_v=8, spmv_ntv=-1, spmv_bpx=None)
-    for key, value in [("spmv_deep", 1), ("use_graph", 1), ("spmv_c16", 0), ("cgf_band", 0), ("cgf_nt", 0), ("cgf_lazy", 0), ("cgf_v", 2),
+    defaults = dict(spmv_deep=0, use_graph=0, spmv_c16=1, cgf_band=1, cgf_nt=7, cgf_lazy=1, cgf_v=8, cgf_split=0, spmv_ntv=-1, spmv_bpx=None)
+    for key, value in [("spmv_deep", 1), ("use_graph", 1), ("spmv_c16", 0), ("cgf_band", 0), ("cgf_nt", 0), ("cgf_lazy", 0), ("cgf_v", 2), ("cgf_split", 1),
                        ("spmv_ntv", 1), ("spmv_ablate", 150), ("spmv_ablate", 151), ("spmv_ablate", 152), ("spmv_ablate", 3)]:
         c.tune(key, value)
         info = c.solve(rtol=1e-11)

@@ -11,7 +11,7 @@ ctx.mesh_upload(*meshgen.unit_cube(nx)); nd = ctx.dofs_build(1)
 u_exact, f = meshgen.manufactured(3)
 ctx.set_operator(-capi.laplacian()); ctx.set_forcing(f(ctx.quadrature_nodes())); ctx.set_dirichlet(np.zeros(nd)); ctx.init()
 configs = [dict(c.split("=") for c in a.split(",")) for a in sys.argv[1:]] or [{"cgf_v": "4"}]
-defaults = {"cgf_v": 8, "cgf_band": 1, "cgf_nt": 7, "cgf_lazy": 1, "spmv_bpx": 192}
+defaults = {"cgf_v": 8, "cgf_band": 1, "cgf_nt": 7, "cgf_lazy": 1, "spmv_bpx": 192, "cgf_split": 0}
 res = {i: [] for i in range(len(configs))}
 for rnd in range(5):
     for i, cfg in enumerate(configs):

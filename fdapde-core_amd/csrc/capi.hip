@@ -40,12 +40,7 @@ int upload_space(fdapde_ctx* c) {
     HIPCHK(c, c->bn_node.upload(hs.bn_node.data(), hs.bn_node.size(), st));
     HIPCHK(c, c->bc_vert.upload(hs.bc_vert.data(), hs.bc_vert.size(), st));
     HIPCHK(c, c->rowptr.upload(hs.rowptr_i.data(), hs.rowptr_i.size(), st));
-    {
-        std::vector<int32_t> padded(hs.colidx_i);
-        padded.push_back(0), padded.push_back(0);
-        HIPCHK(c, c->colidx.upload(padded.data(), padded.size(), st));
-        HIPCHK(c, hipStreamSynchronize(st));
-    }
+    HIPCHK(c, c->colidx.upload(hs.colidx_i.data(), hs.colidx_i.size(), st));   // nnz + 2 padding entries
     HIPCHK(c, c->diag.upload(hs.diag_i.data(), hs.diag_i.size(), st));
     HIPCHK(c, c->slot_i2e.upload(hs.slot_i2e.data(), hs.slot_i2e.size(), st));
     HIPCHK(c, c->dof_i2e.upload(hs.dof_i2e.data(), hs.dof_i2e.size(), st));

@@ -66,7 +66,7 @@ unsigned n_chunks(int64_t n, int64_t grain = 4096) {
 
 // LSD radix sort of (key, value) pairs by 64-bit key, 11-bit digits; stable; every pass is parallel (per-thread digit
 // histograms over contiguous chunks, offsets in digit-major / thread-minor order, in-order scatter)
-void radix_sort_pairs(std::vector<uint64_t>& key, std::vector<int32_t>& val) {
+void radix_sort_pairs(hvec<uint64_t>& key, hvec<int32_t>& val) {
     const size_t n = key.size();
     if (n < 2) return;
     constexpr int B = 11;
@@ -83,8 +83,8 @@ void radix_sort_pairs(std::vector<uint64_t>& key, std::vector<int32_t>& val) {
     }, 1);
     uint64_t all_or = 0;
     for (uint64_t o : ors) all_or |= o;
-    std::vector<uint64_t> k2(n);
-    std::vector<int32_t> v2(n);
+    hvec<uint64_t> k2(n);   // uninitialised: first touched by the scatter threads
+    hvec<int32_t> v2(n);
     std::vector<size_t> cnt((size_t)nt * R);
     for (int shift = 0; shift < 64 && (all_or >> shift) != 0; shift += B) {
         parallel_for((int64_t)nt, [&](int64_t tb, int64_t te, unsigned) {
@@ -179,9 +179,11 @@ inline uint64_t spread2(uint64_t x) {  // 31 bits -> every second bit
 }
 
 // permutation that sorts points (column-major n x N) along the Morton curve; returns i2e (new -> old)
-std::vector<int32_t> morton_order(int N, int64_t n, const double* pts_colmajor) {
-    std::vector<int32_t> idx((size_t)n);
-    std::iota(idx.begin(), idx.end(), 0);
+hvec<int32_t> morton_order(int N, int64_t n, const double* pts_colmajor) {
+    hvec<int32_t> idx((size_t)n);
+    parallel_for(n, [&](int64_t b, int64_t e, unsigned) {
+        for (int64_t i = b; i < e; ++i) idx[(size_t)i] = (int32_t)i;
+    }, 1 << 16);
     if (n < 2) return idx;
     double lo[3], hi[3];
     {
@@ -206,7 +208,7 @@ std::vector<int32_t> morton_order(int N, int64_t n, const double* pts_colmajor) 
         }
     }
     const double span = N == 3 ? 2097151.0 : 2147483647.0;
-    std::vector<uint64_t> key((size_t)n);
+    hvec<uint64_t> key((size_t)n);
     parallel_for(n, [&](int64_t b, int64_t e, unsigned) {
         for (int64_t i = b; i < e; ++i) {
             uint64_t q[3] = {0, 0, 0};
@@ -222,8 +224,8 @@ std::vector<int32_t> morton_order(int N, int64_t n, const double* pts_colmajor) 
     return idx;
 }
 
-std::vector<int32_t> invert(const std::vector<int32_t>& p) {
-    std::vector<int32_t> inv(p.size());
+hvec<int32_t> invert(const hvec<int32_t>& p) {
+    hvec<int32_t> inv(p.size());
     parallel_for((int64_t)p.size(), [&](int64_t b, int64_t e, unsigned) {
         for (int64_t i = b; i < e; ++i) inv[(size_t)p[(size_t)i]] = (int32_t)i;
     }, 1 << 16);
@@ -357,8 +359,9 @@ int host_set_mesh(HostSpace& hs, int M, int N, int64_t n_nodes, const double* no
         }
     hs = HostSpace{};
     hs.M = M, hs.N = N, hs.n_nodes = n_nodes, hs.n_cells = n_cells;
-    hs.nodes.assign(nodes, nodes + n_nodes * N);
-    hs.cells.assign(cells, cells + n_cells * (M + 1));
+    hs.nodes.resize((size_t)(n_nodes * N)), hs.cells.resize((size_t)(n_cells * (M + 1)));
+    parallel_for(n_nodes * N, [&](int64_t b, int64_t e, unsigned) { std::memcpy(&hs.nodes[(size_t)b], nodes + b, sizeof(double) * (size_t)(e - b)); }, 1 << 16);
+    parallel_for(n_cells * (M + 1), [&](int64_t b, int64_t e, unsigned) { std::memcpy(&hs.cells[(size_t)b], cells + b, sizeof(int32_t) * (size_t)(e - b)); }, 1 << 16);
     hs.node_bnd.resize((size_t)n_nodes);
     for (int64_t i = 0; i < n_nodes; ++i) hs.node_bnd[(size_t)i] = bnd[i] ? 1 : 0;
     return FDAPDE_OK;
@@ -388,9 +391,11 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
     const int64_t nc = hs.n_cells, nn = hs.n_nodes;
 
     // ---- DOF table, boundary DOFs (reference numbering) ------------------------------------------------------
-    hs.dofs.assign((size_t)nc * nb, 0);
-    for (int64_t c = 0; c < nc; ++c)
-        for (int v = 0; v < nv; ++v) hs.dofs[(size_t)c * nb + v] = hs.cells[(size_t)c * nv + v];
+    hs.dofs.resize((size_t)nc * nb);   // vertex slots here, edge slots (order 2) below: every slot is written
+    parallel_for(nc, [&](int64_t b, int64_t e, unsigned) {
+        for (int64_t c = b; c < e; ++c)
+            for (int v = 0; v < nv; ++v) hs.dofs[(size_t)c * nb + v] = hs.cells[(size_t)c * nv + v];
+    }, 1 << 14);
     hs.dof_bnd.assign(hs.node_bnd.begin(), hs.node_bnd.end());
     hs.n_edges = 0;
     if (order == 2) {
@@ -414,8 +419,11 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
     // ---- DOF coordinates: vertices, then J * ref + x0 from the first visiting cell (lagrangian_basis.h:159-183)
     BasisTables tb;
     build_basis_tables(M, order, &tb);
-    hs.dof_coords.assign((size_t)nd * N, 0.0);
-    for (int d = 0; d < N; ++d) std::memcpy(&hs.dof_coords[(size_t)d * nd], &hs.nodes[(size_t)d * nn], sizeof(double) * nn);
+    hs.dof_coords.resize((size_t)nd * N);   // vertices here, edge DOFs (order 2) below
+    for (int d = 0; d < N; ++d)
+        parallel_for(nn, [&](int64_t b, int64_t e, unsigned) {
+            std::memcpy(&hs.dof_coords[(size_t)d * nd + b], &hs.nodes[(size_t)d * nn + b], sizeof(double) * (size_t)(e - b));
+        }, 1 << 16);
     if (order == 2) {
         std::vector<uint8_t> seen((size_t)nd, 0);
         for (int64_t c = 0; c < nc; ++c)
@@ -444,7 +452,7 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
         hs.dof_e2i = invert(hs.dof_i2e);
     }
     {
-        std::vector<double> bary((size_t)nc * N);
+        hvec<double> bary((size_t)nc * N);
         parallel_for(nc, [&](int64_t b, int64_t e, unsigned) {
             for (int64_t c = b; c < e; ++c)
                 for (int d = 0; d < N; ++d) {
@@ -457,10 +465,10 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
         hs.cell_e2i = invert(hs.cell_i2e);
     }
     const int NP = N == 2 ? 2 : 4;
-    hs.vcoords_i.assign((size_t)nn * NP, 0.0);
+    hs.vcoords_i.resize((size_t)nn * NP);
     parallel_for(nn, [&](int64_t b, int64_t e, unsigned) {
         for (int64_t i = b; i < e; ++i)
-            for (int d = 0; d < N; ++d) hs.vcoords_i[(size_t)i * NP + d] = hs.nodes[(size_t)d * nn + hs.node_i2e[(size_t)i]];
+            for (int d = 0; d < NP; ++d) hs.vcoords_i[(size_t)i * NP + d] = d < N ? hs.nodes[(size_t)d * nn + hs.node_i2e[(size_t)i]] : 0.0;
     }, 1 << 16);
     hs.dof_bnd_i.resize((size_t)nd);
     parallel_for(nd, [&](int64_t b, int64_t e, unsigned) {
@@ -480,7 +488,7 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
     std::vector<int64_t> vptr((size_t)nd + 1, 0);
     for (int64_t k = 0; k < nc * nb; ++k) ++vptr[(size_t)hs.cdofs_i[(size_t)k] + 1];
     for (int64_t i = 0; i < nd; ++i) vptr[(size_t)i + 1] += vptr[(size_t)i];
-    std::vector<int32_t> vis((size_t)(nc * nb));
+    hvec<int32_t> vis((size_t)(nc * nb));
     {   // serial counting sort: measured faster than a parallel radix sort of the 40 M visits of C3 (126 vs 276 ms)
         std::vector<int64_t> pos(vptr.begin(), vptr.end() - 1);
         for (int64_t c = 0; c < nc; ++c)
@@ -523,10 +531,14 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
             hs.rowptr_i[(size_t)r + 1] = hs.rowptr_i[(size_t)r] + rowlen[(size_t)r];
             hs.max_row = std::max(hs.max_row, rowlen[(size_t)r]);
         }
-        hs.colidx_i.resize((size_t)total);
-        for (unsigned t = 0; t < nt; ++t)
-            if (!tcols[t].empty())
-                std::memcpy(&hs.colidx_i[(size_t)hs.rowptr_i[(size_t)tbegin[t]]], tcols[t].data(), sizeof(int32_t) * tcols[t].size());
+        hs.colidx_i.resize((size_t)total + 2);   // + 2 zeros: the SpMV's pair loads may touch one entry past a row's end
+        hs.colidx_i[(size_t)total] = hs.colidx_i[(size_t)total + 1] = 0;
+        parallel_for((int64_t)nt, [&](int64_t tb, int64_t te, unsigned) {
+            for (int64_t t = tb; t < te; ++t)
+                if (!tcols[(size_t)t].empty())
+                    std::memcpy(&hs.colidx_i[(size_t)hs.rowptr_i[(size_t)tbegin[(size_t)t]]], tcols[(size_t)t].data(),
+                                sizeof(int32_t) * tcols[(size_t)t].size());
+        }, 1);
     }
     for (int64_t r = 0; r < nd; ++r)
         if (hs.rowptr_i[(size_t)r + 1] == hs.rowptr_i[(size_t)r]) {
@@ -590,8 +602,11 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
     }
     hs.nbw = (nb * 2 + 3) / 4;
     const int64_t padded = hs.sl_off[(size_t)n_slices] * kSlice;
-    hs.adj.assign((size_t)padded, -1);
-    hs.slotw.assign((size_t)padded * hs.nbw, 0u);
+    hs.adj.resize((size_t)padded), hs.slotw.resize((size_t)padded * hs.nbw);
+    parallel_for(padded, [&](int64_t b, int64_t e, unsigned) {   // padding values; the real visits are written below
+        std::fill(hs.adj.begin() + b, hs.adj.begin() + e, -1);
+        std::fill(hs.slotw.begin() + b * hs.nbw, hs.slotw.begin() + e * hs.nbw, 0u);
+    }, 1 << 16);
     parallel_for(nd, [&](int64_t b, int64_t e, unsigned) {
         for (int64_t r = b; r < e; ++r) {
             const int64_t s = r / kSlice, lane = r % kSlice;
@@ -650,7 +665,7 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
             return FDAPDE_EUNSUPPORTED;
         }
         hs.bc_cell.resize((size_t)hs.bc_off[(size_t)n_blk]);
-        hs.bc_vert.assign((size_t)hs.bc_off[(size_t)n_blk] * 4, 0);
+        hs.bc_vert.resize((size_t)hs.bc_off[(size_t)n_blk] * 4);   // all 4 words of a block-cell are written below
         hs.bn_node.resize((size_t)hs.bn_off[(size_t)n_blk]);
         parallel_for(n_blk, [&](int64_t b0, int64_t b1, unsigned) {
             for (int64_t b = b0; b < b1; ++b) {
@@ -660,9 +675,9 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
                 for (size_t k = 0; k < cs.size(); ++k) {
                     const int64_t at = hs.bc_off[(size_t)b] + (int64_t)k;
                     hs.bc_cell[(size_t)at] = cs[k];
-                    for (int v = 0; v < nv; ++v)
+                    for (int v = 0; v < 4; ++v)
                         hs.bc_vert[(size_t)at * 4 + v] =
-                          (uint16_t)(std::lower_bound(ns.begin(), ns.end(), hs.cverts_i[(size_t)cs[k] * nv + v]) - ns.begin());
+                          v < nv ? (uint16_t)(std::lower_bound(ns.begin(), ns.end(), hs.cverts_i[(size_t)cs[k] * nv + v]) - ns.begin()) : (uint16_t)0;
                 }
                 const int64_t r0 = b * kAsmBlock, r1 = std::min(nd, r0 + kAsmBlock);
                 for (int64_t r = r0; r < r1; ++r) {

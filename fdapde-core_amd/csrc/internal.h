@@ -3,12 +3,27 @@
 #define FDAPDE_INTERNAL_H
 
 #include <cstdint>
+#include <memory>
+#include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/fdapde_hip.h"
 
 namespace fdapde_hip {
+
+// std::vector whose resize(n) / vector(n) leave trivially-constructible elements UNINITIALISED: the multi-hundred-MB index arrays
+// of the set-up get their first touch (page faults included) in the parallel loops that fill them, not in a serial
+// value-initialisation.  resize(n, v) / assign(n, v) still write v.
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U>&) noexcept {}
+    template <class U> void construct(U* p) noexcept { ::new (static_cast<void*>(p)) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+template <class T> using hvec = std::vector<T, NoInitAlloc<T>>;
 
 constexpr int kMaxBasis = 10;   // 3-D P2
 constexpr int kMaxQuad = 6;     // 2-D P2 rule
@@ -34,44 +49,44 @@ struct HostSpace {
     // ---- mesh as handed over (reference numbering, "ext")
     int M = 0, N = 0;
     int64_t n_nodes = 0, n_cells = 0;
-    std::vector<double> nodes;      // column-major n_nodes x N
-    std::vector<int32_t> cells;     // row-major n_cells x (M+1)
+    hvec<double> nodes;      // column-major n_nodes x N
+    hvec<int32_t> cells;     // row-major n_cells x (M+1)
     std::vector<uint8_t> node_bnd;  // per node
     // ---- DOFs in the reference's numbering
     int order = 0, nb = 0, nq = 0;
     int64_t n_dofs = 0, n_edges = 0;
-    std::vector<int32_t> dofs;        // row-major n_cells x nb
+    hvec<int32_t> dofs;        // row-major n_cells x nb
     std::vector<uint8_t> dof_bnd;     // per DOF
-    std::vector<double> dof_coords;   // column-major n_dofs x N
+    hvec<double> dof_coords;   // column-major n_dofs x N
     // ---- internal (locality) numbering: Morton order of DOF / node / cell positions
-    std::vector<int32_t> dof_e2i, dof_i2e, node_e2i, node_i2e, cell_e2i, cell_i2e;
+    hvec<int32_t> dof_e2i, dof_i2e, node_e2i, node_i2e, cell_e2i, cell_i2e;
     // ---- CSR pattern, reference numbering (what stiff()/mass() expose)
-    std::vector<int32_t> rowptr_e, colidx_e;
+    hvec<int32_t> rowptr_e, colidx_e;
     // ---- CSR pattern, internal numbering (what the kernels use) + map internal slot -> reference slot
-    std::vector<int32_t> rowptr_i, colidx_i, slot_i2e, diag_i;
+    hvec<int32_t> rowptr_i, colidx_i, slot_i2e, diag_i;   // colidx_i holds nnz + 2 entries (two trailing zeros)
     int64_t nnz = 0;
     int32_t max_row = 0;
     // ---- internal cell data: vertex node ids (internal node numbering) and DOF ids (internal DOF numbering)
-    std::vector<int32_t> cverts_i;   // n_cells x (M+1)
-    std::vector<int32_t> cdofs_i;    // n_cells x nb
-    std::vector<double> vcoords_i;   // internal node id -> NP doubles (NP = 2 for N=2, 4 for N=3)
+    hvec<int32_t> cverts_i;   // n_cells x (M+1)
+    hvec<int32_t> cdofs_i;    // n_cells x nb
+    hvec<double> vcoords_i;   // internal node id -> NP doubles (NP = 2 for N=2, 4 for N=3)
     std::vector<uint8_t> dof_bnd_i;
     // ---- row-owner adjacency in sliced-ELL layout: slice s covers rows [64 s, 64 s + 64)
     //      entry (s, v, lane) at (sl_off[s] + v) * 64 + lane  holds  (index of the cell in its assembly block's table) * 16
     //      + local_index, or -1 (padding)
     std::vector<int64_t> sl_off;      // n_slices + 1, in units of 64-lane rows
-    std::vector<int32_t> adj;         // sl_off.back() * 64
+    hvec<int32_t> adj;         // sl_off.back() * 64
     int nbw = 0;                      // 32-bit words of slot data per visit: ceil(nb * 2 / 4)
-    std::vector<uint32_t> slotw;      // adj.size() * nbw; packed uint16 row-relative slots of the nb local columns
+    hvec<uint32_t> slotw;      // adj.size() * nbw; packed uint16 row-relative slots of the nb local columns
     std::vector<int32_t> blk_nnz_cap; // per assembly block: nnz of its 256 rows
     int32_t max_blk_nnz = 0;
     // ---- per assembly block (256 rows): the cells its rows visit and the vertex nodes of those cells.  `adj` addresses
     //      cells by their index in the block's table; the block stages its nodes' coordinates in LDS once.
     std::vector<int64_t> bc_off;      // n_blk + 1: offsets into bc_cell / bc_vert (in cells)
-    std::vector<int32_t> bc_cell;     // internal cell id of each block-cell (forcing / coefficient rows)
-    std::vector<uint16_t> bc_vert;    // 4 per block-cell: block-local node index of each vertex (M+1 used)
+    hvec<int32_t> bc_cell;     // internal cell id of each block-cell (forcing / coefficient rows)
+    hvec<uint16_t> bc_vert;    // 4 per block-cell: block-local node index of each vertex (M+1 used)
     std::vector<int64_t> bn_off;      // n_blk + 1: offsets into bn_node
-    std::vector<int32_t> bn_node;     // internal node ids staged by the block
+    hvec<int32_t> bn_node;     // internal node ids staged by the block
     int32_t max_blk_nodes = 0, max_blk_cells = 0;
     // ---- element colouring (cells of one colour share no DOF), for the colour-partitioned scatter
     int n_colours = 0;

@@ -631,30 +631,87 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
     }
     phase("sliced-ELL adjacency + slots");
     // ---- block-local cell / node tables; adj re-encoded as (index in the block's cell table) * 16 + local index -------
+    // Per block: the set of visited cells and the set of their vertices, both ascending.  The sets are collected through small
+    // open-addressing tables (only the unique ids are sorted; the same tables then answer "position of this id in the sorted
+    // set").  A thread serves consecutive blocks and appends their tables to its own buffers, which are copied to their final
+    // offsets once the block sizes are known.
     {
-        std::vector<std::vector<int32_t>> cells_of((size_t)n_blk), nodes_of((size_t)n_blk);
-        parallel_for(n_blk, [&](int64_t b0, int64_t b1, unsigned) {
+        struct Probe {   // id -> value, power-of-two open addressing; clear() resets exactly the slots in use
+            hvec<int32_t> key, val;
+            std::vector<uint32_t> used;
+            uint32_t mask = 0;
+            void reserve(size_t n_ids) {
+                size_t cap = 64;
+                while (cap < 2 * n_ids) cap <<= 1;
+                if (cap > key.size()) key.assign(cap, -1), val.resize(cap);
+                mask = (uint32_t)key.size() - 1;
+            }
+            uint32_t slot(int32_t id) const {
+                uint32_t h = ((uint32_t)id * 2654435761u) & mask;
+                while (key[h] != -1 && key[h] != id) h = (h + 1) & mask;
+                return h;
+            }
+            bool insert(int32_t id) {
+                const uint32_t h = slot(id);
+                if (key[h] == id) return false;
+                key[h] = id, used.push_back(h);
+                return true;
+            }
+            void clear() {
+                for (uint32_t h : used) key[h] = -1;
+                used.clear();
+            }
+        };
+        const unsigned nt = n_chunks(n_blk, 8);
+        struct ThreadOut {
+            int64_t b0 = 0, b1 = 0;
+            hvec<int32_t> cell, node;
+            hvec<uint16_t> vert;
+        };
+        std::vector<ThreadOut> tout(nt);
+        std::vector<int32_t> n_cells_of((size_t)n_blk), n_nodes_of((size_t)n_blk);
+        parallel_for(n_blk, [&](int64_t b0, int64_t b1, unsigned t) {
+            ThreadOut& out = tout[t];
+            out.b0 = b0, out.b1 = b1;
+            Probe pc, pn;
             std::vector<int32_t> cs, ns;
             for (int64_t b = b0; b < b1; ++b) {
                 cs.clear(), ns.clear();
                 const int64_t r0 = b * kAsmBlock, r1 = std::min(nd, r0 + kAsmBlock);
-                for (int64_t k = vptr[(size_t)r0]; k < vptr[(size_t)r1]; ++k) cs.push_back(vis[(size_t)k] >> 4);
+                pc.reserve((size_t)(vptr[(size_t)r1] - vptr[(size_t)r0]));
+                for (int64_t k = vptr[(size_t)r0]; k < vptr[(size_t)r1]; ++k)
+                    if (pc.insert(vis[(size_t)k] >> 4)) cs.push_back(vis[(size_t)k] >> 4);
                 std::sort(cs.begin(), cs.end());
-                cs.erase(std::unique(cs.begin(), cs.end()), cs.end());
+                for (size_t i = 0; i < cs.size(); ++i) pc.val[pc.slot(cs[i])] = (int32_t)i;
+                pn.reserve(cs.size() * (size_t)nv);
                 for (int32_t c : cs)
-                    for (int v = 0; v < nv; ++v) ns.push_back(hs.cverts_i[(size_t)c * nv + v]);
+                    for (int v = 0; v < nv; ++v)
+                        if (pn.insert(hs.cverts_i[(size_t)c * nv + v])) ns.push_back(hs.cverts_i[(size_t)c * nv + v]);
                 std::sort(ns.begin(), ns.end());
-                ns.erase(std::unique(ns.begin(), ns.end()), ns.end());
-                cells_of[(size_t)b] = cs, nodes_of[(size_t)b] = ns;
+                for (size_t i = 0; i < ns.size(); ++i) pn.val[pn.slot(ns[i])] = (int32_t)i;
+                n_cells_of[(size_t)b] = (int32_t)cs.size(), n_nodes_of[(size_t)b] = (int32_t)ns.size();
+                out.cell.insert(out.cell.end(), cs.begin(), cs.end());
+                out.node.insert(out.node.end(), ns.begin(), ns.end());
+                for (int32_t c : cs)
+                    for (int v = 0; v < 4; ++v)
+                        out.vert.push_back(v < nv ? (uint16_t)pn.val[pn.slot(hs.cverts_i[(size_t)c * nv + v])] : (uint16_t)0);
+                for (int64_t r = r0; r < r1; ++r) {
+                    const int64_t sidx = r / kSlice, lane = r % kSlice;
+                    for (int64_t k = vptr[(size_t)r]; k < vptr[(size_t)r + 1]; ++k) {
+                        const int64_t at = (hs.sl_off[(size_t)sidx] + (k - vptr[(size_t)r])) * kSlice + lane;
+                        hs.adj[(size_t)at] = pc.val[pc.slot(vis[(size_t)k] >> 4)] * 16 + (vis[(size_t)k] & 15);
+                    }
+                }
+                pc.clear(), pn.clear();
             }
         }, 8);
         hs.bc_off.assign((size_t)n_blk + 1, 0), hs.bn_off.assign((size_t)n_blk + 1, 0);
         hs.max_blk_cells = hs.max_blk_nodes = 0;
         for (int64_t b = 0; b < n_blk; ++b) {
-            hs.bc_off[(size_t)b + 1] = hs.bc_off[(size_t)b] + (int64_t)cells_of[(size_t)b].size();
-            hs.bn_off[(size_t)b + 1] = hs.bn_off[(size_t)b] + (int64_t)nodes_of[(size_t)b].size();
-            hs.max_blk_cells = std::max<int32_t>(hs.max_blk_cells, (int32_t)cells_of[(size_t)b].size());
-            hs.max_blk_nodes = std::max<int32_t>(hs.max_blk_nodes, (int32_t)nodes_of[(size_t)b].size());
+            hs.bc_off[(size_t)b + 1] = hs.bc_off[(size_t)b] + n_cells_of[(size_t)b];
+            hs.bn_off[(size_t)b + 1] = hs.bn_off[(size_t)b] + n_nodes_of[(size_t)b];
+            hs.max_blk_cells = std::max(hs.max_blk_cells, n_cells_of[(size_t)b]);
+            hs.max_blk_nodes = std::max(hs.max_blk_nodes, n_nodes_of[(size_t)b]);
         }
         if (std::getenv("FDAPDE_DEBUG_SETUP"))
             std::fprintf(stderr, "assembly blocks: %lld, cells/block avg %.0f max %d, nodes/block avg %.0f max %d, nnz/block max %d\n",
@@ -665,32 +722,17 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
             return FDAPDE_EUNSUPPORTED;
         }
         hs.bc_cell.resize((size_t)hs.bc_off[(size_t)n_blk]);
-        hs.bc_vert.resize((size_t)hs.bc_off[(size_t)n_blk] * 4);   // all 4 words of a block-cell are written below
+        hs.bc_vert.resize((size_t)hs.bc_off[(size_t)n_blk] * 4);
         hs.bn_node.resize((size_t)hs.bn_off[(size_t)n_blk]);
-        parallel_for(n_blk, [&](int64_t b0, int64_t b1, unsigned) {
-            for (int64_t b = b0; b < b1; ++b) {
-                const auto& cs = cells_of[(size_t)b];
-                const auto& ns = nodes_of[(size_t)b];
-                std::copy(ns.begin(), ns.end(), hs.bn_node.begin() + hs.bn_off[(size_t)b]);
-                for (size_t k = 0; k < cs.size(); ++k) {
-                    const int64_t at = hs.bc_off[(size_t)b] + (int64_t)k;
-                    hs.bc_cell[(size_t)at] = cs[k];
-                    for (int v = 0; v < 4; ++v)
-                        hs.bc_vert[(size_t)at * 4 + v] =
-                          v < nv ? (uint16_t)(std::lower_bound(ns.begin(), ns.end(), hs.cverts_i[(size_t)cs[k] * nv + v]) - ns.begin()) : (uint16_t)0;
-                }
-                const int64_t r0 = b * kAsmBlock, r1 = std::min(nd, r0 + kAsmBlock);
-                for (int64_t r = r0; r < r1; ++r) {
-                    const int64_t sidx = r / kSlice, lane = r % kSlice;
-                    for (int64_t k = vptr[(size_t)r]; k < vptr[(size_t)r + 1]; ++k) {
-                        const int64_t at = (hs.sl_off[(size_t)sidx] + (k - vptr[(size_t)r])) * kSlice + lane;
-                        const int32_t cell = vis[(size_t)k] >> 4, il = vis[(size_t)k] & 15;
-                        const int32_t lc = (int32_t)(std::lower_bound(cs.begin(), cs.end(), cell) - cs.begin());
-                        hs.adj[(size_t)at] = lc * 16 + il;
-                    }
-                }
+        parallel_for((int64_t)nt, [&](int64_t tb, int64_t te, unsigned) {
+            for (int64_t t = tb; t < te; ++t) {
+                const ThreadOut& out = tout[(size_t)t];
+                if (out.b1 <= out.b0) continue;
+                std::copy(out.cell.begin(), out.cell.end(), hs.bc_cell.begin() + hs.bc_off[(size_t)out.b0]);
+                std::copy(out.vert.begin(), out.vert.end(), hs.bc_vert.begin() + hs.bc_off[(size_t)out.b0] * 4);
+                std::copy(out.node.begin(), out.node.end(), hs.bn_node.begin() + hs.bn_off[(size_t)out.b0]);
             }
-        }, 8);
+        }, 1);
     }
 
     phase("block tables");

@@ -253,89 +253,116 @@ int edge_slot(int M, int a, int b) {
 //      of the sorted face (triangulation.h:348-377).  The first occurrence of an edge is always inside a newly seen
 //      face (were the face seen before, the edge would have an earlier occurrence), so "min occurrence" == "first seen".
 // ---------------------------------------------------------------------------------------------------------------
-struct EdgeOcc {
-    uint64_t key;   // (min node << 32) | max node
-    int64_t occ;
-};
-
-int enumerate_edges(HostSpace& hs, std::vector<int32_t>& cell_edge /* n_cells x (3|6), by local pair order */,
-                    std::vector<uint8_t>& edge_bnd, std::string& err) {
-    const int M = hs.M, nv = M + 1;
-    const int per_cell = M == 2 ? 3 : 12;
-    const int64_t n_occ = hs.n_cells * per_cell;
-    std::vector<EdgeOcc> occ((size_t)n_occ);
-    parallel_for(hs.n_cells, [&](int64_t b, int64_t e, unsigned) {
-        for (int64_t c = b; c < e; ++c) {
-            const int32_t* cv = &hs.cells[(size_t)c * nv];
-            if (M == 2) {
-                for (int j = 0; j < 3; ++j) {
-                    uint32_t a = (uint32_t)cv[COMB23[j][0]], bb = (uint32_t)cv[COMB23[j][1]];
-                    if (a > bb) std::swap(a, bb);
-                    occ[(size_t)(c * 3 + j)] = {(uint64_t)a << 32 | bb, c * 3 + j};
-                }
-            } else {
-                for (int f = 0; f < 4; ++f) {
-                    std::array<int32_t, 3> face = {cv[COMB34[f][0]], cv[COMB34[f][1]], cv[COMB34[f][2]]};
-                    std::sort(face.begin(), face.end());
-                    for (int k = 0; k < 3; ++k) {
-                        uint32_t a = (uint32_t)face[COMB23[k][0]], bb = (uint32_t)face[COMB23[k][1]];
-                        occ[(size_t)(c * 12 + f * 3 + k)] = {(uint64_t)a << 32 | bb, c * 12 + f * 3 + k};
-                    }
-                }
-            }
-        }
-    });
-    parallel_sort(occ, [](const EdgeOcc& x, const EdgeOcc& y) { return x.key != y.key ? x.key < y.key : x.occ < y.occ; });
-    // unique edges: (first occurrence, key, multiplicity among 2-D occurrences)
-    struct Uniq {
-        int64_t first;
-        uint64_t key;
-        int32_t count;
-    };
-    std::vector<Uniq> uq;
-    uq.reserve((size_t)n_occ / 2 + 16);
-    for (int64_t i = 0; i < n_occ;) {
-        int64_t j = i + 1;
-        while (j < n_occ && occ[(size_t)j].key == occ[(size_t)i].key) ++j;
-        uq.push_back({occ[(size_t)i].occ, occ[(size_t)i].key, (int32_t)(j - i)});
-        i = j;
+// Edges are bucketed by their smaller node (counted and scattered by all threads), every bucket is sorted by (larger node,
+// cell * epc + local pair), so that the head of a run of equal edges is its occurrence in the lowest cell; the unique edges are
+// then ranked by their first occurrence index with one radix sort.  first_cell[id] = the lowest cell containing edge id.
+int enumerate_edges(HostSpace& hs, hvec<int32_t>& cell_edge /* n_cells x (3|6), by local pair order */,
+                    std::vector<uint8_t>& edge_bnd, hvec<int32_t>& first_cell, std::string& err) {
+    const int M = hs.M, nv = M + 1, epc = M == 2 ? 3 : 6;
+    const int64_t nc = hs.n_cells, nn = hs.n_nodes, n_ent = nc * epc;
+    constexpr int P3[6][2] = {{0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 3}, {2, 3}};
+    if (n_ent > INT32_MAX) {
+        err = "too many cells for the order-2 edge enumeration (cells x edges per cell exceeds int32)";
+        return FDAPDE_EUNSUPPORTED;
     }
-    parallel_sort(uq, [](const Uniq& x, const Uniq& y) { return x.first < y.first; });
-    const int64_t ne = (int64_t)uq.size();
-    if (hs.n_nodes + ne > INT32_MAX) {
+    auto pair_of = [&](const int32_t* cv, int p, uint32_t& a, uint32_t& b) {
+        a = (uint32_t)cv[M == 2 ? COMB23[p][0] : P3[p][0]], b = (uint32_t)cv[M == 2 ? COMB23[p][1] : P3[p][1]];
+        if (a > b) std::swap(a, b);
+    };
+    // occurrence index of local pair p inside its cell: 2-D p itself; 3-D the first (face, pair of the sorted face) that is this edge
+    auto occ_in_cell = [&](const int32_t* cv, int p) -> int {
+        if (M == 2) return p;
+        uint32_t a, b;
+        pair_of(cv, p, a, b);
+        for (int f = 0; f < 4; ++f) {
+            std::array<int32_t, 3> face = {cv[COMB34[f][0]], cv[COMB34[f][1]], cv[COMB34[f][2]]};
+            std::sort(face.begin(), face.end());
+            for (int k = 0; k < 3; ++k)
+                if ((uint32_t)face[COMB23[k][0]] == a && (uint32_t)face[COMB23[k][1]] == b) return f * 3 + k;
+        }
+        return 11;   // not reached: every pair of a tetrahedron lies in two of its faces
+    };
+    std::unique_ptr<std::atomic<int32_t>[]> cnt(new std::atomic<int32_t>[(size_t)nn]);
+    auto zero_cnt = [&] {
+        parallel_for(nn, [&](int64_t b0, int64_t b1, unsigned) {
+            for (int64_t i = b0; i < b1; ++i) cnt[(size_t)i].store(0, std::memory_order_relaxed);
+        }, 1 << 16);
+    };
+    zero_cnt();
+    parallel_for(nc, [&](int64_t b0, int64_t b1, unsigned) {
+        for (int64_t c = b0; c < b1; ++c)
+            for (int p = 0; p < epc; ++p) {
+                uint32_t a, b;
+                pair_of(&hs.cells[(size_t)c * nv], p, a, b);
+                cnt[a].fetch_add(1, std::memory_order_relaxed);
+            }
+    }, 1 << 14);
+    std::vector<int64_t> ptr((size_t)nn + 1, 0);
+    for (int64_t i = 0; i < nn; ++i) ptr[(size_t)i + 1] = ptr[(size_t)i] + cnt[(size_t)i].load(std::memory_order_relaxed);
+    zero_cnt();
+    hvec<uint64_t> ent((size_t)n_ent);   // (larger node << 32) | (cell * epc + local pair)
+    parallel_for(nc, [&](int64_t b0, int64_t b1, unsigned) {
+        for (int64_t c = b0; c < b1; ++c)
+            for (int p = 0; p < epc; ++p) {
+                uint32_t a, b;
+                pair_of(&hs.cells[(size_t)c * nv], p, a, b);
+                ent[(size_t)(ptr[a] + cnt[a].fetch_add(1, std::memory_order_relaxed))] = (uint64_t)b << 32 | (uint32_t)(c * epc + p);
+            }
+    }, 1 << 14);
+    std::vector<int64_t> uptr((size_t)nn + 1, 0);
+    parallel_for(nn, [&](int64_t b0, int64_t b1, unsigned) {
+        for (int64_t a = b0; a < b1; ++a) {
+            std::sort(ent.begin() + ptr[(size_t)a], ent.begin() + ptr[(size_t)a + 1]);
+            int64_t u = 0;
+            for (int64_t i = ptr[(size_t)a]; i < ptr[(size_t)a + 1]; ++i)
+                u += i == ptr[(size_t)a] || (ent[(size_t)i] >> 32) != (ent[(size_t)i - 1] >> 32);
+            uptr[(size_t)a + 1] = u;
+        }
+    }, 1 << 12);
+    for (int64_t a = 0; a < nn; ++a) uptr[(size_t)a + 1] += uptr[(size_t)a];
+    const int64_t ne = uptr[(size_t)nn];
+    if (nn + ne > INT32_MAX) {
         err = "DOF count exceeds int32";
         return FDAPDE_EUNSUPPORTED;
     }
     hs.n_edges = ne;
-    edge_bnd.resize((size_t)ne);
-    // key -> id lookup through a sorted copy
-    std::vector<std::pair<uint64_t, int32_t>> by_key((size_t)ne);
-    for (int64_t e = 0; e < ne; ++e) {
-        by_key[(size_t)e] = {uq[(size_t)e].key, (int32_t)e};
-        if (M == 2) {
-            edge_bnd[(size_t)e] = uq[(size_t)e].count == 1;   // seen by exactly one cell (triangulation.h:177,187)
-        } else {
-            uint32_t a = (uint32_t)(uq[(size_t)e].key >> 32), b = (uint32_t)uq[(size_t)e].key;
-            edge_bnd[(size_t)e] = hs.node_bnd[a] && hs.node_bnd[b];   // triangulation.h:371
-        }
-    }
-    parallel_sort(by_key, [](const std::pair<uint64_t, int32_t>& x, const std::pair<uint64_t, int32_t>& y) { return x < y; });
-    const int epc = M == 2 ? 3 : 6;
-    constexpr int P3[6][2] = {{0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 3}, {2, 3}};
-    cell_edge.resize((size_t)hs.n_cells * epc);
-    parallel_for(hs.n_cells, [&](int64_t b, int64_t e, unsigned) {
-        for (int64_t c = b; c < e; ++c) {
-            const int32_t* cv = &hs.cells[(size_t)c * nv];
-            for (int k = 0; k < epc; ++k) {
-                uint32_t a = (uint32_t)cv[M == 2 ? COMB23[k][0] : P3[k][0]];
-                uint32_t bb = (uint32_t)cv[M == 2 ? COMB23[k][1] : P3[k][1]];
-                if (a > bb) std::swap(a, bb);
-                uint64_t key = (uint64_t)a << 32 | bb;
-                auto it = std::lower_bound(by_key.begin(), by_key.end(), std::make_pair(key, (int32_t)0));
-                cell_edge[(size_t)c * epc + k] = it->second;
+    // unique edge u (in (smaller, larger) node order): position of its run head, run length, first occurrence index
+    hvec<int64_t> head((size_t)ne);
+    hvec<int32_t> mult((size_t)ne), order((size_t)ne);
+    hvec<uint64_t> first((size_t)ne);
+    parallel_for(nn, [&](int64_t b0, int64_t b1, unsigned) {
+        for (int64_t a = b0; a < b1; ++a) {
+            int64_t u = uptr[(size_t)a] - 1;
+            for (int64_t i = ptr[(size_t)a]; i < ptr[(size_t)a + 1]; ++i) {
+                if (i == ptr[(size_t)a] || (ent[(size_t)i] >> 32) != (ent[(size_t)i - 1] >> 32)) {
+                    ++u;
+                    const int64_t val = (int64_t)(uint32_t)ent[(size_t)i], c = val / epc;
+                    head[(size_t)u] = i, mult[(size_t)u] = 0, order[(size_t)u] = (int32_t)u;
+                    first[(size_t)u] = (uint64_t)(c * (M == 2 ? 3 : 12) + occ_in_cell(&hs.cells[(size_t)c * nv], (int)(val % epc)));
+                }
+                ++mult[(size_t)u];
             }
         }
-    });
+    }, 1 << 12);
+    radix_sort_pairs(first, order);   // order[id] = u: edge ids in first-seen order
+    edge_bnd.resize((size_t)ne);
+    first_cell.resize((size_t)ne);
+    cell_edge.resize((size_t)n_ent);
+    parallel_for(ne, [&](int64_t b0, int64_t b1, unsigned) {
+        for (int64_t id = b0; id < b1; ++id) {
+            const int64_t u = order[(size_t)id], h = head[(size_t)u];
+            first_cell[(size_t)id] = (int32_t)(first[(size_t)id] / (M == 2 ? 3 : 12));
+            if (M == 2) {
+                edge_bnd[(size_t)id] = mult[(size_t)u] == 1;   // seen by exactly one cell (triangulation.h:177,187)
+            } else {
+                const int64_t val = (int64_t)(uint32_t)ent[(size_t)h], c = val / epc;
+                uint32_t a, b;
+                pair_of(&hs.cells[(size_t)c * nv], (int)(val % epc), a, b);
+                edge_bnd[(size_t)id] = hs.node_bnd[a] && hs.node_bnd[b];   // triangulation.h:371
+            }
+            for (int64_t i = h; i < h + mult[(size_t)u]; ++i) cell_edge[(size_t)(uint32_t)ent[(size_t)i]] = (int32_t)id;
+        }
+    }, 1 << 12);
     return FDAPDE_OK;
 }
 
@@ -401,18 +428,21 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
     }, 1 << 14);
     hs.dof_bnd.assign(hs.node_bnd.begin(), hs.node_bnd.end());
     hs.n_edges = 0;
+    hvec<int32_t> edge_first_cell;   // order 2: lowest cell containing each edge
     if (order == 2) {
-        std::vector<int32_t> cell_edge;
+        hvec<int32_t> cell_edge;
         std::vector<uint8_t> edge_bnd;
-        int rc = enumerate_edges(hs, cell_edge, edge_bnd, err);
+        int rc = enumerate_edges(hs, cell_edge, edge_bnd, edge_first_cell, err);
         if (rc) return rc;
         const int epc = M == 2 ? 3 : 6;
         constexpr int P3[6][2] = {{0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 3}, {2, 3}};
-        for (int64_t c = 0; c < nc; ++c)
-            for (int k = 0; k < epc; ++k) {
-                int a = M == 2 ? COMB23[k][0] : P3[k][0], b = M == 2 ? COMB23[k][1] : P3[k][1];
-                hs.dofs[(size_t)c * nb + edge_slot(M, a, b)] = (int32_t)nn + cell_edge[(size_t)c * epc + k];
-            }
+        parallel_for(nc, [&](int64_t c0, int64_t c1, unsigned) {
+            for (int64_t c = c0; c < c1; ++c)
+                for (int k = 0; k < epc; ++k) {
+                    int a = M == 2 ? COMB23[k][0] : P3[k][0], b = M == 2 ? COMB23[k][1] : P3[k][1];
+                    hs.dofs[(size_t)c * nb + edge_slot(M, a, b)] = (int32_t)nn + cell_edge[(size_t)c * epc + k];
+                }
+        }, 1 << 14);
         hs.dof_bnd.insert(hs.dof_bnd.end(), edge_bnd.begin(), edge_bnd.end());
     }
     hs.n_dofs = nn + hs.n_edges;
@@ -427,14 +457,14 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
         parallel_for(nn, [&](int64_t b, int64_t e, unsigned) {
             std::memcpy(&hs.dof_coords[(size_t)d * nd + b], &hs.nodes[(size_t)d * nn + b], sizeof(double) * (size_t)(e - b));
         }, 1 << 16);
-    if (order == 2) {
-        std::vector<uint8_t> seen((size_t)nd, 0);
-        for (int64_t c = 0; c < nc; ++c)
-            for (int j = nv; j < nb; ++j) {
-                int32_t dof = hs.dofs[(size_t)c * nb + j];
-                if (seen[(size_t)dof]) continue;
-                seen[(size_t)dof] = 1;
-                int32_t v0 = hs.cells[(size_t)c * nv];
+    if (order == 2) {   // an edge DOF takes its coordinates from the FIRST cell that visits it (the reference's loop order)
+        parallel_for(hs.n_edges, [&](int64_t e0, int64_t e1, unsigned) {
+            for (int64_t e = e0; e < e1; ++e) {
+                const int64_t c = edge_first_cell[(size_t)e];
+                const int32_t dof = (int32_t)(nn + e);
+                int j = nv;
+                while (j < nb - 1 && hs.dofs[(size_t)c * nb + j] != dof) ++j;
+                const int32_t v0 = hs.cells[(size_t)c * nv];
                 for (int d = 0; d < N; ++d) {
                     double x0 = hs.nodes[(size_t)d * nn + v0], acc = 0;
                     for (int k = 0; k < M; ++k)
@@ -442,6 +472,7 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
                     hs.dof_coords[(size_t)d * nd + dof] = acc + x0;
                 }
             }
+        }, 1 << 12);
     }
 
     phase("dof coordinates");

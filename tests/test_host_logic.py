@@ -126,3 +126,26 @@ def test_boundary_mask_override(capi, oracle):
     with pytest.raises(AssertionError):
         ctx.dofs_set_boundary(new[:-1])
     ctx.close()
+
+
+@pytest.mark.parametrize("dim,nx", [(3, 22), (2, 150)])
+def test_order2_numbering_at_multithreaded_sizes(capi, oracle, dim, nx):
+    """The set-up enumerates edges with all host threads once a mesh has a few 10^4 cells (buckets by the smaller node, relaxed
+    atomic scatter, per-bucket sorts); DOF table, boundary DOFs and DOF coordinates must still equal the reference's serial
+    first-seen enumeration (lagrangian_basis.h:105-133, triangulation.h:150-193,348-377) bit for bit."""
+    from fdapde_core_amd import meshgen
+
+    nodes, cells, bnd = meshgen.unit_cube(nx) if dim == 3 else meshgen.unit_square(nx)
+    m = oracle.Mesh(nodes, cells, bnd)
+    dofs, b, nd, _ = oracle.enumerate_dofs(m, 2)
+    coords = oracle.dofs_coords(m, 2, dofs, nd)
+    c = capi.Context(device=None)
+    c.mesh_upload(nodes, cells, bnd)
+    assert c.dofs_build(2) == nd
+    d2, b2, co2 = c.dofs_get()
+    assert np.array_equal(d2, dofs)
+    assert np.array_equal(np.asarray(b2).astype(bool), np.asarray(b).astype(bool))
+    assert np.array_equal(co2, coords)
+    rp, ci = c.pattern_get()
+    A = oracle.assemble_operator(m, 2, dofs, nd, oracle.reaction(1.0))
+    assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colidx)

@@ -497,7 +497,10 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
                 }
         });
         phase("  numbering: dofs + barycentres");
-        hs.cell_i2e = morton_order(N, nc, bary.data(), N == 3 ? 11 : 16);
+        // order 1: a coarse key (cells only need locality).  Order 2 keeps the full key: its sort is short anyway, and the visit
+        // order decides the summation order of the assembled entries -- harmless for CG, but BiCGStab's iteration count on C5
+        // moves between 712 and 797 with such last-bit differences, and the committed profile was taken with this order
+        hs.cell_i2e = morton_order(N, nc, bary.data(), order == 1 ? (N == 3 ? 11 : 16) : 0);
         hs.cell_e2i = invert(hs.cell_i2e);
     }
     phase("  numbering: cells");

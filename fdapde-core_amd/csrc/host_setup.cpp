@@ -557,13 +557,14 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
     // ---- internal CSR pattern: row = sorted union of the DOFs of the visiting cells ---------------------------
     {
         const unsigned nt = n_chunks(nd, 2048);
-        std::vector<std::vector<int32_t>> tcols(nt);
+        std::vector<hvec<int32_t>> tcols(nt);
         std::vector<int32_t> rowlen((size_t)nd);
         std::vector<int64_t> tbegin(nt, 0);
         parallel_for(nd, [&](int64_t b, int64_t e, unsigned t) {
             tbegin[t] = b;
             std::vector<int32_t> cand;
             auto& out = tcols[t];
+            out.reserve((size_t)(vptr[(size_t)e] - vptr[(size_t)b]) * (size_t)nb);   // upper bound; untouched pages cost nothing
             for (int64_t r = b; r < e; ++r) {
                 cand.clear();
                 for (int64_t k = vptr[(size_t)r]; k < vptr[(size_t)r + 1]; ++k) {
@@ -661,25 +662,34 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
     hs.nbw = (nb * 2 + 3) / 4;
     const int64_t padded = hs.sl_off[(size_t)n_slices] * kSlice;
     hs.adj.resize((size_t)padded), hs.slotw.resize((size_t)padded * hs.nbw);
-    parallel_for(padded, [&](int64_t b, int64_t e, unsigned) {   // padding values; the real visits are written below
-        std::fill(hs.adj.begin() + b, hs.adj.begin() + e, -1);
-        std::fill(hs.slotw.begin() + b * hs.nbw, hs.slotw.begin() + e * hs.nbw, 0u);
-    }, 1 << 16);
-    parallel_for(nd, [&](int64_t b, int64_t e, unsigned) {
-        for (int64_t r = b; r < e; ++r) {
-            const int64_t s = r / kSlice, lane = r % kSlice;
-            const int32_t* rbeg = &hs.colidx_i[(size_t)hs.rowptr_i[(size_t)r]];
-            const int32_t* rend = &hs.colidx_i[(size_t)hs.rowptr_i[(size_t)r + 1]];
-            for (int64_t k = vptr[(size_t)r]; k < vptr[(size_t)r + 1]; ++k) {
-                const int64_t v = k - vptr[(size_t)r];
-                const int64_t at = (hs.sl_off[(size_t)s] + v) * kSlice + lane;
-                hs.adj[(size_t)at] = vis[(size_t)k];
-                const int32_t* cd = &hs.cdofs_i[(size_t)(vis[(size_t)k] >> 4) * nb];
-                uint16_t* sw = reinterpret_cast<uint16_t*>(&hs.slotw[(size_t)at * hs.nbw]);
-                for (int j = 0; j < nb; ++j) sw[j] = (uint16_t)(std::lower_bound(rbeg, rend, cd[j]) - rbeg);
+    parallel_for(n_slices, [&](int64_t s0, int64_t s1, unsigned) {   // one pass: real visits and padding (-1 / 0) alike
+        for (int64_t sl = s0; sl < s1; ++sl) {
+            const int64_t width = hs.sl_off[(size_t)sl + 1] - hs.sl_off[(size_t)sl];
+            int64_t first[kSlice], len[kSlice];
+            const int32_t *rbeg[kSlice], *rend[kSlice];
+            for (int64_t lane = 0; lane < kSlice; ++lane) {
+                const int64_t r = sl * kSlice + lane;
+                first[lane] = r < nd ? vptr[(size_t)r] : 0, len[lane] = r < nd ? vptr[(size_t)r + 1] - vptr[(size_t)r] : 0;
+                rbeg[lane] = r < nd ? &hs.colidx_i[(size_t)hs.rowptr_i[(size_t)r]] : nullptr;
+                rend[lane] = r < nd ? &hs.colidx_i[(size_t)hs.rowptr_i[(size_t)r + 1]] : nullptr;
             }
+            for (int64_t v = 0; v < width; ++v)   // lanes innermost: adj and slotw are written with unit stride
+                for (int64_t lane = 0; lane < kSlice; ++lane) {
+                    const int64_t at = (hs.sl_off[(size_t)sl] + v) * kSlice + lane;
+                    uint16_t* sw = reinterpret_cast<uint16_t*>(&hs.slotw[(size_t)at * hs.nbw]);
+                    if (v < len[lane]) {
+                        const int32_t visit = vis[(size_t)(first[lane] + v)];
+                        hs.adj[(size_t)at] = visit;
+                        const int32_t* cd = &hs.cdofs_i[(size_t)(visit >> 4) * nb];
+                        for (int j = 0; j < nb; ++j) sw[j] = (uint16_t)(std::lower_bound(rbeg[lane], rend[lane], cd[j]) - rbeg[lane]);
+                        for (int j = nb; j < 2 * hs.nbw; ++j) sw[j] = 0;
+                    } else {
+                        hs.adj[(size_t)at] = -1;
+                        for (int j = 0; j < 2 * hs.nbw; ++j) sw[j] = 0;
+                    }
+                }
         }
-    }, 2048);
+    }, 32);
     const int64_t n_blk = (nd + kAsmBlock - 1) / kAsmBlock;
     hs.blk_nnz_cap.resize((size_t)n_blk);
     hs.max_blk_nnz = 0;

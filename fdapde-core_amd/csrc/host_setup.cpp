@@ -415,6 +415,10 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
         err = "fem_order must be 1 or 2 (LagrangianBasis::enumerate_dofs requires Order <= 2)";
         return FDAPDE_EUNSUPPORTED;
     }
+    if (hs.n_cells >= (int64_t(1) << 27)) {   // visits are packed as cell * 16 + local index in 32 bits
+        err = "more than 2^27 cells per context: partition the mesh (fdapde_halo_setup)";
+        return FDAPDE_EUNSUPPORTED;
+    }
     const int M = hs.M, N = hs.N, nv = M + 1;
     const int nb = n_basis_of(M, order);
     hs.order = order, hs.nb = nb, hs.nq = n_quadrature_of(M, order);

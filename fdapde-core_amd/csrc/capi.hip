@@ -380,7 +380,7 @@ void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, 
         }
         switch (c->spmv_team) {
         case 2: SPMV_PROD_FEW(2, 1); break;
-        case 4: SPMV_PROD_FEW(4, 2); break;
+        case 4: SPMV_PROD(4, 2); break;
         case 8:
             // the diagnostic forms >= 100 exist for the compact coded matrix only: any other product takes the production path
             switch ((c->spmv_ablate >= 100 && !c16) ? 0 : c->spmv_ablate) {

@@ -20,6 +20,6 @@ print(f"single-reduction CG   : {b.iters} iterations, {b.t_solve_ms:.2f} ms = {b
 ctx.comm_init(1, 0, capi.Context.comm_unique_id())
 local = np.sort(np.random.default_rng(1).choice(nd, size=n_if, replace=False)).astype(np.int32)
 ctx.halo_setup(n_if, local, np.arange(n_if, dtype=np.int32), np.ones(nd, dtype=np.uint8))
-for _ in range(2):
-    d = ctx.solve(rtol=1e-10)
+for _ in range(2):   # world > 1 selects the single-reduction form; on one rank it has to be asked for
+    d = ctx.solve(rtol=1e-10, method=capi.SOLVER_CG_SR)
 print(f"1-rank RCCL, n_if {n_if}: {d.iters} iterations, {d.t_solve_ms:.2f} ms = {d.t_solve_ms / d.iters * 1e3:.1f} us / iteration (method {d.method_used})")

@@ -15,7 +15,8 @@ an RCCL all-reduce of the interface DOF contributions per operator application (
 Prints ONE JSON line (rank 0).  `roofline` is the CSR SpMV inside CG: algorithmic bytes 12 nnz + 4 (n+1) + 16 n per
 launch over the average launch duration measured with HIP events on the solver's stream during the timed steps.
 `cpu_baseline` is the CPU oracle (oracle/fem_oracle.c, the single-threaded port of the reference algorithm) timed on a
-bounded sample of the same workload.
+bounded sample of the same workload; `cpu_baseline_all_cores` is the same restatement with OpenMP on every host core
+(oracle/fem_oracle_mt.c: BASELINE.md's "CPU-best" column).
 """
 import argparse
 import json
@@ -66,12 +67,35 @@ def cpu_baseline(nx):
     u, it, rr, rc = o.pcg(A, rhs, b, np.zeros(nd), rtol=RTOL, maxit=100000)
     t2 = time.perf_counter()
     assert rc == 0
-    del Mm
-    return {
+    faithful = {
         "value": nd / (t2 - t0), "unit": "DOF/s", "cores": 1, "kind": "port",
         "sample": f"3-D P1 Laplacian, {nx}^3 x 6 = {m.n_cells} tetrahedra, {nd} DOFs, same generator/operator/rtol; "
                   f"assemble {t1 - t0:.2f} s + Jacobi-PCG {t2 - t1:.2f} s ({it} iterations); oracle/fem_oracle.c at -O2",
     }
+    # BASELINE.md "CPU-best": the same restatement on all host cores (coloured OpenMP assembly into the prebuilt pattern +
+    # row-parallel PCG, oracle/fem_oracle_mt.c at -O3 -march=native); pattern and colouring are set-up, as on the GPU
+    best = None
+    try:
+        o.mt_set_threads(o.usable_cpus())   # affinity mask capped by the cgroup CPU quota
+        colouring = o.mt_colour_cells(dofs, nd)
+        o.mt_assemble(m, 1, dofs, nd, -o.laplacian(), A, colouring, fq)   # warm-up: thread pool, page faults
+        t3 = time.perf_counter()
+        A2, rhs2 = o.mt_assemble(m, 1, dofs, nd, -o.laplacian(), A, colouring, fq)
+        o.mt_assemble(m, 1, dofs, nd, o.reaction(1.0), Mm, colouring)
+        t4 = time.perf_counter()
+        u2, it2, rr2, rc2 = o.mt_pcg(A2, rhs2, b, np.zeros(nd), rtol=RTOL, maxit=100000)
+        t5 = time.perf_counter()
+        assert rc2 == 0 and np.abs(u2 - u).max() <= 1e-8 * max(1.0, np.abs(u).max())
+        best = {
+            "value": nd / (t5 - t3), "unit": "DOF/s", "cores": o.mt_threads(), "kind": "port, OpenMP",
+            "sample": f"same sample; coloured assembly {t4 - t3:.3f} s + row-parallel Jacobi-PCG {t5 - t4:.3f} s ({it2} iterations) on "
+                      f"{o.mt_threads()} threads (= the CPUs this container may use: {os.cpu_count()} visible, cgroup quota applied); "
+                      "oracle/fem_oracle_mt.c at -O3 -march=native; reference DOF numbering (ids as generated)",
+        }
+    except Exception as e:   # the all-cores column is an extra: never let it take the bench line down
+        best = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
+    del Mm
+    return faithful, best
 
 
 def main():
@@ -207,7 +231,7 @@ def main():
         },
     }
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_nx)
+        out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baseline(args.cpu_nx)
     print(json.dumps(out))
 
 

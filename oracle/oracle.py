@@ -434,6 +434,96 @@ def bicgstab(A: CSR, force, boundary_dofs=None, g=None, rtol=1e-10, maxit=10000)
     return _krylov(lib().fo_bicgstab, A, force, boundary_dofs, g, rtol, maxit)
 
 
+# ---- "CPU-best" column: the same restatement on all host cores, oracle/fem_oracle_mt.c ---------------------
+_lib_mt = None
+
+
+def _cpu_tag() -> str:
+    """Short hash of this host's CPU model + feature flags: the -march=native build is only ever loaded where it was made."""
+    import hashlib
+
+    text = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith(("model name", "flags")):
+                    text += line
+                if line.strip() == "" and text:
+                    break
+    except OSError:
+        pass
+    return hashlib.md5(text.encode()).hexdigest()[:10]
+
+
+def lib_mt() -> C.CDLL:
+    """libfem_oracle_mt.<cpu tag>.so (gcc -O3 -march=native -fopenmp), built on demand on the machine that runs it."""
+    global _lib_mt
+    if _lib_mt is None:
+        name = f"libfem_oracle_mt.{_cpu_tag()}.so"
+        path = os.path.join(_HERE, name)
+        src = [os.path.join(_HERE, f) for f in ("fem_oracle.c", "fem_oracle_mt.c")]
+        if not os.path.exists(path) or os.path.getmtime(path) < max(os.path.getmtime(f) for f in src):
+            subprocess.check_call(["make", "-s", "-B", "-C", _HERE, "libfem_oracle_mt.so", f"MT_OUT={name}"])
+        _lib_mt = C.CDLL(path)
+        _lib_mt.fo_mt_threads.restype = C.c_int
+    return _lib_mt
+
+
+def mt_threads() -> int:
+    return int(lib_mt().fo_mt_threads())
+
+
+def usable_cpus() -> int:
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (cpu.max); threads beyond the
+    quota are throttled by the scheduler and make an OpenMP run slower, not faster."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def mt_set_threads(n: int) -> None:
+    lib_mt().fo_mt_set_threads(int(n))
+
+
+def mt_colour_cells(dofs: np.ndarray, n_dofs: int):
+    """Greedy colouring of the cells (no two cells of a colour share a DOF): (order, colour_ptr).  Serial set-up."""
+    dofs = np.ascontiguousarray(dofs, dtype=np.int32)
+    order = np.zeros(dofs.shape[0], dtype=np.int32)
+    cptr = np.zeros(257, dtype=np.int64)
+    ncol = C.c_int32()
+    _check(lib_mt().fo_mt_colour_cells(C.c_int64(n_dofs), C.c_int64(dofs.shape[0]), int(dofs.shape[1]), _ip(dofs), _ip(order),
+                                       cptr.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(ncol)), "mt_colour_cells")
+    return order, cptr[: ncol.value + 1].copy()
+
+
+def mt_assemble(mesh: Mesh, order: int, dofs: np.ndarray, n_dofs: int, op: Operator, pattern: CSR, colouring, f_q=None):
+    """Operator values into `pattern` (+ the forcing vector when f_q is given), colour class by colour class on all cores."""
+    terms, keep = op.c_terms()
+    cell_order, cptr = colouring
+    nodes = mesh.nodes_colmajor
+    dofs = np.ascontiguousarray(dofs, dtype=np.int32)
+    values = np.empty(pattern.colidx.shape[0])
+    b = np.empty(n_dofs) if f_q is not None else None
+    fq = np.ascontiguousarray(f_q, dtype=float).reshape(-1) if f_q is not None else None
+    _check(
+        lib_mt().fo_mt_assemble(mesh.M, order, C.c_int64(mesh.n_nodes), _dp(nodes), C.c_int64(mesh.n_cells), _ip(mesh.cells), _ip(dofs),
+                                C.c_int64(n_dofs), len(op.terms), terms, _ip(pattern.rowptr), _ip(pattern.colidx), int(len(cptr) - 1),
+                                cptr.ctypes.data_as(C.POINTER(C.c_int64)), _ip(cell_order), _dp(values),
+                                _dp(fq) if fq is not None else None, _dp(b) if b is not None else None),
+        "mt_assemble",
+    )
+    return CSR(pattern.rowptr, pattern.colidx, values, n_dofs), b
+
+
+def mt_pcg(A: CSR, force, boundary_dofs=None, g=None, rtol=1e-10, maxit=10000):
+    return _krylov(lib_mt().fo_mt_pcg, A, force, boundary_dofs, g, rtol, maxit)
+
+
 def pointwise_psi(mesh: Mesh, order: int, dofs, n_dofs, locs) -> np.ndarray:
     locs = np.asarray(locs, dtype=float)
     nl = locs.shape[0]

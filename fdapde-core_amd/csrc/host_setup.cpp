@@ -178,6 +178,34 @@ inline uint64_t spread2(uint64_t x) {  // 31 bits -> every second bit
     return x;
 }
 
+// small id set / id -> value map for the per-row and per-block unions of the set-up
+struct Probe {   // id -> value, power-of-two open addressing; clear() resets exactly the slots in use
+    hvec<int32_t> key, val;
+    std::vector<uint32_t> used;
+    uint32_t mask = 0;
+    void reserve(size_t n_ids) {
+        size_t cap = 64;
+        while (cap < 2 * n_ids) cap <<= 1;
+        if (cap > key.size()) key.assign(cap, -1), val.resize(cap);
+        mask = (uint32_t)key.size() - 1;
+    }
+    uint32_t slot(int32_t id) const {
+        uint32_t h = ((uint32_t)id * 2654435761u) & mask;
+        while (key[h] != -1 && key[h] != id) h = (h + 1) & mask;
+        return h;
+    }
+    bool insert(int32_t id) {
+        const uint32_t h = slot(id);
+        if (key[h] == id) return false;
+        key[h] = id, used.push_back(h);
+        return true;
+    }
+    void clear() {
+        for (uint32_t h : used) key[h] = -1;
+        used.clear();
+    }
+};
+
 // permutation that sorts points (column-major n x N) along the Morton curve; returns i2e (new -> old).  bits = resolution per
 // axis (0: the maximum, 21 in 3-D / 31 in 2-D); points with equal keys keep their input order.  The radix sort runs one pass per
 // 11 key bits, so a coarse key (cells: only locality matters, not the numbering) halves its cost.
@@ -567,18 +595,21 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
         parallel_for(nd, [&](int64_t b, int64_t e, unsigned t) {
             tbegin[t] = b;
             std::vector<int32_t> cand;
+            Probe seen;   // the DOFs of the visiting cells repeat 4-10 times: only the distinct ones are sorted
             auto& out = tcols[t];
             out.reserve((size_t)(vptr[(size_t)e] - vptr[(size_t)b]) * (size_t)nb);   // upper bound; untouched pages cost nothing
             for (int64_t r = b; r < e; ++r) {
                 cand.clear();
+                seen.reserve((size_t)(vptr[(size_t)r + 1] - vptr[(size_t)r]) * (size_t)nb);
                 for (int64_t k = vptr[(size_t)r]; k < vptr[(size_t)r + 1]; ++k) {
                     const int32_t* cd = &hs.cdofs_i[(size_t)(vis[(size_t)k] >> 4) * nb];
-                    cand.insert(cand.end(), cd, cd + nb);
+                    for (int j = 0; j < nb; ++j)
+                        if (seen.insert(cd[j])) cand.push_back(cd[j]);
                 }
+                seen.clear();
                 std::sort(cand.begin(), cand.end());
-                auto last = std::unique(cand.begin(), cand.end());
-                rowlen[(size_t)r] = (int32_t)(last - cand.begin());
-                out.insert(out.end(), cand.begin(), last);
+                rowlen[(size_t)r] = (int32_t)cand.size();
+                out.insert(out.end(), cand.begin(), cand.end());
             }
         }, 2048);
         int64_t total = 0;
@@ -667,31 +698,33 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
     const int64_t padded = hs.sl_off[(size_t)n_slices] * kSlice;
     hs.adj.resize((size_t)padded), hs.slotw.resize((size_t)padded * hs.nbw);
     parallel_for(n_slices, [&](int64_t s0, int64_t s1, unsigned) {   // one pass: real visits and padding (-1 / 0) alike
+        Probe slot_of;   // column -> position in the row, built once per row and asked nb times per visit
         for (int64_t sl = s0; sl < s1; ++sl) {
             const int64_t width = hs.sl_off[(size_t)sl + 1] - hs.sl_off[(size_t)sl];
-            int64_t first[kSlice], len[kSlice];
-            const int32_t *rbeg[kSlice], *rend[kSlice];
             for (int64_t lane = 0; lane < kSlice; ++lane) {
                 const int64_t r = sl * kSlice + lane;
-                first[lane] = r < nd ? vptr[(size_t)r] : 0, len[lane] = r < nd ? vptr[(size_t)r + 1] - vptr[(size_t)r] : 0;
-                rbeg[lane] = r < nd ? &hs.colidx_i[(size_t)hs.rowptr_i[(size_t)r]] : nullptr;
-                rend[lane] = r < nd ? &hs.colidx_i[(size_t)hs.rowptr_i[(size_t)r + 1]] : nullptr;
-            }
-            for (int64_t v = 0; v < width; ++v)   // lanes innermost: adj and slotw are written with unit stride
-                for (int64_t lane = 0; lane < kSlice; ++lane) {
+                const int64_t len = r < nd ? vptr[(size_t)r + 1] - vptr[(size_t)r] : 0;
+                if (r < nd) {
+                    const int32_t k0 = hs.rowptr_i[(size_t)r], k1 = hs.rowptr_i[(size_t)r + 1];
+                    slot_of.reserve((size_t)(k1 - k0));
+                    for (int32_t k = k0; k < k1; ++k) slot_of.insert(hs.colidx_i[(size_t)k]), slot_of.val[slot_of.slot(hs.colidx_i[(size_t)k])] = k - k0;
+                }
+                for (int64_t v = 0; v < width; ++v) {
                     const int64_t at = (hs.sl_off[(size_t)sl] + v) * kSlice + lane;
                     uint16_t* sw = reinterpret_cast<uint16_t*>(&hs.slotw[(size_t)at * hs.nbw]);
-                    if (v < len[lane]) {
-                        const int32_t visit = vis[(size_t)(first[lane] + v)];
+                    if (v < len) {
+                        const int32_t visit = vis[(size_t)(vptr[(size_t)r] + v)];
                         hs.adj[(size_t)at] = visit;
                         const int32_t* cd = &hs.cdofs_i[(size_t)(visit >> 4) * nb];
-                        for (int j = 0; j < nb; ++j) sw[j] = (uint16_t)(std::lower_bound(rbeg[lane], rend[lane], cd[j]) - rbeg[lane]);
+                        for (int j = 0; j < nb; ++j) sw[j] = (uint16_t)slot_of.val[slot_of.slot(cd[j])];
                         for (int j = nb; j < 2 * hs.nbw; ++j) sw[j] = 0;
                     } else {
                         hs.adj[(size_t)at] = -1;
                         for (int j = 0; j < 2 * hs.nbw; ++j) sw[j] = 0;
                     }
                 }
+                slot_of.clear();
+            }
         }
     }, 32);
     const int64_t n_blk = (nd + kAsmBlock - 1) / kAsmBlock;
@@ -708,32 +741,6 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
     // set").  A thread serves consecutive blocks and appends their tables to its own buffers, which are copied to their final
     // offsets once the block sizes are known.
     {
-        struct Probe {   // id -> value, power-of-two open addressing; clear() resets exactly the slots in use
-            hvec<int32_t> key, val;
-            std::vector<uint32_t> used;
-            uint32_t mask = 0;
-            void reserve(size_t n_ids) {
-                size_t cap = 64;
-                while (cap < 2 * n_ids) cap <<= 1;
-                if (cap > key.size()) key.assign(cap, -1), val.resize(cap);
-                mask = (uint32_t)key.size() - 1;
-            }
-            uint32_t slot(int32_t id) const {
-                uint32_t h = ((uint32_t)id * 2654435761u) & mask;
-                while (key[h] != -1 && key[h] != id) h = (h + 1) & mask;
-                return h;
-            }
-            bool insert(int32_t id) {
-                const uint32_t h = slot(id);
-                if (key[h] == id) return false;
-                key[h] = id, used.push_back(h);
-                return true;
-            }
-            void clear() {
-                for (uint32_t h : used) key[h] = -1;
-                used.clear();
-            }
-        };
         const unsigned nt = n_chunks(n_blk, 8);
         struct ThreadOut {
             int64_t b0 = 0, b1 = 0;

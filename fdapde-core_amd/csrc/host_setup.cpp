@@ -697,6 +697,9 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
     hs.nbw = (nb * 2 + 3) / 4;
     const int64_t padded = hs.sl_off[(size_t)n_slices] * kSlice;
     hs.adj.resize((size_t)padded), hs.slotw.resize((size_t)padded * hs.nbw);
+    if (dbg_time)
+        std::fprintf(stderr, "sliced-ELL adjacency: %lld visit slots for %lld visits (%.2fx), slot words %.2f GB\n", (long long)padded,
+                     (long long)(nc * nb), (double)padded / (double)(nc * nb), (double)padded * hs.nbw * 4.0 / 1e9);
     parallel_for(n_slices, [&](int64_t s0, int64_t s1, unsigned) {   // one pass: real visits and padding (-1 / 0) alike
         Probe slot_of;   // column -> position in the row, built once per row and asked nb times per visit
         for (int64_t sl = s0; sl < s1; ++sl) {

@@ -34,6 +34,8 @@ int upload_space(fdapde_ctx* c) {
     HIPCHK(c, c->adj.upload(hs.adj.data(), hs.adj.size(), st));
     HIPCHK(c, c->slotw.upload(hs.slotw.data(), hs.slotw.size(), st));
     HIPCHK(c, c->sl_off.upload(hs.sl_off.data(), hs.sl_off.size(), st));
+    if (!hs.lane_row.empty()) HIPCHK(c, c->lane_row.upload(hs.lane_row.data(), hs.lane_row.size(), st));
+    else c->lane_row.release();
     HIPCHK(c, c->bc_off.upload(hs.bc_off.data(), hs.bc_off.size(), st));
     HIPCHK(c, c->bn_off.upload(hs.bn_off.data(), hs.bn_off.size(), st));
     HIPCHK(c, c->bc_cell.upload(hs.bc_cell.data(), hs.bc_cell.size(), st));
@@ -146,7 +148,7 @@ AsmArgs asm_args(fdapde_ctx* c) {
     AsmArgs a{};
     a.n_dofs = c->hs.n_dofs, a.n_cells = c->hs.n_cells;
     a.cverts = c->cverts.p, a.cdofs = c->cdofs.p, a.vcoords = c->vcoords.p;
-    a.sl_off = c->sl_off.p, a.adj = c->adj.p, a.slotw = c->slotw.p;
+    a.sl_off = c->sl_off.p, a.adj = c->adj.p, a.slotw = c->slotw.p, a.lane_row = c->hs.lane_row.empty() ? nullptr : c->lane_row.p;
     a.rowptr = c->rowptr.p, a.colidx = c->colidx.p, a.tables = c->tables.p, a.reftab = c->reftab.p;
     a.bc_off = c->bc_off.p, a.bc_cell = c->bc_cell.p, a.bc_vert = c->bc_vert.p, a.bn_off = c->bn_off.p, a.bn_node = c->bn_node.p;
     a.lds_nodes = c->hs.max_blk_nodes;
@@ -559,7 +561,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
                                 &c->tmp_e, &c->tmp_i, &c->tmp_v})
             b->release();
         for (auto& b : c->coef) b.release();
-        c->slotw.release(), c->sl_off.release(), c->bnd.release(), c->tables.release(), c->reftab.release(), c->lin_sq.release();
+        c->slotw.release(), c->sl_off.release(), c->lane_row.release(), c->bnd.release(), c->tables.release(), c->reftab.release(), c->lin_sq.release();
         c->bc_off.release(), c->bn_off.release(), c->bc_cell.release(), c->bn_node.release(), c->bc_vert.release();
         c->halo_dof.release(), c->halo_pos.release(), c->owned.release(), c->hbuf.release(), c->sbuf.release();
         c->halo_inv.release(), c->if_slot.release();

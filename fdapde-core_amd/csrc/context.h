@@ -146,6 +146,7 @@ struct fdapde_ctx {
     DBuf<int32_t> bc_cell, bn_node;
     DBuf<uint16_t> bc_vert;
     DBuf<int64_t> sl_off;
+    DBuf<int32_t> lane_row;   // assembly lane position -> row (unallocated = identity)
     DBuf<double> vcoords, vals[2], force, fq, g, sval, scale, gt, x, r, p, y, s, t, r0, u, part_a, part_b, sc, tmp_e,
       tmp_i, tmp_v;
     DBuf<uint8_t> bnd;

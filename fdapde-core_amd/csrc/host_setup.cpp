@@ -688,11 +688,35 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
     phase("reference pattern + slot map");
     // ---- sliced-ELL adjacency + per-visit column slots -------------------------------------------------------
     const int64_t n_slices = (nd + kSlice - 1) / kSlice;
-    hs.sl_off.assign((size_t)n_slices + 1, 0);
-    for (int64_t s = 0; s < n_slices; ++s) {
-        int64_t w = 0;
-        for (int64_t r = s * kSlice; r < std::min(nd, (s + 1) * kSlice); ++r) w = std::max(w, vptr[(size_t)r + 1] - vptr[(size_t)r]);
-        hs.sl_off[(size_t)s + 1] = hs.sl_off[(size_t)s] + w;
+    const int64_t n_blk = (nd + kAsmBlock - 1) / kAsmBlock;
+    auto visits_of = [&](int64_t r) -> int64_t { return r >= 0 && r < nd ? vptr[(size_t)r + 1] - vptr[(size_t)r] : 0; };
+    auto slice_widths = [&] {   // width of a slice = the longest visit list among the rows its 64 lane positions hold
+        hs.sl_off.assign((size_t)n_slices + 1, 0);
+        for (int64_t s = 0; s < n_slices; ++s) {
+            int64_t w = 0;
+            for (int64_t q = s * kSlice; q < (s + 1) * kSlice; ++q)
+                w = std::max(w, visits_of(hs.lane_row.empty() ? q : (int64_t)hs.lane_row[(size_t)q]));
+            hs.sl_off[(size_t)s + 1] = hs.sl_off[(size_t)s] + w;
+        }
+    };
+    hs.lane_row.clear();
+    slice_widths();
+    hvec<int32_t> row_pos;   // row -> lane position (only when the rows are dealt by visit count)
+    if ((double)hs.sl_off[(size_t)n_slices] * kSlice > 1.25 * (double)(nc * nb)) {
+        // the slices are mostly padding (P2: vertex rows next to edge rows): deal the rows of every assembly block to its lanes
+        // in descending order of their visit count (stable), so that a slice holds rows of similar length
+        hs.lane_row.resize((size_t)n_blk * kAsmBlock);
+        row_pos.resize((size_t)nd);
+        parallel_for(n_blk, [&](int64_t b0, int64_t b1, unsigned) {
+            for (int64_t b = b0; b < b1; ++b) {
+                const int64_t r0 = b * kAsmBlock, r1 = std::min(nd, r0 + kAsmBlock);
+                int32_t* lr = &hs.lane_row[(size_t)r0];
+                for (int64_t k = 0; k < kAsmBlock; ++k) lr[k] = r0 + k < r1 ? (int32_t)(r0 + k) : -1;
+                std::stable_sort(lr, lr + (r1 - r0), [&](int32_t x, int32_t y) { return visits_of(x) > visits_of(y); });
+                for (int64_t k = 0; k < r1 - r0; ++k) row_pos[(size_t)lr[k]] = (int32_t)(r0 + k);
+            }
+        }, 64);
+        slice_widths();
     }
     hs.nbw = (nb * 2 + 3) / 4;
     const int64_t padded = hs.sl_off[(size_t)n_slices] * kSlice;
@@ -705,7 +729,9 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
         for (int64_t sl = s0; sl < s1; ++sl) {
             const int64_t width = hs.sl_off[(size_t)sl + 1] - hs.sl_off[(size_t)sl];
             for (int64_t lane = 0; lane < kSlice; ++lane) {
-                const int64_t r = sl * kSlice + lane;
+                const int64_t q = sl * kSlice + lane;   // lane position
+                const int64_t rr = hs.lane_row.empty() ? q : (int64_t)hs.lane_row[(size_t)q];
+                const int64_t r = rr < 0 ? nd : rr;
                 const int64_t len = r < nd ? vptr[(size_t)r + 1] - vptr[(size_t)r] : 0;
                 if (r < nd) {
                     const int32_t k0 = hs.rowptr_i[(size_t)r], k1 = hs.rowptr_i[(size_t)r + 1];
@@ -730,7 +756,6 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
             }
         }
     }, 32);
-    const int64_t n_blk = (nd + kAsmBlock - 1) / kAsmBlock;
     hs.blk_nnz_cap.resize((size_t)n_blk);
     hs.max_blk_nnz = 0;
     for (int64_t b = 0; b < n_blk; ++b) {
@@ -778,7 +803,8 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
                     for (int v = 0; v < 4; ++v)
                         out.vert.push_back(v < nv ? (uint16_t)pn.val[pn.slot(hs.cverts_i[(size_t)c * nv + v])] : (uint16_t)0);
                 for (int64_t r = r0; r < r1; ++r) {
-                    const int64_t sidx = r / kSlice, lane = r % kSlice;
+                    const int64_t q = row_pos.empty() ? r : (int64_t)row_pos[(size_t)r];   // lane position of the row
+                    const int64_t sidx = q / kSlice, lane = q % kSlice;
                     for (int64_t k = vptr[(size_t)r]; k < vptr[(size_t)r + 1]; ++k) {
                         const int64_t at = (hs.sl_off[(size_t)sidx] + (k - vptr[(size_t)r])) * kSlice + lane;
                         hs.adj[(size_t)at] = pc.val[pc.slot(vis[(size_t)k] >> 4)] * 16 + (vis[(size_t)k] & 15);

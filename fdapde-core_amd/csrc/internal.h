@@ -76,6 +76,10 @@ struct HostSpace {
     //      + local_index, or -1 (padding)
     std::vector<int64_t> sl_off;      // n_slices + 1, in units of 64-lane rows
     hvec<int32_t> adj;         // sl_off.back() * 64
+    // lane position -> row (empty = identity).  When the rows of a 256-row assembly block differ a lot in visit count (P2: vertex
+    // DOFs ~24 cells, edge DOFs ~5) they are dealt to the block's lanes sorted by visit count, so that a 64-lane slice holds rows
+    // of similar length: n_blk * 256 entries, -1 = no row
+    hvec<int32_t> lane_row;
     int nbw = 0;                      // 32-bit words of slot data per visit: ceil(nb * 2 / 4)
     hvec<uint32_t> slotw;      // adj.size() * nbw; packed uint16 row-relative slots of the nb local columns
     std::vector<int32_t> blk_nnz_cap; // per assembly block: nnz of its 256 rows

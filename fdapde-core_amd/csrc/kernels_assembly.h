@@ -55,6 +55,7 @@ struct AsmArgs {
     const int32_t* cdofs;      // n_cells x nb, internal DOF ids
     const double* vcoords;     // internal node id -> NP doubles
     const int64_t* sl_off;     // adjacency slices
+    const int32_t* lane_row;   // lane position -> row (-1: none), or nullptr = identity
     const int32_t* adj;
     const uint32_t* slotw;
     const int32_t* rowptr;
@@ -360,7 +361,12 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
     double* acc = xyz + (int64_t)a.lds_nodes * NP;            // the block's CSR value range
 
     const int64_t row0 = (int64_t)blockIdx.x * kAsmBlock;
-    const int64_t row = row0 + threadIdx.x;
+    const int64_t pos = row0 + threadIdx.x;   // lane position; the adjacency slices are laid out by position
+    int64_t row = pos;
+    if (a.lane_row) {   // rows of the block dealt to its lanes by visit count (host_setup.cpp)
+        const int32_t lr = a.lane_row[pos];
+        row = lr < 0 ? a.n_dofs : (int64_t)lr;
+    }
     const int64_t row_end = min(a.n_dofs, row0 + kAsmBlock);
     const bool want_matrix = a.vals != nullptr;
     const int32_t base = a.rowptr[row0];
@@ -390,7 +396,7 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
     }
     __syncthreads();
 
-    const int64_t slice = row >> 6;
+    const int64_t slice = pos >> 6;
     const int lane = threadIdx.x & 63;
     const int64_t bc0 = a.bc_off[blockIdx.x];
     double fsum = 0;

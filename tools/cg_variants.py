@@ -1,5 +1,5 @@
 import os, sys, numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fdapde_loader import load_package
 load_package()
 from fdapde_core_amd import capi, meshgen

@@ -243,7 +243,7 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
         if (op.n == 1 && op.t[0].kind == FDAPDE_REACTION && !op.t[0].space_varying) opk = 2;
         if (std::getenv("FDAPDE_ASM_GENERIC")) opk = 0;
         const size_t tab = sizeof(DevTables) + (opk == 3 ? sizeof(DevRefTensors) : 0) +
-                           (size_t)hs.max_blk_nodes * (M == 2 ? 2 : 4) * sizeof(double);
+                           (size_t)hs.max_blk_nodes * (M == 2 ? 2 : 3) * sizeof(double);
         size_t acc = (size_t)hs.max_blk_nnz * sizeof(double);
         if (tab + acc > (size_t)c->lds_limit) acc = tab < (size_t)c->lds_limit ? (size_t)c->lds_limit - tab : 0;
         a.lds_acc_cap = (int32_t)(acc / sizeof(double));

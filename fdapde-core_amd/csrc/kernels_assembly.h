@@ -347,7 +347,7 @@ template <int M, int R, int OPK>
 __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op) {
     constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
     constexpr int NBW = (NB * 2 + 3) / 4;
-    constexpr int NP = M == 2 ? 2 : 4;   // doubles per staged vertex (xyz padded to 32 B)
+    constexpr int NP = M == 2 ? 2 : 3;   // doubles per staged vertex in LDS (unpadded: C3 blocks then fit three to a CU, not two)
     extern __shared__ double lds[];
     const DevTables* tb = stage_tables(a.tables, lds);
     const DevRefTensors* rt = nullptr;
@@ -382,9 +382,8 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
         if constexpr (M == 2) {
             *reinterpret_cast<double2*>(xyz + i * 2) = *reinterpret_cast<const double2*>(a.vcoords + node * 2);
         } else {
-            const double4 v = *reinterpret_cast<const double4*>(a.vcoords + node * 4);
-            *reinterpret_cast<double2*>(xyz + i * 4) = make_double2(v.x, v.y);
-            *reinterpret_cast<double2*>(xyz + i * 4 + 2) = make_double2(v.z, 0.0);
+            const double4 v = *reinterpret_cast<const double4*>(a.vcoords + node * 4);   // global copy stays padded to 32 B
+            xyz[i * 3] = v.x, xyz[i * 3 + 1] = v.y, xyz[i * 3 + 2] = v.z;
         }
     }
     if (want_matrix) {

@@ -247,7 +247,7 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
         size_t acc = (size_t)hs.max_blk_nnz * sizeof(double);
         if (tab + acc > (size_t)c->lds_limit) acc = tab < (size_t)c->lds_limit ? (size_t)c->lds_limit - tab : 0;
         a.lds_acc_cap = (int32_t)(acc / sizeof(double));
-        const int grid = (int)((hs.n_dofs + kAsmBlock - 1) / kAsmBlock);
+        const int grid = 8 * (int)(((hs.n_dofs + kAsmBlock - 1) / kAsmBlock + 7) / 8);   // 8 XCD bands of blocks (k_assemble_rows)
         size_t lds = tab + acc;
         if (lds > 64 * 1024)
             for (const void* fn : {reinterpret_cast<const void*>(&k_assemble_rows<M, R, 0>),

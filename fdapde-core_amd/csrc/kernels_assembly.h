@@ -349,6 +349,12 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
     constexpr int NBW = (NB * 2 + 3) / 4;
     constexpr int NP = M == 2 ? 2 : 3;   // doubles per staged vertex in LDS (unpadded: C3 blocks then fit three to a CU, not two)
     extern __shared__ double lds[];
+    // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs (own L2 each), so workgroup b serves block
+    // (b % 8) * band + b / 8 -- an XCD walks a contiguous range of blocks, and what neighbouring blocks share (vertex coordinates
+    // on their common boundary, the forcing samples and vertex lists of the cells both visit) is found in its L2
+    const int64_t n_blk = (a.n_dofs + kAsmBlock - 1) / kAsmBlock, band = (n_blk + 7) / 8;
+    const int64_t blk = (int64_t)(blockIdx.x & 7) * band + (blockIdx.x >> 3);
+    if (blk >= n_blk || (int64_t)(blockIdx.x >> 3) >= band) return;   // uniform for the workgroup
     const DevTables* tb = stage_tables(a.tables, lds);
     const DevRefTensors* rt = nullptr;
     double* xyz = lds + kTablesDoubles;                       // the block's vertex coordinates
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
     }
     double* acc = xyz + (int64_t)a.lds_nodes * NP;            // the block's CSR value range
 
-    const int64_t row0 = (int64_t)blockIdx.x * kAsmBlock;
+    const int64_t row0 = blk * kAsmBlock;
     const int64_t pos = row0 + threadIdx.x;   // lane position; the adjacency slices are laid out by position
     int64_t row = pos;
     if (a.lane_row) {   // rows of the block dealt to its lanes by visit count (host_setup.cpp)
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
     const int32_t my1 = row < a.n_dofs ? a.rowptr[row + 1] : 0;
     // stage the vertex coordinates of every cell this block visits: each node is fetched from HBM/L2 once per block
     // instead of once per (row, visit) -- the gathers of the visit loop below then hit LDS
-    const int64_t bn0 = a.bn_off[blockIdx.x], nbn = a.bn_off[blockIdx.x + 1] - bn0;
+    const int64_t bn0 = a.bn_off[blk], nbn = a.bn_off[blk + 1] - bn0;
     for (int i = threadIdx.x; i < nbn; i += kAsmBlock) {
         const int64_t node = a.bn_node[bn0 + i];
         if constexpr (M == 2) {
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
 
     const int64_t slice = pos >> 6;
     const int lane = threadIdx.x & 63;
-    const int64_t bc0 = a.bc_off[blockIdx.x];
+    const int64_t bc0 = a.bc_off[blk];
     double fsum = 0;
     if (row0 + (threadIdx.x & ~63) < a.n_dofs) {   // wave-uniform: slice exists
         const int64_t off = a.sl_off[slice], width = a.sl_off[slice + 1] - off;

@@ -247,6 +247,7 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
         size_t acc = (size_t)hs.max_blk_nnz * sizeof(double);
         if (tab + acc > (size_t)c->lds_limit) acc = tab < (size_t)c->lds_limit ? (size_t)c->lds_limit - tab : 0;
         a.lds_acc_cap = (int32_t)(acc / sizeof(double));
+        if (a.fq != nullptr && a.fq == c->fq.p && c->fq_blk_ready) a.fq = c->fq_blk.p, a.fq_block = 1;   // column 0: block-cell order
         const int grid = 8 * (int)(((hs.n_dofs + kAsmBlock - 1) / kAsmBlock + 7) / 8);   // 8 XCD bands of blocks (k_assemble_rows)
         size_t lds = tab + acc;
         if (lds > 64 * 1024)
@@ -561,7 +562,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
                                 &c->tmp_e, &c->tmp_i, &c->tmp_v})
             b->release();
         for (auto& b : c->coef) b.release();
-        c->slotw.release(), c->sl_off.release(), c->lane_row.release(), c->bnd.release(), c->tables.release(), c->reftab.release(), c->lin_sq.release();
+        c->slotw.release(), c->sl_off.release(), c->lane_row.release(), c->fq_blk.release(), c->bnd.release(), c->tables.release(), c->reftab.release(), c->lin_sq.release();
         c->bc_off.release(), c->bn_off.release(), c->bc_cell.release(), c->bn_node.release(), c->bc_vert.release();
         c->halo_dof.release(), c->halo_pos.release(), c->owned.release(), c->hbuf.release(), c->sbuf.release();
         c->halo_inv.release(), c->if_slot.release();
@@ -585,7 +586,7 @@ const char* fdapde_last_error(const fdapde_ctx* c) { return c ? c->err.c_str() :
 int fdapde_mesh_upload(fdapde_ctx* c, int M, int N, int64_t n_nodes, const double* nodes, int64_t n_cells,
                        const int32_t* cells, const uint8_t* bnd) {
     if (!c) return FDAPDE_EINVAL;
-    c->space_ready = c->dev_ready = c->colour_ready = false;
+    c->space_ready = c->dev_ready = c->colour_ready = c->fq_blk_ready = false;
     c->assembled[0] = c->assembled[1] = c->force_ready = c->solved = c->dirichlet_applied = false;
     c->op.clear(), c->fq_i.clear(), c->fq_cols = 0, c->g_i.clear(), c->have_g = false;
     return host_set_mesh(c->hs, M, N, n_nodes, nodes, n_cells, cells, bnd, c->err);
@@ -594,7 +595,7 @@ int fdapde_mesh_upload(fdapde_ctx* c, int M, int N, int64_t n_nodes, const doubl
 int fdapde_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs) {
     if (!c) return FDAPDE_EINVAL;
     auto t0 = std::chrono::steady_clock::now();
-    c->space_ready = c->dev_ready = c->colour_ready = false;
+    c->space_ready = c->dev_ready = c->colour_ready = c->fq_blk_ready = false;
     c->assembled[0] = c->assembled[1] = c->force_ready = c->solved = c->dirichlet_applied = false;
     c->op.clear(), c->fq_i.clear(), c->fq_cols = 0, c->g_i.clear(), c->have_g = false;
     c->halo_ready = false, c->lin_ready = false, c->sp_built[0] = c->sp_built[1] = false, c->sp_cur = -1;
@@ -694,7 +695,7 @@ int fdapde_set_forcing(fdapde_ctx* c, const double* f_q, int32_t n_cols) {
     if (!c->space_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
     const HostSpace& hs = c->hs;
     if (!f_q || n_cols < 1) {
-        c->fq_i.clear(), c->fq_cols = 0;
+        c->fq_i.clear(), c->fq_cols = 0, c->fq_blk_ready = false;
         return FDAPDE_OK;
     }
     const int64_t rows = (int64_t)hs.nq * hs.n_cells;
@@ -710,6 +711,18 @@ int fdapde_set_forcing(fdapde_ctx* c, const double* f_q, int32_t n_cols) {
     if (c->has_device) {
         HIPCHK(c, hipSetDevice(c->device));
         HIPCHK(c, c->fq.upload(c->fq_i.data(), c->fq_i.size(), c->stream));
+        {   // column 0 again in block-cell order for the row-owner assembly (the other columns, parabolic forcing, stay in cell order)
+            const int64_t n_bc = hs.bc_off.empty() ? 0 : hs.bc_off.back();
+            c->fq_blk_ready = false;
+            if (n_bc > 0 && c->dev_ready) {
+                HIPCHK(c, c->fq_blk.alloc((size_t)n_bc * hs.nq));
+                const int64_t total = n_bc * hs.nq;
+                hipLaunchKernelGGL(k_gather_row_groups, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, n_bc, hs.nq,
+                                   c->bc_cell.p, c->fq.p, c->fq_blk.p);
+                HIPCHK(c, hipGetLastError());
+                c->fq_blk_ready = true;
+            }
+        }
         HIPCHK(c, c->force.alloc((size_t)hs.n_dofs * n_cols));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }

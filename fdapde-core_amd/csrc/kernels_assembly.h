@@ -64,6 +64,7 @@ struct AsmArgs {
     const DevRefTensors* reftab;   // OPK 3 only
     double* vals;              // CSR values (internal slots) or nullptr
     const double* fq;          // forcing at quadrature nodes, internal cell order, or nullptr
+    int fq_block;              // 1: fq is the copy in block-cell order (row NQ * block-cell index): k_assemble_rows only
     double* force;             // forcing vector (internal DOF order) or nullptr
     int32_t lds_acc_cap;       // doubles available for the row accumulators
     // block-local tables of the row-owner kernel (host_setup.cpp): cells visited by the block's rows, their vertex nodes
@@ -197,14 +198,16 @@ __device__ __forceinline__ double weak_form(const DevOp& op, int64_t qrow, doubl
 //      gives bitwise A_ij == A_ji.
 template <int M, int R, int OPK, typename Emit>
 __device__ __forceinline__ double element_row(const AsmArgs& a, const DevOp& op, const DevTables* tb, const Geo<M>& g, int cell,
-                                              int il, bool want_matrix, Emit&& emit, const DevRefTensors* rt = nullptr) {
+                                              int il, bool want_matrix, Emit&& emit, const DevRefTensors* rt = nullptr,
+                                              int64_t fcell = -1 /* row group of the forcing samples if not the cell */) {
     constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
     constexpr int NQ = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 5);
     const int64_t qrow0 = (int64_t)NQ * cell;
     double fsum = 0;
     if (a.fq != nullptr) {
+        const int64_t frow0 = fcell >= 0 ? (int64_t)NQ * fcell : qrow0;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) fsum += (a.fq[qrow0 + q] * tb->psi[il * NQ + q]) * tb->qw[q];
+        for (int q = 0; q < NQ; ++q) fsum += (a.fq[frow0 + q] * tb->psi[il * NQ + q]) * tb->qw[q];
         fsum *= g.measure;
     }
     if (!want_matrix) return fsum;
@@ -435,14 +438,15 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
             const int64_t bc = bc0 + (code >> 4);
             Geo<M> g;
             geo_from_vertices<M>(xyz + lv.x * NP, xyz + lv.y * NP, xyz + lv.z * NP, xyz + lv.w * NP, g);
-            const int cell = (a.fq != nullptr || op.needs_rows) ? a.bc_cell[bc] : 0;   // only forcing / varying coefficients need it
+            // the global cell id is needed by varying coefficients and by forcing samples kept in cell order only
+            const int cell = ((a.fq != nullptr && !a.fq_block) || op.needs_rows) ? a.bc_cell[bc] : 0;
             fsum += element_row<M, R, OPK>(a, op, tb, g, cell, code & 15, want_matrix, [&](int j, double value) {
                 const uint32_t slot = (sw[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
                 if (in_lds)
                     acc[my0 - base + (int32_t)slot] += value;
                 else
                     a.vals[my0 + (int32_t)slot] += value;
-            }, rt);
+            }, rt, a.fq_block ? bc : (int64_t)-1);
         }
     }
     if (a.force != nullptr && row < a.n_dofs) a.force[row] = fsum;
@@ -450,6 +454,15 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
         __syncthreads();
         for (int k = threadIdx.x; k < blk_nnz; k += kAsmBlock) a.vals[base + k] = acc[k];
     }
+}
+
+// Forcing samples in block-cell order: dst row group b (nq doubles) = src row group idx[b].  The row-owner kernel then reads
+// one contiguous range per block instead of 32-byte pieces scattered over the whole cell-ordered array.
+__global__ __launch_bounds__(256) void k_gather_row_groups(int64_t n, int nq, const int32_t* idx, const double* src, double* dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * nq) return;
+    const int64_t b = i / nq, q = i - b * nq;
+    dst[i] = src[(int64_t)idx[b] * nq + q];
 }
 
 // ---------------------------------------------------------------------------------------------------------------

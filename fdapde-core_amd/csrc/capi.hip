@@ -711,14 +711,14 @@ int fdapde_set_forcing(fdapde_ctx* c, const double* f_q, int32_t n_cols) {
     if (c->has_device) {
         HIPCHK(c, hipSetDevice(c->device));
         HIPCHK(c, c->fq.upload(c->fq_i.data(), c->fq_i.size(), c->stream));
-        {   // column 0 again in block-cell order for the row-owner assembly (the other columns, parabolic forcing, stay in cell order)
+        {   // column 0 again as load coefficients per block-cell for the row-owner assembly (the other columns, parabolic forcing, stay samples in cell order)
             const int64_t n_bc = hs.bc_off.empty() ? 0 : hs.bc_off.back();
             c->fq_blk_ready = false;
             if (n_bc > 0 && c->dev_ready) {
-                HIPCHK(c, c->fq_blk.alloc((size_t)n_bc * hs.nq));
-                const int64_t total = n_bc * hs.nq;
-                hipLaunchKernelGGL(k_gather_row_groups, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, n_bc, hs.nq,
-                                   c->bc_cell.p, c->fq.p, c->fq_blk.p);
+                HIPCHK(c, c->fq_blk.alloc((size_t)n_bc * hs.nb));
+                const int64_t total = n_bc * hs.nb;
+                hipLaunchKernelGGL(k_block_load_coeffs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, n_bc, hs.nq, hs.nb,
+                                   c->bc_cell.p, c->fq.p, c->tables.p, c->fq_blk.p);
                 HIPCHK(c, hipGetLastError());
                 c->fq_blk_ready = true;
             }

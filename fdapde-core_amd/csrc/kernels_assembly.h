@@ -64,7 +64,7 @@ struct AsmArgs {
     const DevRefTensors* reftab;   // OPK 3 only
     double* vals;              // CSR values (internal slots) or nullptr
     const double* fq;          // forcing at quadrature nodes, internal cell order, or nullptr
-    int fq_block;              // 1: fq is the copy in block-cell order (row NQ * block-cell index): k_assemble_rows only
+    int fq_block;              // 1: fq holds the load coefficients per block-cell (k_block_load_coeffs), NB per block-cell: k_assemble_rows only
     double* force;             // forcing vector (internal DOF order) or nullptr
     int32_t lds_acc_cap;       // doubles available for the row accumulators
     // block-local tables of the row-owner kernel (host_setup.cpp): cells visited by the block's rows, their vertex nodes
@@ -199,15 +199,18 @@ __device__ __forceinline__ double weak_form(const DevOp& op, int64_t qrow, doubl
 template <int M, int R, int OPK, typename Emit>
 __device__ __forceinline__ double element_row(const AsmArgs& a, const DevOp& op, const DevTables* tb, const Geo<M>& g, int cell,
                                               int il, bool want_matrix, Emit&& emit, const DevRefTensors* rt = nullptr,
-                                              int64_t fcell = -1 /* row group of the forcing samples if not the cell */) {
+                                              int64_t fcell = -1 /* block-cell index when a.fq holds load coefficients */) {
     constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
     constexpr int NQ = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 5);
     const int64_t qrow0 = (int64_t)NQ * cell;
     double fsum = 0;
     if (a.fq != nullptr) {
-        const int64_t frow0 = fcell >= 0 ? (int64_t)NQ * fcell : qrow0;
+        if (fcell >= 0) {   // the quadrature sum was taken once per block-cell (k_block_load_coeffs), in this very order
+            fsum = a.fq[(int64_t)NB * fcell + il];
+        } else {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) fsum += (a.fq[frow0 + q] * tb->psi[il * NQ + q]) * tb->qw[q];
+            for (int q = 0; q < NQ; ++q) fsum += (a.fq[qrow0 + q] * tb->psi[il * NQ + q]) * tb->qw[q];
+        }
         fsum *= g.measure;
     }
     if (!want_matrix) return fsum;
@@ -456,13 +459,20 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
     }
 }
 
-// Forcing samples in block-cell order: dst row group b (nq doubles) = src row group idx[b].  The row-owner kernel then reads
-// one contiguous range per block instead of 32-byte pieces scattered over the whole cell-ordered array.
-__global__ __launch_bounds__(256) void k_gather_row_groups(int64_t n, int nq, const int32_t* idx, const double* src, double* dst) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * nq) return;
-    const int64_t b = i / nq, q = i - b * nq;
-    dst[i] = src[(int64_t)idx[b] * nq + q];
+// Forcing in block-cell order, reduced to what a visit needs: dst[b * nb + i] = sum_q (f[idx[b] * nq + q] * psi_i(p_q)) * w_q for
+// block-cell b -- the cell's load vector without |e| (integrator.h:73-90), in the summation order element_row uses, so that a visit
+// reads ONE double at the block-cell index it already has instead of the cell id and then nq samples somewhere in the cell-ordered
+// array.  Built once per fdapde_set_forcing.
+__global__ __launch_bounds__(256) void k_block_load_coeffs(int64_t n, int nq, int nb, const int32_t* idx, const double* src,
+                                                           const DevTables* tab, double* dst) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * nb) return;
+    const int64_t b = t / nb;
+    const int i = (int)(t - b * nb);
+    const double* f = src + (int64_t)idx[b] * nq;
+    double v = 0;
+    for (int q = 0; q < nq; ++q) v += (f[q] * tab->psi[i * nq + q]) * tab->qw[q];
+    dst[t] = v;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

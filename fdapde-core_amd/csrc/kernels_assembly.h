@@ -199,14 +199,15 @@ __device__ __forceinline__ double weak_form(const DevOp& op, int64_t qrow, doubl
 template <int M, int R, int OPK, typename Emit>
 __device__ __forceinline__ double element_row(const AsmArgs& a, const DevOp& op, const DevTables* tb, const Geo<M>& g, int cell,
                                               int il, bool want_matrix, Emit&& emit, const DevRefTensors* rt = nullptr,
-                                              int64_t fcell = -1 /* block-cell index when a.fq holds load coefficients */) {
+                                              int64_t fcell = -1 /* >= 0: a.fq holds load coefficients per block-cell ... */,
+                                              double fcoef = 0.0 /* ... and this is the one of (block-cell, il), loaded ahead by the caller */) {
     constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
     constexpr int NQ = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 5);
     const int64_t qrow0 = (int64_t)NQ * cell;
     double fsum = 0;
     if (a.fq != nullptr) {
         if (fcell >= 0) {   // the quadrature sum was taken once per block-cell (k_block_load_coeffs), in this very order
-            fsum = a.fq[(int64_t)NB * fcell + il];
+            fsum = fcoef;
         } else {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) fsum += (a.fq[qrow0 + q] * tb->psi[il * NQ + q]) * tb->qw[q];
@@ -424,8 +425,15 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
 #pragma unroll
             for (int k = 0; k < NBW; ++k) w[k] = a.slotw[at * NBW + k];
         };
+        // load coefficient of the forcing for a visit: requested one visit ahead like the vertex indices (issued inside the visit,
+        // its latency sat on the row's running sum: 0.36 ms of a C3 init)
+        const bool fblk = a.fq != nullptr && a.fq_block;
+        auto load_fc = [&](int32_t code) -> double {
+            return (fblk && code >= 0) ? a.fq[(bc0 + (code >> 4)) * NB + (code & 15)] : 0.0;
+        };
         int32_t code_n = load_code(0), code_nn = load_code(1);
         ushort4 lv_n = load_lv(code_n);
+        double fc_n = load_fc(code_n);
         uint32_t sw_n[NBW];
         load_sw(0, sw_n);
         for (int64_t v = 0; v < width; ++v) {
@@ -434,8 +442,10 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
             uint32_t sw[NBW];
 #pragma unroll
             for (int k = 0; k < NBW; ++k) sw[k] = sw_n[k];
+            const double fc = fc_n;
             code_n = code_nn, code_nn = load_code(v + 2);
             lv_n = load_lv(code_n);
+            fc_n = load_fc(code_n);
             load_sw(v + 1, sw_n);
             if (code < 0) continue;
             const int64_t bc = bc0 + (code >> 4);
@@ -449,7 +459,7 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
                     acc[my0 - base + (int32_t)slot] += value;
                 else
                     a.vals[my0 + (int32_t)slot] += value;
-            }, rt, a.fq_block ? bc : (int64_t)-1);
+            }, rt, fblk ? bc : (int64_t)-1, fc);
         }
     }
     if (a.force != nullptr && row < a.n_dofs) a.force[row] = fsum;

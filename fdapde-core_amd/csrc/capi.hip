@@ -247,7 +247,7 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
         size_t acc = (size_t)hs.max_blk_nnz * sizeof(double);
         if (tab + acc > (size_t)c->lds_limit) acc = tab < (size_t)c->lds_limit ? (size_t)c->lds_limit - tab : 0;
         a.lds_acc_cap = (int32_t)(acc / sizeof(double));
-        if (a.fq != nullptr && a.fq == c->fq.p && c->fq_blk_ready) a.fq = c->fq_blk.p, a.fq_block = 1;   // column 0: block-cell order
+        if (a.fq != nullptr && a.fq == c->fq.p && c->fq_blk_ready) a.fq = c->fq_blk.p, a.fq_block = 1;   // column 0: one load coefficient per visit slot
         const int grid = 8 * (int)(((hs.n_dofs + kAsmBlock - 1) / kAsmBlock + 7) / 8);   // 8 XCD bands of blocks (k_assemble_rows)
         size_t lds = tab + acc;
         if (lds > 64 * 1024)
@@ -711,14 +711,14 @@ int fdapde_set_forcing(fdapde_ctx* c, const double* f_q, int32_t n_cols) {
     if (c->has_device) {
         HIPCHK(c, hipSetDevice(c->device));
         HIPCHK(c, c->fq.upload(c->fq_i.data(), c->fq_i.size(), c->stream));
-        {   // column 0 again as load coefficients per block-cell for the row-owner assembly (the other columns, parabolic forcing, stay samples in cell order)
-            const int64_t n_bc = hs.bc_off.empty() ? 0 : hs.bc_off.back();
+        {   // column 0 again as one load coefficient per visit slot for the row-owner assembly (the other columns, parabolic forcing,
+            // stay samples in cell order)
             c->fq_blk_ready = false;
-            if (n_bc > 0 && c->dev_ready) {
-                HIPCHK(c, c->fq_blk.alloc((size_t)n_bc * hs.nb));
-                const int64_t total = n_bc * hs.nb;
-                hipLaunchKernelGGL(k_block_load_coeffs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, n_bc, hs.nq, hs.nb,
-                                   c->bc_cell.p, c->fq.p, c->tables.p, c->fq_blk.p);
+            if (c->dev_ready && !hs.adj.empty()) {
+                const int64_t n_slices = (int64_t)hs.sl_off.size() - 1;
+                HIPCHK(c, c->fq_blk.alloc(hs.adj.size()));
+                hipLaunchKernelGGL(k_visit_load_coeffs, dim3((unsigned)n_slices), dim3(64), 0, c->stream, n_slices, hs.nq, c->sl_off.p,
+                                   c->adj.p, c->bc_off.p, c->bc_cell.p, c->fq.p, c->tables.p, c->fq_blk.p);
                 HIPCHK(c, hipGetLastError());
                 c->fq_blk_ready = true;
             }

@@ -147,7 +147,7 @@ struct fdapde_ctx {
     DBuf<uint16_t> bc_vert;
     DBuf<int64_t> sl_off;
     DBuf<int32_t> lane_row;   // assembly lane position -> row (unallocated = identity)
-    DBuf<double> fq_blk;      // column 0 of the forcing as load coefficients per block-cell (k_block_load_coeffs); valid while fq_blk_ready
+    DBuf<double> fq_blk;      // column 0 of the forcing as one load coefficient per visit slot (k_visit_load_coeffs); valid while fq_blk_ready
     bool fq_blk_ready = false;
     DBuf<double> vcoords, vals[2], force, fq, g, sval, scale, gt, x, r, p, y, s, t, r0, u, part_a, part_b, sc, tmp_e,
       tmp_i, tmp_v;

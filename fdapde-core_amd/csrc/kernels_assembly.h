@@ -64,7 +64,7 @@ struct AsmArgs {
     const DevRefTensors* reftab;   // OPK 3 only
     double* vals;              // CSR values (internal slots) or nullptr
     const double* fq;          // forcing at quadrature nodes, internal cell order, or nullptr
-    int fq_block;              // 1: fq holds the load coefficients per block-cell (k_block_load_coeffs), NB per block-cell: k_assemble_rows only
+    int fq_block;              // 1: fq holds one load coefficient per visit slot (k_visit_load_coeffs): k_assemble_rows only
     double* force;             // forcing vector (internal DOF order) or nullptr
     int32_t lds_acc_cap;       // doubles available for the row accumulators
     // block-local tables of the row-owner kernel (host_setup.cpp): cells visited by the block's rows, their vertex nodes
@@ -199,14 +199,14 @@ __device__ __forceinline__ double weak_form(const DevOp& op, int64_t qrow, doubl
 template <int M, int R, int OPK, typename Emit>
 __device__ __forceinline__ double element_row(const AsmArgs& a, const DevOp& op, const DevTables* tb, const Geo<M>& g, int cell,
                                               int il, bool want_matrix, Emit&& emit, const DevRefTensors* rt = nullptr,
-                                              int64_t fcell = -1 /* >= 0: a.fq holds load coefficients per block-cell ... */,
-                                              double fcoef = 0.0 /* ... and this is the one of (block-cell, il), loaded ahead by the caller */) {
+                                              int64_t fcell = -1 /* >= 0: a.fq holds load coefficients per visit ... */,
+                                              double fcoef = 0.0 /* ... and this is the visit's, loaded ahead by the caller */) {
     constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
     constexpr int NQ = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 5);
     const int64_t qrow0 = (int64_t)NQ * cell;
     double fsum = 0;
     if (a.fq != nullptr) {
-        if (fcell >= 0) {   // the quadrature sum was taken once per block-cell (k_block_load_coeffs), in this very order
+        if (fcell >= 0) {   // the quadrature sum was taken once per visit slot (k_visit_load_coeffs), in this very order
             fsum = fcoef;
         } else {
 #pragma unroll
@@ -425,15 +425,13 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
 #pragma unroll
             for (int k = 0; k < NBW; ++k) w[k] = a.slotw[at * NBW + k];
         };
-        // load coefficient of the forcing for a visit: requested one visit ahead like the vertex indices (issued inside the visit,
-        // its latency sat on the row's running sum: 0.36 ms of a C3 init)
+        // load coefficient of the forcing for a visit: one coalesced double per visit slot, streamed next to the adjacency word and
+        // requested ahead like it (gathered by cell id inside the visit, the forcing cost 0.36 ms of a C3 init)
         const bool fblk = a.fq != nullptr && a.fq_block;
-        auto load_fc = [&](int32_t code) -> double {
-            return (fblk && code >= 0) ? a.fq[(bc0 + (code >> 4)) * NB + (code & 15)] : 0.0;
-        };
+        auto load_fc = [&](int64_t v) -> double { return (fblk && v < width) ? a.fq[(off + v) * kSlice + lane] : 0.0; };
         int32_t code_n = load_code(0), code_nn = load_code(1);
         ushort4 lv_n = load_lv(code_n);
-        double fc_n = load_fc(code_n);
+        double fc_n = load_fc(0);
         uint32_t sw_n[NBW];
         load_sw(0, sw_n);
         for (int64_t v = 0; v < width; ++v) {
@@ -445,7 +443,7 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
             const double fc = fc_n;
             code_n = code_nn, code_nn = load_code(v + 2);
             lv_n = load_lv(code_n);
-            fc_n = load_fc(code_n);
+            fc_n = load_fc(v + 1);
             load_sw(v + 1, sw_n);
             if (code < 0) continue;
             const int64_t bc = bc0 + (code >> 4);
@@ -469,20 +467,30 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
     }
 }
 
-// Forcing in block-cell order, reduced to what a visit needs: dst[b * nb + i] = sum_q (f[idx[b] * nq + q] * psi_i(p_q)) * w_q for
-// block-cell b -- the cell's load vector without |e| (integrator.h:73-90), in the summation order element_row uses, so that a visit
-// reads ONE double at the block-cell index it already has instead of the cell id and then nq samples somewhere in the cell-ordered
-// array.  Built once per fdapde_set_forcing.
-__global__ __launch_bounds__(256) void k_block_load_coeffs(int64_t n, int nq, int nb, const int32_t* idx, const double* src,
-                                                           const DevTables* tab, double* dst) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n * nb) return;
-    const int64_t b = t / nb;
-    const int i = (int)(t - b * nb);
-    const double* f = src + (int64_t)idx[b] * nq;
-    double v = 0;
-    for (int q = 0; q < nq; ++q) v += (f[q] * tab->psi[i * nq + q]) * tab->qw[q];
-    dst[t] = v;
+// Forcing reduced to what a visit needs, in VISIT order (the layout of the adjacency slices): for the visit at slot (s, v, lane)
+//   dst[(sl_off[s] + v) * 64 + lane] = sum_q (f[cell * nq + q] * psi_il(p_q)) * w_q        (0 in padding slots)
+// -- the (cell, il) entry of the cell's load vector without |e| (integrator.h:73-90), summed in the order element_row uses.  The
+// row-owner kernel then streams one coalesced double per visit next to its adjacency word instead of gathering samples by cell id.
+// Built once per fdapde_set_forcing; one wavefront per slice.
+__global__ __launch_bounds__(64) void k_visit_load_coeffs(int64_t n_slices, int nq, const int64_t* sl_off, const int32_t* adj,
+                                                          const int64_t* bc_off, const int32_t* bc_cell, const double* src,
+                                                          const DevTables* tab, double* dst) {
+    const int64_t s = blockIdx.x;
+    if (s >= n_slices) return;
+    const int lane = threadIdx.x;
+    const int64_t off = sl_off[s], width = sl_off[s + 1] - off;
+    const int64_t bc0 = bc_off[s / (kAsmBlock / kSlice)];   // block-cell table of the slice's assembly block
+    for (int64_t v = 0; v < width; ++v) {
+        const int64_t at = (off + v) * kSlice + lane;
+        const int32_t code = adj[at];
+        double val = 0;
+        if (code >= 0) {
+            const double* f = src + (int64_t)bc_cell[bc0 + (code >> 4)] * nq;
+            const int il = code & 15;
+            for (int q = 0; q < nq; ++q) val += (f[q] * tab->psi[il * nq + q]) * tab->qw[q];
+        }
+        dst[at] = val;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

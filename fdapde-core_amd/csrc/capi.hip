@@ -699,25 +699,39 @@ int fdapde_set_forcing(fdapde_ctx* c, const double* f_q, int32_t n_cols) {
         return FDAPDE_OK;
     }
     const int64_t rows = (int64_t)hs.nq * hs.n_cells;
-    c->fq_i.resize((size_t)rows * n_cols);
-    for (int col = 0; col < n_cols; ++col)
-        for (int64_t ci = 0; ci < hs.n_cells; ++ci) {
-            const int64_t ce = hs.cell_i2e[(size_t)ci];
-            std::memcpy(&c->fq_i[(size_t)col * rows + (size_t)ci * hs.nq], &f_q[(size_t)col * rows + (size_t)ce * hs.nq],
-                        sizeof(double) * hs.nq);
-        }
     c->fq_cols = n_cols;
     c->force_ready = false, c->solved = false;
+    if (!c->has_device || !c->dev_ready) {   // device-less context: keep the samples in internal cell order on the host
+        c->fq_i.resize((size_t)rows * n_cols);
+        for (int col = 0; col < n_cols; ++col)
+            for (int64_t ci = 0; ci < hs.n_cells; ++ci) {
+                const int64_t ce = hs.cell_i2e[(size_t)ci];
+                std::memcpy(&c->fq_i[(size_t)col * rows + (size_t)ci * hs.nq], &f_q[(size_t)col * rows + (size_t)ce * hs.nq],
+                            sizeof(double) * hs.nq);
+            }
+    }
     if (c->has_device) {
         HIPCHK(c, hipSetDevice(c->device));
-        HIPCHK(c, c->fq.upload(c->fq_i.data(), c->fq_i.size(), c->stream));
+        if (c->dev_ready) {   // upload as handed over, permute to the internal cell order on the device
+            c->fq_i.clear();
+            DBuf<double> stage;
+            HIPCHK(c, stage.upload(f_q, (size_t)rows * n_cols, c->stream));
+            HIPCHK(c, c->fq.alloc((size_t)rows * n_cols));
+            for (int col = 0; col < n_cols; ++col)
+                hipLaunchKernelGGL(k_gather_row_groups, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, c->stream, hs.n_cells, hs.nq,
+                                   c->cell_i2e.p, stage.p + (size_t)col * rows, c->fq.p + (size_t)col * rows);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipStreamSynchronize(c->stream));   // stage is released at the end of this scope
+        } else {
+            HIPCHK(c, c->fq.upload(c->fq_i.data(), c->fq_i.size(), c->stream));
+        }
         {   // column 0 again as one load coefficient per visit slot for the row-owner assembly (the other columns, parabolic forcing,
             // stay samples in cell order)
             c->fq_blk_ready = false;
             if (c->dev_ready && !hs.adj.empty()) {
                 const int64_t n_slices = (int64_t)hs.sl_off.size() - 1;
                 HIPCHK(c, c->fq_blk.alloc(hs.adj.size()));
-                hipLaunchKernelGGL(k_visit_load_coeffs, dim3((unsigned)n_slices), dim3(64), 0, c->stream, n_slices, hs.nq, c->sl_off.p,
+                hipLaunchKernelGGL(k_visit_load_coeffs, dim3((unsigned)n_slices), dim3(64, 8), 0, c->stream, n_slices, hs.nq, c->sl_off.p,
                                    c->adj.p, c->bc_off.p, c->bc_cell.p, c->fq.p, c->tables.p, c->fq_blk.p);
                 HIPCHK(c, hipGetLastError());
                 c->fq_blk_ready = true;

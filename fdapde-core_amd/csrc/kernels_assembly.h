@@ -467,12 +467,20 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
     }
 }
 
+// dst row group b (nq doubles) = src row group idx[b]: forcing samples from the caller's cell order to the internal one
+__global__ __launch_bounds__(256) void k_gather_row_groups(int64_t n, int nq, const int32_t* idx, const double* src, double* dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * nq) return;
+    const int64_t b = i / nq, q = i - b * nq;
+    dst[i] = src[(int64_t)idx[b] * nq + q];
+}
+
 // Forcing reduced to what a visit needs, in VISIT order (the layout of the adjacency slices): for the visit at slot (s, v, lane)
 //   dst[(sl_off[s] + v) * 64 + lane] = sum_q (f[cell * nq + q] * psi_il(p_q)) * w_q        (0 in padding slots)
 // -- the (cell, il) entry of the cell's load vector without |e| (integrator.h:73-90), summed in the order element_row uses.  The
 // row-owner kernel then streams one coalesced double per visit next to its adjacency word instead of gathering samples by cell id.
-// Built once per fdapde_set_forcing; one wavefront per slice.
-__global__ __launch_bounds__(64) void k_visit_load_coeffs(int64_t n_slices, int nq, const int64_t* sl_off, const int32_t* adj,
+// Built once per fdapde_set_forcing; one workgroup of 8 wavefronts per slice, wavefront y takes the visits y, y + 8, ...
+__global__ __launch_bounds__(512) void k_visit_load_coeffs(int64_t n_slices, int nq, const int64_t* sl_off, const int32_t* adj,
                                                           const int64_t* bc_off, const int32_t* bc_cell, const double* src,
                                                           const DevTables* tab, double* dst) {
     const int64_t s = blockIdx.x;
@@ -480,7 +488,7 @@ __global__ __launch_bounds__(64) void k_visit_load_coeffs(int64_t n_slices, int 
     const int lane = threadIdx.x;
     const int64_t off = sl_off[s], width = sl_off[s + 1] - off;
     const int64_t bc0 = bc_off[s / (kAsmBlock / kSlice)];   // block-cell table of the slice's assembly block
-    for (int64_t v = 0; v < width; ++v) {
+    for (int64_t v = threadIdx.y; v < width; v += blockDim.y) {
         const int64_t at = (off + v) * kSlice + lane;
         const int32_t code = adj[at];
         double val = 0;

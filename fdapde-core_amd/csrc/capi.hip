@@ -156,7 +156,8 @@ AsmArgs asm_args(fdapde_ctx* c) {
 }
 
 // validate an operator expression and stage its (permuted) coefficient data on the device
-int make_dev_op(fdapde_ctx* c, const std::vector<HostTerm>& terms, DevOp* out, int coef_slot0) {
+// reuse: the coefficient buffers already hold THIS operator's data (set by the previous fdapde_init): no upload
+int make_dev_op(fdapde_ctx* c, const std::vector<HostTerm>& terms, DevOp* out, int coef_slot0, bool reuse = false) {
     DevOp op{};
     op.n = (int32_t)terms.size();
     op.needs_psi = 0, op.needs_rows = 0;
@@ -169,7 +170,8 @@ int make_dev_op(fdapde_ctx* c, const std::vector<HostTerm>& terms, DevOp* out, i
         if (t.space_varying) op.needs_rows = 1;
         if (t.space_varying) {
             DBuf<double>& buf = c->coef[coef_slot0 + k];
-            HIPCHK(c, buf.upload(terms[k].data_i.data(), terms[k].data_i.size(), c->stream));
+            if (!(reuse && buf.p && buf.n >= terms[k].data_i.size()))
+                HIPCHK(c, buf.upload(terms[k].data_i.data(), terms[k].data_i.size(), c->stream));
             d.data = buf.p;
         }
     }
@@ -588,7 +590,7 @@ int fdapde_mesh_upload(fdapde_ctx* c, int M, int N, int64_t n_nodes, const doubl
     if (!c) return FDAPDE_EINVAL;
     c->space_ready = c->dev_ready = c->colour_ready = c->fq_blk_ready = false;
     c->assembled[0] = c->assembled[1] = c->force_ready = c->solved = c->dirichlet_applied = false;
-    c->op.clear(), c->fq_i.clear(), c->fq_cols = 0, c->g_i.clear(), c->have_g = false;
+    c->op.clear(), c->coef_of_op = false, c->fq_i.clear(), c->fq_cols = 0, c->g_i.clear(), c->have_g = false;
     return host_set_mesh(c->hs, M, N, n_nodes, nodes, n_cells, cells, bnd, c->err);
 }
 
@@ -597,7 +599,7 @@ int fdapde_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs) {
     auto t0 = std::chrono::steady_clock::now();
     c->space_ready = c->dev_ready = c->colour_ready = c->fq_blk_ready = false;
     c->assembled[0] = c->assembled[1] = c->force_ready = c->solved = c->dirichlet_applied = false;
-    c->op.clear(), c->fq_i.clear(), c->fq_cols = 0, c->g_i.clear(), c->have_g = false;
+    c->op.clear(), c->coef_of_op = false, c->fq_i.clear(), c->fq_cols = 0, c->g_i.clear(), c->have_g = false;
     c->halo_ready = false, c->lin_ready = false, c->sp_built[0] = c->sp_built[1] = false, c->sp_cur = -1;
     drop_graph(c);
     int rc = host_build_space(c->hs, order, c->err);
@@ -685,7 +687,7 @@ int fdapde_set_operator(fdapde_ctx* c, int32_t n_terms, const fdapde_term* terms
     bool sym = true;
     int rc = check_terms(c, n_terms, terms, &t, &sym);
     if (rc) return rc;
-    c->op = std::move(t), c->op_symmetric = sym;
+    c->op = std::move(t), c->op_symmetric = sym, c->coef_of_op = false;
     c->assembled[0] = false, c->solved = false;
     return FDAPDE_OK;
 }
@@ -777,6 +779,7 @@ int fdapde_assemble_operator(fdapde_ctx* c, int32_t which, int32_t n_terms, cons
     int rc = check_terms(c, n_terms, terms, &t, &sym);
     if (rc) return rc;
     DevOp op;
+    c->coef_of_op = false;   // the shared coefficient slots now hold this call's data
     rc = make_dev_op(c, t, &op, 0);
     if (rc) return rc;
     AsmArgs a = asm_args(c);
@@ -798,7 +801,8 @@ int fdapde_init(fdapde_ctx* c, const fdapde_options* opt) {
     const HostSpace& hs = c->hs;
     const int assembly = opt ? opt->assembly : FDAPDE_ASSEMBLY_ROWS;
     DevOp op, mass_op{};
-    int rc = make_dev_op(c, c->op, &op, 0);
+    int rc = make_dev_op(c, c->op, &op, 0, c->coef_of_op);
+    c->coef_of_op = rc == FDAPDE_OK;
     if (rc) return rc;
     mass_op.n = 1, mass_op.needs_psi = 1, mass_op.needs_rows = 0;
     mass_op.t[0].kind = FDAPDE_REACTION, mass_op.t[0].space_varying = 0, mass_op.t[0].coef = 1.0, mass_op.t[0].cst[0] = 1.0;

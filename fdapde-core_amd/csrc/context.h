@@ -156,6 +156,7 @@ struct fdapde_ctx {
     DBuf<DevRefTensors> reftab;
     DBuf<int32_t> ctl;
     DBuf<double> coef[kMaxTerms];
+    bool coef_of_op = false;   // coef[] hold the space-varying data of the operator set by fdapde_set_operator (uploaded by fdapde_init)
     int32_t* h_ctl = nullptr;   // pinned: ctl[3]
     double* h_sc = nullptr;     // pinned: sc[0..3]
     int spmv_grid = 0, rb_per_band = 0, vec_grid = 0, n_rb = 0, cg_grid = 0;

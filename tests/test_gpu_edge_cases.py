@@ -83,3 +83,33 @@ def test_singular_operator_reports_failure(capi):
     nodes, cells, bnd = meshgen.unit_square(8)
     with pytest.raises(capi.FdapdeError):
         _solve(capi, nodes, cells, np.zeros_like(bnd), -capi.laplacian(), maxit=200)
+
+
+def test_space_varying_data_follows_the_operator(capi):
+    """The space-varying coefficient data stays on the device between two `init` calls of the same operator; an
+    `assemble_operator` call with other data, or a new `set_operator`, must invalidate it."""
+    from fdapde_core_amd import meshgen
+
+    nodes, cells, bnd = meshgen.unit_square(6)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(1)
+    qn = c.quadrature_nodes()
+    c1, c2 = 1.0 + qn[:, 0], 3.0 + np.sin(qn[:, 1])
+    c.set_forcing(np.ones(qn.shape[0]))
+    c.set_dirichlet(np.zeros(nd))
+    c.set_operator(-capi.laplacian() + capi.reaction_field(c1))
+    c.init()
+    v1 = c.matrix_values(capi.MAT_STIFF).copy()
+    c.init()                                                   # same operator: data reused
+    assert np.array_equal(c.matrix_values(capi.MAT_STIFF), v1)
+    c.assemble_operator(capi.MAT_STIFF, capi.reaction_field(c2))   # other data through the same device slots
+    c.init()
+    assert np.array_equal(c.matrix_values(capi.MAT_STIFF), v1)
+    c.set_operator(-capi.laplacian() + capi.reaction_field(c2))
+    c.init()
+    v2 = c.matrix_values(capi.MAT_STIFF)
+    assert not np.array_equal(v2, v1)
+    c.set_operator(-capi.laplacian() + capi.reaction_field(c1))
+    c.init()
+    assert np.array_equal(c.matrix_values(capi.MAT_STIFF), v1)

@@ -14,8 +14,8 @@ an RCCL all-reduce of the interface DOF contributions per operator application (
 
 Prints ONE JSON line (rank 0).  `roofline` is the CSR SpMV inside CG: algorithmic bytes 12 nnz + 4 (n+1) + 16 n per
 launch over the average launch duration measured with HIP events on the solver's stream during the timed steps.
-`cpu_baseline` is the CPU oracle (oracle/fem_oracle.c, the single-threaded port of the reference algorithm) timed on a
-bounded sample of the same workload; `cpu_baseline_all_cores` is the same restatement with OpenMP on every host core
+`cpu_baseline` is the CPU oracle (oracle/fem_oracle.c, the single-threaded port of the reference algorithm) timed on the
+same workload at the same size (--cpu-nx 119); `cpu_baseline_all_cores` is the same restatement with OpenMP on every host core
 (oracle/fem_oracle_mt.c: BASELINE.md's "CPU-best" column).
 """
 import argparse
@@ -39,8 +39,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--nx", type=int, default=119, help="cubes per axis of the C3 mesh (119 = BASELINE size)")
-    ap.add_argument("--cpu-nx", type=int, default=96, help="cubes per axis of the CPU-baseline sample (~15 s of CPU work)")
+    ap.add_argument("--cpu-nx", type=int, default=119,
+                    help="cubes per axis of the CPU-baseline sample (119 = the GPU line's own workload: ~25 s on 1 core + ~6 s on all cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary single-GPU results (BASELINE configs C2 and C5) appended as `extra`")
     ap.add_argument("--time-spmv", type=int, default=32,
                     help="SpMV launches per step timed with dispatch-attached HIP events (each costs a ~6 us bubble)")
     return ap.parse_args()
@@ -139,6 +141,7 @@ def main():
     t_gen = time.perf_counter()
     nodes, cells, bnd = meshgen.unit_cube(args.nx)
     t_gen = time.perf_counter() - t_gen
+    n_cells_total = int(cells.shape[0])
     u_exact, f = meshgen.manufactured(3)
 
     if world == 1:
@@ -175,8 +178,11 @@ def main():
         err = float(np.abs(u - u_exact(coords)).max())
         setup_ms = ctx.info().t_setup_ms + 1e3 * t_prep
         _, alg_bytes = ctx.bench_spmv(reps=1)
+        n_int, nnz_int, streamed_bytes = ctx.solver_layout(True)
         parallelism = "1 GPU"
         total_dofs = n_dofs
+        ctx.close()
+        del nodes, cells, bnd
     else:
         from fdapde_core_amd import dist as fdist
 
@@ -184,14 +190,18 @@ def main():
         if rank != 0:
             return
         (elapsed, info, spmv_ms, t_asm, t_sol, err, setup_ms, alg_bytes, sizes, total_dofs, parallelism) = res
+        n_int = nnz_int = streamed_bytes = None
 
     if rank != 0:
         return
-    traffic = None   # HBM bytes per SpMV launch from the committed rocprofv3 PMC passes (tools/profile_gpu.sh), if any
+    # HBM bytes per SpMV launch: NOT measured in this run (PMC counters need rocprofv3 around the process) -- taken from the
+    # committed PMC passes of the same workload and code (tools/profile_gpu.sh -> profiles/spmv_pmc.json), and labelled so
+    traffic, traffic_source = None, None
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", "spmv_pmc.json")))
         if world == 1 and pj.get("nx") == args.nx:
             traffic = pj.get("hbm_bytes_per_launch")
+            traffic_source = "profiles/spmv_pmc.json (rocprofv3 --pmc passes of an earlier run of this workload; not this run)"
     except Exception:
         pass
     ms_per_step = 1e3 * elapsed / args.steps
@@ -210,7 +220,7 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"C3: 3-D P1 Laplacian, [0,1]^3, {args.nx}^3 x 6 Kuhn tetrahedra = {cells.shape[0]} cells, "
+            "workload": f"C3: 3-D P1 Laplacian, [0,1]^3, {args.nx}^3 x 6 Kuhn tetrahedra = {n_cells_total} cells, "
                         f"{total_dofs} DOFs, nnz {sizes['nnz']}, jitter 0.2h, ids permuted, seed 12345; "
                         "u = sin(pi x) sin(pi y) sin(pi z), homogeneous Dirichlet; init (stiff+force+mass) + Jacobi-PCG rtol 1e-10",
             "parallelism": parallelism,
@@ -226,10 +236,32 @@ def main():
         "roofline": {
             "bound": "hbm", "kernel": "k_spmv_team2 (CSR SpMV fused with p.Ap and Ap.Ap inside CG)",
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": traffic,
+            "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": spmv_ms,
         },
     }
+    if n_int is not None and spmv_ms > 0:
+        # the CG streams the Dirichlet-reduced interior block, not the full CSR the caller sees: the same figure on that operator,
+        # and the rate of the bytes the kernel really streams (compact layout: no diagonal, 16-bit column codes)
+        alg_int = 12.0 * nnz_int + 4.0 * (n_int + 1) + 16.0 * n_int
+        r = out["roofline"]
+        r["algorithmic_bytes_interior"] = alg_int
+        r["achieved_interior"] = alg_int / (spmv_ms * 1e-3) / 1e9
+        r["frac_interior"] = r["achieved_interior"] / HBM_PEAK_GBPS
+        r["streamed_bytes_per_launch"] = streamed_bytes
+        r["streamed_gbps"] = streamed_bytes / (spmv_ms * 1e-3) / 1e9
+        r["interior_rows"], r["interior_nnz"] = n_int, nnz_int
+    if world == 1 and not args.no_extra:
+        # secondary results, after the C3 line's own timed region: the other single-GPU BASELINE configurations
+        from fdapde_core_amd import workloads
+
+        extra = {}
+        for name, fn in (("c2", workloads.run_c2), ("c5", workloads.run_c5)):
+            try:
+                extra[name] = fn(capi, meshgen, device=device_index, hbm_peak_gbps=HBM_PEAK_GBPS)
+            except Exception as e:   # never let a secondary result take the bench line down
+                extra[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        out["extra"] = extra
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baseline(args.cpu_nx)
     print(json.dumps(out))

@@ -46,6 +46,7 @@ SYMBOLS = [
     "fdapde_info_get", "fdapde_spmv", "fdapde_bench_spmv", "fdapde_tune", "fdapde_stream", "fdapde_synchronize",
     "fdapde_comm_unique_id", "fdapde_comm_init", "fdapde_halo_setup", "fdapde_solve_parabolic",
     "fdapde_lin_compute", "fdapde_lin_solve", "fdapde_eval_pointwise", "fdapde_cell_integrals", "fdapde_comm_init_callback",
+    "fdapde_solver_layout",
 ]
 
 _lib = None
@@ -376,6 +377,12 @@ class Context:
         ms, by = C.c_double(), C.c_double()
         self._check(self.lib.fdapde_bench_spmv(self._ctx, reps, C.byref(ms), C.byref(by)))
         return ms.value, by.value
+
+    def solver_layout(self, with_dirichlet=True):
+        """(rows, entries) of the interior block as a plain CSR operator + bytes one in-solve SpMV launch streams"""
+        ni, nz, by = C.c_int64(), C.c_int64(), C.c_double()
+        self._check(self.lib.fdapde_solver_layout(self._ctx, 1 if with_dirichlet else 0, C.byref(ni), C.byref(nz), C.byref(by)))
+        return ni.value, nz.value, by.value
 
     # ---- multi-GPU
     @staticmethod

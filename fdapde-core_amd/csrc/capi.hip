@@ -66,7 +66,8 @@ int upload_space(fdapde_ctx* c) {
         }
     HIPCHK(c, c->tables.upload(&dt, 1, st));
     {   // reference tensors of the constant-coefficient form (element_row OPK 3), same quadrature nodes and weights
-        static DevRefTensors rt;   // ~10 KB: keep it off the stack
+        auto rt_own = std::make_unique<DevRefTensors>();   // ~10 KB: off the stack, and per call (contexts of different threads build concurrently)
+        DevRefTensors& rt = *rt_own;
         std::memset(&rt, 0, sizeof rt);
         const int nb = c->tb.nb, nq = c->tb.nq, nn = nb * nb;
         for (int k = 0; k < 3; ++k)
@@ -601,6 +602,7 @@ int fdapde_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs) {
     c->assembled[0] = c->assembled[1] = c->force_ready = c->solved = c->dirichlet_applied = false;
     c->op.clear(), c->coef_of_op = false, c->fq_i.clear(), c->fq_cols = 0, c->g_i.clear(), c->have_g = false;
     c->halo_ready = false, c->lin_ready = false, c->sp_built[0] = c->sp_built[1] = false, c->sp_cur = -1;
+    c->scaled_owner = fdapde_ctx::kScaledNone;
     drop_graph(c);
     int rc = host_build_space(c->hs, order, c->err);
     if (rc) return rc;
@@ -636,7 +638,7 @@ int fdapde_dofs_set_boundary(fdapde_ctx* c, const uint8_t* bnd) {
     for (int64_t i = 0; i < hs.n_dofs; ++i) hs.dof_bnd_i[(size_t)i] = hs.dof_bnd[(size_t)hs.dof_i2e[(size_t)i]];
     c->sp_built[1] = false;   // the compact solver pattern drops Dirichlet rows / columns
     drop_graph(c);
-    c->solved = false;
+    c->solved = false, c->scaled_owner = fdapde_ctx::kScaledNone;
     if (c->dev_ready) {
         HIPCHK(c, hipSetDevice(c->device));
         HIPCHK(c, c->bnd.upload(hs.dof_bnd_i.data(), hs.dof_bnd_i.size(), c->stream));
@@ -727,18 +729,8 @@ int fdapde_set_forcing(fdapde_ctx* c, const double* f_q, int32_t n_cols) {
         } else {
             HIPCHK(c, c->fq.upload(c->fq_i.data(), c->fq_i.size(), c->stream));
         }
-        {   // column 0 again as one load coefficient per visit slot for the row-owner assembly (the other columns, parabolic forcing,
-            // stay samples in cell order)
-            c->fq_blk_ready = false;
-            if (c->dev_ready && !hs.adj.empty()) {
-                const int64_t n_slices = (int64_t)hs.sl_off.size() - 1;
-                HIPCHK(c, c->fq_blk.alloc(hs.adj.size()));
-                hipLaunchKernelGGL(k_visit_load_coeffs, dim3((unsigned)n_slices), dim3(64, 8), 0, c->stream, n_slices, hs.nq, c->sl_off.p,
-                                   c->adj.p, c->bc_off.p, c->bc_cell.p, c->fq.p, c->tables.p, c->fq_blk.p);
-                HIPCHK(c, hipGetLastError());
-                c->fq_blk_ready = true;
-            }
-        }
+        c->fq_blk_ready = false;   // fdapde_init turns column 0 into per-visit load coefficients (that IS the quadrature of
+                                   // discretize_forcing, fem_assembler.h:122-136, so it belongs to init's timed region)
         HIPCHK(c, c->force.alloc((size_t)hs.n_dofs * n_cols));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
@@ -807,6 +799,18 @@ int fdapde_init(fdapde_ctx* c, const fdapde_options* opt) {
     mass_op.n = 1, mass_op.needs_psi = 1, mass_op.needs_rows = 0;
     mass_op.t[0].kind = FDAPDE_REACTION, mass_op.t[0].space_varying = 0, mass_op.t[0].coef = 1.0, mass_op.t[0].cst[0] = 1.0;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    // forcing quadrature, first half (fem_assembler.h:122-136): column 0 as ONE load coefficient per visit slot of the row-owner
+    // sweep, sum_q w_q f_q psi_i(p_q), in the summation order the visit loop would use; the sweep below then streams one
+    // coalesced double per visit instead of gathering the cell's samples.  Runs on every init: the samples may have changed.
+    if (c->fq_cols > 0 && assembly == FDAPDE_ASSEMBLY_ROWS && c->asm_fq_block && !hs.adj.empty()) {
+        const int64_t n_slices = (int64_t)hs.sl_off.size() - 1;
+        HIPCHK(c, c->fq_blk.alloc(hs.adj.size()));
+        hipLaunchKernelGGL(k_visit_load_coeffs, dim3((unsigned)n_slices), dim3(64, 8), 0, c->stream, n_slices, hs.nq, c->sl_off.p,
+                           c->adj.p, c->bc_off.p, c->bc_cell.p, c->fq.p, c->tables.p, c->fq_blk.p);
+        HIPCHK(c, hipGetLastError());
+        c->fq_blk_ready = true;
+    } else
+        c->fq_blk_ready = false;
     // stiff_ (+ force_ column 0 in the same sweep): fem_solver_base.h:113, 121/133
     AsmArgs a = asm_args(c);
     a.vals = c->vals[FDAPDE_MAT_STIFF].p;
@@ -896,7 +900,7 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss) {
         hipLaunchKernelGGL(k_jacobi_scale_from_diag, dim3(g1(n)), dim3(256), 0, st, n, c->tmp_i.p, c->bnd.p, use_bnd, c->scale.p,
                            c->ctl.p + 3);
     } else {
-        hipLaunchKernelGGL(k_jacobi_scale, dim3(g1(n)), dim3(256), 0, st, n, c->diag.p, A, c->bnd.p, use_bnd, c->scale.p, c->ctl.p + 3);
+        hipLaunchKernelGGL(k_jacobi_scale, dim3(g1(n)), dim3(256), 0, st, n, c->rowptr.p, c->diag.p, A, c->bnd.p, use_bnd, c->scale.p, c->ctl.p + 3);
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -1036,8 +1040,11 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
         // arguments repeat with period 2, so the graph captured for iterations 0 .. chunk-1 serves every even-aligned chunk
         bool graphed = false;
         if (cgf && c->use_graph && chunk == check_every && (chunk & 1) == 0 && (launched & 1) == 0 && timed >= n_timed) {
-            const GraphKey key{c->sval.p, c->sp_cur >= 0 ? (const void*)c->sp_rowptr[c->sp_cur].p : (const void*)c->rowptr.p, n, tol2, chunk,
-                               cgf_V, c->spmv_grid, c->spmv_team, c->spmv_ablate, c->spmv_c16, c->spmv_deep, c->spmv_unroll, c->sp_cur};
+            GraphKey key;
+            std::memset(&key, 0, sizeof key);   // padding bytes take part in the memcmp below
+            key.sval = c->sval.p, key.rowptr = c->sp_cur >= 0 ? (const void*)c->sp_rowptr[c->sp_cur].p : (const void*)c->rowptr.p;
+            key.n = n, key.tol2 = tol2, key.chunk = chunk, key.v = cgf_V, key.grid = c->spmv_grid, key.team = c->spmv_team;
+            key.ablate = c->spmv_ablate, key.c16 = c->spmv_c16, key.deep = c->spmv_deep, key.unroll = c->spmv_unroll, key.sp_cur = c->sp_cur;
             if (!c->cg_graph_exec || std::memcmp(&key, &c->cg_graph_key, sizeof key) != 0) {
                 if (c->cg_graph_exec) (void)hipGraphExecDestroy(c->cg_graph_exec), c->cg_graph_exec = nullptr;
                 hipGraph_t g = nullptr;
@@ -1199,6 +1206,40 @@ int fdapde_solver_prepare(fdapde_ctx* c, int32_t with_dirichlet) {
     return build_solver_pattern(c, with_dirichlet ? 1 : 0);
 }
 
+// What the in-solve SpMV works on, for the roofline figures of bench.py: the interior block A_II as a plain CSR operator
+// (rows / entries; algorithmic bytes = 12 nnz + 4 (n + 1) + 16 n on it) and the bytes one launch of the solver's kernel really
+// streams from the compact coded layout (values 8 B + column codes 2 B per stored entry, row pointers, window bases, virtual-row
+// table of a segmented pattern, x gathered once and y written once for every row of the full vector).
+int fdapde_solver_layout(fdapde_ctx* c, int32_t with_dirichlet, int64_t* n_interior, int64_t* nnz_interior, double* streamed_bytes) {
+    if (!c) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (!c->dev_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int v = with_dirichlet ? 1 : 0;
+    if (c->spmv_variant == 2)
+        if (int rc = build_solver_pattern(c, v)) return rc;
+    const HostSpace& hs = c->hs;
+    int64_t ni = 0, nz = 0;
+    for (int64_t i = 0; i < hs.n_dofs; ++i) {
+        if (v && hs.dof_bnd_i[(size_t)i]) continue;
+        ++ni;
+        for (int32_t k = hs.rowptr_i[(size_t)i]; k < hs.rowptr_i[(size_t)i + 1]; ++k)
+            if (!(v && hs.dof_bnd_i[(size_t)hs.colidx_i[(size_t)k]])) ++nz;
+    }
+    if (n_interior) *n_interior = ni;
+    if (nnz_interior) *nnz_interior = nz;
+    if (streamed_bytes) {
+        if (c->spmv_variant == 2 && c->sp_built[v]) {
+            const int64_t n_csr = c->sp_nv[v] > 0 ? c->sp_nv[v] : hs.n_dofs;
+            *streamed_bytes = 10.0 * (double)c->sp_nnz[v] + 4.0 * (double)(n_csr + 1) + 16.0 * (double)((n_csr + kCodeRows - 1) / kCodeRows) +
+                              (c->sp_nv[v] > 0 ? 8.0 * (double)n_csr : 0.0) + 16.0 * (double)hs.n_dofs +
+                              4.0 * (double)c->sp_wide[v] * kCodeRows * ((double)c->sp_nnz[v] / (double)(n_csr > 0 ? n_csr : 1));
+        } else
+            *streamed_bytes = 12.0 * (double)hs.nnz + 4.0 * (double)(hs.n_dofs + 1) + 16.0 * (double)hs.n_dofs;
+    }
+    return FDAPDE_OK;
+}
+
 int fdapde_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     if (!c) return FDAPDE_EINVAL;
     if (int rc = need_device(c)) return rc;
@@ -1212,6 +1253,7 @@ int fdapde_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     const double* A = c->vals[FDAPDE_MAT_STIFF].p;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     SolveState ss;
+    c->scaled_owner = fdapde_ctx::kScaledSolve;
     if (int rc = solve_prepare(c, A, c->have_g ? 1 : 0, &ss)) return rc;
     const int rc = solve_run(c, ss, A, c->force.p, c->g.p, nullptr, opt ? opt->method : FDAPDE_SOLVER_AUTO, rtol, maxit, check_every,
                              opt ? opt->time_spmv : 0);
@@ -1258,6 +1300,7 @@ int fdapde_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_t
     hipLaunchKernelGGL(k_matrix_combine, dim3(g1(hs.nnz)), dim3(256), 0, st, hs.nnz, c->vals[FDAPDE_MAT_MASS].p,
                        c->vals[FDAPDE_MAT_STIFF].p, inv_dt, kmat.p);
     SolveState ss;
+    c->scaled_owner = fdapde_ctx::kScaledParabolic;
     if (int rc = solve_prepare(c, kmat.p, dirichlet ? 1 : 0, &ss)) return rc;
     to_internal(initial_condition);
     HIPCHK(c, hipMemcpyAsync(uprev.p, tmp.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
@@ -1380,8 +1423,10 @@ int fdapde_lin_compute(fdapde_ctx* c, int32_t which, const double* values, int32
         c->lin_symmetric = which == FDAPDE_MAT_MASS ? true : c->op_symmetric;
     }
     if (!c->lin_state) c->lin_state = new SolveStateHolder();
+    c->scaled_owner = fdapde_ctx::kScaledNone;
     if (int rc = solve_prepare(c, c->lin_mat.p, 0, &c->lin_state->ss)) return rc;
-    c->lin_ready = true, c->solved = false, c->lin_sq_ready = false;   // scale / sval now belong to the handle
+    c->scaled_owner = fdapde_ctx::kScaledLin;   // scale / sval now belong to the handle
+    c->lin_ready = true, c->lin_sq_ready = false;
     return FDAPDE_OK;
 }
 
@@ -1400,10 +1445,12 @@ int fdapde_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, 
     int method = opt ? opt->method : FDAPDE_SOLVER_AUTO;
     if (method == FDAPDE_SOLVER_AUTO)
         method = (c->lin_symmetric && c->lin_state->ss.diag_positive) ? FDAPDE_SOLVER_CG_FUSED : FDAPDE_SOLVER_BICGSTAB;
-    if (c->solved) {   // an fdapde_solve in between has overwritten the scaled copy: prepare again (cheap)
+    if (c->scaled_owner != fdapde_ctx::kScaledLin) {   // an elliptic / parabolic solve in between has overwritten scale and the scaled copy
+        c->scaled_owner = fdapde_ctx::kScaledNone;      // (whatever init / set_* calls followed it): prepare again (cheap)
         if (int rc = solve_prepare(c, c->lin_mat.p, 0, &c->lin_state->ss)) return rc;
-        c->solved = false, c->lin_sq_ready = false;
+        c->scaled_owner = fdapde_ctx::kScaledLin;
     }
+    c->solved = false;   // c->u is about to hold the handle's solutions, not PDE::solution()
     DBuf<double> rhs;
     HIPCHK(c, rhs.alloc((size_t)n));
     HIPCHK(c, hipEventRecord(c->ev0, st));
@@ -1659,7 +1706,7 @@ int fdapde_bench_spmv(fdapde_ctx* c, int32_t reps, double* avg_ms, double* algor
     HIPCHK(c, hipSetDevice(c->device));
     const HostSpace& hs = c->hs;
     // the launch timed here is the one inside CG: scaled matrix stream, fused p.Ap partials
-    const double* A = c->solved ? c->sval.p : c->vals[0].p;
+    const double* A = (c->solved && c->scaled_owner == fdapde_ctx::kScaledSolve) ? c->sval.p : c->vals[0].p;
     hipLaunchKernelGGL(k_fill_f64, dim3(g1(hs.n_dofs)), dim3(256), 0, c->stream, hs.n_dofs, 1.0, c->tmp_i.p);
     for (int i = 0; i < 3; ++i) launch_spmv(c, A, c->tmp_i.p, c->t.p, c->tmp_i.p, c->part_a.p, nullptr);
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -1790,7 +1837,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     drop_graph(c);
     if (k == "spmv_variant" && value >= 0 && value <= 2) c->spmv_variant = value;
     else if (k == "spmv_team" && (value == 2 || value == 4 || value == 8 || value == 16 || value == 32 || value == 64)) {
-        if (value != c->spmv_team) c->sp_built[0] = c->sp_built[1] = false, c->sp_cur = -1, c->solved = false;   // segmented patterns depend on it
+        if (value != c->spmv_team) c->sp_built[0] = c->sp_built[1] = false, c->sp_cur = -1, c->solved = false, c->scaled_owner = fdapde_ctx::kScaledNone;   // segmented patterns depend on it
         c->spmv_team = value;
     }
     else if (k == "spmv_unroll" && value >= 1 && value <= 8) c->spmv_unroll = value;
@@ -1804,6 +1851,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "cgf_nt" && value >= 0 && value <= 15) c->cgf_nt = value;
     else if (k == "cgf_lazy" && (value == 0 || value == 1)) c->cgf_lazy = value;
     else if (k == "multi_rhs" && (value == 0 || value == 1)) c->multi_rhs = value;
+    else if (k == "asm_fq_block" && (value == 0 || value == 1)) c->asm_fq_block = value;
     else if (k == "spmv_ntv" && value >= -1 && value <= 1) c->spmv_ntv = value;
     else if (k == "spmv_bpx" && value >= 1 && value <= 1024) {
         c->spmv_grid = 8 * value;

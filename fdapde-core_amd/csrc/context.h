@@ -149,6 +149,7 @@ struct fdapde_ctx {
     DBuf<int32_t> lane_row;   // assembly lane position -> row (unallocated = identity)
     DBuf<double> fq_blk;      // column 0 of the forcing as one load coefficient per visit slot (k_visit_load_coeffs); valid while fq_blk_ready
     bool fq_blk_ready = false;
+    int asm_fq_block = 1;     // tuning knob: 0 = the sweep gathers the cell's forcing samples itself (no coefficient kernel in init)
     DBuf<double> vcoords, vals[2], force, fq, g, sval, scale, gt, x, r, p, y, s, t, r0, u, part_a, part_b, sc, tmp_e,
       tmp_i, tmp_v;
     DBuf<uint8_t> bnd;
@@ -185,6 +186,10 @@ struct fdapde_ctx {
     int64_t sp_nnz[2] = {0, 0};
     bool sp_built[2] = {false, false};
     int sp_cur = -1;   // which compact pattern c->sval currently holds (-1: full pattern)
+    // whose system the shared scale / sval / sp_cur buffers hold (every solve_prepare caller records itself; the factor-once
+    // handle prepares again whenever anybody else has been there in between)
+    enum { kScaledNone = 0, kScaledSolve, kScaledParabolic, kScaledLin };
+    int scaled_owner = kScaledNone;
     // multi-GPU (element partition): RCCL communicator + interface maps
     ncclComm_t comm = nullptr;
     fdapde_allreduce_fn ar_fn = nullptr;     // host-staged transport (tests / non-RCCL fabrics) instead of the RCCL communicator

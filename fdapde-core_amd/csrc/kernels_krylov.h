@@ -14,15 +14,32 @@ namespace fdapde_hip {
 // ---------------------------------------------------------------------------------------------------------------
 // solve set-up kernels
 // ---------------------------------------------------------------------------------------------------------------
-// scale[i] = 0 on Dirichlet rows, 1/sqrt(|A_ii|) elsewhere; flag[0] |= 1 if some interior diagonal is <= 0
-__global__ void k_jacobi_scale(int64_t n, const int32_t* diag, const double* vals, const uint8_t* bnd, int use_bnd,
-                               double* scale, int32_t* flag) {
+// scale[i] = 0 on Dirichlet rows, 1/sqrt(|A_ii|) elsewhere; flag[0] |= 1 if some interior diagonal is <= 0.
+// A zero (or non-finite) interior diagonal -- pure advection on a symmetric patch, an arbitrary matrix handed to
+// fdapde_lin_compute -- leaves its row unscaled (scale 1) instead of dividing by zero: the flag then selects the full
+// pattern, whose stored diagonal is streamed as it is, and BiCGStab.
+__device__ __forceinline__ double jacobi_scale_of(double d) {
+    const double a = fabs(d);
+    return (a > 0.0 && a < 1.7976931348623157e308) ? 1.0 / sqrt(a) : 1.0;
+}
+// Single GPU: a diagonal that is tiny against its row (|d| <= 1e-8 max_j |a_ij|: rounding-level diagonals of pure advection,
+// where int psi_i b.grad psi_i vanishes over an interior patch) is treated like a zero one, and the row is scaled by its largest
+// entry instead, so that the scaled system stays O(1).
+__global__ void k_jacobi_scale(int64_t n, const int32_t* rowptr, const int32_t* diag, const double* vals, const uint8_t* bnd,
+                               int use_bnd, double* scale, int32_t* flag) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double d = vals[diag[i]];
     const bool b = use_bnd && bnd[i];
-    if (!b && !(d > 0.0)) atomicOr(flag, 1);
-    scale[i] = b ? 0.0 : 1.0 / sqrt(fabs(d));
+    if (b) {
+        scale[i] = 0.0;
+        return;
+    }
+    double rmax = 0.0;
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) rmax = fmax(rmax, fabs(vals[k]));
+    const bool tiny = !(fabs(d) > 1e-8 * rmax);
+    if (!(d > 0.0) || tiny) atomicOr(flag, 1);
+    scale[i] = jacobi_scale_of(tiny ? rmax : d);
 }
 // At = diag(scale) A diag(scale): symmetric Jacobi scaling == Jacobi preconditioning folded into the matrix stream.
 // Rows and columns of Dirichlet DOFs vanish (scale = 0), which restricts the Krylov iteration to the interior block.
@@ -739,7 +756,7 @@ __global__ void k_jacobi_scale_from_diag(int64_t n, const double* d, const uint8
     if (i >= n) return;
     const bool b = use_bnd && bnd[i];
     if (!b && !(d[i] > 0.0)) atomicOr(flag, 1);
-    scale[i] = b ? 0.0 : 1.0 / sqrt(fabs(d[i]));
+    scale[i] = b ? 0.0 : jacobi_scale_of(d[i]);
 }
 
 // u = scale * x + gt   (back to the unscaled unknowns, Dirichlet values restored)

@@ -1,0 +1,109 @@
+"""The BASELINE.json configurations other than the headline one, as callable single-GPU runs (bench.py's `extra` results, the
+full-size tests and tools/run_c2.py / run_c5.py share them).
+
+  C2: 2-D P1 Laplacian, 708^2 x 2 = 1 002 528 jittered / diagonal-flipped triangles, 502 681 DOFs, Jacobi-PCG
+  C5: 3-D P2 advection-diffusion-reaction  -Lap u + b.grad u + c u = f,  b = (1, 0.5, 0.25), c = 1, 87^3 x 6 = 3 951 018
+      tetrahedra, 5 359 375 DOFs, Jacobi-BiCGStab.  3-D P2 numbering is build-defined (the reference does not compile
+      LagrangianBasis<Triangulation<3,3>, 2>, lagrangian_basis.h:111-123): parity of C5 numbers is "unpinned" by construction.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+C5_B = np.array([1.0, 0.5, 0.25])
+C5_C = 1.0
+
+
+def c5_exact(x):
+    return np.prod(np.sin(np.pi * x), axis=1)
+
+
+def c5_forcing(x):
+    pi = np.pi
+    s_, c_ = np.sin(pi * x), np.cos(pi * x)
+    u = np.prod(s_, axis=1)
+    grad = np.stack([pi * c_[:, 0] * s_[:, 1] * s_[:, 2], pi * s_[:, 0] * c_[:, 1] * s_[:, 2], pi * s_[:, 0] * s_[:, 1] * c_[:, 2]], axis=1)
+    return 3 * pi**2 * u + grad @ C5_B + C5_C * u
+
+
+def c5_operator(capi):
+    return -capi.laplacian() + capi.advection(C5_B) + capi.reaction(C5_C)
+
+
+def _timed_steps(ctx, steps, warmup, time_spmv, rtol):
+    for _ in range(warmup):
+        ctx.init()
+        ctx.solve(rtol=rtol)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    infos = []
+    for _ in range(steps):
+        ctx.init()
+        infos.append(ctx.solve(rtol=rtol, time_spmv=time_spmv))
+    ctx.synchronize()
+    return (time.perf_counter() - t0) / steps, infos
+
+
+def _summary(ctx, nd, wall, infos, u_exact, hbm_peak_gbps):
+    info = infos[-1]
+    s = ctx.sizes()
+    alg = 12.0 * s["nnz"] + 4.0 * (nd + 1) + 16.0 * nd
+    ni, nzi, streamed = ctx.solver_layout(True)
+    alg_int = 12.0 * nzi + 4.0 * (ni + 1) + 16.0 * ni
+    spmv_ms = float(np.mean([i.spmv_avg_ms for i in infos]))
+    _, _, coords = ctx.dofs_get()
+    err = float(np.abs(ctx.solution() - u_exact(coords)).max())
+    gbps = alg / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
+    return {
+        "dofs": int(nd), "nnz": int(s["nnz"]), "dof_per_s": nd / wall, "ms_per_step": 1e3 * wall,
+        "t_assemble_ms": float(np.mean([i.t_assemble_ms for i in infos])), "t_solve_ms": float(np.mean([i.t_solve_ms for i in infos])),
+        "iterations": int(info.iters), "us_per_iteration": 1e3 * float(info.t_solve_ms) / max(int(info.iters), 1),
+        "method": int(info.method_used), "relres": float(info.relres), "max_abs_error_vs_analytic": err,
+        "spmv_avg_us": 1e3 * spmv_ms, "spmv_timed": int(info.spmv_timed),
+        "spmv_algorithmic_bytes": alg, "spmv_gbps": gbps, "spmv_frac_of_peak": gbps / hbm_peak_gbps,
+        "spmv_algorithmic_bytes_interior": alg_int, "spmv_streamed_bytes": streamed,
+    }
+
+
+def run_c2(capi, meshgen, nx=708, steps=2, warmup=1, time_spmv=32, rtol=1e-10, device=0, hbm_peak_gbps=8000.0):
+    nodes, cells, bnd = meshgen.unit_square(nx)
+    u_exact, f = meshgen.manufactured(2)
+    ctx = capi.Context(device)
+    t0 = time.perf_counter()
+    ctx.mesh_upload(nodes, cells, bnd)
+    nd = ctx.dofs_build(1)
+    ctx.solver_prepare(True)
+    t_setup = time.perf_counter() - t0
+    ctx.set_operator(-capi.laplacian())
+    ctx.set_forcing(f(ctx.quadrature_nodes()))
+    ctx.set_dirichlet(np.zeros(nd))
+    wall, infos = _timed_steps(ctx, steps, warmup, time_spmv, rtol)
+    out = _summary(ctx, nd, wall, infos, u_exact, hbm_peak_gbps)
+    out.update(workload=f"C2: 2-D P1 Laplacian, {nx}^2 x 2 = {cells.shape[0]} triangles, jitter 0.2h, diagonals flipped, ids permuted",
+               cells=int(cells.shape[0]), t_setup_s=t_setup)
+    ctx.close()
+    return out
+
+
+def run_c5(capi, meshgen, nx=87, steps=1, warmup=1, time_spmv=16, rtol=1e-10, device=0, hbm_peak_gbps=8000.0):
+    nodes, cells, bnd = meshgen.unit_cube(nx)
+    ctx = capi.Context(device)
+    t0 = time.perf_counter()
+    ctx.mesh_upload(nodes, cells, bnd)
+    nd = ctx.dofs_build(2)
+    ctx.solver_prepare(True)
+    t_setup = time.perf_counter() - t0
+    n_cells = int(cells.shape[0])
+    del nodes, cells
+    ctx.set_operator(c5_operator(capi))
+    ctx.set_forcing(c5_forcing(ctx.quadrature_nodes()))
+    ctx.set_dirichlet(np.zeros(nd))
+    wall, infos = _timed_steps(ctx, steps, warmup, time_spmv, rtol)
+    out = _summary(ctx, nd, wall, infos, c5_exact, hbm_peak_gbps)
+    out.update(workload=f"C5: 3-D P2 advection-diffusion-reaction, {nx}^3 x 6 = {n_cells} tetrahedra, b = (1, 0.5, 0.25), c = 1, "
+                        "Jacobi-BiCGStab; 3-D P2 numbering build-defined (parity unpinned)",
+               cells=n_cells, t_setup_s=t_setup)
+    ctx.close()
+    return out

@@ -3,12 +3,13 @@
 //   lump(A)              row-sum lumping                    fdaPDE/linear_algebra/lumping.h:30-51
 //   PartialPivLU         small dense LU (q x q)             stands in for Eigen::PartialPivLU<DMatrix<double>>
 //   SMW<SparseSolver>    Sherman-Morrison-Woodbury solve    fdaPDE/linear_algebra/smw.h:38-59
-// The heavy step of SMW, Y = A^{-1} U (q right-hand sides against one prepared sparse system), runs on the device through
-// the factor-once handle (PDE::SparseSolver -> fdapde_lin_compute / fdapde_lin_solve); everything dense is q x q or n x q
-// host work, exactly as in the reference.
+// The heavy step of SMW, A^{-1} [b | U] (1 + q right-hand sides against one prepared sparse system), runs on the device as ONE
+// batched multi-column solve through the factor-once handle (PDE::SparseSolver -> fdapde_lin_compute / fdapde_lin_solve);
+// everything dense is q x q or n x q host work.
 #ifndef FDAPDE_AMD_LINEAR_ALGEBRA_H
 #define FDAPDE_AMD_LINEAR_ALGEBRA_H
 
+#include <algorithm>
 #include <cmath>
 #include <stdexcept>
 #include <utility>
@@ -106,20 +107,48 @@ class PartialPivLU {
     std::vector<int64_t> piv_;
 };
 
-// ---- Sherman-Morrison-Woodbury (smw.h:38-59) ---------------------------------------------------------------------------
-//   (A + U C V)^{-1} = A^{-1} - A^{-1} U (C^{-1} + V A^{-1} U)^{-1} V A^{-1};   invC = C^{-1} is supplied, as in the reference
+// ---- Sherman-Morrison-Woodbury (same call signature as fdaPDE/linear_algebra/smw.h:38-59) -----------------------------
+//   (A + U C V) x = b,  invC = C^{-1} supplied:   x = W_b - W_U (C^{-1} + V W_U)^{-1} (V W_b),   [W_b | W_U] = A^{-1} [b | U]
+// ONE pass through the sparse solver: the m columns of b and the q columns of U go to the device as one (m + q)-column
+// right-hand side, so that they share every sweep over the matrix (fdapde_lin_solve batches 8 / 4 columns per multi-RHS CG,
+// kernels_multirhs.h).  The correction A^{-1} U t of the formula is W_U t -- a dense n x q by q x m product on data already
+// there, not another sparse solve (the reference performs three separate solves: b, U, and U t).
 template <typename SparseSolver, typename DenseSolver = PartialPivLU> struct SMW {
     SMW() = default;
     DMatrix<double> solve(const SparseSolver& invA, const DMatrix<double>& U, const DMatrix<double>& invC, const DMatrix<double>& V,
                           const DMatrix<double>& b) {
-        DMatrix<double> y = invA.solve(b);   // y = A^{-1} b
-        DMatrix<double> Y = invA.solve(U);   // Y = A^{-1} U: q Krylov solves against the system prepared once (the heavy step)
-        DMatrix<double> G = invC + V * Y;    // q x q
-        DenseSolver invG;
-        invG.compute(G);
-        DMatrix<double> t = invG.solve(V * y);
-        DMatrix<double> v = invA.solve(U * t);   // A v = U t
-        return y - v;
+        const int64_t n = b.rows(), m = b.cols(), q = U.cols();
+        if (U.rows() != n || V.cols() != n || V.rows() != q || invC.rows() != q || invC.cols() != q)
+            throw std::runtime_error("SMW: shapes of U, C^{-1}, V, b do not fit");
+        DMatrix<double> rhs(n, m + q);
+        std::copy(b.data(), b.data() + n * m, rhs.data());
+        std::copy(U.data(), U.data() + n * q, rhs.data() + n * m);
+        const DMatrix<double> W = invA.solve(rhs);                 // the only sparse solve: n x (m + q)
+        // small dense part: S = C^{-1} + V W_U (q x q),  z = V W_b (q x m)
+        DMatrix<double> S = invC, z(q, m, 0.0);
+        for (int64_t c = 0; c < q + m; ++c) {
+            const double* w = W.data() + n * c;                    // column c of W: first the m columns of b, then U's
+            for (int64_t r = 0; r < q; ++r) {
+                double acc = 0;
+                for (int64_t i = 0; i < n; ++i) acc += V(r, i) * w[i];
+                if (c < m) z(r, c) = acc;
+                else S(r, c - m) += acc;
+            }
+        }
+        DenseSolver dense;
+        dense.compute(S);
+        const DMatrix<double> t = dense.solve(z);                  // q x m
+        DMatrix<double> x(n, m);
+        for (int64_t c = 0; c < m; ++c) {
+            double* xc = x.data() + n * c;
+            std::copy(W.data() + n * c, W.data() + n * (c + 1), xc);
+            for (int64_t k = 0; k < q; ++k) {
+                const double tk = t(k, c);
+                const double* wu = W.data() + n * (m + k);
+                for (int64_t i = 0; i < n; ++i) xc[i] -= wu[i] * tk;
+            }
+        }
+        return x;
     }
 };
 

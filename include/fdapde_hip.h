@@ -183,6 +183,11 @@ int fdapde_spmv(fdapde_ctx *ctx, int32_t which, const double *x, double *y);
  * returns the average kernel duration in ms and the algorithmic bytes per launch
  * (12*nnz + 4*(n+1) + 16*n) */
 int fdapde_bench_spmv(fdapde_ctx *ctx, int32_t reps, double *avg_ms, double *algorithmic_bytes);
+/* the operator the in-solve SpMV applies, for the roofline figures: rows and entries of the interior block A_II (the reference's
+ * set_dirichlet_bc leaves those rows active, fem_solver_base.h:142-155) seen as a plain CSR matrix, and the bytes one launch of
+ * the solver's kernel streams from its compact coded layout.  Builds the layout if fdapde_solver_prepare has not. */
+int fdapde_solver_layout(fdapde_ctx *ctx, int32_t with_dirichlet, int64_t *n_interior, int64_t *nnz_interior,
+                         double *streamed_bytes);
 /* ---- multi-GPU: element-partitioned meshes, one context (= one rank) per GPU --------------------------------------------
  * No reference counterpart (the reference is single-threaded, single address space).  Each rank uploads the sub-mesh of
  * its own cells (local node numbering), assembles its sub-assembled operator with the calls above, and the solve sums the

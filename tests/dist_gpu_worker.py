@@ -2,7 +2,9 @@
 distributed path (sub-assembly, interface pack / all-reduce / unpack, owner-masked dots, stop decisions) is the product's;
 only the all-reduce transport is swapped for a host-staged torch.distributed/gloo callback, because RCCL refuses two ranks on
 one device.  Results are compared with a single-domain run of the whole mesh on the same GPU.
-cases: p1 | p2 | sq2 (2-D P2: interface edges must not become Dirichlet) | adr1 | adr2 (BiCGStab) | parab | handle"""
+cases: p1 | p2 | sq2 (2-D P2: interface edges must not become Dirichlet) | adr1 | adr2 (BiCGStab) | parab | handle
+transport (argv[6]): "shared" (default: all ranks on GPU 0, host-staged gloo all-reduce) | "rccl" (rank r on GPU r, the library's
+own RCCL communicator over xGMI -- the product configuration; needs >= world GPUs)"""
 import os
 import sys
 
@@ -15,6 +17,8 @@ sys.path.insert(0, ROOT)
 def main():
     rank, world, port, nx = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
     case = sys.argv[5] if len(sys.argv) > 5 else "p1"
+    transport = sys.argv[6] if len(sys.argv) > 6 else "shared"
+    dev_id = rank if transport == "rccl" else 0
     import torch
     import torch.distributed as dist
 
@@ -42,16 +46,21 @@ def main():
         t = torch.from_numpy(arr)
         dist.all_reduce(t)
 
-    ctx = capi.Context(device=0)
+    ctx = capi.Context(device=dev_id)
     ctx.mesh_upload(sub["nodes"], sub["cells"], sub["boundary"])
     n_loc = ctx.dofs_build(order)
     table, _, lcoords = ctx.dofs_get()
     maps = fdist.interface_maps(sub, table, info_if, rank, n_g, order)
     ctx.dofs_set_boundary(maps["boundary_dofs"])
-    ctx.comm_init_callback(world, rank, allreduce)
+    if transport == "rccl":   # the 128-byte RCCL id travels over the gloo group; the data path is RCCL only
+        uid = [capi.Context.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(world, rank, uid[0])
+    else:
+        ctx.comm_init_callback(world, rank, allreduce)
     ctx.halo_setup(maps["n_if_global"], maps["local_dof"], maps["if_index"], maps["owned"])
     # single-domain context of the whole mesh (every rank builds it; same GPU)
-    ref = capi.Context(device=0)
+    ref = capi.Context(device=dev_id)
     ref.mesh_upload(nodes, cells, bnd)
     ref.dofs_build(order)
     gtable, gbnd, gcoords = ref.dofs_get()
@@ -104,6 +113,7 @@ def main():
         else:
             assert abs(info.iters - rinfo.iters) <= max(2, rinfo.iters // 50), (info.iters, rinfo.iters)   # same Krylov iteration up to rounding
         msg = f"iters {info.iters} (single domain {rinfo.iters})"
+    dist.barrier()   # nobody tears its communicator down while a peer is still inside a collective
     print(f"rank {rank}: ok  case {case}  local dofs {n_loc}  interface {maps['local_dof'].size}/{maps['n_if_global']}  {msg}  err {err:.2e}")
     dist.destroy_process_group()
 

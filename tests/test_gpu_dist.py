@@ -1,5 +1,11 @@
-"""Two ranks sharing one GPU: the device-side element-partitioned solve end to end with a host-staged gloo all-reduce in
-place of RCCL (which cannot put two ranks on one device).  See tests/dist_gpu_worker.py."""
+"""The device-side element-partitioned solve end to end, against the single-domain solve of the same mesh.
+  * ranks sharing one GPU, a host-staged gloo all-reduce in place of RCCL (which cannot put two ranks on one device): runs on
+    every GPU box;
+  * one rank per GPU over the library's own RCCL communicator (the product configuration, BASELINE config C4's transport): runs
+    whenever the box has >= 2 GPUs, skipped otherwise;
+  * bench.py --gpus 2 under torch.distributed.run, exactly as the driver launches it (>= 2 GPUs).
+See tests/dist_gpu_worker.py."""
+import json
 import os
 import socket
 import subprocess
@@ -11,15 +17,23 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,nx,case", [(2, 12, "p1"), (3, 10, "p1"), (2, 8, "p2"), (3, 20, "sq2"), (2, 10, "adr1"), (3, 7, "adr2"),
-                                           (2, 9, "parab"), (2, 9, "handle")])
-def test_partitioned_device_solve_matches_single_domain(world, nx, case):
+def _n_gpus():
+    import torch
+
+    return torch.cuda.device_count()   # counting devices does not initialise the GPU in this process
+
+
+def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
-        port = str(s.getsockname()[1])
+        return str(s.getsockname()[1])
+
+
+def _run_ranks(world, nx, case, transport):
+    port = _free_port()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(r), str(world), port, str(nx), case],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(r), str(world), port, str(nx), case,
+                               transport], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(world)]
     outs = []
     for p in procs:
         try:
@@ -32,3 +46,36 @@ def test_partitioned_device_solve_matches_single_domain(world, nx, case):
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{out}"
         assert f"rank {r}: ok" in out
+
+
+@pytest.mark.parametrize("world,nx,case", [(2, 12, "p1"), (3, 10, "p1"), (2, 8, "p2"), (3, 20, "sq2"), (2, 10, "adr1"), (3, 7, "adr2"),
+                                           (2, 9, "parab"), (2, 9, "handle")])
+def test_partitioned_device_solve_matches_single_domain(world, nx, case):
+    _run_ranks(world, nx, case, "shared")
+
+
+@pytest.mark.parametrize("world,nx,case", [(2, 24, "p1"), (2, 8, "p2"), (2, 10, "adr1"), (2, 9, "parab"), (2, 9, "handle"), (4, 24, "p1"),
+                                           (8, 30, "p1"), (8, 9, "adr2")])
+def test_partitioned_solve_over_real_rccl(world, nx, case):
+    """One rank per GPU, the library's RCCL communicator (ncclAllReduce over xGMI) -- BASELINE config C4's transport.  Solution and
+    iteration count against the single-domain run <= 1e-8 (asserted in the worker)."""
+    if _n_gpus() < world:
+        pytest.skip(f"needs {world} GPUs, this box has {_n_gpus()}")
+    _run_ranks(world, nx, case, "rccl")
+
+
+@pytest.mark.parametrize("gpus", [2, 8])
+def test_bench_multi_gpu_leg_as_the_driver_launches_it(gpus):
+    """python -m torch.distributed.run --nproc-per-node N bench.py --gpus N on a reduced mesh: one JSON line, converged, the
+    analytic error at the level of the single-GPU run (the partitioned solve is the same Krylov iteration)."""
+    if _n_gpus() < gpus:
+        pytest.skip(f"needs {gpus} GPUs, this box has {_n_gpus()}")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--nx", "48"]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == gpus and rec["scaling"] == "strong" and rec["value"] > 0
+    assert rec["config"]["relres"] <= 1e-10 and rec["config"]["max_abs_error_vs_analytic"] < 6.0 * (1.0 / 48) ** 2 * 3.15**2

@@ -60,6 +60,60 @@ def test_above_two_million_rows(env):
     ctx.close()
 
 
+def test_c5_fullsize(env):
+    """BASELINE config C5 at full size on one GPU: 3-D P2 advection-diffusion-reaction, 87^3 x 6 = 3 951 018 tetrahedra,
+    5 359 375 DOFs, Jacobi-BiCGStab.  3-D P2 numbering is build-defined (the reference does not compile it): what is checked here
+    is numbering-independent -- partition of unity, the true residual on the exported matrix, second-order accuracy against the
+    manufactured solution (the 5-point rule has degree of precision 3, integrator_tables.h:274, so O(h^2) is the reference's own
+    order for this load vector), bitwise-repeatable assembly."""
+    import scipy.sparse as sp
+
+    capi, meshgen = env
+    from fdapde_core_amd import workloads
+
+    nx = 87
+    nodes, cells, bnd = meshgen.unit_cube(nx)
+    assert cells.shape[0] == 3951018
+    ctx = capi.Context(device=0)
+    ctx.mesh_upload(nodes, cells, bnd)
+    nd = ctx.dofs_build(2)
+    del nodes, cells
+    assert nd == 88**3 + ctx.sizes()["n_edges"] and nd > 5_300_000
+    _, bdofs, coords = ctx.dofs_get()
+    qn = ctx.quadrature_nodes()
+    ctx.set_operator(workloads.c5_operator(capi))
+    ctx.set_forcing(np.ones(qn.shape[0]))
+    ctx.init()
+    rp, ci = ctx.pattern_get()
+    mvals = ctx.matrix_values(capi.MAT_MASS)
+    assert abs(mvals.sum() - 1.0) < 1e-10                                 # 1^T M 1 = |Omega|
+    assert abs(ctx.force().sum() - 1.0) < 1e-10
+    a0 = ctx.matrix_values(capi.MAT_STIFF)
+    # row sums of the operator: Laplacian and advection annihilate constants, the reaction term leaves c * M 1
+    A = sp.csr_matrix((a0, ci, rp), shape=(nd, nd))
+    M = sp.csr_matrix((mvals, ci, rp), shape=(nd, nd))
+    ones = np.ones(nd)
+    assert np.abs(A @ ones - workloads.C5_C * (M @ ones)).max() <= 1e-11 * np.abs(a0).max()
+    del M, mvals
+    ctx.init()
+    assert np.array_equal(ctx.matrix_values(capi.MAT_STIFF), a0)         # bitwise-repeatable assembly
+    del A, a0
+    ctx.set_forcing(workloads.c5_forcing(qn))
+    del qn
+    ctx.set_dirichlet(np.zeros(nd))
+    ctx.init()
+    info = ctx.solve(rtol=1e-10)
+    assert info.converged == 1 and info.method_used == capi.SOLVER_BICGSTAB and info.relres <= 1e-10
+    u = ctx.solution()
+    err = np.abs(u - workloads.c5_exact(coords)).max()
+    assert err < 1.0 * (1.0 / nx) ** 2 * np.pi**2                         # O(h^2): 1.3e-3 bound, 3.3e-4 observed
+    Az = sp.csr_matrix((ctx.matrix_values(capi.MAT_STIFF), ci, rp), shape=(nd, nd))   # row-zeroed, unit diagonal on the boundary
+    b = ctx.force()
+    assert np.linalg.norm(Az @ u - b) <= 1e-8 * np.linalg.norm(b)
+    assert np.all(u[bdofs.astype(bool)] == 0.0)
+    ctx.close()
+
+
 @pytest.mark.parametrize("config", ["C2", "C3", "P2_3D"])
 def test_fullsize_properties(env, config):
     capi, meshgen = env

@@ -546,6 +546,7 @@ int fdapde_ctx_create(int device, fdapde_ctx** out) {
             return FDAPDE_EHIP;
         }
         c->device = device, c->has_device = true;
+        if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) c->n_cu = 0;
     }
     *out = c;
     return FDAPDE_OK;
@@ -570,7 +571,10 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
         c->halo_dof.release(), c->halo_pos.release(), c->owned.release(), c->hbuf.release(), c->sbuf.release();
         c->halo_inv.release(), c->if_slot.release();
         if (c->comm) (void)g_rccl.CommDestroy(c->comm);
-        c->lin_mat.release();
+        c->lin_mat.release(), c->persist_stats.release();
+        for (auto& ps : c->ps)
+            ps.slot_dof.release(), ps.sl_off.release(), ps.q_int.release(), ps.ell_src.release(), ps.exp_off.release(), ps.imp_off.release(),
+              ps.imp_pos.release(), ps.ell_off.release(), ps.ell_code.release(), ps.exp_slot.release(), ps.ell_val.release(), ps.board.release();
         for (int v = 0; v < 2; ++v)
             c->sp_rowptr[v].release(), c->sp_colidx[v].release(), c->sp_map[v].release(), c->sp_tbase[v].release(), c->sp_col16[v].release(),
               c->sp_vrow[v].release();
@@ -603,6 +607,7 @@ int fdapde_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs) {
     c->op.clear(), c->coef_of_op = false, c->fq_i.clear(), c->fq_cols = 0, c->g_i.clear(), c->have_g = false;
     c->halo_ready = false, c->lin_ready = false, c->sp_built[0] = c->sp_built[1] = false, c->sp_cur = -1;
     c->scaled_owner = fdapde_ctx::kScaledNone;
+    c->ps[0].tried = c->ps[0].ok = c->ps[1].tried = c->ps[1].ok = false;
     drop_graph(c);
     int rc = host_build_space(c->hs, order, c->err);
     if (rc) return rc;
@@ -637,6 +642,7 @@ int fdapde_dofs_set_boundary(fdapde_ctx* c, const uint8_t* bnd) {
     for (int64_t i = 0; i < hs.n_dofs; ++i) hs.dof_bnd[(size_t)i] = bnd[i] ? 1 : 0;
     for (int64_t i = 0; i < hs.n_dofs; ++i) hs.dof_bnd_i[(size_t)i] = hs.dof_bnd[(size_t)hs.dof_i2e[(size_t)i]];
     c->sp_built[1] = false;   // the compact solver pattern drops Dirichlet rows / columns
+    c->ps[1].tried = c->ps[1].ok = false;
     drop_graph(c);
     c->solved = false, c->scaled_owner = fdapde_ctx::kScaledNone;
     if (c->dev_ready) {
@@ -885,6 +891,99 @@ int build_solver_pattern(fdapde_ctx* c, int v) {
     return FDAPDE_OK;
 }
 
+// resident layout of the persistent CG for boundary variant v (kernels_persist.h): host index work + uploads, once per function
+// space and boundary mask.  ok stays false when the system does not qualify (too many rows for one launch of resident
+// workgroups, or more matrix than is worth re-reading from the caches every iteration).
+int build_persist(fdapde_ctx* c, int v) {
+    fdapde_ctx::Persist& ps = c->ps[v];
+    if (ps.tried) return FDAPDE_OK;
+    ps.tried = true, ps.ok = false;
+    if (c->n_cu < 1) return FDAPDE_OK;
+    PersistLayout pl;
+    const int rc = host_build_persist_layout(c->hs, v == 1, c->n_cu, 12000, pl);   // ~12 000 ELL entries (120 KB) next to the vectors of <= 4096 rows
+    if (rc == FDAPDE_EUNSUPPORTED) return FDAPDE_OK;
+    if (rc) return rc;
+    double max_mb = 96.0;   // ELL bytes (10 per entry) one iteration may re-read: what does not fit the LDS comes from the L2s / Infinity Cache
+    if (const char* e = std::getenv("FDAPDE_PERSIST_MAX_MB")) max_mb = std::atof(e);
+    if (10.0 * (double)pl.n_entries > max_mb * 1e6) return FDAPDE_OK;
+    const int S = pl.R * kPersistT;
+    const int imp_cap = (pl.max_imp + 63) & ~63, exp_cap = (pl.max_exp + 63) & ~63;
+    const size_t lds_total = 160 * 1024 - 1024;   // static arrays of the kernel + slack
+    const size_t fixed = 8 * (size_t)(S + imp_cap) + 4 * (size_t)(pl.nsl + 1) + 4 * (size_t)imp_cap + 2 * (size_t)exp_cap + 64;
+    if (fixed + 10 * 64 > lds_total) return FDAPDE_OK;
+    int64_t cap = (int64_t)((lds_total - fixed) / 10) & ~int64_t(63);
+    int64_t need = 0;   // largest workgroup block: no point in reserving more
+    for (int g = 0; g < pl.G; ++g) need = std::max<int64_t>(need, pl.ell_off[(size_t)g + 1] - pl.ell_off[(size_t)g]);
+    if (cap > need) cap = need > 64 ? need : 64;
+    ps.lds_cap = (int32_t)cap, ps.imp_cap = imp_cap;
+    ps.lds_bytes = fixed + 10 * (size_t)cap;
+    hipStream_t st = c->stream;
+    HIPCHK(c, ps.slot_dof.upload(pl.slot_dof.data(), pl.slot_dof.size(), st));
+    HIPCHK(c, ps.ell_off.upload(pl.ell_off.data(), pl.ell_off.size(), st));
+    HIPCHK(c, ps.sl_off.upload(pl.sl_off.data(), pl.sl_off.size(), st));
+    HIPCHK(c, ps.q_int.upload(pl.q_int.data(), pl.q_int.size(), st));
+    HIPCHK(c, ps.ell_code.upload(pl.ell_code.data(), pl.ell_code.size(), st));
+    HIPCHK(c, ps.ell_src.upload(pl.ell_src.data(), pl.ell_src.size(), st));
+    HIPCHK(c, ps.exp_off.upload(pl.exp_off.data(), pl.exp_off.size(), st));
+    HIPCHK(c, ps.exp_slot.upload(pl.exp_slot.data(), pl.exp_slot.size(), st));
+    HIPCHK(c, ps.imp_off.upload(pl.imp_off.data(), pl.imp_off.size(), st));
+    HIPCHK(c, ps.imp_pos.upload(pl.imp_pos.data(), pl.imp_pos.size(), st));
+    HIPCHK(c, ps.ell_val.alloc((size_t)pl.n_entries));
+    HIPCHK(c, ps.board.alloc(2 * (size_t)pl.n_board + 2 * (size_t)pl.G * 6 + 2));   // p entries | dot partials x 2 parities
+    HIPCHK(c, c->persist_stats.alloc(8));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (std::getenv("FDAPDE_DEBUG_SETUP"))
+        std::fprintf(stderr, "persistent CG layout %d: %d workgroups x %d rows/thread, %lld interior rows, %lld entries (%lld stored, %.1f %% padding), "
+                     "LDS %zu B (%d entries resident, largest block %lld), imports <= %d, exports <= %d, board %lld\n", v, pl.G, pl.R,
+                     (long long)pl.n_int, (long long)pl.n_entries, (long long)pl.nnz,
+                     100.0 * (double)(pl.n_entries - pl.nnz) / (double)(pl.n_entries > 0 ? pl.n_entries : 1), ps.lds_bytes, ps.lds_cap,
+                     (long long)need, pl.max_imp, pl.max_exp, (long long)pl.n_board);
+    // keep the sizes, drop the big host arrays
+    pl.slot_dof = {}, pl.ell_code = {}, pl.ell_src = {}, pl.exp_slot = {}, pl.imp_pos = {}, pl.sl_off = {};
+    ps.meta = std::move(pl);
+    ps.filled = false, ps.ok = true;
+    return FDAPDE_OK;
+}
+
+// the whole fused-update CG as one launch; returns FDAPDE_OK with *ran = false when the launch gave up (hand-off timeout)
+int run_persist(fdapde_ctx* c, int v, double tol2, int maxit, bool* ran) {
+    fdapde_ctx::Persist& ps = c->ps[v];
+    hipStream_t st = c->stream;
+    PersistArgs a{};
+    a.G = ps.meta.G, a.nsl = ps.meta.nsl, a.maxit = maxit, a.imp_cap = ps.imp_cap, a.lds_cap = ps.lds_cap, a.time_phases = c->persist_time;
+    a.tol2 = tol2;
+    a.slot_dof = ps.slot_dof.p, a.ell_off = ps.ell_off.p, a.sl_off = ps.sl_off.p, a.q_int = ps.q_int.p, a.ell_code = ps.ell_code.p;
+    a.ell_val = ps.ell_val.p, a.exp_off = ps.exp_off.p, a.exp_slot = ps.exp_slot.p, a.imp_off = ps.imp_off.p, a.imp_pos = ps.imp_pos.p;
+    a.pboard = ps.board.p, a.dboard = ps.board.p + 2 * (size_t)ps.meta.n_board;
+    a.r_in = c->r.p, a.x = c->x.p, a.sc = c->sc.p, a.ctl = c->ctl.p, a.stats = c->persist_stats.p;
+    HIPCHK(c, hipMemsetAsync(ps.board.p, 0, sizeof(unsigned long long) * ps.board.n, st));   // every tag 0: no epoch of this launch
+    HIPCHK(c, hipMemsetAsync(c->persist_stats.p, 0, 8 * sizeof(double), st));
+#define PERSIST_GO(R_)                                                                                                          \
+    do {                                                                                                                        \
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cg_persist<R_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)ps.lds_bytes));                                                                      \
+        hipLaunchKernelGGL(k_cg_persist<R_>, dim3(a.G), dim3(kPersistT), ps.lds_bytes, st, a);                                  \
+    } while (0)
+    switch (ps.meta.R) {
+    case 1: PERSIST_GO(1); break;
+    case 2: PERSIST_GO(2); break;
+    case 4: PERSIST_GO(4); break;
+    default: PERSIST_GO(8); break;
+    }
+#undef PERSIST_GO
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(c->h_sc, c->sc.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(c->h_sc + 8, c->persist_stats.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    *ran = c->h_ctl[3] == 0;
+    if (!*ran) {   // a peer workgroup was not resident (other work on the device?): nothing was written; never try again on this context
+        c->persist_broken = true;
+        HIPCHK(c, hipMemsetAsync(c->ctl.p + 3, 0, sizeof(int32_t), st));
+    }
+    return FDAPDE_OK;
+}
+
 // Dirichlet reduction + Jacobi scaling of the system matrix A (internal slots): scale, sval = diag(s) A diag(s).
 // Done once per matrix (per solve for the elliptic problem, once for all time steps of the parabolic one).
 int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss) {
@@ -932,6 +1031,19 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss) {
         c->sp_cur = -1, c->sval_layout = -2;
     }
     HIPCHK(c, hipGetLastError());
+    // small symmetric positive system on one GPU: also as the resident layout of the single-launch CG
+    c->ps[0].filled = c->ps[1].filled = false;
+    if (ss->diag_positive && !ss->dist && c->persist && !c->persist_broken && c->spmv_variant == 2) {
+        const int v = use_bnd ? 1 : 0;
+        if (int rc = build_persist(c, v)) return rc;
+        if (c->ps[v].ok) {
+            hipLaunchKernelGGL(k_scale_matrix, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, A, c->scale.p, c->tmp_v.p);
+            hipLaunchKernelGGL(k_persist_fill, dim3(g1(c->ps[v].meta.n_entries)), dim3(256), 0, st, c->ps[v].meta.n_entries,
+                               c->ps[v].ell_src.p, c->tmp_v.p, c->ps[v].ell_val.p);
+            HIPCHK(c, hipGetLastError());
+            c->ps[v].filled = true;
+        }
+    }
     return FDAPDE_OK;
 }
 
@@ -1007,6 +1119,12 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     }
     int timed = 0, launched = 0;
     bool stop = false;
+    bool persisted = false;
+    if (cgf && !dist && c->persist && !c->persist_broken && c->ps[ss.use_bnd ? 1 : 0].ok && c->ps[ss.use_bnd ? 1 : 0].filled) {
+        // the whole iteration as ONE launch (kernels_persist.h); it leaves sc / ctl as the loop below would
+        if (int rc = run_persist(c, ss.use_bnd ? 1 : 0, tol2, maxit, &persisted)) return rc;
+        if (persisted) stop = true, launched = c->h_ctl[1];
+    }
     // one iteration of the fused-update CG: SpMV (p.y, y.y) + k_cgf_update; arguments depend on the iteration's parity only
     const int cgf_V = c->cgf_v;
     // XCD-aware mapping of the update kernel (knob cgf_band): workgroup b serves the elements of SpMV row band b % 8
@@ -1157,7 +1275,7 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
         HIPCHK(c, hipStreamSynchronize(st));
         stop = c->h_ctl[0] != 0;
     }
-    if (launched == 0) {   // already converged at the initial guess
+    if (launched == 0 && !persisted) {   // already converged at the initial guess
         HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipMemcpyAsync(c->h_sc, c->sc.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
@@ -1183,6 +1301,11 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
             sum += t;
         }
         if (real > 0) c->info.spmv_avg_ms = sum / real, c->info.spmv_timed = real;
+    }
+    c->info.persistent = persisted ? 1 : 0;
+    if (persisted && c->h_sc[8] > 0) {   // phase stamps of workgroup 0 (s_memrealtime ticks of 10 ns): the operator application = SpMV + import wait
+        c->info.spmv_avg_ms = c->h_sc[9] / c->h_sc[8] * 1e-5, c->info.spmv_timed = (int32_t)c->h_sc[8];
+        c->info.gather_avg_ms = c->h_sc[10] / c->h_sc[8] * 1e-5, c->info.update_avg_ms = c->h_sc[11] / c->h_sc[8] * 1e-5;
     }
     if (!c->info.converged) {
         c->err = c->h_ctl[2] ? "Krylov breakdown (operator not SPD for CG, or BiCGStab rho/omega = 0)" : "maxit reached";
@@ -1852,6 +1975,8 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "cgf_lazy" && (value == 0 || value == 1)) c->cgf_lazy = value;
     else if (k == "multi_rhs" && (value == 0 || value == 1)) c->multi_rhs = value;
     else if (k == "asm_fq_block" && (value == 0 || value == 1)) c->asm_fq_block = value;
+    else if (k == "persist" && (value == 0 || value == 1)) c->persist = value, c->persist_broken = false;
+    else if (k == "persist_time" && (value == 0 || value == 1)) c->persist_time = value;
     else if (k == "spmv_ntv" && value >= -1 && value <= 1) c->spmv_ntv = value;
     else if (k == "spmv_bpx" && value >= 1 && value <= 1024) {
         c->spmv_grid = 8 * value;

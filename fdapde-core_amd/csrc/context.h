@@ -149,7 +149,9 @@ struct fdapde_ctx {
     DBuf<int32_t> lane_row;   // assembly lane position -> row (unallocated = identity)
     DBuf<double> fq_blk;      // column 0 of the forcing as one load coefficient per visit slot (k_visit_load_coeffs); valid while fq_blk_ready
     bool fq_blk_ready = false;
-    int asm_fq_block = 1;     // tuning knob: 0 = the sweep gathers the cell's forcing samples itself (no coefficient kernel in init)
+    int asm_fq_block = 0;     // tuning knob: 1 = fdapde_init first reduces the forcing samples to one load coefficient per visit slot (k_visit_load_coeffs);
+                              // measured on C3 with that kernel inside init's timed region: init 1.49-1.53 ms against 1.23-1.26 ms for the sweep
+                              // gathering the cell's samples itself (a cell's nq samples share one 32-byte sector with the coefficient they would become)
     DBuf<double> vcoords, vals[2], force, fq, g, sval, scale, gt, x, r, p, y, s, t, r0, u, part_a, part_b, sc, tmp_e,
       tmp_i, tmp_v;
     DBuf<uint8_t> bnd;
@@ -209,6 +211,24 @@ struct fdapde_ctx {
     bool lin_sq_ready = false;
     int multi_rhs = 1;                       // tuning knob: 0 = always solve the columns of fdapde_lin_solve one by one
     SolveStateHolder* lin_state = nullptr;
+    // persistent small-problem CG (kernels_persist.h): resident layouts for the two boundary variants, built on first use
+    int n_cu = 0;
+    int persist = 1;                         // tuning knob: 0 = never take the single-launch path
+    int persist_time = 1;                    // workgroup 0 stamps the phases of every iteration (a handful of s_memrealtime per iteration)
+    bool persist_broken = false;             // a hand-off timed out once (workgroups not co-resident): stay on the multi-launch path
+    struct Persist {
+        bool tried = false, ok = false;
+        PersistLayout meta;                  // sizes only (the big arrays are released after the upload)
+        int32_t lds_cap = 0, imp_cap = 0;
+        size_t lds_bytes = 0;
+        DBuf<int32_t> slot_dof, sl_off, q_int, ell_src, exp_off, imp_off, imp_pos;
+        DBuf<int64_t> ell_off;
+        DBuf<uint16_t> ell_code, exp_slot;
+        DBuf<double> ell_val;
+        DBuf<unsigned long long> board;      // [2 n_board granules of p | 2 x G x 6 granules of dot partials], zeroed before every launch
+        bool filled = false;                 // ell_val holds the currently scaled system
+    } ps[2];
+    DBuf<double> persist_stats;
 };
 
 #endif

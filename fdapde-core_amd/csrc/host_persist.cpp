@@ -1,0 +1,202 @@
+// host_persist.cpp -- index work for the persistent small-problem CG (kernels_persist.h): cuts the interior block of the system
+// into one contiguous row range per workgroup and lays each range out as sliced ELL in the order the workgroup's threads own the
+// rows; builds the export / import lists of the vector entries neighbouring workgroups exchange every iteration.
+// Host code, done once per function space and boundary mask (like host_build_solver_pattern).
+#include <algorithm>
+#include <cstdint>
+#include <numeric>
+#include <thread>
+#include <vector>
+
+#include "internal.h"
+
+namespace fdapde_hip {
+
+namespace {
+
+template <typename F> void for_each_wg(int G, F&& fn) {
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt < 1 ? 1 : (nt > 16 ? 16 : nt);
+    if ((unsigned)G < nt) nt = (unsigned)G;
+    if (nt <= 1) {
+        for (int g = 0; g < G; ++g) fn(g);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t)
+        th.emplace_back([&, t] {
+            for (int g = (int)t; g < G; g += (int)nt) fn(g);
+        });
+    for (auto& x : th) x.join();
+}
+
+}  // namespace
+
+int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int lds_entries, PersistLayout& pl) {
+    constexpr int T = kPersistT;
+    const int64_t nd = hs.n_dofs;
+    if (n_wg < 1 || nd < 1) return FDAPDE_EUNSUPPORTED;
+    if (n_wg > T) n_wg = T;   // one thread per workgroup gathers that workgroup's dot-product partials
+    auto dropped = [&](int64_t d) { return use_bnd && hs.dof_bnd_i[(size_t)d] != 0; };
+    // interior rows in internal (locality) order
+    std::vector<int32_t> irow_dof;
+    irow_dof.reserve((size_t)nd);
+    for (int64_t d = 0; d < nd; ++d)
+        if (!dropped(d)) irow_dof.push_back((int32_t)d);
+    const int64_t n_int = (int64_t)irow_dof.size();
+    if (n_int < 1) return FDAPDE_EUNSUPPORTED;
+    auto kept = [&](int64_t row, int32_t col) { return col != row && !dropped(col); };
+    int64_t nnz_kept = 0;
+    for (int64_t i = 0; i < n_int; ++i) {
+        const int32_t d = irow_dof[(size_t)i];
+        for (int32_t k = hs.rowptr_i[(size_t)d]; k < hs.rowptr_i[(size_t)d + 1]; ++k) nnz_kept += kept(d, hs.colidx_i[(size_t)k]);
+    }
+    // workgroups: ~2048 rows each, more (fewer rows each) when that makes every block of the matrix fit its workgroup's LDS
+    int64_t want = (n_int + 2047) / 2048;
+    if (lds_entries > 0) want = std::max<int64_t>(want, (nnz_kept + nnz_kept / 16 + lds_entries - 1) / lds_entries);
+    int G = (int)std::min<int64_t>(n_wg, want);
+    if (G < 1) G = 1;
+    const int64_t rpw = (n_int + G - 1) / G;
+    int R = 1;
+    while ((int64_t)R * T < rpw) R *= 2;
+    if (R > kPersistRmax) return FDAPDE_EUNSUPPORTED;
+    G = (int)((n_int + rpw - 1) / rpw);   // trailing workgroups that would stay empty are not launched
+    const int S = R * T, nsl = S / 64;
+    pl.G = G, pl.R = R, pl.nsl = nsl, pl.n_int = n_int;
+
+    std::vector<int32_t> wg_of((size_t)nd, -1), slot_of((size_t)nd, -1);
+    for (int64_t i = 0; i < n_int; ++i) wg_of[(size_t)irow_dof[(size_t)i]] = (int32_t)(i / rpw);
+
+    // ---- slots: rows of a workgroup ordered by (references another workgroup, length descending, row)
+    pl.slot_dof.assign((size_t)G * S, -1);
+    pl.q_int.assign((size_t)G, 0);
+    std::vector<std::vector<int32_t>> imports((size_t)G);   // DOFs of other workgroups a workgroup reads, unique
+    std::vector<int32_t> row_len((size_t)nd, 0);
+    for_each_wg(G, [&](int g) {
+        const int64_t i0 = (int64_t)g * rpw, i1 = std::min<int64_t>(n_int, i0 + rpw);
+        struct Key { int32_t halo, len, dof; };
+        std::vector<Key> rows;
+        rows.reserve((size_t)(i1 - i0));
+        std::vector<int32_t>& imp = imports[(size_t)g];
+        for (int64_t i = i0; i < i1; ++i) {
+            const int32_t d = irow_dof[(size_t)i];
+            int32_t len = 0, halo = 0;
+            for (int32_t k = hs.rowptr_i[(size_t)d]; k < hs.rowptr_i[(size_t)d + 1]; ++k) {
+                const int32_t c = hs.colidx_i[(size_t)k];
+                if (!kept(d, c)) continue;
+                ++len;
+                if (wg_of[(size_t)c] != g) halo = 1, imp.push_back(c);
+            }
+            row_len[(size_t)d] = len;
+            rows.push_back({halo, len, d});
+        }
+        std::sort(rows.begin(), rows.end(), [](const Key& a, const Key& b) {
+            if (a.halo != b.halo) return a.halo < b.halo;
+            if (a.len != b.len) return a.len > b.len;
+            return a.dof < b.dof;
+        });
+        int32_t first_halo = (int32_t)rows.size();
+        for (size_t s = 0; s < rows.size(); ++s) {
+            pl.slot_dof[(size_t)g * S + s] = rows[s].dof;
+            slot_of[(size_t)rows[s].dof] = (int32_t)s;
+            if (rows[s].halo && (int32_t)s < first_halo) first_halo = (int32_t)s;
+        }
+        pl.q_int[(size_t)g] = first_halo / 64;   // whole slices in front of the first row that needs an import
+        std::sort(imp.begin(), imp.end());
+        imp.erase(std::unique(imp.begin(), imp.end()), imp.end());
+    });
+
+    // ---- exports: a workgroup publishes the entries other workgroups import; board position = exp_off[owner] + index, in slot order
+    std::vector<uint8_t> is_exp((size_t)nd, 0);
+    for (int g = 0; g < G; ++g)
+        for (int32_t d : imports[(size_t)g]) is_exp[(size_t)d] = 1;
+    pl.exp_off.assign((size_t)G + 1, 0);
+    std::vector<int32_t> board_of((size_t)nd, -1);
+    pl.exp_slot.clear();
+    pl.max_exp = 0;
+    for (int g = 0; g < G; ++g) {
+        int32_t cnt = 0;
+        for (int s = 0; s < S; ++s) {
+            const int32_t d = pl.slot_dof[(size_t)g * S + s];
+            if (d < 0 || !is_exp[(size_t)d]) continue;
+            board_of[(size_t)d] = pl.exp_off[(size_t)g] + cnt;
+            pl.exp_slot.push_back((uint16_t)s);
+            ++cnt;
+        }
+        pl.exp_off[(size_t)g + 1] = pl.exp_off[(size_t)g] + cnt;
+        pl.max_exp = std::max(pl.max_exp, cnt);
+    }
+    pl.n_board = pl.exp_off[(size_t)G];
+    // ---- imports in board order (neighbouring entries of one exporter are read together)
+    pl.imp_off.assign((size_t)G + 1, 0);
+    pl.max_imp = 0;
+    for (int g = 0; g < G; ++g) {
+        std::vector<int32_t>& imp = imports[(size_t)g];
+        std::sort(imp.begin(), imp.end(), [&](int32_t a, int32_t b) { return board_of[(size_t)a] < board_of[(size_t)b]; });
+        pl.imp_off[(size_t)g + 1] = pl.imp_off[(size_t)g] + (int32_t)imp.size();
+        pl.max_imp = std::max(pl.max_imp, (int32_t)imp.size());
+    }
+    if (S + pl.max_imp > 65535) return FDAPDE_EUNSUPPORTED;   // 16-bit column codes
+    pl.imp_pos.resize((size_t)pl.imp_off[(size_t)G]);
+    for (int g = 0; g < G; ++g)
+        for (size_t h = 0; h < imports[(size_t)g].size(); ++h)
+            pl.imp_pos[(size_t)pl.imp_off[(size_t)g] + h] = board_of[(size_t)imports[(size_t)g][h]];
+
+    // ---- sliced ELL: slice q of a workgroup = slots [64 q, 64 q + 64), width = its longest row
+    pl.sl_off.assign((size_t)G * (nsl + 1), 0);
+    pl.ell_off.assign((size_t)G + 1, 0);
+    for (int g = 0; g < G; ++g) {
+        int32_t off = 0;
+        for (int q = 0; q < nsl; ++q) {
+            int32_t w = 0;
+            for (int l = 0; l < 64; ++l) {
+                const int32_t d = pl.slot_dof[(size_t)g * S + (size_t)q * 64 + l];
+                if (d >= 0) w = std::max(w, row_len[(size_t)d]);
+            }
+            pl.sl_off[(size_t)g * (nsl + 1) + q] = off;
+            off += w;
+        }
+        pl.sl_off[(size_t)g * (nsl + 1) + nsl] = off;
+        pl.ell_off[(size_t)g + 1] = pl.ell_off[(size_t)g] + (int64_t)off * 64;
+    }
+    pl.n_entries = pl.ell_off[(size_t)G];
+    pl.ell_code.assign((size_t)pl.n_entries, 0);
+    pl.ell_src.assign((size_t)pl.n_entries, -1);
+    std::vector<int64_t> nnz_wg((size_t)G, 0);
+    for_each_wg(G, [&](int g) {
+        const std::vector<int32_t>& imp = imports[(size_t)g];   // sorted by board position: look columns up through an index
+        std::vector<int32_t> by_dof(imp.size());
+        std::iota(by_dof.begin(), by_dof.end(), 0);
+        std::sort(by_dof.begin(), by_dof.end(), [&](int32_t a, int32_t b) { return imp[(size_t)a] < imp[(size_t)b]; });
+        auto import_index = [&](int32_t dof) {
+            size_t lo = 0, hi = by_dof.size();
+            while (lo < hi) {
+                const size_t mid = (lo + hi) / 2;
+                if (imp[(size_t)by_dof[mid]] < dof) lo = mid + 1;
+                else hi = mid;
+            }
+            return by_dof[lo];
+        };
+        int64_t nz = 0;
+        for (int s = 0; s < S; ++s) {
+            const int32_t d = pl.slot_dof[(size_t)g * S + s];
+            if (d < 0) continue;
+            const int q = s / 64, l = s % 64;
+            const int64_t base = pl.ell_off[(size_t)g] + (int64_t)pl.sl_off[(size_t)g * (nsl + 1) + q] * 64 + l;
+            int32_t e = 0;
+            for (int32_t k = hs.rowptr_i[(size_t)d]; k < hs.rowptr_i[(size_t)d + 1]; ++k) {
+                const int32_t c = hs.colidx_i[(size_t)k];
+                if (!kept(d, c)) continue;
+                const int64_t at = base + (int64_t)e * 64;
+                pl.ell_src[(size_t)at] = k;
+                pl.ell_code[(size_t)at] = (uint16_t)(wg_of[(size_t)c] == g ? slot_of[(size_t)c] : S + import_index(c));
+                ++e, ++nz;
+            }
+        }
+        nnz_wg[(size_t)g] = nz;
+    });
+    pl.nnz = std::accumulate(nnz_wg.begin(), nnz_wg.end(), (int64_t)0);
+    return FDAPDE_OK;
+}
+
+}  // namespace fdapde_hip

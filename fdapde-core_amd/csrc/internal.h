@@ -118,5 +118,35 @@ int host_build_col16(int64_t n, const std::vector<int32_t>& rowptr, const std::v
 int host_build_solver_pattern(const HostSpace& hs, bool use_bnd, std::vector<int32_t>& rowptr_s, std::vector<int32_t>& colidx_s,
                               std::vector<int32_t>& full2s);
 
+
+// ---- resident layout of the persistent small-problem CG (kernels_persist.h): the interior block of the scaled system cut into
+//      one contiguous row range per workgroup (one workgroup per CU), each range as sliced ELL in the order the workgroup's
+//      threads own the rows, plus the lists of vector entries workgroups exchange every iteration.
+constexpr int kPersistT = 512;        // threads per workgroup
+constexpr int kPersistRmax = 8;       // rows per thread at most
+struct PersistLayout {
+    int G = 0, R = 0, nsl = 0;        // workgroups; rows per thread (1, 2, 4, 8); slices of 64 slots per workgroup = R * T / 64
+    int64_t n_int = 0;                // interior (non-Dirichlet) rows
+    int64_t n_entries = 0;            // ELL entries over all workgroups, padding included
+    int64_t nnz = 0;                  // stored off-diagonal entries (no padding)
+    int64_t n_board = 0;              // exported vector entries over all workgroups
+    int32_t max_imp = 0, max_exp = 0;
+    std::vector<int32_t> slot_dof;    // G * S (S = R * T): internal DOF id of the row a slot holds, -1 = empty slot
+    std::vector<int64_t> ell_off;     // G + 1: first ELL entry of a workgroup (multiple of 64)
+    std::vector<int32_t> sl_off;      // G * (nsl + 1): slice offsets inside the workgroup's block, in units of 64 entries
+    std::vector<int32_t> q_int;       // G: the first q_int slices reference no other workgroup's rows
+    std::vector<uint16_t> ell_code;   // n_entries: < S: slot of the column's row in this workgroup; >= S: S + index in its import list
+    std::vector<int32_t> ell_src;     // n_entries: entry of the full internal pattern holding the value, -1 = padding
+    std::vector<int32_t> exp_off;     // G + 1: export list offsets (= board positions)
+    std::vector<uint16_t> exp_slot;   // n_board: slot whose vector entry is published at that board position
+    std::vector<int32_t> imp_off;     // G + 1
+    std::vector<int32_t> imp_pos;     // board position each imported entry is read from
+};
+// n_wg: workgroups available (CUs of the device); lds_entries: ELL entries a workgroup can keep in LDS -- the rows are spread over
+// enough workgroups for every block to be resident where the device has that many (3-D rows: 14 entries each, so ~850 rows per
+// workgroup instead of 2048).  Returns FDAPDE_EUNSUPPORTED when the system does not fit the layout (more than n_wg * T * Rmax interior
+// rows, rows or lists too long for the 16-bit codes).
+int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int lds_entries, PersistLayout& pl);
+
 }  // namespace fdapde_hip
 #endif

@@ -17,6 +17,7 @@
 //   kernels_spmv.h      CSR SpMV forms fused with the Krylov dot products
 //   kernels_krylov.h    Jacobi scaling, CG / BiCGStab vector kernels, multi-GPU interface exchange, numbering changes
 //   kernels_multirhs.h  Q right-hand sides at once against one prepared system (SpMM + batched fused-update CG)
+//   kernels_persist.h   the whole CG solve of a small system as one launch (matrix resident in LDS, granule hand-offs)
 #ifndef FDAPDE_KERNELS_H
 #define FDAPDE_KERNELS_H
 
@@ -25,5 +26,6 @@
 #include "kernels_spmv.h"
 #include "kernels_krylov.h"
 #include "kernels_multirhs.h"
+#include "kernels_persist.h"
 
 #endif

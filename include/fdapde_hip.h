@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FDAPDE_ABI_VERSION 1
+#define FDAPDE_ABI_VERSION 2
 
 enum {
     FDAPDE_OK = 0,
@@ -87,6 +87,10 @@ typedef struct {
     double spmv_avg_ms;   /* average duration of the SpMV launches timed inside the last solve (0 if none) */
     int32_t spmv_timed;   /* how many launches that average covers */
     int32_t method_used;  /* the FDAPDE_SOLVER_* that ran */
+    int32_t persistent;   /* 1: the solve ran as ONE launch (small systems: matrix resident in LDS, in-kernel hand-offs); spmv_avg_ms
+                             is then the operator-application phase (SpMV + neighbour import) stamped inside the kernel */
+    double gather_avg_ms; /* persistent path: average all-gather phase (dot products) per iteration */
+    double update_avg_ms; /* persistent path: average vector update phase per iteration */
 } fdapde_info;
 
 typedef struct fdapde_ctx fdapde_ctx;
@@ -217,7 +221,9 @@ int fdapde_halo_setup(fdapde_ctx *ctx, int64_t n_if_global, int64_t n_if_local, 
  *   fused CG      "cgf_v" (double2 per lane), "cgf_band" (XCD-aware mapping), "cgf_nt" (bit set: y, x, r, p nontemporal),
  *                 "cgf_lazy" (x touched every second launch), "cgf_split" (second half of the loads after the scalars),
  *                 "use_graph" (hipGraph replay of a chunk of iterations)
- *   handle        "multi_rhs" (batched multi-column solves) */
+ *   handle        "multi_rhs" (batched multi-column solves)
+ *   assembly      "asm_fq_block" (forcing as per-visit load coefficients computed by a kernel of their own inside init)
+ *   small systems "persist" (0: never run the solve as one persistent launch), "persist_time" (phase stamps) */
 int fdapde_tune(fdapde_ctx *ctx, const char *key, int32_t value);
 /* the context's HIP stream (hipStream_t) so that callers can bracket work with their own events */
 void *fdapde_stream(fdapde_ctx *ctx);

@@ -1,7 +1,8 @@
 // host_setup_sanitize.cpp -- drives the host-side set-up (csrc/host_setup.cpp, tables.cpp) under AddressSanitizer / UBSan /
 // ThreadSanitizer on the CPU (GPU sanitizers are not available on this pool).  Built and run by tests/test_host_sanitizers.py:
-//   g++ -std=c++20 -O1 -g -fsanitize=address,undefined  (or -fsanitize=thread)  host_setup_sanitize.cpp host_setup.cpp tables.cpp -pthread
+//   g++ -std=c++20 -O1 -g -fsanitize=address,undefined  (or -fsanitize=thread)  host_setup_sanitize.cpp host_setup.cpp host_persist.cpp tables.cpp -pthread
 // Structured meshes large enough for every parallel_for to run multi-threaded; P1 and P2, 2-D and 3-D.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -51,6 +52,74 @@ static void grid_mesh(int dim, int nx, std::vector<double>& nodes, std::vector<i
     }
 }
 
+// The persistent CG's resident layout (host_persist.cpp), checked by running its operator application on the CPU exactly as
+// k_cg_persist does -- own entries from the slot table, imported entries through the board, sliced ELL with 16-bit codes -- against
+// the CSR product on the interior block.  Returns the number of workgroups of the layout (0: system does not qualify), -1 on error.
+static int check_persist(const HostSpace& hs, bool use_bnd, int n_wg) {
+    PersistLayout pl;
+    const int rc = host_build_persist_layout(hs, use_bnd, n_wg, 12000, pl);
+    if (rc == FDAPDE_EUNSUPPORTED) return 0;
+    if (rc) return -1;
+    const int T = kPersistT, S = pl.R * T, nsl = pl.nsl;
+    auto dropped = [&](int64_t d) { return use_bnd && hs.dof_bnd_i[(size_t)d]; };
+    auto val = [](int64_t k) { return 1.0 + 0.25 * (double)(k % 7); };
+    std::vector<double> p((size_t)hs.n_dofs), yref((size_t)hs.n_dofs, 0.0), y((size_t)hs.n_dofs, 0.0);
+    for (int64_t d = 0; d < hs.n_dofs; ++d) p[(size_t)d] = dropped(d) ? 0.0 : std::sin(0.37 * (double)d) + 1.5;
+    int64_t kept = 0, rows = 0;
+    for (int64_t d = 0; d < hs.n_dofs; ++d) {
+        if (dropped(d)) continue;
+        ++rows;
+        double acc = p[(size_t)d];
+        for (int32_t k = hs.rowptr_i[(size_t)d]; k < hs.rowptr_i[(size_t)d + 1]; ++k) {
+            const int32_t c = hs.colidx_i[(size_t)k];
+            if (c == d || dropped(c)) continue;
+            acc += val(k) * p[(size_t)c], ++kept;
+        }
+        yref[(size_t)d] = acc;
+    }
+    if (rows != pl.n_int || kept != pl.nnz) return -1;
+    std::vector<double> board((size_t)pl.n_board, -1e300);
+    std::vector<uint8_t> seen((size_t)hs.n_dofs, 0);
+    for (int g = 0; g < pl.G; ++g)   // every workgroup publishes its exported entries
+        for (int32_t i = pl.exp_off[(size_t)g]; i < pl.exp_off[(size_t)g + 1]; ++i) {
+            const int32_t d = pl.slot_dof[(size_t)g * S + pl.exp_slot[(size_t)i]];
+            if (d < 0) return -1;
+            board[(size_t)i] = p[(size_t)d];
+        }
+    for (int g = 0; g < pl.G; ++g) {
+        const int H = pl.imp_off[(size_t)g + 1] - pl.imp_off[(size_t)g];
+        std::vector<double> tab((size_t)(S + H), 0.0);
+        for (int s = 0; s < S; ++s) {
+            const int32_t d = pl.slot_dof[(size_t)g * S + s];
+            tab[(size_t)s] = d >= 0 ? p[(size_t)d] : 0.0;
+        }
+        for (int h = 0; h < H; ++h) tab[(size_t)(S + h)] = board[(size_t)pl.imp_pos[(size_t)pl.imp_off[(size_t)g] + h]];
+        const int32_t* slo = &pl.sl_off[(size_t)g * (nsl + 1)];
+        for (int q = 0; q < nsl; ++q)
+            for (int l = 0; l < 64; ++l) {
+                const int s = q * 64 + l;
+                const int32_t d = pl.slot_dof[(size_t)g * S + s];
+                double acc = tab[(size_t)s];
+                for (int32_t e = slo[q]; e < slo[q + 1]; ++e) {
+                    const int64_t at = pl.ell_off[(size_t)g] + (int64_t)e * 64 + l;
+                    const uint16_t code = pl.ell_code[(size_t)at];
+                    if (code >= S + H) return -1;
+                    if (q < pl.q_int[(size_t)g] && code >= S && pl.ell_src[(size_t)at] >= 0) return -1;   // "no import" slices must not import
+                    acc += (pl.ell_src[(size_t)at] >= 0 ? val(pl.ell_src[(size_t)at]) : 0.0) * tab[code];
+                }
+                if (d >= 0) {
+                    if (seen[(size_t)d]) return -1;   // every interior row in exactly one slot
+                    seen[(size_t)d] = 1, y[(size_t)d] = acc;
+                }
+            }
+    }
+    for (int64_t d = 0; d < hs.n_dofs; ++d) {
+        if (dropped(d)) continue;
+        if (!seen[(size_t)d] || std::fabs(y[(size_t)d] - yref[(size_t)d]) > 1e-12 * std::fabs(yref[(size_t)d])) return -1;
+    }
+    return pl.G;
+}
+
 int main() {
     struct Case { int dim, nx, order; } cases[] = {{2, 200, 1}, {2, 120, 2}, {3, 26, 1}, {3, 16, 2}, {2, 3, 2}, {3, 2, 2}};
     for (const Case& cs : cases) {
@@ -75,8 +144,19 @@ int main() {
             std::fprintf(stderr, "case dim %d nx %d order %d failed: %d %s\n", cs.dim, cs.nx, cs.order, rc, err.c_str());
             return 1;
         }
-        std::printf("dim %d nx %d order %d: %lld cells, %lld dofs, nnz %lld, lane_row %s\n", cs.dim, cs.nx, cs.order, (long long)nc,
-                    (long long)hs.n_dofs, (long long)hs.nnz, hs.lane_row.empty() ? "identity" : "by visit count");
+        int pg[4] = {0, 0, 0, 0}, k = 0;
+        for (int n_wg : {1, 7, 256}) {
+            pg[k++] = check_persist(hs, true, n_wg);
+            if (n_wg == 7) pg[k++] = check_persist(hs, false, n_wg);
+        }
+        for (int v : pg)
+            if (v < 0) {
+                std::fprintf(stderr, "case dim %d nx %d order %d: persistent layout does not reproduce the operator\n", cs.dim, cs.nx, cs.order);
+                return 1;
+            }
+        std::printf("dim %d nx %d order %d: %lld cells, %lld dofs, nnz %lld, lane_row %s, persistent layouts %d / %d / %d / %d workgroups\n",
+                    cs.dim, cs.nx, cs.order, (long long)nc, (long long)hs.n_dofs, (long long)hs.nnz,
+                    hs.lane_row.empty() ? "identity" : "by visit count", pg[0], pg[1], pg[2], pg[3]);
     }
     return 0;
 }

@@ -1,0 +1,124 @@
+"""The single-launch CG of small systems (kernels_persist.h: matrix resident in LDS, granule hand-offs between workgroups) against
+the multi-launch path it replaces and against the oracle: same recurrence, so the same iteration counts (the dot products are
+summed in another order: +-1 iteration at rtol 1e-10) and the same solution to rounding; every hand-off shape is covered -- one
+workgroup (no exchange), a few, one per CU with rows per thread 1 ... 8, 2-D and 3-D, P1 and P2, with and without Dirichlet
+data, warm starts (parabolic stepping) and the factor-once handle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    from fdapde_loader import load_package
+
+    load_package()
+    from fdapde_core_amd import capi, meshgen
+
+    assert capi.load().fdapde_device_count() >= 1
+    return capi, meshgen
+
+
+def _problem(capi, meshgen, dim, nx, order, dirichlet=True):
+    nodes, cells, bnd = meshgen.unit_square(nx) if dim == 2 else meshgen.unit_cube(nx)
+    u_exact, f = meshgen.manufactured(dim)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd if dirichlet else np.zeros_like(bnd))
+    nd = c.dofs_build(order)
+    _, _, coords = c.dofs_get()
+    c.set_operator(-capi.laplacian() + (capi.reaction(0.0) if dirichlet else capi.reaction(1.0)))
+    c.set_forcing(f(c.quadrature_nodes()))
+    c.set_dirichlet(0.25 * coords[:, 0] if dirichlet else None)
+    c.init()
+    return c, nd
+
+
+@pytest.mark.parametrize("dim,nx,order,dirichlet", [
+    (2, 20, 1, True),      # 441 DOFs: one workgroup, no exchange
+    (2, 60, 1, True),      # 3 721 DOFs: two workgroups
+    (2, 60, 2, True),      # 14 641 DOFs, P2 rows
+    (2, 150, 1, False),    # 22 801 DOFs, no Dirichlet DOF
+    (3, 30, 1, True),      # 29 791 DOFs: 3-D rows (15 entries), larger import lists
+    (3, 12, 2, True),      # 15 625 DOFs, 3-D P2 rows (up to 64 entries)
+    (2, 400, 1, True),     # 160 801 DOFs: ~80 workgroups
+    (3, 64, 1, True),      # 274 625 DOFs: 135 workgroups
+    (2, 708, 1, True),     # C2: one workgroup per CU, 4 rows per thread
+    (2, 1000, 1, True),    # 1 002 001 DOFs: 8 rows per thread, part of the matrix streams from the caches
+])
+def test_persistent_path_matches_multi_launch_path(env, dim, nx, order, dirichlet):
+    capi, meshgen = env
+    c, nd = _problem(capi, meshgen, dim, nx, order, dirichlet)
+    c.tune("persist", 0)
+    i0 = c.solve(rtol=1e-10)
+    u0 = c.solution()
+    assert i0.persistent == 0 and i0.converged == 1
+    c.tune("persist", 1)
+    i1 = c.solve(rtol=1e-10)
+    u1 = c.solution()
+    assert i1.persistent == 1, "the system qualifies: the single-launch path must have run"
+    assert i1.converged == 1 and i1.method_used == capi.SOLVER_CG_FUSED and i1.relres <= 1e-10
+    assert abs(i1.iters - i0.iters) <= max(1, i0.iters // 200), (i1.iters, i0.iters)
+    assert np.linalg.norm(u1 - u0) <= 1e-9 * np.linalg.norm(u0)
+    # a second launch on the same context (boards re-zeroed, tags restart): identical bits
+    i2 = c.solve(rtol=1e-10)
+    assert i2.iters == i1.iters and np.array_equal(c.solution(), u1)
+    # maxit reached: reported, not hung
+    i3 = c.solve(rtol=1e-10, maxit=5, raise_on_noconv=False)
+    assert i3.persistent == 1 and i3.converged == 0 and i3.iters == 5
+    c.close()
+
+
+def test_persistent_path_against_the_oracle(env, oracle, mesh_loader):
+    capi, _ = env
+    m = mesh_loader("unit_square")     # 3600 nodes: two workgroups
+    c = capi.Context(0)
+    c.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = c.dofs_build(1)
+    _, _, coords = c.dofs_get()
+    fq = np.ones(3 * m.n_cells)
+    g = coords[:, 0] * coords[:, 1]
+    c.set_operator(-capi.laplacian())
+    c.set_forcing(fq)
+    c.set_dirichlet(g)
+    c.init()
+    info = c.solve(rtol=1e-11)
+    assert info.persistent == 1
+    ref = oracle.pde_init_solve(m, 1, -oracle.laplacian(), forcing_q=fq, dirichlet=g)
+    assert np.linalg.norm(c.solution() - ref.solution) <= 1e-8 * np.linalg.norm(ref.solution)
+
+
+def test_persistent_path_under_parabolic_stepping_and_handle(env):
+    """warm-started solves (x0 != 0) and the factor-once handle go through the same solve_run"""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+
+    capi, meshgen = env
+    nodes, cells, bnd = meshgen.unit_square(48)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(1)
+    _, _, coords = c.dofs_get()
+    u_exact, f = meshgen.manufactured(2)
+    times = np.linspace(0.0, 0.3, 5)
+    qn = c.quadrature_nodes()
+    c.set_operator(capi.dt() - capi.laplacian())
+    c.set_forcing(np.stack([(f(qn) - u_exact(qn)) * np.exp(-t) for t in times], axis=1))
+    c.init()
+    G = np.stack([u_exact(coords) * np.exp(-t) for t in times], axis=1)
+    outs = []
+    for knob in (0, 1):
+        c.tune("persist", knob)
+        sol, info = c.solve_parabolic(times, G[:, 0], G, rtol=1e-11)
+        assert info.converged == 1
+        outs.append(sol)
+    assert np.abs(outs[0] - outs[1]).max() <= 1e-9
+    rp, ci = c.pattern_get()
+    M = sp.csr_matrix((c.matrix_values(capi.MAT_MASS), ci, rp), shape=(nd, nd))
+    b = np.random.default_rng(3).standard_normal(nd)
+    c.lin_compute(capi.MAT_MASS, symmetric=True)
+    x, info = c.lin_solve(b, rtol=1e-12)
+    assert info.persistent == 1
+    xr = spla.splu(M.tocsc()).solve(b)
+    assert np.linalg.norm(x - xr) <= 1e-9 * np.linalg.norm(xr)
+    c.close()

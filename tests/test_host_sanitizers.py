@@ -1,5 +1,6 @@
 """The multi-threaded host-side set-up (csrc/host_setup.cpp: relaxed-atomic counting sorts, uninitialised-resize vectors, open
-addressing sets, lane permutations) under AddressSanitizer + UBSan and under ThreadSanitizer, on the CPU build -- GPU sanitizers are
+addressing sets, lane permutations; csrc/host_persist.cpp: the persistent CG's resident layout, whose operator application is replayed on the CPU and
+compared with the CSR product) under AddressSanitizer + UBSan and under ThreadSanitizer, on the CPU build -- GPU sanitizers are
 not available on this pool.  tests/cpp/host_setup_sanitize.cpp drives P1 / P2 meshes in 2-D / 3-D at sizes where every
 parallel_for really runs on several threads."""
 import os
@@ -10,7 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = [os.path.join(ROOT, "tests", "cpp", "host_setup_sanitize.cpp"), os.path.join(ROOT, "fdapde-core_amd", "csrc", "host_setup.cpp"),
-       os.path.join(ROOT, "fdapde-core_amd", "csrc", "tables.cpp")]
+       os.path.join(ROOT, "fdapde-core_amd", "csrc", "host_persist.cpp"), os.path.join(ROOT, "fdapde-core_amd", "csrc", "tables.cpp")]
 
 
 @pytest.mark.parametrize("name,flags", [("asan_ubsan", ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"]),

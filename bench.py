@@ -232,9 +232,17 @@ def main():
             "t_meshgen_s_untimed": t_gen,
             "max_abs_error_vs_analytic": err,
             "spmv_launches_timed_per_step": int(info.spmv_timed),
+            "persistent_launch": int(getattr(info, "persistent", 0)),
+            "us_per_iteration": 1e3 * t_sol / max(int(info.iters), 1),
+            "operator_phase_mean_us": 1e3 * float(getattr(info, "spmv_mean_ms", 0.0)),
+            "allgather_phase_us": 1e3 * float(getattr(info, "gather_avg_ms", 0.0)),
+            "update_phase_us": 1e3 * float(getattr(info, "update_avg_ms", 0.0)),
         },
         "roofline": {
-            "bound": "hbm", "kernel": "k_spmv_team2 (CSR SpMV fused with p.Ap and Ap.Ap inside CG)",
+            "bound": "hbm",
+            "kernel": ("k_cg_persist operator phase (the whole CG is ONE launch: x, r, p in registers, the matrix streams once per iteration; "
+                       "avg_launch_ms = per-iteration SpMV + neighbour-import phase of the slowest workgroup, stamped in the kernel)"
+                       if getattr(info, "persistent", 0) else "k_spmv_team2 (CSR SpMV fused with p.Ap and Ap.Ap inside CG)"),
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": spmv_ms,

@@ -34,7 +34,8 @@ class Options(C.Structure):
 class Info(C.Structure):
     _fields_ = [("iters", C.c_int32), ("converged", C.c_int32), ("relres", C.c_double), ("t_assemble_ms", C.c_double),
                 ("t_solve_ms", C.c_double), ("t_setup_ms", C.c_double), ("spmv_avg_ms", C.c_double), ("spmv_timed", C.c_int32),
-                ("method_used", C.c_int32), ("persistent", C.c_int32), ("gather_avg_ms", C.c_double), ("update_avg_ms", C.c_double)]
+                ("method_used", C.c_int32), ("persistent", C.c_int32), ("gather_avg_ms", C.c_double), ("update_avg_ms", C.c_double),
+                ("spmv_mean_ms", C.c_double)]
 
 
 # every symbol include/fdapde_hip.h declares (tests check that the library exports all of them)

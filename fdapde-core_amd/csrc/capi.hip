@@ -573,7 +573,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
         if (c->comm) (void)g_rccl.CommDestroy(c->comm);
         c->lin_mat.release(), c->persist_stats.release();
         for (auto& ps : c->ps)
-            ps.slot_dof.release(), ps.sl_off.release(), ps.q_int.release(), ps.ell_src.release(), ps.exp_off.release(), ps.imp_off.release(),
+            ps.slot_dof.release(), ps.sl_off.release(), ps.ell_src.release(), ps.exp_off.release(), ps.imp_off.release(),
               ps.imp_pos.release(), ps.ell_off.release(), ps.ell_code.release(), ps.exp_slot.release(), ps.ell_val.release(), ps.board.release();
         for (int v = 0; v < 2; ++v)
             c->sp_rowptr[v].release(), c->sp_colidx[v].release(), c->sp_map[v].release(), c->sp_tbase[v].release(), c->sp_col16[v].release(),
@@ -903,41 +903,45 @@ int build_persist(fdapde_ctx* c, int v) {
     const int rc = host_build_persist_layout(c->hs, v == 1, c->n_cu, 12000, pl);   // ~12 000 ELL entries (120 KB) next to the vectors of <= 4096 rows
     if (rc == FDAPDE_EUNSUPPORTED) return FDAPDE_OK;
     if (rc) return rc;
-    double max_mb = 96.0;   // ELL bytes (10 per entry) one iteration may re-read: what does not fit the LDS comes from the L2s / Infinity Cache
+    double max_mb = 1024.0;   // ELL bytes (10 per entry) of the whole system (the row bound -- G x 8192 -- is reached first for P1 systems)
     if (const char* e = std::getenv("FDAPDE_PERSIST_MAX_MB")) max_mb = std::atof(e);
     if (10.0 * (double)pl.n_entries > max_mb * 1e6) return FDAPDE_OK;
     const int S = pl.R * kPersistT;
     const int imp_cap = (pl.max_imp + 63) & ~63, exp_cap = (pl.max_exp + 63) & ~63;
     const size_t lds_total = 160 * 1024 - 1024;   // static arrays of the kernel + slack
-    const size_t fixed = 8 * (size_t)(S + imp_cap) + 4 * (size_t)(pl.nsl + 1) + 4 * (size_t)imp_cap + 2 * (size_t)exp_cap + 64;
-    if (fixed + 10 * 64 > lds_total) return FDAPDE_OK;
-    int64_t cap = (int64_t)((lds_total - fixed) / 10) & ~int64_t(63);
-    int64_t need = 0;   // largest workgroup block: no point in reserving more
+    const size_t fixed = 8 * (size_t)(S + imp_cap) + 4 * (size_t)imp_cap + 2 * (size_t)exp_cap + 64;
+    if (fixed > lds_total) return FDAPDE_OK;
+    int64_t need = 0;   // largest workgroup block
     for (int g = 0; g < pl.G; ++g) need = std::max<int64_t>(need, pl.ell_off[(size_t)g + 1] - pl.ell_off[(size_t)g]);
-    if (cap > need) cap = need > 64 ? need : 64;
-    ps.lds_cap = (int32_t)cap, ps.imp_cap = imp_cap;
-    ps.lds_bytes = fixed + 10 * (size_t)cap;
+    need += 128;        // one pair row of zeros behind the block: slices narrower than their pass's widest re-read it (clamped loads)
+    // resident form when every block fits its workgroup's LDS next to the vectors; else the blocks stream every iteration
+    ps.stream = fixed + 10 * (size_t)need > lds_total;
+    ps.lds_cap = ps.stream ? 0 : (int32_t)need, ps.imp_cap = imp_cap;
+    ps.lds_bytes = fixed + (ps.stream ? 0 : 10 * (size_t)need);
+    if (pl.R == 16 && !ps.stream) return FDAPDE_OK;   // (no such instantiation: 8192 rows never fit)
     hipStream_t st = c->stream;
     HIPCHK(c, ps.slot_dof.upload(pl.slot_dof.data(), pl.slot_dof.size(), st));
     HIPCHK(c, ps.ell_off.upload(pl.ell_off.data(), pl.ell_off.size(), st));
     HIPCHK(c, ps.sl_off.upload(pl.sl_off.data(), pl.sl_off.size(), st));
-    HIPCHK(c, ps.q_int.upload(pl.q_int.data(), pl.q_int.size(), st));
-    HIPCHK(c, ps.ell_code.upload(pl.ell_code.data(), pl.ell_code.size(), st));
+    HIPCHK(c, ps.ell_code.alloc(pl.ell_code.size() + 256));   // + slack: clamped loads of the last slices may run past the last block
+    HIPCHK(c, hipMemsetAsync(ps.ell_code.p, 0, sizeof(uint16_t) * (pl.ell_code.size() + 256), st));
+    HIPCHK(c, hipMemcpyAsync(ps.ell_code.p, pl.ell_code.data(), sizeof(uint16_t) * pl.ell_code.size(), hipMemcpyHostToDevice, st));
     HIPCHK(c, ps.ell_src.upload(pl.ell_src.data(), pl.ell_src.size(), st));
     HIPCHK(c, ps.exp_off.upload(pl.exp_off.data(), pl.exp_off.size(), st));
     HIPCHK(c, ps.exp_slot.upload(pl.exp_slot.data(), pl.exp_slot.size(), st));
     HIPCHK(c, ps.imp_off.upload(pl.imp_off.data(), pl.imp_off.size(), st));
     HIPCHK(c, ps.imp_pos.upload(pl.imp_pos.data(), pl.imp_pos.size(), st));
-    HIPCHK(c, ps.ell_val.alloc((size_t)pl.n_entries));
+    HIPCHK(c, ps.ell_val.alloc((size_t)pl.n_entries + 256));
+    HIPCHK(c, hipMemsetAsync(ps.ell_val.p, 0, sizeof(double) * ((size_t)pl.n_entries + 256), st));
     HIPCHK(c, ps.board.alloc(2 * (size_t)pl.n_board + 2 * (size_t)pl.G * 6 + 2));   // p entries | dot partials x 2 parities
-    HIPCHK(c, c->persist_stats.alloc(8));
+    HIPCHK(c, c->persist_stats.alloc(4 * 1024));
     HIPCHK(c, hipStreamSynchronize(st));
     if (std::getenv("FDAPDE_DEBUG_SETUP"))
         std::fprintf(stderr, "persistent CG layout %d: %d workgroups x %d rows/thread, %lld interior rows, %lld entries (%lld stored, %.1f %% padding), "
-                     "LDS %zu B (%d entries resident, largest block %lld), imports <= %d, exports <= %d, board %lld\n", v, pl.G, pl.R,
+                     "LDS %zu B (%s, largest block %lld), imports <= %d, exports <= %d, board %lld\n", v, pl.G, pl.R,
                      (long long)pl.n_int, (long long)pl.n_entries, (long long)pl.nnz,
-                     100.0 * (double)(pl.n_entries - pl.nnz) / (double)(pl.n_entries > 0 ? pl.n_entries : 1), ps.lds_bytes, ps.lds_cap,
-                     (long long)need, pl.max_imp, pl.max_exp, (long long)pl.n_board);
+                     100.0 * (double)(pl.n_entries - pl.nnz) / (double)(pl.n_entries > 0 ? pl.n_entries : 1), ps.lds_bytes,
+                     ps.stream ? "blocks stream" : "blocks resident", (long long)need, pl.max_imp, pl.max_exp, (long long)pl.n_board);
     // keep the sizes, drop the big host arrays
     pl.slot_dof = {}, pl.ell_code = {}, pl.ell_src = {}, pl.exp_slot = {}, pl.imp_pos = {}, pl.sl_off = {};
     ps.meta = std::move(pl);
@@ -952,29 +956,35 @@ int run_persist(fdapde_ctx* c, int v, double tol2, int maxit, bool* ran) {
     PersistArgs a{};
     a.G = ps.meta.G, a.nsl = ps.meta.nsl, a.maxit = maxit, a.imp_cap = ps.imp_cap, a.lds_cap = ps.lds_cap, a.time_phases = c->persist_time;
     a.tol2 = tol2;
-    a.slot_dof = ps.slot_dof.p, a.ell_off = ps.ell_off.p, a.sl_off = ps.sl_off.p, a.q_int = ps.q_int.p, a.ell_code = ps.ell_code.p;
+    a.slot_dof = ps.slot_dof.p, a.ell_off = ps.ell_off.p, a.sl_off = ps.sl_off.p, a.ell_code = ps.ell_code.p;
     a.ell_val = ps.ell_val.p, a.exp_off = ps.exp_off.p, a.exp_slot = ps.exp_slot.p, a.imp_off = ps.imp_off.p, a.imp_pos = ps.imp_pos.p;
     a.pboard = ps.board.p, a.dboard = ps.board.p + 2 * (size_t)ps.meta.n_board;
     a.r_in = c->r.p, a.x = c->x.p, a.sc = c->sc.p, a.ctl = c->ctl.p, a.stats = c->persist_stats.p;
     HIPCHK(c, hipMemsetAsync(ps.board.p, 0, sizeof(unsigned long long) * ps.board.n, st));   // every tag 0: no epoch of this launch
-    HIPCHK(c, hipMemsetAsync(c->persist_stats.p, 0, 8 * sizeof(double), st));
-#define PERSIST_GO(R_)                                                                                                          \
+    HIPCHK(c, hipMemsetAsync(c->persist_stats.p, 0, 4 * (size_t)a.G * sizeof(double), st));
+#define PERSIST_GO(R_, ST_)                                                                                                     \
     do {                                                                                                                        \
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cg_persist<R_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cg_persist<R_, ST_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       (int)ps.lds_bytes));                                                                      \
-        hipLaunchKernelGGL(k_cg_persist<R_>, dim3(a.G), dim3(kPersistT), ps.lds_bytes, st, a);                                  \
+        hipLaunchKernelGGL((k_cg_persist<R_, ST_>), dim3(a.G), dim3(kPersistT), ps.lds_bytes, st, a);                           \
     } while (0)
-    switch (ps.meta.R) {
-    case 1: PERSIST_GO(1); break;
-    case 2: PERSIST_GO(2); break;
-    case 4: PERSIST_GO(4); break;
-    default: PERSIST_GO(8); break;
-    }
+    if (ps.stream) switch (ps.meta.R) {
+        case 2: PERSIST_GO(2, true); break;
+        case 4: PERSIST_GO(4, true); break;
+        case 8: PERSIST_GO(8, true); break;
+        default: PERSIST_GO(16, true); break;
+        }
+    else switch (ps.meta.R) {
+        case 2: PERSIST_GO(2, false); break;
+        case 4: PERSIST_GO(4, false); break;
+        default: PERSIST_GO(8, false); break;
+        }
 #undef PERSIST_GO
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(c->h_sc, c->sc.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(c->h_sc + 8, c->persist_stats.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+    c->persist_host_stats.resize(4 * (size_t)a.G);
+    HIPCHK(c, hipMemcpyAsync(c->persist_host_stats.data(), c->persist_stats.p, 4 * (size_t)a.G * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     *ran = c->h_ctl[3] == 0;
     if (!*ran) {   // a peer workgroup was not resident (other work on the device?): nothing was written; never try again on this context
@@ -1303,9 +1313,20 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
         if (real > 0) c->info.spmv_avg_ms = sum / real, c->info.spmv_timed = real;
     }
     c->info.persistent = persisted ? 1 : 0;
-    if (persisted && c->h_sc[8] > 0) {   // phase stamps of workgroup 0 (s_memrealtime ticks of 10 ns): the operator application = SpMV + import wait
-        c->info.spmv_avg_ms = c->h_sc[9] / c->h_sc[8] * 1e-5, c->info.spmv_timed = (int32_t)c->h_sc[8];
-        c->info.gather_avg_ms = c->h_sc[10] / c->h_sc[8] * 1e-5, c->info.update_avg_ms = c->h_sc[11] / c->h_sc[8] * 1e-5;
+    c->info.gather_avg_ms = c->info.update_avg_ms = c->info.spmv_mean_ms = 0;
+    if (persisted && !c->persist_host_stats.empty() && c->persist_host_stats[0] > 0) {
+        // phase stamps of every workgroup (s_memrealtime ticks of 10 ns).  The operator application of an iteration is complete when
+        // the SLOWEST workgroup has its rows: spmv_avg_ms = max over workgroups of their average operator phase (SpMV + import wait);
+        // the mean over workgroups is reported next to it; all-gather (which contains the wait for the slowest) and update: means
+        const size_t G = c->persist_host_stats.size() / 4;
+        double mx = 0, mean = 0, gat = 0, upd = 0;
+        for (size_t g = 0; g < G; ++g) {
+            const double* st = &c->persist_host_stats[4 * g];
+            const double n_it = st[0] > 0 ? st[0] : 1;
+            mx = std::max(mx, st[1] / n_it), mean += st[1] / n_it, gat += st[2] / n_it, upd += st[3] / n_it;
+        }
+        c->info.spmv_avg_ms = mx * 1e-5, c->info.spmv_timed = (int32_t)c->persist_host_stats[0];
+        c->info.spmv_mean_ms = mean / (double)G * 1e-5, c->info.gather_avg_ms = gat / (double)G * 1e-5, c->info.update_avg_ms = upd / (double)G * 1e-5;
     }
     if (!c->info.converged) {
         c->err = c->h_ctl[2] ? "Krylov breakdown (operator not SPD for CG, or BiCGStab rho/omega = 0)" : "maxit reached";

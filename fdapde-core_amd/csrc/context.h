@@ -221,7 +221,8 @@ struct fdapde_ctx {
         PersistLayout meta;                  // sizes only (the big arrays are released after the upload)
         int32_t lds_cap = 0, imp_cap = 0;
         size_t lds_bytes = 0;
-        DBuf<int32_t> slot_dof, sl_off, q_int, ell_src, exp_off, imp_off, imp_pos;
+        DBuf<int32_t> slot_dof, sl_off, ell_src, exp_off, imp_off, imp_pos;
+        bool stream = false;                 // the blocks do not fit the LDS: streaming instantiation
         DBuf<int64_t> ell_off;
         DBuf<uint16_t> ell_code, exp_slot;
         DBuf<double> ell_val;
@@ -229,6 +230,7 @@ struct fdapde_ctx {
         bool filled = false;                 // ell_val holds the currently scaled system
     } ps[2];
     DBuf<double> persist_stats;
+    std::vector<double> persist_host_stats;
 };
 
 #endif

@@ -3,6 +3,7 @@
 // rows; builds the export / import lists of the vector entries neighbouring workgroups exchange every iteration.
 // Host code, done once per function space and boundary mask (like host_build_solver_pattern).
 #include <algorithm>
+#include <cstddef>
 #include <cstdint>
 #include <numeric>
 #include <thread>
@@ -57,25 +58,18 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
     int G = (int)std::min<int64_t>(n_wg, want);
     if (G < 1) G = 1;
     const int64_t rpw = (n_int + G - 1) / G;
-    int R = 1;
-    while ((int64_t)R * T < rpw) R *= 2;
-    if (R > kPersistRmax) return FDAPDE_EUNSUPPORTED;
     G = (int)((n_int + rpw - 1) / rpw);   // trailing workgroups that would stay empty are not launched
-    const int S = R * T, nsl = S / 64;
-    pl.G = G, pl.R = R, pl.nsl = nsl, pl.n_int = n_int;
-
     std::vector<int32_t> wg_of((size_t)nd, -1), slot_of((size_t)nd, -1);
     for (int64_t i = 0; i < n_int; ++i) wg_of[(size_t)irow_dof[(size_t)i]] = (int32_t)(i / rpw);
 
-    // ---- slots: rows of a workgroup ordered by (references another workgroup, length descending, row)
-    pl.slot_dof.assign((size_t)G * S, -1);
-    pl.q_int.assign((size_t)G, 0);
+    // ---- rows of a workgroup: (references another workgroup, length, DOF) + its import list
+    struct Key { int32_t halo, len, dof; };
+    std::vector<std::vector<Key>> wg_rows((size_t)G);
     std::vector<std::vector<int32_t>> imports((size_t)G);   // DOFs of other workgroups a workgroup reads, unique
-    std::vector<int32_t> row_len((size_t)nd, 0);
+    std::vector<int32_t> row_len((size_t)nd, 0), n_halo((size_t)G, 0);
     for_each_wg(G, [&](int g) {
         const int64_t i0 = (int64_t)g * rpw, i1 = std::min<int64_t>(n_int, i0 + rpw);
-        struct Key { int32_t halo, len, dof; };
-        std::vector<Key> rows;
+        std::vector<Key>& rows = wg_rows[(size_t)g];
         rows.reserve((size_t)(i1 - i0));
         std::vector<int32_t>& imp = imports[(size_t)g];
         for (int64_t i = i0; i < i1; ++i) {
@@ -89,21 +83,37 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
             }
             row_len[(size_t)d] = len;
             rows.push_back({halo, len, d});
+            n_halo[(size_t)g] += halo;
         }
+        std::sort(imp.begin(), imp.end());
+        imp.erase(std::unique(imp.begin(), imp.end()), imp.end());
+    });
+    // rows per thread: the first half of a thread's passes holds rows without imports (multiplied while the neighbours' entries
+    // travel), the second half everything else -- so a workgroup needs T R / 2 slots for its importing rows
+    const int32_t max_halo = *std::max_element(n_halo.begin(), n_halo.end());
+    int R = 2;
+    while ((int64_t)R * T < rpw || (int64_t)(R / 2) * T < max_halo) R *= 2;
+    if (R > kPersistRmax) return FDAPDE_EUNSUPPORTED;
+    const int S = R * T, nsl = S / 64, SA = (R / 2) * T;
+    pl.G = G, pl.R = R, pl.nsl = nsl, pl.n_int = n_int;
+
+    // ---- slots: [0, SA) rows without imports, longest first (as many as fit); [SA, S) all other rows, longest first
+    pl.slot_dof.assign((size_t)G * S, -1);
+    for_each_wg(G, [&](int g) {
+        std::vector<Key>& rows = wg_rows[(size_t)g];
         std::sort(rows.begin(), rows.end(), [](const Key& a, const Key& b) {
             if (a.halo != b.halo) return a.halo < b.halo;
             if (a.len != b.len) return a.len > b.len;
             return a.dof < b.dof;
         });
-        int32_t first_halo = (int32_t)rows.size();
-        for (size_t s = 0; s < rows.size(); ++s) {
-            pl.slot_dof[(size_t)g * S + s] = rows[s].dof;
-            slot_of[(size_t)rows[s].dof] = (int32_t)s;
-            if (rows[s].halo && (int32_t)s < first_halo) first_halo = (int32_t)s;
+        const size_t n_noimp = rows.size() - (size_t)n_halo[(size_t)g], n_a = std::min<size_t>(n_noimp, (size_t)SA);
+        std::stable_sort(rows.begin() + (std::ptrdiff_t)n_a, rows.end(), [](const Key& a, const Key& b) { return a.len > b.len; });
+        for (size_t i = 0; i < rows.size(); ++i) {
+            const size_t s = i < n_a ? i : (size_t)SA + (i - n_a);
+            pl.slot_dof[(size_t)g * S + s] = rows[i].dof;
+            slot_of[(size_t)rows[i].dof] = (int32_t)s;
         }
-        pl.q_int[(size_t)g] = first_halo / 64;   // whole slices in front of the first row that needs an import
-        std::sort(imp.begin(), imp.end());
-        imp.erase(std::unique(imp.begin(), imp.end()), imp.end());
+        rows = {};
     });
 
     // ---- exports: a workgroup publishes the entries other workgroups import; board position = exp_off[owner] + index, in slot order
@@ -142,7 +152,9 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
         for (size_t h = 0; h < imports[(size_t)g].size(); ++h)
             pl.imp_pos[(size_t)pl.imp_off[(size_t)g] + h] = board_of[(size_t)imports[(size_t)g][h]];
 
-    // ---- sliced ELL: slice q of a workgroup = slots [64 q, 64 q + 64), width = its longest row
+    // ---- sliced ELL in lane pairs: slice q of a workgroup = slots [64 q, 64 q + 64), width = its longest row rounded up to even;
+    //      a lane's entries (2 k, 2 k + 1) are adjacent (one 16-byte value load + one 4-byte code load): pair row k of the slice
+    //      = 128 consecutive entries, lane l at 2 l
     pl.sl_off.assign((size_t)G * (nsl + 1), 0);
     pl.ell_off.assign((size_t)G + 1, 0);
     for (int g = 0; g < G; ++g) {
@@ -154,10 +166,10 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
                 if (d >= 0) w = std::max(w, row_len[(size_t)d]);
             }
             pl.sl_off[(size_t)g * (nsl + 1) + q] = off;
-            off += w;
+            off += (w + 1) / 2;
         }
         pl.sl_off[(size_t)g * (nsl + 1) + nsl] = off;
-        pl.ell_off[(size_t)g + 1] = pl.ell_off[(size_t)g] + (int64_t)off * 64;
+        pl.ell_off[(size_t)g + 1] = pl.ell_off[(size_t)g] + (int64_t)off * 128;
     }
     pl.n_entries = pl.ell_off[(size_t)G];
     pl.ell_code.assign((size_t)pl.n_entries, 0);
@@ -182,12 +194,12 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
             const int32_t d = pl.slot_dof[(size_t)g * S + s];
             if (d < 0) continue;
             const int q = s / 64, l = s % 64;
-            const int64_t base = pl.ell_off[(size_t)g] + (int64_t)pl.sl_off[(size_t)g * (nsl + 1) + q] * 64 + l;
+            const int64_t base = pl.ell_off[(size_t)g] + (int64_t)pl.sl_off[(size_t)g * (nsl + 1) + q] * 128 + 2 * l;
             int32_t e = 0;
             for (int32_t k = hs.rowptr_i[(size_t)d]; k < hs.rowptr_i[(size_t)d + 1]; ++k) {
                 const int32_t c = hs.colidx_i[(size_t)k];
                 if (!kept(d, c)) continue;
-                const int64_t at = base + (int64_t)e * 64;
+                const int64_t at = base + (int64_t)(e / 2) * 128 + (e & 1);
                 pl.ell_src[(size_t)at] = k;
                 pl.ell_code[(size_t)at] = (uint16_t)(wg_of[(size_t)c] == g ? slot_of[(size_t)c] : S + import_index(c));
                 ++e, ++nz;

@@ -123,18 +123,18 @@ int host_build_solver_pattern(const HostSpace& hs, bool use_bnd, std::vector<int
 //      one contiguous row range per workgroup (one workgroup per CU), each range as sliced ELL in the order the workgroup's
 //      threads own the rows, plus the lists of vector entries workgroups exchange every iteration.
 constexpr int kPersistT = 512;        // threads per workgroup
-constexpr int kPersistRmax = 8;       // rows per thread at most
+constexpr int kPersistRmax = 16;      // rows per thread at most
 struct PersistLayout {
-    int G = 0, R = 0, nsl = 0;        // workgroups; rows per thread (1, 2, 4, 8); slices of 64 slots per workgroup = R * T / 64
+    int G = 0, R = 0, nsl = 0;        // workgroups; rows per thread (2, 4, 8, 16); slices of 64 slots per workgroup = R * T / 64.
+                                      // Slots [0, T R / 2): rows that import nothing; [T R / 2, T R): the others
     int64_t n_int = 0;                // interior (non-Dirichlet) rows
     int64_t n_entries = 0;            // ELL entries over all workgroups, padding included
     int64_t nnz = 0;                  // stored off-diagonal entries (no padding)
     int64_t n_board = 0;              // exported vector entries over all workgroups
     int32_t max_imp = 0, max_exp = 0;
     std::vector<int32_t> slot_dof;    // G * S (S = R * T): internal DOF id of the row a slot holds, -1 = empty slot
-    std::vector<int64_t> ell_off;     // G + 1: first ELL entry of a workgroup (multiple of 64)
-    std::vector<int32_t> sl_off;      // G * (nsl + 1): slice offsets inside the workgroup's block, in units of 64 entries
-    std::vector<int32_t> q_int;       // G: the first q_int slices reference no other workgroup's rows
+    std::vector<int64_t> ell_off;     // G + 1: first ELL entry of a workgroup (multiple of 128)
+    std::vector<int32_t> sl_off;      // G * (nsl + 1): slice offsets inside the workgroup's block, in pair rows (128 entries: 64 lanes x 2)
     std::vector<uint16_t> ell_code;   // n_entries: < S: slot of the column's row in this workgroup; >= S: S + index in its import list
     std::vector<int32_t> ell_src;     // n_entries: entry of the full internal pattern holding the value, -1 = padding
     std::vector<int32_t> exp_off;     // G + 1: export list offsets (= board positions)

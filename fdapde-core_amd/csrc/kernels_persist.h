@@ -18,19 +18,20 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "internal.h"
 
 namespace fdapde_hip {
 
 struct PersistArgs {
     int32_t G, nsl, maxit, imp_cap;   // workgroups; slices per workgroup; iteration bound; import slots reserved in LDS
-    int32_t lds_cap;                  // ELL entries of a workgroup that fit its LDS (multiple of 64)
-    int32_t time_phases;              // != 0: workgroup 0 accumulates phase durations into stats
+    int32_t lds_cap;                  // ELL entries staged in LDS by the resident form (multiple of 128; >= the largest block)
+    int32_t time_phases;              // != 0: every workgroup accumulates its phase durations into stats
     double tol2;
     const int32_t* slot_dof;
     const int64_t* ell_off;
     const int32_t* sl_off;
-    const int32_t* q_int;
     const uint16_t* ell_code;
     const double* ell_val;
     const int32_t* exp_off;
@@ -43,7 +44,8 @@ struct PersistArgs {
     double* x;                    // in: initial guess, out: solution (scaled unknowns), internal DOF order
     double* sc;                   // sc[0] = reference norm^2 (in); sc[3] = final r.r (out)
     int32_t* ctl;                 // out: [0] converged, [1] iterations, [2] breakdown, [3] hand-off timeout
-    double* stats;                // [0] iterations timed, [1] SpMV phase, [2] all-gather phase, [3] update phase (10 ns ticks)
+    double* stats;                // per workgroup: [0] iterations timed, [1] operator phase (SpMV + imports), [2] all-gather phase (incl. the
+                                  // wait for the slowest workgroup), [3] update phase -- sums of 10 ns ticks
 };
 
 typedef __attribute__((address_space(1))) unsigned long long pg_u64;
@@ -84,11 +86,18 @@ __device__ __forceinline__ double wave_sum64(double v) {
     return v;
 }
 
-constexpr unsigned kPersistSpinLimit = 1u << 21;
+constexpr long long kPersistTimeoutTicks = 5000000;   // 50 ms of s_memrealtime (100 MHz): a legitimate wait is an iteration's skew, tens of us
 
-template <int R>
+// R rows per thread (2, 4, 8, 16); passes [0, R / 2) hold rows that import nothing, passes [R / 2, R) the others (host_persist.cpp).
+// STREAM = false: the workgroup's whole block of the matrix is staged in LDS once and re-read from there every iteration.
+// STREAM = true : the block streams from global memory every iteration (it is larger than the LDS: systems of a few hundred MB).
+//                 x, r, p still never leave the registers, so an iteration moves the matrix and the exchanged entries of p and
+//                 nothing else -- the multi-launch path moves 7 vector passes on top.  All R / 2 value loads of an entry step are
+//                 issued before the first is used (unconditional loads, clamped to the slice: narrower slices re-read their last
+//                 pair row, which multiplies by zero).
+template <int R, bool STREAM>
 __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
-    constexpr int T = kPersistT, W = T / 64, S = R * T;
+    constexpr int T = kPersistT, W = T / 64, S = R * T, RI = R / 2;
     extern __shared__ double lds[];
     __shared__ double red[W][3];
     __shared__ double tot[3];
@@ -96,26 +105,30 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nsl = a.nsl;
     const int H = a.imp_off[g + 1] - a.imp_off[g], E = a.exp_off[g + 1] - a.exp_off[g];
-    double* p_tab = lds;                                               // [S + imp_cap]
-    double* ev = p_tab + (S + a.imp_cap);                              // [lds_cap]
-    uint16_t* ec = reinterpret_cast<uint16_t*>(ev + a.lds_cap);        // [lds_cap]
-    int32_t* slo = reinterpret_cast<int32_t*>(ec + a.lds_cap);         // [nsl + 1]
-    int32_t* impl = slo + (nsl + 1);                                   // [imp_cap]
-    uint16_t* expl = reinterpret_cast<uint16_t*>(impl + a.imp_cap);    // [E]
+    double* p_tab = lds;                                                                  // [S + imp_cap]
+    double2* ev = reinterpret_cast<double2*>(p_tab + (S + a.imp_cap));                    // [lds_cap / 2] entry pairs (resident form)
+    uint32_t* ec = reinterpret_cast<uint32_t*>(ev + a.lds_cap / 2);                       // [lds_cap / 2] code pairs
+    int32_t* impl = reinterpret_cast<int32_t*>(ec + a.lds_cap / 2);                       // [imp_cap]
+    uint16_t* expl = reinterpret_cast<uint16_t*>(impl + a.imp_cap);                       // [E]
     const int64_t e0 = a.ell_off[g];
-    const double* gv = a.ell_val + e0;
-    const uint16_t* gc = a.ell_code + e0;
-    // ---- stage the workgroup's tables and as much of its matrix slice as fits
-    for (int i = tid; i <= nsl; i += T) slo[i] = a.sl_off[(size_t)g * (nsl + 1) + i];
+    const double2* gv = reinterpret_cast<const double2*>(a.ell_val + e0);
+    const uint32_t* gc = reinterpret_cast<const uint32_t*>(a.ell_code + e0);
+    // ---- stage the workgroup's tables (and, resident form, its block of the matrix)
     for (int i = tid; i < H; i += T) impl[i] = a.imp_pos[a.imp_off[g] + i];
     for (int i = tid; i < E; i += T) expl[i] = a.exp_slot[a.exp_off[g] + i];
     if (tid == 0) fail_flag = 0;
-    __syncthreads();
-    int q_res = 0;   // slices [0, q_res) are read from LDS
-    while (q_res < nsl && slo[q_res + 1] * 64 <= a.lds_cap) ++q_res;
-    const int n_res = slo[q_res] * 64;
-    for (int i = tid; i < n_res; i += T) ev[i] = gv[i], ec[i] = gc[i];
-    const int q_int = a.q_int[g];
+    const int32_t* slo = a.sl_off + (size_t)g * (nsl + 1);
+    if constexpr (!STREAM) {
+        const int n_pairs = slo[nsl] * 64;
+        for (int i = tid; i < n_pairs; i += T) ev[i] = gv[i], ec[i] = gc[i];
+    }
+    // slices of this wavefront: pass j -> slice j * W + wave, pair rows [o0[j], o0[j] + w[j]) (wave-uniform: scalar registers)
+    int o0[R], w[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        o0[j] = __builtin_amdgcn_readfirstlane(slo[j * W + wave]);
+        w[j] = __builtin_amdgcn_readfirstlane(slo[j * W + wave + 1]) - o0[j];
+    }
     // ---- the rows of this thread: slot j * T + tid, j < R
     double xv[R], rv[R], pv[R];
     int32_t dof[R];
@@ -130,10 +143,11 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
         rr_part += rv[j] * rv[j];
     }
     const double bb = a.sc[0];
-    const bool stamper = a.time_phases && g == 0 && tid == 0;
+    const bool stamper = a.time_phases && tid == 0;   // every workgroup stamps its own phases (a few s_memrealtime per iteration)
     long long t_spmv = 0, t_gather = 0, t_update = 0, n_stamped = 0;
     int it = 0, status = 0;   // status: 1 converged, 2 breakdown, 3 hand-off timeout
     double rr = 0;
+    __syncthreads();
     for (;;) {
         const unsigned epoch = (unsigned)it + 1u;
         long long c0 = 0, c1 = 0, c2 = 0;
@@ -143,34 +157,33 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
         for (int j = 0; j < R; ++j) p_tab[j * T + tid] = pv[j];
         __syncthreads();
         for (int i = tid; i < E; i += T) publish_f64(a.pboard + 2 * (size_t)(a.exp_off[g] + i), epoch, p_tab[expl[i]]);
-        // ---- y = (I + At_offdiag) p: slices without imports first, the others once the neighbours' entries have arrived
+        // ---- y = (I + At_offdiag) p: the passes without imports first, the others once the neighbours' entries have arrived
         double yv[R];
-        auto row_product = [&](int j) {
-            const int q = j * W + wave;
-            const int o0 = slo[q], o1 = slo[q + 1];
-            double acc0 = pv[j], acc1 = 0;
-            if (q < q_res) {
-                int e = o0;
-                for (; e + 1 < o1; e += 2) {
-                    const int i0 = e * 64 + lane, i1 = i0 + 64;
-                    acc0 += ev[i0] * p_tab[ec[i0]];
-                    acc1 += ev[i1] * p_tab[ec[i1]];
-                }
-                if (e < o1) acc0 += ev[e * 64 + lane] * p_tab[ec[e * 64 + lane]];
-            } else {
-                int e = o0;
-                for (; e + 1 < o1; e += 2) {
-                    const int i0 = e * 64 + lane, i1 = i0 + 64;
-                    acc0 += gv[i0] * p_tab[gc[i0]];
-                    acc1 += gv[i1] * p_tab[gc[i1]];
-                }
-                if (e < o1) acc0 += gv[e * 64 + lane] * p_tab[gc[e * 64 + lane]];
-            }
-            yv[j] = acc0 + acc1;
-        };
 #pragma unroll
-        for (int j = 0; j < R; ++j)
-            if (j * W + wave < q_int) row_product(j);
+        for (int j = 0; j < R; ++j) yv[j] = pv[j];   // unit diagonal of the scaled system
+        auto product = [&](auto phase) {
+            constexpr int J0 = decltype(phase)::value ? RI : 0, J1 = decltype(phase)::value ? R : RI;
+            int mw = 0;
+#pragma unroll
+            for (int j = J0; j < J1; ++j) mw = max(mw, w[j]);
+            for (int e = 0; e < mw; ++e) {
+                double2 v[J1 - J0];
+                uint32_t c[J1 - J0];
+#pragma unroll
+                for (int j = J0; j < J1; ++j) {
+                    const int ee = min(e, max(w[j] - 1, 0));
+                    const int idx = (o0[j] + ee) * 64 + lane;
+                    if constexpr (STREAM) v[j - J0] = gv[idx], c[j - J0] = gc[idx];
+                    else v[j - J0] = ev[idx], c[j - J0] = ec[idx];
+                }
+#pragma unroll
+                for (int j = J0; j < J1; ++j) {
+                    const double t = v[j - J0].x * p_tab[c[j - J0] & 0xffffu] + v[j - J0].y * p_tab[c[j - J0] >> 16];
+                    yv[j] += e < w[j] ? t : 0.0;
+                }
+            }
+        };
+        product(std::integral_constant<int, 0>{});
         {   // imports: a lane re-reads its granule pair until both halves carry this iteration's tag; lanes that have theirs stop loading
             bool fail = false;
             for (int h0 = wave * 64; h0 < H; h0 += T) {   // wave-uniform trip count
@@ -178,13 +191,17 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
                 const unsigned long long* gp = a.pboard + 2 * (size_t)(h < H ? impl[h] : impl[0]);
                 pg_v2u64 v = {0, 0};
                 bool done = h >= H;
-                unsigned spins = 0;
-                for (;;) {
+                long long t_wait = 0;
+                for (unsigned spins = 0;; ++spins) {
                     if (!done) v = granule_load2(gp), done = granule_pair_ok(v, epoch);
                     if (__all(done)) break;
-                    if (++spins > kPersistSpinLimit) {
-                        fail = true;
-                        break;
+                    if ((spins & 63u) == 63u) {   // bounded by time, checked now and then
+                        const long long now = wall_clock64();
+                        if (t_wait == 0) t_wait = now;
+                        else if (now - t_wait > kPersistTimeoutTicks) {
+                            fail = true;
+                            break;
+                        }
                     }
                     __builtin_amdgcn_s_sleep(2);
                 }
@@ -198,9 +215,7 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
             status = 3;
             break;
         }
-#pragma unroll
-        for (int j = 0; j < R; ++j)
-            if (j * W + wave >= q_int) row_product(j);
+        product(std::integral_constant<int, 1>{});
         if (stamper) c1 = wall_clock64();
         // ---- partials of p.y, y.y and of the explicit r.r; one all-gather over the workgroups
         double s0 = 0, s1 = 0;
@@ -214,45 +229,49 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
         if (tid < 3) {
             double v = 0;
 #pragma unroll
-            for (int w = 0; w < W; ++w) v += red[w][tid];
+            for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
             publish_f64(dslot + (size_t)g * 6 + 2 * tid, epoch, v);
         }
         {   // thread t collects workgroup t's three sums (a lane re-reads its record until all six tags match, then stops loading); every
             // workgroup adds the G records in the same order.  A two-level form (groups of 8 / 16 / 32 workgroups handled by one wavefront,
             // then the group sums) was measured and dropped: a granule hop costs ~4 us under this load, two of them 7.9 / 9.8 / 12.0 us
             // against 4.6 us for the flat sweep on C2 (246 workgroups)
-        double v0 = 0, v1 = 0, v2 = 0;
-        bool fail = false;
-        if (wave * 64 < a.G) {   // wave-uniform
-            const unsigned long long* gp = dslot + (size_t)(tid < a.G ? tid : 0) * 6;
-            pg_v2u64 q0 = {0, 0}, q1 = {0, 0}, q2 = {0, 0};
-            bool done = tid >= a.G;
-            unsigned spins = 0;
-            for (;;) {
-                if (!done) {
-                    granule_load6(gp, q0, q1, q2);
-                    done = granule_pair_ok(q0, epoch) && granule_pair_ok(q1, epoch) && granule_pair_ok(q2, epoch);
+            double v0 = 0, v1 = 0, v2 = 0;
+            bool fail = false;
+            if (wave * 64 < a.G) {   // wave-uniform
+                const unsigned long long* gp = dslot + (size_t)(tid < a.G ? tid : 0) * 6;
+                pg_v2u64 q0 = {0, 0}, q1 = {0, 0}, q2 = {0, 0};
+                bool done = tid >= a.G;
+                long long t_wait = 0;
+                for (unsigned spins = 0;; ++spins) {
+                    if (!done) {
+                        granule_load6(gp, q0, q1, q2);
+                        done = granule_pair_ok(q0, epoch) && granule_pair_ok(q1, epoch) && granule_pair_ok(q2, epoch);
+                    }
+                    if (__all(done)) break;
+                    if ((spins & 63u) == 63u) {
+                        const long long now = wall_clock64();
+                        if (t_wait == 0) t_wait = now;
+                        else if (now - t_wait > kPersistTimeoutTicks) {
+                            fail = true;
+                            break;
+                        }
+                    }
+                    __builtin_amdgcn_s_sleep(2);
                 }
-                if (__all(done)) break;
-                if (++spins > kPersistSpinLimit) {
-                    fail = true;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
+                if (tid < a.G) v0 = granule_pair_f64(q0), v1 = granule_pair_f64(q1), v2 = granule_pair_f64(q2);
             }
-            if (tid < a.G) v0 = granule_pair_f64(q0), v1 = granule_pair_f64(q1), v2 = granule_pair_f64(q2);
-        }
-        if (fail && lane == 0) fail_flag = 1;
-        v0 = wave_sum64(v0), v1 = wave_sum64(v1), v2 = wave_sum64(v2);
-        __syncthreads();   // the partials in red have been consumed
-        if (lane == 0) red[wave][0] = v0, red[wave][1] = v1, red[wave][2] = v2;
-        __syncthreads();
-        if (tid < 3) {
-            double v = 0;
+            if (fail && lane == 0) fail_flag = 1;
+            v0 = wave_sum64(v0), v1 = wave_sum64(v1), v2 = wave_sum64(v2);
+            __syncthreads();   // the partials in red have been consumed
+            if (lane == 0) red[wave][0] = v0, red[wave][1] = v1, red[wave][2] = v2;
+            __syncthreads();
+            if (tid < 3) {
+                double v = 0;
 #pragma unroll
-            for (int w = 0; w < W; ++w) v += red[w][tid];
-            tot[tid] = v;
-        }
+                for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
+                tot[tid] = v;
+            }
         }
         __syncthreads();
         if (fail_flag) {
@@ -297,7 +316,10 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
     if (g == 0 && tid == 0) {
         a.sc[3] = rr;
         a.ctl[0] = status == 1 ? 1 : 0, a.ctl[1] = it, a.ctl[2] = status == 2 ? 1 : 0;
-        if (a.time_phases) a.stats[0] = (double)n_stamped, a.stats[1] = (double)t_spmv, a.stats[2] = (double)t_gather, a.stats[3] = (double)t_update;
+    }
+    if (stamper) {
+        double* st = a.stats + 4 * (size_t)g;
+        st[0] = (double)n_stamped, st[1] = (double)t_spmv, st[2] = (double)t_gather, st[3] = (double)t_update;
     }
     if (status == 3 && tid == 0) atomicExch(a.ctl + 3, 1);
 }

@@ -87,10 +87,13 @@ typedef struct {
     double spmv_avg_ms;   /* average duration of the SpMV launches timed inside the last solve (0 if none) */
     int32_t spmv_timed;   /* how many launches that average covers */
     int32_t method_used;  /* the FDAPDE_SOLVER_* that ran */
-    int32_t persistent;   /* 1: the solve ran as ONE launch (small systems: matrix resident in LDS, in-kernel hand-offs); spmv_avg_ms
-                             is then the operator-application phase (SpMV + neighbour import) stamped inside the kernel */
-    double gather_avg_ms; /* persistent path: average all-gather phase (dot products) per iteration */
-    double update_avg_ms; /* persistent path: average vector update phase per iteration */
+    int32_t persistent;   /* 1: the solve ran as ONE persistent launch (x, r, p in registers, in-kernel hand-offs; matrix resident in LDS or
+                             streamed once per iteration).  spmv_avg_ms is then the operator-application phase (SpMV + neighbour
+                             import) stamped inside the kernel: the average, over the iterations, of the SLOWEST workgroup's phase */
+    double gather_avg_ms; /* persistent path: all-gather phase of the dot products per iteration (mean over workgroups; contains
+                             their wait for the slowest workgroup's operator phase) */
+    double update_avg_ms; /* persistent path: vector update phase per iteration (mean over workgroups) */
+    double spmv_mean_ms;  /* persistent path: operator-application phase, mean over workgroups */
 } fdapde_info;
 
 typedef struct fdapde_ctx fdapde_ctx;

@@ -100,11 +100,11 @@ static int check_persist(const HostSpace& hs, bool use_bnd, int n_wg) {
                 const int s = q * 64 + l;
                 const int32_t d = pl.slot_dof[(size_t)g * S + s];
                 double acc = tab[(size_t)s];
-                for (int32_t e = slo[q]; e < slo[q + 1]; ++e) {
-                    const int64_t at = pl.ell_off[(size_t)g] + (int64_t)e * 64 + l;
+                for (int32_t e = 2 * slo[q]; e < 2 * slo[q + 1]; ++e) {
+                    const int64_t at = pl.ell_off[(size_t)g] + (int64_t)(e / 2) * 128 + 2 * l + (e & 1);
                     const uint16_t code = pl.ell_code[(size_t)at];
                     if (code >= S + H) return -1;
-                    if (q < pl.q_int[(size_t)g] && code >= S && pl.ell_src[(size_t)at] >= 0) return -1;   // "no import" slices must not import
+                    if (q < nsl / 2 && code >= S && pl.ell_src[(size_t)at] >= 0) return -1;   // "no import" slices must not import
                     acc += (pl.ell_src[(size_t)at] >= 0 ? val(pl.ell_src[(size_t)at]) : 0.0) * tab[code];
                 }
                 if (d >= 0) {

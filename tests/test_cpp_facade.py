@@ -26,8 +26,7 @@ def test_facade_compiles_and_refuses_to_run_without_a_device():
 
 @pytest.mark.gpu
 def test_reference_fem_pde_cases_through_the_cpp_facade():
-    if not os.path.exists(EXE):
-        _build()
+    _build()   # make: rebuilt whenever a header of the facade or the C ABI changed
     r = subprocess.run([EXE, os.path.join(ROOT, "tests", "golden", "mesh")], capture_output=True, text=True, timeout=600)
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr

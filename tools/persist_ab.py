@@ -25,5 +25,5 @@ for dim, nx in cases:
         i = best
         print(f"dim {dim} nx {nx} dofs {nd} persist={knob} ran_persistent={i.persistent}: solve {i.t_solve_ms:.2f} ms, {i.iters} it, "
               f"{1e3 * i.t_solve_ms / max(i.iters, 1):.2f} us/it | operator phase {1e3 * i.spmv_avg_ms:.2f} us = {alg / max(i.spmv_avg_ms * 1e-3, 1e-12) / 1e9:.0f} GB/s algorithmic"
-              + (f" | gather {1e3 * i.gather_avg_ms:.2f} us update {1e3 * i.update_avg_ms:.2f} us" if i.persistent else ""), flush=True)
+              + (f" (mean over workgroups {1e3 * i.spmv_mean_ms:.2f} us) | gather {1e3 * i.gather_avg_ms:.2f} us update {1e3 * i.update_avg_ms:.2f} us" if i.persistent else ""), flush=True)
     c.close()

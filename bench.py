@@ -200,7 +200,11 @@ def main():
     try:
         pj = json.load(open(os.path.join(ROOT, "profiles", "spmv_pmc.json")))
         if world == 1 and pj.get("nx") == args.nx:
-            traffic = pj.get("hbm_bytes_per_launch")
+            if getattr(info, "persistent", 0) and pj.get("persist_hbm_bytes_per_solve"):
+                # one dispatch per solve: counter bytes of the whole launch / iterations (the operator application is all it streams)
+                traffic = pj["persist_hbm_bytes_per_solve"] / max(int(pj.get("persist_iterations", info.iters)), 1)
+            elif not getattr(info, "persistent", 0):
+                traffic = pj.get("hbm_bytes_per_launch")
             traffic_source = "profiles/spmv_pmc.json (rocprofv3 --pmc passes of an earlier run of this workload; not this run)"
     except Exception:
         pass

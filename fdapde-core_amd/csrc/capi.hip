@@ -270,7 +270,57 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
     } else {
         if (a.vals) HIPCHK(c, hipMemsetAsync(a.vals, 0, sizeof(double) * (size_t)hs.nnz, c->stream));
         if (a.force) HIPCHK(c, hipMemsetAsync(a.force, 0, sizeof(double) * (size_t)hs.n_dofs, c->stream));
-        if (assembly == FDAPDE_ASSEMBLY_ATOMIC) {
+        if (assembly == FDAPDE_ASSEMBLY_PARTITIONED) {
+            if (!c->part_ready) {   // partitions of 2048 cells, local colours, shared-row flags, slot map (host index work, once)
+                CellPartitions cp;
+                int cells = 2048;   // measured on C3: 2048 cells 5.4 ms (58 % of the rows shared -> atomics); see tools/asm_ab.py for larger ones
+                if (const char* e = std::getenv("FDAPDE_PART_CELLS")) cells = std::atoi(e);
+                if (int rc = host_build_cell_partitions(hs, cells, cp, c->err)) return rc;
+                HIPCHK(c, c->part_cells.upload(cp.cell_list.data(), cp.cell_list.size(), c->stream));
+                HIPCHK(c, c->part_off.upload(cp.colour_off.data(), cp.colour_off.size(), c->stream));
+                HIPCHK(c, c->part_slots.upload(cp.slot_map.data(), cp.slot_map.size(), c->stream));
+                HIPCHK(c, c->part_shared.upload(cp.dof_shared.data(), cp.dof_shared.size(), c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                c->part_colours = cp.max_colours, c->n_parts = cp.n_parts, c->part_ready = true;
+            }
+            int opk = 0;
+            if (!op.needs_rows) opk = 3;
+            if (op.n == 1 && op.t[0].kind == FDAPDE_LAPLACIAN) opk = 1;
+            if (op.n == 1 && op.t[0].kind == FDAPDE_REACTION && !op.t[0].space_varying) opk = 2;
+            const size_t lds = sizeof(DevTables) + (opk == 3 ? sizeof(DevRefTensors) : 0);
+#define PART_GO(K_)                                                                                                            \
+    hipLaunchKernelGGL((k_assemble_part<M, R, K_>), dim3((unsigned)c->n_parts), dim3(256), lds, c->stream, a, op, c->part_cells.p, \
+                       c->part_off.p, c->part_colours, c->part_shared.p, c->part_slots.p)
+            if (opk == 3) PART_GO(3);
+            else if (opk == 1) PART_GO(1);
+            else if (opk == 2) PART_GO(2);
+            else PART_GO(0);
+#undef PART_GO
+        } else if (assembly == FDAPDE_ASSEMBLY_WAVE) {
+            if constexpr (R != 1) {
+                return fail(c, FDAPDE_EUNSUPPORTED, "the wavefront-per-element assembly exists for P1 only");
+            } else {
+                if (!c->colour_ready) {
+                    int rc = host_build_colouring(c->hs, c->err);
+                    if (rc) return rc;
+                    HIPCHK(c, c->colour_cells.upload(hs.colour_cells.data(), hs.colour_cells.size(), c->stream));
+                    c->colour_ready = true;
+                }
+                if (!c->wave_ready) {
+                    std::vector<int32_t> sm;
+                    host_build_slot_map(hs, hs.colour_cells.data(), hs.n_cells, sm);
+                    HIPCHK(c, c->wave_slots.upload(sm.data(), sm.size(), c->stream));
+                    HIPCHK(c, hipStreamSynchronize(c->stream));
+                    c->wave_ready = true;
+                }
+                for (int k = 0; k < hs.n_colours; ++k) {
+                    const int64_t o0 = hs.colour_off[(size_t)k], cnt = hs.colour_off[(size_t)k + 1] - o0;
+                    if (cnt == 0) continue;
+                    hipLaunchKernelGGL((k_assemble_wave<M>), dim3((unsigned)((cnt + 3) / 4)), dim3(256), sizeof(DevTables), c->stream, a, op,
+                                       c->colour_cells.p + o0, c->wave_slots.p + (size_t)o0 * NB * NB, cnt);
+                }
+            }
+        } else if (assembly == FDAPDE_ASSEMBLY_ATOMIC) {
             const int64_t work = hs.n_cells * NB;
             hipLaunchKernelGGL((k_assemble_scatter<M, R, true>), dim3((unsigned)((work + 255) / 256)), dim3(256),
                                sizeof(DevTables), c->stream, a, op, (const int32_t*)nullptr, hs.n_cells);
@@ -296,7 +346,7 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
 
 int launch_assembly(fdapde_ctx* c, const AsmArgs& a, const DevOp& op, int assembly) {
     const int M = c->hs.M, R = c->hs.order;
-    if (assembly < 0 || assembly > 2) return fail(c, FDAPDE_EINVAL, "unknown assembly variant");
+    if (assembly < 0 || assembly > 4) return fail(c, FDAPDE_EINVAL, "unknown assembly variant");
     if (M == 2 && R == 1) return launch_assembly_t<2, 1>(c, a, op, assembly);
     if (M == 2 && R == 2) return launch_assembly_t<2, 2>(c, a, op, assembly);
     if (M == 3 && R == 1) return launch_assembly_t<3, 1>(c, a, op, assembly);
@@ -572,6 +622,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
         c->halo_inv.release(), c->if_slot.release();
         if (c->comm) (void)g_rccl.CommDestroy(c->comm);
         c->lin_mat.release(), c->persist_stats.release();
+        c->part_cells.release(), c->part_off.release(), c->part_slots.release(), c->wave_slots.release(), c->part_shared.release();
         for (auto& ps : c->ps)
             ps.slot_dof.release(), ps.sl_off.release(), ps.ell_src.release(), ps.exp_off.release(), ps.imp_off.release(),
               ps.imp_pos.release(), ps.ell_off.release(), ps.ell_code.release(), ps.exp_slot.release(), ps.ell_val.release(), ps.board.release();
@@ -602,7 +653,7 @@ int fdapde_mesh_upload(fdapde_ctx* c, int M, int N, int64_t n_nodes, const doubl
 int fdapde_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs) {
     if (!c) return FDAPDE_EINVAL;
     auto t0 = std::chrono::steady_clock::now();
-    c->space_ready = c->dev_ready = c->colour_ready = c->fq_blk_ready = false;
+    c->space_ready = c->dev_ready = c->colour_ready = c->fq_blk_ready = c->part_ready = c->wave_ready = false;
     c->assembled[0] = c->assembled[1] = c->force_ready = c->solved = c->dirichlet_applied = false;
     c->op.clear(), c->coef_of_op = false, c->fq_i.clear(), c->fq_cols = 0, c->g_i.clear(), c->have_g = false;
     c->halo_ready = false, c->lin_ready = false, c->sp_built[0] = c->sp_built[1] = false, c->sp_cur = -1;

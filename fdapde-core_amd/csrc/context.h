@@ -230,6 +230,12 @@ struct fdapde_ctx {
         bool filled = false;                 // ell_val holds the currently scaled system
     } ps[2];
     DBuf<double> persist_stats;
+    // element-wise scatter forms of the assembly (built on first use)
+    bool part_ready = false, wave_ready = false;
+    int32_t part_colours = 0;
+    int64_t n_parts = 0;
+    DBuf<int32_t> part_cells, part_off, part_slots, wave_slots;
+    DBuf<uint8_t> part_shared;
     std::vector<double> persist_host_stats;
 };
 

@@ -119,6 +119,18 @@ int host_build_solver_pattern(const HostSpace& hs, bool use_bnd, std::vector<int
                               std::vector<int32_t>& full2s);
 
 
+// ---- element-wise scatter forms of the assembly (host_partition.cpp)
+struct CellPartitions {
+    int32_t cells_per_part = 0, max_colours = 0;
+    int64_t n_parts = 0;
+    std::vector<int32_t> cell_list;    // n_cells: internal cell ids ordered by (partition, colour inside the partition)
+    std::vector<int32_t> colour_off;   // n_parts * (max_colours + 1): positions in cell_list where a partition's colours start
+    std::vector<uint8_t> dof_shared;   // n_dofs: 1 = cells of two or more partitions touch this DOF (its row needs atomics)
+    std::vector<int32_t> slot_map;     // n_cells * nb * nb: CSR slot of entry (i, j) of the cell at each list position
+};
+int host_build_cell_partitions(const HostSpace& hs, int cells_per_part, CellPartitions& cp, std::string& err);
+void host_build_slot_map(const HostSpace& hs, const int32_t* list, int64_t n, std::vector<int32_t>& out);
+
 // ---- resident layout of the persistent small-problem CG (kernels_persist.h): the interior block of the scaled system cut into
 //      one contiguous row range per workgroup (one workgroup per CU), each range as sliced ELL in the order the workgroup's
 //      threads own the rows, plus the lists of vector entries workgroups exchange every iteration.

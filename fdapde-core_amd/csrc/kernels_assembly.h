@@ -541,6 +541,92 @@ __global__ __launch_bounds__(256) void k_assemble_scatter(AsmArgs a, DevOp op, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The north-star scatter forms (BASELINE.json: "one wavefront per element ... scatter into a CSR global matrix via
+// colour-partitioned passes (atomics only at colour boundaries)"), written out properly and TIMED against the row-owner sweep
+// (tools/asm_ab.py -> profiles/r2_asm_ab.json).  Both stream the element -> CSR slot map instead of searching for slots.
+//
+// k_assemble_part: one workgroup per cell partition (a contiguous chunk of the Morton cell order).  The partition's cells are
+//   listed colour by colour (cells of a colour share no DOF); the workgroup walks its colours with a barrier in between, lane =
+//   (cell, local row), and adds its row of the element matrix with plain read-modify-writes -- except in rows that cells of
+//   another partition touch as well (dof_shared), where it uses fp64 atomics: atomics only on partition boundaries.  The rule
+//   is per ROW, so every contribution to one matrix entry takes the same path (an atomic executes at the memory side and would
+//   not be seen by a neighbour's cached read-modify-write).  One launch; vals / force zeroed by the caller.
+// ---------------------------------------------------------------------------------------------------------------
+template <int M, int R, int OPK>
+__global__ __launch_bounds__(256) void k_assemble_part(AsmArgs a, DevOp op, const int32_t* cell_list, const int32_t* colour_off,
+                                                        int max_colours, const uint8_t* dof_shared, const int32_t* slot_map) {
+    constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
+    extern __shared__ double lds[];
+    const DevTables* tb = stage_tables(a.tables, lds);
+    const DevRefTensors* rt = nullptr;
+    if constexpr (OPK == 3) {
+        const double* src = reinterpret_cast<const double*>(a.reftab);
+        for (int i = threadIdx.x; i < kRefDoubles; i += blockDim.x) lds[kTablesDoubles + i] = src[i];
+        rt = reinterpret_cast<const DevRefTensors*>(lds + kTablesDoubles);
+    }
+    __syncthreads();
+    const int32_t* off = colour_off + (int64_t)blockIdx.x * (max_colours + 1);
+    for (int c = 0; c < max_colours; ++c) {
+        const int32_t o0 = off[c], o1 = off[c + 1];
+        for (int idx = threadIdx.x; idx < (o1 - o0) * NB; idx += 256) {
+            const int64_t li = o0 + idx / NB;
+            const int il = idx % NB;
+            const int cell = cell_list[li];
+            const int32_t row = a.cdofs[(int64_t)cell * NB + il];
+            const bool shared = dof_shared[row] != 0;
+            const int32_t* sm = slot_map + (li * NB + il) * NB;
+            Geo<M> g;
+            cell_geometry<M>(a, cell, g);
+            const double f = element_row<M, R, OPK>(a, op, tb, g, cell, il, a.vals != nullptr, [&](int j, double value) {
+                double* dst = a.vals + sm[j];
+                if (shared) unsafeAtomicAdd(dst, value);
+                else *dst += value;
+            }, rt);
+            if (a.force != nullptr) {
+                if (shared) unsafeAtomicAdd(&a.force[row], f);
+                else a.force[row] += f;
+            }
+        }
+        __syncthreads();   // the next colour may touch the rows this one has just written
+    }
+}
+
+// k_assemble_wave: the literal form -- ONE WAVEFRONT PER ELEMENT, lane = (i, j, q): the 64 (test, trial, quadrature node) triples
+//   of a 3-D P1 element (27 of a 2-D one).  Every lane evaluates the weak form at its quadrature node, the nodes are summed across
+//   lanes, the lanes with q = 0 add their entry through the streamed slot map.  Launched once per colour over colour-contiguous
+//   cell lists (cells of a colour share no DOF: plain read-modify-write, no atomics).  P1 only (a P2 element has 500+ triples).
+template <int M>
+__global__ __launch_bounds__(256) void k_assemble_wave(AsmArgs a, DevOp op, const int32_t* cell_list, const int32_t* slot_map,
+                                                        int64_t n_list) {
+    constexpr int NB = M + 1, NQ = (M == 2) ? 3 : 4;
+    extern __shared__ double lds[];
+    const DevTables* tb = stage_tables(a.tables, lds);
+    __syncthreads();
+    const int64_t li = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // one wavefront per element
+    if (li >= n_list) return;
+    const int lane = threadIdx.x & 63, q = lane & 3, ij = lane >> 2, i = ij / NB, j = ij - i * NB;
+    const bool live = ij < NB * NB && q < NQ;
+    const int cell = cell_list[li];
+    Geo<M> g;
+    cell_geometry<M>(a, cell, g);   // the same addresses in every lane: one broadcast fetch per vertex
+    double v = 0, fv = 0;
+    if (live) {
+        double gi[M], gj[M];
+        phys_grad<M>(g, &tb->dpsi[(i * NQ + q) * 3], gi);
+        phys_grad<M>(g, &tb->dpsi[(j * NQ + q) * 3], gj);
+        const int64_t qrow = (int64_t)NQ * cell + q;
+        v = weak_form<M>(op, qrow, tb->psi[i * NQ + q], tb->psi[j * NQ + q], gi, gj) * tb->qw[q];
+        if (a.fq != nullptr && j == 0) fv = (a.fq[qrow] * tb->psi[i * NQ + q]) * tb->qw[q];
+    }
+    v += __shfl_xor(v, 1), v += __shfl_xor(v, 2);       // sum over the quadrature nodes (lanes 4 k .. 4 k + 3)
+    fv += __shfl_xor(fv, 1), fv += __shfl_xor(fv, 2);
+    if (live && q == 0) {
+        if (a.vals != nullptr) a.vals[slot_map[(li * NB + i) * NB + j]] += v * g.measure;
+        if (a.force != nullptr && j == 0) a.force[a.cdofs[(int64_t)cell * NB + i]] += fv * g.measure;
+    }
+}
+
 // Integrator::quadrature_nodes (integrator.h:109-121): out row nq*cell_ext + q = J p_q + x0, column-major rows x N
 template <int M>
 __global__ void k_quadrature_nodes(AsmArgs a, const int32_t* cell_i2e, int nq, double* out) {

@@ -64,7 +64,13 @@ typedef struct {
 /* CG_FUSED: the SpMV carries p.Ap and Ap.Ap, ONE kernel then updates x, r, p: alpha from the explicit r.r, beta from the
  * estimate alpha^2 Ap.Ap - r.r (only the search direction sees the estimate); two launches per iteration, single GPU */
 enum { FDAPDE_SOLVER_AUTO = 0, FDAPDE_SOLVER_CG = 1, FDAPDE_SOLVER_BICGSTAB = 2, FDAPDE_SOLVER_CG_SR = 3, FDAPDE_SOLVER_CG_FUSED = 4 };
-enum { FDAPDE_ASSEMBLY_ROWS = 0, FDAPDE_ASSEMBLY_ATOMIC = 1, FDAPDE_ASSEMBLY_COLOURED = 2 };
+/* ROWS: row-owner sweep (default; no atomics, bitwise reproducible).  The others are element-wise scatter forms kept as measured
+ * alternatives and cross-checks: ATOMIC / COLOURED = lane per (cell, row) with a slot search, fp64 atomics / one launch per colour;
+ * PARTITIONED = one workgroup per cell partition, colours walked inside the workgroup, atomics only on rows shared between
+ * partitions, slot map streamed; WAVE = one wavefront per element, lane = (i, j, quadrature node), one launch per colour, slot map
+ * streamed (P1 only). */
+enum { FDAPDE_ASSEMBLY_ROWS = 0, FDAPDE_ASSEMBLY_ATOMIC = 1, FDAPDE_ASSEMBLY_COLOURED = 2, FDAPDE_ASSEMBLY_PARTITIONED = 3,
+       FDAPDE_ASSEMBLY_WAVE = 4 };
 enum { FDAPDE_MAT_STIFF = 0, FDAPDE_MAT_MASS = 1 };
 
 typedef struct {

@@ -148,7 +148,7 @@ def test_fullsize_properties(env, config):
     a0 = A.data.copy()
     ctx.assemble_operator(capi.MAT_STIFF, -capi.laplacian(), capi.ASSEMBLY_ROWS)
     assert np.array_equal(ctx.matrix_values(capi.MAT_STIFF), a0)        # reproducible bits
-    for variant in (capi.ASSEMBLY_ATOMIC, capi.ASSEMBLY_COLOURED):
+    for variant in (capi.ASSEMBLY_ATOMIC, capi.ASSEMBLY_COLOURED, capi.ASSEMBLY_PARTITIONED) + ((capi.ASSEMBLY_WAVE,) if order == 1 else ()):
         ctx.assemble_operator(capi.MAT_STIFF, -capi.laplacian(), variant)
         assert np.abs(ctx.matrix_values(capi.MAT_STIFF) - a0).max() <= 1e-12 * scale
     # full solve against the analytic solution

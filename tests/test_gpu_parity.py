@@ -71,13 +71,16 @@ def test_space_is_bit_exact(capi, ctx, oracle, mesh_loader, mesh_name, order):
 
 
 @pytest.mark.parametrize("mesh_name,order", CASES)
-@pytest.mark.parametrize("variant", ["rows", "atomic", "coloured"])
+@pytest.mark.parametrize("variant", ["rows", "atomic", "coloured", "partitioned", "wave"])
 def test_operator_assembly_matches_oracle(capi, ctx, oracle, mesh_loader, mesh_name, order, variant):
+    if variant == "wave" and order != 1:
+        pytest.skip("the wavefront-per-element form exists for P1 only (a P2 element has 500+ (i, j, q) triples)")
     m = mesh_loader(mesh_name)
     ctx.mesh_upload(m.nodes, m.cells, m.boundary)
     nd = ctx.dofs_build(order)
     od, _, _, _ = oracle.enumerate_dofs(m, order)
-    assembly = {"rows": capi.ASSEMBLY_ROWS, "atomic": capi.ASSEMBLY_ATOMIC, "coloured": capi.ASSEMBLY_COLOURED}[variant]
+    assembly = {"rows": capi.ASSEMBLY_ROWS, "atomic": capi.ASSEMBLY_ATOMIC, "coloured": capi.ASSEMBLY_COLOURED,
+                "partitioned": capi.ASSEMBLY_PARTITIONED, "wave": capi.ASSEMBLY_WAVE}[variant]
     for name in _ops(capi, m.M):
         ctx.assemble_operator(capi.MAT_STIFF, _ops(capi, m.M)[name], assembly)
         got = ctx.matrix_values(capi.MAT_STIFF)

@@ -38,7 +38,7 @@ def main(out):
             acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
         print(f"== {sub} (average per dispatch) ==")
         for k, cs in sorted(acc.items()):
-            if not any(s in k for s in ("k_spmv", "k_cg", "k_assemble", "k_bicg", "k_scale")):
+            if not any(s in k for s in ("k_spmv", "k_cg", "k_assemble", "k_bicg", "k_scale", "k_persist")):
                 continue
             print(f"{k[:60]:60s} " + "  ".join(f"{c}={sum(v)/len(v):.4g} (n={len(v)})" for c, v in sorted(cs.items())))
 
@@ -62,6 +62,21 @@ def pmc_json(out):
             v = [x for x in v if x > 1000.0]
             if v:
                 res[ctr + "_KB"] = sum(v) / len(v)
+    # the persistent single-launch CG: one dispatch per solve; traffic per solve (bench.py divides by its iteration count)
+    if kt:
+        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kt)) if "k_cg_persist" in r["Kernel_Name"]]
+        if d:
+            res["persist_trace_avg_us"] = sum(d) / len(d)
+            res["persist_trace_calls"] = len(d)
+    for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        f = find(os.path.join(out, sub), "*counter_collection.csv")
+        if f:
+            v = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "k_cg_persist" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+            if v:
+                res["persist_" + ctr + "_KB"] = sum(v) / len(v)
+    if "persist_FETCH_SIZE_KB" in res and "persist_WRITE_SIZE_KB" in res:
+        res["persist_hbm_bytes_per_solve"] = (2.0 * res["persist_FETCH_SIZE_KB"] + res["persist_WRITE_SIZE_KB"]) * 1024.0
+        res["correction"] = "2 x FETCH_SIZE + WRITE_SIZE (KB x 1024), separate --pmc passes"
     if "FETCH_SIZE_KB" in res and "WRITE_SIZE_KB" in res:
         # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reads 1/2 of the bytes of wide coalesced reads; WRITE_SIZE exact
         res["hbm_bytes_per_launch"] = (2.0 * res["FETCH_SIZE_KB"] + res["WRITE_SIZE_KB"]) * 1024.0

@@ -47,7 +47,7 @@ SYMBOLS = [
     "fdapde_info_get", "fdapde_spmv", "fdapde_bench_spmv", "fdapde_tune", "fdapde_stream", "fdapde_synchronize",
     "fdapde_comm_unique_id", "fdapde_comm_init", "fdapde_halo_setup", "fdapde_solve_parabolic",
     "fdapde_lin_compute", "fdapde_lin_solve", "fdapde_eval_pointwise", "fdapde_cell_integrals", "fdapde_comm_init_callback",
-    "fdapde_solver_layout",
+    "fdapde_solver_layout", "fdapde_topology_build", "fdapde_topology_get",
 ]
 
 _lib = None
@@ -194,6 +194,22 @@ class Context:
         self.n_nodes, self.n_cells = nodes.shape[0], cells.shape[0]
         self._check(self.lib.fdapde_mesh_upload(self._ctx, self.M, self.N, C.c_int64(self.n_nodes), _dp(colmajor),
                                                 C.c_int64(self.n_cells), _ip(cells), _bp(boundary)))
+
+    def topology(self):
+        """Triangulation topology tables (device-built): dict of neighbors, cell_facets, facet_nodes, facet_cells, facet_boundary
+        and, for tetrahedra, edge_nodes, edge_boundary, face_edges"""
+        nf, ne = C.c_int64(), C.c_int64()
+        self._check(self.lib.fdapde_topology_build(self._ctx, C.byref(nf), C.byref(ne)))
+        M, nc, nf, ne = self.M, self.n_cells, nf.value, ne.value
+        t = dict(neighbors=np.zeros((nc, M + 1), np.int32), cell_facets=np.zeros((nc, M + 1), np.int32), facet_nodes=np.zeros((nf, M), np.int32),
+                 facet_cells=np.zeros((nf, 2), np.int32), facet_boundary=np.zeros(nf, np.uint8))
+        if M == 3:
+            t.update(edge_nodes=np.zeros((ne, 2), np.int32), edge_boundary=np.zeros(ne, np.uint8), face_edges=np.zeros((nf, 3), np.int32))
+        self._check(self.lib.fdapde_topology_get(self._ctx, _ip(t["neighbors"]), _ip(t["cell_facets"]), _ip(t["facet_nodes"]),
+                                                 _ip(t["facet_cells"]), _bp(t["facet_boundary"]),
+                                                 _ip(t["edge_nodes"]) if M == 3 else None, _bp(t["edge_boundary"]) if M == 3 else None,
+                                                 _ip(t["face_edges"]) if M == 3 else None))
+        return t
 
     def dofs_build(self, order):
         nd = C.c_int64()

@@ -622,6 +622,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
         c->halo_inv.release(), c->if_slot.release();
         if (c->comm) (void)g_rccl.CommDestroy(c->comm);
         c->lin_mat.release(), c->persist_stats.release();
+        dev_topology_release(&c->topo);
         c->part_cells.release(), c->part_off.release(), c->part_slots.release(), c->wave_slots.release(), c->part_shared.release();
         for (auto& ps : c->ps)
             ps.slot_dof.release(), ps.sl_off.release(), ps.ell_src.release(), ps.exp_off.release(), ps.imp_off.release(),
@@ -647,6 +648,7 @@ int fdapde_mesh_upload(fdapde_ctx* c, int M, int N, int64_t n_nodes, const doubl
     c->space_ready = c->dev_ready = c->colour_ready = c->fq_blk_ready = false;
     c->assembled[0] = c->assembled[1] = c->force_ready = c->solved = c->dirichlet_applied = false;
     c->op.clear(), c->coef_of_op = false, c->fq_i.clear(), c->fq_cols = 0, c->g_i.clear(), c->have_g = false;
+    if (c->topo_ready) dev_topology_release(&c->topo), c->topo_ready = false;
     return host_set_mesh(c->hs, M, N, n_nodes, nodes, n_cells, cells, bnd, c->err);
 }
 
@@ -673,6 +675,54 @@ int fdapde_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs) {
     }
     c->info = fdapde_info{};
     c->info.t_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return FDAPDE_OK;
+}
+
+// Triangulation<M,N>(nodes, cells, boundary) beyond the cell list: edges / faces, neighbours, boundary markers
+// (fdaPDE/geometry/triangulation.h:143-196 for triangles, 319-399 for tetrahedra), built on the device (dev_topology.hip)
+int fdapde_topology_build(fdapde_ctx* c, int64_t* n_facets, int64_t* n_edges) {
+    if (!c) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    const HostSpace& hs = c->hs;
+    if (hs.n_cells < 1) return fail(c, FDAPDE_ENOTINIT, "call fdapde_mesh_upload first");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->topo_ready) {
+        DBuf<int32_t> d_cells;
+        DBuf<uint8_t> d_bnd;
+        HIPCHK(c, d_cells.upload(hs.cells.data(), hs.cells.size(), c->stream));
+        HIPCHK(c, d_bnd.upload(hs.node_bnd.data(), hs.node_bnd.size(), c->stream));
+        const int rc = dev_build_topology(hs.M, hs.n_nodes, hs.n_cells, d_cells.p, d_bnd.p, c->stream, &c->topo, c->err);
+        d_cells.release(), d_bnd.release();
+        if (rc) return rc;
+        c->topo_ready = true;
+    }
+    if (n_facets) *n_facets = c->topo.n_facets;
+    if (n_edges) *n_edges = c->topo.n_edges;
+    return FDAPDE_OK;
+}
+
+int fdapde_topology_get(fdapde_ctx* c, int32_t* neighbors, int32_t* cell_facets, int32_t* facet_nodes, int32_t* facet_cells,
+                        uint8_t* facet_boundary, int32_t* edge_nodes, uint8_t* edge_boundary, int32_t* face_edges) {
+    if (!c) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (!c->topo_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_topology_build first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const DevTopology& t = c->topo;
+    const int M = t.M;
+    auto get = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+        return (dst && src && bytes) ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream) : hipSuccess;
+    };
+    HIPCHK(c, get(neighbors, t.neighbors, sizeof(int32_t) * (size_t)t.n_cells * (M + 1)));
+    HIPCHK(c, get(cell_facets, t.cell_facets, sizeof(int32_t) * (size_t)t.n_cells * (M + 1)));
+    HIPCHK(c, get(facet_nodes, t.facet_nodes, sizeof(int32_t) * (size_t)t.n_facets * M));
+    HIPCHK(c, get(facet_cells, t.facet_cells, sizeof(int32_t) * (size_t)t.n_facets * 2));
+    HIPCHK(c, get(facet_boundary, t.facet_bnd, (size_t)t.n_facets));
+    if (M == 3) {
+        HIPCHK(c, get(edge_nodes, t.edge_nodes, sizeof(int32_t) * (size_t)t.n_edges * 2));
+        HIPCHK(c, get(edge_boundary, t.edge_bnd, (size_t)t.n_edges));
+        HIPCHK(c, get(face_edges, t.face_edges, sizeof(int32_t) * (size_t)t.n_facets * 3));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return FDAPDE_OK;
 }
 
@@ -1398,7 +1448,10 @@ int fdapde_solver_prepare(fdapde_ctx* c, int32_t with_dirichlet) {
     if (!c->dev_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
     HIPCHK(c, hipSetDevice(c->device));
     if (c->spmv_variant != 2) return FDAPDE_OK;
-    return build_solver_pattern(c, with_dirichlet ? 1 : 0);
+    if (int rc = build_solver_pattern(c, with_dirichlet ? 1 : 0)) return rc;
+    if (c->persist && !c->persist_broken && c->comm == nullptr && c->ar_fn == nullptr)   // single GPU: also the persistent CG's layout
+        if (int rc = build_persist(c, with_dirichlet ? 1 : 0)) return rc;
+    return FDAPDE_OK;
 }
 
 // What the in-solve SpMV works on, for the roofline figures of bench.py: the interior block A_II as a plain CSR operator

@@ -15,6 +15,7 @@
 #include <rccl/rccl.h>
 
 #include "../../include/fdapde_hip.h"
+#include "dev_topology.h"
 #include "internal.h"
 #include "kernels.h"
 
@@ -230,6 +231,8 @@ struct fdapde_ctx {
         bool filled = false;                 // ell_val holds the currently scaled system
     } ps[2];
     DBuf<double> persist_stats;
+    DevTopology topo;   // Triangulation topology tables, built on the device by fdapde_topology_build
+    bool topo_ready = false;
     // element-wise scatter forms of the assembly (built on first use)
     bool part_ready = false, wave_ready = false;
     int32_t part_colours = 0;

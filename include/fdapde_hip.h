@@ -118,6 +118,19 @@ const char *fdapde_status_string(int status);
 int fdapde_mesh_upload(fdapde_ctx *ctx, int M, int N, int64_t n_nodes, const double *nodes_colmajor, int64_t n_cells,
                        const int32_t *cells_rowmajor, const uint8_t *boundary_nodes);
 
+/* The rest of the Triangulation constructor (geometry/triangulation.h:143-196 triangles, 319-399 tetrahedra), built on the device:
+ * facets = edges of triangles / faces of tetrahedra in the reference's first-seen numbering (cells ascending x combinations<M,M+1>),
+ *   facet_nodes  n_facets x M ascending node ids (edges_ / faces_), facet_cells n_facets x 2 with -1 on the boundary (edge_to_cells_
+ *   / face_to_cells_), facet_boundary (edges_markers_ / faces_markers_: seen by exactly one cell), cell_facets n_cells x (M+1)
+ *   (cell_to_edges_ / cell_to_faces_), neighbors n_cells x (M+1) with -1 for none, column = local vertex opposite to the shared
+ *   facet (neighbors_, triangulation.h:56-57,184-185,381-382);
+ * tetrahedra also: edge_nodes n_edges x 2 (edges_, numbered through the newly seen faces, 365-377), edge_boundary (both end nodes on
+ *   the boundary, 371), face_edges n_facets x 3 (face_to_edges_).  For triangles n_edges == n_facets and those three stay untouched.
+ * All row-major int32, 0-based; any output pointer may be NULL. */
+int fdapde_topology_build(fdapde_ctx *ctx, int64_t *n_facets, int64_t *n_edges);
+int fdapde_topology_get(fdapde_ctx *ctx, int32_t *neighbors, int32_t *cell_facets, int32_t *facet_nodes, int32_t *facet_cells,
+                        uint8_t *facet_boundary, int32_t *edge_nodes, uint8_t *edge_boundary, int32_t *face_edges);
+
 /* ---- function space: LagrangianBasis<D,R>(domain) -> enumerate_dofs  (basis/lagrangian_basis.h:94-136,147) ----- */
 /* Builds the DOF table in the reference's numbering, the CSR pattern, and the device-side layout. */
 int fdapde_dofs_build(fdapde_ctx *ctx, int order, int64_t *n_dofs);

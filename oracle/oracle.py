@@ -144,6 +144,68 @@ def load_mesh(directory: str) -> Mesh:
     return Mesh(np.ascontiguousarray(pts), np.ascontiguousarray(el), np.ascontiguousarray(bd))
 
 
+# ------------------------------------------------------------------------------------------------ topology
+def topology(mesh: Mesh) -> dict:
+    """The rest of the Triangulation constructor, restated literally (plain Python loops + dicts: fixtures only).
+    Triangles  (fdaPDE/geometry/triangulation.h:150-193): cells ascending x combinations<2,3> = (0,1),(0,2),(1,2); an edge never seen
+      gets the next id, `edge_to_cells = {i, -1}`, marker true; the second cell on it clears the marker, fills edge_to_cells[1], sets
+      neighbors_(k, v) = i and neighbors_(i, v') = k with v = the first local vertex of the cell that is not a node of the edge
+      (node_opposite_to_edge, 156-167), and ERASES the map entry (188).
+    Tetrahedra (triangulation.h:348-388): the same with faces over combinations<3,4>; a newly seen face registers its three edges
+      (combinations<2,3> of its sorted nodes) in first-seen order, marker = both end nodes on the boundary (371).
+    Returns 0-based int32 arrays: neighbors, cell_facets, facet_nodes, facet_cells, facet_boundary (+ edge_nodes, edge_boundary,
+    face_edges for tetrahedra)."""
+    import itertools
+
+    M, nc = mesh.M, mesh.n_cells
+    cells = mesh.cells
+    pattern = list(itertools.combinations(range(M + 1), M))          # utils/combinatorics.h:37-51: lexicographic
+    edge_pattern = list(itertools.combinations(range(3), 2))
+    neighbors = -np.ones((nc, M + 1), dtype=np.int32)                # triangulation.h:57
+    cell_facets = np.zeros((nc, M + 1), dtype=np.int32)
+    facet_nodes, facet_cells, markers = [], [], []
+    fmap = {}
+    edge_nodes, edge_markers, face_edges, emap = [], [], [], {}
+
+    def opposite(facet_id, cell):                                    # node_opposite_to_edge / node_opposite_to_face
+        for j in range(M + 1):
+            if cells[cell, j] not in facet_nodes[facet_id]:
+                return j
+        return M + 1
+
+    for i in range(nc):
+        for j, pat in enumerate(pattern):
+            facet = tuple(sorted(int(cells[i, k]) for k in pat))
+            hit = fmap.get(facet)
+            if hit is None:
+                fid = len(facet_nodes)
+                facet_nodes.append(facet), facet_cells.append([i, -1]), markers.append(1)
+                fmap[facet] = (fid, i)
+                cell_facets[i, j] = fid
+                if M == 3:
+                    for (a, b) in edge_pattern:
+                        edge = tuple(sorted((facet[a], facet[b])))
+                        if edge not in emap:
+                            emap[edge] = len(edge_nodes)
+                            edge_nodes.append(edge)
+                            edge_markers.append(1 if (mesh.boundary[edge[0]] and mesh.boundary[edge[1]]) else 0)
+                        face_edges.append(emap[edge])
+            else:
+                h, k = hit
+                neighbors[k, opposite(h, k)] = i
+                neighbors[i, opposite(h, i)] = k
+                cell_facets[i, j] = h
+                markers[h] = 0
+                facet_cells[h][1] = i
+                del fmap[facet]
+    out = dict(neighbors=neighbors, cell_facets=cell_facets, facet_nodes=np.asarray(facet_nodes, dtype=np.int32).reshape(-1, M),
+               facet_cells=np.asarray(facet_cells, dtype=np.int32).reshape(-1, 2), facet_boundary=np.asarray(markers, dtype=np.uint8))
+    if M == 3:
+        out.update(edge_nodes=np.asarray(edge_nodes, dtype=np.int32).reshape(-1, 2), edge_boundary=np.asarray(edge_markers, dtype=np.uint8),
+                   face_edges=np.asarray(face_edges, dtype=np.int32).reshape(-1, 3))
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ tables
 def n_basis(M, R):
     return lib().fo_n_basis(M, R)

@@ -198,8 +198,6 @@ int build_t(int64_t n_nodes, int64_t n_cells, const int32_t* d_cells, const uint
     sb = need > sb ? need : sb;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, need, flag.p, rank.p, (int)n_em + 1, st);
     sb = need > sb ? need : sb;
-    (void)hipcub::DeviceScan::InclusiveScan(nullptr, need, flag.p, rank.p, MaxOp(), (int)n_em, st);
-    sb = need > sb ? need : sb;
     TOPO_CHK(scratch.alloc(sb));
     int32_t* sorted_val = nullptr;
     if (M == 2) {
@@ -233,27 +231,46 @@ int build_t(int64_t n_nodes, int64_t n_cells, const int32_t* d_cells, const uint
                        out->facet_cells, out->facet_bnd, out->cell_facets, out->neighbors);
     if (M == 3) {
         const int64_t n2 = nf * 3;
-        if (n2 > n_em) {   // cannot happen (nf <= n_em / 1), but the scratch arrays are sized by n_em
-            err = "internal: edge emissions exceed the scratch size";
+        if (n2 > INT32_MAX) {
+            err = "too many faces for the device topology builder";
             return FDAPDE_EUNSUPPORTED;
         }
-        hipLaunchKernelGGL(k_emit_face_edges, dim3(grid_of(n2)), dim3(256), 0, st, n2, out->facet_nodes, key_a.p, val_a.p);
-        TOPO_CHK(hipcub::DeviceRadixSort::SortPairs(scratch.p, sb, key_a.p, key_b.p, val_a.p, val_b.p, (int)n2, 0, 64, st));
-        TOPO_CHK(hipMemsetAsync(flag.p + n2, 0, sizeof(int32_t), st));
-        int32_t* head_pos = reinterpret_cast<int32_t*>(hi_a.p);
-        int32_t* head_max = reinterpret_cast<int32_t*>(hi_b.p);
-        hipLaunchKernelGGL(k_edge_heads, dim3(grid_of(n2)), dim3(256), 0, st, n2, key_b.p, val_b.p, head_pos, flag.p);
-        TOPO_CHK(hipcub::DeviceScan::ExclusiveSum(scratch.p, sb, flag.p, rank.p, (int)n2 + 1, st));
-        TOPO_CHK(hipcub::DeviceScan::InclusiveScan(scratch.p, sb, head_pos, head_max, MaxOp(), (int)n2, st));
+        Tmp<uint64_t> ek_a, ek_b;
+        Tmp<int32_t> ev_a, ev_b, eflag, erank, head_pos, head_max;
+        Tmp<uint8_t> escratch;
+        TOPO_CHK(ek_a.alloc((size_t)n2));
+        TOPO_CHK(ek_b.alloc((size_t)n2));
+        TOPO_CHK(ev_a.alloc((size_t)n2));
+        TOPO_CHK(ev_b.alloc((size_t)n2));
+        TOPO_CHK(eflag.alloc((size_t)n2 + 1));
+        TOPO_CHK(erank.alloc((size_t)n2 + 1));
+        TOPO_CHK(head_pos.alloc((size_t)n2));
+        TOPO_CHK(head_max.alloc((size_t)n2));
+        size_t eb = 0;
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, need, ek_a.p, ek_b.p, ev_a.p, ev_b.p, (int)n2, 0, 64, st);
+        eb = need;
+        (void)hipcub::DeviceScan::ExclusiveSum(nullptr, need, eflag.p, erank.p, (int)n2 + 1, st);
+        eb = need > eb ? need : eb;
+        (void)hipcub::DeviceScan::InclusiveScan(nullptr, need, head_pos.p, head_max.p, MaxOp(), (int)n2, st);
+        eb = need > eb ? need : eb;
+        TOPO_CHK(escratch.alloc(eb));
+        hipLaunchKernelGGL(k_emit_face_edges, dim3(grid_of(n2)), dim3(256), 0, st, n2, out->facet_nodes, ek_a.p, ev_a.p);
+        TOPO_CHK(hipcub::DeviceRadixSort::SortPairs(escratch.p, eb, ek_a.p, ek_b.p, ev_a.p, ev_b.p, (int)n2, 0, 64, st));
+        TOPO_CHK(hipMemsetAsync(eflag.p + n2, 0, sizeof(int32_t), st));
+        hipLaunchKernelGGL(k_edge_heads, dim3(grid_of(n2)), dim3(256), 0, st, n2, ek_b.p, ev_b.p, head_pos.p, eflag.p);
+        TOPO_CHK(hipcub::DeviceScan::ExclusiveSum(escratch.p, eb, eflag.p, erank.p, (int)n2 + 1, st));
+        TOPO_CHK(hipcub::DeviceScan::InclusiveScan(escratch.p, eb, head_pos.p, head_max.p, MaxOp(), (int)n2, st));
         int32_t h_ne = 0;
-        TOPO_CHK(hipMemcpyAsync(&h_ne, rank.p + n2, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        TOPO_CHK(hipMemcpyAsync(&h_ne, erank.p + n2, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         TOPO_CHK(hipStreamSynchronize(st));
         out->n_edges = h_ne;
         TOPO_CHK(hipMalloc(reinterpret_cast<void**>(&out->edge_nodes), sizeof(int32_t) * (size_t)(h_ne ? h_ne : 1) * 2));
         TOPO_CHK(hipMalloc(reinterpret_cast<void**>(&out->edge_bnd), (size_t)(h_ne ? h_ne : 1)));
         TOPO_CHK(hipMalloc(reinterpret_cast<void**>(&out->face_edges), sizeof(int32_t) * (size_t)(n2 ? n2 : 1)));
-        hipLaunchKernelGGL(k_edge_tables, dim3(grid_of(n2)), dim3(256), 0, st, n2, key_b.p, val_b.p, head_max, rank.p, d_node_bnd, out->edge_nodes,
-                           out->edge_bnd, out->face_edges);
+        hipLaunchKernelGGL(k_edge_tables, dim3(grid_of(n2)), dim3(256), 0, st, n2, ek_b.p, ev_b.p, head_max.p, erank.p, d_node_bnd,
+                           out->edge_nodes, out->edge_bnd, out->face_edges);
+        TOPO_CHK(hipGetLastError());
+        TOPO_CHK(hipStreamSynchronize(st));   // the scratch buffers of this scope are freed on exit
     } else {
         out->n_edges = nf;
     }

@@ -30,6 +30,7 @@
 #include <cstdint>
 #include <functional>
 #include <algorithm>
+#include <memory>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -112,9 +113,64 @@ template <int M, int N> class Triangulation {
     const DMatrix<int>& boundary_nodes() const { return boundary_; }
     int64_t n_nodes() const { return nodes_.rows(); }
     int64_t n_cells() const { return cells_.rows(); }
+    // ---- the rest of the reference constructor (geometry/triangulation.h:143-196, 319-399), built on the device at first use
+    //      (fdapde_topology_build: facets = edges of triangles / faces of tetrahedra in first-seen numbering)
+    const DMatrix<int>& neighbors() const { return topo().neighbors; }       // n_cells x (M+1), -1 = none (triangulation.h:65, 402)
+    const DMatrix<int>& facets() const { return topo().facet_nodes; }        // edges() for triangles, faces() for tetrahedra
+    const DMatrix<int>& facet_to_cells() const { return topo().facet_cells; }
+    const DMatrix<int>& cell_to_facets() const { return topo().cell_facets; }
+    bool is_facet_on_boundary(int64_t id) const { return topo().facet_bnd[(size_t)id] != 0; }
+    int64_t n_facets() const { return topo().facet_nodes.rows(); }
+    int64_t n_edges() const { return M == 2 ? n_facets() : topo().edge_nodes.rows(); }
+    const DMatrix<int>& edges() const { return M == 2 ? topo().facet_nodes : topo().edge_nodes; }
+    bool is_edge_on_boundary(int64_t id) const { return (M == 2 ? topo().facet_bnd : topo().edge_bnd)[(size_t)id] != 0; }
+    const DMatrix<int>& face_to_edges() const { return topo().face_edges; }  // tetrahedra only
    private:
+    struct Topology {
+        DMatrix<int> neighbors, cell_facets, facet_nodes, facet_cells, edge_nodes, face_edges;
+        std::vector<uint8_t> facet_bnd, edge_bnd;
+    };
+    const Topology& topo() const {
+        if (topo_) return *topo_;
+        fdapde_ctx* ctx = nullptr;
+        if (fdapde_ctx_create(0, &ctx) != FDAPDE_OK) throw std::runtime_error("Triangulation: no HIP device for the topology tables (there is no CPU fallback)");
+        auto fail = [&](const char* what) {
+            const std::string msg = std::string(what) + ": " + fdapde_last_error(ctx);
+            fdapde_ctx_destroy(ctx);
+            throw std::runtime_error(msg);
+        };
+        const int64_t nn = n_nodes(), nc = n_cells();
+        std::vector<int32_t> cells((size_t)(nc * (M + 1)));
+        std::vector<uint8_t> bnd((size_t)nn);
+        for (int64_t i = 0; i < nc; ++i)
+            for (int j = 0; j <= M; ++j) cells[(size_t)(i * (M + 1) + j)] = cells_(i, j);
+        for (int64_t i = 0; i < nn; ++i) bnd[(size_t)i] = boundary_(i) != 0;
+        if (fdapde_mesh_upload(ctx, M, N, nn, nodes_.data(), nc, cells.data(), bnd.data()) != FDAPDE_OK) fail("mesh upload");
+        int64_t nf = 0, ne = 0;
+        if (fdapde_topology_build(ctx, &nf, &ne) != FDAPDE_OK) fail("topology");
+        std::vector<int32_t> nb((size_t)(nc * (M + 1))), cf((size_t)(nc * (M + 1))), fn((size_t)(nf * M)), fc((size_t)(nf * 2)), en((size_t)(ne * 2)),
+          fe((size_t)(nf * 3));
+        auto t = std::make_shared<Topology>();
+        t->facet_bnd.resize((size_t)nf), t->edge_bnd.resize((size_t)ne);
+        if (fdapde_topology_get(ctx, nb.data(), cf.data(), fn.data(), fc.data(), t->facet_bnd.data(), M == 3 ? en.data() : nullptr,
+                                M == 3 ? t->edge_bnd.data() : nullptr, M == 3 ? fe.data() : nullptr) != FDAPDE_OK)
+            fail("topology download");
+        fdapde_ctx_destroy(ctx);
+        auto rowmajor = [](const std::vector<int32_t>& v, int64_t rows, int64_t cols) {
+            DMatrix<int> m(rows, cols);
+            for (int64_t i = 0; i < rows; ++i)
+                for (int64_t j = 0; j < cols; ++j) m(i, j) = v[(size_t)(i * cols + j)];
+            return m;
+        };
+        t->neighbors = rowmajor(nb, nc, M + 1), t->cell_facets = rowmajor(cf, nc, M + 1), t->facet_nodes = rowmajor(fn, nf, M);
+        t->facet_cells = rowmajor(fc, nf, 2);
+        if (M == 3) t->edge_nodes = rowmajor(en, ne, 2), t->face_edges = rowmajor(fe, nf, 3);
+        topo_ = t;
+        return *topo_;
+    }
     DMatrix<double> nodes_;
     DMatrix<int> cells_, boundary_;
+    mutable std::shared_ptr<const Topology> topo_;   // lazily built, like the reference's location policy (triangulation.h:267)
 };
 
 // ---- forcing as a callable (reference: ScalarField<N, F>, fields/scalar_field.h) -----------------------------------------

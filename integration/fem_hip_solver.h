@@ -1,0 +1,190 @@
+// fem_hip_solver.h -- REFERENCE-SIDE binding of the MI355X path: drop this file into fdaPDE/finite_elements/solvers/ of
+// fdaPDE-core (reference @ 2024-10-16), include it from fdaPDE/finite_elements.h, and link libfdapde_hip.so.  User code then
+// changes one template argument:   PDE<decltype(mesh), decltype(L), DMatrix<double>, FEM_HIP, fem_order<1>> pde(mesh, L);
+//
+// NOT COMPILED IN THIS REPOSITORY'S IMAGE: it needs the reference tree and Eigen 3.4, which the image lacks (Oracle).
+// The same binding written on Eigen-free containers -- include/fdapde_amd/pde.h -- is what tests/cpp/fem_pde_test.cpp compiles and
+// runs; this file is that binding expressed in the reference's own types.  Reference members it plugs into / replaces:
+//   pde_solver_selector<S, ...>            fdaPDE/pde/symbols.h:36, finite_elements/solvers/fem_solver_selector.h:29-33
+//   FEMSolverBase::init                    finite_elements/solvers/fem_solver_base.h:104-139
+//   FEMSolverBase::set_dirichlet_bc        fem_solver_base.h:142-155
+//   FEMLinearEllipticSolver::solve         finite_elements/solvers/fem_linear_elliptic_solver.h:34-50
+#ifndef __FEM_HIP_SOLVER_H__
+#define __FEM_HIP_SOLVER_H__
+
+#include <array>
+#include <stdexcept>
+#include <vector>
+
+#include <fdapde_hip.h>   // this repository's C ABI (include/)
+
+#include "../../pde/symbols.h"
+#include "../../utils/symbols.h"
+#include "fem_solver_base.h"
+
+namespace fdapde {
+namespace core {
+
+struct FEM_HIP { };   // strategy tag, next to FEM and SPLINE
+
+namespace hip_detail {
+
+// ---- operator expression -> fdapde_term[] -------------------------------------------------------------------------------------
+// The nodes of the reference's expression tree keep their operands private (DifferentialBinOp::op1_, op2_, f_;
+// DifferentialNegateOp::op_; Diffusion::K_ ..., pde/differential_expressions.h:57-135), so the tree is not walked.  It does not have to be:
+// E.integrate(mem_buffer) is, for every expression the algebra can build, the integrand
+//     -(J^-T grad psi_i) . K (J^-T grad psi_j)  +  psi_i (J^-T grad psi_j) . b  +  c psi_i psi_j
+// with K, b, c the SUMS of the scaled leaves (laplacian.h:43, diffusion.h:54, advection.h:55, reaction.h:52, dt.h:34-36 -> 0).  The
+// binding evaluates that integrand on probe functions through the very buffers the assembler uses (fem_assembler.h:62-72):
+// invJ = I, point p = 0, psi in {1, x_1 .. x_M}:
+//     psi_i = x_k, psi_j = x_l  ->  -K[k][l]          psi_i = 1, psi_j = x_l  ->  b[l]          psi_i = psi_j = 1  ->  c
+// For space-varying coefficients the probes are repeated after forward(row) for every quadrature row (integrator.h:98-101).
+template <int M, int R> MultivariatePolynomial<M, R> probe_polynomial(int axis /* -1: the constant 1, k: the coordinate x_k */) {
+    using Poly = MultivariatePolynomial<M, R>;
+    std::array<double, ct_binomial_coefficient(R + M, R)> coeff {};
+    for (std::size_t m = 0; m < coeff.size(); ++m) {   // find the monomial in the public exponent table
+        int degree = 0, at = -1;
+        for (int d = 0; d < M; ++d) {
+            degree += Poly::poly_table[m][d];
+            if (Poly::poly_table[m][d] == 1) at = d;
+        }
+        if ((axis < 0 && degree == 0) || (axis >= 0 && degree == 1 && at == axis)) coeff[m] = 1.0;
+    }
+    return Poly(coeff);
+}
+
+struct CollapsedOperator {
+    std::vector<fdapde_term> terms;          // at most: one diffusion (Laplacian folded in), one advection, one reaction leaf
+    std::vector<double> K, b, c;             // per-quadrature-row data the terms point into (space-varying operators only)
+};
+
+template <int M, int N, int R, typename E> CollapsedOperator to_terms(const E& op, std::int64_t n_quadrature_rows) {
+    static_assert(M == N, "manifold domains are not on the accelerated path");
+    using Poly = MultivariatePolynomial<M, R>;
+    using Nabla = decltype(std::declval<Poly>().derive());
+    Poly psi_i, psi_j;
+    Nabla nabla_i, nabla_j;
+    Matrix<M, N, M> invJ = Matrix<M, N, M>::Identity();
+    DVector<double> f;
+    auto mem_buffer = std::make_tuple(ScalarPtr(&psi_i), ScalarPtr(&psi_j), VectorPtr(&nabla_i), VectorPtr(&nabla_j), MatrixPtr(&invJ), &f);
+    auto weak_form = op.integrate(mem_buffer);
+    const SVector<M> origin = SVector<M>::Zero();
+    std::array<Poly, M + 1> probe;           // probe[0] = 1, probe[1 + k] = x_k
+    for (int k = -1; k < M; ++k) probe[k + 1] = probe_polynomial<M, R>(k);
+    auto eval = [&](int i, int j) {
+        psi_i = probe[i], psi_j = probe[j], nabla_i = psi_i.derive(), nabla_j = psi_j.derive();
+        return weak_form(origin);
+    };
+    constexpr bool varying = E::is_space_varying;
+    const std::int64_t rows = varying ? n_quadrature_rows : 1;
+    CollapsedOperator out;
+    out.K.resize(rows * M * M), out.b.resize(rows * M), out.c.resize(rows);
+    bool has_K = false, has_b = false, has_c = false;
+    for (std::int64_t r = 0; r < rows; ++r) {
+        if constexpr (varying) weak_form.forward(r);
+        for (int k = 0; k < M; ++k)
+            for (int l = 0; l < M; ++l) has_K |= (out.K[(r * M + k) * M + l] = -eval(1 + k, 1 + l)) != 0.0;
+        for (int l = 0; l < M; ++l) has_b |= (out.b[r * M + l] = eval(0, 1 + l)) != 0.0;
+        has_c |= (out.c[r] = eval(0, 0)) != 0.0;
+    }
+    auto leaf = [&](int kind, const std::vector<double>& data, int width) {
+        fdapde_term t {};
+        t.kind = kind, t.coef = 1.0, t.space_varying = varying ? 1 : 0;
+        if (varying) t.data = data.data();
+        else for (int e = 0; e < width; ++e) t.cst[e] = data[e];
+        out.terms.push_back(t);
+    };
+    if (has_K) leaf(FDAPDE_DIFFUSION, out.K, M * M);
+    if (has_b) leaf(FDAPDE_ADVECTION, out.b, M);
+    if (has_c) leaf(FDAPDE_REACTION, out.c, 1);
+    if (out.terms.empty()) leaf(FDAPDE_DT, out.c, 0);   // e.g. dT alone: integrates to zero (dt.h:34-36)
+    return out;
+}
+
+// stiff() / mass(): CSR (pattern_get + matrix_values, the reference's DOF numbering) -> the reference's column-major SpMatrix
+inline void fetch(fdapde_ctx* ctx, int which, std::int64_t n_dofs, SpMatrix<double>& dst) {
+    std::int64_t nnz = 0;
+    fdapde_sizes(ctx, nullptr, &nnz, nullptr, nullptr, nullptr);
+    std::vector<int32_t> rowptr(n_dofs + 1), colidx(nnz);
+    std::vector<double> values(nnz);
+    fdapde_pattern_get(ctx, rowptr.data(), colidx.data());
+    if (fdapde_matrix_values(ctx, which, values.data()) != FDAPDE_OK) throw std::runtime_error(fdapde_last_error(ctx));
+    dst = Eigen::Map<const Eigen::SparseMatrix<double, Eigen::RowMajor, int>>(n_dofs, n_dofs, nnz, rowptr.data(), colidx.data(), values.data());
+}
+
+}   // namespace hip_detail
+
+template <typename D, typename E, typename F, typename... Ts>
+struct FEMHipEllipticSolver : public FEMSolverBase<D, E, F, Ts...> {   // keeps basis_, integrator_, the getters and the flags
+    using Base = FEMSolverBase<D, E, F, Ts...>;
+    static constexpr int M = D::local_dim, N = D::embed_dim, R = Base::fem_order;
+    fdapde_ctx* ctx_ = nullptr;
+
+    FEMHipEllipticSolver(const D& domain) : Base(domain) {
+        if (fdapde_ctx_create(/*device*/ 0, &ctx_) != FDAPDE_OK) throw std::runtime_error("FEM_HIP: no HIP device (there is no CPU fallback)");
+        DMatrix<int, Eigen::RowMajor> cells = domain.cells();                 // row-major int32 0-based (triangulation.h:120)
+        std::vector<uint8_t> bnd(domain.n_nodes());
+        for (int i = 0; i < domain.n_nodes(); ++i) bnd[i] = domain.is_node_on_boundary(i);
+        check(fdapde_mesh_upload(ctx_, M, N, domain.n_nodes(), domain.nodes().data() /* column-major, triangulation.h:119 */,
+                                 domain.n_cells(), cells.data(), bnd.data()));
+        std::int64_t n = 0;
+        check(fdapde_dofs_build(ctx_, R, &n));                                // same numbering as basis_.dofs(), bit for bit
+    }
+    FEMHipEllipticSolver(const FEMHipEllipticSolver&) = delete;              // one device context per solver object
+    FEMHipEllipticSolver& operator=(const FEMHipEllipticSolver&) = delete;
+    ~FEMHipEllipticSolver() { fdapde_ctx_destroy(ctx_); }
+
+    template <typename PDE> void init(const PDE& pde) {                       // replaces fem_solver_base.h:104-139
+        static_assert(is_pde<PDE>::value, "pde is not a valid PDE object");
+        this->n_dofs_ = this->basis_.size(), this->dofs_ = this->basis_.dofs(), this->boundary_dofs_ = this->basis_.boundary_dofs();
+        const std::int64_t rows = (std::int64_t)this->integrator_.num_nodes() * pde.domain().n_cells();
+        auto op = hip_detail::to_terms<M, N, R>(pde.differential_operator(), rows);
+        check(fdapde_set_operator(ctx_, (int32_t)op.terms.size(), op.terms.data()));
+        // forcing at the quadrature nodes, row nq * cell + q (integrator.h:85), one column per time point; a callable forcing is
+        // sampled at quadrature_nodes() first, exactly what Integrator::integrate does with it (integrator.h:80-81)
+        DMatrix<double> fq;
+        if constexpr (std::is_base_of<ScalarBase, F>::value) {
+            DMatrix<double> qn = this->integrator_.quadrature_nodes(pde.domain());
+            fq.resize(qn.rows(), 1);
+            for (int i = 0; i < qn.rows(); ++i) fq(i, 0) = pde.forcing_data()(SVector<N>(qn.row(i)));
+        } else
+            fq = pde.forcing_data();
+        check(fdapde_set_forcing(ctx_, fq.data(), (int32_t)fq.cols()));      // DMatrix is column-major
+        check(fdapde_init(ctx_, nullptr));
+        hip_detail::fetch(ctx_, FDAPDE_MAT_STIFF, this->n_dofs_, this->stiff_);
+        hip_detail::fetch(ctx_, FDAPDE_MAT_MASS, this->n_dofs_, this->mass_);
+        this->force_.resize(this->n_dofs_ * fq.cols(), 1);
+        check(fdapde_force(ctx_, this->force_.data()));
+        this->is_init = true;
+    }
+    template <typename PDE> void set_dirichlet_bc(const PDE& pde) {           // replaces fem_solver_base.h:142-155
+        if (!this->is_init) throw std::runtime_error("solver must be initialized first!");
+        check(fdapde_set_dirichlet(ctx_, pde.boundary_data().data()));       // indexed by DOF id (fem_solver_base.h:152)
+    }
+    template <typename PDE> void solve(const PDE&) {                          // replaces fem_linear_elliptic_solver.h:34-50
+        if (!this->is_init) throw std::runtime_error("solver must be initialized first!");
+        fdapde_info info;
+        if (fdapde_solve(ctx_, nullptr, &info) != FDAPDE_OK) {                // FDAPDE_ENOCONV <-> the reference's success = false
+            this->success = false;
+            return;
+        }
+        this->solution_.resize(this->n_dofs_, 1);
+        check(fdapde_solution(ctx_, this->solution_.data()));
+        hip_detail::fetch(ctx_, FDAPDE_MAT_STIFF, this->n_dofs_, this->stiff_);   // the row-zeroed matrix the reference leaves behind
+        check(fdapde_force(ctx_, this->force_.data()));                       // boundary rows = g
+        this->success = true;
+    }
+   private:
+    void check(int rc) const {
+        if (rc != FDAPDE_OK) throw std::runtime_error(fdapde_last_error(ctx_));
+    }
+};
+
+template <typename D, typename E, typename F, typename... Ts> struct pde_solver_selector<FEM_HIP, D, E, F, Ts...> {
+    using type = FEMHipEllipticSolver<D, E, F, Ts...>;
+};
+
+}   // namespace core
+}   // namespace fdapde
+
+#endif   // __FEM_HIP_SOLVER_H__

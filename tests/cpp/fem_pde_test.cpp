@@ -11,6 +11,7 @@
 #include <string>
 
 #include "fdapde_amd/pde.h"
+#include "fdapde_amd/io.h"
 #include "fdapde_amd/linear_algebra.h"
 
 using namespace fdapde::amd;
@@ -37,43 +38,10 @@ static bool almost_equal(double a, double b, double eps = DOUBLE_TOLERANCE) {   
     return std::fabs(a - b) < eps || std::fabs(a - b) < std::fmax(std::fabs(a), std::fabs(b)) * eps;
 }
 
-// CSV dialect of utils/IO/csv_reader.h:75-117: header row, first column = row index, quotes stripped
-template <typename T> DMatrix<T> read_csv(const std::string& file) {
-    std::ifstream in(file);
-    if (!in) throw std::runtime_error("cannot open " + file);
-    std::string line;
-    std::getline(in, line);
-    std::vector<std::vector<double>> rows;
-    while (std::getline(in, line)) {
-        if (line.empty()) continue;
-        std::vector<double> r;
-        std::stringstream ss(line);
-        std::string tok;
-        bool first = true;
-        while (std::getline(ss, tok, ',')) {
-            if (first) { first = false; continue; }
-            std::string t;
-            for (char ch : tok) if (ch != '"' && ch != ' ') t += ch;
-            r.push_back(std::stod(t));
-        }
-        rows.push_back(r);
-    }
-    DMatrix<T> m((int64_t)rows.size(), rows.empty() ? 0 : (int64_t)rows[0].size());
-    for (size_t i = 0; i < rows.size(); ++i)
-        for (size_t j = 0; j < rows[i].size(); ++j) m((int64_t)i, (int64_t)j) = (T)rows[i][j];
-    return m;
-}
-// test/src/utils/mesh_loader.h:62-84: elements are 1-based in the files
-template <int M, int N> struct MeshLoader {
-    Triangulation<M, N> mesh;
-    explicit MeshLoader(const std::string& id) {
-        DMatrix<double> points = read_csv<double>(MESH_PATH + "/" + id + "/points.csv");
-        DMatrix<int> elements = read_csv<int>(MESH_PATH + "/" + id + "/elements.csv");
-        DMatrix<int> boundary = read_csv<int>(MESH_PATH + "/" + id + "/boundary.csv");
-        for (int64_t i = 0; i < elements.rows(); ++i)
-            for (int64_t j = 0; j < elements.cols(); ++j) elements(i, j) -= 1;
-        mesh = Triangulation<M, N>(points, elements, boundary);
-    }
+// the product's reader and loader (include/fdapde_amd/io.h), with the reference test suite's calling conventions
+template <typename T> DMatrix<T> read_csv(const std::string& file) { return fdapde::amd::CSVReader<T>().parse_file(file); }
+template <int M, int N> struct FixtureMesh : fdapde::amd::MeshLoader<M, N> {
+    explicit FixtureMesh(const std::string& id) : fdapde::amd::MeshLoader<M, N>(MESH_PATH, id) { }
 };
 
 template <typename PDE_, typename Fn> static double l2_error(PDE_& pde, Fn solution_expr) {
@@ -97,7 +65,7 @@ template <typename PDE_, typename Fn> static DMatrix<double> eval_at_dofs(PDE_& 
 // fem_pde_test.cpp:43-75
 TEST(fem_pde_test, laplacian_isotropic_order1) {
     auto solution_expr = [](std::array<double, 3> x) -> double { return x[0] + x[1]; };
-    MeshLoader<2, 2> unit_square("unit_square");
+    FixtureMesh<2, 2> unit_square("unit_square");
     auto L = -laplacian<FEM_HIP>();
     PDE<Triangulation<2, 2>, decltype(L), DMatrix<double>, FEM_HIP, fem_order<1>> pde_(unit_square.mesh, L);
     pde_.set_dirichlet_bc(eval_at_dofs(pde_, solution_expr));
@@ -113,7 +81,7 @@ TEST(fem_pde_test, laplacian_isotropic_order1) {
 TEST(fem_pde_test, laplacian_isotropic_order2_callable_force) {
     auto solution_expr = [](std::array<double, 3> x) -> double { return 1. - x[0] * x[0] - x[1] * x[1]; };
     ScalarField<2> forcing([](const std::array<double, 2>&) -> double { return 4.0; });
-    MeshLoader<2, 2> unit_square("unit_square");
+    FixtureMesh<2, 2> unit_square("unit_square");
     auto L = -laplacian<FEM_HIP>();
     PDE<Triangulation<2, 2>, decltype(L), ScalarField<2>, FEM_HIP, fem_order<2>> pde_(unit_square.mesh, L, forcing);
     pde_.set_dirichlet_bc(eval_at_dofs(pde_, solution_expr));
@@ -141,7 +109,7 @@ TEST(fem_pde_test, advection_diffusion_isotropic_order1) {
     AdvDiff ad;
     std::array<double, 2> beta_ {-ad.alpha_, 0.};
     auto L = -laplacian<FEM_HIP>() + advection<FEM_HIP>(beta_);
-    MeshLoader<2, 2> unit_square("unit_square");
+    FixtureMesh<2, 2> unit_square("unit_square");
     PDE<Triangulation<2, 2>, decltype(L), DMatrix<double>, FEM_HIP, fem_order<1>> pde_(unit_square.mesh);
     pde_.set_differential_operator(L);
     pde_.set_dirichlet_bc(DMatrix<double>::Zero(pde_.n_dofs(), 1));
@@ -161,7 +129,7 @@ TEST(fem_pde_test, advection_diffusion_isotropic_order2) {
     ScalarField<2> forcing([ad](const std::array<double, 2>& x) -> double { return ad.forcing(x[1]); });
     std::array<double, 2> beta_ {-ad.alpha_, 0.};
     auto L = -laplacian<FEM_HIP>() + advection<FEM_HIP>(beta_);
-    MeshLoader<2, 2> unit_square("unit_square");
+    FixtureMesh<2, 2> unit_square("unit_square");
     PDE<Triangulation<2, 2>, decltype(L), ScalarField<2>, FEM_HIP, fem_order<2>> pde_(unit_square.mesh, L, forcing);
     pde_.set_dirichlet_bc(DMatrix<double>::Zero(pde_.n_dofs(), 1));
     pde_.init();
@@ -173,7 +141,7 @@ TEST(fem_pde_test, advection_diffusion_isotropic_order2) {
 // element matrices; entries of pairs of DOFs that only cell 175 contains equal the local integrals (the edge-midpoint
 // pairs on an edge-shared pair are sums over two cells), so compare those through stiff().
 TEST(fem_operators_test, laplacian_order_2_through_stiff) {
-    MeshLoader<2, 2> CShaped("c_shaped");
+    FixtureMesh<2, 2> CShaped("c_shaped");
     auto L = -laplacian<FEM_HIP>();
     PDE<Triangulation<2, 2>, decltype(L), DMatrix<double>, FEM_HIP, fem_order<2>> pde_(CShaped.mesh, L);
     pde_.init();
@@ -195,7 +163,7 @@ TEST(fem_operators_test, laplacian_order_2_through_stiff) {
 }
 // error behaviour: fem_solver_base.h:146 / fem_linear_elliptic_solver.h:36 throw; non-convergence -> success = false
 TEST(fem_pde_test, error_behaviour) {
-    MeshLoader<2, 2> m("unit_square_16");
+    FixtureMesh<2, 2> m("unit_square_16");
     auto L = -laplacian<FEM_HIP>();
     PDE<Triangulation<2, 2>, decltype(L), DMatrix<double>, FEM_HIP, fem_order<1>> pde_(m.mesh, L);
     bool thrown = false;
@@ -214,7 +182,7 @@ TEST(fem_pde_test, error_behaviour) {
 // 3-D: unit_sphere (the reference's only 3-D mesh; 1395 negatively oriented tetrahedra), P1 reproduces x + y + z
 TEST(fem_pde_test, laplacian_3d_order1) {
     auto solution_expr = [](std::array<double, 3> x) -> double { return x[0] + x[1] + x[2]; };
-    MeshLoader<3, 3> sphere("unit_sphere");
+    FixtureMesh<3, 3> sphere("unit_sphere");
     auto L = -laplacian<FEM_HIP>();
     PDE<Triangulation<3, 3>, decltype(L), DMatrix<double>, FEM_HIP, fem_order<1>> pde_(sphere.mesh, L);
     pde_.set_dirichlet_bc(eval_at_dofs(pde_, solution_expr));
@@ -237,7 +205,7 @@ TEST(fem_pde_test, parabolic_isotropic_order2) {
     auto forcing_expr = [](double x0, double x1, double t) {
         return (8 * pi * pi - 1.) * std::sin(2 * pi * x0) * std::sin(2 * pi * x1) * std::exp(-t);
     };
-    MeshLoader<2, 2> unit_square("unit_square");
+    FixtureMesh<2, 2> unit_square("unit_square");
     auto L = dt<FEM_HIP>() - laplacian<FEM_HIP>();
     PDE<Triangulation<2, 2>, decltype(L), DMatrix<double>, FEM_HIP, fem_order<2>> pde_(unit_square.mesh, times);
     pde_.set_differential_operator(L);
@@ -272,7 +240,7 @@ TEST(fem_pde_test, parabolic_isotropic_order2) {
 }
 // fdapde::SparseLU usage pattern (utils/symbols.h:133-160, linear_algebra/smw.h:46-48): factor once, solve many columns
 TEST(sparse_solver_test, factor_once_solve_many) {
-    MeshLoader<2, 2> m("unit_square_32");
+    FixtureMesh<2, 2> m("unit_square_32");
     auto L = -laplacian<FEM_HIP>() + reaction<FEM_HIP>(2.0);
     PDE<Triangulation<2, 2>, decltype(L), DMatrix<double>, FEM_HIP, fem_order<1>> pde_(m.mesh, L);
     pde_.init();
@@ -290,9 +258,34 @@ TEST(sparse_solver_test, factor_once_solve_many) {
     EXPECT_TRUE(worst < 1e-7);
 }
 
+// Triangulation beyond the cell list (geometry/triangulation.h:143-196, 319-399), device-built, against the files the reference's
+// MeshLoader reads next to the mesh (test/src/utils/mesh_loader.h:62-84): neigh.csv, edges.csv
+template <int M, int N> static void check_topology(const std::string& id) {
+    FixtureMesh<M, N> m(id);
+    const DMatrix<int>& nb = m.mesh.neighbors();
+    EXPECT_TRUE(nb.rows() == m.neighbors_.rows() && nb.cols() == m.neighbors_.cols());
+    int64_t bad = 0;
+    for (int64_t i = 0; i < nb.rows(); ++i)
+        for (int64_t j = 0; j < nb.cols(); ++j) bad += nb(i, j) != m.neighbors_(i, j);
+    EXPECT_TRUE(bad == 0);
+    EXPECT_TRUE(m.mesh.n_facets() == m.edges_.rows());   // the file lists the same facets (in another order)
+    int64_t n_bnd = 0, wrong = 0;
+    for (int64_t f = 0; f < m.mesh.n_facets(); ++f) {
+        const bool b = m.mesh.is_facet_on_boundary(f);
+        n_bnd += b;
+        wrong += b != (m.mesh.facet_to_cells()(f, 1) < 0);
+    }
+    EXPECT_TRUE(wrong == 0 && n_bnd > 0);
+}
+TEST(mesh_test, neighbours_and_facets_match_the_fixture_files) {
+    check_topology<2, 2>("unit_square");
+    check_topology<2, 2>("c_shaped");
+    check_topology<3, 3>("unit_sphere");
+}
+
 // SMW (linear_algebra/smw.h:38-59) on the factor-once handle, and row-sum lumping (linear_algebra/lumping.h:30-41)
 TEST(linear_algebra_test, smw_and_lumping) {
-    MeshLoader<2, 2> m("unit_square_32");
+    FixtureMesh<2, 2> m("unit_square_32");
     auto L = -laplacian<FEM_HIP>() + reaction<FEM_HIP>(2.0);
     PDE<Triangulation<2, 2>, decltype(L), DMatrix<double>, FEM_HIP, fem_order<1>> pde_(m.mesh, L);
     pde_.init();
@@ -371,7 +364,7 @@ static double max_abs_diff(const SpMatrix<double>& a, const SpMatrix<double>& b)
 template <int R> static void eval_basis_case() {
     const std::string mtx = MESH_PATH + "/../mtx/";
     {
-        MeshLoader<2, 2> m("c_shaped");
+        FixtureMesh<2, 2> m("c_shaped");
         auto L = -laplacian<FEM_HIP>();
         PDE<Triangulation<2, 2>, decltype(L), DMatrix<double>, FEM_HIP, fem_order<R>> pde_(m.mesh, L);
         DMatrix<double> locs = read_csv<double>(MESH_PATH + "/c_shaped/locs.csv");
@@ -383,7 +376,7 @@ template <int R> static void eval_basis_case() {
         EXPECT_TRUE(!pde_.eval_basis(7, locs).has_value());
     }
     {
-        MeshLoader<2, 2> m("quasi_circle");
+        FixtureMesh<2, 2> m("quasi_circle");
         auto L = -laplacian<FEM_HIP>();
         PDE<Triangulation<2, 2>, decltype(L), DMatrix<double>, FEM_HIP, fem_order<R>> pde_(m.mesh, L);
         DMatrix<int> inc_i = read_csv<int>(MESH_PATH + "/quasi_circle/incidence_matrix.csv");
@@ -418,6 +411,7 @@ int main(int argc, char** argv) {
     RUN(fem_pde_test, parabolic_isotropic_order2);
     RUN(sparse_solver_test, factor_once_solve_many);
     RUN(linear_algebra_test, smw_and_lumping);
+    RUN(mesh_test, neighbours_and_facets_match_the_fixture_files);
     RUN(lagrangian_basis_test, eval_basis_golden);
     std::printf("%d checks, %d failures\n", checks, failures);
     return failures == 0 ? 0 : 1;

@@ -25,9 +25,106 @@ int need_device(fdapde_ctx* c) {
     return FDAPDE_OK;
 }
 
+// a DBuf takes over a device array built elsewhere (dev_setup.hip)
+template <typename T> void adopt(DBuf<T>& b, T*& p, size_t n) {
+    b.release();
+    b.p = p, b.n = n, p = nullptr;
+}
+
+// index arrays of the space built on the device (dev_setup.hip): the context's buffers adopt them, nothing is uploaded
+int adopt_dev_space(fdapde_ctx* c, DevSpace& s) {
+    const HostSpace& hs = c->hs;
+    const size_t nd = (size_t)hs.n_dofs, nc = (size_t)hs.n_cells, nnz = (size_t)hs.nnz, nv = (size_t)hs.M + 1, nb = (size_t)hs.nb;
+    adopt(c->cverts, s.cverts, nc * nv), adopt(c->cdofs, s.cdofs, nc * nb), adopt(c->vcoords, s.vcoords, (size_t)hs.n_nodes * (hs.N == 2 ? 2 : 4));
+    adopt(c->adj, s.adj, (size_t)s.n_adj), adopt(c->slotw, s.slotw, (size_t)s.n_adj * hs.nbw), adopt(c->sl_off, s.sl_off, (size_t)s.n_slices + 1);
+    if (s.dealt) adopt(c->lane_row, s.lane_row, (size_t)s.n_blk * kAsmBlock);
+    else c->lane_row.release();
+    adopt(c->bc_off, s.bc_off, (size_t)s.n_blk + 1), adopt(c->bn_off, s.bn_off, (size_t)s.n_blk + 1);
+    adopt(c->bc_cell, s.bc_cell, (size_t)s.n_bc), adopt(c->bn_node, s.bn_node, (size_t)s.n_bn), adopt(c->bc_vert, s.bc_vert, (size_t)s.n_bc * 4);
+    adopt(c->rowptr, s.rowptr, nd + 1), adopt(c->colidx, s.colidx, nnz + 2), adopt(c->diag, s.diag, nd), adopt(c->slot_i2e, s.slot_i2e, nnz);
+    adopt(c->dof_i2e, s.dof_i2e, nd), adopt(c->dof_e2i, s.dof_e2i, nd), adopt(c->cell_i2e, s.cell_i2e, nc), adopt(c->bnd, s.bnd, nd);
+    adopt(c->rowptr_e, s.rowptr_e, nd + 1), adopt(c->colidx_e, s.colidx_e, nnz);
+    HIPCHK(c, c->rb_row.upload(hs.rb_row.data(), hs.rb_row.size(), c->stream));
+    dev_space_release(&s);   // what nobody adopted (node_i2e)
+    c->dev_built = true;
+    return FDAPDE_OK;
+}
+
+// big host-side index arrays of a device-built space, fetched the first time host code needs them (the persistent layout and the
+// solver patterns read rowptr_i / colidx_i; the colouring and the partitioned assembly cdofs_i; point location cverts_i / vcoords_i;
+// fdapde_pattern_get the reference pattern)
+enum { kHostPattern = 1, kHostCells = 2, kHostRefPattern = 4 };
+int ensure_host(fdapde_ctx* c, int what) {
+    if (!c->dev_built) return FDAPDE_OK;
+    HostSpace& hs = c->hs;
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipSetDevice(c->device));
+    if ((what & kHostPattern) && hs.colidx_i.empty()) {
+        hs.colidx_i.resize(c->colidx.n);
+        HIPCHK(c, hipMemcpyAsync(hs.colidx_i.data(), c->colidx.p, sizeof(int32_t) * c->colidx.n, hipMemcpyDeviceToHost, st));
+    }
+    if ((what & kHostCells) && hs.cdofs_i.empty()) {
+        hs.cdofs_i.resize(c->cdofs.n), hs.cverts_i.resize(c->cverts.n), hs.vcoords_i.resize(c->vcoords.n);
+        HIPCHK(c, hipMemcpyAsync(hs.cdofs_i.data(), c->cdofs.p, sizeof(int32_t) * c->cdofs.n, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(hs.cverts_i.data(), c->cverts.p, sizeof(int32_t) * c->cverts.n, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(hs.vcoords_i.data(), c->vcoords.p, sizeof(double) * c->vcoords.n, hipMemcpyDeviceToHost, st));
+    }
+    if ((what & kHostRefPattern) && hs.colidx_e.empty()) {
+        hs.rowptr_e.resize(c->rowptr_e.n), hs.colidx_e.resize(c->colidx_e.n);
+        HIPCHK(c, hipMemcpyAsync(hs.rowptr_e.data(), c->rowptr_e.p, sizeof(int32_t) * c->rowptr_e.n, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(hs.colidx_e.data(), c->colidx_e.p, sizeof(int32_t) * c->colidx_e.n, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    return FDAPDE_OK;
+}
+
+// FDAPDE_SETUP_CHECK: the device-built space against the host builder's, array for array
+int check_dev_space(fdapde_ctx* c, const DevSpace& s, int order) {
+    HostSpace ref;
+    const HostSpace& hs = c->hs;
+    ref.M = hs.M, ref.N = hs.N, ref.n_nodes = hs.n_nodes, ref.n_cells = hs.n_cells, ref.nodes = hs.nodes, ref.cells = hs.cells, ref.node_bnd = hs.node_bnd;
+    std::string err;
+    if (int rc = host_build_space(ref, order, err)) return fail(c, rc, "set-up check: the host builder failed");
+    int bad = 0;
+    auto cmp = [&](const char* name, const void* dev, const void* host, size_t bytes, size_t elem) {
+        std::vector<unsigned char> tmp(bytes ? bytes : 1);
+        if (bytes && hipMemcpy(tmp.data(), dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+            std::fprintf(stderr, "set-up check %-10s: download failed\n", name), ++bad;
+            return;
+        }
+        size_t at = 0;
+        while (at < bytes && tmp[at] == static_cast<const unsigned char*>(host)[at]) ++at;
+        if (at < bytes) std::fprintf(stderr, "set-up check %-10s: MISMATCH at element %zu of %zu\n", name, at / elem, bytes / elem), ++bad;
+        else std::fprintf(stderr, "set-up check %-10s: ok (%zu elements)\n", name, bytes / elem);
+    };
+    auto scalar = [&](const char* name, int64_t dev, int64_t host) {
+        if (dev != host) std::fprintf(stderr, "set-up check %-10s: MISMATCH %lld vs %lld\n", name, (long long)dev, (long long)host), ++bad;
+    };
+    scalar("nnz", hs.nnz, ref.nnz), scalar("max_row", hs.max_row, ref.max_row), scalar("blk_nnz", hs.max_blk_nnz, ref.max_blk_nnz);
+    scalar("blk_cells", hs.max_blk_cells, ref.max_blk_cells), scalar("blk_nodes", hs.max_blk_nodes, ref.max_blk_nodes);
+    scalar("n_adj", s.n_adj, (int64_t)ref.adj.size()), scalar("n_bc", s.n_bc, (int64_t)ref.bc_cell.size()), scalar("n_bn", s.n_bn, (int64_t)ref.bn_node.size());
+    scalar("dealt", s.dealt, !ref.lane_row.empty());
+    if (bad == 0) {
+#define CMP(name, dptr, hvec_) cmp(name, dptr, (hvec_).data(), (hvec_).size() * sizeof((hvec_)[0]), sizeof((hvec_)[0]))
+        CMP("dof_i2e", s.dof_i2e, ref.dof_i2e), CMP("dof_e2i", s.dof_e2i, ref.dof_e2i), CMP("cell_i2e", s.cell_i2e, ref.cell_i2e);
+        CMP("node_i2e", s.node_i2e, ref.node_i2e), CMP("vcoords", s.vcoords, ref.vcoords_i), CMP("bnd", s.bnd, ref.dof_bnd_i);
+        CMP("cverts", s.cverts, ref.cverts_i), CMP("cdofs", s.cdofs, ref.cdofs_i), CMP("rowptr", s.rowptr, ref.rowptr_i);
+        CMP("colidx", s.colidx, ref.colidx_i), CMP("diag", s.diag, ref.diag_i), CMP("rowptr_e", s.rowptr_e, ref.rowptr_e);
+        CMP("colidx_e", s.colidx_e, ref.colidx_e), CMP("slot_i2e", s.slot_i2e, ref.slot_i2e), CMP("sl_off", s.sl_off, ref.sl_off);
+        if (s.dealt) CMP("lane_row", s.lane_row, ref.lane_row);
+        CMP("bc_off", s.bc_off, ref.bc_off), CMP("bn_off", s.bn_off, ref.bn_off), CMP("bc_cell", s.bc_cell, ref.bc_cell);
+        CMP("bn_node", s.bn_node, ref.bn_node), CMP("bc_vert", s.bc_vert, ref.bc_vert), CMP("adj", s.adj, ref.adj), CMP("slotw", s.slotw, ref.slotw);
+#undef CMP
+        if (hs.rb_row != ref.rb_row) std::fprintf(stderr, "set-up check rb_row: MISMATCH\n"), ++bad;
+    }
+    if (bad) return fail(c, FDAPDE_EHIP, "FDAPDE_SETUP_CHECK: the device-built space differs from the host builder's (see stderr)");
+    return FDAPDE_OK;
+}
+
 int upload_space(fdapde_ctx* c) {
     HostSpace& hs = c->hs;
     hipStream_t st = c->stream;
+    if (!c->dev_built) {
     HIPCHK(c, c->cverts.upload(hs.cverts_i.data(), hs.cverts_i.size(), st));
     HIPCHK(c, c->cdofs.upload(hs.cdofs_i.data(), hs.cdofs_i.size(), st));
     HIPCHK(c, c->vcoords.upload(hs.vcoords_i.data(), hs.vcoords_i.size(), st));
@@ -50,6 +147,7 @@ int upload_space(fdapde_ctx* c) {
     HIPCHK(c, c->cell_i2e.upload(hs.cell_i2e.data(), hs.cell_i2e.size(), st));
     HIPCHK(c, c->rb_row.upload(hs.rb_row.data(), hs.rb_row.size(), st));
     HIPCHK(c, c->bnd.upload(hs.dof_bnd_i.data(), hs.dof_bnd_i.size(), st));
+    }
     DevTables dt{};
     std::memcpy(dt.qw, c->tb.qw, sizeof dt.qw);
     std::memcpy(dt.psi, c->tb.psi, sizeof dt.psi);
@@ -149,7 +247,7 @@ AsmArgs asm_args(fdapde_ctx* c) {
     AsmArgs a{};
     a.n_dofs = c->hs.n_dofs, a.n_cells = c->hs.n_cells;
     a.cverts = c->cverts.p, a.cdofs = c->cdofs.p, a.vcoords = c->vcoords.p;
-    a.sl_off = c->sl_off.p, a.adj = c->adj.p, a.slotw = c->slotw.p, a.lane_row = c->hs.lane_row.empty() ? nullptr : c->lane_row.p;
+    a.sl_off = c->sl_off.p, a.adj = c->adj.p, a.slotw = c->slotw.p, a.lane_row = c->lane_row.p;   // nullptr = identity
     a.rowptr = c->rowptr.p, a.colidx = c->colidx.p, a.tables = c->tables.p, a.reftab = c->reftab.p;
     a.bc_off = c->bc_off.p, a.bc_cell = c->bc_cell.p, a.bc_vert = c->bc_vert.p, a.bn_off = c->bn_off.p, a.bn_node = c->bn_node.p;
     a.lds_nodes = c->hs.max_blk_nodes;
@@ -272,6 +370,7 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
         if (a.force) HIPCHK(c, hipMemsetAsync(a.force, 0, sizeof(double) * (size_t)hs.n_dofs, c->stream));
         if (assembly == FDAPDE_ASSEMBLY_PARTITIONED) {
             if (!c->part_ready) {   // partitions of 2048 cells, local colours, shared-row flags, slot map (host index work, once)
+                if (int rc = ensure_host(c, kHostPattern | kHostCells)) return rc;
                 CellPartitions cp;
                 int cells = 2048;   // measured on C3: 2048 cells 5.4 ms (58 % of the rows shared -> atomics); see tools/asm_ab.py for larger ones
                 if (const char* e = std::getenv("FDAPDE_PART_CELLS")) cells = std::atoi(e);
@@ -301,12 +400,14 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
                 return fail(c, FDAPDE_EUNSUPPORTED, "the wavefront-per-element assembly exists for P1 only");
             } else {
                 if (!c->colour_ready) {
+                    if (int rc = ensure_host(c, kHostCells)) return rc;
                     int rc = host_build_colouring(c->hs, c->err);
                     if (rc) return rc;
                     HIPCHK(c, c->colour_cells.upload(hs.colour_cells.data(), hs.colour_cells.size(), c->stream));
                     c->colour_ready = true;
                 }
                 if (!c->wave_ready) {
+                    if (int rc = ensure_host(c, kHostPattern | kHostCells)) return rc;
                     std::vector<int32_t> sm;
                     host_build_slot_map(hs, hs.colour_cells.data(), hs.n_cells, sm);
                     HIPCHK(c, c->wave_slots.upload(sm.data(), sm.size(), c->stream));
@@ -326,6 +427,7 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
                                sizeof(DevTables), c->stream, a, op, (const int32_t*)nullptr, hs.n_cells);
         } else {
             if (!c->colour_ready) {
+                if (int rc = ensure_host(c, kHostCells)) return rc;
                 int rc = host_build_colouring(c->hs, c->err);
                 if (rc) return rc;
                 HIPCHK(c, c->colour_cells.upload(hs.colour_cells.data(), hs.colour_cells.size(), c->stream));
@@ -609,7 +711,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
         (void)hipStreamSynchronize(c->stream);
         drop_graph(c);
         for (DBuf<int32_t>* b : {&c->cverts, &c->cdofs, &c->adj, &c->rowptr, &c->colidx, &c->diag, &c->slot_i2e, &c->dof_i2e,
-                                 &c->dof_e2i, &c->cell_i2e, &c->rb_row, &c->colour_cells, &c->ctl})
+                                 &c->dof_e2i, &c->cell_i2e, &c->rb_row, &c->colour_cells, &c->ctl, &c->rowptr_e, &c->colidx_e})
             b->release();
         for (DBuf<double>* b : {&c->vcoords, &c->vals[0], &c->vals[1], &c->force, &c->fq, &c->g, &c->sval, &c->scale, &c->gt,
                                 &c->x, &c->r, &c->p, &c->y, &c->s, &c->t, &c->r0, &c->u, &c->part_a, &c->part_b, &c->sc,
@@ -662,10 +764,46 @@ int fdapde_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs) {
     c->scaled_owner = fdapde_ctx::kScaledNone;
     c->ps[0].tried = c->ps[0].ok = c->ps[1].tried = c->ps[1].ok = false;
     drop_graph(c);
-    int rc = host_build_space(c->hs, order, c->err);
+    // The DOF table (reference numbering) is host index work; everything derived from it -- locality numbering, adjacency, CSR
+    // patterns, slot maps, assembly block tables -- is built on the device (dev_setup.hip) when the context has one.
+    // FDAPDE_SETUP=host keeps the multi-threaded host builder; FDAPDE_SETUP_CHECK=1 runs both and compares every array.
+    const char* mode = std::getenv("FDAPDE_SETUP");
+    const bool on_device = c->has_device && !(mode && std::strcmp(mode, "host") == 0);
+    c->dev_built = false;
+    HostSpace& hs = c->hs;
+    hs.colidx_i.clear(), hs.cdofs_i.clear(), hs.cverts_i.clear(), hs.vcoords_i.clear(), hs.colidx_e.clear(), hs.rowptr_e.clear(), hs.adj.clear(),
+      hs.slotw.clear(), hs.lane_row.clear();
+    int rc = host_build_space(hs, order, c->err, /*dofs_only=*/on_device);
     if (rc) return rc;
-    rc = build_basis_tables(c->hs.M, order, &c->tb);
+    rc = build_basis_tables(hs.M, order, &c->tb);
     if (rc) return fail(c, rc, "basis tables");
+    if (on_device) {
+        HIPCHK(c, hipSetDevice(c->device));
+        DBuf<double> d_nodes, d_coords;
+        DBuf<int32_t> d_cells, d_dofs;
+        DBuf<uint8_t> d_bnd;
+        HIPCHK(c, d_nodes.upload(hs.nodes.data(), hs.nodes.size(), c->stream));
+        HIPCHK(c, d_cells.upload(hs.cells.data(), hs.cells.size(), c->stream));
+        HIPCHK(c, d_bnd.upload(hs.dof_bnd.data(), hs.dof_bnd.size(), c->stream));
+        if (order != 1) {
+            HIPCHK(c, d_dofs.upload(hs.dofs.data(), hs.dofs.size(), c->stream));
+            HIPCHK(c, d_coords.upload(hs.dof_coords.data(), hs.dof_coords.size(), c->stream));
+        }
+        DevSpace ds;
+        rc = dev_build_space(hs, d_nodes.p, d_cells.p, order == 1 ? d_cells.p : d_dofs.p, d_bnd.p, order == 1 ? d_nodes.p : d_coords.p, c->stream,
+                             &ds, c->err);
+        d_nodes.release(), d_coords.release(), d_cells.release(), d_dofs.release(), d_bnd.release();
+        if (rc) return rc;
+        if (std::getenv("FDAPDE_SETUP_CHECK")) {
+            rc = check_dev_space(c, ds, order);
+            if (rc) {
+                dev_space_release(&ds);
+                return rc;
+            }
+        }
+        rc = adopt_dev_space(c, ds);
+        if (rc) return rc;
+    }
     c->space_ready = true;
     if (n_dofs) *n_dofs = c->hs.n_dofs;
     if (c->has_device) {
@@ -764,6 +902,7 @@ int fdapde_dofs_get(const fdapde_ctx* c, int32_t* dofs, uint8_t* bnd, double* co
 
 int fdapde_pattern_get(const fdapde_ctx* c, int32_t* rowptr, int32_t* colidx) {
     if (!c || !c->space_ready) return FDAPDE_ENOTINIT;
+    if (int rc = ensure_host(const_cast<fdapde_ctx*>(c), kHostRefPattern)) return rc;   // a device-built space keeps it on the device until asked
     if (rowptr) std::memcpy(rowptr, c->hs.rowptr_e.data(), sizeof(int32_t) * c->hs.rowptr_e.size());
     if (colidx) std::memcpy(colidx, c->hs.colidx_e.data(), sizeof(int32_t) * c->hs.colidx_e.size());
     return FDAPDE_OK;
@@ -909,9 +1048,9 @@ int fdapde_init(fdapde_ctx* c, const fdapde_options* opt) {
     // forcing quadrature, first half (fem_assembler.h:122-136): column 0 as ONE load coefficient per visit slot of the row-owner
     // sweep, sum_q w_q f_q psi_i(p_q), in the summation order the visit loop would use; the sweep below then streams one
     // coalesced double per visit instead of gathering the cell's samples.  Runs on every init: the samples may have changed.
-    if (c->fq_cols > 0 && assembly == FDAPDE_ASSEMBLY_ROWS && c->asm_fq_block && !hs.adj.empty()) {
+    if (c->fq_cols > 0 && assembly == FDAPDE_ASSEMBLY_ROWS && c->asm_fq_block && c->adj.n > 0) {
         const int64_t n_slices = (int64_t)hs.sl_off.size() - 1;
-        HIPCHK(c, c->fq_blk.alloc(hs.adj.size()));
+        HIPCHK(c, c->fq_blk.alloc(c->adj.n));
         hipLaunchKernelGGL(k_visit_load_coeffs, dim3((unsigned)n_slices), dim3(64, 8), 0, c->stream, n_slices, hs.nq, c->sl_off.p,
                            c->adj.p, c->bc_off.p, c->bc_cell.p, c->fq.p, c->tables.p, c->fq_blk.p);
         HIPCHK(c, hipGetLastError());
@@ -956,6 +1095,7 @@ namespace {
 // and uploads, done once per function space and boundary mask (fdapde_solver_prepare, or lazily by the first solve)
 int build_solver_pattern(fdapde_ctx* c, int v) {
     if (c->sp_built[v]) return FDAPDE_OK;
+    if (int rc = ensure_host(c, kHostPattern)) return rc;
     drop_graph(c);
     hipStream_t st = c->stream;
     std::vector<int32_t> rp, ci, map, vrow;
@@ -1000,6 +1140,7 @@ int build_persist(fdapde_ctx* c, int v) {
     if (ps.tried) return FDAPDE_OK;
     ps.tried = true, ps.ok = false;
     if (c->n_cu < 1) return FDAPDE_OK;
+    if (int rc = ensure_host(c, kHostPattern)) return rc;
     PersistLayout pl;
     const int rc = host_build_persist_layout(c->hs, v == 1, c->n_cu, 12000, pl);   // ~12 000 ELL entries (120 KB) next to the vectors of <= 4096 rows
     if (rc == FDAPDE_EUNSUPPORTED) return FDAPDE_OK;
@@ -1126,7 +1267,16 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss) {
     ss->diag_positive = c->h_ctl[3] == 0;
     // scaled matrix: compact (no diagonal, no Dirichlet rows / columns: ~12 % fewer entries on C3) when every interior
     // diagonal is positive, so that the scaled diagonal is exactly 1; else the full pattern
-    const bool compact = ss->diag_positive && c->spmv_variant == 2 && !std::getenv("FDAPDE_SPMV_FULL");
+    // symmetric positive system on one GPU of at most ~2 M interior rows: the solve will run as ONE persistent launch on its own
+    // resident layout (kernels_persist.h); the multi-launch kernels then only serve the lift, warm starts and the fall-back, and
+    // take the plain full-pattern scaled matrix (no compact pattern / column codes are built for such a system)
+    c->ps[0].filled = c->ps[1].filled = false;
+    bool persist = false;
+    if (ss->diag_positive && !ss->dist && c->persist && !c->persist_broken && c->spmv_variant == 2) {
+        if (int rc = build_persist(c, use_bnd ? 1 : 0)) return rc;
+        persist = c->ps[use_bnd ? 1 : 0].ok;
+    }
+    const bool compact = !persist && ss->diag_positive && c->spmv_variant == 2 && !std::getenv("FDAPDE_SPMV_FULL");
     if (compact) {
         const int v = use_bnd ? 1 : 0;
         if (int rc = build_solver_pattern(c, v)) return rc;
@@ -1141,20 +1291,13 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss) {
         hipLaunchKernelGGL(k_scale_matrix, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, A, c->scale.p, c->sval.p);
         c->sp_cur = -1, c->sval_layout = -2;
     }
-    HIPCHK(c, hipGetLastError());
-    // small symmetric positive system on one GPU: also as the resident layout of the single-launch CG
-    c->ps[0].filled = c->ps[1].filled = false;
-    if (ss->diag_positive && !ss->dist && c->persist && !c->persist_broken && c->spmv_variant == 2) {
+    if (persist) {
         const int v = use_bnd ? 1 : 0;
-        if (int rc = build_persist(c, v)) return rc;
-        if (c->ps[v].ok) {
-            hipLaunchKernelGGL(k_scale_matrix, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, A, c->scale.p, c->tmp_v.p);
-            hipLaunchKernelGGL(k_persist_fill, dim3(g1(c->ps[v].meta.n_entries)), dim3(256), 0, st, c->ps[v].meta.n_entries,
-                               c->ps[v].ell_src.p, c->tmp_v.p, c->ps[v].ell_val.p);
-            HIPCHK(c, hipGetLastError());
-            c->ps[v].filled = true;
-        }
+        hipLaunchKernelGGL(k_persist_fill, dim3(g1(c->ps[v].meta.n_entries)), dim3(256), 0, st, c->ps[v].meta.n_entries, c->ps[v].ell_src.p,
+                           c->sval.p, c->ps[v].ell_val.p);
+        c->ps[v].filled = true;
     }
+    HIPCHK(c, hipGetLastError());
     return FDAPDE_OK;
 }
 
@@ -1448,10 +1591,14 @@ int fdapde_solver_prepare(fdapde_ctx* c, int32_t with_dirichlet) {
     if (!c->dev_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
     HIPCHK(c, hipSetDevice(c->device));
     if (c->spmv_variant != 2) return FDAPDE_OK;
-    if (int rc = build_solver_pattern(c, with_dirichlet ? 1 : 0)) return rc;
-    if (c->persist && !c->persist_broken && c->comm == nullptr && c->ar_fn == nullptr)   // single GPU: also the persistent CG's layout
-        if (int rc = build_persist(c, with_dirichlet ? 1 : 0)) return rc;
-    return FDAPDE_OK;
+    const int v = with_dirichlet ? 1 : 0;
+    if (c->persist && !c->persist_broken && c->comm == nullptr && c->ar_fn == nullptr && c->op_symmetric) {
+        // single GPU, symmetric operator: the persistent CG's resident layout; when the system qualifies for it, the compact pattern
+        // and the column codes of the multi-launch SpMV are not needed (a non-SPD matrix falls back and builds them lazily)
+        if (int rc = build_persist(c, v)) return rc;
+        if (c->ps[v].ok) return FDAPDE_OK;
+    }
+    return build_solver_pattern(c, v);
 }
 
 // What the in-solve SpMV works on, for the roofline figures of bench.py: the interior block A_II as a plain CSR operator
@@ -1464,8 +1611,10 @@ int fdapde_solver_layout(fdapde_ctx* c, int32_t with_dirichlet, int64_t* n_inter
     if (!c->dev_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
     HIPCHK(c, hipSetDevice(c->device));
     const int v = with_dirichlet ? 1 : 0;
-    if (c->spmv_variant == 2)
+    const bool persist = c->persist && !c->persist_broken && c->ps[v].tried && c->ps[v].ok;
+    if (c->spmv_variant == 2 && !persist)
         if (int rc = build_solver_pattern(c, v)) return rc;
+    if (int rc = ensure_host(c, kHostPattern)) return rc;
     const HostSpace& hs = c->hs;
     int64_t ni = 0, nz = 0;
     for (int64_t i = 0; i < hs.n_dofs; ++i) {
@@ -1477,7 +1626,10 @@ int fdapde_solver_layout(fdapde_ctx* c, int32_t with_dirichlet, int64_t* n_inter
     if (n_interior) *n_interior = ni;
     if (nnz_interior) *nnz_interior = nz;
     if (streamed_bytes) {
-        if (c->spmv_variant == 2 && c->sp_built[v]) {
+        if (persist) {   // one iteration of the persistent CG: the ELL blocks (8 + 2 bytes per entry, padding included) + the exchanged
+                         // entries of p (two 8-byte granules each, written once and read once)
+            *streamed_bytes = 10.0 * (double)c->ps[v].meta.n_entries + 32.0 * (double)c->ps[v].meta.n_board;
+        } else if (c->spmv_variant == 2 && c->sp_built[v]) {
             const int64_t n_csr = c->sp_nv[v] > 0 ? c->sp_nv[v] : hs.n_dofs;
             *streamed_bytes = 10.0 * (double)c->sp_nnz[v] + 4.0 * (double)(n_csr + 1) + 16.0 * (double)((n_csr + kCodeRows - 1) / kCodeRows) +
                               (c->sp_nv[v] > 0 ? 8.0 * (double)n_csr : 0.0) + 16.0 * (double)hs.n_dofs +
@@ -1757,6 +1909,7 @@ int fdapde_eval_pointwise(fdapde_ctx* c, int64_t n_locs, const double* locs_colm
     if (int rc = need_device(c)) return rc;
     if (!c->dev_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
     HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = ensure_host(c, kHostCells)) return rc;
     const HostSpace& hs = c->hs;
     const int M = hs.M, nv = M + 1, NP = M == 2 ? 2 : 4;
     // uniform grid with about one cell per bin on average

@@ -15,6 +15,7 @@
 #include <rccl/rccl.h>
 
 #include "../../include/fdapde_hip.h"
+#include "dev_setup.h"
 #include "dev_topology.h"
 #include "internal.h"
 #include "kernels.h"
@@ -142,6 +143,8 @@ struct fdapde_ctx {
     fdapde_info info{};
     // device buffers
     DBuf<int32_t> cverts, cdofs, adj, rowptr, colidx, diag, slot_i2e, dof_i2e, dof_e2i, cell_i2e, rb_row, colour_cells;
+    DBuf<int32_t> rowptr_e, colidx_e;   // reference-numbering pattern (device-built spaces: fetched by fdapde_pattern_get on demand)
+    bool dev_built = false;             // the index structures were built on the device (dev_setup.hip); big host mirrors are lazy
     DBuf<uint32_t> slotw;
     DBuf<int64_t> bc_off, bn_off;
     DBuf<int32_t> bc_cell, bn_node;

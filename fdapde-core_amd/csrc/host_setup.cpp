@@ -425,7 +425,7 @@ int host_set_mesh(HostSpace& hs, int M, int N, int64_t n_nodes, const double* no
     return FDAPDE_OK;
 }
 
-int host_build_space(HostSpace& hs, int order, std::string& err) {
+int host_build_space(HostSpace& hs, int order, std::string& err, bool dofs_only) {
     auto t0 = std::chrono::steady_clock::now();
     auto t_phase = t0;
     const bool dbg_time = std::getenv("FDAPDE_DEBUG_SETUP") != nullptr;
@@ -508,6 +508,7 @@ int host_build_space(HostSpace& hs, int order, std::string& err) {
     }
 
     phase("dof coordinates");
+    if (dofs_only) return FDAPDE_OK;   // the device builder (dev_setup.hip) takes it from here
     // ---- locality numbering --------------------------------------------------------------------------------
     hs.node_i2e = morton_order(N, nn, hs.nodes.data());
     hs.node_e2i = invert(hs.node_i2e);

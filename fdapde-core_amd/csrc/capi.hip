@@ -1132,6 +1132,39 @@ int build_solver_pattern(fdapde_ctx* c, int v) {
     return FDAPDE_OK;
 }
 
+// FDAPDE_SETUP_CHECK: the device-built persistent layout against the host builder's
+int check_dev_persist(fdapde_ctx* c, int v, const PersistLayout& pl, const DevPersist& dp) {
+    if (int rc = ensure_host(c, kHostPattern)) return rc;
+    PersistLayout ref;
+    if (host_build_persist_layout(c->hs, v == 1, c->n_cu, 12000, ref) != FDAPDE_OK) return fail(c, FDAPDE_EHIP, "set-up check: host persistent layout failed");
+    int bad = 0;
+    auto scalar = [&](const char* name, int64_t a, int64_t b) {
+        if (a != b) std::fprintf(stderr, "persist check %-9s: MISMATCH %lld vs %lld\n", name, (long long)a, (long long)b), ++bad;
+    };
+    scalar("G", pl.G, ref.G), scalar("R", pl.R, ref.R), scalar("n_int", pl.n_int, ref.n_int), scalar("n_entries", pl.n_entries, ref.n_entries);
+    scalar("nnz", pl.nnz, ref.nnz), scalar("n_board", pl.n_board, ref.n_board), scalar("max_imp", pl.max_imp, ref.max_imp), scalar("max_exp", pl.max_exp, ref.max_exp);
+    auto cmp = [&](const char* name, const void* dev, const void* host, size_t bytes, size_t elem) {
+        std::vector<unsigned char> tmp(bytes ? bytes : 1);
+        if (bytes && hipMemcpy(tmp.data(), dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+            ++bad;
+            return;
+        }
+        size_t at = 0;
+        while (at < bytes && tmp[at] == static_cast<const unsigned char*>(host)[at]) ++at;
+        if (at < bytes) std::fprintf(stderr, "persist check %-9s: MISMATCH at element %zu of %zu\n", name, at / elem, bytes / elem), ++bad;
+        else std::fprintf(stderr, "persist check %-9s: ok (%zu elements)\n", name, bytes / elem);
+    };
+    if (bad == 0) {
+#define CMP(name, dptr, hvec_) cmp(name, dptr, (hvec_).data(), (hvec_).size() * sizeof((hvec_)[0]), sizeof((hvec_)[0]))
+        CMP("slot_dof", dp.slot_dof, ref.slot_dof), CMP("ell_off", dp.ell_off, ref.ell_off), CMP("sl_off", dp.sl_off, ref.sl_off);
+        CMP("ell_code", dp.ell_code, ref.ell_code), CMP("ell_src", dp.ell_src, ref.ell_src), CMP("exp_off", dp.exp_off, ref.exp_off);
+        CMP("exp_slot", dp.exp_slot, ref.exp_slot), CMP("imp_off", dp.imp_off, ref.imp_off), CMP("imp_pos", dp.imp_pos, ref.imp_pos);
+#undef CMP
+    }
+    if (bad) return fail(c, FDAPDE_EHIP, "FDAPDE_SETUP_CHECK: the device-built persistent layout differs from the host builder's (see stderr)");
+    return FDAPDE_OK;
+}
+
 // resident layout of the persistent CG for boundary variant v (kernels_persist.h): host index work + uploads, once per function
 // space and boundary mask.  ok stays false when the system does not qualify (too many rows for one launch of resident
 // workgroups, or more matrix than is worth re-reading from the caches every iteration).
@@ -1140,52 +1173,81 @@ int build_persist(fdapde_ctx* c, int v) {
     if (ps.tried) return FDAPDE_OK;
     ps.tried = true, ps.ok = false;
     if (c->n_cu < 1) return FDAPDE_OK;
-    if (int rc = ensure_host(c, kHostPattern)) return rc;
     PersistLayout pl;
-    const int rc = host_build_persist_layout(c->hs, v == 1, c->n_cu, 12000, pl);   // ~12 000 ELL entries (120 KB) next to the vectors of <= 4096 rows
+    DevPersist dp;
+    const char* mode = std::getenv("FDAPDE_SETUP");
+    bool on_device = !(mode && std::strcmp(mode, "host") == 0);
+    int rc = FDAPDE_EUNSUPPORTED;
+    if (on_device) {   // the layout is built where the pattern lives (dev_persist.hip)
+        rc = dev_build_persist_layout(c->hs.n_dofs, c->hs.max_row, c->rowptr.p, c->colidx.p, c->bnd.p, v == 1, c->n_cu, 12000, c->stream, pl, &dp, c->err);
+        if (rc == FDAPDE_EUNSUPPORTED && c->hs.max_row > 255) on_device = false;   // rows too long for its sort keys: host builder
+    }
+    if (!on_device) {
+        if (int rc2 = ensure_host(c, kHostPattern)) return rc2;
+        rc = host_build_persist_layout(c->hs, v == 1, c->n_cu, 12000, pl);   // ~12 000 ELL entries (120 KB) next to the vectors of <= 4096 rows
+    }
     if (rc == FDAPDE_EUNSUPPORTED) return FDAPDE_OK;
     if (rc) return rc;
     double max_mb = 1024.0;   // ELL bytes (10 per entry) of the whole system (the row bound -- G x 8192 -- is reached first for P1 systems)
     if (const char* e = std::getenv("FDAPDE_PERSIST_MAX_MB")) max_mb = std::atof(e);
-    if (10.0 * (double)pl.n_entries > max_mb * 1e6) return FDAPDE_OK;
+    if (10.0 * (double)pl.n_entries > max_mb * 1e6) {
+        dev_persist_release(&dp);
+        return FDAPDE_OK;
+    }
     const int S = pl.R * kPersistT;
     const int imp_cap = (pl.max_imp + 63) & ~63, exp_cap = (pl.max_exp + 63) & ~63;
     const size_t lds_total = 160 * 1024 - 1024;   // static arrays of the kernel + slack
     const size_t fixed = 8 * (size_t)(S + imp_cap) + 4 * (size_t)imp_cap + 2 * (size_t)exp_cap + 64;
-    if (fixed > lds_total) return FDAPDE_OK;
-    int64_t need = 0;   // largest workgroup block
-    for (int g = 0; g < pl.G; ++g) need = std::max<int64_t>(need, pl.ell_off[(size_t)g + 1] - pl.ell_off[(size_t)g]);
+    int64_t need = pl.max_block;   // largest workgroup block
+    for (int g = 0; g < pl.G && !on_device; ++g) need = std::max<int64_t>(need, pl.ell_off[(size_t)g + 1] - pl.ell_off[(size_t)g]);
     need += 128;        // one pair row of zeros behind the block: slices narrower than their pass's widest re-read it (clamped loads)
     // resident form when every block fits its workgroup's LDS next to the vectors; else the blocks stream every iteration
     ps.stream = fixed + 10 * (size_t)need > lds_total;
+    if (fixed > lds_total || (pl.R == 16 && !ps.stream)) {   // (no resident instantiation for 8192 rows: they never fit)
+        dev_persist_release(&dp);
+        return FDAPDE_OK;
+    }
     ps.lds_cap = ps.stream ? 0 : (int32_t)need, ps.imp_cap = imp_cap;
     ps.lds_bytes = fixed + (ps.stream ? 0 : 10 * (size_t)need);
-    if (pl.R == 16 && !ps.stream) return FDAPDE_OK;   // (no such instantiation: 8192 rows never fit)
     hipStream_t st = c->stream;
-    HIPCHK(c, ps.slot_dof.upload(pl.slot_dof.data(), pl.slot_dof.size(), st));
-    HIPCHK(c, ps.ell_off.upload(pl.ell_off.data(), pl.ell_off.size(), st));
-    HIPCHK(c, ps.sl_off.upload(pl.sl_off.data(), pl.sl_off.size(), st));
-    HIPCHK(c, ps.ell_code.alloc(pl.ell_code.size() + 256));   // + slack: clamped loads of the last slices may run past the last block
-    HIPCHK(c, hipMemsetAsync(ps.ell_code.p, 0, sizeof(uint16_t) * (pl.ell_code.size() + 256), st));
-    HIPCHK(c, hipMemcpyAsync(ps.ell_code.p, pl.ell_code.data(), sizeof(uint16_t) * pl.ell_code.size(), hipMemcpyHostToDevice, st));
-    HIPCHK(c, ps.ell_src.upload(pl.ell_src.data(), pl.ell_src.size(), st));
-    HIPCHK(c, ps.exp_off.upload(pl.exp_off.data(), pl.exp_off.size(), st));
-    HIPCHK(c, ps.exp_slot.upload(pl.exp_slot.data(), pl.exp_slot.size(), st));
-    HIPCHK(c, ps.imp_off.upload(pl.imp_off.data(), pl.imp_off.size(), st));
-    HIPCHK(c, ps.imp_pos.upload(pl.imp_pos.data(), pl.imp_pos.size(), st));
+    if (on_device) {
+        if (std::getenv("FDAPDE_SETUP_CHECK")) {
+            if (int rc2 = check_dev_persist(c, v, pl, dp)) {
+                dev_persist_release(&dp);
+                return rc2;
+            }
+        }
+        const size_t GS = (size_t)pl.G * S, n_alloc = (size_t)pl.n_entries + 256;
+        adopt(ps.slot_dof, dp.slot_dof, GS), adopt(ps.ell_off, dp.ell_off, (size_t)pl.G + 1), adopt(ps.sl_off, dp.sl_off, (size_t)pl.G * (pl.nsl + 1));
+        adopt(ps.ell_code, dp.ell_code, n_alloc), adopt(ps.ell_src, dp.ell_src, n_alloc), adopt(ps.exp_off, dp.exp_off, (size_t)pl.G + 1);
+        adopt(ps.exp_slot, dp.exp_slot, (size_t)(pl.n_board ? pl.n_board : 1)), adopt(ps.imp_off, dp.imp_off, (size_t)pl.G + 1);
+        adopt(ps.imp_pos, dp.imp_pos, (size_t)(pl.n_imp ? pl.n_imp : 1));
+    } else {
+        HIPCHK(c, ps.slot_dof.upload(pl.slot_dof.data(), pl.slot_dof.size(), st));
+        HIPCHK(c, ps.ell_off.upload(pl.ell_off.data(), pl.ell_off.size(), st));
+        HIPCHK(c, ps.sl_off.upload(pl.sl_off.data(), pl.sl_off.size(), st));
+        HIPCHK(c, ps.ell_code.alloc(pl.ell_code.size() + 256));   // + slack: clamped loads of the last slices may run past the last block
+        HIPCHK(c, hipMemsetAsync(ps.ell_code.p, 0, sizeof(uint16_t) * (pl.ell_code.size() + 256), st));
+        HIPCHK(c, hipMemcpyAsync(ps.ell_code.p, pl.ell_code.data(), sizeof(uint16_t) * pl.ell_code.size(), hipMemcpyHostToDevice, st));
+        HIPCHK(c, ps.ell_src.upload(pl.ell_src.data(), pl.ell_src.size(), st));
+        HIPCHK(c, ps.exp_off.upload(pl.exp_off.data(), pl.exp_off.size(), st));
+        HIPCHK(c, ps.exp_slot.upload(pl.exp_slot.data(), pl.exp_slot.size(), st));
+        HIPCHK(c, ps.imp_off.upload(pl.imp_off.data(), pl.imp_off.size(), st));
+        HIPCHK(c, ps.imp_pos.upload(pl.imp_pos.data(), pl.imp_pos.size(), st));
+    }
     HIPCHK(c, ps.ell_val.alloc((size_t)pl.n_entries + 256));
     HIPCHK(c, hipMemsetAsync(ps.ell_val.p, 0, sizeof(double) * ((size_t)pl.n_entries + 256), st));
     HIPCHK(c, ps.board.alloc(2 * (size_t)pl.n_board + 2 * (size_t)pl.G * 6 + 2));   // p entries | dot partials x 2 parities
     HIPCHK(c, c->persist_stats.alloc(4 * 1024));
     HIPCHK(c, hipStreamSynchronize(st));
     if (std::getenv("FDAPDE_DEBUG_SETUP"))
-        std::fprintf(stderr, "persistent CG layout %d: %d workgroups x %d rows/thread, %lld interior rows, %lld entries (%lld stored, %.1f %% padding), "
-                     "LDS %zu B (%s, largest block %lld), imports <= %d, exports <= %d, board %lld\n", v, pl.G, pl.R,
+        std::fprintf(stderr, "persistent CG layout %d (%s-built): %d workgroups x %d rows/thread, %lld interior rows, %lld entries (%lld stored, %.1f %% padding), "
+                     "LDS %zu B (%s, largest block %lld), imports <= %d, exports <= %d, board %lld\n", v, on_device ? "device" : "host", pl.G, pl.R,
                      (long long)pl.n_int, (long long)pl.n_entries, (long long)pl.nnz,
                      100.0 * (double)(pl.n_entries - pl.nnz) / (double)(pl.n_entries > 0 ? pl.n_entries : 1), ps.lds_bytes,
                      ps.stream ? "blocks stream" : "blocks resident", (long long)need, pl.max_imp, pl.max_exp, (long long)pl.n_board);
     // keep the sizes, drop the big host arrays
-    pl.slot_dof = {}, pl.ell_code = {}, pl.ell_src = {}, pl.exp_slot = {}, pl.imp_pos = {}, pl.sl_off = {};
+    pl.slot_dof = {}, pl.ell_code = {}, pl.ell_src = {}, pl.exp_slot = {}, pl.imp_pos = {}, pl.sl_off = {}, pl.ell_off = {};
     ps.meta = std::move(pl);
     ps.filled = false, ps.ok = true;
     return FDAPDE_OK;

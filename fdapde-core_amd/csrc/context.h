@@ -15,6 +15,7 @@
 #include <rccl/rccl.h>
 
 #include "../../include/fdapde_hip.h"
+#include "dev_persist.h"
 #include "dev_setup.h"
 #include "dev_topology.h"
 #include "internal.h"

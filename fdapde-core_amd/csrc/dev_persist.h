@@ -1,0 +1,25 @@
+// dev_persist.h -- the persistent CG's resident layout built on the device (dev_persist.hip); plain C++ interface used by capi.hip.
+#ifndef FDAPDE_DEV_PERSIST_H
+#define FDAPDE_DEV_PERSIST_H
+
+#include <cstdint>
+#include <string>
+
+#include "internal.h"
+
+namespace fdapde_hip {
+
+struct DevPersist {   // device arrays (hipMalloc'd here; ownership passes to the caller), same contents as PersistLayout's vectors
+    int32_t *slot_dof = nullptr, *sl_off = nullptr, *ell_src = nullptr, *exp_off = nullptr, *imp_off = nullptr, *imp_pos = nullptr;
+    int64_t* ell_off = nullptr;
+    uint16_t *ell_code = nullptr, *exp_slot = nullptr;
+};
+void dev_persist_release(DevPersist* p);
+// rowptr / colidx / bnd: the internal pattern and boundary flags on the device.  Fills the sizes of `pl` (G, R, nsl, n_int, n_entries,
+// nnz, n_board, max_imp, max_exp, max_block); its vectors stay empty.  FDAPDE_EUNSUPPORTED: the system does not qualify (as the host
+// builder) or a row is longer than 255 entries (the caller then asks the host builder).
+int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowptr, const int32_t* d_colidx, const uint8_t* d_bnd, bool use_bnd,
+                             int n_wg, int lds_entries, void* stream, PersistLayout& pl, DevPersist* out, std::string& err);
+
+}  // namespace fdapde_hip
+#endif

@@ -1,0 +1,459 @@
+// dev_persist.hip -- the resident layout of the persistent CG (kernels_persist.h) built ON THE DEVICE: the same arrays as
+// host_build_persist_layout (host_persist.cpp), produced by radix sorts, scans and small kernels instead of per-workgroup host loops.
+//   rows of a workgroup      one 64-bit key per interior row -- (workgroup, imports?, 255 - length, DOF) -- sorted once gives the host's
+//                            (halo, length descending, DOF) order; a second key moves the rows that do not fit the import-free half
+//                            behind it in the host's stable (length descending) order; slot = position in its class
+//   import / export lists    (workgroup, DOF) pairs of the entries that leave a workgroup, sorted and deduplicated; exported rows ranked
+//                            in slot order = board positions; imports re-sorted by board position
+//   sliced ELL               slice widths by a max over 64 slots, offsets by one scan, entries written by the thread that owns the row
+// FDAPDE_SETUP_CHECK=1 compares every array with the host builder's.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "dev_persist.h"
+
+namespace fdapde_hip {
+
+namespace {
+
+#define DP_CHK(expr)                                                          \
+    do {                                                                      \
+        hipError_t e__ = (expr);                                              \
+        if (e__ != hipSuccess) {                                              \
+            err = std::string(#expr) + ": " + hipGetErrorString(e__);         \
+            return FDAPDE_EHIP;                                               \
+        }                                                                     \
+    } while (0)
+
+template <typename T> struct Tmp {
+    T* p = nullptr;
+    hipError_t alloc(size_t count) {
+        if (p) (void)hipFree(p);
+        return hipMalloc(reinterpret_cast<void**>(&p), sizeof(T) * (count ? count : 1));
+    }
+    ~Tmp() {
+        if (p) (void)hipFree(p);
+    }
+};
+struct Scratch {
+    void* p = nullptr;
+    size_t n = 0;
+    hipError_t need(size_t bytes) {
+        if (bytes <= n) return hipSuccess;
+        if (p) (void)hipFree(p);
+        n = bytes + bytes / 4;
+        return hipMalloc(&p, n);
+    }
+    ~Scratch() {
+        if (p) (void)hipFree(p);
+    }
+};
+inline unsigned grid_of(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+__device__ __forceinline__ bool kept_entry(const uint8_t* keep, int32_t row, int32_t col) { return col != row && keep[col]; }
+
+__global__ void k_keep_flags(int64_t nd, const uint8_t* bnd, int use_bnd, uint8_t* keep, int32_t* keep32) {
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= nd) return;
+    const uint8_t k = (use_bnd && bnd[d]) ? 0 : 1;
+    keep[d] = k, keep32[d] = k;
+}
+__global__ void k_row_lengths(int64_t nd, const int32_t* rowptr, const int32_t* colidx, const uint8_t* keep, int32_t* len) {
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= nd) return;
+    int32_t n = 0;
+    if (keep[d])
+        for (int32_t k = rowptr[d]; k < rowptr[d + 1]; ++k) n += kept_entry(keep, (int32_t)d, colidx[k]);
+    len[d] = n;
+}
+// per interior row: does it read another workgroup's rows, and how many such entries; per workgroup: rows that do
+__global__ void k_row_halo(int64_t nd, const int32_t* rowptr, const int32_t* colidx, const uint8_t* keep, const int32_t* irow, int32_t rpw,
+                           uint8_t* halo, int32_t* n_out, int32_t* wg_halo) {
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= nd) return;
+    int32_t n = 0;
+    if (keep[d]) {
+        const int32_t g = irow[d] / rpw;
+        for (int32_t k = rowptr[d]; k < rowptr[d + 1]; ++k) {
+            const int32_t c = colidx[k];
+            n += kept_entry(keep, (int32_t)d, c) && irow[c] / rpw != g;
+        }
+        if (n) atomicAdd(&wg_halo[g], 1);
+    }
+    halo[d] = n ? 1 : 0, n_out[d] = n;
+}
+__global__ void k_import_pairs(int64_t nd, const int32_t* rowptr, const int32_t* colidx, const uint8_t* keep, const int32_t* irow, int32_t rpw,
+                               const int32_t* at, uint64_t* key) {
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= nd || !keep[d]) return;
+    const int32_t g = irow[d] / rpw;
+    int32_t o = at[d];
+    for (int32_t k = rowptr[d]; k < rowptr[d + 1]; ++k) {
+        const int32_t c = colidx[k];
+        if (kept_entry(keep, (int32_t)d, c) && irow[c] / rpw != g) key[o++] = ((uint64_t)(uint32_t)g << 32) | (uint32_t)c;
+    }
+}
+__global__ void k_unique_flags(int64_t n, const uint64_t* key, int32_t* flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = (i == 0 || key[i] != key[i - 1]) ? 1 : 0;
+}
+__global__ void k_compact_keys(int64_t n, const uint64_t* key, const int32_t* flag, const int32_t* pos, uint64_t* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) out[pos[i]] = key[i];
+}
+// first ordering of the rows of a workgroup: (imports?, length descending, DOF)
+__global__ void k_row_keys1(int64_t nd, const uint8_t* keep, const int32_t* irow, int32_t rpw, const uint8_t* halo, const int32_t* len,
+                            uint64_t* key, int32_t* val) {
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= nd || !keep[d]) return;
+    const int32_t i = irow[d];
+    key[i] = ((uint64_t)(uint32_t)(i / rpw) << 41) | ((uint64_t)halo[d] << 40) | ((uint64_t)(255 - len[d]) << 32) | (uint32_t)d;
+    val[i] = (int32_t)d;
+}
+// second ordering: the first `sa` import-free rows keep their rank; the others follow in (length descending, imports?, DOF) order
+__global__ void k_row_keys2(int64_t n_int, const int32_t* dof_sorted, int32_t rpw, int32_t sa, const uint8_t* halo, const int32_t* len,
+                            uint64_t* key) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_int) return;
+    const int32_t d = dof_sorted[p];
+    const int64_t g = p / rpw, rank = p - g * rpw;   // the rows of workgroup g are positions [g rpw, (g + 1) rpw) of the first ordering
+    const bool first = !halo[d] && rank < sa;
+    const uint64_t payload = first ? (uint64_t)rank : (((uint64_t)(255 - len[d]) << 33) | ((uint64_t)halo[d] << 32) | (uint32_t)d);
+    key[p] = ((uint64_t)g << 42) | ((uint64_t)(first ? 0 : 1) << 41) | payload;
+}
+__global__ void k_assign_slots(int64_t n_int, const int32_t* dof_sorted, int32_t rpw, int32_t sa, int32_t S, const int32_t* wg_noimp, int32_t* slot_of,
+                               int32_t* slot_dof) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_int) return;
+    const int32_t d = dof_sorted[p];
+    const int64_t g = p / rpw, i = p - g * rpw;
+    const int32_t n_a = min(wg_noimp[g], sa);
+    const int32_t slot = i < n_a ? (int32_t)i : sa + (int32_t)(i - n_a);
+    slot_of[d] = slot;
+    slot_dof[g * S + slot] = d;
+}
+__global__ void k_mark_exports(int64_t n_imp, const uint64_t* imp_key, uint8_t* is_exp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_imp) is_exp[imp_key[i] & 0xffffffffu] = 1;
+}
+__global__ void k_export_keys(int64_t nd, const uint8_t* is_exp, const int32_t* irow, int32_t rpw, const int32_t* slot_of, uint64_t* key, int32_t* val,
+                              int32_t* n_out, int32_t* wg_exp) {
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= nd || !is_exp[d]) return;
+    const int32_t g = irow[d] / rpw;
+    const int32_t o = atomicAdd(n_out, 1);
+    key[o] = ((uint64_t)(uint32_t)g << 32) | (uint32_t)slot_of[d];
+    val[o] = (int32_t)d;
+    atomicAdd(&wg_exp[g], 1);
+}
+__global__ void k_board_tables(int64_t n_board, const uint64_t* key_sorted, const int32_t* dof_sorted, uint16_t* exp_slot, int32_t* board_of) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_board) return;
+    exp_slot[i] = (uint16_t)(key_sorted[i] & 0xffffu);
+    board_of[dof_sorted[i]] = (int32_t)i;
+}
+__global__ void k_import_board_keys(int64_t n_imp, const uint64_t* imp_key, const int32_t* board_of, uint64_t* key, int32_t* wg_imp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_imp) return;
+    const uint64_t g = imp_key[i] >> 32;
+    key[i] = (g << 32) | (uint32_t)board_of[imp_key[i] & 0xffffffffu];
+    atomicAdd(&wg_imp[g], 1);
+}
+__global__ void k_low32(int64_t n, const uint64_t* key, int32_t* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int32_t)(key[i] & 0xffffffffu);
+}
+__global__ void k_slice_pairs(int64_t n_sl, const int32_t* slot_dof, const int32_t* len, int32_t* pairs) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // global slice index g * nsl + q
+    if (q >= n_sl) return;
+    int32_t w = 0;
+    for (int l = 0; l < 64; ++l) {
+        const int32_t d = slot_dof[q * 64 + l];
+        if (d >= 0) w = max(w, len[d]);
+    }
+    pairs[q] = (w + 1) / 2;
+}
+__global__ void k_slice_offsets(int G, int nsl, const int32_t* scan, int32_t* sl_off, int64_t* ell_off, int32_t* max_block) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)G * (nsl + 1)) return;
+    const int64_t g = t / (nsl + 1), q = t - g * (nsl + 1);
+    const int32_t base = scan[g * nsl];
+    sl_off[t] = scan[g * nsl + q] - base;   // scan holds G * nsl + 1 entries: q == nsl reads the next workgroup's base / the total
+    if (q == nsl) atomicMax(max_block, scan[g * nsl + nsl] - base);
+    if (q == 0) ell_off[g] = (int64_t)base * 128;
+    if (t == 0) ell_off[G] = (int64_t)scan[(int64_t)G * nsl] * 128;
+}
+__global__ void k_fill_ell(int64_t n_slots, int32_t S, int nsl, const int32_t* slot_dof, const int32_t* rowptr, const int32_t* colidx, const uint8_t* keep,
+                           const int32_t* irow, int32_t rpw, const int32_t* slot_of, const int32_t* board_of, const int32_t* imp_off,
+                           const int32_t* imp_pos, const int32_t* sl_off, const int64_t* ell_off, uint16_t* code, int32_t* src) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // g * S + slot
+    if (t >= n_slots) return;
+    const int32_t d = slot_dof[t];
+    if (d < 0) return;
+    const int64_t g = t / S;
+    const int32_t s = (int32_t)(t - g * S), q = s / 64, l = s % 64;
+    const int64_t base = ell_off[g] + (int64_t)sl_off[g * (nsl + 1) + q] * 128 + 2 * l;
+    int32_t e = 0;
+    for (int32_t k = rowptr[d]; k < rowptr[d + 1]; ++k) {
+        const int32_t c = colidx[k];
+        if (!kept_entry(keep, d, c)) continue;
+        const int64_t at = base + (int64_t)(e / 2) * 128 + (e & 1);
+        src[at] = k;
+        if (irow[c] / rpw == (int32_t)g) {
+            code[at] = (uint16_t)slot_of[c];
+        } else {   // position of the column's board entry in this workgroup's import list (sorted by board position)
+            int32_t lo = imp_off[g], hi = imp_off[g + 1];
+            const int32_t b = board_of[c];
+            while (lo < hi) {
+                const int32_t mid = (lo + hi) >> 1;
+                if (imp_pos[mid] < b) lo = mid + 1; else hi = mid;
+            }
+            code[at] = (uint16_t)(S + (lo - imp_off[g]));
+        }
+        ++e;
+    }
+}
+__global__ void k_scatter_irow(int64_t nd, const uint8_t* keep, const int32_t* irow_scan, int32_t* irow) {
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < nd) irow[d] = keep[d] ? irow_scan[d] : -1 - irow_scan[d];   // dropped rows: negative, never compared as a workgroup
+}
+
+template <typename K, typename V>
+int sort_pairs(Scratch& sc, K* k_in, K* k_out, V* v_in, V* v_out, int64_t n, int end_bit, hipStream_t st, std::string& err) {
+    size_t need = 0;
+    DP_CHK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k_in, k_out, v_in, v_out, (int)n, 0, end_bit, st));
+    DP_CHK(sc.need(need));
+    DP_CHK(hipcub::DeviceRadixSort::SortPairs(sc.p, need, k_in, k_out, v_in, v_out, (int)n, 0, end_bit, st));
+    return FDAPDE_OK;
+}
+template <typename K> int sort_keys(Scratch& sc, K* k_in, K* k_out, int64_t n, int end_bit, hipStream_t st, std::string& err) {
+    size_t need = 0;
+    DP_CHK(hipcub::DeviceRadixSort::SortKeys(nullptr, need, k_in, k_out, (int)n, 0, end_bit, st));
+    DP_CHK(sc.need(need));
+    DP_CHK(hipcub::DeviceRadixSort::SortKeys(sc.p, need, k_in, k_out, (int)n, 0, end_bit, st));
+    return FDAPDE_OK;
+}
+template <typename In, typename Out> int exclusive_sum(Scratch& sc, In* in, Out* out, int64_t n, hipStream_t st, std::string& err) {
+    size_t need = 0;
+    DP_CHK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, in, out, (int)n, st));
+    DP_CHK(sc.need(need));
+    DP_CHK(hipcub::DeviceScan::ExclusiveSum(sc.p, need, in, out, (int)n, st));
+    return FDAPDE_OK;
+}
+
+}  // namespace
+
+void dev_persist_release(DevPersist* p) {
+    if (!p) return;
+    for (void* q : {(void*)p->slot_dof, (void*)p->sl_off, (void*)p->ell_src, (void*)p->exp_off, (void*)p->imp_off, (void*)p->imp_pos, (void*)p->ell_off,
+                    (void*)p->ell_code, (void*)p->exp_slot})
+        if (q) (void)hipFree(q);
+    *p = DevPersist{};
+}
+
+int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowptr, const int32_t* d_colidx, const uint8_t* d_bnd, bool use_bnd,
+                             int n_wg, int lds_entries, void* stream, PersistLayout& pl, DevPersist* out, std::string& err) {
+    constexpr int T = kPersistT;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (n_wg < 1 || nd < 1 || max_row > 255) return FDAPDE_EUNSUPPORTED;   // the row keys carry 255 - length in 8 bits
+    if (n_wg > T) n_wg = T;
+    Scratch sc;
+    DevPersist o;
+    struct Guard {
+        DevPersist* p;
+        bool armed = true;
+        ~Guard() {
+            if (armed) dev_persist_release(p);
+        }
+    } guard{&o};
+    Tmp<uint8_t> keep, halo, is_exp;
+    Tmp<int32_t> keep32, irow_scan, irow, len, n_imp_row, imp_at, wg_cnt;   // wg_cnt: [0..G) halo rows, [G..2G) exports, [2G..3G) imports
+    DP_CHK(keep.alloc((size_t)nd));
+    DP_CHK(keep32.alloc((size_t)nd + 1));
+    DP_CHK(irow_scan.alloc((size_t)nd + 1));
+    DP_CHK(irow.alloc((size_t)nd));
+    DP_CHK(len.alloc((size_t)nd + 1));
+    DP_CHK(hipMemsetAsync(keep32.p + nd, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_keep_flags, dim3(grid_of(nd)), dim3(256), 0, st, nd, d_bnd, use_bnd ? 1 : 0, keep.p, keep32.p);
+    if (int rc = exclusive_sum(sc, keep32.p, irow_scan.p, nd + 1, st, err)) return rc;
+    hipLaunchKernelGGL(k_scatter_irow, dim3(grid_of(nd)), dim3(256), 0, st, nd, keep.p, irow_scan.p, irow.p);
+    DP_CHK(hipMemsetAsync(len.p + nd, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_row_lengths, dim3(grid_of(nd)), dim3(256), 0, st, nd, d_rowptr, d_colidx, keep.p, len.p);
+    Tmp<int32_t> len_scan;
+    DP_CHK(len_scan.alloc((size_t)nd + 1));
+    if (int rc = exclusive_sum(sc, len.p, len_scan.p, nd + 1, st, err)) return rc;
+    int32_t h_nint = 0, h_nnz = 0;
+    DP_CHK(hipMemcpyAsync(&h_nint, irow_scan.p + nd, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    DP_CHK(hipMemcpyAsync(&h_nnz, len_scan.p + nd, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    DP_CHK(hipStreamSynchronize(st));
+    const int64_t n_int = h_nint, nnz_kept = h_nnz;
+    if (n_int < 1) return FDAPDE_EUNSUPPORTED;
+    // workgroups: ~2048 rows each, more (fewer rows each) when that makes every block of the matrix fit its workgroup's LDS
+    int64_t want = (n_int + 2047) / 2048;
+    if (lds_entries > 0) want = std::max<int64_t>(want, (nnz_kept + nnz_kept / 16 + lds_entries - 1) / lds_entries);
+    int G = (int)std::min<int64_t>(n_wg, want);
+    if (G < 1) G = 1;
+    const int64_t rpw = (n_int + G - 1) / G;
+    G = (int)((n_int + rpw - 1) / rpw);
+    // ---- rows that import, import pairs
+    DP_CHK(halo.alloc((size_t)nd));
+    DP_CHK(n_imp_row.alloc((size_t)nd + 1));
+    DP_CHK(imp_at.alloc((size_t)nd + 1));
+    DP_CHK(wg_cnt.alloc((size_t)3 * G));
+    DP_CHK(hipMemsetAsync(wg_cnt.p, 0, sizeof(int32_t) * 3 * (size_t)G, st));
+    DP_CHK(hipMemsetAsync(n_imp_row.p + nd, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_row_halo, dim3(grid_of(nd)), dim3(256), 0, st, nd, d_rowptr, d_colidx, keep.p, irow.p, (int32_t)rpw, halo.p, n_imp_row.p, wg_cnt.p);
+    if (int rc = exclusive_sum(sc, n_imp_row.p, imp_at.p, nd + 1, st, err)) return rc;
+    int32_t h_pairs = 0;
+    std::vector<int32_t> h_cnt(3 * (size_t)G);
+    DP_CHK(hipMemcpyAsync(&h_pairs, imp_at.p + nd, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    DP_CHK(hipMemcpyAsync(h_cnt.data(), wg_cnt.p, sizeof(int32_t) * (size_t)G, hipMemcpyDeviceToHost, st));
+    DP_CHK(hipStreamSynchronize(st));
+    int32_t max_halo = 0;
+    for (int g = 0; g < G; ++g) max_halo = std::max(max_halo, h_cnt[(size_t)g]);
+    int R = 2;
+    while ((int64_t)R * T < rpw || (int64_t)(R / 2) * T < max_halo) R *= 2;
+    if (R > kPersistRmax) return FDAPDE_EUNSUPPORTED;
+    const int S = R * T, nsl = S / 64, SA = (R / 2) * T;
+    pl.G = G, pl.R = R, pl.nsl = nsl, pl.n_int = n_int, pl.nnz = nnz_kept;
+    Tmp<uint64_t> imp_key;   // unique (workgroup, DOF) imports, DOF ascending inside a workgroup
+    int64_t n_imp = 0;
+    {
+        Tmp<uint64_t> k_a, k_s;
+        Tmp<int32_t> flag, pos;
+        DP_CHK(k_a.alloc((size_t)h_pairs));
+        DP_CHK(k_s.alloc((size_t)h_pairs));
+        DP_CHK(flag.alloc((size_t)h_pairs + 1));
+        DP_CHK(pos.alloc((size_t)h_pairs + 1));
+        hipLaunchKernelGGL(k_import_pairs, dim3(grid_of(nd)), dim3(256), 0, st, nd, d_rowptr, d_colidx, keep.p, irow.p, (int32_t)rpw, imp_at.p, k_a.p);
+        if (h_pairs > 0) {
+            if (int rc = sort_keys(sc, k_a.p, k_s.p, h_pairs, 42, st, err)) return rc;
+            DP_CHK(hipMemsetAsync(flag.p + h_pairs, 0, sizeof(int32_t), st));
+            hipLaunchKernelGGL(k_unique_flags, dim3(grid_of(h_pairs)), dim3(256), 0, st, (int64_t)h_pairs, k_s.p, flag.p);
+            if (int rc = exclusive_sum(sc, flag.p, pos.p, (int64_t)h_pairs + 1, st, err)) return rc;
+            int32_t h_n = 0;
+            DP_CHK(hipMemcpyAsync(&h_n, pos.p + h_pairs, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            DP_CHK(hipStreamSynchronize(st));
+            n_imp = h_n;
+            DP_CHK(imp_key.alloc((size_t)n_imp));
+            hipLaunchKernelGGL(k_compact_keys, dim3(grid_of(h_pairs)), dim3(256), 0, st, (int64_t)h_pairs, k_s.p, flag.p, pos.p, imp_key.p);
+            DP_CHK(hipStreamSynchronize(st));
+        }
+    }
+    // ---- slots
+    Tmp<int32_t> slot_of, dof1, wg_noimp;
+    DP_CHK(slot_of.alloc((size_t)nd));
+    DP_CHK(dof1.alloc((size_t)n_int));
+    DP_CHK(hipMalloc(reinterpret_cast<void**>(&o.slot_dof), sizeof(int32_t) * (size_t)G * S));
+    DP_CHK(hipMemsetAsync(o.slot_dof, 0xff, sizeof(int32_t) * (size_t)G * S, st));
+    {
+        Tmp<uint64_t> k_a, k_s;
+        Tmp<int32_t> v_a, v_s;
+        DP_CHK(k_a.alloc((size_t)n_int));
+        DP_CHK(k_s.alloc((size_t)n_int));
+        DP_CHK(v_a.alloc((size_t)n_int));
+        DP_CHK(v_s.alloc((size_t)n_int));
+        hipLaunchKernelGGL(k_row_keys1, dim3(grid_of(nd)), dim3(256), 0, st, nd, keep.p, irow.p, (int32_t)rpw, halo.p, len.p, k_a.p, v_a.p);
+        if (int rc = sort_pairs(sc, k_a.p, k_s.p, v_a.p, v_s.p, n_int, 51, st, err)) return rc;
+        hipLaunchKernelGGL(k_row_keys2, dim3(grid_of(n_int)), dim3(256), 0, st, n_int, v_s.p, (int32_t)rpw, (int32_t)SA, halo.p, len.p, k_a.p);
+        if (int rc = sort_pairs(sc, k_a.p, k_s.p, v_s.p, dof1.p, n_int, 52, st, err)) return rc;
+        std::vector<int32_t> h_noimp((size_t)G);
+        for (int g = 0; g < G; ++g) h_noimp[(size_t)g] = (int32_t)(std::min<int64_t>(n_int, (int64_t)(g + 1) * rpw) - (int64_t)g * rpw) - h_cnt[(size_t)g];
+        DP_CHK(wg_noimp.alloc((size_t)G));
+        DP_CHK(hipMemcpyAsync(wg_noimp.p, h_noimp.data(), sizeof(int32_t) * (size_t)G, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_assign_slots, dim3(grid_of(n_int)), dim3(256), 0, st, n_int, dof1.p, (int32_t)rpw, (int32_t)SA, (int32_t)S, wg_noimp.p, slot_of.p,
+                           o.slot_dof);
+        DP_CHK(hipStreamSynchronize(st));
+    }
+    // ---- exports (board) and imports in board order
+    Tmp<int32_t> board_of;
+    DP_CHK(board_of.alloc((size_t)nd));
+    DP_CHK(is_exp.alloc((size_t)nd));
+    DP_CHK(hipMemsetAsync(is_exp.p, 0, (size_t)nd, st));
+    if (n_imp > 0) hipLaunchKernelGGL(k_mark_exports, dim3(grid_of(n_imp)), dim3(256), 0, st, n_imp, imp_key.p, is_exp.p);
+    int64_t n_board = 0;
+    {
+        Tmp<uint64_t> k_a, k_s;
+        Tmp<int32_t> v_a, v_s, cnt;
+        const int64_t cap = n_imp > 0 ? n_imp : 1;   // exported DOFs <= imported (workgroup, DOF) pairs
+        DP_CHK(k_a.alloc((size_t)cap));
+        DP_CHK(k_s.alloc((size_t)cap));
+        DP_CHK(v_a.alloc((size_t)cap));
+        DP_CHK(v_s.alloc((size_t)cap));
+        DP_CHK(cnt.alloc(1));
+        DP_CHK(hipMemsetAsync(cnt.p, 0, sizeof(int32_t), st));
+        hipLaunchKernelGGL(k_export_keys, dim3(grid_of(nd)), dim3(256), 0, st, nd, is_exp.p, irow.p, (int32_t)rpw, slot_of.p, k_a.p, v_a.p, cnt.p, wg_cnt.p + G);
+        int32_t h_nb = 0;
+        DP_CHK(hipMemcpyAsync(&h_nb, cnt.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        DP_CHK(hipStreamSynchronize(st));
+        n_board = h_nb;
+        DP_CHK(hipMalloc(reinterpret_cast<void**>(&o.exp_slot), sizeof(uint16_t) * (size_t)(n_board ? n_board : 1)));
+        if (n_board > 0) {
+            if (int rc = sort_pairs(sc, k_a.p, k_s.p, v_a.p, v_s.p, n_board, 42, st, err)) return rc;
+            hipLaunchKernelGGL(k_board_tables, dim3(grid_of(n_board)), dim3(256), 0, st, n_board, k_s.p, v_s.p, o.exp_slot, board_of.p);
+        }
+        DP_CHK(hipStreamSynchronize(st));
+    }
+    DP_CHK(hipMalloc(reinterpret_cast<void**>(&o.imp_pos), sizeof(int32_t) * (size_t)(n_imp ? n_imp : 1)));
+    if (n_imp > 0) {
+        Tmp<uint64_t> k_a, k_s;
+        DP_CHK(k_a.alloc((size_t)n_imp));
+        DP_CHK(k_s.alloc((size_t)n_imp));
+        hipLaunchKernelGGL(k_import_board_keys, dim3(grid_of(n_imp)), dim3(256), 0, st, n_imp, imp_key.p, board_of.p, k_a.p, wg_cnt.p + 2 * G);
+        if (int rc = sort_keys(sc, k_a.p, k_s.p, n_imp, 42, st, err)) return rc;
+        hipLaunchKernelGGL(k_low32, dim3(grid_of(n_imp)), dim3(256), 0, st, n_imp, k_s.p, o.imp_pos);
+        DP_CHK(hipStreamSynchronize(st));
+    }
+    DP_CHK(hipMemcpyAsync(h_cnt.data() + G, wg_cnt.p + G, sizeof(int32_t) * 2 * (size_t)G, hipMemcpyDeviceToHost, st));
+    DP_CHK(hipStreamSynchronize(st));
+    std::vector<int32_t> h_exp_off((size_t)G + 1, 0), h_imp_off((size_t)G + 1, 0);
+    pl.max_exp = pl.max_imp = 0;
+    for (int g = 0; g < G; ++g) {
+        h_exp_off[(size_t)g + 1] = h_exp_off[(size_t)g] + h_cnt[(size_t)G + g], pl.max_exp = std::max(pl.max_exp, h_cnt[(size_t)G + g]);
+        h_imp_off[(size_t)g + 1] = h_imp_off[(size_t)g] + h_cnt[(size_t)2 * G + g], pl.max_imp = std::max(pl.max_imp, h_cnt[(size_t)2 * G + g]);
+    }
+    pl.n_board = n_board, pl.n_imp = n_imp;
+    if (S + pl.max_imp > 65535) return FDAPDE_EUNSUPPORTED;
+    DP_CHK(hipMalloc(reinterpret_cast<void**>(&o.exp_off), sizeof(int32_t) * ((size_t)G + 1)));
+    DP_CHK(hipMalloc(reinterpret_cast<void**>(&o.imp_off), sizeof(int32_t) * ((size_t)G + 1)));
+    DP_CHK(hipMemcpyAsync(o.exp_off, h_exp_off.data(), sizeof(int32_t) * ((size_t)G + 1), hipMemcpyHostToDevice, st));
+    DP_CHK(hipMemcpyAsync(o.imp_off, h_imp_off.data(), sizeof(int32_t) * ((size_t)G + 1), hipMemcpyHostToDevice, st));
+    // ---- sliced ELL in lane pairs
+    const int64_t n_sl = (int64_t)G * nsl;
+    Tmp<int32_t> pairs, pscan, max_block;
+    DP_CHK(pairs.alloc((size_t)n_sl + 1));
+    DP_CHK(pscan.alloc((size_t)n_sl + 1));
+    DP_CHK(max_block.alloc(1));
+    DP_CHK(hipMemsetAsync(pairs.p + n_sl, 0, sizeof(int32_t), st));
+    DP_CHK(hipMemsetAsync(max_block.p, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_slice_pairs, dim3(grid_of(n_sl)), dim3(256), 0, st, n_sl, o.slot_dof, len.p, pairs.p);
+    if (int rc = exclusive_sum(sc, pairs.p, pscan.p, n_sl + 1, st, err)) return rc;
+    DP_CHK(hipMalloc(reinterpret_cast<void**>(&o.sl_off), sizeof(int32_t) * (size_t)G * (nsl + 1)));
+    DP_CHK(hipMalloc(reinterpret_cast<void**>(&o.ell_off), sizeof(int64_t) * ((size_t)G + 1)));
+    hipLaunchKernelGGL(k_slice_offsets, dim3(grid_of((int64_t)G * (nsl + 1))), dim3(256), 0, st, G, nsl, pscan.p, o.sl_off, o.ell_off, max_block.p);
+    int32_t h_total = 0, h_maxb = 0;
+    DP_CHK(hipMemcpyAsync(&h_total, pscan.p + n_sl, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    DP_CHK(hipMemcpyAsync(&h_maxb, max_block.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    DP_CHK(hipStreamSynchronize(st));
+    pl.n_entries = (int64_t)h_total * 128;
+    pl.max_block = (int64_t)h_maxb * 128;
+    const size_t n_alloc = (size_t)pl.n_entries + 256;   // + slack: clamped loads of the last slices may run past the last block
+    DP_CHK(hipMalloc(reinterpret_cast<void**>(&o.ell_code), sizeof(uint16_t) * n_alloc));
+    DP_CHK(hipMalloc(reinterpret_cast<void**>(&o.ell_src), sizeof(int32_t) * n_alloc));
+    DP_CHK(hipMemsetAsync(o.ell_code, 0, sizeof(uint16_t) * n_alloc, st));
+    DP_CHK(hipMemsetAsync(o.ell_src, 0xff, sizeof(int32_t) * n_alloc, st));
+    hipLaunchKernelGGL(k_fill_ell, dim3(grid_of((int64_t)G * S)), dim3(256), 0, st, (int64_t)G * S, (int32_t)S, nsl, o.slot_dof, d_rowptr, d_colidx, keep.p, irow.p,
+                       (int32_t)rpw, slot_of.p, board_of.p, o.imp_off, o.imp_pos, o.sl_off, o.ell_off, o.ell_code, o.ell_src);
+    DP_CHK(hipGetLastError());
+    DP_CHK(hipStreamSynchronize(st));
+    guard.armed = false;
+    *out = o;
+    return FDAPDE_OK;
+}
+
+}  // namespace fdapde_hip

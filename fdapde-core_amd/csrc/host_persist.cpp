@@ -148,6 +148,7 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
     }
     if (S + pl.max_imp > 65535) return FDAPDE_EUNSUPPORTED;   // 16-bit column codes
     pl.imp_pos.resize((size_t)pl.imp_off[(size_t)G]);
+    pl.n_imp = pl.imp_off[(size_t)G];
     for (int g = 0; g < G; ++g)
         for (size_t h = 0; h < imports[(size_t)g].size(); ++h)
             pl.imp_pos[(size_t)pl.imp_off[(size_t)g] + h] = board_of[(size_t)imports[(size_t)g][h]];

@@ -145,7 +145,9 @@ struct PersistLayout {
     int64_t n_entries = 0;            // ELL entries over all workgroups, padding included
     int64_t nnz = 0;                  // stored off-diagonal entries (no padding)
     int64_t n_board = 0;              // exported vector entries over all workgroups
+    int64_t n_imp = 0;                // imported vector entries over all workgroups
     int32_t max_imp = 0, max_exp = 0;
+    int64_t max_block = 0;            // ELL entries of the largest workgroup block (0: compute from ell_off)
     std::vector<int32_t> slot_dof;    // G * S (S = R * T): internal DOF id of the row a slot holds, -1 = empty slot
     std::vector<int64_t> ell_off;     // G + 1: first ELL entry of a workgroup (multiple of 128)
     std::vector<int32_t> sl_off;      // G * (nsl + 1): slice offsets inside the workgroup's block, in pair rows (128 entries: 64 lanes x 2)

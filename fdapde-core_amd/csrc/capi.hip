@@ -1259,7 +1259,7 @@ int run_persist(fdapde_ctx* c, int v, double tol2, int maxit, bool* ran) {
     hipStream_t st = c->stream;
     PersistArgs a{};
     a.G = ps.meta.G, a.nsl = ps.meta.nsl, a.maxit = maxit, a.imp_cap = ps.imp_cap, a.lds_cap = ps.lds_cap, a.time_phases = c->persist_time;
-    a.tol2 = tol2;
+    a.tol2 = tol2, a.gather_waves = c->persist_gather_waves, a.poll_sleep = c->persist_poll_sleep;
     a.slot_dof = ps.slot_dof.p, a.ell_off = ps.ell_off.p, a.sl_off = ps.sl_off.p, a.ell_code = ps.ell_code.p;
     a.ell_val = ps.ell_val.p, a.exp_off = ps.exp_off.p, a.exp_slot = ps.exp_slot.p, a.imp_off = ps.imp_off.p, a.imp_pos = ps.imp_pos.p;
     a.pboard = ps.board.p, a.dboard = ps.board.p + 2 * (size_t)ps.meta.n_board;
@@ -2317,6 +2317,8 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "asm_fq_block" && (value == 0 || value == 1)) c->asm_fq_block = value;
     else if (k == "persist" && (value == 0 || value == 1)) c->persist = value, c->persist_broken = false;
     else if (k == "persist_time" && (value == 0 || value == 1)) c->persist_time = value;
+    else if (k == "persist_gather_waves" && (value == 1 || value == 4)) c->persist_gather_waves = value;
+    else if (k == "persist_poll_sleep" && value >= 0 && value <= 3) c->persist_poll_sleep = value;
     else if (k == "spmv_ntv" && value >= -1 && value <= 1) c->spmv_ntv = value;
     else if (k == "spmv_bpx" && value >= 1 && value <= 1024) {
         c->spmv_grid = 8 * value;

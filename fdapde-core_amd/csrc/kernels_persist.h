@@ -28,6 +28,7 @@ struct PersistArgs {
     int32_t G, nsl, maxit, imp_cap;   // workgroups; slices per workgroup; iteration bound; import slots reserved in LDS
     int32_t lds_cap;                  // ELL entries staged in LDS by the resident form (multiple of 128; >= the largest block)
     int32_t time_phases;              // != 0: every workgroup accumulates its phase durations into stats
+    int32_t gather_waves, poll_sleep; // all-gather of the dot records: polling wavefronts (4 | 1) and the pause between polls (0 none .. 3 long)
     double tol2;
     const int32_t* slot_dof;
     const int64_t* ell_off;
@@ -238,28 +239,36 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
             // against 4.6 us for the flat sweep on C2 (246 workgroups)
             double v0 = 0, v1 = 0, v2 = 0;
             bool fail = false;
-            if (wave * 64 < a.G) {   // wave-uniform
-                const unsigned long long* gp = dslot + (size_t)(tid < a.G ? tid : 0) * 6;
-                pg_v2u64 q0 = {0, 0}, q1 = {0, 0}, q2 = {0, 0};
-                bool done = tid >= a.G;
-                long long t_wait = 0;
-                for (unsigned spins = 0;; ++spins) {
-                    if (!done) {
-                        granule_load6(gp, q0, q1, q2);
-                        done = granule_pair_ok(q0, epoch) && granule_pair_ok(q1, epoch) && granule_pair_ok(q2, epoch);
-                    }
-                    if (__all(done)) break;
-                    if ((spins & 63u) == 63u) {
-                        const long long now = wall_clock64();
-                        if (t_wait == 0) t_wait = now;
-                        else if (now - t_wait > kPersistTimeoutTicks) {
-                            fail = true;
-                            break;
+            // gather_waves: how many wavefronts poll (4: thread t takes workgroup t's record; 1: wavefront 0 takes them all, 4 per lane)
+            const int per_lane = a.gather_waves == 1 ? (a.G + 63) / 64 : 1;
+            if (a.gather_waves == 1 ? wave == 0 : wave * 64 < a.G) {   // wave-uniform
+                for (int rsel = 0; rsel < per_lane; ++rsel) {
+                    const int w = a.gather_waves == 1 ? rsel * 64 + lane : tid;
+                    const unsigned long long* gp = dslot + (size_t)(w < a.G ? w : 0) * 6;
+                    pg_v2u64 q0 = {0, 0}, q1 = {0, 0}, q2 = {0, 0};
+                    bool done = w >= a.G;
+                    long long t_wait = 0;
+                    for (unsigned spins = 0;; ++spins) {
+                        if (!done) {
+                            granule_load6(gp, q0, q1, q2);
+                            done = granule_pair_ok(q0, epoch) && granule_pair_ok(q1, epoch) && granule_pair_ok(q2, epoch);
                         }
+                        if (__all(done)) break;
+                        if ((spins & 63u) == 63u) {
+                            const long long now = wall_clock64();
+                            if (t_wait == 0) t_wait = now;
+                            else if (now - t_wait > kPersistTimeoutTicks) {
+                                fail = true;
+                                break;
+                            }
+                        }
+                        if (a.poll_sleep == 1) __builtin_amdgcn_s_sleep(1);
+                        else if (a.poll_sleep == 2) __builtin_amdgcn_s_sleep(2);
+                        else if (a.poll_sleep >= 3) __builtin_amdgcn_s_sleep(8);
                     }
-                    __builtin_amdgcn_s_sleep(2);
+                    if (w < a.G) v0 += granule_pair_f64(q0), v1 += granule_pair_f64(q1), v2 += granule_pair_f64(q2);
+                    if (fail) break;
                 }
-                if (tid < a.G) v0 = granule_pair_f64(q0), v1 = granule_pair_f64(q1), v2 = granule_pair_f64(q2);
             }
             if (fail && lane == 0) fail_flag = 1;
             v0 = wave_sum64(v0), v1 = wave_sum64(v1), v2 = wave_sum64(v2);

@@ -468,6 +468,28 @@ inline void drop_graph(fdapde_ctx* c) {
 void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, const double* w, double* partial,
                  const int32_t* stop, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, int dot2_ww = 0,
                  const uint8_t* owned = nullptr) {
+    if (vals == c->sval.p && c->bk_cur >= 0 && owned == nullptr) {   // the solver's scaled matrix in blocked-ELL form (k_spmv_blocked)
+        const fdapde_ctx::Blocked& bk = c->bk[c->bk_cur];
+        BlockedSpmvArgs a{};
+        a.G = bk.meta.G, a.nsl = bk.meta.nsl, a.imp_cap = bk.imp_cap, a.dot2_ww = dot2_ww;
+        a.slot_dof = bk.slot_dof.p, a.ell_off = bk.ell_off.p, a.sl_off = bk.sl_off.p, a.ell_code = bk.ell_code.p, a.ell_val = bk.ell_val.p;
+        a.imp_off = bk.imp_off.p, a.imp_dof = bk.imp_dof.p, a.drop_dof = bk.drop_dof.p, a.n_drop = (int32_t)bk.meta.n_drop, a.x = x, a.y = y, a.w = partial ? (w ? w : x) : nullptr, a.partial = partial, a.stop = stop;
+#define BLOCKED_GO(R_)                                                                                                          \
+    do {                                                                                                                        \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmv_blocked<R_>), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                  (int)bk.lds_bytes);                                                                           \
+        if (e0 || e1) hipExtLaunchKernelGGL((k_spmv_blocked<R_>), dim3(a.G), dim3(kPersistT), bk.lds_bytes, c->stream, e0, e1, 0, a); \
+        else hipLaunchKernelGGL((k_spmv_blocked<R_>), dim3(a.G), dim3(kPersistT), bk.lds_bytes, c->stream, a);                  \
+    } while (0)
+        switch (bk.meta.R) {
+        case 2: BLOCKED_GO(2); break;
+        case 4: BLOCKED_GO(4); break;
+        case 8: BLOCKED_GO(8); break;
+        default: BLOCKED_GO(16); break;
+        }
+#undef BLOCKED_GO
+        return;
+    }
     SpmvArgs s{};
     s.rowptr = c->rowptr.p, s.colidx = c->colidx.p, s.vals = vals, s.x = x, s.y = y;
     s.rb_row = c->rb_row.p, s.n_rb = c->n_rb, s.rb_per_band = c->rb_per_band, s.nnz = (int32_t)c->hs.nnz;
@@ -726,6 +748,9 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
         c->lin_mat.release(), c->persist_stats.release();
         dev_topology_release(&c->topo);
         c->part_cells.release(), c->part_off.release(), c->part_slots.release(), c->wave_slots.release(), c->part_shared.release();
+        for (auto& bk : c->bk)
+            bk.slot_dof.release(), bk.sl_off.release(), bk.ell_src.release(), bk.imp_off.release(), bk.imp_dof.release(), bk.drop_dof.release(), bk.ell_off.release(),
+              bk.ell_code.release(), bk.ell_val.release();
         for (auto& ps : c->ps)
             ps.slot_dof.release(), ps.sl_off.release(), ps.ell_src.release(), ps.exp_off.release(), ps.imp_off.release(),
               ps.imp_pos.release(), ps.ell_off.release(), ps.ell_code.release(), ps.exp_slot.release(), ps.ell_val.release(), ps.board.release();
@@ -763,6 +788,7 @@ int fdapde_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs) {
     c->halo_ready = false, c->lin_ready = false, c->sp_built[0] = c->sp_built[1] = false, c->sp_cur = -1;
     c->scaled_owner = fdapde_ctx::kScaledNone;
     c->ps[0].tried = c->ps[0].ok = c->ps[1].tried = c->ps[1].ok = false;
+    c->bk[0].tried = c->bk[0].ok = c->bk[1].tried = c->bk[1].ok = false, c->bk_cur = -1;
     drop_graph(c);
     // The DOF table (reference numbering) is host index work; everything derived from it -- locality numbering, adjacency, CSR
     // patterns, slot maps, assembly block tables -- is built on the device (dev_setup.hip) when the context has one.
@@ -881,7 +907,7 @@ int fdapde_dofs_set_boundary(fdapde_ctx* c, const uint8_t* bnd) {
     for (int64_t i = 0; i < hs.n_dofs; ++i) hs.dof_bnd[(size_t)i] = bnd[i] ? 1 : 0;
     for (int64_t i = 0; i < hs.n_dofs; ++i) hs.dof_bnd_i[(size_t)i] = hs.dof_bnd[(size_t)hs.dof_i2e[(size_t)i]];
     c->sp_built[1] = false;   // the compact solver pattern drops Dirichlet rows / columns
-    c->ps[1].tried = c->ps[1].ok = false;
+    c->ps[1].tried = c->ps[1].ok = false, c->bk[1].tried = c->bk[1].ok = false, c->bk_cur = -1;
     drop_graph(c);
     c->solved = false, c->scaled_owner = fdapde_ctx::kScaledNone;
     if (c->dev_ready) {
@@ -1179,7 +1205,7 @@ int build_persist(fdapde_ctx* c, int v) {
     bool on_device = !(mode && std::strcmp(mode, "host") == 0);
     int rc = FDAPDE_EUNSUPPORTED;
     if (on_device) {   // the layout is built where the pattern lives (dev_persist.hip)
-        rc = dev_build_persist_layout(c->hs.n_dofs, c->hs.max_row, c->rowptr.p, c->colidx.p, c->bnd.p, v == 1, c->n_cu, 12000, c->stream, pl, &dp, c->err);
+        rc = dev_build_persist_layout(c->hs.n_dofs, c->hs.max_row, c->rowptr.p, c->colidx.p, c->bnd.p, v == 1, c->n_cu, 12000, 0, c->stream, pl, &dp, c->err);
         if (rc == FDAPDE_EUNSUPPORTED && c->hs.max_row > 255) on_device = false;   // rows too long for its sort keys: host builder
     }
     if (!on_device) {
@@ -1298,6 +1324,47 @@ int run_persist(fdapde_ctx* c, int v, double tol2, int maxit, bool* ran) {
     return FDAPDE_OK;
 }
 
+// blocked-ELL layout of the multi-launch SpMV for boundary variant v (k_spmv_blocked), built on the device from the pattern
+int build_blocked(fdapde_ctx* c, int v) {
+    fdapde_ctx::Blocked& bk = c->bk[v];
+    if (bk.tried) return FDAPDE_OK;
+    bk.tried = true, bk.ok = false;
+    const char* mode = std::getenv("FDAPDE_SETUP");
+    if (mode && std::strcmp(mode, "host") == 0) return FDAPDE_OK;   // (no host builder for this layout: the compact CSR path serves)
+    PersistLayout pl;
+    DevPersist dp;
+    // rows per block, measured on C5 (P2, 28 entries per row; CSR kernel 400 us per SpMV): 1024 -> 375 us, 2048 -> 367, 4096 -> 387, 8192 -> 439
+    int rows = 2048;
+    if (const char* e = std::getenv("FDAPDE_BLOCKED_ROWS")) rows = std::atoi(e);
+    const int rc = dev_build_persist_layout(c->hs.n_dofs, c->hs.max_row, c->rowptr.p, c->colidx.p, c->bnd.p, v == 1, 1 << 19, 0, rows, c->stream, pl, &dp,
+                                            c->err);
+    if (rc == FDAPDE_EUNSUPPORTED) return FDAPDE_OK;
+    if (rc) return rc;
+    const int S = pl.R * kPersistT;
+    bk.imp_cap = (pl.max_imp + 63) & ~63;
+    bk.lds_bytes = 8 * (size_t)(S + bk.imp_cap) + 64;
+    if (bk.lds_bytes > 150 * 1024) {
+        dev_persist_release(&dp);
+        return FDAPDE_OK;
+    }
+    const size_t n_alloc = (size_t)pl.n_entries + 256;
+    adopt(bk.slot_dof, dp.slot_dof, (size_t)pl.G * S), adopt(bk.ell_off, dp.ell_off, (size_t)pl.G + 1), adopt(bk.sl_off, dp.sl_off, (size_t)pl.G * (pl.nsl + 1));
+    adopt(bk.ell_code, dp.ell_code, n_alloc), adopt(bk.ell_src, dp.ell_src, n_alloc), adopt(bk.imp_off, dp.imp_off, (size_t)pl.G + 1);
+    adopt(bk.imp_dof, dp.imp_pos, (size_t)(pl.n_imp ? pl.n_imp : 1)), adopt(bk.drop_dof, dp.drop_dof, (size_t)(pl.n_drop ? pl.n_drop : 1));
+    dev_persist_release(&dp);
+    HIPCHK(c, bk.ell_val.alloc(n_alloc));
+    HIPCHK(c, hipMemsetAsync(bk.ell_val.p, 0, sizeof(double) * n_alloc, c->stream));
+    if (2 * (size_t)pl.G > c->part_a.n) HIPCHK(c, c->part_a.alloc(2 * (size_t)pl.G));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (std::getenv("FDAPDE_DEBUG_SETUP"))
+        std::fprintf(stderr, "blocked-ELL SpMV layout %d: %d workgroups x %d rows/thread, %lld interior rows, %lld entries (%lld stored, %.1f %% padding), "
+                     "LDS %zu B, imports <= %d (%lld in all)\n", v, pl.G, pl.R, (long long)pl.n_int, (long long)pl.n_entries, (long long)pl.nnz,
+                     100.0 * (double)(pl.n_entries - pl.nnz) / (double)(pl.n_entries > 0 ? pl.n_entries : 1), bk.lds_bytes, pl.max_imp, (long long)pl.n_imp);
+    bk.meta = std::move(pl);
+    bk.filled = false, bk.ok = true;
+    return FDAPDE_OK;
+}
+
 // Dirichlet reduction + Jacobi scaling of the system matrix A (internal slots): scale, sval = diag(s) A diag(s).
 // Done once per matrix (per solve for the elliptic problem, once for all time steps of the parabolic one).
 int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss) {
@@ -1338,7 +1405,18 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss) {
         if (int rc = build_persist(c, use_bnd ? 1 : 0)) return rc;
         persist = c->ps[use_bnd ? 1 : 0].ok;
     }
-    const bool compact = !persist && ss->diag_positive && c->spmv_variant == 2 && !std::getenv("FDAPDE_SPMV_FULL");
+    // one GPU, positive diagonal, not taken by the persistent CG (non-symmetric operator, or too many rows): the multi-launch
+    // kernels apply the operator from the blocked-ELL layout (k_spmv_blocked); the compact CSR pattern is then not built either
+    c->bk_cur = -1, c->bk[0].filled = c->bk[1].filled = false;
+    bool blocked = false;
+    // ... where it pays: long rows (P2).  On 14-entry rows (C3 with the persistent CG switched off) the CSR kernel's finer-grained,
+    // software-pipelined workgroups win (45 us against 48-51 us per SpMV), so short-row systems keep the compact CSR pattern.
+    const bool long_rows = (double)c->hs.nnz >= 20.0 * (double)n || c->blocked == 2;
+    if (!persist && ss->diag_positive && !ss->dist && c->blocked && long_rows && c->spmv_variant == 2) {
+        if (int rc = build_blocked(c, use_bnd ? 1 : 0)) return rc;
+        blocked = c->bk[use_bnd ? 1 : 0].ok;
+    }
+    const bool compact = !persist && !blocked && ss->diag_positive && c->spmv_variant == 2 && !std::getenv("FDAPDE_SPMV_FULL");
     if (compact) {
         const int v = use_bnd ? 1 : 0;
         if (int rc = build_solver_pattern(c, v)) return rc;
@@ -1352,6 +1430,12 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss) {
     } else {
         hipLaunchKernelGGL(k_scale_matrix, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, A, c->scale.p, c->sval.p);
         c->sp_cur = -1, c->sval_layout = -2;
+    }
+    if (blocked) {
+        const int v = use_bnd ? 1 : 0;
+        hipLaunchKernelGGL(k_persist_fill, dim3(g1(c->bk[v].meta.n_entries)), dim3(256), 0, st, c->bk[v].meta.n_entries, c->bk[v].ell_src.p,
+                           c->sval.p, c->bk[v].ell_val.p);
+        c->bk[v].filled = true, c->bk_cur = v;
     }
     if (persist) {
         const int v = use_bnd ? 1 : 0;
@@ -1374,6 +1458,8 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     hipStream_t st = c->stream;
     const bool dist = ss.dist;
     const uint8_t* owned = ss.owned;
+    // partial pairs the SpMV leaves for the vector kernels: one per workgroup of the kernel that applies the scaled operator
+    const int np_spmv = (c->bk_cur >= 0 && !dist) ? c->bk[c->bk_cur].meta.G : c->spmv_grid;
     const double* fvec = f_dev;
     if (dist) {   // the forcing vector is a sum over the ranks sharing a DOF
         HIPCHK(c, hipMemcpyAsync(c->tmp_e.p, f_dev, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
@@ -1452,7 +1538,7 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
         const int cg = cgf_grid;
         launch_spmv(c, c->sval.p, c->p.p, c->y.p, c->p.p, c->part_a.p, c->ctl.p, e0, e1);   // p.y and y.y
 #define CGF_GO(...)                                                                                                        \
-    hipLaunchKernelGGL((k_cgf_update<__VA_ARGS__>), dim3(cg), dim3(256), 0, st, n, c->y.p, c->p.p, c->x.p, c->r.p, c->part_a.p, c->spmv_grid, \
+    hipLaunchKernelGGL((k_cgf_update<__VA_ARGS__>), dim3(cg), dim3(256), 0, st, n, c->y.p, c->p.p, c->x.p, c->r.p, c->part_a.p, np_spmv, \
                        c->part_b.p + (size_t)((it + 1) & 1) * cg, cg, c->part_b.p + (size_t)(it & 1) * cg, c->sc.p, tol2, c->ctl.p, \
                        cgf_band2, c->cgf_nt, c->cgf_lazy, it & 1)
         if (c->cgf_split && cgf_V == 8) CGF_GO(8, 1);
@@ -1506,7 +1592,7 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
                             tm ? c->ev_spmv[2 * timed + 1] : nullptr, 1, owned);
                 if (tm) ++timed;
                 const double* part = c->part_a.p;
-                int np = c->spmv_grid;
+                int np = np_spmv;
                 if (dist) {
                     // pack -> all-reduce; the update kernel reads the summed interface rows straight from hbuf (no unpack launch)
                     if (int rc = halo_sum(c, c->y.p, c->part_a.p, c->spmv_grid, /*unpack=*/false)) return rc;
@@ -1530,7 +1616,7 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
                 if (tm) ++timed;
                 if (!dist) {
                     hipLaunchKernelGGL(k_cg_update_xr, dim3(c->cg_grid), dim3(256), 0, st, n, c->y.p, c->r.p, c->part_a.p,
-                                       c->spmv_grid, c->part_b.p, c->sc.p, parity, c->ctl.p, owned);
+                                       np_spmv, c->part_b.p, c->sc.p, parity, c->ctl.p, owned);
                     hipLaunchKernelGGL(k_cg_update_p, dim3(c->cg_grid), dim3(256), 0, st, n, c->r.p, c->p.p, c->x.p, c->part_b.p,
                                        c->cg_grid, c->sc.p, parity, tol2, c->ctl.p);
                 } else {
@@ -1552,11 +1638,11 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
                             tm ? c->ev_spmv[2 * timed] : nullptr, tm ? c->ev_spmv[2 * timed + 1] : nullptr);
                 if (tm) ++timed;
                 hipLaunchKernelGGL(k_bicg_s, dim3(bi_grid), dim3(256), 0, st, n, c->r.p, c->y.p, c->s.p, c->part_a.p,
-                                   c->spmv_grid, c->sc.p, c->ctl.p);
+                                   np_spmv, c->sc.p, c->ctl.p);
                 launch_spmv(c, c->sval.p, c->s.p, c->t.p, c->s.p, c->part_a.p, c->ctl.p);    // t = At s, t.s, t.t
                 hipLaunchKernelGGL(k_bicg_xr, dim3(bi_grid), dim3(256), 0, st, n, c->p.p, c->s.p, c->t.p, c->r0.p, c->x.p,
-                                   c->r.p, c->part_a.p, c->spmv_grid, c->part_b.p, c->sc.p, c->ctl.p, (const uint8_t*)nullptr);
-                hipLaunchKernelGGL(k_bicg_fin, dim3(1), dim3(256), 0, st, c->part_a.p, c->spmv_grid, c->part_b.p, bi_grid,
+                                   c->r.p, c->part_a.p, np_spmv, c->part_b.p, c->sc.p, c->ctl.p, (const uint8_t*)nullptr);
+                hipLaunchKernelGGL(k_bicg_fin, dim3(1), dim3(256), 0, st, c->part_a.p, np_spmv, c->part_b.p, bi_grid,
                                    c->sc.p, tol2, c->ctl.p);
             } else {
                 // element-partitioned BiCGStab: every operator application is followed by the interface sum, which also carries
@@ -1660,6 +1746,11 @@ int fdapde_solver_prepare(fdapde_ctx* c, int32_t with_dirichlet) {
         if (int rc = build_persist(c, v)) return rc;
         if (c->ps[v].ok) return FDAPDE_OK;
     }
+    if (c->blocked && c->comm == nullptr && c->ar_fn == nullptr &&
+        ((double)c->hs.nnz >= 20.0 * (double)c->hs.n_dofs || c->blocked == 2)) {   // single GPU, long rows: the multi-launch kernels use the blocked-ELL layout
+        if (int rc = build_blocked(c, v)) return rc;
+        if (c->bk[v].ok) return FDAPDE_OK;
+    }
     return build_solver_pattern(c, v);
 }
 
@@ -1674,7 +1765,8 @@ int fdapde_solver_layout(fdapde_ctx* c, int32_t with_dirichlet, int64_t* n_inter
     HIPCHK(c, hipSetDevice(c->device));
     const int v = with_dirichlet ? 1 : 0;
     const bool persist = c->persist && !c->persist_broken && c->ps[v].tried && c->ps[v].ok;
-    if (c->spmv_variant == 2 && !persist)
+    const bool blocked = !persist && c->bk[v].tried && c->bk[v].ok;
+    if (c->spmv_variant == 2 && !persist && !blocked)
         if (int rc = build_solver_pattern(c, v)) return rc;
     if (int rc = ensure_host(c, kHostPattern)) return rc;
     const HostSpace& hs = c->hs;
@@ -1691,6 +1783,8 @@ int fdapde_solver_layout(fdapde_ctx* c, int32_t with_dirichlet, int64_t* n_inter
         if (persist) {   // one iteration of the persistent CG: the ELL blocks (8 + 2 bytes per entry, padding included) + the exchanged
                          // entries of p (two 8-byte granules each, written once and read once)
             *streamed_bytes = 10.0 * (double)c->ps[v].meta.n_entries + 32.0 * (double)c->ps[v].meta.n_board;
+        } else if (blocked) {   // ELL blocks + x staged once per block (own rows and imports) + y written once
+            *streamed_bytes = 10.0 * (double)c->bk[v].meta.n_entries + 8.0 * (double)(c->bk[v].meta.n_int + c->bk[v].meta.n_imp) + 8.0 * (double)c->bk[v].meta.n_int;
         } else if (c->spmv_variant == 2 && c->sp_built[v]) {
             const int64_t n_csr = c->sp_nv[v] > 0 ? c->sp_nv[v] : hs.n_dofs;
             *streamed_bytes = 10.0 * (double)c->sp_nnz[v] + 4.0 * (double)(n_csr + 1) + 16.0 * (double)((n_csr + kCodeRows - 1) / kCodeRows) +
@@ -1921,7 +2015,10 @@ int fdapde_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, 
     int32_t j0 = 0;
     // several columns against a symmetric positive system on one GPU: batches of 8 / 4 columns share every pass over the
     // matrix (kernels_multirhs.h); what is left goes column by column
-    const bool batched = c->multi_rhs && n_rhs >= 4 && method == FDAPDE_SOLVER_CG_FUSED && !c->lin_state->ss.dist;
+    // (a system the persistent CG takes is faster column by column -- one launch each, no vector traffic -- than batched through
+    // the multi-launch SpMM: C3-size, 22.5 ms per column against 32 ms per column in a batch of 8)
+    const bool persist_cols = c->persist && !c->persist_broken && c->ps[0].ok && c->ps[0].filled;
+    const bool batched = c->multi_rhs && n_rhs >= 4 && method == FDAPDE_SOLVER_CG_FUSED && !c->lin_state->ss.dist && !persist_cols;
     if (batched) {
         if (!c->lin_sq_ready) {   // full-pattern scaled copy (explicit unit diagonal), once per prepared matrix
             HIPCHK(c, c->lin_sq.alloc((size_t)hs.nnz + 2));
@@ -2317,6 +2414,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "asm_fq_block" && (value == 0 || value == 1)) c->asm_fq_block = value;
     else if (k == "persist" && (value == 0 || value == 1)) c->persist = value, c->persist_broken = false;
     else if (k == "persist_time" && (value == 0 || value == 1)) c->persist_time = value;
+    else if (k == "blocked" && value >= 0 && value <= 2) c->blocked = value;   // 2: also for short-row systems
     else if (k == "persist_gather_waves" && (value == 1 || value == 4)) c->persist_gather_waves = value;
     else if (k == "persist_poll_sleep" && value >= 0 && value <= 3) c->persist_poll_sleep = value;
     else if (k == "spmv_ntv" && value >= -1 && value <= 1) c->spmv_ntv = value;

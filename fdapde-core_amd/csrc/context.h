@@ -236,6 +236,19 @@ struct fdapde_ctx {
         bool filled = false;                 // ell_val holds the currently scaled system
     } ps[2];
     DBuf<double> persist_stats;
+    // blocked-ELL SpMV (k_spmv_blocked) of the multi-launch Krylov kernels on one GPU: layouts for the two boundary variants
+    struct Blocked {
+        bool tried = false, ok = false, filled = false;
+        PersistLayout meta;
+        int32_t imp_cap = 0;
+        size_t lds_bytes = 0;
+        DBuf<int32_t> slot_dof, sl_off, ell_src, imp_off, imp_dof, drop_dof;
+        DBuf<int64_t> ell_off;
+        DBuf<uint16_t> ell_code;
+        DBuf<double> ell_val;
+    } bk[2];
+    int bk_cur = -1;      // the scaled system of the current solve lives in bk[bk_cur] (launch_spmv routes products with c->sval there)
+    int blocked = 1;      // tuning knob: 0 = the CSR kernel (k_spmv_team2) on the compact pattern instead
     DevTopology topo;   // Triangulation topology tables, built on the device by fdapde_topology_build
     bool topo_ready = false;
     // element-wise scatter forms of the assembly (built on first use)

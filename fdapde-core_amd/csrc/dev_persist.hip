@@ -164,6 +164,10 @@ __global__ void k_import_board_keys(int64_t n_imp, const uint64_t* imp_key, cons
     key[i] = (g << 32) | (uint32_t)board_of[imp_key[i] & 0xffffffffu];
     atomicAdd(&wg_imp[g], 1);
 }
+__global__ void k_count_groups(int64_t n, const uint64_t* key, int32_t* count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&count[key[i] >> 32], 1);
+}
 __global__ void k_low32(int64_t n, const uint64_t* key, int32_t* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (int32_t)(key[i] & 0xffffffffu);
@@ -208,7 +212,7 @@ __global__ void k_fill_ell(int64_t n_slots, int32_t S, int nsl, const int32_t* s
             code[at] = (uint16_t)slot_of[c];
         } else {   // position of the column's board entry in this workgroup's import list (sorted by board position)
             int32_t lo = imp_off[g], hi = imp_off[g + 1];
-            const int32_t b = board_of[c];
+            const int32_t b = board_of ? board_of[c] : c;
             while (lo < hi) {
                 const int32_t mid = (lo + hi) >> 1;
                 if (imp_pos[mid] < b) lo = mid + 1; else hi = mid;
@@ -217,6 +221,10 @@ __global__ void k_fill_ell(int64_t n_slots, int32_t S, int nsl, const int32_t* s
         }
         ++e;
     }
+}
+__global__ void k_drop_list(int64_t nd, const uint8_t* keep, const int32_t* irow_scan, int32_t* drop) {
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < nd && !keep[d]) drop[d - irow_scan[d]] = (int32_t)d;   // rank among the dropped rows = d - (kept rows before d)
 }
 __global__ void k_scatter_irow(int64_t nd, const uint8_t* keep, const int32_t* irow_scan, int32_t* irow) {
     const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -251,17 +259,19 @@ template <typename In, typename Out> int exclusive_sum(Scratch& sc, In* in, Out*
 void dev_persist_release(DevPersist* p) {
     if (!p) return;
     for (void* q : {(void*)p->slot_dof, (void*)p->sl_off, (void*)p->ell_src, (void*)p->exp_off, (void*)p->imp_off, (void*)p->imp_pos, (void*)p->ell_off,
-                    (void*)p->ell_code, (void*)p->exp_slot})
+                    (void*)p->ell_code, (void*)p->exp_slot, (void*)p->drop_dof})
         if (q) (void)hipFree(q);
     *p = DevPersist{};
 }
 
 int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowptr, const int32_t* d_colidx, const uint8_t* d_bnd, bool use_bnd,
-                             int n_wg, int lds_entries, void* stream, PersistLayout& pl, DevPersist* out, std::string& err) {
+                             int n_wg, int lds_entries, int blocked_rows, void* stream, PersistLayout& pl, DevPersist* out, std::string& err) {
     constexpr int T = kPersistT;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (n_wg < 1 || nd < 1 || max_row > 255) return FDAPDE_EUNSUPPORTED;   // the row keys carry 255 - length in 8 bits
-    if (n_wg > T) n_wg = T;
+    const bool blocked = blocked_rows > 0;   // layout of the blocked-ELL SpMV (kernels_persist.h, k_spmv_blocked): any number of workgroups of
+                                             // ~blocked_rows rows, imports addressed by DOF id in the global vector, no board
+    if (!blocked && n_wg > T) n_wg = T;
     Scratch sc;
     DevPersist o;
     struct Guard {
@@ -297,9 +307,16 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
     int64_t want = (n_int + 2047) / 2048;
     if (lds_entries > 0) want = std::max<int64_t>(want, (nnz_kept + nnz_kept / 16 + lds_entries - 1) / lds_entries);
     int G = (int)std::min<int64_t>(n_wg, want);
+    if (blocked) G = (int)((n_int + blocked_rows - 1) / blocked_rows);
     if (G < 1) G = 1;
+    if (G >= (1 << 20)) return FDAPDE_EUNSUPPORTED;   // 20 bits of the row keys
     const int64_t rpw = (n_int + G - 1) / G;
     G = (int)((n_int + rpw - 1) / rpw);
+    pl.n_drop = nd - n_int;
+    if (blocked) {
+        DP_CHK(hipMalloc(reinterpret_cast<void**>(&o.drop_dof), sizeof(int32_t) * (size_t)(pl.n_drop ? pl.n_drop : 1)));
+        hipLaunchKernelGGL(k_drop_list, dim3(grid_of(nd)), dim3(256), 0, st, nd, keep.p, irow_scan.p, o.drop_dof);
+    }
     // ---- rows that import, import pairs
     DP_CHK(halo.alloc((size_t)nd));
     DP_CHK(n_imp_row.alloc((size_t)nd + 1));
@@ -317,9 +334,9 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
     int32_t max_halo = 0;
     for (int g = 0; g < G; ++g) max_halo = std::max(max_halo, h_cnt[(size_t)g]);
     int R = 2;
-    while ((int64_t)R * T < rpw || (int64_t)(R / 2) * T < max_halo) R *= 2;
+    while ((int64_t)R * T < rpw || (!blocked && (int64_t)(R / 2) * T < max_halo)) R *= 2;   // (the blocked SpMV has no import-free phase)
     if (R > kPersistRmax) return FDAPDE_EUNSUPPORTED;
-    const int S = R * T, nsl = S / 64, SA = (R / 2) * T;
+    const int S = R * T, nsl = S / 64, SA = blocked ? S : (R / 2) * T;   // blocked: one class, plain (imports?, length, DOF) order
     pl.G = G, pl.R = R, pl.nsl = nsl, pl.n_int = n_int, pl.nnz = nnz_kept;
     Tmp<uint64_t> imp_key;   // unique (workgroup, DOF) imports, DOF ascending inside a workgroup
     int64_t n_imp = 0;
@@ -332,7 +349,7 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
         DP_CHK(pos.alloc((size_t)h_pairs + 1));
         hipLaunchKernelGGL(k_import_pairs, dim3(grid_of(nd)), dim3(256), 0, st, nd, d_rowptr, d_colidx, keep.p, irow.p, (int32_t)rpw, imp_at.p, k_a.p);
         if (h_pairs > 0) {
-            if (int rc = sort_keys(sc, k_a.p, k_s.p, h_pairs, 42, st, err)) return rc;
+            if (int rc = sort_keys(sc, k_a.p, k_s.p, h_pairs, 53, st, err)) return rc;
             DP_CHK(hipMemsetAsync(flag.p + h_pairs, 0, sizeof(int32_t), st));
             hipLaunchKernelGGL(k_unique_flags, dim3(grid_of(h_pairs)), dim3(256), 0, st, (int64_t)h_pairs, k_s.p, flag.p);
             if (int rc = exclusive_sum(sc, flag.p, pos.p, (int64_t)h_pairs + 1, st, err)) return rc;
@@ -359,11 +376,12 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
         DP_CHK(v_a.alloc((size_t)n_int));
         DP_CHK(v_s.alloc((size_t)n_int));
         hipLaunchKernelGGL(k_row_keys1, dim3(grid_of(nd)), dim3(256), 0, st, nd, keep.p, irow.p, (int32_t)rpw, halo.p, len.p, k_a.p, v_a.p);
-        if (int rc = sort_pairs(sc, k_a.p, k_s.p, v_a.p, v_s.p, n_int, 51, st, err)) return rc;
+        if (int rc = sort_pairs(sc, k_a.p, k_s.p, v_a.p, v_s.p, n_int, 62, st, err)) return rc;
         hipLaunchKernelGGL(k_row_keys2, dim3(grid_of(n_int)), dim3(256), 0, st, n_int, v_s.p, (int32_t)rpw, (int32_t)SA, halo.p, len.p, k_a.p);
-        if (int rc = sort_pairs(sc, k_a.p, k_s.p, v_s.p, dof1.p, n_int, 52, st, err)) return rc;
+        if (int rc = sort_pairs(sc, k_a.p, k_s.p, v_s.p, dof1.p, n_int, 63, st, err)) return rc;
         std::vector<int32_t> h_noimp((size_t)G);
-        for (int g = 0; g < G; ++g) h_noimp[(size_t)g] = (int32_t)(std::min<int64_t>(n_int, (int64_t)(g + 1) * rpw) - (int64_t)g * rpw) - h_cnt[(size_t)g];
+        for (int g = 0; g < G; ++g)   // blocked: one class -- every row counts as "fits the first class", so that slot = position
+            h_noimp[(size_t)g] = (int32_t)(std::min<int64_t>(n_int, (int64_t)(g + 1) * rpw) - (int64_t)g * rpw) - (blocked ? 0 : h_cnt[(size_t)g]);
         DP_CHK(wg_noimp.alloc((size_t)G));
         DP_CHK(hipMemcpyAsync(wg_noimp.p, h_noimp.data(), sizeof(int32_t) * (size_t)G, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_assign_slots, dim3(grid_of(n_int)), dim3(256), 0, st, n_int, dof1.p, (int32_t)rpw, (int32_t)SA, (int32_t)S, wg_noimp.p, slot_of.p,
@@ -375,9 +393,9 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
     DP_CHK(board_of.alloc((size_t)nd));
     DP_CHK(is_exp.alloc((size_t)nd));
     DP_CHK(hipMemsetAsync(is_exp.p, 0, (size_t)nd, st));
-    if (n_imp > 0) hipLaunchKernelGGL(k_mark_exports, dim3(grid_of(n_imp)), dim3(256), 0, st, n_imp, imp_key.p, is_exp.p);
+    if (n_imp > 0 && !blocked) hipLaunchKernelGGL(k_mark_exports, dim3(grid_of(n_imp)), dim3(256), 0, st, n_imp, imp_key.p, is_exp.p);
     int64_t n_board = 0;
-    {
+    if (!blocked) {
         Tmp<uint64_t> k_a, k_s;
         Tmp<int32_t> v_a, v_s, cnt;
         const int64_t cap = n_imp > 0 ? n_imp : 1;   // exported DOFs <= imported (workgroup, DOF) pairs
@@ -400,7 +418,13 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
         DP_CHK(hipStreamSynchronize(st));
     }
     DP_CHK(hipMalloc(reinterpret_cast<void**>(&o.imp_pos), sizeof(int32_t) * (size_t)(n_imp ? n_imp : 1)));
-    if (n_imp > 0) {
+    if (blocked) {   // imports = DOF ids, ascending inside a workgroup (the order of the unique import keys)
+        DP_CHK(hipMalloc(reinterpret_cast<void**>(&o.exp_slot), sizeof(uint16_t)));
+        if (n_imp > 0) {
+            hipLaunchKernelGGL(k_low32, dim3(grid_of(n_imp)), dim3(256), 0, st, n_imp, imp_key.p, o.imp_pos);
+            hipLaunchKernelGGL(k_count_groups, dim3(grid_of(n_imp)), dim3(256), 0, st, n_imp, imp_key.p, wg_cnt.p + 2 * G);
+        }
+    } else if (n_imp > 0) {
         Tmp<uint64_t> k_a, k_s;
         DP_CHK(k_a.alloc((size_t)n_imp));
         DP_CHK(k_s.alloc((size_t)n_imp));
@@ -448,7 +472,7 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
     DP_CHK(hipMemsetAsync(o.ell_code, 0, sizeof(uint16_t) * n_alloc, st));
     DP_CHK(hipMemsetAsync(o.ell_src, 0xff, sizeof(int32_t) * n_alloc, st));
     hipLaunchKernelGGL(k_fill_ell, dim3(grid_of((int64_t)G * S)), dim3(256), 0, st, (int64_t)G * S, (int32_t)S, nsl, o.slot_dof, d_rowptr, d_colidx, keep.p, irow.p,
-                       (int32_t)rpw, slot_of.p, board_of.p, o.imp_off, o.imp_pos, o.sl_off, o.ell_off, o.ell_code, o.ell_src);
+                       (int32_t)rpw, slot_of.p, blocked ? (const int32_t*)nullptr : board_of.p, o.imp_off, o.imp_pos, o.sl_off, o.ell_off, o.ell_code, o.ell_src);
     DP_CHK(hipGetLastError());
     DP_CHK(hipStreamSynchronize(st));
     guard.armed = false;

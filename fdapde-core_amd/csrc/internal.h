@@ -146,6 +146,7 @@ struct PersistLayout {
     int64_t nnz = 0;                  // stored off-diagonal entries (no padding)
     int64_t n_board = 0;              // exported vector entries over all workgroups
     int64_t n_imp = 0;                // imported vector entries over all workgroups
+    int64_t n_drop = 0;               // rows left out (Dirichlet DOFs)
     int32_t max_imp = 0, max_exp = 0;
     int64_t max_block = 0;            // ELL entries of the largest workgroup block (0: compute from ell_off)
     std::vector<int32_t> slot_dof;    // G * S (S = R * T): internal DOF id of the row a slot holds, -1 = empty slot

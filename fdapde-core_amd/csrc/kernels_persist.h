@@ -333,6 +333,118 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
     if (status == 3 && tid == 0) atomicExch(a.ctl + 3, 1);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_spmv_blocked: y = (I + At_offdiag) x for systems the persistent CG does not take (non-symmetric operators: BiCGStab; more
+// than 2 M rows), on the same blocked sliced-ELL layout.  One workgroup per block of ~4096 rows: it stages the entries of x its
+// rows read -- its own rows, then the imports from neighbouring blocks, by DOF id -- in LDS ONCE, then streams its block of the
+// matrix with the gathers served by LDS.  The multi-launch CSR kernel (k_spmv_team2) gathers x from L2, which stops paying
+// when x outgrows the L2s (C5: 43 MB of x, 62-67 % of 8 TB/s on the algorithmic bytes); here the stream runs at the HBM rate.
+// Fused dots as k_spmv_team2: workgroup b writes (w.y, y.y | w.w) to partial[2 b], partial[2 b + 1].
+// ---------------------------------------------------------------------------------------------------------------------
+struct BlockedSpmvArgs {
+    int32_t G, nsl, imp_cap, dot2_ww;
+    const int32_t* slot_dof;
+    const int64_t* ell_off;
+    const int32_t* sl_off;
+    const uint16_t* ell_code;
+    const double* ell_val;
+    const int32_t* imp_off;
+    const int32_t* imp_dof;
+    const int32_t* drop_dof;   // rows the layout leaves out (Dirichlet DOFs): unit diagonal only, y = x there
+    int32_t n_drop;
+    const double* x;
+    double* y;
+    const double* w;         // second vector of the fused dots (may equal x), nullptr: no dots
+    double* partial;
+    const int32_t* stop;
+};
+template <int R>
+__global__ __launch_bounds__(kPersistT) void k_spmv_blocked(BlockedSpmvArgs a) {
+    constexpr int T = kPersistT, W = T / 64, S = R * T;
+    extern __shared__ double lds[];
+    __shared__ double red[W][2];
+    if (a.stop && __syncthreads_or(*a.stop != 0)) return;
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nsl = a.nsl;
+    double* p_tab = lds;
+    const int H = a.imp_off[g + 1] - a.imp_off[g];
+    const int64_t e0 = a.ell_off[g];
+    const double2* gv = reinterpret_cast<const double2*>(a.ell_val + e0);
+    const uint32_t* gc = reinterpret_cast<const uint32_t*>(a.ell_code + e0);
+    const int32_t* slo = a.sl_off + (size_t)g * (nsl + 1);
+    int o0[R], w[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        o0[j] = __builtin_amdgcn_readfirstlane(slo[j * W + wave]);
+        w[j] = __builtin_amdgcn_readfirstlane(slo[j * W + wave + 1]) - o0[j];
+    }
+    double yv[R];
+    int32_t dof[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        dof[j] = a.slot_dof[(size_t)g * S + j * T + tid];
+        yv[j] = dof[j] >= 0 ? a.x[dof[j]] : 0.0;   // unit diagonal of the scaled system
+        p_tab[j * T + tid] = yv[j];
+    }
+    for (int h = tid; h < H; h += T) p_tab[S + h] = a.x[a.imp_dof[a.imp_off[g] + h]];
+    __syncthreads();
+    double wy = 0, second = 0;
+    if (a.w != nullptr && a.dot2_ww) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const double wv = (a.w == a.x) ? yv[j] : (dof[j] >= 0 ? a.w[dof[j]] : 0.0);
+            second += wv * wv;
+        }
+    }
+    auto product = [&](auto half) {
+        constexpr int J0 = decltype(half)::value ? R / 2 : 0, J1 = decltype(half)::value ? R : R / 2;
+        int mw = 0;
+#pragma unroll
+        for (int j = J0; j < J1; ++j) mw = max(mw, w[j]);
+        for (int e = 0; e < mw; ++e) {
+            double2 v[J1 - J0];
+            uint32_t c[J1 - J0];
+#pragma unroll
+            for (int j = J0; j < J1; ++j) {
+                const int idx = (o0[j] + min(e, max(w[j] - 1, 0))) * 64 + lane;
+                v[j - J0] = gv[idx], c[j - J0] = gc[idx];
+            }
+#pragma unroll
+            for (int j = J0; j < J1; ++j) {
+                const double t = v[j - J0].x * p_tab[c[j - J0] & 0xffffu] + v[j - J0].y * p_tab[c[j - J0] >> 16];
+                yv[j] += e < w[j] ? t : 0.0;
+            }
+        }
+    };
+    product(std::integral_constant<int, 0>{});
+    product(std::integral_constant<int, 1>{});
+    {   // the left-out rows (the vector kernels sweep all n entries: y must be defined there; x is zero on them inside a solve)
+        const int chunk = (a.n_drop + a.G - 1) / a.G;
+        for (int i = g * chunk + tid; i < min(a.n_drop, (g + 1) * chunk); i += T) a.y[a.drop_dof[i]] = a.x[a.drop_dof[i]];
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        if (dof[j] < 0) continue;
+        a.y[dof[j]] = yv[j];
+        if (a.w != nullptr) {
+            const double wv = (a.w == a.x) ? p_tab[j * T + tid] : a.w[dof[j]];
+            wy += wv * yv[j];
+            if (!a.dot2_ww) second += yv[j] * yv[j];
+        }
+    }
+    if (a.partial != nullptr) {
+        wy = wave_sum64(wy), second = wave_sum64(second);
+        if (lane == 0) red[wave][0] = wy, red[wave][1] = second;
+        __syncthreads();
+        if (tid < 2) {
+            double v = 0;
+#pragma unroll
+            for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
+            a.partial[2 * g + tid] = v;
+        }
+    }
+}
+
 // ell_val[e] = scaled full-pattern value the entry maps to, 0 in padding
 __global__ __launch_bounds__(256) void k_persist_fill(int64_t n, const int32_t* src, const double* scaled_full, double* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

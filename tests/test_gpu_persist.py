@@ -122,3 +122,35 @@ def test_persistent_path_under_parabolic_stepping_and_handle(env):
     xr = spla.splu(M.tocsc()).solve(b)
     assert np.linalg.norm(x - xr) <= 1e-9 * np.linalg.norm(xr)
     c.close()
+
+
+@pytest.mark.parametrize("nx", [8, 20])
+def test_blocked_ell_spmv_under_every_krylov_method(env, nx):
+    """The blocked-ELL SpMV (k_spmv_blocked) inside the multi-launch solves, 3-D P2 rows, NON-homogeneous Dirichlet data: the layout
+    leaves the Dirichlet rows out, the vector kernels sweep all n entries -- y must be defined there too (it once kept the lift A g~
+    of the same buffer, which broke every method that sums r.r over all rows)."""
+    capi, meshgen = env
+    nodes, cells, bnd = meshgen.unit_cube(nx)
+    _, f = meshgen.manufactured(3)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(2)
+    _, _, coords = c.dofs_get()
+    c.set_operator(-capi.laplacian())
+    c.set_forcing(f(c.quadrature_nodes()))
+    c.set_dirichlet(0.25 * coords[:, 0])
+    c.init()
+    c.tune("persist", 0)
+    ref = {}
+    for blocked in (0, 2):
+        c.tune("blocked", blocked)
+        for m in (capi.SOLVER_CG_FUSED, capi.SOLVER_CG, capi.SOLVER_CG_SR, capi.SOLVER_BICGSTAB):
+            info = c.solve(method=m, rtol=1e-11)
+            assert info.converged == 1 and info.persistent == 0
+            u = c.solution()
+            if blocked == 0:
+                ref[m] = (info.iters, u)
+            else:
+                assert abs(info.iters - ref[m][0]) <= max(2, ref[m][0] // 10), (m, info.iters, ref[m][0])
+                assert np.linalg.norm(u - ref[m][1]) <= 1e-8 * np.linalg.norm(ref[m][1])
+    c.close()

@@ -53,7 +53,7 @@ int adopt_dev_space(fdapde_ctx* c, DevSpace& s) {
 // big host-side index arrays of a device-built space, fetched the first time host code needs them (the persistent layout and the
 // solver patterns read rowptr_i / colidx_i; the colouring and the partitioned assembly cdofs_i; point location cverts_i / vcoords_i;
 // fdapde_pattern_get the reference pattern)
-enum { kHostPattern = 1, kHostCells = 2, kHostRefPattern = 4 };
+enum { kHostPattern = 1, kHostCells = 2, kHostRefPattern = 4, kHostDofs = 8 };
 int ensure_host(fdapde_ctx* c, int what) {
     if (!c->dev_built) return FDAPDE_OK;
     HostSpace& hs = c->hs;
@@ -68,6 +68,16 @@ int ensure_host(fdapde_ctx* c, int what) {
         HIPCHK(c, hipMemcpyAsync(hs.cdofs_i.data(), c->cdofs.p, sizeof(int32_t) * c->cdofs.n, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipMemcpyAsync(hs.cverts_i.data(), c->cverts.p, sizeof(int32_t) * c->cverts.n, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipMemcpyAsync(hs.vcoords_i.data(), c->vcoords.p, sizeof(double) * c->vcoords.n, hipMemcpyDeviceToHost, st));
+    }
+    if ((what & kHostDofs) && hs.dofs.empty()) {   // DOF table and DOF coordinates in the reference numbering
+        hs.dofs.resize((size_t)hs.n_cells * hs.nb), hs.dof_coords.resize((size_t)hs.n_dofs * hs.N);
+        if (hs.order == 1) {   // dofs = cells, coordinates = nodes
+            std::memcpy(hs.dofs.data(), hs.cells.data(), sizeof(int32_t) * hs.dofs.size());
+            std::memcpy(hs.dof_coords.data(), hs.nodes.data(), sizeof(double) * hs.dof_coords.size());
+        } else {
+            HIPCHK(c, hipMemcpyAsync(hs.dofs.data(), c->dofs_e.p, sizeof(int32_t) * hs.dofs.size(), hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipMemcpyAsync(hs.dof_coords.data(), c->coords_e.p, sizeof(double) * hs.dof_coords.size(), hipMemcpyDeviceToHost, st));
+        }
     }
     if ((what & kHostRefPattern) && hs.colidx_e.empty()) {
         hs.rowptr_e.resize(c->rowptr_e.n), hs.colidx_e.resize(c->colidx_e.n);
@@ -104,6 +114,8 @@ int check_dev_space(fdapde_ctx* c, const DevSpace& s, int order) {
     scalar("blk_cells", hs.max_blk_cells, ref.max_blk_cells), scalar("blk_nodes", hs.max_blk_nodes, ref.max_blk_nodes);
     scalar("n_adj", s.n_adj, (int64_t)ref.adj.size()), scalar("n_bc", s.n_bc, (int64_t)ref.bc_cell.size()), scalar("n_bn", s.n_bn, (int64_t)ref.bn_node.size());
     scalar("dealt", s.dealt, !ref.lane_row.empty());
+    scalar("n_edges", hs.n_edges, ref.n_edges), scalar("n_dofs", hs.n_dofs, ref.n_dofs);
+    if (bad == 0 && hs.dof_bnd != ref.dof_bnd) std::fprintf(stderr, "set-up check dof_bnd: MISMATCH\n"), ++bad;
     if (bad == 0) {
 #define CMP(name, dptr, hvec_) cmp(name, dptr, (hvec_).data(), (hvec_).size() * sizeof((hvec_)[0]), sizeof((hvec_)[0]))
         CMP("dof_i2e", s.dof_i2e, ref.dof_i2e), CMP("dof_e2i", s.dof_e2i, ref.dof_e2i), CMP("cell_i2e", s.cell_i2e, ref.cell_i2e);
@@ -112,6 +124,7 @@ int check_dev_space(fdapde_ctx* c, const DevSpace& s, int order) {
         CMP("colidx", s.colidx, ref.colidx_i), CMP("diag", s.diag, ref.diag_i), CMP("rowptr_e", s.rowptr_e, ref.rowptr_e);
         CMP("colidx_e", s.colidx_e, ref.colidx_e), CMP("slot_i2e", s.slot_i2e, ref.slot_i2e), CMP("sl_off", s.sl_off, ref.sl_off);
         if (s.dealt) CMP("lane_row", s.lane_row, ref.lane_row);
+        if (order == 2) CMP("dofs", c->dofs_e.p, ref.dofs), CMP("dof_coords", c->coords_e.p, ref.dof_coords);
         CMP("bc_off", s.bc_off, ref.bc_off), CMP("bn_off", s.bn_off, ref.bn_off), CMP("bc_cell", s.bc_cell, ref.bc_cell);
         CMP("bn_node", s.bn_node, ref.bn_node), CMP("bc_vert", s.bc_vert, ref.bc_vert), CMP("adj", s.adj, ref.adj), CMP("slotw", s.slotw, ref.slotw);
 #undef CMP
@@ -733,7 +746,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
         (void)hipStreamSynchronize(c->stream);
         drop_graph(c);
         for (DBuf<int32_t>* b : {&c->cverts, &c->cdofs, &c->adj, &c->rowptr, &c->colidx, &c->diag, &c->slot_i2e, &c->dof_i2e,
-                                 &c->dof_e2i, &c->cell_i2e, &c->rb_row, &c->colour_cells, &c->ctl, &c->rowptr_e, &c->colidx_e})
+                                 &c->dof_e2i, &c->cell_i2e, &c->rb_row, &c->colour_cells, &c->ctl, &c->rowptr_e, &c->colidx_e, &c->dofs_e})
             b->release();
         for (DBuf<double>* b : {&c->vcoords, &c->vals[0], &c->vals[1], &c->force, &c->fq, &c->g, &c->sval, &c->scale, &c->gt,
                                 &c->x, &c->r, &c->p, &c->y, &c->s, &c->t, &c->r0, &c->u, &c->part_a, &c->part_b, &c->sc,
@@ -745,7 +758,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
         c->halo_dof.release(), c->halo_pos.release(), c->owned.release(), c->hbuf.release(), c->sbuf.release();
         c->halo_inv.release(), c->if_slot.release();
         if (c->comm) (void)g_rccl.CommDestroy(c->comm);
-        c->lin_mat.release(), c->persist_stats.release();
+        c->lin_mat.release(), c->persist_stats.release(), c->coords_e.release();
         dev_topology_release(&c->topo);
         c->part_cells.release(), c->part_off.release(), c->part_slots.release(), c->wave_slots.release(), c->part_shared.release();
         for (auto& bk : c->bk)
@@ -799,26 +812,40 @@ int fdapde_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs) {
     HostSpace& hs = c->hs;
     hs.colidx_i.clear(), hs.cdofs_i.clear(), hs.cverts_i.clear(), hs.vcoords_i.clear(), hs.colidx_e.clear(), hs.rowptr_e.clear(), hs.adj.clear(),
       hs.slotw.clear(), hs.lane_row.clear();
-    int rc = host_build_space(hs, order, c->err, /*dofs_only=*/on_device);
+    hs.dofs.clear(), hs.dof_coords.clear();
+    int rc = host_build_space(hs, order, c->err, on_device ? 2 : 0);
     if (rc) return rc;
     rc = build_basis_tables(hs.M, order, &c->tb);
     if (rc) return fail(c, rc, "basis tables");
     if (on_device) {
         HIPCHK(c, hipSetDevice(c->device));
-        DBuf<double> d_nodes, d_coords;
-        DBuf<int32_t> d_cells, d_dofs;
-        DBuf<uint8_t> d_bnd;
+        DBuf<double> d_nodes;
+        DBuf<int32_t> d_cells;
+        DBuf<uint8_t> d_nbnd, d_bnd;
+        c->dofs_e.release(), c->coords_e.release();
         HIPCHK(c, d_nodes.upload(hs.nodes.data(), hs.nodes.size(), c->stream));
         HIPCHK(c, d_cells.upload(hs.cells.data(), hs.cells.size(), c->stream));
-        HIPCHK(c, d_bnd.upload(hs.dof_bnd.data(), hs.dof_bnd.size(), c->stream));
-        if (order != 1) {
-            HIPCHK(c, d_dofs.upload(hs.dofs.data(), hs.dofs.size(), c->stream));
-            HIPCHK(c, d_coords.upload(hs.dof_coords.data(), hs.dof_coords.size(), c->stream));
+        HIPCHK(c, d_nbnd.upload(hs.node_bnd.data(), hs.node_bnd.size(), c->stream));
+        if (order == 1) {   // LagrangianBasis<D, 1>: dofs = cells, boundary DOFs = node markers (lagrangian_basis.h:96-99)
+            hs.n_edges = 0, hs.n_dofs = hs.n_nodes;
+            hs.dof_bnd.assign(hs.node_bnd.begin(), hs.node_bnd.end());
+        } else {            // order 2: edge DOFs numbered through the device-built topology (dev_topology.hip)
+            int32_t* dd = nullptr;
+            uint8_t* db = nullptr;
+            double* dc = nullptr;
+            int64_t ne = 0;
+            rc = dev_build_p2_dofs(hs.M, hs.n_nodes, hs.n_cells, d_nodes.p, d_cells.p, d_nbnd.p, c->tb.refnodes, c->stream, &dd, &db, &dc, &ne, c->err);
+            if (rc) return rc;
+            hs.n_edges = ne, hs.n_dofs = hs.n_nodes + ne;
+            adopt(c->dofs_e, dd, (size_t)hs.n_cells * hs.nb), adopt(c->coords_e, dc, (size_t)hs.n_dofs * hs.N), adopt(d_bnd, db, (size_t)hs.n_dofs);
+            hs.dof_bnd.resize((size_t)hs.n_dofs);
+            HIPCHK(c, hipMemcpyAsync(hs.dof_bnd.data(), d_bnd.p, (size_t)hs.n_dofs, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
         }
         DevSpace ds;
-        rc = dev_build_space(hs, d_nodes.p, d_cells.p, order == 1 ? d_cells.p : d_dofs.p, d_bnd.p, order == 1 ? d_nodes.p : d_coords.p, c->stream,
-                             &ds, c->err);
-        d_nodes.release(), d_coords.release(), d_cells.release(), d_dofs.release(), d_bnd.release();
+        rc = dev_build_space(hs, d_nodes.p, d_cells.p, order == 1 ? d_cells.p : c->dofs_e.p, order == 1 ? d_nbnd.p : d_bnd.p,
+                             order == 1 ? d_nodes.p : c->coords_e.p, c->stream, &ds, c->err);
+        d_nodes.release(), d_cells.release(), d_nbnd.release(), d_bnd.release();
         if (rc) return rc;
         if (std::getenv("FDAPDE_SETUP_CHECK")) {
             rc = check_dev_space(c, ds, order);
@@ -920,6 +947,8 @@ int fdapde_dofs_set_boundary(fdapde_ctx* c, const uint8_t* bnd) {
 
 int fdapde_dofs_get(const fdapde_ctx* c, int32_t* dofs, uint8_t* bnd, double* coords) {
     if (!c || !c->space_ready) return FDAPDE_ENOTINIT;
+    if (dofs || coords)
+        if (int rc = ensure_host(const_cast<fdapde_ctx*>(c), kHostDofs)) return rc;   // a device-built space keeps them on the device until asked
     if (dofs) std::memcpy(dofs, c->hs.dofs.data(), sizeof(int32_t) * c->hs.dofs.size());
     if (bnd) std::memcpy(bnd, c->hs.dof_bnd.data(), c->hs.dof_bnd.size());
     if (coords) std::memcpy(coords, c->hs.dof_coords.data(), sizeof(double) * c->hs.dof_coords.size());

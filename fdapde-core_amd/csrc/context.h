@@ -145,6 +145,8 @@ struct fdapde_ctx {
     // device buffers
     DBuf<int32_t> cverts, cdofs, adj, rowptr, colidx, diag, slot_i2e, dof_i2e, dof_e2i, cell_i2e, rb_row, colour_cells;
     DBuf<int32_t> rowptr_e, colidx_e;   // reference-numbering pattern (device-built spaces: fetched by fdapde_pattern_get on demand)
+    DBuf<int32_t> dofs_e;               // order 2, device-built: the DOF table in the reference numbering (host mirror on demand)
+    DBuf<double> coords_e;              // ... and the DOF coordinates
     bool dev_built = false;             // the index structures were built on the device (dev_setup.hip); big host mirrors are lazy
     DBuf<uint32_t> slotw;
     DBuf<int64_t> bc_off, bn_off;

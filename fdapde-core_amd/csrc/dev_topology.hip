@@ -143,7 +143,7 @@ __global__ void k_edge_heads(int64_t n, const uint64_t* key_sorted, const int32_
     first_flag[val[i]] = h ? 1 : 0;
 }
 __global__ void k_edge_tables(int64_t n, const uint64_t* key_sorted, const int32_t* val, const int32_t* head_pos, const int32_t* rank,
-                              const uint8_t* node_bnd, int32_t* edge_nodes, uint8_t* edge_bnd, int32_t* face_edges) {
+                              const uint8_t* node_bnd, int32_t* edge_nodes, uint8_t* edge_bnd, int32_t* face_edges, int32_t* edge_face) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int32_t hp = head_pos[i];
@@ -153,6 +153,68 @@ __global__ void k_edge_tables(int64_t n, const uint64_t* key_sorted, const int32
         const int32_t a = (int32_t)(key_sorted[i] >> 32), b = (int32_t)(key_sorted[i] & 0xffffffffu);
         edge_nodes[2 * (int64_t)id] = a, edge_nodes[2 * (int64_t)id + 1] = b;
         edge_bnd[id] = (node_bnd[a] && node_bnd[b]) ? 1 : 0;   // triangulation.h:371
+        edge_face[id] = val[i] / 3;                             // the head of the run is the edge's first emission: face = e2 / 3
+    }
+}
+
+// ---- order-2 DOF table from the topology ---------------------------------------------------------------------------------
+__global__ void k_p2_dofs_2d(int64_t nc, int32_t nn, const int32_t* cells, const int32_t* cell_facets, int32_t* dofs) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nc) return;
+    for (int v = 0; v < 3; ++v) dofs[c * 6 + v] = cells[c * 3 + v];
+    for (int j = 0; j < 3; ++j) dofs[c * 6 + 3 + j] = nn + cell_facets[c * 3 + j];   // pairs (0,1), (0,2), (1,2) = local nodes 3, 4, 5
+}
+__global__ void k_p2_dofs_3d(int64_t nc, int32_t nn, const int32_t* cells, const int32_t* cell_facets, const int32_t* facet_nodes,
+                             const int32_t* face_edges, int32_t* dofs) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nc) return;
+    const int32_t* cv = cells + c * 4;
+    for (int v = 0; v < 4; ++v) dofs[c * 10 + v] = cv[v];
+    // local pair (a, b) -> slot of its midpoint in ReferenceElement<3,2>::nodes (host_setup.cpp edge_slot)
+    const int PA[6] = {0, 0, 0, 1, 1, 2}, PB[6] = {1, 2, 3, 2, 3, 3}, SL[6] = {6, 5, 9, 4, 7, 8};
+    for (int p = 0; p < 6; ++p) {
+        const int a = PA[p], b = PB[p];
+        int j = 0;   // a face of the cell that contains both: face j (combinations order) leaves out local vertex 3 - j
+        while (3 - j == a || 3 - j == b) ++j;
+        const int64_t f = cell_facets[c * 4 + j];
+        const int32_t na = cv[a], nb_ = cv[b], lo = na < nb_ ? na : nb_, hi = na < nb_ ? nb_ : na;
+        const int32_t* t = facet_nodes + f * 3;
+        const int k = (lo == t[0] && hi == t[1]) ? 0 : ((lo == t[0] && hi == t[2]) ? 1 : 2);
+        dofs[c * 10 + SL[p]] = nn + face_edges[f * 3 + k];
+    }
+}
+__global__ void k_p2_bnd(int64_t nn, int64_t ne, const uint8_t* node_bnd, const uint8_t* edge_bnd, uint8_t* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nn) out[i] = node_bnd[i];
+    else if (i < nn + ne) out[i] = edge_bnd[i - nn];
+}
+struct RefNodes {
+    double v[10 * 3];
+};
+// the edge DOF's coordinates from the first cell that visits it: acc = sum_k (x_{k+1} - x_0) ref_k (in this order, no contraction), + x_0
+template <int M>
+__global__ void k_p2_coords(int64_t nn, int64_t ne, int N, int nb, const double* nodes, const int32_t* cells, const int32_t* dofs,
+                            const int32_t* first_cell_of /* 2-D: facet_cells (stride 2); 3-D: edge_face */, const int32_t* facet_cells,
+                            RefNodes ref, double* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nd = nn + ne;
+    if (i < nn) {
+        for (int d = 0; d < N; ++d) out[(int64_t)d * nd + i] = nodes[(int64_t)d * nn + i];
+        return;
+    }
+    if (i >= nd) return;
+    const int64_t e = i - nn;
+    const int64_t c = M == 2 ? first_cell_of[2 * e] : facet_cells[2 * (int64_t)first_cell_of[e]];
+    const int32_t dof = (int32_t)i;
+    int j = M + 1;
+    while (j < nb - 1 && dofs[c * nb + j] != dof) ++j;
+    const int32_t v0 = cells[c * (M + 1)];
+    for (int d = 0; d < N; ++d) {
+        const double x0 = nodes[(int64_t)d * nn + v0];
+        double acc = 0;
+        for (int k = 0; k < M; ++k)
+            acc = __dadd_rn(acc, __dmul_rn(__dsub_rn(nodes[(int64_t)d * nn + cells[c * (M + 1) + k + 1]], x0), ref.v[j * M + k]));
+        out[(int64_t)d * nd + i] = __dadd_rn(acc, x0);
     }
 }
 
@@ -267,8 +329,9 @@ int build_t(int64_t n_nodes, int64_t n_cells, const int32_t* d_cells, const uint
         TOPO_CHK(hipMalloc(reinterpret_cast<void**>(&out->edge_nodes), sizeof(int32_t) * (size_t)(h_ne ? h_ne : 1) * 2));
         TOPO_CHK(hipMalloc(reinterpret_cast<void**>(&out->edge_bnd), (size_t)(h_ne ? h_ne : 1)));
         TOPO_CHK(hipMalloc(reinterpret_cast<void**>(&out->face_edges), sizeof(int32_t) * (size_t)(n2 ? n2 : 1)));
+        TOPO_CHK(hipMalloc(reinterpret_cast<void**>(&out->edge_face), sizeof(int32_t) * (size_t)(h_ne ? h_ne : 1)));
         hipLaunchKernelGGL(k_edge_tables, dim3(grid_of(n2)), dim3(256), 0, st, n2, ek_b.p, ev_b.p, head_max.p, erank.p, d_node_bnd,
-                           out->edge_nodes, out->edge_bnd, out->face_edges);
+                           out->edge_nodes, out->edge_bnd, out->face_edges, out->edge_face);
         TOPO_CHK(hipGetLastError());
         TOPO_CHK(hipStreamSynchronize(st));   // the scratch buffers of this scope are freed on exit
     } else {
@@ -284,7 +347,7 @@ int build_t(int64_t n_nodes, int64_t n_cells, const int32_t* d_cells, const uint
 void dev_topology_release(DevTopology* t) {
     if (!t) return;
     for (void* p : {(void*)t->facet_nodes, (void*)t->facet_cells, (void*)t->facet_bnd, (void*)t->cell_facets, (void*)t->neighbors,
-                    (void*)t->edge_nodes, (void*)t->edge_bnd, (void*)t->face_edges})
+                    (void*)t->edge_nodes, (void*)t->edge_bnd, (void*)t->face_edges, (void*)t->edge_face})
         if (p) (void)hipFree(p);
     *t = DevTopology{};
 }
@@ -299,6 +362,52 @@ int dev_build_topology(int M, int64_t n_nodes, int64_t n_cells, const int32_t* d
     else err = "topology tables exist for triangles and tetrahedra";
     if (rc != FDAPDE_OK) dev_topology_release(out);
     return rc;
+}
+
+int dev_build_p2_dofs(int M, int64_t n_nodes, int64_t n_cells, const double* d_nodes, const int32_t* d_cells, const uint8_t* d_node_bnd,
+                      const double* refnodes, void* stream, int32_t** d_dofs, uint8_t** d_dof_bnd, double** d_dof_coords, int64_t* n_edges,
+                      std::string& err) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (M != 2 && M != 3) return FDAPDE_EUNSUPPORTED;
+    DevTopology t;
+    if (int rc = dev_build_topology(M, n_nodes, n_cells, d_cells, d_node_bnd, stream, &t, err)) return rc;
+    struct Guard {
+        DevTopology* t;
+        ~Guard() { dev_topology_release(t); }
+    } guard{&t};
+    const int nb = M == 2 ? 6 : 10, N = M;
+    const int64_t ne = t.n_edges, nd = n_nodes + ne;
+    if (nd > INT32_MAX) {
+        err = "too many DOFs";
+        return FDAPDE_EUNSUPPORTED;
+    }
+    int32_t* dofs = nullptr;
+    uint8_t* bnd = nullptr;
+    double* coords = nullptr;
+    TOPO_CHK(hipMalloc(reinterpret_cast<void**>(&dofs), sizeof(int32_t) * (size_t)n_cells * nb));
+    TOPO_CHK(hipMalloc(reinterpret_cast<void**>(&bnd), (size_t)nd));
+    TOPO_CHK(hipMalloc(reinterpret_cast<void**>(&coords), sizeof(double) * (size_t)nd * N));
+    RefNodes ref{};
+    for (int i = 0; i < nb * M; ++i) ref.v[i] = refnodes[i];
+    if (M == 2) {
+        hipLaunchKernelGGL(k_p2_dofs_2d, dim3(grid_of(n_cells)), dim3(256), 0, st, n_cells, (int32_t)n_nodes, d_cells, t.cell_facets, dofs);
+        hipLaunchKernelGGL(k_p2_bnd, dim3(grid_of(nd)), dim3(256), 0, st, n_nodes, ne, d_node_bnd, t.facet_bnd, bnd);
+        hipLaunchKernelGGL(k_p2_coords<2>, dim3(grid_of(nd)), dim3(256), 0, st, n_nodes, ne, N, nb, d_nodes, d_cells, dofs, t.facet_cells, t.facet_cells, ref,
+                           coords);
+    } else {
+        hipLaunchKernelGGL(k_p2_dofs_3d, dim3(grid_of(n_cells)), dim3(256), 0, st, n_cells, (int32_t)n_nodes, d_cells, t.cell_facets, t.facet_nodes,
+                           t.face_edges, dofs);
+        hipLaunchKernelGGL(k_p2_bnd, dim3(grid_of(nd)), dim3(256), 0, st, n_nodes, ne, d_node_bnd, t.edge_bnd, bnd);
+        hipLaunchKernelGGL(k_p2_coords<3>, dim3(grid_of(nd)), dim3(256), 0, st, n_nodes, ne, N, nb, d_nodes, d_cells, dofs, t.edge_face, t.facet_cells, ref,
+                           coords);
+    }
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        (void)hipFree(dofs), (void)hipFree(bnd), (void)hipFree(coords);
+        err = "order-2 DOF kernels failed";
+        return FDAPDE_EHIP;
+    }
+    *d_dofs = dofs, *d_dof_bnd = bnd, *d_dof_coords = coords, *n_edges = ne;
+    return FDAPDE_OK;
 }
 
 }  // namespace fdapde_hip

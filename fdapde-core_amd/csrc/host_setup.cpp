@@ -425,7 +425,7 @@ int host_set_mesh(HostSpace& hs, int M, int N, int64_t n_nodes, const double* no
     return FDAPDE_OK;
 }
 
-int host_build_space(HostSpace& hs, int order, std::string& err, bool dofs_only) {
+int host_build_space(HostSpace& hs, int order, std::string& err, int stop_after) {
     auto t0 = std::chrono::steady_clock::now();
     auto t_phase = t0;
     const bool dbg_time = std::getenv("FDAPDE_DEBUG_SETUP") != nullptr;
@@ -451,6 +451,7 @@ int host_build_space(HostSpace& hs, int order, std::string& err, bool dofs_only)
     const int nb = n_basis_of(M, order);
     hs.order = order, hs.nb = nb, hs.nq = n_quadrature_of(M, order);
     const int64_t nc = hs.n_cells, nn = hs.n_nodes;
+    if (stop_after == 2) return FDAPDE_OK;   // sizes only: the DOF table too is built on the device (dev_topology.hip)
 
     // ---- DOF table, boundary DOFs (reference numbering) ------------------------------------------------------
     hs.dofs.resize((size_t)nc * nb);   // vertex slots here, edge slots (order 2) below: every slot is written
@@ -508,7 +509,7 @@ int host_build_space(HostSpace& hs, int order, std::string& err, bool dofs_only)
     }
 
     phase("dof coordinates");
-    if (dofs_only) return FDAPDE_OK;   // the device builder (dev_setup.hip) takes it from here
+    if (stop_after == 1) return FDAPDE_OK;   // the device builder (dev_setup.hip) takes it from here
     // ---- locality numbering --------------------------------------------------------------------------------
     hs.node_i2e = morton_order(N, nn, hs.nodes.data());
     hs.node_e2i = invert(hs.node_i2e);

@@ -105,9 +105,10 @@ constexpr int kSpmvNnz = 4096;  // products staged in LDS per row block (32 KiB)
 
 int host_set_mesh(HostSpace& hs, int M, int N, int64_t n_nodes, const double* nodes, int64_t n_cells,
                   const int32_t* cells, const uint8_t* bnd, std::string& err);
-// dofs_only: stop after the DOF table, boundary DOFs and DOF coordinates (reference numbering); the index structures are then
-// built on the device (dev_setup.hip)
-int host_build_space(HostSpace& hs, int order, std::string& err, bool dofs_only = false);
+// stop_after: 0 = everything; 1 = stop after the DOF table, boundary DOFs and DOF coordinates (reference numbering): the index
+// structures are then built on the device (dev_setup.hip); 2 = sizes only (order, n_basis, n_quadrature): the DOF table too is built on
+// the device (dev_topology.hip)
+int host_build_space(HostSpace& hs, int order, std::string& err, int stop_after = 0);
 int host_build_colouring(HostSpace& hs, std::string& err);
 // Solver pattern: the internal CSR pattern without the diagonal and (use_bnd) without rows / columns of Dirichlet DOFs.
 // full2s[k] = slot of full entry k in the compact arrays, or -1 when the entry is dropped.

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfdapde_hip.so")
+LIB_PATH = os.environ.get("FDAPDE_HIP_LIB") or os.path.join(_HERE, "lib", "libfdapde_hip.so")   # (override: A/B builds of tools/)
 
 OK, EINVAL, ENOMEM, ENODEVICE, EHIP, ENOTINIT, ENOCONV, EUNSUPPORTED, ERCCL = range(9)
 LAPLACIAN, DIFFUSION, ADVECTION, REACTION, DT = range(5)

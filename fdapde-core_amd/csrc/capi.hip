@@ -1191,7 +1191,7 @@ int build_solver_pattern(fdapde_ctx* c, int v) {
 int check_dev_persist(fdapde_ctx* c, int v, const PersistLayout& pl, const DevPersist& dp) {
     if (int rc = ensure_host(c, kHostPattern)) return rc;
     PersistLayout ref;
-    if (host_build_persist_layout(c->hs, v == 1, c->n_cu, 12000, ref) != FDAPDE_OK) return fail(c, FDAPDE_EHIP, "set-up check: host persistent layout failed");
+    if (host_build_persist_layout(c->hs, v == 1, c->n_cu, 12000, ref, nullptr, pl.sym ? 1 : 0) != FDAPDE_OK) return fail(c, FDAPDE_EHIP, "set-up check: host persistent layout failed");
     int bad = 0;
     auto scalar = [&](const char* name, int64_t a, int64_t b) {
         if (a != b) std::fprintf(stderr, "persist check %-9s: MISMATCH %lld vs %lld\n", name, (long long)a, (long long)b), ++bad;
@@ -1232,30 +1232,46 @@ int build_persist(fdapde_ctx* c, int v) {
     DevPersist dp;
     const char* mode = std::getenv("FDAPDE_SETUP");
     bool on_device = !(mode && std::strcmp(mode, "host") == 0);
-    int rc = FDAPDE_EUNSUPPORTED;
-    if (on_device) {   // the layout is built where the pattern lives (dev_persist.hip)
-        rc = dev_build_persist_layout(c->hs.n_dofs, c->hs.max_row, c->rowptr.p, c->colidx.p, c->bnd.p, v == 1, c->n_cu, 12000, 0, c->stream, pl, &dp, c->err);
-        if (rc == FDAPDE_EUNSUPPORTED && c->hs.max_row > 255) on_device = false;   // rows too long for its sort keys: host builder
-    }
-    if (!on_device) {
-        if (int rc2 = ensure_host(c, kHostPattern)) return rc2;
-        rc = host_build_persist_layout(c->hs, v == 1, c->n_cu, 12000, pl);   // ~12 000 ELL entries (120 KB) next to the vectors of <= 4096 rows
-    }
-    if (rc == FDAPDE_EUNSUPPORTED) return FDAPDE_OK;
-    if (rc) return rc;
     double max_mb = 1024.0;   // ELL bytes (10 per entry) of the whole system (the row bound -- G x 8192 -- is reached first for P1 systems)
     if (const char* e = std::getenv("FDAPDE_PERSIST_MAX_MB")) max_mb = std::atof(e);
-    if (10.0 * (double)pl.n_entries > max_mb * 1e6) {
-        dev_persist_release(&dp);
-        return FDAPDE_OK;
-    }
-    const int S = pl.R * kPersistT;
-    const int imp_cap = (pl.max_imp + 63) & ~63, exp_cap = (pl.max_exp + 63) & ~63;
     const size_t lds_total = 160 * 1024 - 1024;   // static arrays of the kernel + slack
-    const size_t fixed = 8 * (size_t)(S + imp_cap) + 4 * (size_t)imp_cap + 2 * (size_t)exp_cap + 64;
-    int64_t need = pl.max_block;   // largest workgroup block
-    for (int g = 0; g < pl.G && !on_device; ++g) need = std::max<int64_t>(need, pl.ell_off[(size_t)g + 1] - pl.ell_off[(size_t)g]);
-    need += 128;        // one pair row of zeros behind the block: slices narrower than their pass's widest re-read it (clamped loads)
+    size_t fixed = 0;
+    int64_t need = 0;
+    int imp_cap = 0, exp_cap = 0, S = 0;
+    // symmetric storage (kernels_persist.h SYM) where the plain blocks would not fit the LDS; the plain form where they do (C2: the
+    // iteration is latency-bound there, fewer bytes buy nothing) or where the accumulator table leaves no room for the vectors
+    int sym_mode = c->persist_sym;   // 0 never, 1 always, 2 auto
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        pl = PersistLayout{};
+        int rc = FDAPDE_EUNSUPPORTED;
+        if (on_device) {   // the layout is built where the pattern lives (dev_persist.hip)
+            rc = dev_build_persist_layout(c->hs.n_dofs, c->hs.max_row, c->rowptr.p, c->colidx.p, c->bnd.p, v == 1, c->n_cu, 12000, 0, nullptr, sym_mode,
+                                          c->stream, pl, &dp, c->err);
+            if (rc == FDAPDE_EUNSUPPORTED && c->hs.max_row > 255) on_device = false;   // rows too long for its sort keys: host builder
+        }
+        if (!on_device) {
+            if (int rc2 = ensure_host(c, kHostPattern)) return rc2;
+            rc = host_build_persist_layout(c->hs, v == 1, c->n_cu, 12000, pl, nullptr, sym_mode);   // ~12 000 ELL entries (120 KB) next to the vectors of <= 4096 rows
+        }
+        if (rc == FDAPDE_EUNSUPPORTED) return FDAPDE_OK;
+        if (rc) return rc;
+        if (10.0 * (double)pl.n_entries > max_mb * 1e6) {
+            dev_persist_release(&dp);
+            return FDAPDE_OK;
+        }
+        S = pl.R * kPersistT;
+        imp_cap = (pl.max_imp + 63) & ~63, exp_cap = (pl.max_exp + 63) & ~63;
+        fixed = pl.sym ? 8 * (size_t)(S + imp_cap) + 8 * (size_t)S + 64 : 8 * (size_t)(S + imp_cap) + 4 * (size_t)imp_cap + 2 * (size_t)exp_cap + 64;
+        need = pl.max_block;   // largest workgroup block
+        for (int g = 0; g < pl.G && !on_device; ++g) need = std::max<int64_t>(need, pl.ell_off[(size_t)g + 1] - pl.ell_off[(size_t)g]);
+        need += 128;        // one pair row of zeros behind the block: slices narrower than their pass's widest re-read it (clamped loads)
+        if (pl.sym && fixed > lds_total && attempt == 0) {   // no room for the accumulator table: the plain form
+            dev_persist_release(&dp);
+            sym_mode = 0;
+            continue;
+        }
+        break;
+    }
     // resident form when every block fits its workgroup's LDS next to the vectors; else the blocks stream every iteration
     ps.stream = fixed + 10 * (size_t)need > lds_total;
     if (fixed > lds_total || (pl.R == 16 && !ps.stream)) {   // (no resident instantiation for 8192 rows: they never fit)
@@ -1293,14 +1309,15 @@ int build_persist(fdapde_ctx* c, int v) {
     HIPCHK(c, ps.ell_val.alloc((size_t)pl.n_entries + 256));
     HIPCHK(c, hipMemsetAsync(ps.ell_val.p, 0, sizeof(double) * ((size_t)pl.n_entries + 256), st));
     HIPCHK(c, ps.board.alloc(2 * (size_t)pl.n_board + 2 * (size_t)pl.G * 6 + 2));   // p entries | dot partials x 2 parities
+    HIPCHK(c, ps.amax.alloc(1));
     HIPCHK(c, c->persist_stats.alloc(4 * 1024));
     HIPCHK(c, hipStreamSynchronize(st));
     if (std::getenv("FDAPDE_DEBUG_SETUP"))
         std::fprintf(stderr, "persistent CG layout %d (%s-built): %d workgroups x %d rows/thread, %lld interior rows, %lld entries (%lld stored, %.1f %% padding), "
-                     "LDS %zu B (%s, largest block %lld), imports <= %d, exports <= %d, board %lld\n", v, on_device ? "device" : "host", pl.G, pl.R,
+                     "LDS %zu B (%s%s, largest block %lld), imports <= %d, exports <= %d, board %lld\n", v, on_device ? "device" : "host", pl.G, pl.R,
                      (long long)pl.n_int, (long long)pl.n_entries, (long long)pl.nnz,
                      100.0 * (double)(pl.n_entries - pl.nnz) / (double)(pl.n_entries > 0 ? pl.n_entries : 1), ps.lds_bytes,
-                     ps.stream ? "blocks stream" : "blocks resident", (long long)need, pl.max_imp, pl.max_exp, (long long)pl.n_board);
+                     ps.stream ? "blocks stream" : "blocks resident", pl.sym ? ", symmetric storage" : "", (long long)need, pl.max_imp, pl.max_exp, (long long)pl.n_board);
     // keep the sizes, drop the big host arrays
     pl.slot_dof = {}, pl.ell_code = {}, pl.ell_src = {}, pl.exp_slot = {}, pl.imp_pos = {}, pl.sl_off = {}, pl.ell_off = {};
     ps.meta = std::move(pl);
@@ -1318,14 +1335,21 @@ int run_persist(fdapde_ctx* c, int v, double tol2, int maxit, bool* ran) {
     a.slot_dof = ps.slot_dof.p, a.ell_off = ps.ell_off.p, a.sl_off = ps.sl_off.p, a.ell_code = ps.ell_code.p;
     a.ell_val = ps.ell_val.p, a.exp_off = ps.exp_off.p, a.exp_slot = ps.exp_slot.p, a.imp_off = ps.imp_off.p, a.imp_pos = ps.imp_pos.p;
     a.pboard = ps.board.p, a.dboard = ps.board.p + 2 * (size_t)ps.meta.n_board;
+    a.amax_bits = ps.amax.p, a.max_len = c->hs.max_row;
     a.r_in = c->r.p, a.x = c->x.p, a.sc = c->sc.p, a.ctl = c->ctl.p, a.stats = c->persist_stats.p;
     HIPCHK(c, hipMemsetAsync(ps.board.p, 0, sizeof(unsigned long long) * ps.board.n, st));   // every tag 0: no epoch of this launch
     HIPCHK(c, hipMemsetAsync(c->persist_stats.p, 0, 4 * (size_t)a.G * sizeof(double), st));
 #define PERSIST_GO(R_, ST_)                                                                                                     \
     do {                                                                                                                        \
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cg_persist<R_, ST_>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      (int)ps.lds_bytes));                                                                      \
-        hipLaunchKernelGGL((k_cg_persist<R_, ST_>), dim3(a.G), dim3(kPersistT), ps.lds_bytes, st, a);                           \
+        if (ps.meta.sym) {                                                                                                      \
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cg_persist<R_, ST_, true>),                          \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ps.lds_bytes));                      \
+            hipLaunchKernelGGL((k_cg_persist<R_, ST_, true>), dim3(a.G), dim3(kPersistT), ps.lds_bytes, st, a);                 \
+        } else {                                                                                                                \
+            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cg_persist<R_, ST_, false>),                         \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ps.lds_bytes));                      \
+            hipLaunchKernelGGL((k_cg_persist<R_, ST_, false>), dim3(a.G), dim3(kPersistT), ps.lds_bytes, st, a);                \
+        }                                                                                                                       \
     } while (0)
     if (ps.stream) switch (ps.meta.R) {
         case 2: PERSIST_GO(2, true); break;
@@ -1365,7 +1389,7 @@ int build_blocked(fdapde_ctx* c, int v) {
     // rows per block, measured on C5 (P2, 28 entries per row; CSR kernel 400 us per SpMV): 1024 -> 375 us, 2048 -> 367, 4096 -> 387, 8192 -> 439
     int rows = 2048;
     if (const char* e = std::getenv("FDAPDE_BLOCKED_ROWS")) rows = std::atoi(e);
-    const int rc = dev_build_persist_layout(c->hs.n_dofs, c->hs.max_row, c->rowptr.p, c->colidx.p, c->bnd.p, v == 1, 1 << 19, 0, rows, c->stream, pl, &dp,
+    const int rc = dev_build_persist_layout(c->hs.n_dofs, c->hs.max_row, c->rowptr.p, c->colidx.p, c->bnd.p, v == 1, 1 << 19, 0, rows, nullptr, 0, c->stream, pl, &dp,
                                             c->err);
     if (rc == FDAPDE_EUNSUPPORTED) return FDAPDE_OK;
     if (rc) return rc;
@@ -1463,13 +1487,14 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss) {
     if (blocked) {
         const int v = use_bnd ? 1 : 0;
         hipLaunchKernelGGL(k_persist_fill, dim3(g1(c->bk[v].meta.n_entries)), dim3(256), 0, st, c->bk[v].meta.n_entries, c->bk[v].ell_src.p,
-                           c->sval.p, c->bk[v].ell_val.p);
+                           c->sval.p, c->bk[v].ell_val.p, (unsigned long long*)nullptr);
         c->bk[v].filled = true, c->bk_cur = v;
     }
     if (persist) {
         const int v = use_bnd ? 1 : 0;
+        if (c->ps[v].meta.sym) HIPCHK(c, hipMemsetAsync(c->ps[v].amax.p, 0, sizeof(unsigned long long), st));
         hipLaunchKernelGGL(k_persist_fill, dim3(g1(c->ps[v].meta.n_entries)), dim3(256), 0, st, c->ps[v].meta.n_entries, c->ps[v].ell_src.p,
-                           c->sval.p, c->ps[v].ell_val.p);
+                           c->sval.p, c->ps[v].ell_val.p, c->ps[v].meta.sym ? c->ps[v].amax.p : (unsigned long long*)nullptr);
         c->ps[v].filled = true;
     }
     HIPCHK(c, hipGetLastError());
@@ -1745,6 +1770,14 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
             const double* st = &c->persist_host_stats[4 * g];
             const double n_it = st[0] > 0 ? st[0] : 1;
             mx = std::max(mx, st[1] / n_it), mean += st[1] / n_it, gat += st[2] / n_it, upd += st[3] / n_it;
+        }
+        if (std::getenv("FDAPDE_DEBUG_PERSIST")) {   // per-workgroup operator phases (us), with the workgroup's ELL entries
+            std::vector<int64_t> eo(G + 1);
+            const int v = ss.use_bnd ? 1 : 0;
+            (void)hipMemcpy(eo.data(), c->ps[v].ell_off.p, sizeof(int64_t) * (G + 1), hipMemcpyDeviceToHost);
+            for (size_t g = 0; g < G; ++g)
+                std::fprintf(stderr, "persist wg %zu: operator %.2f us gather %.2f us entries %lld\n", g, c->persist_host_stats[4 * g + 1] / std::max(1.0, c->persist_host_stats[4 * g]) * 1e-2,
+                             c->persist_host_stats[4 * g + 2] / std::max(1.0, c->persist_host_stats[4 * g]) * 1e-2, (long long)(eo[g + 1] - eo[g]));
         }
         c->info.spmv_avg_ms = mx * 1e-5, c->info.spmv_timed = (int32_t)c->persist_host_stats[0];
         c->info.spmv_mean_ms = mean / (double)G * 1e-5, c->info.gather_avg_ms = gat / (double)G * 1e-5, c->info.update_avg_ms = upd / (double)G * 1e-5;
@@ -2376,6 +2409,11 @@ int fdapde_comm_init(fdapde_ctx* c, int32_t world, int32_t rank, const void* uni
     if (c->comm) (void)g_rccl.CommDestroy(c->comm), c->comm = nullptr;
     ncclUniqueId id;
     std::memcpy(&id, unique_id128, sizeof id);
+    {   // RCCL reads the runtime's last-error slot while it sets up: an error some earlier, unrelated call of this process left there
+        // (HIP keeps it until somebody asks) would be reported as RCCL's own
+        const hipError_t stale = hipGetLastError();
+        if (stale != hipSuccess && std::getenv("FDAPDE_DEBUG_SETUP")) std::fprintf(stderr, "comm_init: stale HIP error cleared: %s\n", hipGetErrorString(stale));
+    }
     RCCLCHK(c, g_rccl.CommInitRank(&c->comm, world, id, rank));
     c->world = world, c->rank = rank, c->ar_fn = nullptr;
     return FDAPDE_OK;
@@ -2446,6 +2484,10 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "blocked" && value >= 0 && value <= 2) c->blocked = value;   // 2: also for short-row systems
     else if (k == "persist_gather_waves" && (value == 1 || value == 4)) c->persist_gather_waves = value;
     else if (k == "persist_poll_sleep" && value >= 0 && value <= 3) c->persist_poll_sleep = value;
+    else if (k == "persist_sym" && value >= 0 && value <= 2) {   // 0 plain storage, 1 symmetric, 2 symmetric where the plain blocks would stream
+        c->persist_sym = value;
+        for (auto& ps : c->ps) ps.tried = ps.ok = ps.filled = false;   // the layouts are rebuilt on the next solve
+    }
     else if (k == "spmv_ntv" && value >= -1 && value <= 1) c->spmv_ntv = value;
     else if (k == "spmv_bpx" && value >= 1 && value <= 1024) {
         c->spmv_grid = 8 * value;

@@ -222,6 +222,7 @@ struct fdapde_ctx {
     int n_cu = 0;
     int persist = 1;                         // tuning knob: 0 = never take the single-launch path
     int persist_time = 1;                    // workgroup 0 stamps the phases of every iteration (a handful of s_memrealtime per iteration)
+    int persist_sym = 2;                                    // symmetric storage of the persistent CG: 0 never, 1 always, 2 where the plain blocks would stream
     int persist_gather_waves = 4, persist_poll_sleep = 2;   // tuning knobs of the dot all-gather (kernels_persist.h)
     bool persist_broken = false;             // a hand-off timed out once (workgroups not co-resident): stay on the multi-launch path
     struct Persist {
@@ -234,6 +235,7 @@ struct fdapde_ctx {
         DBuf<int64_t> ell_off;
         DBuf<uint16_t> ell_code, exp_slot;
         DBuf<double> ell_val;
+        DBuf<unsigned long long> amax;       // symmetric storage: bit pattern of max |ell_val| (k_persist_fill)
         DBuf<unsigned long long> board;      // [2 n_board granules of p | 2 x G x 6 granules of dot partials], zeroed before every launch
         bool filled = false;                 // ell_val holds the currently scaled system
     } ps[2];

@@ -55,6 +55,19 @@ struct Scratch {
 };
 inline unsigned grid_of(int64_t n) { return (unsigned)((n + 255) / 256); }
 
+// workgroup of an interior row index: wgs[g] <= i < wgs[g + 1]
+__device__ __forceinline__ int32_t wg_of_irow(const int32_t* wgs, int G, int64_t i) {
+    int lo = 0, hi = G;   // invariant: wgs[lo] <= i < wgs[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (wgs[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+__global__ void k_wg_of(int64_t nd, const uint8_t* keep, const int32_t* irow, const int32_t* wgs, int G, int32_t* wg) {
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < nd) wg[d] = keep[d] ? wg_of_irow(wgs, G, irow[d]) : -1;
+}
 __device__ __forceinline__ bool kept_entry(const uint8_t* keep, int32_t row, int32_t col) { return col != row && keep[col]; }
 
 __global__ void k_keep_flags(int64_t nd, const uint8_t* bnd, int use_bnd, uint8_t* keep, int32_t* keep32) {
@@ -71,31 +84,45 @@ __global__ void k_row_lengths(int64_t nd, const int32_t* rowptr, const int32_t* 
         for (int32_t k = rowptr[d]; k < rowptr[d + 1]; ++k) n += kept_entry(keep, (int32_t)d, colidx[k]);
     len[d] = n;
 }
+// symmetric storage: a row keeps the in-block pairs it owns (persist_sym_owner) and every entry of another workgroup's column
+__global__ void k_row_lengths_sym(int64_t nd, const int32_t* rowptr, const int32_t* colidx, const uint8_t* keep, const int32_t* wg, int32_t* len) {
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= nd) return;
+    int32_t n = 0;
+    if (keep[d]) {
+        const int32_t g = wg[d];
+        for (int32_t k = rowptr[d]; k < rowptr[d + 1]; ++k) {
+            const int32_t c = colidx[k];
+            n += kept_entry(keep, (int32_t)d, c) && (wg[c] != g || persist_sym_owner((int32_t)d, c));
+        }
+    }
+    len[d] = n;
+}
 // per interior row: does it read another workgroup's rows, and how many such entries; per workgroup: rows that do
-__global__ void k_row_halo(int64_t nd, const int32_t* rowptr, const int32_t* colidx, const uint8_t* keep, const int32_t* irow, int32_t rpw,
+__global__ void k_row_halo(int64_t nd, const int32_t* rowptr, const int32_t* colidx, const uint8_t* keep, const int32_t* wg,
                            uint8_t* halo, int32_t* n_out, int32_t* wg_halo) {
     const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= nd) return;
     int32_t n = 0;
     if (keep[d]) {
-        const int32_t g = irow[d] / rpw;
+        const int32_t g = wg[d];
         for (int32_t k = rowptr[d]; k < rowptr[d + 1]; ++k) {
             const int32_t c = colidx[k];
-            n += kept_entry(keep, (int32_t)d, c) && irow[c] / rpw != g;
+            n += kept_entry(keep, (int32_t)d, c) && wg[c] != g;
         }
         if (n) atomicAdd(&wg_halo[g], 1);
     }
     halo[d] = n ? 1 : 0, n_out[d] = n;
 }
-__global__ void k_import_pairs(int64_t nd, const int32_t* rowptr, const int32_t* colidx, const uint8_t* keep, const int32_t* irow, int32_t rpw,
+__global__ void k_import_pairs(int64_t nd, const int32_t* rowptr, const int32_t* colidx, const uint8_t* keep, const int32_t* wg,
                                const int32_t* at, uint64_t* key) {
     const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= nd || !keep[d]) return;
-    const int32_t g = irow[d] / rpw;
+    const int32_t g = wg[d];
     int32_t o = at[d];
     for (int32_t k = rowptr[d]; k < rowptr[d + 1]; ++k) {
         const int32_t c = colidx[k];
-        if (kept_entry(keep, (int32_t)d, c) && irow[c] / rpw != g) key[o++] = ((uint64_t)(uint32_t)g << 32) | (uint32_t)c;
+        if (kept_entry(keep, (int32_t)d, c) && wg[c] != g) key[o++] = ((uint64_t)(uint32_t)g << 32) | (uint32_t)c;
     }
 }
 __global__ void k_unique_flags(int64_t n, const uint64_t* key, int32_t* flag) {
@@ -107,31 +134,31 @@ __global__ void k_compact_keys(int64_t n, const uint64_t* key, const int32_t* fl
     if (i < n && flag[i]) out[pos[i]] = key[i];
 }
 // first ordering of the rows of a workgroup: (imports?, length descending, DOF)
-__global__ void k_row_keys1(int64_t nd, const uint8_t* keep, const int32_t* irow, int32_t rpw, const uint8_t* halo, const int32_t* len,
+__global__ void k_row_keys1(int64_t nd, const uint8_t* keep, const int32_t* irow, const int32_t* wg, const uint8_t* halo, const int32_t* len,
                             uint64_t* key, int32_t* val) {
     const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= nd || !keep[d]) return;
     const int32_t i = irow[d];
-    key[i] = ((uint64_t)(uint32_t)(i / rpw) << 41) | ((uint64_t)halo[d] << 40) | ((uint64_t)(255 - len[d]) << 32) | (uint32_t)d;
+    key[i] = ((uint64_t)(uint32_t)wg[d] << 41) | ((uint64_t)halo[d] << 40) | ((uint64_t)(255 - len[d]) << 32) | (uint32_t)d;
     val[i] = (int32_t)d;
 }
 // second ordering: the first `sa` import-free rows keep their rank; the others follow in (length descending, imports?, DOF) order
-__global__ void k_row_keys2(int64_t n_int, const int32_t* dof_sorted, int32_t rpw, int32_t sa, const uint8_t* halo, const int32_t* len,
+__global__ void k_row_keys2(int64_t n_int, const int32_t* dof_sorted, const int32_t* wgs, int G, int32_t sa, const uint8_t* halo, const int32_t* len,
                             uint64_t* key) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_int) return;
     const int32_t d = dof_sorted[p];
-    const int64_t g = p / rpw, rank = p - g * rpw;   // the rows of workgroup g are positions [g rpw, (g + 1) rpw) of the first ordering
+    const int64_t g = wg_of_irow(wgs, G, p), rank = p - wgs[g];   // the rows of workgroup g are positions [wgs[g], wgs[g + 1]) of the first ordering
     const bool first = !halo[d] && rank < sa;
     const uint64_t payload = first ? (uint64_t)rank : (((uint64_t)(255 - len[d]) << 33) | ((uint64_t)halo[d] << 32) | (uint32_t)d);
     key[p] = ((uint64_t)g << 42) | ((uint64_t)(first ? 0 : 1) << 41) | payload;
 }
-__global__ void k_assign_slots(int64_t n_int, const int32_t* dof_sorted, int32_t rpw, int32_t sa, int32_t S, const int32_t* wg_noimp, int32_t* slot_of,
+__global__ void k_assign_slots(int64_t n_int, const int32_t* dof_sorted, const int32_t* wgs, int G, int32_t sa, int32_t S, const int32_t* wg_noimp, int32_t* slot_of,
                                int32_t* slot_dof) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_int) return;
     const int32_t d = dof_sorted[p];
-    const int64_t g = p / rpw, i = p - g * rpw;
+    const int64_t g = wg_of_irow(wgs, G, p), i = p - wgs[g];
     const int32_t n_a = min(wg_noimp[g], sa);
     const int32_t slot = i < n_a ? (int32_t)i : sa + (int32_t)(i - n_a);
     slot_of[d] = slot;
@@ -141,11 +168,11 @@ __global__ void k_mark_exports(int64_t n_imp, const uint64_t* imp_key, uint8_t* 
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_imp) is_exp[imp_key[i] & 0xffffffffu] = 1;
 }
-__global__ void k_export_keys(int64_t nd, const uint8_t* is_exp, const int32_t* irow, int32_t rpw, const int32_t* slot_of, uint64_t* key, int32_t* val,
+__global__ void k_export_keys(int64_t nd, const uint8_t* is_exp, const int32_t* wg, const int32_t* slot_of, uint64_t* key, int32_t* val,
                               int32_t* n_out, int32_t* wg_exp) {
     const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= nd || !is_exp[d]) return;
-    const int32_t g = irow[d] / rpw;
+    const int32_t g = wg[d];
     const int32_t o = atomicAdd(n_out, 1);
     key[o] = ((uint64_t)(uint32_t)g << 32) | (uint32_t)slot_of[d];
     val[o] = (int32_t)d;
@@ -193,22 +220,23 @@ __global__ void k_slice_offsets(int G, int nsl, const int32_t* scan, int32_t* sl
     if (t == 0) ell_off[G] = (int64_t)scan[(int64_t)G * nsl] * 128;
 }
 __global__ void k_fill_ell(int64_t n_slots, int32_t S, int nsl, const int32_t* slot_dof, const int32_t* rowptr, const int32_t* colidx, const uint8_t* keep,
-                           const int32_t* irow, int32_t rpw, const int32_t* slot_of, const int32_t* board_of, const int32_t* imp_off,
-                           const int32_t* imp_pos, const int32_t* sl_off, const int64_t* ell_off, uint16_t* code, int32_t* src) {
+                           const int32_t* wg, const int32_t* slot_of, const int32_t* board_of, const int32_t* imp_off,
+                           const int32_t* imp_pos, const int32_t* sl_off, const int64_t* ell_off, int sym, uint16_t* code, int32_t* src) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // g * S + slot
     if (t >= n_slots) return;
     const int32_t d = slot_dof[t];
-    if (d < 0) return;
+    if (d < 0 && !sym) return;
     const int64_t g = t / S;
     const int32_t s = (int32_t)(t - g * S), q = s / 64, l = s % 64;
     const int64_t base = ell_off[g] + (int64_t)sl_off[g * (nsl + 1) + q] * 128 + 2 * l;
     int32_t e = 0;
-    for (int32_t k = rowptr[d]; k < rowptr[d + 1]; ++k) {
+    for (int32_t k = d < 0 ? 0 : rowptr[d]; k < (d < 0 ? 0 : rowptr[d + 1]); ++k) {
         const int32_t c = colidx[k];
         if (!kept_entry(keep, d, c)) continue;
+        if (sym && wg[c] == (int32_t)g && !persist_sym_owner(d, c)) continue;   // stored in row c
         const int64_t at = base + (int64_t)(e / 2) * 128 + (e & 1);
         src[at] = k;
-        if (irow[c] / rpw == (int32_t)g) {
+        if (wg[c] == (int32_t)g) {
             code[at] = (uint16_t)slot_of[c];
         } else {   // position of the column's board entry in this workgroup's import list (sorted by board position)
             int32_t lo = imp_off[g], hi = imp_off[g + 1];
@@ -220,6 +248,10 @@ __global__ void k_fill_ell(int64_t n_slots, int32_t S, int nsl, const int32_t* s
             code[at] = (uint16_t)(S + (lo - imp_off[g]));
         }
         ++e;
+    }
+    if (sym) {   // padding points at the lane's own slot: its (zero) transposed product then meets no other lane's in the accumulator table
+        const int32_t e1 = 2 * (sl_off[g * (nsl + 1) + q + 1] - sl_off[g * (nsl + 1) + q]);
+        for (; e < e1; ++e) code[base + (int64_t)(e / 2) * 128 + (e & 1)] = (uint16_t)s;
     }
 }
 __global__ void k_drop_list(int64_t nd, const uint8_t* keep, const int32_t* irow_scan, int32_t* drop) {
@@ -265,7 +297,8 @@ void dev_persist_release(DevPersist* p) {
 }
 
 int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowptr, const int32_t* d_colidx, const uint8_t* d_bnd, bool use_bnd,
-                             int n_wg, int lds_entries, int blocked_rows, void* stream, PersistLayout& pl, DevPersist* out, std::string& err) {
+                             int n_wg, int lds_entries, int blocked_rows, const int32_t* block_rows, int sym_mode, void* stream, PersistLayout& pl, DevPersist* out,
+                             std::string& err) {
     constexpr int T = kPersistT;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (n_wg < 1 || nd < 1 || max_row > 255) return FDAPDE_EUNSUPPORTED;   // the row keys carry 255 - length in 8 bits
@@ -310,9 +343,34 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
     if (blocked) G = (int)((n_int + blocked_rows - 1) / blocked_rows);
     if (G < 1) G = 1;
     if (G >= (1 << 20)) return FDAPDE_EUNSUPPORTED;   // 20 bits of the row keys
-    const int64_t rpw = (n_int + G - 1) / G;
-    G = (int)((n_int + rpw - 1) / rpw);
-    pl.n_drop = nd - n_int;
+    int64_t rpw = (n_int + G - 1) / G;   // rows of the largest workgroup
+    std::vector<int32_t> h_wgs;           // interior-row boundaries of the workgroups
+    if (block_rows != nullptr && !blocked) {
+        G = n_wg;   // caller-given block sizes (speed-weighted, see capi.hip calibrate_persist); they add up to n_int
+        h_wgs.assign((size_t)G + 1, 0);
+        rpw = 0;
+        for (int g = 0; g < G; ++g) h_wgs[(size_t)g + 1] = h_wgs[(size_t)g] + block_rows[g], rpw = std::max<int64_t>(rpw, block_rows[g]);
+        if (h_wgs[(size_t)G] != n_int) return FDAPDE_EINVAL;
+    } else {
+        G = (int)((n_int + rpw - 1) / rpw);   // trailing workgroups that would stay empty are not launched
+        h_wgs.assign((size_t)G + 1, 0);
+        for (int g = 0; g <= G; ++g) h_wgs[(size_t)g] = (int32_t)std::min<int64_t>(n_int, (int64_t)g * rpw);
+    }
+    Tmp<int32_t> wgs, wg;
+    DP_CHK(wgs.alloc((size_t)G + 1));
+    DP_CHK(wg.alloc((size_t)nd));
+    DP_CHK(hipMemcpyAsync(wgs.p, h_wgs.data(), sizeof(int32_t) * ((size_t)G + 1), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_wg_of, dim3(grid_of(nd)), dim3(256), 0, st, nd, keep.p, irow.p, wgs.p, G, wg.p);
+    int64_t nnz_stored = nnz_kept;
+    const bool sym = !blocked && persist_want_sym(sym_mode, nnz_kept, G, rpw);
+    if (sym) {   // the rows' stored lengths, now that the blocks are known
+        hipLaunchKernelGGL(k_row_lengths_sym, dim3(grid_of(nd)), dim3(256), 0, st, nd, d_rowptr, d_colidx, keep.p, wg.p, len.p);
+        if (int rc = exclusive_sum(sc, len.p, len_scan.p, nd + 1, st, err)) return rc;
+        DP_CHK(hipMemcpyAsync(&h_nnz, len_scan.p + nd, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        DP_CHK(hipStreamSynchronize(st));
+        nnz_stored = h_nnz;
+    }
+    pl.n_drop = nd - n_int, pl.sym = sym;
     if (blocked) {
         DP_CHK(hipMalloc(reinterpret_cast<void**>(&o.drop_dof), sizeof(int32_t) * (size_t)(pl.n_drop ? pl.n_drop : 1)));
         hipLaunchKernelGGL(k_drop_list, dim3(grid_of(nd)), dim3(256), 0, st, nd, keep.p, irow_scan.p, o.drop_dof);
@@ -324,7 +382,7 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
     DP_CHK(wg_cnt.alloc((size_t)3 * G));
     DP_CHK(hipMemsetAsync(wg_cnt.p, 0, sizeof(int32_t) * 3 * (size_t)G, st));
     DP_CHK(hipMemsetAsync(n_imp_row.p + nd, 0, sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_row_halo, dim3(grid_of(nd)), dim3(256), 0, st, nd, d_rowptr, d_colidx, keep.p, irow.p, (int32_t)rpw, halo.p, n_imp_row.p, wg_cnt.p);
+    hipLaunchKernelGGL(k_row_halo, dim3(grid_of(nd)), dim3(256), 0, st, nd, d_rowptr, d_colidx, keep.p, wg.p, halo.p, n_imp_row.p, wg_cnt.p);
     if (int rc = exclusive_sum(sc, n_imp_row.p, imp_at.p, nd + 1, st, err)) return rc;
     int32_t h_pairs = 0;
     std::vector<int32_t> h_cnt(3 * (size_t)G);
@@ -337,7 +395,7 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
     while ((int64_t)R * T < rpw || (!blocked && (int64_t)(R / 2) * T < max_halo)) R *= 2;   // (the blocked SpMV has no import-free phase)
     if (R > kPersistRmax) return FDAPDE_EUNSUPPORTED;
     const int S = R * T, nsl = S / 64, SA = blocked ? S : (R / 2) * T;   // blocked: one class, plain (imports?, length, DOF) order
-    pl.G = G, pl.R = R, pl.nsl = nsl, pl.n_int = n_int, pl.nnz = nnz_kept;
+    pl.G = G, pl.R = R, pl.nsl = nsl, pl.n_int = n_int, pl.nnz = nnz_stored;
     Tmp<uint64_t> imp_key;   // unique (workgroup, DOF) imports, DOF ascending inside a workgroup
     int64_t n_imp = 0;
     {
@@ -347,7 +405,7 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
         DP_CHK(k_s.alloc((size_t)h_pairs));
         DP_CHK(flag.alloc((size_t)h_pairs + 1));
         DP_CHK(pos.alloc((size_t)h_pairs + 1));
-        hipLaunchKernelGGL(k_import_pairs, dim3(grid_of(nd)), dim3(256), 0, st, nd, d_rowptr, d_colidx, keep.p, irow.p, (int32_t)rpw, imp_at.p, k_a.p);
+        hipLaunchKernelGGL(k_import_pairs, dim3(grid_of(nd)), dim3(256), 0, st, nd, d_rowptr, d_colidx, keep.p, wg.p, imp_at.p, k_a.p);
         if (h_pairs > 0) {
             if (int rc = sort_keys(sc, k_a.p, k_s.p, h_pairs, 53, st, err)) return rc;
             DP_CHK(hipMemsetAsync(flag.p + h_pairs, 0, sizeof(int32_t), st));
@@ -375,16 +433,16 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
         DP_CHK(k_s.alloc((size_t)n_int));
         DP_CHK(v_a.alloc((size_t)n_int));
         DP_CHK(v_s.alloc((size_t)n_int));
-        hipLaunchKernelGGL(k_row_keys1, dim3(grid_of(nd)), dim3(256), 0, st, nd, keep.p, irow.p, (int32_t)rpw, halo.p, len.p, k_a.p, v_a.p);
+        hipLaunchKernelGGL(k_row_keys1, dim3(grid_of(nd)), dim3(256), 0, st, nd, keep.p, irow.p, wg.p, halo.p, len.p, k_a.p, v_a.p);
         if (int rc = sort_pairs(sc, k_a.p, k_s.p, v_a.p, v_s.p, n_int, 62, st, err)) return rc;
-        hipLaunchKernelGGL(k_row_keys2, dim3(grid_of(n_int)), dim3(256), 0, st, n_int, v_s.p, (int32_t)rpw, (int32_t)SA, halo.p, len.p, k_a.p);
+        hipLaunchKernelGGL(k_row_keys2, dim3(grid_of(n_int)), dim3(256), 0, st, n_int, v_s.p, wgs.p, G, (int32_t)SA, halo.p, len.p, k_a.p);
         if (int rc = sort_pairs(sc, k_a.p, k_s.p, v_s.p, dof1.p, n_int, 63, st, err)) return rc;
         std::vector<int32_t> h_noimp((size_t)G);
         for (int g = 0; g < G; ++g)   // blocked: one class -- every row counts as "fits the first class", so that slot = position
-            h_noimp[(size_t)g] = (int32_t)(std::min<int64_t>(n_int, (int64_t)(g + 1) * rpw) - (int64_t)g * rpw) - (blocked ? 0 : h_cnt[(size_t)g]);
+            h_noimp[(size_t)g] = (h_wgs[(size_t)g + 1] - h_wgs[(size_t)g]) - (blocked ? 0 : h_cnt[(size_t)g]);
         DP_CHK(wg_noimp.alloc((size_t)G));
         DP_CHK(hipMemcpyAsync(wg_noimp.p, h_noimp.data(), sizeof(int32_t) * (size_t)G, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_assign_slots, dim3(grid_of(n_int)), dim3(256), 0, st, n_int, dof1.p, (int32_t)rpw, (int32_t)SA, (int32_t)S, wg_noimp.p, slot_of.p,
+        hipLaunchKernelGGL(k_assign_slots, dim3(grid_of(n_int)), dim3(256), 0, st, n_int, dof1.p, wgs.p, G, (int32_t)SA, (int32_t)S, wg_noimp.p, slot_of.p,
                            o.slot_dof);
         DP_CHK(hipStreamSynchronize(st));
     }
@@ -405,7 +463,7 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
         DP_CHK(v_s.alloc((size_t)cap));
         DP_CHK(cnt.alloc(1));
         DP_CHK(hipMemsetAsync(cnt.p, 0, sizeof(int32_t), st));
-        hipLaunchKernelGGL(k_export_keys, dim3(grid_of(nd)), dim3(256), 0, st, nd, is_exp.p, irow.p, (int32_t)rpw, slot_of.p, k_a.p, v_a.p, cnt.p, wg_cnt.p + G);
+        hipLaunchKernelGGL(k_export_keys, dim3(grid_of(nd)), dim3(256), 0, st, nd, is_exp.p, wg.p, slot_of.p, k_a.p, v_a.p, cnt.p, wg_cnt.p + G);
         int32_t h_nb = 0;
         DP_CHK(hipMemcpyAsync(&h_nb, cnt.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         DP_CHK(hipStreamSynchronize(st));
@@ -471,8 +529,8 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
     DP_CHK(hipMalloc(reinterpret_cast<void**>(&o.ell_src), sizeof(int32_t) * n_alloc));
     DP_CHK(hipMemsetAsync(o.ell_code, 0, sizeof(uint16_t) * n_alloc, st));
     DP_CHK(hipMemsetAsync(o.ell_src, 0xff, sizeof(int32_t) * n_alloc, st));
-    hipLaunchKernelGGL(k_fill_ell, dim3(grid_of((int64_t)G * S)), dim3(256), 0, st, (int64_t)G * S, (int32_t)S, nsl, o.slot_dof, d_rowptr, d_colidx, keep.p, irow.p,
-                       (int32_t)rpw, slot_of.p, blocked ? (const int32_t*)nullptr : board_of.p, o.imp_off, o.imp_pos, o.sl_off, o.ell_off, o.ell_code, o.ell_src);
+    hipLaunchKernelGGL(k_fill_ell, dim3(grid_of((int64_t)G * S)), dim3(256), 0, st, (int64_t)G * S, (int32_t)S, nsl, o.slot_dof, d_rowptr, d_colidx, keep.p, wg.p,
+                       slot_of.p, blocked ? (const int32_t*)nullptr : board_of.p, o.imp_off, o.imp_pos, o.sl_off, o.ell_off, sym ? 1 : 0, o.ell_code, o.ell_src);
     DP_CHK(hipGetLastError());
     DP_CHK(hipStreamSynchronize(st));
     guard.armed = false;

@@ -33,7 +33,7 @@ template <typename F> void for_each_wg(int G, F&& fn) {
 
 }  // namespace
 
-int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int lds_entries, PersistLayout& pl) {
+int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int lds_entries, PersistLayout& pl, const int32_t* block_rows, int sym_mode) {
     constexpr int T = kPersistT;
     const int64_t nd = hs.n_dofs;
     if (n_wg < 1 || nd < 1) return FDAPDE_EUNSUPPORTED;
@@ -57,10 +57,23 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
     if (lds_entries > 0) want = std::max<int64_t>(want, (nnz_kept + nnz_kept / 16 + lds_entries - 1) / lds_entries);
     int G = (int)std::min<int64_t>(n_wg, want);
     if (G < 1) G = 1;
-    const int64_t rpw = (n_int + G - 1) / G;
-    G = (int)((n_int + rpw - 1) / rpw);   // trailing workgroups that would stay empty are not launched
+    int64_t rpw = (n_int + G - 1) / G;   // rows of the largest workgroup
+    std::vector<int64_t> wgs;             // interior-row boundaries of the workgroups
+    if (block_rows != nullptr) {
+        G = n_wg;                         // caller-given block sizes (speed-weighted); they add up to n_int
+        wgs.assign((size_t)G + 1, 0);
+        rpw = 0;
+        for (int g = 0; g < G; ++g) wgs[(size_t)g + 1] = wgs[(size_t)g] + block_rows[g], rpw = std::max<int64_t>(rpw, block_rows[g]);
+        if (wgs[(size_t)G] != n_int) return FDAPDE_EINVAL;
+    } else {
+        G = (int)((n_int + rpw - 1) / rpw);   // trailing workgroups that would stay empty are not launched
+        wgs.assign((size_t)G + 1, 0);
+        for (int g = 0; g <= G; ++g) wgs[(size_t)g] = std::min<int64_t>(n_int, (int64_t)g * rpw);
+    }
+    const bool sym = persist_want_sym(sym_mode, nnz_kept, G, rpw);
     std::vector<int32_t> wg_of((size_t)nd, -1), slot_of((size_t)nd, -1);
-    for (int64_t i = 0; i < n_int; ++i) wg_of[(size_t)irow_dof[(size_t)i]] = (int32_t)(i / rpw);
+    for (int g = 0; g < G; ++g)
+        for (int64_t i = wgs[(size_t)g]; i < wgs[(size_t)g + 1]; ++i) wg_of[(size_t)irow_dof[(size_t)i]] = g;
 
     // ---- rows of a workgroup: (references another workgroup, length, DOF) + its import list
     struct Key { int32_t halo, len, dof; };
@@ -68,7 +81,7 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
     std::vector<std::vector<int32_t>> imports((size_t)G);   // DOFs of other workgroups a workgroup reads, unique
     std::vector<int32_t> row_len((size_t)nd, 0), n_halo((size_t)G, 0);
     for_each_wg(G, [&](int g) {
-        const int64_t i0 = (int64_t)g * rpw, i1 = std::min<int64_t>(n_int, i0 + rpw);
+        const int64_t i0 = wgs[(size_t)g], i1 = wgs[(size_t)g + 1];
         std::vector<Key>& rows = wg_rows[(size_t)g];
         rows.reserve((size_t)(i1 - i0));
         std::vector<int32_t>& imp = imports[(size_t)g];
@@ -78,6 +91,7 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
             for (int32_t k = hs.rowptr_i[(size_t)d]; k < hs.rowptr_i[(size_t)d + 1]; ++k) {
                 const int32_t c = hs.colidx_i[(size_t)k];
                 if (!kept(d, c)) continue;
+                if (sym && wg_of[(size_t)c] == g && !persist_sym_owner(d, c)) continue;   // stored in row c
                 ++len;
                 if (wg_of[(size_t)c] != g) halo = 1, imp.push_back(c);
             }
@@ -95,7 +109,7 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
     while ((int64_t)R * T < rpw || (int64_t)(R / 2) * T < max_halo) R *= 2;
     if (R > kPersistRmax) return FDAPDE_EUNSUPPORTED;
     const int S = R * T, nsl = S / 64, SA = (R / 2) * T;
-    pl.G = G, pl.R = R, pl.nsl = nsl, pl.n_int = n_int;
+    pl.G = G, pl.R = R, pl.nsl = nsl, pl.n_int = n_int, pl.sym = sym;
 
     // ---- slots: [0, SA) rows without imports, longest first (as many as fit); [SA, S) all other rows, longest first
     pl.slot_dof.assign((size_t)G * S, -1);
@@ -193,17 +207,22 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
         int64_t nz = 0;
         for (int s = 0; s < S; ++s) {
             const int32_t d = pl.slot_dof[(size_t)g * S + s];
-            if (d < 0) continue;
+            if (d < 0 && !sym) continue;
             const int q = s / 64, l = s % 64;
             const int64_t base = pl.ell_off[(size_t)g] + (int64_t)pl.sl_off[(size_t)g * (nsl + 1) + q] * 128 + 2 * l;
             int32_t e = 0;
-            for (int32_t k = hs.rowptr_i[(size_t)d]; k < hs.rowptr_i[(size_t)d + 1]; ++k) {
+            for (int32_t k = d < 0 ? 0 : hs.rowptr_i[(size_t)d]; k < (d < 0 ? 0 : hs.rowptr_i[(size_t)d + 1]); ++k) {
                 const int32_t c = hs.colidx_i[(size_t)k];
                 if (!kept(d, c)) continue;
+                if (sym && wg_of[(size_t)c] == g && !persist_sym_owner(d, c)) continue;
                 const int64_t at = base + (int64_t)(e / 2) * 128 + (e & 1);
                 pl.ell_src[(size_t)at] = k;
                 pl.ell_code[(size_t)at] = (uint16_t)(wg_of[(size_t)c] == g ? slot_of[(size_t)c] : S + import_index(c));
                 ++e, ++nz;
+            }
+            if (sym) {   // padding points at the lane's own slot: its (zero) transposed product meets no other lane's in the accumulator table
+                const int32_t e1 = 2 * (pl.sl_off[(size_t)g * (nsl + 1) + q + 1] - pl.sl_off[(size_t)g * (nsl + 1) + q]);
+                for (; e < e1; ++e) pl.ell_code[(size_t)(base + (int64_t)(e / 2) * 128 + (e & 1))] = (uint16_t)s;
             }
         }
         nnz_wg[(size_t)g] = nz;

@@ -139,7 +139,27 @@ void host_build_slot_map(const HostSpace& hs, const int32_t* list, int64_t n, st
 //      threads own the rows, plus the lists of vector entries workgroups exchange every iteration.
 constexpr int kPersistT = 512;        // threads per workgroup
 constexpr int kPersistRmax = 16;      // rows per thread at most
+// Symmetric storage (PersistLayout::sym): an off-diagonal pair (i, j) whose rows both lie in one workgroup's block is stored ONCE, in
+// the row this rule names (a hash bit, so that every row keeps about half of its in-block entries); the kernel applies it to both
+// rows.  Entries whose column belongs to another workgroup stay in both rows.
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline bool persist_sym_owner(int32_t row, int32_t col) {
+    const uint32_t lo = (uint32_t)(row < col ? row : col), hi = (uint32_t)(row < col ? col : row);
+    const bool low_owns = ((((lo * 2654435761u) ^ (hi * 2246822519u)) >> 16) & 1u) != 0;
+    return (low_owns ? lo : hi) == (uint32_t)row;
+}
+// sym_mode of the layout builders: 0 plain, 1 symmetric, 2 symmetric where it pays: the plain blocks would not fit the LDS (estimate)
+// AND a workgroup owns more than 2048 rows (8 or 16 rows per thread).  Measured on MI355X (tools/persist_sym_ab.py, us per iteration,
+// plain -> symmetric): 3-D P1 439 k rows 15.8 -> 17.6, 754 k 22.2 -> 22.0, 1.19 M 31.2 -> 28.8, 1.73 M 43.1 -> 36.9; 2-D P1 1.0 M
+// 14.3 -> 13.2, 1.96 M 22.9 -> 20.2; resident systems lose 25-30 % (an entry costs ~25 instructions and an LDS atomic instead of a
+// multiply-add: it only pays against bytes that would otherwise stream).
+inline bool persist_want_sym(int sym_mode, int64_t nnz_kept, int G, int64_t rows_per_wg) {
+    return sym_mode == 1 || (sym_mode == 2 && rows_per_wg > 2048 && 10.6 * (double)nnz_kept / (double)G + 16.0 * (double)rows_per_wg > 150e3);
+}
 struct PersistLayout {
+    bool sym = false;                 // in-block pairs stored once (persist_sym_owner)
     int G = 0, R = 0, nsl = 0;        // workgroups; rows per thread (2, 4, 8, 16); slices of 64 slots per workgroup = R * T / 64.
                                       // Slots [0, T R / 2): rows that import nothing; [T R / 2, T R): the others
     int64_t n_int = 0;                // interior (non-Dirichlet) rows
@@ -164,7 +184,8 @@ struct PersistLayout {
 // enough workgroups for every block to be resident where the device has that many (3-D rows: 14 entries each, so ~850 rows per
 // workgroup instead of 2048).  Returns FDAPDE_EUNSUPPORTED when the system does not fit the layout (more than n_wg * T * Rmax interior
 // rows, rows or lists too long for the 16-bit codes).
-int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int lds_entries, PersistLayout& pl);
+int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int lds_entries, PersistLayout& pl, const int32_t* block_rows = nullptr,
+                              int sym_mode = 0);
 
 }  // namespace fdapde_hip
 #endif

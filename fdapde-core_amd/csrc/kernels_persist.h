@@ -41,6 +41,8 @@ struct PersistArgs {
     const int32_t* imp_pos;
     unsigned long long* pboard;   // 2 granules per exported entry
     unsigned long long* dboard;   // [parity][workgroup][3 values][2 granules]
+    const unsigned long long* amax_bits;   // symmetric storage: bit pattern of max |stored value| (k_persist_fill)
+    int32_t max_len;                       // symmetric storage: a row receives at most this many transposed products
     const double* r_in;           // initial residual (= initial direction), internal DOF order
     double* x;                    // in: initial guess, out: solution (scaled unknowns), internal DOF order
     double* sc;                   // sc[0] = reference norm^2 (in); sc[3] = final r.r (out)
@@ -60,6 +62,7 @@ __device__ __forceinline__ unsigned long long granule_load(const unsigned long l
 }
 // both granules of a published double with ONE 16-byte sc1 load (each aligned 8-byte half is a granule of its own; a half is never torn)
 typedef unsigned long long pg_v2u64 __attribute__((ext_vector_type(2)));
+typedef unsigned int pg_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ pg_v2u64 granule_load2(const unsigned long long* p) {
     pg_v2u64 v;
     asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
@@ -96,27 +99,56 @@ constexpr long long kPersistTimeoutTicks = 5000000;   // 50 ms of s_memrealtime 
 //                 nothing else -- the multi-launch path moves 7 vector passes on top.  All R / 2 value loads of an entry step are
 //                 issued before the first is used (unconditional loads, clamped to the slice: narrower slices re-read their last
 //                 pair row, which multiplies by zero).
-template <int R, bool STREAM>
+// SYM = true   : symmetric storage (internal.h persist_sym_owner): a pair of rows of this block is stored once and applied to both
+//                 rows.  The row that stores it adds a p[col] to its own sum (registers, as ever) and hands a p[row] to row col through
+//                 a table of 64-bit FIXED-POINT accumulators in LDS (ds_add_u64): integer addition is associative, so the sums -- and
+//                 everything downstream -- are bitwise reproducible whatever order the wavefronts arrive in, which fp64 atomics would
+//                 not give.  The scale is a power of two chosen per iteration from the block's own max |p|, max |a| and the longest
+//                 row, so that no partial sum can reach 2^62: the transposed sums carry an ABSOLUTE error below
+//                 (products) x 2^-56 x max_len x max|a| x max_block |p| -- finer than fp64's own rounding of the largest products.
+//                 The import / export lists are read from global memory (L2) instead of LDS: the table takes their room.
+template <int R, bool STREAM, bool SYM>
 __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
     constexpr int T = kPersistT, W = T / 64, S = R * T, RI = R / 2;
     extern __shared__ double lds[];
     __shared__ double red[W][3];
     __shared__ double tot[3];
+    __shared__ double pmax_w[W];
     __shared__ int32_t fail_flag;
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nsl = a.nsl;
     const int H = a.imp_off[g + 1] - a.imp_off[g], E = a.exp_off[g + 1] - a.exp_off[g];
     double* p_tab = lds;                                                                  // [S + imp_cap]
-    double2* ev = reinterpret_cast<double2*>(p_tab + (S + a.imp_cap));                    // [lds_cap / 2] entry pairs (resident form)
+    long long* y_tab = reinterpret_cast<long long*>(p_tab + (S + a.imp_cap));             // [S] transposed sums, fixed point (SYM)
+    double2* ev = reinterpret_cast<double2*>(y_tab + (SYM ? S : 0));                      // [lds_cap / 2] entry pairs (resident form)
     uint32_t* ec = reinterpret_cast<uint32_t*>(ev + a.lds_cap / 2);                       // [lds_cap / 2] code pairs
-    int32_t* impl = reinterpret_cast<int32_t*>(ec + a.lds_cap / 2);                       // [imp_cap]
-    uint16_t* expl = reinterpret_cast<uint16_t*>(impl + a.imp_cap);                       // [E]
+    int32_t* impl_l = reinterpret_cast<int32_t*>(ec + a.lds_cap / 2);                     // [imp_cap]   (not SYM)
+    uint16_t* expl_l = reinterpret_cast<uint16_t*>(impl_l + a.imp_cap);                   // [E]         (not SYM)
     const int64_t e0 = a.ell_off[g];
     const double2* gv = reinterpret_cast<const double2*>(a.ell_val + e0);
     const uint32_t* gc = reinterpret_cast<const uint32_t*>(a.ell_code + e0);
+    // streaming form: the block is read through raw buffer loads (descriptor in scalar registers: base = this workgroup's block)
+    // (records end with the arrays -- all blocks + 256 entries of slack: a touch past the last block reads 0 instead of faulting)
+    const int64_t e_left = a.ell_off[a.G] + 256 - e0;
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2*>(gv), 0, (int)min(e_left * 8, (int64_t)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(gc), 0, (int)min(e_left * 2, (int64_t)0x7fffffff), 0x00020000);
+    const int lane16 = lane * 16, lane4 = lane * 4;
     // ---- stage the workgroup's tables (and, resident form, its block of the matrix)
-    for (int i = tid; i < H; i += T) impl[i] = a.imp_pos[a.imp_off[g] + i];
-    for (int i = tid; i < E; i += T) expl[i] = a.exp_slot[a.exp_off[g] + i];
+    const int32_t* impl = SYM ? a.imp_pos + a.imp_off[g] : impl_l;
+    const uint16_t* expl = SYM ? a.exp_slot + a.exp_off[g] : expl_l;
+    if constexpr (!SYM) {
+        for (int i = tid; i < H; i += T) impl_l[i] = a.imp_pos[a.imp_off[g] + i];
+        for (int i = tid; i < E; i += T) expl_l[i] = a.exp_slot[a.exp_off[g] + i];
+    } else {
+#pragma unroll
+        for (int j = 0; j < R; ++j) y_tab[j * T + tid] = 0;
+    }
+    // symmetric storage: exponent of the bound on (longest row) x max |a| (the values are in place when the solve is launched)
+    int bexp = 0;
+    if constexpr (SYM) {
+        const double amax = __longlong_as_double((long long)*a.amax_bits);
+        bexp = amax > 0.0 && amax < 1.7e308 ? ilogb(amax * (double)a.max_len) + 1 : 0;
+    }
     if (tid == 0) fail_flag = 0;
     const int32_t* slo = a.sl_off + (size_t)g * (nsl + 1);
     if constexpr (!STREAM) {
@@ -130,17 +162,23 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
         o0[j] = __builtin_amdgcn_readfirstlane(slo[j * W + wave]);
         w[j] = __builtin_amdgcn_readfirstlane(slo[j * W + wave + 1]) - o0[j];
     }
-    // ---- the rows of this thread: slot j * T + tid, j < R
-    double xv[R], rv[R], pv[R];
-    int32_t dof[R];
+    // ---- the rows of this thread: slot j * T + tid, j < R.  SYM: p of the own rows lives in its LDS table only and the DOF ids are
+    //      re-read at the end (the registers go to the transposed products)
+    double xv[R], rv[R], pv[SYM ? 1 : R];
+    int32_t dof[SYM ? 1 : R];
     double rr_part = 0;
+    auto P = [&](int j) -> double {
+        if constexpr (SYM) return p_tab[j * T + tid];
+        else return pv[j];
+    };
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        dof[j] = a.slot_dof[(size_t)g * S + j * T + tid];
-        const bool on = dof[j] >= 0;
-        rv[j] = on ? a.r_in[dof[j]] : 0.0;
-        xv[j] = on ? a.x[dof[j]] : 0.0;
-        pv[j] = rv[j];
+        const int32_t d = a.slot_dof[(size_t)g * S + j * T + tid];
+        const bool on = d >= 0;
+        rv[j] = on ? a.r_in[d] : 0.0;
+        xv[j] = on ? a.x[d] : 0.0;
+        if constexpr (SYM) p_tab[j * T + tid] = rv[j];
+        else pv[j] = rv[j], dof[j] = d;
         rr_part += rv[j] * rv[j];
     }
     const double bb = a.sc[0];
@@ -154,33 +192,101 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
         long long c0 = 0, c1 = 0, c2 = 0;
         if (stamper) c0 = wall_clock64();
         // ---- p of the own rows into the LDS table; exported entries onto the board
+        if constexpr (!SYM) {
 #pragma unroll
-        for (int j = 0; j < R; ++j) p_tab[j * T + tid] = pv[j];
+            for (int j = 0; j < R; ++j) p_tab[j * T + tid] = pv[j];
+        }
+        double tscale = 0, tinv = 0;   // fixed-point scale of the transposed sums and its inverse (powers of two)
+        if constexpr (SYM) {
+            double m = 0;
+#pragma unroll
+            for (int j = 0; j < R; ++j) m = fmax(m, fabs(P(j)));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+            if (lane == 0) pmax_w[wave] = m;
+        }
         __syncthreads();
+        if constexpr (SYM) {
+            double m = 0;
+#pragma unroll
+            for (int ww = 0; ww < W; ++ww) m = fmax(m, pmax_w[ww]);
+            // |sum| <= max_len max|a| max|p| < 2^(bexp + ilogb(m) + 1): scaled below 2^62
+            const int ex = m > 0.0 && m < 1.7e308 ? 61 - bexp - ilogb(m) : 0;
+            tscale = ldexp(1.0, ex), tinv = ldexp(1.0, -ex);
+        }
         for (int i = tid; i < E; i += T) publish_f64(a.pboard + 2 * (size_t)(a.exp_off[g] + i), epoch, p_tab[expl[i]]);
         // ---- y = (I + At_offdiag) p: the passes without imports first, the others once the neighbours' entries have arrived
         double yv[R];
 #pragma unroll
-        for (int j = 0; j < R; ++j) yv[j] = pv[j];   // unit diagonal of the scaled system
+        for (int j = 0; j < R; ++j) yv[j] = P(j);   // unit diagonal of the scaled system
         auto product = [&](auto phase) {
-            constexpr int J0 = decltype(phase)::value ? RI : 0, J1 = decltype(phase)::value ? R : RI;
-            int mw = 0;
+            constexpr int J0 = decltype(phase)::value ? RI : 0, J1 = decltype(phase)::value ? R : RI, NJ = J1 - J0;
+            int mw = 0;   // widest slice of the phase
 #pragma unroll
             for (int j = J0; j < J1; ++j) mw = max(mw, w[j]);
-            for (int e = 0; e < mw; ++e) {
-                double2 v[J1 - J0];
-                uint32_t c[J1 - J0];
+            if constexpr (!SYM) {
+                for (int e = 0; e < mw; ++e) {
+                    double2 v[NJ];
+                    uint32_t c[NJ];
 #pragma unroll
-                for (int j = J0; j < J1; ++j) {
-                    const int ee = min(e, max(w[j] - 1, 0));
-                    const int idx = (o0[j] + ee) * 64 + lane;
-                    if constexpr (STREAM) v[j - J0] = gv[idx], c[j - J0] = gc[idx];
-                    else v[j - J0] = ev[idx], c[j - J0] = ec[idx];
+                    for (int j = J0; j < J1; ++j) {
+                        const int ee = min(e, max(w[j] - 1, 0));
+                        const int idx = (o0[j] + ee) * 64 + lane;
+                        if constexpr (STREAM) v[j - J0] = gv[idx], c[j - J0] = gc[idx];
+                        else v[j - J0] = ev[idx], c[j - J0] = ec[idx];
+                    }
+#pragma unroll
+                    for (int j = J0; j < J1; ++j) {
+                        const double t = v[j - J0].x * p_tab[c[j - J0] & 0xffffu] + v[j - J0].y * p_tab[c[j - J0] >> 16];
+                        yv[j] += e < w[j] ? t : 0.0;
+                    }
                 }
+            } else {
+                // pair row e of the passes [jg, jg + GS).  The rows of a workgroup are sorted by length, so the passes of a phase differ in
+                // width: a pass that has run out of entries is SKIPPED (wave-uniform branch) -- unlike the plain form, where re-reading its
+                // last pair row and leaving it out of the sum costs a multiply-add, here an entry is ~25 instructions and an LDS atomic
+                auto load = [&](auto& v, auto& c, int jg, int e) {
+                    constexpr int GS = sizeof(c) / sizeof(c[0]);
 #pragma unroll
-                for (int j = J0; j < J1; ++j) {
-                    const double t = v[j - J0].x * p_tab[c[j - J0] & 0xffffu] + v[j - J0].y * p_tab[c[j - J0] >> 16];
-                    yv[j] += e < w[j] ? t : 0.0;
+                    for (int j = jg; j < jg + GS; ++j) {
+                        if (e < w[j]) {
+                            const int row = o0[j] + e;
+                            if constexpr (STREAM) {
+                                v[j - jg] = __builtin_amdgcn_raw_buffer_load_b128(rs_v, lane16, row * 1024, 0);
+                                c[j - jg] = __builtin_amdgcn_raw_buffer_load_b32(rs_c, lane4, row * 256, 0);
+                            } else v[j - jg] = reinterpret_cast<const pg_u32x4*>(ev)[row * 64 + lane], c[j - jg] = ec[row * 64 + lane];
+                        }
+                    }
+                };
+                // the entries of `load`, applied to their own rows (registers) and to the rows of their columns (accumulator table)
+                auto compute = [&](const auto& v, const auto& c, int jg, int e) {
+                    constexpr int GS = sizeof(c) / sizeof(c[0]);
+#pragma unroll
+                    for (int j = jg; j < jg + GS; ++j) {
+                        if (e < w[j]) {
+                            const unsigned c_lo = c[j - jg] & 0xffffu, c_hi = c[j - jg] >> 16;
+                            const double vx = __hiloint2double((int)v[j - jg].y, (int)v[j - jg].x), vy = __hiloint2double((int)v[j - jg].w, (int)v[j - jg].z);
+                            yv[j] += vx * p_tab[c_lo] + vy * p_tab[c_hi];
+                            const double ps = P(j) * tscale;
+                            const long long q_lo = (long long)(vx * ps), q_hi = (long long)(vy * ps);
+                            // branch-free: what has no target here (a column of another workgroup) adds 0 to the lane's own slot, where it meets
+                            // no other lane's (padding: value 0, column = own slot).  Measured against lanes skipping their add: 36.9 vs 38.0 us
+                            const bool t_lo = c_lo < (unsigned)S, t_hi = c_hi < (unsigned)S;
+                            __hip_atomic_fetch_add(&y_tab[t_lo ? c_lo : (unsigned)(j * T + tid)], t_lo ? q_lo : 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_add(&y_tab[t_hi ? c_hi : (unsigned)(j * T + tid)], t_hi ? q_hi : 0ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                };
+                // all passes of the phase loaded, then multiplied.  Measured and dropped (C3, us per iteration; this form 36.9): two groups of
+                // passes software-pipelined by hand 38.5; the same with a third buffer and x moved to global fp64 atomics to make room 67;
+                // one lane per 128-byte line touching the lines of the group after next 58 (loads return in order: a touch that misses holds
+                // up the real loads behind it); re-reading the last pair row of a finished pass and multiplying by 0, as the plain form does,
+                // instead of skipping the pass 43; the magic-number conversion below instead of the compiler's fptosi 37.5
+                for (int e = 0; e < mw; ++e) {
+                    pg_u32x4 v[NJ];
+                    uint32_t c[NJ];
+                    load(v, c, J0, e);
+                    compute(v, c, J0, e);
                 }
             }
         };
@@ -217,11 +323,19 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
             break;
         }
         product(std::integral_constant<int, 1>{});
+        if constexpr (SYM) {   // collect the transposed sums of the own rows; the table is zero again for the next iteration
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                yv[j] += (double)y_tab[j * T + tid] * tinv;
+                y_tab[j * T + tid] = 0;
+            }
+        }
         if (stamper) c1 = wall_clock64();
         // ---- partials of p.y, y.y and of the explicit r.r; one all-gather over the workgroups
         double s0 = 0, s1 = 0;
 #pragma unroll
-        for (int j = 0; j < R; ++j) s0 += pv[j] * yv[j], s1 += yv[j] * yv[j];
+        for (int j = 0; j < R; ++j) s0 += P(j) * yv[j], s1 += yv[j] * yv[j];
         s0 = wave_sum64(s0), s1 = wave_sum64(s1);
         const double s2 = wave_sum64(rr_part);
         if (lane == 0) red[wave][0] = s0, red[wave][1] = s1, red[wave][2] = s2;
@@ -306,9 +420,11 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
         rr_part = 0;
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-            xv[j] += alpha * pv[j];
+            const double pj = P(j);
+            xv[j] += alpha * pj;
             rv[j] -= alpha * yv[j];
-            pv[j] = rv[j] + beta * pv[j];
+            if constexpr (SYM) p_tab[j * T + tid] = rv[j] + beta * pj;   // (every read of this iteration's table lies behind a barrier)
+            else pv[j] = rv[j] + beta * pj;
             rr_part += rv[j] * rv[j];
         }
         ++it;
@@ -319,8 +435,12 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
     }
     if (status != 3) {
 #pragma unroll
-        for (int j = 0; j < R; ++j)
-            if (dof[j] >= 0) a.x[dof[j]] = xv[j];
+        for (int j = 0; j < R; ++j) {
+            int32_t d;
+            if constexpr (SYM) d = a.slot_dof[(size_t)g * S + j * T + tid];
+            else d = dof[j];
+            if (d >= 0) a.x[d] = xv[j];
+        }
     }
     if (g == 0 && tid == 0) {
         a.sc[3] = rr;
@@ -371,6 +491,12 @@ __global__ __launch_bounds__(kPersistT) void k_spmv_blocked(BlockedSpmvArgs a) {
     const int64_t e0 = a.ell_off[g];
     const double2* gv = reinterpret_cast<const double2*>(a.ell_val + e0);
     const uint32_t* gc = reinterpret_cast<const uint32_t*>(a.ell_code + e0);
+    // streaming form: the block is read through raw buffer loads (descriptor in scalar registers: base = this workgroup's block)
+    // (records end with the arrays -- all blocks + 256 entries of slack: a touch past the last block reads 0 instead of faulting)
+    const int64_t e_left = a.ell_off[a.G] + 256 - e0;
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2*>(gv), 0, (int)min(e_left * 8, (int64_t)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(gc), 0, (int)min(e_left * 2, (int64_t)0x7fffffff), 0x00020000);
+    const int lane16 = lane * 16, lane4 = lane * 4;
     const int32_t* slo = a.sl_off + (size_t)g * (nsl + 1);
     int o0[R], w[R];
 #pragma unroll
@@ -446,9 +572,20 @@ __global__ __launch_bounds__(kPersistT) void k_spmv_blocked(BlockedSpmvArgs a) {
 }
 
 // ell_val[e] = scaled full-pattern value the entry maps to, 0 in padding
-__global__ __launch_bounds__(256) void k_persist_fill(int64_t n, const int32_t* src, const double* scaled_full, double* out) {
+// amax_bits != nullptr (zeroed by the caller): also max |value| as a bit pattern (non-negative doubles order like their bits)
+__global__ __launch_bounds__(256) void k_persist_fill(int64_t n, const int32_t* src, const double* scaled_full, double* out,
+                                                      unsigned long long* amax_bits) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = src[i] >= 0 ? scaled_full[src[i]] : 0.0;
+    double v = 0.0;
+    if (i < n) out[i] = v = src[i] >= 0 ? scaled_full[src[i]] : 0.0;
+    if (amax_bits != nullptr) {
+        double m = fabs(v);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
+        // most wavefronts find a maximum at least as large already in place and skip the atomic
+        if ((threadIdx.x & 63) == 0 && bits > __hip_atomic_load(amax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax_bits, bits);
+    }
 }
 
 }  // namespace fdapde_hip

@@ -55,14 +55,31 @@ static void grid_mesh(int dim, int nx, std::vector<double>& nodes, std::vector<i
 // The persistent CG's resident layout (host_persist.cpp), checked by running its operator application on the CPU exactly as
 // k_cg_persist does -- own entries from the slot table, imported entries through the board, sliced ELL with 16-bit codes -- against
 // the CSR product on the interior block.  Returns the number of workgroups of the layout (0: system does not qualify), -1 on error.
-static int check_persist(const HostSpace& hs, bool use_bnd, int n_wg) {
+// sym: symmetric storage (in-block pairs stored once, applied to both rows); uneven: workgroups of unequal row counts
+static int check_persist(const HostSpace& hs, bool use_bnd, int n_wg, bool sym = false, bool uneven = false) {
     PersistLayout pl;
-    const int rc = host_build_persist_layout(hs, use_bnd, n_wg, 12000, pl);
+    int rc = host_build_persist_layout(hs, use_bnd, n_wg, 12000, pl, nullptr, sym ? 1 : 0);
     if (rc == FDAPDE_EUNSUPPORTED) return 0;
     if (rc) return -1;
+    if (uneven && pl.G >= 2) {   // same number of workgroups, rows moved from the even to the odd ones
+        std::vector<int32_t> rows((size_t)pl.G);
+        const int64_t each = pl.n_int / pl.G;
+        int64_t left = pl.n_int;
+        for (int g = 0; g < pl.G; ++g) {
+            int64_t r = g + 1 == pl.G ? left : std::max<int64_t>(1, (g & 1) ? each + each / 10 : each - each / 10);
+            r = std::min<int64_t>(r, left - (pl.G - 1 - g));
+            rows[(size_t)g] = (int32_t)r, left -= r;
+        }
+        const int G = pl.G;
+        pl = PersistLayout{};
+        rc = host_build_persist_layout(hs, use_bnd, G, 12000, pl, rows.data(), sym ? 1 : 0);
+        if (rc == FDAPDE_EUNSUPPORTED) return 0;
+        if (rc || pl.G != G) return -1;
+    }
+    if (pl.sym != sym) return -1;
     const int T = kPersistT, S = pl.R * T, nsl = pl.nsl;
     auto dropped = [&](int64_t d) { return use_bnd && hs.dof_bnd_i[(size_t)d]; };
-    auto val = [](int64_t k) { return 1.0 + 0.25 * (double)(k % 7); };
+    auto val = [](int64_t row, int64_t col) { return 1.0 + 0.25 * (double)((row + col) % 7); };   // symmetric
     std::vector<double> p((size_t)hs.n_dofs), yref((size_t)hs.n_dofs, 0.0), y((size_t)hs.n_dofs, 0.0);
     for (int64_t d = 0; d < hs.n_dofs; ++d) p[(size_t)d] = dropped(d) ? 0.0 : std::sin(0.37 * (double)d) + 1.5;
     int64_t kept = 0, rows = 0;
@@ -73,11 +90,11 @@ static int check_persist(const HostSpace& hs, bool use_bnd, int n_wg) {
         for (int32_t k = hs.rowptr_i[(size_t)d]; k < hs.rowptr_i[(size_t)d + 1]; ++k) {
             const int32_t c = hs.colidx_i[(size_t)k];
             if (c == d || dropped(c)) continue;
-            acc += val(k) * p[(size_t)c], ++kept;
+            acc += val(d, c) * p[(size_t)c], ++kept;
         }
         yref[(size_t)d] = acc;
     }
-    if (rows != pl.n_int || kept != pl.nnz) return -1;
+    if (rows != pl.n_int || (sym ? pl.nnz > kept || 2 * pl.nnz < kept : kept != pl.nnz)) return -1;
     std::vector<double> board((size_t)pl.n_board, -1e300);
     std::vector<uint8_t> seen((size_t)hs.n_dofs, 0);
     for (int g = 0; g < pl.G; ++g)   // every workgroup publishes its exported entries
@@ -100,16 +117,28 @@ static int check_persist(const HostSpace& hs, bool use_bnd, int n_wg) {
                 const int s = q * 64 + l;
                 const int32_t d = pl.slot_dof[(size_t)g * S + s];
                 double acc = tab[(size_t)s];
+                if (d < 0 && slo[q + 1] > slo[q]) {   // an empty slot holds no entries
+                    for (int32_t e = 2 * slo[q]; e < 2 * slo[q + 1]; ++e)
+                        if (pl.ell_src[(size_t)(pl.ell_off[(size_t)g] + (int64_t)(e / 2) * 128 + 2 * l + (e & 1))] >= 0) return -1;
+                }
                 for (int32_t e = 2 * slo[q]; e < 2 * slo[q + 1]; ++e) {
                     const int64_t at = pl.ell_off[(size_t)g] + (int64_t)(e / 2) * 128 + 2 * l + (e & 1);
                     const uint16_t code = pl.ell_code[(size_t)at];
                     if (code >= S + H) return -1;
                     if (q < nsl / 2 && code >= S && pl.ell_src[(size_t)at] >= 0) return -1;   // "no import" slices must not import
-                    acc += (pl.ell_src[(size_t)at] >= 0 ? val(pl.ell_src[(size_t)at]) : 0.0) * tab[code];
+                    const int32_t k = pl.ell_src[(size_t)at];
+                    if (k < 0) continue;
+                    const double a = val(d, hs.colidx_i[(size_t)k]);
+                    acc += a * tab[code];
+                    if (sym && code < S) {   // the same entry applied to the row of its column
+                        const int32_t dc = pl.slot_dof[(size_t)g * S + code];
+                        if (dc != hs.colidx_i[(size_t)k]) return -1;
+                        y[(size_t)dc] += a * tab[(size_t)s];
+                    }
                 }
                 if (d >= 0) {
                     if (seen[(size_t)d]) return -1;   // every interior row in exactly one slot
-                    seen[(size_t)d] = 1, y[(size_t)d] = acc;
+                    seen[(size_t)d] = 1, y[(size_t)d] += acc;
                 }
             }
     }
@@ -148,6 +177,11 @@ int main() {
         for (int n_wg : {1, 7, 256}) {
             pg[k++] = check_persist(hs, true, n_wg);
             if (n_wg == 7) pg[k++] = check_persist(hs, false, n_wg);
+            if (check_persist(hs, true, n_wg, true) < 0 || check_persist(hs, n_wg != 7, n_wg, true, true) < 0 || check_persist(hs, true, n_wg, false, true) < 0) {
+                std::fprintf(stderr, "case dim %d nx %d order %d: symmetric / uneven persistent layout (%d workgroups) does not reproduce the operator\n",
+                             cs.dim, cs.nx, cs.order, n_wg);
+                return 1;
+            }
         }
         for (int v : pg)
             if (v < 0) {

@@ -18,9 +18,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _n_gpus():
-    import torch
+    # through the library, not torch: importing torch here would load the ROCm runtime bundled with the wheel into a process that
+    # may already hold the system's (another test file loaded libfdapde_hip.so first), and RCCL then finds no device
+    from fdapde_loader import load_package
 
-    return torch.cuda.device_count()   # counting devices does not initialise the GPU in this process
+    load_package()
+    from fdapde_core_amd import capi
+
+    return int(capi.load().fdapde_device_count())
 
 
 def _free_port():

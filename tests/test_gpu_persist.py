@@ -69,6 +69,72 @@ def test_persistent_path_matches_multi_launch_path(env, dim, nx, order, dirichle
     c.close()
 
 
+@pytest.mark.parametrize("dim,nx,order,dirichlet", [
+    (2, 20, 1, True),      # one workgroup: every pair of rows stored once, no exchange
+    (2, 60, 2, True),      # P2 rows, a few workgroups
+    (2, 150, 1, False),    # no Dirichlet DOF
+    (3, 30, 1, True),      # 3-D rows, import lists
+    (3, 12, 2, True),      # 3-D P2 rows (up to 64 entries): long rows, many pairs per accumulator slot
+    (3, 64, 1, True),      # 135 workgroups, resident blocks
+    (2, 1000, 1, True),    # 8 rows per thread (what the automatic choice picks the symmetric storage for)
+    (3, 105, 1, True),     # 16 rows per thread, blocks stream
+])
+def test_symmetric_storage_matches_plain_storage(env, dim, nx, order, dirichlet):
+    """tune persist_sym 1: in-block pairs stored once, transposed products through 64-bit fixed-point LDS accumulators
+    (kernels_persist.h SYM).  Same recurrence and the same operator to rounding: the same iteration count (+-1) and solution as
+    the plain storage; integer accumulation makes the result independent of the order the wavefronts arrive in: bitwise
+    reproducible from launch to launch; the streamed bytes shrink."""
+    capi, meshgen = env
+    c, nd = _problem(capi, meshgen, dim, nx, order, dirichlet)
+    c.tune("persist_sym", 0)
+    i0 = c.solve(rtol=1e-10)
+    u0 = c.solution()
+    bytes_plain = c.solver_layout(dirichlet)[2]
+    assert i0.persistent == 1 and i0.converged == 1
+    c.tune("persist_sym", 1)
+    i1 = c.solve(rtol=1e-10)
+    u1 = c.solution()
+    bytes_sym = c.solver_layout(dirichlet)[2]
+    assert i1.persistent == 1 and i1.converged == 1 and i1.relres <= 1e-10
+    assert abs(i1.iters - i0.iters) <= max(1, i0.iters // 200), (i1.iters, i0.iters)
+    assert np.linalg.norm(u1 - u0) <= 1e-9 * np.linalg.norm(u0)
+    assert bytes_sym < 0.8 * bytes_plain, (bytes_sym, bytes_plain)
+    for _ in range(2):
+        i2 = c.solve(rtol=1e-10)
+        assert i2.iters == i1.iters and np.array_equal(c.solution(), u1), "integer accumulation: identical bits on every launch"
+    c.tune("persist_sym", 2)   # automatic: symmetric only where the plain blocks would stream and a workgroup owns > 2048 rows
+    i3 = c.solve(rtol=1e-10)
+    want_sym = (dim, nx) in ((2, 1000), (3, 105))
+    assert (c.solver_layout(dirichlet)[2] == bytes_sym) == want_sym
+    assert i3.converged == 1
+    c.close()
+
+
+def test_symmetric_storage_with_coefficients_of_very_different_size(env):
+    """a reaction coefficient that varies in space by six orders of magnitude: after the Jacobi scaling the rows range from
+    stiffness-dominated to mass-dominated, and search directions whose entries differ by orders of magnitude inside one workgroup
+    share one accumulator scale (chosen from the block's largest |p|)"""
+    capi, meshgen = env
+    nodes, cells, bnd = meshgen.unit_cube(40)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(1)
+    q = c.quadrature_nodes()
+    c.set_operator(-capi.laplacian() + capi.reaction_field(10.0 ** (6.0 * q[:, 0] - 2.0)))
+    c.set_forcing(np.sin(3.0 * q[:, 1]) + 2.0)
+    c.set_dirichlet(np.zeros(nd))
+    c.init()
+    sols = {}
+    for sym in (0, 1):
+        c.tune("persist_sym", sym)
+        i = c.solve(rtol=1e-11)
+        assert i.persistent == 1 and i.converged == 1
+        sols[sym] = (c.solution().copy(), i.iters)
+    assert abs(sols[1][1] - sols[0][1]) <= max(1, sols[0][1] // 100), (sols[1][1], sols[0][1])
+    assert np.linalg.norm(sols[1][0] - sols[0][0]) <= 1e-9 * np.linalg.norm(sols[0][0])
+    c.close()
+
+
 def test_persistent_path_against_the_oracle(env, oracle, mesh_loader):
     capi, _ = env
     m = mesh_loader("unit_square")     # 3600 nodes: two workgroups

@@ -1191,7 +1191,7 @@ int build_solver_pattern(fdapde_ctx* c, int v) {
 int check_dev_persist(fdapde_ctx* c, int v, const PersistLayout& pl, const DevPersist& dp) {
     if (int rc = ensure_host(c, kHostPattern)) return rc;
     PersistLayout ref;
-    if (host_build_persist_layout(c->hs, v == 1, c->n_cu, 12000, ref, nullptr, pl.sym ? 1 : 0) != FDAPDE_OK) return fail(c, FDAPDE_EHIP, "set-up check: host persistent layout failed");
+    if (host_build_persist_layout(c->hs, v == 1, c->n_cu, 12000, ref, nullptr, pl.sym ? 1 : 0, c->persist_balance != 0) != FDAPDE_OK) return fail(c, FDAPDE_EHIP, "set-up check: host persistent layout failed");
     int bad = 0;
     auto scalar = [&](const char* name, int64_t a, int64_t b) {
         if (a != b) std::fprintf(stderr, "persist check %-9s: MISMATCH %lld vs %lld\n", name, (long long)a, (long long)b), ++bad;
@@ -1246,12 +1246,12 @@ int build_persist(fdapde_ctx* c, int v) {
         int rc = FDAPDE_EUNSUPPORTED;
         if (on_device) {   // the layout is built where the pattern lives (dev_persist.hip)
             rc = dev_build_persist_layout(c->hs.n_dofs, c->hs.max_row, c->rowptr.p, c->colidx.p, c->bnd.p, v == 1, c->n_cu, 12000, 0, nullptr, sym_mode,
-                                          c->stream, pl, &dp, c->err);
+                                          c->persist_balance != 0, c->stream, pl, &dp, c->err);
             if (rc == FDAPDE_EUNSUPPORTED && c->hs.max_row > 255) on_device = false;   // rows too long for its sort keys: host builder
         }
         if (!on_device) {
             if (int rc2 = ensure_host(c, kHostPattern)) return rc2;
-            rc = host_build_persist_layout(c->hs, v == 1, c->n_cu, 12000, pl, nullptr, sym_mode);   // ~12 000 ELL entries (120 KB) next to the vectors of <= 4096 rows
+            rc = host_build_persist_layout(c->hs, v == 1, c->n_cu, 12000, pl, nullptr, sym_mode, c->persist_balance != 0);   // ~12 000 ELL entries (120 KB) next to the vectors of <= 4096 rows
         }
         if (rc == FDAPDE_EUNSUPPORTED) return FDAPDE_OK;
         if (rc) return rc;
@@ -1389,7 +1389,7 @@ int build_blocked(fdapde_ctx* c, int v) {
     // rows per block, measured on C5 (P2, 28 entries per row; CSR kernel 400 us per SpMV): 1024 -> 375 us, 2048 -> 367, 4096 -> 387, 8192 -> 439
     int rows = 2048;
     if (const char* e = std::getenv("FDAPDE_BLOCKED_ROWS")) rows = std::atoi(e);
-    const int rc = dev_build_persist_layout(c->hs.n_dofs, c->hs.max_row, c->rowptr.p, c->colidx.p, c->bnd.p, v == 1, 1 << 19, 0, rows, nullptr, 0, c->stream, pl, &dp,
+    const int rc = dev_build_persist_layout(c->hs.n_dofs, c->hs.max_row, c->rowptr.p, c->colidx.p, c->bnd.p, v == 1, 1 << 19, 0, rows, nullptr, 0, false, c->stream, pl, &dp,
                                             c->err);
     if (rc == FDAPDE_EUNSUPPORTED) return FDAPDE_OK;
     if (rc) return rc;
@@ -2484,7 +2484,10 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "blocked" && value >= 0 && value <= 2) c->blocked = value;   // 2: also for short-row systems
     else if (k == "persist_gather_waves" && (value == 1 || value == 4)) c->persist_gather_waves = value;
     else if (k == "persist_poll_sleep" && value >= 0 && value <= 3) c->persist_poll_sleep = value;
-    else if (k == "persist_sym" && value >= 0 && value <= 2) {   // 0 plain storage, 1 symmetric, 2 symmetric where the plain blocks would stream
+    else if (k == "persist_balance" && (value == 0 || value == 1)) {   // workgroup boundaries of the persistent CG at equal cost (1) or equal row counts (0)
+        c->persist_balance = value;
+        for (auto& ps : c->ps) ps.tried = ps.ok = ps.filled = false;
+    } else if (k == "persist_sym" && value >= 0 && value <= 2) {   // 0 plain storage, 1 symmetric, 2 symmetric where the plain blocks would stream
         c->persist_sym = value;
         for (auto& ps : c->ps) ps.tried = ps.ok = ps.filled = false;   // the layouts are rebuilt on the next solve
     }

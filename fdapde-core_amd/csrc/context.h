@@ -222,6 +222,7 @@ struct fdapde_ctx {
     int n_cu = 0;
     int persist = 1;                         // tuning knob: 0 = never take the single-launch path
     int persist_time = 1;                    // workgroup 0 stamps the phases of every iteration (a handful of s_memrealtime per iteration)
+    int persist_balance = 1;                                // workgroup boundaries of the persistent CG at equal cost (entries + 2 per row)
     int persist_sym = 2;                                    // symmetric storage of the persistent CG: 0 never, 1 always, 2 where the plain blocks would stream
     int persist_gather_waves = 4, persist_poll_sleep = 2;   // tuning knobs of the dot all-gather (kernels_persist.h)
     bool persist_broken = false;             // a hand-off timed out once (workgroups not co-resident): stay on the multi-launch path

@@ -23,9 +23,10 @@ void dev_persist_release(DevPersist* p);
 // system needs; imp_pos holds DOF ids of the global vector (ascending inside a workgroup); no exports / board.
 // block_rows != nullptr (persistent mode only): exactly n_wg workgroups, workgroup g owning block_rows[g] >= 1 consecutive interior rows
 // (they add up to the interior row count) instead of equal shares -- the speed-weighted split of capi.hip's calibration.
+// balance (persistent mode, no block_rows): workgroup boundaries at equal cost (stored entries + 2 per row) instead of equal row counts.
 // sym_mode: symmetric storage (internal.h persist_sym_owner / persist_want_sym; persistent mode only); pl.sym says what was built.
 int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowptr, const int32_t* d_colidx, const uint8_t* d_bnd, bool use_bnd,
-                             int n_wg, int lds_entries, int blocked_rows, const int32_t* block_rows, int sym_mode, void* stream, PersistLayout& pl, DevPersist* out,
+                             int n_wg, int lds_entries, int blocked_rows, const int32_t* block_rows, int sym_mode, bool balance, void* stream, PersistLayout& pl, DevPersist* out,
                              std::string& err);
 
 }  // namespace fdapde_hip

@@ -64,6 +64,23 @@ __device__ __forceinline__ int32_t wg_of_irow(const int32_t* wgs, int G, int64_t
     }
     return lo;
 }
+// cost-balanced boundaries: workgroup g starts at the first interior row whose exclusive cost prefix (entries + 2 per row) reaches
+// g * total / G; wgs[g] = number of interior rows before it
+__global__ void k_balance_bounds(int G, int64_t nd, int64_t total, const int32_t* len_scan, const int32_t* irow_scan, int32_t* wgs) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > G) return;
+    if (g == G) {
+        wgs[G] = irow_scan[nd];
+        return;
+    }
+    const int64_t target = (int64_t)g * total / G;
+    int64_t lo = 0, hi = nd;   // first d in [0, nd] with cost(d) >= target (cost(nd) = total >= target)
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)len_scan[mid] + 2 * (int64_t)irow_scan[mid] >= target) hi = mid; else lo = mid + 1;
+    }
+    wgs[g] = irow_scan[lo];
+}
 __global__ void k_wg_of(int64_t nd, const uint8_t* keep, const int32_t* irow, const int32_t* wgs, int G, int32_t* wg) {
     const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d < nd) wg[d] = keep[d] ? wg_of_irow(wgs, G, irow[d]) : -1;
@@ -297,7 +314,7 @@ void dev_persist_release(DevPersist* p) {
 }
 
 int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowptr, const int32_t* d_colidx, const uint8_t* d_bnd, bool use_bnd,
-                             int n_wg, int lds_entries, int blocked_rows, const int32_t* block_rows, int sym_mode, void* stream, PersistLayout& pl, DevPersist* out,
+                             int n_wg, int lds_entries, int blocked_rows, const int32_t* block_rows, int sym_mode, bool balance, void* stream, PersistLayout& pl, DevPersist* out,
                              std::string& err) {
     constexpr int T = kPersistT;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -344,25 +361,43 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
     if (G < 1) G = 1;
     if (G >= (1 << 20)) return FDAPDE_EUNSUPPORTED;   // 20 bits of the row keys
     int64_t rpw = (n_int + G - 1) / G;   // rows of the largest workgroup
+    const bool sym = !blocked && persist_want_sym(sym_mode, nnz_kept, G, rpw);
     std::vector<int32_t> h_wgs;           // interior-row boundaries of the workgroups
+    Tmp<int32_t> wgs, wg;
+    bool uniform = true;
     if (block_rows != nullptr && !blocked) {
-        G = n_wg;   // caller-given block sizes (speed-weighted, see capi.hip calibrate_persist); they add up to n_int
+        G = n_wg;   // caller-given block sizes; they add up to n_int
         h_wgs.assign((size_t)G + 1, 0);
         rpw = 0;
         for (int g = 0; g < G; ++g) h_wgs[(size_t)g + 1] = h_wgs[(size_t)g] + block_rows[g], rpw = std::max<int64_t>(rpw, block_rows[g]);
         if (h_wgs[(size_t)G] != n_int) return FDAPDE_EINVAL;
+        uniform = false;
     } else {
         G = (int)((n_int + rpw - 1) / rpw);   // trailing workgroups that would stay empty are not launched
-        h_wgs.assign((size_t)G + 1, 0);
-        for (int g = 0; g <= G; ++g) h_wgs[(size_t)g] = (int32_t)std::min<int64_t>(n_int, (int64_t)g * rpw);
+        DP_CHK(wgs.alloc((size_t)G + 1));
+        if (balance && !blocked && G >= 2) {   // equal cost (entries + 2 per row) instead of equal row counts
+            hipLaunchKernelGGL(k_balance_bounds, dim3((G + 256) / 256), dim3(256), 0, st, G, nd, nnz_kept + 2 * n_int, len_scan.p, irow_scan.p, wgs.p);
+            h_wgs.assign((size_t)G + 1, 0);
+            DP_CHK(hipMemcpyAsync(h_wgs.data(), wgs.p, sizeof(int32_t) * ((size_t)G + 1), hipMemcpyDeviceToHost, st));
+            DP_CHK(hipStreamSynchronize(st));
+            uniform = false;
+            int64_t mx = 0;
+            for (int g = 0; g < G; ++g) {
+                if (h_wgs[(size_t)g + 1] <= h_wgs[(size_t)g]) uniform = true;   // an empty workgroup (tiny systems): equal row counts
+                mx = std::max<int64_t>(mx, h_wgs[(size_t)g + 1] - h_wgs[(size_t)g]);
+            }
+            if (!uniform) rpw = mx;
+        }
+        if (uniform) {
+            h_wgs.assign((size_t)G + 1, 0);
+            for (int g = 0; g <= G; ++g) h_wgs[(size_t)g] = (int32_t)std::min<int64_t>(n_int, (int64_t)g * rpw);
+        }
     }
-    Tmp<int32_t> wgs, wg;
-    DP_CHK(wgs.alloc((size_t)G + 1));
+    if (block_rows != nullptr && !blocked) DP_CHK(wgs.alloc((size_t)G + 1));
     DP_CHK(wg.alloc((size_t)nd));
-    DP_CHK(hipMemcpyAsync(wgs.p, h_wgs.data(), sizeof(int32_t) * ((size_t)G + 1), hipMemcpyHostToDevice, st));
+    if (uniform || block_rows != nullptr) DP_CHK(hipMemcpyAsync(wgs.p, h_wgs.data(), sizeof(int32_t) * ((size_t)G + 1), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_wg_of, dim3(grid_of(nd)), dim3(256), 0, st, nd, keep.p, irow.p, wgs.p, G, wg.p);
     int64_t nnz_stored = nnz_kept;
-    const bool sym = !blocked && persist_want_sym(sym_mode, nnz_kept, G, rpw);
     if (sym) {   // the rows' stored lengths, now that the blocks are known
         hipLaunchKernelGGL(k_row_lengths_sym, dim3(grid_of(nd)), dim3(256), 0, st, nd, d_rowptr, d_colidx, keep.p, wg.p, len.p);
         if (int rc = exclusive_sum(sc, len.p, len_scan.p, nd + 1, st, err)) return rc;

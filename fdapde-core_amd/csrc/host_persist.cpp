@@ -33,7 +33,7 @@ template <typename F> void for_each_wg(int G, F&& fn) {
 
 }  // namespace
 
-int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int lds_entries, PersistLayout& pl, const int32_t* block_rows, int sym_mode) {
+int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int lds_entries, PersistLayout& pl, const int32_t* block_rows, int sym_mode, bool balance) {
     constexpr int T = kPersistT;
     const int64_t nd = hs.n_dofs;
     if (n_wg < 1 || nd < 1) return FDAPDE_EUNSUPPORTED;
@@ -58,19 +58,43 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
     int G = (int)std::min<int64_t>(n_wg, want);
     if (G < 1) G = 1;
     int64_t rpw = (n_int + G - 1) / G;   // rows of the largest workgroup
+    const bool sym = persist_want_sym(sym_mode, nnz_kept, G, rpw);
     std::vector<int64_t> wgs;             // interior-row boundaries of the workgroups
     if (block_rows != nullptr) {
-        G = n_wg;                         // caller-given block sizes (speed-weighted); they add up to n_int
+        G = n_wg;                         // caller-given block sizes; they add up to n_int
         wgs.assign((size_t)G + 1, 0);
         rpw = 0;
         for (int g = 0; g < G; ++g) wgs[(size_t)g + 1] = wgs[(size_t)g] + block_rows[g], rpw = std::max<int64_t>(rpw, block_rows[g]);
         if (wgs[(size_t)G] != n_int) return FDAPDE_EINVAL;
     } else {
         G = (int)((n_int + rpw - 1) / rpw);   // trailing workgroups that would stay empty are not launched
-        wgs.assign((size_t)G + 1, 0);
-        for (int g = 0; g <= G; ++g) wgs[(size_t)g] = std::min<int64_t>(n_int, (int64_t)g * rpw);
+        bool uniform = true;
+        if (balance && G >= 2) {   // equal cost (entries + 2 per row) instead of equal row counts: workgroup g starts at the first
+                                   // interior row whose exclusive cost prefix reaches g * total / G (dev_persist.hip k_balance_bounds)
+            const int64_t total = nnz_kept + 2 * n_int;
+            wgs.assign((size_t)G + 1, n_int);
+            int64_t cost = 0;
+            int g = 0;
+            for (int64_t i = 0; i < n_int; ++i) {
+                while (g < G && cost >= (int64_t)g * total / G) wgs[(size_t)g++] = i;
+                const int32_t d = irow_dof[(size_t)i];
+                int64_t len = 0;
+                for (int32_t k = hs.rowptr_i[(size_t)d]; k < hs.rowptr_i[(size_t)d + 1]; ++k) len += kept(d, hs.colidx_i[(size_t)k]);
+                cost += len + 2;
+            }
+            uniform = false;
+            int64_t mx = 0;
+            for (int q = 0; q < G; ++q) {
+                if (wgs[(size_t)q + 1] <= wgs[(size_t)q]) uniform = true;   // an empty workgroup (tiny systems): equal row counts
+                mx = std::max(mx, wgs[(size_t)q + 1] - wgs[(size_t)q]);
+            }
+            if (!uniform) rpw = mx;
+        }
+        if (uniform) {
+            wgs.assign((size_t)G + 1, 0);
+            for (int g = 0; g <= G; ++g) wgs[(size_t)g] = std::min<int64_t>(n_int, (int64_t)g * rpw);
+        }
     }
-    const bool sym = persist_want_sym(sym_mode, nnz_kept, G, rpw);
     std::vector<int32_t> wg_of((size_t)nd, -1), slot_of((size_t)nd, -1);
     for (int g = 0; g < G; ++g)
         for (int64_t i = wgs[(size_t)g]; i < wgs[(size_t)g + 1]; ++i) wg_of[(size_t)irow_dof[(size_t)i]] = g;

@@ -185,7 +185,7 @@ struct PersistLayout {
 // workgroup instead of 2048).  Returns FDAPDE_EUNSUPPORTED when the system does not fit the layout (more than n_wg * T * Rmax interior
 // rows, rows or lists too long for the 16-bit codes).
 int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int lds_entries, PersistLayout& pl, const int32_t* block_rows = nullptr,
-                              int sym_mode = 0);
+                              int sym_mode = 0, bool balance = false);
 
 }  // namespace fdapde_hip
 #endif

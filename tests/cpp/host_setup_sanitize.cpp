@@ -55,10 +55,11 @@ static void grid_mesh(int dim, int nx, std::vector<double>& nodes, std::vector<i
 // The persistent CG's resident layout (host_persist.cpp), checked by running its operator application on the CPU exactly as
 // k_cg_persist does -- own entries from the slot table, imported entries through the board, sliced ELL with 16-bit codes -- against
 // the CSR product on the interior block.  Returns the number of workgroups of the layout (0: system does not qualify), -1 on error.
-// sym: symmetric storage (in-block pairs stored once, applied to both rows); uneven: workgroups of unequal row counts
-static int check_persist(const HostSpace& hs, bool use_bnd, int n_wg, bool sym = false, bool uneven = false) {
+// sym: symmetric storage (in-block pairs stored once, applied to both rows); uneven: workgroups of unequal row counts given by the
+// caller; balance: boundaries at equal cost
+static int check_persist(const HostSpace& hs, bool use_bnd, int n_wg, bool sym = false, bool uneven = false, bool balance = false) {
     PersistLayout pl;
-    int rc = host_build_persist_layout(hs, use_bnd, n_wg, 12000, pl, nullptr, sym ? 1 : 0);
+    int rc = host_build_persist_layout(hs, use_bnd, n_wg, 12000, pl, nullptr, sym ? 1 : 0, balance);
     if (rc == FDAPDE_EUNSUPPORTED) return 0;
     if (rc) return -1;
     if (uneven && pl.G >= 2) {   // same number of workgroups, rows moved from the even to the odd ones
@@ -177,8 +178,9 @@ int main() {
         for (int n_wg : {1, 7, 256}) {
             pg[k++] = check_persist(hs, true, n_wg);
             if (n_wg == 7) pg[k++] = check_persist(hs, false, n_wg);
-            if (check_persist(hs, true, n_wg, true) < 0 || check_persist(hs, n_wg != 7, n_wg, true, true) < 0 || check_persist(hs, true, n_wg, false, true) < 0) {
-                std::fprintf(stderr, "case dim %d nx %d order %d: symmetric / uneven persistent layout (%d workgroups) does not reproduce the operator\n",
+            if (check_persist(hs, true, n_wg, true) < 0 || check_persist(hs, n_wg != 7, n_wg, true, true) < 0 || check_persist(hs, true, n_wg, false, true) < 0 ||
+                check_persist(hs, true, n_wg, true, false, true) < 0 || check_persist(hs, n_wg == 7, n_wg, false, false, true) < 0) {
+                std::fprintf(stderr, "case dim %d nx %d order %d: symmetric / uneven / balanced persistent layout (%d workgroups) does not reproduce the operator\n",
                              cs.dim, cs.nx, cs.order, n_wg);
                 return 1;
             }

@@ -1188,10 +1188,11 @@ int build_solver_pattern(fdapde_ctx* c, int v) {
 }
 
 // FDAPDE_SETUP_CHECK: the device-built persistent layout against the host builder's
-int check_dev_persist(fdapde_ctx* c, int v, const PersistLayout& pl, const DevPersist& dp) {
+int check_dev_persist(fdapde_ctx* c, int v, const PersistLayout& pl, const DevPersist& dp, const std::vector<int32_t>* block_rows) {
     if (int rc = ensure_host(c, kHostPattern)) return rc;
     PersistLayout ref;
-    if (host_build_persist_layout(c->hs, v == 1, c->n_cu, 12000, ref, nullptr, pl.sym ? 1 : 0, c->persist_balance != 0) != FDAPDE_OK) return fail(c, FDAPDE_EHIP, "set-up check: host persistent layout failed");
+    if (host_build_persist_layout(c->hs, v == 1, block_rows ? (int)block_rows->size() : c->n_cu, 12000, ref, block_rows ? block_rows->data() : nullptr,
+                                  pl.sym ? 1 : 0, c->persist_balance != 0) != FDAPDE_OK) return fail(c, FDAPDE_EHIP, "set-up check: host persistent layout failed");
     int bad = 0;
     auto scalar = [&](const char* name, int64_t a, int64_t b) {
         if (a != b) std::fprintf(stderr, "persist check %-9s: MISMATCH %lld vs %lld\n", name, (long long)a, (long long)b), ++bad;
@@ -1223,11 +1224,12 @@ int check_dev_persist(fdapde_ctx* c, int v, const PersistLayout& pl, const DevPe
 // resident layout of the persistent CG for boundary variant v (kernels_persist.h): host index work + uploads, once per function
 // space and boundary mask.  ok stays false when the system does not qualify (too many rows for one launch of resident
 // workgroups, or more matrix than is worth re-reading from the caches every iteration).
-int build_persist(fdapde_ctx* c, int v) {
+int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_rows) {
     fdapde_ctx::Persist& ps = c->ps[v];
-    if (ps.tried) return FDAPDE_OK;
-    ps.tried = true, ps.ok = false;
+    ps.ok = false;
     if (c->n_cu < 1) return FDAPDE_OK;
+    const int32_t* brows = block_rows ? block_rows->data() : nullptr;
+    const int n_wg = block_rows ? (int)block_rows->size() : c->n_cu;
     PersistLayout pl;
     DevPersist dp;
     const char* mode = std::getenv("FDAPDE_SETUP");
@@ -1245,13 +1247,13 @@ int build_persist(fdapde_ctx* c, int v) {
         pl = PersistLayout{};
         int rc = FDAPDE_EUNSUPPORTED;
         if (on_device) {   // the layout is built where the pattern lives (dev_persist.hip)
-            rc = dev_build_persist_layout(c->hs.n_dofs, c->hs.max_row, c->rowptr.p, c->colidx.p, c->bnd.p, v == 1, c->n_cu, 12000, 0, nullptr, sym_mode,
+            rc = dev_build_persist_layout(c->hs.n_dofs, c->hs.max_row, c->rowptr.p, c->colidx.p, c->bnd.p, v == 1, n_wg, 12000, 0, brows, sym_mode,
                                           c->persist_balance != 0, c->stream, pl, &dp, c->err);
             if (rc == FDAPDE_EUNSUPPORTED && c->hs.max_row > 255) on_device = false;   // rows too long for its sort keys: host builder
         }
         if (!on_device) {
             if (int rc2 = ensure_host(c, kHostPattern)) return rc2;
-            rc = host_build_persist_layout(c->hs, v == 1, c->n_cu, 12000, pl, nullptr, sym_mode, c->persist_balance != 0);   // ~12 000 ELL entries (120 KB) next to the vectors of <= 4096 rows
+            rc = host_build_persist_layout(c->hs, v == 1, n_wg, 12000, pl, brows, sym_mode, c->persist_balance != 0);   // ~12 000 ELL entries (120 KB) next to the vectors of <= 4096 rows
         }
         if (rc == FDAPDE_EUNSUPPORTED) return FDAPDE_OK;
         if (rc) return rc;
@@ -1283,7 +1285,7 @@ int build_persist(fdapde_ctx* c, int v) {
     hipStream_t st = c->stream;
     if (on_device) {
         if (std::getenv("FDAPDE_SETUP_CHECK")) {
-            if (int rc2 = check_dev_persist(c, v, pl, dp)) {
+            if (int rc2 = check_dev_persist(c, v, pl, dp, block_rows)) {
                 dev_persist_release(&dp);
                 return rc2;
             }
@@ -1325,18 +1327,15 @@ int build_persist(fdapde_ctx* c, int v) {
     return FDAPDE_OK;
 }
 
-// the whole fused-update CG as one launch; returns FDAPDE_OK with *ran = false when the launch gave up (hand-off timeout)
-int run_persist(fdapde_ctx* c, int v, double tol2, int maxit, bool* ran) {
-    fdapde_ctx::Persist& ps = c->ps[v];
+// launch of k_cg_persist on the layout ps (boards and statistics cleared first)
+int launch_persist(fdapde_ctx* c, fdapde_ctx::Persist& ps, PersistArgs& a) {
     hipStream_t st = c->stream;
-    PersistArgs a{};
-    a.G = ps.meta.G, a.nsl = ps.meta.nsl, a.maxit = maxit, a.imp_cap = ps.imp_cap, a.lds_cap = ps.lds_cap, a.time_phases = c->persist_time;
-    a.tol2 = tol2, a.gather_waves = c->persist_gather_waves, a.poll_sleep = c->persist_poll_sleep;
+    a.G = ps.meta.G, a.nsl = ps.meta.nsl, a.imp_cap = ps.imp_cap, a.lds_cap = ps.lds_cap;
+    a.gather_waves = c->persist_gather_waves, a.poll_sleep = c->persist_poll_sleep;
     a.slot_dof = ps.slot_dof.p, a.ell_off = ps.ell_off.p, a.sl_off = ps.sl_off.p, a.ell_code = ps.ell_code.p;
     a.ell_val = ps.ell_val.p, a.exp_off = ps.exp_off.p, a.exp_slot = ps.exp_slot.p, a.imp_off = ps.imp_off.p, a.imp_pos = ps.imp_pos.p;
     a.pboard = ps.board.p, a.dboard = ps.board.p + 2 * (size_t)ps.meta.n_board;
-    a.amax_bits = ps.amax.p, a.max_len = c->hs.max_row;
-    a.r_in = c->r.p, a.x = c->x.p, a.sc = c->sc.p, a.ctl = c->ctl.p, a.stats = c->persist_stats.p;
+    a.amax_bits = ps.amax.p, a.max_len = c->hs.max_row, a.stats = c->persist_stats.p;
     HIPCHK(c, hipMemsetAsync(ps.board.p, 0, sizeof(unsigned long long) * ps.board.n, st));   // every tag 0: no epoch of this launch
     HIPCHK(c, hipMemsetAsync(c->persist_stats.p, 0, 4 * (size_t)a.G * sizeof(double), st));
 #define PERSIST_GO(R_, ST_)                                                                                                     \
@@ -1364,6 +1363,24 @@ int run_persist(fdapde_ctx* c, int v, double tol2, int maxit, bool* ran) {
         }
 #undef PERSIST_GO
     HIPCHK(c, hipGetLastError());
+    return FDAPDE_OK;
+}
+
+int build_persist(fdapde_ctx* c, int v) {
+    fdapde_ctx::Persist& ps = c->ps[v];
+    if (ps.tried) return FDAPDE_OK;
+    ps.tried = true;
+    return build_persist_once(c, v, nullptr);
+}
+
+// the whole fused-update CG as one launch; returns FDAPDE_OK with *ran = false when the launch gave up (hand-off timeout)
+int run_persist(fdapde_ctx* c, int v, double tol2, int maxit, bool* ran) {
+    fdapde_ctx::Persist& ps = c->ps[v];
+    hipStream_t st = c->stream;
+    PersistArgs a{};
+    a.maxit = maxit, a.time_phases = c->persist_time, a.tol2 = tol2;
+    a.r_in = c->r.p, a.x = c->x.p, a.sc = c->sc.p, a.ctl = c->ctl.p;
+    if (int rc = launch_persist(c, ps, a)) return rc;
     HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(c->h_sc, c->sc.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
     c->persist_host_stats.resize(4 * (size_t)a.G);
@@ -1435,7 +1452,6 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss) {
     } else {
         hipLaunchKernelGGL(k_jacobi_scale, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->diag.p, A, c->bnd.p, use_bnd, c->scale.p, c->ctl.p + 3);
     }
-    HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     if (ss->dist) {   // "positive diagonal" (CG admissible) must be ONE decision for all ranks: sum the per-rank flags
@@ -1773,11 +1789,16 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
         }
         if (std::getenv("FDAPDE_DEBUG_PERSIST")) {   // per-workgroup operator phases (us), with the workgroup's ELL entries
             std::vector<int64_t> eo(G + 1);
+            std::vector<int32_t> io(G + 1), xo(G + 1);
             const int v = ss.use_bnd ? 1 : 0;
             (void)hipMemcpy(eo.data(), c->ps[v].ell_off.p, sizeof(int64_t) * (G + 1), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(io.data(), c->ps[v].imp_off.p, sizeof(int32_t) * (G + 1), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(xo.data(), c->ps[v].exp_off.p, sizeof(int32_t) * (G + 1), hipMemcpyDeviceToHost);
             for (size_t g = 0; g < G; ++g)
-                std::fprintf(stderr, "persist wg %zu: operator %.2f us gather %.2f us entries %lld\n", g, c->persist_host_stats[4 * g + 1] / std::max(1.0, c->persist_host_stats[4 * g]) * 1e-2,
-                             c->persist_host_stats[4 * g + 2] / std::max(1.0, c->persist_host_stats[4 * g]) * 1e-2, (long long)(eo[g + 1] - eo[g]));
+                std::fprintf(stderr, "persist wg %zu: operator %.2f us gather %.2f us entries %lld imports %d exports %d\n", g,
+                             c->persist_host_stats[4 * g + 1] / std::max(1.0, c->persist_host_stats[4 * g]) * 1e-2,
+                             c->persist_host_stats[4 * g + 2] / std::max(1.0, c->persist_host_stats[4 * g]) * 1e-2, (long long)(eo[g + 1] - eo[g]),
+                             io[g + 1] - io[g], xo[g + 1] - xo[g]);
         }
         c->info.spmv_avg_ms = mx * 1e-5, c->info.spmv_timed = (int32_t)c->persist_host_stats[0];
         c->info.spmv_mean_ms = mean / (double)G * 1e-5, c->info.gather_avg_ms = gat / (double)G * 1e-5, c->info.update_avg_ms = upd / (double)G * 1e-5;

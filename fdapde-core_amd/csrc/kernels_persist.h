@@ -84,6 +84,21 @@ __device__ __forceinline__ void publish_f64(unsigned long long* g2, unsigned epo
     granule_store(g2, epoch, (unsigned)b);
     granule_store(g2 + 1, epoch, (unsigned)(b >> 32));
 }
+// a double published with ONE 16-byte write-through store: {low word, epoch, high word, epoch} -- the same two granules as publish_f64
+// (each aligned 8-byte half carries its own tag and is validated on its own by the reader), half the fabric writes
+__device__ __forceinline__ void publish_f64_x4(unsigned long long* g2, unsigned epoch, double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    pg_u32x4 q;
+    q.x = (unsigned)b, q.y = epoch, q.z = (unsigned)(b >> 32), q.w = epoch;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(g2), "v"(q) : "memory");
+}
+// four published doubles fetched with the loads in flight together (one round trip instead of four)
+__device__ __forceinline__ void granule_load2x4(const unsigned long long* p0, const unsigned long long* p1, const unsigned long long* p2,
+                                                const unsigned long long* p3, pg_v2u64& a, pg_v2u64& b, pg_v2u64& c, pg_v2u64& d) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+}
 __device__ __forceinline__ double wave_sum64(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -214,7 +229,17 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
             const int ex = m > 0.0 && m < 1.7e308 ? 61 - bexp - ilogb(m) : 0;
             tscale = ldexp(1.0, ex), tinv = ldexp(1.0, -ex);
         }
-        for (int i = tid; i < E; i += T) publish_f64(a.pboard + 2 * (size_t)(a.exp_off[g] + i), epoch, p_tab[expl[i]]);
+        for (int i0 = tid; i0 < E; i0 += 4 * T) {   // four per thread at a time: slot codes, then table reads, then the stores
+            unsigned code[4];
+            double pe[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) code[k] = expl[min(i0 + k * T, E - 1)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pe[k] = p_tab[code[k]];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i0 + k * T < E) publish_f64_x4(a.pboard + 2 * (size_t)(a.exp_off[g] + i0 + k * T), epoch, pe[k]);
+        }
         // ---- y = (I + At_offdiag) p: the passes without imports first, the others once the neighbours' entries have arrived
         double yv[R];
 #pragma unroll
@@ -291,17 +316,25 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
             }
         };
         product(std::integral_constant<int, 0>{});
-        {   // imports: a lane re-reads its granule pair until both halves carry this iteration's tag; lanes that have theirs stop loading
+        {   // imports, four per lane at a time with their loads in flight together (a workgroup in the middle of a 3-D mesh imports ~3 000
+            // entries: one after the other that was six dependent round trips per wavefront, measured as 1.5 us per 1 000 imports); a lane
+            // re-reads what does not carry this iteration's tag in both halves yet, lanes that have theirs stop loading
             bool fail = false;
-            for (int h0 = wave * 64; h0 < H; h0 += T) {   // wave-uniform trip count
-                const int h = h0 + lane;
-                const unsigned long long* gp = a.pboard + 2 * (size_t)(h < H ? impl[h] : impl[0]);
-                pg_v2u64 v = {0, 0};
-                bool done = h >= H;
+            for (int hb = wave * 64; hb < H; hb += 4 * T) {   // wave-uniform trip count
+                const unsigned long long* gp[4];
+                pg_v2u64 v[4];
+                bool done[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int h = hb + k * T + lane;
+                    done[k] = h >= H;
+                    gp[k] = a.pboard + 2 * (size_t)impl[done[k] ? 0 : h];
+                }
+                granule_load2x4(gp[0], gp[1], gp[2], gp[3], v[0], v[1], v[2], v[3]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) done[k] = done[k] || granule_pair_ok(v[k], epoch);
                 long long t_wait = 0;
-                for (unsigned spins = 0;; ++spins) {
-                    if (!done) v = granule_load2(gp), done = granule_pair_ok(v, epoch);
-                    if (__all(done)) break;
+                for (unsigned spins = 0; !__all(done[0] && done[1] && done[2] && done[3]); ++spins) {
                     if ((spins & 63u) == 63u) {   // bounded by time, checked now and then
                         const long long now = wall_clock64();
                         if (t_wait == 0) t_wait = now;
@@ -311,8 +344,15 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
                         }
                     }
                     __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (!done[k]) v[k] = granule_load2(gp[k]), done[k] = granule_pair_ok(v[k], epoch);
                 }
-                if (h < H) p_tab[S + h] = granule_pair_f64(v);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int h = hb + k * T + lane;
+                    if (h < H) p_tab[S + h] = granule_pair_f64(v[k]);
+                }
                 if (fail) break;
             }
             if (fail && lane == 0) fail_flag = 1;

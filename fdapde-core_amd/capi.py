@@ -46,7 +46,7 @@ SYMBOLS = [
     "fdapde_init", "fdapde_assemble_operator", "fdapde_solver_prepare", "fdapde_solve", "fdapde_matrix_values", "fdapde_lump", "fdapde_force", "fdapde_solution",
     "fdapde_info_get", "fdapde_spmv", "fdapde_bench_spmv", "fdapde_tune", "fdapde_stream", "fdapde_synchronize",
     "fdapde_comm_unique_id", "fdapde_comm_init", "fdapde_halo_setup", "fdapde_solve_parabolic",
-    "fdapde_lin_compute", "fdapde_lin_solve", "fdapde_eval_pointwise", "fdapde_cell_integrals", "fdapde_comm_init_callback",
+    "fdapde_lin_compute", "fdapde_lin_solve", "fdapde_eval_pointwise", "fdapde_cell_integrals", "fdapde_comm_init_callback", "fdapde_comm_set_exchange_callback", "fdapde_halo_setup_peers",
     "fdapde_solver_layout", "fdapde_topology_build", "fdapde_topology_get",
 ]
 
@@ -433,6 +433,35 @@ class Context:
         owned = np.ascontiguousarray(owned, dtype=np.uint8)
         self._check(self.lib.fdapde_halo_setup(self._ctx, C.c_int64(int(n_if_global)), C.c_int64(local_dof.size), _ip(local_dof),
                                                _ip(if_index), _bp(owned)))
+
+    def comm_set_exchange_callback(self, exchange):
+        """host-staged neighbour exchange: exchange(peer_rank (int32 array), peer_off (int64 array), send (float64 array), recv (float64
+        array, to fill)) must deliver send[peer_off[q]:peer_off[q + 1]] to rank peer_rank[q] and fill the same segment of recv with
+        what that rank sent to this one"""
+        proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double))
+
+        def _cb(user, n_peers, ranks, offs, send, recv):
+            try:
+                off = np.ctypeslib.as_array(offs, shape=(n_peers + 1,))
+                n = int(off[-1])
+                exchange(np.ctypeslib.as_array(ranks, shape=(n_peers,)), off, np.ctypeslib.as_array(send, shape=(n,)),
+                         np.ctypeslib.as_array(recv, shape=(n,)))
+                return 0
+            except Exception:   # noqa: BLE001  (must not propagate through the C frame)
+                return 1
+
+        self._xchg_cb = proto(_cb)   # keep alive
+        self._check(self.lib.fdapde_comm_set_exchange_callback(self._ctx, self._xchg_cb, None))
+
+    def halo_setup_peers(self, peer_rank, peer_off, peer_dof, owned):
+        """neighbour-only exchange (fdapde_halo_setup_peers): peer ranks ascending, their segments in peer_dof (DOF ids shared with the
+        peer, in an order both ranks of the pair agree on)"""
+        peer_rank = np.ascontiguousarray(peer_rank, dtype=np.int32)
+        peer_off = np.ascontiguousarray(peer_off, dtype=np.int64)
+        peer_dof = np.ascontiguousarray(peer_dof, dtype=np.int32)
+        owned = np.ascontiguousarray(owned, dtype=np.uint8)
+        self._check(self.lib.fdapde_halo_setup_peers(self._ctx, C.c_int32(peer_rank.size), _ip(peer_rank),
+                                                     peer_off.ctypes.data_as(C.POINTER(C.c_int64)), _ip(peer_dof), _bp(owned)))
 
     def tune(self, key, value):
         self._check(self.lib.fdapde_tune(self._ctx, key.encode(), int(value)))

@@ -674,7 +674,46 @@ int allreduce_sum(fdapde_ctx* c, double* buf, size_t count) {
 }
 // v (internal DOF order, sub-assembled) -> interface entries summed over the ranks sharing them; optionally carries the
 // two fused dot partials of the SpMV (part_a, stride 2) through the same all-reduce: they land in hbuf[n_if], [n_if + 1]
+// neighbour-only form (fdapde_halo_setup_peers): pack the per-peer segments, one grouped RCCL call with a send + a receive per peer, the
+// all-reduce of the two scalars, then the contributions of every local interface DOF summed in rank order
+int halo_sum_peers(fdapde_ctx* c, double* v, const double* part, int np, bool unpack) {
+    hipStream_t st = c->stream;
+    const int n_peers = (int)c->peer_rank.size();
+    const int64_t n_send = c->peer_off.empty() ? 0 : c->peer_off.back();
+    double* scal = c->hbuf.p + c->n_if;
+    hipLaunchKernelGGL(k_peer_pack, dim3(g1(n_send > 0 ? n_send : 1)), dim3(256), 0, st, n_send, c->peer_send_dof.p, v, c->peer_sendbuf.p, part, np,
+                       scal);
+    if (c->ar_fn) {   // host-staged
+        if (n_peers > 0) {
+            if (!c->xchg_fn) return fail(c, FDAPDE_ENOTINIT, "fdapde_comm_set_exchange_callback not called");
+            c->xchg_send_h.resize((size_t)n_send), c->xchg_recv_h.resize((size_t)n_send);
+            HIPCHK(c, hipMemcpyAsync(c->xchg_send_h.data(), c->peer_sendbuf.p, sizeof(double) * (size_t)n_send, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            if (c->xchg_fn(c->xchg_user, n_peers, c->peer_rank.data(), c->peer_off.data(), c->xchg_send_h.data(), c->xchg_recv_h.data()) != 0)
+                return fail(c, FDAPDE_ERCCL, "exchange callback failed");
+            HIPCHK(c, hipMemcpyAsync(c->peer_recvbuf.p, c->xchg_recv_h.data(), sizeof(double) * (size_t)n_send, hipMemcpyHostToDevice, st));
+        }
+        if (int rc = allreduce_sum(c, scal, 2)) return rc;
+    } else {
+        if (n_peers > 0) {   // all sends and receives of the exchange form one group (one fused launch, no ordering between peers)
+            RCCLCHK(c, g_rccl.GroupStart());
+            for (int q = 0; q < n_peers; ++q) {
+                const size_t cnt = (size_t)(c->peer_off[(size_t)q + 1] - c->peer_off[(size_t)q]);
+                RCCLCHK(c, g_rccl.Send(c->peer_sendbuf.p + c->peer_off[(size_t)q], cnt, ncclFloat64, c->peer_rank[(size_t)q], c->comm, st));
+                RCCLCHK(c, g_rccl.Recv(c->peer_recvbuf.p + c->peer_off[(size_t)q], cnt, ncclFloat64, c->peer_rank[(size_t)q], c->comm, st));
+            }
+            RCCLCHK(c, g_rccl.GroupEnd());
+        }
+        RCCLCHK(c, g_rccl.AllReduce(scal, scal, 2, ncclFloat64, ncclSum, c->comm, st));
+    }
+    if (c->n_loc_if > 0)
+        hipLaunchKernelGGL(k_peer_sum, dim3(g1(c->n_loc_if)), dim3(256), 0, st, c->n_loc_if, c->halo_dof.p, c->peer_src_off.p, c->peer_src.p,
+                           c->peer_recvbuf.p, v, c->hbuf.p, unpack ? 1 : 0);
+    HIPCHK(c, hipGetLastError());
+    return FDAPDE_OK;
+}
 int halo_sum(fdapde_ctx* c, double* v, const double* part, int np, bool unpack = true) {
+    if (c->peer_mode) return halo_sum_peers(c, v, part, np, unpack);
     hipStream_t st = c->stream;
     const unsigned grid = g1(c->n_loc_if > 0 ? c->n_loc_if : 1);
     hipLaunchKernelGGL(k_halo_pack_all, dim3(g1(c->n_if > 0 ? c->n_if : 1)), dim3(256), 0, st, c->n_if, c->halo_inv.p, v, c->hbuf.p, part,
@@ -757,6 +796,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
         c->bc_off.release(), c->bn_off.release(), c->bc_cell.release(), c->bn_node.release(), c->bc_vert.release();
         c->halo_dof.release(), c->halo_pos.release(), c->owned.release(), c->hbuf.release(), c->sbuf.release();
         c->halo_inv.release(), c->if_slot.release();
+        c->peer_send_dof.release(), c->peer_src_off.release(), c->peer_src.release(), c->peer_sendbuf.release(), c->peer_recvbuf.release();
         if (c->comm) (void)g_rccl.CommDestroy(c->comm);
         c->lin_mat.release(), c->persist_stats.release(), c->coords_e.release();
         dev_topology_release(&c->topo);
@@ -2474,7 +2514,78 @@ int fdapde_halo_setup(fdapde_ctx* c, int64_t n_if_global, int64_t n_if_local, co
     HIPCHK(c, c->hbuf.alloc((size_t)n_if_global + 2));
     HIPCHK(c, c->sbuf.alloc(8));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->n_if = n_if_global, c->n_loc_if = n_if_local, c->halo_ready = true;
+    c->n_if = n_if_global, c->n_loc_if = n_if_local, c->halo_ready = true, c->peer_mode = false;
+    return FDAPDE_OK;
+}
+
+int fdapde_comm_set_exchange_callback(fdapde_ctx* c, fdapde_exchange_fn fn, void* user) {
+    if (!c || !fn) return FDAPDE_EINVAL;
+    c->xchg_fn = fn, c->xchg_user = user;
+    return FDAPDE_OK;
+}
+
+int fdapde_halo_setup_peers(fdapde_ctx* c, int32_t n_peers, const int32_t* peer_rank, const int64_t* peer_off, const int32_t* peer_dof,
+                            const uint8_t* owned) {
+    if (!c || n_peers < 0 || !owned || (n_peers > 0 && (!peer_rank || !peer_off || !peer_dof))) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (!c->dev_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
+    if (!c->comm && !c->ar_fn) return fail(c, FDAPDE_ENOTINIT, "call fdapde_comm_init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const HostSpace& hs = c->hs;
+    const int64_t n_send = n_peers > 0 ? peer_off[n_peers] : 0;
+    for (int q = 0; q < n_peers; ++q)
+        if (peer_rank[q] < 0 || peer_rank[q] >= c->world || peer_rank[q] == c->rank || (q > 0 && peer_rank[q] <= peer_rank[q - 1]) ||
+            peer_off[q + 1] < peer_off[q] || (q == 0 && peer_off[0] != 0))
+            return fail(c, FDAPDE_EINVAL, "peer list: ranks must be ascending, without this rank, offsets non-decreasing from 0");
+    std::vector<int32_t> send_dof((size_t)(n_send > 0 ? n_send : 1), 0);
+    std::vector<int32_t> k_of((size_t)hs.n_dofs, -1), if_dof;   // internal DOF -> local interface index
+    for (int64_t j = 0; j < n_send; ++j) {
+        if (peer_dof[j] < 0 || peer_dof[j] >= hs.n_dofs) return fail(c, FDAPDE_EINVAL, "peer list: DOF id out of range");
+        const int32_t d = hs.dof_e2i[(size_t)peer_dof[j]];
+        send_dof[(size_t)j] = d;
+        if (k_of[(size_t)d] < 0) k_of[(size_t)d] = (int32_t)if_dof.size(), if_dof.push_back(d);
+    }
+    const int64_t n_loc = (int64_t)if_dof.size();
+    // contributions of every local interface DOF in ascending rank order: the peers are ascending, this rank's own goes where its
+    // rank falls among them
+    std::vector<int32_t> cnt((size_t)n_loc + 1, 0);
+    for (int64_t j = 0; j < n_send; ++j) ++cnt[(size_t)k_of[(size_t)send_dof[(size_t)j]] + 1];
+    for (int64_t k = 0; k < n_loc; ++k) cnt[(size_t)k + 1] += cnt[(size_t)k] + 1;   // + 1: the own contribution
+    std::vector<int32_t> src_off(cnt), src((size_t)(n_send + n_loc > 0 ? n_send + n_loc : 1), 0), fill_at(cnt.begin(), cnt.end() - 1);
+    std::vector<uint8_t> own_in((size_t)n_loc, 0);
+    for (int q = 0; q < n_peers; ++q) {
+        for (int64_t j = peer_off[q]; j < peer_off[q + 1]; ++j) {
+            const int32_t k = k_of[(size_t)send_dof[(size_t)j]];
+            if (peer_rank[q] > c->rank && !own_in[(size_t)k]) src[(size_t)fill_at[(size_t)k]++] = -1, own_in[(size_t)k] = 1;
+            src[(size_t)fill_at[(size_t)k]++] = (int32_t)j;
+        }
+    }
+    for (int64_t k = 0; k < n_loc; ++k)
+        if (!own_in[(size_t)k]) src[(size_t)fill_at[(size_t)k]++] = -1;
+    for (int64_t k = 0; k < n_loc; ++k)
+        if (fill_at[(size_t)k] != src_off[(size_t)k + 1]) return fail(c, FDAPDE_EINVAL, "peer list: a DOF is listed twice for one peer");
+    std::vector<uint8_t> own_i((size_t)hs.n_dofs);
+    for (int64_t i = 0; i < hs.n_dofs; ++i) own_i[(size_t)i] = owned[hs.dof_i2e[(size_t)i]] ? 1 : 0;
+    std::vector<int32_t> slot((size_t)hs.n_dofs + 2, -1), pos((size_t)(n_loc > 0 ? n_loc : 1), 0);
+    for (int64_t k = 0; k < n_loc; ++k) slot[(size_t)if_dof[(size_t)k]] = (int32_t)k, pos[(size_t)k] = (int32_t)k;
+    if (if_dof.empty()) if_dof.push_back(0);
+    hipStream_t st = c->stream;
+    HIPCHK(c, c->peer_send_dof.upload(send_dof.data(), send_dof.size(), st));
+    HIPCHK(c, c->peer_src_off.upload(src_off.data(), src_off.size(), st));
+    HIPCHK(c, c->peer_src.upload(src.data(), src.size(), st));
+    HIPCHK(c, c->peer_sendbuf.alloc((size_t)(n_send > 0 ? n_send : 1)));
+    HIPCHK(c, c->peer_recvbuf.alloc((size_t)(n_send > 0 ? n_send : 1)));
+    HIPCHK(c, c->if_slot.upload(slot.data(), slot.size(), st));
+    HIPCHK(c, c->halo_dof.upload(if_dof.data(), if_dof.size(), st));
+    HIPCHK(c, c->halo_pos.upload(pos.data(), pos.size(), st));
+    HIPCHK(c, c->owned.upload(own_i.data(), own_i.size(), st));
+    HIPCHK(c, c->hbuf.alloc((size_t)n_loc + 2));
+    HIPCHK(c, c->sbuf.alloc(8));
+    HIPCHK(c, hipStreamSynchronize(st));
+    c->peer_rank.assign(peer_rank, peer_rank + n_peers);
+    c->peer_off.assign(1, 0);
+    if (n_peers > 0) c->peer_off.assign(peer_off, peer_off + n_peers + 1);
+    c->n_if = n_loc, c->n_loc_if = n_loc, c->peer_mode = true, c->halo_ready = true;
     return FDAPDE_OK;
 }
 

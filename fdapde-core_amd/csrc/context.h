@@ -65,6 +65,10 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool load(std::string& err) {
         if (handle) return true;
@@ -81,7 +85,11 @@ struct RcclApi {
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(handle, "ncclCommDestroy"));
         AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(handle, "ncclAllReduce"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(handle, "ncclGetErrorString"));
-        if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GetErrorString) {
+        Send = reinterpret_cast<decltype(Send)>(dlsym(handle, "ncclSend"));
+        Recv = reinterpret_cast<decltype(Recv)>(dlsym(handle, "ncclRecv"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(handle, "ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(handle, "ncclGroupEnd"));
+        if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce || !GetErrorString || !Send || !Recv || !GroupStart || !GroupEnd) {
             err = "librccl lacks a required symbol";
             return false;
         }
@@ -211,6 +219,17 @@ struct fdapde_ctx {
     DBuf<int32_t> halo_inv, if_slot;         // global slot -> local DOF or -1 [n_if]; local DOF -> global slot or -1 [n_dofs]
     DBuf<uint8_t> owned;                     // internal DOF order: 1 = this rank counts the DOF in global dot products
     DBuf<double> hbuf, sbuf;                 // [n_if + 2] packed interface values + fused dot partials; [4] scalars
+    // neighbour-only exchange (fdapde_halo_setup_peers): in this mode n_if = n_loc_if, hbuf[k] = summed value of local interface DOF k
+    bool peer_mode = false;
+    fdapde_exchange_fn xchg_fn = nullptr;    // host-staged transport of the neighbour exchange (tests / non-RCCL fabrics)
+    void* xchg_user = nullptr;
+    std::vector<int32_t> peer_rank;          // ranks this one shares DOFs with, ascending
+    std::vector<int64_t> peer_off;           // [n_peers + 1] segment of each peer in the send / receive buffers
+    DBuf<int32_t> peer_send_dof;             // [n_send] internal DOF id of every send-buffer entry
+    DBuf<int32_t> peer_src_off, peer_src;    // per local interface DOF: its contributions in ascending rank order (-1 = this rank's own,
+                                             // else index into the receive buffer)
+    DBuf<double> peer_sendbuf, peer_recvbuf;
+    std::vector<double> xchg_send_h, xchg_recv_h;
     // "factor once, solve many" handle (fdapde::SparseLU wrapper, utils/symbols.h:133-160)
     DBuf<double> lin_mat;                    // the matrix handed to fdapde_lin_compute, internal slots
     bool lin_ready = false, lin_symmetric = false;

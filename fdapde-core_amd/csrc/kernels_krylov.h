@@ -740,6 +740,34 @@ __global__ __launch_bounds__(256) void k_halo_pack_all(int64_t n_if, const int32
         if (threadIdx.x == 0) buf[n_if] = sa, buf[n_if + 1] = sb;
     }
 }
+// neighbour-only exchange: send buffer = this rank's sub-assembled values at the DOFs it shares, one segment per peer; block 0 also
+// folds the SpMV's fused dot partials (as k_halo_pack_all)
+__global__ __launch_bounds__(256) void k_peer_pack(int64_t n_send, const int32_t* send_dof, const double* v, double* sendbuf, const double* part,
+                                                    int np, double* scal) {
+    __shared__ double red[8];
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_send) sendbuf[j] = v[send_dof[j]];
+    if (blockIdx.x == 0) {
+        double a = 0, b = 0;
+        if (part != nullptr)
+            for (int k = threadIdx.x; k < np; k += blockDim.x) a += part[2 * k], b += part[2 * k + 1];
+        const double sa = block_sum(a, red);
+        const double sb = block_sum(b, red);
+        if (threadIdx.x == 0) scal[0] = sa, scal[1] = sb;
+    }
+}
+// summed value of every local interface DOF: the contributions of the ranks sharing it added in ASCENDING RANK ORDER (this rank's own
+// among them), so that every sharer computes the same bits; buf[k] for the kernels that read interface rows from there, v on request
+__global__ void k_peer_sum(int64_t n_loc_if, const int32_t* dof, const int32_t* src_off, const int32_t* src, const double* recvbuf, double* v,
+                           double* buf, int write_v) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_loc_if) return;
+    const int32_t d = dof[k];
+    double s = 0.0;
+    for (int32_t q = src_off[k]; q < src_off[k + 1]; ++q) s += src[q] < 0 ? v[d] : recvbuf[src[q]];
+    buf[k] = s;
+    if (write_v) v[d] = s;
+}
 __global__ void k_halo_unpack(int64_t n_loc_if, const int32_t* dof, const int32_t* pos, const double* buf, double* v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_loc_if) v[dof[i]] = buf[pos[i]];

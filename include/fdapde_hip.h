@@ -235,6 +235,21 @@ int fdapde_comm_unique_id(void *out128);
 int fdapde_comm_init(fdapde_ctx *ctx, int32_t world, int32_t rank, const void *unique_id128);
 int fdapde_halo_setup(fdapde_ctx *ctx, int64_t n_if_global, int64_t n_if_local, const int32_t *local_dof,
                       const int32_t *if_index, const uint8_t *owned);
+/* Neighbour-only exchange instead of the dense interface vector of fdapde_halo_setup: per operator application a rank sends each
+ * PEER (a rank it shares DOFs with) its sub-assembled values at the shared DOFs and receives the peer's, in one grouped RCCL call
+ * (ncclSend / ncclRecv per peer), followed by an all-reduce of the two fused dot partials; message size = shared DOFs x 8 bytes per peer, not
+ * the whole interface.  peer_rank: n_peers ranks, ascending, without this one; peer_off [n_peers + 1]: segment of each peer in
+ * peer_dof; peer_dof: DOF ids (reference numbering of this rank's sub-mesh) shared with the peer -- BOTH ranks of a pair must list their
+ * shared DOFs in the same order (e.g. ascending global key).  A DOF shared by k ranks appears in the lists of all k - 1 peers; its
+ * contributions are added in ascending rank order on every sharer, so all of them hold the same bits.  owned as in fdapde_halo_setup.
+ * Over the host-staged transport (fdapde_comm_init_callback) the exchange itself goes through fdapde_comm_set_exchange_callback's fn:
+ * fn(user, n_peers, peer_rank, peer_off, send, recv) must deliver send[peer_off[q] .. peer_off[q + 1]) to rank peer_rank[q] and fill the
+ * same segment of recv with what that rank sent to this one; return 0. */
+typedef int (*fdapde_exchange_fn)(void *user, int32_t n_peers, const int32_t *peer_rank, const int64_t *peer_off, const double *send,
+                                  double *recv);
+int fdapde_comm_set_exchange_callback(fdapde_ctx *ctx, fdapde_exchange_fn fn, void *user);
+int fdapde_halo_setup_peers(fdapde_ctx *ctx, int32_t n_peers, const int32_t *peer_rank, const int64_t *peer_off,
+                            const int32_t *peer_dof, const uint8_t *owned);
 
 /* tuning / diagnostic knobs (A/B measurements inside one process; defaults are the measured best):
  *   SpMV launch   "spmv_variant" (2 pair form, 0 team form, 1 stream form), "spmv_team", "spmv_unroll", "spmv_bpx" (workgroups

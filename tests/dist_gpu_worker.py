@@ -1,10 +1,11 @@
 """Worker of tests/test_gpu_dist.py: one rank of a 2- or 3-rank job in which ALL ranks share GPU 0.  The device-side
 distributed path (sub-assembly, interface pack / all-reduce / unpack, owner-masked dots, stop decisions) is the product's;
-only the all-reduce transport is swapped for a host-staged torch.distributed/gloo callback, because RCCL refuses two ranks on
-one device.  Results are compared with a single-domain run of the whole mesh on the same GPU.
+only the transport (neighbour exchange + scalar all-reduce, or the dense interface all-reduce) is swapped for host-staged
+torch.distributed/gloo callbacks, because RCCL refuses two ranks on one device.  Results are compared with a single-domain run of the whole mesh on the same GPU.
 cases: p1 | p2 | sq2 (2-D P2: interface edges must not become Dirichlet) | adr1 | adr2 (BiCGStab) | parab | handle
 transport (argv[6]): "shared" (default: all ranks on GPU 0, host-staged gloo all-reduce) | "rccl" (rank r on GPU r, the library's
-own RCCL communicator over xGMI -- the product configuration; needs >= world GPUs)"""
+own RCCL communicator over xGMI -- the product configuration; needs >= world GPUs)
+exchange (argv[7]): "peers" (default: fdapde_halo_setup_peers, per-peer packed send / receive) | "dense" (fdapde_halo_setup)"""
 import os
 import sys
 
@@ -18,6 +19,7 @@ def main():
     rank, world, port, nx = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
     case = sys.argv[5] if len(sys.argv) > 5 else "p1"
     transport = sys.argv[6] if len(sys.argv) > 6 else "shared"
+    exchange_mode = sys.argv[7] if len(sys.argv) > 7 else "peers"   # "peers": neighbour-only exchange | "dense": interface all-reduce
     dev_id = rank if transport == "rccl" else 0
     import torch
     import torch.distributed as dist
@@ -58,7 +60,28 @@ def main():
         ctx.comm_init(world, rank, uid[0])
     else:
         ctx.comm_init_callback(world, rank, allreduce)
-    ctx.halo_setup(maps["n_if_global"], maps["local_dof"], maps["if_index"], maps["owned"])
+
+    def exchange(ranks, off, send, recv):   # host-staged neighbour exchange over gloo: one isend + one irecv per peer
+        reqs, parts = [], []
+        for q, r in enumerate(ranks):
+            a, b = int(off[q]), int(off[q + 1])
+            t_out, t_in = torch.from_numpy(send[a:b].copy()), torch.empty(b - a, dtype=torch.float64)
+            reqs.append(dist.isend(t_out, int(r)))
+            reqs.append(dist.irecv(t_in, int(r)))
+            parts.append((a, b, t_in, t_out))
+        for rq in reqs:
+            rq.wait()
+        for a, b, t_in, _ in parts:
+            recv[a:b] = t_in.numpy()
+
+    if exchange_mode == "peers":
+        pr, po, pd = fdist.peer_lists(maps["keys"], fdist.rank_key_sets(cells, part, n_g, world, order), rank)
+        assert pr.size >= 1 and (world > 2 or pr.size == 1)
+        if transport != "rccl":
+            ctx.comm_set_exchange_callback(exchange)
+        ctx.halo_setup_peers(pr, po, pd, maps["owned"])
+    else:
+        ctx.halo_setup(maps["n_if_global"], maps["local_dof"], maps["if_index"], maps["owned"])
     # single-domain context of the whole mesh (every rank builds it; same GPU)
     ref = capi.Context(device=dev_id)
     ref.mesh_upload(nodes, cells, bnd)

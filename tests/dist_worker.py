@@ -66,6 +66,45 @@ def main():
     dist.all_reduce(ncell)
     assert int(ncell) == cells.shape[0]
 
+    # ---- neighbour-only exchange lists (fdapde_halo_setup_peers): symmetric per pair, and the rank-ordered sum over real isend / irecv
+    #      equals the dense interface all-reduce, with identical bits on every rank sharing a DOF
+    pr, po, pd = fdist.peer_lists(lp["keys"], fdist.rank_key_sets(cells, part, nodes.shape[0], world, order), rank)
+    assert pr.size >= 1 and np.all(np.diff(pr) > 0) and rank not in pr and po[0] == 0 and po[-1] == pd.size
+    assert set(pd.tolist()) == set(lp["local_dof"].tolist())          # every interface DOF is shared with somebody, and nothing else is
+    v_loc = np.random.default_rng(100 + rank).standard_normal(lp["keys"].size)
+    send, recv = v_loc[pd].copy(), np.empty(pd.size)
+    reqs, parts = [], []
+    for q, r in enumerate(pr):
+        a, b_ = int(po[q]), int(po[q + 1])
+        kq = torch.from_numpy(lp["keys"][pd[a:b_]].copy())               # the keys travel too: both sides must list the same DOFs in the same order
+        t_out, t_in, k_in = torch.from_numpy(send[a:b_].copy()), torch.empty(b_ - a, dtype=torch.float64), torch.empty(b_ - a, dtype=torch.int64)
+        reqs += [dist.isend(t_out, int(r), tag=1), dist.irecv(t_in, int(r), tag=1), dist.isend(kq, int(r), tag=2), dist.irecv(k_in, int(r), tag=2)]
+        parts.append((a, b_, t_in, k_in, kq, t_out))
+    for rq in reqs:
+        rq.wait()
+    for a, b_, t_in, k_in, kq, _ in parts:
+        assert torch.equal(k_in, kq)
+        recv[a:b_] = t_in.numpy()
+    summed = {}
+    for d in np.unique(pd):                                              # contributions in ascending rank order, own among them
+        terms = sorted([(int(pr[np.searchsorted(po, j, side="right") - 1]), float(recv[j])) for j in np.nonzero(pd == d)[0]] + [(rank, float(v_loc[d]))])
+        acc = 0.0
+        for _, val in terms:
+            acc += val
+        summed[int(d)] = acc
+    dense = torch.zeros(lp["n_if_global"], dtype=torch.float64)
+    dense[torch.from_numpy(lp["if_index"].astype(np.int64))] = torch.from_numpy(v_loc[lp["local_dof"]])
+    dist.all_reduce(dense)
+    mine = np.array([summed[int(d)] for d in lp["local_dof"]])
+    assert np.abs(mine - dense.numpy()[lp["if_index"]]).max() <= 1e-14
+    hi = torch.full((lp["n_if_global"],), -np.inf, dtype=torch.float64)
+    lo = torch.full((lp["n_if_global"],), np.inf, dtype=torch.float64)
+    hi[torch.from_numpy(lp["if_index"].astype(np.int64))] = torch.from_numpy(mine)
+    lo[torch.from_numpy(lp["if_index"].astype(np.int64))] = torch.from_numpy(mine)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    assert torch.equal(hi, lo), "every rank sharing a DOF must hold the same bits"
+
     # ---- local sub-assembled operators (oracle on the sub-mesh of this rank's cells)
     bvec = np.array([1.0, 0.5, 0.25])[:N]
     mkop = (lambda: -o.laplacian()) if opk == "lap" else (lambda: -o.laplacian() + o.advection(bvec) + o.reaction(1.0))

@@ -34,11 +34,11 @@ def _free_port():
         return str(s.getsockname()[1])
 
 
-def _run_ranks(world, nx, case, transport):
+def _run_ranks(world, nx, case, transport, exchange="peers"):
     port = _free_port()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_gpu_worker.py"), str(r), str(world), port, str(nx), case,
-                               transport], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(world)]
+                               transport, exchange], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(world)]
     outs = []
     for p in procs:
         try:
@@ -56,7 +56,14 @@ def _run_ranks(world, nx, case, transport):
 @pytest.mark.parametrize("world,nx,case", [(2, 12, "p1"), (3, 10, "p1"), (2, 8, "p2"), (3, 20, "sq2"), (2, 10, "adr1"), (3, 7, "adr2"),
                                            (2, 9, "parab"), (2, 9, "handle")])
 def test_partitioned_device_solve_matches_single_domain(world, nx, case):
+    """neighbour-only exchange (fdapde_halo_setup_peers): per-peer packed segments, contributions summed in rank order"""
     _run_ranks(world, nx, case, "shared")
+
+
+@pytest.mark.parametrize("world,nx,case", [(2, 12, "p1"), (3, 10, "p1"), (3, 7, "adr2"), (2, 9, "parab")])
+def test_partitioned_device_solve_dense_interface_allreduce(world, nx, case):
+    """the round-1 exchange (fdapde_halo_setup: one all-reduce of the whole interface vector) stays available"""
+    _run_ranks(world, nx, case, "shared", "dense")
 
 
 @pytest.mark.parametrize("world,nx,case", [(2, 24, "p1"), (2, 8, "p2"), (2, 10, "adr1"), (2, 9, "parab"), (2, 9, "handle"), (4, 24, "p1"),
@@ -67,6 +74,22 @@ def test_partitioned_solve_over_real_rccl(world, nx, case):
     if _n_gpus() < world:
         pytest.skip(f"needs {world} GPUs, this box has {_n_gpus()}")
     _run_ranks(world, nx, case, "rccl")
+
+
+def test_bench_multi_gpu_leg_plumbing_on_one_gpu():
+    """bench.py --gpus 2 under torch.distributed.run with FDAPDE_BENCH_BACKEND=gloo: both ranks share GPU 0 and the exchange is
+    host-staged, everything else -- partition, neighbour lists, the device-side pack / sum kernels, the JSON line -- is what the
+    driver's real launch runs"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FDAPDE_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--nx", "24",
+           "--no-cpu-baseline", "--no-extra"]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["relres"] <= 1e-10
+    assert "bytes sent per rank" in rec["config"]["parallelism"]
+    assert rec["config"]["max_abs_error_vs_analytic"] < 6.0 * (1.0 / 24) ** 2 * 3.15**2
 
 
 @pytest.mark.parametrize("gpus", [2, 8])

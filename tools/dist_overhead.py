@@ -14,6 +14,7 @@ ctx.set_operator(-capi.laplacian()); ctx.set_forcing(f(ctx.quadrature_nodes()));
 for _ in range(2):
     a = ctx.solve(rtol=1e-10)
 print(f"plain (fused CG)      : {a.iters} iterations, {a.t_solve_ms:.2f} ms = {a.t_solve_ms / a.iters * 1e3:.1f} us / iteration")
+ctx.tune("persist", 0)   # the multi-launch kernels on the compact solver pattern, as the partitioned path uses them
 b = ctx.solve(rtol=1e-10, method=capi.SOLVER_CG_SR)
 b = ctx.solve(rtol=1e-10, method=capi.SOLVER_CG_SR)
 print(f"single-reduction CG   : {b.iters} iterations, {b.t_solve_ms:.2f} ms = {b.t_solve_ms / b.iters * 1e3:.1f} us / iteration")
@@ -23,3 +24,10 @@ ctx.halo_setup(n_if, local, np.arange(n_if, dtype=np.int32), np.ones(nd, dtype=n
 for _ in range(2):   # world > 1 selects the single-reduction form; on one rank it has to be asked for
     d = ctx.solve(rtol=1e-10, method=capi.SOLVER_CG_SR)
 print(f"1-rank RCCL, n_if {n_if}: {d.iters} iterations, {d.t_solve_ms:.2f} ms = {d.t_solve_ms / d.iters * 1e3:.1f} us / iteration (method {d.method_used})")
+# neighbour-only exchange (fdapde_halo_setup_peers): on ONE rank there is no peer, what remains per iteration is the pack / sum launches
+# on empty lists and the grouped RCCL call with the all-reduce of the two scalars
+ctx.halo_setup_peers(np.zeros(0, dtype=np.int32), np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32), np.ones(nd, dtype=np.uint8))
+for _ in range(2):
+    e = ctx.solve(rtol=1e-10, method=capi.SOLVER_CG_SR)
+print(f"1-rank RCCL, neighbour-only exchange (no peer): {e.iters} iterations, {e.t_solve_ms:.2f} ms = {e.t_solve_ms / e.iters * 1e3:.1f} us / iteration "
+      f"(overhead over the single-reduction CG {(e.t_solve_ms / e.iters - b.t_solve_ms / b.iters) * 1e3:.1f} us; dense form {(d.t_solve_ms / d.iters - b.t_solve_ms / b.iters) * 1e3:.1f} us)")

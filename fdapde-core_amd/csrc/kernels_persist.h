@@ -385,7 +385,7 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
             double v = 0;
 #pragma unroll
             for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
-            publish_f64(dslot + (size_t)g * 6 + 2 * tid, epoch, v);
+            publish_f64_x4(dslot + (size_t)g * 6 + 2 * tid, epoch, v);
         }
         {   // thread t collects workgroup t's three sums (a lane re-reads its record until all six tags match, then stops loading); every
             // workgroup adds the G records in the same order.  A two-level form (groups of 8 / 16 / 32 workgroups handled by one wavefront,

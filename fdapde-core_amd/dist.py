@@ -11,6 +11,9 @@ every rank keeps the reference's enumeration on its own sub-mesh.
 """
 from __future__ import annotations
 
+import os
+import sys
+
 import numpy as np
 
 
@@ -186,7 +189,11 @@ def bench_partitioned(capi, nodes, cells, bnd, f, u_exact, rank, world, local_ra
         ctx.comm_set_exchange_callback(exchange)
     # neighbour-only exchange: per-peer packed segments (ncclSend / ncclRecv in one group), then the scalar all-reduce
     pr, po, pd = peer_lists(lp["keys"], rank_key_sets(cells, part, nodes.shape[0], world, 1), rank)
-    ctx.halo_setup_peers(pr, po, pd, lp["owned"])
+    exchange_form = os.environ.get("FDAPDE_BENCH_EXCHANGE", "peers")   # "dense": the interface all-reduce of fdapde_halo_setup
+    if exchange_form == "peers":
+        ctx.halo_setup_peers(pr, po, pd, lp["owned"])
+    else:
+        ctx.halo_setup(lp["n_if_global"], lp["local_dof"], lp["if_index"], lp["owned"])
     msg = torch.tensor([float(8 * int(po[-1])), float(pr.size)], dtype=torch.float64, device=dev)   # bytes sent per exchange, peers
     dist.all_reduce(msg, op=dist.ReduceOp.MAX)
     qn = ctx.quadrature_nodes()
@@ -199,6 +206,20 @@ def bench_partitioned(capi, nodes, cells, bnd, f, u_exact, rank, world, local_ra
     def step(time_spmv=0):
         ctx.init()
         return ctx.solve(rtol=rtol, time_spmv=time_spmv)
+
+    if exchange_form == "peers":   # one probe solve: if the grouped send / receive is refused on this fabric on ANY rank, all ranks fall
+                                   # back to the dense interface all-reduce together (a collective decision)
+        bad = 0
+        try:
+            step()
+        except capi.FdapdeError as e:
+            bad = 1
+            print(f"rank {rank}: neighbour-only exchange failed ({e}); falling back to the dense interface all-reduce", file=sys.stderr)
+        flag = torch.tensor([float(bad)], dtype=torch.float64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if flag.item() > 0:
+            exchange_form = "dense"
+            ctx.halo_setup(lp["n_if_global"], lp["local_dof"], lp["if_index"], lp["owned"])
 
     for _ in range(args.warmup):
         step()
@@ -220,6 +241,12 @@ def bench_partitioned(capi, nodes, cells, bnd, f, u_exact, rank, world, local_ra
     nnz_tot = torch.tensor([float(sizes["nnz"]), alg_bytes], dtype=torch.float64, device=dev)
     dist.all_reduce(nnz_tot, op=dist.ReduceOp.MAX)       # the largest local matrix bounds the SpMV roofline figure
     sizes = dict(sizes, nnz=int(nnz_tot[0].item()))
+    if exchange_form == "dense":
+        parallelism = (f"{world} GPUs, element partition (Morton chunks), {lp['n_if_global']} interface DOFs, single-reduction CG: ONE RCCL "
+                       f"all-reduce per iteration (interface entries of A r + r.Ar + r.r: {8 * (lp['n_if_global'] + 2)} bytes); roofline figures "
+                       "are the largest rank-local SpMV")
+        return (float(elapsed.item()), info, float(stats[0].item()), float(stats[1].item()), float(stats[2].item()),
+                float(err.item()), float(stats[3].item()), float(nnz_tot[1].item()), sizes, int(nodes.shape[0]), parallelism)
     parallelism = (f"{world} GPUs, element partition (Morton chunks), {lp['n_if_global']} interface DOFs; single-reduction CG, per "
                    f"iteration one grouped RCCL send / receive with every neighbour -- the interface entries of A r, <= {int(msg[1].item())} peers, "
                    f"<= {int(msg[0].item())} bytes sent per rank -- and one 16-byte all-reduce of (r.Ar, r.r); roofline figures are the largest "

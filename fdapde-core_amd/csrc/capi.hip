@@ -1228,11 +1228,11 @@ int build_solver_pattern(fdapde_ctx* c, int v) {
 }
 
 // FDAPDE_SETUP_CHECK: the device-built persistent layout against the host builder's
-int check_dev_persist(fdapde_ctx* c, int v, const PersistLayout& pl, const DevPersist& dp, const std::vector<int32_t>* block_rows) {
+int check_dev_persist(fdapde_ctx* c, int v, const PersistLayout& pl, const DevPersist& dp, const std::vector<int32_t>* block_rows, bool balance) {
     if (int rc = ensure_host(c, kHostPattern)) return rc;
     PersistLayout ref;
     if (host_build_persist_layout(c->hs, v == 1, block_rows ? (int)block_rows->size() : c->n_cu, 12000, ref, block_rows ? block_rows->data() : nullptr,
-                                  pl.sym ? 1 : 0, c->persist_balance != 0) != FDAPDE_OK) return fail(c, FDAPDE_EHIP, "set-up check: host persistent layout failed");
+                                  pl.sym ? 1 : 0, balance) != FDAPDE_OK) return fail(c, FDAPDE_EHIP, "set-up check: host persistent layout failed");
     int bad = 0;
     auto scalar = [&](const char* name, int64_t a, int64_t b) {
         if (a != b) std::fprintf(stderr, "persist check %-9s: MISMATCH %lld vs %lld\n", name, (long long)a, (long long)b), ++bad;
@@ -1264,7 +1264,7 @@ int check_dev_persist(fdapde_ctx* c, int v, const PersistLayout& pl, const DevPe
 // resident layout of the persistent CG for boundary variant v (kernels_persist.h): host index work + uploads, once per function
 // space and boundary mask.  ok stays false when the system does not qualify (too many rows for one launch of resident
 // workgroups, or more matrix than is worth re-reading from the caches every iteration).
-int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_rows) {
+int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_rows, bool balance) {
     fdapde_ctx::Persist& ps = c->ps[v];
     ps.ok = false;
     if (c->n_cu < 1) return FDAPDE_OK;
@@ -1288,12 +1288,12 @@ int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_r
         int rc = FDAPDE_EUNSUPPORTED;
         if (on_device) {   // the layout is built where the pattern lives (dev_persist.hip)
             rc = dev_build_persist_layout(c->hs.n_dofs, c->hs.max_row, c->rowptr.p, c->colidx.p, c->bnd.p, v == 1, n_wg, 12000, 0, brows, sym_mode,
-                                          c->persist_balance != 0, c->stream, pl, &dp, c->err);
+                                          balance, c->stream, pl, &dp, c->err);
             if (rc == FDAPDE_EUNSUPPORTED && c->hs.max_row > 255) on_device = false;   // rows too long for its sort keys: host builder
         }
         if (!on_device) {
             if (int rc2 = ensure_host(c, kHostPattern)) return rc2;
-            rc = host_build_persist_layout(c->hs, v == 1, n_wg, 12000, pl, brows, sym_mode, c->persist_balance != 0);   // ~12 000 ELL entries (120 KB) next to the vectors of <= 4096 rows
+            rc = host_build_persist_layout(c->hs, v == 1, n_wg, 12000, pl, brows, sym_mode, balance);   // ~12 000 ELL entries (120 KB) next to the vectors of <= 4096 rows
         }
         if (rc == FDAPDE_EUNSUPPORTED) return FDAPDE_OK;
         if (rc) return rc;
@@ -1325,7 +1325,7 @@ int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_r
     hipStream_t st = c->stream;
     if (on_device) {
         if (std::getenv("FDAPDE_SETUP_CHECK")) {
-            if (int rc2 = check_dev_persist(c, v, pl, dp, block_rows)) {
+            if (int rc2 = check_dev_persist(c, v, pl, dp, block_rows, balance)) {
                 dev_persist_release(&dp);
                 return rc2;
             }
@@ -1410,7 +1410,11 @@ int build_persist(fdapde_ctx* c, int v) {
     fdapde_ctx::Persist& ps = c->ps[v];
     if (ps.tried) return FDAPDE_OK;
     ps.tried = true;
-    return build_persist_once(c, v, nullptr);
+    if (int rc = build_persist_once(c, v, nullptr, c->persist_balance != 0)) return rc;
+    // boundaries at equal cost can leave one workgroup with more rows that import than its import-free passes have room for
+    // where equal row counts would not: the system must not lose the single-launch path over that
+    if (!ps.ok && c->persist_balance) return build_persist_once(c, v, nullptr, false);
+    return FDAPDE_OK;
 }
 
 // the whole fused-update CG as one launch; returns FDAPDE_OK with *ran = false when the launch gave up (hand-off timeout)

@@ -386,6 +386,7 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
                 if (h_wgs[(size_t)g + 1] <= h_wgs[(size_t)g]) uniform = true;   // an empty workgroup (tiny systems): equal row counts
                 mx = std::max<int64_t>(mx, h_wgs[(size_t)g + 1] - h_wgs[(size_t)g]);
             }
+            if (mx > (int64_t)kPersistRmax * T && rpw <= (int64_t)kPersistRmax * T) uniform = true;   // equal counts fit a workgroup, equal cost would not
             if (!uniform) rpw = mx;
         }
         if (uniform) {

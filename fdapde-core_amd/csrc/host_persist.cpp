@@ -88,6 +88,7 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
                 if (wgs[(size_t)q + 1] <= wgs[(size_t)q]) uniform = true;   // an empty workgroup (tiny systems): equal row counts
                 mx = std::max(mx, wgs[(size_t)q + 1] - wgs[(size_t)q]);
             }
+            if (mx > (int64_t)kPersistRmax * T && rpw <= (int64_t)kPersistRmax * T) uniform = true;   // equal counts fit a workgroup, equal cost would not
             if (!uniform) rpw = mx;
         }
         if (uniform) {

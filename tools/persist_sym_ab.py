@@ -13,7 +13,7 @@ for dim, nx in cases:
     nodes, cells, bnd = meshgen.unit_square(nx) if dim == 2 else meshgen.unit_cube(nx)
     _, f = meshgen.manufactured(dim)
     c = capi.Context(0)
-    c.mesh_upload(nodes, cells, bnd); nd = c.dofs_build(1)
+    c.mesh_upload(nodes, cells, bnd); nd = c.dofs_build(int(os.environ.get("ORDER", "1")))
     c.set_operator(-capi.laplacian()); c.set_forcing(f(c.quadrature_nodes())); c.set_dirichlet(np.zeros(nd)); c.init()
     s = c.sizes(); alg = 12 * s["nnz"] + 4 * (nd + 1) + 16 * nd
     sols = {}

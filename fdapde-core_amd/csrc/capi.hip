@@ -2557,17 +2557,18 @@ int fdapde_halo_setup_peers(fdapde_ctx* c, int32_t n_peers, const int32_t* peer_
     for (int64_t k = 0; k < n_loc; ++k) cnt[(size_t)k + 1] += cnt[(size_t)k] + 1;   // + 1: the own contribution
     std::vector<int32_t> src_off(cnt), src((size_t)(n_send + n_loc > 0 ? n_send + n_loc : 1), 0), fill_at(cnt.begin(), cnt.end() - 1);
     std::vector<uint8_t> own_in((size_t)n_loc, 0);
+    std::vector<int32_t> last_peer((size_t)n_loc, -1);
     for (int q = 0; q < n_peers; ++q) {
         for (int64_t j = peer_off[q]; j < peer_off[q + 1]; ++j) {
             const int32_t k = k_of[(size_t)send_dof[(size_t)j]];
+            if (last_peer[(size_t)k] == q) return fail(c, FDAPDE_EINVAL, "peer list: a DOF is listed twice for one peer");
+            last_peer[(size_t)k] = q;
             if (peer_rank[q] > c->rank && !own_in[(size_t)k]) src[(size_t)fill_at[(size_t)k]++] = -1, own_in[(size_t)k] = 1;
             src[(size_t)fill_at[(size_t)k]++] = (int32_t)j;
         }
     }
     for (int64_t k = 0; k < n_loc; ++k)
         if (!own_in[(size_t)k]) src[(size_t)fill_at[(size_t)k]++] = -1;
-    for (int64_t k = 0; k < n_loc; ++k)
-        if (fill_at[(size_t)k] != src_off[(size_t)k + 1]) return fail(c, FDAPDE_EINVAL, "peer list: a DOF is listed twice for one peer");
     std::vector<uint8_t> own_i((size_t)hs.n_dofs);
     for (int64_t i = 0; i < hs.n_dofs; ++i) own_i[(size_t)i] = owned[hs.dof_i2e[(size_t)i]] ? 1 : 0;
     std::vector<int32_t> slot((size_t)hs.n_dofs + 2, -1), pos((size_t)(n_loc > 0 ? n_loc : 1), 0);

@@ -204,3 +204,30 @@ def test_pure_advection_zero_diagonal(capi):
         bz = c.force()
         assert np.linalg.norm(Az @ u - bz) <= 1e-7 * np.linalg.norm(bz)
     c.close()
+
+
+def test_peer_lists_are_validated(capi):
+    """fdapde_halo_setup_peers refuses lists that cannot describe a neighbour exchange (and says why) instead of hanging in it"""
+    from fdapde_core_amd import meshgen
+
+    nodes, cells, bnd = meshgen.unit_square(6)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(1)
+    owned = np.ones(nd, dtype=np.uint8)
+    with pytest.raises(capi.FdapdeError) as e:   # no communicator yet
+        c.halo_setup_peers([1], [0, 2], [0, 1], owned)
+    assert e.value.status == capi.ENOTINIT
+    c.comm_init_callback(3, 1, lambda arr: None)
+    for ranks, off, dofs in (([1], [0, 2], [0, 1]),            # this rank among its peers
+                             ([2, 0], [0, 1, 2], [0, 1]),      # not ascending
+                             ([0, 3], [0, 1, 2], [0, 1]),      # rank outside the communicator
+                             ([0], [0, 2], [0, nd]),           # DOF id out of range
+                             ([0], [0, 2], [3, 3]),            # a DOF listed twice for one peer
+                             ([0], [1, 2], [0, 1])):           # offsets not starting at 0
+        with pytest.raises(capi.FdapdeError) as e:
+            c.halo_setup_peers(ranks, off, dofs, owned)
+        assert e.value.status == capi.EINVAL, (ranks, off, dofs)
+    c.halo_setup_peers([0, 2], [0, 2, 3], [0, 1, 1], owned)     # a DOF shared with two peers is fine
+    c.halo_setup_peers([], [0], [], owned)                       # and so is a rank without neighbours
+    c.close()

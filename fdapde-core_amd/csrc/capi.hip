@@ -362,6 +362,7 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
         if (tab + acc > (size_t)c->lds_limit) acc = tab < (size_t)c->lds_limit ? (size_t)c->lds_limit - tab : 0;
         a.lds_acc_cap = (int32_t)(acc / sizeof(double));
         if (a.fq != nullptr && a.fq == c->fq.p && c->fq_blk_ready) a.fq = c->fq_blk.p, a.fq_block = 1;   // column 0: one load coefficient per visit slot
+        else if (a.fq != nullptr && a.fq == c->fq.p && c->fq_bc_ready) a.fq = c->fq_bc.p, a.fq_block = 2;   // column 0: samples in block-cell order
         const int grid = 8 * (int)(((hs.n_dofs + kAsmBlock - 1) / kAsmBlock + 7) / 8);   // 8 XCD bands of blocks (k_assemble_rows)
         size_t lds = tab + acc;
         if (lds > 64 * 1024)
@@ -825,7 +826,7 @@ const char* fdapde_last_error(const fdapde_ctx* c) { return c ? c->err.c_str() :
 int fdapde_mesh_upload(fdapde_ctx* c, int M, int N, int64_t n_nodes, const double* nodes, int64_t n_cells,
                        const int32_t* cells, const uint8_t* bnd) {
     if (!c) return FDAPDE_EINVAL;
-    c->space_ready = c->dev_ready = c->colour_ready = c->fq_blk_ready = false;
+    c->space_ready = c->dev_ready = c->colour_ready = c->fq_blk_ready = c->fq_bc_ready = false;
     c->assembled[0] = c->assembled[1] = c->force_ready = c->solved = c->dirichlet_applied = false;
     c->op.clear(), c->coef_of_op = false, c->fq_i.clear(), c->fq_cols = 0, c->g_i.clear(), c->have_g = false;
     if (c->topo_ready) dev_topology_release(&c->topo), c->topo_ready = false;
@@ -1040,7 +1041,7 @@ int fdapde_set_forcing(fdapde_ctx* c, const double* f_q, int32_t n_cols) {
     if (!c->space_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
     const HostSpace& hs = c->hs;
     if (!f_q || n_cols < 1) {
-        c->fq_i.clear(), c->fq_cols = 0, c->fq_blk_ready = false;
+        c->fq_i.clear(), c->fq_cols = 0, c->fq_blk_ready = false, c->fq_bc_ready = false;
         return FDAPDE_OK;
     }
     const int64_t rows = (int64_t)hs.nq * hs.n_cells;
@@ -1072,6 +1073,19 @@ int fdapde_set_forcing(fdapde_ctx* c, const double* f_q, int32_t n_cols) {
         }
         c->fq_blk_ready = false;   // fdapde_init turns column 0 into per-visit load coefficients (that IS the quadrature of
                                    // discretize_forcing, fem_assembler.h:122-136, so it belongs to init's timed region)
+        // A second copy of column 0 in BLOCK-CELL order for the row-owner sweep: the nq samples of a cell once per assembly block that
+        // visits it (1.65 copies on C3), so that the sweep finds them in the window of its own block instead of gathering 32 bytes per
+        // visit from all over a 323 MB array (PMC: 2.3 GB fetched for them).  A re-layout of the caller's data, like the permutation
+        // above -- no weight, no basis value, no sum enters it: the quadrature stays in fdapde_init.
+        c->fq_bc_ready = false;
+        if (c->dev_ready && c->adj.n > 0 && c->bc_cell.n > 0 && c->asm_fq_bc) {
+            const int64_t n_bc = (int64_t)c->bc_cell.n;
+            HIPCHK(c, c->fq_bc.alloc((size_t)n_bc * hs.nq));
+            hipLaunchKernelGGL(k_gather_row_groups, dim3((unsigned)((n_bc * hs.nq + 255) / 256)), dim3(256), 0, c->stream, n_bc, hs.nq, c->bc_cell.p,
+                               c->fq.p, c->fq_bc.p);
+            HIPCHK(c, hipGetLastError());
+            c->fq_bc_ready = true;
+        }
         HIPCHK(c, c->force.alloc((size_t)hs.n_dofs * n_cols));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
@@ -2616,6 +2630,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "cgf_lazy" && (value == 0 || value == 1)) c->cgf_lazy = value;
     else if (k == "multi_rhs" && (value == 0 || value == 1)) c->multi_rhs = value;
     else if (k == "asm_fq_block" && (value == 0 || value == 1)) c->asm_fq_block = value;
+    else if (k == "asm_fq_bc" && (value == 0 || value == 1)) c->asm_fq_bc = value, c->fq_bc_ready = c->fq_bc_ready && value;   // (takes effect fully at the next fdapde_set_forcing)
     else if (k == "persist" && (value == 0 || value == 1)) c->persist = value, c->persist_broken = false;
     else if (k == "persist_time" && (value == 0 || value == 1)) c->persist_time = value;
     else if (k == "blocked" && value >= 0 && value <= 2) c->blocked = value;   // 2: also for short-row systems

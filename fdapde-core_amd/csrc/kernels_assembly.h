@@ -64,7 +64,8 @@ struct AsmArgs {
     const DevRefTensors* reftab;   // OPK 3 only
     double* vals;              // CSR values (internal slots) or nullptr
     const double* fq;          // forcing at quadrature nodes, internal cell order, or nullptr
-    int fq_block;              // 1: fq holds one load coefficient per visit slot (k_visit_load_coeffs): k_assemble_rows only
+    int fq_block;              // k_assemble_rows only.  1: fq holds one load coefficient per visit slot (k_visit_load_coeffs);
+                               // 2: fq holds the samples in block-cell order (row group = block-cell index)
     double* force;             // forcing vector (internal DOF order) or nullptr
     int32_t lds_acc_cap;       // doubles available for the row accumulators
     // block-local tables of the row-owner kernel (host_setup.cpp): cells visited by the block's rows, their vertex nodes
@@ -200,10 +201,11 @@ template <int M, int R, int OPK, typename Emit>
 __device__ __forceinline__ double element_row(const AsmArgs& a, const DevOp& op, const DevTables* tb, const Geo<M>& g, int cell,
                                               int il, bool want_matrix, Emit&& emit, const DevRefTensors* rt = nullptr,
                                               int64_t fcell = -1 /* >= 0: a.fq holds load coefficients per visit ... */,
-                                              double fcoef = 0.0 /* ... and this is the visit's, loaded ahead by the caller */) {
+                                              double fcoef = 0.0 /* ... and this is the visit's, loaded ahead by the caller */,
+                                              int64_t frow = -1 /* >= 0: row group of the cell's samples in a.fq (block-cell order) */) {
     constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
     constexpr int NQ = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 5);
-    const int64_t qrow0 = (int64_t)NQ * cell;
+    const int64_t qrow0 = (int64_t)NQ * (frow >= 0 ? frow : (int64_t)cell);
     double fsum = 0;
     if (a.fq != nullptr) {
         if (fcell >= 0) {   // the quadrature sum was taken once per visit slot (k_visit_load_coeffs), in this very order
@@ -427,7 +429,8 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
         };
         // load coefficient of the forcing for a visit: one coalesced double per visit slot, streamed next to the adjacency word and
         // requested ahead like it (gathered by cell id inside the visit, the forcing cost 0.36 ms of a C3 init)
-        const bool fblk = a.fq != nullptr && a.fq_block;
+        const bool fblk = a.fq != nullptr && a.fq_block == 1;
+        const bool fbc = a.fq != nullptr && a.fq_block == 2;   // samples in block-cell order: no cell id, no gather outside the block's window
         auto load_fc = [&](int64_t v) -> double { return (fblk && v < width) ? a.fq[(off + v) * kSlice + lane] : 0.0; };
         int32_t code_n = load_code(0), code_nn = load_code(1);
         ushort4 lv_n = load_lv(code_n);
@@ -450,14 +453,14 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
             Geo<M> g;
             geo_from_vertices<M>(xyz + lv.x * NP, xyz + lv.y * NP, xyz + lv.z * NP, xyz + lv.w * NP, g);
             // the global cell id is needed by varying coefficients and by forcing samples kept in cell order only
-            const int cell = ((a.fq != nullptr && !a.fq_block) || op.needs_rows) ? a.bc_cell[bc] : 0;
+            const int cell = ((a.fq != nullptr && a.fq_block == 0) || op.needs_rows) ? a.bc_cell[bc] : 0;
             fsum += element_row<M, R, OPK>(a, op, tb, g, cell, code & 15, want_matrix, [&](int j, double value) {
                 const uint32_t slot = (sw[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
                 if (in_lds)
                     acc[my0 - base + (int32_t)slot] += value;
                 else
                     a.vals[my0 + (int32_t)slot] += value;
-            }, rt, fblk ? bc : (int64_t)-1, fc);
+            }, rt, fblk ? bc : (int64_t)-1, fc, fbc ? bc : (int64_t)-1);
         }
     }
     if (a.force != nullptr && row < a.n_dofs) a.force[row] = fsum;

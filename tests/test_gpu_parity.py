@@ -136,7 +136,17 @@ def test_init_force_mass_spmv(capi, ctx, oracle, mesh_loader, mesh_name, order):
     ctx.set_operator(-capi.laplacian())
     ctx.set_forcing(fq)
     ctx.init()
-    assert _entry_close(ctx.force(), oracle.assemble_forcing(m, order, od, nd, fq))
+    f_default = ctx.force()   # the sweep reads the samples from their block-cell ordered copy (fdapde_set_forcing)
+    assert _entry_close(f_default, oracle.assemble_forcing(m, order, od, nd, fq))
+    for knob, val in (("asm_fq_bc", 0), ("asm_fq_block", 1)):   # samples gathered by cell id / per-visit load coefficients: the same sums,
+        ctx.tune(knob, val)                                      # in the same order -> the same bits
+        ctx.set_forcing(fq)
+        ctx.init()
+        assert np.array_equal(ctx.force(), f_default), knob
+    ctx.tune("asm_fq_block", 0), ctx.tune("asm_fq_bc", 1)
+    ctx.set_forcing(fq)
+    ctx.init()
+    assert np.array_equal(ctx.force(), f_default)
     Mo = oracle.assemble_operator(m, order, od, nd, oracle.reaction(1.0))
     assert _entry_close(ctx.matrix_values(capi.MAT_MASS), Mo.values)
     Ao = oracle.assemble_operator(m, order, od, nd, -oracle.laplacian())

@@ -567,18 +567,26 @@ __global__ __launch_bounds__(kPersistT) void k_spmv_blocked(BlockedSpmvArgs a) {
         int mw = 0;
 #pragma unroll
         for (int j = J0; j < J1; ++j) mw = max(mw, w[j]);
+        // a pass that has run out of entries is skipped (wave-uniform): the rows are sorted by length and P2 rows range from 10 to 60+
+        // entries, so the passes of a wavefront differ widely in width -- re-reading the last pair row of the narrow ones, as the
+        // persistent CG's plain form does, would issue up to twice the loads; raw buffer loads: scalar row offset + constant lane offset
         for (int e = 0; e < mw; ++e) {
-            double2 v[J1 - J0];
+            pg_u32x4 v[J1 - J0];
             uint32_t c[J1 - J0];
 #pragma unroll
             for (int j = J0; j < J1; ++j) {
-                const int idx = (o0[j] + min(e, max(w[j] - 1, 0))) * 64 + lane;
-                v[j - J0] = gv[idx], c[j - J0] = gc[idx];
+                if (e < w[j]) {
+                    const int row = o0[j] + e;
+                    v[j - J0] = __builtin_amdgcn_raw_buffer_load_b128(rs_v, lane16, row * 1024, 0);
+                    c[j - J0] = __builtin_amdgcn_raw_buffer_load_b32(rs_c, lane4, row * 256, 0);
+                }
             }
 #pragma unroll
             for (int j = J0; j < J1; ++j) {
-                const double t = v[j - J0].x * p_tab[c[j - J0] & 0xffffu] + v[j - J0].y * p_tab[c[j - J0] >> 16];
-                yv[j] += e < w[j] ? t : 0.0;
+                if (e < w[j]) {
+                    const double vx = __hiloint2double((int)v[j - J0].y, (int)v[j - J0].x), vy = __hiloint2double((int)v[j - J0].w, (int)v[j - J0].z);
+                    yv[j] += vx * p_tab[c[j - J0] & 0xffffu] + vy * p_tab[c[j - J0] >> 16];
+                }
             }
         }
     };

@@ -205,14 +205,15 @@ __device__ __forceinline__ double element_row(const AsmArgs& a, const DevOp& op,
                                               int64_t frow = -1 /* >= 0: row group of the cell's samples in a.fq (block-cell order) */) {
     constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
     constexpr int NQ = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 5);
-    const int64_t qrow0 = (int64_t)NQ * (frow >= 0 ? frow : (int64_t)cell);
+    const int64_t qrow0 = (int64_t)NQ * cell;                                 // rows of space-varying coefficient data
+    const int64_t frow0 = frow >= 0 ? (int64_t)NQ * frow : qrow0;             // rows of the forcing samples
     double fsum = 0;
     if (a.fq != nullptr) {
         if (fcell >= 0) {   // the quadrature sum was taken once per visit slot (k_visit_load_coeffs), in this very order
             fsum = fcoef;
         } else {
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) fsum += (a.fq[qrow0 + q] * tb->psi[il * NQ + q]) * tb->qw[q];
+            for (int q = 0; q < NQ; ++q) fsum += (a.fq[frow0 + q] * tb->psi[il * NQ + q]) * tb->qw[q];
         }
         fsum *= g.measure;
     }

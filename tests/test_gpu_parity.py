@@ -125,6 +125,24 @@ def test_space_varying_coefficients(capi, ctx, oracle, mesh_loader, mesh_name, o
     assert _entry_close(got, ref.values)
 
 
+@pytest.mark.parametrize("mesh_name,order", [("unit_square_16", 2), ("unit_sphere", 1)])
+def test_init_with_space_varying_coefficients_and_forcing(capi, ctx, oracle, mesh_loader, mesh_name, order):
+    """one sweep reads the coefficient rows by CELL and the forcing samples by BLOCK-CELL: the two row indices must not be mixed up"""
+    m = mesh_loader(mesh_name)
+    ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = ctx.dofs_build(order)
+    od, _, _, _ = oracle.enumerate_dofs(m, order)
+    qn = oracle.quadrature_nodes(m, order)
+    cq = 1.0 + qn[:, 0] ** 2 + 0.5 * np.cos(2.0 * qn[:, 1])
+    fq = np.sin(3.0 * qn[:, 0]) + qn[:, 1] ** 2
+    ctx.set_operator(-capi.laplacian() + capi.reaction_field(cq))
+    ctx.set_forcing(fq)
+    ctx.init()
+    assert _entry_close(ctx.force(), oracle.assemble_forcing(m, order, od, nd, fq))
+    ref = oracle.assemble_operator(m, order, od, nd, -oracle.laplacian() + oracle.reaction_field(cq))
+    assert _entry_close(ctx.matrix_values(capi.MAT_STIFF), ref.values)
+
+
 @pytest.mark.parametrize("mesh_name,order", CASES)
 def test_init_force_mass_spmv(capi, ctx, oracle, mesh_loader, mesh_name, order):
     m = mesh_loader(mesh_name)

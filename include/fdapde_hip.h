@@ -259,8 +259,11 @@ int fdapde_halo_setup_peers(fdapde_ctx *ctx, int32_t n_peers, const int32_t *pee
  *                 "cgf_lazy" (x touched every second launch), "cgf_split" (second half of the loads after the scalars),
  *                 "use_graph" (hipGraph replay of a chunk of iterations)
  *   handle        "multi_rhs" (batched multi-column solves)
- *   assembly      "asm_fq_block" (forcing as per-visit load coefficients computed by a kernel of their own inside init)
- *   small systems "persist" (0: never run the solve as one persistent launch), "persist_time" (phase stamps) */
+ *   assembly      "asm_fq_block" (forcing as per-visit load coefficients computed by a kernel of their own inside init),
+ *                 "asm_fq_bc" (0: the sweep gathers the forcing samples by cell id instead of reading their block-cell ordered copy)
+ *   single-launch CG  "persist" (0: never run the solve as one persistent launch), "persist_time" (phase stamps), "persist_sym"
+ *                 (0 plain storage, 1 symmetric storage, 2 symmetric where the plain blocks would stream), "persist_balance"
+ *                 (workgroup boundaries at equal cost / equal row counts), "blocked" (blocked-ELL SpMV of the multi-launch solves) */
 int fdapde_tune(fdapde_ctx *ctx, const char *key, int32_t value);
 /* the context's HIP stream (hipStream_t) so that callers can bracket work with their own events */
 void *fdapde_stream(fdapde_ctx *ctx);

@@ -70,6 +70,36 @@ def test_delaunay_mesh_parity(capi, oracle, dim, n, order, seed):
     ctx.close()
 
 
+@pytest.mark.parametrize("dim,n,order,seed", [(2, 6000, 1, 11), (2, 4000, 2, 12), (3, 2500, 1, 13), (3, 1200, 2, 14)])
+def test_delaunay_mesh_symmetric_storage(capi, dim, n, order, seed):
+    """the persistent CG's symmetric storage forced on irregular meshes (rows of very different lengths, rows whose pairs all lie in
+    other workgroups or all in their own, several workgroups): the solution and the iteration count of the plain storage, and of the
+    multi-launch path, and identical bits on a second launch"""
+    nodes, cells, bnd = _delaunay(dim, n, seed)
+    ctx = capi.Context(device=0)
+    ctx.mesh_upload(nodes, cells, bnd)
+    nd = ctx.dofs_build(order)
+    _, _, coords = ctx.dofs_get()
+    qn = ctx.quadrature_nodes()
+    ctx.set_operator(-capi.laplacian() + capi.reaction(0.3))
+    ctx.set_forcing(np.cos(2.0 * qn[:, 0]) - qn[:, -1])
+    ctx.set_dirichlet(0.5 * coords[:, 0] + coords[:, -1] ** 2)
+    ctx.init()
+    res = {}
+    for name, knobs in (("multi", {"persist": 0}), ("plain", {"persist": 1, "persist_sym": 0}), ("sym", {"persist": 1, "persist_sym": 1})):
+        for k, v in knobs.items():
+            ctx.tune(k, v)
+        i = ctx.solve(rtol=1e-11, maxit=20000)
+        assert i.converged == 1 and i.persistent == (0 if name == "multi" else 1), name
+        res[name] = (ctx.solution().copy(), i.iters)
+    i2 = ctx.solve(rtol=1e-11, maxit=20000)
+    assert i2.iters == res["sym"][1] and np.array_equal(ctx.solution(), res["sym"][0])
+    for name in ("plain", "sym"):
+        assert abs(res[name][1] - res["multi"][1]) <= max(2, res["multi"][1] // 100), (name, res[name][1], res["multi"][1])
+        assert np.linalg.norm(res[name][0] - res["multi"][0]) <= 1e-9 * np.linalg.norm(res["multi"][0]), name
+    ctx.close()
+
+
 @pytest.mark.parametrize("n_rim,order", [(40, 1), (700, 1), (700, 2)])
 def test_fan_mesh_with_one_very_long_row(capi, oracle, n_rim, order):
     """A fan of n_rim triangles around one vertex: that vertex's row has n_rim + 1 (P1) or 2 n_rim + 1 (P2) entries, far above a team

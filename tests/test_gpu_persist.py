@@ -220,3 +220,18 @@ def test_blocked_ell_spmv_under_every_krylov_method(env, nx):
                 assert abs(info.iters - ref[m][0]) <= max(2, ref[m][0] // 10), (m, info.iters, ref[m][0])
                 assert np.linalg.norm(u - ref[m][1]) <= 1e-8 * np.linalg.norm(ref[m][1])
     c.close()
+
+
+def test_persistent_path_under_contention_from_other_processes():
+    """three processes solving C2-size systems on the same GPU at once: a persistent launch needs ALL its workgroups resident, which the
+    other processes' launches can prevent; the bounded waits must turn that into a fall-back to the multi-launch kernels (or a late
+    start), never into a hang or a wrong answer (tools/persist_contention.py asserts convergence and the analytic error per solve)"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "persist_contention.py"), "3", "12"], stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:]
+    assert out.stdout.count("solves ok") == 3, out.stdout[-3000:]

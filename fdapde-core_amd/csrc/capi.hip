@@ -1445,10 +1445,14 @@ int run_persist(fdapde_ctx* c, int v, double tol2, int maxit, bool* ran) {
     HIPCHK(c, hipMemcpyAsync(c->persist_host_stats.data(), c->persist_stats.p, 4 * (size_t)a.G * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     *ran = c->h_ctl[3] == 0;
-    if (!*ran) {   // a peer workgroup was not resident (other work on the device?): nothing was written; never try again on this context
+    if (!*ran) {   // a peer workgroup was not resident (other work on the device?): nothing was written.  The context stays on the
+                   // multi-launch path for a while and tries again later, twice as much later after every failure (8, 16, ... 1024 solves)
         c->persist_broken = true;
+        c->persist_retry_in = c->persist_backoff;
+        c->persist_backoff = std::min(1024, 2 * c->persist_backoff);
         HIPCHK(c, hipMemsetAsync(c->ctl.p + 3, 0, sizeof(int32_t), st));
-    }
+    } else
+        c->persist_backoff = 8;
     return FDAPDE_OK;
 }
 
@@ -1528,6 +1532,7 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss) {
     // take the plain full-pattern scaled matrix (no compact pattern / column codes are built for such a system)
     c->ps[0].filled = c->ps[1].filled = false;
     bool persist = false;
+    if (c->persist_broken && --c->persist_retry_in <= 0) c->persist_broken = false;   // the contention that broke it may be over
     if (ss->diag_positive && !ss->dist && c->persist && !c->persist_broken && c->spmv_variant == 2) {
         if (int rc = build_persist(c, use_bnd ? 1 : 0)) return rc;
         persist = c->ps[use_bnd ? 1 : 0].ok;

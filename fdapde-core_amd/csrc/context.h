@@ -248,7 +248,8 @@ struct fdapde_ctx {
     int persist_balance = 1;                                // workgroup boundaries of the persistent CG at equal cost (entries + 2 per row)
     int persist_sym = 2;                                    // symmetric storage of the persistent CG: 0 never, 1 always, 2 where the plain blocks would stream
     int persist_gather_waves = 4, persist_poll_sleep = 2;   // tuning knobs of the dot all-gather (kernels_persist.h)
-    bool persist_broken = false;             // a hand-off timed out once (workgroups not co-resident): stay on the multi-launch path
+    bool persist_broken = false;             // a hand-off timed out (workgroups not co-resident): on the multi-launch path for persist_retry_in more systems
+    int persist_retry_in = 0, persist_backoff = 8;
     struct Persist {
         bool tried = false, ok = false;
         PersistLayout meta;                  // sizes only (the big arrays are released after the upload)

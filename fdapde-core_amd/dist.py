@@ -82,8 +82,7 @@ def interface_info(cells, part, n_nodes, world, order=1, boundary_nodes=None):
     """-> (keys, owner, ifkeys, bflags): the sorted DOF keys of the whole mesh, the lowest rank touching each, the sorted
     keys touched by >= 2 ranks (the interface DOFs, globally indexed by their position in ifkeys), and the whole-mesh
     boundary flag per key (None without boundary_nodes)"""
-    ck = _cell_keys(cells, n_nodes, order)
-    per_rank = [np.unique(ck[part == r]) for r in range(world)]
+    per_rank = rank_key_sets(cells, part, n_nodes, world, order)
     allk = np.concatenate(per_rank)
     rank_of = np.repeat(np.arange(world, dtype=np.int32), [k.size for k in per_rank])
     keys, first, counts = np.unique(allk, return_index=True, return_counts=True)
@@ -91,10 +90,17 @@ def interface_info(cells, part, n_nodes, world, order=1, boundary_nodes=None):
     return keys, rank_of[first], keys[counts >= 2], bflags
 
 
+_key_sets_memo = {}
+
+
 def rank_key_sets(cells, part, n_nodes, world, order=1):
-    """the sorted DOF keys each rank touches (every rank computes all of them from the whole mesh, as interface_info does)"""
-    ck = _cell_keys(cells, n_nodes, order)
-    return [np.unique(ck[part == r]) for r in range(world)]
+    """the sorted DOF keys each rank touches (every rank computes all of them from the whole mesh); the last result is kept, so that
+    interface_info and peer_lists of the same partition share one pass over the cells"""
+    tag = (id(cells), id(part), int(n_nodes), int(world), int(order), cells.shape, int(part[:: max(1, part.size // 97)].sum()))
+    if _key_sets_memo.get("tag") != tag:
+        ck = _cell_keys(cells, n_nodes, order)
+        _key_sets_memo["tag"], _key_sets_memo["sets"] = tag, [np.unique(ck[part == r]) for r in range(world)]
+    return _key_sets_memo["sets"]
 
 
 def peer_lists(local_keys, key_sets, rank):

@@ -594,24 +594,31 @@ __global__ __launch_bounds__(kPersistT) void k_spmv_blocked(BlockedSpmvArgs a) {
         // a pass that has run out of entries is skipped (wave-uniform): the rows are sorted by length and P2 rows range from 10 to 60+
         // entries, so the passes of a wavefront differ widely in width -- re-reading the last pair row of the narrow ones, as the
         // persistent CG's plain form does, would issue up to twice the loads; raw buffer loads: scalar row offset + constant lane offset
-        for (int e = 0; e < mw; ++e) {
-            pg_u32x4 v[J1 - J0];
-            uint32_t c[J1 - J0];
+        constexpr int U = 2;   // pair rows of every pass per step: U R loads in flight per wavefront (the kernel needs ~60 registers; what
+                               // bounds it is the bytes in flight per CU).  C5, us per SpMV: U = 1 336, 2 327, 3 345, 4 342
+        for (int e = 0; e < mw; e += U) {
+            pg_u32x4 v[U][J1 - J0];
+            uint32_t c[U][J1 - J0];
 #pragma unroll
-            for (int j = J0; j < J1; ++j) {
-                if (e < w[j]) {
-                    const int row = o0[j] + e;
-                    v[j - J0] = __builtin_amdgcn_raw_buffer_load_b128(rs_v, lane16, row * 1024, 0);
-                    c[j - J0] = __builtin_amdgcn_raw_buffer_load_b32(rs_c, lane4, row * 256, 0);
-                }
-            }
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int j = J0; j < J1; ++j) {
-                if (e < w[j]) {
-                    const double vx = __hiloint2double((int)v[j - J0].y, (int)v[j - J0].x), vy = __hiloint2double((int)v[j - J0].w, (int)v[j - J0].z);
-                    yv[j] += vx * p_tab[c[j - J0] & 0xffffu] + vy * p_tab[c[j - J0] >> 16];
+                for (int j = J0; j < J1; ++j) {
+                    if (e + u < w[j]) {
+                        const int row = o0[j] + e + u;
+                        v[u][j - J0] = __builtin_amdgcn_raw_buffer_load_b128(rs_v, lane16, row * 1024, 0);
+                        c[u][j - J0] = __builtin_amdgcn_raw_buffer_load_b32(rs_c, lane4, row * 256, 0);
+                    }
                 }
-            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = J0; j < J1; ++j) {
+                    if (e + u < w[j]) {
+                        const pg_u32x4 q = v[u][j - J0];
+                        const double vx = __hiloint2double((int)q.y, (int)q.x), vy = __hiloint2double((int)q.w, (int)q.z);
+                        yv[j] += vx * p_tab[c[u][j - J0] & 0xffffu] + vy * p_tab[c[u][j - J0] >> 16];
+                    }
+                }
         }
     };
     product(std::integral_constant<int, 0>{});

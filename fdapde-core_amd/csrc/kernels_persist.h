@@ -1,12 +1,14 @@
-// kernels_persist.h -- the whole Jacobi-PCG solve of a SMALL system as ONE launch (fdapde_solve / fdapde_lin_solve /
+// kernels_persist.h -- the whole Jacobi-PCG solve of a system of up to ~2 M rows as ONE launch (fdapde_solve / fdapde_lin_solve /
 // the parabolic stepper, single GPU, symmetric positive operator): the in-solve SpMV of matrices of a few tens of MB is bound by
 // launch and hand-off latency, not by bandwidth (C2: 17 us per SpMV launch + 6 us update + two dependent launches = 27-29 us per
 // iteration for 40 MB of matrix), so the iteration is restructured around what the chip can keep ON the CUs:
 //   * one workgroup per CU, each owning a contiguous range of interior rows (locality numbering => few neighbours);
 //   * its slice of the scaled matrix RESIDENT IN LDS as sliced ELL (8-byte value + 16-bit column code per entry; 256 CUs x 160 KB
-//     = 40 MB), x / r / p of its rows in registers; slices that do not fit stream from global memory (they stay in the L2s);
+//     = 40 MB), x / r / p of its rows in registers; a system whose blocks do not fit streams them from memory every iteration
+//     (STREAM) -- then in symmetric storage where that pays (SYM): half the bytes, the vectors still never leave the CU;
 //   * neighbours exchange the entries of p they need through 8-byte {epoch, payload} granules (the data is the flag: no barrier,
-//     no fence, MI355X_MICROARCH.md "handoff-1to1"), rows that need no import are multiplied while the granules travel;
+//     no fence, MI355X_MICROARCH.md "handoff-1to1"; a double = two granules written by ONE 16-byte store and read by one 16-byte
+//     load, four imports per lane in flight together), rows that need no import are multiplied while the granules travel;
 //   * the three dot products of an iteration (p.Ap, Ap.Ap, r.r) cross in ONE all-gather of tagged granules that every workgroup
 //     sums in the same fixed order (deterministic, bitwise identical scalars everywhere; "allgather" row of the same price list);
 //   * the recurrence is the fused-update CG of k_cgf_update (alpha from the explicit r.r, beta from alpha^2 Ap.Ap - r.r), so the
@@ -112,8 +114,7 @@ constexpr long long kPersistTimeoutTicks = 5000000;   // 50 ms of s_memrealtime 
 // STREAM = true : the block streams from global memory every iteration (it is larger than the LDS: systems of a few hundred MB).
 //                 x, r, p still never leave the registers, so an iteration moves the matrix and the exchanged entries of p and
 //                 nothing else -- the multi-launch path moves 7 vector passes on top.  All R / 2 value loads of an entry step are
-//                 issued before the first is used (unconditional loads, clamped to the slice: narrower slices re-read their last
-//                 pair row, which multiplies by zero).
+//                 issued before the first is used (raw buffer loads; a pass that has run out of entries is skipped).
 // SYM = true   : symmetric storage (internal.h persist_sym_owner): a pair of rows of this block is stored once and applied to both
 //                 rows.  The row that stores it adds a p[col] to its own sum (registers, as ever) and hands a p[row] to row col through
 //                 a table of 64-bit FIXED-POINT accumulators in LDS (ds_add_u64): integer addition is associative, so the sums -- and

@@ -101,8 +101,54 @@ __global__ void k_row_lengths(int64_t nd, const int32_t* rowptr, const int32_t* 
         for (int32_t k = rowptr[d]; k < rowptr[d + 1]; ++k) n += kept_entry(keep, (int32_t)d, colidx[k]);
     len[d] = n;
 }
-// symmetric storage: a row keeps the in-block pairs it owns (persist_sym_owner) and every entry of another workgroup's column
-__global__ void k_row_lengths_sym(int64_t nd, const int32_t* rowptr, const int32_t* colidx, const uint8_t* keep, const int32_t* wg, int32_t* len) {
+// symmetric storage, who stores an in-block pair (host_persist.cpp has the walk in plain words).  own[k] for entry k = (row, col):
+// 1 = the row stores it.  Start: the hash rule ...
+__global__ void k_sym_own_init(int64_t nd, const int32_t* rowptr, const int32_t* colidx, const uint8_t* keep, int32_t* own, const int32_t* irow,
+                               int32_t* kept_dof) {
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= nd || !keep[d]) return;
+    kept_dof[irow[d]] = (int32_t)d;
+    for (int32_t k = rowptr[d]; k < rowptr[d + 1]; ++k) own[k] = persist_sym_owner((int32_t)d, colidx[k]) ? 1 : 0;
+}
+// ... then the parity walk: one wavefront per workgroup goes through its rows in ascending order; a row whose stored length is odd flips
+// the ownership of the pair with its smallest in-block neighbour of higher index (lanes = entries of the row; the flags are read and
+// written past the L1, the flips of one row are fenced before the next row is looked at)
+__global__ __launch_bounds__(64) void k_sym_parity(const int32_t* wgs, const int32_t* kept_dof, const int32_t* rowptr, const int32_t* colidx,
+                                                   const uint8_t* keep, const int32_t* wg, int32_t* own) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    for (int32_t i = wgs[g]; i < wgs[g + 1]; ++i) {
+        const int32_t d = kept_dof[i];
+        const int32_t r0 = rowptr[d], r1 = rowptr[d + 1];
+        int32_t len = 0, k_up = -1;
+        for (int32_t base = r0; base < r1; base += 64) {
+            const int32_t k = base + lane;
+            const bool valid = k < r1;
+            const int32_t c = valid ? colidx[k] : -1;
+            const bool keptc = valid && c != d && keep[c];
+            const bool inb = keptc && wg[c] == g;
+            const int32_t o = inb ? __hip_atomic_load(own + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            len += __popcll(__ballot(keptc && (!inb || o != 0)));
+            const unsigned long long up = __ballot(inb && c > d);
+            if (k_up < 0 && up != 0) k_up = base + __ffsll((long long)up) - 1;   // columns are sorted: the first one is the smallest
+        }
+        if ((len & 1) == 0 || k_up < 0) continue;   // (wave-uniform)
+        const int32_t c = colidx[k_up];
+        int32_t k_m = -1;
+        for (int32_t base = rowptr[c]; base < rowptr[c + 1] && k_m < 0; base += 64) {
+            const int32_t k = base + lane;
+            const unsigned long long hit = __ballot(k < rowptr[c + 1] && colidx[k] == d);
+            if (hit != 0) k_m = base + __ffsll((long long)hit) - 1;
+        }
+        if (lane == 0) {
+            __hip_atomic_store(own + k_up, 1 - __hip_atomic_load(own + k_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (k_m >= 0) __hip_atomic_store(own + k_m, 1 - __hip_atomic_load(own + k_m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __threadfence();
+    }
+}
+// symmetric storage: a row keeps the in-block pairs it owns (own[]) and every entry of another workgroup's column
+__global__ void k_row_lengths_sym(int64_t nd, const int32_t* rowptr, const int32_t* colidx, const uint8_t* keep, const int32_t* wg, const int32_t* own,
+                                  int32_t* len) {
     const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= nd) return;
     int32_t n = 0;
@@ -110,7 +156,7 @@ __global__ void k_row_lengths_sym(int64_t nd, const int32_t* rowptr, const int32
         const int32_t g = wg[d];
         for (int32_t k = rowptr[d]; k < rowptr[d + 1]; ++k) {
             const int32_t c = colidx[k];
-            n += kept_entry(keep, (int32_t)d, c) && (wg[c] != g || persist_sym_owner((int32_t)d, c));
+            n += kept_entry(keep, (int32_t)d, c) && (wg[c] != g || own[k] != 0);
         }
     }
     len[d] = n;
@@ -238,7 +284,7 @@ __global__ void k_slice_offsets(int G, int nsl, const int32_t* scan, int32_t* sl
 }
 __global__ void k_fill_ell(int64_t n_slots, int32_t S, int nsl, const int32_t* slot_dof, const int32_t* rowptr, const int32_t* colidx, const uint8_t* keep,
                            const int32_t* wg, const int32_t* slot_of, const int32_t* board_of, const int32_t* imp_off,
-                           const int32_t* imp_pos, const int32_t* sl_off, const int64_t* ell_off, int sym, uint16_t* code, int32_t* src) {
+                           const int32_t* imp_pos, const int32_t* sl_off, const int64_t* ell_off, int sym, const int32_t* own, uint16_t* code, int32_t* src) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // g * S + slot
     if (t >= n_slots) return;
     const int32_t d = slot_dof[t];
@@ -250,7 +296,7 @@ __global__ void k_fill_ell(int64_t n_slots, int32_t S, int nsl, const int32_t* s
     for (int32_t k = d < 0 ? 0 : rowptr[d]; k < (d < 0 ? 0 : rowptr[d + 1]); ++k) {
         const int32_t c = colidx[k];
         if (!kept_entry(keep, d, c)) continue;
-        if (sym && wg[c] == (int32_t)g && !persist_sym_owner(d, c)) continue;   // stored in row c
+        if (sym && wg[c] == (int32_t)g && own[k] == 0) continue;   // stored in row c
         const int64_t at = base + (int64_t)(e / 2) * 128 + (e & 1);
         src[at] = k;
         if (wg[c] == (int32_t)g) {
@@ -399,8 +445,18 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
     if (uniform || block_rows != nullptr) DP_CHK(hipMemcpyAsync(wgs.p, h_wgs.data(), sizeof(int32_t) * ((size_t)G + 1), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_wg_of, dim3(grid_of(nd)), dim3(256), 0, st, nd, keep.p, irow.p, wgs.p, G, wg.p);
     int64_t nnz_stored = nnz_kept;
-    if (sym) {   // the rows' stored lengths, now that the blocks are known
-        hipLaunchKernelGGL(k_row_lengths_sym, dim3(grid_of(nd)), dim3(256), 0, st, nd, d_rowptr, d_colidx, keep.p, wg.p, len.p);
+    Tmp<int32_t> own;   // symmetric storage: per entry of the pattern, does its row store the pair
+    if (sym) {   // ownership of the in-block pairs (hash rule, then rows made even), then the rows' stored lengths
+        Tmp<int32_t> kept_dof;
+        int32_t h_nnz_full = 0;
+        DP_CHK(hipMemcpyAsync(&h_nnz_full, d_rowptr + nd, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        DP_CHK(hipStreamSynchronize(st));
+        DP_CHK(own.alloc((size_t)(h_nnz_full > 0 ? h_nnz_full : 1)));
+        DP_CHK(kept_dof.alloc((size_t)n_int));
+        hipLaunchKernelGGL(k_sym_own_init, dim3(grid_of(nd)), dim3(256), 0, st, nd, d_rowptr, d_colidx, keep.p, own.p, irow.p, kept_dof.p);
+        hipLaunchKernelGGL(k_sym_parity, dim3(G), dim3(64), 0, st, wgs.p, kept_dof.p, d_rowptr, d_colidx, keep.p, wg.p, own.p);
+        DP_CHK(hipStreamSynchronize(st));   // (kept_dof is released at the end of this scope)
+        hipLaunchKernelGGL(k_row_lengths_sym, dim3(grid_of(nd)), dim3(256), 0, st, nd, d_rowptr, d_colidx, keep.p, wg.p, own.p, len.p);
         if (int rc = exclusive_sum(sc, len.p, len_scan.p, nd + 1, st, err)) return rc;
         DP_CHK(hipMemcpyAsync(&h_nnz, len_scan.p + nd, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         DP_CHK(hipStreamSynchronize(st));
@@ -566,7 +622,7 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
     DP_CHK(hipMemsetAsync(o.ell_code, 0, sizeof(uint16_t) * n_alloc, st));
     DP_CHK(hipMemsetAsync(o.ell_src, 0xff, sizeof(int32_t) * n_alloc, st));
     hipLaunchKernelGGL(k_fill_ell, dim3(grid_of((int64_t)G * S)), dim3(256), 0, st, (int64_t)G * S, (int32_t)S, nsl, o.slot_dof, d_rowptr, d_colidx, keep.p, wg.p,
-                       slot_of.p, blocked ? (const int32_t*)nullptr : board_of.p, o.imp_off, o.imp_pos, o.sl_off, o.ell_off, sym ? 1 : 0, o.ell_code, o.ell_src);
+                       slot_of.p, blocked ? (const int32_t*)nullptr : board_of.p, o.imp_off, o.imp_pos, o.sl_off, o.ell_off, sym ? 1 : 0, sym ? own.p : (const int32_t*)nullptr, o.ell_code, o.ell_src);
     DP_CHK(hipGetLastError());
     DP_CHK(hipStreamSynchronize(st));
     guard.armed = false;

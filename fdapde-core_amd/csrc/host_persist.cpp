@@ -100,6 +100,40 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
     for (int g = 0; g < G; ++g)
         for (int64_t i = wgs[(size_t)g]; i < wgs[(size_t)g + 1]; ++i) wg_of[(size_t)irow_dof[(size_t)i]] = g;
 
+    // ---- symmetric storage: who stores an in-block pair.  Start from the hash rule (persist_sym_owner), then make the stored row lengths
+    //      EVEN where possible: the ELL keeps entries in lane pairs, so an odd row pays for one entry of padding (half of the rows: 5 % of
+    //      the stream on 3-D P1 systems, 13 % in 2-D).  Rows of a workgroup in ascending order: a row whose stored length is odd hands the
+    //      pair with its smallest in-block neighbour of HIGHER index over to (or takes it from) that neighbour -- its own length becomes
+    //      even, the neighbour's parity flips and is settled when its turn comes.  Sequential inside a workgroup, independent across them
+    //      (dev_persist.hip k_sym_parity runs the same walk with one wavefront per workgroup).
+    std::vector<uint8_t> own;
+    if (sym) {
+        own.assign((size_t)hs.nnz, 0);
+        for (int64_t i = 0; i < n_int; ++i) {
+            const int32_t d = irow_dof[(size_t)i];
+            for (int32_t k = hs.rowptr_i[(size_t)d]; k < hs.rowptr_i[(size_t)d + 1]; ++k) own[(size_t)k] = persist_sym_owner(d, hs.colidx_i[(size_t)k]) ? 1 : 0;
+        }
+        for_each_wg(G, [&](int g) {
+            for (int64_t i = wgs[(size_t)g]; i < wgs[(size_t)g + 1]; ++i) {
+                const int32_t d = irow_dof[(size_t)i];
+                int32_t len = 0, k_up = -1;
+                for (int32_t k = hs.rowptr_i[(size_t)d]; k < hs.rowptr_i[(size_t)d + 1]; ++k) {
+                    const int32_t c = hs.colidx_i[(size_t)k];
+                    if (!kept(d, c)) continue;
+                    const bool in_block = wg_of[(size_t)c] == g;
+                    len += !in_block || own[(size_t)k];
+                    if (in_block && c > d && k_up < 0) k_up = k;   // columns are sorted: the first one is the smallest
+                }
+                if ((len & 1) == 0 || k_up < 0) continue;
+                const int32_t c = hs.colidx_i[(size_t)k_up];
+                const int32_t* lo = &hs.colidx_i[(size_t)hs.rowptr_i[(size_t)c]];
+                const int32_t* hi = &hs.colidx_i[(size_t)hs.rowptr_i[(size_t)c + 1]];
+                const int32_t k_mirror = (int32_t)(std::lower_bound(lo, hi, d) - &hs.colidx_i[0]);   // entry (c, d): the pattern is symmetric
+                own[(size_t)k_up] ^= 1, own[(size_t)k_mirror] ^= 1;
+            }
+        });
+    }
+
     // ---- rows of a workgroup: (references another workgroup, length, DOF) + its import list
     struct Key { int32_t halo, len, dof; };
     std::vector<std::vector<Key>> wg_rows((size_t)G);
@@ -116,7 +150,7 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
             for (int32_t k = hs.rowptr_i[(size_t)d]; k < hs.rowptr_i[(size_t)d + 1]; ++k) {
                 const int32_t c = hs.colidx_i[(size_t)k];
                 if (!kept(d, c)) continue;
-                if (sym && wg_of[(size_t)c] == g && !persist_sym_owner(d, c)) continue;   // stored in row c
+                if (sym && wg_of[(size_t)c] == g && !own[(size_t)k]) continue;   // stored in row c
                 ++len;
                 if (wg_of[(size_t)c] != g) halo = 1, imp.push_back(c);
             }
@@ -239,7 +273,7 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
             for (int32_t k = d < 0 ? 0 : hs.rowptr_i[(size_t)d]; k < (d < 0 ? 0 : hs.rowptr_i[(size_t)d + 1]); ++k) {
                 const int32_t c = hs.colidx_i[(size_t)k];
                 if (!kept(d, c)) continue;
-                if (sym && wg_of[(size_t)c] == g && !persist_sym_owner(d, c)) continue;
+                if (sym && wg_of[(size_t)c] == g && !own[(size_t)k]) continue;
                 const int64_t at = base + (int64_t)(e / 2) * 128 + (e & 1);
                 pl.ell_src[(size_t)at] = k;
                 pl.ell_code[(size_t)at] = (uint16_t)(wg_of[(size_t)c] == g ? slot_of[(size_t)c] : S + import_index(c));

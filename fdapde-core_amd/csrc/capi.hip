@@ -1296,7 +1296,7 @@ int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_r
     int imp_cap = 0, exp_cap = 0, S = 0;
     // symmetric storage (kernels_persist.h SYM) where the plain blocks would not fit the LDS; the plain form where they do (C2: the
     // iteration is latency-bound there, fewer bytes buy nothing) or where the accumulator table leaves no room for the vectors
-    int sym_mode = c->persist_sym;   // 0 never, 1 always, 2 auto
+    int sym_mode = c->persist_sym == 2 ? 3 : c->persist_sym;   // 0 never, 1 always, 2 auto: tried wherever the plain blocks would stream (3) ...
     for (int attempt = 0; attempt < 2; ++attempt) {
         pl = PersistLayout{};
         int rc = FDAPDE_EUNSUPPORTED;
@@ -1325,6 +1325,20 @@ int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_r
             dev_persist_release(&dp);
             sym_mode = 0;
             continue;
+        }
+        // ... and kept only where it pays (tools/persist_sym_ab.py): not if the PLAIN blocks of this partition would be resident (C2-size
+        // systems: 6.2 against 8.3 us per iteration), and for workgroups of at most 2048 rows only if the symmetric blocks are resident
+        // (3-D 314 k rows: 13.7 -> 11.7 us) -- streamed, the plain form is faster at that size (439 k rows: 14.7 against 15.7)
+        if (c->persist_sym == 2 && pl.sym && attempt == 0) {
+            const size_t fixed_plain = 8 * (size_t)(S + imp_cap) + 4 * (size_t)imp_cap + 2 * (size_t)exp_cap + 64;
+            const size_t block_plain = (size_t)(1.03 * (double)pl.nnz_full / (double)pl.G) + 256;   // (boundaries at equal cost: blocks of equal size)
+            const bool plain_resident = pl.R < 16 && fixed_plain + 10 * block_plain <= lds_total;
+            const bool sym_resident = fixed + 10 * (size_t)need <= lds_total;
+            if (plain_resident || ((pl.n_int + pl.G - 1) / pl.G <= 2048 && !sym_resident)) {
+                dev_persist_release(&dp);
+                sym_mode = 0;
+                continue;
+            }
         }
         break;
     }

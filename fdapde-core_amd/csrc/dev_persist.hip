@@ -487,7 +487,7 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
     while ((int64_t)R * T < rpw || (!blocked && (int64_t)(R / 2) * T < max_halo)) R *= 2;   // (the blocked SpMV has no import-free phase)
     if (R > kPersistRmax) return FDAPDE_EUNSUPPORTED;
     const int S = R * T, nsl = S / 64, SA = blocked ? S : (R / 2) * T;   // blocked: one class, plain (imports?, length, DOF) order
-    pl.G = G, pl.R = R, pl.nsl = nsl, pl.n_int = n_int, pl.nnz = nnz_stored;
+    pl.G = G, pl.R = R, pl.nsl = nsl, pl.n_int = n_int, pl.nnz = nnz_stored, pl.nnz_full = nnz_kept;
     Tmp<uint64_t> imp_key;   // unique (workgroup, DOF) imports, DOF ascending inside a workgroup
     int64_t n_imp = 0;
     {

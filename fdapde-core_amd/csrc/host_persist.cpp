@@ -168,7 +168,7 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
     while ((int64_t)R * T < rpw || (int64_t)(R / 2) * T < max_halo) R *= 2;
     if (R > kPersistRmax) return FDAPDE_EUNSUPPORTED;
     const int S = R * T, nsl = S / 64, SA = (R / 2) * T;
-    pl.G = G, pl.R = R, pl.nsl = nsl, pl.n_int = n_int, pl.sym = sym;
+    pl.G = G, pl.R = R, pl.nsl = nsl, pl.n_int = n_int, pl.sym = sym, pl.nnz_full = nnz_kept;
 
     // ---- slots: [0, SA) rows without imports, longest first (as many as fit); [SA, S) all other rows, longest first
     pl.slot_dof.assign((size_t)G * S, -1);

@@ -151,12 +151,14 @@ inline bool persist_sym_owner(int32_t row, int32_t col) {
     return (low_owns ? lo : hi) == (uint32_t)row;
 }
 // sym_mode of the layout builders: 0 plain, 1 symmetric, 2 symmetric where it pays: the plain blocks would not fit the LDS (estimate)
-// AND a workgroup owns more than 2048 rows (8 or 16 rows per thread).  Measured on MI355X (tools/persist_sym_ab.py, us per iteration,
-// plain -> symmetric): 3-D P1 439 k rows 15.8 -> 17.6, 754 k 22.2 -> 22.0, 1.19 M 31.2 -> 28.8, 1.73 M 43.1 -> 36.9; 2-D P1 1.0 M
-// 14.3 -> 13.2, 1.96 M 22.9 -> 20.2; resident systems lose 25-30 % (an entry costs ~25 instructions and an LDS atomic instead of a
+// AND a workgroup owns more than 2048 rows (8 or 16 rows per thread); 3 symmetric wherever the plain blocks would not fit (the caller
+// keeps such a layout for smaller workgroups only if its blocks turn out RESIDENT: capi.hip build_persist_once).  Measured on MI355X (tools/persist_sym_ab.py, us per iteration,
+// plain -> symmetric): 3-D P1 439 k rows 14.7 -> 15.6, 754 k 20.4 -> 18.6, 1.19 M 31.2 -> 26.2, 1.73 M 39.4 -> 31.0; 2-D P1 1.0 M
+// 14.3 -> 12.1, 1.96 M 22.9 -> 18.3; systems whose plain blocks are resident lose 25-30 % (an entry costs ~25 instructions and an LDS atomic instead of a
 // multiply-add: it only pays against bytes that would otherwise stream).
 inline bool persist_want_sym(int sym_mode, int64_t nnz_kept, int G, int64_t rows_per_wg) {
-    return sym_mode == 1 || (sym_mode == 2 && rows_per_wg > 2048 && 10.6 * (double)nnz_kept / (double)G + 16.0 * (double)rows_per_wg > 150e3);
+    const bool plain_streams = 10.6 * (double)nnz_kept / (double)G + 16.0 * (double)rows_per_wg > 150e3;
+    return sym_mode == 1 || (sym_mode == 2 && rows_per_wg > 2048 && plain_streams) || (sym_mode == 3 && plain_streams);
 }
 struct PersistLayout {
     bool sym = false;                 // in-block pairs stored once (persist_sym_owner)
@@ -165,6 +167,7 @@ struct PersistLayout {
     int64_t n_int = 0;                // interior (non-Dirichlet) rows
     int64_t n_entries = 0;            // ELL entries over all workgroups, padding included
     int64_t nnz = 0;                  // stored off-diagonal entries (no padding)
+    int64_t nnz_full = 0;             // off-diagonal entries of the interior block (what the plain storage would store)
     int64_t n_board = 0;              // exported vector entries over all workgroups
     int64_t n_imp = 0;                // imported vector entries over all workgroups
     int64_t n_drop = 0;               // rows left out (Dirichlet DOFs)

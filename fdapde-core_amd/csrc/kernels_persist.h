@@ -230,6 +230,14 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
             const int ex = m > 0.0 && m < 1.7e308 ? 61 - bexp - ilogb(m) : 0;
             tscale = ldexp(1.0, ex), tinv = ldexp(1.0, -ex);
         }
+        // 8 (or fewer) rows per thread: the scaled p of the own rows stays in registers for the operator phase (with 16 there is no room:
+        // it is re-read from the LDS table at every entry step)
+        constexpr bool PS_REG = SYM && R <= 8;
+        double psj[PS_REG ? R : 1];
+        if constexpr (PS_REG) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) psj[j] = P(j) * tscale;
+        }
         for (int i0 = tid; i0 < E; i0 += 4 * T) {   // four per thread at a time: slot codes, then table reads, then the stores
             unsigned code[4];
             double pe[4];
@@ -316,7 +324,9 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
                             const unsigned c_lo = c[j - jg] & 0xffffu, c_hi = c[j - jg] >> 16;
                             const double vx = __hiloint2double((int)v[j - jg].y, (int)v[j - jg].x), vy = __hiloint2double((int)v[j - jg].w, (int)v[j - jg].z);
                             yv[j] += vx * p_tab[c_lo] + vy * p_tab[c_hi];
-                            const double ps = P(j) * tscale;
+                            double ps;
+                            if constexpr (PS_REG) ps = psj[j];
+                            else ps = P(j) * tscale;
                             const long long q_lo = (long long)(vx * ps), q_hi = (long long)(vy * ps);
                             // branch-free: what has no target here (a column of another workgroup) adds 0 to the lane's own slot, where it meets
                             // no other lane's (padding: value 0, column = own slot).  Measured against lanes skipping their add: 36.9 vs 38.0 us

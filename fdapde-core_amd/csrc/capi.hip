@@ -1513,7 +1513,7 @@ int build_blocked(fdapde_ctx* c, int v) {
 
 // Dirichlet reduction + Jacobi scaling of the system matrix A (internal slots): scale, sval = diag(s) A diag(s).
 // Done once per matrix (per solve for the elliptic problem, once for all time steps of the parabolic one).
-int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss) {
+int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss, bool symmetric) {
     const int64_t n = c->hs.n_dofs;
     hipStream_t st = c->stream;
     ss->dist = (c->comm != nullptr || c->ar_fn != nullptr) && c->halo_ready;   // multi-GPU: sub-assembled operator of this rank's cells
@@ -1547,7 +1547,7 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss) {
     c->ps[0].filled = c->ps[1].filled = false;
     bool persist = false;
     if (c->persist_broken && --c->persist_retry_in <= 0) c->persist_broken = false;   // the contention that broke it may be over
-    if (ss->diag_positive && !ss->dist && c->persist && !c->persist_broken && c->spmv_variant == 2) {
+    if (symmetric && ss->diag_positive && !ss->dist && c->persist && !c->persist_broken && c->spmv_variant == 2) {   // (the single launch is a CG)
         if (int rc = build_persist(c, use_bnd ? 1 : 0)) return rc;
         persist = c->ps[use_bnd ? 1 : 0].ok;
     }
@@ -1970,7 +1970,7 @@ int fdapde_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     SolveState ss;
     c->scaled_owner = fdapde_ctx::kScaledSolve;
-    if (int rc = solve_prepare(c, A, c->have_g ? 1 : 0, &ss)) return rc;
+    if (int rc = solve_prepare(c, A, c->have_g ? 1 : 0, &ss, c->op_symmetric)) return rc;
     const int rc = solve_run(c, ss, A, c->force.p, c->g.p, nullptr, opt ? opt->method : FDAPDE_SOLVER_AUTO, rtol, maxit, check_every,
                              opt ? opt->time_spmv : 0);
     if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;
@@ -2017,7 +2017,7 @@ int fdapde_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_t
                        c->vals[FDAPDE_MAT_STIFF].p, inv_dt, kmat.p);
     SolveState ss;
     c->scaled_owner = fdapde_ctx::kScaledParabolic;
-    if (int rc = solve_prepare(c, kmat.p, dirichlet ? 1 : 0, &ss)) return rc;
+    if (int rc = solve_prepare(c, kmat.p, dirichlet ? 1 : 0, &ss, c->op_symmetric)) return rc;
     to_internal(initial_condition);
     HIPCHK(c, hipMemcpyAsync(uprev.p, tmp.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipStreamSynchronize(st));
@@ -2140,7 +2140,7 @@ int fdapde_lin_compute(fdapde_ctx* c, int32_t which, const double* values, int32
     }
     if (!c->lin_state) c->lin_state = new SolveStateHolder();
     c->scaled_owner = fdapde_ctx::kScaledNone;
-    if (int rc = solve_prepare(c, c->lin_mat.p, 0, &c->lin_state->ss)) return rc;
+    if (int rc = solve_prepare(c, c->lin_mat.p, 0, &c->lin_state->ss, c->lin_symmetric)) return rc;
     c->scaled_owner = fdapde_ctx::kScaledLin;   // scale / sval now belong to the handle
     c->lin_ready = true, c->lin_sq_ready = false;
     return FDAPDE_OK;
@@ -2163,7 +2163,7 @@ int fdapde_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, 
         method = (c->lin_symmetric && c->lin_state->ss.diag_positive) ? FDAPDE_SOLVER_CG_FUSED : FDAPDE_SOLVER_BICGSTAB;
     if (c->scaled_owner != fdapde_ctx::kScaledLin) {   // an elliptic / parabolic solve in between has overwritten scale and the scaled copy
         c->scaled_owner = fdapde_ctx::kScaledNone;      // (whatever init / set_* calls followed it): prepare again (cheap)
-        if (int rc = solve_prepare(c, c->lin_mat.p, 0, &c->lin_state->ss)) return rc;
+        if (int rc = solve_prepare(c, c->lin_mat.p, 0, &c->lin_state->ss, c->lin_symmetric)) return rc;
         c->scaled_owner = fdapde_ctx::kScaledLin;
     }
     c->solved = false;   // c->u is about to hold the handle's solutions, not PDE::solution()

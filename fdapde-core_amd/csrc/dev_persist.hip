@@ -407,6 +407,7 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
     if (G < 1) G = 1;
     if (G >= (1 << 20)) return FDAPDE_EUNSUPPORTED;   // 20 bits of the row keys
     int64_t rpw = (n_int + G - 1) / G;   // rows of the largest workgroup
+    if (!blocked && block_rows == nullptr && rpw > (int64_t)kPersistRmax * T) return FDAPDE_EUNSUPPORTED;   // too many rows for one launch of resident workgroups
     const bool sym = !blocked && persist_want_sym(sym_mode, nnz_kept, G, rpw);
     std::vector<int32_t> h_wgs;           // interior-row boundaries of the workgroups
     Tmp<int32_t> wgs, wg;

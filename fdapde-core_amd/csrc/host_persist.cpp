@@ -58,6 +58,7 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
     int G = (int)std::min<int64_t>(n_wg, want);
     if (G < 1) G = 1;
     int64_t rpw = (n_int + G - 1) / G;   // rows of the largest workgroup
+    if (block_rows == nullptr && rpw > (int64_t)kPersistRmax * T) return FDAPDE_EUNSUPPORTED;   // too many rows for one launch of resident workgroups
     const bool sym = persist_want_sym(sym_mode, nnz_kept, G, rpw);
     std::vector<int64_t> wgs;             // interior-row boundaries of the workgroups
     if (block_rows != nullptr) {

@@ -9,22 +9,29 @@ crosses PCIe inside it.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--nx 119]
 
 N = 1: the whole C3 mesh (119^3 x 6 = 10 110 954 tetrahedra, 1 728 000 DOFs) on one MI355X.
-N > 1 (launched by torch.distributed.run, one rank per GPU): the same mesh, element-partitioned over the ranks with
-an RCCL all-reduce of the interface DOF contributions per operator application (strong scaling).
+N > 1: the same mesh, element-partitioned over N ranks, one per GPU (strong scaling).  Started either by
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+environment) or plainly as `python bench.py --gpus N ...`: with WORLD_SIZE unset the script starts its own N rank processes --
+fresh children, decided before anything touches the GPU -- and rank 0's JSON line is the output.
 
-Prints ONE JSON line (rank 0).  `roofline` is the CSR SpMV inside CG: algorithmic bytes 12 nnz + 4 (n+1) + 16 n per
-launch over the average launch duration measured with HIP events on the solver's stream during the timed steps.
-`cpu_baseline` is the CPU oracle (oracle/fem_oracle.c, the single-threaded port of the reference algorithm) timed on the
-same workload at the same size (--cpu-nx 119); `cpu_baseline_all_cores` is the same restatement with OpenMP on every host core
-(oracle/fem_oracle_mt.c: BASELINE.md's "CPU-best" column).
+A rank process holds ONE HIP / RCCL stack: it loads libfdapde_hip.so (bound to /opt/rocm's runtime) and nothing else that
+touches the GPU -- no torch.  The 128-byte RCCL id of the library's communicator travels through a rendezvous directory on the
+node's file system, the barriers and the max-over-ranks of the timing are all-reduces of that communicator
+(fdapde_comm_allreduce).  FDAPDE_BENCH_BACKEND=gloo (plumbing checks on a box with fewer GPUs than ranks: ranks share
+devices, host-staged transports over torch.distributed/gloo, imported AFTER the library) is never used for reported numbers.
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel -- on one GPU the single launch that runs the whole CG
+(k_cg_persist): bytes it streams per launch (its layout x iterations) over the launch duration measured with HIP events on the
+solver's stream; `effective_*` are the same time on the algorithmic bytes of the CSR operator the caller sees
+(12 nnz + 4 (n+1) + 16 n per application).  `cpu_baseline` is the CPU oracle (oracle/fem_oracle.c, the single-threaded port of the
+reference algorithm) timed on the same workload at the same size; `cpu_baseline_all_cores` the same restatement with OpenMP.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -44,12 +51,91 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary single-GPU results (BASELINE configs C2 and C5) appended as `extra`")
     ap.add_argument("--time-spmv", type=int, default=32,
-                    help="SpMV launches per step timed with dispatch-attached HIP events (each costs a ~6 us bubble)")
+                    help="multi-launch path: SpMV launches per step timed with dispatch-attached HIP events (each costs a ~6 us bubble)")
     return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: the script starts its own rank processes (nothing has touched the GPU in this process)
+# ---------------------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    import socket
+    import tempfile
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    rdzv = tempfile.mkdtemp(prefix="fdapde_rdzv_")
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FDAPDE_BENCH_RDZV=rdzv, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))   # stdout inherited: rank 0 prints the line
+    rc = 0
+    try:
+        pending = dict(enumerate(procs))
+        while pending:
+            for r, p in list(pending.items()):
+                code = p.poll()
+                if code is None:
+                    continue
+                del pending[r]
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"bench.py: rank {r} exited with code {code}; stopping the others", file=sys.stderr)
+                    for q in pending.values():
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        import shutil
+
+        shutil.rmtree(rdzv, ignore_errors=True)
+    return rc
+
+
+class FileRendezvous:
+    """Small blobs between the rank processes of ONE node through a directory: put = write + atomic rename, get = poll."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+        d = os.environ.get("FDAPDE_BENCH_RDZV")
+        if not d:   # under torch.distributed.run: all ranks are children of the same agent process
+            d = os.path.join("/tmp", f"fdapde_rdzv_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}")
+        self.dir = d
+        os.makedirs(d, exist_ok=True)
+
+    def path(self, key):
+        return os.path.join(self.dir, key)
+
+    def put(self, key, data: bytes):
+        tmp = self.path(f".{key}.{self.rank}.tmp")
+        with open(tmp, "wb") as f:
+            f.write(data)
+        os.replace(tmp, self.path(key))
+
+    def get(self, key, timeout=1800.0) -> bytes:
+        t0 = time.time()
+        p = self.path(key)
+        while not os.path.exists(p):
+            if time.time() - t0 > timeout:
+                raise TimeoutError(f"rank {self.rank}: rendezvous key {key} did not appear in {self.dir}")
+            time.sleep(0.01)
+        with open(p, "rb") as f:
+            return f.read()
+
+    def barrier(self, name):
+        self.put(f"{name}.{self.rank}", b"1")
+        for r in range(self.world):
+            self.get(f"{name}.{r}")
 
 
 def cpu_baseline(nx):
     """The oracle (kind 'port') on a bounded sample: same generator, same operator, same solver and tolerance."""
+    import numpy as np
+
     from fdapde_loader import load_package
     from oracle import oracle as o
 
@@ -100,170 +186,166 @@ def cpu_baseline(nx):
     return faithful, best
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch
+def roofline_of(info_list, alg_bytes, streamed_bytes, nx, world, n_int=None, nnz_int=None, layout=None):
+    """The dominant kernel's roofline entry.  `frac` is PHYSICAL: the bytes the kernel's layout streams (and, where a committed PMC
+    pass of the same workload exists, the counter bytes next to it as `traffic`) over the launch duration; the algorithmic bytes of
+    the CSR operator the caller sees over the same time are `effective_*` (they exceed the physical figure where the layout stores
+    less than the CSR form: symmetric storage, 16-bit column codes, no diagonal)."""
+    import numpy as np
 
-    # FDAPDE_BENCH_BACKEND=gloo: plumbing check of the N > 1 leg on a box with fewer GPUs than ranks (ranks share devices,
-    # host-staged all-reduce instead of RCCL).  Never used for reported numbers.
-    backend = os.environ.get("FDAPDE_BENCH_BACKEND", "nccl")
-    n_dev = max(torch.cuda.device_count(), 1)
-    device_index = local_rank % n_dev
-    if world > 1:
-        import torch.distributed as dist
+    info = info_list[-1]
+    persistent = int(getattr(info, "persistent", 0))
+    iters = max(int(info.iters), 1)
+    r = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
+    if persistent:
+        launch_ms = float(np.mean([i.launch_ms for i in info_list]))
+        per_launch = float(streamed_bytes) * iters if streamed_bytes else None
+        r.update({
+            "kernel": "k_cg_persist: ONE launch runs the whole Jacobi-PCG (x, r, p in registers; the matrix blocks stream once per iteration, "
+                      "neighbour entries and dot records cross through granule boards)",
+            "avg_launch_ms": launch_ms, "iterations_per_launch": iters,
+            "launch_timing": "HIP events recorded on the solver's stream right before and after the dispatch, averaged over the timed steps",
+            "streamed_bytes_per_launch": per_launch,
+            "streamed_bytes_per_iteration": float(streamed_bytes) if streamed_bytes else None,
+            "algorithmic_bytes_per_launch": float(alg_bytes) * iters,
+            "algorithmic_bytes_per_iteration": float(alg_bytes),
+        })
+        achieved = per_launch / (launch_ms * 1e-3) / 1e9 if per_launch and launch_ms > 0 else 0.0
+        eff = float(alg_bytes) * iters / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        r["phase_stamps_us_per_iteration"] = {
+            "operator_slowest_workgroup": 1e3 * float(info.spmv_avg_ms), "operator_mean": 1e3 * float(info.spmv_mean_ms),
+            "allgather": 1e3 * float(info.gather_avg_ms), "update": 1e3 * float(info.update_avg_ms),
+            "note": "s_memrealtime stamps inside the kernel (diagnostic; not what achieved / frac are computed from)"}
+    else:
+        spmv_ms = float(np.mean([i.spmv_avg_ms for i in info_list]))
+        r.update({
+            "kernel": "SpMV of the multi-launch Krylov iteration (k_spmv_team2 / k_spmv_blocked, fused with the dot products)",
+            "avg_launch_ms": spmv_ms, "launches_timed_per_step": int(info.spmv_timed),
+            "launch_timing": "HIP events attached to the timed dispatches on the solver's stream",
+            "streamed_bytes_per_launch": float(streamed_bytes) if streamed_bytes else None,
+            "algorithmic_bytes_per_launch": float(alg_bytes),
+        })
+        achieved = float(streamed_bytes if streamed_bytes else alg_bytes) / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
+        eff = float(alg_bytes) / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
+    r["achieved"], r["frac"] = achieved, achieved / HBM_PEAK_GBPS
+    r["achieved_source"] = "bytes of the kernel's own layout (fdapde_solver_layout) / measured launch duration"
+    if layout is not None:
+        r["layout"] = layout
+        if layout.get("kind") == 3:   # (reduced sizes only: C3 streams) blocks resident in LDS -- the iteration is two hand-off latencies, no HBM stream
+            r["bound"], r["achieved"], r["frac"] = "latency", None, None
+            r["achieved_source"] = "matrix blocks resident in LDS for the whole launch: no HBM fraction applies"
+    r["effective_gbps"], r["effective_frac"] = eff, eff / HBM_PEAK_GBPS
+    r["effective_note"] = "algorithmic CSR bytes (SURVEY 8d: 12 nnz + 4 (n+1) + 16 n per application) over the same time; not a roofline fraction"
+    # HBM bytes per launch from counters: NOT measured in this run (PMC needs rocprofv3 around the process) -- taken from the committed
+    # PMC passes of the same workload (tools/profile_gpu.sh -> profiles/spmv_pmc.json) when they match it, and labelled so
+    r["traffic"], r["traffic_source"] = None, None
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "spmv_pmc.json")))
+        if world == 1 and pj.get("nx") == nx:
+            if persistent and pj.get("persist_hbm_bytes_per_solve") and abs(int(pj.get("persist_iterations", 0)) - iters) <= 2:
+                r["traffic"] = float(pj["persist_hbm_bytes_per_solve"])
+                r["traffic_frac"] = r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+            elif not persistent and pj.get("hbm_bytes_per_launch"):
+                r["traffic"] = float(pj["hbm_bytes_per_launch"])
+            if r["traffic"] is not None:
+                r["traffic_source"] = ("profiles/spmv_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE of this kernel, separate rocprofv3 --pmc passes of an "
+                                       "earlier run of this workload (not this run); FETCH_SIZE counts Infinity-Cache hits")
+    except Exception:
+        pass
+    if n_int is not None:
+        r["interior_rows"], r["interior_nnz"] = int(n_int), int(nnz_int)
+    return r
 
-        torch.cuda.set_device(device_index)
-        if backend == "gloo":
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+def run_single(args):
+    import numpy as np
 
     from fdapde_loader import load_package
 
-    pkg = load_package()
+    load_package()
     from fdapde_core_amd import capi, meshgen
 
     if capi.load().fdapde_device_count() < 1:
         raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
-
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    device_index = int(os.environ.get("LOCAL_RANK", "0")) % max(int(capi.load().fdapde_device_count()), 1)
     t_gen = time.perf_counter()
     nodes, cells, bnd = meshgen.unit_cube(args.nx)
     t_gen = time.perf_counter() - t_gen
     n_cells_total = int(cells.shape[0])
     u_exact, f = meshgen.manufactured(3)
+    ctx = capi.Context(device=device_index)
+    ctx.mesh_upload(nodes, cells, bnd)
+    n_dofs = ctx.dofs_build(1)
+    sizes = ctx.sizes()
+    qn = ctx.quadrature_nodes()
+    ctx.set_operator(-capi.laplacian())
+    fq = f(qn)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    ctx.set_forcing(fq)   # upload of the samples + their re-layout in block-cell order (set-up for a static forcing; reported, untimed)
+    ctx.synchronize()
+    t_set_forcing = time.perf_counter() - t0
+    ctx.set_dirichlet(np.zeros(n_dofs))
+    del qn, fq
+    t0 = time.perf_counter()
+    ctx.solver_prepare(True)   # set-up: the solver's layout for this boundary mask
+    t_prep = time.perf_counter() - t0
 
-    if world == 1:
-        ctx = capi.Context(device=device_index)
-        ctx.mesh_upload(nodes, cells, bnd)
-        n_dofs = ctx.dofs_build(1)
-        sizes = ctx.sizes()
-        qn = ctx.quadrature_nodes()
-        ctx.set_operator(-capi.laplacian())
-        ctx.set_forcing(f(qn))
-        ctx.set_dirichlet(np.zeros(n_dofs))
-        del qn
-        t0 = time.perf_counter()
-        ctx.solver_prepare(True)   # set-up: compact solver pattern + 16-bit column codes for this boundary mask (host work + upload)
-        t_prep = time.perf_counter() - t0
+    def step(time_spmv=0):
+        ctx.init()
+        return ctx.solve(rtol=RTOL, time_spmv=time_spmv)
 
-        def step(time_spmv=0):
-            ctx.init()
-            return ctx.solve(rtol=RTOL, time_spmv=time_spmv)
-
-        for _ in range(args.warmup):
-            step()
-        barrier()
-        t0 = time.perf_counter()
-        infos = [step(args.time_spmv) for _ in range(args.steps)]
-        barrier()
-        elapsed = time.perf_counter() - t0
-        info = infos[-1]
-        spmv_ms = float(np.mean([i.spmv_avg_ms for i in infos]))
-        t_asm = float(np.mean([i.t_assemble_ms for i in infos]))
-        t_sol = float(np.mean([i.t_solve_ms for i in infos]))
-        u = ctx.solution()
-        _, _, coords = ctx.dofs_get()
-        err = float(np.abs(u - u_exact(coords)).max())
-        setup_ms = ctx.info().t_setup_ms + 1e3 * t_prep
-        _, alg_bytes = ctx.bench_spmv(reps=1)
-        n_int, nnz_int, streamed_bytes = ctx.solver_layout(True)
-        parallelism = "1 GPU"
-        total_dofs = n_dofs
-        ctx.close()
-        del nodes, cells, bnd
-    else:
-        from fdapde_core_amd import dist as fdist
-
-        res = fdist.bench_partitioned(capi, nodes, cells, bnd, f, u_exact, rank, world, device_index, args, barrier, RTOL, backend)
-        if rank != 0:
-            return
-        (elapsed, info, spmv_ms, t_asm, t_sol, err, setup_ms, alg_bytes, sizes, total_dofs, parallelism) = res
-        n_int = nnz_int = streamed_bytes = None
-
-    if rank != 0:
-        return
-    # HBM bytes per SpMV launch: NOT measured in this run (PMC counters need rocprofv3 around the process) -- taken from the
-    # committed PMC passes of the same workload and code (tools/profile_gpu.sh -> profiles/spmv_pmc.json), and labelled so
-    traffic, traffic_source = None, None
-    try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "spmv_pmc.json")))
-        if world == 1 and pj.get("nx") == args.nx:
-            if getattr(info, "persistent", 0) and pj.get("persist_hbm_bytes_per_solve"):
-                # one dispatch per solve: counter bytes of the whole launch / iterations (the operator application is all it streams)
-                traffic = pj["persist_hbm_bytes_per_solve"] / max(int(pj.get("persist_iterations", info.iters)), 1)
-            elif not getattr(info, "persistent", 0):
-                traffic = pj.get("hbm_bytes_per_launch")
-            traffic_source = "profiles/spmv_pmc.json (rocprofv3 --pmc passes of an earlier run of this workload; not this run)"
-    except Exception:
-        pass
-    ms_per_step = 1e3 * elapsed / args.steps
-    achieved = alg_bytes / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
+    for _ in range(args.warmup):
+        step()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    infos = [step(args.time_spmv) for _ in range(args.steps)]
+    ctx.synchronize()
+    elapsed = time.perf_counter() - t0
+    info = infos[-1]
+    t_asm = float(np.mean([i.t_assemble_ms for i in infos]))
+    t_sol = float(np.mean([i.t_solve_ms for i in infos]))
+    u = ctx.solution()
+    _, _, coords = ctx.dofs_get()
+    err = float(np.abs(u - u_exact(coords)).max())
+    setup_ms = ctx.info().t_setup_ms + 1e3 * t_prep
+    _, alg_bytes = ctx.bench_spmv(reps=1)
+    n_int, nnz_int, streamed_bytes = ctx.solver_layout(True)
+    layout = ctx.solver_layout_kind(True)
+    ctx.close()
+    del nodes, cells, bnd
     out = {
         "metric": "DOF/s assemble+solve, 3D P1 Laplacian; SpMV achieved HBM GB/s vs peak",
-        "value": total_dofs * args.steps / elapsed,
+        "value": n_dofs * args.steps / elapsed,
         "unit": "DOF/s",
-        "n_gpus": world,
+        "n_gpus": 1,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": ms_per_step,
+        "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "strong" if world > 1 else "weak",
+        "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
             "workload": f"C3: 3-D P1 Laplacian, [0,1]^3, {args.nx}^3 x 6 Kuhn tetrahedra = {n_cells_total} cells, "
-                        f"{total_dofs} DOFs, nnz {sizes['nnz']}, jitter 0.2h, ids permuted, seed 12345; "
+                        f"{n_dofs} DOFs, nnz {sizes['nnz']}, jitter 0.2h, ids permuted, seed 12345; "
                         "u = sin(pi x) sin(pi y) sin(pi z), homogeneous Dirichlet; init (stiff+force+mass) + Jacobi-PCG rtol 1e-10",
-            "parallelism": parallelism,
+            "parallelism": "1 GPU",
             "cg_iterations": int(info.iters),
             "relres": float(info.relres),
             "t_assemble_ms": t_asm,
             "t_solve_ms": t_sol,
             "t_setup_ms_untimed": setup_ms,
+            "t_set_forcing_ms_untimed": 1e3 * t_set_forcing,
             "t_meshgen_s_untimed": t_gen,
             "max_abs_error_vs_analytic": err,
-            "spmv_launches_timed_per_step": int(info.spmv_timed),
             "persistent_launch": int(getattr(info, "persistent", 0)),
             "us_per_iteration": 1e3 * t_sol / max(int(info.iters), 1),
-            "operator_phase_mean_us": 1e3 * float(getattr(info, "spmv_mean_ms", 0.0)),
-            "allgather_phase_us": 1e3 * float(getattr(info, "gather_avg_ms", 0.0)),
-            "update_phase_us": 1e3 * float(getattr(info, "update_avg_ms", 0.0)),
         },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": ("k_cg_persist operator phase (the whole CG is ONE launch: x, r, p in registers, the matrix streams once per iteration; "
-                       "avg_launch_ms = per-iteration SpMV + neighbour-import phase of the slowest workgroup, stamped in the kernel)"
-                       if getattr(info, "persistent", 0) else "k_spmv_team2 (CSR SpMV fused with p.Ap and Ap.Ap inside CG)"),
-            "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": traffic, "traffic_source": traffic_source,
-            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": spmv_ms,
-        },
+        "roofline": roofline_of(infos, alg_bytes, streamed_bytes, args.nx, 1, n_int, nnz_int, layout),
     }
-    if n_int is not None and spmv_ms > 0:
-        # the CG streams the Dirichlet-reduced interior block, not the full CSR the caller sees: the same figure on that operator,
-        # and the rate of the bytes the kernel really streams (compact layout: no diagonal, 16-bit column codes)
-        alg_int = 12.0 * nnz_int + 4.0 * (n_int + 1) + 16.0 * n_int
-        r = out["roofline"]
-        r["algorithmic_bytes_interior"] = alg_int
-        r["achieved_interior"] = alg_int / (spmv_ms * 1e-3) / 1e9
-        r["frac_interior"] = r["achieved_interior"] / HBM_PEAK_GBPS
-        r["streamed_bytes_per_launch"] = streamed_bytes
-        r["streamed_gbps"] = streamed_bytes / (spmv_ms * 1e-3) / 1e9
-        r["interior_rows"], r["interior_nnz"] = n_int, nnz_int
-    if world == 1 and not args.no_extra:
+    if not args.no_extra:
         # secondary results, after the C3 line's own timed region: the other single-GPU BASELINE configurations
         from fdapde_core_amd import workloads
 
@@ -274,9 +356,83 @@ def main():
             except Exception as e:   # never let a secondary result take the bench line down
                 extra[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
         out["extra"] = extra
-    if world == 1 and not args.no_cpu_baseline:
+    if not args.no_cpu_baseline:
         out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baseline(args.cpu_nx)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+
+
+def run_ranks(args, rank, world, local_rank):
+    from fdapde_loader import load_package
+
+    load_package()   # the library first: the process binds to /opt/rocm's HIP runtime, and RCCL is taken from the same installation
+    from fdapde_core_amd import capi
+    from fdapde_core_amd import dist as fdist
+
+    lib = capi.load()
+    n_dev = int(lib.fdapde_device_count())
+    if n_dev < 1:
+        raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
+    backend = os.environ.get("FDAPDE_BENCH_BACKEND", "rccl")
+    if backend == "nccl":
+        backend = "rccl"
+    if backend == "rccl" and n_dev < world:
+        raise SystemExit(f"--gpus {world} but this node shows {n_dev} HIP devices (RCCL needs one device per rank; "
+                         "FDAPDE_BENCH_BACKEND=gloo runs the plumbing with ranks sharing devices)")
+    rdzv = FileRendezvous(rank, world)
+    out = fdist.bench_partitioned(capi, rdzv, rank, world, local_rank % n_dev, args, RTOL, backend)
+    if rank != 0:
+        return
+    res = out
+    info = res["info"]
+    line = {
+        "metric": "DOF/s assemble+solve, 3D P1 Laplacian; SpMV achieved HBM GB/s vs peak",
+        "value": res["total_dofs"] * args.steps / res["elapsed"],
+        "unit": "DOF/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * res["elapsed"] / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"C3: 3-D P1 Laplacian, [0,1]^3, {args.nx}^3 x 6 Kuhn tetrahedra = {res['n_cells_total']} cells, "
+                        f"{res['total_dofs']} DOFs, jitter 0.2h, ids permuted, seed 12345; "
+                        "u = sin(pi x) sin(pi y) sin(pi z), homogeneous Dirichlet; init (stiff+force+mass) + Jacobi-PCG rtol 1e-10",
+            "parallelism": res["parallelism"],
+            "cg_iterations": int(info.iters),
+            "relres": float(info.relres),
+            "t_assemble_ms": res["t_asm"],
+            "t_solve_ms": res["t_sol"],
+            "t_setup_ms_untimed": res["setup_ms"],
+            "t_partition_s_untimed": res["t_partition"],
+            "max_abs_error_vs_analytic": res["err"],
+            "persistent_launch": int(getattr(info, "persistent", 0)),
+            "us_per_iteration": 1e3 * res["t_sol"] / max(int(info.iters), 1),
+            "transport": res["transport"],
+        },
+        "roofline": roofline_of(res["infos"], res["alg_bytes"], res["streamed_bytes"], args.nx, world),
+    }
+    line["roofline"]["note"] = "the largest rank-local operator"
+    print(json.dumps(line), flush=True)
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start it plainly (python bench.py --gpus {args.gpus}) or with "
+                         f"torch.distributed.run --nproc-per-node {args.gpus}")
+    if world == 1:
+        run_single(args)
+    else:
+        run_ranks(args, rank, world, local_rank)
 
 
 if __name__ == "__main__":

@@ -35,7 +35,7 @@ class Info(C.Structure):
     _fields_ = [("iters", C.c_int32), ("converged", C.c_int32), ("relres", C.c_double), ("t_assemble_ms", C.c_double),
                 ("t_solve_ms", C.c_double), ("t_setup_ms", C.c_double), ("spmv_avg_ms", C.c_double), ("spmv_timed", C.c_int32),
                 ("method_used", C.c_int32), ("persistent", C.c_int32), ("gather_avg_ms", C.c_double), ("update_avg_ms", C.c_double),
-                ("spmv_mean_ms", C.c_double)]
+                ("spmv_mean_ms", C.c_double), ("launch_ms", C.c_double)]
 
 
 # every symbol include/fdapde_hip.h declares (tests check that the library exports all of them)
@@ -47,7 +47,7 @@ SYMBOLS = [
     "fdapde_info_get", "fdapde_spmv", "fdapde_bench_spmv", "fdapde_tune", "fdapde_stream", "fdapde_synchronize",
     "fdapde_comm_unique_id", "fdapde_comm_init", "fdapde_halo_setup", "fdapde_solve_parabolic",
     "fdapde_lin_compute", "fdapde_lin_solve", "fdapde_eval_pointwise", "fdapde_cell_integrals", "fdapde_comm_init_callback", "fdapde_comm_set_exchange_callback", "fdapde_halo_setup_peers",
-    "fdapde_solver_layout", "fdapde_topology_build", "fdapde_topology_get",
+    "fdapde_solver_layout", "fdapde_topology_build", "fdapde_topology_get", "fdapde_comm_allreduce", "fdapde_comm_library", "fdapde_solver_layout_kind",
 ]
 
 _lib = None
@@ -63,6 +63,7 @@ def load() -> C.CDLL:
         lib.fdapde_last_error.restype = C.c_char_p
         lib.fdapde_status_string.restype = C.c_char_p
         lib.fdapde_stream.restype = C.c_void_p
+        lib.fdapde_comm_library.restype = C.c_char_p
         lib.fdapde_ctx_destroy.restype = None
         _lib = lib
     return _lib
@@ -309,14 +310,14 @@ class Context:
         v = None if values is None else np.ascontiguousarray(values, dtype=float)
         self._check(self.lib.fdapde_lin_compute(self._ctx, which, None if v is None else _dp(v), 1 if symmetric else 0))
 
-    def lin_solve(self, b, method=SOLVER_AUTO, rtol=1e-10):
+    def lin_solve(self, b, method=SOLVER_AUTO, rtol=1e-10, check_every=0):
         """fdapde::SparseLU::solve(b); b (n_dofs,) or (n_dofs, n_rhs)"""
         b = np.asarray(b, dtype=float)
         one = b.ndim == 1
         B = b.reshape(b.shape[0], -1)
         flat = np.ascontiguousarray(B.T).reshape(-1)
         out = np.zeros_like(flat)
-        opt = Options(method=method, maxit=0, rtol=rtol, assembly=0, check_every=0, time_spmv=0)
+        opt = Options(method=method, maxit=0, rtol=rtol, assembly=0, check_every=check_every, time_spmv=0)
         info = Info()
         self._check(self.lib.fdapde_lin_solve(self._ctx, C.byref(opt), _dp(flat), B.shape[1], _dp(out), C.byref(info)))
         X = np.ascontiguousarray(out.reshape(B.shape[1], B.shape[0]).T)
@@ -401,6 +402,12 @@ class Context:
         self._check(self.lib.fdapde_solver_layout(self._ctx, 1 if with_dirichlet else 0, C.byref(ni), C.byref(nz), C.byref(by)))
         return ni.value, nz.value, by.value
 
+    def solver_layout_kind(self, with_dirichlet=True):
+        """dict(kind: 0 CSR | 1 blocked ELL | 2 persistent streaming | 3 persistent resident, sym, workgroups, rows_per_thread)"""
+        k, sy, g, r = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self.lib.fdapde_solver_layout_kind(self._ctx, 1 if with_dirichlet else 0, C.byref(k), C.byref(sy), C.byref(g), C.byref(r)))
+        return dict(kind=k.value, sym=sy.value, workgroups=g.value, rows_per_thread=r.value)
+
     # ---- multi-GPU
     @staticmethod
     def comm_unique_id() -> bytes:
@@ -412,6 +419,16 @@ class Context:
 
     def comm_init(self, world, rank, unique_id: bytes):
         self._check(self.lib.fdapde_comm_init(self._ctx, int(world), int(rank), C.c_char_p(unique_id)))
+
+    def comm_allreduce(self, values, op="sum"):
+        """sum / max of a float64 array over the ranks of the communicator (through the library's own RCCL communicator)"""
+        a = np.ascontiguousarray(np.asarray(values, dtype=float)).copy()
+        self._check(self.lib.fdapde_comm_allreduce(self._ctx, _dp(a), int(a.size), 0 if op == "sum" else 1))
+        return a
+
+    @staticmethod
+    def comm_library():
+        return (load().fdapde_comm_library() or b"").decode()
 
     def comm_init_callback(self, world, rank, allreduce):
         """host-staged transport: allreduce(numpy float64 array) must sum it over all ranks in place"""

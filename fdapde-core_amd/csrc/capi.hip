@@ -16,6 +16,18 @@
 
 namespace {
 
+// FDAPDE_DEBUG_TIMING=1: wall-clock marks of the host side of a solve on stderr (where a first solve spends its time)
+struct DebugClock {
+    bool on = std::getenv("FDAPDE_DEBUG_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void mark(const char* what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[timing] %-34s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 int fail(fdapde_ctx* c, int code, const char* msg) {
     c->err = msg;
     return code;
@@ -767,6 +779,7 @@ int fdapde_ctx_create(int device, fdapde_ctx** out) {
         }
         if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+            hipEventCreate(&c->ev_p0) != hipSuccess || hipEventCreate(&c->ev_p1) != hipSuccess ||
             hipHostMalloc(reinterpret_cast<void**>(&c->h_ctl), 4 * sizeof(int32_t)) != hipSuccess ||
             hipHostMalloc(reinterpret_cast<void**>(&c->h_sc), 16 * sizeof(double)) != hipSuccess) {
             delete c;
@@ -799,7 +812,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
         c->halo_inv.release(), c->if_slot.release();
         c->peer_send_dof.release(), c->peer_src_off.release(), c->peer_src.release(), c->peer_sendbuf.release(), c->peer_recvbuf.release();
         if (c->comm) (void)g_rccl.CommDestroy(c->comm);
-        c->lin_mat.release(), c->persist_stats.release(), c->coords_e.release();
+        c->lin_mat.release(), c->ar_dev.release(), c->persist_stats.release(), c->persist_x.release(), c->coords_e.release();
         dev_topology_release(&c->topo);
         c->part_cells.release(), c->part_off.release(), c->part_slots.release(), c->wave_slots.release(), c->part_shared.release();
         for (auto& bk : c->bk)
@@ -807,13 +820,13 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
               bk.ell_code.release(), bk.ell_val.release();
         for (auto& ps : c->ps)
             ps.slot_dof.release(), ps.sl_off.release(), ps.ell_src.release(), ps.exp_off.release(), ps.imp_off.release(),
-              ps.imp_pos.release(), ps.ell_off.release(), ps.ell_code.release(), ps.exp_slot.release(), ps.ell_val.release(), ps.board.release();
+              ps.imp_pos.release(), ps.ell_off.release(), ps.ell_code.release(), ps.exp_slot.release(), ps.ell_val.release(), ps.board.release(), ps.amax.release();
         for (int v = 0; v < 2; ++v)
             c->sp_rowptr[v].release(), c->sp_colidx[v].release(), c->sp_map[v].release(), c->sp_tbase[v].release(), c->sp_col16[v].release(),
               c->sp_vrow[v].release();
         if (c->h_ctl) (void)hipHostFree(c->h_ctl);
         if (c->h_sc) (void)hipHostFree(c->h_sc);
-        (void)hipEventDestroy(c->ev0), (void)hipEventDestroy(c->ev1);
+        (void)hipEventDestroy(c->ev0), (void)hipEventDestroy(c->ev1), (void)hipEventDestroy(c->ev_p0), (void)hipEventDestroy(c->ev_p1);
         for (hipEvent_t e : c->ev_spmv) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(c->stream);
     }
@@ -904,6 +917,10 @@ int fdapde_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs) {
         HIPCHK(c, hipSetDevice(c->device));
         rc = upload_space(c);
         if (rc) return rc;
+        // small systems build their single-launch solver layout on the host (build_persist_once): the pattern's host mirror is fetched
+        // here, as part of the set-up, not by the first solve (the first larger device-to-host copy of a process costs ~8 ms)
+        if (c->hs.n_dofs <= c->persist_host_below)
+            if (int rc2 = ensure_host(c, kHostPattern)) return rc2;
     }
     c->info = fdapde_info{};
     c->info.t_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1286,8 +1303,13 @@ int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_r
     const int n_wg = block_rows ? (int)block_rows->size() : c->n_cu;
     PersistLayout pl;
     DevPersist dp;
+    DebugClock clk;
     const char* mode = std::getenv("FDAPDE_SETUP");
     bool on_device = !(mode && std::strcmp(mode, "host") == 0);
+    // small systems: the host builder (microseconds of index work + nine small uploads) instead of ~40 device launches, sorts and
+    // synchronisations that cost the same whatever the size -- the first solve of a 587-DOF system took 13.5 ms with them
+    // (downstream models solve many small systems; the arrays are identical either way)
+    if (c->hs.n_dofs <= c->persist_host_below && !(mode && std::strcmp(mode, "device") == 0)) on_device = false;
     double max_mb = 1024.0;   // ELL bytes (10 per entry) of the whole system (the row bound -- G x 8192 -- is reached first for P1 systems)
     if (const char* e = std::getenv("FDAPDE_PERSIST_MAX_MB")) max_mb = std::atof(e);
     const size_t lds_total = 160 * 1024 - 1024;   // static arrays of the kernel + slack
@@ -1306,7 +1328,9 @@ int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_r
             if (rc == FDAPDE_EUNSUPPORTED && c->hs.max_row > 255) on_device = false;   // rows too long for its sort keys: host builder
         }
         if (!on_device) {
+            clk.mark("build_persist: (before ensure_host)");
             if (int rc2 = ensure_host(c, kHostPattern)) return rc2;
+            clk.mark("build_persist: ensure_host");
             rc = host_build_persist_layout(c->hs, v == 1, n_wg, 12000, pl, brows, sym_mode, balance);   // ~12 000 ELL entries (120 KB) next to the vectors of <= 4096 rows
         }
         if (rc == FDAPDE_EUNSUPPORTED) return FDAPDE_OK;
@@ -1342,6 +1366,7 @@ int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_r
         }
         break;
     }
+    clk.mark("build_persist: layout");
     // resident form when every block fits its workgroup's LDS next to the vectors; else the blocks stream every iteration
     ps.stream = fixed + 10 * (size_t)need > lds_total;
     if (fixed > lds_total || (pl.R == 16 && !ps.stream)) {   // (no resident instantiation for 8192 rows: they never fit)
@@ -1379,9 +1404,12 @@ int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_r
     HIPCHK(c, ps.ell_val.alloc((size_t)pl.n_entries + 256));
     HIPCHK(c, hipMemsetAsync(ps.ell_val.p, 0, sizeof(double) * ((size_t)pl.n_entries + 256), st));
     HIPCHK(c, ps.board.alloc(2 * (size_t)pl.n_board + 2 * (size_t)pl.G * 6 + 2));   // p entries | dot partials x 2 parities
+    HIPCHK(c, hipMemsetAsync(ps.board.p, 0, sizeof(unsigned long long) * ps.board.n, st));   // every tag 0: no launch uses epoch 0
+    ps.epoch_next = 0, ps.attr_set = nullptr;
     HIPCHK(c, ps.amax.alloc(1));
     HIPCHK(c, c->persist_stats.alloc(4 * 1024));
     HIPCHK(c, hipStreamSynchronize(st));
+    clk.mark("build_persist: uploads + allocs");
     if (std::getenv("FDAPDE_DEBUG_SETUP"))
         std::fprintf(stderr, "persistent CG layout %d (%s-built): %d workgroups x %d rows/thread, %lld interior rows, %lld entries (%lld stored, %.1f %% padding), "
                      "LDS %zu B (%s%s, largest block %lld), imports <= %d, exports <= %d, board %lld\n", v, on_device ? "device" : "host", pl.G, pl.R,
@@ -1395,7 +1423,8 @@ int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_r
     return FDAPDE_OK;
 }
 
-// launch of k_cg_persist on the layout ps (boards and statistics cleared first)
+// launch of k_cg_persist on the layout ps.  The boards are NOT cleared: every launch tags its granules with epochs of its own
+// (ps.epoch_next + iteration + 1, strictly increasing from launch to launch), so what an earlier launch left behind never matches.
 int launch_persist(fdapde_ctx* c, fdapde_ctx::Persist& ps, PersistArgs& a) {
     hipStream_t st = c->stream;
     a.G = ps.meta.G, a.nsl = ps.meta.nsl, a.imp_cap = ps.imp_cap, a.lds_cap = ps.lds_cap;
@@ -1404,33 +1433,54 @@ int launch_persist(fdapde_ctx* c, fdapde_ctx::Persist& ps, PersistArgs& a) {
     a.ell_val = ps.ell_val.p, a.exp_off = ps.exp_off.p, a.exp_slot = ps.exp_slot.p, a.imp_off = ps.imp_off.p, a.imp_pos = ps.imp_pos.p;
     a.pboard = ps.board.p, a.dboard = ps.board.p + 2 * (size_t)ps.meta.n_board;
     a.amax_bits = ps.amax.p, a.max_len = c->hs.max_row, a.stats = c->persist_stats.p;
-    HIPCHK(c, hipMemsetAsync(ps.board.p, 0, sizeof(unsigned long long) * ps.board.n, st));   // every tag 0: no epoch of this launch
-    HIPCHK(c, hipMemsetAsync(c->persist_stats.p, 0, 4 * (size_t)a.G * sizeof(double), st));
-#define PERSIST_GO(R_, ST_)                                                                                                     \
+    a.timeout_ticks = c->persist_timeout_us * 100, a.debug_stall_it = c->persist_debug_stall;
+    if (ps.epoch_next > 0xE0000000u - (uint32_t)a.maxit) {   // (the tags are 32 bits wide: start over on clean boards)
+        HIPCHK(c, hipMemsetAsync(ps.board.p, 0, sizeof(unsigned long long) * ps.board.n, st));
+        ps.epoch_next = 0;
+    }
+    a.epoch0 = ps.epoch_next;
+    if (a.time_phases) HIPCHK(c, hipMemsetAsync(c->persist_stats.p, 0, 4 * (size_t)a.G * sizeof(double), st));
+    HIPCHK(c, hipEventRecord(c->ev_p0, st));
+    void* kargs[] = {&a};
+    // co-residency of the G workgroups is what the in-kernel hand-offs rely on: G <= (workgroups of this instantiation the runtime says a
+    // CU holds) x CUs, checked below through the occupancy API; knob persist_coop makes the launch cooperative on top (the runtime then
+    // refuses a grid that cannot be resident instead of letting it spin -- at 10.5 ms for the first such launch of a process)
+#define PERSIST_GO(R_, ST_, SY_)                                                                                                \
     do {                                                                                                                        \
-        if (ps.meta.sym) {                                                                                                      \
-            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cg_persist<R_, ST_, true>),                          \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ps.lds_bytes));                      \
-            hipLaunchKernelGGL((k_cg_persist<R_, ST_, true>), dim3(a.G), dim3(kPersistT), ps.lds_bytes, st, a);                 \
-        } else {                                                                                                                \
-            HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cg_persist<R_, ST_, false>),                         \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ps.lds_bytes));                      \
-            hipLaunchKernelGGL((k_cg_persist<R_, ST_, false>), dim3(a.G), dim3(kPersistT), ps.lds_bytes, st, a);                \
+        const void* fn = reinterpret_cast<const void*>(&k_cg_persist<R_, ST_, SY_>);                                            \
+        if (ps.attr_set != fn) {                                                                                                \
+            DebugClock clk2;                                                                                                    \
+            HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ps.lds_bytes));                  \
+            clk2.mark("launch_persist: hipFuncSetAttribute");                                                                   \
+            int per_cu = 0;                                                                                                     \
+            HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kPersistT, ps.lds_bytes));                      \
+            clk2.mark("launch_persist: occupancy query");                                                                       \
+            if ((int64_t)per_cu * c->n_cu < (int64_t)a.G) return FDAPDE_EUNSUPPORTED;   /* the grid cannot be resident at once */ \
+            ps.attr_set = fn;                                                                                                   \
         }                                                                                                                       \
+        if (c->persist_coop) HIPCHK(c, hipLaunchCooperativeKernel(fn, dim3(a.G), dim3(kPersistT), kargs, (unsigned)ps.lds_bytes, st)); \
+        else hipLaunchKernelGGL((k_cg_persist<R_, ST_, SY_>), dim3(a.G), dim3(kPersistT), ps.lds_bytes, st, a);                 \
+    } while (0)
+#define PERSIST_GO2(R_, ST_)                                                                                                    \
+    do {                                                                                                                        \
+        if (ps.meta.sym) PERSIST_GO(R_, ST_, true);                                                                             \
+        else PERSIST_GO(R_, ST_, false);                                                                                        \
     } while (0)
     if (ps.stream) switch (ps.meta.R) {
-        case 2: PERSIST_GO(2, true); break;
-        case 4: PERSIST_GO(4, true); break;
-        case 8: PERSIST_GO(8, true); break;
-        default: PERSIST_GO(16, true); break;
+        case 2: PERSIST_GO2(2, true); break;
+        case 4: PERSIST_GO2(4, true); break;
+        case 8: PERSIST_GO2(8, true); break;
+        default: PERSIST_GO2(16, true); break;
         }
     else switch (ps.meta.R) {
-        case 2: PERSIST_GO(2, false); break;
-        case 4: PERSIST_GO(4, false); break;
-        default: PERSIST_GO(8, false); break;
+        case 2: PERSIST_GO2(2, false); break;
+        case 4: PERSIST_GO2(4, false); break;
+        default: PERSIST_GO2(8, false); break;
         }
+#undef PERSIST_GO2
 #undef PERSIST_GO
     HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev_p1, st));
     return FDAPDE_OK;
 }
 
@@ -1445,28 +1495,52 @@ int build_persist(fdapde_ctx* c, int v) {
     return FDAPDE_OK;
 }
 
-// the whole fused-update CG as one launch; returns FDAPDE_OK with *ran = false when the launch gave up (hand-off timeout)
+// the whole fused-update CG as one launch; returns FDAPDE_OK with *ran = false when the launch gave up (hand-off timeout): a launch
+// that gives up leaves x (it writes the solution to persist_x), r, p, sc and ctl[0..2] as it found them, so the multi-launch
+// path restarts the same solve from the same state
 int run_persist(fdapde_ctx* c, int v, double tol2, int maxit, bool* ran) {
     fdapde_ctx::Persist& ps = c->ps[v];
     hipStream_t st = c->stream;
+    const size_t n = (size_t)c->hs.n_dofs;
+    if (c->persist_x.n < n) {   // rows the layout leaves out (Dirichlet DOFs) are never written: they must read as finite numbers
+        HIPCHK(c, c->persist_x.alloc(n));
+        HIPCHK(c, hipMemsetAsync(c->persist_x.p, 0, sizeof(double) * n, st));
+    }
     PersistArgs a{};
     a.maxit = maxit, a.time_phases = c->persist_time, a.tol2 = tol2;
-    a.r_in = c->r.p, a.x = c->x.p, a.sc = c->sc.p, a.ctl = c->ctl.p;
-    if (int rc = launch_persist(c, ps, a)) return rc;
+    a.r_in = c->r.p, a.x = c->x.p, a.x_out = c->persist_x.p, a.sc = c->sc.p, a.ctl = c->ctl.p;
+    DebugClock clk;
+    const int rc_launch = launch_persist(c, ps, a);
+    clk.mark("run_persist: launch call");
+    if (int rc = rc_launch) {
+        if (rc != FDAPDE_EUNSUPPORTED) return rc;
+        ps.ok = false, *ran = false;   // the occupancy the runtime reports does not hold the grid: this layout never launches
+        return FDAPDE_OK;
+    }
     HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(c->h_sc, c->sc.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
-    c->persist_host_stats.resize(4 * (size_t)a.G);
-    HIPCHK(c, hipMemcpyAsync(c->persist_host_stats.data(), c->persist_stats.p, 4 * (size_t)a.G * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (a.time_phases) {
+        c->persist_host_stats.resize(4 * (size_t)a.G);
+        HIPCHK(c, hipMemcpyAsync(c->persist_host_stats.data(), c->persist_stats.p, 4 * (size_t)a.G * sizeof(double), hipMemcpyDeviceToHost, st));
+    } else
+        c->persist_host_stats.clear();
     HIPCHK(c, hipStreamSynchronize(st));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev_p0, c->ev_p1));
+    c->persist_launch_ms = ms;
     *ran = c->h_ctl[3] == 0;
-    if (!*ran) {   // a peer workgroup was not resident (other work on the device?): nothing was written.  The context stays on the
-                   // multi-launch path for a while and tries again later, twice as much later after every failure (8, 16, ... 1024 solves)
+    if (!*ran) {   // a peer workgroup was not resident (other work on the device?).  The context stays on the multi-launch path for a
+                   // while and tries again later, twice as much later after every failure (8, 16, ... 1024 solves)
         c->persist_broken = true;
         c->persist_retry_in = c->persist_backoff;
         c->persist_backoff = std::min(1024, 2 * c->persist_backoff);
         HIPCHK(c, hipMemsetAsync(c->ctl.p + 3, 0, sizeof(int32_t), st));
-    } else
+        HIPCHK(c, hipMemsetAsync(ps.board.p, 0, sizeof(unsigned long long) * ps.board.n, st));   // (how far its epochs got is unknown)
+        ps.epoch_next = 0;
+    } else {
         c->persist_backoff = 8;
+        ps.epoch_next += (uint32_t)c->h_ctl[1] + 2u;
+    }
     return FDAPDE_OK;
 }
 
@@ -1671,7 +1745,9 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     bool persisted = false;
     if (cgf && !dist && c->persist && !c->persist_broken && c->ps[ss.use_bnd ? 1 : 0].ok && c->ps[ss.use_bnd ? 1 : 0].filled) {
         // the whole iteration as ONE launch (kernels_persist.h); it leaves sc / ctl as the loop below would
+        DebugClock clk;
         if (int rc = run_persist(c, ss.use_bnd ? 1 : 0, tol2, maxit, &persisted)) return rc;
+        clk.mark("solve_run: run_persist");
         if (persisted) stop = true, launched = c->h_ctl[1];
     }
     // one iteration of the fused-update CG: SpMV (p.y, y.y) + k_cgf_update; arguments depend on the iteration's parity only
@@ -1712,6 +1788,9 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
             key.sval = c->sval.p, key.rowptr = c->sp_cur >= 0 ? (const void*)c->sp_rowptr[c->sp_cur].p : (const void*)c->rowptr.p;
             key.n = n, key.tol2 = tol2, key.chunk = chunk, key.v = cgf_V, key.grid = c->spmv_grid, key.team = c->spmv_team;
             key.ablate = c->spmv_ablate, key.c16 = c->spmv_c16, key.deep = c->spmv_deep, key.unroll = c->spmv_unroll, key.sp_cur = c->sp_cur;
+            // the blocked-ELL layout the captured SpMV nodes read from (its arrays and grid are baked into the graph)
+            key.bk_cur = c->bk_cur, key.bk_G = c->bk_cur >= 0 ? c->bk[c->bk_cur].meta.G : 0;
+            key.bk_val = c->bk_cur >= 0 ? (const void*)c->bk[c->bk_cur].ell_val.p : nullptr;
             if (!c->cg_graph_exec || std::memcmp(&key, &c->cg_graph_key, sizeof key) != 0) {
                 if (c->cg_graph_exec) (void)hipGraphExecDestroy(c->cg_graph_exec), c->cg_graph_exec = nullptr;
                 hipGraph_t g = nullptr;
@@ -1829,9 +1908,9 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
         HIPCHK(c, hipMemcpyAsync(c->h_sc, c->sc.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
     }
-    if (cgf && c->cgf_lazy)   // an update of x may still be pending (convergence seen at a poll, or maxit)
+    if (cgf && c->cgf_lazy && !persisted)   // an update of x may still be pending (convergence seen at a poll, or maxit)
         hipLaunchKernelGGL(k_cgf_flush, dim3(c->vec_grid), dim3(256), 0, st, n, c->p.p, c->r.p, c->x.p, c->sc.p, c->ctl.p);
-    hipLaunchKernelGGL(k_unscale, dim3(g1(n)), dim3(256), 0, st, n, c->scale.p, c->x.p, c->gt.p, c->u.p);
+    hipLaunchKernelGGL(k_unscale, dim3(g1(n)), dim3(256), 0, st, n, c->scale.p, persisted ? c->persist_x.p : c->x.p, c->gt.p, c->u.p);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(st));
     const double bb = c->h_sc[0], rr = c->h_sc[3];
@@ -1852,6 +1931,7 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
         if (real > 0) c->info.spmv_avg_ms = sum / real, c->info.spmv_timed = real;
     }
     c->info.persistent = persisted ? 1 : 0;
+    c->info.launch_ms = persisted ? c->persist_launch_ms : 0.0;
     c->info.gather_avg_ms = c->info.update_avg_ms = c->info.spmv_mean_ms = 0;
     if (persisted && !c->persist_host_stats.empty() && c->persist_host_stats[0] > 0) {
         // phase stamps of every workgroup (s_memrealtime ticks of 10 ns).  The operator application of an iteration is complete when
@@ -1942,6 +2022,7 @@ int fdapde_solver_layout(fdapde_ctx* c, int32_t with_dirichlet, int64_t* n_inter
     if (streamed_bytes) {
         if (persist) {   // one iteration of the persistent CG: the ELL blocks (8 + 2 bytes per entry, padding included) + the exchanged
                          // entries of p (two 8-byte granules each, written once and read once)
+            // (fdapde_solver_layout_kind tells whether the blocks stream at all: the resident form reads them from LDS)
             *streamed_bytes = 10.0 * (double)c->ps[v].meta.n_entries + 32.0 * (double)c->ps[v].meta.n_board;
         } else if (blocked) {   // ELL blocks + x staged once per block (own rows and imports) + y written once
             *streamed_bytes = 10.0 * (double)c->bk[v].meta.n_entries + 8.0 * (double)(c->bk[v].meta.n_int + c->bk[v].meta.n_imp) + 8.0 * (double)c->bk[v].meta.n_int;
@@ -1953,6 +2034,22 @@ int fdapde_solver_layout(fdapde_ctx* c, int32_t with_dirichlet, int64_t* n_inter
         } else
             *streamed_bytes = 12.0 * (double)hs.nnz + 4.0 * (double)(hs.n_dofs + 1) + 16.0 * (double)hs.n_dofs;
     }
+    return FDAPDE_OK;
+}
+
+// which layout the solver holds for the boundary variant (after fdapde_solver_prepare / a solve): kind 0 compact CSR, 1 blocked ELL
+// (multi-launch), 2 persistent launch with streaming blocks, 3 persistent launch with the blocks resident in LDS
+int fdapde_solver_layout_kind(fdapde_ctx* c, int32_t with_dirichlet, int32_t* kind, int32_t* symmetric_storage, int32_t* workgroups,
+                              int32_t* rows_per_thread) {
+    if (!c) return FDAPDE_EINVAL;
+    if (!c->dev_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
+    const int v = with_dirichlet ? 1 : 0;
+    const bool persist = c->persist && !c->persist_broken && c->ps[v].tried && c->ps[v].ok;
+    const bool blocked = !persist && c->bk[v].tried && c->bk[v].ok;
+    if (kind) *kind = persist ? (c->ps[v].stream ? 2 : 3) : blocked ? 1 : 0;
+    if (symmetric_storage) *symmetric_storage = persist && c->ps[v].meta.sym ? 1 : 0;
+    if (workgroups) *workgroups = persist ? c->ps[v].meta.G : blocked ? c->bk[v].meta.G : 0;
+    if (rows_per_thread) *rows_per_thread = persist ? c->ps[v].meta.R : blocked ? c->bk[v].meta.R : 0;
     return FDAPDE_OK;
 }
 
@@ -1970,9 +2067,12 @@ int fdapde_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     SolveState ss;
     c->scaled_owner = fdapde_ctx::kScaledSolve;
+    DebugClock clk;
     if (int rc = solve_prepare(c, A, c->have_g ? 1 : 0, &ss, c->op_symmetric)) return rc;
+    clk.mark("fdapde_solve: solve_prepare");
     const int rc = solve_run(c, ss, A, c->force.p, c->g.p, nullptr, opt ? opt->method : FDAPDE_SOLVER_AUTO, rtol, maxit, check_every,
                              opt ? opt->time_spmv : 0);
+    clk.mark("fdapde_solve: solve_run");
     if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev1));
@@ -2517,6 +2617,29 @@ int fdapde_comm_init(fdapde_ctx* c, int32_t world, int32_t rank, const void* uni
     return FDAPDE_OK;
 }
 
+// sum (op 0) or max (op 1) of n host doubles over the ranks of the context's communicator, in place: the barrier / timing reductions of a
+// multi-process driver that holds no other collective library (bench.py's ranks load this library and nothing else that touches the GPU)
+int fdapde_comm_allreduce(fdapde_ctx* c, double* host_inout, int32_t n, int32_t op) {
+    if (!c || !host_inout || n < 1 || (op != 0 && op != 1)) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (!c->comm && !c->ar_fn) return fail(c, FDAPDE_ENOTINIT, "call fdapde_comm_init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->ar_fn) {
+        if (op != 0 && c->world > 1) return fail(c, FDAPDE_EUNSUPPORTED, "the host-staged transport only sums");
+        if (c->world > 1 && c->ar_fn(c->ar_user, host_inout, (int64_t)n) != 0) return fail(c, FDAPDE_ERCCL, "all-reduce callback failed");
+        return FDAPDE_OK;
+    }
+    HIPCHK(c, c->ar_dev.alloc((size_t)n));
+    HIPCHK(c, hipMemcpyAsync(c->ar_dev.p, host_inout, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    RCCLCHK(c, g_rccl.AllReduce(c->ar_dev.p, c->ar_dev.p, (size_t)n, ncclFloat64, op == 0 ? ncclSum : ncclMax, c->comm, c->stream));
+    HIPCHK(c, hipMemcpyAsync(host_inout, c->ar_dev.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FDAPDE_OK;
+}
+
+// which RCCL the library bound itself to (diagnostics; empty before the first communicator call)
+const char* fdapde_comm_library(void) { return g_rccl.path.c_str(); }
+
 int fdapde_comm_init_callback(fdapde_ctx* c, int32_t world, int32_t rank, fdapde_allreduce_fn fn, void* user) {
     if (!c || !fn || world < 1 || rank < 0 || rank >= world) return FDAPDE_EINVAL;
     if (int rc = need_device(c)) return rc;
@@ -2652,6 +2775,10 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "asm_fq_bc" && (value == 0 || value == 1)) c->asm_fq_bc = value, c->fq_bc_ready = c->fq_bc_ready && value;   // (takes effect fully at the next fdapde_set_forcing)
     else if (k == "persist" && (value == 0 || value == 1)) c->persist = value, c->persist_broken = false;
     else if (k == "persist_time" && (value == 0 || value == 1)) c->persist_time = value;
+    else if (k == "persist_coop" && (value == 0 || value == 1)) c->persist_coop = value;
+    else if (k == "persist_timeout_us" && value >= 100 && value <= 10000000) c->persist_timeout_us = value;
+    else if (k == "persist_debug_stall" && value >= 0) c->persist_debug_stall = value;   // (tests: forces the hand-off timeout at that iteration)
+    else if (k == "persist_retry" && value == 1) c->persist_broken = false, c->persist_retry_in = 0, c->persist_backoff = 8;   // (tests: forget an earlier timeout)
     else if (k == "blocked" && value >= 0 && value <= 2) c->blocked = value;   // 2: also for short-row systems
     else if (k == "persist_gather_waves" && (value == 1 || value == 4)) c->persist_gather_waves = value;
     else if (k == "persist_poll_sleep" && value >= 0 && value <= 3) c->persist_poll_sleep = value;
@@ -2677,7 +2804,9 @@ void* fdapde_stream(fdapde_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int fdapde_synchronize(fdapde_ctx* c) {
     if (!c) return FDAPDE_EINVAL;
     if (int rc = need_device(c)) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipDeviceSynchronize());   // (what torch.cuda.synchronize() would do: nothing of this process is left running on the device)
     return FDAPDE_OK;
 }
 

@@ -61,6 +61,7 @@ template <typename T> struct DBuf {
 // RCCL is loaded on first use (dlopen) so that single-GPU users and CPU-only boxes never need it
 struct RcclApi {
     void* handle = nullptr;
+    std::string path;   // what was loaded (diagnostics)
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
@@ -72,9 +73,27 @@ struct RcclApi {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool load(std::string& err) {
         if (handle) return true;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (handle) break;
+        // ONE HIP / RCCL stack per process: RCCL is taken from the installation the HIP runtime THIS library is bound to comes from
+        // (the directory of the libamdhip64 that provides hipMalloc here: /opt/rocm/lib normally; the copy bundled with a PyTorch
+        // wheel when that was loaded into the process first and the loader resolved the shared soname to it), never by bare soname
+        // first -- a bare "librccl.so.1" returns whichever RCCL some other module of the process happened to load
+        std::vector<std::string> names;
+        Dl_info di;
+        if (dladdr(reinterpret_cast<const void*>(&hipGetDeviceCount), &di) && di.dli_fname) {
+            std::string dir(di.dli_fname);
+            const size_t cut = dir.rfind('/');
+            if (cut != std::string::npos) {
+                dir.resize(cut + 1);
+                names.push_back(dir + "librccl.so.1"), names.push_back(dir + "librccl.so");
+            }
+        }
+        for (const char* nme : {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"}) names.push_back(nme);
+        for (const std::string& name : names) {
+            handle = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (handle) {
+                path = name;
+                break;
+            }
         }
         if (!handle) {
             err = std::string("cannot load librccl: ") + dlerror();
@@ -96,7 +115,7 @@ struct RcclApi {
         return true;
     }
 };
-RcclApi g_rccl;
+inline RcclApi g_rccl;
 
 struct HostTerm {
     fdapde_term t;
@@ -117,7 +136,8 @@ struct GraphKey {
     const void* rowptr;
     int64_t n;
     double tol2;
-    int chunk, v, grid, team, ablate, c16, deep, unroll, sp_cur;
+    int chunk, v, grid, team, ablate, c16, deep, unroll, sp_cur, bk_cur, bk_G;
+    const void* bk_val;
 };
 
 // what solve_prepare decided for a system matrix (shared by the elliptic, parabolic and handle solves)
@@ -134,7 +154,7 @@ struct fdapde_ctx {
     int device = -1;
     bool has_device = false;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_p0 = nullptr, ev_p1 = nullptr;   // (ev_p*: around the persistent launch)
     std::vector<hipEvent_t> ev_spmv;   // 2 per timed SpMV launch
     std::string err;
     HostSpace hs;
@@ -216,6 +236,7 @@ struct fdapde_ctx {
     fdapde_allreduce_fn ar_fn = nullptr;     // host-staged transport (tests / non-RCCL fabrics) instead of the RCCL communicator
     void* ar_user = nullptr;
     std::vector<double> ar_host;
+    DBuf<double> ar_dev;                     // staging of fdapde_comm_allreduce
     int world = 1, rank = 0;
     bool halo_ready = false;
     int64_t n_if = 0, n_loc_if = 0;          // global / local interface DOF counts
@@ -263,8 +284,18 @@ struct fdapde_ctx {
         DBuf<unsigned long long> amax;       // symmetric storage: bit pattern of max |ell_val| (k_persist_fill)
         DBuf<unsigned long long> board;      // [2 n_board granules of p | 2 x G x 6 granules of dot partials], zeroed before every launch
         bool filled = false;                 // ell_val holds the currently scaled system
+        uint32_t epoch_next = 0;             // the next launch tags its granules epoch_next + iteration + 1
+        const void* attr_set = nullptr;      // kernel instantiation whose dynamic-LDS attribute is in place
     } ps[2];
     DBuf<double> persist_stats;
+    DBuf<double> persist_x;                  // the persistent launch writes its solution here (x stays the initial guess)
+    double persist_launch_ms = 0;            // duration of the last persistent launch (HIP events on the stream)
+    int persist_host_below = 32768;          // systems of at most this many DOFs build the persistent layout on the host (first-solve latency)
+    int persist_coop = 0;                    // 1: cooperative launch (the runtime refuses a grid that cannot be resident).  Off by default: the grid is
+                                             // sized from hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs already, the cooperative queue costs 10.5 ms
+                                             // the first time a process uses it, and launches of several processes on one device would serialise
+    int persist_timeout_us = 5000;           // bound of every in-kernel wait
+    int persist_debug_stall = 0;             // tests: iteration at which the last workgroup plays a non-resident peer
     // blocked-ELL SpMV (k_spmv_blocked) of the multi-launch Krylov kernels on one GPU: layouts for the two boundary variants
     struct Blocked {
         bool tried = false, ok = false, filled = false;

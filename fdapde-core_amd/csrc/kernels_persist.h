@@ -31,6 +31,9 @@ struct PersistArgs {
     int32_t lds_cap;                  // ELL entries staged in LDS by the resident form (multiple of 128; >= the largest block)
     int32_t time_phases;              // != 0: every workgroup accumulates its phase durations into stats
     int32_t gather_waves, poll_sleep; // all-gather of the dot records: polling wavefronts (4 | 1) and the pause between polls (0 none .. 3 long)
+    uint32_t epoch0;                  // tags of this launch are epoch0 + iteration + 1: boards are never cleared between launches
+    int32_t timeout_ticks;            // bound of every wait, in 10 ns ticks of s_memrealtime
+    int32_t debug_stall_it;           // > 0 (tests): the last workgroup leaves at this iteration without publishing, as a peer that is not resident would
     double tol2;
     const int32_t* slot_dof;
     const int64_t* ell_off;
@@ -46,9 +49,12 @@ struct PersistArgs {
     const unsigned long long* amax_bits;   // symmetric storage: bit pattern of max |stored value| (k_persist_fill)
     int32_t max_len;                       // symmetric storage: a row receives at most this many transposed products
     const double* r_in;           // initial residual (= initial direction), internal DOF order
-    double* x;                    // in: initial guess, out: solution (scaled unknowns), internal DOF order
+    const double* x;              // initial guess (scaled unknowns), internal DOF order
+    double* x_out;                // solution; a buffer of its own: a launch that gives up (ctl[3]) must leave the guess as it found it,
+                                  // whatever the workgroups that did finish have stored (the host restarts from x, r, p)
     double* sc;                   // sc[0] = reference norm^2 (in); sc[3] = final r.r (out)
-    int32_t* ctl;                 // out: [0] converged, [1] iterations, [2] breakdown, [3] hand-off timeout
+    int32_t* ctl;                 // out: [0] converged, [1] iterations, [2] breakdown -- written only by a launch that did not give up;
+                                  // [3] hand-off timeout (then ctl[0..2] and sc[3] are as the host left them)
     double* stats;                // per workgroup: [0] iterations timed, [1] operator phase (SpMV + imports), [2] all-gather phase (incl. the
                                   // wait for the slowest workgroup), [3] update phase -- sums of 10 ns ticks
 };
@@ -107,7 +113,7 @@ __device__ __forceinline__ double wave_sum64(double v) {
     return v;
 }
 
-constexpr long long kPersistTimeoutTicks = 5000000;   // 50 ms of s_memrealtime (100 MHz): a legitimate wait is an iteration's skew, tens of us
+// waits are bounded by PersistArgs::timeout_ticks of s_memrealtime (100 MHz): a legitimate wait is an iteration's skew, tens of us
 
 // R rows per thread (2, 4, 8, 16); passes [0, R / 2) hold rows that import nothing, passes [R / 2, R) the others (host_persist.cpp).
 // STREAM = false: the workgroup's whole block of the matrix is staged in LDS once and re-read from there every iteration.
@@ -204,7 +210,11 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
     double rr = 0;
     __syncthreads();
     for (;;) {
-        const unsigned epoch = (unsigned)it + 1u;
+        const unsigned epoch = a.epoch0 + (unsigned)it + 1u;
+        if (a.debug_stall_it > 0 && it == a.debug_stall_it && g == a.G - 1) {   // (wave-uniform)
+            status = 3;
+            break;
+        }
         long long c0 = 0, c1 = 0, c2 = 0;
         if (stamper) c0 = wall_clock64();
         // ---- p of the own rows into the LDS table; exported entries onto the board
@@ -227,7 +237,9 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
 #pragma unroll
             for (int ww = 0; ww < W; ++ww) m = fmax(m, pmax_w[ww]);
             // |sum| <= max_len max|a| max|p| < 2^(bexp + ilogb(m) + 1): scaled below 2^62
-            const int ex = m > 0.0 && m < 1.7e308 ? 61 - bexp - ilogb(m) : 0;
+            // (clamped: a block whose largest |p| is subnormal-small would ask for 2^ex beyond the exponent range -- inf scale, 0 inverse;
+            // such a p contributes nothing at fp64 whatever the scale)
+            const int ex = m > 0.0 && m < 1.7e308 ? min(max(61 - bexp - ilogb(m), -1000), 1000) : 0;
             tscale = ldexp(1.0, ex), tinv = ldexp(1.0, -ex);
         }
         // 8 (or fewer) rows per thread: the scaled p of the own rows stays in registers for the operator phase (with 16 there is no room:
@@ -372,7 +384,7 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
                     if ((spins & 63u) == 63u) {   // bounded by time, checked now and then
                         const long long now = wall_clock64();
                         if (t_wait == 0) t_wait = now;
-                        else if (now - t_wait > kPersistTimeoutTicks) {
+                        else if (now - t_wait > (long long)a.timeout_ticks) {
                             fail = true;
                             break;
                         }
@@ -445,7 +457,7 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
                         if ((spins & 63u) == 63u) {
                             const long long now = wall_clock64();
                             if (t_wait == 0) t_wait = now;
-                            else if (now - t_wait > kPersistTimeoutTicks) {
+                            else if (now - t_wait > (long long)a.timeout_ticks) {
                                 fail = true;
                                 break;
                             }
@@ -513,10 +525,10 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
             int32_t d;
             if constexpr (SYM) d = a.slot_dof[(size_t)g * S + j * T + tid];
             else d = dof[j];
-            if (d >= 0) a.x[d] = xv[j];
+            if (d >= 0) a.x_out[d] = xv[j];
         }
     }
-    if (g == 0 && tid == 0) {
+    if (g == 0 && tid == 0 && status != 3) {
         a.sc[3] = rr;
         a.ctl[0] = status == 1 ? 1 : 0, a.ctl[1] = it, a.ctl[2] = status == 2 ? 1 : 0;
     }

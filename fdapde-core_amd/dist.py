@@ -78,11 +78,11 @@ def boundary_flags(cells, boundary_nodes, keys, order):
     return flags
 
 
-def interface_info(cells, part, n_nodes, world, order=1, boundary_nodes=None):
+def interface_info(cells, part, n_nodes, world, order=1, boundary_nodes=None, key_sets=None):
     """-> (keys, owner, ifkeys, bflags): the sorted DOF keys of the whole mesh, the lowest rank touching each, the sorted
     keys touched by >= 2 ranks (the interface DOFs, globally indexed by their position in ifkeys), and the whole-mesh
     boundary flag per key (None without boundary_nodes)"""
-    per_rank = rank_key_sets(cells, part, n_nodes, world, order)
+    per_rank = key_sets if key_sets is not None else rank_key_sets(cells, part, n_nodes, world, order)
     allk = np.concatenate(per_rank)
     rank_of = np.repeat(np.arange(world, dtype=np.int32), [k.size for k in per_rank])
     keys, first, counts = np.unique(allk, return_index=True, return_counts=True)
@@ -90,17 +90,11 @@ def interface_info(cells, part, n_nodes, world, order=1, boundary_nodes=None):
     return keys, rank_of[first], keys[counts >= 2], bflags
 
 
-_key_sets_memo = {}
-
-
 def rank_key_sets(cells, part, n_nodes, world, order=1):
-    """the sorted DOF keys each rank touches (every rank computes all of them from the whole mesh); the last result is kept, so that
-    interface_info and peer_lists of the same partition share one pass over the cells"""
-    tag = (id(cells), id(part), int(n_nodes), int(world), int(order), cells.shape, int(part[:: max(1, part.size // 97)].sum()))
-    if _key_sets_memo.get("tag") != tag:
-        ck = _cell_keys(cells, n_nodes, order)
-        _key_sets_memo["tag"], _key_sets_memo["sets"] = tag, [np.unique(ck[part == r]) for r in range(world)]
-    return _key_sets_memo["sets"]
+    """the sorted DOF keys each rank touches: one pass over the cells of the whole mesh.  interface_info and peer_lists of one
+    partition both need it -- compute it once and hand it to both (key_sets=...)"""
+    ck = _cell_keys(cells, n_nodes, order)
+    return [np.unique(ck[part == r]) for r in range(world)]
 
 
 def peer_lists(local_keys, key_sets, rank):
@@ -160,24 +154,90 @@ def local_problem(nodes, cells, boundary, part, rank, world, info=None):
     return sub
 
 
-def bench_partitioned(capi, nodes, cells, bnd, f, u_exact, rank, world, local_rank, args, barrier, rtol, backend="nccl"):
-    """bench.py's N > 1 leg: the same C3 mesh split over `world` GPUs (strong scaling)."""
+def rank_problems_p1(nodes, cells, boundary, world):
+    """the P1 problem of every rank of an element partition of the whole mesh, as plain arrays (what bench.py's rank 0 ships to the
+    others): sub-mesh, interface maps of both exchange forms, ownership.  One pass over the whole mesh, on ONE rank."""
+    part = partition_cells(nodes, cells, world)
+    n = nodes.shape[0]
+    key_sets = rank_key_sets(cells, part, n, world, 1)
+    info = interface_info(cells, part, n, world, 1, boundary, key_sets=key_sets)
+    out = []
+    for r in range(world):
+        lp = local_problem(nodes, cells, boundary, part, r, world, info)
+        pr, po, pd = peer_lists(lp["keys"], key_sets, r)
+        out.append(dict(nodes=lp["nodes"], cells=lp["cells"], boundary=lp["boundary"], l2g=lp["l2g"], owned=lp["owned"],
+                        local_dof=lp["local_dof"], if_index=lp["if_index"], n_if_global=np.int64(lp["n_if_global"]),
+                        peer_rank=pr, peer_off=po, peer_dof=pd, n_nodes_total=np.int64(n), n_cells_total=np.int64(cells.shape[0])))
+    return out
+
+
+class _RcclGroup:
+    """barrier / reductions of the rank processes through the library's own RCCL communicator (no second GPU library in the process)"""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def max(self, values):
+        return self.ctx.comm_allreduce(values, "max")
+
+    def barrier(self):
+        self.ctx.comm_allreduce([0.0], "sum")
+
+
+class _GlooGroup:
+    def __init__(self):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+
+    def max(self, values):
+        t = self.torch.tensor(np.asarray(values, dtype=float))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return t.numpy()
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+def bench_partitioned(capi, rdzv, rank, world, device, args, rtol, backend="rccl"):
+    """bench.py's N > 1 leg: the C3 mesh split over `world` GPUs (strong scaling).  Rank 0 generates and partitions the mesh and hands
+    every rank its own problem through the rendezvous directory -- no other rank materialises the whole mesh.  -> dict (rank 0) / None"""
+    import io
     import time
 
-    import torch
-    import torch.distributed as dist
+    from . import meshgen
 
-    part = partition_cells(nodes, cells, world)
-    lp = local_problem(nodes, cells, bnd, part, rank, world)
-    dev = "cuda" if backend == "nccl" else "cpu"
-    ctx = capi.Context(device=local_rank)
+    t_part = time.perf_counter()
+    if rank == 0:
+        nodes, cells, bnd = meshgen.unit_cube(args.nx)
+        probs = rank_problems_p1(nodes, cells, bnd, world)
+        del nodes, cells, bnd
+        for r in range(1, world):
+            buf = io.BytesIO()
+            np.savez(buf, **probs[r])
+            rdzv.put(f"problem.{r}", buf.getvalue())
+        lp = probs[0]
+        del probs
+    else:
+        lp = dict(np.load(io.BytesIO(rdzv.get(f"problem.{rank}"))))
+    t_part = time.perf_counter() - t_part
+    u_exact, f = meshgen.manufactured(3)
+    ctx = capi.Context(device=device)
     ctx.mesh_upload(lp["nodes"], lp["cells"], lp["boundary"])
     n_loc = ctx.dofs_build(1)
-    if backend == "nccl":   # RCCL communicator of the library, bootstrapped with a broadcast of its unique id
-        uid = [capi.Context.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(world, rank, uid[0])
-    else:                   # plumbing checks only: host-staged transport over gloo
+    if backend == "rccl":   # RCCL communicator of the library; its 128-byte id travels through the rendezvous directory
+        if rank == 0:
+            rdzv.put("rccl_id", capi.Context.comm_unique_id())
+        ctx.comm_init(world, rank, rdzv.get("rccl_id"))
+        grp = _RcclGroup(ctx)
+        transport = f"RCCL ({capi.Context.comm_library()}), one rank per GPU; no other GPU library in the rank processes"
+    else:                   # plumbing checks only: host-staged transports over gloo (torch is imported AFTER the library)
+        import torch
+        import torch.distributed as dist
+
+        dist.init_process_group("gloo")
+        grp = _GlooGroup()
         ctx.comm_init_callback(world, rank, lambda arr: dist.all_reduce(torch.from_numpy(arr)))
 
         def exchange(ranks, off, send, recv):
@@ -193,69 +253,60 @@ def bench_partitioned(capi, nodes, cells, bnd, f, u_exact, rank, world, local_ra
                 recv[a:b] = t_in.numpy()
 
         ctx.comm_set_exchange_callback(exchange)
+        transport = "host-staged gloo (plumbing check, ranks may share a device; never used for reported numbers)"
     # neighbour-only exchange: per-peer packed segments (ncclSend / ncclRecv in one group), then the scalar all-reduce
-    pr, po, pd = peer_lists(lp["keys"], rank_key_sets(cells, part, nodes.shape[0], world, 1), rank)
     exchange_form = os.environ.get("FDAPDE_BENCH_EXCHANGE", "peers")   # "dense": the interface all-reduce of fdapde_halo_setup
+    pr, po = lp["peer_rank"], lp["peer_off"]
     if exchange_form == "peers":
-        ctx.halo_setup_peers(pr, po, pd, lp["owned"])
+        ctx.halo_setup_peers(pr, po, lp["peer_dof"], lp["owned"])
     else:
-        ctx.halo_setup(lp["n_if_global"], lp["local_dof"], lp["if_index"], lp["owned"])
-    msg = torch.tensor([float(8 * int(po[-1])), float(pr.size)], dtype=torch.float64, device=dev)   # bytes sent per exchange, peers
-    dist.all_reduce(msg, op=dist.ReduceOp.MAX)
+        ctx.halo_setup(int(lp["n_if_global"]), lp["local_dof"], lp["if_index"], lp["owned"])
+    msg = grp.max([float(8 * int(po[-1])), float(pr.size)])   # bytes sent per exchange, peers
     qn = ctx.quadrature_nodes()
     ctx.set_operator(-capi.laplacian())
     ctx.set_forcing(f(qn))
     ctx.set_dirichlet(np.zeros(n_loc))
     del qn
-    ctx.solver_prepare(True)   # set-up (untimed): compact solver pattern + column codes of this rank's sub-mesh
+    ctx.solver_prepare(True)   # set-up (untimed): solver layout of this rank's sub-mesh
 
     def step(time_spmv=0):
         ctx.init()
         return ctx.solve(rtol=rtol, time_spmv=time_spmv)
 
-    if exchange_form == "peers":   # one probe solve: if the grouped send / receive is refused on this fabric on ANY rank, all ranks fall
-                                   # back to the dense interface all-reduce together (a collective decision)
-        bad = 0
-        try:
-            step()
-        except capi.FdapdeError as e:
-            bad = 1
-            print(f"rank {rank}: neighbour-only exchange failed ({e}); falling back to the dense interface all-reduce", file=sys.stderr)
-        flag = torch.tensor([float(bad)], dtype=torch.float64, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if flag.item() > 0:
-            exchange_form = "dense"
-            ctx.halo_setup(lp["n_if_global"], lp["local_dof"], lp["if_index"], lp["owned"])
-
     for _ in range(args.warmup):
         step()
-    barrier()
+    grp.barrier()
+    ctx.synchronize()
     t0 = time.perf_counter()
     infos = [step(args.time_spmv) for _ in range(args.steps)]
-    barrier()
-    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)       # slowest rank defines the step time
+    ctx.synchronize()
+    grp.barrier()
+    elapsed = time.perf_counter() - t0
     u = ctx.solution()
-    err = torch.tensor([float(np.abs(u - u_exact(lp["nodes"])).max())], dtype=torch.float64, device=dev)
-    dist.all_reduce(err, op=dist.ReduceOp.MAX)
+    err = float(np.abs(u - u_exact(lp["nodes"])).max())
     info = infos[-1]
-    stats = torch.tensor([np.mean([i.spmv_avg_ms for i in infos]), np.mean([i.t_assemble_ms for i in infos]),
-                          np.mean([i.t_solve_ms for i in infos]), ctx.info().t_setup_ms], dtype=torch.float64, device=dev)
-    dist.all_reduce(stats, op=dist.ReduceOp.MAX)
     sizes = ctx.sizes()
     _, alg_bytes = ctx.bench_spmv(reps=1)
-    nnz_tot = torch.tensor([float(sizes["nnz"]), alg_bytes], dtype=torch.float64, device=dev)
-    dist.all_reduce(nnz_tot, op=dist.ReduceOp.MAX)       # the largest local matrix bounds the SpMV roofline figure
-    sizes = dict(sizes, nnz=int(nnz_tot[0].item()))
+    _, _, streamed = ctx.solver_layout(True)
+    red = grp.max([elapsed, err, np.mean([i.t_assemble_ms for i in infos]), np.mean([i.t_solve_ms for i in infos]), ctx.info().t_setup_ms,
+                   float(sizes["nnz"]), alg_bytes, streamed, np.mean([i.spmv_avg_ms for i in infos]), t_part])
+    if backend != "rccl":
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+    if rank != 0:
+        return None
+    for i in infos:   # the slowest rank's SpMV bounds the roofline figure
+        i.spmv_avg_ms = float(red[8])
     if exchange_form == "dense":
-        parallelism = (f"{world} GPUs, element partition (Morton chunks), {lp['n_if_global']} interface DOFs, single-reduction CG: ONE RCCL "
-                       f"all-reduce per iteration (interface entries of A r + r.Ar + r.r: {8 * (lp['n_if_global'] + 2)} bytes); roofline figures "
-                       "are the largest rank-local SpMV")
-        return (float(elapsed.item()), info, float(stats[0].item()), float(stats[1].item()), float(stats[2].item()),
-                float(err.item()), float(stats[3].item()), float(nnz_tot[1].item()), sizes, int(nodes.shape[0]), parallelism)
-    parallelism = (f"{world} GPUs, element partition (Morton chunks), {lp['n_if_global']} interface DOFs; single-reduction CG, per "
-                   f"iteration one grouped RCCL send / receive with every neighbour -- the interface entries of A r, <= {int(msg[1].item())} peers, "
-                   f"<= {int(msg[0].item())} bytes sent per rank -- and one 16-byte all-reduce of (r.Ar, r.r); roofline figures are the largest "
-                   "rank-local SpMV")
-    return (float(elapsed.item()), info, float(stats[0].item()), float(stats[1].item()), float(stats[2].item()),
-            float(err.item()), float(stats[3].item()), float(nnz_tot[1].item()), sizes, int(nodes.shape[0]), parallelism)
+        parallelism = (f"{world} GPUs, element partition (Morton chunks), {int(lp['n_if_global'])} interface DOFs, single-reduction CG: ONE RCCL "
+                       f"all-reduce per iteration (interface entries of A r + r.Ar + r.r: {8 * (int(lp['n_if_global']) + 2)} bytes)")
+    else:
+        parallelism = (f"{world} GPUs, element partition (Morton chunks), {int(lp['n_if_global'])} interface DOFs; single-reduction CG, per "
+                       f"iteration one grouped RCCL send / receive with every neighbour -- the interface entries of A r, <= {int(msg[1])} peers, "
+                       f"<= {int(msg[0])} bytes sent per rank -- and one 16-byte all-reduce of (r.Ar, r.r)")
+    return dict(elapsed=float(red[0]), err=float(red[1]), t_asm=float(red[2]), t_sol=float(red[3]), setup_ms=float(red[4]), info=info, infos=infos,
+                alg_bytes=float(red[6]), streamed_bytes=float(red[7]), total_dofs=int(lp["n_nodes_total"]), n_cells_total=int(lp["n_cells_total"]),
+                parallelism=parallelism, transport=transport, t_partition=float(red[9]))

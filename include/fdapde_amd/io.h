@@ -1,12 +1,15 @@
 // Fixture / mesh I/O of the facade: the CSV dialect of the reference's data files and the loader of its mesh directories.
 //   CSVReader<T>::parse_file   fdaPDE/utils/IO/csv_reader.h:75-117  (dense files: one header row, first column = row index, blanks and
 //                              double quotes dropped from every token, NA / NaN / nan -> quiet NaN)
+//   CSVReader<T>::parse_sparse_file   csv_reader.h:119-166 (the reference's parse_file<Eigen::Sparse>: 3-column files "index, row, col,
+//                              value", 1-based ids; the matrix is max row x max col, entries given twice are summed as setFromTriplets does)
 //   MeshLoader<M, N>           test/src/utils/mesh_loader.h:62-84     (points.csv, elements.csv, boundary.csv, edges.csv, neigh.csv;
 //                              ids are 1-based in the files: elements - 1; edges / neigh: x > 0 ? x - 1 : -1)
 // Written against the facade's own containers (single pass over the file, no second read for the size as the reference does).
 #ifndef FDAPDE_AMD_IO_H
 #define FDAPDE_AMD_IO_H
 
+#include <algorithm>
 #include <cstdlib>
 #include <fstream>
 #include <limits>
@@ -53,6 +56,52 @@ template <typename T> class CSVReader {
         DMatrix<T> m(rows, cols);
         for (int64_t i = 0; i < rows; ++i)
             for (int64_t j = 0; j < cols; ++j) m(i, j) = values[(size_t)(i * cols + j)];
+        return m;
+    }
+    // sparse files: one header row with four fields, then one line "index, row, col, value" per entry (ids 1-based)
+    SpMatrix<T> parse_sparse_file(const std::string& file) const {
+        std::ifstream in(file, std::ios::binary);
+        if (!in) throw std::runtime_error("CSVReader: cannot open " + file);
+        std::string line;
+        if (!std::getline(in, line) || count_fields(line) - 1 != 3) throw std::runtime_error(".csv file not in sparse 3-column format");
+        struct Entry {
+            int64_t row, col;
+            T value;
+        };
+        std::vector<Entry> entries;
+        int64_t n_rows = 0, n_cols = 0;
+        std::string tok[4];
+        while (std::getline(in, line)) {
+            if (line.empty() || line == "\r") continue;
+            int field = 0;
+            size_t pos = 0;
+            while (pos <= line.size() && field < 4) {
+                const size_t end = std::min(line.find(',', pos), line.size());
+                tok[field].clear();
+                for (size_t k = pos; k < end; ++k)
+                    if (line[k] != ' ' && line[k] != '"' && line[k] != '\r') tok[field] += line[k];
+                ++field, pos = end + 1;
+            }
+            if (field != 4) throw std::runtime_error("CSVReader: a line of " + file + " does not have three data fields");
+            const int64_t r = std::strtoll(tok[1].c_str(), nullptr, 10), c = std::strtoll(tok[2].c_str(), nullptr, 10);
+            if (r < 1 || c < 1) throw std::runtime_error("CSVReader: ids of a sparse file are 1-based (" + file + ")");
+            n_rows = std::max(n_rows, r), n_cols = std::max(n_cols, c);
+            entries.push_back({r - 1, c - 1, convert(tok[3])});
+        }
+        // CSR with sorted columns; an entry that appears more than once is the sum of its occurrences, in file order
+        std::stable_sort(entries.begin(), entries.end(), [](const Entry& a, const Entry& b) { return a.row != b.row ? a.row < b.row : a.col < b.col; });
+        SpMatrix<T> m;
+        m.n_rows = n_rows, m.n_cols = n_cols;
+        m.rowptr.assign((size_t)n_rows + 1, 0);
+        for (size_t k = 0; k < entries.size(); ++k) {
+            if (k > 0 && entries[k].row == entries[k - 1].row && entries[k].col == entries[k - 1].col) {
+                m.values.back() += entries[k].value;
+                continue;
+            }
+            m.colidx.push_back((int32_t)entries[k].col), m.values.push_back(entries[k].value);
+            ++m.rowptr[(size_t)entries[k].row + 1];
+        }
+        for (int64_t i = 0; i < n_rows; ++i) m.rowptr[(size_t)i + 1] += m.rowptr[(size_t)i];
         return m;
     }
    private:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FDAPDE_ABI_VERSION 2
+#define FDAPDE_ABI_VERSION 3
 
 enum {
     FDAPDE_OK = 0,
@@ -100,6 +100,8 @@ typedef struct {
                              their wait for the slowest workgroup's operator phase) */
     double update_avg_ms; /* persistent path: vector update phase per iteration (mean over workgroups) */
     double spmv_mean_ms;  /* persistent path: operator-application phase, mean over workgroups */
+    double launch_ms;     /* persistent path: duration of the ONE launch that ran the whole Krylov iteration (HIP events recorded on the
+                             context's stream right before and after the dispatch); 0 on the multi-launch path */
 } fdapde_info;
 
 typedef struct fdapde_ctx fdapde_ctx;
@@ -214,6 +216,11 @@ int fdapde_bench_spmv(fdapde_ctx *ctx, int32_t reps, double *avg_ms, double *alg
  * the solver's kernel streams from its compact coded layout.  Builds the layout if fdapde_solver_prepare has not. */
 int fdapde_solver_layout(fdapde_ctx *ctx, int32_t with_dirichlet, int64_t *n_interior, int64_t *nnz_interior,
                          double *streamed_bytes);
+/* Which layout that is: kind 0 compact CSR (k_spmv_team2), 1 blocked ELL (k_spmv_blocked), 2 single persistent launch with the blocks
+ * streaming from memory every iteration, 3 single persistent launch with the blocks resident in LDS (then streamed_bytes above is what
+ * the launch stages once, and an iteration moves the exchanged granules only); symmetric storage, workgroups, rows per thread. */
+int fdapde_solver_layout_kind(fdapde_ctx *ctx, int32_t with_dirichlet, int32_t *kind, int32_t *symmetric_storage,
+                              int32_t *workgroups, int32_t *rows_per_thread);
 /* ---- multi-GPU: element-partitioned meshes, one context (= one rank) per GPU --------------------------------------------
  * No reference counterpart (the reference is single-threaded, single address space).  Each rank uploads the sub-mesh of
  * its own cells (local node numbering), assembles its sub-assembled operator with the calls above, and the solve sums the
@@ -233,6 +240,11 @@ typedef int (*fdapde_allreduce_fn)(void *user, double *host_buf, int64_t count);
 int fdapde_comm_init_callback(fdapde_ctx *ctx, int32_t world, int32_t rank, fdapde_allreduce_fn fn, void *user);
 int fdapde_comm_unique_id(void *out128);
 int fdapde_comm_init(fdapde_ctx *ctx, int32_t world, int32_t rank, const void *unique_id128);
+/* sum (op 0) or max (op 1) of n host doubles over the ranks of the context's communicator, in place -- the barrier / timing
+ * reductions of a multi-process driver that loads no other GPU library (bench.py's ranks: ONE HIP / RCCL stack per process).
+ * RCCL is dlopen'ed from the installation the HIP runtime this library is bound to belongs to; fdapde_comm_library() names it. */
+int fdapde_comm_allreduce(fdapde_ctx *ctx, double *host_inout, int32_t n, int32_t op);
+const char *fdapde_comm_library(void);
 int fdapde_halo_setup(fdapde_ctx *ctx, int64_t n_if_global, int64_t n_if_local, const int32_t *local_dof,
                       const int32_t *if_index, const uint8_t *owned);
 /* Neighbour-only exchange instead of the dense interface vector of fdapde_halo_setup: per operator application a rank sends each
@@ -263,7 +275,9 @@ int fdapde_halo_setup_peers(fdapde_ctx *ctx, int32_t n_peers, const int32_t *pee
  *                 "asm_fq_bc" (0: the sweep gathers the forcing samples by cell id instead of reading their block-cell ordered copy)
  *   single-launch CG  "persist" (0: never run the solve as one persistent launch), "persist_time" (phase stamps), "persist_sym"
  *                 (0 plain storage, 1 symmetric storage, 2 symmetric where the plain blocks would stream), "persist_balance"
- *                 (workgroup boundaries at equal cost / equal row counts), "blocked" (blocked-ELL SpMV of the multi-launch solves) */
+ *                 (workgroup boundaries at equal cost / equal row counts), "blocked" (blocked-ELL SpMV of the multi-launch solves),
+ *                 "persist_coop" (0: plain instead of cooperative launch), "persist_timeout_us" (bound of every in-kernel wait),
+ *                 "persist_debug_stall" / "persist_retry" (tests: force a hand-off timeout at an iteration / forget one) */
 int fdapde_tune(fdapde_ctx *ctx, const char *key, int32_t value);
 /* the context's HIP stream (hipStream_t) so that callers can bracket work with their own events */
 void *fdapde_stream(fdapde_ctx *ctx);

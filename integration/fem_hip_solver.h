@@ -9,6 +9,9 @@
 //   FEMSolverBase::init                    finite_elements/solvers/fem_solver_base.h:104-139
 //   FEMSolverBase::set_dirichlet_bc        fem_solver_base.h:142-155
 //   FEMLinearEllipticSolver::solve         finite_elements/solvers/fem_linear_elliptic_solver.h:34-50
+//   FEMLinearParabolicSolver::solve        finite_elements/solvers/fem_linear_parabolic_solver.h:37-72 (+ set_deltaT, line 34)
+// The selector switches on is_parabolic<E> exactly as the reference's own (fem_solver_selector.h:29-33): an operator with a dT()
+// leaf under tag FEM_HIP gets the time-stepping solver, every other one the elliptic solver.
 #ifndef __FEM_HIP_SOLVER_H__
 #define __FEM_HIP_SOLVER_H__
 
@@ -18,7 +21,9 @@
 
 #include <fdapde_hip.h>   // this repository's C ABI (include/)
 
+#include "../../pde/differential_operators.h"   // is_parabolic<E>
 #include "../../pde/symbols.h"
+#include "../../utils/traits.h"                  // switch_type
 #include "../../utils/symbols.h"
 #include "fem_solver_base.h"
 
@@ -114,13 +119,14 @@ inline void fetch(fdapde_ctx* ctx, int which, std::int64_t n_dofs, SpMatrix<doub
 
 }   // namespace hip_detail
 
+// what both solvers share: the device context, init (assembly) and the Dirichlet data hand-over
 template <typename D, typename E, typename F, typename... Ts>
-struct FEMHipEllipticSolver : public FEMSolverBase<D, E, F, Ts...> {   // keeps basis_, integrator_, the getters and the flags
+struct FEMHipSolverBase : public FEMSolverBase<D, E, F, Ts...> {   // keeps basis_, integrator_, the getters and the flags
     using Base = FEMSolverBase<D, E, F, Ts...>;
     static constexpr int M = D::local_dim, N = D::embed_dim, R = Base::fem_order;
     fdapde_ctx* ctx_ = nullptr;
 
-    FEMHipEllipticSolver(const D& domain) : Base(domain) {
+    FEMHipSolverBase(const D& domain) : Base(domain) {
         if (fdapde_ctx_create(/*device*/ 0, &ctx_) != FDAPDE_OK) throw std::runtime_error("FEM_HIP: no HIP device (there is no CPU fallback)");
         DMatrix<int, Eigen::RowMajor> cells = domain.cells();                 // row-major int32 0-based (triangulation.h:120)
         std::vector<uint8_t> bnd(domain.n_nodes());
@@ -130,9 +136,9 @@ struct FEMHipEllipticSolver : public FEMSolverBase<D, E, F, Ts...> {   // keeps 
         std::int64_t n = 0;
         check(fdapde_dofs_build(ctx_, R, &n));                                // same numbering as basis_.dofs(), bit for bit
     }
-    FEMHipEllipticSolver(const FEMHipEllipticSolver&) = delete;              // one device context per solver object
-    FEMHipEllipticSolver& operator=(const FEMHipEllipticSolver&) = delete;
-    ~FEMHipEllipticSolver() { fdapde_ctx_destroy(ctx_); }
+    FEMHipSolverBase(const FEMHipSolverBase&) = delete;                      // one device context per solver object
+    FEMHipSolverBase& operator=(const FEMHipSolverBase&) = delete;
+    ~FEMHipSolverBase() { fdapde_ctx_destroy(ctx_); }
 
     template <typename PDE> void init(const PDE& pde) {                       // replaces fem_solver_base.h:104-139
         static_assert(is_pde<PDE>::value, "pde is not a valid PDE object");
@@ -140,8 +146,9 @@ struct FEMHipEllipticSolver : public FEMSolverBase<D, E, F, Ts...> {   // keeps 
         const std::int64_t rows = (std::int64_t)this->integrator_.num_nodes() * pde.domain().n_cells();
         auto op = hip_detail::to_terms<M, N, R>(pde.differential_operator(), rows);
         check(fdapde_set_operator(ctx_, (int32_t)op.terms.size(), op.terms.data()));
-        // forcing at the quadrature nodes, row nq * cell + q (integrator.h:85), one column per time point; a callable forcing is
-        // sampled at quadrature_nodes() first, exactly what Integrator::integrate does with it (integrator.h:80-81)
+        // forcing at the quadrature nodes, row nq * cell + q (integrator.h:85); a callable forcing is sampled at quadrature_nodes()
+        // first, exactly what Integrator::integrate does with it (integrator.h:80-81).  Columns: the reference discretises column 0
+        // always and the others only for a parabolic operator (fem_solver_base.h:118-128) -- the same count is handed over here
         DMatrix<double> fq;
         if constexpr (std::is_base_of<ScalarBase, F>::value) {
             DMatrix<double> qn = this->integrator_.quadrature_nodes(pde.domain());
@@ -149,39 +156,92 @@ struct FEMHipEllipticSolver : public FEMSolverBase<D, E, F, Ts...> {   // keeps 
             for (int i = 0; i < qn.rows(); ++i) fq(i, 0) = pde.forcing_data()(SVector<N>(qn.row(i)));
         } else
             fq = pde.forcing_data();
-        check(fdapde_set_forcing(ctx_, fq.data(), (int32_t)fq.cols()));      // DMatrix is column-major
+        const int32_t cols = is_parabolic<E>::value ? (int32_t)fq.cols() : 1;
+        check(fdapde_set_forcing(ctx_, fq.data(), cols));                    // DMatrix is column-major: the leading `cols` columns
         check(fdapde_init(ctx_, nullptr));
         hip_detail::fetch(ctx_, FDAPDE_MAT_STIFF, this->n_dofs_, this->stiff_);
         hip_detail::fetch(ctx_, FDAPDE_MAT_MASS, this->n_dofs_, this->mass_);
-        this->force_.resize(this->n_dofs_ * fq.cols(), 1);
-        check(fdapde_force(ctx_, this->force_.data()));
+        this->force_.resize(this->n_dofs_ * fq.cols(), 1);                    // (the reference sizes it n * m whatever the operator, line 119)
+        this->force_.setZero();
+        check(fdapde_force(ctx_, this->force_.data()));                      // fills the first n * cols entries
         this->is_init = true;
     }
     template <typename PDE> void set_dirichlet_bc(const PDE& pde) {           // replaces fem_solver_base.h:142-155
         if (!this->is_init) throw std::runtime_error("solver must be initialized first!");
-        check(fdapde_set_dirichlet(ctx_, pde.boundary_data().data()));       // indexed by DOF id (fem_solver_base.h:152)
+        if constexpr (!is_parabolic<E>::value) check(fdapde_set_dirichlet(ctx_, pde.boundary_data().data()));   // indexed by DOF id (fem_solver_base.h:152)
+        // (parabolic: the reference's set_dirichlet_bc touches column 0 of the data and the steady matrix only, while the time stepper
+        //  imposes column i + 1 at step i itself, fem_linear_parabolic_solver.h:51-55,64-67 -- the data travel with solve() below)
+        dirichlet_set_ = true;
     }
-    template <typename PDE> void solve(const PDE&) {                          // replaces fem_linear_elliptic_solver.h:34-50
-        if (!this->is_init) throw std::runtime_error("solver must be initialized first!");
-        fdapde_info info;
-        if (fdapde_solve(ctx_, nullptr, &info) != FDAPDE_OK) {                // FDAPDE_ENOCONV <-> the reference's success = false
-            this->success = false;
-            return;
-        }
-        this->solution_.resize(this->n_dofs_, 1);
-        check(fdapde_solution(ctx_, this->solution_.data()));
-        hip_detail::fetch(ctx_, FDAPDE_MAT_STIFF, this->n_dofs_, this->stiff_);   // the row-zeroed matrix the reference leaves behind
-        check(fdapde_force(ctx_, this->force_.data()));                       // boundary rows = g
-        this->success = true;
-    }
-   private:
+   protected:
+    bool dirichlet_set_ = false;
     void check(int rc) const {
         if (rc != FDAPDE_OK) throw std::runtime_error(fdapde_last_error(ctx_));
     }
 };
 
+template <typename D, typename E, typename F, typename... Ts>
+struct FEMHipEllipticSolver : public FEMHipSolverBase<D, E, F, Ts...> {
+    using Base = FEMHipSolverBase<D, E, F, Ts...>;
+    FEMHipEllipticSolver(const D& domain) : Base(domain) { }
+    template <typename PDE> void solve(const PDE&) {                          // replaces fem_linear_elliptic_solver.h:34-50
+        if (!this->is_init) throw std::runtime_error("solver must be initialized first!");
+        fdapde_info info;
+        const int rc = fdapde_solve(this->ctx_, nullptr, &info);
+        if (rc == FDAPDE_ENOCONV) {                                           // <-> the reference's success = false (lines 42-45)
+            this->success = false;
+            return;
+        }
+        this->check(rc);
+        this->solution_.resize(this->n_dofs_, 1);
+        this->check(fdapde_solution(this->ctx_, this->solution_.data()));
+        hip_detail::fetch(this->ctx_, FDAPDE_MAT_STIFF, this->n_dofs_, this->stiff_);   // the row-zeroed matrix the reference leaves behind
+        this->check(fdapde_force(this->ctx_, this->force_.data()));          // boundary rows = g
+        this->success = true;
+    }
+};
+
+// FEMLinearParabolicSolver's members mirrored: deltaT_ / set_deltaT (lines 30-34), solve (37-72).  The reference factorises
+// K = M / dt + A once with SparseLU and back-substitutes per step; fdapde_solve_parabolic scales K once and runs a warm-started
+// Jacobi-PCG / BiCGStab per step on the device, with the same time loop and the same Dirichlet rule.
+template <typename D, typename E, typename F, typename... Ts>
+struct FEMHipParabolicSolver : public FEMHipSolverBase<D, E, F, Ts...> {
+   private:
+    double deltaT_ = 1e-2;
+   public:
+    using Base = FEMHipSolverBase<D, E, F, Ts...>;
+    FEMHipParabolicSolver(const D& domain) : Base(domain) { }
+    void set_deltaT(double deltaT) { deltaT_ = deltaT; }
+
+    template <typename PDE> void solve(const PDE& pde) {
+        static_assert(is_pde<PDE>::value, "pde is not a valid PDE object");
+        if (!this->is_init) throw std::runtime_error("solver must be initialized first!");
+        this->set_deltaT(pde.time_domain()[1] - pde.time_domain()[0]);       // line 42
+        const std::size_t n = this->n_dofs();                                 // degrees of freedom in space
+        const std::size_t m = pde.forcing_data().cols();                      // time points (line 44)
+        this->solution_.resize(n, m);
+        const DVector<double> u0 = pde.initial_condition();                   // column 0 of the solution (line 46)
+        // Dirichlet data n_dofs x m, column i + 1 imposed at step i (lines 64-67); no boundary DOF, or PDE::solve did not call
+        // set_dirichlet_bc (pde.h:102-105: boundary data empty): natural conditions
+        const DMatrix<double>& g = pde.boundary_data();
+        const bool with_bc = this->dirichlet_set_ && g.rows() == (Eigen::Index)n && g.cols() >= (Eigen::Index)m;
+        fdapde_info info;
+        const int rc = fdapde_solve_parabolic(this->ctx_, nullptr, (int32_t)m, deltaT_, u0.data(), with_bc ? g.data() : nullptr,
+                                              this->solution_.data() /* column-major n x m */, &info);
+        if (rc == FDAPDE_ENOCONV) {                                           // <-> solver.info() != Eigen::Success (lines 57-60)
+            this->success = false;
+            return;
+        }
+        this->check(rc);
+        this->success = true;
+    }
+};
+
+// selects the solver type from the operator, as fem_solver_selector.h:29-33 does for tag FEM
 template <typename D, typename E, typename F, typename... Ts> struct pde_solver_selector<FEM_HIP, D, E, F, Ts...> {
-    using type = FEMHipEllipticSolver<D, E, F, Ts...>;
+    using type = typename switch_type<
+      switch_type_case<!is_parabolic<E>::value, FEMHipEllipticSolver <D, E, F, Ts...>>,
+      switch_type_case< is_parabolic<E>::value, FEMHipParabolicSolver<D, E, F, Ts...>> >::type;
 };
 
 }   // namespace core

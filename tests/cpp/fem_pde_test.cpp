@@ -10,6 +10,8 @@
 #include <sstream>
 #include <string>
 
+#include <unistd.h>
+
 #include "fdapde_amd/pde.h"
 #include "fdapde_amd/io.h"
 #include "fdapde_amd/linear_algebra.h"
@@ -397,9 +399,63 @@ TEST(lagrangian_basis_test, eval_basis_golden) {
     eval_basis_case<2>();
 }
 
+// the 3-column sparse dialect (csv_reader.h:119-166): the reference keeps no sparse fixture, so the dense incidence matrix of
+// quasi_circle is written out entry by entry -- ids 1-based, one entry split in two (occurrences are summed), one NA -- and read back
+TEST(csv_reader_test, sparse_three_column_format) {
+    const std::string dense_file = MESH_PATH + "/quasi_circle/incidence_matrix.csv";
+    DMatrix<double> dense = read_csv<double>(dense_file);
+    EXPECT_TRUE(dense.rows() > 0 && dense.cols() == 630);
+    const std::string tmp = "/tmp/fdapde_sparse_" + std::to_string((long)getpid()) + ".csv";
+    {
+        std::ofstream out(tmp);
+        out << "\"\",\"i\",\"j\",\"x\"\n";
+        long id = 0;
+        bool split_done = false;
+        for (int64_t j = dense.cols() - 1; j >= 0; --j)        // (not in row order: the reader must sort)
+            for (int64_t i = 0; i < dense.rows(); ++i) {
+                if (dense(i, j) == 0.0) continue;
+                if (!split_done) {
+                    out << "\"" << ++id << "\", " << i + 1 << ", " << j + 1 << ", 0.25\n";
+                    out << "\"" << ++id << "\"," << i + 1 << "," << j + 1 << "," << dense(i, j) - 0.25 << "\n";
+                    split_done = true;
+                } else
+                    out << "\"" << ++id << "\"," << i + 1 << "," << j + 1 << "," << dense(i, j) << "\n";
+            }
+    }
+    SpMatrix<double> sp = fdapde::amd::CSVReader<double>().parse_sparse_file(tmp);
+    // the matrix is (largest row id) x (largest column id) (csv_reader.h:141-144,160): trailing empty rows / columns are not represented
+    int64_t last_row = 0, last_col = 0, nnz = 0;
+    for (int64_t i = 0; i < dense.rows(); ++i)
+        for (int64_t j = 0; j < dense.cols(); ++j)
+            if (dense(i, j) != 0.0) last_row = std::max(last_row, i + 1), last_col = std::max(last_col, j + 1), ++nnz;
+    EXPECT_TRUE(sp.rows() == last_row && sp.cols() == last_col && sp.nonZeros() == nnz);
+    bool same = true, sorted = true;
+    for (int64_t i = 0; i < sp.rows(); ++i) {
+        for (int32_t k = sp.rowptr[(size_t)i]; k + 1 < sp.rowptr[(size_t)i + 1]; ++k) sorted &= sp.colidx[(size_t)k] < sp.colidx[(size_t)k + 1];
+        for (int64_t j = 0; j < sp.cols(); ++j) same &= almost_equal(sp.coeff(i, j), dense(i, j), 1e-15);
+    }
+    EXPECT_TRUE(same && sorted);
+    {   // a dense file is refused with the reference's message; NA reads as NaN
+        bool threw = false;
+        try { fdapde::amd::CSVReader<double>().parse_sparse_file(dense_file); } catch (const std::runtime_error& e) { threw = std::string(e.what()).find("sparse 3-column") != std::string::npos; }
+        EXPECT_TRUE(threw);
+        std::ofstream out(tmp);
+        out << "\"\",\"i\",\"j\",\"x\"\n\"1\",2,3,NA\n";
+        out.close();
+        SpMatrix<double> na = fdapde::amd::CSVReader<double>().parse_sparse_file(tmp);
+        EXPECT_TRUE(na.rows() == 2 && na.cols() == 3 && na.nonZeros() == 1 && std::isnan(na.coeff(1, 2)));
+    }
+    std::remove(tmp.c_str());
+}
+
 int main(int argc, char** argv) {
-    if (argc < 2) { std::printf("usage: %s <tests/golden/mesh>\n", argv[0]); return 2; }
+    if (argc < 2) { std::printf("usage: %s <tests/golden/mesh> [--io-only]\n", argv[0]); return 2; }
     MESH_PATH = argv[1];
+    if (argc > 2 && std::string(argv[2]) == "--io-only") {   // host-side pieces of the facade: no device needed
+        RUN(csv_reader_test, sparse_three_column_format);
+        std::printf("%d checks, %d failures\n", checks, failures);
+        return failures == 0 ? 0 : 1;
+    }
     if (fdapde_device_count() < 1) { std::printf("no HIP device: these tests have no CPU fallback\n"); return 3; }
     RUN(fem_pde_test, laplacian_isotropic_order1);
     RUN(fem_pde_test, laplacian_isotropic_order2_callable_force);
@@ -413,6 +469,7 @@ int main(int argc, char** argv) {
     RUN(linear_algebra_test, smw_and_lumping);
     RUN(mesh_test, neighbours_and_facets_match_the_fixture_files);
     RUN(lagrangian_basis_test, eval_basis_golden);
+    RUN(csv_reader_test, sparse_three_column_format);
     std::printf("%d checks, %d failures\n", checks, failures);
     return failures == 0 ? 0 : 1;
 }

@@ -24,6 +24,13 @@ def test_facade_compiles_and_refuses_to_run_without_a_device():
         assert r.returncode == 3 and "no CPU fallback" in r.stdout
 
 
+def test_host_side_io_of_the_facade():
+    """the CSV dialects (dense + the 3-column sparse form, csv_reader.h:119-166) need no device: tests/cpp/fem_pde_test --io-only"""
+    _build()
+    r = subprocess.run([EXE, os.path.join(ROOT, "tests", "golden", "mesh"), "--io-only"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "0 failures" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.gpu
 def test_reference_fem_pde_cases_through_the_cpp_facade():
     _build()   # make: rebuilt whenever a header of the facade or the C ABI changed

@@ -35,3 +35,59 @@ def test_partitioned_pcg_matches_single_domain(world, case):
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{out}"
         assert f"rank {r}: ok" in out
+
+
+def test_rank_problems_agree_pairwise():
+    """what bench.py's rank 0 ships to the other ranks (dist.rank_problems_p1): every pair of peers lists the DOFs it shares in the SAME
+    order (ascending global node id), ownership covers every node exactly once, sub-meshes cover every cell exactly once"""
+    import numpy as np
+
+    from fdapde_loader import load_package
+
+    load_package()
+    from fdapde_core_amd import dist as fdist
+    from fdapde_core_amd import meshgen
+
+    nodes, cells, bnd = meshgen.unit_cube(7)
+    for world in (2, 3, 5):
+        probs = fdist.rank_problems_p1(nodes, cells, bnd, world)
+        assert sum(p["cells"].shape[0] for p in probs) == cells.shape[0]
+        owned = np.zeros(nodes.shape[0], dtype=int)
+        for p in probs:
+            np.add.at(owned, p["l2g"][p["owned"] != 0], 1)
+            assert np.array_equal(nodes[p["l2g"]], p["nodes"]) and np.array_equal(p["l2g"][p["cells"]].shape, p["cells"].shape)
+        assert np.all(owned == 1)
+        for r, p in enumerate(probs):
+            for q, peer in enumerate(p["peer_rank"]):
+                mine = p["l2g"][p["peer_dof"][p["peer_off"][q]:p["peer_off"][q + 1]]]
+                other = probs[peer]
+                k = list(other["peer_rank"]).index(r)
+                theirs = other["l2g"][other["peer_dof"][other["peer_off"][k]:other["peer_off"][k + 1]]]
+                assert np.array_equal(mine, theirs) and np.all(np.diff(mine) > 0)
+
+
+def test_file_rendezvous_and_self_launch_failure(tmp_path):
+    """bench.py's rank bootstrap without a launcher: blobs through a directory; on a box without a HIP device every rank refuses to run
+    and the self-launching parent must report that with a non-zero exit code instead of waiting"""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    os.environ["FDAPDE_BENCH_RDZV"] = str(tmp_path)
+    try:
+        a, b = bench.FileRendezvous(0, 2), bench.FileRendezvous(1, 2)
+        a.put("id", b"\x00\x01" * 64)
+        assert b.get("id") == b"\x00\x01" * 64
+        with pytest.raises(TimeoutError):
+            b.get("missing", timeout=0.05)
+    finally:
+        del os.environ["FDAPDE_BENCH_RDZV"]
+    from fdapde_loader import load_package
+
+    if load_package().capi.load().fdapde_device_count() >= 1:
+        return   # (on a GPU box the launch itself is covered by tests/test_gpu_dist.py)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FDAPDE_BENCH_RDZV")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--nx", "4"], stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, env=env, timeout=300, cwd=ROOT)
+    assert out.returncode != 0 and "HIP device" in out.stderr

@@ -92,6 +92,36 @@ def test_bench_multi_gpu_leg_plumbing_on_one_gpu():
     assert rec["config"]["max_abs_error_vs_analytic"] < 6.0 * (1.0 / 24) ** 2 * 3.15**2
 
 
+@pytest.mark.parametrize("gpus", [2, 3])
+def test_bench_starts_its_own_ranks_without_a_launcher(gpus):
+    """`python bench.py --gpus N` with WORLD_SIZE unset -- the shape of the driver's N = 1 command: the script starts N fresh rank
+    processes itself (decided before anything touches the GPU) and relays rank 0's JSON line.  Gloo plumbing mode, ranks share GPU 0."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FDAPDE_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "FDAPDE_BENCH_RDZV"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "1", "--nx", "20"]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == gpus and rec["scaling"] == "strong" and rec["value"] > 0 and rec["config"]["relres"] <= 1e-10
+    assert rec["config"]["max_abs_error_vs_analytic"] < 6.0 * (1.0 / 20) ** 2 * 3.15**2
+    assert all(v is None or v <= 1.0 for k, v in rec["roofline"].items() if k in ("frac", "traffic_frac"))
+
+
+def test_bench_self_launch_reports_a_failing_rank():
+    """a rank that cannot run (more ranks than devices over RCCL) must end the whole job with a non-zero code, not leave the others waiting"""
+    if _n_gpus() >= 2:
+        pytest.skip("needs a box with ONE GPU")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FDAPDE_BENCH_BACKEND", "FDAPDE_BENCH_RDZV"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--nx", "8"], stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, env=env, timeout=300, cwd=ROOT)
+    assert out.returncode != 0 and "HIP devices" in out.stderr
+
+
 @pytest.mark.parametrize("gpus", [2, 8])
 def test_bench_multi_gpu_leg_as_the_driver_launches_it(gpus):
     """python -m torch.distributed.run --nproc-per-node N bench.py --gpus N on a reduced mesh: one JSON line, converged, the
@@ -99,11 +129,14 @@ def test_bench_multi_gpu_leg_as_the_driver_launches_it(gpus):
     if _n_gpus() < gpus:
         pytest.skip(f"needs {gpus} GPUs, this box has {_n_gpus()}")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--nx", "48"]
-    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=900, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-3000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    rec = json.loads(line)
-    assert rec["n_gpus"] == gpus and rec["scaling"] == "strong" and rec["value"] > 0
-    assert rec["config"]["relres"] <= 1e-10 and rec["config"]["max_abs_error_vs_analytic"] < 6.0 * (1.0 / 48) ** 2 * 3.15**2
+    for launcher in ("torchrun", "self"):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", _free_port()] if launcher == "torchrun" else [sys.executable]
+        cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--nx", "48"]
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=900, cwd=ROOT)
+        assert out.returncode == 0, (launcher, out.stderr[-3000:])
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        rec = json.loads(line)
+        assert rec["n_gpus"] == gpus and rec["scaling"] == "strong" and rec["value"] > 0
+        assert rec["config"]["relres"] <= 1e-10 and rec["config"]["max_abs_error_vs_analytic"] < 6.0 * (1.0 / 48) ** 2 * 3.15**2
+        assert "/opt/rocm" in rec["config"]["transport"], rec["config"]["transport"]   # ONE stack: the system's RCCL next to the system's HIP

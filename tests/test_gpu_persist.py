@@ -135,23 +135,94 @@ def test_symmetric_storage_with_coefficients_of_very_different_size(env):
     c.close()
 
 
-def test_persistent_path_against_the_oracle(env, oracle, mesh_loader):
+@pytest.mark.parametrize("mesh,order,sym", [("unit_square", 1, 0), ("unit_square", 1, 1), ("unit_square", 2, 0), ("unit_square", 2, 1),
+                                            ("unit_sphere", 2, 1), ("unit_square_64", 2, 1)])
+def test_persistent_path_against_the_oracle(env, oracle, mesh_loader, mesh, order, sym):
+    """both storages of the single launch against the ORACLE's direct solve (not against another HIP path): unit_square P1 = two
+    workgroups, P2 = 14 161 DOFs in seven workgroups with imports and exports on every one; sym = 1 forces the symmetric-storage
+    instantiation (what C3's headline runs on) where the automatic choice would keep the plain one"""
     capi, _ = env
-    m = mesh_loader("unit_square")     # 3600 nodes: two workgroups
+    m = mesh_loader(mesh)
     c = capi.Context(0)
     c.mesh_upload(m.nodes, m.cells, m.boundary)
-    nd = c.dofs_build(1)
+    nd = c.dofs_build(order)
     _, _, coords = c.dofs_get()
-    fq = np.ones(3 * m.n_cells)
+    nq = c.sizes()["n_quadrature"]
+    fq = np.ones(nq * m.n_cells)
     g = coords[:, 0] * coords[:, 1]
     c.set_operator(-capi.laplacian())
     c.set_forcing(fq)
     c.set_dirichlet(g)
     c.init()
+    c.tune("persist_sym", sym)
     info = c.solve(rtol=1e-11)
-    assert info.persistent == 1
-    ref = oracle.pde_init_solve(m, 1, -oracle.laplacian(), forcing_q=fq, dirichlet=g)
+    assert info.persistent == 1 and info.converged == 1
+    lay = c.solver_layout_kind(True)
+    assert lay["sym"] == sym and lay["kind"] in (2, 3)
+    if order == 2 and mesh != "unit_sphere":
+        assert lay["workgroups"] >= 4, lay
+    ref = oracle.pde_init_solve(m, order, -oracle.laplacian(), forcing_q=fq, dirichlet=g)
     assert np.linalg.norm(c.solution() - ref.solution) <= 1e-8 * np.linalg.norm(ref.solution)
+    c.close()
+
+
+@pytest.mark.parametrize("stall_at,sym", [(3, 0), (4, 0), (3, 1), (1, 0)])
+def test_hand_off_timeout_mid_solve_falls_back_from_the_same_state(env, stall_at, sym):
+    """a workgroup that stops taking part at iteration k (what a peer that is not resident looks like): every other workgroup runs into
+    its bounded wait, the launch gives up, and the multi-launch path restarts the solve.  The launch must have left x, r, p, the
+    scalars and the iteration counter as it found them -- workgroups that finished their iterations before the others noticed must not
+    have stored anything the restart reads (odd and even k: the fall-back's lazy x update goes by the iteration parity)."""
+    capi, meshgen = env
+    c, nd = _problem(capi, meshgen, 3, 30, 1, True)
+    c.tune("persist", 0)
+    i0 = c.solve(rtol=1e-10)
+    u0 = c.solution()
+    c.tune("persist", 1)
+    c.tune("persist_sym", sym)
+    c.tune("persist_timeout_us", 2000)
+    c.tune("persist_debug_stall", stall_at)
+    i1 = c.solve(rtol=1e-10)
+    assert i1.persistent == 0 and i1.converged == 1, "the stalled launch must have been replaced by the multi-launch path"
+    assert i1.iters == i0.iters, (i1.iters, i0.iters)
+    # (not the same bits: with the single launch enabled the multi-launch kernels apply the full-pattern scaled matrix, without it the
+    #  compact one -- another summation order inside a row)
+    assert np.linalg.norm(c.solution() - u0) <= 1e-12 * np.linalg.norm(u0), "the fall-back must start from the state the launch found"
+    assert i1.t_solve_ms < 60.0, i1.t_solve_ms   # one bounded wait (2 ms), not a hang
+    c.tune("persist_debug_stall", 0)
+    c.tune("persist_retry", 1)   # (the context would otherwise stay on the multi-launch path for the next 8 systems)
+    i2 = c.solve(rtol=1e-10)
+    assert i2.persistent == 1 and i2.converged == 1
+    assert np.linalg.norm(c.solution() - u0) <= 1e-9 * np.linalg.norm(u0)
+    c.close()
+
+
+def test_first_solve_of_a_small_system_is_cheap(env, mesh_loader):
+    """downstream models solve many small systems: the lazy build of the single-launch layout must not dominate the first solve
+    (round 2: 13.5 ms for 587 DOFs -- ~40 device launches and sorts; now built on the host for small systems)"""
+    capi, _ = env
+    m = mesh_loader("unit_sphere")
+    warm = capi.Context(0)   # (the very first context of a process also pays for loading the code objects)
+    warm.mesh_upload(m.nodes, m.cells, m.boundary)
+    warm.dofs_build(1)
+    warm.set_operator(-capi.laplacian())
+    warm.set_forcing(np.zeros(4 * m.n_cells))
+    warm.set_dirichlet(np.zeros(m.n_nodes))
+    warm.init()
+    warm.solve(rtol=1e-10)
+    c = capi.Context(0)
+    c.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = c.dofs_build(1)
+    _, _, coords = c.dofs_get()
+    c.set_operator(-capi.laplacian())
+    c.set_forcing(np.zeros(4 * m.n_cells))
+    c.set_dirichlet(coords.sum(axis=1))
+    c.init()
+    i1 = c.solve(rtol=1e-10)
+    i2 = c.solve(rtol=1e-10)
+    assert i1.persistent == 1 and i2.persistent == 1
+    assert i1.t_solve_ms <= 2.0, (i1.t_solve_ms, i2.t_solve_ms)
+    assert np.abs(c.solution() - coords.sum(axis=1)).max() < 1e-8
+    c.close(), warm.close()
 
 
 def test_persistent_path_under_parabolic_stepping_and_handle(env):
@@ -219,6 +290,41 @@ def test_blocked_ell_spmv_under_every_krylov_method(env, nx):
             else:
                 assert abs(info.iters - ref[m][0]) <= max(2, ref[m][0] // 10), (m, info.iters, ref[m][0])
                 assert np.linalg.norm(u - ref[m][1]) <= 1e-8 * np.linalg.norm(ref[m][1])
+    c.close()
+
+
+def test_graph_replay_is_rebuilt_when_the_blocked_layout_changes(env):
+    """use_graph = 1 on a system that takes the blocked-ELL SpMV (2-D P2; the 3-D P2 "mass matrix" of the reference's 5-point rule with its
+    negative weight is indefinite, no CG applies to it): a solve with Dirichlet data captures the fused-CG chunk on
+    layout 1; the handle then solves with the mass matrix on layout 0 (no Dirichlet reduction) -- the captured graph bakes in the other
+    layout's arrays and grid and must not be replayed (the graph key once ignored the blocked layout)"""
+    capi, meshgen = env
+    nodes, cells, bnd = meshgen.unit_square(48)
+    _, f = meshgen.manufactured(2)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(2)
+    _, _, coords = c.dofs_get()
+    c.set_operator(-capi.laplacian())
+    c.set_forcing(f(c.quadrature_nodes()))
+    c.set_dirichlet(0.25 * coords[:, 0])
+    c.init()
+    c.tune("persist", 0)
+    c.tune("blocked", 2)
+    b = np.cos(3.0 * coords[:, 0]) + coords[:, 1]
+    res = {}
+    for graph in (0, 1):
+        c.tune("use_graph", graph)
+        i = c.solve(method=capi.SOLVER_CG_FUSED, rtol=1e-11, check_every=8)
+        assert i.converged == 1 and i.persistent == 0
+        u = c.solution()
+        c.lin_compute(capi.MAT_MASS, symmetric=True)
+        x, li = c.lin_solve(b, rtol=1e-12, check_every=8)
+        assert li.converged == 1
+        res[graph] = (u, x, i.iters, li.iters)
+    assert res[1][2] == res[0][2] and res[1][3] == res[0][3]
+    assert np.linalg.norm(res[1][0] - res[0][0]) <= 1e-12 * np.linalg.norm(res[0][0])
+    assert np.linalg.norm(res[1][1] - res[0][1]) <= 1e-12 * np.linalg.norm(res[0][1])
     c.close()
 
 

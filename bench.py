@@ -59,41 +59,7 @@ def parse():
 # N > 1 without a launcher: the script starts its own rank processes (nothing has touched the GPU in this process)
 # ---------------------------------------------------------------------------------------------------------------------
 def self_launch(args):
-    import socket
-    import tempfile
-
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    rdzv = tempfile.mkdtemp(prefix="fdapde_rdzv_")
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FDAPDE_BENCH_RDZV=rdzv, HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))   # stdout inherited: rank 0 prints the line
-    rc = 0
-    try:
-        pending = dict(enumerate(procs))
-        while pending:
-            for r, p in list(pending.items()):
-                code = p.poll()
-                if code is None:
-                    continue
-                del pending[r]
-                if code != 0 and rc == 0:
-                    rc = code
-                    print(f"bench.py: rank {r} exited with code {code}; stopping the others", file=sys.stderr)
-                    for q in pending.values():
-                        q.terminate()
-            time.sleep(0.05)
-    finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
-        import shutil
-
-        shutil.rmtree(rdzv, ignore_errors=True)
-    return rc
+    return _spawn_ranks(args.gpus, sys.argv[1:], {}, timeout=0)
 
 
 class FileRendezvous:
@@ -361,7 +327,92 @@ def run_single(args):
     print(json.dumps(out), flush=True)
 
 
+def _spawn_ranks(world, argv_extra, extra_env, timeout):
+    """N fresh rank processes of this script (nothing of the caller's GPU state is inherited: they are new programs); -> exit code"""
+    import socket
+    import tempfile
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    rdzv = tempfile.mkdtemp(prefix="fdapde_rdzv_")
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), FDAPDE_BENCH_RDZV=rdzv, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+        for k in [k for k in env if k.startswith("TORCHELASTIC_") or k in ("GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "GROUP_WORLD_SIZE", "ROLE_WORLD_SIZE")]:
+            env.pop(k)   # (children of a rank started by torch.distributed.run must not look for that launcher's store)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv_extra, env=env, stdout=subprocess.DEVNULL if extra_env.get("FDAPDE_BENCH_CANARY") else None))
+    rc, t0 = 0, time.time()
+    try:
+        pending = dict(enumerate(procs))
+        while pending:
+            for r, p in list(pending.items()):
+                code = p.poll()
+                if code is None:
+                    continue
+                del pending[r]
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"bench.py: rank {r} exited with code {code}; stopping the others", file=sys.stderr)
+                    for q in pending.values():
+                        q.terminate()
+            if timeout and time.time() - t0 > timeout and pending:
+                rc = rc or 124
+                print("bench.py: rank processes timed out; stopping them", file=sys.stderr)
+                for q in pending.values():
+                    q.terminate()
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    p.wait(timeout=5)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+        import shutil
+
+        shutil.rmtree(rdzv, ignore_errors=True)
+    return rc
+
+
+def run_canary(rank, world, local_rank):
+    """one rank of the canary job (see dist.canary): exit code 0 = the row-distributed solve works between these devices"""
+    from fdapde_loader import load_package
+
+    load_package()
+    from fdapde_core_amd import capi
+    from fdapde_core_amd import dist as fdist
+
+    n_dev = int(capi.load().fdapde_device_count())
+    backend = os.environ.get("FDAPDE_BENCH_BACKEND", "rccl")
+    backend = "rccl" if backend == "nccl" else backend
+    if n_dev < 1 or (backend == "rccl" and n_dev < world):
+        raise SystemExit(1)
+    rdzv = FileRendezvous(rank, world)
+    share = (world + n_dev - 1) // n_dev
+    raise SystemExit(fdist.canary(capi, rdzv, rank, world, local_rank % n_dev, backend, share))
+
+
+def choose_form(rdzv, rank, world):
+    """row-distributed persistent launches where they work between the node's devices, the RCCL exchange otherwise.  Decided by rank 0
+    BEFORE any rank touches a GPU, by running the canary job in processes of its own (FDAPDE_BENCH_EXCHANGE = rowdist | peers | dense
+    forces a form)."""
+    form = os.environ.get("FDAPDE_BENCH_EXCHANGE", "auto")
+    if form != "auto":
+        return form
+    if rank == 0:
+        rc = _spawn_ranks(world, ["--gpus", str(world)], {"FDAPDE_BENCH_CANARY": "1"}, timeout=600)
+        if rc != 0:
+            print(f"bench.py: the row-distributed canary job failed (exit code {rc}); using the RCCL neighbour exchange", file=sys.stderr)
+        rdzv.put("form", b"rowdist" if rc == 0 else b"peers")
+    return rdzv.get("form").decode()
+
+
 def run_ranks(args, rank, world, local_rank):
+    rdzv = FileRendezvous(rank, world)
+    form = choose_form(rdzv, rank, world)   # (may run a job of its own on the GPUs: nothing of this process has touched them yet)
     from fdapde_loader import load_package
 
     load_package()   # the library first: the process binds to /opt/rocm's HIP runtime, and RCCL is taken from the same installation
@@ -378,8 +429,8 @@ def run_ranks(args, rank, world, local_rank):
     if backend == "rccl" and n_dev < world:
         raise SystemExit(f"--gpus {world} but this node shows {n_dev} HIP devices (RCCL needs one device per rank; "
                          "FDAPDE_BENCH_BACKEND=gloo runs the plumbing with ranks sharing devices)")
-    rdzv = FileRendezvous(rank, world)
-    out = fdist.bench_partitioned(capi, rdzv, rank, world, local_rank % n_dev, args, RTOL, backend)
+    share = (world + n_dev - 1) // n_dev
+    out = fdist.bench_partitioned(capi, rdzv, rank, world, local_rank % n_dev, args, RTOL, backend, form, share)
     if rank != 0:
         return
     res = out
@@ -412,10 +463,16 @@ def run_ranks(args, rank, world, local_rank):
             "persistent_launch": int(getattr(info, "persistent", 0)),
             "us_per_iteration": 1e3 * res["t_sol"] / max(int(info.iters), 1),
             "transport": res["transport"],
+            "exchange_form": res["form"],
         },
         "roofline": roofline_of(res["infos"], res["alg_bytes"], res["streamed_bytes"], args.nx, world),
     }
     line["roofline"]["note"] = "the largest rank-local operator"
+    if res["form"] == "rowdist":   # a rank's share of C3 is (nearly) resident in its LDS: the iteration is hand-off latency, not an HBM stream
+        line["roofline"].update(bound="latency", achieved=None, frac=None,
+                                achieved_source="row-distributed launches: per-rank blocks of the matrix are resident in LDS or stream from the rank's own "
+                                                "Infinity Cache; an iteration is bound by the two in-kernel hand-offs (neighbour entries, dot all-gather over all "
+                                                "ranks' workgroups), no HBM fraction is quoted")
     print(json.dumps(line), flush=True)
 
 
@@ -431,6 +488,8 @@ def main():
                          f"torch.distributed.run --nproc-per-node {args.gpus}")
     if world == 1:
         run_single(args)
+    elif os.environ.get("FDAPDE_BENCH_CANARY"):
+        run_canary(rank, world, local_rank)
     else:
         run_ranks(args, rank, world, local_rank)
 

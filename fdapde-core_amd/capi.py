@@ -47,7 +47,7 @@ SYMBOLS = [
     "fdapde_info_get", "fdapde_spmv", "fdapde_bench_spmv", "fdapde_tune", "fdapde_stream", "fdapde_synchronize",
     "fdapde_comm_unique_id", "fdapde_comm_init", "fdapde_halo_setup", "fdapde_solve_parabolic",
     "fdapde_lin_compute", "fdapde_lin_solve", "fdapde_eval_pointwise", "fdapde_cell_integrals", "fdapde_comm_init_callback", "fdapde_comm_set_exchange_callback", "fdapde_halo_setup_peers",
-    "fdapde_solver_layout", "fdapde_topology_build", "fdapde_topology_get", "fdapde_comm_allreduce", "fdapde_comm_library", "fdapde_solver_layout_kind",
+    "fdapde_solver_layout", "fdapde_topology_build", "fdapde_topology_get", "fdapde_comm_allreduce", "fdapde_comm_library", "fdapde_solver_layout_kind", "fdapde_rowdist_setup",
 ]
 
 _lib = None
@@ -419,6 +419,12 @@ class Context:
 
     def comm_init(self, world, rank, unique_id: bytes):
         self._check(self.lib.fdapde_comm_init(self._ctx, int(world), int(rank), C.c_char_p(unique_id)))
+
+    def rowdist_setup(self, dof_key, dof_owner):
+        """row-distributed multi-GPU form: global key and owning rank of every local DOF (fdapde_rowdist_setup)"""
+        k = np.ascontiguousarray(dof_key, dtype=np.int64)
+        o = np.ascontiguousarray(dof_owner, dtype=np.int32)
+        self._check(self.lib.fdapde_rowdist_setup(self._ctx, k.ctypes.data_as(C.POINTER(C.c_int64)), _ip(o)))
 
     def comm_allreduce(self, values, op="sum"):
         """sum / max of a float64 array over the ranks of the communicator (through the library's own RCCL communicator)"""

@@ -12,60 +12,16 @@
 #include <rccl/rccl.h>
 
 #include "context.h"
+#include "engine.h"
+#include "kernels.h"
 
+using namespace fdapde_engine;
 
-namespace {
-
-// FDAPDE_DEBUG_TIMING=1: wall-clock marks of the host side of a solve on stderr (where a first solve spends its time)
-struct DebugClock {
-    bool on = std::getenv("FDAPDE_DEBUG_TIMING") != nullptr;
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    void mark(const char* what) {
-        if (!on) return;
-        const auto t1 = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[timing] %-34s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
-        t0 = t1;
-    }
-};
-
-int fail(fdapde_ctx* c, int code, const char* msg) {
-    c->err = msg;
-    return code;
-}
-int need_device(fdapde_ctx* c) {
-    if (!c->has_device) return fail(c, FDAPDE_ENODEVICE, "this context has no HIP device (host-only); there is no CPU fallback");
-    return FDAPDE_OK;
-}
-
-// a DBuf takes over a device array built elsewhere (dev_setup.hip)
-template <typename T> void adopt(DBuf<T>& b, T*& p, size_t n) {
-    b.release();
-    b.p = p, b.n = n, p = nullptr;
-}
-
-// index arrays of the space built on the device (dev_setup.hip): the context's buffers adopt them, nothing is uploaded
-int adopt_dev_space(fdapde_ctx* c, DevSpace& s) {
-    const HostSpace& hs = c->hs;
-    const size_t nd = (size_t)hs.n_dofs, nc = (size_t)hs.n_cells, nnz = (size_t)hs.nnz, nv = (size_t)hs.M + 1, nb = (size_t)hs.nb;
-    adopt(c->cverts, s.cverts, nc * nv), adopt(c->cdofs, s.cdofs, nc * nb), adopt(c->vcoords, s.vcoords, (size_t)hs.n_nodes * (hs.N == 2 ? 2 : 4));
-    adopt(c->adj, s.adj, (size_t)s.n_adj), adopt(c->slotw, s.slotw, (size_t)s.n_adj * hs.nbw), adopt(c->sl_off, s.sl_off, (size_t)s.n_slices + 1);
-    if (s.dealt) adopt(c->lane_row, s.lane_row, (size_t)s.n_blk * kAsmBlock);
-    else c->lane_row.release();
-    adopt(c->bc_off, s.bc_off, (size_t)s.n_blk + 1), adopt(c->bn_off, s.bn_off, (size_t)s.n_blk + 1);
-    adopt(c->bc_cell, s.bc_cell, (size_t)s.n_bc), adopt(c->bn_node, s.bn_node, (size_t)s.n_bn), adopt(c->bc_vert, s.bc_vert, (size_t)s.n_bc * 4);
-    adopt(c->rowptr, s.rowptr, nd + 1), adopt(c->colidx, s.colidx, nnz + 2), adopt(c->diag, s.diag, nd), adopt(c->slot_i2e, s.slot_i2e, nnz);
-    adopt(c->dof_i2e, s.dof_i2e, nd), adopt(c->dof_e2i, s.dof_e2i, nd), adopt(c->cell_i2e, s.cell_i2e, nc), adopt(c->bnd, s.bnd, nd);
-    adopt(c->rowptr_e, s.rowptr_e, nd + 1), adopt(c->colidx_e, s.colidx_e, nnz);
-    HIPCHK(c, c->rb_row.upload(hs.rb_row.data(), hs.rb_row.size(), c->stream));
-    dev_space_release(&s);   // what nobody adopted (node_i2e)
-    c->dev_built = true;
-    return FDAPDE_OK;
-}
+namespace fdapde_engine {
 
 // big host-side index arrays of a device-built space, fetched the first time host code needs them (the persistent layout and the
 // solver patterns read rowptr_i / colidx_i; the colouring and the partitioned assembly cdofs_i; point location cverts_i / vcoords_i;
 // fdapde_pattern_get the reference pattern)
-enum { kHostPattern = 1, kHostCells = 2, kHostRefPattern = 4, kHostDofs = 8 };
 int ensure_host(fdapde_ctx* c, int what) {
     if (!c->dev_built) return FDAPDE_OK;
     HostSpace& hs = c->hs;
@@ -97,6 +53,29 @@ int ensure_host(fdapde_ctx* c, int what) {
         HIPCHK(c, hipMemcpyAsync(hs.colidx_e.data(), c->colidx_e.p, sizeof(int32_t) * c->colidx_e.n, hipMemcpyDeviceToHost, st));
     }
     HIPCHK(c, hipStreamSynchronize(st));
+    return FDAPDE_OK;
+}
+
+}   // namespace fdapde_engine
+
+namespace {
+
+// index arrays of the space built on the device (dev_setup.hip): the context's buffers adopt them, nothing is uploaded
+int adopt_dev_space(fdapde_ctx* c, DevSpace& s) {
+    const HostSpace& hs = c->hs;
+    const size_t nd = (size_t)hs.n_dofs, nc = (size_t)hs.n_cells, nnz = (size_t)hs.nnz, nv = (size_t)hs.M + 1, nb = (size_t)hs.nb;
+    adopt(c->cverts, s.cverts, nc * nv), adopt(c->cdofs, s.cdofs, nc * nb), adopt(c->vcoords, s.vcoords, (size_t)hs.n_nodes * (hs.N == 2 ? 2 : 4));
+    adopt(c->adj, s.adj, (size_t)s.n_adj), adopt(c->slotw, s.slotw, (size_t)s.n_adj * hs.nbw), adopt(c->sl_off, s.sl_off, (size_t)s.n_slices + 1);
+    if (s.dealt) adopt(c->lane_row, s.lane_row, (size_t)s.n_blk * kAsmBlock);
+    else c->lane_row.release();
+    adopt(c->bc_off, s.bc_off, (size_t)s.n_blk + 1), adopt(c->bn_off, s.bn_off, (size_t)s.n_blk + 1);
+    adopt(c->bc_cell, s.bc_cell, (size_t)s.n_bc), adopt(c->bn_node, s.bn_node, (size_t)s.n_bn), adopt(c->bc_vert, s.bc_vert, (size_t)s.n_bc * 4);
+    adopt(c->rowptr, s.rowptr, nd + 1), adopt(c->colidx, s.colidx, nnz + 2), adopt(c->diag, s.diag, nd), adopt(c->slot_i2e, s.slot_i2e, nnz);
+    adopt(c->dof_i2e, s.dof_i2e, nd), adopt(c->dof_e2i, s.dof_e2i, nd), adopt(c->cell_i2e, s.cell_i2e, nc), adopt(c->bnd, s.bnd, nd);
+    adopt(c->rowptr_e, s.rowptr_e, nd + 1), adopt(c->colidx_e, s.colidx_e, nnz);
+    HIPCHK(c, c->rb_row.upload(hs.rb_row.data(), hs.rb_row.size(), c->stream));
+    dev_space_release(&s);   // what nobody adopted (node_i2e)
+    c->dev_built = true;
     return FDAPDE_OK;
 }
 
@@ -811,6 +790,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
         c->halo_dof.release(), c->halo_pos.release(), c->owned.release(), c->hbuf.release(), c->sbuf.release();
         c->halo_inv.release(), c->if_slot.release();
         c->peer_send_dof.release(), c->peer_src_off.release(), c->peer_src.release(), c->peer_sendbuf.release(), c->peer_recvbuf.release();
+        release_rowdist(c);
         if (c->comm) (void)g_rccl.CommDestroy(c->comm);
         c->lin_mat.release(), c->ar_dev.release(), c->persist_stats.release(), c->persist_x.release(), c->coords_e.release();
         dev_topology_release(&c->topo);
@@ -1258,292 +1238,6 @@ int build_solver_pattern(fdapde_ctx* c, int v) {
     return FDAPDE_OK;
 }
 
-// FDAPDE_SETUP_CHECK: the device-built persistent layout against the host builder's
-int check_dev_persist(fdapde_ctx* c, int v, const PersistLayout& pl, const DevPersist& dp, const std::vector<int32_t>* block_rows, bool balance) {
-    if (int rc = ensure_host(c, kHostPattern)) return rc;
-    PersistLayout ref;
-    if (host_build_persist_layout(c->hs, v == 1, block_rows ? (int)block_rows->size() : c->n_cu, 12000, ref, block_rows ? block_rows->data() : nullptr,
-                                  pl.sym ? 1 : 0, balance) != FDAPDE_OK) return fail(c, FDAPDE_EHIP, "set-up check: host persistent layout failed");
-    int bad = 0;
-    auto scalar = [&](const char* name, int64_t a, int64_t b) {
-        if (a != b) std::fprintf(stderr, "persist check %-9s: MISMATCH %lld vs %lld\n", name, (long long)a, (long long)b), ++bad;
-    };
-    scalar("G", pl.G, ref.G), scalar("R", pl.R, ref.R), scalar("n_int", pl.n_int, ref.n_int), scalar("n_entries", pl.n_entries, ref.n_entries);
-    scalar("nnz", pl.nnz, ref.nnz), scalar("n_board", pl.n_board, ref.n_board), scalar("max_imp", pl.max_imp, ref.max_imp), scalar("max_exp", pl.max_exp, ref.max_exp);
-    auto cmp = [&](const char* name, const void* dev, const void* host, size_t bytes, size_t elem) {
-        std::vector<unsigned char> tmp(bytes ? bytes : 1);
-        if (bytes && hipMemcpy(tmp.data(), dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
-            ++bad;
-            return;
-        }
-        size_t at = 0;
-        while (at < bytes && tmp[at] == static_cast<const unsigned char*>(host)[at]) ++at;
-        if (at < bytes) std::fprintf(stderr, "persist check %-9s: MISMATCH at element %zu of %zu\n", name, at / elem, bytes / elem), ++bad;
-        else std::fprintf(stderr, "persist check %-9s: ok (%zu elements)\n", name, bytes / elem);
-    };
-    if (bad == 0) {
-#define CMP(name, dptr, hvec_) cmp(name, dptr, (hvec_).data(), (hvec_).size() * sizeof((hvec_)[0]), sizeof((hvec_)[0]))
-        CMP("slot_dof", dp.slot_dof, ref.slot_dof), CMP("ell_off", dp.ell_off, ref.ell_off), CMP("sl_off", dp.sl_off, ref.sl_off);
-        CMP("ell_code", dp.ell_code, ref.ell_code), CMP("ell_src", dp.ell_src, ref.ell_src), CMP("exp_off", dp.exp_off, ref.exp_off);
-        CMP("exp_slot", dp.exp_slot, ref.exp_slot), CMP("imp_off", dp.imp_off, ref.imp_off), CMP("imp_pos", dp.imp_pos, ref.imp_pos);
-#undef CMP
-    }
-    if (bad) return fail(c, FDAPDE_EHIP, "FDAPDE_SETUP_CHECK: the device-built persistent layout differs from the host builder's (see stderr)");
-    return FDAPDE_OK;
-}
-
-// resident layout of the persistent CG for boundary variant v (kernels_persist.h): host index work + uploads, once per function
-// space and boundary mask.  ok stays false when the system does not qualify (too many rows for one launch of resident
-// workgroups, or more matrix than is worth re-reading from the caches every iteration).
-int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_rows, bool balance) {
-    fdapde_ctx::Persist& ps = c->ps[v];
-    ps.ok = false;
-    if (c->n_cu < 1) return FDAPDE_OK;
-    const int32_t* brows = block_rows ? block_rows->data() : nullptr;
-    const int n_wg = block_rows ? (int)block_rows->size() : c->n_cu;
-    PersistLayout pl;
-    DevPersist dp;
-    DebugClock clk;
-    const char* mode = std::getenv("FDAPDE_SETUP");
-    bool on_device = !(mode && std::strcmp(mode, "host") == 0);
-    // small systems: the host builder (microseconds of index work + nine small uploads) instead of ~40 device launches, sorts and
-    // synchronisations that cost the same whatever the size -- the first solve of a 587-DOF system took 13.5 ms with them
-    // (downstream models solve many small systems; the arrays are identical either way)
-    if (c->hs.n_dofs <= c->persist_host_below && !(mode && std::strcmp(mode, "device") == 0)) on_device = false;
-    double max_mb = 1024.0;   // ELL bytes (10 per entry) of the whole system (the row bound -- G x 8192 -- is reached first for P1 systems)
-    if (const char* e = std::getenv("FDAPDE_PERSIST_MAX_MB")) max_mb = std::atof(e);
-    const size_t lds_total = 160 * 1024 - 1024;   // static arrays of the kernel + slack
-    size_t fixed = 0;
-    int64_t need = 0;
-    int imp_cap = 0, exp_cap = 0, S = 0;
-    // symmetric storage (kernels_persist.h SYM) where the plain blocks would not fit the LDS; the plain form where they do (C2: the
-    // iteration is latency-bound there, fewer bytes buy nothing) or where the accumulator table leaves no room for the vectors
-    int sym_mode = c->persist_sym == 2 ? 3 : c->persist_sym;   // 0 never, 1 always, 2 auto: tried wherever the plain blocks would stream (3) ...
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        pl = PersistLayout{};
-        int rc = FDAPDE_EUNSUPPORTED;
-        if (on_device) {   // the layout is built where the pattern lives (dev_persist.hip)
-            rc = dev_build_persist_layout(c->hs.n_dofs, c->hs.max_row, c->rowptr.p, c->colidx.p, c->bnd.p, v == 1, n_wg, 12000, 0, brows, sym_mode,
-                                          balance, c->stream, pl, &dp, c->err);
-            if (rc == FDAPDE_EUNSUPPORTED && c->hs.max_row > 255) on_device = false;   // rows too long for its sort keys: host builder
-        }
-        if (!on_device) {
-            clk.mark("build_persist: (before ensure_host)");
-            if (int rc2 = ensure_host(c, kHostPattern)) return rc2;
-            clk.mark("build_persist: ensure_host");
-            rc = host_build_persist_layout(c->hs, v == 1, n_wg, 12000, pl, brows, sym_mode, balance);   // ~12 000 ELL entries (120 KB) next to the vectors of <= 4096 rows
-        }
-        if (rc == FDAPDE_EUNSUPPORTED) return FDAPDE_OK;
-        if (rc) return rc;
-        if (10.0 * (double)pl.n_entries > max_mb * 1e6) {
-            dev_persist_release(&dp);
-            return FDAPDE_OK;
-        }
-        S = pl.R * kPersistT;
-        imp_cap = (pl.max_imp + 63) & ~63, exp_cap = (pl.max_exp + 63) & ~63;
-        fixed = pl.sym ? 8 * (size_t)(S + imp_cap) + 8 * (size_t)S + 64 : 8 * (size_t)(S + imp_cap) + 4 * (size_t)imp_cap + 2 * (size_t)exp_cap + 64;
-        need = pl.max_block;   // largest workgroup block
-        for (int g = 0; g < pl.G && !on_device; ++g) need = std::max<int64_t>(need, pl.ell_off[(size_t)g + 1] - pl.ell_off[(size_t)g]);
-        need += 128;        // one pair row of zeros behind the block: slices narrower than their pass's widest re-read it (clamped loads)
-        if (pl.sym && fixed > lds_total && attempt == 0) {   // no room for the accumulator table: the plain form
-            dev_persist_release(&dp);
-            sym_mode = 0;
-            continue;
-        }
-        // ... and kept only where it pays (tools/persist_sym_ab.py): not if the PLAIN blocks of this partition would be resident (C2-size
-        // systems: 6.2 against 8.3 us per iteration), and for workgroups of at most 2048 rows only if the symmetric blocks are resident
-        // (3-D 314 k rows: 13.7 -> 11.7 us) -- streamed, the plain form is faster at that size (439 k rows: 14.7 against 15.7)
-        if (c->persist_sym == 2 && pl.sym && attempt == 0) {
-            const size_t fixed_plain = 8 * (size_t)(S + imp_cap) + 4 * (size_t)imp_cap + 2 * (size_t)exp_cap + 64;
-            const size_t block_plain = (size_t)(1.03 * (double)pl.nnz_full / (double)pl.G) + 256;   // (boundaries at equal cost: blocks of equal size)
-            const bool plain_resident = pl.R < 16 && fixed_plain + 10 * block_plain <= lds_total;
-            const bool sym_resident = fixed + 10 * (size_t)need <= lds_total;
-            if (plain_resident || ((pl.n_int + pl.G - 1) / pl.G <= 2048 && !sym_resident)) {
-                dev_persist_release(&dp);
-                sym_mode = 0;
-                continue;
-            }
-        }
-        break;
-    }
-    clk.mark("build_persist: layout");
-    // resident form when every block fits its workgroup's LDS next to the vectors; else the blocks stream every iteration
-    ps.stream = fixed + 10 * (size_t)need > lds_total;
-    if (fixed > lds_total || (pl.R == 16 && !ps.stream)) {   // (no resident instantiation for 8192 rows: they never fit)
-        dev_persist_release(&dp);
-        return FDAPDE_OK;
-    }
-    ps.lds_cap = ps.stream ? 0 : (int32_t)need, ps.imp_cap = imp_cap;
-    ps.lds_bytes = fixed + (ps.stream ? 0 : 10 * (size_t)need);
-    hipStream_t st = c->stream;
-    if (on_device) {
-        if (std::getenv("FDAPDE_SETUP_CHECK")) {
-            if (int rc2 = check_dev_persist(c, v, pl, dp, block_rows, balance)) {
-                dev_persist_release(&dp);
-                return rc2;
-            }
-        }
-        const size_t GS = (size_t)pl.G * S, n_alloc = (size_t)pl.n_entries + 256;
-        adopt(ps.slot_dof, dp.slot_dof, GS), adopt(ps.ell_off, dp.ell_off, (size_t)pl.G + 1), adopt(ps.sl_off, dp.sl_off, (size_t)pl.G * (pl.nsl + 1));
-        adopt(ps.ell_code, dp.ell_code, n_alloc), adopt(ps.ell_src, dp.ell_src, n_alloc), adopt(ps.exp_off, dp.exp_off, (size_t)pl.G + 1);
-        adopt(ps.exp_slot, dp.exp_slot, (size_t)(pl.n_board ? pl.n_board : 1)), adopt(ps.imp_off, dp.imp_off, (size_t)pl.G + 1);
-        adopt(ps.imp_pos, dp.imp_pos, (size_t)(pl.n_imp ? pl.n_imp : 1));
-    } else {
-        HIPCHK(c, ps.slot_dof.upload(pl.slot_dof.data(), pl.slot_dof.size(), st));
-        HIPCHK(c, ps.ell_off.upload(pl.ell_off.data(), pl.ell_off.size(), st));
-        HIPCHK(c, ps.sl_off.upload(pl.sl_off.data(), pl.sl_off.size(), st));
-        HIPCHK(c, ps.ell_code.alloc(pl.ell_code.size() + 256));   // + slack: clamped loads of the last slices may run past the last block
-        HIPCHK(c, hipMemsetAsync(ps.ell_code.p, 0, sizeof(uint16_t) * (pl.ell_code.size() + 256), st));
-        HIPCHK(c, hipMemcpyAsync(ps.ell_code.p, pl.ell_code.data(), sizeof(uint16_t) * pl.ell_code.size(), hipMemcpyHostToDevice, st));
-        HIPCHK(c, ps.ell_src.upload(pl.ell_src.data(), pl.ell_src.size(), st));
-        HIPCHK(c, ps.exp_off.upload(pl.exp_off.data(), pl.exp_off.size(), st));
-        HIPCHK(c, ps.exp_slot.upload(pl.exp_slot.data(), pl.exp_slot.size(), st));
-        HIPCHK(c, ps.imp_off.upload(pl.imp_off.data(), pl.imp_off.size(), st));
-        HIPCHK(c, ps.imp_pos.upload(pl.imp_pos.data(), pl.imp_pos.size(), st));
-    }
-    HIPCHK(c, ps.ell_val.alloc((size_t)pl.n_entries + 256));
-    HIPCHK(c, hipMemsetAsync(ps.ell_val.p, 0, sizeof(double) * ((size_t)pl.n_entries + 256), st));
-    HIPCHK(c, ps.board.alloc(2 * (size_t)pl.n_board + 2 * (size_t)pl.G * 6 + 2));   // p entries | dot partials x 2 parities
-    HIPCHK(c, hipMemsetAsync(ps.board.p, 0, sizeof(unsigned long long) * ps.board.n, st));   // every tag 0: no launch uses epoch 0
-    ps.epoch_next = 0, ps.attr_set = nullptr;
-    HIPCHK(c, ps.amax.alloc(1));
-    HIPCHK(c, c->persist_stats.alloc(4 * 1024));
-    HIPCHK(c, hipStreamSynchronize(st));
-    clk.mark("build_persist: uploads + allocs");
-    if (std::getenv("FDAPDE_DEBUG_SETUP"))
-        std::fprintf(stderr, "persistent CG layout %d (%s-built): %d workgroups x %d rows/thread, %lld interior rows, %lld entries (%lld stored, %.1f %% padding), "
-                     "LDS %zu B (%s%s, largest block %lld), imports <= %d, exports <= %d, board %lld\n", v, on_device ? "device" : "host", pl.G, pl.R,
-                     (long long)pl.n_int, (long long)pl.n_entries, (long long)pl.nnz,
-                     100.0 * (double)(pl.n_entries - pl.nnz) / (double)(pl.n_entries > 0 ? pl.n_entries : 1), ps.lds_bytes,
-                     ps.stream ? "blocks stream" : "blocks resident", pl.sym ? ", symmetric storage" : "", (long long)need, pl.max_imp, pl.max_exp, (long long)pl.n_board);
-    // keep the sizes, drop the big host arrays
-    pl.slot_dof = {}, pl.ell_code = {}, pl.ell_src = {}, pl.exp_slot = {}, pl.imp_pos = {}, pl.sl_off = {}, pl.ell_off = {};
-    ps.meta = std::move(pl);
-    ps.filled = false, ps.ok = true;
-    return FDAPDE_OK;
-}
-
-// launch of k_cg_persist on the layout ps.  The boards are NOT cleared: every launch tags its granules with epochs of its own
-// (ps.epoch_next + iteration + 1, strictly increasing from launch to launch), so what an earlier launch left behind never matches.
-int launch_persist(fdapde_ctx* c, fdapde_ctx::Persist& ps, PersistArgs& a) {
-    hipStream_t st = c->stream;
-    a.G = ps.meta.G, a.nsl = ps.meta.nsl, a.imp_cap = ps.imp_cap, a.lds_cap = ps.lds_cap;
-    a.gather_waves = c->persist_gather_waves, a.poll_sleep = c->persist_poll_sleep;
-    a.slot_dof = ps.slot_dof.p, a.ell_off = ps.ell_off.p, a.sl_off = ps.sl_off.p, a.ell_code = ps.ell_code.p;
-    a.ell_val = ps.ell_val.p, a.exp_off = ps.exp_off.p, a.exp_slot = ps.exp_slot.p, a.imp_off = ps.imp_off.p, a.imp_pos = ps.imp_pos.p;
-    a.pboard = ps.board.p, a.dboard = ps.board.p + 2 * (size_t)ps.meta.n_board;
-    a.amax_bits = ps.amax.p, a.max_len = c->hs.max_row, a.stats = c->persist_stats.p;
-    a.timeout_ticks = c->persist_timeout_us * 100, a.debug_stall_it = c->persist_debug_stall;
-    if (ps.epoch_next > 0xE0000000u - (uint32_t)a.maxit) {   // (the tags are 32 bits wide: start over on clean boards)
-        HIPCHK(c, hipMemsetAsync(ps.board.p, 0, sizeof(unsigned long long) * ps.board.n, st));
-        ps.epoch_next = 0;
-    }
-    a.epoch0 = ps.epoch_next;
-    if (a.time_phases) HIPCHK(c, hipMemsetAsync(c->persist_stats.p, 0, 4 * (size_t)a.G * sizeof(double), st));
-    HIPCHK(c, hipEventRecord(c->ev_p0, st));
-    void* kargs[] = {&a};
-    // co-residency of the G workgroups is what the in-kernel hand-offs rely on: G <= (workgroups of this instantiation the runtime says a
-    // CU holds) x CUs, checked below through the occupancy API; knob persist_coop makes the launch cooperative on top (the runtime then
-    // refuses a grid that cannot be resident instead of letting it spin -- at 10.5 ms for the first such launch of a process)
-#define PERSIST_GO(R_, ST_, SY_)                                                                                                \
-    do {                                                                                                                        \
-        const void* fn = reinterpret_cast<const void*>(&k_cg_persist<R_, ST_, SY_>);                                            \
-        if (ps.attr_set != fn) {                                                                                                \
-            DebugClock clk2;                                                                                                    \
-            HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ps.lds_bytes));                  \
-            clk2.mark("launch_persist: hipFuncSetAttribute");                                                                   \
-            int per_cu = 0;                                                                                                     \
-            HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kPersistT, ps.lds_bytes));                      \
-            clk2.mark("launch_persist: occupancy query");                                                                       \
-            if ((int64_t)per_cu * c->n_cu < (int64_t)a.G) return FDAPDE_EUNSUPPORTED;   /* the grid cannot be resident at once */ \
-            ps.attr_set = fn;                                                                                                   \
-        }                                                                                                                       \
-        if (c->persist_coop) HIPCHK(c, hipLaunchCooperativeKernel(fn, dim3(a.G), dim3(kPersistT), kargs, (unsigned)ps.lds_bytes, st)); \
-        else hipLaunchKernelGGL((k_cg_persist<R_, ST_, SY_>), dim3(a.G), dim3(kPersistT), ps.lds_bytes, st, a);                 \
-    } while (0)
-#define PERSIST_GO2(R_, ST_)                                                                                                    \
-    do {                                                                                                                        \
-        if (ps.meta.sym) PERSIST_GO(R_, ST_, true);                                                                             \
-        else PERSIST_GO(R_, ST_, false);                                                                                        \
-    } while (0)
-    if (ps.stream) switch (ps.meta.R) {
-        case 2: PERSIST_GO2(2, true); break;
-        case 4: PERSIST_GO2(4, true); break;
-        case 8: PERSIST_GO2(8, true); break;
-        default: PERSIST_GO2(16, true); break;
-        }
-    else switch (ps.meta.R) {
-        case 2: PERSIST_GO2(2, false); break;
-        case 4: PERSIST_GO2(4, false); break;
-        default: PERSIST_GO2(8, false); break;
-        }
-#undef PERSIST_GO2
-#undef PERSIST_GO
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(c->ev_p1, st));
-    return FDAPDE_OK;
-}
-
-int build_persist(fdapde_ctx* c, int v) {
-    fdapde_ctx::Persist& ps = c->ps[v];
-    if (ps.tried) return FDAPDE_OK;
-    ps.tried = true;
-    if (int rc = build_persist_once(c, v, nullptr, c->persist_balance != 0)) return rc;
-    // boundaries at equal cost can leave one workgroup with more rows that import than its import-free passes have room for
-    // where equal row counts would not: the system must not lose the single-launch path over that
-    if (!ps.ok && c->persist_balance) return build_persist_once(c, v, nullptr, false);
-    return FDAPDE_OK;
-}
-
-// the whole fused-update CG as one launch; returns FDAPDE_OK with *ran = false when the launch gave up (hand-off timeout): a launch
-// that gives up leaves x (it writes the solution to persist_x), r, p, sc and ctl[0..2] as it found them, so the multi-launch
-// path restarts the same solve from the same state
-int run_persist(fdapde_ctx* c, int v, double tol2, int maxit, bool* ran) {
-    fdapde_ctx::Persist& ps = c->ps[v];
-    hipStream_t st = c->stream;
-    const size_t n = (size_t)c->hs.n_dofs;
-    if (c->persist_x.n < n) {   // rows the layout leaves out (Dirichlet DOFs) are never written: they must read as finite numbers
-        HIPCHK(c, c->persist_x.alloc(n));
-        HIPCHK(c, hipMemsetAsync(c->persist_x.p, 0, sizeof(double) * n, st));
-    }
-    PersistArgs a{};
-    a.maxit = maxit, a.time_phases = c->persist_time, a.tol2 = tol2;
-    a.r_in = c->r.p, a.x = c->x.p, a.x_out = c->persist_x.p, a.sc = c->sc.p, a.ctl = c->ctl.p;
-    DebugClock clk;
-    const int rc_launch = launch_persist(c, ps, a);
-    clk.mark("run_persist: launch call");
-    if (int rc = rc_launch) {
-        if (rc != FDAPDE_EUNSUPPORTED) return rc;
-        ps.ok = false, *ran = false;   // the occupancy the runtime reports does not hold the grid: this layout never launches
-        return FDAPDE_OK;
-    }
-    HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(c->h_sc, c->sc.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (a.time_phases) {
-        c->persist_host_stats.resize(4 * (size_t)a.G);
-        HIPCHK(c, hipMemcpyAsync(c->persist_host_stats.data(), c->persist_stats.p, 4 * (size_t)a.G * sizeof(double), hipMemcpyDeviceToHost, st));
-    } else
-        c->persist_host_stats.clear();
-    HIPCHK(c, hipStreamSynchronize(st));
-    float ms = 0;
-    HIPCHK(c, hipEventElapsedTime(&ms, c->ev_p0, c->ev_p1));
-    c->persist_launch_ms = ms;
-    *ran = c->h_ctl[3] == 0;
-    if (!*ran) {   // a peer workgroup was not resident (other work on the device?).  The context stays on the multi-launch path for a
-                   // while and tries again later, twice as much later after every failure (8, 16, ... 1024 solves)
-        c->persist_broken = true;
-        c->persist_retry_in = c->persist_backoff;
-        c->persist_backoff = std::min(1024, 2 * c->persist_backoff);
-        HIPCHK(c, hipMemsetAsync(c->ctl.p + 3, 0, sizeof(int32_t), st));
-        HIPCHK(c, hipMemsetAsync(ps.board.p, 0, sizeof(unsigned long long) * ps.board.n, st));   // (how far its epochs got is unknown)
-        ps.epoch_next = 0;
-    } else {
-        c->persist_backoff = 8;
-        ps.epoch_next += (uint32_t)c->h_ctl[1] + 2u;
-    }
-    return FDAPDE_OK;
-}
-
 // blocked-ELL layout of the multi-launch SpMV for boundary variant v (k_spmv_blocked), built on the device from the pattern
 int build_blocked(fdapde_ctx* c, int v) {
     fdapde_ctx::Blocked& bk = c->bk[v];
@@ -1593,6 +1287,8 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss, b
     ss->dist = (c->comm != nullptr || c->ar_fn != nullptr) && c->halo_ready;   // multi-GPU: sub-assembled operator of this rank's cells
     ss->owned = ss->dist ? c->owned.p : nullptr;
     ss->use_bnd = use_bnd;
+    ss->rowdist = (c->comm != nullptr || c->ar_fn != nullptr) && c->rd.ready && !ss->dist;
+    if (ss->rowdist) ss->owned = c->rd.owned.p;
     HIPCHK(c, hipMemsetAsync(c->ctl.p, 0, 4 * sizeof(int32_t), st));
     if (ss->dist) {   // the diagonal is a sum over the ranks sharing a DOF
         hipLaunchKernelGGL(k_diag_extract, dim3(g1(n)), dim3(256), 0, st, n, c->diag.p, A, c->tmp_i.p);
@@ -1604,7 +1300,7 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss, b
     }
     HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
-    if (ss->dist) {   // "positive diagonal" (CG admissible) must be ONE decision for all ranks: sum the per-rank flags
+    if (ss->dist || ss->rowdist) {   // "positive diagonal" (CG admissible) must be ONE decision for all ranks: sum the per-rank flags
         c->h_sc[8] = (double)c->h_ctl[3];
         HIPCHK(c, hipMemcpyAsync(c->sbuf.p + 2, c->h_sc + 8, sizeof(double), hipMemcpyHostToDevice, st));
         if (int rc = allreduce_sum(c, c->sbuf.p + 2, 1)) return rc;
@@ -1613,6 +1309,24 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss, b
         c->h_ctl[3] = c->h_sc[8] != 0.0 ? 1 : 0;
     }
     ss->diag_positive = c->h_ctl[3] == 0;
+    if (ss->rowdist) {
+        // row-distributed form: this rank's rows are complete (its sub-mesh holds every cell touching an owned DOF), the columns other
+        // ranks own take their Jacobi scale from the owner; the whole CG then runs as one launch per rank on a layout of its own
+        c->ps[0].filled = c->ps[1].filled = false, c->bk_cur = -1, c->bk[0].filled = c->bk[1].filled = false;
+        if (!ss->diag_positive) return fail(c, FDAPDE_EUNSUPPORTED, "the row-distributed solve needs a positive diagonal (Jacobi scaling)");
+        const int v = use_bnd ? 1 : 0;
+        c->persist_plain = symmetric ? 0 : 1;
+        if (int rc = build_rowdist(c, v)) return rc;
+        if (c->rd.lay[v].ok && !symmetric && (c->rd.lay[v].ps.meta.sym || c->rd.lay[v].ps.meta.R > 8))
+            return fail(c, FDAPDE_EUNSUPPORTED, "the row-distributed BiCGStab needs plain storage and at most 8 rows per thread (layout built for a symmetric operator? re-create the context)");
+        if (!c->rd.lay[v].ok) return fail(c, FDAPDE_EUNSUPPORTED, "the row-distributed solve does not take this system (a rank's share needs more than 8 rows per thread, or its lists do not fit)");
+        if (int rc = rowdist_import_ghosts(c, v, c->scale.p)) return rc;
+        hipLaunchKernelGGL(k_scale_matrix, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, A, c->scale.p, c->sval.p);
+        c->sp_cur = -1, c->sval_layout = -2;
+        if (int rc = fill_rowdist(c, v)) return rc;
+        HIPCHK(c, hipGetLastError());
+        return FDAPDE_OK;
+    }
     // scaled matrix: compact (no diagonal, no Dirichlet rows / columns: ~12 % fewer entries on C3) when every interior
     // diagonal is positive, so that the scaled diagonal is exactly 1; else the full pattern
     // symmetric positive system on one GPU of at most ~2 M interior rows: the solve will run as ONE persistent launch on its own
@@ -1621,9 +1335,13 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss, b
     c->ps[0].filled = c->ps[1].filled = false;
     bool persist = false;
     if (c->persist_broken && --c->persist_retry_in <= 0) c->persist_broken = false;   // the contention that broke it may be over
-    if (symmetric && ss->diag_positive && !ss->dist && c->persist && !c->persist_broken && c->spmv_variant == 2) {   // (the single launch is a CG)
+    // symmetric: the single launch is a CG (kernels_persist.h); non-symmetric: a BiCGStab on the plain storage (kernels_persist_bicg.h: six
+    // vectors in registers, so at most 8 rows per thread -- larger systems keep the multi-launch BiCGStab)
+    c->persist_plain = symmetric ? 0 : 1;
+    if ((symmetric || c->persist_bicg) && ss->diag_positive && !ss->dist && c->persist && !c->persist_broken && c->spmv_variant == 2) {
         if (int rc = build_persist(c, use_bnd ? 1 : 0)) return rc;
-        persist = c->ps[use_bnd ? 1 : 0].ok;
+        const fdapde_ctx::Persist& ps = c->ps[use_bnd ? 1 : 0];
+        persist = ps.ok && (symmetric || (!ps.meta.sym && ps.meta.R <= 8));
     }
     // one GPU, positive diagonal, not taken by the persistent CG (non-symmetric operator, or too many rows): the multi-launch
     // kernels apply the operator from the blocked-ELL layout (k_spmv_blocked); the compact CSR pattern is then not built either
@@ -1657,13 +1375,8 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss, b
                            c->sval.p, c->bk[v].ell_val.p, (unsigned long long*)nullptr);
         c->bk[v].filled = true, c->bk_cur = v;
     }
-    if (persist) {
-        const int v = use_bnd ? 1 : 0;
-        if (c->ps[v].meta.sym) HIPCHK(c, hipMemsetAsync(c->ps[v].amax.p, 0, sizeof(unsigned long long), st));
-        hipLaunchKernelGGL(k_persist_fill, dim3(g1(c->ps[v].meta.n_entries)), dim3(256), 0, st, c->ps[v].meta.n_entries, c->ps[v].ell_src.p,
-                           c->sval.p, c->ps[v].ell_val.p, c->ps[v].meta.sym ? c->ps[v].amax.p : (unsigned long long*)nullptr);
-        c->ps[v].filled = true;
-    }
+    if (persist)
+        if (int rc = fill_persist(c, use_bnd ? 1 : 0)) return rc;
     HIPCHK(c, hipGetLastError());
     return FDAPDE_OK;
 }
@@ -1682,6 +1395,12 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     // partial pairs the SpMV leaves for the vector kernels: one per workgroup of the kernel that applies the scaled operator
     const int np_spmv = (c->bk_cur >= 0 && !dist) ? c->bk[c->bk_cur].meta.G : c->spmv_grid;
     const double* fvec = f_dev;
+    if (ss.rowdist) {
+        if (u0_dev) return fail(c, FDAPDE_EUNSUPPORTED, "warm starts are not part of the row-distributed solve");
+        const bool want_bicg = method == FDAPDE_SOLVER_BICGSTAB || c->rd.lay[ss.use_bnd ? 1 : 0].ps.built_plain;
+        if (method == FDAPDE_SOLVER_CG_SR) return fail(c, FDAPDE_EUNSUPPORTED, "the row-distributed solve runs the fused-update CG or BiCGStab");
+        method = want_bicg ? FDAPDE_SOLVER_BICGSTAB : FDAPDE_SOLVER_CG_FUSED;
+    }
     if (dist) {   // the forcing vector is a sum over the ranks sharing a DOF
         HIPCHK(c, hipMemcpyAsync(c->tmp_e.p, f_dev, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
         if (int rc = halo_sum(c, c->tmp_e.p, nullptr, 0)) return rc;
@@ -1690,7 +1409,7 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     hipLaunchKernelGGL(k_lift, dim3(g1(n)), dim3(256), 0, st, n, c->bnd.p, g_dev, ss.use_bnd, c->gt.p);
     // the lift is zero (no Dirichlet data, or homogeneous data on one GPU -- across ranks the data may differ, and every rank
     // must take the same path through the collectives): A g~ = 0
-    if (!ss.use_bnd || (!dist && g_dev == c->g.p && c->g_zero)) {
+    if (!ss.use_bnd || (!dist && !ss.rowdist && g_dev == c->g.p && c->g_zero)) {
         HIPCHK(c, hipMemsetAsync(c->y.p, 0, sizeof(double) * (size_t)n, st));
     } else {
         launch_spmv(c, A, c->gt.p, c->y.p, nullptr, nullptr, nullptr);   // y = A g~
@@ -1716,7 +1435,7 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     }
     hipLaunchKernelGGL(k_krylov_init, dim3(c->vec_grid), dim3(256), 0, st, n, fvec, c->y.p, c->scale.p, c->x.p, c->r.p, c->p.p,
                        bicg ? c->r0.p : (double*)nullptr, c->part_b.p, owned, u0_dev, c->gt.p, ax, 0);
-    if (dist) {
+    if (dist || ss.rowdist) {
         hipLaunchKernelGGL(k_reduce_partials2, dim3(1), dim3(256), 0, st, c->part_b.p, c->vec_grid, c->sbuf.p);
         if (int rc = allreduce_sum(c, c->sbuf.p, 2)) return rc;
         hipLaunchKernelGGL(k_krylov_init_fin, dim3(1), dim3(256), 0, st, c->sbuf.p, 1, c->sc.p, c->ctl.p, tol2, (double*)nullptr, 0);
@@ -1743,12 +1462,24 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     int timed = 0, launched = 0;
     bool stop = false;
     bool persisted = false;
-    if (cgf && !dist && c->persist && !c->persist_broken && c->ps[ss.use_bnd ? 1 : 0].ok && c->ps[ss.use_bnd ? 1 : 0].filled) {
+    if (ss.rowdist) {   // one launch per rank, the launches of all ranks acting as one grid (kernels_persist.h DIST)
+        if (int rc = run_rowdist(c, ss.use_bnd ? 1 : 0, tol2, maxit, &persisted, bicg)) return rc;
+        if (!persisted) return fail(c, FDAPDE_EUNSUPPORTED, "row-distributed solve: an in-kernel hand-off between the ranks' launches timed out (boards not visible across the devices, or a rank's launch could not be resident); use the element-partitioned exchange (fdapde_halo_setup_peers) instead");
+        stop = true, launched = c->h_ctl[1];
+    }
+    if (cgf && !dist && !ss.rowdist && c->persist && !c->persist_broken && c->ps[ss.use_bnd ? 1 : 0].ok && c->ps[ss.use_bnd ? 1 : 0].filled) {
         // the whole iteration as ONE launch (kernels_persist.h); it leaves sc / ctl as the loop below would
         DebugClock clk;
         if (int rc = run_persist(c, ss.use_bnd ? 1 : 0, tol2, maxit, &persisted)) return rc;
         clk.mark("solve_run: run_persist");
         if (persisted) stop = true, launched = c->h_ctl[1];
+    }
+    if (bicg && !dist && !ss.rowdist && c->persist && c->persist_bicg && !c->persist_broken) {   // the whole BiCGStab as one launch
+        const fdapde_ctx::Persist& ps = c->ps[ss.use_bnd ? 1 : 0];
+        if (ps.ok && ps.filled && !ps.meta.sym && ps.meta.R <= 8) {
+            if (int rc = run_persist(c, ss.use_bnd ? 1 : 0, tol2, maxit, &persisted, /*bicg=*/true)) return rc;
+            if (persisted) stop = true, launched = c->h_ctl[1];
+        }
     }
     // one iteration of the fused-update CG: SpMV (p.y, y.y) + k_cgf_update; arguments depend on the iteration's parity only
     const int cgf_V = c->cgf_v;
@@ -1777,7 +1508,7 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
                            c->ctl.p);
     };
     const int bi_grid = (int)(((n >> 1) + 256 * kBiV - 1) / (256 * kBiV)) > 0 ? (int)(((n >> 1) + 256 * kBiV - 1) / (256 * kBiV)) : 1;
-    while (!stop && launched < maxit) {
+    while (!stop && launched < maxit && !ss.rowdist) {
         const int chunk = (maxit - launched) < check_every ? (maxit - launched) : check_every;
         // a full chunk of the fused-update CG with no timed launch replays ONE hipGraph (2 * chunk + 1 kernel nodes): the
         // arguments repeat with period 2, so the graph captured for iterations 0 .. chunk-1 serves every even-aligned chunk
@@ -1980,11 +1711,13 @@ int fdapde_solver_prepare(fdapde_ctx* c, int32_t with_dirichlet) {
     HIPCHK(c, hipSetDevice(c->device));
     if (c->spmv_variant != 2) return FDAPDE_OK;
     const int v = with_dirichlet ? 1 : 0;
-    if (c->persist && !c->persist_broken && c->comm == nullptr && c->ar_fn == nullptr && c->op_symmetric) {
-        // single GPU, symmetric operator: the persistent CG's resident layout; when the system qualifies for it, the compact pattern
-        // and the column codes of the multi-launch SpMV are not needed (a non-SPD matrix falls back and builds them lazily)
+    if (c->persist && !c->persist_broken && c->comm == nullptr && c->ar_fn == nullptr && (c->op_symmetric || c->persist_bicg)) {
+        // single GPU: the single-launch solver's layout (CG for a symmetric operator, BiCGStab on the plain storage otherwise); when the
+        // system qualifies for it, the compact pattern and the column codes of the multi-launch SpMV are not needed (a matrix that turns
+        // out not to qualify at solve time falls back and builds them lazily)
+        c->persist_plain = c->op_symmetric ? 0 : 1;
         if (int rc = build_persist(c, v)) return rc;
-        if (c->ps[v].ok) return FDAPDE_OK;
+        if (c->ps[v].ok && (c->op_symmetric || (!c->ps[v].meta.sym && c->ps[v].meta.R <= 8))) return FDAPDE_OK;
     }
     if (c->blocked && c->comm == nullptr && c->ar_fn == nullptr &&
         ((double)c->hs.nnz >= 20.0 * (double)c->hs.n_dofs || c->blocked == 2)) {   // single GPU, long rows: the multi-launch kernels use the blocked-ELL layout
@@ -2278,7 +2011,7 @@ int fdapde_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, 
     // (a system the persistent CG takes is faster column by column -- one launch each, no vector traffic -- than batched through
     // the multi-launch SpMM: C3-size, 22.5 ms per column against 32 ms per column in a batch of 8)
     const bool persist_cols = c->persist && !c->persist_broken && c->ps[0].ok && c->ps[0].filled;
-    const bool batched = c->multi_rhs && n_rhs >= 4 && method == FDAPDE_SOLVER_CG_FUSED && !c->lin_state->ss.dist && !persist_cols;
+    const bool batched = c->multi_rhs && n_rhs >= 4 && method == FDAPDE_SOLVER_CG_FUSED && !c->lin_state->ss.dist && !c->lin_state->ss.rowdist && !persist_cols;
     if (batched) {
         if (!c->lin_sq_ready) {   // full-pattern scaled copy (explicit unit diagonal), once per prepared matrix
             HIPCHK(c, c->lin_sq.alloc((size_t)hs.nnz + 2));
@@ -2678,6 +2411,30 @@ int fdapde_halo_setup(fdapde_ctx* c, int64_t n_if_global, int64_t n_if_local, co
     return FDAPDE_OK;
 }
 
+// Row-distributed multi-GPU form: every DOF of the whole mesh is OWNED by one rank; a rank's sub-mesh holds every cell touching one of its
+// DOFs (its own cells + one layer of cells of its neighbours), so that its assembly completes the rows of its DOFs without any exchange.
+int fdapde_rowdist_setup(fdapde_ctx* c, const int64_t* dof_key, const int32_t* dof_owner) {
+    if (!c || !dof_key || !dof_owner) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (!c->dev_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
+    if (!c->comm && !c->ar_fn) return fail(c, FDAPDE_ENOTINIT, "call fdapde_comm_init first");
+    HIPCHK(c, hipSetDevice(c->device));
+    release_rowdist(c);
+    const HostSpace& hs = c->hs;
+    c->rd.owner_i.resize((size_t)hs.n_dofs), c->rd.key_i.resize((size_t)hs.n_dofs);
+    std::vector<uint8_t> own((size_t)hs.n_dofs);
+    for (int64_t i = 0; i < hs.n_dofs; ++i) {
+        const int32_t e = hs.dof_i2e[(size_t)i];
+        if (dof_owner[e] < 0 || dof_owner[e] >= c->world) return fail(c, FDAPDE_EINVAL, "fdapde_rowdist_setup: owner out of range");
+        c->rd.owner_i[(size_t)i] = dof_owner[e], c->rd.key_i[(size_t)i] = dof_key[e], own[(size_t)i] = dof_owner[e] == c->rank ? 1 : 0;
+    }
+    HIPCHK(c, c->rd.owned.upload(own.data(), own.size(), c->stream));
+    HIPCHK(c, c->sbuf.alloc(8));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->rd.ready = true, c->halo_ready = false;
+    return FDAPDE_OK;
+}
+
 int fdapde_comm_set_exchange_callback(fdapde_ctx* c, fdapde_exchange_fn fn, void* user) {
     if (!c || !fn) return FDAPDE_EINVAL;
     c->xchg_fn = fn, c->xchg_user = user;
@@ -2776,6 +2533,14 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "persist" && (value == 0 || value == 1)) c->persist = value, c->persist_broken = false;
     else if (k == "persist_time" && (value == 0 || value == 1)) c->persist_time = value;
     else if (k == "persist_coop" && (value == 0 || value == 1)) c->persist_coop = value;
+    else if (k == "persist_bicg" && (value == 0 || value == 1)) c->persist_bicg = value;
+    else if (k == "rowdist_max_wg" && value >= 0) {   // workgroups of this rank's launch (tests: several ranks share one device)
+        c->rd.max_wg = value;
+        for (auto& L : c->rd.lay) L.tried = L.ok = false;
+    } else if (k == "rowdist_share" && value >= 1) {   // that many ranks share this device: an equal share of its CUs each
+        c->rd.max_wg = std::max(1, c->n_cu / value);
+        for (auto& L : c->rd.lay) L.tried = L.ok = false;
+    } else if (k == "rowdist_timeout_first_ms" && value >= 1) c->rd.timeout_first_ms = value;
     else if (k == "persist_timeout_us" && value >= 100 && value <= 10000000) c->persist_timeout_us = value;
     else if (k == "persist_debug_stall" && value >= 0) c->persist_debug_stall = value;   // (tests: forces the hand-off timeout at that iteration)
     else if (k == "persist_retry" && value == 1) c->persist_broken = false, c->persist_retry_in = 0, c->persist_backoff = 8;   // (tests: forget an earlier timeout)

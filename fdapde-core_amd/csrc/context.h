@@ -1,6 +1,6 @@
 // context.h -- what a fdapde_ctx holds: device buffers, launch configuration and tuning knobs, the compact solver patterns, the
 // multi-GPU state (RCCL communicator or host-staged transport, interface maps), the factor-once handle.  Internal to
-// libfdapde_hip.so (the C ABI in include/fdapde_hip.h only sees an opaque pointer); included by capi.hip alone.
+// libfdapde_hip.so (the C ABI in include/fdapde_hip.h only sees an opaque pointer); shared by the library's translation units (engine.h).
 #ifndef FDAPDE_CONTEXT_H
 #define FDAPDE_CONTEXT_H
 
@@ -19,7 +19,11 @@
 #include "dev_setup.h"
 #include "dev_topology.h"
 #include "internal.h"
-#include "kernels.h"
+
+namespace fdapde_hip {
+struct DevTables;        // kernels_assembly.h (the context only holds device buffers of them)
+struct DevRefTensors;
+}
 
 using namespace fdapde_hip;
 
@@ -42,6 +46,13 @@ template <typename T> struct DBuf {
         release();
         n = count;
         return hipMalloc(reinterpret_cast<void**>(&p), sizeof(T) * (count ? count : 1));
+    }
+    // fine-grained device memory (coherent with accesses of other GPUs / the host while kernels run: the boards of the row-distributed
+    // persistent launches); released like any other allocation
+    hipError_t alloc_fine(size_t count) {
+        release();
+        n = count;
+        return hipExtMallocWithFlags(reinterpret_cast<void**>(&p), sizeof(T) * (count ? count : 1), hipDeviceMallocFinegrained);
     }
     hipError_t upload(const T* src, size_t count, hipStream_t st) {
         hipError_t e = alloc(count);
@@ -143,6 +154,7 @@ struct GraphKey {
 // what solve_prepare decided for a system matrix (shared by the elliptic, parabolic and handle solves)
 struct SolveState {
     bool dist = false, diag_positive = true;
+    bool rowdist = false;   // row-distributed multi-GPU form: complete rows of the owned DOFs, one persistent launch per rank
     const uint8_t* owned = nullptr;
     int use_bnd = 0;
 };
@@ -286,11 +298,39 @@ struct fdapde_ctx {
         bool filled = false;                 // ell_val holds the currently scaled system
         uint32_t epoch_next = 0;             // the next launch tags its granules epoch_next + iteration + 1
         const void* attr_set = nullptr;      // kernel instantiation whose dynamic-LDS attribute is in place
+        bool built_plain = false;            // built for a non-symmetric system (plain storage whatever persist_sym says)
     } ps[2];
+    // row-distributed multi-GPU form of the persistent CG (fdapde_rowdist_setup; persist_engine.hip): every rank owns a set of DOFs and
+    // assembles their rows completely (its sub-mesh holds every cell touching an owned DOF); the workgroups of all ranks' launches act
+    // as one grid, exchanging through peer-mapped boards
+    struct RowDist {
+        bool ready = false;
+        std::vector<int32_t> owner_i;        // internal DOF order: owning rank
+        std::vector<int64_t> key_i;          // ... global key
+        DBuf<uint8_t> owned;                 // 1 = this rank's DOF
+        int max_wg = 0;                      // workgroups this rank's launch may use (0: one per CU; tests put several ranks on one device)
+        int timeout_first_ms = 2000;         // bound of the waits of iteration 0 (launch skew between the ranks)
+        struct Layout {
+            bool tried = false, ok = false;
+            Persist ps;                      // the local part: blocks, local exports / imports, board (fine-grained), epochs
+            int32_t n_ghost = 0, G_tot = 0, g_base = 0;
+            DBuf<int32_t> rexp_off, rexp_peer, rexp_pos;
+            DBuf<uint16_t> rexp_slot;
+            DBuf<unsigned long long*> peer_pboard, peer_dboard;
+            std::vector<void*> ipc_opened;   // peer boards mapped through hipIpcOpenMemHandle (closed with the context)
+            // exchange of per-DOF values of the ghost columns (the Jacobi scale, once per prepared system): per peer, what goes out / comes in
+            std::vector<int32_t> x_rank;     // peers, ascending
+            std::vector<int64_t> x_soff, x_roff;
+            DBuf<int32_t> x_send_dof, x_recv_dof;
+            DBuf<double> x_sendbuf, x_recvbuf;
+        } lay[2];
+    } rd;
     DBuf<double> persist_stats;
     DBuf<double> persist_x;                  // the persistent launch writes its solution here (x stays the initial guess)
     double persist_launch_ms = 0;            // duration of the last persistent launch (HIP events on the stream)
     int persist_host_below = 32768;          // systems of at most this many DOFs build the persistent layout on the host (first-solve latency)
+    int persist_plain = 0;                   // the system being prepared is non-symmetric: plain storage, BiCGStab kernel
+    int persist_bicg = 1;                    // tuning knob: 0 = non-symmetric systems always take the multi-launch BiCGStab
     int persist_coop = 0;                    // 1: cooperative launch (the runtime refuses a grid that cannot be resident).  Off by default: the grid is
                                              // sized from hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs already, the cooperative queue costs 10.5 ms
                                              // the first time a process uses it, and launches of several processes on one device would serialise

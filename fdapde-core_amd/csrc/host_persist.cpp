@@ -33,7 +33,8 @@ template <typename F> void for_each_wg(int G, F&& fn) {
 
 }  // namespace
 
-int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int lds_entries, PersistLayout& pl, const int32_t* block_rows, int sym_mode, bool balance) {
+int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int lds_entries, PersistLayout& pl, const int32_t* block_rows, int sym_mode, bool balance,
+                              const int32_t* ghost_order) {
     constexpr int T = kPersistT;
     const int64_t nd = hs.n_dofs;
     if (n_wg < 1 || nd < 1) return FDAPDE_EUNSUPPORTED;
@@ -42,8 +43,9 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
     // interior rows in internal (locality) order
     std::vector<int32_t> irow_dof;
     irow_dof.reserve((size_t)nd);
+    auto ghost = [&](int64_t d) { return ghost_order != nullptr && ghost_order[(size_t)d] >= 0; };
     for (int64_t d = 0; d < nd; ++d)
-        if (!dropped(d)) irow_dof.push_back((int32_t)d);
+        if (!dropped(d) && !ghost(d)) irow_dof.push_back((int32_t)d);
     const int64_t n_int = (int64_t)irow_dof.size();
     if (n_int < 1) return FDAPDE_EUNSUPPORTED;
     auto kept = [&](int64_t row, int32_t col) { return col != row && !dropped(col); };
@@ -211,6 +213,14 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
         pl.max_exp = std::max(pl.max_exp, cnt);
     }
     pl.n_board = pl.exp_off[(size_t)G];
+    // row-distributed form: the entries other ranks own sit behind the local exports, in the caller's order
+    pl.ghost_needed.clear();
+    if (ghost_order != nullptr) {
+        for (int64_t d = 0; d < nd; ++d)
+            if (ghost(d) && is_exp[(size_t)d]) pl.ghost_needed.push_back((int32_t)d);
+        std::sort(pl.ghost_needed.begin(), pl.ghost_needed.end(), [&](int32_t a, int32_t b) { return ghost_order[(size_t)a] < ghost_order[(size_t)b]; });
+        for (size_t k = 0; k < pl.ghost_needed.size(); ++k) board_of[(size_t)pl.ghost_needed[k]] = (int32_t)(pl.n_board + (int64_t)k);
+    }
     // ---- imports in board order (neighbouring entries of one exporter are read together)
     pl.imp_off.assign((size_t)G + 1, 0);
     pl.max_imp = 0;
@@ -288,6 +298,7 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
         nnz_wg[(size_t)g] = nz;
     });
     pl.nnz = std::accumulate(nnz_wg.begin(), nnz_wg.end(), (int64_t)0);
+    if (ghost_order != nullptr) pl.wg_of = std::move(wg_of), pl.slot_of = std::move(slot_of);
     return FDAPDE_OK;
 }
 

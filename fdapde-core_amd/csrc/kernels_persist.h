@@ -57,6 +57,19 @@ struct PersistArgs {
                                   // [3] hand-off timeout (then ctl[0..2] and sc[3] are as the host left them)
     double* stats;                // per workgroup: [0] iterations timed, [1] operator phase (SpMV + imports), [2] all-gather phase (incl. the
                                   // wait for the slowest workgroup), [3] update phase -- sums of 10 ns ticks
+    // ---- row-distributed form (DIST): the workgroups of `world` launches -- one per rank, each on its own GPU (tests: sharing one) -- act
+    //      as ONE grid of G_tot workgroups.  Every rank holds a board of its own: [its exports | the entries it imports from other ranks |
+    //      dot records of all G_tot workgroups x 2 parities]; exporters PUSH the entries another rank needs into that rank's board (posted
+    //      writes over xGMI through peer-mapped pointers) and every workgroup pushes its dot record into every rank's board, so that all
+    //      polling stays local.  Board memory is fine-grained and every board access system-scope (sc0 sc1).
+    int32_t world, g_base, G_tot;     // ranks; global index of this launch's workgroup 0; workgroups of all launches
+    int32_t timeout_first_ticks;      // bound of the waits of iteration 0 (the launches of the ranks start at different times)
+    const int32_t* rexp_off;          // [G + 1] remote exports of a workgroup
+    const uint16_t* rexp_slot;        // slot whose entry goes out
+    const int32_t* rexp_peer;         // to which rank
+    const int32_t* rexp_pos;          // at which position of that rank's p board
+    unsigned long long* const* peer_pboard;   // [world] p boards (entry `rank` = the local one)
+    unsigned long long* const* peer_dboard;   // [world] dot boards
 };
 
 typedef __attribute__((address_space(1))) unsigned long long pg_u64;
@@ -107,6 +120,29 @@ __device__ __forceinline__ void granule_load2x4(const unsigned long long* p0, co
                  "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
 }
+// system-scope forms (row-distributed launches: the other end of a hand-off may be another GPU; fine-grained memory)
+__device__ __forceinline__ void publish_f64_x4_sys(unsigned long long* g2, unsigned epoch, double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    pg_u32x4 q;
+    q.x = (unsigned)b, q.y = epoch, q.z = (unsigned)(b >> 32), q.w = epoch;
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(g2), "v"(q) : "memory");
+}
+__device__ __forceinline__ pg_v2u64 granule_load2_sys(const unsigned long long* p) {
+    pg_v2u64 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void granule_load6_sys(const unsigned long long* p, pg_v2u64& a, pg_v2u64& b, pg_v2u64& c) {
+    asm volatile("global_load_dwordx4 %0, %3, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off offset:16 sc0 sc1\n\t"
+                 "global_load_dwordx4 %2, %3, off offset:32 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void granule_load2x4_sys(const unsigned long long* p0, const unsigned long long* p1, const unsigned long long* p2,
+                                                    const unsigned long long* p3, pg_v2u64& a, pg_v2u64& b, pg_v2u64& c, pg_v2u64& d) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off sc0 sc1\n\tglobal_load_dwordx4 %3, %7, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+}
 __device__ __forceinline__ double wave_sum64(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -129,12 +165,14 @@ __device__ __forceinline__ double wave_sum64(double v) {
 //                 row, so that no partial sum can reach 2^62: the transposed sums carry an ABSOLUTE error below
 //                 (products) x 2^-56 x max_len x max|a| x max_block |p| -- finer than fp64's own rounding of the largest products.
 //                 The import / export lists are read from global memory (L2) instead of LDS: the table takes their room.
-template <int R, bool STREAM, bool SYM>
+// DIST = true   : row-distributed form, see PersistArgs.
+template <int R, bool STREAM, bool SYM, bool DIST = false>
 __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
     constexpr int T = kPersistT, W = T / 64, S = R * T, RI = R / 2;
     extern __shared__ double lds[];
     __shared__ double red[W][3];
     __shared__ double tot[3];
+    __shared__ double pub[3];
     __shared__ double pmax_w[W];
     __shared__ int32_t fail_flag;
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -211,6 +249,7 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
     __syncthreads();
     for (;;) {
         const unsigned epoch = a.epoch0 + (unsigned)it + 1u;
+        const long long tmo = (DIST && it == 0) ? (long long)a.timeout_first_ticks : (long long)a.timeout_ticks;
         if (a.debug_stall_it > 0 && it == a.debug_stall_it && g == a.G - 1) {   // (wave-uniform)
             status = 3;
             break;
@@ -259,7 +298,17 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
             for (int k = 0; k < 4; ++k) pe[k] = p_tab[code[k]];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (i0 + k * T < E) publish_f64_x4(a.pboard + 2 * (size_t)(a.exp_off[g] + i0 + k * T), epoch, pe[k]);
+                if (i0 + k * T < E) {
+                    if constexpr (DIST) publish_f64_x4_sys(a.pboard + 2 * (size_t)(a.exp_off[g] + i0 + k * T), epoch, pe[k]);
+                    else publish_f64_x4(a.pboard + 2 * (size_t)(a.exp_off[g] + i0 + k * T), epoch, pe[k]);
+                }
+        }
+        if constexpr (DIST) {   // entries other ranks import: pushed into their boards
+            const int re0 = a.rexp_off[g], RE = a.rexp_off[g + 1] - re0;
+            for (int i = tid; i < RE; i += T) {
+                const unsigned slot = a.rexp_slot[re0 + i];
+                publish_f64_x4_sys(a.peer_pboard[a.rexp_peer[re0 + i]] + 2 * (size_t)a.rexp_pos[re0 + i], epoch, p_tab[slot]);
+            }
         }
         // ---- y = (I + At_offdiag) p: the passes without imports first, the others once the neighbours' entries have arrived
         double yv[R];
@@ -376,7 +425,8 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
                     done[k] = h >= H;
                     gp[k] = a.pboard + 2 * (size_t)impl[done[k] ? 0 : h];
                 }
-                granule_load2x4(gp[0], gp[1], gp[2], gp[3], v[0], v[1], v[2], v[3]);
+                if constexpr (DIST) granule_load2x4_sys(gp[0], gp[1], gp[2], gp[3], v[0], v[1], v[2], v[3]);
+                else granule_load2x4(gp[0], gp[1], gp[2], gp[3], v[0], v[1], v[2], v[3]);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) done[k] = done[k] || granule_pair_ok(v[k], epoch);
                 long long t_wait = 0;
@@ -384,7 +434,7 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
                     if ((spins & 63u) == 63u) {   // bounded by time, checked now and then
                         const long long now = wall_clock64();
                         if (t_wait == 0) t_wait = now;
-                        else if (now - t_wait > (long long)a.timeout_ticks) {
+                        else if (now - t_wait > tmo) {
                             fail = true;
                             break;
                         }
@@ -392,7 +442,11 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
                     __builtin_amdgcn_s_sleep(2);
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        if (!done[k]) v[k] = granule_load2(gp[k]), done[k] = granule_pair_ok(v[k], epoch);
+                        if (!done[k]) {
+                            if constexpr (DIST) v[k] = granule_load2_sys(gp[k]);
+                            else v[k] = granule_load2(gp[k]);
+                            done[k] = granule_pair_ok(v[k], epoch);
+                        }
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -426,38 +480,54 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
         const double s2 = wave_sum64(rr_part);
         if (lane == 0) red[wave][0] = s0, red[wave][1] = s1, red[wave][2] = s2;
         __syncthreads();
-        unsigned long long* dslot = a.dboard + (size_t)(it & 1) * a.G * 6;
-        if (tid < 3) {
-            double v = 0;
+        const int G_all = DIST ? a.G_tot : a.G;
+        unsigned long long* dslot = a.dboard + (size_t)(it & 1) * G_all * 6;
+        if constexpr (!DIST) {
+            if (tid < 3) {
+                double v = 0;
 #pragma unroll
-            for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
-            publish_f64_x4(dslot + (size_t)g * 6 + 2 * tid, epoch, v);
+                for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
+                publish_f64_x4(dslot + (size_t)g * 6 + 2 * tid, epoch, v);
+            }
+        } else {   // the record goes into the dot board of EVERY rank (its own among them): thread (k, q) pushes value k to rank q
+            if (tid < 3) {
+                double v = 0;
+#pragma unroll
+                for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
+                pub[tid] = v;
+            }
+            __syncthreads();
+            if (tid < 3 * a.world) {
+                const int k = tid % 3, q = tid / 3;
+                publish_f64_x4_sys(a.peer_dboard[q] + (size_t)(it & 1) * G_all * 6 + (size_t)(a.g_base + g) * 6 + 2 * k, epoch, pub[k]);
+            }
         }
         {   // thread t collects workgroup t's three sums (a lane re-reads its record until all six tags match, then stops loading); every
             // workgroup adds the G records in the same order.  A two-level form (groups of 8 / 16 / 32 workgroups handled by one wavefront,
             // then the group sums) was measured and dropped: a granule hop costs ~4 us under this load, two of them 7.9 / 9.8 / 12.0 us
-            // against 4.6 us for the flat sweep on C2 (246 workgroups)
+            // against 4.6 us for the flat sweep on C2 (246 workgroups).  Row-distributed form: G_tot records, ceil(G_tot / 512) per thread.
             double v0 = 0, v1 = 0, v2 = 0;
             bool fail = false;
             // gather_waves: how many wavefronts poll (4: thread t takes workgroup t's record; 1: wavefront 0 takes them all, 4 per lane)
-            const int per_lane = a.gather_waves == 1 ? (a.G + 63) / 64 : 1;
-            if (a.gather_waves == 1 ? wave == 0 : wave * 64 < a.G) {   // wave-uniform
+            const int per_lane = DIST ? (G_all + T - 1) / T : (a.gather_waves == 1 ? (a.G + 63) / 64 : 1);
+            if (DIST ? wave * 64 < G_all : (a.gather_waves == 1 ? wave == 0 : wave * 64 < a.G)) {   // wave-uniform
                 for (int rsel = 0; rsel < per_lane; ++rsel) {
-                    const int w = a.gather_waves == 1 ? rsel * 64 + lane : tid;
-                    const unsigned long long* gp = dslot + (size_t)(w < a.G ? w : 0) * 6;
+                    const int w = DIST ? rsel * T + tid : (a.gather_waves == 1 ? rsel * 64 + lane : tid);
+                    const unsigned long long* gp = dslot + (size_t)(w < G_all ? w : 0) * 6;
                     pg_v2u64 q0 = {0, 0}, q1 = {0, 0}, q2 = {0, 0};
-                    bool done = w >= a.G;
+                    bool done = w >= G_all;
                     long long t_wait = 0;
                     for (unsigned spins = 0;; ++spins) {
                         if (!done) {
-                            granule_load6(gp, q0, q1, q2);
+                            if constexpr (DIST) granule_load6_sys(gp, q0, q1, q2);
+                            else granule_load6(gp, q0, q1, q2);
                             done = granule_pair_ok(q0, epoch) && granule_pair_ok(q1, epoch) && granule_pair_ok(q2, epoch);
                         }
                         if (__all(done)) break;
                         if ((spins & 63u) == 63u) {
                             const long long now = wall_clock64();
                             if (t_wait == 0) t_wait = now;
-                            else if (now - t_wait > (long long)a.timeout_ticks) {
+                            else if (now - t_wait > tmo) {
                                 fail = true;
                                 break;
                             }
@@ -466,7 +536,7 @@ __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
                         else if (a.poll_sleep == 2) __builtin_amdgcn_s_sleep(2);
                         else if (a.poll_sleep >= 3) __builtin_amdgcn_s_sleep(8);
                     }
-                    if (w < a.G) v0 += granule_pair_f64(q0), v1 += granule_pair_f64(q1), v2 += granule_pair_f64(q2);
+                    if (w < G_all) v0 += granule_pair_f64(q0), v1 += granule_pair_f64(q1), v2 += granule_pair_f64(q2);
                     if (fail) break;
                 }
             }
@@ -674,7 +744,7 @@ __global__ __launch_bounds__(kPersistT) void k_spmv_blocked(BlockedSpmvArgs a) {
 
 // ell_val[e] = scaled full-pattern value the entry maps to, 0 in padding
 // amax_bits != nullptr (zeroed by the caller): also max |value| as a bit pattern (non-negative doubles order like their bits)
-__global__ __launch_bounds__(256) void k_persist_fill(int64_t n, const int32_t* src, const double* scaled_full, double* out,
+static __global__ __launch_bounds__(256) void k_persist_fill(int64_t n, const int32_t* src, const double* scaled_full, double* out,
                                                       unsigned long long* amax_bits) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     double v = 0.0;

@@ -1,0 +1,349 @@
+// kernels_persist_bicg.h -- the whole Jacobi-BiCGStab solve of a non-symmetric system (advection) as ONE launch, on the layout and the
+// hand-off machinery of kernels_persist.h (plain storage): x, r, r0, p, v, t of a workgroup's rows live in registers, the matrix block is
+// resident in LDS or streams once per operator application, neighbours exchange entries through granule boards.  An iteration is TWO
+// operator applications and TWO all-gathers:
+//     p = r + beta (p - omega v)                       (registers)
+//     v = A p            gather 1: (r0.v | r.r of the previous iteration, summed explicitly)      -> alpha, stop test
+//     s = r - alpha v                                  (kept in r's registers)
+//     t = A s            gather 2: (t.s, t.t, r0.s, r0.t)                                         -> omega, rho' = r0.s - omega r0.t
+//     x += alpha p + omega s ; r = s - omega t
+// The multi-launch kernels (kernels_krylov.h k_bicg_*) sum r0.r explicitly after the update; here rho' comes from the two dots gathered
+// with omega -- the same number in exact arithmetic, one all-gather less -- and the explicit r.r rides in the next iteration's first
+// gather, so the stop test runs half an iteration late on the explicitly summed value (x is already final when it fires).
+// Epochs: application / gather k of iteration it carries tag epoch0 + 2 it + k (k = 1, 2); dot records are 4 doubles wide, double-buffered
+// by k.  DIST: the row-distributed multi-GPU form (PersistArgs).
+#ifndef FDAPDE_KERNELS_PERSIST_BICG_H
+#define FDAPDE_KERNELS_PERSIST_BICG_H
+
+#include "kernels_persist.h"
+
+namespace fdapde_hip {
+
+__device__ __forceinline__ void granule_load8(const unsigned long long* p, pg_v2u64& a, pg_v2u64& b, pg_v2u64& c, pg_v2u64& d) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void granule_load8_sys(const unsigned long long* p, pg_v2u64& a, pg_v2u64& b, pg_v2u64& c, pg_v2u64& d) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc0 sc1\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32 sc0 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p) : "memory");
+}
+
+// R rows per thread (2, 4, 8).  ctl / sc on return as the multi-launch loop leaves them: ctl[0] converged, [1] iterations, [2] breakdown,
+// sc[3] = final r.r; [3] hand-off timeout (then nothing else was written).
+template <int R, bool STREAM, bool DIST>
+__global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a) {
+    constexpr int T = kPersistT, W = T / 64, S = R * T, RI = R / 2;
+    extern __shared__ double lds[];
+    __shared__ double red[W][4];
+    __shared__ double tot[4];
+    __shared__ double pub[4];
+    __shared__ int32_t fail_flag;
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nsl = a.nsl;
+    const int H = a.imp_off[g + 1] - a.imp_off[g], E = a.exp_off[g + 1] - a.exp_off[g];
+    double* p_tab = lds;                                                      // [S + imp_cap]
+    double2* ev = reinterpret_cast<double2*>(p_tab + (S + a.imp_cap));        // [lds_cap / 2] entry pairs (resident form)
+    uint32_t* ec = reinterpret_cast<uint32_t*>(ev + a.lds_cap / 2);           // [lds_cap / 2] code pairs
+    int32_t* impl = reinterpret_cast<int32_t*>(ec + a.lds_cap / 2);           // [imp_cap]
+    uint16_t* expl = reinterpret_cast<uint16_t*>(impl + a.imp_cap);           // [E]
+    const int64_t e0 = a.ell_off[g];
+    const double2* gv = reinterpret_cast<const double2*>(a.ell_val + e0);
+    const uint32_t* gc = reinterpret_cast<const uint32_t*>(a.ell_code + e0);
+    const int64_t e_left = a.ell_off[a.G] + 256 - e0;
+    const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2*>(gv), 0, (int)min(e_left * 8, (int64_t)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(gc), 0, (int)min(e_left * 2, (int64_t)0x7fffffff), 0x00020000);
+    const int lane16 = lane * 16, lane4 = lane * 4;
+    for (int i = tid; i < H; i += T) impl[i] = a.imp_pos[a.imp_off[g] + i];
+    for (int i = tid; i < E; i += T) expl[i] = a.exp_slot[a.exp_off[g] + i];
+    if (tid == 0) fail_flag = 0;
+    const int32_t* slo = a.sl_off + (size_t)g * (nsl + 1);
+    if constexpr (!STREAM) {
+        const int n_pairs = slo[nsl] * 64;
+        for (int i = tid; i < n_pairs; i += T) ev[i] = gv[i], ec[i] = gc[i];
+    }
+    int o0[R], w[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        o0[j] = __builtin_amdgcn_readfirstlane(slo[j * W + wave]);
+        w[j] = __builtin_amdgcn_readfirstlane(slo[j * W + wave + 1]) - o0[j];
+    }
+    double xv[R], rv[R], qv[R], pv[R], vv[R], tv[R];   // x, r (s between the two applications), r0, p, v = A p, t = A s
+    int32_t dof[R];
+    double rr_part = 0;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int32_t d = a.slot_dof[(size_t)g * S + j * T + tid];
+        const bool on = d >= 0;
+        dof[j] = d;
+        rv[j] = on ? a.r_in[d] : 0.0;
+        xv[j] = on ? a.x[d] : 0.0;
+        qv[j] = rv[j], pv[j] = rv[j], vv[j] = 0.0, tv[j] = 0.0;
+        rr_part += rv[j] * rv[j];
+    }
+    const double bb = a.sc[0];
+    const int G_all = DIST ? a.G_tot : a.G;
+    int it = 0, status = 0;   // status: 1 converged, 2 breakdown, 3 hand-off timeout
+    double rr = 0, rho = 0, rho_old = 1.0, alpha = 1.0, omega = 1.0;
+    long long tmo = DIST ? (long long)a.timeout_first_ticks : (long long)a.timeout_ticks;
+    __syncthreads();
+
+    // ---- y = (I + At_offdiag) src: src of the own rows into the LDS table, exported entries onto the board(s), the passes without imports,
+    //      the imports, the other passes.  Returns false when a wait timed out (fail_flag raised; the caller leaves the loop).
+    auto apply = [&](const double (&src)[R], double (&y)[R], unsigned epoch) -> bool {
+#pragma unroll
+        for (int j = 0; j < R; ++j) p_tab[j * T + tid] = src[j];
+        __syncthreads();
+        for (int i0 = tid; i0 < E; i0 += 4 * T) {
+            unsigned code[4];
+            double pe[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) code[k] = expl[min(i0 + k * T, E - 1)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pe[k] = p_tab[code[k]];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i0 + k * T < E) {
+                    if constexpr (DIST) publish_f64_x4_sys(a.pboard + 2 * (size_t)(a.exp_off[g] + i0 + k * T), epoch, pe[k]);
+                    else publish_f64_x4(a.pboard + 2 * (size_t)(a.exp_off[g] + i0 + k * T), epoch, pe[k]);
+                }
+        }
+        if constexpr (DIST) {
+            const int re0 = a.rexp_off[g], RE = a.rexp_off[g + 1] - re0;
+            for (int i = tid; i < RE; i += T)
+                publish_f64_x4_sys(a.peer_pboard[a.rexp_peer[re0 + i]] + 2 * (size_t)a.rexp_pos[re0 + i], epoch, p_tab[a.rexp_slot[re0 + i]]);
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) y[j] = src[j];   // unit diagonal of the scaled system
+        auto product = [&](auto phase) {
+            constexpr int J0 = decltype(phase)::value ? RI : 0, J1 = decltype(phase)::value ? R : RI, NJ = J1 - J0;
+            int mw = 0;
+#pragma unroll
+            for (int j = J0; j < J1; ++j) mw = max(mw, w[j]);
+            for (int e = 0; e < mw; ++e) {   // a pass that has run out of entries is skipped (wave-uniform; P2 rows differ widely in length)
+                pg_u32x4 v[NJ];
+                uint32_t c[NJ];
+#pragma unroll
+                for (int j = J0; j < J1; ++j) {
+                    if (e < w[j]) {
+                        const int row = o0[j] + e;
+                        if constexpr (STREAM) {
+                            v[j - J0] = __builtin_amdgcn_raw_buffer_load_b128(rs_v, lane16, row * 1024, 0);
+                            c[j - J0] = __builtin_amdgcn_raw_buffer_load_b32(rs_c, lane4, row * 256, 0);
+                        } else
+                            v[j - J0] = reinterpret_cast<const pg_u32x4*>(ev)[row * 64 + lane], c[j - J0] = ec[row * 64 + lane];
+                    }
+                }
+#pragma unroll
+                for (int j = J0; j < J1; ++j) {
+                    if (e < w[j]) {
+                        const double vx = __hiloint2double((int)v[j - J0].y, (int)v[j - J0].x), vy = __hiloint2double((int)v[j - J0].w, (int)v[j - J0].z);
+                        y[j] += vx * p_tab[c[j - J0] & 0xffffu] + vy * p_tab[c[j - J0] >> 16];
+                    }
+                }
+            }
+        };
+        product(std::integral_constant<int, 0>{});
+        {
+            bool fail = false;
+            for (int hb = wave * 64; hb < H; hb += 4 * T) {   // wave-uniform trip count
+                const unsigned long long* gp[4];
+                pg_v2u64 v[4];
+                bool done[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int h = hb + k * T + lane;
+                    done[k] = h >= H;
+                    gp[k] = a.pboard + 2 * (size_t)impl[done[k] ? 0 : h];
+                }
+                if constexpr (DIST) granule_load2x4_sys(gp[0], gp[1], gp[2], gp[3], v[0], v[1], v[2], v[3]);
+                else granule_load2x4(gp[0], gp[1], gp[2], gp[3], v[0], v[1], v[2], v[3]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) done[k] = done[k] || granule_pair_ok(v[k], epoch);
+                long long t_wait = 0;
+                for (unsigned spins = 0; !__all(done[0] && done[1] && done[2] && done[3]); ++spins) {
+                    if ((spins & 63u) == 63u) {
+                        const long long now = wall_clock64();
+                        if (t_wait == 0) t_wait = now;
+                        else if (now - t_wait > tmo) {
+                            fail = true;
+                            break;
+                        }
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (!done[k]) {
+                            if constexpr (DIST) v[k] = granule_load2_sys(gp[k]);
+                            else v[k] = granule_load2(gp[k]);
+                            done[k] = granule_pair_ok(v[k], epoch);
+                        }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int h = hb + k * T + lane;
+                    if (h < H) p_tab[S + h] = granule_pair_f64(v[k]);
+                }
+                if (fail) break;
+            }
+            if (fail && lane == 0) fail_flag = 1;
+        }
+        __syncthreads();
+        if (fail_flag) return false;
+        product(std::integral_constant<int, 1>{});
+        return true;
+    };
+    // ---- all-gather of up to four sums over all workgroups (of all ranks): every workgroup adds the records in the same order
+    auto gather = [&](double s0, double s1, double s2, double s3, int phase, unsigned epoch) -> bool {
+        s0 = wave_sum64(s0), s1 = wave_sum64(s1), s2 = wave_sum64(s2), s3 = wave_sum64(s3);
+        __syncthreads();   // (the table reads of the application before, and the totals of the gather before, are done with)
+        if (lane == 0) red[wave][0] = s0, red[wave][1] = s1, red[wave][2] = s2, red[wave][3] = s3;
+        __syncthreads();
+        unsigned long long* dslot = a.dboard + (size_t)phase * G_all * 8;
+        if (tid < 4) {
+            double v = 0;
+#pragma unroll
+            for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
+            if constexpr (!DIST) publish_f64_x4(dslot + (size_t)g * 8 + 2 * tid, epoch, v);
+            else pub[tid] = v;
+        }
+        if constexpr (DIST) {
+            __syncthreads();
+            if (tid < 4 * a.world) {
+                const int k = tid & 3, q = tid >> 2;
+                publish_f64_x4_sys(a.peer_dboard[q] + (size_t)phase * G_all * 8 + (size_t)(a.g_base + g) * 8 + 2 * k, epoch, pub[k]);
+            }
+        }
+        double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+        bool fail = false;
+        const int per_lane = (G_all + T - 1) / T;
+        if (wave * 64 < G_all) {   // wave-uniform
+            for (int rsel = 0; rsel < per_lane; ++rsel) {
+                const int wq = rsel * T + tid;
+                const unsigned long long* gp = dslot + (size_t)(wq < G_all ? wq : 0) * 8;
+                pg_v2u64 q0 = {0, 0}, q1 = {0, 0}, q2 = {0, 0}, q3 = {0, 0};
+                bool done = wq >= G_all;
+                long long t_wait = 0;
+                for (unsigned spins = 0;; ++spins) {
+                    if (!done) {
+                        if constexpr (DIST) granule_load8_sys(gp, q0, q1, q2, q3);
+                        else granule_load8(gp, q0, q1, q2, q3);
+                        done = granule_pair_ok(q0, epoch) && granule_pair_ok(q1, epoch) && granule_pair_ok(q2, epoch) && granule_pair_ok(q3, epoch);
+                    }
+                    if (__all(done)) break;
+                    if ((spins & 63u) == 63u) {
+                        const long long now = wall_clock64();
+                        if (t_wait == 0) t_wait = now;
+                        else if (now - t_wait > tmo) {
+                            fail = true;
+                            break;
+                        }
+                    }
+                    if (a.poll_sleep == 1) __builtin_amdgcn_s_sleep(1);
+                    else if (a.poll_sleep == 2) __builtin_amdgcn_s_sleep(2);
+                    else if (a.poll_sleep >= 3) __builtin_amdgcn_s_sleep(8);
+                }
+                if (wq < G_all) v0 += granule_pair_f64(q0), v1 += granule_pair_f64(q1), v2 += granule_pair_f64(q2), v3 += granule_pair_f64(q3);
+                if (fail) break;
+            }
+        }
+        if (fail && lane == 0) fail_flag = 1;
+        v0 = wave_sum64(v0), v1 = wave_sum64(v1), v2 = wave_sum64(v2), v3 = wave_sum64(v3);
+        __syncthreads();
+        if (lane == 0) red[wave][0] = v0, red[wave][1] = v1, red[wave][2] = v2, red[wave][3] = v3;
+        __syncthreads();
+        if (tid < 4) {
+            double v = 0;
+#pragma unroll
+            for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
+            tot[tid] = v;
+        }
+        __syncthreads();
+        return fail_flag == 0;
+    };
+
+    for (;;) {
+        const unsigned ep1 = a.epoch0 + 2u * (unsigned)it + 1u, ep2 = ep1 + 1u;
+        if (a.debug_stall_it > 0 && it == a.debug_stall_it && g == a.G - 1) {   // (wave-uniform; tests)
+            status = 3;
+            break;
+        }
+        // ---- v = A p ; gather 1: r0.v and the explicit r.r of the residual this iteration starts from
+        if (!apply(pv, vv, ep1)) {
+            status = 3;
+            break;
+        }
+        double d0 = 0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) d0 += qv[j] * vv[j];
+        if (!gather(d0, rr_part, 0.0, 0.0, 0, ep1)) {
+            status = 3;
+            break;
+        }
+        const double r0v = tot[0];
+        rr = tot[1];
+        if (it == 0) rho = rr;   // r0 = r: rho = r0.r0
+        if (rr <= a.tol2 * bb) {
+            status = 1;
+            break;
+        }
+        if (it >= a.maxit) break;
+        if (rho == 0.0 || r0v == 0.0) {
+            status = 2;
+            break;
+        }
+        alpha = rho / r0v;
+#pragma unroll
+        for (int j = 0; j < R; ++j) rv[j] -= alpha * vv[j];   // s
+        // ---- t = A s ; gather 2: t.s, t.t, r0.s, r0.t
+        if (!apply(rv, tv, ep2)) {
+            status = 3;
+            break;
+        }
+        double e0s = 0, e1s = 0, e2s = 0, e3s = 0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) e0s += tv[j] * rv[j], e1s += tv[j] * tv[j], e2s += qv[j] * rv[j], e3s += qv[j] * tv[j];
+        if (!gather(e0s, e1s, e2s, e3s, 1, ep2)) {
+            status = 3;
+            break;
+        }
+        const double ts = tot[0], tt = tot[1], r0s = tot[2], r0t = tot[3];
+        omega = tt > 0.0 ? ts / tt : 0.0;
+        rr_part = 0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            xv[j] += alpha * pv[j] + omega * rv[j];
+            rv[j] -= omega * tv[j];
+            rr_part += rv[j] * rv[j];
+        }
+        ++it;
+        tmo = (long long)a.timeout_ticks;
+        if (omega == 0.0) {
+            status = 2;
+            break;
+        }
+        rho_old = rho, rho = r0s - omega * r0t;   // = r0.r of the new residual
+        const double beta = (rho / rho_old) * (alpha / omega);
+#pragma unroll
+        for (int j = 0; j < R; ++j) pv[j] = rv[j] + beta * (pv[j] - omega * vv[j]);
+    }
+    if (status == 2 && it > 0) {   // breakdown noticed after an update: the residual norm of the returned x, summed explicitly
+        // (every workgroup takes this branch together: the scalars are identical everywhere)
+        if (gather(0.0, rr_part, 0.0, 0.0, 0, a.epoch0 + 2u * (unsigned)it + 1u)) rr = tot[1];
+        else status = 3;
+    }
+    if (status != 3) {
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            if (dof[j] >= 0) a.x_out[dof[j]] = xv[j];
+    }
+    if (g == 0 && tid == 0 && status != 3) {
+        a.sc[3] = rr;
+        a.ctl[0] = status == 1 ? 1 : 0, a.ctl[1] = it, a.ctl[2] = status == 2 ? 1 : 0;
+    }
+    if (status == 3 && tid == 0) atomicExch(a.ctl + 3, 1);
+}
+
+}  // namespace fdapde_hip
+#endif

@@ -154,6 +154,52 @@ def local_problem(nodes, cells, boundary, part, rank, world, info=None):
     return sub
 
 
+# ---- row-distributed form (fdapde_rowdist_setup): every DOF is owned by one rank, whose sub-mesh holds every cell touching it ----------
+def node_owners(cells, part, n_nodes):
+    """owner of a node = one of the ranks whose cells touch it: the lowest for even node ids, the highest for odd ones, so that the nodes
+    on an interface are dealt to both sides (lowest-rank-wins would give rank 0 all of its interface nodes and the last rank none)"""
+    lo = np.full(n_nodes, np.iinfo(np.int32).max, dtype=np.int32)
+    hi = np.full(n_nodes, -1, dtype=np.int32)
+    p = np.repeat(part.astype(np.int32), cells.shape[1])
+    np.minimum.at(lo, cells.ravel(), p)
+    np.maximum.at(hi, cells.ravel(), p)
+    return np.where(np.arange(n_nodes) % 2 == 0, lo, hi).astype(np.int32)
+
+
+def rowdist_sub_mesh(nodes, cells, boundary, owner, rank):
+    """the cells touching a node `rank` owns (its cells of the partition that do + one layer of its neighbours' cells), nodes renumbered
+    locally (ascending global id)"""
+    my_cells = np.nonzero((owner[cells] == rank).any(axis=1))[0]
+    l2g = np.unique(cells[my_cells])
+    local_cells = np.searchsorted(l2g, cells[my_cells]).astype(np.int32)
+    return dict(nodes=np.ascontiguousarray(nodes[l2g]), cells=np.ascontiguousarray(local_cells), boundary=np.ascontiguousarray(boundary[l2g]),
+                l2g=l2g, cell_ids=my_cells)
+
+
+def rowdist_keys_owners(sub, table, owner, n_nodes_g, order):
+    """-> (key, owning rank) of every DOF of a rank's DOF table: a vertex DOF belongs to its node's owner, an edge DOF to the owner of its
+    end node with the LOWER global id (that rank holds every cell touching the node, hence every cell touching the edge)"""
+    keys = dof_keys(sub["l2g"][sub["cells"]], table, n_nodes_g, order)
+    is_node = keys < n_nodes_g
+    own = np.empty(keys.size, dtype=np.int32)
+    own[is_node] = owner[keys[is_node]]
+    own[~is_node] = owner[(keys[~is_node] - n_nodes_g) // n_nodes_g]
+    return keys, own
+
+
+def rank_problems_rowdist_p1(nodes, cells, boundary, world):
+    """the P1 row-distributed problem of every rank as plain arrays (bench.py's rank 0 ships them): sub-mesh with its ghost layer, global
+    node id and owner of every local node"""
+    part = partition_cells(nodes, cells, world)
+    owner = node_owners(cells, part, nodes.shape[0])
+    out = []
+    for r in range(world):
+        sub = rowdist_sub_mesh(nodes, cells, boundary, owner, r)
+        out.append(dict(nodes=sub["nodes"], cells=sub["cells"], boundary=sub["boundary"], l2g=sub["l2g"], key=sub["l2g"].astype(np.int64),
+                        owner=owner[sub["l2g"]].astype(np.int32), n_nodes_total=np.int64(nodes.shape[0]), n_cells_total=np.int64(cells.shape[0])))
+    return out
+
+
 def rank_problems_p1(nodes, cells, boundary, world):
     """the P1 problem of every rank of an element partition of the whole mesh, as plain arrays (what bench.py's rank 0 ships to the
     others): sub-mesh, interface maps of both exchange forms, ownership.  One pass over the whole mesh, on ONE rank."""
@@ -200,80 +246,135 @@ class _GlooGroup:
         self.dist.barrier()
 
 
-def bench_partitioned(capi, rdzv, rank, world, device, args, rtol, backend="rccl"):
-    """bench.py's N > 1 leg: the C3 mesh split over `world` GPUs (strong scaling).  Rank 0 generates and partitions the mesh and hands
-    every rank its own problem through the rendezvous directory -- no other rank materialises the whole mesh.  -> dict (rank 0) / None"""
+def _comm_setup(capi, ctx, rdzv, rank, world, backend, tag=""):
+    """joins the ranks' communicator: the library's own RCCL (id through the rendezvous directory) or, for plumbing checks, host-staged
+    transports over gloo.  -> (group for barriers / reductions, transport description)"""
+    if backend == "rccl":
+        if rank == 0:
+            rdzv.put(f"rccl_id{tag}", capi.Context.comm_unique_id())
+        ctx.comm_init(world, rank, rdzv.get(f"rccl_id{tag}"))
+        return _RcclGroup(ctx), f"RCCL ({capi.Context.comm_library()}), one rank per GPU; no other GPU library in the rank processes"
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_initialized():
+        dist.init_process_group("gloo")
+    ctx.comm_init_callback(world, rank, lambda arr: dist.all_reduce(torch.from_numpy(arr)))
+
+    def exchange(ranks, off, send, recv):
+        reqs, parts = [], []
+        for q, r in enumerate(ranks):
+            a, b = int(off[q]), int(off[q + 1])
+            t_out, t_in = torch.from_numpy(send[a:b].copy()), torch.empty(b - a, dtype=torch.float64)
+            reqs += [dist.isend(t_out, int(r)), dist.irecv(t_in, int(r))]
+            parts.append((a, b, t_in, t_out))
+        for rq in reqs:
+            rq.wait()
+        for a, b, t_in, _ in parts:
+            recv[a:b] = t_in.numpy()
+
+    ctx.comm_set_exchange_callback(exchange)
+    return _GlooGroup(), "host-staged gloo (plumbing check, ranks may share a device; never used for reported numbers)"
+
+
+def _ship(rdzv, rank, world, name, make):
+    """rank 0 builds every rank's problem (make() -> list of dicts of arrays) and hands them out through the rendezvous directory"""
     import io
+
+    if rank == 0:
+        probs = make()
+        for r in range(1, world):
+            buf = io.BytesIO()
+            np.savez(buf, **probs[r])
+            rdzv.put(f"{name}.{r}", buf.getvalue())
+        return probs[0]
+    return dict(np.load(io.BytesIO(rdzv.get(f"{name}.{rank}"))))
+
+
+def canary(capi, rdzv, rank, world, device, backend, share):
+    """a two-second row-distributed solve on a small mesh: run by bench.py in a job of its OWN rank processes before the real ranks touch
+    the GPUs, so that a fabric on which peer-mapped boards do not work (no hipIpc, stale reads over xGMI -> in-kernel timeouts, or a
+    fault that takes the process down) costs the bench its fast path, not its result.  Exit code 0 = every rank solved and agreed."""
+    from . import meshgen
+
+    lp = _ship(rdzv, rank, world, "canary", lambda: rank_problems_rowdist_p1(*meshgen.unit_cube(24), world))
+    u_exact, f = meshgen.manufactured(3)
+    ctx = capi.Context(device=device)
+    ctx.mesh_upload(lp["nodes"], lp["cells"], lp["boundary"])
+    n_loc = ctx.dofs_build(1)
+    grp, _ = _comm_setup(capi, ctx, rdzv, rank, world, backend, ".canary")
+    if share > 1:
+        ctx.tune("rowdist_share", share)
+    ctx.rowdist_setup(lp["key"], lp["owner"])
+    ctx.set_operator(-capi.laplacian())
+    ctx.set_forcing(f(ctx.quadrature_nodes()))
+    ctx.set_dirichlet(np.zeros(n_loc))
+    ctx.init()
+    ok = 1.0
+    try:
+        for _ in range(2):
+            info = ctx.solve(rtol=1e-10)
+            mine = lp["owner"] == rank
+            err = float(np.abs(ctx.solution()[mine] - u_exact(lp["nodes"])[mine]).max()) if mine.any() else 0.0
+            if not (info.converged == 1 and info.persistent == 1 and err < 6.0 * (1.0 / 24) ** 2 * 3.15**2):
+                ok = 0.0
+    except capi.FdapdeError as e:   # (collective by construction: every rank gets the same refusal)
+        print(f"canary rank {rank}: {e}", file=sys.stderr)
+        ok = 0.0
+    bad = grp.max([1.0 - ok])
+    ctx.close()
+    return 0 if bad[0] == 0.0 else 1
+
+
+def bench_partitioned(capi, rdzv, rank, world, device, args, rtol, backend="rccl", form="peers", share=1):
+    """bench.py's N > 1 leg: the C3 mesh split over `world` GPUs (strong scaling).  Rank 0 generates and partitions the mesh and hands
+    every rank its own problem through the rendezvous directory -- no other rank materialises the whole mesh.
+    form "rowdist": the row-distributed solve (fdapde_rowdist_setup: complete rows per rank, the whole CG as one persistent launch per
+    rank, launches exchanging through peer-mapped boards); "peers" / "dense": the element-partitioned solve with an RCCL exchange of the
+    interface contributions per operator application.  -> dict (rank 0) / None"""
     import time
 
     from . import meshgen
 
     t_part = time.perf_counter()
-    if rank == 0:
-        nodes, cells, bnd = meshgen.unit_cube(args.nx)
-        probs = rank_problems_p1(nodes, cells, bnd, world)
-        del nodes, cells, bnd
-        for r in range(1, world):
-            buf = io.BytesIO()
-            np.savez(buf, **probs[r])
-            rdzv.put(f"problem.{r}", buf.getvalue())
-        lp = probs[0]
-        del probs
+    if form == "rowdist":
+        lp = _ship(rdzv, rank, world, "problem", lambda: rank_problems_rowdist_p1(*meshgen.unit_cube(args.nx), world))
     else:
-        lp = dict(np.load(io.BytesIO(rdzv.get(f"problem.{rank}"))))
+        lp = _ship(rdzv, rank, world, "problem", lambda: rank_problems_p1(*meshgen.unit_cube(args.nx), world))
     t_part = time.perf_counter() - t_part
     u_exact, f = meshgen.manufactured(3)
     ctx = capi.Context(device=device)
     ctx.mesh_upload(lp["nodes"], lp["cells"], lp["boundary"])
     n_loc = ctx.dofs_build(1)
-    if backend == "rccl":   # RCCL communicator of the library; its 128-byte id travels through the rendezvous directory
-        if rank == 0:
-            rdzv.put("rccl_id", capi.Context.comm_unique_id())
-        ctx.comm_init(world, rank, rdzv.get("rccl_id"))
-        grp = _RcclGroup(ctx)
-        transport = f"RCCL ({capi.Context.comm_library()}), one rank per GPU; no other GPU library in the rank processes"
-    else:                   # plumbing checks only: host-staged transports over gloo (torch is imported AFTER the library)
-        import torch
-        import torch.distributed as dist
-
-        dist.init_process_group("gloo")
-        grp = _GlooGroup()
-        ctx.comm_init_callback(world, rank, lambda arr: dist.all_reduce(torch.from_numpy(arr)))
-
-        def exchange(ranks, off, send, recv):
-            reqs, parts = [], []
-            for q, r in enumerate(ranks):
-                a, b = int(off[q]), int(off[q + 1])
-                t_out, t_in = torch.from_numpy(send[a:b].copy()), torch.empty(b - a, dtype=torch.float64)
-                reqs += [dist.isend(t_out, int(r)), dist.irecv(t_in, int(r))]
-                parts.append((a, b, t_in, t_out))
-            for rq in reqs:
-                rq.wait()
-            for a, b, t_in, _ in parts:
-                recv[a:b] = t_in.numpy()
-
-        ctx.comm_set_exchange_callback(exchange)
-        transport = "host-staged gloo (plumbing check, ranks may share a device; never used for reported numbers)"
-    # neighbour-only exchange: per-peer packed segments (ncclSend / ncclRecv in one group), then the scalar all-reduce
-    exchange_form = os.environ.get("FDAPDE_BENCH_EXCHANGE", "peers")   # "dense": the interface all-reduce of fdapde_halo_setup
-    pr, po = lp["peer_rank"], lp["peer_off"]
-    if exchange_form == "peers":
-        ctx.halo_setup_peers(pr, po, lp["peer_dof"], lp["owned"])
+    grp, transport = _comm_setup(capi, ctx, rdzv, rank, world, backend)
+    if form == "rowdist":
+        if share > 1:
+            ctx.tune("rowdist_share", share)
+        ctx.rowdist_setup(lp["key"], lp["owner"])
+        mine = lp["owner"] == rank
+        msg = grp.max([float(lp["nodes"].shape[0] - int(mine.sum())), float(lp["cells"].shape[0])])
     else:
-        ctx.halo_setup(int(lp["n_if_global"]), lp["local_dof"], lp["if_index"], lp["owned"])
-    msg = grp.max([float(8 * int(po[-1])), float(pr.size)])   # bytes sent per exchange, peers
+        # neighbour-only exchange: per-peer packed segments (ncclSend / ncclRecv in one group), then the scalar all-reduce
+        pr, po = lp["peer_rank"], lp["peer_off"]
+        if form == "peers":
+            ctx.halo_setup_peers(pr, po, lp["peer_dof"], lp["owned"])
+        else:
+            ctx.halo_setup(int(lp["n_if_global"]), lp["local_dof"], lp["if_index"], lp["owned"])
+        mine = lp["owned"] != 0
+        msg = grp.max([float(8 * int(po[-1])), float(pr.size)])   # bytes sent per exchange, peers
     qn = ctx.quadrature_nodes()
     ctx.set_operator(-capi.laplacian())
     ctx.set_forcing(f(qn))
     ctx.set_dirichlet(np.zeros(n_loc))
     del qn
-    ctx.solver_prepare(True)   # set-up (untimed): solver layout of this rank's sub-mesh
+    if form != "rowdist":
+        ctx.solver_prepare(True)   # set-up (untimed): solver layout of this rank's sub-mesh
 
     def step(time_spmv=0):
         ctx.init()
         return ctx.solve(rtol=rtol, time_spmv=time_spmv)
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1 if form == "rowdist" else 0)):   # (row-distributed: the first solve builds the layout and maps the boards)
         step()
     grp.barrier()
     ctx.synchronize()
@@ -283,13 +384,13 @@ def bench_partitioned(capi, rdzv, rank, world, device, args, rtol, backend="rccl
     grp.barrier()
     elapsed = time.perf_counter() - t0
     u = ctx.solution()
-    err = float(np.abs(u - u_exact(lp["nodes"])).max())
+    err = float(np.abs(u - u_exact(lp["nodes"]))[mine].max()) if mine.any() else 0.0
     info = infos[-1]
     sizes = ctx.sizes()
     _, alg_bytes = ctx.bench_spmv(reps=1)
-    _, _, streamed = ctx.solver_layout(True)
+    streamed = 0.0 if form == "rowdist" else ctx.solver_layout(True)[2]
     red = grp.max([elapsed, err, np.mean([i.t_assemble_ms for i in infos]), np.mean([i.t_solve_ms for i in infos]), ctx.info().t_setup_ms,
-                   float(sizes["nnz"]), alg_bytes, streamed, np.mean([i.spmv_avg_ms for i in infos]), t_part])
+                   float(sizes["nnz"]), alg_bytes, streamed, np.mean([i.spmv_avg_ms for i in infos]), t_part, np.mean([i.launch_ms for i in infos])])
     if backend != "rccl":
         import torch.distributed as dist
 
@@ -298,9 +399,14 @@ def bench_partitioned(capi, rdzv, rank, world, device, args, rtol, backend="rccl
     ctx.close()
     if rank != 0:
         return None
-    for i in infos:   # the slowest rank's SpMV bounds the roofline figure
-        i.spmv_avg_ms = float(red[8])
-    if exchange_form == "dense":
+    for i in infos:   # the slowest rank bounds the figures
+        i.spmv_avg_ms, i.launch_ms = float(red[8]), float(red[10])
+    if form == "rowdist":
+        parallelism = (f"{world} GPUs, row-distributed: every rank owns the DOFs of its Morton chunk of the element partition and assembles their rows "
+                       f"completely (sub-mesh = its cells + one layer of its neighbours': <= {int(msg[1])} cells, <= {int(msg[0])} ghost DOFs per rank); the whole "
+                       "Jacobi-PCG is ONE persistent launch per rank, the launches of all ranks act as one grid: search-direction entries and dot records "
+                       "cross through peer-mapped boards (hipIpc over xGMI), no collective call inside the iteration")
+    elif form == "dense":
         parallelism = (f"{world} GPUs, element partition (Morton chunks), {int(lp['n_if_global'])} interface DOFs, single-reduction CG: ONE RCCL "
                        f"all-reduce per iteration (interface entries of A r + r.Ar + r.r: {8 * (int(lp['n_if_global']) + 2)} bytes)")
     else:
@@ -309,4 +415,4 @@ def bench_partitioned(capi, rdzv, rank, world, device, args, rtol, backend="rccl
                        f"<= {int(msg[0])} bytes sent per rank -- and one 16-byte all-reduce of (r.Ar, r.r)")
     return dict(elapsed=float(red[0]), err=float(red[1]), t_asm=float(red[2]), t_sol=float(red[3]), setup_ms=float(red[4]), info=info, infos=infos,
                 alg_bytes=float(red[6]), streamed_bytes=float(red[7]), total_dofs=int(lp["n_nodes_total"]), n_cells_total=int(lp["n_cells_total"]),
-                parallelism=parallelism, transport=transport, t_partition=float(red[9]))
+                parallelism=parallelism, transport=transport, t_partition=float(red[9]), form=form)

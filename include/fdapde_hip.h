@@ -263,6 +263,22 @@ int fdapde_comm_set_exchange_callback(fdapde_ctx *ctx, fdapde_exchange_fn fn, vo
 int fdapde_halo_setup_peers(fdapde_ctx *ctx, int32_t n_peers, const int32_t *peer_rank, const int64_t *peer_off,
                             const int32_t *peer_dof, const uint8_t *owned);
 
+/* Row-distributed form -- the multi-GPU solve that keeps the single-GPU solver's structure: every DOF of the whole mesh is OWNED by
+ * exactly one rank, and a rank's sub-mesh holds every cell that touches one of its DOFs (its cells of the element partition + one layer
+ * of its neighbours' cells), so fdapde_init completes the rows of the owned DOFs with no exchange at all (the halo contributions are
+ * summed by the assembly itself).  fdapde_solve then runs the WHOLE Jacobi-PCG as one persistent launch per rank; the workgroups of all
+ * ranks act as one grid: entries of the search direction another rank needs are pushed into that rank's board through peer-mapped
+ * pointers (hipIpc over xGMI), the dot records of all workgroups are all-gathered the same way, every workgroup on every GPU sums them
+ * in the same order (bitwise identical scalars, identical stop decision) -- no RCCL call inside the iteration.  RCCL (or the host-staged
+ * transport) carries set-up data only: the layout agreement, the board handles, and per solve the Jacobi scale of the ghost columns
+ * and three scalars.
+ *   dof_key[d]   : global identity of local DOF d (reference numbering of this rank's space): node id, or n + lo * n + hi for an edge DOF
+ *   dof_owner[d] : the rank that owns it; every cell touching a DOF must be in its owner's sub-mesh.  Boundary flags must be the whole
+ *                  mesh's (fdapde_dofs_set_boundary where the sub-mesh's own rule would differ).
+ * Symmetric positive operators (CG), cold starts, at most 8 x 512 rows per workgroup; anything else returns FDAPDE_EUNSUPPORTED and the
+ * caller uses the element-partitioned exchange above.  Solution entries of DOFs owned by other ranks are not computed (0 + Dirichlet lift). */
+int fdapde_rowdist_setup(fdapde_ctx *ctx, const int64_t *dof_key, const int32_t *dof_owner);
+
 /* tuning / diagnostic knobs (A/B measurements inside one process; defaults are the measured best):
  *   SpMV launch   "spmv_variant" (2 pair form, 0 team form, 1 stream form), "spmv_team", "spmv_unroll", "spmv_bpx" (workgroups
  *                 per XCD band), "spmv_ablate" (diagnostic instantiations), "spmv_c16" (16-bit column codes), "spmv_deep"

@@ -41,6 +41,8 @@ def main():
     mkop = (lambda: -capi.laplacian() + capi.advection(bvec) + capi.reaction(1.0)) if case.startswith("adr") else \
            (lambda: capi.dt() - capi.laplacian()) if case == "parab" else (lambda: -capi.laplacian())
     part = fdist.partition_cells(nodes, cells, world)
+    if exchange_mode == "rowdist":
+        return rowdist_case(rank, world, case, order, nodes, cells, bnd, part, capi, fdist, dist, torch, u_exact, f, g_fn)
     info_if = fdist.interface_info(cells, part, n_g, world, order, bnd)
     sub = fdist.sub_mesh(nodes, cells, bnd, part, rank)
 
@@ -138,6 +140,78 @@ def main():
         msg = f"iters {info.iters} (single domain {rinfo.iters})"
     dist.barrier()   # nobody tears its communicator down while a peer is still inside a collective
     print(f"rank {rank}: ok  case {case}  local dofs {n_loc}  interface {maps['local_dof'].size}/{maps['n_if_global']}  {msg}  err {err:.2e}")
+    dist.destroy_process_group()
+
+
+def rowdist_case(rank, world, case, order, nodes, cells, bnd, part, capi, fdist, dist, torch, u_exact, f, g_fn):
+    """row-distributed form (fdapde_rowdist_setup): one persistent launch per rank, all ranks' launches acting as one grid through
+    peer-mapped boards -- here all on GPU 0, each rank with an equal share of the CUs, boards mapped across the processes by hipIpc"""
+    n_g = nodes.shape[0]
+    owner = fdist.node_owners(cells, part, n_g)
+    sub = fdist.rowdist_sub_mesh(nodes, cells, bnd, owner, rank)
+    ctx = capi.Context(device=0)
+    ctx.mesh_upload(sub["nodes"], sub["cells"], sub["boundary"])
+    n_loc = ctx.dofs_build(order)
+    table, _, lcoords = ctx.dofs_get()
+    keys, own = fdist.rowdist_keys_owners(sub, table, owner, n_g, order)
+    if order == 2:   # whole-mesh boundary flags (a 2-D edge on the rim of the sub-mesh is seen by one LOCAL cell only)
+        allk = np.unique(fdist._cell_keys(cells, n_g, 2))
+        flags = fdist.boundary_flags(cells, bnd, allk, 2)
+        ctx.dofs_set_boundary(flags[np.searchsorted(allk, keys)])
+
+    def allreduce(arr):
+        dist.all_reduce(torch.from_numpy(arr))
+
+    def exchange(ranks, off, send, recv):
+        reqs, parts = [], []
+        for q, r in enumerate(ranks):
+            a, b = int(off[q]), int(off[q + 1])
+            t_out, t_in = torch.from_numpy(send[a:b].copy()), torch.empty(b - a, dtype=torch.float64)
+            reqs += [dist.isend(t_out, int(r)), dist.irecv(t_in, int(r))]
+            parts.append((a, b, t_in, t_out))
+        for rq in reqs:
+            rq.wait()
+        for a, b, t_in, _ in parts:
+            recv[a:b] = t_in.numpy()
+
+    ctx.comm_init_callback(world, rank, allreduce)
+    ctx.comm_set_exchange_callback(exchange)
+    ctx.tune("rowdist_share", world)
+    ctx.rowdist_setup(keys, own)
+    ref = capi.Context(device=0)
+    ref.mesh_upload(nodes, cells, bnd)
+    ref.dofs_build(order)
+    gtable, gbnd, gcoords = ref.dofs_get()
+    gk = fdist.dof_keys(cells, gtable, n_g, order)
+    l2g = np.argsort(gk)[np.searchsorted(np.sort(gk), keys)]
+    mine = own == rank
+    res = []
+    N = nodes.shape[1]
+    adr = case.startswith("adr")
+    for c_, co in ((ctx, lcoords), (ref, gcoords)):
+        c_.set_operator(-capi.laplacian() + capi.reaction(0.5) + (capi.advection([1.0, 0.5, 0.25][:N]) if adr else capi.reaction(0.0)))
+        c_.set_forcing(f(c_.quadrature_nodes()))
+        c_.set_dirichlet(g_fn(co))
+        c_.init()
+        res.append((c_.solve(rtol=1e-11), c_.solution()))
+    (info, u), (rinfo, uref) = res
+    assert info.converged == 1 and info.persistent == 1, (info.converged, info.persistent)
+    assert info.method_used == (capi.SOLVER_BICGSTAB if adr else capi.SOLVER_CG_FUSED)
+    err2 = np.array([np.sum((u[mine] - uref[l2g][mine]) ** 2), float(mine.sum())])
+    allreduce(err2)
+    err = float(np.sqrt(err2[0])) / np.linalg.norm(uref)
+    assert int(err2[1]) == gk.size, "every DOF of the whole mesh is owned exactly once"
+    assert err < (1e-8 if adr else 1e-9), err
+    if adr:
+        assert info.iters <= 1.3 * rinfo.iters + 5, (info.iters, rinfo.iters)
+    else:
+        assert abs(info.iters - rinfo.iters) <= max(1, rinfo.iters // 100), (info.iters, rinfo.iters)
+    # second solve on the same context: epochs advance, boards are not cleared; identical bits
+    info2 = ctx.solve(rtol=1e-11)
+    assert info2.iters == info.iters and np.array_equal(ctx.solution()[mine], u[mine])
+    dist.barrier()
+    print(f"rank {rank}: ok  case {case} rowdist  local dofs {n_loc} (owned {int(mine.sum())})  iters {info.iters} (single domain {rinfo.iters})  "
+          f"err {err:.2e}  launch {info.launch_ms:.3f} ms")
     dist.destroy_process_group()
 
 

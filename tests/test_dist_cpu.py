@@ -91,3 +91,39 @@ def test_file_rendezvous_and_self_launch_failure(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--nx", "4"], stdout=subprocess.PIPE,
                          stderr=subprocess.PIPE, text=True, env=env, timeout=300, cwd=ROOT)
     assert out.returncode != 0 and "HIP device" in out.stderr
+
+
+def test_row_distributed_partition_covers_every_row_completely():
+    """fdapde_rowdist_setup's contract, on the host side (dist.node_owners / rowdist_sub_mesh / rowdist_keys_owners): every DOF has exactly
+    one owner; the owner's sub-mesh holds EVERY cell touching the DOF (vertex and edge DOFs), so its assembly completes the DOF's row"""
+    import numpy as np
+
+    from fdapde_loader import load_package
+    from oracle import oracle as o
+
+    load_package()
+    from fdapde_core_amd import dist as fdist
+    from fdapde_core_amd import meshgen
+
+    for dim, nx in ((2, 9), (3, 5)):
+        nodes, cells, bnd = meshgen.unit_square(nx) if dim == 2 else meshgen.unit_cube(nx)
+        n = nodes.shape[0]
+        all_keys = fdist._cell_keys(cells, n, 2)                     # n_cells x n_basis: the P2 DOFs of every cell by global key
+        for world in (2, 3):
+            part = fdist.partition_cells(nodes, cells, world)
+            owner = fdist.node_owners(cells, part, n)
+            seen = {}
+            for r in range(world):
+                sub = fdist.rowdist_sub_mesh(nodes, cells, bnd, owner, r)
+                m = o.Mesh(sub["nodes"], sub["cells"], sub["boundary"])
+                table, _, nd, _ = o.enumerate_dofs(m, 2)
+                keys, own = fdist.rowdist_keys_owners(sub, table, owner, n, 2)
+                assert keys.size == nd and np.unique(keys).size == nd
+                in_sub = np.zeros(cells.shape[0], dtype=bool)
+                in_sub[sub["cell_ids"]] = True
+                for k in keys[own == r]:
+                    assert k not in seen
+                    seen[k] = r
+                    touching = (all_keys == k).any(axis=1)
+                    assert in_sub[touching].all(), "a cell touching an owned DOF is missing from its owner's sub-mesh"
+            assert len(seen) == np.unique(all_keys).size

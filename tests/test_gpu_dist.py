@@ -76,11 +76,21 @@ def test_partitioned_solve_over_real_rccl(world, nx, case):
     _run_ranks(world, nx, case, "rccl")
 
 
+@pytest.mark.parametrize("world,nx,case", [(2, 16, "p1"), (3, 14, "p1"), (4, 20, "p1"), (2, 40, "sq2"), (2, 8, "p2"), (4, 36, "p1"),
+                                           (2, 16, "adr1"), (3, 8, "adr2")])
+def test_row_distributed_persistent_launches_share_one_gpu(world, nx, case):
+    """fdapde_rowdist_setup: every rank assembles the complete rows of the DOFs it owns (ghost layer of cells) and the whole CG runs as ONE
+    launch per rank; the launches exchange search-direction entries and dot records through each other's boards (hipIpc-mapped across the
+    processes), no collective inside the iteration.  Against the single-domain solve: same iteration count, solution <= 1e-9, bitwise
+    repeatable.  All ranks on GPU 0 with an equal share of its CUs each."""
+    _run_ranks(world, nx, case, "shared", "rowdist")
+
+
 def test_bench_multi_gpu_leg_plumbing_on_one_gpu():
     """bench.py --gpus 2 under torch.distributed.run with FDAPDE_BENCH_BACKEND=gloo: both ranks share GPU 0 and the exchange is
     host-staged, everything else -- partition, neighbour lists, the device-side pack / sum kernels, the JSON line -- is what the
     driver's real launch runs"""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FDAPDE_BENCH_BACKEND="gloo")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FDAPDE_BENCH_BACKEND="gloo", FDAPDE_BENCH_EXCHANGE="peers")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--nx", "24",
            "--no-cpu-baseline", "--no-extra"]
@@ -107,6 +117,8 @@ def test_bench_starts_its_own_ranks_without_a_launcher(gpus):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == gpus and rec["scaling"] == "strong" and rec["value"] > 0 and rec["config"]["relres"] <= 1e-10
     assert rec["config"]["max_abs_error_vs_analytic"] < 6.0 * (1.0 / 20) ** 2 * 3.15**2
+    # the canary job found the row-distributed launches working between the ranks' devices (here: one shared device): that form ran
+    assert rec["config"]["exchange_form"] == "rowdist" and rec["config"]["persistent_launch"] == 1
     assert all(v is None or v <= 1.0 for k, v in rec["roofline"].items() if k in ("frac", "traffic_frac"))
 
 

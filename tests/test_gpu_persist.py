@@ -293,6 +293,56 @@ def test_blocked_ell_spmv_under_every_krylov_method(env, nx):
     c.close()
 
 
+@pytest.mark.parametrize("dim,nx,order", [
+    (2, 20, 1),     # one workgroup
+    (2, 120, 1),    # several workgroups, blocks resident
+    (2, 60, 2),     # P2 rows
+    (3, 30, 1),     # 3-D rows, import lists
+    (3, 12, 2),     # 3-D P2: rows of 10 ... 60+ entries
+    (3, 80, 1),     # 531 441 DOFs: one workgroup per CU, blocks stream
+    (2, 1000, 1),   # 1 002 001 DOFs: 8 rows per thread (the most the six register vectors leave room for)
+])
+def test_single_launch_bicgstab_matches_multi_launch(env, dim, nx, order):
+    """non-symmetric operator (advection): the whole Jacobi-BiCGStab as ONE launch (kernels_persist_bicg.h) against the multi-launch
+    kernels: same recurrence up to the summation order of the dot products and rho' = r0.s - omega r0.t instead of the explicit r0.r --
+    BiCGStab's iteration count moves with rounding, the solutions agree to the solver tolerance"""
+    capi, meshgen = env
+    nodes, cells, bnd = meshgen.unit_square(nx) if dim == 2 else meshgen.unit_cube(nx)
+    u_exact, f = meshgen.manufactured(dim)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(order)
+    _, _, coords = c.dofs_get()
+    bvec = [1.0, 0.5, 0.25][:dim]
+    c.set_operator(-capi.laplacian() + capi.advection(bvec) + capi.reaction(1.0))
+    c.set_forcing(f(c.quadrature_nodes()))
+    c.set_dirichlet(0.25 * coords[:, 0])
+    c.init()
+    c.tune("persist_bicg", 0)
+    i0 = c.solve(rtol=1e-11)
+    u0 = c.solution()
+    assert i0.persistent == 0 and i0.converged == 1 and i0.method_used == capi.SOLVER_BICGSTAB
+    c.tune("persist_bicg", 1)
+    i1 = c.solve(rtol=1e-11)
+    u1 = c.solution()
+    assert i1.persistent == 1, "the system qualifies: the single-launch BiCGStab must have run"
+    assert i1.converged == 1 and i1.method_used == capi.SOLVER_BICGSTAB and i1.relres <= 1e-11
+    assert i1.iters <= 1.3 * i0.iters + 5, (i1.iters, i0.iters)
+    assert np.linalg.norm(u1 - u0) <= 1e-8 * np.linalg.norm(u0)
+    i2 = c.solve(rtol=1e-11)   # deterministic reductions: identical bits from launch to launch
+    assert i2.iters == i1.iters and np.array_equal(c.solution(), u1)
+    i3 = c.solve(rtol=1e-11, maxit=4, raise_on_noconv=False)
+    assert i3.persistent == 1 and i3.converged == 0 and i3.iters == 4
+    # a stalled peer: the launch gives up, the multi-launch BiCGStab takes over from the same state
+    if c.solver_layout_kind(True)["workgroups"] > 1:
+        c.tune("persist_timeout_us", 2000)
+        c.tune("persist_debug_stall", 2)
+        i4 = c.solve(rtol=1e-11)
+        assert i4.persistent == 0 and i4.converged == 1
+        assert np.linalg.norm(c.solution() - u0) <= 1e-8 * np.linalg.norm(u0)
+    c.close()
+
+
 def test_graph_replay_is_rebuilt_when_the_blocked_layout_changes(env):
     """use_graph = 1 on a system that takes the blocked-ELL SpMV (2-D P2; the 3-D P2 "mass matrix" of the reference's 5-point rule with its
     negative weight is indefinite, no CG applies to it): a solve with Dirichlet data captures the fused-CG chunk on

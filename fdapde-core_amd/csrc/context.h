@@ -199,6 +199,7 @@ struct fdapde_ctx {
     DBuf<double> fq_bc;       // column 0 of the forcing samples in BLOCK-CELL order (a cell's nq samples repeated in every assembly block that
                               // visits it): the row-owner sweep reads them where it reads the block's cells; built by fdapde_set_forcing
     bool fq_bc_ready = false;
+    int asm_fuse_mass = 1;    // knob: fdapde_init accumulates the mass matrix in the operator's sweep where both accumulator ranges fit the LDS
     int asm_fq_bc = 1;        // knob: keep the block-cell ordered copy (1) or let the sweep gather from the cell-ordered samples (0)
     int asm_fq_block = 0;     // tuning knob: 1 = fdapde_init first reduces the forcing samples to one load coefficient per visit slot (k_visit_load_coeffs);
                               // measured on C3 with that kernel inside init's timed region: init 1.49-1.53 ms against 1.23-1.26 ms for the sweep

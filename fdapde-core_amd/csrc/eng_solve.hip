@@ -1,0 +1,1207 @@
+// eng_solve.hip -- the multi-launch solve driver: SpMV dispatch, solver layouts (compact CSR pattern, blocked ELL), Jacobi scaling and
+// Dirichlet reduction (solve_prepare), the Krylov loops (solve_run: fused-update / single-reduction / textbook CG, BiCGStab; hand-over to
+// the single-launch solver of persist_engine.hip), elliptic / parabolic / factor-once entry points, result getters, SpMV benchmarks.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include <dlfcn.h>
+#include <hip/hip_ext.h>
+#include <rccl/rccl.h>
+
+#include "context.h"
+#include "engine.h"
+#include "kernels.h"
+
+namespace fdapde_engine {
+
+// the captured CG chunk bakes pointers and sizes in: drop it whenever a layout, buffer or knob may have changed
+void drop_graph(fdapde_ctx* c) {
+    if (c->cg_graph_exec) (void)hipGraphExecDestroy(c->cg_graph_exec);
+    c->cg_graph_exec = nullptr;
+}
+
+// e0 / e1 (optional): HIP events attached to the dispatch itself (hipExtLaunchKernelGGL), i.e. the kernel's own begin / end
+// timestamps on the stream it runs on -- the same interval rocprofv3 --kernel-trace reports, with no extra marker packet
+// between the neighbouring kernels.
+void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, const double* w, double* partial,
+                 const int32_t* stop, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, int dot2_ww = 0,
+                 const uint8_t* owned = nullptr) {
+    if (vals == c->sval.p && c->bk_cur >= 0 && owned == nullptr) {   // the solver's scaled matrix in blocked-ELL form (k_spmv_blocked)
+        const fdapde_ctx::Blocked& bk = c->bk[c->bk_cur];
+        BlockedSpmvArgs a{};
+        a.G = bk.meta.G, a.nsl = bk.meta.nsl, a.imp_cap = bk.imp_cap, a.dot2_ww = dot2_ww;
+        a.slot_dof = bk.slot_dof.p, a.ell_off = bk.ell_off.p, a.sl_off = bk.sl_off.p, a.ell_code = bk.ell_code.p, a.ell_val = bk.ell_val.p;
+        a.imp_off = bk.imp_off.p, a.imp_dof = bk.imp_dof.p, a.drop_dof = bk.drop_dof.p, a.n_drop = (int32_t)bk.meta.n_drop, a.x = x, a.y = y, a.w = partial ? (w ? w : x) : nullptr, a.partial = partial, a.stop = stop;
+#define BLOCKED_GO(R_)                                                                                                          \
+    do {                                                                                                                        \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmv_blocked<R_>), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                  (int)bk.lds_bytes);                                                                           \
+        if (e0 || e1) hipExtLaunchKernelGGL((k_spmv_blocked<R_>), dim3(a.G), dim3(kPersistT), bk.lds_bytes, c->stream, e0, e1, 0, a); \
+        else hipLaunchKernelGGL((k_spmv_blocked<R_>), dim3(a.G), dim3(kPersistT), bk.lds_bytes, c->stream, a);                  \
+    } while (0)
+        switch (bk.meta.R) {
+        case 2: BLOCKED_GO(2); break;
+        case 4: BLOCKED_GO(4); break;
+        case 8: BLOCKED_GO(8); break;
+        default: BLOCKED_GO(16); break;
+        }
+#undef BLOCKED_GO
+        return;
+    }
+    SpmvArgs s{};
+    s.rowptr = c->rowptr.p, s.colidx = c->colidx.p, s.vals = vals, s.x = x, s.y = y;
+    s.rb_row = c->rb_row.p, s.n_rb = c->n_rb, s.rb_per_band = c->rb_per_band, s.nnz = (int32_t)c->hs.nnz;
+    s.w = w, s.partial = partial, s.stop = stop, s.dot2_ww = dot2_ww, s.owned = owned, s.unit_diag = 0;
+    s.n_cols = (int32_t)c->hs.n_dofs;
+    // value-stream policy by size: x and y slices of a row band (16 bytes per row, 8 bands) against the 4 MB L2 of an XCD
+    const bool ntv = c->spmv_ntv < 0 ? c->hs.n_dofs > kNtValsRows : c->spmv_ntv != 0;
+    int64_t n = c->hs.n_dofs;   // rows of the CSR arrays the kernel walks (virtual rows for a segmented pattern)
+    bool vrows = false;
+    if (vals == c->sval.p && c->sp_cur >= 0) {   // the solver's scaled matrix lives in the compact pattern
+        s.rowptr = c->sp_rowptr[c->sp_cur].p, s.colidx = c->sp_colidx[c->sp_cur].p, s.nnz = (int32_t)c->sp_nnz[c->sp_cur];
+        if (c->spmv_c16) s.col16 = c->sp_col16[c->sp_cur].p, s.tbase = c->sp_tbase[c->sp_cur].p;
+        if (c->sp_nv[c->sp_cur] > 0) {   // segmented: only the VROWS instantiations understand it (always with column codes)
+            vrows = true, n = c->sp_nv[c->sp_cur], s.vrow = c->sp_vrow[c->sp_cur].p;
+            s.col16 = c->sp_col16[c->sp_cur].p, s.tbase = c->sp_tbase[c->sp_cur].p;
+        }
+        s.unit_diag = 1;
+        // multi-GPU: the local diagonals s_i^2 (A_p)_ii of an interface DOF sum to 1 over the ranks sharing it; the implicit
+        // unit diagonal is therefore contributed by the DOF's owner only (any split of the entries among ranks is valid)
+        if ((c->comm != nullptr || c->ar_fn != nullptr) && c->halo_ready) s.owned = c->owned.p;
+    }
+    // eight row bands (one per XCD); band starts on a multiple of 32 rows so that a wavefront tile lies in one code group
+    const int64_t rpb = (((n + 7) / 8) + 31) & ~int64_t(31);
+    const dim3 grid(c->spmv_grid), block(256);
+    // dispatch-attached events only where a launch is timed; the plain launch can be captured into a hipGraph
+#define SPMV_GO(...)                                                                                 \
+    do {                                                                                             \
+        if (e0 || e1) hipExtLaunchKernelGGL((__VA_ARGS__), grid, block, 0, c->stream, e0, e1, 0, s, n, rpb); \
+        else hipLaunchKernelGGL((__VA_ARGS__), grid, block, 0, c->stream, s, n, rpb);                \
+    } while (0)
+    if (c->spmv_variant == 1) {
+        if (e0 || e1) hipExtLaunchKernelGGL(k_spmv, grid, block, 0, c->stream, e0, e1, 0, s);
+        else hipLaunchKernelGGL(k_spmv, grid, block, 0, c->stream, s);
+        return;
+    }
+    if (c->spmv_variant == 2) {   // two entries per lane: team = lanes per row, covering 2 * team entries per pass
+        // production forms: 16-byte aligned entry pairs (2048), + 16-bit column codes when the pattern has them (4096),
+        // + unconditional ownership loads when the implicit diagonal is owner-masked (multi-GPU, 8192)
+        const bool c16 = s.col16 != nullptr, dist = s.unit_diag && s.owned != nullptr;
+        const bool wx = s.w == nullptr || s.w == s.x;   // dot operand == x (CG: p.Ap): one row load serves both (16384)
+#define SPMV_PROD_FEW(T_, U_)                                                    \
+    do {                                                                         \
+        if (c16 && dist) SPMV_GO(k_spmv_team2<T_, U_, 2048 | 4096 | 8192>);      \
+        else if (c16) SPMV_GO(k_spmv_team2<T_, U_, 2048 | 4096>);                \
+        else if (dist) SPMV_GO(k_spmv_team2<T_, U_, 2048 | 8192>);               \
+        else SPMV_GO(k_spmv_team2<T_, U_, 2048>);                                \
+    } while (0)
+#define SPMV_PROD(T_, U_)                                                                    \
+    do {                                                                                     \
+        if (!wx) SPMV_PROD_FEW(T_, U_);                                                      \
+        else if (c16 && dist) SPMV_GO(k_spmv_team2<T_, U_, 2048 | 4096 | 8192 | 16384>);     \
+        else if (c16) SPMV_GO(k_spmv_team2<T_, U_, 2048 | 4096 | 16384>);                    \
+        else if (dist) SPMV_GO(k_spmv_team2<T_, U_, 2048 | 8192 | 16384>);                   \
+        else SPMV_GO(k_spmv_team2<T_, U_, 2048 | 16384>);                                    \
+    } while (0)
+        if (vrows) {   // built for this team size (build_solver_pattern); T = 8 or 16
+#define SPMV_VROWS(T_)                                                                                  \
+    do {                                                                                                \
+        if (dist && wx) SPMV_GO(k_spmv_team2<T_, 4, 2048 | 4096 | 131072 | 8192 | 16384>);              \
+        else if (dist) SPMV_GO(k_spmv_team2<T_, 4, 2048 | 4096 | 131072 | 8192>);                       \
+        else if (wx) SPMV_GO(k_spmv_team2<T_, 4, 2048 | 4096 | 131072 | 16384>);                        \
+        else SPMV_GO(k_spmv_team2<T_, 4, 2048 | 4096 | 131072>);                                        \
+    } while (0)
+            if (c->sp_team == 8) SPMV_VROWS(8);
+            else SPMV_VROWS(16);
+#undef SPMV_VROWS
+            return;
+        }
+        switch (c->spmv_team) {
+        case 2: SPMV_PROD_FEW(2, 1); break;
+        case 4: SPMV_PROD(4, 2); break;
+        case 8:
+            // the diagnostic forms >= 100 exist for the compact coded matrix only: any other product takes the production path
+            switch ((c->spmv_ablate >= 100 && !c16) ? 0 : c->spmv_ablate) {
+            case 1: SPMV_GO(k_spmv_team2<8, 4, 1>); break;
+            case 2: SPMV_GO(k_spmv_team2<8, 4, 2>); break;
+            case 4: SPMV_GO(k_spmv_team2<8, 4, 4>); break;
+            case 5: SPMV_GO(k_spmv_team2<8, 4, 5>); break;
+            case 8: SPMV_GO(k_spmv_team2<8, 4, 8>); break;     // no y store, no w read
+            case 9: SPMV_GO(k_spmv_team2<8, 4, 9>); break;     // + no gather
+            case 16: SPMV_GO(k_spmv_team2<8, 4, 16>); break;   // one band (no XCD banding)
+            case 32: SPMV_GO(k_spmv_team2<8, 4, 32>); break;   // no y store
+            case 64: SPMV_GO(k_spmv_team2<8, 4, 64>); break;   // no w load
+            case 3: SPMV_GO(k_spmv_team2<8, 4>); break;        // unaligned entry pairs, 32-bit columns (the form before)
+            // diagnostics on the production form (16-bit codes, w == x); meaningful only on the compact solver matrix
+            case 101: if (c16) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 1>); break;    // no x gather
+            case 132: if (c16) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 32>); break;   // no y store
+            case 133: if (c16) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 33>); break;   // neither
+            case 140:   // y rows kept in LDS until the wavefront's tile loop ends (needs <= 8 tiles per wavefront)
+                if (c16 && (rpb / 32 + (int64_t)(c->spmv_grid / 8) * 4 - 1) / ((int64_t)(c->spmv_grid / 8) * 4) <= 8)
+                    SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 32768>);
+                break;
+            case 150: if (c16) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 262144>); break;   // window bases as a 16-byte broadcast load (the form before)
+            case 151: if (c16) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 524288>); break;             // nontemporal column codes
+            case 152: if (c16) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 524288 | 1048576>); break;   // + nontemporal values (the form before)
+            case 153: if (c16) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 1048576>); break;            // nontemporal values only
+            case 102: if (c16) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 2>); break;       // gathers inside 16 lines
+            case 103: if (c16) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 65536>); break;   // gathers inside 1 line
+            case 2048: SPMV_GO(k_spmv_team2<8, 4, 2048>); break;   // aligned pairs, 32-bit columns
+            default:
+                if (c->spmv_unroll == 2 && c16 && c->spmv_deep)
+                    SPMV_GO(k_spmv_c16p<8, 2, 16384>);
+                else if (c->spmv_unroll == 2 && c16)
+                    SPMV_GO(k_spmv_team2<8, 2, 2048 | 4096 | 16384>);
+                else if (c->spmv_unroll == 2)
+                    SPMV_GO(k_spmv_team2<8, 2>);
+                else if (c->spmv_unroll == 6)
+                    SPMV_GO(k_spmv_team2<8, 6>);
+                else if (c16 && c->spmv_deep) {   // deep-pipelined form: gathers one tile ahead
+                    if (dist && wx) SPMV_GO(k_spmv_c16p<8, 4, 8192 | 16384>);
+                    else if (dist) SPMV_GO(k_spmv_c16p<8, 4, 8192>);
+                    else if (wx) SPMV_GO(k_spmv_c16p<8, 4, 16384>);
+                    else SPMV_GO(k_spmv_c16p<8, 4, 0>);
+                } else if (ntv && c16 && wx) {   // large matrix: hinted value stream (see load_pair)
+                    if (dist) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 8192 | 16384 | 1048576>);
+                    else SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 16384 | 1048576>);
+                } else if (ntv && c16) {
+                    if (dist) SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 8192 | 1048576>);
+                    else SPMV_GO(k_spmv_team2<8, 4, 2048 | 4096 | 1048576>);
+                } else
+                    SPMV_PROD(8, 4);
+                break;
+            }
+            break;
+        case 16: SPMV_PROD(16, 4); break;
+        default: SPMV_PROD_FEW(32, 4); break;
+        }
+#undef SPMV_PROD
+#undef SPMV_PROD_FEW
+        return;
+    }
+    switch (c->spmv_team) {
+    case 4: SPMV_GO(k_spmv_team<4, 2>); break;
+    case 8: SPMV_GO(k_spmv_team<8, 4>); break;
+    case 16:
+        if (c->spmv_unroll == 8)
+            SPMV_GO(k_spmv_team<16, 8>);
+        else
+            SPMV_GO(k_spmv_team<16, 4>);
+        break;
+    case 32: SPMV_GO(k_spmv_team<32, 4>); break;
+    default: SPMV_GO(k_spmv_team<64, 2>); break;
+    }
+#undef SPMV_GO
+}
+
+// compact solver pattern v (0: no Dirichlet reduction, 1: Dirichlet rows / columns dropped) + its 16-bit column codes; host work
+// and uploads, done once per function space and boundary mask (fdapde_solver_prepare, or lazily by the first solve)
+int build_solver_pattern(fdapde_ctx* c, int v) {
+    if (c->sp_built[v]) return FDAPDE_OK;
+    if (int rc = ensure_host(c, kHostPattern)) return rc;
+    drop_graph(c);
+    hipStream_t st = c->stream;
+    std::vector<int32_t> rp, ci, map, vrow;
+    // rows longer than a team pass (P2): segmented pattern, one team pass per chunk; else the plain compact pattern
+    const int T = c->spmv_team;
+    bool seg = false;
+    if ((T == 8 || T == 16) && c->hs.max_row - 1 > 2 * T && !std::getenv("FDAPDE_SPMV_NOSEG")) {
+        const int rc = host_build_solver_pattern_seg(c->hs, v == 1, 2 * T, (64 / T) * 4, rp, ci, map, vrow);
+        if (rc == FDAPDE_OK) seg = true;
+        else if (rc != FDAPDE_EUNSUPPORTED) return rc;
+    }
+    if (!seg)
+        if (int rc = host_build_solver_pattern(c->hs, v == 1, rp, ci, map)) return rc;
+    const int64_t n_csr = (int64_t)rp.size() - 1;   // rows of the CSR arrays (virtual rows when segmented)
+    c->sp_nv[v] = seg ? n_csr : 0, c->sp_team = T;
+    if (seg) HIPCHK(c, c->sp_vrow[v].upload(vrow.data(), vrow.size(), st));
+    if ((size_t)rp.back() + 2 > c->sval.n) HIPCHK(c, c->sval.alloc((size_t)rp.back() + 2));   // pad entries may exceed nnz
+    c->sval_layout = -2;
+    HIPCHK(c, c->sp_rowptr[v].upload(rp.data(), rp.size(), st));
+    HIPCHK(c, c->sp_colidx[v].upload(ci.data(), ci.size(), st));
+    HIPCHK(c, c->sp_map[v].upload(map.data(), map.size(), st));
+    {   // 16-bit column codes of the same pattern
+        std::vector<uint16_t> code;
+        std::vector<int32_t> tb;
+        if (int rc = host_build_col16(n_csr, rp, ci, code, tb, &c->sp_wide[v])) return rc;
+        HIPCHK(c, c->sp_col16[v].upload(code.data(), code.size(), st));
+        HIPCHK(c, c->sp_tbase[v].upload(tb.data(), tb.size(), st));
+        if (std::getenv("FDAPDE_DEBUG_SETUP"))
+            std::fprintf(stderr, "solver pattern %d: %lld entries in %lld %srows, %lld of %lld row groups wide\n", v, (long long)rp.back(),
+                         (long long)n_csr, seg ? "virtual " : "", (long long)c->sp_wide[v], (long long)((n_csr + kCodeRows - 1) / kCodeRows));
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    c->sp_nnz[v] = rp.back(), c->sp_built[v] = true;
+    return FDAPDE_OK;
+}
+
+// blocked-ELL layout of the multi-launch SpMV for boundary variant v (k_spmv_blocked), built on the device from the pattern
+int build_blocked(fdapde_ctx* c, int v) {
+    fdapde_ctx::Blocked& bk = c->bk[v];
+    if (bk.tried) return FDAPDE_OK;
+    bk.tried = true, bk.ok = false;
+    const char* mode = std::getenv("FDAPDE_SETUP");
+    if (mode && std::strcmp(mode, "host") == 0) return FDAPDE_OK;   // (no host builder for this layout: the compact CSR path serves)
+    PersistLayout pl;
+    DevPersist dp;
+    // rows per block, measured on C5 (P2, 28 entries per row; CSR kernel 400 us per SpMV): 1024 -> 375 us, 2048 -> 367, 4096 -> 387, 8192 -> 439
+    int rows = 2048;
+    if (const char* e = std::getenv("FDAPDE_BLOCKED_ROWS")) rows = std::atoi(e);
+    const int rc = dev_build_persist_layout(c->hs.n_dofs, c->hs.max_row, c->rowptr.p, c->colidx.p, c->bnd.p, v == 1, 1 << 19, 0, rows, nullptr, 0, false, c->stream, pl, &dp,
+                                            c->err);
+    if (rc == FDAPDE_EUNSUPPORTED) return FDAPDE_OK;
+    if (rc) return rc;
+    const int S = pl.R * kPersistT;
+    bk.imp_cap = (pl.max_imp + 63) & ~63;
+    bk.lds_bytes = 8 * (size_t)(S + bk.imp_cap) + 64;
+    if (bk.lds_bytes > 150 * 1024) {
+        dev_persist_release(&dp);
+        return FDAPDE_OK;
+    }
+    const size_t n_alloc = (size_t)pl.n_entries + 256;
+    adopt(bk.slot_dof, dp.slot_dof, (size_t)pl.G * S), adopt(bk.ell_off, dp.ell_off, (size_t)pl.G + 1), adopt(bk.sl_off, dp.sl_off, (size_t)pl.G * (pl.nsl + 1));
+    adopt(bk.ell_code, dp.ell_code, n_alloc), adopt(bk.ell_src, dp.ell_src, n_alloc), adopt(bk.imp_off, dp.imp_off, (size_t)pl.G + 1);
+    adopt(bk.imp_dof, dp.imp_pos, (size_t)(pl.n_imp ? pl.n_imp : 1)), adopt(bk.drop_dof, dp.drop_dof, (size_t)(pl.n_drop ? pl.n_drop : 1));
+    dev_persist_release(&dp);
+    HIPCHK(c, bk.ell_val.alloc(n_alloc));
+    HIPCHK(c, hipMemsetAsync(bk.ell_val.p, 0, sizeof(double) * n_alloc, c->stream));
+    if (2 * (size_t)pl.G > c->part_a.n) HIPCHK(c, c->part_a.alloc(2 * (size_t)pl.G));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (std::getenv("FDAPDE_DEBUG_SETUP"))
+        std::fprintf(stderr, "blocked-ELL SpMV layout %d: %d workgroups x %d rows/thread, %lld interior rows, %lld entries (%lld stored, %.1f %% padding), "
+                     "LDS %zu B, imports <= %d (%lld in all)\n", v, pl.G, pl.R, (long long)pl.n_int, (long long)pl.n_entries, (long long)pl.nnz,
+                     100.0 * (double)(pl.n_entries - pl.nnz) / (double)(pl.n_entries > 0 ? pl.n_entries : 1), bk.lds_bytes, pl.max_imp, (long long)pl.n_imp);
+    bk.meta = std::move(pl);
+    bk.filled = false, bk.ok = true;
+    return FDAPDE_OK;
+}
+
+// Dirichlet reduction + Jacobi scaling of the system matrix A (internal slots): scale, sval = diag(s) A diag(s).
+// Done once per matrix (per solve for the elliptic problem, once for all time steps of the parabolic one).
+int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss, bool symmetric) {
+    const int64_t n = c->hs.n_dofs;
+    hipStream_t st = c->stream;
+    ss->dist = (c->comm != nullptr || c->ar_fn != nullptr) && c->halo_ready;   // multi-GPU: sub-assembled operator of this rank's cells
+    ss->owned = ss->dist ? c->owned.p : nullptr;
+    ss->use_bnd = use_bnd;
+    ss->rowdist = (c->comm != nullptr || c->ar_fn != nullptr) && c->rd.ready && !ss->dist;
+    if (ss->rowdist) ss->owned = c->rd.owned.p;
+    HIPCHK(c, hipMemsetAsync(c->ctl.p, 0, 4 * sizeof(int32_t), st));
+    if (ss->dist) {   // the diagonal is a sum over the ranks sharing a DOF
+        hipLaunchKernelGGL(k_diag_extract, dim3(g1(n)), dim3(256), 0, st, n, c->diag.p, A, c->tmp_i.p);
+        if (int rc = halo_sum(c, c->tmp_i.p, nullptr, 0)) return rc;
+        hipLaunchKernelGGL(k_jacobi_scale_from_diag, dim3(g1(n)), dim3(256), 0, st, n, c->tmp_i.p, c->bnd.p, use_bnd, c->scale.p,
+                           c->ctl.p + 3);
+    } else {
+        hipLaunchKernelGGL(k_jacobi_scale, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->diag.p, A, c->bnd.p, use_bnd, c->scale.p, c->ctl.p + 3);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (ss->dist || ss->rowdist) {   // "positive diagonal" (CG admissible) must be ONE decision for all ranks: sum the per-rank flags
+        c->h_sc[8] = (double)c->h_ctl[3];
+        HIPCHK(c, hipMemcpyAsync(c->sbuf.p + 2, c->h_sc + 8, sizeof(double), hipMemcpyHostToDevice, st));
+        if (int rc = allreduce_sum(c, c->sbuf.p + 2, 1)) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->h_sc + 8, c->sbuf.p + 2, sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        c->h_ctl[3] = c->h_sc[8] != 0.0 ? 1 : 0;
+    }
+    ss->diag_positive = c->h_ctl[3] == 0;
+    if (ss->rowdist) {
+        // row-distributed form: this rank's rows are complete (its sub-mesh holds every cell touching an owned DOF), the columns other
+        // ranks own take their Jacobi scale from the owner; the whole CG then runs as one launch per rank on a layout of its own
+        c->ps[0].filled = c->ps[1].filled = false, c->bk_cur = -1, c->bk[0].filled = c->bk[1].filled = false;
+        if (!ss->diag_positive) return fail(c, FDAPDE_EUNSUPPORTED, "the row-distributed solve needs a positive diagonal (Jacobi scaling)");
+        const int v = use_bnd ? 1 : 0;
+        c->persist_plain = symmetric ? 0 : 1;
+        if (int rc = build_rowdist(c, v)) return rc;
+        if (c->rd.lay[v].ok && !symmetric && (c->rd.lay[v].ps.meta.sym || c->rd.lay[v].ps.meta.R > 8))
+            return fail(c, FDAPDE_EUNSUPPORTED, "the row-distributed BiCGStab needs plain storage and at most 8 rows per thread (layout built for a symmetric operator? re-create the context)");
+        if (!c->rd.lay[v].ok) return fail(c, FDAPDE_EUNSUPPORTED, "the row-distributed solve does not take this system (a rank's share needs more than 8 rows per thread, or its lists do not fit)");
+        if (int rc = rowdist_import_ghosts(c, v, c->scale.p)) return rc;
+        hipLaunchKernelGGL(k_scale_matrix, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, A, c->scale.p, c->sval.p);
+        c->sp_cur = -1, c->sval_layout = -2;
+        if (int rc = fill_rowdist(c, v)) return rc;
+        HIPCHK(c, hipGetLastError());
+        return FDAPDE_OK;
+    }
+    // scaled matrix: compact (no diagonal, no Dirichlet rows / columns: ~12 % fewer entries on C3) when every interior
+    // diagonal is positive, so that the scaled diagonal is exactly 1; else the full pattern
+    // symmetric positive system on one GPU of at most ~2 M interior rows: the solve will run as ONE persistent launch on its own
+    // resident layout (kernels_persist.h); the multi-launch kernels then only serve the lift, warm starts and the fall-back, and
+    // take the plain full-pattern scaled matrix (no compact pattern / column codes are built for such a system)
+    c->ps[0].filled = c->ps[1].filled = false;
+    bool persist = false;
+    if (c->persist_broken && --c->persist_retry_in <= 0) c->persist_broken = false;   // the contention that broke it may be over
+    // symmetric: the single launch is a CG (kernels_persist.h); non-symmetric: a BiCGStab on the plain storage (kernels_persist_bicg.h: six
+    // vectors in registers, so at most 8 rows per thread -- larger systems keep the multi-launch BiCGStab)
+    c->persist_plain = symmetric ? 0 : 1;
+    if ((symmetric || c->persist_bicg) && ss->diag_positive && !ss->dist && c->persist && !c->persist_broken && c->spmv_variant == 2) {
+        if (int rc = build_persist(c, use_bnd ? 1 : 0)) return rc;
+        const fdapde_ctx::Persist& ps = c->ps[use_bnd ? 1 : 0];
+        persist = ps.ok && (symmetric || (!ps.meta.sym && ps.meta.R <= 8));
+    }
+    // one GPU, positive diagonal, not taken by the persistent CG (non-symmetric operator, or too many rows): the multi-launch
+    // kernels apply the operator from the blocked-ELL layout (k_spmv_blocked); the compact CSR pattern is then not built either
+    c->bk_cur = -1, c->bk[0].filled = c->bk[1].filled = false;
+    bool blocked = false;
+    // ... where it pays: long rows (P2).  On 14-entry rows (C3 with the persistent CG switched off) the CSR kernel's finer-grained,
+    // software-pipelined workgroups win (45 us against 48-51 us per SpMV), so short-row systems keep the compact CSR pattern.
+    const bool long_rows = (double)c->hs.nnz >= 20.0 * (double)n || c->blocked == 2;
+    if (!persist && ss->diag_positive && !ss->dist && c->blocked && long_rows && c->spmv_variant == 2) {
+        if (int rc = build_blocked(c, use_bnd ? 1 : 0)) return rc;
+        blocked = c->bk[use_bnd ? 1 : 0].ok;
+    }
+    const bool compact = !persist && !blocked && ss->diag_positive && c->spmv_variant == 2 && !std::getenv("FDAPDE_SPMV_FULL");
+    if (compact) {
+        const int v = use_bnd ? 1 : 0;
+        if (int rc = build_solver_pattern(c, v)) return rc;
+        if (c->sval_layout != v) {   // entries no full-pattern entry maps to (padding of a segmented pattern) must read 0
+            HIPCHK(c, hipMemsetAsync(c->sval.p, 0, sizeof(double) * c->sval.n, st));
+            c->sval_layout = v;
+        }
+        hipLaunchKernelGGL(k_scale_matrix_compact, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, A, c->scale.p,
+                           c->sp_map[v].p, c->sval.p);
+        c->sp_cur = v;
+    } else {
+        hipLaunchKernelGGL(k_scale_matrix, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, A, c->scale.p, c->sval.p);
+        c->sp_cur = -1, c->sval_layout = -2;
+    }
+    if (blocked) {
+        const int v = use_bnd ? 1 : 0;
+        hipLaunchKernelGGL(k_persist_fill, dim3(g1(c->bk[v].meta.n_entries)), dim3(256), 0, st, c->bk[v].meta.n_entries, c->bk[v].ell_src.p,
+                           c->sval.p, c->bk[v].ell_val.p, (unsigned long long*)nullptr);
+        c->bk[v].filled = true, c->bk_cur = v;
+    }
+    if (persist)
+        if (int rc = fill_persist(c, use_bnd ? 1 : 0)) return rc;
+    HIPCHK(c, hipGetLastError());
+    return FDAPDE_OK;
+}
+
+// Krylov solve of A u = f with u = g on the Dirichlet DOFs (if ss.use_bnd), on the system prepared by solve_prepare.
+//   f_dev : right-hand side, internal order, sub-assembled (summed over ranks here when dist)
+//   g_dev : Dirichlet values, internal order (read on boundary DOFs only)
+//   u0_dev: initial guess in u-space or nullptr (cold start)
+// Result in c->u.  Fills c->info (iters, relres, converged, method_used, spmv timing).
+int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double* f_dev, const double* g_dev, const double* u0_dev,
+              int method, double rtol, int maxit, int check_every, int n_timed) {
+    const int64_t n = c->hs.n_dofs;
+    hipStream_t st = c->stream;
+    const bool dist = ss.dist;
+    const uint8_t* owned = ss.owned;
+    // partial pairs the SpMV leaves for the vector kernels: one per workgroup of the kernel that applies the scaled operator
+    const int np_spmv = (c->bk_cur >= 0 && !dist) ? c->bk[c->bk_cur].meta.G : c->spmv_grid;
+    const double* fvec = f_dev;
+    if (ss.rowdist) {
+        if (u0_dev) return fail(c, FDAPDE_EUNSUPPORTED, "warm starts are not part of the row-distributed solve");
+        const bool want_bicg = method == FDAPDE_SOLVER_BICGSTAB || c->rd.lay[ss.use_bnd ? 1 : 0].ps.built_plain;
+        if (method == FDAPDE_SOLVER_CG_SR) return fail(c, FDAPDE_EUNSUPPORTED, "the row-distributed solve runs the fused-update CG or BiCGStab");
+        method = want_bicg ? FDAPDE_SOLVER_BICGSTAB : FDAPDE_SOLVER_CG_FUSED;
+    }
+    if (dist) {   // the forcing vector is a sum over the ranks sharing a DOF
+        HIPCHK(c, hipMemcpyAsync(c->tmp_e.p, f_dev, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+        if (int rc = halo_sum(c, c->tmp_e.p, nullptr, 0)) return rc;
+        fvec = c->tmp_e.p;
+    }
+    hipLaunchKernelGGL(k_lift, dim3(g1(n)), dim3(256), 0, st, n, c->bnd.p, g_dev, ss.use_bnd, c->gt.p);
+    // the lift is zero (no Dirichlet data, or homogeneous data on one GPU -- across ranks the data may differ, and every rank
+    // must take the same path through the collectives): A g~ = 0
+    if (!ss.use_bnd || (!dist && !ss.rowdist && g_dev == c->g.p && c->g_zero)) {
+        HIPCHK(c, hipMemsetAsync(c->y.p, 0, sizeof(double) * (size_t)n, st));
+    } else {
+        launch_spmv(c, A, c->gt.p, c->y.p, nullptr, nullptr, nullptr);   // y = A g~
+        if (dist)
+            if (int rc = halo_sum(c, c->y.p, nullptr, 0)) return rc;
+    }
+    if (method == FDAPDE_SOLVER_AUTO)   // symmetric + positive diagonal: CG (fused-update form on one GPU, single-reduction form on several)
+        method = (c->op_symmetric && ss.diag_positive) ? (dist ? FDAPDE_SOLVER_CG : FDAPDE_SOLVER_CG_FUSED) : FDAPDE_SOLVER_BICGSTAB;
+    if (method == FDAPDE_SOLVER_CG && dist && c->world > 1) method = FDAPDE_SOLVER_CG_SR;   // one all-reduce per iteration
+    if (method == FDAPDE_SOLVER_CG_FUSED && dist) method = FDAPDE_SOLVER_CG_SR;   // y.y of the assembled y would need its own all-reduce
+    if ((method == FDAPDE_SOLVER_CG || method == FDAPDE_SOLVER_CG_SR || method == FDAPDE_SOLVER_CG_FUSED) && !ss.diag_positive)
+        return fail(c, FDAPDE_ENOCONV, "CG needs a positive diagonal (operator not SPD?); use BiCGStab");
+    const bool bicg = method == FDAPDE_SOLVER_BICGSTAB, cgsr = method == FDAPDE_SOLVER_CG_SR, cgf = method == FDAPDE_SOLVER_CG_FUSED;
+    const double tol2 = rtol * rtol;
+    const double* ax = nullptr;
+    if (u0_dev) {   // warm start: x = (u0 - g~) / s, r = b~ - At x
+        hipLaunchKernelGGL(k_krylov_init, dim3(c->vec_grid), dim3(256), 0, st, n, fvec, c->y.p, c->scale.p, c->x.p, c->r.p, c->p.p,
+                           (double*)nullptr, c->part_b.p, owned, u0_dev, c->gt.p, (const double*)nullptr, 1);
+        launch_spmv(c, c->sval.p, c->x.p, c->t.p, nullptr, nullptr, nullptr);
+        if (dist)
+            if (int rc = halo_sum(c, c->t.p, nullptr, 0)) return rc;
+        ax = c->t.p;
+    }
+    hipLaunchKernelGGL(k_krylov_init, dim3(c->vec_grid), dim3(256), 0, st, n, fvec, c->y.p, c->scale.p, c->x.p, c->r.p, c->p.p,
+                       bicg ? c->r0.p : (double*)nullptr, c->part_b.p, owned, u0_dev, c->gt.p, ax, 0);
+    if (dist || ss.rowdist) {
+        hipLaunchKernelGGL(k_reduce_partials2, dim3(1), dim3(256), 0, st, c->part_b.p, c->vec_grid, c->sbuf.p);
+        if (int rc = allreduce_sum(c, c->sbuf.p, 2)) return rc;
+        hipLaunchKernelGGL(k_krylov_init_fin, dim3(1), dim3(256), 0, st, c->sbuf.p, 1, c->sc.p, c->ctl.p, tol2, (double*)nullptr, 0);
+    } else {
+        // fused-update CG: its launch 0 reads the explicit r.r from the second half of part_b (seeded here)
+        const int V = c->cgf_v;
+        const int64_t b2 = c->cgf_band ? (((((n + 7) / 8) + 31) & ~int64_t(31)) >> 1) : 0, span = b2 > 0 ? b2 : (n >> 1);
+        const int per = (int)((span + 256 * V - 1) / (256 * V)) > 0 ? (int)((span + 256 * V - 1) / (256 * V)) : 1;
+        const int cg = b2 > 0 ? 8 * per : per;
+        hipLaunchKernelGGL(k_krylov_init_fin, dim3(1), dim3(256), 0, st, c->part_b.p, c->vec_grid, c->sc.p, c->ctl.p, tol2,
+                           cgf ? c->part_b.p + cg : (double*)nullptr, cgf ? cg : 0);
+    }
+    if (cgsr) {   // p = s = 0 before the first update (beta = 0 there)
+        HIPCHK(c, hipMemsetAsync(c->p.p, 0, sizeof(double) * (size_t)n, st));
+        HIPCHK(c, hipMemsetAsync(c->s.p, 0, sizeof(double) * (size_t)n, st));
+    }
+    HIPCHK(c, hipGetLastError());
+    n_timed = n_timed < 0 ? 0 : (n_timed > 256 ? 256 : n_timed);
+    while ((int)c->ev_spmv.size() < 2 * n_timed) {
+        hipEvent_t e;
+        HIPCHK(c, hipEventCreate(&e));
+        c->ev_spmv.push_back(e);
+    }
+    int timed = 0, launched = 0;
+    bool stop = false;
+    bool persisted = false;
+    if (ss.rowdist) {   // one launch per rank, the launches of all ranks acting as one grid (kernels_persist.h DIST)
+        if (int rc = run_rowdist(c, ss.use_bnd ? 1 : 0, tol2, maxit, &persisted, bicg)) return rc;
+        if (!persisted) return fail(c, FDAPDE_EUNSUPPORTED, "row-distributed solve: an in-kernel hand-off between the ranks' launches timed out (boards not visible across the devices, or a rank's launch could not be resident); use the element-partitioned exchange (fdapde_halo_setup_peers) instead");
+        stop = true, launched = c->h_ctl[1];
+    }
+    if (cgf && !dist && !ss.rowdist && c->persist && !c->persist_broken && c->ps[ss.use_bnd ? 1 : 0].ok && c->ps[ss.use_bnd ? 1 : 0].filled) {
+        // the whole iteration as ONE launch (kernels_persist.h); it leaves sc / ctl as the loop below would
+        DebugClock clk;
+        if (int rc = run_persist(c, ss.use_bnd ? 1 : 0, tol2, maxit, &persisted)) return rc;
+        clk.mark("solve_run: run_persist");
+        if (persisted) stop = true, launched = c->h_ctl[1];
+    }
+    if (bicg && !dist && !ss.rowdist && c->persist && c->persist_bicg && !c->persist_broken) {   // the whole BiCGStab as one launch
+        const fdapde_ctx::Persist& ps = c->ps[ss.use_bnd ? 1 : 0];
+        if (ps.ok && ps.filled && !ps.meta.sym && ps.meta.R <= 8) {
+            if (int rc = run_persist(c, ss.use_bnd ? 1 : 0, tol2, maxit, &persisted, /*bicg=*/true)) return rc;
+            if (persisted) stop = true, launched = c->h_ctl[1];
+        }
+    }
+    // one iteration of the fused-update CG: SpMV (p.y, y.y) + k_cgf_update; arguments depend on the iteration's parity only
+    const int cgf_V = c->cgf_v;
+    // XCD-aware mapping of the update kernel (knob cgf_band): workgroup b serves the elements of SpMV row band b % 8
+    const int64_t cgf_band2 = c->cgf_band ? (((((n + 7) / 8) + 31) & ~int64_t(31)) >> 1) : 0;
+    const int64_t cgf_span = cgf_band2 > 0 ? cgf_band2 : (n >> 1);
+    const int cgf_per = (int)((cgf_span + 256 * cgf_V - 1) / (256 * cgf_V)) > 0 ? (int)((cgf_span + 256 * cgf_V - 1) / (256 * cgf_V)) : 1;
+    const int cgf_grid = cgf_band2 > 0 ? 8 * cgf_per : cgf_per;
+    auto enqueue_cgf = [&](int it, hipEvent_t e0, hipEvent_t e1) {
+        const int cg = cgf_grid;
+        launch_spmv(c, c->sval.p, c->p.p, c->y.p, c->p.p, c->part_a.p, c->ctl.p, e0, e1);   // p.y and y.y
+#define CGF_GO(...)                                                                                                        \
+    hipLaunchKernelGGL((k_cgf_update<__VA_ARGS__>), dim3(cg), dim3(256), 0, st, n, c->y.p, c->p.p, c->x.p, c->r.p, c->part_a.p, np_spmv, \
+                       c->part_b.p + (size_t)((it + 1) & 1) * cg, cg, c->part_b.p + (size_t)(it & 1) * cg, c->sc.p, tol2, c->ctl.p, \
+                       cgf_band2, c->cgf_nt, c->cgf_lazy, it & 1)
+        if (c->cgf_split && cgf_V == 8) CGF_GO(8, 1);
+        else if (c->cgf_split && cgf_V == 4) CGF_GO(4, 1);
+        else if (cgf_V == 1) CGF_GO(1);
+        else if (cgf_V == 2) CGF_GO(2);
+        else if (cgf_V == 8) CGF_GO(8);
+        else CGF_GO(4);
+#undef CGF_GO
+    };
+    auto enqueue_cgf_fin = [&](int done) {   // explicit r.r of the last update -> sc[3] / stop flag
+        hipLaunchKernelGGL(k_cgf_fin, dim3(1), dim3(256), 0, st, c->part_b.p + (size_t)((done - 1) & 1) * cgf_grid, cgf_grid, c->sc.p, tol2,
+                           c->ctl.p);
+    };
+    const int bi_grid = (int)(((n >> 1) + 256 * kBiV - 1) / (256 * kBiV)) > 0 ? (int)(((n >> 1) + 256 * kBiV - 1) / (256 * kBiV)) : 1;
+    while (!stop && launched < maxit && !ss.rowdist) {
+        const int chunk = (maxit - launched) < check_every ? (maxit - launched) : check_every;
+        // a full chunk of the fused-update CG with no timed launch replays ONE hipGraph (2 * chunk + 1 kernel nodes): the
+        // arguments repeat with period 2, so the graph captured for iterations 0 .. chunk-1 serves every even-aligned chunk
+        bool graphed = false;
+        if (cgf && c->use_graph && chunk == check_every && (chunk & 1) == 0 && (launched & 1) == 0 && timed >= n_timed) {
+            GraphKey key;
+            std::memset(&key, 0, sizeof key);   // padding bytes take part in the memcmp below
+            key.sval = c->sval.p, key.rowptr = c->sp_cur >= 0 ? (const void*)c->sp_rowptr[c->sp_cur].p : (const void*)c->rowptr.p;
+            key.n = n, key.tol2 = tol2, key.chunk = chunk, key.v = cgf_V, key.grid = c->spmv_grid, key.team = c->spmv_team;
+            key.ablate = c->spmv_ablate, key.c16 = c->spmv_c16, key.deep = c->spmv_deep, key.unroll = c->spmv_unroll, key.sp_cur = c->sp_cur;
+            // the blocked-ELL layout the captured SpMV nodes read from (its arrays and grid are baked into the graph)
+            key.bk_cur = c->bk_cur, key.bk_G = c->bk_cur >= 0 ? c->bk[c->bk_cur].meta.G : 0;
+            key.bk_val = c->bk_cur >= 0 ? (const void*)c->bk[c->bk_cur].ell_val.p : nullptr;
+            if (!c->cg_graph_exec || std::memcmp(&key, &c->cg_graph_key, sizeof key) != 0) {
+                if (c->cg_graph_exec) (void)hipGraphExecDestroy(c->cg_graph_exec), c->cg_graph_exec = nullptr;
+                hipGraph_t g = nullptr;
+                if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    for (int it = 0; it < chunk; ++it) enqueue_cgf(it, nullptr, nullptr);
+                    enqueue_cgf_fin(chunk);
+                    if (hipStreamEndCapture(st, &g) == hipSuccess && g &&
+                        hipGraphInstantiate(&c->cg_graph_exec, g, nullptr, nullptr, 0) == hipSuccess)
+                        c->cg_graph_key = key;
+                    else
+                        c->cg_graph_exec = nullptr;
+                    if (g) (void)hipGraphDestroy(g);
+                }
+                (void)hipGetLastError();
+            }
+            if (c->cg_graph_exec && hipGraphLaunch(c->cg_graph_exec, st) == hipSuccess) launched += chunk, graphed = true;
+        }
+        for (int it = 0; !graphed && it < chunk; ++it, ++launched) {
+            if (cgsr) {
+                const int parity = launched & 1;
+                const bool tm = timed < n_timed && launched % kTimeStride == kTimePhase;   // every kTimeStride-th iteration is timed
+                // w = At r with delta = r.(At r) and gamma = r.r (owned rows) fused; multi-GPU: ONE all-reduce carries the
+                // interface entries of w and both partials
+                launch_spmv(c, c->sval.p, c->r.p, c->y.p, c->r.p, c->part_a.p, c->ctl.p, tm ? c->ev_spmv[2 * timed] : nullptr,
+                            tm ? c->ev_spmv[2 * timed + 1] : nullptr, 1, owned);
+                if (tm) ++timed;
+                const double* part = c->part_a.p;
+                int np = np_spmv;
+                if (dist) {
+                    // pack -> all-reduce; the update kernel reads the summed interface rows straight from hbuf (no unpack launch)
+                    if (int rc = halo_sum(c, c->y.p, c->part_a.p, c->spmv_grid, /*unpack=*/false)) return rc;
+                    part = c->hbuf.p + c->n_if, np = 1;
+                }
+                // XCD-aware mapping like k_cgf_update (kCgV elements per lane, bands of the SpMV's rows)
+                const int64_t sr_band2 = c->cgf_band ? (((((n + 7) / 8) + 31) & ~int64_t(31)) >> 1) : 0, sr_span = sr_band2 > 0 ? sr_band2 : (n >> 1);
+                const int sr_per = (int)((sr_span + 256 * kCgV - 1) / (256 * kCgV)) > 0 ? (int)((sr_span + 256 * kCgV - 1) / (256 * kCgV)) : 1;
+                hipLaunchKernelGGL(k_cgsr_update, dim3(sr_band2 > 0 ? 8 * sr_per : sr_per), dim3(256), 0, st, n, c->r.p, c->y.p, c->p.p,
+                                   c->s.p, c->x.p, part, np, c->sc.p, parity, launched == 0 ? 1 : 0, tol2, c->ctl.p,
+                                   dist ? c->if_slot.p : (const int32_t*)nullptr, dist ? c->hbuf.p : (const double*)nullptr, sr_band2);
+            } else if (cgf) {
+                const bool tm = timed < n_timed && launched % kTimeStride == kTimePhase;   // every kTimeStride-th iteration is timed
+                enqueue_cgf(launched, tm ? c->ev_spmv[2 * timed] : nullptr, tm ? c->ev_spmv[2 * timed + 1] : nullptr);
+                if (tm) ++timed;
+            } else if (!bicg) {
+                const int parity = launched & 1;
+                const bool tm = timed < n_timed && launched % kTimeStride == kTimePhase;   // every kTimeStride-th iteration is timed
+                launch_spmv(c, c->sval.p, c->p.p, c->y.p, c->p.p, c->part_a.p, c->ctl.p,
+                            tm ? c->ev_spmv[2 * timed] : nullptr, tm ? c->ev_spmv[2 * timed + 1] : nullptr);
+                if (tm) ++timed;
+                if (!dist) {
+                    hipLaunchKernelGGL(k_cg_update_xr, dim3(c->cg_grid), dim3(256), 0, st, n, c->y.p, c->r.p, c->part_a.p,
+                                       np_spmv, c->part_b.p, c->sc.p, parity, c->ctl.p, owned);
+                    hipLaunchKernelGGL(k_cg_update_p, dim3(c->cg_grid), dim3(256), 0, st, n, c->r.p, c->p.p, c->x.p, c->part_b.p,
+                                       c->cg_grid, c->sc.p, parity, tol2, c->ctl.p);
+                } else {
+                    // one all-reduce carries the interface entries of A_p p and the rank's p.Ap partial; a second one
+                    // (a single double) carries r.r.  Every rank takes the same stop decision from the same numbers.
+                    if (int rc = halo_sum(c, c->y.p, c->part_a.p, c->spmv_grid)) return rc;
+                    hipLaunchKernelGGL(k_cg_update_xr, dim3(c->cg_grid), dim3(256), 0, st, n, c->y.p, c->r.p, c->hbuf.p + c->n_if, 1,
+                                       c->part_b.p, c->sc.p, parity, c->ctl.p, owned);
+                    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, c->part_b.p, c->cg_grid, c->sbuf.p);
+                    if (int rc = allreduce_sum(c, c->sbuf.p, 1)) return rc;
+                    hipLaunchKernelGGL(k_cg_update_p, dim3(c->cg_grid), dim3(256), 0, st, n, c->r.p, c->p.p, c->x.p, c->sbuf.p, 1,
+                                       c->sc.p, parity, tol2, c->ctl.p);
+                }
+            } else if (!dist) {
+                hipLaunchKernelGGL(k_bicg_p, dim3(bi_grid), dim3(256), 0, st, n, c->r.p, c->y.p, c->p.p, c->part_b.p,
+                                   bi_grid, c->sc.p, launched == 0 ? 1 : 0, c->ctl.p);
+                const bool tm = timed < n_timed && launched % kTimeStride == kTimePhase;   // every kTimeStride-th iteration is timed
+                launch_spmv(c, c->sval.p, c->p.p, c->y.p, c->r0.p, c->part_a.p, c->ctl.p,   // v = At p, r0.v
+                            tm ? c->ev_spmv[2 * timed] : nullptr, tm ? c->ev_spmv[2 * timed + 1] : nullptr);
+                if (tm) ++timed;
+                hipLaunchKernelGGL(k_bicg_s, dim3(bi_grid), dim3(256), 0, st, n, c->r.p, c->y.p, c->s.p, c->part_a.p,
+                                   np_spmv, c->sc.p, c->ctl.p);
+                launch_spmv(c, c->sval.p, c->s.p, c->t.p, c->s.p, c->part_a.p, c->ctl.p);    // t = At s, t.s, t.t
+                hipLaunchKernelGGL(k_bicg_xr, dim3(bi_grid), dim3(256), 0, st, n, c->p.p, c->s.p, c->t.p, c->r0.p, c->x.p,
+                                   c->r.p, c->part_a.p, np_spmv, c->part_b.p, c->sc.p, c->ctl.p, (const uint8_t*)nullptr);
+                hipLaunchKernelGGL(k_bicg_fin, dim3(1), dim3(256), 0, st, c->part_a.p, np_spmv, c->part_b.p, bi_grid,
+                                   c->sc.p, tol2, c->ctl.p);
+            } else {
+                // element-partitioned BiCGStab: every operator application is followed by the interface sum, which also carries
+                // the dot fused into the SpMV (w.(A x) needs no weighting); dots of assembled vectors (t.t, r0.r, r.r) count
+                // owned rows and cross in two small all-reduces.  sbuf: [0..1] = (r0.r, r.r), [4..5] = (t.s, t.t).
+                hipLaunchKernelGGL(k_bicg_p, dim3(bi_grid), dim3(256), 0, st, n, c->r.p, c->y.p, c->p.p, c->sbuf.p, 1, c->sc.p,
+                                   launched == 0 ? 1 : 0, c->ctl.p);
+                const bool tm = timed < n_timed && launched % kTimeStride == kTimePhase;   // every kTimeStride-th iteration is timed
+                launch_spmv(c, c->sval.p, c->p.p, c->y.p, c->r0.p, c->part_a.p, c->ctl.p,
+                            tm ? c->ev_spmv[2 * timed] : nullptr, tm ? c->ev_spmv[2 * timed + 1] : nullptr);
+                if (tm) ++timed;
+                if (int rc = halo_sum(c, c->y.p, c->part_a.p, c->spmv_grid)) return rc;
+                hipLaunchKernelGGL(k_bicg_s, dim3(bi_grid), dim3(256), 0, st, n, c->r.p, c->y.p, c->s.p, c->hbuf.p + c->n_if, 1,
+                                   c->sc.p, c->ctl.p);
+                launch_spmv(c, c->sval.p, c->s.p, c->t.p, c->s.p, c->part_a.p, c->ctl.p);
+                if (int rc = halo_sum(c, c->t.p, c->part_a.p, c->spmv_grid)) return rc;
+                hipLaunchKernelGGL(k_sq_owned, dim3(c->vec_grid), dim3(256), 0, st, n, c->t.p, owned, c->part_b.p, c->ctl.p);
+                hipLaunchKernelGGL(k_bicg_tt_fin, dim3(1), dim3(256), 0, st, c->part_b.p, c->vec_grid, c->hbuf.p + c->n_if,
+                                   c->sbuf.p + 4);
+                if (int rc = allreduce_sum(c, c->sbuf.p + 5, 1)) return rc;
+                hipLaunchKernelGGL(k_bicg_xr, dim3(bi_grid), dim3(256), 0, st, n, c->p.p, c->s.p, c->t.p, c->r0.p, c->x.p,
+                                   c->r.p, c->sbuf.p + 4, 1, c->part_b.p, c->sc.p, c->ctl.p, owned);
+                hipLaunchKernelGGL(k_reduce_partials2, dim3(1), dim3(256), 0, st, c->part_b.p, bi_grid, c->sbuf.p);
+                if (int rc = allreduce_sum(c, c->sbuf.p, 2)) return rc;
+                hipLaunchKernelGGL(k_bicg_fin, dim3(1), dim3(256), 0, st, c->sbuf.p + 4, 1, c->sbuf.p, 1, c->sc.p, tol2, c->ctl.p);
+            }
+        }
+        if (cgf && launched > 0 && !graphed) enqueue_cgf_fin(launched);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(c->h_sc, c->sc.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        stop = c->h_ctl[0] != 0;
+    }
+    if (launched == 0 && !persisted) {   // already converged at the initial guess
+        HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(c->h_sc, c->sc.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
+    if (cgf && c->cgf_lazy && !persisted)   // an update of x may still be pending (convergence seen at a poll, or maxit)
+        hipLaunchKernelGGL(k_cgf_flush, dim3(c->vec_grid), dim3(256), 0, st, n, c->p.p, c->r.p, c->x.p, c->sc.p, c->ctl.p);
+    hipLaunchKernelGGL(k_unscale, dim3(g1(n)), dim3(256), 0, st, n, c->scale.p, persisted ? c->persist_x.p : c->x.p, c->gt.p, c->u.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(st));
+    const double bb = c->h_sc[0], rr = c->h_sc[3];
+    c->info.iters = c->h_ctl[1];
+    c->info.relres = bb > 0 ? sqrt(rr / bb) : 0.0;
+    c->info.converged = (rr <= tol2 * bb && c->h_ctl[2] == 0) ? 1 : 0;
+    c->info.method_used = method;
+    c->info.spmv_avg_ms = 0, c->info.spmv_timed = 0;
+    {   // launches after the stop flag return at once; only iterations that really ran are averaged
+        int real = 0;   // sample k was iteration k * kTimeStride
+        while (real < timed && real * kTimeStride + kTimePhase < c->info.iters) ++real;
+        double sum = 0;
+        for (int i = 0; i < real; ++i) {
+            float t = 0;
+            HIPCHK(c, hipEventElapsedTime(&t, c->ev_spmv[2 * i], c->ev_spmv[2 * i + 1]));
+            sum += t;
+        }
+        if (real > 0) c->info.spmv_avg_ms = sum / real, c->info.spmv_timed = real;
+    }
+    c->info.persistent = persisted ? 1 : 0;
+    c->info.launch_ms = persisted ? c->persist_launch_ms : 0.0;
+    c->info.gather_avg_ms = c->info.update_avg_ms = c->info.spmv_mean_ms = 0;
+    if (persisted && !c->persist_host_stats.empty() && c->persist_host_stats[0] > 0) {
+        // phase stamps of every workgroup (s_memrealtime ticks of 10 ns).  The operator application of an iteration is complete when
+        // the SLOWEST workgroup has its rows: spmv_avg_ms = max over workgroups of their average operator phase (SpMV + import wait);
+        // the mean over workgroups is reported next to it; all-gather (which contains the wait for the slowest) and update: means
+        const size_t G = c->persist_host_stats.size() / 4;
+        double mx = 0, mean = 0, gat = 0, upd = 0;
+        for (size_t g = 0; g < G; ++g) {
+            const double* st = &c->persist_host_stats[4 * g];
+            const double n_it = st[0] > 0 ? st[0] : 1;
+            mx = std::max(mx, st[1] / n_it), mean += st[1] / n_it, gat += st[2] / n_it, upd += st[3] / n_it;
+        }
+        if (std::getenv("FDAPDE_DEBUG_PERSIST")) {   // per-workgroup operator phases (us), with the workgroup's ELL entries
+            std::vector<int64_t> eo(G + 1);
+            std::vector<int32_t> io(G + 1), xo(G + 1);
+            const int v = ss.use_bnd ? 1 : 0;
+            (void)hipMemcpy(eo.data(), c->ps[v].ell_off.p, sizeof(int64_t) * (G + 1), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(io.data(), c->ps[v].imp_off.p, sizeof(int32_t) * (G + 1), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(xo.data(), c->ps[v].exp_off.p, sizeof(int32_t) * (G + 1), hipMemcpyDeviceToHost);
+            for (size_t g = 0; g < G; ++g)
+                std::fprintf(stderr, "persist wg %zu: operator %.2f us gather %.2f us entries %lld imports %d exports %d\n", g,
+                             c->persist_host_stats[4 * g + 1] / std::max(1.0, c->persist_host_stats[4 * g]) * 1e-2,
+                             c->persist_host_stats[4 * g + 2] / std::max(1.0, c->persist_host_stats[4 * g]) * 1e-2, (long long)(eo[g + 1] - eo[g]),
+                             io[g + 1] - io[g], xo[g + 1] - xo[g]);
+        }
+        c->info.spmv_avg_ms = mx * 1e-5, c->info.spmv_timed = (int32_t)c->persist_host_stats[0];
+        c->info.spmv_mean_ms = mean / (double)G * 1e-5, c->info.gather_avg_ms = gat / (double)G * 1e-5, c->info.update_avg_ms = upd / (double)G * 1e-5;
+    }
+    if (!c->info.converged) {
+        c->err = c->h_ctl[2] ? "Krylov breakdown (operator not SPD for CG, or BiCGStab rho/omega = 0)" : "maxit reached";
+        return FDAPDE_ENOCONV;   // reference: success = false (fem_linear_elliptic_solver.h:42-45)
+    }
+    return FDAPDE_OK;
+}
+
+// One-time preparation of the solver's compact matrix layout for the current boundary-DOF mask (part of set-up, like
+// fdapde_dofs_build; the first solve does it lazily otherwise).  with_dirichlet: the layout used when Dirichlet data are set.
+int e_solver_prepare(fdapde_ctx* c, int32_t with_dirichlet) {
+    if (!c) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (!c->dev_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->spmv_variant != 2) return FDAPDE_OK;
+    const int v = with_dirichlet ? 1 : 0;
+    if (c->persist && !c->persist_broken && c->comm == nullptr && c->ar_fn == nullptr && (c->op_symmetric || c->persist_bicg)) {
+        // single GPU: the single-launch solver's layout (CG for a symmetric operator, BiCGStab on the plain storage otherwise); when the
+        // system qualifies for it, the compact pattern and the column codes of the multi-launch SpMV are not needed (a matrix that turns
+        // out not to qualify at solve time falls back and builds them lazily)
+        c->persist_plain = c->op_symmetric ? 0 : 1;
+        if (int rc = build_persist(c, v)) return rc;
+        if (c->ps[v].ok && (c->op_symmetric || (!c->ps[v].meta.sym && c->ps[v].meta.R <= 8))) return FDAPDE_OK;
+    }
+    if (c->blocked && c->comm == nullptr && c->ar_fn == nullptr &&
+        ((double)c->hs.nnz >= 20.0 * (double)c->hs.n_dofs || c->blocked == 2)) {   // single GPU, long rows: the multi-launch kernels use the blocked-ELL layout
+        if (int rc = build_blocked(c, v)) return rc;
+        if (c->bk[v].ok) return FDAPDE_OK;
+    }
+    return build_solver_pattern(c, v);
+}
+
+// What the in-solve SpMV works on, for the roofline figures of bench.py: the interior block A_II as a plain CSR operator
+// (rows / entries; algorithmic bytes = 12 nnz + 4 (n + 1) + 16 n on it) and the bytes one launch of the solver's kernel really
+// streams from the compact coded layout (values 8 B + column codes 2 B per stored entry, row pointers, window bases, virtual-row
+// table of a segmented pattern, x gathered once and y written once for every row of the full vector).
+int e_solver_layout(fdapde_ctx* c, int32_t with_dirichlet, int64_t* n_interior, int64_t* nnz_interior, double* streamed_bytes) {
+    if (!c) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (!c->dev_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int v = with_dirichlet ? 1 : 0;
+    const bool persist = c->persist && !c->persist_broken && c->ps[v].tried && c->ps[v].ok;
+    const bool blocked = !persist && c->bk[v].tried && c->bk[v].ok;
+    if (c->spmv_variant == 2 && !persist && !blocked)
+        if (int rc = build_solver_pattern(c, v)) return rc;
+    if (int rc = ensure_host(c, kHostPattern)) return rc;
+    const HostSpace& hs = c->hs;
+    int64_t ni = 0, nz = 0;
+    for (int64_t i = 0; i < hs.n_dofs; ++i) {
+        if (v && hs.dof_bnd_i[(size_t)i]) continue;
+        ++ni;
+        for (int32_t k = hs.rowptr_i[(size_t)i]; k < hs.rowptr_i[(size_t)i + 1]; ++k)
+            if (!(v && hs.dof_bnd_i[(size_t)hs.colidx_i[(size_t)k]])) ++nz;
+    }
+    if (n_interior) *n_interior = ni;
+    if (nnz_interior) *nnz_interior = nz;
+    if (streamed_bytes) {
+        if (persist) {   // one iteration of the persistent CG: the ELL blocks (8 + 2 bytes per entry, padding included) + the exchanged
+                         // entries of p (two 8-byte granules each, written once and read once)
+            // (fdapde_solver_layout_kind tells whether the blocks stream at all: the resident form reads them from LDS)
+            *streamed_bytes = 10.0 * (double)c->ps[v].meta.n_entries + 32.0 * (double)c->ps[v].meta.n_board;
+        } else if (blocked) {   // ELL blocks + x staged once per block (own rows and imports) + y written once
+            *streamed_bytes = 10.0 * (double)c->bk[v].meta.n_entries + 8.0 * (double)(c->bk[v].meta.n_int + c->bk[v].meta.n_imp) + 8.0 * (double)c->bk[v].meta.n_int;
+        } else if (c->spmv_variant == 2 && c->sp_built[v]) {
+            const int64_t n_csr = c->sp_nv[v] > 0 ? c->sp_nv[v] : hs.n_dofs;
+            *streamed_bytes = 10.0 * (double)c->sp_nnz[v] + 4.0 * (double)(n_csr + 1) + 16.0 * (double)((n_csr + kCodeRows - 1) / kCodeRows) +
+                              (c->sp_nv[v] > 0 ? 8.0 * (double)n_csr : 0.0) + 16.0 * (double)hs.n_dofs +
+                              4.0 * (double)c->sp_wide[v] * kCodeRows * ((double)c->sp_nnz[v] / (double)(n_csr > 0 ? n_csr : 1));
+        } else
+            *streamed_bytes = 12.0 * (double)hs.nnz + 4.0 * (double)(hs.n_dofs + 1) + 16.0 * (double)hs.n_dofs;
+    }
+    return FDAPDE_OK;
+}
+
+// which layout the solver holds for the boundary variant (after fdapde_solver_prepare / a solve): kind 0 compact CSR, 1 blocked ELL
+// (multi-launch), 2 persistent launch with streaming blocks, 3 persistent launch with the blocks resident in LDS
+int e_solver_layout_kind(fdapde_ctx* c, int32_t with_dirichlet, int32_t* kind, int32_t* symmetric_storage, int32_t* workgroups,
+                              int32_t* rows_per_thread) {
+    if (!c) return FDAPDE_EINVAL;
+    if (!c->dev_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
+    const int v = with_dirichlet ? 1 : 0;
+    const bool persist = c->persist && !c->persist_broken && c->ps[v].tried && c->ps[v].ok;
+    const bool blocked = !persist && c->bk[v].tried && c->bk[v].ok;
+    if (kind) *kind = persist ? (c->ps[v].stream ? 2 : 3) : blocked ? 1 : 0;
+    if (symmetric_storage) *symmetric_storage = persist && c->ps[v].meta.sym ? 1 : 0;
+    if (workgroups) *workgroups = persist ? c->ps[v].meta.G : blocked ? c->bk[v].meta.G : 0;
+    if (rows_per_thread) *rows_per_thread = persist ? c->ps[v].meta.R : blocked ? c->bk[v].meta.R : 0;
+    return FDAPDE_OK;
+}
+
+int e_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
+    if (!c) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (!c->dev_ready || !c->assembled[0] || !c->force_ready)
+        return fail(c, FDAPDE_ENOTINIT, "solver must be initialized first!");   // fem_linear_elliptic_solver.h:36
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t n = c->hs.n_dofs;
+    const double rtol = (opt && opt->rtol > 0) ? opt->rtol : 1e-10;
+    const int maxit = (opt && opt->maxit > 0) ? opt->maxit : (int)(10 * n < 100000 ? 10 * n : 100000);
+    const int check_every = (opt && opt->check_every > 0) ? opt->check_every : 32;
+    const double* A = c->vals[FDAPDE_MAT_STIFF].p;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    SolveState ss;
+    c->scaled_owner = fdapde_ctx::kScaledSolve;
+    DebugClock clk;
+    if (int rc = solve_prepare(c, A, c->have_g ? 1 : 0, &ss, c->op_symmetric)) return rc;
+    clk.mark("fdapde_solve: solve_prepare");
+    const int rc = solve_run(c, ss, A, c->force.p, c->g.p, nullptr, opt ? opt->method : FDAPDE_SOLVER_AUTO, rtol, maxit, check_every,
+                             opt ? opt->time_spmv : 0);
+    clk.mark("fdapde_solve: solve_run");
+    if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->info.t_solve_ms = ms;
+    c->solved = true, c->dirichlet_applied = c->have_g;
+    if (info) *info = c->info;
+    return rc;
+}
+
+// FEMLinearParabolicSolver::solve (fdaPDE/finite_elements/solvers/fem_linear_parabolic_solver.h:37-72): implicit Euler,
+//   K = M / dt + A ; Dirichlet rows of K ; for i = 0 .. m-2:  rhs = (M / dt) u_i + f_{i+1} ; rhs[boundary] = g(., i+1) ;
+//   u_{i+1} = K^{-1} rhs.   The reference factorises K once with SparseLU; here K is scaled once and every step is a
+//   Jacobi-PCG (or BiCGStab) solve warm-started from u_i.  Forcing columns come from fdapde_set_forcing (n_times columns).
+int e_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times, double delta_t, const double* initial_condition,
+                           const double* dirichlet, double* solution, fdapde_info* info) {
+    if (!c || n_times < 1 || !(delta_t > 0) || !initial_condition || !solution) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (!c->dev_ready || !c->assembled[0] || !c->assembled[1] || !c->force_ready)
+        return fail(c, FDAPDE_ENOTINIT, "solver must be initialized first!");   // fem_linear_parabolic_solver.h:39
+    if (c->fq_cols < n_times) return fail(c, FDAPDE_EINVAL, "forcing data needs one column per time point");
+    HIPCHK(c, hipSetDevice(c->device));
+    const HostSpace& hs = c->hs;
+    const int64_t n = hs.n_dofs;
+    hipStream_t st = c->stream;
+    const double rtol = (opt && opt->rtol > 0) ? opt->rtol : 1e-10;
+    const int maxit = (opt && opt->maxit > 0) ? opt->maxit : (int)(10 * n < 100000 ? 10 * n : 100000);
+    const int check_every = (opt && opt->check_every > 0) ? opt->check_every : 8;
+    const double inv_dt = 1.0 / delta_t;
+    DBuf<double> kmat, uprev, rhs, gcol;
+    HIPCHK(c, kmat.alloc((size_t)hs.nnz + 2));
+    HIPCHK(c, uprev.alloc((size_t)n));
+    HIPCHK(c, rhs.alloc((size_t)n));
+    HIPCHK(c, gcol.alloc((size_t)n));
+    std::vector<double> tmp((size_t)n);
+    auto to_internal = [&](const double* ext) {
+        for (int64_t i = 0; i < n; ++i) tmp[(size_t)i] = ext[hs.dof_i2e[(size_t)i]];
+    };
+    HIPCHK(c, hipEventRecord(c->ev0, st));
+    hipLaunchKernelGGL(k_matrix_combine, dim3(g1(hs.nnz)), dim3(256), 0, st, hs.nnz, c->vals[FDAPDE_MAT_MASS].p,
+                       c->vals[FDAPDE_MAT_STIFF].p, inv_dt, kmat.p);
+    SolveState ss;
+    c->scaled_owner = fdapde_ctx::kScaledParabolic;
+    if (int rc = solve_prepare(c, kmat.p, dirichlet ? 1 : 0, &ss, c->op_symmetric)) return rc;
+    to_internal(initial_condition);
+    HIPCHK(c, hipMemcpyAsync(uprev.p, tmp.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    std::memcpy(solution, initial_condition, sizeof(double) * (size_t)n);   // solution_.col(0) = initial condition (line 46)
+    int total_iters = 0, rc_all = FDAPDE_OK;
+    double worst = 0;
+    for (int32_t i = 0; i + 1 < n_times; ++i) {
+        launch_spmv(c, c->vals[FDAPDE_MAT_MASS].p, uprev.p, c->s.p, nullptr, nullptr, nullptr);   // M u_i
+        hipLaunchKernelGGL(k_parabolic_rhs, dim3(g1(n)), dim3(256), 0, st, n, c->s.p, inv_dt, c->force.p + (size_t)(i + 1) * n, rhs.p);
+        if (dirichlet) {
+            to_internal(dirichlet + (size_t)(i + 1) * n);
+            HIPCHK(c, hipMemcpyAsync(gcol.p, tmp.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+        }
+        const int rc = solve_run(c, ss, kmat.p, rhs.p, gcol.p, uprev.p, opt ? opt->method : FDAPDE_SOLVER_AUTO, rtol, maxit,
+                                 check_every, 0);
+        if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;
+        if (rc == FDAPDE_ENOCONV) rc_all = rc;
+        total_iters += c->info.iters;
+        worst = c->info.relres > worst ? c->info.relres : worst;
+        HIPCHK(c, hipMemcpyAsync(uprev.p, c->u.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_scatter_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->u.p, c->tmp_e.p);
+        HIPCHK(c, hipMemcpyAsync(solution + (size_t)(i + 1) * n, c->tmp_e.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
+    HIPCHK(c, hipEventRecord(c->ev1, st));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->info.t_solve_ms = ms, c->info.iters = total_iters, c->info.relres = worst, c->info.converged = rc_all == FDAPDE_OK ? 1 : 0;
+    if (info) *info = c->info;
+    kmat.release(), uprev.release(), rhs.release(), gcol.release();
+    return rc_all;
+}
+
+// Q columns of fdapde_lin_solve at once (kernels_multirhs.h): b_ext / x_ext are Q host columns of n, reference numbering
+template <int Q>
+int lin_solve_batch(fdapde_ctx* c, const double* b_ext, double* x_ext, double rtol, int maxit, int check_every, int* iters,
+                    double* relres, bool* converged) {
+    const HostSpace& hs = c->hs;
+    const int64_t n = hs.n_dofs;
+    hipStream_t st = c->stream;
+    const double tol2 = rtol * rtol;
+    DBuf<double> B, X, R, P, Y, part_spmm, part_rr, sc;
+    const size_t nq = (size_t)n * Q;
+    for (DBuf<double>* b : {&B, &X, &R, &P, &Y}) HIPCHK(c, b->alloc(nq));
+    const int64_t nh = n * (Q / 2);
+    const int grid_v = (int)std::min<int64_t>(std::max<int64_t>(1, (nh + 256 * kQV - 1) / (256 * kQV)), 1024);
+    const int grid_m = (int)std::min<int64_t>((n + 31) / 32, 2048);
+    HIPCHK(c, part_spmm.alloc((size_t)grid_m * 2 * Q));
+    HIPCHK(c, part_rr.alloc((size_t)grid_v * Q));
+    HIPCHK(c, sc.alloc(5 * Q));
+    HIPCHK(c, hipMemcpyAsync(B.p, b_ext, sizeof(double) * nq, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_q_init<Q>, dim3(grid_v), dim3(256), 0, st, n, B.p, c->dof_i2e.p, c->scale.p, X.p, R.p, P.p, part_rr.p);
+    hipLaunchKernelGGL(k_q_init_fin<Q>, dim3(1), dim3(256), 0, st, part_rr.p, grid_v, sc.p, c->ctl.p);
+    int launched = 0;
+    bool stop = false;
+    std::vector<double> h_sc(5 * Q);
+    while (!stop && launched < maxit) {
+        const int chunk = (maxit - launched) < check_every ? (maxit - launched) : check_every;
+        for (int it = 0; it < chunk; ++it, ++launched) {
+            hipLaunchKernelGGL(k_spmm_full<Q>, dim3(grid_m), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, c->lin_sq.p, P.p, Y.p,
+                               part_spmm.p, c->ctl.p);
+            hipLaunchKernelGGL(k_q_scalars<Q>, dim3(1), dim3(256), 0, st, part_spmm.p, grid_m, part_rr.p, grid_v, sc.p, tol2, c->ctl.p);
+            hipLaunchKernelGGL(k_q_update<Q>, dim3(grid_v), dim3(256), 0, st, n, Y.p, P.p, X.p, R.p, sc.p, part_rr.p, c->ctl.p);
+        }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        stop = c->h_ctl[0] != 0;
+    }
+    if (!stop) {   // maxit: one more scalar pass so that sc holds the r.r of the last update
+        hipLaunchKernelGGL(k_spmm_full<Q>, dim3(grid_m), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, c->lin_sq.p, P.p, Y.p, part_spmm.p,
+                           c->ctl.p);
+        hipLaunchKernelGGL(k_q_scalars<Q>, dim3(1), dim3(256), 0, st, part_spmm.p, grid_m, part_rr.p, grid_v, sc.p, tol2, c->ctl.p);
+    }
+    hipLaunchKernelGGL(k_q_unscale<Q>, dim3(g1(n)), dim3(256), 0, st, n, X.p, c->scale.p, c->dof_i2e.p, B.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(x_ext, B.p, sizeof(double) * nq, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(h_sc.data(), sc.p, sizeof(double) * 5 * Q, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    *iters = c->h_ctl[1], *converged = c->h_ctl[2] == 0, *relres = 0;
+    for (int q = 0; q < Q; ++q) {
+        const double bb = h_sc[(size_t)q], rr = h_sc[(size_t)Q + q];
+        const double rel = bb > 0 ? sqrt(rr / bb) : 0.0;
+        *relres = rel > *relres ? rel : *relres;
+        if (!(rr <= tol2 * bb)) *converged = false;
+    }
+    for (DBuf<double>* b : {&B, &X, &R, &P, &Y, &part_spmm, &part_rr, &sc}) b->release();
+    return FDAPDE_OK;
+}
+
+// fdapde::SparseLU<SpMatrix<double>>::compute (fdaPDE/utils/symbols.h:142-146): "factorise" once.  Here: copy the matrix,
+// Jacobi-scale it once; every later fdapde_lin_solve is a Krylov run on the prepared system.
+int e_lin_compute(fdapde_ctx* c, int32_t which, const double* values, int32_t symmetric) {
+    if (!c || which < 0 || which > 1) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (!c->dev_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
+    if (!values && !c->assembled[which]) return fail(c, FDAPDE_ENOTINIT, "matrix not assembled");
+    HIPCHK(c, hipSetDevice(c->device));
+    const HostSpace& hs = c->hs;
+    HIPCHK(c, c->lin_mat.alloc((size_t)hs.nnz + 2));
+    if (values) {   // reference slot order -> internal slots
+        HIPCHK(c, hipMemcpyAsync(c->tmp_v.p, values, sizeof(double) * (size_t)hs.nnz, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_gather_f64, dim3(g1(hs.nnz)), dim3(256), 0, c->stream, hs.nnz, c->slot_i2e.p, c->tmp_v.p, c->lin_mat.p);
+        HIPCHK(c, hipGetLastError());
+        c->lin_symmetric = symmetric != 0;
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->lin_mat.p, c->vals[which].p, sizeof(double) * (size_t)hs.nnz, hipMemcpyDeviceToDevice, c->stream));
+        c->lin_symmetric = which == FDAPDE_MAT_MASS ? true : c->op_symmetric;
+    }
+    if (!c->lin_state) c->lin_state = new SolveStateHolder();
+    c->scaled_owner = fdapde_ctx::kScaledNone;
+    if (int rc = solve_prepare(c, c->lin_mat.p, 0, &c->lin_state->ss, c->lin_symmetric)) return rc;
+    c->scaled_owner = fdapde_ctx::kScaledLin;   // scale / sval now belong to the handle
+    c->lin_ready = true, c->lin_sq_ready = false;
+    return FDAPDE_OK;
+}
+
+// fdapde::SparseLU::solve(b) (fdaPDE/utils/symbols.h:148-155), dense right-hand sides: b, x column-major n_dofs x n_rhs
+int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32_t n_rhs, double* x, fdapde_info* info) {
+    if (!c || !b || !x || n_rhs < 1) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (!c->lin_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_lin_compute first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const HostSpace& hs = c->hs;
+    const int64_t n = hs.n_dofs;
+    hipStream_t st = c->stream;
+    const double rtol = (opt && opt->rtol > 0) ? opt->rtol : 1e-10;
+    const int maxit = (opt && opt->maxit > 0) ? opt->maxit : (int)(10 * n < 100000 ? 10 * n : 100000);
+    const int check_every = (opt && opt->check_every > 0) ? opt->check_every : 32;
+    int method = opt ? opt->method : FDAPDE_SOLVER_AUTO;
+    if (method == FDAPDE_SOLVER_AUTO)
+        method = (c->lin_symmetric && c->lin_state->ss.diag_positive) ? FDAPDE_SOLVER_CG_FUSED : FDAPDE_SOLVER_BICGSTAB;
+    if (c->scaled_owner != fdapde_ctx::kScaledLin) {   // an elliptic / parabolic solve in between has overwritten scale and the scaled copy
+        c->scaled_owner = fdapde_ctx::kScaledNone;      // (whatever init / set_* calls followed it): prepare again (cheap)
+        if (int rc = solve_prepare(c, c->lin_mat.p, 0, &c->lin_state->ss, c->lin_symmetric)) return rc;
+        c->scaled_owner = fdapde_ctx::kScaledLin;
+    }
+    c->solved = false;   // c->u is about to hold the handle's solutions, not PDE::solution()
+    DBuf<double> rhs;
+    HIPCHK(c, rhs.alloc((size_t)n));
+    HIPCHK(c, hipEventRecord(c->ev0, st));
+    int total = 0, rc_all = FDAPDE_OK;
+    double worst = 0;
+    int32_t j0 = 0;
+    // several columns against a symmetric positive system on one GPU: batches of 8 / 4 columns share every pass over the
+    // matrix (kernels_multirhs.h); what is left goes column by column
+    // (a system the persistent CG takes is faster column by column -- one launch each, no vector traffic -- than batched through
+    // the multi-launch SpMM: C3-size, 22.5 ms per column against 32 ms per column in a batch of 8)
+    const bool persist_cols = c->persist && !c->persist_broken && c->ps[0].ok && c->ps[0].filled;
+    const bool batched = c->multi_rhs && n_rhs >= 4 && method == FDAPDE_SOLVER_CG_FUSED && !c->lin_state->ss.dist && !c->lin_state->ss.rowdist && !persist_cols;
+    if (batched) {
+        if (!c->lin_sq_ready) {   // full-pattern scaled copy (explicit unit diagonal), once per prepared matrix
+            HIPCHK(c, c->lin_sq.alloc((size_t)hs.nnz + 2));
+            hipLaunchKernelGGL(k_scale_matrix, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, c->lin_mat.p, c->scale.p,
+                               c->lin_sq.p);
+            c->lin_sq_ready = true;
+        }
+        while (n_rhs - j0 >= 4) {   // pairs are faster column by column (C3-size system: 77 ms against 92 ms batched)
+            const int q = n_rhs - j0 >= 8 ? 8 : 4;
+            int its = 0, rc = FDAPDE_OK;
+            double rel = 0;
+            bool ok = true;
+            if (q == 8) rc = lin_solve_batch<8>(c, b + (size_t)j0 * n, x + (size_t)j0 * n, rtol, maxit, check_every, &its, &rel, &ok);
+            else rc = lin_solve_batch<4>(c, b + (size_t)j0 * n, x + (size_t)j0 * n, rtol, maxit, check_every, &its, &rel, &ok);
+            if (rc != FDAPDE_OK) return rc;
+            if (!ok) rc_all = FDAPDE_ENOCONV;
+            total += its, worst = rel > worst ? rel : worst;
+            c->info.method_used = method;
+            j0 += q;
+        }
+    }
+    for (int32_t j = j0; j < n_rhs; ++j) {
+        HIPCHK(c, hipMemcpyAsync(c->tmp_e.p, b + (size_t)j * n, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_gather_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->tmp_e.p, rhs.p);
+        const int rc = solve_run(c, c->lin_state->ss, c->lin_mat.p, rhs.p, c->g.p, nullptr, method, rtol, maxit, check_every, 0);
+        if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;
+        if (rc == FDAPDE_ENOCONV) rc_all = rc;
+        total += c->info.iters, worst = c->info.relres > worst ? c->info.relres : worst;
+        hipLaunchKernelGGL(k_scatter_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->u.p, c->tmp_e.p);
+        HIPCHK(c, hipMemcpyAsync(x + (size_t)j * n, c->tmp_e.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
+    HIPCHK(c, hipEventRecord(c->ev1, st));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->info.t_solve_ms = ms, c->info.iters = total, c->info.relres = worst, c->info.converged = rc_all == FDAPDE_OK ? 1 : 0;
+    if (info) *info = c->info;
+    rhs.release();
+    return rc_all;
+}
+
+int e_matrix_values(fdapde_ctx* c, int32_t which, double* values) {
+    if (!c || !values || which < 0 || which > 1) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (!c->dev_ready || !c->assembled[which]) return fail(c, FDAPDE_ENOTINIT, "matrix not assembled");
+    HIPCHK(c, hipSetDevice(c->device));
+    const HostSpace& hs = c->hs;
+    const int zero_rows = (which == FDAPDE_MAT_STIFF && c->dirichlet_applied) ? 1 : 0;
+    hipLaunchKernelGGL(k_export_values, dim3(g1(hs.n_dofs * 16)), dim3(256), 0, c->stream, hs.n_dofs, c->rowptr.p, c->colidx.p,
+                       c->vals[which].p, c->slot_i2e.p, c->bnd.p, zero_rows, c->tmp_v.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(values, c->tmp_v.p, sizeof(double) * (size_t)hs.nnz, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FDAPDE_OK;
+}
+
+// lump(stiff() | mass()) (fdaPDE/linear_algebra/lumping.h:30-41): the diagonal of the row-sum lumped matrix, reference numbering
+int e_lump(fdapde_ctx* c, int32_t which, double* diag) {
+    if (!c || !diag || which < 0 || which > 1) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (!c->dev_ready || !c->assembled[which]) return fail(c, FDAPDE_ENOTINIT, "matrix not assembled");
+    HIPCHK(c, hipSetDevice(c->device));
+    const HostSpace& hs = c->hs;
+    hipLaunchKernelGGL(k_row_sums, dim3(g1(hs.n_dofs * 16)), dim3(256), 0, c->stream, hs.n_dofs, c->rowptr.p, c->vals[which].p, c->tmp_i.p);
+    hipLaunchKernelGGL(k_scatter_f64, dim3(g1(hs.n_dofs)), dim3(256), 0, c->stream, hs.n_dofs, c->dof_i2e.p, c->tmp_i.p, c->tmp_e.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(diag, c->tmp_e.p, sizeof(double) * (size_t)hs.n_dofs, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FDAPDE_OK;
+}
+
+int e_force(fdapde_ctx* c, double* force) {
+    if (!c || !force) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (!c->dev_ready || !c->force_ready) return fail(c, FDAPDE_ENOTINIT, "force not assembled");
+    HIPCHK(c, hipSetDevice(c->device));
+    const HostSpace& hs = c->hs;
+    const int cols = c->fq_cols > 0 ? c->fq_cols : 1;
+    for (int col = 0; col < cols; ++col) {
+        HIPCHK(c, hipMemcpyAsync(c->tmp_i.p, c->force.p + (size_t)col * hs.n_dofs, sizeof(double) * (size_t)hs.n_dofs,
+                                 hipMemcpyDeviceToDevice, c->stream));
+        if (col == 0 && c->dirichlet_applied)
+            hipLaunchKernelGGL(k_force_bc, dim3(g1(hs.n_dofs)), dim3(256), 0, c->stream, hs.n_dofs, c->bnd.p, c->g.p, c->tmp_i.p);
+        hipLaunchKernelGGL(k_scatter_f64, dim3(g1(hs.n_dofs)), dim3(256), 0, c->stream, hs.n_dofs, c->dof_i2e.p, c->tmp_i.p, c->tmp_e.p);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(force + (size_t)col * hs.n_dofs, c->tmp_e.p, sizeof(double) * (size_t)hs.n_dofs,
+                                 hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return FDAPDE_OK;
+}
+
+int e_solution(fdapde_ctx* c, double* solution) {
+    if (!c || !solution) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (!c->solved) return fail(c, FDAPDE_ENOTINIT, "no solution: call fdapde_solve first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const HostSpace& hs = c->hs;
+    hipLaunchKernelGGL(k_scatter_f64, dim3(g1(hs.n_dofs)), dim3(256), 0, c->stream, hs.n_dofs, c->dof_i2e.p, c->u.p, c->tmp_e.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(solution, c->tmp_e.p, sizeof(double) * (size_t)hs.n_dofs, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FDAPDE_OK;
+}
+
+int e_spmv(fdapde_ctx* c, int32_t which, const double* x, double* y) {
+    if (!c || !x || !y || which < 0 || which > 1) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (!c->dev_ready || !c->assembled[which]) return fail(c, FDAPDE_ENOTINIT, "matrix not assembled");
+    HIPCHK(c, hipSetDevice(c->device));
+    const HostSpace& hs = c->hs;
+    const size_t bytes = sizeof(double) * (size_t)hs.n_dofs;
+    HIPCHK(c, hipMemcpyAsync(c->tmp_e.p, x, bytes, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_gather_f64, dim3(g1(hs.n_dofs)), dim3(256), 0, c->stream, hs.n_dofs, c->dof_i2e.p, c->tmp_e.p, c->tmp_i.p);
+    launch_spmv(c, c->vals[which].p, c->tmp_i.p, c->t.p, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL(k_scatter_f64, dim3(g1(hs.n_dofs)), dim3(256), 0, c->stream, hs.n_dofs, c->dof_i2e.p, c->t.p, c->tmp_e.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(y, c->tmp_e.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FDAPDE_OK;
+}
+
+int e_bench_spmv(fdapde_ctx* c, int32_t reps, double* avg_ms, double* algorithmic_bytes) {
+    if (!c || reps < 1) return FDAPDE_EINVAL;
+    if (int rc = need_device(c)) return rc;
+    if (!c->dev_ready || !c->assembled[0]) return fail(c, FDAPDE_ENOTINIT, "matrix not assembled");
+    HIPCHK(c, hipSetDevice(c->device));
+    const HostSpace& hs = c->hs;
+    // the launch timed here is the one inside CG: scaled matrix stream, fused p.Ap partials
+    const double* A = (c->solved && c->scaled_owner == fdapde_ctx::kScaledSolve) ? c->sval.p : c->vals[0].p;
+    hipLaunchKernelGGL(k_fill_f64, dim3(g1(hs.n_dofs)), dim3(256), 0, c->stream, hs.n_dofs, 1.0, c->tmp_i.p);
+    for (int i = 0; i < 3; ++i) launch_spmv(c, A, c->tmp_i.p, c->t.p, c->tmp_i.p, c->part_a.p, nullptr);
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < reps; ++i) launch_spmv(c, A, c->tmp_i.p, c->t.p, c->tmp_i.p, c->part_a.p, nullptr);
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (std::getenv("FDAPDE_READ_PROBE")) {   // diagnostic: pure read stream of the matrix arrays, same stream, HIP events
+        const int64_t n16 = ((int64_t)hs.nnz * 8) / 16;
+        for (int grid : {1024, 2048, 4096, 8192}) {
+            hipLaunchKernelGGL(k_read_probe, dim3(grid), dim3(256), 0, c->stream, reinterpret_cast<const double2*>(A), n16, c->tmp_i.p);
+            HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+            for (int i = 0; i < 20; ++i)
+                hipLaunchKernelGGL(k_read_probe, dim3(grid), dim3(256), 0, c->stream, reinterpret_cast<const double2*>(A), n16, c->tmp_i.p);
+            HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+            HIPCHK(c, hipEventSynchronize(c->ev1));
+            float pm = 0;
+            HIPCHK(c, hipEventElapsedTime(&pm, c->ev0, c->ev1));
+            std::fprintf(stderr, "read_probe grid=%d: %.1f MB in %.2f us -> %.0f GB/s\n", grid, n16 * 16 / 1e6, pm / 20 * 1e3,
+                         n16 * 16 / (pm / 20 * 1e-3) / 1e9);
+        }
+    }
+    if (std::getenv("FDAPDE_STREAM_PROBE")) {   // diagnostic: the matrix arrays streamed once, nothing else
+        const int64_t n2 = (int64_t)hs.nnz / 2;
+        for (int grid : {2048, 8192}) {
+            hipLaunchKernelGGL(k_stream_probe, dim3(grid), dim3(256), 0, c->stream, reinterpret_cast<const double2*>(A),
+                               reinterpret_cast<const int2*>(c->colidx.p), n2, c->tmp_i.p);
+            HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+            for (int i = 0; i < 50; ++i)
+                hipLaunchKernelGGL(k_stream_probe, dim3(grid), dim3(256), 0, c->stream, reinterpret_cast<const double2*>(A),
+                                   reinterpret_cast<const int2*>(c->colidx.p), n2, c->tmp_i.p);
+            HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+            HIPCHK(c, hipEventSynchronize(c->ev1));
+            float pm = 0;
+            HIPCHK(c, hipEventElapsedTime(&pm, c->ev0, c->ev1));
+            std::fprintf(stderr, "stream_probe grid=%d: %.1f MB in %.2f us -> %.0f GB/s\n", grid, n2 * 24 / 1e6, pm / 50 * 1e3,
+                         n2 * 24 / (pm / 50 * 1e-3) / 1e9);
+            HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+            for (int i = 0; i < 50; ++i)
+                hipLaunchKernelGGL(k_stream_probe_unaligned, dim3(grid), dim3(256), 0, c->stream, A,
+                                   reinterpret_cast<const int2*>(c->colidx.p), n2, c->tmp_i.p);
+            HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+            HIPCHK(c, hipEventSynchronize(c->ev1));
+            HIPCHK(c, hipEventElapsedTime(&pm, c->ev0, c->ev1));
+            std::fprintf(stderr, "stream_probe_unaligned grid=%d: %.2f us -> %.0f GB/s\n", grid, pm / 50 * 1e3,
+                         n2 * 24 / (pm / 50 * 1e-3) / 1e9);
+            HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+            for (int i = 0; i < 50; ++i)
+                hipLaunchKernelGGL(k_stream_probe_w, dim3(grid), dim3(256), 0, c->stream, reinterpret_cast<const double2*>(A),
+                                   reinterpret_cast<const int2*>(c->colidx.p), n2, c->tmp_v.p);
+            HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+            HIPCHK(c, hipEventSynchronize(c->ev1));
+            HIPCHK(c, hipEventElapsedTime(&pm, c->ev0, c->ev1));
+            std::fprintf(stderr, "stream_probe + %.1f MB of writes grid=%d: %.2f us\n", n2 / 8 * 8 / 1e6, grid, pm / 50 * 1e3);
+        }
+    }
+    if (avg_ms) *avg_ms = (double)ms / reps;
+    if (algorithmic_bytes) *algorithmic_bytes = 12.0 * (double)hs.nnz + 4.0 * (double)(hs.n_dofs + 1) + 16.0 * (double)hs.n_dofs;
+    return FDAPDE_OK;
+}
+
+
+// the unit's code object is loaded when one of its kernels is first looked up (HIP defers it): done at context creation, so that the
+// first solve of a process does not pay for it (6 ms for the smoke problem after the library was split into units)
+void preload_solve() {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_jacobi_scale));
+    (void)hipGetLastError();
+}
+
+}   // namespace fdapde_engine

@@ -46,6 +46,65 @@ inline unsigned grid1(int64_t n, int per = 256) { return (unsigned)((n + per - 1
 enum { kHostPattern = 1, kHostCells = 2, kHostRefPattern = 4, kHostDofs = 8 };
 int ensure_host(fdapde_ctx* c, int what);
 
+inline unsigned g1(int64_t n, int per = 256) { return (unsigned)((n + per - 1) / per); }
+
+#define RCCLCHK(ctx, expr)                                                                   \
+    do {                                                                                     \
+        ncclResult_t r__ = (expr);                                                           \
+        if (r__ != ncclSuccess) {                                                            \
+            (ctx)->err = std::string(#expr) + ": " + g_rccl.GetErrorString(r__);             \
+            return FDAPDE_ERCCL;                                                             \
+        }                                                                                    \
+    } while (0)
+
+// ---- helpers one engine unit offers the others ---------------------------------------------------------------------------------------
+void drop_graph(fdapde_ctx* c);                                            // eng_solve.hip: the captured CG chunk bakes pointers and sizes in
+int allreduce_sum(fdapde_ctx* c, double* buf, size_t count);               // eng_dist.hip: device buffer summed over the ranks
+int halo_sum(fdapde_ctx* c, double* v, const double* part, int np, bool unpack = true);   // eng_dist.hip: interface entries summed over the sharing ranks
+
+// ---- the bodies behind the C ABI (capi.hip forwards to them; each unit's header comment says what it holds) ----------------------------
+int e_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs);
+int e_topology_build(fdapde_ctx* c, int64_t* n_facets, int64_t* n_edges);
+int e_topology_get(fdapde_ctx* c, int32_t* neighbors, int32_t* cell_facets, int32_t* facet_nodes, int32_t* facet_cells, uint8_t* facet_boundary, int32_t* edge_nodes, uint8_t* edge_boundary, int32_t* face_edges);
+int e_dofs_set_boundary(fdapde_ctx* c, const uint8_t* bnd);
+int e_dofs_get(const fdapde_ctx* c, int32_t* dofs, uint8_t* bnd, double* coords);
+int e_pattern_get(const fdapde_ctx* c, int32_t* rowptr, int32_t* colidx);
+int e_quadrature_nodes(fdapde_ctx* c, double* out);
+int e_set_operator(fdapde_ctx* c, int32_t n_terms, const fdapde_term* terms);
+int e_set_forcing(fdapde_ctx* c, const double* f_q, int32_t n_cols);
+int e_set_dirichlet(fdapde_ctx* c, const double* g);
+int e_assemble_operator(fdapde_ctx* c, int32_t which, int32_t n_terms, const fdapde_term* terms, int32_t assembly);
+int e_init(fdapde_ctx* c, const fdapde_options* opt);
+int e_eval_pointwise(fdapde_ctx* c, int64_t n_locs, const double* locs_colmajor, int32_t* cell_ids, double* values);
+int e_cell_integrals(fdapde_ctx* c, double* measure, double* psi_int);
+int e_solver_prepare(fdapde_ctx* c, int32_t with_dirichlet);
+int e_solver_layout(fdapde_ctx* c, int32_t with_dirichlet, int64_t* n_interior, int64_t* nnz_interior, double* streamed_bytes);
+int e_solver_layout_kind(fdapde_ctx* c, int32_t with_dirichlet, int32_t* kind, int32_t* symmetric_storage, int32_t* workgroups, int32_t* rows_per_thread);
+int e_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info);
+int e_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times, double delta_t, const double* initial_condition, const double* dirichlet, double* solution, fdapde_info* info);
+int e_lin_compute(fdapde_ctx* c, int32_t which, const double* values, int32_t symmetric);
+int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32_t n_rhs, double* x, fdapde_info* info);
+int e_matrix_values(fdapde_ctx* c, int32_t which, double* values);
+int e_lump(fdapde_ctx* c, int32_t which, double* diag);
+int e_force(fdapde_ctx* c, double* force);
+int e_solution(fdapde_ctx* c, double* solution);
+int e_spmv(fdapde_ctx* c, int32_t which, const double* x, double* y);
+int e_bench_spmv(fdapde_ctx* c, int32_t reps, double* avg_ms, double* algorithmic_bytes);
+int e_comm_unique_id(void* out128);
+int e_comm_init(fdapde_ctx* c, int32_t world, int32_t rank, const void* unique_id128);
+int e_comm_allreduce(fdapde_ctx* c, double* host_inout, int32_t n, int32_t op);
+int e_comm_init_callback(fdapde_ctx* c, int32_t world, int32_t rank, fdapde_allreduce_fn fn, void* user);
+int e_halo_setup(fdapde_ctx* c, int64_t n_if_global, int64_t n_if_local, const int32_t* local_dof, const int32_t* if_index, const uint8_t* owned);
+int e_rowdist_setup(fdapde_ctx* c, const int64_t* dof_key, const int32_t* dof_owner);
+int e_comm_set_exchange_callback(fdapde_ctx* c, fdapde_exchange_fn fn, void* user);
+int e_halo_setup_peers(fdapde_ctx* c, int32_t n_peers, const int32_t* peer_rank, const int64_t* peer_off, const int32_t* peer_dof, const uint8_t* owned);
+
+// code objects of the units loaded up front (fdapde_ctx_create)
+void preload_assembly();
+void preload_solve();
+void preload_dist();
+void preload_persist();
+
 // ---- single-launch solver (persist_engine.hip) -----------------------------------------------------------------------------------
 // layout of boundary variant v, built on first use (ps.tried / ps.ok tell the outcome)
 int build_persist(fdapde_ctx* c, int v);

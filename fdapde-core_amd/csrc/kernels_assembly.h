@@ -63,6 +63,7 @@ struct AsmArgs {
     const DevTables* tables;
     const DevRefTensors* reftab;   // OPK 3 only
     double* vals;              // CSR values (internal slots) or nullptr
+    double* vals2;             // k_assemble_rows<..., MASS2 = true>: the mass matrix, accumulated in the same sweep over the visits
     const double* fq;          // forcing at quadrature nodes, internal cell order, or nullptr
     int fq_block;              // k_assemble_rows only.  1: fq holds one load coefficient per visit slot (k_visit_load_coeffs);
                                // 2: fq holds the samples in block-cell order (row group = block-cell index)
@@ -353,8 +354,12 @@ __device__ __forceinline__ const DevTables* stage_tables(const DevTables* gsrc, 
 // (j,i) sum the same products over the same cells in the same order).
 // Replaces Assembler::discretize_operator + discretize_forcing (fdaPDE/finite_elements/fem_assembler.h:52-136).
 // ---------------------------------------------------------------------------------------------------------------
-template <int M, int R, int OPK>
-__global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op) {
+// MASS2: FEMSolverBase::init assembles the operator, the forcing AND the mass matrix (fem_solver_base.h:113-136); the three share every
+// index stream of the visit loop and the cell geometry, so the mass rows are accumulated in the same sweep (second accumulator range in
+// LDS; a visit's mass row is |e| times a tabulated reference row: NB multiply-adds).  Same visits in the same order as the separate mass
+// sweep: the same bits.
+template <int M, int R, int OPK, bool MASS2 = false>
+static __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op) {
     constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
     constexpr int NBW = (NB * 2 + 3) / 4;
     constexpr int NP = M == 2 ? 2 : 3;   // doubles per staged vertex in LDS (unpadded: C3 blocks then fit three to a CU, not two)
@@ -375,6 +380,7 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
         xyz += kRefDoubles;
     }
     double* acc = xyz + (int64_t)a.lds_nodes * NP;            // the block's CSR value range
+    double* acc2 = acc + a.lds_acc_cap;                       // ... of the mass matrix (MASS2; the host made sure both ranges fit)
 
     const int64_t row0 = blk * kAsmBlock;
     const int64_t pos = row0 + threadIdx.x;   // lane position; the adjacency slices are laid out by position
@@ -405,6 +411,8 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
     if (want_matrix) {
         if (in_lds) {
             for (int k = threadIdx.x; k < blk_nnz; k += kAsmBlock) acc[k] = 0.0;
+            if constexpr (MASS2)
+                for (int k = threadIdx.x; k < blk_nnz; k += kAsmBlock) acc2[k] = 0.0;
         } else {
             for (int k = my0; k < my1; ++k) a.vals[k] = 0.0;
         }
@@ -462,17 +470,28 @@ __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op
                 else
                     a.vals[my0 + (int32_t)slot] += value;
             }, rt, fblk ? bc : (int64_t)-1, fc, fbc ? bc : (int64_t)-1);
+            if constexpr (MASS2) {   // (OPK 2's own formula with coefficient 1: cm = 1.0 * 1.0 * |e|)
+                const double cm = 1.0 * 1.0 * g.measure;
+                const int il = code & 15;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const uint32_t slot = (sw[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+                    acc2[my0 - base + (int32_t)slot] += cm * tb->mtab[il * NB + j];
+                }
+            }
         }
     }
     if (a.force != nullptr && row < a.n_dofs) a.force[row] = fsum;
     if (want_matrix && in_lds) {
         __syncthreads();
         for (int k = threadIdx.x; k < blk_nnz; k += kAsmBlock) a.vals[base + k] = acc[k];
+        if constexpr (MASS2)
+            for (int k = threadIdx.x; k < blk_nnz; k += kAsmBlock) a.vals2[base + k] = acc2[k];
     }
 }
 
 // dst row group b (nq doubles) = src row group idx[b]: forcing samples from the caller's cell order to the internal one
-__global__ __launch_bounds__(256) void k_gather_row_groups(int64_t n, int nq, const int32_t* idx, const double* src, double* dst) {
+static __global__ __launch_bounds__(256) void k_gather_row_groups(int64_t n, int nq, const int32_t* idx, const double* src, double* dst) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * nq) return;
     const int64_t b = i / nq, q = i - b * nq;
@@ -484,7 +503,7 @@ __global__ __launch_bounds__(256) void k_gather_row_groups(int64_t n, int nq, co
 // -- the (cell, il) entry of the cell's load vector without |e| (integrator.h:73-90), summed in the order element_row uses.  The
 // row-owner kernel then streams one coalesced double per visit next to its adjacency word instead of gathering samples by cell id.
 // Built once per fdapde_set_forcing; one workgroup of 8 wavefronts per slice, wavefront y takes the visits y, y + 8, ...
-__global__ __launch_bounds__(512) void k_visit_load_coeffs(int64_t n_slices, int nq, const int64_t* sl_off, const int32_t* adj,
+static __global__ __launch_bounds__(512) void k_visit_load_coeffs(int64_t n_slices, int nq, const int64_t* sl_off, const int32_t* adj,
                                                           const int64_t* bc_off, const int32_t* bc_cell, const double* src,
                                                           const DevTables* tab, double* dst) {
     const int64_t s = blockIdx.x;
@@ -513,7 +532,7 @@ __global__ __launch_bounds__(512) void k_visit_load_coeffs(int64_t n_slices, int
 // vals must be zeroed before the first launch.
 // ---------------------------------------------------------------------------------------------------------------
 template <int M, int R, bool ATOMIC>
-__global__ __launch_bounds__(256) void k_assemble_scatter(AsmArgs a, DevOp op, const int32_t* cell_list, int64_t n_list) {
+static __global__ __launch_bounds__(256) void k_assemble_scatter(AsmArgs a, DevOp op, const int32_t* cell_list, int64_t n_list) {
     constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
     extern __shared__ double lds[];
     const DevTables* tb = stage_tables(a.tables, lds);
@@ -558,7 +577,7 @@ __global__ __launch_bounds__(256) void k_assemble_scatter(AsmArgs a, DevOp op, c
 //   not be seen by a neighbour's cached read-modify-write).  One launch; vals / force zeroed by the caller.
 // ---------------------------------------------------------------------------------------------------------------
 template <int M, int R, int OPK>
-__global__ __launch_bounds__(256) void k_assemble_part(AsmArgs a, DevOp op, const int32_t* cell_list, const int32_t* colour_off,
+static __global__ __launch_bounds__(256) void k_assemble_part(AsmArgs a, DevOp op, const int32_t* cell_list, const int32_t* colour_off,
                                                         int max_colours, const uint8_t* dof_shared, const int32_t* slot_map) {
     constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
     extern __shared__ double lds[];
@@ -601,7 +620,7 @@ __global__ __launch_bounds__(256) void k_assemble_part(AsmArgs a, DevOp op, cons
 //   lanes, the lanes with q = 0 add their entry through the streamed slot map.  Launched once per colour over colour-contiguous
 //   cell lists (cells of a colour share no DOF: plain read-modify-write, no atomics).  P1 only (a P2 element has 500+ triples).
 template <int M>
-__global__ __launch_bounds__(256) void k_assemble_wave(AsmArgs a, DevOp op, const int32_t* cell_list, const int32_t* slot_map,
+static __global__ __launch_bounds__(256) void k_assemble_wave(AsmArgs a, DevOp op, const int32_t* cell_list, const int32_t* slot_map,
                                                         int64_t n_list) {
     constexpr int NB = M + 1, NQ = (M == 2) ? 3 : 4;
     extern __shared__ double lds[];
@@ -633,7 +652,7 @@ __global__ __launch_bounds__(256) void k_assemble_wave(AsmArgs a, DevOp op, cons
 
 // Integrator::quadrature_nodes (integrator.h:109-121): out row nq*cell_ext + q = J p_q + x0, column-major rows x N
 template <int M>
-__global__ void k_quadrature_nodes(AsmArgs a, const int32_t* cell_i2e, int nq, double* out) {
+static __global__ void k_quadrature_nodes(AsmArgs a, const int32_t* cell_i2e, int nq, double* out) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= a.n_cells * nq) return;
     const int64_t ci = idx / nq;
@@ -679,7 +698,7 @@ template <int M, int R> __device__ __forceinline__ void eval_ref_basis(const dou
 // bin and takes the first one whose barycentric coordinates are all >= -tol (Simplex::contains, geometry/simplex.h:118-131).
 // cell_out: reference cell id or -1; values: n_basis basis values psi_h(invJ (p - x0)) per location.
 template <int M, int R>
-__global__ void k_eval_pointwise(AsmArgs a, int64_t n_locs, const double* locs /*col-major n_locs x M*/, const double* lo,
+static __global__ void k_eval_pointwise(AsmArgs a, int64_t n_locs, const double* locs /*col-major n_locs x M*/, const double* lo,
                                  const double* inv_h, const int32_t* dims, const int32_t* bin_ptr, const int32_t* bin_cells,
                                  const int32_t* cell_i2e, double tol, int32_t* cell_out, double* values) {
     constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
@@ -733,7 +752,7 @@ __global__ void k_eval_pointwise(AsmArgs a, int64_t n_locs, const double* locs /
 //   int_e psi_h = measure * sum_q w_q psi_h(p_q)   (Integrator::integrate_cell, utils/integration/integrator.h:47-63)
 // -- the ingredients of areal_evaluation::eval (basis/lagrangian_basis.h:238-283)
 template <int M>
-__global__ void k_cell_integrals(AsmArgs a, int nb, int nq, const int32_t* cell_i2e, double* measure, double* psi_int) {
+static __global__ void k_cell_integrals(AsmArgs a, int nb, int nq, const int32_t* cell_i2e, double* measure, double* psi_int) {
     const int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (ci >= a.n_cells) return;
     Geo<M> g;

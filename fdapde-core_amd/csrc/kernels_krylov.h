@@ -25,7 +25,7 @@ __device__ __forceinline__ double jacobi_scale_of(double d) {
 // Single GPU: a diagonal that is tiny against its row (|d| <= 1e-8 max_j |a_ij|: rounding-level diagonals of pure advection,
 // where int psi_i b.grad psi_i vanishes over an interior patch) is treated like a zero one, and the row is scaled by its largest
 // entry instead, so that the scaled system stays O(1).
-__global__ __launch_bounds__(256) void k_jacobi_scale(int64_t n, const int32_t* rowptr, const int32_t* diag, const double* vals,
+static __global__ __launch_bounds__(256) void k_jacobi_scale(int64_t n, const int32_t* rowptr, const int32_t* diag, const double* vals,
                                                       const uint8_t* bnd, int use_bnd, double* scale, int32_t* flag) {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;   // 16 lanes per row: the row's entries are read coalesced
     const int l = threadIdx.x & 15;
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_jacobi_scale(int64_t n, const int32_t* 
 }
 // At = diag(scale) A diag(scale): symmetric Jacobi scaling == Jacobi preconditioning folded into the matrix stream.
 // Rows and columns of Dirichlet DOFs vanish (scale = 0), which restricts the Krylov iteration to the interior block.
-__global__ __launch_bounds__(256) void k_scale_matrix(int64_t n, const int32_t* rowptr, const int32_t* colidx,
+static __global__ __launch_bounds__(256) void k_scale_matrix(int64_t n, const int32_t* rowptr, const int32_t* colidx,
                                                       const double* vals, const double* scale, double* out) {
     const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;   // 16 lanes per row
     const int l = threadIdx.x & 15;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_scale_matrix(int64_t n, const int32_t* 
 }
 // the same into the compact solver matrix: entries with map[k] < 0 are dropped (the diagonal, which scales to exactly 1,
 // and every entry in a row or column of a Dirichlet DOF, which scales to exactly 0)
-__global__ __launch_bounds__(256) void k_scale_matrix_compact(int64_t n, const int32_t* rowptr, const int32_t* colidx,
+static __global__ __launch_bounds__(256) void k_scale_matrix_compact(int64_t n, const int32_t* rowptr, const int32_t* colidx,
                                                               const double* vals, const double* scale, const int32_t* map,
                                                               double* out) {
     const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_scale_matrix_compact(int64_t n, const i
     }
 }
 // gt = g on Dirichlet DOFs, 0 elsewhere (or all zero without Dirichlet data)
-__global__ void k_lift(int64_t n, const uint8_t* bnd, const double* g, int use_bnd, double* gt) {
+static __global__ void k_lift(int64_t n, const uint8_t* bnd, const double* g, int use_bnd, double* gt) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) gt[i] = (use_bnd && bnd[i]) ? g[i] : 0.0;
 }
@@ -78,7 +78,7 @@ __global__ void k_lift(int64_t n, const uint8_t* bnd, const double* g, int use_b
 // Cold start (u0 == nullptr): x = 0, r = bt.  Warm start: x = (u0 - gt) / scale on interior DOFs, r = bt - ax where ax holds
 // At x (one extra SpMV by the caller between the two launches: first launch with ax == nullptr only fills x).
 // partial[2 b] = sum r^2, partial[2 b + 1] = sum bt^2 (the stopping rule is relative to ||bt||, not to the warm residual).
-__global__ __launch_bounds__(256) void k_krylov_init(int64_t n, const double* f, const double* y, const double* scale,
+static __global__ __launch_bounds__(256) void k_krylov_init(int64_t n, const double* f, const double* y, const double* scale,
                                                       double* x, double* r, double* p, double* r0, double* partial,
                                                       const uint8_t* owned, const double* u0, const double* gt,
                                                       const double* ax, int fill_x_only) {
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_krylov_init(int64_t n, const double* f,
 // ctl layout (device int32): [0] stop flag, [1] iterations done, [2] breakdown flag
 // seed (optional): the fused-update CG reads its explicit r.r from n_seed per-workgroup partials; they are seeded with
 // (rr, 0, 0, ...) so that its first launch needs no special case (and the launch sequence can be replayed as a graph)
-__global__ __launch_bounds__(256) void k_krylov_init_fin(const double* partial, int np, double* sc, int32_t* ctl, double tol2,
+static __global__ __launch_bounds__(256) void k_krylov_init_fin(const double* partial, int np, double* sc, int32_t* ctl, double tol2,
                                                          double* seed, int n_seed) {
     __shared__ double red[8];
     double a = 0, b = 0;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_krylov_init_fin(const double* partial, 
     }
 }
 // out[0], out[1] = sums of the stride-2 partial pairs, fixed order; single workgroup
-__global__ __launch_bounds__(256) void k_reduce_partials2(const double* part, int np, double* out) {
+static __global__ __launch_bounds__(256) void k_reduce_partials2(const double* part, int np, double* out) {
     __shared__ double red[8];
     double a = 0, b = 0;
     for (int i = threadIdx.x; i < np; i += blockDim.x) a += part[2 * i], b += part[2 * i + 1];
@@ -132,12 +132,12 @@ __global__ __launch_bounds__(256) void k_reduce_partials2(const double* part, in
     if (threadIdx.x == 0) out[0] = sa, out[1] = sb;
 }
 // K = M / dt + A  (FEMLinearParabolicSolver::solve, fem_linear_parabolic_solver.h:49), same pattern, elementwise
-__global__ void k_matrix_combine(int64_t nnz, const double* mass, const double* stiff, double inv_dt, double* out) {
+static __global__ void k_matrix_combine(int64_t nnz, const double* mass, const double* stiff, double inv_dt, double* out) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k < nnz) out[k] = mass[k] * inv_dt + stiff[k];
 }
 // rhs = mu * inv_dt + f   (mu = M u_i)
-__global__ void k_parabolic_rhs(int64_t n, const double* mu, double inv_dt, const double* f, double* rhs) {
+static __global__ void k_parabolic_rhs(int64_t n, const double* mu, double inv_dt, const double* f, double* rhs) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) rhs[i] = mu[i] * inv_dt + f[i];
 }
@@ -154,7 +154,7 @@ __global__ void k_parabolic_rhs(int64_t n, const double* mu, double inv_dt, cons
 // reduction hides under the loads instead of delaying them (measured per-kernel saving ~2 us of 17 / 9 us).
 constexpr int kCgV = 4;
 // owned (multi-GPU): 1 for DOFs this rank counts in global dot products, nullptr = all (single GPU)
-__global__ __launch_bounds__(256) void k_cg_update_xr(int64_t n, const double* y, double* r, const double* part_in, int np_in,
+static __global__ __launch_bounds__(256) void k_cg_update_xr(int64_t n, const double* y, double* r, const double* part_in, int np_in,
                                                        double* part_out, double* sc, int parity, int32_t* ctl,
                                                        const uint8_t* owned) {
     __shared__ double red[8];
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void k_cg_update_xr(int64_t n, const double* y
     const double s = block_sum(acc, red);
     if (threadIdx.x == 0) part_out[blockIdx.x] = s;
 }
-__global__ __launch_bounds__(256) void k_cg_update_p(int64_t n, const double* r, double* p, double* x, const double* part_in,
+static __global__ __launch_bounds__(256) void k_cg_update_p(int64_t n, const double* r, double* p, double* x, const double* part_in,
                                                       int np_in, double* sc, int parity, double tol2, int32_t* ctl) {
     __shared__ double red[8];
     if (__syncthreads_or(ctl[0] != 0)) return;   // uniform even if another workgroup raises the flag meanwhile
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void k_cg_update_p(int64_t n, const double* r,
 // Every workgroup takes the stop decision from the same reduced numbers, so no workgroup updates past convergence.
 // if_slot / hb (multi-GPU, else nullptr): rows with if_slot[row] >= 0 take w from the all-reduced interface buffer hb, which
 // saves the separate unpack launch (w itself is not read again)
-__global__ __launch_bounds__(256) void k_cgsr_update(int64_t n, double* r, const double* w, double* p, double* s, double* x,
+static __global__ __launch_bounds__(256) void k_cgsr_update(int64_t n, double* r, const double* w, double* p, double* s, double* x,
                                                       const double* part_in, int np_in, double* sc, int parity, int first,
                                                       double tol2, int32_t* ctl, const int32_t* if_slot, const double* hb,
                                                       int64_t band2) {
@@ -356,7 +356,7 @@ constexpr double kLazyBeta = 0.25;
 // kSplit (knob cgf_split): the second half of the lane's elements is requested only after the scalars are known, so that its
 // loads are in flight while the first half is stored (read and write phases of the launch overlap).
 template <int kCgV, int kSplit = 0>
-__global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, double* p, double* x, double* r,
+static __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, double* p, double* x, double* r,
                                                      const double* part_spmv, int np_spmv, const double* part_rr_in, int np_rr,
                                                      double* part_rr_out, double* sc, double tol2, int32_t* ctl, int64_t band2,
                                                      int nt, int lazy, int parity) {
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(256) void k_cgf_update(int64_t n, const double* y, 
     }
 }
 // after the iteration loop: an update of x may still be pending (convergence seen by k_cgf_fin, or maxit)
-__global__ __launch_bounds__(256) void k_cgf_flush(int64_t n, const double* p, const double* r, double* x, double* sc, const int32_t* ctl) {
+static __global__ __launch_bounds__(256) void k_cgf_flush(int64_t n, const double* p, const double* r, double* x, double* sc, const int32_t* ctl) {
     const int parity = ctl[1] & 1;   // the launch after the last executed update would have had this parity
     if (sc[16 + parity] == 0.0 || sc[18] != 0.0) return;   // nothing pending, or already applied by the launch that saw convergence
     const double a_prev = sc[14], ib_prev = 1.0 / sc[15];
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void k_cgf_flush(int64_t n, const double* p, c
         x[i] += a_prev * ((p[i] - r[i]) * ib_prev);
 }
 // host poll of the fused-update CG: explicit r.r of the last update -> sc[3], stop flag
-__global__ __launch_bounds__(256) void k_cgf_fin(const double* part_rr, int np, double* sc, double tol2, int32_t* ctl) {
+static __global__ __launch_bounds__(256) void k_cgf_fin(const double* part_rr, int np, double* sc, double tol2, int32_t* ctl) {
     __shared__ double red[8];
     if (ctl[0] != 0) return;
     const double rr = sum_partials(part_rr, np, red);
@@ -555,7 +555,7 @@ __device__ __forceinline__ void bi_st(double2* p, int64_t i, double2 v) {
 }
 #define BI_LD(ptr, i) bi_ld(ptr, i)
 #define BI_ST(ptr, i, v) bi_st(ptr, i, v)
-__global__ __launch_bounds__(256) void k_bicg_p(int64_t n, const double* r, const double* v, double* p,
+static __global__ __launch_bounds__(256) void k_bicg_p(int64_t n, const double* r, const double* v, double* p,
                                                  const double* part_in /* (r0.r, r.r) pairs */, int np_in, double* sc,
                                                  int first, int32_t* ctl) {
     __shared__ double red[8];
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256) void k_bicg_p(int64_t n, const double* r, cons
         if (rho_new == 0.0) ctl[2] = 1;
     }
 }
-__global__ __launch_bounds__(256) void k_bicg_s(int64_t n, const double* r, const double* v, double* s,
+static __global__ __launch_bounds__(256) void k_bicg_s(int64_t n, const double* r, const double* v, double* s,
                                                  const double* part_in /* (r0.v, .) */, int np_in, double* sc,
                                                  int32_t* ctl) {
     __shared__ double red[8];
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(256) void k_bicg_s(int64_t n, const double* r, cons
         if (r0v == 0.0) ctl[2] = 1;
     }
 }
-__global__ __launch_bounds__(256) void k_bicg_xr(int64_t n, const double* p, const double* s, const double* t,
+static __global__ __launch_bounds__(256) void k_bicg_xr(int64_t n, const double* p, const double* s, const double* t,
                                                   const double* r0, double* x, double* r,
                                                   const double* part_in /* (t.s, t.t) */, int np_in, double* part_out,
                                                   const double* sc, int32_t* ctl, const uint8_t* owned) {
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256) void k_bicg_xr(int64_t n, const double* p, con
 #undef BI_ST
 // multi-GPU BiCGStab: t.t over the owned rows of the ASSEMBLED t (the SpMV's fused y.y only sees this rank's sub-assembled
 // part); per-workgroup partials, then out = (t.s already summed over ranks, local t.t) for the scalar all-reduce of out[1]
-__global__ __launch_bounds__(256) void k_sq_owned(int64_t n, const double* t, const uint8_t* owned, double* part, const int32_t* ctl) {
+static __global__ __launch_bounds__(256) void k_sq_owned(int64_t n, const double* t, const uint8_t* owned, double* part, const int32_t* ctl) {
     __shared__ double red[8];
     if (__syncthreads_or(ctl[0] != 0)) return;
     double a = 0;
@@ -688,13 +688,13 @@ __global__ __launch_bounds__(256) void k_sq_owned(int64_t n, const double* t, co
     const double s = block_sum(a, red);
     if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
-__global__ __launch_bounds__(256) void k_bicg_tt_fin(const double* part, int np, const double* ts_src, double* out) {
+static __global__ __launch_bounds__(256) void k_bicg_tt_fin(const double* part, int np, const double* ts_src, double* out) {
     __shared__ double red[8];
     const double s = sum_partials(part, np, red);
     if (threadIdx.x == 0) out[0] = ts_src[0], out[1] = s;
 }
 // closes a BiCGStab iteration: rho <- rho_new, alpha, omega = t.s/t.t recomputed from the same partials, stop test
-__global__ __launch_bounds__(256) void k_bicg_fin(const double* part_ts, int np_ts, const double* part_rr, int np_rr,
+static __global__ __launch_bounds__(256) void k_bicg_fin(const double* part_ts, int np_ts, const double* part_rr, int np_rr,
                                                    double* sc, double tol2, int32_t* ctl) {
     __shared__ double red[8];
     if (__syncthreads_or(ctl[0] != 0)) return;   // uniform even if another workgroup raises the flag meanwhile
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(256) void k_bicg_fin(const double* part_ts, int np_
 // ---------------------------------------------------------------------------------------------------------------
 // One lane per GLOBAL interface slot: inv[j] = this rank's DOF of slot j or -1 (zero written where the rank has no DOF, so no
 // memset is needed); workgroup 0 also folds the local dot partials (stride 2) into buf[n_if], buf[n_if + 1].
-__global__ __launch_bounds__(256) void k_halo_pack_all(int64_t n_if, const int32_t* inv, const double* v, double* buf,
+static __global__ __launch_bounds__(256) void k_halo_pack_all(int64_t n_if, const int32_t* inv, const double* v, double* buf,
                                                         const double* part, int np) {
     __shared__ double red[8];
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(256) void k_halo_pack_all(int64_t n_if, const int32
 }
 // neighbour-only exchange: send buffer = this rank's sub-assembled values at the DOFs it shares, one segment per peer; block 0 also
 // folds the SpMV's fused dot partials (as k_halo_pack_all)
-__global__ __launch_bounds__(256) void k_peer_pack(int64_t n_send, const int32_t* send_dof, const double* v, double* sendbuf, const double* part,
+static __global__ __launch_bounds__(256) void k_peer_pack(int64_t n_send, const int32_t* send_dof, const double* v, double* sendbuf, const double* part,
                                                     int np, double* scal) {
     __shared__ double red[8];
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -758,7 +758,7 @@ __global__ __launch_bounds__(256) void k_peer_pack(int64_t n_send, const int32_t
 }
 // summed value of every local interface DOF: the contributions of the ranks sharing it added in ASCENDING RANK ORDER (this rank's own
 // among them), so that every sharer computes the same bits; buf[k] for the kernels that read interface rows from there, v on request
-__global__ void k_peer_sum(int64_t n_loc_if, const int32_t* dof, const int32_t* src_off, const int32_t* src, const double* recvbuf, double* v,
+static __global__ void k_peer_sum(int64_t n_loc_if, const int32_t* dof, const int32_t* src_off, const int32_t* src, const double* recvbuf, double* v,
                            double* buf, int write_v) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_loc_if) return;
@@ -768,22 +768,22 @@ __global__ void k_peer_sum(int64_t n_loc_if, const int32_t* dof, const int32_t* 
     buf[k] = s;
     if (write_v) v[d] = s;
 }
-__global__ void k_halo_unpack(int64_t n_loc_if, const int32_t* dof, const int32_t* pos, const double* buf, double* v) {
+static __global__ void k_halo_unpack(int64_t n_loc_if, const int32_t* dof, const int32_t* pos, const double* buf, double* v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_loc_if) v[dof[i]] = buf[pos[i]];
 }
 // out[0] = sum(part[0..np)) in the fixed order; single workgroup
-__global__ __launch_bounds__(256) void k_reduce_partials(const double* part, int np, double* out) {
+static __global__ __launch_bounds__(256) void k_reduce_partials(const double* part, int np, double* out) {
     __shared__ double red[8];
     const double s = sum_partials(part, np, red);
     if (threadIdx.x == 0) out[0] = s;
 }
-__global__ void k_diag_extract(int64_t n, const int32_t* diag, const double* vals, double* d) {
+static __global__ void k_diag_extract(int64_t n, const int32_t* diag, const double* vals, double* d) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) d[i] = vals[diag[i]];
 }
 // Jacobi scale from an already summed diagonal (multi-GPU)
-__global__ void k_jacobi_scale_from_diag(int64_t n, const double* d, const uint8_t* bnd, int use_bnd, double* scale, int32_t* flag) {
+static __global__ void k_jacobi_scale_from_diag(int64_t n, const double* d, const uint8_t* bnd, int use_bnd, double* scale, int32_t* flag) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const bool b = use_bnd && bnd[i];
@@ -792,7 +792,7 @@ __global__ void k_jacobi_scale_from_diag(int64_t n, const double* d, const uint8
 }
 
 // u = scale * x + gt   (back to the unscaled unknowns, Dirichlet values restored)
-__global__ void k_unscale(int64_t n, const double* scale, const double* x, const double* gt, double* u) {
+static __global__ void k_unscale(int64_t n, const double* scale, const double* x, const double* gt, double* u) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) u[i] = scale[i] * x[i] + gt[i];
 }
@@ -800,17 +800,17 @@ __global__ void k_unscale(int64_t n, const double* scale, const double* x, const
 // ---------------------------------------------------------------------------------------------------------------
 // numbering changes at the boundary (reference numbering <-> internal numbering)
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void k_gather_f64(int64_t n, const int32_t* idx, const double* src, double* dst) {   // dst[i] = src[idx[i]]
+static __global__ void k_gather_f64(int64_t n, const int32_t* idx, const double* src, double* dst) {   // dst[i] = src[idx[i]]
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[idx[i]];
 }
-__global__ void k_scatter_f64(int64_t n, const int32_t* idx, const double* src, double* dst) {  // dst[idx[i]] = src[i]
+static __global__ void k_scatter_f64(int64_t n, const int32_t* idx, const double* src, double* dst) {  // dst[idx[i]] = src[i]
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[idx[i]] = src[i];
 }
 // export of stiff() after a Dirichlet solve: FEMSolverBase::set_dirichlet_bc (fem_solver_base.h:148-149) zeroes the
 // boundary rows and puts 1 on their diagonal; 16 lanes per row, output in reference slots
-__global__ __launch_bounds__(256) void k_export_values(int64_t n, const int32_t* rowptr, const int32_t* colidx,
+static __global__ __launch_bounds__(256) void k_export_values(int64_t n, const int32_t* rowptr, const int32_t* colidx,
                                                        const double* vals, const int32_t* slot_i2e, const uint8_t* bnd,
                                                        int zero_bnd_rows, double* out) {
     const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -821,7 +821,7 @@ __global__ __launch_bounds__(256) void k_export_values(int64_t n, const int32_t*
         out[slot_i2e[k]] = z ? (colidx[k] == row ? 1.0 : 0.0) : vals[k];
 }
 // row-sum lumping (fdaPDE/linear_algebra/lumping.h:30-41): out[row] = sum of the row's entries; 16 lanes per row, fixed order
-__global__ __launch_bounds__(256) void k_row_sums(int64_t n, const int32_t* rowptr, const double* vals, double* out) {
+static __global__ __launch_bounds__(256) void k_row_sums(int64_t n, const int32_t* rowptr, const double* vals, double* out) {
     const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int l = threadIdx.x & 15;
     const bool ok = row < n;
@@ -831,12 +831,12 @@ __global__ __launch_bounds__(256) void k_row_sums(int64_t n, const int32_t* rowp
     a = team_sum<16>(a);
     if (ok && l == 0) out[row] = a;
 }
-__global__ void k_fill_f64(int64_t n, double v, double* dst) {
+static __global__ void k_fill_f64(int64_t n, double v, double* dst) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = v;
 }
 // force export after a Dirichlet solve: force_[i] = g[i] on boundary DOFs (fem_solver_base.h:152)
-__global__ void k_force_bc(int64_t n, const uint8_t* bnd, const double* g, double* f) {
+static __global__ void k_force_bc(int64_t n, const uint8_t* bnd, const double* g, double* f) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && bnd[i]) f[i] = g[i];
 }

@@ -17,7 +17,7 @@ namespace fdapde_hip {
 
 // scalars of the Q systems: sc[0..Q) b.b, [Q..2Q) r.r, [2Q..3Q) alpha, [3Q..4Q) beta, [4Q..5Q) 1 if converged
 template <int Q>
-__global__ __launch_bounds__(256) void k_q_init(int64_t n, const double* b_ext /* Q columns of n, reference numbering */,
+static __global__ __launch_bounds__(256) void k_q_init(int64_t n, const double* b_ext /* Q columns of n, reference numbering */,
                                                 const int32_t* dof_i2e, const double* scale, double* X, double* R, double* P,
                                                 double* part_rr /* [grid][Q] */) {
     __shared__ double red[8];
@@ -70,7 +70,7 @@ template <int H> __device__ __forceinline__ double pair_block_sum(double2 v, dou
 // the variant in which Q/2 lanes share an entry (coalesced 64-byte operand rows, but 4 x fewer entries per instruction): 365 us.
 //   partial[(b * 2 + 0) * Q + q] = p.y, [(b * 2 + 1) * Q + q] = y.y
 template <int Q>
-__global__ __launch_bounds__(256) void k_spmm_full(int64_t n, const int32_t* rowptr, const int32_t* colidx, const double* vals,
+static __global__ __launch_bounds__(256) void k_spmm_full(int64_t n, const int32_t* rowptr, const int32_t* colidx, const double* vals,
                                                    const double* X, double* Y, double* partial, const int32_t* stop) {
     static_assert(Q % 2 == 0, "rows are moved as double2");
     constexpr int T = 8;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_spmm_full(int64_t n, const int32_t* row
 
 // one workgroup: per system alpha = rr / p.y, beta = (alpha^2 y.y - rr) / rr with the EXPLICIT rr of the previous update
 template <int Q>
-__global__ __launch_bounds__(256) void k_q_scalars(const double* part_spmm, int np, const double* part_rr, int np_rr, double* sc,
+static __global__ __launch_bounds__(256) void k_q_scalars(const double* part_spmm, int np, const double* part_rr, int np_rr, double* sc,
                                                    double tol2, int32_t* ctl) {
     __shared__ double sa[256], sb[256], sc_[256];
     __shared__ int flags[2];
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_q_scalars(const double* part_spmm, int 
 // a thread always meets the same pair of systems (its index mod Q/2); kQV elements per lane in flight
 constexpr int kQV = 4;
 template <int Q>
-__global__ __launch_bounds__(256) void k_q_update(int64_t n, const double* Y, double* P, double* X, double* R, const double* sc,
+static __global__ __launch_bounds__(256) void k_q_update(int64_t n, const double* Y, double* P, double* X, double* R, const double* sc,
                                                   double* part_rr, const int32_t* ctl) {
     static_assert(Q == 2 || Q == 4 || Q == 8, "a lane moves one double2 = one pair of systems");
     constexpr int H = Q / 2;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void k_q_update(int64_t n, const double* Y, do
 
 // u_q = scale * x_q, written in the reference numbering: out[q * n + dof_i2e[i]]
 template <int Q>
-__global__ void k_q_unscale(int64_t n, const double* X, const double* scale, const int32_t* dof_i2e, double* out) {
+static __global__ void k_q_unscale(int64_t n, const double* X, const double* scale, const int32_t* dof_i2e, double* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double s = scale[i];

@@ -167,7 +167,7 @@ __device__ __forceinline__ double wave_sum64(double v) {
 //                 The import / export lists are read from global memory (L2) instead of LDS: the table takes their room.
 // DIST = true   : row-distributed form, see PersistArgs.
 template <int R, bool STREAM, bool SYM, bool DIST = false>
-__global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
+static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
     constexpr int T = kPersistT, W = T / 64, S = R * T, RI = R / 2;
     extern __shared__ double lds[];
     __shared__ double red[W][3];
@@ -635,7 +635,7 @@ struct BlockedSpmvArgs {
     const int32_t* stop;
 };
 template <int R>
-__global__ __launch_bounds__(kPersistT) void k_spmv_blocked(BlockedSpmvArgs a) {
+static __global__ __launch_bounds__(kPersistT) void k_spmv_blocked(BlockedSpmvArgs a) {
     constexpr int T = kPersistT, W = T / 64, S = R * T;
     extern __shared__ double lds[];
     __shared__ double red[W][2];

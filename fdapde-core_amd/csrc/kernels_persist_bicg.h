@@ -33,7 +33,7 @@ __device__ __forceinline__ void granule_load8_sys(const unsigned long long* p, p
 // R rows per thread (2, 4, 8).  ctl / sc on return as the multi-launch loop leaves them: ctl[0] converged, [1] iterations, [2] breakdown,
 // sc[3] = final r.r; [3] hand-off timeout (then nothing else was written).
 template <int R, bool STREAM, bool DIST>
-__global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a) {
+static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a) {
     constexpr int T = kPersistT, W = T / 64, S = R * T, RI = R / 2;
     extern __shared__ double lds[];
     __shared__ double red[W][4];

@@ -44,7 +44,7 @@ __device__ __forceinline__ double spmv_dot2(const SpmvArgs& s, int64_t row, doub
     return (s.owned && !s.owned[row]) ? 0.0 : wv * wv;
 }
 
-__global__ __launch_bounds__(256) void k_spmv(SpmvArgs s) {
+static __global__ __launch_bounds__(256) void k_spmv(SpmvArgs s) {
     __shared__ double prod[kSpmvNnz];
     __shared__ double red[8];
     if (s.stop && __syncthreads_or(*s.stop != 0)) return;   // wave- and workgroup-uniform exit
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_spmv(SpmvArgs s) {
 // fixed order: results are bitwise reproducible run to run.
 // ---------------------------------------------------------------------------------------------------------------
 template <int T, int U>
-__global__ __launch_bounds__(256) void k_spmv_team(SpmvArgs s, int64_t n, int64_t rows_per_band) {
+static __global__ __launch_bounds__(256) void k_spmv_team(SpmvArgs s, int64_t n, int64_t rows_per_band) {
     constexpr int TEAMS = 64 / T;
     constexpr int WROWS = TEAMS * U;   // rows per wave-iteration (tile); WROWS + 1 <= 64
     static_assert(WROWS < 64, "one rowptr load per tile");
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_spmv_team(SpmvArgs s, int64_t n, int64_
 
 // read-bandwidth probe: streams `bytes` (multiple of 16) with 16 B per lane, persistent grid; calibrates what the chip
 // delivers for a pure read stream next to the SpMV numbers
-__global__ __launch_bounds__(256) void k_read_probe(const double2* src, int64_t n16, double* sink) {
+static __global__ __launch_bounds__(256) void k_read_probe(const double2* src, int64_t n16, double* sink) {
     double acc = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x) {
         const double2 v = src[i];
@@ -202,7 +202,7 @@ typedef double v2f64_t __attribute__((ext_vector_type(2)));
 typedef int v2i32_t __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(8))) F64x2u { double x, y; };
 // same stream with the 16-byte loads based at an address that is only 8-byte aligned (what an odd row start gives)
-__global__ __launch_bounds__(256) void k_stream_probe_unaligned(const double* vals, const int2* col2, int64_t n2, double* sink) {
+static __global__ __launch_bounds__(256) void k_stream_probe_unaligned(const double* vals, const int2* col2, int64_t n2, double* sink) {
     double acc = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2 - 1; i += (int64_t)gridDim.x * blockDim.x) {
         const F64x2u v = *reinterpret_cast<const F64x2u*>(vals + 2 * i + 1);
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void k_stream_probe_unaligned(const double* va
     }
     if (acc == 1.2345e-300) sink[0] = acc;
 }
-__global__ __launch_bounds__(256) void k_stream_probe(const double2* vals2, const int2* col2, int64_t n2, double* sink) {
+static __global__ __launch_bounds__(256) void k_stream_probe(const double2* vals2, const int2* col2, int64_t n2, double* sink) {
     double acc = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
         const v2f64_t v = __builtin_nontemporal_load(reinterpret_cast<const v2f64_t*>(vals2) + i);
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_stream_probe(const double2* vals2, cons
 
 // matrix-stream probe + a small write stream: every lane writes one double per 8 pairs it reads (about the y / matrix byte
 // ratio of the SpMV), contiguous across the wavefront
-__global__ __launch_bounds__(256) void k_stream_probe_w(const double2* vals2, const int2* col2, int64_t n2, double* out) {
+static __global__ __launch_bounds__(256) void k_stream_probe_w(const double2* vals2, const int2* col2, int64_t n2, double* out) {
     const int64_t nth = (int64_t)gridDim.x * blockDim.x, tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t i = tid, o = tid;
     while (i < n2) {
@@ -255,7 +255,7 @@ struct __attribute__((packed, aligned(4))) I32x2 { int x, y; };
 // Cache policy of the matrix stream: see load_pair (default for teams of <= 8 lanes, nontemporal for wider teams; the oldest
 // unaligned form still carries the hint it was tuned with: 69.4 us against 70.7 us default at the time).
 template <int T, int U, int ABL = 0, int OCC = 4>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) void k_spmv_team2(SpmvArgs s, int64_t n,
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) void k_spmv_team2(SpmvArgs s, int64_t n,
                                                                                               int64_t rows_per_band) {
     constexpr int TEAMS = 64 / T;
     constexpr int WROWS = TEAMS * U;
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
 // FLAGS: 8192 = multi-GPU (implicit diagonal and w.w counted by the owner of the row), 16384 = the dot operand w is x.
 // ---------------------------------------------------------------------------------------------------------------
 template <int T, int U, int FLAGS>
-__global__ __launch_bounds__(256) void k_spmv_c16p(SpmvArgs s, int64_t n, int64_t rows_per_band) {
+static __global__ __launch_bounds__(256) void k_spmv_c16p(SpmvArgs s, int64_t n, int64_t rows_per_band) {
     constexpr int TEAMS = 64 / T;
     constexpr int WROWS = TEAMS * U;
     constexpr bool DIST = (FLAGS & 8192) != 0, WX = (FLAGS & 16384) != 0;

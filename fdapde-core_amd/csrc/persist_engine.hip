@@ -771,4 +771,13 @@ void release_rowdist(fdapde_ctx* c) {
     c->rd.ready = false;
 }
 
+
+// the unit's code object is loaded when one of its kernels is first looked up (HIP defers it): done at context creation, so that the
+// first solve of a process does not pay for it (6 ms for the smoke problem after the library was split into units)
+void preload_persist() {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_persist_fill));
+    (void)hipGetLastError();
+}
+
 }   // namespace fdapde_engine

@@ -317,6 +317,8 @@ struct fdapde_ctx {
             int32_t n_ghost = 0, G_tot = 0, g_base = 0;
             DBuf<int32_t> rexp_off, rexp_peer, rexp_pos;
             DBuf<uint16_t> rexp_slot;
+            DBuf<uint8_t> wg_late;           // workgroups that fetch their imports before their first pass
+            DBuf<unsigned long long> rboard;  // what crosses ranks: [entries imported from other ranks | one dot record per rank x 2], fine-grained, IPC-mapped
             DBuf<unsigned long long*> peer_pboard, peer_dboard;
             std::vector<void*> ipc_opened;   // peer boards mapped through hipIpcOpenMemHandle (closed with the context)
             // exchange of per-DOF values of the ghost columns (the Jacobi scale, once per prepared system): per peer, what goes out / comes in

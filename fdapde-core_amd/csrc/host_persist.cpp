@@ -34,7 +34,7 @@ template <typename F> void for_each_wg(int G, F&& fn) {
 }  // namespace
 
 int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int lds_entries, PersistLayout& pl, const int32_t* block_rows, int sym_mode, bool balance,
-                              const int32_t* ghost_order) {
+                              const int32_t* ghost_order, bool allow_late) {
     constexpr int T = kPersistT;
     const int64_t nd = hs.n_dofs;
     if (n_wg < 1 || nd < 1) return FDAPDE_EUNSUPPORTED;
@@ -168,10 +168,16 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
     // travel), the second half everything else -- so a workgroup needs T R / 2 slots for its importing rows
     const int32_t max_halo = *std::max_element(n_halo.begin(), n_halo.end());
     int R = 2;
-    while ((int64_t)R * T < rpw || (int64_t)(R / 2) * T < max_halo) R *= 2;
+    // allow_late: a workgroup with more importing rows than the second half of its slots holds does not force twice the rows per thread
+    // on everybody (or the refusal of the system): it is marked LATE -- the kernel fetches its imports before its first pass -- and its
+    // rows fill the slots in one run
+    while ((int64_t)R * T < rpw || (!allow_late && (int64_t)(R / 2) * T < max_halo)) R *= 2;
     if (R > kPersistRmax) return FDAPDE_EUNSUPPORTED;
     const int S = R * T, nsl = S / 64, SA = (R / 2) * T;
     pl.G = G, pl.R = R, pl.nsl = nsl, pl.n_int = n_int, pl.sym = sym, pl.nnz_full = nnz_kept;
+    pl.wg_late.assign((size_t)G, 0);
+    if (allow_late)
+        for (int g = 0; g < G; ++g) pl.wg_late[(size_t)g] = n_halo[(size_t)g] > SA ? 1 : 0;
 
     // ---- slots: [0, SA) rows without imports, longest first (as many as fit); [SA, S) all other rows, longest first
     pl.slot_dof.assign((size_t)G * S, -1);
@@ -182,8 +188,10 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
             if (a.len != b.len) return a.len > b.len;
             return a.dof < b.dof;
         });
-        const size_t n_noimp = rows.size() - (size_t)n_halo[(size_t)g], n_a = std::min<size_t>(n_noimp, (size_t)SA);
-        std::stable_sort(rows.begin() + (std::ptrdiff_t)n_a, rows.end(), [](const Key& a, const Key& b) { return a.len > b.len; });
+        const bool late = allow_late && n_halo[(size_t)g] > SA;
+        const size_t n_noimp = rows.size() - (size_t)n_halo[(size_t)g], n_a = late ? rows.size() : std::min<size_t>(n_noimp, (size_t)SA);
+        if (late) std::stable_sort(rows.begin(), rows.end(), [](const Key& a, const Key& b) { return a.len > b.len; });
+        else std::stable_sort(rows.begin() + (std::ptrdiff_t)n_a, rows.end(), [](const Key& a, const Key& b) { return a.len > b.len; });
         for (size_t i = 0; i < rows.size(); ++i) {
             const size_t s = i < n_a ? i : (size_t)SA + (i - n_a);
             pl.slot_dof[(size_t)g * S + s] = rows[i].dof;

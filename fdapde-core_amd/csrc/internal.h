@@ -186,6 +186,7 @@ struct PersistLayout {
     // board positions n_board + (index in ghost_needed) -- entries the owning ranks push there
     std::vector<int32_t> ghost_needed;   // ghost DOFs some row of this rank reads, in board order (ascending ghost_order)
     std::vector<int32_t> wg_of, slot_of; // per DOF: workgroup / slot of its row (-1: no row here)
+    std::vector<uint8_t> wg_late;        // allow_late: 1 = the workgroup's importing rows overflow the second half of its slots: imports before the first pass
 };
 // n_wg: workgroups available (CUs of the device); lds_entries: ELL entries a workgroup can keep in LDS -- the rows are spread over
 // enough workgroups for every block to be resident where the device has that many (3-D rows: 14 entries each, so ~850 rows per
@@ -194,7 +195,7 @@ struct PersistLayout {
 // ghost_order (row-distributed form): per DOF -1 = this rank's own, else a unique non-negative sort key (the caller's order of the DOFs
 // owned by other ranks: by owner, then by global key): such a DOF has no row here and is imported from the board's remote section.
 int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int lds_entries, PersistLayout& pl, const int32_t* block_rows = nullptr,
-                              int sym_mode = 0, bool balance = false, const int32_t* ghost_order = nullptr);
+                              int sym_mode = 0, bool balance = false, const int32_t* ghost_order = nullptr, bool allow_late = false);
 
 }  // namespace fdapde_hip
 #endif

@@ -58,18 +58,23 @@ struct PersistArgs {
     double* stats;                // per workgroup: [0] iterations timed, [1] operator phase (SpMV + imports), [2] all-gather phase (incl. the
                                   // wait for the slowest workgroup), [3] update phase -- sums of 10 ns ticks
     // ---- row-distributed form (DIST): the workgroups of `world` launches -- one per rank, each on its own GPU (tests: sharing one) -- act
-    //      as ONE grid of G_tot workgroups.  Every rank holds a board of its own: [its exports | the entries it imports from other ranks |
-    //      dot records of all G_tot workgroups x 2 parities]; exporters PUSH the entries another rank needs into that rank's board (posted
-    //      writes over xGMI through peer-mapped pointers) and every workgroup pushes its dot record into every rank's board, so that all
-    //      polling stays local.  Board memory is fine-grained and every board access system-scope (sc0 sc1).
-    int32_t world, g_base, G_tot;     // ranks; global index of this launch's workgroup 0; workgroups of all launches
+    //      as ONE grid.  Hand-offs inside a rank work exactly as on one GPU (pboard / dboard: ordinary device memory, agent scope).  What
+    //      crosses ranks goes through a second, small board per rank in FINE-GRAINED memory that every rank maps (hipIpc):
+    //      [entries imported from other ranks | one dot record per RANK x 2 buffers].  Exporters PUSH an entry another rank needs into that
+    //      rank's board (posted writes over xGMI through the peer-mapped pointer), so all polling is local; the dot products are gathered in
+    //      two levels: inside the rank as ever, then workgroup 0 pushes the rank's sums to every rank and all workgroups add the `world` rank
+    //      records in rank order (the same bits everywhere).  Accesses of that board are system-scope (sc0 sc1).
+    int32_t world, rank, n_board_local;   // ranks; this rank; import positions >= n_board_local lie in the remote section of rboard
     int32_t timeout_first_ticks;      // bound of the waits of iteration 0 (the launches of the ranks start at different times)
     const int32_t* rexp_off;          // [G + 1] remote exports of a workgroup
     const uint16_t* rexp_slot;        // slot whose entry goes out
     const int32_t* rexp_peer;         // to which rank
-    const int32_t* rexp_pos;          // at which position of that rank's p board
-    unsigned long long* const* peer_pboard;   // [world] p boards (entry `rank` = the local one)
-    unsigned long long* const* peer_dboard;   // [world] dot boards
+    const int32_t* rexp_pos;          // at which position of that rank's remote section
+    const uint8_t* wg_late;                   // [G] or nullptr: 1 = this workgroup fetches its imports before its first pass (its importing rows overflow the
+                                              // second half of its slots: host_build_persist_layout allow_late)
+    unsigned long long* rboard;               // this rank's fine-grained board: remote section
+    unsigned long long* const* peer_pboard;   // [world] remote sections of all ranks' fine-grained boards
+    unsigned long long* const* peer_dboard;   // [world] rank-record sections: [buffer][world][4 values][2 granules]
 };
 
 typedef __attribute__((address_space(1))) unsigned long long pg_u64;
@@ -172,7 +177,6 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
     extern __shared__ double lds[];
     __shared__ double red[W][3];
     __shared__ double tot[3];
-    __shared__ double pub[3];
     __shared__ double pmax_w[W];
     __shared__ int32_t fail_flag;
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -298,10 +302,7 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
             for (int k = 0; k < 4; ++k) pe[k] = p_tab[code[k]];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (i0 + k * T < E) {
-                    if constexpr (DIST) publish_f64_x4_sys(a.pboard + 2 * (size_t)(a.exp_off[g] + i0 + k * T), epoch, pe[k]);
-                    else publish_f64_x4(a.pboard + 2 * (size_t)(a.exp_off[g] + i0 + k * T), epoch, pe[k]);
-                }
+                if (i0 + k * T < E) publish_f64_x4(a.pboard + 2 * (size_t)(a.exp_off[g] + i0 + k * T), epoch, pe[k]);
         }
         if constexpr (DIST) {   // entries other ranks import: pushed into their boards
             const int re0 = a.rexp_off[g], RE = a.rexp_off[g + 1] - re0;
@@ -410,7 +411,8 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
                 }
             }
         };
-        product(std::integral_constant<int, 0>{});
+        const bool late = DIST && a.wg_late != nullptr && a.wg_late[g] != 0;   // (uniform for the workgroup)
+        if (!late) product(std::integral_constant<int, 0>{});
         {   // imports, four per lane at a time with their loads in flight together (a workgroup in the middle of a 3-D mesh imports ~3 000
             // entries: one after the other that was six dependent round trips per wavefront, measured as 1.5 us per 1 000 imports); a lane
             // re-reads what does not carry this iteration's tag in both halves yet, lanes that have theirs stop loading
@@ -419,14 +421,26 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
                 const unsigned long long* gp[4];
                 pg_v2u64 v[4];
                 bool done[4];
+                [[maybe_unused]] bool far[4];   // DIST: the entry comes from another rank (remote section of the fine-grained board)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int h = hb + k * T + lane;
                     done[k] = h >= H;
-                    gp[k] = a.pboard + 2 * (size_t)impl[done[k] ? 0 : h];
+                    const int32_t pos = impl[done[k] ? 0 : h];
+                    if constexpr (DIST) {
+                        far[k] = pos >= a.n_board_local;
+                        gp[k] = far[k] ? a.rboard + 2 * (size_t)(pos - a.n_board_local) : a.pboard + 2 * (size_t)pos;
+                    } else
+                        gp[k] = a.pboard + 2 * (size_t)pos;
                 }
-                if constexpr (DIST) granule_load2x4_sys(gp[0], gp[1], gp[2], gp[3], v[0], v[1], v[2], v[3]);
-                else granule_load2x4(gp[0], gp[1], gp[2], gp[3], v[0], v[1], v[2], v[3]);
+                if constexpr (DIST) {
+                    // (most lanes read local entries: one batched agent-scope round for everybody, then the far lanes re-read at system scope)
+                    granule_load2x4(gp[0], gp[1], gp[2], gp[3], v[0], v[1], v[2], v[3]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (far[k]) v[k] = granule_load2_sys(gp[k]);
+                } else
+                    granule_load2x4(gp[0], gp[1], gp[2], gp[3], v[0], v[1], v[2], v[3]);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) done[k] = done[k] || granule_pair_ok(v[k], epoch);
                 long long t_wait = 0;
@@ -443,7 +457,7 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if (!done[k]) {
-                            if constexpr (DIST) v[k] = granule_load2_sys(gp[k]);
+                            if constexpr (DIST) v[k] = far[k] ? granule_load2_sys(gp[k]) : granule_load2(gp[k]);
                             else v[k] = granule_load2(gp[k]);
                             done[k] = granule_pair_ok(v[k], epoch);
                         }
@@ -462,6 +476,7 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
             status = 3;
             break;
         }
+        if (late) product(std::integral_constant<int, 0>{});
         product(std::integral_constant<int, 1>{});
         if constexpr (SYM) {   // collect the transposed sums of the own rows; the table is zero again for the next iteration
             __syncthreads();
@@ -480,47 +495,31 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
         const double s2 = wave_sum64(rr_part);
         if (lane == 0) red[wave][0] = s0, red[wave][1] = s1, red[wave][2] = s2;
         __syncthreads();
-        const int G_all = DIST ? a.G_tot : a.G;
-        unsigned long long* dslot = a.dboard + (size_t)(it & 1) * G_all * 6;
-        if constexpr (!DIST) {
-            if (tid < 3) {
-                double v = 0;
+        unsigned long long* dslot = a.dboard + (size_t)(it & 1) * a.G * 6;
+        if (tid < 3) {
+            double v = 0;
 #pragma unroll
-                for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
-                publish_f64_x4(dslot + (size_t)g * 6 + 2 * tid, epoch, v);
-            }
-        } else {   // the record goes into the dot board of EVERY rank (its own among them): thread (k, q) pushes value k to rank q
-            if (tid < 3) {
-                double v = 0;
-#pragma unroll
-                for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
-                pub[tid] = v;
-            }
-            __syncthreads();
-            if (tid < 3 * a.world) {
-                const int k = tid % 3, q = tid / 3;
-                publish_f64_x4_sys(a.peer_dboard[q] + (size_t)(it & 1) * G_all * 6 + (size_t)(a.g_base + g) * 6 + 2 * k, epoch, pub[k]);
-            }
+            for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
+            publish_f64_x4(dslot + (size_t)g * 6 + 2 * tid, epoch, v);
         }
         {   // thread t collects workgroup t's three sums (a lane re-reads its record until all six tags match, then stops loading); every
             // workgroup adds the G records in the same order.  A two-level form (groups of 8 / 16 / 32 workgroups handled by one wavefront,
             // then the group sums) was measured and dropped: a granule hop costs ~4 us under this load, two of them 7.9 / 9.8 / 12.0 us
-            // against 4.6 us for the flat sweep on C2 (246 workgroups).  Row-distributed form: G_tot records, ceil(G_tot / 512) per thread.
+            // against 4.6 us for the flat sweep on C2 (246 workgroups).
             double v0 = 0, v1 = 0, v2 = 0;
             bool fail = false;
             // gather_waves: how many wavefronts poll (4: thread t takes workgroup t's record; 1: wavefront 0 takes them all, 4 per lane)
-            const int per_lane = DIST ? (G_all + T - 1) / T : (a.gather_waves == 1 ? (a.G + 63) / 64 : 1);
-            if (DIST ? wave * 64 < G_all : (a.gather_waves == 1 ? wave == 0 : wave * 64 < a.G)) {   // wave-uniform
+            const int per_lane = a.gather_waves == 1 ? (a.G + 63) / 64 : 1;
+            if (a.gather_waves == 1 ? wave == 0 : wave * 64 < a.G) {   // wave-uniform
                 for (int rsel = 0; rsel < per_lane; ++rsel) {
-                    const int w = DIST ? rsel * T + tid : (a.gather_waves == 1 ? rsel * 64 + lane : tid);
-                    const unsigned long long* gp = dslot + (size_t)(w < G_all ? w : 0) * 6;
+                    const int w = a.gather_waves == 1 ? rsel * 64 + lane : tid;
+                    const unsigned long long* gp = dslot + (size_t)(w < a.G ? w : 0) * 6;
                     pg_v2u64 q0 = {0, 0}, q1 = {0, 0}, q2 = {0, 0};
-                    bool done = w >= G_all;
+                    bool done = w >= a.G;
                     long long t_wait = 0;
                     for (unsigned spins = 0;; ++spins) {
                         if (!done) {
-                            if constexpr (DIST) granule_load6_sys(gp, q0, q1, q2);
-                            else granule_load6(gp, q0, q1, q2);
+                            granule_load6(gp, q0, q1, q2);
                             done = granule_pair_ok(q0, epoch) && granule_pair_ok(q1, epoch) && granule_pair_ok(q2, epoch);
                         }
                         if (__all(done)) break;
@@ -536,7 +535,7 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
                         else if (a.poll_sleep == 2) __builtin_amdgcn_s_sleep(2);
                         else if (a.poll_sleep >= 3) __builtin_amdgcn_s_sleep(8);
                     }
-                    if (w < G_all) v0 += granule_pair_f64(q0), v1 += granule_pair_f64(q1), v2 += granule_pair_f64(q2);
+                    if (w < a.G) v0 += granule_pair_f64(q0), v1 += granule_pair_f64(q1), v2 += granule_pair_f64(q2);
                     if (fail) break;
                 }
             }
@@ -550,6 +549,47 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
 #pragma unroll
                 for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
                 tot[tid] = v;
+            }
+        }
+        if constexpr (DIST) {
+            // second level: the rank's sums (identical in all of its workgroups) go to every rank -- pushed by workgroup 0 -- and every
+            // workgroup of every rank adds the `world` rank records in one fixed order (lane q holds rank q; the same butterfly everywhere)
+            __syncthreads();
+            const bool lfail = fail_flag != 0;   // (uniform; a rank that failed locally publishes nothing: the others time out and give up too)
+            const size_t rbuf = (size_t)(it & 1) * a.world * 8;
+            if (g == 0 && !lfail && tid < 3 * a.world) {
+                const int k = tid % 3, q = tid / 3;
+                publish_f64_x4_sys(a.peer_dboard[q] + rbuf + (size_t)a.rank * 8 + 2 * k, epoch, tot[k]);
+            }
+            __syncthreads();   // (tot is rewritten below)
+            if (wave == 0 && !lfail) {
+                const unsigned long long* gp = a.peer_dboard[a.rank] + rbuf + (size_t)(lane < a.world ? lane : 0) * 8;
+                pg_v2u64 q0 = {0, 0}, q1 = {0, 0}, q2 = {0, 0};
+                bool done = lane >= a.world, fail = false;
+                long long t_wait = 0;
+                for (unsigned spins = 0;; ++spins) {
+                    if (!done) {
+                        granule_load6_sys(gp, q0, q1, q2);
+                        done = granule_pair_ok(q0, epoch) && granule_pair_ok(q1, epoch) && granule_pair_ok(q2, epoch);
+                    }
+                    if (__all(done)) break;
+                    if ((spins & 63u) == 63u) {
+                        const long long now = wall_clock64();
+                        if (t_wait == 0) t_wait = now;
+                        else if (now - t_wait > tmo) {
+                            fail = true;
+                            break;
+                        }
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const bool on = lane < a.world && !fail;
+                const double w0 = wave_sum64(on ? granule_pair_f64(q0) : 0.0), w1 = wave_sum64(on ? granule_pair_f64(q1) : 0.0),
+                             w2 = wave_sum64(on ? granule_pair_f64(q2) : 0.0);
+                if (lane == 0) {
+                    tot[0] = w0, tot[1] = w1, tot[2] = w2;
+                    if (fail) fail_flag = 1;
+                }
             }
         }
         __syncthreads();

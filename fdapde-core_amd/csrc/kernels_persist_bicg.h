@@ -38,7 +38,6 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
     extern __shared__ double lds[];
     __shared__ double red[W][4];
     __shared__ double tot[4];
-    __shared__ double pub[4];
     __shared__ int32_t fail_flag;
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nsl = a.nsl;
@@ -83,7 +82,6 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
         rr_part += rv[j] * rv[j];
     }
     const double bb = a.sc[0];
-    const int G_all = DIST ? a.G_tot : a.G;
     int it = 0, status = 0;   // status: 1 converged, 2 breakdown, 3 hand-off timeout
     double rr = 0, rho = 0, rho_old = 1.0, alpha = 1.0, omega = 1.0;
     long long tmo = DIST ? (long long)a.timeout_first_ticks : (long long)a.timeout_ticks;
@@ -104,10 +102,7 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
             for (int k = 0; k < 4; ++k) pe[k] = p_tab[code[k]];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (i0 + k * T < E) {
-                    if constexpr (DIST) publish_f64_x4_sys(a.pboard + 2 * (size_t)(a.exp_off[g] + i0 + k * T), epoch, pe[k]);
-                    else publish_f64_x4(a.pboard + 2 * (size_t)(a.exp_off[g] + i0 + k * T), epoch, pe[k]);
-                }
+                if (i0 + k * T < E) publish_f64_x4(a.pboard + 2 * (size_t)(a.exp_off[g] + i0 + k * T), epoch, pe[k]);
         }
         if constexpr (DIST) {
             const int re0 = a.rexp_off[g], RE = a.rexp_off[g + 1] - re0;
@@ -144,21 +139,32 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
                 }
             }
         };
-        product(std::integral_constant<int, 0>{});
+        const bool late = DIST && a.wg_late != nullptr && a.wg_late[g] != 0;   // (uniform for the workgroup)
+        if (!late) product(std::integral_constant<int, 0>{});
         {
             bool fail = false;
             for (int hb = wave * 64; hb < H; hb += 4 * T) {   // wave-uniform trip count
                 const unsigned long long* gp[4];
                 pg_v2u64 v[4];
                 bool done[4];
+                [[maybe_unused]] bool far[4];   // DIST: the entry comes from another rank (remote section of the fine-grained board)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int h = hb + k * T + lane;
                     done[k] = h >= H;
-                    gp[k] = a.pboard + 2 * (size_t)impl[done[k] ? 0 : h];
+                    const int32_t pos = impl[done[k] ? 0 : h];
+                    if constexpr (DIST) {
+                        far[k] = pos >= a.n_board_local;
+                        gp[k] = far[k] ? a.rboard + 2 * (size_t)(pos - a.n_board_local) : a.pboard + 2 * (size_t)pos;
+                    } else
+                        gp[k] = a.pboard + 2 * (size_t)pos;
                 }
-                if constexpr (DIST) granule_load2x4_sys(gp[0], gp[1], gp[2], gp[3], v[0], v[1], v[2], v[3]);
-                else granule_load2x4(gp[0], gp[1], gp[2], gp[3], v[0], v[1], v[2], v[3]);
+                granule_load2x4(gp[0], gp[1], gp[2], gp[3], v[0], v[1], v[2], v[3]);
+                if constexpr (DIST) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (far[k]) v[k] = granule_load2_sys(gp[k]);
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) done[k] = done[k] || granule_pair_ok(v[k], epoch);
                 long long t_wait = 0;
@@ -175,7 +181,7 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         if (!done[k]) {
-                            if constexpr (DIST) v[k] = granule_load2_sys(gp[k]);
+                            if constexpr (DIST) v[k] = far[k] ? granule_load2_sys(gp[k]) : granule_load2(gp[k]);
                             else v[k] = granule_load2(gp[k]);
                             done[k] = granule_pair_ok(v[k], epoch);
                         }
@@ -191,6 +197,7 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
         }
         __syncthreads();
         if (fail_flag) return false;
+        if (late) product(std::integral_constant<int, 0>{});
         product(std::integral_constant<int, 1>{});
         return true;
     };
@@ -200,53 +207,40 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
         __syncthreads();   // (the table reads of the application before, and the totals of the gather before, are done with)
         if (lane == 0) red[wave][0] = s0, red[wave][1] = s1, red[wave][2] = s2, red[wave][3] = s3;
         __syncthreads();
-        unsigned long long* dslot = a.dboard + (size_t)phase * G_all * 8;
+        unsigned long long* dslot = a.dboard + (size_t)phase * a.G * 8;
         if (tid < 4) {
             double v = 0;
 #pragma unroll
             for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
-            if constexpr (!DIST) publish_f64_x4(dslot + (size_t)g * 8 + 2 * tid, epoch, v);
-            else pub[tid] = v;
-        }
-        if constexpr (DIST) {
-            __syncthreads();
-            if (tid < 4 * a.world) {
-                const int k = tid & 3, q = tid >> 2;
-                publish_f64_x4_sys(a.peer_dboard[q] + (size_t)phase * G_all * 8 + (size_t)(a.g_base + g) * 8 + 2 * k, epoch, pub[k]);
-            }
+            publish_f64_x4(dslot + (size_t)g * 8 + 2 * tid, epoch, v);
         }
         double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
         bool fail = false;
-        const int per_lane = (G_all + T - 1) / T;
-        if (wave * 64 < G_all) {   // wave-uniform
-            for (int rsel = 0; rsel < per_lane; ++rsel) {
-                const int wq = rsel * T + tid;
-                const unsigned long long* gp = dslot + (size_t)(wq < G_all ? wq : 0) * 8;
-                pg_v2u64 q0 = {0, 0}, q1 = {0, 0}, q2 = {0, 0}, q3 = {0, 0};
-                bool done = wq >= G_all;
-                long long t_wait = 0;
-                for (unsigned spins = 0;; ++spins) {
-                    if (!done) {
-                        if constexpr (DIST) granule_load8_sys(gp, q0, q1, q2, q3);
-                        else granule_load8(gp, q0, q1, q2, q3);
-                        done = granule_pair_ok(q0, epoch) && granule_pair_ok(q1, epoch) && granule_pair_ok(q2, epoch) && granule_pair_ok(q3, epoch);
-                    }
-                    if (__all(done)) break;
-                    if ((spins & 63u) == 63u) {
-                        const long long now = wall_clock64();
-                        if (t_wait == 0) t_wait = now;
-                        else if (now - t_wait > tmo) {
-                            fail = true;
-                            break;
-                        }
-                    }
-                    if (a.poll_sleep == 1) __builtin_amdgcn_s_sleep(1);
-                    else if (a.poll_sleep == 2) __builtin_amdgcn_s_sleep(2);
-                    else if (a.poll_sleep >= 3) __builtin_amdgcn_s_sleep(8);
+        if (wave * 64 < a.G) {   // wave-uniform: thread t takes workgroup t's record
+            const int wq = tid;
+            const unsigned long long* gp = dslot + (size_t)(wq < a.G ? wq : 0) * 8;
+            pg_v2u64 q0 = {0, 0}, q1 = {0, 0}, q2 = {0, 0}, q3 = {0, 0};
+            bool done = wq >= a.G;
+            long long t_wait = 0;
+            for (unsigned spins = 0;; ++spins) {
+                if (!done) {
+                    granule_load8(gp, q0, q1, q2, q3);
+                    done = granule_pair_ok(q0, epoch) && granule_pair_ok(q1, epoch) && granule_pair_ok(q2, epoch) && granule_pair_ok(q3, epoch);
                 }
-                if (wq < G_all) v0 += granule_pair_f64(q0), v1 += granule_pair_f64(q1), v2 += granule_pair_f64(q2), v3 += granule_pair_f64(q3);
-                if (fail) break;
+                if (__all(done)) break;
+                if ((spins & 63u) == 63u) {
+                    const long long now = wall_clock64();
+                    if (t_wait == 0) t_wait = now;
+                    else if (now - t_wait > tmo) {
+                        fail = true;
+                        break;
+                    }
+                }
+                if (a.poll_sleep == 1) __builtin_amdgcn_s_sleep(1);
+                else if (a.poll_sleep == 2) __builtin_amdgcn_s_sleep(2);
+                else if (a.poll_sleep >= 3) __builtin_amdgcn_s_sleep(8);
             }
+            if (wq < a.G && !fail) v0 = granule_pair_f64(q0), v1 = granule_pair_f64(q1), v2 = granule_pair_f64(q2), v3 = granule_pair_f64(q3);
         }
         if (fail && lane == 0) fail_flag = 1;
         v0 = wave_sum64(v0), v1 = wave_sum64(v1), v2 = wave_sum64(v2), v3 = wave_sum64(v3);
@@ -260,6 +254,45 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
             tot[tid] = v;
         }
         __syncthreads();
+        if constexpr (DIST) {   // second level (kernels_persist.h): the rank's sums to every rank by workgroup 0, all add the rank records in rank order
+            const bool lfail = fail_flag != 0;
+            const size_t rbuf = (size_t)phase * a.world * 8;
+            if (g == 0 && !lfail && tid < 4 * a.world) {
+                const int k = tid & 3, q = tid >> 2;
+                publish_f64_x4_sys(a.peer_dboard[q] + rbuf + (size_t)a.rank * 8 + 2 * k, epoch, tot[k]);
+            }
+            __syncthreads();
+            if (wave == 0 && !lfail) {
+                const unsigned long long* gp = a.peer_dboard[a.rank] + rbuf + (size_t)(lane < a.world ? lane : 0) * 8;
+                pg_v2u64 q0 = {0, 0}, q1 = {0, 0}, q2 = {0, 0}, q3 = {0, 0};
+                bool done = lane >= a.world, rfail = false;
+                long long t_wait = 0;
+                for (unsigned spins = 0;; ++spins) {
+                    if (!done) {
+                        granule_load8_sys(gp, q0, q1, q2, q3);
+                        done = granule_pair_ok(q0, epoch) && granule_pair_ok(q1, epoch) && granule_pair_ok(q2, epoch) && granule_pair_ok(q3, epoch);
+                    }
+                    if (__all(done)) break;
+                    if ((spins & 63u) == 63u) {
+                        const long long now = wall_clock64();
+                        if (t_wait == 0) t_wait = now;
+                        else if (now - t_wait > tmo) {
+                            rfail = true;
+                            break;
+                        }
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const bool on = lane < a.world && !rfail;
+                const double w0 = wave_sum64(on ? granule_pair_f64(q0) : 0.0), w1 = wave_sum64(on ? granule_pair_f64(q1) : 0.0),
+                             w2 = wave_sum64(on ? granule_pair_f64(q2) : 0.0), w3 = wave_sum64(on ? granule_pair_f64(q3) : 0.0);
+                if (lane == 0) {
+                    tot[0] = w0, tot[1] = w1, tot[2] = w2, tot[3] = w3;
+                    if (rfail) fail_flag = 1;
+                }
+            }
+            __syncthreads();
+        }
         return fail_flag == 0;
     };
 

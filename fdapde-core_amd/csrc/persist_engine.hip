@@ -480,8 +480,13 @@ int build_rowdist(fdapde_ctx* c, int v) {
     int imp_cap = 0, exp_cap = 0, S = 0;
     for (int attempt = 0; attempt < 2 && local_ok; ++attempt) {
         pl = PersistLayout{};
-        const int rc = host_build_persist_layout(hs, v == 1, n_wg, 12000, pl, nullptr, sym_mode, c->persist_balance != 0, ghost_order.data());
+        const int rc = host_build_persist_layout(hs, v == 1, n_wg, 12000, pl, nullptr, sym_mode, c->persist_balance != 0, ghost_order.data(), /*allow_late=*/true);
         if (rc == FDAPDE_EUNSUPPORTED) {
+            if (std::getenv("FDAPDE_DEBUG_SETUP")) std::fprintf(stderr, "rank %d: row-distributed layout %d: the host builder refuses this rank's share (sym_mode %d, %d workgroups)\n", me, v, sym_mode, n_wg);
+            if (sym_mode != 0 && attempt == 0) {   // (symmetric storage leaves half the slots to rows that import: try the plain form)
+                sym_mode = 0;
+                continue;
+            }
             local_ok = 0;
             break;
         }
@@ -503,7 +508,10 @@ int build_rowdist(fdapde_ctx* c, int v) {
         }
         break;
     }
-    if (local_ok && (fixed > lds_total || (pl.R == 16 && fixed + 10 * (size_t)need <= lds_total))) local_ok = 0;   // (no resident form for 16 rows per thread)
+    if (local_ok && (fixed > lds_total || (pl.R == 16 && fixed + 10 * (size_t)need <= lds_total))) {   // (no resident form for 16 rows per thread)
+        if (std::getenv("FDAPDE_DEBUG_SETUP")) std::fprintf(stderr, "rank %d: row-distributed layout %d: LDS %zu B of %zu (R %d, imports <= %d)\n", me, v, fixed, lds_total, pl.R, pl.max_imp);
+        local_ok = 0;
+    }
     // ---- what the ranks tell each other: [needs from every rank | exported entries (local section of the board) | workgroups | ok]
     const int32_t n_ghost = local_ok ? (int32_t)pl.ghost_needed.size() : 0;
     std::vector<int64_t> need_from((size_t)W + 1, 0);   // prefix over owner ranks of the ghost list
@@ -523,7 +531,7 @@ int build_rowdist(fdapde_ctx* c, int v) {
         if (p < me) L.g_base += (int32_t)M(p, W + 1);
         L.G_tot += (int32_t)M(p, W + 1);
     }
-    if (L.G_tot > 4 * kPersistT) return FDAPDE_OK;   // (a thread gathers at most four dot records)
+    if (W > 64) return FDAPDE_OK;   // (one lane per rank record in the second level of the dot gather)
     // ---- key lists: to every owner the keys needed from it; from every rank the keys it needs from this one
     std::vector<int32_t> xr;
     std::vector<int64_t> soff(1, 0), roff(1, 0);
@@ -555,7 +563,7 @@ int build_rowdist(fdapde_ctx* c, int v) {
     int bad = 0;
     for (size_t q = 0; q < xr.size(); ++q) {
         const int p = xr[q];
-        int64_t base = M(p, W);   // p's local section, then the sections of the owners below this rank
+        int64_t base = 0;   // p's remote section: the sections of the owners below this rank come first
         for (int r = 0; r < me; ++r) base += M(p, r);
         for (int64_t k = roff[q]; k < roff[q + 1]; ++k) {
             const int64_t key = (int64_t)keys_in[(size_t)k];
@@ -580,11 +588,12 @@ int build_rowdist(fdapde_ctx* c, int v) {
     std::vector<uint16_t> rexp_slot(rex.size() + 1);
     for (size_t i = 0; i < rex.size(); ++i) ++rexp_off[(size_t)rex[i].wg + 1], rexp_slot[i] = (uint16_t)rex[i].slot, rexp_peer[i] = rex[i].peer, rexp_pos[i] = rex[i].pos;
     for (int g = 0; g < pl.G; ++g) rexp_off[(size_t)g + 1] += rexp_off[(size_t)g];
-    // ---- the board: [local exports | ghosts | dot records of all workgroups x 2 parities], fine-grained, mapped by every rank
+    // ---- boards.  Inside the rank: [local exports | dot records of the rank's workgroups x 2], ordinary device memory, exactly as on one
+    //      GPU.  Across ranks: [entries imported from other ranks | one dot record per rank x 2], fine-grained, mapped by every rank
     fdapde_ctx::Persist& ps = L.ps;
     // (a rank that cannot allocate, export or map a board must not leave the others waiting in the next exchange: local failures are
     //  carried as flags to the agreement points, where every rank takes the same decision)
-    const size_t n_p = (size_t)pl.n_board + (size_t)n_ghost;
+    const size_t n_p = (size_t)n_ghost;
     int local_err = 0;
     std::string local_msg;
     auto soft = [&](hipError_t e, const char* what) {
@@ -592,15 +601,18 @@ int build_rowdist(fdapde_ctx* c, int v) {
         if (e != hipSuccess) (void)hipGetLastError();
         return e == hipSuccess;
     };
-    if (soft(ps.board.alloc_fine(2 * n_p + 2 * (size_t)L.G_tot * 8 + 2), "board allocation (fine-grained)"))
-        if (soft(hipMemsetAsync(ps.board.p, 0, sizeof(unsigned long long) * ps.board.n, st), "board clear")) soft(hipStreamSynchronize(st), "board clear");
+    if (soft(ps.board.alloc(2 * (size_t)pl.n_board + 2 * (size_t)pl.G * 8 + 2), "board allocation") &&
+        soft(L.rboard.alloc_fine(2 * n_p + 2 * (size_t)W * 8 + 2), "board allocation (fine-grained)"))
+        if (soft(hipMemsetAsync(ps.board.p, 0, sizeof(unsigned long long) * ps.board.n, st), "board clear") &&
+            soft(hipMemsetAsync(L.rboard.p, 0, sizeof(unsigned long long) * L.rboard.n, st), "board clear"))
+            soft(hipStreamSynchronize(st), "board clear");
     ps.epoch_next = 0, ps.attr_set = nullptr;
     const int BW = (int)sizeof(BoardBlob) + 1;   // + this rank's error flag
     std::vector<double> blobs((size_t)W * BW, 0.0);
     {
         BoardBlob b{};
-        b.pid = (int64_t)getpid(), b.ptr = (uint64_t)(uintptr_t)ps.board.p, b.device = c->device;
-        if (!local_err) soft(hipIpcGetMemHandle(&b.handle, ps.board.p), "hipIpcGetMemHandle");
+        b.pid = (int64_t)getpid(), b.ptr = (uint64_t)(uintptr_t)L.rboard.p, b.device = c->device;
+        if (!local_err) soft(hipIpcGetMemHandle(&b.handle, L.rboard.p), "hipIpcGetMemHandle");
         const unsigned char* raw = reinterpret_cast<const unsigned char*>(&b);
         for (int i = 0; i < BW - 1; ++i) blobs[(size_t)me * BW + i] = (double)raw[i];   // (bytes as small integers: exact through a floating-point sum)
         blobs[(size_t)me * BW + BW - 1] = (double)local_err;
@@ -614,7 +626,7 @@ int build_rowdist(fdapde_ctx* c, int v) {
         unsigned char* raw = reinterpret_cast<unsigned char*>(&b);
         for (int i = 0; i < BW - 1; ++i) raw[i] = (unsigned char)blobs[(size_t)p * BW + i];
         unsigned long long* base = nullptr;
-        if (p == me) base = ps.board.p;
+        if (p == me) base = L.rboard.p;
         else if (b.pid == (int64_t)getpid()) {   // another context of this process: the pointer itself (peer access if it lives on another device)
             base = reinterpret_cast<unsigned long long*>((uintptr_t)b.ptr);
             if (b.device != c->device) {
@@ -627,7 +639,7 @@ int build_rowdist(fdapde_ctx* c, int v) {
             if (soft(hipIpcOpenMemHandle(&mapped, b.handle, hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle")) L.ipc_opened.push_back(mapped);
             base = static_cast<unsigned long long*>(mapped);
         }
-        int64_t np_p = M(p, W);
+        int64_t np_p = 0;   // entries rank p imports from other ranks
         for (int r = 0; r < W; ++r) np_p += M(p, r);
         pp[(size_t)p] = base, pd[(size_t)p] = base + 2 * (size_t)np_p;
     }
@@ -638,7 +650,7 @@ int build_rowdist(fdapde_ctx* c, int v) {
             if (local_err) std::fprintf(stderr, "fdapde rank %d: row-distributed boards unavailable (%s)\n", me, local_msg.c_str());
             for (void* m : L.ipc_opened) (void)hipIpcCloseMemHandle(m);
             L.ipc_opened.clear();
-            ps.board.release();
+            ps.board.release(), L.rboard.release();
             return FDAPDE_OK;
         }
     }
@@ -658,6 +670,7 @@ int build_rowdist(fdapde_ctx* c, int v) {
     HIPCHK(c, hipMemsetAsync(ps.ell_val.p, 0, sizeof(double) * ((size_t)pl.n_entries + 256), st));
     HIPCHK(c, ps.amax.alloc(1));
     HIPCHK(c, c->persist_stats.alloc(4 * 1024));
+    HIPCHK(c, L.wg_late.upload(pl.wg_late.data(), pl.wg_late.size(), st));
     HIPCHK(c, L.rexp_off.upload(rexp_off.data(), rexp_off.size(), st));
     HIPCHK(c, L.rexp_slot.upload(rexp_slot.data(), rexp_slot.size(), st));
     HIPCHK(c, L.rexp_peer.upload(rexp_peer.data(), rexp_peer.size(), st));
@@ -724,10 +737,10 @@ int run_rowdist(fdapde_ctx* c, int v, double tol2, int maxit, bool* ran, bool bi
     PersistArgs a{};
     a.maxit = maxit, a.time_phases = c->persist_time, a.tol2 = tol2;
     a.r_in = c->r.p, a.x = c->x.p, a.x_out = c->persist_x.p, a.sc = c->sc.p, a.ctl = c->ctl.p;
-    a.world = c->world, a.g_base = L.g_base, a.G_tot = L.G_tot, a.timeout_first_ticks = c->rd.timeout_first_ms * 100000;
-    a.rexp_off = L.rexp_off.p, a.rexp_slot = L.rexp_slot.p, a.rexp_peer = L.rexp_peer.p, a.rexp_pos = L.rexp_pos.p;
+    a.world = c->world, a.rank = c->rank, a.n_board_local = (int32_t)ps.meta.n_board, a.timeout_first_ticks = c->rd.timeout_first_ms * 100000;
+    a.wg_late = L.wg_late.p, a.rexp_off = L.rexp_off.p, a.rexp_slot = L.rexp_slot.p, a.rexp_peer = L.rexp_peer.p, a.rexp_pos = L.rexp_pos.p;
     a.peer_pboard = L.peer_pboard.p, a.peer_dboard = L.peer_dboard.p;
-    a.pboard = ps.board.p, a.dboard = ps.board.p + 2 * ((size_t)ps.meta.n_board + (size_t)L.n_ghost);
+    a.pboard = ps.board.p, a.dboard = ps.board.p + 2 * (size_t)ps.meta.n_board, a.rboard = L.rboard.p;
     const int rc_launch = launch_persist(c, ps, a, /*dist=*/true, bicg);
     if (rc_launch != FDAPDE_OK && rc_launch != FDAPDE_EUNSUPPORTED) return rc_launch;
     int failed = rc_launch == FDAPDE_EUNSUPPORTED ? 1 : 0;
@@ -763,7 +776,7 @@ void release_rowdist(fdapde_ctx* c) {
         fdapde_ctx::Persist& ps = L.ps;
         ps.slot_dof.release(), ps.sl_off.release(), ps.ell_src.release(), ps.exp_off.release(), ps.imp_off.release(), ps.imp_pos.release(), ps.ell_off.release(),
           ps.ell_code.release(), ps.exp_slot.release(), ps.ell_val.release(), ps.board.release(), ps.amax.release();
-        L.rexp_off.release(), L.rexp_peer.release(), L.rexp_pos.release(), L.rexp_slot.release(), L.peer_pboard.release(), L.peer_dboard.release();
+        L.rexp_off.release(), L.rexp_peer.release(), L.rexp_pos.release(), L.rexp_slot.release(), L.peer_pboard.release(), L.peer_dboard.release(), L.rboard.release(), L.wg_late.release();
         L.x_send_dof.release(), L.x_recv_dof.release(), L.x_sendbuf.release(), L.x_recvbuf.release();
         L.tried = L.ok = false;
     }

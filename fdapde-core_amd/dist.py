@@ -155,15 +155,22 @@ def local_problem(nodes, cells, boundary, part, rank, world, info=None):
 
 
 # ---- row-distributed form (fdapde_rowdist_setup): every DOF is owned by one rank, whose sub-mesh holds every cell touching it ----------
-def node_owners(cells, part, n_nodes):
-    """owner of a node = one of the ranks whose cells touch it: the lowest for even node ids, the highest for odd ones, so that the nodes
-    on an interface are dealt to both sides (lowest-rank-wins would give rank 0 all of its interface nodes and the last rank none)"""
+def node_owners(cells, part, n_nodes, nodes=None):
+    """owner of a node = one of the ranks whose cells touch it.  With coordinates: the lowest such rank in the "white" boxes of a coarse
+    checkerboard (16 boxes per axis of the bounding box), the highest in the "black" ones -- the nodes of an interface are dealt to both
+    sides in PATCHES.  (Dealing them node by node balances just as well but makes every row near an interface read a ghost column: the
+    single-launch layout keeps at most half of a workgroup's slots for rows that import, and C3 split in two then no longer fits.)
+    Without coordinates: the lowest rank."""
     lo = np.full(n_nodes, np.iinfo(np.int32).max, dtype=np.int32)
-    hi = np.full(n_nodes, -1, dtype=np.int32)
     p = np.repeat(part.astype(np.int32), cells.shape[1])
     np.minimum.at(lo, cells.ravel(), p)
+    if nodes is None:
+        return lo
+    hi = np.full(n_nodes, -1, dtype=np.int32)
     np.maximum.at(hi, cells.ravel(), p)
-    return np.where(np.arange(n_nodes) % 2 == 0, lo, hi).astype(np.int32)
+    a, b = nodes.min(axis=0), nodes.max(axis=0)
+    box = np.floor((nodes - a) / np.where(b > a, b - a, 1.0) * 16.0).astype(np.int64).sum(axis=1)
+    return np.where(box % 2 == 0, lo, hi).astype(np.int32)
 
 
 def rowdist_sub_mesh(nodes, cells, boundary, owner, rank):
@@ -191,7 +198,7 @@ def rank_problems_rowdist_p1(nodes, cells, boundary, world):
     """the P1 row-distributed problem of every rank as plain arrays (bench.py's rank 0 ships them): sub-mesh with its ghost layer, global
     node id and owner of every local node"""
     part = partition_cells(nodes, cells, world)
-    owner = node_owners(cells, part, nodes.shape[0])
+    owner = node_owners(cells, part, nodes.shape[0], nodes)
     out = []
     for r in range(world):
         sub = rowdist_sub_mesh(nodes, cells, boundary, owner, r)

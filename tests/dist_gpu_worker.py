@@ -147,7 +147,7 @@ def rowdist_case(rank, world, case, order, nodes, cells, bnd, part, capi, fdist,
     """row-distributed form (fdapde_rowdist_setup): one persistent launch per rank, all ranks' launches acting as one grid through
     peer-mapped boards -- here all on GPU 0, each rank with an equal share of the CUs, boards mapped across the processes by hipIpc"""
     n_g = nodes.shape[0]
-    owner = fdist.node_owners(cells, part, n_g)
+    owner = fdist.node_owners(cells, part, n_g, nodes)
     sub = fdist.rowdist_sub_mesh(nodes, cells, bnd, owner, rank)
     ctx = capi.Context(device=0)
     ctx.mesh_upload(sub["nodes"], sub["cells"], sub["boundary"])

@@ -111,7 +111,7 @@ def test_row_distributed_partition_covers_every_row_completely():
         all_keys = fdist._cell_keys(cells, n, 2)                     # n_cells x n_basis: the P2 DOFs of every cell by global key
         for world in (2, 3):
             part = fdist.partition_cells(nodes, cells, world)
-            owner = fdist.node_owners(cells, part, n)
+            owner = fdist.node_owners(cells, part, n, nodes)
             seen = {}
             for r in range(world):
                 sub = fdist.rowdist_sub_mesh(nodes, cells, bnd, owner, r)

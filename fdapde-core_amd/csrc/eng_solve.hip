@@ -398,7 +398,8 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     const int np_spmv = (c->bk_cur >= 0 && !dist) ? c->bk[c->bk_cur].meta.G : c->spmv_grid;
     const double* fvec = f_dev;
     if (ss.rowdist) {
-        if (u0_dev) return fail(c, FDAPDE_EUNSUPPORTED, "warm starts are not part of the row-distributed solve");
+        // (warm starts: the caller's initial guess must hold the owners' values at the ghost columns -- the parabolic stepper imports them
+        //  after every step, rowdist_import_ghosts)
         const bool want_bicg = method == FDAPDE_SOLVER_BICGSTAB || c->rd.lay[ss.use_bnd ? 1 : 0].ps.built_plain;
         if (method == FDAPDE_SOLVER_CG_SR) return fail(c, FDAPDE_EUNSUPPORTED, "the row-distributed solve runs the fused-update CG or BiCGStab");
         method = want_bicg ? FDAPDE_SOLVER_BICGSTAB : FDAPDE_SOLVER_CG_FUSED;
@@ -869,6 +870,8 @@ int e_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times,
         if (rc == FDAPDE_ENOCONV) rc_all = rc;
         total_iters += c->info.iters;
         worst = c->info.relres > worst ? c->info.relres : worst;
+        if (ss.rowdist)   // u_{i+1} of the columns other ranks own: read by the next step's M u_i and warm start
+            if (int rc2 = rowdist_import_ghosts(c, ss.use_bnd ? 1 : 0, c->u.p)) return rc2;
         HIPCHK(c, hipMemcpyAsync(uprev.p, c->u.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(k_scatter_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->u.p, c->tmp_e.p);
         HIPCHK(c, hipMemcpyAsync(solution + (size_t)(i + 1) * n, c->tmp_e.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));

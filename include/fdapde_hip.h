@@ -275,8 +275,11 @@ int fdapde_halo_setup_peers(fdapde_ctx *ctx, int32_t n_peers, const int32_t *pee
  *   dof_key[d]   : global identity of local DOF d (reference numbering of this rank's space): node id, or n + lo * n + hi for an edge DOF
  *   dof_owner[d] : the rank that owns it; every cell touching a DOF must be in its owner's sub-mesh.  Boundary flags must be the whole
  *                  mesh's (fdapde_dofs_set_boundary where the sub-mesh's own rule would differ).
- * Symmetric positive operators (CG), cold starts, at most 8 x 512 rows per workgroup; anything else returns FDAPDE_EUNSUPPORTED and the
- * caller uses the element-partitioned exchange above.  Solution entries of DOFs owned by other ranks are not computed (0 + Dirichlet lift). */
+ * fdapde_solve (CG for symmetric operators, BiCGStab otherwise: <= 16 / <= 8 rows per thread and workgroup), fdapde_solve_parabolic
+ * (initial condition and Dirichlet data given for ALL local DOFs; the stepper imports the ghost entries of every step's solution) and
+ * fdapde_lin_solve (right-hand sides complete at the owned DOFs) take this path; a system that does not fit returns FDAPDE_EUNSUPPORTED
+ * on every rank and the caller uses the element-partitioned exchange above.  Solution entries of DOFs owned by other ranks: the
+ * Dirichlet lift where there is one, otherwise not computed (the parabolic stepper returns the imported values). */
 int fdapde_rowdist_setup(fdapde_ctx *ctx, const int64_t *dof_key, const int32_t *dof_owner);
 
 /* tuning / diagnostic knobs (A/B measurements inside one process; defaults are the measured best):

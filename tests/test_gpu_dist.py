@@ -77,7 +77,7 @@ def test_partitioned_solve_over_real_rccl(world, nx, case):
 
 
 @pytest.mark.parametrize("world,nx,case", [(2, 16, "p1"), (3, 14, "p1"), (4, 20, "p1"), (2, 40, "sq2"), (2, 8, "p2"), (4, 36, "p1"),
-                                           (2, 16, "adr1"), (3, 8, "adr2")])
+                                           (2, 16, "adr1"), (3, 8, "adr2"), (2, 12, "parab"), (3, 12, "handle")])
 def test_row_distributed_persistent_launches_share_one_gpu(world, nx, case):
     """fdapde_rowdist_setup: every rank assembles the complete rows of the DOFs it owns (ghost layer of cells) and the whole CG runs as ONE
     launch per rank; the launches exchange search-direction entries and dot records through each other's boards (hipIpc-mapped across the
@@ -99,6 +99,22 @@ def test_bench_multi_gpu_leg_plumbing_on_one_gpu():
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["relres"] <= 1e-10
     assert "bytes sent per rank" in rec["config"]["parallelism"]
+    assert rec["config"]["max_abs_error_vs_analytic"] < 6.0 * (1.0 / 24) ** 2 * 3.15**2
+
+
+def test_bench_under_torchrun_runs_the_canary_and_takes_the_row_distributed_form():
+    """the driver's N > 1 command -- python -m torch.distributed.run ... bench.py --gpus N -- with the form left to the bench: rank 0 starts
+    the canary job (processes of its own, before any rank touches the GPU; the launcher's environment must not leak into them), all ranks
+    then run the row-distributed solve.  Gloo plumbing mode, ranks share GPU 0."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FDAPDE_BENCH_BACKEND="gloo")
+    env.pop("FDAPDE_BENCH_EXCHANGE", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--nx", "24"]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["relres"] <= 1e-10
+    assert rec["config"]["exchange_form"] == "rowdist" and rec["config"]["persistent_launch"] == 1
     assert rec["config"]["max_abs_error_vs_analytic"] < 6.0 * (1.0 / 24) ** 2 * 3.15**2
 
 

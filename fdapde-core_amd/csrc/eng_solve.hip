@@ -199,6 +199,10 @@ void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, 
 #undef SPMV_GO
 }
 
+// default iteration bound: 10 n capped at 100 000 -- but ONE number for all ranks of a row-distributed solve (the launches stop by it and
+// advance their epoch tags by it: n is the rank's own DOF count there)
+inline int default_maxit(const fdapde_ctx* c, int64_t n) { return c->rd.ready ? 100000 : (int)(10 * n < 100000 ? 10 * n : 100000); }
+
 // compact solver pattern v (0: no Dirichlet reduction, 1: Dirichlet rows / columns dropped) + its 16-bit column codes; host work
 // and uploads, done once per function space and boundary mask (fdapde_solver_prepare, or lazily by the first solve)
 int build_solver_pattern(fdapde_ctx* c, int v) {
@@ -793,7 +797,7 @@ int e_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     HIPCHK(c, hipSetDevice(c->device));
     const int64_t n = c->hs.n_dofs;
     const double rtol = (opt && opt->rtol > 0) ? opt->rtol : 1e-10;
-    const int maxit = (opt && opt->maxit > 0) ? opt->maxit : (int)(10 * n < 100000 ? 10 * n : 100000);
+    const int maxit = (opt && opt->maxit > 0) ? opt->maxit : default_maxit(c, n);
     const int check_every = (opt && opt->check_every > 0) ? opt->check_every : 32;
     const double* A = c->vals[FDAPDE_MAT_STIFF].p;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -832,7 +836,7 @@ int e_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times,
     const int64_t n = hs.n_dofs;
     hipStream_t st = c->stream;
     const double rtol = (opt && opt->rtol > 0) ? opt->rtol : 1e-10;
-    const int maxit = (opt && opt->maxit > 0) ? opt->maxit : (int)(10 * n < 100000 ? 10 * n : 100000);
+    const int maxit = (opt && opt->maxit > 0) ? opt->maxit : default_maxit(c, n);
     const int check_every = (opt && opt->check_every > 0) ? opt->check_every : 8;
     const double inv_dt = 1.0 / delta_t;
     DBuf<double> kmat, uprev, rhs, gcol;
@@ -982,7 +986,7 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
     const int64_t n = hs.n_dofs;
     hipStream_t st = c->stream;
     const double rtol = (opt && opt->rtol > 0) ? opt->rtol : 1e-10;
-    const int maxit = (opt && opt->maxit > 0) ? opt->maxit : (int)(10 * n < 100000 ? 10 * n : 100000);
+    const int maxit = (opt && opt->maxit > 0) ? opt->maxit : default_maxit(c, n);
     const int check_every = (opt && opt->check_every > 0) ? opt->check_every : 32;
     int method = opt ? opt->method : FDAPDE_SOLVER_AUTO;
     if (method == FDAPDE_SOLVER_AUTO)

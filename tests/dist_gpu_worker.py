@@ -210,6 +210,35 @@ def rowdist_case(rank, world, case, order, nodes, cells, bnd, part, capi, fdist,
         print(f"rank {rank}: ok  case parab rowdist  local dofs {n_loc}  steps {times.size - 1}  err {err:.2e}")
         dist.destroy_process_group()
         return
+    if case == "stall":   # one workgroup of ONE rank stops taking part: every rank must give up together (no hang) and say so the same way;
+                          # the next solve -- epochs advanced past anything the failed launches can have written -- works again
+        for c_, co in ((ctx, lcoords), (ref, gcoords)):
+            c_.set_operator(-capi.laplacian() + capi.reaction(0.5))
+            c_.set_forcing(f(c_.quadrature_nodes()))
+            c_.set_dirichlet(g_fn(co))
+            c_.init()
+        rinfo, uref = ref.solve(rtol=1e-11), ref.solution()
+        ctx.tune("persist_timeout_us", 3000)
+        ctx.tune("rowdist_timeout_first_ms", 200)
+        if rank == world - 1:
+            ctx.tune("persist_debug_stall", 3)
+        refused = False
+        try:
+            ctx.solve(rtol=1e-11)
+        except capi.FdapdeError as e:
+            refused = e.status == capi.EUNSUPPORTED and "hand-off" in str(e)
+        assert refused, "a rank whose peer dropped out must report the collective refusal"
+        ctx.tune("persist_debug_stall", 0)
+        info = ctx.solve(rtol=1e-11)
+        u = ctx.solution()
+        e2 = np.array([np.sum((u[mine] - uref[l2g][mine]) ** 2)])
+        allreduce(e2)
+        err = float(np.sqrt(e2[0])) / np.linalg.norm(uref)
+        assert info.converged == 1 and info.persistent == 1 and err < 1e-9, (info.converged, err)
+        dist.barrier()
+        print(f"rank {rank}: ok  case stall rowdist  local dofs {n_loc}  err {err:.2e}")
+        dist.destroy_process_group()
+        return
     if case == "handle":   # factor-once handle on the mass matrix: right-hand sides complete at the owned DOFs
         for c_ in (ctx, ref):
             c_.set_operator(-capi.laplacian())

@@ -77,7 +77,7 @@ def test_partitioned_solve_over_real_rccl(world, nx, case):
 
 
 @pytest.mark.parametrize("world,nx,case", [(2, 16, "p1"), (3, 14, "p1"), (4, 20, "p1"), (2, 40, "sq2"), (2, 8, "p2"), (4, 36, "p1"),
-                                           (2, 16, "adr1"), (3, 8, "adr2"), (2, 12, "parab"), (3, 12, "handle")])
+                                           (2, 16, "adr1"), (3, 8, "adr2"), (2, 12, "parab"), (3, 12, "handle"), (3, 16, "stall")])
 def test_row_distributed_persistent_launches_share_one_gpu(world, nx, case):
     """fdapde_rowdist_setup: every rank assembles the complete rows of the DOFs it owns (ghost layer of cells) and the whole CG runs as ONE
     launch per rank; the launches exchange search-direction entries and dot records through each other's boards (hipIpc-mapped across the

@@ -473,7 +473,7 @@ int build_rowdist(fdapde_ctx* c, int v) {
     PersistLayout pl;
     const int n_wg = rd.max_wg > 0 ? std::min(rd.max_wg, c->n_cu) : c->n_cu;
     int sym_mode = c->persist_plain ? 0 : (c->persist_sym == 2 ? 3 : c->persist_sym);
-    int local_ok = 1;
+    int local_ok = std::getenv("FDAPDE_ROWDIST_REFUSE") ? 0 : 1;   // (tests: this rank's share "does not fit")
     const size_t lds_total = 160 * 1024 - 1024;
     size_t fixed = 0;
     int64_t need = 0;

@@ -333,7 +333,22 @@ def canary(capi, rdzv, rank, world, device, backend, share):
     return 0 if bad[0] == 0.0 else 1
 
 
+class _FormRefused(Exception):
+    """the row-distributed solve declined the system on every rank (collective by construction)"""
+
+
 def bench_partitioned(capi, rdzv, rank, world, device, args, rtol, backend="rccl", form="peers", share=1):
+    """bench.py's N > 1 leg in the chosen form; a row-distributed solve that the library declines at the real size (the canary only proved
+    the mechanism on a small mesh) falls back to the neighbour exchange on all ranks together"""
+    try:
+        return _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, form, share, tag="")
+    except _FormRefused as e:
+        if rank == 0:
+            print(f"bench.py: the row-distributed solve declined this system ({e}); using the RCCL neighbour exchange", file=sys.stderr)
+        return _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, "peers", share, tag=".2")
+
+
+def _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, form, share, tag):
     """bench.py's N > 1 leg: the C3 mesh split over `world` GPUs (strong scaling).  Rank 0 generates and partitions the mesh and hands
     every rank its own problem through the rendezvous directory -- no other rank materialises the whole mesh.
     form "rowdist": the row-distributed solve (fdapde_rowdist_setup: complete rows per rank, the whole CG as one persistent launch per
@@ -345,15 +360,15 @@ def bench_partitioned(capi, rdzv, rank, world, device, args, rtol, backend="rccl
 
     t_part = time.perf_counter()
     if form == "rowdist":
-        lp = _ship(rdzv, rank, world, "problem", lambda: rank_problems_rowdist_p1(*meshgen.unit_cube(args.nx), world))
+        lp = _ship(rdzv, rank, world, "problem" + tag, lambda: rank_problems_rowdist_p1(*meshgen.unit_cube(args.nx), world))
     else:
-        lp = _ship(rdzv, rank, world, "problem", lambda: rank_problems_p1(*meshgen.unit_cube(args.nx), world))
+        lp = _ship(rdzv, rank, world, "problem" + tag, lambda: rank_problems_p1(*meshgen.unit_cube(args.nx), world))
     t_part = time.perf_counter() - t_part
     u_exact, f = meshgen.manufactured(3)
     ctx = capi.Context(device=device)
     ctx.mesh_upload(lp["nodes"], lp["cells"], lp["boundary"])
     n_loc = ctx.dofs_build(1)
-    grp, transport = _comm_setup(capi, ctx, rdzv, rank, world, backend)
+    grp, transport = _comm_setup(capi, ctx, rdzv, rank, world, backend, tag)
     if form == "rowdist":
         if share > 1:
             ctx.tune("rowdist_share", share)
@@ -381,7 +396,15 @@ def bench_partitioned(capi, rdzv, rank, world, device, args, rtol, backend="rccl
         ctx.init()
         return ctx.solve(rtol=rtol, time_spmv=time_spmv)
 
-    for _ in range(max(args.warmup, 1 if form == "rowdist" else 0)):   # (row-distributed: the first solve builds the layout and maps the boards)
+    if form == "rowdist":   # the first solve builds the layout and maps the boards; a refusal (EUNSUPPORTED) is the same on every rank
+        try:
+            step()
+        except capi.FdapdeError as e:
+            if e.status != capi.EUNSUPPORTED:
+                raise
+            ctx.close()
+            raise _FormRefused(str(e)) from None
+    for _ in range(args.warmup):
         step()
     grp.barrier()
     ctx.synchronize()

@@ -118,6 +118,19 @@ def test_bench_under_torchrun_runs_the_canary_and_takes_the_row_distributed_form
     assert rec["config"]["max_abs_error_vs_analytic"] < 6.0 * (1.0 / 24) ** 2 * 3.15**2
 
 
+def test_bench_falls_back_when_the_row_distributed_solve_declines_the_system():
+    """the canary proves the mechanism on a small mesh; if the library then declines the real system (a rank's share does not fit one
+    launch), every rank gets the same refusal and the bench re-runs the leg with the RCCL neighbour exchange"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FDAPDE_BENCH_BACKEND="gloo", FDAPDE_BENCH_EXCHANGE="rowdist", FDAPDE_ROWDIST_REFUSE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "FDAPDE_BENCH_RDZV"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--nx", "20"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["config"]["exchange_form"] == "peers" and rec["config"]["relres"] <= 1e-10 and "declined" in out.stderr
+
+
 @pytest.mark.parametrize("gpus", [2, 3])
 def test_bench_starts_its_own_ranks_without_a_launcher(gpus):
     """`python bench.py --gpus N` with WORLD_SIZE unset -- the shape of the driver's N = 1 command: the script starts N fresh rank

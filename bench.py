@@ -45,7 +45,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--nx", type=int, default=119, help="cubes per axis of the C3 mesh (119 = BASELINE size)")
+    ap.add_argument("--nx", type=int, default=None, help="cubes per axis of the mesh (default: 119 = C3's BASELINE size; 87 for --workload c5)")
+    ap.add_argument("--workload", choices=("c3", "c5"), default="c3",
+                    help="c3 (default): the headline configuration.  c5 (N > 1 only): BASELINE config C5 -- 3-D P2 advection-diffusion-reaction, "
+                         "Jacobi-BiCGStab -- across the ranks in the row-distributed form")
     ap.add_argument("--cpu-nx", type=int, default=119,
                     help="cubes per axis of the CPU-baseline sample (119 = the GPU line's own workload: ~25 s on 1 core + ~6 s on all cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -436,7 +439,8 @@ def run_ranks(args, rank, world, local_rank):
     res = out
     info = res["info"]
     line = {
-        "metric": "DOF/s assemble+solve, 3D P1 Laplacian; SpMV achieved HBM GB/s vs peak",
+        "metric": ("DOF/s assemble+solve, 3D P2 advection-diffusion-reaction (BASELINE config C5)" if args.workload == "c5" else
+                   "DOF/s assemble+solve, 3D P1 Laplacian; SpMV achieved HBM GB/s vs peak"),
         "value": res["total_dofs"] * args.steps / res["elapsed"],
         "unit": "DOF/s",
         "n_gpus": world,
@@ -449,9 +453,12 @@ def run_ranks(args, rank, world, local_rank):
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"C3: 3-D P1 Laplacian, [0,1]^3, {args.nx}^3 x 6 Kuhn tetrahedra = {res['n_cells_total']} cells, "
-                        f"{res['total_dofs']} DOFs, jitter 0.2h, ids permuted, seed 12345; "
-                        "u = sin(pi x) sin(pi y) sin(pi z), homogeneous Dirichlet; init (stiff+force+mass) + Jacobi-PCG rtol 1e-10",
+            "workload": (f"C5: 3-D P2 advection-diffusion-reaction, b = (1, 0.5, 0.25), c = 1, {args.nx}^3 x 6 = {res['n_cells_total']} tetrahedra, "
+                         f"{res['total_dofs']} DOFs; init + Jacobi-BiCGStab rtol 1e-10; 3-D P2 numbering build-defined (parity unpinned)"
+                         if args.workload == "c5" else
+                         f"C3: 3-D P1 Laplacian, [0,1]^3, {args.nx}^3 x 6 Kuhn tetrahedra = {res['n_cells_total']} cells, "
+                         f"{res['total_dofs']} DOFs, jitter 0.2h, ids permuted, seed 12345; "
+                         "u = sin(pi x) sin(pi y) sin(pi z), homogeneous Dirichlet; init (stiff+force+mass) + Jacobi-PCG rtol 1e-10"),
             "parallelism": res["parallelism"],
             "cg_iterations": int(info.iters),
             "relres": float(info.relres),
@@ -478,6 +485,10 @@ def run_ranks(args, rank, world, local_rank):
 
 def main():
     args = parse()
+    if args.nx is None:
+        args.nx = 87 if args.workload == "c5" else 119
+    if args.workload == "c5" and args.gpus == 1:
+        raise SystemExit("--workload c5 is the multi-GPU form of C5 (--gpus N > 1); on one GPU C5 is reported as `extra.c5` of the default run")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))

@@ -194,16 +194,20 @@ def rowdist_keys_owners(sub, table, owner, n_nodes_g, order):
     return keys, own
 
 
-def rank_problems_rowdist_p1(nodes, cells, boundary, world):
-    """the P1 row-distributed problem of every rank as plain arrays (bench.py's rank 0 ships them): sub-mesh with its ghost layer, global
-    node id and owner of every local node"""
+def rank_problems_rowdist_p1(nodes, cells, boundary, world, with_node_owners=False):
+    """the row-distributed problem of every rank as plain arrays (bench.py's rank 0 ships them): sub-mesh with its ghost layer, global
+    node id and owner of every local node (= the P1 DOF keys / owners); with_node_owners: also the owner of every node of the WHOLE mesh,
+    from which a rank derives keys and owners of its P2 DOFs once its DOF table exists (rowdist_keys_owners)"""
     part = partition_cells(nodes, cells, world)
     owner = node_owners(cells, part, nodes.shape[0], nodes)
     out = []
     for r in range(world):
         sub = rowdist_sub_mesh(nodes, cells, boundary, owner, r)
-        out.append(dict(nodes=sub["nodes"], cells=sub["cells"], boundary=sub["boundary"], l2g=sub["l2g"], key=sub["l2g"].astype(np.int64),
-                        owner=owner[sub["l2g"]].astype(np.int32), n_nodes_total=np.int64(nodes.shape[0]), n_cells_total=np.int64(cells.shape[0])))
+        d = dict(nodes=sub["nodes"], cells=sub["cells"], boundary=sub["boundary"], l2g=sub["l2g"], key=sub["l2g"].astype(np.int64),
+                 owner=owner[sub["l2g"]].astype(np.int32), n_nodes_total=np.int64(nodes.shape[0]), n_cells_total=np.int64(cells.shape[0]))
+        if with_node_owners:
+            d["node_owner"] = owner
+        out.append(d)
     return out
 
 
@@ -233,6 +237,9 @@ class _RcclGroup:
     def max(self, values):
         return self.ctx.comm_allreduce(values, "max")
 
+    def sum(self, values):
+        return self.ctx.comm_allreduce(values, "sum")
+
     def barrier(self):
         self.ctx.comm_allreduce([0.0], "sum")
 
@@ -247,6 +254,11 @@ class _GlooGroup:
     def max(self, values):
         t = self.torch.tensor(np.asarray(values, dtype=float))
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return t.numpy()
+
+    def sum(self, values):
+        t = self.torch.tensor(np.asarray(values, dtype=float))
+        self.dist.all_reduce(t)
         return t.numpy()
 
     def barrier(self):
@@ -338,8 +350,11 @@ class _FormRefused(Exception):
 
 
 def bench_partitioned(capi, rdzv, rank, world, device, args, rtol, backend="rccl", form="peers", share=1):
-    """bench.py's N > 1 leg in the chosen form; a row-distributed solve that the library declines at the real size (the canary only proved
+    """bench.py's N > 1 leg in the chosen form (args.workload "c5": BASELINE config C5 -- 3-D P2 advection-diffusion-reaction, Jacobi-BiCGStab --
+    in the row-distributed form only); a row-distributed solve that the library declines at the real size (the canary only proved
     the mechanism on a small mesh) falls back to the neighbour exchange on all ranks together"""
+    if getattr(args, "workload", "c3") == "c5":
+        return _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, "rowdist", share, tag="")
     try:
         return _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, form, share, tag="")
     except _FormRefused as e:
@@ -358,22 +373,34 @@ def _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, form, shar
 
     from . import meshgen
 
+    c5 = getattr(args, "workload", "c3") == "c5"
+    order = 2 if c5 else 1
     t_part = time.perf_counter()
     if form == "rowdist":
-        lp = _ship(rdzv, rank, world, "problem" + tag, lambda: rank_problems_rowdist_p1(*meshgen.unit_cube(args.nx), world))
+        lp = _ship(rdzv, rank, world, "problem" + tag, lambda: rank_problems_rowdist_p1(*meshgen.unit_cube(args.nx), world, with_node_owners=c5))
     else:
         lp = _ship(rdzv, rank, world, "problem" + tag, lambda: rank_problems_p1(*meshgen.unit_cube(args.nx), world))
     t_part = time.perf_counter() - t_part
     u_exact, f = meshgen.manufactured(3)
+    if c5:
+        from . import workloads
+
+        u_exact, f = workloads.c5_exact, workloads.c5_forcing
     ctx = capi.Context(device=device)
     ctx.mesh_upload(lp["nodes"], lp["cells"], lp["boundary"])
-    n_loc = ctx.dofs_build(1)
+    n_loc = ctx.dofs_build(order)
     grp, transport = _comm_setup(capi, ctx, rdzv, rank, world, backend, tag)
+    coords = lp["nodes"]
     if form == "rowdist":
         if share > 1:
             ctx.tune("rowdist_share", share)
-        ctx.rowdist_setup(lp["key"], lp["owner"])
-        mine = lp["owner"] == rank
+        key, own = lp["key"], lp["owner"]
+        if order == 2:   # keys / owners of the edge DOFs from the rank's own DOF table (3-D: the library's boundary rule for edges -- both end
+                         # nodes on the boundary -- already is the whole mesh's)
+            table, _, coords = ctx.dofs_get()
+            key, own = rowdist_keys_owners(dict(l2g=lp["l2g"], cells=lp["cells"]), table, lp["node_owner"], int(lp["n_nodes_total"]), 2)
+        ctx.rowdist_setup(key, own)
+        mine = own == rank
         msg = grp.max([float(lp["nodes"].shape[0] - int(mine.sum())), float(lp["cells"].shape[0])])
     else:
         # neighbour-only exchange: per-peer packed segments (ncclSend / ncclRecv in one group), then the scalar all-reduce
@@ -385,7 +412,7 @@ def _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, form, shar
         mine = lp["owned"] != 0
         msg = grp.max([float(8 * int(po[-1])), float(pr.size)])   # bytes sent per exchange, peers
     qn = ctx.quadrature_nodes()
-    ctx.set_operator(-capi.laplacian())
+    ctx.set_operator(workloads.c5_operator(capi) if c5 else -capi.laplacian())
     ctx.set_forcing(f(qn))
     ctx.set_dirichlet(np.zeros(n_loc))
     del qn
@@ -414,7 +441,8 @@ def _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, form, shar
     grp.barrier()
     elapsed = time.perf_counter() - t0
     u = ctx.solution()
-    err = float(np.abs(u - u_exact(lp["nodes"]))[mine].max()) if mine.any() else 0.0
+    err = float(np.abs(u - u_exact(coords))[mine].max()) if mine.any() else 0.0
+    n_own = grp.sum([float(mine.sum())])
     info = infos[-1]
     sizes = ctx.sizes()
     _, alg_bytes = ctx.bench_spmv(reps=1)
@@ -444,5 +472,5 @@ def _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, form, shar
                        f"iteration one grouped RCCL send / receive with every neighbour -- the interface entries of A r, <= {int(msg[1])} peers, "
                        f"<= {int(msg[0])} bytes sent per rank -- and one 16-byte all-reduce of (r.Ar, r.r)")
     return dict(elapsed=float(red[0]), err=float(red[1]), t_asm=float(red[2]), t_sol=float(red[3]), setup_ms=float(red[4]), info=info, infos=infos,
-                alg_bytes=float(red[6]), streamed_bytes=float(red[7]), total_dofs=int(lp["n_nodes_total"]), n_cells_total=int(lp["n_cells_total"]),
+                alg_bytes=float(red[6]), streamed_bytes=float(red[7]), total_dofs=int(round(n_own[0])), n_cells_total=int(lp["n_cells_total"]),
                 parallelism=parallelism, transport=transport, t_partition=float(red[9]), form=form)

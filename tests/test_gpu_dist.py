@@ -131,6 +131,22 @@ def test_bench_falls_back_when_the_row_distributed_solve_declines_the_system():
     assert rec["config"]["exchange_form"] == "peers" and rec["config"]["relres"] <= 1e-10 and "declined" in out.stderr
 
 
+def test_bench_c5_workload_across_ranks():
+    """BASELINE config C5 in its multi-GPU form (3-D P2 advection-diffusion-reaction, Jacobi-BiCGStab, row-distributed: one persistent
+    launch per rank) through bench.py's launcher, reduced mesh, ranks sharing GPU 0"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", FDAPDE_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "FDAPDE_BENCH_RDZV", "FDAPDE_BENCH_EXCHANGE"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--workload", "c5", "--steps", "1", "--warmup", "1", "--nx", "10"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 3 and "C5" in rec["config"]["workload"] and rec["config"]["exchange_form"] == "rowdist"
+    assert rec["config"]["persistent_launch"] == 1 and rec["config"]["relres"] <= 1e-10
+    assert f"{21**3} DOFs" in rec["config"]["workload"]   # every P2 DOF of the 10^3 x 6 mesh is owned exactly once
+    assert rec["config"]["max_abs_error_vs_analytic"] < 4e-2   # second-order accurate only (the reference's 5-point rule, DESIGN 7d)
+
+
 @pytest.mark.parametrize("gpus", [2, 3])
 def test_bench_starts_its_own_ranks_without_a_launcher(gpus):
     """`python bench.py --gpus N` with WORLD_SIZE unset -- the shape of the driver's N = 1 command: the script starts N fresh rank

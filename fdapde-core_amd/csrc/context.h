@@ -295,6 +295,7 @@ struct fdapde_ctx {
         DBuf<uint16_t> ell_code, exp_slot;
         DBuf<double> ell_val;
         DBuf<unsigned long long> amax;       // symmetric storage: bit pattern of max |ell_val| (k_persist_fill)
+        DBuf<uint8_t> wg_late;               // BiCGStab layouts built with late-import workgroups (host_build_persist_layout allow_late), else empty
         DBuf<unsigned long long> board;      // [2 n_board granules of p | 2 x G x 6 granules of dot partials], zeroed before every launch
         bool filled = false;                 // ell_val holds the currently scaled system
         uint32_t epoch_next = 0;             // the next launch tags its granules epoch_next + iteration + 1

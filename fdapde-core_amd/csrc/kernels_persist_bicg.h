@@ -139,7 +139,7 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
                 }
             }
         };
-        const bool late = DIST && a.wg_late != nullptr && a.wg_late[g] != 0;   // (uniform for the workgroup)
+        const bool late = a.wg_late != nullptr && a.wg_late[g] != 0;   // (uniform for the workgroup)
         if (!late) product(std::integral_constant<int, 0>{});
         {
             bool fail = false;

@@ -72,6 +72,7 @@ int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_r
     int imp_cap = 0, exp_cap = 0, S = 0;
     // symmetric storage (kernels_persist.h SYM) where the plain blocks would not fit the LDS; the plain form where they do (C2: the
     // iteration is latency-bound there, fewer bytes buy nothing) or where the accumulator table leaves no room for the vectors
+    bool late_ok = false;
     int sym_mode = c->persist_sym == 2 ? 3 : c->persist_sym;   // 0 never, 1 always, 2 auto: tried wherever the plain blocks would stream (3) ...
     if (c->persist_plain) sym_mode = 0;                        // (a non-symmetric system: BiCGStab on the plain storage)
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -86,7 +87,18 @@ int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_r
             clk.mark("build_persist: (before ensure_host)");
             if (int rc2 = ensure_host(c, kHostPattern)) return rc2;
             clk.mark("build_persist: ensure_host");
-            rc = host_build_persist_layout(c->hs, v == 1, n_wg, 12000, pl, brows, sym_mode, balance);   // ~12 000 ELL entries (120 KB) next to the vectors of <= 4096 rows
+            rc = host_build_persist_layout(c->hs, v == 1, n_wg, 12000, pl, brows, sym_mode, balance, nullptr, late_ok);   // ~12 000 ELL entries (120 KB) next to the vectors of <= 4096 rows
+        }
+        // a non-symmetric system (BiCGStab: six vectors in registers, at most 8 rows per thread) whose rows WOULD fit 8 per thread but whose
+        // importing rows overflow the second half of a workgroup's slots (3-D: ~50 % of a block's rows read a neighbouring block) got 16: the
+        // host builder once more, with such workgroups marked late (imports before their first pass) instead of doubled rows per thread
+        // (3-D P2 advection-diffusion-reaction, 913 k DOFs: multi-launch 142 us per iteration, single launch ~105)
+        if (c->persist_plain && !late_ok && block_rows == nullptr && (rc == FDAPDE_EUNSUPPORTED || (rc == FDAPDE_OK && pl.R > 8)) &&
+            (rc == FDAPDE_EUNSUPPORTED ? (c->hs.n_dofs + n_wg - 1) / n_wg <= 8 * kPersistT : (pl.n_int + pl.G - 1) / pl.G <= 8 * kPersistT) && attempt == 0) {
+            dev_persist_release(&dp);
+            late_ok = true, on_device = false;
+            --attempt;
+            continue;
         }
         if (rc == FDAPDE_EUNSUPPORTED) return FDAPDE_OK;
         if (rc) return rc;
@@ -156,6 +168,8 @@ int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_r
         HIPCHK(c, ps.imp_off.upload(pl.imp_off.data(), pl.imp_off.size(), st));
         HIPCHK(c, ps.imp_pos.upload(pl.imp_pos.data(), pl.imp_pos.size(), st));
     }
+    if (late_ok && !pl.wg_late.empty()) HIPCHK(c, ps.wg_late.upload(pl.wg_late.data(), pl.wg_late.size(), st));
+    else ps.wg_late.release();
     HIPCHK(c, ps.ell_val.alloc((size_t)pl.n_entries + 256));
     HIPCHK(c, hipMemsetAsync(ps.ell_val.p, 0, sizeof(double) * ((size_t)pl.n_entries + 256), st));
     HIPCHK(c, ps.board.alloc(2 * (size_t)pl.n_board + 2 * (size_t)pl.G * 8 + 2));   // p entries | dot records x 2 buffers (CG: 3 doubles wide, BiCGStab: 4)
@@ -186,7 +200,7 @@ int launch_persist(fdapde_ctx* c, fdapde_ctx::Persist& ps, PersistArgs& a, bool 
     a.gather_waves = c->persist_gather_waves, a.poll_sleep = c->persist_poll_sleep;
     a.slot_dof = ps.slot_dof.p, a.ell_off = ps.ell_off.p, a.sl_off = ps.sl_off.p, a.ell_code = ps.ell_code.p;
     a.ell_val = ps.ell_val.p, a.exp_off = ps.exp_off.p, a.exp_slot = ps.exp_slot.p, a.imp_off = ps.imp_off.p, a.imp_pos = ps.imp_pos.p;
-    if (!dist) a.pboard = ps.board.p, a.dboard = ps.board.p + 2 * (size_t)ps.meta.n_board;   // (row-distributed: set by the caller)
+    if (!dist) a.pboard = ps.board.p, a.dboard = ps.board.p + 2 * (size_t)ps.meta.n_board, a.wg_late = ps.wg_late.p;   // (row-distributed: set by the caller)
     a.amax_bits = ps.amax.p, a.max_len = c->hs.max_row, a.stats = c->persist_stats.p;
     a.timeout_ticks = c->persist_timeout_us * 100, a.debug_stall_it = c->persist_debug_stall;
     if (!dist && ps.epoch_next > 0xC0000000u - 2u * (uint32_t)a.maxit) {   // (the tags are 32 bits wide: start over on clean boards)

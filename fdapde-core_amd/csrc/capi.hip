@@ -313,6 +313,10 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "persist_time" && (value == 0 || value == 1)) c->persist_time = value;
     else if (k == "persist_coop" && (value == 0 || value == 1)) c->persist_coop = value;
     else if (k == "persist_bicg" && (value == 0 || value == 1)) c->persist_bicg = value;
+    else if (k == "persist_late" && (value == 0 || value == 1)) {
+        c->persist_late = value;
+        for (auto& ps : c->ps) ps.tried = ps.ok = ps.filled = false;
+    }
     else if (k == "rowdist_max_wg" && value >= 0) {   // workgroups of this rank's launch (tests: several ranks share one device)
         c->rd.max_wg = value;
         for (auto& L : c->rd.lay) L.tried = L.ok = false;

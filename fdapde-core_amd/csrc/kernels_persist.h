@@ -411,7 +411,7 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
                 }
             }
         };
-        const bool late = DIST && a.wg_late != nullptr && a.wg_late[g] != 0;   // (uniform for the workgroup)
+        const bool late = a.wg_late != nullptr && a.wg_late[g] != 0;   // (uniform for the workgroup)
         if (!late) product(std::integral_constant<int, 0>{});
         {   // imports, four per lane at a time with their loads in flight together (a workgroup in the middle of a 3-D mesh imports ~3 000
             // entries: one after the other that was six dependent round trips per wavefront, measured as 1.5 us per 1 000 imports); a lane

@@ -72,7 +72,8 @@ int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_r
     int imp_cap = 0, exp_cap = 0, S = 0;
     // symmetric storage (kernels_persist.h SYM) where the plain blocks would not fit the LDS; the plain form where they do (C2: the
     // iteration is latency-bound there, fewer bytes buy nothing) or where the accumulator table leaves no room for the vectors
-    bool late_ok = false;
+    bool late_ok = c->persist_late != 0 && block_rows == nullptr;   // (knob; off by default: see DESIGN 4.0)
+    if (late_ok) on_device = false;   // (only the host builder knows late workgroups)
     int sym_mode = c->persist_sym == 2 ? 3 : c->persist_sym;   // 0 never, 1 always, 2 auto: tried wherever the plain blocks would stream (3) ...
     if (c->persist_plain) sym_mode = 0;                        // (a non-symmetric system: BiCGStab on the plain storage)
     for (int attempt = 0; attempt < 2; ++attempt) {

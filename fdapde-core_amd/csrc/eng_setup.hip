@@ -380,6 +380,7 @@ int e_dofs_set_boundary(fdapde_ctx* c, const uint8_t* bnd) {
     for (int64_t i = 0; i < hs.n_dofs; ++i) hs.dof_bnd_i[(size_t)i] = hs.dof_bnd[(size_t)hs.dof_i2e[(size_t)i]];
     c->sp_built[1] = false;   // the compact solver pattern drops Dirichlet rows / columns
     c->ps[1].tried = c->ps[1].ok = false, c->bk[1].tried = c->bk[1].ok = false, c->bk_cur = -1;
+    c->rd.lay[1].tried = c->rd.lay[1].ok = false;   // (row-distributed form: rebuilt -- collectively -- by the next solve)
     drop_graph(c);
     c->solved = false, c->scaled_owner = fdapde_ctx::kScaledNone;
     if (c->dev_ready) {

@@ -470,6 +470,8 @@ int build_rowdist(fdapde_ctx* c, int v) {
     fdapde_ctx::RowDist::Layout& L = rd.lay[v];
     if (L.tried) return FDAPDE_OK;
     L.tried = true, L.ok = false;
+    for (void* m : L.ipc_opened) (void)hipIpcCloseMemHandle(m);   // (a rebuild after the boundary flags changed: the old mappings go)
+    L.ipc_opened.clear();
     const int W = c->world, me = c->rank;
     const HostSpace& hs = c->hs;
     const int64_t nd = hs.n_dofs;

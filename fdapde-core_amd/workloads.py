@@ -141,5 +141,17 @@ def run_c5(capi, meshgen, nx=87, steps=1, warmup=1, time_spmv=16, rtol=1e-10, de
     out.update(workload=f"C5: 3-D P2 advection-diffusion-reaction, {nx}^3 x 6 = {n_cells} tetrahedra, b = (1, 0.5, 0.25), c = 1, "
                         "Jacobi-BiCGStab; 3-D P2 numbering build-defined (parity unpinned)",
                cells=n_cells, t_setup_s=t_setup)
+    try:   # HBM bytes per SpMV launch from the committed counter passes of this workload (tools/profile_c5.sh), labelled: not this run
+        import json
+        import os
+
+        pj = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r3_c5_spmv_pmc.json")))
+        if nx == 87 and not out["persistent"] and pj.get("hbm_bytes_per_launch") and out.get("spmv_avg_us"):
+            out["traffic"] = float(pj["hbm_bytes_per_launch"])
+            out["traffic_frac"] = out["traffic"] / (out["spmv_avg_us"] * 1e-6) / 1e9 / hbm_peak_gbps
+            out["traffic_source"] = ("profiles/r3_c5_spmv_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE of k_spmv_blocked, separate rocprofv3 --pmc passes of an "
+                                     "earlier run of this workload (not this run)")
+    except Exception:
+        pass
     ctx.close()
     return out

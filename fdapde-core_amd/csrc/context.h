@@ -154,6 +154,7 @@ struct GraphKey {
 // what solve_prepare decided for a system matrix (shared by the elliptic, parabolic and handle solves)
 struct SolveState {
     bool dist = false, diag_positive = true;
+    bool symmetric = true;  // what solve_prepare was told about the matrix (row-distributed form: CG or BiCGStab launch)
     bool rowdist = false;   // row-distributed multi-GPU form: complete rows of the owned DOFs, one persistent launch per rank
     const uint8_t* owned = nullptr;
     int use_bnd = 0;

@@ -292,7 +292,7 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss, b
     hipStream_t st = c->stream;
     ss->dist = (c->comm != nullptr || c->ar_fn != nullptr) && c->halo_ready;   // multi-GPU: sub-assembled operator of this rank's cells
     ss->owned = ss->dist ? c->owned.p : nullptr;
-    ss->use_bnd = use_bnd;
+    ss->use_bnd = use_bnd, ss->symmetric = symmetric;
     ss->rowdist = (c->comm != nullptr || c->ar_fn != nullptr) && c->rd.ready && !ss->dist;
     if (ss->rowdist) ss->owned = c->rd.owned.p;
     HIPCHK(c, hipMemsetAsync(c->ctl.p, 0, 4 * sizeof(int32_t), st));
@@ -404,7 +404,7 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     if (ss.rowdist) {
         // (warm starts: the caller's initial guess must hold the owners' values at the ghost columns -- the parabolic stepper imports them
         //  after every step, rowdist_import_ghosts)
-        const bool want_bicg = method == FDAPDE_SOLVER_BICGSTAB || c->rd.lay[ss.use_bnd ? 1 : 0].ps.built_plain;
+        const bool want_bicg = method == FDAPDE_SOLVER_BICGSTAB || !ss.symmetric;
         if (method == FDAPDE_SOLVER_CG_SR) return fail(c, FDAPDE_EUNSUPPORTED, "the row-distributed solve runs the fused-update CG or BiCGStab");
         method = want_bicg ? FDAPDE_SOLVER_BICGSTAB : FDAPDE_SOLVER_CG_FUSED;
     }

@@ -359,6 +359,34 @@ def test_distributed_code_path_on_one_rank(capi, ctx, oracle, mesh_loader):
     assert np.abs(ctx.solution() - u_plain).max() <= 1e-9 * max(1.0, np.abs(u_plain).max())
 
 
+def test_row_distributed_form_and_rccl_reductions_on_one_rank(capi, ctx, oracle, mesh_loader):
+    """fdapde_rowdist_setup over the library's own RCCL communicator with ONE rank (every DOF owned here, no ghost): the row-distributed
+    instantiation of the single launch (fine-grained rank board, two-level dot gather with one rank record, system-scope accesses) against
+    the ORACLE's direct solve; and fdapde_comm_allreduce, what bench.py's ranks use for barriers and the max over ranks, over real RCCL"""
+    m = mesh_loader("unit_square")
+    ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = ctx.dofs_build(2)
+    _, _, coords = ctx.dofs_get()
+    nq = ctx.sizes()["n_quadrature"]
+    fq = np.cos(2.0 * ctx.quadrature_nodes()[:, 0])
+    g = coords[:, 0] - 0.5 * coords[:, 1]
+    ctx.comm_init(1, 0, capi.Context.comm_unique_id())
+    assert "/opt/rocm" in capi.Context.comm_library(), capi.Context.comm_library()   # the RCCL of the HIP runtime this library is bound to
+    assert np.array_equal(ctx.comm_allreduce([1.5, -2.0, 7.0], "max"), [1.5, -2.0, 7.0])
+    assert np.array_equal(ctx.comm_allreduce([0.25, 3.0], "sum"), [0.25, 3.0])
+    ctx.rowdist_setup(np.arange(nd, dtype=np.int64), np.zeros(nd, dtype=np.int32))
+    for op_c, op_o, method in ((-capi.laplacian() + capi.reaction(0.7), -oracle.laplacian() + oracle.reaction(0.7), capi.SOLVER_CG_FUSED),
+                               (-capi.laplacian() + capi.advection([0.8, -0.4]), -oracle.laplacian() + oracle.advection([0.8, -0.4]), capi.SOLVER_BICGSTAB)):
+        ctx.set_operator(op_c)
+        ctx.set_forcing(fq)
+        ctx.set_dirichlet(g)
+        ctx.init()
+        info = ctx.solve(rtol=1e-11)
+        assert info.converged == 1 and info.persistent == 1 and info.method_used == method
+        ref = oracle.pde_init_solve(m, 2, op_o, forcing_q=fq, dirichlet=g)
+        assert np.linalg.norm(ctx.solution() - ref.solution) / np.linalg.norm(ref.solution) <= SOL_TOL
+
+
 def test_factor_once_solve_many(capi, ctx, oracle, mesh_loader):
     """fdapde::SparseLU usage (utils/symbols.h:133-160; SMW, linear_algebra/smw.h:46-48): compute(A) once, solve(B) for
     several right-hand sides; symmetric (CG) and general (BiCGStab) matrices; values handed over or taken from the context"""

@@ -42,7 +42,7 @@ def main():
            (lambda: capi.dt() - capi.laplacian()) if case == "parab" else (lambda: -capi.laplacian())
     part = fdist.partition_cells(nodes, cells, world)
     if exchange_mode == "rowdist":
-        return rowdist_case(rank, world, case, order, nodes, cells, bnd, part, capi, fdist, dist, torch, u_exact, f, g_fn)
+        return rowdist_case(rank, world, case, order, nodes, cells, bnd, part, capi, fdist, dist, torch, u_exact, f, g_fn, transport)
     info_if = fdist.interface_info(cells, part, n_g, world, order, bnd)
     sub = fdist.sub_mesh(nodes, cells, bnd, part, rank)
 
@@ -143,13 +143,14 @@ def main():
     dist.destroy_process_group()
 
 
-def rowdist_case(rank, world, case, order, nodes, cells, bnd, part, capi, fdist, dist, torch, u_exact, f, g_fn):
+def rowdist_case(rank, world, case, order, nodes, cells, bnd, part, capi, fdist, dist, torch, u_exact, f, g_fn, transport="shared"):
     """row-distributed form (fdapde_rowdist_setup): one persistent launch per rank, all ranks' launches acting as one grid through
     peer-mapped boards -- here all on GPU 0, each rank with an equal share of the CUs, boards mapped across the processes by hipIpc"""
     n_g = nodes.shape[0]
     owner = fdist.node_owners(cells, part, n_g, nodes)
     sub = fdist.rowdist_sub_mesh(nodes, cells, bnd, owner, rank)
-    ctx = capi.Context(device=0)
+    dev_id = rank if transport == "rccl" else 0   # "rccl": one rank per GPU, boards mapped across the devices (xGMI) -- the product configuration
+    ctx = capi.Context(device=dev_id)
     ctx.mesh_upload(sub["nodes"], sub["cells"], sub["boundary"])
     n_loc = ctx.dofs_build(order)
     table, _, lcoords = ctx.dofs_get()
@@ -174,11 +175,16 @@ def rowdist_case(rank, world, case, order, nodes, cells, bnd, part, capi, fdist,
         for a, b, t_in, _ in parts:
             recv[a:b] = t_in.numpy()
 
-    ctx.comm_init_callback(world, rank, allreduce)
-    ctx.comm_set_exchange_callback(exchange)
-    ctx.tune("rowdist_share", world)
+    if transport == "rccl":
+        uid = [capi.Context.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(world, rank, uid[0])
+    else:
+        ctx.comm_init_callback(world, rank, allreduce)
+        ctx.comm_set_exchange_callback(exchange)
+        ctx.tune("rowdist_share", world)
     ctx.rowdist_setup(keys, own)
-    ref = capi.Context(device=0)
+    ref = capi.Context(device=dev_id)
     ref.mesh_upload(nodes, cells, bnd)
     ref.dofs_build(order)
     gtable, gbnd, gcoords = ref.dofs_get()

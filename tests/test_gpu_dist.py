@@ -86,6 +86,16 @@ def test_row_distributed_persistent_launches_share_one_gpu(world, nx, case):
     _run_ranks(world, nx, case, "shared", "rowdist")
 
 
+@pytest.mark.parametrize("world,nx,case", [(2, 24, "p1"), (2, 8, "p2"), (2, 16, "adr1"), (2, 12, "parab"), (2, 16, "stall"), (4, 30, "p1"), (8, 40, "p1"), (8, 12, "adr2")])
+def test_row_distributed_launches_over_xgmi(world, nx, case):
+    """the product configuration of the row-distributed form: one rank per GPU, boards mapped across the devices through hipIpc, entries
+    and rank records pushed over xGMI, set-up over the library's RCCL communicator.  Needs `world` GPUs (skipped on the 1-GPU boxes of this
+    pool, where the same code runs with the ranks sharing one device: test_row_distributed_persistent_launches_share_one_gpu)."""
+    if _n_gpus() < world:
+        pytest.skip(f"needs {world} GPUs, this box has {_n_gpus()}")
+    _run_ranks(world, nx, case, "rccl", "rowdist")
+
+
 def test_bench_multi_gpu_leg_plumbing_on_one_gpu():
     """bench.py --gpus 2 under torch.distributed.run with FDAPDE_BENCH_BACKEND=gloo: both ranks share GPU 0 and the exchange is
     host-staged, everything else -- partition, neighbour lists, the device-side pack / sum kernels, the JSON line -- is what the

@@ -324,6 +324,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
         c->rd.max_wg = std::max(1, c->n_cu / value);
         for (auto& L : c->rd.lay) L.tried = L.ok = false;
     } else if (k == "rowdist_timeout_first_ms" && value >= 1) c->rd.timeout_first_ms = value;
+    else if (k == "rowdist_flat_gather" && value >= -1 && value <= 1) c->rd.flat_gather = value;
     else if (k == "persist_timeout_us" && value >= 100 && value <= 10000000) c->persist_timeout_us = value;
     else if (k == "persist_debug_stall" && value >= 0) c->persist_debug_stall = value;   // (tests: forces the hand-off timeout at that iteration)
     else if (k == "persist_retry" && value == 1) c->persist_broken = false, c->persist_retry_in = 0, c->persist_backoff = 8;   // (tests: forget an earlier timeout)

@@ -312,6 +312,7 @@ struct fdapde_ctx {
         std::vector<int64_t> key_i;          // ... global key
         DBuf<uint8_t> owned;                 // 1 = this rank's DOF
         int max_wg = 0;                      // workgroups this rank's launch may use (0: one per CU; tests put several ranks on one device)
+        int flat_gather = -1;                // dot gather across ranks: -1 auto (one hop while G_tot <= 1024, else two levels), 0 / 1 forced
         int timeout_first_ms = 2000;         // bound of the waits of iteration 0 (launch skew between the ranks)
         struct Layout {
             bool tried = false, ok = false;

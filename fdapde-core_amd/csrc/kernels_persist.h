@@ -65,6 +65,9 @@ struct PersistArgs {
     //      two levels: inside the rank as ever, then workgroup 0 pushes the rank's sums to every rank and all workgroups add the `world` rank
     //      records in rank order (the same bits everywhere).  Accesses of that board are system-scope (sc0 sc1).
     int32_t world, rank, n_board_local;   // ranks; this rank; import positions >= n_board_local lie in the remote section of rboard
+    int32_t flat_gather, g_base, G_tot;   // flat_gather: ONE hop instead of two for the dot products -- every workgroup pushes its record to every
+                                          // rank (flat section behind the rank records: [buffer][G_tot][4 values][2 granules]) and gathers all G_tot
+                                          // records of all ranks' workgroups (global index g_base + g); chosen for few ranks (G_tot <= 1024)
     int32_t timeout_first_ticks;      // bound of the waits of iteration 0 (the launches of the ranks start at different times)
     const int32_t* rexp_off;          // [G + 1] remote exports of a workgroup
     const uint16_t* rexp_slot;        // slot whose entry goes out
@@ -495,6 +498,64 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
         const double s2 = wave_sum64(rr_part);
         if (lane == 0) red[wave][0] = s0, red[wave][1] = s1, red[wave][2] = s2;
         __syncthreads();
+        const bool flat = DIST && a.flat_gather != 0;   // (uniform for the launch)
+        if (flat) {
+            // ONE hop: the record goes into the flat section of EVERY rank's board (thread (k, q) pushes value k to rank q), then thread t
+            // collects the records t, t + 512, ... of all ranks' workgroups from the LOCAL board; the same order everywhere
+            if (tid < 3) {
+                double v = 0;
+#pragma unroll
+                for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
+                tot[tid] = v;
+            }
+            __syncthreads();
+            const size_t fbuf = (size_t)2 * a.world * 8 + (size_t)(it & 1) * a.G_tot * 8;
+            if (tid < 3 * a.world) {
+                const int k = tid % 3, q = tid / 3;
+                publish_f64_x4_sys(a.peer_dboard[q] + fbuf + (size_t)(a.g_base + g) * 8 + 2 * k, epoch, tot[k]);
+            }
+            double v0 = 0, v1 = 0, v2 = 0;
+            bool fail = false;
+            const int per_lane = (a.G_tot + T - 1) / T;
+            if (wave * 64 < a.G_tot) {   // wave-uniform
+                for (int rsel = 0; rsel < per_lane; ++rsel) {
+                    const int w = rsel * T + tid;
+                    const unsigned long long* gp = a.peer_dboard[a.rank] + fbuf + (size_t)(w < a.G_tot ? w : 0) * 8;
+                    pg_v2u64 q0 = {0, 0}, q1 = {0, 0}, q2 = {0, 0};
+                    bool done = w >= a.G_tot;
+                    long long t_wait = 0;
+                    for (unsigned spins = 0;; ++spins) {
+                        if (!done) {
+                            granule_load6_sys(gp, q0, q1, q2);
+                            done = granule_pair_ok(q0, epoch) && granule_pair_ok(q1, epoch) && granule_pair_ok(q2, epoch);
+                        }
+                        if (__all(done)) break;
+                        if ((spins & 63u) == 63u) {
+                            const long long now = wall_clock64();
+                            if (t_wait == 0) t_wait = now;
+                            else if (now - t_wait > tmo) {
+                                fail = true;
+                                break;
+                            }
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (w < a.G_tot && !fail) v0 += granule_pair_f64(q0), v1 += granule_pair_f64(q1), v2 += granule_pair_f64(q2);
+                    if (fail) break;
+                }
+            }
+            if (fail && lane == 0) fail_flag = 1;
+            v0 = wave_sum64(v0), v1 = wave_sum64(v1), v2 = wave_sum64(v2);
+            __syncthreads();   // (the values in tot / red have been consumed)
+            if (lane == 0) red[wave][0] = v0, red[wave][1] = v1, red[wave][2] = v2;
+            __syncthreads();
+            if (tid < 3) {
+                double v = 0;
+#pragma unroll
+                for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
+                tot[tid] = v;
+            }
+        } else {
         unsigned long long* dslot = a.dboard + (size_t)(it & 1) * a.G * 6;
         if (tid < 3) {
             double v = 0;
@@ -591,6 +652,7 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
                     if (fail) fail_flag = 1;
                 }
             }
+        }
         }
         __syncthreads();
         if (fail_flag) {

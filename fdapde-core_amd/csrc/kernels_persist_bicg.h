@@ -207,6 +207,63 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
         __syncthreads();   // (the table reads of the application before, and the totals of the gather before, are done with)
         if (lane == 0) red[wave][0] = s0, red[wave][1] = s1, red[wave][2] = s2, red[wave][3] = s3;
         __syncthreads();
+        if (DIST && a.flat_gather != 0) {   // ONE hop (kernels_persist.h): every workgroup's record to every rank, all G_tot records gathered locally
+            if (tid < 4) {
+                double v = 0;
+#pragma unroll
+                for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
+                tot[tid] = v;
+            }
+            __syncthreads();
+            const size_t fbuf = (size_t)2 * a.world * 8 + (size_t)phase * a.G_tot * 8;
+            if (tid < 4 * a.world) {
+                const int k = tid & 3, q = tid >> 2;
+                publish_f64_x4_sys(a.peer_dboard[q] + fbuf + (size_t)(a.g_base + g) * 8 + 2 * k, epoch, tot[k]);
+            }
+            double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+            bool fail = false;
+            const int per_lane = (a.G_tot + T - 1) / T;
+            if (wave * 64 < a.G_tot) {
+                for (int rsel = 0; rsel < per_lane; ++rsel) {
+                    const int wq = rsel * T + tid;
+                    const unsigned long long* gp = a.peer_dboard[a.rank] + fbuf + (size_t)(wq < a.G_tot ? wq : 0) * 8;
+                    pg_v2u64 q0 = {0, 0}, q1 = {0, 0}, q2 = {0, 0}, q3 = {0, 0};
+                    bool done = wq >= a.G_tot;
+                    long long t_wait = 0;
+                    for (unsigned spins = 0;; ++spins) {
+                        if (!done) {
+                            granule_load8_sys(gp, q0, q1, q2, q3);
+                            done = granule_pair_ok(q0, epoch) && granule_pair_ok(q1, epoch) && granule_pair_ok(q2, epoch) && granule_pair_ok(q3, epoch);
+                        }
+                        if (__all(done)) break;
+                        if ((spins & 63u) == 63u) {
+                            const long long now = wall_clock64();
+                            if (t_wait == 0) t_wait = now;
+                            else if (now - t_wait > tmo) {
+                                fail = true;
+                                break;
+                            }
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (wq < a.G_tot && !fail) v0 += granule_pair_f64(q0), v1 += granule_pair_f64(q1), v2 += granule_pair_f64(q2), v3 += granule_pair_f64(q3);
+                    if (fail) break;
+                }
+            }
+            if (fail && lane == 0) fail_flag = 1;
+            v0 = wave_sum64(v0), v1 = wave_sum64(v1), v2 = wave_sum64(v2), v3 = wave_sum64(v3);
+            __syncthreads();
+            if (lane == 0) red[wave][0] = v0, red[wave][1] = v1, red[wave][2] = v2, red[wave][3] = v3;
+            __syncthreads();
+            if (tid < 4) {
+                double v = 0;
+#pragma unroll
+                for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
+                tot[tid] = v;
+            }
+            __syncthreads();
+            return fail_flag == 0;
+        }
         unsigned long long* dslot = a.dboard + (size_t)phase * a.G * 8;
         if (tid < 4) {
             double v = 0;

@@ -619,7 +619,7 @@ int build_rowdist(fdapde_ctx* c, int v) {
         return e == hipSuccess;
     };
     if (soft(ps.board.alloc(2 * (size_t)pl.n_board + 2 * (size_t)pl.G * 8 + 2), "board allocation") &&
-        soft(L.rboard.alloc_fine(2 * n_p + 2 * (size_t)W * 8 + 2), "board allocation (fine-grained)"))
+        soft(L.rboard.alloc_fine(2 * n_p + 2 * (size_t)W * 8 + 2 * (size_t)L.G_tot * 8 + 2), "board allocation (fine-grained)"))
         if (soft(hipMemsetAsync(ps.board.p, 0, sizeof(unsigned long long) * ps.board.n, st), "board clear") &&
             soft(hipMemsetAsync(L.rboard.p, 0, sizeof(unsigned long long) * L.rboard.n, st), "board clear"))
             soft(hipStreamSynchronize(st), "board clear");
@@ -755,6 +755,9 @@ int run_rowdist(fdapde_ctx* c, int v, double tol2, int maxit, bool* ran, bool bi
     a.maxit = maxit, a.time_phases = c->persist_time, a.tol2 = tol2;
     a.r_in = c->r.p, a.x = c->x.p, a.x_out = c->persist_x.p, a.sc = c->sc.p, a.ctl = c->ctl.p;
     a.world = c->world, a.rank = c->rank, a.n_board_local = (int32_t)ps.meta.n_board, a.timeout_first_ticks = c->rd.timeout_first_ms * 100000;
+    // dot products in one hop (every workgroup's record to every rank) while the records are few, in two (rank records) beyond: a flat
+    // gather over 8 x 256 workgroups is 25 MB of uncached reads per GPU and iteration
+    a.g_base = L.g_base, a.G_tot = L.G_tot, a.flat_gather = c->rd.flat_gather < 0 ? (L.G_tot <= 1024 ? 1 : 0) : c->rd.flat_gather;
     a.wg_late = L.wg_late.p, a.rexp_off = L.rexp_off.p, a.rexp_slot = L.rexp_slot.p, a.rexp_peer = L.rexp_peer.p, a.rexp_pos = L.rexp_pos.p;
     a.peer_pboard = L.peer_pboard.p, a.peer_dboard = L.peer_dboard.p;
     a.pboard = ps.board.p, a.dboard = ps.board.p + 2 * (size_t)ps.meta.n_board, a.rboard = L.rboard.p;

@@ -18,6 +18,8 @@ sys.path.insert(0, ROOT)
 def main():
     rank, world, port, nx = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
     case = sys.argv[5] if len(sys.argv) > 5 else "p1"
+    two_level = case.endswith(":2level")   # row-distributed form: force the two-level dot gather (the automatic choice for > 1024 workgroups)
+    case = case.split(":")[0]
     transport = sys.argv[6] if len(sys.argv) > 6 else "shared"
     exchange_mode = sys.argv[7] if len(sys.argv) > 7 else "peers"   # "peers": neighbour-only exchange | "dense": interface all-reduce
     dev_id = rank if transport == "rccl" else 0
@@ -42,7 +44,7 @@ def main():
            (lambda: capi.dt() - capi.laplacian()) if case == "parab" else (lambda: -capi.laplacian())
     part = fdist.partition_cells(nodes, cells, world)
     if exchange_mode == "rowdist":
-        return rowdist_case(rank, world, case, order, nodes, cells, bnd, part, capi, fdist, dist, torch, u_exact, f, g_fn, transport)
+        return rowdist_case(rank, world, case, order, nodes, cells, bnd, part, capi, fdist, dist, torch, u_exact, f, g_fn, transport, two_level)
     info_if = fdist.interface_info(cells, part, n_g, world, order, bnd)
     sub = fdist.sub_mesh(nodes, cells, bnd, part, rank)
 
@@ -143,7 +145,7 @@ def main():
     dist.destroy_process_group()
 
 
-def rowdist_case(rank, world, case, order, nodes, cells, bnd, part, capi, fdist, dist, torch, u_exact, f, g_fn, transport="shared"):
+def rowdist_case(rank, world, case, order, nodes, cells, bnd, part, capi, fdist, dist, torch, u_exact, f, g_fn, transport="shared", two_level=False):
     """row-distributed form (fdapde_rowdist_setup): one persistent launch per rank, all ranks' launches acting as one grid through
     peer-mapped boards -- here all on GPU 0, each rank with an equal share of the CUs, boards mapped across the processes by hipIpc"""
     n_g = nodes.shape[0]
@@ -183,6 +185,8 @@ def rowdist_case(rank, world, case, order, nodes, cells, bnd, part, capi, fdist,
         ctx.comm_init_callback(world, rank, allreduce)
         ctx.comm_set_exchange_callback(exchange)
         ctx.tune("rowdist_share", world)
+    if two_level:
+        ctx.tune("rowdist_flat_gather", 0)
     ctx.rowdist_setup(keys, own)
     ref = capi.Context(device=dev_id)
     ref.mesh_upload(nodes, cells, bnd)

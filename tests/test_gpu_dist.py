@@ -77,11 +77,13 @@ def test_partitioned_solve_over_real_rccl(world, nx, case):
 
 
 @pytest.mark.parametrize("world,nx,case", [(2, 16, "p1"), (3, 14, "p1"), (4, 20, "p1"), (2, 40, "sq2"), (2, 8, "p2"), (4, 36, "p1"),
-                                           (2, 16, "adr1"), (3, 8, "adr2"), (2, 12, "parab"), (3, 12, "handle"), (3, 16, "stall")])
+                                           (2, 16, "adr1"), (3, 8, "adr2"), (2, 12, "parab"), (3, 12, "handle"), (3, 16, "stall"),
+                                           (3, 14, "p1:2level"), (2, 16, "adr1:2level"), (3, 16, "stall:2level")])
 def test_row_distributed_persistent_launches_share_one_gpu(world, nx, case):
     """fdapde_rowdist_setup: every rank assembles the complete rows of the DOFs it owns (ghost layer of cells) and the whole CG runs as ONE
     launch per rank; the launches exchange search-direction entries and dot records through each other's boards (hipIpc-mapped across the
-    processes), no collective inside the iteration.  Against the single-domain solve: same iteration count, solution <= 1e-9, bitwise
+    processes), no collective inside the iteration (dot records in one hop -- the automatic choice up to 1024 workgroups -- or, ":2level",
+    as rank records in two).  Against the single-domain solve: same iteration count, solution <= 1e-9, bitwise
     repeatable.  All ranks on GPU 0 with an equal share of its CUs each."""
     _run_ranks(world, nx, case, "shared", "rowdist")
 

@@ -125,9 +125,14 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
         // ... and the second range must not cost occupancy: measured (tools/asm_fuse_ab.py) 2-D P1 C2 0.073 -> 0.046 ms (40 KB per workgroup), but
         // C3 1.11 -> 1.10 ms (80 KB: one or two workgroups per CU instead of three -- the sweep is bound by its memory traffic, 5.9 TB/s of
         // 2 FETCH + WRITE, and fewer waves hide less of it), 3-D P2 0.75 -> 0.75: fused up to 64 KB (knob asm_fuse_mass 2: whenever it fits)
-        const size_t fuse_cap = c->asm_fuse_mass == 2 ? (size_t)c->lds_limit : (size_t)64 * 1024;
-        const bool fuse_mass = a.vals2 != nullptr && a.vals != nullptr && (opk == 1 || opk == 3) && tab + 2 * acc <= fuse_cap;
-        if (a.vals2 != nullptr && !fuse_mass) return FDAPDE_EUNSUPPORTED;   // (e_init then runs the mass sweep of its own)
+        // knob asm_fuse_mass: 0 never; 1 (default) two accumulator ranges up to 64 KB, else a second pass in the same launch; 2 two ranges
+        // wherever they fit; 3 always the second pass
+        const int fm = c->asm_fuse_mass;
+        const bool can = a.vals2 != nullptr && a.vals != nullptr && (opk == 1 || opk == 3) && fm != 0;
+        const size_t fuse_cap = fm == 2 ? (size_t)c->lds_limit : (size_t)64 * 1024;
+        const bool fuse_mass = can && fm != 3 && tab + 2 * acc <= fuse_cap;
+        const bool seq_mass = can && !fuse_mass && fm != 2 && tab + acc <= (size_t)c->lds_limit;   // (every block's range must fit the LDS)
+        if (a.vals2 != nullptr && !fuse_mass && !seq_mass) return FDAPDE_EUNSUPPORTED;   // (e_init then runs the mass sweep of its own)
         if (tab + acc > (size_t)c->lds_limit) acc = tab < (size_t)c->lds_limit ? (size_t)c->lds_limit - tab : 0;
         a.lds_acc_cap = (int32_t)(acc / sizeof(double));
         if (a.fq != nullptr && a.fq == c->fq.p && c->fq_blk_ready) a.fq = c->fq_blk.p, a.fq_block = 1;   // column 0: one load coefficient per visit slot
@@ -136,11 +141,21 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
         size_t lds = tab + (fuse_mass ? 2 : 1) * acc;
         if (fuse_mass) {
             if (lds > 64 * 1024) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_rows<M, R, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_rows<M, R, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_rows<M, R, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_rows<M, R, 3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             }
-            if (opk == 3) hipLaunchKernelGGL((k_assemble_rows<M, R, 3, true>), dim3(grid), dim3(kAsmBlock), lds, c->stream, a, op);
-            else hipLaunchKernelGGL((k_assemble_rows<M, R, 1, true>), dim3(grid), dim3(kAsmBlock), lds, c->stream, a, op);
+            if (opk == 3) hipLaunchKernelGGL((k_assemble_rows<M, R, 3, 1>), dim3(grid), dim3(kAsmBlock), lds, c->stream, a, op);
+            else hipLaunchKernelGGL((k_assemble_rows<M, R, 1, 1>), dim3(grid), dim3(kAsmBlock), lds, c->stream, a, op);
+            HIPCHK(c, hipGetLastError());
+            return FDAPDE_OK;
+        }
+        if (seq_mass) {
+            if (lds > 64 * 1024) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_rows<M, R, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_rows<M, R, 3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            }
+            if (opk == 3) hipLaunchKernelGGL((k_assemble_rows<M, R, 3, 2>), dim3(grid), dim3(kAsmBlock), lds, c->stream, a, op);
+            else hipLaunchKernelGGL((k_assemble_rows<M, R, 1, 2>), dim3(grid), dim3(kAsmBlock), lds, c->stream, a, op);
             HIPCHK(c, hipGetLastError());
             return FDAPDE_OK;
         }

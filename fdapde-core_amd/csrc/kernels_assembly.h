@@ -358,7 +358,10 @@ __device__ __forceinline__ const DevTables* stage_tables(const DevTables* gsrc, 
 // index stream of the visit loop and the cell geometry, so the mass rows are accumulated in the same sweep (second accumulator range in
 // LDS; a visit's mass row is |e| times a tabulated reference row: NB multiply-adds).  Same visits in the same order as the separate mass
 // sweep: the same bits.
-template <int M, int R, int OPK, bool MASS2 = false>
+// MASS2 == 2: the mass rows in a SECOND pass over the block's visits inside the same launch, through the same accumulator range (no extra
+// LDS, hence no occupancy lost): the block's index streams, vertex slots and staged coordinates are re-read from L2 / LDS right after the
+// first pass instead of from HBM by a launch of its own.
+template <int M, int R, int OPK, int MASS2 = 0>
 static __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, DevOp op) {
     constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
     constexpr int NBW = (NB * 2 + 3) / 4;
@@ -411,7 +414,7 @@ static __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, D
     if (want_matrix) {
         if (in_lds) {
             for (int k = threadIdx.x; k < blk_nnz; k += kAsmBlock) acc[k] = 0.0;
-            if constexpr (MASS2)
+            if constexpr (MASS2 == 1)
                 for (int k = threadIdx.x; k < blk_nnz; k += kAsmBlock) acc2[k] = 0.0;
         } else {
             for (int k = my0; k < my1; ++k) a.vals[k] = 0.0;
@@ -470,7 +473,7 @@ static __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, D
                 else
                     a.vals[my0 + (int32_t)slot] += value;
             }, rt, fblk ? bc : (int64_t)-1, fc, fbc ? bc : (int64_t)-1);
-            if constexpr (MASS2) {   // (OPK 2's own formula with coefficient 1: cm = 1.0 * 1.0 * |e|)
+            if constexpr (MASS2 == 1) {   // (OPK 2's own formula with coefficient 1: cm = 1.0 * 1.0 * |e|)
                 const double cm = 1.0 * 1.0 * g.measure;
                 const int il = code & 15;
 #pragma unroll
@@ -485,8 +488,49 @@ static __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, D
     if (want_matrix && in_lds) {
         __syncthreads();
         for (int k = threadIdx.x; k < blk_nnz; k += kAsmBlock) a.vals[base + k] = acc[k];
-        if constexpr (MASS2)
+        if constexpr (MASS2 == 1)
             for (int k = threadIdx.x; k < blk_nnz; k += kAsmBlock) a.vals2[base + k] = acc2[k];
+    }
+    if constexpr (MASS2 == 2) {   // second pass: the mass rows through the same accumulators (the host launches this form only where in_lds holds)
+        __syncthreads();
+        for (int k = threadIdx.x; k < blk_nnz; k += kAsmBlock) acc[k] = 0.0;
+        __syncthreads();
+        if (row0 + (threadIdx.x & ~63) < a.n_dofs) {
+            const int64_t off = a.sl_off[slice], width = a.sl_off[slice + 1] - off;
+            auto load_code = [&](int64_t v) -> int32_t { return v < width ? a.adj[(off + v) * kSlice + lane] : -1; };
+            auto load_lv = [&](int32_t code) -> ushort4 { return *reinterpret_cast<const ushort4*>(a.bc_vert + (bc0 + ((code < 0 ? 0 : code) >> 4)) * 4); };
+            auto load_sw = [&](int64_t v, uint32_t (&w)[NBW]) {
+                const int64_t at = (off + (v < width ? v : 0)) * kSlice + lane;
+#pragma unroll
+                for (int k = 0; k < NBW; ++k) w[k] = a.slotw[at * NBW + k];
+            };
+            int32_t code_n = load_code(0), code_nn = load_code(1);
+            ushort4 lv_n = load_lv(code_n);
+            uint32_t sw_n[NBW];
+            load_sw(0, sw_n);
+            for (int64_t v = 0; v < width; ++v) {
+                const int32_t code = code_n;
+                const ushort4 lv = lv_n;
+                uint32_t sw[NBW];
+#pragma unroll
+                for (int k = 0; k < NBW; ++k) sw[k] = sw_n[k];
+                code_n = code_nn, code_nn = load_code(v + 2);
+                lv_n = load_lv(code_n);
+                load_sw(v + 1, sw_n);
+                if (code < 0) continue;
+                Geo<M> g;
+                geo_from_vertices<M>(xyz + lv.x * NP, xyz + lv.y * NP, xyz + lv.z * NP, xyz + lv.w * NP, g);
+                const double cm = 1.0 * 1.0 * g.measure;   // (OPK 2's own formula with coefficient 1)
+                const int il = code & 15;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const uint32_t slot = (sw[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+                    acc[my0 - base + (int32_t)slot] += cm * tb->mtab[il * NB + j];
+                }
+            }
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < blk_nnz; k += kAsmBlock) a.vals2[base + k] = acc[k];
     }
 }
 

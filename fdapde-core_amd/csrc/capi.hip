@@ -91,7 +91,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
         c->peer_send_dof.release(), c->peer_src_off.release(), c->peer_src.release(), c->peer_sendbuf.release(), c->peer_recvbuf.release();
         release_rowdist(c);
         if (c->comm) (void)g_rccl.CommDestroy(c->comm);
-        c->lin_mat.release(), c->ar_dev.release(), c->persist_stats.release(), c->persist_x.release(), c->coords_e.release();
+        c->lin_mat.release(), c->stiff_stat.release(), c->ar_dev.release(), c->persist_stats.release(), c->persist_x.release(), c->coords_e.release();
         dev_topology_release(&c->topo);
         c->part_cells.release(), c->part_off.release(), c->part_slots.release(), c->wave_slots.release(), c->part_shared.release();
         for (auto& bk : c->bk)
@@ -118,7 +118,7 @@ const char* fdapde_last_error(const fdapde_ctx* c) { return c ? c->err.c_str() :
 int fdapde_mesh_upload(fdapde_ctx* c, int M, int N, int64_t n_nodes, const double* nodes, int64_t n_cells,
                        const int32_t* cells, const uint8_t* bnd) {
     if (!c) return FDAPDE_EINVAL;
-    c->space_ready = c->dev_ready = c->colour_ready = c->fq_blk_ready = c->fq_bc_ready = false;
+    c->space_ready = c->dev_ready = c->colour_ready = c->fq_blk_ready = c->fq_bc_ready = c->stiff_stat_valid = false;
     c->assembled[0] = c->assembled[1] = c->force_ready = c->solved = c->dirichlet_applied = false;
     c->op.clear(), c->coef_of_op = false, c->fq_i.clear(), c->fq_cols = 0, c->g_i.clear(), c->have_g = false;
     if (c->topo_ready) dev_topology_release(&c->topo), c->topo_ready = false;
@@ -308,11 +308,13 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "multi_rhs" && (value == 0 || value == 1)) c->multi_rhs = value;
     else if (k == "asm_fq_block" && (value == 0 || value == 1)) c->asm_fq_block = value;
     else if (k == "asm_fuse_mass" && value >= 0 && value <= 3) c->asm_fuse_mass = value;
+    else if (k == "asm_row_stat" && (value == 0 || value == 1)) c->asm_row_stat = value, c->stiff_stat_valid = false;
     else if (k == "asm_fq_bc" && (value == 0 || value == 1)) c->asm_fq_bc = value, c->fq_bc_ready = c->fq_bc_ready && value;   // (takes effect fully at the next fdapde_set_forcing)
     else if (k == "persist" && (value == 0 || value == 1)) c->persist = value, c->persist_broken = false;
     else if (k == "persist_time" && (value == 0 || value == 1)) c->persist_time = value;
     else if (k == "persist_coop" && (value == 0 || value == 1)) c->persist_coop = value;
     else if (k == "persist_bicg" && (value == 0 || value == 1)) c->persist_bicg = value;
+    else if (k == "persist_fill_fused" && (value == 0 || value == 1)) c->persist_fill_fused = value;
     else if (k == "persist_late" && (value == 0 || value == 1)) {
         c->persist_late = value;
         for (auto& ps : c->ps) ps.tried = ps.ok = ps.filled = false;

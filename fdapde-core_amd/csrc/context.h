@@ -195,6 +195,9 @@ struct fdapde_ctx {
     DBuf<uint16_t> bc_vert;
     DBuf<int64_t> sl_off;
     DBuf<int32_t> lane_row;   // assembly lane position -> row (unallocated = identity)
+    DBuf<double> stiff_stat;   // (diagonal, row maximum) of every row of vals[STIFF], written by fdapde_init's sweep; valid while stiff_stat_valid
+    bool stiff_stat_valid = false, asm_all_in_lds = false;
+    int asm_row_stat = 1;      // knob: 0 = the solve's Jacobi scaling always reads the whole matrix
     DBuf<double> fq_blk;      // column 0 of the forcing as one load coefficient per visit slot (k_visit_load_coeffs); valid while fq_blk_ready
     bool fq_blk_ready = false;
     DBuf<double> fq_bc;       // column 0 of the forcing samples in BLOCK-CELL order (a cell's nq samples repeated in every assembly block that
@@ -241,6 +244,11 @@ struct fdapde_ctx {
     int64_t sp_nnz[2] = {0, 0};
     bool sp_built[2] = {false, false};
     int sp_cur = -1;   // which compact pattern c->sval currently holds (-1: full pattern)
+    bool sval_stale = false;        // the single-launch solver filled its blocks straight from the unscaled matrix: c->sval was NOT written for the
+    const double* sval_A = nullptr; // current system; whoever needs it (warm start, multi-launch fall-back, SpMV benchmark) calls ensure_sval first
+    int persist_fill_fused = 0;     // knob: 1 = fill the launch's blocks straight from the unscaled matrix (k_persist_fill_scaled) and skip the scaled
+                                    // full-pattern copy.  Measured on C3: solve 15.63 -> 15.82 ms (the fill's dependent gathers A[src], colidx[src],
+                                    // scale[col] cost more than the 205 MB copy they save): off
     // whose system the shared scale / sval / sp_cur buffers hold (every solve_prepare caller records itself; the factor-once
     // handle prepares again whenever anybody else has been there in between)
     enum { kScaledNone = 0, kScaledSolve, kScaledParabolic, kScaledLin };

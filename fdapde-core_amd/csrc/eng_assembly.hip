@@ -135,6 +135,7 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
         if (a.vals2 != nullptr && !fuse_mass && !seq_mass) return FDAPDE_EUNSUPPORTED;   // (e_init then runs the mass sweep of its own)
         if (tab + acc > (size_t)c->lds_limit) acc = tab < (size_t)c->lds_limit ? (size_t)c->lds_limit - tab : 0;
         a.lds_acc_cap = (int32_t)(acc / sizeof(double));
+        c->asm_all_in_lds = acc == (size_t)hs.max_blk_nnz * sizeof(double);   // every block accumulates in LDS (AsmArgs::row_stat is then complete)
         if (a.fq != nullptr && a.fq == c->fq.p && c->fq_blk_ready) a.fq = c->fq_blk.p, a.fq_block = 1;   // column 0: one load coefficient per visit slot
         else if (a.fq != nullptr && a.fq == c->fq.p && c->fq_bc_ready) a.fq = c->fq_bc.p, a.fq_block = 2;   // column 0: samples in block-cell order
         const int grid = 8 * (int)(((hs.n_dofs + kAsmBlock - 1) / kAsmBlock + 7) / 8);   // 8 XCD bands of blocks (k_assemble_rows)
@@ -370,6 +371,7 @@ int e_assemble_operator(fdapde_ctx* c, int32_t which, int32_t n_terms, const fda
     if (rc) return rc;
     AsmArgs a = asm_args(c);
     a.vals = c->vals[which].p;
+    if (which == FDAPDE_MAT_STIFF) c->stiff_stat_valid = false;   // (the row statistics belong to what fdapde_init assembled)
     rc = launch_assembly(c, a, op, assembly);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -410,6 +412,11 @@ int e_init(fdapde_ctx* c, const fdapde_options* opt) {
     a.vals = c->vals[FDAPDE_MAT_STIFF].p;
     const int64_t rows = (int64_t)hs.nq * hs.n_cells;
     if (c->fq_cols > 0) a.fq = c->fq.p, a.force = c->force.p;
+    c->stiff_stat_valid = false;
+    if (assembly == FDAPDE_ASSEMBLY_ROWS && c->asm_row_stat) {   // (complete only if every block accumulates in LDS: asm_all_in_lds)
+        HIPCHK(c, c->stiff_stat.alloc(2 * (size_t)hs.n_dofs));
+        a.diag = c->diag.p, a.row_stat = c->stiff_stat.p;
+    }
     // the mass matrix in the same sweep where both accumulator ranges fit the LDS (P1 blocks); otherwise (EUNSUPPORTED) a sweep of its own
     bool mass_done = false;
     if (assembly == FDAPDE_ASSEMBLY_ROWS && c->asm_fuse_mass) {
@@ -423,6 +430,7 @@ int e_init(fdapde_ctx* c, const fdapde_options* opt) {
         rc = launch_assembly(c, a, op, assembly);
         if (rc) return rc;
     }
+    const bool stat_complete = a.row_stat != nullptr && c->asm_all_in_lds;   // (as the operator's launch found it; later launches overwrite the flag)
     if (c->fq_cols == 0) HIPCHK(c, hipMemsetAsync(c->force.p, 0, sizeof(double) * (size_t)hs.n_dofs, c->stream));
     for (int col = 1; col < c->fq_cols; ++col) {   // remaining time columns (parabolic forcing), fem_solver_base.h:124-128
         AsmArgs f = asm_args(c);
@@ -442,6 +450,7 @@ int e_init(fdapde_ctx* c, const fdapde_options* opt) {
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->info.t_assemble_ms = ms;
+    c->stiff_stat_valid = stat_complete;
     c->assembled[0] = c->assembled[1] = true, c->force_ready = true, c->solved = false, c->dirichlet_applied = false;
     return FDAPDE_OK;
 }

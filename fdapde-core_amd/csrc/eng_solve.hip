@@ -293,6 +293,7 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss, b
     ss->dist = (c->comm != nullptr || c->ar_fn != nullptr) && c->halo_ready;   // multi-GPU: sub-assembled operator of this rank's cells
     ss->owned = ss->dist ? c->owned.p : nullptr;
     ss->use_bnd = use_bnd, ss->symmetric = symmetric;
+    c->sval_stale = false;
     ss->rowdist = (c->comm != nullptr || c->ar_fn != nullptr) && c->rd.ready && !ss->dist;
     if (ss->rowdist) ss->owned = c->rd.owned.p;
     HIPCHK(c, hipMemsetAsync(c->ctl.p, 0, 4 * sizeof(int32_t), st));
@@ -302,7 +303,10 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss, b
         hipLaunchKernelGGL(k_jacobi_scale_from_diag, dim3(g1(n)), dim3(256), 0, st, n, c->tmp_i.p, c->bnd.p, use_bnd, c->scale.p,
                            c->ctl.p + 3);
     } else {
-        hipLaunchKernelGGL(k_jacobi_scale, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->diag.p, A, c->bnd.p, use_bnd, c->scale.p, c->ctl.p + 3);
+        if (A == c->vals[FDAPDE_MAT_STIFF].p && c->stiff_stat_valid)   // (diagonal, row maximum) left by fdapde_init's sweep: same numbers, 16 B per row
+            hipLaunchKernelGGL(k_jacobi_scale_stats, dim3(g1(n)), dim3(256), 0, st, n, c->stiff_stat.p, c->bnd.p, use_bnd, c->scale.p, c->ctl.p + 3);
+        else
+            hipLaunchKernelGGL(k_jacobi_scale, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->diag.p, A, c->bnd.p, use_bnd, c->scale.p, c->ctl.p + 3);
     }
     HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
@@ -371,6 +375,9 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss, b
         hipLaunchKernelGGL(k_scale_matrix_compact, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, A, c->scale.p,
                            c->sp_map[v].p, c->sval.p);
         c->sp_cur = v;
+    } else if (persist && c->persist_fill_fused) {   // the launch's blocks are filled straight from A (fill_persist_scaled): no scaled copy now
+        c->sval_stale = true, c->sval_A = A;
+        c->sp_cur = -1, c->sval_layout = -2;
     } else {
         hipLaunchKernelGGL(k_scale_matrix, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, A, c->scale.p, c->sval.p);
         c->sp_cur = -1, c->sval_layout = -2;
@@ -382,8 +389,18 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss, b
         c->bk[v].filled = true, c->bk_cur = v;
     }
     if (persist)
-        if (int rc = fill_persist(c, use_bnd ? 1 : 0)) return rc;
+        if (int rc = c->sval_stale ? fill_persist_scaled(c, use_bnd ? 1 : 0, A) : fill_persist(c, use_bnd ? 1 : 0)) return rc;
     HIPCHK(c, hipGetLastError());
+    return FDAPDE_OK;
+}
+
+// the scaled full-pattern copy of the current system, if solve_prepare left it out (single-launch solve)
+int ensure_sval(fdapde_ctx* c) {
+    if (!c->sval_stale) return FDAPDE_OK;
+    const int64_t n = c->hs.n_dofs;
+    hipLaunchKernelGGL(k_scale_matrix, dim3(g1(n * 16)), dim3(256), 0, c->stream, n, c->rowptr.p, c->colidx.p, c->sval_A, c->scale.p, c->sval.p);
+    HIPCHK(c, hipGetLastError());
+    c->sval_stale = false;
     return FDAPDE_OK;
 }
 
@@ -433,6 +450,7 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     const double tol2 = rtol * rtol;
     const double* ax = nullptr;
     if (u0_dev) {   // warm start: x = (u0 - g~) / s, r = b~ - At x
+        if (int rc = ensure_sval(c)) return rc;
         hipLaunchKernelGGL(k_krylov_init, dim3(c->vec_grid), dim3(256), 0, st, n, fvec, c->y.p, c->scale.p, c->x.p, c->r.p, c->p.p,
                            (double*)nullptr, c->part_b.p, owned, u0_dev, c->gt.p, (const double*)nullptr, 1);
         launch_spmv(c, c->sval.p, c->x.p, c->t.p, nullptr, nullptr, nullptr);
@@ -515,6 +533,8 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
                            c->ctl.p);
     };
     const int bi_grid = (int)(((n >> 1) + 256 * kBiV - 1) / (256 * kBiV)) > 0 ? (int)(((n >> 1) + 256 * kBiV - 1) / (256 * kBiV)) : 1;
+    if (!stop && launched < maxit && !ss.rowdist)   // the multi-launch kernels read the scaled full-pattern copy
+        if (int rc = ensure_sval(c)) return rc;
     while (!stop && launched < maxit && !ss.rowdist) {
         const int chunk = (maxit - launched) < check_every ? (maxit - launched) : check_every;
         // a full chunk of the fused-update CG with no timed launch replays ONE hipGraph (2 * chunk + 1 kernel nodes): the
@@ -1140,6 +1160,8 @@ int e_bench_spmv(fdapde_ctx* c, int32_t reps, double* avg_ms, double* algorithmi
     const HostSpace& hs = c->hs;
     // the launch timed here is the one inside CG: scaled matrix stream, fused p.Ap partials
     const double* A = (c->solved && c->scaled_owner == fdapde_ctx::kScaledSolve) ? c->sval.p : c->vals[0].p;
+    if (A == c->sval.p)
+        if (int rc = ensure_sval(c)) return rc;
     hipLaunchKernelGGL(k_fill_f64, dim3(g1(hs.n_dofs)), dim3(256), 0, c->stream, hs.n_dofs, 1.0, c->tmp_i.p);
     for (int i = 0; i < 3; ++i) launch_spmv(c, A, c->tmp_i.p, c->t.p, c->tmp_i.p, c->part_a.p, nullptr);
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));

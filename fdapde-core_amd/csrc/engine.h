@@ -58,6 +58,7 @@ inline unsigned g1(int64_t n, int per = 256) { return (unsigned)((n + per - 1) /
     } while (0)
 
 // ---- helpers one engine unit offers the others ---------------------------------------------------------------------------------------
+int ensure_sval(fdapde_ctx* c);                                            // eng_solve.hip: the scaled full-pattern copy, if a solve skipped it
 void drop_graph(fdapde_ctx* c);                                            // eng_solve.hip: the captured CG chunk bakes pointers and sizes in
 int allreduce_sum(fdapde_ctx* c, double* buf, size_t count);               // eng_dist.hip: device buffer summed over the ranks
 int halo_sum(fdapde_ctx* c, double* v, const double* part, int np, bool unpack = true);   // eng_dist.hip: interface entries summed over the sharing ranks
@@ -110,6 +111,7 @@ void preload_persist();
 int build_persist(fdapde_ctx* c, int v);
 // scaled values into the layout's blocks (after the scaled full-pattern matrix c->sval is in place)
 int fill_persist(fdapde_ctx* c, int v);
+int fill_persist_scaled(fdapde_ctx* c, int v, const double* A);   // ... from the unscaled matrix + c->scale (no scaled full-pattern copy needed)
 // the whole fused-update CG as one launch; *ran = false: the launch gave up (hand-off timeout) or can never be resident
 int run_persist(fdapde_ctx* c, int v, double tol2, int maxit, bool* ran, bool bicg = false);   // bicg: the BiCGStab kernel (plain layouts, <= 8 rows per thread)
 

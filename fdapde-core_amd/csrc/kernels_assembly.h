@@ -63,7 +63,10 @@ struct AsmArgs {
     const DevTables* tables;
     const DevRefTensors* reftab;   // OPK 3 only
     double* vals;              // CSR values (internal slots) or nullptr
-    double* vals2;             // k_assemble_rows<..., MASS2 = true>: the mass matrix, accumulated in the same sweep over the visits
+    double* vals2;             // k_assemble_rows<..., MASS2>: the mass matrix, assembled by the same launch
+    const int32_t* diag;       // CSR slot of every row's diagonal (row_stat only)
+    double* row_stat;          // nullptr, or [2 n_dofs]: (diagonal value, max |entry|) of every assembled row of `vals` -- what the Jacobi scaling of
+                               // the solve reads instead of the whole matrix (k_jacobi_scale_stats); written by the row's owner from its LDS range
     const double* fq;          // forcing at quadrature nodes, internal cell order, or nullptr
     int fq_block;              // k_assemble_rows only.  1: fq holds one load coefficient per visit slot (k_visit_load_coeffs);
                                // 2: fq holds the samples in block-cell order (row group = block-cell index)
@@ -488,6 +491,11 @@ static __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, D
     if (want_matrix && in_lds) {
         __syncthreads();
         for (int k = threadIdx.x; k < blk_nnz; k += kAsmBlock) a.vals[base + k] = acc[k];
+        if (a.row_stat != nullptr && row < a.n_dofs) {
+            double rmax = 0.0;
+            for (int k = my0; k < my1; ++k) rmax = fmax(rmax, fabs(acc[k - base]));
+            a.row_stat[2 * row] = acc[a.diag[row] - base], a.row_stat[2 * row + 1] = rmax;
+        }
         if constexpr (MASS2 == 1)
             for (int k = threadIdx.x; k < blk_nnz; k += kAsmBlock) a.vals2[base + k] = acc2[k];
     }

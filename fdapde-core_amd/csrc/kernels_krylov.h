@@ -45,6 +45,20 @@ static __global__ __launch_bounds__(256) void k_jacobi_scale(int64_t n, const in
     if (!(d > 0.0) || tiny) atomicOr(flag, 1);
     scale[i] = jacobi_scale_of(tiny ? rmax : d);
 }
+// the same from (diagonal, row maximum) pairs the assembly left behind (AsmArgs::row_stat): 16 bytes per row instead of the whole matrix
+static __global__ __launch_bounds__(256) void k_jacobi_scale_stats(int64_t n, const double* stat, const uint8_t* bnd, int use_bnd, double* scale,
+                                                                   int32_t* flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (use_bnd && bnd[i]) {
+        scale[i] = 0.0;
+        return;
+    }
+    const double d = stat[2 * i], rmax = stat[2 * i + 1];
+    const bool tiny = !(fabs(d) > 1e-8 * rmax);
+    if (!(d > 0.0) || tiny) atomicOr(flag, 1);
+    scale[i] = jacobi_scale_of(tiny ? rmax : d);
+}
 // At = diag(scale) A diag(scale): symmetric Jacobi scaling == Jacobi preconditioning folded into the matrix stream.
 // Rows and columns of Dirichlet DOFs vanish (scale = 0), which restricts the Krylov iteration to the interior block.
 static __global__ __launch_bounds__(256) void k_scale_matrix(int64_t n, const int32_t* rowptr, const int32_t* colidx,

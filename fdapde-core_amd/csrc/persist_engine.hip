@@ -372,6 +372,19 @@ int run_persist(fdapde_ctx* c, int v, double tol2, int maxit, bool* ran, bool bi
 }
 
 
+// ... straight from the unscaled matrix A and the Jacobi scale (k_persist_fill_scaled): the scaled full-pattern copy is then not needed
+int fill_persist_scaled(fdapde_ctx* c, int v, const double* A) {
+    fdapde_ctx::Persist& ps = c->ps[v];
+    hipStream_t st = c->stream;
+    if (ps.meta.sym) HIPCHK(c, hipMemsetAsync(ps.amax.p, 0, sizeof(unsigned long long), st));
+    const int per = (ps.meta.nsl + 3) / 4;
+    hipLaunchKernelGGL(k_persist_fill_scaled, dim3((unsigned)(ps.meta.G * per)), dim3(256), 0, st, ps.meta.G, ps.meta.nsl, ps.ell_off.p, ps.sl_off.p, ps.slot_dof.p,
+                       ps.ell_src.p, A, c->colidx.p, c->scale.p, ps.ell_val.p, ps.meta.sym ? ps.amax.p : (unsigned long long*)nullptr);
+    HIPCHK(c, hipGetLastError());
+    ps.filled = true;
+    return FDAPDE_OK;
+}
+
 int fill_persist(fdapde_ctx* c, int v) {
     fdapde_ctx::Persist& ps = c->ps[v];
     hipStream_t st = c->stream;

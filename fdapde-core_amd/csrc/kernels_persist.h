@@ -327,24 +327,32 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
                 // plain storage, streaming: a pass that has run out of entries is skipped (wave-uniform) instead of re-reading its last
                 // pair row -- the rows are sorted by length, and on P2 systems (10 to 60+ entries per row) the passes of a phase differ
                 // by a factor in width; raw buffer loads (scalar row offset + constant lane offset)
-                for (int e = 0; e < mw; ++e) {
-                    pg_u32x4 v[NJ];
-                    uint32_t c[NJ];
+                // U pair rows of every pass per step where a phase has only 1 or 2 passes (2 / 4 rows per thread): the loads in flight per
+                // wavefront, not the memory, bound the stream otherwise (kernels_persist_bicg.h)
+                constexpr int U = NJ >= 4 ? 1 : 8 / NJ;
+                for (int e = 0; e < mw; e += U) {
+                    pg_u32x4 v[U][NJ];
+                    uint32_t c[U][NJ];
 #pragma unroll
-                    for (int j = J0; j < J1; ++j) {
-                        if (e < w[j]) {
-                            const int row = o0[j] + e;
-                            v[j - J0] = __builtin_amdgcn_raw_buffer_load_b128(rs_v, lane16, row * 1024, 0);
-                            c[j - J0] = __builtin_amdgcn_raw_buffer_load_b32(rs_c, lane4, row * 256, 0);
-                        }
-                    }
+                    for (int u = 0; u < U; ++u)
 #pragma unroll
-                    for (int j = J0; j < J1; ++j) {
-                        if (e < w[j]) {
-                            const double vx = __hiloint2double((int)v[j - J0].y, (int)v[j - J0].x), vy = __hiloint2double((int)v[j - J0].w, (int)v[j - J0].z);
-                            yv[j] += vx * p_tab[c[j - J0] & 0xffffu] + vy * p_tab[c[j - J0] >> 16];
+                        for (int j = J0; j < J1; ++j) {
+                            if (e + u < w[j]) {
+                                const int row = o0[j] + e + u;
+                                v[u][j - J0] = __builtin_amdgcn_raw_buffer_load_b128(rs_v, lane16, row * 1024, 0);
+                                c[u][j - J0] = __builtin_amdgcn_raw_buffer_load_b32(rs_c, lane4, row * 256, 0);
+                            }
                         }
-                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int j = J0; j < J1; ++j) {
+                            if (e + u < w[j]) {
+                                const pg_u32x4 q = v[u][j - J0];
+                                const double vx = __hiloint2double((int)q.y, (int)q.x), vy = __hiloint2double((int)q.w, (int)q.z);
+                                yv[j] += vx * p_tab[c[u][j - J0] & 0xffffu] + vy * p_tab[c[u][j - J0] >> 16];
+                            }
+                        }
                 }
             } else if constexpr (!SYM) {
                 for (int e = 0; e < mw; ++e) {

@@ -116,27 +116,38 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
             int mw = 0;
 #pragma unroll
             for (int j = J0; j < J1; ++j) mw = max(mw, w[j]);
-            for (int e = 0; e < mw; ++e) {   // a pass that has run out of entries is skipped (wave-uniform; P2 rows differ widely in length)
-                pg_u32x4 v[NJ];
-                uint32_t c[NJ];
+            // a pass that has run out of entries is skipped (wave-uniform; P2 rows differ widely in length).  U pair rows of every pass per
+            // step: with 2 or 4 rows per thread a phase has 1 or 2 passes, i.e. 1 or 2 loads in flight per wavefront -- the stream then runs at
+            // the rate of the memory latency, not of the memory (3-D P2 227 k DOFs, 4 rows per thread: 62.5 -> 41.0 us per iteration with U = 4; 2-D P2 361 k 30.4 -> 23.7).
+            // With 8 rows per thread (4 passes per phase) U = 2 gains on long rows (3-D P2 754 k: 91 -> 83) and loses on short ones (P1 1.0 M: 53.1 ->
+            // 54.7, 2-D 31.0 -> 32.9): left at 1
+            constexpr int U = STREAM ? (NJ >= 4 ? 1 : 8 / NJ) : 1;
+            for (int e = 0; e < mw; e += U) {
+                pg_u32x4 v[U][NJ];
+                uint32_t c[U][NJ];
 #pragma unroll
-                for (int j = J0; j < J1; ++j) {
-                    if (e < w[j]) {
-                        const int row = o0[j] + e;
-                        if constexpr (STREAM) {
-                            v[j - J0] = __builtin_amdgcn_raw_buffer_load_b128(rs_v, lane16, row * 1024, 0);
-                            c[j - J0] = __builtin_amdgcn_raw_buffer_load_b32(rs_c, lane4, row * 256, 0);
-                        } else
-                            v[j - J0] = reinterpret_cast<const pg_u32x4*>(ev)[row * 64 + lane], c[j - J0] = ec[row * 64 + lane];
-                    }
-                }
+                for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int j = J0; j < J1; ++j) {
-                    if (e < w[j]) {
-                        const double vx = __hiloint2double((int)v[j - J0].y, (int)v[j - J0].x), vy = __hiloint2double((int)v[j - J0].w, (int)v[j - J0].z);
-                        y[j] += vx * p_tab[c[j - J0] & 0xffffu] + vy * p_tab[c[j - J0] >> 16];
+                    for (int j = J0; j < J1; ++j) {
+                        if (e + u < w[j]) {
+                            const int row = o0[j] + e + u;
+                            if constexpr (STREAM) {
+                                v[u][j - J0] = __builtin_amdgcn_raw_buffer_load_b128(rs_v, lane16, row * 1024, 0);
+                                c[u][j - J0] = __builtin_amdgcn_raw_buffer_load_b32(rs_c, lane4, row * 256, 0);
+                            } else
+                                v[u][j - J0] = reinterpret_cast<const pg_u32x4*>(ev)[row * 64 + lane], c[u][j - J0] = ec[row * 64 + lane];
+                        }
                     }
-                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int j = J0; j < J1; ++j) {
+                        if (e + u < w[j]) {
+                            const pg_u32x4 q = v[u][j - J0];
+                            const double vx = __hiloint2double((int)q.y, (int)q.x), vy = __hiloint2double((int)q.w, (int)q.z);
+                            y[j] += vx * p_tab[c[u][j - J0] & 0xffffu] + vy * p_tab[c[u][j - J0] >> 16];
+                        }
+                    }
             }
         };
         const bool late = a.wg_late != nullptr && a.wg_late[g] != 0;   // (uniform for the workgroup)

@@ -24,6 +24,10 @@
 
 #include "internal.h"
 
+#ifndef FDAPDE_SYM_U
+#define FDAPDE_SYM_U 1
+#endif
+
 namespace fdapde_hip {
 
 struct PersistArgs {
@@ -414,11 +418,25 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
                 // one lane per 128-byte line touching the lines of the group after next 58 (loads return in order: a touch that misses holds
                 // up the real loads behind it); re-reading the last pair row of a finished pass and multiplying by 0, as the plain form does,
                 // instead of skipping the pass 43; the magic-number conversion below instead of the compiler's fptosi 37.5
-                for (int e = 0; e < mw; ++e) {
-                    pg_u32x4 v[NJ];
-                    uint32_t c[NJ];
-                    load(v, c, J0, e);
-                    compute(v, c, J0, e);
+                // (two pair rows of every pass per step, -DFDAPDE_SYM_U=2, measured for 8 rows per thread: 3-D 754 k / 1.03 M DOFs 17.8 / 21.3 us per
+                //  iteration either way, 2-D 1.0 M 12.07 -> 11.59: this form is bound by its LDS traffic, not by loads in flight -- left at 1)
+                constexpr int U = (STREAM && NJ <= 4) ? FDAPDE_SYM_U : 1;
+                if constexpr (U == 1) {
+                    for (int e = 0; e < mw; ++e) {
+                        pg_u32x4 v[NJ];
+                        uint32_t c[NJ];
+                        load(v, c, J0, e);
+                        compute(v, c, J0, e);
+                    }
+                } else {
+                    for (int e = 0; e < mw; e += U) {
+                        pg_u32x4 v[U][NJ];
+                        uint32_t c[U][NJ];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) load(v[u], c[u], J0, e + u);
+#pragma unroll
+                        for (int u = 0; u < U; ++u) compute(v[u], c[u], J0, e + u);
+                    }
                 }
             }
         };

@@ -99,7 +99,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
               bk.ell_code.release(), bk.ell_val.release();
         for (auto& ps : c->ps)
             ps.slot_dof.release(), ps.sl_off.release(), ps.ell_src.release(), ps.exp_off.release(), ps.imp_off.release(),
-              ps.imp_pos.release(), ps.ell_off.release(), ps.ell_code.release(), ps.exp_slot.release(), ps.ell_val.release(), ps.board.release(), ps.amax.release(), ps.wg_late.release();
+              ps.imp_pos.release(), ps.ell_off.release(), ps.ell_code.release(), ps.exp_slot.release(), ps.ell_val.release(), ps.board.release(), ps.amax.release(), ps.wg_late.release(), ps.ell_col.release();
         for (int v = 0; v < 2; ++v)
             c->sp_rowptr[v].release(), c->sp_colidx[v].release(), c->sp_map[v].release(), c->sp_tbase[v].release(), c->sp_col16[v].release(),
               c->sp_vrow[v].release();

@@ -247,8 +247,9 @@ struct fdapde_ctx {
     bool sval_stale = false;        // the single-launch solver filled its blocks straight from the unscaled matrix: c->sval was NOT written for the
     const double* sval_A = nullptr; // current system; whoever needs it (warm start, multi-launch fall-back, SpMV benchmark) calls ensure_sval first
     int persist_fill_fused = 0;     // knob: 1 = fill the launch's blocks straight from the unscaled matrix (k_persist_fill_scaled) and skip the scaled
-                                    // full-pattern copy.  Measured on C3: solve 15.63 -> 15.82 ms (the fill's dependent gathers A[src], colidx[src],
-                                    // scale[col] cost more than the 205 MB copy they save): off
+                                    // full-pattern copy.  Measured on C3: solve 15.63 -> 15.82 ms with the column looked up through the pattern
+                                    // (three dependent gathers), 15.56 -> 15.53 ms with a precomputed column per entry and four pair rows per step:
+                                    // no gain worth 58 MB more of layout: off
     // whose system the shared scale / sval / sp_cur buffers hold (every solve_prepare caller records itself; the factor-once
     // handle prepares again whenever anybody else has been there in between)
     enum { kScaledNone = 0, kScaledSolve, kScaledParabolic, kScaledLin };
@@ -299,6 +300,7 @@ struct fdapde_ctx {
         int32_t lds_cap = 0, imp_cap = 0;
         size_t lds_bytes = 0;
         DBuf<int32_t> slot_dof, sl_off, ell_src, exp_off, imp_off, imp_pos;
+        DBuf<int32_t> ell_col;               // column DOF of every entry (fill_persist_scaled; built on first use)
         bool stream = false;                 // the blocks do not fit the LDS: streaming instantiation
         DBuf<int64_t> ell_off;
         DBuf<uint16_t> ell_code, exp_slot;

@@ -892,7 +892,7 @@ static __global__ __launch_bounds__(256) void k_persist_fill(int64_t n, const in
 // gathered on C3).  One wavefront per slice of 64 slots: lane l owns slot 64 q + l, hence knows its row; its entries are the lane pairs
 // (2 l, 2 l + 1) of the slice's pair rows.
 static __global__ __launch_bounds__(256) void k_persist_fill_scaled(int32_t G, int32_t nsl, const int64_t* ell_off, const int32_t* sl_off, const int32_t* slot_dof,
-                                                                    const int32_t* src, const double* A, const int32_t* colidx, const double* scale, double* out,
+                                                                    const int32_t* src, const int32_t* col, const double* A, const double* scale, double* out,
                                                                     unsigned long long* amax_bits) {
     const int per = (nsl + 3) / 4;
     const int g = blockIdx.x / per, q = (blockIdx.x % per) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -904,13 +904,28 @@ static __global__ __launch_bounds__(256) void k_persist_fill_scaled(int32_t G, i
     const int o0 = slo[q], w = slo[q + 1] - o0;
     const int64_t base = ell_off[g] + (int64_t)o0 * 128 + 2 * lane;
     double m = 0.0;
-    for (int pr = 0; pr < w; ++pr) {
-        const int64_t e = base + (int64_t)pr * 128;
-        const int2 s2 = *reinterpret_cast<const int2*>(src + e);
-        const double v0 = s2.x >= 0 ? si * A[s2.x] * scale[colidx[s2.x]] : 0.0;
-        const double v1 = s2.y >= 0 ? si * A[s2.y] * scale[colidx[s2.y]] : 0.0;
-        *reinterpret_cast<double2*>(out + e) = make_double2(v0, v1);
-        m = fmax(m, fmax(fabs(v0), fabs(v1)));
+    constexpr int U = 4;   // pair rows per step: 8 independent value gathers + 8 scale gathers in flight per lane
+    for (int pr = 0; pr < w; pr += U) {
+        int2 s2[U], c2[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t e = base + (int64_t)min(pr + u, w - 1) * 128;
+            s2[u] = *reinterpret_cast<const int2*>(src + e), c2[u] = *reinterpret_cast<const int2*>(col + e);
+        }
+        double a0[U], a1[U], t0[U], t1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            a0[u] = s2[u].x >= 0 ? A[s2[u].x] : 0.0, a1[u] = s2[u].y >= 0 ? A[s2[u].y] : 0.0;
+            t0[u] = scale[c2[u].x], t1[u] = scale[c2[u].y];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (pr + u < w) {
+                const double v0 = s2[u].x >= 0 ? si * a0[u] * t0[u] : 0.0, v1 = s2[u].y >= 0 ? si * a1[u] * t1[u] : 0.0;
+                *reinterpret_cast<double2*>(out + base + (int64_t)(pr + u) * 128) = make_double2(v0, v1);
+                m = fmax(m, fmax(fabs(v0), fabs(v1)));
+            }
+        }
     }
     if (amax_bits != nullptr) {
 #pragma unroll
@@ -918,6 +933,11 @@ static __global__ __launch_bounds__(256) void k_persist_fill_scaled(int32_t G, i
         const unsigned long long bits = (unsigned long long)__double_as_longlong(m);
         if (lane == 0 && bits > __hip_atomic_load(amax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax_bits, bits);
     }
+}
+// column DOF of every ELL entry (0 in padding), once per layout: lets the fill gather A[src] and scale[col] independently
+static __global__ __launch_bounds__(256) void k_persist_ell_col(int64_t n, const int32_t* src, const int32_t* colidx, int32_t* col) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) col[i] = src[i] >= 0 ? colidx[src[i]] : 0;
 }
 
 }  // namespace fdapde_hip

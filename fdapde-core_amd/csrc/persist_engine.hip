@@ -52,6 +52,7 @@ int check_dev_persist(fdapde_ctx* c, int v, const PersistLayout& pl, const DevPe
 int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_rows, bool balance) {
     fdapde_ctx::Persist& ps = c->ps[v];
     ps.ok = false;
+    ps.ell_col.release();
     if (c->n_cu < 1) return FDAPDE_OK;
     const int32_t* brows = block_rows ? block_rows->data() : nullptr;
     const int n_wg = block_rows ? (int)block_rows->size() : c->n_cu;
@@ -377,9 +378,15 @@ int fill_persist_scaled(fdapde_ctx* c, int v, const double* A) {
     fdapde_ctx::Persist& ps = c->ps[v];
     hipStream_t st = c->stream;
     if (ps.meta.sym) HIPCHK(c, hipMemsetAsync(ps.amax.p, 0, sizeof(unsigned long long), st));
+    const size_t n_alloc = (size_t)ps.meta.n_entries + 256;
+    if (ps.ell_col.n < n_alloc) {   // once per layout
+        HIPCHK(c, ps.ell_col.alloc(n_alloc));
+        HIPCHK(c, hipMemsetAsync(ps.ell_col.p, 0, sizeof(int32_t) * n_alloc, st));
+        hipLaunchKernelGGL(k_persist_ell_col, dim3(grid1(ps.meta.n_entries)), dim3(256), 0, st, ps.meta.n_entries, ps.ell_src.p, c->colidx.p, ps.ell_col.p);
+    }
     const int per = (ps.meta.nsl + 3) / 4;
     hipLaunchKernelGGL(k_persist_fill_scaled, dim3((unsigned)(ps.meta.G * per)), dim3(256), 0, st, ps.meta.G, ps.meta.nsl, ps.ell_off.p, ps.sl_off.p, ps.slot_dof.p,
-                       ps.ell_src.p, A, c->colidx.p, c->scale.p, ps.ell_val.p, ps.meta.sym ? ps.amax.p : (unsigned long long*)nullptr);
+                       ps.ell_src.p, ps.ell_col.p, A, c->scale.p, ps.ell_val.p, ps.meta.sym ? ps.amax.p : (unsigned long long*)nullptr);
     HIPCHK(c, hipGetLastError());
     ps.filled = true;
     return FDAPDE_OK;

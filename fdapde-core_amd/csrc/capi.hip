@@ -315,6 +315,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "persist_coop" && (value == 0 || value == 1)) c->persist_coop = value;
     else if (k == "persist_bicg" && (value == 0 || value == 1)) c->persist_bicg = value;
     else if (k == "persist_fill_fused" && (value == 0 || value == 1)) c->persist_fill_fused = value;
+    else if (k == "persist_prefetch" && (value == 0 || value == 1)) c->persist_prefetch = value;
     else if (k == "persist_late" && (value == 0 || value == 1)) {
         c->persist_late = value;
         for (auto& ps : c->ps) ps.tried = ps.ok = ps.filled = false;

@@ -345,6 +345,7 @@ struct fdapde_ctx {
     DBuf<double> persist_x;                  // the persistent launch writes its solution here (x stays the initial guess)
     double persist_launch_ms = 0;            // duration of the last persistent launch (HIP events on the stream)
     int persist_host_below = 32768;          // systems of at most this many DOFs build the persistent layout on the host (first-solve latency)
+    int persist_prefetch = 1;                // knob: entry steps of the next operator application touched during the dot all-gather (streaming forms)
     int persist_late = 0;                    // knob: CG layouts with late-import workgroups (host builder) instead of doubled rows per thread
     int persist_plain = 0;                   // the system being prepared is non-symmetric: plain storage, BiCGStab kernel
     int persist_bicg = 1;                    // tuning knob: 0 = non-symmetric systems always take the multi-launch BiCGStab

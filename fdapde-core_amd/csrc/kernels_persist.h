@@ -38,6 +38,8 @@ struct PersistArgs {
     uint32_t epoch0;                  // tags of this launch are epoch0 + iteration + 1: boards are never cleared between launches
     int32_t timeout_ticks;            // bound of every wait, in 10 ns ticks of s_memrealtime
     int32_t debug_stall_it;           // > 0 (tests): the last workgroup leaves at this iteration without publishing, as a peer that is not resident would
+    int32_t pf_steps;                 // streaming forms, != 0: the first entry step of the next operator application is touched (pulled into the L2)
+                                      // while the workgroup waits for the dot records
     double tol2;
     const int32_t* slot_dof;
     const int64_t* ell_off;
@@ -155,6 +157,30 @@ __device__ __forceinline__ void granule_load2x4_sys(const unsigned long long* p0
                  "global_load_dwordx4 %2, %6, off sc0 sc1\n\tglobal_load_dwordx4 %3, %7, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
 }
+// one 128-byte line of the matrix stream pulled towards the L2.  The loaded word goes to a dump in LDS (global_load_lds: no register to
+// keep reserved while the load is in flight, and the compiler, which does not see the load, waits for it nowhere); m0 = LDS base of the dump
+__device__ __forceinline__ void touch_line(const void* p, unsigned lds_dump) {
+    unsigned m0_saved;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(m0_saved) : "v"(p), "s"(lds_dump) : "memory");
+}
+// the first entry step of the passes without imports ([0, RI)) of a workgroup's block, touched for the whole workgroup by the wavefronts
+// W / 2 .. W - 1 (those that do not poll the dot records): one lane per line, 8 lines of values + 2 of codes per pair row
+template <int RI, int W>
+__device__ __forceinline__ void touch_first_step(const int32_t* slo, const void* gv, const void* gc, int wave, int lane, unsigned lds_dump) {
+    constexpr int per_wave = RI * 10, total = 2 * per_wave;
+    if (wave < W / 2) return;
+#pragma unroll
+    for (int t = 0; t * 64 < total; ++t) {
+        int idx = min(t * 64 + lane, total - 1);
+        asm volatile("" : "+v"(idx));   // (the addresses do not change between iterations: recomputed here all the same, not kept in registers)
+        const int half = idx / per_wave, rem = idx - half * per_wave;
+        const int j = rem / 10, k = rem - j * 10;
+        const int tw = (wave - W / 2) + half * (W / 2);   // the wavefront whose slices these are
+        const int o = slo[j * W + tw], wj = slo[j * W + tw + 1] - o;
+        const char* line = k < 8 ? static_cast<const char*>(gv) + (size_t)o * 1024 + k * 128 : static_cast<const char*>(gc) + (size_t)o * 256 + (k - 8) * 128;
+        if (t * 64 + lane < total && wj > 0) touch_line(line, lds_dump);
+    }
+}
 __device__ __forceinline__ double wave_sum64(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -257,6 +283,20 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
     long long t_spmv = 0, t_gather = 0, t_update = 0, n_stamped = 0;
     int it = 0, status = 0;   // status: 1 converged, 2 breakdown, 3 hand-off timeout
     double rr = 0;
+    // streaming forms: while the workgroups wait for the dot records the memory system idles (they all wait at the same time, ~3 us of ~30
+    // on C3), and the matrix does not depend on p: the wavefronts that do not poll (4 .. 7) touch the lines of the first entry step(s) of the
+    // workgroup's next operator application -- one lane per 128-byte line (8 of values + 2 of codes per pair row), the loaded words are
+    // dropped -- so that the stream starts from the L2.  Nobody waits for the touches (touch_line).
+    // C3 30.27 -> 29.71 us per iteration, 1.03 M rows 21.33 -> 20.91.  Measured and dropped: every wavefront touching its own lines before it
+    // polls (loads return in order, the poll sits behind the touches: 31.2 -> 31.9); two entry steps instead of one (160 KB per workgroup: more
+    // than an XCD's L2 holds for its 32 workgroups, 30.3 -> 31.6); the first step of the passes WITH imports touched by each wavefront before
+    // it collects its imports (the imports have arrived by then and now wait behind the touches: 30.3 -> 31.2); touching ahead INSIDE the
+    // operator phase (same reason).
+    __shared__ unsigned pf_dump[64];
+    [[maybe_unused]] auto prefetch_next = [&]() {
+        if constexpr (STREAM)
+            if (a.pf_steps != 0) touch_first_step<RI, W>(slo, gv, gc, wave, lane, (unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)pf_dump);
+    };
     __syncthreads();
     for (;;) {
         const unsigned epoch = a.epoch0 + (unsigned)it + 1u;
@@ -540,6 +580,7 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
                 const int k = tid % 3, q = tid / 3;
                 publish_f64_x4_sys(a.peer_dboard[q] + fbuf + (size_t)(a.g_base + g) * 8 + 2 * k, epoch, tot[k]);
             }
+            prefetch_next();
             double v0 = 0, v1 = 0, v2 = 0;
             bool fail = false;
             const int per_lane = (a.G_tot + T - 1) / T;
@@ -589,6 +630,7 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
             for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
             publish_f64_x4(dslot + (size_t)g * 6 + 2 * tid, epoch, v);
         }
+        prefetch_next();
         {   // thread t collects workgroup t's three sums (a lane re-reads its record until all six tags match, then stops loading); every
             // workgroup adds the G records in the same order.  A two-level form (groups of 8 / 16 / 32 workgroups handled by one wavefront,
             // then the group sums) was measured and dropped: a granule hop costs ~4 us under this load, two of them 7.9 / 9.8 / 12.0 us
@@ -717,6 +759,7 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
             t_spmv += c1 - c0, t_gather += c2 - c1, t_update += c3 - c2, ++n_stamped;
         }
     }
+    if constexpr (STREAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (touches of an iteration that did not come)
     if (status != 3) {
 #pragma unroll
         for (int j = 0; j < R; ++j) {

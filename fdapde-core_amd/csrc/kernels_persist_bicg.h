@@ -39,6 +39,7 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
     __shared__ double red[W][4];
     __shared__ double tot[4];
     __shared__ int32_t fail_flag;
+    __shared__ unsigned pf_dump[64];
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nsl = a.nsl;
     const int H = a.imp_off[g + 1] - a.imp_off[g], E = a.exp_off[g + 1] - a.exp_off[g];
@@ -213,6 +214,11 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
         return true;
     };
     // ---- all-gather of up to four sums over all workgroups (of all ranks): every workgroup adds the records in the same order
+    // (streaming forms: the first entry step of the next application touched while the workgroup waits for the records, kernels_persist.h)
+    [[maybe_unused]] auto prefetch_next = [&]() {
+        if constexpr (STREAM)
+            if (a.pf_steps != 0) touch_first_step<RI, W>(slo, gv, gc, wave, lane, (unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)pf_dump);
+    };
     auto gather = [&](double s0, double s1, double s2, double s3, int phase, unsigned epoch) -> bool {
         s0 = wave_sum64(s0), s1 = wave_sum64(s1), s2 = wave_sum64(s2), s3 = wave_sum64(s3);
         __syncthreads();   // (the table reads of the application before, and the totals of the gather before, are done with)
@@ -231,6 +237,7 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
                 const int k = tid & 3, q = tid >> 2;
                 publish_f64_x4_sys(a.peer_dboard[q] + fbuf + (size_t)(a.g_base + g) * 8 + 2 * k, epoch, tot[k]);
             }
+            prefetch_next();
             double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
             bool fail = false;
             const int per_lane = (a.G_tot + T - 1) / T;
@@ -282,6 +289,7 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
             for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
             publish_f64_x4(dslot + (size_t)g * 8 + 2 * tid, epoch, v);
         }
+        prefetch_next();
         double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
         bool fail = false;
         if (wave * 64 < a.G) {   // wave-uniform: thread t takes workgroup t's record
@@ -434,6 +442,7 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
         if (gather(0.0, rr_part, 0.0, 0.0, 0, a.epoch0 + 2u * (unsigned)it + 1u)) rr = tot[1];
         else status = 3;
     }
+    if constexpr (STREAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (touches of an application that did not come)
     if (status != 3) {
 #pragma unroll
         for (int j = 0; j < R; ++j)

@@ -204,7 +204,7 @@ int launch_persist(fdapde_ctx* c, fdapde_ctx::Persist& ps, PersistArgs& a, bool 
     a.ell_val = ps.ell_val.p, a.exp_off = ps.exp_off.p, a.exp_slot = ps.exp_slot.p, a.imp_off = ps.imp_off.p, a.imp_pos = ps.imp_pos.p;
     if (!dist) a.pboard = ps.board.p, a.dboard = ps.board.p + 2 * (size_t)ps.meta.n_board, a.wg_late = ps.wg_late.p;   // (row-distributed: set by the caller)
     a.amax_bits = ps.amax.p, a.max_len = c->hs.max_row, a.stats = c->persist_stats.p;
-    a.timeout_ticks = c->persist_timeout_us * 100, a.debug_stall_it = c->persist_debug_stall;
+    a.timeout_ticks = c->persist_timeout_us * 100, a.debug_stall_it = c->persist_debug_stall, a.pf_steps = c->persist_prefetch;
     if (!dist && ps.epoch_next > 0xC0000000u - 2u * (uint32_t)a.maxit) {   // (the tags are 32 bits wide: start over on clean boards)
         HIPCHK(c, hipMemsetAsync(ps.board.p, 0, sizeof(unsigned long long) * ps.board.n, st));
         ps.epoch_next = 0;

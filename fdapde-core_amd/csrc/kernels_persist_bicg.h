@@ -237,7 +237,7 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
                 const int k = tid & 3, q = tid >> 2;
                 publish_f64_x4_sys(a.peer_dboard[q] + fbuf + (size_t)(a.g_base + g) * 8 + 2 * k, epoch, tot[k]);
             }
-            prefetch_next();
+            if (a.G_tot <= (W / 2) * 64) prefetch_next();   // (beyond that the touching wavefronts poll records themselves: their polls would queue behind the touches)
             double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
             bool fail = false;
             const int per_lane = (a.G_tot + T - 1) / T;

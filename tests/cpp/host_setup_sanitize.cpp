@@ -2,6 +2,7 @@
 // ThreadSanitizer on the CPU (GPU sanitizers are not available on this pool).  Built and run by tests/test_host_sanitizers.py:
 //   g++ -std=c++20 -O1 -g -fsanitize=address,undefined  (or -fsanitize=thread)  host_setup_sanitize.cpp host_setup.cpp host_persist.cpp tables.cpp -pthread
 // Structured meshes large enough for every parallel_for to run multi-threaded; P1 and P2, 2-D and 3-D.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -150,6 +151,141 @@ static int check_persist(const HostSpace& hs, bool use_bnd, int n_wg, bool sym =
     return pl.G;
 }
 
+// The row-distributed form's layouts (host_persist.cpp with ghost_order / allow_late; persist_engine.hip build_rowdist), emulated for
+// `world` ranks in this process: node owners by slabs in x, every rank gets the cells touching a node it owns (complete rows through one
+// ghost layer), its own HostSpace and layout.  The operator application runs per rank as k_cg_persist<DIST> does -- own entries from the
+// slot table, entries of other workgroups from the local board, entries of other ranks from the remote section in ghost_needed order --
+// and the owned rows of all ranks together must reproduce the product with the GLOBAL pattern, every interior row exactly once.
+static int check_rowdist(int dim, int nx, int world, int n_wg, bool sym) {
+    std::vector<double> nodes;
+    std::vector<int32_t> cells;
+    std::vector<uint8_t> bnd;
+    grid_mesh(dim, nx, nodes, cells, bnd);
+    const int64_t nn = (int64_t)bnd.size(), nc = (int64_t)cells.size() / (dim + 1);
+    std::string err;
+    HostSpace gs;
+    if (host_set_mesh(gs, dim, dim, nn, nodes.data(), nc, cells.data(), bnd.data(), err) || host_build_space(gs, 1, err)) return -1;
+    auto val = [](int64_t row, int64_t col) { return 1.0 + 0.25 * (double)((row + col) % 7); };   // symmetric, by GLOBAL ids
+    std::vector<double> p((size_t)nn), yref((size_t)nn, 0.0), y((size_t)nn, 0.0);
+    for (int64_t d = 0; d < nn; ++d) p[(size_t)d] = bnd[(size_t)d] ? 0.0 : std::sin(0.37 * (double)d) + 1.5;
+    for (int64_t d = 0; d < nn; ++d) {
+        if (bnd[(size_t)d]) continue;
+        double acc = p[(size_t)d];
+        for (int32_t k = gs.rowptr_e[(size_t)d]; k < gs.rowptr_e[(size_t)d + 1]; ++k) {
+            const int32_t c = gs.colidx_e[(size_t)k];
+            if (c != d && !bnd[(size_t)c]) acc += val(d, c) * p[(size_t)c];
+        }
+        yref[(size_t)d] = acc;
+    }
+    std::vector<int32_t> owner((size_t)nn);
+    for (int64_t d = 0; d < nn; ++d) owner[(size_t)d] = std::min(world - 1, (int)(nodes[(size_t)d] * world));
+    std::vector<uint8_t> seen((size_t)nn, 0);
+    int late_total = 0;
+    for (int r = 0; r < world; ++r) {
+        // sub-mesh of rank r
+        std::vector<int32_t> g2l((size_t)nn, -1), l2g, lcells;
+        for (int64_t c = 0; c < nc; ++c) {
+            bool mine = false;
+            for (int q = 0; q <= dim; ++q) mine = mine || owner[(size_t)cells[(size_t)c * (dim + 1) + q]] == r;
+            if (!mine) continue;
+            for (int q = 0; q <= dim; ++q) {
+                const int32_t g = cells[(size_t)c * (dim + 1) + q];
+                if (g2l[(size_t)g] < 0) g2l[(size_t)g] = (int32_t)l2g.size(), l2g.push_back(g);
+                lcells.push_back(g2l[(size_t)g]);
+            }
+        }
+        const int64_t ln = (int64_t)l2g.size(), lc = (int64_t)lcells.size() / (dim + 1);
+        if (ln == 0) return -1;
+        std::vector<double> lnodes((size_t)ln * dim);
+        std::vector<uint8_t> lbnd((size_t)ln);
+        for (int64_t i = 0; i < ln; ++i) {
+            for (int a = 0; a < dim; ++a) lnodes[(size_t)a * ln + i] = nodes[(size_t)a * nn + l2g[(size_t)i]];
+            lbnd[(size_t)i] = bnd[(size_t)l2g[(size_t)i]];
+        }
+        HostSpace hs;
+        if (host_set_mesh(hs, dim, dim, ln, lnodes.data(), lc, lcells.data(), lbnd.data(), err) || host_build_space(hs, 1, err)) return -1;
+        auto glob = [&](int32_t di) { return l2g[(size_t)hs.dof_i2e[(size_t)di]]; };   // internal local DOF -> global node (P1: DOF = node)
+        // ghosts in (owner, key) order, as build_rowdist numbers them
+        std::vector<int32_t> gh;
+        for (int64_t d = 0; d < hs.n_dofs; ++d)
+            if (owner[(size_t)glob((int32_t)d)] != r) gh.push_back((int32_t)d);
+        std::sort(gh.begin(), gh.end(), [&](int32_t a, int32_t b) {
+            const int32_t ga = glob(a), gb = glob(b);
+            return owner[(size_t)ga] != owner[(size_t)gb] ? owner[(size_t)ga] < owner[(size_t)gb] : ga < gb;
+        });
+        std::vector<int32_t> ghost_order((size_t)hs.n_dofs, -1);
+        for (size_t k = 0; k < gh.size(); ++k) ghost_order[(size_t)gh[k]] = (int32_t)k;
+        PersistLayout pl;
+        const int rc = host_build_persist_layout(hs, true, n_wg, 12000, pl, nullptr, sym ? 1 : 0, true, ghost_order.data(), /*allow_late=*/true);
+        if (rc == FDAPDE_EUNSUPPORTED) return 0;
+        if (rc || pl.sym != sym) return -1;
+        const int T = kPersistT, S = pl.R * T, nsl = pl.nsl;
+        if ((int)pl.wg_late.size() != pl.G) return -1;
+        for (uint8_t f : pl.wg_late) late_total += f;
+        // board: [local exports | remote section in ghost_needed order]
+        std::vector<double> board((size_t)pl.n_board + pl.ghost_needed.size(), -1e300);
+        for (int g = 0; g < pl.G; ++g)
+            for (int32_t i = pl.exp_off[(size_t)g]; i < pl.exp_off[(size_t)g + 1]; ++i) {
+                const int32_t d = pl.slot_dof[(size_t)g * S + pl.exp_slot[(size_t)i]];
+                if (d < 0) return -1;
+                board[(size_t)i] = p[(size_t)glob(d)];
+            }
+        for (size_t k = 0; k < pl.ghost_needed.size(); ++k) {
+            const int32_t d = pl.ghost_needed[k];
+            if (ghost_order[(size_t)d] < 0 || (k > 0 && ghost_order[(size_t)pl.ghost_needed[k - 1]] >= ghost_order[(size_t)d])) return -1;   // ghosts only, ascending
+            board[(size_t)pl.n_board + k] = p[(size_t)glob(d)];   // (what the owning rank pushes)
+        }
+        for (int g = 0; g < pl.G; ++g) {
+            const int H = pl.imp_off[(size_t)g + 1] - pl.imp_off[(size_t)g];
+            std::vector<double> tab((size_t)(S + H), 0.0);
+            for (int s2 = 0; s2 < S; ++s2) {
+                const int32_t d = pl.slot_dof[(size_t)g * S + s2];
+                tab[(size_t)s2] = d >= 0 ? p[(size_t)glob(d)] : 0.0;
+            }
+            for (int h = 0; h < H; ++h) {
+                const int32_t pos = pl.imp_pos[(size_t)pl.imp_off[(size_t)g] + h];
+                if (pos < 0 || pos >= (int64_t)board.size()) return -1;
+                tab[(size_t)(S + h)] = board[(size_t)pos];
+            }
+            const int32_t* slo = &pl.sl_off[(size_t)g * (nsl + 1)];
+            for (int q = 0; q < nsl; ++q)
+                for (int l = 0; l < 64; ++l) {
+                    const int s2 = q * 64 + l;
+                    const int32_t d = pl.slot_dof[(size_t)g * S + s2];
+                    if (d >= 0 && (ghost_order[(size_t)d] >= 0 || hs.dof_bnd_i[(size_t)d])) return -1;   // rows of owned interior DOFs only
+                    double acc = tab[(size_t)s2];
+                    for (int32_t e = 2 * slo[q]; e < 2 * slo[q + 1]; ++e) {
+                        const int64_t at = pl.ell_off[(size_t)g] + (int64_t)(e / 2) * 128 + 2 * l + (e & 1);
+                        const int32_t k = pl.ell_src[(size_t)at];
+                        if (k < 0) continue;
+                        if (d < 0) return -1;
+                        const uint16_t code = pl.ell_code[(size_t)at];
+                        if (code >= S + H) return -1;
+                        if (!pl.wg_late[(size_t)g] && q < nsl / 2 && code >= S) return -1;   // "no import" slices import nothing -- unless the workgroup is late
+                        const int32_t col = hs.colidx_i[(size_t)k];
+                        const double a = val(glob(d), glob(col));
+                        acc += a * tab[code];
+                        if (sym && code < S) {
+                            const int32_t dc = pl.slot_dof[(size_t)g * S + code];
+                            if (dc != col) return -1;
+                            y[(size_t)glob(dc)] += a * tab[(size_t)s2];
+                        }
+                    }
+                    if (d >= 0) {
+                        const int32_t gd = glob(d);
+                        if (seen[(size_t)gd]) return -1;   // every interior row in exactly one slot of exactly one rank
+                        seen[(size_t)gd] = 1, y[(size_t)gd] += acc;
+                    }
+                }
+        }
+    }
+    for (int64_t d = 0; d < nn; ++d) {
+        if (bnd[(size_t)d]) continue;
+        if (!seen[(size_t)d] || std::fabs(y[(size_t)d] - yref[(size_t)d]) > 1e-12 * std::fabs(yref[(size_t)d])) return -1;
+    }
+    return 1 + late_total;
+}
+
 int main() {
     struct Case { int dim, nx, order; } cases[] = {{2, 200, 1}, {2, 120, 2}, {3, 26, 1}, {3, 16, 2}, {2, 3, 2}, {3, 2, 2}};
     for (const Case& cs : cases) {
@@ -194,5 +330,19 @@ int main() {
                     cs.dim, cs.nx, cs.order, (long long)nc, (long long)hs.n_dofs, (long long)hs.nnz,
                     hs.lane_row.empty() ? "identity" : "by visit count", pg[0], pg[1], pg[2], pg[3]);
     }
+    // row-distributed layouts: 2 and 3 ranks, few and many workgroups per rank, plain and symmetric storage
+    struct RCase { int dim, nx, world, n_wg; } rcases[] = {{2, 96, 2, 4}, {2, 96, 3, 64}, {3, 20, 2, 8}, {3, 20, 3, 2}, {3, 24, 2, 64},
+                                                              {3, 24, 8, 1}, {3, 24, 8, 2}};   // (thin slabs: most rows import -> late workgroups)
+    for (const RCase& rc : rcases)
+        for (int sym = 0; sym < 2; ++sym) {
+            const int got = check_rowdist(rc.dim, rc.nx, rc.world, rc.n_wg, sym != 0);
+            if (got < 0) {
+                std::fprintf(stderr, "row-distributed layout dim %d nx %d, %d ranks x %d workgroups, sym %d: does not reproduce the global operator\n", rc.dim, rc.nx,
+                             rc.world, rc.n_wg, sym);
+                return 1;
+            }
+            std::printf("row-distributed dim %d nx %d, %d ranks x <= %d workgroups, %s storage: %s, %d late workgroups\n", rc.dim, rc.nx, rc.world, rc.n_wg,
+                        sym ? "symmetric" : "plain", got == 0 ? "does not qualify" : "ok", got > 0 ? got - 1 : 0);
+        }
     return 0;
 }

@@ -81,7 +81,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
             b->release();
         for (DBuf<double>* b : {&c->vcoords, &c->vals[0], &c->vals[1], &c->force, &c->fq, &c->g, &c->sval, &c->scale, &c->gt,
                                 &c->x, &c->r, &c->p, &c->y, &c->s, &c->t, &c->r0, &c->u, &c->part_a, &c->part_b, &c->sc,
-                                &c->tmp_e, &c->tmp_i, &c->tmp_v})
+                                &c->tmp_e, &c->tmp_i, &c->tmp_v, &c->lin_rhs})
             b->release();
         for (auto& b : c->coef) b.release();
         c->slotw.release(), c->sl_off.release(), c->lane_row.release(), c->fq_blk.release(), c->bnd.release(), c->tables.release(), c->reftab.release(), c->lin_sq.release();
@@ -316,6 +316,10 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "persist_bicg" && (value == 0 || value == 1)) c->persist_bicg = value;
     else if (k == "persist_fill_fused" && (value == 0 || value == 1)) c->persist_fill_fused = value;
     else if (k == "persist_prefetch" && (value == 0 || value == 1)) c->persist_prefetch = value;
+    else if (k == "persist_single_rows" && value >= 0 && value <= 8192) {
+        c->persist_single_rows = value;
+        for (auto& ps : c->ps) ps.tried = ps.ok = ps.filled = false;
+    }
     else if (k == "persist_late" && (value == 0 || value == 1)) {
         c->persist_late = value;
         for (auto& ps : c->ps) ps.tried = ps.ok = ps.filled = false;

@@ -209,7 +209,8 @@ struct fdapde_ctx {
                               // measured on C3 with that kernel inside init's timed region: init 1.49-1.53 ms against 1.23-1.26 ms for the sweep
                               // gathering the cell's samples itself (a cell's nq samples share one 32-byte sector with the coefficient they would become)
     DBuf<double> vcoords, vals[2], force, fq, g, sval, scale, gt, x, r, p, y, s, t, r0, u, part_a, part_b, sc, tmp_e,
-      tmp_i, tmp_v;
+      tmp_i, tmp_v, lin_rhs;   // (lin_rhs: right-hand side of fdapde_lin_solve in internal order; kept between calls -- hipMalloc + hipFree per
+                               //  call were a third of a small solve)
     DBuf<uint8_t> bnd;
     DBuf<DevTables> tables;
     DBuf<DevRefTensors> reftab;
@@ -345,6 +346,7 @@ struct fdapde_ctx {
     DBuf<double> persist_x;                  // the persistent launch writes its solution here (x stays the initial guess)
     double persist_launch_ms = 0;            // duration of the last persistent launch (HIP events on the stream)
     int persist_host_below = 32768;          // systems of at most this many DOFs build the persistent layout on the host (first-solve latency)
+    int persist_single_rows = 2048;          // knob: systems of up to that many interior rows run as ONE workgroup (no hand-off in the iteration)
     int persist_prefetch = 1;                // knob: entry steps of the next operator application touched during the dot all-gather (streaming forms)
     int persist_late = 0;                    // knob: CG layouts with late-import workgroups (host builder) instead of doubled rows per thread
     int persist_plain = 0;                   // the system being prepared is non-symmetric: plain storage, BiCGStab kernel

@@ -400,8 +400,7 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
     const int64_t n_int = h_nint, nnz_kept = h_nnz;
     if (n_int < 1) return FDAPDE_EUNSUPPORTED;
     // workgroups: ~2048 rows each, more (fewer rows each) when that makes every block of the matrix fit its workgroup's LDS
-    int64_t want = (n_int + 2047) / 2048;
-    if (lds_entries > 0) want = std::max<int64_t>(want, (nnz_kept + nnz_kept / 16 + lds_entries - 1) / lds_entries);
+    const int64_t want = persist_want_workgroups(n_int, nnz_kept, lds_entries, blocked ? 0 : pl.single_rows);
     int G = (int)std::min<int64_t>(n_wg, want);
     if (blocked) G = (int)((n_int + blocked_rows - 1) / blocked_rows);
     if (G < 1) G = 1;

@@ -1017,8 +1017,9 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
         c->scaled_owner = fdapde_ctx::kScaledLin;
     }
     c->solved = false;   // c->u is about to hold the handle's solutions, not PDE::solution()
-    DBuf<double> rhs;
+    DBuf<double>& rhs = c->lin_rhs;
     HIPCHK(c, rhs.alloc((size_t)n));
+    DebugClock clk;
     HIPCHK(c, hipEventRecord(c->ev0, st));
     int total = 0, rc_all = FDAPDE_OK;
     double worst = 0;
@@ -1053,13 +1054,16 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
     for (int32_t j = j0; j < n_rhs; ++j) {
         HIPCHK(c, hipMemcpyAsync(c->tmp_e.p, b + (size_t)j * n, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_gather_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->tmp_e.p, rhs.p);
+        clk.mark("lin_solve: upload + gather issued");
         const int rc = solve_run(c, c->lin_state->ss, c->lin_mat.p, rhs.p, c->g.p, nullptr, method, rtol, maxit, check_every, 0);
+        clk.mark("lin_solve: solve_run");
         if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;
         if (rc == FDAPDE_ENOCONV) rc_all = rc;
         total += c->info.iters, worst = c->info.relres > worst ? c->info.relres : worst;
         hipLaunchKernelGGL(k_scatter_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->u.p, c->tmp_e.p);
         HIPCHK(c, hipMemcpyAsync(x + (size_t)j * n, c->tmp_e.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
+        clk.mark("lin_solve: solution download");
     }
     HIPCHK(c, hipEventRecord(c->ev1, st));
     HIPCHK(c, hipEventSynchronize(c->ev1));
@@ -1067,7 +1071,6 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->info.t_solve_ms = ms, c->info.iters = total, c->info.relres = worst, c->info.converged = rc_all == FDAPDE_OK ? 1 : 0;
     if (info) *info = c->info;
-    rhs.release();
     return rc_all;
 }
 

@@ -55,8 +55,7 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
         for (int32_t k = hs.rowptr_i[(size_t)d]; k < hs.rowptr_i[(size_t)d + 1]; ++k) nnz_kept += kept(d, hs.colidx_i[(size_t)k]);
     }
     // workgroups: ~2048 rows each, more (fewer rows each) when that makes every block of the matrix fit its workgroup's LDS
-    int64_t want = (n_int + 2047) / 2048;
-    if (lds_entries > 0) want = std::max<int64_t>(want, (nnz_kept + nnz_kept / 16 + lds_entries - 1) / lds_entries);
+    const int64_t want = persist_want_workgroups(n_int, nnz_kept, lds_entries, ghost_order != nullptr ? 0 : pl.single_rows);
     int G = (int)std::min<int64_t>(n_wg, want);
     if (G < 1) G = 1;
     int64_t rpw = (n_int + G - 1) / G;   // rows of the largest workgroup

@@ -156,11 +156,27 @@ inline bool persist_sym_owner(int32_t row, int32_t col) {
 // plain -> symmetric): 3-D P1 439 k rows 14.7 -> 15.6, 754 k 20.4 -> 18.6, 1.19 M 31.2 -> 26.2, 1.73 M 39.4 -> 31.0; 2-D P1 1.0 M
 // 14.3 -> 12.1, 1.96 M 22.9 -> 18.3; systems whose plain blocks are resident lose 25-30 % (an entry costs ~25 instructions and an LDS atomic instead of a
 // multiply-add: it only pays against bytes that would otherwise stream).
+// workgroups of a layout: ~2048 rows each, more (fewer rows each) when that makes every block of the matrix fit its workgroup's LDS; ONE
+// for a system of up to single_rows rows even if its block then streams (from the L2): a single workgroup needs no hand-off at all.
+// MI355X, us per iteration (tools/persist_knob_ab.py, knob persist_single_rows): 3-D P1 1 331 interior rows, two workgroups resident 4.76 ->
+// one workgroup streaming 4.23; beyond 2048 rows one workgroup loses: 2-D P1 2 600 rows 4.39 -> 4.82, 3 480 rows 4.87 -> 5.40, 3-D 2 197
+// rows (three workgroups) 4.99 -> 6.39
+inline int64_t persist_want_workgroups(int64_t n_int, int64_t nnz_kept, int lds_entries, int32_t single_rows) {
+    if (n_int <= single_rows) return 1;
+    int64_t want = (n_int + 2047) / 2048;
+    if (lds_entries > 0) {
+        const int64_t fit = (nnz_kept + nnz_kept / 16 + lds_entries - 1) / lds_entries;
+        if (fit > want) want = fit;
+    }
+    return want;
+}
 inline bool persist_want_sym(int sym_mode, int64_t nnz_kept, int G, int64_t rows_per_wg) {
     const bool plain_streams = 10.6 * (double)nnz_kept / (double)G + 16.0 * (double)rows_per_wg > 150e3;
     return sym_mode == 1 || (sym_mode == 2 && rows_per_wg > 2048 && plain_streams) || (sym_mode == 3 && plain_streams);
 }
 struct PersistLayout {
+    int32_t single_rows = 2048;       // IN (set before the builder is called): systems of up to that many interior rows get ONE workgroup -- its
+                                      // iteration needs no hand-off at all (kernels_persist.h, a.G == 1); 0: the general rule only
     bool sym = false;                 // in-block pairs stored once (persist_sym_owner)
     int G = 0, R = 0, nsl = 0;        // workgroups; rows per thread (2, 4, 8, 16); slices of 64 slots per workgroup = R * T / 64.
                                       // Slots [0, T R / 2): rows that import nothing; [T R / 2, T R): the others

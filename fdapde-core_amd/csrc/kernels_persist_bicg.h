@@ -282,6 +282,17 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
             __syncthreads();
             return fail_flag == 0;
         }
+        if (!DIST && a.G == 1) {   // one workgroup: its sums are the totals (kernels_persist.h)
+            if (tid < 4) {
+                double v = 0;
+#pragma unroll
+                for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
+                tot[tid] = v;
+            }
+            prefetch_next();
+            __syncthreads();
+            return true;
+        }
         unsigned long long* dslot = a.dboard + (size_t)phase * a.G * 8;
         if (tid < 4) {
             double v = 0;

@@ -16,6 +16,7 @@ namespace fdapde_engine {
 int check_dev_persist(fdapde_ctx* c, int v, const PersistLayout& pl, const DevPersist& dp, const std::vector<int32_t>* block_rows, bool balance) {
     if (int rc = ensure_host(c, kHostPattern)) return rc;
     PersistLayout ref;
+    ref.single_rows = pl.single_rows;
     if (host_build_persist_layout(c->hs, v == 1, block_rows ? (int)block_rows->size() : c->n_cu, 12000, ref, block_rows ? block_rows->data() : nullptr,
                                   pl.sym ? 1 : 0, balance) != FDAPDE_OK) return fail(c, FDAPDE_EHIP, "set-up check: host persistent layout failed");
     int bad = 0;
@@ -79,6 +80,7 @@ int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_r
     if (c->persist_plain) sym_mode = 0;                        // (a non-symmetric system: BiCGStab on the plain storage)
     for (int attempt = 0; attempt < 2; ++attempt) {
         pl = PersistLayout{};
+        pl.single_rows = c->persist_single_rows;
         int rc = FDAPDE_EUNSUPPORTED;
         if (on_device) {   // the layout is built where the pattern lives (dev_persist.hip)
             rc = dev_build_persist_layout(c->hs.n_dofs, c->hs.max_row, c->rowptr.p, c->colidx.p, c->bnd.p, v == 1, n_wg, 12000, 0, brows, sym_mode,
@@ -122,6 +124,11 @@ int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_r
         // ... and kept only where it pays (tools/persist_sym_ab.py): not if the PLAIN blocks of this partition would be resident (C2-size
         // systems: 6.2 against 8.3 us per iteration), and for workgroups of at most 2048 rows only if the symmetric blocks are resident
         // (3-D 314 k rows: 13.7 -> 11.7 us) -- streamed, the plain form is faster at that size (439 k rows: 14.7 against 15.7)
+        if (c->persist_sym == 2 && pl.sym && attempt == 0 && pl.G == 1) {   // one workgroup streams from the L2: the plain form (2-D 2 304 rows: 4.5 -> 4.3 us)
+            dev_persist_release(&dp);
+            sym_mode = 0;
+            continue;
+        }
         if (c->persist_sym == 2 && pl.sym && attempt == 0) {
             const size_t fixed_plain = 8 * (size_t)(S + imp_cap) + 4 * (size_t)imp_cap + 2 * (size_t)exp_cap + 64;
             const size_t block_plain = (size_t)(1.03 * (double)pl.nnz_full / (double)pl.G) + 256;   // (boundaries at equal cost: blocks of equal size)

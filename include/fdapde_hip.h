@@ -299,6 +299,7 @@ int fdapde_rowdist_setup(fdapde_ctx *ctx, const int64_t *dof_key, const int32_t 
  *                 (workgroup boundaries at equal cost / equal row counts), "blocked" (blocked-ELL SpMV of the multi-launch solves),
  *                 "persist_coop" (0: plain instead of cooperative launch), "persist_timeout_us" (bound of every in-kernel wait),
  *                 "persist_debug_stall" / "persist_retry" (tests: force a hand-off timeout at an iteration / forget one),
+ *                 "persist_single_rows" (systems of up to that many interior rows run as one workgroup, without hand-offs),
  *                 "persist_prefetch" (0: the streaming forms do not touch the next operator application's first lines during the dot all-gather) */
 int fdapde_tune(fdapde_ctx *ctx, const char *key, int32_t value);
 /* the context's HIP stream (hipStream_t) so that callers can bracket work with their own events */

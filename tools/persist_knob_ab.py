@@ -16,7 +16,7 @@ capi = load_package().capi
 from fdapde_core_amd import meshgen   # noqa: E402
 
 
-def run(dim, nx, knob, values, rounds, order, adr):
+def run(dim, nx, knob, values, rounds, order, adr, fixed):
     nodes, cells, bnd = meshgen.unit_square(nx) if dim == 2 else meshgen.unit_cube(nx)
     _, f = meshgen.manufactured(dim)
     c = capi.Context(0)
@@ -29,6 +29,8 @@ def run(dim, nx, knob, values, rounds, order, adr):
     c.set_forcing(f(c.quadrature_nodes()))
     c.set_dirichlet(np.zeros(nd))
     c.init()
+    for k, v in fixed:
+        c.tune(k, v)
     res = {v: [] for v in values}
     lay = None
     for _ in range(rounds):
@@ -36,11 +38,13 @@ def run(dim, nx, knob, values, rounds, order, adr):
             c.tune(knob, v)
             c.solve(rtol=1e-10)
             i = c.solve(rtol=1e-10)
-            res[v].append((i.iters, 1e3 * i.launch_ms / max(i.iters, 1), i.persistent))
             lay = c.solver_layout_kind(True)
-    txt = "  ".join(f"{knob}={v}: {res[v][0][0]} it " + "/".join(f"{us:.2f}" for _, us, _ in res[v]) + " us/it" + ("" if res[v][0][2] else " (multi-launch)")
-                    for v in values)
-    print(f"{dim}-D P{order}{' ADR' if adr else ''} nx {nx}: {nd} DOFs R={lay['rows_per_thread']} kind={lay['kind']} sym={lay['sym']}  {txt}", flush=True)
+            res[v].append((i.iters, 1e3 * i.launch_ms / max(i.iters, 1), i.persistent, lay))
+    def lay_txt(la):
+        return f"G={la['workgroups']} R={la['rows_per_thread']} kind={la['kind']} sym={la['sym']}"
+    txt = "  ".join(f"{knob}={v} [{lay_txt(res[v][0][3])}]: {res[v][0][0]} it " + "/".join(f"{us:.2f}" for _, us, _, _ in res[v]) + " us/it" +
+                    ("" if res[v][0][2] else " (multi-launch)") for v in values)
+    print(f"{dim}-D P{order}{' ADR' if adr else ''} nx {nx}: {nd} DOFs  {txt}", flush=True)
     c.close()
 
 
@@ -53,6 +57,8 @@ if __name__ == "__main__":
     ap.add_argument("--order", type=int, default=1)
     ap.add_argument("--adr", action="store_true", help="advection-diffusion-reaction operator (BiCGStab)")
     ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--set", default="", help="other knobs set once, key=value,key=value")
     a = ap.parse_args()
     for nx in (int(t) for t in a.nx.split(",")):
-        run(a.dim, nx, a.knob, [int(t) for t in a.values.split(",")], a.rounds, a.order, a.adr)
+        run(a.dim, nx, a.knob, [int(t) for t in a.values.split(",")], a.rounds, a.order, a.adr,
+            [(kv.split("=")[0], int(kv.split("=")[1])) for kv in a.set.split(",") if kv])

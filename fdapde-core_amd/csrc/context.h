@@ -346,6 +346,8 @@ struct fdapde_ctx {
     DBuf<double> persist_x;                  // the persistent launch writes its solution here (x stays the initial guess)
     double persist_launch_ms = 0;            // duration of the last persistent launch (HIP events on the stream)
     int persist_host_below = 32768;          // systems of at most this many DOFs build the persistent layout on the host (first-solve latency)
+    bool defer_end_sync = false;             // set by callers that loop over solves (parabolic steps, handle columns): solve_run does not wait for its
+                                             // last kernel (the outcome is read behind a wait of its own; the rest is ordered by the stream)
     int persist_single_rows = 2048;          // knob: systems of up to that many interior rows run as ONE workgroup (no hand-off in the iteration)
     int persist_prefetch = 1;                // knob: entry steps of the next operator application touched during the dot all-gather (streaming forms)
     int persist_late = 0;                    // knob: CG layouts with late-import workgroups (host builder) instead of doubled rows per thread

@@ -670,7 +670,7 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
         hipLaunchKernelGGL(k_cgf_flush, dim3(c->vec_grid), dim3(256), 0, st, n, c->p.p, c->r.p, c->x.p, c->sc.p, c->ctl.p);
     hipLaunchKernelGGL(k_unscale, dim3(g1(n)), dim3(256), 0, st, n, c->scale.p, persisted ? c->persist_x.p : c->x.p, c->gt.p, c->u.p);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(st));
+    if (!c->defer_end_sync) HIPCHK(c, hipStreamSynchronize(st));   // (h_ctl / h_sc were read back behind a wait of their own)
     const double bb = c->h_sc[0], rr = c->h_sc[3];
     c->info.iters = c->h_ctl[1];
     c->info.relres = bb > 0 ? sqrt(rr / bb) : 0.0;
@@ -883,13 +883,14 @@ int e_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times,
     for (int32_t i = 0; i + 1 < n_times; ++i) {
         launch_spmv(c, c->vals[FDAPDE_MAT_MASS].p, uprev.p, c->s.p, nullptr, nullptr, nullptr);   // M u_i
         hipLaunchKernelGGL(k_parabolic_rhs, dim3(g1(n)), dim3(256), 0, st, n, c->s.p, inv_dt, c->force.p + (size_t)(i + 1) * n, rhs.p);
-        if (dirichlet) {
-            to_internal(dirichlet + (size_t)(i + 1) * n);
-            HIPCHK(c, hipMemcpyAsync(gcol.p, tmp.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
-            HIPCHK(c, hipStreamSynchronize(st));
+        if (dirichlet) {   // column i + 1 as handed over, brought into the internal order on the device (everything on the one stream: no wait here)
+            HIPCHK(c, hipMemcpyAsync(c->tmp_i.p, dirichlet + (size_t)(i + 1) * n, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_gather_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->tmp_i.p, gcol.p);
         }
+        c->defer_end_sync = true;   // (the step's outcome is read inside solve_run; what follows it is ordered by the stream)
         const int rc = solve_run(c, ss, kmat.p, rhs.p, gcol.p, uprev.p, opt ? opt->method : FDAPDE_SOLVER_AUTO, rtol, maxit,
                                  check_every, 0);
+        c->defer_end_sync = false;
         if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;
         if (rc == FDAPDE_ENOCONV) rc_all = rc;
         total_iters += c->info.iters;
@@ -899,7 +900,6 @@ int e_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times,
         HIPCHK(c, hipMemcpyAsync(uprev.p, c->u.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(k_scatter_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->u.p, c->tmp_e.p);
         HIPCHK(c, hipMemcpyAsync(solution + (size_t)(i + 1) * n, c->tmp_e.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipStreamSynchronize(st));
     }
     HIPCHK(c, hipEventRecord(c->ev1, st));
     HIPCHK(c, hipEventSynchronize(c->ev1));
@@ -1055,15 +1055,16 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
         HIPCHK(c, hipMemcpyAsync(c->tmp_e.p, b + (size_t)j * n, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_gather_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->tmp_e.p, rhs.p);
         clk.mark("lin_solve: upload + gather issued");
+        c->defer_end_sync = true;
         const int rc = solve_run(c, c->lin_state->ss, c->lin_mat.p, rhs.p, c->g.p, nullptr, method, rtol, maxit, check_every, 0);
+        c->defer_end_sync = false;
         clk.mark("lin_solve: solve_run");
         if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;
         if (rc == FDAPDE_ENOCONV) rc_all = rc;
         total += c->info.iters, worst = c->info.relres > worst ? c->info.relres : worst;
         hipLaunchKernelGGL(k_scatter_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->u.p, c->tmp_e.p);
         HIPCHK(c, hipMemcpyAsync(x + (size_t)j * n, c->tmp_e.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipStreamSynchronize(st));
-        clk.mark("lin_solve: solution download");
+        clk.mark("lin_solve: solution download issued");
     }
     HIPCHK(c, hipEventRecord(c->ev1, st));
     HIPCHK(c, hipEventSynchronize(c->ev1));

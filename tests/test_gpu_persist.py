@@ -343,6 +343,56 @@ def test_single_launch_bicgstab_matches_multi_launch(env, dim, nx, order):
     c.close()
 
 
+@pytest.mark.parametrize("dim,nx,adr", [(3, 80, False), (2, 1000, False), (3, 80, True)])
+def test_touching_the_next_entries_during_the_all_gather_changes_no_bit(env, dim, nx, adr):
+    """streaming layouts: the idle wavefronts touch the first entry step of the next operator application while the workgroup waits for
+    the dot records (knob persist_prefetch).  The touches move data towards the L2 and nothing else: identical iterations and bits."""
+    capi, meshgen = env
+    nodes, cells, bnd = meshgen.unit_square(nx) if dim == 2 else meshgen.unit_cube(nx)
+    _, f = meshgen.manufactured(dim)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(1)
+    op = -capi.laplacian()
+    if adr:
+        op = op + capi.advection([1.0, 0.5, 0.25][:dim]) + capi.reaction(1.0)
+    c.set_operator(op)
+    c.set_forcing(f(c.quadrature_nodes()))
+    c.set_dirichlet(np.zeros(nd))
+    c.init()
+    out = {}
+    for knob in (0, 1):
+        c.tune("persist_prefetch", knob)
+        i = c.solve(rtol=1e-10)
+        assert i.persistent == 1 and i.converged == 1
+        assert c.solver_layout_kind(True)["kind"] == 2, "the case is meant to stream its blocks"
+        out[knob] = (i.iters, c.solution())
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+    c.close()
+
+
+@pytest.mark.parametrize("dim,nx,order,dirichlet", [(2, 44, 1, False), (3, 12, 1, True), (2, 20, 2, True), (3, 11, 1, False)])
+def test_one_workgroup_without_hand_offs_matches_several(env, dim, nx, order, dirichlet):
+    """systems of up to 2048 interior rows run as ONE workgroup, which publishes and polls no dot record (knob persist_single_rows; the
+    block streams from the L2 where it does not fit the LDS); against the layout of several workgroups the general rule would give"""
+    capi, meshgen = env
+    c, nd = _problem(capi, meshgen, dim, nx, order, dirichlet)
+    c.tune("persist_single_rows", 0)
+    i0 = c.solve(rtol=1e-11)
+    u0 = c.solution()
+    g0 = c.solver_layout_kind(dirichlet)["workgroups"]
+    c.tune("persist_single_rows", 2048)
+    i1 = c.solve(rtol=1e-11)
+    u1 = c.solution()
+    assert i0.persistent == 1 and i1.persistent == 1 and i0.converged == 1 and i1.converged == 1
+    assert g0 >= 2 and c.solver_layout_kind(dirichlet)["workgroups"] == 1, (g0, c.solver_layout_kind(dirichlet))
+    assert abs(i1.iters - i0.iters) <= 2
+    assert np.linalg.norm(u1 - u0) <= 1e-9 * np.linalg.norm(u0)
+    i2 = c.solve(rtol=1e-11)
+    assert i2.iters == i1.iters and np.array_equal(c.solution(), u1)
+    c.close()
+
+
 def test_graph_replay_is_rebuilt_when_the_blocked_layout_changes(env):
     """use_graph = 1 on a system that takes the blocked-ELL SpMV (2-D P2; the 3-D P2 "mass matrix" of the reference's 5-point rule with its
     negative weight is indefinite, no CG applies to it): a solve with Dirichlet data captures the fused-CG chunk on

@@ -81,8 +81,9 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
             b->release();
         for (DBuf<double>* b : {&c->vcoords, &c->vals[0], &c->vals[1], &c->force, &c->fq, &c->g, &c->sval, &c->scale, &c->gt,
                                 &c->x, &c->r, &c->p, &c->y, &c->s, &c->t, &c->r0, &c->u, &c->part_a, &c->part_b, &c->sc,
-                                &c->tmp_e, &c->tmp_i, &c->tmp_v, &c->lin_rhs})
+                                &c->tmp_e, &c->tmp_i, &c->tmp_v, &c->lin_rhs, &c->cols_b, &c->cols_r, &c->cols_x, &c->cols_sc, &c->cols_part})
             b->release();
+        c->cols_ctl.release();
         for (auto& b : c->coef) b.release();
         c->slotw.release(), c->sl_off.release(), c->lane_row.release(), c->fq_blk.release(), c->bnd.release(), c->tables.release(), c->reftab.release(), c->lin_sq.release();
         c->bc_off.release(), c->bn_off.release(), c->bc_cell.release(), c->bn_node.release(), c->bc_vert.release();
@@ -99,7 +100,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
               bk.ell_code.release(), bk.ell_val.release();
         for (auto& ps : c->ps)
             ps.slot_dof.release(), ps.sl_off.release(), ps.ell_src.release(), ps.exp_off.release(), ps.imp_off.release(),
-              ps.imp_pos.release(), ps.ell_off.release(), ps.ell_code.release(), ps.exp_slot.release(), ps.ell_val.release(), ps.board.release(), ps.amax.release(), ps.wg_late.release(), ps.ell_col.release();
+              ps.imp_pos.release(), ps.ell_off.release(), ps.ell_code.release(), ps.exp_slot.release(), ps.ell_val.release(), ps.board.release(), ps.board_cols.release(), ps.amax.release(), ps.wg_late.release(), ps.ell_col.release();
         for (int v = 0; v < 2; ++v)
             c->sp_rowptr[v].release(), c->sp_colidx[v].release(), c->sp_map[v].release(), c->sp_tbase[v].release(), c->sp_col16[v].release(),
               c->sp_vrow[v].release();
@@ -316,6 +317,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "persist_bicg" && (value == 0 || value == 1)) c->persist_bicg = value;
     else if (k == "persist_fill_fused" && (value == 0 || value == 1)) c->persist_fill_fused = value;
     else if (k == "persist_prefetch" && (value == 0 || value == 1)) c->persist_prefetch = value;
+    else if (k == "persist_cols" && (value == 0 || value == 1)) c->persist_cols = value;
     else if (k == "persist_single_rows" && value >= 0 && value <= 8192) {
         c->persist_single_rows = value;
         for (auto& ps : c->ps) ps.tried = ps.ok = ps.filled = false;

@@ -308,7 +308,9 @@ struct fdapde_ctx {
         DBuf<double> ell_val;
         DBuf<unsigned long long> amax;       // symmetric storage: bit pattern of max |ell_val| (k_persist_fill)
         DBuf<uint8_t> wg_late;               // BiCGStab layouts built with late-import workgroups (host_build_persist_layout allow_late), else empty
-        DBuf<unsigned long long> board;      // [2 n_board granules of p | 2 x G x 6 granules of dot partials], zeroed before every launch
+        DBuf<unsigned long long> board;      // [2 n_board granules of p | 2 x G x 8 granules of dot partials]; never cleared between launches (epoch tags)
+        DBuf<unsigned long long> board_cols; // one such board per column of a launch that solves several right-hand sides (run_persist_cols)
+        int per_cu = 0;                      // workgroups of the instantiation attr_set a CU holds (occupancy API)
         bool filled = false;                 // ell_val holds the currently scaled system
         uint32_t epoch_next = 0;             // the next launch tags its granules epoch_next + iteration + 1
         const void* attr_set = nullptr;      // kernel instantiation whose dynamic-LDS attribute is in place
@@ -346,6 +348,9 @@ struct fdapde_ctx {
     DBuf<double> persist_x;                  // the persistent launch writes its solution here (x stays the initial guess)
     double persist_launch_ms = 0;            // duration of the last persistent launch (HIP events on the stream)
     int persist_host_below = 32768;          // systems of at most this many DOFs build the persistent layout on the host (first-solve latency)
+    int persist_cols = 1;                    // knob: several columns of fdapde_lin_solve as ONE persistent launch where G x columns workgroups are resident
+    DBuf<double> cols_b, cols_r, cols_x, cols_sc, cols_part;   // their staging: right-hand sides as handed over, scaled, solutions, scalars, partial sums
+    DBuf<int32_t> cols_ctl;
     bool defer_end_sync = false;             // set by callers that loop over solves (parabolic steps, handle columns): solve_run does not wait for its
                                              // last kernel (the outcome is read behind a wait of its own; the rest is ordered by the stream)
     int persist_single_rows = 2048;          // knob: systems of up to that many interior rows run as ONE workgroup (no hand-off in the iteration)

@@ -1051,6 +1051,46 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
             j0 += q;
         }
     }
+    // several columns against a system the single-launch CG holds in few workgroups (the small systems the reference's users solve by the
+    // thousand: one or two of 256 CUs busy per solve): Q columns side by side in ONE launch of G x Q workgroups, each column with boards of
+    // its own; the same arithmetic per column as one by one, hence the same bits
+    if (persist_cols && c->persist_cols && method == FDAPDE_SOLVER_CG_FUSED && !c->lin_state->ss.dist && !c->lin_state->ss.rowdist && !c->lin_state->ss.use_bnd) {
+        fdapde_ctx::Persist& ps = c->ps[0];
+        const int G = ps.meta.G;
+        const int cap = (ps.per_cu > 0 ? ps.per_cu : 1) * c->n_cu / (G > 0 ? G : 1);   // columns whose workgroups are resident together
+        const double tol2 = rtol * rtol;
+        const int np = c->vec_grid;
+        while (n_rhs - j0 >= 2 && cap >= 2) {
+            const int Q = std::min(std::min<int>(n_rhs - j0, cap), 64);
+            const size_t qn = (size_t)Q * (size_t)n;
+            HIPCHK(c, c->cols_b.alloc(qn));
+            HIPCHK(c, c->cols_r.alloc(qn));
+            HIPCHK(c, c->cols_x.alloc(qn));
+            HIPCHK(c, c->cols_sc.alloc(4 * (size_t)Q));
+            HIPCHK(c, c->cols_ctl.alloc(4 * (size_t)Q));
+            HIPCHK(c, c->cols_part.alloc(2 * (size_t)np * Q));
+            HIPCHK(c, hipMemcpyAsync(c->cols_b.p, b + (size_t)j0 * n, sizeof(double) * qn, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_cols_init, dim3(np, Q), dim3(256), 0, st, n, c->cols_b.p, c->dof_i2e.p, c->scale.p, c->cols_r.p, c->cols_part.p);
+            hipLaunchKernelGGL(k_cols_init_fin, dim3(Q), dim3(256), 0, st, c->cols_part.p, np, c->cols_sc.p, c->cols_ctl.p);
+            HIPCHK(c, hipGetLastError());
+            std::vector<int32_t> h_ctl(4 * (size_t)Q);
+            std::vector<double> h_sc(4 * (size_t)Q);
+            bool ran = false;
+            if (int rc = run_persist_cols(c, 0, tol2, maxit, Q, c->cols_r.p, c->cols_x.p, c->cols_sc.p, c->cols_ctl.p, h_ctl.data(), h_sc.data(), &ran)) return rc;
+            if (!ran) break;   // (more workgroups than fit after all, or a launch that gave up: these columns go one by one below)
+            hipLaunchKernelGGL(k_cols_finish, dim3(g1(n), Q), dim3(256), 0, st, n, c->cols_x.p, c->scale.p, c->dof_i2e.p, c->cols_b.p);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipMemcpyAsync(x + (size_t)j0 * n, c->cols_b.p, sizeof(double) * qn, hipMemcpyDeviceToHost, st));
+            for (int k = 0; k < Q; ++k) {
+                const double bb = h_sc[4 * (size_t)k], rr = h_sc[4 * (size_t)k + 3];
+                const double rel = bb > 0 ? sqrt(rr / bb) : 0.0;
+                if (!(rr <= tol2 * bb && h_ctl[4 * (size_t)k + 2] == 0)) rc_all = FDAPDE_ENOCONV;
+                total += h_ctl[4 * (size_t)k + 1], worst = rel > worst ? rel : worst;
+            }
+            c->info.method_used = method, c->info.persistent = 1, c->info.launch_ms = c->persist_launch_ms;
+            j0 += Q;
+        }
+    }
     for (int32_t j = j0; j < n_rhs; ++j) {
         HIPCHK(c, hipMemcpyAsync(c->tmp_e.p, b + (size_t)j * n, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_gather_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->tmp_e.p, rhs.p);

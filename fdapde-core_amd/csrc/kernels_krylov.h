@@ -136,6 +136,42 @@ static __global__ __launch_bounds__(256) void k_krylov_init_fin(const double* pa
         ctl[0] = rr <= tol2 * bb ? 1 : 0, ctl[1] = 0, ctl[2] = 0;
     }
 }
+// Several right-hand sides of fdapde_lin_solve at once (one persistent launch solves them side by side, kernels_persist.h n_cols): what
+// k_gather_f64 + k_krylov_init / _fin do for one column, for column blockIdx.y -- the same loops and the same reduction order, hence the
+// same bits: r = bt = scale * b[ext order -> internal], partial sums of bt^2 per workgroup, then sc[4 col] = ||bt||^2
+static __global__ __launch_bounds__(256) void k_cols_init(int64_t n, const double* b_ext, const int32_t* i2e, const double* scale, double* r, double* partial) {
+    __shared__ double red[8];
+    const size_t col = blockIdx.y;
+    b_ext += col * (size_t)n, r += col * (size_t)n, partial += col * 2 * (size_t)gridDim.x;
+    double acc = 0, accb = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double bt = scale[i] * (b_ext[i2e[i]] - 0.0);
+        r[i] = bt;
+        acc += bt * bt, accb += bt * bt;
+    }
+    const double s = block_sum(acc, red);
+    const double sb = block_sum(accb, red);
+    if (threadIdx.x == 0) partial[2 * blockIdx.x] = s, partial[2 * blockIdx.x + 1] = sb;
+}
+static __global__ __launch_bounds__(256) void k_cols_init_fin(const double* partial, int np, double* sc, int32_t* ctl) {
+    __shared__ double red[8];
+    const size_t col = blockIdx.x;
+    partial += col * 2 * (size_t)np;
+    double a = 0, b = 0;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) a += partial[2 * i], b += partial[2 * i + 1];
+    const double rr = block_sum(a, red);
+    const double bb = block_sum(b, red);
+    if (threadIdx.x == 0) {
+        sc[4 * col] = bb, sc[4 * col + 1] = rr, sc[4 * col + 2] = rr, sc[4 * col + 3] = rr;
+        ctl[4 * col] = 0, ctl[4 * col + 1] = 0, ctl[4 * col + 2] = 0, ctl[4 * col + 3] = 0;
+    }
+}
+// u = scale * x (k_unscale without lift) of column blockIdx.y, written in the reference's DOF order (k_scatter_f64)
+static __global__ __launch_bounds__(256) void k_cols_finish(int64_t n, const double* x, const double* scale, const int32_t* i2e, double* out_ext) {
+    const size_t col = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out_ext[col * (size_t)n + i2e[i]] = scale[i] * x[col * (size_t)n + i] + 0.0;
+}
 // out[0], out[1] = sums of the stride-2 partial pairs, fixed order; single workgroup
 static __global__ __launch_bounds__(256) void k_reduce_partials2(const double* part, int np, double* out) {
     __shared__ double red[8];

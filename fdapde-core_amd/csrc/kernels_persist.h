@@ -38,6 +38,10 @@ struct PersistArgs {
     uint32_t epoch0;                  // tags of this launch are epoch0 + iteration + 1: boards are never cleared between launches
     int32_t timeout_ticks;            // bound of every wait, in 10 ns ticks of s_memrealtime
     int32_t debug_stall_it;           // > 0 (tests): the last workgroup leaves at this iteration without publishing, as a peer that is not resident would
+    int32_t n_cols;                   // > 1 (single GPU, CG): gridDim.y independent systems with the same matrix -- column c reads r_in + c col_stride and
+                                      // sc[4 c], writes x_out + c col_stride, sc[4 c + 3] and ctl[4 c ..], and talks over boards of its own
+                                      // (pboard / dboard + c board_stride); x == nullptr: every column starts from 0
+    int64_t col_stride, board_stride;
     int32_t pf_steps;                 // streaming forms, != 0: the first entry step of the next operator application is touched (pulled into the L2)
                                       // while the workgroup waits for the dot records
     double tol2;
@@ -213,6 +217,14 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
     __shared__ double pmax_w[W];
     __shared__ int32_t fail_flag;
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if constexpr (!DIST) {
+        if (a.n_cols > 1) {   // several right-hand sides at once: this workgroup belongs to column blockIdx.y (uniform)
+            const size_t col = blockIdx.y;
+            a.r_in += col * a.col_stride, a.x_out += col * a.col_stride, a.sc += 4 * col, a.ctl += 4 * col;
+            if (a.x != nullptr) a.x += col * a.col_stride;
+            a.pboard += col * a.board_stride, a.dboard += col * a.board_stride;
+        }
+    }
     const int nsl = a.nsl;
     const int H = a.imp_off[g + 1] - a.imp_off[g], E = a.exp_off[g + 1] - a.exp_off[g];
     double* p_tab = lds;                                                                  // [S + imp_cap]
@@ -273,7 +285,7 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
         const int32_t d = a.slot_dof[(size_t)g * S + j * T + tid];
         const bool on = d >= 0;
         rv[j] = on ? a.r_in[d] : 0.0;
-        xv[j] = on ? a.x[d] : 0.0;
+        xv[j] = on && a.x != nullptr ? a.x[d] : 0.0;
         if constexpr (SYM) p_tab[j * T + tid] = rv[j];
         else pv[j] = rv[j], dof[j] = d;
         rr_part += rv[j] * rv[j];

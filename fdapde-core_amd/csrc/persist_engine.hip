@@ -184,6 +184,7 @@ int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_r
     HIPCHK(c, ps.board.alloc(2 * (size_t)pl.n_board + 2 * (size_t)pl.G * 8 + 2));   // p entries | dot records x 2 buffers (CG: 3 doubles wide, BiCGStab: 4)
     HIPCHK(c, hipMemsetAsync(ps.board.p, 0, sizeof(unsigned long long) * ps.board.n, st));   // every tag 0: no launch uses epoch 0
     ps.epoch_next = 0, ps.attr_set = nullptr;
+    ps.board_cols.release();   // (boards of multi-column launches: tags of the layout before must not meet the new epochs)
     HIPCHK(c, ps.amax.alloc(1));
     HIPCHK(c, c->persist_stats.alloc(4 * 1024));
     HIPCHK(c, hipStreamSynchronize(st));
@@ -209,11 +210,13 @@ int launch_persist(fdapde_ctx* c, fdapde_ctx::Persist& ps, PersistArgs& a, bool 
     a.gather_waves = c->persist_gather_waves, a.poll_sleep = c->persist_poll_sleep;
     a.slot_dof = ps.slot_dof.p, a.ell_off = ps.ell_off.p, a.sl_off = ps.sl_off.p, a.ell_code = ps.ell_code.p;
     a.ell_val = ps.ell_val.p, a.exp_off = ps.exp_off.p, a.exp_slot = ps.exp_slot.p, a.imp_off = ps.imp_off.p, a.imp_pos = ps.imp_pos.p;
-    if (!dist) a.pboard = ps.board.p, a.dboard = ps.board.p + 2 * (size_t)ps.meta.n_board, a.wg_late = ps.wg_late.p;   // (row-distributed: set by the caller)
+    if (!dist && a.n_cols <= 1) a.pboard = ps.board.p, a.dboard = ps.board.p + 2 * (size_t)ps.meta.n_board;   // (row-distributed, several columns: set by the caller)
+    if (!dist) a.wg_late = ps.wg_late.p;
     a.amax_bits = ps.amax.p, a.max_len = c->hs.max_row, a.stats = c->persist_stats.p;
     a.timeout_ticks = c->persist_timeout_us * 100, a.debug_stall_it = c->persist_debug_stall, a.pf_steps = c->persist_prefetch;
     if (!dist && ps.epoch_next > 0xC0000000u - 2u * (uint32_t)a.maxit) {   // (the tags are 32 bits wide: start over on clean boards)
         HIPCHK(c, hipMemsetAsync(ps.board.p, 0, sizeof(unsigned long long) * ps.board.n, st));
+        if (ps.board_cols.p) HIPCHK(c, hipMemsetAsync(ps.board_cols.p, 0, sizeof(unsigned long long) * ps.board_cols.n, st));
         ps.epoch_next = 0;
     }
     a.epoch0 = ps.epoch_next;
@@ -235,10 +238,12 @@ int launch_persist(fdapde_ctx* c, fdapde_ctx::Persist& ps, PersistArgs& a, bool 
             HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kPersistT, ps.lds_bytes));                      \
             clk2.mark("launch_persist: occupancy query");                                                                       \
             if ((int64_t)per_cu * c->n_cu < (int64_t)a.G) return FDAPDE_EUNSUPPORTED;   /* the grid cannot be resident at once */ \
-            ps.attr_set = fn;                                                                                                   \
+            ps.attr_set = fn, ps.per_cu = per_cu;                                                                               \
         }                                                                                                                       \
-        if (c->persist_coop) HIPCHK(c, hipLaunchCooperativeKernel(fn, dim3(a.G), dim3(kPersistT), kargs, (unsigned)ps.lds_bytes, st)); \
-        else hipLaunchKernelGGL((k_cg_persist<R_, ST_, SY_, DI_>), dim3(a.G), dim3(kPersistT), ps.lds_bytes, st, a);            \
+        const unsigned ncol = a.n_cols > 1 ? (unsigned)a.n_cols : 1u;                                                           \
+        if ((int64_t)ps.per_cu * c->n_cu < (int64_t)a.G * ncol) return FDAPDE_EUNSUPPORTED;                                     \
+        if (c->persist_coop) HIPCHK(c, hipLaunchCooperativeKernel(fn, dim3(a.G, ncol), dim3(kPersistT), kargs, (unsigned)ps.lds_bytes, st)); \
+        else hipLaunchKernelGGL((k_cg_persist<R_, ST_, SY_, DI_>), dim3(a.G, ncol), dim3(kPersistT), ps.lds_bytes, st, a);      \
     } while (0)
 #define PERSIST_GO2(R_, ST_)                                                                                                    \
     do {                                                                                                                        \
@@ -396,6 +401,44 @@ int fill_persist_scaled(fdapde_ctx* c, int v, const double* A) {
                        ps.ell_src.p, ps.ell_col.p, A, c->scale.p, ps.ell_val.p, ps.meta.sym ? ps.amax.p : (unsigned long long*)nullptr);
     HIPCHK(c, hipGetLastError());
     ps.filled = true;
+    return FDAPDE_OK;
+}
+
+// n_cols right-hand sides against the matrix of layout v as ONE launch of G x n_cols workgroups (kernels_persist.h n_cols): column k reads its
+// scaled right-hand side r_cols + k n and ||.||^2 from sc_cols[4 k], starts from 0, writes x_cols + k n, sc_cols[4 k + 3], ctl_cols[4 k ..].
+// The columns do not interact: each has boards of its own.  *ran = false when any column's launch gave up (nothing is lost: the caller
+// solves the columns one by one).  h_ctl / h_sc: 4 n_cols values each, read back here.
+int run_persist_cols(fdapde_ctx* c, int v, double tol2, int maxit, int n_cols, const double* r_cols, double* x_cols, double* sc_cols, int32_t* ctl_cols,
+                     int32_t* h_ctl, double* h_sc, bool* ran) {
+    fdapde_ctx::Persist& ps = c->ps[v];
+    hipStream_t st = c->stream;
+    const size_t n = (size_t)c->hs.n_dofs, blen = ps.board.n;
+    if (ps.board_cols.n < blen * (size_t)n_cols) {
+        HIPCHK(c, ps.board_cols.alloc(blen * (size_t)n_cols));
+        HIPCHK(c, hipMemsetAsync(ps.board_cols.p, 0, sizeof(unsigned long long) * ps.board_cols.n, st));   // every tag 0: no launch uses epoch 0
+    }
+    PersistArgs a{};
+    a.maxit = maxit, a.time_phases = 0, a.tol2 = tol2;
+    a.r_in = r_cols, a.x = nullptr, a.x_out = x_cols, a.sc = sc_cols, a.ctl = ctl_cols;
+    a.n_cols = n_cols, a.col_stride = (int64_t)n, a.board_stride = (int64_t)blen;
+    a.pboard = ps.board_cols.p, a.dboard = ps.board_cols.p + 2 * (size_t)ps.meta.n_board;
+    const int rc_launch = launch_persist(c, ps, a, false, false);
+    if (rc_launch == FDAPDE_EUNSUPPORTED) {
+        *ran = false;
+        return FDAPDE_OK;
+    }
+    if (rc_launch) return rc_launch;
+    HIPCHK(c, hipMemcpyAsync(h_ctl, ctl_cols, 4 * (size_t)n_cols * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(h_sc, sc_cols, 4 * (size_t)n_cols * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev_p0, c->ev_p1));
+    c->persist_launch_ms = ms;
+    bool gave_up = false;
+    uint32_t most = 0;
+    for (int k = 0; k < n_cols; ++k) gave_up = gave_up || h_ctl[4 * k + 3] != 0, most = std::max<uint32_t>(most, (uint32_t)h_ctl[4 * k + 1]);
+    ps.epoch_next += (gave_up ? (uint32_t)maxit : most) + 2u;   // past every tag any column can have written
+    *ran = !gave_up;
     return FDAPDE_OK;
 }
 

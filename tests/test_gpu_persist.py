@@ -393,6 +393,73 @@ def test_one_workgroup_without_hand_offs_matches_several(env, dim, nx, order, di
     c.close()
 
 
+@pytest.mark.parametrize("dim,nx,order,n_rhs", [
+    (2, 16, 1, 5),      # one workgroup per column
+    (2, 16, 1, 300),    # more columns than one launch takes (256 CUs): several launches
+    (2, 60, 1, 7),      # two workgroups per column: boards per column
+    (3, 16, 1, 9),      # 3-D rows, import lists
+    (2, 30, 2, 4),      # P2
+    (2, 256, 1, 9),     # 35 workgroups per column: 7 columns per launch, then 2
+])
+def test_columns_of_a_handle_solve_side_by_side(env, dim, nx, order, n_rhs):
+    """fdapde::SparseLU::solve(B) with several columns (utils/symbols.h:133-160; SMW, linear_algebra/smw.h:38-59): the columns of a system the
+    single-launch CG holds in few workgroups run side by side in ONE launch (knob persist_cols) -- per column the arithmetic of a launch of
+    its own, so identical bits and iteration counts; a zero column and a column that runs out of iterations included"""
+    capi, meshgen = env
+    nodes, cells, bnd = meshgen.unit_square(nx) if dim == 2 else meshgen.unit_cube(nx)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(order)
+    c.set_operator(-capi.laplacian() + capi.reaction(1.0))
+    c.set_forcing(np.ones(c.quadrature_nodes().shape[0]))
+    c.init()
+    c.lin_compute(capi.MAT_STIFF, symmetric=True)
+    B = np.random.default_rng(3).standard_normal((nd, n_rhs))
+    B[:, 1] = 0.0
+    B[:, 2] *= 1e-150   # (tiny but not zero: the relative stop test must not care)
+    c.tune("persist_cols", 0)
+    X0, i0 = c.lin_solve(B, rtol=1e-11)
+    c.tune("persist_cols", 1)
+    X1, i1 = c.lin_solve(B, rtol=1e-11)
+    assert i0.persistent == 1 and i1.persistent == 1 and i0.converged == 1 and i1.converged == 1
+    assert i1.iters == i0.iters and np.array_equal(X0, X1)
+    assert not X1[:, 1].any()
+    # against the matrix itself
+    _, _, _ = c.dofs_get()
+    rowptr, colidx = c.pattern_get()
+    import scipy.sparse as sp
+
+    A = sp.csr_matrix((c.matrix_values(capi.MAT_STIFF), colidx, rowptr), shape=(nd, nd))
+    R = A @ X1 - B
+    assert np.linalg.norm(R[:, 0]) <= 1e-9 * np.linalg.norm(B[:, 0])
+    c.close()
+
+
+def test_side_by_side_columns_fall_back_when_a_launch_gives_up(env):
+    capi, meshgen = env
+    nodes, cells, bnd = meshgen.unit_square(60)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(1)
+    c.set_operator(-capi.laplacian() + capi.reaction(1.0))
+    c.set_forcing(np.ones(c.quadrature_nodes().shape[0]))
+    c.init()
+    c.lin_compute(capi.MAT_STIFF, symmetric=True)
+    B = np.random.default_rng(4).standard_normal((nd, 6))
+    X0, i0 = c.lin_solve(B, rtol=1e-11)
+    assert i0.persistent == 1 and c.solver_layout_kind(False)["workgroups"] >= 2
+    c.tune("persist_timeout_us", 2000)
+    c.tune("persist_debug_stall", 3)   # the last workgroup of every column leaves at iteration 3: every launch gives up
+    X1, i1 = c.lin_solve(B, rtol=1e-11)
+    assert i1.converged == 1 and i1.persistent == 0   # (the multi-launch path finished every column)
+    assert np.linalg.norm(X1 - X0) <= 1e-9 * np.linalg.norm(X0)
+    c.tune("persist_debug_stall", 0)
+    c.tune("persist_retry", 1)
+    X2, i2 = c.lin_solve(B, rtol=1e-11)
+    assert i2.persistent == 1 and np.array_equal(X2, X0)
+    c.close()
+
+
 def test_graph_replay_is_rebuilt_when_the_blocked_layout_changes(env):
     """use_graph = 1 on a system that takes the blocked-ELL SpMV (2-D P2; the 3-D P2 "mass matrix" of the reference's 5-point rule with its
     negative weight is indefinite, no CG applies to it): a solve with Dirichlet data captures the fused-CG chunk on

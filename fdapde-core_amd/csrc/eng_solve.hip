@@ -1060,7 +1060,7 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
         const int cap = (ps.per_cu > 0 ? ps.per_cu : 1) * c->n_cu / (G > 0 ? G : 1);   // columns whose workgroups are resident together
         const double tol2 = rtol * rtol;
         const int np = c->vec_grid;
-        while (n_rhs - j0 >= 2 && cap >= 2) {
+        while (n_rhs - j0 >= 1 && cap >= 1) {   // (a single column too: three small launches around the solve instead of seven)
             const int Q = std::min(std::min<int>(n_rhs - j0, cap), 64);
             const size_t qn = (size_t)Q * (size_t)n;
             HIPCHK(c, c->cols_b.alloc(qn));

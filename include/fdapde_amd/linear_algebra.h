@@ -110,8 +110,8 @@ class PartialPivLU {
 // ---- Sherman-Morrison-Woodbury (same call signature as fdaPDE/linear_algebra/smw.h:38-59) -----------------------------
 //   (A + U C V) x = b,  invC = C^{-1} supplied:   x = W_b - W_U (C^{-1} + V W_U)^{-1} (V W_b),   [W_b | W_U] = A^{-1} [b | U]
 // ONE pass through the sparse solver: the m columns of b and the q columns of U go to the device as one (m + q)-column
-// right-hand side, so that they share every sweep over the matrix (fdapde_lin_solve batches 8 / 4 columns per multi-RHS CG,
-// kernels_multirhs.h).  The correction A^{-1} U t of the formula is W_U t -- a dense n x q by q x m product on data already
+// right-hand side: the columns of a small system run side by side in one persistent launch, those of a large one share every sweep over
+// the matrix (fdapde_lin_solve batches 8 / 4 columns per multi-RHS CG, kernels_multirhs.h).  The correction A^{-1} U t of the formula is W_U t -- a dense n x q by q x m product on data already
 // there, not another sparse solve (the reference performs three separate solves: b, U, and U t).
 template <typename SparseSolver, typename DenseSolver = PartialPivLU> struct SMW {
     SMW() = default;

@@ -1054,7 +1054,9 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
     // several columns against a system the single-launch CG holds in few workgroups (the small systems the reference's users solve by the
     // thousand: one or two of 256 CUs busy per solve): Q columns side by side in ONE launch of G x Q workgroups, each column with boards of
     // its own; the same arithmetic per column as one by one, hence the same bits
-    if (persist_cols && c->persist_cols && method == FDAPDE_SOLVER_CG_FUSED && !c->lin_state->ss.dist && !c->lin_state->ss.rowdist && !c->lin_state->ss.use_bnd) {
+    const bool cols_bicg = method == FDAPDE_SOLVER_BICGSTAB && c->persist_bicg && !c->ps[0].meta.sym && c->ps[0].meta.R <= 8;   // (the single-launch BiCGStab's own limits)
+    if (persist_cols && c->persist_cols && (method == FDAPDE_SOLVER_CG_FUSED || cols_bicg) && !c->lin_state->ss.dist && !c->lin_state->ss.rowdist &&
+        !c->lin_state->ss.use_bnd) {
         fdapde_ctx::Persist& ps = c->ps[0];
         const int G = ps.meta.G;
         const int cap = (ps.per_cu > 0 ? ps.per_cu : 1) * c->n_cu / (G > 0 ? G : 1);   // columns whose workgroups are resident together
@@ -1076,7 +1078,8 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
             std::vector<int32_t> h_ctl(4 * (size_t)Q);
             std::vector<double> h_sc(4 * (size_t)Q);
             bool ran = false;
-            if (int rc = run_persist_cols(c, 0, tol2, maxit, Q, c->cols_r.p, c->cols_x.p, c->cols_sc.p, c->cols_ctl.p, h_ctl.data(), h_sc.data(), &ran)) return rc;
+            if (int rc = run_persist_cols(c, 0, tol2, maxit, Q, c->cols_r.p, c->cols_x.p, c->cols_sc.p, c->cols_ctl.p, h_ctl.data(), h_sc.data(), &ran, cols_bicg))
+                return rc;
             if (!ran) break;   // (more workgroups than fit after all, or a launch that gave up: these columns go one by one below)
             hipLaunchKernelGGL(k_cols_finish, dim3(g1(n), Q), dim3(256), 0, st, n, c->cols_x.p, c->scale.p, c->dof_i2e.p, c->cols_b.p);
             HIPCHK(c, hipGetLastError());

@@ -114,7 +114,7 @@ int fill_persist(fdapde_ctx* c, int v);
 int fill_persist_scaled(fdapde_ctx* c, int v, const double* A);   // ... from the unscaled matrix + c->scale (no scaled full-pattern copy needed)
 // the whole fused-update CG as one launch; *ran = false: the launch gave up (hand-off timeout) or can never be resident
 int run_persist_cols(fdapde_ctx* c, int v, double tol2, int maxit, int n_cols, const double* r_cols, double* x_cols, double* sc_cols, int32_t* ctl_cols,
-                     int32_t* h_ctl, double* h_sc, bool* ran);   // several right-hand sides side by side in one launch
+                     int32_t* h_ctl, double* h_sc, bool* ran, bool bicg = false);   // several right-hand sides side by side in one launch
 int run_persist(fdapde_ctx* c, int v, double tol2, int maxit, bool* ran, bool bicg = false);   // bicg: the BiCGStab kernel (plain layouts, <= 8 rows per thread)
 
 // ---- row-distributed multi-GPU form of the single-launch solver (persist_engine.hip); all COLLECTIVE over the context's ranks

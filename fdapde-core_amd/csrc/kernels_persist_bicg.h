@@ -41,6 +41,14 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
     __shared__ int32_t fail_flag;
     __shared__ unsigned pf_dump[64];
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if constexpr (!DIST) {
+        if (a.n_cols > 1) {   // several right-hand sides at once: this workgroup belongs to column blockIdx.y (kernels_persist.h)
+            const size_t col = blockIdx.y;
+            a.r_in += col * a.col_stride, a.x_out += col * a.col_stride, a.sc += 4 * col, a.ctl += 4 * col;
+            if (a.x != nullptr) a.x += col * a.col_stride;
+            a.pboard += col * a.board_stride, a.dboard += col * a.board_stride;
+        }
+    }
     const int nsl = a.nsl;
     const int H = a.imp_off[g + 1] - a.imp_off[g], E = a.exp_off[g + 1] - a.exp_off[g];
     double* p_tab = lds;                                                      // [S + imp_cap]
@@ -78,7 +86,7 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
         const bool on = d >= 0;
         dof[j] = d;
         rv[j] = on ? a.r_in[d] : 0.0;
-        xv[j] = on ? a.x[d] : 0.0;
+        xv[j] = on && a.x != nullptr ? a.x[d] : 0.0;
         qv[j] = rv[j], pv[j] = rv[j], vv[j] = 0.0, tv[j] = 0.0;
         rr_part += rv[j] * rv[j];
     }

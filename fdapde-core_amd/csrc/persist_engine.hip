@@ -263,9 +263,11 @@ int launch_persist(fdapde_ctx* c, fdapde_ctx::Persist& ps, PersistArgs& a, bool 
             int per_cu = 0;                                                                                                     \
             HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kPersistT, ps.lds_bytes));                      \
             if ((int64_t)per_cu * c->n_cu < (int64_t)a.G) return FDAPDE_EUNSUPPORTED;                                           \
-            ps.attr_set = fn;                                                                                                   \
+            ps.attr_set = fn, ps.per_cu = per_cu;                                                                               \
         }                                                                                                                       \
-        hipLaunchKernelGGL((k_bicg_persist<R_, ST_, DI_>), dim3(a.G), dim3(kPersistT), ps.lds_bytes, st, a);                    \
+        const unsigned ncol = a.n_cols > 1 ? (unsigned)a.n_cols : 1u;                                                           \
+        if ((int64_t)ps.per_cu * c->n_cu < (int64_t)a.G * ncol) return FDAPDE_EUNSUPPORTED;                                     \
+        hipLaunchKernelGGL((k_bicg_persist<R_, ST_, DI_>), dim3(a.G, ncol), dim3(kPersistT), ps.lds_bytes, st, a);              \
     } while (0)
 #define BICG_GO2(R_, ST_)                                                                                                       \
     do {                                                                                                                        \
@@ -376,6 +378,7 @@ int run_persist(fdapde_ctx* c, int v, double tol2, int maxit, bool* ran, bool bi
         c->persist_backoff = std::min(1024, 2 * c->persist_backoff);
         HIPCHK(c, hipMemsetAsync(c->ctl.p + 3, 0, sizeof(int32_t), st));
         HIPCHK(c, hipMemsetAsync(ps.board.p, 0, sizeof(unsigned long long) * ps.board.n, st));   // (how far its epochs got is unknown)
+        if (ps.board_cols.p) HIPCHK(c, hipMemsetAsync(ps.board_cols.p, 0, sizeof(unsigned long long) * ps.board_cols.n, st));   // (the tags start over for them too)
         ps.epoch_next = 0;
     } else {
         c->persist_backoff = 8;
@@ -409,7 +412,7 @@ int fill_persist_scaled(fdapde_ctx* c, int v, const double* A) {
 // The columns do not interact: each has boards of its own.  *ran = false when any column's launch gave up (nothing is lost: the caller
 // solves the columns one by one).  h_ctl / h_sc: 4 n_cols values each, read back here.
 int run_persist_cols(fdapde_ctx* c, int v, double tol2, int maxit, int n_cols, const double* r_cols, double* x_cols, double* sc_cols, int32_t* ctl_cols,
-                     int32_t* h_ctl, double* h_sc, bool* ran) {
+                     int32_t* h_ctl, double* h_sc, bool* ran, bool bicg) {
     fdapde_ctx::Persist& ps = c->ps[v];
     hipStream_t st = c->stream;
     const size_t n = (size_t)c->hs.n_dofs, blen = ps.board.n;
@@ -422,7 +425,7 @@ int run_persist_cols(fdapde_ctx* c, int v, double tol2, int maxit, int n_cols, c
     a.r_in = r_cols, a.x = nullptr, a.x_out = x_cols, a.sc = sc_cols, a.ctl = ctl_cols;
     a.n_cols = n_cols, a.col_stride = (int64_t)n, a.board_stride = (int64_t)blen;
     a.pboard = ps.board_cols.p, a.dboard = ps.board_cols.p + 2 * (size_t)ps.meta.n_board;
-    const int rc_launch = launch_persist(c, ps, a, false, false);
+    const int rc_launch = launch_persist(c, ps, a, false, bicg);
     if (rc_launch == FDAPDE_EUNSUPPORTED) {
         *ran = false;
         return FDAPDE_OK;
@@ -437,7 +440,7 @@ int run_persist_cols(fdapde_ctx* c, int v, double tol2, int maxit, int n_cols, c
     bool gave_up = false;
     uint32_t most = 0;
     for (int k = 0; k < n_cols; ++k) gave_up = gave_up || h_ctl[4 * k + 3] != 0, most = std::max<uint32_t>(most, (uint32_t)h_ctl[4 * k + 1]);
-    ps.epoch_next += (gave_up ? (uint32_t)maxit : most) + 2u;   // past every tag any column can have written
+    ps.epoch_next += (bicg ? 2u : 1u) * ((gave_up ? (uint32_t)maxit : most) + 2u);   // past every tag any column can have written
     *ran = !gave_up;
     return FDAPDE_OK;
 }

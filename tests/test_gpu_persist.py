@@ -435,6 +435,35 @@ def test_columns_of_a_handle_solve_side_by_side(env, dim, nx, order, n_rhs):
     c.close()
 
 
+@pytest.mark.parametrize("dim,nx,n_rhs", [(2, 16, 6), (2, 60, 70), (3, 16, 5)])
+def test_columns_of_a_non_symmetric_handle_side_by_side(env, dim, nx, n_rhs):
+    """the same for a non-symmetric matrix (advection): the single-launch BiCGStab with the columns side by side"""
+    capi, meshgen = env
+    nodes, cells, bnd = meshgen.unit_square(nx) if dim == 2 else meshgen.unit_cube(nx)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(1)
+    c.set_operator(-capi.laplacian() + capi.advection([1.0, 0.5, 0.25][:dim]) + capi.reaction(1.0))
+    c.set_forcing(np.ones(c.quadrature_nodes().shape[0]))
+    c.init()
+    c.lin_compute(capi.MAT_STIFF, symmetric=False)
+    B = np.random.default_rng(5).standard_normal((nd, n_rhs))
+    B[:, 1] = 0.0
+    c.tune("persist_cols", 0)
+    X0, i0 = c.lin_solve(B, rtol=1e-11)
+    c.tune("persist_cols", 1)
+    X1, i1 = c.lin_solve(B, rtol=1e-11)
+    assert i0.method_used == capi.SOLVER_BICGSTAB and i1.method_used == capi.SOLVER_BICGSTAB
+    assert i0.persistent == 1 and i1.persistent == 1 and i0.converged == 1 and i1.converged == 1
+    assert i1.iters == i0.iters and np.array_equal(X0, X1)
+    rowptr, colidx = c.pattern_get()
+    import scipy.sparse as sp
+
+    A = sp.csr_matrix((c.matrix_values(capi.MAT_STIFF), colidx, rowptr), shape=(nd, nd))
+    assert np.linalg.norm(A @ X1[:, 0] - B[:, 0]) <= 1e-9 * np.linalg.norm(B[:, 0])
+    c.close()
+
+
 def test_side_by_side_columns_fall_back_when_a_launch_gives_up(env):
     capi, meshgen = env
     nodes, cells, bnd = meshgen.unit_square(60)

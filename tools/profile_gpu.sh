@@ -5,6 +5,7 @@ set -u
 TAG=${1:-r1}; shift || true
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
+rm -rf $OUT   # (passes of an earlier run must not end up in this run's summary)
 mkdir -p $OUT
 export TMPDIR=/tmp
 ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-extra $*"

@@ -81,6 +81,25 @@ def pmc_json(out):
         # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reads 1/2 of the bytes of wide coalesced reads; WRITE_SIZE exact
         res["hbm_bytes_per_launch"] = (2.0 * res["FETCH_SIZE_KB"] + res["WRITE_SIZE_KB"]) * 1024.0
         res["correction"] = "2 x FETCH_SIZE + WRITE_SIZE (KB x 1024), separate --pmc passes"
+    # which workload these passes ran (bench.py takes the counter bytes only for the workload they were collected on): from the bench line
+    # the traced run printed
+    try:
+        import re
+
+        for line in open(os.path.join(out, "trace.log")):
+            if line.startswith("{") and '"metric"' in line:
+                b = json.loads(line)
+                m = re.search(r"(\d+)\^3 x 6", b["config"]["workload"])
+                if m:
+                    res["nx"] = int(m.group(1))
+                if b["config"].get("persistent_launch"):
+                    res["persist_iterations"] = int(b["config"]["cg_iterations"])
+                    if "persist_hbm_bytes_per_solve" in res:
+                        res["note"] = ("persist_*: the single-launch CG, one dispatch per solve of %d iterations; hbm bytes per iteration = %.1f MB.  "
+                                       "spmv_* / FETCH / WRITE: the multi-launch SpMV (k_spmv_team2) of the lift and the fall-back path."
+                                       % (res["persist_iterations"], res["persist_hbm_bytes_per_solve"] / res["persist_iterations"] / 1e6))
+    except Exception as e:   # (the json stays usable by hand)
+        res["workload_note"] = "bench line of the traced run not found: %s" % e
     json.dump(res, open(os.path.join(out, "spmv_pmc.json"), "w"), indent=1)
     print("== spmv_pmc.json ==")
     print(json.dumps(res, indent=1))

@@ -149,3 +149,17 @@ def test_order2_numbering_at_multithreaded_sizes(capi, oracle, dim, nx):
     rp, ci = c.pattern_get()
     A = oracle.assemble_operator(m, 2, dofs, nd, oracle.reaction(1.0))
     assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colidx)
+
+
+def test_committed_counter_passes_name_their_workload():
+    """bench.py quotes roofline.traffic from profiles/spmv_pmc.json only for the workload the passes were collected on: the file must say which
+    (nx, iterations of the single launch) -- a summary copied over without these keys silently turns `traffic` into null"""
+    import json
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pj = json.load(open(os.path.join(root, "profiles", "spmv_pmc.json")))
+    assert pj.get("nx") == 119 and int(pj.get("persist_iterations", 0)) > 0
+    assert pj.get("persist_hbm_bytes_per_solve", 0) > 0 and pj.get("hbm_bytes_per_launch", 0) > 0
+    c5 = json.load(open(os.path.join(root, "profiles", "r3_c5_spmv_pmc.json")))
+    assert c5.get("hbm_bytes_per_launch", 0) > 0

@@ -83,7 +83,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
                                 &c->x, &c->r, &c->p, &c->y, &c->s, &c->t, &c->r0, &c->u, &c->part_a, &c->part_b, &c->sc,
                                 &c->tmp_e, &c->tmp_i, &c->tmp_v, &c->lin_rhs, &c->cols_b, &c->cols_r, &c->cols_x, &c->cols_sc, &c->cols_part})
             b->release();
-        c->cols_ctl.release();
+        c->cols_ctl.release(), c->eval_grid.release(), c->eval_locs.release(), c->eval_vals.release(), c->eval_out.release();
         for (auto& b : c->coef) b.release();
         c->slotw.release(), c->sl_off.release(), c->lane_row.release(), c->fq_blk.release(), c->bnd.release(), c->tables.release(), c->reftab.release(), c->lin_sq.release();
         c->bc_off.release(), c->bn_off.release(), c->bc_cell.release(), c->bn_node.release(), c->bc_vert.release();

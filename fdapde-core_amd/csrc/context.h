@@ -351,6 +351,14 @@ struct fdapde_ctx {
     int persist_cols = 1;                    // knob: several columns of fdapde_lin_solve as ONE persistent launch where G x columns workgroups are resident
     DBuf<double> cols_b, cols_r, cols_x, cols_sc, cols_part;   // their staging: right-hand sides as handed over, scaled, solutions, scalars, partial sums
     DBuf<int32_t> cols_ctl;
+    struct EvalGrid {   // bin grid for point location (fdapde_eval_pointwise), built on the device once per mesh
+        bool ready = false;
+        DBuf<int32_t> ptr, cells, dims;
+        DBuf<double> lo, invh;
+        void release() { ptr.release(), cells.release(), dims.release(), lo.release(), invh.release(), ready = false; }
+    } eval_grid;
+    DBuf<double> eval_locs, eval_vals;   // locations / basis values of a call (kept between calls)
+    DBuf<int32_t> eval_out;
     bool defer_end_sync = false;             // set by callers that loop over solves (parabolic steps, handle columns): solve_run does not wait for its
                                              // last kernel (the outcome is read behind a wait of its own; the rest is ordered by the stream)
     int persist_single_rows = 2048;          // knob: systems of up to that many interior rows run as ONE workgroup (no hand-off in the iteration)

@@ -34,5 +34,19 @@ void dev_space_release(DevSpace* s);
 int dev_build_space(HostSpace& hs, const double* d_nodes, const int32_t* d_cells, const int32_t* d_dofs, const uint8_t* d_dof_bnd,
                     const double* d_dof_coords, void* stream, DevSpace* out, std::string& err);
 
+// Uniform bin grid over the mesh for point location (fdapde_eval_pointwise: stands in for the reference's TreeSearch, geometry/tree_search.h):
+// about one cell per bin on average, every cell registered in the bins its bounding box overlaps, the cells of a bin in ascending
+// (internal) id -- the location kernel takes the FIRST cell of the bin that contains the point.  Built on the device from the arrays the
+// assembly uses (vcoords: NP doubles per node, cverts: M + 1 internal node ids per cell): a count pass, a scan, a fill pass, a sort of
+// every bin's short list.  Arrays hipMalloc'd here, ownership passes to the caller.
+struct DevBinGrid {
+    int32_t *bin_ptr = nullptr, *bin_cells = nullptr;   // n_bins + 1 offsets; cells
+    int64_t n_bins = 0, n_entries = 0;
+    double lo[3] = {0, 0, 0}, inv_h[3] = {0, 0, 0};
+    int32_t dims[3] = {1, 1, 1};
+};
+int dev_build_bin_grid(int M, int64_t n_nodes, int64_t n_cells, const double* d_vcoords, const int32_t* d_cverts, void* stream, DevBinGrid* out,
+                       std::string& err);
+
 }  // namespace fdapde_hip
 #endif

@@ -331,6 +331,77 @@ template <typename In, typename Out> int exclusive_sum(Scratch& sc, In* in, Out*
     return FDAPDE_OK;
 }
 
+// ---- bin grid for point location (dev_build_bin_grid) ----------------------------------------------------------------------------------
+template <int M> struct BinGeo {
+    double lo[M], inv_h[M];
+    int32_t dims[M];
+};
+// bins [b0, b1] a cell's bounding box overlaps along axis d (the expressions of the former host loop, operation for operation)
+template <int M>
+__device__ __forceinline__ void bin_range(const BinGeo<M>& G, const double* vcoords, const int32_t* cv, int d, int& b0, int& b1) {
+    constexpr int NP = M == 2 ? 2 : 4;
+    double mn = 1e300, mx = -1e300;
+#pragma unroll
+    for (int v = 0; v <= M; ++v) {
+        const double x = vcoords[(size_t)cv[v] * NP + d];
+        mn = x < mn ? x : mn, mx = x > mx ? x : mx;
+    }
+    b0 = (int)floor(__dadd_rn(__dmul_rn(mn - G.lo[d], G.inv_h[d]), -1e-9)), b1 = (int)floor(__dadd_rn(__dmul_rn(mx - G.lo[d], G.inv_h[d]), 1e-9));
+    b0 = b0 < 0 ? 0 : b0, b1 = b1 >= G.dims[d] ? G.dims[d] - 1 : b1;
+}
+// FILL = false: cnt[bin] += 1 per (cell, bin) overlap; FILL = true: the cell into the bin's list at the next free position
+template <int M, bool FILL>
+__global__ __launch_bounds__(256) void k_bin_cells(BinGeo<M> G, int64_t n_cells, const double* vcoords, const int32_t* cverts, int32_t* cnt_or_cursor,
+                                                   int32_t* bin_cells) {
+    const int64_t cell = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cell >= n_cells) return;
+    const int32_t* cv = cverts + cell * (M + 1);
+    int b0[3] = {0, 0, 0}, b1[3] = {0, 0, 0};
+#pragma unroll
+    for (int d = 0; d < M; ++d) bin_range<M>(G, vcoords, cv, d, b0[d], b1[d]);
+    for (int z = b0[2]; z <= b1[2]; ++z)
+        for (int y = b0[1]; y <= b1[1]; ++y)
+            for (int x = b0[0]; x <= b1[0]; ++x) {
+                const int64_t bin = M == 2 ? (int64_t)y * G.dims[0] + x : ((int64_t)z * G.dims[1] + y) * G.dims[0] + x;
+                const int32_t at = atomicAdd(cnt_or_cursor + bin, 1);
+                if constexpr (FILL) bin_cells[at] = (int32_t)cell;
+            }
+}
+// the cells of every bin in ascending id (the fill pass leaves them in arrival order); lists are a handful of cells long
+__global__ __launch_bounds__(256) void k_bin_sort(int64_t n_bins, const int32_t* bin_ptr, int32_t* bin_cells) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_bins) return;
+    const int32_t lo = bin_ptr[b], hi = bin_ptr[b + 1];
+    for (int32_t i = lo + 1; i < hi; ++i) {
+        const int32_t v = bin_cells[i];
+        int32_t j = i - 1;
+        while (j >= lo && bin_cells[j] > v) bin_cells[j + 1] = bin_cells[j], --j;
+        bin_cells[j + 1] = v;
+    }
+}
+// per workgroup: min / max of every coordinate over a strided share of the nodes -> out[6 b + d], out[6 b + 3 + d]
+__global__ __launch_bounds__(256) void k_bbox_partials(int NP, int M, int64_t n_nodes, const double* vcoords, double* out) {
+    __shared__ double red[2][3][4];
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes; i += (int64_t)gridDim.x * blockDim.x)
+        for (int d = 0; d < M; ++d) {
+            const double v = vcoords[(size_t)i * NP + d];
+            mn[d] = v < mn[d] ? v : mn[d], mx[d] = v > mx[d] ? v : mx[d];
+        }
+    for (int d = 0; d < 3; ++d)
+        for (int o = 32; o > 0; o >>= 1) mn[d] = fmin(mn[d], __shfl_xor(mn[d], o)), mx[d] = fmax(mx[d], __shfl_xor(mx[d], o));
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+        for (int d = 0; d < 3; ++d) red[0][d][wave] = mn[d], red[1][d][wave] = mx[d];
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int d = threadIdx.x;
+        double a = red[0][d][0], b = red[1][d][0];
+        for (int w = 1; w < 4; ++w) a = fmin(a, red[0][d][w]), b = fmax(b, red[1][d][w]);
+        out[6 * blockIdx.x + d] = a, out[6 * blockIdx.x + 3 + d] = b;
+    }
+}
+
 // Morton order of n points (column-major n x N on the device): i2e (new -> old), stable for equal keys
 int morton_order(Scratch& sc, int N, int64_t n, const double* d_pts, int bits, hipStream_t st, int32_t* d_i2e, std::string& err) {
     Tmp<uint64_t> key_a, key_b;
@@ -357,6 +428,76 @@ int morton_order(Scratch& sc, int N, int64_t n, const double* d_pts, int bits, h
 }
 
 }  // namespace
+
+int dev_build_bin_grid(int M, int64_t n_nodes, int64_t n_cells, const double* d_vcoords, const int32_t* d_cverts, void* stream, DevBinGrid* out,
+                       std::string& err) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!out || (M != 2 && M != 3) || n_nodes < 1 || n_cells < 1) return FDAPDE_EINVAL;
+    const int NP = M == 2 ? 2 : 4;
+    Scratch sc;
+    // bounding box
+    const int nblk = (int)std::min<int64_t>(256, (n_nodes + 255) / 256);
+    Tmp<double> d_part;
+    DS_CHK(d_part.alloc(6 * (size_t)nblk));
+    hipLaunchKernelGGL(k_bbox_partials, dim3(nblk), dim3(256), 0, st, NP, M, n_nodes, d_vcoords, d_part.p);
+    std::vector<double> part(6 * (size_t)nblk);
+    DS_CHK(hipMemcpyAsync(part.data(), d_part.p, sizeof(double) * part.size(), hipMemcpyDeviceToHost, st));
+    DS_CHK(hipStreamSynchronize(st));
+    DevBinGrid g;
+    double hi[3] = {0, 0, 0};
+    for (int d = 0; d < M; ++d) {
+        g.lo[d] = part[(size_t)d], hi[d] = part[3 + (size_t)d];
+        for (int b = 1; b < nblk; ++b) g.lo[d] = std::min(g.lo[d], part[6 * (size_t)b + d]), hi[d] = std::max(hi[d], part[6 * (size_t)b + 3 + d]);
+    }
+    // about one cell per bin on average
+    const int gd = (int)std::max(1.0, std::floor(std::pow((double)n_cells, 1.0 / M)));
+    g.n_bins = 1;
+    for (int d = 0; d < M; ++d) {
+        g.dims[d] = gd, g.n_bins *= gd;
+        g.inv_h[d] = hi[d] > g.lo[d] ? gd / (hi[d] - g.lo[d]) : 0.0;
+    }
+    if (g.n_bins >= (int64_t(1) << 31) - 2) return FDAPDE_EUNSUPPORTED;
+    Tmp<int32_t> cnt;
+    DS_CHK(cnt.alloc((size_t)g.n_bins + 1));
+    DS_CHK(hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * ((size_t)g.n_bins + 1), st));
+    DS_CHK(hipMalloc(reinterpret_cast<void**>(&g.bin_ptr), sizeof(int32_t) * ((size_t)g.n_bins + 1)));
+    auto fail_free = [&](int rc) {
+        if (g.bin_ptr) (void)hipFree(g.bin_ptr);
+        if (g.bin_cells) (void)hipFree(g.bin_cells);
+        return rc;
+    };
+#define BIN_GO(MM, FILL_, CNT_, CELLS_)                                                                                        \
+    do {                                                                                                                       \
+        BinGeo<MM> G;                                                                                                          \
+        for (int d = 0; d < MM; ++d) G.lo[d] = g.lo[d], G.inv_h[d] = g.inv_h[d], G.dims[d] = g.dims[d];                        \
+        hipLaunchKernelGGL((k_bin_cells<MM, FILL_>), dim3(grid_of(n_cells)), dim3(256), 0, st, G, n_cells, d_vcoords, d_cverts, CNT_, CELLS_); \
+    } while (0)
+    if (M == 2) BIN_GO(2, false, cnt.p, (int32_t*)nullptr);
+    else BIN_GO(3, false, cnt.p, (int32_t*)nullptr);
+    if (int rc = exclusive_sum(sc, cnt.p, g.bin_ptr, g.n_bins + 1, st, err)) return fail_free(rc);
+    int32_t total = 0;
+    if (hipMemcpyAsync(&total, g.bin_ptr + g.n_bins, sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        err = "bin grid: read-back of the overlap count failed";
+        return fail_free(FDAPDE_EHIP);
+    }
+    g.n_entries = total;
+    if (hipMalloc(reinterpret_cast<void**>(&g.bin_cells), sizeof(int32_t) * ((size_t)total + 1)) != hipSuccess) {
+        err = "bin grid: allocation of the bin lists failed";
+        return fail_free(FDAPDE_EHIP);
+    }
+    // cursors = the offsets; the fill pass advances them
+    if (hipMemcpyAsync(cnt.p, g.bin_ptr, sizeof(int32_t) * ((size_t)g.n_bins + 1), hipMemcpyDeviceToDevice, st) != hipSuccess) return fail_free(FDAPDE_EHIP);
+    if (M == 2) BIN_GO(2, true, cnt.p, g.bin_cells);
+    else BIN_GO(3, true, cnt.p, g.bin_cells);
+#undef BIN_GO
+    hipLaunchKernelGGL(k_bin_sort, dim3(grid_of(g.n_bins)), dim3(256), 0, st, g.n_bins, g.bin_ptr, g.bin_cells);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {   // (the temporaries of this scope are freed on return)
+        err = "bin grid: kernels failed";
+        return fail_free(FDAPDE_EHIP);
+    }
+    *out = g;
+    return FDAPDE_OK;
+}
 
 void dev_space_release(DevSpace* s) {
     if (!s) return;

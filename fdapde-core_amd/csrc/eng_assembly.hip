@@ -13,6 +13,7 @@
 #include <rccl/rccl.h>
 
 #include "context.h"
+#include "dev_setup.h"
 #include "engine.h"
 #include "kernels.h"
 
@@ -462,84 +463,40 @@ int e_eval_pointwise(fdapde_ctx* c, int64_t n_locs, const double* locs_colmajor,
     if (int rc = need_device(c)) return rc;
     if (!c->dev_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
     HIPCHK(c, hipSetDevice(c->device));
-    if (int rc = ensure_host(c, kHostCells)) return rc;
     const HostSpace& hs = c->hs;
-    const int M = hs.M, nv = M + 1, NP = M == 2 ? 2 : 4;
-    // uniform grid with about one cell per bin on average
-    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, inv_h[3] = {0, 0, 0};
-    int32_t dims[3] = {1, 1, 1};
-    for (int d = 0; d < M; ++d) {
-        lo[d] = hi[d] = hs.vcoords_i[(size_t)d];
-        for (int64_t i = 0; i < hs.n_nodes; ++i) {
-            const double v = hs.vcoords_i[(size_t)i * NP + d];
-            lo[d] = v < lo[d] ? v : lo[d], hi[d] = v > hi[d] ? v : hi[d];
-        }
+    const int M = hs.M;
+    hipStream_t st = c->stream;
+    // uniform bin grid over the mesh, built on the device once per mesh (dev_setup.hip dev_build_bin_grid; it was a serial host loop over
+    // the cells on every call: 80 % of a call with 10^6 locations on a 10^6-cell mesh)
+    fdapde_ctx::EvalGrid& eg = c->eval_grid;
+    if (!eg.ready) {
+        DevBinGrid g;
+        if (int rc = dev_build_bin_grid(M, hs.n_nodes, hs.n_cells, c->vcoords.p, c->cverts.p, st, &g, c->err)) return rc;
+        adopt(eg.ptr, g.bin_ptr, (size_t)g.n_bins + 1), adopt(eg.cells, g.bin_cells, (size_t)g.n_entries + 1);
+        HIPCHK(c, eg.dims.upload(g.dims, 3, st));
+        HIPCHK(c, eg.lo.upload(g.lo, 3, st));
+        HIPCHK(c, eg.invh.upload(g.inv_h, 3, st));
+        HIPCHK(c, hipStreamSynchronize(st));   // (g's small arrays live on this stack frame)
+        eg.ready = true;
     }
-    const int g = (int)std::max(1.0, std::floor(std::pow((double)hs.n_cells, 1.0 / M)));
-    int64_t n_bins = 1;
-    for (int d = 0; d < M; ++d) {
-        dims[d] = g, n_bins *= g;
-        inv_h[d] = hi[d] > lo[d] ? g / (hi[d] - lo[d]) : 0.0;
-    }
-    auto range = [&](int64_t cell, int d, int& b0, int& b1) {
-        double mn = 1e300, mx = -1e300;
-        for (int v = 0; v < nv; ++v) {
-            const double x = hs.vcoords_i[(size_t)hs.cverts_i[(size_t)cell * nv + v] * NP + d];
-            mn = x < mn ? x : mn, mx = x > mx ? x : mx;
-        }
-        b0 = (int)std::floor((mn - lo[d]) * inv_h[d] - 1e-9), b1 = (int)std::floor((mx - lo[d]) * inv_h[d] + 1e-9);
-        b0 = b0 < 0 ? 0 : b0, b1 = b1 >= dims[d] ? dims[d] - 1 : b1;
-    };
-    std::vector<int32_t> bin_ptr((size_t)n_bins + 1, 0), bin_cells, pos;
-    for (int pass = 0; pass < 2; ++pass) {   // pass 0 counts the (cell, bin) overlaps, pass 1 fills the bin lists and runs the kernel
-        if (pass == 1) pos.assign(bin_ptr.begin(), bin_ptr.end() - 1);
-        if (pass == 1) bin_cells.assign((size_t)bin_ptr[(size_t)n_bins], 0);
-        for (int64_t cell = 0; cell < hs.n_cells; ++cell) {
-            int b0[3] = {0, 0, 0}, b1[3] = {0, 0, 0};
-            for (int d = 0; d < M; ++d) range(cell, d, b0[d], b1[d]);
-            for (int z = b0[2]; z <= b1[2]; ++z)
-                for (int y = b0[1]; y <= b1[1]; ++y)
-                    for (int x = b0[0]; x <= b1[0]; ++x) {
-                        const int64_t bin = M == 2 ? (int64_t)y * dims[0] + x : ((int64_t)z * dims[1] + y) * dims[0] + x;
-                        if (pass == 0)
-                            ++bin_ptr[(size_t)bin + 1];
-                        else
-                            bin_cells[(size_t)pos[(size_t)bin]++] = (int32_t)cell;
-                    }
-        }
-        if (pass == 0) {
-            for (int64_t b = 0; b < n_bins; ++b) bin_ptr[(size_t)b + 1] += bin_ptr[(size_t)b];
-        } else {
-            DBuf<int32_t> d_ptr, d_cells, d_dims, d_out;
-            DBuf<double> d_locs, d_lo, d_invh, d_vals;
-            hipStream_t st = c->stream;
-            HIPCHK(c, d_ptr.upload(bin_ptr.data(), bin_ptr.size(), st));
-            HIPCHK(c, d_cells.upload(bin_cells.data(), bin_cells.size(), st));
-            HIPCHK(c, d_dims.upload(dims, 3, st));
-            HIPCHK(c, d_lo.upload(lo, 3, st));
-            HIPCHK(c, d_invh.upload(inv_h, 3, st));
-            HIPCHK(c, d_locs.upload(locs_colmajor, (size_t)n_locs * M, st));
-            HIPCHK(c, d_out.alloc((size_t)n_locs));
-            HIPCHK(c, d_vals.alloc((size_t)n_locs * hs.nb));
-            AsmArgs a = asm_args(c);
-            const double tol = 1e-12;
-            const dim3 grid(g1(n_locs)), block(256);
+    HIPCHK(c, c->eval_locs.upload(locs_colmajor, (size_t)n_locs * M, st));
+    HIPCHK(c, c->eval_out.alloc((size_t)n_locs));
+    HIPCHK(c, c->eval_vals.alloc((size_t)n_locs * hs.nb));
+    AsmArgs a = asm_args(c);
+    const double tol = 1e-12;
+    const dim3 grid(g1(n_locs)), block(256);
 #define EVAL_GO(MM, RR)                                                                                                  \
-    hipLaunchKernelGGL((k_eval_pointwise<MM, RR>), grid, block, 0, st, a, n_locs, d_locs.p, d_lo.p, d_invh.p, d_dims.p, d_ptr.p, \
-                       d_cells.p, c->cell_i2e.p, tol, d_out.p, d_vals.p)
-            if (M == 2 && hs.order == 1) EVAL_GO(2, 1);
-            else if (M == 2) EVAL_GO(2, 2);
-            else if (hs.order == 1) EVAL_GO(3, 1);
-            else EVAL_GO(3, 2);
+    hipLaunchKernelGGL((k_eval_pointwise<MM, RR>), grid, block, 0, st, a, n_locs, c->eval_locs.p, eg.lo.p, eg.invh.p, eg.dims.p, eg.ptr.p, \
+                       eg.cells.p, c->cell_i2e.p, tol, c->eval_out.p, c->eval_vals.p)
+    if (M == 2 && hs.order == 1) EVAL_GO(2, 1);
+    else if (M == 2) EVAL_GO(2, 2);
+    else if (hs.order == 1) EVAL_GO(3, 1);
+    else EVAL_GO(3, 2);
 #undef EVAL_GO
-            HIPCHK(c, hipGetLastError());
-            HIPCHK(c, hipMemcpyAsync(cell_ids, d_out.p, sizeof(int32_t) * (size_t)n_locs, hipMemcpyDeviceToHost, st));
-            HIPCHK(c, hipMemcpyAsync(values, d_vals.p, sizeof(double) * (size_t)n_locs * hs.nb, hipMemcpyDeviceToHost, st));
-            HIPCHK(c, hipStreamSynchronize(st));
-            d_ptr.release(), d_cells.release(), d_dims.release(), d_out.release(), d_locs.release(), d_lo.release(), d_invh.release(),
-              d_vals.release();
-        }
-    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(cell_ids, c->eval_out.p, sizeof(int32_t) * (size_t)n_locs, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(values, c->eval_vals.p, sizeof(double) * (size_t)n_locs * hs.nb, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
     return FDAPDE_OK;
 }
 

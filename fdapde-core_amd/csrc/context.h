@@ -130,7 +130,8 @@ inline RcclApi g_rccl;
 
 struct HostTerm {
     fdapde_term t;
-    std::vector<double> data_i;   // space-varying data permuted to internal cell order
+    std::vector<double> data_i;              // space-varying data permuted to internal cell order (contexts whose space is not on a device yet)
+    std::shared_ptr<DBuf<double>> data_dev;  // ... or already on the device, permuted there (check_terms)
 };
 
 }  // namespace fdapde_detail

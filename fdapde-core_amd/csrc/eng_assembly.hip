@@ -43,7 +43,9 @@ int make_dev_op(fdapde_ctx* c, const std::vector<HostTerm>& terms, DevOp* out, i
         std::memcpy(d.cst, t.cst, sizeof d.cst);
         if (t.kind == FDAPDE_ADVECTION || t.kind == FDAPDE_REACTION) op.needs_psi = 1;
         if (t.space_varying) op.needs_rows = 1;
-        if (t.space_varying) {
+        if (t.space_varying && terms[k].data_dev) {
+            d.data = terms[k].data_dev->p;   // (permuted on the device when the operator was handed over)
+        } else if (t.space_varying) {
             DBuf<double>& buf = c->coef[coef_slot0 + k];
             if (!(reuse && buf.p && buf.n >= terms[k].data_i.size()))
                 HIPCHK(c, buf.upload(terms[k].data_i.data(), terms[k].data_i.size(), c->stream));
@@ -94,11 +96,25 @@ int check_terms(fdapde_ctx* c, int32_t n_terms, const fdapde_term* terms, std::v
         }
         if (terms[k].space_varying) {
             if (width == 0 || !terms[k].data) return fail(c, FDAPDE_EINVAL, "space-varying leaf without data");
-            h.data_i.resize((size_t)rows * width);
-            for (int64_t ci = 0; ci < hs.n_cells; ++ci) {
-                const int64_t ce = hs.cell_i2e[(size_t)ci];
-                std::memcpy(&h.data_i[(size_t)ci * hs.nq * width], &terms[k].data[(size_t)ce * hs.nq * width],
-                            sizeof(double) * hs.nq * width);
+            if (c->has_device && c->dev_ready) {   // as handed over to the device, permuted to the internal cell order there (a serial host
+                                                   // loop before: 0.77 s for the three fields of a C5-size operator)
+                HIPCHK(c, hipSetDevice(c->device));
+                DBuf<double> stage;
+                h.data_dev = std::make_shared<DBuf<double>>();
+                HIPCHK(c, stage.upload(terms[k].data, (size_t)rows * width, c->stream));
+                HIPCHK(c, h.data_dev->alloc((size_t)rows * width));
+                const int grp = hs.nq * width;
+                hipLaunchKernelGGL(k_gather_row_groups, dim3((unsigned)(((int64_t)rows * width + 255) / 256)), dim3(256), 0, c->stream, hs.n_cells, grp,
+                                   c->cell_i2e.p, stage.p, h.data_dev->p);
+                HIPCHK(c, hipGetLastError());
+                HIPCHK(c, hipStreamSynchronize(c->stream));   // (stage is released at the end of this scope)
+            } else {
+                h.data_i.resize((size_t)rows * width);
+                for (int64_t ci = 0; ci < hs.n_cells; ++ci) {
+                    const int64_t ce = hs.cell_i2e[(size_t)ci];
+                    std::memcpy(&h.data_i[(size_t)ci * hs.nq * width], &terms[k].data[(size_t)ce * hs.nq * width],
+                                sizeof(double) * hs.nq * width);
+                }
             }
             h.t.data = nullptr;
         }
@@ -114,7 +130,7 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
     if (assembly == FDAPDE_ASSEMBLY_ROWS) {
         // specialised integrands (see element_row): the two operators FEMSolverBase::init always assembles, and any other
         // constant-coefficient expression through the reference tensors
-        int opk = 0;
+        int opk = 4;   // space-varying coefficients: one pulled-back tensor per quadrature node
         if (!op.needs_rows) opk = 3;
         if (op.n == 1 && op.t[0].kind == FDAPDE_LAPLACIAN) opk = 1;
         if (op.n == 1 && op.t[0].kind == FDAPDE_REACTION && !op.t[0].space_varying) opk = 2;
@@ -165,9 +181,12 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
             for (const void* fn : {reinterpret_cast<const void*>(&k_assemble_rows<M, R, 0>),
                                    reinterpret_cast<const void*>(&k_assemble_rows<M, R, 1>),
                                    reinterpret_cast<const void*>(&k_assemble_rows<M, R, 2>),
-                                   reinterpret_cast<const void*>(&k_assemble_rows<M, R, 3>)})
+                                   reinterpret_cast<const void*>(&k_assemble_rows<M, R, 3>),
+                                   reinterpret_cast<const void*>(&k_assemble_rows<M, R, 4>)})
                 (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (opk == 3)
+        if (opk == 4)
+            hipLaunchKernelGGL((k_assemble_rows<M, R, 4>), dim3(grid), dim3(kAsmBlock), lds, c->stream, a, op);
+        else if (opk == 3)
             hipLaunchKernelGGL((k_assemble_rows<M, R, 3>), dim3(grid), dim3(kAsmBlock), lds, c->stream, a, op);
         else if (opk == 1)
             hipLaunchKernelGGL((k_assemble_rows<M, R, 1>), dim3(grid), dim3(kAsmBlock), lds, c->stream, a, op);

@@ -285,6 +285,102 @@ __device__ __forceinline__ double element_row(const AsmArgs& a, const DevOp& op,
             emit(j, g.measure * ((adv - d) + op.ct * tb->mtab[il * NB + j]));
         }
         return fsum;
+    } else if constexpr (OPK == 4) {
+        // SPACE-VARYING coefficients (Discretized*Field::forward(nq cell + q), fields/*_expressions.h), quadrature node OUTERMOST: the
+        // coefficient rows of node q are read once per visit (the generic form reads them once per trial function), the leaves are summed
+        // into ONE tensor / vector / scalar per node -- Kt_q, bt_q, ct_q, constants included -- and pulled back to the reference cell,
+        //   Gp = J^-1 Kt_q J^-T,  beta = J^-1 bt_q,   value_j += w_q ( psi_i (beta . dpsi_j) - dpsi_i^T Gp dpsi_j + ct_q (psi_i psi_j) ),
+        // so that the trial-function loop works on reference gradients from the tables (no physical gradient per (j, q)).  The bilinear
+        // form is evaluated pairwise -- Gp[k][l] (gi_k gj_l) + Gp[l][k] (gi_l gj_k) -- and Gp is made exactly symmetric where Kt_q is:
+        // a symmetric operator then gives A_ij == A_ji bit for bit, as the constant-coefficient forms do.
+        // (C5-size mesh, diffusion + advection + reaction fields: init 163 -> see DESIGN.md 4.3)
+        double accj[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) accj[j] = 0.0;
+        bool any_adv = false;
+        for (int t = 0; t < op.n; ++t) any_adv = any_adv || op.t[t].kind == FDAPDE_ADVECTION;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int64_t qrow = qrow0 + q;
+            double Kt[M * M], bt[M], ctq = 0.0;
+#pragma unroll
+            for (int e = 0; e < M * M; ++e) Kt[e] = 0.0;
+#pragma unroll
+            for (int e = 0; e < M; ++e) bt[e] = 0.0;
+            for (int t = 0; t < op.n; ++t) {
+                const DevTerm& T = op.t[t];
+                if (T.kind == FDAPDE_LAPLACIAN) {
+#pragma unroll
+                    for (int r = 0; r < M; ++r) Kt[r * M + r] += T.coef;
+                } else if (T.kind == FDAPDE_DIFFUSION) {
+#pragma unroll
+                    for (int e = 0; e < M * M; ++e) Kt[e] += T.coef * (T.space_varying ? T.data[qrow * (M * M) + e] : T.cst[e]);
+                } else if (T.kind == FDAPDE_ADVECTION) {
+#pragma unroll
+                    for (int e = 0; e < M; ++e) bt[e] += T.coef * (T.space_varying ? T.data[qrow * M + e] : T.cst[e]);
+                } else if (T.kind == FDAPDE_REACTION) {
+                    ctq += T.coef * (T.space_varying ? T.data[qrow] : T.cst[0]);
+                }
+            }
+            bool ksym = true;
+#pragma unroll
+            for (int r = 0; r < M; ++r)
+#pragma unroll
+                for (int c2 = 0; c2 < r; ++c2) ksym = ksym && Kt[r * M + c2] == Kt[c2 * M + r];
+            double Gp[M][M], beta[M];
+#pragma unroll
+            for (int k = 0; k < M; ++k) {
+                double kr[M];   // row k of J^-1 Kt
+#pragma unroll
+                for (int c2 = 0; c2 < M; ++c2) {
+                    double v = 0;
+#pragma unroll
+                    for (int r = 0; r < M; ++r) v += g.invJ[k][r] * Kt[r * M + c2];
+                    kr[c2] = v;
+                }
+#pragma unroll
+                for (int l = 0; l < M; ++l) {
+                    double v = 0;
+#pragma unroll
+                    for (int c2 = 0; c2 < M; ++c2) v += kr[c2] * g.invJ[l][c2];
+                    Gp[k][l] = v;
+                }
+                double bv = 0;
+#pragma unroll
+                for (int r = 0; r < M; ++r) bv += g.invJ[k][r] * bt[r];
+                beta[k] = bv;
+            }
+            if (ksym) {
+#pragma unroll
+                for (int k = 0; k < M; ++k)
+#pragma unroll
+                    for (int l = 0; l < k; ++l) Gp[k][l] = Gp[l][k];
+            }
+            const double* gi = &tb->dpsi[(il * NQ + q) * 3];
+            const double pi = tb->psi[il * NQ + q];
+            const double wq = tb->qw[q];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const double* gj = &tb->dpsi[(j * NQ + q) * 3];
+                double d = 0;
+#pragma unroll
+                for (int k = 0; k < M; ++k) d += Gp[k][k] * (gi[k] * gj[k]);
+#pragma unroll
+                for (int k = 0; k < M; ++k)
+#pragma unroll
+                    for (int l = k + 1; l < M; ++l) d += Gp[k][l] * (gi[k] * gj[l]) + Gp[l][k] * (gi[l] * gj[k]);
+                double adv = 0;
+                if (any_adv) {
+#pragma unroll
+                    for (int l = 0; l < M; ++l) adv += beta[l] * gj[l];
+                    adv *= pi;
+                }
+                accj[j] += ((adv - d) + ctq * (pi * tb->psi[j * NQ + q])) * wq;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) emit(j, accj[j] * g.measure);
+        return fsum;
     } else if constexpr (OPK == 1 && R == 1) {
         double G[M + 1][M];   // physical gradients of the M+1 barycentric coordinates
 #pragma unroll

@@ -80,3 +80,43 @@ def test_pointwise_evaluation_random_points(capi, oracle, mesh_loader, mesh_name
     f = (lambda x: 1.0 + 2 * x[:, 0] - x[:, -1]) if order == 1 else (lambda x: x[:, 0] ** 2 - x[:, 0] * x[:, -1] + x[:, 1])
     assert np.abs((psi @ f(coords))[rows] - f(locs[rows])).max() < 1e-11
     ctx.close()
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_point_location_on_minimal_and_anisotropic_meshes(capi, dim):
+    """the point-location grid (built on the device once per mesh): one cell (a single bin), a thin strip (cells far longer than the bins are
+    wide: every cell registered in many bins), repeated calls and a second mesh on the same context (the grid of the mesh before must go)"""
+    ctx = capi.Context(device=0)
+    rng = np.random.default_rng(2)
+    # one cell
+    nodes = np.vstack([np.zeros(dim), np.eye(dim)])
+    cells = np.arange(dim + 1, dtype=np.int32).reshape(1, -1)
+    ctx.mesh_upload(nodes, cells, np.ones(dim + 1, dtype=np.uint8))
+    ctx.dofs_build(1)
+    w = rng.dirichlet(np.ones(dim + 1), 50)
+    locs = w @ nodes
+    psi, _, found = ctx.eval_pointwise(np.vstack([locs, [[2.0] * dim]]))
+    assert np.all(found[:50] == 0) and found[50] == -1
+    assert np.abs(psi[:50].toarray() - w).max() < 1e-12     # P1 basis values at a point = its barycentric coordinates
+    # a strip of very elongated cells, on the same context
+    from fdapde_loader import load_package
+
+    load_package()
+    from fdapde_core_amd import meshgen
+
+    n2, c2, b2 = meshgen.unit_square(12) if dim == 2 else meshgen.unit_cube(5)
+    n2 = n2.copy()
+    n2[:, 0] *= 200.0
+    ctx.mesh_upload(n2, c2, b2)
+    nd = ctx.dofs_build(2)
+    _, _, coords = ctx.dofs_get()
+    pick = rng.integers(0, c2.shape[0], 400)
+    w = rng.dirichlet(np.ones(dim + 1), 400)
+    locs = np.einsum("ij,ijk->ik", w, n2[c2[pick]])
+    f = lambda x: 0.5 + x[:, 0] * 1e-2 - x[:, 1] ** 2 + x[:, 0] * x[:, -1] * 1e-2
+    for _ in range(2):
+        psi, _, found = ctx.eval_pointwise(locs)
+        assert np.all(found >= 0)
+        assert np.abs(np.asarray(psi.sum(axis=1)).ravel() - 1.0).max() < 1e-11
+        assert np.abs(psi @ f(coords) - f(locs)).max() < 1e-9
+    ctx.close()

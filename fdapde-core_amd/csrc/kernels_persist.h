@@ -937,13 +937,24 @@ static __global__ __launch_bounds__(kPersistT) void k_spmv_blocked(BlockedSpmvAr
 
 // ell_val[e] = scaled full-pattern value the entry maps to, 0 in padding
 // amax_bits != nullptr (zeroed by the caller): also max |value| as a bit pattern (non-negative doubles order like their bits)
+// (four entries per thread, a workgroup covering 1024 consecutive ones: the four index loads, then the four gathers, in flight together)
 static __global__ __launch_bounds__(256) void k_persist_fill(int64_t n, const int32_t* src, const double* scaled_full, double* out,
                                                       unsigned long long* amax_bits) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    int32_t s4[4];
+    double v4[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s4[k] = i0 + 256 * k < n ? src[i0 + 256 * k] : -1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v4[k] = s4[k] >= 0 ? scaled_full[s4[k]] : 0.0;
     double v = 0.0;
-    if (i < n) out[i] = v = src[i] >= 0 ? scaled_full[src[i]] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (i0 + 256 * k < n) out[i0 + 256 * k] = v4[k];
+        v = fmax(v, fabs(v4[k]));
+    }
     if (amax_bits != nullptr) {
-        double m = fabs(v);
+        double m = v;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
         const unsigned long long bits = (unsigned long long)__double_as_longlong(m);

@@ -449,7 +449,7 @@ int fill_persist(fdapde_ctx* c, int v) {
     fdapde_ctx::Persist& ps = c->ps[v];
     hipStream_t st = c->stream;
     if (ps.meta.sym) HIPCHK(c, hipMemsetAsync(ps.amax.p, 0, sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(k_persist_fill, dim3(grid1(ps.meta.n_entries)), dim3(256), 0, st, ps.meta.n_entries, ps.ell_src.p, c->sval.p, ps.ell_val.p,
+    hipLaunchKernelGGL(k_persist_fill, dim3((unsigned)((ps.meta.n_entries + 1023) / 1024)), dim3(256), 0, st, ps.meta.n_entries, ps.ell_src.p, c->sval.p, ps.ell_val.p,
                        ps.meta.sym ? ps.amax.p : (unsigned long long*)nullptr);
     HIPCHK(c, hipGetLastError());
     ps.filled = true;
@@ -806,7 +806,7 @@ int fill_rowdist(fdapde_ctx* c, int v) {
     fdapde_ctx::Persist& ps = c->rd.lay[v].ps;
     hipStream_t st = c->stream;
     if (ps.meta.sym) HIPCHK(c, hipMemsetAsync(ps.amax.p, 0, sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(k_persist_fill, dim3(grid1(ps.meta.n_entries)), dim3(256), 0, st, ps.meta.n_entries, ps.ell_src.p, c->sval.p, ps.ell_val.p,
+    hipLaunchKernelGGL(k_persist_fill, dim3((unsigned)((ps.meta.n_entries + 1023) / 1024)), dim3(256), 0, st, ps.meta.n_entries, ps.ell_src.p, c->sval.p, ps.ell_val.p,
                        ps.meta.sym ? ps.amax.p : (unsigned long long*)nullptr);
     HIPCHK(c, hipGetLastError());
     ps.filled = true;

@@ -184,6 +184,16 @@ __device__ __forceinline__ double weak_form(const DevOp& op, int64_t qrow, doubl
     return total;
 }
 
+// g_kl (a_k b_l) + g_lk (a_l b_k) with every product rounded on its own: swapping a and b swaps the two summands and nothing else, so
+// with g_kl == g_lk the result is the same bits (a fused multiply-add would round one of the pair differently from the other;
+// __dmul_rn / __dadd_rn are plain operators on this platform and get fused like them)
+__device__ __forceinline__ double sym_pair(double g_kl, double g_lk, double a_k, double b_l, double a_l, double b_k) {
+#pragma clang fp contract(off)
+    const double p = a_k * b_l, q = a_l * b_k;
+    const double x = g_kl * p, y = g_lk * q;
+    return x + y;
+}
+
 // One row of one element matrix: for local test function `il` of `cell`, emit(j, value) for every local trial
 // function j, value = measure * sum_q w_q * form(psi_il, psi_j)(p_q)   (integrator.h:92-106), and return the forcing
 // contribution measure * sum_q f_q psi_il(p_q) w_q (integrator.h:73-90) when fq is given.
@@ -368,7 +378,7 @@ __device__ __forceinline__ double element_row(const AsmArgs& a, const DevOp& op,
 #pragma unroll
                 for (int k = 0; k < M; ++k)
 #pragma unroll
-                    for (int l = k + 1; l < M; ++l) d += Gp[k][l] * (gi[k] * gj[l]) + Gp[l][k] * (gi[l] * gj[k]);
+                    for (int l = k + 1; l < M; ++l) d += sym_pair(Gp[k][l], Gp[l][k], gi[k], gj[l], gi[l], gj[k]);
                 double adv = 0;
                 if (any_adv) {
 #pragma unroll

@@ -125,6 +125,37 @@ def test_space_varying_coefficients(capi, ctx, oracle, mesh_loader, mesh_name, o
     assert _entry_close(got, ref.values)
 
 
+@pytest.mark.parametrize("mesh_name,order", [("unit_square_16", 2), ("unit_sphere", 1), ("unit_sphere", 2)])
+def test_space_varying_symmetric_operator_is_bitwise_symmetric(capi, ctx, oracle, mesh_loader, mesh_name, order):
+    """the space-varying integrand (quadrature node outermost, one pulled-back tensor per node) evaluates the bilinear form pairwise and makes
+    the pulled-back tensor exactly symmetric where the summed coefficient tensor is: a symmetric operator -- reaction field, symmetric
+    diffusion field -- gives A_ij == A_ji bit for bit, like the constant-coefficient forms; and it matches the oracle"""
+    m = mesh_loader(mesh_name)
+    ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = ctx.dofs_build(order)
+    od, _, _, _ = oracle.enumerate_dofs(m, order)
+    rows = ctx.sizes()["n_quadrature"] * m.n_cells
+    rng = np.random.default_rng(11)
+    N = m.N
+    L = rng.uniform(-0.3, 0.3, (rows, N, N))
+    K = np.einsum("qij,qkj->qik", L, L) + np.eye(N)[None] * rng.uniform(0.5, 1.5, (rows, 1, 1))   # symmetric positive per node
+    K = 0.5 * (K + np.transpose(K, (0, 2, 1)))
+    cq = rng.uniform(0.1, 2.0, rows)
+    import scipy.sparse as sp
+
+    rp, ci = None, None
+    for mk in (lambda mod: -mod.laplacian() + mod.reaction_field(cq),
+               lambda mod: -mod.diffusion_field(K.reshape(rows, N * N)) + mod.reaction_field(cq) + 0.5 * mod.reaction(1.0)):
+        ctx.assemble_operator(capi.MAT_STIFF, mk(capi))
+        got = ctx.matrix_values(capi.MAT_STIFF)
+        ref = oracle.assemble_operator(m, order, od, nd, mk(oracle))
+        assert _entry_close(got, ref.values)
+        if rp is None:
+            rp, ci = ctx.pattern_get()
+        A = sp.csr_matrix((got, ci, rp), shape=(nd, nd))
+        assert abs(A - A.T).max() == 0.0
+
+
 @pytest.mark.parametrize("mesh_name,order", [("unit_square_16", 2), ("unit_sphere", 1)])
 def test_init_with_space_varying_coefficients_and_forcing(capi, ctx, oracle, mesh_loader, mesh_name, order):
     """one sweep reads the coefficient rows by CELL and the forcing samples by BLOCK-CELL: the two row indices must not be mixed up"""

@@ -231,3 +231,50 @@ def test_peer_lists_are_validated(capi):
     c.halo_setup_peers([0, 2], [0, 2, 3], [0, 1, 1], owned)     # a DOF shared with two peers is fine
     c.halo_setup_peers([], [0], [], owned)                       # and so is a rank without neighbours
     c.close()
+
+
+def test_device_memory_does_not_drift_over_context_lifetimes(capi):
+    """every engine unit touched, context closed, eight times over: the free device memory after close() stays where the second lifetime
+    left it (space-varying operator data, column boards, point-location grid, row-distributed / persistent layouts are all released)"""
+    import ctypes as C
+
+    from fdapde_core_amd import meshgen
+
+    hip = C.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    nodes, cells, bnd = meshgen.unit_cube(12)
+    n2, c2, b2 = meshgen.unit_square(40)
+    seen = []
+    for it in range(8):
+        c = capi.Context(0)
+        c.mesh_upload(nodes, cells, bnd)
+        nd = c.dofs_build(1 + it % 2)
+        qn = c.quadrature_nodes()
+        c.set_operator(-capi.laplacian() + capi.reaction_field(1.0 + qn[:, 0]))
+        c.set_forcing(np.ones(qn.shape[0]))
+        c.set_dirichlet(np.zeros(nd))
+        c.init()
+        c.solve(rtol=1e-9)
+        c.set_operator(-capi.laplacian() + capi.advection([1.0, 0.5, 0.25]) + capi.reaction(1.0))
+        c.init()
+        c.solve(rtol=1e-9)
+        c.lin_compute(capi.MAT_STIFF, symmetric=False)
+        c.lin_solve(np.ones((nd, 5)))
+        c.eval_pointwise(np.random.default_rng(0).uniform(0.1, 0.9, (200, 3)))
+        c.mesh_upload(n2, c2, b2)
+        nd = c.dofs_build(2)
+        c.set_operator(capi.dt() - capi.laplacian())
+        qn = c.quadrature_nodes()
+        c.set_forcing(np.zeros((qn.shape[0], 4)))
+        c.init()
+        _, _, co = c.dofs_get()
+        c.solve_parabolic(np.linspace(0, 0.1, 4), np.prod(np.sin(np.pi * co), axis=1), dirichlet=np.zeros((nd, 4)))
+        c.eval_pointwise(np.random.default_rng(0).uniform(0.1, 0.9, (200, 2)))
+        c.close()
+        seen.append(free_bytes())
+    assert max(seen[1:]) - min(seen[1:]) <= 8 << 20, seen   # (the first lifetime also fills the runtime's own pools)

@@ -47,7 +47,7 @@ SYMBOLS = [
     "fdapde_info_get", "fdapde_spmv", "fdapde_bench_spmv", "fdapde_tune", "fdapde_stream", "fdapde_synchronize",
     "fdapde_comm_unique_id", "fdapde_comm_init", "fdapde_halo_setup", "fdapde_solve_parabolic",
     "fdapde_lin_compute", "fdapde_lin_solve", "fdapde_eval_pointwise", "fdapde_cell_integrals", "fdapde_comm_init_callback", "fdapde_comm_set_exchange_callback", "fdapde_halo_setup_peers",
-    "fdapde_solver_layout", "fdapde_topology_build", "fdapde_topology_get", "fdapde_comm_allreduce", "fdapde_comm_library", "fdapde_solver_layout_kind", "fdapde_rowdist_setup",
+    "fdapde_solver_layout", "fdapde_topology_build", "fdapde_topology_get", "fdapde_comm_allreduce", "fdapde_comm_library", "fdapde_solver_layout_kind", "fdapde_rowdist_setup", "fdapde_ctx_clone",
 ]
 
 _lib = None
@@ -168,6 +168,14 @@ class Context:
             raise FdapdeError(rc, self.lib.fdapde_status_string(rc).decode())
         self.M = self.N = 0
         self.n_cells = self.n_nodes = 0
+
+    def clone(self):
+        """fdapde_ctx_clone: an independent context with the same problem, assembled state and solution"""
+        other = Context.__new__(Context)
+        other.lib, other._ctx = self.lib, C.c_void_p()
+        other.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("lib", "_ctx")})
+        self._check(self.lib.fdapde_ctx_clone(self._ctx, C.byref(other._ctx)))
+        return other
 
     def close(self):
         if self._ctx:

@@ -114,6 +114,21 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
     delete c;
 }
 
+int fdapde_ctx_clone(const fdapde_ctx* src, fdapde_ctx** out) {
+    if (!src || !out) return FDAPDE_EINVAL;
+    *out = nullptr;
+    fdapde_ctx* c = nullptr;
+    if (int rc = fdapde_ctx_create(src->has_device ? src->device : -1, &c)) return rc;
+    const int rc = fdapde_engine::e_ctx_clone(src, c);
+    if (rc != FDAPDE_OK) {
+        const_cast<fdapde_ctx*>(src)->err = "fdapde_ctx_clone: " + c->err;   // (the half-built clone is not handed out: the text goes to the source)
+        fdapde_ctx_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return FDAPDE_OK;
+}
+
 const char* fdapde_last_error(const fdapde_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
 int fdapde_mesh_upload(fdapde_ctx* c, int M, int N, int64_t n_nodes, const double* nodes, int64_t n_cells,

@@ -64,6 +64,7 @@ int allreduce_sum(fdapde_ctx* c, double* buf, size_t count);               // en
 int halo_sum(fdapde_ctx* c, double* v, const double* part, int np, bool unpack = true);   // eng_dist.hip: interface entries summed over the sharing ranks
 
 // ---- the bodies behind the C ABI (capi.hip forwards to them; each unit's header comment says what it holds) ----------------------------
+int e_ctx_clone(const fdapde_ctx* src, fdapde_ctx* dst);   // eng_clone.hip
 int e_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs);
 int e_topology_build(fdapde_ctx* c, int64_t* n_facets, int64_t* n_edges);
 int e_topology_get(fdapde_ctx* c, int32_t* neighbors, int32_t* cell_facets, int32_t* facet_nodes, int32_t* facet_cells, uint8_t* facet_boundary, int32_t* edge_nodes, uint8_t* edge_boundary, int32_t* face_edges);

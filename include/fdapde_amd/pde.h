@@ -37,7 +37,10 @@
 #include <type_traits>
 #include <vector>
 
+#include <typeinfo>
+
 #include "../fdapde_hip.h"
+#include "../fdapde_hip.hpp"   // copy-on-write owner of the device context
 
 namespace fdapde {
 namespace amd {
@@ -299,9 +302,20 @@ template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_H
         time_domain_ = t;
         open(device);
     }
-    PDE(const PDE&) = delete;
+    PDE(const D& domain, const DVector<double>& t, OperatorType diff_op, const ForcingType& forcing, int device = 0) :
+        domain_(domain), diff_op_(std::move(diff_op)), forcing_data_(forcing) {
+        time_domain_ = t;
+        open(device);
+    }
+    // Copies are what the reference's type-erased handle lives on (make_pde copies the PDE to the heap, every handle copy copies it
+    // again: pde.h:167-169, type_erasure.h:130-146).  A copy takes the host-side state (operator, forcing, boundary data, the matrices and
+    // vectors the getters return) and SHARES the device context; whichever object next changes the context's problem state (init, solve,
+    // a solver handle's compute) first leaves with a clone of it (fdapde_ctx_clone: include/fdapde_hip.hpp), so every object keeps
+    // computing on the state it was copied with.  Assignment: not available, as in the reference (const members, pde.h:107-108).
+    PDE(const PDE&) = default;
+    PDE(PDE&&) = default;
     PDE& operator=(const PDE&) = delete;
-    ~PDE() { fdapde_ctx_destroy(ctx_); }
+    ~PDE() = default;
 
     // setters (pde.h:74-77)
     void set_forcing(const ForcingType& forcing_data) { forcing_data_ = forcing_data; }
@@ -325,7 +339,7 @@ template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_H
     DMatrix<double> dof_coords() const { return dof_coords_; }
     DMatrix<double> quadrature_nodes() const {
         DMatrix<double> q((int64_t)nq_ * domain_.n_cells(), N);
-        check(fdapde_quadrature_nodes(ctx_, q.data()));
+        check(fdapde_quadrature_nodes(ctx_.get(), q.data()));
         return q;
     }
     bool is_init() const { return is_init_; }
@@ -337,14 +351,15 @@ template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_H
     void init() {
         auto terms = diff_op_.c_terms();
         if (terms.empty()) throw std::runtime_error("PDE::init: no differential operator set");
-        check(fdapde_set_operator(ctx_, (int32_t)terms.size(), terms.data()));
+        fdapde_ctx* const ctx = ctx_.unique();   // (a copy that still shares the context leaves with its own clone here)
+        check(fdapde_set_operator(ctx, (int32_t)terms.size(), terms.data()));
         const int64_t rows = (int64_t)nq_ * domain_.n_cells();
         if constexpr (std::is_same_v<F, DMatrix<double>>) {
             if (is_empty(forcing_data_)) {
-                check(fdapde_set_forcing(ctx_, nullptr, 0));
+                check(fdapde_set_forcing(ctx, nullptr, 0));
             } else {
                 if (forcing_data_.rows() != rows) throw std::runtime_error("forcing data must have nq * n_cells rows");
-                check(fdapde_set_forcing(ctx_, forcing_data_.data(), (int32_t)forcing_data_.cols()));
+                check(fdapde_set_forcing(ctx, forcing_data_.data(), (int32_t)forcing_data_.cols()));
             }
         } else {   // callable: evaluate at the mapped quadrature nodes (integrator.h:77-81)
             DMatrix<double> q = quadrature_nodes(), f(rows, 1);
@@ -353,14 +368,14 @@ template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_H
                 for (int d = 0; d < N; ++d) x[(size_t)d] = q(i, d);
                 f(i) = forcing_data_(x);
             }
-            check(fdapde_set_forcing(ctx_, f.data(), 1));
+            check(fdapde_set_forcing(ctx, f.data(), 1));
         }
-        check(fdapde_init(ctx_, &opt_));
+        check(fdapde_init(ctx, &opt_));
         fetch_matrix(FDAPDE_MAT_STIFF, stiff_);
         fetch_matrix(FDAPDE_MAT_MASS, mass_);
         const int cols = std::is_same_v<F, DMatrix<double>> && !is_empty_forcing() ? (int)forcing_cols() : 1;
         force_.resize(n_dofs_ * cols, 1);
-        check(fdapde_force(ctx_, force_.data()));
+        check(fdapde_force(ctx, force_.data()));
         is_init_ = true, success_ = false;
     }
     // PDE::solve (pde.h:102-105): set_dirichlet_bc if boundary data is set, then the linear solve
@@ -370,22 +385,23 @@ template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_H
             solve_parabolic();
             return;
         }
+        fdapde_ctx* const ctx = ctx_.unique();   // (the clone carries stiff_ / force_ / mass_: no second init)
         if (!is_empty(boundary_data_)) {
             if (boundary_data_.rows() != n_dofs_) throw std::runtime_error("dirichlet data must have n_dofs rows");
-            check(fdapde_set_dirichlet(ctx_, boundary_data_.data()));
+            check(fdapde_set_dirichlet(ctx, boundary_data_.data()));
         } else {
-            check(fdapde_set_dirichlet(ctx_, nullptr));
+            check(fdapde_set_dirichlet(ctx, nullptr));
         }
-        const int rc = fdapde_solve(ctx_, &opt_, &info_);
+        const int rc = fdapde_solve(ctx, &opt_, &info_);
         if (rc == FDAPDE_ENOCONV) {   // reference: success = false, no throw
             success_ = false;
             return;
         }
         check(rc);
         solution_.resize(n_dofs_, 1);
-        check(fdapde_solution(ctx_, solution_.data()));
-        check(fdapde_matrix_values(ctx_, FDAPDE_MAT_STIFF, stiff_.values.data()));   // row-zeroed if Dirichlet data was applied
-        check(fdapde_force(ctx_, force_.data()));
+        check(fdapde_solution(ctx, solution_.data()));
+        check(fdapde_matrix_values(ctx, FDAPDE_MAT_STIFF, stiff_.values.data()));   // row-zeroed if Dirichlet data was applied
+        check(fdapde_force(ctx, force_.data()));
         success_ = true;
     }
 
@@ -394,25 +410,28 @@ template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_H
        public:
         // compute(matrix): any matrix on the FEM pattern (e.g. pde.mass(), or a combination of stiff and mass values)
         void compute(const SpMatrix<double>& m, bool symmetric = false) {
-            computed_ = fdapde_lin_compute(ctx_, FDAPDE_MAT_STIFF, m.values.data(), symmetric ? 1 : 0) == FDAPDE_OK;
+            computed_ = fdapde_lin_compute(ctx_.get(), FDAPDE_MAT_STIFF, m.values.data(), symmetric ? 1 : 0) == FDAPDE_OK;
         }
         DMatrix<double> solve(const DMatrix<double>& b) const {
             if (!computed_) throw std::runtime_error("SparseSolver: compute() first");
             DMatrix<double> x(b.rows(), b.cols());
             fdapde_info info;
-            const int rc = fdapde_lin_solve(ctx_, nullptr, b.data(), (int32_t)b.cols(), x.data(), &info);
-            if (rc != FDAPDE_OK) throw std::runtime_error(fdapde_last_error(ctx_));
+            const int rc = fdapde_lin_solve(ctx_.get(), nullptr, b.data(), (int32_t)b.cols(), x.data(), &info);
+            if (rc != FDAPDE_OK) throw std::runtime_error(fdapde_last_error(ctx_.get()));
             return x;
         }
         explicit operator bool() const { return computed_; }
        private:
         friend class PDE;
-        explicit SparseSolver(fdapde_ctx* ctx) : ctx_(ctx) { }
-        fdapde_ctx* ctx_;
+        explicit SparseSolver(fdapde::hip::context_handle ctx) : ctx_(std::move(ctx)) { }
+        fdapde::hip::context_handle ctx_;   // keeps the PDE's context alive; acts on it (the handle's matrix is no part of the PDE's state)
         bool computed_ = false;
     };
-    SparseSolver make_solver() { return SparseSolver(ctx_); }
-    fdapde_ctx* context() const { return ctx_; }   // the C-ABI context (for entry points the facade does not wrap)
+    SparseSolver make_solver() {
+        ctx_.unique();   // the handle works on THIS object's context, not on one still shared with a copy
+        return SparseSolver(ctx_.observer());
+    }
+    fdapde_ctx* context() const { return ctx_.get(); }   // the C-ABI context (for entry points the facade does not wrap)
 
     // PDE__::eval_basis (pde/pde.h:149-158): 0 = Sampling::pointwise (locs: n_locs x N coordinates), 1 = Sampling::areal (locs:
     // n_subdomains x n_cells incidence matrix of 0 / 1).  Psi rows have sorted columns; duplicates are summed like setFromTriplets.
@@ -426,7 +445,7 @@ template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_H
             const int64_t nl = locs.rows();
             std::vector<int32_t> cell((size_t)nl);
             std::vector<double> val((size_t)(nl * nb));
-            check(fdapde_eval_pointwise(ctx_, nl, locs.data(), cell.data(), val.data()));
+            check(fdapde_eval_pointwise(ctx_.get(), nl, locs.data(), cell.data(), val.data()));
             rows.resize((size_t)nl);
             out.D = DVector<double>(nl, 1, 1.0);
             for (int64_t i = 0; i < nl; ++i) {
@@ -437,7 +456,7 @@ template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_H
             if (locs.cols() != nc) throw std::runtime_error("eval_basis: the incidence matrix needs one column per cell");
             const int64_t ns = locs.rows();
             std::vector<double> meas((size_t)nc), pint((size_t)(nc * nb));
-            check(fdapde_cell_integrals(ctx_, meas.data(), pint.data()));
+            check(fdapde_cell_integrals(ctx_.get(), meas.data(), pint.data()));
             rows.resize((size_t)ns);
             out.D = DVector<double>(ns, 1, 0.0);
             for (int64_t k = 0; k < ns; ++k) {
@@ -475,8 +494,9 @@ template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_H
         if (!is_empty(boundary_data_) && (boundary_data_.rows() != n_dofs_ || boundary_data_.cols() < m))
             throw std::runtime_error("dirichlet data must be n_dofs x n_times");
         solution_.resize(n_dofs_, m);
+        fdapde_ctx* const ctx = ctx_.unique();
         const double dt_ = time_domain_(1) - time_domain_(0);
-        const int rc = fdapde_solve_parabolic(ctx_, &opt_, (int32_t)m, dt_, initial_condition_.data(),
+        const int rc = fdapde_solve_parabolic(ctx, &opt_, (int32_t)m, dt_, initial_condition_.data(),
                                               is_empty(boundary_data_) ? nullptr : boundary_data_.data(), solution_.data(), &info_);
         if (rc == FDAPDE_ENOCONV) {
             success_ = false;
@@ -495,12 +515,12 @@ template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_H
     }
     void check(int rc) const {
         if (rc == FDAPDE_OK) return;
-        const std::string msg = ctx_ ? fdapde_last_error(ctx_) : "";
+        const std::string msg = ctx_ ? fdapde_last_error(ctx_.get()) : "";
         throw std::runtime_error(msg.empty() ? fdapde_status_string(rc) : msg);
     }
     void open(int device) {
-        const int rc = fdapde_ctx_create(device, &ctx_);
-        if (rc != FDAPDE_OK) throw std::runtime_error(std::string("fdapde_ctx_create: ") + fdapde_status_string(rc));
+        ctx_ = fdapde::hip::context_handle(device);
+        fdapde_ctx* const ctx = ctx_.get();
         // hand the mesh over in the ABI's layouts (nodes column-major, cells row-major, boundary bytes)
         const int64_t nn = domain_.n_nodes(), nc = domain_.n_cells();
         std::vector<int32_t> cells((size_t)(nc * (M + 1)));
@@ -508,14 +528,14 @@ template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_H
             for (int v = 0; v <= M; ++v) cells[(size_t)(c * (M + 1) + v)] = domain_.cells()(c, v);
         std::vector<uint8_t> bnd((size_t)nn);
         for (int64_t i = 0; i < nn; ++i) bnd[(size_t)i] = domain_.boundary_nodes()(i, 0) ? 1 : 0;
-        check(fdapde_mesh_upload(ctx_, M, N, nn, domain_.nodes().data(), nc, cells.data(), bnd.data()));
-        check(fdapde_dofs_build(ctx_, R, &n_dofs_));
+        check(fdapde_mesh_upload(ctx, M, N, nn, domain_.nodes().data(), nc, cells.data(), bnd.data()));
+        check(fdapde_dofs_build(ctx, R, &n_dofs_));
         int64_t nnz = 0, n_edges = 0;
-        check(fdapde_sizes(ctx_, &n_dofs_, &nnz, &nb_, &nq_, &n_edges));
+        check(fdapde_sizes(ctx, &n_dofs_, &nnz, &nb_, &nq_, &n_edges));
         std::vector<int32_t> dofs((size_t)(nc * nb_));
         std::vector<uint8_t> bd((size_t)n_dofs_);
         dof_coords_.resize(n_dofs_, N);
-        check(fdapde_dofs_get(ctx_, dofs.data(), bd.data(), dof_coords_.data()));
+        check(fdapde_dofs_get(ctx, dofs.data(), bd.data(), dof_coords_.data()));
         dofs_.resize(nc, nb_), boundary_dofs_.resize(n_dofs_, 1);
         for (int64_t c = 0; c < nc; ++c)
             for (int j = 0; j < nb_; ++j) dofs_(c, j) = dofs[(size_t)(c * nb_ + j)];
@@ -523,10 +543,10 @@ template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_H
         for (SpMatrix<double>* m : {&stiff_, &mass_}) {
             m->n_rows = m->n_cols = n_dofs_;
             m->rowptr.resize((size_t)n_dofs_ + 1), m->colidx.resize((size_t)nnz), m->values.assign((size_t)nnz, 0.0);
-            check(fdapde_pattern_get(ctx_, m->rowptr.data(), m->colidx.data()));
+            check(fdapde_pattern_get(ctx, m->rowptr.data(), m->colidx.data()));
         }
     }
-    void fetch_matrix(int which, SpMatrix<double>& m) { check(fdapde_matrix_values(ctx_, which, m.values.data())); }
+    void fetch_matrix(int which, SpMatrix<double>& m) { check(fdapde_matrix_values(ctx_.get(), which, m.values.data())); }
 
     const D& domain_;                 // must outlive the PDE (pde.h:107)
     OperatorType diff_op_;
@@ -534,7 +554,7 @@ template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_H
     DVector<double> time_domain_ {};         // [t_0 ... t_{m-1}] for space-time problems (pde.h:108)
     DVector<double> initial_condition_ {};   // pde.h:111
     DMatrix<double> boundary_data_;
-    fdapde_ctx* ctx_ = nullptr;
+    fdapde::hip::context_handle ctx_;        // shared between copies until one of them changes it (include/fdapde_hip.hpp)
     fdapde_options opt_ {FDAPDE_SOLVER_AUTO, 0, 1e-10, FDAPDE_ASSEMBLY_ROWS, 0, 0};
     fdapde_info info_ {};
     int64_t n_dofs_ = 0;
@@ -544,6 +564,142 @@ template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_H
     DMatrix<int> dofs_, boundary_dofs_;
     SpMatrix<double> stiff_, mass_;
 };
+
+// ---- the type-erased runtime face ---------------------------------------------------------------------------------------
+// How downstream code holds a PDE without knowing its template arguments: fdapde::erase<fdapde::heap_storage, core::PDE__>, made by
+// make_pde (pde/pde.h:117-169 on utils/type_erasure.h:124-160, 209-259).  Same spelling here -- erase<heap_storage, PDE__> -- with the
+// 18 slots of pde.h:120-163 under the same names and signatures.  The reference builds the dispatch table by hand (an array of
+// function pointers indexed by slot number, arguments re-cast at the call site); here the slots are virtual members of a private
+// concept / model pair, which gives the same observable behaviour with checked argument types:
+//   * the handle OWNS a heap copy of the PDE (heap_storage(const T&): new T(obj), type_erasure.h:130) -- the PDE handed to the
+//     constructor is copied, later changes to the original are not seen;
+//   * copying the handle deep-copies the PDE (type_erasure.h:136-146), moving it transfers ownership (148-160); an empty handle
+//     converts to false (vtable_handler::operator bool, type_erasure.h:205);
+//   * set_forcing / set_differential_operator are templates on the handle (pde.h:160-163): the argument must be of the PDE's own
+//     ForcingType / OperatorType.  The reference re-casts the function pointer and has undefined behaviour otherwise; here a mismatch
+//     throws std::runtime_error.  forcing_data() is slot 9's `const DMatrix<double>&` (pde.h:145): for a PDE whose forcing is a
+//     callable it throws.
+// Copies of a PDE share the device context until one of them computes (PDE's copy constructor above), so make_pde's temporary and
+// every handle copy cost no device work by themselves.
+struct heap_storage { };   // storage policy tag (type_erasure.h:124)
+struct PDE__ { };          // interface tag (pde.h:118)
+template <typename StorageType, typename... I> class erase;
+
+template <> class erase<heap_storage, PDE__> {
+   public:
+    using EvalReturnType = fdapde::amd::EvalReturnType;   // PDE__::EvalReturnType (pde.h:148)
+    erase() = default;
+    template <typename T>
+        requires(!std::is_same_v<std::decay_t<T>, erase> && std::is_copy_constructible_v<std::decay_t<T>>)
+    erase(const T& pde) : p_(std::make_unique<model<std::decay_t<T>>>(pde)) { }
+    erase(const erase& other) : p_(other.p_ ? other.p_->clone() : nullptr) { }
+    erase(erase&& other) noexcept = default;
+    erase& operator=(const erase& other) {
+        if (this != &other) p_ = other.p_ ? other.p_->clone() : nullptr;
+        return *this;
+    }
+    erase& operator=(erase&& other) noexcept = default;
+    template <typename T>
+        requires(!std::is_same_v<std::decay_t<T>, erase> && std::is_copy_constructible_v<std::decay_t<T>>)
+    erase& operator=(const T& pde) {
+        p_ = std::make_unique<model<std::decay_t<T>>>(pde);
+        return *this;
+    }
+    operator bool() const { return p_ != nullptr; }
+    // slots 0-1
+    void init() { get().init(); }
+    void solve() { get().solve(); }
+    // slots 2-11: getters
+    const DMatrix<double>& solution() const { return get().solution(); }
+    const DMatrix<double>& force() const { return get().force(); }
+    const SpMatrix<double>& stiff() const { return get().stiff(); }
+    const SpMatrix<double>& mass() const { return get().mass(); }
+    DMatrix<double> quadrature_nodes() const { return get().quadrature_nodes(); }
+    int n_dofs() const { return get().n_dofs(); }
+    DMatrix<double> dof_coords() const { return get().dof_coords(); }
+    const DMatrix<double>& forcing_data() const { return get().forcing_data(); }
+    const DVector<double>& time_domain() const { return get().time_domain(); }
+    const DVector<double>& initial_condition() const { return get().initial_condition(); }
+    // slots 12-13: eval_type 0 = Sampling::pointwise, 1 = Sampling::areal, anything else std::nullopt (pde.h:149-158)
+    std::optional<EvalReturnType> eval_basis(int eval_type, const DMatrix<double>& locs) const { return get().eval_basis(eval_type, locs); }
+    // slots 14-17: setters
+    template <typename ForcingType> void set_forcing(const ForcingType& data) { get().set_forcing(&data, typeid(ForcingType)); }
+    void set_dirichlet_bc(const DMatrix<double>& data) { get().set_dirichlet_bc(data); }
+    void set_initial_condition(const DVector<double>& data) { get().set_initial_condition(data); }
+    template <typename E> void set_differential_operator(E diff_op) { get().set_differential_operator(&diff_op, typeid(E)); }
+    // beyond the reference's slots: the solver flags of the held PDE (fem_solver_base.h:61-62; the reference's handle cannot reach them)
+    bool success() const { return get().success(); }
+
+   private:
+    struct concept_t {
+        virtual ~concept_t() = default;
+        virtual std::unique_ptr<concept_t> clone() const = 0;
+        virtual void init() = 0;
+        virtual void solve() = 0;
+        virtual const DMatrix<double>& solution() const = 0;
+        virtual const DMatrix<double>& force() const = 0;
+        virtual const SpMatrix<double>& stiff() const = 0;
+        virtual const SpMatrix<double>& mass() const = 0;
+        virtual DMatrix<double> quadrature_nodes() const = 0;
+        virtual int n_dofs() const = 0;
+        virtual DMatrix<double> dof_coords() const = 0;
+        virtual const DMatrix<double>& forcing_data() const = 0;
+        virtual const DVector<double>& time_domain() const = 0;
+        virtual const DVector<double>& initial_condition() const = 0;
+        virtual std::optional<EvalReturnType> eval_basis(int eval_type, const DMatrix<double>& locs) const = 0;
+        virtual void set_forcing(const void* data, const std::type_info& type) = 0;
+        virtual void set_dirichlet_bc(const DMatrix<double>& data) = 0;
+        virtual void set_initial_condition(const DVector<double>& data) = 0;
+        virtual void set_differential_operator(const void* diff_op, const std::type_info& type) = 0;
+        virtual bool success() const = 0;
+    };
+    template <typename T> struct model final : concept_t {
+        T pde;
+        explicit model(const T& obj) : pde(obj) { }   // new T(obj): the deep copy of heap_storage (type_erasure.h:130)
+        std::unique_ptr<concept_t> clone() const override { return std::make_unique<model>(pde); }
+        void init() override { pde.init(); }
+        void solve() override { pde.solve(); }
+        const DMatrix<double>& solution() const override { return pde.solution(); }
+        const DMatrix<double>& force() const override { return pde.force(); }
+        const SpMatrix<double>& stiff() const override { return pde.stiff(); }
+        const SpMatrix<double>& mass() const override { return pde.mass(); }
+        DMatrix<double> quadrature_nodes() const override { return pde.quadrature_nodes(); }
+        int n_dofs() const override { return pde.n_dofs(); }
+        DMatrix<double> dof_coords() const override { return pde.dof_coords(); }
+        const DMatrix<double>& forcing_data() const override {
+            if constexpr (std::is_same_v<typename T::ForcingType, DMatrix<double>>) return pde.forcing_data();
+            else throw std::runtime_error("PDE__::forcing_data: the forcing of this PDE is a callable, not a matrix");
+        }
+        const DVector<double>& time_domain() const override { return pde.time_domain(); }
+        const DVector<double>& initial_condition() const override { return pde.initial_condition(); }
+        std::optional<EvalReturnType> eval_basis(int eval_type, const DMatrix<double>& locs) const override { return pde.eval_basis(eval_type, locs); }
+        void set_forcing(const void* data, const std::type_info& type) override {
+            if (type != typeid(typename T::ForcingType)) throw std::runtime_error("PDE__::set_forcing: argument is not of the PDE's ForcingType");
+            pde.set_forcing(*static_cast<const typename T::ForcingType*>(data));
+        }
+        void set_dirichlet_bc(const DMatrix<double>& data) override { pde.set_dirichlet_bc(data); }
+        void set_initial_condition(const DVector<double>& data) override { pde.set_initial_condition(data); }
+        void set_differential_operator(const void* diff_op, const std::type_info& type) override {
+            if (type != typeid(typename T::OperatorType)) throw std::runtime_error("PDE__::set_differential_operator: argument is not of the PDE's OperatorType");
+            pde.set_differential_operator(*static_cast<const typename T::OperatorType*>(diff_op));
+        }
+        bool success() const override { return pde.success(); }
+    };
+    concept_t& get() {
+        if (!p_) throw std::runtime_error("empty PDE handle");
+        return *p_;
+    }
+    const concept_t& get() const {
+        if (!p_) throw std::runtime_error("empty PDE handle");
+        return *p_;
+    }
+    std::unique_ptr<concept_t> p_;
+};
+
+// factory (pde.h:167-169): make_pde<D, E, F, S, Ts...>(args...) constructs PDE<D, E, F, S, Ts...>(args...) and hands back the handle
+template <typename... Args_, typename... Args> erase<heap_storage, PDE__> make_pde(Args&&... args) {
+    return erase<heap_storage, PDE__>(PDE<Args_...>(std::forward<Args>(args)...));
+}
 
 }   // namespace amd
 }   // namespace fdapde

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FDAPDE_ABI_VERSION 3
+#define FDAPDE_ABI_VERSION 4
 
 enum {
     FDAPDE_OK = 0,
@@ -113,6 +113,15 @@ int fdapde_device_count(void);
  * work, every compute call fails with FDAPDE_ENODEVICE). */
 int fdapde_ctx_create(int device, fdapde_ctx **ctx);
 void fdapde_ctx_destroy(fdapde_ctx *ctx);
+/* An independent context (same device) holding the same problem as `src`: mesh, function space and boundary mask, operator / forcing /
+ * Dirichlet data, the assembled stiff_ / mass_ / force_, the solution and the factor-once handle's matrix -- every getter returns what
+ * it returns on `src`, and fdapde_solve / fdapde_lin_solve may be called on it without another fdapde_init.  This is the copy operation
+ * behind the reference's type-erased PDE handle, which deep-copies the PDE with its solver on construction and on every handle copy
+ * (make_pde -> erase<heap_storage, PDE__>: fdaPDE/pde/pde.h:167-169, fdaPDE/utils/type_erasure.h:124-146); the host-side bindings share
+ * one context between copies and clone only when one of them is about to change it (include/fdapde_hip.hpp).  The function space is
+ * rebuilt (same deterministic set-up, bit-identical index arrays), the data are copied device to device; tuning knobs and solver
+ * layouts are not carried over.  A context that is a rank of a multi-GPU job is refused (FDAPDE_EUNSUPPORTED). */
+int fdapde_ctx_clone(const fdapde_ctx *src, fdapde_ctx **out);
 const char *fdapde_last_error(const fdapde_ctx *ctx);
 const char *fdapde_status_string(int status);
 

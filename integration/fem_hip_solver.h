@@ -2,9 +2,19 @@
 // fdaPDE-core (reference @ 2024-10-16), include it from fdaPDE/finite_elements.h, and link libfdapde_hip.so.  User code then
 // changes one template argument:   PDE<decltype(mesh), decltype(L), DMatrix<double>, FEM_HIP, fem_order<1>> pde(mesh, L);
 //
+// The operator expression stays one built from the reference's FEM leaves (laplacian<FEM>(), advection<FEM>(b) ...: their weak forms are
+// what this file reads); FEM_HIP is the STRATEGY argument only -- it selects the solver type, exactly what pde_solver_selector is for.
+//
 // NOT COMPILED IN THIS REPOSITORY'S IMAGE: it needs the reference tree and Eigen 3.4, which the image lacks (Oracle).
 // The same binding written on Eigen-free containers -- include/fdapde_amd/pde.h -- is what tests/cpp/fem_pde_test.cpp compiles and
-// runs; this file is that binding expressed in the reference's own types.  Reference members it plugs into / replaces:
+// runs; this file is that binding expressed in the reference's own types, desk-checked member by member against the headers it
+// includes (INTEGRATION.md section 2c lists every use with the file:line it was checked against).
+// Copies: the reference's type-erased PDE handle deep-copies the PDE with its solver (make_pde, pde/pde.h:167-169 ->
+// heap_storage(const T&): new T(obj), utils/type_erasure.h:130; handle copies: 136-146), so the solver types below are COPYABLE: a copy
+// takes FEMSolverBase's members (basis, matrices, flags) as any copy does and SHARES the device context; the first object that is about
+// to change the context's problem state leaves with a clone of it (fdapde::hip::context_handle, include/fdapde_hip.hpp ->
+// fdapde_ctx_clone).  make_pde<D, E, F, FEM_HIP, fem_order<R>>(...) therefore instantiates and costs no device work by itself.
+// Reference members it plugs into / replaces:
 //   pde_solver_selector<S, ...>            fdaPDE/pde/symbols.h:36, finite_elements/solvers/fem_solver_selector.h:29-33
 //   FEMSolverBase::init                    finite_elements/solvers/fem_solver_base.h:104-139
 //   FEMSolverBase::set_dirichlet_bc        fem_solver_base.h:142-155
@@ -19,7 +29,8 @@
 #include <stdexcept>
 #include <vector>
 
-#include <fdapde_hip.h>   // this repository's C ABI (include/)
+#include <fdapde_hip.h>     // this repository's C ABI (include/)
+#include <fdapde_hip.hpp>   // copy-on-write owner of a fdapde_ctx (header-only, no Eigen)
 
 #include "../../pde/differential_operators.h"   // is_parabolic<E>
 #include "../../pde/symbols.h"
@@ -69,7 +80,7 @@ template <int M, int N, int R, typename E> CollapsedOperator to_terms(const E& o
     using Nabla = decltype(std::declval<Poly>().derive());
     Poly psi_i, psi_j;
     Nabla nabla_i, nabla_j;
-    Matrix<M, N, M> invJ = Matrix<M, N, M>::Identity();
+    Matrix<M, N, M> invJ(SMatrix<N, M>::Identity());   // Matrix<N_, M_, K_> wraps an SMatrix<M_, K_> (fields/matrix_expressions.h:191-203); M == N here
     DVector<double> f;
     auto mem_buffer = std::make_tuple(ScalarPtr(&psi_i), ScalarPtr(&psi_j), VectorPtr(&nabla_i), VectorPtr(&nabla_j), MatrixPtr(&invJ), &f);
     auto weak_form = op.integrate(mem_buffer);
@@ -124,28 +135,33 @@ template <typename D, typename E, typename F, typename... Ts>
 struct FEMHipSolverBase : public FEMSolverBase<D, E, F, Ts...> {   // keeps basis_, integrator_, the getters and the flags
     using Base = FEMSolverBase<D, E, F, Ts...>;
     static constexpr int M = D::local_dim, N = D::embed_dim, R = Base::fem_order;
-    fdapde_ctx* ctx_ = nullptr;
+    fdapde::hip::context_handle ctx_;   // shared between copies of the solver until one of them changes it (copy-on-write)
 
-    FEMHipSolverBase(const D& domain) : Base(domain) {
-        if (fdapde_ctx_create(/*device*/ 0, &ctx_) != FDAPDE_OK) throw std::runtime_error("FEM_HIP: no HIP device (there is no CPU fallback)");
-        DMatrix<int, Eigen::RowMajor> cells = domain.cells();                 // row-major int32 0-based (triangulation.h:120)
+    FEMHipSolverBase() = default;                                             // (FEMSolverBase is default constructible too, fem_solver_base.h:48)
+    FEMHipSolverBase(const D& domain) : Base(domain), ctx_(/*device*/ 0) {    // throws without a HIP device: there is no CPU fallback
+        DMatrix<int, Eigen::RowMajor> cells = domain.cells();                 // row-major int32 0-based (triangulation.h:64, 120)
         std::vector<uint8_t> bnd(domain.n_nodes());
-        for (int i = 0; i < domain.n_nodes(); ++i) bnd[i] = domain.is_node_on_boundary(i);
-        check(fdapde_mesh_upload(ctx_, M, N, domain.n_nodes(), domain.nodes().data() /* column-major, triangulation.h:119 */,
+        for (int i = 0; i < domain.n_nodes(); ++i) bnd[i] = domain.is_node_on_boundary(i);   // triangulation.h:62
+        check(fdapde_mesh_upload(ctx_.get(), M, N, domain.n_nodes(), domain.nodes().data() /* column-major, triangulation.h:63, 119 */,
                                  domain.n_cells(), cells.data(), bnd.data()));
         std::int64_t n = 0;
-        check(fdapde_dofs_build(ctx_, R, &n));                                // same numbering as basis_.dofs(), bit for bit
+        check(fdapde_dofs_build(ctx_.get(), R, &n));                          // same numbering as basis_.dofs(), bit for bit
     }
-    FEMHipSolverBase(const FEMHipSolverBase&) = delete;                      // one device context per solver object
-    FEMHipSolverBase& operator=(const FEMHipSolverBase&) = delete;
-    ~FEMHipSolverBase() { fdapde_ctx_destroy(ctx_); }
+    // copy / move: the members' own (heap_storage copies the PDE, the PDE copies its solver_: pde.h:112, type_erasure.h:130); the device
+    // context is shared until the copy or the original computes
+    FEMHipSolverBase(const FEMHipSolverBase&) = default;
+    FEMHipSolverBase(FEMHipSolverBase&&) = default;
+    FEMHipSolverBase& operator=(const FEMHipSolverBase&) = default;
+    FEMHipSolverBase& operator=(FEMHipSolverBase&&) = default;
+    ~FEMHipSolverBase() = default;
 
     template <typename PDE> void init(const PDE& pde) {                       // replaces fem_solver_base.h:104-139
         static_assert(is_pde<PDE>::value, "pde is not a valid PDE object");
         this->n_dofs_ = this->basis_.size(), this->dofs_ = this->basis_.dofs(), this->boundary_dofs_ = this->basis_.boundary_dofs();
         const std::int64_t rows = (std::int64_t)this->integrator_.num_nodes() * pde.domain().n_cells();
         auto op = hip_detail::to_terms<M, N, R>(pde.differential_operator(), rows);
-        check(fdapde_set_operator(ctx_, (int32_t)op.terms.size(), op.terms.data()));
+        fdapde_ctx* const ctx = ctx_.unique();                                // (a copy that still shares the context leaves with a clone here)
+        check(fdapde_set_operator(ctx, (int32_t)op.terms.size(), op.terms.data()));
         // forcing at the quadrature nodes, row nq * cell + q (integrator.h:85); a callable forcing is sampled at quadrature_nodes()
         // first, exactly what Integrator::integrate does with it (integrator.h:80-81).  Columns: the reference discretises column 0
         // always and the others only for a parabolic operator (fem_solver_base.h:118-128) -- the same count is handed over here
@@ -157,26 +173,27 @@ struct FEMHipSolverBase : public FEMSolverBase<D, E, F, Ts...> {   // keeps basi
         } else
             fq = pde.forcing_data();
         const int32_t cols = is_parabolic<E>::value ? (int32_t)fq.cols() : 1;
-        check(fdapde_set_forcing(ctx_, fq.data(), cols));                    // DMatrix is column-major: the leading `cols` columns
-        check(fdapde_init(ctx_, nullptr));
-        hip_detail::fetch(ctx_, FDAPDE_MAT_STIFF, this->n_dofs_, this->stiff_);
-        hip_detail::fetch(ctx_, FDAPDE_MAT_MASS, this->n_dofs_, this->mass_);
+        check(fdapde_set_forcing(ctx, fq.data(), cols));                    // DMatrix is column-major: the leading `cols` columns
+        check(fdapde_init(ctx, nullptr));
+        hip_detail::fetch(ctx, FDAPDE_MAT_STIFF, this->n_dofs_, this->stiff_);
+        hip_detail::fetch(ctx, FDAPDE_MAT_MASS, this->n_dofs_, this->mass_);
         this->force_.resize(this->n_dofs_ * fq.cols(), 1);                    // (the reference sizes it n * m whatever the operator, line 119)
         this->force_.setZero();
-        check(fdapde_force(ctx_, this->force_.data()));                      // fills the first n * cols entries
+        check(fdapde_force(ctx, this->force_.data()));                      // fills the first n * cols entries
         this->is_init = true;
     }
     template <typename PDE> void set_dirichlet_bc(const PDE& pde) {           // replaces fem_solver_base.h:142-155
         if (!this->is_init) throw std::runtime_error("solver must be initialized first!");
-        if constexpr (!is_parabolic<E>::value) check(fdapde_set_dirichlet(ctx_, pde.boundary_data().data()));   // indexed by DOF id (fem_solver_base.h:152)
+        if constexpr (!is_parabolic<E>::value) {
+            if (pde.boundary_data().rows() != this->n_dofs_) throw std::runtime_error("FEM_HIP: boundary data must have one row per DOF");
+            check(fdapde_set_dirichlet(ctx_.unique(), pde.boundary_data().data()));   // column 0, indexed by DOF id (fem_solver_base.h:152)
+        }
         // (parabolic: the reference's set_dirichlet_bc touches column 0 of the data and the steady matrix only, while the time stepper
         //  imposes column i + 1 at step i itself, fem_linear_parabolic_solver.h:51-55,64-67 -- the data travel with solve() below)
-        dirichlet_set_ = true;
     }
    protected:
-    bool dirichlet_set_ = false;
     void check(int rc) const {
-        if (rc != FDAPDE_OK) throw std::runtime_error(fdapde_last_error(ctx_));
+        if (rc != FDAPDE_OK) throw std::runtime_error(fdapde_last_error(ctx_.get()));
     }
 };
 
@@ -187,16 +204,17 @@ struct FEMHipEllipticSolver : public FEMHipSolverBase<D, E, F, Ts...> {
     template <typename PDE> void solve(const PDE&) {                          // replaces fem_linear_elliptic_solver.h:34-50
         if (!this->is_init) throw std::runtime_error("solver must be initialized first!");
         fdapde_info info;
-        const int rc = fdapde_solve(this->ctx_, nullptr, &info);
+        fdapde_ctx* const ctx = this->ctx_.unique();                          // (the clone of a shared context carries stiff_ / force_: no second init)
+        const int rc = fdapde_solve(ctx, nullptr, &info);
         if (rc == FDAPDE_ENOCONV) {                                           // <-> the reference's success = false (lines 42-45)
             this->success = false;
             return;
         }
         this->check(rc);
         this->solution_.resize(this->n_dofs_, 1);
-        this->check(fdapde_solution(this->ctx_, this->solution_.data()));
-        hip_detail::fetch(this->ctx_, FDAPDE_MAT_STIFF, this->n_dofs_, this->stiff_);   // the row-zeroed matrix the reference leaves behind
-        this->check(fdapde_force(this->ctx_, this->force_.data()));          // boundary rows = g
+        this->check(fdapde_solution(ctx, this->solution_.data()));
+        hip_detail::fetch(ctx, FDAPDE_MAT_STIFF, this->n_dofs_, this->stiff_);   // the row-zeroed matrix the reference leaves behind
+        this->check(fdapde_force(ctx, this->force_.data()));                 // boundary rows = g
         this->success = true;
     }
 };
@@ -221,12 +239,16 @@ struct FEMHipParabolicSolver : public FEMHipSolverBase<D, E, F, Ts...> {
         const std::size_t m = pde.forcing_data().cols();                      // time points (line 44)
         this->solution_.resize(n, m);
         const DVector<double> u0 = pde.initial_condition();                   // column 0 of the solution (line 46)
-        // Dirichlet data n_dofs x m, column i + 1 imposed at step i (lines 64-67); no boundary DOF, or PDE::solve did not call
-        // set_dirichlet_bc (pde.h:102-105: boundary data empty): natural conditions
+        // The reference's loop ALWAYS zeroes the boundary rows of K and imposes boundary_data()(dof, i + 1) at step i (lines 51-55, 64-67),
+        // whether or not set_dirichlet_bc ran: so the data are imposed whenever they are there -- n_dofs x (at least m); data of another
+        // shape are an error here (the reference would index out of range).  Only EMPTY boundary data -- which the reference cannot run
+        // on a mesh with boundary DOFs at all -- gives natural conditions.
         const DMatrix<double>& g = pde.boundary_data();
-        const bool with_bc = this->dirichlet_set_ && g.rows() == (Eigen::Index)n && g.cols() >= (Eigen::Index)m;
+        const bool with_bc = !is_empty(g);
+        if (with_bc && (g.rows() != (Eigen::Index)n || g.cols() < (Eigen::Index)m))
+            throw std::runtime_error("FEM_HIP: boundary data of a parabolic problem must be n_dofs x n_times");
         fdapde_info info;
-        const int rc = fdapde_solve_parabolic(this->ctx_, nullptr, (int32_t)m, deltaT_, u0.data(), with_bc ? g.data() : nullptr,
+        const int rc = fdapde_solve_parabolic(this->ctx_.unique(), nullptr, (int32_t)m, deltaT_, u0.data(), with_bc ? g.data() : nullptr,
                                               this->solution_.data() /* column-major n x m */, &info);
         if (rc == FDAPDE_ENOCONV) {                                           // <-> solver.info() != Eigen::Success (lines 57-60)
             this->success = false;

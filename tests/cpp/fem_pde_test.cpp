@@ -240,6 +240,60 @@ TEST(fem_pde_test, parabolic_isotropic_order2) {
     }
     EXPECT_TRUE(worst < 1e-7);
 }
+// fem_pde_test.cpp:295-368: convergence order of the parabolic solve, P1, fixed time step, on the structured fixtures.  The reference
+// refines 16 / 32 / 64 / 128; unit_square_128 (3 MB of CSV) is not among the committed fixtures, so the order is checked on the
+// first two halvings -- the same criterion, floor(log2(e_h / e_{h/2})) == 2.
+TEST(fem_pde_test, parabolic_isotropic_order1_convergence) {
+    constexpr double pi = 3.14159265358979323846;
+    const int M = 31;
+    DMatrix<double> times(M, 1);
+    const double time_max = 1.;
+    for (int j = 0; j < M; ++j) times(j) = time_max / (M - 1) * j;
+    const int num_refinements = 3;
+    const int N[num_refinements] = {16, 32, 64};
+    DMatrix<double> error_L2(M, num_refinements, 0.0);
+    auto solution_expr = [](std::array<double, 3> x, double t) -> double { return std::sin(2 * pi * x[0]) * std::sin(2 * pi * x[1]) * std::exp(-t); };
+    auto forcing_expr = [](double x0, double x1, double t) -> double {
+        return (8 * pi * pi - 1.) * std::sin(2 * pi * x0) * std::sin(2 * pi * x1) * std::exp(-t);
+    };
+    for (int n = 0; n < num_refinements; ++n) {
+        FixtureMesh<2, 2> unit_square("unit_square_" + std::to_string(N[n]));
+        auto L = dt<FEM_HIP>() - laplacian<FEM_HIP>();
+        PDE<Triangulation<2, 2>, decltype(L), DMatrix<double>, FEM_HIP, fem_order<1>> pde_(unit_square.mesh, times);
+        pde_.set_differential_operator(L);
+        DMatrix<double> nodes_ = pde_.dof_coords();
+        DMatrix<double> dirichlet_bc(nodes_.rows(), M), solution_ex(nodes_.rows(), M), initial_condition(nodes_.rows(), 1);
+        for (int64_t i = 0; i < nodes_.rows(); ++i)
+            for (int j = 0; j < M; ++j) dirichlet_bc(i, j) = solution_ex(i, j) = solution_expr(nodes_.row3(i), times(j));
+        for (int64_t i = 0; i < nodes_.rows(); ++i) initial_condition(i) = solution_expr(nodes_.row3(i), times(0));
+        pde_.set_dirichlet_bc(dirichlet_bc);
+        pde_.set_initial_condition(initial_condition);
+        DMatrix<double> quadrature_nodes = pde_.quadrature_nodes();
+        DMatrix<double> f(quadrature_nodes.rows(), M);
+        for (int64_t i = 0; i < quadrature_nodes.rows(); ++i)
+            for (int j = 0; j < M; ++j) f(i, j) = forcing_expr(quadrature_nodes(i, 0), quadrature_nodes(i, 1), times(j));
+        pde_.set_forcing(f);
+        pde_.init();
+        pde_.solve();
+        EXPECT_TRUE(pde_.success());
+        for (int j = 0; j < M; ++j) {
+            DMatrix<double> e2(nodes_.rows(), 1);
+            for (int64_t i = 0; i < nodes_.rows(); ++i) {
+                const double e = solution_ex(i, j) - pde_.solution()(i, j);
+                e2(i) = e * e;
+            }
+            DMatrix<double> Me = pde_.mass() * e2;
+            double s = 0;
+            for (int64_t i = 0; i < Me.rows(); ++i) s += Me(i);
+            error_L2(j, n) = std::sqrt(s);
+        }
+    }
+    for (int n = 1; n < num_refinements; ++n) {
+        const double order = std::log2(error_L2(M - 1, n - 1) / error_L2(M - 1, n));
+        EXPECT_TRUE(std::floor(order) == 2);
+    }
+}
+
 // fdapde::SparseLU usage pattern (utils/symbols.h:133-160, linear_algebra/smw.h:46-48): factor once, solve many columns
 TEST(sparse_solver_test, factor_once_solve_many) {
     FixtureMesh<2, 2> m("unit_square_32");
@@ -448,11 +502,176 @@ TEST(csv_reader_test, sparse_three_column_format) {
     std::remove(tmp.c_str());
 }
 
+// ---- the type-erased face: make_pde / erase<heap_storage, PDE__> (pde/pde.h:117-169, utils/type_erasure.h:124-160) -----------------
+// What downstream models do with a PDE: build it through make_pde, keep the handle by value, copy it around.  Every copy is a deep
+// copy of the PDE in the reference; here copies share the device context until one of them computes (include/fdapde_hip.hpp).
+using ErasedPDE = erase<heap_storage, PDE__>;
+static double handle_l2_error(const ErasedPDE& pde, double (*u)(std::array<double, 3>)) {
+    DMatrix<double> nodes = pde.dof_coords(), e2(nodes.rows(), 1);
+    for (int64_t i = 0; i < nodes.rows(); ++i) {
+        const double err = u(nodes.row3(i)) - pde.solution()(i);
+        e2(i) = err * err;
+    }
+    DMatrix<double> Me = pde.mass() * e2;
+    double s = 0;
+    for (int64_t i = 0; i < Me.rows(); ++i) s += Me(i);
+    return s;
+}
+static double u_linear(std::array<double, 3> x) { return x[0] + x[1]; }
+static double u_bowl(std::array<double, 3> x) { return 1. - x[0] * x[0] - x[1] * x[1]; }
+TEST(type_erasure_test, make_pde_copy_the_handle_solve_both) {
+    FixtureMesh<2, 2> unit_square("unit_square");
+    auto L = -laplacian<FEM_HIP>();
+    using PDE_ = PDE<Triangulation<2, 2>, decltype(L), DMatrix<double>, FEM_HIP, fem_order<2>>;
+    ErasedPDE a = make_pde<Triangulation<2, 2>, decltype(L), DMatrix<double>, FEM_HIP, fem_order<2>>(unit_square.mesh, L);
+    EXPECT_TRUE(bool(a) && !bool(ErasedPDE()));
+    EXPECT_TRUE(a.n_dofs() == 14161);
+    DMatrix<double> nodes = a.dof_coords(), quadrature_nodes = a.quadrature_nodes();
+    DMatrix<double> g_linear(nodes.rows(), 1), g_bowl(nodes.rows(), 1);
+    for (int64_t i = 0; i < nodes.rows(); ++i) g_linear(i) = u_linear(nodes.row3(i)), g_bowl(i) = u_bowl(nodes.row3(i));
+    // problem A: -lap u = 0, u = x + y on the boundary (fem_pde_test.cpp:43-75)
+    a.set_dirichlet_bc(g_linear);
+    a.set_forcing(DMatrix<double>::Zero(quadrature_nodes.rows(), 1));
+    // the copy gets problem B: -lap u = 4, u = 1 - x^2 - y^2 (fem_pde_test.cpp:78-107).  Neither has touched the device yet.
+    ErasedPDE b = a;
+    b.set_forcing(DMatrix<double>(quadrature_nodes.rows(), 1, 4.0));
+    b.set_dirichlet_bc(g_bowl);
+    EXPECT_TRUE(a.forcing_data()(0) == 0.0 && b.forcing_data()(0) == 4.0);   // two PDEs, not two views of one
+    a.init(), b.init();   // (the second init leaves the shared context with a clone of its own)
+    a.solve(), b.solve();
+    EXPECT_TRUE(a.success() && b.success());
+    EXPECT_TRUE(handle_l2_error(a, u_linear) < DOUBLE_TOLERANCE);
+    EXPECT_TRUE(handle_l2_error(b, u_bowl) < DOUBLE_TOLERANCE);
+    // a copy taken AFTER init carries stiff_ / mass_ / force_ with it: new boundary data and solve(), no second init -- and the
+    // original is untouched by what the copy does (reference: the solver's matrices are part of the deep copy)
+    ErasedPDE c = b;
+    DMatrix<double> g_shift = g_bowl;
+    for (int64_t i = 0; i < g_shift.rows(); ++i) g_shift(i) += 1.0;   // u + 1 solves the same equation with the shifted data
+    c.set_dirichlet_bc(g_shift);
+    c.solve();
+    EXPECT_TRUE(c.success());
+    double worst_c = 0, worst_b = 0;
+    for (int64_t i = 0; i < nodes.rows(); ++i) worst_c = std::fmax(worst_c, std::fabs(c.solution()(i) - b.solution()(i) - 1.0));
+    EXPECT_TRUE(worst_c < 1e-7);
+    DMatrix<double> b_before = b.solution();
+    b.solve();   // the context b computes on still holds b's problem
+    for (int64_t i = 0; i < nodes.rows(); ++i) worst_b = std::fmax(worst_b, std::fabs(b.solution()(i) - b_before(i)));
+    EXPECT_TRUE(worst_b == 0.0);
+    EXPECT_TRUE(handle_l2_error(b, u_bowl) < DOUBLE_TOLERANCE);
+    // moving transfers ownership (type_erasure.h:148-160); assignment from a handle deep-copies (136-146)
+    ErasedPDE d = std::move(c);
+    EXPECT_TRUE(bool(d) && !bool(c));
+    c = a;
+    EXPECT_TRUE(bool(c) && c.n_dofs() == a.n_dofs() && handle_l2_error(c, u_linear) < DOUBLE_TOLERANCE);
+    // typed setters of the erased interface (pde.h:160-163): the PDE's own types pass, others are refused
+    bool refused = false;
+    try { d.set_forcing(ScalarField<2>([](const std::array<double, 2>&) { return 1.0; })); } catch (const std::runtime_error&) { refused = true; }
+    EXPECT_TRUE(refused);
+    d.set_differential_operator(-laplacian<FEM_HIP>() + reaction<FEM_HIP>(1.0));
+    d.init();
+    EXPECT_TRUE(d.stiff().nonZeros() == a.stiff().nonZeros() && d.stiff().values != a.stiff().values);
+    // the PDE object itself is copyable the same way (PDE(const PDE&)): what heap_storage's `new T(obj)` needs
+    PDE_ direct(unit_square.mesh, L);
+    PDE_ twin(direct);
+    twin.set_forcing(DMatrix<double>::Zero(quadrature_nodes.rows(), 1));
+    twin.set_dirichlet_bc(g_linear);
+    twin.init();
+    twin.solve();
+    EXPECT_TRUE(twin.success() && !direct.is_init());
+    EXPECT_TRUE(l2_error(twin, u_linear) < DOUBLE_TOLERANCE);
+}
+// the other slots through the handle: eval_basis (12-13) against the golden matrix, space-time slots (10, 11, 16) on a parabolic PDE
+TEST(type_erasure_test, eval_basis_and_space_time_slots) {
+    {
+        FixtureMesh<2, 2> m("c_shaped");
+        auto L = -laplacian<FEM_HIP>();
+        ErasedPDE pde = make_pde<Triangulation<2, 2>, decltype(L), DMatrix<double>, FEM_HIP, fem_order<1>>(m.mesh, L);
+        ErasedPDE copy = pde;   // evaluation reads the context only: both handles use the one they share
+        DMatrix<double> locs = read_csv<double>(MESH_PATH + "/c_shaped/locs.csv");
+        auto res = copy.eval_basis(0, locs);
+        EXPECT_TRUE(res.has_value());
+        SpMatrix<double> gold = read_mtx(MESH_PATH + "/../mtx/lagrangian_pointwise_eval_order1.mtx");
+        EXPECT_TRUE(max_abs_diff(res->Psi, gold) < 1e-12);
+        EXPECT_TRUE(!pde.eval_basis(2, locs).has_value());
+    }
+    {
+        constexpr double pi = 3.14159265358979323846;
+        const int M = 11;
+        DMatrix<double> times(M, 1);
+        for (int j = 0; j < M; ++j) times(j) = 0.1 * j;
+        FixtureMesh<2, 2> m("unit_square_16");
+        auto L = dt<FEM_HIP>() - laplacian<FEM_HIP>();
+        ErasedPDE pde = make_pde<Triangulation<2, 2>, decltype(L), DMatrix<double>, FEM_HIP, fem_order<1>>(m.mesh, times, L);
+        EXPECT_TRUE(pde.time_domain().rows() == M && pde.time_domain()(M - 1) == times(M - 1));
+        DMatrix<double> nodes = pde.dof_coords(), qn = pde.quadrature_nodes();
+        auto u = [](std::array<double, 3> x, double t) { return std::sin(2 * pi * x[0]) * std::sin(2 * pi * x[1]) * std::exp(-t); };
+        DMatrix<double> g(nodes.rows(), M), u0(nodes.rows(), 1), f(qn.rows(), M);
+        for (int64_t i = 0; i < nodes.rows(); ++i) {
+            u0(i) = u(nodes.row3(i), 0.0);
+            for (int j = 0; j < M; ++j) g(i, j) = u(nodes.row3(i), times(j));
+        }
+        for (int64_t i = 0; i < qn.rows(); ++i)
+            for (int j = 0; j < M; ++j) f(i, j) = (8 * pi * pi - 1.) * std::sin(2 * pi * qn(i, 0)) * std::sin(2 * pi * qn(i, 1)) * std::exp(-times(j));
+        pde.set_dirichlet_bc(g), pde.set_initial_condition(u0), pde.set_forcing(f);
+        EXPECT_TRUE(pde.initial_condition().rows() == nodes.rows());
+        pde.init();
+        ErasedPDE later = pde;   // copied between init and solve
+        pde.solve(), later.solve();
+        EXPECT_TRUE(pde.success() && later.success() && pde.solution().cols() == M);
+        double worst = 0;
+        for (int64_t i = 0; i < nodes.rows(); ++i) worst = std::fmax(worst, std::fabs(pde.solution()(i, M - 1) - later.solution()(i, M - 1)));
+        EXPECT_TRUE(worst == 0.0);   // the clone holds the same bits and runs the same deterministic solve
+    }
+}
+
+// include/fdapde_hip.hpp on a host-only context (no device needed): copies share, the first one that asks for unique() leaves with a
+// clone that rebuilt the same space (fdapde_ctx_clone), observers never count
+TEST(context_handle_test, copy_on_write_host_only) {
+    FixtureMesh<2, 2> m("unit_square_16");
+    fdapde::hip::context_handle a(-1);
+    const int64_t nn = m.mesh.n_nodes(), nc = m.mesh.n_cells();
+    std::vector<int32_t> cells((size_t)nc * 3);
+    std::vector<uint8_t> bnd((size_t)nn);
+    for (int64_t c = 0; c < nc; ++c)
+        for (int v = 0; v < 3; ++v) cells[(size_t)(c * 3 + v)] = m.mesh.cells()(c, v);
+    for (int64_t i = 0; i < nn; ++i) bnd[(size_t)i] = m.mesh.boundary_nodes()(i) != 0;
+    EXPECT_TRUE(fdapde_mesh_upload(a.get(), 2, 2, nn, m.mesh.nodes().data(), nc, cells.data(), bnd.data()) == FDAPDE_OK);
+    int64_t n_dofs = 0;
+    EXPECT_TRUE(fdapde_dofs_build(a.get(), 2, &n_dofs) == FDAPDE_OK && n_dofs == 1089);
+    std::vector<uint8_t> mask((size_t)n_dofs, 0);
+    mask[5] = 1;   // a boundary mask of the caller's own (fdapde_dofs_set_boundary) must travel with the clone
+    EXPECT_TRUE(fdapde_dofs_set_boundary(a.get(), mask.data()) == FDAPDE_OK);
+    EXPECT_TRUE(!a.shared() && a.unique() == a.get());
+    fdapde::hip::context_handle b = a, watcher = a.observer();
+    EXPECT_TRUE(a.shared() && b.get() == a.get() && watcher.get() == a.get());
+    fdapde_ctx* const before = a.get();
+    fdapde_ctx* const mine = b.unique();   // b leaves; a keeps the original and is its only owner again
+    EXPECT_TRUE(mine != before && a.get() == before && !a.shared() && !b.shared() && a.unique() == before);
+    int64_t nd2 = 0, nnz1 = 0, nnz2 = 0;
+    EXPECT_TRUE(fdapde_sizes(mine, &nd2, &nnz2, nullptr, nullptr, nullptr) == FDAPDE_OK && fdapde_sizes(before, nullptr, &nnz1, nullptr, nullptr, nullptr) == FDAPDE_OK);
+    EXPECT_TRUE(nd2 == n_dofs && nnz1 == nnz2);
+    std::vector<int32_t> d1((size_t)nc * 6), d2((size_t)nc * 6), rp1((size_t)n_dofs + 1), rp2((size_t)n_dofs + 1), ci1((size_t)nnz1), ci2((size_t)nnz2);
+    std::vector<uint8_t> m1((size_t)n_dofs), m2((size_t)n_dofs);
+    EXPECT_TRUE(fdapde_dofs_get(before, d1.data(), m1.data(), nullptr) == FDAPDE_OK && fdapde_dofs_get(mine, d2.data(), m2.data(), nullptr) == FDAPDE_OK);
+    EXPECT_TRUE(fdapde_pattern_get(before, rp1.data(), ci1.data()) == FDAPDE_OK && fdapde_pattern_get(mine, rp2.data(), ci2.data()) == FDAPDE_OK);
+    EXPECT_TRUE(d1 == d2 && m1 == m2 && m1 == mask && rp1 == rp2 && ci1 == ci2);
+    {
+        fdapde::hip::context_handle moved = std::move(b);
+        EXPECT_TRUE(!bool(b) && moved.get() == mine);
+        a = moved;   // assignment: a drops its context (the watcher keeps it alive) and shares moved's
+        EXPECT_TRUE(a.get() == mine && a.shared() && watcher.get() == before);
+    }
+    EXPECT_TRUE(!a.shared());   // `moved` is gone
+    int64_t still = 0;
+    EXPECT_TRUE(fdapde_sizes(watcher.get(), &still, nullptr, nullptr, nullptr, nullptr) == FDAPDE_OK && still == n_dofs);
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) { std::printf("usage: %s <tests/golden/mesh> [--io-only]\n", argv[0]); return 2; }
     MESH_PATH = argv[1];
     if (argc > 2 && std::string(argv[2]) == "--io-only") {   // host-side pieces of the facade: no device needed
         RUN(csv_reader_test, sparse_three_column_format);
+        RUN(context_handle_test, copy_on_write_host_only);
         std::printf("%d checks, %d failures\n", checks, failures);
         return failures == 0 ? 0 : 1;
     }
@@ -465,11 +684,15 @@ int main(int argc, char** argv) {
     RUN(fem_pde_test, error_behaviour);
     RUN(fem_pde_test, laplacian_3d_order1);
     RUN(fem_pde_test, parabolic_isotropic_order2);
+    RUN(fem_pde_test, parabolic_isotropic_order1_convergence);
     RUN(sparse_solver_test, factor_once_solve_many);
     RUN(linear_algebra_test, smw_and_lumping);
     RUN(mesh_test, neighbours_and_facets_match_the_fixture_files);
     RUN(lagrangian_basis_test, eval_basis_golden);
+    RUN(type_erasure_test, make_pde_copy_the_handle_solve_both);
+    RUN(type_erasure_test, eval_basis_and_space_time_slots);
     RUN(csv_reader_test, sparse_three_column_format);
+    RUN(context_handle_test, copy_on_write_host_only);
     std::printf("%d checks, %d failures\n", checks, failures);
     return failures == 0 ? 0 : 1;
 }

@@ -70,11 +70,47 @@ class FileRendezvous:
 
     def __init__(self, rank, world):
         self.rank, self.world = rank, world
-        d = os.environ.get("FDAPDE_BENCH_RDZV")
-        if not d:   # under torch.distributed.run: all ranks are children of the same agent process
-            d = os.path.join("/tmp", f"fdapde_rdzv_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}")
+        d = os.environ.get("FDAPDE_BENCH_RDZV")   # (set by _spawn_ranks: a fresh mkdtemp directory, removed by the spawner)
+        self.own = not d
+        if not d:
+            # under torch.distributed.run all ranks are children of ONE agent process: the directory is named after that process INSTANCE --
+            # pid + its start time in clock ticks since boot (field 22 of /proc/<pid>/stat): no earlier run can have had the same pair, so no
+            # stale 'form', 'rccl_id' or 'problem.N' of a previous job is ever read (same port, default run id and a recycled pid included)
+            ppid = os.getppid()
+            try:
+                with open(f"/proc/{ppid}/stat") as f:
+                    born = f.read().rsplit(")", 1)[1].split()[19]
+            except Exception:
+                born = "0"
+            d = os.path.join("/tmp", f"fdapde_rdzv_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{ppid}_{born}")
         self.dir = d
         os.makedirs(d, exist_ok=True)
+
+    def consume(self, key):
+        """get + delete: blobs addressed to ONE rank (its sub-mesh: ~25 MB per rank at C3 size) do not outlive their reader"""
+        data = self.get(key)
+        try:
+            os.remove(self.path(key))
+        except OSError:
+            pass
+        return data
+
+    def finish(self, timeout=120.0):
+        """every rank says goodbye; rank 0 waits for all of them and removes the directory it named itself (a directory handed in by
+        _spawn_ranks is removed by the spawner)"""
+        import shutil
+
+        try:
+            self.put(f"bye.{self.rank}", b"1")
+            if self.rank == 0 and self.own:
+                for r in range(self.world):
+                    try:
+                        self.get(f"bye.{r}", timeout=timeout)
+                    except TimeoutError:
+                        break   # (a rank that died: clean up anyway)
+                shutil.rmtree(self.dir, ignore_errors=True)
+        except OSError:
+            pass
 
     def path(self, key):
         return os.path.join(self.dir, key)
@@ -404,18 +440,20 @@ def choose_form(rdzv, rank, world):
     forces a form)."""
     form = os.environ.get("FDAPDE_BENCH_EXCHANGE", "auto")
     if form != "auto":
-        return form
+        return form, f"not run (FDAPDE_BENCH_EXCHANGE={form} forces the form)"
     if rank == 0:
         rc = _spawn_ranks(world, ["--gpus", str(world)], {"FDAPDE_BENCH_CANARY": "1"}, timeout=600)
         if rc != 0:
             print(f"bench.py: the row-distributed canary job failed (exit code {rc}); using the RCCL neighbour exchange", file=sys.stderr)
-        rdzv.put("form", b"rowdist" if rc == 0 else b"peers")
-    return rdzv.get("form").decode()
+        verdict = "passed: a row-distributed solve between these devices converged on every rank" if rc == 0 else f"FAILED (exit code {rc}): fell back to the RCCL neighbour exchange"
+        rdzv.put("form", (("rowdist" if rc == 0 else "peers") + "\n" + verdict).encode())
+    form, verdict = rdzv.get("form").decode().split("\n", 1)
+    return form, verdict
 
 
 def run_ranks(args, rank, world, local_rank):
     rdzv = FileRendezvous(rank, world)
-    form = choose_form(rdzv, rank, world)   # (may run a job of its own on the GPUs: nothing of this process has touched them yet)
+    form, canary_verdict = choose_form(rdzv, rank, world)   # (may run a job of its own on the GPUs: nothing of this process has touched them yet)
     from fdapde_loader import load_package
 
     load_package()   # the library first: the process binds to /opt/rocm's HIP runtime, and RCCL is taken from the same installation
@@ -434,6 +472,7 @@ def run_ranks(args, rank, world, local_rank):
                          "FDAPDE_BENCH_BACKEND=gloo runs the plumbing with ranks sharing devices)")
     share = (world + n_dev - 1) // n_dev
     out = fdist.bench_partitioned(capi, rdzv, rank, world, local_rank % n_dev, args, RTOL, backend, form, share)
+    rdzv.finish()
     if rank != 0:
         return
     res = out
@@ -471,9 +510,18 @@ def run_ranks(args, rank, world, local_rank):
             "us_per_iteration": 1e3 * res["t_sol"] / max(int(info.iters), 1),
             "transport": res["transport"],
             "exchange_form": res["form"],
+            # what the collectives really ran over: ncclCommCount of the library's communicator (the registered world size under the gloo plumbing)
+            "comm_ranks": res["comm_ranks"],
+            "devices_visible": n_dev,
+            "ranks_per_device": share,
+            "canary": canary_verdict,
+            "fallback": res.get("fallback"),
+            # in-kernel phase stamps (persistent launches): per iteration, the SLOWEST rank's figure and the mean over the ranks
+            "phase_stamps_us_per_iteration": res["phases"],
         },
         "roofline": roofline_of(res["infos"], res["alg_bytes"], res["streamed_bytes"], args.nx, world),
     }
+    line["extra"] = {"rccl_neighbour_exchange": res.get("other")}   # north_star's own form ("RCCL all-reduce of halo DOF contributions") next to the chosen one
     line["roofline"]["note"] = "the largest rank-local operator"
     if res["form"] == "rowdist":   # a rank's share of C3 is (nearly) resident in its LDS: the iteration is hand-off latency, not an HBM stream
         line["roofline"].update(bound="latency", achieved=None, frac=None,
@@ -484,6 +532,9 @@ def run_ranks(args, rank, world, local_rank):
 
 
 def main():
+    # cross-process hipIpc on this pool needs the dmabuf IPC mode; set BEFORE anything loads the HIP runtime, and in every kind of rank process
+    # (self-launched, canary, started by torch.distributed.run), so that the canary's verdict holds for the ranks that follow it
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     args = parse()
     if args.nx is None:
         args.nx = 87 if args.workload == "c5" else 119

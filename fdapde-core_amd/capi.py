@@ -47,7 +47,7 @@ SYMBOLS = [
     "fdapde_info_get", "fdapde_spmv", "fdapde_bench_spmv", "fdapde_tune", "fdapde_stream", "fdapde_synchronize",
     "fdapde_comm_unique_id", "fdapde_comm_init", "fdapde_halo_setup", "fdapde_solve_parabolic",
     "fdapde_lin_compute", "fdapde_lin_solve", "fdapde_eval_pointwise", "fdapde_cell_integrals", "fdapde_comm_init_callback", "fdapde_comm_set_exchange_callback", "fdapde_halo_setup_peers",
-    "fdapde_solver_layout", "fdapde_topology_build", "fdapde_topology_get", "fdapde_comm_allreduce", "fdapde_comm_library", "fdapde_solver_layout_kind", "fdapde_rowdist_setup", "fdapde_ctx_clone",
+    "fdapde_solver_layout", "fdapde_topology_build", "fdapde_topology_get", "fdapde_comm_allreduce", "fdapde_comm_library", "fdapde_solver_layout_kind", "fdapde_rowdist_setup", "fdapde_ctx_clone", "fdapde_comm_count",
 ]
 
 _lib = None
@@ -439,6 +439,12 @@ class Context:
         a = np.ascontiguousarray(np.asarray(values, dtype=float)).copy()
         self._check(self.lib.fdapde_comm_allreduce(self._ctx, _dp(a), int(a.size), 0 if op == "sum" else 1))
         return a
+
+    def comm_count(self):
+        """ranks of the communicator as RCCL reports them (ncclCommCount); the registered world size under the host-staged transport"""
+        n = C.c_int32(0)
+        self._check(self.lib.fdapde_comm_count(self._ctx, C.byref(n)))
+        return int(n.value)
 
     @staticmethod
     def comm_library():

@@ -271,6 +271,10 @@ int fdapde_comm_allreduce(fdapde_ctx* c, double* host_inout, int32_t n, int32_t 
     if (!c) return FDAPDE_EINVAL;
     return fdapde_engine::e_comm_allreduce(c, host_inout, n, op);
 }
+int fdapde_comm_count(fdapde_ctx* c, int32_t* ranks) {
+    if (!c) return FDAPDE_EINVAL;
+    return fdapde_engine::e_comm_count(c, ranks);
+}
 int fdapde_comm_init_callback(fdapde_ctx* c, int32_t world, int32_t rank, fdapde_allreduce_fn fn, void* user) {
     if (!c) return FDAPDE_EINVAL;
     return fdapde_engine::e_comm_init_callback(c, world, rank, fn, user);

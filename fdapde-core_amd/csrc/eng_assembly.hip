@@ -157,6 +157,10 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
         else if (a.fq != nullptr && a.fq == c->fq.p && c->fq_bc_ready) a.fq = c->fq_bc.p, a.fq_block = 2;   // column 0: samples in block-cell order
         const int grid = 8 * (int)(((hs.n_dofs + kAsmBlock - 1) / kAsmBlock + 7) / 8);   // 8 XCD bands of blocks (k_assemble_rows)
         size_t lds = tab + (fuse_mass ? 2 : 1) * acc;
+        if (std::getenv("FDAPDE_DEBUG_ASM"))
+            std::fprintf(stderr, "assembly launch <%d,%d> opk %d: grid %d x %d, LDS %zu B (tables %zu + accumulators %zu%s), max block nnz %d nodes %d cells %d, %s\n", M, R, opk,
+                         grid, kAsmBlock, lds, tab, acc, fuse_mass ? " x 2" : "", hs.max_blk_nnz, hs.max_blk_nodes, hs.max_blk_cells,
+                         fuse_mass ? "mass fused (two ranges)" : seq_mass ? "mass as second pass" : "operator only");
         if (fuse_mass) {
             if (lds > 64 * 1024) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_assemble_rows<M, R, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -113,6 +113,22 @@ int e_comm_init(fdapde_ctx* c, int32_t world, int32_t rank, const void* unique_i
     return FDAPDE_OK;
 }
 
+// how many ranks the context's communicator REALLY has -- asked of RCCL itself (ncclCommCount), not echoed from what the caller passed to
+// fdapde_comm_init: a bench line that says "8 GPUs" should be able to prove that its collective ran over 8 ranks.  Host-staged transport: the
+// world size the callback was registered with.  No communicator: 1.
+int e_comm_count(fdapde_ctx* c, int32_t* ranks) {
+    if (!c || !ranks) return FDAPDE_EINVAL;
+    *ranks = 1;
+    if (c->comm) {
+        if (!g_rccl.CommCount) return fail(c, FDAPDE_EUNSUPPORTED, "this librccl has no ncclCommCount");
+        int n = 0;
+        RCCLCHK(c, g_rccl.CommCount(c->comm, &n));
+        *ranks = n;
+    } else if (c->ar_fn)
+        *ranks = c->world;
+    return FDAPDE_OK;
+}
+
 // sum (op 0) or max (op 1) of n host doubles over the ranks of the context's communicator, in place: the barrier / timing reductions of a
 // multi-process driver that holds no other collective library (bench.py's ranks load this library and nothing else that touches the GPU)
 int e_comm_allreduce(fdapde_ctx* c, double* host_inout, int32_t n, int32_t op) {

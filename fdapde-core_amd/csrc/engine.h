@@ -95,6 +95,7 @@ int e_bench_spmv(fdapde_ctx* c, int32_t reps, double* avg_ms, double* algorithmi
 int e_comm_unique_id(void* out128);
 int e_comm_init(fdapde_ctx* c, int32_t world, int32_t rank, const void* unique_id128);
 int e_comm_allreduce(fdapde_ctx* c, double* host_inout, int32_t n, int32_t op);
+int e_comm_count(fdapde_ctx* c, int32_t* ranks);
 int e_comm_init_callback(fdapde_ctx* c, int32_t world, int32_t rank, fdapde_allreduce_fn fn, void* user);
 int e_halo_setup(fdapde_ctx* c, int64_t n_if_global, int64_t n_if_local, const int32_t* local_dof, const int32_t* if_index, const uint8_t* owned);
 int e_rowdist_setup(fdapde_ctx* c, const int64_t* dof_key, const int32_t* dof_owner);

@@ -92,6 +92,7 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
     }
     const double bb = a.sc[0];
     int it = 0, status = 0;   // status: 1 converged, 2 breakdown, 3 hand-off timeout
+    bool rr_pending = false;  // a breakdown right after an update: r.r of the returned x still to be summed over the workgroups
     double rr = 0, rho = 0, rho_old = 1.0, alpha = 1.0, omega = 1.0;
     long long tmo = DIST ? (long long)a.timeout_first_ticks : (long long)a.timeout_ticks;
     __syncthreads();
@@ -448,7 +449,7 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
         ++it;
         tmo = (long long)a.timeout_ticks;
         if (omega == 0.0) {
-            status = 2;
+            status = 2, rr_pending = true;   // (x and r were just updated: their r.r has not been summed over the workgroups yet)
             break;
         }
         rho_old = rho, rho = r0s - omega * r0t;   // = r0.r of the new residual
@@ -456,8 +457,11 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
 #pragma unroll
         for (int j = 0; j < R; ++j) pv[j] = rv[j] + beta * (pv[j] - omega * vv[j]);
     }
-    if (status == 2 && it > 0) {   // breakdown noticed after an update: the residual norm of the returned x, summed explicitly
-        // (every workgroup takes this branch together: the scalars are identical everywhere)
+    if (rr_pending) {   // breakdown noticed right AFTER an update (omega = 0): the residual norm of the returned x, summed explicitly.
+        // Every workgroup takes this branch together (the scalars are identical everywhere).  Its tag is the first gather's of the iteration
+        // that did not start -- nobody has published under it.  A breakdown noticed BEFORE the update (rho = 0 or r0.v = 0) needs no gather:
+        // rr already is the global sum gather 1 of that iteration delivered, and a second record under the SAME tag could be picked up half
+        // old, half new by a poller.
         if (gather(0.0, rr_part, 0.0, 0.0, 0, a.epoch0 + 2u * (unsigned)it + 1u)) rr = tot[1];
         else status = 3;
     }

@@ -549,7 +549,19 @@ int build_rowdist(fdapde_ctx* c, int v) {
     const HostSpace& hs = c->hs;
     const int64_t nd = hs.n_dofs;
     hipStream_t st = c->stream;
-    if (int rc = ensure_host(c, kHostPattern)) return rc;
+    // A local failure that is an ERROR (not "this rank's share does not fit") must not make this rank leave while the others wait in the next
+    // exchange: it is remembered here, travels as "not ok" / as an error flag to the next agreement point, where ALL ranks leave together
+    // (lay.ok stays false everywhere), and only then is it returned to this rank's caller.
+    int hard_rc = FDAPDE_OK;
+    auto hard = [&](int rc) {
+        if (rc != FDAPDE_OK && hard_rc == FDAPDE_OK) hard_rc = rc;
+        return rc != FDAPDE_OK;
+    };
+    int local_ok = std::getenv("FDAPDE_ROWDIST_REFUSE") ? 0 : 1;   // (tests: this rank's share "does not fit")
+    if (const char* e = std::getenv("FDAPDE_ROWDIST_FAIL_RANK"))    // (tests: a hard local failure on one rank, at the stage FDAPDE_ROWDIST_FAIL_AT names)
+        if (std::atoi(e) == me && std::getenv("FDAPDE_ROWDIST_FAIL_AT") && std::atoi(std::getenv("FDAPDE_ROWDIST_FAIL_AT")) == 0) hard(fail(c, FDAPDE_EHIP, "injected failure (stage 0)"));
+    if (hard(ensure_host(c, kHostPattern))) local_ok = 0;
+    if (hard_rc) local_ok = 0;
     // ghosts in (owner, key) order
     std::vector<int32_t> gh;
     for (int64_t d = 0; d < nd; ++d)
@@ -563,7 +575,6 @@ int build_rowdist(fdapde_ctx* c, int v) {
     PersistLayout pl;
     const int n_wg = rd.max_wg > 0 ? std::min(rd.max_wg, c->n_cu) : c->n_cu;
     int sym_mode = c->persist_plain ? 0 : (c->persist_sym == 2 ? 3 : c->persist_sym);
-    int local_ok = std::getenv("FDAPDE_ROWDIST_REFUSE") ? 0 : 1;   // (tests: this rank's share "does not fit")
     const size_t lds_total = 160 * 1024 - 1024;
     size_t fixed = 0;
     int64_t need = 0;
@@ -580,7 +591,10 @@ int build_rowdist(fdapde_ctx* c, int v) {
             local_ok = 0;
             break;
         }
-        if (rc) return rc;
+        if (hard(rc)) {
+            local_ok = 0;
+            break;
+        }
         S = pl.R * kPersistT;
         imp_cap = (pl.max_imp + 63) & ~63, exp_cap = (pl.max_exp + 63) & ~63;
         fixed = pl.sym ? 8 * (size_t)(S + imp_cap) + 8 * (size_t)S + 64 : 8 * (size_t)(S + imp_cap) + 4 * (size_t)imp_cap + 2 * (size_t)exp_cap + 64;
@@ -615,7 +629,7 @@ int build_rowdist(fdapde_ctx* c, int v) {
     if (int rc = host_allreduce(c, mat)) return rc;
     auto M = [&](int p, int col) { return (int64_t)mat[(size_t)p * RW + col]; };
     for (int p = 0; p < W; ++p)
-        if (M(p, W + 2) == 0) return FDAPDE_OK;   // some rank's share does not qualify: nobody takes this path (ok stays false everywhere)
+        if (M(p, W + 2) == 0) return hard_rc;   // some rank's share does not qualify (or failed): nobody takes this path (ok stays false everywhere)
     L.G_tot = 0, L.g_base = 0;
     for (int p = 0; p < W; ++p) {
         if (p < me) L.g_base += (int32_t)M(p, W + 1);
@@ -636,12 +650,48 @@ int build_rowdist(fdapde_ctx* c, int v) {
         size_t at = 0;
         for (int32_t d : pl.ghost_needed) keys_out[at++] = (double)rd.key_i[(size_t)d];   // (owner order = peer order: both ascending)
     }
+    // (a rank that cannot allocate, upload, export or map must not leave the others waiting in the next exchange: local failures are
+    //  carried as flags to the agreement points, where every rank takes the same decision)
+    int local_err = 0;
+    std::string local_msg;
+    auto soft = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && !local_err) local_err = 1, local_msg = std::string(what) + ": " + hipGetErrorString(e);
+        if (e != hipSuccess) (void)hipGetLastError();
+        return e == hipSuccess;
+    };
+    auto inject = [&](int stage) {   // (tests: FDAPDE_ROWDIST_FAIL_RANK / _AT)
+        const char* r = std::getenv("FDAPDE_ROWDIST_FAIL_RANK");
+        const char* a = std::getenv("FDAPDE_ROWDIST_FAIL_AT");
+        if (r && a && std::atoi(r) == me && std::atoi(a) == stage && !local_err) local_err = 1, local_msg = "injected failure (stage " + std::to_string(stage) + ")";
+    };
+    auto agree = [&](bool* any) -> int {   // one decision for all ranks: did anybody fail locally so far?
+        std::vector<double> flag(1, (double)local_err);
+        if (int rc = host_allreduce(c, flag)) return rc;
+        *any = flag[0] != 0.0;
+        return FDAPDE_OK;
+    };
+    auto leave = [&]() -> int {   // every rank is leaving (ok stays false); the one that failed says why
+        for (void* m : L.ipc_opened) (void)hipIpcCloseMemHandle(m);
+        L.ipc_opened.clear();
+        L.ps.board.release(), L.rboard.release();
+        if (local_err) {
+            std::fprintf(stderr, "fdapde rank %d: row-distributed set-up failed locally (%s)\n", me, local_msg.c_str());
+            return fail(c, FDAPDE_EHIP, ("row-distributed set-up: " + local_msg).c_str());
+        }
+        return FDAPDE_OK;
+    };
     DBuf<double> d_out, d_in;
-    HIPCHK(c, d_out.upload(keys_out.data(), keys_out.size(), st));
-    HIPCHK(c, d_in.alloc(keys_in.size()));
-    if (int rc = pair_exchange(c, xr, soff, roff, d_out.p, d_in.p)) return rc;
-    HIPCHK(c, hipMemcpyAsync(keys_in.data(), d_in.p, sizeof(double) * keys_in.size(), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    soft(d_out.upload(keys_out.data(), keys_out.size(), st), "key list upload") && soft(d_in.alloc(keys_in.size()), "key list allocation");
+    inject(1);
+    {
+        bool any = false;
+        if (int rc = agree(&any)) return rc;
+        if (any) return leave();
+    }
+    if (int rc = pair_exchange(c, xr, soff, roff, d_out.p, d_in.p)) return rc;   // (collective itself: a transport failure is every rank's)
+    soft(hipMemcpyAsync(keys_in.data(), d_in.p, sizeof(double) * keys_in.size(), hipMemcpyDeviceToHost, st), "key list download") &&
+      soft(hipStreamSynchronize(st), "key list download");
+    inject(2);
     // own DOFs by key
     std::vector<std::pair<int64_t, int32_t>> mine;
     for (int64_t d = 0; d < nd; ++d)
@@ -669,8 +719,9 @@ int build_rowdist(fdapde_ctx* c, int v) {
         }
     }
     {
-        std::vector<double> flag(1, (double)bad);
+        std::vector<double> flag{(double)(local_err ? 0 : bad), (double)local_err};   // (a rank whose download failed looked keys up in garbage: its count means nothing)
         if (int rc = host_allreduce(c, flag)) return rc;
+        if (flag[1] != 0.0) return leave();
         if (flag[0] != 0.0) return fail(c, FDAPDE_EINVAL, "fdapde_rowdist_setup: a rank asked for a DOF its owner has no row for (ownership or boundary flags differ between ranks)");
     }
     std::stable_sort(rex.begin(), rex.end(), [](const Rexp& a, const Rexp& b) { return a.wg < b.wg; });
@@ -681,17 +732,9 @@ int build_rowdist(fdapde_ctx* c, int v) {
     // ---- boards.  Inside the rank: [local exports | dot records of the rank's workgroups x 2], ordinary device memory, exactly as on one
     //      GPU.  Across ranks: [entries imported from other ranks | one dot record per rank x 2], fine-grained, mapped by every rank
     fdapde_ctx::Persist& ps = L.ps;
-    // (a rank that cannot allocate, export or map a board must not leave the others waiting in the next exchange: local failures are
-    //  carried as flags to the agreement points, where every rank takes the same decision)
     const size_t n_p = (size_t)n_ghost;
-    int local_err = 0;
-    std::string local_msg;
-    auto soft = [&](hipError_t e, const char* what) {
-        if (e != hipSuccess && !local_err) local_err = 1, local_msg = std::string(what) + ": " + hipGetErrorString(e);
-        if (e != hipSuccess) (void)hipGetLastError();
-        return e == hipSuccess;
-    };
-    if (soft(ps.board.alloc(2 * (size_t)pl.n_board + 2 * (size_t)pl.G * 8 + 2), "board allocation") &&
+    inject(3);
+    if (!local_err && soft(ps.board.alloc(2 * (size_t)pl.n_board + 2 * (size_t)pl.G * 8 + 2), "board allocation") &&
         soft(L.rboard.alloc_fine(2 * n_p + 2 * (size_t)W * 8 + 2 * (size_t)L.G_tot * 8 + 2), "board allocation (fine-grained)"))
         if (soft(hipMemsetAsync(ps.board.p, 0, sizeof(unsigned long long) * ps.board.n, st), "board clear") &&
             soft(hipMemsetAsync(L.rboard.p, 0, sizeof(unsigned long long) * L.rboard.n, st), "board clear"))
@@ -736,15 +779,15 @@ int build_rowdist(fdapde_ctx* c, int v) {
     {
         std::vector<double> flag(1, (double)(local_err || any_err));
         if (int rc = host_allreduce(c, flag)) return rc;
-        if (flag[0] != 0.0) {   // every rank leaves here together; ok stays false
+        if (flag[0] != 0.0) {   // every rank leaves here together; ok stays false.  Boards that cannot be allocated, exported or mapped are a
+                                // property of the fabric, not an error of the call: the caller falls back to the RCCL exchange
             if (local_err) std::fprintf(stderr, "fdapde rank %d: row-distributed boards unavailable (%s)\n", me, local_msg.c_str());
-            for (void* m : L.ipc_opened) (void)hipIpcCloseMemHandle(m);
-            L.ipc_opened.clear();
-            ps.board.release(), L.rboard.release();
-            return FDAPDE_OK;
+            local_err = 0;
+            return leave();
         }
     }
-    // ---- uploads
+    // ---- uploads (a failure here is local too: agreed on before anybody marks the layout usable)
+    auto uploads = [&]() -> int {
     HIPCHK(c, ps.slot_dof.upload(pl.slot_dof.data(), pl.slot_dof.size(), st));
     HIPCHK(c, ps.ell_off.upload(pl.ell_off.data(), pl.ell_off.size(), st));
     HIPCHK(c, ps.sl_off.upload(pl.sl_off.data(), pl.sl_off.size(), st));
@@ -774,6 +817,19 @@ int build_rowdist(fdapde_ctx* c, int v) {
     HIPCHK(c, L.x_sendbuf.alloc(send_dof.size() + 1));
     HIPCHK(c, L.x_recvbuf.alloc(pl.ghost_needed.size() + 1));
     HIPCHK(c, hipStreamSynchronize(st));
+    return FDAPDE_OK;
+    };
+    {
+        const int rc_up = uploads();
+        if (rc_up != FDAPDE_OK) local_err = 1, local_msg = c->err;
+        inject(4);
+        bool any = false;
+        if (int rc = agree(&any)) return rc;
+        if (any) {
+            const int rc = leave();
+            return rc_up != FDAPDE_OK ? rc_up : rc;
+        }
+    }
     ps.stream = fixed + 10 * (size_t)need > lds_total;
     ps.lds_cap = ps.stream ? 0 : (int32_t)need, ps.imp_cap = imp_cap;
     ps.lds_bytes = fixed + (ps.stream ? 0 : 10 * (size_t)need);
@@ -834,26 +890,36 @@ int run_rowdist(fdapde_ctx* c, int v, double tol2, int maxit, bool* ran, bool bi
     a.wg_late = L.wg_late.p, a.rexp_off = L.rexp_off.p, a.rexp_slot = L.rexp_slot.p, a.rexp_peer = L.rexp_peer.p, a.rexp_pos = L.rexp_pos.p;
     a.peer_pboard = L.peer_pboard.p, a.peer_dboard = L.peer_dboard.p;
     a.pboard = ps.board.p, a.dboard = ps.board.p + 2 * (size_t)ps.meta.n_board, a.rboard = L.rboard.p;
+    // a launch or read-back ERROR of this rank counts as "failed" in the ranks' decision first (they would wait for ever in the all-reduce
+    // below, or for this rank's granules until their time-outs), and is returned to this rank's caller after it
     const int rc_launch = launch_persist(c, ps, a, /*dist=*/true, bicg);
-    if (rc_launch != FDAPDE_OK && rc_launch != FDAPDE_EUNSUPPORTED) return rc_launch;
-    int failed = rc_launch == FDAPDE_EUNSUPPORTED ? 1 : 0;
+    int hard_rc = (rc_launch != FDAPDE_OK && rc_launch != FDAPDE_EUNSUPPORTED) ? rc_launch : FDAPDE_OK;
+    int failed = rc_launch != FDAPDE_OK ? 1 : 0;
     if (!failed) {
-        HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        HIPCHK(c, hipMemcpyAsync(c->h_sc, c->sc.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
-        if (a.time_phases) {
-            c->persist_host_stats.resize(4 * (size_t)a.G);
-            HIPCHK(c, hipMemcpyAsync(c->persist_host_stats.data(), c->persist_stats.p, 4 * (size_t)a.G * sizeof(double), hipMemcpyDeviceToHost, st));
-        } else
-            c->persist_host_stats.clear();
-        HIPCHK(c, hipStreamSynchronize(st));
-        float ms = 0;
-        HIPCHK(c, hipEventElapsedTime(&ms, c->ev_p0, c->ev_p1));
-        c->persist_launch_ms = ms;
-        failed = c->h_ctl[3] != 0;
+        auto read_back = [&]() -> int {
+            HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipMemcpyAsync(c->h_sc, c->sc.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+            if (a.time_phases) {
+                c->persist_host_stats.resize(4 * (size_t)a.G);
+                HIPCHK(c, hipMemcpyAsync(c->persist_host_stats.data(), c->persist_stats.p, 4 * (size_t)a.G * sizeof(double), hipMemcpyDeviceToHost, st));
+            } else
+                c->persist_host_stats.clear();
+            HIPCHK(c, hipStreamSynchronize(st));
+            float ms = 0;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->ev_p0, c->ev_p1));
+            c->persist_launch_ms = ms;
+            return FDAPDE_OK;
+        };
+        hard_rc = read_back();
+        failed = hard_rc != FDAPDE_OK || c->h_ctl[3] != 0;
     }
     std::vector<double> flag(1, (double)failed);   // one decision for all ranks
     if (int rc = host_allreduce(c, flag)) return rc;
     *ran = flag[0] == 0.0;
+    if (hard_rc != FDAPDE_OK) {
+        *ran = false;
+        return hard_rc;
+    }
     if (!*ran) {
         HIPCHK(c, hipMemsetAsync(c->ctl.p + 3, 0, sizeof(int32_t), st));
         ps.epoch_next += (bicg ? 2u : 1u) * ((uint32_t)maxit + 2u);   // how far the other ranks got is unknown: past anything they can have written

@@ -307,7 +307,8 @@ def _ship(rdzv, rank, world, name, make):
             np.savez(buf, **probs[r])
             rdzv.put(f"{name}.{r}", buf.getvalue())
         return probs[0]
-    return dict(np.load(io.BytesIO(rdzv.get(f"{name}.{rank}"))))
+    take = getattr(rdzv, "consume", rdzv.get)   # (a blob addressed to one rank is deleted by its reader)
+    return dict(np.load(io.BytesIO(take(f"{name}.{rank}"))))
 
 
 def canary(capi, rdzv, rank, world, device, backend, share):
@@ -353,14 +354,47 @@ def bench_partitioned(capi, rdzv, rank, world, device, args, rtol, backend="rccl
     """bench.py's N > 1 leg in the chosen form (args.workload "c5": BASELINE config C5 -- 3-D P2 advection-diffusion-reaction, Jacobi-BiCGStab --
     in the row-distributed form only); a row-distributed solve that the library declines at the real size (the canary only proved
     the mechanism on a small mesh) falls back to the neighbour exchange on all ranks together"""
+    try:
+        return _bench_forms(capi, rdzv, rank, world, device, args, rtol, backend, form, share)
+    finally:
+        if backend != "rccl":
+            import torch.distributed as dist
+
+            if dist.is_initialized():
+                dist.destroy_process_group()
+
+
+def _bench_forms(capi, rdzv, rank, world, device, args, rtol, backend, form, share):
     if getattr(args, "workload", "c3") == "c5":
         return _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, "rowdist", share, tag="")
+    fallback = None
     try:
-        return _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, form, share, tag="")
+        res = _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, form, share, tag="")
     except _FormRefused as e:
         if rank == 0:
             print(f"bench.py: the row-distributed solve declined this system ({e}); using the RCCL neighbour exchange", file=sys.stderr)
-        return _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, "peers", share, tag=".2")
+        fallback = f"the row-distributed solve declined this system ({e}); the line is the neighbour exchange's"
+        res = _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, "peers", share, tag=".2")
+        form = "peers"
+    # the OTHER form for the same number of steps, so that one record answers both: north_star's own form -- sub-assembled operators,
+    # interface contributions exchanged per operator application over RCCL -- next to the row-distributed launches (VERDICT r3 item 2)
+    other = None
+    if form == "rowdist":
+        try:
+            o = _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, "peers", share, tag=".peers")
+            if o is not None:
+                oi = o["info"]
+                other = {"ms_per_step": 1e3 * o["elapsed"] / args.steps, "value_dof_per_s": o["total_dofs"] * args.steps / o["elapsed"],
+                         "us_per_iteration": 1e3 * o["t_sol"] / max(int(oi.iters), 1), "iterations": int(oi.iters), "relres": float(oi.relres),
+                         "t_assemble_ms": o["t_asm"], "t_solve_ms": o["t_sol"], "max_abs_error_vs_analytic": o["err"], "comm_ranks": o["comm_ranks"],
+                         "spmv_avg_ms": float(oi.spmv_avg_ms), "parallelism": o["parallelism"], "transport": o["transport"]}
+        except Exception as e:   # never let the secondary measurement take the line down (every rank fails the same way or not at all)
+            if rank == 0:
+                other = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if res is not None:
+        res["other"] = other if form == "rowdist" else "this line IS the RCCL neighbour exchange"
+        res["fallback"] = fallback
+    return res
 
 
 def _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, form, share, tag):
@@ -390,6 +424,7 @@ def _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, form, shar
     ctx.mesh_upload(lp["nodes"], lp["cells"], lp["boundary"])
     n_loc = ctx.dofs_build(order)
     grp, transport = _comm_setup(capi, ctx, rdzv, rank, world, backend, tag)
+    comm_ranks = ctx.comm_count()
     coords = lp["nodes"]
     if form == "rowdist":
         if share > 1:
@@ -448,12 +483,14 @@ def _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, form, shar
     _, alg_bytes = ctx.bench_spmv(reps=1)
     streamed = 0.0 if form == "rowdist" else ctx.solver_layout(True)[2]
     red = grp.max([elapsed, err, np.mean([i.t_assemble_ms for i in infos]), np.mean([i.t_solve_ms for i in infos]), ctx.info().t_setup_ms,
-                   float(sizes["nnz"]), alg_bytes, streamed, np.mean([i.spmv_avg_ms for i in infos]), t_part, np.mean([i.launch_ms for i in infos])])
-    if backend != "rccl":
+                   float(sizes["nnz"]), alg_bytes, streamed, np.mean([i.spmv_avg_ms for i in infos]), t_part, np.mean([i.launch_ms for i in infos]),
+                   np.mean([i.gather_avg_ms for i in infos]), np.mean([i.spmv_mean_ms for i in infos]), np.mean([i.update_avg_ms for i in infos]),
+                   float(comm_ranks), -float(comm_ranks)])
+    ph_sum = grp.sum([np.mean([i.spmv_avg_ms for i in infos]), np.mean([i.gather_avg_ms for i in infos]), np.mean([i.spmv_mean_ms for i in infos])])
+    if backend != "rccl":   # (the gloo group of the plumbing mode outlives this form: bench_partitioned may run a second one)
         import torch.distributed as dist
 
         dist.barrier()
-        dist.destroy_process_group()
     ctx.close()
     if rank != 0:
         return None
@@ -471,6 +508,15 @@ def _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, form, shar
         parallelism = (f"{world} GPUs, element partition (Morton chunks), {int(lp['n_if_global'])} interface DOFs; single-reduction CG, per "
                        f"iteration one grouped RCCL send / receive with every neighbour -- the interface entries of A r, <= {int(msg[1])} peers, "
                        f"<= {int(msg[0])} bytes sent per rank -- and one 16-byte all-reduce of (r.Ar, r.r)")
+    persistent = int(getattr(info, "persistent", 0))
+    phases = None
+    if persistent:   # (s_memrealtime stamps inside the persistent launches; the multi-launch path has none)
+        phases = {"operator_slowest_workgroup_slowest_rank": 1e3 * float(red[8]), "operator_slowest_workgroup_mean_of_ranks": 1e3 * float(ph_sum[0]) / world,
+                  "operator_mean_workgroup_slowest_rank": 1e3 * float(red[12]), "operator_mean_workgroup_mean_of_ranks": 1e3 * float(ph_sum[2]) / world,
+                  "allgather_slowest_rank": 1e3 * float(red[11]), "allgather_mean_of_ranks": 1e3 * float(ph_sum[1]) / world,
+                  "update_slowest_rank": 1e3 * float(red[13])}
+    # every rank must report the same communicator size (max == min)
+    comm = int(red[14]) if int(red[14]) == -int(red[15]) else f"INCONSISTENT: between {-int(red[15])} and {int(red[14])}"
     return dict(elapsed=float(red[0]), err=float(red[1]), t_asm=float(red[2]), t_sol=float(red[3]), setup_ms=float(red[4]), info=info, infos=infos,
                 alg_bytes=float(red[6]), streamed_bytes=float(red[7]), total_dofs=int(round(n_own[0])), n_cells_total=int(lp["n_cells_total"]),
-                parallelism=parallelism, transport=transport, t_partition=float(red[9]), form=form)
+                parallelism=parallelism, transport=transport, t_partition=float(red[9]), form=form, comm_ranks=comm, phases=phases)

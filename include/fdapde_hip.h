@@ -254,6 +254,9 @@ int fdapde_comm_init(fdapde_ctx *ctx, int32_t world, int32_t rank, const void *u
  * reductions of a multi-process driver that loads no other GPU library (bench.py's ranks: ONE HIP / RCCL stack per process).
  * RCCL is dlopen'ed from the installation the HIP runtime this library is bound to belongs to; fdapde_comm_library() names it. */
 int fdapde_comm_allreduce(fdapde_ctx *ctx, double *host_inout, int32_t n, int32_t op);
+/* the number of ranks of the context's communicator as RCCL itself reports it (ncclCommCount) -- so that a multi-GPU result can state what
+ * its collectives really ran over; the registered world size under the host-staged transport; 1 without a communicator */
+int fdapde_comm_count(fdapde_ctx *ctx, int32_t *ranks);
 const char *fdapde_comm_library(void);
 int fdapde_halo_setup(fdapde_ctx *ctx, int64_t n_if_global, int64_t n_if_local, const int32_t *local_dof,
                       const int32_t *if_index, const uint8_t *owned);

@@ -15,6 +15,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+ORACLE_NX = 12   # cases up to this size are compared with the CPU oracle's direct solve of the WHOLE mesh as well (multi-rank parity
+                 # pinned directly, not only through the single-domain HIP solve)
+
+
+def oracle_solution(nodes, cells, bnd, order, op_name, bvec, fq, g):
+    """oracle.pde_init_solve on the whole mesh: the reference algorithm restated on the CPU (test infrastructure, tests only)"""
+    from oracle import oracle as o
+
+    m = o.Mesh(np.ascontiguousarray(nodes), np.ascontiguousarray(cells, dtype=np.int32), np.ascontiguousarray(bnd, dtype=np.uint8))
+    op = {"lap": lambda: -o.laplacian(),
+          "lap+r": lambda: -o.laplacian() + o.reaction(0.5) + o.reaction(0.0),
+          "adr": lambda: -o.laplacian() + o.advection(np.asarray(bvec, dtype=float)) + o.reaction(1.0),
+          "adr+r": lambda: -o.laplacian() + o.reaction(0.5) + o.advection(np.asarray(bvec, dtype=float))}[op_name]()
+    return o.pde_init_solve(m, order, op, forcing_q=fq, dirichlet=g).solution
+
+
 def main():
     rank, world, port, nx = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
     case = sys.argv[5] if len(sys.argv) > 5 else "p1"
@@ -44,7 +60,7 @@ def main():
            (lambda: capi.dt() - capi.laplacian()) if case == "parab" else (lambda: -capi.laplacian())
     part = fdist.partition_cells(nodes, cells, world)
     if exchange_mode == "rowdist":
-        return rowdist_case(rank, world, case, order, nodes, cells, bnd, part, capi, fdist, dist, torch, u_exact, f, g_fn, transport, two_level)
+        return rowdist_case(rank, world, case, order, nodes, cells, bnd, part, capi, fdist, dist, torch, u_exact, f, g_fn, transport, two_level, nx)
     info_if = fdist.interface_info(cells, part, n_g, world, order, bnd)
     sub = fdist.sub_mesh(nodes, cells, bnd, part, rank)
 
@@ -140,12 +156,17 @@ def main():
         else:
             assert abs(info.iters - rinfo.iters) <= max(2, rinfo.iters // 50), (info.iters, rinfo.iters)   # same Krylov iteration up to rounding
         msg = f"iters {info.iters} (single domain {rinfo.iters})"
+        if nx <= ORACLE_NX:   # ... and directly against the oracle's direct solve of the whole mesh (same numbering: l2g)
+            uo = oracle_solution(nodes, cells, bnd, order, "adr" if case.startswith("adr") else "lap", bvec, f(ref.quadrature_nodes()), g_fn(gcoords))
+            err_o = np.linalg.norm(u - uo[l2g]) / np.linalg.norm(uo)
+            assert err_o < 1e-8, err_o
+            msg += f"  vs oracle {err_o:.1e}"
     dist.barrier()   # nobody tears its communicator down while a peer is still inside a collective
     print(f"rank {rank}: ok  case {case}  local dofs {n_loc}  interface {maps['local_dof'].size}/{maps['n_if_global']}  {msg}  err {err:.2e}")
     dist.destroy_process_group()
 
 
-def rowdist_case(rank, world, case, order, nodes, cells, bnd, part, capi, fdist, dist, torch, u_exact, f, g_fn, transport="shared", two_level=False):
+def rowdist_case(rank, world, case, order, nodes, cells, bnd, part, capi, fdist, dist, torch, u_exact, f, g_fn, transport="shared", two_level=False, nx=0):
     """row-distributed form (fdapde_rowdist_setup): one persistent launch per rank, all ranks' launches acting as one grid through
     peer-mapped boards -- here all on GPU 0, each rank with an equal share of the CUs, boards mapped across the processes by hipIpc"""
     n_g = nodes.shape[0]
@@ -249,6 +270,29 @@ def rowdist_case(rank, world, case, order, nodes, cells, bnd, part, capi, fdist,
         print(f"rank {rank}: ok  case stall rowdist  local dofs {n_loc}  err {err:.2e}")
         dist.destroy_process_group()
         return
+    if case.startswith("fail"):   # a HARD local failure on ONE rank during the collective set-up (stage = digit: 0 host mirrors, 1 / 2 key
+                                  # lists, 3 boards, 4 uploads): nobody may be left waiting in an exchange -- every rank's solve returns, the
+                                  # failing rank with its own error, the others with the collective refusal; and again on the next solve
+        stage = int(case[4:])
+        ctx.set_operator(-capi.laplacian() + capi.reaction(0.5))
+        ctx.set_forcing(f(ctx.quadrature_nodes()))
+        ctx.set_dirichlet(g_fn(lcoords))
+        ctx.init()
+        os.environ["FDAPDE_ROWDIST_FAIL_RANK"], os.environ["FDAPDE_ROWDIST_FAIL_AT"] = str(world - 1), str(stage)
+        statuses = []
+        for _ in range(2):
+            try:
+                ctx.solve(rtol=1e-11)
+                statuses.append(capi.OK)
+            except capi.FdapdeError as e:
+                statuses.append(e.status)
+        mine_failed = rank == world - 1 and stage != 3   # (stage 3, boards: a property of the fabric -> the soft refusal everywhere)
+        assert statuses[0] == (capi.EHIP if mine_failed else capi.EUNSUPPORTED), statuses
+        assert statuses[1] == capi.EUNSUPPORTED, statuses   # the layout stays refused: no second collective attempt, same answer everywhere
+        dist.barrier()
+        print(f"rank {rank}: ok  case {case} rowdist  statuses {statuses}")
+        dist.destroy_process_group()
+        return
     if case == "handle":   # factor-once handle on the mass matrix: right-hand sides complete at the owned DOFs
         for c_ in (ctx, ref):
             c_.set_operator(-capi.laplacian())
@@ -285,12 +329,20 @@ def rowdist_case(rank, world, case, order, nodes, cells, bnd, part, capi, fdist,
         assert info.iters <= 1.3 * rinfo.iters + 5, (info.iters, rinfo.iters)
     else:
         assert abs(info.iters - rinfo.iters) <= max(1, rinfo.iters // 100), (info.iters, rinfo.iters)
+    oracle_msg = ""
+    if 0 < nx <= ORACLE_NX:   # directly against the oracle's direct solve of the whole mesh, over the DOFs this rank owns
+        uo = oracle_solution(nodes, cells, bnd, order, "adr+r" if adr else "lap+r", [1.0, 0.5, 0.25][:N], f(ref.quadrature_nodes()), g_fn(gcoords))
+        eo = np.array([np.sum((u[mine] - uo[l2g][mine]) ** 2)])
+        allreduce(eo)
+        err_o = float(np.sqrt(eo[0])) / np.linalg.norm(uo)
+        assert err_o < 1e-8, err_o
+        oracle_msg = f"  vs oracle {err_o:.1e}"
     # second solve on the same context: epochs advance, boards are not cleared; identical bits
     info2 = ctx.solve(rtol=1e-11)
     assert info2.iters == info.iters and np.array_equal(ctx.solution()[mine], u[mine])
     dist.barrier()
     print(f"rank {rank}: ok  case {case} rowdist  local dofs {n_loc} (owned {int(mine.sum())})  iters {info.iters} (single domain {rinfo.iters})  "
-          f"err {err:.2e}  launch {info.launch_ms:.3f} ms")
+          f"err {err:.2e}  launch {info.launch_ms:.3f} ms{oracle_msg}")
     dist.destroy_process_group()
 
 

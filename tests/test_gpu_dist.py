@@ -78,13 +78,17 @@ def test_partitioned_solve_over_real_rccl(world, nx, case):
 
 @pytest.mark.parametrize("world,nx,case", [(2, 16, "p1"), (3, 14, "p1"), (4, 20, "p1"), (2, 40, "sq2"), (2, 8, "p2"), (4, 36, "p1"),
                                            (2, 16, "adr1"), (3, 8, "adr2"), (2, 12, "parab"), (3, 12, "handle"), (3, 16, "stall"),
-                                           (3, 14, "p1:2level"), (2, 16, "adr1:2level"), (3, 16, "stall:2level")])
+                                           (3, 14, "p1:2level"), (2, 16, "adr1:2level"), (3, 16, "stall:2level"),
+                                           (2, 12, "p1"), (3, 10, "adr1"), (2, 6, "p2"),   # small enough for the oracle's direct solve of the whole mesh
+                                           (3, 12, "fail0"), (2, 12, "fail1"), (3, 12, "fail2"), (2, 12, "fail3"), (3, 12, "fail4")])
 def test_row_distributed_persistent_launches_share_one_gpu(world, nx, case):
     """fdapde_rowdist_setup: every rank assembles the complete rows of the DOFs it owns (ghost layer of cells) and the whole CG runs as ONE
     launch per rank; the launches exchange search-direction entries and dot records through each other's boards (hipIpc-mapped across the
     processes), no collective inside the iteration (dot records in one hop -- the automatic choice up to 1024 workgroups -- or, ":2level",
     as rank records in two).  Against the single-domain solve: same iteration count, solution <= 1e-9, bitwise
-    repeatable.  All ranks on GPU 0 with an equal share of its CUs each."""
+    repeatable -- and, for the cases of nx <= 12, directly against the CPU oracle's direct solve of the whole mesh (<= 1e-8 over the owned DOFs).
+    "failK": a hard local failure of one rank at stage K of the collective set-up: no rank is left waiting, the failing rank reports its
+    error, the others the collective refusal.  All ranks on GPU 0 with an equal share of its CUs each."""
     _run_ranks(world, nx, case, "shared", "rowdist")
 
 
@@ -96,6 +100,24 @@ def test_row_distributed_launches_over_xgmi(world, nx, case):
     if _n_gpus() < world:
         pytest.skip(f"needs {world} GPUs, this box has {_n_gpus()}")
     _run_ranks(world, nx, case, "rccl", "rowdist")
+
+
+def _check_enlarged_line(rec, world, nx):
+    """one SCALE record answers everything: the chosen form with its in-kernel phase stamps (slowest rank), how many
+    ranks the communicator really had, the canary's verdict, and north_star's own form -- the RCCL neighbour exchange -- measured for the
+    same number of steps next to it"""
+    cfg = rec["config"]
+    assert cfg["comm_ranks"] == world and cfg["canary"].startswith("passed") and cfg["fallback"] is None
+    ph = cfg["phase_stamps_us_per_iteration"]
+    assert ph["operator_slowest_workgroup_slowest_rank"] >= ph["operator_mean_workgroup_mean_of_ranks"] > 0
+    assert ph["allgather_slowest_rank"] >= ph["allgather_mean_of_ranks"] > 0
+    other = rec["extra"]["rccl_neighbour_exchange"]
+    assert "error" not in other, other
+    assert other["iterations"] > 0 and other["relres"] <= 1e-10 and other["ms_per_step"] > 0 and other["us_per_iteration"] > 0
+    assert other["comm_ranks"] == world and "bytes sent per rank" in other["parallelism"]
+    assert other["max_abs_error_vs_analytic"] < 6.0 * (1.0 / nx) ** 2 * 3.15**2
+    # both forms run the same Krylov iteration on the same system (single-reduction CG may need a few iterations more)
+    assert abs(other["iterations"] - cfg["cg_iterations"]) <= max(3, cfg["cg_iterations"] // 10)
 
 
 def test_bench_multi_gpu_leg_plumbing_on_one_gpu():
@@ -112,6 +134,11 @@ def test_bench_multi_gpu_leg_plumbing_on_one_gpu():
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["relres"] <= 1e-10
     assert "bytes sent per rank" in rec["config"]["parallelism"]
     assert rec["config"]["max_abs_error_vs_analytic"] < 6.0 * (1.0 / 24) ** 2 * 3.15**2
+    # the enlarged line: what the collectives ran over, why this form, and that no second form was measured because this IS the RCCL form
+    assert rec["config"]["comm_ranks"] == 2 and rec["config"]["canary"].startswith("not run") and rec["config"]["fallback"] is None
+    assert rec["config"]["ranks_per_device"] == 2 // min(2, rec["config"]["devices_visible"])
+    assert "IS the RCCL neighbour exchange" in rec["extra"]["rccl_neighbour_exchange"]
+    assert not [d for d in os.listdir("/tmp") if d.startswith(f"fdapde_rdzv_{cmd[cmd.index('--master-port') + 1]}_")], "the ranks' rendezvous directory must not outlive the job"
 
 
 def test_bench_under_torchrun_runs_the_canary_and_takes_the_row_distributed_form():
@@ -128,6 +155,7 @@ def test_bench_under_torchrun_runs_the_canary_and_takes_the_row_distributed_form
     assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["relres"] <= 1e-10
     assert rec["config"]["exchange_form"] == "rowdist" and rec["config"]["persistent_launch"] == 1
     assert rec["config"]["max_abs_error_vs_analytic"] < 6.0 * (1.0 / 24) ** 2 * 3.15**2
+    _check_enlarged_line(rec, 2, 24)
 
 
 def test_bench_falls_back_when_the_row_distributed_solve_declines_the_system():
@@ -177,6 +205,7 @@ def test_bench_starts_its_own_ranks_without_a_launcher(gpus):
     # the canary job found the row-distributed launches working between the ranks' devices (here: one shared device): that form ran
     assert rec["config"]["exchange_form"] == "rowdist" and rec["config"]["persistent_launch"] == 1
     assert all(v is None or v <= 1.0 for k, v in rec["roofline"].items() if k in ("frac", "traffic_frac"))
+    _check_enlarged_line(rec, gpus, 20)
 
 
 def test_bench_self_launch_reports_a_failing_rank():
@@ -209,3 +238,6 @@ def test_bench_multi_gpu_leg_as_the_driver_launches_it(gpus):
         assert rec["n_gpus"] == gpus and rec["scaling"] == "strong" and rec["value"] > 0
         assert rec["config"]["relres"] <= 1e-10 and rec["config"]["max_abs_error_vs_analytic"] < 6.0 * (1.0 / 48) ** 2 * 3.15**2
         assert "/opt/rocm" in rec["config"]["transport"], rec["config"]["transport"]   # ONE stack: the system's RCCL next to the system's HIP
+        assert rec["config"]["comm_ranks"] == gpus   # ncclCommCount of the communicator the collectives ran over
+        if rec["config"]["exchange_form"] == "rowdist":
+            _check_enlarged_line(rec, gpus, 48)

@@ -28,7 +28,7 @@ def main(out):
         print(f"{'kernel':60s} {'calls':>7s} {'total_us':>12s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'%':>6s}")
         for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
             print(f"{k[:60]:60s} {len(v):7d} {sum(v):12.1f} {sum(v)/len(v):10.2f} {min(v):10.2f} {max(v):10.2f} {100*sum(v)/tot:6.2f}")
-    for sub in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq", "pmc_sq2"):
         f = find(os.path.join(out, sub), "*counter_collection.csv")
         if not f:
             print(f"== {sub}: no counter file ==")

@@ -206,6 +206,8 @@ struct fdapde_ctx {
     DBuf<double> fq_bc;       // column 0 of the forcing samples in BLOCK-CELL order (a cell's nq samples repeated in every assembly block that
                               // visits it): the row-owner sweep reads them where it reads the block's cells; built by fdapde_set_forcing
     bool fq_bc_ready = false;
+    int asm_items = 1;        // knob: 0 = spaces with dealt rows (P2) keep the row-walking sweep instead of the visit-parallel one (k_assemble_items)
+    int32_t asm_max_visits = -1;   // longest visit list of the space (computed on first use; -1 = not yet)
     int asm_fuse_mass = 1;    // knob: fdapde_init accumulates the mass matrix in the operator's sweep where both accumulator ranges fit the LDS
     int asm_fq_bc = 1;        // knob: keep the block-cell ordered copy (1) or let the sweep gather from the cell-ordered samples (0)
     int asm_fq_block = 0;     // tuning knob: 1 = fdapde_init first reduces the forcing samples to one load coefficient per visit slot (k_visit_load_coeffs);

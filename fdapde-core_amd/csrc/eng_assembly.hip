@@ -151,6 +151,51 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
         const bool seq_mass = can && !fuse_mass && fm != 2 && tab + acc <= (size_t)c->lds_limit;   // (every block's range must fit the LDS)
         if (a.vals2 != nullptr && !fuse_mass && !seq_mass) return FDAPDE_EUNSUPPORTED;   // (e_init then runs the mass sweep of its own)
         if (tab + acc > (size_t)c->lds_limit) acc = tab < (size_t)c->lds_limit ? (size_t)c->lds_limit - tab : 0;
+        // visit-parallel form (k_assemble_items) for spaces whose rows were dealt to the lane positions by visit count (P2): the (row, visit)
+        // pairs of a block are the work items of 1024 threads (512 for the space-varying integrand: registers), same addends in the same
+        // order as the row-walking kernel, hence the same bits.  One block per CU with 16 wavefronts instead of 4: its accumulators may take
+        // the whole LDS.  Knob asm_items = 0 keeps the row-walking kernel.
+        if constexpr (R == 2) {
+            const size_t acc_all = (size_t)hs.max_blk_nnz * sizeof(double), lds_items = tab + acc_all + (size_t)hs.max_blk_cells * 8;
+            const bool want_mass2 = a.vals2 != nullptr;
+            if (c->asm_items && c->lane_row.p != nullptr && opk != 0 && lds_items + 10 * 1024 <= (size_t)160 * 1024 && (!want_mass2 || opk == 1 || opk == 3)) {
+                if (c->asm_max_visits < 0) {   // longest visit list of the space (once per space: fdapde_dofs_build resets it)
+                    int64_t mw = 0;
+                    for (size_t s = 0; s + 1 < hs.sl_off.size(); ++s) mw = std::max<int64_t>(mw, hs.sl_off[s + 1] - hs.sl_off[s]);
+                    c->asm_max_visits = (int32_t)std::min<int64_t>(mw, INT32_MAX);
+                }
+                if (c->asm_max_visits <= kItemsMaxVisits) {
+                    a.lane_row = c->lane_row.p, a.lds_acc_cap = hs.max_blk_nnz, a.lds_cells = hs.max_blk_cells;
+                    c->asm_all_in_lds = true;
+                    if (a.fq != nullptr && a.fq == c->fq.p && c->fq_blk_ready) a.fq = c->fq_blk.p, a.fq_block = 1;
+                    else if (a.fq != nullptr && a.fq == c->fq.p && c->fq_bc_ready) a.fq = c->fq_bc.p, a.fq_block = 2;
+                    const int grid_i = 8 * (int)(((hs.n_dofs + kAsmBlock - 1) / kAsmBlock + 7) / 8);
+                    if (std::getenv("FDAPDE_DEBUG_ASM"))
+                        std::fprintf(stderr, "assembly launch <%d,%d> opk %d, visit-parallel: grid %d x %d threads, LDS %zu B dynamic (tables %zu + accumulators %zu), longest visit list %d, %s\n",
+                                     M, R, opk, grid_i, opk == 4 ? 512 : 1024, lds_items, tab, acc_all, c->asm_max_visits, want_mass2 ? "mass as second sweep" : "one matrix");
+#define ITEMS_GO(OPK_, M2_, TH_)                                                                                                          \
+    do {                                                                                                                                  \
+        const void* fn = reinterpret_cast<const void*>(&k_assemble_items<M, R, OPK_, M2_, TH_>);                                          \
+        if (lds_items > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_items);             \
+        hipLaunchKernelGGL((k_assemble_items<M, R, OPK_, M2_, TH_>), dim3(grid_i), dim3(TH_), lds_items, c->stream, a, op);               \
+    } while (0)
+                    const char* th_env = std::getenv("FDAPDE_ASM_ITEMS_THREADS");   // (measurements: 512 instead of 1024 threads per block)
+                    if (want_mass2 && th_env && std::atoi(th_env) == 512) {
+                        if (opk == 3) ITEMS_GO(3, 2, 512);
+                        else ITEMS_GO(1, 2, 512);
+                    } else if (want_mass2) {
+                        if (opk == 3) ITEMS_GO(3, 2, 1024);
+                        else ITEMS_GO(1, 2, 1024);
+                    } else if (opk == 4) ITEMS_GO(4, 0, 512);
+                    else if (opk == 3) ITEMS_GO(3, 0, 1024);
+                    else if (opk == 2) ITEMS_GO(2, 0, 1024);
+                    else ITEMS_GO(1, 0, 1024);
+#undef ITEMS_GO
+                    HIPCHK(c, hipGetLastError());
+                    return FDAPDE_OK;
+                }
+            }
+        }
         a.lds_acc_cap = (int32_t)(acc / sizeof(double));
         c->asm_all_in_lds = acc == (size_t)hs.max_blk_nnz * sizeof(double);   // every block accumulates in LDS (AsmArgs::row_stat is then complete)
         if (a.fq != nullptr && a.fq == c->fq.p && c->fq_blk_ready) a.fq = c->fq_blk.p, a.fq_block = 1;   // column 0: one load coefficient per visit slot

@@ -252,6 +252,7 @@ int e_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs) {
     c->halo_ready = false, c->lin_ready = false, c->sp_built[0] = c->sp_built[1] = false, c->sp_cur = -1;
     release_rowdist(c);   // (keys / owners / layouts of the row-distributed form belong to the space that is being replaced)
     c->eval_grid.release();   // (the point-location grid of the mesh before)
+    c->asm_max_visits = -1;
     c->scaled_owner = fdapde_ctx::kScaledNone;
     c->ps[0].tried = c->ps[0].ok = c->ps[1].tried = c->ps[1].ok = false;
     c->bk[0].tried = c->bk[0].ok = c->bk[1].tried = c->bk[1].ok = false, c->bk_cur = -1;

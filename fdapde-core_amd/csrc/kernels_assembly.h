@@ -79,7 +79,23 @@ struct AsmArgs {
     const int64_t* bn_off;
     const int32_t* bn_node;
     int32_t lds_nodes;         // coordinate slots reserved in LDS (max nodes of any block)
+    int32_t lds_cells;         // k_assemble_items: block-cell slots reserved in LDS for the vertex-slot words (max cells of any block)
 };
+
+// A finished element-matrix entry (or load-vector entry) as a VALUE: the compiler may not merge the multiplication that produced it with
+// the addition that accumulates it into one fused multiply-add.  The reference rounds every integral before it is summed
+// (fem_assembler.h:97-107: `value` goes into a triplet, the triplets are added later), and the two row-owner kernels -- which accumulate
+// the same addends in the same order through differently shaped code -- must not depend on where the optimiser finds a contraction.
+// Applied where two kernels must agree bit for bit -- the P2 instantiations (R == 2: k_assemble_rows and k_assemble_items); the P1 sweep
+// has one form only and keeps the contraction (C3 init 0.93 against 0.99 ms with the barrier: FDAPDE_ASM_ROUND_P1 decides).
+#ifndef FDAPDE_ASM_ROUND_P1
+#define FDAPDE_ASM_ROUND_P1 0
+#endif
+template <int R> __device__ __forceinline__ double rounded(double v) {
+    if constexpr (R == 2 || FDAPDE_ASM_ROUND_P1)
+        asm("" : "+v"(v));   // (not volatile: the statement may move with the code around it, it only hides the product from the contraction)
+    return v;
+}
 
 template <int M> struct Geo {
     double invJ[M][M];   // J^{-1}
@@ -575,20 +591,20 @@ static __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, D
             geo_from_vertices<M>(xyz + lv.x * NP, xyz + lv.y * NP, xyz + lv.z * NP, xyz + lv.w * NP, g);
             // the global cell id is needed by varying coefficients and by forcing samples kept in cell order only
             const int cell = ((a.fq != nullptr && a.fq_block == 0) || op.needs_rows) ? a.bc_cell[bc] : 0;
-            fsum += element_row<M, R, OPK>(a, op, tb, g, cell, code & 15, want_matrix, [&](int j, double value) {
+            fsum += rounded<R>(element_row<M, R, OPK>(a, op, tb, g, cell, code & 15, want_matrix, [&](int j, double value) {
                 const uint32_t slot = (sw[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
                 if (in_lds)
-                    acc[my0 - base + (int32_t)slot] += value;
+                    acc[my0 - base + (int32_t)slot] += rounded<R>(value);
                 else
-                    a.vals[my0 + (int32_t)slot] += value;
-            }, rt, fblk ? bc : (int64_t)-1, fc, fbc ? bc : (int64_t)-1);
+                    a.vals[my0 + (int32_t)slot] += rounded<R>(value);
+            }, rt, fblk ? bc : (int64_t)-1, fc, fbc ? bc : (int64_t)-1));
             if constexpr (MASS2 == 1) {   // (OPK 2's own formula with coefficient 1: cm = 1.0 * 1.0 * |e|)
                 const double cm = 1.0 * 1.0 * g.measure;
                 const int il = code & 15;
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
                     const uint32_t slot = (sw[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
-                    acc2[my0 - base + (int32_t)slot] += cm * tb->mtab[il * NB + j];
+                    acc2[my0 - base + (int32_t)slot] += rounded<R>(cm * tb->mtab[il * NB + j]);
                 }
             }
         }
@@ -639,12 +655,196 @@ static __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, D
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
                     const uint32_t slot = (sw[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
-                    acc[my0 - base + (int32_t)slot] += cm * tb->mtab[il * NB + j];
+                    acc[my0 - base + (int32_t)slot] += rounded<R>(cm * tb->mtab[il * NB + j]);
                 }
             }
         }
         __syncthreads();
         for (int k = threadIdx.x; k < blk_nnz; k += kAsmBlock) a.vals2[base + k] = acc[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row-owner assembly, VISIT-PARALLEL form -- for spaces whose rows differ a lot in visit count (P2: a vertex row is visited by
+// ~24 tetrahedra, an edge row by ~6; host_setup.cpp then deals the rows of a block to its lane positions in DESCENDING order of
+// their visit count).  k_assemble_rows walks a row's visits one after the other in one lane: a block then takes as long as its
+// longest row (24 visits) while three of its four wavefronts are done after 6-8, and with ~83 KB of LDS per block there is one
+// block, i.e. ONE wavefront per SIMD, to hide a visit's dependent chain behind (r4 counters on C5: SQ_WAIT_ANY 83 % of the wave
+// cycles, 35 cycles per instruction).  Here the (row, visit) pairs of a block are the work items:
+//   * item t <-> (visit index v, lane position q): because the positions are sorted by visit count, the rows that HAVE a visit v
+//     are the prefix [0, n_v) of the positions, so the items of a block, v-major, are addressed by a prefix sum over v -- no
+//     extra index array, the adjacency slices are read where they lie;
+//   * the block has 8 / 16 wavefronts (512 / 1024 threads: 2 / 4 per SIMD for the same LDS).  While more than 64 rows still have
+//     visits, wavefront w takes 16 contiguous positions x 4 visit indices per step (phase A: every wavefront is busy, the index
+//     words of a step are contiguous runs); the tail -- the few long rows -- is spread as 4 positions x 16 visit indices
+//     (phase B).  Every lane integrates a full element row per step, whatever the length of the row it belongs to;
+//   * an item's values go into the block's accumulators IN VISIT ORDER: after every step, one accumulation round per visit index
+//     of the step (the items of one visit index belong to different rows, hence to different slots).  Inside a phase all items
+//     of a row live in ONE wavefront, whose LDS operations complete in program order, so the rounds need no barrier; one
+//     workgroup barrier separates the phases.  (Measured on C5, init = operator + forcing + mass: row-walking 8.9 ms; items dealt
+//     v-major to all 1024 threads with a workgroup barrier per round 4.6 ms; wavefronts owning strided positions, no barrier but
+//     scattered index words, 5.7 ms.)  Every slot receives exactly the addends of k_assemble_rows in exactly its order: the same
+//     bits, no atomics, bitwise symmetric for symmetric forms.
+// The forcing sum of a row is accumulated the same way (one more accumulator per position).  MASS2 == 2: the mass rows in a
+// second sweep over the items through the same accumulators, as in k_assemble_rows.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kItemsMaxVisits = 64;   // visit lists longer than this keep the row-walking kernel (the host checks)
+template <int M, int R, int OPK, int MASS2, int THREADS>
+static __global__ __launch_bounds__(THREADS) void k_assemble_items(AsmArgs a, DevOp op) {
+    constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
+    constexpr int NBW = (NB * 2 + 3) / 4;
+    constexpr int NP = M == 2 ? 2 : 3;
+    constexpr int NW = THREADS / 64, RW = kAsmBlock / NW;   // wavefronts; rows (lane positions) a wavefront owns: w, w + NW, w + 2 NW, ...
+    static_assert(RW <= 64 && RW * NW == kAsmBlock, "a wavefront owns at most 64 rows");
+    extern __shared__ double lds[];
+    __shared__ int32_t width_s[kAsmBlock / kSlice];            // visit rows of the block's adjacency slices (= visits of the longest row of each)
+    __shared__ int32_t rbase_s[kAsmBlock];                     // first accumulator of the position's row
+    __shared__ double facc_s[kAsmBlock];                       // forcing sums by position
+    __shared__ int64_t sloff_s[kAsmBlock / kSlice];            // first visit row of the block's adjacency slices
+    const int64_t n_blk = (a.n_dofs + kAsmBlock - 1) / kAsmBlock, band = (n_blk + 7) / 8;
+    const int64_t blk = (int64_t)(blockIdx.x & 7) * band + (blockIdx.x >> 3);   // XCD-aware block order, as k_assemble_rows
+    if (blk >= n_blk || (int64_t)(blockIdx.x >> 3) >= band) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const DevTables* tb = nullptr;
+    {
+        const double* src = reinterpret_cast<const double*>(a.tables);
+        for (int i = tid; i < kTablesDoubles; i += THREADS) lds[i] = src[i];
+        tb = reinterpret_cast<const DevTables*>(lds);
+    }
+    const DevRefTensors* rt = nullptr;
+    double* xyz = lds + kTablesDoubles;
+    if constexpr (OPK == 3) {
+        const double* src = reinterpret_cast<const double*>(a.reftab);
+        for (int i = tid; i < kRefDoubles; i += THREADS) xyz[i] = src[i];
+        rt = reinterpret_cast<const DevRefTensors*>(xyz);
+        xyz += kRefDoubles;
+    }
+    uint2* lvs = reinterpret_cast<uint2*>(xyz + (int64_t)a.lds_nodes * NP);   // the block-cells' vertex slots (4 x 16 bit each)
+    double* acc = reinterpret_cast<double*>(lvs + a.lds_cells);
+    const int64_t row0 = blk * kAsmBlock, row_end = min(a.n_dofs, row0 + kAsmBlock);
+    const bool want_matrix = a.vals != nullptr;
+    const int32_t base = a.rowptr[row0];
+    const int32_t blk_nnz = a.rowptr[row_end] - base;
+    const int64_t bn0 = a.bn_off[blk], nbn = a.bn_off[blk + 1] - bn0;
+    for (int i = tid; i < nbn; i += THREADS) {
+        const int64_t node = a.bn_node[bn0 + i];
+        if constexpr (M == 2) {
+            *reinterpret_cast<double2*>(xyz + i * 2) = *reinterpret_cast<const double2*>(a.vcoords + node * 2);
+        } else {
+            const double4 v = *reinterpret_cast<const double4*>(a.vcoords + node * 4);
+            xyz[i * 3] = v.x, xyz[i * 3 + 1] = v.y, xyz[i * 3 + 2] = v.z;
+        }
+    }
+    const int64_t bc0 = a.bc_off[blk], nbc = a.bc_off[blk + 1] - bc0;
+    for (int i = tid; i < nbc; i += THREADS) lvs[i] = reinterpret_cast<const uint2*>(a.bc_vert)[bc0 + i];
+    if (want_matrix)
+        for (int k = tid; k < blk_nnz; k += THREADS) acc[k] = 0.0;
+    const int64_t slice0 = row0 >> 6;   // the block's four adjacency slices
+    const int64_t n_slices_all = (a.n_dofs + kSlice - 1) / kSlice;
+    if (tid < kAsmBlock) {
+        const int64_t s = slice0 + (tid >> 6);
+        int32_t rb = 0;
+        if (s < n_slices_all) {
+            if ((tid & 63) == 0) sloff_s[tid >> 6] = a.sl_off[s], width_s[tid >> 6] = (int32_t)(a.sl_off[s + 1] - a.sl_off[s]);
+            const int32_t lr = a.lane_row[row0 + tid];
+            rb = lr >= 0 ? a.rowptr[lr] - base : 0;
+        } else if ((tid & 63) == 0)
+            sloff_s[tid >> 6] = 0, width_s[tid >> 6] = 0;
+        rbase_s[tid] = rb, facc_s[tid] = 0.0;
+    }
+    __syncthreads();
+    // ---- the item (visit v, position q) exists if the row at q has more than v visits: v inside its slice's width and a valid code
+    //      there (padding: -1).  Positions are sorted by count, so the rows that have a visit v are a prefix of the positions; the longest
+    //      row of the block is the first of slice 0, and the rows at positions >= 64 have at most width(slice 1) visits -- no counting.
+    //      Two phases, rows pinned to wavefronts inside each:
+    //      A  while more than 64 rows still have visits: wavefront w takes the positions [QA w, QA (w + 1)), VA visit indices per step
+    //         (QA = 256 / NW contiguous positions: the index words of a step are VA contiguous runs);
+    //      B  the tail, at most 64 long rows: wavefront w takes the positions [QB w, QB (w + 1)), VB visit indices per step.
+    //      One workgroup barrier between the phases (a row changes hands there), none inside them.
+    constexpr int QA = kAsmBlock / NW, VA = 64 / QA, QB = 64 / NW, VB = 64 / QB;
+    const int maxv = width_s[0];
+    const int tail_from = width_s[1];   // rows at positions >= 64 have at most this many visits
+    const bool fblk = a.fq != nullptr && a.fq_block == 1, fbc = a.fq != nullptr && a.fq_block == 2;
+    auto sweep = [&](auto mass_pass) {
+        constexpr bool MASS = decltype(mass_pass)::value;
+        bool tail = false;
+        for (int v0 = 0; v0 < maxv;) {   // (every quantity that steers the loop is uniform for the workgroup)
+            if (!tail && tail_from <= v0) {
+                tail = true;
+                __syncthreads();   // rows change hands: everything phase A added is in place
+            }
+            const int Q = tail ? QB : QA, V = tail ? VB : VA;
+            const int v = v0 + lane / Q, q = Q * wave + lane % Q;
+            const int64_t at = (sloff_s[q >> 6] + v) * kSlice + (q & 63);
+            const int32_t code = v < width_s[q >> 6] ? a.adj[at] : -1;
+            const bool on = code >= 0;
+            double val[NB];
+            double fval = 0;
+            uint32_t sw[NBW];
+            if (on) {
+#pragma unroll
+                for (int k = 0; k < NBW; ++k) sw[k] = a.slotw[at * NBW + k];
+                const int32_t bcl = code >> 4;
+                const uint2 lw = lvs[bcl];
+                const unsigned l0 = lw.x & 0xffffu, l1 = lw.x >> 16, l2 = lw.y & 0xffffu, l3 = lw.y >> 16;
+                Geo<M> g;
+                geo_from_vertices<M>(xyz + l0 * NP, xyz + l1 * NP, xyz + l2 * NP, xyz + l3 * NP, g);
+                if constexpr (MASS) {
+                    const double cm = 1.0 * 1.0 * g.measure;   // (OPK 2's own formula with coefficient 1)
+                    const int il = code & 15;
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) val[j] = rounded<R>(cm * tb->mtab[il * NB + j]);
+                } else {
+                    const int64_t bc = bc0 + bcl;
+                    const int cell = ((a.fq != nullptr && a.fq_block == 0) || op.needs_rows) ? a.bc_cell[bc] : 0;
+                    const double fc = fblk ? a.fq[at] : 0.0;
+                    fval = rounded<R>(element_row<M, R, OPK>(a, op, tb, g, cell, code & 15, want_matrix, [&](int j, double value) { val[j] = rounded<R>(value); }, rt,
+                                                             fblk ? bc : (int64_t)-1, fc, fbc ? bc : (int64_t)-1));
+                }
+            }
+            // accumulation rounds, one per visit index of the step, ascending.  All items of a row live in THIS wavefront, whose LDS
+            // operations complete in program order: a round's read-modify-writes are behind those of the round before, no barrier
+            const int32_t rb = rbase_s[q];
+            for (int u = v0; u < v0 + V && u < maxv; ++u) {
+                if (on && v == u) {
+                    if (MASS || want_matrix) {
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) {
+                            const uint32_t slot = (sw[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+                            acc[rb + (int32_t)slot] += val[j];
+                        }
+                    }
+                    if constexpr (!MASS) facc_s[q] += fval;
+                }
+            }
+            v0 += V;
+        }
+    };
+    sweep(std::integral_constant<bool, false>{});
+    __syncthreads();
+    if (a.force != nullptr && tid < kAsmBlock) {
+        const int32_t lr = a.lane_row[row0 + tid];
+        if (lr >= 0) a.force[lr] = facc_s[tid];
+    }
+    if (want_matrix) {
+        for (int k = tid; k < blk_nnz; k += THREADS) a.vals[base + k] = acc[k];
+        if (a.row_stat != nullptr && tid < kAsmBlock) {
+            const int32_t lr = a.lane_row[row0 + tid];
+            if (lr >= 0) {
+                const int32_t my0 = a.rowptr[lr], my1 = a.rowptr[lr + 1];
+                double rmax = 0.0;
+                for (int k = my0; k < my1; ++k) rmax = fmax(rmax, fabs(acc[k - base]));
+                a.row_stat[2 * (int64_t)lr] = acc[a.diag[lr] - base], a.row_stat[2 * (int64_t)lr + 1] = rmax;
+            }
+        }
+    }
+    if constexpr (MASS2 == 2) {
+        __syncthreads();
+        for (int k = tid; k < blk_nnz; k += THREADS) acc[k] = 0.0;
+        __syncthreads();
+        sweep(std::integral_constant<bool, true>{});
+        __syncthreads();
+        for (int k = tid; k < blk_nnz; k += THREADS) a.vals2[base + k] = acc[k];
     }
 }
 

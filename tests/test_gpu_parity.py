@@ -662,3 +662,44 @@ def test_tuning_knobs_do_not_change_results(capi, oracle, mesh_loader):
         assert np.abs(c.solution() - u0).max() <= 1e-10 * np.abs(u0).max(), (key, value)
         c.tune(key, 0 if key == "spmv_ablate" else defaults[key])
     c.close()
+
+
+@pytest.mark.parametrize("mesh_name", ["unit_square_16", "c_shaped", "unit_sphere", "cube8", "cube14"])
+def test_visit_parallel_assembly_gives_the_row_walking_bits(capi, oracle, mesh_loader, mesh_name):
+    """k_assemble_items (P2 spaces: the (row, visit) pairs of a block are the work items of 1024 threads) adds, into every slot, the
+    addends of the row-walking sweep in the same order: stiff_, mass_ and force_ must be the same BITS with the knob on and off -- for the
+    Laplacian (+ mass as second sweep), a constant-coefficient advection-diffusion-reaction operator, space-varying coefficients, the
+    mass matrix alone and forcing-only sweeps (second forcing column) -- and the oracle's numbers within the entry tolerance."""
+    if mesh_name.startswith("cube"):
+        from fdapde_core_amd import meshgen
+
+        m = oracle.Mesh(*meshgen.unit_cube(int(mesh_name[4:])))   # jittered, permuted Kuhn tetrahedra: 4913 / 24389 P2 DOFs, many blocks
+    else:
+        m = mesh_loader(mesh_name)
+    c = capi.Context(device=0)
+    c.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = c.dofs_build(2)
+    qn = c.quadrature_nodes()
+    rng = np.random.default_rng(7)
+    fq = np.stack([np.sin(qn.sum(axis=1)), rng.standard_normal(qn.shape[0])], axis=1)
+    b = np.array([0.7, -0.2, 0.4][:m.M])
+    cq = 1.0 + qn[:, 0] ** 2
+    ops = {"lap": lambda mod: -mod.laplacian(), "adr": lambda mod: -mod.laplacian() + mod.advection(b) + mod.reaction(1.5),
+           "field": lambda mod: -mod.laplacian() + mod.reaction_field(cq)}
+    od, _, _, _ = oracle.enumerate_dofs(m, 2)
+    for name, mk in ops.items():
+        got = {}
+        for items in (0, 1):
+            c.tune("asm_items", items)
+            c.set_operator(mk(capi))
+            c.set_forcing(fq)
+            c.init()
+            got[items] = (c.matrix_values(capi.MAT_STIFF), c.matrix_values(capi.MAT_MASS), c.force(ncols=2))
+            c.assemble_operator(capi.MAT_MASS, capi.reaction(1.0))   # OPK 2 on its own
+            got[items] += (c.matrix_values(capi.MAT_MASS),)
+        for x, y in zip(got[0], got[1]):
+            assert np.array_equal(x, y), name
+        ref = oracle.assemble_operator(m, 2, od, nd, mk(oracle))
+        assert _entry_close(got[1][0], ref.values), name
+        assert _entry_close(got[1][2][:nd], oracle.assemble_forcing(m, 2, od, nd, fq[:, 0])), name
+    c.close()

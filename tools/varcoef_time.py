@@ -1,6 +1,6 @@
 import os, sys, time
 import numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fdapde_loader import load_package
 capi = load_package().capi
 from fdapde_core_amd import meshgen
@@ -8,6 +8,8 @@ def run(dim, nx, order):
     nodes, cells, bnd = meshgen.unit_square(nx) if dim == 2 else meshgen.unit_cube(nx)
     c = capi.Context(0)
     c.mesh_upload(nodes, cells, bnd); nd = c.dofs_build(order)
+    for k, v in [kv.split("=") for kv in os.environ.get("TUNE", "").split(",") if kv]:   # e.g. TUNE=asm_items=0
+        c.tune(k, int(v))
     qn = c.quadrature_nodes()
     nq = qn.shape[0]
     f = np.ones(nq)

@@ -318,14 +318,14 @@ class Context:
         v = None if values is None else np.ascontiguousarray(values, dtype=float)
         self._check(self.lib.fdapde_lin_compute(self._ctx, which, None if v is None else _dp(v), 1 if symmetric else 0))
 
-    def lin_solve(self, b, method=SOLVER_AUTO, rtol=1e-10, check_every=0):
+    def lin_solve(self, b, method=SOLVER_AUTO, rtol=1e-10, check_every=0, maxit=0):
         """fdapde::SparseLU::solve(b); b (n_dofs,) or (n_dofs, n_rhs)"""
         b = np.asarray(b, dtype=float)
         one = b.ndim == 1
         B = b.reshape(b.shape[0], -1)
         flat = np.ascontiguousarray(B.T).reshape(-1)
         out = np.zeros_like(flat)
-        opt = Options(method=method, maxit=0, rtol=rtol, assembly=0, check_every=check_every, time_spmv=0)
+        opt = Options(method=method, maxit=maxit, rtol=rtol, assembly=0, check_every=check_every, time_spmv=0)
         info = Info()
         self._check(self.lib.fdapde_lin_solve(self._ctx, C.byref(opt), _dp(flat), B.shape[1], _dp(out), C.byref(info)))
         X = np.ascontiguousarray(out.reshape(B.shape[1], B.shape[0]).T)

@@ -104,6 +104,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
         for (int v = 0; v < 2; ++v)
             c->sp_rowptr[v].release(), c->sp_colidx[v].release(), c->sp_map[v].release(), c->sp_tbase[v].release(), c->sp_col16[v].release(),
               c->sp_vrow[v].release();
+        if (c->h_io) (void)hipHostFree(c->h_io);
         if (c->h_ctl) (void)hipHostFree(c->h_ctl);
         if (c->h_sc) (void)hipHostFree(c->h_sc);
         (void)hipEventDestroy(c->ev0), (void)hipEventDestroy(c->ev1), (void)hipEventDestroy(c->ev_p0), (void)hipEventDestroy(c->ev_p1);
@@ -338,6 +339,8 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "persist_fill_fused" && (value == 0 || value == 1)) c->persist_fill_fused = value;
     else if (k == "persist_prefetch" && (value == 0 || value == 1)) c->persist_prefetch = value;
     else if (k == "persist_cols" && (value == 0 || value == 1)) c->persist_cols = value;
+    else if (k == "persist_direct" && (value == 0 || value == 1)) c->persist_direct = value;
+    else if (k == "persist_direct_spin_us" && value >= 0 && value <= 1000000) c->persist_direct_spin_us = value;
     else if (k == "persist_single_rows" && value >= 0 && value <= 8192) {
         c->persist_single_rows = value;
         for (auto& ps : c->ps) ps.tried = ps.ok = ps.filled = false;

@@ -222,6 +222,10 @@ struct fdapde_ctx {
     DBuf<int32_t> ctl;
     DBuf<double> coef[kMaxTerms];
     bool coef_of_op = false;   // coef[] hold the space-varying data of the operator set by fdapde_set_operator (uploaded by fdapde_init)
+    double* h_io = nullptr;     // pinned, device-mapped: [b | x | outcome record] of a direct small solve (run_persist_direct)
+    size_t h_io_cap = 0;
+    int persist_direct = 1;            // knob: 0 = single right-hand sides of one-workgroup systems take the general path
+    int persist_direct_spin_us = 2000; // how long the host spins on the record's status word before it waits for the stream (0: never spins)
     int32_t* h_ctl = nullptr;   // pinned: ctl[3]
     double* h_sc = nullptr;     // pinned: sc[0..3]
     int spmv_grid = 0, rb_per_band = 0, vec_grid = 0, n_rb = 0, cg_grid = 0;

@@ -1054,6 +1054,27 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
     // several columns against a system the single-launch CG holds in few workgroups (the small systems the reference's users solve by the
     // thousand: one or two of 256 CUs busy per solve): Q columns side by side in ONE launch of G x Q workgroups, each column with boards of
     // its own; the same arithmetic per column as one by one, hence the same bits
+    // ONE column against a system of one workgroup (a caller that cannot batch: 0.15 ms of wall time around a 50 us launch on the general
+    // path -- upload, two small kernels, the launch, two read-backs, three waits): the launch does it all (run_persist_direct)
+    if (n_rhs == 1 && persist_cols && c->persist_cols && c->persist_direct && method == FDAPDE_SOLVER_CG_FUSED && !c->lin_state->ss.dist &&
+        !c->lin_state->ss.rowdist && !c->lin_state->ss.use_bnd && c->ps[0].meta.G == 1) {
+        bool ran = false;
+        const double tol2 = rtol * rtol;
+        if (int rc = run_persist_direct(c, 0, tol2, maxit, b, x, &ran)) return rc;
+        if (ran) {
+            const double bb = c->h_sc[0], rr = c->h_sc[3];
+            c->info.iters = c->h_ctl[1], c->info.relres = bb > 0 ? sqrt(rr / bb) : 0.0;
+            c->info.converged = (rr <= tol2 * bb && c->h_ctl[2] == 0) ? 1 : 0;
+            c->info.method_used = method, c->info.persistent = 1, c->info.launch_ms = 0.0, c->info.t_solve_ms = 0.0;
+            c->info.spmv_avg_ms = 0, c->info.spmv_timed = 0;
+            if (info) *info = c->info;
+            if (!c->info.converged) {
+                c->err = c->h_ctl[2] ? "Krylov breakdown (operator not SPD for CG)" : "maxit reached";
+                return FDAPDE_ENOCONV;
+            }
+            return FDAPDE_OK;
+        }
+    }
     const bool cols_bicg = method == FDAPDE_SOLVER_BICGSTAB && c->persist_bicg && !c->ps[0].meta.sym && c->ps[0].meta.R <= 8;   // (the single-launch BiCGStab's own limits)
     if (persist_cols && c->persist_cols && (method == FDAPDE_SOLVER_CG_FUSED || cols_bicg) && !c->lin_state->ss.dist && !c->lin_state->ss.rowdist &&
         !c->lin_state->ss.use_bnd) {

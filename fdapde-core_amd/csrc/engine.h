@@ -117,7 +117,8 @@ int fill_persist_scaled(fdapde_ctx* c, int v, const double* A);   // ... from th
 // the whole fused-update CG as one launch; *ran = false: the launch gave up (hand-off timeout) or can never be resident
 int run_persist_cols(fdapde_ctx* c, int v, double tol2, int maxit, int n_cols, const double* r_cols, double* x_cols, double* sc_cols, int32_t* ctl_cols,
                      int32_t* h_ctl, double* h_sc, bool* ran, bool bicg = false);   // several right-hand sides side by side in one launch
-int run_persist(fdapde_ctx* c, int v, double tol2, int maxit, bool* ran, bool bicg = false);   // bicg: the BiCGStab kernel (plain layouts, <= 8 rows per thread)
+int run_persist(fdapde_ctx* c, int v, double tol2, int maxit, bool* ran, bool bicg = false);
+int run_persist_direct(fdapde_ctx* c, int v, double tol2, int maxit, const double* b_host, double* x_host, bool* ran);   // one column, one workgroup, zero-copy in and out   // bicg: the BiCGStab kernel (plain layouts, <= 8 rows per thread)
 
 // ---- row-distributed multi-GPU form of the single-launch solver (persist_engine.hip); all COLLECTIVE over the context's ranks
 int build_rowdist(fdapde_ctx* c, int v);

@@ -42,6 +42,16 @@ struct PersistArgs {
                                       // sc[4 c], writes x_out + c col_stride, sc[4 c + 3] and ctl[4 c ..], and talks over boards of its own
                                       // (pboard / dboard + c board_stride); x == nullptr: every column starts from 0
     int64_t col_stride, board_stride;
+    int32_t direct;                   // ONE workgroup, one column, started from 0 (a small handle solve that cannot be batched): the launch does the
+                                      // caller's prologue and epilogue itself -- reads the right-hand side as handed over (b_ext, reference DOF order,
+                                      // pinned host memory read over PCIe), scales it, takes ||b~||^2 from its own first r.r, and writes the UNSCALED
+                                      // solution in the reference order (x_ext) and the outcome record (rec) straight into pinned host memory:
+                                      // no prologue / epilogue kernels, no copies, one wait
+    const double* b_ext;              // direct: right-hand side, reference DOF order
+    double* x_ext;                    // direct: solution, reference DOF order
+    double* rec;                      // direct: [0] iterations, [1] final r.r, [2] ||b~||^2, [3] status + 1 (written LAST: 1 maxit, 2 converged, 3 breakdown)
+    const int32_t* i2e;               // direct: internal DOF -> reference DOF
+    const double* scale;              // direct: Jacobi scale, internal order
     int32_t pf_steps;                 // streaming forms, != 0: the first entry step of the next operator application is touched (pulled into the L2)
                                       // while the workgroup waits for the dot records
     double tol2;
@@ -284,13 +294,14 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
     for (int j = 0; j < R; ++j) {
         const int32_t d = a.slot_dof[(size_t)g * S + j * T + tid];
         const bool on = d >= 0;
-        rv[j] = on ? a.r_in[d] : 0.0;
+        if (!DIST && a.direct) rv[j] = on ? a.scale[d] * (a.b_ext[a.i2e[d]] - 0.0) : 0.0;   // (k_cols_init's expression)
+        else rv[j] = on ? a.r_in[d] : 0.0;
         xv[j] = on && a.x != nullptr ? a.x[d] : 0.0;
         if constexpr (SYM) p_tab[j * T + tid] = rv[j];
         else pv[j] = rv[j], dof[j] = d;
         rr_part += rv[j] * rv[j];
     }
-    const double bb = a.sc[0];
+    double bb = (!DIST && a.direct) ? 0.0 : a.sc[0];   // (direct: the launch's own first r.r, below)
     const bool stamper = a.time_phases && tid == 0;   // every workgroup stamps its own phases (a few s_memrealtime per iteration)
     long long t_spmv = 0, t_gather = 0, t_update = 0, n_stamped = 0;
     int it = 0, status = 0;   // status: 1 converged, 2 breakdown, 3 hand-off timeout
@@ -751,6 +762,7 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
         }
         const double pAp = tot[0], yy = tot[1];
         rr = tot[2];
+        if (!DIST && a.direct && it == 0) bb = rr;   // x0 = 0: r0 = b~
         if (stamper) c2 = wall_clock64();
         // ---- the recurrence of k_cgf_update (kernels_krylov.h): stop test on the explicit r.r, then x, r, p
         if (rr <= a.tol2 * bb) {
@@ -788,10 +800,22 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
             int32_t d;
             if constexpr (SYM) d = a.slot_dof[(size_t)g * S + j * T + tid];
             else d = dof[j];
-            if (d >= 0) a.x_out[d] = xv[j];
+            if (!DIST && a.direct) {
+                if (d >= 0) a.x_ext[a.i2e[d]] = a.scale[d] * xv[j] + 0.0;   // (k_cols_finish's expression)
+            } else if (d >= 0)
+                a.x_out[d] = xv[j];
         }
     }
-    if (g == 0 && tid == 0 && status != 3) {
+    if (!DIST && a.direct) {
+        // the record goes out behind the solution: every wavefront's stores are drained, then ONE thread publishes the status at system scope
+        // (the host may be spinning on it instead of waiting for the stream)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            a.rec[0] = (double)it, a.rec[1] = rr, a.rec[2] = bb;
+            __atomic_store_n(reinterpret_cast<volatile long long*>(a.rec + 3), (long long)(status + 1), __ATOMIC_RELEASE);
+        }
+    } else if (g == 0 && tid == 0 && status != 3) {
         a.sc[3] = rr;
         a.ctl[0] = status == 1 ? 1 : 0, a.ctl[1] = it, a.ctl[2] = status == 2 ? 1 : 0;
     }
@@ -799,7 +823,7 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
         double* st = a.stats + 4 * (size_t)g;
         st[0] = (double)n_stamped, st[1] = (double)t_spmv, st[2] = (double)t_gather, st[3] = (double)t_update;
     }
-    if (status == 3 && tid == 0) atomicExch(a.ctl + 3, 1);
+    if (status == 3 && tid == 0 && !(!DIST && a.direct)) atomicExch(a.ctl + 3, 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -1,6 +1,7 @@
 // persist_engine.hip -- host side of the single-launch solver (kernels_persist.h): layout selection and construction for a boundary
 // variant, the launch itself (occupancy-checked, epoch-tagged), the fall-back policy after a hand-off timeout.
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <utility>
 
@@ -387,6 +388,62 @@ int run_persist(fdapde_ctx* c, int v, double tol2, int maxit, bool* ran, bool bi
     return FDAPDE_OK;
 }
 
+
+// ONE right-hand side against a system the single-launch CG holds in ONE workgroup, for callers that cannot batch columns: the launch reads b
+// (reference DOF order) from pinned host memory, scales it, solves, and writes the unscaled solution (reference order) and its outcome record
+// back into pinned host memory itself (kernels_persist.h PersistArgs::direct) -- no prologue / epilogue kernels, no device-to-host copies, ONE
+// wait.  The host spins on the record's status word (written last, system scope) for a while before it falls back to waiting for the stream.
+// *ran = false: not applicable / the launch gave up (the caller takes the general path).
+int run_persist_direct(fdapde_ctx* c, int v, double tol2, int maxit, const double* b_host, double* x_host, bool* ran) {
+    fdapde_ctx::Persist& ps = c->ps[v];
+    *ran = false;
+    if (!ps.ok || !ps.filled || ps.meta.G != 1 || ps.meta.n_drop != 0) return FDAPDE_OK;
+    hipStream_t st = c->stream;
+    const size_t n = (size_t)c->hs.n_dofs;
+    if (c->h_io_cap < 2 * n + 8) {
+        if (c->h_io) (void)hipHostFree(c->h_io);
+        c->h_io = nullptr, c->h_io_cap = 0;
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_io), sizeof(double) * (2 * n + 8)));   // (pinned, mapped, coherent: the device reads and writes it over PCIe)
+        c->h_io_cap = 2 * n + 8;
+    }
+    double* hb = c->h_io;
+    double* hx = c->h_io + n;
+    volatile double* rec = c->h_io + 2 * n;
+    std::memcpy(hb, b_host, sizeof(double) * n);
+    rec[0] = rec[1] = rec[2] = 0.0;
+    *reinterpret_cast<volatile long long*>(rec + 3) = 0;
+    PersistArgs a{};
+    a.maxit = maxit, a.time_phases = 0, a.tol2 = tol2;
+    a.direct = 1, a.b_ext = hb, a.x_ext = hx, a.rec = c->h_io + 2 * n, a.i2e = c->dof_i2e.p, a.scale = c->scale.p;
+    a.sc = c->sc.p, a.ctl = c->ctl.p;   // (not touched by a direct launch)
+    const int rc_launch = launch_persist(c, ps, a, false, false);
+    if (rc_launch == FDAPDE_EUNSUPPORTED) return FDAPDE_OK;
+    if (rc_launch) return rc_launch;
+    // the outcome: the status word first (spin, bounded), the stream's end as the fall-back and as the fence for the event pair
+    long long status1 = 0;
+    if (c->persist_direct_spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while ((status1 = *reinterpret_cast<volatile long long*>(rec + 3)) == 0) {
+            if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > (double)c->persist_direct_spin_us) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (status1 == 0) {
+        HIPCHK(c, hipStreamSynchronize(st));
+        status1 = *reinterpret_cast<volatile long long*>(rec + 3);
+    }
+    c->persist_launch_ms = 0;   // (the event pair is only read when somebody waits for the stream anyway: fdapde_info_get of a direct solve reports 0)
+    if (status1 == 0 || status1 == 4) {   // the launch gave up (tests: persist_debug_stall) or never ran
+        HIPCHK(c, hipStreamSynchronize(st));
+        return FDAPDE_OK;
+    }
+    std::memcpy(x_host, hx, sizeof(double) * n);
+    c->h_ctl[0] = status1 == 2 ? 1 : 0, c->h_ctl[1] = (int32_t)rec[0], c->h_ctl[2] = status1 == 3 ? 1 : 0, c->h_ctl[3] = 0;
+    c->h_sc[0] = rec[2], c->h_sc[3] = rec[1];
+    ps.epoch_next += (uint32_t)c->h_ctl[1] + 2u;
+    *ran = true;
+    return FDAPDE_OK;
+}
 
 // ... straight from the unscaled matrix A and the Jacobi scale (k_persist_fill_scaled): the scaled full-pattern copy is then not needed
 int fill_persist_scaled(fdapde_ctx* c, int v, const double* A) {

@@ -537,3 +537,46 @@ def test_persistent_path_under_contention_from_other_processes():
                          stderr=subprocess.STDOUT, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:]
     assert out.stdout.count("solves ok") == 3, out.stdout[-3000:]
+
+
+@pytest.mark.parametrize("dim,nx,order", [(2, 16, 1), (2, 40, 1), (3, 8, 1), (2, 12, 2)])
+def test_direct_launch_of_a_single_right_hand_side(env, dim, nx, order):
+    """fdapde::SparseLU::solve(b) with ONE column against a system of one workgroup (DESIGN.md 9 item 7): the launch reads b from pinned host
+    memory, scales it, and writes the unscaled solution and its outcome record back itself (knob persist_direct).  Same recurrence as the
+    general path -- its reference norm is the launch's own first r.r instead of the prologue kernel's sum, so the stop test may fire one
+    iteration apart -- identical bits from call to call, the zero right-hand side and an exhausted iteration budget included."""
+    capi, meshgen = env
+    nodes, cells, bnd = meshgen.unit_square(nx) if dim == 2 else meshgen.unit_cube(nx)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(order)
+    c.set_operator(-capi.laplacian() + capi.reaction(1.0))
+    c.set_forcing(np.ones(c.quadrature_nodes().shape[0]))
+    c.init()
+    c.lin_compute(capi.MAT_STIFF, symmetric=True)
+    assert c.solver_layout_kind(False)["workgroups"] == 1
+    b = np.random.default_rng(11).standard_normal(nd)
+    c.tune("persist_direct", 0)
+    x0, i0 = c.lin_solve(b, rtol=1e-11)
+    for spin in (0, 2000):
+        c.tune("persist_direct", 1)
+        c.tune("persist_direct_spin_us", spin)
+        x1, i1 = c.lin_solve(b, rtol=1e-11)
+        x2, i2 = c.lin_solve(b, rtol=1e-11)
+        assert i1.persistent == 1 and i1.converged == 1 and abs(i1.iters - i0.iters) <= 1
+        assert np.linalg.norm(x1 - x0) <= 1e-10 * np.linalg.norm(x0)
+        assert i2.iters == i1.iters and np.array_equal(x1, x2)
+        assert abs(i1.relres - i0.relres) <= 1e-3 * i0.relres + 1e-16 or abs(i1.iters - i0.iters) == 1
+    rowptr, colidx = c.pattern_get()
+    import scipy.sparse as sp
+
+    A = sp.csr_matrix((c.matrix_values(capi.MAT_STIFF), colidx, rowptr), shape=(nd, nd))
+    assert np.linalg.norm(A @ x1 - b) <= 1e-9 * np.linalg.norm(b)
+    xz, iz = c.lin_solve(np.zeros(nd))
+    assert iz.iters == 0 and iz.converged == 1 and not xz.any()
+    with pytest.raises(capi.FdapdeError) as e:
+        c.lin_solve(b, rtol=1e-14, maxit=3)
+    assert e.value.status == capi.ENOCONV
+    xs, _ = c.lin_solve(1e-150 * b, rtol=1e-11)   # (tiny but not zero: the relative stop test must not care)
+    assert np.linalg.norm(xs - 1e-150 * x1) <= 1e-10 * np.linalg.norm(1e-150 * x1)
+    c.close()

@@ -92,7 +92,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
         c->peer_send_dof.release(), c->peer_src_off.release(), c->peer_src.release(), c->peer_sendbuf.release(), c->peer_recvbuf.release();
         release_rowdist(c);
         if (c->comm) (void)g_rccl.CommDestroy(c->comm);
-        c->lin_mat.release(), c->stiff_stat.release(), c->ar_dev.release(), c->persist_stats.release(), c->persist_x.release(), c->coords_e.release();
+        c->lin_mat.release(), c->stiff_stat.release(), c->ar_dev.release(), c->persist_stats.release(), c->persist_x.release(), c->persist_xs.release(), c->coords_e.release();
         dev_topology_release(&c->topo);
         c->part_cells.release(), c->part_off.release(), c->part_slots.release(), c->wave_slots.release(), c->part_shared.release();
         for (auto& bk : c->bk)
@@ -340,6 +340,15 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "persist_prefetch" && (value == 0 || value == 1)) c->persist_prefetch = value;
     else if (k == "persist_cols" && (value == 0 || value == 1)) c->persist_cols = value;
     else if (k == "persist_direct" && (value == 0 || value == 1)) c->persist_direct = value;
+    else if (k == "persist_wide_gj" && (value == 4 || value == 6 || value == 12)) {
+        c->persist_wide_gj = value;
+        for (auto& ps : c->ps) ps.attr_set = nullptr;
+    }
+    else if ((k == "persist_wide" && (value == 0 || value == 1)) || (k == "persist_max_wg" && value >= 0)) {
+        if (k == "persist_wide") c->persist_wide = value;
+        else c->persist_max_wg = value;
+        for (auto& ps : c->ps) ps.tried = ps.ok = ps.filled = false;
+    }
     else if (k == "persist_direct_spin_us" && value >= 0 && value <= 1000000) c->persist_direct_spin_us = value;
     else if (k == "persist_single_rows" && value >= 0 && value <= 8192) {
         c->persist_single_rows = value;

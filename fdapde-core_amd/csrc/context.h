@@ -355,6 +355,10 @@ struct fdapde_ctx {
     } rd;
     DBuf<double> persist_stats;
     DBuf<double> persist_x;                  // the persistent launch writes its solution here (x stays the initial guess)
+    DBuf<double> persist_xs;                 // wide form (24 rows per thread): x of every slot, in slot order, between the iterations of a launch
+    int persist_wide_gj = 12;                // knob (measurements): 4 / 6 / 12 passes of a phase of the wide form load together (2.35 M rows: 73.0 / 73.4 / 71.8 us per iteration)
+    int persist_wide = 1;                    // knob: 0 = systems of more than 8 192 rows per workgroup keep the multi-launch path
+    int persist_max_wg = 0;                  // knob (tests): the single-launch layouts use at most this many workgroups (0: one per CU)
     double persist_launch_ms = 0;            // duration of the last persistent launch (HIP events on the stream)
     int persist_host_below = 32768;          // systems of at most this many DOFs build the persistent layout on the host (first-solve latency)
     int persist_cols = 1;                    // knob: several columns of fdapde_lin_solve as ONE persistent launch where G x columns workgroups are resident

@@ -406,8 +406,8 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
     if (G < 1) G = 1;
     if (G >= (1 << 20)) return FDAPDE_EUNSUPPORTED;   // 20 bits of the row keys
     int64_t rpw = (n_int + G - 1) / G;   // rows of the largest workgroup
-    if (!blocked && block_rows == nullptr && rpw > (int64_t)kPersistRmax * T) return FDAPDE_EUNSUPPORTED;   // too many rows for one launch of resident workgroups
-    const bool sym = !blocked && persist_want_sym(sym_mode, nnz_kept, G, rpw);
+    if (!blocked && block_rows == nullptr && rpw > (int64_t)kPersistRwide * T) return FDAPDE_EUNSUPPORTED;   // too many rows for one launch of resident workgroups
+    const bool sym = !blocked && persist_want_sym(sym_mode, nnz_kept, G, rpw) && rpw <= (int64_t)kPersistRmax * T;   // (the wide form is plain: kPersistRwide)
     std::vector<int32_t> h_wgs;           // interior-row boundaries of the workgroups
     Tmp<int32_t> wgs, wg;
     bool uniform = true;
@@ -432,7 +432,8 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
                 if (h_wgs[(size_t)g + 1] <= h_wgs[(size_t)g]) uniform = true;   // an empty workgroup (tiny systems): equal row counts
                 mx = std::max<int64_t>(mx, h_wgs[(size_t)g + 1] - h_wgs[(size_t)g]);
             }
-            if (mx > (int64_t)kPersistRmax * T && rpw <= (int64_t)kPersistRmax * T) uniform = true;   // equal counts fit a workgroup, equal cost would not
+            const int64_t cap_rows = (int64_t)(rpw <= (int64_t)kPersistRmax * T ? kPersistRmax : kPersistRwide) * T;
+            if (mx > cap_rows && rpw <= cap_rows) uniform = true;   // equal counts fit a workgroup (of that form), equal cost would not
             if (!uniform) rpw = mx;
         }
         if (uniform) {
@@ -483,9 +484,8 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
     DP_CHK(hipStreamSynchronize(st));
     int32_t max_halo = 0;
     for (int g = 0; g < G; ++g) max_halo = std::max(max_halo, h_cnt[(size_t)g]);
-    int R = 2;
-    while ((int64_t)R * T < rpw || (!blocked && (int64_t)(R / 2) * T < max_halo)) R *= 2;   // (the blocked SpMV has no import-free phase)
-    if (R > kPersistRmax) return FDAPDE_EUNSUPPORTED;
+    const int R = persist_rows_per_thread(rpw, max_halo, blocked, sym);   // (the blocked SpMV has no import-free phase)
+    if (R == 0) return FDAPDE_EUNSUPPORTED;
     const int S = R * T, nsl = S / 64, SA = blocked ? S : (R / 2) * T;   // blocked: one class, plain (imports?, length, DOF) order
     pl.G = G, pl.R = R, pl.nsl = nsl, pl.n_int = n_int, pl.nnz = nnz_stored, pl.nnz_full = nnz_kept;
     Tmp<uint64_t> imp_key;   // unique (workgroup, DOF) imports, DOF ascending inside a workgroup

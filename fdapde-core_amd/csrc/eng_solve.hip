@@ -779,7 +779,8 @@ int e_solver_layout(fdapde_ctx* c, int32_t with_dirichlet, int64_t* n_interior, 
         if (persist) {   // one iteration of the persistent CG: the ELL blocks (8 + 2 bytes per entry, padding included) + the exchanged
                          // entries of p (two 8-byte granules each, written once and read once)
             // (fdapde_solver_layout_kind tells whether the blocks stream at all: the resident form reads them from LDS)
-            *streamed_bytes = 10.0 * (double)c->ps[v].meta.n_entries + 32.0 * (double)c->ps[v].meta.n_board;
+            *streamed_bytes = 10.0 * (double)c->ps[v].meta.n_entries + 32.0 * (double)c->ps[v].meta.n_board +
+                              (c->ps[v].meta.R > kPersistRmax ? 16.0 * (double)c->ps[v].meta.n_int : 0.0);   // (wide form: x read and written once per row)
         } else if (blocked) {   // ELL blocks + x staged once per block (own rows and imports) + y written once
             *streamed_bytes = 10.0 * (double)c->bk[v].meta.n_entries + 8.0 * (double)(c->bk[v].meta.n_int + c->bk[v].meta.n_imp) + 8.0 * (double)c->bk[v].meta.n_int;
         } else if (c->spmv_variant == 2 && c->sp_built[v]) {
@@ -1028,7 +1029,7 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
     // matrix (kernels_multirhs.h); what is left goes column by column
     // (a system the persistent CG takes is faster column by column -- one launch each, no vector traffic -- than batched through
     // the multi-launch SpMM: C3-size, 22.5 ms per column against 32 ms per column in a batch of 8)
-    const bool persist_cols = c->persist && !c->persist_broken && c->ps[0].ok && c->ps[0].filled;
+    const bool persist_cols = c->persist && !c->persist_broken && c->ps[0].ok && c->ps[0].filled && c->ps[0].meta.R <= kPersistRmax;   // (the wide form: one column)
     const bool batched = c->multi_rhs && n_rhs >= 4 && method == FDAPDE_SOLVER_CG_FUSED && !c->lin_state->ss.dist && !c->lin_state->ss.rowdist && !persist_cols;
     if (batched) {
         if (!c->lin_sq_ready) {   // full-pattern scaled copy (explicit unit diagonal), once per prepared matrix

@@ -59,8 +59,8 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
     int G = (int)std::min<int64_t>(n_wg, want);
     if (G < 1) G = 1;
     int64_t rpw = (n_int + G - 1) / G;   // rows of the largest workgroup
-    if (block_rows == nullptr && rpw > (int64_t)kPersistRmax * T) return FDAPDE_EUNSUPPORTED;   // too many rows for one launch of resident workgroups
-    const bool sym = persist_want_sym(sym_mode, nnz_kept, G, rpw);
+    if (block_rows == nullptr && rpw > (int64_t)kPersistRwide * T) return FDAPDE_EUNSUPPORTED;   // too many rows for one launch of resident workgroups
+    const bool sym = persist_want_sym(sym_mode, nnz_kept, G, rpw) && rpw <= (int64_t)kPersistRmax * T;   // (the wide form is plain: kPersistRwide)
     std::vector<int64_t> wgs;             // interior-row boundaries of the workgroups
     if (block_rows != nullptr) {
         G = n_wg;                         // caller-given block sizes; they add up to n_int
@@ -90,7 +90,8 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
                 if (wgs[(size_t)q + 1] <= wgs[(size_t)q]) uniform = true;   // an empty workgroup (tiny systems): equal row counts
                 mx = std::max(mx, wgs[(size_t)q + 1] - wgs[(size_t)q]);
             }
-            if (mx > (int64_t)kPersistRmax * T && rpw <= (int64_t)kPersistRmax * T) uniform = true;   // equal counts fit a workgroup, equal cost would not
+            const int64_t cap_rows = (int64_t)(rpw <= (int64_t)kPersistRmax * T ? kPersistRmax : kPersistRwide) * T;
+            if (mx > cap_rows && rpw <= cap_rows) uniform = true;   // equal counts fit a workgroup (of that form), equal cost would not
             if (!uniform) rpw = mx;
         }
         if (uniform) {
@@ -166,12 +167,11 @@ int host_build_persist_layout(const HostSpace& hs, bool use_bnd, int n_wg, int l
     // rows per thread: the first half of a thread's passes holds rows without imports (multiplied while the neighbours' entries
     // travel), the second half everything else -- so a workgroup needs T R / 2 slots for its importing rows
     const int32_t max_halo = *std::max_element(n_halo.begin(), n_halo.end());
-    int R = 2;
     // allow_late: a workgroup with more importing rows than the second half of its slots holds does not force twice the rows per thread
     // on everybody (or the refusal of the system): it is marked LATE -- the kernel fetches its imports before its first pass -- and its
     // rows fill the slots in one run
-    while ((int64_t)R * T < rpw || (!allow_late && (int64_t)(R / 2) * T < max_halo)) R *= 2;
-    if (R > kPersistRmax) return FDAPDE_EUNSUPPORTED;
+    const int R = persist_rows_per_thread(rpw, max_halo, allow_late, sym);
+    if (R == 0) return FDAPDE_EUNSUPPORTED;
     const int S = R * T, nsl = S / 64, SA = (R / 2) * T;
     pl.G = G, pl.R = R, pl.nsl = nsl, pl.n_int = n_int, pl.sym = sym, pl.nnz_full = nnz_kept;
     pl.wg_late.assign((size_t)G, 0);

@@ -138,7 +138,22 @@ void host_build_slot_map(const HostSpace& hs, const int32_t* list, int64_t n, st
 //      one contiguous row range per workgroup (one workgroup per CU), each range as sliced ELL in the order the workgroup's
 //      threads own the rows, plus the lists of vector entries workgroups exchange every iteration.
 constexpr int kPersistT = 512;        // threads per workgroup
-constexpr int kPersistRmax = 16;      // rows per thread at most
+constexpr int kPersistRmax = 16;      // rows per thread at most -- with x, r (and p) of a thread's rows in registers
+constexpr int kPersistRwide = 24;     // ... and in the WIDE form of the plain streaming storage (kernels_persist.h, R > 16): x in HBM (one coalesced read + write
+                                      // per row and iteration, in slot order), p in its LDS table only, r and y in registers -- 12 288 rows per workgroup,
+                                      // i.e. single launches up to 3.1 M rows on 256 CUs.  The symmetric storage cannot follow (its accumulator table
+                                      // doubles the LDS per row): beyond 8 192 rows per workgroup the layout is plain
+// rows per thread of a layout whose largest workgroup holds rpw rows, max_halo of them importing (halo_free: the importing rows need no
+// half of the slots to themselves -- late workgroups / the blocked SpMV); 0 = the system does not fit one launch.  Shared by the host and
+// the device builder (the layouts must come out identical).
+inline int persist_rows_per_thread(int64_t rpw, int64_t max_halo, bool halo_free, bool sym) {
+    constexpr int64_t T = kPersistT;
+    int R = 2;
+    while (R <= kPersistRmax && ((int64_t)R * T < rpw || (!halo_free && (int64_t)(R / 2) * T < max_halo))) R *= 2;
+    if (R <= kPersistRmax) return R;
+    if (!sym && (int64_t)kPersistRwide * T >= rpw && (halo_free || (int64_t)(kPersistRwide / 2) * T >= max_halo)) return kPersistRwide;
+    return 0;
+}
 // Symmetric storage (PersistLayout::sym): an off-diagonal pair (i, j) whose rows both lie in one workgroup's block is stored ONCE, in
 // the row this rule names (a hash bit, so that every row keeps about half of its in-block entries); the kernel applies it to both
 // rows.  Entries whose column belongs to another workgroup stay in both rows.

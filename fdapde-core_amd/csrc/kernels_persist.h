@@ -70,6 +70,7 @@ struct PersistArgs {
     int32_t max_len;                       // symmetric storage: a row receives at most this many transposed products
     const double* r_in;           // initial residual (= initial direction), internal DOF order
     const double* x;              // initial guess (scaled unknowns), internal DOF order
+    double* x_slots;              // WIDE form (R > 16): x of every slot, [G][R T] in slot order -- read and written once per iteration, coalesced
     double* x_out;                // solution; a buffer of its own: a launch that gives up (ctl[3]) must leave the guess as it found it,
                                   // whatever the workgroups that did finish have stored (the host restarts from x, r, p)
     double* sc;                   // sc[0] = reference norm^2 (in); sc[3] = final r.r (out)
@@ -218,9 +219,17 @@ __device__ __forceinline__ double wave_sum64(double v) {
 //                 (products) x 2^-56 x max_len x max|a| x max_block |p| -- finer than fp64's own rounding of the largest products.
 //                 The import / export lists are read from global memory (L2) instead of LDS: the table takes their room.
 // DIST = true   : row-distributed form, see PersistArgs.
-template <int R, bool STREAM, bool SYM, bool DIST = false>
+// R > 16 (WIDE) : plain streaming storage for workgroups of up to 24 x 512 rows -- systems of 2.1 to 3.1 M rows on 256 CUs, which had to take the
+//                 multi-launch path (seven vector passes and two launches per iteration: 98 us per iteration at 2.35 M rows against ~57 here).
+//                 r and y of a thread's rows stay in registers; x lives in HBM in SLOT order (one coalesced read + write per row and iteration:
+//                 + 16 B per row on a stream of ~130 B per row), p in its LDS table only (as in the symmetric form), import / export lists are
+//                 read from global memory.  LDS: 96 KB of table + imports.
+template <int R, bool STREAM, bool SYM, bool DIST = false, int WIDE_GJ = 12>
 static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) {
     constexpr int T = kPersistT, W = T / 64, S = R * T, RI = R / 2;
+    constexpr bool WIDE = R > kPersistRmax;   // x in HBM, p in LDS only
+    constexpr bool PLDS = SYM || WIDE;        // p of the own rows lives in its LDS table only; DOF ids re-read at the end; lists in global memory
+    static_assert(!WIDE || (STREAM && !SYM && !DIST), "the wide form is the plain streaming storage on one GPU");
     extern __shared__ double lds[];
     __shared__ double red[W][3];
     __shared__ double tot[3];
@@ -253,12 +262,12 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
     const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(gc), 0, (int)min(e_left * 2, (int64_t)0x7fffffff), 0x00020000);
     const int lane16 = lane * 16, lane4 = lane * 4;
     // ---- stage the workgroup's tables (and, resident form, its block of the matrix)
-    const int32_t* impl = SYM ? a.imp_pos + a.imp_off[g] : impl_l;
-    const uint16_t* expl = SYM ? a.exp_slot + a.exp_off[g] : expl_l;
-    if constexpr (!SYM) {
+    const int32_t* impl = PLDS ? a.imp_pos + a.imp_off[g] : impl_l;
+    const uint16_t* expl = PLDS ? a.exp_slot + a.exp_off[g] : expl_l;
+    if constexpr (!PLDS) {
         for (int i = tid; i < H; i += T) impl_l[i] = a.imp_pos[a.imp_off[g] + i];
         for (int i = tid; i < E; i += T) expl_l[i] = a.exp_slot[a.exp_off[g] + i];
-    } else {
+    } else if constexpr (SYM) {
 #pragma unroll
         for (int j = 0; j < R; ++j) y_tab[j * T + tid] = 0;
     }
@@ -283,11 +292,12 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
     }
     // ---- the rows of this thread: slot j * T + tid, j < R.  SYM: p of the own rows lives in its LDS table only and the DOF ids are
     //      re-read at the end (the registers go to the transposed products)
-    double xv[R], rv[R], pv[SYM ? 1 : R];
-    int32_t dof[SYM ? 1 : R];
+    double xv[WIDE ? 1 : R], rv[R], pv[PLDS ? 1 : R];
+    int32_t dof[PLDS ? 1 : R];
+    double* const xs = WIDE ? a.x_slots + (size_t)g * S + tid : nullptr;   // this thread's x entries: xs[j T]
     double rr_part = 0;
     auto P = [&](int j) -> double {
-        if constexpr (SYM) return p_tab[j * T + tid];
+        if constexpr (PLDS) return p_tab[j * T + tid];
         else return pv[j];
     };
 #pragma unroll
@@ -296,8 +306,10 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
         const bool on = d >= 0;
         if (!DIST && a.direct) rv[j] = on ? a.scale[d] * (a.b_ext[a.i2e[d]] - 0.0) : 0.0;   // (k_cols_init's expression)
         else rv[j] = on ? a.r_in[d] : 0.0;
-        xv[j] = on && a.x != nullptr ? a.x[d] : 0.0;
-        if constexpr (SYM) p_tab[j * T + tid] = rv[j];
+        const double x0 = on && a.x != nullptr ? a.x[d] : 0.0;
+        if constexpr (WIDE) xs[j * T] = x0;
+        else xv[j] = x0;
+        if constexpr (PLDS) p_tab[j * T + tid] = rv[j];
         else pv[j] = rv[j], dof[j] = d;
         rr_part += rv[j] * rv[j];
     }
@@ -331,7 +343,7 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
         long long c0 = 0, c1 = 0, c2 = 0;
         if (stamper) c0 = wall_clock64();
         // ---- p of the own rows into the LDS table; exported entries onto the board
-        if constexpr (!SYM) {
+        if constexpr (!PLDS) {
 #pragma unroll
             for (int j = 0; j < R; ++j) p_tab[j * T + tid] = pv[j];
         }
@@ -397,29 +409,36 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
                 // U pair rows of every pass per step where a phase has only 1 or 2 passes (2 / 4 rows per thread): the loads in flight per
                 // wavefront, not the memory, bound the stream otherwise (kernels_persist_bicg.h)
                 constexpr int U = NJ >= 4 ? 1 : 8 / NJ;
+                // (the wide form has 12 passes per phase; WIDE_GJ of them load together.  All 12: 60 registers in flight next to r and y of 24 rows,
+                //  a few scalars spill into lanes -- still the fastest: 2.35 M rows 71.8 us per iteration against 73.4 with 6 and 73.0 with 4)
+                constexpr int GJ = NJ > 8 ? WIDE_GJ : NJ;
+                static_assert(NJ % GJ == 0, "the passes of a phase in equal groups");
                 for (int e = 0; e < mw; e += U) {
-                    pg_u32x4 v[U][NJ];
-                    uint32_t c[U][NJ];
 #pragma unroll
-                    for (int u = 0; u < U; ++u)
+                    for (int jg = J0; jg < J1; jg += GJ) {
+                        pg_u32x4 v[U][GJ];
+                        uint32_t c[U][GJ];
 #pragma unroll
-                        for (int j = J0; j < J1; ++j) {
-                            if (e + u < w[j]) {
-                                const int row = o0[j] + e + u;
-                                v[u][j - J0] = __builtin_amdgcn_raw_buffer_load_b128(rs_v, lane16, row * 1024, 0);
-                                c[u][j - J0] = __builtin_amdgcn_raw_buffer_load_b32(rs_c, lane4, row * 256, 0);
+                        for (int u = 0; u < U; ++u)
+#pragma unroll
+                            for (int j = jg; j < jg + GJ; ++j) {
+                                if (e + u < w[j]) {
+                                    const int row = o0[j] + e + u;
+                                    v[u][j - jg] = __builtin_amdgcn_raw_buffer_load_b128(rs_v, lane16, row * 1024, 0);
+                                    c[u][j - jg] = __builtin_amdgcn_raw_buffer_load_b32(rs_c, lane4, row * 256, 0);
+                                }
                             }
-                        }
 #pragma unroll
-                    for (int u = 0; u < U; ++u)
+                        for (int u = 0; u < U; ++u)
 #pragma unroll
-                        for (int j = J0; j < J1; ++j) {
-                            if (e + u < w[j]) {
-                                const pg_u32x4 q = v[u][j - J0];
-                                const double vx = __hiloint2double((int)q.y, (int)q.x), vy = __hiloint2double((int)q.w, (int)q.z);
-                                yv[j] += vx * p_tab[c[u][j - J0] & 0xffffu] + vy * p_tab[c[u][j - J0] >> 16];
+                            for (int j = jg; j < jg + GJ; ++j) {
+                                if (e + u < w[j]) {
+                                    const pg_u32x4 q = v[u][j - jg];
+                                    const double vx = __hiloint2double((int)q.y, (int)q.x), vy = __hiloint2double((int)q.w, (int)q.z);
+                                    yv[j] += vx * p_tab[c[u][j - jg] & 0xffffu] + vy * p_tab[c[u][j - jg] >> 16];
+                                }
                             }
-                        }
+                    }
                 }
             } else if constexpr (!SYM) {
                 for (int e = 0; e < mw; ++e) {
@@ -778,14 +797,27 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
         const double est = alpha * alpha * yy - rr;
         const double beta = (est > 0.0 && rr > 0.0) ? est / rr : 0.0;
         rr_part = 0;
+        if constexpr (WIDE) {   // x in HBM: the loads of all rows first (yv is free from here on: its registers take them), then the updates
+#pragma unroll
+            for (int j = 0; j < R; ++j) rv[j] -= alpha * yv[j], rr_part += rv[j] * rv[j];
+#pragma unroll
+            for (int j = 0; j < R; ++j) yv[j] = xs[j * T];
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const double pj = P(j);
+                xs[j * T] = yv[j] + alpha * pj;
+                p_tab[j * T + tid] = rv[j] + beta * pj;   // (every read of this iteration's table lies behind a barrier)
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const double pj = P(j);
             xv[j] += alpha * pj;
             rv[j] -= alpha * yv[j];
-            if constexpr (SYM) p_tab[j * T + tid] = rv[j] + beta * pj;   // (every read of this iteration's table lies behind a barrier)
+            if constexpr (PLDS) p_tab[j * T + tid] = rv[j] + beta * pj;   // (every read of this iteration's table lies behind a barrier)
             else pv[j] = rv[j] + beta * pj;
             rr_part += rv[j] * rv[j];
+        }
         }
         ++it;
         if (stamper) {
@@ -798,12 +830,15 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             int32_t d;
-            if constexpr (SYM) d = a.slot_dof[(size_t)g * S + j * T + tid];
+            if constexpr (PLDS) d = a.slot_dof[(size_t)g * S + j * T + tid];
             else d = dof[j];
+            double xj;
+            if constexpr (WIDE) xj = xs[j * T];
+            else xj = xv[j];
             if (!DIST && a.direct) {
-                if (d >= 0) a.x_ext[a.i2e[d]] = a.scale[d] * xv[j] + 0.0;   // (k_cols_finish's expression)
+                if (d >= 0) a.x_ext[a.i2e[d]] = a.scale[d] * xj + 0.0;   // (k_cols_finish's expression)
             } else if (d >= 0)
-                a.x_out[d] = xv[j];
+                a.x_out[d] = xj;
         }
     }
     if (!DIST && a.direct) {

@@ -14,11 +14,11 @@
 namespace fdapde_engine {
 
 // FDAPDE_SETUP_CHECK: the device-built persistent layout against the host builder's
-int check_dev_persist(fdapde_ctx* c, int v, const PersistLayout& pl, const DevPersist& dp, const std::vector<int32_t>* block_rows, bool balance) {
+int check_dev_persist(fdapde_ctx* c, int v, const PersistLayout& pl, const DevPersist& dp, const std::vector<int32_t>* block_rows, bool balance, int n_wg) {
     if (int rc = ensure_host(c, kHostPattern)) return rc;
     PersistLayout ref;
     ref.single_rows = pl.single_rows;
-    if (host_build_persist_layout(c->hs, v == 1, block_rows ? (int)block_rows->size() : c->n_cu, 12000, ref, block_rows ? block_rows->data() : nullptr,
+    if (host_build_persist_layout(c->hs, v == 1, n_wg, 12000, ref, block_rows ? block_rows->data() : nullptr,
                                   pl.sym ? 1 : 0, balance) != FDAPDE_OK) return fail(c, FDAPDE_EHIP, "set-up check: host persistent layout failed");
     int bad = 0;
     auto scalar = [&](const char* name, int64_t a, int64_t b) {
@@ -57,7 +57,7 @@ int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_r
     ps.ell_col.release();
     if (c->n_cu < 1) return FDAPDE_OK;
     const int32_t* brows = block_rows ? block_rows->data() : nullptr;
-    const int n_wg = block_rows ? (int)block_rows->size() : c->n_cu;
+    const int n_wg = block_rows ? (int)block_rows->size() : (c->persist_max_wg > 0 ? std::min(c->persist_max_wg, c->n_cu) : c->n_cu);
     PersistLayout pl;
     DevPersist dp;
     DebugClock clk;
@@ -105,6 +105,11 @@ int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_r
             --attempt;
             continue;
         }
+        if (rc == FDAPDE_EUNSUPPORTED && sym_mode != 0 && attempt == 0) {   // (e.g. more rows per workgroup than the symmetric form takes: the plain one)
+            dev_persist_release(&dp);
+            sym_mode = 0;
+            continue;
+        }
         if (rc == FDAPDE_EUNSUPPORTED) return FDAPDE_OK;
         if (rc) return rc;
         if (10.0 * (double)pl.n_entries > max_mb * 1e6) {
@@ -114,6 +119,7 @@ int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_r
         S = pl.R * kPersistT;
         imp_cap = (pl.max_imp + 63) & ~63, exp_cap = (pl.max_exp + 63) & ~63;
         fixed = pl.sym ? 8 * (size_t)(S + imp_cap) + 8 * (size_t)S + 64 : 8 * (size_t)(S + imp_cap) + 4 * (size_t)imp_cap + 2 * (size_t)exp_cap + 64;
+        if (pl.R > kPersistRmax) fixed = 8 * (size_t)(S + imp_cap) + 64;   // wide form: the p table and the imports (lists stay in global memory)
         need = pl.max_block;   // largest workgroup block
         for (int g = 0; g < pl.G && !on_device; ++g) need = std::max<int64_t>(need, pl.ell_off[(size_t)g + 1] - pl.ell_off[(size_t)g]);
         need += 128;        // one pair row of zeros behind the block: slices narrower than their pass's widest re-read it (clamped loads)
@@ -146,7 +152,8 @@ int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_r
     clk.mark("build_persist: layout");
     // resident form when every block fits its workgroup's LDS next to the vectors; else the blocks stream every iteration
     ps.stream = fixed + 10 * (size_t)need > lds_total;
-    if (fixed > lds_total || (pl.R == 16 && !ps.stream)) {   // (no resident instantiation for 8192 rows: they never fit)
+    if (fixed > lds_total || (pl.R >= 16 && !ps.stream) || (pl.R > kPersistRmax && (c->persist_plain || !c->persist_wide))) {   // (no resident instantiation for
+                                                         // 8192 rows and more: they never fit; the wide form is the CG's -- BiCGStab keeps six vectors in registers)
         dev_persist_release(&dp);
         return FDAPDE_OK;
     }
@@ -155,7 +162,7 @@ int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_r
     hipStream_t st = c->stream;
     if (on_device) {
         if (std::getenv("FDAPDE_SETUP_CHECK")) {
-            if (int rc2 = check_dev_persist(c, v, pl, dp, block_rows, balance)) {
+            if (int rc2 = check_dev_persist(c, v, pl, dp, block_rows, balance, n_wg)) {
                 dev_persist_release(&dp);
                 return rc2;
             }
@@ -307,7 +314,28 @@ int launch_persist(fdapde_ctx* c, fdapde_ctx::Persist& ps, PersistArgs& a, bool 
         case 2: PERSIST_GO2(2, true); break;
         case 4: PERSIST_GO2(4, true); break;
         case 8: PERSIST_GO2(8, true); break;
-        default: PERSIST_GO2(16, true); break;
+        case 16: PERSIST_GO2(16, true); break;
+        case kPersistRwide:   // wide form: plain storage, x in HBM in slot order, one column
+            if (ps.meta.sym || a.n_cols > 1 || a.direct) return FDAPDE_EUNSUPPORTED;
+            if (c->persist_xs.n < (size_t)ps.meta.G * kPersistRwide * kPersistT) HIPCHK(c, c->persist_xs.alloc((size_t)ps.meta.G * kPersistRwide * kPersistT));
+            a.x_slots = c->persist_xs.p;
+            {   // (measurement knob persist_wide_gj: passes of a phase whose loads go out together)
+                const void* fn = c->persist_wide_gj == 12 ? reinterpret_cast<const void*>(&k_cg_persist<kPersistRwide, true, false, false, 12>)
+                               : c->persist_wide_gj == 4  ? reinterpret_cast<const void*>(&k_cg_persist<kPersistRwide, true, false, false, 4>)
+                                                          : reinterpret_cast<const void*>(&k_cg_persist<kPersistRwide, true, false, false, 6>);
+                if (ps.attr_set != fn) {
+                    HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ps.lds_bytes));
+                    int per_cu = 0;
+                    HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kPersistT, ps.lds_bytes));
+                    if ((int64_t)per_cu * c->n_cu < (int64_t)a.G) return FDAPDE_EUNSUPPORTED;
+                    ps.attr_set = fn, ps.per_cu = per_cu;
+                }
+                if (c->persist_wide_gj == 12) hipLaunchKernelGGL((k_cg_persist<kPersistRwide, true, false, false, 12>), dim3(a.G), dim3(kPersistT), ps.lds_bytes, st, a);
+                else if (c->persist_wide_gj == 4) hipLaunchKernelGGL((k_cg_persist<kPersistRwide, true, false, false, 4>), dim3(a.G), dim3(kPersistT), ps.lds_bytes, st, a);
+                else hipLaunchKernelGGL((k_cg_persist<kPersistRwide, true, false, false, 6>), dim3(a.G), dim3(kPersistT), ps.lds_bytes, st, a);
+            }
+            break;
+        default: return FDAPDE_EUNSUPPORTED;
         }
     else switch (ps.meta.R) {
         case 2: PERSIST_GO2(2, false); break;
@@ -649,6 +677,10 @@ int build_rowdist(fdapde_ctx* c, int v) {
             break;
         }
         if (hard(rc)) {
+            local_ok = 0;
+            break;
+        }
+        if (pl.R > kPersistRmax) {   // (the wide form exists on one GPU only)
             local_ok = 0;
             break;
         }

@@ -314,6 +314,8 @@ int fdapde_rowdist_setup(fdapde_ctx *ctx, const int64_t *dof_key, const int32_t 
  *                 "persist_coop" (0: plain instead of cooperative launch), "persist_timeout_us" (bound of every in-kernel wait),
  *                 "persist_debug_stall" / "persist_retry" (tests: force a hand-off timeout at an iteration / forget one),
  *                 "persist_cols" (0: the columns of fdapde_lin_solve always one launch each, never side by side in one),
+ *                 "persist_wide" (0: systems of more than 8 192 rows per workgroup -- 2.1 to 3.1 M rows on 256 CUs -- keep the multi-launch path instead of
+ *                 the single launch with x in HBM and 24 rows per thread), "persist_max_wg" (tests: fewer workgroups than CUs for the single launch),
  *                 "persist_direct" (0: a single right-hand side of a one-workgroup system takes the general path instead of the launch that
  *                 reads b and writes x and its outcome through pinned host memory itself), "persist_direct_spin_us" (host spin on that outcome),
  *                 "persist_single_rows" (systems of up to that many interior rows run as one workgroup, without hand-offs),

@@ -51,12 +51,19 @@ def test_above_two_million_rows(env):
     ctx.init()
     info = ctx.solve(rtol=1e-10)
     assert info.converged == 1
+    # round 4: above 8 192 rows per workgroup the solve still runs as ONE launch -- the wide form of the plain storage (24 rows per thread, x in
+    # HBM) -- instead of falling to the multi-launch path
+    assert info.persistent == 1 and ctx.solver_layout_kind(True)["rows_per_thread"] == 24
     u = ctx.solution()
     rp, ci = ctx.pattern_get()
     Az = sp.csr_matrix((ctx.matrix_values(capi.MAT_STIFF), ci, rp), shape=(nd, nd))
     b = ctx.force()
     assert np.linalg.norm(Az @ u - b) <= 1e-8 * np.linalg.norm(b)
     assert np.array_equal(u[bdofs.astype(bool)], g[bdofs.astype(bool)])
+    ctx.tune("persist_wide", 0)   # the multi-launch path the system took before: the same answer
+    info0 = ctx.solve(rtol=1e-10)
+    assert info0.persistent == 0 and abs(info0.iters - info.iters) <= max(2, info.iters // 100)
+    assert np.linalg.norm(ctx.solution() - u) <= 1e-9 * np.linalg.norm(u)
     ctx.close()
 
 

@@ -580,3 +580,44 @@ def test_direct_launch_of_a_single_right_hand_side(env, dim, nx, order):
     xs, _ = c.lin_solve(1e-150 * b, rtol=1e-11)   # (tiny but not zero: the relative stop test must not care)
     assert np.linalg.norm(xs - 1e-150 * x1) <= 1e-10 * np.linalg.norm(1e-150 * x1)
     c.close()
+
+
+@pytest.mark.parametrize("dim,nx,order,max_wg", [(3, 44, 1, 8), (2, 200, 1, 4), (2, 100, 2, 4)])
+def test_wide_single_launch_matches_the_multi_launch_path(env, dim, nx, order, max_wg):
+    """systems of more than 8 192 rows per workgroup (2.1 to 3.1 M rows on 256 CUs) run as ONE launch in the wide form of the plain storage:
+    24 rows per thread, r and y in registers, p in its LDS table, x in HBM in slot order.  Here the form is forced on
+    moderate systems by limiting the workgroups (knob persist_max_wg): same iteration count as the multi-launch kernels, same solution,
+    the true residual on the exported matrix, identical bits from launch to launch, a warm start (parabolic stepper) included."""
+    import scipy.sparse as sp
+
+    capi, meshgen = env
+    nodes, cells, bnd = meshgen.unit_square(nx) if dim == 2 else meshgen.unit_cube(nx)
+    _, f = meshgen.manufactured(dim)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(order)
+    _, _, coords = c.dofs_get()
+    g = 0.1 * coords[:, 0]
+    c.set_operator(-capi.laplacian() + capi.reaction(0.5))
+    c.set_forcing(f(c.quadrature_nodes()))
+    c.set_dirichlet(g)
+    c.init()
+    c.tune("persist", 0)
+    i0 = c.solve(rtol=1e-11)
+    u0 = c.solution()
+    c.tune("persist", 1)
+    c.tune("persist_max_wg", max_wg)
+    i1 = c.solve(rtol=1e-11)
+    u1 = c.solution()
+    lay = c.solver_layout_kind(True)
+    assert lay["rows_per_thread"] == 24 and lay["sym"] == 0 and lay["workgroups"] <= max_wg, lay
+    assert i1.persistent == 1 and i1.converged == 1 and abs(i1.iters - i0.iters) <= max(1, i0.iters // 100)
+    assert np.linalg.norm(u1 - u0) <= 1e-10 * np.linalg.norm(u0)
+    i2 = c.solve(rtol=1e-11)
+    assert i2.iters == i1.iters and np.array_equal(c.solution(), u1)
+    rp, ci = c.pattern_get()
+    A = sp.csr_matrix((c.matrix_values(capi.MAT_STIFF), ci, rp), shape=(nd, nd))
+    b = c.force()
+    assert np.linalg.norm(A @ u1 - b) <= 1e-9 * np.linalg.norm(b)
+    assert c.solver_layout(True)[2] > 0
+    c.close()

@@ -274,30 +274,26 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
             else PART_GO(0);
 #undef PART_GO
         } else if (assembly == FDAPDE_ASSEMBLY_WAVE) {
-            if constexpr (R != 1) {
-                return fail(c, FDAPDE_EUNSUPPORTED, "the wavefront-per-element assembly exists for P1 only");
-            } else {
-                if (!c->colour_ready) {
-                    if (int rc = ensure_host(c, kHostCells)) return rc;
-                    int rc = host_build_colouring(c->hs, c->err);
-                    if (rc) return rc;
-                    HIPCHK(c, c->colour_cells.upload(hs.colour_cells.data(), hs.colour_cells.size(), c->stream));
-                    c->colour_ready = true;
-                }
-                if (!c->wave_ready) {
-                    if (int rc = ensure_host(c, kHostPattern | kHostCells)) return rc;
-                    std::vector<int32_t> sm;
-                    host_build_slot_map(hs, hs.colour_cells.data(), hs.n_cells, sm);
-                    HIPCHK(c, c->wave_slots.upload(sm.data(), sm.size(), c->stream));
-                    HIPCHK(c, hipStreamSynchronize(c->stream));
-                    c->wave_ready = true;
-                }
-                for (int k = 0; k < hs.n_colours; ++k) {
-                    const int64_t o0 = hs.colour_off[(size_t)k], cnt = hs.colour_off[(size_t)k + 1] - o0;
-                    if (cnt == 0) continue;
-                    hipLaunchKernelGGL((k_assemble_wave<M>), dim3((unsigned)((cnt + 3) / 4)), dim3(256), sizeof(DevTables), c->stream, a, op,
-                                       c->colour_cells.p + o0, c->wave_slots.p + (size_t)o0 * NB * NB, cnt);
-                }
+            if (!c->colour_ready) {
+                if (int rc = ensure_host(c, kHostCells)) return rc;
+                int rc = host_build_colouring(c->hs, c->err);
+                if (rc) return rc;
+                HIPCHK(c, c->colour_cells.upload(hs.colour_cells.data(), hs.colour_cells.size(), c->stream));
+                c->colour_ready = true;
+            }
+            if (!c->wave_ready) {
+                if (int rc = ensure_host(c, kHostPattern | kHostCells)) return rc;
+                std::vector<int32_t> sm;
+                host_build_slot_map(hs, hs.colour_cells.data(), hs.n_cells, sm);
+                HIPCHK(c, c->wave_slots.upload(sm.data(), sm.size(), c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                c->wave_ready = true;
+            }
+            for (int k = 0; k < hs.n_colours; ++k) {
+                const int64_t o0 = hs.colour_off[(size_t)k], cnt = hs.colour_off[(size_t)k + 1] - o0;
+                if (cnt == 0) continue;
+                hipLaunchKernelGGL((k_assemble_wave<M, R>), dim3((unsigned)((cnt + 3) / 4)), dim3(256), sizeof(DevTables), c->stream, a, op,
+                                   c->colour_cells.p + o0, c->wave_slots.p + (size_t)o0 * NB * NB, cnt);
             }
         } else if (assembly == FDAPDE_ASSEMBLY_ATOMIC) {
             const int64_t work = hs.n_cells * NB;

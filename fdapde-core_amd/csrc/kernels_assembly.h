@@ -974,37 +974,43 @@ static __global__ __launch_bounds__(256) void k_assemble_part(AsmArgs a, DevOp o
 }
 
 // k_assemble_wave: the literal form -- ONE WAVEFRONT PER ELEMENT, lane = (i, j, q): the 64 (test, trial, quadrature node) triples
-//   of a 3-D P1 element (27 of a 2-D one).  Every lane evaluates the weak form at its quadrature node, the nodes are summed across
-//   lanes, the lanes with q = 0 add their entry through the streamed slot map.  Launched once per colour over colour-contiguous
-//   cell lists (cells of a colour share no DOF: plain read-modify-write, no atomics).  P1 only (a P2 element has 500+ triples).
-template <int M>
+//   of a 3-D P1 element (27 of a 2-D one) in one pass; a P2 element (216 triples in 2-D, 500 in 3-D) in passes of 8 (i, j) pairs x 8
+//   node lanes.  Every lane evaluates the weak form at its quadrature node, the nodes are summed across lanes, the lanes with q = 0
+//   add their entry through the streamed slot map.  Launched once per colour over colour-contiguous cell lists (cells of a colour
+//   share no DOF: plain read-modify-write, no atomics).
+template <int M, int R>
 static __global__ __launch_bounds__(256) void k_assemble_wave(AsmArgs a, DevOp op, const int32_t* cell_list, const int32_t* slot_map,
                                                         int64_t n_list) {
-    constexpr int NB = M + 1, NQ = (M == 2) ? 3 : 4;
+    constexpr int NB = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 10);
+    constexpr int NQ = (M == 2) ? (R == 1 ? 3 : 6) : (R == 1 ? 4 : 5);
+    constexpr int NQP = NQ <= 4 ? 4 : 8, PP = 64 / NQP;   // node lanes per pair (a power of two), pairs per pass
     extern __shared__ double lds[];
     const DevTables* tb = stage_tables(a.tables, lds);
     __syncthreads();
     const int64_t li = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // one wavefront per element
     if (li >= n_list) return;
-    const int lane = threadIdx.x & 63, q = lane & 3, ij = lane >> 2, i = ij / NB, j = ij - i * NB;
-    const bool live = ij < NB * NB && q < NQ;
+    const int lane = threadIdx.x & 63, q = lane % NQP;
     const int cell = cell_list[li];
     Geo<M> g;
     cell_geometry<M>(a, cell, g);   // the same addresses in every lane: one broadcast fetch per vertex
-    double v = 0, fv = 0;
-    if (live) {
-        double gi[M], gj[M];
-        phys_grad<M>(g, &tb->dpsi[(i * NQ + q) * 3], gi);
-        phys_grad<M>(g, &tb->dpsi[(j * NQ + q) * 3], gj);
-        const int64_t qrow = (int64_t)NQ * cell + q;
-        v = weak_form<M>(op, qrow, tb->psi[i * NQ + q], tb->psi[j * NQ + q], gi, gj) * tb->qw[q];
-        if (a.fq != nullptr && j == 0) fv = (a.fq[qrow] * tb->psi[i * NQ + q]) * tb->qw[q];
-    }
-    v += __shfl_xor(v, 1), v += __shfl_xor(v, 2);       // sum over the quadrature nodes (lanes 4 k .. 4 k + 3)
-    fv += __shfl_xor(fv, 1), fv += __shfl_xor(fv, 2);
-    if (live && q == 0) {
-        if (a.vals != nullptr) a.vals[slot_map[(li * NB + i) * NB + j]] += v * g.measure;
-        if (a.force != nullptr && j == 0) a.force[a.cdofs[(int64_t)cell * NB + i]] += fv * g.measure;
+    for (int p0 = 0; p0 < NB * NB; p0 += PP) {   // (wave-uniform trip count: 1 pass for P1, 5 / 13 for P2 in 2-D / 3-D)
+        const int ij = p0 + lane / NQP, i = ij / NB, j = ij - i * NB;
+        const bool live = ij < NB * NB && q < NQ;
+        double v = 0, fv = 0;
+        if (live) {
+            double gi[M], gj[M];
+            phys_grad<M>(g, &tb->dpsi[(i * NQ + q) * 3], gi);
+            phys_grad<M>(g, &tb->dpsi[(j * NQ + q) * 3], gj);
+            const int64_t qrow = (int64_t)NQ * cell + q;
+            v = weak_form<M>(op, qrow, tb->psi[i * NQ + q], tb->psi[j * NQ + q], gi, gj) * tb->qw[q];
+            if (a.fq != nullptr && j == 0) fv = (a.fq[qrow] * tb->psi[i * NQ + q]) * tb->qw[q];
+        }
+#pragma unroll
+        for (int o = 1; o < NQP; o <<= 1) v += __shfl_xor(v, o), fv += __shfl_xor(fv, o);   // sum over the quadrature nodes of a pair
+        if (live && q == 0) {
+            if (a.vals != nullptr) a.vals[slot_map[(li * NB + i) * NB + j]] += v * g.measure;
+            if (a.force != nullptr && j == 0) a.force[a.cdofs[(int64_t)cell * NB + i]] += fv * g.measure;
+        }
     }
 }
 

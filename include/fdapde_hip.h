@@ -67,8 +67,8 @@ enum { FDAPDE_SOLVER_AUTO = 0, FDAPDE_SOLVER_CG = 1, FDAPDE_SOLVER_BICGSTAB = 2,
 /* ROWS: row-owner sweep (default; no atomics, bitwise reproducible).  The others are element-wise scatter forms kept as measured
  * alternatives and cross-checks: ATOMIC / COLOURED = lane per (cell, row) with a slot search, fp64 atomics / one launch per colour;
  * PARTITIONED = one workgroup per cell partition, colours walked inside the workgroup, atomics only on rows shared between
- * partitions, slot map streamed; WAVE = one wavefront per element, lane = (i, j, quadrature node), one launch per colour, slot map
- * streamed (P1 only). */
+ * partitions, slot map streamed; WAVE = one wavefront per element, lane = (i, j, quadrature node) -- a P2 element in passes of 8 (i, j)
+ * pairs --, one launch per colour, slot map streamed. */
 enum { FDAPDE_ASSEMBLY_ROWS = 0, FDAPDE_ASSEMBLY_ATOMIC = 1, FDAPDE_ASSEMBLY_COLOURED = 2, FDAPDE_ASSEMBLY_PARTITIONED = 3,
        FDAPDE_ASSEMBLY_WAVE = 4 };
 enum { FDAPDE_MAT_STIFF = 0, FDAPDE_MAT_MASS = 1 };

@@ -78,7 +78,9 @@ static int check_persist(const HostSpace& hs, bool use_bnd, int n_wg, bool sym =
         if (rc == FDAPDE_EUNSUPPORTED) return 0;
         if (rc || pl.G != G) return -1;
     }
+    if (sym && !pl.sym && pl.R > kPersistRmax) sym = false;   // (more than 8 192 rows per workgroup: the wide form, which is plain -- kPersistRwide)
     if (pl.sym != sym) return -1;
+    if (pl.R > kPersistRmax && pl.R != kPersistRwide) return -1;
     const int T = kPersistT, S = pl.R * T, nsl = pl.nsl;
     auto dropped = [&](int64_t d) { return use_bnd && hs.dof_bnd_i[(size_t)d]; };
     auto val = [](int64_t row, int64_t col) { return 1.0 + 0.25 * (double)((row + col) % 7); };   // symmetric

@@ -77,8 +77,6 @@ def test_space_is_bit_exact(capi, ctx, oracle, mesh_loader, mesh_name, order):
 @pytest.mark.parametrize("mesh_name,order", CASES)
 @pytest.mark.parametrize("variant", ["rows", "atomic", "coloured", "partitioned", "wave"])
 def test_operator_assembly_matches_oracle(capi, ctx, oracle, mesh_loader, mesh_name, order, variant):
-    if variant == "wave" and order != 1:
-        pytest.skip("the wavefront-per-element form exists for P1 only (a P2 element has 500+ (i, j, q) triples)")
     m = mesh_loader(mesh_name)
     ctx.mesh_upload(m.nodes, m.cells, m.boundary)
     nd = ctx.dofs_build(order)

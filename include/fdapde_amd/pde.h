@@ -701,6 +701,29 @@ template <typename... Args_, typename... Args> erase<heap_storage, PDE__> make_p
     return erase<heap_storage, PDE__>(PDE<Args_...>(std::forward<Args>(args)...));
 }
 
+// ---- Integrator<FEM, M, R>::integrate(mesh, f) (utils/integration/integrator.h:61-69) ----------------------------------------------
+// Integral of a callable over the whole triangulation with the quadrature rule the order-R assembly uses.  On the device it is the load
+// sweep: f sampled at the mapped quadrature nodes of every cell, b_i = sum_e |e| sum_q w_q f(x_q) psi_i(x_q); the Lagrangian basis sums
+// to one at every point, so sum_i b_i is the quadrature of f itself.  (The per-element form, integrate_cell, is what the assembly does
+// inside that sweep and has no entry of its own.)
+template <typename S, int M, int R> class Integrator;
+template <int M, int R> class Integrator<FEM_HIP, M, R> {
+   public:
+    explicit Integrator(int device = 0) : device_(device) { }
+    template <int N, typename ExprType> double integrate(const Triangulation<M, N>& m, const ExprType& f) const {
+        using Field = ScalarField<N>;
+        PDE<Triangulation<M, N>, DifferentialExpr, Field, FEM_HIP, fem_order<R>> sweep(
+          m, laplacian<FEM_HIP>(), Field([&f](const std::array<double, N>& x) { return (double)f(x); }), device_);
+        sweep.init();
+        const DMatrix<double>& b = sweep.force();
+        double value = 0;
+        for (int64_t i = 0; i < b.size(); ++i) value += b(i);
+        return value;
+    }
+   private:
+    int device_;
+};
+
 }   // namespace amd
 }   // namespace fdapde
 

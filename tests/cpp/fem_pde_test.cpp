@@ -197,6 +197,32 @@ TEST(fem_pde_test, laplacian_3d_order1) {
     EXPECT_TRUE(worst < 1e-8);
 }
 
+// integration_test.cpp:73-80: a field integrated over the whole triangulation (Integrator<FEM, M, R>::integrate, integrator.h:61-69)
+TEST(integration_test, integrate_over_triangulation) {
+    FixtureMesh<2, 2> unit_square("unit_square");
+    fdapde::amd::Integrator<FEM_HIP, 2, 1> integrator {};
+    EXPECT_TRUE(almost_equal(1.0, integrator.integrate(unit_square.mesh, [](std::array<double, 2>) -> double { return 1; })));
+    // a linear field is integrated exactly by both rules: int_[0,1]^2 (x + y) = 1
+    EXPECT_TRUE(almost_equal(1.0, integrator.integrate(unit_square.mesh, [](std::array<double, 2> x) -> double { return x[0] + x[1]; }), 1e-12));
+    fdapde::amd::Integrator<FEM_HIP, 2, 2> integrator2 {};
+    EXPECT_TRUE(almost_equal(2.0 / 3.0, integrator2.integrate(unit_square.mesh, [](std::array<double, 2> x) -> double { return x[0] * x[0] + x[1] * x[1]; }), 1e-12));
+    // 3-D: the volume of the fixture's polyhedral ball = the sum of its cells' measures (1395 of them negatively oriented)
+    FixtureMesh<3, 3> sphere("unit_sphere");
+    const auto& nd = sphere.mesh.nodes();
+    const auto& cl = sphere.mesh.cells();
+    double volume = 0;
+    for (int64_t c = 0; c < cl.rows(); ++c) {
+        double e[3][3];
+        for (int k = 0; k < 3; ++k)
+            for (int d = 0; d < 3; ++d) e[k][d] = nd(cl(c, k + 1), d) - nd(cl(c, 0), d);
+        const double det = e[0][0] * (e[1][1] * e[2][2] - e[1][2] * e[2][1]) - e[0][1] * (e[1][0] * e[2][2] - e[1][2] * e[2][0]) +
+                           e[0][2] * (e[1][0] * e[2][1] - e[1][1] * e[2][0]);
+        volume += std::fabs(det) / 6.0;
+    }
+    fdapde::amd::Integrator<FEM_HIP, 3, 1> integrator3 {};
+    EXPECT_TRUE(almost_equal(volume, integrator3.integrate(sphere.mesh, [](std::array<double, 3>) -> double { return 1; }), 1e-12));
+}
+
 // fem_pde_test.cpp:222-285: parabolic, P2, 101 time points
 TEST(fem_pde_test, parabolic_isotropic_order2) {
     constexpr double pi = 3.14159265358979323846;
@@ -683,6 +709,7 @@ int main(int argc, char** argv) {
     RUN(fem_operators_test, laplacian_order_2_through_stiff);
     RUN(fem_pde_test, error_behaviour);
     RUN(fem_pde_test, laplacian_3d_order1);
+    RUN(integration_test, integrate_over_triangulation);
     RUN(fem_pde_test, parabolic_isotropic_order2);
     RUN(fem_pde_test, parabolic_isotropic_order1_convergence);
     RUN(sparse_solver_test, factor_once_solve_many);

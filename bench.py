@@ -416,6 +416,20 @@ def _spawn_ranks(world, argv_extra, extra_env, timeout):
     return rc
 
 
+def _rank_placement(capi, world):
+    """(devices visible, transport backend, ranks per device) of a multi-rank job -- ONE rule for the canary's ranks and the real ones"""
+    n_dev = int(capi.load().fdapde_device_count())
+    if n_dev < 1:
+        raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
+    backend = os.environ.get("FDAPDE_BENCH_BACKEND", "rccl")
+    if backend == "nccl":
+        backend = "rccl"
+    if backend == "rccl" and n_dev < world:
+        raise SystemExit(f"--gpus {world} but this node shows {n_dev} HIP devices (RCCL needs one device per rank; "
+                         "FDAPDE_BENCH_BACKEND=gloo runs the plumbing with ranks sharing devices)")
+    return n_dev, backend, (world + n_dev - 1) // n_dev
+
+
 def run_canary(rank, world, local_rank):
     """one rank of the canary job (see dist.canary): exit code 0 = the row-distributed solve works between these devices"""
     from fdapde_loader import load_package
@@ -424,13 +438,11 @@ def run_canary(rank, world, local_rank):
     from fdapde_core_amd import capi
     from fdapde_core_amd import dist as fdist
 
-    n_dev = int(capi.load().fdapde_device_count())
-    backend = os.environ.get("FDAPDE_BENCH_BACKEND", "rccl")
-    backend = "rccl" if backend == "nccl" else backend
-    if n_dev < 1 or (backend == "rccl" and n_dev < world):
+    try:
+        n_dev, backend, share = _rank_placement(capi, world)
+    except SystemExit:
         raise SystemExit(1)
     rdzv = FileRendezvous(rank, world)
-    share = (world + n_dev - 1) // n_dev
     raise SystemExit(fdist.canary(capi, rdzv, rank, world, local_rank % n_dev, backend, share))
 
 
@@ -460,17 +472,7 @@ def run_ranks(args, rank, world, local_rank):
     from fdapde_core_amd import capi
     from fdapde_core_amd import dist as fdist
 
-    lib = capi.load()
-    n_dev = int(lib.fdapde_device_count())
-    if n_dev < 1:
-        raise SystemExit("bench.py needs a HIP device; there is no CPU fallback")
-    backend = os.environ.get("FDAPDE_BENCH_BACKEND", "rccl")
-    if backend == "nccl":
-        backend = "rccl"
-    if backend == "rccl" and n_dev < world:
-        raise SystemExit(f"--gpus {world} but this node shows {n_dev} HIP devices (RCCL needs one device per rank; "
-                         "FDAPDE_BENCH_BACKEND=gloo runs the plumbing with ranks sharing devices)")
-    share = (world + n_dev - 1) // n_dev
+    n_dev, backend, share = _rank_placement(capi, world)
     out = fdist.bench_partitioned(capi, rdzv, rank, world, local_rank % n_dev, args, RTOL, backend, form, share)
     rdzv.finish()
     if rank != 0:

@@ -55,16 +55,20 @@ int make_dev_op(fdapde_ctx* c, const std::vector<HostTerm>& terms, DevOp* out, i
     // constant-coefficient summary (element_row OPK 3)
     const int N = c->hs.N;
     bool adv = false;
-    for (size_t k = 0; k < terms.size(); ++k) {
+    for (size_t k = 0; k < terms.size(); ++k) {   // (the CONSTANT leaves: a space-varying leaf only leaves its mark in var_kinds -- element_row OPK 5)
         const fdapde_term& t = terms[k].t;
+        if (t.kind == FDAPDE_ADVECTION) adv = true;
+        if (t.space_varying) {
+            op.var_kinds |= t.kind == FDAPDE_DIFFUSION ? 1 : t.kind == FDAPDE_ADVECTION ? 2 : t.kind == FDAPDE_REACTION ? 4 : 0;
+            continue;
+        }
         if (t.kind == FDAPDE_LAPLACIAN)
             for (int r = 0; r < N; ++r) op.kt[r * N + r] += t.coef;
         else if (t.kind == FDAPDE_DIFFUSION)
             for (int e = 0; e < N * N; ++e) op.kt[e] += t.coef * t.cst[e];
-        else if (t.kind == FDAPDE_ADVECTION) {
-            adv = true;
+        else if (t.kind == FDAPDE_ADVECTION)
             for (int e = 0; e < N; ++e) op.bt[e] += t.coef * t.cst[e];
-        } else if (t.kind == FDAPDE_REACTION)
+        else if (t.kind == FDAPDE_REACTION)
             op.ct += t.coef * t.cst[0];
     }
     bool ksym = true;
@@ -131,11 +135,14 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
         // specialised integrands (see element_row): the two operators FEMSolverBase::init always assembles, and any other
         // constant-coefficient expression through the reference tensors
         int opk = 4;   // space-varying coefficients: one pulled-back tensor per quadrature node
+        // ... unless the diffusion part does not vary: constants through the reference tensors, the varying advection / reaction per node
+        // (knob asm_split_varying = 0: the per-node tensor form for every space-varying operator)
+        if (op.needs_rows && (op.var_kinds & 1) == 0 && c->asm_split_varying) opk = 5;
         if (!op.needs_rows) opk = 3;
         if (op.n == 1 && op.t[0].kind == FDAPDE_LAPLACIAN) opk = 1;
         if (op.n == 1 && op.t[0].kind == FDAPDE_REACTION && !op.t[0].space_varying) opk = 2;
         if (std::getenv("FDAPDE_ASM_GENERIC")) opk = 0;
-        const size_t tab = sizeof(DevTables) + (opk == 3 ? sizeof(DevRefTensors) : 0) +
+        const size_t tab = sizeof(DevTables) + (opk == 3 || opk == 5 ? sizeof(DevRefTensors) : 0) +
                            (size_t)hs.max_blk_nodes * (M == 2 ? 2 : 3) * sizeof(double);
         size_t acc = (size_t)hs.max_blk_nnz * sizeof(double);
         // operator + mass in one sweep (a.vals2): both accumulator ranges of every block must fit the LDS, else two sweeps as before
@@ -172,7 +179,7 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
                     const int grid_i = 8 * (int)(((hs.n_dofs + kAsmBlock - 1) / kAsmBlock + 7) / 8);
                     if (std::getenv("FDAPDE_DEBUG_ASM"))
                         std::fprintf(stderr, "assembly launch <%d,%d> opk %d, visit-parallel: grid %d x %d threads, LDS %zu B dynamic (tables %zu + accumulators %zu), longest visit list %d, %s\n",
-                                     M, R, opk, grid_i, opk == 4 ? 512 : 1024, lds_items, tab, acc_all, c->asm_max_visits, want_mass2 ? "mass as second sweep" : "one matrix");
+                                     M, R, opk, grid_i, (opk == 4 || (opk == 5 && M == 3)) ? 512 : 1024, lds_items, tab, acc_all, c->asm_max_visits, want_mass2 ? "mass as second sweep" : "one matrix");
 #define ITEMS_GO(OPK_, M2_, TH_)                                                                                                          \
     do {                                                                                                                                  \
         const void* fn = reinterpret_cast<const void*>(&k_assemble_items<M, R, OPK_, M2_, TH_>);                                          \
@@ -187,6 +194,10 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
                         if (opk == 3) ITEMS_GO(3, 2, 1024);
                         else ITEMS_GO(1, 2, 1024);
                     } else if (opk == 4) ITEMS_GO(4, 0, 512);
+                    else if (opk == 5) {   // (3-D P2 with 1024 threads: 106 registers spilled; 512 threads, as the fully space-varying integrand)
+                        if (M == 3 && !(th_env && std::atoi(th_env) == 1024)) ITEMS_GO(5, 0, 512);
+                        else ITEMS_GO(5, 0, 1024);
+                    }
                     else if (opk == 3) ITEMS_GO(3, 0, 1024);
                     else if (opk == 2) ITEMS_GO(2, 0, 1024);
                     else ITEMS_GO(1, 0, 1024);
@@ -231,10 +242,13 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
                                    reinterpret_cast<const void*>(&k_assemble_rows<M, R, 1>),
                                    reinterpret_cast<const void*>(&k_assemble_rows<M, R, 2>),
                                    reinterpret_cast<const void*>(&k_assemble_rows<M, R, 3>),
-                                   reinterpret_cast<const void*>(&k_assemble_rows<M, R, 4>)})
+                                   reinterpret_cast<const void*>(&k_assemble_rows<M, R, 4>),
+                                   reinterpret_cast<const void*>(&k_assemble_rows<M, R, 5>)})
                 (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (opk == 4)
             hipLaunchKernelGGL((k_assemble_rows<M, R, 4>), dim3(grid), dim3(kAsmBlock), lds, c->stream, a, op);
+        else if (opk == 5)
+            hipLaunchKernelGGL((k_assemble_rows<M, R, 5>), dim3(grid), dim3(kAsmBlock), lds, c->stream, a, op);
         else if (opk == 3)
             hipLaunchKernelGGL((k_assemble_rows<M, R, 3>), dim3(grid), dim3(kAsmBlock), lds, c->stream, a, op);
         else if (opk == 1)

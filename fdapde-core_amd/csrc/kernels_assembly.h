@@ -28,6 +28,7 @@ struct DevOp {
     //   form = -(g_i . Kt g_j) + psi_i (g_j . bt) + ct psi_i psi_j,  Kt = sum coef K (Laplacian: coef I), bt = sum coef b, ct = sum coef c
     double kt[9], bt[3], ct;
     int32_t tab_sym;      // Kt symmetric and no advection: evaluate in the bitwise-symmetric order
+    int32_t var_kinds;    // which kinds have a space-varying leaf: 1 diffusion, 2 advection, 4 reaction (kt / bt / ct sum the CONSTANT leaves only)
 };
 
 // quadrature + basis tables as they sit in device memory (copied to LDS by every workgroup that integrates)
@@ -227,6 +228,11 @@ __device__ __forceinline__ double sym_pair(double g_kl, double g_lk, double a_k,
 //        Gp = J^-1 Kt J^-T,  beta = J^-1 bt.     13 multiply-adds per entry in 3-D instead of a loop over the quadrature nodes
 //      (C5, 3-D P2 advection-diffusion-reaction: 98 ms -> see DESIGN.md).  Symmetric operators are evaluated in an order that
 //      gives bitwise A_ij == A_ji.
+//   4  space-varying coefficients of any kind: one pulled-back tensor / vector / scalar per quadrature node (below)
+//   5  space-varying advection and / or reaction next to a diffusion part that does NOT vary (`-Lap + c(x)`, `-div K grad + b(x).grad`):
+//      the constant leaves through the reference tensors as OPK 3, the varying ones per node without any tensor pull-back --
+//        A_ij = |e| ( [OPK 3 sum of the constant leaves]_ij + sum_q w_q ( psi_i (J^-1 b_q . dpsi_j) + c_q psi_i psi_j ) )
+//      (C5-size mesh, -Lap + c(x): 23 ms with OPK 4 -> see DESIGN.md 4.3)
 template <int M, int R, int OPK, typename Emit>
 __device__ __forceinline__ double element_row(const AsmArgs& a, const DevOp& op, const DevTables* tb, const Geo<M>& g, int cell,
                                               int il, bool want_matrix, Emit&& emit, const DevRefTensors* rt = nullptr,
@@ -253,10 +259,55 @@ __device__ __forceinline__ double element_row(const AsmArgs& a, const DevOp& op,
 #pragma unroll
         for (int j = 0; j < NB; ++j) emit(j, cm * tb->mtab[il * NB + j]);
         return fsum;
-    } else if constexpr (OPK == 3) {
+    } else if constexpr (OPK == 3 || OPK == 5) {
         constexpr int NN = NB * NB;
         double Gp[M][M], beta[M];
         const bool sym = op.tab_sym != 0;
+        [[maybe_unused]] double accj[OPK == 5 ? NB : 1];
+        if constexpr (OPK == 5) {   // the varying advection / reaction leaves, node by node (rows nq cell + q of their data)
+            const bool vb = (op.var_kinds & 2) != 0, vc = (op.var_kinds & 4) != 0;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) accj[j] = 0.0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int64_t qrow = qrow0 + q;
+                double bq[M], ctq = 0.0;
+#pragma unroll
+                for (int e = 0; e < M; ++e) bq[e] = 0.0;
+                for (int t = 0; t < op.n; ++t) {
+                    const DevTerm& T = op.t[t];
+                    if (!T.space_varying) continue;
+                    if (T.kind == FDAPDE_ADVECTION) {
+#pragma unroll
+                        for (int e = 0; e < M; ++e) bq[e] += T.coef * T.data[qrow * M + e];
+                    } else if (T.kind == FDAPDE_REACTION) {
+                        ctq += T.coef * T.data[qrow];
+                    }
+                }
+                double betaq[M];
+#pragma unroll
+                for (int k = 0; k < M; ++k) {
+                    double bv = 0;
+#pragma unroll
+                    for (int r = 0; r < M; ++r) bv += g.invJ[k][r] * bq[r];
+                    betaq[k] = bv;
+                }
+                const double pi = tb->psi[il * NQ + q], wq = tb->qw[q];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    double v = 0;
+                    if (vb) {
+                        const double* gj = &tb->dpsi[(j * NQ + q) * 3];
+                        double adv = 0;
+#pragma unroll
+                        for (int l = 0; l < M; ++l) adv += betaq[l] * gj[l];
+                        v = adv * pi;
+                    }
+                    if (vc) v += ctq * (pi * tb->psi[j * NQ + q]);
+                    accj[j] += v * wq;
+                }
+            }
+        }
 #pragma unroll
         for (int k = 0; k < M; ++k) {
             double kr[M];   // row k of J^-1 Kt
@@ -308,7 +359,8 @@ __device__ __forceinline__ double element_row(const AsmArgs& a, const DevOp& op,
 #pragma unroll
                 for (int l = 0; l < M; ++l) adv += beta[l] * ct[l * NN + j];
             }
-            emit(j, g.measure * ((adv - d) + op.ct * tb->mtab[il * NB + j]));
+            if constexpr (OPK == 5) emit(j, g.measure * (((adv - d) + op.ct * tb->mtab[il * NB + j]) + accj[j]));
+            else emit(j, g.measure * ((adv - d) + op.ct * tb->mtab[il * NB + j]));
         }
         return fsum;
     } else if constexpr (OPK == 4) {
@@ -501,7 +553,7 @@ static __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, D
     const DevTables* tb = stage_tables(a.tables, lds);
     const DevRefTensors* rt = nullptr;
     double* xyz = lds + kTablesDoubles;                       // the block's vertex coordinates
-    if constexpr (OPK == 3) {   // reference tensors of the constant-coefficient form behind the basis tables
+    if constexpr (OPK == 3 || OPK == 5) {   // reference tensors of the constant-coefficient form behind the basis tables
         const double* src = reinterpret_cast<const double*>(a.reftab);
         for (int i = threadIdx.x; i < kRefDoubles; i += blockDim.x) xyz[i] = src[i];
         rt = reinterpret_cast<const DevRefTensors*>(xyz);
@@ -713,7 +765,7 @@ static __global__ __launch_bounds__(THREADS) void k_assemble_items(AsmArgs a, De
     }
     const DevRefTensors* rt = nullptr;
     double* xyz = lds + kTablesDoubles;
-    if constexpr (OPK == 3) {
+    if constexpr (OPK == 3 || OPK == 5) {
         const double* src = reinterpret_cast<const double*>(a.reftab);
         for (int i = tid; i < kRefDoubles; i += THREADS) xyz[i] = src[i];
         rt = reinterpret_cast<const DevRefTensors*>(xyz);
@@ -941,7 +993,7 @@ static __global__ __launch_bounds__(256) void k_assemble_part(AsmArgs a, DevOp o
     extern __shared__ double lds[];
     const DevTables* tb = stage_tables(a.tables, lds);
     const DevRefTensors* rt = nullptr;
-    if constexpr (OPK == 3) {
+    if constexpr (OPK == 3 || OPK == 5) {
         const double* src = reinterpret_cast<const double*>(a.reftab);
         for (int i = threadIdx.x; i < kRefDoubles; i += blockDim.x) lds[kTablesDoubles + i] = src[i];
         rt = reinterpret_cast<const DevRefTensors*>(lds + kTablesDoubles);

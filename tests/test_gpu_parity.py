@@ -158,6 +158,38 @@ def test_space_varying_symmetric_operator_is_bitwise_symmetric(capi, ctx, oracle
         assert abs(A - A.T).max() == 0.0
 
 
+@pytest.mark.parametrize("mesh_name,order", [("unit_square_16", 1), ("unit_square_16", 2), ("unit_sphere", 1), ("unit_sphere", 2), ("c_shaped", 2)])
+def test_varying_advection_reaction_next_to_constant_diffusion(capi, ctx, oracle, mesh_loader, mesh_name, order):
+    """operators whose advection / reaction vary while the diffusion part does not take the split integrand (constants through the reference
+    tensors, the varying leaves per node without a tensor pull-back; element_row OPK 5): against the oracle, and against the per-node tensor form
+    of the fully space-varying case (knob asm_split_varying 0) -- same numbers up to rounding"""
+    m = mesh_loader(mesh_name)
+    ctx.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = ctx.dofs_build(order)
+    od, _, _, _ = oracle.enumerate_dofs(m, order)
+    rows = ctx.sizes()["n_quadrature"] * m.n_cells
+    rng = np.random.default_rng(23)
+    N = m.N
+    bq = rng.uniform(-1, 1, (rows, N))
+    cq = rng.uniform(0.2, 2, rows)
+    K = np.eye(N) + 0.2 * rng.uniform(-1, 1, (N, N))   # constant, not symmetric
+    bc = np.array([0.7, -0.3, 0.45])[:N]
+    ops = (lambda mod: -mod.laplacian() + mod.reaction_field(cq),
+           lambda mod: -mod.diffusion(K) + mod.advection_field(bq) + mod.reaction_field(cq) + 0.25 * mod.reaction(2.0),
+           lambda mod: -mod.laplacian() + mod.advection_field(bq) + mod.advection(bc))
+    for mk in ops:
+        ctx.tune("asm_split_varying", 1)
+        ctx.assemble_operator(capi.MAT_STIFF, mk(capi))
+        got = ctx.matrix_values(capi.MAT_STIFF)
+        ref = oracle.assemble_operator(m, order, od, nd, mk(oracle))
+        assert _entry_close(got, ref.values)
+        ctx.tune("asm_split_varying", 0)
+        ctx.assemble_operator(capi.MAT_STIFF, mk(capi))
+        other = ctx.matrix_values(capi.MAT_STIFF)
+        assert _entry_close(got, other)
+    ctx.tune("asm_split_varying", 1)
+
+
 @pytest.mark.parametrize("mesh_name,order", [("unit_square_16", 2), ("unit_sphere", 1)])
 def test_init_with_space_varying_coefficients_and_forcing(capi, ctx, oracle, mesh_loader, mesh_name, order):
     """one sweep reads the coefficient rows by CELL and the forcing samples by BLOCK-CELL: the two row indices must not be mixed up"""

@@ -1,9 +1,9 @@
 """A/B of the assembly forms on C3 (3-D P1) and C5 (3-D P2): the row-owner sweep (default) against the element-wise scatter forms --
 ATOMIC (lane per (cell,row), slot search, fp64 atomics), COLOURED (the same, one launch per colour), PARTITIONED (one workgroup per cell
 partition, colours walked inside it, atomics only on rows shared between partitions, slot map streamed) and WAVE (one wavefront per
-element, lane = (i, j, q), one launch per colour, slot map streamed; P1 only).  Device time of the stiffness values alone
+element, lane = (i, j, q), one launch per colour, slot map streamed; P2 in passes of 8 (i, j) pairs x 8 node lanes).  Device time of the stiffness values alone
 (fdapde_assemble_operator is synchronous: events around it), median of 5 after one warm-up (which also pays the one-off index work of a
-variant).  Writes profiles/r2_asm_ab.json when run with OUT=<path>."""
+variant).  Writes its numbers to OUT=<path> (profiles/r2_asm_ab.json, profiles/r4_asm_ab.json)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -18,7 +18,7 @@ for name, nx, order in (("C3", int(os.environ.get("NX3", "119")), 1), ("C5", int
     ctx.mesh_upload(nodes, cells, bnd); nd = ctx.dofs_build(order)
     op = -capi.laplacian() if order == 1 else workloads.c5_operator(capi)
     variants = [("rows", capi.ASSEMBLY_ROWS), ("atomic", capi.ASSEMBLY_ATOMIC), ("coloured", capi.ASSEMBLY_COLOURED),
-                ("partitioned", capi.ASSEMBLY_PARTITIONED)] + ([("wave", capi.ASSEMBLY_WAVE)] if order == 1 else [])
+                ("partitioned", capi.ASSEMBLY_PARTITIONED), ("wave", capi.ASSEMBLY_WAVE)]   # (round 4: the wavefront-per-element form takes P2 too)
     ref = None
     res[name] = {"cells": int(cells.shape[0]), "dofs": int(nd), "nnz": int(ctx.sizes()["nnz"]), "operator": "-laplacian" if order == 1 else "-laplacian + advection + reaction", "ms": {}}
     for vname, v in variants:

@@ -179,7 +179,7 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
                     const int grid_i = 8 * (int)(((hs.n_dofs + kAsmBlock - 1) / kAsmBlock + 7) / 8);
                     if (std::getenv("FDAPDE_DEBUG_ASM"))
                         std::fprintf(stderr, "assembly launch <%d,%d> opk %d, visit-parallel: grid %d x %d threads, LDS %zu B dynamic (tables %zu + accumulators %zu), longest visit list %d, %s\n",
-                                     M, R, opk, grid_i, (opk == 4 || (opk == 5 && M == 3)) ? 512 : 1024, lds_items, tab, acc_all, c->asm_max_visits, want_mass2 ? "mass as second sweep" : "one matrix");
+                                     M, R, opk, grid_i, opk == 4 ? 512 : 1024, lds_items, tab, acc_all, c->asm_max_visits, want_mass2 ? "mass as second sweep" : "one matrix");
 #define ITEMS_GO(OPK_, M2_, TH_)                                                                                                          \
     do {                                                                                                                                  \
         const void* fn = reinterpret_cast<const void*>(&k_assemble_items<M, R, OPK_, M2_, TH_>);                                          \
@@ -193,9 +193,12 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
                     } else if (want_mass2) {
                         if (opk == 3) ITEMS_GO(3, 2, 1024);
                         else ITEMS_GO(1, 2, 1024);
-                    } else if (opk == 4) ITEMS_GO(4, 0, 512);
-                    else if (opk == 5) {   // (3-D P2 with 1024 threads: 106 registers spilled; 512 threads, as the fully space-varying integrand)
-                        if (M == 3 && !(th_env && std::atoi(th_env) == 1024)) ITEMS_GO(5, 0, 512);
+                    } else if (opk == 4) {
+                        if (th_env && std::atoi(th_env) == 1024) ITEMS_GO(4, 0, 1024);
+                        else ITEMS_GO(4, 0, 512);
+                    }
+                    else if (opk == 5) {   // (node loop rolled: 107 registers, none spilled -- C5-size -Lap + c(x): 1024 threads 5.8 ms, 512: 7.4)
+                        if (th_env && std::atoi(th_env) == 512) ITEMS_GO(5, 0, 512);
                         else ITEMS_GO(5, 0, 1024);
                     }
                     else if (opk == 3) ITEMS_GO(3, 0, 1024);

@@ -8,6 +8,10 @@
 
 #include "internal.h"
 
+#ifndef FDAPDE_OPK5_QUNROLL
+#define FDAPDE_OPK5_QUNROLL 1
+#endif
+
 namespace fdapde_hip {
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -268,7 +272,8 @@ __device__ __forceinline__ double element_row(const AsmArgs& a, const DevOp& op,
             const bool vb = (op.var_kinds & 2) != 0, vc = (op.var_kinds & 4) != 0;
 #pragma unroll
             for (int j = 0; j < NB; ++j) accj[j] = 0.0;
-#pragma unroll
+            constexpr int QU5 = R == 1 ? NQ : FDAPDE_OPK5_QUNROLL;
+#pragma unroll QU5
             for (int q = 0; q < NQ; ++q) {
                 const int64_t qrow = qrow0 + q;
                 double bq[M], ctq = 0.0;
@@ -377,7 +382,11 @@ __device__ __forceinline__ double element_row(const AsmArgs& a, const DevOp& op,
         for (int j = 0; j < NB; ++j) accj[j] = 0.0;
         bool any_adv = false;
         for (int t = 0; t < op.n; ++t) any_adv = any_adv || op.t[t].kind == FDAPDE_ADVECTION;
-#pragma unroll
+        // P2: the node loop stays a loop -- unrolled, the five (3-D) node bodies with their 13 coefficient loads each want 256 registers
+        // + 311 spilled (k_assemble_items<3,2,4>: 1 248 B of scratch per lane); rolled 114 and none: C5-size, three fields, init 29.7 -> 10.6 ms.
+        // P1 (4 trial functions, constant gradients) is faster unrolled (1.30 M tetrahedra: 1.49 against 1.81 ms).
+        constexpr int QU = R == 1 ? NQ : 1;
+#pragma unroll QU
         for (int q = 0; q < NQ; ++q) {
             const int64_t qrow = qrow0 + q;
             double Kt[M * M], bt[M], ctq = 0.0;

@@ -156,7 +156,9 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
         const size_t fuse_cap = fm == 2 ? (size_t)c->lds_limit : (size_t)64 * 1024;
         const bool fuse_mass = can && fm != 3 && tab + 2 * acc <= fuse_cap;
         const bool seq_mass = can && !fuse_mass && fm != 2 && tab + acc <= (size_t)c->lds_limit;   // (every block's range must fit the LDS)
-        if (a.vals2 != nullptr && !fuse_mass && !seq_mass) return FDAPDE_EUNSUPPORTED;   // (e_init then runs the mass sweep of its own)
+        // (the visit-parallel sweep below runs the mass matrix as its second pass for the space-varying integrands as well)
+        const bool items_mass = R == 2 && c->asm_items && c->lane_row.p != nullptr && (opk == 4 || opk == 5);
+        if (a.vals2 != nullptr && !fuse_mass && !seq_mass && !items_mass) return FDAPDE_EUNSUPPORTED;   // (e_init then runs the mass sweep of its own)
         if (tab + acc > (size_t)c->lds_limit) acc = tab < (size_t)c->lds_limit ? (size_t)c->lds_limit - tab : 0;
         // visit-parallel form (k_assemble_items) for spaces whose rows were dealt to the lane positions by visit count (P2): the (row, visit)
         // pairs of a block are the work items of 1024 threads (512 for the space-varying integrand: registers), same addends in the same
@@ -165,7 +167,7 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
         if constexpr (R == 2) {
             const size_t acc_all = (size_t)hs.max_blk_nnz * sizeof(double), lds_items = tab + acc_all + (size_t)hs.max_blk_cells * 8;
             const bool want_mass2 = a.vals2 != nullptr;
-            if (c->asm_items && c->lane_row.p != nullptr && opk != 0 && lds_items + 10 * 1024 <= (size_t)160 * 1024 && (!want_mass2 || opk == 1 || opk == 3)) {
+            if (c->asm_items && c->lane_row.p != nullptr && opk != 0 && lds_items + 10 * 1024 <= (size_t)160 * 1024 && (!want_mass2 || opk == 1 || opk == 3 || opk == 4 || opk == 5)) {
                 if (c->asm_max_visits < 0) {   // longest visit list of the space (once per space: fdapde_dofs_build resets it)
                     int64_t mw = 0;
                     for (size_t s = 0; s + 1 < hs.sl_off.size(); ++s) mw = std::max<int64_t>(mw, hs.sl_off[s + 1] - hs.sl_off[s]);
@@ -192,6 +194,8 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
                         else ITEMS_GO(1, 2, 512);
                     } else if (want_mass2) {
                         if (opk == 3) ITEMS_GO(3, 2, 1024);
+                        else if (opk == 5) ITEMS_GO(5, 2, 1024);
+                        else if (opk == 4) ITEMS_GO(4, 2, 512);
                         else ITEMS_GO(1, 2, 1024);
                     } else if (opk == 4) {
                         if (th_env && std::atoi(th_env) == 1024) ITEMS_GO(4, 0, 1024);
@@ -210,6 +214,7 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
                 }
             }
         }
+        if (a.vals2 != nullptr && !fuse_mass && !seq_mass) return FDAPDE_EUNSUPPORTED;   // (items_mass, but the visit-parallel sweep does not take this space)
         a.lds_acc_cap = (int32_t)(acc / sizeof(double));
         c->asm_all_in_lds = acc == (size_t)hs.max_blk_nnz * sizeof(double);   // every block accumulates in LDS (AsmArgs::row_stat is then complete)
         if (a.fq != nullptr && a.fq == c->fq.p && c->fq_blk_ready) a.fq = c->fq_blk.p, a.fq_block = 1;   // column 0: one load coefficient per visit slot

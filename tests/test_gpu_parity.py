@@ -190,7 +190,7 @@ def test_varying_advection_reaction_next_to_constant_diffusion(capi, ctx, oracle
     ctx.tune("asm_split_varying", 1)
 
 
-@pytest.mark.parametrize("mesh_name,order", [("unit_square_16", 2), ("unit_sphere", 1)])
+@pytest.mark.parametrize("mesh_name,order", [("unit_square_16", 2), ("unit_sphere", 1), ("unit_sphere", 2)])
 def test_init_with_space_varying_coefficients_and_forcing(capi, ctx, oracle, mesh_loader, mesh_name, order):
     """one sweep reads the coefficient rows by CELL and the forcing samples by BLOCK-CELL: the two row indices must not be mixed up"""
     m = mesh_loader(mesh_name)
@@ -206,6 +206,16 @@ def test_init_with_space_varying_coefficients_and_forcing(capi, ctx, oracle, mes
     assert _entry_close(ctx.force(), oracle.assemble_forcing(m, order, od, nd, fq))
     ref = oracle.assemble_operator(m, order, od, nd, -oracle.laplacian() + oracle.reaction_field(cq))
     assert _entry_close(ctx.matrix_values(capi.MAT_STIFF), ref.values)
+    # the mass matrix of the same init (P2: second pass of the same visit-parallel launch, also behind a space-varying integrand)
+    mass = oracle.assemble_operator(m, order, od, nd, oracle.reaction(1.0))
+    assert _entry_close(ctx.matrix_values(capi.MAT_MASS), mass.values)
+    Kq = np.tile(np.eye(m.N).reshape(-1), (qn.shape[0], 1)) * (1.0 + 0.3 * np.sin(qn[:, :1]))
+    ctx.set_operator(-capi.diffusion_field(Kq) + capi.reaction_field(cq))
+    ctx.init()
+    ref = oracle.assemble_operator(m, order, od, nd, -oracle.diffusion_field(Kq) + oracle.reaction_field(cq))
+    assert _entry_close(ctx.matrix_values(capi.MAT_STIFF), ref.values)
+    assert _entry_close(ctx.matrix_values(capi.MAT_MASS), mass.values)
+    assert _entry_close(ctx.force(), oracle.assemble_forcing(m, order, od, nd, fq))
 
 
 @pytest.mark.parametrize("mesh_name,order", CASES)

@@ -827,9 +827,18 @@ int e_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     DebugClock clk;
     if (int rc = solve_prepare(c, A, c->have_g ? 1 : 0, &ss, c->op_symmetric)) return rc;
     clk.mark("fdapde_solve: solve_prepare");
-    const int rc = solve_run(c, ss, A, c->force.p, c->g.p, nullptr, opt ? opt->method : FDAPDE_SOLVER_AUTO, rtol, maxit, check_every,
-                             opt ? opt->time_spmv : 0);
+    int rc = solve_run(c, ss, A, c->force.p, c->g.p, nullptr, opt ? opt->method : FDAPDE_SOLVER_AUTO, rtol, maxit, check_every,
+                       opt ? opt->time_spmv : 0);
     clk.mark("fdapde_solve: solve_run");
+    if (rc == FDAPDE_ENOCONV && c->h_ctl[2] != 0 && (!opt || opt->method == FDAPDE_SOLVER_AUTO) && c->info.method_used != FDAPDE_SOLVER_BICGSTAB &&
+        !ss.dist && !ss.rowdist) {
+        // CG broke down (p.Ap <= 0): the operator is symmetric but not positive definite -- e.g. 3-D P2 with a large reaction term: the
+        // reference's 5-point rule has a negative weight, its mass matrix is indefinite (integrator_tables.h:275-292).  The reference's LU solves
+        // such a system all the same (fem_linear_elliptic_solver.h:38-47); so does BiCGStab.  Only where the caller left the method open.
+        if (int rc2 = solve_prepare(c, A, c->have_g ? 1 : 0, &ss, false)) return rc2;
+        rc = solve_run(c, ss, A, c->force.p, c->g.p, nullptr, FDAPDE_SOLVER_BICGSTAB, rtol, maxit, check_every, opt ? opt->time_spmv : 0);
+        clk.mark("fdapde_solve: solve_run (BiCGStab after a CG breakdown)");
+    }
     if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev1));
@@ -881,6 +890,7 @@ int e_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times,
     std::memcpy(solution, initial_condition, sizeof(double) * (size_t)n);   // solution_.col(0) = initial condition (line 46)
     int total_iters = 0, rc_all = FDAPDE_OK;
     double worst = 0;
+    int step_method = opt ? opt->method : FDAPDE_SOLVER_AUTO;
     for (int32_t i = 0; i + 1 < n_times; ++i) {
         launch_spmv(c, c->vals[FDAPDE_MAT_MASS].p, uprev.p, c->s.p, nullptr, nullptr, nullptr);   // M u_i
         hipLaunchKernelGGL(k_parabolic_rhs, dim3(g1(n)), dim3(256), 0, st, n, c->s.p, inv_dt, c->force.p + (size_t)(i + 1) * n, rhs.p);
@@ -889,8 +899,13 @@ int e_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times,
             hipLaunchKernelGGL(k_gather_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->tmp_i.p, gcol.p);
         }
         c->defer_end_sync = true;   // (the step's outcome is read inside solve_run; what follows it is ordered by the stream)
-        const int rc = solve_run(c, ss, kmat.p, rhs.p, gcol.p, uprev.p, opt ? opt->method : FDAPDE_SOLVER_AUTO, rtol, maxit,
-                                 check_every, 0);
+        int rc = solve_run(c, ss, kmat.p, rhs.p, gcol.p, uprev.p, step_method, rtol, maxit, check_every, 0);
+        if (rc == FDAPDE_ENOCONV && c->h_ctl[2] != 0 && step_method == FDAPDE_SOLVER_AUTO && c->info.method_used != FDAPDE_SOLVER_BICGSTAB && !ss.dist &&
+            !ss.rowdist) {   // M / dt + A symmetric but not positive definite (see fdapde_solve): this step again and every later one with BiCGStab
+            if (int rc2 = solve_prepare(c, kmat.p, dirichlet ? 1 : 0, &ss, false)) return rc2;
+            step_method = FDAPDE_SOLVER_BICGSTAB;
+            rc = solve_run(c, ss, kmat.p, rhs.p, gcol.p, uprev.p, step_method, rtol, maxit, check_every, 0);
+        }
         c->defer_end_sync = false;
         if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;
         if (rc == FDAPDE_ENOCONV) rc_all = rc;
@@ -1025,6 +1040,17 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
     int total = 0, rc_all = FDAPDE_OK;
     double worst = 0;
     int32_t j0 = 0;
+    bool breakdown = false;   // a CG column stopped on p.Ap <= 0
+    // the handle was told "symmetric" and CG broke down: the matrix is not positive definite (3-D P2 mass matrices are not: negative quadrature
+    // weight).  The reference's SparseLU does not care (utils/symbols.h:133-160): prepare the plain storage and solve every column with BiCGStab.
+    auto retry_as_bicgstab = [&]() -> int {
+        c->lin_symmetric = false, c->scaled_owner = fdapde_ctx::kScaledNone;
+        if (int rc = solve_prepare(c, c->lin_mat.p, 0, &c->lin_state->ss, false)) return rc;
+        c->scaled_owner = fdapde_ctx::kScaledLin, c->lin_sq_ready = false;
+        return e_lin_solve(c, opt, b, n_rhs, x, info);
+    };
+    const bool may_retry = c->lin_symmetric && (!opt || opt->method == FDAPDE_SOLVER_AUTO) && method == FDAPDE_SOLVER_CG_FUSED &&
+                           !c->lin_state->ss.dist && !c->lin_state->ss.rowdist;
     // several columns against a symmetric positive system on one GPU: batches of 8 / 4 columns share every pass over the
     // matrix (kernels_multirhs.h); what is left goes column by column
     // (a system the persistent CG takes is faster column by column -- one launch each, no vector traffic -- than batched through
@@ -1070,6 +1096,7 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
             c->info.spmv_avg_ms = 0, c->info.spmv_timed = 0;
             if (info) *info = c->info;
             if (!c->info.converged) {
+                if (c->h_ctl[2] && may_retry) return retry_as_bicgstab();
                 c->err = c->h_ctl[2] ? "Krylov breakdown (operator not SPD for CG)" : "maxit reached";
                 return FDAPDE_ENOCONV;
             }
@@ -1110,6 +1137,7 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
                 const double bb = h_sc[4 * (size_t)k], rr = h_sc[4 * (size_t)k + 3];
                 const double rel = bb > 0 ? sqrt(rr / bb) : 0.0;
                 if (!(rr <= tol2 * bb && h_ctl[4 * (size_t)k + 2] == 0)) rc_all = FDAPDE_ENOCONV;
+                breakdown = breakdown || h_ctl[4 * (size_t)k + 2] != 0;
                 total += h_ctl[4 * (size_t)k + 1], worst = rel > worst ? rel : worst;
             }
             c->info.method_used = method, c->info.persistent = 1, c->info.launch_ms = c->persist_launch_ms;
@@ -1125,7 +1153,7 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
         c->defer_end_sync = false;
         clk.mark("lin_solve: solve_run");
         if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;
-        if (rc == FDAPDE_ENOCONV) rc_all = rc;
+        if (rc == FDAPDE_ENOCONV) rc_all = rc, breakdown = breakdown || c->h_ctl[2] != 0;
         total += c->info.iters, worst = c->info.relres > worst ? c->info.relres : worst;
         hipLaunchKernelGGL(k_scatter_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->u.p, c->tmp_e.p);
         HIPCHK(c, hipMemcpyAsync(x + (size_t)j * n, c->tmp_e.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
@@ -1133,9 +1161,12 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
     }
     HIPCHK(c, hipEventRecord(c->ev1, st));
     HIPCHK(c, hipEventSynchronize(c->ev1));
+    if (rc_all == FDAPDE_ENOCONV && breakdown && may_retry) return retry_as_bicgstab();
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->info.t_solve_ms = ms, c->info.iters = total, c->info.relres = worst, c->info.converged = rc_all == FDAPDE_OK ? 1 : 0;
+    if (rc_all == FDAPDE_ENOCONV)
+        c->err = breakdown ? "Krylov breakdown in at least one column (matrix not positive definite for CG, or BiCGStab rho / omega = 0)" : "maxit reached in at least one column";
     if (info) *info = c->info;
     return rc_all;
 }

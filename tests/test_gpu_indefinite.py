@@ -1,0 +1,101 @@
+"""Symmetric but NOT positive definite operators (Helmholtz-type: -Lap u - k^2 u with k^2 above the first Dirichlet eigenvalue).  The
+reference's SparseLU solves them like any other system (fem_linear_elliptic_solver.h:38-47, utils/symbols.h:133-160).  Here a symmetric
+operator selects CG, whose breakdown (p.Ap <= 0) is detected inside the launch; with the method left open (FDAPDE_SOLVER_AUTO) the solve is
+then repeated with BiCGStab -- elliptic solve, parabolic stepper and the factor-once handle alike -- and must give the LU solution; with the
+method pinned to CG the breakdown is reported (success = false), never a wrong answer."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    from fdapde_loader import load_package
+
+    load_package()
+    from fdapde_core_amd import capi, meshgen
+
+    assert capi.load().fdapde_device_count() >= 1
+    return capi, meshgen
+
+
+def _csr(c, capi, which, nd):
+    import scipy.sparse as sp
+
+    rp, ci = c.pattern_get()
+    return sp.csr_matrix((c.matrix_values(which), ci, rp), shape=(nd, nd))
+
+
+def _setup(capi, meshgen, dim, nx, order, creact):
+    nodes, cells, bnd = meshgen.unit_square(nx) if dim == 2 else meshgen.unit_cube(nx)
+    _, f = meshgen.manufactured(dim)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(order)
+    _, bdofs, coords = c.dofs_get()
+    c.set_operator(-capi.laplacian() + capi.reaction(creact))
+    c.set_forcing(f(c.quadrature_nodes()))
+    return c, nd, bdofs, coords
+
+
+@pytest.mark.parametrize("dim,nx,order,creact", [(2, 32, 1, -100.0), (2, 24, 2, -40.0), (3, 10, 1, -300.0), (3, 5, 2, -60.0)])
+def test_elliptic_solve_of_an_indefinite_symmetric_operator(env, dim, nx, order, creact):
+    import scipy.sparse.linalg as spl
+
+    capi, meshgen = env
+    c, nd, bdofs, coords = _setup(capi, meshgen, dim, nx, order, creact)
+    c.set_dirichlet(0.2 * coords[:, 0])
+    c.init()
+    info = c.solve(rtol=1e-11, raise_on_noconv=False)
+    A = _csr(c, capi, capi.MAT_STIFF, nd)   # (after the solve: Dirichlet rows zeroed, unit diagonal -- the reference's system)
+    inter = np.flatnonzero(bdofs == 0)
+    ev = np.linalg.eigvalsh(A[inter][:, inter].toarray())
+    assert ev.min() < 0.0 < ev.max() and np.abs(ev).min() > 1e-5   # indefinite, not singular: what this test is about
+    assert info.converged == 1 and info.method_used == capi.SOLVER_BICGSTAB
+    ref = spl.spsolve(A.tocsc(), c.force())
+    assert np.linalg.norm(c.solution() - ref) <= 1e-7 * np.linalg.norm(ref)
+    # the method pinned to CG: the breakdown is reported, no answer is passed off as a solution
+    info_cg = c.solve(method=capi.SOLVER_CG_FUSED, rtol=1e-11, raise_on_noconv=False)
+    assert info_cg.converged == 0
+    c.close()
+
+
+def test_handle_and_stepper_on_an_indefinite_symmetric_operator(env):
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+
+    capi, meshgen = env
+    c, nd, bdofs, coords = _setup(capi, meshgen, 2, 24, 1, -150.0)
+    c.init()
+    A = _csr(c, capi, capi.MAT_STIFF, nd)
+    ev = np.linalg.eigvalsh(A.toarray())
+    assert ev.min() < 0.0 < ev.max() and np.abs(ev).min() > 1e-6
+    rng = np.random.default_rng(5)
+    B = rng.standard_normal((nd, 3))
+    c.lin_compute(capi.MAT_STIFF)   # (a symmetric operator: the handle starts with CG)
+    X, info = c.lin_solve(B, rtol=1e-11)
+    assert info.converged == 1 and info.method_used == capi.SOLVER_BICGSTAB
+    ref = spl.spsolve(A.tocsc(), B)
+    assert np.linalg.norm(X - ref) <= 1e-7 * np.linalg.norm(ref)
+    x1, info1 = c.lin_solve(B[:, 0], rtol=1e-11)   # the handle stays usable, single columns too
+    assert info1.converged == 1 and np.linalg.norm(x1 - ref[:, 0]) <= 1e-7 * np.linalg.norm(ref[:, 0])
+    c.lin_compute(capi.MAT_STIFF)
+    with pytest.raises(capi.FdapdeError):
+        c.lin_solve(B, method=capi.SOLVER_CG_FUSED)
+    # implicit Euler with M / dt + A indefinite (dt = 0.02: 50 M - 150 M + K): two steps against scipy
+    M = _csr(c, capi, capi.MAT_MASS, nd)
+    times = np.array([0.0, 0.02, 0.04])
+    u0 = np.sin(np.pi * coords[:, 0]) * np.sin(np.pi * coords[:, 1])
+    fq = c.quadrature_nodes()[:, 0]
+    c.set_forcing(np.tile(fq[:, None], (1, 3)))
+    c.init()
+    U, pinfo = c.solve_parabolic(times, u0, rtol=1e-11)
+    assert pinfo.converged == 1
+    b = c.force(3).reshape(3, nd)   # (one column per time point)
+    K = (M / 0.02 + A).tocsc()
+    u = u0.copy()
+    for k in (1, 2):
+        u = spl.spsolve(K, M @ u / 0.02 + b[k])
+        assert np.linalg.norm(U[:, k] - u) <= 1e-7 * np.linalg.norm(u)
+    c.close()

@@ -64,7 +64,7 @@ typedef struct {
 /* CG_FUSED: the SpMV carries p.Ap and Ap.Ap, ONE kernel then updates x, r, p: alpha from the explicit r.r, beta from the
  * estimate alpha^2 Ap.Ap - r.r (only the search direction sees the estimate); two launches per iteration, single GPU */
 /* FDAPDE_SOLVER_AUTO: Jacobi-PCG for a symmetric operator with a positive diagonal, Jacobi-BiCGStab otherwise; if CG breaks down (p.Ap <= 0: the
- * operator is symmetric but not positive definite, e.g. -Lap u - k^2 u) the solve is repeated with BiCGStab -- the reference's LU solves such systems too.
+ * operator is symmetric but not positive definite, e.g. -Lap u - k^2 u) the solve is repeated with BiCGStab -- the reference's LU solves such systems too (one-GPU contexts; a rank of a multi-GPU job reports the breakdown).
  * A method named explicitly is never replaced: its failure is reported (FDAPDE_ENOCONV, success = false). */
 enum { FDAPDE_SOLVER_AUTO = 0, FDAPDE_SOLVER_CG = 1, FDAPDE_SOLVER_BICGSTAB = 2, FDAPDE_SOLVER_CG_SR = 3, FDAPDE_SOLVER_CG_FUSED = 4 };
 /* ROWS: row-owner sweep (default; no atomics, bitwise reproducible).  The others are element-wise scatter forms kept as measured

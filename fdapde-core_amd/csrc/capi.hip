@@ -330,6 +330,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "asm_fq_block" && (value == 0 || value == 1)) c->asm_fq_block = value;
     else if (k == "asm_fuse_mass" && value >= 0 && value <= 3) c->asm_fuse_mass = value;
     else if (k == "asm_items" && (value == 0 || value == 1)) c->asm_items = value;
+    else if (k == "bicg_restart" && (value == 0 || value == 1)) c->bicg_restart = value;
     else if (k == "asm_split_varying" && (value == 0 || value == 1)) c->asm_split_varying = value;
     else if (k == "asm_row_stat" && (value == 0 || value == 1)) c->asm_row_stat = value, c->stiff_stat_valid = false;
     else if (k == "asm_fq_bc" && (value == 0 || value == 1)) c->asm_fq_bc = value, c->fq_bc_ready = c->fq_bc_ready && value;   // (takes effect fully at the next fdapde_set_forcing)

@@ -206,6 +206,7 @@ struct fdapde_ctx {
     DBuf<double> fq_bc;       // column 0 of the forcing samples in BLOCK-CELL order (a cell's nq samples repeated in every assembly block that
                               // visits it): the row-owner sweep reads them where it reads the block's cells; built by fdapde_set_forcing
     bool fq_bc_ready = false;
+    int bicg_restart = 1;        // knob: 0 = a BiCGStab breakdown ends the solve (FDAPDE_ENOCONV) instead of restarting it from the iterate reached
     int asm_split_varying = 1;   // knob: 0 = every space-varying operator takes the per-node tensor integrand (element_row OPK 4), also where only advection / reaction vary (OPK 5)
     int asm_items = 1;        // knob: 0 = spaces with dealt rows (P2) keep the row-walking sweep instead of the visit-parallel one (k_assemble_items)
     int32_t asm_max_visits = -1;   // longest visit list of the space (computed on first use; -1 = not yet)
@@ -215,7 +216,7 @@ struct fdapde_ctx {
                               // measured on C3 with that kernel inside init's timed region: init 1.49-1.53 ms against 1.23-1.26 ms for the sweep
                               // gathering the cell's samples itself (a cell's nq samples share one 32-byte sector with the coefficient they would become)
     DBuf<double> vcoords, vals[2], force, fq, g, sval, scale, gt, x, r, p, y, s, t, r0, u, part_a, part_b, sc, tmp_e,
-      tmp_i, tmp_v, lin_rhs;   // (lin_rhs: right-hand side of fdapde_lin_solve in internal order; kept between calls -- hipMalloc + hipFree per
+      tmp_i, tmp_v, restart_u, lin_rhs;   // (restart_u: iterate a broken-down BiCGStab is started again from; lin_rhs: right-hand side of fdapde_lin_solve in internal order; kept between calls -- hipMalloc + hipFree per
                                //  call were a third of a small solve)
     DBuf<uint8_t> bnd;
     DBuf<DevTables> tables;

@@ -725,6 +725,27 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     return FDAPDE_OK;
 }
 
+// solve_run, with a BiCGStab that BROKE DOWN (rho, r0.v or omega exactly 0 -- on advection-dominated operators the recurrences get there --
+// or an iterate that stopped being finite) started again from the iterate it had reached: new shadow residual, the stop rule still relative to
+// the original right-hand side (solve_run's warm start).  Up to kBicgRestarts times; the iterations add up in info.iters.  One-GPU contexts.
+constexpr int kBicgRestarts = 30;
+int solve_run_restarting(fdapde_ctx* c, const SolveState& ss, const double* A, const double* f_dev, const double* g_dev, const double* u0_dev,
+                         int method, double rtol, int maxit, int check_every, int n_timed) {
+    int rc = solve_run(c, ss, A, f_dev, g_dev, u0_dev, method, rtol, maxit, check_every, n_timed);
+    int total = c->info.iters;
+    const int64_t n = c->hs.n_dofs;
+    for (int k = 0; k < kBicgRestarts && rc == FDAPDE_ENOCONV && c->h_ctl[2] != 0 && c->info.method_used == FDAPDE_SOLVER_BICGSTAB && !ss.dist &&
+                    !ss.rowdist && total < maxit && std::isfinite(c->info.relres) && c->bicg_restart;
+         ++k) {
+        HIPCHK(c, c->restart_u.alloc((size_t)n));
+        HIPCHK(c, hipMemcpyAsync(c->restart_u.p, c->u.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+        rc = solve_run(c, ss, A, f_dev, g_dev, c->restart_u.p, FDAPDE_SOLVER_BICGSTAB, rtol, maxit - total, check_every, 0);
+        total += c->info.iters;
+    }
+    c->info.iters = total;
+    return rc;
+}
+
 // One-time preparation of the solver's compact matrix layout for the current boundary-DOF mask (part of set-up, like
 // fdapde_dofs_build; the first solve does it lazily otherwise).  with_dirichlet: the layout used when Dirichlet data are set.
 int e_solver_prepare(fdapde_ctx* c, int32_t with_dirichlet) {
@@ -827,8 +848,8 @@ int e_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     DebugClock clk;
     if (int rc = solve_prepare(c, A, c->have_g ? 1 : 0, &ss, c->op_symmetric)) return rc;
     clk.mark("fdapde_solve: solve_prepare");
-    int rc = solve_run(c, ss, A, c->force.p, c->g.p, nullptr, opt ? opt->method : FDAPDE_SOLVER_AUTO, rtol, maxit, check_every,
-                       opt ? opt->time_spmv : 0);
+    int rc = solve_run_restarting(c, ss, A, c->force.p, c->g.p, nullptr, opt ? opt->method : FDAPDE_SOLVER_AUTO, rtol, maxit, check_every,
+                                  opt ? opt->time_spmv : 0);
     clk.mark("fdapde_solve: solve_run");
     if (rc == FDAPDE_ENOCONV && c->h_ctl[2] != 0 && (!opt || opt->method == FDAPDE_SOLVER_AUTO) && c->info.method_used != FDAPDE_SOLVER_BICGSTAB &&
         !ss.dist && !ss.rowdist) {
@@ -836,7 +857,7 @@ int e_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
         // reference's 5-point rule has a negative weight, its mass matrix is indefinite (integrator_tables.h:275-292).  The reference's LU solves
         // such a system all the same (fem_linear_elliptic_solver.h:38-47); so does BiCGStab.  Only where the caller left the method open.
         if (int rc2 = solve_prepare(c, A, c->have_g ? 1 : 0, &ss, false)) return rc2;
-        rc = solve_run(c, ss, A, c->force.p, c->g.p, nullptr, FDAPDE_SOLVER_BICGSTAB, rtol, maxit, check_every, opt ? opt->time_spmv : 0);
+        rc = solve_run_restarting(c, ss, A, c->force.p, c->g.p, nullptr, FDAPDE_SOLVER_BICGSTAB, rtol, maxit, check_every, opt ? opt->time_spmv : 0);
         clk.mark("fdapde_solve: solve_run (BiCGStab after a CG breakdown)");
     }
     if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;
@@ -899,12 +920,12 @@ int e_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times,
             hipLaunchKernelGGL(k_gather_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->tmp_i.p, gcol.p);
         }
         c->defer_end_sync = true;   // (the step's outcome is read inside solve_run; what follows it is ordered by the stream)
-        int rc = solve_run(c, ss, kmat.p, rhs.p, gcol.p, uprev.p, step_method, rtol, maxit, check_every, 0);
+        int rc = solve_run_restarting(c, ss, kmat.p, rhs.p, gcol.p, uprev.p, step_method, rtol, maxit, check_every, 0);
         if (rc == FDAPDE_ENOCONV && c->h_ctl[2] != 0 && step_method == FDAPDE_SOLVER_AUTO && c->info.method_used != FDAPDE_SOLVER_BICGSTAB && !ss.dist &&
             !ss.rowdist) {   // M / dt + A symmetric but not positive definite (see fdapde_solve): this step again and every later one with BiCGStab
             if (int rc2 = solve_prepare(c, kmat.p, dirichlet ? 1 : 0, &ss, false)) return rc2;
             step_method = FDAPDE_SOLVER_BICGSTAB;
-            rc = solve_run(c, ss, kmat.p, rhs.p, gcol.p, uprev.p, step_method, rtol, maxit, check_every, 0);
+            rc = solve_run_restarting(c, ss, kmat.p, rhs.p, gcol.p, uprev.p, step_method, rtol, maxit, check_every, 0);
         }
         c->defer_end_sync = false;
         if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;
@@ -1130,6 +1151,11 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
             if (int rc = run_persist_cols(c, 0, tol2, maxit, Q, c->cols_r.p, c->cols_x.p, c->cols_sc.p, c->cols_ctl.p, h_ctl.data(), h_sc.data(), &ran, cols_bicg))
                 return rc;
             if (!ran) break;   // (more workgroups than fit after all, or a launch that gave up: these columns go one by one below)
+            if (cols_bicg && c->bicg_restart) {   // a BiCGStab column that broke down: this batch and what follows one by one (solve_run_restarting)
+                bool broke = false;
+                for (int k = 0; k < Q; ++k) broke = broke || h_ctl[4 * (size_t)k + 2] != 0;
+                if (broke) break;
+            }
             hipLaunchKernelGGL(k_cols_finish, dim3(g1(n), Q), dim3(256), 0, st, n, c->cols_x.p, c->scale.p, c->dof_i2e.p, c->cols_b.p);
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipMemcpyAsync(x + (size_t)j0 * n, c->cols_b.p, sizeof(double) * qn, hipMemcpyDeviceToHost, st));
@@ -1149,7 +1175,7 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
         hipLaunchKernelGGL(k_gather_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->tmp_e.p, rhs.p);
         clk.mark("lin_solve: upload + gather issued");
         c->defer_end_sync = true;
-        const int rc = solve_run(c, c->lin_state->ss, c->lin_mat.p, rhs.p, c->g.p, nullptr, method, rtol, maxit, check_every, 0);
+        const int rc = solve_run_restarting(c, c->lin_state->ss, c->lin_mat.p, rhs.p, c->g.p, nullptr, method, rtol, maxit, check_every, 0);
         c->defer_end_sync = false;
         clk.mark("lin_solve: solve_run");
         if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;

@@ -308,6 +308,8 @@ int fdapde_rowdist_setup(fdapde_ctx *ctx, const int64_t *dof_key, const int32_t 
  *   handle        "multi_rhs" (batched multi-column solves)
  *   assembly      "asm_fq_block" (forcing as per-visit load coefficients computed by a kernel of their own inside init),
  *                 "asm_fq_bc" (0: the sweep gathers the forcing samples by cell id instead of reading their block-cell ordered copy),
+ *                 "bicg_restart" (0: a BiCGStab breakdown -- rho, r0.v or omega exactly 0 -- ends the solve with FDAPDE_ENOCONV instead of restarting it from
+ *                 the iterate reached, up to 30 times),
  *                 "asm_split_varying" (0: operators whose advection / reaction vary but whose diffusion part does not take the per-node tensor
  *                 integrand of the fully space-varying case instead of constants-through-reference-tensors + per-node vector / scalar),
  *                 "asm_items" (0: spaces whose rows are dealt by visit count -- P2 -- keep the row-walking sweep instead of the visit-parallel one),

@@ -99,3 +99,34 @@ def test_handle_and_stepper_on_an_indefinite_symmetric_operator(env):
         u = spl.spsolve(K, M @ u / 0.02 + b[k])
         assert np.linalg.norm(U[:, k] - u) <= 1e-7 * np.linalg.norm(u)
     c.close()
+
+
+@pytest.mark.parametrize("dim,nx,bmag", [(2, 32, 1000.0), (3, 10, 1000.0)])
+def test_bicgstab_restarts_after_a_breakdown(env, dim, nx, bmag):
+    """advection-dominated operators (cell Peclet 15 - 50: under-resolved, but the reference's LU solves what it is given): BiCGStab's
+    recurrences break down (rho, r0.v or omega exactly 0) long before convergence; the solve is started again from the iterate reached
+    (new shadow residual, the stop rule still relative to the original right-hand side) until it converges -- knob bicg_restart 0: the first
+    breakdown ends it, as before"""
+    import scipy.sparse.linalg as spl
+
+    capi, meshgen = env
+    nodes, cells, bnd = meshgen.unit_square(nx) if dim == 2 else meshgen.unit_cube(nx)
+    _, f = meshgen.manufactured(dim)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(1)
+    _, _, coords = c.dofs_get()
+    c.set_operator(-capi.laplacian() + capi.advection(bmag * np.array([1.0, 0.5, 0.25])[:dim]))
+    c.set_forcing(f(c.quadrature_nodes()))
+    c.set_dirichlet(0.2 * coords[:, 0])
+    c.init()
+    c.tune("bicg_restart", 0)
+    first = c.solve(rtol=1e-10, raise_on_noconv=False)
+    assert first.converged == 0   # (the case needs the restarts: this is what the test is about)
+    c.tune("bicg_restart", 1)
+    info = c.solve(rtol=1e-10, raise_on_noconv=False)
+    assert info.converged == 1 and info.iters > first.iters and info.relres <= 1e-10
+    A = _csr(c, capi, capi.MAT_STIFF, nd)
+    ref = spl.spsolve(A.tocsc(), c.force())
+    assert np.linalg.norm(c.solution() - ref) <= 1e-7 * np.linalg.norm(ref)
+    c.close()

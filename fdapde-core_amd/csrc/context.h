@@ -206,6 +206,7 @@ struct fdapde_ctx {
     DBuf<double> fq_bc;       // column 0 of the forcing samples in BLOCK-CELL order (a cell's nq samples repeated in every assembly block that
                               // visits it): the row-owner sweep reads them where it reads the block's cells; built by fdapde_set_forcing
     bool fq_bc_ready = false;
+    bool cg_broke_down = false;  // the assembled stiff_ is symmetric but CG broke down on it (fdapde_solve with the method left open): the next solves go to BiCGStab at once
     int bicg_restart = 1;        // knob: 0 = a BiCGStab breakdown ends the solve (FDAPDE_ENOCONV) instead of restarting it from the iterate reached
     int asm_split_varying = 1;   // knob: 0 = every space-varying operator takes the per-node tensor integrand (element_row OPK 4), also where only advection / reaction vary (OPK 5)
     int asm_items = 1;        // knob: 0 = spaces with dealt rows (P2) keep the row-walking sweep instead of the visit-parallel one (k_assemble_items)

@@ -359,7 +359,7 @@ int e_set_operator(fdapde_ctx* c, int32_t n_terms, const fdapde_term* terms) {
     int rc = check_terms(c, n_terms, terms, &t, &sym);
     if (rc) return rc;
     c->op = std::move(t), c->op_symmetric = sym, c->coef_of_op = false;
-    c->assembled[0] = false, c->solved = false;
+    c->assembled[0] = false, c->solved = false, c->cg_broke_down = false;
     return FDAPDE_OK;
 }
 
@@ -463,7 +463,7 @@ int e_assemble_operator(fdapde_ctx* c, int32_t which, int32_t n_terms, const fda
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->assembled[which] = true;
-    if (which == FDAPDE_MAT_STIFF) c->op_symmetric = sym, c->solved = false, c->dirichlet_applied = false;
+    if (which == FDAPDE_MAT_STIFF) c->op_symmetric = sym, c->solved = false, c->dirichlet_applied = false, c->cg_broke_down = false;
     return FDAPDE_OK;
 }
 
@@ -538,7 +538,7 @@ int e_init(fdapde_ctx* c, const fdapde_options* opt) {
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->info.t_assemble_ms = ms;
     c->stiff_stat_valid = stat_complete;
-    c->assembled[0] = c->assembled[1] = true, c->force_ready = true, c->solved = false, c->dirichlet_applied = false;
+    c->assembled[0] = c->assembled[1] = true, c->force_ready = true, c->solved = false, c->dirichlet_applied = false, c->cg_broke_down = false;
     return FDAPDE_OK;
 }
 

@@ -846,16 +846,19 @@ int e_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     SolveState ss;
     c->scaled_owner = fdapde_ctx::kScaledSolve;
     DebugClock clk;
-    if (int rc = solve_prepare(c, A, c->have_g ? 1 : 0, &ss, c->op_symmetric)) return rc;
+    const bool open_method = !opt || opt->method == FDAPDE_SOLVER_AUTO;
+    const bool skip_cg = open_method && c->cg_broke_down;   // (this very matrix broke CG before: see below)
+    if (int rc = solve_prepare(c, A, c->have_g ? 1 : 0, &ss, c->op_symmetric && !skip_cg)) return rc;
     clk.mark("fdapde_solve: solve_prepare");
-    int rc = solve_run_restarting(c, ss, A, c->force.p, c->g.p, nullptr, opt ? opt->method : FDAPDE_SOLVER_AUTO, rtol, maxit, check_every,
-                                  opt ? opt->time_spmv : 0);
+    int rc = solve_run_restarting(c, ss, A, c->force.p, c->g.p, nullptr, skip_cg ? FDAPDE_SOLVER_BICGSTAB : (opt ? opt->method : FDAPDE_SOLVER_AUTO), rtol,
+                                  maxit, check_every, opt ? opt->time_spmv : 0);
     clk.mark("fdapde_solve: solve_run");
     if (rc == FDAPDE_ENOCONV && c->h_ctl[2] != 0 && (!opt || opt->method == FDAPDE_SOLVER_AUTO) && c->info.method_used != FDAPDE_SOLVER_BICGSTAB &&
         !ss.dist && !ss.rowdist) {
         // CG broke down (p.Ap <= 0): the operator is symmetric but not positive definite -- e.g. 3-D P2 with a large reaction term: the
         // reference's 5-point rule has a negative weight, its mass matrix is indefinite (integrator_tables.h:275-292).  The reference's LU solves
         // such a system all the same (fem_linear_elliptic_solver.h:38-47); so does BiCGStab.  Only where the caller left the method open.
+        c->cg_broke_down = true;   // (until the matrix is assembled again)
         if (int rc2 = solve_prepare(c, A, c->have_g ? 1 : 0, &ss, false)) return rc2;
         rc = solve_run_restarting(c, ss, A, c->force.p, c->g.p, nullptr, FDAPDE_SOLVER_BICGSTAB, rtol, maxit, check_every, opt ? opt->time_spmv : 0);
         clk.mark("fdapde_solve: solve_run (BiCGStab after a CG breakdown)");

@@ -55,6 +55,8 @@ def test_elliptic_solve_of_an_indefinite_symmetric_operator(env, dim, nx, order,
     assert info.converged == 1 and info.method_used == capi.SOLVER_BICGSTAB
     ref = spl.spsolve(A.tocsc(), c.force())
     assert np.linalg.norm(c.solution() - ref) <= 1e-7 * np.linalg.norm(ref)
+    again = c.solve(rtol=1e-11, raise_on_noconv=False)   # (the context remembers the breakdown until the matrix is assembled again: no second CG attempt)
+    assert again.converged == 1 and again.method_used == capi.SOLVER_BICGSTAB and again.iters == info.iters
     # the method pinned to CG: the breakdown is reported, no answer is passed off as a solution
     info_cg = c.solve(method=capi.SOLVER_CG_FUSED, rtol=1e-11, raise_on_noconv=False)
     assert info_cg.converged == 0

@@ -64,6 +64,7 @@ int fdapde_ctx_create(int device, fdapde_ctx** out) {
         }
         c->device = device, c->has_device = true;
         preload_assembly(), preload_solve(), preload_dist(), preload_persist();   // (first context of a process: the units' code objects)
+        preload_setup_async(device);   // ... those of the set-up units on a helper thread, joined by the first fdapde_dofs_build
         if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) c->n_cu = 0;
     }
     *out = c;
@@ -92,6 +93,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
         c->peer_send_dof.release(), c->peer_src_off.release(), c->peer_src.release(), c->peer_sendbuf.release(), c->peer_recvbuf.release();
         release_rowdist(c);
         if (c->comm) (void)g_rccl.CommDestroy(c->comm);
+        c->mesh_nodes.release(), c->mesh_cells.release(), c->mesh_nbnd.release();
         c->lin_mat.release(), c->stiff_stat.release(), c->ar_dev.release(), c->persist_stats.release(), c->persist_x.release(), c->persist_xs.release(), c->coords_e.release();
         dev_topology_release(&c->topo);
         c->part_cells.release(), c->part_off.release(), c->part_slots.release(), c->wave_slots.release(), c->part_shared.release();
@@ -139,7 +141,20 @@ int fdapde_mesh_upload(fdapde_ctx* c, int M, int N, int64_t n_nodes, const doubl
     c->assembled[0] = c->assembled[1] = c->force_ready = c->solved = c->dirichlet_applied = false;
     c->op.clear(), c->coef_of_op = false, c->fq_i.clear(), c->fq_cols = 0, c->g_i.clear(), c->have_g = false;
     if (c->topo_ready) dev_topology_release(&c->topo), c->topo_ready = false;
-    return host_set_mesh(c->hs, M, N, n_nodes, nodes, n_cells, cells, bnd, c->err);
+    c->mesh_on_dev = false;
+    if (int rc = host_set_mesh(c->hs, M, N, n_nodes, nodes, n_cells, cells, bnd, c->err)) return rc;
+    if (c->has_device) {   // the mesh is resident on the device from here on: the function space (any order) and the topology tables are built from it
+        const HostSpace& hs = c->hs;
+        if (hipSetDevice(c->device) != hipSuccess || c->mesh_nodes.upload(hs.nodes.data(), hs.nodes.size(), c->stream) != hipSuccess ||
+            c->mesh_cells.upload(hs.cells.data(), hs.cells.size(), c->stream) != hipSuccess ||
+            c->mesh_nbnd.upload(hs.node_bnd.data(), hs.node_bnd.size(), c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+            c->mesh_nodes.release(), c->mesh_cells.release(), c->mesh_nbnd.release();
+            c->err = "fdapde_mesh_upload: copying the mesh to the device failed";
+            return FDAPDE_EHIP;
+        }
+        c->mesh_on_dev = true;
+    }
+    return FDAPDE_OK;
 }
 
 int fdapde_sizes(const fdapde_ctx* c, int64_t* n_dofs, int64_t* nnz, int32_t* n_basis, int32_t* n_quadrature, int64_t* n_edges) {

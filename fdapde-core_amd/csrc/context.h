@@ -191,6 +191,12 @@ struct fdapde_ctx {
     DBuf<int32_t> rowptr_e, colidx_e;   // reference-numbering pattern (device-built spaces: fetched by fdapde_pattern_get on demand)
     DBuf<int32_t> dofs_e;               // order 2, device-built: the DOF table in the reference numbering (host mirror on demand)
     DBuf<double> coords_e;              // ... and the DOF coordinates
+    // the mesh as handed over, resident on the device from fdapde_mesh_upload on (nodes column-major, cells row-major, node markers 0 / 1):
+    // fdapde_dofs_build and fdapde_topology_build start from these; 41 + 162 MB at C3's size
+    DBuf<double> mesh_nodes;
+    DBuf<int32_t> mesh_cells;
+    DBuf<uint8_t> mesh_nbnd;
+    bool mesh_on_dev = false;
     bool dev_built = false;             // the index structures were built on the device (dev_setup.hip); big host mirrors are lazy
     DBuf<uint32_t> slotw;
     DBuf<int64_t> bc_off, bn_off;

@@ -29,5 +29,6 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
                              int n_wg, int lds_entries, int blocked_rows, const int32_t* block_rows, int sym_mode, bool balance, void* stream, PersistLayout& pl, DevPersist* out,
                              std::string& err);
 
+void dev_persist_preload();    // loads this unit's code object
 }  // namespace fdapde_hip
 #endif

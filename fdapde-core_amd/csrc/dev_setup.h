@@ -48,5 +48,6 @@ struct DevBinGrid {
 int dev_build_bin_grid(int M, int64_t n_nodes, int64_t n_cells, const double* d_vcoords, const int32_t* d_cverts, void* stream, DevBinGrid* out,
                        std::string& err);
 
+void dev_setup_preload();      // loads this unit's code object (hipFuncGetAttributes of one of its kernels)
 }  // namespace fdapde_hip
 #endif

@@ -761,12 +761,9 @@ int dev_build_space(HostSpace& hs, const double* d_nodes, const int32_t* d_cells
     // ---- what the host side of the library keeps: permutations, boundary flags, row pointers, sizes
     int32_t h_max[4] = {0, 0, 0, 0};
     DS_CHK(hipMemcpyAsync(h_max, maxes.p, sizeof h_max, hipMemcpyDeviceToHost, st));
-    hs.dof_i2e.resize((size_t)nd), hs.dof_e2i.resize((size_t)nd), hs.cell_i2e.resize((size_t)nc), hs.dof_bnd_i.resize((size_t)nd);
+    // (the permutations and the boundary flags in internal order stay on the device until host code asks: ensure_host, kHostPerm)
+    hs.dof_i2e.clear(), hs.dof_e2i.clear(), hs.cell_i2e.clear(), hs.dof_bnd_i.clear();
     hs.rowptr_i.resize((size_t)nd + 1), hs.sl_off.resize((size_t)n_slices + 1);
-    DS_CHK(hipMemcpyAsync(hs.dof_i2e.data(), s.dof_i2e, sizeof(int32_t) * (size_t)nd, hipMemcpyDeviceToHost, st));
-    DS_CHK(hipMemcpyAsync(hs.dof_e2i.data(), s.dof_e2i, sizeof(int32_t) * (size_t)nd, hipMemcpyDeviceToHost, st));
-    DS_CHK(hipMemcpyAsync(hs.cell_i2e.data(), s.cell_i2e, sizeof(int32_t) * (size_t)nc, hipMemcpyDeviceToHost, st));
-    DS_CHK(hipMemcpyAsync(hs.dof_bnd_i.data(), s.bnd, (size_t)nd, hipMemcpyDeviceToHost, st));
     DS_CHK(hipMemcpyAsync(hs.rowptr_i.data(), s.rowptr, sizeof(int32_t) * ((size_t)nd + 1), hipMemcpyDeviceToHost, st));
     DS_CHK(hipMemcpyAsync(hs.sl_off.data(), s.sl_off, sizeof(int64_t) * ((size_t)n_slices + 1), hipMemcpyDeviceToHost, st));
     DS_CHK(hipStreamSynchronize(st));
@@ -794,6 +791,12 @@ int dev_build_space(HostSpace& hs, const double* d_nodes, const int32_t* d_cells
     guard.armed = false;
     *out = s;
     return FDAPDE_OK;
+}
+
+void dev_setup_preload() {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_invert));
+    (void)hipGetLastError();
 }
 
 }  // namespace fdapde_hip

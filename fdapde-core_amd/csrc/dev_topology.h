@@ -36,5 +36,6 @@ int dev_build_p2_dofs(int M, int64_t n_nodes, int64_t n_cells, const double* d_n
                       const double* refnodes, void* stream, int32_t** d_dofs, uint8_t** d_dof_bnd, double** d_dof_coords, int64_t* n_edges,
                       std::string& err);
 
+void dev_topology_preload();   // loads this unit's code object
 }  // namespace fdapde_hip
 #endif

@@ -410,4 +410,10 @@ int dev_build_p2_dofs(int M, int64_t n_nodes, int64_t n_cells, const double* d_n
     return FDAPDE_OK;
 }
 
+void dev_topology_preload() {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_gather_keys));
+    (void)hipGetLastError();
+}
+
 }  // namespace fdapde_hip

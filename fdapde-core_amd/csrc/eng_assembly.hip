@@ -428,18 +428,31 @@ int e_set_dirichlet(fdapde_ctx* c, const double* g) {
         c->have_g = false, c->g_i.clear();
         return FDAPDE_OK;
     }
-    c->g_i.resize((size_t)hs.n_dofs);
     bool all_zero = true;
-    for (int64_t i = 0; i < hs.n_dofs; ++i) {
-        c->g_i[(size_t)i] = g[hs.dof_i2e[(size_t)i]];
-        all_zero = all_zero && c->g_i[(size_t)i] == 0.0;
+    if (c->has_device && c->dev_ready) {   // as handed over to the device, permuted to the internal DOF order there (a serial host gather through
+                                           // dof_i2e before: 6 ms at C3's size; the permutation's host mirror is not needed any more)
+        for (int64_t i = 0; i < hs.n_dofs && all_zero; ++i) all_zero = g[i] == 0.0;
+        c->g_i.clear();
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, c->g.alloc((size_t)hs.n_dofs));
+        HIPCHK(c, hipMemcpyAsync(c->tmp_e.p, g, sizeof(double) * (size_t)hs.n_dofs, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_gather_f64, dim3(g1(hs.n_dofs)), dim3(256), 0, c->stream, hs.n_dofs, c->dof_i2e.p, c->tmp_e.p, c->g.p);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // (the caller's buffer is free again when the call returns)
+    } else {
+        if (int rc = ensure_host(c, kHostPerm)) return rc;
+        c->g_i.resize((size_t)hs.n_dofs);
+        for (int64_t i = 0; i < hs.n_dofs; ++i) {
+            c->g_i[(size_t)i] = g[hs.dof_i2e[(size_t)i]];
+            all_zero = all_zero && c->g_i[(size_t)i] == 0.0;
+        }
+        if (c->has_device) {
+            HIPCHK(c, hipSetDevice(c->device));
+            HIPCHK(c, c->g.upload(c->g_i.data(), c->g_i.size(), c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
     }
     c->have_g = true, c->g_zero = all_zero;
-    if (c->has_device) {
-        HIPCHK(c, hipSetDevice(c->device));
-        HIPCHK(c, c->g.upload(c->g_i.data(), c->g_i.size(), c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
     return FDAPDE_OK;
 }
 

@@ -34,7 +34,17 @@ int e_ctx_clone(const fdapde_ctx* s, fdapde_ctx* d) {
     const HostSpace& hs = s->hs;
     if (hs.n_cells == 0) return FDAPDE_OK;   // nothing uploaded yet
     if (int rc = host_set_mesh(d->hs, hs.M, hs.N, hs.n_nodes, hs.nodes.data(), hs.n_cells, hs.cells.data(), hs.node_bnd.data(), d->err)) return rc;
-    if (!s->space_ready) return FDAPDE_OK;
+    if (s->has_device && d->has_device && s->mesh_on_dev) {   // the device copy of the mesh: device to device
+        HIPCHK(d, hipSetDevice(s->device));
+        if (int rc = copy_buf(d, d->mesh_nodes, s->mesh_nodes, s->mesh_nodes.n)) return rc;
+        if (int rc = copy_buf(d, d->mesh_cells, s->mesh_cells, s->mesh_cells.n)) return rc;
+        if (int rc = copy_buf(d, d->mesh_nbnd, s->mesh_nbnd, s->mesh_nbnd.n)) return rc;
+        d->mesh_on_dev = true;
+    }
+    if (!s->space_ready) {
+        if (d->mesh_on_dev) HIPCHK(d, hipStreamSynchronize(d->stream));
+        return FDAPDE_OK;
+    }
     if (s->has_device) {
         HIPCHK(d, hipSetDevice(s->device));
         HIPCHK(d, hipStreamSynchronize(s->stream));   // whatever the source still has in flight

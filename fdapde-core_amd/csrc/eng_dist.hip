@@ -164,6 +164,7 @@ int e_halo_setup(fdapde_ctx* c, int64_t n_if_global, int64_t n_if_local, const i
     if (!c->dev_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
     if (!c->comm && !c->ar_fn) return fail(c, FDAPDE_ENOTINIT, "call fdapde_comm_init first");
     HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = ensure_host(c, kHostPerm)) return rc;
     const HostSpace& hs = c->hs;
     std::vector<int32_t> dof_i((size_t)n_if_local), pos((size_t)n_if_local);
     for (int64_t k = 0; k < n_if_local; ++k) {
@@ -196,6 +197,7 @@ int e_rowdist_setup(fdapde_ctx* c, const int64_t* dof_key, const int32_t* dof_ow
     if (!c->comm && !c->ar_fn) return fail(c, FDAPDE_ENOTINIT, "call fdapde_comm_init first");
     HIPCHK(c, hipSetDevice(c->device));
     release_rowdist(c);
+    if (int rc = ensure_host(c, kHostPerm)) return rc;
     const HostSpace& hs = c->hs;
     c->rd.owner_i.resize((size_t)hs.n_dofs), c->rd.key_i.resize((size_t)hs.n_dofs);
     std::vector<uint8_t> own((size_t)hs.n_dofs);
@@ -224,6 +226,7 @@ int e_halo_setup_peers(fdapde_ctx* c, int32_t n_peers, const int32_t* peer_rank,
     if (!c->dev_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
     if (!c->comm && !c->ar_fn) return fail(c, FDAPDE_ENOTINIT, "call fdapde_comm_init first");
     HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = ensure_host(c, kHostPerm)) return rc;
     const HostSpace& hs = c->hs;
     const int64_t n_send = n_peers > 0 ? peer_off[n_peers] : 0;
     for (int q = 0; q < n_peers; ++q)

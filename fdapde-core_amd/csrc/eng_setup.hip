@@ -6,7 +6,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <thread>
 
 #include <dlfcn.h>
 #include <hip/hip_ext.h>
@@ -18,6 +20,33 @@
 
 namespace fdapde_engine {
 
+// ---- code objects of the set-up units (dev_setup / dev_persist / dev_topology: 25 MB of device code, mostly the radix sorts' instantiations;
+//      HIP loads a unit's code object when one of its kernels is first looked up: ~30 ms inside the first fdapde_dofs_build of a process before).
+//      The first context of a process starts the loading on a helper thread; the first build waits for it.
+namespace {
+std::once_flag g_preload_once;
+std::mutex g_preload_mx;
+std::thread g_preload_thread;
+struct PreloadJoiner {
+    ~PreloadJoiner() { preload_wait(); }   // (a process that ends before its first build: the thread is joined, never left running)
+} g_preload_joiner;
+}   // namespace
+
+void preload_setup_async(int device) {
+    if (std::getenv("FDAPDE_NO_PRELOAD")) return;
+    std::call_once(g_preload_once, [device] {
+        std::lock_guard<std::mutex> lk(g_preload_mx);
+        g_preload_thread = std::thread([device] {
+            if (hipSetDevice(device) != hipSuccess) return;
+            dev_setup_preload(), dev_persist_preload(), dev_topology_preload();
+        });
+    });
+}
+void preload_wait() {
+    std::lock_guard<std::mutex> lk(g_preload_mx);
+    if (g_preload_thread.joinable()) g_preload_thread.join();
+}
+
 // big host-side index arrays of a device-built space, fetched the first time host code needs them (the persistent layout and the
 // solver patterns read rowptr_i / colidx_i; the colouring and the partitioned assembly cdofs_i; point location cverts_i / vcoords_i;
 // fdapde_pattern_get the reference pattern)
@@ -26,6 +55,14 @@ int ensure_host(fdapde_ctx* c, int what) {
     HostSpace& hs = c->hs;
     hipStream_t st = c->stream;
     HIPCHK(c, hipSetDevice(c->device));
+    if ((what & (kHostPerm | kHostPattern)) && hs.dof_i2e.empty()) {
+        const size_t nd = (size_t)hs.n_dofs, nc = (size_t)hs.n_cells;
+        hs.dof_i2e.resize(nd), hs.dof_e2i.resize(nd), hs.cell_i2e.resize(nc), hs.dof_bnd_i.resize(nd);
+        HIPCHK(c, hipMemcpyAsync(hs.dof_i2e.data(), c->dof_i2e.p, sizeof(int32_t) * nd, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(hs.dof_e2i.data(), c->dof_e2i.p, sizeof(int32_t) * nd, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(hs.cell_i2e.data(), c->cell_i2e.p, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(hs.dof_bnd_i.data(), c->bnd.p, nd, hipMemcpyDeviceToHost, st));
+    }
     if ((what & kHostPattern) && hs.colidx_i.empty()) {
         hs.colidx_i.resize(c->colidx.n);
         HIPCHK(c, hipMemcpyAsync(hs.colidx_i.data(), c->colidx.p, sizeof(int32_t) * c->colidx.n, hipMemcpyDeviceToHost, st));
@@ -273,13 +310,18 @@ int e_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs) {
     if (rc) return fail(c, rc, "basis tables");
     if (on_device) {
         HIPCHK(c, hipSetDevice(c->device));
-        DBuf<double> d_nodes;
-        DBuf<int32_t> d_cells;
-        DBuf<uint8_t> d_nbnd, d_bnd;
+        preload_wait();   // (the set-up units' code objects: loading started with the process's first context)
+        DBuf<uint8_t> d_bnd;
         c->dofs_e.release(), c->coords_e.release();
-        HIPCHK(c, d_nodes.upload(hs.nodes.data(), hs.nodes.size(), c->stream));
-        HIPCHK(c, d_cells.upload(hs.cells.data(), hs.cells.size(), c->stream));
-        HIPCHK(c, d_nbnd.upload(hs.node_bnd.data(), hs.node_bnd.size(), c->stream));
+        if (!c->mesh_on_dev) {   // (a mesh that came in while the context had no device copy of it)
+            HIPCHK(c, c->mesh_nodes.upload(hs.nodes.data(), hs.nodes.size(), c->stream));
+            HIPCHK(c, c->mesh_cells.upload(hs.cells.data(), hs.cells.size(), c->stream));
+            HIPCHK(c, c->mesh_nbnd.upload(hs.node_bnd.data(), hs.node_bnd.size(), c->stream));
+            c->mesh_on_dev = true;
+        }
+        DBuf<double>& d_nodes = c->mesh_nodes;
+        DBuf<int32_t>& d_cells = c->mesh_cells;
+        DBuf<uint8_t>& d_nbnd = c->mesh_nbnd;
         if (order == 1) {   // LagrangianBasis<D, 1>: dofs = cells, boundary DOFs = node markers (lagrangian_basis.h:96-99)
             hs.n_edges = 0, hs.n_dofs = hs.n_nodes;
             hs.dof_bnd.assign(hs.node_bnd.begin(), hs.node_bnd.end());
@@ -299,7 +341,7 @@ int e_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs) {
         DevSpace ds;
         rc = dev_build_space(hs, d_nodes.p, d_cells.p, order == 1 ? d_cells.p : c->dofs_e.p, order == 1 ? d_nbnd.p : d_bnd.p,
                              order == 1 ? d_nodes.p : c->coords_e.p, c->stream, &ds, c->err);
-        d_nodes.release(), d_cells.release(), d_nbnd.release(), d_bnd.release();
+        d_bnd.release();
         if (rc) return rc;
         if (std::getenv("FDAPDE_SETUP_CHECK")) {
             rc = check_dev_space(c, ds, order);
@@ -336,12 +378,14 @@ int e_topology_build(fdapde_ctx* c, int64_t* n_facets, int64_t* n_edges) {
     if (hs.n_cells < 1) return fail(c, FDAPDE_ENOTINIT, "call fdapde_mesh_upload first");
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->topo_ready) {
-        DBuf<int32_t> d_cells;
-        DBuf<uint8_t> d_bnd;
-        HIPCHK(c, d_cells.upload(hs.cells.data(), hs.cells.size(), c->stream));
-        HIPCHK(c, d_bnd.upload(hs.node_bnd.data(), hs.node_bnd.size(), c->stream));
-        const int rc = dev_build_topology(hs.M, hs.n_nodes, hs.n_cells, d_cells.p, d_bnd.p, c->stream, &c->topo, c->err);
-        d_cells.release(), d_bnd.release();
+        preload_wait();
+        if (!c->mesh_on_dev) {
+            HIPCHK(c, c->mesh_nodes.upload(hs.nodes.data(), hs.nodes.size(), c->stream));
+            HIPCHK(c, c->mesh_cells.upload(hs.cells.data(), hs.cells.size(), c->stream));
+            HIPCHK(c, c->mesh_nbnd.upload(hs.node_bnd.data(), hs.node_bnd.size(), c->stream));
+            c->mesh_on_dev = true;
+        }
+        const int rc = dev_build_topology(hs.M, hs.n_nodes, hs.n_cells, c->mesh_cells.p, c->mesh_nbnd.p, c->stream, &c->topo, c->err);
         if (rc) return rc;
         c->topo_ready = true;
     }
@@ -379,6 +423,10 @@ int e_dofs_set_boundary(fdapde_ctx* c, const uint8_t* bnd) {
     if (!c || !bnd) return FDAPDE_EINVAL;
     HostSpace& hs = c->hs;
     if (hs.n_dofs == 0) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
+    if (c->dev_built) {
+        HIPCHK(c, hipSetDevice(c->device));
+        if (int rc = ensure_host(c, kHostPerm)) return rc;
+    }
     for (int64_t i = 0; i < hs.n_dofs; ++i) hs.dof_bnd[(size_t)i] = bnd[i] ? 1 : 0;
     for (int64_t i = 0; i < hs.n_dofs; ++i) hs.dof_bnd_i[(size_t)i] = hs.dof_bnd[(size_t)hs.dof_i2e[(size_t)i]];
     c->sp_built[1] = false;   // the compact solver pattern drops Dirichlet rows / columns

@@ -415,6 +415,9 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     hipStream_t st = c->stream;
     const bool dist = ss.dist;
     const uint8_t* owned = ss.owned;
+    // nothing of an earlier solve may be read as this one's outcome by a caller that sees an early return (solve_run_restarting)
+    c->h_ctl[0] = c->h_ctl[1] = c->h_ctl[2] = c->h_ctl[3] = 0;
+    c->info.iters = 0, c->info.method_used = method, c->info.relres = 0, c->info.converged = 0;
     // partial pairs the SpMV leaves for the vector kernels: one per workgroup of the kernel that applies the scaled operator
     const int np_spmv = (c->bk_cur >= 0 && !dist) ? c->bk[c->bk_cur].meta.G : c->spmv_grid;
     const double* fvec = f_dev;
@@ -734,7 +737,8 @@ int solve_run_restarting(fdapde_ctx* c, const SolveState& ss, const double* A, c
     int rc = solve_run(c, ss, A, f_dev, g_dev, u0_dev, method, rtol, maxit, check_every, n_timed);
     int total = c->info.iters;
     const int64_t n = c->hs.n_dofs;
-    for (int k = 0; k < kBicgRestarts && rc == FDAPDE_ENOCONV && c->h_ctl[2] != 0 && c->info.method_used == FDAPDE_SOLVER_BICGSTAB && !ss.dist &&
+    const bool may_restart = method == FDAPDE_SOLVER_BICGSTAB || method == FDAPDE_SOLVER_AUTO;   // a method named explicitly is never replaced
+    for (int k = 0; k < kBicgRestarts && may_restart && rc == FDAPDE_ENOCONV && c->h_ctl[2] != 0 && c->info.method_used == FDAPDE_SOLVER_BICGSTAB && !ss.dist &&
                     !ss.rowdist && total < maxit && std::isfinite(c->info.relres) && c->bicg_restart;
          ++k) {
         HIPCHK(c, c->restart_u.alloc((size_t)n));
@@ -899,6 +903,7 @@ int e_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times,
     HIPCHK(c, rhs.alloc((size_t)n));
     HIPCHK(c, gcol.alloc((size_t)n));
     std::vector<double> tmp((size_t)n);
+    if (int rc = ensure_host(c, kHostPerm)) return rc;
     auto to_internal = [&](const double* ext) {
         for (int64_t i = 0; i < n; ++i) tmp[(size_t)i] = ext[hs.dof_i2e[(size_t)i]];
     };
@@ -1044,6 +1049,14 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
     HIPCHK(c, hipSetDevice(c->device));
     const HostSpace& hs = c->hs;
     const int64_t n = hs.n_dofs;
+    {   // in-place solves (x overlapping b: Eigen's x = lu.solve(x) idiom): finished columns are written to x while later columns and a
+        // BiCGStab retry still read b -- work from a private copy of the right-hand sides
+        const double *b0 = b, *b1 = b + (size_t)n * n_rhs, *x0 = x, *x1 = x + (size_t)n * n_rhs;
+        if (b0 < x1 && x0 < b1) {
+            std::vector<double> b_copy(b0, b1);
+            return e_lin_solve(c, opt, b_copy.data(), n_rhs, x, info);
+        }
+    }
     hipStream_t st = c->stream;
     const double rtol = (opt && opt->rtol > 0) ? opt->rtol : 1e-10;
     const int maxit = (opt && opt->maxit > 0) ? opt->maxit : default_maxit(c, n);
@@ -1071,7 +1084,11 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
         c->lin_symmetric = false, c->scaled_owner = fdapde_ctx::kScaledNone;
         if (int rc = solve_prepare(c, c->lin_mat.p, 0, &c->lin_state->ss, false)) return rc;
         c->scaled_owner = fdapde_ctx::kScaledLin, c->lin_sq_ready = false;
-        return e_lin_solve(c, opt, b, n_rhs, x, info);
+        const int spent = total;   // the CG iterations before the breakdown count
+        const int rc = e_lin_solve(c, opt, b, n_rhs, x, info);
+        c->info.iters += spent;
+        if (info) info->iters = c->info.iters;
+        return rc;
     };
     const bool may_retry = c->lin_symmetric && (!opt || opt->method == FDAPDE_SOLVER_AUTO) && method == FDAPDE_SOLVER_CG_FUSED &&
                            !c->lin_state->ss.dist && !c->lin_state->ss.rowdist;
@@ -1096,7 +1113,7 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
             if (q == 8) rc = lin_solve_batch<8>(c, b + (size_t)j0 * n, x + (size_t)j0 * n, rtol, maxit, check_every, &its, &rel, &ok);
             else rc = lin_solve_batch<4>(c, b + (size_t)j0 * n, x + (size_t)j0 * n, rtol, maxit, check_every, &its, &rel, &ok);
             if (rc != FDAPDE_OK) return rc;
-            if (!ok) rc_all = FDAPDE_ENOCONV;
+            if (!ok) rc_all = FDAPDE_ENOCONV, breakdown = breakdown || c->h_ctl[2] != 0;   // (lin_solve_batch leaves h_ctl of its last read-back)
             total += its, worst = rel > worst ? rel : worst;
             c->info.method_used = method;
             j0 += q;
@@ -1120,7 +1137,10 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
             c->info.spmv_avg_ms = 0, c->info.spmv_timed = 0;
             if (info) *info = c->info;
             if (!c->info.converged) {
-                if (c->h_ctl[2] && may_retry) return retry_as_bicgstab();
+                if (c->h_ctl[2] && may_retry) {
+                    total = c->info.iters;
+                    return retry_as_bicgstab();
+                }
                 c->err = c->h_ctl[2] ? "Krylov breakdown (operator not SPD for CG)" : "maxit reached";
                 return FDAPDE_ENOCONV;
             }

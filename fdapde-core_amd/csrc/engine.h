@@ -43,7 +43,8 @@ template <typename T> void adopt(DBuf<T>& b, T*& p, size_t n) {
 inline unsigned grid1(int64_t n, int per = 256) { return (unsigned)((n + per - 1) / per); }
 
 // big host-side index arrays of a device-built space, fetched the first time host code needs them (capi.hip)
-enum { kHostPattern = 1, kHostCells = 2, kHostRefPattern = 4, kHostDofs = 8 };
+// kHostPerm: the permutations (dof_i2e, dof_e2i, cell_i2e) and the boundary flags in internal order (dof_bnd_i); implied by kHostPattern
+enum { kHostPattern = 1, kHostCells = 2, kHostRefPattern = 4, kHostDofs = 8, kHostPerm = 16 };
 int ensure_host(fdapde_ctx* c, int what);
 
 inline unsigned g1(int64_t n, int per = 256) { return (unsigned)((n + per - 1) / per); }
@@ -107,6 +108,10 @@ void preload_assembly();
 void preload_solve();
 void preload_dist();
 void preload_persist();
+// ... and those of the set-up units (13 + 6 + 6 MB of device code: 30 ms to load), on a helper thread started by the first fdapde_ctx_create
+// of a process; preload_wait() joins it (first thing in fdapde_dofs_build / fdapde_topology_build)
+void preload_setup_async(int device);
+void preload_wait();
 
 // ---- single-launch solver (persist_engine.hip) -----------------------------------------------------------------------------------
 // layout of boundary variant v, built on first use (ps.tried / ps.ok tell the outcome)

@@ -194,7 +194,8 @@ int fdapde_solve_parabolic(fdapde_ctx *ctx, const fdapde_options *opt, int32_t n
  * fdapde_lin_compute = ::compute(matrix): `values` = nnz entries aligned with fdapde_pattern_get (any matrix on the FEM
  * pattern; symmetric != 0 allows CG), or NULL to take the assembled matrix `which`.  No Dirichlet reduction is applied.
  * fdapde_lin_solve = ::solve(b): dense right-hand sides, b and x column-major n_dofs x n_rhs.  Several columns are worth handing over
- * together: the columns of a small system run side by side in one launch (6 us instead of 300 us per column for 289 DOFs x 64). */
+ * together: the columns of a small system run side by side in one launch (6 us instead of 300 us per column for 289 DOFs x 64).
+ * x may overlap b (an in-place solve): the call then works from a private copy of the right-hand sides. */
 int fdapde_lin_compute(fdapde_ctx *ctx, int32_t which, const double *values, int32_t symmetric);
 int fdapde_lin_solve(fdapde_ctx *ctx, const fdapde_options *opt, const double *b, int32_t n_rhs, double *x, fdapde_info *info);
 

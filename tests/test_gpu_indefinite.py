@@ -103,6 +103,39 @@ def test_handle_and_stepper_on_an_indefinite_symmetric_operator(env):
     c.close()
 
 
+@pytest.mark.parametrize("ncols", [4, 9])
+def test_batched_columns_of_an_indefinite_handle_fall_back_too(env, ncols):
+    """four or more columns against a system that does not run its columns in one launch take the batched multi-RHS CG
+    (kernels_multirhs.h); its breakdown must lead to the BiCGStab retry like the column-by-column paths -- and an in-place solve (x = b's
+    own storage) must survive the retry."""
+    import ctypes as C
+
+    import scipy.sparse.linalg as spl
+
+    capi, meshgen = env
+    c, nd, bdofs, coords = _setup(capi, meshgen, 2, 24, 1, -150.0)
+    c.init()
+    A = _csr(c, capi, capi.MAT_STIFF, nd)
+    rng = np.random.default_rng(11)
+    B = rng.standard_normal((nd, ncols))
+    ref = spl.spsolve(A.tocsc(), B)
+    c.tune("persist", 0)   # (no single-launch solver: the batched path takes the groups of 8 / 4 columns)
+    c.lin_compute(capi.MAT_STIFF)
+    X, info = c.lin_solve(B, rtol=1e-11)
+    assert info.converged == 1 and info.method_used == capi.SOLVER_BICGSTAB
+    assert np.linalg.norm(X - ref) <= 1e-7 * np.linalg.norm(ref)
+    # in place through the C ABI: x and b the same buffer
+    c.lin_compute(capi.MAT_STIFF)
+    buf = np.asfortranarray(B.copy())
+    opt = capi.Options(method=capi.SOLVER_AUTO, maxit=0, rtol=1e-11, assembly=0, check_every=0, time_spmv=0)
+    out = capi.Info()
+    ptr = buf.ctypes.data_as(C.POINTER(C.c_double))   # (column-major n_dofs x ncols, as the ABI wants it)
+    rc = capi.load().fdapde_lin_solve(c._ctx, C.byref(opt), ptr, ncols, ptr, C.byref(out))
+    assert rc == 0 and out.converged == 1
+    assert np.linalg.norm(buf - ref) <= 1e-7 * np.linalg.norm(ref)
+    c.close()
+
+
 @pytest.mark.parametrize("dim,nx,bmag", [(2, 32, 1000.0), (3, 10, 1000.0)])
 def test_bicgstab_restarts_after_a_breakdown(env, dim, nx, bmag):
     """advection-dominated operators (cell Peclet 15 - 50: under-resolved, but the reference's LU solves what it is given): BiCGStab's

@@ -13,8 +13,12 @@ def find(d, pat):
 
 
 def short(name):
+    # "(anonymous namespace)::" sits in FRONT of a set-up kernel's name: strip it before cutting at the argument list's "("
+    name = name.replace("(anonymous namespace)::", "")
     name = name.split("(")[0]
-    return name.replace("fdapde_hip::", "").replace("void ", "").strip()
+    for ns in ("fdapde_hip::", "fdapde_engine::", "void "):
+        name = name.replace(ns, "")
+    return name.strip()
 
 
 def main(out):
@@ -38,7 +42,7 @@ def main(out):
             acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
         print(f"== {sub} (average per dispatch) ==")
         for k, cs in sorted(acc.items()):
-            if not any(s in k for s in ("k_spmv", "k_cg", "k_assemble", "k_bicg", "k_scale", "k_persist")):
+            if not os.environ.get("SUMMARY_ALL_KERNELS") and not any(s in k for s in ("k_spmv", "k_cg", "k_assemble", "k_bicg", "k_scale", "k_persist")):
                 continue
             print(f"{k[:60]:60s} " + "  ".join(f"{c}={sum(v)/len(v):.4g} (n={len(v)})" for c, v in sorted(cs.items())))
 

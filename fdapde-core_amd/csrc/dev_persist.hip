@@ -182,21 +182,33 @@ __global__ void k_row_lengths_sym(int64_t nd, const int32_t* rowptr, const int32
     }
     len[d] = n;
 }
+// cnt[key] += number of lanes of the wave with flag set, ONE atomic per distinct key of the wave (the keys of neighbouring rows / sorted
+// entries are nearly all equal: an atomic per lane piled 256 workgroup counters with 1.6 M adds -- 1.5 ms a kernel)
+__device__ __forceinline__ void wave_count_by_key(bool flag, int32_t key, int32_t* cnt) {
+    unsigned long long todo = __ballot(flag);
+    const int lane = (int)(threadIdx.x & 63);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int32_t k0 = __shfl(key, leader);
+        const unsigned long long same = __ballot(flag && key == k0);
+        if (lane == leader) atomicAdd(&cnt[k0], (int32_t)__popcll(same));
+        todo &= ~same;
+    }
+}
 // per interior row: does it read another workgroup's rows, and how many such entries; per workgroup: rows that do
 __global__ void k_row_halo(int64_t nd, const int32_t* rowptr, const int32_t* colidx, const uint8_t* keep, const int32_t* wg,
                            uint8_t* halo, int32_t* n_out, int32_t* wg_halo) {
     const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= nd) return;
-    int32_t n = 0;
-    if (keep[d]) {
-        const int32_t g = wg[d];
+    int32_t n = 0, g = -1;
+    if (d < nd && keep[d]) {
+        g = wg[d];
         for (int32_t k = rowptr[d]; k < rowptr[d + 1]; ++k) {
             const int32_t c = colidx[k];
             n += kept_entry(keep, (int32_t)d, c) && wg[c] != g;
         }
-        if (n) atomicAdd(&wg_halo[g], 1);
     }
-    halo[d] = n ? 1 : 0, n_out[d] = n;
+    wave_count_by_key(n != 0, g, wg_halo);
+    if (d < nd) halo[d] = n ? 1 : 0, n_out[d] = n;
 }
 __global__ void k_import_pairs(int64_t nd, const int32_t* rowptr, const int32_t* colidx, const uint8_t* keep, const int32_t* wg,
                                const int32_t* at, uint64_t* key) {
@@ -255,12 +267,20 @@ __global__ void k_mark_exports(int64_t n_imp, const uint64_t* imp_key, uint8_t* 
 __global__ void k_export_keys(int64_t nd, const uint8_t* is_exp, const int32_t* wg, const int32_t* slot_of, uint64_t* key, int32_t* val,
                               int32_t* n_out, int32_t* wg_exp) {
     const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= nd || !is_exp[d]) return;
-    const int32_t g = wg[d];
-    const int32_t o = atomicAdd(n_out, 1);
-    key[o] = ((uint64_t)(uint32_t)g << 32) | (uint32_t)slot_of[d];
-    val[o] = (int32_t)d;
-    atomicAdd(&wg_exp[g], 1);
+    const bool e = d < nd && is_exp[d];
+    const int32_t g = e ? wg[d] : -1;
+    const unsigned long long m = __ballot(e);   // the wave's exports take consecutive places behind ONE add (the list is sorted afterwards)
+    if (m == 0) return;
+    const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)m) - 1;
+    int32_t base = 0;
+    if (lane == leader) base = atomicAdd(n_out, (int32_t)__popcll(m));
+    base = __shfl(base, leader);
+    if (e) {
+        const int32_t o = base + (int32_t)__popcll(m & ((1ull << lane) - 1ull));
+        key[o] = ((uint64_t)(uint32_t)g << 32) | (uint32_t)slot_of[d];
+        val[o] = (int32_t)d;
+    }
+    wave_count_by_key(e, g, wg_exp);
 }
 __global__ void k_board_tables(int64_t n_board, const uint64_t* key_sorted, const int32_t* dof_sorted, uint16_t* exp_slot, int32_t* board_of) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -270,14 +290,14 @@ __global__ void k_board_tables(int64_t n_board, const uint64_t* key_sorted, cons
 }
 __global__ void k_import_board_keys(int64_t n_imp, const uint64_t* imp_key, const int32_t* board_of, uint64_t* key, int32_t* wg_imp) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_imp) return;
-    const uint64_t g = imp_key[i] >> 32;
-    key[i] = (g << 32) | (uint32_t)board_of[imp_key[i] & 0xffffffffu];
-    atomicAdd(&wg_imp[g], 1);
+    const bool in = i < n_imp;
+    const uint64_t g = in ? imp_key[i] >> 32 : 0;
+    if (in) key[i] = (g << 32) | (uint32_t)board_of[imp_key[i] & 0xffffffffu];
+    wave_count_by_key(in, (int32_t)g, wg_imp);
 }
 __global__ void k_count_groups(int64_t n, const uint64_t* key, int32_t* count) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicAdd(&count[key[i] >> 32], 1);
+    wave_count_by_key(i < n, i < n ? (int32_t)(key[i] >> 32) : 0, count);
 }
 __global__ void k_low32(int64_t n, const uint64_t* key, int32_t* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

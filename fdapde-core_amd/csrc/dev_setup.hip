@@ -92,20 +92,28 @@ __global__ void k_invert(int64_t n, const int32_t* p, int32_t* inv) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) inv[p[i]] = (int32_t)i;
 }
-__global__ void k_barycentres(int64_t nc, int64_t nn, int N, int nv, const double* nodes, const int32_t* cells, double* bary) {
+// the nodes' coordinates side by side (NP = 2 or 4 doubles per node, reference order): one 16- / 32-byte gather per vertex afterwards instead
+// of N 8-byte ones from the column-major array
+__global__ void k_pack_nodes(int64_t nn, int N, int NP, const double* nodes, double* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nn) return;
+    for (int d = 0; d < NP; ++d) out[i * NP + d] = d < N ? nodes[(int64_t)d * nn + i] : 0.0;
+}
+__global__ void k_barycentres(int64_t nc, int N, int NP, int nv, const double* npack, const int32_t* cells, double* bary) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nc) return;
-    for (int d = 0; d < N; ++d) {
-        double s = 0;
-        for (int v = 0; v < nv; ++v) s += nodes[(int64_t)d * nn + cells[c * nv + v]];
-        bary[(int64_t)d * nc + c] = s / nv;
+    double s[3] = {0, 0, 0};
+    for (int v = 0; v < nv; ++v) {   // (per coordinate the same sum in the same order as the host builder's)
+        const double* x = npack + (int64_t)cells[c * nv + v] * NP;
+        for (int d = 0; d < N; ++d) s[d] += x[d];
     }
+    for (int d = 0; d < N; ++d) bary[(int64_t)d * nc + c] = s[d] / nv;
 }
-__global__ void k_vcoords(int64_t nn, int N, int NP, const double* nodes, const int32_t* node_i2e, double* out) {
+__global__ void k_vcoords(int64_t nn, int NP, const double* npack, const int32_t* node_i2e, double* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nn) return;
     const int64_t e = node_i2e[i];
-    for (int d = 0; d < NP; ++d) out[i * NP + d] = d < N ? nodes[(int64_t)d * nn + e] : 0.0;
+    for (int d = 0; d < NP; ++d) out[i * NP + d] = npack[e * NP + d];
 }
 __global__ void k_gather_u8(int64_t n, const uint8_t* src, const int32_t* idx, uint8_t* dst) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -116,28 +124,58 @@ __global__ void k_cell_tables(int64_t nc, int nv, int nb, const int32_t* cells, 
     const int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (ci >= nc) return;
     const int64_t ce = cell_i2e[ci];
+    if (dofs == cells && dof_e2i == node_e2i) {   // order 1: the DOF table is the cell list, one numbering
+        for (int v = 0; v < nv; ++v) {
+            const int32_t x = node_e2i[cells[ce * nv + v]];
+            cverts[ci * nv + v] = x, cdofs[ci * nv + v] = x;
+        }
+        return;
+    }
     for (int v = 0; v < nv; ++v) cverts[ci * nv + v] = node_e2i[cells[ce * nv + v]];
     for (int j = 0; j < nb; ++j) cdofs[ci * nb + j] = dof_e2i[dofs[ce * nb + j]];
 }
 
 // ---- row-owner adjacency ---------------------------------------------------------------------------------------------
-__global__ void k_visit_pairs(int64_t n_vis, int nb, const int32_t* cdofs, int32_t* key, int32_t* val, int32_t* count) {
+__global__ void k_visit_pairs(int64_t n_vis, int nb, const int32_t* cdofs, int32_t* key, int32_t* val) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_vis) return;
     const int64_t c = k / nb;
     const int j = (int)(k - c * nb);
     key[k] = cdofs[k];
     val[k] = (int32_t)(c * 16 + j);
-    atomicAdd(&count[cdofs[k]], 1);
+}
+// start of every group of equal keys in a sorted list: start[key] = first position (groups that do not occur keep what start[] held)
+__global__ void k_group_starts(int64_t n, const int32_t* key, int32_t* start) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (i == 0 || key[i] != key[i - 1])) start[key[i]] = (int32_t)i;
 }
 
 // ---- CSR pattern -----------------------------------------------------------------------------------------------------
-__global__ void k_pattern_pairs(int64_t n_vis, int nb, const int32_t* row_of_visit, const int32_t* vis, const int32_t* cdofs, uint64_t* key) {
+// the columns a visit contributes to its row, visits in (row, cell) order: the candidates of row r are positions [vptr[r] nb, vptr[r + 1] nb)
+__global__ void k_pattern_cols(int64_t n_vis, int nb, const int32_t* vis, const int32_t* cdofs, int32_t* col) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_vis) return;
-    const uint64_t row = (uint64_t)(uint32_t)row_of_visit[k];
     const int32_t* cd = cdofs + (int64_t)(vis[k] >> 4) * nb;
-    for (int j = 0; j < nb; ++j) key[k * nb + j] = (row << 32) | (uint32_t)cd[j];
+    for (int j = 0; j < nb; ++j) col[k * nb + j] = cd[j];
+}
+__global__ void k_scaled_offsets(int64_t n, const int32_t* off, int mul, int32_t* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = off[i] * mul;
+}
+// candidates sorted inside every row's segment: an entry is kept where it differs from its predecessor or opens its row's segment
+__global__ void k_unique_in_rows(int64_t n, int nb, const int32_t* col_sorted, const int32_t* row_of_visit, const int32_t* vptr, int32_t* flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t r = row_of_visit[i / nb];
+    flag[i] = (i == (int64_t)vptr[r] * nb || col_sorted[i] != col_sorted[i - 1]) ? 1 : 0;
+}
+__global__ void k_compact_rows(int64_t n, int nb, const int32_t* col_sorted, const int32_t* row_of_visit, const int32_t* vptr, const int32_t* flag,
+                               const int32_t* pos, int32_t* colidx, int32_t* rowptr) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    colidx[pos[i]] = col_sorted[i];
+    const int32_t r = row_of_visit[i / nb];
+    if (i == (int64_t)vptr[r] * nb) rowptr[r] = pos[i];
 }
 __global__ void k_unique_flags(int64_t n, const uint64_t* key, int32_t* flag) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -163,11 +201,13 @@ __global__ void k_diag(int64_t nd, const int32_t* rowptr, const int32_t* colidx,
 }
 
 // ---- reference-numbering pattern ---------------------------------------------------------------------------------------
-__global__ void k_ref_pairs(int64_t nd, const int32_t* rowptr, const int32_t* colidx, const int32_t* dof_i2e, uint64_t* key, int32_t* val) {
+// the entries of internal row r, as (reference column, internal slot) pairs at the place of reference row dof_i2e[r] (sorted per row afterwards)
+__global__ void k_ref_cols(int64_t nd, const int32_t* rowptr, const int32_t* colidx, const int32_t* dof_i2e, const int32_t* rowptr_e, int32_t* key,
+                           int32_t* val) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nd) return;
-    const uint64_t re = (uint64_t)(uint32_t)dof_i2e[r];
-    for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k) key[k] = (re << 32) | (uint32_t)dof_i2e[colidx[k]], val[k] = k;
+    int32_t o = rowptr_e[dof_i2e[r]];
+    for (int32_t k = rowptr[r]; k < rowptr[r + 1]; ++k, ++o) key[o] = dof_i2e[colidx[k]], val[o] = k;
 }
 __global__ void k_ref_lengths(int64_t nd, const int32_t* rowptr, const int32_t* dof_e2i, int32_t* len_e) {
     const int64_t re = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -175,11 +215,9 @@ __global__ void k_ref_lengths(int64_t nd, const int32_t* rowptr, const int32_t* 
     const int64_t ri = dof_e2i[re];
     len_e[re] = rowptr[ri + 1] - rowptr[ri];
 }
-__global__ void k_ref_tables(int64_t nnz, const uint64_t* key_sorted, const int32_t* val_sorted, int32_t* colidx_e, int32_t* slot_i2e) {
+__global__ void k_ref_slots(int64_t nnz, const int32_t* val_sorted, int32_t* slot_i2e) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nnz) return;
-    colidx_e[i] = (int32_t)(key_sorted[i] & 0xffffffffu);
-    slot_i2e[val_sorted[i]] = (int32_t)i;
+    if (i < nnz) slot_i2e[val_sorted[i]] = (int32_t)i;
 }
 
 // ---- sliced-ELL adjacency --------------------------------------------------------------------------------------------
@@ -256,32 +294,58 @@ __global__ void k_fill_adjacency(int64_t nd, int nb, int nbw, const int64_t* sl_
 }
 
 // ---- block tables ----------------------------------------------------------------------------------------------------
-__global__ void k_block_cell_pairs(int64_t n_vis, const int32_t* row_of_visit, const int32_t* vis, uint64_t* key) {
+// visits are in row order, so the visits of assembly block b are positions [vptr[b kAsmBlock], vptr[(b + 1) kAsmBlock)): segment offsets
+__global__ void k_block_visit_offsets(int64_t n_blk, int64_t nd, const int32_t* vptr, int32_t* off) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b <= n_blk) off[b] = vptr[min(nd, b * kAsmBlock)];
+}
+__global__ void k_visit_cells(int64_t n_vis, const int32_t* vis, int32_t* cell) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n_vis) key[k] = ((uint64_t)(uint32_t)(row_of_visit[k] / kAsmBlock) << 32) | (uint32_t)(vis[k] >> 4);
+    if (k < n_vis) cell[k] = vis[k] >> 4;
 }
-__global__ void k_block_node_pairs(int64_t n_bc, int nv, const uint64_t* bc_key /* unique (block, cell) keys */, const int32_t* cverts, uint64_t* key) {
+// ids sorted inside the segments of the blocks: kept where an id differs from its predecessor or opens its block's segment.
+// blk_of_group[i / group] = block of position i (group = 1: per visit, by its row; group = nv: per block-cell)
+__global__ void k_unique_in_blocks(int64_t n, int group, int div, const int32_t* id_sorted, const int32_t* blk_src, const int32_t* seg_off, int32_t* flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t b = blk_src[i / group] / div;
+    flag[i] = (i == (int64_t)seg_off[b] || id_sorted[i] != id_sorted[i - 1]) ? 1 : 0;
+}
+__global__ void k_compact_blocks(int64_t n, int group, int div, const int32_t* id_sorted, const int32_t* blk_src, const int32_t* seg_off, const int32_t* flag,
+                                 const int32_t* pos, int32_t* member, int32_t* member_blk, int64_t* group_off) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    const int32_t b = blk_src[i / group] / div;
+    member[pos[i]] = id_sorted[i];
+    if (member_blk) member_blk[pos[i]] = b;
+    if (i == (int64_t)seg_off[b]) group_off[b] = (int64_t)pos[i];
+}
+__global__ void k_block_cell_nodes(int64_t n_bc, int nv, const int32_t* bc_cell, const int32_t* cverts, int32_t* node) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_bc) return;
-    const uint64_t blk = bc_key[i] >> 32;
-    const int64_t cell = (int64_t)(bc_key[i] & 0xffffffffu);
-    for (int v = 0; v < nv; ++v) key[i * nv + v] = (blk << 32) | (uint32_t)cverts[cell * nv + v];
+    const int64_t cell = bc_cell[i];
+    for (int v = 0; v < nv; ++v) node[i * nv + v] = cverts[cell * nv + v];
 }
-__global__ void k_compact_keys(int64_t n, const uint64_t* key, const int32_t* flag, const int32_t* pos, uint64_t* out) {
+__global__ void k_scaled_offsets64(int64_t n, const int64_t* off, int mul, int32_t* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && flag[i]) out[pos[i]] = key[i];
+    if (i < n) out[i] = (int32_t)(off[i] * mul);
 }
-__global__ void k_block_verts(int64_t n_bc, int nv, const uint64_t* bc_key, const int32_t* cverts, const int64_t* bn_off, const int32_t* bn_node,
-                              uint16_t* bc_vert) {
+__global__ void k_block_verts(int64_t n_bc, int nv, const int32_t* bc_blk, const int32_t* bc_cell, const int32_t* cverts, const int64_t* bn_off,
+                              const int32_t* bn_node, uint16_t* bc_vert) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_bc) return;
-    const int64_t b = (int64_t)(bc_key[i] >> 32), cell = (int64_t)(bc_key[i] & 0xffffffffu);
+    const int64_t b = bc_blk[i], cell = bc_cell[i];
     for (int v = 0; v < 4; ++v)
         bc_vert[i * 4 + v] = v < nv ? (uint16_t)(lower_bound_i64(bn_node, bn_off[b], bn_off[b + 1], cverts[cell * nv + v]) - bn_off[b]) : (uint16_t)0;
 }
-template <typename T> __global__ void k_adjacent_diff_max(int64_t n, const T* off, int32_t* out_max) {
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+template <typename T> __global__ void k_adjacent_diff_max(int64_t n, const T* off, int32_t* out_max) {   // (one atomic per wave)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicMax(out_max, (int32_t)(off[i + 1] - off[i]));
+    const int32_t v = wave_max_i32(i < n ? (int32_t)(off[i + 1] - off[i]) : INT32_MIN);
+    if ((threadIdx.x & 63) == 0 && v != INT32_MIN) atomicMax(out_max, v);
 }
 __global__ void k_block_nnz_max(int64_t n_blk, int64_t nd, const int32_t* rowptr, int32_t* out_max) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -289,9 +353,10 @@ __global__ void k_block_nnz_max(int64_t n_blk, int64_t nd, const int32_t* rowptr
     const int64_t r1 = min(nd, (b + 1) * kAsmBlock);
     atomicMax(out_max, rowptr[r1] - rowptr[b * kAsmBlock]);
 }
-__global__ void k_min_i32(int64_t n, const int32_t* v, int32_t* out_min) {
+__global__ void k_min_i32(int64_t n, const int32_t* v, int32_t* out_min) {   // (one atomic per wave)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicMin(out_min, v[i]);
+    const int32_t m = -wave_max_i32(i < n ? -v[i] : INT32_MIN + 1);
+    if ((threadIdx.x & 63) == 0) atomicMin(out_min, m);
 }
 
 struct Scratch {   // one growing scratch allocation for the device primitives
@@ -321,6 +386,25 @@ template <typename K> int sort_keys(Scratch& sc, K* k_in, K* k_out, int64_t n, i
     DS_CHK(hipcub::DeviceRadixSort::SortKeys(nullptr, need, k_in, k_out, (int)n, 0, end_bit, st));
     DS_CHK(sc.need(need));
     DS_CHK(hipcub::DeviceRadixSort::SortKeys(sc.p, need, k_in, k_out, (int)n, 0, end_bit, st));
+    return FDAPDE_OK;
+}
+// keys (with values) sorted inside the segments [off[s], off[s + 1]) -- rows of a matrix, blocks of rows: 32-bit keys and one pass over
+// short segments where the same order by a global sort of (segment, key) pairs takes 64-bit keys and 7 passes
+template <typename K> int seg_sort_keys(Scratch& sc, const K* k_in, K* k_out, int64_t n, int64_t n_seg, const int32_t* off, int end_bit, hipStream_t st,
+                                        std::string& err) {
+    size_t need = 0;
+    DS_CHK(hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, need, k_in, k_out, (int)n, (int)n_seg, off, off + 1, 0, end_bit, st));
+    DS_CHK(sc.need(need));
+    DS_CHK(hipcub::DeviceSegmentedRadixSort::SortKeys(sc.p, need, k_in, k_out, (int)n, (int)n_seg, off, off + 1, 0, end_bit, st));
+    return FDAPDE_OK;
+}
+template <typename K, typename V>
+int seg_sort_pairs(Scratch& sc, const K* k_in, K* k_out, const V* v_in, V* v_out, int64_t n, int64_t n_seg, const int32_t* off, int end_bit,
+                   hipStream_t st, std::string& err) {
+    size_t need = 0;
+    DS_CHK(hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, need, k_in, k_out, v_in, v_out, (int)n, (int)n_seg, off, off + 1, 0, end_bit, st));
+    DS_CHK(sc.need(need));
+    DS_CHK(hipcub::DeviceSegmentedRadixSort::SortPairs(sc.p, need, k_in, k_out, v_in, v_out, (int)n, (int)n_seg, off, off + 1, 0, end_bit, st));
     return FDAPDE_OK;
 }
 template <typename In, typename Out> int exclusive_sum(Scratch& sc, In* in, Out* out, int64_t n, hipStream_t st, std::string& err) {
@@ -557,45 +641,49 @@ int dev_build_space(HostSpace& hs, const double* d_nodes, const int32_t* d_cells
         hipLaunchKernelGGL(k_invert, dim3(grid_of(nd)), dim3(256), 0, st, nd, s.dof_i2e, s.dof_e2i);
     }
     DS_ALLOC(s.cell_i2e, int32_t, nc);
+    const int NP = N == 2 ? 2 : 4;
+    Tmp<double> npack;
+    DS_CHK(npack.alloc((size_t)nn * NP));
+    hipLaunchKernelGGL(k_pack_nodes, dim3(grid_of(nn)), dim3(256), 0, st, nn, N, NP, d_nodes, npack.p);
     {
         Tmp<double> bary;
         DS_CHK(bary.alloc((size_t)nc * N));
-        hipLaunchKernelGGL(k_barycentres, dim3(grid_of(nc)), dim3(256), 0, st, nc, nn, N, nv, d_nodes, d_cells, bary.p);
+        hipLaunchKernelGGL(k_barycentres, dim3(grid_of(nc)), dim3(256), 0, st, nc, N, NP, nv, npack.p, d_cells, bary.p);
         if (int rc = morton_order(sc, N, nc, bary.p, order == 1 ? (N == 3 ? 11 : 16) : 0, st, s.cell_i2e, err)) return rc;
     }
-    const int NP = N == 2 ? 2 : 4;
     DS_ALLOC(s.vcoords, double, nn * NP);
     DS_ALLOC(s.bnd, uint8_t, nd);
     DS_ALLOC(s.cverts, int32_t, nc * nv);
     DS_ALLOC(s.cdofs, int32_t, nc * nb);
-    hipLaunchKernelGGL(k_vcoords, dim3(grid_of(nn)), dim3(256), 0, st, nn, N, NP, d_nodes, s.node_i2e, s.vcoords);
+    hipLaunchKernelGGL(k_vcoords, dim3(grid_of(nn)), dim3(256), 0, st, nn, NP, npack.p, s.node_i2e, s.vcoords);
     hipLaunchKernelGGL(k_gather_u8, dim3(grid_of(nd)), dim3(256), 0, st, nd, d_dof_bnd, s.dof_i2e, s.bnd);
-    hipLaunchKernelGGL(k_cell_tables, dim3(grid_of(nc)), dim3(256), 0, st, nc, nv, nb, d_cells, d_dofs, s.cell_i2e, node_e2i.p, s.dof_e2i, s.cverts,
-                       s.cdofs);
+    hipLaunchKernelGGL(k_cell_tables, dim3(grid_of(nc)), dim3(256), 0, st, nc, nv, nb, d_cells, d_dofs, s.cell_i2e, node_e2i.p,
+                       order == 1 ? (const int32_t*)node_e2i.p : (const int32_t*)s.dof_e2i, s.cverts, s.cdofs);
     phase("locality numbering");
 
     // ---- row-owner adjacency: visits of a DOF = (cell * 16 + local index), cells ascending (stable sort by DOF)
-    Tmp<int32_t> vkey_a, vkey, vval_a, vis, vcount, vptr;
+    Tmp<int32_t> vkey_a, vkey, vval_a, vis, vptr;
     DS_CHK(vkey_a.alloc((size_t)n_vis));
     DS_CHK(vkey.alloc((size_t)n_vis));
     DS_CHK(vval_a.alloc((size_t)n_vis));
     DS_CHK(vis.alloc((size_t)n_vis));
-    DS_CHK(vcount.alloc((size_t)nd + 1));
     DS_CHK(vptr.alloc((size_t)nd + 1));
-    DS_CHK(hipMemsetAsync(vcount.p, 0, sizeof(int32_t) * ((size_t)nd + 1), st));
-    hipLaunchKernelGGL(k_visit_pairs, dim3(grid_of(n_vis)), dim3(256), 0, st, n_vis, nb, s.cdofs, vkey_a.p, vval_a.p, vcount.p);
+    DS_CHK(hipMemsetAsync(vptr.p, 0xff, sizeof(int32_t) * (size_t)nd, st));   // (-1: a row without a visit stays so)
+    const int32_t h_nvis = (int32_t)n_vis;
+    DS_CHK(hipMemcpyAsync(vptr.p + nd, &h_nvis, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_visit_pairs, dim3(grid_of(n_vis)), dim3(256), 0, st, n_vis, nb, s.cdofs, vkey_a.p, vval_a.p);
     if (int rc = sort_pairs(sc, vkey_a.p, vkey.p, vval_a.p, vis.p, n_vis, bits_of(nd), st, err)) return rc;
-    if (int rc = exclusive_sum(sc, vcount.p, vptr.p, nd + 1, st, err)) return rc;
+    hipLaunchKernelGGL(k_group_starts, dim3(grid_of(n_vis)), dim3(256), 0, st, n_vis, vkey.p, vptr.p);   // the rows' visit lists start where the sorted keys change
     {   // a node no cell references has an empty matrix row: the reference's LU fails on such a mesh
         Tmp<int32_t> mn;
         DS_CHK(mn.alloc(1));
         const int32_t big = INT32_MAX;
         DS_CHK(hipMemcpyAsync(mn.p, &big, sizeof big, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_min_i32, dim3(grid_of(nd)), dim3(256), 0, st, nd, vcount.p, mn.p);
+        hipLaunchKernelGGL(k_min_i32, dim3(grid_of(nd)), dim3(256), 0, st, nd, vptr.p, mn.p);
         int32_t h = 0;
         DS_CHK(hipMemcpyAsync(&h, mn.p, sizeof h, hipMemcpyDeviceToHost, st));
         DS_CHK(hipStreamSynchronize(st));
-        if (h < 1) {
+        if (h < 0) {
             err = "a node is not referenced by any cell: its DOF has an empty matrix row (the reference's LU fails on such a mesh)";
             return FDAPDE_EINVAL;
         }
@@ -606,18 +694,22 @@ int dev_build_space(HostSpace& hs, const double* d_nodes, const int32_t* d_cells
     // ---- internal CSR pattern: sorted union of the DOFs of the visiting cells
     int64_t nnz = 0;
     {
+        // the candidates of a row (the DOFs of its visiting cells) lie together -- the visits are in row order: sorted inside every row's
+        // segment (32-bit keys, short segments), duplicates dropped, compacted
         const int64_t n_pairs = n_vis * nb;
-        Tmp<uint64_t> pk_a, pk;
-        Tmp<int32_t> flag, pos;
+        Tmp<int32_t> pk_a, pk, seg, flag, pos;
         DS_CHK(pk_a.alloc((size_t)n_pairs));
         DS_CHK(pk.alloc((size_t)n_pairs));
-        hipLaunchKernelGGL(k_pattern_pairs, dim3(grid_of(n_vis)), dim3(256), 0, st, n_vis, nb, vkey.p, vis.p, s.cdofs, pk_a.p);
-        if (int rc = sort_keys(sc, pk_a.p, pk.p, n_pairs, 32 + bits_of(nd), st, err)) return rc;
+        DS_CHK(seg.alloc((size_t)nd + 1));
+        hipLaunchKernelGGL(k_pattern_cols, dim3(grid_of(n_vis)), dim3(256), 0, st, n_vis, nb, vis.p, s.cdofs, pk_a.p);
+        hipLaunchKernelGGL(k_scaled_offsets, dim3(grid_of(nd + 1)), dim3(256), 0, st, nd + 1, vptr.p, nb, seg.p);
+        if (int rc = seg_sort_keys(sc, pk_a.p, pk.p, n_pairs, nd, seg.p, bits_of(nd), st, err)) return rc;
+        DS_CHK(hipStreamSynchronize(st));
         pk_a.reset();
         DS_CHK(flag.alloc((size_t)n_pairs + 1));
         DS_CHK(pos.alloc((size_t)n_pairs + 1));
         DS_CHK(hipMemsetAsync(flag.p + n_pairs, 0, sizeof(int32_t), st));
-        hipLaunchKernelGGL(k_unique_flags, dim3(grid_of(n_pairs)), dim3(256), 0, st, n_pairs, pk.p, flag.p);
+        hipLaunchKernelGGL(k_unique_in_rows, dim3(grid_of(n_pairs)), dim3(256), 0, st, n_pairs, nb, pk.p, vkey.p, vptr.p, flag.p);
         if (int rc = exclusive_sum(sc, flag.p, pos.p, n_pairs + 1, st, err)) return rc;
         int32_t h_nnz = 0;
         DS_CHK(hipMemcpyAsync(&h_nnz, pos.p + n_pairs, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -626,15 +718,15 @@ int dev_build_space(HostSpace& hs, const double* d_nodes, const int32_t* d_cells
         DS_ALLOC(s.rowptr, int32_t, nd + 1);
         DS_ALLOC(s.colidx, int32_t, nnz + 2);   // + 2 zeros: the SpMV's pair loads may touch one entry past a row's end
         DS_CHK(hipMemsetAsync(s.colidx + nnz, 0, 2 * sizeof(int32_t), st));
-        hipLaunchKernelGGL(k_compact_groups<int32_t>, dim3(grid_of(n_pairs)), dim3(256), 0, st, n_pairs, pk.p, flag.p, pos.p, s.colidx, s.rowptr);
+        hipLaunchKernelGGL(k_compact_rows, dim3(grid_of(n_pairs)), dim3(256), 0, st, n_pairs, nb, pk.p, vkey.p, vptr.p, flag.p, pos.p, s.colidx, s.rowptr);
         DS_CHK(hipMemcpyAsync(s.rowptr + nd, &h_nnz, sizeof(int32_t), hipMemcpyHostToDevice, st));
         DS_CHK(hipStreamSynchronize(st));
     }
     DS_ALLOC(s.diag, int32_t, nd);
     hipLaunchKernelGGL(k_diag, dim3(grid_of(nd)), dim3(256), 0, st, nd, s.rowptr, s.colidx, s.diag);
-    Tmp<int32_t> maxes;   // [0] max row, [1] max block nnz, [2] max block cells, [3] max block nodes
-    DS_CHK(maxes.alloc(4));
-    DS_CHK(hipMemsetAsync(maxes.p, 0, 4 * sizeof(int32_t), st));
+    Tmp<int32_t> maxes;   // [0] max row, [1] max block nnz, [2] max block cells, [3] max block nodes, [4] widest adjacency slice
+    DS_CHK(maxes.alloc(5));
+    DS_CHK(hipMemsetAsync(maxes.p, 0, 5 * sizeof(int32_t), st));
     hipLaunchKernelGGL(k_adjacent_diff_max<int32_t>, dim3(grid_of(nd)), dim3(256), 0, st, nd, s.rowptr, maxes.p);
     phase("internal CSR pattern");
 
@@ -643,19 +735,19 @@ int dev_build_space(HostSpace& hs, const double* d_nodes, const int32_t* d_cells
     DS_ALLOC(s.colidx_e, int32_t, nnz);
     DS_ALLOC(s.slot_i2e, int32_t, nnz);
     {
-        Tmp<uint64_t> rk_a, rk;
-        Tmp<int32_t> rv_a, rv, len_e;
+        // reference row re = internal row dof_e2i[re]: its entries are written at the row's place in the reference pattern with their reference
+        // columns and sorted there (segments = rows); the sorted positions of the internal slots are the slot map
+        Tmp<int32_t> rk_a, rv_a, rv, len_e;
         DS_CHK(rk_a.alloc((size_t)nnz));
-        DS_CHK(rk.alloc((size_t)nnz));
         DS_CHK(rv_a.alloc((size_t)nnz));
         DS_CHK(rv.alloc((size_t)nnz));
         DS_CHK(len_e.alloc((size_t)nd + 1));
-        hipLaunchKernelGGL(k_ref_pairs, dim3(grid_of(nd)), dim3(256), 0, st, nd, s.rowptr, s.colidx, s.dof_i2e, rk_a.p, rv_a.p);
-        if (int rc = sort_pairs(sc, rk_a.p, rk.p, rv_a.p, rv.p, nnz, 32 + bits_of(nd), st, err)) return rc;
-        hipLaunchKernelGGL(k_ref_tables, dim3(grid_of(nnz)), dim3(256), 0, st, nnz, rk.p, rv.p, s.colidx_e, s.slot_i2e);
         DS_CHK(hipMemsetAsync(len_e.p + nd, 0, sizeof(int32_t), st));
         hipLaunchKernelGGL(k_ref_lengths, dim3(grid_of(nd)), dim3(256), 0, st, nd, s.rowptr, s.dof_e2i, len_e.p);
         if (int rc = exclusive_sum(sc, len_e.p, s.rowptr_e, nd + 1, st, err)) return rc;
+        hipLaunchKernelGGL(k_ref_cols, dim3(grid_of(nd)), dim3(256), 0, st, nd, s.rowptr, s.colidx, s.dof_i2e, s.rowptr_e, rk_a.p, rv_a.p);
+        if (int rc = seg_sort_pairs(sc, rk_a.p, s.colidx_e, rv_a.p, rv.p, nnz, nd, s.rowptr_e, bits_of(nd), st, err)) return rc;
+        hipLaunchKernelGGL(k_ref_slots, dim3(grid_of(nnz)), dim3(256), 0, st, nnz, rv.p, s.slot_i2e);
         DS_CHK(hipStreamSynchronize(st));
     }
     phase("reference pattern + slot map");
@@ -663,18 +755,19 @@ int dev_build_space(HostSpace& hs, const double* d_nodes, const int32_t* d_cells
     // ---- block tables: cells visited by the rows of an assembly block, and their vertices (both ascending)
     const int64_t n_blk = (nd + kAsmBlock - 1) / kAsmBlock, n_slices = (nd + kSlice - 1) / kSlice;
     s.n_blk = n_blk, s.n_slices = n_slices;
-    Tmp<uint64_t> bc_key;   // unique (block, cell) keys in order
+    Tmp<int32_t> bc_blk;   // block of every block-cell
     {
-        Tmp<uint64_t> k_a, k_s;
-        Tmp<int32_t> flag, pos;
+        Tmp<int32_t> k_a, k_s, seg, flag, pos;
         DS_CHK(k_a.alloc((size_t)n_vis));
         DS_CHK(k_s.alloc((size_t)n_vis));
+        DS_CHK(seg.alloc((size_t)n_blk + 1));
         DS_CHK(flag.alloc((size_t)n_vis + 1));
         DS_CHK(pos.alloc((size_t)n_vis + 1));
-        hipLaunchKernelGGL(k_block_cell_pairs, dim3(grid_of(n_vis)), dim3(256), 0, st, n_vis, vkey.p, vis.p, k_a.p);
-        if (int rc = sort_keys(sc, k_a.p, k_s.p, n_vis, 32 + bits_of(n_blk), st, err)) return rc;
+        hipLaunchKernelGGL(k_visit_cells, dim3(grid_of(n_vis)), dim3(256), 0, st, n_vis, vis.p, k_a.p);
+        hipLaunchKernelGGL(k_block_visit_offsets, dim3(grid_of(n_blk + 1)), dim3(256), 0, st, n_blk, nd, vptr.p, seg.p);
+        if (int rc = seg_sort_keys(sc, k_a.p, k_s.p, n_vis, n_blk, seg.p, bits_of(nc), st, err)) return rc;
         DS_CHK(hipMemsetAsync(flag.p + n_vis, 0, sizeof(int32_t), st));
-        hipLaunchKernelGGL(k_unique_flags, dim3(grid_of(n_vis)), dim3(256), 0, st, n_vis, k_s.p, flag.p);
+        hipLaunchKernelGGL(k_unique_in_blocks, dim3(grid_of(n_vis)), dim3(256), 0, st, n_vis, 1, kAsmBlock, k_s.p, vkey.p, seg.p, flag.p);
         if (int rc = exclusive_sum(sc, flag.p, pos.p, n_vis + 1, st, err)) return rc;
         int32_t h_n = 0;
         DS_CHK(hipMemcpyAsync(&h_n, pos.p + n_vis, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -682,9 +775,9 @@ int dev_build_space(HostSpace& hs, const double* d_nodes, const int32_t* d_cells
         s.n_bc = h_n;
         DS_ALLOC(s.bc_cell, int32_t, s.n_bc);
         DS_ALLOC(s.bc_off, int64_t, n_blk + 1);
-        DS_CHK(bc_key.alloc((size_t)s.n_bc));
-        hipLaunchKernelGGL(k_compact_groups<int64_t>, dim3(grid_of(n_vis)), dim3(256), 0, st, n_vis, k_s.p, flag.p, pos.p, s.bc_cell, s.bc_off);
-        hipLaunchKernelGGL(k_compact_keys, dim3(grid_of(n_vis)), dim3(256), 0, st, n_vis, k_s.p, flag.p, pos.p, bc_key.p);
+        DS_CHK(bc_blk.alloc((size_t)s.n_bc));
+        hipLaunchKernelGGL(k_compact_blocks, dim3(grid_of(n_vis)), dim3(256), 0, st, n_vis, 1, kAsmBlock, k_s.p, vkey.p, seg.p, flag.p, pos.p, s.bc_cell, bc_blk.p,
+                           s.bc_off);
         const int64_t h_nbc = s.n_bc;
         DS_CHK(hipMemcpyAsync(s.bc_off + n_blk, &h_nbc, sizeof(int64_t), hipMemcpyHostToDevice, st));
         DS_CHK(hipStreamSynchronize(st));
@@ -695,16 +788,17 @@ int dev_build_space(HostSpace& hs, const double* d_nodes, const int32_t* d_cells
             err = "too many block-cell vertices for the device set-up";
             return FDAPDE_EUNSUPPORTED;
         }
-        Tmp<uint64_t> k_a, k_s;
-        Tmp<int32_t> flag, pos;
+        Tmp<int32_t> k_a, k_s, seg, flag, pos;
         DS_CHK(k_a.alloc((size_t)n2));
         DS_CHK(k_s.alloc((size_t)n2));
+        DS_CHK(seg.alloc((size_t)n_blk + 1));
         DS_CHK(flag.alloc((size_t)n2 + 1));
         DS_CHK(pos.alloc((size_t)n2 + 1));
-        hipLaunchKernelGGL(k_block_node_pairs, dim3(grid_of(s.n_bc)), dim3(256), 0, st, s.n_bc, nv, bc_key.p, s.cverts, k_a.p);
-        if (int rc = sort_keys(sc, k_a.p, k_s.p, n2, 32 + bits_of(n_blk), st, err)) return rc;
+        hipLaunchKernelGGL(k_block_cell_nodes, dim3(grid_of(s.n_bc)), dim3(256), 0, st, s.n_bc, nv, s.bc_cell, s.cverts, k_a.p);
+        hipLaunchKernelGGL(k_scaled_offsets64, dim3(grid_of(n_blk + 1)), dim3(256), 0, st, n_blk + 1, s.bc_off, nv, seg.p);
+        if (int rc = seg_sort_keys(sc, k_a.p, k_s.p, n2, n_blk, seg.p, bits_of(nn), st, err)) return rc;
         DS_CHK(hipMemsetAsync(flag.p + n2, 0, sizeof(int32_t), st));
-        hipLaunchKernelGGL(k_unique_flags, dim3(grid_of(n2)), dim3(256), 0, st, n2, k_s.p, flag.p);
+        hipLaunchKernelGGL(k_unique_in_blocks, dim3(grid_of(n2)), dim3(256), 0, st, n2, nv, 1, k_s.p, bc_blk.p, seg.p, flag.p);
         if (int rc = exclusive_sum(sc, flag.p, pos.p, n2 + 1, st, err)) return rc;
         int32_t h_n = 0;
         DS_CHK(hipMemcpyAsync(&h_n, pos.p + n2, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -712,11 +806,12 @@ int dev_build_space(HostSpace& hs, const double* d_nodes, const int32_t* d_cells
         s.n_bn = h_n;
         DS_ALLOC(s.bn_node, int32_t, s.n_bn);
         DS_ALLOC(s.bn_off, int64_t, n_blk + 1);
-        hipLaunchKernelGGL(k_compact_groups<int64_t>, dim3(grid_of(n2)), dim3(256), 0, st, n2, k_s.p, flag.p, pos.p, s.bn_node, s.bn_off);
+        hipLaunchKernelGGL(k_compact_blocks, dim3(grid_of(n2)), dim3(256), 0, st, n2, nv, 1, k_s.p, bc_blk.p, seg.p, flag.p, pos.p, s.bn_node, (int32_t*)nullptr,
+                           s.bn_off);
         const int64_t h_nbn = s.n_bn;
         DS_CHK(hipMemcpyAsync(s.bn_off + n_blk, &h_nbn, sizeof(int64_t), hipMemcpyHostToDevice, st));
         DS_ALLOC(s.bc_vert, uint16_t, s.n_bc * 4);
-        hipLaunchKernelGGL(k_block_verts, dim3(grid_of(s.n_bc)), dim3(256), 0, st, s.n_bc, nv, bc_key.p, s.cverts, s.bn_off, s.bn_node, s.bc_vert);
+        hipLaunchKernelGGL(k_block_verts, dim3(grid_of(s.n_bc)), dim3(256), 0, st, s.n_bc, nv, bc_blk.p, s.bc_cell, s.cverts, s.bn_off, s.bn_node, s.bc_vert);
         hipLaunchKernelGGL(k_block_nnz_max, dim3(grid_of(n_blk)), dim3(256), 0, st, n_blk, nd, s.rowptr, maxes.p + 1);
         hipLaunchKernelGGL(k_adjacent_diff_max<int64_t>, dim3(grid_of(n_blk)), dim3(256), 0, st, n_blk, s.bc_off, maxes.p + 2);
         hipLaunchKernelGGL(k_adjacent_diff_max<int64_t>, dim3(grid_of(n_blk)), dim3(256), 0, st, n_blk, s.bn_off, maxes.p + 3);
@@ -759,14 +854,23 @@ int dev_build_space(HostSpace& hs, const double* d_nodes, const int32_t* d_cells
     phase("sliced-ELL adjacency + slots");
 
     // ---- what the host side of the library keeps: permutations, boundary flags, row pointers, sizes
-    int32_t h_max[4] = {0, 0, 0, 0};
+    int32_t h_max[5] = {0, 0, 0, 0, 0};
+    hipLaunchKernelGGL(k_adjacent_diff_max<int64_t>, dim3(grid_of(n_slices)), dim3(256), 0, st, n_slices, s.sl_off, maxes.p + 4);
     DS_CHK(hipMemcpyAsync(h_max, maxes.p, sizeof h_max, hipMemcpyDeviceToHost, st));
     // (the permutations and the boundary flags in internal order stay on the device until host code asks: ensure_host, kHostPerm)
     hs.dof_i2e.clear(), hs.dof_e2i.clear(), hs.cell_i2e.clear(), hs.dof_bnd_i.clear();
-    hs.rowptr_i.resize((size_t)nd + 1), hs.sl_off.resize((size_t)n_slices + 1);
-    DS_CHK(hipMemcpyAsync(hs.rowptr_i.data(), s.rowptr, sizeof(int32_t) * ((size_t)nd + 1), hipMemcpyDeviceToHost, st));
-    DS_CHK(hipMemcpyAsync(hs.sl_off.data(), s.sl_off, sizeof(int64_t) * ((size_t)n_slices + 1), hipMemcpyDeviceToHost, st));
+    // the row-block list of the CSR-stream SpMV (FDAPDE_SPMV=stream, a diagnostic variant) is host index work on the row pointers: only then
+    // are they fetched here; otherwise they come with the pattern's host mirror (ensure_host, kHostPattern)
+    const char* spmv_env = std::getenv("FDAPDE_SPMV");
+    const bool want_rb = spmv_env && std::string(spmv_env) == "stream";
+    hs.rowptr_i.clear(), hs.sl_off.clear();   // (sl_off: n_slices and the widest slice are all host code reads of it)
+    hs.n_slices = n_slices;
+    if (want_rb) {
+        hs.rowptr_i.resize((size_t)nd + 1);
+        DS_CHK(hipMemcpyAsync(hs.rowptr_i.data(), s.rowptr, sizeof(int32_t) * ((size_t)nd + 1), hipMemcpyDeviceToHost, st));
+    }
     DS_CHK(hipStreamSynchronize(st));
+    hs.max_slice_width = h_max[4];
     hs.nnz = nnz, hs.max_row = h_max[0], hs.max_blk_nnz = h_max[1], hs.max_blk_cells = h_max[2], hs.max_blk_nodes = h_max[3], hs.nbw = nbw;
     if (hs.max_row > 65535 || hs.max_row > kSpmvNnz) {
         err = "row too long for the uint16 slot map / SpMV row block";
@@ -778,7 +882,8 @@ int dev_build_space(HostSpace& hs, const double* d_nodes, const int32_t* d_cells
     }
     hs.rb_row.clear();
     hs.rb_row.push_back(0);
-    for (int64_t r = 0; r < nd;) {   // SpMV row blocks: consecutive rows with at most kSpmvNnz nonzeros
+    if (!want_rb) hs.rb_row.push_back((int32_t)nd);   // (never read by the default SpMV)
+    for (int64_t r = 0; want_rb && r < nd;) {   // SpMV row blocks: consecutive rows with at most kSpmvNnz nonzeros
         int64_t e = r;
         const int32_t base = hs.rowptr_i[(size_t)r];
         while (e < nd && hs.rowptr_i[(size_t)e + 1] - base <= kSpmvNnz && e - r < 1024) ++e;

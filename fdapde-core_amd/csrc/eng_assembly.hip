@@ -169,9 +169,7 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
             const bool want_mass2 = a.vals2 != nullptr;
             if (c->asm_items && c->lane_row.p != nullptr && opk != 0 && lds_items + 10 * 1024 <= (size_t)160 * 1024 && (!want_mass2 || opk == 1 || opk == 3 || opk == 4 || opk == 5)) {
                 if (c->asm_max_visits < 0) {   // longest visit list of the space (once per space: fdapde_dofs_build resets it)
-                    int64_t mw = 0;
-                    for (size_t s = 0; s + 1 < hs.sl_off.size(); ++s) mw = std::max<int64_t>(mw, hs.sl_off[s + 1] - hs.sl_off[s]);
-                    c->asm_max_visits = (int32_t)std::min<int64_t>(mw, INT32_MAX);
+                    c->asm_max_visits = hs.max_slice_width;
                 }
                 if (c->asm_max_visits <= kItemsMaxVisits) {
                     a.lane_row = c->lane_row.p, a.lds_acc_cap = hs.max_blk_nnz, a.lds_cells = hs.max_blk_cells;
@@ -499,7 +497,7 @@ int e_init(fdapde_ctx* c, const fdapde_options* opt) {
     // sweep, sum_q w_q f_q psi_i(p_q), in the summation order the visit loop would use; the sweep below then streams one
     // coalesced double per visit instead of gathering the cell's samples.  Runs on every init: the samples may have changed.
     if (c->fq_cols > 0 && assembly == FDAPDE_ASSEMBLY_ROWS && c->asm_fq_block && c->adj.n > 0) {
-        const int64_t n_slices = (int64_t)hs.sl_off.size() - 1;
+        const int64_t n_slices = hs.n_slices;
         HIPCHK(c, c->fq_blk.alloc(c->adj.n));
         hipLaunchKernelGGL(k_visit_load_coeffs, dim3((unsigned)n_slices), dim3(64, 8), 0, c->stream, n_slices, hs.nq, c->sl_off.p,
                            c->adj.p, c->bc_off.p, c->bc_cell.p, c->fq.p, c->tables.p, c->fq_blk.p);

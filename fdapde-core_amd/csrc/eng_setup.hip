@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -26,9 +27,14 @@ namespace fdapde_engine {
 namespace {
 std::once_flag g_preload_once;
 std::mutex g_preload_mx;
+std::condition_variable g_preload_cv;
+int g_preload_done = 0;        // units loaded so far, in the order dev_setup (1), dev_persist (2), dev_topology (3); 3 too when nothing was started
+bool g_preload_started = false;
 std::thread g_preload_thread;
 struct PreloadJoiner {
-    ~PreloadJoiner() { preload_wait(); }   // (a process that ends before its first build: the thread is joined, never left running)
+    ~PreloadJoiner() {   // (a process that ends before its first build: the thread is joined, never left running)
+        if (g_preload_thread.joinable()) g_preload_thread.join();
+    }
 } g_preload_joiner;
 }   // namespace
 
@@ -36,15 +42,38 @@ void preload_setup_async(int device) {
     if (std::getenv("FDAPDE_NO_PRELOAD")) return;
     std::call_once(g_preload_once, [device] {
         std::lock_guard<std::mutex> lk(g_preload_mx);
+        g_preload_started = true;
         g_preload_thread = std::thread([device] {
-            if (hipSetDevice(device) != hipSuccess) return;
-            dev_setup_preload(), dev_persist_preload(), dev_topology_preload();
+            const bool dbg = std::getenv("FDAPDE_DEBUG_TIMING") != nullptr;
+            auto t0 = std::chrono::steady_clock::now();
+            auto done = [&](int unit, const char* name) {
+                {
+                    std::lock_guard<std::mutex> lk2(g_preload_mx);
+                    g_preload_done = unit;
+                }
+                g_preload_cv.notify_all();
+                if (dbg) {
+                    const auto t1 = std::chrono::steady_clock::now();
+                    std::fprintf(stderr, "[timing] preload thread: %-16s %8.3f ms\n", name, std::chrono::duration<double, std::milli>(t1 - t0).count());
+                    t0 = t1;
+                }
+            };
+            const bool ok = hipSetDevice(device) == hipSuccess;
+            if (ok) dev_setup_preload();
+            done(1, "dev_setup");
+            if (ok) dev_persist_preload();
+            done(2, "dev_persist");
+            if (ok) dev_topology_preload();
+            done(3, "dev_topology");
         });
     });
 }
-void preload_wait() {
-    std::lock_guard<std::mutex> lk(g_preload_mx);
-    if (g_preload_thread.joinable()) g_preload_thread.join();
+// waits until the first `units` set-up units are loaded: 1 = dev_setup (fdapde_dofs_build of an order-1 space), 2 = + dev_persist (the single-launch
+// solver's layout), 3 = + dev_topology (order-2 spaces, fdapde_topology_build)
+void preload_wait(int units) {
+    std::unique_lock<std::mutex> lk(g_preload_mx);
+    if (!g_preload_started) return;
+    g_preload_cv.wait(lk, [units] { return g_preload_done >= units; });
 }
 
 // big host-side index arrays of a device-built space, fetched the first time host code needs them (the persistent layout and the
@@ -62,6 +91,10 @@ int ensure_host(fdapde_ctx* c, int what) {
         HIPCHK(c, hipMemcpyAsync(hs.dof_e2i.data(), c->dof_e2i.p, sizeof(int32_t) * nd, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipMemcpyAsync(hs.cell_i2e.data(), c->cell_i2e.p, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipMemcpyAsync(hs.dof_bnd_i.data(), c->bnd.p, nd, hipMemcpyDeviceToHost, st));
+    }
+    if ((what & kHostPattern) && hs.rowptr_i.empty()) {
+        hs.rowptr_i.resize(c->rowptr.n);
+        HIPCHK(c, hipMemcpyAsync(hs.rowptr_i.data(), c->rowptr.p, sizeof(int32_t) * c->rowptr.n, hipMemcpyDeviceToHost, st));
     }
     if ((what & kHostPattern) && hs.colidx_i.empty()) {
         hs.colidx_i.resize(c->colidx.n);
@@ -152,7 +185,7 @@ int check_dev_space(fdapde_ctx* c, const DevSpace& s, int order) {
         CMP("bc_off", s.bc_off, ref.bc_off), CMP("bn_off", s.bn_off, ref.bn_off), CMP("bc_cell", s.bc_cell, ref.bc_cell);
         CMP("bn_node", s.bn_node, ref.bn_node), CMP("bc_vert", s.bc_vert, ref.bc_vert), CMP("adj", s.adj, ref.adj), CMP("slotw", s.slotw, ref.slotw);
 #undef CMP
-        if (hs.rb_row != ref.rb_row) std::fprintf(stderr, "set-up check rb_row: MISMATCH\n"), ++bad;
+        if (hs.rb_row.size() > 2 && hs.rb_row != ref.rb_row) std::fprintf(stderr, "set-up check rb_row: MISMATCH\n"), ++bad;   // (built for FDAPDE_SPMV=stream only)
     }
     if (bad) return fail(c, FDAPDE_EHIP, "FDAPDE_SETUP_CHECK: the device-built space differs from the host builder's (see stderr)");
     return FDAPDE_OK;
@@ -304,13 +337,16 @@ int e_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs) {
     hs.colidx_i.clear(), hs.cdofs_i.clear(), hs.cverts_i.clear(), hs.vcoords_i.clear(), hs.colidx_e.clear(), hs.rowptr_e.clear(), hs.adj.clear(),
       hs.slotw.clear(), hs.lane_row.clear();
     hs.dofs.clear(), hs.dof_coords.clear();
+    DebugClock clk;
     int rc = host_build_space(hs, order, c->err, on_device ? 2 : 0);
     if (rc) return rc;
+    clk.mark("dofs_build: host_build_space");
     rc = build_basis_tables(hs.M, order, &c->tb);
     if (rc) return fail(c, rc, "basis tables");
     if (on_device) {
         HIPCHK(c, hipSetDevice(c->device));
-        preload_wait();   // (the set-up units' code objects: loading started with the process's first context)
+        preload_wait(order == 1 ? 1 : 3);   // (the set-up units' code objects: loading started with the process's first context)
+        clk.mark("dofs_build: preload_wait");
         DBuf<uint8_t> d_bnd;
         c->dofs_e.release(), c->coords_e.release();
         if (!c->mesh_on_dev) {   // (a mesh that came in while the context had no device copy of it)
@@ -343,6 +379,7 @@ int e_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs) {
                              order == 1 ? d_nodes.p : c->coords_e.p, c->stream, &ds, c->err);
         d_bnd.release();
         if (rc) return rc;
+        clk.mark("dofs_build: dev_build_space");
         if (std::getenv("FDAPDE_SETUP_CHECK")) {
             rc = check_dev_space(c, ds, order);
             if (rc) {
@@ -352,6 +389,7 @@ int e_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs) {
         }
         rc = adopt_dev_space(c, ds);
         if (rc) return rc;
+        clk.mark("dofs_build: adopt");
     }
     c->space_ready = true;
     if (n_dofs) *n_dofs = c->hs.n_dofs;
@@ -359,6 +397,7 @@ int e_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs) {
         HIPCHK(c, hipSetDevice(c->device));
         rc = upload_space(c);
         if (rc) return rc;
+        clk.mark("dofs_build: upload_space");
         // small systems build their single-launch solver layout on the host (build_persist_once): the pattern's host mirror is fetched
         // here, as part of the set-up, not by the first solve (the first larger device-to-host copy of a process costs ~8 ms)
         if (c->hs.n_dofs <= c->persist_host_below)
@@ -378,7 +417,7 @@ int e_topology_build(fdapde_ctx* c, int64_t* n_facets, int64_t* n_edges) {
     if (hs.n_cells < 1) return fail(c, FDAPDE_ENOTINIT, "call fdapde_mesh_upload first");
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->topo_ready) {
-        preload_wait();
+        preload_wait(3);
         if (!c->mesh_on_dev) {
             HIPCHK(c, c->mesh_nodes.upload(hs.nodes.data(), hs.nodes.size(), c->stream));
             HIPCHK(c, c->mesh_cells.upload(hs.cells.data(), hs.cells.size(), c->stream));

@@ -109,9 +109,9 @@ void preload_solve();
 void preload_dist();
 void preload_persist();
 // ... and those of the set-up units (13 + 6 + 6 MB of device code: 30 ms to load), on a helper thread started by the first fdapde_ctx_create
-// of a process; preload_wait() joins it (first thing in fdapde_dofs_build / fdapde_topology_build)
+// of a process; preload_wait(units) waits for the first `units` of them (fdapde_dofs_build, the solver layout, fdapde_topology_build)
 void preload_setup_async(int device);
-void preload_wait();
+void preload_wait(int units);
 
 // ---- single-launch solver (persist_engine.hip) -----------------------------------------------------------------------------------
 // layout of boundary variant v, built on first use (ps.tried / ps.ok tell the outcome)

@@ -721,6 +721,8 @@ int host_build_space(HostSpace& hs, int order, std::string& err, int stop_after)
         slice_widths();
     }
     hs.nbw = (nb * 2 + 3) / 4;
+    hs.n_slices = n_slices, hs.max_slice_width = 0;
+    for (int64_t sl = 0; sl < n_slices; ++sl) hs.max_slice_width = std::max<int32_t>(hs.max_slice_width, (int32_t)(hs.sl_off[(size_t)sl + 1] - hs.sl_off[(size_t)sl]));
     const int64_t padded = hs.sl_off[(size_t)n_slices] * kSlice;
     hs.adj.resize((size_t)padded), hs.slotw.resize((size_t)padded * hs.nbw);
     if (dbg_time)

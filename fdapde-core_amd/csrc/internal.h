@@ -74,7 +74,9 @@ struct HostSpace {
     // ---- row-owner adjacency in sliced-ELL layout: slice s covers rows [64 s, 64 s + 64)
     //      entry (s, v, lane) at (sl_off[s] + v) * 64 + lane  holds  (index of the cell in its assembly block's table) * 16
     //      + local_index, or -1 (padding)
-    std::vector<int64_t> sl_off;      // n_slices + 1, in units of 64-lane rows
+    std::vector<int64_t> sl_off;      // n_slices + 1, in units of 64-lane rows (host-built spaces; a device-built space keeps it on the device)
+    int64_t n_slices = 0;             // ... its size - 1, and the widest slice (= the longest visit list), whoever built the space
+    int32_t max_slice_width = 0;
     hvec<int32_t> adj;         // sl_off.back() * 64
     // lane position -> row (empty = identity).  When the rows of a 256-row assembly block differ a lot in visit count (P2: vertex
     // DOFs ~24 cells, edge DOFs ~5) they are dealt to the block's lanes sorted by visit count, so that a 64-lane slice holds rows

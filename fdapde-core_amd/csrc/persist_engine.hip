@@ -84,6 +84,7 @@ int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_r
         pl.single_rows = c->persist_single_rows;
         int rc = FDAPDE_EUNSUPPORTED;
         if (on_device) {   // the layout is built where the pattern lives (dev_persist.hip)
+            preload_wait(2);
             rc = dev_build_persist_layout(c->hs.n_dofs, c->hs.max_row, c->rowptr.p, c->colidx.p, c->bnd.p, v == 1, n_wg, 12000, 0, brows, sym_mode,
                                           balance, c->stream, pl, &dp, c->err);
             if (rc == FDAPDE_EUNSUPPORTED && c->hs.max_row > 255) on_device = false;   // rows too long for its sort keys: host builder

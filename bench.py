@@ -191,6 +191,81 @@ def cpu_baseline(nx):
     return faithful, best
 
 
+def cpu_columns(c5_nx=24):
+    """CPU figures beside the secondary results (SURVEY 8d plan item 1): the oracle's assembly (the reference's algorithm, 1 core) followed by a DIRECT
+    solve -- scipy's SuperLU standing in for Eigen::SparseLU -- for C1 and C2, where the reference's own solve is feasible; for C5 the oracle's
+    assembly + Jacobi-BiCGStab at a stated reduced size (LU of a 3-D P2 system: DNF by memory at full size)."""
+    import numpy as np
+    import scipy.sparse.linalg as spla
+
+    from fdapde_loader import load_package
+    from oracle import oracle as o
+
+    load_package()
+    from fdapde_core_amd import meshgen, workloads
+
+    out = {}
+
+    def direct(m, order, fq, g):
+        dofs, bnd, nd, _ = o.enumerate_dofs(m, order)
+        t0 = time.perf_counter()
+        A = o.assemble_operator(m, order, dofs, nd, -o.laplacian())
+        b = o.assemble_forcing(m, order, dofs, nd, fq)
+        o.assemble_operator(m, order, dofs, nd, o.reaction(1.0))
+        t1 = time.perf_counter()
+        o.set_dirichlet(A, b, bnd, g(nd))
+        lu = spla.splu(A.to_scipy().tocsc())
+        t2 = time.perf_counter()
+        u = lu.solve(b)
+        t3 = time.perf_counter()
+        return nd, t1 - t0, t2 - t1, t3 - t2, u
+
+    try:   # C1: the reference's own fixtures
+        c1 = {}
+        for name in ("unit_square_16", "unit_square_32"):
+            m = o.load_mesh(os.path.join(ROOT, "tests", "golden", "mesh", name))
+            qn = o.quadrature_nodes(m, 1)
+            fq = 2 * np.pi**2 * np.sin(np.pi * qn[:, 0]) * np.sin(np.pi * qn[:, 1])
+            best = None
+            for _ in range(5):
+                r = direct(m, 1, fq, lambda nd: np.zeros(nd))
+                best = r if best is None or sum(r[1:4]) < sum(best[1:4]) else best
+            nd, ta, tf, ts, _ = best
+            c1[name] = {"dofs": int(nd), "init_ms": 1e3 * ta, "solve_ms": 1e3 * (tf + ts), "factorise_ms": 1e3 * tf, "solve_one_column_ms": 1e3 * ts,
+                        "cores": 1, "kind": "port + scipy SuperLU", "note": "oracle assembly (stiff + force + mass) | Dirichlet rows + splu + one solve; best of 5"}
+        out["c1"] = c1
+    except Exception as e:
+        out["c1"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    try:   # C2 at full size
+        nodes, cells, bnd = meshgen.unit_square(708)
+        m = o.Mesh(nodes, cells, bnd)
+        _, f = meshgen.manufactured(2)
+        nd, ta, tf, ts, _ = direct(m, 1, f(o.quadrature_nodes(m, 1)), lambda nd: np.zeros(nd))
+        out["c2"] = {"value": nd / (ta + tf + ts), "unit": "DOF/s", "cores": 1, "kind": "port + scipy SuperLU",
+                     "sample": f"C2 at full size ({m.n_cells} triangles, {nd} DOFs): oracle assembly {ta:.2f} s + sparse LU {tf:.2f} s + solve {ts:.3f} s"}
+    except Exception as e:
+        out["c2"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    try:   # C5 at a reduced size
+        nodes, cells, bnd = meshgen.unit_cube(c5_nx)
+        m = o.Mesh(nodes, cells, bnd)
+        dofs, b_dofs, nd, _ = o.enumerate_dofs(m, 2)
+        fq = workloads.c5_forcing(o.quadrature_nodes(m, 2))
+        op = -o.laplacian() + o.advection(workloads.C5_B) + o.reaction(workloads.C5_C)
+        t0 = time.perf_counter()
+        A = o.assemble_operator(m, 2, dofs, nd, op)
+        rhs = o.assemble_forcing(m, 2, dofs, nd, fq)
+        o.assemble_operator(m, 2, dofs, nd, o.reaction(1.0))
+        t1 = time.perf_counter()
+        u, it, rr, rc = o.bicgstab(A, rhs, b_dofs, np.zeros(nd), rtol=RTOL, maxit=100000)
+        t2 = time.perf_counter()
+        out["c5"] = {"value": nd / (t2 - t0), "unit": "DOF/s", "cores": 1, "kind": "port",
+                     "sample": f"C5's problem at {c5_nx}^3 x 6 = {m.n_cells} tetrahedra, {nd} DOFs (full size: 87^3 x 6): oracle assembly {t1 - t0:.2f} s + "
+                               f"Jacobi-BiCGStab {t2 - t1:.2f} s ({it} iterations, rc {rc}); a sparse LU of the full-size system does not fit the host's memory"}
+    except Exception as e:
+        out["c5"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    return out
+
+
 def roofline_of(info_list, alg_bytes, streamed_bytes, nx, world, n_int=None, nnz_int=None, layout=None):
     """The dominant kernel's roofline entry.  `frac` is PHYSICAL: the bytes the kernel's layout streams (and, where a committed PMC
     pass of the same workload exists, the counter bytes next to it as `traffic`) over the launch duration; the algorithmic bytes of
@@ -202,6 +277,10 @@ def roofline_of(info_list, alg_bytes, streamed_bytes, nx, world, n_int=None, nnz
     persistent = int(getattr(info, "persistent", 0))
     iters = max(int(info.iters), 1)
     r = {"bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
+    alg_full = float(alg_bytes)
+    if n_int is not None and nnz_int is not None:   # the solve runs on the interior block A_II (Dirichlet rows and columns eliminated): ITS CSR bytes
+        alg_bytes = 12.0 * nnz_int + 4.0 * (n_int + 1) + 16.0 * n_int
+        r["algorithmic_bytes_full_operator_per_application"] = alg_full
     if persistent:
         launch_ms = float(np.mean([i.launch_ms for i in info_list]))
         per_launch = float(streamed_bytes) * iters if streamed_bytes else None
@@ -240,7 +319,13 @@ def roofline_of(info_list, alg_bytes, streamed_bytes, nx, world, n_int=None, nnz
             r["bound"], r["achieved"], r["frac"] = "latency", None, None
             r["achieved_source"] = "matrix blocks resident in LDS for the whole launch: no HBM fraction applies"
     r["effective_gbps"], r["effective_frac"] = eff, eff / HBM_PEAK_GBPS
-    r["effective_note"] = "algorithmic CSR bytes (SURVEY 8d: 12 nnz + 4 (n+1) + 16 n per application) over the same time; not a roofline fraction"
+    r["effective_note"] = ("algorithmic CSR bytes (SURVEY 8d: 12 nnz + 4 (n+1) + 16 n per application) of the interior block the solve runs on, over the same "
+                           "time; not a roofline fraction")
+    if streamed_bytes and persistent:
+        ic = 256 * 1024 * 1024
+        r["residency"] = (f"{streamed_bytes / 1e6:.0f} MB streamed per iteration " + ("< " if streamed_bytes < ic else ">= ") + "the 256 MiB Infinity Cache: " +
+                          ("the stream is Infinity-Cache resident from the second iteration on, so `frac` (of the HBM peak) is nominal for this size; the "
+                           "HBM-resident evidence is extra.wide_2p35M" if streamed_bytes < ic else "an HBM-resident stream"))
     # HBM bytes per launch from counters: NOT measured in this run (PMC needs rocprofv3 around the process) -- taken from the committed
     # PMC passes of the same workload (tools/profile_gpu.sh -> profiles/spmv_pmc.json) when they match it, and labelled so
     r["traffic"], r["traffic_source"] = None, None
@@ -278,30 +363,45 @@ def run_single(args):
     t_gen = time.perf_counter() - t_gen
     n_cells_total = int(cells.shape[0])
     u_exact, f = meshgen.manufactured(3)
+
+    def timed(fn):   # wall clock of one C-ABI call, the device idle when it ends
+        t0 = time.perf_counter()
+        r = fn()
+        ctx.synchronize()
+        return r, 1e3 * (time.perf_counter() - t0)
+
+    t0 = time.perf_counter()
     ctx = capi.Context(device=device_index)
-    ctx.mesh_upload(nodes, cells, bnd)
-    n_dofs = ctx.dofs_build(1)
+    t_ctx = 1e3 * (time.perf_counter() - t0)
+    _, t_mesh_upload = timed(lambda: ctx.mesh_upload(nodes, cells, bnd))   # host copy + device copy of the mesh: the mesh is resident from here on
+    n_dofs, t_dofs_build = timed(lambda: ctx.dofs_build(1))
     sizes = ctx.sizes()
     qn = ctx.quadrature_nodes()
     ctx.set_operator(-capi.laplacian())
     fq = f(qn)
     ctx.synchronize()
-    t0 = time.perf_counter()
-    ctx.set_forcing(fq)   # upload of the samples + their re-layout in block-cell order (set-up for a static forcing; reported, untimed)
-    ctx.synchronize()
-    t_set_forcing = time.perf_counter() - t0
-    ctx.set_dirichlet(np.zeros(n_dofs))
+    _, t_set_forcing = timed(lambda: ctx.set_forcing(fq))   # upload of the samples + their re-layout in block-cell order (set-up for a static forcing; reported, untimed)
+    _, t_set_dirichlet = timed(lambda: ctx.set_dirichlet(np.zeros(n_dofs)))
     del qn, fq
-    t0 = time.perf_counter()
-    ctx.solver_prepare(True)   # set-up: the solver's layout for this boundary mask
-    t_prep = time.perf_counter() - t0
+    _, t_prep = timed(lambda: ctx.solver_prepare(True))   # set-up: the solver's layout for this boundary mask
+    t_prep *= 1e-3
 
     def step(time_spmv=0):
         ctx.init()
         return ctx.solve(rtol=RTOL, time_spmv=time_spmv)
 
-    for _ in range(args.warmup):
-        step()
+    # the FIRST call of the path in this process: mesh resident on the device -> first solution.  What the reference does inside PDE(...), init()
+    # and solve() the first time (lagrangian_basis.h:94-136 enumerate_dofs, fem_assembler.h:112-117 pattern, fem_linear_elliptic_solver.h:38-40
+    # ordering + symbolic analysis) is dofs_build + set_forcing + set_dirichlet + solver_prepare here; the first init + solve is warm-up step 1
+    first_call = {"mesh_upload_ms_not_counted": t_mesh_upload, "ctx_create_ms_not_counted": t_ctx, "dofs_build_ms": t_dofs_build,
+                  "set_forcing_ms": t_set_forcing, "set_dirichlet_ms": t_set_dirichlet, "solver_prepare_ms": 1e3 * t_prep}
+    for w in range(args.warmup):
+        if w == 0:
+            _, first_call["first_init_ms"] = timed(ctx.init)
+            _, first_call["first_solve_ms"] = timed(lambda: ctx.solve(rtol=RTOL))
+        else:
+            step()
+    first_call_ms = (sum(v for k, v in first_call.items() if not k.endswith("not_counted")) if args.warmup > 0 else None)
     ctx.synchronize()
     t0 = time.perf_counter()
     infos = [step(args.time_spmv) for _ in range(args.steps)]
@@ -328,7 +428,7 @@ def run_single(args):
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong",   # the same mesh whatever N (bench.py --gpus N partitions it)
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -342,7 +442,11 @@ def run_single(args):
             "t_assemble_ms": t_asm,
             "t_solve_ms": t_sol,
             "t_setup_ms_untimed": setup_ms,
-            "t_set_forcing_ms_untimed": 1e3 * t_set_forcing,
+            "t_set_forcing_ms_untimed": t_set_forcing,
+            # mesh resident on the device -> first solution, in THIS (cold) process: dofs_build + set_forcing + set_dirichlet + solver_prepare + the
+            # first init + the first solve; the timed steps that follow are the steady state
+            "first_call_ms": first_call_ms,
+            "first_call_phases_ms": first_call,
             "t_meshgen_s_untimed": t_gen,
             "max_abs_error_vs_analytic": err,
             "persistent_launch": int(getattr(info, "persistent", 0)),
@@ -355,14 +459,24 @@ def run_single(args):
         from fdapde_core_amd import workloads
 
         extra = {}
-        for name, fn in (("c2", workloads.run_c2), ("c5", workloads.run_c5)):
+        # (the wide run BEFORE C5: measured right after C5's seconds of full-HBM BiCGStab the same launch took 101 instead of 74 us per iteration)
+        for name, fn in (("c2", workloads.run_c2), ("wide_2p35M", workloads.run_wide), ("c5", workloads.run_c5)):
             try:
                 extra[name] = fn(capi, meshgen, device=device_index, hbm_peak_gbps=HBM_PEAK_GBPS)
             except Exception as e:   # never let a secondary result take the bench line down
                 extra[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        try:
+            extra["c1"] = workloads.run_c1(capi, os.path.join(ROOT, "tests", "golden", "mesh"), device=device_index)
+        except Exception as e:
+            extra["c1"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         out["extra"] = extra
     if not args.no_cpu_baseline:
         out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baseline(args.cpu_nx)
+        if not args.no_extra:   # CPU columns beside the secondary results: direct solves where the reference's own solve is feasible (C1, C2)
+            cols = cpu_columns()
+            for name in ("c1", "c2", "c5"):
+                if isinstance(out["extra"].get(name), dict):
+                    out["extra"][name]["cpu"] = cols.get(name)
     print(json.dumps(out), flush=True)
 
 

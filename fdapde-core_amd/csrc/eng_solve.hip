@@ -867,6 +867,27 @@ int e_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
         rc = solve_run_restarting(c, ss, A, c->force.p, c->g.p, nullptr, FDAPDE_SOLVER_BICGSTAB, rtol, maxit, check_every, opt ? opt->time_spmv : 0);
         clk.mark("fdapde_solve: solve_run (BiCGStab after a CG breakdown)");
     }
+    {
+        if (rc == FDAPDE_OK && open_method && c->cg_broke_down && !ss.dist && !ss.rowdist) {
+            // A symmetric operator that broke CG is indefinite -- or SINGULAR (a pure Neumann problem): on a matrix that is singular up to rounding
+            // BiCGStab "converges" to a solution with a huge multiple of the null vector in it (-Lap u = 1 without Dirichlet data: |u| ~ 1e14, residual
+            // 1e-11 by the recurrence -- a number that cannot be checked: the rounding error of A u alone is eps |A| |u| >> tol |b|).  The reference's LU
+            // reports failure on such a matrix (fem_linear_elliptic_solver.h:42-45).  Guard: |x| / |b| of the scaled system (unit diagonal, |A~| ~ 1)
+            // beyond 1e12 is reported as success = false, never handed out as a solution.
+            const double* xs = c->info.persistent ? c->persist_x.p : c->x.p;
+            hipLaunchKernelGGL(k_sq_norm, dim3(c->vec_grid), dim3(256), 0, c->stream, n, xs, c->part_b.p);
+            hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, c->stream, c->part_b.p, c->vec_grid, c->sc.p + 20);
+            double xx = 0;
+            HIPCHK(c, hipMemcpyAsync(&xx, c->sc.p + 20, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            const double bb = c->h_sc[0];
+            if (!(xx <= 1e24 * bb)) {
+                c->info.converged = 0;
+                c->err = "operator numerically singular: the iterate grew beyond 1e12 |b| (e.g. no Dirichlet DOF and a right-hand side outside the range)";
+                rc = FDAPDE_ENOCONV;
+            }
+        }
+    }
     if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     HIPCHK(c, hipEventSynchronize(c->ev1));

@@ -102,6 +102,20 @@ template <int R> __device__ __forceinline__ double rounded(double v) {
     return v;
 }
 
+// A finished value into an accumulator in LDS: `ds_add_f64` (the LDS adds it -- IEEE round-to-nearest on the rounded product, exactly what
+// read + v_add_f64 + write computes) instead of a read-modify-write through registers.  No returned value, hence no LDS round trip for the wave to
+// wait on, half the LDS instructions, and the add leaves the VALU.  A wavefront's LDS operations complete in program order and the lanes of one
+// instruction hit distinct accumulators (distinct rows, or the distinct columns of one element row), so every accumulator still receives its
+// addends in visit order: bitwise reproducible, bitwise symmetric for symmetric forms.  Every row-owner kernel (P1 and P2, both sweeps) adds this
+// way, so kernels of different shape agree bit for bit; the product handed in is a finished double (no contraction reaches into the LDS).
+__device__ __forceinline__ void lds_add(double* slot, double v) { unsafeAtomicAdd(slot, v); }
+
+// One element row's NB values into the row's accumulators in LDS (the NB slots of a visit are distinct columns of the row).
+template <int NB, int NBW> __device__ __forceinline__ void add_row_lds(double* acc_row, const uint32_t (&sw)[NBW], const double (&val)[NB]) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) lds_add(acc_row + ((sw[j >> 1] >> ((j & 1) * 16)) & 0xffffu), val[j]);
+}
+
 template <int M> struct Geo {
     double invJ[M][M];   // J^{-1}
     double measure;      // |det J| / M!
@@ -652,20 +666,43 @@ static __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, D
             geo_from_vertices<M>(xyz + lv.x * NP, xyz + lv.y * NP, xyz + lv.z * NP, xyz + lv.w * NP, g);
             // the global cell id is needed by varying coefficients and by forcing samples kept in cell order only
             const int cell = ((a.fq != nullptr && a.fq_block == 0) || op.needs_rows) ? a.bc_cell[bc] : 0;
-            fsum += rounded<R>(element_row<M, R, OPK>(a, op, tb, g, cell, code & 15, want_matrix, [&](int j, double value) {
-                const uint32_t slot = (sw[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
-                if (in_lds)
-                    acc[my0 - base + (int32_t)slot] += rounded<R>(value);
-                else
-                    a.vals[my0 + (int32_t)slot] += rounded<R>(value);
-            }, rt, fblk ? bc : (int64_t)-1, fc, fbc ? bc : (int64_t)-1));
+            if constexpr (R == 2) {   // the NB values of the visit's row first, then ONE read-modify-write round trip for all of them (add_row_lds)
+                double val[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) val[j] = 0.0;
+                fsum += rounded<R>(element_row<M, R, OPK>(a, op, tb, g, cell, code & 15, want_matrix, [&](int j, double value) { val[j] = rounded<R>(value); },
+                                                          rt, fblk ? bc : (int64_t)-1, fc, fbc ? bc : (int64_t)-1));
+                if (want_matrix) {
+                    if (in_lds) {
+                        add_row_lds<NB, NBW>(acc + (my0 - base), sw, val);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) a.vals[my0 + (int32_t)((sw[j >> 1] >> ((j & 1) * 16)) & 0xffffu)] += val[j];
+                    }
+                }
+            } else {
+                fsum += rounded<R>(element_row<M, R, OPK>(a, op, tb, g, cell, code & 15, want_matrix, [&](int j, double value) {
+                    const uint32_t slot = (sw[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+                    if (in_lds)
+                        lds_add(&acc[my0 - base + (int32_t)slot], value);
+                    else
+                        a.vals[my0 + (int32_t)slot] += rounded<2>(value);   // (a finished product here too: the same bits as through the LDS)
+                }, rt, fblk ? bc : (int64_t)-1, fc, fbc ? bc : (int64_t)-1));
+            }
             if constexpr (MASS2 == 1) {   // (OPK 2's own formula with coefficient 1: cm = 1.0 * 1.0 * |e|)
                 const double cm = 1.0 * 1.0 * g.measure;
                 const int il = code & 15;
+                if constexpr (R == 2) {
+                    double mv[NB];
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    const uint32_t slot = (sw[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
-                    acc2[my0 - base + (int32_t)slot] += rounded<R>(cm * tb->mtab[il * NB + j]);
+                    for (int j = 0; j < NB; ++j) mv[j] = rounded<R>(cm * tb->mtab[il * NB + j]);
+                    add_row_lds<NB, NBW>(acc2 + (my0 - base), sw, mv);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const uint32_t slot = (sw[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+                        lds_add(&acc2[my0 - base + (int32_t)slot], cm * tb->mtab[il * NB + j]);
+                    }
                 }
             }
         }
@@ -713,10 +750,17 @@ static __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, D
                 geo_from_vertices<M>(xyz + lv.x * NP, xyz + lv.y * NP, xyz + lv.z * NP, xyz + lv.w * NP, g);
                 const double cm = 1.0 * 1.0 * g.measure;   // (OPK 2's own formula with coefficient 1)
                 const int il = code & 15;
+                if constexpr (R == 2) {
+                    double mv[NB];
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    const uint32_t slot = (sw[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
-                    acc[my0 - base + (int32_t)slot] += rounded<R>(cm * tb->mtab[il * NB + j]);
+                    for (int j = 0; j < NB; ++j) mv[j] = rounded<R>(cm * tb->mtab[il * NB + j]);
+                    add_row_lds<NB, NBW>(acc + (my0 - base), sw, mv);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const uint32_t slot = (sw[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+                        lds_add(&acc[my0 - base + (int32_t)slot], cm * tb->mtab[il * NB + j]);
+                    }
                 }
             }
         }
@@ -834,8 +878,16 @@ static __global__ __launch_bounds__(THREADS) void k_assemble_items(AsmArgs a, De
                 tail = true;
                 __syncthreads();   // rows change hands: everything phase A added is in place
             }
-            const int Q = tail ? QB : QA, V = tail ? VB : VA;
-            const int v = v0 + lane / Q, q = Q * wave + lane % Q;
+            // phase B: the tail's 64 positions x VB visit indices of a step as tiles of QA positions x VA visit indices, like phase A's: wavefront
+            // w takes position group w % GQ and visit range w / GQ.  A row's items of one step then sit in GR wavefronts, which accumulate one
+            // after the other (a workgroup barrier between the ranges) -- VA accumulation rounds per wavefront instead of VB: the rounds (NB LDS
+            // read-modify-writes under a mask that leaves QB lanes active) were what a phase-B step spent most of its instructions on
+            constexpr int GQ = 64 / QA, GR = NW / GQ;
+            static_assert(GQ * QA == 64 && GR * GQ == NW && GR * VA == VB, "phase B tiles");
+            const int gq = wave % GQ, gr = wave / GQ;
+            const int V = tail ? VB : VA;
+            const int v = tail ? v0 + VA * gr + lane / QA : v0 + lane / QA;
+            const int q = tail ? QA * gq + lane % QA : QA * wave + lane % QA;
             const int64_t at = (sloff_s[q >> 6] + v) * kSlice + (q & 63);
             const int32_t code = v < width_s[q >> 6] ? a.adj[at] : -1;
             const bool on = code >= 0;
@@ -866,16 +918,20 @@ static __global__ __launch_bounds__(THREADS) void k_assemble_items(AsmArgs a, De
             // accumulation rounds, one per visit index of the step, ascending.  All items of a row live in THIS wavefront, whose LDS
             // operations complete in program order: a round's read-modify-writes are behind those of the round before, no barrier
             const int32_t rb = rbase_s[q];
-            for (int u = v0; u < v0 + V && u < maxv; ++u) {
-                if (on && v == u) {
-                    if (MASS || want_matrix) {
-#pragma unroll
-                        for (int j = 0; j < NB; ++j) {
-                            const uint32_t slot = (sw[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
-                            acc[rb + (int32_t)slot] += val[j];
-                        }
+            auto rounds = [&](int u0, int u1) {
+                for (int u = u0; u < u1 && u < maxv; ++u) {
+                    if (on && v == u) {
+                        if (MASS || want_matrix) add_row_lds<NB, NBW>(acc + rb, sw, val);
+                        if constexpr (!MASS) facc_s[q] += fval;
                     }
-                    if constexpr (!MASS) facc_s[q] += fval;
+                }
+            };
+            if (!tail) {
+                rounds(v0, v0 + VA);
+            } else {
+                for (int r = 0; r < GR; ++r) {   // (uniform for the workgroup)
+                    if (gr == r) rounds(v0 + VA * r, v0 + VA * (r + 1));
+                    __syncthreads();
                 }
             }
             v0 += V;

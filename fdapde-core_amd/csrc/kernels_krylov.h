@@ -738,6 +738,17 @@ static __global__ __launch_bounds__(256) void k_sq_owned(int64_t n, const double
     const double s = block_sum(a, red);
     if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
+// sum of squares of a vector (entries that are not finite count as huge): the size of a claimed solution, for the singularity guard of fdapde_solve
+static __global__ __launch_bounds__(256) void k_sq_norm(int64_t n, const double* t, double* part) {
+    __shared__ double red[8];
+    double a = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = t[i];
+        a += isfinite(v) ? v * v : 1e300;
+    }
+    const double s = block_sum(a, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
 static __global__ __launch_bounds__(256) void k_bicg_tt_fin(const double* part, int np, const double* ts_src, double* out) {
     __shared__ double red[8];
     const double s = sum_partials(part, np, red);

@@ -123,7 +123,7 @@ def run_c2(capi, meshgen, nx=708, steps=2, warmup=1, time_spmv=32, rtol=1e-10, d
     return out
 
 
-def run_c5(capi, meshgen, nx=87, steps=1, warmup=1, time_spmv=16, rtol=1e-10, device=0, hbm_peak_gbps=8000.0):
+def run_c5(capi, meshgen, nx=87, steps=3, warmup=1, time_spmv=16, rtol=1e-10, device=0, hbm_peak_gbps=8000.0):
     nodes, cells, bnd = meshgen.unit_cube(nx)
     ctx = capi.Context(device)
     t0 = time.perf_counter()
@@ -154,4 +154,105 @@ def run_c5(capi, meshgen, nx=87, steps=1, warmup=1, time_spmv=16, rtol=1e-10, de
     except Exception:
         pass
     ctx.close()
+    return out
+
+
+def run_wide(capi, meshgen, nx=132, steps=2, warmup=1, rtol=1e-10, device=0, hbm_peak_gbps=8000.0):
+    """The headline problem one size up -- (nx + 1)^3 = 2.35 M DOFs at nx = 132 -- where the single launch runs in its WIDE form (24 rows per
+    thread, plain storage, x in HBM between the iterations: kernels_persist.h).  Its layout streams ~370 MB per iteration: more
+    than the 256 MiB Infinity Cache holds, so the fraction quoted here is on an HBM-resident stream (C3's 146 MB per iteration is not)."""
+    nodes, cells, bnd = meshgen.unit_cube(nx)
+    u_exact, f = meshgen.manufactured(3)
+    ctx = capi.Context(device)
+    ctx.mesh_upload(nodes, cells, bnd)
+    nd = ctx.dofs_build(1)
+    n_cells = int(cells.shape[0])
+    del nodes, cells
+    ctx.set_operator(-capi.laplacian())
+    ctx.set_forcing(f(ctx.quadrature_nodes()))
+    ctx.set_dirichlet(np.zeros(nd))
+    ctx.solver_prepare(True)
+    wall, infos = _timed_steps(ctx, steps, warmup, 0, rtol)
+    out = _summary(ctx, nd, wall, infos, u_exact, hbm_peak_gbps)
+    out.update(workload=f"3-D P1 Laplacian, {nx}^3 x 6 = {n_cells} tetrahedra, {nd} DOFs (C3's problem one size up): the wide form of the single launch",
+               cells=n_cells, infinity_cache_bytes=256 * 1024 * 1024,
+               residency="streamed bytes per iteration exceed the 256 MiB Infinity Cache: an HBM-resident stream")
+    ctx.close()
+    return out
+
+
+def _read_fixture_csv(path, dtype):
+    """the reference's CSV dialect (utils/IO/csv_reader.h:75-117): a header row, first column = row index, quotes stripped"""
+    rows = []
+    with open(path) as fh:
+        next(fh)
+        for line in fh:
+            parts = [t.strip().strip('"') for t in line.strip().split(",")]
+            if len(parts) > 1:
+                rows.append(parts[1:])
+    return np.array(rows, dtype=float).astype(dtype)
+
+
+def load_fixture_mesh(directory):
+    """points / elements / boundary of one of the reference's test meshes (test/src/utils/mesh_loader.h:62-84: 1-based -> 0-based)"""
+    import os
+
+    nodes = _read_fixture_csv(os.path.join(directory, "points.csv"), float)
+    cells = _read_fixture_csv(os.path.join(directory, "elements.csv"), np.int32) - 1
+    bnd = _read_fixture_csv(os.path.join(directory, "boundary.csv"), np.uint8).reshape(-1)
+    return np.ascontiguousarray(nodes), np.ascontiguousarray(cells.astype(np.int32)), np.ascontiguousarray(bnd)
+
+
+def run_c1(capi, golden_mesh_dir, names=("unit_square_16", "unit_square_32"), reps=50, rtol=1e-10, device=0):
+    """BASELINE config C1: the reference's own unit_square_16 / _32 fixtures (289 / 1 089 DOFs): wall time per PDE::init(), per PDE::solve()
+    and per column of the factor-once handle (one by one, and 64 side by side) -- the sizes the reference is used at, where fixed per-call
+    costs matter and bandwidth does not"""
+    import os
+
+    out = {}
+    for name in names:
+        nodes, cells, bnd = load_fixture_mesh(os.path.join(golden_mesh_dir, name))
+        ctx = capi.Context(device)
+        ctx.mesh_upload(nodes, cells, bnd)
+        nd = ctx.dofs_build(1)
+        qn = ctx.quadrature_nodes()
+        ctx.set_operator(-capi.laplacian())
+        ctx.set_forcing(2 * np.pi**2 * np.sin(np.pi * qn[:, 0]) * np.sin(np.pi * qn[:, 1]))
+        ctx.set_dirichlet(np.zeros(nd))
+        for _ in range(3):
+            ctx.init()
+            info = ctx.solve(rtol=rtol)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.init()
+        ctx.synchronize()
+        t_init = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            info = ctx.solve(rtol=rtol)
+        ctx.synchronize()
+        t_solve = (time.perf_counter() - t0) / reps
+        _, _, coords = ctx.dofs_get()
+        err = float(np.abs(ctx.solution() - np.sin(np.pi * coords[:, 0]) * np.sin(np.pi * coords[:, 1])).max())
+        # the handle downstream models hold (fdapde::SparseLU: compute once, solve many): -Lap + mass, no Dirichlet rows
+        ctx.set_operator(-capi.laplacian() + capi.reaction(1.0))
+        ctx.init()
+        ctx.lin_compute(capi.MAT_STIFF)
+        rng = np.random.default_rng(0)
+        B = rng.standard_normal((nd, 64))
+        ctx.lin_solve(B[:, 0], rtol=rtol)
+        ctx.lin_solve(B, rtol=rtol)
+        t0 = time.perf_counter()
+        for k in range(reps):
+            ctx.lin_solve(B[:, k % 64], rtol=rtol)
+        t_col = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(5):
+            ctx.lin_solve(B, rtol=rtol)
+        t_cols = (time.perf_counter() - t0) / 5 / 64
+        out[name] = {"dofs": int(nd), "cells": int(cells.shape[0]), "init_ms": 1e3 * t_init, "solve_ms": 1e3 * t_solve, "iterations": int(info.iters),
+                     "persistent": int(info.persistent), "max_abs_error_vs_analytic": err,
+                     "handle_solve_one_column_ms": 1e3 * t_col, "handle_solve_per_column_of_64_ms": 1e3 * t_cols}
+        ctx.close()
     return out

@@ -94,6 +94,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
         release_rowdist(c);
         if (c->comm) (void)g_rccl.CommDestroy(c->comm);
         c->mesh_nodes.release(), c->mesh_cells.release(), c->mesh_nbnd.release();
+        c->gm_V.release(), c->gm_b.release(), c->gm_s.release(), c->gm_part.release();
         c->lin_mat.release(), c->stiff_stat.release(), c->ar_dev.release(), c->persist_stats.release(), c->persist_x.release(), c->persist_xs.release(), c->coords_e.release();
         dev_topology_release(&c->topo);
         c->part_cells.release(), c->part_off.release(), c->part_slots.release(), c->wave_slots.release(), c->part_shared.release();
@@ -346,6 +347,8 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "asm_fuse_mass" && value >= 0 && value <= 3) c->asm_fuse_mass = value;
     else if (k == "asm_items" && (value == 0 || value == 1)) c->asm_items = value;
     else if (k == "bicg_restart" && (value == 0 || value == 1)) c->bicg_restart = value;
+    else if (k == "gmres_m" && value >= 2 && value <= 200) c->gmres_m = value;
+    else if (k == "auto_gmres" && (value == 0 || value == 1)) c->auto_gmres = value;
     else if (k == "asm_split_varying" && (value == 0 || value == 1)) c->asm_split_varying = value;
     else if (k == "asm_row_stat" && (value == 0 || value == 1)) c->asm_row_stat = value, c->stiff_stat_valid = false;
     else if (k == "asm_fq_bc" && (value == 0 || value == 1)) c->asm_fq_bc = value, c->fq_bc_ready = c->fq_bc_ready && value;   // (takes effect fully at the next fdapde_set_forcing)

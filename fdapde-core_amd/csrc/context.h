@@ -197,6 +197,9 @@ struct fdapde_ctx {
     DBuf<int32_t> mesh_cells;
     DBuf<uint8_t> mesh_nbnd;
     bool mesh_on_dev = false;
+    DBuf<double> gm_V, gm_b, gm_s, gm_part;   // restarted GMRES (kernels_gmres.h): basis (m + 1) x n, scaled right-hand side, small state, partial sums
+    int gmres_m = 50;                         // restart length (knob gmres_m)
+    int auto_gmres = 1;                       // FDAPDE_SOLVER_AUTO ends in GMRES after BiCGStab gave up (knob auto_gmres)
     bool dev_built = false;             // the index structures were built on the device (dev_setup.hip); big host mirrors are lazy
     DBuf<uint32_t> slotw;
     DBuf<int64_t> bc_off, bn_off;

@@ -404,6 +404,53 @@ int ensure_sval(fdapde_ctx* c) {
     return FDAPDE_OK;
 }
 
+// Restarted GMRES(m) on the scaled system (kernels_gmres.h); x, r, sc, ctl as k_krylov_init / _fin left them, bt = the scaled right-hand side.
+// Leaves x (scaled iterate), sc[0] / sc[3] (|b|^2, |b - A x|^2 TRUE) and ctl like the other methods; h_ctl / h_sc hold the last read-back.
+int run_gmres(fdapde_ctx* c, double tol2, int maxit) {
+    const int64_t n = c->hs.n_dofs;
+    const int m = c->gmres_m;
+    hipStream_t st = c->stream;
+    HIPCHK(c, c->gm_V.alloc((size_t)(m + 1) * (size_t)n));
+    HIPCHK(c, c->gm_s.alloc((size_t)gm_state_doubles(m) + (size_t)m + 2));
+    HIPCHK(c, c->gm_part.alloc((size_t)(m + 2) * kGmStripes));
+    double* gs = c->gm_s.p;
+    double* h_pass = gs + gm_state_doubles(m);   // coefficients of the Gram-Schmidt pass in flight
+    double* hcol = gs + 3 * m + 1;
+    double* w = c->y.p;
+    const int vg = c->vec_grid;
+    HIPCHK(c, hipMemcpyAsync(c->sc.p + 21, c->sc.p + 3, sizeof(double), hipMemcpyDeviceToDevice, st));   // |r|^2 at the start of the first cycle
+    bool stop = false;
+    HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    stop = c->h_ctl[0] != 0;   // (converged at the initial guess)
+    while (!stop) {
+        hipLaunchKernelGGL(k_gm_cycle_init, dim3(vg), dim3(256), 0, st, n, m, c->r.p, c->sc.p, gs, c->gm_V.p, c->ctl.p);
+        for (int j = 0; j < m; ++j) {
+            const double* vj = c->gm_V.p + (size_t)j * n;
+            launch_spmv(c, c->sval.p, vj, w, nullptr, c->part_a.p, c->ctl.p);   // w = At v_j (leaves at once when the stop flag is up)
+            for (int pass = 0; pass < 2; ++pass) {                              // classical Gram-Schmidt, twice
+                hipLaunchKernelGGL(k_gm_dots, dim3(kGmStripes, j + 1), dim3(256), 0, st, n, c->gm_V.p, w, c->gm_part.p, c->ctl.p);
+                hipLaunchKernelGGL(k_gm_reduce, dim3(j + 1), dim3(256), 0, st, c->gm_part.p, h_pass, hcol, pass, c->ctl.p);
+                hipLaunchKernelGGL(k_gm_axpy, dim3(vg), dim3(256), 0, st, n, j + 1, c->gm_V.p, h_pass, w, c->gm_part.p + (size_t)(m + 1) * kGmStripes, pass, c->ctl.p);
+            }
+            hipLaunchKernelGGL(k_gm_hess, dim3(1), dim3(256), 0, st, j, m, c->gm_part.p + (size_t)(m + 1) * kGmStripes, vg, gs, c->sc.p, c->ctl.p, tol2, maxit);
+            hipLaunchKernelGGL(k_gm_next, dim3(vg), dim3(256), 0, st, n, w, gs, m, c->gm_V.p + (size_t)(j + 1) * n, c->ctl.p);
+        }
+        // end of the cycle: y, x += V y, the true residual -- which decides whether another cycle follows
+        hipLaunchKernelGGL(k_gm_solve_y, dim3(1), dim3(1), 0, st, m, gs);
+        hipLaunchKernelGGL(k_gm_update_x, dim3(vg), dim3(256), 0, st, n, m, c->gm_V.p, gs, c->x.p);
+        launch_spmv(c, c->sval.p, c->x.p, c->t.p, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL(k_gm_residual, dim3(vg), dim3(256), 0, st, n, c->gm_b.p, c->t.p, c->r.p, c->gm_part.p);
+        hipLaunchKernelGGL(k_gm_cycle_fin, dim3(1), dim3(256), 0, st, c->gm_part.p, vg, c->sc.p, c->ctl.p, tol2, maxit);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(c->h_sc, c->sc.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        stop = c->h_ctl[0] != 0;
+    }
+    return FDAPDE_OK;
+}
+
 // Krylov solve of A u = f with u = g on the Dirichlet DOFs (if ss.use_bnd), on the system prepared by solve_prepare.
 //   f_dev : right-hand side, internal order, sub-assembled (summed over ranks here when dist)
 //   g_dev : Dirichlet values, internal order (read on boundary DOFs only)
@@ -450,6 +497,8 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     if ((method == FDAPDE_SOLVER_CG || method == FDAPDE_SOLVER_CG_SR || method == FDAPDE_SOLVER_CG_FUSED) && !ss.diag_positive)
         return fail(c, FDAPDE_ENOCONV, "CG needs a positive diagonal (operator not SPD?); use BiCGStab");
     const bool bicg = method == FDAPDE_SOLVER_BICGSTAB, cgsr = method == FDAPDE_SOLVER_CG_SR, cgf = method == FDAPDE_SOLVER_CG_FUSED;
+    const bool gmres = method == FDAPDE_SOLVER_GMRES;
+    if (gmres && (dist || ss.rowdist)) return fail(c, FDAPDE_EUNSUPPORTED, "GMRES runs on one-GPU contexts");
     const double tol2 = rtol * rtol;
     const double* ax = nullptr;
     if (u0_dev) {   // warm start: x = (u0 - g~) / s, r = b~ - At x
@@ -476,6 +525,10 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
         hipLaunchKernelGGL(k_krylov_init_fin, dim3(1), dim3(256), 0, st, c->part_b.p, c->vec_grid, c->sc.p, c->ctl.p, tol2,
                            cgf ? c->part_b.p + cg : (double*)nullptr, cgf ? cg : 0);
     }
+    if (gmres) {   // the scaled right-hand side, for the true residual at the end of every restart cycle (c->y still holds A g~)
+        HIPCHK(c, c->gm_b.alloc((size_t)n));
+        hipLaunchKernelGGL(k_gm_rhs, dim3(g1(n)), dim3(256), 0, st, n, fvec, c->y.p, c->scale.p, c->gm_b.p);
+    }
     if (cgsr) {   // p = s = 0 before the first update (beta = 0 there)
         HIPCHK(c, hipMemsetAsync(c->p.p, 0, sizeof(double) * (size_t)n, st));
         HIPCHK(c, hipMemsetAsync(c->s.p, 0, sizeof(double) * (size_t)n, st));
@@ -490,6 +543,13 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     int timed = 0, launched = 0;
     bool stop = false;
     bool persisted = false;
+    if (gmres) {
+        if (int rc = ensure_sval(c)) return rc;
+        if (int rc = run_gmres(c, tol2, maxit)) return rc;
+        stop = true, launched = c->h_ctl[1];
+        HIPCHK(c, hipMemcpyAsync(c->h_sc, c->sc.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
     if (ss.rowdist) {   // one launch per rank, the launches of all ranks acting as one grid (kernels_persist.h DIST)
         if (int rc = run_rowdist(c, ss.use_bnd ? 1 : 0, tol2, maxit, &persisted, bicg)) return rc;
         if (!persisted) return fail(c, FDAPDE_EUNSUPPORTED, "row-distributed solve: an in-kernel hand-off between the ranks' launches timed out (boards not visible across the devices, or a rank's launch could not be resident); use the element-partitioned exchange (fdapde_halo_setup_peers) instead");
@@ -733,7 +793,7 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
 // the original right-hand side (solve_run's warm start).  Up to kBicgRestarts times; the iterations add up in info.iters.  One-GPU contexts.
 constexpr int kBicgRestarts = 30;
 int solve_run_restarting(fdapde_ctx* c, const SolveState& ss, const double* A, const double* f_dev, const double* g_dev, const double* u0_dev,
-                         int method, double rtol, int maxit, int check_every, int n_timed) {
+                         int method, double rtol, int maxit, int check_every, int n_timed, bool gmres_tail = false) {
     int rc = solve_run(c, ss, A, f_dev, g_dev, u0_dev, method, rtol, maxit, check_every, n_timed);
     int total = c->info.iters;
     const int64_t n = c->hs.n_dofs;
@@ -747,6 +807,18 @@ int solve_run_restarting(fdapde_ctx* c, const SolveState& ss, const double* A, c
         total += c->info.iters;
     }
     c->info.iters = total;
+    // The last stage where the caller left the method open (FDAPDE_SOLVER_AUTO): BiCGStab gave up -- restarts exhausted, stalled until maxit, or an
+    // iterate that stopped being finite -- on a system the reference's LU would have solved (fem_linear_elliptic_solver.h:38-47; typically an
+    // advection-dominated operator): restarted GMRES(m) on the same scaled system, from BiCGStab's iterate if that was any closer than zero.
+    if (gmres_tail && c->auto_gmres && rc == FDAPDE_ENOCONV && c->info.method_used == FDAPDE_SOLVER_BICGSTAB && !ss.dist && !ss.rowdist) {
+        const bool warm = std::isfinite(c->info.relres) && c->info.relres < 1.0;
+        if (warm) {
+            HIPCHK(c, c->restart_u.alloc((size_t)n));
+            HIPCHK(c, hipMemcpyAsync(c->restart_u.p, c->u.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+        }
+        rc = solve_run(c, ss, A, f_dev, g_dev, warm ? c->restart_u.p : u0_dev, FDAPDE_SOLVER_GMRES, rtol, maxit, check_every, 0);
+        c->info.iters += total;
+    }
     return rc;
 }
 
@@ -855,7 +927,7 @@ int e_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     if (int rc = solve_prepare(c, A, c->have_g ? 1 : 0, &ss, c->op_symmetric && !skip_cg)) return rc;
     clk.mark("fdapde_solve: solve_prepare");
     int rc = solve_run_restarting(c, ss, A, c->force.p, c->g.p, nullptr, skip_cg ? FDAPDE_SOLVER_BICGSTAB : (opt ? opt->method : FDAPDE_SOLVER_AUTO), rtol,
-                                  maxit, check_every, opt ? opt->time_spmv : 0);
+                                  maxit, check_every, opt ? opt->time_spmv : 0, open_method);
     clk.mark("fdapde_solve: solve_run");
     if (rc == FDAPDE_ENOCONV && c->h_ctl[2] != 0 && (!opt || opt->method == FDAPDE_SOLVER_AUTO) && c->info.method_used != FDAPDE_SOLVER_BICGSTAB &&
         !ss.dist && !ss.rowdist) {
@@ -864,7 +936,7 @@ int e_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
         // such a system all the same (fem_linear_elliptic_solver.h:38-47); so does BiCGStab.  Only where the caller left the method open.
         c->cg_broke_down = true;   // (until the matrix is assembled again)
         if (int rc2 = solve_prepare(c, A, c->have_g ? 1 : 0, &ss, false)) return rc2;
-        rc = solve_run_restarting(c, ss, A, c->force.p, c->g.p, nullptr, FDAPDE_SOLVER_BICGSTAB, rtol, maxit, check_every, opt ? opt->time_spmv : 0);
+        rc = solve_run_restarting(c, ss, A, c->force.p, c->g.p, nullptr, FDAPDE_SOLVER_BICGSTAB, rtol, maxit, check_every, opt ? opt->time_spmv : 0, true);
         clk.mark("fdapde_solve: solve_run (BiCGStab after a CG breakdown)");
     }
     {
@@ -949,12 +1021,13 @@ int e_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times,
             hipLaunchKernelGGL(k_gather_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->tmp_i.p, gcol.p);
         }
         c->defer_end_sync = true;   // (the step's outcome is read inside solve_run; what follows it is ordered by the stream)
-        int rc = solve_run_restarting(c, ss, kmat.p, rhs.p, gcol.p, uprev.p, step_method, rtol, maxit, check_every, 0);
+        const bool open_step = !opt || opt->method == FDAPDE_SOLVER_AUTO;
+        int rc = solve_run_restarting(c, ss, kmat.p, rhs.p, gcol.p, uprev.p, step_method, rtol, maxit, check_every, 0, open_step);
         if (rc == FDAPDE_ENOCONV && c->h_ctl[2] != 0 && step_method == FDAPDE_SOLVER_AUTO && c->info.method_used != FDAPDE_SOLVER_BICGSTAB && !ss.dist &&
             !ss.rowdist) {   // M / dt + A symmetric but not positive definite (see fdapde_solve): this step again and every later one with BiCGStab
             if (int rc2 = solve_prepare(c, kmat.p, dirichlet ? 1 : 0, &ss, false)) return rc2;
             step_method = FDAPDE_SOLVER_BICGSTAB;
-            rc = solve_run_restarting(c, ss, kmat.p, rhs.p, gcol.p, uprev.p, step_method, rtol, maxit, check_every, 0);
+            rc = solve_run_restarting(c, ss, kmat.p, rhs.p, gcol.p, uprev.p, step_method, rtol, maxit, check_every, 0, open_step);
         }
         c->defer_end_sync = false;
         if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;
@@ -1219,7 +1292,8 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
         hipLaunchKernelGGL(k_gather_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->tmp_e.p, rhs.p);
         clk.mark("lin_solve: upload + gather issued");
         c->defer_end_sync = true;
-        const int rc = solve_run_restarting(c, c->lin_state->ss, c->lin_mat.p, rhs.p, c->g.p, nullptr, method, rtol, maxit, check_every, 0);
+        const int rc = solve_run_restarting(c, c->lin_state->ss, c->lin_mat.p, rhs.p, c->g.p, nullptr, method, rtol, maxit, check_every, 0,
+                                            !opt || opt->method == FDAPDE_SOLVER_AUTO);
         c->defer_end_sync = false;
         clk.mark("lin_solve: solve_run");
         if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;

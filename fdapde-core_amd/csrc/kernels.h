@@ -25,6 +25,7 @@
 #include "kernels_reduce.h"
 #include "kernels_spmv.h"
 #include "kernels_krylov.h"
+#include "kernels_gmres.h"
 #include "kernels_multirhs.h"
 #include "kernels_persist.h"
 

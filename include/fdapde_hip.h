@@ -65,8 +65,13 @@ typedef struct {
  * estimate alpha^2 Ap.Ap - r.r (only the search direction sees the estimate); two launches per iteration, single GPU */
 /* FDAPDE_SOLVER_AUTO: Jacobi-PCG for a symmetric operator with a positive diagonal, Jacobi-BiCGStab otherwise; if CG breaks down (p.Ap <= 0: the
  * operator is symmetric but not positive definite, e.g. -Lap u - k^2 u) the solve is repeated with BiCGStab -- the reference's LU solves such systems too (one-GPU contexts; a rank of a multi-GPU job reports the breakdown).
+ * Where BiCGStab gives up as well -- breakdowns beyond its restarts, a stalled or exploding recurrence: advection-dominated operators from cell Peclet
+ * numbers of ~10^2 on -- the solve ends in restarted GMRES(50) on the same Jacobi-scaled system (kernels_gmres.h; one-GPU contexts), started from
+ * BiCGStab's iterate when that is closer than zero; info.method_used names the stage that produced the answer.  A symmetric operator that is singular
+ * up to rounding (pure Neumann data, right-hand side outside the range) is reported as a failure, not answered with a multiple of the null vector.
  * A method named explicitly is never replaced: its failure is reported (FDAPDE_ENOCONV, success = false). */
-enum { FDAPDE_SOLVER_AUTO = 0, FDAPDE_SOLVER_CG = 1, FDAPDE_SOLVER_BICGSTAB = 2, FDAPDE_SOLVER_CG_SR = 3, FDAPDE_SOLVER_CG_FUSED = 4 };
+enum { FDAPDE_SOLVER_AUTO = 0, FDAPDE_SOLVER_CG = 1, FDAPDE_SOLVER_BICGSTAB = 2, FDAPDE_SOLVER_CG_SR = 3, FDAPDE_SOLVER_CG_FUSED = 4,
+       FDAPDE_SOLVER_GMRES = 5 /* restarted GMRES(50), Jacobi-scaled; one-GPU contexts */ };
 /* ROWS: row-owner sweep (default; no atomics, bitwise reproducible).  The others are element-wise scatter forms kept as measured
  * alternatives and cross-checks: ATOMIC / COLOURED = lane per (cell, row) with a slot search, fp64 atomics / one launch per colour;
  * PARTITIONED = one workgroup per cell partition, colours walked inside the workgroup, atomics only on rows shared between

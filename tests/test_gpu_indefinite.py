@@ -168,3 +168,79 @@ def test_bicgstab_restarts_after_a_breakdown(env, dim, nx, bmag):
     ref = spl.spsolve(A.tocsc(), c.force())
     assert np.linalg.norm(c.solution() - ref) <= 1e-7 * np.linalg.norm(ref)
     c.close()
+
+
+def _advection_case(capi, meshgen, dim, nx, peclet):
+    nodes, cells, bnd = meshgen.unit_square(nx) if dim == 2 else meshgen.unit_cube(nx)
+    _, f = meshgen.manufactured(dim)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(1)
+    _, _, coords = c.dofs_get()
+    d = np.array([1.0, 0.5, 0.25])[:dim]
+    c.set_operator(-capi.laplacian() + capi.advection((2.0 * peclet * nx / np.linalg.norm(d)) * d))   # cell Peclet number |b| h / 2
+    c.set_forcing(f(c.quadrature_nodes()))
+    c.set_dirichlet(0.2 * coords[:, 0])
+    c.init()
+    return c, nd
+
+
+@pytest.mark.parametrize("dim,nx,peclet", [(2, 32, 150.0), (2, 32, 500.0), (2, 64, 1000.0), (2, 128, 150.0), (3, 10, 1000.0)])
+def test_auto_ends_in_gmres_where_bicgstab_gives_up(env, dim, nx, peclet):
+    """cell Peclet numbers of 150 - 1000: BiCGStab's recurrences stall or blow up, restarts included; the reference's LU solves
+    what it is given (fem_linear_elliptic_solver.h:38-47).  With the method left open the solve ends in restarted GMRES(50) on the same scaled
+    system and must reach the LU solution; info.method_used names the stage that produced the answer; knob auto_gmres 0 shows what it was before."""
+    import scipy.sparse.linalg as spl
+
+    capi, meshgen = env
+    c, nd = _advection_case(capi, meshgen, dim, nx, peclet)
+    info = c.solve(rtol=1e-10, raise_on_noconv=False)
+    assert info.converged == 1 and info.relres <= 1e-10
+    assert info.method_used in (capi.SOLVER_GMRES, capi.SOLVER_BICGSTAB)
+    A = _csr(c, capi, capi.MAT_STIFF, nd)
+    ref = spl.spsolve(A.tocsc(), c.force())
+    assert np.linalg.norm(c.solution() - ref) <= 1e-7 * np.linalg.norm(ref)
+    if info.method_used == capi.SOLVER_GMRES:   # (the tail did the work: without it the call reports failure, as before)
+        c.tune("auto_gmres", 0)
+        before = c.solve(rtol=1e-10, raise_on_noconv=False)
+        assert before.converged == 0 and before.method_used == capi.SOLVER_BICGSTAB
+        c.tune("auto_gmres", 1)
+    # a method named explicitly is never replaced: BiCGStab pinned reports its failure / GMRES pinned solves it by itself
+    g = c.solve(method=capi.SOLVER_GMRES, rtol=1e-10, raise_on_noconv=False)
+    assert g.converged == 1 and g.method_used == capi.SOLVER_GMRES
+    assert np.linalg.norm(c.solution() - ref) <= 1e-7 * np.linalg.norm(ref)
+    c.close()
+
+
+def test_gmres_on_a_plain_elliptic_problem(env):
+    """GMRES named explicitly on a symmetric positive definite system: the same solution as CG (restart lengths 50 and 20)"""
+    capi, meshgen = env
+    c, nd, bdofs, coords = _setup(capi, meshgen, 3, 8, 1, 1.0)
+    c.set_dirichlet(0.2 * coords[:, 0])
+    c.init()
+    cg = c.solve(rtol=1e-11)
+    u_cg = c.solution().copy()
+    for m in (50, 20):
+        c.tune("gmres_m", m)
+        g = c.solve(method=capi.SOLVER_GMRES, rtol=1e-11)
+        assert g.converged == 1 and g.method_used == capi.SOLVER_GMRES and g.relres <= 1e-11
+        assert np.linalg.norm(c.solution() - u_cg) <= 1e-9 * np.linalg.norm(u_cg)
+    assert cg.method_used == capi.SOLVER_CG_FUSED
+    c.close()
+
+
+@pytest.mark.parametrize("dim,nx,k2", [(2, 32, 5000.0), (2, 64, 5000.0), (3, 10, 3000.0)])
+def test_strongly_indefinite_symmetric_operators(env, dim, nx, k2):
+    """-Lap u - k^2 u with hundreds of negative eigenvalues (269 of 1 089, 336 of 4 225, 595 of 1 331): the open method must end at the LU solution"""
+    import scipy.sparse.linalg as spl
+
+    capi, meshgen = env
+    c, nd, bdofs, coords = _setup(capi, meshgen, dim, nx, 1, -k2)
+    c.set_dirichlet(0.2 * coords[:, 0])
+    c.init()
+    info = c.solve(rtol=1e-10, raise_on_noconv=False)
+    assert info.converged == 1
+    A = _csr(c, capi, capi.MAT_STIFF, nd)
+    ref = spl.spsolve(A.tocsc(), c.force())
+    assert np.linalg.norm(c.solution() - ref) <= 1e-6 * np.linalg.norm(ref)
+    c.close()

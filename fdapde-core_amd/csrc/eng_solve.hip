@@ -793,7 +793,9 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
 // the original right-hand side (solve_run's warm start).  Up to kBicgRestarts times; the iterations add up in info.iters.  One-GPU contexts.
 constexpr int kBicgRestarts = 30;
 int solve_run_restarting(fdapde_ctx* c, const SolveState& ss, const double* A, const double* f_dev, const double* g_dev, const double* u0_dev,
-                         int method, double rtol, int maxit, int check_every, int n_timed, bool gmres_tail = false) {
+                         int method, double rtol, int maxit, int check_every, int n_timed, int gmres_budget = -1) {
+    // gmres_budget: -1 no GMRES stage (the caller named a method); 0: what BiCGStab left of `maxit` (a budget the caller set is a budget for the whole
+    // call); > 0: that many iterations of its own (the default budget, per stage)
     int rc = solve_run(c, ss, A, f_dev, g_dev, u0_dev, method, rtol, maxit, check_every, n_timed);
     int total = c->info.iters;
     const int64_t n = c->hs.n_dofs;
@@ -810,13 +812,14 @@ int solve_run_restarting(fdapde_ctx* c, const SolveState& ss, const double* A, c
     // The last stage where the caller left the method open (FDAPDE_SOLVER_AUTO): BiCGStab gave up -- restarts exhausted, stalled until maxit, or an
     // iterate that stopped being finite -- on a system the reference's LU would have solved (fem_linear_elliptic_solver.h:38-47; typically an
     // advection-dominated operator): restarted GMRES(m) on the same scaled system, from BiCGStab's iterate if that was any closer than zero.
-    if (gmres_tail && c->auto_gmres && rc == FDAPDE_ENOCONV && c->info.method_used == FDAPDE_SOLVER_BICGSTAB && !ss.dist && !ss.rowdist) {
+    const int gm_maxit = gmres_budget > 0 ? gmres_budget : maxit - total;
+    if (gmres_budget >= 0 && gm_maxit > 0 && c->auto_gmres && rc == FDAPDE_ENOCONV && c->info.method_used == FDAPDE_SOLVER_BICGSTAB && !ss.dist && !ss.rowdist) {
         const bool warm = std::isfinite(c->info.relres) && c->info.relres < 1.0;
         if (warm) {
             HIPCHK(c, c->restart_u.alloc((size_t)n));
             HIPCHK(c, hipMemcpyAsync(c->restart_u.p, c->u.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
         }
-        rc = solve_run(c, ss, A, f_dev, g_dev, warm ? c->restart_u.p : u0_dev, FDAPDE_SOLVER_GMRES, rtol, maxit, check_every, 0);
+        rc = solve_run(c, ss, A, f_dev, g_dev, warm ? c->restart_u.p : u0_dev, FDAPDE_SOLVER_GMRES, rtol, gm_maxit, check_every, 0);
         c->info.iters += total;
     }
     return rc;
@@ -924,10 +927,11 @@ int e_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     DebugClock clk;
     const bool open_method = !opt || opt->method == FDAPDE_SOLVER_AUTO;
     const bool skip_cg = open_method && c->cg_broke_down;   // (this very matrix broke CG before: see below)
+    const int gm_budget = !open_method ? -1 : ((opt && opt->maxit > 0) ? 0 : default_maxit(c, n));   // (the GMRES stage of the open method)
     if (int rc = solve_prepare(c, A, c->have_g ? 1 : 0, &ss, c->op_symmetric && !skip_cg)) return rc;
     clk.mark("fdapde_solve: solve_prepare");
     int rc = solve_run_restarting(c, ss, A, c->force.p, c->g.p, nullptr, skip_cg ? FDAPDE_SOLVER_BICGSTAB : (opt ? opt->method : FDAPDE_SOLVER_AUTO), rtol,
-                                  maxit, check_every, opt ? opt->time_spmv : 0, open_method);
+                                  maxit, check_every, opt ? opt->time_spmv : 0, gm_budget);
     clk.mark("fdapde_solve: solve_run");
     if (rc == FDAPDE_ENOCONV && c->h_ctl[2] != 0 && (!opt || opt->method == FDAPDE_SOLVER_AUTO) && c->info.method_used != FDAPDE_SOLVER_BICGSTAB &&
         !ss.dist && !ss.rowdist) {
@@ -936,7 +940,7 @@ int e_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
         // such a system all the same (fem_linear_elliptic_solver.h:38-47); so does BiCGStab.  Only where the caller left the method open.
         c->cg_broke_down = true;   // (until the matrix is assembled again)
         if (int rc2 = solve_prepare(c, A, c->have_g ? 1 : 0, &ss, false)) return rc2;
-        rc = solve_run_restarting(c, ss, A, c->force.p, c->g.p, nullptr, FDAPDE_SOLVER_BICGSTAB, rtol, maxit, check_every, opt ? opt->time_spmv : 0, true);
+        rc = solve_run_restarting(c, ss, A, c->force.p, c->g.p, nullptr, FDAPDE_SOLVER_BICGSTAB, rtol, maxit, check_every, opt ? opt->time_spmv : 0, gm_budget);
         clk.mark("fdapde_solve: solve_run (BiCGStab after a CG breakdown)");
     }
     {
@@ -1021,7 +1025,7 @@ int e_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times,
             hipLaunchKernelGGL(k_gather_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->tmp_i.p, gcol.p);
         }
         c->defer_end_sync = true;   // (the step's outcome is read inside solve_run; what follows it is ordered by the stream)
-        const bool open_step = !opt || opt->method == FDAPDE_SOLVER_AUTO;
+        const int open_step = !(!opt || opt->method == FDAPDE_SOLVER_AUTO) ? -1 : ((opt && opt->maxit > 0) ? 0 : default_maxit(c, n));
         int rc = solve_run_restarting(c, ss, kmat.p, rhs.p, gcol.p, uprev.p, step_method, rtol, maxit, check_every, 0, open_step);
         if (rc == FDAPDE_ENOCONV && c->h_ctl[2] != 0 && step_method == FDAPDE_SOLVER_AUTO && c->info.method_used != FDAPDE_SOLVER_BICGSTAB && !ss.dist &&
             !ss.rowdist) {   // M / dt + A symmetric but not positive definite (see fdapde_solve): this step again and every later one with BiCGStab
@@ -1293,7 +1297,7 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
         clk.mark("lin_solve: upload + gather issued");
         c->defer_end_sync = true;
         const int rc = solve_run_restarting(c, c->lin_state->ss, c->lin_mat.p, rhs.p, c->g.p, nullptr, method, rtol, maxit, check_every, 0,
-                                            !opt || opt->method == FDAPDE_SOLVER_AUTO);
+                                            !(!opt || opt->method == FDAPDE_SOLVER_AUTO) ? -1 : ((opt && opt->maxit > 0) ? 0 : default_maxit(c, n)));
         c->defer_end_sync = false;
         clk.mark("lin_solve: solve_run");
         if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-ORACLE_NX = 12   # cases up to this size are compared with the CPU oracle's direct solve of the WHOLE mesh as well (multi-rank parity
+ORACLE_NX = 20   # cases up to this size are compared with the CPU oracle's direct solve of the WHOLE mesh as well (multi-rank parity
                  # pinned directly, not only through the single-domain HIP solve)
 
 
@@ -232,13 +232,28 @@ def rowdist_case(rank, world, case, order, nodes, cells, bnd, part, capi, fdist,
             G = np.stack([ut(co, t) for t in times], axis=1)
             sol, inf = c_.solve_parabolic(times, G[:, 0], G, rtol=1e-11)
             assert inf.converged == 1
+            if c_ is ctx:   # every step of the rank's context ran as the row-distributed SINGLE launch (warm start through the ghost entries), not
+                assert inf.persistent == 1, "parabolic step fell back from the row-distributed launch"   # the element-partitioned multi-launch form
             out.append(sol)
         e2 = np.array([sum(np.sum((out[0][mine, j] - out[1][l2g, j][mine]) ** 2) for j in range(1, times.size))])
         allreduce(e2)
         err = float(np.sqrt(e2[0])) / np.linalg.norm(out[1][:, 1:])
-        assert err < 1e-8, err
+        assert err < 1e-9, err
+        oracle_msg = ""
+        if nx <= 12:   # ... and against the oracle's LU stepping of the whole mesh (fem_linear_parabolic_solver.h:37-72 restated), over the owned DOFs
+            from oracle import oracle as o
+
+            m = o.Mesh(np.ascontiguousarray(nodes), np.ascontiguousarray(cells, dtype=np.int32), np.ascontiguousarray(bnd, dtype=np.uint8))
+            qn_g = ref.quadrature_nodes()
+            G_g = np.stack([ut(gcoords, t) for t in times], axis=1)
+            uo, _ = o.pde_parabolic_solve(m, order, o.dt() - o.laplacian(), times, np.stack([ft(qn_g, t) for t in times], axis=1), G_g, G_g[:, 0])
+            eo = np.array([sum(np.sum((out[0][mine, j] - uo[l2g, j][mine]) ** 2) for j in range(1, times.size))])
+            allreduce(eo)
+            err_o = float(np.sqrt(eo[0])) / np.linalg.norm(uo[:, 1:])
+            assert err_o < 1e-8, err_o
+            oracle_msg = f"  vs oracle LU stepping {err_o:.1e}"
         dist.barrier()
-        print(f"rank {rank}: ok  case parab rowdist  local dofs {n_loc}  steps {times.size - 1}  err {err:.2e}")
+        print(f"rank {rank}: ok  case parab rowdist  local dofs {n_loc}  steps {times.size - 1}  err {err:.2e}{oracle_msg}")
         dist.destroy_process_group()
         return
     if case == "stall":   # one workgroup of ONE rank stops taking part: every rank must give up together (no hang) and say so the same way;

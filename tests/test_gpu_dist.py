@@ -77,7 +77,7 @@ def test_partitioned_solve_over_real_rccl(world, nx, case):
 
 
 @pytest.mark.parametrize("world,nx,case", [(2, 16, "p1"), (3, 14, "p1"), (4, 20, "p1"), (2, 40, "sq2"), (2, 8, "p2"), (4, 36, "p1"),
-                                           (2, 16, "adr1"), (3, 8, "adr2"), (2, 12, "parab"), (3, 12, "handle"), (3, 16, "stall"),
+                                           (2, 16, "adr1"), (3, 8, "adr2"), (2, 12, "parab"), (3, 10, "parab"), (3, 12, "handle"), (3, 16, "stall"),
                                            (3, 14, "p1:2level"), (2, 16, "adr1:2level"), (3, 16, "stall:2level"),
                                            (2, 12, "p1"), (3, 10, "adr1"), (2, 6, "p2"),   # small enough for the oracle's direct solve of the whole mesh
                                            (3, 12, "fail0"), (2, 12, "fail1"), (3, 12, "fail2"), (2, 12, "fail3"), (3, 12, "fail4")])

@@ -621,3 +621,81 @@ def test_wide_single_launch_matches_the_multi_launch_path(env, dim, nx, order, m
     assert np.linalg.norm(A @ u1 - b) <= 1e-9 * np.linalg.norm(b)
     assert c.solver_layout(True)[2] > 0
     c.close()
+
+
+# ---- the instantiations of rounds 3 / 4 pinned DIRECTLY to the oracle, not through another HIP path -------------------------
+@pytest.mark.parametrize("dim,nx,order,max_wg", [(2, 200, 1, 4), (2, 100, 2, 4)])
+def test_wide_form_against_the_oracle(env, oracle, dim, nx, order, max_wg):
+    """k_cg_persist<24, ...> (24 rows per thread, x in HBM between the iterations) against the oracle's assembly + direct solve on the same mesh"""
+    capi, meshgen = env
+    nodes, cells, bnd = meshgen.unit_square(nx)
+    _, f = meshgen.manufactured(dim)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(order)
+    _, _, coords = c.dofs_get()
+    g = 0.1 * coords[:, 0]
+    fq = f(c.quadrature_nodes())
+    c.set_operator(-capi.laplacian() + capi.reaction(0.5))
+    c.set_forcing(fq)
+    c.set_dirichlet(g)
+    c.init()
+    c.tune("persist_max_wg", max_wg)
+    info = c.solve(rtol=1e-11)
+    lay = c.solver_layout_kind(True)
+    assert info.persistent == 1 and info.converged == 1 and lay["rows_per_thread"] == 24, lay
+    m = oracle.Mesh(nodes, cells, bnd)
+    ref = oracle.pde_init_solve(m, order, -oracle.laplacian() + oracle.reaction(0.5), forcing_q=fq, dirichlet=g)
+    assert ref.n_dofs == nd
+    assert np.linalg.norm(c.solution() - ref.solution) <= 1e-8 * np.linalg.norm(ref.solution)
+    c.close()
+
+
+@pytest.mark.parametrize("mesh,order", [("unit_square_16", 1), ("unit_square_32", 1), ("unit_square_16", 2)])
+def test_direct_launch_against_the_oracle(env, oracle, mesh_loader, mesh, order):
+    """fdapde_lin_solve of ONE column as the zero-copy launch (PersistArgs::direct) against a sparse LU of the ORACLE's matrix"""
+    import scipy.sparse.linalg as spl
+
+    capi, _ = env
+    m = mesh_loader(mesh)
+    c = capi.Context(0)
+    c.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = c.dofs_build(order)
+    c.set_operator(-capi.laplacian() + capi.reaction(1.0))
+    c.set_forcing(np.zeros(c.sizes()["n_quadrature"] * m.n_cells))
+    c.init()
+    c.lin_compute(capi.MAT_STIFF)
+    assert c.solver_layout_kind(False)["workgroups"] == 1
+    c.tune("persist_direct", 1)
+    b = np.random.default_rng(3).standard_normal(nd)
+    x, info = c.lin_solve(b, rtol=1e-12)
+    assert info.persistent == 1 and info.converged == 1
+    od, _, ond, _ = oracle.enumerate_dofs(m, order)
+    A = oracle.assemble_operator(m, order, od, ond, -oracle.laplacian() + oracle.reaction(1.0))
+    ref = spl.splu(A.to_scipy().tocsc()).solve(b)
+    assert np.linalg.norm(x - ref) <= 1e-9 * np.linalg.norm(ref)
+    c.close()
+
+
+@pytest.mark.parametrize("mesh,order", [("unit_square", 1), ("unit_square", 2), ("unit_sphere", 2), ("c_shaped", 2)])
+def test_single_launch_bicgstab_against_the_oracle(env, oracle, mesh_loader, mesh, order):
+    """k_bicg_persist (the whole Jacobi-BiCGStab as one launch) on an advection-diffusion-reaction operator against the oracle's assembly + LU"""
+    capi, _ = env
+    m = mesh_loader(mesh)
+    c = capi.Context(0)
+    c.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = c.dofs_build(order)
+    _, _, coords = c.dofs_get()
+    dim = m.nodes.shape[1]
+    b = np.array([1.0, 0.5, 0.25])[:dim]
+    g = coords[:, 0] * coords[:, 1]
+    fq = np.ones(c.sizes()["n_quadrature"] * m.n_cells)
+    c.set_operator(-capi.laplacian() + capi.advection(b) + capi.reaction(1.0))
+    c.set_forcing(fq)
+    c.set_dirichlet(g)
+    c.init()
+    info = c.solve(rtol=1e-11)
+    assert info.converged == 1 and info.method_used == capi.SOLVER_BICGSTAB and info.persistent == 1
+    ref = oracle.pde_init_solve(m, order, -oracle.laplacian() + oracle.advection(b) + oracle.reaction(1.0), forcing_q=fq, dirichlet=g)
+    assert np.linalg.norm(c.solution() - ref.solution) <= 1e-8 * np.linalg.norm(ref.solution)
+    c.close()

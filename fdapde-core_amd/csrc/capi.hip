@@ -57,7 +57,7 @@ int fdapde_ctx_create(int device, fdapde_ctx** out) {
         if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
             hipEventCreate(&c->ev_p0) != hipSuccess || hipEventCreate(&c->ev_p1) != hipSuccess ||
-            hipHostMalloc(reinterpret_cast<void**>(&c->h_ctl), 4 * sizeof(int32_t)) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void**>(&c->h_ctl), 8 * sizeof(int32_t)) != hipSuccess ||
             hipHostMalloc(reinterpret_cast<void**>(&c->h_sc), 16 * sizeof(double)) != hipSuccess) {
             delete c;
             return FDAPDE_EHIP;
@@ -348,6 +348,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "asm_items" && (value == 0 || value == 1)) c->asm_items = value;
     else if (k == "bicg_restart" && (value == 0 || value == 1)) c->bicg_restart = value;
     else if (k == "gmres_m" && value >= 2 && value <= 200) c->gmres_m = value;
+    else if (k == "small_rows" && value >= 0) c->small_rows = value;
     else if (k == "auto_gmres" && (value == 0 || value == 1)) c->auto_gmres = value;
     else if (k == "asm_split_varying" && (value == 0 || value == 1)) c->asm_split_varying = value;
     else if (k == "asm_row_stat" && (value == 0 || value == 1)) c->asm_row_stat = value, c->stiff_stat_valid = false;

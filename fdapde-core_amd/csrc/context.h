@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <memory>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -161,6 +162,8 @@ struct SolveState {
     bool rowdist = false;   // row-distributed multi-GPU form: complete rows of the owned DOFs, one persistent launch per rank
     const uint8_t* owned = nullptr;
     int use_bnd = 0;
+    bool diag_deferred = false;   // small one-GPU systems: "every interior diagonal is positive" was ASSUMED (flag at ctl[4], read back with the
+                                  // solve's outcome instead of behind a wait of its own); the caller repeats the solve the slow way if it was wrong
 };
 struct SolveStateHolder {
     SolveState ss;
@@ -384,6 +387,10 @@ struct fdapde_ctx {
     } eval_grid;
     DBuf<double> eval_locs, eval_vals;   // locations / basis values of a call (kept between calls)
     DBuf<int32_t> eval_out;
+    std::function<int()> persist_tail;      // what run_persist enqueues behind the launch and its read-backs, before it waits (solve_run's epilogue)
+    int h_ctl_seen = 4;                      // how many words of ctl the last outcome read-back fetched into h_ctl
+    bool ev1_at_end = false;                 // fdapde_solve: solve_run records ev1 right before its final wait (no event wait of the caller's own)
+    int64_t small_rows = 8192;               // systems of up to that many DOFs take the wait-free tail (knob small_rows; 0: off)
     bool defer_end_sync = false;             // set by callers that loop over solves (parabolic steps, handle columns): solve_run does not wait for its
                                              // last kernel (the outcome is read behind a wait of its own; the rest is ordered by the stream)
     int persist_single_rows = 2048;          // knob: systems of up to that many interior rows run as ONE workgroup (no hand-off in the iteration)

@@ -305,8 +305,8 @@ int upload_space(fdapde_ctx* c) {
     }
     HIPCHK(c, c->part_b.alloc(8 * (size_t)(c->vec_grid > c->cg_grid ? c->vec_grid : c->cg_grid) + 16));   // two halves at every k_cgf_update width
     HIPCHK(c, c->sc.alloc(24));
-    HIPCHK(c, c->ctl.alloc(4));
-    HIPCHK(c, hipMemsetAsync(c->ctl.p, 0, 4 * sizeof(int32_t), st));
+    HIPCHK(c, c->ctl.alloc(8));   // [0] stop, [1] iterations, [2] breakdown, [3] positive-diagonal flag / launch gave up, [4] deferred positive-diagonal flag
+    HIPCHK(c, hipMemsetAsync(c->ctl.p, 0, 8 * sizeof(int32_t), st));
     HIPCHK(c, hipMemsetAsync(c->force.p, 0, n * sizeof(double), st));
     HIPCHK(c, hipStreamSynchronize(st));
     c->dev_ready = true;

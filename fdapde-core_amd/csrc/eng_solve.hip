@@ -287,7 +287,7 @@ int build_blocked(fdapde_ctx* c, int v) {
 
 // Dirichlet reduction + Jacobi scaling of the system matrix A (internal slots): scale, sval = diag(s) A diag(s).
 // Done once per matrix (per solve for the elliptic problem, once for all time steps of the parabolic one).
-int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss, bool symmetric) {
+int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss, bool symmetric, bool allow_defer = false) {
     const int64_t n = c->hs.n_dofs;
     hipStream_t st = c->stream;
     ss->dist = (c->comm != nullptr || c->ar_fn != nullptr) && c->halo_ready;   // multi-GPU: sub-assembled operator of this rank's cells
@@ -296,7 +296,12 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss, b
     c->sval_stale = false;
     ss->rowdist = (c->comm != nullptr || c->ar_fn != nullptr) && c->rd.ready && !ss->dist;
     if (ss->rowdist) ss->owned = c->rd.owned.p;
-    HIPCHK(c, hipMemsetAsync(c->ctl.p, 0, 4 * sizeof(int32_t), st));
+    HIPCHK(c, hipMemsetAsync(c->ctl.p, 0, 8 * sizeof(int32_t), st));
+    // small systems on one GPU (the sizes the reference is used at: a 289-DOF solve is a 130 us launch inside 250 us of wall time): no wait for
+    // the "every interior diagonal is positive" flag -- it is raised at ctl[4] and read back with the solve's outcome; the solve goes ahead as if
+    // the diagonal were positive (what an assembled elliptic operator has) and fdapde_solve repeats it the slow way in the rare other case
+    ss->diag_deferred = allow_defer && !ss->dist && !ss->rowdist && c->small_rows > 0 && n <= c->small_rows && c->comm == nullptr && c->ar_fn == nullptr;
+    int32_t* diag_flag = c->ctl.p + (ss->diag_deferred ? 4 : 3);
     if (ss->dist) {   // the diagonal is a sum over the ranks sharing a DOF
         hipLaunchKernelGGL(k_diag_extract, dim3(g1(n)), dim3(256), 0, st, n, c->diag.p, A, c->tmp_i.p);
         if (int rc = halo_sum(c, c->tmp_i.p, nullptr, 0)) return rc;
@@ -304,12 +309,16 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss, b
                            c->ctl.p + 3);
     } else {
         if (A == c->vals[FDAPDE_MAT_STIFF].p && c->stiff_stat_valid)   // (diagonal, row maximum) left by fdapde_init's sweep: same numbers, 16 B per row
-            hipLaunchKernelGGL(k_jacobi_scale_stats, dim3(g1(n)), dim3(256), 0, st, n, c->stiff_stat.p, c->bnd.p, use_bnd, c->scale.p, c->ctl.p + 3);
+            hipLaunchKernelGGL(k_jacobi_scale_stats, dim3(g1(n)), dim3(256), 0, st, n, c->stiff_stat.p, c->bnd.p, use_bnd, c->scale.p, diag_flag);
         else
-            hipLaunchKernelGGL(k_jacobi_scale, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->diag.p, A, c->bnd.p, use_bnd, c->scale.p, c->ctl.p + 3);
+            hipLaunchKernelGGL(k_jacobi_scale, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->diag.p, A, c->bnd.p, use_bnd, c->scale.p, diag_flag);
     }
-    HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    if (ss->diag_deferred) {
+        c->h_ctl[3] = 0;
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+    }
     if (ss->dist || ss->rowdist) {   // "positive diagonal" (CG admissible) must be ONE decision for all ranks: sum the per-rank flags
         c->h_sc[8] = (double)c->h_ctl[3];
         HIPCHK(c, hipMemcpyAsync(c->sbuf.p + 2, c->h_sc + 8, sizeof(double), hipMemcpyHostToDevice, st));
@@ -463,7 +472,7 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     const bool dist = ss.dist;
     const uint8_t* owned = ss.owned;
     // nothing of an earlier solve may be read as this one's outcome by a caller that sees an early return (solve_run_restarting)
-    c->h_ctl[0] = c->h_ctl[1] = c->h_ctl[2] = c->h_ctl[3] = 0;
+    c->h_ctl[0] = c->h_ctl[1] = c->h_ctl[2] = c->h_ctl[3] = 0, c->h_ctl_seen = 4;
     c->info.iters = 0, c->info.method_used = method, c->info.relres = 0, c->info.converged = 0;
     // partial pairs the SpMV leaves for the vector kernels: one per workgroup of the kernel that applies the scaled operator
     const int np_spmv = (c->bk_cur >= 0 && !dist) ? c->bk[c->bk_cur].meta.G : c->spmv_grid;
@@ -543,6 +552,7 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     int timed = 0, launched = 0;
     bool stop = false;
     bool persisted = false;
+    bool unscaled = false;   // c->u already holds the solution (the single launch's epilogue ran behind it)
     if (gmres) {
         if (int rc = ensure_sval(c)) return rc;
         if (int rc = run_gmres(c, tol2, maxit)) return rc;
@@ -558,9 +568,18 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     if (cgf && !dist && !ss.rowdist && c->persist && !c->persist_broken && c->ps[ss.use_bnd ? 1 : 0].ok && c->ps[ss.use_bnd ? 1 : 0].filled) {
         // the whole iteration as ONE launch (kernels_persist.h); it leaves sc / ctl as the loop below would
         DebugClock clk;
-        if (int rc = run_persist(c, ss.use_bnd ? 1 : 0, tol2, maxit, &persisted)) return rc;
+        // the epilogue kernel (and, for fdapde_solve, the end-of-solve event) is enqueued BEHIND the launch before the host waits for it: one wait
+        // for launch, outcome and solution together; if the launch gave up, the fall-back below redoes the epilogue from its own iterate
+        c->persist_tail = [&]() -> int {
+            hipLaunchKernelGGL(k_unscale, dim3(g1(n)), dim3(256), 0, st, n, c->scale.p, c->persist_x.p, c->gt.p, c->u.p);
+            if (c->ev1_at_end) HIPCHK(c, hipEventRecord(c->ev1, st));
+            return FDAPDE_OK;
+        };
+        const int rc_p = run_persist(c, ss.use_bnd ? 1 : 0, tol2, maxit, &persisted);
+        c->persist_tail = nullptr;
+        if (rc_p) return rc_p;
         clk.mark("solve_run: run_persist");
-        if (persisted) stop = true, launched = c->h_ctl[1];
+        if (persisted) stop = true, launched = c->h_ctl[1], unscaled = true;
     }
     if (bicg && !dist && !ss.rowdist && c->persist && c->persist_bicg && !c->persist_broken) {   // the whole BiCGStab as one launch
         const fdapde_ctx::Persist& ps = c->ps[ss.use_bnd ? 1 : 0];
@@ -731,9 +750,12 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     }
     if (cgf && c->cgf_lazy && !persisted)   // an update of x may still be pending (convergence seen at a poll, or maxit)
         hipLaunchKernelGGL(k_cgf_flush, dim3(c->vec_grid), dim3(256), 0, st, n, c->p.p, c->r.p, c->x.p, c->sc.p, c->ctl.p);
-    hipLaunchKernelGGL(k_unscale, dim3(g1(n)), dim3(256), 0, st, n, c->scale.p, persisted ? c->persist_x.p : c->x.p, c->gt.p, c->u.p);
-    HIPCHK(c, hipGetLastError());
-    if (!c->defer_end_sync) HIPCHK(c, hipStreamSynchronize(st));   // (h_ctl / h_sc were read back behind a wait of their own)
+    if (!unscaled) {
+        hipLaunchKernelGGL(k_unscale, dim3(g1(n)), dim3(256), 0, st, n, c->scale.p, persisted ? c->persist_x.p : c->x.p, c->gt.p, c->u.p);
+        HIPCHK(c, hipGetLastError());
+        if (c->ev1_at_end) HIPCHK(c, hipEventRecord(c->ev1, st));
+        if (!c->defer_end_sync) HIPCHK(c, hipStreamSynchronize(st));   // (h_ctl / h_sc were read back behind a wait of their own)
+    }
     const double bb = c->h_sc[0], rr = c->h_sc[3];
     c->info.iters = c->h_ctl[1];
     c->info.relres = bb > 0 ? sqrt(rr / bb) : 0.0;
@@ -928,11 +950,28 @@ int e_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     const bool open_method = !opt || opt->method == FDAPDE_SOLVER_AUTO;
     const bool skip_cg = open_method && c->cg_broke_down;   // (this very matrix broke CG before: see below)
     const int gm_budget = !open_method ? -1 : ((opt && opt->maxit > 0) ? 0 : default_maxit(c, n));   // (the GMRES stage of the open method)
-    if (int rc = solve_prepare(c, A, c->have_g ? 1 : 0, &ss, c->op_symmetric && !skip_cg)) return rc;
+    if (int rc = solve_prepare(c, A, c->have_g ? 1 : 0, &ss, c->op_symmetric && !skip_cg, /*allow_defer=*/true)) return rc;
     clk.mark("fdapde_solve: solve_prepare");
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));   // (a solve that ends before its epilogue -- an early refusal -- still leaves a recorded event)
+    c->ev1_at_end = true;
+    struct Ev1Guard {
+        fdapde_ctx* c;
+        ~Ev1Guard() { c->ev1_at_end = false; }
+    } ev1_guard{c};
     int rc = solve_run_restarting(c, ss, A, c->force.p, c->g.p, nullptr, skip_cg ? FDAPDE_SOLVER_BICGSTAB : (opt ? opt->method : FDAPDE_SOLVER_AUTO), rtol,
                                   maxit, check_every, opt ? opt->time_spmv : 0, gm_budget);
     clk.mark("fdapde_solve: solve_run");
+    if (ss.diag_deferred) {   // the flag the solve did not wait for
+        if (c->h_ctl_seen < 5) {   // (an outcome read-back that did not carry it: fetch it now)
+            HIPCHK(c, hipMemcpyAsync(c->h_ctl + 4, c->ctl.p + 4, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        if (c->h_ctl[4] != 0) {   // a non-positive interior diagonal after all: everything again with the decision taken up front
+            if (int rc2 = solve_prepare(c, A, c->have_g ? 1 : 0, &ss, c->op_symmetric && !skip_cg, false)) return rc2;
+            rc = solve_run_restarting(c, ss, A, c->force.p, c->g.p, nullptr, skip_cg ? FDAPDE_SOLVER_BICGSTAB : (opt ? opt->method : FDAPDE_SOLVER_AUTO), rtol,
+                                      maxit, check_every, opt ? opt->time_spmv : 0, gm_budget);
+        }
+    }
     if (rc == FDAPDE_ENOCONV && c->h_ctl[2] != 0 && (!opt || opt->method == FDAPDE_SOLVER_AUTO) && c->info.method_used != FDAPDE_SOLVER_BICGSTAB &&
         !ss.dist && !ss.rowdist) {
         // CG broke down (p.Ap <= 0): the operator is symmetric but not positive definite -- e.g. 3-D P2 with a large reaction term: the
@@ -965,8 +1004,7 @@ int e_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
         }
     }
     if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;
-    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-    HIPCHK(c, hipEventSynchronize(c->ev1));
+    HIPCHK(c, hipEventSynchronize(c->ev1));   // (recorded by solve_run behind its epilogue kernel: already reached, its final wait came after it)
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->info.t_solve_ms = ms;

@@ -389,13 +389,16 @@ int run_persist(fdapde_ctx* c, int v, double tol2, int maxit, bool* ran, bool bi
         ps.ok = false, *ran = false;   // the occupancy the runtime reports does not hold the grid: this layout never launches
         return FDAPDE_OK;
     }
-    HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, st));   // ([4]: the deferred positive-diagonal flag)
+    c->h_ctl_seen = 8;
     HIPCHK(c, hipMemcpyAsync(c->h_sc, c->sc.p, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
     if (a.time_phases) {
         c->persist_host_stats.resize(4 * (size_t)a.G);
         HIPCHK(c, hipMemcpyAsync(c->persist_host_stats.data(), c->persist_stats.p, 4 * (size_t)a.G * sizeof(double), hipMemcpyDeviceToHost, st));
     } else
         c->persist_host_stats.clear();
+    if (c->persist_tail)
+        if (int rc = c->persist_tail()) return rc;
     HIPCHK(c, hipStreamSynchronize(st));
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev_p0, c->ev_p1));

@@ -198,7 +198,7 @@ def test_pure_advection_zero_diagonal(capi):
     info = c.solve(rtol=1e-10, maxit=2000, raise_on_noconv=False)
     u = c.solution()
     assert np.all(np.isfinite(u)) and np.isfinite(info.relres)
-    assert info.method_used == capi.SOLVER_BICGSTAB
+    assert info.method_used in (capi.SOLVER_BICGSTAB, capi.SOLVER_GMRES)   # (the open method: BiCGStab, then GMRES with what is left of the budget)
     if info.converged:
         Az = sp.csr_matrix((c.matrix_values(capi.MAT_STIFF), ci, rp), shape=(nd, nd))
         bz = c.force()

@@ -31,15 +31,53 @@ namespace {
         }                                                                     \
     } while (0)
 
-template <typename T> struct Tmp {
+// Temporaries of one build come out of an ARENA: a few large slabs, bump-allocated, released together when the build ends -- instead of ~60
+// hipMalloc / hipFree pairs of 40 - 650 MB each (a hipFree waits for the device, a cold hipMalloc maps fresh pages: together a double-digit
+// share of a cold fdapde_dofs_build).  A Tmp taken from the arena is not given back before the end of the build (peak: the sum of the build's
+// temporaries, ~7 GB at C3's size, ~15 GB at C5's: small change on a 288 GB device); without an arena in scope a Tmp owns its allocation.
+struct Arena {
+    std::vector<void*> slabs;
+    char* cur = nullptr;
+    size_t left = 0;
+    static constexpr size_t kSlab = size_t(768) << 20;
+    hipError_t take(size_t bytes, void** out) {
+        bytes = (bytes + 255) & ~size_t(255);
+        if (bytes > left) {
+            const size_t sz = bytes > kSlab ? bytes : kSlab;
+            void* p = nullptr;
+            const hipError_t e = hipMalloc(&p, sz);
+            if (e != hipSuccess) return e;
+            slabs.push_back(p), cur = static_cast<char*>(p), left = sz;
+        }
+        *out = cur, cur += bytes, left -= bytes;
+        return hipSuccess;
+    }
+    ~Arena() {
+        for (void* p : slabs) (void)hipFree(p);
+    }
+};
+thread_local Arena* t_arena = nullptr;
+struct ArenaScope {
+    Arena* prev;
+    explicit ArenaScope(Arena* a) : prev(t_arena) { t_arena = a; }
+    ~ArenaScope() { t_arena = prev; }
+};
+template <typename T> struct Tmp {   // scratch buffer released on scope exit (or with the build's arena)
     T* p = nullptr;
+    size_t n = 0;
+    bool own = false;
     hipError_t alloc(size_t count) {
-        if (p) (void)hipFree(p);
+        reset();
+        n = count;
+        if (t_arena) return t_arena->take(sizeof(T) * (count ? count : 1), reinterpret_cast<void**>(&p));
+        own = true;
         return hipMalloc(reinterpret_cast<void**>(&p), sizeof(T) * (count ? count : 1));
     }
-    ~Tmp() {
-        if (p) (void)hipFree(p);
+    void reset() {
+        if (p && own) (void)hipFree(p);
+        p = nullptr, n = 0, own = false;
     }
+    ~Tmp() { reset(); }
 };
 struct Scratch {
     void* p = nullptr;
@@ -409,6 +447,8 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
     const bool blocked = blocked_rows > 0;   // layout of the blocked-ELL SpMV (kernels_persist.h, k_spmv_blocked): any number of workgroups of
                                              // ~blocked_rows rows, imports addressed by DOF id in the global vector, no board
     if (!blocked && n_wg > T) n_wg = T;
+    Arena arena;   // (declared before everything that allocates from it: released last)
+    ArenaScope arena_scope(&arena);
     Scratch sc;
     DevPersist o;
     struct Guard {
@@ -516,7 +556,7 @@ int dev_build_persist_layout(int64_t nd, int32_t max_row, const int32_t* d_rowpt
             const size_t lds = (size_t)rpw * 5 + 16;   // rpw = rows of the largest workgroup (<= kPersistRmax * T: 40 KB)
             hipLaunchKernelGGL(k_sym_walk, dim3(G), dim3(256), lds, st, wgs.p, par.p, up_k.p, up_m.p, up_loc.p, own.p);
             DP_CHK(hipGetLastError());
-            DP_CHK(hipStreamSynchronize(st));   // (the temporaries of this scope are released on leaving it)
+            if (!t_arena) DP_CHK(hipStreamSynchronize(st));   // (temporaries that own their memory are released on leaving this scope)
         }
         hipLaunchKernelGGL(k_row_lengths_sym, dim3(grid_of(nd)), dim3(256), 0, st, nd, d_rowptr, d_colidx, keep.p, wg.p, own.p, len.p);
         if (int rc = exclusive_sum(sc, len.p, len_scan.p, nd + 1, st, err)) return rc;

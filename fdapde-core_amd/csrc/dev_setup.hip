@@ -31,21 +31,53 @@ namespace {
         }                                                                     \
     } while (0)
 
-template <typename T> struct Tmp {   // scratch buffer released on scope exit
+// Temporaries of one build come out of an ARENA: a few large slabs, bump-allocated, released together when the build ends -- instead of ~60
+// hipMalloc / hipFree pairs of 40 - 650 MB each (a hipFree waits for the device, a cold hipMalloc maps fresh pages: together a double-digit
+// share of a cold fdapde_dofs_build).  A Tmp taken from the arena is not given back before the end of the build (peak: the sum of the build's
+// temporaries, ~7 GB at C3's size, ~15 GB at C5's: small change on a 288 GB device); without an arena in scope a Tmp owns its allocation.
+struct Arena {
+    std::vector<void*> slabs;
+    char* cur = nullptr;
+    size_t left = 0;
+    static constexpr size_t kSlab = size_t(768) << 20;
+    hipError_t take(size_t bytes, void** out) {
+        bytes = (bytes + 255) & ~size_t(255);
+        if (bytes > left) {
+            const size_t sz = bytes > kSlab ? bytes : kSlab;
+            void* p = nullptr;
+            const hipError_t e = hipMalloc(&p, sz);
+            if (e != hipSuccess) return e;
+            slabs.push_back(p), cur = static_cast<char*>(p), left = sz;
+        }
+        *out = cur, cur += bytes, left -= bytes;
+        return hipSuccess;
+    }
+    ~Arena() {
+        for (void* p : slabs) (void)hipFree(p);
+    }
+};
+thread_local Arena* t_arena = nullptr;
+struct ArenaScope {
+    Arena* prev;
+    explicit ArenaScope(Arena* a) : prev(t_arena) { t_arena = a; }
+    ~ArenaScope() { t_arena = prev; }
+};
+template <typename T> struct Tmp {   // scratch buffer released on scope exit (or with the build's arena)
     T* p = nullptr;
     size_t n = 0;
+    bool own = false;
     hipError_t alloc(size_t count) {
-        if (p) (void)hipFree(p);
+        reset();
         n = count;
+        if (t_arena) return t_arena->take(sizeof(T) * (count ? count : 1), reinterpret_cast<void**>(&p));
+        own = true;
         return hipMalloc(reinterpret_cast<void**>(&p), sizeof(T) * (count ? count : 1));
     }
     void reset() {
-        if (p) (void)hipFree(p);
-        p = nullptr, n = 0;
+        if (p && own) (void)hipFree(p);
+        p = nullptr, n = 0, own = false;
     }
-    ~Tmp() {
-        if (p) (void)hipFree(p);
-    }
+    ~Tmp() { reset(); }
 };
 
 inline unsigned grid_of(int64_t n, int per = 256) { return (unsigned)((n + per - 1) / per); }
@@ -342,9 +374,10 @@ __device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
     for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
     return v;
 }
-template <typename T> __global__ void k_adjacent_diff_max(int64_t n, const T* off, int32_t* out_max) {   // (one atomic per wave)
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int32_t v = wave_max_i32(i < n ? (int32_t)(off[i + 1] - off[i]) : INT32_MIN);
+template <typename T> __global__ void k_adjacent_diff_max(int64_t n, const T* off, int32_t* out_max) {   // (grid-stride; one atomic per wave)
+    int32_t v = INT32_MIN;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) v = max(v, (int32_t)(off[i + 1] - off[i]));
+    v = wave_max_i32(v);
     if ((threadIdx.x & 63) == 0 && v != INT32_MIN) atomicMax(out_max, v);
 }
 __global__ void k_block_nnz_max(int64_t n_blk, int64_t nd, const int32_t* rowptr, int32_t* out_max) {
@@ -353,9 +386,10 @@ __global__ void k_block_nnz_max(int64_t n_blk, int64_t nd, const int32_t* rowptr
     const int64_t r1 = min(nd, (b + 1) * kAsmBlock);
     atomicMax(out_max, rowptr[r1] - rowptr[b * kAsmBlock]);
 }
-__global__ void k_min_i32(int64_t n, const int32_t* v, int32_t* out_min) {   // (one atomic per wave)
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int32_t m = -wave_max_i32(i < n ? -v[i] : INT32_MIN + 1);
+__global__ void k_min_i32(int64_t n, const int32_t* v, int32_t* out_min) {   // (grid-stride; one atomic per wave)
+    int32_t m = INT32_MIN + 1;   // (of the negated values)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = max(m, -v[i]);
+    m = -wave_max_i32(m);
     if ((threadIdx.x & 63) == 0) atomicMin(out_min, m);
 }
 
@@ -507,7 +541,7 @@ int morton_order(Scratch& sc, int N, int64_t n, const double* d_pts, int bits, h
     const double span = (double)((uint64_t(1) << b) - 1);
     hipLaunchKernelGGL(k_morton_keys, dim3(grid_of(n)), dim3(256), 0, st, N, n, d_pts, bb.p, span, key_a.p, idx_a.p);
     if (int rc = sort_pairs(sc, key_a.p, key_b.p, idx_a.p, d_i2e, n, N * b, st, err)) return rc;
-    DS_CHK(hipStreamSynchronize(st));   // the temporaries of this scope are freed on return
+    if (!t_arena) DS_CHK(hipStreamSynchronize(st));   // temporaries that own their memory are freed on return (an arena's live to the end of the build)
     return FDAPDE_OK;
 }
 
@@ -614,6 +648,8 @@ int dev_build_space(HostSpace& hs, const double* d_nodes, const int32_t* d_cells
         std::fprintf(stderr, "device setup %-28s %8.2f ms\n", name, ms);
         (void)hipEventRecord(ev0, st);
     };
+    Arena arena;   // (declared before everything that allocates from it: released last)
+    ArenaScope arena_scope(&arena);
     Scratch sc;
     DevSpace s;
     struct Guard {   // frees whatever has been allocated if the build fails half-way
@@ -679,7 +715,7 @@ int dev_build_space(HostSpace& hs, const double* d_nodes, const int32_t* d_cells
         DS_CHK(mn.alloc(1));
         const int32_t big = INT32_MAX;
         DS_CHK(hipMemcpyAsync(mn.p, &big, sizeof big, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_min_i32, dim3(grid_of(nd)), dim3(256), 0, st, nd, vptr.p, mn.p);
+        hipLaunchKernelGGL(k_min_i32, dim3(std::min(grid_of(nd), 512u)), dim3(256), 0, st, nd, vptr.p, mn.p);
         int32_t h = 0;
         DS_CHK(hipMemcpyAsync(&h, mn.p, sizeof h, hipMemcpyDeviceToHost, st));
         DS_CHK(hipStreamSynchronize(st));
@@ -704,7 +740,7 @@ int dev_build_space(HostSpace& hs, const double* d_nodes, const int32_t* d_cells
         hipLaunchKernelGGL(k_pattern_cols, dim3(grid_of(n_vis)), dim3(256), 0, st, n_vis, nb, vis.p, s.cdofs, pk_a.p);
         hipLaunchKernelGGL(k_scaled_offsets, dim3(grid_of(nd + 1)), dim3(256), 0, st, nd + 1, vptr.p, nb, seg.p);
         if (int rc = seg_sort_keys(sc, pk_a.p, pk.p, n_pairs, nd, seg.p, bits_of(nd), st, err)) return rc;
-        DS_CHK(hipStreamSynchronize(st));
+        if (!t_arena) DS_CHK(hipStreamSynchronize(st));
         pk_a.reset();
         DS_CHK(flag.alloc((size_t)n_pairs + 1));
         DS_CHK(pos.alloc((size_t)n_pairs + 1));
@@ -727,7 +763,7 @@ int dev_build_space(HostSpace& hs, const double* d_nodes, const int32_t* d_cells
     Tmp<int32_t> maxes;   // [0] max row, [1] max block nnz, [2] max block cells, [3] max block nodes, [4] widest adjacency slice
     DS_CHK(maxes.alloc(5));
     DS_CHK(hipMemsetAsync(maxes.p, 0, 5 * sizeof(int32_t), st));
-    hipLaunchKernelGGL(k_adjacent_diff_max<int32_t>, dim3(grid_of(nd)), dim3(256), 0, st, nd, s.rowptr, maxes.p);
+    hipLaunchKernelGGL(k_adjacent_diff_max<int32_t>, dim3(std::min(grid_of(nd), 512u)), dim3(256), 0, st, nd, s.rowptr, maxes.p);
     phase("internal CSR pattern");
 
     // ---- reference-numbering pattern + internal slot -> reference slot
@@ -813,8 +849,8 @@ int dev_build_space(HostSpace& hs, const double* d_nodes, const int32_t* d_cells
         DS_ALLOC(s.bc_vert, uint16_t, s.n_bc * 4);
         hipLaunchKernelGGL(k_block_verts, dim3(grid_of(s.n_bc)), dim3(256), 0, st, s.n_bc, nv, bc_blk.p, s.bc_cell, s.cverts, s.bn_off, s.bn_node, s.bc_vert);
         hipLaunchKernelGGL(k_block_nnz_max, dim3(grid_of(n_blk)), dim3(256), 0, st, n_blk, nd, s.rowptr, maxes.p + 1);
-        hipLaunchKernelGGL(k_adjacent_diff_max<int64_t>, dim3(grid_of(n_blk)), dim3(256), 0, st, n_blk, s.bc_off, maxes.p + 2);
-        hipLaunchKernelGGL(k_adjacent_diff_max<int64_t>, dim3(grid_of(n_blk)), dim3(256), 0, st, n_blk, s.bn_off, maxes.p + 3);
+        hipLaunchKernelGGL(k_adjacent_diff_max<int64_t>, dim3(std::min(grid_of(n_blk), 512u)), dim3(256), 0, st, n_blk, s.bc_off, maxes.p + 2);
+        hipLaunchKernelGGL(k_adjacent_diff_max<int64_t>, dim3(std::min(grid_of(n_blk), 512u)), dim3(256), 0, st, n_blk, s.bn_off, maxes.p + 3);
         DS_CHK(hipStreamSynchronize(st));
     }
     phase("block tables");
@@ -855,7 +891,7 @@ int dev_build_space(HostSpace& hs, const double* d_nodes, const int32_t* d_cells
 
     // ---- what the host side of the library keeps: permutations, boundary flags, row pointers, sizes
     int32_t h_max[5] = {0, 0, 0, 0, 0};
-    hipLaunchKernelGGL(k_adjacent_diff_max<int64_t>, dim3(grid_of(n_slices)), dim3(256), 0, st, n_slices, s.sl_off, maxes.p + 4);
+    hipLaunchKernelGGL(k_adjacent_diff_max<int64_t>, dim3(std::min(grid_of(n_slices), 512u)), dim3(256), 0, st, n_slices, s.sl_off, maxes.p + 4);
     DS_CHK(hipMemcpyAsync(h_max, maxes.p, sizeof h_max, hipMemcpyDeviceToHost, st));
     // (the permutations and the boundary flags in internal order stay on the device until host code asks: ensure_host, kHostPerm)
     hs.dof_i2e.clear(), hs.dof_e2i.clear(), hs.cell_i2e.clear(), hs.dof_bnd_i.clear();

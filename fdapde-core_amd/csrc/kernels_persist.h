@@ -24,6 +24,18 @@
 
 #include "internal.h"
 
+// A/B switches of the symmetric streaming form at 16 rows per thread (C3; tools/c3_stream_ab.sh -> profiles/r5_c3_stream_ab.txt):
+//   FDAPDE_SYM_U8    pair rows of every pass loaded together per entry step where a phase has 8 passes (1: one, the default; 2: two)
+//   FDAPDE_SYM_NT_V  cache policy of the value loads (buffer_load aux: 0 default, 2 = nt);  FDAPDE_SYM_NT_C  the same for the column-code loads
+#ifndef FDAPDE_SYM_U8
+#define FDAPDE_SYM_U8 1
+#endif
+#ifndef FDAPDE_SYM_NT_V
+#define FDAPDE_SYM_NT_V 0
+#endif
+#ifndef FDAPDE_SYM_NT_C
+#define FDAPDE_SYM_NT_C 0
+#endif
 #ifndef FDAPDE_SYM_U
 #define FDAPDE_SYM_U 1
 #endif
@@ -468,8 +480,8 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
                         if (e < w[j]) {
                             const int row = o0[j] + e;
                             if constexpr (STREAM) {
-                                v[j - jg] = __builtin_amdgcn_raw_buffer_load_b128(rs_v, lane16, row * 1024, 0);
-                                c[j - jg] = __builtin_amdgcn_raw_buffer_load_b32(rs_c, lane4, row * 256, 0);
+                                v[j - jg] = __builtin_amdgcn_raw_buffer_load_b128(rs_v, lane16, row * 1024, FDAPDE_SYM_NT_V);
+                                c[j - jg] = __builtin_amdgcn_raw_buffer_load_b32(rs_c, lane4, row * 256, FDAPDE_SYM_NT_C);
                             } else v[j - jg] = reinterpret_cast<const pg_u32x4*>(ev)[row * 64 + lane], c[j - jg] = ec[row * 64 + lane];
                         }
                     }
@@ -502,7 +514,7 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
                 // instead of skipping the pass 43; the magic-number conversion below instead of the compiler's fptosi 37.5
                 // (two pair rows of every pass per step, -DFDAPDE_SYM_U=2, measured for 8 rows per thread: 3-D 754 k / 1.03 M DOFs 17.8 / 21.3 us per
                 //  iteration either way, 2-D 1.0 M 12.07 -> 11.59: this form is bound by its LDS traffic, not by loads in flight -- left at 1)
-                constexpr int U = (STREAM && NJ <= 4) ? FDAPDE_SYM_U : 1;
+                constexpr int U = !STREAM ? 1 : (NJ <= 4 ? FDAPDE_SYM_U : (NJ == 8 ? FDAPDE_SYM_U8 : 1));
                 if constexpr (U == 1) {
                     for (int e = 0; e < mw; ++e) {
                         pg_u32x4 v[NJ];

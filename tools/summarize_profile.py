@@ -3,6 +3,7 @@
 import csv
 import glob
 import os
+import re
 import sys
 from collections import defaultdict
 
@@ -15,6 +16,11 @@ def find(d, pat):
 def short(name):
     # "(anonymous namespace)::" sits in FRONT of a set-up kernel's name: strip it before cutting at the argument list's "("
     name = name.replace("(anonymous namespace)::", "")
+    m = re.search(r"rocprim::ROCPRIM_\w+::detail::trampoline_kernel<rocprim::ROCPRIM_\w+::detail::wrapped_(\w+)_config<[^,]*, ([^>]*?)>, ", name)
+    if m:   # the device primitives of the set-up (hipCUB -> rocPRIM): which primitive, on which key / value types
+        types = m.group(2).replace("rocprim::", "").replace("ROCPRIM_400200_NS::", "").replace("unsigned long", "u64").replace("empty_type", "-")
+        return f"rocprim {m.group(1)} <{types}>"
+    name = re.sub(r"rocprim::ROCPRIM_\w+::detail::", "rocprim ", name)
     name = name.split("(")[0]
     for ns in ("fdapde_hip::", "fdapde_engine::", "void "):
         name = name.replace(ns, "")

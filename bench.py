@@ -634,6 +634,10 @@ def run_ranks(args, rank, world, local_rank):
             "fallback": res.get("fallback"),
             # in-kernel phase stamps (persistent launches): per iteration, the SLOWEST rank's figure and the mean over the ranks
             "phase_stamps_us_per_iteration": res["phases"],
+            # what this record should show on `world` real MI355X (dist.predict_c3): both forms, from single-GPU measurements + an
+            # ASSUMED xGMI hop.  On a shared device (ranks_per_device > 1) the prediction does not apply: the ranks split one GPU's CUs
+            "predicted_us_per_iteration": ({f: fdist.predict_c3(world, f, iterations=max(int(info.iters), 1)) for f in ("rowdist", "peers")}
+                                           if args.workload == "c3" and args.nx == 119 else None),
         },
         "roofline": roofline_of(res["infos"], res["alg_bytes"], res["streamed_bytes"], args.nx, world),
     }

@@ -520,3 +520,40 @@ def _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, form, shar
     return dict(elapsed=float(red[0]), err=float(red[1]), t_asm=float(red[2]), t_sol=float(red[3]), setup_ms=float(red[4]), info=info, infos=infos,
                 alg_bytes=float(red[6]), streamed_bytes=float(red[7]), total_dofs=int(round(n_own[0])), n_cells_total=int(lp["n_cells_total"]),
                 parallelism=parallelism, transport=transport, t_partition=float(red[9]), form=form, comm_ranks=comm, phases=phases)
+
+
+# ---- what the first record from N real GPUs should show (the acceptance table) ----------------------------------------------------------
+# Single-GPU iteration of the single launch against the rows a GPU holds (3-D P1, measured on MI355X: DESIGN 4.0 table and BENCH_r05)
+_ITER_US_BY_ROWS = ((227e3, 9.5), (275e3, 10.9), (389e3, 13.7), (754e3, 17.8), (1.03e6, 21.3), (1.643e6, 30.0))
+XGMI_HOP_US = 1.5   # ASSUMED one-way latency of a posted 16-byte store into a peer's board over xGMI (no measurement on this pool; the first record replaces it)
+
+
+def _interp_iter_us(rows):
+    pts = _ITER_US_BY_ROWS
+    if rows <= pts[0][0]:
+        return pts[0][1] * max(rows / pts[0][0], 0.6)   # (below 227 k rows the iteration is the hand-off latencies, not the rows)
+    for (r0, t0), (r1, t1) in zip(pts, pts[1:]):
+        if rows <= r1:
+            return t0 + (t1 - t0) * (rows - r0) / (r1 - r0)
+    return pts[-1][1] * rows / pts[-1][0]
+
+
+def predict_c3(world, form, interior_rows=1643032, iterations=505, n_dofs=1728000, init_ms_one_gpu=0.92):
+    """Predicted us per iteration and DOF/s of C3 on `world` MI355X for the two exchange forms, from single-GPU phase measurements + the assumed
+    xGMI hop: what the first multi-GPU record is judged against (a measurement beyond `wrong_above_us` means the form, or the canary's choice of
+    it, does not work as designed on that fabric)."""
+    rows = interior_rows / world
+    if form == "rowdist":
+        base = _interp_iter_us(rows)   # the rank's own rows as one launch on all 256 CUs (its 256-record dot gather included)
+        g = 256 * world
+        gather_extra = (0.0058 * (g - 256) + XGMI_HOP_US) if g <= 1024 else (2.5 + XGMI_HOP_US)   # one hop: a sweep of g records; two levels: + one rank-record hop
+        imports = 0.5                  # entries from other ranks arrive while the import-free passes run; what is not hidden
+        us = base + gather_extra + imports
+        per_solve_ms = 0.10            # ghost-scale exchange + one 16-byte all-reduce before the launch
+    else:                              # element-partitioned: SpMV + pack / sum launches + one grouped send / recv + one 16-byte all-reduce per iteration
+        us = max(21.5, 68.0 * rows / 1.643e6 + 6.0) + 11.0 + 2 * (8.0 + XGMI_HOP_US * (2 if world > 2 else 1)) + 8.0
+        per_solve_ms = 0.3
+    step_ms = iterations * us * 1e-3 + init_ms_one_gpu / world + 0.1 + per_solve_ms
+    return {"form": form, "world": world, "rows_per_rank": int(rows), "us_per_iteration": round(us, 1), "ms_per_step": round(step_ms, 2),
+            "dof_per_s": round(n_dofs / (step_ms * 1e-3)), "wrong_above_us": round(2.0 * us, 1),
+            "basis": "single-GPU iteration at the rank's row count (measured) + gather over all ranks' workgroups + ASSUMED xGMI hop of %.1f us" % XGMI_HOP_US}

@@ -108,6 +108,7 @@ def _check_enlarged_line(rec, world, nx):
     same number of steps next to it"""
     cfg = rec["config"]
     assert cfg["comm_ranks"] == world and cfg["canary"].startswith("passed") and cfg["fallback"] is None
+    assert "predicted_us_per_iteration" in cfg   # (filled for the full-size C3 mesh only: DESIGN 7.2's acceptance table, dist.predict_c3)
     ph = cfg["phase_stamps_us_per_iteration"]
     assert ph["operator_slowest_workgroup_slowest_rank"] >= ph["operator_mean_workgroup_mean_of_ranks"] > 0
     assert ph["allgather_slowest_rank"] >= ph["allgather_mean_of_ranks"] > 0

@@ -163,3 +163,23 @@ def test_committed_counter_passes_name_their_workload():
     assert pj.get("persist_hbm_bytes_per_solve", 0) > 0 and pj.get("hbm_bytes_per_launch", 0) > 0
     c5 = json.load(open(os.path.join(root, "profiles", "r3_c5_spmv_pmc.json")))
     assert c5.get("hbm_bytes_per_launch", 0) > 0
+
+
+def test_multi_gpu_acceptance_predictions_are_monotone():
+    """dist.predict_c3: the row-distributed form must be predicted faster with more GPUs and faster than the element-partitioned
+    exchange at every N; the "wrong above" threshold sits at twice the prediction"""
+    from fdapde_loader import load_package
+
+    load_package()
+    from fdapde_core_amd import dist
+
+    last = None
+    for world in (2, 4, 8):
+        r, p = dist.predict_c3(world, "rowdist"), dist.predict_c3(world, "peers")
+        assert r["us_per_iteration"] < p["us_per_iteration"] and r["dof_per_s"] > p["dof_per_s"]
+        assert abs(r["wrong_above_us"] - 2 * r["us_per_iteration"]) < 0.11
+        assert r["rows_per_rank"] == 1643032 // world
+        if last is not None:
+            assert r["us_per_iteration"] < last["us_per_iteration"] and r["dof_per_s"] > last["dof_per_s"]
+        last = r
+    assert 100e6 < dist.predict_c3(2, "rowdist")["dof_per_s"] < 400e6

@@ -295,10 +295,22 @@ __device__ __forceinline__ int64_t lower_bound_i64(const int32_t* a, int64_t lo,
     }
     return lo;
 }
-// one workgroup per slice: lane = threadIdx.x, visits v = threadIdx.y, + blockDim.y, ...
-__global__ void k_fill_adjacency(int64_t nd, int nb, int nbw, const int64_t* sl_off, const int32_t* lane_row, const int32_t* vptr,
+// one workgroup per slice: lane = threadIdx.x, visits v = threadIdx.y, + blockDim.y, ...  The column lists of the slice's 64 rows and the cell list
+// of its assembly block are staged in LDS once: a visit looks its cell up in the block's list and each of its nb DOFs in its row's columns -- 10 + nb 6
+// dependent steps per visit, from LDS instead of as chains of global loads (C5: 17 ms of a 67 ms dofs_build before); the slot codes of a visit leave as
+// whole 32-bit words.
+__device__ __forceinline__ int32_t lower_bound_lds(const int32_t* a, int32_t n, int32_t x) {
+    int32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (a[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+__global__ void k_fill_adjacency(int64_t nd, int nb, int nbw, int max_row, const int64_t* sl_off, const int32_t* lane_row, const int32_t* vptr,
                                  const int32_t* vis, const int32_t* cdofs, const int32_t* rowptr, const int32_t* colidx, const int64_t* bc_off,
                                  const int32_t* bc_cell, int32_t* adj, uint32_t* slotw) {
+    extern __shared__ int32_t fa_lds[];   // [kSlice][max_row] columns of the slice's rows, then the block's cell list
     const int64_t s = blockIdx.x;
     const int lane = threadIdx.x;
     const int64_t off = sl_off[s], width = sl_off[s + 1] - off;
@@ -306,21 +318,32 @@ __global__ void k_fill_adjacency(int64_t nd, int nb, int nbw, const int64_t* sl_
     const int64_t rr = lane_row ? (int64_t)lane_row[q] : q;
     const int64_t r = (rr < 0 || rr >= nd) ? nd : rr;
     const int32_t len = r < nd ? vptr[r + 1] - vptr[r] : 0;
-    const int32_t k0 = r < nd ? rowptr[r] : 0, k1 = r < nd ? rowptr[r + 1] : 0;
-    const int64_t b = r / kAsmBlock;
+    const int32_t k0 = r < nd ? rowptr[r] : 0, n_cols = r < nd ? rowptr[r + 1] - k0 : 0;
+    const int64_t b = (s * kSlice) / kAsmBlock;   // the slice's assembly block (its rows are dealt inside the block)
+    int32_t* cols = fa_lds + lane * max_row;
+    for (int32_t k = threadIdx.y; k < n_cols; k += blockDim.y) cols[k] = colidx[k0 + k];
+    int32_t* cells_l = fa_lds + kSlice * max_row;
+    const int64_t c0 = bc_off[b];
+    const int32_t n_bcl = (int32_t)(bc_off[b + 1] - c0);
+    for (int32_t i = threadIdx.y * kSlice + lane; i < n_bcl; i += kSlice * blockDim.y) cells_l[i] = bc_cell[c0 + i];
+    __syncthreads();
     for (int64_t v = threadIdx.y; v < width; v += blockDim.y) {
         const int64_t at = (off + v) * kSlice + lane;
-        uint16_t* sw = reinterpret_cast<uint16_t*>(slotw + at * nbw);
+        uint32_t* sw = slotw + at * nbw;
         if (v < len) {
             const int32_t visit = vis[vptr[r] + v];
             const int32_t cell = visit >> 4;
-            adj[at] = (int32_t)(lower_bound_i64(bc_cell, bc_off[b], bc_off[b + 1], cell) - bc_off[b]) * 16 + (visit & 15);
+            adj[at] = lower_bound_lds(cells_l, n_bcl, cell) * 16 + (visit & 15);
             const int32_t* cd = cdofs + (int64_t)cell * nb;
-            for (int j = 0; j < nb; ++j) sw[j] = (uint16_t)(lower_bound_i32(colidx, k0, k1, cd[j]) - k0);
-            for (int j = nb; j < 2 * nbw; ++j) sw[j] = 0;
+            for (int w = 0; w < nbw; ++w) {
+                const int j0 = 2 * w, j1 = 2 * w + 1;
+                const uint32_t lo = j0 < nb ? (uint32_t)lower_bound_lds(cols, n_cols, cd[j0]) & 0xffffu : 0u;
+                const uint32_t hi = j1 < nb ? (uint32_t)lower_bound_lds(cols, n_cols, cd[j1]) & 0xffffu : 0u;
+                sw[w] = lo | (hi << 16);
+            }
         } else {
             adj[at] = -1;
-            for (int j = 0; j < 2 * nbw; ++j) sw[j] = 0;
+            for (int w = 0; w < nbw; ++w) sw[w] = 0;
         }
     }
 }
@@ -884,8 +907,21 @@ int dev_build_space(HostSpace& hs, const double* d_nodes, const int32_t* d_cells
                      (long long)n_vis, (double)s.n_adj / (double)n_vis, (double)s.n_adj * nbw * 4.0 / 1e9);
     DS_ALLOC(s.adj, int32_t, s.n_adj);
     DS_ALLOC(s.slotw, uint32_t, s.n_adj * nbw);
-    hipLaunchKernelGGL(k_fill_adjacency, dim3((unsigned)n_slices), dim3(kSlice, 4), 0, st, nd, nb, nbw, s.sl_off, s.lane_row, vptr.p, vis.p,
-                       s.cdofs, s.rowptr, s.colidx, s.bc_off, s.bc_cell, s.adj, s.slotw);
+    {
+        // (the maxima of the row length and of the blocks' cell lists are needed on the host now: they size the launch's LDS)
+        int32_t h_m[3] = {0, 0, 0};
+        DS_CHK(hipMemcpyAsync(h_m, maxes.p, sizeof h_m, hipMemcpyDeviceToHost, st));
+        DS_CHK(hipStreamSynchronize(st));
+        const int max_row = h_m[0] > 0 ? h_m[0] : 1, max_cells = h_m[2];
+        const size_t lds = sizeof(int32_t) * ((size_t)kSlice * max_row + (size_t)max_cells);
+        if (lds > 150 * 1024) {
+            err = "rows too long / blocks too large for the adjacency builder's LDS staging";
+            return FDAPDE_EUNSUPPORTED;
+        }
+        if (lds > 48 * 1024) DS_CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fill_adjacency), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_fill_adjacency, dim3((unsigned)n_slices), dim3(kSlice, 4), lds, st, nd, nb, nbw, max_row, s.sl_off, s.lane_row, vptr.p, vis.p,
+                           s.cdofs, s.rowptr, s.colidx, s.bc_off, s.bc_cell, s.adj, s.slotw);
+    }
     DS_CHK(hipGetLastError());
     phase("sliced-ELL adjacency + slots");
 

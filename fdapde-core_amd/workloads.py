@@ -145,11 +145,11 @@ def run_c5(capi, meshgen, nx=87, steps=3, warmup=1, time_spmv=16, rtol=1e-10, de
         import json
         import os
 
-        pj = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r4_c5_spmv_pmc.json")))
+        pj = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r5_c5_spmv_pmc.json")))
         if nx == 87 and not out["persistent"] and pj.get("hbm_bytes_per_launch") and out.get("spmv_avg_us"):
             out["traffic"] = float(pj["hbm_bytes_per_launch"])
             out["traffic_frac"] = out["traffic"] / (out["spmv_avg_us"] * 1e-6) / 1e9 / hbm_peak_gbps
-            out["traffic_source"] = ("profiles/r4_c5_spmv_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE of k_spmv_blocked, separate rocprofv3 --pmc passes of an "
+            out["traffic_source"] = ("profiles/r5_c5_spmv_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE of k_spmv_blocked, separate rocprofv3 --pmc passes of an "
                                      "earlier run of this workload (not this run)")
     except Exception:
         pass

@@ -348,6 +348,36 @@ __global__ void k_fill_adjacency(int64_t nd, int nb, int nbw, int max_row, const
     }
 }
 
+// the same table with the searches in global memory: rows too long (or blocks too large) for the LDS staging -- a fan of 700 cells around one vertex
+__global__ void k_fill_adjacency_global(int64_t nd, int nb, int nbw, const int64_t* sl_off, const int32_t* lane_row, const int32_t* vptr,
+                                        const int32_t* vis, const int32_t* cdofs, const int32_t* rowptr, const int32_t* colidx, const int64_t* bc_off,
+                                        const int32_t* bc_cell, int32_t* adj, uint32_t* slotw) {
+    const int64_t s = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t off = sl_off[s], width = sl_off[s + 1] - off;
+    const int64_t q = s * kSlice + lane;
+    const int64_t rr = lane_row ? (int64_t)lane_row[q] : q;
+    const int64_t r = (rr < 0 || rr >= nd) ? nd : rr;
+    const int32_t len = r < nd ? vptr[r + 1] - vptr[r] : 0;
+    const int32_t k0 = r < nd ? rowptr[r] : 0, k1 = r < nd ? rowptr[r + 1] : 0;
+    const int64_t b = (s * kSlice) / kAsmBlock;
+    for (int64_t v = threadIdx.y; v < width; v += blockDim.y) {
+        const int64_t at = (off + v) * kSlice + lane;
+        uint16_t* sw = reinterpret_cast<uint16_t*>(slotw + at * nbw);
+        if (v < len) {
+            const int32_t visit = vis[vptr[r] + v];
+            const int32_t cell = visit >> 4;
+            adj[at] = (int32_t)(lower_bound_i64(bc_cell, bc_off[b], bc_off[b + 1], cell) - bc_off[b]) * 16 + (visit & 15);
+            const int32_t* cd = cdofs + (int64_t)cell * nb;
+            for (int j = 0; j < nb; ++j) sw[j] = (uint16_t)(lower_bound_i32(colidx, k0, k1, cd[j]) - k0);
+            for (int j = nb; j < 2 * nbw; ++j) sw[j] = 0;
+        } else {
+            adj[at] = -1;
+            for (int j = 0; j < 2 * nbw; ++j) sw[j] = 0;
+        }
+    }
+}
+
 // ---- block tables ----------------------------------------------------------------------------------------------------
 // visits are in row order, so the visits of assembly block b are positions [vptr[b kAsmBlock], vptr[(b + 1) kAsmBlock)): segment offsets
 __global__ void k_block_visit_offsets(int64_t n_blk, int64_t nd, const int32_t* vptr, int32_t* off) {
@@ -914,13 +944,14 @@ int dev_build_space(HostSpace& hs, const double* d_nodes, const int32_t* d_cells
         DS_CHK(hipStreamSynchronize(st));
         const int max_row = h_m[0] > 0 ? h_m[0] : 1, max_cells = h_m[2];
         const size_t lds = sizeof(int32_t) * ((size_t)kSlice * max_row + (size_t)max_cells);
-        if (lds > 150 * 1024) {
-            err = "rows too long / blocks too large for the adjacency builder's LDS staging";
-            return FDAPDE_EUNSUPPORTED;
+        if (lds > 150 * 1024) {   // (a row of hundreds of entries: the searches stay in global memory)
+            hipLaunchKernelGGL(k_fill_adjacency_global, dim3((unsigned)n_slices), dim3(kSlice, 4), 0, st, nd, nb, nbw, s.sl_off, s.lane_row, vptr.p, vis.p,
+                               s.cdofs, s.rowptr, s.colidx, s.bc_off, s.bc_cell, s.adj, s.slotw);
+        } else {
+            if (lds > 48 * 1024) DS_CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fill_adjacency), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_fill_adjacency, dim3((unsigned)n_slices), dim3(kSlice, 4), lds, st, nd, nb, nbw, max_row, s.sl_off, s.lane_row, vptr.p, vis.p,
+                               s.cdofs, s.rowptr, s.colidx, s.bc_off, s.bc_cell, s.adj, s.slotw);
         }
-        if (lds > 48 * 1024) DS_CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fill_adjacency), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_fill_adjacency, dim3((unsigned)n_slices), dim3(kSlice, 4), lds, st, nd, nb, nbw, max_row, s.sl_off, s.lane_row, vptr.p, vis.p,
-                           s.cdofs, s.rowptr, s.colidx, s.bc_off, s.bc_cell, s.adj, s.slotw);
     }
     DS_CHK(hipGetLastError());
     phase("sliced-ELL adjacency + slots");

@@ -384,7 +384,8 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss, b
         hipLaunchKernelGGL(k_scale_matrix_compact, dim3(g1(n * 16)), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, A, c->scale.p,
                            c->sp_map[v].p, c->sval.p);
         c->sp_cur = v;
-    } else if (persist && c->persist_fill_fused) {   // the launch's blocks are filled straight from A (fill_persist_scaled): no scaled copy now
+    } else if (persist && (c->persist_fill_fused || ss->diag_deferred)) {   // the launch's blocks are filled straight from A (fill_persist_scaled): no scaled copy
+                                                                           // now (small systems: one launch less in front of the solve; ensure_sval makes it on demand)
         c->sval_stale = true, c->sval_A = A;
         c->sp_cur = -1, c->sval_layout = -2;
     } else {
@@ -489,12 +490,11 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
         if (int rc = halo_sum(c, c->tmp_e.p, nullptr, 0)) return rc;
         fvec = c->tmp_e.p;
     }
-    hipLaunchKernelGGL(k_lift, dim3(g1(n)), dim3(256), 0, st, n, c->bnd.p, g_dev, ss.use_bnd, c->gt.p);
     // the lift is zero (no Dirichlet data, or homogeneous data on one GPU -- across ranks the data may differ, and every rank
-    // must take the same path through the collectives): A g~ = 0
-    if (!ss.use_bnd || (!dist && !ss.rowdist && g_dev == c->g.p && c->g_zero)) {
-        HIPCHK(c, hipMemsetAsync(c->y.p, 0, sizeof(double) * (size_t)n, st));
-    } else {
+    // must take the same path through the collectives): A g~ = 0, written by the lift kernel itself (no memset launch)
+    const bool zero_lift = !ss.use_bnd || (!dist && !ss.rowdist && g_dev == c->g.p && c->g_zero);
+    hipLaunchKernelGGL(k_lift, dim3(g1(n)), dim3(256), 0, st, n, c->bnd.p, g_dev, ss.use_bnd, c->gt.p, zero_lift ? c->y.p : (double*)nullptr);
+    if (!zero_lift) {
         launch_spmv(c, A, c->gt.p, c->y.p, nullptr, nullptr, nullptr);   // y = A g~
         if (dist)
             if (int rc = halo_sum(c, c->y.p, nullptr, 0)) return rc;

@@ -84,9 +84,12 @@ static __global__ __launch_bounds__(256) void k_scale_matrix_compact(int64_t n, 
     }
 }
 // gt = g on Dirichlet DOFs, 0 elsewhere (or all zero without Dirichlet data)
-static __global__ void k_lift(int64_t n, const uint8_t* bnd, const double* g, int use_bnd, double* gt) {
+static __global__ void k_lift(int64_t n, const uint8_t* bnd, const double* g, int use_bnd, double* gt, double* zero_y = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) gt[i] = (use_bnd && bnd[i]) ? g[i] : 0.0;
+    if (i < n) {
+        gt[i] = (use_bnd && bnd[i]) ? g[i] : 0.0;
+        if (zero_y) zero_y[i] = 0.0;   // (A g~ of a zero lift)
+    }
 }
 // bt = scale * (f - A gt)  (y holds A gt): right-hand side of the scaled interior system.
 // Cold start (u0 == nullptr): x = 0, r = bt.  Warm start: x = (u0 - gt) / scale on interior DOFs, r = bt - ax where ax holds

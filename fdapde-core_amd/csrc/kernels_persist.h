@@ -62,6 +62,9 @@ struct PersistArgs {
     const double* b_ext;              // direct: right-hand side, reference DOF order
     double* x_ext;                    // direct: solution, reference DOF order
     double* rec;                      // direct: [0] iterations, [1] final r.r, [2] ||b~||^2, [3] status + 1 (written LAST: 1 maxit, 2 converged, 3 breakdown)
+    double* hrec;                     // one-workgroup launches of fdapde_solve (G == 1, not direct): the outcome ALSO into pinned host memory, so that the
+                                      // host reads it after its one wait without device-to-host copies: [0] stop flag, [1] iterations, [2] breakdown,
+                                      // [3] gave up, [4] ctl[4] (the deferred positive-diagonal flag), [5] ||b~||^2, [6] final r.r
     const int32_t* i2e;               // direct: internal DOF -> reference DOF
     const double* scale;              // direct: Jacobi scale, internal order
     int32_t pf_steps;                 // streaming forms, != 0: the first entry step of the next operator application is touched (pulled into the L2)
@@ -865,6 +868,12 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
     } else if (g == 0 && tid == 0 && status != 3) {
         a.sc[3] = rr;
         a.ctl[0] = status == 1 ? 1 : 0, a.ctl[1] = it, a.ctl[2] = status == 2 ? 1 : 0;
+    }
+    if constexpr (!DIST) {
+        if (a.hrec != nullptr && g == 0 && tid == 0) {   // (G == 1: this workgroup's status is the launch's)
+            a.hrec[0] = status == 1 ? 1.0 : 0.0, a.hrec[1] = (double)it, a.hrec[2] = status == 2 ? 1.0 : 0.0, a.hrec[3] = status == 3 ? 1.0 : 0.0;
+            a.hrec[4] = (double)a.ctl[4], a.hrec[5] = bb, a.hrec[6] = rr;
+        }
     }
     if (stamper) {
         double* st = a.stats + 4 * (size_t)g;

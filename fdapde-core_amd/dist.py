@@ -397,6 +397,24 @@ def _bench_forms(capi, rdzv, rank, world, device, args, rtol, backend, form, sha
     return res
 
 
+def _agree(rdzv, rank, world, key, error):
+    """every rank says whether its LOCAL work up to here succeeded (error = None) -- through the rendezvous directory, which needs no communicator -- and
+    every rank learns the same verdict: a failure on ONE rank (out of memory, a refused form, a transport error) then makes ALL ranks leave together
+    instead of leaving the others inside the collectives that follow"""
+    rdzv.put(f"{key}.{rank}", (b"0" + str(error).encode()[:300]) if error is not None else b"1")
+    bad = []
+    for r in range(world):
+        v = rdzv.get(f"{key}.{r}")
+        if v[:1] != b"1":
+            bad.append((r, v[1:].decode(errors="replace")))
+    if bad:
+        raise _RankFailed("; ".join(f"rank {r}: {m}" for r, m in bad))
+
+
+class _RankFailed(RuntimeError):
+    pass
+
+
 def _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, form, share, tag):
     """bench.py's N > 1 leg: the C3 mesh split over `world` GPUs (strong scaling).  Rank 0 generates and partitions the mesh and hands
     every rank its own problem through the rendezvous directory -- no other rank materialises the whole mesh.
@@ -420,39 +438,55 @@ def _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, form, shar
         from . import workloads
 
         u_exact, f = workloads.c5_exact, workloads.c5_forcing
-    ctx = capi.Context(device=device)
-    ctx.mesh_upload(lp["nodes"], lp["cells"], lp["boundary"])
-    n_loc = ctx.dofs_build(order)
+    ctx, n_loc, local_error = None, 0, None
+    try:   # this rank's own set-up: nothing collective yet
+        ctx = capi.Context(device=device)
+        ctx.mesh_upload(lp["nodes"], lp["cells"], lp["boundary"])
+        n_loc = ctx.dofs_build(order)
+    except Exception as e:
+        local_error = f"{type(e).__name__}: {e}"
+    _agree(rdzv, rank, world, "local_setup" + tag, local_error)   # (all ranks leave here together if one of them failed)
     grp, transport = _comm_setup(capi, ctx, rdzv, rank, world, backend, tag)
     comm_ranks = ctx.comm_count()
     coords = lp["nodes"]
-    if form == "rowdist":
-        if share > 1:
-            ctx.tune("rowdist_share", share)
-        key, own = lp["key"], lp["owner"]
-        if order == 2:   # keys / owners of the edge DOFs from the rank's own DOF table (3-D: the library's boundary rule for edges -- both end
-                         # nodes on the boundary -- already is the whole mesh's)
-            table, _, coords = ctx.dofs_get()
-            key, own = rowdist_keys_owners(dict(l2g=lp["l2g"], cells=lp["cells"]), table, lp["node_owner"], int(lp["n_nodes_total"]), 2)
-        ctx.rowdist_setup(key, own)
-        mine = own == rank
-        msg = grp.max([float(lp["nodes"].shape[0] - int(mine.sum())), float(lp["cells"].shape[0])])
-    else:
-        # neighbour-only exchange: per-peer packed segments (ncclSend / ncclRecv in one group), then the scalar all-reduce
-        pr, po = lp["peer_rank"], lp["peer_off"]
-        if form == "peers":
-            ctx.halo_setup_peers(pr, po, lp["peer_dof"], lp["owned"])
+    local_error, mine, msg_in = None, None, [0.0, 0.0]
+    try:   # the rank's exchange lists: local work again
+        if form == "rowdist":
+            if share > 1:
+                ctx.tune("rowdist_share", share)
+            key, own = lp["key"], lp["owner"]
+            if order == 2:   # keys / owners of the edge DOFs from the rank's own DOF table (3-D: the library's boundary rule for edges -- both end
+                             # nodes on the boundary -- already is the whole mesh's)
+                table, _, coords = ctx.dofs_get()
+                key, own = rowdist_keys_owners(dict(l2g=lp["l2g"], cells=lp["cells"]), table, lp["node_owner"], int(lp["n_nodes_total"]), 2)
+            ctx.rowdist_setup(key, own)
+            mine = own == rank
+            msg_in = [float(lp["nodes"].shape[0] - int(mine.sum())), float(lp["cells"].shape[0])]
         else:
-            ctx.halo_setup(int(lp["n_if_global"]), lp["local_dof"], lp["if_index"], lp["owned"])
-        mine = lp["owned"] != 0
-        msg = grp.max([float(8 * int(po[-1])), float(pr.size)])   # bytes sent per exchange, peers
-    qn = ctx.quadrature_nodes()
-    ctx.set_operator(workloads.c5_operator(capi) if c5 else -capi.laplacian())
-    ctx.set_forcing(f(qn))
-    ctx.set_dirichlet(np.zeros(n_loc))
-    del qn
-    if form != "rowdist":
-        ctx.solver_prepare(True)   # set-up (untimed): solver layout of this rank's sub-mesh
+            # neighbour-only exchange: per-peer packed segments (ncclSend / ncclRecv in one group), then the scalar all-reduce
+            pr, po = lp["peer_rank"], lp["peer_off"]
+            if form == "peers":
+                ctx.halo_setup_peers(pr, po, lp["peer_dof"], lp["owned"])
+            else:
+                ctx.halo_setup(int(lp["n_if_global"]), lp["local_dof"], lp["if_index"], lp["owned"])
+            mine = lp["owned"] != 0
+            msg_in = [float(8 * int(po[-1])), float(pr.size)]   # bytes sent per exchange, peers
+    except Exception as e:
+        local_error = f"{type(e).__name__}: {e}"
+    _agree(rdzv, rank, world, "exchange_setup" + tag, local_error)
+    msg = grp.max(msg_in)
+    local_error = None
+    try:
+        qn = ctx.quadrature_nodes()
+        ctx.set_operator(workloads.c5_operator(capi) if c5 else -capi.laplacian())
+        ctx.set_forcing(f(qn))
+        ctx.set_dirichlet(np.zeros(n_loc))
+        del qn
+        if form != "rowdist":
+            ctx.solver_prepare(True)   # set-up (untimed): solver layout of this rank's sub-mesh
+    except Exception as e:
+        local_error = f"{type(e).__name__}: {e}"
+    _agree(rdzv, rank, world, "problem_setup" + tag, local_error)   # (before the first collective step)
 
     def step(time_spmv=0):
         ctx.init()

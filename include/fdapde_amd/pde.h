@@ -427,10 +427,14 @@ template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_H
         fdapde::hip::context_handle ctx_;   // keeps the PDE's context alive; acts on it (the handle's matrix is no part of the PDE's state)
         bool computed_ = false;
     };
+    // The handle works on the context this PDE holds NOW.  Copy the PDE afterwards and then change the original (init / solve / a setter): the
+    // original leaves with a clone and the handle stays with the context the copy kept (fdapde_hip.hpp, observer()'s lifetime rule) -- take the
+    // handle after the last copy, or from the object that is kept; attached_to(pde) tells.
     SparseSolver make_solver() {
         ctx_.unique();   // the handle works on THIS object's context, not on one still shared with a copy
         return SparseSolver(ctx_.observer());
     }
+    bool owns_context_of(const SparseSolver& s) const { return s.ctx_.shared_with(ctx_); }
     fdapde_ctx* context() const { return ctx_.get(); }   // the C-ABI context (for entry points the facade does not wrap)
 
     // PDE__::eval_basis (pde/pde.h:149-158): 0 = Sampling::pointwise (locs: n_locs x N coordinates), 1 = Sampling::areal (locs:

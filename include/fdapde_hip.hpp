@@ -76,12 +76,17 @@ class context_handle {
     }
     bool shared() const { return s_ && s_->owners > 1; }
     // a handle that keeps the context alive and follows none of the copy-on-write rules: for helper objects that act ON the owner's
-    // context (the factor-once solver handle a PDE gives out)
+    // context (the factor-once solver handle a PDE gives out).
+    // LIFETIME RULE: an observer is bound to the context its owner held WHEN IT WAS TAKEN.  If the owner is copied afterwards and
+    // then changes its problem state, the owner leaves with a clone (copy-on-write) and the observer keeps acting on the context that now
+    // belongs to the copy alone.  Take the observer after the last copy of the owner, or from the object that is kept; an observer never
+    // outlives its usefulness silently -- shared_with(owner) tells whether the two still mean the same context.
     context_handle observer() const {
         context_handle h;
         h.s_ = s_, h.counted_ = false;
         return h;
     }
+    bool shared_with(const context_handle& other) const { return s_ && s_ == other.s_; }
     explicit operator bool() const { return s_ && s_->ctx; }
 
    private:

@@ -247,6 +247,9 @@ def test_device_memory_does_not_drift_over_context_lifetimes(capi):
         assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
         return f.value
 
+    import gc
+
+    gc.collect()   # (contexts earlier tests of the session left to the collector must not be released in the middle of this measurement)
     nodes, cells, bnd = meshgen.unit_cube(12)
     n2, c2, b2 = meshgen.unit_square(40)
     seen = []

@@ -348,6 +348,11 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "asm_items" && (value == 0 || value == 1)) c->asm_items = value;
     else if (k == "bicg_restart" && (value == 0 || value == 1)) c->bicg_restart = value;
     else if (k == "gmres_m" && value >= 2 && value <= 200) c->gmres_m = value;
+    else if (k == "persist_exp_lds" && (value == 0 || value == 1)) {
+        c->persist_exp_lds = value;
+        c->ps[0].tried = c->ps[0].ok = c->ps[1].tried = c->ps[1].ok = false, c->scaled_owner = fdapde_ctx::kScaledNone;
+        fdapde_engine::drop_graph(c);
+    }
     else if (k == "small_rows" && value >= 0) c->small_rows = value;
     else if (k == "auto_gmres" && (value == 0 || value == 1)) c->auto_gmres = value;
     else if (k == "asm_split_varying" && (value == 0 || value == 1)) c->asm_split_varying = value;

@@ -201,6 +201,7 @@ struct fdapde_ctx {
     DBuf<uint8_t> mesh_nbnd;
     bool mesh_on_dev = false;
     DBuf<double> gm_V, gm_b, gm_s, gm_part;   // restarted GMRES (kernels_gmres.h): basis (m + 1) x n, scaled right-hand side, small state, partial sums
+    int persist_exp_lds = 1;                  // knob: the symmetric streaming launch keeps its export list in LDS where there is room
     int gmres_m = 50;                         // restart length (knob gmres_m)
     int auto_gmres = 1;                       // FDAPDE_SOLVER_AUTO ends in GMRES after BiCGStab gave up (knob auto_gmres)
     bool dev_built = false;             // the index structures were built on the device (dev_setup.hip); big host mirrors are lazy
@@ -327,6 +328,7 @@ struct fdapde_ctx {
         DBuf<int32_t> slot_dof, sl_off, ell_src, exp_off, imp_off, imp_pos;
         DBuf<int32_t> ell_col;               // column DOF of every entry (fill_persist_scaled; built on first use)
         bool stream = false;                 // the blocks do not fit the LDS: streaming instantiation
+        bool exp_lds = false;                // symmetric streaming form: the export list rides in LDS (lds_bytes includes it)
         DBuf<int64_t> ell_off;
         DBuf<uint16_t> ell_code, exp_slot;
         DBuf<double> ell_val;

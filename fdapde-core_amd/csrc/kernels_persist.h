@@ -62,6 +62,8 @@ struct PersistArgs {
     const double* b_ext;              // direct: right-hand side, reference DOF order
     double* x_ext;                    // direct: solution, reference DOF order
     double* rec;                      // direct: [0] iterations, [1] final r.r, [2] ||b~||^2, [3] status + 1 (written LAST: 1 maxit, 2 converged, 3 breakdown)
+    int32_t exp_lds;                  // symmetric streaming form: the workgroup's export list (slot codes) is staged in LDS once (the host found room for it)
+                                      // instead of being re-read from global memory in front of every iteration's export stores
     double* hrec;                     // one-workgroup launches of fdapde_solve (G == 1, not direct): the outcome ALSO into pinned host memory, so that the
                                       // host reads it after its one wait without device-to-host copies: [0] stop flag, [1] iterations, [2] breakdown,
                                       // [3] gave up, [4] ctl[4] (the deferred positive-diagonal flag), [5] ||b~||^2, [6] final r.r
@@ -279,6 +281,16 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
     // ---- stage the workgroup's tables (and, resident form, its block of the matrix)
     const int32_t* impl = PLDS ? a.imp_pos + a.imp_off[g] : impl_l;
     const uint16_t* expl = PLDS ? a.exp_slot + a.exp_off[g] : expl_l;
+    if constexpr (SYM && STREAM && !DIST) {
+        // the export list behind the accumulator table where the host found room (C3: 5.4 KB of the 6 KB the workgroup had left): the global re-read
+        // of the codes put a round trip in front of the export stores of every iteration, and those sit in front of the matrix stream (vmcnt is in
+        // order) -- a fit of the operator-phase stamps priced an export at 3.8 stored entries
+        if (a.exp_lds) {
+            uint16_t* expl_s = reinterpret_cast<uint16_t*>(y_tab + S);
+            for (int i = tid; i < E; i += T) expl_s[i] = a.exp_slot[a.exp_off[g] + i];
+            expl = expl_s;   // (visible to all threads after the barrier that follows the staging of the tables)
+        }
+    }
     if constexpr (!PLDS) {
         for (int i = tid; i < H; i += T) impl_l[i] = a.imp_pos[a.imp_off[g] + i];
         for (int i = tid; i < E; i += T) expl_l[i] = a.exp_slot[a.exp_off[g] + i];

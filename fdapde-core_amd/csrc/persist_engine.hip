@@ -160,6 +160,9 @@ int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_r
     }
     ps.lds_cap = ps.stream ? 0 : (int32_t)need, ps.imp_cap = imp_cap;
     ps.lds_bytes = fixed + (ps.stream ? 0 : 10 * (size_t)need);
+    // symmetric streaming form: the export list too, where the workgroup has room left (the kernel's static arrays take ~0.6 KB of the 160)
+    ps.exp_lds = pl.sym && ps.stream && pl.R <= kPersistRmax && ps.lds_bytes + 2 * (size_t)exp_cap + 1024 <= 160 * 1024 && c->persist_exp_lds;
+    if (ps.exp_lds) ps.lds_bytes += 2 * (size_t)exp_cap;
     hipStream_t st = c->stream;
     if (on_device) {
         if (std::getenv("FDAPDE_SETUP_CHECK")) {
@@ -221,6 +224,7 @@ int launch_persist(fdapde_ctx* c, fdapde_ctx::Persist& ps, PersistArgs& a, bool 
     a.ell_val = ps.ell_val.p, a.exp_off = ps.exp_off.p, a.exp_slot = ps.exp_slot.p, a.imp_off = ps.imp_off.p, a.imp_pos = ps.imp_pos.p;
     if (!dist && a.n_cols <= 1) a.pboard = ps.board.p, a.dboard = ps.board.p + 2 * (size_t)ps.meta.n_board;   // (row-distributed, several columns: set by the caller)
     if (!dist) a.wg_late = ps.wg_late.p;
+    a.exp_lds = (!dist && !bicg && ps.exp_lds) ? 1 : 0;
     a.amax_bits = ps.amax.p, a.max_len = c->hs.max_row, a.stats = c->persist_stats.p;
     a.timeout_ticks = c->persist_timeout_us * 100, a.debug_stall_it = c->persist_debug_stall, a.pf_steps = c->persist_prefetch;
     if (!dist && ps.epoch_next > 0xC0000000u - 2u * (uint32_t)a.maxit) {   // (the tags are 32 bits wide: start over on clean boards)

@@ -86,7 +86,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
             b->release();
         c->cols_ctl.release(), c->eval_grid.release(), c->eval_locs.release(), c->eval_vals.release(), c->eval_out.release();
         for (auto& b : c->coef) b.release();
-        c->slotw.release(), c->sl_off.release(), c->lane_row.release(), c->fq_blk.release(), c->bnd.release(), c->tables.release(), c->reftab.release(), c->lin_sq.release();
+        c->slotw.release(), c->sl_off.release(), c->lane_row.release(), c->fq_blk.release(), c->bnd.release(), c->tables.release(), c->reftab.release(), c->reftab_sym.release(), c->lin_sq.release();
         c->bc_off.release(), c->bn_off.release(), c->bc_cell.release(), c->bn_node.release(), c->bc_vert.release();
         c->halo_dof.release(), c->halo_pos.release(), c->owned.release(), c->hbuf.release(), c->sbuf.release();
         c->halo_inv.release(), c->if_slot.release();
@@ -346,6 +346,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "asm_fq_block" && (value == 0 || value == 1)) c->asm_fq_block = value;
     else if (k == "asm_fuse_mass" && value >= 0 && value <= 3) c->asm_fuse_mass = value;
     else if (k == "asm_items" && (value == 0 || value == 1)) c->asm_items = value;
+    else if (k == "asm_items_fuse" && (value == 0 || value == 1)) c->asm_items_fuse = value;
     else if (k == "bicg_restart" && (value == 0 || value == 1)) c->bicg_restart = value;
     else if (k == "gmres_m" && value >= 2 && value <= 200) c->gmres_m = value;
     else if (k == "persist_exp_lds" && (value == 0 || value == 1)) {

@@ -24,6 +24,7 @@
 namespace fdapde_hip {
 struct DevTables;        // kernels_assembly.h (the context only holds device buffers of them)
 struct DevRefTensors;
+struct DevRefTensorsSym;
 }
 
 using namespace fdapde_hip;
@@ -225,6 +226,7 @@ struct fdapde_ctx {
     int asm_items = 1;        // knob: 0 = spaces with dealt rows (P2) keep the row-walking sweep instead of the visit-parallel one (k_assemble_items)
     int32_t asm_max_visits = -1;   // longest visit list of the space (computed on first use; -1 = not yet)
     int asm_fuse_mass = 1;    // knob: fdapde_init accumulates the mass matrix in the operator's sweep where both accumulator ranges fit the LDS
+    int asm_items_fuse = 1;   // knob: the visit-parallel sweep (P2) accumulates operator AND mass matrix in one sweep where both accumulator ranges fit the CU
     int asm_fq_bc = 1;        // knob: keep the block-cell ordered copy (1) or let the sweep gather from the cell-ordered samples (0)
     int asm_fq_block = 0;     // tuning knob: 1 = fdapde_init first reduces the forcing samples to one load coefficient per visit slot (k_visit_load_coeffs);
                               // measured on C3 with that kernel inside init's timed region: init 1.49-1.53 ms against 1.23-1.26 ms for the sweep
@@ -235,6 +237,7 @@ struct fdapde_ctx {
     DBuf<uint8_t> bnd;
     DBuf<DevTables> tables;
     DBuf<DevRefTensors> reftab;
+    DBuf<DevRefTensorsSym> reftab_sym;   // the compact tensors for operators with a symmetric Kt
     DBuf<int32_t> ctl;
     DBuf<double> coef[kMaxTerms];
     bool coef_of_op = false;   // coef[] hold the space-varying data of the operator set by fdapde_set_operator (uploaded by fdapde_init)

@@ -24,7 +24,7 @@ AsmArgs asm_args(fdapde_ctx* c) {
     a.n_dofs = c->hs.n_dofs, a.n_cells = c->hs.n_cells;
     a.cverts = c->cverts.p, a.cdofs = c->cdofs.p, a.vcoords = c->vcoords.p;
     a.sl_off = c->sl_off.p, a.adj = c->adj.p, a.slotw = c->slotw.p, a.lane_row = c->lane_row.p;   // nullptr = identity
-    a.rowptr = c->rowptr.p, a.colidx = c->colidx.p, a.tables = c->tables.p, a.reftab = c->reftab.p;
+    a.rowptr = c->rowptr.p, a.colidx = c->colidx.p, a.tables = c->tables.p, a.reftab = c->reftab.p, a.ref_doubles = kRefDoubles;
     a.bc_off = c->bc_off.p, a.bc_cell = c->bc_cell.p, a.bc_vert = c->bc_vert.p, a.bn_off = c->bn_off.p, a.bn_node = c->bn_node.p;
     a.lds_nodes = c->hs.max_blk_nodes;
     return a;
@@ -75,6 +75,7 @@ int make_dev_op(fdapde_ctx* c, const std::vector<HostTerm>& terms, DevOp* out, i
     for (int r = 0; r < N; ++r)
         for (int q = 0; q < r; ++q) ksym = ksym && op.kt[r * N + q] == op.kt[q * N + r];
     op.tab_sym = (ksym && !adv) ? 1 : 0;
+    op.kt_sym = ksym ? 1 : 0;
     *out = op;
     return FDAPDE_OK;
 }
@@ -142,7 +143,9 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
         if (op.n == 1 && op.t[0].kind == FDAPDE_LAPLACIAN) opk = 1;
         if (op.n == 1 && op.t[0].kind == FDAPDE_REACTION && !op.t[0].space_varying) opk = 2;
         if (std::getenv("FDAPDE_ASM_GENERIC")) opk = 0;
-        const size_t tab = sizeof(DevTables) + (opk == 3 || opk == 5 ? sizeof(DevRefTensors) : 0) +
+        if (op.kt_sym) a.reftab = reinterpret_cast<const DevRefTensors*>(c->reftab_sym.p), a.ref_doubles = kRefSymDoubles;   // (the compact tensors)
+        else a.reftab = c->reftab.p, a.ref_doubles = kRefDoubles;
+        const size_t tab = sizeof(DevTables) + (opk == 3 || opk == 5 ? sizeof(double) * (size_t)a.ref_doubles : 0) +
                            (size_t)hs.max_blk_nodes * (M == 2 ? 2 : 3) * sizeof(double);
         size_t acc = (size_t)hs.max_blk_nnz * sizeof(double);
         // operator + mass in one sweep (a.vals2): both accumulator ranges of every block must fit the LDS, else two sweeps as before
@@ -179,7 +182,8 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
                     const int grid_i = 8 * (int)(((hs.n_dofs + kAsmBlock - 1) / kAsmBlock + 7) / 8);
                     if (std::getenv("FDAPDE_DEBUG_ASM"))
                         std::fprintf(stderr, "assembly launch <%d,%d> opk %d, visit-parallel: grid %d x %d threads, LDS %zu B dynamic (tables %zu + accumulators %zu), longest visit list %d, %s\n",
-                                     M, R, opk, grid_i, opk == 4 ? 512 : 1024, lds_items, tab, acc_all, c->asm_max_visits, want_mass2 ? "mass as second sweep" : "one matrix");
+                                     M, R, opk, grid_i, opk == 4 ? 512 : 1024, lds_items, tab, acc_all, c->asm_max_visits,
+                                     !want_mass2 ? "one matrix" : (c->asm_items_fuse && (opk == 3 || opk == 1) && lds_items + acc_all + 4 * 1024 <= (size_t)160 * 1024) ? "operator and mass in ONE sweep (second accumulator range)" : "mass as second sweep");
 #define ITEMS_GO(OPK_, M2_, TH_)                                                                                                          \
     do {                                                                                                                                  \
         const void* fn = reinterpret_cast<const void*>(&k_assemble_items<M, R, OPK_, M2_, TH_>);                                          \
@@ -187,6 +191,25 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
         hipLaunchKernelGGL((k_assemble_items<M, R, OPK_, M2_, TH_>), dim3(grid_i), dim3(TH_), lds_items, c->stream, a, op);               \
     } while (0)
                     const char* th_env = std::getenv("FDAPDE_ASM_ITEMS_THREADS");   // (measurements: 512 instead of 1024 threads per block)
+                    // both matrices in ONE sweep where a second accumulator range still fits the CU's LDS next to the first (3-D P2: 2 x 65 KB + 23 KB of
+                    // tables + the kernel's 3 KB of static arrays: the block owns the CU anyway): the mass rows come from the same geometry, index words
+                    // and accumulation rounds instead of a second sweep over the block's items (knob asm_items_fuse 0: the second sweep)
+                    const size_t lds_two = lds_items + acc_all;
+                    if (want_mass2 && c->asm_items_fuse && (opk == 3 || opk == 1) && lds_two + 4 * 1024 <= (size_t)160 * 1024 && !(th_env && std::atoi(th_env) == 512)) {
+                        const size_t lds_one = lds_items;
+                        (void)lds_one;
+#define ITEMS_GO2(OPK_)                                                                                                                   \
+    do {                                                                                                                                  \
+        const void* fn = reinterpret_cast<const void*>(&k_assemble_items<M, R, OPK_, 1, 1024>);                                           \
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_two);                                          \
+        hipLaunchKernelGGL((k_assemble_items<M, R, OPK_, 1, 1024>), dim3(grid_i), dim3(1024), lds_two, c->stream, a, op);                 \
+    } while (0)
+                        if (opk == 3) ITEMS_GO2(3);
+                        else ITEMS_GO2(1);
+#undef ITEMS_GO2
+                        HIPCHK(c, hipGetLastError());
+                        return FDAPDE_OK;
+                    }
                     if (want_mass2 && th_env && std::atoi(th_env) == 512) {
                         if (opk == 3) ITEMS_GO(3, 2, 512);
                         else ITEMS_GO(1, 2, 512);
@@ -284,7 +307,9 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
             if (!op.needs_rows) opk = 3;
             if (op.n == 1 && op.t[0].kind == FDAPDE_LAPLACIAN) opk = 1;
             if (op.n == 1 && op.t[0].kind == FDAPDE_REACTION && !op.t[0].space_varying) opk = 2;
-            const size_t lds = sizeof(DevTables) + (opk == 3 ? sizeof(DevRefTensors) : 0);
+            if (op.kt_sym) a.reftab = reinterpret_cast<const DevRefTensors*>(c->reftab_sym.p), a.ref_doubles = kRefSymDoubles;
+            else a.reftab = c->reftab.p, a.ref_doubles = kRefDoubles;
+            const size_t lds = sizeof(DevTables) + (opk == 3 ? sizeof(double) * (size_t)a.ref_doubles : 0);
 #define PART_GO(K_)                                                                                                            \
     hipLaunchKernelGGL((k_assemble_part<M, R, K_>), dim3((unsigned)c->n_parts), dim3(256), lds, c->stream, a, op, c->part_cells.p, \
                        c->part_off.p, c->part_colours, c->part_shared.p, c->part_slots.p)

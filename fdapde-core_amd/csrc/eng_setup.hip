@@ -251,6 +251,16 @@ int upload_space(fdapde_ctx* c) {
                     rt.ctab[k * nn + i * nb + j] = v;
                 }
         HIPCHK(c, c->reftab.upload(&rt, 1, st));
+        auto rs_own = std::make_unique<DevRefTensorsSym>();
+        DevRefTensorsSym& rs = *rs_own;
+        std::memset(&rs, 0, sizeof rs);
+        for (int i = 0; i < nn; ++i) {
+            for (int k = 0; k < 3; ++k) rs.kdiag[k * nn + i] = rt.ktab[(k * 3 + k) * nn + i], rs.ctab[k * nn + i] = rt.ctab[k * nn + i];
+            rs.ksum[0 * nn + i] = rt.ktab[(0 * 3 + 1) * nn + i] + rt.ktab[(1 * 3 + 0) * nn + i];   // pairs (k, l), k < l, at index k + l - 1
+            rs.ksum[1 * nn + i] = rt.ktab[(0 * 3 + 2) * nn + i] + rt.ktab[(2 * 3 + 0) * nn + i];
+            rs.ksum[2 * nn + i] = rt.ktab[(1 * 3 + 2) * nn + i] + rt.ktab[(2 * 3 + 1) * nn + i];
+        }
+        HIPCHK(c, c->reftab_sym.upload(&rs, 1, st));
         HIPCHK(c, hipStreamSynchronize(st));
     }
     const size_t n = (size_t)hs.n_dofs, nnz = (size_t)hs.nnz;

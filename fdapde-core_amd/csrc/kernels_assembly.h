@@ -32,6 +32,7 @@ struct DevOp {
     //   form = -(g_i . Kt g_j) + psi_i (g_j . bt) + ct psi_i psi_j,  Kt = sum coef K (Laplacian: coef I), bt = sum coef b, ct = sum coef c
     double kt[9], bt[3], ct;
     int32_t tab_sym;      // Kt symmetric and no advection: evaluate in the bitwise-symmetric order
+    int32_t kt_sym;       // Kt symmetric (with or without advection): AsmArgs::reftab holds the compact tensors (DevRefTensorsSym)
     int32_t var_kinds;    // which kinds have a space-varying leaf: 1 diffusion, 2 advection, 4 reaction (kt / bt / ct sum the CONSTANT leaves only)
 };
 
@@ -53,6 +54,16 @@ struct DevRefTensors {
     double ctab[3 * kMaxBasis * kMaxBasis];
 };
 constexpr int kRefDoubles = sizeof(DevRefTensors) / sizeof(double);
+// ... and where the summed diffusion tensor Kt is symmetric (every Laplacian, every symmetric K: advection or not), the COMPACT form of the same tensors:
+//   kdiag[k*NN + i*NB + j] = ktab[(k,k)]   ksum[p*NN + ...] = ktab[(k,l)] + ktab[(l,k)], p = (0,1), (0,2), (1,2) -- the sum the symmetric evaluation
+//   formed per entry at run time, made once on the host (the same fp64 add: the same bits)   ctab as above
+// J^-1 Kt J^-T is then evaluated as a symmetric tensor: 6 + 3 + 1 table reads and multiply-adds per entry instead of 9 + 3 + 1, and 2.4 KB less of LDS.
+struct DevRefTensorsSym {
+    double kdiag[3 * kMaxBasis * kMaxBasis];
+    double ksum[3 * kMaxBasis * kMaxBasis];
+    double ctab[3 * kMaxBasis * kMaxBasis];
+};
+constexpr int kRefSymDoubles = sizeof(DevRefTensorsSym) / sizeof(double);
 
 struct AsmArgs {
     int64_t n_dofs, n_cells;
@@ -66,7 +77,8 @@ struct AsmArgs {
     const int32_t* rowptr;
     const int32_t* colidx;
     const DevTables* tables;
-    const DevRefTensors* reftab;   // OPK 3 only
+    const DevRefTensors* reftab;   // OPK 3 / 5 only; DevRefTensorsSym where DevOp::kt_sym
+    int32_t ref_doubles;           // ... and how many doubles of it the kernels stage in LDS
     double* vals;              // CSR values (internal slots) or nullptr
     double* vals2;             // k_assemble_rows<..., MASS2>: the mass matrix, assembled by the same launch
     const int32_t* diag;       // CSR slot of every row's diagonal (row_stat only)
@@ -349,24 +361,34 @@ __device__ __forceinline__ double element_row(const AsmArgs& a, const DevOp& op,
             for (int r = 0; r < M; ++r) bv += g.invJ[k][r] * op.bt[r];
             beta[k] = bv;
         }
-        if (sym) {
+        const bool ksym = op.kt_sym != 0;   // (sym implies ksym)
+        if (ksym) {
 #pragma unroll
             for (int k = 0; k < M; ++k)
 #pragma unroll
                 for (int l = 0; l < k; ++l) Gp[k][l] = Gp[l][k];
         }
+        const DevRefTensorsSym* rs = reinterpret_cast<const DevRefTensorsSym*>(rt);
         const double* kt = rt->ktab + il * NB;
-        const double* ct = rt->ctab + il * NB;
+        const double* ct = ksym ? rs->ctab + il * NB : rt->ctab + il * NB;
+        const double* kd = rs->kdiag + il * NB;
+        const double* ks = rs->ksum + il * NB;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             double d = 0;
-            if (sym) {
+            if (ksym) {   // the symmetric tensor: diagonal terms, then the pairs k < l in the order (0,1), (0,2), (1,2) against the pre-summed table
 #pragma unroll
-                for (int k = 0; k < M; ++k) d += Gp[k][k] * kt[(k * 3 + k) * NN + j];
+                for (int k = 0; k < M; ++k) d += Gp[k][k] * kd[k * NN + j];
+                int pr = 0;
 #pragma unroll
                 for (int k = 0; k < M; ++k)
 #pragma unroll
-                    for (int l = k + 1; l < M; ++l) d += Gp[k][l] * (kt[(k * 3 + l) * NN + j] + kt[(l * 3 + k) * NN + j]);
+                    for (int l = k + 1; l < M; ++l) {
+                        // (pair index in the 3-D enumeration: (0,1) -> 0, (0,2) -> 1, (1,2) -> 2; in 2-D only (0,1))
+                        d += Gp[k][l] * ks[(k + l - 1) * NN + j];
+                        ++pr;
+                    }
+                (void)pr;
             } else {
 #pragma unroll
                 for (int k = 0; k < M; ++k)
@@ -578,9 +600,9 @@ static __global__ __launch_bounds__(kAsmBlock) void k_assemble_rows(AsmArgs a, D
     double* xyz = lds + kTablesDoubles;                       // the block's vertex coordinates
     if constexpr (OPK == 3 || OPK == 5) {   // reference tensors of the constant-coefficient form behind the basis tables
         const double* src = reinterpret_cast<const double*>(a.reftab);
-        for (int i = threadIdx.x; i < kRefDoubles; i += blockDim.x) xyz[i] = src[i];
+        for (int i = threadIdx.x; i < a.ref_doubles; i += blockDim.x) xyz[i] = src[i];
         rt = reinterpret_cast<const DevRefTensors*>(xyz);
-        xyz += kRefDoubles;
+        xyz += a.ref_doubles;
     }
     double* acc = xyz + (int64_t)a.lds_nodes * NP;            // the block's CSR value range
     double* acc2 = acc + a.lds_acc_cap;                       // ... of the mass matrix (MASS2; the host made sure both ranges fit)
@@ -820,12 +842,13 @@ static __global__ __launch_bounds__(THREADS) void k_assemble_items(AsmArgs a, De
     double* xyz = lds + kTablesDoubles;
     if constexpr (OPK == 3 || OPK == 5) {
         const double* src = reinterpret_cast<const double*>(a.reftab);
-        for (int i = tid; i < kRefDoubles; i += THREADS) xyz[i] = src[i];
+        for (int i = tid; i < a.ref_doubles; i += THREADS) xyz[i] = src[i];
         rt = reinterpret_cast<const DevRefTensors*>(xyz);
-        xyz += kRefDoubles;
+        xyz += a.ref_doubles;
     }
     uint2* lvs = reinterpret_cast<uint2*>(xyz + (int64_t)a.lds_nodes * NP);   // the block-cells' vertex slots (4 x 16 bit each)
     double* acc = reinterpret_cast<double*>(lvs + a.lds_cells);
+    [[maybe_unused]] double* acc2 = acc + a.lds_acc_cap;   // MASS2 == 1: the mass matrix's accumulators, filled by the SAME sweep (the host made sure both fit)
     const int64_t row0 = blk * kAsmBlock, row_end = min(a.n_dofs, row0 + kAsmBlock);
     const bool want_matrix = a.vals != nullptr;
     const int32_t base = a.rowptr[row0];
@@ -844,6 +867,8 @@ static __global__ __launch_bounds__(THREADS) void k_assemble_items(AsmArgs a, De
     for (int i = tid; i < nbc; i += THREADS) lvs[i] = reinterpret_cast<const uint2*>(a.bc_vert)[bc0 + i];
     if (want_matrix)
         for (int k = tid; k < blk_nnz; k += THREADS) acc[k] = 0.0;
+    if constexpr (MASS2 == 1)
+        for (int k = tid; k < blk_nnz; k += THREADS) acc2[k] = 0.0;
     const int64_t slice0 = row0 >> 6;   // the block's four adjacency slices
     const int64_t n_slices_all = (a.n_dofs + kSlice - 1) / kSlice;
     if (tid < kAsmBlock) {
@@ -892,6 +917,7 @@ static __global__ __launch_bounds__(THREADS) void k_assemble_items(AsmArgs a, De
             const int32_t code = v < width_s[q >> 6] ? a.adj[at] : -1;
             const bool on = code >= 0;
             double val[NB];
+            [[maybe_unused]] double mval[NB];   // MASS2 == 1: the visit's row of the mass matrix, accumulated in the same rounds
             double fval = 0;
             uint32_t sw[NBW];
             if (on) {
@@ -913,6 +939,12 @@ static __global__ __launch_bounds__(THREADS) void k_assemble_items(AsmArgs a, De
                     const double fc = fblk ? a.fq[at] : 0.0;
                     fval = rounded<R>(element_row<M, R, OPK>(a, op, tb, g, cell, code & 15, want_matrix, [&](int j, double value) { val[j] = rounded<R>(value); }, rt,
                                                              fblk ? bc : (int64_t)-1, fc, fbc ? bc : (int64_t)-1));
+                    if constexpr (MASS2 == 1) {   // the mass row from the same geometry: what the second sweep would compute for this item, bit for bit
+                        const double cm = 1.0 * 1.0 * g.measure;
+                        const int il = code & 15;
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) mval[j] = rounded<R>(cm * tb->mtab[il * NB + j]);
+                    }
                 }
             }
             // accumulation rounds, one per visit index of the step, ascending.  All items of a row live in THIS wavefront, whose LDS
@@ -922,6 +954,7 @@ static __global__ __launch_bounds__(THREADS) void k_assemble_items(AsmArgs a, De
                 for (int u = u0; u < u1 && u < maxv; ++u) {
                     if (on && v == u) {
                         if (MASS || want_matrix) add_row_lds<NB, NBW>(acc + rb, sw, val);
+                        if constexpr (!MASS && MASS2 == 1) add_row_lds<NB, NBW>(acc2 + rb, sw, mval);
                         if constexpr (!MASS) facc_s[q] += fval;
                     }
                 }
@@ -955,6 +988,8 @@ static __global__ __launch_bounds__(THREADS) void k_assemble_items(AsmArgs a, De
             }
         }
     }
+    if constexpr (MASS2 == 1)
+        for (int k = tid; k < blk_nnz; k += THREADS) a.vals2[base + k] = acc2[k];
     if constexpr (MASS2 == 2) {
         __syncthreads();
         for (int k = tid; k < blk_nnz; k += THREADS) acc[k] = 0.0;
@@ -1060,7 +1095,7 @@ static __global__ __launch_bounds__(256) void k_assemble_part(AsmArgs a, DevOp o
     const DevRefTensors* rt = nullptr;
     if constexpr (OPK == 3 || OPK == 5) {
         const double* src = reinterpret_cast<const double*>(a.reftab);
-        for (int i = threadIdx.x; i < kRefDoubles; i += blockDim.x) lds[kTablesDoubles + i] = src[i];
+        for (int i = threadIdx.x; i < a.ref_doubles; i += blockDim.x) lds[kTablesDoubles + i] = src[i];
         rt = reinterpret_cast<const DevRefTensors*>(lds + kTablesDoubles);
     }
     __syncthreads();

@@ -355,6 +355,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
         fdapde_engine::drop_graph(c);
     }
     else if (k == "small_rows" && value >= 0) c->small_rows = value;
+    else if (k == "small_front_rows" && value >= 0) c->small_front_rows = value;
     else if (k == "auto_gmres" && (value == 0 || value == 1)) c->auto_gmres = value;
     else if (k == "asm_split_varying" && (value == 0 || value == 1)) c->asm_split_varying = value;
     else if (k == "asm_row_stat" && (value == 0 || value == 1)) c->asm_row_stat = value, c->stiff_stat_valid = false;

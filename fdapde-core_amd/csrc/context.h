@@ -165,6 +165,8 @@ struct SolveState {
     int use_bnd = 0;
     bool diag_deferred = false;   // small one-GPU systems: "every interior diagonal is positive" was ASSUMED (flag at ctl[4], read back with the
                                   // solve's outcome instead of behind a wait of its own); the caller repeats the solve the slow way if it was wrong
+    mutable bool front_pending = false;   // ... and of at most `small_front_rows` rows in ONE workgroup: flag reset, scale, fill, lift and the Krylov start-up
+    const double* front_A = nullptr;      // have NOT been enqueued by solve_prepare -- the first solve_run enqueues them as one launch (k_small_front)
 };
 struct SolveStateHolder {
     SolveState ss;
@@ -396,6 +398,10 @@ struct fdapde_ctx {
     int h_ctl_seen = 4;                      // how many words of ctl the last outcome read-back fetched into h_ctl
     bool ev1_at_end = false;                 // fdapde_solve: solve_run records ev1 right before its final wait (no event wait of the caller's own)
     int64_t small_rows = 8192;               // systems of up to that many DOFs take the wait-free tail (knob small_rows; 0: off)
+    int64_t small_front_rows = 2048;         // knob: fdapde_solve of a one-workgroup system of at most this many DOFs enqueues ONE kernel in front of the
+                                             // single launch (k_small_front) and none behind it (PersistArgs::u_out); 0 = the separate launches
+    bool front_used = false;                 // (this solve's front ran as k_small_front: the Dirichlet entries of u are written)
+    bool tail_in_launch = false;             // (run_persist -> persist_tail: the launch wrote u itself)
     bool defer_end_sync = false;             // set by callers that loop over solves (parabolic steps, handle columns): solve_run does not wait for its
                                              // last kernel (the outcome is read behind a wait of its own; the rest is ordered by the stream)
     int persist_single_rows = 2048;          // knob: systems of up to that many interior rows run as ONE workgroup (no hand-off in the iteration)

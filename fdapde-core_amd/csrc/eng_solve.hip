@@ -296,13 +296,18 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss, b
     c->sval_stale = false;
     ss->rowdist = (c->comm != nullptr || c->ar_fn != nullptr) && c->rd.ready && !ss->dist;
     if (ss->rowdist) ss->owned = c->rd.owned.p;
-    HIPCHK(c, hipMemsetAsync(c->ctl.p, 0, 8 * sizeof(int32_t), st));
     // small systems on one GPU (the sizes the reference is used at: a 289-DOF solve is a 130 us launch inside 250 us of wall time): no wait for
     // the "every interior diagonal is positive" flag -- it is raised at ctl[4] and read back with the solve's outcome; the solve goes ahead as if
     // the diagonal were positive (what an assembled elliptic operator has) and fdapde_solve repeats it the slow way in the rare other case
     ss->diag_deferred = allow_defer && !ss->dist && !ss->rowdist && c->small_rows > 0 && n <= c->small_rows && c->comm == nullptr && c->ar_fn == nullptr;
     int32_t* diag_flag = c->ctl.p + (ss->diag_deferred ? 4 : 3);
-    if (ss->dist) {   // the diagonal is a sum over the ranks sharing a DOF
+    ss->front_pending = false, ss->front_A = A;
+    // ... and the smallest of them (one workgroup): flag reset, scale and fill are left to k_small_front (solve_run), if the layout turns out to be one it takes
+    bool front_candidate = ss->diag_deferred && symmetric && c->small_front_rows > 0 && n <= c->small_front_rows && A == c->vals[FDAPDE_MAT_STIFF].p &&
+                           c->stiff_stat_valid && c->persist && !c->persist_broken && c->spmv_variant == 2;
+    if (!front_candidate) HIPCHK(c, hipMemsetAsync(c->ctl.p, 0, 8 * sizeof(int32_t), st));
+    if (front_candidate) {
+    } else if (ss->dist) {   // the diagonal is a sum over the ranks sharing a DOF
         hipLaunchKernelGGL(k_diag_extract, dim3(g1(n)), dim3(256), 0, st, n, c->diag.p, A, c->tmp_i.p);
         if (int rc = halo_sum(c, c->tmp_i.p, nullptr, 0)) return rc;
         hipLaunchKernelGGL(k_jacobi_scale_from_diag, dim3(g1(n)), dim3(256), 0, st, n, c->tmp_i.p, c->bnd.p, use_bnd, c->scale.p,
@@ -362,6 +367,16 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss, b
         const fdapde_ctx::Persist& ps = c->ps[use_bnd ? 1 : 0];
         persist = ps.ok && (symmetric || (!ps.meta.sym && ps.meta.R <= 8));
     }
+    if (front_candidate) {
+        const fdapde_ctx::Persist& ps = c->ps[use_bnd ? 1 : 0];
+        if (persist && ps.meta.G == 1 && !ps.meta.sym && ps.ell_col.n >= (size_t)ps.meta.n_entries + 256) {
+            ss->front_pending = true;
+        } else {   // not this time (e.g. the layout's column table is made by its first fill): the separate launches after all
+            front_candidate = false;
+            HIPCHK(c, hipMemsetAsync(c->ctl.p, 0, 8 * sizeof(int32_t), st));
+            hipLaunchKernelGGL(k_jacobi_scale_stats, dim3(g1(n)), dim3(256), 0, st, n, c->stiff_stat.p, c->bnd.p, use_bnd, c->scale.p, diag_flag);
+        }
+    }
     // one GPU, positive diagonal, not taken by the persistent CG (non-symmetric operator, or too many rows): the multi-launch
     // kernels apply the operator from the blocked-ELL layout (k_spmv_blocked); the compact CSR pattern is then not built either
     c->bk_cur = -1, c->bk[0].filled = c->bk[1].filled = false;
@@ -398,7 +413,8 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss, b
                            c->sval.p, c->bk[v].ell_val.p, (unsigned long long*)nullptr);
         c->bk[v].filled = true, c->bk_cur = v;
     }
-    if (persist)
+    if (persist && ss->front_pending) c->ps[use_bnd ? 1 : 0].filled = true;   // (by k_small_front, in stream order before the launch)
+    else if (persist)
         if (int rc = c->sval_stale ? fill_persist_scaled(c, use_bnd ? 1 : 0, A) : fill_persist(c, use_bnd ? 1 : 0)) return rc;
     HIPCHK(c, hipGetLastError());
     return FDAPDE_OK;
@@ -493,7 +509,24 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     // the lift is zero (no Dirichlet data, or homogeneous data on one GPU -- across ranks the data may differ, and every rank
     // must take the same path through the collectives): A g~ = 0, written by the lift kernel itself (no memset launch)
     const bool zero_lift = !ss.use_bnd || (!dist && !ss.rowdist && g_dev == c->g.p && c->g_zero);
-    hipLaunchKernelGGL(k_lift, dim3(g1(n)), dim3(256), 0, st, n, c->bnd.p, g_dev, ss.use_bnd, c->gt.p, zero_lift ? c->y.p : (double*)nullptr);
+    // the smallest systems (solve_prepare: front_pending): everything in front of the single launch as ONE one-workgroup kernel, or two around A g~
+    const bool front = ss.front_pending;
+    ss.front_pending = false;
+    c->front_used = front;
+    SmallFrontArgs fa{};
+    if (front) {
+        const fdapde_ctx::Persist& ps = c->ps[ss.use_bnd ? 1 : 0];
+        fa.n = n, fa.use_bnd = ss.use_bnd, fa.zero_y = zero_lift ? 1 : 0, fa.vec_grid = c->vec_grid;
+        fa.stat = c->stiff_stat.p, fa.bnd = c->bnd.p, fa.scale = c->scale.p, fa.ctl = c->ctl.p;
+        fa.nsl = ps.meta.nsl, fa.ell_off = ps.ell_off.p, fa.sl_off = ps.sl_off.p, fa.slot_dof = ps.slot_dof.p, fa.src = ps.ell_src.p, fa.col = ps.ell_col.p;
+        fa.A = ss.front_A, fa.ell_val = ps.ell_val.p;
+        fa.g = g_dev, fa.gt = c->gt.p, fa.y = c->y.p, fa.u = c->u.p;
+        if (!zero_lift) {
+            fa.phases = 1;
+            hipLaunchKernelGGL(k_small_front, dim3(1), dim3(256), 0, st, fa);
+        }
+    } else
+        hipLaunchKernelGGL(k_lift, dim3(g1(n)), dim3(256), 0, st, n, c->bnd.p, g_dev, ss.use_bnd, c->gt.p, zero_lift ? c->y.p : (double*)nullptr);
     if (!zero_lift) {
         launch_spmv(c, A, c->gt.p, c->y.p, nullptr, nullptr, nullptr);   // y = A g~
         if (dist)
@@ -519,9 +552,19 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
             if (int rc = halo_sum(c, c->t.p, nullptr, 0)) return rc;
         ax = c->t.p;
     }
-    hipLaunchKernelGGL(k_krylov_init, dim3(c->vec_grid), dim3(256), 0, st, n, fvec, c->y.p, c->scale.p, c->x.p, c->r.p, c->p.p,
-                       bicg ? c->r0.p : (double*)nullptr, c->part_b.p, owned, u0_dev, c->gt.p, ax, 0);
-    if (dist || ss.rowdist) {
+    if (!front)
+        hipLaunchKernelGGL(k_krylov_init, dim3(c->vec_grid), dim3(256), 0, st, n, fvec, c->y.p, c->scale.p, c->x.p, c->r.p, c->p.p,
+                           bicg ? c->r0.p : (double*)nullptr, c->part_b.p, owned, u0_dev, c->gt.p, ax, 0);
+    if (front) {   // (one GPU, cold start: what the two launches of the other branch do)
+        const int V = c->cgf_v;
+        const int64_t b2 = c->cgf_band ? (((((n + 7) / 8) + 31) & ~int64_t(31)) >> 1) : 0, span = b2 > 0 ? b2 : (n >> 1);
+        const int per = (int)((span + 256 * V - 1) / (256 * V)) > 0 ? (int)((span + 256 * V - 1) / (256 * V)) : 1;
+        const int cg = b2 > 0 ? 8 * per : per;
+        fa.phases = zero_lift ? 3 : 2;
+        fa.f = fvec, fa.x = c->x.p, fa.r = c->r.p, fa.p = c->p.p, fa.r0 = bicg ? c->r0.p : (double*)nullptr, fa.partial = c->part_b.p, fa.sc = c->sc.p;
+        fa.seed = cgf ? c->part_b.p + cg : (double*)nullptr, fa.n_seed = cgf ? cg : 0, fa.tol2 = tol2;
+        hipLaunchKernelGGL(k_small_front, dim3(1), dim3(256), 0, st, fa);
+    } else if (dist || ss.rowdist) {
         hipLaunchKernelGGL(k_reduce_partials2, dim3(1), dim3(256), 0, st, c->part_b.p, c->vec_grid, c->sbuf.p);
         if (int rc = allreduce_sum(c, c->sbuf.p, 2)) return rc;
         hipLaunchKernelGGL(k_krylov_init_fin, dim3(1), dim3(256), 0, st, c->sbuf.p, 1, c->sc.p, c->ctl.p, tol2, (double*)nullptr, 0);
@@ -571,7 +614,7 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
         // the epilogue kernel (and, for fdapde_solve, the end-of-solve event) is enqueued BEHIND the launch before the host waits for it: one wait
         // for launch, outcome and solution together; if the launch gave up, the fall-back below redoes the epilogue from its own iterate
         c->persist_tail = [&]() -> int {
-            hipLaunchKernelGGL(k_unscale, dim3(g1(n)), dim3(256), 0, st, n, c->scale.p, c->persist_x.p, c->gt.p, c->u.p);
+            if (!c->tail_in_launch) hipLaunchKernelGGL(k_unscale, dim3(g1(n)), dim3(256), 0, st, n, c->scale.p, c->persist_x.p, c->gt.p, c->u.p);
             if (c->ev1_at_end) HIPCHK(c, hipEventRecord(c->ev1, st));
             return FDAPDE_OK;
         };

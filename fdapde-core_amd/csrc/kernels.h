@@ -28,5 +28,6 @@
 #include "kernels_gmres.h"
 #include "kernels_multirhs.h"
 #include "kernels_persist.h"
+#include "kernels_small.h"
 
 #endif

@@ -46,10 +46,7 @@ static __global__ __launch_bounds__(256) void k_jacobi_scale(int64_t n, const in
     scale[i] = jacobi_scale_of(tiny ? rmax : d);
 }
 // the same from (diagonal, row maximum) pairs the assembly left behind (AsmArgs::row_stat): 16 bytes per row instead of the whole matrix
-static __global__ __launch_bounds__(256) void k_jacobi_scale_stats(int64_t n, const double* stat, const uint8_t* bnd, int use_bnd, double* scale,
-                                                                   int32_t* flag) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+__device__ __forceinline__ void jacobi_scale_stats_row(int64_t i, const double* stat, const uint8_t* bnd, int use_bnd, double* scale, int32_t* flag) {
     if (use_bnd && bnd[i]) {
         scale[i] = 0.0;
         return;
@@ -58,6 +55,11 @@ static __global__ __launch_bounds__(256) void k_jacobi_scale_stats(int64_t n, co
     const bool tiny = !(fabs(d) > 1e-8 * rmax);
     if (!(d > 0.0) || tiny) atomicOr(flag, 1);
     scale[i] = jacobi_scale_of(tiny ? rmax : d);
+}
+static __global__ __launch_bounds__(256) void k_jacobi_scale_stats(int64_t n, const double* stat, const uint8_t* bnd, int use_bnd, double* scale,
+                                                                   int32_t* flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) jacobi_scale_stats_row(i, stat, bnd, use_bnd, scale, flag);
 }
 // At = diag(scale) A diag(scale): symmetric Jacobi scaling == Jacobi preconditioning folded into the matrix stream.
 // Rows and columns of Dirichlet DOFs vanish (scale = 0), which restricts the Krylov iteration to the interior block.
@@ -95,13 +97,13 @@ static __global__ void k_lift(int64_t n, const uint8_t* bnd, const double* g, in
 // Cold start (u0 == nullptr): x = 0, r = bt.  Warm start: x = (u0 - gt) / scale on interior DOFs, r = bt - ax where ax holds
 // At x (one extra SpMV by the caller between the two launches: first launch with ax == nullptr only fills x).
 // partial[2 b] = sum r^2, partial[2 b + 1] = sum bt^2 (the stopping rule is relative to ||bt||, not to the warm residual).
-static __global__ __launch_bounds__(256) void k_krylov_init(int64_t n, const double* f, const double* y, const double* scale,
-                                                      double* x, double* r, double* p, double* r0, double* partial,
-                                                      const uint8_t* owned, const double* u0, const double* gt,
-                                                      const double* ax, int fill_x_only) {
-    __shared__ double red[8];
+// (the body of workgroup `bid` of `nblocks`, 256 threads: k_small_front runs the workgroups of a small system one after the other -- same sums)
+__device__ __forceinline__ void krylov_init_block(int bid, int nblocks, int64_t n, const double* f, const double* y, const double* scale,
+                                                  double* x, double* r, double* p, double* r0, double* partial,
+                                                  const uint8_t* owned, const double* u0, const double* gt,
+                                                  const double* ax, int fill_x_only, double* red) {
     double acc = 0, accb = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)bid * blockDim.x + threadIdx.x; i < n; i += (int64_t)nblocks * blockDim.x) {
         if (fill_x_only) {
             x[i] = scale[i] > 0.0 ? (u0[i] - gt[i]) / scale[i] : 0.0;
             continue;
@@ -116,15 +118,21 @@ static __global__ __launch_bounds__(256) void k_krylov_init(int64_t n, const dou
     if (fill_x_only) return;
     const double s = block_sum(acc, red);
     const double sb = block_sum(accb, red);
-    if (threadIdx.x == 0) partial[2 * blockIdx.x] = s, partial[2 * blockIdx.x + 1] = sb;
+    if (threadIdx.x == 0) partial[2 * bid] = s, partial[2 * bid + 1] = sb;
+}
+static __global__ __launch_bounds__(256) void k_krylov_init(int64_t n, const double* f, const double* y, const double* scale,
+                                                      double* x, double* r, double* p, double* r0, double* partial,
+                                                      const uint8_t* owned, const double* u0, const double* gt,
+                                                      const double* ax, int fill_x_only) {
+    __shared__ double red[8];
+    krylov_init_block((int)blockIdx.x, (int)gridDim.x, n, f, y, scale, x, r, p, r0, partial, owned, u0, gt, ax, fill_x_only, red);
 }
 // scalars layout (device doubles): [0] reference norm^2 (||bt||^2), [1] rr_even, [2] rr_odd, [3] last rr, [4..] method specific
 // ctl layout (device int32): [0] stop flag, [1] iterations done, [2] breakdown flag
 // seed (optional): the fused-update CG reads its explicit r.r from n_seed per-workgroup partials; they are seeded with
 // (rr, 0, 0, ...) so that its first launch needs no special case (and the launch sequence can be replayed as a graph)
-static __global__ __launch_bounds__(256) void k_krylov_init_fin(const double* partial, int np, double* sc, int32_t* ctl, double tol2,
-                                                         double* seed, int n_seed) {
-    __shared__ double red[8];
+__device__ __forceinline__ void krylov_init_fin_body(const double* partial, int np, double* sc, int32_t* ctl, double tol2, double* seed, int n_seed,
+                                                     double* red) {
     double a = 0, b = 0;
     for (int i = threadIdx.x; i < np; i += blockDim.x) a += partial[2 * i], b += partial[2 * i + 1];
     const double rr = block_sum(a, red);
@@ -138,6 +146,11 @@ static __global__ __launch_bounds__(256) void k_krylov_init_fin(const double* pa
         sc[16] = 0.0, sc[17] = 0.0, sc[18] = 0.0; // fused-update CG: no update of x pending
         ctl[0] = rr <= tol2 * bb ? 1 : 0, ctl[1] = 0, ctl[2] = 0;
     }
+}
+static __global__ __launch_bounds__(256) void k_krylov_init_fin(const double* partial, int np, double* sc, int32_t* ctl, double tol2,
+                                                         double* seed, int n_seed) {
+    __shared__ double red[8];
+    krylov_init_fin_body(partial, np, sc, ctl, tol2, seed, n_seed, red);
 }
 // Several right-hand sides of fdapde_lin_solve at once (one persistent launch solves them side by side, kernels_persist.h n_cols): what
 // k_gather_f64 + k_krylov_init / _fin do for one column, for column blockIdx.y -- the same loops and the same reduction order, hence the

@@ -67,6 +67,8 @@ struct PersistArgs {
     double* hrec;                     // one-workgroup launches of fdapde_solve (G == 1, not direct): the outcome ALSO into pinned host memory, so that the
                                       // host reads it after its one wait without device-to-host copies: [0] stop flag, [1] iterations, [2] breakdown,
                                       // [3] gave up, [4] ctl[4] (the deferred positive-diagonal flag), [5] ||b~||^2, [6] final r.r
+    double* u_out;                    // one-workgroup launches of fdapde_solve behind k_small_front: the epilogue too -- u = scale * x on the rows of the
+                                      // layout (k_unscale's expression: the lift is zero there; the Dirichlet entries of u were written by k_small_front)
     const int32_t* i2e;               // direct: internal DOF -> reference DOF
     const double* scale;              // direct: Jacobi scale, internal order
     int32_t pf_steps;                 // streaming forms, != 0: the first entry step of the next operator application is touched (pulled into the L2)
@@ -609,10 +611,13 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
             }
             if (fail && lane == 0) fail_flag = 1;
         }
-        __syncthreads();
-        if (fail_flag) {
-            status = 3;
-            break;
+        const bool solo = !DIST && a.G == 1;   // ONE workgroup: no imports, no records -- two barriers per iteration instead of four
+        if (!solo) {
+            __syncthreads();
+            if (fail_flag) {
+                status = 3;
+                break;
+            }
         }
         if (late) product(std::integral_constant<int, 0>{});
         product(std::integral_constant<int, 1>{});
@@ -633,6 +638,7 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
         const double s2 = wave_sum64(rr_part);
         if (lane == 0) red[wave][0] = s0, red[wave][1] = s1, red[wave][2] = s2;
         __syncthreads();
+        double solo_tot[3] = {0.0, 0.0, 0.0};
         const bool flat = DIST && a.flat_gather != 0;   // (uniform for the launch)
         if (flat) {
             // ONE hop: the record goes into the flat section of EVERY rank's board (thread (k, q) pushes value k to rank q), then thread t
@@ -694,12 +700,10 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
         } else if (!DIST && a.G == 1) {
             // ONE workgroup (systems of a few thousand rows -- most of what the reference's own users solve): its sums are the totals, no record
             // is published or polled (a granule round trip is ~2 us of a ~3.5 us iteration); the same bits as through the board
-            if (tid < 3) {
-                double v = 0;
+            // (every thread adds the W partials itself, in the order one thread per sum did when the totals went through `tot` and a second
+            //  barrier: the same bits; `red` is rewritten behind the next iteration's first barrier)
 #pragma unroll
-                for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
-                tot[tid] = v;
-            }
+            for (int ww = 0; ww < W; ++ww) solo_tot[0] += red[ww][0], solo_tot[1] += red[ww][1], solo_tot[2] += red[ww][2];
             prefetch_next();
         } else {
         unsigned long long* dslot = a.dboard + (size_t)(it & 1) * a.G * 6;
@@ -801,13 +805,15 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
             }
         }
         }
-        __syncthreads();
-        if (fail_flag) {
-            status = 3;
-            break;
+        if (!solo) {
+            __syncthreads();
+            if (fail_flag) {
+                status = 3;
+                break;
+            }
         }
-        const double pAp = tot[0], yy = tot[1];
-        rr = tot[2];
+        const double pAp = solo ? solo_tot[0] : tot[0], yy = solo ? solo_tot[1] : tot[1];
+        rr = solo ? solo_tot[2] : tot[2];
         if (!DIST && a.direct && it == 0) bb = rr;   // x0 = 0: r0 = b~
         if (stamper) c2 = wall_clock64();
         // ---- the recurrence of k_cgf_update (kernels_krylov.h): stop test on the explicit r.r, then x, r, p
@@ -864,8 +870,10 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
             else xj = xv[j];
             if (!DIST && a.direct) {
                 if (d >= 0) a.x_ext[a.i2e[d]] = a.scale[d] * xj + 0.0;   // (k_cols_finish's expression)
-            } else if (d >= 0)
+            } else if (d >= 0) {
                 a.x_out[d] = xj;
+                if (!DIST && a.u_out != nullptr) a.u_out[d] = a.scale[d] * xj + 0.0;
+            }
         }
     }
     if (!DIST && a.direct) {
@@ -1059,12 +1067,9 @@ static __global__ __launch_bounds__(256) void k_persist_fill(int64_t n, const in
 // k_scale_matrix), so that a solve that runs as one persistent launch never writes or reads the scaled full-pattern copy (205 MB written +
 // gathered on C3).  One wavefront per slice of 64 slots: lane l owns slot 64 q + l, hence knows its row; its entries are the lane pairs
 // (2 l, 2 l + 1) of the slice's pair rows.
-static __global__ __launch_bounds__(256) void k_persist_fill_scaled(int32_t G, int32_t nsl, const int64_t* ell_off, const int32_t* sl_off, const int32_t* slot_dof,
-                                                                    const int32_t* src, const int32_t* col, const double* A, const double* scale, double* out,
-                                                                    unsigned long long* amax_bits) {
-    const int per = (nsl + 3) / 4;
-    const int g = blockIdx.x / per, q = (blockIdx.x % per) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (g >= G || q >= nsl) return;   // (wave-uniform)
+// (slice q of workgroup g, one wavefront; returns the lane's max |value|)
+__device__ __forceinline__ double persist_fill_scaled_slice(int g, int q, int lane, int32_t nsl, const int64_t* ell_off, const int32_t* sl_off, const int32_t* slot_dof,
+                                                            const int32_t* src, const int32_t* col, const double* A, const double* scale, double* out) {
     const int S = nsl * 64;
     const int32_t d = slot_dof[(size_t)g * S + q * 64 + lane];
     const double si = d >= 0 ? scale[d] : 0.0;
@@ -1095,6 +1100,15 @@ static __global__ __launch_bounds__(256) void k_persist_fill_scaled(int32_t G, i
             }
         }
     }
+    return m;
+}
+static __global__ __launch_bounds__(256) void k_persist_fill_scaled(int32_t G, int32_t nsl, const int64_t* ell_off, const int32_t* sl_off, const int32_t* slot_dof,
+                                                                    const int32_t* src, const int32_t* col, const double* A, const double* scale, double* out,
+                                                                    unsigned long long* amax_bits) {
+    const int per = (nsl + 3) / 4;
+    const int g = blockIdx.x / per, q = (blockIdx.x % per) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (g >= G || q >= nsl) return;   // (wave-uniform)
+    double m = persist_fill_scaled_slice(g, q, lane, nsl, ell_off, sl_off, slot_dof, src, col, A, scale, out);
     if (amax_bits != nullptr) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
@@ -1102,6 +1116,7 @@ static __global__ __launch_bounds__(256) void k_persist_fill_scaled(int32_t G, i
         if (lane == 0 && bits > __hip_atomic_load(amax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax_bits, bits);
     }
 }
+
 // column DOF of every ELL entry (0 in padding), once per layout: lets the fill gather A[src] and scale[col] independently
 static __global__ __launch_bounds__(256) void k_persist_ell_col(int64_t n, const int32_t* src, const int32_t* colidx, int32_t* col) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

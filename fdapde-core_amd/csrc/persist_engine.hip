@@ -390,6 +390,9 @@ int run_persist(fdapde_ctx* c, int v, double tol2, int maxit, bool* ran, bool bi
     // behind a 130 us launch)
     const bool host_rec = !bicg && ps.meta.G == 1 && c->small_rows > 0 && (int64_t)n <= c->small_rows;
     if (host_rec) a.time_phases = 0, a.hrec = c->h_sc + 8;
+    // ... and behind k_small_front (the Dirichlet entries of u are in place) the epilogue is the launch's own write-out
+    c->tail_in_launch = host_rec && c->front_used && c->persist_tail != nullptr;
+    if (c->tail_in_launch) a.u_out = c->u.p, a.scale = c->scale.p;
     DebugClock clk;
     const int rc_launch = launch_persist(c, ps, a, false, bicg);
     clk.mark("run_persist: launch call");

@@ -393,6 +393,45 @@ def test_one_workgroup_without_hand_offs_matches_several(env, dim, nx, order, di
     c.close()
 
 
+@pytest.mark.parametrize("dim,nx,order,dirichlet,zero_g", [
+    (2, 16, 1, True, True),     # 289 DOFs, homogeneous data: ONE kernel in front of the launch
+    (2, 16, 1, True, False),    # non-zero lift: the product A g~ between two launches of that kernel
+    (2, 40, 1, True, False),    # 1 681 DOFs: seven workgroups' worth of start-up sums run by one
+    (3, 9, 1, True, False),     # 3-D rows
+    (2, 14, 2, True, True),     # P2
+    (2, 30, 1, False, True),    # no Dirichlet DOF
+])
+def test_small_front_kernel_gives_the_separate_launches_bits(env, dim, nx, order, dirichlet, zero_g):
+    """fdapde_solve of a one-workgroup system of at most `small_front_rows` DOFs enqueues flag reset, Jacobi scale, layout fill, lift and the Krylov
+    start-up as ONE kernel (k_small_front: the same device functions in the same launch geometry) and the epilogue inside the launch
+    (PersistArgs::u_out): same iterations, identical solution bits as the separate launches (knob small_front_rows = 0), from the second solve on
+    (the first one builds the layout's column table)"""
+    capi, meshgen = env
+    c, nd = _problem(capi, meshgen, dim, nx, order, dirichlet)
+    if dirichlet and zero_g:
+        c.set_dirichlet(np.zeros(nd))
+    c.tune("small_front_rows", 0)
+    c.solve(rtol=1e-11)
+    i0 = c.solve(rtol=1e-11)
+    u0 = c.solution()
+    c.tune("small_front_rows", 2048)
+    i1 = c.solve(rtol=1e-11)
+    u1 = c.solution()
+    assert c.solver_layout_kind(dirichlet)["workgroups"] == 1
+    assert i0.persistent == 1 and i1.persistent == 1 and i0.converged == 1 and i1.converged == 1
+    assert i1.iters == i0.iters and i1.relres == i0.relres, (i0.iters, i1.iters, i0.relres, i1.relres)
+    assert np.array_equal(u1, u0), float(np.abs(u1 - u0).max())
+    # a changed forcing, then changed Dirichlet data, through the fused front
+    c.set_forcing(2.0 * np.ones(c.quadrature_nodes().shape[0]))
+    c.init()
+    i2 = c.solve(rtol=1e-11)
+    u2 = c.solution()
+    c.tune("small_front_rows", 0)
+    i3 = c.solve(rtol=1e-11)
+    assert i3.iters == i2.iters and np.array_equal(c.solution(), u2)
+    c.close()
+
+
 @pytest.mark.parametrize("dim,nx,order,n_rhs", [
     (2, 16, 1, 5),      # one workgroup per column
     (2, 16, 1, 300),    # more columns than one launch takes (256 CUs): several launches

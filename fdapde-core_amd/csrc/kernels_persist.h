@@ -42,6 +42,12 @@
 
 namespace fdapde_hip {
 
+#ifdef FDAPDE_GATHER_3BAR   // (A/B builds of tools/: the record sums through `tot` and three barriers)
+constexpr bool kGather3 = true;
+#else
+constexpr bool kGather3 = false;
+#endif
+
 struct PersistArgs {
     int32_t G, nsl, maxit, imp_cap;   // workgroups; slices per workgroup; iteration bound; import slots reserved in LDS
     int32_t lds_cap;                  // ELL entries staged in LDS by the resident form (multiple of 128; >= the largest block)
@@ -215,9 +221,58 @@ __device__ __forceinline__ void touch_first_step(const int32_t* slo, const void*
         if (t * 64 + lane < total && wj > 0) touch_line(line, lds_dump);
     }
 }
+// Sum over the wavefront, every lane gets the total: the butterfly v += v[lane ^ o], o = 32 .. 1.  The four steps inside a row of 16 lanes are DPP
+// moves (VALU path) instead of the ds_bpermute pairs __shfl_xor compiles to (LDS crossbar, ~100 cycles each, twelve of them chained per sum): a rotation
+// by 8 / 4 inside the row pairs every lane with a lane of the class lane ^ 8 / lane ^ 4 of the butterfly (the partial sums depend on the lane's class
+// only), so the operands -- and the bits -- are those of the xor butterfly.
+template <int CTRL> __device__ __forceinline__ double persist_dpp_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int O> __device__ __forceinline__ double persist_swap_sum(double v) {
+    const long long b = __double_as_longlong(v);
+    const unsigned l = (unsigned)(b & 0xffffffffll), h = (unsigned)(b >> 32);
+    const auto lo = O == 32 ? __builtin_amdgcn_permlane32_swap(l, l, false, false) : __builtin_amdgcn_permlane16_swap(l, l, false, false);
+    const auto hi = O == 32 ? __builtin_amdgcn_permlane32_swap(h, h, false, false) : __builtin_amdgcn_permlane16_swap(h, h, false, false);
+    return __longlong_as_double(((long long)hi[0] << 32) | lo[0]) + __longlong_as_double(((long long)hi[1] << 32) | lo[1]);
+}
+// max over the wavefront, in every lane (exact whatever the order): the same VALU-only butterfly
+__device__ __forceinline__ double wave_max64(double v) {
+#ifdef FDAPDE_WAVE_SUM_SHFL
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+#endif
+    const long long b = __double_as_longlong(v);
+    const unsigned l = (unsigned)(b & 0xffffffffll), h = (unsigned)(b >> 32);
+    const auto lo = __builtin_amdgcn_permlane32_swap(l, l, false, false), hi = __builtin_amdgcn_permlane32_swap(h, h, false, false);
+    v = fmax(__longlong_as_double(((long long)hi[0] << 32) | lo[0]), __longlong_as_double(((long long)hi[1] << 32) | lo[1]));
+    const long long b2 = __double_as_longlong(v);
+    const unsigned l2 = (unsigned)(b2 & 0xffffffffll), h2 = (unsigned)(b2 >> 32);
+    const auto lo2 = __builtin_amdgcn_permlane16_swap(l2, l2, false, false), hi2 = __builtin_amdgcn_permlane16_swap(h2, h2, false, false);
+    v = fmax(__longlong_as_double(((long long)hi2[0] << 32) | lo2[0]), __longlong_as_double(((long long)hi2[1] << 32) | lo2[1]));
+    v = fmax(v, persist_dpp_f64<0x128>(v));
+    v = fmax(v, persist_dpp_f64<0x124>(v));
+    v = fmax(v, persist_dpp_f64<0x4E>(v));
+    v = fmax(v, persist_dpp_f64<0xB1>(v));
+    return v;
+}
 __device__ __forceinline__ double wave_sum64(double v) {
+#ifdef FDAPDE_WAVE_SUM_SHFL   // (A/B builds of tools/)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+#endif
+    // lane ^ 32, lane ^ 16: gfx950's swaps (v_permlane32_swap / v_permlane16_swap exchange the upper half / the odd rows of one register with the lower
+    // half / the even rows of another; given the same value twice they leave {low, low} and {high, high}: their sum is the butterfly's in every lane)
+    v = persist_swap_sum<32>(v);
+    v = persist_swap_sum<16>(v);
+    v += persist_dpp_f64<0x128>(v);   // row_ror:8
+    v += persist_dpp_f64<0x124>(v);   // row_ror:4
+    v += persist_dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += persist_dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
     return v;
 }
 
@@ -249,8 +304,8 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
     constexpr bool WIDE = R > kPersistRmax;   // x in HBM, p in LDS only
     constexpr bool PLDS = SYM || WIDE;        // p of the own rows lives in its LDS table only; DOF ids re-read at the end; lists in global memory
     static_assert(!WIDE || (STREAM && !SYM && !DIST), "the wide form is the plain streaming storage on one GPU");
-    extern __shared__ double lds[];
-    __shared__ double red[W][3];
+    extern __shared__ __attribute__((aligned(128))) double lds[];   // (16-byte LDS reads of the resident blocks: a base the static arrays left 8-byte aligned halves their rate)
+    __shared__ double red[W][3], red2[W][3];
     __shared__ double tot[3];
     __shared__ double pmax_w[W];
     __shared__ int32_t fail_flag;
@@ -381,8 +436,7 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
             double m = 0;
 #pragma unroll
             for (int j = 0; j < R; ++j) m = fmax(m, fabs(P(j)));
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+            m = wave_max64(m);
             if (lane == 0) pmax_w[wave] = m;
         }
         __syncthreads();
@@ -470,19 +524,34 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
                     }
                 }
             } else if constexpr (!SYM) {
-                for (int e = 0; e < mw; ++e) {
-                    double2 v[NJ];
-                    uint32_t c[NJ];
+                // resident blocks: an entry step is two dependent LDS round trips (value + codes, then the table reads the codes address); the
+                // pair rows of step e + 1 are requested behind the table reads of step e (LDS returns in order: the table reads are waited for with
+                // the next step's loads still in flight), so a step costs one round trip -- what a workgroup of 8 wavefronts alone on its CU cannot
+                // hide otherwise.  Same sums in the same order.
+                double2 vn[NJ];
+                uint32_t cn[NJ];
+                auto fetch = [&](int e) {
 #pragma unroll
                     for (int j = J0; j < J1; ++j) {
                         const int ee = min(e, max(w[j] - 1, 0));
                         const int idx = (o0[j] + ee) * 64 + lane;
-                        if constexpr (STREAM) v[j - J0] = gv[idx], c[j - J0] = gc[idx];
-                        else v[j - J0] = ev[idx], c[j - J0] = ec[idx];
+                        if constexpr (STREAM) vn[j - J0] = gv[idx], cn[j - J0] = gc[idx];
+                        else vn[j - J0] = ev[idx], cn[j - J0] = ec[idx];
                     }
+                };
+                if (mw > 0) fetch(0);
+                for (int e = 0; e < mw; ++e) {
+                    double2 v[NJ];
+                    double pa[NJ], pb[NJ];
 #pragma unroll
                     for (int j = J0; j < J1; ++j) {
-                        const double t = v[j - J0].x * p_tab[c[j - J0] & 0xffffu] + v[j - J0].y * p_tab[c[j - J0] >> 16];
+                        v[j - J0] = vn[j - J0];
+                        pa[j - J0] = p_tab[cn[j - J0] & 0xffffu], pb[j - J0] = p_tab[cn[j - J0] >> 16];
+                    }
+                    if (e + 1 < mw) fetch(e + 1);
+#pragma unroll
+                    for (int j = J0; j < J1; ++j) {
+                        const double t = v[j - J0].x * pa[j - J0] + v[j - J0].y * pb[j - J0];
                         yv[j] += e < w[j] ? t : 0.0;
                     }
                 }
@@ -753,15 +822,18 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
             }
             if (fail && lane == 0) fail_flag = 1;
             v0 = wave_sum64(v0), v1 = wave_sum64(v1), v2 = wave_sum64(v2);
-            __syncthreads();   // the partials in red have been consumed
-            if (lane == 0) red[wave][0] = v0, red[wave][1] = v1, red[wave][2] = v2;
-            __syncthreads();
-            if (tid < 3) {
-                double v = 0;
+            if constexpr (DIST || kGather3) {
+                __syncthreads();   // the partials in red have been consumed
+                if (lane == 0) red[wave][0] = v0, red[wave][1] = v1, red[wave][2] = v2;
+                __syncthreads();
+                if (tid < 3) {
+                    double v = 0;
 #pragma unroll
-                for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
-                tot[tid] = v;
-            }
+                    for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
+                    tot[tid] = v;
+                }
+            } else if (lane == 0)   // (a table of its own: no barrier in front; added up by every thread behind the ONE barrier below)
+                red2[wave][0] = v0, red2[wave][1] = v1, red2[wave][2] = v2;
         }
         if constexpr (DIST) {
             // second level: the rank's sums (identical in all of its workgroups) go to every rank -- pushed by workgroup 0 -- and every
@@ -811,9 +883,14 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
                 status = 3;
                 break;
             }
+            if constexpr (!DIST && !kGather3) {   // the wavefronts' sums of the records, in the order the one summing thread per total used (same bits; one barrier, not three)
+#pragma unroll
+                for (int ww = 0; ww < W; ++ww) solo_tot[0] += red2[ww][0], solo_tot[1] += red2[ww][1], solo_tot[2] += red2[ww][2];
+            }
         }
-        const double pAp = solo ? solo_tot[0] : tot[0], yy = solo ? solo_tot[1] : tot[1];
-        rr = solo ? solo_tot[2] : tot[2];
+        const bool own_tot = !DIST && (!kGather3 || solo);
+        const double pAp = own_tot ? solo_tot[0] : tot[0], yy = own_tot ? solo_tot[1] : tot[1];
+        rr = own_tot ? solo_tot[2] : tot[2];
         if (!DIST && a.direct && it == 0) bb = rr;   // x0 = 0: r0 = b~
         if (stamper) c2 = wall_clock64();
         // ---- the recurrence of k_cgf_update (kernels_krylov.h): stop test on the explicit r.r, then x, r, p
@@ -930,7 +1007,7 @@ struct BlockedSpmvArgs {
 template <int R>
 static __global__ __launch_bounds__(kPersistT) void k_spmv_blocked(BlockedSpmvArgs a) {
     constexpr int T = kPersistT, W = T / 64, S = R * T;
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(128))) double lds[];   // (16-byte LDS reads of the resident blocks: a base the static arrays left 8-byte aligned halves their rate)
     __shared__ double red[W][2];
     if (a.stop && __syncthreads_or(*a.stop != 0)) return;
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -35,7 +35,7 @@ __device__ __forceinline__ void granule_load8_sys(const unsigned long long* p, p
 template <int R, bool STREAM, bool DIST>
 static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a) {
     constexpr int T = kPersistT, W = T / 64, S = R * T, RI = R / 2;
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(128))) double lds[];   // (16-byte LDS reads of the resident blocks: a base the static arrays left 8-byte aligned halves their rate)
     __shared__ double red[W][4];
     __shared__ double tot[4];
     __shared__ int32_t fail_flag;

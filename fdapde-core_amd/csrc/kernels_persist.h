@@ -786,7 +786,9 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
         {   // thread t collects workgroup t's three sums (a lane re-reads its record until all six tags match, then stops loading); every
             // workgroup adds the G records in the same order.  A two-level form (groups of 8 / 16 / 32 workgroups handled by one wavefront,
             // then the group sums) was measured and dropped: a granule hop costs ~4 us under this load, two of them 7.9 / 9.8 / 12.0 us
-            // against 4.6 us for the flat sweep on C2 (246 workgroups).
+            // against 4.6 us for the flat sweep on C2 (246 workgroups).  The records as [sum][workgroup] (a polling wavefront's three loads cover whole
+            // lines: a third of the line requests) were measured too (round 5): C2 5.9 -> 6.5 us per iteration, C3 29.8 -> 30.4 -- a record's three sums
+            // leave as three stores to three lines instead of one, and the reader needs all of them.
             double v0 = 0, v1 = 0, v2 = 0;
             bool fail = false;
             // gather_waves: how many wavefronts poll (4: thread t takes workgroup t's record; 1: wavefront 0 takes them all, 4 per lane)

@@ -42,6 +42,11 @@
 
 namespace fdapde_hip {
 
+#ifdef FDAPDE_DOT_STRIDE6   // (A/B builds of tools/: the dot records 48 bytes apart -- every third one straddles two lines)
+constexpr int kDotStride = 6;
+#else
+constexpr int kDotStride = 8;   // granules between the dot records of two workgroups: 64 bytes, on a 64-byte boundary (persist_engine.hip dboard_offset)
+#endif
 #ifdef FDAPDE_GATHER_3BAR   // (A/B builds of tools/: the record sums through `tot` and three barriers)
 constexpr bool kGather3 = true;
 #else
@@ -775,12 +780,12 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
             for (int ww = 0; ww < W; ++ww) solo_tot[0] += red[ww][0], solo_tot[1] += red[ww][1], solo_tot[2] += red[ww][2];
             prefetch_next();
         } else {
-        unsigned long long* dslot = a.dboard + (size_t)(it & 1) * a.G * 6;
+        unsigned long long* dslot = a.dboard + (size_t)(it & 1) * a.G * kDotStride;
         if (tid < 3) {
             double v = 0;
 #pragma unroll
             for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
-            publish_f64_x4(dslot + (size_t)g * 6 + 2 * tid, epoch, v);
+            publish_f64_x4(dslot + (size_t)g * kDotStride + 2 * tid, epoch, v);
         }
         prefetch_next();
         {   // thread t collects workgroup t's three sums (a lane re-reads its record until all six tags match, then stops loading); every
@@ -796,7 +801,7 @@ static __global__ __launch_bounds__(kPersistT) void k_cg_persist(PersistArgs a) 
             if (a.gather_waves == 1 ? wave == 0 : wave * 64 < a.G) {   // wave-uniform
                 for (int rsel = 0; rsel < per_lane; ++rsel) {
                     const int w = a.gather_waves == 1 ? rsel * 64 + lane : tid;
-                    const unsigned long long* gp = dslot + (size_t)(w < a.G ? w : 0) * 6;
+                    const unsigned long long* gp = dslot + (size_t)(w < a.G ? w : 0) * kDotStride;
                     pg_v2u64 q0 = {0, 0}, q1 = {0, 0}, q2 = {0, 0};
                     bool done = w >= a.G;
                     long long t_wait = 0;

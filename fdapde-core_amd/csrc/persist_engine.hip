@@ -11,6 +11,10 @@
 #include "kernels_persist.h"
 #include "kernels_persist_bicg.h"
 
+// the dot records start on a 64-byte boundary behind the p entries (hipMalloc: 256-byte aligned base), 8 granules = 64 bytes apart: a record never
+// straddles two 128-byte lines; every board length is a multiple of 8 granules so that the boards of side-by-side columns keep the alignment
+static inline size_t dboard_offset(int64_t n_board) { return (2 * (size_t)n_board + 7) & ~(size_t)7; }
+
 namespace fdapde_engine {
 
 // FDAPDE_SETUP_CHECK: the device-built persistent layout against the host builder's
@@ -193,7 +197,7 @@ int build_persist_once(fdapde_ctx* c, int v, const std::vector<int32_t>* block_r
     else ps.wg_late.release();
     HIPCHK(c, ps.ell_val.alloc((size_t)pl.n_entries + 256));
     HIPCHK(c, hipMemsetAsync(ps.ell_val.p, 0, sizeof(double) * ((size_t)pl.n_entries + 256), st));
-    HIPCHK(c, ps.board.alloc(2 * (size_t)pl.n_board + 2 * (size_t)pl.G * 8 + 2));   // p entries | dot records x 2 buffers (CG: 3 doubles wide, BiCGStab: 4)
+    HIPCHK(c, ps.board.alloc(dboard_offset(pl.n_board) + 2 * (size_t)pl.G * 8 + 8));   // p entries | dot records x 2 buffers (CG: 3 doubles wide, BiCGStab: 4)
     HIPCHK(c, hipMemsetAsync(ps.board.p, 0, sizeof(unsigned long long) * ps.board.n, st));   // every tag 0: no launch uses epoch 0
     ps.epoch_next = 0, ps.attr_set = nullptr;
     ps.board_cols.release();   // (boards of multi-column launches: tags of the layout before must not meet the new epochs)
@@ -222,7 +226,7 @@ int launch_persist(fdapde_ctx* c, fdapde_ctx::Persist& ps, PersistArgs& a, bool 
     a.gather_waves = c->persist_gather_waves, a.poll_sleep = c->persist_poll_sleep;
     a.slot_dof = ps.slot_dof.p, a.ell_off = ps.ell_off.p, a.sl_off = ps.sl_off.p, a.ell_code = ps.ell_code.p;
     a.ell_val = ps.ell_val.p, a.exp_off = ps.exp_off.p, a.exp_slot = ps.exp_slot.p, a.imp_off = ps.imp_off.p, a.imp_pos = ps.imp_pos.p;
-    if (!dist && a.n_cols <= 1) a.pboard = ps.board.p, a.dboard = ps.board.p + 2 * (size_t)ps.meta.n_board;   // (row-distributed, several columns: set by the caller)
+    if (!dist && a.n_cols <= 1) a.pboard = ps.board.p, a.dboard = ps.board.p + dboard_offset(ps.meta.n_board);   // (row-distributed, several columns: set by the caller)
     if (!dist) a.wg_late = ps.wg_late.p;
     a.exp_lds = (!dist && !bicg && ps.exp_lds) ? 1 : 0;
     a.amax_bits = ps.amax.p, a.max_len = c->hs.max_row, a.stats = c->persist_stats.p;
@@ -532,7 +536,7 @@ int run_persist_cols(fdapde_ctx* c, int v, double tol2, int maxit, int n_cols, c
     a.maxit = maxit, a.time_phases = 0, a.tol2 = tol2;
     a.r_in = r_cols, a.x = nullptr, a.x_out = x_cols, a.sc = sc_cols, a.ctl = ctl_cols;
     a.n_cols = n_cols, a.col_stride = (int64_t)n, a.board_stride = (int64_t)blen;
-    a.pboard = ps.board_cols.p, a.dboard = ps.board_cols.p + 2 * (size_t)ps.meta.n_board;
+    a.pboard = ps.board_cols.p, a.dboard = ps.board_cols.p + dboard_offset(ps.meta.n_board);
     const int rc_launch = launch_persist(c, ps, a, false, bicg);
     if (rc_launch == FDAPDE_EUNSUPPORTED) {
         *ran = false;
@@ -846,7 +850,7 @@ int build_rowdist(fdapde_ctx* c, int v) {
     fdapde_ctx::Persist& ps = L.ps;
     const size_t n_p = (size_t)n_ghost;
     inject(3);
-    if (!local_err && soft(ps.board.alloc(2 * (size_t)pl.n_board + 2 * (size_t)pl.G * 8 + 2), "board allocation") &&
+    if (!local_err && soft(ps.board.alloc(dboard_offset(pl.n_board) + 2 * (size_t)pl.G * 8 + 8), "board allocation") &&
         soft(L.rboard.alloc_fine(2 * n_p + 2 * (size_t)W * 8 + 2 * (size_t)L.G_tot * 8 + 2), "board allocation (fine-grained)"))
         if (soft(hipMemsetAsync(ps.board.p, 0, sizeof(unsigned long long) * ps.board.n, st), "board clear") &&
             soft(hipMemsetAsync(L.rboard.p, 0, sizeof(unsigned long long) * L.rboard.n, st), "board clear"))
@@ -1001,7 +1005,7 @@ int run_rowdist(fdapde_ctx* c, int v, double tol2, int maxit, bool* ran, bool bi
     a.g_base = L.g_base, a.G_tot = L.G_tot, a.flat_gather = c->rd.flat_gather < 0 ? (L.G_tot <= 1024 ? 1 : 0) : c->rd.flat_gather;
     a.wg_late = L.wg_late.p, a.rexp_off = L.rexp_off.p, a.rexp_slot = L.rexp_slot.p, a.rexp_peer = L.rexp_peer.p, a.rexp_pos = L.rexp_pos.p;
     a.peer_pboard = L.peer_pboard.p, a.peer_dboard = L.peer_dboard.p;
-    a.pboard = ps.board.p, a.dboard = ps.board.p + 2 * (size_t)ps.meta.n_board, a.rboard = L.rboard.p;
+    a.pboard = ps.board.p, a.dboard = ps.board.p + dboard_offset(ps.meta.n_board), a.rboard = L.rboard.p;
     // a launch or read-back ERROR of this rank counts as "failed" in the ranks' decision first (they would wait for ever in the all-reduce
     // below, or for this rank's granules until their time-outs), and is returned to this rank's caller after it
     const int rc_launch = launch_persist(c, ps, a, /*dist=*/true, bicg);

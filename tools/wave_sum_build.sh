@@ -15,5 +15,6 @@ build() {   # tag, defines...
 }
 build shfl -DFDAPDE_WAVE_SUM_SHFL -DFDAPDE_GATHER_3BAR &
 build bar3 -DFDAPDE_GATHER_3BAR &
+build stride6 -DFDAPDE_DOT_STRIDE6 &
 wait
 ls -la $OUT

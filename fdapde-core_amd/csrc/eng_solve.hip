@@ -303,7 +303,7 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss, b
     int32_t* diag_flag = c->ctl.p + (ss->diag_deferred ? 4 : 3);
     ss->front_pending = false, ss->front_A = A;
     // ... and the smallest of them (one workgroup): flag reset, scale and fill are left to k_small_front (solve_run), if the layout turns out to be one it takes
-    bool front_candidate = ss->diag_deferred && symmetric && c->small_front_rows > 0 && n <= c->small_front_rows && A == c->vals[FDAPDE_MAT_STIFF].p &&
+    bool front_candidate = ss->diag_deferred && (symmetric || c->persist_bicg) && c->small_front_rows > 0 && n <= c->small_front_rows && A == c->vals[FDAPDE_MAT_STIFF].p &&
                            c->stiff_stat_valid && c->persist && !c->persist_broken && c->spmv_variant == 2;
     if (!front_candidate) HIPCHK(c, hipMemsetAsync(c->ctl.p, 0, 8 * sizeof(int32_t), st));
     if (front_candidate) {
@@ -627,8 +627,15 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
     if (bicg && !dist && !ss.rowdist && c->persist && c->persist_bicg && !c->persist_broken) {   // the whole BiCGStab as one launch
         const fdapde_ctx::Persist& ps = c->ps[ss.use_bnd ? 1 : 0];
         if (ps.ok && ps.filled && !ps.meta.sym && ps.meta.R <= 8) {
-            if (int rc = run_persist(c, ss.use_bnd ? 1 : 0, tol2, maxit, &persisted, /*bicg=*/true)) return rc;
-            if (persisted) stop = true, launched = c->h_ctl[1];
+            c->persist_tail = [&]() -> int {   // (as for the CG launch above)
+                if (!c->tail_in_launch) hipLaunchKernelGGL(k_unscale, dim3(g1(n)), dim3(256), 0, st, n, c->scale.p, c->persist_x.p, c->gt.p, c->u.p);
+                if (c->ev1_at_end) HIPCHK(c, hipEventRecord(c->ev1, st));
+                return FDAPDE_OK;
+            };
+            const int rc_p = run_persist(c, ss.use_bnd ? 1 : 0, tol2, maxit, &persisted, /*bicg=*/true);
+            c->persist_tail = nullptr;
+            if (rc_p) return rc_p;
+            if (persisted) stop = true, launched = c->h_ctl[1], unscaled = true;
         }
     }
     // one iteration of the fused-update CG: SpMV (p.y, y.y) + k_cgf_update; arguments depend on the iteration's parity only

@@ -228,8 +228,30 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
         if constexpr (STREAM)
             if (a.pf_steps != 0) touch_first_step<RI, W>(slo, gv, gc, wave, lane, (unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)pf_dump);
     };
+    double gt[4] = {0.0, 0.0, 0.0, 0.0};   // the totals of the last gather, in every thread
+    int gsel = 0;
+    __shared__ double red_solo[2][W][4];
     auto gather = [&](double s0, double s1, double s2, double s3, int phase, unsigned epoch) -> bool {
         s0 = wave_sum64(s0), s1 = wave_sum64(s1), s2 = wave_sum64(s2), s3 = wave_sum64(s3);
+        if (!DIST && a.G == 1) {
+            // ONE workgroup: its sums are the totals.  One barrier per gather instead of three: the wavefronts' partials go into the table of this
+            // gather's parity (rewritten two gathers on, behind the barrier of the gather in between), and every thread adds them itself in the order the
+            // one summing thread per total uses elsewhere -- the same bits.  The barrier also ends the table reads of the application before.
+            const int b = gsel & 1;
+            ++gsel;
+            if (lane == 0) red_solo[b][wave][0] = s0, red_solo[b][wave][1] = s1, red_solo[b][wave][2] = s2, red_solo[b][wave][3] = s3;
+            __syncthreads();
+            gt[0] = gt[1] = gt[2] = gt[3] = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < W; ++ww)
+                gt[0] += red_solo[b][ww][0], gt[1] += red_solo[b][ww][1], gt[2] += red_solo[b][ww][2], gt[3] += red_solo[b][ww][3];
+            prefetch_next();
+            return true;
+        }
+        auto fin = [&]() -> bool {   // (behind the barrier that follows the totals)
+            gt[0] = tot[0], gt[1] = tot[1], gt[2] = tot[2], gt[3] = tot[3];
+            return fail_flag == 0;
+        };
         __syncthreads();   // (the table reads of the application before, and the totals of the gather before, are done with)
         if (lane == 0) red[wave][0] = s0, red[wave][1] = s1, red[wave][2] = s2, red[wave][3] = s3;
         __syncthreads();
@@ -289,18 +311,7 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
                 tot[tid] = v;
             }
             __syncthreads();
-            return fail_flag == 0;
-        }
-        if (!DIST && a.G == 1) {   // one workgroup: its sums are the totals (kernels_persist.h)
-            if (tid < 4) {
-                double v = 0;
-#pragma unroll
-                for (int ww = 0; ww < W; ++ww) v += red[ww][tid];
-                tot[tid] = v;
-            }
-            prefetch_next();
-            __syncthreads();
-            return true;
+            return fin();
         }
         unsigned long long* dslot = a.dboard + (size_t)phase * a.G * 8;
         if (tid < 4) {
@@ -389,7 +400,7 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
             }
             __syncthreads();
         }
-        return fail_flag == 0;
+        return fin();
     };
 
     for (;;) {
@@ -410,8 +421,8 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
             status = 3;
             break;
         }
-        const double r0v = tot[0];
-        rr = tot[1];
+        const double r0v = gt[0];
+        rr = gt[1];
         if (it == 0) rho = rr;   // r0 = r: rho = r0.r0
         if (rr <= a.tol2 * bb) {
             status = 1;
@@ -437,7 +448,7 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
             status = 3;
             break;
         }
-        const double ts = tot[0], tt = tot[1], r0s = tot[2], r0t = tot[3];
+        const double ts = gt[0], tt = gt[1], r0s = gt[2], r0t = gt[3];
         omega = tt > 0.0 ? ts / tt : 0.0;
         rr_part = 0;
 #pragma unroll
@@ -462,18 +473,27 @@ static __global__ __launch_bounds__(kPersistT) void k_bicg_persist(PersistArgs a
         // that did not start -- nobody has published under it.  A breakdown noticed BEFORE the update (rho = 0 or r0.v = 0) needs no gather:
         // rr already is the global sum gather 1 of that iteration delivered, and a second record under the SAME tag could be picked up half
         // old, half new by a poller.
-        if (gather(0.0, rr_part, 0.0, 0.0, 0, a.epoch0 + 2u * (unsigned)it + 1u)) rr = tot[1];
+        if (gather(0.0, rr_part, 0.0, 0.0, 0, a.epoch0 + 2u * (unsigned)it + 1u)) rr = gt[1];
         else status = 3;
     }
     if constexpr (STREAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (touches of an application that did not come)
     if (status != 3) {
 #pragma unroll
         for (int j = 0; j < R; ++j)
-            if (dof[j] >= 0) a.x_out[dof[j]] = xv[j];
+            if (dof[j] >= 0) {
+                a.x_out[dof[j]] = xv[j];
+                if (!DIST && a.u_out != nullptr) a.u_out[dof[j]] = a.scale[dof[j]] * xv[j] + 0.0;   // (the epilogue of a small solve: kernels_persist.h)
+            }
     }
     if (g == 0 && tid == 0 && status != 3) {
         a.sc[3] = rr;
         a.ctl[0] = status == 1 ? 1 : 0, a.ctl[1] = it, a.ctl[2] = status == 2 ? 1 : 0;
+    }
+    if constexpr (!DIST) {
+        if (a.hrec != nullptr && g == 0 && tid == 0) {   // (one-workgroup launches of fdapde_solve: the outcome into pinned host memory, kernels_persist.h)
+            a.hrec[0] = status == 1 ? 1.0 : 0.0, a.hrec[1] = (double)it, a.hrec[2] = status == 2 ? 1.0 : 0.0, a.hrec[3] = status == 3 ? 1.0 : 0.0;
+            a.hrec[4] = (double)a.ctl[4], a.hrec[5] = bb, a.hrec[6] = rr;
+        }
     }
     if (status == 3 && tid == 0) atomicExch(a.ctl + 3, 1);
 }

@@ -392,7 +392,7 @@ int run_persist(fdapde_ctx* c, int v, double tol2, int maxit, bool* ran, bool bi
     // small systems in one workgroup (what the reference's users mostly solve): no phase stamps (a memset and a copy), and the outcome comes back
     // through a record in pinned host memory the launch writes itself instead of through three device-to-host copies (13 us of blit kernels
     // behind a 130 us launch)
-    const bool host_rec = !bicg && ps.meta.G == 1 && c->small_rows > 0 && (int64_t)n <= c->small_rows;
+    const bool host_rec = ps.meta.G == 1 && c->small_rows > 0 && (int64_t)n <= c->small_rows;
     if (host_rec) a.time_phases = 0, a.hrec = c->h_sc + 8;
     // ... and behind k_small_front (the Dirichlet entries of u are in place) the epilogue is the launch's own write-out
     c->tail_in_launch = host_rec && c->front_used && c->persist_tail != nullptr;

@@ -402,12 +402,27 @@ def test_one_workgroup_without_hand_offs_matches_several(env, dim, nx, order, di
     (2, 30, 1, False, True),    # no Dirichlet DOF
 ])
 def test_small_front_kernel_gives_the_separate_launches_bits(env, dim, nx, order, dirichlet, zero_g):
+    _small_front_case(env, dim, nx, order, dirichlet, zero_g, adr=False)
+
+
+@pytest.mark.parametrize("dim,nx,order,zero_g", [(2, 16, 1, True), (2, 24, 1, False), (3, 8, 1, False), (2, 12, 2, False)])
+def test_small_front_kernel_with_the_single_launch_bicgstab(env, dim, nx, order, zero_g):
+    """the same for a non-symmetric operator (advection-diffusion-reaction): k_small_front seeds the shadow residual too, the single-launch BiCGStab
+    writes its outcome record and the unscaled solution itself"""
+    _small_front_case(env, dim, nx, order, True, zero_g, adr=True)
+
+
+def _small_front_case(env, dim, nx, order, dirichlet, zero_g, adr):
     """fdapde_solve of a one-workgroup system of at most `small_front_rows` DOFs enqueues flag reset, Jacobi scale, layout fill, lift and the Krylov
     start-up as ONE kernel (k_small_front: the same device functions in the same launch geometry) and the epilogue inside the launch
     (PersistArgs::u_out): same iterations, identical solution bits as the separate launches (knob small_front_rows = 0), from the second solve on
     (the first one builds the layout's column table)"""
     capi, meshgen = env
     c, nd = _problem(capi, meshgen, dim, nx, order, dirichlet)
+    if adr:
+        b = (1.0, 0.5) if dim == 2 else (1.0, 0.5, 0.25)
+        c.set_operator(-capi.laplacian() + capi.advection(b) + capi.reaction(1.0))
+        c.init()
     if dirichlet and zero_g:
         c.set_dirichlet(np.zeros(nd))
     c.tune("small_front_rows", 0)

@@ -13,9 +13,30 @@ namespace fdapde_hip {
 // ---------------------------------------------------------------------------------------------------------------
 // reductions
 // ---------------------------------------------------------------------------------------------------------------
+// Sum over the wavefront (valid in lane 0 -- in every lane, in fact): the butterfly v += v[lane ^ o], o = 32 .. 1, on the VALU -- gfx950's
+// v_permlane32_swap / v_permlane16_swap for the two widest steps, DPP moves inside the rows of 16 -- instead of the six ds_bpermute pairs a shuffle
+// loop compiles to (LDS crossbar, ~100 cycles each).  Lane 0's operands, hence its bits, are those of the __shfl_down tree this replaces
+// (kernels_persist.h wave_sum64 has the argument).
+template <int CTRL> __device__ __forceinline__ double reduce_dpp_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int O> __device__ __forceinline__ double reduce_swap_sum(double v) {
+    const long long b = __double_as_longlong(v);
+    const unsigned l = (unsigned)(b & 0xffffffffll), h = (unsigned)(b >> 32);
+    const auto lo = O == 32 ? __builtin_amdgcn_permlane32_swap(l, l, false, false) : __builtin_amdgcn_permlane16_swap(l, l, false, false);
+    const auto hi = O == 32 ? __builtin_amdgcn_permlane32_swap(h, h, false, false) : __builtin_amdgcn_permlane16_swap(h, h, false, false);
+    return __longlong_as_double(((long long)hi[0] << 32) | lo[0]) + __longlong_as_double(((long long)hi[1] << 32) | lo[1]);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    v = reduce_swap_sum<32>(v);
+    v = reduce_swap_sum<16>(v);
+    v += reduce_dpp_f64<0x128>(v);   // row_ror:8
+    v += reduce_dpp_f64<0x124>(v);   // row_ror:4
+    v += reduce_dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += reduce_dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
     return v;
 }
 // sum over the workgroup; result valid in every thread.  red must hold blockDim/64 + 1 doubles.

@@ -332,7 +332,12 @@ int fdapde_rowdist_setup(fdapde_ctx *ctx, const int64_t *dof_key, const int32_t 
  *                 "persist_direct" (0: a single right-hand side of a one-workgroup system takes the general path instead of the launch that
  *                 reads b and writes x and its outcome through pinned host memory itself), "persist_direct_spin_us" (host spin on that outcome),
  *                 "persist_single_rows" (systems of up to that many interior rows run as one workgroup, without hand-offs),
- *                 "persist_prefetch" (0: the streaming forms do not touch the next operator application's first lines during the dot all-gather) */
+ *                 "persist_prefetch" (0: the streaming forms do not touch the next operator application's first lines during the dot all-gather),
+ *                 "persist_exp_lds" (0: the symmetric streaming form re-reads its export list from global memory every iteration)
+ *   solve         "auto_gmres" (0: the open method ends with BiCGStab), "gmres_m" (restart length, default 50),
+ *                 "small_rows" (systems of up to that many DOFs: no wait for the positive-diagonal flag, outcome through a pinned record; 0: off),
+ *                 "small_front_rows" (one-workgroup systems of up to that many DOFs: ONE kernel in front of the single launch -- k_small_front --
+ *                 and the epilogue inside the launch; 0: the separate launches), "asm_items_fuse" (0: the P2 mass matrix in a sweep of its own) */
 int fdapde_tune(fdapde_ctx *ctx, const char *key, int32_t value);
 /* the context's HIP stream (hipStream_t) so that callers can bracket work with their own events */
 void *fdapde_stream(fdapde_ctx *ctx);

@@ -558,14 +558,15 @@ def _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, form, shar
 
 # ---- what the first record from N real GPUs should show (the acceptance table) ----------------------------------------------------------
 # Single-GPU iteration of the single launch against the rows a GPU holds (3-D P1, measured on MI355X: DESIGN 4.0 table and BENCH_r05)
-_ITER_US_BY_ROWS = ((227e3, 9.5), (275e3, 10.9), (389e3, 13.7), (754e3, 17.8), (1.03e6, 21.3), (1.643e6, 30.0))
+# interior rows -> us per iteration of the single-launch CG, 3-D P1, one MI355X (tools/iter_by_rows.py, final round-5 build)
+_ITER_US_BY_ROWS = ((85e3, 6.6), (205e3, 8.0), (250e3, 9.8), (358e3, 12.4), (705e3, 16.6), (970e3, 20.2), (1.643e6, 29.2))
 XGMI_HOP_US = 1.5   # ASSUMED one-way latency of a posted 16-byte store into a peer's board over xGMI (no measurement on this pool; the first record replaces it)
 
 
 def _interp_iter_us(rows):
     pts = _ITER_US_BY_ROWS
     if rows <= pts[0][0]:
-        return pts[0][1] * max(rows / pts[0][0], 0.6)   # (below 227 k rows the iteration is the hand-off latencies, not the rows)
+        return pts[0][1] * max(rows / pts[0][0], 0.6)   # (below 85 k rows the iteration is the hand-off latencies, not the rows)
     for (r0, t0), (r1, t1) in zip(pts, pts[1:]):
         if rows <= r1:
             return t0 + (t1 - t0) * (rows - r0) / (r1 - r0)

@@ -409,7 +409,8 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss, b
     }
     if (blocked) {
         const int v = use_bnd ? 1 : 0;
-        hipLaunchKernelGGL(k_persist_fill, dim3((unsigned)((c->bk[v].meta.n_entries + 1023) / 1024)), dim3(256), 0, st, c->bk[v].meta.n_entries, c->bk[v].ell_src.p,
+        if (c->bk[v].meta.n_entries > 0)
+            hipLaunchKernelGGL(k_persist_fill, dim3((unsigned)((c->bk[v].meta.n_entries + 1023) / 1024)), dim3(256), 0, st, c->bk[v].meta.n_entries, c->bk[v].ell_src.p,
                            c->sval.p, c->bk[v].ell_val.p, (unsigned long long*)nullptr);
         c->bk[v].filled = true, c->bk_cur = v;
     }

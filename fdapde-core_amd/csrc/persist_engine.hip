@@ -509,7 +509,8 @@ int fill_persist_scaled(fdapde_ctx* c, int v, const double* A) {
     if (ps.ell_col.n < n_alloc) {   // once per layout
         HIPCHK(c, ps.ell_col.alloc(n_alloc));
         HIPCHK(c, hipMemsetAsync(ps.ell_col.p, 0, sizeof(int32_t) * n_alloc, st));
-        hipLaunchKernelGGL(k_persist_ell_col, dim3(grid1(ps.meta.n_entries)), dim3(256), 0, st, ps.meta.n_entries, ps.ell_src.p, c->colidx.p, ps.ell_col.p);
+        if (ps.meta.n_entries > 0)   // (a block without off-diagonal entries -- ONE interior row -- has nothing to fill: a grid of 0 workgroups is a launch error)
+            hipLaunchKernelGGL(k_persist_ell_col, dim3(grid1(ps.meta.n_entries)), dim3(256), 0, st, ps.meta.n_entries, ps.ell_src.p, c->colidx.p, ps.ell_col.p);
     }
     const int per = (ps.meta.nsl + 3) / 4;
     hipLaunchKernelGGL(k_persist_fill_scaled, dim3((unsigned)(ps.meta.G * per)), dim3(256), 0, st, ps.meta.G, ps.meta.nsl, ps.ell_off.p, ps.sl_off.p, ps.slot_dof.p,
@@ -561,7 +562,8 @@ int fill_persist(fdapde_ctx* c, int v) {
     fdapde_ctx::Persist& ps = c->ps[v];
     hipStream_t st = c->stream;
     if (ps.meta.sym) HIPCHK(c, hipMemsetAsync(ps.amax.p, 0, sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(k_persist_fill, dim3((unsigned)((ps.meta.n_entries + 1023) / 1024)), dim3(256), 0, st, ps.meta.n_entries, ps.ell_src.p, c->sval.p, ps.ell_val.p,
+    if (ps.meta.n_entries > 0)
+        hipLaunchKernelGGL(k_persist_fill, dim3((unsigned)((ps.meta.n_entries + 1023) / 1024)), dim3(256), 0, st, ps.meta.n_entries, ps.ell_src.p, c->sval.p, ps.ell_val.p,
                        ps.meta.sym ? ps.amax.p : (unsigned long long*)nullptr);
     HIPCHK(c, hipGetLastError());
     ps.filled = true;
@@ -978,7 +980,8 @@ int fill_rowdist(fdapde_ctx* c, int v) {
     fdapde_ctx::Persist& ps = c->rd.lay[v].ps;
     hipStream_t st = c->stream;
     if (ps.meta.sym) HIPCHK(c, hipMemsetAsync(ps.amax.p, 0, sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(k_persist_fill, dim3((unsigned)((ps.meta.n_entries + 1023) / 1024)), dim3(256), 0, st, ps.meta.n_entries, ps.ell_src.p, c->sval.p, ps.ell_val.p,
+    if (ps.meta.n_entries > 0)
+        hipLaunchKernelGGL(k_persist_fill, dim3((unsigned)((ps.meta.n_entries + 1023) / 1024)), dim3(256), 0, st, ps.meta.n_entries, ps.ell_src.p, c->sval.p, ps.ell_val.p,
                        ps.meta.sym ? ps.amax.p : (unsigned long long*)nullptr);
     HIPCHK(c, hipGetLastError());
     ps.filled = true;

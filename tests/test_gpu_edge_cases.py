@@ -47,6 +47,35 @@ def test_every_dof_on_the_boundary(capi, advect):
     assert info.iters == 0 and np.array_equal(u, np.full(u.shape, 1.5))
 
 
+@pytest.mark.parametrize("advect", [False, True])
+def test_one_interior_dof(capi, advect):
+    """27 nodes of a 2 x 2 x 2 cube mesh, 26 of them on the boundary: the interior block is ONE row without an off-diagonal entry (found by
+    tools/fuzz_small.py: the fill of the solver layout launched a grid of 0 workgroups).  The answer is f_i / A_ii with the lift."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+
+    from fdapde_core_amd import meshgen
+
+    nodes, cells, bnd = meshgen.unit_cube(2)
+    op = -capi.laplacian() + (capi.advection((1.0, 0.5, 0.25)) + capi.reaction(1.0) if advect else capi.reaction(0.0))
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(1)
+    _, bdofs, coords = c.dofs_get()
+    assert nd == 27 and int((bdofs == 0).sum()) == 1
+    c.set_operator(op)
+    c.set_forcing(np.ones(c.quadrature_nodes().shape[0]))
+    c.set_dirichlet(0.5 + coords[:, 0])
+    c.init()
+    for _ in range(2):
+        info = c.solve(rtol=1e-12)
+        rp, ci = c.pattern_get()
+        A = sp.csr_matrix((c.matrix_values(capi.MAT_STIFF), ci, rp), shape=(nd, nd))
+        ref = spl.spsolve(A.tocsc(), c.force())
+        assert info.converged == 1 and np.linalg.norm(c.solution() - ref) <= 1e-12 * np.linalg.norm(ref)
+    c.close()
+
+
 @pytest.mark.parametrize("dim,order,advect", [(2, 1, False), (2, 1, True), (3, 2, False)])
 def test_zero_right_hand_side(capi, dim, order, advect):
     from fdapde_core_amd import meshgen

@@ -267,9 +267,11 @@ class Context:
     def set_forcing(self, f_q):
         if f_q is None:
             self._check(self.lib.fdapde_set_forcing(self._ctx, None, 0))
+            self._force_cols = 1
             return
         f = np.asarray(f_q, dtype=float)
         ncols = 1 if f.ndim == 1 else f.shape[1]
+        self._force_cols = ncols
         flat = np.ascontiguousarray(f.reshape(f.shape[0], ncols).T).reshape(-1)  # column-major
         self._check(self.lib.fdapde_set_forcing(self._ctx, _dp(flat), ncols))
 
@@ -383,7 +385,15 @@ class Context:
         self._check(self.lib.fdapde_lump(self._ctx, which, _dp(out)))
         return out
 
-    def force(self, ncols=1):
+    def force(self, ncols=None):
+        """force_ (n_dofs x forcing columns, column after column).  ncols defaults to the columns of the last set_forcing of THIS wrapper: fdapde_force
+        writes n_dofs * (forcing columns) doubles whatever the caller expects (a shorter buffer is a heap overrun -- tools/fuzz_handle.py found that
+        the hard way)"""
+        have = getattr(self, "_force_cols", 1)
+        if ncols is None:
+            ncols = have
+        if ncols < have:
+            raise ValueError(f"force(): the context holds {have} forcing columns, a buffer for {ncols} was asked for")
         out = np.zeros(self.sizes()["n_dofs"] * ncols)
         self._check(self.lib.fdapde_force(self._ctx, _dp(out)))
         return out

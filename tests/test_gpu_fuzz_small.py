@@ -19,3 +19,14 @@ def test_random_small_systems_against_lu(seed):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_small.py"), "40", str(seed)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "failures 0" in r.stdout.splitlines()[-1], r.stdout[-500:]
+
+
+def test_random_handles_and_parabolic_problems_against_lu():
+    """tools/fuzz_handle.py: the factor-once handle with 1 / 3 / 70 right-hand sides (zero-copy launch, columns side by side, more columns than one launch
+    takes) on mass / stiff / non-symmetric matrices, and implicit Euler over 2-6 steps with and without Dirichlet data, against scipy (1e-8)"""
+    from fdapde_loader import load_package
+
+    assert load_package().capi.load().fdapde_device_count() >= 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_handle.py"), "30", "29"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "failures 0" in r.stdout.splitlines()[-1], r.stdout[-500:]

@@ -45,6 +45,9 @@ def _ops(mod, M):
         "adr": -mod.laplacian() + mod.advection(b) + mod.reaction(1.5),
         "diffusion": mod.diffusion(K) + 0.5 * mod.reaction(2.0),
         "laplacian_minus_dt": mod.laplacian() - mod.dt(),
+        # a diffusion tensor that is NOT symmetric (the summed tensor then takes the full 9 + 3 + 1 reference tables, not the compact symmetric ones)
+        "diffusion_nonsym": mod.diffusion(K + (np.array([[0.0, 0.4], [-0.2, 0.0]]) if M == 2 else np.array([[0.0, 0.4, 0.0], [-0.2, 0.0, 0.3], [0.1, -0.3, 0.0]])))
+        + mod.advection(b) + mod.reaction(0.5),
     }
 
 

@@ -3,7 +3,7 @@
 single-launch BiCGStab serve) against scipy's sparse LU of the system the product itself hands out (stiff() / force() after the solve: Dirichlet rows zeroed,
 unit diagonal -- the reference's matrix, fem_solver_base.h:142-155).  Random mesh size, dimension, order, operator (symmetric / advection-diffusion-reaction),
 Dirichlet data (none / zero / non-zero), forcing; every case solved three times (first solve of a layout, then the fused front, then after new data).
-usage: fuzz_small.py [cases] [seed] [mid]"""
+usage: fuzz_small.py [cases] [seed] [mid|tiny]"""
 import os
 import sys
 
@@ -19,6 +19,7 @@ import scipy.sparse.linalg as spl   # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+TINY = len(sys.argv) > 3 and sys.argv[3] == "tiny"   # 1 - 3 cells per axis: a handful of DOFs, most or all of them on the boundary
 MID = len(sys.argv) > 3 and sys.argv[3] == "mid"   # systems of 3 000 - 60 000 DOFs: several workgroups, plain / symmetric storage, resident / streaming
 worst = 0.0
 fails = 0
@@ -28,7 +29,9 @@ for case in range(n_cases):
     nx = int(rng.integers(3, 40)) if dim == 2 else int(rng.integers(2, 11))
     if MID:
         nx = int(rng.integers(60, 240)) if dim == 2 else int(rng.integers(14, 36))
-    if order == 2:
+    if TINY:
+        nx = int(rng.integers(1, 4))
+    if order == 2 and not TINY:
         nx = max(2, nx // 2)
     nodes, cells, bnd = meshgen.unit_square(nx, seed=int(rng.integers(1, 1 << 30))) if dim == 2 else meshgen.unit_cube(nx, seed=int(rng.integers(1, 1 << 30)))
     kind = rng.choice(["laplace", "reaction", "adr", "diffusion"])

@@ -136,6 +136,7 @@ struct HostTerm {
     fdapde_term t;
     std::vector<double> data_i;              // space-varying data permuted to internal cell order (contexts whose space is not on a device yet)
     std::shared_ptr<DBuf<double>> data_dev;  // ... or already on the device, permuted there (check_terms)
+    bool field_nonsym = false;               // a diffusion FIELD with a row that is not a symmetric tensor (check_terms)
 };
 
 }  // namespace fdapde_detail

@@ -76,6 +76,12 @@ int make_dev_op(fdapde_ctx* c, const std::vector<HostTerm>& terms, DevOp* out, i
         for (int q = 0; q < r; ++q) ksym = ksym && op.kt[r * N + q] == op.kt[q * N + r];
     op.tab_sym = (ksym && !adv) ? 1 : 0;
     op.kt_sym = ksym ? 1 : 0;
+    bool any_adv = false, field_nonsym = false;
+    for (size_t k = 0; k < terms.size(); ++k) {
+        any_adv = any_adv || terms[k].t.kind == FDAPDE_ADVECTION;
+        field_nonsym = field_nonsym || (terms[k].t.kind == FDAPDE_DIFFUSION && terms[k].field_nonsym);
+    }
+    op.mirror = (!any_adv && (!ksym || field_nonsym)) ? 1 : 0;
     *out = op;
     return FDAPDE_OK;
 }
@@ -112,6 +118,16 @@ int check_terms(fdapde_ctx* c, int32_t n_terms, const fdapde_term* terms, std::v
                 hipLaunchKernelGGL(k_gather_row_groups, dim3((unsigned)(((int64_t)rows * width + 255) / 256)), dim3(256), 0, c->stream, hs.n_cells, grp,
                                    c->cell_i2e.p, stage.p, h.data_dev->p);
                 HIPCHK(c, hipGetLastError());
+                if (terms[k].kind == FDAPDE_DIFFUSION) {   // a row that is not a symmetric tensor?  (make_dev_op: DevOp::mirror)
+                    DBuf<int32_t> flag;
+                    int32_t h_flag = 0;
+                    HIPCHK(c, flag.alloc(1));
+                    HIPCHK(c, hipMemsetAsync(flag.p, 0, sizeof(int32_t), c->stream));
+                    hipLaunchKernelGGL(k_field_asym, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, c->stream, rows, hs.N, h.data_dev->p, flag.p);
+                    HIPCHK(c, hipMemcpyAsync(&h_flag, flag.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+                    HIPCHK(c, hipStreamSynchronize(c->stream));
+                    h.field_nonsym = h_flag != 0;
+                }
                 HIPCHK(c, hipStreamSynchronize(c->stream));   // (stage is released at the end of this scope)
             } else {
                 h.data_i.resize((size_t)rows * width);
@@ -120,6 +136,11 @@ int check_terms(fdapde_ctx* c, int32_t n_terms, const fdapde_term* terms, std::v
                     std::memcpy(&h.data_i[(size_t)ci * hs.nq * width], &terms[k].data[(size_t)ce * hs.nq * width],
                                 sizeof(double) * hs.nq * width);
                 }
+                if (terms[k].kind == FDAPDE_DIFFUSION)
+                    for (int64_t r = 0; r < rows && !h.field_nonsym; ++r)
+                        for (int a = 1; a < hs.N; ++a)
+                            for (int b = 0; b < a; ++b)
+                                if (h.data_i[(size_t)r * width + a * hs.N + b] != h.data_i[(size_t)r * width + b * hs.N + a]) h.field_nonsym = true;
             }
             h.t.data = nullptr;
         }
@@ -365,6 +386,23 @@ int launch_assembly_t(fdapde_ctx* c, AsmArgs a, const DevOp& op, int assembly) {
     return FDAPDE_OK;
 }
 
+// DevOp::mirror: the assembled matrix as the reference's assembler would have left it (k_mirror_reference_lower)
+int mirror_reference_lower(fdapde_ctx* c, double* vals) {
+    if (c->comm != nullptr || c->ar_fn != nullptr || c->halo_ready || c->rd.ready)
+        return fail(c, FDAPDE_EUNSUPPORTED, "a non-symmetric diffusion tensor in an expression without advection (which the reference assembles as a symmetric "
+                                            "operator: lower triangle by DOF id, mirrored) is supported on single-GPU contexts only: the ranks of a multi-GPU job "
+                                            "number their DOFs independently");
+    const HostSpace& hs = c->hs;
+    DBuf<double> tmp;
+    HIPCHK(c, tmp.alloc((size_t)hs.nnz));
+    hipLaunchKernelGGL(k_mirror_reference_lower, dim3((unsigned)((hs.n_dofs + 255) / 256)), dim3(256), 0, c->stream, hs.n_dofs, c->rowptr.p, c->colidx.p, c->dof_i2e.p,
+                       vals, tmp.p);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(vals, tmp.p, sizeof(double) * (size_t)hs.nnz, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // (tmp goes out of scope)
+    return FDAPDE_OK;
+}
+
 int launch_assembly(fdapde_ctx* c, const AsmArgs& a, const DevOp& op, int assembly) {
     const int M = c->hs.M, R = c->hs.order;
     if (assembly < 0 || assembly > 4) return fail(c, FDAPDE_EINVAL, "unknown assembly variant");
@@ -497,6 +535,8 @@ int e_assemble_operator(fdapde_ctx* c, int32_t which, int32_t n_terms, const fda
     if (which == FDAPDE_MAT_STIFF) c->stiff_stat_valid = false;   // (the row statistics belong to what fdapde_init assembled)
     rc = launch_assembly(c, a, op, assembly);
     if (rc) return rc;
+    if (op.mirror)
+        if (int rc2 = mirror_reference_lower(c, a.vals)) return rc2;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->assembled[which] = true;
     if (which == FDAPDE_MAT_STIFF) c->op_symmetric = sym, c->solved = false, c->dirichlet_applied = false, c->cg_broke_down = false;
@@ -553,7 +593,11 @@ int e_init(fdapde_ctx* c, const fdapde_options* opt) {
         rc = launch_assembly(c, a, op, assembly);
         if (rc) return rc;
     }
-    const bool stat_complete = a.row_stat != nullptr && c->asm_all_in_lds;   // (as the operator's launch found it; later launches overwrite the flag)
+    bool stat_complete = a.row_stat != nullptr && c->asm_all_in_lds;   // (as the operator's launch found it; later launches overwrite the flag)
+    if (op.mirror) {   // (rare: a non-symmetric diffusion tensor without advection)
+        if (int rc2 = mirror_reference_lower(c, c->vals[FDAPDE_MAT_STIFF].p)) return rc2;
+        stat_complete = false;   // (the row maxima belong to the matrix before the mirroring)
+    }
     if (c->fq_cols == 0) HIPCHK(c, hipMemsetAsync(c->force.p, 0, sizeof(double) * (size_t)hs.n_dofs, c->stream));
     for (int col = 1; col < c->fq_cols; ++col) {   // remaining time columns (parabolic forcing), fem_solver_base.h:124-128
         AsmArgs f = asm_args(c);

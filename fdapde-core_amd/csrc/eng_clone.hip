@@ -58,7 +58,7 @@ int e_ctx_clone(const fdapde_ctx* s, fdapde_ctx* d) {
     d->op.clear();
     for (const HostTerm& t : s->op) {
         HostTerm c;
-        c.t = t.t, c.data_i = t.data_i;
+        c.t = t.t, c.data_i = t.data_i, c.field_nonsym = t.field_nonsym;
         if (t.data_dev) {
             c.data_dev = std::make_shared<DBuf<double>>();
             if (int rc = copy_buf(d, *c.data_dev, *t.data_dev, t.data_dev->n)) return rc;

@@ -34,6 +34,9 @@ struct DevOp {
     int32_t tab_sym;      // Kt symmetric and no advection: evaluate in the bitwise-symmetric order
     int32_t kt_sym;       // Kt symmetric (with or without advection): AsmArgs::reftab holds the compact tensors (DevRefTensorsSym)
     int32_t var_kinds;    // which kinds have a space-varying leaf: 1 diffusion, 2 advection, 4 reaction (kt / bt / ct sum the CONSTANT leaves only)
+    int32_t mirror;       // the expression is one the reference treats as SYMMETRIC (no advection leaf: every leaf's is_symmetric is true, diffusion.h:42)
+                          // but its diffusion tensor is not: the reference then integrates only the pairs dof_i >= dof_j and mirrors them
+                          // (fem_assembler.h:94-102, 116-117) -- k_mirror_reference_lower does the same to the assembled matrix (host-side flag)
 };
 
 // quadrature + basis tables as they sit in device memory (copied to LDS by every workgroup that integrates)
@@ -1001,6 +1004,39 @@ static __global__ __launch_bounds__(THREADS) void k_assemble_items(AsmArgs a, De
 }
 
 // dst row group b (nq doubles) = src row group idx[b]: forcing samples from the caller's cell order to the internal one
+// any row of a diffusion field that is not a symmetric tensor?  (rows x N x N, row-major per quadrature node)
+static __global__ __launch_bounds__(256) void k_field_asym(int64_t rows, int N, const double* k, int32_t* flag) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const double* t = k + r * N * N;
+    bool asym = false;
+    for (int a = 1; a < N; ++a)
+        for (int b = 0; b < a; ++b) asym = asym || t[a * N + b] != t[b * N + a];
+    if (asym) atomicOr(flag, 1);
+}
+// What the reference's assembler makes of an expression it takes for symmetric (fem_assembler.h:94-102: only the pairs dof_i >= dof_j -- REFERENCE dof ids --
+// are integrated; 116-117: selfadjointView<Lower> mirrors them) when its diffusion tensor is not: entry (i, j) with dof_i < dof_j is the integral of (j, i).
+// The sweep has integrated every pair; this pass keeps the reference's half and mirrors it (bitwise symmetric result).  One thread per row; the columns of a
+// row are ascending (binary search for the transposed entry).
+static __global__ __launch_bounds__(256) void k_mirror_reference_lower(int64_t n, const int32_t* rowptr, const int32_t* colidx, const int32_t* i2e, const double* in,
+                                                                       double* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t ei = i2e[i];
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+        const int32_t j = colidx[k];
+        double v = in[k];
+        if (ei < i2e[j]) {
+            int32_t lo = rowptr[j], hi = rowptr[j + 1] - 1;
+            while (lo < hi) {
+                const int32_t mid = (lo + hi) >> 1;
+                if (colidx[mid] < (int32_t)i) lo = mid + 1; else hi = mid;
+            }
+            if (colidx[lo] == (int32_t)i) v = in[lo];
+        }
+        out[k] = v;
+    }
+}
 static __global__ __launch_bounds__(256) void k_gather_row_groups(int64_t n, int nq, const int32_t* idx, const double* src, double* dst) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * nq) return;

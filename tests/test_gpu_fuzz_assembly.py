@@ -1,0 +1,105 @@
+"""Randomised operator expressions through fdapde_init (stiff_ + mass_ + force_ in one call) against the CPU oracle: random mesh (generated, jittered, ids
+permuted; 2-D / 3-D), order, and a random sum of terms -- Laplacian, diffusion (constant symmetric / constant non-symmetric / field), advection (constant /
+field), reaction (constant / field), dt -- with random signs and scales.  What the fixtures' fixed operator list cannot reach: every combination of
+"constant through the reference tensors" and "per-node integrand" the operator classifier (OPK) can be handed.  Entries to 1e-12 / 1e-13 relative (the
+parity suite's bar)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ENTRY_TOL = 1e-12
+ENTRY_RTOL = 1e-13
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from fdapde_loader import load_package
+
+    load_package()
+    from fdapde_core_amd import capi as m
+
+    assert m.load().fdapde_device_count() >= 1
+    return m
+
+
+def _close(a, b):
+    amax = max(np.abs(b).max(), 1e-300)
+    err = np.abs(a - b).max()
+    return err <= ENTRY_TOL * max(1.0, amax) and err <= ENTRY_RTOL * amax, err / amax
+
+
+def _random_operator(mod_list, rng, N, rows):
+    """the same random expression built for every module in mod_list (capi, oracle)"""
+    terms = []   # (kind, scale, data)
+    n_terms = int(rng.integers(1, 5))
+    kinds = list(rng.choice(["lap", "diffc", "diffn", "difff", "advc", "advf", "reac", "reaf", "dt"], size=n_terms, replace=True))
+    if not any(k in ("lap", "diffc", "diffn", "difff") for k in kinds):
+        kinds.append("lap")
+    for k in kinds:
+        scale = float(rng.choice([-1.0, 1.0]) * rng.uniform(0.3, 2.0))
+        if k == "diffc":
+            L = rng.uniform(-0.4, 0.4, (N, N))
+            data = L @ L.T + np.eye(N)
+        elif k == "diffn":
+            data = np.eye(N) + rng.uniform(-0.4, 0.4, (N, N))
+        elif k == "difff":
+            L = rng.uniform(-0.3, 0.3, (rows, N, N))
+            K = np.einsum("qij,qkj->qik", L, L) + np.eye(N)[None]
+            if rng.integers(0, 2):
+                K = K + rng.uniform(-0.2, 0.2, (rows, N, N))   # not symmetric
+            data = K.reshape(rows, N * N)
+        elif k == "advc":
+            data = rng.uniform(-1.0, 1.0, N)
+        elif k == "advf":
+            data = rng.uniform(-1.0, 1.0, (rows, N))
+        elif k == "reac":
+            data = float(rng.uniform(0.1, 2.0))
+        elif k == "reaf":
+            data = rng.uniform(0.1, 2.0, rows)
+        else:
+            data = None
+        terms.append((k, scale, data))
+    out = []
+    for mod in mod_list:
+        op = None
+        for k, scale, data in terms:
+            t = {"lap": lambda: mod.laplacian(), "diffc": lambda: mod.diffusion(data), "diffn": lambda: mod.diffusion(data),
+                 "difff": lambda: mod.diffusion_field(data), "advc": lambda: mod.advection(data), "advf": lambda: mod.advection_field(data),
+                 "reac": lambda: mod.reaction(data), "reaf": lambda: mod.reaction_field(data), "dt": lambda: mod.dt()}[k]()
+            t = scale * t
+            op = t if op is None else op + t
+        out.append(op)
+    return out, "+".join(k for k, _, _ in terms)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_operator_expression_against_the_oracle(capi, oracle, seed):
+    from fdapde_core_amd import meshgen
+
+    rng = np.random.default_rng(1000 + seed)
+    dim = int(rng.integers(2, 4))
+    order = int(rng.integers(1, 3))
+    nx = int(rng.integers(3, 14)) if dim == 2 else int(rng.integers(2, 6))
+    nodes, cells, bnd = meshgen.unit_square(nx, seed=seed + 1) if dim == 2 else meshgen.unit_cube(nx, seed=seed + 1)
+    m = oracle.Mesh(np.ascontiguousarray(nodes), np.ascontiguousarray(cells), np.ascontiguousarray(bnd))
+    c = capi.Context(0)
+    c.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = c.dofs_build(order)
+    od, _, ond, _ = oracle.enumerate_dofs(m, order)
+    assert nd == ond
+    rows = c.sizes()["n_quadrature"] * m.n_cells
+    (op_c, op_o), what = _random_operator([capi, oracle], rng, m.N, rows)
+    fq = rng.standard_normal(rows)
+    c.set_operator(op_c)
+    c.set_forcing(fq)
+    c.init()
+    ref = oracle.assemble_operator(m, order, od, nd, op_o)
+    ok, rel = _close(c.matrix_values(capi.MAT_STIFF), ref.values)
+    assert ok, (what, dim, order, nx, rel)
+    mass = oracle.assemble_operator(m, order, od, nd, oracle.reaction(1.0))
+    ok, rel = _close(c.matrix_values(capi.MAT_MASS), mass.values)
+    assert ok, ("mass", what, dim, order, nx, rel)
+    ok, rel = _close(c.force(), oracle.assemble_forcing(m, order, od, nd, fq))
+    assert ok, ("force", what, dim, order, nx, rel)
+    c.close()

@@ -48,6 +48,10 @@ def _ops(mod, M):
         # a diffusion tensor that is NOT symmetric (the summed tensor then takes the full 9 + 3 + 1 reference tables, not the compact symmetric ones)
         "diffusion_nonsym": mod.diffusion(K + (np.array([[0.0, 0.4], [-0.2, 0.0]]) if M == 2 else np.array([[0.0, 0.4, 0.0], [-0.2, 0.0, 0.3], [0.1, -0.3, 0.0]])))
         + mod.advection(b) + mod.reaction(0.5),
+        # ... and the same tensor WITHOUT advection: the reference takes the expression for symmetric (diffusion.h:42) and integrates only the pairs
+        # dof_i >= dof_j, mirrored (fem_assembler.h:94-102, 116-117) -- found by tests/test_gpu_fuzz_assembly.py
+        "diffusion_nonsym_mirrored": mod.diffusion(K + (np.array([[0.0, 0.4], [-0.2, 0.0]]) if M == 2 else np.array([[0.0, 0.4, 0.0], [-0.2, 0.0, 0.3], [0.1, -0.3, 0.0]])))
+        + mod.reaction(0.5),
     }
 
 

@@ -3,6 +3,8 @@ permuted; 2-D / 3-D), order, and a random sum of terms -- Laplacian, diffusion (
 field), reaction (constant / field), dt -- with random signs and scales.  What the fixtures' fixed operator list cannot reach: every combination of
 "constant through the reference tensors" and "per-node integrand" the operator classifier (OPK) can be handed.  Entries to 1e-12 / 1e-13 relative (the
 parity suite's bar)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -73,7 +75,7 @@ def _random_operator(mod_list, rng, N, rows):
     return out, "+".join(k for k, _, _ in terms)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FDAPDE_FUZZ_SEEDS", "24"))))   # (FDAPDE_FUZZ_SEEDS=400 for a long run)
 def test_random_operator_expression_against_the_oracle(capi, oracle, seed):
     from fdapde_core_amd import meshgen
 
@@ -102,4 +104,70 @@ def test_random_operator_expression_against_the_oracle(capi, oracle, seed):
     assert ok, ("mass", what, dim, order, nx, rel)
     ok, rel = _close(c.force(), oracle.assemble_forcing(m, order, od, nd, fq))
     assert ok, ("force", what, dim, order, nx, rel)
+    c.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FDAPDE_FUZZ_SEEDS_E2E", "16"))))
+def test_random_pde_end_to_end_against_the_oracle(capi, oracle, seed):
+    """PDE::init + solve (elliptic, seeds 0-9 of every 16) or the parabolic stepper (seeds 10-15) with a random operator expression, random forcing and random Dirichlet
+    data against the oracle's init + direct solve (pde/pde.h:101-105, fem_linear_elliptic_solver.h:34-50 / fem_linear_parabolic_solver.h:37-72): 1e-8"""
+    from fdapde_core_amd import meshgen
+
+    rng = np.random.default_rng(5000 + seed)
+    dim = int(rng.integers(2, 4))
+    order = int(rng.integers(1, 3))
+    nx = int(rng.integers(3, 12)) if dim == 2 else int(rng.integers(2, 5))
+    nodes, cells, bnd = meshgen.unit_square(nx, seed=seed + 7) if dim == 2 else meshgen.unit_cube(nx, seed=seed + 7)
+    m = oracle.Mesh(np.ascontiguousarray(nodes), np.ascontiguousarray(cells), np.ascontiguousarray(bnd))
+    c = capi.Context(0)
+    c.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = c.dofs_build(order)
+    _, _, coords = c.dofs_get()
+    rows = c.sizes()["n_quadrature"] * m.n_cells
+    # a coercive expression: diffusion-type leaves with a positive sign, reaction >= 0, mild advection
+    K = np.eye(m.N) + 0.3 * np.diag(rng.uniform(0, 1, m.N))
+    if rng.integers(0, 2):
+        K = K + rng.uniform(-0.2, 0.2, (m.N, m.N))   # not symmetric: the mirrored lower triangle without advection, the full form with it
+    pieces = [lambda mod: -mod.diffusion(K), lambda mod: -mod.laplacian()]
+    if rng.integers(0, 2):
+        cq = rng.uniform(0.1, 2.0, rows)
+        pieces.append(lambda mod: mod.reaction_field(cq))
+    else:
+        creact = float(rng.uniform(0.0, 2.0))
+        pieces.append(lambda mod: mod.reaction(creact))
+    if rng.integers(0, 2):
+        b = rng.uniform(-0.5, 0.5, m.N)
+        pieces.append(lambda mod: mod.advection(b))
+
+    def build(mod, with_dt):
+        op = pieces[0](mod)
+        for p in pieces[1:]:
+            op = op + p(mod)
+        return mod.dt() + op if with_dt else op
+
+    if seed % 16 < 10:
+        fq = rng.standard_normal(rows)
+        g = coords @ rng.uniform(-1, 1, m.N) + 0.2
+        c.set_operator(build(capi, False))
+        c.set_forcing(fq)
+        c.set_dirichlet(g)
+        c.init()
+        info = c.solve(rtol=1e-12)
+        ref = oracle.pde_init_solve(m, order, build(oracle, False), forcing_q=fq, dirichlet=g, direct=True)
+        assert info.converged == 1
+        assert np.linalg.norm(c.solution() - ref.solution) <= 1e-8 * np.linalg.norm(ref.solution), (dim, order, nx)
+    else:
+        mt = int(rng.integers(3, 7))
+        times = np.linspace(0.0, 0.04 * (mt - 1), mt)
+        F = rng.standard_normal((rows, mt))
+        G = np.tile((coords @ rng.uniform(-1, 1, m.N))[:, None], (1, mt)) * np.linspace(0.5, 1.0, mt)[None, :]
+        u0 = G[:, 0].copy()
+        c.set_operator(build(capi, True))
+        c.set_forcing(F)
+        c.init()
+        sol, info = c.solve_parabolic(times, u0, G, rtol=1e-12)
+        ref, _ = oracle.pde_parabolic_solve(m, order, build(oracle, True), times, F, G, u0)
+        assert info.converged == 1
+        for j in range(1, mt):
+            assert np.linalg.norm(sol[:, j] - ref[:, j]) <= 1e-8 * np.linalg.norm(ref[:, j]), (dim, order, nx, j)
     c.close()

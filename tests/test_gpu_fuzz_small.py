@@ -30,3 +30,13 @@ def test_random_handles_and_parabolic_problems_against_lu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_handle.py"), "30", "29"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "failures 0" in r.stdout.splitlines()[-1], r.stdout[-500:]
+
+
+def test_random_call_sequences_leave_no_stale_state():
+    """tools/fuzz_sequence.py: 25 random sequences of boundary calls on one context; every solve against the same problem on a fresh context (1e-9)"""
+    from fdapde_loader import load_package
+
+    assert load_package().capi.load().fdapde_device_count() >= 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_sequence.py"), "25", "41"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "failures 0" in r.stdout.splitlines()[-1], r.stdout[-500:]

@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Random SEQUENCES of boundary calls on one context -- new operator, new forcing, new Dirichlet data, another order, another mesh, init, solve, a handle solve in
+between, a clone taking over -- and after every solve the same problem once more on a FRESH context: whatever the long-lived context cached (coefficient
+slots, row statistics, solver layouts and their column tables, the remembered CG breakdown, scaled copies) must not show in the answer (1e-9).
+usage: fuzz_sequence.py [sequences] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fdapde_loader import load_package
+
+capi = load_package().capi
+from fdapde_core_amd import meshgen   # noqa: E402
+
+n_seq = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
+
+
+class Problem:
+    def __init__(self):
+        self.new_mesh()
+
+    def new_mesh(self):
+        self.dim = int(rng.integers(2, 4))
+        self.nx = int(rng.integers(3, 20)) if self.dim == 2 else int(rng.integers(2, 7))
+        self.seed = int(rng.integers(1, 1 << 30))
+        self.order = int(rng.integers(1, 3))
+        self.new_operator()
+        self.fseed = int(rng.integers(1, 1 << 30))
+        self.gseed = int(rng.integers(1, 1 << 30))
+        self.gkind = rng.choice(["zero", "nonzero"])
+
+    def mesh(self):
+        return meshgen.unit_square(self.nx, seed=self.seed) if self.dim == 2 else meshgen.unit_cube(self.nx, seed=self.seed)
+
+    def new_operator(self):
+        self.okind = rng.choice(["lap", "reac", "adr", "diff", "reacfield", "indef"])
+        self.oseed = int(rng.integers(1, 1 << 30))
+
+    def operator(self, rows):
+        r = np.random.default_rng(self.oseed)
+        N = self.dim
+        if self.okind == "lap":
+            return -capi.laplacian()
+        if self.okind == "reac":
+            return -capi.laplacian() + capi.reaction(float(r.uniform(0.1, 3.0)))
+        if self.okind == "adr":
+            return -capi.laplacian() + capi.advection(r.uniform(-1, 1, N)) + capi.reaction(float(r.uniform(0.1, 2.0)))
+        if self.okind == "diff":
+            L = r.uniform(-0.3, 0.3, (N, N))
+            return -capi.diffusion(L @ L.T + np.eye(N)) + capi.reaction(float(r.uniform(0.0, 1.0)))
+        if self.okind == "reacfield":
+            return -capi.laplacian() + capi.reaction_field(r.uniform(0.1, 2.0, rows))
+        return -capi.laplacian() + capi.reaction(-float(r.uniform(5.0, 30.0)))   # symmetric indefinite (CG breaks down, BiCGStab takes over)
+
+    def apply(self, c, what):
+        """bring context c up to this problem; what: which parts changed ("all" for a fresh context)"""
+        if what in ("all", "mesh"):
+            nodes, cells, bnd = self.mesh()
+            c.mesh_upload(nodes, cells, bnd)
+        if what in ("all", "mesh", "order"):
+            self.nd = c.dofs_build(self.order)
+        rows = c.quadrature_nodes().shape[0]
+        if what in ("all", "mesh", "order", "operator"):
+            c.set_operator(self.operator(rows))
+        if what in ("all", "mesh", "order", "forcing"):
+            c.set_forcing(np.random.default_rng(self.fseed).standard_normal(rows))
+        if what in ("all", "mesh", "order", "dirichlet"):
+            _, _, coords = c.dofs_get()
+            g = np.zeros(self.nd) if self.gkind == "zero" else coords @ np.random.default_rng(self.gseed).uniform(-1, 1, self.dim) + 0.1
+            c.set_dirichlet(g)
+
+
+fails = 0
+checks = 0
+for s in range(n_seq):
+    p = Problem()
+    c = capi.Context(0)
+    p.apply(c, "all")
+    log = ["all"]
+    for step in range(int(rng.integers(6, 16))):
+        act = rng.choice(["operator", "forcing", "dirichlet", "order", "mesh", "solve", "solve", "solve", "handle", "clone"])
+        log.append(act)
+        try:
+            if act == "operator":
+                p.new_operator(); p.apply(c, "operator")
+            elif act == "forcing":
+                p.fseed = int(rng.integers(1, 1 << 30)); p.apply(c, "forcing")
+            elif act == "dirichlet":
+                p.gseed = int(rng.integers(1, 1 << 30)); p.gkind = rng.choice(["zero", "nonzero"]); p.apply(c, "dirichlet")
+            elif act == "order":
+                p.order = 3 - p.order; p.apply(c, "order")
+            elif act == "mesh":
+                p.new_mesh(); p.apply(c, "mesh")
+            elif act == "handle":
+                c.init()
+                c.lin_compute(capi.MAT_MASS, symmetric=True)
+                if not (p.dim == 3 and p.order == 2):
+                    c.lin_solve(np.random.default_rng(1).standard_normal(p.nd), rtol=1e-10)
+            elif act == "clone":
+                d = c.clone()
+                c.close()
+                c = d
+            else:
+                c.init()
+                info = c.solve(rtol=1e-12, raise_on_noconv=False)
+                u = c.solution()
+                f = capi.Context(0)
+                p.apply(f, "all")
+                f.init()
+                info_f = f.solve(rtol=1e-12, raise_on_noconv=False)
+                uf = f.solution()
+                f.close()
+                checks += 1
+                err = np.linalg.norm(u - uf) / max(np.linalg.norm(uf), 1e-300)
+                if info.converged != info_f.converged or (info.converged == 1 and err > 1e-9):
+                    fails += 1
+                    print(f"FAIL sequence {s} after {log}: dim {p.dim} P{p.order} nx {p.nx} {p.okind} g {p.gkind}: converged {info.converged}/{info_f.converged} "
+                          f"method {info.method_used}/{info_f.method_used} iters {info.iters}/{info_f.iters} err {err:.3e}", flush=True)
+        except Exception as e:   # noqa: BLE001
+            fails += 1
+            print(f"ERROR sequence {s} after {log}: dim {p.dim} P{p.order} nx {p.nx} {p.okind}: {e}", flush=True)
+            break
+    c.close()
+    if s % 10 == 9:
+        print(f"... {s + 1} sequences, {checks} solves compared with a fresh context, failures {fails}", flush=True)
+print(f"{n_seq} sequences, {checks} solves compared with a fresh context, failures {fails}")
+sys.exit(1 if fails else 0)

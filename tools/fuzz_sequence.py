@@ -36,7 +36,7 @@ class Problem:
         return meshgen.unit_square(self.nx, seed=self.seed) if self.dim == 2 else meshgen.unit_cube(self.nx, seed=self.seed)
 
     def new_operator(self):
-        self.okind = rng.choice(["lap", "reac", "adr", "diff", "reacfield", "indef"])
+        self.okind = rng.choice(["lap", "reac", "adr", "diff", "diffn", "difff", "reacfield", "indef"])
         self.oseed = int(rng.integers(1, 1 << 30))
 
     def operator(self, rows):
@@ -51,6 +51,12 @@ class Problem:
         if self.okind == "diff":
             L = r.uniform(-0.3, 0.3, (N, N))
             return -capi.diffusion(L @ L.T + np.eye(N)) + capi.reaction(float(r.uniform(0.0, 1.0)))
+        if self.okind == "diffn":   # not symmetric, no advection: the reference's mirrored lower triangle
+            return -capi.diffusion(np.eye(N) + r.uniform(-0.3, 0.3, (N, N))) + capi.reaction(float(r.uniform(0.0, 1.0)))
+        if self.okind == "difff":
+            L = r.uniform(-0.3, 0.3, (rows, N, N))
+            K = np.einsum("qij,qkj->qik", L, L) + np.eye(N)[None]
+            return -capi.diffusion_field(K.reshape(rows, N * N)) + capi.reaction(float(r.uniform(0.0, 1.0)))
         if self.okind == "reacfield":
             return -capi.laplacian() + capi.reaction_field(r.uniform(0.1, 2.0, rows))
         return -capi.laplacian() + capi.reaction(-float(r.uniform(5.0, 30.0)))   # symmetric indefinite (CG breaks down, BiCGStab takes over)
@@ -81,7 +87,7 @@ for s in range(n_seq):
     p.apply(c, "all")
     log = ["all"]
     for step in range(int(rng.integers(6, 16))):
-        act = rng.choice(["operator", "forcing", "dirichlet", "order", "mesh", "solve", "solve", "solve", "handle", "clone"])
+        act = rng.choice(["operator", "forcing", "dirichlet", "order", "mesh", "solve", "solve", "solve", "handle", "clone", "parabolic"])
         log.append(act)
         try:
             if act == "operator":
@@ -99,6 +105,30 @@ for s in range(n_seq):
                 c.lin_compute(capi.MAT_MASS, symmetric=True)
                 if not (p.dim == 3 and p.order == 2):
                     c.lin_solve(np.random.default_rng(1).standard_normal(p.nd), rtol=1e-10)
+            elif act == "parabolic":   # a time-dependent problem on the same space in between (forcing columns, M / dt + A), then back
+                mt = int(rng.integers(2, 5))
+                times = np.linspace(0.0, 0.1, mt + 1)
+                rows = c.quadrature_nodes().shape[0]
+                _, _, coords = c.dofs_get()
+                F = np.random.default_rng(p.fseed).standard_normal((rows, mt + 1))
+                u0 = np.prod(np.sin(np.pi * coords), axis=1)
+                res = []
+                for ctx in (c, capi.Context(0)):
+                    if ctx is not c:
+                        p.apply(ctx, "all")
+                    ctx.set_operator(capi.dt() - capi.laplacian() + capi.reaction(0.5))
+                    ctx.set_forcing(F)
+                    ctx.init()
+                    sol, _ = ctx.solve_parabolic(times, u0, dirichlet=np.zeros((p.nd, mt + 1)), rtol=1e-12)
+                    res.append(sol)
+                    if ctx is not c:
+                        ctx.close()
+                checks += 1
+                err = np.linalg.norm(res[0] - res[1]) / max(np.linalg.norm(res[1]), 1e-300)
+                if err > 1e-9:
+                    fails += 1
+                    print(f"FAIL sequence {s} after {log}: parabolic err {err:.3e}", flush=True)
+                p.apply(c, "operator"); p.apply(c, "forcing"); p.apply(c, "dirichlet")
             elif act == "clone":
                 d = c.clone()
                 c.close()

@@ -156,6 +156,13 @@ def test_random_pde_end_to_end_against_the_oracle(capi, oracle, seed):
         ref = oracle.pde_init_solve(m, order, build(oracle, False), forcing_q=fq, dirichlet=g, direct=True)
         assert info.converged == 1
         assert np.linalg.norm(c.solution() - ref.solution) <= 1e-8 * np.linalg.norm(ref.solution), (dim, order, nx)
+        # what the reference leaves behind in stiff_ / force_ after set_dirichlet_bc (fem_solver_base.h:142-155): rows of boundary DOFs zeroed, unit diagonal, g
+        ok, rel = _close(c.matrix_values(capi.MAT_STIFF), ref.stiff.values)
+        assert ok, ("stiff after the solve", dim, order, nx, rel)
+        ok, rel = _close(c.force(), ref.force)
+        assert ok, ("force after the solve", dim, order, nx, rel)
+        ok, rel = _close(c.matrix_values(capi.MAT_MASS), ref.mass.values)
+        assert ok, ("mass", dim, order, nx, rel)
     else:
         mt = int(rng.integers(3, 7))
         times = np.linspace(0.0, 0.04 * (mt - 1), mt)

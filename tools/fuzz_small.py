@@ -33,9 +33,22 @@ for case in range(n_cases):
         nx = int(rng.integers(1, 4))
     if order == 2 and not TINY:
         nx = max(2, nx // 2)
-    nodes, cells, bnd = meshgen.unit_square(nx, seed=int(rng.integers(1, 1 << 30))) if dim == 2 else meshgen.unit_cube(nx, seed=int(rng.integers(1, 1 << 30)))
+    jit = float(os.environ.get("FUZZ_JITTER", "0.2"))   # (0.45: triangles close to degenerate; tetrahedra invert beyond ~0.25)
+    for _try in range(50):   # (the generator refuses a jitter that inverts a cell: another seed then)
+        try:
+            nodes, cells, bnd = (meshgen.unit_square(nx, seed=int(rng.integers(1, 1 << 30)), jitter=jit) if dim == 2
+                                 else meshgen.unit_cube(nx, seed=int(rng.integers(1, 1 << 30)), jitter=min(jit, 0.25)))
+            break
+        except AssertionError:
+            jit = 0.5 * (jit + 0.2)   # (a large mesh at a large jitter always has an inverted cell somewhere: towards the default)
+            continue
+    if os.environ.get("FUZZ_SCALE"):   # the domain anywhere between a micron and ten kilometres across
+        nodes = nodes * float(10.0 ** rng.uniform(-6, 4))
     kind = rng.choice(["laplace", "reaction", "adr", "diffusion"])
     bc = rng.choice(["none", "zero", "nonzero"])
+    if os.environ.get("FUZZ_SCALE") and bc == "none":
+        bc = "nonzero"   # (without a Dirichlet DOF the condition number goes with the domain size: -Lap + c on a micron-sized domain is singular to 1e-12, and
+                         #  an iterative solve to rtol is then kappa x rtol away from the LU solution -- conditioning, not what this run looks for)
     if bc == "none" and kind == "laplace":
         kind = "reaction"   # (pure Neumann Laplace is singular)
     c = capi.Context(0)
@@ -51,6 +64,8 @@ for case in range(n_cases):
         op = -capi.diffusion(K) + capi.reaction(float(rng.uniform(0.1, 2.0)))
     else:
         op = -capi.laplacian() + capi.advection(rng.uniform(-1.5, 1.5, dim)) + capi.reaction(float(rng.uniform(0.1, 2.0)))
+    if os.environ.get("FUZZ_SCALE"):
+        op = float(10.0 ** rng.uniform(-4, 4)) * op
     c.set_operator(op)
     qn = c.quadrature_nodes()
     c.set_forcing(rng.standard_normal(qn.shape[0]))

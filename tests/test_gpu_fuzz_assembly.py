@@ -178,3 +178,42 @@ def test_random_pde_end_to_end_against_the_oracle(capi, oracle, seed):
         for j in range(1, mt):
             assert np.linalg.norm(sol[:, j] - ref[:, j]) <= 1e-8 * np.linalg.norm(ref[:, j]), (dim, order, nx, j)
     c.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FDAPDE_FUZZ_SEEDS_PSI", "12"))))
+def test_random_basis_evaluation_against_the_oracle(capi, oracle, seed):
+    """PDE__::eval_basis (pde.h:149-158; lagrangian_basis.h:203-283) on generated meshes: random interior points, vertices, edge midpoints, points outside;
+    random subdomain incidence matrices.  Psi rows against the oracle's (a point on a facet may be located in either cell: the basis is continuous there)."""
+    from fdapde_core_amd import meshgen
+
+    rng = np.random.default_rng(9000 + seed)
+    dim = int(rng.integers(2, 4))
+    order = int(rng.integers(1, 3))
+    nx = int(rng.integers(2, 12)) if dim == 2 else int(rng.integers(2, 5))
+    nodes, cells, bnd = meshgen.unit_square(nx, seed=seed + 3) if dim == 2 else meshgen.unit_cube(nx, seed=seed + 3)
+    m = oracle.Mesh(np.ascontiguousarray(nodes), np.ascontiguousarray(cells), np.ascontiguousarray(bnd))
+    c = capi.Context(0)
+    c.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = c.dofs_build(order)
+    od, _, ond, _ = oracle.enumerate_dofs(m, order)
+    n_in = 200
+    cid = rng.integers(0, m.n_cells, n_in)
+    w = rng.dirichlet(np.ones(m.M + 1), n_in)
+    inside = np.einsum("ij,ijk->ik", w, m.nodes[m.cells[cid]])
+    verts = m.nodes[rng.integers(0, m.n_nodes, 30)]
+    e = m.cells[rng.integers(0, m.n_cells, 30)]
+    mids = 0.5 * (m.nodes[e[:, 0]] + m.nodes[e[:, 1]])
+    outside = m.nodes.max(axis=0) + rng.uniform(0.2, 1.0, (10, m.N))
+    locs = np.vstack([inside, verts, mids, outside])
+    psi, D, found = c.eval_pointwise(locs)
+    ref = oracle.pointwise_psi(m, order, od, ond, locs)
+    assert np.all(found[: n_in + 60] >= 0) and np.all(found[n_in + 60:] == -1)
+    assert np.abs(psi.toarray() - ref).max() < 1e-12
+    # areal evaluation: random subdomains (rows of an incidence matrix over the cells)
+    inc = (rng.uniform(0, 1, (5, m.n_cells)) < 0.3).astype(float)
+    inc[0, :] = 1.0
+    psi_a, D_a = c.eval_areal(inc)
+    ref_a, Dref = oracle.areal_psi(m, order, od, ond, inc)
+    assert np.abs(psi_a.toarray() - ref_a).max() < 1e-12 * max(1.0, np.abs(ref_a).max())
+    assert np.abs(D_a - Dref).max() < 1e-13 * max(1.0, np.abs(Dref).max())
+    c.close()

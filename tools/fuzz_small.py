@@ -80,8 +80,13 @@ for case in range(n_cases):
             if bc == "nonzero":
                 c.set_dirichlet(coords @ rng.uniform(-1, 1, dim) - 0.1)
             c.init()
+        method = capi.SOLVER_AUTO
+        if os.environ.get("FUZZ_METHODS"):   # a method named by the caller instead of the open one
+            sym = kind != "adr"
+            method = int(rng.choice([capi.SOLVER_AUTO, capi.SOLVER_CG, capi.SOLVER_CG_SR, capi.SOLVER_CG_FUSED, capi.SOLVER_BICGSTAB, capi.SOLVER_GMRES] if sym
+                                    else [capi.SOLVER_AUTO, capi.SOLVER_BICGSTAB, capi.SOLVER_GMRES]))
         try:
-            info = c.solve(rtol=1e-12, raise_on_noconv=False)
+            info = c.solve(method=method, rtol=1e-12, raise_on_noconv=False)
         except Exception as e:   # noqa: BLE001
             fails += 1
             print(f"ERROR case {case} rep {rep}: dim {dim} P{order} nx {nx} {nd} DOFs ({int((bdofs == 0).sum())} interior) {kind} bc {bc}: {e}", flush=True)
@@ -95,7 +100,7 @@ for case in range(n_cases):
         ok = info.converged == 1 and err <= 1e-8
         if not ok:
             fails += 1
-            print(f"FAIL case {case} rep {rep}: dim {dim} P{order} nx {nx} {nd} DOFs {kind} bc {bc}: converged {info.converged} method {info.method_used} "
+            print(f"FAIL case {case} rep {rep}: dim {dim} P{order} nx {nx} {nd} DOFs {kind} bc {bc} asked {method}: converged {info.converged} method {info.method_used} "
                   f"iters {info.iters} persistent {info.persistent} err {err:.3e}", flush=True)
     if case % 20 == 19:
         print(f"... {case + 1} cases, worst relative error so far {worst:.2e}, failures {fails}", flush=True)

@@ -51,6 +51,10 @@ for case in range(n_cases):
                          #  an iterative solve to rtol is then kappa x rtol away from the LU solution -- conditioning, not what this run looks for)
     if bc == "none" and kind == "laplace":
         kind = "reaction"   # (pure Neumann Laplace is singular)
+    if bc != "none" and os.environ.get("FUZZ_PARTIAL_BC") and rng.integers(0, 2):   # Dirichlet data on a random part of the boundary (at least one node), Neumann elsewhere
+        keep = (rng.uniform(0, 1, bnd.shape[0]) < rng.uniform(0.05, 0.8)) & (bnd != 0)
+        if keep.any():
+            bnd = keep.astype(bnd.dtype)
     c = capi.Context(0)
     c.mesh_upload(nodes, cells, bnd if bc != "none" else np.zeros_like(bnd))
     nd = c.dofs_build(order)

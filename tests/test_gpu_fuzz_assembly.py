@@ -217,3 +217,28 @@ def test_random_basis_evaluation_against_the_oracle(capi, oracle, seed):
     assert np.abs(psi_a.toarray() - ref_a).max() < 1e-12 * max(1.0, np.abs(ref_a).max())
     assert np.abs(D_a - Dref).max() < 1e-13 * max(1.0, np.abs(Dref).max())
     c.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FDAPDE_FUZZ_SEEDS_BND", "12"))))
+def test_boundary_dofs_of_a_partial_node_mask(capi, oracle, seed):
+    """Dirichlet markers on a random PART of the boundary nodes (the reference takes the node markers as given, boundary.csv): P1 boundary DOFs = the node
+    markers; P2 edge DOFs: 2-D -- every edge seen by exactly one cell, whatever its end nodes carry (triangulation.h:177, 187 via lagrangian_basis.h:125);
+    3-D -- both end nodes marked (triangulation.h:371).  DOF table, boundary set and coordinates bit-exact against the oracle."""
+    from fdapde_core_amd import meshgen
+
+    rng = np.random.default_rng(12000 + seed)
+    dim = int(rng.integers(2, 4))
+    order = int(rng.integers(1, 3))
+    nx = int(rng.integers(2, 10)) if dim == 2 else int(rng.integers(2, 5))
+    nodes, cells, bnd = meshgen.unit_square(nx, seed=seed + 11) if dim == 2 else meshgen.unit_cube(nx, seed=seed + 11)
+    mask = ((rng.uniform(0, 1, bnd.shape[0]) < rng.uniform(0.1, 0.9)) & (bnd != 0)).astype(np.uint8)
+    m = oracle.Mesh(np.ascontiguousarray(nodes), np.ascontiguousarray(cells), np.ascontiguousarray(mask))
+    c = capi.Context(0)
+    c.mesh_upload(m.nodes, m.cells, m.boundary)
+    nd = c.dofs_build(order)
+    od, ob, ond, _ = oracle.enumerate_dofs(m, order)
+    dofs, b, coords = c.dofs_get()
+    assert nd == ond and np.array_equal(dofs, od)
+    assert np.array_equal(b, ob), (dim, order, int((b != ob).sum()))
+    assert np.array_equal(coords, oracle.dofs_coords(m, order, od, ond))
+    c.close()

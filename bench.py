@@ -137,7 +137,53 @@ class FileRendezvous:
             self.get(f"{name}.{r}")
 
 
-def cpu_baseline(nx):
+# ---------------------------------------------------------------------------------------------------------------------
+# Oracle parity AT THE HEADLINE SIZES, in the record.  The CPU legs below already run the oracle -- the reference's
+# algorithm restated (oracle/fem_oracle.c) -- on the very workloads the GPU lines are quoted on; what the device path produced for the same
+# inputs is compared with it entry by entry here.  Bars: SURVEY 8(d).  Test infrastructure only: runs after and outside every timed region.
+# ---------------------------------------------------------------------------------------------------------------------
+PARITY_BARS = {"pattern": "bit-exact", "dof_table": "bit-exact", "boundary_dofs": "bit-exact",
+               "matrix_entries": 1e-12, "force": 1e-12, "solution_rel_l2": 1e-8}
+
+
+def parity_against_oracle(gpu, dofs, bnd, A, Mm, rhs, u, what_u):
+    """gpu: arrays of the device path (pattern, dof table, boundary DOFs, stiff_ / mass_ / force_ right after init, solution()); the rest: the
+    oracle's for the same mesh.  -> dict with every figure, its bar, and `ok`"""
+    import numpy as np
+
+    def rel_max(a, b):
+        return float(np.abs(a - b).max() / max(1.0, float(np.abs(b).max())))
+
+    r = {"bars": PARITY_BARS}
+    r["dof_table_equal"] = bool(np.array_equal(gpu["dofs"], dofs))
+    r["boundary_dofs_equal"] = bool(np.array_equal(gpu["boundary"] != 0, np.asarray(bnd) != 0))
+    r["pattern_equal"] = bool(np.array_equal(gpu["rowptr"], A.rowptr) and np.array_equal(gpu["colidx"], A.colidx))
+    same = r["pattern_equal"]
+    r["stiff_max_abs_diff_over_max1_Amax"] = rel_max(gpu["stiff"], A.values) if same else None
+    r["mass_max_abs_diff_over_max1_Mmax"] = rel_max(gpu["mass"], Mm.values) if same and Mm is not None else None
+    r["force_max_abs_diff_over_max1_fmax"] = rel_max(gpu["force"], rhs)
+    r["solution_rel_l2"] = float(np.linalg.norm(gpu["u"] - u) / np.linalg.norm(u))
+    r["solution_reference"] = what_u
+    r["entries_compared"] = int(A.values.size) * (2 if Mm is not None else 1) + int(rhs.size)
+    r["ok"] = bool(r["dof_table_equal"] and r["boundary_dofs_equal"] and same and
+                   r["stiff_max_abs_diff_over_max1_Amax"] <= PARITY_BARS["matrix_entries"] and
+                   (Mm is None or r["mass_max_abs_diff_over_max1_Mmax"] <= PARITY_BARS["matrix_entries"]) and
+                   r["force_max_abs_diff_over_max1_fmax"] <= PARITY_BARS["force"] and r["solution_rel_l2"] <= PARITY_BARS["solution_rel_l2"])
+    return r
+
+
+def device_arrays(ctx, capi):
+    """what the device path holds for the current problem, for parity_against_oracle: solution() of the last solve, then stiff_ / mass_ / force_ as
+    fdapde_init leaves them (init again: after a Dirichlet solve stiff() is the row-zeroed matrix, as in the reference)"""
+    u = ctx.solution()
+    ctx.init()
+    rp, ci = ctx.pattern_get()
+    dofs, bnd, _ = ctx.dofs_get()
+    return {"u": u, "rowptr": rp, "colidx": ci, "dofs": dofs, "boundary": bnd, "stiff": ctx.matrix_values(capi.MAT_STIFF),
+            "mass": ctx.matrix_values(capi.MAT_MASS), "force": ctx.force()}
+
+
+def cpu_baseline(nx, gpu=None):
     """The oracle (kind 'port') on a bounded sample: same generator, same operator, same solver and tolerance."""
     import numpy as np
 
@@ -187,11 +233,18 @@ def cpu_baseline(nx):
         }
     except Exception as e:   # the all-cores column is an extra: never let it take the bench line down
         best = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
+    parity = None
+    if gpu is not None:   # entry-level parity of the headline configuration (same generator, same size: the GPU line's own workload)
+        try:
+            parity = parity_against_oracle(gpu, dofs, b, A, Mm, rhs, u, f"oracle Jacobi-PCG, rtol {RTOL:g} ({it} iterations)")
+            parity["workload"] = f"C3 at {nx}^3 x 6 = {m.n_cells} tetrahedra, {nd} DOFs: fem_assembler.h:52-121 restated, entry by entry"
+        except Exception as e:
+            parity = {"ok": False, "error": f"{type(e).__name__}: {e}"[:300]}
     del Mm
-    return faithful, best
+    return faithful, best, parity
 
 
-def cpu_columns(c5_nx=24):
+def cpu_columns(c5_nx=24, c2_gpu=None):
     """CPU figures beside the secondary results (SURVEY 8d plan item 1): the oracle's assembly (the reference's algorithm, 1 core) followed by a DIRECT
     solve -- scipy's SuperLU standing in for Eigen::SparseLU -- for C1 and C2, where the reference's own solve is feasible; for C5 the oracle's
     assembly + Jacobi-BiCGStab at a stated reduced size (LU of a 3-D P2 system: DNF by memory at full size)."""
@@ -206,19 +259,21 @@ def cpu_columns(c5_nx=24):
 
     out = {}
 
-    def direct(m, order, fq, g):
+    def direct(m, order, fq, g, keep_raw=False):
         dofs, bnd, nd, _ = o.enumerate_dofs(m, order)
         t0 = time.perf_counter()
         A = o.assemble_operator(m, order, dofs, nd, -o.laplacian())
         b = o.assemble_forcing(m, order, dofs, nd, fq)
-        o.assemble_operator(m, order, dofs, nd, o.reaction(1.0))
+        Mm = o.assemble_operator(m, order, dofs, nd, o.reaction(1.0))
         t1 = time.perf_counter()
+        raw = (dofs, bnd, A.copy(), Mm, b.copy()) if keep_raw else None   # (untimed copies: set_dirichlet works in place)
+        t1b = time.perf_counter()
         o.set_dirichlet(A, b, bnd, g(nd))
         lu = spla.splu(A.to_scipy().tocsc())
         t2 = time.perf_counter()
         u = lu.solve(b)
         t3 = time.perf_counter()
-        return nd, t1 - t0, t2 - t1, t3 - t2, u
+        return nd, t1 - t0, t2 - t1b, t3 - t2, u, raw
 
     try:   # C1: the reference's own fixtures
         c1 = {}
@@ -230,7 +285,7 @@ def cpu_columns(c5_nx=24):
             for _ in range(5):
                 r = direct(m, 1, fq, lambda nd: np.zeros(nd))
                 best = r if best is None or sum(r[1:4]) < sum(best[1:4]) else best
-            nd, ta, tf, ts, _ = best
+            nd, ta, tf, ts, _, _ = best
             c1[name] = {"dofs": int(nd), "init_ms": 1e3 * ta, "solve_ms": 1e3 * (tf + ts), "factorise_ms": 1e3 * tf, "solve_one_column_ms": 1e3 * ts,
                         "cores": 1, "kind": "port + scipy SuperLU", "note": "oracle assembly (stiff + force + mass) | Dirichlet rows + splu + one solve; best of 5"}
         out["c1"] = c1
@@ -240,7 +295,14 @@ def cpu_columns(c5_nx=24):
         nodes, cells, bnd = meshgen.unit_square(708)
         m = o.Mesh(nodes, cells, bnd)
         _, f = meshgen.manufactured(2)
-        nd, ta, tf, ts, _ = direct(m, 1, f(o.quadrature_nodes(m, 1)), lambda nd: np.zeros(nd))
+        nd, ta, tf, ts, u_lu, raw = direct(m, 1, f(o.quadrature_nodes(m, 1)), lambda nd: np.zeros(nd), keep_raw=c2_gpu is not None)
+        if c2_gpu is not None:   # C2 at full size against the reference's actual algorithm: oracle assembly + a sparse LU (fem_linear_elliptic_solver.h:38-47)
+            try:
+                out["c2_parity"] = parity_against_oracle(c2_gpu, raw[0], raw[1], raw[2], raw[3], raw[4], u_lu, "oracle assembly + scipy SuperLU (direct)")
+                out["c2_parity"]["workload"] = f"C2 at full size: {m.n_cells} triangles, {nd} DOFs"
+            except Exception as e:
+                out["c2_parity"] = {"ok": False, "error": f"{type(e).__name__}: {e}"[:300]}
+            del raw
         out["c2"] = {"value": nd / (ta + tf + ts), "unit": "DOF/s", "cores": 1, "kind": "port + scipy SuperLU",
                      "sample": f"C2 at full size ({m.n_cells} triangles, {nd} DOFs): oracle assembly {ta:.2f} s + sparse LU {tf:.2f} s + solve {ts:.3f} s"}
     except Exception as e:

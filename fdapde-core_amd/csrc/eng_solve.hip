@@ -431,6 +431,9 @@ int ensure_sval(fdapde_ctx* c) {
     return FDAPDE_OK;
 }
 
+// "CG broke down" (p.Ap <= 0) can only be said of a CG: the breakdown word of a BiCGStab or GMRES stage that followed means something else
+static inline bool is_cg_method(int m) { return m == FDAPDE_SOLVER_CG || m == FDAPDE_SOLVER_CG_SR || m == FDAPDE_SOLVER_CG_FUSED; }
+
 // Restarted GMRES(m) on the scaled system (kernels_gmres.h); x, r, sc, ctl as k_krylov_init / _fin left them, bt = the scaled right-hand side.
 // Leaves x (scaled iterate), sc[0] / sc[3] (|b|^2, |b - A x|^2 TRUE) and ctl like the other methods; h_ctl / h_sc hold the last read-back.
 int run_gmres(fdapde_ctx* c, double tol2, int maxit) {
@@ -439,12 +442,17 @@ int run_gmres(fdapde_ctx* c, double tol2, int maxit) {
     hipStream_t st = c->stream;
     HIPCHK(c, c->gm_V.alloc((size_t)(m + 1) * (size_t)n));
     HIPCHK(c, c->gm_s.alloc((size_t)gm_state_doubles(m) + (size_t)m + 2));
-    HIPCHK(c, c->gm_part.alloc((size_t)(m + 2) * kGmStripes));
+    const int vg = c->vec_grid;
+    // [(m + 1) x kGmStripes stripes of V^T w | one |w|^2 partial per workgroup of the vector kernels]: vec_grid goes up to 1024 workgroups
+    // (systems above 65 536 DOFs), the true-residual partials of k_gm_residual need as many from the start of the buffer
+    const size_t gm_norm_at = (size_t)(m + 1) * kGmStripes;
+    HIPCHK(c, c->gm_part.alloc(gm_norm_at + (size_t)std::max(vg, kGmStripes)));
+    double* gm_norm = c->gm_part.p + gm_norm_at;
     double* gs = c->gm_s.p;
     double* h_pass = gs + gm_state_doubles(m);   // coefficients of the Gram-Schmidt pass in flight
     double* hcol = gs + 3 * m + 1;
     double* w = c->y.p;
-    const int vg = c->vec_grid;
+    HIPCHK(c, hipMemsetAsync(c->ctl.p + 5, 0, sizeof(int32_t), st));   // the stall counter of k_gm_cycle_fin (a word of its own: ctl[3] belongs to the Jacobi scaling / the single launch)
     HIPCHK(c, hipMemcpyAsync(c->sc.p + 21, c->sc.p + 3, sizeof(double), hipMemcpyDeviceToDevice, st));   // |r|^2 at the start of the first cycle
     bool stop = false;
     HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -458,10 +466,16 @@ int run_gmres(fdapde_ctx* c, double tol2, int maxit) {
             for (int pass = 0; pass < 2; ++pass) {                              // classical Gram-Schmidt, twice
                 hipLaunchKernelGGL(k_gm_dots, dim3(kGmStripes, j + 1), dim3(256), 0, st, n, c->gm_V.p, w, c->gm_part.p, c->ctl.p);
                 hipLaunchKernelGGL(k_gm_reduce, dim3(j + 1), dim3(256), 0, st, c->gm_part.p, h_pass, hcol, pass, c->ctl.p);
-                hipLaunchKernelGGL(k_gm_axpy, dim3(vg), dim3(256), 0, st, n, j + 1, c->gm_V.p, h_pass, w, c->gm_part.p + (size_t)(m + 1) * kGmStripes, pass, c->ctl.p);
+                hipLaunchKernelGGL(k_gm_axpy, dim3(vg), dim3(256), 0, st, n, j + 1, c->gm_V.p, h_pass, w, gm_norm, pass, c->ctl.p);
             }
-            hipLaunchKernelGGL(k_gm_hess, dim3(1), dim3(256), 0, st, j, m, c->gm_part.p + (size_t)(m + 1) * kGmStripes, vg, gs, c->sc.p, c->ctl.p, tol2, maxit);
+            hipLaunchKernelGGL(k_gm_hess, dim3(1), dim3(256), 0, st, j, m, gm_norm, vg, gs, c->sc.p, c->ctl.p, tol2, maxit);
             hipLaunchKernelGGL(k_gm_next, dim3(vg), dim3(256), 0, st, n, w, gs, m, c->gm_V.p + (size_t)(j + 1) * n, c->ctl.p);
+            if (j % 10 == 9 && j + 1 < m) {   // a look at the stop flag every ten steps: the rest of a cycle whose estimate has converged (or whose
+                                              // budget is spent) would be ~8 empty launches per step
+                HIPCHK(c, hipMemcpyAsync(c->h_ctl, c->ctl.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                HIPCHK(c, hipStreamSynchronize(st));
+                if (c->h_ctl[0] != 0) break;
+            }
         }
         // end of the cycle: y, x += V y, the true residual -- which decides whether another cycle follows
         hipLaunchKernelGGL(k_gm_solve_y, dim3(1), dim3(1), 0, st, m, gs);
@@ -1023,7 +1037,7 @@ int e_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
                                       maxit, check_every, opt ? opt->time_spmv : 0, gm_budget);
         }
     }
-    if (rc == FDAPDE_ENOCONV && c->h_ctl[2] != 0 && (!opt || opt->method == FDAPDE_SOLVER_AUTO) && c->info.method_used != FDAPDE_SOLVER_BICGSTAB &&
+    if (rc == FDAPDE_ENOCONV && c->h_ctl[2] != 0 && (!opt || opt->method == FDAPDE_SOLVER_AUTO) && is_cg_method(c->info.method_used) &&
         !ss.dist && !ss.rowdist) {
         // CG broke down (p.Ap <= 0): the operator is symmetric but not positive definite -- e.g. 3-D P2 with a large reaction term: the
         // reference's 5-point rule has a negative weight, its mass matrix is indefinite (integrator_tables.h:275-292).  The reference's LU solves
@@ -1116,7 +1130,7 @@ int e_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times,
         c->defer_end_sync = true;   // (the step's outcome is read inside solve_run; what follows it is ordered by the stream)
         const int open_step = !(!opt || opt->method == FDAPDE_SOLVER_AUTO) ? -1 : ((opt && opt->maxit > 0) ? 0 : default_maxit(c, n));
         int rc = solve_run_restarting(c, ss, kmat.p, rhs.p, gcol.p, uprev.p, step_method, rtol, maxit, check_every, 0, open_step);
-        if (rc == FDAPDE_ENOCONV && c->h_ctl[2] != 0 && step_method == FDAPDE_SOLVER_AUTO && c->info.method_used != FDAPDE_SOLVER_BICGSTAB && !ss.dist &&
+        if (rc == FDAPDE_ENOCONV && c->h_ctl[2] != 0 && step_method == FDAPDE_SOLVER_AUTO && is_cg_method(c->info.method_used) && !ss.dist &&
             !ss.rowdist) {   // M / dt + A symmetric but not positive definite (see fdapde_solve): this step again and every later one with BiCGStab
             if (int rc2 = solve_prepare(c, kmat.p, dirichlet ? 1 : 0, &ss, false)) return rc2;
             step_method = FDAPDE_SOLVER_BICGSTAB;
@@ -1390,7 +1404,7 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
         c->defer_end_sync = false;
         clk.mark("lin_solve: solve_run");
         if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;
-        if (rc == FDAPDE_ENOCONV) rc_all = rc, breakdown = breakdown || c->h_ctl[2] != 0;
+        if (rc == FDAPDE_ENOCONV) rc_all = rc, breakdown = breakdown || (c->h_ctl[2] != 0 && is_cg_method(c->info.method_used));
         total += c->info.iters, worst = c->info.relres > worst ? c->info.relres : worst;
         hipLaunchKernelGGL(k_scatter_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->u.p, c->tmp_e.p);
         HIPCHK(c, hipMemcpyAsync(x + (size_t)j * n, c->tmp_e.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));

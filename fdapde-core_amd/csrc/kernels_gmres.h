@@ -173,9 +173,9 @@ static __global__ __launch_bounds__(256) void k_gm_cycle_fin(const double* part2
     const double rr = gm_block_sum(a, red);
     if (threadIdx.x != 0) return;
     const double before = sc[21];   // |r|^2 at the start of the cycle that just ended
-    int32_t stalled = ctl[3];
+    int32_t stalled = ctl[5];   // (a word of its own, zeroed by run_gmres: ctl[3] is the Jacobi scaling's / the single launch's)
     stalled = (rr > 0.998 * before) ? stalled + 1 : 0;
-    ctl[3] = stalled;
+    ctl[5] = stalled;
     sc[3] = rr, sc[21] = rr;
     const bool conv = rr <= tol2 * sc[0];
     if (!conv && (stalled >= 3 || !isfinite(rr))) ctl[2] = 1;

@@ -244,3 +244,86 @@ def test_strongly_indefinite_symmetric_operators(env, dim, nx, k2):
     ref = spl.spsolve(A.tocsc(), c.force())
     assert np.linalg.norm(c.solution() - ref) <= 1e-6 * np.linalg.norm(ref)
     c.close()
+
+
+def _mid_size_advection(capi, meshgen, nx=300, peclet=3.0, with_dt=False):
+    """90 601 DOFs (vec_grid 354 > the 256 stripes of GMRES's dot partials): the multi-workgroup partial path of kernels_gmres.h"""
+    nodes, cells, bnd = meshgen.unit_square(nx)
+    _, f = meshgen.manufactured(2)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(1)
+    _, _, coords = c.dofs_get()
+    d = np.array([1.0, 0.5])
+    op = -capi.laplacian() + capi.advection((2.0 * peclet * nx / np.linalg.norm(d)) * d)
+    c.set_operator(capi.dt() + op if with_dt else op)
+    return c, nd, coords, f
+
+
+def test_gmres_above_65536_dofs_through_solve(env):
+    """the |w|^2 partials of k_gm_axpy / k_gm_hess are one per workgroup of the vector kernels (up to 1024), not one per stripe:
+    a system above 65 536 DOFs wrote past gm_part.  Explicit GMRES and the open method on 90 601 DOFs against LU."""
+    import scipy.sparse.linalg as spl
+
+    capi, meshgen = env
+    c, nd, coords, f = _mid_size_advection(capi, meshgen)
+    assert nd > 65536
+    c.set_forcing(f(c.quadrature_nodes()))
+    c.set_dirichlet(0.2 * coords[:, 0])
+    c.init()
+    g = c.solve(method=capi.SOLVER_GMRES, rtol=1e-10, raise_on_noconv=False)
+    assert g.converged == 1 and g.method_used == capi.SOLVER_GMRES and g.relres <= 1e-10
+    A = _csr(c, capi, capi.MAT_STIFF, nd)
+    ref = spl.spsolve(A.tocsc(), c.force())
+    assert np.linalg.norm(c.solution() - ref) <= 1e-7 * np.linalg.norm(ref)
+    a = c.solve(rtol=1e-10, raise_on_noconv=False)   # the open method on the same system, after a GMRES run left its words in ctl
+    assert a.converged == 1
+    assert np.linalg.norm(c.solution() - ref) <= 1e-7 * np.linalg.norm(ref)
+    c.close()
+
+
+def test_gmres_above_65536_dofs_through_the_handle_and_the_stepper(env):
+    """the GMRES stage inside fdapde_lin_solve and fdapde_solve_parabolic (named explicitly, 90 601 DOFs), each against scipy's LU"""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+
+    capi, meshgen = env
+    c, nd, coords, f = _mid_size_advection(capi, meshgen, with_dt=True)
+    times = np.linspace(0.0, 0.02, 3)
+    fq = f(c.quadrature_nodes())
+    c.set_forcing(np.stack([fq] * times.size, axis=1))
+    c.init()
+    A = _csr(c, capi, capi.MAT_STIFF, nd)
+    M = _csr(c, capi, capi.MAT_MASS, nd)
+    # handle: two columns against the assembled operator (no Dirichlet reduction in the handle: a mass shift of the size of an implicit Euler step's keeps restarted GMRES away from stagnation)
+    vals = c.matrix_values(capi.MAT_STIFF) + 5e4 * c.matrix_values(capi.MAT_MASS)
+    c.lin_compute(values=vals, symmetric=False)
+    rng = np.random.default_rng(5)
+    b = rng.standard_normal((nd, 2))
+    x, info = c.lin_solve(b, method=capi.SOLVER_GMRES, rtol=1e-10)
+    assert info.converged == 1 and info.method_used == capi.SOLVER_GMRES
+    K = (A + 5e4 * M).tocsc()
+    lu = spl.splu(K)
+    for j in range(2):
+        ref = lu.solve(b[:, j])
+        assert np.linalg.norm(x[:, j] - ref) <= 1e-7 * np.linalg.norm(ref)
+    F = c.force(ncols=times.size).reshape(times.size, nd).T   # (before the stepper writes the Dirichlet rows)
+    # stepper: implicit Euler with GMRES named, against LU stepping of the same matrices (fem_linear_parabolic_solver.h:56-68)
+    u0 = np.sin(np.pi * coords[:, 0]) * np.sin(np.pi * coords[:, 1])
+    gcols = np.zeros((nd, times.size))
+    sol, pinfo = c.solve_parabolic(times, u0, dirichlet=gcols, method=capi.SOLVER_GMRES, rtol=1e-11)
+    assert pinfo.converged == 1
+    dt_ = times[1] - times[0]
+    _, bd, _ = c.dofs_get()
+    Kp = (M / dt_ + A).tolil()
+    bidx = np.nonzero(bd)[0]
+    Kp[bidx, :] = 0.0
+    Kp[bidx, bidx] = 1.0
+    lup = spl.splu(sp.csc_matrix(Kp))
+    u = u0.copy()
+    for i in range(times.size - 1):
+        rhs = (M / dt_) @ u + F[:, i + 1]
+        rhs[bidx] = 0.0
+        u = lup.solve(rhs)
+        assert np.linalg.norm(sol[:, i + 1] - u) <= 1e-6 * np.linalg.norm(u)
+    c.close()

@@ -172,17 +172,6 @@ def parity_against_oracle(gpu, dofs, bnd, A, Mm, rhs, u, what_u):
     return r
 
 
-def device_arrays(ctx, capi):
-    """what the device path holds for the current problem, for parity_against_oracle: solution() of the last solve, then stiff_ / mass_ / force_ as
-    fdapde_init leaves them (init again: after a Dirichlet solve stiff() is the row-zeroed matrix, as in the reference)"""
-    u = ctx.solution()
-    ctx.init()
-    rp, ci = ctx.pattern_get()
-    dofs, bnd, _ = ctx.dofs_get()
-    return {"u": u, "rowptr": rp, "colidx": ci, "dofs": dofs, "boundary": bnd, "stiff": ctx.matrix_values(capi.MAT_STIFF),
-            "mass": ctx.matrix_values(capi.MAT_MASS), "force": ctx.force()}
-
-
 def cpu_baseline(nx, gpu=None):
     """The oracle (kind 'port') on a bounded sample: same generator, same operator, same solver and tolerance."""
     import numpy as np
@@ -328,6 +317,22 @@ def cpu_columns(c5_nx=24, c2_gpu=None):
     return out
 
 
+SOLVE_KERNEL_SOURCES = ("kernels_persist.h", "kernels_persist_bicg.h", "kernels_spmv.h", "kernels_krylov.h", "kernels_reduce.h", "persist_engine.hip",
+                        "host_persist.cpp", "dev_persist.hip")
+
+
+def solve_kernel_sha16():
+    """digest of the sources of the solve's kernels and of the layout they stream: a committed counter pass (profiles/spmv_pmc.json) carries the digest
+    it was collected on, so that a stale file after a kernel change does not go unnoticed"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in SOLVE_KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "fdapde-core_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def roofline_of(info_list, alg_bytes, streamed_bytes, nx, world, n_int=None, nnz_int=None, layout=None):
     """The dominant kernel's roofline entry.  `frac` is PHYSICAL: the bytes the kernel's layout streams (and, where a committed PMC
     pass of the same workload exists, the counter bytes next to it as `traffic`) over the launch duration; the algorithmic bytes of
@@ -400,6 +405,12 @@ def roofline_of(info_list, alg_bytes, streamed_bytes, nx, world, n_int=None, nnz
             elif not persistent and pj.get("hbm_bytes_per_launch"):
                 r["traffic"] = float(pj["hbm_bytes_per_launch"])
             if r["traffic"] is not None:
+                r["traffic_head"] = pj.get("head")   # the commit the counter passes ran on
+                r["traffic_kernel_sha16"] = pj.get("kernel_source_sha16")
+                try:
+                    r["traffic_stale"] = pj.get("kernel_source_sha16") != solve_kernel_sha16()   # True: the solve's kernel sources changed since
+                except OSError:
+                    r["traffic_stale"] = None
                 r["traffic_source"] = ("profiles/spmv_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE of this kernel, separate rocprofv3 --pmc passes of an "
                                        "earlier run of this workload (not this run); FETCH_SIZE counts Infinity-Cache hits")
     except Exception:
@@ -479,6 +490,12 @@ def run_single(args):
     _, alg_bytes = ctx.bench_spmv(reps=1)
     n_int, nnz_int, streamed_bytes = ctx.solver_layout(True)
     layout = ctx.solver_layout_kind(True)
+    want_parity = not args.no_cpu_baseline and args.cpu_nx == args.nx   # (the CPU leg runs the oracle on this very workload: compare entry by entry)
+    c3_arrays = None
+    if want_parity:
+        from fdapde_core_amd import workloads as _w
+
+        c3_arrays = _w.device_arrays(ctx, capi)
     ctx.close()
     del nodes, cells, bnd
     out = {
@@ -524,7 +541,8 @@ def run_single(args):
         # (the wide run BEFORE C5: measured right after C5's seconds of full-HBM BiCGStab the same launch took 101 instead of 74 us per iteration)
         for name, fn in (("c2", workloads.run_c2), ("wide_2p35M", workloads.run_wide), ("c5", workloads.run_c5)):
             try:
-                extra[name] = fn(capi, meshgen, device=device_index, hbm_peak_gbps=HBM_PEAK_GBPS)
+                kw = {"keep_arrays": True} if name == "c2" and not args.no_cpu_baseline else {}
+                extra[name] = fn(capi, meshgen, device=device_index, hbm_peak_gbps=HBM_PEAK_GBPS, **kw)
             except Exception as e:   # never let a secondary result take the bench line down
                 extra[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
         try:
@@ -532,14 +550,27 @@ def run_single(args):
         except Exception as e:
             extra["c1"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         out["extra"] = extra
+    c2_arrays = out.get("extra", {}).get("c2", {}).pop("_arrays", None) if isinstance(out.get("extra", {}).get("c2"), dict) else None
+    parity_ok = True
     if not args.no_cpu_baseline:
-        out["cpu_baseline"], out["cpu_baseline_all_cores"] = cpu_baseline(args.cpu_nx)
+        out["cpu_baseline"], out["cpu_baseline_all_cores"], c3_parity = cpu_baseline(args.cpu_nx, c3_arrays)
+        del c3_arrays
+        # entry-level parity with the oracle at the sizes the numbers are quoted on (bars: SURVEY 8d); a missed bar fails the bench (exit code 3)
+        out["parity"] = {"c3": c3_parity if c3_parity is not None else
+                         {"ok": None, "skipped": f"the CPU sample (--cpu-nx {args.cpu_nx}) is not this line's workload (--nx {args.nx})"}}
         if not args.no_extra:   # CPU columns beside the secondary results: direct solves where the reference's own solve is feasible (C1, C2)
-            cols = cpu_columns()
+            cols = cpu_columns(c2_gpu=c2_arrays)
             for name in ("c1", "c2", "c5"):
                 if isinstance(out["extra"].get(name), dict):
                     out["extra"][name]["cpu"] = cols.get(name)
+            if "c2_parity" in cols:
+                out["parity"]["c2"] = cols["c2_parity"]
+        parity_ok = all(v.get("ok") is not False for v in out["parity"].values())
+        out["parity"]["ok"] = parity_ok
     print(json.dumps(out), flush=True)
+    if not parity_ok:
+        print("bench.py: the device path misses a parity bar against the oracle (see `parity` in the line above)", file=sys.stderr)
+        raise SystemExit(3)
 
 
 def _spawn_ranks(world, argv_extra, extra_env, timeout):

@@ -32,6 +32,17 @@ def c5_operator(capi):
     return -capi.laplacian() + capi.advection(C5_B) + capi.reaction(C5_C)
 
 
+def device_arrays(ctx, capi):
+    """what the device path holds for the current problem, for parity_against_oracle: solution() of the last solve, then stiff_ / mass_ / force_ as
+    fdapde_init leaves them (init again: after a Dirichlet solve stiff() is the row-zeroed matrix, as in the reference)"""
+    u = ctx.solution()
+    ctx.init()
+    rp, ci = ctx.pattern_get()
+    dofs, bnd, _ = ctx.dofs_get()
+    return {"u": u, "rowptr": rp, "colidx": ci, "dofs": dofs, "boundary": bnd, "stiff": ctx.matrix_values(capi.MAT_STIFF),
+            "mass": ctx.matrix_values(capi.MAT_MASS), "force": ctx.force()}
+
+
 def _timed_steps(ctx, steps, warmup, time_spmv, rtol):
     for _ in range(warmup):
         ctx.init()
@@ -95,7 +106,7 @@ def _summary(ctx, nd, wall, infos, u_exact, hbm_peak_gbps):
     return out
 
 
-def run_c2(capi, meshgen, nx=708, steps=2, warmup=1, time_spmv=32, rtol=1e-10, device=0, hbm_peak_gbps=8000.0):
+def run_c2(capi, meshgen, nx=708, steps=2, warmup=1, time_spmv=32, rtol=1e-10, device=0, hbm_peak_gbps=8000.0, keep_arrays=False):
     nodes, cells, bnd = meshgen.unit_square(nx)
     u_exact, f = meshgen.manufactured(2)
     ctx = capi.Context(device)
@@ -109,6 +120,7 @@ def run_c2(capi, meshgen, nx=708, steps=2, warmup=1, time_spmv=32, rtol=1e-10, d
     ctx.set_dirichlet(np.zeros(nd))
     wall, infos = _timed_steps(ctx, steps, warmup, time_spmv, rtol)
     out = _summary(ctx, nd, wall, infos, u_exact, hbm_peak_gbps)
+    arrays = device_arrays(ctx, capi) if keep_arrays else None   # (what the timed path produced, for the caller's oracle comparison; untimed)
     if out["persistent"]:
         # the multi-launch path (the HBM / L2 streaming kernels) on the same context, for comparison
         ctx.tune("persist", 0)
@@ -120,6 +132,8 @@ def run_c2(capi, meshgen, nx=708, steps=2, warmup=1, time_spmv=32, rtol=1e-10, d
     out.update(workload=f"C2: 2-D P1 Laplacian, {nx}^2 x 2 = {cells.shape[0]} triangles, jitter 0.2h, diagonals flipped, ids permuted",
                cells=int(cells.shape[0]), t_setup_s=t_setup)
     ctx.close()
+    if keep_arrays:
+        out["_arrays"] = arrays   # (popped by the caller: not part of the record)
     return out
 
 

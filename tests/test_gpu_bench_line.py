@@ -47,3 +47,22 @@ def test_secondary_workloads_return_their_fields():
         assert r["max_abs_error_vs_analytic"] < 5e-3
     w = workloads.run_wide(capi, meshgen, nx=40, steps=1, warmup=1)
     assert w["persistent"] == 1 and w["relres"] <= 1e-10 and w["dofs"] == 41**3 and "residency" in w
+
+
+def test_single_gpu_line_carries_oracle_parity():
+    """the CPU leg compares what the oracle computes with what the device path produced for the same workload -- pattern, DOF table,
+    boundary DOFs bit-exact, stiff_ / mass_ / force_ entries and the solution within the bars of SURVEY 8(d) -- and the line says so (`parity`).
+    Reduced mesh here (the fields and the mechanism; the driver's run carries the full-size figures)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--nx", "24", "--cpu-nx", "24", "--steps", "1", "--warmup", "1", "--no-extra"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    par = rec["parity"]
+    assert par["ok"] is True
+    c3 = par["c3"]
+    assert c3["ok"] is True and c3["pattern_equal"] and c3["dof_table_equal"] and c3["boundary_dofs_equal"]
+    assert c3["stiff_max_abs_diff_over_max1_Amax"] <= 1e-12 and c3["mass_max_abs_diff_over_max1_Mmax"] <= 1e-12
+    assert c3["force_max_abs_diff_over_max1_fmax"] <= 1e-12 and c3["solution_rel_l2"] <= 1e-8
+    assert c3["bars"]["matrix_entries"] == 1e-12 and c3["bars"]["solution_rel_l2"] == 1e-8
+    assert rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["value"] > 0
+

@@ -178,3 +178,43 @@ def test_fullsize_properties(env, config):
     yr = M @ x
     assert np.abs(y - yr).max() <= 1e-12 * max(1.0, np.abs(yr).max())
     ctx.close()
+
+
+@pytest.mark.parametrize("config", ["C3", "C2"])
+def test_entries_against_the_oracle_at_full_size(env, config):
+    """the headline matrices entry by entry.  The oracle (oracle/fem_oracle.c: fem_assembler.h:52-121 restated, triplets summed in the
+    reference's order) assembles the very meshes the numbers are quoted on -- 10 110 954 tetrahedra in ~17 s, 1 002 528 triangles in ~1 s -- and every one
+    of the 25.6 M (3.5 M) entries of stiff_ and mass_ and every entry of force_ is compared at the bar of SURVEY 8(d): |d| <= 1e-12 max(1, |A|max);
+    DOF table, boundary DOFs and CSR pattern bit-exact."""
+    from oracle import oracle as o
+
+    capi, meshgen = env
+    if config == "C3":
+        nodes, cells, bnd = meshgen.unit_cube(119)
+    else:
+        nodes, cells, bnd = meshgen.unit_square(708)
+    _, f = meshgen.manufactured(nodes.shape[1])
+    ctx = capi.Context(device=0)
+    ctx.mesh_upload(nodes, cells, bnd)
+    nd = ctx.dofs_build(1)
+    qn = ctx.quadrature_nodes()
+    fq = f(qn)
+    ctx.set_operator(-capi.laplacian())
+    ctx.set_forcing(fq)
+    ctx.init()
+    m = o.Mesh(nodes, cells, bnd)
+    od, ob, ond, _ = o.enumerate_dofs(m, 1)
+    dofs, bdofs, _ = ctx.dofs_get()
+    assert nd == ond and np.array_equal(dofs, od) and np.array_equal(bdofs != 0, ob != 0)
+    assert np.abs(qn - o.quadrature_nodes(m, 1)).max() <= 1e-15
+    rp, ci = ctx.pattern_get()
+    A = o.assemble_operator(m, 1, od, ond, -o.laplacian())
+    assert np.array_equal(rp, A.rowptr) and np.array_equal(ci, A.colidx)
+    assert np.abs(ctx.matrix_values(capi.MAT_STIFF) - A.values).max() <= 1e-12 * max(1.0, np.abs(A.values).max())
+    del A
+    Mm = o.assemble_operator(m, 1, od, ond, o.reaction(1.0))
+    assert np.abs(ctx.matrix_values(capi.MAT_MASS) - Mm.values).max() <= 1e-12 * max(1.0, np.abs(Mm.values).max())
+    del Mm
+    rhs = o.assemble_forcing(m, 1, od, ond, fq)
+    assert np.abs(ctx.force() - rhs).max() <= 1e-12 * max(1.0, np.abs(rhs).max())
+    ctx.close()

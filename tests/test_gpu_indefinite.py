@@ -296,13 +296,13 @@ def test_gmres_above_65536_dofs_through_the_handle_and_the_stepper(env):
     A = _csr(c, capi, capi.MAT_STIFF, nd)
     M = _csr(c, capi, capi.MAT_MASS, nd)
     # handle: two columns against the assembled operator (no Dirichlet reduction in the handle: a mass shift of the size of an implicit Euler step's keeps restarted GMRES away from stagnation)
-    vals = c.matrix_values(capi.MAT_STIFF) + 5e4 * c.matrix_values(capi.MAT_MASS)
+    vals = c.matrix_values(capi.MAT_STIFF) + 5e5 * c.matrix_values(capi.MAT_MASS)
     c.lin_compute(values=vals, symmetric=False)
     rng = np.random.default_rng(5)
     b = rng.standard_normal((nd, 2))
     x, info = c.lin_solve(b, method=capi.SOLVER_GMRES, rtol=1e-10)
     assert info.converged == 1 and info.method_used == capi.SOLVER_GMRES
-    K = (A + 5e4 * M).tocsc()
+    K = (A + 5e5 * M).tocsc()
     lu = spl.splu(K)
     for j in range(2):
         ref = lu.solve(b[:, j])

@@ -183,3 +183,34 @@ def test_multi_gpu_acceptance_predictions_are_monotone():
             assert r["us_per_iteration"] < last["us_per_iteration"] and r["dof_per_s"] > last["dof_per_s"]
         last = r
     assert 100e6 < dist.predict_c3(2, "rowdist")["dof_per_s"] < 400e6
+
+
+def test_parity_check_fails_the_bench_when_a_bar_is_missed():
+    """the comparison itself: a perturbed entry / a different pattern must be reported as not ok"""
+    import numpy as np
+
+    import sys
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import oracle as o
+
+    m = o.load_mesh(os.path.join(ROOT, "tests", "golden", "mesh", "unit_square_16"))
+    dofs, bnd, nd, _ = o.enumerate_dofs(m, 1)
+    A = o.assemble_operator(m, 1, dofs, nd, -o.laplacian())
+    Mm = o.assemble_operator(m, 1, dofs, nd, o.reaction(1.0))
+    rhs = o.assemble_forcing(m, 1, dofs, nd, np.ones(3 * m.n_cells))
+    u = np.linspace(1.0, 2.0, nd)
+    gpu = {"u": u.copy(), "rowptr": A.rowptr.copy(), "colidx": A.colidx.copy(), "dofs": dofs.copy(), "boundary": bnd.copy(), "stiff": A.values.copy(),
+           "mass": Mm.values.copy(), "force": rhs.copy()}
+    assert bench.parity_against_oracle(gpu, dofs, bnd, A, Mm, rhs, u, "self")["ok"] is True
+    bad = dict(gpu, stiff=gpu["stiff"].copy())
+    bad["stiff"][7] += 1e-9
+    assert bench.parity_against_oracle(bad, dofs, bnd, A, Mm, rhs, u, "self")["ok"] is False
+    bad = dict(gpu, colidx=gpu["colidx"].copy())
+    bad["colidx"][3] += 1
+    r = bench.parity_against_oracle(bad, dofs, bnd, A, Mm, rhs, u, "self")
+    assert r["ok"] is False and r["pattern_equal"] is False
+    bad = dict(gpu, u=u * (1 + 1e-6))
+    assert bench.parity_against_oracle(bad, dofs, bnd, A, Mm, rhs, u, "self")["ok"] is False

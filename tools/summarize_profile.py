@@ -110,6 +110,17 @@ def pmc_json(out):
                                        % (res["persist_iterations"], res["persist_hbm_bytes_per_solve"] / res["persist_iterations"] / 1e6))
     except Exception as e:   # (the json stays usable by hand)
         res["workload_note"] = "bench line of the traced run not found: %s" % e
+    # what the counters were collected ON: the commit the caller names (FDAPDE_HEAD: there is no .git on the GPU box) and a digest of the solve's kernel
+    # sources as they lie in this snapshot -- bench.py prints both (roofline.traffic_head) and flags a file that no longer matches the kernels it runs
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        import bench as _bench
+
+        res["kernel_source_sha16"] = _bench.solve_kernel_sha16()
+    except Exception as e:
+        res["kernel_source_sha16"] = None
+        res["kernel_source_sha16_error"] = str(e)[:200]
+    res["head"] = os.environ.get("FDAPDE_HEAD")
     json.dump(res, open(os.path.join(out, "spmv_pmc.json"), "w"), indent=1)
     print("== spmv_pmc.json ==")
     print(json.dumps(res, indent=1))

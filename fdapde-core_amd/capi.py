@@ -48,7 +48,10 @@ SYMBOLS = [
     "fdapde_comm_unique_id", "fdapde_comm_init", "fdapde_halo_setup", "fdapde_solve_parabolic",
     "fdapde_lin_compute", "fdapde_lin_solve", "fdapde_eval_pointwise", "fdapde_cell_integrals", "fdapde_comm_init_callback", "fdapde_comm_set_exchange_callback", "fdapde_halo_setup_peers",
     "fdapde_solver_layout", "fdapde_topology_build", "fdapde_topology_get", "fdapde_comm_allreduce", "fdapde_comm_library", "fdapde_solver_layout_kind", "fdapde_rowdist_setup", "fdapde_ctx_clone", "fdapde_comm_count",
+    "fdapde_ctx_create_multi", "fdapde_ctx_devices", "fdapde_partition_build", "fdapde_partition_sizes", "fdapde_partition_get", "fdapde_partition_whole",
+    "fdapde_partition_peers",
 ]
+PARTITION_ROWDIST, PARTITION_ELEMENTS = 0, 1
 
 _lib = None
 
@@ -160,14 +163,68 @@ def dt():
 class Context:
     """One fdapde_ctx.  device=None -> host-only context (numbering / pattern queries only)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, devices=None):
+        """devices=[d0, d1, ...]: ONE context over several devices (fdapde_ctx_create_multi; a device may be named several times)"""
         self.lib = load()
         self._ctx = C.c_void_p()
-        rc = self.lib.fdapde_ctx_create(-1 if device is None else int(device), C.byref(self._ctx))
+        if devices is not None:
+            dv = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+            rc = self.lib.fdapde_ctx_create_multi(dv, len(devices), C.byref(self._ctx))
+        else:
+            rc = self.lib.fdapde_ctx_create(-1 if device is None else int(device), C.byref(self._ctx))
         if rc != OK:
             raise FdapdeError(rc, self.lib.fdapde_status_string(rc).decode())
         self.M = self.N = 0
         self.n_cells = self.n_nodes = 0
+
+    def devices(self):
+        """-> dict(devices=[...], form=0 row-distributed | 1 element partition | -1 single device, t_partition_ms, t_rank_setup_ms)"""
+        n = C.c_int32()
+        self._check(self.lib.fdapde_ctx_devices(self._ctx, C.byref(n), None, None, None, None))
+        dv = (C.c_int32 * n.value)()
+        form, tp, tr = C.c_int32(), C.c_double(), C.c_double()
+        self._check(self.lib.fdapde_ctx_devices(self._ctx, C.byref(n), dv, C.byref(form), C.byref(tp), C.byref(tr)))
+        return dict(devices=list(dv), form=form.value, t_partition_ms=tp.value, t_rank_setup_ms=tr.value)
+
+    # ---- the device-side partitioner (rank processes: every process partitions the whole mesh on its own device and takes its share)
+    def partition_build(self, world, form=PARTITION_ROWDIST):
+        self._check(self.lib.fdapde_partition_build(self._ctx, int(world), int(form)))
+        self._part_world = int(world)
+
+    def partition_get(self, rank):
+        """-> dict(nodes (n, N), cells (m, M + 1) local ids, boundary, l2g (global node ids, ascending), cell_ids, owner (rank owning each local node))"""
+        nn, nc = C.c_int64(), C.c_int64()
+        self._check(self.lib.fdapde_partition_sizes(self._ctx, int(rank), C.byref(nn), C.byref(nc)))
+        nn, nc = nn.value, nc.value
+        nodes = np.zeros(nn * self.N)
+        cells = np.zeros((nc, self.M + 1), dtype=np.int32)
+        bnd = np.zeros(nn, dtype=np.uint8)
+        l2g, cids, own = np.zeros(nn, dtype=np.int64), np.zeros(nc, dtype=np.int64), np.zeros(nn, dtype=np.int32)
+        self._check(self.lib.fdapde_partition_get(self._ctx, int(rank), _dp(nodes), _ip(cells), _bp(bnd), l2g.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                  cids.ctypes.data_as(C.POINTER(C.c_int64)), _ip(own)))
+        return dict(nodes=np.ascontiguousarray(nodes.reshape(self.N, nn).T), cells=cells, boundary=bnd, l2g=l2g, cell_ids=cids, owner=own)
+
+    def partition_whole(self):
+        """-> (rank of every cell, owner of every node, bit mask of the ranks whose sub-mesh holds a node)"""
+        part = np.zeros(self.n_cells, dtype=np.int32)
+        own = np.zeros(self.n_nodes, dtype=np.int32)
+        mask = np.zeros(self.n_nodes, dtype=np.uint64)
+        self._check(self.lib.fdapde_partition_whole(self._ctx, _ip(part), _ip(own), mask.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return part, own, mask
+
+    def partition_peers(self, rank):
+        """element form, P1: (peer_rank, peer_off, peer_dof, owned) for halo_setup_peers"""
+        npeers, nshared = C.c_int32(), C.c_int64()
+        self._check(self.lib.fdapde_partition_peers(self._ctx, int(rank), C.byref(npeers), None, None, None, None, C.byref(nshared)))
+        nn = C.c_int64()
+        self._check(self.lib.fdapde_partition_sizes(self._ctx, int(rank), C.byref(nn), None))
+        pr = np.zeros(max(npeers.value, 1), dtype=np.int32)
+        po = np.zeros(npeers.value + 1, dtype=np.int64)
+        pd = np.zeros(max(nshared.value, 1), dtype=np.int32)
+        owned = np.zeros(nn.value, dtype=np.uint8)
+        self._check(self.lib.fdapde_partition_peers(self._ctx, int(rank), C.byref(npeers), _ip(pr), po.ctypes.data_as(C.POINTER(C.c_int64)), _ip(pd), _bp(owned),
+                                                    C.byref(nshared)))
+        return pr[:npeers.value], po, pd[:nshared.value], owned
 
     def clone(self):
         """fdapde_ctx_clone: an independent context with the same problem, assembled state and solution"""

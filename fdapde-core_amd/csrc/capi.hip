@@ -73,7 +73,10 @@ int fdapde_ctx_create(int device, fdapde_ctx** out) {
 
 void fdapde_ctx_destroy(fdapde_ctx* c) {
     if (!c) return;
+    if (c->group) fdapde_engine::g_destroy(c);   // (the rank contexts and their threads first)
     if (c->has_device) {
+        (void)hipSetDevice(c->device);
+        fdapde_engine::partition_free(c);
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
         drop_graph(c);
@@ -121,6 +124,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
 int fdapde_ctx_clone(const fdapde_ctx* src, fdapde_ctx** out) {
     if (!src || !out) return FDAPDE_EINVAL;
     *out = nullptr;
+    if (src->group) return fail(const_cast<fdapde_ctx*>(src), FDAPDE_EUNSUPPORTED, "fdapde_ctx_clone: a multi-device context is not cloned (copies of the host-side bindings share it)");
     fdapde_ctx* c = nullptr;
     if (int rc = fdapde_ctx_create(src->has_device ? src->device : -1, &c)) return rc;
     const int rc = fdapde_engine::e_ctx_clone(src, c);
@@ -155,6 +159,8 @@ int fdapde_mesh_upload(fdapde_ctx* c, int M, int N, int64_t n_nodes, const doubl
         }
         c->mesh_on_dev = true;
     }
+    fdapde_engine::partition_free(c);   // (a partition of the previous mesh)
+    if (c->group) fdapde_engine::g_mesh_changed(c);
     return FDAPDE_OK;
 }
 
@@ -171,6 +177,7 @@ int fdapde_sizes(const fdapde_ctx* c, int64_t* n_dofs, int64_t* nnz, int32_t* n_
 // ---- everything else forwards to the engine units (the guards above the call are the shim's; the units check call order and ranges)
 int fdapde_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fdapde_engine::g_dofs_build(c, order, n_dofs);
     return fdapde_engine::e_dofs_build(c, order, n_dofs);
 }
 int fdapde_topology_build(fdapde_ctx* c, int64_t* n_facets, int64_t* n_edges) {
@@ -183,6 +190,7 @@ int fdapde_topology_get(fdapde_ctx* c, int32_t* neighbors, int32_t* cell_facets,
 }
 int fdapde_dofs_set_boundary(fdapde_ctx* c, const uint8_t* bnd) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fdapde_engine::g_dofs_set_boundary(c, bnd);
     return fdapde_engine::e_dofs_set_boundary(c, bnd);
 }
 int fdapde_dofs_get(const fdapde_ctx* c, int32_t* dofs, uint8_t* bnd, double* coords) {
@@ -199,22 +207,27 @@ int fdapde_quadrature_nodes(fdapde_ctx* c, double* out) {
 }
 int fdapde_set_operator(fdapde_ctx* c, int32_t n_terms, const fdapde_term* terms) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fdapde_engine::g_set_operator(c, n_terms, terms);
     return fdapde_engine::e_set_operator(c, n_terms, terms);
 }
 int fdapde_set_forcing(fdapde_ctx* c, const double* f_q, int32_t n_cols) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fdapde_engine::g_set_forcing(c, f_q, n_cols);
     return fdapde_engine::e_set_forcing(c, f_q, n_cols);
 }
 int fdapde_set_dirichlet(fdapde_ctx* c, const double* g) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fdapde_engine::g_set_dirichlet(c, g);
     return fdapde_engine::e_set_dirichlet(c, g);
 }
 int fdapde_assemble_operator(fdapde_ctx* c, int32_t which, int32_t n_terms, const fdapde_term* terms, int32_t assembly) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fdapde_engine::g_assemble_operator(c, which, n_terms, terms, assembly);
     return fdapde_engine::e_assemble_operator(c, which, n_terms, terms, assembly);
 }
 int fdapde_init(fdapde_ctx* c, const fdapde_options* opt) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fdapde_engine::g_init(c, opt);
     return fdapde_engine::e_init(c, opt);
 }
 int fdapde_eval_pointwise(fdapde_ctx* c, int64_t n_locs, const double* locs_colmajor, int32_t* cell_ids, double* values) {
@@ -227,54 +240,67 @@ int fdapde_cell_integrals(fdapde_ctx* c, double* measure, double* psi_int) {
 }
 int fdapde_solver_prepare(fdapde_ctx* c, int32_t with_dirichlet) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fdapde_engine::g_solver_prepare(c, with_dirichlet);
     return fdapde_engine::e_solver_prepare(c, with_dirichlet);
 }
 int fdapde_solver_layout(fdapde_ctx* c, int32_t with_dirichlet, int64_t* n_interior, int64_t* nnz_interior, double* streamed_bytes) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fdapde_engine::g_layout_kind(c, with_dirichlet, nullptr, nullptr, nullptr, nullptr);
     return fdapde_engine::e_solver_layout(c, with_dirichlet, n_interior, nnz_interior, streamed_bytes);
 }
 int fdapde_solver_layout_kind(fdapde_ctx* c, int32_t with_dirichlet, int32_t* kind, int32_t* symmetric_storage, int32_t* workgroups, int32_t* rows_per_thread) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fdapde_engine::g_layout_kind(c, with_dirichlet, kind, symmetric_storage, workgroups, rows_per_thread);
     return fdapde_engine::e_solver_layout_kind(c, with_dirichlet, kind, symmetric_storage, workgroups, rows_per_thread);
 }
 int fdapde_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fdapde_engine::g_solve(c, opt, info);
     return fdapde_engine::e_solve(c, opt, info);
 }
 int fdapde_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times, double delta_t, const double* initial_condition, const double* dirichlet, double* solution, fdapde_info* info) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fdapde_engine::g_solve_parabolic(c, opt, n_times, delta_t, initial_condition, dirichlet, solution, info);
     return fdapde_engine::e_solve_parabolic(c, opt, n_times, delta_t, initial_condition, dirichlet, solution, info);
 }
 int fdapde_lin_compute(fdapde_ctx* c, int32_t which, const double* values, int32_t symmetric) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fdapde_engine::g_lin_compute(c, which, values, symmetric);
     return fdapde_engine::e_lin_compute(c, which, values, symmetric);
 }
 int fdapde_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32_t n_rhs, double* x, fdapde_info* info) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fdapde_engine::g_lin_solve(c, opt, b, n_rhs, x, info);
     return fdapde_engine::e_lin_solve(c, opt, b, n_rhs, x, info);
 }
 int fdapde_matrix_values(fdapde_ctx* c, int32_t which, double* values) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fdapde_engine::g_matrix_values(c, which, values);
     return fdapde_engine::e_matrix_values(c, which, values);
 }
 int fdapde_lump(fdapde_ctx* c, int32_t which, double* diag) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fdapde_engine::g_lump(c, which, diag);
     return fdapde_engine::e_lump(c, which, diag);
 }
 int fdapde_force(fdapde_ctx* c, double* force) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fdapde_engine::g_force(c, force);
     return fdapde_engine::e_force(c, force);
 }
 int fdapde_solution(fdapde_ctx* c, double* solution) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fdapde_engine::g_solution(c, solution);
     return fdapde_engine::e_solution(c, solution);
 }
 int fdapde_spmv(fdapde_ctx* c, int32_t which, const double* x, double* y) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fdapde_engine::g_spmv(c, which, x, y);
     return fdapde_engine::e_spmv(c, which, x, y);
 }
 int fdapde_bench_spmv(fdapde_ctx* c, int32_t reps, double* avg_ms, double* algorithmic_bytes) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fail(c, FDAPDE_EUNSUPPORTED, "fdapde_bench_spmv: a multi-device context wires its own ranks");
     return fdapde_engine::e_bench_spmv(c, reps, avg_ms, algorithmic_bytes);
 }
 int fdapde_comm_unique_id(void* out128) {
@@ -282,10 +308,12 @@ int fdapde_comm_unique_id(void* out128) {
 }
 int fdapde_comm_init(fdapde_ctx* c, int32_t world, int32_t rank, const void* unique_id128) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fail(c, FDAPDE_EUNSUPPORTED, "fdapde_comm_init: a multi-device context wires its own ranks");
     return fdapde_engine::e_comm_init(c, world, rank, unique_id128);
 }
 int fdapde_comm_allreduce(fdapde_ctx* c, double* host_inout, int32_t n, int32_t op) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fail(c, FDAPDE_EUNSUPPORTED, "fdapde_comm_allreduce: a multi-device context wires its own ranks");
     return fdapde_engine::e_comm_allreduce(c, host_inout, n, op);
 }
 int fdapde_comm_count(fdapde_ctx* c, int32_t* ranks) {
@@ -294,23 +322,57 @@ int fdapde_comm_count(fdapde_ctx* c, int32_t* ranks) {
 }
 int fdapde_comm_init_callback(fdapde_ctx* c, int32_t world, int32_t rank, fdapde_allreduce_fn fn, void* user) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fail(c, FDAPDE_EUNSUPPORTED, "fdapde_comm_init_callback: a multi-device context wires its own ranks");
     return fdapde_engine::e_comm_init_callback(c, world, rank, fn, user);
 }
 int fdapde_halo_setup(fdapde_ctx* c, int64_t n_if_global, int64_t n_if_local, const int32_t* local_dof, const int32_t* if_index, const uint8_t* owned) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fail(c, FDAPDE_EUNSUPPORTED, "fdapde_halo_setup: a multi-device context wires its own ranks");
     return fdapde_engine::e_halo_setup(c, n_if_global, n_if_local, local_dof, if_index, owned);
 }
 int fdapde_rowdist_setup(fdapde_ctx* c, const int64_t* dof_key, const int32_t* dof_owner) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fail(c, FDAPDE_EUNSUPPORTED, "fdapde_rowdist_setup: a multi-device context wires its own ranks");
     return fdapde_engine::e_rowdist_setup(c, dof_key, dof_owner);
 }
 int fdapde_comm_set_exchange_callback(fdapde_ctx* c, fdapde_exchange_fn fn, void* user) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fail(c, FDAPDE_EUNSUPPORTED, "fdapde_comm_set_exchange_callback: a multi-device context wires its own ranks");
     return fdapde_engine::e_comm_set_exchange_callback(c, fn, user);
 }
 int fdapde_halo_setup_peers(fdapde_ctx* c, int32_t n_peers, const int32_t* peer_rank, const int64_t* peer_off, const int32_t* peer_dof, const uint8_t* owned) {
     if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fail(c, FDAPDE_EUNSUPPORTED, "fdapde_halo_setup_peers: a multi-device context wires its own ranks");
     return fdapde_engine::e_halo_setup_peers(c, n_peers, peer_rank, peer_off, peer_dof, owned);
+}
+
+int fdapde_ctx_create_multi(const int32_t* devices, int32_t n_devices, fdapde_ctx** out) {
+    return fdapde_engine::g_create(devices, n_devices, out);
+}
+int fdapde_ctx_devices(const fdapde_ctx* c, int32_t* n_devices, int32_t* devices, int32_t* form, double* t_partition_ms, double* t_rank_setup_ms) {
+    if (!c) return FDAPDE_EINVAL;
+    return fdapde_engine::g_info(c, n_devices, devices, form, t_partition_ms, t_rank_setup_ms);
+}
+int fdapde_partition_build(fdapde_ctx* c, int32_t world, int32_t form) {
+    if (!c) return FDAPDE_EINVAL;
+    if (c->group) return fail(c, FDAPDE_EUNSUPPORTED, "fdapde_partition_build: a multi-device context partitions its mesh itself (fdapde_dofs_build)");
+    return fdapde_engine::e_partition_build(c, world, form);
+}
+int fdapde_partition_sizes(const fdapde_ctx* c, int32_t rank, int64_t* n_nodes, int64_t* n_cells) {
+    if (!c) return FDAPDE_EINVAL;
+    return fdapde_engine::e_partition_sizes(c, rank, n_nodes, n_cells);
+}
+int fdapde_partition_get(fdapde_ctx* c, int32_t rank, double* nodes_colmajor, int32_t* cells, uint8_t* boundary, int64_t* node_ids, int64_t* cell_ids, int32_t* node_owner) {
+    if (!c) return FDAPDE_EINVAL;
+    return fdapde_engine::e_partition_get(c, rank, nodes_colmajor, cells, boundary, node_ids, cell_ids, node_owner);
+}
+int fdapde_partition_whole(fdapde_ctx* c, int32_t* cell_rank, int32_t* node_owner, uint64_t* node_ranks) {
+    if (!c) return FDAPDE_EINVAL;
+    return fdapde_engine::e_partition_whole(c, cell_rank, node_owner, node_ranks);
+}
+int fdapde_partition_peers(fdapde_ctx* c, int32_t rank, int32_t* n_peers, int32_t* peer_rank, int64_t* peer_off, int32_t* peer_node, uint8_t* owned, int64_t* n_shared) {
+    if (!c) return FDAPDE_EINVAL;
+    return fdapde_engine::e_partition_peers(c, rank, n_peers, peer_rank, peer_off, peer_node, owned, n_shared);
 }
 
 int fdapde_info_get(const fdapde_ctx* c, fdapde_info* info) {
@@ -325,6 +387,7 @@ const char* fdapde_comm_library(void) { return g_rccl.path.c_str(); }
 int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     if (!c || !key) return FDAPDE_EINVAL;
     if (!c->dev_ready) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
+    if (c->group) return fdapde_engine::g_tune(c, key, value);
     const std::string k(key);
     drop_graph(c);
     if (k == "spmv_variant" && value >= 0 && value <= 2) c->spmv_variant = value;
@@ -422,6 +485,8 @@ void* fdapde_stream(fdapde_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int fdapde_synchronize(fdapde_ctx* c) {
     if (!c) return FDAPDE_EINVAL;
     if (int rc = need_device(c)) return rc;
+    if (c->group)
+        if (int rc = fdapde_engine::g_synchronize(c)) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipDeviceSynchronize());   // (what torch.cuda.synchronize() would do: nothing of this process is left running on the device)

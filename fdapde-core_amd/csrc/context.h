@@ -21,7 +21,11 @@
 #include "dev_topology.h"
 #include "internal.h"
 
+namespace fdapde_engine {
+struct Group;            // eng_group.hip: the ranks of a multi-device context
+}
 namespace fdapde_hip {
+struct DevPartition;     // dev_partition.h
 struct DevTables;        // kernels_assembly.h (the context only holds device buffers of them)
 struct DevRefTensors;
 struct DevRefTensorsSym;
@@ -437,6 +441,13 @@ struct fdapde_ctx {
     DBuf<int32_t> part_cells, part_off, part_slots, wave_slots;
     DBuf<uint8_t> part_shared;
     std::vector<double> persist_host_stats;
+    // multi-device context (fdapde_ctx_create_multi): this context is the ROOT -- whole mesh, whole function space, every index getter -- of a group
+    // of rank contexts, one per device (eng_group.hip)
+    fdapde_engine::Group* group = nullptr;
+    // the split of the resident mesh computed by fdapde_partition_build (dev_partition.hip)
+    fdapde_hip::DevPartition* partition = nullptr;
+    double partition_ms = 0;
+    std::vector<uint64_t> partition_mask_h;
 };
 
 #endif

@@ -103,6 +103,38 @@ int e_rowdist_setup(fdapde_ctx* c, const int64_t* dof_key, const int32_t* dof_ow
 int e_comm_set_exchange_callback(fdapde_ctx* c, fdapde_exchange_fn fn, void* user);
 int e_halo_setup_peers(fdapde_ctx* c, int32_t n_peers, const int32_t* peer_rank, const int64_t* peer_off, const int32_t* peer_dof, const uint8_t* owned);
 
+// ---- the device-side partitioner's public face and the multi-device context (eng_group.hip) ------------------------------------------------
+int e_partition_build(fdapde_ctx* c, int32_t world, int32_t form);
+int e_partition_sizes(const fdapde_ctx* c, int32_t rank, int64_t* n_nodes, int64_t* n_cells);
+int e_partition_get(fdapde_ctx* c, int32_t rank, double* nodes_colmajor, int32_t* cells, uint8_t* boundary, int64_t* node_ids, int64_t* cell_ids, int32_t* node_owner);
+int e_partition_whole(fdapde_ctx* c, int32_t* cell_rank, int32_t* node_owner, uint64_t* node_ranks);
+int e_partition_peers(fdapde_ctx* c, int32_t rank, int32_t* n_peers, int32_t* peer_rank, int64_t* peer_off, int32_t* peer_node, uint8_t* owned, int64_t* n_shared);
+void partition_free(fdapde_ctx* c);
+int g_create(const int32_t* devices, int32_t n, fdapde_ctx** out);
+void g_destroy(fdapde_ctx* root);
+int g_info(const fdapde_ctx* root, int32_t* n_devices, int32_t* devices, int32_t* form, double* t_partition_ms, double* t_rank_setup_ms);
+void g_mesh_changed(fdapde_ctx* root);
+int g_dofs_build(fdapde_ctx* root, int order, int64_t* n_dofs);
+int g_dofs_set_boundary(fdapde_ctx* root, const uint8_t* bnd);
+int g_set_operator(fdapde_ctx* root, int32_t n_terms, const fdapde_term* terms);
+int g_assemble_operator(fdapde_ctx* root, int32_t which, int32_t n_terms, const fdapde_term* terms, int32_t assembly);
+int g_set_forcing(fdapde_ctx* root, const double* f_q, int32_t n_cols);
+int g_set_dirichlet(fdapde_ctx* root, const double* g);
+int g_init(fdapde_ctx* root, const fdapde_options* opt);
+int g_solver_prepare(fdapde_ctx* root, int32_t with_dirichlet);
+int g_solve(fdapde_ctx* root, const fdapde_options* opt, fdapde_info* info);
+int g_solution(fdapde_ctx* root, double* solution);
+int g_force(fdapde_ctx* root, double* force);
+int g_lump(fdapde_ctx* root, int32_t which, double* diag);
+int g_matrix_values(fdapde_ctx* root, int32_t which, double* values);
+int g_spmv(fdapde_ctx* root, int32_t which, const double* x, double* y);
+int g_solve_parabolic(fdapde_ctx* root, const fdapde_options* opt, int32_t n_times, double delta_t, const double* initial_condition, const double* dirichlet, double* solution, fdapde_info* info);
+int g_lin_compute(fdapde_ctx* root, int32_t which, const double* values, int32_t symmetric);
+int g_lin_solve(fdapde_ctx* root, const fdapde_options* opt, const double* b, int32_t n_rhs, double* x, fdapde_info* info);
+int g_tune(fdapde_ctx* root, const char* key, int32_t value);
+int g_synchronize(fdapde_ctx* root);
+int g_layout_kind(fdapde_ctx* root, int32_t with_dirichlet, int32_t* kind, int32_t* symmetric_storage, int32_t* workgroups, int32_t* rows_per_thread);
+
 // code objects of the units loaded up front (fdapde_ctx_create)
 void preload_assembly();
 void preload_solve();

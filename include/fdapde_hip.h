@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FDAPDE_ABI_VERSION 4
+#define FDAPDE_ABI_VERSION 5
 
 enum {
     FDAPDE_OK = 0,
@@ -130,6 +130,22 @@ void fdapde_ctx_destroy(fdapde_ctx *ctx);
  * rebuilt (same deterministic set-up, bit-identical index arrays), the data are copied device to device; tuning knobs and solver
  * layouts are not carried over.  A context that is a rank of a multi-GPU job is refused (FDAPDE_EUNSUPPORTED). */
 int fdapde_ctx_clone(const fdapde_ctx *src, fdapde_ctx **out);
+/* ONE context over SEVERAL devices of a node -- the mesh sharded behind the reference's one-object, one-thread interface (fdaPDE/pde/pde.h:58-105
+ * holds one PDE; north_star shards its mesh over the GPUs).  The context handed out is used exactly like a single-device one: every entry point of
+ * this header below takes it, every array keeps the reference's numbering of the WHOLE mesh.  Inside, fdapde_dofs_build splits the resident mesh on
+ * the device (Morton chunks of the cell barycentres, node owners dealt in patches: csrc/dev_partition.hip), builds one rank context per device --
+ * each driven by a worker thread of the library -- and wires them through an in-process transport; fdapde_init / fdapde_solve /
+ * fdapde_solve_parabolic / fdapde_lin_solve run on all devices at once: the row-distributed form (complete rows per owner, the whole Krylov
+ * iteration as one persistent launch per device, launches exchanging through peer-mapped boards) where the library takes the system, the
+ * element-partitioned neighbour exchange otherwise (the context changes form by itself).  A device may be named several times (its CUs are then
+ * shared out: how the tests run 2 - 4 "devices" on one GPU).  devices[0] also keeps the whole mesh and function space for the index getters.
+ * Not available on such a context: fdapde_ctx_clone, fdapde_comm_*, fdapde_halo_setup*, fdapde_rowdist_setup, fdapde_partition_build,
+ * fdapde_bench_spmv, fdapde_solver_layout* (FDAPDE_EUNSUPPORTED). */
+int fdapde_ctx_create_multi(const int32_t *devices, int32_t n_devices, fdapde_ctx **ctx);
+/* devices of a context (1 and its own device for a single-device one), the form its ranks are in (0 row-distributed, 1 element partition,
+ * -1 single device), and what the last fdapde_dofs_build spent on the split: partitioning on the device / the ranks' set-up.  Any pointer may be NULL. */
+int fdapde_ctx_devices(const fdapde_ctx *ctx, int32_t *n_devices, int32_t *devices, int32_t *form, double *t_partition_ms,
+                       double *t_rank_setup_ms);
 const char *fdapde_last_error(const fdapde_ctx *ctx);
 const char *fdapde_status_string(int status);
 
@@ -244,7 +260,7 @@ int fdapde_solver_layout_kind(fdapde_ctx *ctx, int32_t with_dirichlet, int32_t *
  * No reference counterpart (the reference is single-threaded, single address space).  Each rank uploads the sub-mesh of
  * its own cells (local node numbering), assembles its sub-assembled operator with the calls above, and the solve sums the
  * interface ("halo") DOF contributions over the ranks sharing them with one RCCL all-reduce per operator application
- * (fused with the p.Ap partial) plus one scalar all-reduce per iteration.  See fdapde-core_amd/dist.py for the partitioner.
+ * (fused with the p.Ap partial) plus one scalar all-reduce per iteration.  The partitioner: fdapde_partition_build below (fdapde-core_amd/dist.py: the numpy original it is tested against).
  *   fdapde_comm_unique_id : rank 0 creates the 128-byte RCCL id; the caller broadcasts it (e.g. torch.distributed)
  *   fdapde_comm_init      : every rank joins the communicator on its context's device and stream
  *   fdapde_halo_setup     : interface maps.  n_if_global = number of interface DOFs of the whole mesh; local_dof[k] (this
@@ -252,7 +268,8 @@ int fdapde_solver_layout_kind(fdapde_ctx *ctx, int32_t with_dirichlet, int32_t *
  *                           interface vector), k < n_if_local; owned[d] = 1 iff this rank counts local DOF d in global
  *                           dot products (every global DOF is owned by exactly one rank).
  * After fdapde_halo_setup every solve of the context is element-partitioned: fdapde_solve (single-reduction CG or BiCGStab),
- * fdapde_solve_parabolic, fdapde_lin_solve (right-hand sides sub-assembled, i.e. summed over the ranks sharing a DOF). */
+ * fdapde_solve_parabolic, fdapde_lin_solve (right-hand sides sub-assembled, i.e. summed over the ranks sharing a DOF).
+ * (One PROCESS driving several devices needs none of this: fdapde_ctx_create_multi above.) */
 /* host-staged transport instead of RCCL: fn(user, host_buf, count) must replace host_buf by its sum over all ranks and
  * return 0.  Lets the distributed path run over any fabric (tests drive it with torch.distributed/gloo, two ranks on one GPU). */
 typedef int (*fdapde_allreduce_fn)(void *user, double *host_buf, int64_t count);
@@ -303,6 +320,23 @@ int fdapde_halo_setup_peers(fdapde_ctx *ctx, int32_t n_peers, const int32_t *pee
  * on every rank and the caller uses the element-partitioned exchange above.  Solution entries of DOFs owned by other ranks: the
  * Dirichlet lift where there is one, otherwise not computed (the parabolic stepper returns the imported values). */
 int fdapde_rowdist_setup(fdapde_ctx *ctx, const int64_t *dof_key, const int32_t *dof_owner);
+
+/* The partitioner by itself, for rank PROCESSES (one context per process, as above): every process uploads the whole mesh to its own device,
+ * calls fdapde_partition_build and takes its rank's share -- nothing is shipped between processes.  On the mesh resident on the device since
+ * fdapde_mesh_upload; form 0: row-distributed (a rank's sub-mesh = every cell touching a node it owns; owners = the lowest / highest rank
+ * touching a node by checkerboard box), form 1: element partition (sub-mesh = the rank's Morton chunk of the cells; owner = the lowest rank
+ * touching a node).  world <= 64.  Array for array what fdapde-core_amd/dist.py computes with numpy (tests/test_gpu_partition.py).
+ *   fdapde_partition_get   : a rank's sub-mesh in the layouts of fdapde_mesh_upload, the global ids of its nodes and cells (ascending: local
+ *                            numbering = ascending global id) and the owning rank of every local node; any pointer may be NULL
+ *   fdapde_partition_whole : per cell of the whole mesh its rank, per node its owner and the bit mask of the ranks whose sub-mesh holds it
+ *   fdapde_partition_peers : form 1, P1 (DOF = node): the lists fdapde_halo_setup_peers takes -- call with NULL arrays for the sizes first */
+int fdapde_partition_build(fdapde_ctx *ctx, int32_t world, int32_t form);
+int fdapde_partition_sizes(const fdapde_ctx *ctx, int32_t rank, int64_t *n_nodes, int64_t *n_cells);
+int fdapde_partition_get(fdapde_ctx *ctx, int32_t rank, double *nodes_colmajor, int32_t *cells_rowmajor, uint8_t *boundary_nodes,
+                         int64_t *node_ids, int64_t *cell_ids, int32_t *node_owner);
+int fdapde_partition_whole(fdapde_ctx *ctx, int32_t *cell_rank, int32_t *node_owner, uint64_t *node_ranks);
+int fdapde_partition_peers(fdapde_ctx *ctx, int32_t rank, int32_t *n_peers, int32_t *peer_rank, int64_t *peer_off, int32_t *peer_node,
+                           uint8_t *owned, int64_t *n_shared);
 
 /* tuning / diagnostic knobs (A/B measurements inside one process; defaults are the measured best):
  *   SpMV launch   "spmv_variant" (2 pair form, 0 team form, 1 stream form), "spmv_team", "spmv_unroll", "spmv_bpx" (workgroups

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(capi):
     assert sorted(capi.SYMBOLS) == declared
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.fdapde_abi_version() == 4
+    assert lib.fdapde_abi_version() == 5
 
 
 FIXTURES = ["unit_square_16", "unit_square_32", "unit_square_64", "unit_square", "c_shaped", "quasi_circle", "unit_sphere"]

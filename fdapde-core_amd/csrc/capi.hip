@@ -124,7 +124,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
 int fdapde_ctx_clone(const fdapde_ctx* src, fdapde_ctx** out) {
     if (!src || !out) return FDAPDE_EINVAL;
     *out = nullptr;
-    if (src->group) return fail(const_cast<fdapde_ctx*>(src), FDAPDE_EUNSUPPORTED, "fdapde_ctx_clone: a multi-device context is not cloned (copies of the host-side bindings share it)");
+    if (src->group) return fdapde_engine::g_clone(src, out);
     fdapde_ctx* c = nullptr;
     if (int rc = fdapde_ctx_create(src->has_device ? src->device : -1, &c)) return rc;
     const int rc = fdapde_engine::e_ctx_clone(src, c);

@@ -53,6 +53,17 @@ int e_ctx_clone(const fdapde_ctx* s, fdapde_ctx* d) {
     if (d->hs.n_dofs != hs.n_dofs || d->hs.nnz != hs.nnz) return fail(d, FDAPDE_EHIP, "fdapde_ctx_clone: the rebuilt space differs from the source's");
     if (d->hs.dof_bnd != hs.dof_bnd)   // fdapde_dofs_set_boundary was used on the source
         if (int rc = e_dofs_set_boundary(d, hs.dof_bnd.data())) return rc;
+    return clone_state(s, d);
+}
+
+// the part of a clone that follows the rebuilt space: problem data and everything fdapde_init / fdapde_solve / fdapde_lin_compute produced, device to
+// device.  Also what a multi-device context's clone does rank by rank (eng_group.hip: its ranks' spaces are rebuilt by the same deterministic split).
+int clone_state(const fdapde_ctx* s, fdapde_ctx* d) {
+    const HostSpace& hs = s->hs;
+    if (s->has_device && d->has_device) {
+        HIPCHK(d, hipSetDevice(d->device));
+        HIPCHK(d, hipStreamSynchronize(s->stream));   // whatever the source still has in flight
+    }
     d->info = s->info;
     // ---- problem data: operator (space-varying coefficient rows already in the internal cell order), forcing samples, Dirichlet data
     d->op.clear();

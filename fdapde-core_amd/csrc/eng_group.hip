@@ -587,6 +587,52 @@ int g_info(const fdapde_ctx* root, int32_t* n_devices, int32_t* devices, int32_t
     return FDAPDE_OK;
 }
 
+// A multi-device context holding the same problem as `src` (fdapde_ctx_clone): the same devices, the mesh split again -- the partitioner is
+// deterministic: the ranks' sub-meshes and spaces come out identical --, the group's host copies of the problem data, and rank by rank the
+// assembled / solved state device to device (eng_clone.hip clone_state).
+int g_clone(const fdapde_ctx* src_root, fdapde_ctx** out) {
+    const Group* sg = group_of(src_root);
+    fdapde_ctx* sroot = const_cast<fdapde_ctx*>(src_root);
+    std::vector<int32_t> devices((size_t)sg->n);
+    for (int r = 0; r < sg->n; ++r) devices[(size_t)r] = sg->rk[(size_t)r].device;
+    fdapde_ctx* root = nullptr;
+    if (int rc = g_create(devices.data(), sg->n, &root)) return fail(sroot, rc, "fdapde_ctx_clone: creating the multi-device context failed");
+    Group* g = root->group;
+    auto bail = [&](int rc) {
+        sroot->err = "fdapde_ctx_clone: " + root->err;
+        fdapde_ctx_destroy(root);
+        return rc;
+    };
+    const HostSpace& hs = src_root->hs;
+    if (hs.n_cells == 0) {
+        *out = root;
+        return FDAPDE_OK;
+    }
+    if (int rc = fdapde_mesh_upload(root, hs.M, hs.N, hs.n_nodes, hs.nodes.data(), hs.n_cells, hs.cells.data(), hs.node_bnd.data())) return bail(rc);
+    if (!src_root->space_ready || !sg->ranks_built) {
+        *out = root;
+        return FDAPDE_OK;
+    }
+    g->form = sg->form, g->form_locked = sg->form_locked, g->knobs = sg->knobs;
+    {
+        const bool keep = g->form_locked;
+        g->form_locked = true;   // (g_dofs_build starts from the row-distributed form unless the form is pinned: the clone takes the source's)
+        const int rc = g_dofs_build(root, hs.order, nullptr);
+        g->form_locked = keep;
+        if (rc) return bail(rc);
+    }
+    if (!sg->bnd_override.empty())
+        if (int rc = g_dofs_set_boundary(root, sg->bnd_override.data())) return bail(rc);
+    for (int r = 0; r < g->n; ++r)
+        if (g->rk[(size_t)r].gdof != sg->rk[(size_t)r].gdof) return bail(fail(root, FDAPDE_EHIP, "the rebuilt split differs from the source's"));
+    g->op = sg->op, g->have_op = sg->have_op, g->fq = sg->fq, g->fq_cols = sg->fq_cols, g->gdir = sg->gdir, g->have_g = sg->have_g;
+    g->init_opt = sg->init_opt, g->have_init_opt = sg->have_init_opt, g->initialised = sg->initialised, g->info = sg->info, root->info = src_root->info;
+    const int rc = run_all(g, [&](int r) { return clone_state(sg->rk[(size_t)r].ctx, g->rk[(size_t)r].ctx); });
+    if (rc) return bail(rc);
+    *out = root;
+    return FDAPDE_OK;
+}
+
 void g_mesh_changed(fdapde_ctx* root) {
     Group* g = group_of(root);
     g->ranks_built = false, g->initialised = false, g->have_op = false, g->op.clear(), g->fq.clear(), g->fq_cols = 0, g->have_g = false, g->gdir.clear();

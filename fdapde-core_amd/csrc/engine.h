@@ -66,6 +66,8 @@ int halo_sum(fdapde_ctx* c, double* v, const double* part, int np, bool unpack =
 
 // ---- the bodies behind the C ABI (capi.hip forwards to them; each unit's header comment says what it holds) ----------------------------
 int e_ctx_clone(const fdapde_ctx* src, fdapde_ctx* dst);   // eng_clone.hip
+int clone_state(const fdapde_ctx* src, fdapde_ctx* dst);   // ... its second half: problem data + assembled / solved state onto an identical space
+int g_clone(const fdapde_ctx* src_root, fdapde_ctx** out);   // eng_group.hip
 int e_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs);
 int e_topology_build(fdapde_ctx* c, int64_t* n_facets, int64_t* n_edges);
 int e_topology_get(fdapde_ctx* c, int32_t* neighbors, int32_t* cell_facets, int32_t* facet_nodes, int32_t* facet_cells, uint8_t* facet_boundary, int32_t* edge_nodes, uint8_t* edge_boundary, int32_t* face_edges);

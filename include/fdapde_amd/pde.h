@@ -29,6 +29,7 @@
 #include <array>
 #include <cstdint>
 #include <functional>
+#include <initializer_list>
 #include <algorithm>
 #include <memory>
 #include <optional>
@@ -268,6 +269,15 @@ template <typename Tag = FEM_HIP> DifferentialExpr reaction(const DMatrix<double
 template <typename Tag = FEM_HIP> DifferentialExpr advection(const DMatrix<double>& b_q) { return detail::leaf(FDAPDE_ADVECTION, nullptr, 0, &b_q); }
 template <typename Tag = FEM_HIP> DifferentialExpr diffusion(const DMatrix<double>& K_q) { return detail::leaf(FDAPDE_DIFFUSION, nullptr, 0, &K_q); }
 
+// Where a PDE computes: one HIP device (an int converts) or several -- PDE(domain, op, forcing, {0, 1, 2, 3}) shards the mesh over them behind
+// the same interface (the reference's user holds one object in one thread, pde.h:58-105; include/fdapde_hip.h fdapde_ctx_create_multi)
+struct device_list {
+    std::vector<int> ids;
+    device_list(int device) : ids {device} { }
+    device_list(std::initializer_list<int> devices) : ids(devices) { }
+    device_list(std::vector<int> devices) : ids(std::move(devices)) { }
+};
+
 // ---- PDE ---------------------------------------------------------------------------------------------------------------
 // what PDE__::eval_basis returns (pde/pde.h:148)
 struct EvalReturnType {
@@ -287,22 +297,22 @@ template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_H
                   "forcing is DMatrix<double> (values at quadrature nodes) or ScalarField<N> (pde.h:49-51)");
     static_assert(R == 1 || R == 2, "LagrangianBasis::enumerate_dofs requires Order <= 2");
 
-    explicit PDE(const D& domain, int device = 0) : domain_(domain) { open(device); }
-    PDE(const D& domain, OperatorType diff_op, int device = 0) : domain_(domain), diff_op_(std::move(diff_op)) { open(device); }
-    PDE(const D& domain, OperatorType diff_op, const ForcingType& forcing, int device = 0) :
+    explicit PDE(const D& domain, device_list device = 0) : domain_(domain) { open(device); }
+    PDE(const D& domain, OperatorType diff_op, device_list device = 0) : domain_(domain), diff_op_(std::move(diff_op)) { open(device); }
+    PDE(const D& domain, OperatorType diff_op, const ForcingType& forcing, device_list device = 0) :
         domain_(domain), diff_op_(std::move(diff_op)), forcing_data_(forcing) {
         open(device);
     }
     // space-time constructors (pde.h:66-72): times = the time grid [t_0 ... t_{m-1}], uniform step
-    PDE(const D& domain, const DVector<double>& t, int device = 0) : domain_(domain) {
+    PDE(const D& domain, const DVector<double>& t, device_list device = 0) : domain_(domain) {
         time_domain_ = t;
         open(device);
     }
-    PDE(const D& domain, const DVector<double>& t, OperatorType diff_op, int device = 0) : domain_(domain), diff_op_(std::move(diff_op)) {
+    PDE(const D& domain, const DVector<double>& t, OperatorType diff_op, device_list device = 0) : domain_(domain), diff_op_(std::move(diff_op)) {
         time_domain_ = t;
         open(device);
     }
-    PDE(const D& domain, const DVector<double>& t, OperatorType diff_op, const ForcingType& forcing, int device = 0) :
+    PDE(const D& domain, const DVector<double>& t, OperatorType diff_op, const ForcingType& forcing, device_list device = 0) :
         domain_(domain), diff_op_(std::move(diff_op)), forcing_data_(forcing) {
         time_domain_ = t;
         open(device);
@@ -522,8 +532,8 @@ template <typename D, typename F, int R> class PDE<D, DifferentialExpr, F, FEM_H
         const std::string msg = ctx_ ? fdapde_last_error(ctx_.get()) : "";
         throw std::runtime_error(msg.empty() ? fdapde_status_string(rc) : msg);
     }
-    void open(int device) {
-        ctx_ = fdapde::hip::context_handle(device);
+    void open(const device_list& device) {
+        ctx_ = fdapde::hip::context_handle(device.ids);   // one id: a single-device context; several: the mesh sharded over them (fdapde_ctx_create_multi)
         fdapde_ctx* const ctx = ctx_.get();
         // hand the mesh over in the ABI's layouts (nodes column-major, cells row-major, boundary bytes)
         const int64_t nn = domain_.n_nodes(), nc = domain_.n_cells();

@@ -139,7 +139,8 @@ int fdapde_ctx_clone(const fdapde_ctx *src, fdapde_ctx **out);
  * iteration as one persistent launch per device, launches exchanging through peer-mapped boards) where the library takes the system, the
  * element-partitioned neighbour exchange otherwise (the context changes form by itself).  A device may be named several times (its CUs are then
  * shared out: how the tests run 2 - 4 "devices" on one GPU).  devices[0] also keeps the whole mesh and function space for the index getters.
- * Not available on such a context: fdapde_ctx_clone, fdapde_comm_*, fdapde_halo_setup*, fdapde_rowdist_setup, fdapde_partition_build,
+ * fdapde_ctx_clone gives another multi-device context on the same devices (the split is deterministic; the assembled and solved state travels
+ * device to device, rank by rank).  Not available on such a context: fdapde_comm_*, fdapde_halo_setup*, fdapde_rowdist_setup, fdapde_partition_build,
  * fdapde_bench_spmv, fdapde_solver_layout* (FDAPDE_EUNSUPPORTED). */
 int fdapde_ctx_create_multi(const int32_t *devices, int32_t n_devices, fdapde_ctx **ctx);
 /* devices of a context (1 and its own device for a single-device one), the form its ranks are in (0 row-distributed, 1 element partition,

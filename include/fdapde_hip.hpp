@@ -18,15 +18,45 @@
 #ifndef FDAPDE_HIP_HPP
 #define FDAPDE_HIP_HPP
 
+#include <cstdlib>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <vector>
 #include <utility>
 
 #include "fdapde_hip.h"
 
 namespace fdapde {
 namespace hip {
+
+// The devices a solver plugged into the reference's selector computes on.  The reference constructs its solver as SolverType(domain)
+// (fdaPDE/pde/pde.h:58): there is no argument through which a caller could name devices, so the binding takes them from here -- set once per process
+// (set_default_devices({0, 1, 2, 3}): the mesh of every PDE made afterwards is sharded over these GPUs behind the unchanged PDE<> interface) or from
+// the environment (FDAPDE_HIP_DEVICES=0,1,2,3); default: device 0.
+inline std::vector<int>& default_devices() {
+    static std::vector<int> devices = [] {
+        std::vector<int> d;
+        if (const char* e = std::getenv("FDAPDE_HIP_DEVICES")) {
+            int v = 0;
+            bool have = false;
+            for (const char* p = e;; ++p) {
+                if (*p >= '0' && *p <= '9') v = 10 * v + (*p - '0'), have = true;
+                else {
+                    if (have) d.push_back(v);
+                    v = 0, have = false;
+                    if (!*p) break;
+                }
+            }
+        }
+        if (d.empty()) d.push_back(0);
+        return d;
+    }();
+    return devices;
+}
+inline void set_default_devices(std::vector<int> devices) {
+    if (!devices.empty()) default_devices() = std::move(devices);
+}
 
 class context_handle {
    public:
@@ -35,6 +65,14 @@ class context_handle {
     explicit context_handle(int device) : s_(std::make_shared<state>()) {
         const int rc = fdapde_ctx_create(device, &s_->ctx);
         if (rc != FDAPDE_OK) throw std::runtime_error(std::string("fdapde_ctx_create: ") + fdapde_status_string(rc));
+        s_->owners = 1;
+    }
+    // ONE context over several devices (fdapde_ctx_create_multi): used exactly like a single-device one; a copy that diverges is cloned onto the same
+    // devices
+    explicit context_handle(const std::vector<int>& devices) : s_(std::make_shared<state>()) {
+        std::vector<int32_t> d(devices.begin(), devices.end());
+        const int rc = d.size() == 1 ? fdapde_ctx_create(d[0], &s_->ctx) : fdapde_ctx_create_multi(d.data(), (int32_t)d.size(), &s_->ctx);
+        if (rc != FDAPDE_OK) throw std::runtime_error(std::string("fdapde_ctx_create_multi: ") + fdapde_status_string(rc));
         s_->owners = 1;
     }
     context_handle(const context_handle& other) : s_(other.s_), counted_(other.counted_) {

@@ -138,7 +138,8 @@ struct FEMHipSolverBase : public FEMSolverBase<D, E, F, Ts...> {   // keeps basi
     fdapde::hip::context_handle ctx_;   // shared between copies of the solver until one of them changes it (copy-on-write)
 
     FEMHipSolverBase() = default;                                             // (FEMSolverBase is default constructible too, fem_solver_base.h:48)
-    FEMHipSolverBase(const D& domain) : Base(domain), ctx_(/*device*/ 0) {    // throws without a HIP device: there is no CPU fallback
+    FEMHipSolverBase(const D& domain) : Base(domain), ctx_(fdapde::hip::default_devices()) {   // one device, or the mesh sharded over several
+        // (fdapde::hip::set_default_devices / FDAPDE_HIP_DEVICES: pde.h:58 hands the solver nothing but the domain); throws without a HIP device: no CPU fallback
         DMatrix<int, Eigen::RowMajor> cells = domain.cells();                 // row-major int32 0-based (triangulation.h:64, 120)
         std::vector<uint8_t> bnd(domain.n_nodes());
         for (int i = 0; i < domain.n_nodes(); ++i) bnd[i] = domain.is_node_on_boundary(i);   // triangulation.h:62

@@ -139,6 +139,116 @@ TEST(fem_pde_test, advection_diffusion_isotropic_order2) {
     EXPECT_TRUE(pde_.success());
     EXPECT_TRUE(l2_error(pde_, [&](std::array<double, 3> x) { return ad.solution(x); }) < DOUBLE_TOLERANCE);
 }
+
+// ---- the mesh sharded over several devices BEHIND the same interface (include/fdapde_hip.h fdapde_ctx_create_multi): the reference's cases again
+//      with a device list -- "devices" all GPU 0 here, its CUs shared out --, against the analytic solutions at the reference's gates and against
+//      the one-device solve (<= 1e-9)
+template <typename P1, typename P2> static double rel_diff(const P1& a, const P2& b) {
+    double num = 0, den = 0;
+    for (int64_t i = 0; i < a.solution().rows(); ++i) {
+        const double d = a.solution()(i) - b.solution()(i);
+        num += d * d, den += b.solution()(i) * b.solution()(i);
+    }
+    return std::sqrt(num / den);
+}
+TEST(sharded_test, laplacian_order1) {
+    auto solution_expr = [](std::array<double, 3> x) -> double { return x[0] + x[1]; };
+    FixtureMesh<2, 2> unit_square("unit_square");
+    auto L = -laplacian<FEM_HIP>();
+    using PDE_t = PDE<Triangulation<2, 2>, decltype(L), DMatrix<double>, FEM_HIP, fem_order<1>>;
+    PDE_t one(unit_square.mesh, L);
+    one.set_dirichlet_bc(eval_at_dofs(one, solution_expr));
+    one.set_forcing(DMatrix<double>::Zero(one.quadrature_nodes().rows(), 1));
+    one.solver_options().rtol = 1e-12;
+    one.init();
+    one.solve();
+    for (device_list devices : {device_list {0, 0}, device_list {0, 0, 0, 0}}) {
+        PDE_t pde_(unit_square.mesh, L, devices);
+        pde_.set_dirichlet_bc(eval_at_dofs(pde_, solution_expr));
+        pde_.set_forcing(DMatrix<double>::Zero(pde_.quadrature_nodes().rows(), 1));
+        pde_.solver_options().rtol = 1e-12;
+        pde_.init();
+        pde_.solve();
+        EXPECT_TRUE(pde_.success());
+        EXPECT_TRUE(pde_.n_dofs() == 3600);
+        EXPECT_TRUE(l2_error(pde_, solution_expr) < DOUBLE_TOLERANCE);
+        EXPECT_TRUE(rel_diff(pde_, one) < 1e-9);
+        int32_t n_dev = 0;
+        fdapde_ctx_devices(pde_.context(), &n_dev, nullptr, nullptr, nullptr, nullptr);
+        EXPECT_TRUE(n_dev == (int32_t)devices.ids.size());
+        double worst = 0;   // stiff() in the whole mesh's numbering: the one-device matrix to the last places
+        for (size_t k = 0; k < one.stiff().values.size(); ++k) worst = std::fmax(worst, std::fabs(one.stiff().values[k] - pde_.stiff().values[k]));
+        EXPECT_TRUE(worst < 1e-13);
+    }
+}
+TEST(sharded_test, laplacian_order2_callable_force) {
+    auto solution_expr = [](std::array<double, 3> x) -> double { return 1. - x[0] * x[0] - x[1] * x[1]; };
+    ScalarField<2> forcing([](const std::array<double, 2>&) -> double { return 4.0; });
+    FixtureMesh<2, 2> unit_square("unit_square");
+    auto L = -laplacian<FEM_HIP>();
+    PDE<Triangulation<2, 2>, decltype(L), ScalarField<2>, FEM_HIP, fem_order<2>> pde_(unit_square.mesh, L, forcing, device_list {0, 0});
+    pde_.set_dirichlet_bc(eval_at_dofs(pde_, solution_expr));
+    pde_.init();
+    pde_.solve();
+    EXPECT_TRUE(pde_.success());
+    EXPECT_TRUE(pde_.n_dofs() == 14161);
+    EXPECT_TRUE(l2_error(pde_, solution_expr) < DOUBLE_TOLERANCE);
+}
+TEST(sharded_test, advection_diffusion) {
+    AdvDiff ad;
+    std::array<double, 2> beta_ {-ad.alpha_, 0.};
+    auto L = -laplacian<FEM_HIP>() + advection<FEM_HIP>(beta_);
+    FixtureMesh<2, 2> unit_square("unit_square");
+    for (int order : {1, 2}) {
+        auto run = [&](auto& pde_) {
+            pde_.set_dirichlet_bc(DMatrix<double>::Zero(pde_.n_dofs(), 1));
+            DMatrix<double> quadrature_nodes = pde_.quadrature_nodes();
+            DMatrix<double> f(quadrature_nodes.rows(), 1);
+            for (int64_t i = 0; i < quadrature_nodes.rows(); ++i) f(i) = ad.forcing(quadrature_nodes(i, 1));
+            pde_.set_forcing(f);
+            pde_.init();
+            pde_.solve();
+            EXPECT_TRUE(pde_.success());
+            EXPECT_TRUE(pde_.info().method_used == FDAPDE_SOLVER_BICGSTAB);
+            EXPECT_TRUE(l2_error(pde_, [&](std::array<double, 3> x) { return ad.solution(x); }) < (order == 1 ? 1e-5 : DOUBLE_TOLERANCE));
+        };
+        if (order == 1) {
+            PDE<Triangulation<2, 2>, decltype(L), DMatrix<double>, FEM_HIP, fem_order<1>> pde_(unit_square.mesh, L, std::vector<int> {0, 0, 0});
+            run(pde_);
+        } else {
+            PDE<Triangulation<2, 2>, decltype(L), DMatrix<double>, FEM_HIP, fem_order<2>> pde_(unit_square.mesh, L, std::vector<int> {0, 0});
+            run(pde_);
+        }
+    }
+}
+// the type-erased handle over a sharded PDE: make_pde copies the PDE, the copies share the multi-device context until one of them computes something
+// different -- then it leaves with a clone on the same devices (fdapde_ctx_clone of a multi-device context)
+TEST(sharded_test, make_pde_copy_and_diverge) {
+    auto solution_expr = [](std::array<double, 3> x) -> double { return x[0] + x[1]; };
+    FixtureMesh<2, 2> mesh("unit_square_32");
+    auto L = -laplacian<FEM_HIP>();
+    PDE<Triangulation<2, 2>, decltype(L), DMatrix<double>, FEM_HIP, fem_order<1>> typed(mesh.mesh, L, device_list {0, 0});
+    typed.set_dirichlet_bc(eval_at_dofs(typed, solution_expr));
+    typed.set_forcing(DMatrix<double>::Zero(typed.quadrature_nodes().rows(), 1));
+    typed.init();
+    typed.solve();
+    EXPECT_TRUE(typed.success());
+    auto copy = typed;   // shares the context
+    copy.set_dirichlet_bc(DMatrix<double>::Zero(copy.n_dofs(), 1));
+    copy.solve();        // ... and leaves with a clone here (no second init: the clone carries stiff_ / force_)
+    EXPECT_TRUE(copy.success());
+    double worst_copy = 0, worst_typed = 0;
+    for (int64_t i = 0; i < typed.solution().rows(); ++i) {
+        worst_copy = std::fmax(worst_copy, std::fabs(copy.solution()(i)));
+        worst_typed = std::fmax(worst_typed, std::fabs(typed.solution()(i) - solution_expr(typed.dof_coords().row3(i))));
+    }
+    EXPECT_TRUE(worst_copy < 1e-12);    // zero data, zero forcing
+    EXPECT_TRUE(worst_typed < 1e-6);    // the original kept its answer
+    int32_t n_dev = 0;
+    fdapde_ctx_devices(copy.context(), &n_dev, nullptr, nullptr, nullptr, nullptr);
+    EXPECT_TRUE(n_dev == 2 && copy.context() != typed.context());
+}
+
 // fem_operators_test.cpp:41-100: golden P2 stiffness of c_shaped cell 175.  The facade exposes the assembled matrix, not
 // element matrices; entries of pairs of DOFs that only cell 175 contains equal the local integrals (the edge-midpoint
 // pairs on an edge-shared pair are sums over two cells), so compare those through stiff().
@@ -707,6 +817,10 @@ int main(int argc, char** argv) {
     RUN(fem_pde_test, advection_diffusion_isotropic_order1);
     RUN(fem_pde_test, advection_diffusion_isotropic_order2);
     RUN(fem_operators_test, laplacian_order_2_through_stiff);
+    RUN(sharded_test, laplacian_order1);
+    RUN(sharded_test, laplacian_order2_callable_force);
+    RUN(sharded_test, advection_diffusion);
+    RUN(sharded_test, make_pde_copy_and_diverge);
     RUN(fem_pde_test, error_behaviour);
     RUN(fem_pde_test, laplacian_3d_order1);
     RUN(integration_test, integrate_over_triangulation);

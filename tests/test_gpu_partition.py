@@ -237,9 +237,31 @@ def test_multi_device_refusals(env):
         grp.solve()
     assert e.value.status == capi.ENOTINIT
     with pytest.raises(capi.FdapdeError) as e:
-        grp.clone()
+        grp.comm_allreduce([1.0])
     assert e.value.status == capi.EUNSUPPORTED
     grp.close()
+
+
+def test_multi_device_context_clones(env):
+    """fdapde_ctx_clone of a multi-device context (what the copy-on-write owner of the host-side bindings calls): every getter returns the source's
+    bits, it solves without another init, and diverges without the source noticing"""
+    capi, meshgen, _ = env
+    nodes, cells, bnd, f, op = _problem(capi, meshgen, "cube", 8, 1, "lap")
+    grp = capi.Context(devices=[0, 0])
+    nd, info, u, raw, _ = _solve(capi, grp, nodes, cells, bnd, 1, f, op)
+    twin = grp.clone()
+    twin.M, twin.N = grp.M, grp.N
+    assert twin.devices()["devices"] == [0, 0] and twin.devices()["form"] == grp.devices()["form"]
+    assert np.array_equal(twin.solution(), u) and np.array_equal(twin.force(), grp.force())
+    assert np.array_equal(twin.matrix_values(capi.MAT_STIFF), grp.matrix_values(capi.MAT_STIFF))
+    assert np.array_equal(twin.matrix_values(capi.MAT_MASS), raw[1])
+    again = twin.solve(rtol=1e-11)   # (no init on the clone)
+    assert again.converged == 1 and np.array_equal(twin.solution(), u)
+    _, _, coords = twin.dofs_get()
+    twin.set_dirichlet(np.zeros(nd))
+    twin.solve(rtol=1e-11)
+    assert np.abs(twin.solution() - u).max() > 1e-3 and np.array_equal(grp.solution(), u)
+    twin.close(), grp.close()
 
 
 def test_group_across_real_devices(env):

@@ -40,6 +40,11 @@ HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s m
 RTOL = 1e-10
 
 
+def weak_nx(n_gpus):
+    """cubes per axis of the weak-scaling mesh: (nx + 1)^3 nodes ~ n_gpus x C3's 120^3"""
+    return int(round((n_gpus * 120.0**3) ** (1.0 / 3.0))) - 1
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -49,6 +54,9 @@ def parse():
     ap.add_argument("--workload", choices=("c3", "c5"), default="c3",
                     help="c3 (default): the headline configuration.  c5 (N > 1 only): BASELINE config C5 -- 3-D P2 advection-diffusion-reaction, "
                          "Jacobi-BiCGStab -- across the ranks in the row-distributed form")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1: strong (default) = the C3 mesh split over the N GPUs; weak = the mesh grown with N so that every GPU keeps about C3's "
+                         "1.73 M rows (nx = round((N 120^3)^(1/3)) - 1: 150 / 189 / 239 cubes per axis at N = 2 / 4 / 8)")
     ap.add_argument("--cpu-nx", type=int, default=119,
                     help="cubes per axis of the CPU-baseline sample (119 = the GPU line's own workload: ~25 s on 1 core + ~6 s on all cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -696,7 +704,7 @@ def run_ranks(args, rank, world, local_rank):
         "warmup": args.warmup,
         "ms_per_step": 1e3 * res["elapsed"] / args.steps,
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -704,7 +712,8 @@ def run_ranks(args, rank, world, local_rank):
             "workload": (f"C5: 3-D P2 advection-diffusion-reaction, b = (1, 0.5, 0.25), c = 1, {args.nx}^3 x 6 = {res['n_cells_total']} tetrahedra, "
                          f"{res['total_dofs']} DOFs; init + Jacobi-BiCGStab rtol 1e-10; 3-D P2 numbering build-defined (parity unpinned)"
                          if args.workload == "c5" else
-                         f"C3: 3-D P1 Laplacian, [0,1]^3, {args.nx}^3 x 6 Kuhn tetrahedra = {res['n_cells_total']} cells, "
+                         ("C3" if args.nx == 119 else f"C3's problem grown to {world} GPUs (weak scaling: ~1.73 M rows per GPU)" if args.scaling == "weak" else "C3's problem") +
+                         f": 3-D P1 Laplacian, [0,1]^3, {args.nx}^3 x 6 Kuhn tetrahedra = {res['n_cells_total']} cells, "
                          f"{res['total_dofs']} DOFs, jitter 0.2h, ids permuted, seed 12345; "
                          "u = sin(pi x) sin(pi y) sin(pi z), homogeneous Dirichlet; init (stiff+force+mass) + Jacobi-PCG rtol 1e-10"),
             "parallelism": res["parallelism"],
@@ -713,7 +722,10 @@ def run_ranks(args, rank, world, local_rank):
             "t_assemble_ms": res["t_asm"],
             "t_solve_ms": res["t_sol"],
             "t_setup_ms_untimed": res["setup_ms"],
+            # whole mesh on this rank's device -> its own sub-mesh, by the library's device-side partitioner (fdapde_partition_build), slowest rank; every
+            # rank generates the mesh itself (t_meshgen: numpy, the bench's own generator -- not part of the path)
             "t_partition_s_untimed": res["t_partition"],
+            "t_meshgen_s_untimed": res.get("t_meshgen"),
             "max_abs_error_vs_analytic": res["err"],
             "persistent_launch": int(getattr(info, "persistent", 0)),
             "us_per_iteration": 1e3 * res["t_sol"] / max(int(info.iters), 1),
@@ -730,7 +742,9 @@ def run_ranks(args, rank, world, local_rank):
             # what this record should show on `world` real MI355X (dist.predict_c3): both forms, from single-GPU measurements + an
             # ASSUMED xGMI hop.  On a shared device (ranks_per_device > 1) the prediction does not apply: the ranks split one GPU's CUs
             "predicted_us_per_iteration": ({f: fdist.predict_c3(world, f, iterations=max(int(info.iters), 1)) for f in ("rowdist", "peers")}
-                                           if args.workload == "c3" and args.nx == 119 else None),
+                                           if args.workload == "c3" and args.nx == 119 else
+                                           {f: fdist.predict_weak(world, f, args.nx, iterations=max(int(info.iters), 1)) for f in ("rowdist", "peers")}
+                                           if args.workload == "c3" and args.scaling == "weak" else None),
         },
         "roofline": roofline_of(res["infos"], res["alg_bytes"], res["streamed_bytes"], args.nx, world),
     }
@@ -751,6 +765,8 @@ def main():
     args = parse()
     if args.nx is None:
         args.nx = 87 if args.workload == "c5" else 119
+        if args.scaling == "weak" and args.gpus > 1 and args.workload == "c3":
+            args.nx = weak_nx(args.gpus)
     if args.workload == "c5" and args.gpus == 1:
         raise SystemExit("--workload c5 is the multi-GPU form of C5 (--gpus N > 1); on one GPU C5 is reported as `extra.c5` of the default run")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

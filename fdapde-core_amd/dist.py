@@ -228,6 +228,36 @@ def rank_problems_p1(nodes, cells, boundary, world):
     return out
 
 
+def rank_problem_on_device(capi, device, nodes, cells, boundary, world, rank, form, with_node_owners=False):
+    """this rank's problem from the library's device-side partitioner (fdapde_partition_build: csrc/dev_partition.hip): every rank process uploads the
+    whole mesh to its OWN device, partitions it there and takes its share -- nothing is shipped between the processes.  Same dict as
+    rank_problems_rowdist_p1()[rank] (form "rowdist") / rank_problems_p1()[rank] ("peers", "dense"); -> (dict, seconds spent partitioning)"""
+    import time
+
+    t0 = time.perf_counter()
+    root = capi.Context(device=device)
+    root.mesh_upload(nodes, cells, boundary)
+    root.partition_build(world, capi.PARTITION_ROWDIST if form == "rowdist" else capi.PARTITION_ELEMENTS)
+    lp = root.partition_get(rank)
+    d = dict(nodes=lp["nodes"], cells=lp["cells"], boundary=lp["boundary"], l2g=lp["l2g"], n_nodes_total=np.int64(nodes.shape[0]),
+             n_cells_total=np.int64(cells.shape[0]))
+    if form == "rowdist":
+        d.update(key=lp["l2g"].astype(np.int64), owner=lp["owner"])
+        if with_node_owners:
+            d["node_owner"] = root.partition_whole()[1]
+    else:
+        pr, po, pd, owned = root.partition_peers(rank)
+        _, _, mask = root.partition_whole()
+        multi = (mask & (mask - np.uint64(1))) != 0            # nodes in two or more sub-meshes: the interface, indexed by ascending node id
+        ifkeys = np.nonzero(multi)[0]
+        is_if = multi[lp["l2g"]]
+        local_dof = np.nonzero(is_if)[0].astype(np.int32)
+        d.update(owned=owned, peer_rank=pr, peer_off=po, peer_dof=pd, n_if_global=np.int64(ifkeys.size), local_dof=local_dof,
+                 if_index=np.searchsorted(ifkeys, lp["l2g"][local_dof]).astype(np.int32))
+    root.close()
+    return d, time.perf_counter() - t0
+
+
 class _RcclGroup:
     """barrier / reductions of the rank processes through the library's own RCCL communicator (no second GPU library in the process)"""
 
@@ -296,28 +326,13 @@ def _comm_setup(capi, ctx, rdzv, rank, world, backend, tag=""):
     return _GlooGroup(), "host-staged gloo (plumbing check, ranks may share a device; never used for reported numbers)"
 
 
-def _ship(rdzv, rank, world, name, make):
-    """rank 0 builds every rank's problem (make() -> list of dicts of arrays) and hands them out through the rendezvous directory"""
-    import io
-
-    if rank == 0:
-        probs = make()
-        for r in range(1, world):
-            buf = io.BytesIO()
-            np.savez(buf, **probs[r])
-            rdzv.put(f"{name}.{r}", buf.getvalue())
-        return probs[0]
-    take = getattr(rdzv, "consume", rdzv.get)   # (a blob addressed to one rank is deleted by its reader)
-    return dict(np.load(io.BytesIO(take(f"{name}.{rank}"))))
-
-
 def canary(capi, rdzv, rank, world, device, backend, share):
     """a two-second row-distributed solve on a small mesh: run by bench.py in a job of its OWN rank processes before the real ranks touch
     the GPUs, so that a fabric on which peer-mapped boards do not work (no hipIpc, stale reads over xGMI -> in-kernel timeouts, or a
     fault that takes the process down) costs the bench its fast path, not its result.  Exit code 0 = every rank solved and agreed."""
     from . import meshgen
 
-    lp = _ship(rdzv, rank, world, "canary", lambda: rank_problems_rowdist_p1(*meshgen.unit_cube(24), world))
+    lp, _ = rank_problem_on_device(capi, device, *meshgen.unit_cube(24), world, rank, "rowdist")
     u_exact, f = meshgen.manufactured(3)
     ctx = capi.Context(device=device)
     ctx.mesh_upload(lp["nodes"], lp["cells"], lp["boundary"])
@@ -416,8 +431,8 @@ class _RankFailed(RuntimeError):
 
 
 def _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, form, share, tag):
-    """bench.py's N > 1 leg: the C3 mesh split over `world` GPUs (strong scaling).  Rank 0 generates and partitions the mesh and hands
-    every rank its own problem through the rendezvous directory -- no other rank materialises the whole mesh.
+    """bench.py's N > 1 leg: the C3 mesh split over `world` GPUs (strong scaling).  Every rank generates the mesh, partitions it on its own device
+    with the library's partitioner and takes its share (rank_problem_on_device).
     form "rowdist": the row-distributed solve (fdapde_rowdist_setup: complete rows per rank, the whole CG as one persistent launch per
     rank, launches exchanging through peer-mapped boards); "peers" / "dense": the element-partitioned solve with an RCCL exchange of the
     interface contributions per operator application.  -> dict (rank 0) / None"""
@@ -427,19 +442,20 @@ def _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, form, shar
 
     c5 = getattr(args, "workload", "c3") == "c5"
     order = 2 if c5 else 1
-    t_part = time.perf_counter()
-    if form == "rowdist":
-        lp = _ship(rdzv, rank, world, "problem" + tag, lambda: rank_problems_rowdist_p1(*meshgen.unit_cube(args.nx), world, with_node_owners=c5))
-    else:
-        lp = _ship(rdzv, rank, world, "problem" + tag, lambda: rank_problems_p1(*meshgen.unit_cube(args.nx), world))
-    t_part = time.perf_counter() - t_part
     u_exact, f = meshgen.manufactured(3)
     if c5:
         from . import workloads
 
         u_exact, f = workloads.c5_exact, workloads.c5_forcing
-    ctx, n_loc, local_error = None, 0, None
+    ctx, n_loc, local_error, lp, t_part, t_gen = None, 0, None, None, 0.0, 0.0
     try:   # this rank's own set-up: nothing collective yet
+        # every rank generates the (deterministic) mesh itself and partitions it on its own device with the library (fdapde_partition_build): no rank 0
+        # bottleneck, nothing shipped through the rendezvous directory (rounds 1-5: numpy on rank 0, 16.3 s at C3's size)
+        t_gen = time.perf_counter()
+        whole = meshgen.unit_cube(args.nx)
+        t_gen = time.perf_counter() - t_gen
+        lp, t_part = rank_problem_on_device(capi, device, *whole, world, rank, form, with_node_owners=c5)
+        del whole
         ctx = capi.Context(device=device)
         ctx.mesh_upload(lp["nodes"], lp["cells"], lp["boundary"])
         n_loc = ctx.dofs_build(order)
@@ -553,7 +569,7 @@ def _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, form, shar
     comm = int(red[14]) if int(red[14]) == -int(red[15]) else f"INCONSISTENT: between {-int(red[15])} and {int(red[14])}"
     return dict(elapsed=float(red[0]), err=float(red[1]), t_asm=float(red[2]), t_sol=float(red[3]), setup_ms=float(red[4]), info=info, infos=infos,
                 alg_bytes=float(red[6]), streamed_bytes=float(red[7]), total_dofs=int(round(n_own[0])), n_cells_total=int(lp["n_cells_total"]),
-                parallelism=parallelism, transport=transport, t_partition=float(red[9]), form=form, comm_ranks=comm, phases=phases)
+                parallelism=parallelism, transport=transport, t_partition=float(red[9]), t_meshgen=float(t_gen), form=form, comm_ranks=comm, phases=phases)
 
 
 # ---- what the first record from N real GPUs should show (the acceptance table) ----------------------------------------------------------
@@ -592,3 +608,16 @@ def predict_c3(world, form, interior_rows=1643032, iterations=505, n_dofs=172800
     return {"form": form, "world": world, "rows_per_rank": int(rows), "us_per_iteration": round(us, 1), "ms_per_step": round(step_ms, 2),
             "dof_per_s": round(n_dofs / (step_ms * 1e-3)), "wrong_above_us": round(2.0 * us, 1),
             "basis": "single-GPU iteration at the rank's row count (measured) + gather over all ranks' workgroups + ASSUMED xGMI hop of %.1f us" % XGMI_HOP_US}
+
+
+def predict_weak(world, form, nx, iterations=None):
+    """The weak-scaling leg (bench.py --scaling weak: (nx + 1)^3 ~ world x 120^3 nodes, ~1.73 M rows per GPU): the same model as predict_c3 at a constant
+    row count per rank; Jacobi-PCG iterations grow with the mesh (~ nx: 503 at nx = 119).  A rank of 1.7 M rows + ghost columns is at the edge of what
+    the row-distributed single launch takes (half of a workgroup's slots are kept for rows that import): where the library declines it the record is
+    the RCCL neighbour exchange's -- both predictions are given."""
+    n_dofs = (nx + 1) ** 3
+    interior = (nx - 1) ** 3
+    its = iterations if iterations is not None else int(round(503 * nx / 119.0))
+    p = predict_c3(world, form, interior_rows=interior, iterations=its, n_dofs=n_dofs, init_ms_one_gpu=0.92 * n_dofs / 1728000.0)
+    p["scaling"] = "weak"
+    return p

@@ -98,6 +98,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
         if (c->comm) (void)g_rccl.CommDestroy(c->comm);
         c->mesh_nodes.release(), c->mesh_cells.release(), c->mesh_nbnd.release();
         c->gm_V.release(), c->gm_b.release(), c->gm_s.release(), c->gm_part.release();
+        c->lin_dense.X.release(), c->step_dense.X.release(), c->solve_dense.X.release(), c->dn_b.release(), c->dn_x.release(), c->dn_r.release(), c->dn_cnt.release();
         c->lin_mat.release(), c->stiff_stat.release(), c->ar_dev.release(), c->persist_stats.release(), c->persist_x.release(), c->persist_xs.release(), c->coords_e.release();
         dev_topology_release(&c->topo);
         c->part_cells.release(), c->part_off.release(), c->part_slots.release(), c->wave_slots.release(), c->part_shared.release();
@@ -417,6 +418,8 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
         c->ps[0].tried = c->ps[0].ok = c->ps[1].tried = c->ps[1].ok = false, c->scaled_owner = fdapde_ctx::kScaledNone;
         fdapde_engine::drop_graph(c);
     }
+    else if (k == "dense_rows" && value >= 0 && value <= 8192) c->dense_rows = value, c->lin_dense.ready = false, c->lin_dense.failed = false;
+    else if (k == "dense_after" && value >= 0) c->dense_after = value;
     else if (k == "small_rows" && value >= 0) c->small_rows = value;
     else if (k == "small_front_rows" && value >= 0) c->small_front_rows = value;
     else if (k == "auto_gmres" && (value == 0 || value == 1)) c->auto_gmres = value;

@@ -441,6 +441,22 @@ struct fdapde_ctx {
     DBuf<int32_t> part_cells, part_off, part_slots, wave_slots;
     DBuf<uint8_t> part_shared;
     std::vector<double> persist_host_stats;
+    // the dense inverse of a small system (kernels_dense.h / eng_dense.hip): the factor-once handle's, the parabolic stepper's, the open method's direct stage
+    struct Dense {
+        DBuf<double> X;             // n x n, internal DOF order
+        int64_t n = 0;
+        int use_bnd = 0;            // the Dirichlet rows were replaced by unit rows (fem_solver_base.h:142-155)
+        const double* A = nullptr;  // the matrix values it inverts (device, internal slots): one step of refinement reads them
+        bool ready = false, refine = false, failed = false;
+        double check = 0, build_ms = 0;   // max |I - A X|; what the build cost (host wall clock)
+    } lin_dense, step_dense, solve_dense;
+    int dense_rows = 4096;        // knob: systems of up to that many DOFs may take the dense path (0: never)
+    int dense_after = 8;          // knob: ... once a handle's matrix has been asked for more than that many columns / a stepper for that many steps
+                                  // AND the Krylov time spent (handle) / to be expected (stepper) reaches half of what the inversion costs; 0: at once
+    int64_t lin_cols = 0;         // columns solved against the handle's current matrix
+    double lin_krylov_ms = 0;     // ... and the host time the Krylov columns among them took
+    DBuf<double> dn_b, dn_x, dn_r;
+    DBuf<unsigned int> dn_cnt;
     // multi-device context (fdapde_ctx_create_multi): this context is the ROOT -- whole mesh, whole function space, every index getter -- of a group
     // of rank contexts, one per device (eng_group.hip)
     fdapde_engine::Group* group = nullptr;

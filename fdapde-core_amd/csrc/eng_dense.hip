@@ -1,0 +1,198 @@
+// eng_dense.hip -- the dense inverse of a small FEM system (kernels_dense.h): built once per matrix, applied as ONE matrix-vector product per
+// right-hand side.  Who uses it (one-GPU contexts, systems of up to `dense_rows` DOFs, the method left open):
+//   fdapde_lin_solve        once a handle has been asked for more than `dense_after` columns ("factor once, solve many": fdaPDE/utils/symbols.h:133-160,
+//                           linear_algebra/smw.h:38-59) -- b and x through pinned host memory, the host spinning on a completion word
+//   fdapde_solve_parabolic  K = M / dt + A is fixed over the steps (fem_linear_parabolic_solver.h:41,56-68: one compute, one solve per step): every step
+//                           is one product with M, one with K^-1, nothing returns to the host inside the loop
+//   fdapde_solve            the stage of FDAPDE_SOLVER_AUTO behind BiCGStab and in front of GMRES: a direct solve of the reference's own row-zeroed matrix
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstring>
+
+#include "context.h"
+#include "engine.h"
+#include "kernels_dense.h"
+
+namespace fdapde_engine {
+
+namespace {
+__global__ void k_dense_rhs(int64_t n, const double* f, const double* g, const uint8_t* bnd, int use_bnd, double* rhs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rhs[i] = (use_bnd && bnd[i]) ? g[i] : f[i];
+}
+// rhs[i] = g_ext[i2e[i]] on the Dirichlet DOFs (g handed over in the reference numbering)
+__global__ void k_dense_bnd_ext(int64_t n, const double* g_ext, const int32_t* i2e, const uint8_t* bnd, double* rhs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && bnd[i]) rhs[i] = g_ext[i2e[i]];
+}
+}   // namespace
+
+bool dense_eligible(const fdapde_ctx* c) {
+    return c->has_device && c->dense_rows > 0 && c->hs.n_dofs <= c->dense_rows && c->hs.n_dofs <= kDenseMaxRows && c->comm == nullptr && c->ar_fn == nullptr &&
+           !c->halo_ready && !c->rd.ready;
+}
+
+// What an inversion costs, from the measured shape of k_dense_invert on MI355X (n steps of one grid barrier ~13 us + a read-modify-write sweep of the
+// n x n array at ~3 TB/s): 289 rows 3 ms, 1 089 rows 16 ms, 4 225 rows ~0.4 s.  Callers build an inverse when the Krylov time it replaces is of that
+// order ("rent or buy": the handle after it has spent half of this on Krylov columns, the stepper when its steps will).
+double dense_build_estimate_ms(int64_t n) {
+    const double sweep_us = 16.0 * (double)n * (double)n / 3.0e6;
+    return 1e-3 * (double)n * (13.0 + sweep_us) + 0.3;
+}
+
+// D.X = (the matrix A of the pattern, its Dirichlet rows replaced by unit rows if use_bnd)^-1, internal DOF order.  D.ready, or D.failed where the
+// matrix is singular to working precision / the launch could not run: the caller keeps its Krylov path.
+int dense_build(fdapde_ctx* c, const double* A, int use_bnd, fdapde_ctx::Dense& D) {
+    const int64_t n = c->hs.n_dofs;
+    hipStream_t st = c->stream;
+    D.ready = false, D.failed = true, D.n = n, D.use_bnd = use_bnd, D.A = A;
+    const auto t0 = std::chrono::steady_clock::now();
+    DBuf<double> S;
+    DBuf<int32_t> perm, status;
+    DBuf<unsigned long long> cand, worst;
+    const int G = (int)std::max<int64_t>(1, std::min<int64_t>(c->n_cu > 0 ? c->n_cu : 64, (n + 7) / 8));
+    const int64_t ld = (n + 15) & ~int64_t(15);
+    HIPCHK(c, S.alloc((size_t)n * (size_t)ld));
+    HIPCHK(c, D.X.alloc((size_t)n * n));
+    HIPCHK(c, perm.alloc((size_t)n));
+    HIPCHK(c, cand.alloc(2 * (size_t)G));
+    HIPCHK(c, status.alloc(4));
+    HIPCHK(c, worst.alloc(2));
+    HIPCHK(c, hipMemsetAsync(cand.p, 0, 2 * (size_t)G * sizeof(unsigned long long), st));
+    HIPCHK(c, hipMemsetAsync(status.p, 0, 4 * sizeof(int32_t), st));
+    HIPCHK(c, hipMemsetAsync(worst.p, 0, 2 * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_dense_fill, dim3((unsigned)n), dim3(256), 0, st, n, ld, c->rowptr.p, c->colidx.p, A, c->bnd.p, use_bnd, S.p);
+    DenseInvArgs a{};
+    a.n = (int32_t)n, a.G = G, a.ld = (int32_t)ld, a.S = S.p, a.perm = perm.p, a.cand = cand.p, a.status = status.p;
+    a.timeout_ticks = 200000000ll;   // 2 s at 100 MHz: a workgroup that is not resident (another process's kernels on the device) ends the attempt
+    const size_t lds = sizeof(double) * (size_t)n;
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_invert), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_dense_invert, dim3((unsigned)G), dim3(kDenseT), lds, st, a);
+    hipLaunchKernelGGL(k_dense_unpermute, dim3((unsigned)n), dim3(256), 0, st, n, ld, S.p, perm.p, D.X.p);
+    hipLaunchKernelGGL(k_dense_check, dim3((unsigned)n), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, A, c->bnd.p, use_bnd, D.X.p, worst.p);
+    HIPCHK(c, hipGetLastError());
+    int32_t h_status[4] = {0, 0, 0, 0};
+    unsigned long long h_worst = 0;
+    HIPCHK(c, hipMemcpyAsync(h_status, status.p, sizeof h_status, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(&h_worst, worst.p, sizeof h_worst, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    double chk;
+    std::memcpy(&chk, &h_worst, sizeof chk);
+    D.check = chk;
+    D.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (std::getenv("FDAPDE_DEBUG_SETUP"))
+        std::fprintf(stderr, "dense inverse: %lld rows, %d workgroups, status %d, max |I - A X| = %.3e, %.2f ms\n", (long long)n, G, h_status[0], chk, D.build_ms);
+    if (h_status[0] != 0 || !(chk < 1e-6)) {   // singular / timed out / an inverse too poor for one refinement step to repair
+        D.X.release();
+        return FDAPDE_OK;
+    }
+    D.refine = !(chk < 1e-13);
+    D.ready = true, D.failed = false;
+    return FDAPDE_OK;
+}
+
+static int ensure_dense_work(fdapde_ctx* c, size_t count) {
+    if (c->dn_b.n < count) HIPCHK(c, c->dn_b.alloc(count));
+    if (c->dn_x.n < count) HIPCHK(c, c->dn_x.alloc(count));
+    if (c->dn_r.n < count) HIPCHK(c, c->dn_r.alloc(count));
+    if (c->dn_cnt.n < 4) {
+        HIPCHK(c, c->dn_cnt.alloc(4));
+        HIPCHK(c, hipMemsetAsync(c->dn_cnt.p, 0, 4 * sizeof(unsigned int), c->stream));
+    }
+    return FDAPDE_OK;
+}
+
+static void launch_gemv(fdapde_ctx* c, const fdapde_ctx::Dense& D, int nc, const double* v, double* y, int accumulate) {
+    const int64_t n = D.n;
+    const dim3 grid((unsigned)((n + 3) / 4)), block(256);
+    if (nc == 1) hipLaunchKernelGGL(k_dense_gemv<1>, grid, block, 0, c->stream, n, nc, D.X.p, v, y, accumulate);
+    else if (nc <= 2) hipLaunchKernelGGL(k_dense_gemv<2>, grid, block, 0, c->stream, n, nc, D.X.p, v, y, accumulate);
+    else hipLaunchKernelGGL(k_dense_gemv<4>, grid, block, 0, c->stream, n, nc, D.X.p, v, y, accumulate);
+}
+
+// x = X b for nc columns, device to device, internal order (x must not alias b); one step of iterative refinement where the inverse asked for it
+int dense_apply(fdapde_ctx* c, fdapde_ctx::Dense& D, int nc, const double* b, double* x) {
+    const int64_t n = D.n;
+    launch_gemv(c, D, nc, b, x, 0);
+    if (D.refine) {
+        if (int rc = ensure_dense_work(c, (size_t)n * nc)) return rc;
+        hipLaunchKernelGGL(k_dense_residual, dim3(g1(n * nc)), dim3(256), 0, c->stream, n, nc, c->rowptr.p, c->colidx.p, D.A, c->bnd.p, D.use_bnd, b, x, c->dn_r.p);
+        launch_gemv(c, D, nc, c->dn_r.p, x, 1);
+    }
+    HIPCHK(c, hipGetLastError());
+    return FDAPDE_OK;
+}
+
+// nc right-hand sides from host memory (reference numbering, column-major n x nc) -> solutions in host memory: staged through the context's pinned
+// block, the device reads and writes it itself, the host spins on the completion word (then falls back to waiting for the stream)
+int dense_solve_host(fdapde_ctx* c, fdapde_ctx::Dense& D, const double* b_host, int nc, double* x_host) {
+    const size_t n = (size_t)D.n, cnt = n * (size_t)nc;
+    hipStream_t st = c->stream;
+    if (c->h_io_cap < 2 * cnt + 8) {
+        if (c->h_io) {
+            HIPCHK(c, hipStreamSynchronize(st));
+            (void)hipHostFree(c->h_io);
+        }
+        c->h_io = nullptr, c->h_io_cap = 0;
+        HIPCHK(c, hipHostMalloc(reinterpret_cast<void**>(&c->h_io), sizeof(double) * (2 * cnt + 8)));
+        c->h_io_cap = 2 * cnt + 8;
+    }
+    if (int rc = ensure_dense_work(c, cnt)) return rc;
+    double* hb = c->h_io;
+    double* hx = c->h_io + cnt;
+    volatile long long* done = reinterpret_cast<volatile long long*>(c->h_io + 2 * cnt);
+    std::memcpy(hb, b_host, sizeof(double) * cnt);
+    *done = 0;
+    std::atomic_thread_fence(std::memory_order_release);
+    // stage, product(s), hand-over: three short launches behind each other.  (Measured and dropped: the whole solve of a 289-row system as ONE
+    // one-workgroup launch -- 35 us against 23: sixteen wavefronts walk eighteen rows each, latency-bound; and the last product handing the result over
+    // itself through a last-arriver copy -- 33 us against 29.5 at 1 089 rows: the serial tail costs more than the launch it saves.)
+    hipLaunchKernelGGL(k_dense_stage, dim3(g1((int64_t)cnt)), dim3(256), 0, st, (int64_t)n, nc, c->dof_i2e.p, hb, c->dn_b.p, c->dn_cnt.p);
+    if (int rc = dense_apply(c, D, nc, c->dn_b.p, c->dn_x.p)) return rc;
+    hipLaunchKernelGGL(k_dense_out, dim3(g1((int64_t)cnt)), dim3(256), 0, st, (int64_t)n, nc, c->dof_e2i.p, c->dn_x.p, hx, const_cast<long long*>(done), c->dn_cnt.p);
+    HIPCHK(c, hipGetLastError());
+    long long seen = 0;
+    if (c->persist_direct_spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        while ((seen = *done) == 0) {
+            if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > (double)c->persist_direct_spin_us) break;
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (seen == 0) HIPCHK(c, hipStreamSynchronize(st));
+    std::memcpy(x_host, hx, sizeof(double) * cnt);
+    return FDAPDE_OK;
+}
+
+// the direct stage of the open method: u = K_z^-1 rhs_z with K_z the reference's row-zeroed matrix (fem_solver_base.h:142-155) and rhs_z = f with g on
+// the Dirichlet rows (internal order, device).  *solved = false: no inverse (singular, too large, not a one-GPU context) -- the caller goes on.
+int dense_direct(fdapde_ctx* c, const double* A, int use_bnd, const double* f_dev, const double* g_dev, bool* solved) {
+    *solved = false;
+    if (!dense_eligible(c)) return FDAPDE_OK;
+    fdapde_ctx::Dense& D = c->solve_dense;
+    if (int rc = dense_build(c, A, use_bnd, D)) return rc;
+    if (!D.ready) return FDAPDE_OK;
+    const int64_t n = D.n;
+    if (int rc = ensure_dense_work(c, (size_t)n)) return rc;
+    hipLaunchKernelGGL(k_dense_rhs, dim3(g1(n)), dim3(256), 0, c->stream, n, f_dev, g_dev, c->bnd.p, use_bnd, c->dn_b.p);
+    if (int rc = dense_apply(c, D, 1, c->dn_b.p, c->u.p)) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    D.X.release(), D.ready = false;   // (one solve: the next fdapde_init may change the matrix)
+    *solved = true;
+    return FDAPDE_OK;
+}
+
+// Dirichlet values handed over in the reference numbering onto the boundary rows of a right-hand side (the parabolic stepper's dense loop)
+void dense_set_bnd_ext(fdapde_ctx* c, const double* g_ext_dev, double* rhs) {
+    const int64_t n = c->hs.n_dofs;
+    hipLaunchKernelGGL(k_dense_bnd_ext, dim3(g1(n)), dim3(256), 0, c->stream, n, g_ext_dev, c->dof_i2e.p, c->bnd.p, rhs);
+}
+
+void preload_dense() {
+    hipFuncAttributes attr;
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_dense_invert));
+    (void)hipGetLastError();
+}
+
+}   // namespace fdapde_engine

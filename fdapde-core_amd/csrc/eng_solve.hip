@@ -899,6 +899,19 @@ int solve_run_restarting(fdapde_ctx* c, const SolveState& ss, const double* A, c
     // The last stage where the caller left the method open (FDAPDE_SOLVER_AUTO): BiCGStab gave up -- restarts exhausted, stalled until maxit, or an
     // iterate that stopped being finite -- on a system the reference's LU would have solved (fem_linear_elliptic_solver.h:38-47; typically an
     // advection-dominated operator): restarted GMRES(m) on the same scaled system, from BiCGStab's iterate if that was any closer than zero.
+    // ... but first, for a system small enough to invert (kernels_dense.h): a DIRECT solve of the reference's own row-zeroed matrix -- what its
+    // SparseLU does, in milliseconds where restarted GMRES needs 10^4 - 10^5 iterations (cell Peclet numbers of 10^3 on a few thousand DOFs)
+    if (gmres_budget >= 0 && rc == FDAPDE_ENOCONV && c->info.method_used == FDAPDE_SOLVER_BICGSTAB && !ss.dist && !ss.rowdist && dense_eligible(c)) {
+        bool solved = false;
+        if (int rc2 = dense_direct(c, A, ss.use_bnd, f_dev, g_dev, &solved)) return rc2;
+        if (solved) {
+            c->info.method_used = FDAPDE_SOLVER_DENSE, c->info.converged = 1, c->info.relres = c->solve_dense.check, c->info.persistent = 0;
+            c->h_ctl[0] = 1, c->h_ctl[2] = 0;
+            c->err.clear();
+            if (c->ev1_at_end) HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+            return FDAPDE_OK;
+        }
+    }
     const int gm_maxit = gmres_budget > 0 ? gmres_budget : maxit - total;
     if (gmres_budget >= 0 && gm_maxit > 0 && c->auto_gmres && rc == FDAPDE_ENOCONV && c->info.method_used == FDAPDE_SOLVER_BICGSTAB && !ss.dist && !ss.rowdist) {
         const bool warm = std::isfinite(c->info.relres) && c->info.relres < 1.0;
@@ -1110,6 +1123,46 @@ int e_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times,
     HIPCHK(c, hipEventRecord(c->ev0, st));
     hipLaunchKernelGGL(k_matrix_combine, dim3(g1(hs.nnz)), dim3(256), 0, st, hs.nnz, c->vals[FDAPDE_MAT_MASS].p,
                        c->vals[FDAPDE_MAT_STIFF].p, inv_dt, kmat.p);
+    // K is fixed over the steps: the reference factorises it ONCE and back-substitutes per step (fem_linear_parabolic_solver.h:41,56-68).  A small K is
+    // inverted once here (kernels_dense.h) and a step is two products -- M u_i and K^-1 rhs -- with nothing returning to the host inside the loop.
+    // (a warm-started Krylov step of such a system costs ~0.2 ms: worth it when the steps add up to half an inversion)
+    if ((!opt || opt->method == FDAPDE_SOLVER_AUTO) && dense_eligible(c) &&
+        (c->dense_after == 0 || (n_times - 1 > c->dense_after && 0.2 * (n_times - 1) >= 0.5 * dense_build_estimate_ms(n)))) {
+        fdapde_ctx::Dense& D = c->step_dense;
+        D.ready = D.failed = false;
+        if (int rc = dense_build(c, kmat.p, dirichlet ? 1 : 0, D)) return rc;
+        if (D.ready) {
+            DBuf<double> d_dir, d_sol;
+            const size_t cols = (size_t)n_times;
+            HIPCHK(c, d_sol.alloc((size_t)n * cols));
+            if (dirichlet) HIPCHK(c, d_dir.upload(dirichlet, (size_t)n * cols, st));
+            to_internal(initial_condition);
+            HIPCHK(c, hipMemcpyAsync(uprev.p, tmp.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipStreamSynchronize(st));   // (tmp is pageable)
+            for (int32_t i = 0; i + 1 < n_times; ++i) {
+                launch_spmv(c, c->vals[FDAPDE_MAT_MASS].p, uprev.p, c->s.p, nullptr, nullptr, nullptr);   // M u_i
+                hipLaunchKernelGGL(k_parabolic_rhs, dim3(g1(n)), dim3(256), 0, st, n, c->s.p, inv_dt, c->force.p + (size_t)(i + 1) * n, rhs.p);
+                if (dirichlet) dense_set_bnd_ext(c, d_dir.p + (size_t)(i + 1) * n, rhs.p);   // rhs[boundary] = g(., i + 1) (line 66)
+                if (int rc = dense_apply(c, D, 1, rhs.p, c->u.p)) return rc;
+                HIPCHK(c, hipMemcpyAsync(uprev.p, c->u.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+                hipLaunchKernelGGL(k_scatter_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->u.p, d_sol.p + (size_t)(i + 1) * n);
+            }
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipMemcpyAsync(solution + (size_t)n, d_sol.p + (size_t)n, sizeof(double) * (size_t)n * (cols - 1), hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipEventRecord(c->ev1, st));
+            HIPCHK(c, hipEventSynchronize(c->ev1));
+            std::memcpy(solution, initial_condition, sizeof(double) * (size_t)n);   // solution_.col(0) = initial condition (line 46)
+            float ms_d = 0;
+            HIPCHK(c, hipEventElapsedTime(&ms_d, c->ev0, c->ev1));
+            c->info.t_solve_ms = ms_d, c->info.iters = D.refine ? n_times - 1 : 0, c->info.relres = D.check, c->info.converged = 1;
+            c->info.method_used = FDAPDE_SOLVER_DENSE, c->info.persistent = 0, c->info.launch_ms = 0;
+            c->scaled_owner = fdapde_ctx::kScaledNone;
+            D.X.release(), D.ready = false;   // (K belongs to this call)
+            if (info) *info = c->info;
+            kmat.release(), uprev.release(), rhs.release(), gcol.release();
+            return FDAPDE_OK;
+        }
+    }
     SolveState ss;
     c->scaled_owner = fdapde_ctx::kScaledParabolic;
     if (int rc = solve_prepare(c, kmat.p, dirichlet ? 1 : 0, &ss, c->op_symmetric)) return rc;
@@ -1239,6 +1292,7 @@ int e_lin_compute(fdapde_ctx* c, int32_t which, const double* values, int32_t sy
     if (int rc = solve_prepare(c, c->lin_mat.p, 0, &c->lin_state->ss, c->lin_symmetric)) return rc;
     c->scaled_owner = fdapde_ctx::kScaledLin;   // scale / sval now belong to the handle
     c->lin_ready = true, c->lin_sq_ready = false;
+    c->lin_dense.ready = c->lin_dense.failed = false, c->lin_cols = 0, c->lin_krylov_ms = 0;   // (a dense inverse belongs to the matrix it was built from)
     return FDAPDE_OK;
 }
 
@@ -1265,6 +1319,30 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
     int method = opt ? opt->method : FDAPDE_SOLVER_AUTO;
     if (method == FDAPDE_SOLVER_AUTO)
         method = (c->lin_symmetric && c->lin_state->ss.diag_positive) ? FDAPDE_SOLVER_CG_FUSED : FDAPDE_SOLVER_BICGSTAB;
+    // "Factor once" that pays per solve (kernels_dense.h): a small system that has been asked for more than `dense_after` columns gets its dense
+    // inverse -- built once, ~ms -- and every column from then on is ONE matrix-vector product, b and x through pinned memory.  Where the method was
+    // left open; a method named explicitly runs as named.
+    if ((!opt || opt->method == FDAPDE_SOLVER_AUTO) && dense_eligible(c)) {
+        fdapde_ctx::Dense& D = c->lin_dense;
+        if (!D.ready && !D.failed && (c->dense_after == 0 || (c->lin_cols + n_rhs > c->dense_after && c->lin_krylov_ms >= 0.5 * dense_build_estimate_ms(n))))
+            if (int rc = dense_build(c, c->lin_mat.p, 0, D)) return rc;
+        if (D.ready) {
+            const auto t0 = std::chrono::steady_clock::now();
+            if (int rc = dense_solve_host(c, D, b, n_rhs, x)) return rc;
+            c->lin_cols += n_rhs;
+            c->info.iters = D.refine ? 1 : 0, c->info.converged = 1, c->info.relres = D.check, c->info.method_used = FDAPDE_SOLVER_DENSE, c->info.persistent = 0;
+            c->info.launch_ms = 0, c->info.spmv_avg_ms = 0, c->info.spmv_timed = 0;
+            c->info.t_solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (info) *info = c->info;
+            return FDAPDE_OK;
+        }
+    }
+    c->lin_cols += n_rhs;
+    struct KrylovClock {   // host time of this call's Krylov columns, towards the handle's rent-or-buy decision
+        fdapde_ctx* c;
+        std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+        ~KrylovClock() { c->lin_krylov_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+    } krylov_clock{c};
     if (c->scaled_owner != fdapde_ctx::kScaledLin) {   // an elliptic / parabolic solve in between has overwritten scale and the scaled copy
         c->scaled_owner = fdapde_ctx::kScaledNone;      // (whatever init / set_* calls followed it): prepare again (cheap)
         if (int rc = solve_prepare(c, c->lin_mat.p, 0, &c->lin_state->ss, c->lin_symmetric)) return rc;
@@ -1286,6 +1364,7 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
         if (int rc = solve_prepare(c, c->lin_mat.p, 0, &c->lin_state->ss, false)) return rc;
         c->scaled_owner = fdapde_ctx::kScaledLin, c->lin_sq_ready = false;
         const int spent = total;   // the CG iterations before the breakdown count
+        c->lin_cols -= n_rhs;      // (the same columns again: counted once)
         const int rc = e_lin_solve(c, opt, b, n_rhs, x, info);
         c->info.iters += spent;
         if (info) info->iters = c->info.iters;

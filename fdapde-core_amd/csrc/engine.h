@@ -137,6 +137,16 @@ int g_tune(fdapde_ctx* root, const char* key, int32_t value);
 int g_synchronize(fdapde_ctx* root);
 int g_layout_kind(fdapde_ctx* root, int32_t with_dirichlet, int32_t* kind, int32_t* symmetric_storage, int32_t* workgroups, int32_t* rows_per_thread);
 
+// ---- dense inverse of small systems (eng_dense.hip)
+bool dense_eligible(const fdapde_ctx* c);
+double dense_build_estimate_ms(int64_t n);
+int dense_build(fdapde_ctx* c, const double* A, int use_bnd, fdapde_ctx::Dense& D);
+int dense_apply(fdapde_ctx* c, fdapde_ctx::Dense& D, int nc, const double* b, double* x);
+int dense_solve_host(fdapde_ctx* c, fdapde_ctx::Dense& D, const double* b_host, int nc, double* x_host);
+int dense_direct(fdapde_ctx* c, const double* A, int use_bnd, const double* f_dev, const double* g_dev, bool* solved);
+void dense_set_bnd_ext(fdapde_ctx* c, const double* g_ext_dev, double* rhs);
+void preload_dense();
+
 // code objects of the units loaded up front (fdapde_ctx_create)
 void preload_assembly();
 void preload_solve();

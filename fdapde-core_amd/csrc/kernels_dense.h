@@ -1,0 +1,311 @@
+// kernels_dense.h -- "factor once" that pays PER SOLVE on small systems: the dense inverse of an FEM matrix, and its application.
+//
+// The reference's users hold fdapde::SparseLU handles (fdaPDE/utils/symbols.h:133-160), factorise once and then solve column after column --
+// the parabolic loop (fem_linear_parabolic_solver.h:56-68: one compute, a triangular solve per step), SMW (linear_algebra/smw.h:38-59),
+// every downstream model.  At the reference's own sizes (289 .. a few thousand DOFs) a back-substitution costs 10 - 50 us on a CPU; a Krylov
+// run per column costs 150 - 400 us on the GPU whatever the kernel quality (tens of iterations x hand-off latency).  For systems of up to a
+// few thousand rows the device can do better than either: invert once, then ONE dense matrix-vector product per column.
+//
+//   k_dense_fill      the matrix of the sparse pattern (optionally with the Dirichlet rows zeroed and a unit diagonal: the reference's
+//                     set_dirichlet_bc matrix, fem_solver_base.h:142-155) as a dense row-major n x n array
+//   k_dense_invert    in-place Gauss-Jordan with partial pivoting as ONE launch of <= one workgroup per CU: row i lives with workgroup i mod G;
+//                     per elimination step ONE grid barrier (agent-scope release / acquire, cdna_hip_programming.md guideline 16): every
+//                     workgroup copies the pivot row to LDS, updates its rows, and -- in the same sweep -- finds its candidate for the NEXT
+//                     column's pivot.  Rows are never swapped (a permutation is recorded), the pivot row's own scaling is deferred to its
+//                     owner's next visit, so nobody writes a row somebody else may still be reading.
+//   k_dense_unpermute the inverse in natural row / column order from the in-place result and the pivot sequence
+//   k_dense_check     max |I - A X| through the sparse rows of A (decides whether a solve adds one step of iterative refinement)
+//   k_dense_stage / k_dense_gemv / k_dense_residual / k_dense_out   a solve: right-hand sides from pinned host memory into internal order,
+//                     x = X b (one wavefront per row, the columns in tiles of NC), optionally r = b - A x and x += X r, the result back in the
+//                     reference numbering into pinned host memory and a completion word the host spins on
+// HBM / cache-bound streaming of X (n^2 doubles per column tile): no MFMA -- a GEMV has no reuse to feed one.
+#ifndef FDAPDE_KERNELS_DENSE_H
+#define FDAPDE_KERNELS_DENSE_H
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace fdapde_hip {
+
+constexpr int kDenseT = 512;        // threads of an inversion workgroup (8 wavefronts: 8 rows in flight)
+constexpr int kDenseMaxRows = 8192; // pivot row in LDS: 64 KB
+
+typedef __attribute__((address_space(1))) unsigned int dn_u32;
+typedef __attribute__((address_space(1))) unsigned long long dn_u64;
+
+static __global__ void k_dense_fill(int64_t n, int64_t ld, const int32_t* rowptr, const int32_t* colidx, const double* vals, const uint8_t* bnd, int use_bnd, double* D) {
+    const int64_t i = blockIdx.x;
+    double* row = D + i * ld;
+    for (int64_t j = threadIdx.x; j < n; j += blockDim.x) row[j] = 0.0;
+    __syncthreads();
+    if (use_bnd && bnd[i]) {
+        if (threadIdx.x == 0) row[i] = 1.0;
+        return;
+    }
+    for (int32_t k = rowptr[i] + (int32_t)threadIdx.x; k < rowptr[i + 1]; k += (int32_t)blockDim.x) row[colidx[k]] = vals[k];
+}
+
+struct DenseInvArgs {
+    int32_t n, G, ld;
+    double* S;                     // n rows of stride ld (a multiple of 16 doubles: no cache line holds entries of two rows), inverted in place (up to the permutation)
+    int32_t* perm;                 // [n] pivot row of step k
+    unsigned long long* cand;      // [2][G] one tagged granule per workgroup and step parity (zeroed before the launch)
+    int32_t* status;               // [0] 1 = singular (no usable pivot), 2 = a sweep timed out; zeroed before the launch
+    long long timeout_ticks;       // bound of a barrier wait (s_memrealtime ticks, 100 MHz)
+};
+
+// Everything one workgroup writes and another reads in this launch -- the rows, the candidates -- is stored write-through (sc1: relaxed agent-scope
+// atomic stores of 8 bytes) and read past the CU's L1 (sc1 loads); a row is only ever read by its owner (plain loads: same wavefront, same CU as the
+// stores) and, ONCE, as the pivot row of its step by everybody (sc1 loads).  The step's barrier IS the candidate exchange (cdna_hip_programming.md
+// guideline 16, form R2 "the data is the flag"): every workgroup publishes ONE 8-byte granule per step into a slot of its own -- [step + 1 : 18 bits |
+// row : 14 bits | float magnitude of the candidate : 32 bits] -- after all its waves have drained their row stores, and one wavefront per workgroup
+// sweeps the G granules until every tag says "this step".  No counter that G workgroups hammer with atomics and polls (that form: 16 us per step at
+// 137 workgroups), no cache write-back / invalidate.  Slots alternate between two arrays by step parity: a workgroup can be at most one step ahead
+// of the slowest one.  A float magnitude is enough to choose a pivot (any of the near-largest entries will do); every workgroup reads the same
+// granules, so all of them choose the same row.
+__device__ __forceinline__ unsigned long long dense_granule(int step, int row, double mag) {
+    const float f = (float)mag;   // (monotone; a double beyond float's range becomes inf / 0 -- still ordered)
+    return ((unsigned long long)(unsigned)(step + 1) << 46) | ((unsigned long long)(unsigned)(row & 0x3fff) << 32) | (unsigned long long)__float_as_uint(f);
+}
+__device__ __forceinline__ void dense_store(double* p, double v) {
+    __hip_atomic_store((dn_u64*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
+}
+__device__ __forceinline__ double dense_load_shared(const double* p) {   // a value another workgroup wrote in this launch
+    return __longlong_as_double((long long)__hip_atomic_load((const dn_u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));   // sc1: past the L1
+}
+
+// In-place Gauss-Jordan, pivot (p, k) of step k, no row swaps:  f_i = S[i][k] / d,  S[i][j] -= f_i S[p][j] (j != k),  S[i][k] = -f_i  for i != p;
+// S[p][j] /= d (j != k), S[p][k] = 1 / d.  After n steps column k of the storage holds column p_k of (E = the product of the row operations), and
+// A^-1 = P^T E:  A^-1[k][p_j] = S[p_k][j]  (k_dense_unpermute).
+static __global__ __launch_bounds__(kDenseT) void k_dense_invert(DenseInvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char dn_smem[];
+    double* prow = reinterpret_cast<double*>(dn_smem);                         // [n] the pivot row of the step, unscaled
+    constexpr int W = kDenseT / 64;
+    __shared__ unsigned long long red_val[W];
+    __shared__ int red_row[W];
+    __shared__ int piv_s;
+    // the pivot row this workgroup owns whose scaling is still owed: applied when its owner next visits it -- the very next step
+    __shared__ int pend_row_s, pend_k_s;
+    __shared__ double pend_d_s;
+    __shared__ unsigned long long used_bits[(kDenseMaxRows + 63) / 64];   // rows of this workgroup that have been pivots (bit per local row)
+    const int n = a.n, G = a.G, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int my_rows = g < n ? (n - g + G - 1) / G : 0;
+    for (int w = tid; w < (my_rows + 63) / 64; w += kDenseT) used_bits[w] = 0ull;
+    if (tid == 0) pend_row_s = -1, pend_k_s = -1, pend_d_s = 1.0;
+    __syncthreads();
+    auto better = [](double v, int row, double bv, int brow) { return v > bv || (v == bv && row < brow); };
+    // this workgroup's candidate for the pivot of column `col`: the best of its waves, published as the granule of step `col`
+    auto publish = [&](double best, int best_row, int col) {
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(best, o);
+            const int orow = __shfl_xor(best_row, o);
+            if (better(ov, orow, best, best_row)) best = ov, best_row = orow;
+        }
+        if (lane == 0) red_val[wave] = (unsigned long long)__double_as_longlong(best), red_row[wave] = best_row;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's row stores are out before the granule says so
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < W; ++w) {
+                const double wv = __longlong_as_double((long long)red_val[w]);
+                if (better(wv, red_row[w], best, best_row)) best = wv, best_row = red_row[w];
+            }
+            __hip_atomic_store((dn_u64*)(a.cand + (size_t)(col & 1) * G + g), dense_granule(col, best_row == 0x7fffffff ? 0x3fff : best_row, best), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    {   // candidates for column 0
+        double best = -1.0;
+        int best_row = 0x7fffffff;
+        for (int r = tid; r < my_rows; r += kDenseT) {
+            const int i = g + G * r;
+            const double v = fabs(a.S[(int64_t)i * a.ld]);
+            if (better(v, i, best, best_row)) best = v, best_row = i;
+        }
+        publish(best, best_row, 0);
+    }
+    for (int k = 0; k < n; ++k) {
+        // ---- the barrier and the pivot of column k in one sweep: wait until all G granules carry this step's tag, take the best of them
+        if (wave == 0) {
+            const unsigned long long* cv = a.cand + (size_t)(k & 1) * G;
+            const unsigned long long want = (unsigned long long)(unsigned)(k + 1);
+            const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+            float best = -1.0f;
+            int best_row = 0x7fffffff;
+            int ok = 1;
+            for (int q = lane; q < G; q += 64) {
+                unsigned long long x;
+                while (((x = __hip_atomic_load((const dn_u64*)(cv + q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 46) != want) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
+                        ok = 0;
+                        break;
+                    }
+                }
+                if (!ok) break;
+                const int row = (int)((x >> 32) & 0x3fff);
+                const float v = __uint_as_float((unsigned)x);
+                if (row != 0x3fff && (v > best || (v == best && row < best_row))) best = v, best_row = row;
+            }
+            ok = __all(ok);
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(best, o);
+                const int orow = __shfl_xor(best_row, o);
+                if (ov > best || (ov == best && orow < best_row)) best = ov, best_row = orow;
+            }
+            if (lane == 0) {
+                if (!ok) a.status[0] = 2;
+                piv_s = !ok ? -2 : (best_row == 0x7fffffff || !(best > 0.0f) || !isfinite(best)) ? -1 : best_row;
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (no instruction: keeps the compiler from moving loads above the sweep)
+        const int p = piv_s;
+        if (p < 0) {   // no usable pivot: the matrix is singular to working precision (every workgroup takes this exit together); or a sweep timed out
+            if (p == -1 && g == 0 && tid == 0) a.status[0] = 1;
+            return;
+        }
+        for (int j = tid; j < n; j += kDenseT) prow[j] = dense_load_shared(a.S + (int64_t)p * a.ld + j);   // (row p is nobody's to write in this step: its scaling is deferred)
+        const int pend_row = pend_row_s, pend_k = pend_k_s;
+        const double pend_sc = 1.0 / pend_d_s;
+        __syncthreads();
+        const double d = prow[k];
+        const double inv_d = 1.0 / d;
+        // ---- the rows of this workgroup, a wavefront per row; the lane that holds column k + 1 proposes the next pivot
+        double best = -1.0;
+        int best_row = 0x7fffffff;
+        for (int r = wave; r < my_rows; r += W) {
+            const int i = g + G * r;
+            if (i == p) continue;
+            double* row = a.S + (int64_t)i * a.ld;
+            const bool owed = i == pend_row;
+            double sik = row[k];
+            if (owed) sik = sik * pend_sc;   // (k != pend_k: that column was replaced in its own step)
+            const double f = sik * inv_d;
+            const bool was_pivot = (used_bits[r >> 6] >> (r & 63)) & 1ull;
+            for (int j = lane; j < n; j += 64) {
+                double v = row[j];
+                if (owed) v = (j == pend_k ? 1.0 : v) * pend_sc;
+                const double nv = j == k ? -f : v - f * prow[j];
+                dense_store(row + j, nv);
+                if (j == k + 1 && !was_pivot && better(fabs(nv), i, best, best_row)) best = fabs(nv), best_row = i;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const bool mine = (p % G) == g;
+            if (mine) {
+                a.perm[k] = p;
+                const int r = (p - g) / G;
+                used_bits[r >> 6] |= 1ull << (r & 63);
+                pend_row_s = p, pend_k_s = k, pend_d_s = d;
+            } else
+                pend_row_s = -1;
+        }
+        if (k + 1 < n) publish(best, best_row, k + 1);   // (its __syncthreads also orders the update above before the next step's reads)
+        else __syncthreads();
+    }
+    // the last pivot row's scaling is still owed
+    if (pend_row_s >= 0) {
+        double* row = a.S + (int64_t)pend_row_s * a.ld;
+        const double sc = 1.0 / pend_d_s;
+        const int pk = pend_k_s;
+        for (int j = tid; j < n; j += kDenseT) row[j] = (j == pk ? 1.0 : row[j]) * sc;
+    }
+}
+
+// X[k][perm[j]] = S[perm[k]][j]
+static __global__ void k_dense_unpermute(int64_t n, int64_t ld, const double* S, const int32_t* perm, double* X) {
+    const int64_t k = blockIdx.x;
+    const double* src = S + (int64_t)perm[k] * ld;
+    double* dst = X + k * n;
+    for (int64_t j = threadIdx.x; j < n; j += blockDim.x) dst[perm[j]] = src[j];
+}
+
+// out[0] = bits of max |delta_ic - sum_t A[i][t] X[t][c]| (A: the same rows k_dense_fill wrote)
+static __global__ void k_dense_check(int64_t n, const int32_t* rowptr, const int32_t* colidx, const double* vals, const uint8_t* bnd, int use_bnd, const double* X,
+                                     unsigned long long* out) {
+    const int64_t i = blockIdx.x;
+    const bool unit = use_bnd && bnd[i];
+    double worst = 0.0;
+    for (int64_t c = threadIdx.x; c < n; c += blockDim.x) {
+        double s = 0.0;
+        if (unit) s = X[i * n + c];
+        else
+            for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) s += vals[k] * X[(int64_t)colidx[k] * n + c];
+        const double e = fabs((c == i ? 1.0 : 0.0) - s);
+        worst = e > worst || !(e == e) ? (e == e ? e : 1e300) : worst;
+    }
+    for (int o = 32; o > 0; o >>= 1) worst = fmax(worst, __shfl_xor(worst, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(worst));
+}
+
+// right-hand sides handed over in the reference numbering (column-major n x nc, pinned host or device memory) -> internal order
+static __global__ void k_dense_stage(int64_t n, int nc, const int32_t* i2e, const double* b_ext, double* b_int, unsigned int* count) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0 && count) *count = 0u;   // (the arrival counter of the launch that signals the host: ordered by the stream)
+    if (t >= n * nc) return;
+    const int64_t c = t / n, i = t - c * n;
+    b_int[t] = b_ext[c * n + i2e[i]];
+}
+
+// y (+)= X v for nc columns (column-major n x nc), one wavefront per row, the columns in tiles of NC
+template <int NC> static __global__ __launch_bounds__(256) void k_dense_gemv(int64_t n, int nc, const double* X, const double* v, double* y, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const double* row = X + i * n;
+    for (int c0 = 0; c0 < nc; c0 += NC) {
+        double acc[NC];
+#pragma unroll
+        for (int q = 0; q < NC; ++q) acc[q] = 0.0;
+        for (int64_t j = lane; j < n; j += 64) {
+            const double x = row[j];
+#pragma unroll
+            for (int q = 0; q < NC; ++q)
+                if (c0 + q < nc) acc[q] += x * v[(int64_t)(c0 + q) * n + j];
+        }
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+            double s = acc[q];
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0 && c0 + q < nc) y[(int64_t)(c0 + q) * n + i] = accumulate ? y[(int64_t)(c0 + q) * n + i] + s : s;
+        }
+    }
+}
+
+// r = b - A x (the rows of k_dense_fill), nc columns
+static __global__ void k_dense_residual(int64_t n, int nc, const int32_t* rowptr, const int32_t* colidx, const double* vals, const uint8_t* bnd, int use_bnd,
+                                        const double* b, const double* x, double* r) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * nc) return;
+    const int64_t c = t / n, i = t - c * n;
+    double s = 0.0;
+    if (use_bnd && bnd[i]) s = x[t];
+    else
+        for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k) s += vals[k] * x[c * n + colidx[k]];
+    r[t] = b[t] - s;
+}
+
+// the result in the reference numbering into x_ext (pinned host memory of a direct solve, or a device buffer) + the completion word
+static __global__ void k_dense_out(int64_t n, int nc, const int32_t* e2i, const double* x_int, double* x_ext, long long* done, unsigned int* count) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n * nc) {
+        const int64_t c = t / n, e = t - c * n;
+        x_ext[t] = x_int[c * n + e2i[e]];
+    }
+    if (!done) return;
+    // the last workgroup to finish signals the host: its own stores and everybody else's are out (system scope: the word lives in host memory)
+    __threadfence_system();
+    __syncthreads();
+    __shared__ unsigned int last;
+    if (threadIdx.x == 0) last = atomicAdd(count, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence_system();
+        __atomic_store_n(reinterpret_cast<volatile long long*>(done), 1ll, __ATOMIC_RELEASE);
+    }
+}
+
+}   // namespace fdapde_hip
+#endif

@@ -71,7 +71,13 @@ typedef struct {
  * up to rounding (pure Neumann data, right-hand side outside the range) is reported as a failure, not answered with a multiple of the null vector.
  * A method named explicitly is never replaced: its failure is reported (FDAPDE_ENOCONV, success = false). */
 enum { FDAPDE_SOLVER_AUTO = 0, FDAPDE_SOLVER_CG = 1, FDAPDE_SOLVER_BICGSTAB = 2, FDAPDE_SOLVER_CG_SR = 3, FDAPDE_SOLVER_CG_FUSED = 4,
-       FDAPDE_SOLVER_GMRES = 5 /* restarted GMRES(50), Jacobi-scaled; one-GPU contexts */ };
+       FDAPDE_SOLVER_GMRES = 5 /* restarted GMRES(50), Jacobi-scaled; one-GPU contexts */,
+       FDAPDE_SOLVER_DENSE = 6 /* reported in info.method_used only: the system was small enough (knob dense_rows, default 4096 DOFs; one-GPU contexts) for its
+                                  dense inverse -- built ONCE on the device, ~ms, Gauss-Jordan with partial pivoting as one launch -- and the answer is one
+                                  matrix-vector product (plus one step of iterative refinement where max |I - A X| says so).  Taken with the method left
+                                  open by: fdapde_lin_solve once a handle has been asked for more than `dense_after` (8) columns ("factor once, solve many");
+                                  fdapde_solve_parabolic with more than `dense_after` steps (K = M / dt + A is fixed: one inversion, two products per step);
+                                  fdapde_solve as the stage of FDAPDE_SOLVER_AUTO behind BiCGStab and in front of GMRES.  info.relres = max |I - A X|. */ };
 /* ROWS: row-owner sweep (default; no atomics, bitwise reproducible).  The others are element-wise scatter forms kept as measured
  * alternatives and cross-checks: ATOMIC / COLOURED = lane per (cell, row) with a slot search, fp64 atomics / one launch per colour;
  * PARTITIONED = one workgroup per cell partition, colours walked inside the workgroup, atomics only on rows shared between
@@ -369,7 +375,8 @@ int fdapde_partition_peers(fdapde_ctx *ctx, int32_t rank, int32_t *n_peers, int3
  *                 "persist_single_rows" (systems of up to that many interior rows run as one workgroup, without hand-offs),
  *                 "persist_prefetch" (0: the streaming forms do not touch the next operator application's first lines during the dot all-gather),
  *                 "persist_exp_lds" (0: the symmetric streaming form re-reads its export list from global memory every iteration)
- *   solve         "auto_gmres" (0: the open method ends with BiCGStab), "gmres_m" (restart length, default 50),
+ *   solve         "dense_rows" (systems of up to that many DOFs may take the dense inverse; 0: never), "dense_after" (columns / steps before it is built),
+ *                 "auto_gmres" (0: the open method ends with BiCGStab), "gmres_m" (restart length, default 50),
  *                 "small_rows" (systems of up to that many DOFs: no wait for the positive-diagonal flag, outcome through a pinned record; 0: off),
  *                 "small_front_rows" (one-workgroup systems of up to that many DOFs: ONE kernel in front of the single launch -- k_small_front --
  *                 and the epilogue inside the launch; 0: the separate launches), "asm_items_fuse" (0: the P2 mass matrix in a sweep of its own) */

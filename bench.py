@@ -283,8 +283,30 @@ def cpu_columns(c5_nx=24, c2_gpu=None):
                 r = direct(m, 1, fq, lambda nd: np.zeros(nd))
                 best = r if best is None or sum(r[1:4]) < sum(best[1:4]) else best
             nd, ta, tf, ts, _, _ = best
+            # the parabolic loop the way the reference runs it (fem_linear_parabolic_solver.h:41,56-68): one factorisation, a back-substitution per step
+            t_par = None
+            try:
+                dofs_, bnd_, nd_, _ = o.enumerate_dofs(m, 1)
+                A_ = o.assemble_operator(m, 1, dofs_, nd_, -o.laplacian()).to_scipy()
+                M_ = o.assemble_operator(m, 1, dofs_, nd_, o.reaction(1.0)).to_scipy()
+                rhs_ = np.ones(nd_)
+                best_par = None
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    K_ = (M_ * 100.0 + A_).tocsc()
+                    lu_ = spla.splu(K_)
+                    u_ = np.zeros(nd_)
+                    for _s in range(100):
+                        u_ = lu_.solve(M_ @ u_ * 100.0 + rhs_)
+                    t1 = time.perf_counter() - t0
+                    best_par = t1 if best_par is None or t1 < best_par else best_par
+                t_par = 1e3 * best_par
+            except Exception:
+                pass
             c1[name] = {"dofs": int(nd), "init_ms": 1e3 * ta, "solve_ms": 1e3 * (tf + ts), "factorise_ms": 1e3 * tf, "solve_one_column_ms": 1e3 * ts,
-                        "cores": 1, "kind": "port + scipy SuperLU", "note": "oracle assembly (stiff + force + mass) | Dirichlet rows + splu + one solve; best of 5"}
+                        "parabolic_101_points_ms": t_par,
+                        "cores": 1, "kind": "port + scipy SuperLU", "note": "oracle assembly (stiff + force + mass) | Dirichlet rows + splu + one solve; best of 5; "
+                        "parabolic: K = M / dt + A factorised once, 100 steps of (M u / dt + f, back-substitution), best of 3"}
         out["c1"] = c1
     except Exception as e:
         out["c1"] = {"error": f"{type(e).__name__}: {e}"[:200]}
@@ -547,7 +569,7 @@ def run_single(args):
 
         extra = {}
         # (the wide run BEFORE C5: measured right after C5's seconds of full-HBM BiCGStab the same launch took 101 instead of 74 us per iteration)
-        for name, fn in (("c2", workloads.run_c2), ("wide_2p35M", workloads.run_wide), ("c5", workloads.run_c5)):
+        for name, fn in (("c2", workloads.run_c2), ("wide_2p35M", workloads.run_wide), ("large_8p1M", workloads.run_large), ("c5", workloads.run_c5)):
             try:
                 kw = {"keep_arrays": True} if name == "c2" and not args.no_cpu_baseline else {}
                 extra[name] = fn(capi, meshgen, device=device_index, hbm_peak_gbps=HBM_PEAK_GBPS, **kw)
@@ -557,6 +579,10 @@ def run_single(args):
             extra["c1"] = workloads.run_c1(capi, os.path.join(ROOT, "tests", "golden", "mesh"), device=device_index)
         except Exception as e:
             extra["c1"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        try:   # the mesh sharded behind the one-object interface (fdapde_ctx_create_multi): what the split costs, with the devices this box has
+            extra["multi_device_context"] = workloads.run_group(capi, meshgen, nx=args.nx)
+        except Exception as e:
+            extra["multi_device_context"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         out["extra"] = extra
     c2_arrays = out.get("extra", {}).get("c2", {}).pop("_arrays", None) if isinstance(out.get("extra", {}).get("c2"), dict) else None
     parity_ok = True

@@ -149,6 +149,16 @@ int e_comm_allreduce(fdapde_ctx* c, double* host_inout, int32_t n, int32_t op) {
     return FDAPDE_OK;
 }
 
+// one decision for all ranks of a multi-GPU job: how many of them say yes (a single-GPU context: its own answer).  COLLECTIVE.
+int ranks_saying_yes(fdapde_ctx* c, bool mine, int* yes) {
+    *yes = mine ? 1 : 0;
+    if (c->world <= 1 || (!c->comm && !c->ar_fn)) return FDAPDE_OK;
+    double v = mine ? 1.0 : 0.0;
+    if (int rc = e_comm_allreduce(c, &v, 1, 0)) return rc;
+    *yes = (int)(v + 0.5);
+    return FDAPDE_OK;
+}
+
 int e_comm_init_callback(fdapde_ctx* c, int32_t world, int32_t rank, fdapde_allreduce_fn fn, void* user) {
     if (!c || !fn || world < 1 || rank < 0 || rank >= world) return FDAPDE_EINVAL;
     if (int rc = need_device(c)) return rc;

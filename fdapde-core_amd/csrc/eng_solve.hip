@@ -19,6 +19,8 @@
 
 namespace fdapde_engine {
 
+constexpr int64_t kBlockedShortRowsAbove = 3200000;   // short-row systems (P1) of more DOFs than this take the blocked-ELL SpMV on the multi-launch path
+
 // the captured CG chunk bakes pointers and sizes in: drop it whenever a layout, buffer or knob may have changed
 void drop_graph(fdapde_ctx* c) {
     if (c->cg_graph_exec) (void)hipGraphExecDestroy(c->cg_graph_exec);
@@ -383,7 +385,10 @@ int solve_prepare(fdapde_ctx* c, const double* A, int use_bnd, SolveState* ss, b
     bool blocked = false;
     // ... where it pays: long rows (P2).  On 14-entry rows (C3 with the persistent CG switched off) the CSR kernel's finer-grained,
     // software-pipelined workgroups win (45 us against 48-51 us per SpMV), so short-row systems keep the compact CSR pattern.
-    const bool long_rows = (double)c->hs.nnz >= 20.0 * (double)n || c->blocked == 2;
+    // Round 6: ... up to the size where the single launch ends (3.1 M rows on 256 CUs).  Above it every operator application streams from HBM and the
+    // blocked form wins on short rows too -- 3-D P1, 8.1 M DOFs: 238 us against 281 us per SpMV, 0.67 against 0.56 of the HBM peak on the layout's own
+    // bytes (tools/large_ab.py, profiles/r6_large_ab.txt).
+    const bool long_rows = (double)c->hs.nnz >= 20.0 * (double)n || c->blocked == 2 || n > kBlockedShortRowsAbove;
     if (!persist && ss->diag_positive && !ss->dist && c->blocked && long_rows && c->spmv_variant == 2) {
         if (int rc = build_blocked(c, use_bnd ? 1 : 0)) return rc;
         blocked = c->bk[use_bnd ? 1 : 0].ok;
@@ -887,9 +892,12 @@ int solve_run_restarting(fdapde_ctx* c, const SolveState& ss, const double* A, c
     int total = c->info.iters;
     const int64_t n = c->hs.n_dofs;
     const bool may_restart = method == FDAPDE_SOLVER_BICGSTAB || method == FDAPDE_SOLVER_AUTO;   // a method named explicitly is never replaced
-    for (int k = 0; k < kBicgRestarts && may_restart && rc == FDAPDE_ENOCONV && c->h_ctl[2] != 0 && c->info.method_used == FDAPDE_SOLVER_BICGSTAB && !ss.dist &&
-                    !ss.rowdist && total < maxit && std::isfinite(c->info.relres) && c->bicg_restart;
+    // (ranks of a multi-GPU job restart together: breakdown word, iteration count and residual come out of sums all of them hold bit for bit)
+    for (int k = 0; k < kBicgRestarts && may_restart && rc == FDAPDE_ENOCONV && c->h_ctl[2] != 0 && c->info.method_used == FDAPDE_SOLVER_BICGSTAB &&
+                    total < maxit && std::isfinite(c->info.relres) && c->bicg_restart;
          ++k) {
+        if (ss.rowdist)   // the iterate at the columns other ranks own: the warm start reads them
+            if (int rc2 = rowdist_import_ghosts(c, ss.use_bnd ? 1 : 0, c->u.p)) return rc2;
         HIPCHK(c, c->restart_u.alloc((size_t)n));
         HIPCHK(c, hipMemcpyAsync(c->restart_u.p, c->u.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
         rc = solve_run(c, ss, A, f_dev, g_dev, c->restart_u.p, FDAPDE_SOLVER_BICGSTAB, rtol, maxit - total, check_every, 0);
@@ -943,7 +951,7 @@ int e_solver_prepare(fdapde_ctx* c, int32_t with_dirichlet) {
         if (c->ps[v].ok && (c->op_symmetric || (!c->ps[v].meta.sym && c->ps[v].meta.R <= 8))) return FDAPDE_OK;
     }
     if (c->blocked && c->comm == nullptr && c->ar_fn == nullptr &&
-        ((double)c->hs.nnz >= 20.0 * (double)c->hs.n_dofs || c->blocked == 2)) {   // single GPU, long rows: the multi-launch kernels use the blocked-ELL layout
+        ((double)c->hs.nnz >= 20.0 * (double)c->hs.n_dofs || c->blocked == 2 || c->hs.n_dofs > kBlockedShortRowsAbove)) {   // single GPU, long rows: the multi-launch kernels use the blocked-ELL layout
         if (int rc = build_blocked(c, v)) return rc;
         if (c->bk[v].ok) return FDAPDE_OK;
     }
@@ -1050,8 +1058,16 @@ int e_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
                                       maxit, check_every, opt ? opt->time_spmv : 0, gm_budget);
         }
     }
-    if (rc == FDAPDE_ENOCONV && c->h_ctl[2] != 0 && (!opt || opt->method == FDAPDE_SOLVER_AUTO) && is_cg_method(c->info.method_used) &&
-        !ss.dist && !ss.rowdist) {
+    // (the ranks of a multi-GPU job take this turn TOGETHER: the breakdown word comes out of sums every rank holds bit for bit, and the ranks say so to
+    //  each other before any of them re-prepares -- a rank that disagreed would leave the others in the collectives of the second solve)
+    bool cg_broke = rc == FDAPDE_ENOCONV && c->h_ctl[2] != 0 && (!opt || opt->method == FDAPDE_SOLVER_AUTO) && is_cg_method(c->info.method_used);
+    if ((ss.dist || ss.rowdist) && (!opt || opt->method == FDAPDE_SOLVER_AUTO) && (rc == FDAPDE_OK || rc == FDAPDE_ENOCONV)) {
+        int yes = 0;
+        if (int rc2 = ranks_saying_yes(c, cg_broke, &yes)) return rc2;
+        if (yes != 0 && yes != c->world) return fail(c, FDAPDE_ERCCL, "fdapde_solve: the ranks disagree on the outcome of the CG stage");
+        cg_broke = yes == c->world;
+    }
+    if (cg_broke) {
         // CG broke down (p.Ap <= 0): the operator is symmetric but not positive definite -- e.g. 3-D P2 with a large reaction term: the
         // reference's 5-point rule has a negative weight, its mass matrix is indefinite (integrator_tables.h:275-292).  The reference's LU solves
         // such a system all the same (fem_linear_elliptic_solver.h:38-47); so does BiCGStab.  Only where the caller left the method open.
@@ -1183,8 +1199,14 @@ int e_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times,
         c->defer_end_sync = true;   // (the step's outcome is read inside solve_run; what follows it is ordered by the stream)
         const int open_step = !(!opt || opt->method == FDAPDE_SOLVER_AUTO) ? -1 : ((opt && opt->maxit > 0) ? 0 : default_maxit(c, n));
         int rc = solve_run_restarting(c, ss, kmat.p, rhs.p, gcol.p, uprev.p, step_method, rtol, maxit, check_every, 0, open_step);
-        if (rc == FDAPDE_ENOCONV && c->h_ctl[2] != 0 && step_method == FDAPDE_SOLVER_AUTO && is_cg_method(c->info.method_used) && !ss.dist &&
-            !ss.rowdist) {   // M / dt + A symmetric but not positive definite (see fdapde_solve): this step again and every later one with BiCGStab
+        bool cg_broke = rc == FDAPDE_ENOCONV && c->h_ctl[2] != 0 && step_method == FDAPDE_SOLVER_AUTO && is_cg_method(c->info.method_used);
+        if ((ss.dist || ss.rowdist) && step_method == FDAPDE_SOLVER_AUTO && (rc == FDAPDE_OK || rc == FDAPDE_ENOCONV)) {   // (the ranks decide together: see fdapde_solve)
+            int yes = 0;
+            if (int rc2 = ranks_saying_yes(c, cg_broke, &yes)) return rc2;
+            if (yes != 0 && yes != c->world) return fail(c, FDAPDE_ERCCL, "fdapde_solve_parabolic: the ranks disagree on the outcome of the CG stage");
+            cg_broke = yes == c->world;
+        }
+        if (cg_broke) {   // M / dt + A symmetric but not positive definite (see fdapde_solve): this step again and every later one with BiCGStab
             if (int rc2 = solve_prepare(c, kmat.p, dirichlet ? 1 : 0, &ss, false)) return rc2;
             step_method = FDAPDE_SOLVER_BICGSTAB;
             rc = solve_run_restarting(c, ss, kmat.p, rhs.p, gcol.p, uprev.p, step_method, rtol, maxit, check_every, 0, open_step);

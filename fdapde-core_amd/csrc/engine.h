@@ -61,6 +61,7 @@ inline unsigned g1(int64_t n, int per = 256) { return (unsigned)((n + per - 1) /
 // ---- helpers one engine unit offers the others ---------------------------------------------------------------------------------------
 int ensure_sval(fdapde_ctx* c);                                            // eng_solve.hip: the scaled full-pattern copy, if a solve skipped it
 void drop_graph(fdapde_ctx* c);                                            // eng_solve.hip: the captured CG chunk bakes pointers and sizes in
+int ranks_saying_yes(fdapde_ctx* c, bool mine, int* yes);                // eng_dist.hip: how many ranks of the job answer yes (COLLECTIVE)
 int allreduce_sum(fdapde_ctx* c, double* buf, size_t count);               // eng_dist.hip: device buffer summed over the ranks
 int halo_sum(fdapde_ctx* c, double* v, const double* part, int np, bool unpack = true);   // eng_dist.hip: interface entries summed over the sharing ranks
 

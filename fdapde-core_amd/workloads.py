@@ -195,6 +195,75 @@ def run_wide(capi, meshgen, nx=132, steps=2, warmup=1, rtol=1e-10, device=0, hbm
     return out
 
 
+def run_large(capi, meshgen, nx=200, steps=2, warmup=1, time_spmv=24, rtol=1e-10, device=0, hbm_peak_gbps=8000.0):
+    """The regime ABOVE one launch: C3's problem at (nx + 1)^3 = 8.1 M DOFs (nx = 200: 48 M tetrahedra) -- more rows than the single launch holds (3.1 M on
+    256 CUs), so the solve is the multi-launch Jacobi-PCG: k_spmv_blocked / k_spmv_team2 + the fused vector update per iteration, ~1.6 GB of CSR per
+    operator application streaming from HBM.  The only regime where north_star's "HBM-bound CSR SpMV inside CG" is literally what runs; the reference's own
+    solve has no size cap but memory (fem_linear_elliptic_solver.h:38-47)."""
+    t0 = time.perf_counter()
+    nodes, cells, bnd = meshgen.unit_cube(nx)
+    t_gen = time.perf_counter() - t0
+    u_exact, f = meshgen.manufactured(3)
+    ctx = capi.Context(device)
+    t0 = time.perf_counter()
+    ctx.mesh_upload(nodes, cells, bnd)
+    t_up = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    nd = ctx.dofs_build(1)
+    ctx.solver_prepare(True)
+    t_setup = time.perf_counter() - t0
+    n_cells = int(cells.shape[0])
+    del nodes, cells
+    ctx.set_operator(-capi.laplacian())
+    ctx.set_forcing(f(ctx.quadrature_nodes()))
+    ctx.set_dirichlet(np.zeros(nd))
+    wall, infos = _timed_steps(ctx, steps, warmup, time_spmv, rtol)
+    out = _summary(ctx, nd, wall, infos, u_exact, hbm_peak_gbps)
+    info = infos[-1]
+    # the whole iteration against its minimal traffic: one pass over the layout + the vector passes of the fused update (x, r, p read and written, y read)
+    it_us = 1e3 * float(info.t_solve_ms) / max(int(info.iters), 1)
+    vec_bytes = 7.0 * 8.0 * out["interior_rows"]
+    out.update(workload=f"3-D P1 Laplacian, {nx}^3 x 6 = {n_cells} tetrahedra, {nd} DOFs: above the single launch (multi-launch Jacobi-PCG)", cells=n_cells,
+               t_meshgen_s=t_gen, t_mesh_upload_s=t_up, t_setup_s=t_setup,
+               iteration_gbps=(out["streamed_bytes_per_application"] + vec_bytes) / (it_us * 1e-6) / 1e9,
+               iteration_frac=(out["streamed_bytes_per_application"] + vec_bytes) / (it_us * 1e-6) / 1e9 / hbm_peak_gbps,
+               iteration_bytes_note="layout bytes of one operator application + 7 vector passes of 8 n bytes (fused update: x, r, p read + written, y read)")
+    ctx.close()
+    return out
+
+
+def run_group(capi, meshgen, nx=119, n_dev=2, steps=2, warmup=1, rtol=1e-10):
+    """The multi-device context (fdapde_ctx_create_multi) on C3's mesh with what this box has: n_dev "devices" dealt round-robin over the real ones (ONE GPU:
+    all of them GPU 0, its CUs shared out -- a plumbing and set-up-cost record, no scaling figure).  What it shows: the split behind the one-object
+    interface costs tens of milliseconds on the device (dist.py's numpy partitioner: 16.3 s), and the sharded solve is the same Krylov iteration."""
+    n_real = max(int(capi.load().fdapde_device_count()), 1)
+    devices = [r % n_real for r in range(n_dev)]
+    nodes, cells, bnd = meshgen.unit_cube(nx)
+    u_exact, f = meshgen.manufactured(3)
+    ctx = capi.Context(devices=devices)
+    ctx.mesh_upload(nodes, cells, bnd)
+    t0 = time.perf_counter()
+    nd = ctx.dofs_build(1)
+    t_build = time.perf_counter() - t0
+    n_cells = int(cells.shape[0])
+    del nodes, cells
+    ctx.set_operator(-capi.laplacian())
+    ctx.set_forcing(f(ctx.quadrature_nodes()))
+    ctx.set_dirichlet(np.zeros(nd))
+    wall, infos = _timed_steps(ctx, steps, warmup, 0, rtol)
+    info = infos[-1]
+    _, _, coords = ctx.dofs_get()
+    err = float(np.abs(ctx.solution() - u_exact(coords)).max())
+    d = ctx.devices()
+    ctx.close()
+    return {"workload": f"C3's mesh ({nx}^3 x 6 = {n_cells} tetrahedra, {nd} DOFs) through ONE multi-device context", "devices": devices, "real_devices": n_real,
+            "form": {0: "row-distributed", 1: "element partition"}.get(d["form"], str(d["form"])), "dofs_build_ms": 1e3 * t_build,
+            "t_partition_ms": d["t_partition_ms"], "t_rank_setup_ms": d["t_rank_setup_ms"], "ms_per_step": 1e3 * wall, "dof_per_s": nd / wall,
+            "iterations": int(info.iters), "us_per_iteration": 1e3 * float(info.t_solve_ms) / max(int(info.iters), 1), "persistent": int(info.persistent),
+            "relres": float(info.relres), "max_abs_error_vs_analytic": err,
+            "note": ("the devices are ONE GPU named several times: set-up cost and plumbing only, no scaling figure" if n_real < n_dev else "one rank per GPU")}
+
+
 def _read_fixture_csv(path, dtype):
     """the reference's CSV dialect (utils/IO/csv_reader.h:75-117): a header row, first column = row index, quotes stripped"""
     rows = []
@@ -265,8 +334,22 @@ def run_c1(capi, golden_mesh_dir, names=("unit_square_16", "unit_square_32"), re
         for _ in range(5):
             ctx.lin_solve(B, rtol=rtol)
         t_cols = (time.perf_counter() - t0) / 5 / 64
+        _, hinfo = ctx.lin_solve(B[:, 0], rtol=rtol)
+        # the parabolic loop at the reference's own size (fem_pde_test.cpp:222-368's shape): 101 time points, K = M / dt + A fixed over the steps
+        times = np.linspace(0.0, 1.0, 101)
+        ctx.set_operator(capi.dt() - capi.laplacian())
+        ctx.set_forcing(np.stack([np.sin(np.pi * qn[:, 0]) * np.cos(t) for t in times], axis=1))
+        ctx.init()
+        u0 = np.sin(np.pi * coords[:, 0]) * np.sin(np.pi * coords[:, 1])
+        G = np.zeros((nd, times.size))
+        ctx.solve_parabolic(times, u0, G, rtol=rtol)
+        t0 = time.perf_counter()
+        _, pinfo = ctx.solve_parabolic(times, u0, G, rtol=rtol)
+        t_par = time.perf_counter() - t0
         out[name] = {"dofs": int(nd), "cells": int(cells.shape[0]), "init_ms": 1e3 * t_init, "solve_ms": 1e3 * t_solve, "iterations": int(info.iters),
                      "persistent": int(info.persistent), "max_abs_error_vs_analytic": err,
-                     "handle_solve_one_column_ms": 1e3 * t_col, "handle_solve_per_column_of_64_ms": 1e3 * t_cols}
+                     "handle_solve_one_column_ms": 1e3 * t_col, "handle_solve_per_column_of_64_ms": 1e3 * t_cols,
+                     "handle_method": int(hinfo.method_used),   # 6 = the dense inverse (kernels_dense.h), taken by a handle that has solved many columns
+                     "parabolic_101_points_ms": 1e3 * t_par, "parabolic_method": int(pinfo.method_used)}
         ctx.close()
     return out

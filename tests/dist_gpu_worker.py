@@ -56,8 +56,13 @@ def main():
     u_exact, f = meshgen.manufactured(N)
     g_fn = lambda x: 0.3 * x[:, 0] - 0.2 * x[:, -1]
     bvec = [1.0, 0.5, 0.25][:N]
+    # "indef": -Lap u - k^2 u with a handful of negative eigenvalues -- symmetric, CG breaks down (p.Ap <= 0), the open method must hand over to
+    # BiCGStab on ALL ranks together; "pe30": cell Peclet number 30 -- BiCGStab breaks down and restarts, collectively
+    pe_b = (2.0 * 30.0 * nx / np.linalg.norm(bvec)) * np.asarray(bvec)
     mkop = (lambda: -capi.laplacian() + capi.advection(bvec) + capi.reaction(1.0)) if case.startswith("adr") else \
-           (lambda: capi.dt() - capi.laplacian()) if case == "parab" else (lambda: -capi.laplacian())
+           (lambda: capi.dt() - capi.laplacian()) if case == "parab" else \
+           (lambda: -capi.laplacian() - capi.reaction(60.0 if N == 3 else 45.0)) if case == "indef" else \
+           (lambda: -capi.laplacian() + capi.advection(pe_b)) if case == "pe30" else (lambda: -capi.laplacian())
     part = fdist.partition_cells(nodes, cells, world)
     if exchange_mode == "rowdist":
         return rowdist_case(rank, world, case, order, nodes, cells, bnd, part, capi, fdist, dist, torch, u_exact, f, g_fn, transport, two_level, nx)
@@ -151,12 +156,14 @@ def main():
         (info, u), (rinfo, uref) = res
         err = np.linalg.norm(u - uref[l2g]) / np.linalg.norm(uref)
         assert info.converged == 1 and err < 1e-8, (info.converged, err)
-        if case.startswith("adr"):
+        if case in ("indef", "pe30"):   # the single-domain context took the same turn (CG -> BiCGStab / BiCGStab restarts); paths differ with rounding
+            assert info.method_used == capi.SOLVER_BICGSTAB and rinfo.converged == 1, (info.method_used, rinfo.converged)
+        elif case.startswith("adr"):
             assert info.method_used == capi.SOLVER_BICGSTAB and info.iters <= 1.3 * rinfo.iters + 5, (info.iters, rinfo.iters)
         else:
             assert abs(info.iters - rinfo.iters) <= max(2, rinfo.iters // 50), (info.iters, rinfo.iters)   # same Krylov iteration up to rounding
         msg = f"iters {info.iters} (single domain {rinfo.iters})"
-        if nx <= ORACLE_NX:   # ... and directly against the oracle's direct solve of the whole mesh (same numbering: l2g)
+        if nx <= ORACLE_NX and case not in ("indef", "pe30"):   # ... and directly against the oracle's direct solve of the whole mesh (same numbering: l2g)
             uo = oracle_solution(nodes, cells, bnd, order, "adr" if case.startswith("adr") else "lap", bvec, f(ref.quadrature_nodes()), g_fn(gcoords))
             err_o = np.linalg.norm(u - uo[l2g]) / np.linalg.norm(uo)
             assert err_o < 1e-8, err_o
@@ -326,26 +333,35 @@ def rowdist_case(rank, world, case, order, nodes, cells, bnd, part, capi, fdist,
         print(f"rank {rank}: ok  case handle rowdist  local dofs {n_loc}  err {err:.2e}")
         dist.destroy_process_group()
         return
+    hard = case in ("indef", "pe30")
+    bdir = np.asarray([1.0, 0.5, 0.25][:N])
     for c_, co in ((ctx, lcoords), (ref, gcoords)):
-        c_.set_operator(-capi.laplacian() + capi.reaction(0.5) + (capi.advection([1.0, 0.5, 0.25][:N]) if adr else capi.reaction(0.0)))
+        if case == "indef":
+            c_.set_operator(-capi.laplacian() - capi.reaction(60.0 if N == 3 else 45.0))
+        elif case == "pe30":
+            c_.set_operator(-capi.laplacian() + capi.advection((2.0 * 30.0 * nx / np.linalg.norm(bdir)) * bdir))
+        else:
+            c_.set_operator(-capi.laplacian() + capi.reaction(0.5) + (capi.advection([1.0, 0.5, 0.25][:N]) if adr else capi.reaction(0.0)))
         c_.set_forcing(f(c_.quadrature_nodes()))
         c_.set_dirichlet(g_fn(co))
         c_.init()
         res.append((c_.solve(rtol=1e-11), c_.solution()))
     (info, u), (rinfo, uref) = res
     assert info.converged == 1 and info.persistent == 1, (info.converged, info.persistent)
-    assert info.method_used == (capi.SOLVER_BICGSTAB if adr else capi.SOLVER_CG_FUSED)
+    assert info.method_used == (capi.SOLVER_BICGSTAB if adr or hard else capi.SOLVER_CG_FUSED)
     err2 = np.array([np.sum((u[mine] - uref[l2g][mine]) ** 2), float(mine.sum())])
     allreduce(err2)
     err = float(np.sqrt(err2[0])) / np.linalg.norm(uref)
     assert int(err2[1]) == gk.size, "every DOF of the whole mesh is owned exactly once"
-    assert err < (1e-8 if adr else 1e-9), err
-    if adr:
+    assert err < (1e-7 if hard else 1e-8 if adr else 1e-9), err
+    if hard:
+        assert rinfo.converged == 1
+    elif adr:
         assert info.iters <= 1.3 * rinfo.iters + 5, (info.iters, rinfo.iters)
     else:
         assert abs(info.iters - rinfo.iters) <= max(1, rinfo.iters // 100), (info.iters, rinfo.iters)
     oracle_msg = ""
-    if 0 < nx <= ORACLE_NX:   # directly against the oracle's direct solve of the whole mesh, over the DOFs this rank owns
+    if 0 < nx <= ORACLE_NX and not hard:   # directly against the oracle's direct solve of the whole mesh, over the DOFs this rank owns
         uo = oracle_solution(nodes, cells, bnd, order, "adr+r" if adr else "lap+r", [1.0, 0.5, 0.25][:N], f(ref.quadrature_nodes()), g_fn(gcoords))
         eo = np.array([np.sum((u[mine] - uo[l2g][mine]) ** 2)])
         allreduce(eo)
@@ -354,7 +370,7 @@ def rowdist_case(rank, world, case, order, nodes, cells, bnd, part, capi, fdist,
         oracle_msg = f"  vs oracle {err_o:.1e}"
     # second solve on the same context: epochs advance, boards are not cleared; identical bits
     info2 = ctx.solve(rtol=1e-11)
-    assert info2.iters == info.iters and np.array_equal(ctx.solution()[mine], u[mine])
+    assert info2.converged == 1 and (hard or (info2.iters == info.iters and np.array_equal(ctx.solution()[mine], u[mine])))
     dist.barrier()
     print(f"rank {rank}: ok  case {case} rowdist  local dofs {n_loc} (owned {int(mine.sum())})  iters {info.iters} (single domain {rinfo.iters})  "
           f"err {err:.2e}  launch {info.launch_ms:.3f} ms{oracle_msg}")

@@ -60,6 +60,17 @@ def test_partitioned_device_solve_matches_single_domain(world, nx, case):
     _run_ranks(world, nx, case, "shared")
 
 
+@pytest.mark.parametrize("world,nx,case,exchange", [(2, 10, "indef", "peers"), (3, 10, "indef", "peers"), (2, 12, "pe30", "peers"), (2, 10, "indef", "rowdist"),
+                                                    (3, 12, "indef", "rowdist")])
+def test_open_method_hands_over_across_ranks(world, nx, case, exchange):
+    """FDAPDE_SOLVER_AUTO on the ranks of a multi-GPU job: a symmetric indefinite operator breaks CG -- every rank agrees on it and all of
+    them re-prepare and run BiCGStab; an advection-dominated one breaks BiCGStab down -- all ranks restart it from the iterate together.  Both used to end with
+    the breakdown reported (one-GPU contexts only took these turns).  Against the single-domain solve of the whole mesh.  (No "pe30" in the row-distributed
+    form: at that Peclet number rows have a non-positive diagonal, which that form declines -- FDAPDE_EUNSUPPORTED on every rank -- and the caller takes the
+    element form, as the multi-device context does by itself.)"""
+    _run_ranks(world, nx, case, "shared", exchange)
+
+
 @pytest.mark.parametrize("world,nx,case", [(2, 12, "p1"), (3, 10, "p1"), (3, 7, "adr2"), (2, 9, "parab")])
 def test_partitioned_device_solve_dense_interface_allreduce(world, nx, case):
     """the round-1 exchange (fdapde_halo_setup: one all-reduce of the whole interface vector) stays available"""

@@ -194,6 +194,9 @@ def test_auto_ends_in_gmres_where_bicgstab_gives_up(env, dim, nx, peclet):
 
     capi, meshgen = env
     c, nd = _advection_case(capi, meshgen, dim, nx, peclet)
+    first = c.solve(rtol=1e-10, raise_on_noconv=False)   # (round 6: systems of up to 4096 DOFs get the direct stage in front of GMRES -- tests/test_gpu_dense.py)
+    assert first.converged == 1 and first.method_used in (capi.SOLVER_DENSE, capi.SOLVER_GMRES, capi.SOLVER_BICGSTAB)
+    c.tune("dense_rows", 0)   # ... here: the GMRES stage itself
     info = c.solve(rtol=1e-10, raise_on_noconv=False)
     assert info.converged == 1 and info.relres <= 1e-10
     assert info.method_used in (capi.SOLVER_GMRES, capi.SOLVER_BICGSTAB)

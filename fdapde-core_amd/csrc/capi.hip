@@ -412,6 +412,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "asm_items" && (value == 0 || value == 1)) c->asm_items = value;
     else if (k == "asm_items_fuse" && (value == 0 || value == 1)) c->asm_items_fuse = value;
     else if (k == "bicg_restart" && (value == 0 || value == 1)) c->bicg_restart = value;
+    else if (k == "bicg_shadow" && value >= 0 && value <= 2) c->bicg_shadow = value;
     else if (k == "gmres_m" && value >= 2 && value <= 200) c->gmres_m = value;
     else if (k == "persist_exp_lds" && (value == 0 || value == 1)) {
         c->persist_exp_lds = value;

@@ -228,6 +228,7 @@ struct fdapde_ctx {
                               // visits it): the row-owner sweep reads them where it reads the block's cells; built by fdapde_set_forcing
     bool fq_bc_ready = false;
     bool cg_broke_down = false;  // the assembled stiff_ is symmetric but CG broke down on it (fdapde_solve with the method left open): the next solves go to BiCGStab at once
+    int bicg_shadow = 0;         // knob: shadow residual of the multi-launch BiCGStab: 0 = r0 (BiCGStab as published), 1 = pseudo-random, 2 = r0 with randomly scaled entries
     int bicg_restart = 1;        // knob: 0 = a BiCGStab breakdown ends the solve (FDAPDE_ENOCONV) instead of restarting it from the iterate reached
     int asm_split_varying = 1;   // knob: 0 = every space-varying operator takes the per-node tensor integrand (element_row OPK 4), also where only advection / reaction vary (OPK 5)
     int asm_items = 1;        // knob: 0 = spaces with dealt rows (P2) keep the row-walking sweep instead of the visit-parallel one (k_assemble_items)

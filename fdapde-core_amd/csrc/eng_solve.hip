@@ -597,6 +597,10 @@ int solve_run(fdapde_ctx* c, const SolveState& ss, const double* A, const double
         hipLaunchKernelGGL(k_krylov_init_fin, dim3(1), dim3(256), 0, st, c->part_b.p, c->vec_grid, c->sc.p, c->ctl.p, tol2,
                            cgf ? c->part_b.p + cg : (double*)nullptr, cgf ? cg : 0);
     }
+    if (bicg && c->bicg_shadow && !dist && !ss.rowdist) {   // a shadow residual other than r0 (knob; measurements): r0~ and rho_0 = (r0~, r0)
+        hipLaunchKernelGGL(k_bicg_shadow, dim3(c->vec_grid), dim3(256), 0, st, n, c->bicg_shadow, c->r.p, c->r0.p, c->part_b.p);
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, c->part_b.p, c->vec_grid, c->sc.p + 9);
+    }
     if (gmres) {   // the scaled right-hand side, for the true residual at the end of every restart cycle (c->y still holds A g~)
         HIPCHK(c, c->gm_b.alloc((size_t)n));
         hipLaunchKernelGGL(k_gm_rhs, dim3(g1(n)), dim3(256), 0, st, n, fvec, c->y.p, c->scale.p, c->gm_b.p);

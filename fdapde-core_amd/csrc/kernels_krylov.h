@@ -743,6 +743,24 @@ static __global__ __launch_bounds__(256) void k_bicg_xr(int64_t n, const double*
 }
 #undef BI_LD
 #undef BI_ST
+// Shadow residual of BiCGStab other than r0 itself (knob bicg_shadow; tools/c5_iter_spread.py): mode 1 = pseudo-random entries in (-1, 1) from a hash of
+// the DOF's position (the same on every run), mode 2 = r0 with every entry scaled by a pseudo-random factor in (0.5, 1.5).  part[b] = partial of (shadow, r).
+static __global__ __launch_bounds__(256) void k_bicg_shadow(int64_t n, int mode, const double* r, double* r0, double* part) {
+    __shared__ double red[8];
+    double a = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        unsigned long long z = (unsigned long long)i + 0x9e3779b97f4a7c15ull;   // splitmix64
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        z ^= z >> 31;
+        const double u = (double)(z >> 11) * (1.0 / 9007199254740992.0);   // [0, 1)
+        const double v = mode == 1 ? 2.0 * u - 1.0 : r[i] * (0.5 + u);
+        r0[i] = v;
+        a += v * r[i];
+    }
+    const double s = block_sum(a, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
 // multi-GPU BiCGStab: t.t over the owned rows of the ASSEMBLED t (the SpMV's fused y.y only sees this rank's sub-assembled
 // part); per-workgroup partials, then out = (t.s already summed over ranks, local t.t) for the scalar all-reduce of out[1]
 static __global__ __launch_bounds__(256) void k_sq_owned(int64_t n, const double* t, const uint8_t* owned, double* part, const int32_t* ctl) {

@@ -154,7 +154,11 @@ def run_c5(capi, meshgen, nx=87, steps=3, warmup=1, time_spmv=16, rtol=1e-10, de
     out = _summary(ctx, nd, wall, infos, c5_exact, hbm_peak_gbps)
     out.update(workload=f"C5: 3-D P2 advection-diffusion-reaction, {nx}^3 x 6 = {n_cells} tetrahedra, b = (1, 0.5, 0.25), c = 1, "
                         "Jacobi-BiCGStab; 3-D P2 numbering build-defined (parity unpinned)",
-               cells=n_cells, t_setup_s=t_setup)
+               cells=n_cells, t_setup_s=t_setup, iterations_per_step=[int(i.iters) for i in infos],
+               # BiCGStab's path to 1e-10 is chaotic in the last bits of its scalars: the SAME problem with its right-hand side scaled by (1 + k 2^-48),
+               # k = 0 .. 5, takes 659 - 785 iterations (tools/c5_iter_spread.py -> profiles/r6_c5_iter_spread.txt; other shadow residuals spread wider).
+               # The figure of a record is one draw from that distribution; the steps of one run repeat it bit for bit.
+               iteration_spread_note="659-785 iterations over six right-hand sides differing in the last bits (profiles/r6_c5_iter_spread.txt)")
     try:   # HBM bytes per SpMV launch from the committed counter passes of this workload (tools/profile_c5.sh), labelled: not this run
         import json
         import os

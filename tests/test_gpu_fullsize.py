@@ -111,6 +111,9 @@ def test_c5_fullsize(env):
     ctx.init()
     info = ctx.solve(rtol=1e-10)
     assert info.converged == 1 and info.method_used == capi.SOLVER_BICGSTAB and info.relres <= 1e-10
+    # The count of this chaotic recurrence is one draw from a distribution (the same problem with its right-hand side scaled by 1 + k 2^-48 takes 659 - 785
+    # iterations: tools/c5_iter_spread.py, profiles/r6_c5_iter_spread.txt): the bound catches a degraded iteration, not a rounding change.
+    assert info.iters <= 900, info.iters
     u = ctx.solution()
     err = np.abs(u - workloads.c5_exact(coords)).max()
     assert err < 1.0 * (1.0 / nx) ** 2 * np.pi**2                         # O(h^2): 1.3e-3 bound, 3.3e-4 observed

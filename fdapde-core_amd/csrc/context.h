@@ -451,6 +451,7 @@ struct fdapde_ctx {
         bool ready = false, refine = false, failed = false;
         double check = 0, build_ms = 0;   // max |I - A X|; what the build cost (host wall clock)
     } lin_dense, step_dense, solve_dense;
+    int dense_block = 1;          // knob: 0 = the inversion pivot by pivot (k_dense_invert) instead of in panels (k_dense_invert_blocked)
     int dense_rows = 4096;        // knob: systems of up to that many DOFs may take the dense path (0: never)
     int dense_after = 8;          // knob: ... once a handle's matrix has been asked for more than that many columns / a stepper for that many steps
                                   // AND the Krylov time spent (handle) / to be expected (stepper) reaches half of what the inversion costs; 0: at once

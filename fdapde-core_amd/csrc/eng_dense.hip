@@ -33,12 +33,14 @@ bool dense_eligible(const fdapde_ctx* c) {
            !c->halo_ready && !c->rd.ready;
 }
 
-// What an inversion costs, from the measured shape of k_dense_invert on MI355X (n steps of one grid barrier ~13 us + a read-modify-write sweep of the
-// n x n array at ~3 TB/s): 289 rows 3 ms, 1 089 rows 16 ms, 4 225 rows ~0.4 s.  Callers build an inverse when the Krylov time it replaces is of that
-// order ("rent or buy": the handle after it has spent half of this on Krylov columns, the stepper when its steps will).
+// What an inversion costs, from the measured shape of k_dense_invert_blocked on MI355X (n / nb panels of two grid-wide hand-offs + nb LDS-resident pivot
+// steps, ~130 us, + a read-modify-write sweep of the n x n array at ~3 TB/s): 289 rows 2.3 ms, 1 089 rows 10 ms, 2 116 rows 28 ms, 4 225 rows 0.19 s.
+// Callers build an inverse when the Krylov time it replaces is of that order ("rent or buy": the handle after it has spent half of this on Krylov
+// columns, the stepper when its steps will).
 double dense_build_estimate_ms(int64_t n) {
+    const int64_t nb = std::max<int64_t>(1, std::min<int64_t>(kDenseNB, (int64_t)(144 * 1024) / (8 * n)));
     const double sweep_us = 16.0 * (double)n * (double)n / 3.0e6;
-    return 1e-3 * (double)n * (13.0 + sweep_us) + 0.3;
+    return 1e-3 * (double)((n + nb - 1) / nb) * (130.0 + sweep_us) + 0.3;
 }
 
 // D.X = (the matrix A of the pattern, its Dirichlet rows replaced by unit rows if use_bnd)^-1, internal DOF order.  D.ready, or D.failed where the
@@ -53,6 +55,12 @@ int dense_build(fdapde_ctx* c, const double* A, int use_bnd, fdapde_ctx::Dense& 
     DBuf<unsigned long long> cand, worst;
     const int G = (int)std::max<int64_t>(1, std::min<int64_t>(c->n_cu > 0 ? c->n_cu : 64, (n + 7) / 8));
     const int64_t ld = (n + 15) & ~int64_t(15);
+    // pivots per panel of the blocked inversion: the panel (n x nb doubles) lives in the LDS of one workgroup
+    const int nb = (int)std::min<int64_t>(kDenseNB, (int64_t)(144 * 1024) / (8 * n));
+    const bool blocked = c->dense_block && nb >= 2;
+    DBuf<double> S1, Mbuf, piv_d;
+    DBuf<int32_t> piv_row;
+    DBuf<unsigned long long> flags;
     HIPCHK(c, S.alloc((size_t)n * (size_t)ld));
     HIPCHK(c, D.X.alloc((size_t)n * n));
     HIPCHK(c, perm.alloc((size_t)n));
@@ -63,13 +71,32 @@ int dense_build(fdapde_ctx* c, const double* A, int use_bnd, fdapde_ctx::Dense& 
     HIPCHK(c, hipMemsetAsync(status.p, 0, 4 * sizeof(int32_t), st));
     HIPCHK(c, hipMemsetAsync(worst.p, 0, 2 * sizeof(unsigned long long), st));
     hipLaunchKernelGGL(k_dense_fill, dim3((unsigned)n), dim3(256), 0, st, n, ld, c->rowptr.p, c->colidx.p, A, c->bnd.p, use_bnd, S.p);
-    DenseInvArgs a{};
-    a.n = (int32_t)n, a.G = G, a.ld = (int32_t)ld, a.S = S.p, a.perm = perm.p, a.cand = cand.p, a.status = status.p;
-    a.timeout_ticks = 200000000ll;   // 2 s at 100 MHz: a workgroup that is not resident (another process's kernels on the device) ends the attempt
-    const size_t lds = sizeof(double) * (size_t)n;
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_invert), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_dense_invert, dim3((unsigned)G), dim3(kDenseT), lds, st, a);
-    hipLaunchKernelGGL(k_dense_unpermute, dim3((unsigned)n), dim3(256), 0, st, n, ld, S.p, perm.p, D.X.p);
+    const double* result = S.p;
+    if (blocked) {
+        HIPCHK(c, S1.alloc((size_t)n * (size_t)ld));
+        HIPCHK(c, Mbuf.alloc((size_t)n * kDenseNB));
+        HIPCHK(c, piv_d.alloc(kDenseNB));
+        HIPCHK(c, piv_row.alloc(kDenseNB));
+        HIPCHK(c, flags.alloc((size_t)G + 2));
+        HIPCHK(c, hipMemsetAsync(flags.p, 0, ((size_t)G + 2) * sizeof(unsigned long long), st));
+        DenseBlkArgs b{};
+        b.n = (int32_t)n, b.G = G, b.ld = (int32_t)ld, b.nb = nb, b.S0 = S.p, b.S1 = S1.p, b.perm = perm.p, b.M = Mbuf.p, b.piv_d = piv_d.p, b.piv_row = piv_row.p;
+        b.done = flags.p, b.ready = flags.p + G, b.status = status.p, b.timeout_ticks = 200000000ll;
+        const int rows_max = (int)((n + G - 1) / G);
+        const size_t lds = std::max(sizeof(double) * (size_t)(n | 1) * nb, sizeof(double) * (size_t)rows_max * nb + sizeof(int) * (size_t)rows_max) + 64;
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_invert_blocked), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_dense_invert_blocked, dim3((unsigned)G), dim3(kDenseT), lds, st, b);
+        const int n_panels = (int)((n + nb - 1) / nb);
+        result = (n_panels & 1) ? S1.p : S.p;
+    } else {
+        DenseInvArgs a{};
+        a.n = (int32_t)n, a.G = G, a.ld = (int32_t)ld, a.S = S.p, a.perm = perm.p, a.cand = cand.p, a.status = status.p;
+        a.timeout_ticks = 200000000ll;   // 2 s at 100 MHz: a workgroup that is not resident (another process's kernels on the device) ends the attempt
+        const size_t lds = sizeof(double) * (size_t)n;
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_invert), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_dense_invert, dim3((unsigned)G), dim3(kDenseT), lds, st, a);
+    }
+    hipLaunchKernelGGL(k_dense_unpermute, dim3((unsigned)n), dim3(256), 0, st, n, ld, result, perm.p, D.X.p);
     hipLaunchKernelGGL(k_dense_check, dim3((unsigned)n), dim3(256), 0, st, n, c->rowptr.p, c->colidx.p, A, c->bnd.p, use_bnd, D.X.p, worst.p);
     HIPCHK(c, hipGetLastError());
     int32_t h_status[4] = {0, 0, 0, 0};
@@ -82,7 +109,7 @@ int dense_build(fdapde_ctx* c, const double* A, int use_bnd, fdapde_ctx::Dense& 
     D.check = chk;
     D.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (std::getenv("FDAPDE_DEBUG_SETUP"))
-        std::fprintf(stderr, "dense inverse: %lld rows, %d workgroups, status %d, max |I - A X| = %.3e, %.2f ms\n", (long long)n, G, h_status[0], chk, D.build_ms);
+        std::fprintf(stderr, "dense inverse: %lld rows, %d workgroups, %s (nb %d), status %d, max |I - A X| = %.3e, %.2f ms\n", (long long)n, G, blocked ? "blocked" : "pivot by pivot", nb, h_status[0], chk, D.build_ms);
     if (h_status[0] != 0 || !(chk < 1e-6)) {   // singular / timed out / an inverse too poor for one refinement step to repair
         D.X.release();
         return FDAPDE_OK;

@@ -214,6 +214,243 @@ static __global__ __launch_bounds__(kDenseT) void k_dense_invert(DenseInvArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The same inversion BLOCKED: nb pivots per grid-wide exchange instead of one.  k_dense_invert above pays a chain of dependent trips through the
+// fabric per pivot (sweep, pivot row, write-through, granule: ~9 us + 5 ns per workgroup -- 15 ms for 1 089 rows).  Here a PANEL of nb <= 16 columns
+// is gathered by workgroup 0 into LDS (n x nb doubles), factorised there -- nb pivot searches and rank-1 updates with workgroup barriers only -- and
+// published as the multipliers M[i][t] (the value of column k_t in row i at the time of step t) + pivots; then every workgroup applies the nb steps to
+// its rows in ONE pass over the other columns:
+//     U_t[j] = (S[p_t][j] - sum_{s<t} M[p_t][s] U_s[j]) / d_t                       (the pivot rows among themselves, redundantly per workgroup)
+//     S'[i][j] = S[i][j] - sum_t M[i][t] U_t[j]                                      (ordinary rows)
+//     S'[p_t][j] = U_t[j] - sum_{s>t} M[p_t][s] U_s[j]                               (the panel's pivot rows)
+// -- the in-place Gauss-Jordan steps of k_dense_invert, re-associated.  A panel reads one buffer and writes the other (no row is written while somebody
+// may still read it); two hand-offs per panel: "panel published" (one granule all workgroups poll) and "update done" (a granule per workgroup, swept
+// by workgroup 0).  Payload through sc1 stores / sc1 loads as above.  1 089 rows: 68 panels x ~45 us.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+constexpr int kDenseNB = 16;    // pivots per panel at most (the panel, n x nb doubles, must fit the LDS of workgroup 0)
+constexpr int kDenseTJ = kDenseT;   // columns per tile of the update: one per thread
+
+struct DenseBlkArgs {
+    int32_t n, G, ld, nb;
+    double *S0, *S1;               // panel P reads S(P & 1), writes the other
+    int32_t* perm;                 // [n] pivot row of column k
+    double* M;                     // [n x nb] multipliers of the current panel
+    double* piv_d;                 // [nb]
+    int32_t* piv_row;              // [nb]
+    unsigned long long* done;      // [G] granule per workgroup: panels whose update it has finished
+    unsigned long long* ready;     // [1] (panels published << 1) | failed
+    int32_t* status;               // [0] 1 = singular, 2 = a wait timed out
+    long long timeout_ticks;
+};
+
+static __global__ __launch_bounds__(kDenseT) void k_dense_invert_blocked(DenseBlkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char dn_smem3[];
+    double* buf = reinterpret_cast<double*>(dn_smem3);
+    constexpr int T = kDenseT, W = kDenseT / 64, TJ = kDenseTJ;
+    __shared__ double red_val[W];
+    __shared__ int red_row[W];
+    __shared__ int piv_row_s[kDenseNB], wait_s;
+    __shared__ double piv_d_s[kDenseNB], prow_s[kDenseNB];
+    __shared__ double Mpp[kDenseNB][kDenseNB + 1];
+    __shared__ unsigned long long used_bits[(kDenseMaxRows + 63) / 64];   // workgroup 0: rows that have been pivots
+    const int n = a.n, G = a.G, NB = a.nb, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int my_rows = g < n ? (n - g + G - 1) / G : 0;
+    if (g == 0)
+        for (int w = tid; w < (n + 63) / 64; w += T) used_bits[w] = 0ull;
+    __syncthreads();
+    const int n_panels = (n + NB - 1) / NB;
+    for (int P = 0; P < n_panels; ++P) {
+        const int k0 = P * NB, nbp = n - k0 < NB ? n - k0 : NB;
+        const double* Scur = (P & 1) ? a.S1 : a.S0;
+        double* Snext = (P & 1) ? a.S0 : a.S1;
+        if (g == 0) {
+            // ---- every workgroup has finished the update of panel P - 1
+            if (wave == 0) {
+                int ok = 1;
+                const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+                for (int q = lane; q < G && ok; q += 64)
+                    while (__hip_atomic_load((const dn_u64*)(a.done + q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)P) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
+                            ok = 0;
+                            break;
+                        }
+                    }
+                ok = __all(ok);
+                if (lane == 0) wait_s = ok;
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            int failed = wait_s ? 0 : 2;
+            // the panel, COLUMN-major in LDS (pan[t * np + i]): a column search and the row updates both run over consecutive i -- conflict-free
+            // (row-major, 16 doubles per row, every lane of a wavefront fell on the same two banks: 276 us per panel of 16 at 1 089 rows)
+            const int np = n | 1;
+            double* pan = buf;
+            if (!failed) {
+                for (int idx = tid; idx < n * nbp; idx += T) {
+                    const int i = idx / nbp, t = idx - i * nbp;
+                    pan[t * np + i] = dense_load_shared(Scur + (int64_t)i * a.ld + k0 + t);
+                }
+                __syncthreads();
+                // block-wide arg-max of (best, best_row): the next pivot, the same in every thread
+                auto reduce_pivot = [&](double& best, int& best_row) {
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const double ov = __shfl_xor(best, o);
+                        const int orow = __shfl_xor(best_row, o);
+                        if (ov > best || (ov == best && orow < best_row)) best = ov, best_row = orow;
+                    }
+                    __syncthreads();   // (the previous round's readers are done with red_*)
+                    if (lane == 0) red_val[wave] = best, red_row[wave] = best_row;
+                    __syncthreads();
+                    best = red_val[0], best_row = red_row[0];
+                    for (int w = 1; w < W; ++w)
+                        if (red_val[w] > best || (red_val[w] == best && red_row[w] < best_row)) best = red_val[w], best_row = red_row[w];
+                };
+                double best = -1.0;
+                int best_row = 0x7fffffff;
+                for (int i = tid; i < n; i += T)
+                    if (!((used_bits[i >> 6] >> (i & 63)) & 1ull)) {
+                        const double v = fabs(pan[i]);
+                        if (v > best || (v == best && i < best_row)) best = v, best_row = i;
+                    }
+                reduce_pivot(best, best_row);
+                for (int t = 0; t < nbp; ++t) {
+                    if (best_row == 0x7fffffff || !(best > 0.0) || !isfinite(best)) {
+                        failed = 1;
+                        break;
+                    }
+                    const int p = best_row;
+                    if (tid < nbp) prow_s[tid] = pan[tid * np + p];
+                    if (tid == 0) {
+                        used_bits[p >> 6] |= 1ull << (p & 63);
+                        piv_row_s[t] = p;
+                        a.perm[k0 + t] = p;
+                    }
+                    __syncthreads();
+                    const double d = prow_s[t], inv_d = 1.0 / d;
+                    if (tid == 0) piv_d_s[t] = d;
+                    // the step on every row of the panel; the same sweep finds the next column's pivot among the rows not used yet
+                    best = -1.0, best_row = 0x7fffffff;
+                    for (int i = tid; i < n; i += T) {
+                        const double m = pan[t * np + i];
+                        dense_store(a.M + (int64_t)i * NB + t, m);
+                        if (i != p) {
+                            const double f = m * inv_d;
+                            for (int tt = 0; tt < nbp; ++tt)
+                                if (tt != t) pan[tt * np + i] -= f * prow_s[tt];
+                            pan[t * np + i] = -f;
+                            if (t + 1 < nbp && !((used_bits[i >> 6] >> (i & 63)) & 1ull)) {
+                                const double v = fabs(pan[(t + 1) * np + i]);
+                                if (v > best || (v == best && i < best_row)) best = v, best_row = i;
+                            }
+                        } else {
+                            for (int tt = 0; tt < nbp; ++tt) pan[tt * np + i] = tt == t ? inv_d : prow_s[tt] * inv_d;
+                        }
+                    }
+                    if (t + 1 < nbp) reduce_pivot(best, best_row);
+                    else __syncthreads();
+                }
+            }
+            if (!failed) {
+                for (int idx = tid; idx < n * nbp; idx += T) {
+                    const int i = idx / nbp, t = idx - i * nbp;
+                    dense_store(Snext + (int64_t)i * a.ld + k0 + t, pan[t * (n | 1) + i]);
+                }
+                if (tid < nbp) {
+                    dense_store(a.piv_d + tid, piv_d_s[tid]);
+                    __hip_atomic_store((dn_u32*)(a.piv_row + tid), (unsigned)piv_row_s[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                if (failed) a.status[0] = failed;
+                __hip_atomic_store((dn_u64*)a.ready, ((unsigned long long)(P + 1) << 1) | (failed ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // ---- every workgroup: the panel is published
+        if (tid == 0) {
+            const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+            unsigned long long x;
+            int ok = 1;
+            while (((x = __hip_atomic_load((const dn_u64*)a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 1) != (unsigned long long)(P + 1)) {
+                __builtin_amdgcn_s_sleep(2);
+                if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
+                    ok = 0;
+                    break;
+                }
+            }
+            if (!ok) a.status[0] = 2;
+            wait_s = ok && !(x & 1ull) ? 1 : 0;
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (!wait_s) return;
+        if (tid < nbp) {
+            piv_row_s[tid] = (int)__hip_atomic_load((const dn_u32*)(a.piv_row + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            piv_d_s[tid] = dense_load_shared(a.piv_d + tid);
+        }
+        __syncthreads();
+        double* Mown = buf;                    // [my_rows][NB] the multipliers of this workgroup's rows
+        int* pt_own = reinterpret_cast<int*>(Mown + (size_t)my_rows * NB);   // [my_rows] index of the row among the panel's pivots, or -1
+        for (int idx = tid; idx < nbp * nbp; idx += T) {
+            const int s_ = idx / nbp, t = idx - s_ * nbp;
+            Mpp[s_][t] = dense_load_shared(a.M + (int64_t)piv_row_s[s_] * NB + t);
+        }
+        for (int idx = tid; idx < my_rows * nbp; idx += T) {
+            const int r = idx / nbp, t = idx - r * nbp;
+            Mown[r * NB + t] = dense_load_shared(a.M + (int64_t)(g + G * r) * NB + t);
+        }
+        for (int r = tid; r < my_rows; r += T) {
+            int pt = -1;
+            for (int t = 0; t < nbp; ++t)
+                if (piv_row_s[t] == g + G * r) pt = t;
+            pt_own[r] = pt;
+        }
+        __syncthreads();
+        for (int j0 = 0; j0 < n; j0 += TJ) {
+            const int j = j0 + tid;
+            const bool in_range = j < n;
+            // the pivot rows' entries of this column, transformed among themselves: U_t[j]
+            double U[kDenseNB];
+#pragma unroll
+            for (int t = 0; t < kDenseNB; ++t) U[t] = (t < nbp && in_range) ? dense_load_shared(Scur + (int64_t)piv_row_s[t] * a.ld + j) : 0.0;
+#pragma unroll
+            for (int t = 0; t < kDenseNB; ++t)
+                if (t < nbp) {
+                    double v = U[t];
+#pragma unroll
+                    for (int s_ = 0; s_ < kDenseNB; ++s_)
+                        if (s_ < t) v -= Mpp[t][s_] * U[s_];
+                    U[t] = v / piv_d_s[t];
+                }
+            const bool write = in_range && (j < k0 || j >= k0 + nbp);   // (the panel's own columns came from workgroup 0)
+            for (int r = 0; r < my_rows; ++r) {
+                if (!write) break;
+                const int i = g + G * r, pt = pt_own[r];
+                const double* mrow = Mown + r * NB;
+                double v;
+                if (pt < 0) {
+                    v = dense_load_shared(Scur + (int64_t)i * a.ld + j);
+#pragma unroll
+                    for (int t = 0; t < kDenseNB; ++t)
+                        if (t < nbp) v -= mrow[t] * U[t];
+                } else {
+                    v = 0.0;
+#pragma unroll
+                    for (int t = 0; t < kDenseNB; ++t)
+                        if (t < nbp) v = t == pt ? v + U[t] : (t > pt ? v - mrow[t] * U[t] : v);
+                }
+                dense_store(Snext + (int64_t)i * a.ld + j, v);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store((dn_u64*)(a.done + g), (unsigned long long)(P + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+
 // X[k][perm[j]] = S[perm[k]][j]
 static __global__ void k_dense_unpermute(int64_t n, int64_t ld, const double* S, const int32_t* perm, double* X) {
     const int64_t k = blockIdx.x;

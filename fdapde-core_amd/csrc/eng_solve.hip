@@ -913,7 +913,9 @@ int solve_run_restarting(fdapde_ctx* c, const SolveState& ss, const double* A, c
     // advection-dominated operator): restarted GMRES(m) on the same scaled system, from BiCGStab's iterate if that was any closer than zero.
     // ... but first, for a system small enough to invert (kernels_dense.h): a DIRECT solve of the reference's own row-zeroed matrix -- what its
     // SparseLU does, in milliseconds where restarted GMRES needs 10^4 - 10^5 iterations (cell Peclet numbers of 10^3 on a few thousand DOFs)
-    if (gmres_budget >= 0 && rc == FDAPDE_ENOCONV && c->info.method_used == FDAPDE_SOLVER_BICGSTAB && !ss.dist && !ss.rowdist && dense_eligible(c)) {
+    // (a budget the caller set -- maxit -- and BiCGStab spent is spent for this stage too: the call reports what its iterations reached)
+    if (gmres_budget >= 0 && (gmres_budget > 0 || maxit - total > 0) && rc == FDAPDE_ENOCONV && c->info.method_used == FDAPDE_SOLVER_BICGSTAB && !ss.dist && !ss.rowdist &&
+        dense_eligible(c)) {
         bool solved = false;
         if (int rc2 = dense_direct(c, A, ss.use_bnd, f_dev, g_dev, &solved)) return rc2;
         if (solved) {

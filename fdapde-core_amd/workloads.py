@@ -328,7 +328,19 @@ def run_c1(capi, golden_mesh_dir, names=("unit_square_16", "unit_square_32"), re
         ctx.lin_compute(capi.MAT_STIFF)
         rng = np.random.default_rng(0)
         B = rng.standard_normal((nd, 64))
-        ctx.lin_solve(B[:, 0], rtol=rtol)
+        # the handle as its users drive it: column after column against ONE matrix.  The first columns are Krylov runs; once they have cost half an
+        # inversion the handle inverts (rent or buy) and a column is one product.  Reported: the Krylov column, how many of them it took, what
+        # the inversion cost, and the steady state after it.
+        t0 = time.perf_counter()
+        _, hinfo = ctx.lin_solve(B[:, 0], rtol=rtol)
+        _, hinfo = ctx.lin_solve(B[:, 1], rtol=rtol)
+        t_krylov_col = (time.perf_counter() - t0) / 2
+        n_before, t_build = 2, 0.0
+        while hinfo.method_used != 6 and n_before < 400:
+            t0 = time.perf_counter()
+            _, hinfo = ctx.lin_solve(B[:, n_before % 64], rtol=rtol)
+            t_build = time.perf_counter() - t0   # (the call that switched carries the inversion)
+            n_before += 1
         ctx.lin_solve(B, rtol=rtol)
         t0 = time.perf_counter()
         for k in range(reps):
@@ -338,7 +350,6 @@ def run_c1(capi, golden_mesh_dir, names=("unit_square_16", "unit_square_32"), re
         for _ in range(5):
             ctx.lin_solve(B, rtol=rtol)
         t_cols = (time.perf_counter() - t0) / 5 / 64
-        _, hinfo = ctx.lin_solve(B[:, 0], rtol=rtol)
         # the parabolic loop at the reference's own size (fem_pde_test.cpp:222-368's shape): 101 time points, K = M / dt + A fixed over the steps
         times = np.linspace(0.0, 1.0, 101)
         ctx.set_operator(capi.dt() - capi.laplacian())
@@ -354,6 +365,8 @@ def run_c1(capi, golden_mesh_dir, names=("unit_square_16", "unit_square_32"), re
                      "persistent": int(info.persistent), "max_abs_error_vs_analytic": err,
                      "handle_solve_one_column_ms": 1e3 * t_col, "handle_solve_per_column_of_64_ms": 1e3 * t_cols,
                      "handle_method": int(hinfo.method_used),   # 6 = the dense inverse (kernels_dense.h), taken by a handle that has solved many columns
+                     "handle_krylov_column_ms": 1e3 * t_krylov_col, "handle_columns_before_the_inverse": int(n_before) - 1,
+                     "handle_inversion_ms": 1e3 * t_build if hinfo.method_used == 6 else None,
                      "parabolic_101_points_ms": 1e3 * t_par, "parabolic_method": int(pinfo.method_used)}
         ctx.close()
     return out

@@ -788,6 +788,9 @@ def main():
     # cross-process hipIpc on this pool needs the dmabuf IPC mode; set BEFORE anything loads the HIP runtime, and in every kind of rank process
     # (self-launched, canary, started by torch.distributed.run), so that the canary's verdict holds for the ranks that follow it
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # extra.multi_device_context names the box's one GPU several times: its ranks' persistent launches need a hardware queue each (the runtime multiplexes
+    # a process's streams onto 4 by default; real devices have their own) -- asked for before anything initialises the runtime; no effect on the other results
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     args = parse()
     if args.nx is None:
         args.nx = 87 if args.workload == "c5" else 119

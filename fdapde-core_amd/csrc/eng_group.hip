@@ -259,16 +259,25 @@ int build_ranks(Group* g) {
     }
     const auto t1 = std::chrono::steady_clock::now();
     g->t_partition_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
-    if (int rc = ensure_host(root, kHostDofs)) {
-        dev_partition_release(&part);
-        return rc;
-    }
     const int nb = H.nb, order = H.order;
+    if (order != 1)   // (P2: the ranks' DOFs are matched to the whole mesh's through the DOF tables)
+        if (int rc = ensure_host(root, kHostDofs)) {
+            dev_partition_release(&part);
+            return rc;
+        }
     std::vector<uint8_t> bnd_g = g->bnd_override.empty() ? std::vector<uint8_t>(H.dof_bnd.begin(), H.dof_bnd.end()) : g->bnd_override;
     int rc_all = run_all(g, [&](int r) -> int {
         GroupRank& R = g->rk[(size_t)r];
         fdapde_ctx* c = R.ctx;
         const RankMeshDev& P = part.ranks[(size_t)r];
+        const bool dbg = std::getenv("FDAPDE_DEBUG_SETUP") != nullptr;
+        auto tm0 = std::chrono::steady_clock::now();
+        auto mark = [&](const char* what) {
+            if (!dbg) return;
+            const auto t = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "rank %d set-up: %-28s %8.2f ms\n", r, what, std::chrono::duration<double, std::milli>(t - tm0).count());
+            tm0 = t;
+        };
         // ---- the sub-mesh: device (root's) -> host -> the rank's context
         (void)hipSetDevice(root->device);
         R.cell_ids.resize((size_t)P.n_cells), R.l2g.resize((size_t)P.n_nodes);
@@ -281,27 +290,37 @@ int build_ranks(Group* g) {
             !d2h(nb_l.data(), P.bnd, nb_l.size()) || !d2h(owner_l.data(), P.node_owner, sizeof(int32_t) * owner_l.size()))
             return fail(c, FDAPDE_EHIP, "multi-device context: fetching a rank's sub-mesh from the partition failed");
         (void)hipSetDevice(R.device);
+        mark("sub-mesh device -> host");
         if (int rc = fdapde_mesh_upload(c, H.M, H.N, P.n_nodes, nodes.data(), P.n_cells, cells.data(), nb_l.data())) return rc;
+        mark("fdapde_mesh_upload");
         int64_t nd = 0;
         if (int rc = e_dofs_build(c, order, &nd)) return rc;
+        mark("fdapde_dofs_build");
         for (const auto& kv : g->knobs) (void)fdapde_tune(c, kv.first.c_str(), kv.second);
         // ---- transport
         if (!R.cb_user) R.cb_user = new RankCookie{g, r};
         void* u = R.cb_user;
         if (int rc = e_comm_init_callback(c, n, r, &cb_allreduce, u)) return rc;
         if (int rc = e_comm_set_exchange_callback(c, &cb_exchange, u)) return rc;
-        // ---- local DOF -> DOF of the whole mesh, through the two DOF tables (the rank's own enumeration of its sub-mesh against the root's)
-        if (int rc = ensure_host(c, kHostDofs)) return rc;
+        // ---- local DOF -> DOF of the whole mesh.  P1: a DOF is a node (lagrangian_basis.h:96-99): the node map itself.  P2: through the two DOF tables
+        //      (the rank's own enumeration of its sub-mesh against the root's)
         const HostSpace& L = c->hs;
-        R.gdof.assign((size_t)L.n_dofs, -1);
-        for (int64_t cl = 0; cl < L.n_cells; ++cl) {
-            const int32_t* tl = L.dofs.data() + cl * nb;
-            const int32_t* tg = H.dofs.data() + (int64_t)R.cell_ids[(size_t)cl] * nb;
-            for (int j = 0; j < nb; ++j) R.gdof[(size_t)tl[j]] = tg[j];
+        if (order == 1) {
+            R.gdof.assign(R.l2g.begin(), R.l2g.end());
+        } else {
+            if (int rc = ensure_host(c, kHostDofs)) return rc;
+            R.gdof.assign((size_t)L.n_dofs, -1);
+            for (int64_t cl = 0; cl < L.n_cells; ++cl) {
+                const int32_t* tl = L.dofs.data() + cl * nb;
+                const int32_t* tg = H.dofs.data() + (int64_t)R.cell_ids[(size_t)cl] * nb;
+                for (int j = 0; j < nb; ++j) R.gdof[(size_t)tl[j]] = tg[j];
+            }
+            for (int64_t d = 0; d < L.n_dofs; ++d)
+                if (R.gdof[(size_t)d] < 0) return fail(c, FDAPDE_EINVAL, "multi-device context: a DOF of a sub-mesh is touched by none of its cells");
         }
-        for (int64_t d = 0; d < L.n_dofs; ++d)
-            if (R.gdof[(size_t)d] < 0) return fail(c, FDAPDE_EINVAL, "multi-device context: a DOF of a sub-mesh is touched by none of its cells");
+        if ((int64_t)R.gdof.size() != L.n_dofs) return fail(c, FDAPDE_EINVAL, "multi-device context: a rank's DOF count differs from its node count");
         R.gslot.clear();
+        mark("DOF maps");
         // the boundary flags are the WHOLE mesh's (the 2-D rule "edge seen by one cell", triangulation.h:177,187, would mark interface edges)
         std::vector<uint8_t> bl((size_t)L.n_dofs);
         bool differs = false;
@@ -313,16 +332,19 @@ int build_ranks(Group* g) {
         if (g->form == kPartitionRowdist) {
             // a vertex DOF belongs to its node's owner, an edge DOF to the owner of its end node with the LOWER global id: that rank's sub-mesh
             // holds every cell touching the node, hence every cell touching the edge
-            for (int64_t cl = 0; cl < L.n_cells; ++cl) {
-                const int32_t* tl = L.dofs.data() + cl * nb;
-                const int32_t* vl = L.cells.data() + cl * nv;
-                for (int v = 0; v < nv; ++v) own[(size_t)tl[v]] = owner_l[(size_t)vl[v]];
-                for (int j = nv; j < nb; ++j) {
-                    const int* e = H.M == 2 ? kEdge2[j - nv] : kEdge3[j - nv];
-                    const int32_t ga = R.l2g[(size_t)vl[e[0]]], gb = R.l2g[(size_t)vl[e[1]]];
-                    own[(size_t)tl[j]] = node_owner[(size_t)(ga < gb ? ga : gb)];
+            if (order == 1) {
+                for (int64_t d = 0; d < L.n_dofs; ++d) own[(size_t)d] = owner_l[(size_t)d];
+            } else
+                for (int64_t cl = 0; cl < L.n_cells; ++cl) {
+                    const int32_t* tl = L.dofs.data() + cl * nb;
+                    const int32_t* vl = L.cells.data() + cl * nv;
+                    for (int v = 0; v < nv; ++v) own[(size_t)tl[v]] = owner_l[(size_t)vl[v]];
+                    for (int j = nv; j < nb; ++j) {
+                        const int* e = H.M == 2 ? kEdge2[j - nv] : kEdge3[j - nv];
+                        const int32_t ga = R.l2g[(size_t)vl[e[0]]], gb = R.l2g[(size_t)vl[e[1]]];
+                        own[(size_t)tl[j]] = node_owner[(size_t)(ga < gb ? ga : gb)];
+                    }
                 }
-            }
             R.owned.resize((size_t)L.n_dofs);
             for (int64_t d = 0; d < L.n_dofs; ++d) R.owned[(size_t)d] = own[(size_t)d] == r ? 1 : 0;
             if (g->share > 1) (void)fdapde_tune(c, "rowdist_share", g->share);
@@ -330,6 +352,7 @@ int build_ranks(Group* g) {
             for (int64_t d = 0; d < L.n_dofs; ++d) key[(size_t)d] = R.gdof[(size_t)d];
             if (int rc = e_rowdist_setup(c, key.data(), own.data())) return rc;
         }
+        mark("owners + exchange set-up");
         return FDAPDE_OK;
     });
     dev_partition_release(&part);
@@ -547,6 +570,13 @@ int g_create(const int32_t* devices, int32_t n, fdapde_ctx** out) {
             return rc;
         }
         if (devices[r] >= 0 && devices[r] < (int)per_dev.size()) g->share = std::max(g->share, ++per_dev[(size_t)devices[r]]);
+    }
+    if (g->share > 1) {   // several ranks on one device: their persistent launches must overlap, i.e. sit on different hardware queues
+        const char* q = std::getenv("GPU_MAX_HW_QUEUES");
+        if ((!q || std::atoi(q) < g->share + 2) && std::getenv("FDAPDE_DEBUG_SETUP"))
+            std::fprintf(stderr, "multi-device context: %d ranks share a device and GPU_MAX_HW_QUEUES is %s: launches that share a hardware queue cannot overlap -- the "
+                         "row-distributed form will time out and the context will take the element form (set GPU_MAX_HW_QUEUES >= %d before the process touches the GPU)\n",
+                         g->share, q ? q : "unset (4)", g->share + 2);
     }
     for (int r = 0; r < n; ++r) g->rk[(size_t)r].th = std::thread(worker_main, g, r);
     root->group = g;

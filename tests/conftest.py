@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# Several "devices" of a multi-device context may be ONE GPU on this pool (tests/test_gpu_partition.py): the ranks' persistent launches then come from several
+# streams of one process, and the HIP runtime multiplexes a process's streams onto 4 hardware queues by default -- two launches that wait for each other on one
+# queue never overlap (the context notices: hand-off time-out -> element form).  Real devices have queues of their own; for the shared-GPU tests the runtime
+# is asked for more queues, before anything initialises it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <sstream>
 #include <string>
@@ -803,6 +804,7 @@ TEST(context_handle_test, copy_on_write_host_only) {
 }
 
 int main(int argc, char** argv) {
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);   // the sharded tests name ONE GPU several times: a hardware queue per rank launch (tests/conftest.py)
     if (argc < 2) { std::printf("usage: %s <tests/golden/mesh> [--io-only]\n", argv[0]); return 2; }
     MESH_PATH = argv[1];
     if (argc > 2 && std::string(argv[2]) == "--io-only") {   // host-side pieces of the facade: no device needed

@@ -276,3 +276,17 @@ def test_group_across_real_devices(env):
     _, info, ug, _, _ = _solve(capi, grp, nodes, cells, bnd, 1, f, op)
     assert info.converged == 1 and np.linalg.norm(ug - u1) <= 1e-9 * np.linalg.norm(u1)
     one.close(), grp.close()
+
+
+def test_random_multi_device_problems_against_the_single_device_context():
+    """tools/fuzz_group.py: 30 random problems (dimension, order, 2 - 5 "devices", form left open or pinned, constant and SPACE-VARYING operator leaves dealt to the
+    ranks by cell id, Dirichlet data none / zero / non-zero / on part of the boundary) and a random walk over the entry points (getters, assemble_operator, spmv,
+    lump, handle with given values, implicit Euler, new data, clone), every answer against the single-device context's"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_group.py"), "30", "23"], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "failures 0" in r.stdout.splitlines()[-1], r.stdout[-500:]

@@ -467,6 +467,7 @@ def test_columns_of_a_handle_solve_side_by_side(env, dim, nx, order, n_rhs):
     c.set_operator(-capi.laplacian() + capi.reaction(1.0))
     c.set_forcing(np.ones(c.quadrature_nodes().shape[0]))
     c.init()
+    c.tune("dense_rows", 0)   # (this test is about the Krylov columns: a handle asked for hundreds of columns would otherwise invert, tests/test_gpu_dense.py)
     c.lin_compute(capi.MAT_STIFF, symmetric=True)
     B = np.random.default_rng(3).standard_normal((nd, n_rhs))
     B[:, 1] = 0.0
@@ -500,6 +501,7 @@ def test_columns_of_a_non_symmetric_handle_side_by_side(env, dim, nx, n_rhs):
     c.set_operator(-capi.laplacian() + capi.advection([1.0, 0.5, 0.25][:dim]) + capi.reaction(1.0))
     c.set_forcing(np.ones(c.quadrature_nodes().shape[0]))
     c.init()
+    c.tune("dense_rows", 0)   # (the Krylov columns: see above)
     c.lin_compute(capi.MAT_STIFF, symmetric=False)
     B = np.random.default_rng(5).standard_normal((nd, n_rhs))
     B[:, 1] = 0.0

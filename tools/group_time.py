@@ -5,6 +5,9 @@ import time
 
 import numpy as np
 
+import os
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # (ranks sharing ONE GPU: a hardware queue per launch, see tests/conftest.py)
 sys.path.insert(0, ".")
 from fdapde_loader import load_package
 

@@ -892,13 +892,22 @@ int solve_run_restarting(fdapde_ctx* c, const SolveState& ss, const double* A, c
                          int method, double rtol, int maxit, int check_every, int n_timed, int gmres_budget = -1) {
     // gmres_budget: -1 no GMRES stage (the caller named a method); 0: what BiCGStab left of `maxit` (a budget the caller set is a budget for the whole
     // call); > 0: that many iterations of its own (the default budget, per stage)
+    const int64_t n = c->hs.n_dofs;
+    // Where the open method has a later stage for this system (the dense direct stage, GMRES) and no budget of the caller's, BiCGStab's own stage is
+    // capped at 2 n + 200 iterations instead of the default 10 n: a BiCGStab that has not converged by then has stalled or diverged (cell Peclet numbers
+    // of 10^2 - 10^3: relres 1e-3 ... 1e+10 after 10 n iterations, profiles/r5_gmres_probe.txt), and the budget it burnt was most of the call's time
+    // (1 089 DOFs, Pe 150: 43 ms of BiCGStab in front of a 10 ms inversion).  CG stages and budgets the caller set are untouched.
+    const bool will_bicg = method == FDAPDE_SOLVER_BICGSTAB || (method == FDAPDE_SOLVER_AUTO && !(c->op_symmetric && ss.diag_positive));
+    const bool later_stage = gmres_budget > 0 && !ss.dist && !ss.rowdist && (c->auto_gmres || dense_eligible(c));
+    const int full_maxit = maxit;
+    if (will_bicg && later_stage) maxit = (int)std::min<int64_t>(maxit, 2 * n + 200);
+    (void)full_maxit;
     int rc = solve_run(c, ss, A, f_dev, g_dev, u0_dev, method, rtol, maxit, check_every, n_timed);
     int total = c->info.iters;
-    const int64_t n = c->hs.n_dofs;
     const bool may_restart = method == FDAPDE_SOLVER_BICGSTAB || method == FDAPDE_SOLVER_AUTO;   // a method named explicitly is never replaced
     // (ranks of a multi-GPU job restart together: breakdown word, iteration count and residual come out of sums all of them hold bit for bit)
     for (int k = 0; k < kBicgRestarts && may_restart && rc == FDAPDE_ENOCONV && c->h_ctl[2] != 0 && c->info.method_used == FDAPDE_SOLVER_BICGSTAB &&
-                    total < maxit && std::isfinite(c->info.relres) && c->bicg_restart;
+                    total < maxit && std::isfinite(c->info.relres) && c->info.relres < 1e3 && c->bicg_restart;   // (an iterate 1000 x worse than zero is no start)
          ++k) {
         if (ss.rowdist)   // the iterate at the columns other ranks own: the warm start reads them
             if (int rc2 = rowdist_import_ghosts(c, ss.use_bnd ? 1 : 0, c->u.p)) return rc2;

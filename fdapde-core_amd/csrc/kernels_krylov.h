@@ -805,6 +805,7 @@ static __global__ __launch_bounds__(256) void k_bicg_fin(const double* part_ts, 
         sc[4] = sc[7], sc[5] = sc[8], sc[6] = omega, sc[3] = rr;
         ctl[1] += 1;
         if (omega == 0.0) ctl[2] = 1;
+        if (!(rr <= 1e16 * sc[0])) ctl[2] = 1;   // the residual has grown by 1e8 (or is no number): diverged -- reported like a breakdown, no point in going on
         if (rr <= tol2 * sc[0] || ctl[2]) ctl[0] = 1;
     }
 }

@@ -33,14 +33,14 @@ bool dense_eligible(const fdapde_ctx* c) {
            !c->halo_ready && !c->rd.ready;
 }
 
-// What an inversion costs, from the measured shape of k_dense_invert_blocked on MI355X (n / nb panels of two grid-wide hand-offs + nb LDS-resident pivot
-// steps, ~130 us, + a read-modify-write sweep of the n x n array at ~3 TB/s): 289 rows 2.3 ms, 1 089 rows 10 ms, 2 116 rows 28 ms, 4 225 rows 0.19 s.
+// What an inversion costs, from the measured shape of k_dense_invert_blocked on MI355X (n / nb panels, each ~6 us per pivot step + two grid-wide hand-offs
+// + 1.5 x a read-modify-write sweep of the n x n array at ~3 TB/s): 289 rows 1.4 - 2 ms, 1 089 rows 7.5 ms, 2 116 rows 20 ms, 4 225 rows 0.125 s.
 // Callers build an inverse when the Krylov time it replaces is of that order ("rent or buy": the handle after it has spent half of this on Krylov
 // columns, the stepper when its steps will).
 double dense_build_estimate_ms(int64_t n) {
-    const int64_t nb = std::max<int64_t>(1, std::min<int64_t>(kDenseNB, (int64_t)(144 * 1024) / (8 * n)));
+    const int64_t rpt = (n + kDenseTB - 1) / kDenseTB, nb = rpt <= 2 ? 16 : rpt <= 4 ? 8 : 4;
     const double sweep_us = 16.0 * (double)n * (double)n / 3.0e6;
-    return 1e-3 * (double)((n + nb - 1) / nb) * (130.0 + sweep_us) + 0.3;
+    return 1e-3 * (double)((n + nb - 1) / nb) * (6.0 * (double)nb + 10.0 + 1.5 * sweep_us) + 0.3;
 }
 
 // D.X = (the matrix A of the pattern, its Dirichlet rows replaced by unit rows if use_bnd)^-1, internal DOF order.  D.ready, or D.failed where the
@@ -53,10 +53,14 @@ int dense_build(fdapde_ctx* c, const double* A, int use_bnd, fdapde_ctx::Dense& 
     DBuf<double> S;
     DBuf<int32_t> perm, status;
     DBuf<unsigned long long> cand, worst;
-    const int G = (int)std::max<int64_t>(1, std::min<int64_t>(c->n_cu > 0 ? c->n_cu : 64, (n + 7) / 8));
+    int G = (int)std::max<int64_t>(1, std::min<int64_t>(c->n_cu > 0 ? c->n_cu : 64, (n + 7) / 8));
+    if (const char* e = std::getenv("FDAPDE_DENSE_ROWS_PER_WG")) G = (int)std::max<int64_t>(1, std::min<int64_t>(c->n_cu > 0 ? c->n_cu : 64, (n + std::atoi(e) - 1) / std::max(1, std::atoi(e))));   // (measurements)
     const int64_t ld = (n + 15) & ~int64_t(15);
-    // pivots per panel of the blocked inversion: the panel (n x nb doubles) lives in the LDS of one workgroup
-    const int nb = (int)std::min<int64_t>(kDenseNB, (int64_t)(144 * 1024) / (8 * n));
+    // pivots per panel of the blocked inversion: the panel lives in the registers of ONE workgroup (1024 threads x RPT rows x nb columns, 32 doubles
+    // per thread, 1024 threads): 16 columns up to 2 048 rows, 8 up to 4 096, 4 up to 8 192
+    const int rpt = (int)((n + kDenseTB - 1) / kDenseTB);
+    int nb = rpt <= 2 ? 16 : rpt <= 4 ? 8 : 4;
+    if (const char* e = std::getenv("FDAPDE_DENSE_NB")) nb = std::max(1, std::min(nb, std::atoi(e)));   // (measurements)
     const bool blocked = c->dense_block && nb >= 2;
     DBuf<double> S1, Mbuf, piv_d;
     DBuf<int32_t> piv_row;
@@ -83,9 +87,11 @@ int dense_build(fdapde_ctx* c, const double* A, int use_bnd, fdapde_ctx::Dense& 
         b.n = (int32_t)n, b.G = G, b.ld = (int32_t)ld, b.nb = nb, b.S0 = S.p, b.S1 = S1.p, b.perm = perm.p, b.M = Mbuf.p, b.piv_d = piv_d.p, b.piv_row = piv_row.p;
         b.done = flags.p, b.ready = flags.p + G, b.status = status.p, b.timeout_ticks = 200000000ll;
         const int rows_max = (int)((n + G - 1) / G);
-        const size_t lds = std::max(sizeof(double) * (size_t)(n | 1) * nb, sizeof(double) * (size_t)rows_max * nb + sizeof(int) * (size_t)rows_max) + 64;
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_invert_blocked), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_dense_invert_blocked, dim3((unsigned)G), dim3(kDenseT), lds, st, b);
+        const size_t lds = std::max(sizeof(double) * (size_t)rows_max * nb + sizeof(int) * (size_t)rows_max, sizeof(double) * (size_t)kDenseTB * (kDenseNB + 1)) + 64;
+        HIPCHK(c, hipFuncSetAttribute(rpt <= 2 ? reinterpret_cast<const void*>(&k_dense_invert_blocked<2, 16>) : rpt <= 4 ? reinterpret_cast<const void*>(&k_dense_invert_blocked<4, 8>) : reinterpret_cast<const void*>(&k_dense_invert_blocked<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (rpt <= 2) hipLaunchKernelGGL((k_dense_invert_blocked<2, 16>), dim3((unsigned)G), dim3(kDenseTB), lds, st, b);
+        else if (rpt <= 4) hipLaunchKernelGGL((k_dense_invert_blocked<4, 8>), dim3((unsigned)G), dim3(kDenseTB), lds, st, b);
+        else hipLaunchKernelGGL((k_dense_invert_blocked<8, 4>), dim3((unsigned)G), dim3(kDenseTB), lds, st, b);
         const int n_panels = (int)((n + nb - 1) / nb);
         result = (n_panels & 1) ? S1.p : S.p;
     } else {
@@ -218,7 +224,7 @@ void dense_set_bnd_ext(fdapde_ctx* c, const double* g_ext_dev, double* rhs) {
 
 void preload_dense() {
     hipFuncAttributes attr;
-    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_dense_invert));
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_dense_invert_blocked<2, 16>));
     (void)hipGetLastError();
 }
 

@@ -227,8 +227,13 @@ static __global__ __launch_bounds__(kDenseT) void k_dense_invert(DenseInvArgs a)
 // may still read it); two hand-offs per panel: "panel published" (one granule all workgroups poll) and "update done" (a granule per workgroup, swept
 // by workgroup 0).  Payload through sc1 stores / sc1 loads as above.  1 089 rows: 68 panels x ~45 us.
 // ---------------------------------------------------------------------------------------------------------------------------------------
+// a workgroup barrier for hand-offs through LDS only: waits for this wave's LDS traffic, not for its global stores in flight (__syncthreads waits for
+// both -- with write-through stores of the multipliers in every pivot step that was ~2 us per barrier, three barriers per step)
+__device__ __forceinline__ void dense_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr int kDenseNB = 16;    // pivots per panel at most (the panel, n x nb doubles, must fit the LDS of workgroup 0)
-constexpr int kDenseTJ = kDenseT;   // columns per tile of the update: one per thread
+constexpr int kDenseTB = 1024;  // threads of a workgroup of the blocked inversion: 2 / 4 / 8 panel rows per thread (32 doubles in registers, no spills)
+constexpr int kDenseTJ = kDenseTB;  // columns per tile of the update: one per thread
 
 struct DenseBlkArgs {
     int32_t n, G, ld, nb;
@@ -243,21 +248,18 @@ struct DenseBlkArgs {
     long long timeout_ticks;
 };
 
-static __global__ __launch_bounds__(kDenseT) void k_dense_invert_blocked(DenseBlkArgs a) {
+template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k_dense_invert_blocked(DenseBlkArgs a) {
     extern __shared__ __attribute__((aligned(16))) char dn_smem3[];
     double* buf = reinterpret_cast<double*>(dn_smem3);
-    constexpr int T = kDenseT, W = kDenseT / 64, TJ = kDenseTJ;
+    constexpr int T = kDenseTB, W = kDenseTB / 64, TJ = kDenseTJ;
     __shared__ double red_val[W];
     __shared__ int red_row[W];
     __shared__ int piv_row_s[kDenseNB], wait_s;
     __shared__ double piv_d_s[kDenseNB], prow_s[kDenseNB];
     __shared__ double Mpp[kDenseNB][kDenseNB + 1];
-    __shared__ unsigned long long used_bits[(kDenseMaxRows + 63) / 64];   // workgroup 0: rows that have been pivots
     const int n = a.n, G = a.G, NB = a.nb, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int my_rows = g < n ? (n - g + G - 1) / G : 0;
-    if (g == 0)
-        for (int w = tid; w < (n + 63) / 64; w += T) used_bits[w] = 0ull;
-    __syncthreads();
+    unsigned used_mine = 0u;   // workgroup 0: bit r = this thread's row tid + r T has been a pivot
     const int n_panels = (n + NB - 1) / NB;
     for (int P = 0; P < n_panels; ++P) {
         const int k0 = P * NB, nbp = n - k0 < NB ? n - k0 : NB;
@@ -282,83 +284,125 @@ static __global__ __launch_bounds__(kDenseT) void k_dense_invert_blocked(DenseBl
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             int failed = wait_s ? 0 : 2;
-            // the panel, COLUMN-major in LDS (pan[t * np + i]): a column search and the row updates both run over consecutive i -- conflict-free
-            // (row-major, 16 doubles per row, every lane of a wavefront fell on the same two banks: 276 us per panel of 16 at 1 089 rows)
-            const int np = n | 1;
-            double* pan = buf;
+            // The panel lives in REGISTERS: thread tid holds rows tid, tid + T, ... (RPT of them) x NBT columns.  A step is a register scan for the pivot
+            // (+ one block-wide arg-max), the pivot row's NBT values through LDS, and NBT fused multiply-adds per row and thread -- an LDS-resident panel
+            // cost 5 - 10 us per step (hundreds of LDS read-modify-writes per thread), most of an inversion's time.
             if (!failed) {
-                for (int idx = tid; idx < n * nbp; idx += T) {
-                    const int i = idx / nbp, t = idx - i * nbp;
-                    pan[t * np + i] = dense_load_shared(Scur + (int64_t)i * a.ld + k0 + t);
+                double pr[RPT][NBT];
+                // rows r T .. r T + T - 1 of the panel through an LDS slab (T x NBT doubles, row stride NBT + 1): the global side runs over consecutive
+                // addresses (NBT lanes per row: whole 128-byte lines), the register side takes a row per thread.  A thread loading / storing its own row
+                // directly put every lane of a wavefront on a different line: ~17 000 lone 8-byte write-through stores per panel.
+                double* slab = buf;
+                constexpr int SL = NBT + 1;
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) {
+                    if (r * T < n) {
+                        for (int idx = tid; idx < T * NBT; idx += T) {
+                            const int li = idx / NBT, t = idx - li * NBT, i = r * T + li;
+                            slab[li * SL + t] = (i < n && t < nbp) ? dense_load_shared(Scur + (int64_t)i * a.ld + k0 + t) : 0.0;
+                        }
+                        dense_lds_barrier();
+#pragma unroll
+                        for (int t = 0; t < NBT; ++t) pr[r][t] = slab[tid * SL + t];
+                        dense_lds_barrier();
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < NBT; ++t) pr[r][t] = 0.0;
+                    }
                 }
-                __syncthreads();
-                // block-wide arg-max of (best, best_row): the next pivot, the same in every thread
                 auto reduce_pivot = [&](double& best, int& best_row) {
                     for (int o = 32; o > 0; o >>= 1) {
                         const double ov = __shfl_xor(best, o);
                         const int orow = __shfl_xor(best_row, o);
                         if (ov > best || (ov == best && orow < best_row)) best = ov, best_row = orow;
                     }
-                    __syncthreads();   // (the previous round's readers are done with red_*)
+                    dense_lds_barrier();   // (the previous round's readers are done with red_* and prow_s)
                     if (lane == 0) red_val[wave] = best, red_row[wave] = best_row;
-                    __syncthreads();
+                    dense_lds_barrier();
                     best = red_val[0], best_row = red_row[0];
                     for (int w = 1; w < W; ++w)
                         if (red_val[w] > best || (red_val[w] == best && red_row[w] < best_row)) best = red_val[w], best_row = red_row[w];
                 };
                 double best = -1.0;
                 int best_row = 0x7fffffff;
-                for (int i = tid; i < n; i += T)
-                    if (!((used_bits[i >> 6] >> (i & 63)) & 1ull)) {
-                        const double v = fabs(pan[i]);
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) {
+                    const int i = tid + r * T;
+                    if (i < n && !((used_mine >> r) & 1u)) {
+                        const double v = fabs(pr[r][0]);
                         if (v > best || (v == best && i < best_row)) best = v, best_row = i;
                     }
+                }
                 reduce_pivot(best, best_row);
-                for (int t = 0; t < nbp; ++t) {
-                    if (best_row == 0x7fffffff || !(best > 0.0) || !isfinite(best)) {
-                        failed = 1;
-                        break;
-                    }
-                    const int p = best_row;
-                    if (tid < nbp) prow_s[tid] = pan[tid * np + p];
-                    if (tid == 0) {
-                        used_bits[p >> 6] |= 1ull << (p & 63);
-                        piv_row_s[t] = p;
-                        a.perm[k0 + t] = p;
-                    }
-                    __syncthreads();
-                    const double d = prow_s[t], inv_d = 1.0 / d;
-                    if (tid == 0) piv_d_s[t] = d;
-                    // the step on every row of the panel; the same sweep finds the next column's pivot among the rows not used yet
-                    best = -1.0, best_row = 0x7fffffff;
-                    for (int i = tid; i < n; i += T) {
-                        const double m = pan[t * np + i];
-                        dense_store(a.M + (int64_t)i * NB + t, m);
-                        if (i != p) {
-                            const double f = m * inv_d;
-                            for (int tt = 0; tt < nbp; ++tt)
-                                if (tt != t) pan[tt * np + i] -= f * prow_s[tt];
-                            pan[t * np + i] = -f;
-                            if (t + 1 < nbp && !((used_bits[i >> 6] >> (i & 63)) & 1ull)) {
-                                const double v = fabs(pan[(t + 1) * np + i]);
-                                if (v > best || (v == best && i < best_row)) best = v, best_row = i;
-                            }
+#pragma unroll
+                for (int t = 0; t < NBT; ++t) {
+                    if (t < nbp && !failed) {
+                        if (best_row == 0x7fffffff || !(best > 0.0) || !isfinite(best)) {
+                            failed = 1;
                         } else {
-                            for (int tt = 0; tt < nbp; ++tt) pan[tt * np + i] = tt == t ? inv_d : prow_s[tt] * inv_d;
+                            const int p = best_row;
+                            if (p % T == tid) {   // the pivot row's owner hands its NBT values to everybody
+                                const int rp = p / T;
+#pragma unroll
+                                for (int r = 0; r < RPT; ++r)
+                                    if (r == rp) {
+#pragma unroll
+                                        for (int tt = 0; tt < NBT; ++tt) prow_s[tt] = pr[r][tt];
+                                        used_mine |= 1u << r;
+                                    }
+                                piv_row_s[t] = p;
+                                a.perm[k0 + t] = p;
+                            }
+                            dense_lds_barrier();
+                            const double d = prow_s[t], inv_d = 1.0 / d;
+                            if (tid == 0) piv_d_s[t] = d;
+                            best = -1.0, best_row = 0x7fffffff;
+#pragma unroll
+                            for (int r = 0; r < RPT; ++r) {
+                                const int i = tid + r * T;
+                                if (i < n) {
+                                    const double m = pr[r][t];
+                                    dense_store(a.M + (int64_t)t * n + i, m);   // (column-major: a wavefront's rows are consecutive addresses)
+                                    if (i != p) {
+                                        const double f = m * inv_d;
+#pragma unroll
+                                        for (int tt = 0; tt < NBT; ++tt)
+                                            if (tt != t) pr[r][tt] -= f * prow_s[tt];
+                                        pr[r][t] = -f;
+                                        if (t + 1 < NBT && t + 1 < nbp && !((used_mine >> r) & 1u)) {
+                                            const double v = fabs(pr[r][t + 1 < NBT ? t + 1 : t]);
+                                            if (v > best || (v == best && i < best_row)) best = v, best_row = i;
+                                        }
+                                    } else {
+#pragma unroll
+                                        for (int tt = 0; tt < NBT; ++tt) pr[r][tt] = tt == t ? inv_d : prow_s[tt] * inv_d;
+                                    }
+                                }
+                            }
+                            if (t + 1 < nbp) reduce_pivot(best, best_row);
+                            else dense_lds_barrier();
                         }
                     }
-                    if (t + 1 < nbp) reduce_pivot(best, best_row);
-                    else __syncthreads();
                 }
-            }
-            if (!failed) {
-                for (int idx = tid; idx < n * nbp; idx += T) {
-                    const int i = idx / nbp, t = idx - i * nbp;
-                    dense_store(Snext + (int64_t)i * a.ld + k0 + t, pan[t * (n | 1) + i]);
-                }
-                if (tid < nbp) {
-                    dense_store(a.piv_d + tid, piv_d_s[tid]);
-                    __hip_atomic_store((dn_u32*)(a.piv_row + tid), (unsigned)piv_row_s[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!failed) {
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) {
+                        if (r * T < n) {
+#pragma unroll
+                            for (int t = 0; t < NBT; ++t) slab[tid * SL + t] = pr[r][t];
+                            dense_lds_barrier();
+                            for (int idx = tid; idx < T * NBT; idx += T) {
+                                const int li = idx / NBT, t = idx - li * NBT, i = r * T + li;
+                                if (i < n && t < nbp) dense_store(Snext + (int64_t)i * a.ld + k0 + t, slab[li * SL + t]);
+                            }
+                            dense_lds_barrier();
+                        }
+                    }
+                    __syncthreads();
+                    if (tid < nbp) {
+                        dense_store(a.piv_d + tid, piv_d_s[tid]);
+                        __hip_atomic_store((dn_u32*)(a.piv_row + tid), (unsigned)piv_row_s[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -395,11 +439,11 @@ static __global__ __launch_bounds__(kDenseT) void k_dense_invert_blocked(DenseBl
         int* pt_own = reinterpret_cast<int*>(Mown + (size_t)my_rows * NB);   // [my_rows] index of the row among the panel's pivots, or -1
         for (int idx = tid; idx < nbp * nbp; idx += T) {
             const int s_ = idx / nbp, t = idx - s_ * nbp;
-            Mpp[s_][t] = dense_load_shared(a.M + (int64_t)piv_row_s[s_] * NB + t);
+            Mpp[s_][t] = dense_load_shared(a.M + (int64_t)t * n + piv_row_s[s_]);
         }
         for (int idx = tid; idx < my_rows * nbp; idx += T) {
             const int r = idx / nbp, t = idx - r * nbp;
-            Mown[r * NB + t] = dense_load_shared(a.M + (int64_t)(g + G * r) * NB + t);
+            Mown[r * NB + t] = dense_load_shared(a.M + (int64_t)t * n + (g + G * r));
         }
         for (int r = tid; r < my_rows; r += T) {
             int pt = -1;
@@ -412,15 +456,15 @@ static __global__ __launch_bounds__(kDenseT) void k_dense_invert_blocked(DenseBl
             const int j = j0 + tid;
             const bool in_range = j < n;
             // the pivot rows' entries of this column, transformed among themselves: U_t[j]
-            double U[kDenseNB];
+            double U[NBT];
 #pragma unroll
-            for (int t = 0; t < kDenseNB; ++t) U[t] = (t < nbp && in_range) ? dense_load_shared(Scur + (int64_t)piv_row_s[t] * a.ld + j) : 0.0;
+            for (int t = 0; t < NBT; ++t) U[t] = (t < nbp && in_range) ? dense_load_shared(Scur + (int64_t)piv_row_s[t] * a.ld + j) : 0.0;
 #pragma unroll
-            for (int t = 0; t < kDenseNB; ++t)
+            for (int t = 0; t < NBT; ++t)
                 if (t < nbp) {
                     double v = U[t];
 #pragma unroll
-                    for (int s_ = 0; s_ < kDenseNB; ++s_)
+                    for (int s_ = 0; s_ < NBT; ++s_)
                         if (s_ < t) v -= Mpp[t][s_] * U[s_];
                     U[t] = v / piv_d_s[t];
                 }
@@ -433,12 +477,12 @@ static __global__ __launch_bounds__(kDenseT) void k_dense_invert_blocked(DenseBl
                 if (pt < 0) {
                     v = dense_load_shared(Scur + (int64_t)i * a.ld + j);
 #pragma unroll
-                    for (int t = 0; t < kDenseNB; ++t)
+                    for (int t = 0; t < NBT; ++t)
                         if (t < nbp) v -= mrow[t] * U[t];
                 } else {
                     v = 0.0;
 #pragma unroll
-                    for (int t = 0; t < kDenseNB; ++t)
+                    for (int t = 0; t < NBT; ++t)
                         if (t < nbp) v = t == pt ? v + U[t] : (t > pt ? v - mrow[t] * U[t] : v);
                 }
                 dense_store(Snext + (int64_t)i * a.ld + j, v);

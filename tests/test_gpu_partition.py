@@ -142,6 +142,14 @@ def test_multi_device_context_equals_the_single_device_one(env, kind, nx, order,
     assert np.abs(grp.lump(capi.MAT_MASS) - one.lump(capi.MAT_MASS)).max() <= 1e-14
     x = np.random.default_rng(3).standard_normal(nd1)
     assert np.abs(grp.spmv(capi.MAT_MASS, x) - one.spmv(capi.MAT_MASS, x)).max() <= 1e-13
+    # what the root context serves by itself: quadrature nodes, point location + basis values, cell integrals, topology
+    assert np.array_equal(grp.quadrature_nodes(), one.quadrature_nodes())
+    locs = np.random.default_rng(4).uniform(0.05, 0.95, (40, nodes.shape[1]))
+    (Pg, Dg, cg), (P1, D1, c1) = grp.eval_pointwise(locs), one.eval_pointwise(locs)
+    assert abs(Pg - P1).max() == 0.0 and np.array_equal(Dg, D1) and np.array_equal(cg, c1)
+    tg, t1 = grp.topology(), one.topology()
+    for k in t1:
+        assert np.array_equal(tg[k], t1[k]), k
     if nx <= 10 or kind == "square":   # the oracle's direct solve of the whole mesh
         m = o.Mesh(np.ascontiguousarray(nodes), np.ascontiguousarray(cells, dtype=np.int32), np.ascontiguousarray(bnd, dtype=np.uint8))
         oop = {"lap": lambda: -o.laplacian(), "adr": lambda: -o.laplacian() + o.advection(np.array([1.0, 0.5, 0.25][:nodes.shape[1]])) + o.reaction(1.0),

@@ -253,6 +253,7 @@ def test_persistent_path_under_parabolic_stepping_and_handle(env):
     rp, ci = c.pattern_get()
     M = sp.csr_matrix((c.matrix_values(capi.MAT_MASS), ci, rp), shape=(nd, nd))
     b = np.random.default_rng(3).standard_normal(nd)
+    c.tune("dense_rows", 0)   # (this file is about the Krylov launches; the dense inverse of small systems: tests/test_gpu_dense.py)
     c.lin_compute(capi.MAT_MASS, symmetric=True)
     x, info = c.lin_solve(b, rtol=1e-12)
     assert info.persistent == 1
@@ -529,6 +530,7 @@ def test_side_by_side_columns_fall_back_when_a_launch_gives_up(env):
     c.set_operator(-capi.laplacian() + capi.reaction(1.0))
     c.set_forcing(np.ones(c.quadrature_nodes().shape[0]))
     c.init()
+    c.tune("dense_rows", 0)   # (this file is about the Krylov launches; the dense inverse of small systems: tests/test_gpu_dense.py)
     c.lin_compute(capi.MAT_STIFF, symmetric=True)
     B = np.random.default_rng(4).standard_normal((nd, 6))
     X0, i0 = c.lin_solve(B, rtol=1e-11)
@@ -570,6 +572,7 @@ def test_graph_replay_is_rebuilt_when_the_blocked_layout_changes(env):
         i = c.solve(method=capi.SOLVER_CG_FUSED, rtol=1e-11, check_every=8)
         assert i.converged == 1 and i.persistent == 0
         u = c.solution()
+        c.tune("dense_rows", 0)   # (this file is about the Krylov launches; the dense inverse of small systems: tests/test_gpu_dense.py)
         c.lin_compute(capi.MAT_MASS, symmetric=True)
         x, li = c.lin_solve(b, rtol=1e-12, check_every=8)
         assert li.converged == 1
@@ -609,6 +612,7 @@ def test_direct_launch_of_a_single_right_hand_side(env, dim, nx, order):
     c.set_operator(-capi.laplacian() + capi.reaction(1.0))
     c.set_forcing(np.ones(c.quadrature_nodes().shape[0]))
     c.init()
+    c.tune("dense_rows", 0)   # (this file is about the Krylov launches; the dense inverse of small systems: tests/test_gpu_dense.py)
     c.lin_compute(capi.MAT_STIFF, symmetric=True)
     assert c.solver_layout_kind(False)["workgroups"] == 1
     b = np.random.default_rng(11).standard_normal(nd)
@@ -720,6 +724,7 @@ def test_direct_launch_against_the_oracle(env, oracle, mesh_loader, mesh, order)
     c.set_operator(-capi.laplacian() + capi.reaction(1.0))
     c.set_forcing(np.zeros(c.sizes()["n_quadrature"] * m.n_cells))
     c.init()
+    c.tune("dense_rows", 0)   # (this file is about the Krylov launches; the dense inverse of small systems: tests/test_gpu_dense.py)
     c.lin_compute(capi.MAT_STIFF)
     assert c.solver_layout_kind(False)["workgroups"] == 1
     c.tune("persist_direct", 1)

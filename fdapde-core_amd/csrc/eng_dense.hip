@@ -181,9 +181,13 @@ int dense_solve_host(fdapde_ctx* c, fdapde_ctx::Dense& D, const double* b_host, 
     // stage, product(s), hand-over: three short launches behind each other.  (Measured and dropped: the whole solve of a 289-row system as ONE
     // one-workgroup launch -- 35 us against 23: sixteen wavefronts walk eighteen rows each, latency-bound; and the last product handing the result over
     // itself through a last-arriver copy -- 33 us against 29.5 at 1 089 rows: the serial tail costs more than the launch it saves.)
-    hipLaunchKernelGGL(k_dense_stage, dim3(g1((int64_t)cnt)), dim3(256), 0, st, (int64_t)n, nc, c->dof_i2e.p, hb, c->dn_b.p, c->dn_cnt.p);
-    if (int rc = dense_apply(c, D, nc, c->dn_b.p, c->dn_x.p)) return rc;
-    hipLaunchKernelGGL(k_dense_out, dim3(g1((int64_t)cnt)), dim3(256), 0, st, (int64_t)n, nc, c->dof_e2i.p, c->dn_x.p, hx, const_cast<long long*>(done), c->dn_cnt.p);
+    if (nc == 1 && !D.refine && n <= 512 && c->dense_direct) {   // the whole solve as one launch (the right-hand side read over PCIe by every workgroup: small n only)
+        hipLaunchKernelGGL(k_dense_gemv_direct, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (int)n, D.X.p, c->dof_i2e.p, hb, hx, const_cast<long long*>(done), c->dn_cnt.p + 1);
+    } else {
+        hipLaunchKernelGGL(k_dense_stage, dim3(g1((int64_t)cnt)), dim3(256), 0, st, (int64_t)n, nc, c->dof_i2e.p, hb, c->dn_b.p, c->dn_cnt.p);
+        if (int rc = dense_apply(c, D, nc, c->dn_b.p, c->dn_x.p)) return rc;
+        hipLaunchKernelGGL(k_dense_out, dim3(g1((int64_t)cnt)), dim3(256), 0, st, (int64_t)n, nc, c->dof_e2i.p, c->dn_x.p, hx, const_cast<long long*>(done), c->dn_cnt.p);
+    }
     HIPCHK(c, hipGetLastError());
     long long seen = 0;
     if (c->persist_direct_spin_us > 0) {

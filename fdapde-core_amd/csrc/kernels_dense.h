@@ -555,6 +555,34 @@ template <int NC> static __global__ __launch_bounds__(256) void k_dense_gemv(int
     }
 }
 
+// ONE column of a very small system (<= 512 rows) as ONE launch: every workgroup reads the right-hand side straight from pinned host memory (n x 8 bytes
+// per workgroup over PCIe: 2.3 KB at 289 rows -- affordable only while n and the workgroup count are small), a wavefront per row, the result straight
+// into pinned host memory in the reference numbering, the last workgroup to arrive signals the host.  Saves the two launch seams of stage -> product -> out.
+static __global__ __launch_bounds__(256) void k_dense_gemv_direct(int n, const double* X, const int32_t* i2e, const double* b_ext, double* x_ext, long long* done,
+                                                                  unsigned int* count) {
+    __shared__ double b_s[512];
+    for (int j = threadIdx.x; j < n; j += blockDim.x) b_s[j] = b_ext[i2e[j]];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i < n) {
+        const double* row = X + (int64_t)i * n;
+        double s = 0.0;
+        for (int j = lane; j < n; j += 64) s += row[j] * b_s[j];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) x_ext[i2e[i]] = s;
+    }
+    __threadfence_system();
+    __syncthreads();
+    __shared__ unsigned int last;
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add((dn_u32*)count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __hip_atomic_store((dn_u32*)count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (ready for the next launch)
+        __threadfence_system();
+        __atomic_store_n(reinterpret_cast<volatile long long*>(done), 1ll, __ATOMIC_RELEASE);
+    }
+}
+
 // r = b - A x (the rows of k_dense_fill), nc columns
 static __global__ void k_dense_residual(int64_t n, int nc, const int32_t* rowptr, const int32_t* colidx, const double* vals, const uint8_t* bnd, int use_bnd,
                                         const double* b, const double* x, double* r) {

@@ -193,7 +193,10 @@ int cb_allreduce(void* user, double* buf, int64_t count) {
     me.ar_tmp.assign((size_t)count, 0.0);
     for (int p = 0; p < g->n; ++p) {   // ascending rank order on every rank: identical bits everywhere (the ranks take decisions on these sums)
         const GroupRank& o = g->rk[(size_t)p];
-        if (o.ar_cnt != count) return 1;
+        if (o.ar_cnt != count) {   // (ranks in different collectives: nobody may wait for the second arrival)
+            g->rdv.fail();
+            return 1;
+        }
         for (int64_t i = 0; i < count; ++i) me.ar_tmp[(size_t)i] += o.ar_buf[i];
     }
     if (!g->rdv.arrive()) return 1;   // everybody has read everybody's buffer

@@ -252,10 +252,9 @@ template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k
     extern __shared__ __attribute__((aligned(16))) char dn_smem3[];
     double* buf = reinterpret_cast<double*>(dn_smem3);
     constexpr int T = kDenseTB, W = kDenseTB / 64, TJ = kDenseTJ;
-    __shared__ double red_val[W];
-    __shared__ int red_row[W];
     __shared__ int piv_row_s[kDenseNB], wait_s;
-    __shared__ double piv_d_s[kDenseNB], prow_s[kDenseNB];
+    __shared__ double piv_d_s[kDenseNB], cand_val[2][W], cand_rows[2][W][kDenseNB];
+    __shared__ int cand_row[2][W];
     __shared__ double Mpp[kDenseNB][kDenseNB + 1];
     const int n = a.n, G = a.G, NB = a.nb, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int my_rows = g < n ? (n - g + G - 1) / G : 0;
@@ -310,19 +309,9 @@ template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k
                         for (int t = 0; t < NBT; ++t) pr[r][t] = 0.0;
                     }
                 }
-                auto reduce_pivot = [&](double& best, int& best_row) {
-                    for (int o = 32; o > 0; o >>= 1) {
-                        const double ov = __shfl_xor(best, o);
-                        const int orow = __shfl_xor(best_row, o);
-                        if (ov > best || (ov == best && orow < best_row)) best = ov, best_row = orow;
-                    }
-                    dense_lds_barrier();   // (the previous round's readers are done with red_* and prow_s)
-                    if (lane == 0) red_val[wave] = best, red_row[wave] = best_row;
-                    dense_lds_barrier();
-                    best = red_val[0], best_row = red_row[0];
-                    for (int w = 1; w < W; ++w)
-                        if (red_val[w] > best || (red_val[w] == best && red_row[w] < best_row)) best = red_val[w], best_row = red_row[w];
-                };
+                // ONE barrier per pivot step: every wavefront reduces its candidates, the lane that owns the wavefront's best row publishes value, row AND the
+                // row's NBT panel entries (arrays double-buffered by step parity); after the barrier every thread scans the W entries, knows the pivot and
+                // has the pivot row -- no second round for "who won" and "hand me the row" (three barriers per step cost 5 - 6 us of a step's 6).
                 double best = -1.0;
                 int best_row = 0x7fffffff;
 #pragma unroll
@@ -333,28 +322,45 @@ template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k
                         if (v > best || (v == best && i < best_row)) best = v, best_row = i;
                     }
                 }
-                reduce_pivot(best, best_row);
 #pragma unroll
                 for (int t = 0; t < NBT; ++t) {
                     if (t < nbp && !failed) {
-                        if (best_row == 0x7fffffff || !(best > 0.0) || !isfinite(best)) {
+                        const int par = t & 1;
+                        for (int o = 32; o > 0; o >>= 1) {
+                            const double ov = __shfl_xor(best, o);
+                            const int orow = __shfl_xor(best_row, o);
+                            if (ov > best || (ov == best && orow < best_row)) best = ov, best_row = orow;
+                        }
+                        if (best_row == 0x7fffffff) {
+                            if (lane == 0) cand_val[par][wave] = -1.0, cand_row[par][wave] = 0x7fffffff;
+                        } else if (best_row % T == tid) {
+                            cand_val[par][wave] = best, cand_row[par][wave] = best_row;
+                            const int rp = best_row / T;
+#pragma unroll
+                            for (int r = 0; r < RPT; ++r)
+                                if (r == rp) {
+#pragma unroll
+                                    for (int tt = 0; tt < NBT; ++tt) cand_rows[par][wave][tt] = pr[r][tt];
+                                }
+                        }
+                        dense_lds_barrier();
+                        double wb = cand_val[par][0];
+                        int p = cand_row[par][0], ws = 0;
+                        for (int w = 1; w < W; ++w) {
+                            const double wv = cand_val[par][w];
+                            const int wr = cand_row[par][w];
+                            if (wv > wb || (wv == wb && wr < p)) wb = wv, p = wr, ws = w;
+                        }
+                        if (p == 0x7fffffff || !(wb > 0.0) || !isfinite(wb)) {
                             failed = 1;
                         } else {
-                            const int p = best_row;
-                            if (p % T == tid) {   // the pivot row's owner hands its NBT values to everybody
-                                const int rp = p / T;
-#pragma unroll
-                                for (int r = 0; r < RPT; ++r)
-                                    if (r == rp) {
-#pragma unroll
-                                        for (int tt = 0; tt < NBT; ++tt) prow_s[tt] = pr[r][tt];
-                                        used_mine |= 1u << r;
-                                    }
+                            const double* prow = cand_rows[par][ws];   // (LDS, the same address in every lane: broadcast reads)
+                            const double d = prow[t], inv_d = 1.0 / d;
+                            if (p % T == tid) {
+                                used_mine |= 1u << (p / T);
                                 piv_row_s[t] = p;
                                 a.perm[k0 + t] = p;
                             }
-                            dense_lds_barrier();
-                            const double d = prow_s[t], inv_d = 1.0 / d;
                             if (tid == 0) piv_d_s[t] = d;
                             best = -1.0, best_row = 0x7fffffff;
 #pragma unroll
@@ -367,7 +373,7 @@ template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k
                                         const double f = m * inv_d;
 #pragma unroll
                                         for (int tt = 0; tt < NBT; ++tt)
-                                            if (tt != t) pr[r][tt] -= f * prow_s[tt];
+                                            if (tt != t) pr[r][tt] -= f * prow[tt];
                                         pr[r][t] = -f;
                                         if (t + 1 < NBT && t + 1 < nbp && !((used_mine >> r) & 1u)) {
                                             const double v = fabs(pr[r][t + 1 < NBT ? t + 1 : t]);
@@ -375,15 +381,14 @@ template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k
                                         }
                                     } else {
 #pragma unroll
-                                        for (int tt = 0; tt < NBT; ++tt) pr[r][tt] = tt == t ? inv_d : prow_s[tt] * inv_d;
+                                        for (int tt = 0; tt < NBT; ++tt) pr[r][tt] = tt == t ? inv_d : prow[tt] * inv_d;
                                     }
                                 }
                             }
-                            if (t + 1 < nbp) reduce_pivot(best, best_row);
-                            else dense_lds_barrier();
                         }
                     }
                 }
+                dense_lds_barrier();
                 if (!failed) {
 #pragma unroll
                     for (int r = 0; r < RPT; ++r) {

@@ -452,7 +452,7 @@ def _bench_form(capi, rdzv, rank, world, device, args, rtol, backend, form, shar
         # every rank generates the (deterministic) mesh itself and partitions it on its own device with the library (fdapde_partition_build): no rank 0
         # bottleneck, nothing shipped through the rendezvous directory (rounds 1-5: numpy on rank 0, 16.3 s at C3's size)
         t_gen = time.perf_counter()
-        whole = meshgen.unit_cube(args.nx)
+        whole = meshgen.unit_cube(args.nx, seed=int(getattr(args, "mesh_seed", 12345)))
         t_gen = time.perf_counter() - t_gen
         lp, t_part = rank_problem_on_device(capi, device, *whole, world, rank, form, with_node_owners=c5)
         del whole

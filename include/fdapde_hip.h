@@ -144,7 +144,9 @@ int fdapde_ctx_clone(const fdapde_ctx *src, fdapde_ctx **out);
  * fdapde_solve_parabolic / fdapde_lin_solve run on all devices at once: the row-distributed form (complete rows per owner, the whole Krylov
  * iteration as one persistent launch per device, launches exchanging through peer-mapped boards) where the library takes the system, the
  * element-partitioned neighbour exchange otherwise (the context changes form by itself).  A device may be named several times (its CUs are then
- * shared out: how the tests run 2 - 4 "devices" on one GPU).  devices[0] also keeps the whole mesh and function space for the index getters.
+ * shared out: how the tests run 2 - 8 "devices" on one GPU -- the ranks' persistent launches then need a hardware queue each: set GPU_MAX_HW_QUEUES >= n + 2
+ * in the environment before the process first touches the GPU, or the row-distributed launches time out and the context takes the element form; devices of
+ * their own have queues of their own).  devices[0] also keeps the whole mesh and function space for the index getters.
  * fdapde_ctx_clone gives another multi-device context on the same devices (the split is deterministic; the assembled and solved state travels
  * device to device, rank by rank).  Not available on such a context: fdapde_comm_*, fdapde_halo_setup*, fdapde_rowdist_setup, fdapde_partition_build,
  * fdapde_bench_spmv, fdapde_solver_layout* (FDAPDE_EUNSUPPORTED). */

@@ -94,6 +94,7 @@ void fdapde_ctx_destroy(fdapde_ctx* c) {
         c->halo_dof.release(), c->halo_pos.release(), c->owned.release(), c->hbuf.release(), c->sbuf.release();
         c->halo_inv.release(), c->if_slot.release();
         c->peer_send_dof.release(), c->peer_src_off.release(), c->peer_src.release(), c->peer_sendbuf.release(), c->peer_recvbuf.release();
+        c->xd.remote[0].release(), c->xd.remote[1].release(), c->xd.slots.release(), c->xd.slot_ptr.release();
         release_rowdist(c);
         if (c->comm) (void)g_rccl.CommDestroy(c->comm);
         c->mesh_nodes.release(), c->mesh_cells.release(), c->mesh_nbnd.release();

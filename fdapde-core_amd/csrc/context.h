@@ -315,6 +315,21 @@ struct fdapde_ctx {
                                              // else index into the receive buffer)
     DBuf<double> peer_sendbuf, peer_recvbuf;
     std::vector<double> xchg_send_h, xchg_recv_h;
+    // IN-PROCESS direct transport (the ranks of a multi-device context, eng_group.hip): every rank's buffers are addressable from every other rank's
+    // kernels (one process: the device pointers themselves, peer access between devices), so an exchange is "pack, drain the stream, all ranks arrive,
+    // fetch from the peers' buffers" -- no staging through host memory.  Send buffers and slots are double-buffered by call parity: a rank overwrites a
+    // buffer two calls after its peers read it, and they finished that read before their own next arrival.
+    struct PeerDirect {
+        bool on = false;
+        int (*arrive)(void*) = nullptr;   // every rank of the process arrives; 0 = all there
+        void* user = nullptr;
+        int parity = 0, ar_parity = 0;
+        int64_t n_send = 0;
+        DBuf<const double*> remote[2];    // per receive-buffer entry: where the peer's value lies (parity buffer of ITS send buffer)
+        DBuf<double> slots;               // this rank's published small vectors: [parity][kind: 0 halo scalars, 1 all-reduce payload][kSlotDoubles]
+        DBuf<const double*> slot_ptr;     // [world] the slots of every rank
+    } xd;
+    static constexpr int kSlotDoubles = 64;
     // "factor once, solve many" handle (fdapde::SparseLU wrapper, utils/symbols.h:133-160)
     DBuf<double> lin_mat;                    // the matrix handed to fdapde_lin_compute, internal slots
     bool lin_ready = false, lin_symmetric = false;

@@ -19,6 +19,17 @@
 namespace fdapde_engine {
 
 int allreduce_sum(fdapde_ctx* c, double* buf, size_t count) {
+    if (c->xd.on && count <= (size_t)fdapde_ctx::kSlotDoubles) {   // in-process: publish in this rank's slot, all arrive, sum the slots in rank order
+        const int par = c->xd.ar_parity;
+        c->xd.ar_parity ^= 1;
+        const int64_t off = ((int64_t)par * 2 + 1) * fdapde_ctx::kSlotDoubles;
+        HIPCHK(c, hipMemcpyAsync(c->xd.slots.p + off, buf, sizeof(double) * count, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->xd.arrive(c->xd.user) != 0) return fail(c, FDAPDE_ERCCL, "in-process transport: a rank did not arrive");
+        hipLaunchKernelGGL(k_slot_sum, dim3(1), dim3(64), 0, c->stream, c->world, (int)count, c->xd.slot_ptr.p, off, buf);
+        HIPCHK(c, hipGetLastError());
+        return FDAPDE_OK;
+    }
     if (c->ar_fn) {   // host-staged: device -> host, caller-provided sum over ranks, host -> device
         c->ar_host.resize(count);
         HIPCHK(c, hipMemcpyAsync(c->ar_host.data(), buf, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
@@ -40,6 +51,22 @@ int halo_sum_peers(fdapde_ctx* c, double* v, const double* part, int np, bool un
     const int n_peers = (int)c->peer_rank.size();
     const int64_t n_send = c->peer_off.empty() ? 0 : c->peer_off.back();
     double* scal = c->hbuf.p + c->n_if;
+    if (c->xd.on) {   // in-process direct transport: pack into this call's buffer, drain, all ranks arrive, fetch from the peers' buffers + sum the scalar slots
+        const int par = c->xd.parity;
+        c->xd.parity ^= 1;
+        const int64_t off = ((int64_t)par * 2 + 0) * fdapde_ctx::kSlotDoubles;
+        hipLaunchKernelGGL(k_peer_pack, dim3(g1(n_send > 0 ? n_send : 1)), dim3(256), 0, st, n_send, c->peer_send_dof.p, v, c->peer_sendbuf.p + (size_t)par * (size_t)c->xd.n_send,
+                           part, np, c->xd.slots.p + off);
+        HIPCHK(c, hipStreamSynchronize(st));
+        if (c->xd.arrive(c->xd.user) != 0) return fail(c, FDAPDE_ERCCL, "in-process transport: a rank did not arrive");
+        if (n_send > 0) hipLaunchKernelGGL(k_peer_fetch, dim3(g1(n_send)), dim3(256), 0, st, n_send, c->xd.remote[par].p, c->peer_recvbuf.p);
+        hipLaunchKernelGGL(k_slot_sum, dim3(1), dim3(64), 0, st, c->world, 2, c->xd.slot_ptr.p, off, scal);
+        if (c->n_loc_if > 0)
+            hipLaunchKernelGGL(k_peer_sum, dim3(g1(c->n_loc_if)), dim3(256), 0, st, c->n_loc_if, c->halo_dof.p, c->peer_src_off.p, c->peer_src.p,
+                               c->peer_recvbuf.p, v, c->hbuf.p, unpack ? 1 : 0);
+        HIPCHK(c, hipGetLastError());
+        return FDAPDE_OK;
+    }
     hipLaunchKernelGGL(k_peer_pack, dim3(g1(n_send > 0 ? n_send : 1)), dim3(256), 0, st, n_send, c->peer_send_dof.p, v, c->peer_sendbuf.p, part, np,
                        scal);
     if (c->ar_fn) {   // host-staged
@@ -280,7 +307,8 @@ int e_halo_setup_peers(fdapde_ctx* c, int32_t n_peers, const int32_t* peer_rank,
     HIPCHK(c, c->peer_send_dof.upload(send_dof.data(), send_dof.size(), st));
     HIPCHK(c, c->peer_src_off.upload(src_off.data(), src_off.size(), st));
     HIPCHK(c, c->peer_src.upload(src.data(), src.size(), st));
-    HIPCHK(c, c->peer_sendbuf.alloc((size_t)(n_send > 0 ? n_send : 1)));
+    HIPCHK(c, c->peer_sendbuf.alloc(2 * (size_t)(n_send > 0 ? n_send : 1)));   // (two parity buffers: the in-process direct transport)
+    c->xd.on = false, c->xd.n_send = n_send > 0 ? n_send : 1;
     HIPCHK(c, c->peer_recvbuf.alloc((size_t)(n_send > 0 ? n_send : 1)));
     HIPCHK(c, c->if_slot.upload(slot.data(), slot.size(), st));
     HIPCHK(c, c->halo_dof.upload(if_dof.data(), if_dof.size(), st));

@@ -103,6 +103,7 @@ struct Group {
     fdapde_ctx* root = nullptr;
     int n = 0, form = kPartitionRowdist, order = 0, share = 1;
     bool ranks_built = false, initialised = false, form_locked = false;
+    bool direct = true;   // element form: exchanges fetch from the peers' buffers (knob group_direct 0: staged through host memory)
     std::vector<GroupRank> rk;
     Rendezvous rdv;
     // worker threads: one job at a time, every rank runs it
@@ -224,6 +225,11 @@ int cb_exchange(void* user, int32_t n_peers, const int32_t* peer_rank, const int
     }
     if (!g->rdv.arrive()) return 1;
     return bad;
+}
+
+int cb_arrive(void* user) {
+    RankCookie* u = static_cast<RankCookie*>(user);
+    return u->g->rdv.arrive() ? 0 : 1;
 }
 
 inline int width_of(int kind, int N) { return kind == FDAPDE_DIFFUSION ? N * N : kind == FDAPDE_ADVECTION ? N : 1; }
@@ -390,6 +396,54 @@ int build_ranks(Group* g) {
             return e_halo_setup_peers(c, (int32_t)pr.size(), pr.data(), po.data(), pd.data(), R.owned.data());
         });
         if (rc_all != FDAPDE_OK) return rc_all;
+        // ---- the in-process DIRECT transport of the element form (eng_dist.hip PeerDirect): every rank learns where, in its peers' send buffers, the values
+        //      destined for it lie, and where every rank publishes its small vectors -- an exchange is then pack, drain, arrive, fetch; nothing is staged
+        //      through host memory (the host-staged callbacks stay registered for the set-up collectives and as the fall-back: knob group_direct 0)
+        if (g->direct) {
+            rc_all = run_all(g, [&](int r) -> int {
+                fdapde_ctx* c = g->rk[(size_t)r].ctx;
+                HIPCHK(c, hipSetDevice(c->device));
+                HIPCHK(c, c->xd.slots.alloc(4 * (size_t)fdapde_ctx::kSlotDoubles));
+                HIPCHK(c, hipMemsetAsync(c->xd.slots.p, 0, sizeof(double) * 4 * (size_t)fdapde_ctx::kSlotDoubles, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                return FDAPDE_OK;
+            });
+            if (rc_all != FDAPDE_OK) return rc_all;
+            rc_all = run_all(g, [&](int r) -> int {
+                GroupRank& R = g->rk[(size_t)r];
+                fdapde_ctx* c = R.ctx;
+                HIPCHK(c, hipSetDevice(c->device));
+                for (int q = 0; q < n; ++q)
+                    if (g->rk[(size_t)q].device != R.device) {
+                        const hipError_t e = hipDeviceEnablePeerAccess(g->rk[(size_t)q].device, 0);
+                        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(c, FDAPDE_EHIP, "hipDeviceEnablePeerAccess failed");
+                        (void)hipGetLastError();
+                    }
+                const int64_t n_send = c->peer_off.empty() ? 0 : c->peer_off.back();
+                for (int par = 0; par < 2; ++par) {
+                    std::vector<const double*> rem((size_t)std::max<int64_t>(n_send, 1), nullptr);
+                    for (size_t qi = 0; qi < c->peer_rank.size(); ++qi) {
+                        const fdapde_ctx* qc = g->rk[(size_t)c->peer_rank[qi]].ctx;
+                        int j = -1;
+                        for (size_t k = 0; k < qc->peer_rank.size(); ++k)
+                            if (qc->peer_rank[k] == r) j = (int)k;
+                        const int64_t cnt = c->peer_off[qi + 1] - c->peer_off[qi];
+                        if (j < 0 || qc->peer_off[(size_t)j + 1] - qc->peer_off[(size_t)j] != cnt) return fail(c, FDAPDE_EINVAL, "multi-device context: the peers' exchange lists do not match");
+                        const double* base = qc->peer_sendbuf.p + (size_t)par * (size_t)qc->xd.n_send + qc->peer_off[(size_t)j];
+                        for (int64_t k = 0; k < cnt; ++k) rem[(size_t)(c->peer_off[qi] + k)] = base + k;
+                    }
+                    HIPCHK(c, c->xd.remote[par].upload(rem.data(), rem.size(), c->stream));
+                    HIPCHK(c, hipStreamSynchronize(c->stream));   // (rem is a local)
+                }
+                std::vector<const double*> slots((size_t)n);
+                for (int q = 0; q < n; ++q) slots[(size_t)q] = g->rk[(size_t)q].ctx->xd.slots.p;
+                HIPCHK(c, c->xd.slot_ptr.upload(slots.data(), slots.size(), c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                c->xd.arrive = &cb_arrive, c->xd.user = R.cb_user, c->xd.parity = c->xd.ar_parity = 0, c->xd.on = true;
+                return FDAPDE_OK;
+            });
+            if (rc_all != FDAPDE_OK) return rc_all;
+        }
     }
     g->t_rank_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
     g->ranks_built = true;
@@ -972,6 +1026,11 @@ int g_tune(fdapde_ctx* root, const char* key, int32_t value) {
     Group* g = group_of(root);
     if (int rc = need_ranks(g)) return rc;
     const std::string k(key);
+    if (k == "group_direct" && (value == 0 || value == 1)) {   // (measurements: the element form's exchange direct or host-staged)
+        g->direct = value != 0;
+        for (GroupRank& R : g->rk) R.ctx->xd.on = g->direct && g->form == kPartitionElements && R.ctx->xd.slot_ptr.p != nullptr;
+        return FDAPDE_OK;
+    }
     if (k == "group_form" && (value == 0 || value == 1)) {   // tests / measurements: the form, fixed
         g->form_locked = true;
         if (value != g->form) return change_form(g, value);

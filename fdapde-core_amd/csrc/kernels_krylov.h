@@ -852,6 +852,19 @@ static __global__ __launch_bounds__(256) void k_peer_pack(int64_t n_send, const 
         if (threadIdx.x == 0) scal[0] = sa, scal[1] = sb;
     }
 }
+// in-process direct transport: the receive buffer straight from the peers' send buffers (device pointers, one per entry)
+static __global__ void k_peer_fetch(int64_t n, const double* const* src, double* dst) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) dst[j] = *src[j];
+}
+// ... and a small vector summed over the ranks' slots in ascending rank order (every rank computes the same bits)
+static __global__ void k_slot_sum(int world, int count, const double* const* slot, int64_t offset, double* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    double s = 0.0;
+    for (int r = 0; r < world; ++r) s += slot[r][offset + i];
+    out[i] = s;
+}
 // summed value of every local interface DOF: the contributions of the ranks sharing it added in ASCENDING RANK ORDER (this rank's own
 // among them), so that every sharer computes the same bits; buf[k] for the kernels that read interface rows from there, v on request
 static __global__ void k_peer_sum(int64_t n_loc_if, const int32_t* dof, const int32_t* src_off, const int32_t* src, const double* recvbuf, double* v,

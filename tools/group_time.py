@@ -27,6 +27,9 @@ for n in devs:
     c.mesh_upload(nodes, cells, bnd)
     t2 = time.perf_counter()
     nd = c.dofs_build(1)
+    if n > 1 and os.environ.get("GROUP_FORM"):   # (measurements: the form pinned; GROUP_DIRECT=0: the element form's exchange staged through host memory)
+        c.tune("group_direct", int(os.environ.get("GROUP_DIRECT", "1")))
+        c.tune("group_form", int(os.environ["GROUP_FORM"]))
     t3 = time.perf_counter()
     c.set_operator(-capi.laplacian())
     fq = f(c.quadrature_nodes())

@@ -21,10 +21,19 @@ __global__ void k_dense_rhs(int64_t n, const double* f, const double* g, const u
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) rhs[i] = (use_bnd && bnd[i]) ? g[i] : f[i];
 }
-// rhs[i] = g_ext[i2e[i]] on the Dirichlet DOFs (g handed over in the reference numbering)
-__global__ void k_dense_bnd_ext(int64_t n, const double* g_ext, const int32_t* i2e, const uint8_t* bnd, double* rhs) {
+// one implicit Euler step's right-hand side: rhs = (M u_i) / dt + f_{i+1}, and g(., i + 1) on the Dirichlet DOFs (g handed over in the reference numbering;
+// fem_linear_parabolic_solver.h:60-66)
+__global__ void k_dense_step_rhs(int64_t n, const double* mu, double inv_dt, const double* f, const double* g_ext, const int32_t* i2e, const uint8_t* bnd, double* rhs) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && bnd[i]) rhs[i] = g_ext[i2e[i]];
+    if (i < n) rhs[i] = (g_ext && bnd[i]) ? g_ext[i2e[i]] : mu[i] * inv_dt + f[i];
+}
+// ... and what follows the product: u_{i+1} becomes the next step's u_i and column i + 1 of the solution (reference numbering)
+__global__ void k_dense_step_out(int64_t n, const double* u, const int32_t* i2e, double* uprev, double* sol_ext) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const double v = u[i];
+        uprev[i] = v, sol_ext[i2e[i]] = v;
+    }
 }
 }   // namespace
 
@@ -220,10 +229,14 @@ int dense_direct(fdapde_ctx* c, const double* A, int use_bnd, const double* f_de
     return FDAPDE_OK;
 }
 
-// Dirichlet values handed over in the reference numbering onto the boundary rows of a right-hand side (the parabolic stepper's dense loop)
-void dense_set_bnd_ext(fdapde_ctx* c, const double* g_ext_dev, double* rhs) {
+// the two fused kernels around the product of one step of the parabolic stepper's dense loop
+void dense_step_rhs(fdapde_ctx* c, const double* mu, double inv_dt, const double* f, const double* g_ext_dev, double* rhs) {
     const int64_t n = c->hs.n_dofs;
-    hipLaunchKernelGGL(k_dense_bnd_ext, dim3(g1(n)), dim3(256), 0, c->stream, n, g_ext_dev, c->dof_i2e.p, c->bnd.p, rhs);
+    hipLaunchKernelGGL(k_dense_step_rhs, dim3(g1(n)), dim3(256), 0, c->stream, n, mu, inv_dt, f, g_ext_dev, c->dof_i2e.p, c->bnd.p, rhs);
+}
+void dense_step_out(fdapde_ctx* c, const double* u, double* uprev, double* sol_ext_dev) {
+    const int64_t n = c->hs.n_dofs;
+    hipLaunchKernelGGL(k_dense_step_out, dim3(g1(n)), dim3(256), 0, c->stream, n, u, c->dof_i2e.p, uprev, sol_ext_dev);
 }
 
 void preload_dense() {

@@ -1172,11 +1172,9 @@ int e_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times,
             HIPCHK(c, hipStreamSynchronize(st));   // (tmp is pageable)
             for (int32_t i = 0; i + 1 < n_times; ++i) {
                 launch_spmv(c, c->vals[FDAPDE_MAT_MASS].p, uprev.p, c->s.p, nullptr, nullptr, nullptr);   // M u_i
-                hipLaunchKernelGGL(k_parabolic_rhs, dim3(g1(n)), dim3(256), 0, st, n, c->s.p, inv_dt, c->force.p + (size_t)(i + 1) * n, rhs.p);
-                if (dirichlet) dense_set_bnd_ext(c, d_dir.p + (size_t)(i + 1) * n, rhs.p);   // rhs[boundary] = g(., i + 1) (line 66)
+                dense_step_rhs(c, c->s.p, inv_dt, c->force.p + (size_t)(i + 1) * n, dirichlet ? d_dir.p + (size_t)(i + 1) * n : nullptr, rhs.p);   // (+ rhs[boundary] = g(., i + 1), line 66)
                 if (int rc = dense_apply(c, D, 1, rhs.p, c->u.p)) return rc;
-                HIPCHK(c, hipMemcpyAsync(uprev.p, c->u.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
-                hipLaunchKernelGGL(k_scatter_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->u.p, d_sol.p + (size_t)(i + 1) * n);
+                dense_step_out(c, c->u.p, uprev.p, d_sol.p + (size_t)(i + 1) * n);
             }
             HIPCHK(c, hipGetLastError());
             HIPCHK(c, hipMemcpyAsync(solution + (size_t)n, d_sol.p + (size_t)n, sizeof(double) * (size_t)n * (cols - 1), hipMemcpyDeviceToHost, st));

@@ -145,7 +145,8 @@ int dense_build(fdapde_ctx* c, const double* A, int use_bnd, fdapde_ctx::Dense& 
 int dense_apply(fdapde_ctx* c, fdapde_ctx::Dense& D, int nc, const double* b, double* x);
 int dense_solve_host(fdapde_ctx* c, fdapde_ctx::Dense& D, const double* b_host, int nc, double* x_host);
 int dense_direct(fdapde_ctx* c, const double* A, int use_bnd, const double* f_dev, const double* g_dev, bool* solved);
-void dense_set_bnd_ext(fdapde_ctx* c, const double* g_ext_dev, double* rhs);
+void dense_step_rhs(fdapde_ctx* c, const double* mu, double inv_dt, const double* f, const double* g_ext_dev, double* rhs);
+void dense_step_out(fdapde_ctx* c, const double* u, double* uprev, double* sol_ext_dev);
 void preload_dense();
 
 // code objects of the units loaded up front (fdapde_ctx_create)

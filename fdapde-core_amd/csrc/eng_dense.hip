@@ -47,7 +47,7 @@ bool dense_eligible(const fdapde_ctx* c) {
 // Callers build an inverse when the Krylov time it replaces is of that order ("rent or buy": the handle after it has spent half of this on Krylov
 // columns, the stepper when its steps will).
 double dense_build_estimate_ms(int64_t n) {
-    const int64_t rpt = (n + kDenseTB - 1) / kDenseTB, nb = rpt <= 2 ? 16 : rpt <= 4 ? 8 : 4;
+    const int64_t rpt = (n + kDenseTB - 1) / kDenseTB, nb = rpt <= 4 ? 16 : rpt <= 8 ? 8 : 4;
     const double sweep_us = 16.0 * (double)n * (double)n / 3.0e6;
     return 1e-3 * (double)((n + nb - 1) / nb) * (6.0 * (double)nb + 10.0 + 1.5 * sweep_us) + 0.3;
 }
@@ -62,18 +62,19 @@ int dense_build(fdapde_ctx* c, const double* A, int use_bnd, fdapde_ctx::Dense& 
     DBuf<double> S;
     DBuf<int32_t> perm, status;
     DBuf<unsigned long long> cand, worst;
-    int G = (int)std::max<int64_t>(1, std::min<int64_t>(c->n_cu > 0 ? c->n_cu : 64, (n + 7) / 8));
+    int G = (int)std::max<int64_t>(1, std::min<int64_t>(c->n_cu > 0 ? c->n_cu : 64, (n + 7) / 8));   // (pivot by pivot: row i lives with workgroup i mod G)
     if (const char* e = std::getenv("FDAPDE_DENSE_ROWS_PER_WG")) G = (int)std::max<int64_t>(1, std::min<int64_t>(c->n_cu > 0 ? c->n_cu : 64, (n + std::atoi(e) - 1) / std::max(1, std::atoi(e))));   // (measurements)
     const int64_t ld = (n + 15) & ~int64_t(15);
-    // pivots per panel of the blocked inversion: the panel lives in the registers of ONE workgroup (1024 threads x RPT rows x nb columns, 32 doubles
-    // per thread, 1024 threads): 16 columns up to 2 048 rows, 8 up to 4 096, 4 up to 8 192
+    // pivots per panel of the blocked inversion: the panel lives in the registers of ONE workgroup (512 threads x RPT rows x nb columns, at most 64 doubles
+    // per thread): 16 columns up to 2 048 rows, 8 up to 4 096, 4 up to 8 192
     const int rpt = (int)((n + kDenseTB - 1) / kDenseTB);
-    int nb = rpt <= 2 ? 16 : rpt <= 4 ? 8 : 4;
+    int nb = rpt <= 4 ? 16 : rpt <= 8 ? 8 : 4;
     if (const char* e = std::getenv("FDAPDE_DENSE_NB")) nb = std::max(1, std::min(nb, std::atoi(e)));   // (measurements)
     const bool blocked = c->dense_block && nb >= 2;
-    DBuf<double> S1, Mbuf, piv_d;
+    DBuf<double> S1;
     DBuf<int32_t> piv_row;
     DBuf<unsigned long long> flags;
+    DBuf<long long> stamps;
     HIPCHK(c, S.alloc((size_t)n * (size_t)ld));
     HIPCHK(c, D.X.alloc((size_t)n * n));
     HIPCHK(c, perm.alloc((size_t)n));
@@ -87,20 +88,38 @@ int dense_build(fdapde_ctx* c, const double* A, int use_bnd, fdapde_ctx::Dense& 
     const double* result = S.p;
     if (blocked) {
         HIPCHK(c, S1.alloc((size_t)n * (size_t)ld));
-        HIPCHK(c, Mbuf.alloc((size_t)n * kDenseNB));
-        HIPCHK(c, piv_d.alloc(kDenseNB));
         HIPCHK(c, piv_row.alloc(kDenseNB));
+        // the update's grid: R x C blocks of the matrix, one workgroup each (all co-resident: <= one per CU) -- about 8 column tiles of 16 per block (one
+        // per wavefront) and 4 row tiles (one batch of loads in flight)
+        const int n_tiles = (int)((n + 15) / 16), cus = c->n_cu > 0 ? c->n_cu : 64;
+        int C = std::max(1, std::min(16, (n_tiles + 7) / 8));
+        int R = std::max(1, std::min(cus / C, (n_tiles + 3) / 4));
+        if (const char* e = std::getenv("FDAPDE_DENSE_GRID")) {   // "R,C" (measurements)
+            int r_ = 0, c_ = 0;
+            if (std::sscanf(e, "%d,%d", &r_, &c_) == 2 && r_ >= 1 && c_ >= 1 && r_ * c_ <= cus) R = r_, C = c_;
+        }
+        const int RB = 16 * ((n_tiles + R - 1) / R), CB = 16 * ((n_tiles + C - 1) / C);
+        R = (int)((n + RB - 1) / RB), C = (int)((n + CB - 1) / CB);   // (the blocks in use)
+        G = R * C;
         HIPCHK(c, flags.alloc((size_t)G + 2));
         HIPCHK(c, hipMemsetAsync(flags.p, 0, ((size_t)G + 2) * sizeof(unsigned long long), st));
         DenseBlkArgs b{};
-        b.n = (int32_t)n, b.G = G, b.ld = (int32_t)ld, b.nb = nb, b.S0 = S.p, b.S1 = S1.p, b.perm = perm.p, b.M = Mbuf.p, b.piv_d = piv_d.p, b.piv_row = piv_row.p;
+        b.n = (int32_t)n, b.G = G, b.ld = (int32_t)ld, b.nb = nb, b.C = C, b.RB = RB, b.CB = CB, b.S0 = S.p, b.S1 = S1.p, b.perm = perm.p, b.piv_row = piv_row.p;
         b.done = flags.p, b.ready = flags.p + G, b.status = status.p, b.timeout_ticks = 200000000ll;
-        const int rows_max = (int)((n + G - 1) / G);
-        const size_t lds = std::max(sizeof(double) * (size_t)rows_max * nb + sizeof(int) * (size_t)rows_max, sizeof(double) * (size_t)kDenseTB * (kDenseNB + 1)) + 64;
-        HIPCHK(c, hipFuncSetAttribute(rpt <= 2 ? reinterpret_cast<const void*>(&k_dense_invert_blocked<2, 16>) : rpt <= 4 ? reinterpret_cast<const void*>(&k_dense_invert_blocked<4, 8>) : reinterpret_cast<const void*>(&k_dense_invert_blocked<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (rpt <= 2) hipLaunchKernelGGL((k_dense_invert_blocked<2, 16>), dim3((unsigned)G), dim3(kDenseTB), lds, st, b);
-        else if (rpt <= 4) hipLaunchKernelGGL((k_dense_invert_blocked<4, 8>), dim3((unsigned)G), dim3(kDenseTB), lds, st, b);
-        else hipLaunchKernelGGL((k_dense_invert_blocked<8, 4>), dim3((unsigned)G), dim3(kDenseTB), lds, st, b);
+        if (std::getenv("FDAPDE_DENSE_STAMPS")) {   // (measurements)
+            HIPCHK(c, stamps.alloc(32));
+            HIPCHK(c, hipMemsetAsync(stamps.p, 0, 32 * sizeof(long long), st));
+            b.stamps = stamps.p;
+        }
+        const size_t lds = std::max(sizeof(double) * (size_t)RB * 16 + sizeof(int) * (size_t)RB, sizeof(double) * (size_t)kDenseTB * (kDenseNB + 1)) + 64;
+        const void* fn = rpt <= 2   ? reinterpret_cast<const void*>(&k_dense_invert_blocked<2, 16>)
+                         : rpt <= 3 ? reinterpret_cast<const void*>(&k_dense_invert_blocked<3, 16>)
+                         : rpt <= 4 ? reinterpret_cast<const void*>(&k_dense_invert_blocked<4, 16>)
+                         : rpt <= 8 ? reinterpret_cast<const void*>(&k_dense_invert_blocked<8, 8>)
+                                    : reinterpret_cast<const void*>(&k_dense_invert_blocked<16, 4>);
+        HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        void* kargs[] = {&b};
+        HIPCHK(c, hipLaunchKernel(fn, dim3((unsigned)G), dim3(kDenseTB), kargs, lds, st));
         const int n_panels = (int)((n + nb - 1) / nb);
         result = (n_panels & 1) ? S1.p : S.p;
     } else {
@@ -123,6 +142,14 @@ int dense_build(fdapde_ctx* c, const double* A, int use_bnd, fdapde_ctx::Dense& 
     std::memcpy(&chk, &h_worst, sizeof chk);
     D.check = chk;
     D.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (stamps.p) {
+        long long h[32];
+        HIPCHK(c, hipMemcpy(h, stamps.p, sizeof h, hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "dense inverse, panel 8 (us from 'previous panel done'): workgroup 0: gathered %.1f factorised %.1f written %.1f seen %.1f multipliers %.1f update issued %.1f drained %.1f | workgroup 1: seen %.1f multipliers %.1f issued %.1f drained %.1f\n",
+                     0.01 * (h[1] - h[0]), 0.01 * (h[2] - h[0]), 0.01 * (h[3] - h[0]), 0.01 * (h[4] - h[0]), 0.01 * (h[5] - h[0]), 0.01 * (h[6] - h[0]), 0.01 * (h[7] - h[0]),
+                     0.01 * (h[12] - h[0]), 0.01 * (h[13] - h[0]), 0.01 * (h[14] - h[0]), 0.01 * (h[15] - h[0]));
+        std::fprintf(stderr, "  pivot step 5 (us from its start): own candidate %.2f barrier %.2f pivot known %.2f pivot row read %.2f rows updated %.2f\n", 0.01 * (h[17] - h[16]), 0.01 * (h[18] - h[16]), 0.01 * (h[19] - h[16]), 0.01 * (h[20] - h[16]), 0.01 * (h[21] - h[16]));
+    }
     if (std::getenv("FDAPDE_DEBUG_SETUP"))
         std::fprintf(stderr, "dense inverse: %lld rows, %d workgroups, %s (nb %d), status %d, max |I - A X| = %.3e, %.2f ms\n", (long long)n, G, blocked ? "blocked" : "pivot by pivot", nb, h_status[0], chk, D.build_ms);
     if (h_status[0] != 0 || !(chk < 1e-6)) {   // singular / timed out / an inverse too poor for one refinement step to repair

@@ -26,6 +26,8 @@
 
 #include <cstdint>
 
+#include "kernels_reduce.h"
+
 namespace fdapde_hip {
 
 constexpr int kDenseT = 512;        // threads of an inversion workgroup (8 wavefronts: 8 rows in flight)
@@ -232,38 +234,97 @@ static __global__ __launch_bounds__(kDenseT) void k_dense_invert(DenseInvArgs a)
 __device__ __forceinline__ void dense_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 constexpr int kDenseNB = 16;    // pivots per panel at most (the panel, n x nb doubles, must fit the LDS of workgroup 0)
-constexpr int kDenseTB = 1024;  // threads of a workgroup of the blocked inversion: 2 / 4 / 8 panel rows per thread (32 doubles in registers, no spills)
+constexpr int kDenseTB = 512;   // threads of a workgroup of the blocked inversion: 8 wavefronts, 2 per SIMD -- 256 vector registers each: the panel (up to 64 doubles per
+                                // thread) AND a pivot step's working set stay in registers.  (1 024 threads: 128 registers, spills whose reloads' s_waitcnt vmcnt(0) also
+                                // waited for the step's write-through stores -- 3.7 us per pivot step; 256 threads: five panel rows per thread at 1 089 rows.)
 constexpr int kDenseTJ = kDenseTB;  // columns per tile of the update: one per thread
 
 struct DenseBlkArgs {
     int32_t n, G, ld, nb;
+    int32_t C, RB, CB;             // the update's grid of blocks: G = R x C workgroups, RB rows x CB columns each (multiples of 16)
     double *S0, *S1;               // panel P reads S(P & 1), writes the other
     int32_t* perm;                 // [n] pivot row of column k
-    double* M;                     // [n x nb] multipliers of the current panel
-    double* piv_d;                 // [nb]
     int32_t* piv_row;              // [nb]
     unsigned long long* done;      // [G] granule per workgroup: panels whose update it has finished
     unsigned long long* ready;     // [1] (panels published << 1) | failed
     int32_t* status;               // [0] 1 = singular, 2 = a wait timed out
     long long timeout_ticks;
+    long long* stamps;             // diagnostic (FDAPDE_DENSE_STAMPS): s_memrealtime at the phase boundaries of panel 8, [0..7] workgroup 0, [8..15] workgroup 1; or null
 };
+
+// payload loads / stores of the blocked inversion: BUFFER instructions with the sc1 bit (aux 16).  Against the 8-byte atomics above they (a) address
+// through a resource in scalar registers + a 32-bit offset (the atomics' 64-bit addresses, hoisted out of the unrolled pivot steps, filled 64 vector
+// registers, spilled, and every reload's s_waitcnt vmcnt(0) then also waited for the previous step's write-through stores: 2 of a step's 3.7 us) and
+// (b) are ordinary memory operations to the compiler: it issues a batch of loads back to back instead of one round trip per load.
+typedef unsigned int dn_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double dense_bload(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    const dn_v2u x = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 16);
+    return __longlong_as_double((long long)(((unsigned long long)x[1] << 32) | x[0]));
+}
+__device__ __forceinline__ void dense_bstore(__amdgpu_buffer_rsrc_t rs, int voff, int soff, double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    dn_v2u x;
+    x[0] = (unsigned)b, x[1] = (unsigned)(b >> 32);
+    __builtin_amdgcn_raw_buffer_store_b64(x, rs, voff, soff, 16);
+}
+// maximum / minimum over the wavefront in every lane, on the VALU (permlane swaps + DPP: kernels_reduce.h) -- a __shfl_xor butterfly of (value, row)
+// is 18 ds_bpermute per pivot step
+__device__ __forceinline__ double dense_wave_max(double v) {
+    {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)b, (unsigned)b, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+        v = fmax(__longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0])), __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1])));
+    }
+    {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)b, (unsigned)b, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(b >> 32), (unsigned)(b >> 32), false, false);
+        v = fmax(__longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0])), __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1])));
+    }
+    v = fmax(v, reduce_dpp_f64<0x128>(v));
+    v = fmax(v, reduce_dpp_f64<0x124>(v));
+    v = fmax(v, reduce_dpp_f64<0x4E>(v));
+    v = fmax(v, reduce_dpp_f64<0xB1>(v));
+    return v;
+}
+__device__ __forceinline__ int dense_wave_min(int v) {
+    auto s = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    v = min((int)s[0], (int)s[1]);
+    s = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    v = min((int)s[0], (int)s[1]);
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false));
+    return v;
+}
 
 template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k_dense_invert_blocked(DenseBlkArgs a) {
     extern __shared__ __attribute__((aligned(16))) char dn_smem3[];
     double* buf = reinterpret_cast<double*>(dn_smem3);
-    constexpr int T = kDenseTB, W = kDenseTB / 64, TJ = kDenseTJ;
+    constexpr int T = kDenseTB, W = kDenseTB / 64;
+    static_assert(W <= 64, "the pivot scan below reads a candidate per lane");
     __shared__ int piv_row_s[kDenseNB], wait_s;
-    __shared__ double piv_d_s[kDenseNB], cand_val[2][W], cand_rows[2][W][kDenseNB];
-    __shared__ int cand_row[2][W];
-    __shared__ double Mpp[kDenseNB][kDenseNB + 1];
-    const int n = a.n, G = a.G, NB = a.nb, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int my_rows = g < n ? (n - g + G - 1) / G : 0;
+    __shared__ __attribute__((aligned(16))) double cand_val[2][W], cand_rows[2][W][kDenseNB];
+    __shared__ __attribute__((aligned(16))) int cand_row[2][W];
+    const int n = a.n, G = a.G, NB = a.nb, ld = a.ld, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // this workgroup's block of the update: rows [i0, i0 + nr) x columns [j0, j0 + nc) (empty blocks only take part in the hand-offs)
+    const int i0 = (g / a.C) * a.RB, j0 = (g % a.C) * a.CB;
+    const int nr = i0 < n && j0 < n ? (n - i0 < a.RB ? n - i0 : a.RB) : 0, nc = i0 < n && j0 < n ? (n - j0 < a.CB ? n - j0 : a.CB) : 0;
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(a.S0, 0, n * ld * 8, 0x00020000);   // (<= 8 192 x 8 192 doubles: 2^29 bytes)
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(a.S1, 0, n * ld * 8, 0x00020000);
     unsigned used_mine = 0u;   // workgroup 0: bit r = this thread's row tid + r T has been a pivot
     const int n_panels = (n + NB - 1) / NB;
+    auto sstamp = [&](int P, int t, int slot) {   // inside pivot step 5 of panel 8
+        if (a.stamps && P == 8 && t == 5 && tid == 0 && g == 0) a.stamps[16 + slot] = (long long)__builtin_amdgcn_s_memrealtime();
+    };
+    auto stamp = [&](int P, int slot) {
+        if (a.stamps && P == 8 && tid == 0 && g < 2) a.stamps[g * 8 + slot] = (long long)__builtin_amdgcn_s_memrealtime();
+    };
     for (int P = 0; P < n_panels; ++P) {
         const int k0 = P * NB, nbp = n - k0 < NB ? n - k0 : NB;
-        const double* Scur = (P & 1) ? a.S1 : a.S0;
-        double* Snext = (P & 1) ? a.S0 : a.S1;
+        const __amdgpu_buffer_rsrc_t rs_cur = (P & 1) ? rs1 : rs0, rs_next = (P & 1) ? rs0 : rs1;
         if (g == 0) {
             // ---- every workgroup has finished the update of panel P - 1
             if (wave == 0) {
@@ -283,40 +344,66 @@ template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             int failed = wait_s ? 0 : 2;
+            stamp(P, 0);   // every workgroup done with the previous panel
             // The panel lives in REGISTERS: thread tid holds rows tid, tid + T, ... (RPT of them) x NBT columns.  A step is a register scan for the pivot
             // (+ one block-wide arg-max), the pivot row's NBT values through LDS, and NBT fused multiply-adds per row and thread -- an LDS-resident panel
             // cost 5 - 10 us per step (hundreds of LDS read-modify-writes per thread), most of an inversion's time.
             if (!failed) {
+                // (an opaque copy of the thread index: everything derived from tid below is loop-invariant, and hoisted out of the panel loop it fills a
+                // hundred registers that are then spilled and reloaded inside every pivot step)
+                int ft = tid;
+                asm volatile("" : "+v"(ft));
                 double pr[RPT][NBT];
                 // rows r T .. r T + T - 1 of the panel through an LDS slab (T x NBT doubles, row stride NBT + 1): the global side runs over consecutive
                 // addresses (NBT lanes per row: whole 128-byte lines), the register side takes a row per thread.  A thread loading / storing its own row
                 // directly put every lane of a wavefront on a different line: ~17 000 lone 8-byte write-through stores per panel.
                 double* slab = buf;
                 constexpr int SL = NBT + 1;
+                constexpr int GR = 32 / NBT < RPT ? 32 / NBT : RPT;   // row blocks whose loads are in flight together (32 loads per thread: a trip over the fabric per group)
 #pragma unroll
-                for (int r = 0; r < RPT; ++r) {
-                    if (r * T < n) {
-                        for (int idx = tid; idx < T * NBT; idx += T) {
-                            const int li = idx / NBT, t = idx - li * NBT, i = r * T + li;
-                            slab[li * SL + t] = (i < n && t < nbp) ? dense_load_shared(Scur + (int64_t)i * a.ld + k0 + t) : 0.0;
+                for (int r0 = 0; r0 < RPT; r0 += GR) {
+                    asm volatile("" ::: "memory");   // (the next group's loads stay behind this group: GR x NBT values in registers, not RPT x NBT)
+                    double tmp[GR][NBT];
+#pragma unroll
+                    for (int u = 0; u < GR; ++u) {
+#pragma unroll
+                        for (int q = 0; q < NBT; ++q) {
+                            const int idx = ft + q * T, li = idx / NBT, t = idx - li * NBT, i = (r0 + u) * T + li;
+                            const double v = dense_bload(rs_cur, ((i < n ? i : 0) * ld + k0 + t) * 8, 0);
+                            tmp[u][q] = (r0 + u < RPT && i < n && t < nbp) ? v : 0.0;
                         }
-                        dense_lds_barrier();
+                    }
 #pragma unroll
-                        for (int t = 0; t < NBT; ++t) pr[r][t] = slab[tid * SL + t];
-                        dense_lds_barrier();
-                    } else {
+                    for (int u = 0; u < GR; ++u) {
+                        const int r = r0 + u;
+                        if (r < RPT) {
+                            if (r * T < n) {
 #pragma unroll
-                        for (int t = 0; t < NBT; ++t) pr[r][t] = 0.0;
+                                for (int q = 0; q < NBT; ++q) {
+                                    const int idx = ft + q * T, li = idx / NBT, t = idx - li * NBT;
+                                    slab[li * SL + t] = tmp[u][q];
+                                }
+                                dense_lds_barrier();
+#pragma unroll
+                                for (int t = 0; t < NBT; ++t) pr[r < RPT ? r : 0][t] = slab[ft * SL + t];
+                                dense_lds_barrier();
+                            } else {
+#pragma unroll
+                                for (int t = 0; t < NBT; ++t) pr[r < RPT ? r : 0][t] = 0.0;
+                            }
+                        }
                     }
                 }
-                // ONE barrier per pivot step: every wavefront reduces its candidates, the lane that owns the wavefront's best row publishes value, row AND the
-                // row's NBT panel entries (arrays double-buffered by step parity); after the barrier every thread scans the W entries, knows the pivot and
-                // has the pivot row -- no second round for "who won" and "hand me the row" (three barriers per step cost 5 - 6 us of a step's 6).
+                stamp(P, 1);   // panel gathered
+                // ONE barrier per pivot step: every wavefront reduces its candidates (VALU), the lane that owns the wavefront's best row publishes value, row
+                // AND the row's NBT panel entries (arrays double-buffered by step parity); after the barrier every thread reads the W entries, knows the pivot
+                // and has the pivot row -- no second round for "who won" and "hand me the row" (three barriers per step cost 5 - 6 us of a step's 6).
+                // The largest magnitude wins, the smallest row among equals: what the pivot-by-pivot kernel chooses.
                 double best = -1.0;
                 int best_row = 0x7fffffff;
 #pragma unroll
                 for (int r = 0; r < RPT; ++r) {
-                    const int i = tid + r * T;
+                    const int i = ft + r * T;
                     if (i < n && !((used_mine >> r) & 1u)) {
                         const double v = fabs(pr[r][0]);
                         if (v > best || (v == best && i < best_row)) best = v, best_row = i;
@@ -326,16 +413,14 @@ template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k
                 for (int t = 0; t < NBT; ++t) {
                     if (t < nbp && !failed) {
                         const int par = t & 1;
-                        for (int o = 32; o > 0; o >>= 1) {
-                            const double ov = __shfl_xor(best, o);
-                            const int orow = __shfl_xor(best_row, o);
-                            if (ov > best || (ov == best && orow < best_row)) best = ov, best_row = orow;
-                        }
-                        if (best_row == 0x7fffffff) {
+                        sstamp(P, t, 0);
+                        const double wmax = dense_wave_max(best);
+                        const int wrow = dense_wave_min(best == wmax ? best_row : 0x7fffffff);
+                        if (wrow == 0x7fffffff) {
                             if (lane == 0) cand_val[par][wave] = -1.0, cand_row[par][wave] = 0x7fffffff;
-                        } else if (best_row % T == tid) {
-                            cand_val[par][wave] = best, cand_row[par][wave] = best_row;
-                            const int rp = best_row / T;
+                        } else if (best_row == wrow) {   // (rows are unique to a lane)
+                            cand_val[par][wave] = wmax, cand_row[par][wave] = wrow;
+                            const int rp = wrow / T;
 #pragma unroll
                             for (int r = 0; r < RPT; ++r)
                                 if (r == rp) {
@@ -343,75 +428,86 @@ template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k
                                     for (int tt = 0; tt < NBT; ++tt) cand_rows[par][wave][tt] = pr[r][tt];
                                 }
                         }
+                        sstamp(P, t, 1);
                         dense_lds_barrier();
-                        double wb = cand_val[par][0];
-                        int p = cand_row[par][0], ws = 0;
-                        for (int w = 1; w < W; ++w) {
-                            const double wv = cand_val[par][w];
-                            const int wr = cand_row[par][w];
-                            if (wv > wb || (wv == wb && wr < p)) wb = wv, p = wr, ws = w;
-                        }
-                        if (p == 0x7fffffff || !(wb > 0.0) || !isfinite(wb)) {
+                        sstamp(P, t, 2);
+                        // the W candidates: lane w of every wavefront reads candidate w, two more VALU reductions -- the maximum, then the smallest
+                        // (row, wavefront) among those that have it (no registers for sixteen values per thread, no chain of dependent LDS reads)
+                        const double cv = lane < W ? cand_val[par][lane] : -1.0;
+                        const int cr = lane < W ? cand_row[par][lane] : 0x7fffffff;
+                        const double wb = dense_wave_max(cv);
+                        const int key = dense_wave_min((cv == wb && cr != 0x7fffffff) ? cr * W + lane : 0x7fffffff);
+                        if (key == 0x7fffffff || !(wb > 0.0) || !isfinite(wb)) {
                             failed = 1;
                         } else {
-                            const double* prow = cand_rows[par][ws];   // (LDS, the same address in every lane: broadcast reads)
-                            const double d = prow[t], inv_d = 1.0 / d;
-                            if (p % T == tid) {
-                                used_mine |= 1u << (p / T);
-                                piv_row_s[t] = p;
-                                a.perm[k0 + t] = p;
-                            }
-                            if (tid == 0) piv_d_s[t] = d;
-                            best = -1.0, best_row = 0x7fffffff;
+                            const int p = key / W, ws = key - p * W;
+                            sstamp(P, t, 3);
+                            double pw[NBT];   // the pivot row's panel entries (LDS, the same address in every lane: broadcast reads), once per step
+#pragma unroll
+                            for (int tt = 0; tt < NBT; ++tt) pw[tt] = cand_rows[par][ws][tt];
+                            const double inv_d = 1.0 / pw[t];
+                            sstamp(P, t, 4);
+                            // every row as an ordinary row, without a branch (rows beyond n hold zeros and keep them; the pivot row itself comes out as
+                            // zeros and is set below by the one thread that owns it)
 #pragma unroll
                             for (int r = 0; r < RPT; ++r) {
-                                const int i = tid + r * T;
-                                if (i < n) {
-                                    const double m = pr[r][t];
-                                    dense_store(a.M + (int64_t)t * n + i, m);   // (column-major: a wavefront's rows are consecutive addresses)
-                                    if (i != p) {
-                                        const double f = m * inv_d;
+                                const double f = pr[r][t] * inv_d;
 #pragma unroll
-                                        for (int tt = 0; tt < NBT; ++tt)
-                                            if (tt != t) pr[r][tt] -= f * prow[tt];
-                                        pr[r][t] = -f;
-                                        if (t + 1 < NBT && t + 1 < nbp && !((used_mine >> r) & 1u)) {
-                                            const double v = fabs(pr[r][t + 1 < NBT ? t + 1 : t]);
-                                            if (v > best || (v == best && i < best_row)) best = v, best_row = i;
-                                        }
-                                    } else {
+                                for (int tt = 0; tt < NBT; ++tt)
+                                    if (tt != t) pr[r][tt] -= f * pw[tt];
+                                pr[r][t] = -f;
+                            }
+                            if (p % T == ft) {
+                                used_mine |= 1u << (p / T);
+                                piv_row_s[t] = p;
+                                const int rp = p / T;
 #pragma unroll
-                                        for (int tt = 0; tt < NBT; ++tt) pr[r][tt] = tt == t ? inv_d : prow[tt] * inv_d;
+                                for (int r = 0; r < RPT; ++r)
+                                    if (r == rp) {
+#pragma unroll
+                                        for (int tt = 0; tt < NBT; ++tt) pr[r][tt] = tt == t ? inv_d : pw[tt] * inv_d;
                                     }
+                            }
+                            sstamp(P, t, 5);
+                            best = -1.0, best_row = 0x7fffffff;
+                            if (t + 1 < NBT && t + 1 < nbp) {
+#pragma unroll
+                                for (int r = 0; r < RPT; ++r) {
+                                    const int i = ft + r * T;
+                                    const double v = (i < n && !((used_mine >> r) & 1u)) ? fabs(pr[r][t + 1 < NBT ? t + 1 : t]) : -1.0;
+                                    const bool take = v > best || (v == best && v >= 0.0 && i < best_row);
+                                    best = take ? v : best, best_row = take ? i : best_row;
                                 }
                             }
                         }
                     }
                 }
                 dense_lds_barrier();
+                stamp(P, 2);   // panel factorised
                 if (!failed) {
 #pragma unroll
                     for (int r = 0; r < RPT; ++r) {
                         if (r * T < n) {
 #pragma unroll
-                            for (int t = 0; t < NBT; ++t) slab[tid * SL + t] = pr[r][t];
+                            for (int t = 0; t < NBT; ++t) slab[ft * SL + t] = pr[r][t];
                             dense_lds_barrier();
-                            for (int idx = tid; idx < T * NBT; idx += T) {
-                                const int li = idx / NBT, t = idx - li * NBT, i = r * T + li;
-                                if (i < n && t < nbp) dense_store(Snext + (int64_t)i * a.ld + k0 + t, slab[li * SL + t]);
+#pragma unroll
+                            for (int q = 0; q < NBT; ++q) {
+                                const int idx = ft + q * T, li = idx / NBT, t = idx - li * NBT, i = r * T + li;
+                                if (i < n && t < nbp) dense_bstore(rs_next, (i * ld + k0 + t) * 8, 0, slab[li * SL + t]);
                             }
                             dense_lds_barrier();
                         }
                     }
-                    __syncthreads();
-                    if (tid < nbp) {
-                        dense_store(a.piv_d + tid, piv_d_s[tid]);
-                        __hip_atomic_store((dn_u32*)(a.piv_row + tid), (unsigned)piv_row_s[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (ft < nbp) {   // (written before the last barrier above; no global store inside the pivot steps)
+                        a.perm[k0 + ft] = piv_row_s[ft];
+                        __hip_atomic_store((dn_u32*)(a.piv_row + ft), (unsigned)piv_row_s[ft], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            stamp(P, 3);   // panel written and drained
             if (tid == 0) {
                 if (failed) a.status[0] = failed;
                 __hip_atomic_store((dn_u64*)a.ready, ((unsigned long long)(P + 1) << 1) | (failed ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -435,66 +531,89 @@ template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (!wait_s) return;
-        if (tid < nbp) {
-            piv_row_s[tid] = (int)__hip_atomic_load((const dn_u32*)(a.piv_row + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            piv_d_s[tid] = dense_load_shared(a.piv_d + tid);
+        stamp(P, 4);   // panel seen
+        // ---- the update of this workgroup's BLOCK -- rows [i0, i0 + nr) x columns [j0, j0 + nc) of an R x C grid of blocks -- as small matrix products on
+        // the matrix cores (v_mfma_f64_16x16x4), 16 rows x 16 columns per operation.  In-place Gauss-Jordan leaves in the panel's columns the row
+        // operations themselves: after the panel's steps, E[i][u] = S'[i][k0 + u] is the coefficient of the ORIGINAL pivot row p_u in the new row i
+        // (one step: S'[i][j] = S[i][j] + S'[i][k] S[p][j] with S'[i][k] = -f_i, and S'[p][j] = S'[p][k] S[p][j] with S'[p][k] = 1 / d; by induction over
+        // the steps).  So, with the panel's final columns E as workgroup 0 has just written them,
+        //     S'[i][j] = base_i[j] + sum_u E[i][u] S[p_u][j],     base_i = S[i][.] for ordinary rows, 0 for the panel's pivot rows:
+        // no multipliers to publish, no triangle to solve -- the workers read their rows of E (one trip) and the pivots' indices.
+        // Why blocks and not whole rows per workgroup: every load here comes over the fabric (sc1: another XCD wrote the line), and with whole rows EVERY
+        // workgroup reads the 16 pivot rows in full -- at 2 116 rows 69 of a panel's 108 MB, 29 us; in blocks the pivot rows cross R times, not G times.
+        // (The scalar forms before: 16 multipliers from LDS per row and column and a 120-term triangle per column -- 38 of a panel's 77 us at 1 089
+        // rows went into LDS broadcasts.)
+        const int rows_pad = (nr + 15) & ~15;
+        double* En = buf;                                                    // [rows_pad][16] the panel's final columns, this block's rows
+        int* pt_own = reinterpret_cast<int*>(En + (size_t)rows_pad * 16);    // [rows_pad] 1: the row is one of the panel's pivots
+        if (tid < nbp) piv_row_s[tid] = (int)__hip_atomic_load((const dn_u32*)(a.piv_row + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int idx = tid; idx < rows_pad * 16; idx += T) {   // (in flight with the pivots above; 16 lanes per row: whole 128-byte lines)
+            const int rr = idx >> 4, t = idx & 15;
+            const double e = dense_bload(rs_next, ((i0 + (rr < nr ? rr : 0)) * ld + k0 + (t < nbp ? t : 0)) * 8, 0);
+            En[idx] = (rr < nr && t < nbp) ? e : 0.0;
         }
         __syncthreads();
-        double* Mown = buf;                    // [my_rows][NB] the multipliers of this workgroup's rows
-        int* pt_own = reinterpret_cast<int*>(Mown + (size_t)my_rows * NB);   // [my_rows] index of the row among the panel's pivots, or -1
-        for (int idx = tid; idx < nbp * nbp; idx += T) {
-            const int s_ = idx / nbp, t = idx - s_ * nbp;
-            Mpp[s_][t] = dense_load_shared(a.M + (int64_t)t * n + piv_row_s[s_]);
-        }
-        for (int idx = tid; idx < my_rows * nbp; idx += T) {
-            const int r = idx / nbp, t = idx - r * nbp;
-            Mown[r * NB + t] = dense_load_shared(a.M + (int64_t)t * n + (g + G * r));
-        }
-        for (int r = tid; r < my_rows; r += T) {
-            int pt = -1;
+        for (int r = tid; r < rows_pad; r += T) {
+            int is_piv = 0;
             for (int t = 0; t < nbp; ++t)
-                if (piv_row_s[t] == g + G * r) pt = t;
-            pt_own[r] = pt;
+                if (r < nr && piv_row_s[t] == i0 + r) is_piv = 1;
+            pt_own[r] = is_piv;
         }
         __syncthreads();
-        for (int j0 = 0; j0 < n; j0 += TJ) {
-            const int j = j0 + tid;
-            const bool in_range = j < n;
-            // the pivot rows' entries of this column, transformed among themselves: U_t[j]
-            double U[NBT];
+        stamp(P, 5);   // the panel's rows in LDS
+        {
+            typedef double dn_v4d __attribute__((ext_vector_type(4)));
+            constexpr int TU = 4;   // row blocks whose loads are in flight together
+            const int q = lane >> 4, jl = lane & 15, n_ct = (nc + 15) >> 4, n_rb = rows_pad >> 4;
+            // operand layouts (measured): A[i][k] in lane 16 k + i, B[k][j] in lane 16 k + j, D[4 v + q][j] in register v of lane 16 q + j
+            int piv_off[4];
 #pragma unroll
-            for (int t = 0; t < NBT; ++t) U[t] = (t < nbp && in_range) ? dense_load_shared(Scur + (int64_t)piv_row_s[t] * a.ld + j) : 0.0;
+            for (int c = 0; c < 4; ++c) piv_off[c] = 4 * c + q < nbp ? piv_row_s[4 * c + q] * ld * 8 : -1;
+            for (int ct = wave; ct < n_ct; ct += W) {   // a column tile per wavefront: its pivot-row fragment once, then the row blocks
+                const int j = j0 + ct * 16 + jl, j8 = j * 8;   // (j < ld: inside the row; columns n .. ld - 1 are computed and not stored)
+                const bool col_ok = j < n && (j < k0 || j >= k0 + nbp);   // (the panel's own columns came from workgroup 0)
+                double bf[4];
 #pragma unroll
-            for (int t = 0; t < NBT; ++t)
-                if (t < nbp) {
-                    double v = U[t];
-#pragma unroll
-                    for (int s_ = 0; s_ < NBT; ++s_)
-                        if (s_ < t) v -= Mpp[t][s_] * U[s_];
-                    U[t] = v / piv_d_s[t];
+                for (int c = 0; c < 4; ++c) {
+                    const double x = dense_bload(rs_cur, piv_off[c] >= 0 ? piv_off[c] + j8 : 0, 0);
+                    bf[c] = piv_off[c] >= 0 ? x : 0.0;
                 }
-            const bool write = in_range && (j < k0 || j >= k0 + nbp);   // (the panel's own columns came from workgroup 0)
-            for (int r = 0; r < my_rows; ++r) {
-                if (!write) break;
-                const int i = g + G * r, pt = pt_own[r];
-                const double* mrow = Mown + r * NB;
-                double v;
-                if (pt < 0) {
-                    v = dense_load_shared(Scur + (int64_t)i * a.ld + j);
+                for (int rb0 = 0; rb0 < n_rb; rb0 += TU) {
+                    dn_v4d acc[TU];
+                    double af[TU][4];
 #pragma unroll
-                    for (int t = 0; t < NBT; ++t)
-                        if (t < nbp) v -= mrow[t] * U[t];
-                } else {
-                    v = 0.0;
+                    for (int u = 0; u < TU; ++u) {
+                        const int rb = rb0 + u;
 #pragma unroll
-                    for (int t = 0; t < NBT; ++t)
-                        if (t < nbp) v = t == pt ? v + U[t] : (t > pt ? v - mrow[t] * U[t] : v);
+                        for (int v = 0; v < 4; ++v) {
+                            const int r = rb * 16 + 4 * v + q;
+                            const bool base = rb < n_rb && r < nr && !pt_own[r < rows_pad ? r : 0];
+                            const double x = dense_bload(rs_cur, base ? (i0 + r) * ld * 8 + j8 : 0, 0);
+                            acc[u][v] = base ? x : 0.0;
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) af[u][c] = rb < n_rb ? En[(rb * 16 + jl) * 16 + 4 * c + q] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < TU; ++u) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[u][c], bf[c], acc[u], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < TU; ++u) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int r = (rb0 + u) * 16 + 4 * v + q;
+                            if (col_ok && r < nr) dense_bstore(rs_next, (i0 + r) * ld * 8 + j8, 0, acc[u][v]);
+                        }
+                    }
                 }
-                dense_store(Snext + (int64_t)i * a.ld + j, v);
             }
         }
+        stamp(P, 6);   // update issued
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        stamp(P, 7);   // ... and drained
         if (tid == 0) __hip_atomic_store((dn_u64*)(a.done + g), (unsigned long long)(P + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }

@@ -42,14 +42,15 @@ bool dense_eligible(const fdapde_ctx* c) {
            !c->halo_ready && !c->rd.ready;
 }
 
-// What an inversion costs, from the measured shape of k_dense_invert_blocked on MI355X (n / nb panels, each ~6 us per pivot step + two grid-wide hand-offs
-// + 1.5 x a read-modify-write sweep of the n x n array at ~3 TB/s): 289 rows 1.4 - 2 ms, 1 089 rows 7.5 ms, 2 116 rows 20 ms, 4 225 rows 0.125 s.
+// What an inversion costs, from the measured shape of k_dense_invert_blocked on MI355X: n / nb panels, each the longer of the panel workgroup's turn
+// (~1.2 us per pivot step + ~4.5 us per 512-row block for the panel's columns out and the next panel's in + hand-offs) and the workers' update (a
+// read-modify-write sweep of the n x n array over the fabric at ~4.5 TB/s): 289 rows 0.5 ms, 1 089 rows 2.6 ms, 2 116 rows 8.5 ms, 4 225 rows 66 ms.
 // Callers build an inverse when the Krylov time it replaces is of that order ("rent or buy": the handle after it has spent half of this on Krylov
 // columns, the stepper when its steps will).
 double dense_build_estimate_ms(int64_t n) {
     const int64_t rpt = (n + kDenseTB - 1) / kDenseTB, nb = rpt <= 4 ? 16 : rpt <= 8 ? 8 : 4;
-    const double sweep_us = 16.0 * (double)n * (double)n / 3.0e6;
-    return 1e-3 * (double)((n + nb - 1) / nb) * (6.0 * (double)nb + 10.0 + 1.5 * sweep_us) + 0.3;
+    const double panel_us = 1.2 * (double)nb + 4.0 + 4.5 * (double)rpt, update_us = 8.0 + 16.0 * (double)n * (double)n / 4.5e6;
+    return 1e-3 * (double)((n + nb - 1) / nb) * std::max(panel_us, update_us) + 0.2;
 }
 
 // D.X = (the matrix A of the pattern, its Dirichlet rows replaced by unit rows if use_bnd)^-1, internal DOF order.  D.ready, or D.failed where the
@@ -92,11 +93,11 @@ int dense_build(fdapde_ctx* c, const double* A, int use_bnd, fdapde_ctx::Dense& 
         // the update's grid: R x C blocks of the matrix, one workgroup each (all co-resident: <= one per CU) -- about 8 column tiles of 16 per block (one
         // per wavefront) and 4 row tiles (one batch of loads in flight)
         const int n_tiles = (int)((n + 15) / 16), cus = c->n_cu > 0 ? c->n_cu : 64;
-        int C = std::max(1, std::min(16, (n_tiles + 7) / 8));
-        int R = std::max(1, std::min(cus / C, (n_tiles + 3) / 4));
+        int C = std::max(1, std::min(17, (n_tiles + 7) / 8));
+        int R = std::max(1, std::min((cus - 1) / C, (n_tiles + 3) / 4));   // (+ the panel workgroup)
         if (const char* e = std::getenv("FDAPDE_DENSE_GRID")) {   // "R,C" (measurements)
             int r_ = 0, c_ = 0;
-            if (std::sscanf(e, "%d,%d", &r_, &c_) == 2 && r_ >= 1 && c_ >= 1 && r_ * c_ <= cus) R = r_, C = c_;
+            if (std::sscanf(e, "%d,%d", &r_, &c_) == 2 && r_ >= 1 && c_ >= 1 && r_ * c_ < cus) R = r_, C = c_;
         }
         const int RB = 16 * ((n_tiles + R - 1) / R), CB = 16 * ((n_tiles + C - 1) / C);
         R = (int)((n + RB - 1) / RB), C = (int)((n + CB - 1) / CB);   // (the blocks in use)
@@ -111,7 +112,7 @@ int dense_build(fdapde_ctx* c, const double* A, int use_bnd, fdapde_ctx::Dense& 
             HIPCHK(c, hipMemsetAsync(stamps.p, 0, 32 * sizeof(long long), st));
             b.stamps = stamps.p;
         }
-        const size_t lds = std::max(sizeof(double) * (size_t)RB * 16 + sizeof(int) * (size_t)RB, sizeof(double) * (size_t)kDenseTB * (kDenseNB + 1)) + 64;
+        const size_t lds = std::max(sizeof(double) * (size_t)RB * 16 + (size_t)RB, sizeof(double) * (size_t)kDenseTB * (kDenseNB + 1)) + 64;
         const void* fn = rpt <= 2   ? reinterpret_cast<const void*>(&k_dense_invert_blocked<2, 16>)
                          : rpt <= 3 ? reinterpret_cast<const void*>(&k_dense_invert_blocked<3, 16>)
                          : rpt <= 4 ? reinterpret_cast<const void*>(&k_dense_invert_blocked<4, 16>)
@@ -119,7 +120,7 @@ int dense_build(fdapde_ctx* c, const double* A, int use_bnd, fdapde_ctx::Dense& 
                                     : reinterpret_cast<const void*>(&k_dense_invert_blocked<16, 4>);
         HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         void* kargs[] = {&b};
-        HIPCHK(c, hipLaunchKernel(fn, dim3((unsigned)G), dim3(kDenseTB), kargs, lds, st));
+        HIPCHK(c, hipLaunchKernel(fn, dim3((unsigned)G + 1), dim3(kDenseTB), kargs, lds, st));
         const int n_panels = (int)((n + nb - 1) / nb);
         result = (n_panels & 1) ? S1.p : S.p;
     } else {
@@ -145,9 +146,8 @@ int dense_build(fdapde_ctx* c, const double* A, int use_bnd, fdapde_ctx::Dense& 
     if (stamps.p) {
         long long h[32];
         HIPCHK(c, hipMemcpy(h, stamps.p, sizeof h, hipMemcpyDeviceToHost));
-        std::fprintf(stderr, "dense inverse, panel 8 (us from 'previous panel done'): workgroup 0: gathered %.1f factorised %.1f written %.1f seen %.1f multipliers %.1f update issued %.1f drained %.1f | workgroup 1: seen %.1f multipliers %.1f issued %.1f drained %.1f\n",
-                     0.01 * (h[1] - h[0]), 0.01 * (h[2] - h[0]), 0.01 * (h[3] - h[0]), 0.01 * (h[4] - h[0]), 0.01 * (h[5] - h[0]), 0.01 * (h[6] - h[0]), 0.01 * (h[7] - h[0]),
-                     0.01 * (h[12] - h[0]), 0.01 * (h[13] - h[0]), 0.01 * (h[14] - h[0]), 0.01 * (h[15] - h[0]));
+        std::fprintf(stderr, "dense inverse, panel 8 (us from 'panel in registers'): panel workgroup: factorised %.1f previous update done %.1f published %.1f next panel ready %.1f | worker 0: seen %.1f rows of E in LDS %.1f update issued %.1f drained %.1f\n",
+                     0.01 * (h[1] - h[0]), 0.01 * (h[2] - h[0]), 0.01 * (h[3] - h[0]), 0.01 * (h[4] - h[0]), 0.01 * (h[8] - h[0]), 0.01 * (h[9] - h[0]), 0.01 * (h[10] - h[0]), 0.01 * (h[11] - h[0]));
         std::fprintf(stderr, "  pivot step 5 (us from its start): own candidate %.2f barrier %.2f pivot known %.2f pivot row read %.2f rows updated %.2f\n", 0.01 * (h[17] - h[16]), 0.01 * (h[18] - h[16]), 0.01 * (h[19] - h[16]), 0.01 * (h[20] - h[16]), 0.01 * (h[21] - h[16]));
     }
     if (std::getenv("FDAPDE_DEBUG_SETUP"))

@@ -218,45 +218,57 @@ static __global__ __launch_bounds__(kDenseT) void k_dense_invert(DenseInvArgs a)
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
 // The same inversion BLOCKED: nb pivots per grid-wide exchange instead of one.  k_dense_invert above pays a chain of dependent trips through the
-// fabric per pivot (sweep, pivot row, write-through, granule: ~9 us + 5 ns per workgroup -- 15 ms for 1 089 rows).  Here a PANEL of nb <= 16 columns
-// is gathered by workgroup 0 into LDS (n x nb doubles), factorised there -- nb pivot searches and rank-1 updates with workgroup barriers only -- and
-// published as the multipliers M[i][t] (the value of column k_t in row i at the time of step t) + pivots; then every workgroup applies the nb steps to
-// its rows in ONE pass over the other columns:
-//     U_t[j] = (S[p_t][j] - sum_{s<t} M[p_t][s] U_s[j]) / d_t                       (the pivot rows among themselves, redundantly per workgroup)
-//     S'[i][j] = S[i][j] - sum_t M[i][t] U_t[j]                                      (ordinary rows)
-//     S'[p_t][j] = U_t[j] - sum_{s>t} M[p_t][s] U_s[j]                               (the panel's pivot rows)
-// -- the in-place Gauss-Jordan steps of k_dense_invert, re-associated.  A panel reads one buffer and writes the other (no row is written while somebody
-// may still read it); two hand-offs per panel: "panel published" (one granule all workgroups poll) and "update done" (a granule per workgroup, swept
-// by workgroup 0).  Payload through sc1 stores / sc1 loads as above.  1 089 rows: 68 panels x ~45 us.
+// fabric per pivot (sweep, pivot row, write-through, granule: ~9 us + 5 ns per workgroup -- 15 ms for 1 089 rows).  Here a PANEL of nb <= 16
+// columns lives in the registers of ONE workgroup (the last of the grid), which factorises it with workgroup barriers only -- nb pivot searches and
+// rank-1 updates -- and every other workgroup applies the nb steps at once to its block of the matrix.  What makes that cheap: in-place Gauss-Jordan
+// leaves in the panel's columns the row operations themselves.  After the panel's steps, E[i][u] = S'[i][k0 + u] is the coefficient of the ORIGINAL
+// pivot row p_u in the new row i (one step: S'[i][j] = S[i][j] + S'[i][k] S[p][j] with S'[i][k] = -f_i, and S'[p][j] = S'[p][k] S[p][j] with
+// S'[p][k] = 1 / d; by induction over the steps).  So
+//     S'[i][j] = base_i[j] + sum_u E[i][u] S[p_u][j],     base_i = S[i][.] for ordinary rows, 0 for the panel's pivot rows
+// -- a 16-deep matrix product per 16 x 16 tile, on the matrix cores (v_mfma_f64_16x16x4); nothing to publish but the panel's final columns (which the
+// result needs anyway) and the pivots' indices.
+//   the panel workgroup  factorises panel P while the others still apply panel P - 1: the columns of panel P as panel P - 1 leaves them it computes
+//                        ITSELF (the same product: it holds E of panel P - 1 and reads 16 x 16 entries of the pivot rows), so the factorisations
+//                        follow each other without a gap; it waits for "update P - 1 done everywhere" only before it publishes panel P
+//   the workers          an R x C grid of blocks, one workgroup each: wait for "panel P published", read their rows of E (one trip) and the pivots,
+//                        16 x 16 tiles (a column tile per wavefront, the pivot-row fragment once, four row tiles' loads in flight), skip the columns of
+//                        panels P and P + 1 (the panel workgroup's), say "done".  Blocks, not whole rows: every load comes over the fabric (sc1: another
+//                        XCD wrote the line), and with whole rows every workgroup reads the 16 pivot rows in full -- 69 of a panel's 108 MB at 2 116 rows.
+// A panel reads one buffer and writes the other (nobody writes what somebody may still read).  Payload through sc1 buffer stores / loads, flags as
+// in k_dense_invert.  History of this kernel (1 089 rows): LDS-resident panel 15 ms; register panel + scalar update with published multipliers 6.8 ms
+// (3.7 us per pivot step: spills whose reloads waited for the step's write-through stores; 38 us per panel in LDS broadcasts of the update);
+// this form 2 ms.
 // ---------------------------------------------------------------------------------------------------------------------------------------
-// a workgroup barrier for hand-offs through LDS only: waits for this wave's LDS traffic, not for its global stores in flight (__syncthreads waits for
-// both -- with write-through stores of the multipliers in every pivot step that was ~2 us per barrier, three barriers per step)
+// a workgroup barrier for hand-offs through LDS only: waits for this wave's LDS traffic, not for its global stores in flight
 __device__ __forceinline__ void dense_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// ... and between the lanes of ONE wavefront (their LDS operations complete in order)
+__device__ __forceinline__ void dense_lds_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-constexpr int kDenseNB = 16;    // pivots per panel at most (the panel, n x nb doubles, must fit the LDS of workgroup 0)
+constexpr int kDenseNB = 16;    // pivots per panel at most
 constexpr int kDenseTB = 512;   // threads of a workgroup of the blocked inversion: 8 wavefronts, 2 per SIMD -- 256 vector registers each: the panel (up to 64 doubles per
                                 // thread) AND a pivot step's working set stay in registers.  (1 024 threads: 128 registers, spills whose reloads' s_waitcnt vmcnt(0) also
-                                // waited for the step's write-through stores -- 3.7 us per pivot step; 256 threads: five panel rows per thread at 1 089 rows.)
-constexpr int kDenseTJ = kDenseTB;  // columns per tile of the update: one per thread
+                                // waited for write-through stores in flight -- 3.7 us per pivot step; 256 threads: five panel rows per thread at 1 089 rows.)
 
 struct DenseBlkArgs {
-    int32_t n, G, ld, nb;
+    int32_t n, G, ld, nb;          // G worker workgroups; the grid is G + 1, the last one the panel workgroup
     int32_t C, RB, CB;             // the update's grid of blocks: G = R x C workgroups, RB rows x CB columns each (multiples of 16)
     double *S0, *S1;               // panel P reads S(P & 1), writes the other
     int32_t* perm;                 // [n] pivot row of column k
     int32_t* piv_row;              // [nb]
-    unsigned long long* done;      // [G] granule per workgroup: panels whose update it has finished
+    unsigned long long* done;      // [G] granule per worker: panels whose update it has finished
     unsigned long long* ready;     // [1] (panels published << 1) | failed
     int32_t* status;               // [0] 1 = singular, 2 = a wait timed out
     long long timeout_ticks;
-    long long* stamps;             // diagnostic (FDAPDE_DENSE_STAMPS): s_memrealtime at the phase boundaries of panel 8, [0..7] workgroup 0, [8..15] workgroup 1; or null
+    long long* stamps;             // diagnostic (FDAPDE_DENSE_STAMPS): s_memrealtime at the phase boundaries of panel 8, [0..7] the panel workgroup, [8..15] worker 0,
+                                   // [16..23] inside pivot step 5; or null
 };
 
 // payload loads / stores of the blocked inversion: BUFFER instructions with the sc1 bit (aux 16).  Against the 8-byte atomics above they (a) address
 // through a resource in scalar registers + a 32-bit offset (the atomics' 64-bit addresses, hoisted out of the unrolled pivot steps, filled 64 vector
-// registers, spilled, and every reload's s_waitcnt vmcnt(0) then also waited for the previous step's write-through stores: 2 of a step's 3.7 us) and
-// (b) are ordinary memory operations to the compiler: it issues a batch of loads back to back instead of one round trip per load.
+// registers and spilled) and (b) are ordinary memory operations to the compiler: it issues a batch of loads back to back instead of one round trip
+// per load.
 typedef unsigned int dn_v2u __attribute__((ext_vector_type(2)));
+typedef double dn_v4d __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ double dense_bload(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
     const dn_v2u x = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 16);
     return __longlong_as_double((long long)(((unsigned long long)x[1] << 32) | x[0]));
@@ -267,8 +279,8 @@ __device__ __forceinline__ void dense_bstore(__amdgpu_buffer_rsrc_t rs, int voff
     x[0] = (unsigned)b, x[1] = (unsigned)(b >> 32);
     __builtin_amdgcn_raw_buffer_store_b64(x, rs, voff, soff, 16);
 }
-// maximum / minimum over the wavefront in every lane, on the VALU (permlane swaps + DPP: kernels_reduce.h) -- a __shfl_xor butterfly of (value, row)
-// is 18 ds_bpermute per pivot step
+// maximum over the wavefront in every lane, on the VALU (permlane swaps + DPP: kernels_reduce.h) -- a __shfl_xor butterfly of (value, row) is 18
+// ds_bpermute per pivot step
 __device__ __forceinline__ double dense_wave_max(double v) {
     {
         const unsigned long long b = (unsigned long long)__double_as_longlong(v);
@@ -288,232 +300,296 @@ __device__ __forceinline__ double dense_wave_max(double v) {
     v = fmax(v, reduce_dpp_f64<0xB1>(v));
     return v;
 }
-__device__ __forceinline__ int dense_wave_min(int v) {
-    auto s = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
-    v = min((int)s[0], (int)s[1]);
-    s = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
-    v = min((int)s[0], (int)s[1]);
-    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false));
-    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false));
-    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false));
-    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false));
-    return v;
+// A pivot candidate as ONE double that orders like (magnitude, then smaller row): the magnitude's low 13 bits replaced by 8 191 - row.  Partial pivoting
+// wants a near-largest entry, not the largest to the last bit (2^-39 relative here), and the tie rule stays "the smallest row"; one reduction per
+// choice instead of a maximum followed by a minimum over the rows that have it.  No candidate: -1.  (NaN entries never win: v_max_f64 drops them.)
+__device__ __forceinline__ double dense_cand_key(double mag, int row) {
+    return __longlong_as_double((long long)(((unsigned long long)__double_as_longlong(mag) & ~0x1fffull) | (unsigned long long)(0x1fff - row)));
 }
+__device__ __forceinline__ int dense_cand_row(double key) { return 0x1fff - (int)((unsigned long long)__double_as_longlong(key) & 0x1fffull); }
+__device__ __forceinline__ double dense_cand_mag(double key) { return __longlong_as_double((long long)((unsigned long long)__double_as_longlong(key) & ~0x1fffull)); }
 
 template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k_dense_invert_blocked(DenseBlkArgs a) {
     extern __shared__ __attribute__((aligned(16))) char dn_smem3[];
     double* buf = reinterpret_cast<double*>(dn_smem3);
     constexpr int T = kDenseTB, W = kDenseTB / 64;
     static_assert(W <= 64, "the pivot scan below reads a candidate per lane");
+    static_assert(kDenseMaxRows <= 0x2000, "a candidate key holds 13 bits of row");
     __shared__ int piv_row_s[kDenseNB], wait_s;
-    __shared__ __attribute__((aligned(16))) double cand_val[2][W], cand_rows[2][W][kDenseNB];
-    __shared__ __attribute__((aligned(16))) int cand_row[2][W];
+    __shared__ __attribute__((aligned(16))) double cand_key[2][W], cand_rows[2][W][kDenseNB];
+    __shared__ unsigned char isp_s[kDenseTB];
     const int n = a.n, G = a.G, NB = a.nb, ld = a.ld, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // this workgroup's block of the update: rows [i0, i0 + nr) x columns [j0, j0 + nc) (empty blocks only take part in the hand-offs)
-    const int i0 = (g / a.C) * a.RB, j0 = (g % a.C) * a.CB;
-    const int nr = i0 < n && j0 < n ? (n - i0 < a.RB ? n - i0 : a.RB) : 0, nc = i0 < n && j0 < n ? (n - j0 < a.CB ? n - j0 : a.CB) : 0;
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(a.S0, 0, n * ld * 8, 0x00020000);   // (<= 8 192 x 8 192 doubles: 2^29 bytes)
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(a.S1, 0, n * ld * 8, 0x00020000);
-    unsigned used_mine = 0u;   // workgroup 0: bit r = this thread's row tid + r T has been a pivot
     const int n_panels = (n + NB - 1) / NB;
+    const int q = lane >> 4, jl = lane & 15;   // MFMA operand layouts (measured): A[i][k] in lane 16 k + i, B[k][j] in lane 16 k + j, D[4 v + q][j] in register v of lane 16 q + j
     auto sstamp = [&](int P, int t, int slot) {   // inside pivot step 5 of panel 8
-        if (a.stamps && P == 8 && t == 5 && tid == 0 && g == 0) a.stamps[16 + slot] = (long long)__builtin_amdgcn_s_memrealtime();
+        if (a.stamps && P == 8 && t == 5 && tid == 0) a.stamps[16 + slot] = (long long)__builtin_amdgcn_s_memrealtime();
     };
-    auto stamp = [&](int P, int slot) {
-        if (a.stamps && P == 8 && tid == 0 && g < 2) a.stamps[g * 8 + slot] = (long long)__builtin_amdgcn_s_memrealtime();
+    auto stamp = [&](int P, int who, int slot) {
+        if (a.stamps && P == 8 && tid == 0) a.stamps[who * 8 + slot] = (long long)__builtin_amdgcn_s_memrealtime();
     };
-    for (int P = 0; P < n_panels; ++P) {
-        const int k0 = P * NB, nbp = n - k0 < NB ? n - k0 : NB;
-        const __amdgpu_buffer_rsrc_t rs_cur = (P & 1) ? rs1 : rs0, rs_next = (P & 1) ? rs0 : rs1;
-        if (g == 0) {
-            // ---- every workgroup has finished the update of panel P - 1
-            if (wave == 0) {
-                int ok = 1;
-                const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
-                for (int q = lane; q < G && ok; q += 64)
-                    while (__hip_atomic_load((const dn_u64*)(a.done + q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)P) {
-                        __builtin_amdgcn_s_sleep(1);
-                        if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
-                            ok = 0;
-                            break;
-                        }
-                    }
-                ok = __all(ok);
-                if (lane == 0) wait_s = ok;
+
+    if (g == G) {
+        // =================================================================== the panel workgroup
+        // The panel lives in REGISTERS: thread tid holds rows tid, tid + T, ... (RPT of them) x NBT columns.  A step is a register scan for the pivot
+        // (+ one block-wide arg-max), the pivot row's NBT values through LDS, and NBT fused multiply-adds per row and thread -- an LDS-resident panel
+        // cost 5 - 10 us per step (hundreds of LDS read-modify-writes per thread).  Rows move between the register layout (a row per thread) and
+        // memory / the MFMA layouts through an LDS slab (T x NBT doubles, row stride NBT + 1) in which every wavefront only touches ITS 64 rows: no
+        // workgroup barrier outside the pivot steps.
+        double* slab = buf + (size_t)wave * 64 * (NBT + 1);   // this wavefront's 64 rows
+        constexpr int SL = NBT + 1;
+        double pr[RPT][NBT];
+        unsigned used_mine = 0u;   // bit r = this thread's row tid + r T has been a pivot
+        // panel 0: the matrix's first columns as they are
+        {
+#pragma unroll
+            for (int r = 0; r < RPT; ++r) {
+                dense_lds_wave_sync();
+#pragma unroll
+                for (int u = 0; u < NBT; ++u) {   // (16 lanes per row: whole 128-byte lines; NBT loads in flight)
+                    const int rl = (64 / NBT) * u + lane / NBT, cl = lane % NBT, i = r * T + wave * 64 + rl;
+                    const double v = dense_bload(rs0, ((i < n ? i : 0) * ld + cl) * 8, 0);
+                    slab[rl * SL + cl] = (i < n && cl < (n < NB ? n : NB)) ? v : 0.0;
+                }
+                dense_lds_wave_sync();
+#pragma unroll
+                for (int t = 0; t < NBT; ++t) pr[r][t] = slab[lane * SL + t];
             }
-            __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            int failed = wait_s ? 0 : 2;
-            stamp(P, 0);   // every workgroup done with the previous panel
-            // The panel lives in REGISTERS: thread tid holds rows tid, tid + T, ... (RPT of them) x NBT columns.  A step is a register scan for the pivot
-            // (+ one block-wide arg-max), the pivot row's NBT values through LDS, and NBT fused multiply-adds per row and thread -- an LDS-resident panel
-            // cost 5 - 10 us per step (hundreds of LDS read-modify-writes per thread), most of an inversion's time.
-            if (!failed) {
-                // (an opaque copy of the thread index: everything derived from tid below is loop-invariant, and hoisted out of the panel loop it fills a
-                // hundred registers that are then spilled and reloaded inside every pivot step)
-                int ft = tid;
-                asm volatile("" : "+v"(ft));
-                double pr[RPT][NBT];
-                // rows r T .. r T + T - 1 of the panel through an LDS slab (T x NBT doubles, row stride NBT + 1): the global side runs over consecutive
-                // addresses (NBT lanes per row: whole 128-byte lines), the register side takes a row per thread.  A thread loading / storing its own row
-                // directly put every lane of a wavefront on a different line: ~17 000 lone 8-byte write-through stores per panel.
-                double* slab = buf;
-                constexpr int SL = NBT + 1;
-                constexpr int GR = 32 / NBT < RPT ? 32 / NBT : RPT;   // row blocks whose loads are in flight together (32 loads per thread: a trip over the fabric per group)
+        }
+        for (int P = 0; P < n_panels; ++P) {
+            const int k0 = P * NB, nbp = n - k0 < NB ? n - k0 : NB;
+            const __amdgpu_buffer_rsrc_t rs_cur = (P & 1) ? rs1 : rs0, rs_next = (P & 1) ? rs0 : rs1;
+            stamp(P, 0, 0);   // panel in registers
+            // (an opaque copy of the thread index: everything derived from tid below is loop-invariant, and hoisted out of the panel loop it fills a
+            // hundred registers that are then spilled and reloaded inside every pivot step)
+            int ft = tid;
+            asm volatile("" : "+v"(ft));
+            int failed = 0;
+            unsigned piv_now = 0u;   // bit r: the row is a pivot of THIS panel
+            // ONE barrier per pivot step: every wavefront reduces its candidates (VALU), the lane that owns the wavefront's best row publishes the key AND
+            // the row's NBT panel entries (arrays double-buffered by step parity); after the barrier every wavefront reduces the W keys, knows the pivot
+            // and reads the pivot row -- no second round for "who won" and "hand me the row".  The largest magnitude wins, the smallest row among equals.
+            double best = -1.0;
 #pragma unroll
-                for (int r0 = 0; r0 < RPT; r0 += GR) {
-                    asm volatile("" ::: "memory");   // (the next group's loads stay behind this group: GR x NBT values in registers, not RPT x NBT)
-                    double tmp[GR][NBT];
+            for (int r = 0; r < RPT; ++r) {
+                const int i = ft + r * T;
+                const double kd = (i < n && !((used_mine >> r) & 1u)) ? dense_cand_key(fabs(pr[r][0]), i) : -1.0;
+                best = fmax(best, kd);
+            }
 #pragma unroll
-                    for (int u = 0; u < GR; ++u) {
+            for (int t = 0; t < NBT; ++t) {
+                if (t < nbp && !failed) {
+                    const int par = t & 1;
+                    sstamp(P, t, 0);
+                    const double wmax = dense_wave_max(best);
+                    if (!(wmax >= 0.0)) {
+                        if (lane == 0) cand_key[par][wave] = -1.0;
+                    } else if (best == wmax) {   // (rows are unique to a lane, so are keys)
+                        cand_key[par][wave] = wmax;
+                        const int rp = dense_cand_row(wmax) / T;
 #pragma unroll
-                        for (int q = 0; q < NBT; ++q) {
-                            const int idx = ft + q * T, li = idx / NBT, t = idx - li * NBT, i = (r0 + u) * T + li;
-                            const double v = dense_bload(rs_cur, ((i < n ? i : 0) * ld + k0 + t) * 8, 0);
-                            tmp[u][q] = (r0 + u < RPT && i < n && t < nbp) ? v : 0.0;
-                        }
-                    }
+                        for (int r = 0; r < RPT; ++r)
+                            if (r == rp) {
 #pragma unroll
-                    for (int u = 0; u < GR; ++u) {
-                        const int r = r0 + u;
-                        if (r < RPT) {
-                            if (r * T < n) {
-#pragma unroll
-                                for (int q = 0; q < NBT; ++q) {
-                                    const int idx = ft + q * T, li = idx / NBT, t = idx - li * NBT;
-                                    slab[li * SL + t] = tmp[u][q];
-                                }
-                                dense_lds_barrier();
-#pragma unroll
-                                for (int t = 0; t < NBT; ++t) pr[r < RPT ? r : 0][t] = slab[ft * SL + t];
-                                dense_lds_barrier();
-                            } else {
-#pragma unroll
-                                for (int t = 0; t < NBT; ++t) pr[r < RPT ? r : 0][t] = 0.0;
+                                for (int tt = 0; tt < NBT; ++tt) cand_rows[par][wave][tt] = pr[r][tt];
                             }
+                    }
+                    sstamp(P, t, 1);
+                    dense_lds_barrier();
+                    sstamp(P, t, 2);
+                    const double ck = lane < W ? cand_key[par][lane] : -1.0;
+                    const double kb = dense_wave_max(ck);
+                    const double mag = dense_cand_mag(kb);
+                    if (!(kb >= 0.0) || !(mag > 0.0) || !isfinite(mag)) {
+                        failed = 1;
+                    } else {
+                        const int p = dense_cand_row(kb);
+                        const int ws = __ffsll((unsigned long long)__ballot(lane < W && ck == kb)) - 1;
+                        sstamp(P, t, 3);
+                        double pw[NBT];   // the pivot row's panel entries (LDS, the same address in every lane: broadcast reads), once per step
+#pragma unroll
+                        for (int tt = 0; tt < NBT; ++tt) pw[tt] = cand_rows[par][ws][tt];
+                        const double inv_d = 1.0 / pw[t];
+                        sstamp(P, t, 4);
+                        // every row as an ordinary row, without a branch (rows beyond n hold zeros and keep them; the pivot row itself comes out as
+                        // zeros and is set below by the one thread that owns it)
+#pragma unroll
+                        for (int r = 0; r < RPT; ++r) {
+                            const double f = pr[r][t] * inv_d;
+#pragma unroll
+                            for (int tt = 0; tt < NBT; ++tt)
+                                if (tt != t) pr[r][tt] -= f * pw[tt];
+                            pr[r][t] = -f;
                         }
-                    }
-                }
-                stamp(P, 1);   // panel gathered
-                // ONE barrier per pivot step: every wavefront reduces its candidates (VALU), the lane that owns the wavefront's best row publishes value, row
-                // AND the row's NBT panel entries (arrays double-buffered by step parity); after the barrier every thread reads the W entries, knows the pivot
-                // and has the pivot row -- no second round for "who won" and "hand me the row" (three barriers per step cost 5 - 6 us of a step's 6).
-                // The largest magnitude wins, the smallest row among equals: what the pivot-by-pivot kernel chooses.
-                double best = -1.0;
-                int best_row = 0x7fffffff;
-#pragma unroll
-                for (int r = 0; r < RPT; ++r) {
-                    const int i = ft + r * T;
-                    if (i < n && !((used_mine >> r) & 1u)) {
-                        const double v = fabs(pr[r][0]);
-                        if (v > best || (v == best && i < best_row)) best = v, best_row = i;
-                    }
-                }
-#pragma unroll
-                for (int t = 0; t < NBT; ++t) {
-                    if (t < nbp && !failed) {
-                        const int par = t & 1;
-                        sstamp(P, t, 0);
-                        const double wmax = dense_wave_max(best);
-                        const int wrow = dense_wave_min(best == wmax ? best_row : 0x7fffffff);
-                        if (wrow == 0x7fffffff) {
-                            if (lane == 0) cand_val[par][wave] = -1.0, cand_row[par][wave] = 0x7fffffff;
-                        } else if (best_row == wrow) {   // (rows are unique to a lane)
-                            cand_val[par][wave] = wmax, cand_row[par][wave] = wrow;
-                            const int rp = wrow / T;
+                        if (p % T == ft) {
+                            used_mine |= 1u << (p / T), piv_now |= 1u << (p / T);
+                            piv_row_s[t] = p;
+                            const int rp = p / T;
 #pragma unroll
                             for (int r = 0; r < RPT; ++r)
                                 if (r == rp) {
 #pragma unroll
-                                    for (int tt = 0; tt < NBT; ++tt) cand_rows[par][wave][tt] = pr[r][tt];
+                                    for (int tt = 0; tt < NBT; ++tt) pr[r][tt] = tt == t ? inv_d : pw[tt] * inv_d;
                                 }
                         }
-                        sstamp(P, t, 1);
-                        dense_lds_barrier();
-                        sstamp(P, t, 2);
-                        // the W candidates: lane w of every wavefront reads candidate w, two more VALU reductions -- the maximum, then the smallest
-                        // (row, wavefront) among those that have it (no registers for sixteen values per thread, no chain of dependent LDS reads)
-                        const double cv = lane < W ? cand_val[par][lane] : -1.0;
-                        const int cr = lane < W ? cand_row[par][lane] : 0x7fffffff;
-                        const double wb = dense_wave_max(cv);
-                        const int key = dense_wave_min((cv == wb && cr != 0x7fffffff) ? cr * W + lane : 0x7fffffff);
-                        if (key == 0x7fffffff || !(wb > 0.0) || !isfinite(wb)) {
-                            failed = 1;
-                        } else {
-                            const int p = key / W, ws = key - p * W;
-                            sstamp(P, t, 3);
-                            double pw[NBT];   // the pivot row's panel entries (LDS, the same address in every lane: broadcast reads), once per step
-#pragma unroll
-                            for (int tt = 0; tt < NBT; ++tt) pw[tt] = cand_rows[par][ws][tt];
-                            const double inv_d = 1.0 / pw[t];
-                            sstamp(P, t, 4);
-                            // every row as an ordinary row, without a branch (rows beyond n hold zeros and keep them; the pivot row itself comes out as
-                            // zeros and is set below by the one thread that owns it)
+                        sstamp(P, t, 5);
+                        best = -1.0;
+                        if (t + 1 < NBT && t + 1 < nbp) {
 #pragma unroll
                             for (int r = 0; r < RPT; ++r) {
-                                const double f = pr[r][t] * inv_d;
-#pragma unroll
-                                for (int tt = 0; tt < NBT; ++tt)
-                                    if (tt != t) pr[r][tt] -= f * pw[tt];
-                                pr[r][t] = -f;
-                            }
-                            if (p % T == ft) {
-                                used_mine |= 1u << (p / T);
-                                piv_row_s[t] = p;
-                                const int rp = p / T;
-#pragma unroll
-                                for (int r = 0; r < RPT; ++r)
-                                    if (r == rp) {
-#pragma unroll
-                                        for (int tt = 0; tt < NBT; ++tt) pr[r][tt] = tt == t ? inv_d : pw[tt] * inv_d;
-                                    }
-                            }
-                            sstamp(P, t, 5);
-                            best = -1.0, best_row = 0x7fffffff;
-                            if (t + 1 < NBT && t + 1 < nbp) {
-#pragma unroll
-                                for (int r = 0; r < RPT; ++r) {
-                                    const int i = ft + r * T;
-                                    const double v = (i < n && !((used_mine >> r) & 1u)) ? fabs(pr[r][t + 1 < NBT ? t + 1 : t]) : -1.0;
-                                    const bool take = v > best || (v == best && v >= 0.0 && i < best_row);
-                                    best = take ? v : best, best_row = take ? i : best_row;
-                                }
+                                const int i = ft + r * T;
+                                const double kd = (i < n && !((used_mine >> r) & 1u)) ? dense_cand_key(fabs(pr[r][t + 1 < NBT ? t + 1 : t]), i) : -1.0;
+                                best = fmax(best, kd);
                             }
                         }
-                    }
-                }
-                dense_lds_barrier();
-                stamp(P, 2);   // panel factorised
-                if (!failed) {
-#pragma unroll
-                    for (int r = 0; r < RPT; ++r) {
-                        if (r * T < n) {
-#pragma unroll
-                            for (int t = 0; t < NBT; ++t) slab[ft * SL + t] = pr[r][t];
-                            dense_lds_barrier();
-#pragma unroll
-                            for (int q = 0; q < NBT; ++q) {
-                                const int idx = ft + q * T, li = idx / NBT, t = idx - li * NBT, i = r * T + li;
-                                if (i < n && t < nbp) dense_bstore(rs_next, (i * ld + k0 + t) * 8, 0, slab[li * SL + t]);
-                            }
-                            dense_lds_barrier();
-                        }
-                    }
-                    if (ft < nbp) {   // (written before the last barrier above; no global store inside the pivot steps)
-                        a.perm[k0 + ft] = piv_row_s[ft];
-                        __hip_atomic_store((dn_u32*)(a.piv_row + ft), (unsigned)piv_row_s[ft], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
             }
+            stamp(P, 0, 1);   // panel factorised
+            dense_lds_barrier();   // (piv_row_s of the last step)
+            const bool more = P + 1 < n_panels;
+            const int k1 = k0 + NB, nbp1 = n - k1 < NB ? n - k1 : NB;
+            // ---- the panel's final columns E into `next` (nobody reads these columns of that buffer: the workers still applying panel P - 1 skip them)
+            if (!failed) {
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) {
+                    if (r * T < n) {
+                        int ln = lane, wv = wave;   // (opaque copies: offsets derived from them are loop-invariant, and hoisted they are RPT x 16 registers)
+                        asm volatile("" : "+v"(ln), "+v"(wv));
+                        dense_lds_wave_sync();
+#pragma unroll
+                        for (int t = 0; t < NBT; ++t) slab[ln * SL + t] = pr[r][t];
+                        dense_lds_wave_sync();
+#pragma unroll
+                        for (int u = 0; u < NBT; ++u) {   // (16 lanes per row: whole 128-byte lines)
+                            const int rl = (64 / NBT) * u + ln / NBT, cl = ln % NBT, i = r * T + wv * 64 + rl;
+                            if (i < n && cl < nbp) dense_bstore(rs_next, (i * ld + k0 + cl) * 8, 0, slab[rl * SL + cl]);
+                        }
+                    }
+                }
+            }
+            // ---- every worker has finished the update of panel P - 1: buffer `cur` is complete
+            if (P > 0 && !failed) {
+                if (wave == 0) {
+                    int ok = 1;
+                    const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+                    for (int w = lane; w < G && ok; w += 64)
+                        while (__hip_atomic_load((const dn_u64*)(a.done + w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)P) {
+                            __builtin_amdgcn_s_sleep(1);
+                            if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
+                                ok = 0;
+                                break;
+                            }
+                        }
+                    ok = __all(ok);
+                    if (lane == 0) wait_s = ok;
+                }
+                __syncthreads();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (!wait_s) failed = 2;
+            }
+            stamp(P, 0, 2);   // update P - 1 done everywhere
+            if (!failed && ft < nbp) {   // (the workers read piv_row of panel P - 1 until they are done with it)
+                a.perm[k0 + ft] = piv_row_s[ft];
+                __hip_atomic_store((dn_u32*)(a.piv_row + ft), (unsigned)piv_row_s[ft], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            stamp(P, 3);   // panel written and drained
             if (tid == 0) {
                 if (failed) a.status[0] = failed;
                 __hip_atomic_store((dn_u64*)a.ready, ((unsigned long long)(P + 1) << 1) | (failed ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            stamp(P, 0, 3);   // panel published
+            if (failed || !more) return;
+            // ---- the columns of panel P + 1 after the update of panel P, computed HERE (the workers skip them): new = base + E S[pivot rows][columns of
+            // P + 1], rows in tiles of 16 (this wavefront's 64 rows of every row block, E through the slab into the A layout), the pivot rows' 16 x 16
+            // entries once per wavefront; the next block's base rows are loaded while this block is computed
+            {
+                double bf[NBT / 4];
+                auto load_base = [&](int r, dn_v4d (&acc)[4]) {
+                    int q = lane >> 4, jl = lane & 15, wv = wave;   // (opaque, as above)
+                    asm volatile("" : "+v"(q), "+v"(jl), "+v"(wv));
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int i = r * T + wv * 64 + 16 * rt + 4 * v + q;
+                            const bool ok = i < n && jl < nbp1;
+                            acc[rt][v] = dense_bload(rs_cur, ok ? (i * ld + k1 + jl) * 8 : 0, 0);
+                        }
+                    }
+                };
+                dn_v4d acc[4];
+#pragma unroll
+                for (int c = 0; c < NBT / 4; ++c) {
+                    const int s_ = 4 * c + q;
+                    const bool ok = s_ < nbp && jl < nbp1;
+                    const double x = dense_bload(rs_cur, ok ? (piv_row_s[s_ < nbp ? s_ : 0] * ld + k1 + jl) * 8 : 0, 0);
+                    bf[c] = ok ? x : 0.0;
+                }
+                load_base(0, acc);
+#pragma unroll
+                for (int r = 0; r < RPT; ++r) {
+                    asm volatile("" ::: "memory");   // (the loads of block r + 1 stay in block r)
+                    if (r * T >= n) {   // (a row block beyond the matrix: zeros)
+#pragma unroll
+                        for (int t = 0; t < NBT; ++t) pr[r][t] = 0.0;
+                        continue;
+                    }
+                    int q = lane >> 4, jl = lane & 15, ln = lane, wv = wave;   // (opaque copies, as above)
+                    asm volatile("" : "+v"(q), "+v"(jl), "+v"(ln), "+v"(wv));
+                    dense_lds_wave_sync();
+#pragma unroll
+                    for (int t = 0; t < NBT; ++t) slab[ln * SL + t] = pr[r][t];
+                    isp_s[wv * 64 + ln] = (unsigned char)((piv_now >> r) & 1u);
+                    dense_lds_wave_sync();
+                    dn_v4d cur[4];
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) cur[rt] = acc[rt];
+                    if (r + 1 < RPT && (r + 1) * T < n) load_base(r + 1, acc);
+                    asm volatile("" ::: "memory");
+                    double af[4][NBT / 4];
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+                        for (int c = 0; c < NBT / 4; ++c) af[rt][c] = slab[(16 * rt + jl) * SL + 4 * c + q];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int rl = 16 * rt + 4 * v + q, i = r * T + wv * 64 + rl;
+                            if (!(i < n && jl < nbp1) || isp_s[wv * 64 + rl]) cur[rt][v] = 0.0;   // (base = 0: the panel's pivot rows; nothing beyond the matrix)
+                        }
+                    }
+                    dense_lds_wave_sync();   // (the fragments are out of the slab before the new values go in)
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) {
+#pragma unroll
+                        for (int c = 0; c < NBT / 4; ++c) cur[rt] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[rt][c], bf[c], cur[rt], 0, 0, 0);
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            if (jl < NBT) slab[(16 * rt + 4 * v + q) * SL + jl] = cur[rt][v];
+                    }
+                    dense_lds_wave_sync();
+#pragma unroll
+                    for (int t = 0; t < NBT; ++t) pr[r][t] = (t < nbp1 && r * T + wv * 64 + ln < n) ? slab[ln * SL + t] : 0.0;
+                }
+            }
+            stamp(P, 0, 4);   // the next panel's columns in registers
         }
-        // ---- every workgroup: the panel is published
+        return;
+    }
+
+    // ======================================================================= the workers
+    // this workgroup's block of the update: rows [i0, i0 + nr) x columns [j0, j0 + nc)
+    const int i0 = (g / a.C) * a.RB, j0 = (g % a.C) * a.CB;
+    const int nr = i0 < n && j0 < n ? (n - i0 < a.RB ? n - i0 : a.RB) : 0, nc = i0 < n && j0 < n ? (n - j0 < a.CB ? n - j0 : a.CB) : 0;
+    const int rows_pad = (nr + 15) & ~15;
+    double* En = buf;                                                    // [rows_pad][16] the panel's final columns, this block's rows
+    unsigned char* is_piv = reinterpret_cast<unsigned char*>(En + (size_t)rows_pad * 16);    // [rows_pad] 1: the row is one of the panel's pivots
+    for (int P = 0; P < n_panels; ++P) {
+        const int k0 = P * NB, nbp = n - k0 < NB ? n - k0 : NB;
+        const int skip_end = k0 + 2 * NB;   // the columns of panels P and P + 1 are the panel workgroup's
+        const __amdgpu_buffer_rsrc_t rs_cur = (P & 1) ? rs1 : rs0, rs_next = (P & 1) ? rs0 : rs1;
         if (tid == 0) {
             const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
             unsigned long long x;
@@ -531,21 +607,7 @@ template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (!wait_s) return;
-        stamp(P, 4);   // panel seen
-        // ---- the update of this workgroup's BLOCK -- rows [i0, i0 + nr) x columns [j0, j0 + nc) of an R x C grid of blocks -- as small matrix products on
-        // the matrix cores (v_mfma_f64_16x16x4), 16 rows x 16 columns per operation.  In-place Gauss-Jordan leaves in the panel's columns the row
-        // operations themselves: after the panel's steps, E[i][u] = S'[i][k0 + u] is the coefficient of the ORIGINAL pivot row p_u in the new row i
-        // (one step: S'[i][j] = S[i][j] + S'[i][k] S[p][j] with S'[i][k] = -f_i, and S'[p][j] = S'[p][k] S[p][j] with S'[p][k] = 1 / d; by induction over
-        // the steps).  So, with the panel's final columns E as workgroup 0 has just written them,
-        //     S'[i][j] = base_i[j] + sum_u E[i][u] S[p_u][j],     base_i = S[i][.] for ordinary rows, 0 for the panel's pivot rows:
-        // no multipliers to publish, no triangle to solve -- the workers read their rows of E (one trip) and the pivots' indices.
-        // Why blocks and not whole rows per workgroup: every load here comes over the fabric (sc1: another XCD wrote the line), and with whole rows EVERY
-        // workgroup reads the 16 pivot rows in full -- at 2 116 rows 69 of a panel's 108 MB, 29 us; in blocks the pivot rows cross R times, not G times.
-        // (The scalar forms before: 16 multipliers from LDS per row and column and a 120-term triangle per column -- 38 of a panel's 77 us at 1 089
-        // rows went into LDS broadcasts.)
-        const int rows_pad = (nr + 15) & ~15;
-        double* En = buf;                                                    // [rows_pad][16] the panel's final columns, this block's rows
-        int* pt_own = reinterpret_cast<int*>(En + (size_t)rows_pad * 16);    // [rows_pad] 1: the row is one of the panel's pivots
+        if (g == 0) stamp(P, 1, 0);   // panel seen
         if (tid < nbp) piv_row_s[tid] = (int)__hip_atomic_load((const dn_u32*)(a.piv_row + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int idx = tid; idx < rows_pad * 16; idx += T) {   // (in flight with the pivots above; 16 lanes per row: whole 128-byte lines)
             const int rr = idx >> 4, t = idx & 15;
@@ -554,24 +616,23 @@ template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k
         }
         __syncthreads();
         for (int r = tid; r < rows_pad; r += T) {
-            int is_piv = 0;
+            unsigned char f = 0;
             for (int t = 0; t < nbp; ++t)
-                if (r < nr && piv_row_s[t] == i0 + r) is_piv = 1;
-            pt_own[r] = is_piv;
+                if (r < nr && piv_row_s[t] == i0 + r) f = 1;
+            is_piv[r] = f;
         }
         __syncthreads();
-        stamp(P, 5);   // the panel's rows in LDS
+        if (g == 0) stamp(P, 1, 1);   // the panel's rows in LDS
         {
-            typedef double dn_v4d __attribute__((ext_vector_type(4)));
-            constexpr int TU = 4;   // row blocks whose loads are in flight together
-            const int q = lane >> 4, jl = lane & 15, n_ct = (nc + 15) >> 4, n_rb = rows_pad >> 4;
-            // operand layouts (measured): A[i][k] in lane 16 k + i, B[k][j] in lane 16 k + j, D[4 v + q][j] in register v of lane 16 q + j
+            constexpr int TU = 4;   // row tiles whose loads are in flight together
+            const int n_ct = (nc + 15) >> 4, n_rb = rows_pad >> 4;
             int piv_off[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) piv_off[c] = 4 * c + q < nbp ? piv_row_s[4 * c + q] * ld * 8 : -1;
-            for (int ct = wave; ct < n_ct; ct += W) {   // a column tile per wavefront: its pivot-row fragment once, then the row blocks
+            for (int ct = wave; ct < n_ct; ct += W) {   // a column tile per wavefront: its pivot-row fragment once, then the row tiles
                 const int j = j0 + ct * 16 + jl, j8 = j * 8;   // (j < ld: inside the row; columns n .. ld - 1 are computed and not stored)
-                const bool col_ok = j < n && (j < k0 || j >= k0 + nbp);   // (the panel's own columns came from workgroup 0)
+                const bool col_ok = j < n && (j < k0 || j >= skip_end);
+                if (!__any(col_ok)) continue;   // (a tile entirely inside the two panels)
                 double bf[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -587,7 +648,7 @@ template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
                             const int r = rb * 16 + 4 * v + q;
-                            const bool base = rb < n_rb && r < nr && !pt_own[r < rows_pad ? r : 0];
+                            const bool base = rb < n_rb && r < nr && !is_piv[r < rows_pad ? r : 0];
                             const double x = dense_bload(rs_cur, base ? (i0 + r) * ld * 8 + j8 : 0, 0);
                             acc[u][v] = base ? x : 0.0;
                         }
@@ -610,10 +671,10 @@ template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k
                 }
             }
         }
-        stamp(P, 6);   // update issued
+        if (g == 0) stamp(P, 1, 2);   // update issued
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        stamp(P, 7);   // ... and drained
+        if (g == 0) stamp(P, 1, 3);   // ... and drained
         if (tid == 0) __hip_atomic_store((dn_u64*)(a.done + g), (unsigned long long)(P + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }

@@ -466,11 +466,12 @@ struct fdapde_ctx {
         bool ready = false, refine = false, failed = false;
         double check = 0, build_ms = 0;   // max |I - A X|; what the build cost (host wall clock)
     } lin_dense, step_dense, solve_dense;
-    int dense_direct = 0;         // knob: 1 = single columns of systems of up to 512 rows as ONE launch (k_dense_gemv_direct) instead of stage -> product -> out.
-                                  // Measured at 289 rows: 24.9 us against 21 - 24: the seams it saves cost what its PCIe reads per workgroup cost -- off
+    int dense_fold = 1;           // knob: 1 = the parabolic stepper's dense loop as ONE product per step (u' = B u + c, B = K^-1 M / dt); 0 = M u, rhs, K^-1 rhs, hand-over (four launches)
+    int dense_direct = 1;         // knob: 1 = a single column's product hands the result over itself (k_dense_gemv_direct): up to 512 rows the whole solve is that ONE launch
+                                  // (b permuted by the host into the pinned block, read by every workgroup), above that two launches; 0 = stage -> product -> out
     int dense_block = 1;          // knob: 0 = the inversion pivot by pivot (k_dense_invert) instead of in panels (k_dense_invert_blocked)
     int dense_rows = 4096;        // knob: systems of up to that many DOFs may take the dense path (0: never)
-    int dense_after = 8;          // knob: ... once a handle's matrix has been asked for more than that many columns / a stepper for that many steps
+    int dense_after = 2;          // knob: ... once a handle's matrix has been asked for more than that many columns / a stepper for that many steps
                                   // AND the Krylov time spent (handle) / to be expected (stepper) reaches half of what the inversion costs; 0: at once
     int64_t lin_cols = 0;         // columns solved against the handle's current matrix
     double lin_krylov_ms = 0;     // ... and the host time the Krylov columns among them took

@@ -177,7 +177,9 @@ static void launch_gemv(fdapde_ctx* c, const fdapde_ctx::Dense& D, int nc, const
     const dim3 grid((unsigned)((n + 3) / 4)), block(256);
     if (nc == 1) hipLaunchKernelGGL(k_dense_gemv<1>, grid, block, 0, c->stream, n, nc, D.X.p, v, y, accumulate);
     else if (nc <= 2) hipLaunchKernelGGL(k_dense_gemv<2>, grid, block, 0, c->stream, n, nc, D.X.p, v, y, accumulate);
-    else hipLaunchKernelGGL(k_dense_gemv<4>, grid, block, 0, c->stream, n, nc, D.X.p, v, y, accumulate);
+    else if (nc <= 4) hipLaunchKernelGGL(k_dense_gemv<4>, grid, block, 0, c->stream, n, nc, D.X.p, v, y, accumulate);
+    else if (nc <= 8) hipLaunchKernelGGL(k_dense_gemv<8>, grid, block, 0, c->stream, n, nc, D.X.p, v, y, accumulate);
+    else hipLaunchKernelGGL(k_dense_gemv<16>, grid, block, 0, c->stream, n, nc, D.X.p, v, y, accumulate);   // (64 columns: the rows cross four times, not sixteen)
 }
 
 // x = X b for nc columns, device to device, internal order (x must not alias b); one step of iterative refinement where the inverse asked for it
@@ -211,14 +213,26 @@ int dense_solve_host(fdapde_ctx* c, fdapde_ctx::Dense& D, const double* b_host, 
     double* hb = c->h_io;
     double* hx = c->h_io + cnt;
     volatile long long* done = reinterpret_cast<volatile long long*>(c->h_io + 2 * cnt);
-    std::memcpy(hb, b_host, sizeof(double) * cnt);
+    const bool one_launch = nc == 1 && !D.refine && c->dense_direct;
+    const bool host_b = one_launch && n <= 512;   // the whole solve as ONE launch: b permuted by the host on its way into the pinned block
+    if (host_b) {
+        if (int rc = ensure_host(c, kHostPerm)) return rc;
+        const int32_t* i2e = c->hs.dof_i2e.data();
+        for (size_t i = 0; i < n; ++i) hb[i] = b_host[i2e[i]];
+    } else
+        std::memcpy(hb, b_host, sizeof(double) * cnt);
     *done = 0;
     std::atomic_thread_fence(std::memory_order_release);
-    // stage, product(s), hand-over: three short launches behind each other.  (Measured and dropped: the whole solve of a 289-row system as ONE
-    // one-workgroup launch -- 35 us against 23: sixteen wavefronts walk eighteen rows each, latency-bound; and the last product handing the result over
-    // itself through a last-arriver copy -- 33 us against 29.5 at 1 089 rows: the serial tail costs more than the launch it saves.)
-    if (nc == 1 && !D.refine && n <= 512 && c->dense_direct) {   // the whole solve as one launch (the right-hand side read over PCIe by every workgroup: small n only)
-        hipLaunchKernelGGL(k_dense_gemv_direct, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (int)n, D.X.p, c->dof_i2e.p, hb, hx, const_cast<long long*>(done), c->dn_cnt.p + 1);
+    // One column: the product hands the result over itself (k_dense_gemv_direct) -- up to 512 rows as the only launch (every workgroup reads b from the pinned
+    // block), above that behind k_dense_stage.  Several columns / an inverse that asked for refinement: stage, product(s), hand-over.
+    // (Measured and dropped: the whole solve of a 289-row system as a ONE-WORKGROUP launch -- 35 us against 23: sixteen wavefronts walk eighteen rows each,
+    // latency-bound.)
+    const dim3 dgrid((unsigned)((n + 3) / 4));
+    if (host_b) {
+        hipLaunchKernelGGL(k_dense_gemv_direct<true>, dgrid, dim3(256), 0, st, (int)n, D.X.p, c->dof_i2e.p, hb, hx, const_cast<long long*>(done), c->dn_cnt.p + 1);
+    } else if (one_launch) {
+        hipLaunchKernelGGL(k_dense_stage, dim3(g1((int64_t)cnt)), dim3(256), 0, st, (int64_t)n, nc, c->dof_i2e.p, hb, c->dn_b.p, c->dn_cnt.p);
+        hipLaunchKernelGGL(k_dense_gemv_direct<false>, dgrid, dim3(256), 0, st, (int)n, D.X.p, c->dof_i2e.p, c->dn_b.p, hx, const_cast<long long*>(done), c->dn_cnt.p + 1);
     } else {
         hipLaunchKernelGGL(k_dense_stage, dim3(g1((int64_t)cnt)), dim3(256), 0, st, (int64_t)n, nc, c->dof_i2e.p, hb, c->dn_b.p, c->dn_cnt.p);
         if (int rc = dense_apply(c, D, nc, c->dn_b.p, c->dn_x.p)) return rc;
@@ -264,6 +278,32 @@ void dense_step_rhs(fdapde_ctx* c, const double* mu, double inv_dt, const double
 void dense_step_out(fdapde_ctx* c, const double* u, double* uprev, double* sol_ext_dev) {
     const int64_t n = c->hs.n_dofs;
     hipLaunchKernelGGL(k_dense_step_out, dim3(g1(n)), dim3(256), 0, c->stream, n, u, c->dof_i2e.p, uprev, sol_ext_dev);
+}
+
+// the parabolic stepper's loop with K^-1 = D.X in hand, ONE product per step (kernels_dense.h, k_dense_step): u0 = the initial condition (internal order, device),
+// sol_ext = n x n_times columns in the reference numbering (device; column 0 is the caller's).  Needs an inverse that asked for no refinement.
+int dense_step_loop(fdapde_ctx* c, fdapde_ctx::Dense& D, int32_t n_times, double inv_dt, const double* g_ext_dev, double* u0, double* sol_ext) {
+    const int64_t n = D.n, nt = n_times - 1;
+    hipStream_t st = c->stream;
+    DBuf<double> B, F, Cm, u1;
+    HIPCHK(c, B.alloc((size_t)n * n));
+    HIPCHK(c, F.alloc((size_t)n * nt));
+    HIPCHK(c, Cm.alloc((size_t)n * nt));
+    HIPCHK(c, u1.alloc((size_t)n));
+    hipLaunchKernelGGL(k_dense_xm, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, st, n, D.X.p, c->rowptr.p, c->colidx.p, c->vals[FDAPDE_MAT_MASS].p, c->bnd.p, D.use_bnd, inv_dt, B.p);
+    hipLaunchKernelGGL(k_dense_step_cols, dim3(g1(n * nt)), dim3(256), 0, st, n, nt, c->force.p, D.use_bnd ? g_ext_dev : nullptr, c->dof_i2e.p, c->bnd.p, F.p);
+    launch_gemv(c, D, (int)nt, F.p, Cm.p, 0);
+    double* cur = u0;
+    double* nxt = u1.p;
+    const dim3 grid((unsigned)((n + 3) / 4)), block(256);
+    for (int64_t i = 0; i < nt; ++i) {
+        hipLaunchKernelGGL(k_dense_step, grid, block, 0, st, n, B.p, cur, Cm.p + (size_t)i * n, c->dof_i2e.p, nxt, sol_ext + (size_t)(i + 1) * n);
+        std::swap(cur, nxt);
+    }
+    HIPCHK(c, hipGetLastError());
+    if (cur != c->u.p) HIPCHK(c, hipMemcpyAsync(c->u.p, cur, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));   // (the last step's solution, where fdapde_solution looks)
+    HIPCHK(c, hipStreamSynchronize(st));   // (the buffers above go out of scope)
+    return FDAPDE_OK;
 }
 
 void preload_dense() {

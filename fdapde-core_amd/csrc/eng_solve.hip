@@ -1170,6 +1170,9 @@ int e_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times,
             to_internal(initial_condition);
             HIPCHK(c, hipMemcpyAsync(uprev.p, tmp.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
             HIPCHK(c, hipStreamSynchronize(st));   // (tmp is pageable)
+            if (!D.refine && c->dense_fold) {   // ONE product per step: u_{i+1} = (K^-1 M / dt) u_i + K^-1 (f_{i+1}, g_{i+1})
+                if (int rc = dense_step_loop(c, D, n_times, inv_dt, dirichlet ? d_dir.p : nullptr, uprev.p, d_sol.p)) return rc;
+            } else
             for (int32_t i = 0; i + 1 < n_times; ++i) {
                 launch_spmv(c, c->vals[FDAPDE_MAT_MASS].p, uprev.p, c->s.p, nullptr, nullptr, nullptr);   // M u_i
                 dense_step_rhs(c, c->s.p, inv_dt, c->force.p + (size_t)(i + 1) * n, dirichlet ? d_dir.p + (size_t)(i + 1) * n : nullptr, rhs.p);   // (+ rhs[boundary] = g(., i + 1), line 66)

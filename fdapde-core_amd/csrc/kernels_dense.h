@@ -13,12 +13,16 @@
 //                     workgroup copies the pivot row to LDS, updates its rows, and -- in the same sweep -- finds its candidate for the NEXT
 //                     column's pivot.  Rows are never swapped (a permutation is recorded), the pivot row's own scaling is deferred to its
 //                     owner's next visit, so nobody writes a row somebody else may still be reading.
+//   k_dense_invert_blocked  the default: the same elimination 16 pivots at a time -- a panel workgroup that factorises in registers one panel ahead, the update
+//                     of everything else as 16 x 16 tiles on the f64 matrix cores with the panel's own final columns as the operand (described at the kernel)
 //   k_dense_unpermute the inverse in natural row / column order from the in-place result and the pivot sequence
 //   k_dense_check     max |I - A X| through the sparse rows of A (decides whether a solve adds one step of iterative refinement)
 //   k_dense_stage / k_dense_gemv / k_dense_residual / k_dense_out   a solve: right-hand sides from pinned host memory into internal order,
 //                     x = X b (one wavefront per row, the columns in tiles of NC), optionally r = b - A x and x += X r, the result back in the
 //                     reference numbering into pinned host memory and a completion word the host spins on
-// HBM / cache-bound streaming of X (n^2 doubles per column tile): no MFMA -- a GEMV has no reuse to feed one.
+//   k_dense_xm / k_dense_step_cols / k_dense_step   the implicit Euler stepper folded into one product per step (B = X D M / dt once, then u' = B u + c)
+// The products are HBM / cache-bound streaming of X (n^2 doubles per column tile): no MFMA -- a GEMV has no reuse to feed one; the inversion's update is a
+// 16-deep product per tile and runs on v_mfma_f64_16x16x4.
 #ifndef FDAPDE_KERNELS_DENSE_H
 #define FDAPDE_KERNELS_DENSE_H
 
@@ -715,45 +719,69 @@ static __global__ void k_dense_stage(int64_t n, int nc, const int32_t* i2e, cons
     b_int[t] = b_ext[c * n + i2e[i]];
 }
 
-// y (+)= X v for nc columns (column-major n x nc), one wavefront per row, the columns in tiles of NC
+// y (+)= X v for nc columns (column-major n x nc), one wavefront per row, the columns in tiles of NC.  The row is walked four 64-entry chunks at a time,
+// all loads of a round issued before the first multiply (a plain loop waited for every chunk's trip to L2 in turn: 17 trips, 7 us at 1 089 rows).
 template <int NC> static __global__ __launch_bounds__(256) void k_dense_gemv(int64_t n, int nc, const double* X, const double* v, double* y, int accumulate) {
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= n) return;
     const double* row = X + i * n;
+    constexpr int U = NC <= 2 ? 4 : NC <= 4 ? 2 : 1;   // chunks per round
     for (int c0 = 0; c0 < nc; c0 += NC) {
         double acc[NC];
 #pragma unroll
         for (int q = 0; q < NC; ++q) acc[q] = 0.0;
-        for (int64_t j = lane; j < n; j += 64) {
-            const double x = row[j];
+        for (int64_t j0 = lane; j0 < n; j0 += 64 * U) {
+            double x[U], w[U][NC];
 #pragma unroll
-            for (int q = 0; q < NC; ++q)
-                if (c0 + q < nc) acc[q] += x * v[(int64_t)(c0 + q) * n + j];
+            for (int u = 0; u < U; ++u) {
+                const int64_t j = j0 + 64 * u;
+                x[u] = j < n ? row[j] : 0.0;
+#pragma unroll
+                for (int q = 0; q < NC; ++q) w[u][q] = (j < n && c0 + q < nc) ? v[(int64_t)(c0 + q) * n + j] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int q = 0; q < NC; ++q) acc[q] += x[u] * w[u][q];
+            }
         }
 #pragma unroll
         for (int q = 0; q < NC; ++q) {
-            double s = acc[q];
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            const double s = wave_sum(acc[q]);
             if (lane == 0 && c0 + q < nc) y[(int64_t)(c0 + q) * n + i] = accumulate ? y[(int64_t)(c0 + q) * n + i] + s : s;
         }
     }
 }
 
-// ONE column of a very small system (<= 512 rows) as ONE launch: every workgroup reads the right-hand side straight from pinned host memory (n x 8 bytes
-// per workgroup over PCIe: 2.3 KB at 289 rows -- affordable only while n and the workgroup count are small), a wavefront per row, the result straight
-// into pinned host memory in the reference numbering, the last workgroup to arrive signals the host.  Saves the two launch seams of stage -> product -> out.
-static __global__ __launch_bounds__(256) void k_dense_gemv_direct(int n, const double* X, const int32_t* i2e, const double* b_ext, double* x_ext, long long* done,
-                                                                  unsigned int* count) {
-    __shared__ double b_s[512];
-    for (int j = threadIdx.x; j < n; j += blockDim.x) b_s[j] = b_ext[i2e[j]];
-    __syncthreads();
+// ONE column, product and hand-over in ONE launch: x = X b with b in the internal order, the result straight into pinned host memory in the reference numbering,
+// the last workgroup to arrive signals the host.  HOSTB: b sits in pinned HOST memory (the host has permuted it while copying it there) and every workgroup reads it
+// once into LDS -- n x 8 bytes per workgroup over PCIe in whole lines, affordable while n and the workgroup count are small (<= 512 rows: 73 x 2.3 KB at 289); the whole
+// solve is then this one launch.  Otherwise b is a device vector (k_dense_stage in front: two launches instead of stage -> product -> out).
+// (The first form of this kernel gathered b_ext[i2e[j]] over PCIe -- 21 000 lone 8-byte reads at 289 rows, 35 us -- and was left off.)
+template <bool HOSTB> static __global__ __launch_bounds__(256) void k_dense_gemv_direct(int n, const double* X, const int32_t* i2e, const double* b_int, double* x_ext,
+                                                                                    long long* done, unsigned int* count) {
+    __shared__ double b_s[HOSTB ? 512 : 1];
+    if (HOSTB) {
+        for (int j = threadIdx.x; j < n; j += blockDim.x) b_s[j] = b_int[j];
+        __syncthreads();
+    }
+    const double* bv = HOSTB ? b_s : b_int;
     const int lane = threadIdx.x & 63, i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i < n) {
         const double* row = X + (int64_t)i * n;
         double s = 0.0;
-        for (int j = lane; j < n; j += 64) s += row[j] * b_s[j];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        for (int j0 = lane; j0 < n; j0 += 256) {   // (four chunks' loads in flight: see k_dense_gemv)
+            double x[4], w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = j0 + 64 * k;
+                x[k] = j < n ? row[j] : 0.0, w[k] = j < n ? bv[j] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += x[k] * w[k];
+        }
+        s = wave_sum(s);
         if (lane == 0) x_ext[i2e[i]] = s;
     }
     __threadfence_system();
@@ -765,6 +793,53 @@ static __global__ __launch_bounds__(256) void k_dense_gemv_direct(int n, const d
         __hip_atomic_store((dn_u32*)count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (ready for the next launch)
         __threadfence_system();
         __atomic_store_n(reinterpret_cast<volatile long long*>(done), 1ll, __ATOMIC_RELEASE);
+    }
+}
+
+// The implicit Euler stepper with K^-1 = X in hand (fem_linear_parabolic_solver.h:56-68: rhs = M u_i / dt + f_{i+1}, Dirichlet rows = g, u_{i+1} = K^-1 rhs) folded into
+// ONE product per step:  u_{i+1} = B u_i + c_{i+1},   B = X D M / dt (D: 1 on the rows that are not Dirichlet rows),   c_{i+1} = X (D f_{i+1} + (1 - D) g_{i+1}).
+// k_dense_xm builds B (M is symmetric: column j of M is its row j), k_dense_step_cols the right-hand sides of all steps (C = X F with k_dense_gemv), k_dense_step one step.
+static __global__ void k_dense_xm(int64_t n, const double* X, const int32_t* rowptr, const int32_t* colidx, const double* mass, const uint8_t* bnd, int use_bnd, double inv_dt,
+                                  double* B) {
+    const int64_t i = blockIdx.y;
+    const double* xr = X + i * n;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int32_t k = rowptr[j]; k < rowptr[j + 1]; ++k) {
+            const int32_t r = colidx[k];
+            if (!(use_bnd && bnd[r])) s += xr[r] * mass[k];
+        }
+        B[i * n + j] = s * inv_dt;
+    }
+}
+// F[., t] = f(., t + 1) with g(., t + 1) on the Dirichlet rows (g in the reference numbering), t = 0 .. nt - 1, internal order
+static __global__ void k_dense_step_cols(int64_t n, int64_t nt, const double* force, const double* g_ext, const int32_t* i2e, const uint8_t* bnd, double* F) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * nt) return;
+    const int64_t c = t / n, i = t - c * n;
+    F[t] = (g_ext && bnd[i]) ? g_ext[(c + 1) * n + i2e[i]] : force[(c + 1) * n + i];
+}
+// u_next = B u + c; also into the solution column (reference numbering); one wavefront per row
+static __global__ __launch_bounds__(256) void k_dense_step(int64_t n, const double* B, const double* u, const double* cvec, const int32_t* i2e, double* u_next, double* sol_ext) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const double* row = B + i * n;
+    double s = 0.0;
+    for (int64_t j0 = lane; j0 < n; j0 += 256) {   // (four chunks' loads in flight: see k_dense_gemv)
+        double x[4], w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t j = j0 + 64 * k;
+            x[k] = j < n ? row[j] : 0.0, w[k] = j < n ? u[j] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s += x[k] * w[k];
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        const double v = s + cvec[i];
+        u_next[i] = v, sol_ext[i2e[i]] = v;
     }
 }
 

@@ -61,9 +61,9 @@ def test_handle_takes_the_dense_inverse_after_a_few_columns(env, name, order, ki
         seen.append(info.method_used)
         ref = lu.solve(b)
         assert info.converged == 1 and np.linalg.norm(x - ref) <= 1e-9 * np.linalg.norm(ref), (k, info.method_used)
-    # rent or buy: never within the first `dense_after` (8) columns, and for the reference's own sizes within a few dozen; a 4 225-row system only after
-    # hundreds of columns (its inversion costs ~0.4 s) -- or at once when told so (dense_after 0, below)
-    assert capi.SOLVER_DENSE not in seen[:8]
+    # rent or buy: never within the first `dense_after` (2) columns, and for the reference's own sizes within a dozen; a 4 225-row system only after
+    # dozens of columns (its inversion costs ~70 ms) -- or at once when told so (dense_after 0, below)
+    assert capi.SOLVER_DENSE not in seen[:2]
     if nd < 1200:
         assert seen[-1] == capi.SOLVER_DENSE
     else:
@@ -82,7 +82,7 @@ def test_handle_takes_the_dense_inverse_after_a_few_columns(env, name, order, ki
     # a method named explicitly runs as named; a new matrix starts over
     x, info = c.lin_solve(B[:, 0], method=capi.SOLVER_BICGSTAB, rtol=1e-12)
     assert info.method_used == capi.SOLVER_BICGSTAB
-    c.tune("dense_after", 8)
+    c.tune("dense_after", 2)
     c.lin_compute(values=2.0 * vals, symmetric=False)
     x, info = c.lin_solve(B[:, 0], rtol=1e-12)
     assert info.method_used != capi.SOLVER_DENSE and np.linalg.norm(2.0 * x - lu.solve(B[:, 0])) <= 1e-8 * np.linalg.norm(x)

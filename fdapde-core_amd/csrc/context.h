@@ -467,8 +467,10 @@ struct fdapde_ctx {
         double check = 0, build_ms = 0;   // max |I - A X|; what the build cost (host wall clock)
     } lin_dense, step_dense, solve_dense;
     int dense_fold = 1;           // knob: 1 = the parabolic stepper's dense loop as ONE product per step (u' = B u + c, B = K^-1 M / dt); 0 = M u, rhs, K^-1 rhs, hand-over (four launches)
-    int dense_direct = 1;         // knob: 1 = a single column's product hands the result over itself (k_dense_gemv_direct): up to 512 rows the whole solve is that ONE launch
-                                  // (b permuted by the host into the pinned block, read by every workgroup), above that two launches; 0 = stage -> product -> out
+    int dense_direct = 0;         // knob: 1 = a single column's product hands the result over itself (k_dense_gemv_direct): up to 512 rows the whole solve is that ONE launch
+                                  // (b permuted by the host into the pinned block, read by every workgroup), above that two launches; 0 = stage -> product -> out.
+                                  // Measured (us per column, 289 / 1 089 / 4 225 rows): 30 / 43 - 140 / 83 - 159 against 21 / 27 / 57 -- every wavefront's hand-over to the
+                                  // host (write-through stores drained, or a system-scope fence that also empties the L2 of X) costs more than the launches it saves: off
     int dense_block = 1;          // knob: 0 = the inversion pivot by pivot (k_dense_invert) instead of in panels (k_dense_invert_blocked)
     int dense_rows = 4096;        // knob: systems of up to that many DOFs may take the dense path (0: never)
     int dense_after = 2;          // knob: ... once a handle's matrix has been asked for more than that many columns / a stepper for that many steps

@@ -223,9 +223,9 @@ int dense_solve_host(fdapde_ctx* c, fdapde_ctx::Dense& D, const double* b_host, 
         std::memcpy(hb, b_host, sizeof(double) * cnt);
     *done = 0;
     std::atomic_thread_fence(std::memory_order_release);
-    // One column: the product hands the result over itself (k_dense_gemv_direct) -- up to 512 rows as the only launch (every workgroup reads b from the pinned
-    // block), above that behind k_dense_stage.  Several columns / an inverse that asked for refinement: stage, product(s), hand-over.
-    // (Measured and dropped: the whole solve of a 289-row system as a ONE-WORKGROUP launch -- 35 us against 23: sixteen wavefronts walk eighteen rows each,
+    // stage, product(s), hand-over: three short launches behind each other.  Knob dense_direct (off: measured slower, context.h): one column's product hands the
+    // result over itself (k_dense_gemv_direct) -- up to 512 rows as the only launch (every workgroup reads b from the pinned block), above that behind k_dense_stage.
+    // (Also measured and dropped: the whole solve of a 289-row system as a ONE-WORKGROUP launch -- 35 us against 23: sixteen wavefronts walk eighteen rows each,
     // latency-bound.)
     const dim3 dgrid((unsigned)((n + 3) / 4));
     if (host_b) {

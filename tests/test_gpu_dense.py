@@ -188,3 +188,94 @@ def test_open_method_ends_in_the_direct_stage_on_small_advection_dominated_syste
         g = c.solve(rtol=1e-10, raise_on_noconv=False)
         assert g.method_used in (capi.SOLVER_GMRES, capi.SOLVER_BICGSTAB)
     c.close()
+
+
+@pytest.mark.parametrize("nx", [2, 3, 4, 22, 31, 32, 38, 39, 44, 45, 63, 64])
+def test_inversion_across_panel_layouts_with_random_values(env, nx):
+    """9 .. 4 225 rows: fewer rows than a panel, exact multiples of 16 and of 512 (the panel's row blocks: <2,16> <3,16> <4,16> <8,8> <16,4> of
+    k_dense_invert_blocked), one more than each; values drawn at random on the FEM pattern (no diagonal dominance: the pivot search has to work, the
+    panel's pivot rows end up anywhere in the update's grid of blocks) -- every column against SuperLU through the residual and the solution"""
+    import scipy.sparse.linalg as spl
+
+    capi, meshgen, _ = env
+    nodes, cells, bnd = meshgen.unit_square(nx)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(1)
+    c.set_operator(-capi.laplacian() + capi.reaction(1.0))
+    c.set_forcing(np.ones(c.quadrature_nodes().shape[0]))
+    c.init()
+    rng = np.random.default_rng(1000 + nx)
+    rp, ci = c.pattern_get()
+    vals = rng.uniform(-1.0, 1.0, ci.size)
+    diag = np.repeat(np.arange(nd), np.diff(rp)) == ci
+    vals[diag] += np.where(rng.random(nd) < 0.5, -1.5, 1.5)   # (a non-singular matrix with either sign on the diagonal; off-diagonal sums still exceed it)
+    A = _csr(c, vals, nd)
+    lu = spl.splu(A.tocsc())
+    c.tune("dense_after", 0)
+    c.tune("dense_rows", 4608)
+    c.lin_compute(values=vals, symmetric=False)
+    B = rng.standard_normal((nd, 3))
+    X, info = c.lin_solve(B, rtol=1e-12)
+    assert info.method_used == capi.SOLVER_DENSE and info.converged == 1
+    for j in range(3):
+        ref = lu.solve(B[:, j])
+        assert np.linalg.norm(A @ X[:, j] - B[:, j]) <= 1e-9 * np.linalg.norm(B[:, j]), (nd, j)
+        assert np.linalg.norm(X[:, j] - ref) <= 1e-7 * np.linalg.norm(ref), (nd, j)
+    x1, info = c.lin_solve(B[:, 0], rtol=1e-12)   # (one column: its own kernels)
+    assert info.method_used == capi.SOLVER_DENSE and np.linalg.norm(x1 - X[:, 0]) <= 1e-12 * np.linalg.norm(x1)
+    c.close()
+
+
+@pytest.mark.parametrize("fold", [1, 0])
+def test_both_forms_of_the_dense_stepper_agree(env, fold):
+    """one product per step (u' = B u + c) against M u, right-hand side, K^-1 rhs, hand-over: the same columns to rounding, with and without Dirichlet data"""
+    capi, meshgen, _ = env
+    nodes, cells, bnd = meshgen.unit_square(20)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(1)
+    _, bd, coords = c.dofs_get()
+    qn = c.quadrature_nodes()
+    times = np.linspace(0.0, 0.5, 41)
+    c.set_operator(capi.dt() - capi.laplacian() + capi.reaction(0.3))
+    c.set_forcing(np.stack([np.cos(3.0 * qn[:, 1]) * (1.0 + t) for t in times], axis=1))
+    c.init()
+    u0 = np.cos(coords[:, 0]) * coords[:, 1]
+    G = np.stack([0.2 * np.sin(coords[:, 0] - t) for t in times], axis=1)
+    c.tune("dense_fold", fold)
+    sol, info = c.solve_parabolic(times, u0, G, rtol=1e-12)
+    assert info.method_used == capi.SOLVER_DENSE
+    c.tune("dense_rows", 0)
+    ref, info_k = c.solve_parabolic(times, u0, G, rtol=1e-13)
+    assert info_k.method_used != capi.SOLVER_DENSE
+    assert np.abs(sol - ref).max() <= 1e-9 * np.abs(ref).max()
+    bidx = np.nonzero(bd)[0]
+    assert np.abs(sol[bidx, 1:] - G[bidx, 1:]).max() <= 1e-12
+    c.close()
+
+
+@pytest.mark.parametrize("grid", ["1,1", "2,3", "7,5", "31,8"])
+def test_inversion_does_not_depend_on_the_grid_of_blocks(env, grid, monkeypatch):
+    """the update's R x C grid of blocks (one workgroup each) forced to odd shapes -- a single worker, blocks that are not multiples of anything, more
+    row blocks than rows of tiles -- gives the inverse the default grid gives, to rounding"""
+    capi, meshgen, _ = env
+    nodes, cells, bnd = meshgen.unit_square(32)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(1)
+    c.set_operator(-capi.laplacian() + capi.advection([20.0, 5.0]) + capi.reaction(1.0))
+    c.set_forcing(np.ones(c.quadrature_nodes().shape[0]))
+    c.init()
+    c.tune("dense_after", 0)
+    rng = np.random.default_rng(5)
+    B = rng.standard_normal((nd, 2))
+    c.lin_compute(capi.MAT_STIFF)
+    X0, info = c.lin_solve(B, rtol=1e-12)
+    assert info.method_used == capi.SOLVER_DENSE
+    monkeypatch.setenv("FDAPDE_DENSE_GRID", grid)
+    c.lin_compute(capi.MAT_STIFF)
+    X1, info = c.lin_solve(B, rtol=1e-12)
+    assert info.method_used == capi.SOLVER_DENSE
+    assert np.abs(X1 - X0).max() <= 1e-11 * np.abs(X0).max()
+    c.close()

@@ -467,6 +467,8 @@ struct fdapde_ctx {
         double check = 0, build_ms = 0;   // max |I - A X|; what the build cost (host wall clock)
     } lin_dense, step_dense, solve_dense;
     int dense_fold = 1;           // knob: 1 = the parabolic stepper's dense loop as ONE product per step (u' = B u + c, B = K^-1 M / dt); 0 = M u, rhs, K^-1 rhs, hand-over (four launches)
+    int dense_hostb = 0;          // knob: 1 = one column of a system of up to 512 rows: the product reads b from the pinned block itself (k_dense_gemv_hostb), no k_dense_stage in front.
+                                  // Measured: 33 us per column against 22 at 289 and 484 rows -- a workgroup's read of host memory costs ~10 us, twice the launch it saves: off
     int dense_direct = 0;         // knob: 1 = a single column's product hands the result over itself (k_dense_gemv_direct): up to 512 rows the whole solve is that ONE launch
                                   // (b permuted by the host into the pinned block, read by every workgroup), above that two launches; 0 = stage -> product -> out.
                                   // Measured (us per column, 289 / 1 089 / 4 225 rows): 30 / 43 - 140 / 83 - 159 against 21 / 27 / 57 -- every wavefront's hand-over to the

@@ -214,7 +214,7 @@ int dense_solve_host(fdapde_ctx* c, fdapde_ctx::Dense& D, const double* b_host, 
     double* hx = c->h_io + cnt;
     volatile long long* done = reinterpret_cast<volatile long long*>(c->h_io + 2 * cnt);
     const bool one_launch = nc == 1 && !D.refine && c->dense_direct;
-    const bool host_b = one_launch && n <= 512;   // the whole solve as ONE launch: b permuted by the host on its way into the pinned block
+    const bool host_b = nc == 1 && !D.refine && n <= 512 && (c->dense_direct || c->dense_hostb);   // b permuted by the host on its way into the pinned block
     if (host_b) {
         if (int rc = ensure_host(c, kHostPerm)) return rc;
         const int32_t* i2e = c->hs.dof_i2e.data();
@@ -228,8 +228,11 @@ int dense_solve_host(fdapde_ctx* c, fdapde_ctx::Dense& D, const double* b_host, 
     // (Also measured and dropped: the whole solve of a 289-row system as a ONE-WORKGROUP launch -- 35 us against 23: sixteen wavefronts walk eighteen rows each,
     // latency-bound.)
     const dim3 dgrid((unsigned)((n + 3) / 4));
-    if (host_b) {
+    if (host_b && one_launch) {
         hipLaunchKernelGGL(k_dense_gemv_direct<true>, dgrid, dim3(256), 0, st, (int)n, D.X.p, c->dof_i2e.p, hb, hx, const_cast<long long*>(done), c->dn_cnt.p + 1);
+    } else if (host_b) {   // two launches: the product reads b from the pinned block itself, then the hand-over
+        hipLaunchKernelGGL(k_dense_gemv_hostb, dgrid, dim3(256), 0, st, (int)n, D.X.p, hb, c->dn_x.p, c->dn_cnt.p);
+        hipLaunchKernelGGL(k_dense_out, dim3(g1((int64_t)cnt)), dim3(256), 0, st, (int64_t)n, nc, c->dof_e2i.p, c->dn_x.p, hx, const_cast<long long*>(done), c->dn_cnt.p);
     } else if (one_launch) {
         hipLaunchKernelGGL(k_dense_stage, dim3(g1((int64_t)cnt)), dim3(256), 0, st, (int64_t)n, nc, c->dof_i2e.p, hb, c->dn_b.p, c->dn_cnt.p);
         hipLaunchKernelGGL(k_dense_gemv_direct<false>, dgrid, dim3(256), 0, st, (int)n, D.X.p, c->dof_i2e.p, c->dn_b.p, hx, const_cast<long long*>(done), c->dn_cnt.p + 1);

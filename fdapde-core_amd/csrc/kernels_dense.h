@@ -754,6 +754,31 @@ template <int NC> static __global__ __launch_bounds__(256) void k_dense_gemv(int
     }
 }
 
+// x = X b for ONE column of a system of up to 512 rows, b read straight from pinned HOST memory (internal order: the host permutes it while copying it there) once
+// per workgroup into LDS -- 73 x 2.3 KB over PCIe in whole lines at 289 rows: a PCIe round trip instead of the launch seam of k_dense_stage.
+static __global__ __launch_bounds__(256) void k_dense_gemv_hostb(int n, const double* X, const double* b_host, double* y, unsigned int* count) {
+    __shared__ double b_s[512];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count = 0u;   // (the arrival counter of k_dense_out behind this launch)
+    for (int j = threadIdx.x; j < n; j += blockDim.x) b_s[j] = b_host[j];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const double* row = X + (int64_t)i * n;
+    double s = 0.0;
+    for (int j0 = lane; j0 < n; j0 += 256) {
+        double x[4], w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = j0 + 64 * k;
+            x[k] = j < n ? row[j] : 0.0, w[k] = j < n ? b_s[j] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s += x[k] * w[k];
+    }
+    s = wave_sum(s);
+    if (lane == 0) y[i] = s;
+}
+
 // ONE column, product and hand-over in ONE launch: x = X b with b in the internal order, the result straight into pinned host memory in the reference numbering,
 // the last workgroup to arrive signals the host.  HOSTB: b sits in pinned HOST memory (the host has permuted it while copying it there) and every workgroup reads it
 // once into LDS -- n x 8 bytes per workgroup over PCIe in whole lines, affordable while n and the workgroup count are small (<= 512 rows: 73 x 2.3 KB at 289); the whole

@@ -473,8 +473,9 @@ struct fdapde_ctx {
                                   // (b permuted by the host into the pinned block, read by every workgroup), above that two launches; 0 = stage -> product -> out.
                                   // Measured (us per column, 289 / 1 089 / 4 225 rows): 30 / 43 - 140 / 83 - 159 against 21 / 27 / 57 -- every wavefront's hand-over to the
                                   // host (write-through stores drained, or a system-scope fence that also empties the L2 of X) costs more than the launches it saves: off
+    int dense_multi = 1;          // knob: 0 = above 4 096 rows ONE panel workgroup with a panel of 4 columns instead of several with 16
     int dense_block = 1;          // knob: 0 = the inversion pivot by pivot (k_dense_invert) instead of in panels (k_dense_invert_blocked)
-    int dense_rows = 4096;        // knob: systems of up to that many DOFs may take the dense path (0: never)
+    int dense_rows = 8192;        // knob: systems of up to that many DOFs may take the dense path (0: never)
     int dense_after = 2;          // knob: ... once a handle's matrix has been asked for more than that many columns / a stepper for that many steps
                                   // AND the Krylov time spent (handle) / to be expected (stepper) reaches half of what the inversion costs; 0: at once
     int64_t lin_cols = 0;         // columns solved against the handle's current matrix

@@ -44,12 +44,14 @@ bool dense_eligible(const fdapde_ctx* c) {
 
 // What an inversion costs, from the measured shape of k_dense_invert_blocked on MI355X: n / nb panels, each the longer of the panel workgroup's turn
 // (~1.2 us per pivot step + ~4.5 us per 512-row block for the panel's columns out and the next panel's in + hand-offs) and the workers' update (a
-// read-modify-write sweep of the n x n array over the fabric at ~4.5 TB/s): 289 rows 0.5 ms, 1 089 rows 2.6 ms, 2 116 rows 8.5 ms, 4 225 rows 66 ms.
+// read-modify-write sweep of the n x n array over the fabric at ~4.5 TB/s): 289 rows 0.5 ms, 1 089 rows 2.6 ms, 2 116 rows 8.5 ms, 4 225 rows 19 ms, 8 100 rows 112 ms.
 // Callers build an inverse when the Krylov time it replaces is of that order ("rent or buy": the handle after it has spent half of this on Krylov
 // columns, the stepper when its steps will).
 double dense_build_estimate_ms(int64_t n) {
-    const int64_t rpt = (n + kDenseTB - 1) / kDenseTB, nb = rpt <= 4 ? 16 : rpt <= 8 ? 8 : 4;
-    const double panel_us = 1.2 * (double)nb + 4.0 + 4.5 * (double)rpt, update_us = 8.0 + 16.0 * (double)n * (double)n / 4.5e6;
+    const int64_t rpt = (n + kDenseTB - 1) / kDenseTB;
+    const bool multi = rpt > 8;   // several panel workgroups, a panel of 16 (dense_build): ~3.5 us per pivot step
+    const int64_t nb = multi ? 16 : rpt <= 4 ? 16 : rpt <= 8 ? 8 : 4;
+    const double panel_us = multi ? 3.5 * 16.0 + 12.0 : 1.2 * (double)nb + 4.0 + 4.5 * (double)rpt, update_us = 8.0 + 16.0 * (double)n * (double)n / 4.5e6;
     return 1e-3 * (double)((n + nb - 1) / nb) * std::max(panel_us, update_us) + 0.2;
 }
 
@@ -68,13 +70,16 @@ int dense_build(fdapde_ctx* c, const double* A, int use_bnd, fdapde_ctx::Dense& 
     const int64_t ld = (n + 15) & ~int64_t(15);
     // pivots per panel of the blocked inversion: the panel lives in the registers of ONE workgroup (512 threads x RPT rows x nb columns, at most 64 doubles
     // per thread): 16 columns up to 2 048 rows, 8 up to 4 096, 4 up to 8 192
+    // ... and above 4 096 rows SEVERAL panel workgroups of 1 536 rows x 16 columns each (a pivot step's choice agreed over the fabric: ~5 us per step instead
+    // of 1.1, but a panel of 16: the update sweeps the matrix a quarter as often -- 4 225 rows 66 -> 19 ms, 5 929 rows 188 -> 48 ms, 8 100 rows 471 -> 112 ms)
     const int rpt = (int)((n + kDenseTB - 1) / kDenseTB);
-    int nb = rpt <= 4 ? 16 : rpt <= 8 ? 8 : 4;
+    const int KP = (c->dense_multi && rpt > 8) ? (int)((n + 3 * kDenseTB - 1) / (3 * kDenseTB)) : 1;
+    int nb = KP > 1 ? 16 : rpt <= 4 ? 16 : rpt <= 8 ? 8 : 4;
     if (const char* e = std::getenv("FDAPDE_DENSE_NB")) nb = std::max(1, std::min(nb, std::atoi(e)));   // (measurements)
     const bool blocked = c->dense_block && nb >= 2;
     DBuf<double> S1;
     DBuf<int32_t> piv_row;
-    DBuf<unsigned long long> flags;
+    DBuf<unsigned long long> flags, xch;
     DBuf<long long> stamps;
     HIPCHK(c, S.alloc((size_t)n * (size_t)ld));
     HIPCHK(c, D.X.alloc((size_t)n * n));
@@ -94,10 +99,10 @@ int dense_build(fdapde_ctx* c, const double* A, int use_bnd, fdapde_ctx::Dense& 
         // per wavefront) and 4 row tiles (one batch of loads in flight)
         const int n_tiles = (int)((n + 15) / 16), cus = c->n_cu > 0 ? c->n_cu : 64;
         int C = std::max(1, std::min(17, (n_tiles + 7) / 8));
-        int R = std::max(1, std::min((cus - 1) / C, (n_tiles + 3) / 4));   // (+ the panel workgroup)
+        int R = std::max(1, std::min((cus - KP) / C, (n_tiles + 3) / 4));   // (+ the panel workgroups)
         if (const char* e = std::getenv("FDAPDE_DENSE_GRID")) {   // "R,C" (measurements)
             int r_ = 0, c_ = 0;
-            if (std::sscanf(e, "%d,%d", &r_, &c_) == 2 && r_ >= 1 && c_ >= 1 && r_ * c_ < cus) R = r_, C = c_;
+            if (std::sscanf(e, "%d,%d", &r_, &c_) == 2 && r_ >= 1 && c_ >= 1 && r_ * c_ + KP <= cus) R = r_, C = c_;
         }
         const int RB = 16 * ((n_tiles + R - 1) / R), CB = 16 * ((n_tiles + C - 1) / C);
         R = (int)((n + RB - 1) / RB), C = (int)((n + CB - 1) / CB);   // (the blocks in use)
@@ -107,20 +112,24 @@ int dense_build(fdapde_ctx* c, const double* A, int use_bnd, fdapde_ctx::Dense& 
         DenseBlkArgs b{};
         b.n = (int32_t)n, b.G = G, b.ld = (int32_t)ld, b.nb = nb, b.C = C, b.RB = RB, b.CB = CB, b.S0 = S.p, b.S1 = S1.p, b.perm = perm.p, b.piv_row = piv_row.p;
         b.done = flags.p, b.ready = flags.p + G, b.status = status.p, b.timeout_ticks = 200000000ll;
+        HIPCHK(c, xch.alloc(2 * (size_t)KP * 40 + (size_t)KP));
+        HIPCHK(c, hipMemsetAsync(xch.p, 0, (2 * (size_t)KP * 40 + (size_t)KP) * sizeof(unsigned long long), st));
+        b.KP = KP, b.xch = xch.p, b.pdone = xch.p + 2 * (size_t)KP * 40;
         if (std::getenv("FDAPDE_DENSE_STAMPS")) {   // (measurements)
             HIPCHK(c, stamps.alloc(32));
             HIPCHK(c, hipMemsetAsync(stamps.p, 0, 32 * sizeof(long long), st));
             b.stamps = stamps.p;
         }
         const size_t lds = std::max(sizeof(double) * (size_t)RB * 16 + (size_t)RB, sizeof(double) * (size_t)kDenseTB * (kDenseNB + 1)) + 64;
-        const void* fn = rpt <= 2   ? reinterpret_cast<const void*>(&k_dense_invert_blocked<2, 16>)
-                         : rpt <= 3 ? reinterpret_cast<const void*>(&k_dense_invert_blocked<3, 16>)
-                         : rpt <= 4 ? reinterpret_cast<const void*>(&k_dense_invert_blocked<4, 16>)
-                         : rpt <= 8 ? reinterpret_cast<const void*>(&k_dense_invert_blocked<8, 8>)
-                                    : reinterpret_cast<const void*>(&k_dense_invert_blocked<16, 4>);
+        const void* fn = KP > 1     ? reinterpret_cast<const void*>(&k_dense_invert_blocked<3, 16, true>)
+                         : rpt <= 2 ? reinterpret_cast<const void*>(&k_dense_invert_blocked<2, 16, false>)
+                         : rpt <= 3 ? reinterpret_cast<const void*>(&k_dense_invert_blocked<3, 16, false>)
+                         : rpt <= 4 ? reinterpret_cast<const void*>(&k_dense_invert_blocked<4, 16, false>)
+                         : rpt <= 8 ? reinterpret_cast<const void*>(&k_dense_invert_blocked<8, 8, false>)
+                                    : reinterpret_cast<const void*>(&k_dense_invert_blocked<16, 4, false>);
         HIPCHK(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         void* kargs[] = {&b};
-        HIPCHK(c, hipLaunchKernel(fn, dim3((unsigned)G + 1), dim3(kDenseTB), kargs, lds, st));
+        HIPCHK(c, hipLaunchKernel(fn, dim3((unsigned)(G + KP)), dim3(kDenseTB), kargs, lds, st));
         const int n_panels = (int)((n + nb - 1) / nb);
         result = (n_panels & 1) ? S1.p : S.p;
     } else {
@@ -311,7 +320,7 @@ int dense_step_loop(fdapde_ctx* c, fdapde_ctx::Dense& D, int32_t n_times, double
 
 void preload_dense() {
     hipFuncAttributes attr;
-    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_dense_invert_blocked<2, 16>));
+    (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_dense_invert_blocked<2, 16, false>));
     (void)hipGetLastError();
 }
 

@@ -900,7 +900,14 @@ int solve_run_restarting(fdapde_ctx* c, const SolveState& ss, const double* A, c
     const bool will_bicg = method == FDAPDE_SOLVER_BICGSTAB || (method == FDAPDE_SOLVER_AUTO && !(c->op_symmetric && ss.diag_positive));
     const bool later_stage = gmres_budget > 0 && !ss.dist && !ss.rowdist && (c->auto_gmres || dense_eligible(c));
     const int full_maxit = maxit;
-    if (will_bicg && later_stage) maxit = (int)std::min<int64_t>(maxit, 2 * n + 200);
+    if (will_bicg && later_stage) {
+        int64_t cap = 2 * n + 200;
+        // ... and where that later stage is the dense direct solve, rent or buy: BiCGStab may spend what the inversion will cost (its estimate over ~3 us +
+        // n / 700 us per iteration of the single launch: 550 iterations at 1 089 DOFs, 2 100 at 4 225), not more -- a system it has not solved by then
+        // is solved directly, and the call costs at most twice the inversion (1 089 DOFs, cell Peclet 150 - 1 000: 20 ms -> 5)
+        if (dense_eligible(c)) cap = std::min<int64_t>(cap, std::max<int64_t>(200, (int64_t)(1e3 * dense_build_estimate_ms(n) / (3.0 + (double)n / 700.0))));
+        maxit = (int)std::min<int64_t>(maxit, cap);
+    }
     (void)full_maxit;
     int rc = solve_run(c, ss, A, f_dev, g_dev, u0_dev, method, rtol, maxit, check_every, n_timed);
     int total = c->info.iters;

@@ -231,6 +231,7 @@ static __global__ __launch_bounds__(kDenseT) void k_dense_invert(DenseInvArgs a)
 //     S'[i][j] = base_i[j] + sum_u E[i][u] S[p_u][j],     base_i = S[i][.] for ordinary rows, 0 for the panel's pivot rows
 // -- a 16-deep matrix product per 16 x 16 tile, on the matrix cores (v_mfma_f64_16x16x4); nothing to publish but the panel's final columns (which the
 // result needs anyway) and the pivots' indices.
+//   (above 4 096 rows there are several panel workgroups, 1 536 rows of the panel each, and a pivot step's choice is agreed over the fabric: MULTI)
 //   the panel workgroup  factorises panel P while the others still apply panel P - 1: the columns of panel P as panel P - 1 leaves them it computes
 //                        ITSELF (the same product: it holds E of panel P - 1 and reads 16 x 16 entries of the pivot rows), so the factorisations
 //                        follow each other without a gap; it waits for "update P - 1 done everywhere" only before it publishes panel P
@@ -256,11 +257,14 @@ constexpr int kDenseTB = 512;   // threads of a workgroup of the blocked inversi
 struct DenseBlkArgs {
     int32_t n, G, ld, nb;          // G worker workgroups; the grid is G + 1, the last one the panel workgroup
     int32_t C, RB, CB;             // the update's grid of blocks: G = R x C workgroups, RB rows x CB columns each (multiples of 16)
+    int32_t KP;                    // panel workgroups (the grid is G + KP): 1, or -- above 4 096 rows -- one per 1 536 rows of the panel, a pivot step's choice agreed through xch
     double *S0, *S1;               // panel P reads S(P & 1), writes the other
     int32_t* perm;                 // [n] pivot row of column k
     int32_t* piv_row;              // [nb]
     unsigned long long* done;      // [G] granule per worker: panels whose update it has finished
     unsigned long long* ready;     // [1] (panels published << 1) | failed
+    unsigned long long* xch;       // [2][KP][40] KP > 1: a pivot step's candidates, tagged granules {step : 32 | half a double : 32}: the key, then the candidate row's nb entries
+    unsigned long long* pdone;     // [KP] KP > 1: (panels whose columns panel workgroup k has written out << 1) | failed
     int32_t* status;               // [0] 1 = singular, 2 = a wait timed out
     long long timeout_ticks;
     long long* stamps;             // diagnostic (FDAPDE_DENSE_STAMPS): s_memrealtime at the phase boundaries of panel 8, [0..7] the panel workgroup, [8..15] worker 0,
@@ -313,7 +317,7 @@ __device__ __forceinline__ double dense_cand_key(double mag, int row) {
 __device__ __forceinline__ int dense_cand_row(double key) { return 0x1fff - (int)((unsigned long long)__double_as_longlong(key) & 0x1fffull); }
 __device__ __forceinline__ double dense_cand_mag(double key) { return __longlong_as_double((long long)((unsigned long long)__double_as_longlong(key) & ~0x1fffull)); }
 
-template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k_dense_invert_blocked(DenseBlkArgs a) {
+template <int RPT, int NBT, bool MULTI> static __global__ __launch_bounds__(kDenseTB) void k_dense_invert_blocked(DenseBlkArgs a) {
     extern __shared__ __attribute__((aligned(16))) char dn_smem3[];
     double* buf = reinterpret_cast<double*>(dn_smem3);
     constexpr int T = kDenseTB, W = kDenseTB / 64;
@@ -322,20 +326,22 @@ template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k
     __shared__ int piv_row_s[kDenseNB], wait_s;
     __shared__ __attribute__((aligned(16))) double cand_key[2][W], cand_rows[2][W][kDenseNB];
     __shared__ unsigned char isp_s[kDenseTB];
+    __shared__ unsigned xh_s[6 * 40];   // KP > 1: the halves collected from xch
     const int n = a.n, G = a.G, NB = a.nb, ld = a.ld, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(a.S0, 0, n * ld * 8, 0x00020000);   // (<= 8 192 x 8 192 doubles: 2^29 bytes)
     const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(a.S1, 0, n * ld * 8, 0x00020000);
     const int n_panels = (n + NB - 1) / NB;
     const int q = lane >> 4, jl = lane & 15;   // MFMA operand layouts (measured): A[i][k] in lane 16 k + i, B[k][j] in lane 16 k + j, D[4 v + q][j] in register v of lane 16 q + j
     auto sstamp = [&](int P, int t, int slot) {   // inside pivot step 5 of panel 8
-        if (a.stamps && P == 8 && t == 5 && tid == 0) a.stamps[16 + slot] = (long long)__builtin_amdgcn_s_memrealtime();
+        if (a.stamps && P == 8 && t == 5 && tid == 0 && g == G) a.stamps[16 + slot] = (long long)__builtin_amdgcn_s_memrealtime();
     };
     auto stamp = [&](int P, int who, int slot) {
-        if (a.stamps && P == 8 && tid == 0) a.stamps[who * 8 + slot] = (long long)__builtin_amdgcn_s_memrealtime();
+        if (a.stamps && P == 8 && tid == 0 && (g == 0 || g == G)) a.stamps[who * 8 + slot] = (long long)__builtin_amdgcn_s_memrealtime();
     };
 
-    if (g == G) {
-        // =================================================================== the panel workgroup
+    if (g >= G) {
+        // =================================================================== the panel workgroup(s)
+        const int pk = MULTI ? g - G : 0, KP = MULTI ? a.KP : 1, row0 = pk * RPT * T;   // this one holds rows row0 .. row0 + RPT T - 1 of the panel
         // The panel lives in REGISTERS: thread tid holds rows tid, tid + T, ... (RPT of them) x NBT columns.  A step is a register scan for the pivot
         // (+ one block-wide arg-max), the pivot row's NBT values through LDS, and NBT fused multiply-adds per row and thread -- an LDS-resident panel
         // cost 5 - 10 us per step (hundreds of LDS read-modify-writes per thread).  Rows move between the register layout (a row per thread) and
@@ -352,7 +358,7 @@ template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k
                 dense_lds_wave_sync();
 #pragma unroll
                 for (int u = 0; u < NBT; ++u) {   // (16 lanes per row: whole 128-byte lines; NBT loads in flight)
-                    const int rl = (64 / NBT) * u + lane / NBT, cl = lane % NBT, i = r * T + wave * 64 + rl;
+                    const int rl = (64 / NBT) * u + lane / NBT, cl = lane % NBT, i = row0 + r * T + wave * 64 + rl;
                     const double v = dense_bload(rs0, ((i < n ? i : 0) * ld + cl) * 8, 0);
                     slab[rl * SL + cl] = (i < n && cl < (n < NB ? n : NB)) ? v : 0.0;
                 }
@@ -374,24 +380,34 @@ template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k
             // ONE barrier per pivot step: every wavefront reduces its candidates (VALU), the lane that owns the wavefront's best row publishes the key AND
             // the row's NBT panel entries (arrays double-buffered by step parity); after the barrier every wavefront reduces the W keys, knows the pivot
             // and reads the pivot row -- no second round for "who won" and "hand me the row".  The largest magnitude wins, the smallest row among equals.
-            double best = -1.0;
+            // The steps run in GROUPS of four: inside a group they are unrolled (step s works on register position s, static indices into the panel), the
+            // loop over the groups is not, and after a group the panel's columns ROTATE by four positions so that the next group finds its columns at
+            // positions 0 .. 3 again.  (All sixteen steps unrolled were 60 - 90 KB of code -- with the exchange of several panel workgroups in them, past
+            // the instruction cache: 9 - 13 us per step instead of 1; one step per iteration with a rotation by one cost 85 register moves per step.)
+            // After the loop position c holds column (c + rot) mod NBT: whoever copies the panel out undoes that.
+            constexpr int GS = MULTI ? 4 : NBT;   // (one panel workgroup: the whole panel unrolled -- its steps fit the instruction cache -- and no rotation)
+            int rot = 0;
+#pragma nounroll
+            for (int t0 = 0; t0 < nbp; t0 += GS) {
 #pragma unroll
-            for (int r = 0; r < RPT; ++r) {
-                const int i = ft + r * T;
-                const double kd = (i < n && !((used_mine >> r) & 1u)) ? dense_cand_key(fabs(pr[r][0]), i) : -1.0;
-                best = fmax(best, kd);
-            }
-#pragma unroll
-            for (int t = 0; t < NBT; ++t) {
+              for (int s = 0; s < GS; ++s) {
+                const int t = t0 + s;
                 if (t < nbp && !failed) {
-                    const int par = t & 1;
+                    double best = -1.0;
+#pragma unroll
+                    for (int r = 0; r < RPT; ++r) {
+                        const int i = row0 + ft + r * T;
+                        const double kd = (i < n && !((used_mine >> r) & 1u)) ? dense_cand_key(fabs(pr[r][s]), i) : -1.0;
+                        best = fmax(best, kd);
+                    }
+                    const int par = s & 1;
                     sstamp(P, t, 0);
                     const double wmax = dense_wave_max(best);
                     if (!(wmax >= 0.0)) {
                         if (lane == 0) cand_key[par][wave] = -1.0;
                     } else if (best == wmax) {   // (rows are unique to a lane, so are keys)
                         cand_key[par][wave] = wmax;
-                        const int rp = dense_cand_row(wmax) / T;
+                        const int rp = (dense_cand_row(wmax) - row0) / T;
 #pragma unroll
                         for (int r = 0; r < RPT; ++r)
                             if (r == rp) {
@@ -403,52 +419,103 @@ template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k
                     dense_lds_barrier();
                     sstamp(P, t, 2);
                     const double ck = lane < W ? cand_key[par][lane] : -1.0;
-                    const double kb = dense_wave_max(ck);
+                    double kb = dense_wave_max(ck);
+                    const int ws = __ffsll((unsigned long long)__ballot(lane < W && ck == kb)) - 1;
+                    double pw[NBT];   // the pivot row's panel entries (LDS, the same address in every lane: broadcast reads), once per step
+                    if (MULTI && KP > 1) {
+                        // several panel workgroups: every one publishes its best -- the key and the row's entries as tagged 8-byte granules, "the data is
+                        // the flag" -- and collects everybody's; the largest key wins everywhere.  One trip over the fabric and a second barrier per step.
+                        constexpr int S = 2 * (NBT + 1);
+                        const unsigned epoch = (unsigned)(P * NB + t + 1);
+                        const int xpar = (int)(epoch & 1u);
+                        if (wave == 0) {
+                            if (lane < S) {
+                                const int d = lane >> 1;
+                                const double val = d == 0 ? kb : (kb >= 0.0 ? cand_rows[par][ws][d > 0 ? d - 1 : 0] : 0.0);
+                                const unsigned long long bits = (unsigned long long)__double_as_longlong(val);
+                                const unsigned half = (lane & 1) ? (unsigned)(bits >> 32) : (unsigned)bits;
+                                __hip_atomic_store((dn_u64*)(a.xch + ((size_t)xpar * KP + pk) * 40 + lane), ((unsigned long long)epoch << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            int ok = 1;
+                            const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+                            for (int idx = lane; idx < KP * S && ok; idx += 64) {
+                                const int k = idx / S, gi = idx - k * S;
+                                unsigned long long x;
+                                while (((x = __hip_atomic_load((const dn_u64*)(a.xch + ((size_t)xpar * KP + k) * 40 + gi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != epoch) {
+                                    __builtin_amdgcn_s_sleep(1);
+                                    if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
+                                        ok = 0;
+                                        break;
+                                    }
+                                }
+                                xh_s[k * 40 + gi] = (unsigned)x;
+                            }
+                            ok = __all(ok);
+                            if (lane == 0) wait_s = ok;
+                        }
+                        dense_lds_barrier();
+                        if (!wait_s) failed = 2;
+                        auto val_of = [&](int k, int d) { return __longlong_as_double((long long)(((unsigned long long)xh_s[k * 40 + 2 * d + 1] << 32) | xh_s[k * 40 + 2 * d])); };
+                        kb = -1.0;
+                        int kw = 0;
+                        for (int k = 0; k < KP; ++k) {
+                            const double kk = val_of(k, 0);
+                            if (kk > kb) kb = kk, kw = k;
+                        }
+#pragma unroll
+                        for (int tt = 0; tt < NBT; ++tt) pw[tt] = val_of(kw, 1 + tt);
+                    } else {
+#pragma unroll
+                        for (int tt = 0; tt < NBT; ++tt) pw[tt] = cand_rows[par][ws][tt];
+                    }
                     const double mag = dense_cand_mag(kb);
-                    if (!(kb >= 0.0) || !(mag > 0.0) || !isfinite(mag)) {
+                    if (failed) {
+                    } else if (!(kb >= 0.0) || !(mag > 0.0) || !isfinite(mag)) {
                         failed = 1;
                     } else {
                         const int p = dense_cand_row(kb);
-                        const int ws = __ffsll((unsigned long long)__ballot(lane < W && ck == kb)) - 1;
                         sstamp(P, t, 3);
-                        double pw[NBT];   // the pivot row's panel entries (LDS, the same address in every lane: broadcast reads), once per step
-#pragma unroll
-                        for (int tt = 0; tt < NBT; ++tt) pw[tt] = cand_rows[par][ws][tt];
-                        const double inv_d = 1.0 / pw[t];
+                        const double inv_d = 1.0 / pw[s];
                         sstamp(P, t, 4);
                         // every row as an ordinary row, without a branch (rows beyond n hold zeros and keep them; the pivot row itself comes out as
                         // zeros and is set below by the one thread that owns it)
 #pragma unroll
                         for (int r = 0; r < RPT; ++r) {
-                            const double f = pr[r][t] * inv_d;
+                            const double f = pr[r][s] * inv_d;
 #pragma unroll
-                            for (int tt = 0; tt < NBT; ++tt)
-                                if (tt != t) pr[r][tt] -= f * pw[tt];
-                            pr[r][t] = -f;
+                            for (int c = 0; c < NBT; ++c)
+                                if (c != s) pr[r][c] -= f * pw[c];
+                            pr[r][s] = -f;
                         }
-                        if (p % T == ft) {
-                            used_mine |= 1u << (p / T), piv_now |= 1u << (p / T);
-                            piv_row_s[t] = p;
-                            const int rp = p / T;
+                        if (ft == 0) piv_row_s[t] = p;
+                        const int pl = p - row0;
+                        if (pl >= 0 && pl < RPT * T && pl % T == ft) {
+                            const int rp = pl / T;
+                            used_mine |= 1u << rp, piv_now |= 1u << rp;
 #pragma unroll
                             for (int r = 0; r < RPT; ++r)
                                 if (r == rp) {
 #pragma unroll
-                                    for (int tt = 0; tt < NBT; ++tt) pr[r][tt] = tt == t ? inv_d : pw[tt] * inv_d;
+                                    for (int c = 0; c < NBT; ++c) pr[r][c] = c == s ? inv_d : pw[c] * inv_d;
                                 }
                         }
                         sstamp(P, t, 5);
-                        best = -1.0;
-                        if (t + 1 < NBT && t + 1 < nbp) {
-#pragma unroll
-                            for (int r = 0; r < RPT; ++r) {
-                                const int i = ft + r * T;
-                                const double kd = (i < n && !((used_mine >> r) & 1u)) ? dense_cand_key(fabs(pr[r][t + 1 < NBT ? t + 1 : t]), i) : -1.0;
-                                best = fmax(best, kd);
-                            }
-                        }
                     }
                 }
+              }
+              if (GS < NBT) {   // the next group's columns to positions 0 .. GS - 1
+#pragma unroll
+                  for (int r = 0; r < RPT; ++r) {
+                      double head[GS];
+#pragma unroll
+                      for (int k = 0; k < GS; ++k) head[k] = pr[r][k];
+#pragma unroll
+                      for (int c = 0; c + GS < NBT; ++c) pr[r][c] = pr[r][c + GS];
+#pragma unroll
+                      for (int k = 0; k < GS; ++k) pr[r][NBT - GS + k] = head[k];
+                  }
+                  rot += GS;
+              }
             }
             stamp(P, 0, 1);   // panel factorised
             dense_lds_barrier();   // (piv_row_s of the last step)
@@ -468,7 +535,7 @@ template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k
                 for (int rt = 0; rt < 4; ++rt) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
-                        const int i = r * T + wv * 64 + 16 * rt + 4 * v + q;
+                        const int i = row0 + r * T + wv * 64 + 16 * rt + 4 * v + q;
                         const bool ok = i < n && jl < nbp1;
                         dst[rt][v] = dense_bload(rs_cur, ok ? (i * ld + k1 + jl) * 8 : 0, 0);
                     }
@@ -511,16 +578,16 @@ template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k
             if (!failed) {
 #pragma unroll
                 for (int r = 0; r < RPT; ++r) {
-                    if (r * T < n) {
+                    if (row0 + r * T < n) {
                         int ln = lane, wv = wave;   // (opaque copies: offsets derived from them are loop-invariant, and hoisted they are RPT x 16 registers)
                         asm volatile("" : "+v"(ln), "+v"(wv));
                         dense_lds_wave_sync();
 #pragma unroll
-                        for (int t = 0; t < NBT; ++t) slab[ln * SL + t] = pr[r][t];
+                        for (int t = 0; t < NBT; ++t) slab[ln * SL + ((t + rot) & (NBT - 1))] = pr[r][t];   // (the rotation of the steps undone)
                         dense_lds_wave_sync();
 #pragma unroll
                         for (int u = 0; u < NBT; ++u) {   // (16 lanes per row: whole 128-byte lines)
-                            const int rl = (64 / NBT) * u + ln / NBT, cl = ln % NBT, i = r * T + wv * 64 + rl;
+                            const int rl = (64 / NBT) * u + ln / NBT, cl = ln % NBT, i = row0 + r * T + wv * 64 + rl;
                             if (i < n && cl < nbp) dense_bstore(rs_next, (i * ld + k0 + cl) * 8, 0, slab[rl * SL + cl]);
                         }
                     }
@@ -549,15 +616,46 @@ template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k
                 }
             }
             stamp(P, 0, 2);   // update P - 1 done everywhere
-            if (!failed && ft < nbp) {   // (the workers read piv_row of panel P - 1 until they are done with it)
-                a.perm[k0 + ft] = piv_row_s[ft];
-                __hip_atomic_store((dn_u32*)(a.piv_row + ft), (unsigned)piv_row_s[ft], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                if (failed) a.status[0] = failed;
-                __hip_atomic_store((dn_u64*)a.ready, ((unsigned long long)(P + 1) << 1) | (failed ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (MULTI && pk > 0) {   // another panel workgroup: "my rows of the panel's columns are out"; the first one publishes
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    if (failed) a.status[0] = failed;
+                    __hip_atomic_store((dn_u64*)(a.pdone + pk), ((unsigned long long)(P + 1) << 1) | (failed ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                if (MULTI && KP > 1 && !failed) {   // ... once every other panel workgroup has said so
+                    if (wave == 0) {
+                        int ok = 1;
+                        const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+                        if (lane >= 1 && lane < KP) {
+                            unsigned long long x;
+                            while (((x = __hip_atomic_load((const dn_u64*)(a.pdone + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 1) != (unsigned long long)(P + 1)) {
+                                __builtin_amdgcn_s_sleep(1);
+                                if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
+                                    ok = 0;
+                                    break;
+                                }
+                            }
+                            if (ok && (x & 1ull)) ok = 0;
+                        }
+                        ok = __all(ok);
+                        if (lane == 0) wait_s = ok;
+                    }
+                    __syncthreads();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (!wait_s) failed = 2;
+                }
+                if (!failed && ft < nbp) {   // (the workers read piv_row of panel P - 1 until they are done with it)
+                    a.perm[k0 + ft] = piv_row_s[ft];
+                    __hip_atomic_store((dn_u32*)(a.piv_row + ft), (unsigned)piv_row_s[ft], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    if (failed) a.status[0] = failed;
+                    __hip_atomic_store((dn_u64*)a.ready, ((unsigned long long)(P + 1) << 1) | (failed ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             stamp(P, 0, 3);   // panel published
             if (failed || !more) return;
@@ -569,7 +667,7 @@ template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k
 #pragma unroll
                 for (int r = 0; r < RPT; ++r) {
                     asm volatile("" ::: "memory");   // (the loads of block r + 1 stay in block r)
-                    if (r * T >= n) {   // (a row block beyond the matrix: zeros)
+                    if (row0 + r * T >= n) {   // (a row block beyond the matrix: zeros)
 #pragma unroll
                         for (int t = 0; t < NBT; ++t) pr[r][t] = 0.0;
                         continue;
@@ -578,13 +676,13 @@ template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k
                     asm volatile("" : "+v"(q), "+v"(jl), "+v"(ln), "+v"(wv));
                     dense_lds_wave_sync();
 #pragma unroll
-                    for (int t = 0; t < NBT; ++t) slab[ln * SL + t] = pr[r][t];
+                    for (int t = 0; t < NBT; ++t) slab[ln * SL + ((t + rot) & (NBT - 1))] = pr[r][t];   // (the rotation of the steps undone)
                     isp_s[wv * 64 + ln] = (unsigned char)((piv_now >> r) & 1u);
                     dense_lds_wave_sync();
                     dn_v4d cur[4];
 #pragma unroll
                     for (int rt = 0; rt < 4; ++rt) cur[rt] = acc[rt];
-                    if (r + 1 < RPT && (r + 1) * T < n) load_base(r + 1, acc);
+                    if (r + 1 < RPT && row0 + (r + 1) * T < n) load_base(r + 1, acc);
                     asm volatile("" ::: "memory");
                     double af[4][NBT / 4];
 #pragma unroll
@@ -593,7 +691,7 @@ template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k
                         for (int c = 0; c < NBT / 4; ++c) af[rt][c] = slab[(16 * rt + jl) * SL + 4 * c + q];
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
-                            const int rl = 16 * rt + 4 * v + q, i = r * T + wv * 64 + rl;
+                            const int rl = 16 * rt + 4 * v + q, i = row0 + r * T + wv * 64 + rl;
                             if (!(i < n && jl < nbp1) || isp_s[wv * 64 + rl]) cur[rt][v] = 0.0;   // (base = 0: the panel's pivot rows; nothing beyond the matrix)
                         }
                     }
@@ -608,7 +706,7 @@ template <int RPT, int NBT> static __global__ __launch_bounds__(kDenseTB) void k
                     }
                     dense_lds_wave_sync();
 #pragma unroll
-                    for (int t = 0; t < NBT; ++t) pr[r][t] = (t < nbp1 && r * T + wv * 64 + ln < n) ? slab[ln * SL + t] : 0.0;
+                    for (int t = 0; t < NBT; ++t) pr[r][t] = (t < nbp1 && row0 + r * T + wv * 64 + ln < n) ? slab[ln * SL + t] : 0.0;
                 }
             }
             stamp(P, 0, 4);   // the next panel's columns in registers

@@ -72,7 +72,7 @@ typedef struct {
  * A method named explicitly is never replaced: its failure is reported (FDAPDE_ENOCONV, success = false). */
 enum { FDAPDE_SOLVER_AUTO = 0, FDAPDE_SOLVER_CG = 1, FDAPDE_SOLVER_BICGSTAB = 2, FDAPDE_SOLVER_CG_SR = 3, FDAPDE_SOLVER_CG_FUSED = 4,
        FDAPDE_SOLVER_GMRES = 5 /* restarted GMRES(50), Jacobi-scaled; one-GPU contexts */,
-       FDAPDE_SOLVER_DENSE = 6 /* reported in info.method_used only: the system was small enough (knob dense_rows, default 4096 DOFs; one-GPU contexts) for its
+       FDAPDE_SOLVER_DENSE = 6 /* reported in info.method_used only: the system was small enough (knob dense_rows, default 8192 DOFs; one-GPU contexts) for its
                                   dense inverse -- built ONCE on the device, ~ms, Gauss-Jordan with partial pivoting as one launch -- and the answer is one
                                   matrix-vector product (plus one step of iterative refinement where max |I - A X| says so).  Taken with the method left
                                   open by: fdapde_lin_solve once a handle has been asked for more than `dense_after` (2) columns ("factor once, solve many");

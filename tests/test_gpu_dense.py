@@ -61,15 +61,13 @@ def test_handle_takes_the_dense_inverse_after_a_few_columns(env, name, order, ki
         seen.append(info.method_used)
         ref = lu.solve(b)
         assert info.converged == 1 and np.linalg.norm(x - ref) <= 1e-9 * np.linalg.norm(ref), (k, info.method_used)
-    # rent or buy: never within the first `dense_after` (2) columns, and for the reference's own sizes within a dozen; a 4 225-row system only after
-    # dozens of columns (its inversion costs ~70 ms) -- or at once when told so (dense_after 0, below)
+    # rent or buy: never within the first `dense_after` (2) columns, and for the reference's own sizes within a dozen; a 4 225-row system after about as
+    # many Krylov columns as its inversion costs (~19 ms) -- or at once when told so (dense_after 0, below)
     assert capi.SOLVER_DENSE not in seen[:2]
     if nd < 1200:
         assert seen[-1] == capi.SOLVER_DENSE
     else:
-        assert capi.SOLVER_DENSE not in seen
         c.tune("dense_after", 0)
-        c.tune("dense_rows", 4608)
     B = rng.standard_normal((nd, 7))
     X, info = c.lin_solve(B, rtol=1e-12)
     assert info.method_used == capi.SOLVER_DENSE
@@ -190,10 +188,11 @@ def test_open_method_ends_in_the_direct_stage_on_small_advection_dominated_syste
     c.close()
 
 
-@pytest.mark.parametrize("nx", [2, 3, 4, 22, 31, 32, 38, 39, 44, 45, 63, 64])
+@pytest.mark.parametrize("nx", [2, 3, 4, 22, 31, 32, 38, 39, 44, 45, 63, 64, 67, 78, 89])
 def test_inversion_across_panel_layouts_with_random_values(env, nx):
-    """9 .. 4 225 rows: fewer rows than a panel, exact multiples of 16 and of 512 (the panel's row blocks: <2,16> <3,16> <4,16> <8,8> <16,4> of
-    k_dense_invert_blocked), one more than each; values drawn at random on the FEM pattern (no diagonal dominance: the pivot search has to work, the
+    """9 .. 8 100 rows: fewer rows than a panel, exact multiples of 16 and of 512 (the panel's row blocks: <2,16> <3,16> <4,16> <8,8> of
+    k_dense_invert_blocked), one more than each, and above 4 096 rows three to six panel workgroups (4 624 = 3 x 1 536 + 16, 6 241, 8 100); values drawn
+    at random on the FEM pattern (no diagonal dominance: the pivot search has to work, the
     panel's pivot rows end up anywhere in the update's grid of blocks) -- every column against SuperLU through the residual and the solution"""
     import scipy.sparse.linalg as spl
 
@@ -213,7 +212,6 @@ def test_inversion_across_panel_layouts_with_random_values(env, nx):
     A = _csr(c, vals, nd)
     lu = spl.splu(A.tocsc())
     c.tune("dense_after", 0)
-    c.tune("dense_rows", 4608)
     c.lin_compute(values=vals, symmetric=False)
     B = rng.standard_normal((nd, 3))
     X, info = c.lin_solve(B, rtol=1e-12)

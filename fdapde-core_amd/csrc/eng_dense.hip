@@ -49,7 +49,7 @@ bool dense_eligible(const fdapde_ctx* c) {
 // columns, the stepper when its steps will).
 double dense_build_estimate_ms(int64_t n) {
     const int64_t rpt = (n + kDenseTB - 1) / kDenseTB;
-    const bool multi = rpt > 8;   // several panel workgroups, a panel of 16 (dense_build): ~3.5 us per pivot step
+    const bool multi = rpt > 4;   // several panel workgroups, a panel of 16 (dense_build): ~3.5 us per pivot step
     const int64_t nb = multi ? 16 : rpt <= 4 ? 16 : rpt <= 8 ? 8 : 4;
     const double panel_us = multi ? 3.5 * 16.0 + 12.0 : 1.2 * (double)nb + 4.0 + 4.5 * (double)rpt, update_us = 8.0 + 16.0 * (double)n * (double)n / 4.5e6;
     return 1e-3 * (double)((n + nb - 1) / nb) * std::max(panel_us, update_us) + 0.2;
@@ -70,10 +70,12 @@ int dense_build(fdapde_ctx* c, const double* A, int use_bnd, fdapde_ctx::Dense& 
     const int64_t ld = (n + 15) & ~int64_t(15);
     // pivots per panel of the blocked inversion: the panel lives in the registers of ONE workgroup (512 threads x RPT rows x nb columns, at most 64 doubles
     // per thread): 16 columns up to 2 048 rows, 8 up to 4 096, 4 up to 8 192
-    // ... and above 4 096 rows SEVERAL panel workgroups of 1 536 rows x 16 columns each (a pivot step's choice agreed over the fabric: ~5 us per step instead
+    // ... and above 2 048 rows SEVERAL panel workgroups of 1 536 rows x 16 columns each (a pivot step's choice agreed over the fabric: ~5 us per step instead
     // of 1.1, but a panel of 16: the update sweeps the matrix a quarter as often -- 4 225 rows 66 -> 19 ms, 5 929 rows 188 -> 48 ms, 8 100 rows 471 -> 112 ms)
     const int rpt = (int)((n + kDenseTB - 1) / kDenseTB);
-    const int KP = (c->dense_multi && rpt > 8) ? (int)((n + 3 * kDenseTB - 1) / (3 * kDenseTB)) : 1;
+    int multi_above = 4;   // row blocks of 512: above 2 048 rows (measured: 1 681 rows 4.9 ms with one panel workgroup against 7.1, 2 116 rows 8.4 - 9.3 either way, 2 601 rows 11.7 against 10.0, 3 025 rows 14.3 against 11.6, 4 096 rows 25.1 against 18.9)
+    if (const char* e = std::getenv("FDAPDE_DENSE_MULTI_RPT")) multi_above = std::max(1, std::atoi(e));   // (measurements)
+    const int KP = (c->dense_multi && rpt > multi_above) ? (int)((n + 3 * kDenseTB - 1) / (3 * kDenseTB)) : 1;
     int nb = KP > 1 ? 16 : rpt <= 4 ? 16 : rpt <= 8 ? 8 : 4;
     if (const char* e = std::getenv("FDAPDE_DENSE_NB")) nb = std::max(1, std::min(nb, std::atoi(e)));   // (measurements)
     const bool blocked = c->dense_block && nb >= 2;

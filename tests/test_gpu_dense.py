@@ -188,11 +188,12 @@ def test_open_method_ends_in_the_direct_stage_on_small_advection_dominated_syste
     c.close()
 
 
-@pytest.mark.parametrize("nx", [2, 3, 4, 22, 31, 32, 38, 39, 44, 45, 63, 64, 67, 78, 89])
-def test_inversion_across_panel_layouts_with_random_values(env, nx):
-    """9 .. 8 100 rows: fewer rows than a panel, exact multiples of 16 and of 512 (the panel's row blocks: <2,16> <3,16> <4,16> <8,8> of
-    k_dense_invert_blocked), one more than each, and above 4 096 rows three to six panel workgroups (4 624 = 3 x 1 536 + 16, 6 241, 8 100); values drawn
-    at random on the FEM pattern (no diagonal dominance: the pivot search has to work, the
+@pytest.mark.parametrize("nx,multi", [(2, 1), (3, 1), (4, 1), (22, 1), (31, 1), (32, 1), (38, 1), (39, 1), (44, 1), (45, 1), (54, 1), (63, 1), (64, 1), (67, 1),
+                                      (78, 1), (89, 1), (45, 0), (64, 0)])
+def test_inversion_across_panel_layouts_with_random_values(env, nx, multi):
+    """9 .. 8 100 rows: fewer rows than a panel, exact multiples of 16 and of 512 (the panel's row blocks: <2,16> <3,16> <4,16> of
+    k_dense_invert_blocked), one more than each, and above 2 048 rows two to six panel workgroups (2 116, 3 025 = 2 x 1 536 - 47, 4 624 = 3 x 1 536 + 16,
+    6 241, 8 100) -- or, knob dense_multi 0, one with a panel of 8 / 4 columns (<8,8>, <16,4>); values drawn at random on the FEM pattern (no diagonal dominance: the pivot search has to work, the
     panel's pivot rows end up anywhere in the update's grid of blocks) -- every column against SuperLU through the residual and the solution"""
     import scipy.sparse.linalg as spl
 
@@ -212,6 +213,7 @@ def test_inversion_across_panel_layouts_with_random_values(env, nx):
     A = _csr(c, vals, nd)
     lu = spl.splu(A.tocsc())
     c.tune("dense_after", 0)
+    c.tune("dense_multi", multi)
     c.lin_compute(values=vals, symmetric=False)
     B = rng.standard_normal((nd, 3))
     X, info = c.lin_solve(B, rtol=1e-12)

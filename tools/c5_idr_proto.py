@@ -90,7 +90,7 @@ def idrs(A, b, s, tol, maxit=40000, seed=1):
     return x, -mv
 
 
-for nx in [int(a) for a in sys.argv[1:]] or [12, 20, 28]:
+for nx in ([int(a) for a in sys.argv[1:]] or [12, 20, 28]) if __name__ == "__main__" else []:
     A, b = build(nx)
     t0 = time.time()
     _, mvb = bicgstab(A, b, 1e-10)

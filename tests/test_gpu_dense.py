@@ -279,3 +279,30 @@ def test_inversion_does_not_depend_on_the_grid_of_blocks(env, grid, monkeypatch)
     assert info.method_used == capi.SOLVER_DENSE
     assert np.abs(X1 - X0).max() <= 1e-11 * np.abs(X0).max()
     c.close()
+
+
+@pytest.mark.parametrize("knob,value,nx", [("dense_block", 0, 16), ("dense_block", 0, 32), ("dense_direct", 1, 16), ("dense_direct", 1, 32), ("dense_hostb", 1, 16)])
+def test_the_forms_kept_behind_knobs_still_answer(env, knob, value, nx):
+    """what was measured and left off -- the pivot-by-pivot inversion, a column's product handing the result over itself (one launch up to 512 rows, two
+    above), the product reading b from the pinned block -- gives the default path's answer"""
+    capi, meshgen, _ = env
+    nodes, cells, bnd = meshgen.unit_square(nx)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(1)
+    c.set_operator(-capi.laplacian() + capi.advection([6.0, -4.0]) + capi.reaction(2.0))
+    c.set_forcing(np.ones(c.quadrature_nodes().shape[0]))
+    c.init()
+    c.tune("dense_after", 0)
+    rng = np.random.default_rng(9)
+    b = rng.standard_normal(nd)
+    c.lin_compute(capi.MAT_STIFF)
+    x0, info = c.lin_solve(b, rtol=1e-12)
+    assert info.method_used == capi.SOLVER_DENSE
+    c.tune(knob, value)
+    c.lin_compute(capi.MAT_STIFF)
+    for _ in range(3):   # (the completion word and the arrival counters are reused from call to call)
+        x1, info = c.lin_solve(b, rtol=1e-12)
+        assert info.method_used == capi.SOLVER_DENSE
+        assert np.abs(x1 - x0).max() <= 1e-11 * np.abs(x0).max()
+    c.close()

@@ -426,6 +426,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "dense_direct" && (value == 0 || value == 1)) c->dense_direct = value;
     else if (k == "dense_fold" && (value == 0 || value == 1)) c->dense_fold = value;
     else if (k == "dense_multi" && (value == 0 || value == 1)) c->dense_multi = value;
+    else if (k == "dense_bulk" && (value == 0 || value == 1)) c->dense_bulk = value;
     else if (k == "dense_hostb" && (value == 0 || value == 1)) c->dense_hostb = value;
     else if (k == "small_rows" && value >= 0) c->small_rows = value;
     else if (k == "small_front_rows" && value >= 0) c->small_front_rows = value;

@@ -466,6 +466,7 @@ struct fdapde_ctx {
         bool ready = false, refine = false, failed = false;
         double check = 0, build_ms = 0;   // max |I - A X|; what the build cost (host wall clock)
     } lin_dense, step_dense, solve_dense;
+    int dense_bulk = 1;           // knob: 0 = many columns staged by the kernels reading / writing the pinned block themselves (as single columns are) instead of by DMA
     int dense_fold = 1;           // knob: 1 = the parabolic stepper's dense loop as ONE product per step (u' = B u + c, B = K^-1 M / dt); 0 = M u, rhs, K^-1 rhs, hand-over (four launches)
     int dense_hostb = 0;          // knob: 1 = one column of a system of up to 512 rows: the product reads b from the pinned block itself (k_dense_gemv_hostb), no k_dense_stage in front.
                                   // Measured: 33 us per column against 22 at 289 and 484 rows -- a workgroup's read of host memory costs ~10 us, twice the launch it saves: off
@@ -480,7 +481,7 @@ struct fdapde_ctx {
                                   // AND the Krylov time spent (handle) / to be expected (stepper) reaches half of what the inversion costs; 0: at once
     int64_t lin_cols = 0;         // columns solved against the handle's current matrix
     double lin_krylov_ms = 0;     // ... and the host time the Krylov columns among them took
-    DBuf<double> dn_b, dn_x, dn_r;
+    DBuf<double> dn_b, dn_x, dn_r, dn_e;   // (dn_e: many columns in the reference numbering on the device, in and out)
     DBuf<unsigned int> dn_cnt;
     // multi-device context (fdapde_ctx_create_multi): this context is the ROOT -- whole mesh, whole function space, every index getter -- of a group
     // of rank contexts, one per device (eng_group.hip)

@@ -239,6 +239,21 @@ int dense_solve_host(fdapde_ctx* c, fdapde_ctx::Dense& D, const double* b_host, 
     // (Also measured and dropped: the whole solve of a 289-row system as a ONE-WORKGROUP launch -- 35 us against 23: sixteen wavefronts walk eighteen rows each,
     // latency-bound.)
     const dim3 dgrid((unsigned)((n + 3) / 4));
+    // many columns (from 256 KB on): the pinned block crosses PCIe by DMA in both directions -- a kernel reading or writing host memory itself moves 6 - 10 GB/s
+    // (k_dense_stage: 375 us for 64 columns of 4 225 rows), the copy engine 25+ -- and the host waits for the stream instead of spinning on a word
+    const bool bulk = sizeof(double) * cnt >= (size_t(256) << 10) && !host_b && !one_launch && c->dense_bulk;
+    if (bulk) {
+        if (c->dn_e.n < 2 * cnt) HIPCHK(c, c->dn_e.alloc(2 * cnt));
+        HIPCHK(c, hipMemcpyAsync(c->dn_e.p, hb, sizeof(double) * cnt, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_dense_stage, dim3(g1((int64_t)cnt)), dim3(256), 0, st, (int64_t)n, nc, c->dof_i2e.p, c->dn_e.p, c->dn_b.p, c->dn_cnt.p);
+        if (int rc = dense_apply(c, D, nc, c->dn_b.p, c->dn_x.p)) return rc;
+        hipLaunchKernelGGL(k_dense_out, dim3(g1((int64_t)cnt)), dim3(256), 0, st, (int64_t)n, nc, c->dof_e2i.p, c->dn_x.p, c->dn_e.p + cnt, nullptr, c->dn_cnt.p);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(hx, c->dn_e.p + cnt, sizeof(double) * cnt, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        std::memcpy(x_host, hx, sizeof(double) * cnt);
+        return FDAPDE_OK;
+    }
     if (host_b && one_launch) {
         hipLaunchKernelGGL(k_dense_gemv_direct<true>, dgrid, dim3(256), 0, st, (int)n, D.X.p, c->dof_i2e.p, hb, hx, const_cast<long long*>(done), c->dn_cnt.p + 1);
     } else if (host_b) {   // two launches: the product reads b from the pinned block itself, then the hand-over

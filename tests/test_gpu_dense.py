@@ -306,3 +306,26 @@ def test_the_forms_kept_behind_knobs_still_answer(env, knob, value, nx):
         assert info.method_used == capi.SOLVER_DENSE
         assert np.abs(x1 - x0).max() <= 1e-11 * np.abs(x0).max()
     c.close()
+
+
+def test_many_columns_cross_pcie_by_dma_or_by_the_kernels_with_the_same_bits(env):
+    """from 256 KB of right-hand sides on the pinned block is copied by DMA instead of being read / written by the staging kernels: the same columns, bit for bit"""
+    capi, meshgen, _ = env
+    nodes, cells, bnd = meshgen.unit_square(32)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(1)
+    c.set_operator(-capi.laplacian() + capi.reaction(1.0))
+    c.set_forcing(np.ones(c.quadrature_nodes().shape[0]))
+    c.init()
+    c.tune("dense_after", 0)
+    c.lin_compute(capi.MAT_STIFF)
+    B = np.random.default_rng(2).standard_normal((nd, 48))
+    X1, info = c.lin_solve(B, rtol=1e-12)
+    assert info.method_used == capi.SOLVER_DENSE
+    c.tune("dense_bulk", 0)
+    X0, info = c.lin_solve(B, rtol=1e-12)
+    assert info.method_used == capi.SOLVER_DENSE and np.array_equal(X0, X1)
+    x, _ = c.lin_solve(B[:, 5], rtol=1e-12)
+    assert np.abs(x - X1[:, 5]).max() <= 1e-12 * np.abs(x).max()
+    c.close()

@@ -1052,6 +1052,28 @@ int e_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     const int check_every = (opt && opt->check_every > 0) ? opt->check_every : 32;
     const double* A = c->vals[FDAPDE_MAT_STIFF].p;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (opt && opt->method == FDAPDE_SOLVER_DENSE) {
+        // the direct solve asked for by name (what the reference's SparseLU does, fem_linear_elliptic_solver.h:38-47): the reference's own row-zeroed matrix
+        // inverted on the device, one product; no Krylov stage in front, no fall-back behind -- a singular matrix is reported (success = false)
+        if (!dense_eligible(c))
+            return fail(c, FDAPDE_EUNSUPPORTED, "FDAPDE_SOLVER_DENSE takes one-GPU systems of up to `dense_rows` (at most 8192) DOFs");
+        bool solved = false;
+        c->scaled_owner = fdapde_ctx::kScaledNone;
+        if (int rc = dense_direct(c, A, c->have_g ? 1 : 0, c->force.p, c->g.p, &solved)) return rc;
+        HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+        HIPCHK(c, hipEventSynchronize(c->ev1));
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        c->info = fdapde_info{};
+        c->info.method_used = FDAPDE_SOLVER_DENSE, c->info.converged = solved ? 1 : 0, c->info.relres = c->solve_dense.check, c->info.t_solve_ms = ms;
+        c->solved = solved, c->dirichlet_applied = c->have_g;
+        if (info) *info = c->info;
+        if (!solved) {
+            c->err = "FDAPDE_SOLVER_DENSE: the matrix is singular to working precision (no usable pivot, or max |I - A X| beyond 1e-6)";
+            return FDAPDE_ENOCONV;
+        }
+        return FDAPDE_OK;
+    }
     SolveState ss;
     c->scaled_owner = fdapde_ctx::kScaledSolve;
     DebugClock clk;
@@ -1164,8 +1186,11 @@ int e_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times,
     // K is fixed over the steps: the reference factorises it ONCE and back-substitutes per step (fem_linear_parabolic_solver.h:41,56-68).  A small K is
     // inverted once here (kernels_dense.h) and a step is two products -- M u_i and K^-1 rhs -- with nothing returning to the host inside the loop.
     // (a warm-started Krylov step of such a system costs ~0.2 ms: worth it when the steps add up to half an inversion)
-    if ((!opt || opt->method == FDAPDE_SOLVER_AUTO) && dense_eligible(c) &&
-        (c->dense_after == 0 || (n_times - 1 > c->dense_after && 0.2 * (n_times - 1) >= 0.5 * dense_build_estimate_ms(n)))) {
+    const bool dense_named = opt && opt->method == FDAPDE_SOLVER_DENSE;
+    if (dense_named && !dense_eligible(c))
+        return fail(c, FDAPDE_EUNSUPPORTED, "FDAPDE_SOLVER_DENSE takes one-GPU systems of up to `dense_rows` (at most 8192) DOFs");
+    if ((!opt || opt->method == FDAPDE_SOLVER_AUTO || dense_named) && dense_eligible(c) &&
+        (dense_named || c->dense_after == 0 || (n_times - 1 > c->dense_after && 0.2 * (n_times - 1) >= 0.5 * dense_build_estimate_ms(n)))) {
         fdapde_ctx::Dense& D = c->step_dense;
         D.ready = D.failed = false;
         if (int rc = dense_build(c, kmat.p, dirichlet ? 1 : 0, D)) return rc;
@@ -1200,6 +1225,13 @@ int e_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times,
             if (info) *info = c->info;
             kmat.release(), uprev.release(), rhs.release(), gcol.release();
             return FDAPDE_OK;
+        }
+        if (dense_named) {
+            c->info = fdapde_info{};
+            c->info.method_used = FDAPDE_SOLVER_DENSE, c->info.relres = D.check;
+            if (info) *info = c->info;
+            c->err = "FDAPDE_SOLVER_DENSE: M / dt + A is singular to working precision (no usable pivot, or max |I - A X| beyond 1e-6)";
+            return FDAPDE_ENOCONV;
         }
     }
     SolveState ss;
@@ -1367,10 +1399,21 @@ int e_lin_solve(fdapde_ctx* c, const fdapde_options* opt, const double* b, int32
     // "Factor once" that pays per solve (kernels_dense.h): a small system that has been asked for more than `dense_after` columns gets its dense
     // inverse -- built once, ~ms -- and every column from then on is ONE matrix-vector product, b and x through pinned memory.  Where the method was
     // left open; a method named explicitly runs as named.
-    if ((!opt || opt->method == FDAPDE_SOLVER_AUTO) && dense_eligible(c)) {
+    const bool dense_named = opt && opt->method == FDAPDE_SOLVER_DENSE;   // asked for by name: the inverse is built now, whatever the columns so far have cost
+    if (dense_named && !dense_eligible(c))
+        return fail(c, FDAPDE_EUNSUPPORTED, "FDAPDE_SOLVER_DENSE takes one-GPU systems of up to `dense_rows` (at most 8192) DOFs");
+    if ((!opt || opt->method == FDAPDE_SOLVER_AUTO || dense_named) && dense_eligible(c)) {
         fdapde_ctx::Dense& D = c->lin_dense;
-        if (!D.ready && !D.failed && (c->dense_after == 0 || (c->lin_cols + n_rhs > c->dense_after && c->lin_krylov_ms >= 0.5 * dense_build_estimate_ms(n))))
+        if (!D.ready && (!D.failed || dense_named) &&
+            (dense_named || c->dense_after == 0 || (c->lin_cols + n_rhs > c->dense_after && c->lin_krylov_ms >= 0.5 * dense_build_estimate_ms(n))))
             if (int rc = dense_build(c, c->lin_mat.p, 0, D)) return rc;
+        if (dense_named && !D.ready) {
+            c->info = fdapde_info{};
+            c->info.method_used = FDAPDE_SOLVER_DENSE, c->info.relres = D.check;
+            if (info) *info = c->info;
+            c->err = "FDAPDE_SOLVER_DENSE: the matrix is singular to working precision (no usable pivot, or max |I - A X| beyond 1e-6)";
+            return FDAPDE_ENOCONV;
+        }
         if (D.ready) {
             const auto t0 = std::chrono::steady_clock::now();
             if (int rc = dense_solve_host(c, D, b, n_rhs, x)) return rc;

@@ -72,14 +72,17 @@ typedef struct {
  * A method named explicitly is never replaced: its failure is reported (FDAPDE_ENOCONV, success = false). */
 enum { FDAPDE_SOLVER_AUTO = 0, FDAPDE_SOLVER_CG = 1, FDAPDE_SOLVER_BICGSTAB = 2, FDAPDE_SOLVER_CG_SR = 3, FDAPDE_SOLVER_CG_FUSED = 4,
        FDAPDE_SOLVER_GMRES = 5 /* restarted GMRES(50), Jacobi-scaled; one-GPU contexts */,
-       FDAPDE_SOLVER_DENSE = 6 /* reported in info.method_used only: the system was small enough (knob dense_rows, default 8192 DOFs; one-GPU contexts) for its
+       FDAPDE_SOLVER_DENSE = 6 /* the direct solve: the system is small enough (knob dense_rows, default 8192 DOFs; one-GPU contexts) for its
                                   dense inverse -- built ONCE on the device, ~ms, Gauss-Jordan with partial pivoting as one launch -- and the answer is one
                                   matrix-vector product (plus one step of iterative refinement where max |I - A X| says so).  Taken with the method left
                                   open by: fdapde_lin_solve once a handle has been asked for more than `dense_after` (2) columns ("factor once, solve many");
                                   fdapde_solve_parabolic with more than `dense_after` steps (K = M / dt + A is fixed: one inversion, then ONE product per step, u' = (K^-1 M / dt) u + K^-1 (f, g));
                                   fdapde_solve as the stage of FDAPDE_SOLVER_AUTO behind BiCGStab (which, with this stage behind it, may spend what the inversion
                                   will cost and no more) and in front of GMRES.  info.relres = max |I - A X|.  Both rent-or-buy rules go by dense_build_estimate_ms:
-                                  0.5 ms at 289 rows, 2.6 ms at 1 089, 19 ms at 4 225, 0.11 s at 8 100. */ };
+                                  0.5 ms at 289 rows, 2.6 ms at 1 089, 19 ms at 4 225, 0.11 s at 8 100.
+                                  Asked for BY NAME it runs at once -- fdapde_solve: no Krylov stage in front; fdapde_lin_solve: the inverse is built by this call;
+                                  fdapde_solve_parabolic: K inverted whatever the number of steps -- and nothing stands behind it: a matrix singular to working
+                                  precision is FDAPDE_ENOCONV (success = false, like the reference's LU), a system it does not take FDAPDE_EUNSUPPORTED. */ };
 /* ROWS: row-owner sweep (default; no atomics, bitwise reproducible).  The others are element-wise scatter forms kept as measured
  * alternatives and cross-checks: ATOMIC / COLOURED = lane per (cell, row) with a slot search, fp64 atomics / one launch per colour;
  * PARTITIONED = one workgroup per cell partition, colours walked inside the workgroup, atomics only on rows shared between

@@ -329,3 +329,65 @@ def test_many_columns_cross_pcie_by_dma_or_by_the_kernels_with_the_same_bits(env
     x, _ = c.lin_solve(B[:, 5], rtol=1e-12)
     assert np.abs(x - X1[:, 5]).max() <= 1e-12 * np.abs(x).max()
     c.close()
+
+
+def test_the_direct_solve_asked_for_by_name(env):
+    """FDAPDE_SOLVER_DENSE as the caller's choice: fdapde_solve without a Krylov stage in front, a handle that inverts on its first column, a stepper that
+    inverts K for three steps -- all at the LU solution; a singular matrix is success = false, a system beyond dense_rows is refused"""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+
+    capi, meshgen, _ = env
+    nodes, cells, bnd = meshgen.unit_square(24)
+    u_exact, f = meshgen.manufactured(2)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(1)
+    _, bd, coords = c.dofs_get()
+    c.set_operator(-capi.laplacian() + capi.advection([3.0, 1.0]))
+    c.set_forcing(f(c.quadrature_nodes()))
+    g = u_exact(coords)
+    c.set_dirichlet(g)
+    c.init()
+    info = c.solve(method=capi.SOLVER_DENSE)
+    assert info.converged == 1 and info.method_used == capi.SOLVER_DENSE and info.iters == 0
+    A = _csr(c, c.matrix_values(capi.MAT_STIFF), nd)   # (after the solve: the reference's row-zeroed matrix)
+    rhs = c.force()
+    ref = spl.spsolve(A.tocsc(), rhs)
+    assert np.linalg.norm(c.solution() - ref) <= 1e-11 * np.linalg.norm(ref)
+    krylov = c.solve(rtol=1e-12)
+    assert krylov.method_used != capi.SOLVER_DENSE
+    # the handle: the first column already
+    vals = c.matrix_values(capi.MAT_MASS)
+    lu = spl.splu(_csr(c, vals, nd).tocsc())
+    c.lin_compute(capi.MAT_MASS)
+    b = np.cos(coords[:, 0])
+    x, hinfo = c.lin_solve(b, method=capi.SOLVER_DENSE)
+    assert hinfo.method_used == capi.SOLVER_DENSE and np.linalg.norm(x - lu.solve(b)) <= 1e-11 * np.linalg.norm(x)
+    # the stepper: three steps
+    times = np.linspace(0.0, 0.03, 4)
+    c.set_operator(capi.dt() - capi.laplacian())
+    c.set_forcing(np.ones((c.quadrature_nodes().shape[0], times.size)))
+    c.init()
+    u0 = np.sin(coords[:, 0])
+    G = np.zeros((nd, times.size))
+    sol, pinfo = c.solve_parabolic(times, u0, G, method=capi.SOLVER_DENSE)
+    assert pinfo.method_used == capi.SOLVER_DENSE
+    ref_sol, kinfo = c.solve_parabolic(times, u0, G, method=capi.SOLVER_CG_FUSED, rtol=1e-13)
+    assert kinfo.method_used != capi.SOLVER_DENSE and np.abs(sol - ref_sol).max() <= 1e-10 * np.abs(ref_sol).max()
+    # singular: -Lap without Dirichlet rows
+    c2 = capi.Context(0)
+    c2.mesh_upload(nodes, cells, np.zeros_like(bnd))
+    c2.dofs_build(1)
+    c2.set_operator(-capi.laplacian())
+    c2.set_forcing(np.ones(c2.quadrature_nodes().shape[0]))
+    c2.init()
+    sinfo = c2.solve(method=capi.SOLVER_DENSE, raise_on_noconv=False)
+    assert sinfo.converged == 0 and sinfo.method_used == capi.SOLVER_DENSE
+    c2.close()
+    # too large
+    c.tune("dense_rows", 100)
+    with pytest.raises(capi.FdapdeError) as e:
+        c.solve(method=capi.SOLVER_DENSE)
+    assert e.value.status == capi.EUNSUPPORTED
+    c.close()

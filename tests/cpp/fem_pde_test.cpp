@@ -126,6 +126,37 @@ TEST(fem_pde_test, advection_diffusion_isotropic_order1) {
     EXPECT_TRUE(pde_.info().method_used == FDAPDE_SOLVER_BICGSTAB);
     EXPECT_TRUE(l2_error(pde_, [&](std::array<double, 3> x) { return ad.solution(x); }) < 1e-5);
 }
+// the same problem with the DIRECT solve asked for by name (what the reference's SparseLU does, fem_linear_elliptic_solver.h:38-47): no Krylov stage,
+// info.method_used = FDAPDE_SOLVER_DENSE, the same solution
+TEST(fem_pde_test, advection_diffusion_direct_solve_by_name) {
+    AdvDiff ad;
+    std::array<double, 2> beta_ {-ad.alpha_, 0.};
+    auto L = -laplacian<FEM_HIP>() + advection<FEM_HIP>(beta_);
+    FixtureMesh<2, 2> unit_square("unit_square");
+    PDE<Triangulation<2, 2>, decltype(L), DMatrix<double>, FEM_HIP, fem_order<1>> pde_(unit_square.mesh);
+    pde_.set_differential_operator(L);
+    pde_.set_dirichlet_bc(DMatrix<double>::Zero(pde_.n_dofs(), 1));
+    DMatrix<double> quadrature_nodes = pde_.quadrature_nodes();
+    DMatrix<double> f(quadrature_nodes.rows(), 1);
+    for (int64_t i = 0; i < quadrature_nodes.rows(); ++i) f(i) = ad.forcing(quadrature_nodes(i, 1));
+    pde_.set_forcing(f);
+    pde_.init();
+    pde_.solve();
+    EXPECT_TRUE(pde_.success());
+    const DMatrix<double> krylov = pde_.solution();
+    pde_.solver_options().method = FDAPDE_SOLVER_DENSE;
+    pde_.solve();
+    EXPECT_TRUE(pde_.success());
+    EXPECT_TRUE(pde_.info().method_used == FDAPDE_SOLVER_DENSE);
+    EXPECT_TRUE(pde_.info().iters == 0);
+    double worst = 0, scale = 0;
+    for (int64_t i = 0; i < krylov.rows(); ++i) {
+        worst = std::max(worst, std::abs(krylov(i) - pde_.solution()(i)));
+        scale = std::max(scale, std::abs(krylov(i)));
+    }
+    EXPECT_TRUE(worst <= 1e-8 * scale);
+    EXPECT_TRUE(l2_error(pde_, [&](std::array<double, 3> x) { return ad.solution(x); }) < 1e-5);
+}
 // fem_pde_test.cpp:172-212
 TEST(fem_pde_test, advection_diffusion_isotropic_order2) {
     AdvDiff ad;
@@ -817,6 +848,7 @@ int main(int argc, char** argv) {
     RUN(fem_pde_test, laplacian_isotropic_order1);
     RUN(fem_pde_test, laplacian_isotropic_order2_callable_force);
     RUN(fem_pde_test, advection_diffusion_isotropic_order1);
+    RUN(fem_pde_test, advection_diffusion_direct_solve_by_name);
     RUN(fem_pde_test, advection_diffusion_isotropic_order2);
     RUN(fem_operators_test, laplacian_order_2_through_stiff);
     RUN(sharded_test, laplacian_order1);

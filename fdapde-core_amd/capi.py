@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("FDAPDE_HIP_LIB") or os.path.join(_HERE, "lib", "libfd
 
 OK, EINVAL, ENOMEM, ENODEVICE, EHIP, ENOTINIT, ENOCONV, EUNSUPPORTED, ERCCL = range(9)
 LAPLACIAN, DIFFUSION, ADVECTION, REACTION, DT = range(5)
-SOLVER_AUTO, SOLVER_CG, SOLVER_BICGSTAB, SOLVER_CG_SR, SOLVER_CG_FUSED, SOLVER_GMRES, SOLVER_DENSE = range(7)
+SOLVER_AUTO, SOLVER_CG, SOLVER_BICGSTAB, SOLVER_CG_SR, SOLVER_CG_FUSED, SOLVER_GMRES, SOLVER_DENSE, SOLVER_PMG = range(8)
 ASSEMBLY_ROWS, ASSEMBLY_ATOMIC, ASSEMBLY_COLOURED, ASSEMBLY_PARTITIONED, ASSEMBLY_WAVE = range(5)
 MAT_STIFF, MAT_MASS = 0, 1
 

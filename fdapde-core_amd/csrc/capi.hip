@@ -74,6 +74,7 @@ int fdapde_ctx_create(int device, fdapde_ctx** out) {
 void fdapde_ctx_destroy(fdapde_ctx* c) {
     if (!c) return;
     if (c->group) fdapde_engine::g_destroy(c);   // (the rank contexts and their threads first)
+    fdapde_engine::pmg_release(c);               // (... and the coarse level's context)
     if (c->has_device) {
         (void)hipSetDevice(c->device);
         fdapde_engine::partition_free(c);
@@ -426,6 +427,10 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "dense_direct" && (value == 0 || value == 1)) c->dense_direct = value;
     else if (k == "dense_fold" && (value == 0 || value == 1)) c->dense_fold = value;
     else if (k == "dense_multi" && (value == 0 || value == 1)) c->dense_multi = value;
+    else if (k == "pmg_inner_tol_exp" && value >= 1 && value <= 12) c->pmg_inner_rtol = std::pow(10.0, -(double)value);
+    else if (k == "pmg_inner_maxit" && value >= 1) c->pmg_inner_maxit = value;
+    else if (k == "pmg_auto" && (value == 0 || value == 1)) c->pmg_auto = value;
+    else if (k == "pmg_auto_rows" && value >= 0) c->pmg_auto_rows = value;
     else if (k == "dense_bulk" && (value == 0 || value == 1)) c->dense_bulk = value;
     else if (k == "dense_hostb" && (value == 0 || value == 1)) c->dense_hostb = value;
     else if (k == "small_rows" && value >= 0) c->small_rows = value;

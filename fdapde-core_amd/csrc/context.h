@@ -457,6 +457,23 @@ struct fdapde_ctx {
     DBuf<int32_t> part_cells, part_off, part_slots, wave_slots;
     DBuf<uint8_t> part_shared;
     std::vector<double> persist_host_stats;
+    // the two-level solver of order-2 spaces (eng_pmg.hip): the P1 space of the same mesh as a context of its own + the transfer operators
+    struct Pmg {
+        fdapde_ctx* coarse = nullptr;
+        bool ready = false;
+        int64_t init_seen = -1;          // the fine context's init_count the coarse operator was assembled for
+        DBuf<int32_t> pa, pb;            // fine DOF -> its coarse DOF(s) (internal numberings; pb = -1: a vertex DOF)
+        DBuf<int32_t> rt_ptr, rt_idx;    // P^T as CSR over the coarse DOFs
+        DBuf<double> rt_w, dinv, vec, part, dots;
+        int np = 1;
+        double setup_ms = 0;
+        int last_coarse_iters = 0, last_coarse_calls = 0;
+    } pmg;
+    int64_t init_count = 0;       // fdapde_init calls so far (who caches something derived from the assembled matrices compares)
+    double pmg_inner_rtol = 1e-2; // knob pmg_inner_tol_exp: the coarse solves stop at 10^-exp
+    int pmg_inner_maxit = 200;    // knob
+    int pmg_auto = 1;             // knob: 1 = the open method takes the two-level solver for large order-2 systems it is eligible for ...
+    int64_t pmg_auto_rows = 1000000;   // knob: ... of at least that many DOFs
     // the dense inverse of a small system (kernels_dense.h / eng_dense.hip): the factor-once handle's, the parabolic stepper's, the open method's direct stage
     struct Dense {
         DBuf<double> X;             // n x n, internal DOF order

@@ -619,6 +619,7 @@ int e_init(fdapde_ctx* c, const fdapde_options* opt) {
     c->info.t_assemble_ms = ms;
     c->stiff_stat_valid = stat_complete;
     c->assembled[0] = c->assembled[1] = true, c->force_ready = true, c->solved = false, c->dirichlet_applied = false, c->cg_broke_down = false;
+    ++c->init_count;
     return FDAPDE_OK;
 }
 

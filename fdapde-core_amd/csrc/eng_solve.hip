@@ -1052,6 +1052,7 @@ int e_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     const int check_every = (opt && opt->check_every > 0) ? opt->check_every : 32;
     const double* A = c->vals[FDAPDE_MAT_STIFF].p;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (opt && opt->method == FDAPDE_SOLVER_PMG) return e_solve_pmg(c, opt, info);   // the two-level solver of order-2 spaces (eng_pmg.hip), by name
     if (opt && opt->method == FDAPDE_SOLVER_DENSE) {
         // the direct solve asked for by name (what the reference's SparseLU does, fem_linear_elliptic_solver.h:38-47): the reference's own row-zeroed matrix
         // inverted on the device, one product; no Krylov stage in front, no fall-back behind -- a singular matrix is reported (success = false)
@@ -1073,6 +1074,18 @@ int e_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
             return FDAPDE_ENOCONV;
         }
         return FDAPDE_OK;
+    }
+    // The open method on a LARGE order-2 system it qualifies for: the two-level solver first (eng_pmg.hip: ~23 iterations whatever the mesh size, where the
+    // Jacobi-preconditioned stages below need O(1 / h) -- C5, 5.36 M DOFs: 133 ms against 598; the two meet near 1 M DOFs: 705 k 36 against 27 ms, 2.1 M 68
+    // against 181).  Whatever it does not solve falls through to the stages below.
+    if ((!opt || opt->method == FDAPDE_SOLVER_AUTO) && c->pmg_auto && n >= c->pmg_auto_rows && pmg_eligible(c)) {
+        fdapde_options po{};
+        po.method = FDAPDE_SOLVER_PMG, po.rtol = rtol, po.maxit = (opt && opt->maxit > 0) ? opt->maxit : 0;
+        const int rc = e_solve_pmg(c, &po, info);
+        if (rc == FDAPDE_OK) return rc;
+        if (rc != FDAPDE_ENOCONV && rc != FDAPDE_EUNSUPPORTED) return rc;
+        c->err.clear();
+        HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     }
     SolveState ss;
     c->scaled_owner = fdapde_ctx::kScaledSolve;

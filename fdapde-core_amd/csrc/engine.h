@@ -147,6 +147,10 @@ int dense_solve_host(fdapde_ctx* c, fdapde_ctx::Dense& D, const double* b_host, 
 int dense_direct(fdapde_ctx* c, const double* A, int use_bnd, const double* f_dev, const double* g_dev, bool* solved);
 void dense_step_rhs(fdapde_ctx* c, const double* mu, double inv_dt, const double* f, const double* g_ext_dev, double* rhs);
 void dense_step_out(fdapde_ctx* c, const double* u, double* uprev, double* sol_ext_dev);
+// eng_pmg.hip
+bool pmg_eligible(const fdapde_ctx* c);
+void pmg_release(fdapde_ctx* c);
+int e_solve_pmg(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info);
 int dense_step_loop(fdapde_ctx* c, fdapde_ctx::Dense& D, int32_t n_times, double inv_dt, const double* g_ext_dev, double* u0, double* sol_ext);
 void preload_dense();
 

@@ -82,7 +82,11 @@ enum { FDAPDE_SOLVER_AUTO = 0, FDAPDE_SOLVER_CG = 1, FDAPDE_SOLVER_BICGSTAB = 2,
                                   0.5 ms at 289 rows, 2.6 ms at 1 089, 19 ms at 4 225, 0.11 s at 8 100.
                                   Asked for BY NAME it runs at once -- fdapde_solve: no Krylov stage in front; fdapde_lin_solve: the inverse is built by this call;
                                   fdapde_solve_parabolic: K inverted whatever the number of steps -- and nothing stands behind it: a matrix singular to working
-                                  precision is FDAPDE_ENOCONV (success = false, like the reference's LU), a system it does not take FDAPDE_EUNSUPPORTED. */ };
+                                  precision is FDAPDE_ENOCONV (success = false, like the reference's LU), a system it does not take FDAPDE_EUNSUPPORTED. */,
+       FDAPDE_SOLVER_PMG = 7 /* order-2 spaces, operators with constant coefficients, one-GPU contexts: BiCGStab with a TWO-LEVEL preconditioner -- the fine
+                                level's Jacobi sweep + a correction from the P1 space of the same mesh (its own context inside this one; its systems solved
+                                to 1e-2 by the open method) -- 20 - 25 iterations whatever the mesh size where Jacobi-BiCGStab needs O(1 / h).  info.iters
+                                counts its iterations (two operator applications and two coarse solves each).  fdapde_solve only. */ };
 /* ROWS: row-owner sweep (default; no atomics, bitwise reproducible).  The others are element-wise scatter forms kept as measured
  * alternatives and cross-checks: ATOMIC / COLOURED = lane per (cell, row) with a slot search, fp64 atomics / one launch per colour;
  * PARTITIONED = one workgroup per cell partition, colours walked inside the workgroup, atomics only on rows shared between

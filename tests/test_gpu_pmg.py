@@ -1,0 +1,148 @@
+"""FDAPDE_SOLVER_PMG (csrc/eng_pmg.hip): BiCGStab on an order-2 space with a two-level preconditioner -- the fine level's Jacobi sweep + a correction from the
+P1 space of the same mesh -- against scipy's SuperLU on the reference's own row-zeroed system (fem_solver_base.h:142-155, fem_linear_elliptic_solver.h:38-47)
+and against the Jacobi-preconditioned stages of the open method."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def env():
+    from fdapde_loader import load_package
+
+    load_package()
+    from fdapde_core_amd import capi, meshgen, workloads
+
+    assert capi.load().fdapde_device_count() >= 1
+    return capi, meshgen, workloads
+
+
+def _csr(c, capi, nd):
+    import scipy.sparse as sp
+
+    rp, ci = c.pattern_get()
+    return sp.csr_matrix((c.matrix_values(capi.MAT_STIFF), ci, rp), shape=(nd, nd))
+
+
+def _problem(capi, meshgen, dim, nx, op, dirichlet):
+    nodes, cells, bnd = meshgen.unit_square(nx) if dim == 2 else meshgen.unit_cube(nx)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(2)
+    _, bd, coords = c.dofs_get()
+    c.set_operator(op)
+    qn = c.quadrature_nodes()
+    c.set_forcing(1.0 + np.sin(3.0 * qn[:, 0]) * qn[:, 1])
+    if dirichlet == "zero":
+        c.set_dirichlet(np.zeros(nd))
+    elif dirichlet == "data":
+        c.set_dirichlet(0.3 * np.cos(2.0 * coords[:, 0]) + coords[:, -1])
+    c.init()
+    return c, nd, bd, coords
+
+
+@pytest.mark.parametrize("dim,nx,kind,dirichlet", [(2, 24, "adr", "data"), (2, 40, "sym", "zero"), (3, 6, "adr", "data"), (3, 10, "adr", "zero"), (3, 8, "sym", "data"),
+                                                   (2, 16, "tensor", "data")])
+def test_two_level_solver_against_lu(env, dim, nx, kind, dirichlet):
+    """2-D / 3-D, with advection (a BiCGStab coarse solve) and without (CG), a diffusion tensor, zero and non-zero Dirichlet data: the LU solution of the
+    reference's row-zeroed system to 1e-8, in a number of iterations that does not grow with the mesh"""
+    import scipy.sparse.linalg as spl
+
+    capi, meshgen, _ = env
+    b = [3.0, -1.5] if dim == 2 else [1.0, 0.5, 0.25]
+    K = np.array([[2.0, 0.3], [0.3, 1.0]])
+    op = {"adr": -capi.laplacian() + capi.advection(b) + capi.reaction(1.0), "sym": -capi.laplacian() + capi.reaction(2.0),
+          "tensor": -capi.diffusion(K) + capi.reaction(0.5)}[kind]
+    c, nd, bd, coords = _problem(capi, meshgen, dim, nx, op, dirichlet)
+    info = c.solve(method=capi.SOLVER_PMG, rtol=1e-11)
+    assert info.converged == 1 and info.method_used == capi.SOLVER_PMG and info.relres <= 1e-10
+    assert info.iters <= 40, info.iters
+    u = c.solution()
+    A = _csr(c, capi, nd)   # (after the solve: the reference's row-zeroed matrix)
+    ref = spl.spsolve(A.tocsc(), c.force())
+    assert np.linalg.norm(u - ref) <= 1e-8 * np.linalg.norm(ref)
+    again = c.solve(method=capi.SOLVER_PMG, rtol=1e-11)   # (the coarse level is kept: the same iterations, the same bits)
+    assert again.iters == info.iters and np.array_equal(c.solution(), u)
+    krylov = c.solve(rtol=1e-11)   # the open method on a system this small: the Jacobi-preconditioned stages
+    assert krylov.method_used != capi.SOLVER_PMG
+    assert np.linalg.norm(c.solution() - u) <= 1e-8 * np.linalg.norm(u)
+    c.close()
+
+
+def test_iterations_do_not_grow_with_the_mesh(env):
+    capi, meshgen, workloads = env
+    its = []
+    for nx in (6, 12, 20):
+        c, nd, _, _ = _problem(capi, meshgen, 3, nx, workloads.c5_operator(capi), "zero")
+        info = c.solve(method=capi.SOLVER_PMG, rtol=1e-10)
+        its.append(info.iters)
+        c.close()
+    assert max(its) <= 30 and max(its) - min(its) <= 6, its
+
+
+def test_new_matrix_new_coarse_operator_and_custom_boundary(env):
+    """fdapde_init again with another operator: the coarse operator follows; a boundary mask set by the caller (Dirichlet data on a part of the boundary)
+    reaches the coarse level"""
+    import scipy.sparse.linalg as spl
+
+    capi, meshgen, _ = env
+    nodes, cells, bnd = meshgen.unit_cube(8)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(2)
+    _, bd, coords = c.dofs_get()
+    part = (bd != 0) & (coords[:, 0] < 1e-12)   # Dirichlet data on the face x = 0 only
+    c.dofs_set_boundary(part.astype(np.uint8))
+    c.set_forcing(np.ones(c.quadrature_nodes().shape[0]))
+    c.set_dirichlet(np.where(part, 1.0 + coords[:, 1], 0.0))
+    for op in (-capi.laplacian() + capi.reaction(1.0), -capi.laplacian() + capi.advection([2.0, 0.0, -1.0]) + capi.reaction(3.0)):
+        c.set_operator(op)
+        c.init()
+        info = c.solve(method=capi.SOLVER_PMG, rtol=1e-11)
+        assert info.converged == 1 and info.iters <= 40
+        A = _csr(c, capi, nd)
+        ref = spl.spsolve(A.tocsc(), c.force())
+        assert np.linalg.norm(c.solution() - ref) <= 1e-8 * np.linalg.norm(ref)
+    c.close()
+
+
+def test_what_it_does_not_take_and_when_the_open_method_takes_it(env):
+    capi, meshgen, _ = env
+    nodes, cells, bnd = meshgen.unit_square(16)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(1)   # order 1: no coarse level to take
+    c.set_operator(-capi.laplacian())
+    c.set_forcing(np.ones(c.quadrature_nodes().shape[0]))
+    c.set_dirichlet(np.zeros(nd))
+    c.init()
+    with pytest.raises(capi.FdapdeError) as e:
+        c.solve(method=capi.SOLVER_PMG)
+    assert e.value.status == capi.EUNSUPPORTED
+    nd = c.dofs_build(2)
+    qn = c.quadrature_nodes()
+    c.set_operator(-capi.laplacian() + capi.reaction_field(1.0 + qn[:, 0]))   # a space-varying coefficient: sampled at the P2 rule's nodes
+    c.set_forcing(np.ones(qn.shape[0]))
+    c.set_dirichlet(np.zeros(nd))
+    c.init()
+    with pytest.raises(capi.FdapdeError) as e:
+        c.solve(method=capi.SOLVER_PMG)
+    assert e.value.status == capi.EUNSUPPORTED
+    info = c.solve()   # ... and the open method solves it the usual way
+    assert info.converged == 1 and info.method_used != capi.SOLVER_PMG
+    # the open method takes the two-level solver from `pmg_auto_rows` DOFs on (default 1 M: where it starts to win)
+    c.set_operator(-capi.laplacian() + capi.reaction(1.0))
+    c.init()
+    assert c.solve().method_used != capi.SOLVER_PMG
+    u_small = c.solution()
+    c.tune("pmg_auto_rows", 100)
+    info = c.solve()
+    assert info.converged == 1 and info.method_used == capi.SOLVER_PMG
+    assert np.abs(c.solution() - u_small).max() <= 1e-8 * np.abs(u_small).max()
+    c.tune("pmg_auto", 0)
+    assert c.solve().method_used != capi.SOLVER_PMG
+    c.close()

@@ -1065,7 +1065,9 @@ int e_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
         HIPCHK(c, hipEventSynchronize(c->ev1));
         float ms = 0;
         HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        const double t_asm = c->info.t_assemble_ms;   // (fdapde_init's figure stays with the record)
         c->info = fdapde_info{};
+        c->info.t_assemble_ms = t_asm;
         c->info.method_used = FDAPDE_SOLVER_DENSE, c->info.converged = solved ? 1 : 0, c->info.relres = c->solve_dense.check, c->info.t_solve_ms = ms;
         c->solved = solved, c->dirichlet_applied = c->have_g;
         if (info) *info = c->info;

@@ -150,10 +150,37 @@ def run_c5(capi, meshgen, nx=87, steps=3, warmup=1, time_spmv=16, rtol=1e-10, de
     ctx.set_operator(c5_operator(capi))
     ctx.set_forcing(c5_forcing(ctx.quadrature_nodes()))
     ctx.set_dirichlet(np.zeros(nd))
+    # the open method as a caller gets it: from 1 M DOFs on an order-2 system with constant coefficients goes to the two-level solver (eng_pmg.hip: the P1
+    # space of the same mesh as the coarse level) -- its first call builds that level (untimed here, like every set-up; reported)
+    t0 = time.perf_counter()
+    ctx.init()
+    first = ctx.solve(rtol=rtol)
+    t_first = time.perf_counter() - t0
+    two_level = None
+    if first.method_used == capi.SOLVER_PMG:
+        wall2, infos2 = _timed_steps(ctx, steps, warmup, 0, rtol)
+        _, _, coords = ctx.dofs_get()
+        two_level = {"dof_per_s": nd / wall2, "ms_per_step": 1e3 * wall2, "iterations": int(infos2[-1].iters), "iterations_per_step": [int(i.iters) for i in infos2],
+                     "fine_operator_applications": 2 * int(infos2[-1].iters) + 2, "method": int(infos2[-1].method_used), "relres_true": float(infos2[-1].relres),
+                     "t_assemble_ms": float(np.mean([i.t_assemble_ms for i in infos2])), "t_solve_ms": float(np.mean([i.t_solve_ms for i in infos2])),
+                     "max_abs_error_vs_analytic": float(np.abs(ctx.solution() - c5_exact(coords)).max()), "first_call_s_with_coarse_level_setup": t_first,
+                     "note": "BiCGStab, right-preconditioned by D^-1 + P A1^-1 P^T (A1: the same operator assembled on the P1 space of the mesh, solved to 1e-2 by the "
+                             "single-launch BiCGStab of a context of its own); iterations do not grow with the mesh (22-26 from 5 k to 5.4 M DOFs)"}
+        u_two = ctx.solution()
+        ctx.tune("pmg_auto", 0)   # ... and the Jacobi-preconditioned stage it replaces, on the same context: what follows is that record
     wall, infos = _timed_steps(ctx, steps, warmup, time_spmv, rtol)
     out = _summary(ctx, nd, wall, infos, c5_exact, hbm_peak_gbps)
-    out.update(workload=f"C5: 3-D P2 advection-diffusion-reaction, {nx}^3 x 6 = {n_cells} tetrahedra, b = (1, 0.5, 0.25), c = 1, "
-                        "Jacobi-BiCGStab; 3-D P2 numbering build-defined (parity unpinned)",
+    if two_level is not None:
+        two_level["max_abs_diff_vs_jacobi_bicgstab"] = float(np.abs(ctx.solution() - u_two).max())
+        jac = {k: out[k] for k in ("dof_per_s", "ms_per_step", "t_solve_ms", "iterations", "us_per_iteration", "method")}
+        out["jacobi_bicgstab"] = jac
+        out["two_level"] = two_level
+        out["dof_per_s"], out["ms_per_step"] = two_level["dof_per_s"], two_level["ms_per_step"]   # the headline of this entry: the open method
+        out["headline_method"] = int(two_level["method"])
+        out["record_note"] = ("dof_per_s / ms_per_step: the open method (two_level); every other top-level key (iterations, us_per_iteration, spmv_avg_us, frac, "
+                              "traffic, layout ...) describes the Jacobi-BiCGStab stage it replaces at this size, as in earlier records (jacobi_bicgstab has its rates)")
+    out.update(workload=f"C5: 3-D P2 advection-diffusion-reaction, {nx}^3 x 6 = {n_cells} tetrahedra, b = (1, 0.5, 0.25), c = 1; "
+                        "3-D P2 numbering build-defined (parity unpinned)",
                cells=n_cells, t_setup_s=t_setup, iterations_per_step=[int(i.iters) for i in infos],
                # BiCGStab's path to 1e-10 is chaotic in the last bits of its scalars: the SAME problem with its right-hand side scaled by (1 + k 2^-48),
                # k = 0 .. 5, takes 659 - 785 iterations (tools/c5_iter_spread.py -> profiles/r6_c5_iter_spread.txt; other shadow residuals spread wider).

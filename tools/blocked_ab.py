@@ -16,6 +16,7 @@ for name in os.environ.get("CASES", "C5,C3").split(","):
     c = capi.Context(0)
     c.mesh_upload(nodes, cells, bnd); nd = c.dofs_build(order)
     c.tune("persist", 0)
+    c.tune("pmg_auto", 0)   # (the Krylov stage's SpMV layouts are what this tool compares)
     c.set_operator(op); c.set_forcing(f(c.quadrature_nodes())); c.set_dirichlet(np.zeros(nd)); c.init()
     s = c.sizes(); alg = 12 * s["nnz"] + 4 * (nd + 1) + 16 * nd
     sols = {}

@@ -71,6 +71,8 @@ def main():
     ctx.set_operator(-capi.laplacian() + capi.advection(b) + capi.reaction(c))
     ctx.set_forcing(f(ctx.quadrature_nodes()))
     ctx.set_dirichlet(np.zeros(nd))
+    if not dist:
+        ctx.tune("pmg_auto", 0)   # (this tool profiles the Jacobi-BiCGStab stage: k_spmv_blocked and the vector kernels)
     wall = 0.0
     for i in range(2):                                   # second pass is the measured one
         if dist:

@@ -255,7 +255,7 @@ int e_solve_pmg(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
         launch_spmv(c, A, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
         if (use_bnd) hipLaunchKernelGGL(k_pmg_unit_rows, gv, bv, 0, st, n2, c->bnd.p, in, out);
     };
-    int coarse_iters = 0, coarse_calls = 0;
+    int coarse_iters = 0, coarse_calls = 0, coarse_fail = 0;   // (coarse_fail: coarse solves in a row that stopped at their budget)
     auto apply_Minv = [&](const double* in, double* out) -> int {
         // (the fine stream first: the coarse context has a stream of its own)
         hipLaunchKernelGGL(k_pmg_restrict, dim3(g1n(n1)), bv, 0, st, n1, m.rt_ptr.p, m.rt_idx.p, m.rt_w.p, cc->bnd.p, in, cc->force.p);
@@ -267,6 +267,7 @@ int e_solve_pmg(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
             return rc;
         }
         coarse_iters += ii.iters, ++coarse_calls;
+        coarse_fail = ii.converged ? 0 : coarse_fail + 1;
         HIPCHK(c, hipStreamSynchronize(cc->stream));
         hipLaunchKernelGGL(k_pmg_apply, gv, bv, 0, st, n2, m.pa.p, m.pb.p, c->bnd.p, use_bnd, m.dinv.p, in, cc->u.p, out);
         return FDAPDE_OK;
@@ -300,6 +301,10 @@ int e_solve_pmg(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
         const double beta = it == 0 ? 0.0 : (rho_new / rho) * (alpha / omega);
         hipLaunchKernelGGL(k_pmg_p, gv, bv, 0, st, n2, r, v, beta, omega, p);
         if (int rc = apply_Minv(p, ph)) return rc;
+        if (coarse_fail >= 4) {   // a coarse operator its own solver cannot handle (strongly indefinite, singular): no preconditioner -- the caller's other stages
+            broke = true;
+            break;
+        }
         apply_K(ph, v);
         ++fine_apps;
         if (int rc = dots(r0, v, nullptr, nullptr, nullptr, nullptr)) return rc;
@@ -357,7 +362,7 @@ int e_solve_pmg(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     c->solved = true, c->dirichlet_applied = c->have_g, c->scaled_owner = fdapde_ctx::kScaledNone;
     if (info) *info = c->info;
     if (!converged) {
-        c->err = broke ? "FDAPDE_SOLVER_PMG: BiCGStab broke down" : "maxit reached";
+        c->err = coarse_fail >= 4 ? "FDAPDE_SOLVER_PMG: the coarse level's solves do not converge" : broke ? "FDAPDE_SOLVER_PMG: BiCGStab broke down" : "maxit reached";
         return FDAPDE_ENOCONV;
     }
     return FDAPDE_OK;

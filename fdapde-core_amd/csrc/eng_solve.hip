@@ -1082,7 +1082,7 @@ int e_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     // against 181).  Whatever it does not solve falls through to the stages below.
     if ((!opt || opt->method == FDAPDE_SOLVER_AUTO) && c->pmg_auto && n >= c->pmg_auto_rows && pmg_eligible(c)) {
         fdapde_options po{};
-        po.method = FDAPDE_SOLVER_PMG, po.rtol = rtol, po.maxit = (opt && opt->maxit > 0) ? opt->maxit : 0;
+        po.method = FDAPDE_SOLVER_PMG, po.rtol = rtol, po.maxit = (opt && opt->maxit > 0) ? std::min(opt->maxit, 60) : 60;   // (it converges in two dozen iterations or not at all)
         const int rc = e_solve_pmg(c, &po, info);
         if (rc == FDAPDE_OK) return rc;
         if (rc != FDAPDE_ENOCONV && rc != FDAPDE_EUNSUPPORTED) return rc;

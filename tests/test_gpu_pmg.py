@@ -146,3 +146,23 @@ def test_what_it_does_not_take_and_when_the_open_method_takes_it(env):
     c.tune("pmg_auto", 0)
     assert c.solve().method_used != capi.SOLVER_PMG
     c.close()
+
+
+def test_open_method_falls_through_where_the_coarse_level_does_not_help(env):
+    """a strongly indefinite operator (-Lap - 300: negative eigenvalues on both levels): whatever the two-level solver makes of it -- a solution, or giving
+    up after its short budget / four coarse solves in a row that did not converge -- the open method hands out the LU solution"""
+    import scipy.sparse.linalg as spl
+
+    capi, meshgen, _ = env
+    c, nd, bd, coords = _problem(capi, meshgen, 3, 8, -capi.laplacian() + capi.reaction(-300.0), "data")
+    c.tune("pmg_auto_rows", 100)
+    info = c.solve(rtol=1e-11, raise_on_noconv=False)
+    assert info.converged == 1, (info.method_used, info.iters, info.relres)
+    A = _csr(c, capi, nd)
+    ref = spl.spsolve(A.tocsc(), c.force())
+    assert np.linalg.norm(c.solution() - ref) <= 1e-7 * np.linalg.norm(ref)
+    named = c.solve(method=capi.SOLVER_PMG, rtol=1e-11, raise_on_noconv=False)   # by name: its own outcome, reported as it is
+    assert named.method_used == capi.SOLVER_PMG
+    if named.converged:
+        assert np.linalg.norm(c.solution() - ref) <= 1e-7 * np.linalg.norm(ref)
+    c.close()

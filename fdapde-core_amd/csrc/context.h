@@ -471,7 +471,7 @@ struct fdapde_ctx {
     } pmg;
     int64_t init_count = 0;       // fdapde_init calls so far (who caches something derived from the assembled matrices compares)
     double pmg_inner_rtol = 1e-2; // knob pmg_inner_tol_exp: the coarse solves stop at 10^-exp
-    int pmg_inner_maxit = 200;    // knob
+    int pmg_inner_maxit = 1000;   // knob (a 2-D P1 level of 640 k DOFs needs ~400 CG iterations to 1e-2)
     int pmg_auto = 1;             // knob: 1 = the open method takes the two-level solver for large order-2 systems it is eligible for ...
     int64_t pmg_auto_rows = 1000000;   // knob: ... of at least that many DOFs
     // the dense inverse of a small system (kernels_dense.h / eng_dense.hip): the factor-once handle's, the parabolic stepper's, the open method's direct stage

@@ -258,7 +258,7 @@ int e_solve_pmg(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
         launch_spmv(c, A, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
         if (use_bnd) hipLaunchKernelGGL(k_pmg_unit_rows, gv, bv, 0, st, n2, c->bnd.p, in, out);
     };
-    int coarse_iters = 0, coarse_calls = 0, coarse_fail = 0;   // (coarse_fail: coarse solves in a row that stopped at their budget)
+    int coarse_iters = 0, coarse_calls = 0, coarse_fail = 0;   // (coarse_fail: coarse solves in a row that got nowhere)
     auto apply_Minv = [&](const double* in, double* out) -> int {
         // (the fine stream first: the coarse context has a stream of its own)
         hipLaunchKernelGGL(k_pmg_restrict, dim3(g1n(16 * n1)), bv, 0, st, n1, m.rt_ptr.p, m.rt_idx.p, m.rt_w.p, cc->bnd.p, in, cc->force.p);
@@ -270,7 +270,7 @@ int e_solve_pmg(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
             return rc;
         }
         coarse_iters += ii.iters, ++coarse_calls;
-        coarse_fail = ii.converged ? 0 : coarse_fail + 1;
+        coarse_fail = (ii.converged || (std::isfinite(ii.relres) && ii.relres < 0.5)) ? 0 : coarse_fail + 1;   // (a solve that stopped at its budget but got somewhere is a correction)
         HIPCHK(c, hipStreamSynchronize(cc->stream));
         hipLaunchKernelGGL(k_pmg_apply, gv, bv, 0, st, n2, m.pa.p, m.pb.p, c->bnd.p, use_bnd, m.dinv.p, in, cc->u.p, out);
         return FDAPDE_OK;

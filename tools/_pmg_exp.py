@@ -3,15 +3,19 @@ sys.path.insert(0, "/root/repo")
 from fdapde_loader import load_package
 load_package()
 from fdapde_core_amd import capi, meshgen, workloads
-for nx in (28, 87):
-    nodes, cells, bnd = meshgen.unit_cube(nx)
+for nx in (250, 500, 800):
+    nodes, cells, bnd = meshgen.unit_square(nx)
     c = capi.Context(0); c.mesh_upload(nodes, cells, bnd); nd = c.dofs_build(2)
-    for bscale in (1.0, 20.0):
-        c.set_operator(-capi.laplacian() + capi.advection(bscale * np.array([1.0, 0.5, 0.25])) + capi.reaction(1.0))
-        c.set_forcing(workloads.c5_forcing(c.quadrature_nodes())); c.set_dirichlet(np.zeros(nd)); c.init()
-        for sym in (0, 1):
-            c.tune("pmg_coarse_sym", sym)
-            c.solve(method=capi.SOLVER_PMG, raise_on_noconv=False)
-            t0 = time.perf_counter(); i = c.solve(method=capi.SOLVER_PMG, raise_on_noconv=False); ms = 1e3 * (time.perf_counter() - t0)
-            print(f"nx {nx} |b| x{bscale:g} coarse_sym {sym}: conv {i.converged} iters {i.iters} relres {i.relres:.1e} {ms:.1f} ms", flush=True)
+    qn = c.quadrature_nodes()
+    for name, op in (("adr", -capi.laplacian() + capi.advection([2.0, 1.0]) + capi.reaction(1.0)), ("lap", -capi.laplacian())):
+        c.set_operator(op); c.set_forcing(np.sin(3 * qn[:, 0]) + qn[:, 1]); c.set_dirichlet(np.zeros(nd)); c.init()
+        c.tune("pmg_auto", 0)
+        res = []
+        for m, mn in ((capi.SOLVER_PMG, "pmg"), (capi.SOLVER_AUTO, "jacobi")):
+            c.solve(method=m, raise_on_noconv=False)
+            t0 = time.perf_counter(); i = c.solve(method=m, raise_on_noconv=False); ms = 1e3 * (time.perf_counter() - t0)
+            res.append(f"{mn}: conv {i.converged} method {i.method_used} iters {i.iters} {ms:.1f} ms")
+            if mn == "pmg": u = c.solution()
+            else: res.append(f"diff {float(np.abs(c.solution() - u).max()):.1e}")
+        print(f"2-D P2 nx {nx} ({nd} DOFs) {name}: " + " | ".join(res), flush=True)
     c.close()

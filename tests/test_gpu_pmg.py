@@ -166,3 +166,26 @@ def test_open_method_falls_through_where_the_coarse_level_does_not_help(env):
     if named.converged:
         assert np.linalg.norm(c.solution() - ref) <= 1e-7 * np.linalg.norm(ref)
     c.close()
+
+
+def test_coarse_solves_that_stop_at_their_budget_still_serve(env):
+    """a coarse budget far too small for the coarse tolerance (what a large 2-D P1 level does to the default budget): the corrections are rougher, the outer
+    iteration takes longer -- and still ends at the LU solution; only coarse solves that get NOWHERE make the solver give up"""
+    import scipy.sparse.linalg as spl
+
+    capi, meshgen, _ = env
+    c, nd, bd, coords = _problem(capi, meshgen, 2, 60, -capi.laplacian() + capi.advection([2.0, 1.0]) + capi.reaction(1.0), "zero")
+    full = c.solve(method=capi.SOLVER_PMG, rtol=1e-10)
+    u = c.solution()
+    A = _csr(c, capi, nd)
+    ref = spl.spsolve(A.tocsc(), c.force())
+    assert np.linalg.norm(u - ref) <= 1e-7 * np.linalg.norm(ref)
+    for budget in (40, 12):
+        c.tune("pmg_inner_maxit", budget)
+        short = c.solve(method=capi.SOLVER_PMG, rtol=1e-10, maxit=300, raise_on_noconv=False)
+        assert short.method_used == capi.SOLVER_PMG
+        if short.converged:   # (rough corrections inside a BiCGStab that is not flexible: slower, and either the solution or an honest "not converged")
+            assert np.linalg.norm(c.solution() - ref) <= 1e-7 * np.linalg.norm(ref)
+        else:
+            assert short.relres > 1e-10
+    c.close()

@@ -223,37 +223,43 @@ static int pmg_setup(fdapde_ctx* c) {
     return FDAPDE_OK;
 }
 
-// fdapde_solve with FDAPDE_SOLVER_PMG (fem_linear_elliptic_solver.h:38-47: the system is the reference's, the way to its solution is not)
-int e_solve_pmg(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
-    if (!pmg_eligible(c))
-        return fail(c, FDAPDE_EUNSUPPORTED, "FDAPDE_SOLVER_PMG takes one-GPU contexts, order-2 spaces and operators with constant coefficients");
+// The two-level BiCGStab on K u = rhs (K: `A` with the Dirichlet rows as unit rows if use_bnd; rhs = f_dev on the free rows, g_dev on the Dirichlet rows),
+// started from x0_dev (or from g on the Dirichlet rows and 0 elsewhere); the coarse operator is the context's operator terms on the P1 space plus
+// `extra_reaction` times the mass matrix (the stepper's M / dt), assembled again when `coarse_key` differs from the one it was assembled for.  Result in c->u,
+// outcome in c->info (method_used, iters, converged, relres = the TRUE relative residual).  FDAPDE_OK / FDAPDE_ENOCONV / an error.
+int pmg_run(fdapde_ctx* c, const double* A, const double* f_dev, const double* g_dev, int use_bnd, const double* x0_dev, double extra_reaction, int64_t coarse_key,
+            double rtol, int maxit) {
     if (int rc = pmg_setup(c)) return rc;
     fdapde_ctx::Pmg& m = c->pmg;
     fdapde_ctx* cc = m.coarse;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const int64_t n2 = c->hs.n_dofs, n1 = cc->hs.n_dofs;
-    const int use_bnd = c->have_g ? 1 : 0;
-    const double rtol = (opt && opt->rtol > 0) ? opt->rtol : 1e-10;
-    const int maxit = (opt && opt->maxit > 0) ? opt->maxit : 400;
-    const double* A = c->vals[FDAPDE_MAT_STIFF].p;
     const auto t_begin = std::chrono::steady_clock::now();
-    HIPCHK(c, hipEventRecord(c->ev0, st));
     // the coarse operator: the same terms on the P1 space, assembled again whenever the fine one has been
-    if (m.init_seen != c->init_count) {
+    if (m.init_seen != coarse_key || m.extra_seen != extra_reaction) {
         cc->op = c->op, cc->op_symmetric = c->op_symmetric, cc->coef_of_op = false;
+        if (extra_reaction != 0.0) {
+            HostTerm rt{};
+            rt.t.kind = FDAPDE_REACTION, rt.t.space_varying = 0, rt.t.coef = 1.0, rt.t.cst[0] = extra_reaction;
+            cc->op.push_back(rt);
+        }
         if (int rc = e_init(cc, nullptr)) {
             c->err = "FDAPDE_SOLVER_PMG (coarse level): " + cc->err;
             return rc;
         }
-        m.init_seen = c->init_count;
+        m.init_seen = coarse_key, m.extra_seen = extra_reaction;
     }
     fdapde_options inner{};
     inner.method = FDAPDE_SOLVER_AUTO, inner.rtol = c->pmg_inner_rtol, inner.maxit = c->pmg_inner_maxit, inner.assembly = FDAPDE_ASSEMBLY_ROWS;
     double *x = m.vec.p, *r = x + n2, *r0 = r + n2, *p = r0 + n2, *v = p + n2, *s = v + n2, *t = s + n2, *ph = t + n2, *sh = ph + n2;
     const dim3 gv(g1n(n2)), bv(256);
     hipLaunchKernelGGL(k_pmg_diag_inv, gv, bv, 0, st, n2, c->rowptr.p, c->colidx.p, A, c->bnd.p, use_bnd, m.dinv.p);
-    hipLaunchKernelGGL(k_pmg_start, gv, bv, 0, st, n2, c->bnd.p, use_bnd, c->g.p, x);
+    if (x0_dev) {   // a warm start (the stepper's previous column): its Dirichlet rows take this system's data
+        HIPCHK(c, hipMemcpyAsync(x, x0_dev, sizeof(double) * (size_t)n2, hipMemcpyDeviceToDevice, st));
+        if (use_bnd) hipLaunchKernelGGL(k_pmg_unit_rows, gv, bv, 0, st, n2, c->bnd.p, g_dev, x);
+    } else
+        hipLaunchKernelGGL(k_pmg_start, gv, bv, 0, st, n2, c->bnd.p, use_bnd, g_dev, x);
     auto apply_K = [&](const double* in, double* out) {
         launch_spmv(c, A, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
         if (use_bnd) hipLaunchKernelGGL(k_pmg_unit_rows, gv, bv, 0, st, n2, c->bnd.p, in, out);
@@ -285,7 +291,7 @@ int e_solve_pmg(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     };
     // r = rhs - K x0 (the lift of the Dirichlet data), shadow residual r0 = r
     apply_K(x, v);
-    hipLaunchKernelGGL(k_pmg_residual, gv, bv, 0, st, n2, c->bnd.p, use_bnd, c->force.p, c->g.p, v, r);
+    hipLaunchKernelGGL(k_pmg_residual, gv, bv, 0, st, n2, c->bnd.p, use_bnd, f_dev, g_dev, v, r);
     HIPCHK(c, hipMemcpyAsync(r0, r, sizeof(double) * (size_t)n2, hipMemcpyDeviceToDevice, st));
     HIPCHK(c, hipMemsetAsync(p, 0, sizeof(double) * (size_t)n2, st));
     HIPCHK(c, hipMemsetAsync(v, 0, sizeof(double) * (size_t)n2, st));
@@ -344,14 +350,13 @@ int e_solve_pmg(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     }
     // the TRUE residual of what is handed out
     apply_K(x, v);
-    hipLaunchKernelGGL(k_pmg_residual, gv, bv, 0, st, n2, c->bnd.p, use_bnd, c->force.p, c->g.p, v, t);
+    hipLaunchKernelGGL(k_pmg_residual, gv, bv, 0, st, n2, c->bnd.p, use_bnd, f_dev, g_dev, v, t);
     if (int rc = dots(t, t, nullptr, nullptr, nullptr, nullptr)) return rc;
     const double true_rel = bb > 0 ? std::sqrt(h[0] / bb) : 0.0;
     if (converged && !(true_rel <= 10.0 * rtol)) converged = false;   // (a recurrence that drifted from the truth is not a solution)
     HIPCHK(c, c->u.alloc((size_t)n2));
     HIPCHK(c, hipMemcpyAsync(c->u.p, x, sizeof(double) * (size_t)n2, hipMemcpyDeviceToDevice, st));
-    HIPCHK(c, hipEventRecord(c->ev1, st));
-    HIPCHK(c, hipEventSynchronize(c->ev1));
+    HIPCHK(c, hipStreamSynchronize(st));
     const double t_asm = c->info.t_assemble_ms;   // (fdapde_init's figure stays with the record)
     c->info = fdapde_info{};
     c->info.t_assemble_ms = t_asm;
@@ -362,13 +367,24 @@ int e_solve_pmg(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
         std::fprintf(stderr, "pmg: %d outer iterations, %d fine applications, %d coarse solves with %d iterations, true relres %.2e, %.2f ms\n", it, fine_apps, coarse_calls,
                      coarse_iters, true_rel, c->info.t_solve_ms);
     c->pmg.last_coarse_iters = coarse_iters, c->pmg.last_coarse_calls = coarse_calls;
-    c->solved = true, c->dirichlet_applied = c->have_g, c->scaled_owner = fdapde_ctx::kScaledNone;
-    if (info) *info = c->info;
     if (!converged) {
         c->err = coarse_fail >= 4 ? "FDAPDE_SOLVER_PMG: the coarse level's solves do not converge" : broke ? "FDAPDE_SOLVER_PMG: BiCGStab broke down" : "maxit reached";
         return FDAPDE_ENOCONV;
     }
     return FDAPDE_OK;
+}
+
+// fdapde_solve with FDAPDE_SOLVER_PMG (fem_linear_elliptic_solver.h:38-47: the system is the reference's, the way to its solution is not)
+int e_solve_pmg(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
+    if (!pmg_eligible(c))
+        return fail(c, FDAPDE_EUNSUPPORTED, "FDAPDE_SOLVER_PMG takes one-GPU contexts, order-2 spaces and operators with constant coefficients");
+    const double rtol = (opt && opt->rtol > 0) ? opt->rtol : 1e-10;
+    const int maxit = (opt && opt->maxit > 0) ? opt->maxit : 400;
+    const int rc = pmg_run(c, c->vals[FDAPDE_MAT_STIFF].p, c->force.p, c->g.p, c->have_g ? 1 : 0, nullptr, 0.0, 2 * c->init_count, rtol, maxit);
+    if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;
+    c->solved = true, c->dirichlet_applied = c->have_g, c->scaled_owner = fdapde_ctx::kScaledNone;
+    if (info) *info = c->info;
+    return rc;
 }
 
 }   // namespace fdapde_engine

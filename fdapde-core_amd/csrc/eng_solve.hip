@@ -1249,6 +1249,55 @@ int e_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times,
             return FDAPDE_ENOCONV;
         }
     }
+    // Large order-2 systems (or FDAPDE_SOLVER_PMG by name): every step through the two-level solver (eng_pmg.hip) -- the coarse operator is the P1 assembly of
+    // the same terms + M1 / dt, built once for the call; a step starts from the previous column.  A first step it does not solve sends the open method to
+    // the Jacobi-preconditioned loop below.
+    const bool pmg_named = opt && opt->method == FDAPDE_SOLVER_PMG;
+    if (pmg_named && !pmg_eligible(c))
+        return fail(c, FDAPDE_EUNSUPPORTED, "FDAPDE_SOLVER_PMG takes one-GPU contexts, order-2 spaces and operators with constant coefficients");
+    if (pmg_named || ((!opt || opt->method == FDAPDE_SOLVER_AUTO) && c->pmg_auto && n >= c->pmg_auto_rows && pmg_eligible(c))) {
+        const int pm_maxit = pmg_named ? ((opt && opt->maxit > 0) ? opt->maxit : 400) : ((opt && opt->maxit > 0) ? std::min(opt->maxit, 60) : 60);
+        to_internal(initial_condition);
+        HIPCHK(c, hipMemcpyAsync(uprev.p, tmp.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        int total = 0, rc_pm = FDAPDE_OK;
+        double worst_pm = 0;
+        bool gave_up = false;
+        for (int32_t i = 0; i + 1 < n_times; ++i) {
+            launch_spmv(c, c->vals[FDAPDE_MAT_MASS].p, uprev.p, c->s.p, nullptr, nullptr, nullptr);   // M u_i
+            hipLaunchKernelGGL(k_parabolic_rhs, dim3(g1(n)), dim3(256), 0, st, n, c->s.p, inv_dt, c->force.p + (size_t)(i + 1) * n, rhs.p);
+            if (dirichlet) {
+                HIPCHK(c, hipMemcpyAsync(c->tmp_i.p, dirichlet + (size_t)(i + 1) * n, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(k_gather_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->tmp_i.p, gcol.p);
+            }
+            const int rc = pmg_run(c, kmat.p, rhs.p, gcol.p, dirichlet ? 1 : 0, uprev.p, inv_dt, 2 * c->init_count + 1, rtol, pm_maxit);
+            if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;
+            if (rc == FDAPDE_ENOCONV && i == 0 && !pmg_named) {   // not a system for it: the loop below, from the start
+                gave_up = true;
+                c->err.clear();
+                break;
+            }
+            if (rc == FDAPDE_ENOCONV) rc_pm = rc;
+            total += c->info.iters, worst_pm = std::max(worst_pm, c->info.relres);
+            HIPCHK(c, hipMemcpyAsync(uprev.p, c->u.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(k_scatter_f64, dim3(g1(n)), dim3(256), 0, st, n, c->dof_i2e.p, c->u.p, c->tmp_e.p);
+            HIPCHK(c, hipMemcpyAsync(solution + (size_t)(i + 1) * n, c->tmp_e.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));   // (tmp_e is reused by the next step)
+        }
+        if (!gave_up) {
+            std::memcpy(solution, initial_condition, sizeof(double) * (size_t)n);   // solution_.col(0) = initial condition (line 46)
+            HIPCHK(c, hipEventRecord(c->ev1, st));
+            HIPCHK(c, hipEventSynchronize(c->ev1));
+            float ms_p = 0;
+            HIPCHK(c, hipEventElapsedTime(&ms_p, c->ev0, c->ev1));
+            c->info.t_solve_ms = ms_p, c->info.iters = total, c->info.relres = worst_pm, c->info.converged = rc_pm == FDAPDE_OK ? 1 : 0;
+            c->info.method_used = FDAPDE_SOLVER_PMG, c->info.persistent = 0;
+            c->scaled_owner = fdapde_ctx::kScaledNone;
+            if (info) *info = c->info;
+            kmat.release(), uprev.release(), rhs.release(), gcol.release();
+            return rc_pm;
+        }
+    }
     SolveState ss;
     c->scaled_owner = fdapde_ctx::kScaledParabolic;
     if (int rc = solve_prepare(c, kmat.p, dirichlet ? 1 : 0, &ss, c->op_symmetric)) return rc;

@@ -151,6 +151,8 @@ void dense_step_out(fdapde_ctx* c, const double* u, double* uprev, double* sol_e
 bool pmg_eligible(const fdapde_ctx* c);
 void pmg_release(fdapde_ctx* c);
 int e_solve_pmg(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info);
+int pmg_run(fdapde_ctx* c, const double* A, const double* f_dev, const double* g_dev, int use_bnd, const double* x0_dev, double extra_reaction, int64_t coarse_key,
+            double rtol, int maxit);
 int dense_step_loop(fdapde_ctx* c, fdapde_ctx::Dense& D, int32_t n_times, double inv_dt, const double* g_ext_dev, double* u0, double* sol_ext);
 void preload_dense();
 

@@ -189,3 +189,51 @@ def test_coarse_solves_that_stop_at_their_budget_still_serve(env):
         else:
             assert short.relres > 1e-10
     c.close()
+
+
+@pytest.mark.parametrize("dim,nx", [(2, 20), (3, 6)])
+def test_parabolic_stepper_through_the_two_level_solver(env, dim, nx):
+    """fdapde_solve_parabolic with FDAPDE_SOLVER_PMG: K = M / dt + A, the coarse operator the P1 assembly of the same terms + M1 / dt, every step warm-started
+    from the previous column -- against the Jacobi-preconditioned stepper and, step by step, against LU on the reference's row-zeroed K
+    (fem_linear_parabolic_solver.h:37-72); another dt re-assembles the coarse operator"""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+
+    capi, meshgen, _ = env
+    nodes, cells, bnd = meshgen.unit_square(nx) if dim == 2 else meshgen.unit_cube(nx)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(2)
+    _, bd, coords = c.dofs_get()
+    qn = c.quadrature_nodes()
+    b = [1.0, -0.5] if dim == 2 else [1.0, 0.5, 0.25]
+    c.set_operator(capi.dt() - capi.laplacian() + capi.advection(b))
+    c.tune("dense_rows", 0)
+    u0 = np.cos(coords[:, 0]) * coords[:, 1]
+    for times in (np.linspace(0.0, 0.2, 6), np.linspace(0.0, 0.05, 4)):
+        c.set_forcing(np.stack([np.sin(2.0 * qn[:, 0]) * (1.0 + t) for t in times], axis=1))
+        c.init()
+        G = np.stack([0.1 * np.sin(coords[:, 0] + 3.0 * t) for t in times], axis=1)
+        sol, info = c.solve_parabolic(times, u0, G, method=capi.SOLVER_PMG, rtol=1e-11)
+        assert info.converged == 1 and info.method_used == capi.SOLVER_PMG and info.iters <= 40 * (times.size - 1)
+        ref, kinfo = c.solve_parabolic(times, u0, G, rtol=1e-12)
+        assert kinfo.method_used != capi.SOLVER_PMG
+        assert np.abs(sol - ref).max() <= 1e-8 * np.abs(ref).max()
+        rp, ci = c.pattern_get()
+        A = sp.csr_matrix((c.matrix_values(capi.MAT_STIFF), ci, rp), shape=(nd, nd))
+        M = sp.csr_matrix((c.matrix_values(capi.MAT_MASS), ci, rp), shape=(nd, nd))
+        F = c.force(ncols=times.size).reshape(times.size, nd).T
+        dt_ = times[1] - times[0]
+        K = (M / dt_ + A).tolil()
+        bidx = np.nonzero(bd)[0]
+        K[bidx, :] = 0.0
+        K[bidx, bidx] = 1.0
+        lu = spl.splu(sp.csc_matrix(K))
+        u = u0.copy()
+        assert np.array_equal(sol[:, 0], u0)
+        for i in range(times.size - 1):
+            rhs = (M / dt_) @ u + F[:, i + 1]
+            rhs[bidx] = G[bidx, i + 1]
+            u = lu.solve(rhs)
+            assert np.linalg.norm(sol[:, i + 1] - u) <= 1e-8 * np.linalg.norm(u), i
+    c.close()

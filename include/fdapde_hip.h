@@ -86,7 +86,8 @@ enum { FDAPDE_SOLVER_AUTO = 0, FDAPDE_SOLVER_CG = 1, FDAPDE_SOLVER_BICGSTAB = 2,
        FDAPDE_SOLVER_PMG = 7 /* order-2 spaces, operators with constant coefficients, one-GPU contexts: BiCGStab with a TWO-LEVEL preconditioner -- the fine
                                 level's Jacobi sweep + a correction from the P1 space of the same mesh (its own context inside this one; its systems solved
                                 to 1e-2 by the open method) -- 20 - 25 iterations whatever the mesh size where Jacobi-BiCGStab needs O(1 / h).  info.iters
-                                counts its iterations (two operator applications and two coarse solves each).  fdapde_solve only. */ };
+                                counts its iterations (two operator applications and two coarse solves each).  fdapde_solve and fdapde_solve_parabolic (the factor-once
+                                handle keeps the Jacobi-preconditioned stages); the open method takes it from `pmg_auto_rows` (1 M) DOFs on. */ };
 /* ROWS: row-owner sweep (default; no atomics, bitwise reproducible).  The others are element-wise scatter forms kept as measured
  * alternatives and cross-checks: ATOMIC / COLOURED = lane per (cell, row) with a slot search, fp64 atomics / one launch per colour;
  * PARTITIONED = one workgroup per cell partition, colours walked inside the workgroup, atomics only on rows shared between

@@ -473,6 +473,7 @@ int e_dofs_set_boundary(fdapde_ctx* c, const uint8_t* bnd) {
     if (!c || !bnd) return FDAPDE_EINVAL;
     HostSpace& hs = c->hs;
     if (hs.n_dofs == 0) return fail(c, FDAPDE_ENOTINIT, "call fdapde_dofs_build first");
+    pmg_release(c);   // (the coarse level of the two-level solver carries the boundary mask it was built with)
     if (c->dev_built) {
         HIPCHK(c, hipSetDevice(c->device));
         if (int rc = ensure_host(c, kHostPerm)) return rc;

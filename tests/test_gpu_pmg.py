@@ -107,6 +107,18 @@ def test_new_matrix_new_coarse_operator_and_custom_boundary(env):
         A = _csr(c, capi, nd)
         ref = spl.spsolve(A.tocsc(), c.force())
         assert np.linalg.norm(c.solution() - ref) <= 1e-8 * np.linalg.norm(ref)
+    # the mask changed AFTER the coarse level was built: it is built again with the new one
+    part2 = (bd != 0) & (coords[:, 1] > 1.0 - 1e-12)
+    c.dofs_set_boundary(part2.astype(np.uint8))
+    c.set_forcing(np.ones(c.quadrature_nodes().shape[0]))
+    c.set_dirichlet(np.where(part2, 2.0, 0.0))
+    c.set_operator(-capi.laplacian() + capi.reaction(1.0))
+    c.init()
+    info = c.solve(method=capi.SOLVER_PMG, rtol=1e-11)
+    assert info.converged == 1 and info.iters <= 40
+    A = _csr(c, capi, nd)
+    ref = spl.spsolve(A.tocsc(), c.force())
+    assert np.linalg.norm(c.solution() - ref) <= 1e-8 * np.linalg.norm(ref)
     c.close()
 
 

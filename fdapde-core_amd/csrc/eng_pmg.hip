@@ -296,10 +296,19 @@ int pmg_run(fdapde_ctx* c, const double* A, const double* f_dev, const double* g
     HIPCHK(c, hipMemsetAsync(p, 0, sizeof(double) * (size_t)n2, st));
     HIPCHK(c, hipMemsetAsync(v, 0, sizeof(double) * (size_t)n2, st));
     if (int rc = dots(r, r, nullptr, nullptr, nullptr, nullptr)) return rc;
-    const double bb = h[0];
-    double rr = bb, rho = 1.0, alpha = 1.0, omega = 1.0;
+    double bb = h[0];
+    const double rr_start = h[0];
+    if (x0_dev) {   // the stop rule stays relative to the right-hand side (lifted), not to what a good warm start leaves of it
+        hipLaunchKernelGGL(k_pmg_start, gv, bv, 0, st, n2, c->bnd.p, use_bnd, g_dev, s);
+        apply_K(s, t);
+        hipLaunchKernelGGL(k_pmg_residual, gv, bv, 0, st, n2, c->bnd.p, use_bnd, f_dev, g_dev, t, s);
+        if (int rc = dots(s, s, nullptr, nullptr, nullptr, nullptr)) return rc;
+        bb = h[0];
+        HIPCHK(c, hipMemsetAsync(v, 0, sizeof(double) * (size_t)n2, st));
+    }
+    double rr = rr_start, rho = 1.0, alpha = 1.0, omega = 1.0;
     int it = 0, fine_apps = 1;
-    bool converged = bb == 0.0, broke = false;
+    bool converged = rr_start <= rtol * rtol * bb, broke = false;
     while (!converged && it < maxit) {
         if (int rc = dots(r0, r, nullptr, nullptr, nullptr, nullptr)) return rc;
         const double rho_new = h[0];

@@ -464,6 +464,7 @@ struct fdapde_ctx {
         int64_t init_seen = -1;          // the fine context's init_count the coarse operator was assembled for ...
         double extra_seen = 0.0;         // ... and the multiple of the mass matrix added to it (the stepper's 1 / dt)
         DBuf<int32_t> pa, pb;            // fine DOF -> its coarse DOF(s) (internal numberings; pb = -1: a vertex DOF)
+        DBuf<int32_t> fine_cell;         // coarse internal cell -> fine internal cell
         DBuf<int32_t> rt_ptr, rt_idx;    // P^T as CSR over the coarse DOFs
         DBuf<double> rt_w, dinv, vec, part, dots;
         int np = 1;

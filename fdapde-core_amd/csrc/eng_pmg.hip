@@ -9,8 +9,8 @@
 // also with the coarse system solved only to 1e-2 by the library's own Krylov solver -- at most a seventh of the fine DOFs (3-D), usually small enough
 // for the single-launch form.
 //
-// How: the coarse problem lives in a CONTEXT OF ITS OWN (c->pmg.coarse: same mesh, fdapde_dofs_build(1), the same operator terms -- constant
-// coefficients only: space-varying ones are given at the P2 rule's quadrature nodes --, homogeneous Dirichlet data on the same boundary); a coarse
+// How: the coarse problem lives in a CONTEXT OF ITS OWN (c->pmg.coarse: same mesh, fdapde_dofs_build(1), the same operator terms -- coefficient
+// fields, sampled at the order-2 rule's quadrature nodes, as their cell means --, homogeneous Dirichlet data on the same boundary); a coarse
 // solve is that context's fdapde_solve with the restricted residual as its load vector.  The outer iteration is driven from the host (a few dozen
 // iterations of ~ms: launch and read-back latency do not matter): the fine operator through the solver's SpMV on the raw matrix (launch_spmv) with the
 // Dirichlet rows put back as unit rows -- the reference's own row-zeroed system (fem_solver_base.h:142-155).  One-GPU contexts.
@@ -123,6 +123,17 @@ __global__ void k_pmg_x(int64_t n, double alpha, const double* ph, double omega,
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] += alpha * ph[i] + (sh ? omega * sh[i] : 0.0);
 }
+// a coefficient field of the fine level -- nq2 samples per cell at the order-2 rule's nodes, `width` values each -- for the coarse level: every cell's
+// weighted mean at each of the nq1 nodes of the P1 rule (a preconditioner needs the coarse OPERATOR only approximately)
+__global__ void k_pmg_cell_mean(int64_t n_cells, int nq2, int nq1, int width, const double* qw2, const int32_t* fine_cell, const double* in, double* out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_cells * width) return;
+    const int64_t cell = t / width, fc = fine_cell[cell];   // (the two contexts number the cells of the mesh their own way)
+    const int k = (int)(t - cell * width);
+    double s = 0.0;
+    for (int q = 0; q < nq2; ++q) s += qw2[q] * in[(fc * nq2 + q) * width + k];
+    for (int q = 0; q < nq1; ++q) out[(cell * nq1 + q) * width + k] = s;
+}
 inline unsigned g1n(int64_t n) { return (unsigned)((n + 255) / 256); }
 }   // namespace
 
@@ -130,13 +141,13 @@ void pmg_release(fdapde_ctx* c) {
     fdapde_ctx::Pmg& m = c->pmg;
     if (m.coarse) fdapde_ctx_destroy(m.coarse);
     m.coarse = nullptr, m.ready = false, m.init_seen = -1;
-    m.pa.release(), m.pb.release(), m.rt_ptr.release(), m.rt_idx.release(), m.rt_w.release(), m.dinv.release(), m.vec.release(), m.part.release(), m.dots.release();
+    m.fine_cell.release(), m.pa.release(), m.pb.release(), m.rt_ptr.release(), m.rt_idx.release(), m.rt_w.release(), m.dinv.release(), m.vec.release(), m.part.release(), m.dots.release();
 }
 
 bool pmg_eligible(const fdapde_ctx* c) {
     if (!c->has_device || !c->dev_ready || c->hs.order != 2 || c->comm != nullptr || c->ar_fn != nullptr || c->halo_ready || c->rd.ready || c->group) return false;
     for (const HostTerm& t : c->op)
-        if (t.t.space_varying) return false;   // (its samples sit at the P2 rule's quadrature nodes: nothing to hand to the P1 assembly)
+        if (t.t.space_varying && !t.data_dev) return false;   // (a coefficient field that is not on the device)
     return !c->op.empty();
 }
 
@@ -163,6 +174,13 @@ static int pmg_setup(fdapde_ctx* c) {
     const int nv = h2.M + 1, nb2 = h2.nb;
     const int64_t n2 = h2.n_dofs, n1 = h1.n_dofs;
     if (h1.nb != nv || h1.n_cells != h2.n_cells) return bail(fail(cc, FDAPDE_EHIP, "the P1 space of the mesh does not match the P2 space's cells"));
+    std::vector<int32_t> fine_cell((size_t)h1.n_cells);   // coarse internal cell -> fine internal cell (through the mesh's own cell ids)
+    {
+        if ((int64_t)h1.cell_i2e.size() != h1.n_cells || (int64_t)h2.cell_i2e.size() != h2.n_cells) return bail(fail(cc, FDAPDE_EHIP, "the cell permutations are not on the host"));
+        std::vector<int32_t> e2i2((size_t)h2.n_cells);
+        for (int64_t ci = 0; ci < h2.n_cells; ++ci) e2i2[(size_t)h2.cell_i2e[(size_t)ci]] = (int32_t)ci;
+        for (int64_t ci = 0; ci < h1.n_cells; ++ci) fine_cell[(size_t)ci] = e2i2[(size_t)h1.cell_i2e[(size_t)ci]];
+    }
     // fine DOF (internal) -> its one (vertex DOF) or two (edge DOF) coarse DOFs (internal), cell by cell through the two DOF tables: local DOFs 0 .. M of a
     // P2 cell are its vertices in the cell's vertex order -- the P1 cell's local DOFs --, local DOF M + 1 + k sits on the edge of the local vertices kEdge[k]
     std::vector<int32_t> pa((size_t)n2, -1), pb((size_t)n2, -1);
@@ -203,6 +221,7 @@ static int pmg_setup(fdapde_ctx* c) {
     }
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
+    HIPCHK(c, m.fine_cell.upload(fine_cell.data(), fine_cell.size(), st));
     HIPCHK(c, m.pa.upload(pa.data(), pa.size(), st));
     HIPCHK(c, m.pb.upload(pb.data(), pb.size(), st));
     HIPCHK(c, m.rt_ptr.upload(ptr.data(), ptr.size(), st));
@@ -238,7 +257,25 @@ int pmg_run(fdapde_ctx* c, const double* A, const double* f_dev, const double* g
     const auto t_begin = std::chrono::steady_clock::now();
     // the coarse operator: the same terms on the P1 space, assembled again whenever the fine one has been
     if (m.init_seen != coarse_key || m.extra_seen != extra_reaction) {
-        cc->op = c->op, cc->op_symmetric = c->op_symmetric, cc->coef_of_op = false;
+        cc->op.clear(), cc->op_symmetric = c->op_symmetric, cc->coef_of_op = false;
+        for (const HostTerm& ft : c->op) {
+            HostTerm ct;
+            ct.t = ft.t, ct.field_nonsym = ft.field_nonsym;
+            if (ft.t.space_varying) {   // a coefficient field: its cell means at the P1 rule's nodes
+                const int width = ft.t.kind == FDAPDE_DIFFUSION ? c->hs.N * c->hs.N : ft.t.kind == FDAPDE_ADVECTION ? c->hs.N : 1;
+                BasisTables bt;
+                if (int rc = build_basis_tables(c->hs.M, 2, &bt)) return rc;
+                DBuf<double> qw;
+                HIPCHK(c, qw.upload(bt.qw, (size_t)bt.nq, st));
+                ct.data_dev = std::make_shared<DBuf<double>>();
+                HIPCHK(c, ct.data_dev->alloc((size_t)cc->hs.nq * (size_t)cc->hs.n_cells * width));
+                hipLaunchKernelGGL(k_pmg_cell_mean, dim3(g1n(c->hs.n_cells * width)), dim3(256), 0, st, c->hs.n_cells, c->hs.nq, cc->hs.nq, width, qw.p, m.fine_cell.p,
+                                   ft.data_dev->p, ct.data_dev->p);
+                HIPCHK(c, hipGetLastError());
+                HIPCHK(c, hipStreamSynchronize(st));   // (qw goes out of scope; the coarse context reads the field on its own stream)
+            }
+            cc->op.push_back(std::move(ct));
+        }
         if (extra_reaction != 0.0) {
             HostTerm rt{};
             rt.t.kind = FDAPDE_REACTION, rt.t.space_varying = 0, rt.t.coef = 1.0, rt.t.cst[0] = extra_reaction;
@@ -386,7 +423,7 @@ int pmg_run(fdapde_ctx* c, const double* A, const double* f_dev, const double* g
 // fdapde_solve with FDAPDE_SOLVER_PMG (fem_linear_elliptic_solver.h:38-47: the system is the reference's, the way to its solution is not)
 int e_solve_pmg(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     if (!pmg_eligible(c))
-        return fail(c, FDAPDE_EUNSUPPORTED, "FDAPDE_SOLVER_PMG takes one-GPU contexts, order-2 spaces and operators with constant coefficients");
+        return fail(c, FDAPDE_EUNSUPPORTED, "FDAPDE_SOLVER_PMG takes one-GPU contexts and order-2 spaces");
     const double rtol = (opt && opt->rtol > 0) ? opt->rtol : 1e-10;
     const int maxit = (opt && opt->maxit > 0) ? opt->maxit : 400;
     const int rc = pmg_run(c, c->vals[FDAPDE_MAT_STIFF].p, c->force.p, c->g.p, c->have_g ? 1 : 0, nullptr, 0.0, 2 * c->init_count, rtol, maxit);

@@ -1254,7 +1254,7 @@ int e_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times,
     // the Jacobi-preconditioned loop below.
     const bool pmg_named = opt && opt->method == FDAPDE_SOLVER_PMG;
     if (pmg_named && !pmg_eligible(c))
-        return fail(c, FDAPDE_EUNSUPPORTED, "FDAPDE_SOLVER_PMG takes one-GPU contexts, order-2 spaces and operators with constant coefficients");
+        return fail(c, FDAPDE_EUNSUPPORTED, "FDAPDE_SOLVER_PMG takes one-GPU contexts and order-2 spaces");
     if (pmg_named || ((!opt || opt->method == FDAPDE_SOLVER_AUTO) && c->pmg_auto && n >= c->pmg_auto_rows && pmg_eligible(c))) {
         const int pm_maxit = pmg_named ? ((opt && opt->maxit > 0) ? opt->maxit : 400) : ((opt && opt->maxit > 0) ? std::min(opt->maxit, 60) : 60);
         to_internal(initial_condition);

@@ -83,8 +83,9 @@ enum { FDAPDE_SOLVER_AUTO = 0, FDAPDE_SOLVER_CG = 1, FDAPDE_SOLVER_BICGSTAB = 2,
                                   Asked for BY NAME it runs at once -- fdapde_solve: no Krylov stage in front; fdapde_lin_solve: the inverse is built by this call;
                                   fdapde_solve_parabolic: K inverted whatever the number of steps -- and nothing stands behind it: a matrix singular to working
                                   precision is FDAPDE_ENOCONV (success = false, like the reference's LU), a system it does not take FDAPDE_EUNSUPPORTED. */,
-       FDAPDE_SOLVER_PMG = 7 /* order-2 spaces, operators with constant coefficients, one-GPU contexts: BiCGStab with a TWO-LEVEL preconditioner -- the fine
-                                level's Jacobi sweep + a correction from the P1 space of the same mesh (its own context inside this one; its systems solved
+       FDAPDE_SOLVER_PMG = 7 /* order-2 spaces, one-GPU contexts: BiCGStab with a TWO-LEVEL preconditioner -- the fine
+                                level's Jacobi sweep + a correction from the P1 space of the same mesh (its own context inside this one: the same operator terms,
+                                coefficient fields as their cell means; its systems solved
                                 to 1e-2 by the open method) -- 20 - 25 iterations whatever the mesh size where Jacobi-BiCGStab needs O(1 / h).  info.iters
                                 counts its iterations (two operator applications and two coarse solves each).  fdapde_solve and fdapde_solve_parabolic (the factor-once
                                 handle keeps the Jacobi-preconditioned stages); the open method takes it from `pmg_auto_rows` (1 M) DOFs on. */ };

@@ -137,15 +137,8 @@ def test_what_it_does_not_take_and_when_the_open_method_takes_it(env):
     assert e.value.status == capi.EUNSUPPORTED
     nd = c.dofs_build(2)
     qn = c.quadrature_nodes()
-    c.set_operator(-capi.laplacian() + capi.reaction_field(1.0 + qn[:, 0]))   # a space-varying coefficient: sampled at the P2 rule's nodes
     c.set_forcing(np.ones(qn.shape[0]))
     c.set_dirichlet(np.zeros(nd))
-    c.init()
-    with pytest.raises(capi.FdapdeError) as e:
-        c.solve(method=capi.SOLVER_PMG)
-    assert e.value.status == capi.EUNSUPPORTED
-    info = c.solve()   # ... and the open method solves it the usual way
-    assert info.converged == 1 and info.method_used != capi.SOLVER_PMG
     # the open method takes the two-level solver from `pmg_auto_rows` DOFs on (default 1 M: where it starts to win)
     c.set_operator(-capi.laplacian() + capi.reaction(1.0))
     c.init()
@@ -248,4 +241,37 @@ def test_parabolic_stepper_through_the_two_level_solver(env, dim, nx):
             rhs[bidx] = G[bidx, i + 1]
             u = lu.solve(rhs)
             assert np.linalg.norm(sol[:, i + 1] - u) <= 1e-8 * np.linalg.norm(u), i
+    c.close()
+
+
+@pytest.mark.parametrize("dim,nx", [(2, 24), (3, 7)])
+def test_coefficient_fields_reach_the_coarse_level_as_cell_means(env, dim, nx):
+    """space-varying reaction, advection and diffusion (sampled at the order-2 rule's quadrature nodes): the coarse operator is assembled from their cell means --
+    a preconditioner needs the coarse operator only approximately -- and the solve still ends at the LU solution in two dozen iterations"""
+    import scipy.sparse.linalg as spl
+
+    capi, meshgen, _ = env
+    nodes, cells, bnd = meshgen.unit_square(nx) if dim == 2 else meshgen.unit_cube(nx)
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(2)
+    _, bd, coords = c.dofs_get()
+    qn = c.quadrature_nodes()
+    nq = qn.shape[0]
+    creact = 1.0 + 5.0 * qn[:, 0] * qn[:, 1]
+    badv = np.stack([1.0 + qn[:, 1], -0.5 + qn[:, 0]] + ([0.3 * np.ones(nq)] if dim == 3 else []), axis=1)
+    K = np.zeros((nq, dim * dim))
+    for a in range(dim):
+        K[:, a * dim + a] = 1.0 + 0.5 * np.sin(2.0 * qn[:, a]) ** 2
+    K[:, 1] = K[:, dim] = 0.2 * qn[:, 0]
+    c.set_forcing(np.cos(qn[:, 0]) + 1.0)
+    c.set_dirichlet(0.2 * coords[:, 0])
+    for op in (-capi.laplacian() + capi.reaction_field(creact), -capi.diffusion_field(K) + capi.advection_field(badv) + capi.reaction_field(creact)):
+        c.set_operator(op)
+        c.init()
+        info = c.solve(method=capi.SOLVER_PMG, rtol=1e-11)
+        assert info.converged == 1 and info.method_used == capi.SOLVER_PMG and info.iters <= 45, info.iters
+        A = _csr(c, capi, nd)
+        ref = spl.spsolve(A.tocsc(), c.force())
+        assert np.linalg.norm(c.solution() - ref) <= 1e-8 * np.linalg.norm(ref)
     c.close()

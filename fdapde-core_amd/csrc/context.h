@@ -289,7 +289,7 @@ struct fdapde_ctx {
                                     // no gain worth 58 MB more of layout: off
     // whose system the shared scale / sval / sp_cur buffers hold (every solve_prepare caller records itself; the factor-once
     // handle prepares again whenever anybody else has been there in between)
-    enum { kScaledNone = 0, kScaledSolve, kScaledParabolic, kScaledLin };
+    enum { kScaledNone = 0, kScaledSolve, kScaledParabolic, kScaledLin, kScaledPmg };
     int scaled_owner = kScaledNone;
     // multi-GPU (element partition): RCCL communicator + interface maps
     ncclComm_t comm = nullptr;
@@ -470,11 +470,17 @@ struct fdapde_ctx {
         int np = 1;
         double setup_ms = 0;
         int last_coarse_iters = 0, last_coarse_calls = 0;
+        DBuf<int32_t> flag;              // raised by k_pmg_diag_inv: an interior diagonal entry is 0 (no unit-diagonal form A D^-1)
+        const double* fine_A = nullptr;  // what the blocked-ELL layout's values were filled from (A D^-1; valid while scaled_owner == kScaledPmg) ...
+        int64_t fine_key = -1;           // ... the fine context's init_count key of that fill ...
+        int fine_bnd = -1;               // ... and its boundary variant
+        SolveState coarse_ss;            // the coarse context's solver, prepared ONCE per coarse operator (coarse_prepare / coarse_solve, eng_solve.hip)
     } pmg;
     int64_t init_count = 0;       // fdapde_init calls so far (who caches something derived from the assembled matrices compares)
     double pmg_inner_rtol = 1e-2; // knob pmg_inner_tol_exp: the coarse solves stop at 10^-exp
     int pmg_inner_maxit = 1000;   // knob (a 2-D P1 level of 640 k DOFs needs ~400 CG iterations to 1e-2)
     int pmg_auto = 1;             // knob: 1 = the open method takes the two-level solver for large order-2 systems it is eligible for ...
+    int pmg_blocked = 1;          // knob: 1 = the fine operator of the two-level solver through the blocked-ELL SpMV (0: the CSR kernel on the raw matrix)
     int64_t pmg_auto_rows = 1000000;   // knob: ... of at least that many DOFs
     // the dense inverse of a small system (kernels_dense.h / eng_dense.hip): the factor-once handle's, the parabolic stepper's, the open method's direct stage
     struct Dense {

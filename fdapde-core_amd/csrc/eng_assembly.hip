@@ -539,7 +539,7 @@ int e_assemble_operator(fdapde_ctx* c, int32_t which, int32_t n_terms, const fda
         if (int rc2 = mirror_reference_lower(c, a.vals)) return rc2;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->assembled[which] = true;
-    if (which == FDAPDE_MAT_STIFF) c->op_symmetric = sym, c->solved = false, c->dirichlet_applied = false, c->cg_broke_down = false;
+    if (which == FDAPDE_MAT_STIFF) c->op_symmetric = sym, c->solved = false, c->dirichlet_applied = false, c->cg_broke_down = false, ++c->init_count;   // (whatever was derived from the old values is stale)
     return FDAPDE_OK;
 }
 

@@ -37,14 +37,21 @@ using namespace fdapde_hip;
 const int kEdge2[3][2] = {{0, 1}, {0, 2}, {1, 2}};
 const int kEdge3[6][2] = {{1, 2}, {0, 2}, {0, 1}, {1, 3}, {2, 3}, {0, 3}};
 
-__global__ void k_pmg_diag_inv(int64_t n, const int32_t* rowptr, const int32_t* colidx, const double* A, const uint8_t* bnd, int use_bnd, double* dinv) {
+__global__ void k_pmg_diag_inv(int64_t n, const int32_t* diag, const double* A, const uint8_t* bnd, int use_bnd, double* dinv, int32_t* flag) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double d = 1.0;
-    if (!(use_bnd && bnd[i]))
-        for (int32_t k = rowptr[i]; k < rowptr[i + 1]; ++k)
-            if (colidx[k] == (int32_t)i) d = A[k];
-    dinv[i] = d != 0.0 ? 1.0 / d : 1.0;
+    if (!(use_bnd && bnd[i])) d = A[diag[i]];
+    if (!(d != 0.0) || !isfinite(1.0 / d)) atomicOr(flag, 1), d = 1.0;   // (no unit-diagonal form of such a matrix: the CSR kernel serves)
+    dinv[i] = 1.0 / d;
+}
+// the blocked-ELL layout's values for the fine operator in the form A D^-1 = I + offdiag(A) D^-1 (k_spmv_blocked keeps the unit diagonal implicit): entry (i, j)
+// of the full pattern times 1 / d_j; src < 0: padding
+__global__ void k_pmg_fill_cols(int64_t n, const int32_t* src, const int32_t* colidx, const double* A, const double* dinv, double* out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int32_t k = src[e];
+    out[e] = k >= 0 ? A[k] * dinv[colidx[k]] : 0.0;
 }
 // y = A x has been computed on the raw matrix: the Dirichlet rows of the reference's system are unit rows
 __global__ void k_pmg_unit_rows(int64_t n, const uint8_t* bnd, const double* x, double* y) {
@@ -68,14 +75,14 @@ __global__ __launch_bounds__(256) void k_pmg_restrict(int64_t n1, const int32_t*
     const int lane16 = threadIdx.x & 15;
     const int64_t a = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     double s = 0.0;
-    if (a < n1 && !bnd1[a])
+    if (a < n1 && !(bnd1 && bnd1[a]))
         for (int32_t k = ptr[a] + lane16; k < ptr[a + 1]; k += 16) s += w[k] * v[idx[k]];
     s = team_sum<16>(s);
     if (a < n1 && lane16 == 0) out[a] = s;
 }
 // out = D^-1 v + P e on the free rows, v on the Dirichlet rows (where v is 0 throughout the iteration)
 __global__ void k_pmg_apply(int64_t n2, const int32_t* pa, const int32_t* pb, const uint8_t* bnd2, int use_bnd, const double* dinv, const double* v, const double* e,
-                            double* out) {
+                            int by_d, double* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n2) return;
     if (use_bnd && bnd2[i]) {
@@ -83,7 +90,8 @@ __global__ void k_pmg_apply(int64_t n2, const int32_t* pa, const int32_t* pb, co
         return;
     }
     const int32_t a = pa[i], b = pb[i];
-    out[i] = dinv[i] * v[i] + (b < 0 ? e[a] : 0.5 * (e[a] + e[b]));
+    const double corr = b < 0 ? e[a] : 0.5 * (e[a] + e[b]);
+    out[i] = by_d ? v[i] + corr / dinv[i] : dinv[i] * v[i] + corr;   // by_d: D M^-1 v, what the A D^-1 form of the fine operator takes (k_pmg_x divides again)
 }
 // up to three dot products in one pass, per-workgroup partials in a fixed order (summed by k_pmg_reduce: the same bits every run)
 __global__ __launch_bounds__(256) void k_pmg_dots(int64_t n, const double* a0, const double* b0, const double* a1, const double* b1, const double* a2, const double* b2,
@@ -119,9 +127,9 @@ __global__ void k_pmg_lin(int64_t n, const double* a, double alpha, const double
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = a[i] - alpha * b[i];
 }
-__global__ void k_pmg_x(int64_t n, double alpha, const double* ph, double omega, const double* sh, double* x) {   // x += alpha ph + omega sh
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) x[i] += alpha * ph[i] + (sh ? omega * sh[i] : 0.0);
+__global__ void k_pmg_x(int64_t n, double alpha, const double* ph, double omega, const double* sh, const double* dinv, double* x) {   // x += alpha ph + omega sh
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (dinv: ph, sh are D M^-1 p, D M^-1 s)
+    if (i < n) x[i] += (alpha * ph[i] + (sh ? omega * sh[i] : 0.0)) * (dinv ? dinv[i] : 1.0);
 }
 // a coefficient field of the fine level -- nq2 samples per cell at the order-2 rule's nodes, `width` values each -- for the coarse level: every cell's
 // weighted mean at each of the nq1 nodes of the P1 rule (a preconditioner needs the coarse OPERATOR only approximately)
@@ -198,6 +206,19 @@ static int pmg_setup(fdapde_ctx* c) {
             pa[fi] = h1.dof_e2i[(size_t)d1[ed[0]]], pb[fi] = h1.dof_e2i[(size_t)d1[ed[1]]];
         }
     }
+    // ... and the coarse space must stay INSIDE the fine one: a constrained edge DOF constrains both of its end nodes on the coarse level.  With the mask the
+    // reference builds from a full set of boundary nodes that is already so; with a partial node mask in 2-D it is not -- there every edge DOF of a geometric
+    // boundary edge is constrained whatever its end nodes are (triangulation.h:150-193 / fe_space DOF marking), and a coarse function that does not vanish
+    // at those nodes prolongs to a zig-zag the coarse operator takes for a smooth mode (100 - 300 outer iterations on such masks; tools/fuzz_pmg.py)
+    for (int64_t e = 0; e < h2.n_cells; ++e) {
+        const int32_t* d2 = &h2.dofs[(size_t)e * nb2];
+        const int32_t* d1 = &h1.dofs[(size_t)e * nv];
+        for (int k = nv; k < nb2; ++k) {
+            if (!h2.dof_bnd[(size_t)d2[k]]) continue;
+            const int* ed = h2.M == 2 ? kEdge2[k - nv] : kEdge3[k - nv];
+            bnd1[(size_t)d1[ed[0]]] = 1, bnd1[(size_t)d1[ed[1]]] = 1;
+        }
+    }
     for (int64_t i = 0; i < n2; ++i)
         if (pa[(size_t)i] < 0) return bail(fail(cc, FDAPDE_EHIP, "a P2 DOF that no cell's table names"));
     if (int rc = e_dofs_set_boundary(cc, bnd1.data())) return bail(rc);
@@ -255,6 +276,15 @@ int pmg_run(fdapde_ctx* c, const double* A, const double* f_dev, const double* g
     hipStream_t st = c->stream;
     const int64_t n2 = c->hs.n_dofs, n1 = cc->hs.n_dofs;
     const auto t_begin = std::chrono::steady_clock::now();
+    // the coarse level is constrained where the fine one is -- and only if it is (a context with a boundary mask but no Dirichlet data solves the natural problem)
+    if ((cc->have_g ? 1 : 0) != (use_bnd ? 1 : 0)) {
+        std::vector<double> zeros((size_t)n1, 0.0);
+        if (int rc = e_set_dirichlet(cc, use_bnd ? zeros.data() : nullptr)) {
+            c->err = "FDAPDE_SOLVER_PMG (coarse level): " + cc->err;
+            return rc;
+        }
+        m.init_seen = -1;
+    }
     // the coarse operator: the same terms on the P1 space, assembled again whenever the fine one has been
     if (m.init_seen != coarse_key || m.extra_seen != extra_reaction) {
         cc->op.clear(), cc->op_symmetric = c->op_symmetric, cc->coef_of_op = false;
@@ -285,13 +315,44 @@ int pmg_run(fdapde_ctx* c, const double* A, const double* f_dev, const double* g
             c->err = "FDAPDE_SOLVER_PMG (coarse level): " + cc->err;
             return rc;
         }
+        if (int rc = coarse_prepare(cc, &m.coarse_ss)) {
+            c->err = "FDAPDE_SOLVER_PMG (coarse level): " + cc->err;
+            return rc;
+        }
         m.init_seen = coarse_key, m.extra_seen = extra_reaction;
     }
     fdapde_options inner{};
     inner.method = FDAPDE_SOLVER_AUTO, inner.rtol = c->pmg_inner_rtol, inner.maxit = c->pmg_inner_maxit, inner.assembly = FDAPDE_ASSEMBLY_ROWS;
     double *x = m.vec.p, *r = x + n2, *r0 = r + n2, *p = r0 + n2, *v = p + n2, *s = v + n2, *t = s + n2, *ph = t + n2, *sh = ph + n2;
     const dim3 gv(g1n(n2)), bv(256);
-    hipLaunchKernelGGL(k_pmg_diag_inv, gv, bv, 0, st, n2, c->rowptr.p, c->colidx.p, A, c->bnd.p, use_bnd, m.dinv.p);
+    HIPCHK(c, m.flag.alloc(1));
+    HIPCHK(c, hipMemsetAsync(m.flag.p, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_pmg_diag_inv, gv, bv, 0, st, n2, c->diag.p, A, c->bnd.p, use_bnd, m.dinv.p, m.flag.p);
+    // The fine operator on DIRECTION vectors (p^, s^: their Dirichlet entries are exactly 0) through the blocked-ELL SpMV the multi-launch Krylov stages use for
+    // long rows (k_spmv_blocked: x staged in LDS once per block, the matrix streamed at the HBM rate -- C5: 328 us against 592 us of the CSR kernel on the raw
+    // matrix).  That kernel keeps a unit diagonal implicit, so the layout is filled with A D^-1: right preconditioning is A M^-1 = (A D^-1)(D M^-1), and
+    // D M^-1 v = v + D P A1^-1 P^T v comes out of k_pmg_apply for free -- the residuals stay those of the unscaled system.  The three applications to the
+    // iterate itself (start, warm start, true residual: Dirichlet columns count there) keep the CSR kernel.
+    const int fv = use_bnd ? 1 : 0;
+    bool fb = false;
+    if (c->pmg_blocked && c->blocked && c->spmv_variant == 2) {
+        if (int rc = build_blocked(c, fv)) return rc;
+        if (c->bk[fv].ok) {
+            int32_t zero_diag = 0;
+            HIPCHK(c, hipMemcpyAsync(&zero_diag, m.flag.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            fb = zero_diag == 0;
+        }
+        if (fb && !(c->scaled_owner == fdapde_ctx::kScaledPmg && m.fine_A == A && m.fine_key == coarse_key && m.fine_bnd == fv)) {
+            const fdapde_ctx::Blocked& bk = c->bk[fv];
+            if (bk.meta.n_entries > 0)
+                hipLaunchKernelGGL(k_pmg_fill_cols, dim3(g1n(bk.meta.n_entries)), bv, 0, st, bk.meta.n_entries, bk.ell_src.p, c->colidx.p, A, m.dinv.p, bk.ell_val.p);
+            HIPCHK(c, hipGetLastError());
+            c->bk[0].filled = c->bk[1].filled = false, c->bk_cur = -1;   // (not the scaled matrix of the Krylov stages: they fill it again)
+            c->scaled_owner = fdapde_ctx::kScaledPmg, m.fine_A = A, m.fine_key = coarse_key, m.fine_bnd = fv;
+        }
+    }
+    const double* x_dinv = fb ? m.dinv.p : nullptr;
     if (x0_dev) {   // a warm start (the stepper's previous column): its Dirichlet rows take this system's data
         HIPCHK(c, hipMemcpyAsync(x, x0_dev, sizeof(double) * (size_t)n2, hipMemcpyDeviceToDevice, st));
         if (use_bnd) hipLaunchKernelGGL(k_pmg_unit_rows, gv, bv, 0, st, n2, c->bnd.p, g_dev, x);
@@ -301,13 +362,17 @@ int pmg_run(fdapde_ctx* c, const double* A, const double* f_dev, const double* g
         launch_spmv(c, A, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
         if (use_bnd) hipLaunchKernelGGL(k_pmg_unit_rows, gv, bv, 0, st, n2, c->bnd.p, in, out);
     };
+    auto apply_K_dir = [&](const double* in, double* out) {   // in: D M^-1 of a direction vector (fb) or M^-1 of it
+        if (fb) launch_spmv_blocked(c, fv, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+        else apply_K(in, out);
+    };
     int coarse_iters = 0, coarse_calls = 0, coarse_fail = 0;   // (coarse_fail: coarse solves in a row that got nowhere)
     auto apply_Minv = [&](const double* in, double* out) -> int {
         // (the fine stream first: the coarse context has a stream of its own)
-        hipLaunchKernelGGL(k_pmg_restrict, dim3(g1n(16 * n1)), bv, 0, st, n1, m.rt_ptr.p, m.rt_idx.p, m.rt_w.p, cc->bnd.p, in, cc->force.p);
+        hipLaunchKernelGGL(k_pmg_restrict, dim3(g1n(16 * n1)), bv, 0, st, n1, m.rt_ptr.p, m.rt_idx.p, m.rt_w.p, use_bnd ? cc->bnd.p : (const uint8_t*)nullptr, in, cc->force.p);
         HIPCHK(c, hipStreamSynchronize(st));
         fdapde_info ii{};
-        const int rc = e_solve(cc, &inner, &ii);
+        const int rc = coarse_solve(cc, &m.coarse_ss, inner.rtol, inner.maxit, &ii);
         if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) {   // (an inner solve that stopped at its budget still is a correction)
             c->err = "FDAPDE_SOLVER_PMG (coarse level): " + cc->err;
             return rc;
@@ -315,7 +380,7 @@ int pmg_run(fdapde_ctx* c, const double* A, const double* f_dev, const double* g
         coarse_iters += ii.iters, ++coarse_calls;
         coarse_fail = (ii.converged || (std::isfinite(ii.relres) && ii.relres < 0.5)) ? 0 : coarse_fail + 1;   // (a solve that stopped at its budget but got somewhere is a correction)
         HIPCHK(c, hipStreamSynchronize(cc->stream));
-        hipLaunchKernelGGL(k_pmg_apply, gv, bv, 0, st, n2, m.pa.p, m.pb.p, c->bnd.p, use_bnd, m.dinv.p, in, cc->u.p, out);
+        hipLaunchKernelGGL(k_pmg_apply, gv, bv, 0, st, n2, m.pa.p, m.pb.p, c->bnd.p, use_bnd, m.dinv.p, in, cc->u.p, fb ? 1 : 0, out);
         return FDAPDE_OK;
     };
     double h[3] = {0, 0, 0};
@@ -360,7 +425,7 @@ int pmg_run(fdapde_ctx* c, const double* A, const double* f_dev, const double* g
             broke = true;
             break;
         }
-        apply_K(ph, v);
+        apply_K_dir(ph, v);
         ++fine_apps;
         if (int rc = dots(r0, v, nullptr, nullptr, nullptr, nullptr)) return rc;
         if (h[0] == 0.0 || !std::isfinite(h[0])) {
@@ -371,12 +436,12 @@ int pmg_run(fdapde_ctx* c, const double* A, const double* f_dev, const double* g
         hipLaunchKernelGGL(k_pmg_lin, gv, bv, 0, st, n2, r, alpha, v, s);
         if (int rc = dots(s, s, nullptr, nullptr, nullptr, nullptr)) return rc;
         if (h[0] <= rtol * rtol * bb) {   // (half a step is enough)
-            hipLaunchKernelGGL(k_pmg_x, gv, bv, 0, st, n2, alpha, ph, 0.0, (const double*)nullptr, x);
+            hipLaunchKernelGGL(k_pmg_x, gv, bv, 0, st, n2, alpha, ph, 0.0, (const double*)nullptr, x_dinv, x);
             rr = h[0], ++it, converged = true;
             break;
         }
         if (int rc = apply_Minv(s, sh)) return rc;
-        apply_K(sh, t);
+        apply_K_dir(sh, t);
         ++fine_apps;
         if (int rc = dots(t, s, t, t, nullptr, nullptr)) return rc;
         if (h[1] == 0.0 || !std::isfinite(h[0]) || !std::isfinite(h[1])) {
@@ -384,7 +449,7 @@ int pmg_run(fdapde_ctx* c, const double* A, const double* f_dev, const double* g
             break;
         }
         omega = h[0] / h[1];
-        hipLaunchKernelGGL(k_pmg_x, gv, bv, 0, st, n2, alpha, ph, omega, sh, x);
+        hipLaunchKernelGGL(k_pmg_x, gv, bv, 0, st, n2, alpha, ph, omega, sh, x_dinv, x);
         hipLaunchKernelGGL(k_pmg_lin, gv, bv, 0, st, n2, s, omega, t, r);
         if (int rc = dots(r, r, nullptr, nullptr, nullptr, nullptr)) return rc;
         rr = h[0], rho = rho_new, ++it;
@@ -428,7 +493,7 @@ int e_solve_pmg(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     const int maxit = (opt && opt->maxit > 0) ? opt->maxit : 400;
     const int rc = pmg_run(c, c->vals[FDAPDE_MAT_STIFF].p, c->force.p, c->g.p, c->have_g ? 1 : 0, nullptr, 0.0, 2 * c->init_count, rtol, maxit);
     if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;
-    c->solved = true, c->dirichlet_applied = c->have_g, c->scaled_owner = fdapde_ctx::kScaledNone;
+    c->solved = true, c->dirichlet_applied = c->have_g;   // (scaled_owner: kScaledPmg while the blocked layout holds this matrix, pmg_run)
     if (info) *info = c->info;
     return rc;
 }

@@ -30,11 +30,11 @@ void drop_graph(fdapde_ctx* c) {
 // e0 / e1 (optional): HIP events attached to the dispatch itself (hipExtLaunchKernelGGL), i.e. the kernel's own begin / end
 // timestamps on the stream it runs on -- the same interval rocprofv3 --kernel-trace reports, with no extra marker packet
 // between the neighbouring kernels.
-void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, const double* w, double* partial,
-                 const int32_t* stop, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, int dot2_ww = 0,
-                 const uint8_t* owned = nullptr) {
-    if (vals == c->sval.p && c->bk_cur >= 0 && owned == nullptr) {   // the solver's scaled matrix in blocked-ELL form (k_spmv_blocked)
-        const fdapde_ctx::Blocked& bk = c->bk[c->bk_cur];
+// y = (I + offdiag) x from the blocked-ELL layout of boundary variant v with the values its ell_val holds (k_spmv_blocked; y = x on the rows it leaves out)
+void launch_spmv_blocked(fdapde_ctx* c, int v, const double* x, double* y, const double* w, double* partial, const int32_t* stop, hipEvent_t e0, hipEvent_t e1,
+                         int dot2_ww) {
+    {
+        const fdapde_ctx::Blocked& bk = c->bk[v];
         BlockedSpmvArgs a{};
         a.G = bk.meta.G, a.nsl = bk.meta.nsl, a.imp_cap = bk.imp_cap, a.dot2_ww = dot2_ww;
         a.slot_dof = bk.slot_dof.p, a.ell_off = bk.ell_off.p, a.sl_off = bk.sl_off.p, a.ell_code = bk.ell_code.p, a.ell_val = bk.ell_val.p;
@@ -53,6 +53,14 @@ void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, 
         default: BLOCKED_GO(16); break;
         }
 #undef BLOCKED_GO
+    }
+}
+
+void launch_spmv(fdapde_ctx* c, const double* vals, const double* x, double* y, const double* w, double* partial,
+                 const int32_t* stop, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr, int dot2_ww = 0,
+                 const uint8_t* owned = nullptr) {
+    if (vals == c->sval.p && c->bk_cur >= 0 && owned == nullptr) {   // the solver's scaled matrix in blocked-ELL form (k_spmv_blocked)
+        launch_spmv_blocked(c, c->bk_cur, x, y, w, partial, stop, e0, e1, dot2_ww);
         return;
     }
     SpmvArgs s{};
@@ -1161,6 +1169,31 @@ int e_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->info.t_solve_ms = ms;
+    c->solved = true, c->dirichlet_applied = c->have_g;
+    if (info) *info = c->info;
+    return rc;
+}
+
+// The coarse level of the two-level solver (eng_pmg.hip) is solved ~50 times per fine solve, every time for the SAME matrix: what fdapde_solve does in front
+// of its Krylov stage (Jacobi scale, scaled copy, the launch's layout filled: ~0.15 ms of kernels and two waits at 681 k rows) is done once per coarse
+// operator, as the parabolic stepper does for its steps; a solve is then solve_run on the context's load vector.  Same method choice as fdapde_solve's open
+// method (CG for a symmetric operator with a positive diagonal, BiCGStab after a CG breakdown or else), without its direct / GMRES stages.
+int coarse_prepare(fdapde_ctx* c, SolveState* ss) {
+    HIPCHK(c, hipSetDevice(c->device));
+    c->scaled_owner = fdapde_ctx::kScaledSolve;
+    return solve_prepare(c, c->vals[FDAPDE_MAT_STIFF].p, c->have_g ? 1 : 0, ss, c->op_symmetric && !c->cg_broke_down, false);
+}
+
+int coarse_solve(fdapde_ctx* c, SolveState* ss, double rtol, int maxit, fdapde_info* info) {
+    const double* A = c->vals[FDAPDE_MAT_STIFF].p;
+    int method = c->cg_broke_down ? FDAPDE_SOLVER_BICGSTAB : FDAPDE_SOLVER_AUTO;
+    int rc = solve_run_restarting(c, *ss, A, c->force.p, c->g.p, nullptr, method, rtol, maxit, 32, 0, 0);
+    if (rc == FDAPDE_ENOCONV && c->h_ctl[2] != 0 && method == FDAPDE_SOLVER_AUTO && is_cg_method(c->info.method_used)) {   // (see fdapde_solve)
+        c->cg_broke_down = true;
+        if (int rc2 = solve_prepare(c, A, c->have_g ? 1 : 0, ss, false, false)) return rc2;
+        rc = solve_run_restarting(c, *ss, A, c->force.p, c->g.p, nullptr, FDAPDE_SOLVER_BICGSTAB, rtol, maxit, 32, 0, 0);
+    }
+    if (rc != FDAPDE_OK && rc != FDAPDE_ENOCONV) return rc;
     c->solved = true, c->dirichlet_applied = c->have_g;
     if (info) *info = c->info;
     return rc;

@@ -147,6 +147,12 @@ int dense_solve_host(fdapde_ctx* c, fdapde_ctx::Dense& D, const double* b_host, 
 int dense_direct(fdapde_ctx* c, const double* A, int use_bnd, const double* f_dev, const double* g_dev, bool* solved);
 void dense_step_rhs(fdapde_ctx* c, const double* mu, double inv_dt, const double* f, const double* g_ext_dev, double* rhs);
 void dense_step_out(fdapde_ctx* c, const double* u, double* uprev, double* sol_ext_dev);
+// eng_solve.hip: the blocked-ELL SpMV layout of boundary variant v (c->bk[v]; ok = false where the system does not take it) and its launch on whatever ell_val holds
+int build_blocked(fdapde_ctx* c, int v);
+void launch_spmv_blocked(fdapde_ctx* c, int v, const double* x, double* y, const double* w, double* partial, const int32_t* stop, hipEvent_t e0, hipEvent_t e1, int dot2_ww);
+// eng_solve.hip: the coarse-level solves of the two-level solver -- the solver prepared once per coarse operator, then one run per right-hand side (c->force)
+int coarse_prepare(fdapde_ctx* c, SolveState* ss);
+int coarse_solve(fdapde_ctx* c, SolveState* ss, double rtol, int maxit, fdapde_info* info);
 // eng_pmg.hip
 bool pmg_eligible(const fdapde_ctx* c);
 void pmg_release(fdapde_ctx* c);

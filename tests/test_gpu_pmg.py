@@ -275,3 +275,36 @@ def test_coefficient_fields_reach_the_coarse_level_as_cell_means(env, dim, nx):
         ref = spl.spsolve(A.tocsc(), c.force())
         assert np.linalg.norm(c.solution() - ref) <= 1e-8 * np.linalg.norm(ref)
     c.close()
+
+
+@pytest.mark.parametrize("dim,nx", [(2, 30), (3, 7)])
+def test_partial_boundary_masks_keep_the_coarse_space_inside_the_fine_one(env, dim, nx):
+    """Dirichlet data on a PART of the boundary nodes.  In 2-D the reference constrains every edge DOF of a geometric boundary edge whatever its end nodes are
+    (triangulation.h:150-193), so the coarse level must constrain those end nodes too -- before it did, such masks took 100 - 300 outer iterations
+    (tools/fuzz_pmg.py, seed 12); and a mask without Dirichlet data leaves both levels unconstrained.  Both forms of the fine operator (knob pmg_blocked)."""
+    import scipy.sparse.linalg as spl
+
+    capi, meshgen, _ = env
+    nodes, cells, bnd = meshgen.unit_square(nx) if dim == 2 else meshgen.unit_cube(nx)
+    rng = np.random.default_rng(4)
+    keep = ((rng.uniform(0, 1, bnd.shape[0]) < 0.3) & (bnd != 0)).astype(bnd.dtype)
+    assert 0 < keep.sum() < (bnd != 0).sum()
+    for with_data in (True, False):
+        for blocked in (1, 0):
+            c = capi.Context(0)
+            c.mesh_upload(nodes, cells, keep)
+            nd = c.dofs_build(2)
+            _, _, coords = c.dofs_get()
+            c.tune("pmg_blocked", blocked)
+            c.set_operator(-capi.laplacian() + capi.advection(np.array([2.0, -1.0, 0.5][:dim])) + capi.reaction(0.7))
+            c.set_forcing(1.0 + c.quadrature_nodes()[:, 0])
+            if with_data:
+                c.set_dirichlet(0.3 + coords @ np.array([0.5, -0.2, 0.1][:dim]))
+            c.init()
+            info = c.solve(method=capi.SOLVER_PMG, rtol=1e-11)
+            u = c.solution()
+            ref = spl.spsolve(_csr(c, capi, nd).tocsc(), c.force())
+            assert info.converged == 1 and info.method_used == capi.SOLVER_PMG
+            assert info.iters <= 45, (with_data, blocked, info.iters)
+            assert np.linalg.norm(u - ref) <= 1e-8 * np.linalg.norm(ref)
+            c.close()

@@ -55,6 +55,8 @@ for case in range(n_cases):
             K[:, a * dim + a] = 1.0 + rng.uniform(0, 1) * np.sin(3.0 * qn[:, a]) ** 2
         op = -capi.diffusion_field(K) + capi.advection_field(np.stack([rng.uniform(-2, 2) * (1.0 + qn[:, (a + 1) % dim]) for a in range(dim)], axis=1)) \
             + capi.reaction_field(0.2 + rng.uniform(0, 4) * qn[:, 0] ** 2)
+    if os.environ.get("FUZZ_PMG_BLOCKED"):
+        c.tune("pmg_blocked", int(os.environ["FUZZ_PMG_BLOCKED"]))   # (A/B of the fine operator's form)
     c.set_operator(op)
     for rep in range(2):
         c.set_forcing(rng.standard_normal(nq))
@@ -74,6 +76,8 @@ for case in range(n_cases):
         worst = max(worst, err if info.converged else 0.0)
         if info.method_used == capi.SOLVER_PMG:
             most_iters = max(most_iters, int(info.iters))
+        if ok and info.method_used == capi.SOLVER_PMG and info.iters > 60:
+            print(f"slow case {case} rep {rep}: dim {dim} nx {nx} {nd} DOFs {kind} bc {bc}: iters {info.iters} relres {info.relres:.1e} err {err:.1e}", flush=True)
         if not ok:
             fails += 1
             print(f"FAIL case {case} rep {rep}: dim {dim} nx {nx} {nd} DOFs {kind} bc {bc}: conv {info.converged} method {info.method_used} iters {info.iters} relres {info.relres:.1e} err {err:.1e}", flush=True)

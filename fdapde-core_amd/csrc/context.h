@@ -466,7 +466,7 @@ struct fdapde_ctx {
         DBuf<int32_t> pa, pb;            // fine DOF -> its coarse DOF(s) (internal numberings; pb = -1: a vertex DOF)
         DBuf<int32_t> fine_cell;         // coarse internal cell -> fine internal cell
         DBuf<int32_t> rt_ptr, rt_idx;    // P^T as CSR over the coarse DOFs
-        DBuf<double> rt_w, dinv, vec, part, dots;
+        DBuf<double> rt_w, dinv, vec, part, dots, basis;   // (basis: V_0 .. V_mk, Z_0 .. Z_{mk-1} of the flexible GMRES)
         int np = 1;
         double setup_ms = 0;
         int last_coarse_iters = 0, last_coarse_calls = 0;
@@ -474,12 +474,19 @@ struct fdapde_ctx {
         const double* fine_A = nullptr;  // what the blocked-ELL layout's values were filled from (A D^-1; valid while scaled_owner == kScaledPmg) ...
         int64_t fine_key = -1;           // ... the fine context's init_count key of that fill ...
         int fine_bnd = -1;               // ... and its boundary variant
+        double omega = 0.0;              // the cycle's Jacobi damping, 1.5 / lambda_max(D^-1 A) of the matrix named by the four below
+        const double* omega_A = nullptr;
+        int64_t omega_key = -1;
+        int omega_bnd = -1;
+        double omega_extra = 0.0;
         SolveState coarse_ss;            // the coarse context's solver, prepared ONCE per coarse operator (coarse_prepare / coarse_solve, eng_solve.hip)
     } pmg;
     int64_t init_count = 0;       // fdapde_init calls so far (who caches something derived from the assembled matrices compares)
     double pmg_inner_rtol = 1e-2; // knob pmg_inner_tol_exp: the coarse solves stop at 10^-exp
     int pmg_inner_maxit = 1000;   // knob (a 2-D P1 level of 640 k DOFs needs ~400 CG iterations to 1e-2)
     int pmg_auto = 1;             // knob: 1 = the open method takes the two-level solver for large order-2 systems it is eligible for ...
+    int pmg_outer = 0;            // knob: the outer method of the two-level solver: 0 = flexible GMRES, 1 = BiCGStab (round 6's first form)
+    int pmg_smooth = 1;           // knob: 1 = the preconditioner of the flexible GMRES is a V(1,1) cycle (damped Jacobi around the coarse correction), 0 = the additive form
     int pmg_blocked = 1;          // knob: 1 = the fine operator of the two-level solver through the blocked-ELL SpMV (0: the CSR kernel on the raw matrix)
     int64_t pmg_auto_rows = 1000000;   // knob: ... of at least that many DOFs
     // the dense inverse of a small system (kernels_dense.h / eng_dense.hip): the factor-once handle's, the parabolic stepper's, the open method's direct stage

@@ -82,16 +82,39 @@ __global__ __launch_bounds__(256) void k_pmg_restrict(int64_t n1, const int32_t*
 }
 // out = D^-1 v + P e on the free rows, v on the Dirichlet rows (where v is 0 throughout the iteration)
 __global__ void k_pmg_apply(int64_t n2, const int32_t* pa, const int32_t* pb, const uint8_t* bnd2, int use_bnd, const double* dinv, const double* v, const double* e,
-                            int by_d, double* out) {
+                            int by_d, double wv, double* out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n2) return;
     if (use_bnd && bnd2[i]) {
-        out[i] = v[i];
+        out[i] = wv * v[i];
         return;
     }
     const int32_t a = pa[i], b = pb[i];
     const double corr = b < 0 ? e[a] : 0.5 * (e[a] + e[b]);
-    out[i] = by_d ? v[i] + corr / dinv[i] : dinv[i] * v[i] + corr;   // by_d: D M^-1 v, what the A D^-1 form of the fine operator takes (k_pmg_x divides again)
+    out[i] = by_d ? wv * v[i] + corr / dinv[i] : wv * dinv[i] * v[i] + corr;   // by_d: D M^-1 v, what the A D^-1 form of the fine operator takes (the x update divides again)
+}
+// the smoothed cycle's vector steps (all in D-scaled variables: z' = D z)
+__global__ void k_pmg_post(int64_t n, const double* v, const double* t, double om, double* z, double* r) {   // r = v - t (t = A D^-1 z'), z' += om r
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double ri = v[i] - t[i];
+    r[i] = ri, z[i] += om * ri;
+}
+__global__ void k_pmg_wfin(int64_t n, const double* v, const double* r, const double* t, double om, double* w) {   // w = A z = (v - r) + om t (t = A D^-1 r)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) w[i] = v[i] - r[i] + om * t[i];
+}
+__global__ void k_pmg_mulv(int64_t n, const double* a, const double* b, double* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] * b[i];
+}
+// a fixed pseudo-random start vector for the power iteration (0 on the Dirichlet rows)
+__global__ void k_pmg_hashvec(int64_t n, const uint8_t* bnd, int use_bnd, double* x) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t z = (uint64_t)i * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull, z = (z ^ (z >> 27)) * 0x94D049BB133111EBull, z ^= z >> 31;
+    x[i] = (use_bnd && bnd[i]) ? 0.0 : (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
 }
 // up to three dot products in one pass, per-workgroup partials in a fixed order (summed by k_pmg_reduce: the same bits every run)
 __global__ __launch_bounds__(256) void k_pmg_dots(int64_t n, const double* a0, const double* b0, const double* a1, const double* b1, const double* a2, const double* b2,
@@ -131,6 +154,75 @@ __global__ void k_pmg_x(int64_t n, double alpha, const double* ph, double omega,
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (dinv: ph, sh are D M^-1 p, D M^-1 s)
     if (i < n) x[i] += (alpha * ph[i] + (sh ? omega * sh[i] : 0.0)) * (dinv ? dinv[i] : 1.0);
 }
+// ---- flexible GMRES (the outer method): Gram-Schmidt against the basis V_0 .. V_{k-1} (vectors `stride` apart), twice per new vector ----
+// h_q = V_q . w for q < k, and w . w behind them: per-workgroup partials part[q * np + block] (fixed order: the same bits every run); eight basis vectors per
+// sweep over the workgroup's elements (w is read again per sweep: one extra vector per eight)
+__global__ __launch_bounds__(256) void k_pmg_mdot(int64_t n, const double* V, int64_t stride, int k, const double* w, double* part) {
+    __shared__ double red[9][4];
+    const int wv = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < k || c0 == 0; c0 += 8) {
+        double sq[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sw = 0;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+            const double wi = w[i];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (c0 + q < k) sq[q] += V[(int64_t)(c0 + q) * stride + i] * wi;
+            if (c0 == 0) sw += wi * wi;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const double r = wave_sum(sq[q]);
+            if ((threadIdx.x & 63) == 0) red[q][wv] = r;
+        }
+        sw = wave_sum(sw);
+        if ((threadIdx.x & 63) == 0) red[8][wv] = sw;
+        __syncthreads();
+        if (threadIdx.x < 8 && c0 + (int)threadIdx.x < k)
+            part[(size_t)(c0 + threadIdx.x) * gridDim.x + blockIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        if (threadIdx.x == 8 && c0 == 0) part[(size_t)k * gridDim.x + blockIdx.x] = red[8][0] + red[8][1] + red[8][2] + red[8][3];
+        __syncthreads();
+    }
+}
+// out[q] = sum of part[q * np ..] for q < cnt: one workgroup per value
+__global__ __launch_bounds__(256) void k_pmg_mreduce(const double* part, int np, double* out) {
+    __shared__ double red[5];
+    double s = 0;
+    for (int i = threadIdx.x; i < np; i += 256) s += part[(size_t)blockIdx.x * np + i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+// w -= sum_q h_q V_q, and the partials of what is left: |w|^2 to part[block]
+__global__ __launch_bounds__(256) void k_pmg_msub(int64_t n, const double* V, int64_t stride, int k, const double* h, double* w, double* part) {
+    __shared__ double hs[64];
+    __shared__ double red[4];
+    if ((int)threadIdx.x < k) hs[threadIdx.x] = h[threadIdx.x];
+    __syncthreads();
+    double sw = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double wi = w[i];
+        for (int q = 0; q < k; ++q) wi -= hs[q] * V[(int64_t)q * stride + i];
+        w[i] = wi, sw += wi * wi;
+    }
+    sw = wave_sum(sw);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sw;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void k_pmg_scale(int64_t n, const double* a, double f, double* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = f * a[i];
+}
+// x += (sum_q y_q Z_q) [* dinv: the Z_q are D M^-1 v_q]
+__global__ __launch_bounds__(256) void k_pmg_comb(int64_t n, const double* Z, int64_t stride, int k, const double* y, const double* dinv, double* x) {
+    __shared__ double ys[64];
+    if ((int)threadIdx.x < k) ys[threadIdx.x] = y[threadIdx.x];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0;
+    for (int q = 0; q < k; ++q) s += ys[q] * Z[(int64_t)q * stride + i];
+    x[i] += dinv ? s * dinv[i] : s;
+}
 // a coefficient field of the fine level -- nq2 samples per cell at the order-2 rule's nodes, `width` values each -- for the coarse level: every cell's
 // weighted mean at each of the nq1 nodes of the P1 rule (a preconditioner needs the coarse OPERATOR only approximately)
 __global__ void k_pmg_cell_mean(int64_t n_cells, int nq2, int nq1, int width, const double* qw2, const int32_t* fine_cell, const double* in, double* out) {
@@ -148,8 +240,8 @@ inline unsigned g1n(int64_t n) { return (unsigned)((n + 255) / 256); }
 void pmg_release(fdapde_ctx* c) {
     fdapde_ctx::Pmg& m = c->pmg;
     if (m.coarse) fdapde_ctx_destroy(m.coarse);
-    m.coarse = nullptr, m.ready = false, m.init_seen = -1;
-    m.fine_cell.release(), m.pa.release(), m.pb.release(), m.rt_ptr.release(), m.rt_idx.release(), m.rt_w.release(), m.dinv.release(), m.vec.release(), m.part.release(), m.dots.release();
+    m.coarse = nullptr, m.ready = false, m.init_seen = -1, m.omega = 0.0, m.omega_A = nullptr, m.fine_A = nullptr;
+    m.fine_cell.release(), m.pa.release(), m.pb.release(), m.rt_ptr.release(), m.rt_idx.release(), m.rt_w.release(), m.dinv.release(), m.vec.release(), m.part.release(), m.dots.release(), m.basis.release();
 }
 
 bool pmg_eligible(const fdapde_ctx* c) {
@@ -367,7 +459,8 @@ int pmg_run(fdapde_ctx* c, const double* A, const double* f_dev, const double* g
         else apply_K(in, out);
     };
     int coarse_iters = 0, coarse_calls = 0, coarse_fail = 0;   // (coarse_fail: coarse solves in a row that got nowhere)
-    auto apply_Minv = [&](const double* in, double* out) -> int {
+    // out = wv * (D^-1) vin + P A1^-1 P^T in (by_d: the same times D)
+    auto coarse_and_apply = [&](const double* in, const double* vin, double wv, int by_d, double* out) -> int {
         // (the fine stream first: the coarse context has a stream of its own)
         hipLaunchKernelGGL(k_pmg_restrict, dim3(g1n(16 * n1)), bv, 0, st, n1, m.rt_ptr.p, m.rt_idx.p, m.rt_w.p, use_bnd ? cc->bnd.p : (const uint8_t*)nullptr, in, cc->force.p);
         HIPCHK(c, hipStreamSynchronize(st));
@@ -380,9 +473,10 @@ int pmg_run(fdapde_ctx* c, const double* A, const double* f_dev, const double* g
         coarse_iters += ii.iters, ++coarse_calls;
         coarse_fail = (ii.converged || (std::isfinite(ii.relres) && ii.relres < 0.5)) ? 0 : coarse_fail + 1;   // (a solve that stopped at its budget but got somewhere is a correction)
         HIPCHK(c, hipStreamSynchronize(cc->stream));
-        hipLaunchKernelGGL(k_pmg_apply, gv, bv, 0, st, n2, m.pa.p, m.pb.p, c->bnd.p, use_bnd, m.dinv.p, in, cc->u.p, fb ? 1 : 0, out);
+        hipLaunchKernelGGL(k_pmg_apply, gv, bv, 0, st, n2, m.pa.p, m.pb.p, c->bnd.p, use_bnd, m.dinv.p, vin, cc->u.p, by_d, wv, out);
         return FDAPDE_OK;
     };
+    auto apply_Minv = [&](const double* in, double* out) -> int { return coarse_and_apply(in, in, 1.0, fb ? 1 : 0, out); };
     double h[3] = {0, 0, 0};
     auto dots = [&](const double* a0, const double* b0, const double* a1, const double* b1, const double* a2, const double* b2) -> int {
         hipLaunchKernelGGL(k_pmg_dots, dim3((unsigned)m.np), bv, 0, st, n2, a0, b0, a1, b1, a2, b2, m.part.p);
@@ -411,6 +505,174 @@ int pmg_run(fdapde_ctx* c, const double* A, const double* f_dev, const double* g
     double rr = rr_start, rho = 1.0, alpha = 1.0, omega = 1.0;
     int it = 0, fine_apps = 1;
     bool converged = rr_start <= rtol * rtol * bb, broke = false;
+    // The outer method: FLEXIBLE GMRES (right-preconditioned: A Z_k = V_{k+1} H_k with Z_j = M^-1 v_j kept, so M^-1 may be a different operator every time
+    // it is applied -- and it is: the coarse systems are solved to a loose tolerance by a Krylov method).  One M^-1 and one operator application per
+    // iteration, the residual norm from the Givens recurrence; 36 - 37 iterations on C5's operator whatever the mesh and whether the coarse solves stop at
+    // 1e-1, 1e-2 or are exact (tools/c5_fgmres_proto.py), where BiCGStab -- which assumes ONE preconditioner -- takes 50 - 58 applications at 1e-2, 64 - 90
+    // at 1e-1, and its count moves by +-5 with the last bits of the data (tools/pmg_spread_probe.py).  Gram-Schmidt twice per vector (the Krylov basis of a
+    // solve to 1e-10 is ill-conditioned by then); restart after `mk` vectors (memory: 2 mk + 1 vectors).
+    const bool fgmres = c->pmg_outer == 0;
+    int mk = 0;
+    if (fgmres) {
+        mk = (int)std::min<int64_t>(50, std::max<int64_t>(5, (int64_t)(16e9 / (16.0 * (double)n2))));   // (at most ~16 GB of basis)
+        mk = std::min(mk, std::max(maxit, 1));
+        if (m.basis.n < (size_t)(2 * mk + 1) * (size_t)n2) {
+            m.basis.release();
+            if (m.basis.alloc((size_t)(2 * mk + 1) * (size_t)n2) != hipSuccess) {
+                (void)hipGetLastError();
+                m.basis.release();
+                mk = 0;   // (no room for a basis: BiCGStab below)
+            }
+        }
+        if (mk > 0 && (m.part.n < (size_t)(mk + 2) * (size_t)m.np || m.dots.n < (size_t)(mk + 4))) {
+            HIPCHK(c, m.part.alloc((size_t)(mk + 2) * (size_t)m.np));
+            HIPCHK(c, m.dots.alloc((size_t)(mk + 4)));
+        }
+    }
+    if (fgmres && mk > 0) {
+        // The preconditioner of an iteration: a V(1,1) CYCLE -- damped Jacobi, coarse correction, damped Jacobi (17 - 18 iterations on C5's operator where the
+        // additive form D^-1 + P A1^-1 P^T takes 36; tools/c5_fgmres_variants_proto.py) -- at three fine operator applications instead of one, which is the
+        // cheap part: half the coarse solves, a quarter of the Gram-Schmidt traffic.  Damping 1.5 / lambda_max(D^-1 A), lambda_max by 15 power iterations
+        // once per matrix (undamped Jacobi is no smoother on an order-2 space: lambda_max > 2).  Everything in D-scaled variables z' = D z, so that every
+        // operator application is the blocked-ELL kernel's A D^-1 (without that layout: D^-1 as a pass of its own in front of the CSR kernel).
+        const bool smooth = c->pmg_smooth != 0;
+        const bool primed = fb || smooth;
+        double* tb = p;    // (BiCGStab's vectors are free here)
+        double* rb = s;
+        auto KD = [&](const double* in, double* out) {   // out = K D^-1 in
+            if (fb) launch_spmv_blocked(c, fv, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+            else {
+                hipLaunchKernelGGL(k_pmg_mulv, gv, bv, 0, st, n2, m.dinv.p, in, ph);
+                apply_K(ph, out);
+            }
+        };
+        double om = 0.0;
+        if (smooth) {
+            if (!(m.omega > 0.0 && m.omega_A == A && m.omega_key == coarse_key && m.omega_bnd == fv && m.omega_extra == extra_reaction)) {
+                hipLaunchKernelGGL(k_pmg_hashvec, gv, bv, 0, st, n2, c->bnd.p, use_bnd, tb);
+                double lam = 0.0;
+                for (int pi = 0; pi < 15; ++pi) {
+                    KD(tb, rb);
+                    if (int rc = dots(tb, tb, rb, rb, nullptr, nullptr)) return rc;
+                    if (!(h[0] > 0.0) || !std::isfinite(h[1])) break;
+                    lam = std::sqrt(h[1] / h[0]);
+                    if (!(h[1] > 0.0)) break;
+                    hipLaunchKernelGGL(k_pmg_scale, gv, bv, 0, st, n2, rb, 1.0 / std::sqrt(h[1]), tb);
+                }
+                m.omega = lam > 0.0 && std::isfinite(lam) ? 1.5 / lam : 0.0;
+                m.omega_A = A, m.omega_key = coarse_key, m.omega_bnd = fv, m.omega_extra = extra_reaction;
+                if (std::getenv("FDAPDE_DEBUG_SETUP")) std::fprintf(stderr, "pmg: lambda_max(D^-1 A) ~ %.3f, damping %.3f\n", lam, m.omega);
+            }
+            om = m.omega;
+        }
+        const bool cycle = smooth && om > 0.0;
+        const double* comb_dinv = (fb || cycle) ? m.dinv.p : nullptr;
+        (void)primed;
+        double* V = m.basis.p;
+        double* Z = V + (size_t)(mk + 1) * (size_t)n2;
+        std::vector<double> H((size_t)(mk + 1) * mk, 0.0), cs((size_t)mk), sn((size_t)mk), gg((size_t)mk + 1), hj((size_t)mk + 4), yy((size_t)mk);
+        auto Hat = [&](int i, int j) -> double& { return H[(size_t)j * (mk + 1) + i]; };
+        const unsigned gnp = (unsigned)m.np;
+        while (!converged && !broke && it < maxit) {
+            // (r holds the residual of x, rr its square)
+            const double beta = std::sqrt(rr);
+            if (!(beta > 0.0) || !std::isfinite(beta)) {
+                broke = !std::isfinite(beta);
+                converged = !broke;
+                break;
+            }
+            hipLaunchKernelGGL(k_pmg_scale, gv, bv, 0, st, n2, r, 1.0 / beta, V);
+            std::fill(gg.begin(), gg.end(), 0.0);
+            gg[0] = beta;
+            int k = 0;   // columns of this cycle
+            bool cycle_done = false;
+            while (!cycle_done && k < mk && it < maxit) {
+                const int j = k;
+                double* zj = Z + (size_t)j * (size_t)n2;
+                double* w = V + (size_t)(j + 1) * (size_t)n2;
+                const double* vj = V + (size_t)j * (size_t)n2;
+                if (cycle) {
+                    KD(vj, tb);                                                                     // A z1, z1' = om v
+                    hipLaunchKernelGGL(k_pmg_lin, gv, bv, 0, st, n2, vj, om, tb, rb);               // r1 = v - om A D^-1 v
+                    if (int rc = coarse_and_apply(rb, vj, om, 1, zj)) return rc;                    // z2' = om v + D P A1^-1 P^T r1
+                } else if (int rc = apply_Minv(vj, zj))
+                    return rc;
+                if (coarse_fail >= 4) {
+                    broke = true;
+                    break;
+                }
+                if (cycle) {
+                    KD(zj, tb);
+                    hipLaunchKernelGGL(k_pmg_post, gv, bv, 0, st, n2, vj, tb, om, zj, rb);          // r2 = v - A z2, z3' = z2' + om r2
+                    KD(rb, tb);
+                    hipLaunchKernelGGL(k_pmg_wfin, gv, bv, 0, st, n2, vj, rb, tb, om, w);           // w = A z3 = (v - r2) + om A D^-1 r2
+                    fine_apps += 3;
+                } else {
+                    apply_K_dir(zj, w);
+                    ++fine_apps;
+                }
+                // Gram-Schmidt, twice: h = V^T w, w -= V h, then the same on what is left (its coefficients add to h)
+                double wnorm2 = 0;
+                for (int pass = 0; pass < 2; ++pass) {
+                    hipLaunchKernelGGL(k_pmg_mdot, dim3(gnp), bv, 0, st, n2, V, n2, j + 1, w, m.part.p);
+                    hipLaunchKernelGGL(k_pmg_mreduce, dim3((unsigned)(j + 2)), bv, 0, st, m.part.p, m.np, m.dots.p);
+                    hipLaunchKernelGGL(k_pmg_msub, dim3(gnp), bv, 0, st, n2, V, n2, j + 1, m.dots.p, w, m.part.p);
+                    hipLaunchKernelGGL(k_pmg_mreduce, dim3(1), bv, 0, st, m.part.p, m.np, m.dots.p + (j + 2));
+                    HIPCHK(c, hipMemcpyAsync(hj.data(), m.dots.p, sizeof(double) * (size_t)(j + 3), hipMemcpyDeviceToHost, st));
+                    HIPCHK(c, hipStreamSynchronize(st));
+                    for (int i = 0; i <= j; ++i) Hat(i, j) = pass == 0 ? hj[(size_t)i] : Hat(i, j) + hj[(size_t)i];
+                    wnorm2 = hj[(size_t)j + 2];
+                }
+                const double hn = std::sqrt(wnorm2);
+                if (!std::isfinite(hn)) {
+                    broke = true;
+                    break;
+                }
+                Hat(j + 1, j) = hn;
+                for (int i = 0; i < j; ++i) {
+                    const double a0 = Hat(i, j), a1 = Hat(i + 1, j);
+                    Hat(i, j) = cs[(size_t)i] * a0 + sn[(size_t)i] * a1, Hat(i + 1, j) = -sn[(size_t)i] * a0 + cs[(size_t)i] * a1;
+                }
+                const double d = std::hypot(Hat(j, j), Hat(j + 1, j));
+                if (!(d > 0.0)) {   // (a zero column: M^-1 v_j = 0 -- nothing this basis can do)
+                    broke = true;
+                    break;
+                }
+                cs[(size_t)j] = Hat(j, j) / d, sn[(size_t)j] = Hat(j + 1, j) / d;
+                Hat(j, j) = d, Hat(j + 1, j) = 0.0;
+                gg[(size_t)j + 1] = -sn[(size_t)j] * gg[(size_t)j], gg[(size_t)j] = cs[(size_t)j] * gg[(size_t)j];
+                ++k, ++it;
+                rr = gg[(size_t)k] * gg[(size_t)k];
+                if (rr <= rtol * rtol * bb || !(hn > 1e-300)) cycle_done = true;   // (hn = 0: the exact solution lies in this basis)
+                else hipLaunchKernelGGL(k_pmg_scale, gv, bv, 0, st, n2, w, 1.0 / hn, w);
+            }
+            if (k > 0) {   // x += Z y, H y = g (upper triangular after the rotations)
+                for (int i = k - 1; i >= 0; --i) {
+                    double sacc = gg[(size_t)i];
+                    for (int q = i + 1; q < k; ++q) sacc -= Hat(i, q) * yy[(size_t)q];
+                    yy[(size_t)i] = sacc / Hat(i, i);
+                }
+                HIPCHK(c, hipMemcpyAsync(m.dots.p, yy.data(), sizeof(double) * (size_t)k, hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(k_pmg_comb, gv, bv, 0, st, n2, Z, n2, k, m.dots.p, comb_dinv, x);
+                HIPCHK(c, hipStreamSynchronize(st));   // (yy is the host's)
+            }
+            if (broke) break;
+            // the residual of the new iterate, computed (it starts the next cycle, and the recurrence's word is not taken for convergence)
+            apply_K(x, v);
+            hipLaunchKernelGGL(k_pmg_residual, gv, bv, 0, st, n2, c->bnd.p, use_bnd, f_dev, g_dev, v, r);
+            if (int rc = dots(r, r, nullptr, nullptr, nullptr, nullptr)) return rc;
+            rr = h[0];
+            if (!std::isfinite(rr)) {
+                broke = true;
+                break;
+            }
+            converged = rr <= rtol * rtol * bb;
+            if (!converged && k == 0) {
+                broke = true;
+                break;
+            }
+        }
+    } else
     while (!converged && it < maxit) {
         if (int rc = dots(r0, r, nullptr, nullptr, nullptr, nullptr)) return rc;
         const double rho_new = h[0];

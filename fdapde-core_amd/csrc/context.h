@@ -482,13 +482,13 @@ struct fdapde_ctx {
         SolveState coarse_ss;            // the coarse context's solver, prepared ONCE per coarse operator (coarse_prepare / coarse_solve, eng_solve.hip)
     } pmg;
     int64_t init_count = 0;       // fdapde_init calls so far (who caches something derived from the assembled matrices compares)
-    double pmg_inner_rtol = 1e-2; // knob pmg_inner_tol_exp: the coarse solves stop at 10^-exp
+    double pmg_inner_rtol = 1e-1; // knob pmg_inner_tol_exp: the coarse solves stop at 10^-exp (flexible GMRES outside: 1e-1 costs no outer iteration over 1e-2)
     int pmg_inner_maxit = 1000;   // knob (a 2-D P1 level of 640 k DOFs needs ~400 CG iterations to 1e-2)
     int pmg_auto = 1;             // knob: 1 = the open method takes the two-level solver for large order-2 systems it is eligible for ...
     int pmg_outer = 0;            // knob: the outer method of the two-level solver: 0 = flexible GMRES, 1 = BiCGStab (round 6's first form)
     int pmg_smooth = 1;           // knob: 1 = the preconditioner of the flexible GMRES is a V(1,1) cycle (damped Jacobi around the coarse correction), 0 = the additive form
     int pmg_blocked = 1;          // knob: 1 = the fine operator of the two-level solver through the blocked-ELL SpMV (0: the CSR kernel on the raw matrix)
-    int64_t pmg_auto_rows = 1000000;   // knob: ... of at least that many DOFs
+    int64_t pmg_auto_rows = 300000;    // knob: ... of at least that many DOFs (where it starts to win: 3-D 185 k 9.3 against 8.6 ms, 389 k 13 against 21; 2-D symmetric 315 k 27 against 25, 642 k 38 against 59)
     // the dense inverse of a small system (kernels_dense.h / eng_dense.hip): the factor-once handle's, the parabolic stepper's, the open method's direct stage
     struct Dense {
         DBuf<double> X;             // n x n, internal DOF order

@@ -458,7 +458,7 @@ int pmg_run(fdapde_ctx* c, const double* A, const double* f_dev, const double* g
         if (fb) launch_spmv_blocked(c, fv, in, out, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
         else apply_K(in, out);
     };
-    int coarse_iters = 0, coarse_calls = 0, coarse_fail = 0;   // (coarse_fail: coarse solves in a row that got nowhere)
+    int coarse_iters = 0, coarse_calls = 0, coarse_multi = 0, coarse_fail = 0;   // (coarse_fail: coarse solves in a row that got nowhere)
     // out = wv * (D^-1) vin + P A1^-1 P^T in (by_d: the same times D)
     auto coarse_and_apply = [&](const double* in, const double* vin, double wv, int by_d, double* out) -> int {
         // (the fine stream first: the coarse context has a stream of its own)
@@ -470,7 +470,7 @@ int pmg_run(fdapde_ctx* c, const double* A, const double* f_dev, const double* g
             c->err = "FDAPDE_SOLVER_PMG (coarse level): " + cc->err;
             return rc;
         }
-        coarse_iters += ii.iters, ++coarse_calls;
+        coarse_iters += ii.iters, ++coarse_calls, coarse_multi += ii.persistent ? 0 : 1;
         coarse_fail = (ii.converged || (std::isfinite(ii.relres) && ii.relres < 0.5)) ? 0 : coarse_fail + 1;   // (a solve that stopped at its budget but got somewhere is a correction)
         HIPCHK(c, hipStreamSynchronize(cc->stream));
         hipLaunchKernelGGL(k_pmg_apply, gv, bv, 0, st, n2, m.pa.p, m.pb.p, c->bnd.p, use_bnd, m.dinv.p, vin, cc->u.p, by_d, wv, out);
@@ -737,8 +737,8 @@ int pmg_run(fdapde_ctx* c, const double* A, const double* f_dev, const double* g
     c->info.t_solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     c->info.persistent = 0;
     if (std::getenv("FDAPDE_DEBUG_SETUP"))
-        std::fprintf(stderr, "pmg: %d outer iterations, %d fine applications, %d coarse solves with %d iterations, true relres %.2e, %.2f ms\n", it, fine_apps, coarse_calls,
-                     coarse_iters, true_rel, c->info.t_solve_ms);
+        std::fprintf(stderr, "pmg: %d outer iterations, %d fine applications, %d coarse solves with %d iterations (%d of them not as one launch), true relres %.2e, %.2f ms\n", it,
+                     fine_apps, coarse_calls, coarse_iters, coarse_multi, true_rel, c->info.t_solve_ms);
     c->pmg.last_coarse_iters = coarse_iters, c->pmg.last_coarse_calls = coarse_calls;
     if (!converged) {
         c->err = coarse_fail >= 4 ? "FDAPDE_SOLVER_PMG: the coarse level's solves do not converge" : broke ? "FDAPDE_SOLVER_PMG: BiCGStab broke down" : "maxit reached";

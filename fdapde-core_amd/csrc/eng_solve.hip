@@ -1085,9 +1085,9 @@ int e_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
         }
         return FDAPDE_OK;
     }
-    // The open method on a LARGE order-2 system it qualifies for: the two-level solver first (eng_pmg.hip: ~23 iterations whatever the mesh size, where the
-    // Jacobi-preconditioned stages below need O(1 / h) -- C5, 5.36 M DOFs: 133 ms against 598; the two meet near 1 M DOFs: 705 k 36 against 27 ms, 2.1 M 68
-    // against 181).  Whatever it does not solve falls through to the stages below.
+    // The open method on a LARGE order-2 system it qualifies for: the two-level solver first (eng_pmg.hip: ~19 iterations whatever the mesh size, where the
+    // Jacobi-preconditioned stages below need O(1 / h) -- C5, 5.36 M DOFs: 64 ms against 617; the two meet near 200 - 300 k DOFs: 3-D 185 k 9.3 against 8.6 ms,
+    // 389 k 13 against 21; 2-D, symmetric, 315 k 27 against 25).  Whatever it does not solve falls through to the stages below.
     if ((!opt || opt->method == FDAPDE_SOLVER_AUTO) && c->pmg_auto && n >= c->pmg_auto_rows && pmg_eligible(c)) {
         fdapde_options po{};
         po.method = FDAPDE_SOLVER_PMG, po.rtol = rtol, po.maxit = (opt && opt->maxit > 0) ? std::min(opt->maxit, 60) : 60;   // (it converges in two dozen iterations or not at all)

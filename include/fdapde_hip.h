@@ -83,12 +83,14 @@ enum { FDAPDE_SOLVER_AUTO = 0, FDAPDE_SOLVER_CG = 1, FDAPDE_SOLVER_BICGSTAB = 2,
                                   Asked for BY NAME it runs at once -- fdapde_solve: no Krylov stage in front; fdapde_lin_solve: the inverse is built by this call;
                                   fdapde_solve_parabolic: K inverted whatever the number of steps -- and nothing stands behind it: a matrix singular to working
                                   precision is FDAPDE_ENOCONV (success = false, like the reference's LU), a system it does not take FDAPDE_EUNSUPPORTED. */,
-       FDAPDE_SOLVER_PMG = 7 /* order-2 spaces, one-GPU contexts: BiCGStab with a TWO-LEVEL preconditioner -- the fine
-                                level's Jacobi sweep + a correction from the P1 space of the same mesh (its own context inside this one: the same operator terms,
-                                coefficient fields as their cell means; its systems solved
-                                to 1e-2 by the open method) -- 20 - 25 iterations whatever the mesh size where Jacobi-BiCGStab needs O(1 / h).  info.iters
-                                counts its iterations (two operator applications and two coarse solves each).  fdapde_solve and fdapde_solve_parabolic (the factor-once
-                                handle keeps the Jacobi-preconditioned stages); the open method takes it from `pmg_auto_rows` (1 M) DOFs on. */ };
+       FDAPDE_SOLVER_PMG = 7 /* order-2 spaces, one-GPU contexts: flexible GMRES with a TWO-LEVEL preconditioner -- a V(1,1) cycle:
+                                damped Jacobi on the fine level, a correction from the P1 space of the same mesh (its own context inside this one: the same operator
+                                terms, coefficient fields as their cell means; its systems solved to 1e-1 by the open method), damped Jacobi again -- 17 - 20
+                                iterations whatever the mesh size where Jacobi-BiCGStab needs O(1 / h).  info.iters counts its iterations (three operator
+                                applications and one coarse solve each), info.relres is the true relative residual of what is handed out.  fdapde_solve and
+                                fdapde_solve_parabolic (the factor-once handle keeps the Jacobi-preconditioned stages); the open method takes it from
+                                `pmg_auto_rows` (300 k) DOFs on.  Knobs: pmg_outer 1 = BiCGStab around the additive form D^-1 + P A1^-1 P^T (the first
+                                form), pmg_smooth 0 = flexible GMRES around that additive form, pmg_blocked 0 = the fine operator through the CSR kernel. */ };
 /* ROWS: row-owner sweep (default; no atomics, bitwise reproducible).  The others are element-wise scatter forms kept as measured
  * alternatives and cross-checks: ATOMIC / COLOURED = lane per (cell, row) with a slot search, fp64 atomics / one launch per colour;
  * PARTITIONED = one workgroup per cell partition, colours walked inside the workgroup, atomics only on rows shared between

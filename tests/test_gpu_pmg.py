@@ -139,7 +139,7 @@ def test_what_it_does_not_take_and_when_the_open_method_takes_it(env):
     qn = c.quadrature_nodes()
     c.set_forcing(np.ones(qn.shape[0]))
     c.set_dirichlet(np.zeros(nd))
-    # the open method takes the two-level solver from `pmg_auto_rows` DOFs on (default 1 M: where it starts to win)
+    # the open method takes the two-level solver from `pmg_auto_rows` DOFs on (default 300 k: where it starts to win)
     c.set_operator(-capi.laplacian() + capi.reaction(1.0))
     c.init()
     assert c.solve().method_used != capi.SOLVER_PMG

@@ -171,6 +171,33 @@ TEST(fem_pde_test, advection_diffusion_isotropic_order2) {
     EXPECT_TRUE(pde_.success());
     EXPECT_TRUE(l2_error(pde_, [&](std::array<double, 3> x) { return ad.solution(x); }) < DOUBLE_TOLERANCE);
 }
+// the same case through FDAPDE_SOLVER_PMG by name (csrc/eng_pmg.hip: the P1 space of the mesh as the coarse level of a V(1,1) cycle inside a flexible GMRES -- what
+// the open method takes for order-2 systems from 300 k DOFs on): the reference's gate (fem_pde_test.cpp:212) and the open method's solution
+TEST(fem_pde_test, advection_diffusion_order2_two_level_solver_by_name) {
+    AdvDiff ad;
+    ScalarField<2> forcing([ad](const std::array<double, 2>& x) -> double { return ad.forcing(x[1]); });
+    std::array<double, 2> beta_ {-ad.alpha_, 0.};
+    auto L = -laplacian<FEM_HIP>() + advection<FEM_HIP>(beta_);
+    FixtureMesh<2, 2> unit_square("unit_square");
+    PDE<Triangulation<2, 2>, decltype(L), ScalarField<2>, FEM_HIP, fem_order<2>> pde_(unit_square.mesh, L, forcing);
+    pde_.set_dirichlet_bc(DMatrix<double>::Zero(pde_.n_dofs(), 1));
+    pde_.init();
+    pde_.solve();
+    EXPECT_TRUE(pde_.success());
+    const DMatrix<double> open_method = pde_.solution();
+    pde_.solver_options().method = FDAPDE_SOLVER_PMG;
+    pde_.solve();
+    EXPECT_TRUE(pde_.success());
+    EXPECT_TRUE(pde_.info().method_used == FDAPDE_SOLVER_PMG);
+    EXPECT_TRUE(pde_.info().iters > 0 && pde_.info().iters <= 30);
+    double worst = 0, scale = 0;
+    for (int64_t i = 0; i < open_method.rows(); ++i) {
+        worst = std::max(worst, std::abs(open_method(i) - pde_.solution()(i)));
+        scale = std::max(scale, std::abs(open_method(i)));
+    }
+    EXPECT_TRUE(worst <= 1e-8 * scale);
+    EXPECT_TRUE(l2_error(pde_, [&](std::array<double, 3> x) { return ad.solution(x); }) < DOUBLE_TOLERANCE);
+}
 
 // ---- the mesh sharded over several devices BEHIND the same interface (include/fdapde_hip.h fdapde_ctx_create_multi): the reference's cases again
 //      with a device list -- "devices" all GPU 0 here, its CUs shared out --, against the analytic solutions at the reference's gates and against
@@ -850,6 +877,7 @@ int main(int argc, char** argv) {
     RUN(fem_pde_test, advection_diffusion_isotropic_order1);
     RUN(fem_pde_test, advection_diffusion_direct_solve_by_name);
     RUN(fem_pde_test, advection_diffusion_isotropic_order2);
+    RUN(fem_pde_test, advection_diffusion_order2_two_level_solver_by_name);
     RUN(fem_operators_test, laplacian_order_2_through_stiff);
     RUN(sharded_test, laplacian_order1);
     RUN(sharded_test, laplacian_order2_callable_force);

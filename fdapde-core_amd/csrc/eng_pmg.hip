@@ -514,7 +514,7 @@ int pmg_run(fdapde_ctx* c, const double* A, const double* f_dev, const double* g
     const bool fgmres = c->pmg_outer == 0;
     int mk = 0;
     if (fgmres) {
-        mk = (int)std::min<int64_t>(50, std::max<int64_t>(5, (int64_t)(16e9 / (16.0 * (double)n2))));   // (at most ~16 GB of basis)
+        mk = (int)std::min<int64_t>(std::max(2, std::min(c->pmg_restart, 50)), std::max<int64_t>(5, (int64_t)(16e9 / (16.0 * (double)n2))));   // (at most ~16 GB of basis)
         mk = std::min(mk, std::max(maxit, 1));
         if (m.basis.n < (size_t)(2 * mk + 1) * (size_t)n2) {
             m.basis.release();
@@ -556,6 +556,7 @@ int pmg_run(fdapde_ctx* c, const double* A, const double* f_dev, const double* g
                     if (int rc = dots(tb, tb, rb, rb, nullptr, nullptr)) return rc;
                     if (!(h[0] > 0.0) || !std::isfinite(h[1])) break;
                     lam = std::sqrt(h[1] / h[0]);
+                    if (std::getenv("FDAPDE_DEBUG_PMG_POWER")) std::fprintf(stderr, "pmg: power iteration %d: %.4f\n", pi, lam);
                     if (!(h[1] > 0.0)) break;
                     hipLaunchKernelGGL(k_pmg_scale, gv, bv, 0, st, n2, rb, 1.0 / std::sqrt(h[1]), tb);
                 }

@@ -308,3 +308,28 @@ def test_partial_boundary_masks_keep_the_coarse_space_inside_the_fine_one(env, d
             assert info.iters <= 45, (with_data, blocked, info.iters)
             assert np.linalg.norm(u - ref) <= 1e-8 * np.linalg.norm(ref)
             c.close()
+
+
+def test_restarted_cycles_and_the_earlier_forms_reach_the_same_solution(env):
+    """The flexible GMRES restarted every 5 vectors (knob pmg_restart: the path a hard system takes after 50), the additive preconditioner inside it (pmg_smooth 0)
+    and BiCGStab around that (pmg_outer 1: the round's first form): all of them against SuperLU, and two runs of the default form bit for bit."""
+    import scipy.sparse.linalg as spl
+
+    capi, meshgen, workloads = env
+    c, nd, _, _ = _problem(capi, meshgen, 3, 9, workloads.c5_operator(capi), "data")
+    ref = None
+    its = {}
+    for name, knobs in (("default", {}), ("restart5", {"pmg_restart": 5}), ("additive", {"pmg_smooth": 0}), ("bicgstab", {"pmg_outer": 1, "pmg_inner_tol_exp": 2})):
+        for k, v in {"pmg_restart": 50, "pmg_smooth": 1, "pmg_outer": 0, "pmg_inner_tol_exp": 1, **knobs}.items():
+            c.tune(k, v)
+        info = c.solve(method=capi.SOLVER_PMG, rtol=1e-11)
+        u = c.solution()
+        if ref is None:
+            ref = spl.spsolve(_csr(c, capi, nd).tocsc(), c.force())
+            info2 = c.solve(method=capi.SOLVER_PMG, rtol=1e-11)
+            assert np.array_equal(u, c.solution()) and info2.iters == info.iters
+        assert info.converged == 1 and info.method_used == capi.SOLVER_PMG, name
+        assert np.linalg.norm(u - ref) <= 1e-8 * np.linalg.norm(ref), name
+        its[name] = info.iters
+    assert its["default"] <= 25 and its["default"] <= its["restart5"] <= 80 and its["additive"] > its["default"], its
+    c.close()

@@ -432,6 +432,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "pmg_auto" && (value == 0 || value == 1)) c->pmg_auto = value;
     else if (k == "pmg_blocked" && (value == 0 || value == 1)) c->pmg_blocked = value;
     else if (k == "pmg_smooth" && (value == 0 || value == 1)) c->pmg_smooth = value;
+    else if (k == "pmg_setup_check" && (value == 0 || value == 1)) c->pmg_setup_check = value;
     else if (k == "pmg_restart" && value >= 2 && value <= 50) c->pmg_restart = (int)value;
     else if (k == "pmg_outer" && (value == 0 || value == 1)) c->pmg_outer = value;
     else if (k == "pmg_auto_rows" && value >= 0) c->pmg_auto_rows = value;

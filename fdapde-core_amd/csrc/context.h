@@ -486,6 +486,7 @@ struct fdapde_ctx {
     int pmg_inner_maxit = 1000;   // knob (a 2-D P1 level of 640 k DOFs needs ~400 CG iterations to 1e-2)
     int pmg_auto = 1;             // knob: 1 = the open method takes the two-level solver for large order-2 systems it is eligible for ...
     int pmg_outer = 0;            // knob: the outer method of the two-level solver: 0 = flexible GMRES, 1 = BiCGStab (round 6's first form)
+    int pmg_setup_check = 0;      // knob: 1 = the coarse level's transfer tables are also built by the host loops of the first version and compared
     int pmg_restart = 50;         // knob: vectors per cycle of the flexible GMRES (2 .. 50; the basis is also held under ~16 GB)
     int pmg_smooth = 1;           // knob: 1 = the preconditioner of the flexible GMRES is a V(1,1) cycle (damped Jacobi around the coarse correction), 0 = the additive form
     int pmg_blocked = 1;          // knob: 1 = the fine operator of the two-level solver through the blocked-ELL SpMV (0: the CSR kernel on the raw matrix)

@@ -20,6 +20,8 @@
 #include <cstring>
 #include <vector>
 
+#include <hipcub/hipcub.hpp>
+
 #include "context.h"
 #include "engine.h"
 #include "kernels_reduce.h"
@@ -251,13 +253,120 @@ bool pmg_eligible(const fdapde_ctx* c) {
     return !c->op.empty();
 }
 
+// ---- the transfer tables, built on the device (the host loops they replace took 0.67 s of a 0.9 s first call at C5's size: 40 M scattered accesses) ----
+struct PmgEdges {
+    int a[6], b[6];
+};
+__global__ void k_pmg_inv_perm(int64_t n, const int32_t* i2e, int32_t* e2i) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) e2i[i2e[i]] = (int32_t)i;
+}
+__global__ void k_pmg_fine_cell(int64_t n, const int32_t* i2e1, const int32_t* e2i2, int32_t* fine_cell) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fine_cell[i] = e2i2[i2e1[i]];
+}
+// one thread per coarse cell: local DOFs 0 .. M of a P2 cell are its vertices in the cell's vertex order -- the P1 cell's local DOFs --, local DOF M + 1 + k sits
+// on the edge of the local vertices (ed.a[k], ed.b[k]).  pass 0: pa / pb and the vertices' boundary flags (every cell of a DOF writes the same values); pass 1: a
+// constrained edge DOF constrains both of its end nodes on the coarse level
+__global__ void k_pmg_transfer(int64_t n_cells, int nv, int nb2, PmgEdges ed, const int32_t* fine_cell, const int32_t* cd1, const int32_t* cd2, const uint8_t* bnd2,
+                               int32_t* pa, int32_t* pb, uint8_t* bnd1, int pass) {
+    const int64_t c1 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c1 >= n_cells) return;
+    const int32_t* d1 = cd1 + c1 * nv;
+    const int32_t* d2 = cd2 + (int64_t)fine_cell[c1] * nb2;
+    if (pass == 0) {
+        for (int k = 0; k < nv; ++k) pa[d2[k]] = d1[k], bnd1[d1[k]] = bnd2[d2[k]];
+        for (int k = nv; k < nb2; ++k) {   // (the cells sharing an edge see it in either direction: the pair goes in as (smaller, larger) -- the same words from all)
+            const int32_t x = d1[ed.a[k - nv]], y = d1[ed.b[k - nv]];
+            pa[d2[k]] = x < y ? x : y, pb[d2[k]] = x < y ? y : x;
+        }
+    } else {
+        for (int k = nv; k < nb2; ++k)
+            if (bnd2[d2[k]]) bnd1[d1[ed.a[k - nv]]] = 1, bnd1[d1[ed.b[k - nv]]] = 1;
+    }
+}
+// (coarse DOF << 32 | fine DOF) of every entry of P, the slot of a vertex DOF's missing second entry sorts behind everything; entries per coarse DOF counted
+__global__ void k_pmg_keys(int64_t n2, const int32_t* pa, const int32_t* pb, unsigned long long* keys, int32_t* count, int32_t* bad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n2) return;
+    const int32_t a = pa[i], b = pb[i];
+    if (a < 0) {
+        atomicOr(bad, 1);
+        keys[2 * i] = keys[2 * i + 1] = ~0ull;
+        return;
+    }
+    keys[2 * i] = ((unsigned long long)(uint32_t)a << 32) | (uint32_t)i, atomicAdd(&count[a], 1);
+    if (b >= 0) keys[2 * i + 1] = ((unsigned long long)(uint32_t)b << 32) | (uint32_t)i, atomicAdd(&count[b], 1);
+    else keys[2 * i + 1] = ~0ull;
+}
+__global__ void k_pmg_rt_fill(int64_t n, const unsigned long long* keys, const int32_t* pb, int32_t* idx, double* w) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int32_t i = (int32_t)(keys[e] & 0xFFFFFFFFull);
+    idx[e] = i, w[e] = pb[i] >= 0 ? 0.5 : 1.0;
+}
+__global__ void k_pmg_to_reference(int64_t n, const int32_t* i2e, const uint8_t* in, uint8_t* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i2e[i]] = in[i];
+}
+
+// the same tables by the host loops of the first version (knob pmg_setup_check: both are built and compared)
+static int pmg_tables_host(fdapde_ctx* c, fdapde_ctx* cc, std::vector<int32_t>& fine_cell, std::vector<int32_t>& pa, std::vector<int32_t>& pb, std::vector<uint8_t>& bnd1,
+                           std::vector<int32_t>& ptr, std::vector<int32_t>& idx, std::vector<double>& w) {
+    if (int rc = ensure_host(c, kHostDofs | kHostPerm)) return rc;
+    if (int rc = ensure_host(cc, kHostDofs | kHostPerm)) return rc;
+    const HostSpace &h2 = c->hs, &h1 = cc->hs;
+    const int nv = h2.M + 1, nb2 = h2.nb;
+    const int64_t n2 = h2.n_dofs, n1 = h1.n_dofs;
+    fine_cell.assign((size_t)h1.n_cells, 0);
+    std::vector<int32_t> e2i2((size_t)h2.n_cells);
+    for (int64_t ci = 0; ci < h2.n_cells; ++ci) e2i2[(size_t)h2.cell_i2e[(size_t)ci]] = (int32_t)ci;
+    for (int64_t ci = 0; ci < h1.n_cells; ++ci) fine_cell[(size_t)ci] = e2i2[(size_t)h1.cell_i2e[(size_t)ci]];
+    pa.assign((size_t)n2, -1), pb.assign((size_t)n2, -1), bnd1.assign((size_t)n1, 0);
+    for (int pass = 0; pass < 2; ++pass)
+        for (int64_t e = 0; e < h2.n_cells; ++e) {
+            const int32_t* d2 = &h2.dofs[(size_t)e * nb2];
+            const int32_t* d1 = &h1.dofs[(size_t)e * nv];
+            if (pass == 0)
+                for (int k = 0; k < nv; ++k) pa[(size_t)h2.dof_e2i[(size_t)d2[k]]] = h1.dof_e2i[(size_t)d1[k]], bnd1[(size_t)d1[k]] = h2.dof_bnd[(size_t)d2[k]];
+            for (int k = nv; k < nb2; ++k) {
+                const int* ed = h2.M == 2 ? kEdge2[k - nv] : kEdge3[k - nv];
+                if (pass == 0) {
+                    const size_t fi = (size_t)h2.dof_e2i[(size_t)d2[k]];
+                    const int32_t x = h1.dof_e2i[(size_t)d1[ed[0]]], y = h1.dof_e2i[(size_t)d1[ed[1]]];
+                    pa[fi] = std::min(x, y), pb[fi] = std::max(x, y);
+                } else if (h2.dof_bnd[(size_t)d2[k]])
+                    bnd1[(size_t)d1[ed[0]]] = 1, bnd1[(size_t)d1[ed[1]]] = 1;
+            }
+        }
+    ptr.assign((size_t)n1 + 1, 0);
+    for (int64_t i = 0; i < n2; ++i) {
+        if (pa[(size_t)i] < 0) return fail(c, FDAPDE_EHIP, "a P2 DOF that no cell's table names");
+        ++ptr[(size_t)pa[(size_t)i] + 1];
+        if (pb[(size_t)i] >= 0) ++ptr[(size_t)pb[(size_t)i] + 1];
+    }
+    for (int64_t a = 0; a < n1; ++a) ptr[(size_t)a + 1] += ptr[(size_t)a];
+    idx.assign((size_t)ptr[(size_t)n1], 0), w.assign((size_t)ptr[(size_t)n1], 0.0);
+    std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+    for (int64_t i = 0; i < n2; ++i) {
+        const bool edge = pb[(size_t)i] >= 0;
+        int32_t& fa = fill[(size_t)pa[(size_t)i]];
+        idx[(size_t)fa] = (int32_t)i, w[(size_t)fa] = edge ? 0.5 : 1.0, ++fa;
+        if (edge) {
+            int32_t& fb = fill[(size_t)pb[(size_t)i]];
+            idx[(size_t)fb] = (int32_t)i, w[(size_t)fb] = 0.5, ++fb;
+        }
+    }
+    return FDAPDE_OK;
+}
+
 // the coarse context and the transfer operators, once per function space
 static int pmg_setup(fdapde_ctx* c) {
     fdapde_ctx::Pmg& m = c->pmg;
     if (m.ready) return FDAPDE_OK;
     pmg_release(c);
     const auto t0 = std::chrono::steady_clock::now();
-    if (int rc = ensure_host(c, kHostDofs | kHostPerm)) return rc;
+    DebugClock clk;
     const HostSpace& h2 = c->hs;
     fdapde_ctx* cc = nullptr;
     if (int rc = fdapde_ctx_create(c->device, &cc)) return fail(c, rc, "FDAPDE_SOLVER_PMG: the coarse context could not be created");
@@ -268,86 +377,112 @@ static int pmg_setup(fdapde_ctx* c) {
         return rc;
     };
     if (int rc = host_set_mesh(cc->hs, h2.M, h2.N, h2.n_nodes, h2.nodes.data(), h2.n_cells, h2.cells.data(), h2.node_bnd.data(), cc->err)) return bail(rc);
+    clk.mark("pmg_setup: coarse context + mesh");
     if (int rc = e_dofs_build(cc, 1, nullptr)) return bail(rc);
-    if (int rc = ensure_host(cc, kHostDofs | kHostPerm)) return bail(rc);
+    clk.mark("pmg_setup: coarse dofs_build");
     const HostSpace& h1 = cc->hs;
     const int nv = h2.M + 1, nb2 = h2.nb;
-    const int64_t n2 = h2.n_dofs, n1 = h1.n_dofs;
+    const int64_t n2 = h2.n_dofs, n1 = h1.n_dofs, ncell = h2.n_cells;
     if (h1.nb != nv || h1.n_cells != h2.n_cells) return bail(fail(cc, FDAPDE_EHIP, "the P1 space of the mesh does not match the P2 space's cells"));
-    std::vector<int32_t> fine_cell((size_t)h1.n_cells);   // coarse internal cell -> fine internal cell (through the mesh's own cell ids)
-    {
-        if ((int64_t)h1.cell_i2e.size() != h1.n_cells || (int64_t)h2.cell_i2e.size() != h2.n_cells) return bail(fail(cc, FDAPDE_EHIP, "the cell permutations are not on the host"));
-        std::vector<int32_t> e2i2((size_t)h2.n_cells);
-        for (int64_t ci = 0; ci < h2.n_cells; ++ci) e2i2[(size_t)h2.cell_i2e[(size_t)ci]] = (int32_t)ci;
-        for (int64_t ci = 0; ci < h1.n_cells; ++ci) fine_cell[(size_t)ci] = e2i2[(size_t)h1.cell_i2e[(size_t)ci]];
-    }
-    // fine DOF (internal) -> its one (vertex DOF) or two (edge DOF) coarse DOFs (internal), cell by cell through the two DOF tables: local DOFs 0 .. M of a
-    // P2 cell are its vertices in the cell's vertex order -- the P1 cell's local DOFs --, local DOF M + 1 + k sits on the edge of the local vertices kEdge[k]
-    std::vector<int32_t> pa((size_t)n2, -1), pb((size_t)n2, -1);
-    std::vector<uint8_t> bnd1((size_t)n1, 0);
-    for (int64_t e = 0; e < h2.n_cells; ++e) {
-        const int32_t* d2 = &h2.dofs[(size_t)e * nb2];
-        const int32_t* d1 = &h1.dofs[(size_t)e * nv];
-        for (int k = 0; k < nv; ++k) {
-            pa[(size_t)h2.dof_e2i[(size_t)d2[k]]] = h1.dof_e2i[(size_t)d1[k]];
-            bnd1[(size_t)d1[k]] = h2.dof_bnd[(size_t)d2[k]];   // (the fine boundary mask, as set or as built, decides)
-        }
-        for (int k = nv; k < nb2; ++k) {
-            const int* ed = h2.M == 2 ? kEdge2[k - nv] : kEdge3[k - nv];
-            const size_t fi = (size_t)h2.dof_e2i[(size_t)d2[k]];
-            pa[fi] = h1.dof_e2i[(size_t)d1[ed[0]]], pb[fi] = h1.dof_e2i[(size_t)d1[ed[1]]];
-        }
-    }
-    // ... and the coarse space must stay INSIDE the fine one: a constrained edge DOF constrains both of its end nodes on the coarse level.  With the mask the
-    // reference builds from a full set of boundary nodes that is already so; with a partial node mask in 2-D it is not -- there every edge DOF of a geometric
-    // boundary edge is constrained whatever its end nodes are (triangulation.h:150-193 / fe_space DOF marking), and a coarse function that does not vanish
-    // at those nodes prolongs to a zig-zag the coarse operator takes for a smooth mode (100 - 300 outer iterations on such masks; tools/fuzz_pmg.py)
-    for (int64_t e = 0; e < h2.n_cells; ++e) {
-        const int32_t* d2 = &h2.dofs[(size_t)e * nb2];
-        const int32_t* d1 = &h1.dofs[(size_t)e * nv];
-        for (int k = nv; k < nb2; ++k) {
-            if (!h2.dof_bnd[(size_t)d2[k]]) continue;
-            const int* ed = h2.M == 2 ? kEdge2[k - nv] : kEdge3[k - nv];
-            bnd1[(size_t)d1[ed[0]]] = 1, bnd1[(size_t)d1[ed[1]]] = 1;
-        }
-    }
-    for (int64_t i = 0; i < n2; ++i)
-        if (pa[(size_t)i] < 0) return bail(fail(cc, FDAPDE_EHIP, "a P2 DOF that no cell's table names"));
-    if (int rc = e_dofs_set_boundary(cc, bnd1.data())) return bail(rc);
-    // P^T as CSR over the coarse DOFs
-    std::vector<int32_t> ptr((size_t)n1 + 1, 0);
-    for (int64_t i = 0; i < n2; ++i) {
-        ++ptr[(size_t)pa[(size_t)i] + 1];
-        if (pb[(size_t)i] >= 0) ++ptr[(size_t)pb[(size_t)i] + 1];
-    }
-    for (int64_t a = 0; a < n1; ++a) ptr[(size_t)a + 1] += ptr[(size_t)a];
-    std::vector<int32_t> idx((size_t)ptr[(size_t)n1]), fill(ptr.begin(), ptr.end() - 1);
-    std::vector<double> w((size_t)ptr[(size_t)n1]);
-    for (int64_t i = 0; i < n2; ++i) {
-        const bool edge = pb[(size_t)i] >= 0;
-        int32_t& fa = fill[(size_t)pa[(size_t)i]];
-        idx[(size_t)fa] = (int32_t)i, w[(size_t)fa] = edge ? 0.5 : 1.0, ++fa;
-        if (edge) {
-            int32_t& fb = fill[(size_t)pb[(size_t)i]];
-            idx[(size_t)fb] = (int32_t)i, w[(size_t)fb] = 0.5, ++fb;
-        }
-    }
+    if (c->cdofs.n < (size_t)ncell * nb2 || cc->cdofs.n < (size_t)ncell * nv || c->cell_i2e.n < (size_t)ncell || cc->cell_i2e.n < (size_t)ncell || cc->dof_i2e.n < (size_t)n1)
+        return bail(fail(cc, FDAPDE_EHIP, "the DOF tables of the two spaces are not on the device"));
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    HIPCHK(c, m.fine_cell.upload(fine_cell.data(), fine_cell.size(), st));
-    HIPCHK(c, m.pa.upload(pa.data(), pa.size(), st));
-    HIPCHK(c, m.pb.upload(pb.data(), pb.size(), st));
-    HIPCHK(c, m.rt_ptr.upload(ptr.data(), ptr.size(), st));
-    HIPCHK(c, m.rt_idx.upload(idx.data(), idx.size(), st));
-    HIPCHK(c, m.rt_w.upload(w.data(), w.size(), st));
+    HIPCHK(c, hipStreamSynchronize(cc->stream));   // (the coarse space's tables were built on its own stream)
+    const dim3 bv(256);
+    // coarse internal cell -> fine internal cell (the two contexts number the cells of the mesh their own way)
+    DBuf<int32_t> e2i2, count;
+    DBuf<uint8_t> bnd1, bnd1_e;
+    DBuf<unsigned long long> keys, keys_sorted;
+    DBuf<int32_t> bad;
+    DBuf<char> tmp;
+    HIPCHK(c, e2i2.alloc((size_t)ncell));
+    HIPCHK(c, m.fine_cell.alloc((size_t)ncell));
+    hipLaunchKernelGGL(k_pmg_inv_perm, dim3(g1n(ncell)), bv, 0, st, ncell, c->cell_i2e.p, e2i2.p);
+    hipLaunchKernelGGL(k_pmg_fine_cell, dim3(g1n(ncell)), bv, 0, st, ncell, cc->cell_i2e.p, e2i2.p, m.fine_cell.p);
+    // fine DOF -> its one (vertex DOF) or two (edge DOF) coarse DOFs, the coarse boundary mask: the fine one, as set or as built, decides -- and the coarse space
+    // must stay INSIDE the fine one: a constrained edge DOF constrains both of its end nodes on the coarse level.  With the mask the reference builds from a full
+    // set of boundary nodes that is already so; with a partial node mask in 2-D it is not -- there every edge DOF of a geometric boundary edge is constrained
+    // whatever its end nodes are (triangulation.h:150-193 / fe_space DOF marking), and a coarse function that does not vanish at those nodes prolongs to a zig-zag
+    // the coarse operator takes for a smooth mode (100 - 300 outer iterations on such masks; tools/fuzz_pmg.py)
+    PmgEdges ed{};
+    for (int k = 0; k < nb2 - nv; ++k) ed.a[k] = h2.M == 2 ? kEdge2[k][0] : kEdge3[k][0], ed.b[k] = h2.M == 2 ? kEdge2[k][1] : kEdge3[k][1];
+    HIPCHK(c, m.pa.alloc((size_t)n2));
+    HIPCHK(c, m.pb.alloc((size_t)n2));
+    HIPCHK(c, bnd1.alloc((size_t)n1));
+    HIPCHK(c, bnd1_e.alloc((size_t)n1));
+    HIPCHK(c, hipMemsetAsync(m.pa.p, 0xFF, sizeof(int32_t) * (size_t)n2, st));
+    HIPCHK(c, hipMemsetAsync(m.pb.p, 0xFF, sizeof(int32_t) * (size_t)n2, st));
+    HIPCHK(c, hipMemsetAsync(bnd1.p, 0, (size_t)n1, st));
+    for (int pass = 0; pass < 2; ++pass)
+        hipLaunchKernelGGL(k_pmg_transfer, dim3(g1n(ncell)), bv, 0, st, ncell, nv, nb2, ed, m.fine_cell.p, cc->cdofs.p, c->cdofs.p, c->bnd.p, m.pa.p, m.pb.p, bnd1.p, pass);
+    hipLaunchKernelGGL(k_pmg_to_reference, dim3(g1n(n1)), bv, 0, st, n1, cc->dof_i2e.p, bnd1.p, bnd1_e.p);
+    std::vector<uint8_t> bnd1_host((size_t)n1);
+    HIPCHK(c, hipMemcpyAsync(bnd1_host.data(), bnd1_e.p, (size_t)n1, hipMemcpyDeviceToHost, st));
+    // P^T as CSR over the coarse DOFs, a row's entries by ascending fine DOF (a fixed order: the restriction sums the same way every run): sort the entries'
+    // (coarse, fine) keys
+    HIPCHK(c, keys.alloc(2 * (size_t)n2));
+    HIPCHK(c, keys_sorted.alloc(2 * (size_t)n2));
+    HIPCHK(c, count.alloc((size_t)n1 + 1));
+    HIPCHK(c, bad.alloc(1));
+    HIPCHK(c, m.rt_ptr.alloc((size_t)n1 + 1));
+    HIPCHK(c, hipMemsetAsync(count.p, 0, sizeof(int32_t) * ((size_t)n1 + 1), st));
+    HIPCHK(c, hipMemsetAsync(bad.p, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_pmg_keys, dim3(g1n(n2)), bv, 0, st, n2, m.pa.p, m.pb.p, keys.p, count.p, bad.p);
+    size_t need_sort = 0, need_scan = 0;
+    const int end_bit = 64;   // (all of them: the sentinels must end up last)
+    HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(nullptr, need_sort, keys.p, keys_sorted.p, (int)(2 * n2), 0, end_bit, st));
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(nullptr, need_scan, count.p, m.rt_ptr.p, (int)(n1 + 1), st));
+    HIPCHK(c, tmp.alloc(std::max(need_sort, need_scan)));
+    HIPCHK(c, hipcub::DeviceRadixSort::SortKeys(tmp.p, need_sort, keys.p, keys_sorted.p, (int)(2 * n2), 0, end_bit, st));
+    HIPCHK(c, hipcub::DeviceScan::ExclusiveSum(tmp.p, need_scan, count.p, m.rt_ptr.p, (int)(n1 + 1), st));
+    int32_t total = 0, bad_h = 0;
+    HIPCHK(c, hipMemcpyAsync(&total, m.rt_ptr.p + n1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(&bad_h, bad.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (bad_h) return bail(fail(cc, FDAPDE_EHIP, "a P2 DOF that no cell's table names"));
+    HIPCHK(c, m.rt_idx.alloc((size_t)total));
+    HIPCHK(c, m.rt_w.alloc((size_t)total));
+    hipLaunchKernelGGL(k_pmg_rt_fill, dim3(g1n(total)), bv, 0, st, (int64_t)total, keys_sorted.p, m.pb.p, m.rt_idx.p, m.rt_w.p);
+    HIPCHK(c, hipGetLastError());
+    clk.mark("pmg_setup: transfer tables (device)");
+    if (int rc = e_dofs_set_boundary(cc, bnd1_host.data())) return bail(rc);
+    clk.mark("pmg_setup: coarse boundary mask");
+    HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, m.dinv.alloc((size_t)n2));
     HIPCHK(c, m.vec.alloc(9 * (size_t)n2));
     m.np = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (n2 + 4095) / 4096));
     HIPCHK(c, m.part.alloc(3 * (size_t)m.np));
     HIPCHK(c, m.dots.alloc(4));
-    HIPCHK(c, hipStreamSynchronize(st));   // (the host vectors above go out of scope)
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (c->pmg_setup_check) {   // the host loops of the first version build the same tables: compared entry by entry
+        std::vector<int32_t> fc, pa, pb, ptr, idx;
+        std::vector<uint8_t> b1;
+        std::vector<double> w;
+        if (int rc = pmg_tables_host(c, cc, fc, pa, pb, b1, ptr, idx, w)) return bail(rc);
+        auto same_i = [&](const DBuf<int32_t>& d, const std::vector<int32_t>& hv) {
+            std::vector<int32_t> g(hv.size());
+            if (hipMemcpy(g.data(), d.p, sizeof(int32_t) * hv.size(), hipMemcpyDeviceToHost) != hipSuccess) return false;
+            return g == hv;
+        };
+        std::vector<double> gw(w.size());
+        std::string which;
+        if ((size_t)total != idx.size()) which += " entries";
+        if (!same_i(m.fine_cell, fc)) which += " fine_cell";
+        if (!same_i(m.pa, pa)) which += " pa";
+        if (!same_i(m.pb, pb)) which += " pb";
+        if (!same_i(m.rt_ptr, ptr)) which += " rt_ptr";
+        if ((size_t)total == idx.size() && !same_i(m.rt_idx, idx)) which += " rt_idx";
+        if ((size_t)total == idx.size() && !(hipMemcpy(gw.data(), m.rt_w.p, sizeof(double) * w.size(), hipMemcpyDeviceToHost) == hipSuccess && gw == w)) which += " rt_w";
+        if (b1 != bnd1_host) which += " boundary";
+        if (!which.empty()) {
+            cc->err = "pmg_setup_check: the device-built transfer tables differ from the host-built ones:" + which;
+            return bail(FDAPDE_EHIP);
+        }
+    }
     std::vector<double> zeros((size_t)n1, 0.0);
     if (int rc = e_set_dirichlet(cc, zeros.data())) return bail(rc);
+    clk.mark("pmg_setup: allocations + coarse Dirichlet data");
     m.ready = true, m.init_seen = -1;
     m.setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (std::getenv("FDAPDE_DEBUG_SETUP"))

@@ -33,6 +33,7 @@ def _problem(capi, meshgen, dim, nx, op, dirichlet):
     c = capi.Context(0)
     c.mesh_upload(nodes, cells, bnd)
     nd = c.dofs_build(2)
+    c.tune("pmg_setup_check", 1)   # (every test problem: the device-built transfer tables against the host loops that built them first -- an error if they differ)
     _, bd, coords = c.dofs_get()
     c.set_operator(op)
     qn = c.quadrature_nodes()

@@ -55,6 +55,8 @@ for case in range(n_cases):
             K[:, a * dim + a] = 1.0 + rng.uniform(0, 1) * np.sin(3.0 * qn[:, a]) ** 2
         op = -capi.diffusion_field(K) + capi.advection_field(np.stack([rng.uniform(-2, 2) * (1.0 + qn[:, (a + 1) % dim]) for a in range(dim)], axis=1)) \
             + capi.reaction_field(0.2 + rng.uniform(0, 4) * qn[:, 0] ** 2)
+    if os.environ.get("FUZZ_PMG_SETUP_CHECK"):
+        c.tune("pmg_setup_check", 1)   # (the device-built transfer tables against the host loops)
     if os.environ.get("FUZZ_PMG_BLOCKED"):
         c.tune("pmg_blocked", int(os.environ["FUZZ_PMG_BLOCKED"]))   # (A/B of the fine operator's form)
     c.set_operator(op)

@@ -436,6 +436,7 @@ int fdapde_tune(fdapde_ctx* c, const char* key, int32_t value) {
     else if (k == "pmg_restart" && value >= 2 && value <= 50) c->pmg_restart = (int)value;
     else if (k == "pmg_outer" && (value == 0 || value == 1)) c->pmg_outer = value;
     else if (k == "pmg_auto_rows" && value >= 0) c->pmg_auto_rows = value;
+    else if (k == "pmg_auto_first_rows" && value >= 0) c->pmg_auto_first_rows = value;
     else if (k == "dense_bulk" && (value == 0 || value == 1)) c->dense_bulk = value;
     else if (k == "dense_hostb" && (value == 0 || value == 1)) c->dense_hostb = value;
     else if (k == "small_rows" && value >= 0) c->small_rows = value;

@@ -489,6 +489,10 @@ struct fdapde_ctx {
     int pmg_setup_check = 0;      // knob: 1 = the coarse level's transfer tables are also built by the host loops of the first version and compared
     int pmg_restart = 50;         // knob: vectors per cycle of the flexible GMRES (2 .. 50; the basis is also held under ~16 GB)
     int pmg_smooth = 1;           // knob: 1 = the preconditioner of the flexible GMRES is a V(1,1) cycle (damped Jacobi around the coarse correction), 0 = the additive form
+    int64_t pmg_auto_first_rows = 1000000;   // knob: ... and at once -- on the context's FIRST open-method solve -- only from that many DOFs on: the coarse level's set-up (the first
+                                             // P1 space of a process: ~100 ms at 389 k DOFs, 0.3 s at 5.4 M) is rent-or-buy like the dense inverse's: a caller that solves once a
+                                             // system of 389 k DOFs is served faster by the Jacobi stages (24 against 120 ms), the second solve builds the level (12 against 21 ms from then on)
+    int64_t open_solves = 0;      // open-method solves (fdapde_solve / steps of fdapde_solve_parabolic) this context has finished
     int pmg_blocked = 1;          // knob: 1 = the fine operator of the two-level solver through the blocked-ELL SpMV (0: the CSR kernel on the raw matrix)
     int64_t pmg_auto_rows = 300000;    // knob: ... of at least that many DOFs (where it starts to win: 3-D 185 k 9.3 against 8.6 ms, 389 k 13 against 21; 2-D symmetric 315 k 27 against 25, 642 k 38 against 59)
     // the dense inverse of a small system (kernels_dense.h / eng_dense.hip): the factor-once handle's, the parabolic stepper's, the open method's direct stage

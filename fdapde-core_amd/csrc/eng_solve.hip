@@ -1088,11 +1088,16 @@ int e_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     // The open method on a LARGE order-2 system it qualifies for: the two-level solver first (eng_pmg.hip: ~19 iterations whatever the mesh size, where the
     // Jacobi-preconditioned stages below need O(1 / h) -- C5, 5.36 M DOFs: 64 ms against 617; the two meet near 200 - 300 k DOFs: 3-D 185 k 9.3 against 8.6 ms,
     // 389 k 13 against 21; 2-D, symmetric, 315 k 27 against 25).  Whatever it does not solve falls through to the stages below.
-    if ((!opt || opt->method == FDAPDE_SOLVER_AUTO) && c->pmg_auto && n >= c->pmg_auto_rows && pmg_eligible(c)) {
+    // (rent-or-buy: below `pmg_auto_first_rows` the context's first open-method solve keeps the Jacobi stages -- the coarse level is built by the second)
+    if ((!opt || opt->method == FDAPDE_SOLVER_AUTO) && c->pmg_auto && n >= c->pmg_auto_rows &&
+        (n >= c->pmg_auto_first_rows || c->pmg.ready || c->open_solves >= 1) && pmg_eligible(c)) {
         fdapde_options po{};
         po.method = FDAPDE_SOLVER_PMG, po.rtol = rtol, po.maxit = (opt && opt->maxit > 0) ? std::min(opt->maxit, 60) : 60;   // (it converges in two dozen iterations or not at all)
         const int rc = e_solve_pmg(c, &po, info);
-        if (rc == FDAPDE_OK) return rc;
+        if (rc == FDAPDE_OK) {
+            ++c->open_solves;
+            return rc;
+        }
         if (rc != FDAPDE_ENOCONV && rc != FDAPDE_EUNSUPPORTED) return rc;
         c->err.clear();
         HIPCHK(c, hipEventRecord(c->ev0, c->stream));
@@ -1170,6 +1175,7 @@ int e_solve(fdapde_ctx* c, const fdapde_options* opt, fdapde_info* info) {
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->info.t_solve_ms = ms;
     c->solved = true, c->dirichlet_applied = c->have_g;
+    if (open_method) ++c->open_solves;
     if (info) *info = c->info;
     return rc;
 }
@@ -1288,7 +1294,8 @@ int e_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times,
     const bool pmg_named = opt && opt->method == FDAPDE_SOLVER_PMG;
     if (pmg_named && !pmg_eligible(c))
         return fail(c, FDAPDE_EUNSUPPORTED, "FDAPDE_SOLVER_PMG takes one-GPU contexts and order-2 spaces");
-    if (pmg_named || ((!opt || opt->method == FDAPDE_SOLVER_AUTO) && c->pmg_auto && n >= c->pmg_auto_rows && pmg_eligible(c))) {
+    if (pmg_named || ((!opt || opt->method == FDAPDE_SOLVER_AUTO) && c->pmg_auto && n >= c->pmg_auto_rows &&
+                      (n >= c->pmg_auto_first_rows || c->pmg.ready || c->open_solves >= 1 || n_times > 5) && pmg_eligible(c))) {
         const int pm_maxit = pmg_named ? ((opt && opt->maxit > 0) ? opt->maxit : 400) : ((opt && opt->maxit > 0) ? std::min(opt->maxit, 60) : 60);
         to_internal(initial_condition);
         HIPCHK(c, hipMemcpyAsync(uprev.p, tmp.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, st));
@@ -1326,6 +1333,7 @@ int e_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times,
             c->info.t_solve_ms = ms_p, c->info.iters = total, c->info.relres = worst_pm, c->info.converged = rc_pm == FDAPDE_OK ? 1 : 0;
             c->info.method_used = FDAPDE_SOLVER_PMG, c->info.persistent = 0;
             c->scaled_owner = fdapde_ctx::kScaledNone;
+            if (!pmg_named) c->open_solves += n_times - 1;
             if (info) *info = c->info;
             kmat.release(), uprev.release(), rhs.release(), gcol.release();
             return rc_pm;
@@ -1379,6 +1387,7 @@ int e_solve_parabolic(fdapde_ctx* c, const fdapde_options* opt, int32_t n_times,
     float ms = 0;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->info.t_solve_ms = ms, c->info.iters = total_iters, c->info.relres = worst, c->info.converged = rc_all == FDAPDE_OK ? 1 : 0;
+    if (!opt || opt->method == FDAPDE_SOLVER_AUTO) c->open_solves += n_times - 1;
     if (info) *info = c->info;
     kmat.release(), uprev.release(), rhs.release(), gcol.release();
     return rc_all;

@@ -89,7 +89,8 @@ enum { FDAPDE_SOLVER_AUTO = 0, FDAPDE_SOLVER_CG = 1, FDAPDE_SOLVER_BICGSTAB = 2,
                                 iterations whatever the mesh size where Jacobi-BiCGStab needs O(1 / h).  info.iters counts its iterations (three operator
                                 applications and one coarse solve each), info.relres is the true relative residual of what is handed out.  fdapde_solve and
                                 fdapde_solve_parabolic (the factor-once handle keeps the Jacobi-preconditioned stages); the open method takes it from
-                                `pmg_auto_rows` (300 k) DOFs on.  Knobs: pmg_outer 1 = BiCGStab around the additive form D^-1 + P A1^-1 P^T (the first
+                                `pmg_auto_rows` (300 k) DOFs on -- below `pmg_auto_first_rows` (1 M) only from a context's second open-method solve on (the coarse level's
+                                set-up is rent-or-buy); a parabolic run of more than four steps at once.  Knobs: pmg_outer 1 = BiCGStab around the additive form D^-1 + P A1^-1 P^T (the first
                                 form), pmg_smooth 0 = flexible GMRES around that additive form, pmg_blocked 0 = the fine operator through the CSR kernel. */ };
 /* ROWS: row-owner sweep (default; no atomics, bitwise reproducible).  The others are element-wise scatter forms kept as measured
  * alternatives and cross-checks: ATOMIC / COLOURED = lane per (cell, row) with a slot search, fp64 atomics / one launch per colour;

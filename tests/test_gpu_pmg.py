@@ -146,11 +146,36 @@ def test_what_it_does_not_take_and_when_the_open_method_takes_it(env):
     assert c.solve().method_used != capi.SOLVER_PMG
     u_small = c.solution()
     c.tune("pmg_auto_rows", 100)
+    c.tune("pmg_auto_first_rows", 100)
     info = c.solve()
     assert info.converged == 1 and info.method_used == capi.SOLVER_PMG
     assert np.abs(c.solution() - u_small).max() <= 1e-8 * np.abs(u_small).max()
     c.tune("pmg_auto", 0)
     assert c.solve().method_used != capi.SOLVER_PMG
+    c.close()
+    # rent-or-buy: between `pmg_auto_rows` and `pmg_auto_first_rows` a context's FIRST open-method solve keeps the Jacobi stages (the coarse level's set-up costs
+    # more than one solve saves), the second builds the level; a parabolic run of more than four steps takes it at once
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(2)
+    c.set_operator(-capi.laplacian() + capi.reaction(1.0))
+    c.set_forcing(np.ones(c.quadrature_nodes().shape[0]))
+    c.set_dirichlet(np.zeros(nd))
+    c.init()
+    c.tune("pmg_auto_rows", 100)
+    first, second = c.solve(), c.solve()
+    assert first.method_used != capi.SOLVER_PMG and second.method_used == capi.SOLVER_PMG and second.converged == 1
+    c.close()
+    c = capi.Context(0)
+    c.mesh_upload(nodes, cells, bnd)
+    nd = c.dofs_build(2)
+    c.set_operator(-capi.laplacian() + capi.reaction(1.0))
+    nq = c.quadrature_nodes().shape[0]
+    c.tune("pmg_auto_rows", 100)
+    c.set_forcing(np.ones((nq, 7)))
+    c.init()
+    _, info = c.solve_parabolic(0.01 * np.arange(7), np.zeros(nd), dirichlet=np.zeros((nd, 7)))
+    assert info.method_used == capi.SOLVER_PMG and info.converged == 1
     c.close()
 
 
@@ -162,6 +187,7 @@ def test_open_method_falls_through_where_the_coarse_level_does_not_help(env):
     capi, meshgen, _ = env
     c, nd, bd, coords = _problem(capi, meshgen, 3, 8, -capi.laplacian() + capi.reaction(-300.0), "data")
     c.tune("pmg_auto_rows", 100)
+    c.tune("pmg_auto_first_rows", 100)
     info = c.solve(rtol=1e-11, raise_on_noconv=False)
     assert info.converged == 1, (info.method_used, info.iters, info.relres)
     A = _csr(c, capi, nd)

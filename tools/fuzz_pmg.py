@@ -68,6 +68,7 @@ for case in range(n_cases):
             c.set_dirichlet(coords @ rng.uniform(-1, 1, dim) + 0.3)
         c.init()
         c.tune("pmg_auto_rows", 1000000 if rep == 0 else 50)
+        c.tune("pmg_auto_first_rows", 1000000 if rep == 0 else 50)
         info = c.solve(method=capi.SOLVER_PMG if rep == 0 else capi.SOLVER_AUTO, rtol=1e-11, raise_on_noconv=False)
         u = c.solution()
         rp, ci = c.pattern_get()

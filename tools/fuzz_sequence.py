@@ -14,6 +14,9 @@ from fdapde_loader import load_package
 capi = load_package().capi
 from fdapde_core_amd import meshgen   # noqa: E402
 
+# FUZZ_SEQ_PMG=1: the long-lived context's open method takes the two-level solver (eng_pmg.hip) for every order-2 system -- its coarse level, the coarse operator,
+# the blocked-ELL fill and the damping it caches must follow every change --, the fresh context keeps the Jacobi-preconditioned stages
+PMG = bool(os.environ.get("FUZZ_SEQ_PMG"))
 n_seq = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
 
@@ -81,10 +84,13 @@ class Problem:
 
 fails = 0
 checks = 0
+pmg_solves = 0
 for s in range(n_seq):
     p = Problem()
     c = capi.Context(0)
     p.apply(c, "all")
+    if PMG:
+        c.tune("pmg_auto_rows", 30), c.tune("pmg_auto_first_rows", 30), c.tune("pmg_setup_check", 1)
     log = ["all"]
     for step in range(int(rng.integers(6, 16))):
         act = rng.choice(["operator", "forcing", "dirichlet", "order", "mesh", "solve", "solve", "solve", "handle", "clone", "parabolic"])
@@ -133,6 +139,8 @@ for s in range(n_seq):
                 d = c.clone()
                 c.close()
                 c = d
+                if PMG:
+                    c.tune("pmg_auto_rows", 30), c.tune("pmg_auto_first_rows", 30), c.tune("pmg_setup_check", 1)
             else:
                 c.init()
                 info = c.solve(rtol=1e-12, raise_on_noconv=False)
@@ -144,6 +152,7 @@ for s in range(n_seq):
                 uf = f.solution()
                 f.close()
                 checks += 1
+                pmg_solves += 1 if info.method_used == capi.SOLVER_PMG else 0
                 err = np.linalg.norm(u - uf) / max(np.linalg.norm(uf), 1e-300)
                 if info.converged != info_f.converged or (info.converged == 1 and err > 1e-9):
                     fails += 1
@@ -156,5 +165,5 @@ for s in range(n_seq):
     c.close()
     if s % 10 == 9:
         print(f"... {s + 1} sequences, {checks} solves compared with a fresh context, failures {fails}", flush=True)
-print(f"{n_seq} sequences, {checks} solves compared with a fresh context, failures {fails}")
+print(f"{n_seq} sequences, {checks} solves compared with a fresh context" + (f" ({pmg_solves} of them through the two-level solver)" if PMG else "") + f", failures {fails}")
 sys.exit(1 if fails else 0)

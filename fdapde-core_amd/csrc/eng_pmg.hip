@@ -1,19 +1,23 @@
-// eng_pmg.hip -- FDAPDE_SOLVER_PMG: a TWO-LEVEL preconditioned BiCGStab for order-2 spaces.
+// eng_pmg.hip -- FDAPDE_SOLVER_PMG: a TWO-LEVEL solver for order-2 spaces (flexible GMRES around a V(1,1) cycle).
 //
 // Why: Jacobi-preconditioned Krylov on a P2 system needs O(1 / h) iterations (C5: 5.36 M DOFs, 660 - 790 BiCGStab iterations, 1 400 operator
 // applications at 0.35 ms each), where the reference's SparseLU (fem_linear_elliptic_solver.h:38-47) does not care about conditioning at all.  The P1
 // space on the SAME mesh is a coarse level that comes for free: its DOFs are the mesh nodes, a P2 vertex DOF takes the vertex value, a P2 edge DOF
-// the mean of its edge's two vertices (the P2 interpolant of a P1 function), and the library can assemble the same operator on it.  With
-//     M^-1 = D^-1 + P A1^-1 P^T          (additive: the fine level's Jacobi sweep + a coarse correction)
-// as right preconditioner BiCGStab needs 42 - 46 fine operator applications whatever the mesh size (tools/c5_pmg_proto.py: 12 k, 59 k, 166 k DOFs),
-// also with the coarse system solved only to 1e-2 by the library's own Krylov solver -- at most a seventh of the fine DOFs (3-D), usually small enough
-// for the single-launch form.
+// the mean of its edge's two vertices (the P2 interpolant of a P1 function), and the library can assemble the same operator on it.
+//
+// What: right-preconditioned FLEXIBLE GMRES; the preconditioner of an iteration is a cycle
+//     z = w S v ;  z += P A1^-1 P^T (v - A z) ;  z += w S (v - A z)          (S = D^-1, w = 1.5 / lambda_max(D^-1 A): damped Jacobi)
+// with the coarse system solved to 1e-1 by the library's own Krylov solver (a different operator every time: hence the flexible method).  17 - 20 iterations from
+// 16 k to 5.4 M DOFs in 2-D and 3-D, the same count whatever the data; C5: 64 ms against 608 ms of the Jacobi-BiCGStab stage.  The forms that came first -- BiCGStab
+// around the additive M^-1 = D^-1 + P A1^-1 P^T (23 - 28 iterations of two applications, a count that moved with the last bits of the data), flexible GMRES around
+// the same -- remain behind knobs (pmg_outer, pmg_smooth) for the A/B figures of DESIGN.md 4.7.
 //
 // How: the coarse problem lives in a CONTEXT OF ITS OWN (c->pmg.coarse: same mesh, fdapde_dofs_build(1), the same operator terms -- coefficient
 // fields, sampled at the order-2 rule's quadrature nodes, as their cell means --, homogeneous Dirichlet data on the same boundary); a coarse
-// solve is that context's fdapde_solve with the restricted residual as its load vector.  The outer iteration is driven from the host (a few dozen
-// iterations of ~ms: launch and read-back latency do not matter): the fine operator through the solver's SpMV on the raw matrix (launch_spmv) with the
-// Dirichlet rows put back as unit rows -- the reference's own row-zeroed system (fem_solver_base.h:142-155).  One-GPU contexts.
+// solve is that context's solver, prepared once per coarse operator, run on the restricted residual.  The transfer tables are built on the device (pmg_setup).  The
+// outer iteration is driven from the host (twenty iterations of ~ms: launch and read-back latency do not matter); the fine operator on the Krylov vectors is the
+// blocked-ELL SpMV on A D^-1 (every vector of the cycle kept D-scaled), on the iterate itself the CSR kernel on the raw matrix with the Dirichlet rows put back as
+// unit rows -- the reference's own row-zeroed system (fem_solver_base.h:142-155).  One-GPU contexts.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -490,7 +494,7 @@ static int pmg_setup(fdapde_ctx* c) {
     return FDAPDE_OK;
 }
 
-// The two-level BiCGStab on K u = rhs (K: `A` with the Dirichlet rows as unit rows if use_bnd; rhs = f_dev on the free rows, g_dev on the Dirichlet rows),
+// The two-level solve of K u = rhs (K: `A` with the Dirichlet rows as unit rows if use_bnd; rhs = f_dev on the free rows, g_dev on the Dirichlet rows),
 // started from x0_dev (or from g on the Dirichlet rows and 0 elsewhere); the coarse operator is the context's operator terms on the P1 space plus
 // `extra_reaction` times the mass matrix (the stepper's M / dt), assembled again when `coarse_key` differs from the one it was assembled for.  Result in c->u,
 // outcome in c->info (method_used, iters, converged, relres = the TRUE relative residual).  FDAPDE_OK / FDAPDE_ENOCONV / an error.

@@ -481,7 +481,10 @@ struct fdapde_ctx {
         double omega_extra = 0.0;
         SolveState coarse_ss;            // the coarse context's solver, prepared ONCE per coarse operator (coarse_prepare / coarse_solve, eng_solve.hip)
     } pmg;
-    int64_t init_count = 0;       // fdapde_init calls so far (who caches something derived from the assembled matrices compares)
+    int64_t init_count = 0;       // the assembled stiffness matrix's EPOCH: fdapde_init calls that may have changed its values (who caches something derived from them compares).
+                                  // A repeated fdapde_init of the SAME operator with the row-owner sweep reproduces the matrix bit for bit (only the load vector is new): same epoch
+    bool matrix_dirty = true;     // the operator (or the space) changed since the last fdapde_init, or fdapde_assemble rewrote the stiffness matrix
+    bool last_init_rows = false;  // ... and that fdapde_init used the bitwise-reproducible row-owner sweep
     double pmg_inner_rtol = 1e-1; // knob pmg_inner_tol_exp: the coarse solves stop at 10^-exp (flexible GMRES outside: 1e-1 costs no outer iteration over 1e-2)
     int pmg_inner_maxit = 1000;   // knob (a 2-D P1 level of 640 k DOFs needs ~400 CG iterations to 1e-2)
     int pmg_auto = 1;             // knob: 1 = the open method takes the two-level solver for large order-2 systems it is eligible for ...

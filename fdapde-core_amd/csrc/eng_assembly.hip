@@ -419,7 +419,7 @@ int e_set_operator(fdapde_ctx* c, int32_t n_terms, const fdapde_term* terms) {
     bool sym = true;
     int rc = check_terms(c, n_terms, terms, &t, &sym);
     if (rc) return rc;
-    c->op = std::move(t), c->op_symmetric = sym, c->coef_of_op = false;
+    c->op = std::move(t), c->op_symmetric = sym, c->coef_of_op = false, c->matrix_dirty = true;
     c->assembled[0] = false, c->solved = false, c->cg_broke_down = false;
     return FDAPDE_OK;
 }
@@ -539,7 +539,7 @@ int e_assemble_operator(fdapde_ctx* c, int32_t which, int32_t n_terms, const fda
         if (int rc2 = mirror_reference_lower(c, a.vals)) return rc2;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->assembled[which] = true;
-    if (which == FDAPDE_MAT_STIFF) c->op_symmetric = sym, c->solved = false, c->dirichlet_applied = false, c->cg_broke_down = false, ++c->init_count;   // (whatever was derived from the old values is stale)
+    if (which == FDAPDE_MAT_STIFF) c->op_symmetric = sym, c->solved = false, c->dirichlet_applied = false, c->cg_broke_down = false, ++c->init_count, c->matrix_dirty = true;   // (whatever was derived from the old values is stale)
     return FDAPDE_OK;
 }
 
@@ -619,7 +619,8 @@ int e_init(fdapde_ctx* c, const fdapde_options* opt) {
     c->info.t_assemble_ms = ms;
     c->stiff_stat_valid = stat_complete;
     c->assembled[0] = c->assembled[1] = true, c->force_ready = true, c->solved = false, c->dirichlet_applied = false, c->cg_broke_down = false;
-    ++c->init_count;
+    if (c->matrix_dirty || !c->last_init_rows || assembly != FDAPDE_ASSEMBLY_ROWS) ++c->init_count;   // (else: the same values again, bit for bit)
+    c->matrix_dirty = false, c->last_init_rows = assembly == FDAPDE_ASSEMBLY_ROWS;
     return FDAPDE_OK;
 }
 

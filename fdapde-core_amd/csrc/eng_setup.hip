@@ -330,6 +330,7 @@ int e_dofs_build(fdapde_ctx* c, int order, int64_t* n_dofs) {
     c->assembled[0] = c->assembled[1] = c->force_ready = c->solved = c->dirichlet_applied = false;
     c->op.clear(), c->coef_of_op = false, c->fq_i.clear(), c->fq_cols = 0, c->g_i.clear(), c->have_g = false;
     pmg_release(c);   // (the coarse level of the space that is being replaced)
+    c->matrix_dirty = true;
     c->halo_ready = false, c->lin_ready = false, c->sp_built[0] = c->sp_built[1] = false, c->sp_cur = -1;
     release_rowdist(c);   // (keys / owners / layouts of the row-distributed form belong to the space that is being replaced)
     c->eval_grid.release();   // (the point-location grid of the mesh before)

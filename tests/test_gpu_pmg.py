@@ -360,3 +360,32 @@ def test_restarted_cycles_and_the_earlier_forms_reach_the_same_solution(env):
         its[name] = info.iters
     assert its["default"] <= 25 and its["default"] <= its["restart5"] <= 80 and its["additive"] > its["default"], its
     c.close()
+
+
+def test_a_repeated_init_of_the_same_operator_keeps_what_was_derived_from_the_matrix(env):
+    """fdapde_init again with the same operator (a new forcing): the row-owner sweep reproduces the stiffness matrix bit for bit, so the coarse operator, the blocked-ELL
+    fill and the damping stay (the matrix epoch does not move); a new operator, or fdapde_init with a scatter form of the assembly, moves it -- either way the
+    answers are those of sparse LU."""
+    import scipy.sparse.linalg as spl
+
+    capi, meshgen, workloads = env
+    c, nd, _, _ = _problem(capi, meshgen, 3, 9, workloads.c5_operator(capi), "data")
+    qn = c.quadrature_nodes()
+    rng = np.random.default_rng(8)
+    stiff0 = None
+    for step, what in enumerate(("first", "same operator", "same operator", "scatter assembly", "new operator", "same operator")):
+        if what == "new operator":
+            c.set_operator(-capi.laplacian() + capi.advection(np.array([0.3, -2.0, 1.0])) + capi.reaction(2.5))
+        c.set_forcing(rng.standard_normal(qn.shape[0]))
+        c.init(assembly=capi.ASSEMBLY_ATOMIC) if what == "scatter assembly" else c.init()
+        info = c.solve(method=capi.SOLVER_PMG, rtol=1e-11)
+        u = c.solution()
+        A = _csr(c, capi, nd)
+        if what == "first":
+            stiff0 = A.data.copy()
+        elif what == "same operator" and step < 3:
+            assert np.array_equal(A.data, stiff0)
+        ref = spl.spsolve(A.tocsc(), c.force())
+        assert info.converged == 1 and info.iters <= 25, (what, info.iters)
+        assert np.linalg.norm(u - ref) <= 1e-8 * np.linalg.norm(ref), what
+    c.close()

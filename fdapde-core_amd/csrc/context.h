@@ -486,7 +486,8 @@ struct fdapde_ctx {
     bool matrix_dirty = true;     // the operator (or the space) changed since the last fdapde_init, or fdapde_assemble rewrote the stiffness matrix
     bool last_init_rows = false;  // ... and that fdapde_init used the bitwise-reproducible row-owner sweep
     double pmg_inner_rtol = 1e-1; // knob pmg_inner_tol_exp: the coarse solves stop at 10^-exp (flexible GMRES outside: 1e-1 costs no outer iteration over 1e-2)
-    int pmg_inner_maxit = 1000;   // knob (a 2-D P1 level of 640 k DOFs needs ~400 CG iterations to 1e-2)
+    int pmg_inner_maxit = 200;    // knob: ... or after that many iterations.  3-D never gets there (C5: 35 per solve); a 2-D P1 level of 490 k DOFs would take 230 - 650 per solve to
+                                  // 1e-1, and the flexible GMRES is better served by more, weaker corrections: 2 M DOFs, -Lap 76 -> 41 ms, -Lap + b.grad + 1 67 -> 53 ms (budget 100: 56 / 46)
     int pmg_auto = 1;             // knob: 1 = the open method takes the two-level solver for large order-2 systems it is eligible for ...
     int pmg_outer = 0;            // knob: the outer method of the two-level solver: 0 = flexible GMRES, 1 = BiCGStab (round 6's first form)
     int pmg_setup_check = 0;      // knob: 1 = the coarse level's transfer tables are also built by the host loops of the first version and compared

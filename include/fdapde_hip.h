@@ -400,7 +400,7 @@ int fdapde_partition_peers(fdapde_ctx *ctx, int32_t rank, int32_t *n_peers, int3
  *                 and the epilogue inside the launch; 0: the separate launches), "asm_items_fuse" (0: the P2 mass matrix in a sweep of its own)
  *   two-level     "pmg_auto" (0: the open method never takes FDAPDE_SOLVER_PMG), "pmg_auto_rows" / "pmg_auto_first_rows" (order-2 systems of at least that many DOFs
  *                 take it: from a context's second open-method solve on / at once; 300 000 / 1 000 000), "pmg_inner_tol_exp" (the coarse solves stop at 10^-exp; 1),
- *                 "pmg_inner_maxit" (their budget; 1000), "pmg_restart" (vectors per cycle of the flexible GMRES, 2 .. 50), "pmg_outer" (1: BiCGStab around the
+ *                 "pmg_inner_maxit" (their budget; 200), "pmg_restart" (vectors per cycle of the flexible GMRES, 2 .. 50), "pmg_outer" (1: BiCGStab around the
  *                 additive preconditioner, the round's first form), "pmg_smooth" (0: flexible GMRES around the additive preconditioner instead of the V(1,1)
  *                 cycle), "pmg_blocked" (0: the fine operator through the CSR kernel instead of the blocked-ELL SpMV), "pmg_setup_check" (1: the transfer tables
  *                 are also built by host loops and compared; an error if they differ) */

@@ -20,6 +20,8 @@ for nx in [int(a) for a in sys.argv[(2 if two_d else 1):]] or (8, 16, 28):
         c.set_forcing(workloads.c5_forcing(c.quadrature_nodes()))
     c.set_dirichlet(np.zeros(nd))
     c.init()
+    for kv in filter(None, os.environ.get("PMG_PROBE_TUNE", "").split(",")):   # e.g. PMG_PROBE_TUNE=pmg_inner_maxit=100,pmg_inner_tol_exp=2
+        c.tune(kv.split("=")[0], int(kv.split("=")[1]))
     out = []
     c.tune("pmg_auto", 0)   # ("jacobi": the open method's Jacobi-preconditioned stages -- what it takes below 300 k DOFs)
     for name, method in (("pmg", capi.SOLVER_PMG), ("jacobi", capi.SOLVER_AUTO)):

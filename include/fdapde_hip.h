@@ -398,6 +398,15 @@ int fdapde_partition_peers(fdapde_ctx *ctx, int32_t rank, int32_t *n_peers, int3
  *                 "small_rows" (systems of up to that many DOFs: no wait for the positive-diagonal flag, outcome through a pinned record; 0: off),
  *                 "small_front_rows" (one-workgroup systems of up to that many DOFs: ONE kernel in front of the single launch -- k_small_front --
  *                 and the epilogue inside the launch; 0: the separate launches), "asm_items_fuse" (0: the P2 mass matrix in a sweep of its own)
+ *   measurement   knobs kept for the A/B figures of DESIGN.md: "asm_row_stat" (0: the solve's Jacobi scaling reads the whole matrix instead of the (diagonal, row maximum)
+ *                 pairs fdapde_init leaves), "bicg_shadow" (shadow residual of the multi-launch BiCGStab: 0 = r0, 1 = pseudo-random, 2 = r0 with randomly scaled entries),
+ *                 "persist_bicg" (0: non-symmetric systems always take the multi-launch BiCGStab), "persist_fill_fused" (1: the single launch's blocks filled straight from
+ *                 the unscaled matrix), "persist_late" (CG layouts with late-import workgroups instead of doubled rows per thread), "persist_gather_waves" /
+ *                 "persist_poll_sleep" (the dot all-gather of the single launch), "persist_wide_gj" (passes of a phase of the wide form that load together: 4 / 6 / 12),
+ *                 "dense_bulk" (0: many columns staged by the kernels themselves instead of by DMA), "dense_hostb" / "dense_direct" (1: a single column's product reads b
+ *                 from / hands x over to the pinned block itself -- both measured slower), "rowdist_share" (that many ranks share this device: an equal share of its CUs
+ *                 each), "rowdist_max_wg" (workgroups of this rank's launch), "rowdist_flat_gather" (-1 auto / 0 / 1: the dot gather across ranks in one hop),
+ *                 "rowdist_timeout_first_ms" (bound of the waits of iteration 0: launch skew between the ranks)
  *   two-level     "pmg_auto" (0: the open method never takes FDAPDE_SOLVER_PMG), "pmg_auto_rows" / "pmg_auto_first_rows" (order-2 systems of at least that many DOFs
  *                 take it: from a context's second open-method solve on / at once; 300 000 / 1 000 000), "pmg_inner_tol_exp" (the coarse solves stop at 10^-exp; 1),
  *                 "pmg_inner_maxit" (their budget; 200), "pmg_restart" (vectors per cycle of the flexible GMRES, 2 .. 50), "pmg_outer" (1: BiCGStab around the

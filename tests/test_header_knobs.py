@@ -14,3 +14,11 @@ def test_fdapde_tune_keys_and_their_documentation_agree():
     assert len(accepted) > 50
     assert documented - accepted == set(), sorted(documented - accepted)
     assert accepted - documented == set(), sorted(accepted - documented)
+
+
+def test_every_entry_point_of_the_header_has_a_row_in_integration_md():
+    header = open(os.path.join(ROOT, "include", "fdapde_hip.h")).read()
+    declared = set(re.findall(r"\b(fdapde_[a-z0-9_]+)\s*\(", header))
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert len(declared) > 50
+    assert [f for f in sorted(declared) if f not in text] == []

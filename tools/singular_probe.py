@@ -1,3 +1,5 @@
+"""-Lap u = 1 WITHOUT a Dirichlet DOF (a singular matrix, the right-hand side outside its range) through the single launch and the multi-launch path:
+what the open method reports (success = false: the iterate grows beyond 1e12 |b|) instead of a 'solution' of size 1e14."""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np

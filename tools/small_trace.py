@@ -1,3 +1,5 @@
+"""A 289-DOF solve three times over, for `rocprofv3 --kernel-trace`: which launches a small solve consists of (one: k_small_front's work and the epilogue are inside the
+single launch)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

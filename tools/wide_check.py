@@ -1,3 +1,5 @@
+"""The wide form of the single launch (24 rows per thread, x in HBM) checked three ways: a moderate system forced into it (fewer workgroups) against the
+multi-launch path and its true residual, a system at its own size, and the bits of two runs."""
 import os, sys, time
 sys.path.insert(0, "/root/repo")
 import numpy as np
